@@ -1,0 +1,182 @@
+/*
+ * tgp_hip.h — C ABI of the MI355X-native SRC pooling hot path (Reduce + Connect).
+ *
+ * The reference (tgp-team/torch-geometric-pool 1.0.1) has no FFI: its operator API is a
+ * Python class protocol whose arithmetic is delegated to ATen / torch_geometric /
+ * torch_scatter.  This header defines the boundary *underneath* that protocol: one entry
+ * point per row of SURVEY.md section 8(a), each citing the reference lines it replaces.
+ * The host-side mirror of the protocol (torch-geometric-pool_amd/tgp) binds these symbols
+ * with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / PyTorch caching allocator) unless
+ *     the name ends in `_host`; index tensors are int64 (reference: utils/ops.py:472-476),
+ *     features / weights are fp32; `[2,E]` edge lists are given as two row pointers.
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it and
+ *     never synchronises, allocates or frees.  Scratch memory comes from the caller
+ *     (`ws`, sized by the matching *_workspace_bytes()).
+ *   - data-dependent output sizes use a count -> fill pair: *_count leaves the number of
+ *     surviving edges in `*d_count` (device int64); the caller reads it (the one host
+ *     sync the reference's own `.item()` calls also pay), allocates exact outputs and
+ *     calls *_fill with the SAME workspace.
+ *   - return value 0 = ok; otherwise a negative tgp_status and tgp_last_error() holds a
+ *     thread-local message.  No exceptions cross the boundary; no global mutable state.
+ */
+#ifndef TGP_HIP_H
+#define TGP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGP_ABI_VERSION 10001 /* 1.0.1: tracks the reference version it mirrors */
+
+enum tgp_status {
+  TGP_OK = 0,
+  TGP_ERR_INVALID = -1,   /* bad argument (null pointer, negative size, unknown enum) */
+  TGP_ERR_WORKSPACE = -2, /* workspace too small */
+  TGP_ERR_LAUNCH = -3,    /* HIP reported an error at launch */
+  TGP_ERR_RANGE = -4      /* size beyond what the int32 internal indices can address */
+};
+
+/* coalesce reduction, reference: utils/typing.py ConnectionType, connect/base_conn.py:87 */
+enum tgp_reduce_op { TGP_SUM = 0, TGP_MEAN = 1, TGP_MIN = 2, TGP_MAX = 3, TGP_MUL = 4 };
+
+/* flag bits shared by the Connect / post-processing entry points */
+enum tgp_flags {
+  TGP_REMOVE_SELF_LOOPS = 1, /* utils/ops.py:370-371, 307-308 */
+  TGP_DEGREE_NORM = 2,       /* utils/ops.py:383-401, 311-319 */
+  TGP_EDGE_WEIGHT_NORM = 4,  /* utils/ops.py:404-417, 322-333 */
+  TGP_SUM_AXIS_ROWS = 8,     /* dense: degree = sum over axis -2 (adj_transpose=True, ops.py:312-314) */
+  TGP_EPS_FILTER = 16,       /* sparse: drop |w| <= 1e-8 when weights are given (ops.py:374-380) */
+  TGP_ADJ_TRANSPOSED = 32,   /* dense: A is handed over as the transposed view (src.py:442-443) */
+  TGP_NODE_FILTER = 64       /* subgraph_fill: node_index was given to the matching _count call */
+};
+
+int tgp_version(void);
+const char* tgp_last_error(void);
+/* number of compute units of the current device (sizing persistent grids); <0 on error */
+int tgp_device_cu_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * A1  BaseReduce.forward, sparse path  (reduce/base_reduce.py:141-155)
+ *     x_pool[c,:] = sum_{i: cluster_index[i]==c} weight[i] * x[node_index[i],:]
+ * The inverted index (assignments grouped by supernode, ascending i inside a group) is a
+ * function of the SelectOutput alone, so it is built once and may be cached by the caller.
+ * ---------------------------------------------------------------------------------- */
+size_t tgp_assign_index_workspace_bytes(int64_t nnz, int64_t num_supernodes);
+int tgp_assign_index_build(const int64_t* cluster_index, int64_t nnz, int64_t num_supernodes,
+                           int32_t* row_ptr /* [num_supernodes+1] */, int32_t* perm /* [nnz] */,
+                           void* ws, size_t ws_bytes, void* stream);
+int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t num_features, int64_t x_row_stride,
+                          const int64_t* node_index, const float* weight /* may be NULL = ones */,
+                          const int32_t* row_ptr, const int32_t* perm, int64_t nnz,
+                          int64_t num_supernodes, float* x_pool /* [K,F] contiguous */, void* stream);
+
+/* A2  Reduce.reduce_batch, sparse branch (reduce/base_reduce.py:37-41):
+ *     out = arange(K); out[cluster_index[i]] = batch[node_index[i]]                      */
+int tgp_reduce_batch_i64(const int64_t* batch, const int64_t* node_index, const int64_t* cluster_index,
+                         int64_t nnz, int64_t num_supernodes, int64_t* batch_pool, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * A5 + A6  sparse_connect, TopK branch (connect/base_conn.py:79-82 -> PyG subgraph with
+ * relabel_nodes=True) fused with the edge filters of postprocess_adj_pool_sparse
+ * (utils/ops.py:370-380).  Output keeps INPUT edge order; endpoints are relabelled to
+ * their position in the ascending `node_index`.  node_index == NULL turns the node
+ * filter/relabel off (plain remove_self_loops + eps filter on an edge list).
+ * ---------------------------------------------------------------------------------- */
+size_t tgp_connect_subgraph_workspace_bytes(int64_t num_edges, int64_t num_nodes);
+int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
+                               int64_t num_edges, const int64_t* node_index /* NULL ok */, int64_t num_kept,
+                               int64_t num_nodes, int flags, void* ws, size_t ws_bytes,
+                               int64_t* d_count, void* stream);
+int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col, const float* edge_weight,
+                              int64_t num_edges, int64_t num_nodes, int flags, const void* ws,
+                              int64_t num_out, int64_t* out_row, int64_t* out_col, float* out_weight,
+                              void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * A4 + A6  sparse_connect, one-over-K branch (connect/base_conn.py:83-89 -> PyG coalesce):
+ * relabel endpoints by cluster_index, sort by (row, col) (stable), merge duplicates with
+ * `reduce_op`, then the filters of utils/ops.py:370-380.  Output is row-major sorted and
+ * unique.  edge_weight == NULL keeps the result unweighted (out_weight unused).
+ * ---------------------------------------------------------------------------------- */
+size_t tgp_connect_coalesce_workspace_bytes(int64_t num_edges, int64_t num_supernodes);
+int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
+                               int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,
+                               int64_t num_supernodes, int reduce_op, int flags, void* ws, size_t ws_bytes,
+                               int64_t* d_count, void* stream);
+int tgp_connect_coalesce_fill(const void* ws, int64_t num_edges, int64_t num_supernodes, int has_weight,
+                              int flags, int64_t num_out, int64_t* out_row, int64_t* out_col,
+                              float* out_weight, void* stream);
+
+/* A6 (rest)  degree / per-graph max normalisation of a pooled edge list, in place
+ * (utils/ops.py:383-417).  edge_weight must be initialised (ones when the list was
+ * unweighted, ops.py:384-385).  ws: tgp_postprocess_sparse_workspace_bytes().           */
+size_t tgp_postprocess_sparse_workspace_bytes(int64_t num_edges, int64_t num_nodes, int64_t num_graphs);
+int tgp_postprocess_sparse_norm_f32(const int64_t* row, const int64_t* col, float* edge_weight,
+                                    int64_t num_edges, int64_t num_nodes, int flags,
+                                    const int64_t* batch_pooled /* needed for EDGE_WEIGHT_NORM */,
+                                    int64_t num_graphs, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * A3 + A7 + A8  dense pooling of a padded batch
+ *   x_pool  [B,K,F] = S^T X                  (reduce/base_reduce.py:158-161)
+ *   adj_raw [B,K,K] = S^T A S                (connect/dense_conn.py:111-122)
+ *   adj_pool[B,K,K] = postprocess(adj_raw)   (utils/ops.py:282-335)
+ * S [B,N,K], X [B,N,F] contiguous fp32; A [B,N,N] contiguous, or its transposed view when
+ * TGP_ADJ_TRANSPOSED is set (then element (b,i,j) is read from A[b*N*N + j*N + i]).
+ * x / x_pool, adj_raw, adj_pool may each be NULL to skip that product.  MinCut
+ * (poolers/mincut.py:226-237) asks for adj_raw AND adj_pool; DiffPool only adj_pool.
+ * ---------------------------------------------------------------------------------- */
+size_t tgp_dense_pool_workspace_bytes(int64_t B, int64_t N, int64_t K, int64_t F);
+int tgp_dense_pool_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K,
+                       int64_t F, int flags, float* x_pool, float* adj_raw, float* adj_pool, void* ws,
+                       size_t ws_bytes, void* stream);
+
+/* Generic batched fp32 GEMM on the matrix cores, C[b] = op(A[b]) B[b] with B[b] [Kd,Nc] row-major.
+ * trans_a = 0: A[b] is [M,Kd] row-major; 1: A[b] is stored [Kd,M] (C = A^T B).  Used by
+ * BaseLift (lift/base_lift.py:138-247: S_inv^T X_pool) and exposed for callers' own products. */
+int tgp_bmm_f32(const float* A, const float* Bm, float* C, int64_t batch, int64_t M, int64_t Nc, int64_t Kd,
+                int trans_a, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
+                void* stream);
+
+/* A3' / A7'  un-padded batch (reduce/base_reduce.py:170-182, connect/dense_conn.py:195-206):
+ * C[b] = S_b^T Y_b where graph b owns node rows ptr[b]..ptr[b+1] of S [Ntot,K] and Y [Ntot,F].
+ * One launch instead of the reference's Python loop over graphs. max_nodes = max_b (ptr[b+1]-ptr[b]). */
+int tgp_segment_gemm_tn_f32(const float* S, const float* Y, const int64_t* ptr, float* C, int64_t B,
+                            int64_t Ntot, int64_t K, int64_t F, int64_t max_nodes, void* stream);
+
+/* A7'  sparse A times dense S (connect/dense_conn.py:165,204: torch.sparse.mm), A in CSR built from a
+ * row-sorted coalesced edge list: T[i,:] = sum_{e in row i} w[e] * S[col[e],:].  w may be NULL. */
+int tgp_rowptr_from_sorted_i64(const int64_t* rows, int64_t n, int64_t num_rows, int32_t* row_ptr, void* stream);
+int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows, int64_t nnz,
+                     const float* S, int64_t K, float* T, void* stream);
+
+/* A8 alone: post-process a [B,K,K] pooled adjacency (src may equal dst).                */
+int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K, int flags, void* stream);
+
+/* A10  dense_to_block_diag (utils/ops.py:53-82): entries with |a| > 1e-8 in (b,row,col)
+ * order, offset by b*K; optional valid-supernode mask [B*K] (src.py:526-552) drops and
+ * renumbers supernodes (relabel[B*K] int64: new id or -1, NULL = keep all).             */
+size_t tgp_block_diag_workspace_bytes(int64_t B, int64_t K);
+int tgp_block_diag_count(const float* adj_pool, int64_t B, int64_t K, const int64_t* relabel /* NULL ok */,
+                         int flags, void* ws, size_t ws_bytes, int64_t* d_count, void* stream);
+int tgp_block_diag_fill(const float* adj_pool, int64_t B, int64_t K, const int64_t* relabel, int flags,
+                        const void* ws, int64_t num_out, int64_t* out_row, int64_t* out_col,
+                        float* out_weight, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * test hooks for the shared primitives (device-wide stable LSD radix sort, block scan)
+ * ---------------------------------------------------------------------------------- */
+size_t tgp_debug_sort_workspace_bytes(int64_t n);
+int tgp_debug_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, int64_t n, int key_bits,
+                             uint64_t* keys_out, uint32_t* vals_out, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGP_HIP_H */

@@ -1,0 +1,87 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every
+symbol ``include/tgp_hip.h`` declares; the ctypes table binds exactly that set; compute entry points are
+never reached with host tensors (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "tgp_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tgp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = declared_symbols()
+    for must in ("tgp_reduce_sparse_f32", "tgp_reduce_batch_i64", "tgp_connect_subgraph_count",
+                 "tgp_connect_subgraph_fill", "tgp_connect_coalesce_count", "tgp_connect_coalesce_fill",
+                 "tgp_postprocess_sparse_norm_f32", "tgp_dense_pool_f32", "tgp_postprocess_dense_f32",
+                 "tgp_block_diag_count", "tgp_block_diag_fill", "tgp_last_error", "tgp_version"):
+        assert must in syms
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from tgp import _native
+    assert os.path.exists(_native.LIB_PATH), "run __graft_entry__.build() first"
+    handle = ctypes.CDLL(_native.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(handle, name), f"{name} declared in include/tgp_hip.h but not exported"
+
+
+def test_ctypes_table_matches_header():
+    from tgp import _native
+    assert sorted(_native.SIGNATURES) == declared_symbols()
+    lib = _native.lib()
+    assert lib.tgp_version() == 10001
+    assert lib.tgp_last_error() is not None
+
+
+def test_flag_values_match_header():
+    from tgp import _native
+    text = open(HEADER).read()
+    for name in ("REMOVE_SELF_LOOPS", "DEGREE_NORM", "EDGE_WEIGHT_NORM", "SUM_AXIS_ROWS", "EPS_FILTER",
+                 "ADJ_TRANSPOSED", "NODE_FILTER"):
+        m = re.search(rf"TGP_{name}\s*=\s*(\d+)", text)
+        assert m and int(m.group(1)) == getattr(_native, name), name
+    for op, val in (("SUM", 0), ("MEAN", 1), ("MIN", 2), ("MAX", 3), ("MUL", 4)):
+        assert re.search(rf"TGP_{op}\s*=\s*{val}\b", text)
+        assert _native.REDUCE_OPS[op.lower()] == val
+
+
+def test_workspace_queries_run_without_a_gpu():
+    from tgp import _native
+    lib = _native.lib()
+    assert lib.tgp_connect_coalesce_workspace_bytes(10_000_000, 550_000) > 10_000_000 * 24
+    assert lib.tgp_dense_pool_workspace_bytes(32, 1024, 128, 64) >= 32 * 1024 * 128 * 4
+    assert lib.tgp_assign_index_workspace_bytes(0, 0) > 0
+
+
+def test_no_cpu_fallback():
+    from tgp import _native
+    from tgp.connect import DenseConnect, SparseConnect
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    x = torch.randn(4, 3)
+    so = SelectOutput(cluster_index=torch.tensor([0, 0, 1, 1]))
+    with pytest.raises(_native.TgpNativeError, match="no CPU fallback"):
+        BaseReduce()(x, so)
+    with pytest.raises(_native.TgpNativeError, match="no CPU fallback"):
+        SparseConnect()(torch.tensor([[0, 1], [1, 0]]), so)
+    with pytest.raises(_native.TgpNativeError, match="no CPU fallback"):
+        DenseConnect()(torch.rand(1, 4, 4), SelectOutput(s=torch.rand(1, 4, 2)))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "torch-geometric-pool_amd", "tgp")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "tgp_oracle" not in src and "import oracle" not in src, f

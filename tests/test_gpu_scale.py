@@ -1,0 +1,250 @@
+"""GPU parity at scale: HIP path vs the CPU oracle on seeded inputs the oracle finishes in seconds, and
+size-independent properties at BASELINE.json's full sizes (sortedness, uniqueness, conservation of
+edge weight, linearity, idempotence)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL = ATOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def undirected_graph(n, pairs, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randint(0, n, (pairs,), generator=g)
+    b = torch.randint(0, n, (pairs,), generator=g)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    return torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+
+
+# ----------------------------------------------------------------------------------- primitives
+@pytest.mark.parametrize("n,bits", [(1, 8), (1000, 17), (4097, 40), (300_000, 39), (2_500_000, 24)])
+def test_radix_sort_stable(dev, n, bits):
+    from tgp import _native as N
+    g = torch.Generator().manual_seed(n)
+    keys = torch.randint(0, 2 ** min(bits, 62), (n,), generator=g, dtype=torch.int64)
+    if n > 10:
+        keys[: n // 3] = keys[n // 2: n // 2 + n // 3]  # plenty of duplicates to exercise stability
+    vals = torch.arange(n, dtype=torch.int32)
+    kd, vd = keys.to(dev), vals.to(dev)
+    ko, vo = torch.empty_like(kd), torch.empty_like(vd)
+    L = N.lib()
+    ws = N.workspace(L.tgp_debug_sort_workspace_bytes(n), dev)
+    N.check(L.tgp_debug_sort_pairs_u64(kd.data_ptr(), vd.data_ptr(), n, bits, ko.data_ptr(), vo.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), N.stream_ptr(dev)), "sort")
+    ref_k, ref_p = torch.sort(keys, stable=True)
+    assert torch.equal(ko.cpu(), ref_k)
+    assert torch.equal(vo.cpu().long(), ref_p)
+
+
+# ----------------------------------------------------------------------------------- sparse reduce
+@pytest.mark.parametrize("n,f", [(50_000, 128), (20_000, 16), (3_000, 7), (1_000, 260)])
+def test_sparse_reduce_vs_oracle_bitexact(dev, n, f):
+    """Summation order equals the sequential CPU scatter and products are rounded before the add, so the
+    fp32 result is bit-identical to the oracle, not merely within tolerance."""
+    import tgp_oracle as O
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    g = torch.Generator().manual_seed(n + f)
+    k = n // 2 + 1
+    cluster = torch.randint(0, k, (n,), generator=g)
+    cluster[:k] = torch.randperm(k, generator=g)
+    w = torch.rand(n, generator=g) + 0.5
+    x = torch.randn(n, f, generator=g)
+    batch = torch.sort(torch.randint(0, 5, (n,), generator=g))[0]
+    so = SelectOutput(cluster_index=cluster.to(dev), num_nodes=n, num_supernodes=k, weight=w.to(dev))
+    xp, bp = BaseReduce()(x.to(dev), so, batch=batch.to(dev))
+    ni, ci, ww = O.sort_assignment(torch.arange(n), cluster, w)
+    ref = O.reduce_sparse(x, ni, ci, ww, k)
+    assert torch.equal(xp.cpu(), ref)
+    # second call hits the cached inverted index and must give the same bits
+    assert torch.equal(BaseReduce()(x.to(dev), so)[0].cpu(), ref)
+
+
+def test_sparse_reduce_linearity_full_size(dev):
+    """C4 size (N = 1M, F = 128): S^T(aX + bY) == a S^T X + b S^T Y up to fp32 rounding, and column sums
+    are conserved for unit weights."""
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    n, f = 1_000_000, 128
+    g = torch.Generator(device=dev).manual_seed(0)
+    pair = torch.randperm(n, device=dev, generator=g)
+    cluster = torch.empty(n, dtype=torch.long, device=dev)
+    cluster[pair] = torch.arange(n, device=dev) // 2   # perfect matching -> K = N/2
+    so = SelectOutput(cluster_index=cluster, num_nodes=n, num_supernodes=n // 2)
+    x = torch.randn(n, f, device=dev, generator=g)
+    y = torch.randn(n, f, device=dev, generator=g)
+    red = BaseReduce()
+    lhs = red(2.0 * x - 3.0 * y, so)[0]
+    rhs = 2.0 * red(x, so)[0] - 3.0 * red(y, so)[0]
+    torch.testing.assert_close(lhs, rhs, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(red(x, so)[0].sum(0), x.sum(0), rtol=1e-4, atol=1e-2)
+
+
+# ----------------------------------------------------------------------------------- sparse connect
+@pytest.mark.parametrize("weighted", [True, False])
+@pytest.mark.parametrize("op", ["sum", "max", "mean"])
+def test_coalesce_connect_vs_oracle(dev, weighted, op):
+    import tgp_oracle as O
+    from tgp.connect import sparse_connect
+    n, k = 40_000, 9_000
+    ei = undirected_graph(n, 200_000, 1)
+    g = torch.Generator().manual_seed(2)
+    ew = torch.randn(ei.size(1), generator=g) if weighted else None
+    cluster = torch.randint(0, k, (n,), generator=g)
+    got_ei, got_ew = sparse_connect(ei.to(dev), None if ew is None else ew.to(dev), node_index=torch.arange(n, device=dev),
+                                    cluster_index=cluster.to(dev), num_nodes=n, num_supernodes=k, reduce_op=op)
+    ref_ei, ref_ew = O.sparse_connect(ei, ew, torch.arange(n), cluster, n, k, reduce_op=op)
+    assert torch.equal(got_ei.cpu(), ref_ei)
+    if weighted:
+        torch.testing.assert_close(got_ew.cpu(), ref_ew, rtol=RTOL, atol=ATOL)
+    else:
+        assert got_ew is None
+
+
+def test_subgraph_connect_vs_oracle(dev):
+    import tgp_oracle as O
+    from tgp.connect import sparse_connect
+    n = 60_000
+    ei = undirected_graph(n, 400_000, 3)
+    g = torch.Generator().manual_seed(4)
+    ew = torch.randn(ei.size(1), generator=g)
+    ew[::11] = 0.0
+    keep = torch.sort(torch.randperm(n, generator=g)[: n // 2])[0]
+    batch_pooled = torch.sort(torch.randint(0, 7, (keep.numel(),), generator=g))[0]
+    for flags in (dict(), dict(degree_norm=True), dict(edge_weight_norm=True, remove_self_loops=False)):
+        got_ei, got_ew = sparse_connect(ei.to(dev), ew.to(dev), node_index=keep.to(dev),
+                                        cluster_index=torch.arange(keep.numel(), device=dev), num_nodes=n,
+                                        num_supernodes=keep.numel(), batch_pooled=batch_pooled.to(dev), **flags)
+        ref_ei, ref_ew = O.sparse_connect(ei, ew, keep, torch.arange(keep.numel()), n, keep.numel(),
+                                          batch_pooled=batch_pooled, **flags)
+        assert torch.equal(got_ei.cpu(), ref_ei), flags
+        torch.testing.assert_close(got_ew.cpu(), ref_ew, rtol=RTOL, atol=ATOL)
+
+
+def test_coalesce_properties_full_size(dev):
+    """C4 size (N = 1M, E = 10M directed entries, unit weights, pair clustering)."""
+    from tgp.connect import sparse_connect
+    n = 1_000_000
+    g = torch.Generator(device=dev).manual_seed(0)
+    a = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    b = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+    ew = torch.ones(ei.size(1), device=dev)
+    pair = torch.randperm(n, device=dev, generator=g)
+    cluster = torch.empty(n, dtype=torch.long, device=dev)
+    cluster[pair] = torch.arange(n, device=dev) // 2
+    k = n // 2
+    oi, ow = sparse_connect(ei, ew, node_index=torch.arange(n, device=dev), cluster_index=cluster, num_nodes=n,
+                            num_supernodes=k)
+    key = oi[0] * k + oi[1]
+    assert bool((key[1:] > key[:-1]).all()), "output must be strictly row-major sorted (sorted + unique)"
+    assert bool((oi[0] != oi[1]).all()), "self loops removed"
+    assert int(oi.min()) >= 0 and int(oi.max()) < k
+    inner = cluster[ei[0]] == cluster[ei[1]]
+    # unit weights: merged weights are exact integers and total weight is conserved
+    assert float(ow.sum()) == float((~inner).sum())
+    # symmetric input -> symmetric output
+    rev = oi[1] * k + oi[0]
+    assert torch.equal(torch.sort(rev)[0], key)
+    # idempotence: coalescing the coalesced graph with the identity clustering changes nothing
+    oi2, ow2 = sparse_connect(oi, ow, node_index=torch.arange(k, device=dev),
+                              cluster_index=torch.arange(k, device=dev), num_nodes=k, num_supernodes=k)
+    assert torch.equal(oi2, oi) and torch.equal(ow2, ow)
+
+
+# ----------------------------------------------------------------------------------- dense
+@pytest.mark.parametrize("B,N,K,F", [(32, 1024, 128, 64), (3, 333, 37, 19), (2, 2048, 512, 128), (64, 60, 20, 32)])
+def test_dense_pool_vs_oracle(dev, B, N, K, F):
+    import tgp_oracle as O
+    from tgp.connect import DenseConnect
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    g = torch.Generator().manual_seed(B * N + K)
+    A = (torch.rand(B, N, N, generator=g) < 0.01).float()
+    A = torch.maximum(A, A.transpose(1, 2))
+    A.diagonal(dim1=1, dim2=2).zero_()
+    X = torch.randn(B, N, F, generator=g)
+    S = torch.softmax(torch.randn(B, N, K, generator=g), -1)
+    so = SelectOutput(s=S.to(dev))
+    xp, _ = BaseReduce()(X.to(dev), so)
+    torch.testing.assert_close(xp.cpu(), O.reduce_dense(S, X), rtol=RTOL, atol=ATOL)
+    raw_ref = O.dense_connect(S, A)
+    conn = DenseConnect()
+    torch.testing.assert_close(conn.dense_connect(adj=A.to(dev), s=S.to(dev)).cpu(), raw_ref, rtol=RTOL, atol=ATOL)
+    out, _ = conn(A.to(dev), so)
+    torch.testing.assert_close(out.cpu(), O.postprocess_dense(raw_ref, True, True, True, False), rtol=RTOL, atol=ATOL)
+
+
+def test_dense_pool_full_size_properties(dev):
+    """C5 shape (N = 8192, K = 512, F = 128), one graph: hard one-hot S makes S^T A S an exact integer
+    block-count matrix and S^T X an exact segment sum, so the MFMA path can be checked without a CPU GEMM."""
+    from tgp.connect import DenseConnect
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    N, K, F = 8192, 512, 128
+    g = torch.Generator(device=dev).manual_seed(0)
+    A = (torch.rand(1, N, N, device=dev, generator=g) < 0.01).float()
+    cl = torch.randint(0, K, (N,), device=dev, generator=g)
+    S = torch.zeros(1, N, K, device=dev)
+    S[0, torch.arange(N, device=dev), cl] = 1.0
+    X = torch.randint(-3, 4, (1, N, F), device=dev, generator=g).float()
+    raw = DenseConnect().dense_connect(adj=A, s=S)
+    r, c = A[0].nonzero(as_tuple=True)
+    ref = torch.zeros(K * K, device=dev).index_add_(0, cl[r] * K + cl[c], torch.ones(r.numel(), device=dev)).view(1, K, K)
+    assert torch.equal(raw, ref)
+    xp, _ = BaseReduce()(X, SelectOutput(s=S))
+    ref_x = torch.zeros(K, F, device=dev).index_add_(0, cl, X[0])
+    assert torch.equal(xp[0], ref_x)
+
+
+def test_dense_unbatched_matches_batched(dev):
+    """Reference pin 11 (tests/poolers/test_dense_poolers_batched_vs_unbatched.py:80-174): batched and
+    unbatched modes agree on x, adj and losses at rtol = atol = 1e-5."""
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(5)
+    sizes = [30, 45, 38, 51]
+    xs, eis, bs, off = [], [], [], 0
+    for gi, n in enumerate(sizes):
+        a = torch.triu(torch.rand(n, n, generator=g) < 0.15, 1)
+        a = a | a.t()
+        eis.append(a.nonzero().t() + off)
+        xs.append(torch.randn(n, 16, generator=g))
+        bs.append(torch.full((n,), gi))
+        off += n
+    x, ei, b = torch.cat(xs).to(dev), torch.cat(eis, 1).to(dev), torch.cat(bs).to(dev)
+    for alias in ("diff", "mincut"):
+        pb = get_pooler(alias, in_channels=16, k=8).to(dev).eval()
+        pu = get_pooler(alias + "_u", in_channels=16, k=8).to(dev).eval()
+        pu.load_state_dict(pb.state_dict())
+        with torch.no_grad():
+            ob, ou = pb(x=x, adj=ei, batch=b), pu(x=x, adj=ei, batch=b)
+        torch.testing.assert_close(ob.x, ou.x, rtol=RTOL, atol=ATOL)
+        # batched mode returns the transposed pooled adjacency (adj_transpose=True); the graphs are
+        # symmetric, so the two agree up to rounding
+        torch.testing.assert_close(ob.edge_index, ou.edge_index, rtol=1e-4, atol=1e-5)
+        for k in ob.loss:
+            torch.testing.assert_close(ob.loss[k], ou.loss[k], rtol=1e-4, atol=1e-5)
+
+
+def test_lift_roundtrip(dev):
+    """Lift is the transposed Reduce: for a one-hot S, lift(reduce(x)) sums each cluster back onto its nodes."""
+    from tgp.poolers import get_pooler
+    n = 5000
+    ei = undirected_graph(n, 20_000, 9).to(dev)
+    x = torch.randn(n, 32, device=dev)
+    pooler = get_pooler("graclus")
+    out = pooler(x=x, adj=ei)
+    lifted = pooler(x=out.x, so=out.so, lifting=True)
+    cl = out.so.cluster_index
+    ref = out.x[cl]
+    torch.testing.assert_close(lifted, ref, rtol=RTOL, atol=ATOL)

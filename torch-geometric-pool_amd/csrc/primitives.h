@@ -1,0 +1,261 @@
+// Device-wide primitives shared by the sparse kernels: block scans, order-preserving
+// compaction ranks, and a stable LSD radix sort (8-bit digits, wave match-any ranking).
+// Everything is written for 64-wide wavefronts and 256-thread workgroups.
+#pragma once
+#include "common.h"
+
+namespace tgp {
+
+// ------------------------------------------------------------------ wave / block scans
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, WAVE);
+    if (lane_id() >= d) v += t;
+  }
+  return v;
+}
+
+// Exclusive scan over the 256 threads of a workgroup.  s_w: 4 words of LDS.
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_w, uint32_t* total) {
+  const uint32_t inc = wave_incl_scan(v);
+  if (lane_id() == WAVE - 1) s_w[wave_id()] = inc;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t c = s_w[w];
+    if (w < wave_id()) off += c;
+    tot += c;
+  }
+  if (total) *total = tot;
+  __syncthreads();
+  return off + inc - v;
+}
+
+// Order-preserving compaction ranks for a 256-thread workgroup that owns ITEMS*256
+// consecutive elements laid out item-major (element = item*256 + tid).  s_cnt: ITEMS*4 words.
+template <int ITEMS>
+__device__ __forceinline__ void block_compact_ranks(const bool (&flag)[ITEMS], uint32_t (&rank)[ITEMS],
+                                                    uint32_t& block_total, uint32_t* s_cnt) {
+  const int w = wave_id();
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const unsigned long long m = __ballot(flag[it]);
+    rank[it] = __popcll(m & lanemask_lt());
+    if (lane_id() == 0) s_cnt[it * 4 + w] = __popcll(m);
+  }
+  __syncthreads();
+  uint32_t run = 0;
+#pragma unroll
+  for (int i = 0; i < ITEMS * 4; ++i) {
+    const uint32_t c = s_cnt[i];
+    if ((i & 3) == w) rank[i >> 2] += run;
+    run += c;
+  }
+  block_total = run;
+  __syncthreads();
+}
+
+// counts[nb] -> exclusive offsets[nb], *total (int64).  One 1024-thread workgroup.
+static __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t* __restrict__ counts, int nb,
+                                                           uint32_t* __restrict__ offsets,
+                                                           int64_t* __restrict__ total) {
+  __shared__ uint32_t s_w[16];
+  __shared__ uint32_t s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + tid;
+    const uint32_t v = i < nb ? counts[i] : 0u;
+    const uint32_t inc = wave_incl_scan(v);
+    if (lane == WAVE - 1) s_w[w] = inc;
+    __syncthreads();
+    uint32_t off = s_carry, tot = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t c = s_w[j];
+      if (j < w) off += c;
+      tot += c;
+    }
+    if (i < nb) offsets[i] = off + inc - v;
+    __syncthreads();
+    if (tid == 0) s_carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) *total = static_cast<int64_t>(s_carry);
+}
+
+// ------------------------------------------------------------------ LSD radix sort
+// Pass structure (per 8-bit digit):  histogram per workgroup chunk -> per-digit scan over
+// chunks -> stable scatter.  A workgroup owns one contiguous chunk of the input, so block
+// order == input order and the sort is stable.
+constexpr int kSortThreads = 256;
+constexpr int kSortItems = 8;
+constexpr int kSortTile = kSortThreads * kSortItems;
+constexpr int kSortMaxBlocks = 1024;
+
+template <typename KeyT>
+__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const KeyT* __restrict__ keys, int64_t n,
+                                                                   int64_t chunk, int shift, int nblocks,
+                                                                   uint32_t* __restrict__ hist) {
+  __shared__ uint32_t s_h[256];
+  const int tid = threadIdx.x;
+  s_h[tid] = 0;
+  __syncthreads();
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * chunk;
+  const int64_t end = begin + chunk < n ? begin + chunk : n;
+  for (int64_t i = begin + tid; i < end; i += kSortThreads) {
+    const uint32_t d = static_cast<uint32_t>(keys[i] >> shift) & 255u;
+    atomicAdd(&s_h[d], 1u);
+  }
+  __syncthreads();
+  hist[static_cast<size_t>(tid) * nblocks + blockIdx.x] = s_h[tid];
+}
+
+// grid = 256 (one workgroup per digit); exclusive scan over the nblocks (<=1024) chunk counts.
+static __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t* __restrict__ hist, int nblocks,
+                                                          uint32_t* __restrict__ digit_total) {
+  __shared__ uint32_t s_w[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  uint32_t* row = hist + static_cast<size_t>(blockIdx.x) * nblocks;
+  const uint32_t v = tid < nblocks ? row[tid] : 0u;
+  const uint32_t inc = wave_incl_scan(v);
+  if (lane == WAVE - 1) s_w[w] = inc;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t c = s_w[j];
+    if (j < w) off += c;
+    tot += c;
+  }
+  if (tid < nblocks) row[tid] = off + inc - v;
+  if (tid == 0) digit_total[blockIdx.x] = tot;
+}
+
+template <typename KeyT, typename ValT>
+__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
+    const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in, KeyT* __restrict__ keys_out,
+    ValT* __restrict__ vals_out, const uint32_t* __restrict__ hist_scanned,
+    const uint32_t* __restrict__ digit_total, int64_t n, int64_t chunk, int shift, int nblocks) {
+  __shared__ uint32_t s_base[256];
+  __shared__ uint32_t s_whist[4][256];
+  __shared__ uint32_t s_w[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+  const uint32_t excl = block_excl_scan_256(digit_total[tid], s_w, nullptr);
+  s_base[tid] = excl + hist_scanned[static_cast<size_t>(tid) * nblocks + blockIdx.x];
+
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * chunk;
+  const int64_t end = begin + chunk < n ? begin + chunk : n;
+  for (int64_t tile = begin; tile < end; tile += kSortTile) {
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) s_whist[ww][tid] = 0;
+    __syncthreads();
+
+    KeyT k[kSortItems];
+    ValT v[kSortItems];
+    uint32_t r[kSortItems];
+    uint32_t dg[kSortItems];
+#pragma unroll
+    for (int it = 0; it < kSortItems; ++it) {
+      const int64_t idx = tile + static_cast<int64_t>(w) * (WAVE * kSortItems) + it * WAVE + lane;
+      const bool valid = idx < end;
+      k[it] = valid ? keys_in[idx] : KeyT(0);
+      v[it] = valid ? vals_in[idx] : ValT(0);
+      const uint32_t d = static_cast<uint32_t>(k[it] >> shift) & 255u;
+      dg[it] = valid ? d : 256u;  // 256 = not participating
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const bool set = (d >> bit) & 1u;
+        const unsigned long long m = __ballot(set);
+        peers &= set ? m : ~m;
+      }
+      const uint32_t cnt = __popcll(peers);
+      const uint32_t lrank = __popcll(peers & lanemask_lt());
+      uint32_t prev = 0;
+      if (valid) prev = s_whist[w][d];
+      __builtin_amdgcn_wave_barrier();
+      if (valid && lrank == 0) s_whist[w][d] = prev + cnt;
+      __builtin_amdgcn_wave_barrier();
+      r[it] = prev + lrank;
+    }
+    __syncthreads();
+    uint32_t run = 0;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      const uint32_t c = s_whist[ww][tid];
+      s_whist[ww][tid] = run;
+      run += c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kSortItems; ++it) {
+      if (dg[it] < 256u) {
+        const uint32_t pos = s_base[dg[it]] + s_whist[w][dg[it]] + r[it];
+        keys_out[pos] = k[it];
+        vals_out[pos] = v[it];
+      }
+    }
+    __syncthreads();
+    s_base[tid] += run;
+  }
+}
+
+struct SortPlan {
+  int nblocks;
+  int64_t chunk;
+};
+
+inline SortPlan sort_plan(int64_t n) {
+  SortPlan p;
+  int64_t tiles = (n + kSortTile - 1) / kSortTile;
+  if (tiles < 1) tiles = 1;
+  p.nblocks = static_cast<int>(tiles < kSortMaxBlocks ? tiles : kSortMaxBlocks);
+  const int64_t tiles_per_block = (tiles + p.nblocks - 1) / p.nblocks;
+  p.chunk = tiles_per_block * kSortTile;
+  p.nblocks = static_cast<int>((n + p.chunk - 1) / p.chunk);
+  if (p.nblocks < 1) p.nblocks = 1;
+  return p;
+}
+
+// scratch words needed besides the two ping-pong (key,val) buffers
+inline size_t sort_scratch_words() { return 256 * static_cast<size_t>(kSortMaxBlocks) + 256; }
+
+// Sorts (keys, vals) by the low `key_bits` bits of the key.  Buffers ping-pong between
+// (k0,v0) and (k1,v1); returns in *result_in_first whether the sorted data ended in (k0,v0).
+template <typename KeyT, typename ValT>
+int radix_sort_pairs(KeyT* k0, ValT* v0, KeyT* k1, ValT* v1, int64_t n, int key_bits, uint32_t* scratch,
+                     hipStream_t stream, bool* result_in_first) {
+  *result_in_first = true;
+  if (n <= 1 || key_bits <= 0) return TGP_OK;
+  const SortPlan p = sort_plan(n);
+  uint32_t* hist = scratch;
+  uint32_t* digit_total = scratch + 256 * static_cast<size_t>(kSortMaxBlocks);
+  const int passes = (key_bits + 7) / 8;
+  KeyT *ki = k0, *ko = k1;
+  ValT *vi = v0, *vo = v1;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = pass * 8;
+    hipLaunchKernelGGL((radix_hist_kernel<KeyT>), dim3(p.nblocks), dim3(kSortThreads), 0, stream, ki, n,
+                       p.chunk, shift, p.nblocks, hist);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(1024), 0, stream, hist, p.nblocks, digit_total);
+    hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT>), dim3(p.nblocks), dim3(kSortThreads), 0, stream,
+                       ki, vi, ko, vo, hist, digit_total, n, p.chunk, shift, p.nblocks);
+    KeyT* tk = ki; ki = ko; ko = tk;
+    ValT* tv = vi; vi = vo; vo = tv;
+  }
+  *result_in_first = (ki == k0);
+  return check_launch("radix_sort_pairs");
+}
+
+inline int bits_for(uint64_t max_value) {
+  int b = 0;
+  while (max_value) { ++b; max_value >>= 1; }
+  return b < 1 ? 1 : b;
+}
+
+}  // namespace tgp

@@ -1,0 +1,656 @@
+// A4 / A5 / A6 / A10: sparse Connect (edge-list coarsening) and its post-processing.
+//
+// Everything here is HBM-bound int64 / fp32 stream processing.  Output order is part of the
+// contract (SURVEY.md 7 "ordering contracts"): PyG `subgraph` keeps input edge order, PyG
+// `coalesce` returns row-major sorted unique edges, `nonzero` returns (b,row,col) order — so all
+// compactions are scan-based (ballot ranks + block offsets), never atomic-append.
+#include "primitives.h"
+
+namespace tgp {
+
+constexpr int kCompactItems = 4;
+constexpr int kCompactTile = 256 * kCompactItems;
+
+// =====================================================================================
+// A5 + A6 filters: induced subgraph with relabelling (connect/base_conn.py:79-82)
+// =====================================================================================
+__global__ __launch_bounds__(256) void relabel_scatter_kernel(const int64_t* __restrict__ node_index, int64_t k,
+                                                              int32_t* __restrict__ relabel) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (j < k) relabel[node_index[j]] = static_cast<int32_t>(j);
+}
+
+struct SubgraphPred {
+  const int64_t* row;
+  const int64_t* col;
+  const float* w;
+  const int32_t* relabel;  // nullptr = no node filter
+  int flags;
+  __device__ __forceinline__ bool operator()(int64_t e, int64_t& r, int64_t& c) const {
+    r = row[e];
+    c = col[e];
+    if (relabel) {
+      r = relabel[r];
+      c = relabel[c];
+      if ((r | c) < 0) return false;
+    }
+    if ((flags & TGP_REMOVE_SELF_LOOPS) && r == c) return false;
+    if (w && (flags & TGP_EPS_FILTER) && !(fabsf(w[e]) > TGP_EPS)) return false;
+    return true;
+  }
+};
+
+__global__ __launch_bounds__(256) void subgraph_count_kernel(SubgraphPred pred, int64_t E,
+                                                             uint32_t* __restrict__ block_counts) {
+  __shared__ uint32_t s_cnt[4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kCompactTile;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int it = 0; it < kCompactItems; ++it) {
+    const int64_t e = base + it * 256 + threadIdx.x;
+    int64_t r, c;
+    const bool keep = e < E && pred(e, r, c);
+    mine += __popcll(__ballot(keep));
+  }
+  if (lane_id() == 0) s_cnt[wave_id()] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ __launch_bounds__(256) void subgraph_fill_kernel(SubgraphPred pred, int64_t E,
+                                                            const uint32_t* __restrict__ block_offsets,
+                                                            int64_t* __restrict__ out_row,
+                                                            int64_t* __restrict__ out_col,
+                                                            float* __restrict__ out_w) {
+  __shared__ uint32_t s_cnt[kCompactItems * 4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kCompactTile;
+  bool keep[kCompactItems];
+  int64_t r[kCompactItems], c[kCompactItems];
+  uint32_t rank[kCompactItems];
+#pragma unroll
+  for (int it = 0; it < kCompactItems; ++it) {
+    const int64_t e = base + it * 256 + threadIdx.x;
+    keep[it] = e < E && pred(e, r[it], c[it]);
+  }
+  uint32_t total;
+  block_compact_ranks<kCompactItems>(keep, rank, total, s_cnt);
+  const int64_t off = block_offsets[blockIdx.x];
+#pragma unroll
+  for (int it = 0; it < kCompactItems; ++it) {
+    if (keep[it]) {
+      const int64_t e = base + it * 256 + threadIdx.x;
+      out_row[off + rank[it]] = r[it];
+      out_col[off + rank[it]] = c[it];
+      if (out_w) out_w[off + rank[it]] = pred.w[e];
+    }
+  }
+}
+
+// =====================================================================================
+// A4: relabel by cluster + coalesce (connect/base_conn.py:83-89)
+// =====================================================================================
+__global__ __launch_bounds__(256) void coalesce_keys_kernel(const int64_t* __restrict__ row,
+                                                            const int64_t* __restrict__ col,
+                                                            const float* __restrict__ w,
+                                                            const int64_t* __restrict__ cluster, int64_t E,
+                                                            uint64_t K, uint64_t* __restrict__ keys,
+                                                            float* __restrict__ vals) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e < E) {
+    keys[e] = static_cast<uint64_t>(cluster[row[e]]) * K + static_cast<uint64_t>(cluster[col[e]]);
+    vals[e] = w ? w[e] : 1.0f;
+  }
+}
+
+// Head of every run of equal keys reduces its run in sorted (= stable input) order, decides
+// whether the merged edge survives the filters, and the block counts survivors.
+// seg[i] holds the merged weight at run heads; keepflag[i] = 1 at surviving heads.
+__global__ __launch_bounds__(256) void coalesce_segment_kernel(const uint64_t* __restrict__ keys,
+                                                               const float* __restrict__ vals, int64_t E,
+                                                               uint64_t K, int has_weight, int reduce_op,
+                                                               int flags, float* __restrict__ seg,
+                                                               uint8_t* __restrict__ keepflag,
+                                                               uint32_t* __restrict__ block_counts) {
+  __shared__ uint32_t s_cnt[4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kCompactTile;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int it = 0; it < kCompactItems; ++it) {
+    const int64_t i = base + it * 256 + threadIdx.x;
+    bool keep = false;
+    if (i < E) {
+      const uint64_t key = keys[i];
+      const bool head = (i == 0) || keys[i - 1] != key;
+      if (head) {
+        keep = true;
+        const uint64_t r = key / K, c = key - r * K;
+        if ((flags & TGP_REMOVE_SELF_LOOPS) && r == c) keep = false;
+        if (has_weight) {
+          float acc = vals[i];
+          int64_t n = 1;
+          for (int64_t j = i + 1; j < E && keys[j] == key; ++j, ++n) {
+            const float v = vals[j];
+            switch (reduce_op) {
+              case TGP_MIN: acc = fminf(acc, v); break;
+              case TGP_MAX: acc = fmaxf(acc, v); break;
+              case TGP_MUL: acc = __fmul_rn(acc, v); break;
+              default: acc = __fadd_rn(acc, v); break;
+            }
+          }
+          if (reduce_op == TGP_MEAN) acc = acc / static_cast<float>(n);
+          seg[i] = acc;
+          if ((flags & TGP_EPS_FILTER) && !(fabsf(acc) > TGP_EPS)) keep = false;
+        }
+      }
+      keepflag[i] = keep ? 1 : 0;
+    }
+    mine += __popcll(__ballot(keep));
+  }
+  if (lane_id() == 0) s_cnt[wave_id()] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ __launch_bounds__(256) void coalesce_fill_kernel(const uint64_t* __restrict__ keys,
+                                                            const float* __restrict__ seg,
+                                                            const uint8_t* __restrict__ keepflag, int64_t E,
+                                                            uint64_t K, const uint32_t* __restrict__ block_offsets,
+                                                            int64_t* __restrict__ out_row,
+                                                            int64_t* __restrict__ out_col,
+                                                            float* __restrict__ out_w) {
+  __shared__ uint32_t s_cnt[kCompactItems * 4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kCompactTile;
+  bool keep[kCompactItems];
+  uint32_t rank[kCompactItems];
+#pragma unroll
+  for (int it = 0; it < kCompactItems; ++it) {
+    const int64_t i = base + it * 256 + threadIdx.x;
+    keep[it] = i < E && keepflag[i] != 0;
+  }
+  uint32_t total;
+  block_compact_ranks<kCompactItems>(keep, rank, total, s_cnt);
+  const int64_t off = block_offsets[blockIdx.x];
+#pragma unroll
+  for (int it = 0; it < kCompactItems; ++it) {
+    if (keep[it]) {
+      const int64_t i = base + it * 256 + threadIdx.x;
+      const uint64_t key = keys[i];
+      const uint64_t r = key / K;
+      out_row[off + rank[it]] = static_cast<int64_t>(r);
+      out_col[off + rank[it]] = static_cast<int64_t>(key - r * K);
+      if (out_w) out_w[off + rank[it]] = seg[i];
+    }
+  }
+}
+
+// =====================================================================================
+// A6 normalisations (utils/ops.py:383-417) on a pooled edge list, in place
+// =====================================================================================
+__global__ __launch_bounds__(256) void fill_f32_kernel(float* p, int64_t n, float v) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// Degree of the pooled graph.  When the edge list is sorted by row (coalesce output, PyG edge
+// lists) the first edge of each row sums its run in list order -- deterministic and in the
+// order of the CPU scatter_add_.  An unsorted list falls back to float atomics.
+__global__ __launch_bounds__(256) void check_sorted_rows_kernel(const int64_t* __restrict__ row, int64_t E,
+                                                                int* __restrict__ unsorted) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e + 1 < E && row[e] > row[e + 1]) *unsorted = 1;
+}
+
+// Sorted rows: the first edge of every row adds up its run sequentially (same order as the CPU
+// scatter_add_).  Skipped (no-op) when *unsorted is set.
+__global__ __launch_bounds__(256) void degree_sorted_kernel(const int64_t* __restrict__ row,
+                                                            const float* __restrict__ w, int64_t E,
+                                                            const int* __restrict__ unsorted,
+                                                            float* __restrict__ deg) {
+  if (*unsorted) return;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int64_t r = row[e];
+  if (e > 0 && row[e - 1] == r) return;
+  float acc = 0.f;
+  for (int64_t j = e; j < E && row[j] == r; ++j) acc = __fadd_rn(acc, w[j]);
+  deg[r] = acc;
+}
+
+__global__ __launch_bounds__(256) void degree_fallback_kernel(const int64_t* __restrict__ row,
+                                                              const float* __restrict__ w, int64_t E,
+                                                              const int* __restrict__ unsorted,
+                                                              float* __restrict__ deg) {
+  if (!*unsorted) return;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e < E) atomicAdd(&deg[row[e]], w[e]);
+}
+
+__global__ __launch_bounds__(256) void degree_scale_kernel(const int64_t* __restrict__ row,
+                                                           const int64_t* __restrict__ col,
+                                                           float* __restrict__ w, int64_t E,
+                                                           const float* __restrict__ deg) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e < E) {
+    // deg.clamp(min=eps).pow(-0.5); w * dis[row] * dis[col]  (ops.py:395-401)
+    const float dr = 1.0f / sqrtf(fmaxf(deg[row[e]], TGP_EPS));
+    const float dc = 1.0f / sqrtf(fmaxf(deg[col[e]], TGP_EPS));
+    w[e] = __fmul_rn(__fmul_rn(w[e], dr), dc);
+  }
+}
+
+// |w| is non-negative, so its IEEE bit pattern orders like an unsigned int: exact, order-free max.
+__global__ __launch_bounds__(256) void graph_max_kernel(const int64_t* __restrict__ row,
+                                                        const float* __restrict__ w, int64_t E,
+                                                        const int64_t* __restrict__ batch_pooled,
+                                                        uint32_t* __restrict__ gmax) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e < E) atomicMax(&gmax[batch_pooled[row[e]]], __float_as_uint(fabsf(w[e])));
+}
+
+__global__ __launch_bounds__(256) void graph_max_scale_kernel(const int64_t* __restrict__ row,
+                                                              float* __restrict__ w, int64_t E,
+                                                              const int64_t* __restrict__ batch_pooled,
+                                                              const uint32_t* __restrict__ gmax) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e < E) {
+    float m = __uint_as_float(gmax[batch_pooled[row[e]]]);
+    if (m == 0.f) m = 1.f;
+    w[e] = w[e] / m;
+  }
+}
+
+// =====================================================================================
+// A10: dense [B,K,K] -> block-diagonal edge list (utils/ops.py:53-82, src.py:526-552)
+// =====================================================================================
+struct BlockDiagPred {
+  const float* adj;
+  const int64_t* relabel;  // [B*K] new id or -1; nullptr = identity
+  int64_t K;
+  int flags;
+  __device__ __forceinline__ bool operator()(int64_t i, int64_t& r, int64_t& c, float& v) const {
+    v = adj[i];
+    const int64_t kk = K * K;
+    const int64_t b = i / kk, rem = i - b * kk;
+    const int64_t rr = rem / K;
+    r = b * K + rr;
+    c = b * K + (rem - rr * K);
+    if (!(fabsf(v) > TGP_EPS)) return false;
+    if (relabel) {
+      r = relabel[r];
+      c = relabel[c];
+      if ((r | c) < 0) return false;
+    }
+    if ((flags & TGP_REMOVE_SELF_LOOPS) && r == c) return false;
+    return true;
+  }
+};
+
+__global__ __launch_bounds__(256) void blockdiag_count_kernel(BlockDiagPred pred, int64_t total,
+                                                              uint32_t* __restrict__ block_counts) {
+  __shared__ uint32_t s_cnt[4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kCompactTile;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int it = 0; it < kCompactItems; ++it) {
+    const int64_t i = base + it * 256 + threadIdx.x;
+    int64_t r, c;
+    float v;
+    const bool keep = i < total && pred(i, r, c, v);
+    mine += __popcll(__ballot(keep));
+  }
+  if (lane_id() == 0) s_cnt[wave_id()] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ __launch_bounds__(256) void blockdiag_fill_kernel(BlockDiagPred pred, int64_t total,
+                                                             const uint32_t* __restrict__ block_offsets,
+                                                             int64_t* __restrict__ out_row,
+                                                             int64_t* __restrict__ out_col,
+                                                             float* __restrict__ out_w) {
+  __shared__ uint32_t s_cnt[kCompactItems * 4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kCompactTile;
+  bool keep[kCompactItems];
+  int64_t r[kCompactItems], c[kCompactItems];
+  float v[kCompactItems];
+  uint32_t rank[kCompactItems];
+#pragma unroll
+  for (int it = 0; it < kCompactItems; ++it) {
+    const int64_t i = base + it * 256 + threadIdx.x;
+    keep[it] = i < total && pred(i, r[it], c[it], v[it]);
+  }
+  uint32_t tot;
+  block_compact_ranks<kCompactItems>(keep, rank, tot, s_cnt);
+  const int64_t off = block_offsets[blockIdx.x];
+#pragma unroll
+  for (int it = 0; it < kCompactItems; ++it) {
+    if (keep[it]) {
+      out_row[off + rank[it]] = r[it];
+      out_col[off + rank[it]] = c[it];
+      out_w[off + rank[it]] = v[it];
+    }
+  }
+}
+
+
+// =====================================================================================
+// A7' helper: CSR SpMM  T[i,:] = sum_e w[e] * S[col[e],:]   (connect/dense_conn.py:165,204)
+// one group of G lanes per row, float4 per lane; rows are summed in CSR (= sorted) order
+// =====================================================================================
+__global__ __launch_bounds__(256) void rowptr_from_sorted_kernel(const int64_t* __restrict__ rows, int64_t n,
+                                                                 int64_t num_rows, int32_t* __restrict__ row_ptr) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (p > n) return;
+  if (p == n) {
+    const int64_t first = n > 0 ? rows[n - 1] + 1 : 0;
+    for (int64_t c = first; c <= num_rows; ++c) row_ptr[c] = static_cast<int32_t>(n);
+    return;
+  }
+  const int64_t cur = rows[p];
+  const int64_t prev = p > 0 ? rows[p - 1] : -1;
+  for (int64_t c = prev + 1; c <= cur; ++c) row_ptr[c] = static_cast<int32_t>(p);
+}
+
+__global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict__ row_ptr,
+                                                       const int64_t* __restrict__ col,
+                                                       const float* __restrict__ w, int64_t num_rows,
+                                                       const float* __restrict__ S, int64_t K,
+                                                       float* __restrict__ T) {
+  const int64_t total = num_rows * K;
+  for (int64_t o = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; o < total;
+       o += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t i = o / K, f = o - i * K;
+    float acc = 0.f;
+    for (int32_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e)
+      acc = __fadd_rn(acc, __fmul_rn(w ? w[e] : 1.0f, S[col[e] * K + f]));
+    T[o] = acc;
+  }
+}
+
+}  // namespace tgp
+
+using namespace tgp;
+
+// ------------------------------------------------------------------------------------- subgraph
+extern "C" size_t tgp_connect_subgraph_workspace_bytes(int64_t E, int64_t N) {
+  const size_t nb = static_cast<size_t>(cdiv(E > 0 ? E : 1, kCompactTile));
+  return align_up((N > 0 ? N : 1) * sizeof(int32_t)) + 2 * align_up(nb * sizeof(uint32_t)) + 256;
+}
+
+struct SubgraphWs {
+  int32_t* relabel;
+  uint32_t* counts;
+  uint32_t* offsets;
+};
+static SubgraphWs carve_subgraph(void* ws, int64_t E, int64_t N) {
+  Carver cv(ws);
+  const size_t nb = static_cast<size_t>(cdiv(E > 0 ? E : 1, kCompactTile));
+  SubgraphWs s;
+  s.relabel = cv.take<int32_t>(N > 0 ? N : 1);
+  s.counts = cv.take<uint32_t>(nb);
+  s.offsets = cv.take<uint32_t>(nb);
+  return s;
+}
+
+extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                          const int64_t* node_index, int64_t k, int64_t N, int flags, void* ws,
+                                          size_t ws_bytes, int64_t* d_count, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E >= 0 && N >= 0 && k >= 0 && d_count && (E == 0 || (row && col)), TGP_ERR_INVALID,
+              "tgp_connect_subgraph_count: bad argument");
+  TGP_REQUIRE(E < (1ll << 31) && N < (1ll << 31), TGP_ERR_RANGE, "tgp_connect_subgraph_count: E/N >= 2^31");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_connect_subgraph_workspace_bytes(E, N), TGP_ERR_WORKSPACE,
+              "tgp_connect_subgraph_count: workspace too small");
+  SubgraphWs s = carve_subgraph(ws, E, N);
+  if (node_index) {
+    (void)hipMemsetAsync(s.relabel, 0xFF, static_cast<size_t>(N > 0 ? N : 1) * sizeof(int32_t), stream);
+    if (k > 0)
+      hipLaunchKernelGGL(relabel_scatter_kernel, dim3(cdiv(k, 256)), dim3(256), 0, stream, node_index, k,
+                         s.relabel);
+  }
+  const int nb = cdiv(E > 0 ? E : 1, kCompactTile);
+  SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, flags};
+  hipLaunchKernelGGL(subgraph_count_kernel, dim3(nb), dim3(256), 0, stream, pred, E, s.counts);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nb, s.offsets, d_count);
+  return check_launch("tgp_connect_subgraph_count");
+}
+
+extern "C" int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                         int64_t N, int flags, const void* ws, int64_t num_out,
+                                         int64_t* out_row, int64_t* out_col, float* out_w, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E >= 0 && num_out >= 0 && ws, TGP_ERR_INVALID, "tgp_connect_subgraph_fill: bad argument");
+  if (num_out == 0 || E == 0) return TGP_OK;
+  TGP_REQUIRE(out_row && out_col && (!w || out_w), TGP_ERR_INVALID, "tgp_connect_subgraph_fill: null output");
+  SubgraphWs s = carve_subgraph(const_cast<void*>(ws), E, N);
+  const int nb = cdiv(E, kCompactTile);
+  SubgraphPred pred{row, col, w, (flags & TGP_NODE_FILTER) ? s.relabel : nullptr,
+                    flags};
+  hipLaunchKernelGGL(subgraph_fill_kernel, dim3(nb), dim3(256), 0, stream, pred, E, s.offsets, out_row, out_col,
+                     w ? out_w : nullptr);
+  return check_launch("tgp_connect_subgraph_fill");
+}
+
+// ------------------------------------------------------------------------------------- coalesce
+struct CoalesceWs {
+  uint64_t *k0, *k1;
+  float *v0, *v1;
+  float* seg;
+  uint8_t* keep;
+  uint32_t *counts, *offsets, *scratch;
+};
+static size_t coalesce_layout(void* ws, int64_t E, CoalesceWs* out) {
+  Carver cv(ws);
+  const size_t n = static_cast<size_t>(E > 0 ? E : 1);
+  const size_t nb = static_cast<size_t>(cdiv(E > 0 ? E : 1, kCompactTile));
+  CoalesceWs s;
+  s.k0 = cv.take<uint64_t>(n);
+  s.k1 = cv.take<uint64_t>(n);
+  s.v0 = cv.take<float>(n);
+  s.v1 = cv.take<float>(n);
+  s.seg = cv.take<float>(n);
+  s.keep = cv.take<uint8_t>(n);
+  s.counts = cv.take<uint32_t>(nb);
+  s.offsets = cv.take<uint32_t>(nb);
+  s.scratch = cv.take<uint32_t>(sort_scratch_words());
+  if (out) *out = s;
+  return cv.off;
+}
+
+extern "C" size_t tgp_connect_coalesce_workspace_bytes(int64_t E, int64_t /*K*/) {
+  return coalesce_layout(nullptr, E, nullptr) + 256;
+}
+
+extern "C" int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                          const int64_t* cluster_index, int64_t N, int64_t K, int reduce_op,
+                                          int flags, void* ws, size_t ws_bytes, int64_t* d_count,
+                                          void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && d_count && (E == 0 || (row && col && cluster_index)),
+              TGP_ERR_INVALID, "tgp_connect_coalesce_count: bad argument");
+  TGP_REQUIRE(reduce_op >= TGP_SUM && reduce_op <= TGP_MUL, TGP_ERR_INVALID,
+              "tgp_connect_coalesce_count: unknown reduce_op %d", reduce_op);
+  TGP_REQUIRE(E < (1ll << 31) && K < (1ll << 31), TGP_ERR_RANGE, "tgp_connect_coalesce_count: E/K >= 2^31");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_connect_coalesce_workspace_bytes(E, K), TGP_ERR_WORKSPACE,
+              "tgp_connect_coalesce_count: workspace too small");
+  CoalesceWs s;
+  coalesce_layout(ws, E, &s);
+  if (E == 0) {
+    (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
+    return check_launch("tgp_connect_coalesce_count");
+  }
+  const uint64_t Ku = static_cast<uint64_t>(K > 0 ? K : 1);
+  hipLaunchKernelGGL(coalesce_keys_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, cluster_index,
+                     E, Ku, s.k0, s.v0);
+  bool first = true;
+  const int rc = radix_sort_pairs<uint64_t, float>(s.k0, s.v0, s.k1, s.v1, E, bits_for(Ku * Ku - 1), s.scratch,
+                                                   stream, &first);
+  if (rc != TGP_OK) return rc;
+  const int nb = cdiv(E, kCompactTile);
+  hipLaunchKernelGGL(coalesce_segment_kernel, dim3(nb), dim3(256), 0, stream, first ? s.k0 : s.k1,
+                     first ? s.v0 : s.v1, E, Ku, w ? 1 : 0, reduce_op, flags, s.seg, s.keep, s.counts);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nb, s.offsets, d_count);
+  return check_launch("tgp_connect_coalesce_count");
+}
+
+extern "C" int tgp_connect_coalesce_fill(const void* ws, int64_t E, int64_t K, int has_weight, int /*flags*/,
+                                         int64_t num_out, int64_t* out_row, int64_t* out_col, float* out_w,
+                                         void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(ws && E >= 0 && num_out >= 0, TGP_ERR_INVALID, "tgp_connect_coalesce_fill: bad argument");
+  if (num_out == 0 || E == 0) return TGP_OK;
+  TGP_REQUIRE(out_row && out_col && (!has_weight || out_w), TGP_ERR_INVALID,
+              "tgp_connect_coalesce_fill: null output");
+  CoalesceWs s;
+  coalesce_layout(const_cast<void*>(ws), E, &s);
+  const uint64_t Ku = static_cast<uint64_t>(K > 0 ? K : 1);
+  // The ping-pong parity is a pure function of (E, K): recompute it instead of reading it back.
+  const int passes = (E <= 1) ? 0 : (bits_for(Ku * Ku - 1) + 7) / 8;
+  const bool first = (passes % 2) == 0;
+  const int nb = cdiv(E, kCompactTile);
+  hipLaunchKernelGGL(coalesce_fill_kernel, dim3(nb), dim3(256), 0, stream, first ? s.k0 : s.k1, s.seg, s.keep, E,
+                     Ku, s.offsets, out_row, out_col, has_weight ? out_w : nullptr);
+  return check_launch("tgp_connect_coalesce_fill");
+}
+
+// ------------------------------------------------------------------------------------- norms
+extern "C" size_t tgp_postprocess_sparse_workspace_bytes(int64_t /*E*/, int64_t num_nodes, int64_t num_graphs) {
+  return align_up((num_nodes > 0 ? num_nodes : 1) * sizeof(float)) +
+         align_up((num_graphs > 0 ? num_graphs : 1) * sizeof(uint32_t)) + 512;
+}
+
+extern "C" int tgp_postprocess_sparse_norm_f32(const int64_t* row, const int64_t* col, float* w, int64_t E,
+                                               int64_t num_nodes, int flags, const int64_t* batch_pooled,
+                                               int64_t num_graphs, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E >= 0 && num_nodes >= 0, TGP_ERR_INVALID, "tgp_postprocess_sparse_norm_f32: bad size");
+  if (E == 0) return TGP_OK;
+  TGP_REQUIRE(row && col && w, TGP_ERR_INVALID, "tgp_postprocess_sparse_norm_f32: null pointer");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_postprocess_sparse_workspace_bytes(E, num_nodes, num_graphs),
+              TGP_ERR_WORKSPACE, "tgp_postprocess_sparse_norm_f32: workspace too small");
+  Carver cv(ws);
+  float* deg = cv.take<float>(num_nodes > 0 ? num_nodes : 1);
+  uint32_t* gmax = cv.take<uint32_t>(num_graphs > 0 ? num_graphs : 1);
+  int* unsorted = cv.take<int>(4);
+  const int nb = cdiv(E, 256);
+  if (flags & TGP_DEGREE_NORM) {
+    (void)hipMemsetAsync(deg, 0, static_cast<size_t>(num_nodes) * sizeof(float), stream);
+    (void)hipMemsetAsync(unsorted, 0, sizeof(int), stream);
+    hipLaunchKernelGGL(check_sorted_rows_kernel, dim3(nb), dim3(256), 0, stream, row, E, unsorted);
+    hipLaunchKernelGGL(degree_sorted_kernel, dim3(nb), dim3(256), 0, stream, row, w, E, unsorted, deg);
+    hipLaunchKernelGGL(degree_fallback_kernel, dim3(nb), dim3(256), 0, stream, row, w, E, unsorted, deg);
+    hipLaunchKernelGGL(degree_scale_kernel, dim3(nb), dim3(256), 0, stream, row, col, w, E, deg);
+  }
+  if (flags & TGP_EDGE_WEIGHT_NORM) {
+    TGP_REQUIRE(batch_pooled && num_graphs > 0, TGP_ERR_INVALID,
+                "tgp_postprocess_sparse_norm_f32: batch_pooled required for edge_weight_norm");
+    (void)hipMemsetAsync(gmax, 0, static_cast<size_t>(num_graphs) * sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(graph_max_kernel, dim3(nb), dim3(256), 0, stream, row, w, E, batch_pooled, gmax);
+    hipLaunchKernelGGL(graph_max_scale_kernel, dim3(nb), dim3(256), 0, stream, row, w, E, batch_pooled, gmax);
+  }
+  return check_launch("tgp_postprocess_sparse_norm_f32");
+}
+
+// ------------------------------------------------------------------------------------- block diag
+extern "C" size_t tgp_block_diag_workspace_bytes(int64_t B, int64_t K) {
+  const int64_t total = B * K * K;
+  const size_t nb = static_cast<size_t>(cdiv(total > 0 ? total : 1, kCompactTile));
+  return 2 * align_up(nb * sizeof(uint32_t)) + 256;
+}
+
+extern "C" int tgp_block_diag_count(const float* adj, int64_t B, int64_t K, const int64_t* relabel, int flags,
+                                    void* ws, size_t ws_bytes, int64_t* d_count, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && K >= 0 && d_count, TGP_ERR_INVALID, "tgp_block_diag_count: bad argument");
+  const int64_t total = B * K * K;
+  TGP_REQUIRE(total < (1ll << 31), TGP_ERR_RANGE, "tgp_block_diag_count: B*K*K >= 2^31");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_block_diag_workspace_bytes(B, K), TGP_ERR_WORKSPACE,
+              "tgp_block_diag_count: workspace too small");
+  if (total == 0) {
+    (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
+    return check_launch("tgp_block_diag_count");
+  }
+  TGP_REQUIRE(adj, TGP_ERR_INVALID, "tgp_block_diag_count: null adjacency");
+  Carver cv(ws);
+  const int nb = cdiv(total, kCompactTile);
+  uint32_t* counts = cv.take<uint32_t>(nb);
+  uint32_t* offsets = cv.take<uint32_t>(nb);
+  BlockDiagPred pred{adj, relabel, K, flags};
+  hipLaunchKernelGGL(blockdiag_count_kernel, dim3(nb), dim3(256), 0, stream, pred, total, counts);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts, nb, offsets, d_count);
+  return check_launch("tgp_block_diag_count");
+}
+
+extern "C" int tgp_block_diag_fill(const float* adj, int64_t B, int64_t K, const int64_t* relabel, int flags,
+                                   const void* ws, int64_t num_out, int64_t* out_row, int64_t* out_col,
+                                   float* out_w, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int64_t total = B * K * K;
+  TGP_REQUIRE(ws && num_out >= 0, TGP_ERR_INVALID, "tgp_block_diag_fill: bad argument");
+  if (num_out == 0 || total == 0) return TGP_OK;
+  TGP_REQUIRE(adj && out_row && out_col && out_w, TGP_ERR_INVALID, "tgp_block_diag_fill: null pointer");
+  Carver cv(const_cast<void*>(ws));
+  const int nb = cdiv(total, kCompactTile);
+  cv.take<uint32_t>(nb);
+  uint32_t* offsets = cv.take<uint32_t>(nb);
+  BlockDiagPred pred{adj, relabel, K, flags};
+  hipLaunchKernelGGL(blockdiag_fill_kernel, dim3(nb), dim3(256), 0, stream, pred, total, offsets, out_row,
+                     out_col, out_w);
+  return check_launch("tgp_block_diag_fill");
+}
+
+// ------------------------------------------------------------------------------------- debug sort
+extern "C" size_t tgp_debug_sort_workspace_bytes(int64_t n) {
+  const size_t m = static_cast<size_t>(n > 0 ? n : 1);
+  return 2 * align_up(m * sizeof(uint64_t)) + 2 * align_up(m * sizeof(uint32_t)) +
+         align_up(sort_scratch_words() * sizeof(uint32_t));
+}
+
+extern "C" int tgp_debug_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, int64_t n,
+                                        int key_bits, uint64_t* keys_out, uint32_t* vals_out, void* ws,
+                                        size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(n >= 0 && key_bits >= 0 && key_bits <= 64, TGP_ERR_INVALID, "tgp_debug_sort_pairs_u64: bad argument");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_debug_sort_workspace_bytes(n), TGP_ERR_WORKSPACE,
+              "tgp_debug_sort_pairs_u64: workspace too small");
+  if (n == 0) return TGP_OK;
+  Carver cv(ws);
+  uint64_t* k0 = cv.take<uint64_t>(n);
+  uint64_t* k1 = cv.take<uint64_t>(n);
+  uint32_t* v0 = cv.take<uint32_t>(n);
+  uint32_t* v1 = cv.take<uint32_t>(n);
+  uint32_t* scratch = cv.take<uint32_t>(sort_scratch_words());
+  (void)hipMemcpyAsync(k0, keys_in, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream);
+  (void)hipMemcpyAsync(v0, vals_in, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+  bool first = true;
+  const int rc = radix_sort_pairs<uint64_t, uint32_t>(k0, v0, k1, v1, n, key_bits, scratch, stream, &first);
+  if (rc != TGP_OK) return rc;
+  (void)hipMemcpyAsync(keys_out, first ? k0 : k1, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream);
+  (void)hipMemcpyAsync(vals_out, first ? v0 : v1, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+  return check_launch("tgp_debug_sort_pairs_u64");
+}
+
+// ------------------------------------------------------------------------------------- SpMM (A7')
+extern "C" int tgp_rowptr_from_sorted_i64(const int64_t* rows, int64_t n, int64_t num_rows, int32_t* row_ptr,
+                                          void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(n >= 0 && num_rows >= 0 && row_ptr && (n == 0 || rows), TGP_ERR_INVALID,
+              "tgp_rowptr_from_sorted_i64: bad argument");
+  TGP_REQUIRE(n < (1ll << 31), TGP_ERR_RANGE, "tgp_rowptr_from_sorted_i64: n >= 2^31");
+  hipLaunchKernelGGL(rowptr_from_sorted_kernel, dim3(cdiv(n + 1, 256)), dim3(256), 0, stream, rows, n, num_rows,
+                     row_ptr);
+  return check_launch("tgp_rowptr_from_sorted_i64");
+}
+
+extern "C" int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows,
+                                int64_t nnz, const float* S, int64_t K, float* T, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(num_rows >= 0 && nnz >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_spmm_csr_f32: negative size");
+  if (num_rows == 0 || K == 0) return TGP_OK;
+  TGP_REQUIRE(row_ptr && T && (nnz == 0 || (col && S)), TGP_ERR_INVALID, "tgp_spmm_csr_f32: null pointer");
+  int64_t blocks = (num_rows * K + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(spmm_csr_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, row_ptr, col, w,
+                     num_rows, S, K, T);
+  return check_launch("tgp_spmm_csr_f32");
+}

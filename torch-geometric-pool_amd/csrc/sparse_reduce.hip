@@ -1,0 +1,196 @@
+// A1 / A2: sparse Reduce  x_pool = S^T X for a sparse assignment S (one HBM pass, no atomics).
+//
+// Reference: tgp/reduce/base_reduce.py:141-155 materialises src = x[node_index] * weight
+// ([nnz,F]) and scatter_add_s it.  Here the assignment list is inverted once (CSR by
+// supernode, stable => ascending assignment order inside a supernode) and every pooled row is
+// produced by one sub-wave that streams its member rows: each x row and each x_pool row
+// crosses HBM exactly once, fully coalesced, and the summation order equals the sequential
+// CPU scatter (so the fp32 result is reproducible and bit-identical to it: the product is
+// rounded before the add, exactly as the reference's two-step form does).
+#include "primitives.h"
+
+namespace tgp {
+
+__global__ __launch_bounds__(256) void assign_keys_kernel(const int64_t* __restrict__ cluster_index,
+                                                          int64_t nnz, uint32_t* __restrict__ keys,
+                                                          uint32_t* __restrict__ vals) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < nnz) {
+    keys[i] = static_cast<uint32_t>(cluster_index[i]);
+    vals[i] = static_cast<uint32_t>(i);
+  }
+}
+
+// sorted keys -> row_ptr[K+1]; perm copied out as int32.
+__global__ __launch_bounds__(256) void assign_rowptr_kernel(const uint32_t* __restrict__ keys,
+                                                            const uint32_t* __restrict__ vals, int64_t nnz,
+                                                            int64_t K, int32_t* __restrict__ row_ptr,
+                                                            int32_t* __restrict__ perm) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (p >= nnz) {
+    if (p == nnz) {  // one extra thread closes the tail (also covers nnz == 0)
+      const int64_t first = nnz > 0 ? static_cast<int64_t>(keys[nnz - 1]) + 1 : 0;
+      for (int64_t c = first; c <= K; ++c) row_ptr[c] = static_cast<int32_t>(nnz);
+    }
+    return;
+  }
+  perm[p] = static_cast<int32_t>(vals[p]);
+  const int64_t cur = keys[p];
+  const int64_t prev = p > 0 ? static_cast<int64_t>(keys[p - 1]) : -1;
+  for (int64_t c = prev + 1; c <= cur; ++c) row_ptr[c] = static_cast<int32_t>(p);
+}
+
+// One group of G lanes per supernode; lane g owns features [4g,4g+4) (+ 4G strides).
+template <int G>
+__global__ __launch_bounds__(256) void reduce_sparse_vec4_kernel(
+    const float* __restrict__ x, int64_t F, int64_t x_stride, const int64_t* __restrict__ node_index,
+    const float* __restrict__ weight, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ perm,
+    int64_t K, float* __restrict__ x_pool) {
+  constexpr int GROUPS = 256 / G;
+  const int g = threadIdx.x % G;
+  const int64_t group = static_cast<int64_t>(blockIdx.x) * GROUPS + threadIdx.x / G;
+  const int64_t ngroups = static_cast<int64_t>(gridDim.x) * GROUPS;
+  for (int64_t c = group; c < K; c += ngroups) {
+    const int32_t beg = row_ptr[c], end = row_ptr[c + 1];
+    for (int64_t f = 4 * g; f < F; f += 4 * G) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int32_t p = beg; p < end; ++p) {
+        const int32_t a = perm[p];
+        const float w = weight ? weight[a] : 1.0f;
+        const float4 v = *reinterpret_cast<const float4*>(x + node_index[a] * x_stride + f);
+        acc.x = __fadd_rn(acc.x, __fmul_rn(v.x, w));
+        acc.y = __fadd_rn(acc.y, __fmul_rn(v.y, w));
+        acc.z = __fadd_rn(acc.z, __fmul_rn(v.z, w));
+        acc.w = __fadd_rn(acc.w, __fmul_rn(v.w, w));
+      }
+      *reinterpret_cast<float4*>(x_pool + c * F + f) = acc;
+    }
+  }
+}
+
+// Fallback for feature counts / strides that are not 16-byte friendly: one lane per feature.
+__global__ __launch_bounds__(256) void reduce_sparse_scalar_kernel(
+    const float* __restrict__ x, int64_t F, int64_t x_stride, const int64_t* __restrict__ node_index,
+    const float* __restrict__ weight, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ perm,
+    int64_t K, float* __restrict__ x_pool) {
+  const int64_t total = K * F;
+  for (int64_t o = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; o < total;
+       o += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t c = o / F, f = o - c * F;
+    float acc = 0.f;
+    for (int32_t p = row_ptr[c]; p < row_ptr[c + 1]; ++p) {
+      const int32_t a = perm[p];
+      const float w = weight ? weight[a] : 1.0f;
+      acc = __fadd_rn(acc, __fmul_rn(x[node_index[a] * x_stride + f], w));
+    }
+    x_pool[o] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void arange_i64_kernel(int64_t* out, int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) out[i] = i;
+}
+
+__global__ __launch_bounds__(256) void reduce_batch_kernel(const int64_t* __restrict__ batch,
+                                                           const int64_t* __restrict__ node_index,
+                                                           const int64_t* __restrict__ cluster_index,
+                                                           int64_t nnz, int64_t* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < nnz) out[cluster_index[i]] = batch[node_index[i]];
+}
+
+}  // namespace tgp
+
+using namespace tgp;
+
+extern "C" size_t tgp_assign_index_workspace_bytes(int64_t nnz, int64_t /*num_supernodes*/) {
+  const size_t n = nnz > 0 ? static_cast<size_t>(nnz) : 1;
+  return 4 * align_up(n * sizeof(uint32_t)) + align_up(sort_scratch_words() * sizeof(uint32_t));
+}
+
+extern "C" int tgp_assign_index_build(const int64_t* cluster_index, int64_t nnz, int64_t K, int32_t* row_ptr,
+                                      int32_t* perm, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(nnz >= 0 && K >= 0 && row_ptr && (nnz == 0 || (cluster_index && perm)), TGP_ERR_INVALID,
+              "tgp_assign_index_build: bad argument");
+  TGP_REQUIRE(nnz < (1ll << 31) && K < (1ll << 31), TGP_ERR_RANGE, "tgp_assign_index_build: nnz/K >= 2^31");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_assign_index_workspace_bytes(nnz, K), TGP_ERR_WORKSPACE,
+              "tgp_assign_index_build: workspace too small");
+  Carver cv(ws);
+  const size_t n = nnz > 0 ? static_cast<size_t>(nnz) : 1;
+  uint32_t* k0 = cv.take<uint32_t>(n);
+  uint32_t* v0 = cv.take<uint32_t>(n);
+  uint32_t* k1 = cv.take<uint32_t>(n);
+  uint32_t* v1 = cv.take<uint32_t>(n);
+  uint32_t* scratch = cv.take<uint32_t>(sort_scratch_words());
+  bool first = true;
+  if (nnz > 0) {
+    hipLaunchKernelGGL(assign_keys_kernel, dim3(cdiv(nnz, 256)), dim3(256), 0, stream, cluster_index, nnz, k0,
+                       v0);
+    const int rc = radix_sort_pairs<uint32_t, uint32_t>(k0, v0, k1, v1, nnz, bits_for(K > 0 ? K - 1 : 0),
+                                                        scratch, stream, &first);
+    if (rc != TGP_OK) return rc;
+  }
+  hipLaunchKernelGGL(assign_rowptr_kernel, dim3(cdiv(nnz + 1, 256)), dim3(256), 0, stream, first ? k0 : k1,
+                     first ? v0 : v1, nnz, K, row_ptr, perm);
+  return check_launch("tgp_assign_index_build");
+}
+
+extern "C" int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t F, int64_t x_stride,
+                                     const int64_t* node_index, const float* weight, const int32_t* row_ptr,
+                                     const int32_t* perm, int64_t nnz, int64_t K, float* x_pool,
+                                     void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(num_nodes >= 0 && F >= 0 && K >= 0 && nnz >= 0 && row_ptr, TGP_ERR_INVALID,
+              "tgp_reduce_sparse_f32: bad argument");
+  if (K == 0 || F == 0) return TGP_OK;
+  TGP_REQUIRE(x_pool && (nnz == 0 || (x && node_index && perm)), TGP_ERR_INVALID,
+              "tgp_reduce_sparse_f32: null pointer");
+  const bool vec = (F % 4 == 0) && (x_stride % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
+                   (reinterpret_cast<uintptr_t>(x_pool) % 16 == 0);
+  const int cus = 256;
+  if (vec) {
+    const int64_t lanes = F / 4;
+    int G = 1;
+    while (G < lanes && G < 64) G <<= 1;
+    const int64_t groups_per_block = 256 / G;
+    int64_t blocks = (K + groups_per_block - 1) / groups_per_block;
+    if (blocks > cus * 16) blocks = cus * 16;
+    dim3 grid(static_cast<unsigned>(blocks)), block(256);
+#define TGP_LAUNCH_G(GG)                                                                                   \
+  hipLaunchKernelGGL((reduce_sparse_vec4_kernel<GG>), grid, block, 0, stream, x, F, x_stride, node_index, \
+                     weight, row_ptr, perm, K, x_pool)
+    switch (G) {
+      case 1: TGP_LAUNCH_G(1); break;
+      case 2: TGP_LAUNCH_G(2); break;
+      case 4: TGP_LAUNCH_G(4); break;
+      case 8: TGP_LAUNCH_G(8); break;
+      case 16: TGP_LAUNCH_G(16); break;
+      case 32: TGP_LAUNCH_G(32); break;
+      default: TGP_LAUNCH_G(64); break;
+    }
+#undef TGP_LAUNCH_G
+  } else {
+    int64_t blocks = (K * F + 255) / 256;
+    if (blocks > cus * 16) blocks = cus * 16;
+    hipLaunchKernelGGL(reduce_sparse_scalar_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, x,
+                       F, x_stride, node_index, weight, row_ptr, perm, K, x_pool);
+  }
+  return check_launch("tgp_reduce_sparse_f32");
+}
+
+extern "C" int tgp_reduce_batch_i64(const int64_t* batch, const int64_t* node_index,
+                                    const int64_t* cluster_index, int64_t nnz, int64_t K, int64_t* batch_pool,
+                                    void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(nnz >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_reduce_batch_i64: bad size");
+  if (K == 0) return TGP_OK;
+  TGP_REQUIRE(batch_pool && (nnz == 0 || (batch && node_index && cluster_index)), TGP_ERR_INVALID,
+              "tgp_reduce_batch_i64: null pointer");
+  hipLaunchKernelGGL(arange_i64_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, batch_pool, K);
+  if (nnz > 0)
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3(cdiv(nnz, 256)), dim3(256), 0, stream, batch, node_index,
+                       cluster_index, nnz, batch_pool);
+  return check_launch("tgp_reduce_batch_i64");
+}

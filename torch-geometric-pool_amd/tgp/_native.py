@@ -1,0 +1,143 @@
+"""ctypes binding of the tgp HIP library (``include/tgp_hip.h``).
+
+There is deliberately **no CPU or PyTorch fallback** behind these wrappers: if
+``lib/libtgp_hip.so`` is missing, or an operator is handed tensors that do not live on a
+ROCm device, the call raises.  PyTorch is used for device memory (outputs and workspaces
+come from its caching allocator) and for the current HIP stream, nothing else.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtgp_hip.so")
+
+# flag bits / enums, mirrored from include/tgp_hip.h
+REMOVE_SELF_LOOPS = 1
+DEGREE_NORM = 2
+EDGE_WEIGHT_NORM = 4
+SUM_AXIS_ROWS = 8
+EPS_FILTER = 16
+ADJ_TRANSPOSED = 32
+NODE_FILTER = 64
+REDUCE_OPS = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3, "mul": 4}
+
+_c_i64, _c_int, _c_sz, _c_p = ctypes.c_int64, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol the header declares
+SIGNATURES = {
+    "tgp_version": (_c_int, []),
+    "tgp_last_error": (ctypes.c_char_p, []),
+    "tgp_device_cu_count": (_c_int, []),
+    "tgp_assign_index_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
+    "tgp_assign_index_build": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_sz, _c_p]),
+    "tgp_reduce_sparse_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64,
+                                       _c_i64, _c_p, _c_p]),
+    "tgp_reduce_batch_i64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
+    "tgp_connect_subgraph_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
+    "tgp_connect_subgraph_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_p,
+                                            _c_sz, _c_p, _c_p]),
+    "tgp_connect_subgraph_fill": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p,
+                                           _c_p, _c_p, _c_p]),
+    "tgp_connect_coalesce_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
+    "tgp_connect_coalesce_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_int,
+                                            _c_p, _c_sz, _c_p, _c_p]),
+    "tgp_connect_coalesce_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_int, _c_i64, _c_p, _c_p, _c_p,
+                                           _c_p]),
+    "tgp_postprocess_sparse_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "tgp_postprocess_sparse_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64,
+                                                 _c_p, _c_sz, _c_p]),
+    "tgp_dense_pool_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64]),
+    "tgp_dense_pool_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p,
+                                    _c_p, _c_p, _c_sz, _c_p]),
+    "tgp_postprocess_dense_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p]),
+    "tgp_bmm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_i64,
+                             _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+    "tgp_segment_gemm_tn_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
+                                         _c_p]),
+    "tgp_rowptr_from_sorted_i64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p]),
+    "tgp_spmm_csr_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
+    "tgp_block_diag_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
+    "tgp_block_diag_count": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_sz, _c_p, _c_p]),
+    "tgp_block_diag_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_i64, _c_p, _c_p, _c_p,
+                                     _c_p]),
+    "tgp_debug_sort_workspace_bytes": (_c_sz, [_c_i64]),
+    "tgp_debug_sort_pairs_u64": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_sz, _c_p]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class TgpNativeError(RuntimeError):
+    """Raised when the HIP library is missing or reports a non-zero status."""
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the C-ABI library; raises loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TgpNativeError(
+                f"tgp HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import "
+                "__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here == ABI mismatch: fail loudly
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().tgp_last_error().decode(errors="replace")
+        raise TgpNativeError(f"{what} failed with status {status}: {msg}")
+
+
+def require_device(*tensors: Optional[Tensor]) -> torch.device:
+    """All given tensors must live on one ROCm device; returns it."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise TgpNativeError(
+                "tgp (MI355X build) runs Reduce/Connect only on ROCm device tensors; got a "
+                f"{t.device} tensor. Move inputs to 'cuda' - there is no CPU fallback.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise TgpNativeError(f"tensors on different devices: {dev} vs {t.device}")
+    if dev is None:
+        raise TgpNativeError("no device tensor given")
+    return dev
+
+
+def ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def workspace(nbytes: int, dev: torch.device) -> Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+def f32c(t: Tensor) -> Tensor:
+    """fp32 + contiguous view/copy (the dtype the path computes in)."""
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def i64c(t: Tensor) -> Tensor:
+    if t.dtype != torch.int64:
+        t = t.to(torch.int64)
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,312 @@
+"""``connect`` operators: pooled connectivity A' (reference tgp/connect/{base,dense,kron}_conn.py)."""
+from __future__ import annotations
+
+import warnings
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .. import kernels as K
+from ..imports import is_sparsetensor
+from ..select import SelectOutput
+from ..utils.ops import (
+    _normalize_pooled_edges,
+    connectivity_to_edge_index,
+    connectivity_to_sparsetensor,
+    connectivity_to_torch_coo,
+    graph_ptr,
+    is_dense_adj,
+    maybe_num_nodes,
+    postprocess_adj_pool_dense,
+    postprocess_adj_pool_sparse,
+)
+
+
+class Connect(torch.nn.Module):
+    """Template of the connect operator."""
+
+    def reset_parameters(self):
+        pass
+
+    def forward(self, edge_index, so: SelectOutput, *, edge_weight: Optional[Tensor] = None, **kwargs):
+        raise NotImplementedError
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}()"
+
+
+def _restore_format(template, edge_index, edge_weight, num_supernodes):
+    """Output adjacency format mirrors the input format (reference base_conn.py:71-76,103-110)."""
+    if is_sparsetensor(template):
+        return connectivity_to_sparsetensor(edge_index, edge_weight, num_supernodes), None
+    if isinstance(template, Tensor) and template.is_sparse:
+        return connectivity_to_torch_coo(edge_index, edge_weight, num_supernodes), None
+    return edge_index, edge_weight
+
+
+def sparse_connect(edge_index, edge_weight: Optional[Tensor] = None, node_index: Tensor = None,
+                   cluster_index: Optional[Tensor] = None, num_nodes: int = None, num_supernodes: int = None,
+                   remove_self_loops: bool = True, reduce_op: str = "sum", edge_weight_norm: bool = False,
+                   batch_pooled: Optional[Tensor] = None, degree_norm: bool = False):
+    r"""Coarsen an edge list (reference connect/base_conn.py:57-112).
+
+    * kept-node selection (TopK): induced subgraph, endpoints relabelled to their position in the
+      ascending ``node_index``; input edge order is kept.
+    * one-over-K clustering (Graclus, ...): endpoints mapped through ``cluster_index``, duplicates
+      merged with ``reduce_op``; output is row-major sorted and unique.
+
+    Both run as one count->fill kernel pair with ``remove_self_loops`` and the ``|w| > eps`` filter of
+    ``postprocess_adj_pool_sparse`` fused into the compaction; the degree / max-abs normalisations
+    follow as in-place kernels on the (much smaller) pooled list.
+    """
+    template = edge_index
+    edge_index, edge_weight = connectivity_to_edge_index(edge_index, edge_weight)
+    if edge_weight is not None:
+        edge_weight = edge_weight.view(-1)
+    num_nodes = maybe_num_nodes(edge_index, num_nodes)
+    if node_index is not None and len(node_index) < num_nodes:
+        ei, ew = K.filter_edges(edge_index, edge_weight, node_index, num_nodes, remove_self_loops)
+    elif cluster_index is not None and len(cluster_index) == num_nodes:
+        ei, ew = K.coalesce_edges(edge_index, edge_weight, cluster_index, num_supernodes, reduce_op,
+                                  remove_self_loops)
+    else:
+        raise RuntimeError
+    ei, ew = _normalize_pooled_edges(ei, ew, num_supernodes, degree_norm, edge_weight_norm, batch_pooled)
+    return _restore_format(template, ei, ew, num_supernodes)
+
+
+class SparseConnect(Connect):
+    r"""Connect for sparse poolers where a node belongs to at most one supernode
+    (reference connect/base_conn.py:115-224)."""
+
+    def __init__(self, reduce_op: str = "sum", remove_self_loops: bool = True, edge_weight_norm: bool = False,
+                 degree_norm: bool = False):
+        super().__init__()
+        self.reduce_op = reduce_op
+        self.remove_self_loops = remove_self_loops
+        self.edge_weight_norm = edge_weight_norm
+        self.degree_norm = degree_norm
+
+    def forward(self, edge_index, so: SelectOutput, *, edge_weight: Optional[Tensor] = None,
+                batch_pooled: Optional[Tensor] = None, **kwargs):
+        if self.edge_weight_norm and batch_pooled is None:
+            raise AssertionError("edge_weight_norm=True but batch_pooled=None. batch_pooled parameter is "
+                                 "required for per-graph normalization in SparseConnect.")
+        return sparse_connect(edge_index, edge_weight, node_index=so.node_index, cluster_index=so.cluster_index,
+                              num_nodes=so.num_nodes, num_supernodes=so.num_supernodes,
+                              remove_self_loops=self.remove_self_loops, reduce_op=self.reduce_op,
+                              edge_weight_norm=self.edge_weight_norm, batch_pooled=batch_pooled,
+                              degree_norm=self.degree_norm)
+
+    def __repr__(self) -> str:
+        return (f"{self.__class__.__name__}(reduce_op={self.reduce_op}, "
+                f"remove_self_loops={self.remove_self_loops}, edge_weight_norm={self.edge_weight_norm}, "
+                f"degree_norm={self.degree_norm})")
+
+
+class _DenseConnectFn(torch.autograd.Function):
+    """R = S^T A S on the matrix cores.  dS = A S dR^T + A^T S dR, dA = S dR S^T."""
+
+    @staticmethod
+    def forward(ctx, s, adj):
+        ctx.save_for_backward(s, adj)
+        return K.dense_pool(s, adj, None, 0, want_raw=True, want_post=False)[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        s, adj = ctx.saved_tensors
+        g = g.contiguous()
+        gs = ga = None
+        if ctx.needs_input_grad[0]:
+            u = K.bmm(adj, s)                     # A S
+            v = K.bmm(adj, s, trans_a=True)       # A^T S
+            gs = K.bmm(u, g.transpose(-1, -2).contiguous()) + K.bmm(v, g)
+        if ctx.needs_input_grad[1]:
+            ga = K.bmm(K.bmm(s, g), s.transpose(-1, -2).contiguous())
+        return gs, ga
+
+
+class DenseConnect(Connect):
+    r"""A' = S^T A S for dense assignments (reference connect/dense_conn.py:22-364).
+
+    Batched dense inputs ([B,N,N], [B,N,K]) run as fp32-MFMA GEMMs with the post-processing fused into
+    the split-K combine.  Unbatched inputs (sparse A, S [N,K]) run as one CSR SpMM + one segment GEMM
+    over all graphs - no densification and no per-graph Python loop.
+    """
+
+    def __init__(self, remove_self_loops: bool = True, degree_norm: bool = True, adj_transpose: bool = True,
+                 edge_weight_norm: bool = False, sparse_output: bool = False):
+        super().__init__()
+        if not isinstance(sparse_output, bool):
+            raise TypeError("sparse_output must be a bool.")
+        self.remove_self_loops = remove_self_loops
+        self.degree_norm = degree_norm
+        self.adj_transpose = adj_transpose
+        self.edge_weight_norm = edge_weight_norm
+        self.sparse_output = sparse_output
+
+    # -- validation helpers (same contracts as the reference) -----------------------------
+    @staticmethod
+    def _prepare_batched_dense_inputs(s: Tensor, adj: Tensor) -> Tuple[Tensor, Tensor]:
+        s = s.unsqueeze(0) if s.dim() == 2 else s
+        adj = adj.unsqueeze(0) if adj.dim() == 2 else adj
+        if s.dim() != 3 or adj.dim() != 3:
+            raise ValueError("Expected batched dense inputs with 3 dimensions.")
+        if s.size(0) != adj.size(0):
+            raise ValueError("Assignment and adjacency batch sizes do not match: "
+                             f"got s.size(0)={s.size(0)} and adj.size(0)={adj.size(0)}.")
+        return s, adj
+
+    @staticmethod
+    def _validate_select_output(so: SelectOutput) -> Tensor:
+        if so is None:
+            raise ValueError("SelectOutput is required for DenseConnect.")
+        if not isinstance(so.s, Tensor):
+            raise TypeError("SelectOutput.s must be a torch.Tensor.")
+        if so.s.is_sparse:
+            raise ValueError("DenseConnect expects a dense assignment matrix.")
+        return so.s
+
+    @staticmethod
+    def _dense_connect(s: Tensor, adj: Tensor) -> Tensor:
+        return _DenseConnectFn.apply(s, adj)
+
+    def dense_connect(self, adj: Tensor, s: Tensor) -> Tensor:
+        """Raw S^T A S (MinCut needs it for its loss before post-processing, poolers/mincut.py:226)."""
+        s, adj = self._prepare_batched_dense_inputs(s, adj)
+        return self._dense_connect(s, adj)
+
+    @staticmethod
+    def _dense_connect_unbatched(edge_index, edge_weight, batch, s, num_nodes, num_clusters, batch_size):
+        """[B,K,K] = per-graph S_b^T A_b S_b from a sparse A (reference dense_conn.py:140-208)."""
+        ei, ew = connectivity_to_edge_index(edge_index, edge_weight)
+        if ei.size(1) == 0:
+            return s.new_zeros((batch_size, num_clusters, num_clusters))
+        # duplicates are SUMMED by the reference's per-graph `.coalesce()`, also for unweighted input
+        ew = torch.ones(ei.size(1), device=ei.device) if ew is None else ew.view(-1)
+        # sorted + duplicate-summed A (what `.coalesce()` does per graph), then T = A S, then S_b^T T_b
+        ident = torch.arange(num_nodes, device=ei.device)
+        ei, ew = K.coalesce_edges(ei, ew, ident, num_nodes, "sum", remove_self_loops=False, eps_filter=False)
+        t = K.spmm_sorted(ei, ew, num_nodes, s)
+        if batch_size == 1:
+            return K.bmm(s, t, trans_a=True).unsqueeze(0)
+        sizes, ptr = graph_ptr(batch, batch_size)
+        return K.segment_gemm_tn(s, t, ptr, int(sizes.max()))
+
+    def forward(self, edge_index, so: SelectOutput, *, edge_weight: Optional[Tensor] = None,
+                batch: Optional[Tensor] = None, batch_pooled: Optional[Tensor] = None, **kwargs):
+        s = self._validate_select_output(so)
+        if is_dense_adj(edge_index):
+            return self._forward_batched_inputs(edge_index, s)
+        return self._forward_unbatched_inputs(edge_index, edge_weight, batch, s, batch_pooled)
+
+    def _forward_batched_inputs(self, adj: Tensor, s: Tensor):
+        s, adj = self._prepare_batched_dense_inputs(s, adj)
+        if torch.is_grad_enabled() and (s.requires_grad or adj.requires_grad):
+            raw = self._dense_connect(s, adj)
+            return postprocess_adj_pool_dense(raw, self.remove_self_loops, self.degree_norm, self.adj_transpose,
+                                              self.edge_weight_norm), None
+        flags = K.dense_flags(self.remove_self_loops, self.degree_norm, self.adj_transpose, self.edge_weight_norm)
+        return K.dense_pool(s, adj, None, flags)[2], None
+
+    def _forward_unbatched_inputs(self, edge_index, edge_weight, batch, s, batch_pooled):
+        batch_size = 1 if batch is None else int(batch.max().item()) + 1
+        if s.dim() == 3 and s.size(0) == 1:
+            s = s.squeeze(0)
+        elif s.dim() != 2:
+            raise ValueError("[DenseConnect - unbatched]: SelectOutput.s must have shape "
+                             f"[N, K] or [1, N, K], but got {s.size()}.")
+        num_nodes, num_clusters = s.size()
+        adj_dense = self._dense_connect_unbatched(edge_index, edge_weight, batch, s, num_nodes, num_clusters,
+                                                  batch_size)
+        if not self.sparse_output:
+            return postprocess_adj_pool_dense(adj_dense, self.remove_self_loops, self.degree_norm, False,
+                                              self.edge_weight_norm), None
+        if self.edge_weight_norm and batch_pooled is None:
+            raise AssertionError("edge_weight_norm=True but batch_pooled=None. batch_pooled parameter is "
+                                 "required for per-graph normalization in DenseConnect.")
+        num_supernodes = batch_size * num_clusters
+        ei, ew = K.block_diag_edges(adj_dense, None, self.remove_self_loops)
+        ei, ew = _normalize_pooled_edges(ei, ew, num_supernodes, self.degree_norm, self.edge_weight_norm,
+                                         batch_pooled)
+        return _restore_format(edge_index, ei, ew, num_supernodes)
+
+    def __repr__(self) -> str:
+        return (f"{self.__class__.__name__}(remove_self_loops={self.remove_self_loops}, "
+                f"degree_norm={self.degree_norm}, adj_transpose={self.adj_transpose}, "
+                f"edge_weight_norm={self.edge_weight_norm}, sparse_output={self.sparse_output})")
+
+
+class KronConnect(Connect):
+    r"""Kron reduction L' = L[+,+] - L[+,-] L[-,-]^{-1} L[-,+] of the graph Laplacian, used by NDP
+    (reference connect/kron_conn.py:26-168).  A sparse direct solve: it runs on the host with scipy
+    exactly as in the reference (SURVEY.md 8(a) A9 keeps the GPU version for a later round)."""
+
+    def __init__(self, sparse_threshold: float = 1e-2):
+        super().__init__()
+        self.sparse_threshold = sparse_threshold
+
+    def forward(self, edge_index, so: SelectOutput, edge_weight: Optional[Tensor] = None, **kwargs):
+        import numpy as np
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+
+        template = edge_index
+        edge_index, edge_weight = connectivity_to_edge_index(edge_index, edge_weight)
+        device = edge_index.device
+        n = so.num_nodes
+        if hasattr(so, "L"):
+            L = sp.csr_matrix(so.L)
+            idx_pos = so.node_index.cpu().numpy()
+        else:
+            warnings.warn("Laplacian not provided. The SelectOutput is not computed with NDPSelect.")
+            ei = edge_index.cpu().numpy()
+            w = np.ones(ei.shape[1], dtype=np.float32) if edge_weight is None else \
+                edge_weight.detach().reshape(-1).cpu().numpy()
+            off = ei[0] != ei[1]
+            A = sp.coo_matrix((w[off], (ei[0][off], ei[1][off])), shape=(n, n)).tocsr()
+            L = (sp.diags(np.asarray(A.sum(1)).reshape(-1).astype(w.dtype)) - A).tocsr()
+            if len(so.node_index) == so.num_supernodes:
+                idx_pos = so.node_index.cpu().numpy()
+            elif getattr(so, "mis", None) is not None:
+                idx_pos = so.mis.cpu().numpy()
+                if (idx_pos >= n).any():
+                    raise ValueError(f"MIS indices out of range: max idx={idx_pos.max()}, but graph has only "
+                                     f"{n} nodes.")
+            else:
+                raise ValueError("Inconsistent number of clusters and node indices.")
+        keep = np.zeros(L.shape[0], dtype=bool)
+        keep[idx_pos] = True
+        idx_neg = np.nonzero(~keep)[0]
+        if len(idx_pos) <= 1:
+            l_new = sp.csc_matrix(-np.ones((1, 1)))
+        else:
+            l_pp = L[np.ix_(idx_pos, idx_pos)]
+            l_pn = L[np.ix_(idx_pos, idx_neg)]
+            l_np = L[np.ix_(idx_neg, idx_pos)].tocsc()
+            l_nn = L[np.ix_(idx_neg, idx_neg)].tocsc()
+            try:
+                l_new = l_pp - l_pn.dot(spla.spsolve(l_nn, l_np))
+            except RuntimeError:
+                damp = sp.csc_matrix(sp.eye(l_nn.shape[0]) * 1e-6)  # Marquardt-Levenberg damping
+                l_new = l_pp - l_pn.dot(spla.spsolve(damp + l_nn, l_np))
+            if np.abs(l_new - l_new.T).sum() < np.spacing(1) * np.abs(l_new).sum():
+                l_new = (l_new + l_new.T) / 2.0
+        a_pool = -l_new
+        if self.sparse_threshold > 0:
+            a_pool = a_pool.multiply(np.abs(a_pool) > self.sparse_threshold)
+        a_pool = sp.lil_matrix(a_pool)
+        a_pool.setdiag(0)
+        a_pool = a_pool.tocsr()
+        a_pool.eliminate_zeros()
+        a_pool = a_pool.astype(np.float32).tocoo()
+        ei_out = torch.stack([torch.from_numpy(a_pool.row).long(), torch.from_numpy(a_pool.col).long()]).to(device)
+        ew_out = torch.from_numpy(a_pool.data).to(device)
+        return _restore_format(template, ei_out, ew_out, so.num_supernodes)
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(sparse_threshold={self.sparse_threshold})"
+
+
+__all__ = ["Connect", "SparseConnect", "DenseConnect", "KronConnect", "sparse_connect"]

@@ -1,0 +1,116 @@
+"""Multi-GPU data parallelism for the pooling hot path: one process per GPU, graphs sharded by id,
+pooled outputs all-gathered with ``torch.distributed`` (backend ``nccl`` == RCCL over xGMI on ROCm).
+
+The reference has no distributed code at all; graphs of a batch are independent in
+Select, Reduce, Connect and their per-graph normalisations, so the path shards without any data-path
+collective.  The only exchange is the final gather of the (small) pooled outputs, whose merge rule is
+the one the reference uses when it collates pooled graphs on the CPU (tgp/data/collate.py:144-153):
+node ids and graph ids of later shards are shifted by the totals of the earlier ones.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def shard_bounds(num_graphs: int, world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced graph-id ranges (``batch`` stays sorted inside every shard)."""
+    base, extra = divmod(num_graphs, world_size)
+    out, lo = [], 0
+    for r in range(world_size):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def shard_sparse_batch(x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor,
+                       rank: int, world_size: int, num_graphs: Optional[int] = None):
+    """Slice a PyG-style batch (sorted ``batch``) down to this rank's graphs; node ids and graph ids are
+    made local (start at 0)."""
+    if num_graphs is None:
+        num_graphs = int(batch.max()) + 1 if batch.numel() else 0
+    lo, hi = shard_bounds(num_graphs, world_size)[rank]
+    node_sel = (batch >= lo) & (batch < hi)
+    nodes = node_sel.nonzero().view(-1)
+    n0 = int(nodes[0]) if nodes.numel() else 0
+    edge_sel = node_sel[edge_index[0]]
+    ei = edge_index[:, edge_sel] - n0
+    ew = None if edge_weight is None else edge_weight[edge_sel]
+    return x[nodes], ei, ew, batch[nodes] - lo
+
+
+def shard_dense_batch(rank: int, world_size: int, *tensors: Tensor):
+    """Slice padded dense tensors [B, ...] along the graph dimension."""
+    lo, hi = shard_bounds(tensors[0].size(0), world_size)[rank]
+    return tuple(t[lo:hi] for t in tensors)
+
+
+def _world(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def all_gather_dense(tensors: Sequence[Tensor], group=None) -> List[Tensor]:
+    """Gather fixed-shape per-graph outputs ([B_local, K, F], [B_local, K, K], ...) from every rank and
+    concatenate along the graph dimension.  Ranks may hold different B_local (padded to the max)."""
+    world = _world(group)
+    if world == 1:
+        return list(tensors)
+    dev = tensors[0].device
+    b_local = torch.tensor([tensors[0].size(0)], dtype=torch.long, device=dev)
+    counts = [torch.zeros_like(b_local) for _ in range(world)]
+    dist.all_gather(counts, b_local, group=group)
+    counts = [int(c) for c in counts]
+    b_max = max(counts)
+    out = []
+    for t in tensors:
+        pad = t
+        if t.size(0) < b_max:
+            pad = torch.cat([t, t.new_zeros((b_max - t.size(0),) + tuple(t.shape[1:]))])
+        buf = torch.empty((world * b_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        dist.all_gather_into_tensor(buf, pad.contiguous(), group=group)
+        parts = [buf[r * b_max: r * b_max + counts[r]] for r in range(world)]
+        out.append(torch.cat(parts) if any(c != b_max for c in counts) else buf)
+    return out
+
+
+def all_gather_sparse(x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor,
+                      num_graphs_local: int, group=None):
+    """Gather variable-size pooled graphs: counts first, then max-padded payloads, then shift the
+    pooled node ids / graph ids of rank r by the totals of ranks < r."""
+    world = _world(group)
+    if world == 1:
+        return x, edge_index, edge_weight, batch
+    dev = x.device
+    mine = torch.tensor([x.size(0), edge_index.size(1), num_graphs_local], dtype=torch.long, device=dev)
+    allc = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allc, mine, group=group)
+    allc = torch.stack(allc).cpu()
+    k_max, e_max = int(allc[:, 0].max()), int(allc[:, 1].max())
+
+    def gather_rows(t: Tensor, n_max: int) -> Tensor:
+        pad = t.new_zeros((n_max,) + tuple(t.shape[1:]))
+        pad[: t.size(0)] = t
+        buf = torch.empty((world * n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        dist.all_gather_into_tensor(buf, pad, group=group)
+        return buf.view((world, n_max) + tuple(t.shape[1:]))
+
+    gx = gather_rows(x, k_max)
+    gb = gather_rows(batch, k_max)
+    ge = gather_rows(edge_index.t().contiguous(), e_max)
+    gw = None if edge_weight is None else gather_rows(edge_weight, e_max)
+    xs, bs, es, ws = [], [], [], []
+    node_off = graph_off = 0
+    for r in range(world):
+        k, e, g = (int(v) for v in allc[r])
+        xs.append(gx[r, :k])
+        bs.append(gb[r, :k] + graph_off)
+        es.append(ge[r, :e] + node_off)
+        if gw is not None:
+            ws.append(gw[r, :e])
+        node_off += k
+        graph_off += g
+    return (torch.cat(xs), torch.cat(es).t().contiguous(), None if gw is None else torch.cat(ws), torch.cat(bs))

@@ -1,0 +1,298 @@
+"""Tensor-level entry points of the hot path: allocate outputs/workspaces with PyTorch,
+hand raw device pointers + the current HIP stream to the C ABI (``include/tgp_hip.h``).
+
+Each function names the reference lines whose arithmetic it replaces.  Nothing here runs
+on the CPU and nothing falls back to ATen kernels.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _native as N
+
+
+# ------------------------------------------------------------------------- A1 / A2
+class AssignIndex:
+    """Inverted index of a sparse assignment (supernode -> its assignments, in ascending
+    assignment order).  A function of the SelectOutput only, so SelectOutput caches it."""
+
+    __slots__ = ("row_ptr", "perm", "nnz", "num_targets")
+
+    def __init__(self, row_ptr: Tensor, perm: Tensor, nnz: int, num_targets: int):
+        self.row_ptr, self.perm, self.nnz, self.num_targets = row_ptr, perm, nnz, num_targets
+
+
+def build_assign_index(target_index: Tensor, num_targets: int) -> AssignIndex:
+    dev = N.require_device(target_index)
+    target_index = N.i64c(target_index)
+    nnz = target_index.numel()
+    row_ptr = torch.empty(num_targets + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    L = N.lib()
+    wsb = L.tgp_assign_index_workspace_bytes(nnz, num_targets)
+    ws = N.workspace(wsb, dev)
+    N.check(L.tgp_assign_index_build(N.ptr(target_index), nnz, num_targets, N.ptr(row_ptr), N.ptr(perm),
+                                     N.ptr(ws), ws.numel(), N.stream_ptr(dev)), "tgp_assign_index_build")
+    return AssignIndex(row_ptr, perm, nnz, num_targets)
+
+
+def reduce_sparse(x: Tensor, source_index: Tensor, weight: Optional[Tensor], index: AssignIndex) -> Tensor:
+    """out[t,:] = sum_{i: target[i]==t} weight[i] * x[source_index[i],:]
+    (reduce/base_reduce.py:146-153; lift/base_lift.py:102-111 with the roles swapped)."""
+    dev = N.require_device(x, source_index, weight)
+    squeeze = x.dim() == 1
+    x2 = x.view(-1, 1) if squeeze else x
+    if x2.dim() != 2:
+        raise ValueError(f"sparse reduce expects x of shape [N, F], got {tuple(x.shape)}")
+    x2 = x2.to(torch.float32) if x2.dtype != torch.float32 else x2
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    source_index = N.i64c(source_index)
+    w = None if weight is None else N.f32c(weight.reshape(-1))
+    F = x2.size(1)
+    out = torch.empty(index.num_targets, F, dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_reduce_sparse_f32(N.ptr(x2), x2.size(0), F, x2.stride(0), N.ptr(source_index), N.ptr(w),
+                                          N.ptr(index.row_ptr), N.ptr(index.perm), index.nnz,
+                                          index.num_targets, N.ptr(out), N.stream_ptr(dev)),
+            "tgp_reduce_sparse_f32")
+    return out.view(-1) if squeeze else out
+
+
+def reduce_batch_sparse(batch: Tensor, node_index: Tensor, cluster_index: Tensor, num_supernodes: int) -> Tensor:
+    """reduce/base_reduce.py:37-41."""
+    dev = N.require_device(batch, node_index, cluster_index)
+    batch, node_index, cluster_index = N.i64c(batch), N.i64c(node_index), N.i64c(cluster_index)
+    out = torch.empty(num_supernodes, dtype=torch.int64, device=dev)
+    N.check(N.lib().tgp_reduce_batch_i64(N.ptr(batch), N.ptr(node_index), N.ptr(cluster_index),
+                                         node_index.numel(), num_supernodes, N.ptr(out), N.stream_ptr(dev)),
+            "tgp_reduce_batch_i64")
+    return out
+
+
+# ------------------------------------------------------------------------- A4 / A5 / A6
+def _edge_rows(edge_index: Tensor) -> Tuple[Tensor, Tensor]:
+    ei = N.i64c(edge_index)
+    return ei[0], ei[1]
+
+
+def _read_count(d_count: Tensor) -> int:
+    # the single host sync of a count -> fill pair (the reference pays `.item()` syncs too)
+    return int(d_count.item())
+
+
+def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: Optional[Tensor],
+                 num_nodes: int, remove_self_loops: bool) -> Tuple[Tensor, Optional[Tensor]]:
+    """Induced subgraph + relabel (connect/base_conn.py:79-82) fused with remove_self_loops and the
+    |w| > eps filter (utils/ops.py:370-380).  node_index=None: filters only.  Keeps input order."""
+    dev = N.require_device(edge_index, edge_weight, node_index)
+    row, col = _edge_rows(edge_index)
+    E = row.numel()
+    w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
+    ni = None if node_index is None else N.i64c(node_index)
+    flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if w is not None else 0)
+    if ni is not None:
+        flags |= N.NODE_FILTER
+    L = N.lib()
+    ws = N.workspace(L.tgp_connect_subgraph_workspace_bytes(E, num_nodes), dev)
+    d_count = torch.empty(1, dtype=torch.int64, device=dev)
+    st = N.stream_ptr(dev)
+    N.check(L.tgp_connect_subgraph_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(ni),
+                                         0 if ni is None else ni.numel(), num_nodes, flags, N.ptr(ws),
+                                         ws.numel(), N.ptr(d_count), st), "tgp_connect_subgraph_count")
+    n_out = _read_count(d_count)
+    out_ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
+    out_w = None if w is None else torch.empty(n_out, dtype=torch.float32, device=dev)
+    N.check(L.tgp_connect_subgraph_fill(N.ptr(row), N.ptr(col), N.ptr(w), E, num_nodes, flags, N.ptr(ws), n_out,
+                                        N.ptr(out_ei[0]) if n_out else None,
+                                        N.ptr(out_ei[1]) if n_out else None, N.ptr(out_w), st),
+            "tgp_connect_subgraph_fill")
+    return out_ei, out_w
+
+
+def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_index: Tensor,
+                   num_supernodes: int, reduce_op: str, remove_self_loops: bool,
+                   eps_filter: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    """cluster_index[edge_index] + PyG coalesce (connect/base_conn.py:86-89) fused with
+    remove_self_loops and the |w| > eps filter (utils/ops.py:370-380)."""
+    if reduce_op not in N.REDUCE_OPS:
+        raise ValueError(f"unknown reduce_op '{reduce_op}', expected one of {sorted(N.REDUCE_OPS)}")
+    dev = N.require_device(edge_index, edge_weight, cluster_index)
+    row, col = _edge_rows(edge_index)
+    E = row.numel()
+    w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
+    cl = N.i64c(cluster_index)
+    flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if (w is not None and eps_filter) else 0)
+    L = N.lib()
+    ws = N.workspace(L.tgp_connect_coalesce_workspace_bytes(E, num_supernodes), dev)
+    d_count = torch.empty(1, dtype=torch.int64, device=dev)
+    st = N.stream_ptr(dev)
+    N.check(L.tgp_connect_coalesce_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
+                                         num_supernodes, N.REDUCE_OPS[reduce_op], flags, N.ptr(ws), ws.numel(),
+                                         N.ptr(d_count), st), "tgp_connect_coalesce_count")
+    n_out = _read_count(d_count)
+    out_ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
+    out_w = None if w is None else torch.empty(n_out, dtype=torch.float32, device=dev)
+    N.check(L.tgp_connect_coalesce_fill(N.ptr(ws), E, num_supernodes, 0 if w is None else 1, flags, n_out,
+                                        N.ptr(out_ei[0]) if n_out else None,
+                                        N.ptr(out_ei[1]) if n_out else None, N.ptr(out_w), st),
+            "tgp_connect_coalesce_fill")
+    return out_ei, out_w
+
+
+def normalize_edges_(edge_index: Tensor, edge_weight: Tensor, num_nodes: int, degree_norm: bool,
+                     edge_weight_norm: bool, batch_pooled: Optional[Tensor], num_graphs: int) -> Tensor:
+    """In-place D^-1/2 A D^-1/2 and per-graph max-abs normalisation (utils/ops.py:383-417)."""
+    dev = N.require_device(edge_index, edge_weight, batch_pooled)
+    row, col = _edge_rows(edge_index)
+    flags = (N.DEGREE_NORM if degree_norm else 0) | (N.EDGE_WEIGHT_NORM if edge_weight_norm else 0)
+    if flags == 0 or row.numel() == 0:
+        return edge_weight
+    bp = None if batch_pooled is None else N.i64c(batch_pooled)
+    L = N.lib()
+    ws = N.workspace(L.tgp_postprocess_sparse_workspace_bytes(row.numel(), num_nodes, num_graphs), dev)
+    N.check(L.tgp_postprocess_sparse_norm_f32(N.ptr(row), N.ptr(col), N.ptr(edge_weight), row.numel(), num_nodes,
+                                              flags, N.ptr(bp), num_graphs, N.ptr(ws), ws.numel(),
+                                              N.stream_ptr(dev)), "tgp_postprocess_sparse_norm_f32")
+    return edge_weight
+
+
+# ------------------------------------------------------------------------- A3 / A7 / A8
+def dense_flags(remove_self_loops: bool, degree_norm: bool, adj_transpose: bool, edge_weight_norm: bool) -> int:
+    return ((N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.DEGREE_NORM if degree_norm else 0)
+            | (N.SUM_AXIS_ROWS if adj_transpose else 0) | (N.EDGE_WEIGHT_NORM if edge_weight_norm else 0))
+
+
+def _dense_adj_layout(adj: Tensor) -> Tuple[Tensor, int]:
+    """Accept A [B,N,N] as contiguous or as the transposed view produced by
+    DenseSRCPooling.preprocessing (src.py:442-443) without materialising the transpose."""
+    if adj.dtype != torch.float32:
+        adj = adj.to(torch.float32)
+    if adj.is_contiguous():
+        return adj, 0
+    t = adj.transpose(-1, -2)
+    if t.is_contiguous():
+        return t, N.ADJ_TRANSPOSED
+    return adj.contiguous(), 0
+
+
+def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int = 0, want_raw: bool = False,
+               want_post: bool = True) -> Tuple[Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
+    """(x_pool, adj_raw, adj_pool) = (S^T X, S^T A S, postprocess(S^T A S)) for a padded batch
+    (reduce/base_reduce.py:158-161, connect/dense_conn.py:111-122, utils/ops.py:282-335)."""
+    dev = N.require_device(s, adj, x)
+    s = N.f32c(s)
+    B, Nn, K = s.shape
+    F = 0
+    x_pool = adj_raw = adj_pool = None
+    if x is not None:
+        x = N.f32c(x)
+        if x.shape[:2] != (B, Nn):
+            raise ValueError(f"x {tuple(x.shape)} does not match s {tuple(s.shape)}")
+        F = x.size(2)
+        x_pool = torch.empty(B, K, F, dtype=torch.float32, device=dev)
+    a = None
+    if adj is not None:
+        if adj.shape != (B, Nn, Nn):
+            raise ValueError(f"adj {tuple(adj.shape)} does not match s {tuple(s.shape)}")
+        a, tflag = _dense_adj_layout(adj)
+        flags |= tflag
+        if want_raw:
+            adj_raw = torch.empty(B, K, K, dtype=torch.float32, device=dev)
+        if want_post:
+            adj_pool = torch.empty(B, K, K, dtype=torch.float32, device=dev)
+    L = N.lib()
+    ws = N.workspace(L.tgp_dense_pool_workspace_bytes(B, Nn, K, F), dev)
+    N.check(L.tgp_dense_pool_f32(N.ptr(s), N.ptr(a), N.ptr(x), B, Nn, K, F, flags, N.ptr(x_pool), N.ptr(adj_raw),
+                                 N.ptr(adj_pool), N.ptr(ws), ws.numel(), N.stream_ptr(dev)), "tgp_dense_pool_f32")
+    return x_pool, adj_raw, adj_pool
+
+
+def postprocess_dense(adj_pool: Tensor, flags: int, inplace: bool = False) -> Tensor:
+    """utils/ops.py:282-335 on a [B,K,K] tensor."""
+    dev = N.require_device(adj_pool)
+    src = N.f32c(adj_pool)
+    dst = src if inplace else torch.empty_like(src)
+    B, K = src.size(0), src.size(1)
+    N.check(N.lib().tgp_postprocess_dense_f32(N.ptr(src), N.ptr(dst), B, K, flags, N.stream_ptr(dev)),
+            "tgp_postprocess_dense_f32")
+    return dst
+
+
+def bmm(a: Tensor, b: Tensor, trans_a: bool = False) -> Tensor:
+    """C[g] = op(A[g]) @ B[g] on the fp32 matrix cores.  a: [G,M,Kd] (or [G,Kd,M] when trans_a),
+    b: [G,Kd,Nc]; 2-D operands are treated as G = 1."""
+    dev = N.require_device(a, b)
+    a3 = N.f32c(a if a.dim() == 3 else a.unsqueeze(0))
+    b3 = N.f32c(b if b.dim() == 3 else b.unsqueeze(0))
+    G = max(a3.size(0), b3.size(0))
+    if trans_a:
+        Kd, M = a3.size(1), a3.size(2)
+    else:
+        M, Kd = a3.size(1), a3.size(2)
+    if b3.size(1) != Kd:
+        raise ValueError(f"bmm inner dimensions differ: {tuple(a.shape)} x {tuple(b.shape)}")
+    Nc = b3.size(2)
+    out = torch.empty(G, M, Nc, dtype=torch.float32, device=dev)
+    sA = 0 if a3.size(0) == 1 else a3.stride(0)
+    sB = 0 if b3.size(0) == 1 else b3.stride(0)
+    N.check(N.lib().tgp_bmm_f32(N.ptr(a3), N.ptr(b3), N.ptr(out), G, M, Nc, Kd, 1 if trans_a else 0, a3.stride(1),
+                                b3.stride(1), Nc, sA, sB, M * Nc, N.stream_ptr(dev)), "tgp_bmm_f32")
+    return out if (a.dim() == 3 or b.dim() == 3) else out[0]
+
+
+def segment_gemm_tn(s: Tensor, y: Tensor, ptr: Tensor, max_nodes: int) -> Tensor:
+    """C[b] = S_b^T Y_b over node rows ptr[b]..ptr[b+1] (reduce/base_reduce.py:170-182,
+    connect/dense_conn.py:195-206) in one launch."""
+    dev = N.require_device(s, y, ptr)
+    s, y, ptr = N.f32c(s), N.f32c(y), N.i64c(ptr)
+    B = ptr.numel() - 1
+    K, F = s.size(1), y.size(1)
+    out = torch.empty(B, K, F, dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_segment_gemm_tn_f32(N.ptr(s), N.ptr(y), N.ptr(ptr), N.ptr(out), B, s.size(0), K, F,
+                                            max_nodes, N.stream_ptr(dev)), "tgp_segment_gemm_tn_f32")
+    return out
+
+
+def spmm_sorted(edge_index: Tensor, edge_weight: Optional[Tensor], num_rows: int, s: Tensor) -> Tensor:
+    """T = A S for a row-sorted (coalesced) edge list (connect/dense_conn.py:165,204)."""
+    dev = N.require_device(edge_index, edge_weight, s)
+    row, col = _edge_rows(edge_index)
+    s = N.f32c(s)
+    w = None if edge_weight is None else N.f32c(edge_weight)
+    L = N.lib()
+    st = N.stream_ptr(dev)
+    row_ptr = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
+    N.check(L.tgp_rowptr_from_sorted_i64(N.ptr(row), row.numel(), num_rows, N.ptr(row_ptr), st),
+            "tgp_rowptr_from_sorted_i64")
+    out = torch.empty(num_rows, s.size(1), dtype=torch.float32, device=dev)
+    N.check(L.tgp_spmm_csr_f32(N.ptr(row_ptr), N.ptr(col), N.ptr(w), num_rows, row.numel(), N.ptr(s), s.size(1),
+                               N.ptr(out), st), "tgp_spmm_csr_f32")
+    return out
+
+
+# ------------------------------------------------------------------------- A10
+def block_diag_edges(adj_pool: Tensor, relabel: Optional[Tensor] = None,
+                     remove_self_loops: bool = False) -> Tuple[Tensor, Tensor]:
+    """dense_to_block_diag (utils/ops.py:53-82) with the optional valid-supernode renumbering of
+    DenseSRCPooling._finalize_sparse_output (src.py:526-552)."""
+    dev = N.require_device(adj_pool, relabel)
+    a = N.f32c(adj_pool if adj_pool.dim() == 3 else adj_pool.unsqueeze(0))
+    B, K = a.size(0), a.size(1)
+    rl = None if relabel is None else N.i64c(relabel)
+    flags = N.REMOVE_SELF_LOOPS if remove_self_loops else 0
+    L = N.lib()
+    ws = N.workspace(L.tgp_block_diag_workspace_bytes(B, K), dev)
+    d_count = torch.empty(1, dtype=torch.int64, device=dev)
+    st = N.stream_ptr(dev)
+    N.check(L.tgp_block_diag_count(N.ptr(a), B, K, N.ptr(rl), flags, N.ptr(ws), ws.numel(), N.ptr(d_count), st),
+            "tgp_block_diag_count")
+    n_out = _read_count(d_count)
+    ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
+    ew = torch.empty(n_out, dtype=torch.float32, device=dev)
+    N.check(L.tgp_block_diag_fill(N.ptr(a), B, K, N.ptr(rl), flags, N.ptr(ws), n_out,
+                                  N.ptr(ei[0]) if n_out else None, N.ptr(ei[1]) if n_out else None,
+                                  N.ptr(ew) if n_out else None, st), "tgp_block_diag_fill")
+    return ei, ew

@@ -1,0 +1,299 @@
+"""Pooling layers of the north-star path and the ``get_pooler`` factory
+(reference tgp/poolers/{__init__,topk,graclus,ndp,diffpool,mincut}.py).
+
+Only the five poolers named by the hot path are built: ``topk``, ``graclus``, ``ndp``, ``diff``,
+``mincut`` (+ ``diff_u`` / ``mincut_u``).  Every other alias of the reference raises the same
+``ValueError("Unknown pooler_name=...")`` an unknown name does.
+"""
+from __future__ import annotations
+
+import inspect
+from typing import Callable, List, Optional, Union
+
+import torch
+from torch import Tensor
+
+from ..connect import DenseConnect, KronConnect, SparseConnect
+from ..lift import BaseLift
+from ..reduce import BaseReduce
+from ..select import GraclusSelect, MLPSelect, NDPSelect, SelectOutput, TopkSelect
+from ..src import BasePrecoarseningMixin, DenseSRCPooling, PoolingOutput, SRCPooling
+from ..utils.losses import (
+    entropy_loss,
+    link_pred_loss,
+    mincut_loss,
+    orthogonality_loss,
+    sparse_link_pred_loss,
+    sparse_mincut_loss,
+    unbatched_entropy_loss,
+    unbatched_orthogonality_loss,
+)
+from ..utils.ops import connectivity_to_edge_index, postprocess_adj_pool_dense
+
+
+# =============================================================================== sparse poolers
+class TopkPooling(SRCPooling):
+    r"""Top-k pooling: keep the best-scoring ``ceil(ratio * n)`` nodes of every graph, gate their
+    features by the score, keep the induced subgraph (reference poolers/topk.py:14-195)."""
+
+    def __init__(self, in_channels: int, ratio: Union[int, float] = 0.5, min_score: Optional[float] = None,
+                 multiplier: float = 1.0, nonlinearity: Union[str, Callable] = "tanh",
+                 lift: str = "precomputed", s_inv_op: str = "transpose", connect_red_op: str = "sum",
+                 lift_red_op: str = "sum", remove_self_loops: bool = True, degree_norm: bool = False,
+                 edge_weight_norm: bool = False):
+        super().__init__(
+            selector=TopkSelect(in_channels=in_channels, ratio=ratio, min_score=min_score, act=nonlinearity,
+                                s_inv_op=s_inv_op),
+            reducer=BaseReduce(),
+            lifter=BaseLift(matrix_op=lift, reduce_op=lift_red_op),
+            connector=SparseConnect(reduce_op=connect_red_op, degree_norm=degree_norm,
+                                    edge_weight_norm=edge_weight_norm, remove_self_loops=remove_self_loops))
+        self.multiplier = multiplier
+
+    def forward(self, x: Tensor, adj=None, edge_weight: Optional[Tensor] = None,
+                so: Optional[SelectOutput] = None, batch: Optional[Tensor] = None,
+                attn: Optional[Tensor] = None, lifting: bool = False, **kwargs):
+        if lifting:
+            return self.lift(x_pool=x, so=so)
+        so = self.select(x=x if attn is None else attn, batch=batch)
+        x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch)
+        if self.multiplier != 1:
+            x_pool = self.multiplier * x_pool
+        ei, ew = self.connect(so=so, edge_index=adj, edge_weight=edge_weight, batch_pooled=batch_pool)
+        return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so)
+
+    def extra_repr_args(self) -> dict:
+        return {"multiplier": self.multiplier}
+
+
+class GraclusPooling(BasePrecoarseningMixin, SRCPooling):
+    r"""Graclus pooling: greedy pairwise matching, features summed per pair, edges coalesced
+    (reference poolers/graclus.py:14-159)."""
+
+    def __init__(self, lift: str = "precomputed", s_inv_op: str = "transpose", connect_red_op: str = "sum",
+                 lift_red_op: str = "sum", cached: bool = False, remove_self_loops: bool = True,
+                 degree_norm: bool = False, edge_weight_norm: bool = False):
+        super().__init__(
+            selector=GraclusSelect(s_inv_op=s_inv_op),
+            reducer=BaseReduce(),
+            lifter=BaseLift(matrix_op=lift, reduce_op=lift_red_op),
+            connector=SparseConnect(reduce_op=connect_red_op, remove_self_loops=remove_self_loops,
+                                    degree_norm=degree_norm, edge_weight_norm=edge_weight_norm),
+            cached=cached)
+        self.cached = cached
+
+    def forward(self, x: Tensor, adj=None, edge_weight: Optional[Tensor] = None,
+                so: Optional[SelectOutput] = None, batch: Optional[Tensor] = None, lifting: bool = False,
+                **kwargs):
+        if lifting:
+            return self.lift(x_pool=x, so=so)
+        so = self.select(edge_index=adj, edge_weight=edge_weight, num_nodes=x.size(0))
+        x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch)
+        ei, ew = self.connect(edge_index=adj, so=so, edge_weight=edge_weight, batch_pooled=batch_pool)
+        return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so)
+
+    def extra_repr_args(self) -> dict:
+        return {"cached": self.cached}
+
+
+class NDPPooling(BasePrecoarseningMixin, SRCPooling):
+    r"""Node Decimation Pooling: spectral +-1 partition, keep one side, Kron-reduce the Laplacian
+    (reference poolers/ndp.py:14-142)."""
+
+    def __init__(self, lift: str = "precomputed", s_inv_op: str = "transpose", lift_red_op: str = "sum",
+                 cached: bool = False):
+        super().__init__(selector=NDPSelect(s_inv_op=s_inv_op), reducer=BaseReduce(),
+                         lifter=BaseLift(matrix_op=lift, reduce_op=lift_red_op), connector=KronConnect(),
+                         cached=cached)
+        self.cached = cached
+
+    def forward(self, x: Tensor, adj=None, edge_weight: Optional[Tensor] = None,
+                so: Optional[SelectOutput] = None, batch: Optional[Tensor] = None, lifting: bool = False,
+                **kwargs):
+        if lifting:
+            return self.lift(x_pool=x, so=so)
+        so = self.select(edge_index=adj, edge_weight=edge_weight, batch=batch, num_nodes=x.size(0))
+        x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch)
+        ei, ew = self.connect(edge_index=adj, so=so, edge_weight=edge_weight)
+        return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so)
+
+    def extra_repr_args(self) -> dict:
+        return {"cached": self.cached}
+
+
+# =============================================================================== dense poolers
+class _DenseMLPPooling(DenseSRCPooling):
+    """What DiffPool and MinCut share: MLPSelect + BaseReduce + DenseConnect wiring, the batched /
+    unbatched control flow, and the optional block-diagonal sparse output."""
+
+    def __init__(self, in_channels, k, act, dropout, remove_self_loops, degree_norm, edge_weight_norm,
+                 adj_transpose, lift, s_inv_op, batched, sparse_output, cache_preprocessing):
+        super().__init__(
+            selector=MLPSelect(in_channels=in_channels, k=k, batched_representation=batched, act=act,
+                               dropout=dropout, s_inv_op=s_inv_op),
+            reducer=BaseReduce(),
+            lifter=BaseLift(matrix_op=lift),
+            connector=DenseConnect(remove_self_loops=remove_self_loops, degree_norm=degree_norm,
+                                   adj_transpose=adj_transpose, edge_weight_norm=edge_weight_norm,
+                                   sparse_output=sparse_output),
+            adj_transpose=adj_transpose, cache_preprocessing=cache_preprocessing, batched=batched,
+            sparse_output=sparse_output)
+
+    # hooks filled in by the two poolers -------------------------------------------------
+    def _batched_connect_and_loss(self, x, adj, so, mask, edge_weight, batch, batch_pooled):
+        raise NotImplementedError
+
+    def compute_sparse_loss(self, edge_index, edge_weight, S, batch) -> dict:
+        raise NotImplementedError
+
+    def _lift(self, x, so, batch, batch_pooled):
+        return self.lift(x_pool=x, so=so, batch=batch, batch_pooled=batch_pooled)
+
+    def forward(self, x: Tensor, adj=None, edge_weight: Optional[Tensor] = None,
+                so: Optional[SelectOutput] = None, mask: Optional[Tensor] = None,
+                batch: Optional[Tensor] = None, batch_pooled: Optional[Tensor] = None, lifting: bool = False,
+                **kwargs):
+        if lifting:
+            return self._lift(x, so, batch, batch_pooled)
+        if self.batched:
+            x, adj, mask = self._ensure_batched_inputs(x=x, edge_index=adj, edge_weight=edge_weight, batch=batch,
+                                                       mask=mask)
+            so = self.select(x=x, mask=mask)
+            x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch)
+            adj_pool, loss = self._batched_connect_and_loss(x, adj, so, mask, edge_weight, batch, batch_pool)
+            if self.sparse_output:
+                x_pool, ei, ew, batch_pool = self._finalize_sparse_output(
+                    x_pool=x_pool, adj_pool=adj_pool, batch=batch, batch_pooled=batch_pool, so=so)
+                return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so, loss=loss)
+            return PoolingOutput(x=x_pool, edge_index=adj_pool, so=so, loss=loss)
+        # unbatched: S [N,K], sparse A, sparse losses
+        so = self.select(x=x, batch=batch)
+        loss = self.compute_sparse_loss(adj, edge_weight, so.s, batch)
+        x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch, return_batched=not self.sparse_output)
+        ei, ew = self.connect(edge_index=adj, so=so, edge_weight=edge_weight, batch=batch,
+                              batch_pooled=batch_pool)
+        return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so, loss=loss)
+
+
+class DiffPool(_DenseMLPPooling):
+    r"""DiffPool: S = softmax(MLP(X)), X' = S^T X, A' = S^T A S, link-prediction + entropy auxiliary
+    losses (reference poolers/diffpool.py:22-331)."""
+
+    def __init__(self, in_channels: Union[int, List[int]], k: int, act: str = None, dropout: float = 0.0,
+                 link_loss_coeff: float = 1.0, ent_loss_coeff: float = 1.0, normalize_loss: bool = False,
+                 remove_self_loops: bool = True, degree_norm: bool = True, edge_weight_norm: bool = False,
+                 adj_transpose: bool = True, lift: str = "precomputed", s_inv_op: str = "transpose",
+                 batched: bool = True, sparse_output: bool = False, cache_preprocessing: bool = False):
+        super().__init__(in_channels, k, act, dropout, remove_self_loops, degree_norm, edge_weight_norm,
+                         adj_transpose, lift, s_inv_op, batched, sparse_output, cache_preprocessing)
+        self.link_loss_coeff = link_loss_coeff
+        self.ent_loss_coeff = ent_loss_coeff
+        self.normalize_loss = normalize_loss
+
+    def _batched_connect_and_loss(self, x, adj, so, mask, edge_weight, batch, batch_pooled):
+        adj_pool, _ = self.connect(edge_index=adj, so=so, edge_weight=edge_weight, batch=batch,
+                                   batch_pooled=batch_pooled)
+        loss = self.compute_loss(adj=adj, S=so.s, num_nodes=mask.sum().item())
+        return adj_pool, loss
+
+    def compute_loss(self, adj: Tensor, S: Tensor, num_nodes: int) -> dict:
+        return {"link_loss": link_pred_loss(S, adj, normalize_loss=self.normalize_loss) * self.link_loss_coeff,
+                "entropy_loss": entropy_loss(S, num_nodes) * self.ent_loss_coeff}
+
+    def compute_sparse_loss(self, edge_index, edge_weight, S, batch) -> dict:
+        ei, ew = connectivity_to_edge_index(edge_index, edge_weight)
+        return {"link_loss": sparse_link_pred_loss(S, ei, ew, batch, normalize_loss=self.normalize_loss)
+                * self.link_loss_coeff,
+                "entropy_loss": unbatched_entropy_loss(S) * self.ent_loss_coeff}
+
+    def extra_repr_args(self) -> dict:
+        return {"batched": self.batched, "link_loss_coeff": self.link_loss_coeff,
+                "ent_loss_coeff": self.ent_loss_coeff, "normalize_loss": self.normalize_loss}
+
+
+class MinCutPooling(_DenseMLPPooling):
+    r"""MinCut pooling: as DiffPool, with the normalised-cut and orthogonality losses computed on the
+    *raw* S^T A S before it is post-processed (reference poolers/mincut.py:22-354)."""
+
+    def __init__(self, in_channels: Union[int, List[int]], k: int, act: str = None, dropout: float = 0.0,
+                 cut_loss_coeff: float = 1.0, ortho_loss_coeff: float = 1.0, remove_self_loops: bool = True,
+                 degree_norm: bool = True, edge_weight_norm: bool = False, adj_transpose: bool = True,
+                 lift: str = "precomputed", s_inv_op: str = "transpose", batched: bool = True,
+                 sparse_output: bool = False, cache_preprocessing: bool = False):
+        super().__init__(in_channels, k, act, dropout, remove_self_loops, degree_norm, edge_weight_norm,
+                         adj_transpose, lift, s_inv_op, batched, sparse_output, cache_preprocessing)
+        self.cut_loss_coeff = cut_loss_coeff
+        self.ortho_loss_coeff = ortho_loss_coeff
+
+    def _lift(self, x, so, batch, batch_pooled):
+        return self.lift(x_pool=x, so=so, batch=batch if batch is not None else so.batch,
+                         batch_pooled=batch_pooled)
+
+    def _batched_connect_and_loss(self, x, adj, so, mask, edge_weight, batch, batch_pooled):
+        c = self.connector
+        raw = c.dense_connect(adj=adj, s=so.s)
+        loss = self.compute_loss(adj, so.s, raw)
+        adj_pool = postprocess_adj_pool_dense(raw, remove_self_loops=c.remove_self_loops,
+                                              degree_norm=c.degree_norm, adj_transpose=c.adj_transpose,
+                                              edge_weight_norm=c.edge_weight_norm)
+        return adj_pool, loss
+
+    def compute_loss(self, adj: Tensor, S: Tensor, adj_pooled: Tensor) -> dict:
+        return {"cut_loss": mincut_loss(adj, S, adj_pooled, batch_reduction="mean") * self.cut_loss_coeff,
+                "ortho_loss": orthogonality_loss(S, batch_reduction="mean") * self.ortho_loss_coeff}
+
+    def compute_sparse_loss(self, edge_index, edge_weight, S, batch) -> dict:
+        ei, ew = connectivity_to_edge_index(edge_index, edge_weight)
+        return {"cut_loss": sparse_mincut_loss(ei, S, ew, batch, batch_reduction="mean") * self.cut_loss_coeff,
+                "ortho_loss": unbatched_orthogonality_loss(S, batch, batch_reduction="mean")
+                * self.ortho_loss_coeff}
+
+    def extra_repr_args(self) -> dict:
+        return {"batched": self.batched, "cut_loss_coeff": self.cut_loss_coeff,
+                "ortho_loss_coeff": self.ortho_loss_coeff}
+
+
+# =============================================================================== factory
+pooler_classes = ["DiffPool", "GraclusPooling", "MinCutPooling", "NDPPooling", "TopkPooling"]
+
+pooler_map = {
+    "diff": DiffPool,
+    "graclus": GraclusPooling,
+    "mincut": MinCutPooling,
+    "ndp": NDPPooling,
+    "topk": TopkPooling,
+}
+
+
+def _missing_required(cls, given: dict) -> List[str]:
+    out = []
+    for name, p in inspect.signature(cls.__init__).parameters.items():
+        if name == "self" or p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD):
+            continue
+        if p.default is p.empty and name not in given:
+            out.append(name)
+    return out
+
+
+def get_pooler(pooler_name: str, **kwargs):
+    """Build a pooler from its alias (reference poolers/__init__.py:91-147): case-insensitive, a ``_u``
+    suffix selects the unbatched mode, kwargs the constructor does not take are dropped silently, a
+    missing required argument raises ``TypeError``."""
+    alias = pooler_name.lower()
+    if alias.endswith("_u") and alias[:-2] in pooler_map:
+        alias = alias[:-2]
+        kwargs.setdefault("batched", False)
+    if alias not in pooler_map:
+        raise ValueError(f"Unknown pooler_name='{pooler_name.lower()}'. "
+                         f"Available poolers: {list(pooler_map.keys())}")
+    cls = pooler_map[alias]
+    sig = cls.get_signature()
+    init_kwargs = kwargs if sig.has_kwargs else {k: v for k, v in kwargs.items() if k in sig.args}
+    missing = _missing_required(cls, init_kwargs)
+    if missing:
+        raise TypeError(f"Missing required argument(s) for pooler '{alias}' ({cls.__name__}): "
+                        f"{', '.join(missing)}")
+    return cls(**init_kwargs)
+
+
+__all__ = ["get_pooler", "pooler_map", "pooler_classes"] + pooler_classes

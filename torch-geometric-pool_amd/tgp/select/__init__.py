@@ -1,0 +1,550 @@
+"""``select`` operators and their output record.
+
+Public surface follows reference ``tgp/select`` (SelectOutput, Select, TopkSelect, MLPSelect,
+GraclusSelect, NDPSelect, cluster_to_s).  Selection is the input generator of the timed
+Reduce+Connect path, so scoring / sorting here uses plain device torch
+ops; the assignment it produces is what the HIP kernels consume.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from collections.abc import Mapping
+from typing import Any, Callable, List, Optional, Union
+
+import torch
+from torch import Tensor
+
+from ..imports import is_sparsetensor
+from ..utils.ops import (
+    connectivity_to_edge_index,
+    get_mask_from_dense_s,
+    graph_ptr,
+    maybe_num_nodes,
+    pseudo_inverse,
+)
+
+
+def cluster_to_s(cluster_index: Tensor, node_index: Optional[Tensor] = None, weight: Optional[Tensor] = None,
+                 as_edge_index: bool = False, num_nodes: Optional[int] = None,
+                 num_supernodes: Optional[int] = None):
+    """Assignment vectors -> sparse COO S [N,K] with node-sorted entries (reference
+    select/base_select.py:19-71).  The node-sorted order is a contract: TopK's Connect relabels
+    edges by *position in the sorted node list* (connect/base_conn.py:79-82)."""
+    if num_nodes is None:
+        num_nodes = cluster_index.size(0)
+    if num_supernodes is None:
+        num_supernodes = int(cluster_index.max().item()) + 1
+    if node_index is None:
+        node_index = torch.arange(num_nodes, dtype=torch.long, device=cluster_index.device)
+    if as_edge_index:
+        return torch.stack([node_index, cluster_index], dim=0), weight
+    node_sorted, order = torch.sort(node_index)
+    values = weight[order] if weight is not None else torch.ones(node_sorted.numel(), device=node_sorted.device)
+    return torch.sparse_coo_tensor(torch.stack([node_sorted, cluster_index[order]], dim=0), values,
+                                   size=(num_nodes, num_supernodes), is_coalesced=True)
+
+
+class SelectOutput:
+    r"""Assignment of nodes to supernodes: ``s`` is a sparse COO ``[N,K]`` or a dense ``[N,K]`` /
+    ``[B,N,K]`` tensor (reference select/base_select.py:76-486).
+
+    Besides the reference's fields it keeps two private caches for the native kernels: the
+    supernode->assignment inverted index (``_assign_index``) and its transpose for Lift.
+    """
+
+    def __init__(self, s: Tensor = None, s_inv: Tensor = None, node_index: Tensor = None,
+                 num_nodes: int = None, cluster_index: Tensor = None, num_supernodes: int = None,
+                 weight: Optional[Tensor] = None, s_inv_op: Optional[str] = "transpose",
+                 batch: Optional[Tensor] = None, in_mask: Optional[Tensor] = None, **extra_args):
+        if isinstance(s, Tensor):
+            given = dict(cluster_index=cluster_index, node_index=node_index)
+            if s.is_sparse:
+                for name, val in given.items():
+                    assert val is None, f"'{name}' cannot be set if 's' is not None"
+                s = s.coalesce()
+                if weight is not None:
+                    s = torch.sparse_coo_tensor(s.indices(), weight, s.size(), dtype=s.dtype, device=s.device,
+                                                is_coalesced=True).coalesce()
+                if num_nodes is not None or num_supernodes is not None:
+                    n0, k0 = s.size()
+                    s = torch.sparse_coo_tensor(s.indices(), s.values(), (num_nodes or n0, num_supernodes or k0),
+                                                dtype=s.dtype, device=s.device, is_coalesced=True).coalesce()
+            else:
+                given.update(num_nodes=num_nodes, num_supernodes=num_supernodes, weight=weight)
+                for name, val in given.items():
+                    assert val is None, f"'{name}' cannot be set if 's' is a dense Tensor"
+        elif s is None:
+            assert cluster_index is not None, "'cluster_index' cannot be None if 's' is None"
+            s = cluster_to_s(cluster_index, node_index=node_index, num_supernodes=num_supernodes,
+                             num_nodes=num_nodes, weight=weight)
+        else:
+            raise ValueError("Either a sparse or dense assignment matrix is provided through 's' or a cluster "
+                             "assignment vector must be provided thorough 'cluster_index'.")
+        self.s = s
+        self.s_inv = s_inv
+        if s_inv is None:
+            self.set_s_inv(s_inv_op)
+        self.batch = batch
+        self.in_mask = self._validate_in_mask(in_mask)
+        self._extra_args = set()
+        if self.in_mask is not None:
+            self._extra_args.add("in_mask")
+        for key, val in extra_args.items():
+            setattr(self, key, val)
+            self._extra_args.add(key)
+        self._assign_index = None
+        self._lift_index = None
+
+    # ---- validation / derived views -------------------------------------------------
+    def _validate_in_mask(self, in_mask: Optional[Tensor]) -> Optional[Tensor]:
+        if in_mask is None:
+            return None
+        if in_mask.dim() != 2:
+            raise ValueError("SelectOutput.in_mask must be 2D with shape [B, N] (batched representations only).")
+        if not self.is_dense or self.s.dim() != 3:
+            raise ValueError("SelectOutput.in_mask is only supported for batched dense assignments "
+                             "with shape [B, N, K].")
+        if in_mask.shape != self.s.shape[:2]:
+            raise ValueError(f"SelectOutput.in_mask must have shape {tuple(self.s.shape[:2])}, "
+                             f"got {tuple(in_mask.shape)}.")
+        return in_mask.to(torch.bool)
+
+    @property
+    def is_sparse(self) -> bool:
+        return isinstance(self.s, Tensor) and self.s.is_sparse
+
+    @property
+    def is_dense(self) -> bool:
+        return isinstance(self.s, Tensor) and not self.s.is_sparse
+
+    @property
+    def num_nodes(self) -> int:
+        return self.s.size(-2)
+
+    @property
+    def num_supernodes(self) -> int:
+        return self.s.size(-1)
+
+    @property
+    def node_index(self) -> Optional[Tensor]:
+        return self.s.indices()[0] if self.is_sparse else None
+
+    @property
+    def cluster_index(self) -> Optional[Tensor]:
+        return self.s.indices()[1] if self.is_sparse else None
+
+    @property
+    def weight(self) -> Optional[Tensor]:
+        return self.s.values() if self.is_sparse else None
+
+    @property
+    def out_mask(self) -> Optional[Tensor]:
+        if not self.is_dense or self.s.dim() not in (2, 3):
+            return None
+        return get_mask_from_dense_s(self.s, self.batch)
+
+    @property
+    def is_expressive(self) -> bool:
+        row_sum = self.s.sum(dim=-1)
+        if row_sum.is_sparse:
+            row_sum = row_sum.to_dense()
+        if self.in_mask is not None:
+            row_sum = row_sum[self.in_mask]
+        if row_sum.numel() == 0:
+            return False
+        first = row_sum.reshape(-1)[0]
+        return bool(torch.allclose(row_sum, first.expand_as(row_sum))) and not bool(
+            torch.allclose(first, torch.zeros((), dtype=first.dtype, device=first.device)))
+
+    def set_s_inv(self, method) -> None:
+        if method == "transpose":
+            self.s_inv = self.s.t() if self.is_sparse else self.s.transpose(-1, -2)
+        elif method == "inverse":
+            self.s_inv = pseudo_inverse(self.s)
+        else:
+            raise ValueError()
+
+    # ---- native-kernel caches ---------------------------------------------------------
+    def assign_index(self):
+        """supernode -> assignments inverted index for the sparse Reduce kernel (cached)."""
+        from .. import kernels
+        if self._assign_index is None:
+            self._assign_index = kernels.build_assign_index(self.cluster_index, self.num_supernodes)
+        return self._assign_index
+
+    def _drop_caches(self) -> None:
+        self._assign_index = None
+        self._lift_index = None
+
+    # ---- tensor plumbing (reference base_select.py:313-379) ---------------------------
+    def __repr__(self) -> str:
+        out = f"{self.__class__.__name__}(num_nodes={self.num_nodes}, num_supernodes={self.num_supernodes}"
+        if len(self._extra_args):
+            out += f", extra={self._extra_args}"
+        return out + ")"
+
+    @staticmethod
+    def _apply_to_value(value: Any, func: Callable) -> Any:
+        if isinstance(value, Tensor):
+            return func(value)
+        if isinstance(value, (list, tuple)):
+            return type(value)(SelectOutput._apply_to_value(v, func) for v in value)
+        if isinstance(value, Mapping):
+            return {k: SelectOutput._apply_to_value(v, func) for k, v in value.items()}
+        return value
+
+    def apply(self, func: Callable) -> "SelectOutput":
+        self.s = func(self.s)
+        if self.s_inv is not None:
+            self.s_inv = func(self.s_inv)
+        for name in self._extra_args:
+            if hasattr(self, name):
+                setattr(self, name, self._apply_to_value(getattr(self, name), func))
+        self._drop_caches()
+        return self
+
+    def clone(self) -> "SelectOutput":
+        return copy.deepcopy(self)
+
+    def _move(self, func: Callable) -> "SelectOutput":
+        self.apply(func)
+        if self.batch is not None:
+            self.batch = func(self.batch)
+        return self
+
+    def to(self, device, non_blocking: bool = False) -> "SelectOutput":
+        return self._move(lambda t: t.to(device=device, non_blocking=non_blocking))
+
+    def cpu(self) -> "SelectOutput":
+        return self._move(lambda t: t.cpu())
+
+    def cuda(self, device=None, non_blocking: bool = False) -> "SelectOutput":
+        return self._move(lambda t: t.cuda(device, non_blocking=non_blocking))
+
+    def detach_(self) -> "SelectOutput":
+        return self.apply(lambda t: t.detach_())
+
+    def detach(self) -> "SelectOutput":
+        return self.apply(lambda t: t.detach())
+
+    def requires_grad_(self, requires_grad: bool = True) -> "SelectOutput":
+        return self.apply(lambda t: t.requires_grad_(requires_grad=requires_grad))
+
+    def assign_all_nodes(self, *args, **kwargs):
+        raise NotImplementedError("assign_all_nodes belongs to the KMIS/MaxCut poolers, which are outside the "
+                                  "scope of this build (SURVEY.md section 2).")
+
+
+class Select(torch.nn.Module):
+    """Base class of the select operators (reference select/base_select.py:489-541)."""
+
+    is_dense: bool = False
+
+    def reset_parameters(self):
+        pass
+
+    def forward(self, x: Optional[Tensor] = None, edge_index=None, edge_weight: Optional[Tensor] = None, *,
+                batch: Optional[Tensor] = None, num_nodes: Optional[int] = None, **kwargs) -> SelectOutput:
+        raise NotImplementedError
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}()"
+
+
+# =============================================================================== TopK
+def _segment_max(src: Tensor, index: Tensor, size: int) -> Tensor:
+    return src.new_zeros(size).scatter_reduce_(0, index, src, reduce="amax", include_self=False)
+
+
+def topk(x: Tensor, ratio, batch: Tensor, min_score: Optional[float] = None, tol: float = 1e-7) -> Tensor:
+    """Per-graph top-k node indices, graph-major and score-descending (the algorithm of PyG 2.6
+    ``torch_geometric.nn.pool.select.topk.topk``, which the reference calls at
+    select/topk_select.py:194)."""
+    nb = int(batch.max()) + 1 if batch.numel() else 0
+    if min_score is not None:
+        floor = (_segment_max(x, batch, nb)[batch] - tol).clamp(max=min_score)
+        return (x > floor).nonzero().view(-1)
+    if ratio is None:
+        raise ValueError("At least one of the 'ratio' and 'min_score' parameters must be specified")
+    sizes, ptr = graph_ptr(batch, nb)
+    if ratio >= 1:
+        k = torch.minimum(torch.full_like(sizes, int(ratio)), sizes)
+    else:
+        k = (float(ratio) * sizes.to(x.dtype)).ceil().to(torch.long)
+    _, by_score = torch.sort(x.view(-1), descending=True)
+    g_sorted, by_graph = torch.sort(batch[by_score], descending=False, stable=True)
+    rank = torch.arange(x.numel(), device=x.device) - ptr[g_sorted]
+    return by_score[by_graph[rank < k[g_sorted]]]
+
+
+_ACTIVATIONS = {"tanh": torch.nn.Tanh, "relu": torch.nn.ReLU, "sigmoid": torch.nn.Sigmoid,
+                "elu": torch.nn.ELU, "leaky_relu": torch.nn.LeakyReLU, "leakyrelu": torch.nn.LeakyReLU,
+                "softplus": torch.nn.Softplus, "gelu": torch.nn.GELU, "silu": torch.nn.SiLU}
+
+
+def _resolve_activation(act):
+    if act is None or not isinstance(act, str):
+        return act
+    try:
+        return _ACTIVATIONS[act.lower()]()
+    except KeyError:
+        raise ValueError(f"Could not resolve activation '{act}'") from None
+
+
+class TopkSelect(Select):
+    r"""score = act(x.w / ||w||) (or a per-graph softmax when ``min_score`` is set), keep the top
+    ``ceil(ratio*n)`` nodes of every graph; the kept nodes become supernodes weighted by their score
+    (reference select/topk_select.py:126-216)."""
+
+    def __init__(self, in_channels: Optional[int] = None, ratio: Union[int, float] = 0.5,
+                 min_score: Optional[float] = None, act: Union[str, Callable] = "tanh",
+                 s_inv_op: str = "transpose"):
+        super().__init__()
+        if ratio is None and min_score is None:
+            raise ValueError("At least one of the 'ratio' and 'min_score' parameters must be specified in "
+                             f"'{self.__class__.__name__}'")
+        self.in_channels, self.ratio, self.min_score, self.s_inv_op = in_channels, ratio, min_score, s_inv_op
+        self.act = (lambda v: v) if act in ("linear", "identity", "none", None) else _resolve_activation(act)
+        if in_channels is None or in_channels <= 1:
+            self.register_parameter("weight", None)
+        else:
+            self.weight = torch.nn.Parameter(torch.empty(1, in_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.weight is not None and self.in_channels is not None:
+            bound = 1.0 / math.sqrt(self.in_channels)
+            self.weight.data.uniform_(-bound, bound)
+
+    def forward(self, x: Tensor, *, batch: Optional[Tensor] = None, **kwargs) -> SelectOutput:
+        if batch is None:
+            batch = x.new_zeros(x.size(0), dtype=torch.long)
+        if self.weight is None:
+            if x.dim() > 1:
+                assert x.size(1) == 1, "x must be 1D when in_channels is None"
+            score = x.reshape(-1)
+        else:
+            feats = x.view(-1, 1) if x.dim() == 1 else x
+            score = (feats * self.weight).sum(dim=-1)
+            if self.min_score is None:
+                score = score / self.weight.norm(p=2, dim=-1)
+        if self.min_score is None:
+            score = self.act(score)
+        else:  # segment softmax, +1e-16 in the denominator as PyG's utils.softmax
+            nb = int(batch.max()) + 1
+            e = (score - _segment_max(score.detach(), batch, nb)[batch]).exp()
+            score = e / (e.new_zeros(nb).index_add_(0, batch, e) + 1e-16)[batch]
+        node_index = topk(score, self.ratio, batch, self.min_score)
+        return SelectOutput(node_index=node_index, num_nodes=x.size(0),
+                            cluster_index=torch.arange(node_index.size(0), device=x.device),
+                            num_supernodes=node_index.size(0), weight=score[node_index],
+                            s_inv_op=self.s_inv_op)
+
+    def __repr__(self) -> str:
+        arg = f"ratio={self.ratio}" if self.min_score is None else f"min_score={self.min_score}"
+        return (f"{self.__class__.__name__}(in_channels={self.in_channels}, {arg}, act={self.act}, "
+                f"s_inv_op={self.s_inv_op})")
+
+
+# =============================================================================== dense MLP
+class MLP(torch.nn.Module):
+    """Linear -> act -> dropout -> ... -> Linear.  Parameter names (``lins.<i>.weight/bias``) match
+    PyG's MLP so reference checkpoints (``selector.mlp.lins.0.weight``) load unchanged."""
+
+    def __init__(self, channel_list: List[int], act: Optional[str] = None, dropout: float = 0.0):
+        super().__init__()
+        self.channel_list = list(channel_list)
+        self.lins = torch.nn.ModuleList(torch.nn.Linear(a, b) for a, b in zip(channel_list[:-1], channel_list[1:]))
+        self.act = _resolve_activation(act)
+        self.dropout = float(dropout)
+
+    def reset_parameters(self):
+        for lin in self.lins:
+            lin.reset_parameters()
+
+    def forward(self, x: Tensor) -> Tensor:
+        for i, lin in enumerate(self.lins):
+            x = lin(x)
+            if i + 1 < len(self.lins):
+                if self.act is not None:
+                    x = self.act(x)
+                x = torch.nn.functional.dropout(x, p=self.dropout, training=self.training)
+        return x
+
+
+class MLPSelect(Select):
+    r"""Dense soft assignment S = softmax(MLP(X)), zeroed on padded rows
+    (reference select/mlp_select.py:47-157)."""
+
+    is_dense: bool = True
+
+    def __init__(self, in_channels: Union[int, List[int]], k: int, batched_representation: bool = True,
+                 act: str = None, dropout: float = 0.0, s_inv_op: str = "transpose"):
+        super().__init__()
+        in_channels = [in_channels] if isinstance(in_channels, int) else list(in_channels)
+        self.mlp = MLP(in_channels + [k], act=act, dropout=dropout)
+        self.in_channels, self.k, self.act, self.dropout = in_channels, k, act, dropout
+        self.s_inv_op, self.batched_representation = s_inv_op, batched_representation
+
+    def reset_parameters(self):
+        self.mlp.reset_parameters()
+
+    def forward(self, x: Tensor, mask: Optional[Tensor] = None, batch: Optional[Tensor] = None,
+                **kwargs) -> SelectOutput:
+        if self.batched_representation:
+            x = x.unsqueeze(0) if x.dim() == 2 else x
+        else:
+            assert x.dim() == 2, "x must be of shape [N, F] for unbatched mode"
+        s = torch.softmax(self.mlp(x), dim=-1)
+        if self.batched_representation:
+            if mask is not None:
+                s = s * mask.unsqueeze(-1)
+            return SelectOutput(s=s, s_inv_op=self.s_inv_op, in_mask=mask)
+        return SelectOutput(s=s, s_inv_op=self.s_inv_op, batch=batch)
+
+    def __repr__(self) -> str:
+        return (f"{self.__class__.__name__}(in_channels={self.in_channels}, k={self.k}, act={self.act}, "
+                f"dropout={self.dropout}, s_inv_op={self.s_inv_op})")
+
+
+# =============================================================================== Graclus
+def graclus_cluster(row: Tensor, col: Tensor, weight: Optional[Tensor] = None,
+                    num_nodes: Optional[int] = None, max_rounds: int = 64) -> Tensor:
+    """Greedy heavy-edge matching; each node is labelled with the smaller id of its pair.
+
+    torch_cluster's ``graclus_cluster`` (what the reference calls, select/graclus_select.py:66) is a
+    randomised parallel matching, so its exact pairs are not part of any contract; any maximal
+    matching is a valid stand-in.  This one is deterministic: in every round each free node proposes
+    to its heaviest free neighbour (smallest id on ties) and mutual proposals are matched; the
+    rounds are data-parallel device ops.  (The globally heaviest free edge with the smallest endpoint
+    ids is always a mutual proposal, so every round makes progress.)
+    """
+    n = int(num_nodes) if num_nodes is not None else (int(max(row.max(), col.max())) + 1 if row.numel() else 0)
+    dev = row.device
+    label = torch.arange(n, device=dev)
+    keep = row != col
+    row, col = row[keep], col[keep]
+    w = torch.ones(row.numel(), device=dev) if weight is None else weight.reshape(-1)[keep].to(torch.float32)
+    free = torch.ones(n, dtype=torch.bool, device=dev)
+    for _ in range(max_rounds):
+        live = free[row] & free[col]
+        if not bool(live.any()):
+            break
+        r, c, ww = row[live], col[live], w[live]
+        best_w = torch.full((n,), -float("inf"), device=dev).scatter_reduce_(0, r, ww, reduce="amax")
+        is_best = ww == best_w[r]
+        cand = torch.full((n,), n, dtype=torch.long, device=dev)
+        cand.scatter_reduce_(0, r[is_best], c[is_best], reduce="amin")
+        has = cand < n
+        proposer = torch.arange(n, device=dev)[has]
+        target = cand[has]
+        mutual = cand[target] == proposer
+        a, b = proposer[mutual], target[mutual]
+        if a.numel() == 0:  # cannot happen (the globally heaviest edge is always mutual); guard anyway
+            break
+        lo = torch.minimum(a, b)
+        label[a] = lo
+        label[b] = lo
+        free[a] = False
+        free[b] = False
+    return label
+
+
+class GraclusSelect(Select):
+    r"""One-over-K hard assignment from a greedy matching, relabelled to consecutive ids
+    (reference select/graclus_select.py:13-84)."""
+
+    def __init__(self, s_inv_op: str = "transpose"):
+        super().__init__()
+        self.s_inv_op = s_inv_op
+
+    def forward(self, edge_index: Tensor, edge_weight: Optional[Tensor] = None,
+                num_nodes: Optional[int] = None, **kwargs) -> SelectOutput:
+        edge_index, edge_weight = connectivity_to_edge_index(edge_index, edge_weight)
+        num_nodes = maybe_num_nodes(edge_index, num_nodes)
+        pair = graclus_cluster(edge_index[0], edge_index[1], edge_weight, num_nodes)
+        ids, assignment = torch.unique(pair, sorted=True, return_inverse=True)
+        return SelectOutput(node_index=torch.arange(num_nodes, device=assignment.device), num_nodes=num_nodes,
+                            cluster_index=assignment, num_supernodes=ids.size(0), s_inv_op=self.s_inv_op)
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(s_inv_op={self.s_inv_op})"
+
+
+# =============================================================================== NDP
+class NDPSelect(Select):
+    r"""Node Decimation Pooling selection: keep the positive side of the sign partition of the largest
+    eigenvector of the symmetric normalised Laplacian of every graph; random +-1 partition when the cut
+    is below 0.5 (reference select/ndp_select.py:21-259).  Host-side (scipy), like the reference."""
+
+    def __init__(self, s_inv_op: str = "transpose"):
+        super().__init__()
+        self.s_inv_op = s_inv_op
+
+    def forward(self, edge_index, edge_weight: Optional[Tensor] = None, *, batch: Optional[Tensor] = None,
+                num_nodes: Optional[int] = None, **kwargs) -> SelectOutput:
+        import numpy as np
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+
+        if num_nodes is None:
+            num_nodes = maybe_num_nodes(edge_index)
+        edge_index, edge_weight = connectivity_to_edge_index(edge_index, edge_weight)
+        dev = edge_index.device
+        ei = edge_index.cpu().numpy()
+        w = np.ones(ei.shape[1], dtype=np.float64) if edge_weight is None else \
+            edge_weight.detach().cpu().numpy().astype(np.float64).reshape(-1)
+        off = ei[0] != ei[1]
+        A = sp.coo_matrix((w[off], (ei[0][off], ei[1][off])), shape=(num_nodes, num_nodes)).tocsr()
+        A = A.maximum(A.T)  # to_undirected(reduce='max') when the input is not symmetric
+        deg = np.asarray(A.sum(1)).reshape(-1)
+        L = (sp.diags(deg) - A).tocsr()
+        b = np.zeros(num_nodes, dtype=np.int64) if batch is None else batch.cpu().numpy()
+        rng = np.random.default_rng(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+        keep = []
+        for g in range(int(b.max()) + 1 if num_nodes else 0):
+            nodes = np.nonzero(b == g)[0]
+            if nodes.size == 0:
+                continue
+            if nodes.size == 1:
+                keep.append(nodes)
+                continue
+            Ag = A[nodes][:, nodes]
+            dg = np.asarray(Ag.sum(1)).reshape(-1)
+            dis = np.where(dg > 0, 1.0 / np.sqrt(np.maximum(dg, 1e-300)), 0.0)
+            Ls = sp.eye(nodes.size) - sp.diags(dis) @ Ag @ sp.diags(dis)
+            Lg = sp.diags(dg) - Ag
+
+            def random_sign():
+                v = rng.integers(0, 2, nodes.size) * 2 - 1
+                v[0], v[1] = 1, -1
+                return v
+
+            try:
+                if nodes.size <= 3:
+                    vals, vecs = np.linalg.eigh(Ls.toarray())
+                    vec = vecs[:, -1]
+                else:
+                    _, vecs = spla.eigsh(Ls.tocsc(), k=1, which="LA", v0=np.ones(nodes.size))
+                    vec = vecs[:, 0]
+                z = np.where(vec >= 0, 1.0, -1.0)
+            except Exception:
+                z = random_sign().astype(np.float64)
+            vol = Ag.sum() if edge_weight is not None else Ag.nnz
+            cut = float(z @ (Lg @ z)) / (2.0 * vol) if vol > 0 else 0.0
+            if cut < 0.5:
+                z = random_sign().astype(np.float64)
+            keep.append(nodes[z >= 0])
+        idx_pos = torch.from_numpy(np.sort(np.concatenate(keep)) if keep else np.zeros(0, dtype=np.int64)).to(dev)
+        k = idx_pos.numel()
+        s = torch.sparse_coo_tensor(torch.stack([idx_pos, torch.arange(k, device=dev)]),
+                                    torch.ones(k, device=dev), size=(num_nodes, k)).coalesce()
+        return SelectOutput(s=s, s_inv_op=self.s_inv_op, L=L.astype(np.float32))
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(s_inv_op={self.s_inv_op})"
+
+
+__all__ = ["SelectOutput", "Select", "TopkSelect", "MLPSelect", "GraclusSelect", "NDPSelect", "cluster_to_s",
+           "topk", "graclus_cluster"]

@@ -1,0 +1,351 @@
+"""Select-Reduce-Connect composition: ``PoolingOutput``, ``SRCPooling``, ``DenseSRCPooling`` and the
+pre-coarsening mix-ins (public surface of reference tgp/src.py)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Dict, Iterator, List, Optional, Tuple, Union
+
+import torch
+from torch import Tensor
+
+from . import kernels as K
+from .connect import Connect
+from .imports import HAS_PYG
+from .lift import Lift
+from .reduce import Reduce
+from .select import Select, SelectOutput
+from .utils import Signature, connectivity_to_edge_index, foo_signature
+from .utils.ops import build_pooled_batch, graph_ptr, is_dense_adj
+
+
+@dataclass
+class PoolingOutput:
+    """Result record of a pooling layer (reference src.py:19-116)."""
+
+    x: Optional[Tensor] = None
+    edge_index: Optional[Tensor] = None
+    edge_weight: Optional[Tensor] = None
+    batch: Optional[Tensor] = None
+    so: Optional[SelectOutput] = None
+    loss: Optional[Dict] = None
+
+    @property
+    def mask(self) -> Optional[Tensor]:
+        return self.so.out_mask if self.so is not None else None
+
+    @staticmethod
+    def _shape(t) -> Optional[list]:
+        return [*t.shape] if t is not None else None
+
+    def __repr__(self) -> str:
+        so = [self.so.num_nodes, self.so.num_supernodes] if self.so is not None else None
+        loss = list(self.loss.keys()) if self.loss is not None else None
+        return (f"PoolingOutput(so={so}, x={self._shape(self.x)}, edge_index={self._shape(self.edge_index)}, "
+                f"edge_weight={self._shape(self.edge_weight)}, batch={self._shape(self.batch)}, "
+                f"mask={self._shape(self.mask)}, loss={loss})")
+
+    def __iter__(self) -> Iterator:
+        return iter((self.x, self.edge_index, self.edge_weight, self.batch, self.mask, self.so, self.loss))
+
+    @property
+    def has_loss(self) -> bool:
+        return bool(isinstance(self.loss, dict) and len(self.loss) > 0)
+
+    def get_loss_value(self, name: str = None) -> Union[float, List[float]]:
+        if not self.has_loss:
+            return 0
+        return list(self.loss.values()) if name is None else self.loss[name]
+
+    def as_data(self):
+        """A ``torch_geometric.data.Data`` when PyG is installed, else an attribute namespace with the
+        same fields (reference src.py:94-116)."""
+        if self.batch is not None:
+            num_nodes = self.batch.numel()
+        elif self.x is not None:
+            num_nodes = self.x.size(-2)
+        else:
+            num_nodes = self.so.num_supernodes if self.so is not None else None
+        fields = dict(x=self.x, edge_index=self.edge_index, edge_weight=self.edge_weight, batch=self.batch,
+                      mask=self.mask, so=self.so, num_nodes=num_nodes)
+        if HAS_PYG:  # pragma: no cover - PyG is absent from the MI355X image
+            from torch_geometric.data import Data
+            return Data(**fields)
+        return SimpleNamespace(**fields)
+
+
+class SRCPooling(torch.nn.Module):
+    """select / reduce / connect / lift dispatch with optional caching of the select and connect results
+    (reference src.py:119-307)."""
+
+    def __init__(self, selector: Select = None, reducer: Reduce = None, lifter: Lift = None,
+                 connector: Connect = None, cached: bool = False):
+        super().__init__()
+        self.selector, self.reducer, self.lifter, self.connector = selector, reducer, lifter, connector
+        self.cached = cached
+        self._so_cached = None
+        self._pooled_edge_index = None
+        self._pooled_edge_weight = None
+
+    def reset_parameters(self):
+        for op in (self.selector, self.reducer, self.lifter, self.connector):
+            op.reset_parameters()
+
+    def select(self, **kwargs) -> SelectOutput:
+        if self.selector is None:
+            raise NotImplementedError
+        if self._so_cached is not None:
+            return self._so_cached
+        so = self.selector(**kwargs)
+        if self.cached:
+            self._so_cached = so
+        return so
+
+    def reduce(self, **kwargs):
+        if self.reducer is None:
+            raise NotImplementedError
+        return self.reducer(**kwargs)
+
+    def lift(self, **kwargs):
+        if self.lifter is None:
+            raise NotImplementedError
+        return self.lifter(**kwargs)
+
+    def connect(self, **kwargs):
+        if self.connector is None:
+            raise NotImplementedError
+        if self._pooled_edge_index is not None:
+            return self._pooled_edge_index, self._pooled_edge_weight
+        ei, ew = self.connector(**kwargs)
+        if self.cached:
+            self._pooled_edge_index, self._pooled_edge_weight = ei, ew
+        return ei, ew
+
+    def preprocessing(self, x: Tensor, edge_index, **kwargs):
+        return x, edge_index, None
+
+    @property
+    def is_dense(self) -> bool:
+        if self.selector is None:
+            raise NotImplementedError
+        return self.selector.is_dense
+
+    @property
+    def is_sparse(self) -> bool:
+        return not self.is_dense
+
+    @property
+    def has_loss(self) -> bool:
+        return self.compute_loss.__qualname__.split(".")[0] != "SRCPooling"
+
+    @property
+    def is_trainable(self) -> bool:
+        return any(p.requires_grad for p in self.parameters())
+
+    def compute_loss(self, *args, **kwargs) -> Optional[dict]:
+        return None
+
+    def clear_cache(self):
+        self._so_cached = None
+        self._pooled_edge_index = None
+        self._pooled_edge_weight = None
+
+    @property
+    def is_precoarsenable(self) -> bool:
+        return isinstance(self, Precoarsenable) and not self.is_trainable
+
+    @classmethod
+    def get_signature(cls) -> Signature:
+        return foo_signature(cls)
+
+    @classmethod
+    def get_forward_signature(cls) -> Signature:
+        return foo_signature(cls.forward)
+
+    @staticmethod
+    def data_transforms():
+        return None
+
+    def extra_repr_args(self) -> dict:
+        return {}
+
+    def __repr__(self) -> str:
+        lines = [f"{self.__class__.__name__}(", f"\tselect={self.selector}", f"\treduce={self.reducer}",
+                 f"\tlift={self.lifter}", f"\tconnect={self.connector}"]
+        lines += [f"\t{k}={v}" for k, v in self.extra_repr_args().items()]
+        return "\n".join(lines + [")"])
+
+
+# --------------------------------------------------------------------------- sparse -> padded dense
+def to_dense_batch(x: Tensor, batch: Optional[Tensor] = None, max_num_nodes: Optional[int] = None,
+                   batch_size: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    """[N,F] + batch -> ([B,Nmax,F], mask [B,Nmax])  (the algorithm of PyG ``to_dense_batch``)."""
+    if batch is None and max_num_nodes is None:
+        return x.unsqueeze(0), torch.ones(1, x.size(0), dtype=torch.bool, device=x.device)
+    if batch is None:
+        batch = x.new_zeros(x.size(0), dtype=torch.long)
+    if batch_size is None:
+        batch_size = int(batch.max()) + 1
+    sizes, ptr = graph_ptr(batch, batch_size)
+    if max_num_nodes is None:
+        max_num_nodes = int(sizes.max())
+    local = torch.arange(batch.numel(), device=x.device) - ptr[batch]
+    keep = local < max_num_nodes
+    slot = (local + batch * max_num_nodes)[keep]
+    out = x.new_zeros((batch_size * max_num_nodes,) + tuple(x.shape[1:]))
+    out[slot] = x[keep]
+    mask = torch.zeros(batch_size * max_num_nodes, dtype=torch.bool, device=x.device)
+    mask[slot] = True
+    return out.view((batch_size, max_num_nodes) + tuple(x.shape[1:])), mask.view(batch_size, max_num_nodes)
+
+
+def to_dense_adj(edge_index: Tensor, batch: Optional[Tensor] = None, edge_attr: Optional[Tensor] = None,
+                 max_num_nodes: Optional[int] = None, batch_size: Optional[int] = None) -> Tensor:
+    """Edge list -> [B,Nmax,Nmax], duplicates summed (the algorithm of PyG ``to_dense_adj``; with
+    ``batch=None`` the node count is inferred from ``edge_index.max()+1`` exactly as PyG does)."""
+    if batch is None:
+        n = int(edge_index.max()) + 1 if edge_index.numel() > 0 else 0
+        batch = edge_index.new_zeros(n)
+    if batch_size is None:
+        batch_size = int(batch.max()) + 1 if batch.numel() > 0 else 1
+    sizes, ptr = graph_ptr(batch, batch_size)
+    g = batch[edge_index[0]]
+    r = edge_index[0] - ptr[g]
+    c = edge_index[1] - ptr[batch[edge_index[1]]]
+    if max_num_nodes is None:
+        max_num_nodes = int(sizes.max()) if sizes.numel() else 0
+    else:
+        ok = (r < max_num_nodes) & (c < max_num_nodes)
+        g, r, c = g[ok], r[ok], c[ok]
+        edge_attr = None if edge_attr is None else edge_attr[ok]
+    w = torch.ones(g.numel(), device=edge_index.device) if edge_attr is None else edge_attr
+    flat = w.new_zeros((batch_size * max_num_nodes * max_num_nodes,) + tuple(w.shape[1:]))
+    flat.index_add_(0, (g * max_num_nodes + r) * max_num_nodes + c, w)
+    return flat.view((batch_size, max_num_nodes, max_num_nodes) + tuple(w.shape[1:]))
+
+
+class DenseSRCPooling(SRCPooling):
+    """Dense poolers: sparse -> padded-dense preprocessing, batched / unbatched modes, optional
+    block-diagonal sparse output (reference src.py:310-557)."""
+
+    def __init__(self, selector: Select = None, reducer: Reduce = None, lifter: Lift = None,
+                 connector: Connect = None, cached: bool = False, adj_transpose: bool = False,
+                 batched: bool = True, sparse_output: bool = False, cache_preprocessing: bool = False):
+        super().__init__(selector=selector, reducer=reducer, lifter=lifter, connector=connector, cached=cached)
+        self.batched = batched
+        self.sparse_output = sparse_output
+        self.adj_transpose = adj_transpose
+        self.cache_preprocessing = cache_preprocessing
+        self.preprocessing_cache = None
+
+    def preprocessing(self, x: Tensor, edge_index, edge_weight: Optional[Tensor] = None,
+                      batch: Optional[Tensor] = None, max_num_nodes: Optional[int] = None,
+                      batch_size: Optional[int] = None, use_cache: bool = False, **kwargs):
+        if use_cache and self.preprocessing_cache is not None:
+            adj = self.preprocessing_cache
+        else:
+            ei, ew = connectivity_to_edge_index(edge_index, edge_weight)
+            adj = to_dense_adj(ei, batch, ew, max_num_nodes, batch_size)
+            if self.adj_transpose:
+                adj = adj.transpose(-1, -2)  # a view: the GEMM kernel reads it through TGP_ADJ_TRANSPOSED
+            if use_cache:
+                self.preprocessing_cache = adj
+        x, mask = to_dense_batch(x, batch, max_num_nodes, batch_size)
+        return x, adj, mask
+
+    def _ensure_batched_inputs(self, x, edge_index, edge_weight, batch, mask, use_cache: Optional[bool] = None):
+        if edge_index is None:
+            raise ValueError("edge_index cannot be None when batched=True.")
+        if use_cache is None:
+            use_cache = self.cache_preprocessing
+        if use_cache and batch is not None and batch.numel() > 0:
+            lo, hi = torch.aminmax(batch)
+            use_cache = int(lo) == int(hi)  # never cache a multi-graph batch
+        if is_dense_adj(edge_index):
+            x = x.unsqueeze(0) if x.dim() == 2 else x
+            if mask is None:
+                mask = x.new_ones(x.size(0), x.size(1), dtype=torch.bool)
+            if use_cache:
+                self.preprocessing_cache = edge_index
+            return x, edge_index, mask
+        return self.preprocessing(x=x, edge_index=edge_index, edge_weight=edge_weight, batch=batch,
+                                  use_cache=use_cache)
+
+    def clear_cache(self):
+        super().clear_cache()
+        self.preprocessing_cache = None
+
+    def _finalize_sparse_output(self, x_pool: Tensor, adj_pool: Tensor, batch: Optional[Tensor],
+                                batch_pooled: Optional[Tensor], so: SelectOutput):
+        """[B,K,F] / [B,K,K] -> compact block-diagonal representation restricted to the supernodes that
+        own at least one node (reference src.py:500-557); the edge extraction + renumbering is one
+        count->fill kernel pair."""
+        B, Kc = adj_pool.size(0), adj_pool.size(1)
+        x_flat = x_pool.reshape(-1, x_pool.size(-1))
+        out_mask = so.out_mask
+        if batch_pooled is None and batch is not None:
+            batch_pooled = self.reducer.reduce_batch(so, batch)
+        if batch_pooled is None and B > 1:
+            batch_pooled = build_pooled_batch(B, Kc, x_pool.device)
+        if batch_pooled is None and out_mask is not None:
+            batch_pooled = torch.zeros(B * Kc, dtype=torch.long, device=x_pool.device)
+        if out_mask is None:
+            ei, ew = K.block_diag_edges(adj_pool)
+            return x_flat, ei, ew, batch_pooled
+        valid = out_mask.reshape(-1)
+        idx = valid.nonzero(as_tuple=True)[0]
+        relabel = torch.full((B * Kc,), -1, dtype=torch.long, device=x_pool.device)
+        relabel[idx] = torch.arange(idx.numel(), device=x_pool.device)
+        ei, ew = K.block_diag_edges(adj_pool, relabel)
+        return x_flat[idx], ei, ew, batch_pooled[valid]
+
+
+class Precoarsenable:
+    def precoarsening(self, **kwargs) -> PoolingOutput:
+        raise NotImplementedError("Precoarsening is not supported by this pooler.")
+
+    def multi_level_precoarsening(self, levels: int, edge_index=None, edge_weight: Optional[Tensor] = None, *,
+                                  batch: Optional[Tensor] = None, num_nodes: Optional[int] = None,
+                                  **kwargs) -> List[PoolingOutput]:
+        """Greedy roll-out of ``levels`` coarsening steps (reference src.py:570-622)."""
+        if levels < 1:
+            raise ValueError(f"'levels' must be >= 1, got {levels}.")
+        clear = getattr(self, "clear_cache", None)
+        out = []
+        for _ in range(levels):
+            if callable(clear):
+                clear()  # a cached SelectOutput of the previous level has the wrong size
+            pooled = self.precoarsening(edge_index=edge_index, edge_weight=edge_weight, batch=batch,
+                                        num_nodes=num_nodes, **kwargs)
+            out.append(pooled)
+            nxt = pooled.as_data()
+            edge_index, edge_weight, batch, num_nodes = nxt.edge_index, nxt.edge_weight, nxt.batch, nxt.num_nodes
+        if callable(clear):
+            clear()
+        return out
+
+
+class BasePrecoarseningMixin(Precoarsenable):
+    """select once + reduce_batch + connect, no features (reference src.py:625-692)."""
+
+    def _precoarsening_from_select_output(self, so: SelectOutput, edge_index, edge_weight: Optional[Tensor] = None,
+                                          *, batch: Optional[Tensor] = None, **kwargs) -> PoolingOutput:
+        if batch is None:
+            batch = getattr(so, "batch", None)
+            if batch is None:
+                batch = torch.zeros(so.num_nodes, dtype=torch.long, device=so.s.device)
+            so.batch = batch
+        batch_pooled = self.reducer.reduce_batch(select_output=so, batch=batch)
+        connector = getattr(self, "preconnector", self.connector)
+        ei, ew = connector(so=so, edge_index=edge_index, edge_weight=edge_weight, batch=batch,
+                           batch_pooled=batch_pooled, **kwargs)
+        return PoolingOutput(edge_index=ei, edge_weight=ew, batch=batch_pooled, so=so)
+
+    def precoarsening(self, edge_index=None, edge_weight: Optional[Tensor] = None, *,
+                      batch: Optional[Tensor] = None, num_nodes: Optional[int] = None, **kwargs) -> PoolingOutput:
+        if edge_index is None:
+            raise ValueError("edge_index cannot be None for precoarsening.")
+        so = self.select(edge_index=edge_index, edge_weight=edge_weight, batch=batch, num_nodes=num_nodes,
+                         **kwargs)
+        return self._precoarsening_from_select_output(so=so, edge_index=edge_index, edge_weight=edge_weight,
+                                                      batch=batch, **kwargs)
