@@ -115,7 +115,7 @@ def test_subgraph_connect_vs_oracle(dev):
     n = 60_000
     ei = undirected_graph(n, 400_000, 3)
     g = torch.Generator().manual_seed(4)
-    ew = torch.randn(ei.size(1), generator=g)
+    ew = torch.rand(ei.size(1), generator=g) + 0.1  # positive: degree normalisation is ill-conditioned otherwise
     ew[::11] = 0.0
     keep = torch.sort(torch.randperm(n, generator=g)[: n // 2])[0]
     batch_pooled = torch.sort(torch.randint(0, 7, (keep.numel(),), generator=g))[0]
