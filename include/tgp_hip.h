@@ -157,7 +157,9 @@ int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, const float* w,
                      const float* S, int64_t K, float* T, void* stream);
 
 /* A8 alone: post-process a [B,K,K] pooled adjacency (src may equal dst).                */
-int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K, int flags, void* stream);
+size_t tgp_postprocess_dense_workspace_bytes(int64_t B, int64_t K);
+int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K, int flags, void* ws,
+                              size_t ws_bytes, void* stream);
 
 /* A10  dense_to_block_diag (utils/ops.py:53-82): entries with |a| > 1e-8 in (b,row,col)
  * order, offset by b*K; optional valid-supernode mask [B*K] (src.py:526-552) drops and

@@ -2,7 +2,7 @@
 //
 //   U        = A  S            [B,N,K]   (2*B*N*N*K flop: the dominant product)
 //   [A'|X']  = S^T [U | X]     [B,K,K+F] (split over N, partial slabs, fixed-order combine)
-//   adj_pool = postprocess(A') fused into the combine (diag=0, D^-1/2 . D^-1/2, /max|.|)
+//   adj_pool = postprocess(A') (diag=0, D^-1/2 . D^-1/2, /max|.|) fused into the slab combine
 //
 // The reference computes (S^T A) S with two torch.matmul calls (connect/dense_conn.py:120-122)
 // and S^T X with a third (reduce/base_reduce.py:159); fp32 in, fp32 out, rtol 1e-5.  That
@@ -12,10 +12,12 @@
 // intermediate is [N,K] (1/8 .. 1/16 of A) and A is streamed from HBM exactly once in full
 // 128-byte row segments.
 //
-// GEMM kernel: 128x128 output tile per 256-thread workgroup (2x2 waves, each 2x2 MFMA tiles of
-// 32x32 -> 64 accumulator VGPRs), BK = 32, register-staged double-buffered LDS.  fp32 MFMA needs
-// only 2 operand dwords per 64-cycle instruction, so LDS bandwidth is a non-issue; the layouts
-// are chosen for conflict-free ds_write/ds_read and coalesced global loads:
+// GEMM kernel: 128x128 output tile per 512-thread workgroup: 8 waves as 4(M) x 2(N), each wave owns
+// 32 x 64 = two 32x32 MFMA tiles (32 accumulator VGPRs); two waves per SIMD so one wave's LDS
+// operand fetch hides behind the other's MFMAs.  BK = 32, register-staged double-buffered LDS,
+// operands for k-step t+1 are fetched from LDS before the MFMAs of step t are issued.
+// fp32 MFMA needs only one operand dword per lane per 64-cycle instruction, so LDS bandwidth is a
+// non-issue; layouts are chosen for conflict-free ds_write/ds_read and coalesced global loads:
 //   * row-major operand tile  (A of A.S):     LDS [128][BK+1]  (odd stride => conflict free)
 //   * k-major operand tile    (S, U, X, A^T): LDS [BK][128]    (lanes read consecutive floats)
 #include "common.h"
@@ -25,43 +27,60 @@ namespace tgp {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int GEMM_THREADS = 512;
 constexpr int LDA_ROWMAJOR = BK + 1;
 constexpr int A_TILE_FLOATS = BM * LDA_ROWMAJOR;  // >= BK*BM, used for both A layouts
 constexpr int B_TILE_FLOATS = BK * BN;
 constexpr int STAGE_FLOATS = A_TILE_FLOATS + B_TILE_FLOATS;
 
-struct GemmArgs {
-  const float* A;
+// One right-hand side / output pair.  A launch may carry two (column tiles >= tiles_n0 use the
+// second), which lets S^T [U | X] run as a single grid.
+struct GemmRhs {
   const float* Bm;
   float* C;
-  int M, Nc, Kd;           // C[M,Nc] = op(A)[M,Kd] * Bm[Kd,Nc]
-  long lda, ldb, ldc;      // leading dimensions (elements)
-  long sA, sB, sC;         // batch strides
-  int splits;              // split of Kd across workgroups
-  int k_per_split;         // multiple of BK
-  long sCsplit;            // stride between partial slabs
-  int tiles_m, tiles_n;
-  const int64_t* k_ptr;    // optional [batches+1]: batch b reduces over rows k_ptr[b]..k_ptr[b+1] (segment GEMM)
+  int Nc;
+  long ldb, ldc, sB, sC, sCsplit;
 };
 
+struct GemmArgs {
+  const float* A;
+  long lda, sA;
+  int M, Kd;               // C[M,Nc] = op(A)[M,Kd] * Bm[Kd,Nc]
+  GemmRhs rhs[2];
+  int tiles_m, tiles_n0, tiles_n;  // tiles_n = tiles_n0 + tiles of rhs[1]
+  int splits;              // split of Kd across workgroups
+  int k_per_split;         // multiple of BK
+  const int64_t* k_ptr;    // optional [batches+1]: batch b reduces over rows k_ptr[b]..k_ptr[b+1]
+};
+
+__device__ __forceinline__ float4 ld4_guarded(const float* p, bool ok) {
+  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // A_KMAJOR = false: A stored [M][Kd] (k contiguous).  true: stored [Kd][M] (m contiguous).
-template <bool A_KMAJOR>
-__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs g) {
+// ALIGNED: every leading dimension / extent is a multiple of 4 floats and every base is 16-byte
+// aligned, so all traffic is float4 with one predicate per vector.  Otherwise: scalar guarded path.
+template <bool A_KMAJOR, bool ALIGNED>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
   // logical block id, XCD-aware: tiles of one batch element share S / U through one L2
-  const int nwg = gridDim.x;
-  int bid = xcd_remap(blockIdx.x, nwg);
-  const int tn = bid % g.tiles_n; bid /= g.tiles_n;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn_all = bid % g.tiles_n; bid /= g.tiles_n;
   const int tm = bid % g.tiles_m; bid /= g.tiles_m;
   const int split = bid % g.splits;
   const int batch = bid / g.splits;
+  const int which = tn_all >= g.tiles_n0 ? 1 : 0;
+  const int tn = which ? tn_all - g.tiles_n0 : tn_all;
+  const GemmRhs& R = g.rhs[which];
 
   const float* __restrict__ A = g.A + static_cast<long>(batch) * g.sA;
-  const float* __restrict__ Bm = g.Bm + static_cast<long>(batch) * g.sB;
-  float* __restrict__ C = g.C + static_cast<long>(batch) * g.sC + static_cast<long>(split) * g.sCsplit;
+  const float* __restrict__ Bm = R.Bm + static_cast<long>(batch) * R.sB;
+  float* __restrict__ C = R.C + static_cast<long>(batch) * R.sC + static_cast<long>(split) * R.sCsplit;
+  const int Nc = R.Nc;
+  const long lda = g.lda, ldb = R.ldb;
 
   const int m0 = tm * BM, n0 = tn * BN;
   int k_lo = 0, k_hi = g.Kd;
@@ -71,122 +90,101 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs g) {
   }
   const int k_begin = k_lo + split * g.k_per_split;
   const int k_end = min(k_hi, k_begin + g.k_per_split);
-  const int nk = (k_end - k_begin + BK - 1) / BK;
+  const int nk = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
 
-  const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-  const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
+  float4 ra[2], rb[2];
 
-  float4 ra[4], rb[4];
-
-  // ---- global -> registers for stage starting at k0 ---------------------------------
-  auto load_a = [&](int k0) {
-    if constexpr (!A_KMAJOR) {
-      // tile [128 m][32 k]; 8 lanes cover one 128-byte row segment
+  auto load_tiles = [&](int k0) {
+    if constexpr (ALIGNED) {
+      if constexpr (!A_KMAJOR) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + (tid >> 3) + i * 32;
-        const int k = k0 + (tid & 7) * 4;
-        const float* p = A + static_cast<long>(m) * g.lda + k;
-        if (m < g.M && k + 3 < k_end && a_vec) {
-          ra[i] = *reinterpret_cast<const float4*>(p);
-        } else {
-          float t[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) t[j] = (m < g.M && k + j < k_end) ? p[j] : 0.f;
-          ra[i] = make_float4(t[0], t[1], t[2], t[3]);
+        for (int i = 0; i < 2; ++i) {  // [128 m][32 k]: 8 lanes cover one 128-byte row segment
+          const int m = m0 + (tid >> 3) + i * 64, k = k0 + (tid & 7) * 4;
+          ra[i] = ld4_guarded(A + static_cast<long>(m) * lda + k, m < g.M && k < k_end);
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  // [32 k][128 m]: 32 lanes cover one 512-byte row
+          const int k = k0 + (tid >> 5) + i * 16, m = m0 + (tid & 31) * 4;
+          ra[i] = ld4_guarded(A + static_cast<long>(k) * lda + m, k < k_end && m < g.M);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int k = k0 + (tid >> 5) + i * 16, n = n0 + (tid & 31) * 4;
+        rb[i] = ld4_guarded(Bm + static_cast<long>(k) * ldb + n, k < k_end && n < Nc);
       }
     } else {
-      // tile [32 k][128 m]; 32 lanes cover one 512-byte row
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = k0 + (tid >> 5) + i * 8;
-        const int m = m0 + (tid & 31) * 4;
-        const float* p = A + static_cast<long>(k) * g.lda + m;
-        if (k < k_end && m + 3 < g.M && a_vec) {
-          ra[i] = *reinterpret_cast<const float4*>(p);
-        } else {
-          float t[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) t[j] = (k < k_end && m + j < g.M) ? p[j] : 0.f;
-          ra[i] = make_float4(t[0], t[1], t[2], t[3]);
-        }
-      }
-    }
-  };
-  auto load_b = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = k0 + (tid >> 5) + i * 8;
-      const int n = n0 + (tid & 31) * 4;
-      const float* p = Bm + static_cast<long>(k) * g.ldb + n;
-      if (k < k_end && n + 3 < g.Nc && b_vec) {
-        rb[i] = *reinterpret_cast<const float4*>(p);
-      } else {
+      for (int i = 0; i < 2; ++i) {
         float t[4];
+        if constexpr (!A_KMAJOR) {
+          const int m = m0 + (tid >> 3) + i * 64, k = k0 + (tid & 7) * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = (k < k_end && n + j < g.Nc) ? p[j] : 0.f;
+          for (int j = 0; j < 4; ++j) t[j] = (m < g.M && k + j < k_end) ? A[static_cast<long>(m) * lda + k + j] : 0.f;
+        } else {
+          const int k = k0 + (tid >> 5) + i * 16, m = m0 + (tid & 31) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t[j] = (k < k_end && m + j < g.M) ? A[static_cast<long>(k) * lda + m + j] : 0.f;
+        }
+        ra[i] = make_float4(t[0], t[1], t[2], t[3]);
+        const int k = k0 + (tid >> 5) + i * 16, n = n0 + (tid & 31) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (k < k_end && n + j < Nc) ? Bm[static_cast<long>(k) * ldb + n + j] : 0.f;
         rb[i] = make_float4(t[0], t[1], t[2], t[3]);
       }
     }
   };
-  // ---- registers -> LDS ----------------------------------------------------------------
   auto store_stage = [&](float* As, float* Bs) {
-    if constexpr (!A_KMAJOR) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float* d = As + ((tid >> 3) + i * 32) * LDA_ROWMAJOR + (tid & 7) * 4;
+    for (int i = 0; i < 2; ++i) {
+      if constexpr (!A_KMAJOR) {
+        float* d = As + ((tid >> 3) + i * 64) * LDA_ROWMAJOR + (tid & 7) * 4;
         d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+      } else {
+        *reinterpret_cast<float4*>(As + ((tid >> 5) + i * 16) * BM + (tid & 31) * 4) = ra[i];
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<float4*>(As + ((tid >> 5) + i * 8) * BM + (tid & 31) * 4) = ra[i];
+      *reinterpret_cast<float4*>(Bs + ((tid >> 5) + i * 16) * BN + (tid & 31) * 4) = rb[i];
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4*>(Bs + ((tid >> 5) + i * 8) * BN + (tid & 31) * 4) = rb[i];
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   if (nk > 0) {
-    load_a(k_begin);
-    load_b(k_begin);
+    load_tiles(k_begin);
     store_stage(smem, smem + A_TILE_FLOATS);
   }
   __syncthreads();
 
   const int lm = lane & 31, lk = lane >> 5;
+  const int a_off = A_KMAJOR ? lk * BM + wm * 32 + lm : (wm * 32 + lm) * LDA_ROWMAJOR + lk;
+  const int a_step = A_KMAJOR ? 2 * BM : 2;
+  const int b_off = lk * BN + wn * 64 + lm;
   for (int t = 0; t < nk; ++t) {
-    float* As = smem + (t & 1) * STAGE_FLOATS;
-    float* Bs = As + A_TILE_FLOATS;
+    const float* As = smem + (t & 1) * STAGE_FLOATS;
+    const float* Bs = As + A_TILE_FLOATS;
     const bool more = (t + 1) < nk;
-    if (more) {
-      load_a(k_begin + (t + 1) * BK);
-      load_b(k_begin + (t + 1) * BK);
-    }
+    if (more) load_tiles(k_begin + (t + 1) * BK);
+    float a_cur = As[a_off], b0_cur = Bs[b_off], b1_cur = Bs[b_off + 32];
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = wm * 64 + i * 32 + lm;
-        a[i] = A_KMAJOR ? As[(kk + lk) * BM + m] : As[m * LDA_ROWMAJOR + kk + lk];
+      float a_nxt = 0.f, b0_nxt = 0.f, b1_nxt = 0.f;
+      if (kk + 2 < BK) {
+        a_nxt = As[a_off + (kk / 2 + 1) * a_step];
+        b0_nxt = Bs[b_off + (kk + 2) * BN];
+        b1_nxt = Bs[b_off + (kk + 2) * BN + 32];
       }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Bs[(kk + lk) * BN + wn * 64 + j * 32 + lm];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b0_cur, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b1_cur, acc[1], 0, 0, 0);
+      // pin the order: LDS reads of step kk+2 are issued BEFORE the MFMAs of step kk, so their
+      // latency hides behind 128 cycles of matrix work (hipcc otherwise sinks them to the use)
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 x ds_read (a, b0|b1 pair)
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 x MFMA
+      a_cur = a_nxt; b0_cur = b0_nxt; b1_cur = b1_nxt;
     }
     if (more) {
       float* An = smem + ((t + 1) & 1) * STAGE_FLOATS;
@@ -197,117 +195,221 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs g) {
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -----------
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + lm;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + lm;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row < g.M && col < g.Nc) C[static_cast<long>(row) * g.ldc + col] = acc[i][j][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (row < g.M && col < Nc) C[static_cast<long>(row) * R.ldc + col] = acc[j][r];
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// Combine the split-K slabs of one graph in fixed order and apply utils/ops.py:282-335.
-// One 1024-thread workgroup per graph; the K x K matrix is re-read from L2 between passes.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block_reduce_max_1024(float v, float* s_red) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_down(v, d, WAVE));
-  if (lane_id() == 0) s_red[wave_id()] = v;
-  __syncthreads();
-  float r = s_red[0];
-  for (int w = 1; w < 16; ++w) r = fmaxf(r, s_red[w]);
-  __syncthreads();
-  return r;
-}
-
-// src: [B][splits][K][ld_src] slabs (splits may be 1, ld_src >= K); raw (optional) and dst: [B][K][K].
-__global__ __launch_bounds__(1024) void dense_post_kernel(const float* __restrict__ src, int splits,
-                                                          long s_split, long s_batch, long ld_src, int K,
-                                                          int flags, float* __restrict__ raw,
-                                                          float* __restrict__ dst) {
-  extern __shared__ __attribute__((aligned(16))) float dvec[];  // [K] degree vector
-  __shared__ float s_red[16];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float* sb = src + static_cast<long>(b) * s_batch;
-  float* rawb = raw ? raw + static_cast<long>(b) * K * K : nullptr;
-  float* dstb = dst ? dst + static_cast<long>(b) * K * K : nullptr;
-  const long kk = static_cast<long>(K) * K;
-
-  // pass 1: combine slabs (fixed order), emit raw, write diag-cleared matrix to dst
-  for (long e = tid; e < kk; e += 1024) {
-    const int i = static_cast<int>(e / K), j = static_cast<int>(e - static_cast<long>(i) * K);
-    float v = sb[static_cast<long>(i) * ld_src + j];
-    for (int s = 1; s < splits; ++s) v = __fadd_rn(v, sb[s * s_split + static_cast<long>(i) * ld_src + j]);
-    if (rawb) rawb[e] = v;
-    if (dstb) {
-      if ((flags & TGP_REMOVE_SELF_LOOPS) && i == j) v = 0.f;
-      dstb[e] = v;
-    }
-  }
-  if (!dstb) return;
-  __syncthreads();
-
-  if (flags & TGP_DEGREE_NORM) {
-    // d = sqrt(clamp(sum over axis, eps)); axis -2 (column sums) when TGP_SUM_AXIS_ROWS
-    for (int j = tid; j < K; j += 1024) {
-      float s = 0.f;
-      if (flags & TGP_SUM_AXIS_ROWS) {
-        for (int i = 0; i < K; ++i) s = __fadd_rn(s, dstb[static_cast<long>(i) * K + j]);
-      } else {
-        for (int i = 0; i < K; ++i) s = __fadd_rn(s, dstb[static_cast<long>(j) * K + i]);
-      }
-      dvec[j] = sqrtf(fmaxf(s, TGP_EPS));
-    }
-    __syncthreads();
-    for (long e = tid; e < kk; e += 1024) {
-      const int i = static_cast<int>(e / K), j = static_cast<int>(e - static_cast<long>(i) * K);
-      // (adj / d) / d^T with d shaped [1,K] (axis -2) or [K,1] (axis -1): ops.py:318-319
-      const float first = (flags & TGP_SUM_AXIS_ROWS) ? dvec[j] : dvec[i];
-      const float second = (flags & TGP_SUM_AXIS_ROWS) ? dvec[i] : dvec[j];
-      dstb[e] = (dstb[e] / first) / second;
-    }
-    __syncthreads();
-  }
-  if (flags & TGP_EDGE_WEIGHT_NORM) {
-    float m = 0.f;
-    for (long e = tid; e < kk; e += 1024) m = fmaxf(m, fabsf(dstb[e]));
-    m = block_reduce_max_1024(m, s_red);
-    if (m == 0.f) m = 1.f;
-    for (long e = tid; e < kk; e += 1024) dstb[e] = dstb[e] / m;
   }
 }
 
-// x_pool slabs -> x_pool (fixed-order combine); src [B][splits][K][ld_src] (columns c0..c0+F)
-__global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restrict__ src, int splits,
-                                                            long s_split, long s_batch, long ld_src, int c0,
-                                                            int K, int F, float* __restrict__ dst) {
-  const long total = static_cast<long>(K) * F;
-  const int b = blockIdx.y;
-  const float* sb = src + static_cast<long>(b) * s_batch;
-  for (long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; e < total;
-       e += static_cast<long>(gridDim.x) * 256) {
-    const int i = static_cast<int>(e / F), f = static_cast<int>(e - static_cast<long>(i) * F);
-    float v = sb[static_cast<long>(i) * ld_src + c0 + f];
-    for (int s = 1; s < splits; ++s) v = __fadd_rn(v, sb[s * s_split + static_cast<long>(i) * ld_src + c0 + f]);
-    dst[static_cast<long>(b) * total + e] = v;
-  }
+static bool gemm_aligned(const GemmArgs& g) {
+  auto ok = [](const void* p, long ld, long s) {
+    return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 4 == 0) && (s % 4 == 0);
+  };
+  bool a = ok(g.A, g.lda, g.sA) && (g.M % 4 == 0) && (g.Kd % 4 == 0) && (g.k_per_split % 4 == 0) && !g.k_ptr;
+  for (int w = 0; w < 2; ++w)
+    if (w == 0 || g.tiles_n > g.tiles_n0) a = a && ok(g.rhs[w].Bm, g.rhs[w].ldb, g.rhs[w].sB) && (g.rhs[w].Nc % 4 == 0);
+  return a;
 }
 
 template <bool A_KMAJOR>
 static void launch_gemm(const GemmArgs& g, int batches, hipStream_t stream) {
   const int nwg = batches * g.splits * g.tiles_m * g.tiles_n;
   const size_t lds = 2 * STAGE_FLOATS * sizeof(float);
-  hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR>), dim3(nwg), dim3(256), lds, stream, g);
+  if (gemm_aligned(g))
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, true>), dim3(nwg), dim3(GEMM_THREADS), lds, stream, g);
+  else
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, false>), dim3(nwg), dim3(GEMM_THREADS), lds, stream, g);
+}
+
+// ------------------------------------------------------------------------------------------
+// Slab combine + utils/ops.py:282-335 (diag <- 0, D^-1/2 A D^-1/2, / max|A| per graph).
+// [B,K,K] is tiny next to A, so these are throughput-shaped elementwise / small-reduction
+// kernels with many workgroups; every reduction has a fixed order (no float atomics).
+//   pass 1  post_combine_kernel : sum the split-K slabs -> raw, diag-cleared dst
+//   pass 2  post_degree_kernel  : d = sqrt(clamp(sum over axis, eps))           (degree_norm)
+//   pass 3  post_scale_kernel   : (a / d) / d^T, per-block max|.|
+//   pass 4  post_maxnorm_kernel : divide by the per-graph max                   (edge_weight_norm)
+// ------------------------------------------------------------------------------------------
+constexpr int POST_BLOCKS = 8;  // workgroups per graph in the elementwise passes
+
+struct PostArgs {
+  const float* src;  // [B][splits][K][ld_src]
+  int splits;
+  long s_split, s_batch, ld_src;
+  int K, flags;
+  float* raw;        // optional [B][K][K]
+  float* dst;        // optional [B][K][K]
+  float* dvec;       // [B][K]
+  float* maxpart;    // [B][POST_BLOCKS]
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void post_combine_kernel(PostArgs p) {
+  const int b = blockIdx.y, K = p.K;
+  const float* sb = p.src + static_cast<long>(b) * p.s_batch;
+  float* rawb = p.raw ? p.raw + static_cast<long>(b) * K * K : nullptr;
+  float* dstb = p.dst ? p.dst + static_cast<long>(b) * K * K : nullptr;
+  const long groups = static_cast<long>(K) * K / VEC;
+  for (long gidx = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; gidx < groups;
+       gidx += static_cast<long>(gridDim.x) * 256) {
+    const long e = gidx * VEC;
+    const int i = static_cast<int>(e / K), j = static_cast<int>(e - static_cast<long>(i) * K);
+    const long o = static_cast<long>(i) * p.ld_src + j;
+    float v[VEC];
+    if constexpr (VEC == 4) {
+      float4 t = *reinterpret_cast<const float4*>(sb + o);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      for (int s = 1; s < p.splits; ++s) {
+        t = *reinterpret_cast<const float4*>(sb + s * p.s_split + o);
+        v[0] = __fadd_rn(v[0], t.x); v[1] = __fadd_rn(v[1], t.y);
+        v[2] = __fadd_rn(v[2], t.z); v[3] = __fadd_rn(v[3], t.w);
+      }
+      if (rawb) *reinterpret_cast<float4*>(rawb + e) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      v[0] = sb[o];
+      for (int s = 1; s < p.splits; ++s) v[0] = __fadd_rn(v[0], sb[s * p.s_split + o]);
+      if (rawb) rawb[e] = v[0];
+    }
+    if (dstb) {
+      if (p.flags & TGP_REMOVE_SELF_LOOPS) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q)
+          if (i == j + q) v[q] = 0.f;
+      }
+      if constexpr (VEC == 4) *reinterpret_cast<float4*>(dstb + e) = make_float4(v[0], v[1], v[2], v[3]);
+      else dstb[e] = v[0];
+    }
+  }
+}
+
+// grid (ceil(K/64), B), 1024 threads = 16 waves.  Column sums (axis -2): lane = column, wave w adds rows
+// w, w+16, ... in order, then the 16 wave partials are added in order.  Row sums (axis -1): the block owns
+// 64 rows, wave w rows w, w+16, ...: lanes stride over the columns, fixed shuffle tree.
+__global__ __launch_bounds__(1024) void post_degree_kernel(PostArgs p) {
+  __shared__ float s_part[16][64];
+  const int b = blockIdx.y, K = p.K, lane = lane_id(), w = wave_id();
+  const float* a = p.dst + static_cast<long>(b) * K * K;
+  const int base = blockIdx.x * 64;
+  if (p.flags & TGP_SUM_AXIS_ROWS) {
+    const int j = base + lane;
+    float s = 0.f;
+    if (j < K)
+      for (int i = w; i < K; i += 16) s = __fadd_rn(s, a[static_cast<long>(i) * K + j]);
+    s_part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && j < K) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t = __fadd_rn(t, s_part[q][lane]);
+      p.dvec[static_cast<long>(b) * K + j] = sqrtf(fmaxf(t, TGP_EPS));  // sqrt(clamp(d, eps)): ops.py:318
+    }
+  } else {
+    for (int r = w; r < 64; r += 16) {
+      const int i = base + r;
+      if (i >= K) break;
+      float s = 0.f;
+      for (int j = lane; j < K; j += 64) s = __fadd_rn(s, a[static_cast<long>(i) * K + j]);
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) s = __fadd_rn(s, __shfl_down(s, d, WAVE));
+      if (lane == 0) p.dvec[static_cast<long>(b) * K + i] = sqrtf(fmaxf(s, TGP_EPS));
+    }
+  }
+}
+
+// grid (POST_BLOCKS, B): contiguous element range per workgroup
+__global__ __launch_bounds__(256) void post_scale_kernel(PostArgs p) {
+  __shared__ float s_max[4];
+  const int b = blockIdx.y, K = p.K, tid = threadIdx.x;
+  float* a = p.dst + static_cast<long>(b) * K * K;
+  const float* dv = p.dvec + static_cast<long>(b) * K;
+  const long kk = static_cast<long>(K) * K;
+  const long per = (kk + POST_BLOCKS - 1) / POST_BLOCKS;
+  const long lo = blockIdx.x * per, hi = min(kk, lo + per);
+  const bool by_cols = p.flags & TGP_SUM_AXIS_ROWS;
+  float mx = 0.f;
+  for (long e = lo + tid; e < hi; e += 256) {
+    float v = a[e];
+    if (p.flags & TGP_DEGREE_NORM) {
+      const int i = static_cast<int>(e / K), j = static_cast<int>(e - static_cast<long>(i) * K);
+      // (adj / d) / d^T with d shaped [1,K] (axis -2) or [K,1] (axis -1): ops.py:319
+      const float first = by_cols ? dv[j] : dv[i];
+      const float second = by_cols ? dv[i] : dv[j];
+      v = (v / first) / second;
+      a[e] = v;
+    }
+    mx = fmaxf(mx, fabsf(v));
+  }
+  if (p.flags & TGP_EDGE_WEIGHT_NORM) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_down(mx, d, WAVE));
+    if (lane_id() == 0) s_max[wave_id()] = mx;
+    __syncthreads();
+    if (tid == 0)
+      p.maxpart[static_cast<long>(b) * POST_BLOCKS + blockIdx.x] =
+          fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  }
+}
+
+__global__ __launch_bounds__(256) void post_maxnorm_kernel(PostArgs p) {
+  const int b = blockIdx.y, K = p.K, tid = threadIdx.x;
+  float m = 0.f;
+#pragma unroll
+  for (int q = 0; q < POST_BLOCKS; ++q) m = fmaxf(m, p.maxpart[static_cast<long>(b) * POST_BLOCKS + q]);
+  if (m == 0.f) m = 1.f;
+  float* a = p.dst + static_cast<long>(b) * K * K;
+  const long kk = static_cast<long>(K) * K;
+  const long per = (kk + POST_BLOCKS - 1) / POST_BLOCKS;
+  const long lo = blockIdx.x * per, hi = min(kk, lo + per);
+  for (long e = lo + tid; e < hi; e += 256) a[e] = a[e] / m;
+}
+
+static size_t post_ws_floats(int64_t B, int64_t K) { return static_cast<size_t>(B * K + B * POST_BLOCKS); }
+
+static void launch_post(PostArgs p, int64_t B, float* ws, hipStream_t stream) {
+  const int K = p.K;
+  p.dvec = ws;
+  p.maxpart = ws + static_cast<size_t>(B) * K;
+  const bool vec = (K % 4 == 0) && (p.ld_src % 4 == 0) && (p.s_split % 4 == 0) && (p.s_batch % 4 == 0) &&
+                   (reinterpret_cast<uintptr_t>(p.src) % 16 == 0) &&
+                   (!p.raw || reinterpret_cast<uintptr_t>(p.raw) % 16 == 0) &&
+                   (!p.dst || reinterpret_cast<uintptr_t>(p.dst) % 16 == 0);
+  const long groups = static_cast<long>(K) * K / (vec ? 4 : 1);
+  int gx = static_cast<int>((groups + 255) / 256);
+  if (gx > 64) gx = 64;
+  const dim3 gridc(gx, static_cast<unsigned>(B));
+  if (vec) hipLaunchKernelGGL(post_combine_kernel<4>, gridc, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(post_combine_kernel<1>, gridc, dim3(256), 0, stream, p);
+  if (!p.dst) return;
+  const dim3 gride(POST_BLOCKS, static_cast<unsigned>(B));
+  if (p.flags & TGP_DEGREE_NORM)
+    hipLaunchKernelGGL(post_degree_kernel, dim3((K + 63) / 64, static_cast<unsigned>(B)), dim3(1024), 0, stream, p);
+  if (p.flags & (TGP_DEGREE_NORM | TGP_EDGE_WEIGHT_NORM))
+    hipLaunchKernelGGL(post_scale_kernel, gride, dim3(256), 0, stream, p);
+  if (p.flags & TGP_EDGE_WEIGHT_NORM) hipLaunchKernelGGL(post_maxnorm_kernel, gride, dim3(256), 0, stream, p);
+}
+
+// x_pool slabs -> x_pool (fixed-order combine); src [B][splits][K][F]
+__global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restrict__ src, int splits,
+                                                            long s_split, long s_batch, long total,
+                                                            float* __restrict__ dst) {
+  const int b = blockIdx.y;
+  const float* sb = src + static_cast<long>(b) * s_batch;
+  for (long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; e < total;
+       e += static_cast<long>(gridDim.x) * 256) {
+    float v = sb[e];
+    for (int s = 1; s < splits; ++s) v = __fadd_rn(v, sb[s * s_split + e]);
+    dst[static_cast<long>(b) * total + e] = v;
+  }
 }
 
 struct DensePlan {
   int splits;
   int k_per_split;
-  size_t u_floats, slab_floats;
+  size_t u_floats, aslab_floats, xslab_floats, post_floats;
 };
 
 static DensePlan dense_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
@@ -316,7 +418,7 @@ static DensePlan dense_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
   const int64_t tiles = ((K + BM - 1) / BM) * (((K + BN - 1) / BN) + ((F + BN - 1) / BN));
   const int64_t base = B * (tiles > 0 ? tiles : 1);
   int64_t splits = (2 * 256 + base - 1) / base;  // aim for ~2 workgroups per CU
-  const int64_t max_splits = (N + BK - 1) / BK;
+  const int64_t max_splits = (N + 4 * BK - 1) / (4 * BK);  // keep >= 4 k-steps per workgroup
   if (splits > max_splits) splits = max_splits;
   if (splits > 32) splits = 32;
   if (splits < 1) splits = 1;
@@ -327,7 +429,9 @@ static DensePlan dense_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
   p.splits = static_cast<int>(splits);
   p.k_per_split = static_cast<int>(kps);
   p.u_floats = static_cast<size_t>(B) * N * K;
-  p.slab_floats = static_cast<size_t>(B) * splits * K * (K + F);
+  p.aslab_floats = static_cast<size_t>(B) * splits * K * K;
+  p.xslab_floats = static_cast<size_t>(B) * splits * K * F;
+  p.post_floats = post_ws_floats(B, K);
   return p;
 }
 
@@ -338,7 +442,8 @@ using namespace tgp;
 extern "C" size_t tgp_dense_pool_workspace_bytes(int64_t B, int64_t N, int64_t K, int64_t F) {
   if (B <= 0 || N <= 0 || K <= 0) return 256;
   const DensePlan p = dense_plan(B, N, K, F > 0 ? F : 0);
-  return align_up(p.u_floats * 4) + align_up(p.slab_floats * 4) + 256;
+  return align_up(p.u_floats * 4) + align_up(p.aslab_floats * 4) + align_up(p.xslab_floats * 4) +
+         align_up(p.post_floats * 4) + 256;
 }
 
 extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N,
@@ -350,7 +455,7 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
   const bool want_x = X && x_pool && F > 0;
   const bool want_a = A && (adj_raw || adj_pool);
   TGP_REQUIRE(S || N == 0, TGP_ERR_INVALID, "tgp_dense_pool_f32: S is null");
-  TGP_REQUIRE(N < (1ll << 31) && K <= 16000 && F < (1ll << 31) && B < (1ll << 24), TGP_ERR_RANGE,
+  TGP_REQUIRE(N < (1ll << 31) && K <= 16000 && F < (1ll << 31) && B < 65536, TGP_ERR_RANGE,
               "tgp_dense_pool_f32: dimension too large");
   if (N == 0) {
     if (want_x) (void)hipMemsetAsync(x_pool, 0, sizeof(float) * B * K * F, stream);
@@ -363,67 +468,73 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
   const DensePlan p = dense_plan(B, N, K, F);
   Carver cv(ws);
   float* U = cv.take<float>(p.u_floats);
-  float* slabs = cv.take<float>(p.slab_floats);
-  const long ldslab = K + F;
-  const long s_split = static_cast<long>(K) * ldslab;
-  const long s_batch = s_split * p.splits;
+  float* aslab = cv.take<float>(p.aslab_floats);
+  float* xslab = cv.take<float>(p.xslab_floats);
+  float* postws = cv.take<float>(p.post_floats);
 
   if (want_a) {
     // U[b] = A[b] S[b]     (M = N, Kd = N, Nc = K)
     GemmArgs g{};
-    g.A = A; g.Bm = S; g.C = U;
-    g.M = static_cast<int>(N); g.Nc = static_cast<int>(K); g.Kd = static_cast<int>(N);
-    g.lda = N; g.ldb = K; g.ldc = K;
-    g.sA = N * N; g.sB = N * K; g.sC = N * K;
-    g.splits = 1; g.k_per_split = static_cast<int>((N + BK - 1) / BK * BK); g.sCsplit = 0;
-    g.tiles_m = cdiv(N, BM); g.tiles_n = cdiv(K, BN);
+    g.A = A; g.lda = N; g.sA = N * N;
+    g.M = static_cast<int>(N); g.Kd = static_cast<int>(N);
+    g.rhs[0] = GemmRhs{S, U, static_cast<int>(K), K, K, N * K, N * K, 0};
+    g.splits = 1; g.k_per_split = static_cast<int>((N + BK - 1) / BK * BK);
+    g.tiles_m = cdiv(N, BM); g.tiles_n0 = cdiv(K, BN); g.tiles_n = g.tiles_n0;
     if (flags & TGP_ADJ_TRANSPOSED) launch_gemm<true>(g, static_cast<int>(B), stream);
     else launch_gemm<false>(g, static_cast<int>(B), stream);
-
-    // slabs[b][s][:, 0:K] = S[b]^T U[b]  over the s-th slice of N
+  }
+  if (want_a || want_x) {
+    // aslab[b][s] = S[b]^T U[b], xslab[b][s] = S[b]^T X[b] over the s-th slice of N: one grid
     GemmArgs h{};
-    h.A = S; h.Bm = U; h.C = slabs;
-    h.M = static_cast<int>(K); h.Nc = static_cast<int>(K); h.Kd = static_cast<int>(N);
-    h.lda = K; h.ldb = K; h.ldc = ldslab;
-    h.sA = N * K; h.sB = N * K; h.sC = s_batch;
-    h.splits = p.splits; h.k_per_split = p.k_per_split; h.sCsplit = s_split;
-    h.tiles_m = cdiv(K, BM); h.tiles_n = cdiv(K, BN);
+    h.A = S; h.lda = K; h.sA = N * K;
+    h.M = static_cast<int>(K); h.Kd = static_cast<int>(N);
+    h.splits = p.splits; h.k_per_split = p.k_per_split;
+    h.tiles_m = cdiv(K, BM);
+    const GemmRhs ra{U, aslab, static_cast<int>(K), K, K, N * K, static_cast<long>(p.splits) * K * K, K * K};
+    const GemmRhs rx{X, xslab, static_cast<int>(F), F, F, N * F, static_cast<long>(p.splits) * K * F, K * F};
+    if (want_a && want_x) {
+      h.rhs[0] = ra; h.rhs[1] = rx;
+      h.tiles_n0 = cdiv(K, BN); h.tiles_n = h.tiles_n0 + cdiv(F, BN);
+    } else {
+      h.rhs[0] = want_a ? ra : rx;
+      h.tiles_n0 = cdiv(want_a ? K : F, BN); h.tiles_n = h.tiles_n0;
+    }
     launch_gemm<true>(h, static_cast<int>(B), stream);
   }
   if (want_x) {
-    // slabs[b][s][:, K:K+F] = S[b]^T X[b]
-    GemmArgs h{};
-    h.A = S; h.Bm = X; h.C = slabs + K;
-    h.M = static_cast<int>(K); h.Nc = static_cast<int>(F); h.Kd = static_cast<int>(N);
-    h.lda = K; h.ldb = F; h.ldc = ldslab;
-    h.sA = N * K; h.sB = N * F; h.sC = s_batch;
-    h.splits = p.splits; h.k_per_split = p.k_per_split; h.sCsplit = s_split;
-    h.tiles_m = cdiv(K, BM); h.tiles_n = cdiv(F, BN);
-    launch_gemm<true>(h, static_cast<int>(B), stream);
     const long total = K * F;
     int gx = static_cast<int>((total + 255) / 256);
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(combine_slabs_kernel, dim3(gx, static_cast<unsigned>(B)), dim3(256), 0, stream, slabs,
-                       p.splits, s_split, s_batch, ldslab, static_cast<int>(K), static_cast<int>(K),
-                       static_cast<int>(F), x_pool);
+    hipLaunchKernelGGL(combine_slabs_kernel, dim3(gx, static_cast<unsigned>(B)), dim3(256), 0, stream, xslab,
+                       p.splits, K * F, static_cast<long>(p.splits) * K * F, total, x_pool);
   }
   if (want_a) {
-    hipLaunchKernelGGL(dense_post_kernel, dim3(static_cast<unsigned>(B)), dim3(1024), K * sizeof(float), stream,
-                       slabs, p.splits, s_split, s_batch, ldslab, static_cast<int>(K), flags, adj_raw, adj_pool);
+    PostArgs q{};
+    q.src = aslab; q.splits = p.splits; q.s_split = K * K; q.s_batch = static_cast<long>(p.splits) * K * K;
+    q.ld_src = K; q.K = static_cast<int>(K); q.flags = flags; q.raw = adj_raw; q.dst = adj_pool;
+    launch_post(q, B, postws, stream);
   }
   return check_launch("tgp_dense_pool_f32");
 }
 
-extern "C" int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K, int flags,
-                                         void* stream_) {
+extern "C" size_t tgp_postprocess_dense_workspace_bytes(int64_t B, int64_t K) {
+  if (B <= 0 || K <= 0) return 256;
+  return align_up(post_ws_floats(B, K) * 4) + 256;
+}
+
+extern "C" int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K, int flags, void* ws,
+                                         size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_postprocess_dense_f32: negative size");
   if (B == 0 || K == 0) return TGP_OK;
   TGP_REQUIRE(src && dst, TGP_ERR_INVALID, "tgp_postprocess_dense_f32: null pointer");
-  TGP_REQUIRE(K <= 16000, TGP_ERR_RANGE, "tgp_postprocess_dense_f32: K > 16000 not supported");
-  hipLaunchKernelGGL(dense_post_kernel, dim3(static_cast<unsigned>(B)), dim3(1024), K * sizeof(float), stream, src,
-                     1, 0L, static_cast<long>(K) * K, static_cast<long>(K), static_cast<int>(K), flags,
-                     static_cast<float*>(nullptr), dst);
+  TGP_REQUIRE(K <= 16000 && B < 65536, TGP_ERR_RANGE, "tgp_postprocess_dense_f32: K > 16000 or B >= 65536");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_postprocess_dense_workspace_bytes(B, K), TGP_ERR_WORKSPACE,
+              "tgp_postprocess_dense_f32: workspace too small");
+  PostArgs q{};
+  q.src = src; q.splits = 1; q.s_split = 0; q.s_batch = K * K; q.ld_src = K;
+  q.K = static_cast<int>(K); q.flags = flags; q.raw = nullptr; q.dst = dst;
+  launch_post(q, B, static_cast<float*>(ws), stream);
   return check_launch("tgp_postprocess_dense_f32");
 }
 
@@ -437,11 +548,11 @@ extern "C" int tgp_bmm_f32(const float* A, const float* Bm, float* C, int64_t ba
   TGP_REQUIRE(C && (Kd == 0 || (A && Bm)), TGP_ERR_INVALID, "tgp_bmm_f32: null pointer");
   TGP_REQUIRE(M < (1ll << 31) && Nc < (1ll << 31) && Kd < (1ll << 31), TGP_ERR_RANGE, "tgp_bmm_f32: too large");
   GemmArgs g{};
-  g.A = A; g.Bm = Bm; g.C = C;
-  g.M = static_cast<int>(M); g.Nc = static_cast<int>(Nc); g.Kd = static_cast<int>(Kd);
-  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = sA; g.sB = sB; g.sC = sC;
-  g.splits = 1; g.k_per_split = static_cast<int>((Kd + BK - 1) / BK * BK); g.sCsplit = 0;
-  g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(Nc, BN);
+  g.A = A; g.lda = lda; g.sA = sA;
+  g.M = static_cast<int>(M); g.Kd = static_cast<int>(Kd);
+  g.rhs[0] = GemmRhs{Bm, C, static_cast<int>(Nc), ldb, ldc, sB, sC, 0};
+  g.splits = 1; g.k_per_split = static_cast<int>((Kd + BK - 1) / BK * BK);
+  g.tiles_m = cdiv(M, BM); g.tiles_n0 = cdiv(Nc, BN); g.tiles_n = g.tiles_n0;
   const int64_t nwg = batch * g.tiles_m * g.tiles_n;
   TGP_REQUIRE(nwg < (1ll << 31), TGP_ERR_RANGE, "tgp_bmm_f32: grid too large");
   if (trans_a) launch_gemm<true>(g, static_cast<int>(batch), stream);
@@ -461,15 +572,14 @@ extern "C" int tgp_segment_gemm_tn_f32(const float* S, const float* Y, const int
   TGP_REQUIRE(Ntot < (1ll << 31) && K < (1ll << 31) && F < (1ll << 31), TGP_ERR_RANGE,
               "tgp_segment_gemm_tn_f32: too large");
   GemmArgs g{};
-  g.A = S; g.Bm = Y; g.C = C;
-  g.M = static_cast<int>(K); g.Nc = static_cast<int>(F); g.Kd = static_cast<int>(Ntot);
-  g.lda = K; g.ldb = F; g.ldc = F; g.sA = 0; g.sB = 0; g.sC = K * F;
+  g.A = S; g.lda = K; g.sA = 0;
+  g.M = static_cast<int>(K); g.Kd = static_cast<int>(Ntot);
+  g.rhs[0] = GemmRhs{Y, C, static_cast<int>(F), F, F, 0, K * F, 0};
   g.splits = 1;
   const int64_t span = max_nodes > 0 ? max_nodes : Ntot;
   g.k_per_split = static_cast<int>((span + BK - 1) / BK * BK);
   if (g.k_per_split < BK) g.k_per_split = BK;
-  g.sCsplit = 0;
-  g.tiles_m = cdiv(K, BM); g.tiles_n = cdiv(F, BN);
+  g.tiles_m = cdiv(K, BM); g.tiles_n0 = cdiv(F, BN); g.tiles_n = g.tiles_n0;
   g.k_ptr = ptr;
   launch_gemm<true>(g, static_cast<int>(B), stream);
   return check_launch("tgp_segment_gemm_tn_f32");

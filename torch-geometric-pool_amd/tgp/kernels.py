@@ -216,8 +216,10 @@ def postprocess_dense(adj_pool: Tensor, flags: int, inplace: bool = False) -> Te
     src = N.f32c(adj_pool)
     dst = src if inplace else torch.empty_like(src)
     B, K = src.size(0), src.size(1)
-    N.check(N.lib().tgp_postprocess_dense_f32(N.ptr(src), N.ptr(dst), B, K, flags, N.stream_ptr(dev)),
-            "tgp_postprocess_dense_f32")
+    L = N.lib()
+    ws = N.workspace(L.tgp_postprocess_dense_workspace_bytes(B, K), dev)
+    N.check(L.tgp_postprocess_dense_f32(N.ptr(src), N.ptr(dst), B, K, flags, N.ptr(ws), ws.numel(),
+                                        N.stream_ptr(dev)), "tgp_postprocess_dense_f32")
     return dst
 
 
