@@ -88,7 +88,7 @@ def cpu_baseline_dense(B, N, K, F, budget_s=12.0):
 
     step()
     n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s and n < 200:
+    while time.perf_counter() - t0 < budget_s:
         step()
         n += 1
     dt = time.perf_counter() - t0
@@ -96,12 +96,105 @@ def cpu_baseline_dense(B, N, K, F, budget_s=12.0):
             "sample": f"{bs} of {B} graphs (N={N},K={K},F={F}) x {n} passes of the CPU oracle, {dt:.1f}s"}
 
 
+def run_other_workload(args, dev):
+    """Secondary workloads for the DESIGN.md / BASELINE.md tables (single GPU, same JSON layout)."""
+    from tgp import kernels
+    from tgp.connect import DenseConnect, SparseConnect
+    from tgp.reduce import BaseReduce
+    from tgp.select import GraclusSelect, SelectOutput
+    from tgp.utils.ops import postprocess_adj_pool_dense
+    g = torch.Generator(device=dev).manual_seed(0)
+    red = BaseReduce()
+    extra = {}
+    if args.workload == "c3":
+        B, Nmax, K, F = 2048, 60, 20, 32
+        n_b = torch.randint(20, 61, (B,), device=dev, generator=g)
+        mask = torch.arange(Nmax, device=dev).unsqueeze(0) < n_b.unsqueeze(1)
+        A = (torch.rand(B, Nmax, Nmax, device=dev, generator=g) < (3.7 / 40)).float()
+        A = torch.maximum(A, A.transpose(1, 2)) * mask.unsqueeze(1) * mask.unsqueeze(2)
+        A.diagonal(dim1=1, dim2=2).zero_()
+        A = A.contiguous()
+        X = torch.randn(B, Nmax, F, device=dev, generator=g) * mask.unsqueeze(-1)
+        S = torch.softmax(torch.randn(B, Nmax, K, device=dev, generator=g), -1) * mask.unsqueeze(-1)
+        so, conn = SelectOutput(s=S, in_mask=mask), DenseConnect()
+        nodes = int(n_b.sum())
+
+        def step():
+            red(X, so)
+            raw = conn.dense_connect(adj=A, s=S)  # MinCut order: raw -> (loss) -> post-process
+            postprocess_adj_pool_dense(raw, True, True, True, False)
+        name = "MinCut PROTEINS-shape batch: B=2048, n~U[20,60] padded to 60, K=20, F=32 (BASELINE configs[2])"
+        alg = 4.0 * B * (Nmax * Nmax + Nmax * K + Nmax * F + K * K + K * F)
+        kern_ms = event_time_ms(step, 20, dev)
+        roof = {"kernel": "whole step (graphs fit in LDS: HBM-bound)", "bound": "hbm",
+                "achieved": round(alg / (kern_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                "bytes_per_launch": alg, "avg_launch_ms": round(kern_ms, 4)}
+    else:
+        n, f = 1_000_000, 128
+        a = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+        b = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+        keep = a != b
+        a, b = a[keep], b[keep]
+        ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+        ew = torch.ones(ei.size(1), device=dev)
+        x = torch.randn(n, f, device=dev, generator=g)
+        batch = torch.zeros(n, dtype=torch.long, device=dev)
+        nodes = n
+        if args.workload == "c4_graclus":
+            so = GraclusSelect()(ei, ew, num_nodes=n)
+            conn = SparseConnect()
+            k = so.num_supernodes
+            extra = {"num_supernodes": k, "edges": int(ei.size(1))}
+
+            def step():
+                so._drop_caches()  # rebuild the inverted index every step (no cross-step caching)
+                xp, bp = red(x, so, batch=batch)
+                conn(ei, so, edge_weight=ew, batch_pooled=bp)
+            name = "Graclus precoarsening on one N=1M E=10M graph, F=128: Reduce + coalesce Connect (BASELINE configs[3])"
+            nnz = n
+        else:
+            if args.workload == "c4_ndp":
+                keep_nodes = (torch.rand(n, device=dev, generator=g) < 0.5).nonzero().view(-1)
+                wts = None
+                name = "NDP-shaped S (random +-1 partition) on N=1M, F=128: Reduce only (Kron excluded, SURVEY 8(d))"
+            else:
+                keep_nodes = torch.sort(torch.randperm(n, device=dev, generator=g)[: n // 2])[0]
+                wts = torch.rand(keep_nodes.numel(), device=dev, generator=g)
+                name = "TopK-shaped S (ratio 0.5, score weights) on N=1M, F=128: scatter-reduce only"
+            k = keep_nodes.numel()
+            so = SelectOutput(node_index=keep_nodes, num_nodes=n, cluster_index=torch.randperm(k, device=dev, generator=g),
+                              num_supernodes=k, weight=wts)
+            extra = {"num_supernodes": k}
+
+            def step():
+                so._drop_caches()
+                red(x, so, batch=batch)
+            nnz = k
+        # roofline of the gather-sum kernel alone (index cached), SURVEY 8(d) A1 byte count
+        idx = so.assign_index()
+        alg = nnz * (4.0 * f + 8 + 8 + 4) + k * 4.0 * f
+        kern_ms = event_time_ms(lambda: kernels.reduce_sparse(x, so.node_index, so.weight, idx), 20, dev)
+        roof = {"kernel": "tgp::reduce_sparse_vec4_kernel (gather-sum, index cached)", "bound": "hbm",
+                "achieved": round(alg / (kern_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                "bytes_per_launch": alg, "avg_launch_ms": round(kern_ms, 4)}
+    dt = timed(step, args.steps, args.warmup, lambda: torch.cuda.synchronize(dev), lambda: None)
+    cfg = {"workload": name, "nodes_counted": "input nodes per step"}
+    cfg.update(extra)
+    print(json.dumps({
+        "metric": "pooled nodes/sec (Reduce+Connect) on batched graphs", "value": round(nodes * args.steps / dt, 1),
+        "unit": "nodes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": roof}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -124,6 +217,11 @@ def main():
     from tgp.select import SelectOutput
     _native.lib()
 
+    if args.workload not in ("c2", "c5"):
+        if distributed:
+            raise SystemExit("secondary workloads are single-GPU (C4 does not shard: replicas only)")
+        run_other_workload(args, dev)
+        return
     if args.workload == "c2":
         B, N, K, F = 32, 1024, 128, 64
         name = "DiffPool dense S^T X / S^T A S, batch=32 graphs N=1024 K=128 F=64 (BASELINE configs[1])"
