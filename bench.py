@@ -163,8 +163,9 @@ def run_other_workload(args, dev):
                 wts = torch.rand(keep_nodes.numel(), device=dev, generator=g)
                 name = "TopK-shaped S (ratio 0.5, score weights) on N=1M, F=128: scatter-reduce only"
             k = keep_nodes.numel()
-            so = SelectOutput(node_index=keep_nodes, num_nodes=n, cluster_index=torch.randperm(k, device=dev, generator=g),
-                              num_supernodes=k, weight=wts)
+            # NDPSelect numbers supernodes in node order (ndp_select.py:128-144); TopK numbers them by score
+            ci = torch.arange(k, device=dev) if args.workload == "c4_ndp" else torch.randperm(k, device=dev, generator=g)
+            so = SelectOutput(node_index=keep_nodes, num_nodes=n, cluster_index=ci, num_supernodes=k, weight=wts)
             extra = {"num_supernodes": k}
 
             def step():

@@ -8,6 +8,7 @@
 // CPU scatter (so the fp32 result is reproducible and bit-identical to it: the product is
 // rounded before the add, exactly as the reference's two-step form does).
 #include "primitives.h"
+#include <stdlib.h>
 
 namespace tgp {
 
@@ -40,8 +41,13 @@ __global__ __launch_bounds__(256) void assign_rowptr_kernel(const uint32_t* __re
   for (int64_t c = prev + 1; c <= cur; ++c) row_ptr[c] = static_cast<int32_t>(p);
 }
 
-// One group of G lanes per supernode; lane g owns features [4g,4g+4) (+ 4G strides).
-template <int G>
+// One group of G lanes per supernode; lane g owns features [4g,4g+4) (+ 4G strides).  Every group
+// works on U supernodes at once: the (row_ptr -> perm -> node_index/weight -> x row) chains of the U
+// supernodes are issued side by side, so U row gathers are in flight per group instead of one
+// (the kernel is latency/occupancy-bound otherwise: supernodes own only 1-2 rows each).
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int G, int U, bool NT>
 __global__ __launch_bounds__(256) void reduce_sparse_vec4_kernel(
     const float* __restrict__ x, int64_t F, int64_t x_stride, const int64_t* __restrict__ node_index,
     const float* __restrict__ weight, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ perm,
@@ -50,20 +56,75 @@ __global__ __launch_bounds__(256) void reduce_sparse_vec4_kernel(
   const int g = threadIdx.x % G;
   const int64_t group = static_cast<int64_t>(blockIdx.x) * GROUPS + threadIdx.x / G;
   const int64_t ngroups = static_cast<int64_t>(gridDim.x) * GROUPS;
-  for (int64_t c = group; c < K; c += ngroups) {
-    const int32_t beg = row_ptr[c], end = row_ptr[c + 1];
-    for (int64_t f = 4 * g; f < F; f += 4 * G) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int32_t p = beg; p < end; ++p) {
-        const int32_t a = perm[p];
-        const float w = weight ? weight[a] : 1.0f;
-        const float4 v = *reinterpret_cast<const float4*>(x + node_index[a] * x_stride + f);
-        acc.x = __fadd_rn(acc.x, __fmul_rn(v.x, w));
-        acc.y = __fadd_rn(acc.y, __fmul_rn(v.y, w));
-        acc.z = __fadd_rn(acc.z, __fmul_rn(v.z, w));
-        acc.w = __fadd_rn(acc.w, __fmul_rn(v.w, w));
+  for (int64_t c0 = group; c0 < K; c0 += ngroups * U) {
+    int32_t beg[U], len[U];
+    int32_t maxlen = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t c = c0 + u * ngroups;
+      beg[u] = 0;
+      len[u] = -1;
+      if (c < K) {
+        beg[u] = row_ptr[c];
+        len[u] = row_ptr[c + 1] - beg[u];
       }
-      *reinterpret_cast<float4*>(x_pool + c * F + f) = acc;
+      maxlen = len[u] > maxlen ? len[u] : maxlen;
+    }
+    for (int64_t f = 4 * g; f < F; f += 4 * G) {
+      float4 acc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int32_t m = 0; m < maxlen; ++m) {
+        int32_t a[U];
+        float w[U];
+        const float* src[U];
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = m < len[u] ? perm[beg[u] + m] : -1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          w[u] = 1.0f;
+          src[u] = x;
+          if (a[u] >= 0) {
+            if (weight) w[u] = weight[a[u]];
+            src[u] = x + node_index[a[u]] * x_stride + f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a[u] >= 0) {
+            if constexpr (NT) {  // rows are read exactly once: keep them out of the way of the index tables
+              const nt_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(src[u]));
+              v[u] = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+              v[u] = *reinterpret_cast<const float4*>(src[u]);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (a[u] >= 0) {  // product rounded before the add, as the reference's two-step form
+            acc[u].x = __fadd_rn(acc[u].x, __fmul_rn(v[u].x, w[u]));
+            acc[u].y = __fadd_rn(acc[u].y, __fmul_rn(v[u].y, w[u]));
+            acc[u].z = __fadd_rn(acc[u].z, __fmul_rn(v[u].z, w[u]));
+            acc[u].w = __fadd_rn(acc[u].w, __fmul_rn(v[u].w, w[u]));
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t c = c0 + u * ngroups;
+        if (len[u] >= 0) {
+          if constexpr (NT) {
+            nt_f32x4 t = {acc[u].x, acc[u].y, acc[u].z, acc[u].w};
+            __builtin_nontemporal_store(t, reinterpret_cast<nt_f32x4*>(x_pool + c * F + f));
+          } else {
+            *reinterpret_cast<float4*>(x_pool + c * F + f) = acc[u];
+          }
+        }
+      }
     }
   }
 }
@@ -155,12 +216,32 @@ extern "C" int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t 
     int G = 1;
     while (G < lanes && G < 64) G <<= 1;
     const int64_t groups_per_block = 256 / G;
-    int64_t blocks = (K + groups_per_block - 1) / groups_per_block;
-    if (blocks > cus * 16) blocks = cus * 16;
+    int64_t blocks = (K + groups_per_block * 4 - 1) / (groups_per_block * 4);
+    if (blocks > cus * 8) blocks = cus * 8;
+    if (blocks < 1) blocks = 1;
     dim3 grid(static_cast<unsigned>(blocks)), block(256);
-#define TGP_LAUNCH_G(GG)                                                                                   \
-  hipLaunchKernelGGL((reduce_sparse_vec4_kernel<GG>), grid, block, 0, stream, x, F, x_stride, node_index, \
-                     weight, row_ptr, perm, K, x_pool)
+    static const int kU = getenv("TGP_REDUCE_U") ? atoi(getenv("TGP_REDUCE_U")) : 2;
+    static const int kNT = getenv("TGP_REDUCE_NT") ? atoi(getenv("TGP_REDUCE_NT")) : 1;
+    static const int kBlocksPerCu = getenv("TGP_REDUCE_BPC") ? atoi(getenv("TGP_REDUCE_BPC")) : 8;
+    blocks = (K + groups_per_block * kU - 1) / (groups_per_block * kU);
+    if (blocks > cus * kBlocksPerCu) blocks = cus * kBlocksPerCu;
+    if (blocks < 1) blocks = 1;
+    grid = dim3(static_cast<unsigned>(blocks));
+#define TGP_LAUNCH_GU(GG, UU)                                                                                  \
+  do {                                                                                                          \
+    if (kNT)                                                                                                    \
+      hipLaunchKernelGGL((reduce_sparse_vec4_kernel<GG, UU, true>), grid, block, 0, stream, x, F, x_stride,     \
+                         node_index, weight, row_ptr, perm, K, x_pool);                                         \
+    else                                                                                                        \
+      hipLaunchKernelGGL((reduce_sparse_vec4_kernel<GG, UU, false>), grid, block, 0, stream, x, F, x_stride,    \
+                         node_index, weight, row_ptr, perm, K, x_pool);                                         \
+  } while (0)
+#define TGP_LAUNCH_G(GG)                  \
+  do {                                    \
+    if (kU == 1) TGP_LAUNCH_GU(GG, 1);    \
+    else if (kU == 2) TGP_LAUNCH_GU(GG, 2); \
+    else TGP_LAUNCH_GU(GG, 4);            \
+  } while (0)
     switch (G) {
       case 1: TGP_LAUNCH_G(1); break;
       case 2: TGP_LAUNCH_G(2); break;

@@ -177,6 +177,19 @@ class SelectOutput:
         self._assign_index = None
         self._lift_index = None
 
+    def _set_one_to_one_index(self) -> None:
+        """Selectors whose supernodes own exactly one node (TopK, NDP) know the inverted index in
+        closed form: it is the inverse permutation of ``cluster_index`` - no sort needed."""
+        from .. import kernels
+        ci = self.cluster_index
+        k = self.num_supernodes
+        if not ci.is_cuda or ci.numel() != k:
+            return
+        perm = torch.empty(max(k, 1), dtype=torch.int32, device=ci.device)
+        perm[ci] = torch.arange(k, dtype=torch.int32, device=ci.device)
+        row_ptr = torch.arange(k + 1, dtype=torch.int32, device=ci.device)
+        self._assign_index = kernels.AssignIndex(row_ptr, perm, k, k)
+
     # ---- tensor plumbing (reference base_select.py:313-379) ---------------------------
     def __repr__(self) -> str:
         out = f"{self.__class__.__name__}(num_nodes={self.num_nodes}, num_supernodes={self.num_supernodes}"
@@ -336,10 +349,12 @@ class TopkSelect(Select):
             e = (score - _segment_max(score.detach(), batch, nb)[batch]).exp()
             score = e / (e.new_zeros(nb).index_add_(0, batch, e) + 1e-16)[batch]
         node_index = topk(score, self.ratio, batch, self.min_score)
-        return SelectOutput(node_index=node_index, num_nodes=x.size(0),
-                            cluster_index=torch.arange(node_index.size(0), device=x.device),
-                            num_supernodes=node_index.size(0), weight=score[node_index],
-                            s_inv_op=self.s_inv_op)
+        so = SelectOutput(node_index=node_index, num_nodes=x.size(0),
+                          cluster_index=torch.arange(node_index.size(0), device=x.device),
+                          num_supernodes=node_index.size(0), weight=score[node_index],
+                          s_inv_op=self.s_inv_op)
+        so._set_one_to_one_index()
+        return so
 
     def __repr__(self) -> str:
         arg = f"ratio={self.ratio}" if self.min_score is None else f"min_score={self.min_score}"
@@ -540,7 +555,9 @@ class NDPSelect(Select):
         k = idx_pos.numel()
         s = torch.sparse_coo_tensor(torch.stack([idx_pos, torch.arange(k, device=dev)]),
                                     torch.ones(k, device=dev), size=(num_nodes, k)).coalesce()
-        return SelectOutput(s=s, s_inv_op=self.s_inv_op, L=L.astype(np.float32))
+        so = SelectOutput(s=s, s_inv_op=self.s_inv_op, L=L.astype(np.float32))
+        so._set_one_to_one_index()
+        return so
 
     def __repr__(self) -> str:
         return f"{self.__class__.__name__}(s_inv_op={self.s_inv_op})"
