@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Launch one hot kernel repeatedly (for rocprofv3 --pmc / --kernel-trace runs).
+usage: python tools/run_kernel.py {gemm_c2|gemm_c5|reduce_topk|coalesce_c4} [reps]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "torch-geometric-pool_amd"))
+from tgp import kernels  # noqa: E402
+from tgp.select import SelectOutput  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "gemm_c2"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+if which.startswith("gemm"):
+    B, N, K = (32, 1024, 128) if which == "gemm_c2" else (2, 8192, 512)
+    A = (torch.rand(B, N, N, device=dev, generator=g) < 0.01).float()
+    S = torch.softmax(torch.randn(B, N, K, device=dev, generator=g), -1)
+    for _ in range(reps):
+        kernels.bmm(A, S)
+elif which == "reduce_topk":
+    n, f = 1_000_000, 128
+    x = torch.randn(n, f, device=dev, generator=g)
+    keep = torch.sort(torch.randperm(n, device=dev, generator=g)[: n // 2])[0]
+    k = keep.numel()
+    so = SelectOutput(node_index=keep, num_nodes=n, cluster_index=torch.randperm(k, device=dev, generator=g),
+                      num_supernodes=k, weight=torch.rand(k, device=dev, generator=g))
+    idx = so.assign_index()
+    for _ in range(reps):
+        kernels.reduce_sparse(x, so.node_index, so.weight, idx)
+elif which == "coalesce_c4":
+    n = 1_000_000
+    a = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    b = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+    ew = torch.ones(ei.size(1), device=dev)
+    pair = torch.randperm(n, device=dev, generator=g)
+    cluster = torch.empty(n, dtype=torch.long, device=dev)
+    cluster[pair] = torch.arange(n, device=dev) // 2
+    for _ in range(reps):
+        kernels.coalesce_edges(ei, ew, cluster, n // 2, "sum", True)
+torch.cuda.synchronize()
+print("done", which, reps)

@@ -21,17 +21,14 @@
 //   * row-major operand tile  (A of A.S):     LDS [128][BK+1]  (odd stride => conflict free)
 //   * k-major operand tile    (S, U, X, A^T): LDS [BK][128]    (lanes read consecutive floats)
 #include "common.h"
+#include <stdlib.h>
 
 namespace tgp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int GEMM_THREADS = 512;
+constexpr int BK = 32;
 constexpr int LDA_ROWMAJOR = BK + 1;
-constexpr int A_TILE_FLOATS = BM * LDA_ROWMAJOR;  // >= BK*BM, used for both A layouts
-constexpr int B_TILE_FLOATS = BK * BN;
-constexpr int STAGE_FLOATS = A_TILE_FLOATS + B_TILE_FLOATS;
 
 // One right-hand side / output pair.  A launch may carry two (column tiles >= tiles_n0 use the
 // second), which lets S^T [U | X] run as a single grid.
@@ -51,17 +48,31 @@ struct GemmArgs {
   int splits;              // split of Kd across workgroups
   int k_per_split;         // multiple of BK
   const int64_t* k_ptr;    // optional [batches+1]: batch b reduces over rows k_ptr[b]..k_ptr[b+1]
+  int stagger;             // s_sleep units (64 cycles each) for the second half of the grid
 };
 
 __device__ __forceinline__ float4 ld4_guarded(const float* p, bool ok) {
   return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// Output tile BM x 128 per workgroup of (BM/32)*2 waves laid out (BM/32)(M) x 2(N); each wave owns a
+// 32 x 64 strip = two 32x32 MFMA tiles.  BM = 128: 512 threads, one workgroup per CU (big problems);
+// BM = 64: 256 threads, two workgroups per CU whose barriers / prologues / epilogues interleave (used
+// when the 128-row tiling would leave fewer than two workgroups per CU).
 // A_KMAJOR = false: A stored [M][Kd] (k contiguous).  true: stored [Kd][M] (m contiguous).
 // ALIGNED: every leading dimension / extent is a multiple of 4 floats and every base is 16-byte
 // aligned, so all traffic is float4 with one predicate per vector.  Otherwise: scalar guarded path.
-template <bool A_KMAJOR, bool ALIGNED>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g) {
+template <bool A_KMAJOR, bool ALIGNED, int BM, int BN>
+__global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
+  constexpr int THREADS = BM * 4;
+  constexpr int NT = BN / 64;                       // 32x32 MFMA tiles per wave (wave strip = 32 x BN/2)
+  constexpr int B_TILE_FLOATS = BK * BN;
+  constexpr int BN_LANES = BN / 4;                  // lanes per k-row of the B tile
+  constexpr int A_TILE_FLOATS = BM * LDA_ROWMAJOR;  // >= BK*BM, used for both A layouts
+  constexpr int STAGE_FLOATS = A_TILE_FLOATS + B_TILE_FLOATS;
+  constexpr int A_VECS = BM * BK / 4 / THREADS;     // float4 per thread per stage (= 2)
+  constexpr int B_VECS = BN * BK / 4 / THREADS;     // 2 (512 threads) or 4 (256 threads)
+  constexpr int AK_LANES = BM / 4;                  // lanes per k-row of a k-major A tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -92,111 +103,137 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_mfma_kernel(GemmArgs g)
   const int k_end = min(k_hi, k_begin + g.k_per_split);
   const int nk = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
 
-  float4 ra[2], rb[2];
+  // register staging: the global loads of tile t+1 are in flight while tile t is multiplied
+  float4 ra0[A_VECS], rb0[B_VECS];
 
-  auto load_tiles = [&](int k0) {
-    if constexpr (ALIGNED) {
-      if constexpr (!A_KMAJOR) {
+  auto load_tiles = [&](float4 (&ra)[A_VECS], float4 (&rb)[B_VECS], int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {  // [128 m][32 k]: 8 lanes cover one 128-byte row segment
-          const int m = m0 + (tid >> 3) + i * 64, k = k0 + (tid & 7) * 4;
-          ra[i] = ld4_guarded(A + static_cast<long>(m) * lda + k, m < g.M && k < k_end);
-        }
+    for (int i = 0; i < A_VECS; ++i) {
+      int m, k;
+      if constexpr (!A_KMAJOR) {  // [BM m][32 k]: 8 lanes cover one 128-byte row segment
+        m = m0 + (tid >> 3) + i * (THREADS / 8);
+        k = k0 + (tid & 7) * 4;
+      } else {                    // [32 k][BM m]: AK_LANES lanes cover one row
+        k = k0 + tid / AK_LANES + i * (THREADS / AK_LANES);
+        m = m0 + (tid % AK_LANES) * 4;
+      }
+      const float* p = A_KMAJOR ? A + static_cast<long>(k) * lda + m : A + static_cast<long>(m) * lda + k;
+      if constexpr (ALIGNED) {
+        ra[i] = ld4_guarded(p, m < g.M && k < k_end);
       } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {  // [32 k][128 m]: 32 lanes cover one 512-byte row
-          const int k = k0 + (tid >> 5) + i * 16, m = m0 + (tid & 31) * 4;
-          ra[i] = ld4_guarded(A + static_cast<long>(k) * lda + m, k < k_end && m < g.M);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int k = k0 + (tid >> 5) + i * 16, n = n0 + (tid & 31) * 4;
-        rb[i] = ld4_guarded(Bm + static_cast<long>(k) * ldb + n, k < k_end && n < Nc);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
         float t[4];
-        if constexpr (!A_KMAJOR) {
-          const int m = m0 + (tid >> 3) + i * 64, k = k0 + (tid & 7) * 4;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) t[j] = (m < g.M && k + j < k_end) ? A[static_cast<long>(m) * lda + k + j] : 0.f;
-        } else {
-          const int k = k0 + (tid >> 5) + i * 16, m = m0 + (tid & 31) * 4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) t[j] = (k < k_end && m + j < g.M) ? A[static_cast<long>(k) * lda + m + j] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = A_KMAJOR ? (k < k_end && m + j < g.M) : (m < g.M && k + j < k_end);
+          t[j] = ok ? p[j] : 0.f;
         }
         ra[i] = make_float4(t[0], t[1], t[2], t[3]);
-        const int k = k0 + (tid >> 5) + i * 16, n = n0 + (tid & 31) * 4;
+      }
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = (k < k_end && n + j < Nc) ? Bm[static_cast<long>(k) * ldb + n + j] : 0.f;
+    for (int i = 0; i < B_VECS; ++i) {  // [32 k][BN n]: BN_LANES lanes cover one row
+      const int k = k0 + tid / BN_LANES + i * (THREADS / BN_LANES), n = n0 + (tid % BN_LANES) * 4;
+      const float* p = Bm + static_cast<long>(k) * ldb + n;
+      if constexpr (ALIGNED) {
+        rb[i] = ld4_guarded(p, k < k_end && n < Nc);
+      } else {
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (k < k_end && n + j < Nc) ? p[j] : 0.f;
         rb[i] = make_float4(t[0], t[1], t[2], t[3]);
       }
     }
   };
-  auto store_stage = [&](float* As, float* Bs) {
+  auto store_stage = [&](const float4 (&ra)[A_VECS], const float4 (&rb)[B_VECS], float* As, float* Bs) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < A_VECS; ++i) {
       if constexpr (!A_KMAJOR) {
-        float* d = As + ((tid >> 3) + i * 64) * LDA_ROWMAJOR + (tid & 7) * 4;
+        float* d = As + ((tid >> 3) + i * (THREADS / 8)) * LDA_ROWMAJOR + (tid & 7) * 4;
         d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
       } else {
-        *reinterpret_cast<float4*>(As + ((tid >> 5) + i * 16) * BM + (tid & 31) * 4) = ra[i];
+        *reinterpret_cast<float4*>(As + (tid / AK_LANES + i * (THREADS / AK_LANES)) * BM + (tid % AK_LANES) * 4) = ra[i];
       }
-      *reinterpret_cast<float4*>(Bs + ((tid >> 5) + i * 16) * BN + (tid & 31) * 4) = rb[i];
     }
+#pragma unroll
+    for (int i = 0; i < B_VECS; ++i)
+      *reinterpret_cast<float4*>(Bs + (tid / BN_LANES + i * (THREADS / BN_LANES)) * BN + (tid % BN_LANES) * 4) = rb[i];
   };
 
-  f32x16 acc[2];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-  if (nk > 0) {
-    load_tiles(k_begin);
-    store_stage(smem, smem + A_TILE_FLOATS);
-  }
-  __syncthreads();
 
   const int lm = lane & 31, lk = lane >> 5;
   const int a_off = A_KMAJOR ? lk * BM + wm * 32 + lm : (wm * 32 + lm) * LDA_ROWMAJOR + lk;
   const int a_step = A_KMAJOR ? 2 * BM : 2;
-  const int b_off = lk * BN + wn * 64 + lm;
-  for (int t = 0; t < nk; ++t) {
-    const float* As = smem + (t & 1) * STAGE_FLOATS;
-    const float* Bs = As + A_TILE_FLOATS;
-    const bool more = (t + 1) < nk;
-    if (more) load_tiles(k_begin + (t + 1) * BK);
-    float a_cur = As[a_off], b0_cur = Bs[b_off], b1_cur = Bs[b_off + 32];
+  const int b_off = lk * BN + wn * (BN / 2) + lm;
+  // MFMAs of k-pairs [p0, p1) of one LDS stage; the LDS operands of pair p+1 are requested before the
+  // MFMAs of pair p are issued (sched_group_barrier pins that order).
+  float a_cur, b_cur[NT];
+  auto mfma_pairs = [&](const float* As, const float* Bs, int p0, int p1) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a_nxt = 0.f, b0_nxt = 0.f, b1_nxt = 0.f;
-      if (kk + 2 < BK) {
-        a_nxt = As[a_off + (kk / 2 + 1) * a_step];
-        b0_nxt = Bs[b_off + (kk + 2) * BN];
-        b1_nxt = Bs[b_off + (kk + 2) * BN + 32];
+    for (int p = p0; p < p1; ++p) {
+      float a_nxt = 0.f, b_nxt[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b_nxt[j] = 0.f;
+      if (p + 1 < BK / 2) {
+        a_nxt = As[a_off + (p + 1) * a_step];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b_nxt[j] = Bs[b_off + 2 * (p + 1) * BN + 32 * j];
       }
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b0_cur, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b1_cur, acc[1], 0, 0, 0);
-      // pin the order: LDS reads of step kk+2 are issued BEFORE the MFMAs of step kk, so their
-      // latency hides behind 128 cycles of matrix work (hipcc otherwise sinks them to the use)
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 x ds_read (a, b0|b1 pair)
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 x MFMA
-      a_cur = a_nxt; b0_cur = b0_nxt; b1_cur = b1_nxt;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 x ds_read (a, b)
+      __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);  // NT x MFMA
+      a_cur = a_nxt;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b_cur[j] = b_nxt[j];
     }
-    if (more) {
-      float* An = smem + ((t + 1) & 1) * STAGE_FLOATS;
-      store_stage(An, An + A_TILE_FLOATS);
-    }
+  };
+
+  // Stage schedule.  Everything that is not an MFMA rides in the shadow of the matrix pipe:
+  //   MFMAs 0-7 | LDS <- registers (tile t+1, loaded during stage t-1) | MFMAs 8-15 |
+  //   global loads of tile t+2 -> the same registers | MFMAs 16-31 | barrier
+  // The tile being written (t+1) lives in the other LDS buffer than the one being read (t).
+  float* L0 = smem;
+  float* L1 = smem + STAGE_FLOATS;
+  auto kof = [&](int t) { return k_begin + t * BK; };
+  // Co-resident workgroups start together and run the same instruction stream, so their non-MFMA
+  // phases (LDS refill, barrier) coincide and the matrix pipe idles during them.  Delaying the
+  // second wave of workgroups by about half a stage keeps one of them on the pipe (speed only).
+  if (g.stagger > 0 && blockIdx.x >= gridDim.x / 2)
+    for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  if (nk > 0) {
+    load_tiles(ra0, rb0, kof(0));
+    store_stage(ra0, rb0, L0, L0 + A_TILE_FLOATS);
+  }
+  if (nk > 1) load_tiles(ra0, rb0, kof(1));
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    const float* As = (t & 1) ? L1 : L0;
+    const float* Bs = As + A_TILE_FLOATS;
+    float* Ln = (t & 1) ? L0 : L1;
+    a_cur = As[a_off];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b_cur[j] = Bs[b_off + 32 * j];
+    mfma_pairs(As, Bs, 0, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nk) store_stage(ra0, rb0, Ln, Ln + A_TILE_FLOATS);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_pairs(As, Bs, 4, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < nk) load_tiles(ra0, rb0, kof(t + 2));
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_pairs(As, Bs, 8, 16);
     __syncthreads();
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -----------
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + lm;
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 32 + lm;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -215,14 +252,52 @@ static bool gemm_aligned(const GemmArgs& g) {
   return a;
 }
 
-template <bool A_KMAJOR>
-static void launch_gemm(const GemmArgs& g, int batches, hipStream_t stream) {
+// Tile shape: 128 x 128 unless that leaves the chip under two 512-thread workgroups per CU; then the
+// tile is halved (128 x 64 first: twice the waves per SIMD at the same A traffic per CU-pair sharing
+// an L2; 64 x 128 for short M).
+struct TileCfg { int bm, bn; };
+static TileCfg pick_tile(int64_t M, int64_t max_nc, int64_t batches_x_splits, const GemmArgs& g) {
+  static const int fbm = getenv("TGP_GEMM_BM") ? atoi(getenv("TGP_GEMM_BM")) : 0;
+  static const int fbn = getenv("TGP_GEMM_BN") ? atoi(getenv("TGP_GEMM_BN")) : 0;
+  TileCfg t{128, 128};
+  auto count = [&](int bm, int bn) {
+    int64_t tn = 0;
+    tn += (g.rhs[0].Nc + bn - 1) / bn;
+    if (g.rhs[1].Bm) tn += (g.rhs[1].Nc + bn - 1) / bn;
+    return ((M + bm - 1) / bm) * tn * batches_x_splits;
+  };
+  if (M <= 64) t.bm = 64;
+  if (count(t.bm, 128) < 2 * 256 && max_nc >= 64) t.bn = 64;
+  if (count(t.bm, t.bn) < 2 * 256 && t.bm == 128 && M > 64) t.bm = 64;
+  if (fbm == 64 || fbm == 128) t.bm = fbm;
+  if (fbn == 64 || fbn == 128) t.bn = fbn;
+  return t;
+}
+
+template <bool A_KMAJOR, int BM, int BN>
+static void launch_gemm_cfg(const GemmArgs& g, int batches, hipStream_t stream) {
   const int nwg = batches * g.splits * g.tiles_m * g.tiles_n;
-  const size_t lds = 2 * STAGE_FLOATS * sizeof(float);
+  const size_t lds = 2 * (BM * LDA_ROWMAJOR + BK * BN) * sizeof(float);
   if (gemm_aligned(g))
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, true>), dim3(nwg), dim3(GEMM_THREADS), lds, stream, g);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, true, BM, BN>), dim3(nwg), dim3(BM * 4), lds, stream, g);
   else
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, false>), dim3(nwg), dim3(GEMM_THREADS), lds, stream, g);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, false, BM, BN>), dim3(nwg), dim3(BM * 4), lds, stream, g);
+}
+
+// g.tiles_* are filled in here: they follow from the tile shape chosen for this problem.
+template <bool A_KMAJOR>
+static void launch_gemm(GemmArgs g, int batches, hipStream_t stream) {
+  static const int stagger = getenv("TGP_GEMM_STAGGER") ? atoi(getenv("TGP_GEMM_STAGGER")) : 0;
+  g.stagger = stagger;
+  const int64_t max_nc = g.rhs[1].Bm && g.rhs[1].Nc > g.rhs[0].Nc ? g.rhs[1].Nc : g.rhs[0].Nc;
+  const TileCfg t = pick_tile(g.M, max_nc, static_cast<int64_t>(batches) * g.splits, g);
+  g.tiles_m = cdiv(g.M, t.bm);
+  g.tiles_n0 = cdiv(g.rhs[0].Nc, t.bn);
+  g.tiles_n = g.tiles_n0 + (g.rhs[1].Bm ? cdiv(g.rhs[1].Nc, t.bn) : 0);
+  if (t.bm == 64 && t.bn == 64) launch_gemm_cfg<A_KMAJOR, 64, 64>(g, batches, stream);
+  else if (t.bm == 64) launch_gemm_cfg<A_KMAJOR, 64, 128>(g, batches, stream);
+  else if (t.bn == 64) launch_gemm_cfg<A_KMAJOR, 128, 64>(g, batches, stream);
+  else launch_gemm_cfg<A_KMAJOR, 128, 128>(g, batches, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -415,7 +490,7 @@ struct DensePlan {
 static DensePlan dense_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
   DensePlan p;
   // second product: output is only K x (K+F) per graph -> split N so the chip is filled
-  const int64_t tiles = ((K + BM - 1) / BM) * (((K + BN - 1) / BN) + ((F + BN - 1) / BN));
+  const int64_t tiles = ((K + 127) / 128) * (((K + 127) / 128) + ((F + 127) / 128));
   const int64_t base = B * (tiles > 0 ? tiles : 1);
   int64_t splits = (2 * 256 + base - 1) / base;  // aim for ~2 workgroups per CU
   const int64_t max_splits = (N + 4 * BK - 1) / (4 * BK);  // keep >= 4 k-steps per workgroup
@@ -479,7 +554,7 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
     g.M = static_cast<int>(N); g.Kd = static_cast<int>(N);
     g.rhs[0] = GemmRhs{S, U, static_cast<int>(K), K, K, N * K, N * K, 0};
     g.splits = 1; g.k_per_split = static_cast<int>((N + BK - 1) / BK * BK);
-    g.tiles_m = cdiv(N, BM); g.tiles_n0 = cdiv(K, BN); g.tiles_n = g.tiles_n0;
+    
     if (flags & TGP_ADJ_TRANSPOSED) launch_gemm<true>(g, static_cast<int>(B), stream);
     else launch_gemm<false>(g, static_cast<int>(B), stream);
   }
@@ -489,15 +564,14 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
     h.A = S; h.lda = K; h.sA = N * K;
     h.M = static_cast<int>(K); h.Kd = static_cast<int>(N);
     h.splits = p.splits; h.k_per_split = p.k_per_split;
-    h.tiles_m = cdiv(K, BM);
     const GemmRhs ra{U, aslab, static_cast<int>(K), K, K, N * K, static_cast<long>(p.splits) * K * K, K * K};
     const GemmRhs rx{X, xslab, static_cast<int>(F), F, F, N * F, static_cast<long>(p.splits) * K * F, K * F};
     if (want_a && want_x) {
       h.rhs[0] = ra; h.rhs[1] = rx;
-      h.tiles_n0 = cdiv(K, BN); h.tiles_n = h.tiles_n0 + cdiv(F, BN);
+
     } else {
       h.rhs[0] = want_a ? ra : rx;
-      h.tiles_n0 = cdiv(want_a ? K : F, BN); h.tiles_n = h.tiles_n0;
+
     }
     launch_gemm<true>(h, static_cast<int>(B), stream);
   }
@@ -552,9 +626,7 @@ extern "C" int tgp_bmm_f32(const float* A, const float* Bm, float* C, int64_t ba
   g.M = static_cast<int>(M); g.Kd = static_cast<int>(Kd);
   g.rhs[0] = GemmRhs{Bm, C, static_cast<int>(Nc), ldb, ldc, sB, sC, 0};
   g.splits = 1; g.k_per_split = static_cast<int>((Kd + BK - 1) / BK * BK);
-  g.tiles_m = cdiv(M, BM); g.tiles_n0 = cdiv(Nc, BN); g.tiles_n = g.tiles_n0;
-  const int64_t nwg = batch * g.tiles_m * g.tiles_n;
-  TGP_REQUIRE(nwg < (1ll << 31), TGP_ERR_RANGE, "tgp_bmm_f32: grid too large");
+  TGP_REQUIRE(batch * ((M + 63) / 64) * ((Nc + 63) / 64) < (1ll << 31), TGP_ERR_RANGE, "tgp_bmm_f32: grid too large");
   if (trans_a) launch_gemm<true>(g, static_cast<int>(batch), stream);
   else launch_gemm<false>(g, static_cast<int>(batch), stream);
   return check_launch("tgp_bmm_f32");
@@ -579,7 +651,6 @@ extern "C" int tgp_segment_gemm_tn_f32(const float* S, const float* Y, const int
   const int64_t span = max_nodes > 0 ? max_nodes : Ntot;
   g.k_per_split = static_cast<int>((span + BK - 1) / BK * BK);
   if (g.k_per_split < BK) g.k_per_split = BK;
-  g.tiles_m = cdiv(K, BM); g.tiles_n0 = cdiv(F, BN); g.tiles_n = g.tiles_n0;
   g.k_ptr = ptr;
   launch_gemm<true>(g, static_cast<int>(B), stream);
   return check_launch("tgp_segment_gemm_tn_f32");
