@@ -248,3 +248,41 @@ def test_lift_roundtrip(dev):
     cl = out.so.cluster_index
     ref = out.x[cl]
     torch.testing.assert_close(lifted, ref, rtol=RTOL, atol=ATOL)
+
+
+def test_small_graph_kernel_flag_grid(dev):
+    """One-wave-per-graph path (N <= 64, K <= 32, F <= 32, B >= 64): every post-processing flag
+    combination, ragged graph sizes (zero-padded rows as MLPSelect leaves them) and both A layouts."""
+    import tgp_oracle as O
+    from tgp import kernels
+    from tgp.connect import DenseConnect
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    g = torch.Generator().manual_seed(11)
+    B, N, K, F = 96, 60, 20, 32
+    n_b = torch.randint(20, 61, (B,), generator=g)
+    mask = torch.arange(N).unsqueeze(0) < n_b.unsqueeze(1)
+    A = (torch.rand(B, N, N, generator=g) < 0.15).float() * torch.rand(B, N, N, generator=g)
+    A = A * mask.unsqueeze(1) * mask.unsqueeze(2)
+    X = torch.randn(B, N, F, generator=g) * mask.unsqueeze(-1)
+    S = torch.softmax(torch.randn(B, N, K, generator=g), -1) * mask.unsqueeze(-1)
+    so = SelectOutput(s=S.to(dev))
+    torch.testing.assert_close(BaseReduce()(X.to(dev), so)[0].cpu(), O.reduce_dense(S, X), rtol=RTOL, atol=ATOL)
+    raw_ref = O.dense_connect(S, A)
+    Ad = A.to(dev)
+    At_view = A.transpose(1, 2).contiguous().to(dev).transpose(1, 2)  # same values, transposed memory layout
+    assert not At_view.is_contiguous()
+    for rsl in (True, False):
+        for dn in (True, False):
+            for at in (True, False):
+                for ewn in (True, False):
+                    conn = DenseConnect(remove_self_loops=rsl, degree_norm=dn, adj_transpose=at, edge_weight_norm=ewn)
+                    ref = O.postprocess_dense(raw_ref, rsl, dn, at, ewn)
+                    for adj in (Ad, At_view):
+                        out, _ = conn(adj, so)
+                        torch.testing.assert_close(out.cpu(), ref, rtol=RTOL, atol=ATOL)
+    x_pool, raw, post = kernels.dense_pool(S.to(dev), Ad, X.to(dev), kernels.dense_flags(True, True, True, False),
+                                           want_raw=True)
+    torch.testing.assert_close(raw.cpu(), raw_ref, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(post.cpu(), O.postprocess_dense(raw_ref, True, True, True, False), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(x_pool.cpu(), O.reduce_dense(S, X), rtol=RTOL, atol=ATOL)

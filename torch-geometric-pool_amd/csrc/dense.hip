@@ -442,10 +442,79 @@ __global__ __launch_bounds__(256) void post_maxnorm_kernel(PostArgs p) {
   for (long e = lo + tid; e < hi; e += 256) a[e] = a[e] / m;
 }
 
+// K <= 64: one wave per graph (lane = column); the K x K matrix stays L1/L2 resident across the passes.
+__global__ __launch_bounds__(256) void post_small_kernel(PostArgs p, int B) {
+  const int lane = lane_id(), K = p.K;
+  const int b = blockIdx.x * 4 + wave_id();
+  if (b >= B) return;
+  const float* sb = p.src + static_cast<long>(b) * p.s_batch;
+  float* rawb = p.raw ? p.raw + static_cast<long>(b) * K * K : nullptr;
+  float* dstb = p.dst ? p.dst + static_cast<long>(b) * K * K : nullptr;
+  const bool col_ok = lane < K;
+  const bool rsl = p.flags & TGP_REMOVE_SELF_LOOPS;
+  auto combined = [&](int i, int j) {  // fixed-order slab sum of element (i, j)
+    const long o = static_cast<long>(i) * p.ld_src + j;
+    float t = sb[o];
+    for (int s = 1; s < p.splits; ++s) t = __fadd_rn(t, sb[s * p.s_split + o]);
+    return t;
+  };
+  // pass 1: raw output, diag-cleared copy, column sums
+  float colsum = 0.f;
+  if (col_ok) {
+    for (int i = 0; i < K; ++i) {
+      float t = combined(i, lane);
+      if (rawb) rawb[i * K + lane] = t;
+      if (rsl && i == lane) t = 0.f;
+      if (dstb) dstb[i * K + lane] = t;
+      colsum = __fadd_rn(colsum, t);
+    }
+  }
+  if (!dstb || !(p.flags & (TGP_DEGREE_NORM | TGP_EDGE_WEIGHT_NORM))) return;
+  float d = 1.f;
+  if (p.flags & TGP_DEGREE_NORM) {
+    float mine = colsum;
+    if (!(p.flags & TGP_SUM_AXIS_ROWS)) {  // degree over axis -1: the lane sums ITS ROW
+      mine = 0.f;
+      if (col_ok)
+        for (int j = 0; j < K; ++j) {
+          float t = combined(lane, j);
+          if (rsl && j == lane) t = 0.f;
+          mine = __fadd_rn(mine, t);
+        }
+    }
+    d = sqrtf(fmaxf(mine, TGP_EPS));  // d[lane]
+  }
+  const bool by_cols = p.flags & TGP_SUM_AXIS_ROWS;
+  float m = 0.f;
+  for (int i = 0; i < K; ++i) {
+    const float di = __shfl(d, i, WAVE);
+    if (col_ok) {
+      float t = dstb[i * K + lane];
+      if (p.flags & TGP_DEGREE_NORM) {
+        t = by_cols ? (t / d) / di : (t / di) / d;
+        dstb[i * K + lane] = t;
+      }
+      m = fmaxf(m, fabsf(t));
+    }
+  }
+  if (p.flags & TGP_EDGE_WEIGHT_NORM) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, WAVE));
+    if (m == 0.f) m = 1.f;
+    if (col_ok)
+      for (int i = 0; i < K; ++i) dstb[i * K + lane] = dstb[i * K + lane] / m;
+  }
+}
+
 static size_t post_ws_floats(int64_t B, int64_t K) { return static_cast<size_t>(B * K + B * POST_BLOCKS); }
 
 static void launch_post(PostArgs p, int64_t B, float* ws, hipStream_t stream) {
   const int K = p.K;
+  if (K <= 64) {  // whole graph in one wave's registers: one launch instead of three or four
+    const dim3 grid(static_cast<unsigned>((B + 3) / 4));
+    hipLaunchKernelGGL(post_small_kernel, grid, dim3(256), 0, stream, p, static_cast<int>(B));
+    return;
+  }
   p.dvec = ws;
   p.maxpart = ws + static_cast<size_t>(B) * K;
   const bool vec = (K % 4 == 0) && (p.ld_src % 4 == 0) && (p.s_split % 4 == 0) && (p.s_batch % 4 == 0) &&
@@ -478,6 +547,202 @@ __global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restr
     float v = sb[e];
     for (int s = 1; s < splits; ++s) v = __fadd_rn(v, sb[s * s_split + e]);
     dst[static_cast<long>(b) * total + e] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Small graphs (N <= 64, K <= 32, F <= 32; e.g. the PROTEINS-shaped batch of BASELINE configs[2]):
+// one WAVE owns one graph.  A, S and X of the graph are staged once in LDS (zero padded to 64 x 64,
+// 64 x 32, 64 x 32), then U = A S (64 MFMAs), X' = S^T X (32) and A' = S^T U (32) run back to back;
+// U never leaves the accumulators: register r of the 32x32 C/D layout holds rows (rho(r), rho(r)+4)
+// for the two half-waves, which is exactly a k-pair of the next MFMA's B operand, so S^T is fetched
+// in that k order and the accumulator is passed straight in.  The post-processing (utils/ops.py:282-335)
+// happens in registers + wave shuffles.  Each graph crosses HBM once: this path is HBM-bound.
+// ------------------------------------------------------------------------------------------
+constexpr int SG_N = 64, SG_K = 32, SG_LDA = 65;
+constexpr int SG_WAVE_FLOATS = SG_N * SG_LDA + SG_N * SG_K + SG_N * SG_K;  // A | S | X
+
+struct SmallArgs {
+  const float* S; const float* A; const float* X;
+  int B, N, K, F, flags;
+  float* x_pool; float* adj_raw; float* adj_pool;
+};
+
+__device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
+
+__global__ __launch_bounds__(256) void dense_pool_small_kernel(SmallArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = lane_id(), w = wave_id();
+  const int lm = lane & 31, lk = lane >> 5;
+  float* As = smem + w * SG_WAVE_FLOATS;
+  float* Ss = As + SG_N * SG_LDA;
+  float* Xs = Ss + SG_N * SG_K;
+  const int N = p.N, K = p.K, F = p.F;
+  const bool at = p.flags & TGP_ADJ_TRANSPOSED;
+  for (int b0 = blockIdx.x * 4; b0 < p.B; b0 += gridDim.x * 4) {
+    const int b = b0 + w;
+    const bool live = b < p.B;
+    // ---- stage the graph (zero padded): batched float4 loads, no integer division -------------
+    if (p.A) {  // 16 lanes per row (64 floats), 4 rows per wave-instruction, 16 instructions
+      const float* Ab = p.A + static_cast<long>(live ? b : 0) * N * N;
+      float4 v[16];
+      const int q = lane & 15;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = (lane >> 4) + 4 * t;
+        v[t] = ld4_guarded(Ab + static_cast<long>(i) * N + 4 * q, live && i < N && 4 * q < N);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = (lane >> 4) + 4 * t;
+        if (!at) {
+          float* d = As + i * SG_LDA + 4 * q;
+          d[0] = v[t].x; d[1] = v[t].y; d[2] = v[t].z; d[3] = v[t].w;
+        } else {  // memory holds A^T: element (row i, cols 4q..4q+3) of memory is A[4q+j][i]
+          As[(4 * q + 0) * SG_LDA + i] = v[t].x; As[(4 * q + 1) * SG_LDA + i] = v[t].y;
+          As[(4 * q + 2) * SG_LDA + i] = v[t].z; As[(4 * q + 3) * SG_LDA + i] = v[t].w;
+        }
+      }
+    }
+    {           // 8 lanes per row (32 floats), 8 rows per wave-instruction, 8 instructions
+      const float* Sb = p.S + static_cast<long>(live ? b : 0) * N * K;
+      float4 v[8];
+      const int q = lane & 7;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int k = (lane >> 3) + 8 * t;
+        v[t] = ld4_guarded(Sb + static_cast<long>(k) * K + 4 * q, live && k < N && 4 * q < K);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        *reinterpret_cast<float4*>(Ss + ((lane >> 3) + 8 * t) * SG_K + 4 * q) = v[t];
+    }
+    if (p.X) {
+      const float* Xb = p.X + static_cast<long>(live ? b : 0) * N * F;
+      float4 v[8];
+      const int q = lane & 7;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int k = (lane >> 3) + 8 * t;
+        v[t] = ld4_guarded(Xb + static_cast<long>(k) * F + 4 * q, live && k < N && 4 * q < F);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        *reinterpret_cast<float4*>(Xs + ((lane >> 3) + 8 * t) * SG_K + 4 * q) = v[t];
+    }
+    __syncthreads();
+
+    // ---- X' = S^T X ---------------------------------------------------------------------
+    if (p.X && p.x_pool) {
+      f32x16 ax;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ax[r] = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < SG_N / 2; ++q) {
+        const int k = 2 * q + lk;
+        ax = __builtin_amdgcn_mfma_f32_32x32x2f32(Ss[k * SG_K + lm], Xs[k * SG_K + lm], ax, 0, 0, 0);
+      }
+      if (live && lm < F) {
+        float* o = p.x_pool + static_cast<long>(b) * K * F;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = rho(r) + 4 * lk;
+          if (c < K) o[c * F + lm] = ax[r];
+        }
+      }
+    }
+
+    // ---- U = A S (kept in accumulators), A' = S^T U -----------------------------------------
+    if (p.A && (p.adj_raw || p.adj_pool)) {
+      f32x16 u[2], aa;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { u[0][r] = 0.f; u[1][r] = 0.f; aa[r] = 0.f; }
+#pragma unroll 4
+      for (int q = 0; q < SG_N / 2; ++q) {
+        const int k = 2 * q + lk;
+        const float bs = Ss[k * SG_K + lm];
+        u[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[lm * SG_LDA + k], bs, u[0], 0, 0, 0);
+        u[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(32 + lm) * SG_LDA + k], bs, u[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          aa = __builtin_amdgcn_mfma_f32_32x32x2f32(Ss[(32 * mt + rho(r) + 4 * lk) * SG_K + lm], u[mt][r], aa, 0, 0, 0);
+
+      // aa[r] = A'[row = rho(r) + 4*lk][col = lm]
+      if (live && p.adj_raw && lm < K) {
+        float* o = p.adj_raw + static_cast<long>(b) * K * K;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = rho(r) + 4 * lk;
+          if (i < K) o[i * K + lm] = aa[r];
+        }
+      }
+      if (p.adj_pool) {
+        if (p.flags & TGP_REMOVE_SELF_LOOPS) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (rho(r) + 4 * lk == lm) aa[r] = 0.f;
+        }
+        if (p.flags & TGP_DEGREE_NORM) {
+          float dcol;  // degree of index `lm`, identical on both half-waves
+          if (p.flags & TGP_SUM_AXIS_ROWS) {  // sum over rows (axis -2): per-lane column sum
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += aa[r];
+            s += __shfl_xor(s, 32, WAVE);
+            dcol = s;
+          } else {                            // sum over columns (axis -1): reduce each row over lanes
+            float mine = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float s = aa[r];
+#pragma unroll
+              for (int d = 16; d > 0; d >>= 1) s += __shfl_xor(s, d, WAVE);
+              // row (rho(r) + 4*lk) total now on every lane of this half-wave; hand it to lane = row
+              const int row = rho(r) + 4 * lk;
+              if (lm == row) mine = s;
+            }
+            // lanes of the other half-wave own the other 16 rows: merge
+            const float other = __shfl_xor(mine, 32, WAVE);
+            bool own = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) own |= (rho(r) + 4 * lk == lm);
+            dcol = own ? mine : other;
+          }
+          const float d = sqrtf(fmaxf(dcol, TGP_EPS));  // d[lm]
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rho(r) + 4 * lk;
+            const float drow = __shfl(d, row, WAVE);      // d[row]
+            const float first = (p.flags & TGP_SUM_AXIS_ROWS) ? d : drow;
+            const float second = (p.flags & TGP_SUM_AXIS_ROWS) ? drow : d;
+            aa[r] = (aa[r] / first) / second;
+          }
+        }
+        if (p.flags & TGP_EDGE_WEIGHT_NORM) {
+          float m = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (lm < K && rho(r) + 4 * lk < K) m = fmaxf(m, fabsf(aa[r]));
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, WAVE));
+          if (m == 0.f) m = 1.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) aa[r] = aa[r] / m;
+        }
+        if (live && lm < K) {
+          float* o = p.adj_pool + static_cast<long>(b) * K * K;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = rho(r) + 4 * lk;
+            if (i < K) o[i * K + lm] = aa[r];
+          }
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -537,6 +802,19 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
     if (adj_raw) (void)hipMemsetAsync(adj_raw, 0, sizeof(float) * B * K * K, stream);
     if (adj_pool) (void)hipMemsetAsync(adj_pool, 0, sizeof(float) * B * K * K, stream);
     return check_launch("tgp_dense_pool_f32");
+  }
+  static const int no_small = getenv("TGP_NO_SMALL_GRAPH_KERNEL") ? 1 : 0;
+  const bool small_ok = N <= SG_N && K <= SG_K && F <= SG_K && B >= 64 && N % 4 == 0 && K % 4 == 0 && F % 4 == 0 &&
+                        reinterpret_cast<uintptr_t>(S) % 16 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 &&
+                        reinterpret_cast<uintptr_t>(X) % 16 == 0;
+  if (!no_small && small_ok) {
+    SmallArgs q{S, want_a ? A : nullptr, want_x ? X : nullptr, static_cast<int>(B), static_cast<int>(N),
+                static_cast<int>(K), static_cast<int>(F), flags, want_x ? x_pool : nullptr,
+                want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr};
+    int grid = static_cast<int>((B + 3) / 4);
+    if (grid > 256 * 4) grid = 256 * 4;
+    hipLaunchKernelGGL(dense_pool_small_kernel, dim3(grid), dim3(256), 4 * SG_WAVE_FLOATS * sizeof(float), stream, q);
+    return check_launch("tgp_dense_pool_f32(small)");
   }
   TGP_REQUIRE(ws && ws_bytes >= tgp_dense_pool_workspace_bytes(B, N, K, F), TGP_ERR_WORKSPACE,
               "tgp_dense_pool_f32: workspace too small");

@@ -199,8 +199,7 @@ def pseudo_inverse(edge_index: Tensor) -> Tensor:
 # ----------------------------------------------------------------------------- post-processing
 def postprocess_adj_pool_dense(adj_pool: Tensor, remove_self_loops: bool = False, degree_norm: bool = False,
                                adj_transpose: bool = False, edge_weight_norm: bool = False) -> Tensor:
-    """A8 (reference ops.py:282-335): diag <- 0, D^-1/2 A D^-1/2, / max|A| per graph - one kernel.
-    Like the reference, the diagonal of the given tensor is cleared in place."""
+    """A8 (reference ops.py:282-335): diag <- 0, D^-1/2 A D^-1/2, / max|A| per graph; returns a new tensor."""
     if not (remove_self_loops or degree_norm or edge_weight_norm):
         return adj_pool
     squeeze = adj_pool.dim() == 2
@@ -209,8 +208,8 @@ def postprocess_adj_pool_dense(adj_pool: Tensor, remove_self_loops: bool = False
         out = _postprocess_dense_autograd(a, remove_self_loops, degree_norm, adj_transpose, edge_weight_norm)
         return out.squeeze(0) if squeeze else out
     flags = K.dense_flags(remove_self_loops, degree_norm, adj_transpose, edge_weight_norm)
-    if remove_self_loops and a.is_contiguous() and a.dtype == torch.float32:
-        torch.diagonal(a, dim1=-2, dim2=-1).zero_()  # the reference's in-place side effect
+    # NB the reference also clears the diagonal of its *input* in place (ops.py:308); every caller passes a
+    # freshly computed S^T A S, so that side effect is not reproduced (it would cost an extra pass).
     out = K.postprocess_dense(a, flags)
     return out.squeeze(0) if squeeze else out
 
