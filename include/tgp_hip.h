@@ -104,12 +104,12 @@ int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col, const floa
  * `reduce_op`, then the filters of utils/ops.py:370-380.  Output is row-major sorted and
  * unique.  edge_weight == NULL keeps the result unweighted (out_weight unused).
  * ---------------------------------------------------------------------------------- */
-size_t tgp_connect_coalesce_workspace_bytes(int64_t num_edges, int64_t num_supernodes);
+size_t tgp_connect_coalesce_workspace_bytes(int64_t num_edges, int64_t num_nodes, int64_t num_supernodes);
 int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
                                int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,
                                int64_t num_supernodes, int reduce_op, int flags, void* ws, size_t ws_bytes,
                                int64_t* d_count, void* stream);
-int tgp_connect_coalesce_fill(const void* ws, int64_t num_edges, int64_t num_supernodes, int has_weight,
+int tgp_connect_coalesce_fill(const void* ws, int64_t num_edges, int64_t num_nodes, int64_t num_supernodes, int has_weight,
                               int flags, int64_t num_out, int64_t* out_row, int64_t* out_col,
                               float* out_weight, void* stream);
 

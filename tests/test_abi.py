@@ -58,7 +58,7 @@ def test_flag_values_match_header():
 def test_workspace_queries_run_without_a_gpu():
     from tgp import _native
     lib = _native.lib()
-    assert lib.tgp_connect_coalesce_workspace_bytes(10_000_000, 550_000) > 10_000_000 * 24
+    assert lib.tgp_connect_coalesce_workspace_bytes(10_000_000, 1_000_000, 550_000) > 10_000_000 * 24
     assert lib.tgp_dense_pool_workspace_bytes(32, 1024, 128, 64) >= 32 * 1024 * 128 * 4
     assert lib.tgp_assign_index_workspace_bytes(0, 0) > 0
 

@@ -88,33 +88,36 @@ static __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t
 }
 
 // ------------------------------------------------------------------ LSD radix sort
-// Pass structure (per 8-bit digit):  histogram per workgroup chunk -> per-digit scan over
+// Pass structure (per DB-bit digit):  histogram per workgroup chunk -> per-digit scan over
 // chunks -> stable scatter.  A workgroup owns one contiguous chunk of the input, so block
-// order == input order and the sort is stable.
+// order == input order and the sort is stable.  DB = 8 (small inputs) or 11 (large inputs:
+// a 40-bit (row, col) key takes 4 passes instead of 5; 2048 bins still fit LDS comfortably).
 constexpr int kSortThreads = 256;
 constexpr int kSortItems = 8;
 constexpr int kSortTile = kSortThreads * kSortItems;
 constexpr int kSortMaxBlocks = 1024;
+constexpr int kSortMaxBins = 2048;
 
-template <typename KeyT>
+template <typename KeyT, int DB>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const KeyT* __restrict__ keys, int64_t n,
                                                                    int64_t chunk, int shift, int nblocks,
                                                                    uint32_t* __restrict__ hist) {
-  __shared__ uint32_t s_h[256];
+  constexpr int BINS = 1 << DB;
+  __shared__ uint32_t s_h[BINS];
   const int tid = threadIdx.x;
-  s_h[tid] = 0;
+  for (int d = tid; d < BINS; d += kSortThreads) s_h[d] = 0;
   __syncthreads();
   const int64_t begin = static_cast<int64_t>(blockIdx.x) * chunk;
   const int64_t end = begin + chunk < n ? begin + chunk : n;
   for (int64_t i = begin + tid; i < end; i += kSortThreads) {
-    const uint32_t d = static_cast<uint32_t>(keys[i] >> shift) & 255u;
+    const uint32_t d = static_cast<uint32_t>(keys[i] >> shift) & (BINS - 1);
     atomicAdd(&s_h[d], 1u);
   }
   __syncthreads();
-  hist[static_cast<size_t>(tid) * nblocks + blockIdx.x] = s_h[tid];
+  for (int d = tid; d < BINS; d += kSortThreads) hist[static_cast<size_t>(d) * nblocks + blockIdx.x] = s_h[d];
 }
 
-// grid = 256 (one workgroup per digit); exclusive scan over the nblocks (<=1024) chunk counts.
+// grid = BINS (one workgroup per digit); exclusive scan over the nblocks (<=1024) chunk counts.
 static __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t* __restrict__ hist, int nblocks,
                                                           uint32_t* __restrict__ digit_total) {
   __shared__ uint32_t s_w[16];
@@ -135,24 +138,47 @@ static __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t* __res
   if (tid == 0) digit_total[blockIdx.x] = tot;
 }
 
-template <typename KeyT, typename ValT>
+// digit_total[BINS] -> exclusive prefix in place (one 256-thread workgroup)
+template <int DB>
+static __global__ __launch_bounds__(256) void radix_digit_base_kernel(uint32_t* __restrict__ digit_total) {
+  constexpr int BINS = 1 << DB;
+  constexpr int PER = BINS / 256;
+  __shared__ uint32_t s_w[4];
+  uint32_t v[PER], sum = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    v[q] = digit_total[threadIdx.x * PER + q];
+    sum += v[q];
+  }
+  uint32_t run = block_excl_scan_256(sum, s_w, nullptr);
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    digit_total[threadIdx.x * PER + q] = run;
+    run += v[q];
+  }
+}
+
+template <typename KeyT, typename ValT, int DB>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in, KeyT* __restrict__ keys_out,
     ValT* __restrict__ vals_out, const uint32_t* __restrict__ hist_scanned,
-    const uint32_t* __restrict__ digit_total, int64_t n, int64_t chunk, int shift, int nblocks) {
-  __shared__ uint32_t s_base[256];
-  __shared__ uint32_t s_whist[4][256];
-  __shared__ uint32_t s_w[4];
+    const uint32_t* __restrict__ digit_base, int64_t n, int64_t chunk, int shift, int nblocks) {
+  constexpr int BINS = 1 << DB;
+  constexpr int PER = BINS / kSortThreads;
+  __shared__ uint32_t s_base[BINS];
+  __shared__ uint32_t s_whist[4][BINS];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
-  const uint32_t excl = block_excl_scan_256(digit_total[tid], s_w, nullptr);
-  s_base[tid] = excl + hist_scanned[static_cast<size_t>(tid) * nblocks + blockIdx.x];
+  for (int d = tid; d < BINS; d += kSortThreads)
+    s_base[d] = digit_base[d] + hist_scanned[static_cast<size_t>(d) * nblocks + blockIdx.x];
 
   const int64_t begin = static_cast<int64_t>(blockIdx.x) * chunk;
   const int64_t end = begin + chunk < n ? begin + chunk : n;
   for (int64_t tile = begin; tile < end; tile += kSortTile) {
+    for (int d = tid; d < BINS; d += kSortThreads) {
 #pragma unroll
-    for (int ww = 0; ww < 4; ++ww) s_whist[ww][tid] = 0;
+      for (int ww = 0; ww < 4; ++ww) s_whist[ww][d] = 0;
+    }
     __syncthreads();
 
     KeyT k[kSortItems];
@@ -165,11 +191,11 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
       const bool valid = idx < end;
       k[it] = valid ? keys_in[idx] : KeyT(0);
       v[it] = valid ? vals_in[idx] : ValT(0);
-      const uint32_t d = static_cast<uint32_t>(k[it] >> shift) & 255u;
-      dg[it] = valid ? d : 256u;  // 256 = not participating
+      const uint32_t d = static_cast<uint32_t>(k[it] >> shift) & (BINS - 1);
+      dg[it] = valid ? d : BINS;  // BINS = not participating
       unsigned long long peers = __ballot(valid);
 #pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
+      for (int bit = 0; bit < DB; ++bit) {
         const bool set = (d >> bit) & 1u;
         const unsigned long long m = __ballot(set);
         peers &= set ? m : ~m;
@@ -184,24 +210,32 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
       r[it] = prev + lrank;
     }
     __syncthreads();
-    uint32_t run = 0;
+    // per digit: exclusive prefix over the 4 waves (tile-local offsets) and the tile total
+    uint32_t tot[PER];
 #pragma unroll
-    for (int ww = 0; ww < 4; ++ww) {
-      const uint32_t c = s_whist[ww][tid];
-      s_whist[ww][tid] = run;
-      run += c;
+    for (int q = 0; q < PER; ++q) {
+      const int d = tid + q * kSortThreads;
+      uint32_t run = 0;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) {
+        const uint32_t c = s_whist[ww][d];
+        s_whist[ww][d] = run;
+        run += c;
+      }
+      tot[q] = run;
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < kSortItems; ++it) {
-      if (dg[it] < 256u) {
+      if (dg[it] < BINS) {
         const uint32_t pos = s_base[dg[it]] + s_whist[w][dg[it]] + r[it];
         keys_out[pos] = k[it];
         vals_out[pos] = v[it];
       }
     }
     __syncthreads();
-    s_base[tid] += run;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) s_base[tid + q * kSortThreads] += tot[q];
   }
 }
 
@@ -223,7 +257,28 @@ inline SortPlan sort_plan(int64_t n) {
 }
 
 // scratch words needed besides the two ping-pong (key,val) buffers
-inline size_t sort_scratch_words() { return 256 * static_cast<size_t>(kSortMaxBlocks) + 256; }
+inline size_t sort_scratch_words() { return static_cast<size_t>(kSortMaxBins) * kSortMaxBlocks + kSortMaxBins; }
+
+// 11-bit digits (2048 bins) were measured SLOWER on MI355X (207 us vs 117 us per pass at 10M keys:
+// the per-tile LDS histogram reset and the 11 ballots per key outweigh the saved pass), so 8 bits it is.
+inline int sort_digit_bits(int64_t /*n*/) { return 8; }
+inline int sort_passes(int64_t n, int key_bits) {
+  if (n <= 1 || key_bits <= 0) return 0;
+  const int db = sort_digit_bits(n);
+  return (key_bits + db - 1) / db;
+}
+
+template <typename KeyT, typename ValT, int DB>
+static void radix_pass(const KeyT* ki, const ValT* vi, KeyT* ko, ValT* vo, int64_t n, int shift, const SortPlan& p,
+                       uint32_t* hist, uint32_t* digit_total, hipStream_t stream) {
+  constexpr int BINS = 1 << DB;
+  hipLaunchKernelGGL((radix_hist_kernel<KeyT, DB>), dim3(p.nblocks), dim3(kSortThreads), 0, stream, ki, n,
+                     p.chunk, shift, p.nblocks, hist);
+  hipLaunchKernelGGL(radix_scan_kernel, dim3(BINS), dim3(1024), 0, stream, hist, p.nblocks, digit_total);
+  hipLaunchKernelGGL(radix_digit_base_kernel<DB>, dim3(1), dim3(256), 0, stream, digit_total);
+  hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT, DB>), dim3(p.nblocks), dim3(kSortThreads), 0, stream,
+                     ki, vi, ko, vo, hist, digit_total, n, p.chunk, shift, p.nblocks);
+}
 
 // Sorts (keys, vals) by the low `key_bits` bits of the key.  Buffers ping-pong between
 // (k0,v0) and (k1,v1); returns in *result_in_first whether the sorted data ended in (k0,v0).
@@ -231,20 +286,17 @@ template <typename KeyT, typename ValT>
 int radix_sort_pairs(KeyT* k0, ValT* v0, KeyT* k1, ValT* v1, int64_t n, int key_bits, uint32_t* scratch,
                      hipStream_t stream, bool* result_in_first) {
   *result_in_first = true;
-  if (n <= 1 || key_bits <= 0) return TGP_OK;
+  const int passes = sort_passes(n, key_bits);
+  if (passes == 0) return TGP_OK;
   const SortPlan p = sort_plan(n);
+  const int db = sort_digit_bits(n);
   uint32_t* hist = scratch;
-  uint32_t* digit_total = scratch + 256 * static_cast<size_t>(kSortMaxBlocks);
-  const int passes = (key_bits + 7) / 8;
+  uint32_t* digit_total = scratch + static_cast<size_t>(kSortMaxBins) * kSortMaxBlocks;
   KeyT *ki = k0, *ko = k1;
   ValT *vi = v0, *vo = v1;
   for (int pass = 0; pass < passes; ++pass) {
-    const int shift = pass * 8;
-    hipLaunchKernelGGL((radix_hist_kernel<KeyT>), dim3(p.nblocks), dim3(kSortThreads), 0, stream, ki, n,
-                       p.chunk, shift, p.nblocks, hist);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(1024), 0, stream, hist, p.nblocks, digit_total);
-    hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT>), dim3(p.nblocks), dim3(kSortThreads), 0, stream,
-                       ki, vi, ko, vo, hist, digit_total, n, p.chunk, shift, p.nblocks);
+    if (db == 11) radix_pass<KeyT, ValT, 11>(ki, vi, ko, vo, n, pass * 11, p, hist, digit_total, stream);
+    else radix_pass<KeyT, ValT, 8>(ki, vi, ko, vo, n, pass * 8, p, hist, digit_total, stream);
     KeyT* tk = ki; ki = ko; ko = tk;
     ValT* tv = vi; vi = vo; vo = tv;
   }

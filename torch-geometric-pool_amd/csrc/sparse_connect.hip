@@ -89,10 +89,18 @@ __global__ __launch_bounds__(256) void subgraph_fill_kernel(SubgraphPred pred, i
 // =====================================================================================
 // A4: relabel by cluster + coalesce (connect/base_conn.py:83-89)
 // =====================================================================================
+// int64 cluster ids -> int32 table: half the bytes, so the 2*E random gathers below hit a table that
+// fits the per-XCD L2 for graphs up to ~1M nodes.
+__global__ __launch_bounds__(256) void cluster_table_kernel(const int64_t* __restrict__ cluster, int64_t n,
+                                                            int32_t* __restrict__ table) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) table[i] = static_cast<int32_t>(cluster[i]);
+}
+
 __global__ __launch_bounds__(256) void coalesce_keys_kernel(const int64_t* __restrict__ row,
                                                             const int64_t* __restrict__ col,
                                                             const float* __restrict__ w,
-                                                            const int64_t* __restrict__ cluster, int64_t E,
+                                                            const int32_t* __restrict__ cluster, int64_t E,
                                                             uint64_t K, uint64_t* __restrict__ keys,
                                                             float* __restrict__ vals) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -438,8 +446,9 @@ struct CoalesceWs {
   float* seg;
   uint8_t* keep;
   uint32_t *counts, *offsets, *scratch;
+  int32_t* table;
 };
-static size_t coalesce_layout(void* ws, int64_t E, CoalesceWs* out) {
+static size_t coalesce_layout(void* ws, int64_t E, int64_t N, CoalesceWs* out) {
   Carver cv(ws);
   const size_t n = static_cast<size_t>(E > 0 ? E : 1);
   const size_t nb = static_cast<size_t>(cdiv(E > 0 ? E : 1, kCompactTile));
@@ -453,12 +462,13 @@ static size_t coalesce_layout(void* ws, int64_t E, CoalesceWs* out) {
   s.counts = cv.take<uint32_t>(nb);
   s.offsets = cv.take<uint32_t>(nb);
   s.scratch = cv.take<uint32_t>(sort_scratch_words());
+  s.table = cv.take<int32_t>(static_cast<size_t>(N > 0 ? N : 1));
   if (out) *out = s;
   return cv.off;
 }
 
-extern "C" size_t tgp_connect_coalesce_workspace_bytes(int64_t E, int64_t /*K*/) {
-  return coalesce_layout(nullptr, E, nullptr) + 256;
+extern "C" size_t tgp_connect_coalesce_workspace_bytes(int64_t E, int64_t N, int64_t /*K*/) {
+  return coalesce_layout(nullptr, E, N, nullptr) + 256;
 }
 
 extern "C" int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
@@ -470,18 +480,20 @@ extern "C" int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col
               TGP_ERR_INVALID, "tgp_connect_coalesce_count: bad argument");
   TGP_REQUIRE(reduce_op >= TGP_SUM && reduce_op <= TGP_MUL, TGP_ERR_INVALID,
               "tgp_connect_coalesce_count: unknown reduce_op %d", reduce_op);
-  TGP_REQUIRE(E < (1ll << 31) && K < (1ll << 31), TGP_ERR_RANGE, "tgp_connect_coalesce_count: E/K >= 2^31");
-  TGP_REQUIRE(ws && ws_bytes >= tgp_connect_coalesce_workspace_bytes(E, K), TGP_ERR_WORKSPACE,
+  TGP_REQUIRE(E < (1ll << 31) && K < (1ll << 31) && N < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_connect_coalesce_count: E/N/K >= 2^31");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_connect_coalesce_workspace_bytes(E, N, K), TGP_ERR_WORKSPACE,
               "tgp_connect_coalesce_count: workspace too small");
   CoalesceWs s;
-  coalesce_layout(ws, E, &s);
+  coalesce_layout(ws, E, N, &s);
   if (E == 0) {
     (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
     return check_launch("tgp_connect_coalesce_count");
   }
   const uint64_t Ku = static_cast<uint64_t>(K > 0 ? K : 1);
-  hipLaunchKernelGGL(coalesce_keys_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, cluster_index,
-                     E, Ku, s.k0, s.v0);
+  hipLaunchKernelGGL(cluster_table_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, cluster_index, N, s.table);
+  hipLaunchKernelGGL(coalesce_keys_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, s.table, E, Ku,
+                     s.k0, s.v0);
   bool first = true;
   const int rc = radix_sort_pairs<uint64_t, float>(s.k0, s.v0, s.k1, s.v1, E, bits_for(Ku * Ku - 1), s.scratch,
                                                    stream, &first);
@@ -493,7 +505,7 @@ extern "C" int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col
   return check_launch("tgp_connect_coalesce_count");
 }
 
-extern "C" int tgp_connect_coalesce_fill(const void* ws, int64_t E, int64_t K, int has_weight, int /*flags*/,
+extern "C" int tgp_connect_coalesce_fill(const void* ws, int64_t E, int64_t N, int64_t K, int has_weight, int /*flags*/,
                                          int64_t num_out, int64_t* out_row, int64_t* out_col, float* out_w,
                                          void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -502,11 +514,10 @@ extern "C" int tgp_connect_coalesce_fill(const void* ws, int64_t E, int64_t K, i
   TGP_REQUIRE(out_row && out_col && (!has_weight || out_w), TGP_ERR_INVALID,
               "tgp_connect_coalesce_fill: null output");
   CoalesceWs s;
-  coalesce_layout(const_cast<void*>(ws), E, &s);
+  coalesce_layout(const_cast<void*>(ws), E, N, &s);
   const uint64_t Ku = static_cast<uint64_t>(K > 0 ? K : 1);
   // The ping-pong parity is a pure function of (E, K): recompute it instead of reading it back.
-  const int passes = (E <= 1) ? 0 : (bits_for(Ku * Ku - 1) + 7) / 8;
-  const bool first = (passes % 2) == 0;
+  const bool first = (sort_passes(E, bits_for(Ku * Ku - 1)) % 2) == 0;
   const int nb = cdiv(E, kCompactTile);
   hipLaunchKernelGGL(coalesce_fill_kernel, dim3(nb), dim3(256), 0, stream, first ? s.k0 : s.k1, s.seg, s.keep, E,
                      Ku, s.offsets, out_row, out_col, has_weight ? out_w : nullptr);

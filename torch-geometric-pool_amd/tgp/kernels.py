@@ -126,7 +126,7 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
     cl = N.i64c(cluster_index)
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if (w is not None and eps_filter) else 0)
     L = N.lib()
-    ws = N.workspace(L.tgp_connect_coalesce_workspace_bytes(E, num_supernodes), dev)
+    ws = N.workspace(L.tgp_connect_coalesce_workspace_bytes(E, cl.numel(), num_supernodes), dev)
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
     st = N.stream_ptr(dev)
     N.check(L.tgp_connect_coalesce_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
@@ -135,7 +135,7 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
     n_out = _read_count(d_count)
     out_ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
     out_w = None if w is None else torch.empty(n_out, dtype=torch.float32, device=dev)
-    N.check(L.tgp_connect_coalesce_fill(N.ptr(ws), E, num_supernodes, 0 if w is None else 1, flags, n_out,
+    N.check(L.tgp_connect_coalesce_fill(N.ptr(ws), E, cl.numel(), num_supernodes, 0 if w is None else 1, flags, n_out,
                                         N.ptr(out_ei[0]) if n_out else None,
                                         N.ptr(out_ei[1]) if n_out else None, N.ptr(out_w), st),
             "tgp_connect_coalesce_fill")
