@@ -213,7 +213,7 @@ def main():
 
     from tgp import _native, kernels
     from tgp.connect import DenseConnect
-    from tgp.distributed import all_gather_dense
+    from tgp.distributed import PackedGather
     from tgp.reduce import BaseReduce
     from tgp.select import SelectOutput
     _native.lib()
@@ -233,15 +233,22 @@ def main():
     so = SelectOutput(s=S)
     reducer, connector = BaseReduce(), DenseConnect()  # DiffPool defaults (diffpool.py:98-115)
 
+    gather = PackedGather() if distributed else None
+
     def step():
         with torch.no_grad():
             x_pool, _ = reducer(X, so)
             adj_pool, _ = connector(A, so)
             if distributed:
-                x_pool, adj_pool = all_gather_dense([x_pool, adj_pool])
+                # one packed RCCL all-gather per step, overlapped with the next step's kernels:
+                # finish the previous step's gather, then start this one
+                gather.wait()
+                gather.start([x_pool, adj_pool])
         return x_pool, adj_pool
 
     def sync():
+        if distributed:
+            gather.wait()  # the last step's gather belongs to the timed region
         torch.cuda.synchronize(dev)
 
     def barrier():

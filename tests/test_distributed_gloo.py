@@ -57,8 +57,13 @@ def _worker(rank, world, port, out_dir):
         xp = O.reduce_dense(sl, xdl)
         ap = O.postprocess_dense(O.dense_connect(sl, al), True, True, True, False)
         gxp, gap = D.all_gather_dense([xp, ap])
+        # packed single-collective variant (equal graph counts per rank): graphs 0..3 only
+        pg = D.PackedGather()
+        pg.start([xp[:2], ap[:2]])
+        pxp, pap = pg.wait()
         if rank == 0:
-            torch.save(dict(gx=gx, gei=gei, gew=gew, gb=gb, gxp=gxp, gap=gap), os.path.join(out_dir, "gathered.pt"))
+            torch.save(dict(gx=gx, gei=gei, gew=gew, gb=gb, gxp=gxp, gap=gap, pxp=pxp, pap=pap),
+                       os.path.join(out_dir, "gathered.pt"))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -98,5 +103,8 @@ def test_two_rank_gather_matches_single_process(tmp_path):
     xd, ad, mask = O.dense_preprocessing(x, ei, ew, batch, True)
     s = torch.softmax(xd @ torch.ones(4, 3), -1) * mask.unsqueeze(-1)
     torch.testing.assert_close(got["gxp"], O.reduce_dense(s, xd), rtol=1e-6, atol=1e-6)
-    torch.testing.assert_close(got["gap"], O.postprocess_dense(O.dense_connect(s, ad), True, True, True, False),
-                               rtol=1e-6, atol=1e-6)
+    ap_full = O.postprocess_dense(O.dense_connect(s, ad), True, True, True, False)
+    torch.testing.assert_close(got["gap"], ap_full, rtol=1e-6, atol=1e-6)
+    # packed gather took graphs [0,1] of rank 0 (global 0,1) and [0,1] of rank 1 (global 3,4)
+    torch.testing.assert_close(got["pxp"], O.reduce_dense(s, xd)[[0, 1, 3, 4]], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(got["pap"], ap_full[[0, 1, 3, 4]], rtol=1e-6, atol=1e-6)

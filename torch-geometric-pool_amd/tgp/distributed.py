@@ -53,6 +53,44 @@ def _world(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+class PackedGather:
+    """One RCCL all-gather per step for fixed-shape pooled outputs: the per-graph tensors
+    ([B,K,F], [B,K,K], ...) are packed into one [B, total] buffer, gathered asynchronously on RCCL's own
+    stream (so it overlaps the next step's kernels) and unpacked on ``wait()``.  Every rank must hold
+    the same number of graphs."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = _world(group)
+        self._pending = None
+
+    def start(self, tensors: Sequence[Tensor]):
+        b = tensors[0].size(0)
+        shapes = [tuple(t.shape[1:]) for t in tensors]
+        packed = torch.cat([t.reshape(b, -1) for t in tensors], dim=1)
+        out = torch.empty((self.world * b, packed.size(1)), dtype=packed.dtype, device=packed.device)
+        work = dist.all_gather_into_tensor(out, packed, group=self.group, async_op=True) if self.world > 1 else None
+        if self.world == 1:
+            out.copy_(packed)
+        self._pending = (work, out, shapes)
+
+    def wait(self) -> Optional[List[Tensor]]:
+        if self._pending is None:
+            return None
+        work, out, shapes = self._pending
+        self._pending = None
+        if work is not None:
+            work.wait()
+        res, col = [], 0
+        for shp in shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            res.append(out[:, col: col + n].reshape((out.size(0),) + shp))
+            col += n
+        return res
+
+
 def all_gather_dense(tensors: Sequence[Tensor], group=None) -> List[Tensor]:
     """Gather fixed-shape per-graph outputs ([B_local, K, F], [B_local, K, K], ...) from every rank and
     concatenate along the graph dimension.  Ranks may hold different B_local (padded to the max)."""
