@@ -48,7 +48,6 @@ struct GemmArgs {
   int splits;              // split of Kd across workgroups
   int k_per_split;         // multiple of BK
   const int64_t* k_ptr;    // optional [batches+1]: batch b reduces over rows k_ptr[b]..k_ptr[b+1]
-  int stagger;             // s_sleep units (64 cycles each) for the second half of the grid
 };
 
 __device__ __forceinline__ float4 ld4_guarded(const float* p, bool ok) {
@@ -200,11 +199,6 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
   float* L0 = smem;
   float* L1 = smem + STAGE_FLOATS;
   auto kof = [&](int t) { return k_begin + t * BK; };
-  // Co-resident workgroups start together and run the same instruction stream, so their non-MFMA
-  // phases (LDS refill, barrier) coincide and the matrix pipe idles during them.  Delaying the
-  // second wave of workgroups by about half a stage keeps one of them on the pipe (speed only).
-  if (g.stagger > 0 && blockIdx.x >= gridDim.x / 2)
-    for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(1);
   if (nk > 0) {
     load_tiles(ra0, rb0, kof(0));
     store_stage(ra0, rb0, L0, L0 + A_TILE_FLOATS);
@@ -287,8 +281,6 @@ static void launch_gemm_cfg(const GemmArgs& g, int batches, hipStream_t stream) 
 // g.tiles_* are filled in here: they follow from the tile shape chosen for this problem.
 template <bool A_KMAJOR>
 static void launch_gemm(GemmArgs g, int batches, hipStream_t stream) {
-  static const int stagger = getenv("TGP_GEMM_STAGGER") ? atoi(getenv("TGP_GEMM_STAGGER")) : 0;
-  g.stagger = stagger;
   const int64_t max_nc = g.rhs[1].Bm && g.rhs[1].Nc > g.rhs[0].Nc ? g.rhs[1].Nc : g.rhs[0].Nc;
   const TileCfg t = pick_tile(g.M, max_nc, static_cast<int64_t>(batches) * g.splits, g);
   g.tiles_m = cdiv(g.M, t.bm);
