@@ -161,6 +161,16 @@ size_t tgp_postprocess_dense_workspace_bytes(int64_t B, int64_t K);
 int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K, int flags, void* ws,
                               size_t ws_bytes, void* stream);
 
+/* A11  DenseSRCPooling.preprocessing (src.py:374-452 -> PyG to_dense_adj / to_dense_batch): the step
+ * right before the timed path.  batch must be sorted; ptr[B+1] = exclusive prefix of the graph sizes.
+ * adj [B,Nmax,Nmax] / out [B,Nmax,F] / mask [B,Nmax] are zero-filled inside.  transposed != 0 writes
+ * A^T (what src.py:442-443 produces as a view).  Duplicated edges are summed (float atomics). */
+int tgp_to_dense_adj_f32(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL = ones */,
+                         int64_t num_edges, const int64_t* batch, const int64_t* ptr, int64_t B, int64_t Nmax,
+                         int transposed, float* adj, void* stream);
+int tgp_to_dense_batch_f32(const float* x, int64_t num_nodes, int64_t num_features, const int64_t* batch,
+                           const int64_t* ptr, int64_t B, int64_t Nmax, float* out, uint8_t* mask, void* stream);
+
 /* A10  dense_to_block_diag (utils/ops.py:53-82): entries with |a| > 1e-8 in (b,row,col)
  * order, offset by b*K; optional valid-supernode mask [B*K] (src.py:526-552) drops and
  * renumbers supernodes (relabel[B*K] int64: new id or -1, NULL = keep all).             */

@@ -1,0 +1,77 @@
+// A11: sparse -> padded dense (the step right before the timed path).
+// Reference: DenseSRCPooling.preprocessing (tgp/src.py:374-452) calls PyG to_dense_adj (scatter-add of the
+// edge weights into zeros [B,Nmax,Nmax], duplicates summed) and to_dense_batch (row scatter + mask).  Here:
+// one memset + one edge-parallel kernel, one memset + one row-parallel kernel.  The transposed adjacency
+// the reference builds as a view (src.py:442-443) is written directly, so the GEMMs read a plain layout.
+#include "common.h"
+
+namespace tgp {
+
+__global__ __launch_bounds__(256) void dense_adj_kernel(const int64_t* __restrict__ row,
+                                                        const int64_t* __restrict__ col,
+                                                        const float* __restrict__ w, int64_t E,
+                                                        const int64_t* __restrict__ batch,
+                                                        const int64_t* __restrict__ ptr, int64_t Nmax,
+                                                        int transposed, float* __restrict__ adj) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int64_t r = row[e], c = col[e];
+  const int64_t b = batch[r];
+  const int64_t lr = r - ptr[b], lc = c - ptr[batch[c]];
+  if (lr >= Nmax || lc >= Nmax) return;  // PyG drops entries beyond max_num_nodes
+  const int64_t o = transposed ? (b * Nmax + lc) * Nmax + lr : (b * Nmax + lr) * Nmax + lc;
+  // no-return float atomic; duplicates (the only contended case) are summed as PyG's scatter-add does
+  atomicAdd(adj + o, w ? w[e] : 1.0f);
+}
+
+__global__ __launch_bounds__(256) void dense_batch_kernel(const float* __restrict__ x, int64_t N, int64_t F,
+                                                          const int64_t* __restrict__ batch,
+                                                          const int64_t* __restrict__ ptr, int64_t Nmax,
+                                                          float* __restrict__ out, uint8_t* __restrict__ mask) {
+  const int64_t total = N * F;
+  for (int64_t o = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; o < total;
+       o += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t i = o / F, f = o - i * F;
+    const int64_t b = batch[i];
+    const int64_t li = i - ptr[b];
+    if (li >= Nmax) continue;
+    out[(b * Nmax + li) * F + f] = x[o];
+    if (f == 0 && mask) mask[b * Nmax + li] = 1;
+  }
+}
+
+}  // namespace tgp
+
+using namespace tgp;
+
+extern "C" int tgp_to_dense_adj_f32(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                    const int64_t* batch, const int64_t* ptr, int64_t B, int64_t Nmax,
+                                    int transposed, float* adj, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E >= 0 && B >= 0 && Nmax >= 0, TGP_ERR_INVALID, "tgp_to_dense_adj_f32: negative size");
+  if (B == 0 || Nmax == 0) return TGP_OK;
+  TGP_REQUIRE(adj && (E == 0 || (row && col && batch && ptr)), TGP_ERR_INVALID, "tgp_to_dense_adj_f32: null pointer");
+  (void)hipMemsetAsync(adj, 0, sizeof(float) * B * Nmax * Nmax, stream);
+  if (E > 0)
+    hipLaunchKernelGGL(dense_adj_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, E, batch, ptr, Nmax,
+                       transposed, adj);
+  return check_launch("tgp_to_dense_adj_f32");
+}
+
+extern "C" int tgp_to_dense_batch_f32(const float* x, int64_t N, int64_t F, const int64_t* batch,
+                                      const int64_t* ptr, int64_t B, int64_t Nmax, float* out, uint8_t* mask,
+                                      void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(N >= 0 && F >= 0 && B >= 0 && Nmax >= 0, TGP_ERR_INVALID, "tgp_to_dense_batch_f32: negative size");
+  if (B == 0 || Nmax == 0) return TGP_OK;
+  TGP_REQUIRE(out && (N == 0 || (x && batch && ptr)), TGP_ERR_INVALID, "tgp_to_dense_batch_f32: null pointer");
+  (void)hipMemsetAsync(out, 0, sizeof(float) * B * Nmax * F, stream);
+  if (mask) (void)hipMemsetAsync(mask, 0, static_cast<size_t>(B) * Nmax, stream);
+  if (N > 0 && F > 0) {
+    int64_t blocks = (N * F + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(dense_batch_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, x, N, F, batch,
+                       ptr, Nmax, out, mask);
+  }
+  return check_launch("tgp_to_dense_batch_f32");
+}

@@ -298,3 +298,31 @@ def block_diag_edges(adj_pool: Tensor, relabel: Optional[Tensor] = None,
                                   N.ptr(ei[0]) if n_out else None, N.ptr(ei[1]) if n_out else None,
                                   N.ptr(ew) if n_out else None, st), "tgp_block_diag_fill")
     return ei, ew
+
+
+# ------------------------------------------------------------------------- A11
+def to_dense_adj(edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor, ptr: Tensor, num_graphs: int,
+                 max_nodes: int, transposed: bool) -> Tensor:
+    """PyG to_dense_adj (src.py:434-443): [B,Nmax,Nmax], duplicates summed; optionally written transposed."""
+    dev = N.require_device(edge_index, edge_weight, batch, ptr)
+    row, col = _edge_rows(edge_index)
+    w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
+    batch, ptr = N.i64c(batch), N.i64c(ptr)
+    adj = torch.empty(num_graphs, max_nodes, max_nodes, dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_to_dense_adj_f32(N.ptr(row), N.ptr(col), N.ptr(w), row.numel(), N.ptr(batch), N.ptr(ptr),
+                                         num_graphs, max_nodes, 1 if transposed else 0, N.ptr(adj),
+                                         N.stream_ptr(dev)), "tgp_to_dense_adj_f32")
+    return adj
+
+
+def to_dense_batch(x: Tensor, batch: Tensor, ptr: Tensor, num_graphs: int, max_nodes: int) -> Tuple[Tensor, Tensor]:
+    """PyG to_dense_batch (src.py:448-450): ([B,Nmax,F], mask [B,Nmax])."""
+    dev = N.require_device(x, batch, ptr)
+    x2 = N.f32c(x if x.dim() == 2 else x.reshape(x.size(0), -1))
+    batch, ptr = N.i64c(batch), N.i64c(ptr)
+    F = x2.size(1)
+    out = torch.empty(num_graphs, max_nodes, F, dtype=torch.float32, device=dev)
+    mask = torch.empty(num_graphs, max_nodes, dtype=torch.bool, device=dev)
+    N.check(N.lib().tgp_to_dense_batch_f32(N.ptr(x2), x2.size(0), F, N.ptr(batch), N.ptr(ptr), num_graphs, max_nodes,
+                                           N.ptr(out), N.ptr(mask), N.stream_ptr(dev)), "tgp_to_dense_batch_f32")
+    return out.view((num_graphs, max_nodes) + tuple(x.shape[1:])), mask

@@ -189,6 +189,8 @@ def to_dense_batch(x: Tensor, batch: Optional[Tensor] = None, max_num_nodes: Opt
     sizes, ptr = graph_ptr(batch, batch_size)
     if max_num_nodes is None:
         max_num_nodes = int(sizes.max())
+    if x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad):
+        return K.to_dense_batch(x, batch, ptr, batch_size, max_num_nodes)  # one HIP kernel
     local = torch.arange(batch.numel(), device=x.device) - ptr[batch]
     keep = local < max_num_nodes
     slot = (local + batch * max_num_nodes)[keep]
@@ -200,7 +202,8 @@ def to_dense_batch(x: Tensor, batch: Optional[Tensor] = None, max_num_nodes: Opt
 
 
 def to_dense_adj(edge_index: Tensor, batch: Optional[Tensor] = None, edge_attr: Optional[Tensor] = None,
-                 max_num_nodes: Optional[int] = None, batch_size: Optional[int] = None) -> Tensor:
+                 max_num_nodes: Optional[int] = None, batch_size: Optional[int] = None,
+                 transposed: bool = False) -> Tensor:
     """Edge list -> [B,Nmax,Nmax], duplicates summed (the algorithm of PyG ``to_dense_adj``; with
     ``batch=None`` the node count is inferred from ``edge_index.max()+1`` exactly as PyG does)."""
     if batch is None:
@@ -209,6 +212,10 @@ def to_dense_adj(edge_index: Tensor, batch: Optional[Tensor] = None, edge_attr: 
     if batch_size is None:
         batch_size = int(batch.max()) + 1 if batch.numel() > 0 else 1
     sizes, ptr = graph_ptr(batch, batch_size)
+    if (edge_index.is_cuda and (edge_attr is None or (edge_attr.dim() == 1 and edge_attr.dtype == torch.float32
+                                                      and not (torch.is_grad_enabled() and edge_attr.requires_grad)))):
+        nmax = max_num_nodes if max_num_nodes is not None else (int(sizes.max()) if sizes.numel() else 0)
+        return K.to_dense_adj(edge_index, edge_attr, batch, ptr, batch_size, nmax, transposed)  # one HIP kernel
     g = batch[edge_index[0]]
     r = edge_index[0] - ptr[g]
     c = edge_index[1] - ptr[batch[edge_index[1]]]
@@ -221,7 +228,8 @@ def to_dense_adj(edge_index: Tensor, batch: Optional[Tensor] = None, edge_attr: 
     w = torch.ones(g.numel(), device=edge_index.device) if edge_attr is None else edge_attr
     flat = w.new_zeros((batch_size * max_num_nodes * max_num_nodes,) + tuple(w.shape[1:]))
     flat.index_add_(0, (g * max_num_nodes + r) * max_num_nodes + c, w)
-    return flat.view((batch_size, max_num_nodes, max_num_nodes) + tuple(w.shape[1:]))
+    adj = flat.view((batch_size, max_num_nodes, max_num_nodes) + tuple(w.shape[1:]))
+    return adj.transpose(1, 2) if transposed else adj
 
 
 class DenseSRCPooling(SRCPooling):
@@ -245,9 +253,9 @@ class DenseSRCPooling(SRCPooling):
             adj = self.preprocessing_cache
         else:
             ei, ew = connectivity_to_edge_index(edge_index, edge_weight)
-            adj = to_dense_adj(ei, batch, ew, max_num_nodes, batch_size)
-            if self.adj_transpose:
-                adj = adj.transpose(-1, -2)  # a view: the GEMM kernel reads it through TGP_ADJ_TRANSPOSED
+            # adj_transpose (src.py:442-443): the HIP kernel writes A^T directly; the torch path (host
+            # tensors / autograd through edge weights) returns the transposed view the reference builds
+            adj = to_dense_adj(ei, batch, ew, max_num_nodes, batch_size, transposed=self.adj_transpose)
             if use_cache:
                 self.preprocessing_cache = adj
         x, mask = to_dense_batch(x, batch, max_num_nodes, batch_size)
