@@ -85,3 +85,20 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "tgp_oracle" not in src and "import oracle" not in src, f
+
+
+def test_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument validation happens before any HIP call, so it can be exercised on the CPU box."""
+    from tgp import _native
+    lib = _native.lib()
+    assert lib.tgp_reduce_sparse_f32(None, -1, 4, 4, None, None, None, None, 0, 1, None, None) == -1  # TGP_ERR_INVALID
+    assert b"tgp_reduce_sparse_f32" in lib.tgp_last_error()
+    assert lib.tgp_connect_coalesce_count(None, None, None, 5, None, 4, 2, 99, 0, None, 0, None, None) == -1
+    assert lib.tgp_connect_coalesce_count(None, None, None, 1 << 31, None, 4, 2, 0, 0, None, 0, None, None) == -1
+    dummy = ctypes.c_int64(0)
+    p = ctypes.addressof(dummy)
+    # valid pointers but a workspace that is too small -> TGP_ERR_WORKSPACE, message names the call
+    assert lib.tgp_connect_subgraph_count(p, p, None, 10, None, 0, 10, 0, p, 8, p, None) == -2
+    assert b"workspace too small" in lib.tgp_last_error()
+    assert lib.tgp_dense_pool_f32(p, p, p, 1, 1 << 31, 4, 4, 0, p, None, p, p, 1 << 20, None) == -4  # TGP_ERR_RANGE
+    assert lib.tgp_block_diag_count(p, 70000, 70000, None, 0, p, 1 << 20, p, None) == -4

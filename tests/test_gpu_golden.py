@@ -405,3 +405,47 @@ def test_empty_graph_edge_cases(dev):
     x = torch.randn(4, 3, device=dev)
     with pytest.raises(ValueError, match="return_batched=True is only supported"):
         BaseReduce()(x, so, return_batched=True)
+
+
+# ----------------------------------------------------------------------------------- protocol behaviour
+def test_pooler_protocol_forward_lift_cache(golden, dev):
+    """What reference tests/test_poolers.py:25-136 exercises for every alias: forward -> lift -> caching ->
+    clear_cache -> reset_parameters, on the five poolers of the path."""
+    from tgp.poolers import get_pooler
+    from tgp.src import PoolingOutput
+    i = golden["topk_batch_w_default"]["inputs"]
+    x, ei, ew, batch = (D(i[k], dev) for k in ("x", "edge_index", "edge_weight", "batch"))
+    n, f = x.shape
+    for alias, kw in (("topk", dict(in_channels=f, ratio=0.5)), ("graclus", {}), ("ndp", {}),
+                      ("diff", dict(in_channels=f, k=4)), ("mincut", dict(in_channels=f, k=4)),
+                      ("diff_u", dict(in_channels=f, k=4)), ("mincut_u", dict(in_channels=f, k=4))):
+        pool = get_pooler(alias, **kw).to(dev).eval()
+        pool.reset_parameters()
+        with torch.no_grad():
+            out = pool(x=x, adj=ei, edge_weight=ew, batch=batch)
+            assert isinstance(out, PoolingOutput) and out.so.num_nodes in (n, out.so.s.size(-2))
+            lifted = pool(x=out.x, so=out.so, batch=batch, batch_pooled=out.batch, lifting=True)
+        if pool.is_dense and pool.batched:
+            assert lifted.shape[-1] == f and lifted.dim() == 3
+        else:
+            assert lifted.shape == (n, f)
+        assert torch.isfinite(lifted).all()
+    # caching (reference tests/poolers/test_graclus.py:30-47): same SelectOutput and pooled graph reused
+    pool = get_pooler("graclus", cached=True)
+    a = pool(x=x, adj=ei, edge_weight=ew, batch=batch)
+    b = pool(x=x, adj=ei, edge_weight=ew, batch=batch)
+    assert b.so is a.so and b.edge_index is a.edge_index and torch.equal(a.x, b.x)
+    pool.clear_cache()
+    c = pool(x=x, adj=ei, edge_weight=ew, batch=batch)
+    assert c.so is not a.so and torch.equal(c.x, a.x)
+    # dense preprocessing cache is only used for single-graph inputs
+    dp = get_pooler("diff", in_channels=f, k=3, cache_preprocessing=True).to(dev).eval()
+    with torch.no_grad():
+        dp(x=x, adj=ei, edge_weight=ew, batch=batch)
+        assert dp.preprocessing_cache is None
+        one = batch == 0
+        keep = one[ei[0]]
+        dp(x=x[one], adj=ei[:, keep], edge_weight=ew[keep], batch=batch[one])
+        assert dp.preprocessing_cache is not None
+        dp.clear_cache()
+        assert dp.preprocessing_cache is None
