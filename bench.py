@@ -137,6 +137,9 @@ def run_other_workload(args, dev):
         keep = a != b
         a, b = a[keep], b[keep]
         ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+        if not args.unsorted_edges:
+            # PyG hands out row-major sorted edge lists (to_undirected / coalesce); sort once at set-up
+            ei = ei[:, torch.argsort(ei[0] * n + ei[1])]
         ew = torch.ones(ei.size(1), device=dev)
         x = torch.randn(n, f, device=dev, generator=g)
         batch = torch.zeros(n, dtype=torch.long, device=dev)
@@ -145,7 +148,8 @@ def run_other_workload(args, dev):
             so = GraclusSelect()(ei, ew, num_nodes=n)
             conn = SparseConnect()
             k = so.num_supernodes
-            extra = {"num_supernodes": k, "edges": int(ei.size(1))}
+            extra = {"num_supernodes": k, "edges": int(ei.size(1)),
+                     "edge_order": "random" if args.unsorted_edges else "row-major sorted (PyG convention)"}
 
             def step():
                 so._drop_caches()  # rebuild the inverted index every step (no cross-step caching)
@@ -197,6 +201,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unsorted-edges", action="store_true",
+                    help="c4_graclus: leave the synthetic edge list in random order (forces the sort-based coalesce)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

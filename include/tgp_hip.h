@@ -113,6 +113,22 @@ int tgp_connect_coalesce_fill(const void* ws, int64_t num_edges, int64_t num_nod
                               int flags, int64_t num_out, int64_t* out_row, int64_t* out_col,
                               float* out_weight, void* stream);
 
+/* A4 + A6 fast path for ROW-SORTED edge lists (the PyG default): no global sort.  Edges are grouped by
+ * supernode row through the CSR of the input and the supernode->member index of the assignment
+ * (assign_row_ptr / assign_perm = what tgp_assign_index_build returns for cluster_index), then every short
+ * row segment is ordered by column, merged and filtered inside LDS.  Same output as the sort-based pair
+ * above.  If the rows are not sorted, or a block of 256 supernode rows exceeds the LDS budget, *d_count is
+ * set to -1 and the caller uses tgp_connect_coalesce_{count,fill} instead. */
+size_t tgp_connect_coalesce_rows_workspace_bytes(int64_t num_edges, int64_t num_nodes, int64_t num_supernodes);
+int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
+                                    int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,
+                                    int64_t num_supernodes, const int32_t* assign_row_ptr,
+                                    const int32_t* assign_perm, int reduce_op, int flags, void* ws,
+                                    size_t ws_bytes, int64_t* d_count, void* stream);
+int tgp_connect_coalesce_rows_fill(const void* ws, int64_t num_edges, int64_t num_nodes, int64_t num_supernodes,
+                                   int has_weight, int64_t num_out, int64_t* out_row, int64_t* out_col,
+                                   float* out_weight, void* stream);
+
 /* A6 (rest)  degree / per-graph max normalisation of a pooled edge list, in place
  * (utils/ops.py:383-417).  edge_weight must be initialised (ones when the list was
  * unweighted, ops.py:384-385).  ws: tgp_postprocess_sparse_workspace_bytes().           */

@@ -286,3 +286,99 @@ def test_small_graph_kernel_flag_grid(dev):
     torch.testing.assert_close(raw.cpu(), raw_ref, rtol=RTOL, atol=ATOL)
     torch.testing.assert_close(post.cpu(), O.postprocess_dense(raw_ref, True, True, True, False), rtol=RTOL, atol=ATOL)
     torch.testing.assert_close(x_pool.cpu(), O.reduce_dense(S, X), rtol=RTOL, atol=ATOL)
+
+
+def _sorted_graph(n, pairs, seed):
+    ei = undirected_graph(n, pairs, seed)
+    order = torch.argsort(ei[0] * n + ei[1], stable=True)
+    return ei[:, order]
+
+
+@pytest.mark.parametrize("weighted", [True, False])
+@pytest.mark.parametrize("op", ["sum", "mean", "min", "max", "mul"])
+def test_rowlocal_coalesce_vs_oracle(dev, weighted, op):
+    """Sort-free coalesce (row-sorted input + supernode->member index): same output as the oracle, and the
+    fast path is really the one that ran."""
+    import tgp_oracle as O
+    from tgp import kernels
+    n, k = 30_000, 11_000
+    ei = _sorted_graph(n, 150_000, 21)
+    ei = torch.cat([ei, ei[:, ::7]], 1)              # duplicated edges ...
+    ei = ei[:, torch.argsort(ei[0], stable=True)]    # ... keeping rows sorted (columns unsorted inside a row)
+    g = torch.Generator().manual_seed(22)
+    ew = (torch.rand(ei.size(1), generator=g) + 0.5) if weighted else None
+    if weighted:
+        ew[::13] = 0.0
+    cluster = torch.randint(0, k, (n,), generator=g)
+    cluster[:k] = torch.randperm(k, generator=g)
+    cl_d = cluster.to(dev)
+    idx = kernels.build_assign_index(cl_d, k)
+    got_ei, got_ew = kernels.coalesce_edges(ei.to(dev), None if ew is None else ew.to(dev), cl_d, k, op, True,
+                                            assign_index=idx)
+    ref_ei, ref_ew = O.sparse_connect(ei, ew, torch.arange(n), cluster, n, k, reduce_op=op)
+    assert torch.equal(got_ei.cpu(), ref_ei)
+    if weighted:
+        torch.testing.assert_close(got_ew.cpu(), ref_ew, rtol=RTOL, atol=ATOL)
+    else:
+        assert got_ew is None
+    # the sort-based path must agree bit for bit (same summation order)
+    gen_ei, gen_ew = kernels.coalesce_edges(ei.to(dev), None if ew is None else ew.to(dev), cl_d, k, op, True)
+    assert torch.equal(gen_ei, got_ei)
+    if weighted:
+        assert torch.equal(gen_ew, got_ew)
+
+
+def test_rowlocal_coalesce_declines_and_falls_back(dev):
+    import tgp_oracle as O
+    from tgp import _native as N
+    from tgp import kernels
+    n = 5_000
+    ei = undirected_graph(n, 40_000, 5)                       # NOT row sorted
+    ew = torch.ones(ei.size(1))
+    cluster = torch.arange(n) // 2
+    k = n // 2
+    cl_d = cluster.to(dev)
+    idx = kernels.build_assign_index(cl_d, k)
+
+    def raw_count(edge_index, cl, kk, index):
+        L = N.lib()
+        row, col = edge_index[0].contiguous(), edge_index[1].contiguous()
+        ws = N.workspace(L.tgp_connect_coalesce_rows_workspace_bytes(row.numel(), cl.numel(), kk), dev)
+        cnt = torch.empty(1, dtype=torch.int64, device=dev)
+        N.check(L.tgp_connect_coalesce_rows_count(row.data_ptr(), col.data_ptr(), None, row.numel(), cl.data_ptr(),
+                                                  cl.numel(), kk, index.row_ptr.data_ptr(), index.perm.data_ptr(), 0, 1,
+                                                  ws.data_ptr(), ws.numel(), cnt.data_ptr(), N.stream_ptr(dev)), "rows")
+        return int(cnt.item())
+
+    assert raw_count(ei.to(dev), cl_d, k, idx) == -1           # unsorted rows -> declined
+    got = kernels.coalesce_edges(ei.to(dev), ew.to(dev), cl_d, k, "sum", True, assign_index=idx)
+    ref = O.sparse_connect(ei, ew, torch.arange(n), cluster, n, k)
+    assert torch.equal(got[0].cpu(), ref[0]) and torch.equal(got[1].cpu(), ref[1])
+    # very long supernode rows (few clusters, > 1024 raw entries each) -> declined, general path still right
+    es = _sorted_graph(n, 40_000, 6)
+    cl2 = torch.arange(n) % 3
+    idx2 = kernels.build_assign_index(cl2.to(dev), 3)
+    assert raw_count(es.to(dev), cl2.to(dev), 3, idx2) == -1
+    got = kernels.coalesce_edges(es.to(dev), torch.ones(es.size(1), device=dev), cl2.to(dev), 3, "sum", False,
+                                 assign_index=idx2)
+    ref = O.sparse_connect(es, torch.ones(es.size(1)), torch.arange(n), cl2, n, 3, remove_self_loops=False)
+    assert torch.equal(got[0].cpu(), ref[0]) and torch.equal(got[1].cpu(), ref[1])
+
+
+def test_rowlocal_coalesce_long_rows(dev):
+    """Supernode rows of 33..1024 raw entries take the LDS bitonic kernel (hub supernodes)."""
+    import tgp_oracle as O
+    from tgp import kernels
+    n, k = 4_000, 150
+    ei = _sorted_graph(n, 20_000, 31)           # ~10 edges per node, ~27 nodes per cluster -> ~270 per row
+    g = torch.Generator().manual_seed(32)
+    ew = torch.randn(ei.size(1), generator=g)
+    cluster = torch.randint(0, k, (n,), generator=g)
+    cluster[:k] = torch.arange(k)
+    cl_d = cluster.to(dev)
+    idx = kernels.build_assign_index(cl_d, k)
+    for op in ("sum", "max"):
+        got_ei, got_ew = kernels.coalesce_edges(ei.to(dev), ew.to(dev), cl_d, k, op, True, assign_index=idx)
+        ref_ei, ref_ew = O.sparse_connect(ei, ew, torch.arange(n), cluster, n, k, reduce_op=op)
+        assert torch.equal(got_ei.cpu(), ref_ei)
+        torch.testing.assert_close(got_ew.cpu(), ref_ew, rtol=RTOL, atol=ATOL)

@@ -1,0 +1,428 @@
+// A4 + A6 fast path: coalesce Connect WITHOUT a global sort, for row-sorted edge lists.
+//
+// PyG edge lists are row-sorted almost everywhere (coalesced inputs, to_undirected, dataset loaders).
+// Then the edges of one supernode r are the union of the contiguous edge ranges of its member nodes, so
+// grouping the relabelled edges by supernode row needs no sort: every edge computes its own slot
+//     raw_off[r] + member_off[node] + (e - node_ptr[node])
+// (stable: members ascending, input order inside a member), and only the short per-row segments
+// (~E/K entries) have to be ordered by column.  Pipeline, all edge- or row-parallel:
+//   K1 check rows sorted + CSR of the input (node_ptr)            read E*8 B
+//   K2 per supernode: raw row length T_r, per-member offsets      K-sized
+//   K3 scan T_r -> raw_off                                          K-sized
+//   K4 scatter (cluster[col], w) into supernode-major order       read E*20 B, write E*8 B
+//   K5 per row segment: stable sort by column (half-wave bitonic network in registers for rows of <= 32
+//      entries, one workgroup + LDS bitonic for rows of 33..1024), merge duplicates with reduce_op in
+//      input order, fused self-loop / eps filters, survivors compacted per row          read+write E*8 B
+//   K6 scan survivors -> output offsets, total                    K-sized            [host reads total]
+//   K7 fill                                                        read E'*8 B, write E'*20 B
+// vs. five radix passes of 32 B/edge each in the general path (sparse_connect.hip).  The result is
+// identical to the general path (row-major sorted, unique, duplicates reduced in input order).
+// Preconditions are checked on the device (rows sorted; no supernode row longer than 1024 raw entries);
+// if they fail *d_count is set to -1 and the caller falls back to the sort-based path.
+#include "primitives.h"
+
+namespace tgp {
+
+constexpr int CR_LONG = 1024;    // longest supernode row (raw entries) the LDS kernel sorts
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_TILE = 256 * SCAN_ITEMS;
+
+// ------------------------------------------------------------------ multi-block exclusive scan (u32)
+__global__ __launch_bounds__(256) void scan_tile_sums_kernel(const uint32_t* __restrict__ in, int64_t n,
+                                                             uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t s_w[4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * SCAN_TILE + static_cast<int64_t>(threadIdx.x) * SCAN_ITEMS;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i)
+    if (base + i < n) s += in[base + i];
+  uint32_t total;
+  block_excl_scan_256(s, s_w, &total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t* __restrict__ in, int64_t n,
+                                                         const uint32_t* __restrict__ tile_offsets,
+                                                         uint32_t* __restrict__ out) {
+  __shared__ uint32_t s_w[4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * SCAN_TILE + static_cast<int64_t>(threadIdx.x) * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    v[i] = base + i < n ? in[base + i] : 0u;
+    s += v[i];
+  }
+  uint32_t run = tile_offsets[blockIdx.x] + block_excl_scan_256(s, s_w, nullptr);
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    if (base + i < n) out[base + i] = run;
+    run += v[i];
+  }
+}
+
+// out[0..n) = exclusive prefix of in, *total = sum.  tile scratch: 2 * ceil(n / SCAN_TILE) words.
+static void device_scan_u32(const uint32_t* in, int64_t n, uint32_t* out, int64_t* total, uint32_t* tile_scratch,
+                            hipStream_t stream) {
+  const int nt = cdiv(n > 0 ? n : 1, SCAN_TILE);
+  uint32_t* sums = tile_scratch;
+  uint32_t* offs = tile_scratch + nt;
+  hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(nt), dim3(256), 0, stream, in, n, sums);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, sums, nt, offs, total);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nt), dim3(256), 0, stream, in, n, offs, out);
+}
+
+// ------------------------------------------------------------------ K1 / K2
+__global__ __launch_bounds__(256) void cr_check_sorted_kernel(const int64_t* __restrict__ row, int64_t E,
+                                                              int* __restrict__ bad) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e + 1 < E && row[e] > row[e + 1]) *bad = 1;
+}
+
+__global__ __launch_bounds__(256) void cr_node_ptr_kernel(const int64_t* __restrict__ rows, int64_t n,
+                                                          int64_t num_rows, const int* __restrict__ bad,
+                                                          uint32_t* __restrict__ node_ptr) {
+  if (*bad) return;  // unsorted rows: the gap loops below would be unbounded garbage
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (p > n) return;
+  if (p == n) {
+    const int64_t first = n > 0 ? rows[n - 1] + 1 : 0;
+    for (int64_t c = first; c <= num_rows; ++c) node_ptr[c] = static_cast<uint32_t>(n);
+    return;
+  }
+  const int64_t cur = rows[p], prev = p > 0 ? rows[p - 1] : -1;
+  for (int64_t c = prev + 1; c <= cur; ++c) node_ptr[c] = static_cast<uint32_t>(p);
+}
+
+// one thread per supernode: raw row length + offset of each member's edge range inside the row
+__global__ __launch_bounds__(256) void cr_row_len_kernel(const int32_t* __restrict__ a_row_ptr,
+                                                         const int32_t* __restrict__ a_perm,
+                                                         const uint32_t* __restrict__ node_ptr, int64_t K,
+                                                         int* __restrict__ bad, uint32_t* __restrict__ T,
+                                                         uint32_t* __restrict__ member_off) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (r >= K) return;
+  if (*bad == 1) {
+    T[r] = 0;
+    return;
+  }
+  uint32_t run = 0;
+  for (int32_t p = a_row_ptr[r]; p < a_row_ptr[r + 1]; ++p) {
+    const int32_t node = a_perm[p];  // members ascending (the inverted index is stable)
+    member_off[node] = run;
+    run += node_ptr[node + 1] - node_ptr[node];
+  }
+  T[r] = run;
+  if (run > CR_LONG) *bad = 2;  // a supernode row too long for the LDS sort: decline
+}
+
+// ------------------------------------------------------------------ K4
+__global__ __launch_bounds__(256) void cr_scatter_kernel(const int64_t* __restrict__ row,
+                                                         const int64_t* __restrict__ col,
+                                                         const float* __restrict__ w, int64_t E,
+                                                         const int32_t* __restrict__ table,
+                                                         const uint32_t* __restrict__ node_ptr,
+                                                         const uint32_t* __restrict__ member_off,
+                                                         const uint32_t* __restrict__ raw_off,
+                                                         const int* __restrict__ bad, uint32_t* __restrict__ tmp_c,
+                                                         float* __restrict__ tmp_w) {
+  if (*bad) return;
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int64_t node = row[e];
+  const uint32_t pos = raw_off[table[node]] + member_off[node] + (static_cast<uint32_t>(e) - node_ptr[node]);
+  tmp_c[pos] = static_cast<uint32_t>(table[col[e]]);
+  if (tmp_w) tmp_w[pos] = w[e];
+}
+
+// ------------------------------------------------------------------ K5
+__device__ __forceinline__ float cr_reduce(float acc, float v, int op) {
+  switch (op) {
+    case TGP_MIN: return fminf(acc, v);
+    case TGP_MAX: return fmaxf(acc, v);
+    case TGP_MUL: return __fmul_rn(acc, v);
+    default: return __fadd_rn(acc, v);
+  }
+}
+
+// Rows of <= 32 raw entries: one HALF-WAVE per row, one entry per lane, bitonic network on the key
+// (column << 5 | input position) => stable; requires K < 2^27 (checked by the host wrapper).
+__global__ __launch_bounds__(256) void cr_rows_short_kernel(uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w,
+                                                            const uint32_t* __restrict__ raw_off, int64_t K,
+                                                            int64_t E, int reduce_op, int flags,
+                                                            const int* __restrict__ bad,
+                                                            uint32_t* __restrict__ n_out) {
+  if (*bad) return;
+  const int l = threadIdx.x & 31;
+  const unsigned long long half_mask = 0xFFFFFFFFull << (threadIdx.x & 32);
+  const int64_t nhalf = static_cast<int64_t>(gridDim.x) * 8;
+  for (int64_t r0 = static_cast<int64_t>(blockIdx.x) * 8; r0 < K; r0 += nhalf) {
+    const int64_t r = r0 + (threadIdx.x >> 5);
+    uint32_t b = 0, T = 0;
+    if (r < K) {
+      b = raw_off[r];
+      T = (r + 1 < K ? raw_off[r + 1] : static_cast<uint32_t>(E)) - b;
+    }
+    const bool mine = r < K && T <= 32;  // longer rows belong to cr_rows_long_kernel
+    const uint32_t Tm = mine ? T : 0;
+    uint32_t key = 0xFFFFFFFFu;
+    float w = 0.f;
+    if (static_cast<uint32_t>(l) < Tm) {
+      key = (tmp_c[b + l] << 5) | static_cast<uint32_t>(l);
+      if (tmp_w) w = tmp_w[b + l];
+    }
+    // bitonic sort of 32 (key, w) pairs across the half-wave
+#pragma unroll
+    for (int k = 2; k <= 32; k <<= 1) {
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const uint32_t ok = __shfl_xor(key, j, 32);
+        const float ow = __shfl_xor(w, j, 32);
+        const bool up = ((l & k) == 0);            // ascending block
+        const bool lower = ((l & j) == 0);         // this lane keeps the smaller one in an ascending block
+        const bool take = (key > ok) == (up == lower);
+        if (take) { key = ok; w = ow; }
+      }
+    }
+    const bool valid = key != 0xFFFFFFFFu;
+    const uint32_t c = key >> 5;
+    const uint32_t pc = __shfl_up(c, 1, 32);
+    const bool pvalid = __shfl_up(valid ? 1 : 0, 1, 32) != 0;
+    const bool head = valid && (l == 0 || !pvalid || pc != c);
+    // every head folds its run in sorted (= input) order
+    float acc = w;
+    uint32_t cnt = 1;
+    bool open = head;
+    for (int d = 1; d < 32; ++d) {
+      const uint32_t nc = __shfl_down(c, d, 32);
+      const float nw = __shfl_down(w, d, 32);
+      const bool nvalid = __shfl_down(valid ? 1 : 0, d, 32) != 0;
+      open = open && (l + d < 32) && nvalid && nc == c;
+      if (open) { acc = cr_reduce(acc, nw, reduce_op); ++cnt; }
+      if (!__any(open)) break;
+    }
+    if (tmp_w && reduce_op == TGP_MEAN) acc = acc / static_cast<float>(cnt);
+    bool keep = head;
+    if ((flags & TGP_REMOVE_SELF_LOOPS) && c == static_cast<uint32_t>(r)) keep = false;
+    if (tmp_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > TGP_EPS)) keep = false;
+    const unsigned long long km = __ballot(keep) & half_mask;
+    const uint32_t rank = __popcll(km & lanemask_lt());
+    if (keep) {
+      tmp_c[b + rank] = c;
+      if (tmp_w) tmp_w[b + rank] = acc;
+    }
+    if (mine && l == 0) n_out[r] = __popcll(km);
+  }
+}
+
+// Rows of 33..1024 raw entries: one workgroup per row, bitonic sort of (column << 32 | position) in LDS.
+__global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w,
+                                                           const uint32_t* __restrict__ raw_off, int64_t K,
+                                                           int64_t E, int reduce_op, int flags,
+                                                           const int* __restrict__ bad,
+                                                           uint32_t* __restrict__ n_out) {
+  __shared__ unsigned long long s_key[CR_LONG];
+  __shared__ float s_w[CR_LONG];
+  __shared__ uint32_t s_cnt[4 * 4];
+  if (*bad) return;
+  const int tid = threadIdx.x;
+  for (int64_t r = blockIdx.x; r < K; r += gridDim.x) {
+    const uint32_t b = raw_off[r];
+    const uint32_t T = (r + 1 < K ? raw_off[r + 1] : static_cast<uint32_t>(E)) - b;
+    if (T <= 32 || T > CR_LONG) continue;  // block-uniform
+    uint32_t P = 64;
+    while (P < T) P <<= 1;
+    for (uint32_t i = tid; i < P; i += 256) {
+      s_key[i] = i < T ? (static_cast<unsigned long long>(tmp_c[b + i]) << 32) | i : ~0ull;
+      s_w[i] = (i < T && tmp_w) ? tmp_w[b + i] : 0.f;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t i = tid; i < P; i += 256) {
+          const uint32_t x = i ^ j;
+          if (x > i) {
+            const bool up = (i & k) == 0;
+            const unsigned long long a = s_key[i], c2 = s_key[x];
+            if ((a > c2) == up) {
+              s_key[i] = c2; s_key[x] = a;
+              const float t = s_w[i]; s_w[i] = s_w[x]; s_w[x] = t;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    bool keep[4];
+    uint32_t rank[4], col[4];
+    float val[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const uint32_t i = it * 256 + tid;
+      keep[it] = false; col[it] = 0; val[it] = 0.f;
+      if (i < T) {
+        const uint32_t c = static_cast<uint32_t>(s_key[i] >> 32);
+        const bool head = i == 0 || static_cast<uint32_t>(s_key[i - 1] >> 32) != c;
+        if (head) {
+          float acc = s_w[i];
+          uint32_t cnt = 1;
+          for (uint32_t q = i + 1; q < T && static_cast<uint32_t>(s_key[q] >> 32) == c; ++q, ++cnt)
+            acc = cr_reduce(acc, s_w[q], reduce_op);
+          if (tmp_w && reduce_op == TGP_MEAN) acc = acc / static_cast<float>(cnt);
+          bool k2 = true;
+          if ((flags & TGP_REMOVE_SELF_LOOPS) && c == static_cast<uint32_t>(r)) k2 = false;
+          if (tmp_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > TGP_EPS)) k2 = false;
+          keep[it] = k2; col[it] = c; val[it] = acc;
+        }
+      }
+    }
+    uint32_t total;
+    block_compact_ranks<4>(keep, rank, total, s_cnt);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      if (keep[it]) {
+        tmp_c[b + rank[it]] = col[it];
+        if (tmp_w) tmp_w[b + rank[it]] = val[it];
+      }
+    }
+    if (tid == 0) n_out[r] = total;
+    __syncthreads();
+  }
+}
+
+// total survivors -> d_count, or -1 when a precondition failed
+__global__ void cr_finish_count_kernel(const int* __restrict__ bad, const int64_t* __restrict__ total,
+                                       int64_t* __restrict__ d_count) {
+  *d_count = *bad ? -1 : *total;
+}
+
+// ------------------------------------------------------------------ K7: one wave per 64 rows, lane per row
+__global__ __launch_bounds__(256) void cr_fill_kernel(const uint32_t* __restrict__ tmp_c,
+                                                      const float* __restrict__ tmp_w,
+                                                      const uint32_t* __restrict__ raw_off,
+                                                      const uint32_t* __restrict__ n_out,
+                                                      const uint32_t* __restrict__ out_off, int64_t K,
+                                                      int64_t* __restrict__ out_row, int64_t* __restrict__ out_col,
+                                                      float* __restrict__ out_w) {
+  // a group of 8 lanes copies one row (rows hold ~E'/K entries): consecutive lanes -> consecutive outputs
+  const int64_t g = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 3;
+  const int l = threadIdx.x & 7;
+  if (g >= K) return;
+  const uint32_t n = n_out[g], src = raw_off[g], dst = out_off[g];
+  for (uint32_t i = l; i < n; i += 8) {
+    out_row[dst + i] = g;
+    out_col[dst + i] = tmp_c[src + i];
+    if (out_w) out_w[dst + i] = tmp_w[src + i];
+  }
+}
+
+struct CrWs {
+  int32_t* table;        // [N]
+  uint32_t* node_ptr;    // [N+1]
+  uint32_t* member_off;  // [N]
+  uint32_t* T;           // [K]
+  uint32_t* raw_off;     // [K]
+  uint32_t* n_out;       // [K]
+  uint32_t* out_off;     // [K]
+  uint32_t* tmp_c;       // [E]
+  float* tmp_w;          // [E]
+  uint32_t* scan_scratch;
+  int64_t* total;
+  int* bad;
+};
+
+static size_t cr_layout(void* ws, int64_t E, int64_t N, int64_t K, CrWs* out) {
+  Carver cv(ws);
+  const size_t n = static_cast<size_t>(N > 0 ? N : 1), k = static_cast<size_t>(K > 0 ? K : 1);
+  const size_t e = static_cast<size_t>(E > 0 ? E : 1);
+  CrWs s;
+  s.table = cv.take<int32_t>(n);
+  s.node_ptr = cv.take<uint32_t>(n + 1);
+  s.member_off = cv.take<uint32_t>(n);
+  s.T = cv.take<uint32_t>(k);
+  s.raw_off = cv.take<uint32_t>(k);
+  s.n_out = cv.take<uint32_t>(k);
+  s.out_off = cv.take<uint32_t>(k);
+  s.tmp_c = cv.take<uint32_t>(e);
+  s.tmp_w = cv.take<float>(e);
+  s.scan_scratch = cv.take<uint32_t>(2 * static_cast<size_t>(cdiv(k, SCAN_TILE)) + 16);
+  s.total = cv.take<int64_t>(2);
+  s.bad = cv.take<int>(4);
+  if (out) *out = s;
+  return cv.off;
+}
+
+__global__ __launch_bounds__(256) void cr_table_kernel(const int64_t* __restrict__ cluster, int64_t n,
+                                                       int32_t* __restrict__ table) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) table[i] = static_cast<int32_t>(cluster[i]);
+}
+
+}  // namespace tgp
+
+using namespace tgp;
+
+extern "C" size_t tgp_connect_coalesce_rows_workspace_bytes(int64_t E, int64_t N, int64_t K) {
+  return cr_layout(nullptr, E, N, K, nullptr) + 256;
+}
+
+extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                               const int64_t* cluster_index, int64_t N, int64_t K,
+                                               const int32_t* assign_row_ptr, const int32_t* assign_perm,
+                                               int reduce_op, int flags, void* ws, size_t ws_bytes,
+                                               int64_t* d_count, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && d_count, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_count: bad argument");
+  TGP_REQUIRE(E == 0 || (row && col && cluster_index && assign_row_ptr && assign_perm), TGP_ERR_INVALID,
+              "tgp_connect_coalesce_rows_count: null pointer");
+  TGP_REQUIRE(reduce_op >= TGP_SUM && reduce_op <= TGP_MUL, TGP_ERR_INVALID,
+              "tgp_connect_coalesce_rows_count: unknown reduce_op %d", reduce_op);
+  TGP_REQUIRE(E < (1ll << 31) && K < (1ll << 27) && N < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_connect_coalesce_rows_count: E/N >= 2^31 or K >= 2^27");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_connect_coalesce_rows_workspace_bytes(E, N, K), TGP_ERR_WORKSPACE,
+              "tgp_connect_coalesce_rows_count: workspace too small");
+  if (E == 0 || K == 0) {
+    (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
+    return check_launch("tgp_connect_coalesce_rows_count");
+  }
+  CrWs s;
+  cr_layout(ws, E, N, K, &s);
+  float* tmp_w = w ? s.tmp_w : nullptr;
+  (void)hipMemsetAsync(s.bad, 0, sizeof(int), stream);
+  hipLaunchKernelGGL(cr_check_sorted_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, E, s.bad);
+  hipLaunchKernelGGL(cr_node_ptr_kernel, dim3(cdiv(E + 1, 256)), dim3(256), 0, stream, row, E, N, s.bad, s.node_ptr);
+  hipLaunchKernelGGL(cr_table_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, cluster_index, N, s.table);
+  hipLaunchKernelGGL(cr_row_len_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, assign_row_ptr, assign_perm,
+                     s.node_ptr, K, s.bad, s.T, s.member_off);
+  device_scan_u32(s.T, K, s.raw_off, s.total, s.scan_scratch, stream);
+  hipLaunchKernelGGL(cr_scatter_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, E, s.table, s.node_ptr,
+                     s.member_off, s.raw_off, s.bad, s.tmp_c, tmp_w);
+  (void)hipMemsetAsync(s.n_out, 0, static_cast<size_t>(K) * sizeof(uint32_t), stream);
+  {
+    int64_t gs = (K + 7) / 8;
+    if (gs > 256 * 16) gs = 256 * 16;
+    hipLaunchKernelGGL(cr_rows_short_kernel, dim3(static_cast<unsigned>(gs)), dim3(256), 0, stream, s.tmp_c, tmp_w,
+                       s.raw_off, K, E, reduce_op, flags, s.bad, s.n_out);
+    int64_t gl = K < 2048 ? K : 2048;
+    hipLaunchKernelGGL(cr_rows_long_kernel, dim3(static_cast<unsigned>(gl)), dim3(256), 0, stream, s.tmp_c, tmp_w,
+                       s.raw_off, K, E, reduce_op, flags, s.bad, s.n_out);
+  }
+  device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream);
+  hipLaunchKernelGGL(cr_finish_count_kernel, dim3(1), dim3(1), 0, stream, s.bad, s.total, d_count);
+  return check_launch("tgp_connect_coalesce_rows_count");
+}
+
+extern "C" int tgp_connect_coalesce_rows_fill(const void* ws, int64_t E, int64_t N, int64_t K, int has_weight,
+                                              int64_t num_out, int64_t* out_row, int64_t* out_col, float* out_w,
+                                              void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(ws && num_out >= 0, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_fill: bad argument");
+  if (num_out == 0 || E == 0 || K == 0) return TGP_OK;
+  TGP_REQUIRE(out_row && out_col && (!has_weight || out_w), TGP_ERR_INVALID,
+              "tgp_connect_coalesce_rows_fill: null output");
+  CrWs s;
+  cr_layout(const_cast<void*>(ws), E, N, K, &s);
+  hipLaunchKernelGGL(cr_fill_kernel, dim3(cdiv(K * 8, 256)), dim3(256), 0, stream, s.tmp_c,
+                     has_weight ? s.tmp_w : nullptr, s.raw_off, s.n_out, s.out_off, K, out_row, out_col,
+                     has_weight ? out_w : nullptr);
+  return check_launch("tgp_connect_coalesce_rows_fill");
+}

@@ -48,7 +48,7 @@ def _restore_format(template, edge_index, edge_weight, num_supernodes):
 def sparse_connect(edge_index, edge_weight: Optional[Tensor] = None, node_index: Tensor = None,
                    cluster_index: Optional[Tensor] = None, num_nodes: int = None, num_supernodes: int = None,
                    remove_self_loops: bool = True, reduce_op: str = "sum", edge_weight_norm: bool = False,
-                   batch_pooled: Optional[Tensor] = None, degree_norm: bool = False):
+                   batch_pooled: Optional[Tensor] = None, degree_norm: bool = False, assign_index=None):
     r"""Coarsen an edge list (reference connect/base_conn.py:57-112).
 
     * kept-node selection (TopK): induced subgraph, endpoints relabelled to their position in the
@@ -69,7 +69,7 @@ def sparse_connect(edge_index, edge_weight: Optional[Tensor] = None, node_index:
         ei, ew = K.filter_edges(edge_index, edge_weight, node_index, num_nodes, remove_self_loops)
     elif cluster_index is not None and len(cluster_index) == num_nodes:
         ei, ew = K.coalesce_edges(edge_index, edge_weight, cluster_index, num_supernodes, reduce_op,
-                                  remove_self_loops)
+                                  remove_self_loops, assign_index=assign_index)
     else:
         raise RuntimeError
     ei, ew = _normalize_pooled_edges(ei, ew, num_supernodes, degree_norm, edge_weight_norm, batch_pooled)
@@ -93,11 +93,15 @@ class SparseConnect(Connect):
         if self.edge_weight_norm and batch_pooled is None:
             raise AssertionError("edge_weight_norm=True but batch_pooled=None. batch_pooled parameter is "
                                  "required for per-graph normalization in SparseConnect.")
+        # every node assigned (one-over-K poolers): hand over the supernode->member index (cached on `so`,
+        # shared with Reduce) so the sort-free row-local coalesce can be used
+        all_assigned = so.node_index.numel() == so.num_nodes and so.node_index.is_cuda
         return sparse_connect(edge_index, edge_weight, node_index=so.node_index, cluster_index=so.cluster_index,
                               num_nodes=so.num_nodes, num_supernodes=so.num_supernodes,
                               remove_self_loops=self.remove_self_loops, reduce_op=self.reduce_op,
                               edge_weight_norm=self.edge_weight_norm, batch_pooled=batch_pooled,
-                              degree_norm=self.degree_norm)
+                              degree_norm=self.degree_norm,
+                              assign_index=so.assign_index() if all_assigned else None)
 
     def __repr__(self) -> str:
         return (f"{self.__class__.__name__}(reduce_op={self.reduce_op}, "

@@ -114,9 +114,12 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
 
 def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_index: Tensor,
                    num_supernodes: int, reduce_op: str, remove_self_loops: bool,
-                   eps_filter: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+                   eps_filter: bool = True, assign_index: Optional[AssignIndex] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """cluster_index[edge_index] + PyG coalesce (connect/base_conn.py:86-89) fused with
-    remove_self_loops and the |w| > eps filter (utils/ops.py:370-380)."""
+    remove_self_loops and the |w| > eps filter (utils/ops.py:370-380).
+
+    With the supernode->member index of the assignment at hand (``assign_index``) the sort-free row-local
+    path is tried first; it declines (count = -1) for unsorted rows or very long supernode rows."""
     if reduce_op not in N.REDUCE_OPS:
         raise ValueError(f"unknown reduce_op '{reduce_op}', expected one of {sorted(N.REDUCE_OPS)}")
     dev = N.require_device(edge_index, edge_weight, cluster_index)
@@ -126,6 +129,25 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
     cl = N.i64c(cluster_index)
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if (w is not None and eps_filter) else 0)
     L = N.lib()
+    if (assign_index is not None and assign_index.nnz == cl.numel() and assign_index.num_targets == num_supernodes
+            and num_supernodes < (1 << 27)):
+        ws = N.workspace(L.tgp_connect_coalesce_rows_workspace_bytes(E, cl.numel(), num_supernodes), dev)
+        d_count = torch.empty(1, dtype=torch.int64, device=dev)
+        st = N.stream_ptr(dev)
+        N.check(L.tgp_connect_coalesce_rows_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
+                                                  num_supernodes, N.ptr(assign_index.row_ptr),
+                                                  N.ptr(assign_index.perm), N.REDUCE_OPS[reduce_op], flags, N.ptr(ws),
+                                                  ws.numel(), N.ptr(d_count), st), "tgp_connect_coalesce_rows_count")
+        n_out = _read_count(d_count)
+        if n_out >= 0:
+            out_ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
+            out_w = None if w is None else torch.empty(n_out, dtype=torch.float32, device=dev)
+            N.check(L.tgp_connect_coalesce_rows_fill(N.ptr(ws), E, cl.numel(), num_supernodes, 0 if w is None else 1,
+                                                     n_out, N.ptr(out_ei[0]) if n_out else None,
+                                                     N.ptr(out_ei[1]) if n_out else None, N.ptr(out_w), st),
+                    "tgp_connect_coalesce_rows_fill")
+            return out_ei, out_w
+        del ws  # declined: fall through to the sort-based path
     ws = N.workspace(L.tgp_connect_coalesce_workspace_bytes(E, cl.numel(), num_supernodes), dev)
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
     st = N.stream_ptr(dev)
