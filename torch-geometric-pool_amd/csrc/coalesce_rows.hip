@@ -223,12 +223,27 @@ __global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict_
   __shared__ unsigned long long s_key[CR_LONG];
   __shared__ float s_w[CR_LONG];
   __shared__ uint32_t s_cnt[4 * 4];
+  __shared__ int s_list[256];
+  __shared__ int s_nlist;
   if (*bad) return;
   const int tid = threadIdx.x;
-  for (int64_t r = blockIdx.x; r < K; r += gridDim.x) {
+  // each workgroup owns 256 consecutive rows: find the long ones with one coalesced look, then sort them
+  if (tid == 0) s_nlist = 0;
+  __syncthreads();
+  {
+    const int64_t rr = static_cast<int64_t>(blockIdx.x) * 256 + tid;
+    if (rr < K) {
+      const uint32_t tb = raw_off[rr];
+      const uint32_t tt = (rr + 1 < K ? raw_off[rr + 1] : static_cast<uint32_t>(E)) - tb;
+      if (tt > 32 && tt <= CR_LONG) s_list[atomicAdd(&s_nlist, 1)] = tid;
+    }
+  }
+  __syncthreads();
+  const int nlist = s_nlist;
+  for (int li = 0; li < nlist; ++li) {
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + s_list[li];
     const uint32_t b = raw_off[r];
     const uint32_t T = (r + 1 < K ? raw_off[r + 1] : static_cast<uint32_t>(E)) - b;
-    if (T <= 32 || T > CR_LONG) continue;  // block-uniform
     uint32_t P = 64;
     while (P < T) P <<= 1;
     for (uint32_t i = tid; i < P; i += 256) {
@@ -402,8 +417,7 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
     if (gs > 256 * 16) gs = 256 * 16;
     hipLaunchKernelGGL(cr_rows_short_kernel, dim3(static_cast<unsigned>(gs)), dim3(256), 0, stream, s.tmp_c, tmp_w,
                        s.raw_off, K, E, reduce_op, flags, s.bad, s.n_out);
-    int64_t gl = K < 2048 ? K : 2048;
-    hipLaunchKernelGGL(cr_rows_long_kernel, dim3(static_cast<unsigned>(gl)), dim3(256), 0, stream, s.tmp_c, tmp_w,
+    hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, s.tmp_c, tmp_w,
                        s.raw_off, K, E, reduce_op, flags, s.bad, s.n_out);
   }
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream);
