@@ -103,6 +103,7 @@ def run_other_workload(args, dev):
     from tgp.reduce import BaseReduce
     from tgp.select import GraclusSelect, SelectOutput
     from tgp.utils.ops import postprocess_adj_pool_dense
+    from tgp.src import DenseSRCPooling
     g = torch.Generator(device=dev).manual_seed(0)
     red = BaseReduce()
     extra = {}
@@ -119,10 +120,16 @@ def run_other_workload(args, dev):
         so, conn = SelectOutput(s=S, in_mask=mask), DenseConnect()
         nodes = int(n_b.sum())
 
+        fused_pool = DenseSRCPooling(reducer=red, connector=conn, adj_transpose=True)
+
         def step():
-            red(X, so)
-            raw = conn.dense_connect(adj=A, s=S)  # MinCut order: raw -> (loss) -> post-process
-            postprocess_adj_pool_dense(raw, True, True, True, False)
+            with torch.no_grad():
+                if args.unfused:
+                    red(X, so)
+                    raw = conn.dense_connect(adj=A, s=S)  # MinCut order: raw -> (loss) -> post-process
+                    postprocess_adj_pool_dense(raw, True, True, True, False)
+                else:  # MinCut forward: x_pool, raw S^T A S (for the cut loss) and post-processed A' at once
+                    fused_pool.reduce_connect(X, A, so, want_raw=True)
         name = "MinCut PROTEINS-shape batch: B=2048, n~U[20,60] padded to 60, K=20, F=32 (BASELINE configs[2])"
         alg = 4.0 * B * (Nmax * Nmax + Nmax * K + Nmax * F + K * K + K * F)
         kern_ms = event_time_ms(step, 20, dev)
@@ -201,6 +208,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true",
+                    help="dense workloads: call the Reduce and Connect operators one after the other")
     ap.add_argument("--unsorted-edges", action="store_true",
                     help="c4_graclus: leave the synthetic edge list in random order (forces the sort-based coalesce)")
     args = ap.parse_args()
@@ -222,6 +231,7 @@ def main():
     from tgp.distributed import PackedGather
     from tgp.reduce import BaseReduce
     from tgp.select import SelectOutput
+    from tgp.src import DenseSRCPooling
     _native.lib()
 
     if args.workload not in ("c2", "c5"):
@@ -238,13 +248,19 @@ def main():
     S, A, X = dense_inputs(B, N, K, F, seed=rank, dev=dev)
     so = SelectOutput(s=S)
     reducer, connector = BaseReduce(), DenseConnect()  # DiffPool defaults (diffpool.py:98-115)
+    # what the dense poolers' forward runs after Select: Reduce + Connect as one native call (SURVEY 8(d) C2:
+    # "time fused A3+A7+A8"); --unfused times the two operators called one after the other instead
+    fused_pool = DenseSRCPooling(reducer=reducer, connector=connector, adj_transpose=True)
 
     gather = PackedGather() if distributed else None
 
     def step():
         with torch.no_grad():
-            x_pool, _ = reducer(X, so)
-            adj_pool, _ = connector(A, so)
+            if args.unfused:
+                x_pool, _ = reducer(X, so)
+                adj_pool, _ = connector(A, so)
+            else:
+                x_pool, _, adj_pool = fused_pool.reduce_connect(X, A, so)
             if distributed:
                 # one packed RCCL all-gather per step, overlapped with the next step's kernels:
                 # finish the previous step's gather, then start this one
@@ -290,7 +306,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": name, "graphs_per_gpu": B, "nodes_per_graph": N, "clusters": K,
                        "features": F, "nodes_counted": "input nodes (B*N per GPU per step)",
-                       "step": "BaseReduce (S^T X) + DenseConnect (S^T A S + diag/degree post-processing)"
+                       "step": ("BaseReduce (S^T X) then DenseConnect (S^T A S + diag/degree post-processing)"
+                                if args.unfused else
+                                "fused Reduce+Connect (S^T X, S^T A S, diag/degree post-processing) as the dense "
+                                "poolers' forward calls it: DenseSRCPooling.reduce_connect")
                                + (" + RCCL all-gather of pooled outputs" if distributed else ""),
                        "parallelism": f"graph-sharded x{world}"},
             "roofline": roofline,

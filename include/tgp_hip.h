@@ -166,6 +166,27 @@ int tgp_bmm_f32(const float* A, const float* Bm, float* C, int64_t batch, int64_
 int tgp_segment_gemm_tn_f32(const float* S, const float* Y, const int64_t* ptr, float* C, int64_t B,
                             int64_t Ntot, int64_t K, int64_t F, int64_t max_nodes, void* stream);
 
+/* ----------------------------------------------------------------------------------
+ * N3  auxiliary losses of the dense poolers, fused.
+ *
+ * tgp_link_loss_f32: sq[b] = || A[b] - S[b] S[b]^T ||_F^2 (utils/losses.py:644-708 link_pred_loss
+ *   materialises S S^T [B,N,N]; here its tiles exist only in the MFMA accumulators and the GEMM
+ *   epilogue reduces the squared residual).  S [B,N,K], A [B,N,N], sq [B].  The caller takes
+ *   sqrt(sum_b sq[b]) (and / numel when normalize_loss).
+ * tgp_entropy_sum_f32: out[0] = sum over all n elements of -S log(S + 1e-8)
+ *   (utils/losses.py:476-483 entropy_loss before the / num_nodes).
+ * tgp_cut_terms_f32: deg[b,i] = sum_j A[b,i,j]; q[b,i] = sum_k S[b,i,k]^2; den[b] = sum_i deg q
+ *   = trace(S^T D S) of utils/losses.py:39-81 mincut_loss without forming D.  deg, q [B,N] are
+ *   returned because the backward pass needs them.
+ * ---------------------------------------------------------------------------------- */
+size_t tgp_link_loss_workspace_bytes(int64_t B, int64_t N, int64_t K);
+int tgp_link_loss_f32(const float* S, const float* A, int64_t B, int64_t N, int64_t K, float* sq, void* ws,
+                      size_t ws_bytes, void* stream);
+size_t tgp_entropy_sum_workspace_bytes(int64_t n);
+int tgp_entropy_sum_f32(const float* S, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
+int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int64_t N, int64_t K, float* deg, float* q,
+                      float* den, void* stream);
+
 /* A7'  sparse A times dense S (connect/dense_conn.py:165,204: torch.sparse.mm), A in CSR built from a
  * row-sorted coalesced edge list: T[i,:] = sum_{e in row i} w[e] * S[col[e],:].  w may be NULL. */
 int tgp_rowptr_from_sorted_i64(const int64_t* rows, int64_t n, int64_t num_rows, int32_t* row_ptr, void* stream);

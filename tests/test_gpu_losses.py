@@ -1,0 +1,134 @@
+"""Fused auxiliary losses of the dense poolers: forward against the CPU oracle
+(oracle/tgp_oracle.py restates utils/losses.py), backward against torch autograd of the reference formulas
+on the same device.  fp32 tolerance: rtol = atol = 1e-5 forward (north_star), 1e-4 on gradients."""
+import math
+
+import pytest
+import torch
+
+import tgp_oracle as O
+
+pytestmark = pytest.mark.gpu
+FWD = dict(rtol=1e-5, atol=1e-5)
+BWD = dict(rtol=1e-4, atol=1e-5)
+SHAPES = [(1, 5, 3), (3, 50, 7), (2, 64, 8), (4, 200, 20), (2, 333, 17), (2, 1024, 128), (64, 60, 20)]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _inputs(dev, B, N, K, seed=0, weighted=True):
+    g = torch.Generator().manual_seed(seed)
+    S = torch.softmax(torch.randn(B, N, K, generator=g), -1)
+    A = (torch.rand(B, N, N, generator=g) < 0.2).float()
+    if weighted:
+        A = A * torch.rand(B, N, N, generator=g)
+    return S, A
+
+
+@pytest.mark.parametrize("B,N,K", SHAPES)
+def test_link_loss_matches_oracle(dev, B, N, K):
+    from tgp.utils.losses import link_pred_loss
+    S, A = _inputs(dev, B, N, K, seed=N)
+    for normalize in (False, True):
+        want = O.link_pred_loss(S.double(), A.double(), normalize).float()
+        got = link_pred_loss(S.to(dev), A.to(dev), normalize_loss=normalize).cpu()
+        torch.testing.assert_close(got, want, **FWD)
+
+
+def test_link_loss_padded_rows_and_strided(dev):
+    """Padded node rows (S = 0, A = 0) contribute nothing; per-graph squares add up."""
+    from tgp import kernels
+    S, A = _inputs(dev, 3, 40, 6, seed=5)
+    S[:, 30:] = 0
+    A[:, 30:, :] = 0
+    A[:, :, 30:] = 0
+    sq = kernels.link_loss_sq(S.to(dev), A.to(dev)).cpu()
+    want = ((A[:, :30, :30] - S[:, :30] @ S[:, :30].transpose(1, 2)) ** 2).sum((1, 2))
+    torch.testing.assert_close(sq, want, **FWD)
+    # exact fit => exactly representable zero residual stays tiny, gradient finite
+    from tgp.utils.losses import link_pred_loss
+    S1 = torch.eye(4).repeat(2, 1, 1).to(dev).requires_grad_(True)
+    A1 = torch.eye(4).repeat(2, 1, 1).to(dev)
+    loss = link_pred_loss(S1, A1, normalize_loss=False)
+    loss.backward()
+    assert float(loss.detach()) == 0.0 and torch.isfinite(S1.grad).all()
+
+
+@pytest.mark.parametrize("B,N,K", [(3, 50, 7), (2, 128, 16), (2, 333, 17)])
+def test_link_loss_gradients(dev, B, N, K):
+    from tgp.utils.losses import link_pred_loss
+    S0, A0 = _inputs(dev, B, N, K, seed=1)
+
+    def run(native):
+        S = S0.to(dev).requires_grad_(True)
+        A = A0.to(dev).requires_grad_(True)
+        if native:
+            loss = link_pred_loss(S, A, normalize_loss=False)
+        else:
+            loss = torch.norm(A - S @ S.transpose(1, 2), p=2)
+        loss.backward()
+        return loss.detach(), S.grad, A.grad
+
+    for a, b in zip(run(True), run(False)):
+        torch.testing.assert_close(a, b, **BWD)
+
+
+@pytest.mark.parametrize("B,N,K", SHAPES)
+def test_entropy_and_cut_and_ortho_match_oracle(dev, B, N, K):
+    from tgp.utils.losses import entropy_loss, mincut_loss, orthogonality_loss
+    S, A = _inputs(dev, B, N, K, seed=N + 1)
+    Sd, Ad = S.to(dev), A.to(dev)
+    n_nodes = B * N - 3
+    torch.testing.assert_close(entropy_loss(Sd, n_nodes).cpu(), O.entropy_loss(S.double(), n_nodes).float(), **FWD)
+    raw = S.transpose(1, 2) @ A @ S
+    torch.testing.assert_close(mincut_loss(Ad, Sd, raw.to(dev)).cpu(), O.mincut_loss(A, S, raw), **FWD)
+    torch.testing.assert_close(orthogonality_loss(Sd).cpu(), O.orthogonality_loss(S), **FWD)
+    with pytest.raises(ValueError):
+        orthogonality_loss(Sd, batch_reduction="max")
+
+
+def test_entropy_cut_ortho_gradients(dev):
+    from tgp.utils.losses import entropy_loss, mincut_loss, orthogonality_loss
+    B, N, K = 3, 70, 9
+    S0, A0 = _inputs(dev, B, N, K, seed=2)
+    eps = 1e-8
+
+    def run(native):
+        S = S0.to(dev).requires_grad_(True)
+        A = A0.to(dev).requires_grad_(True)
+        raw = S.transpose(1, 2) @ A @ S
+        if native:
+            loss = entropy_loss(S, B * N) + 3.0 * mincut_loss(A, S, raw) + 2.0 * orthogonality_loss(S, "sum")
+        else:
+            ent = (-(S * torch.log(S + eps)).sum(-1)).sum() / (B * N)
+            num = torch.einsum("ijj->i", raw)
+            den = torch.einsum("bnk,bn,bnk->b", S, A.sum(-1), S)
+            cut = (-(num / (den + eps))).mean()
+            sts = S.transpose(1, 2) @ S
+            sts = sts / torch.norm(sts, dim=(-2, -1), keepdim=True)
+            ortho = torch.norm(sts - torch.eye(K, device=dev) / math.sqrt(K), dim=(-2, -1)).sum()
+            loss = ent + 3.0 * cut + 2.0 * ortho
+        loss.backward()
+        return loss.detach(), S.grad, A.grad
+
+    for a, b in zip(run(True), run(False)):
+        torch.testing.assert_close(a, b, **BWD)
+
+
+def test_diffpool_trains_with_fused_losses(dev):
+    """End to end: DiffPool forward + loss + backward reaches the selector's weights."""
+    from tgp.poolers import get_pooler
+    torch.manual_seed(0)
+    B, N, F, K = 4, 48, 8, 6
+    pooler = get_pooler("diff", in_channels=F, k=K).to(dev)
+    x = torch.randn(B, N, F, device=dev)
+    adj = (torch.rand(B, N, N, device=dev) < 0.2).float()
+    adj = ((adj + adj.transpose(1, 2)) > 0).float()
+    out = pooler(x=x, adj=adj)
+    total = out.x.sum() + sum(out.get_loss_value())
+    total.backward()
+    grads = [p.grad for p in pooler.parameters()]
+    assert grads and all(g is not None and torch.isfinite(g).all() and g.abs().sum() > 0 for g in grads)

@@ -382,3 +382,31 @@ def test_rowlocal_coalesce_long_rows(dev):
         ref_ei, ref_ew = O.sparse_connect(ei, ew, torch.arange(n), cluster, n, k, reduce_op=op)
         assert torch.equal(got_ei.cpu(), ref_ei)
         torch.testing.assert_close(got_ew.cpu(), ref_ew, rtol=RTOL, atol=ATOL)
+
+
+def test_fused_reduce_connect_equals_operators(dev):
+    """DenseSRCPooling.reduce_connect (one native call) == BaseReduce + DenseConnect called one after the other,
+    bit for bit, on both the generic MFMA path and the one-wave-per-graph path; under autograd it declines."""
+    from tgp.connect import DenseConnect
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    from tgp.src import DenseSRCPooling
+    from tgp.utils.ops import postprocess_adj_pool_dense
+    g = torch.Generator(device=dev).manual_seed(3)
+    for (B, N, K, F) in [(3, 200, 12, 9), (70, 60, 20, 32), (64, 40, 8, 16)]:
+        S = torch.softmax(torch.randn(B, N, K, device=dev, generator=g), -1)
+        A = (torch.rand(B, N, N, device=dev, generator=g) < 0.1).float()
+        X = torch.randn(B, N, F, device=dev, generator=g)
+        so = SelectOutput(s=S)
+        for flags in [(True, True, True, False), (True, False, False, True), (False, True, False, True)]:
+            red, conn = BaseReduce(), DenseConnect(*flags)
+            pool = DenseSRCPooling(reducer=red, connector=conn, adj_transpose=flags[2])
+            with torch.no_grad():
+                xp, raw, ap = pool.reduce_connect(X, A, so, want_raw=True)
+                xp2, _ = red(X, so)
+                raw2 = conn.dense_connect(adj=A, s=S)
+                ap2, _ = conn(A, so)
+                ap3 = postprocess_adj_pool_dense(raw2, *flags)
+            assert torch.equal(xp, xp2) and torch.equal(raw, raw2) and torch.equal(ap, ap2)
+            torch.testing.assert_close(ap, ap3, rtol=1e-5, atol=1e-5)
+    assert pool.reduce_connect(X, A, SelectOutput(s=S.clone().requires_grad_(True))) is None

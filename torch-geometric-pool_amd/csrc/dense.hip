@@ -48,6 +48,10 @@ struct GemmArgs {
   int splits;              // split of Kd across workgroups
   int k_per_split;         // multiple of BK
   const int64_t* k_ptr;    // optional [batches+1]: batch b reduces over rows k_ptr[b]..k_ptr[b+1]
+  // MODE 1 only (residual epilogue): nothing is stored; each workgroup writes sum((resid - C)^2) of its tile
+  const float* resid;
+  long ldr, sR;
+  float* partial;          // [batches][tiles_m * tiles_n]
 };
 
 __device__ __forceinline__ float4 ld4_guarded(const float* p, bool ok) {
@@ -61,11 +65,14 @@ __device__ __forceinline__ float4 ld4_guarded(const float* p, bool ok) {
 // A_KMAJOR = false: A stored [M][Kd] (k contiguous).  true: stored [Kd][M] (m contiguous).
 // ALIGNED: every leading dimension / extent is a multiple of 4 floats and every base is 16-byte
 // aligned, so all traffic is float4 with one predicate per vector.  Otherwise: scalar guarded path.
-template <bool A_KMAJOR, bool ALIGNED, int BM, int BN>
+// MODE 0: C = op(A) Bm.  MODE 1 (link-prediction residual, utils/losses.py:644-708): Bm is stored
+// [Nc][Kd] (n-major, i.e. the product is A Bm^T), and instead of storing C the epilogue accumulates
+// sum((resid - C)^2) over the tile, so S S^T never exists in memory.
+template <bool A_KMAJOR, bool ALIGNED, int BM, int BN, int MODE>
 __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
   constexpr int THREADS = BM * 4;
   constexpr int NT = BN / 64;                       // 32x32 MFMA tiles per wave (wave strip = 32 x BN/2)
-  constexpr int B_TILE_FLOATS = BK * BN;
+  constexpr int B_TILE_FLOATS = MODE == 1 ? BN * LDA_ROWMAJOR : BK * BN;
   constexpr int BN_LANES = BN / 4;                  // lanes per k-row of the B tile
   constexpr int A_TILE_FLOATS = BM * LDA_ROWMAJOR;  // >= BK*BM, used for both A layouts
   constexpr int STAGE_FLOATS = A_TILE_FLOATS + B_TILE_FLOATS;
@@ -130,16 +137,29 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < B_VECS; ++i) {  // [32 k][BN n]: BN_LANES lanes cover one row
-      const int k = k0 + tid / BN_LANES + i * (THREADS / BN_LANES), n = n0 + (tid % BN_LANES) * 4;
-      const float* p = Bm + static_cast<long>(k) * ldb + n;
-      if constexpr (ALIGNED) {
-        rb[i] = ld4_guarded(p, k < k_end && n < Nc);
-      } else {
-        float t[4];
+    for (int i = 0; i < B_VECS; ++i) {
+      if constexpr (MODE == 1) {        // [BN n][32 k]: 8 lanes cover one 128-byte row segment
+        const int n = n0 + (tid >> 3) + i * (THREADS / 8), k = k0 + (tid & 7) * 4;
+        const float* p = Bm + static_cast<long>(n) * ldb + k;
+        if constexpr (ALIGNED) {
+          rb[i] = ld4_guarded(p, n < Nc && k < k_end);
+        } else {
+          float t[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = (k < k_end && n + j < Nc) ? p[j] : 0.f;
-        rb[i] = make_float4(t[0], t[1], t[2], t[3]);
+          for (int j = 0; j < 4; ++j) t[j] = (n < Nc && k + j < k_end) ? p[j] : 0.f;
+          rb[i] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      } else {                          // [32 k][BN n]: BN_LANES lanes cover one row
+        const int k = k0 + tid / BN_LANES + i * (THREADS / BN_LANES), n = n0 + (tid % BN_LANES) * 4;
+        const float* p = Bm + static_cast<long>(k) * ldb + n;
+        if constexpr (ALIGNED) {
+          rb[i] = ld4_guarded(p, k < k_end && n < Nc);
+        } else {
+          float t[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t[j] = (k < k_end && n + j < Nc) ? p[j] : 0.f;
+          rb[i] = make_float4(t[0], t[1], t[2], t[3]);
+        }
       }
     }
   };
@@ -154,8 +174,14 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < B_VECS; ++i)
-      *reinterpret_cast<float4*>(Bs + (tid / BN_LANES + i * (THREADS / BN_LANES)) * BN + (tid % BN_LANES) * 4) = rb[i];
+    for (int i = 0; i < B_VECS; ++i) {
+      if constexpr (MODE == 1) {
+        float* d = Bs + ((tid >> 3) + i * (THREADS / 8)) * LDA_ROWMAJOR + (tid & 7) * 4;
+        d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w;
+      } else {
+        *reinterpret_cast<float4*>(Bs + (tid / BN_LANES + i * (THREADS / BN_LANES)) * BN + (tid % BN_LANES) * 4) = rb[i];
+      }
+    }
   };
 
   f32x16 acc[NT];
@@ -165,9 +191,26 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int lm = lane & 31, lk = lane >> 5;
+  // MODE 1: the residual tile is requested before the first k-step and consumed in the epilogue, so its
+  // HBM latency hides behind the whole product (with Kd = K small the loop is only a few steps long).
+  float rres[MODE == 1 ? NT : 1][16];
+  if constexpr (MODE == 1) {
+    const float* __restrict__ Rm = g.resid + static_cast<long>(batch) * g.sR;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 32 + lm;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        rres[j][r] = (row < g.M && col < Nc) ? Rm[static_cast<long>(row) * g.ldr + col] : 0.f;
+      }
+    }
+  }
   const int a_off = A_KMAJOR ? lk * BM + wm * 32 + lm : (wm * 32 + lm) * LDA_ROWMAJOR + lk;
   const int a_step = A_KMAJOR ? 2 * BM : 2;
-  const int b_off = lk * BN + wn * (BN / 2) + lm;
+  const int b_off = MODE == 1 ? (wn * (BN / 2) + lm) * LDA_ROWMAJOR + lk : lk * BN + wn * (BN / 2) + lm;
+  constexpr int b_step = MODE == 1 ? 2 : 2 * BN;               // one k-pair
+  constexpr int b_tile = MODE == 1 ? 32 * LDA_ROWMAJOR : 32;   // next 32 output columns
   // MFMAs of k-pairs [p0, p1) of one LDS stage; the LDS operands of pair p+1 are requested before the
   // MFMAs of pair p are issued (sched_group_barrier pins that order).
   float a_cur, b_cur[NT];
@@ -180,7 +223,7 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
       if (p + 1 < BK / 2) {
         a_nxt = As[a_off + (p + 1) * a_step];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) b_nxt[j] = Bs[b_off + 2 * (p + 1) * BN + 32 * j];
+        for (int j = 0; j < NT; ++j) b_nxt[j] = Bs[b_off + (p + 1) * b_step + b_tile * j];
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
@@ -211,7 +254,7 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
     float* Ln = (t & 1) ? L0 : L1;
     a_cur = As[a_off];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) b_cur[j] = Bs[b_off + 32 * j];
+    for (int j = 0; j < NT; ++j) b_cur[j] = Bs[b_off + b_tile * j];
     mfma_pairs(As, Bs, 0, 4);
     __builtin_amdgcn_sched_barrier(0);
     if (t + 1 < nk) store_stage(ra0, rb0, Ln, Ln + A_TILE_FLOATS);
@@ -225,6 +268,29 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -----------
+  if constexpr (MODE == 1) {
+    // rows / columns past the edge: operands were zero-filled, so acc = 0 = rres there
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = rres[j][r] - acc[j][r];
+        sq = fmaf(d, d, sq);
+      }
+    // fixed-order reduction: lanes (xor butterfly) -> waves (LDS, summed in wave order)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    __syncthreads();
+    if (lane == 0) smem[wave] = sq;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int w = 0; w < THREADS / 64; ++w) t += smem[w];
+      g.partial[static_cast<long>(batch) * (g.tiles_m * g.tiles_n) + tm * g.tiles_n + tn_all] = t;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + wn * (BN / 2) + j * 32 + lm;
@@ -268,14 +334,14 @@ static TileCfg pick_tile(int64_t M, int64_t max_nc, int64_t batches_x_splits, co
   return t;
 }
 
-template <bool A_KMAJOR, int BM, int BN>
+template <bool A_KMAJOR, int BM, int BN, int MODE = 0>
 static void launch_gemm_cfg(const GemmArgs& g, int batches, hipStream_t stream) {
   const int nwg = batches * g.splits * g.tiles_m * g.tiles_n;
-  const size_t lds = 2 * (BM * LDA_ROWMAJOR + BK * BN) * sizeof(float);
+  const size_t lds = 2 * (BM * LDA_ROWMAJOR + (MODE == 1 ? BN * LDA_ROWMAJOR : BK * BN)) * sizeof(float);
   if (gemm_aligned(g))
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, true, BM, BN>), dim3(nwg), dim3(BM * 4), lds, stream, g);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, true, BM, BN, MODE>), dim3(nwg), dim3(BM * 4), lds, stream, g);
   else
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, false, BM, BN>), dim3(nwg), dim3(BM * 4), lds, stream, g);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, false, BM, BN, MODE>), dim3(nwg), dim3(BM * 4), lds, stream, g);
 }
 
 // g.tiles_* are filled in here: they follow from the tile shape chosen for this problem.
@@ -290,6 +356,19 @@ static void launch_gemm(GemmArgs g, int batches, hipStream_t stream) {
   else if (t.bm == 64) launch_gemm_cfg<A_KMAJOR, 64, 128>(g, batches, stream);
   else if (t.bn == 64) launch_gemm_cfg<A_KMAJOR, 128, 64>(g, batches, stream);
   else launch_gemm_cfg<A_KMAJOR, 128, 128>(g, batches, stream);
+}
+
+// MODE 1 launch: sum((resid - A Bm^T)^2) per tile into g.partial; returns tiles per batch element.
+static int launch_gemm_residual(GemmArgs g, int batches, hipStream_t stream, bool dry_run = false) {
+  const TileCfg t = pick_tile(g.M, g.rhs[0].Nc, batches, g);
+  g.tiles_m = cdiv(g.M, t.bm);
+  g.tiles_n0 = g.tiles_n = cdiv(g.rhs[0].Nc, t.bn);
+  if (dry_run) return g.tiles_m * g.tiles_n;
+  if (t.bm == 64 && t.bn == 64) launch_gemm_cfg<false, 64, 64, 1>(g, batches, stream);
+  else if (t.bm == 64) launch_gemm_cfg<false, 64, 128, 1>(g, batches, stream);
+  else if (t.bn == 64) launch_gemm_cfg<false, 128, 64, 1>(g, batches, stream);
+  else launch_gemm_cfg<false, 128, 128, 1>(g, batches, stream);
+  return g.tiles_m * g.tiles_n;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -498,13 +577,79 @@ __global__ __launch_bounds__(256) void post_small_kernel(PostArgs p, int B) {
   }
 }
 
+// K <= 32: the whole matrix lives in one wave's registers.  Lanes 0..31 hold column `lane`, lanes 32..63
+// hold row `lane - 32` (a second, transposed look at the same 4 KB), so both the axis -2 and the axis -1
+// degree are plain per-lane sums in index order - the same fixed order as post_small_kernel.
+__global__ __launch_bounds__(256) void post_tiny_kernel(PostArgs p, int B) {
+  const int lane = lane_id(), K = p.K;
+  const int b = blockIdx.x * 4 + wave_id();
+  if (b >= B) return;
+  const float* sb = p.src + static_cast<long>(b) * p.s_batch;
+  float* rawb = p.raw ? p.raw + static_cast<long>(b) * K * K : nullptr;
+  float* dstb = p.dst ? p.dst + static_cast<long>(b) * K * K : nullptr;
+  const int idx = lane & 31;
+  const bool hi = lane >= 32, ok = idx < K;
+  const bool rsl = p.flags & TGP_REMOVE_SELF_LOOPS;
+  float t[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    float v = 0.f;
+    if (ok && j < K) {
+      const long o = hi ? static_cast<long>(idx) * p.ld_src + j : static_cast<long>(j) * p.ld_src + idx;
+      v = sb[o];
+      for (int sp = 1; sp < p.splits; ++sp) v = __fadd_rn(v, sb[sp * p.s_split + o]);
+    }
+    t[j] = v;
+  }
+  if (rawb && !hi && ok) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (j < K) rawb[j * K + idx] = t[j];
+  }
+  if (!dstb) return;
+  if (rsl) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (j == idx) t[j] = 0.f;
+  }
+  if (p.flags & TGP_DEGREE_NORM) {
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) sum = __fadd_rn(sum, t[j]);  // lanes < 32: column sums; >= 32: row sums
+    const bool by_cols = p.flags & TGP_SUM_AXIS_ROWS;
+    const float d = sqrtf(fmaxf(__shfl(sum, by_cols ? idx : 32 + idx, WAVE), TGP_EPS));  // d[idx] on every lane
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float dj = __shfl(d, j, WAVE);
+      t[j] = by_cols ? (t[j] / d) / dj : (t[j] / dj) / d;  // lanes < 32 hold element (row j, col idx)
+    }
+  }
+  if (p.flags & TGP_EDGE_WEIGHT_NORM) {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (!hi && ok && j < K) m = fmaxf(m, fabsf(t[j]));
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, WAVE));
+    if (m == 0.f) m = 1.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) t[j] = t[j] / m;
+  }
+  if (!hi && ok) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+      if (j < K) dstb[j * K + idx] = t[j];
+  }
+}
+
 static size_t post_ws_floats(int64_t B, int64_t K) { return static_cast<size_t>(B * K + B * POST_BLOCKS); }
 
 static void launch_post(PostArgs p, int64_t B, float* ws, hipStream_t stream) {
   const int K = p.K;
-  if (K <= 64) {  // whole graph in one wave's registers: one launch instead of three or four
+  if (K <= 64) {  // one wave per graph: one launch instead of three or four
     const dim3 grid(static_cast<unsigned>((B + 3) / 4));
-    hipLaunchKernelGGL(post_small_kernel, grid, dim3(256), 0, stream, p, static_cast<int>(B));
+    if (K <= 32) hipLaunchKernelGGL(post_tiny_kernel, grid, dim3(256), 0, stream, p, static_cast<int>(B));
+    else hipLaunchKernelGGL(post_small_kernel, grid, dim3(256), 0, stream, p, static_cast<int>(B));
     return;
   }
   p.dvec = ws;
@@ -544,15 +689,17 @@ __global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------
 // Small graphs (N <= 64, K <= 32, F <= 32; e.g. the PROTEINS-shaped batch of BASELINE configs[2]):
-// one WAVE owns one graph.  A, S and X of the graph are staged once in LDS (zero padded to 64 x 64,
-// 64 x 32, 64 x 32), then U = A S (64 MFMAs), X' = S^T X (32) and A' = S^T U (32) run back to back;
-// U never leaves the accumulators: register r of the 32x32 C/D layout holds rows (rho(r), rho(r)+4)
-// for the two half-waves, which is exactly a k-pair of the next MFMA's B operand, so S^T is fetched
-// in that k order and the accumulator is passed straight in.  The post-processing (utils/ops.py:282-335)
-// happens in registers + wave shuffles.  Each graph crosses HBM once: this path is HBM-bound.
+// one WAVE owns one graph.  S and X go straight from HBM into the MFMA operand registers (row-coalesced:
+// lane = column, one node row per half-wave); only A, whose operand layout is the transpose of its
+// memory layout, is staged through LDS (zero padded 64 x 65 per wave, so two workgroups fit a CU).
+// Then X' = S^T X (32 MFMAs), U = A S (64) and A' = S^T U (32) run back to back.  U never leaves the
+// accumulators: register r of the 32x32 C/D layout holds rows (rho(r), rho(r)+4) for the two half-waves,
+// which is exactly a k-pair of the next MFMA's B operand, so every product walks the node dimension in
+// that order (node(q) below) and all three share one register copy of S.  The post-processing
+// (utils/ops.py:282-335) happens in registers + wave shuffles.  Each graph crosses HBM once: HBM-bound.
 // ------------------------------------------------------------------------------------------
 constexpr int SG_N = 64, SG_K = 32, SG_LDA = 65;
-constexpr int SG_WAVE_FLOATS = SG_N * SG_LDA + SG_N * SG_K + SG_N * SG_K;  // A | S | X
+constexpr int SG_WAVE_FLOATS = SG_N * SG_LDA;  // A only
 
 struct SmallArgs {
   const float* S; const float* A; const float* X;
@@ -561,29 +708,64 @@ struct SmallArgs {
 };
 
 __device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
+// uniform base + 32-bit per-lane byte offset: lets the load use the SGPR-base addressing form
+__device__ __forceinline__ const float* byte_off(const float* base, int bytes) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + static_cast<unsigned>(bytes));
+}
 
-__global__ __launch_bounds__(256) void dense_pool_small_kernel(SmallArgs p) {
+__global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = lane_id(), w = wave_id();
+  const int lane = lane_id();
+  const int w = __builtin_amdgcn_readfirstlane(wave_id());  // wave-uniform => graph bases stay in SGPRs
   const int lm = lane & 31, lk = lane >> 5;
   float* As = smem + w * SG_WAVE_FLOATS;
-  float* Ss = As + SG_N * SG_LDA;
-  float* Xs = Ss + SG_N * SG_K;
   const int N = p.N, K = p.K, F = p.F;
   const bool at = p.flags & TGP_ADJ_TRANSPOSED;
-  for (int b0 = blockIdx.x * 4; b0 < p.B; b0 += gridDim.x * 4) {
-    const int b = b0 + w;
-    const bool live = b < p.B;
-    // ---- stage the graph (zero padded): batched float4 loads, no integer division -------------
+  const int b = blockIdx.x * 4 + w;  // one graph per wave, no loop (keeps the 64 + 64 load offsets transient)
+  if (b >= p.B) return;
+  {
+    // ---- request everything up front: A (float4 rows), then S and X in operand order ------------
+    // out-of-range elements read element 0 of the graph (always valid) and are replaced by 0 afterwards, so
+    // the loads stay unconditional and are issued back to back
+    float4 v[16];
     if (p.A) {  // 16 lanes per row (64 floats), 4 rows per wave-instruction, 16 instructions
-      const float* Ab = p.A + static_cast<long>(live ? b : 0) * N * N;
-      float4 v[16];
+      const float* Ab = p.A + static_cast<long>(b) * N * N;
       const int q = lane & 15;
+      const bool qok = 4 * q < N;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int i = (lane >> 4) + 4 * t;
-        v[t] = ld4_guarded(Ab + static_cast<long>(i) * N + 4 * q, live && i < N && 4 * q < N);
+        const bool ok = qok && i < N;
+        const float4 r = *reinterpret_cast<const float4*>(byte_off(Ab, ok ? (i * N + 4 * q) * 4 : 0));
+        v[t] = ok ? r : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+    }
+    // step q of every product contracts node rows node(q) = 32*(q>>4) + rho(q&15) + 4*lk
+    float sr[32], xr[32];
+    {
+      const float* Sb = p.S + static_cast<long>(b) * N * K;
+      const bool cok = lm < K;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
+        const bool ok = cok && node < N;
+        const float r = *byte_off(Sb, ok ? (node * K + lm) * 4 : 0);
+        sr[q] = ok ? r : 0.f;
+      }
+    }
+    if (p.X) {
+      const float* Xb = p.X + static_cast<long>(b) * N * F;
+      const bool cok = lm < F;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
+        const bool ok = cok && node < N;
+        const float r = *byte_off(Xb, ok ? (node * F + lm) * 4 : 0);
+        xr[q] = ok ? r : 0.f;
+      }
+    }
+    if (p.A) {
+      const int q = lane & 15;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int i = (lane >> 4) + 4 * t;
@@ -596,45 +778,17 @@ __global__ __launch_bounds__(256) void dense_pool_small_kernel(SmallArgs p) {
         }
       }
     }
-    {           // 8 lanes per row (32 floats), 8 rows per wave-instruction, 8 instructions
-      const float* Sb = p.S + static_cast<long>(live ? b : 0) * N * K;
-      float4 v[8];
-      const int q = lane & 7;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int k = (lane >> 3) + 8 * t;
-        v[t] = ld4_guarded(Sb + static_cast<long>(k) * K + 4 * q, live && k < N && 4 * q < K);
-      }
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-        *reinterpret_cast<float4*>(Ss + ((lane >> 3) + 8 * t) * SG_K + 4 * q) = v[t];
-    }
-    if (p.X) {
-      const float* Xb = p.X + static_cast<long>(live ? b : 0) * N * F;
-      float4 v[8];
-      const int q = lane & 7;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int k = (lane >> 3) + 8 * t;
-        v[t] = ld4_guarded(Xb + static_cast<long>(k) * F + 4 * q, live && k < N && 4 * q < F);
-      }
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-        *reinterpret_cast<float4*>(Xs + ((lane >> 3) + 8 * t) * SG_K + 4 * q) = v[t];
-    }
-    __syncthreads();
+    // the tile belongs to this wave alone and LDS serves a wave's requests in order: no workgroup barrier
+    __builtin_amdgcn_wave_barrier();
 
     // ---- X' = S^T X ---------------------------------------------------------------------
     if (p.X && p.x_pool) {
       f32x16 ax;
 #pragma unroll
       for (int r = 0; r < 16; ++r) ax[r] = 0.f;
-#pragma unroll 8
-      for (int q = 0; q < SG_N / 2; ++q) {
-        const int k = 2 * q + lk;
-        ax = __builtin_amdgcn_mfma_f32_32x32x2f32(Ss[k * SG_K + lm], Xs[k * SG_K + lm], ax, 0, 0, 0);
-      }
-      if (live && lm < F) {
+#pragma unroll
+      for (int q = 0; q < 32; ++q) ax = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[q], xr[q], ax, 0, 0, 0);
+      if (lm < F) {
         float* o = p.x_pool + static_cast<long>(b) * K * F;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -649,21 +803,20 @@ __global__ __launch_bounds__(256) void dense_pool_small_kernel(SmallArgs p) {
       f32x16 u[2], aa;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { u[0][r] = 0.f; u[1][r] = 0.f; aa[r] = 0.f; }
-#pragma unroll 4
-      for (int q = 0; q < SG_N / 2; ++q) {
-        const int k = 2 * q + lk;
-        const float bs = Ss[k * SG_K + lm];
-        u[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[lm * SG_LDA + k], bs, u[0], 0, 0, 0);
-        u[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(32 + lm) * SG_LDA + k], bs, u[1], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
+        u[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[lm * SG_LDA + node], sr[q], u[0], 0, 0, 0);
+        u[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(32 + lm) * SG_LDA + node], sr[q], u[1], 0, 0, 0);
       }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          aa = __builtin_amdgcn_mfma_f32_32x32x2f32(Ss[(32 * mt + rho(r) + 4 * lk) * SG_K + lm], u[mt][r], aa, 0, 0, 0);
+          aa = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[mt * 16 + r], u[mt][r], aa, 0, 0, 0);
 
       // aa[r] = A'[row = rho(r) + 4*lk][col = lm]
-      if (live && p.adj_raw && lm < K) {
+      if (p.adj_raw && lm < K) {
         float* o = p.adj_raw + static_cast<long>(b) * K * K;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -724,7 +877,7 @@ __global__ __launch_bounds__(256) void dense_pool_small_kernel(SmallArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) aa[r] = aa[r] / m;
         }
-        if (live && lm < K) {
+        if (lm < K) {
           float* o = p.adj_pool + static_cast<long>(b) * K * K;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -734,7 +887,6 @@ __global__ __launch_bounds__(256) void dense_pool_small_kernel(SmallArgs p) {
         }
       }
     }
-    __syncthreads();
   }
 }
 
@@ -803,8 +955,7 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
     SmallArgs q{S, want_a ? A : nullptr, want_x ? X : nullptr, static_cast<int>(B), static_cast<int>(N),
                 static_cast<int>(K), static_cast<int>(F), flags, want_x ? x_pool : nullptr,
                 want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr};
-    int grid = static_cast<int>((B + 3) / 4);
-    if (grid > 256 * 4) grid = 256 * 4;
+    const int grid = static_cast<int>((B + 3) / 4);
     hipLaunchKernelGGL(dense_pool_small_kernel, dim3(grid), dim3(256), 4 * SG_WAVE_FLOATS * sizeof(float), stream, q);
     return check_launch("tgp_dense_pool_f32(small)");
   }
@@ -924,4 +1075,62 @@ extern "C" int tgp_segment_gemm_tn_f32(const float* S, const float* Y, const int
   g.k_ptr = ptr;
   launch_gemm<true>(g, static_cast<int>(B), stream);
   return check_launch("tgp_segment_gemm_tn_f32");
+}
+
+// N3: DiffPool's link-prediction residual ||A - S S^T||_F^2 per graph (utils/losses.py:644-708 computes
+// torch.norm(adj - S S^T) after materialising S S^T [B,N,N]).  Here S S^T tiles live only in the MFMA
+// accumulators; the epilogue subtracts them from the A tile and reduces the squares.  sq[b] is summed in a
+// fixed order (tile partials in tile order), so the result is reproducible run to run.
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int T,
+                                                           float* __restrict__ out) {
+  __shared__ float sh[256];
+  const float* p = partial + static_cast<long>(blockIdx.x) * T;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < T; i += 256) s += p[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (static_cast<int>(threadIdx.x) < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
+static tgp::GemmArgs link_loss_args(const float* S, const float* A, int64_t N, int64_t K) {
+  tgp::GemmArgs g{};
+  g.A = S; g.lda = K; g.sA = N * K;
+  g.M = static_cast<int>(N); g.Kd = static_cast<int>(K);
+  g.rhs[0] = tgp::GemmRhs{S, nullptr, static_cast<int>(N), K, 0, N * K, 0, 0};
+  g.splits = 1; g.k_per_split = static_cast<int>((K + tgp::BK - 1) / tgp::BK * tgp::BK);
+  g.resid = A; g.ldr = N; g.sR = N * N;
+  return g;
+}
+
+extern "C" size_t tgp_link_loss_workspace_bytes(int64_t B, int64_t N, int64_t K) {
+  if (B <= 0 || N <= 0) return 256;
+  tgp::GemmArgs g = link_loss_args(nullptr, nullptr, N, K);
+  const int tiles = tgp::launch_gemm_residual(g, static_cast<int>(B), nullptr, true);
+  return tgp::align_up(static_cast<size_t>(B) * tiles * sizeof(float)) + 256;
+}
+
+extern "C" int tgp_link_loss_f32(const float* S, const float* A, int64_t B, int64_t N, int64_t K, float* sq,
+                                 void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_link_loss_f32: negative size");
+  if (B == 0) return TGP_OK;
+  TGP_REQUIRE(sq, TGP_ERR_INVALID, "tgp_link_loss_f32: null output");
+  if (N == 0) {
+    (void)hipMemsetAsync(sq, 0, B * sizeof(float), stream);
+    return tgp::check_launch("tgp_link_loss_f32");
+  }
+  TGP_REQUIRE(S && A && ws, TGP_ERR_INVALID, "tgp_link_loss_f32: null pointer");
+  TGP_REQUIRE(N < (1ll << 31) && K < (1ll << 31), TGP_ERR_RANGE, "tgp_link_loss_f32: too large");
+  TGP_REQUIRE(ws_bytes >= tgp_link_loss_workspace_bytes(B, N, K), TGP_ERR_WORKSPACE,
+              "tgp_link_loss_f32: workspace too small");
+  TGP_REQUIRE(B * ((N + 63) / 64) * ((N + 63) / 64) < (1ll << 31), TGP_ERR_RANGE, "tgp_link_loss_f32: grid too large");
+  tgp::GemmArgs g = link_loss_args(S, A, N, K);
+  g.partial = static_cast<float*>(ws);
+  const int tiles = tgp::launch_gemm_residual(g, static_cast<int>(B), stream);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, g.partial, tiles, sq);
+  return tgp::check_launch("tgp_link_loss_f32");
 }

@@ -1,0 +1,140 @@
+// N3: single-pass reductions behind the dense poolers' auxiliary losses.
+//
+//   entropy   sum(-S log(S + eps))                       utils/losses.py:476-483 (DiffPool)
+//   cut terms deg_i = sum_j A[b,i,j],  q_i = sum_k S[b,i,k]^2,  den[b] = sum_i deg_i q_i = trace(S^T D S)
+//                                                        utils/losses.py:39-81 (MinCut)
+//
+// All HBM-bound: every input byte is read once, reductions run in a fixed order (no float atomics).
+#include "common.h"
+
+namespace tgp {
+
+constexpr int RED_BLOCKS = 1024;
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__device__ __forceinline__ float ent_term(float s) { return -s * logf(s + TGP_EPS); }
+
+__global__ __launch_bounds__(256) void entropy_partial_kernel(const float* __restrict__ S, int64_t n,
+                                                              float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  const int64_t n4 = (reinterpret_cast<uintptr_t>(S) % 16 == 0) ? n / 4 : 0;
+  const nt_f32x4* S4 = reinterpret_cast<const nt_f32x4*>(S);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += 256ll * gridDim.x) {
+    const nt_f32x4 v = __builtin_nontemporal_load(S4 + i);
+    acc += (ent_term(v.x) + ent_term(v.y)) + (ent_term(v.z) + ent_term(v.w));
+  }
+  for (int64_t i = n4 * 4 + static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += 256ll * gridDim.x)
+    acc += ent_term(S[i]);
+  const float t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict__ partial, int n,
+                                                        float* __restrict__ out) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+  const float t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+// One wave per node row: deg (row sum of A), q (squared norm of the S row); 4 rows per workgroup.
+__global__ __launch_bounds__(256) void cut_rows_kernel(const float* __restrict__ A, const float* __restrict__ S,
+                                                       int64_t rows, int N, int K, float* __restrict__ deg,
+                                                       float* __restrict__ q) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* a = A + row * N;
+  const float* s = S + row * K;
+  float d = 0.f, qq = 0.f;
+  if ((N & 3) == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0) {
+    const nt_f32x4* a4 = reinterpret_cast<const nt_f32x4*>(a);
+    for (int j = lane; j < N / 4; j += 64) {
+      const nt_f32x4 v = __builtin_nontemporal_load(a4 + j);
+      d += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (int j = lane; j < N; j += 64) d += a[j];
+  }
+  for (int k = lane; k < K; k += 64) qq = fmaf(s[k], s[k], qq);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    d += __shfl_xor(d, o, 64);
+    qq += __shfl_xor(qq, o, 64);
+  }
+  if (lane == 0) {
+    deg[row] = d;
+    q[row] = qq;
+  }
+}
+
+__global__ __launch_bounds__(256) void cut_den_kernel(const float* __restrict__ deg, const float* __restrict__ q,
+                                                      int N, float* __restrict__ den) {
+  __shared__ float sh[4];
+  const float* d = deg + static_cast<int64_t>(blockIdx.x) * N;
+  const float* qq = q + static_cast<int64_t>(blockIdx.x) * N;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) acc = fmaf(d[i], qq[i], acc);
+  const float t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) den[blockIdx.x] = t;
+}
+
+}  // namespace tgp
+
+using namespace tgp;
+
+extern "C" size_t tgp_entropy_sum_workspace_bytes(int64_t n) {
+  (void)n;
+  return RED_BLOCKS * sizeof(float);
+}
+
+extern "C" int tgp_entropy_sum_f32(const float* S, int64_t n, float* out, void* ws, size_t ws_bytes,
+                                   void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(n >= 0, TGP_ERR_INVALID, "tgp_entropy_sum_f32: negative size");
+  TGP_REQUIRE(out, TGP_ERR_INVALID, "tgp_entropy_sum_f32: null output");
+  if (n == 0) {
+    (void)hipMemsetAsync(out, 0, sizeof(float), stream);
+    return check_launch("tgp_entropy_sum_f32");
+  }
+  TGP_REQUIRE(S && ws, TGP_ERR_INVALID, "tgp_entropy_sum_f32: null pointer");
+  TGP_REQUIRE(ws_bytes >= tgp_entropy_sum_workspace_bytes(n), TGP_ERR_WORKSPACE,
+              "tgp_entropy_sum_f32: workspace too small");
+  int blocks = cdiv(n, 256 * 4 * 4);
+  if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  float* partial = static_cast<float*>(ws);
+  hipLaunchKernelGGL(entropy_partial_kernel, dim3(blocks), dim3(256), 0, stream, S, n, partial);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, out);
+  return check_launch("tgp_entropy_sum_f32");
+}
+
+extern "C" int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int64_t N, int64_t K, float* deg,
+                                 float* q, float* den, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_cut_terms_f32: negative size");
+  if (B == 0) return TGP_OK;
+  TGP_REQUIRE(den, TGP_ERR_INVALID, "tgp_cut_terms_f32: null output");
+  if (N == 0) {
+    (void)hipMemsetAsync(den, 0, B * sizeof(float), stream);
+    return check_launch("tgp_cut_terms_f32");
+  }
+  TGP_REQUIRE(A && deg && q && (K == 0 || S), TGP_ERR_INVALID, "tgp_cut_terms_f32: null pointer");
+  TGP_REQUIRE(N < (1ll << 31) && K < (1ll << 31) && B * N < (1ll << 33), TGP_ERR_RANGE, "tgp_cut_terms_f32: too large");
+  const int64_t rows = B * N;
+  hipLaunchKernelGGL(cut_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, A, S, rows, static_cast<int>(N),
+                     static_cast<int>(K), deg, q);
+  hipLaunchKernelGGL(cut_den_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, deg, q, static_cast<int>(N), den);
+  return check_launch("tgp_cut_terms_f32");
+}

@@ -245,6 +245,49 @@ def postprocess_dense(adj_pool: Tensor, flags: int, inplace: bool = False) -> Te
     return dst
 
 
+def link_loss_sq(s: Tensor, adj: Tensor) -> Tensor:
+    """sq[b] = ||adj[b] - s[b] s[b]^T||_F^2 without materialising s s^T (utils/losses.py:644-708)."""
+    dev = N.require_device(s, adj)
+    s, adj = N.f32c(s), N.f32c(adj)
+    B, Nn, K = s.shape
+    if adj.shape != (B, Nn, Nn):
+        raise ValueError(f"adj {tuple(adj.shape)} does not match s {tuple(s.shape)}")
+    sq = torch.empty(B, dtype=torch.float32, device=dev)
+    L = N.lib()
+    ws = N.workspace(L.tgp_link_loss_workspace_bytes(B, Nn, K), dev)
+    N.check(L.tgp_link_loss_f32(N.ptr(s), N.ptr(adj), B, Nn, K, N.ptr(sq), N.ptr(ws), ws.numel(), N.stream_ptr(dev)),
+            "tgp_link_loss_f32")
+    return sq
+
+
+def entropy_sum(s: Tensor) -> Tensor:
+    """0-d tensor sum(-s log(s + eps)) over every element (utils/losses.py:476-483 before / num_nodes)."""
+    dev = N.require_device(s)
+    s = N.f32c(s)
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    L = N.lib()
+    ws = N.workspace(L.tgp_entropy_sum_workspace_bytes(s.numel()), dev)
+    N.check(L.tgp_entropy_sum_f32(N.ptr(s), s.numel(), N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(dev)),
+            "tgp_entropy_sum_f32")
+    return out
+
+
+def cut_terms(adj: Tensor, s: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """(deg [B,N], q [B,N], den [B]): row sums of adj, squared row norms of s, trace(s^T D s)
+    (utils/losses.py:39-81)."""
+    dev = N.require_device(adj, s)
+    adj, s = N.f32c(adj), N.f32c(s)
+    B, Nn, K = s.shape
+    if adj.shape != (B, Nn, Nn):
+        raise ValueError(f"adj {tuple(adj.shape)} does not match s {tuple(s.shape)}")
+    deg = torch.empty(B, Nn, dtype=torch.float32, device=dev)
+    q = torch.empty(B, Nn, dtype=torch.float32, device=dev)
+    den = torch.empty(B, dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_cut_terms_f32(N.ptr(adj), N.ptr(s), B, Nn, K, N.ptr(deg), N.ptr(q), N.ptr(den),
+                                      N.stream_ptr(dev)), "tgp_cut_terms_f32")
+    return deg, q, den
+
+
 def bmm(a: Tensor, b: Tensor, trans_a: bool = False) -> Tensor:
     """C[g] = op(A[g]) @ B[g] on the fp32 matrix cores.  a: [G,M,Kd] (or [G,Kd,M] when trans_a),
     b: [G,Kd,Nc]; 2-D operands are treated as G = 1."""

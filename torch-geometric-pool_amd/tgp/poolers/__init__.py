@@ -146,6 +146,11 @@ class _DenseMLPPooling(DenseSRCPooling):
     def compute_sparse_loss(self, edge_index, edge_weight, S, batch) -> dict:
         raise NotImplementedError
 
+    _loss_needs_raw = False  # MinCut's cut loss reads the raw S^T A S
+
+    def _loss_from_fused(self, adj, so, mask, raw) -> dict:
+        raise NotImplementedError
+
     def _lift(self, x, so, batch, batch_pooled):
         return self.lift(x_pool=x, so=so, batch=batch, batch_pooled=batch_pooled)
 
@@ -159,8 +164,14 @@ class _DenseMLPPooling(DenseSRCPooling):
             x, adj, mask = self._ensure_batched_inputs(x=x, edge_index=adj, edge_weight=edge_weight, batch=batch,
                                                        mask=mask)
             so = self.select(x=x, mask=mask)
-            x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch)
-            adj_pool, loss = self._batched_connect_and_loss(x, adj, so, mask, edge_weight, batch, batch_pool)
+            fused = self.reduce_connect(x, adj, so, want_raw=self._loss_needs_raw)
+            if fused is not None:  # inference: Reduce + Connect in one native call
+                x_pool, raw, adj_pool = fused
+                batch_pool = self.reducer.reduce_batch(so, batch if batch is not None else so.batch)
+                loss = self._loss_from_fused(adj, so, mask, raw)
+            else:
+                x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch)
+                adj_pool, loss = self._batched_connect_and_loss(x, adj, so, mask, edge_weight, batch, batch_pool)
             if self.sparse_output:
                 x_pool, ei, ew, batch_pool = self._finalize_sparse_output(
                     x_pool=x_pool, adj_pool=adj_pool, batch=batch, batch_pooled=batch_pool, so=so)
@@ -195,6 +206,9 @@ class DiffPool(_DenseMLPPooling):
                                    batch_pooled=batch_pooled)
         loss = self.compute_loss(adj=adj, S=so.s, num_nodes=mask.sum().item())
         return adj_pool, loss
+
+    def _loss_from_fused(self, adj, so, mask, raw) -> dict:
+        return self.compute_loss(adj=adj, S=so.s, num_nodes=mask.sum().item())
 
     def compute_loss(self, adj: Tensor, S: Tensor, num_nodes: int) -> dict:
         return {"link_loss": link_pred_loss(S, adj, normalize_loss=self.normalize_loss) * self.link_loss_coeff,
@@ -237,6 +251,11 @@ class MinCutPooling(_DenseMLPPooling):
                                               degree_norm=c.degree_norm, adj_transpose=c.adj_transpose,
                                               edge_weight_norm=c.edge_weight_norm)
         return adj_pool, loss
+
+    _loss_needs_raw = True
+
+    def _loss_from_fused(self, adj, so, mask, raw) -> dict:
+        return self.compute_loss(adj, so.s, raw)
 
     def compute_loss(self, adj: Tensor, S: Tensor, adj_pooled: Tensor) -> dict:
         return {"cut_loss": mincut_loss(adj, S, adj_pooled, batch_reduction="mean") * self.cut_loss_coeff,

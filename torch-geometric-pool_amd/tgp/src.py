@@ -283,6 +283,29 @@ class DenseSRCPooling(SRCPooling):
         super().clear_cache()
         self.preprocessing_cache = None
 
+    def reduce_connect(self, x: Tensor, adj: Tensor, so: SelectOutput, want_raw: bool = False):
+        """Reduce + Connect of a padded dense batch as ONE native call (fused A3 + A7 + A8):
+        ``(x_pool [B,K,F], raw S^T A S or None, adj_pool [B,K,K])``.  ``U = A S`` is formed once and
+        ``S^T [U | X]`` runs as a single grid (one wave per graph when the graphs fit in LDS), so S is read
+        once for both products.  Used by the dense poolers' forward whenever no gradient is required; under
+        autograd the separately differentiable ``reduce`` / ``connect`` operators are used instead and this
+        returns None."""
+        from .connect import DenseConnect
+        from .reduce import BaseReduce
+        from . import kernels as K
+        c = self.connector
+        s = so.s
+        if not (type(c) is DenseConnect and type(self.reducer) is BaseReduce and isinstance(s, Tensor)
+                and not s.is_sparse and s.dim() == 3 and adj.dim() == 3 and x.dim() == 3 and s.is_cuda):
+            return None
+        if torch.is_grad_enabled() and (s.requires_grad or adj.requires_grad or x.requires_grad):
+            return None
+        if s.size(0) != adj.size(0):
+            raise ValueError("Assignment and adjacency batch sizes do not match: "
+                             f"got s.size(0)={s.size(0)} and adj.size(0)={adj.size(0)}.")
+        flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
+        return K.dense_pool(s, adj, x, flags, want_raw=want_raw, want_post=True)
+
     def _finalize_sparse_output(self, x_pool: Tensor, adj_pool: Tensor, batch: Optional[Tensor],
                                 batch_pooled: Optional[Tensor], so: SelectOutput):
         """[B,K,F] / [B,K,K] -> compact block-diagonal representation restricted to the supernodes that

@@ -1,9 +1,10 @@
 """Auxiliary losses DiffPool / MinCut compute between Reduce and Connect
 (reference: tgp/utils/losses.py:39-123, 476-483, 644-708).
 
-These are training objectives, not part of the timed Reduce+Connect path; they are written with
-differentiable torch ops on the device the inputs live on (SURVEY.md 8(f) N3 lists fusing them
-into the GEMM epilogue as a later step).
+The batched dense losses run on native kernels: the link-prediction residual is
+reduced inside the GEMM epilogue so S S^T [B,N,N] is never materialised, the entropy and the
+trace(S^T D S) terms are single-pass reductions, S^T S runs on the matrix cores; each has a closed-form
+backward.  The unbatched (sparse-adjacency) variants are differentiable torch ops over the edge list.
 """
 from __future__ import annotations
 
@@ -14,6 +15,7 @@ import torch
 from torch import Tensor
 
 from .. import eps
+from .. import kernels as K
 from .ops import check_and_filter_edge_weights
 
 
@@ -29,15 +31,84 @@ def _seg_sum(src: Tensor, index: Tensor, size: int) -> Tensor:
     return src.new_zeros((size,) + tuple(src.shape[1:])).index_add_(0, index, src)
 
 
+class _CutDenFn(torch.autograd.Function):
+    """den[b] = trace(S^T D S) = sum_i deg_i ||S_i||^2 with deg = row sums of adj, one pass over adj."""
+
+    @staticmethod
+    def forward(ctx, adj, S):
+        deg, q, den = K.cut_terms(adj, S)
+        ctx.save_for_backward(S, deg, q)
+        return den
+
+    @staticmethod
+    def backward(ctx, g):
+        S, deg, q = ctx.saved_tensors
+        g = g.view(-1, 1, 1)
+        g_adj = g_s = None
+        if ctx.needs_input_grad[0]:
+            g_adj = (g * q.unsqueeze(-1)).expand(-1, -1, q.size(1)).contiguous()
+        if ctx.needs_input_grad[1]:
+            g_s = 2.0 * g * deg.unsqueeze(-1) * S
+        return g_adj, g_s
+
+
+class _GramFn(torch.autograd.Function):
+    """G = S^T S on the matrix cores (split over the node dimension); dS = S (g + g^T)."""
+
+    @staticmethod
+    def forward(ctx, S):
+        ctx.save_for_backward(S)
+        return K.dense_pool(S, None, S)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (S,) = ctx.saved_tensors
+        return K.bmm(S, (g + g.transpose(-1, -2)).contiguous())
+
+
+class _LinkNormFn(torch.autograd.Function):
+    """||adj - S S^T||_F over the whole batch; S S^T only ever exists tile by tile in the MFMA
+    accumulators (forward) and the backward uses d/dS = (4 S S^T S - 2 (A + A^T) S) / (2 norm)."""
+
+    @staticmethod
+    def forward(ctx, S, adj):
+        norm = torch.sqrt(K.link_loss_sq(S, adj).sum())
+        ctx.save_for_backward(S, adj, norm)
+        return norm
+
+    @staticmethod
+    def backward(ctx, g):
+        S, adj, norm = ctx.saved_tensors
+        coef = torch.where(norm > 0, g / norm, torch.zeros_like(norm))  # torch.norm's subgradient at 0
+        g_s = g_adj = None
+        if ctx.needs_input_grad[0]:
+            gram = K.dense_pool(S, None, S)[0]
+            g_s = (2.0 * K.bmm(S, gram) - K.bmm(adj, S) - K.bmm(adj, S, trans_a=True)) * coef
+        if ctx.needs_input_grad[1]:
+            g_adj = (adj - torch.matmul(S, S.transpose(1, 2))) * coef
+        return g_s, g_adj
+
+
+class _EntropySumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, S):
+        ctx.save_for_backward(S)
+        return K.entropy_sum(S)
+
+    @staticmethod
+    def backward(ctx, g):
+        (S,) = ctx.saved_tensors
+        return -(torch.log(S + eps) + S / (S + eps)) * g
+
+
 def mincut_loss(adj: Tensor, S: Tensor, adj_pooled: Tensor, batch_reduction: str = "mean") -> Tensor:
     num = torch.diagonal(adj_pooled, dim1=-2, dim2=-1).sum(-1)
-    deg = adj.sum(-1)  # [B,N]
-    den = (deg.unsqueeze(-1) * S * S).sum(dim=(-2, -1))  # trace(S^T D S) without forming D
+    den = _CutDenFn.apply(adj, S)  # trace(S^T D S) without forming D
     return _reduce(-(num / (den + eps)), batch_reduction)
 
 
 def orthogonality_loss(S: Tensor, batch_reduction: str = "mean") -> Tensor:
-    sts = torch.matmul(S.transpose(-2, -1), S)
+    sts = _GramFn.apply(S)
     sts = sts / torch.norm(sts, dim=(-2, -1), keepdim=True)
     k = S.size(-1)
     target = torch.eye(k, device=S.device, dtype=S.dtype) / math.sqrt(k)
@@ -45,7 +116,7 @@ def orthogonality_loss(S: Tensor, batch_reduction: str = "mean") -> Tensor:
 
 
 def link_pred_loss(S: Tensor, adj: Tensor, normalize_loss: bool = True) -> Tensor:
-    loss = torch.norm(adj - torch.matmul(S, S.transpose(1, 2)), p=2)
+    loss = _LinkNormFn.apply(S, adj)
     return loss / adj.numel() if normalize_loss is True else loss
 
 
@@ -56,7 +127,7 @@ def unbatched_entropy_loss(S: Tensor, num_nodes: Optional[int] = None) -> Tensor
 
 
 def entropy_loss(S: Tensor, num_nodes: int) -> Tensor:
-    return unbatched_entropy_loss(S.reshape(-1, S.size(-1)), num_nodes)
+    return _EntropySumFn.apply(S) / num_nodes
 
 
 def _edge_weights(edge_index: Tensor, edge_weight: Optional[Tensor], like: Tensor) -> Tensor:
