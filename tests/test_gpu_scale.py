@@ -410,3 +410,19 @@ def test_fused_reduce_connect_equals_operators(dev):
             assert torch.equal(xp, xp2) and torch.equal(raw, raw2) and torch.equal(ap, ap2)
             torch.testing.assert_close(ap, ap3, rtol=1e-5, atol=1e-5)
     assert pool.reduce_connect(X, A, SelectOutput(s=S.clone().requires_grad_(True))) is None
+
+
+@pytest.mark.parametrize("K", [20, 32, 48, 68, 100, 128, 176, 180, 256])
+def test_postprocess_dense_flag_grid(dev, K):
+    """utils/ops.py:282-335 on [B,K,K] for every flag combination, across the register (K <= 32), one-wave
+    (K <= 64), LDS (K <= 176, K % 4 == 0) and multi-kernel post-processing paths."""
+    import itertools
+    import tgp_oracle as O
+    from tgp.utils.ops import postprocess_adj_pool_dense
+    g = torch.Generator().manual_seed(K)
+    raw = torch.rand(5, K, K, generator=g) * (torch.rand(5, K, K, generator=g) < 0.7)
+    raw[3] = 0  # an empty graph: degree clamp + max-norm 0 -> 1 guard
+    for rsl, deg, tr, ewn in itertools.product([False, True], repeat=4):
+        want = O.postprocess_dense(raw.clone(), rsl, deg, tr, ewn)
+        got = postprocess_adj_pool_dense(raw.to(dev), rsl, deg, tr, ewn).cpu()
+        torch.testing.assert_close(got, want, rtol=RTOL, atol=ATOL, msg=lambda m: f"flags {rsl, deg, tr, ewn}: {m}")

@@ -52,6 +52,7 @@ struct GemmArgs {
   const float* resid;
   long ldr, sR;
   float* partial;          // [batches][tiles_m * tiles_n]
+  int force_bm, force_bn;  // 0 = pick_tile decides
 };
 
 __device__ __forceinline__ float4 ld4_guarded(const float* p, bool ok) {
@@ -329,6 +330,8 @@ static TileCfg pick_tile(int64_t M, int64_t max_nc, int64_t batches_x_splits, co
   if (M <= 64) t.bm = 64;
   if (count(t.bm, 128) < 2 * 256 && max_nc >= 64) t.bn = 64;
   if (count(t.bm, t.bn) < 2 * 256 && t.bm == 128 && M > 64) t.bm = 64;
+  if (g.force_bm) t.bm = g.force_bm;
+  if (g.force_bn) t.bn = g.force_bn;
   if (fbm == 64 || fbm == 128) t.bm = fbm;
   if (fbn == 64 || fbn == 128) t.bn = fbn;
   return t;
@@ -642,15 +645,151 @@ __global__ __launch_bounds__(256) void post_tiny_kernel(PostArgs p, int B) {
   }
 }
 
+// 64 < K <= POST_LDS_MAX_K: one 1024-thread workgroup per graph keeps the K x K matrix in LDS, so the slab
+// combine, the degree vector, the scaling and the max-norm are ONE launch (they are latency-, not
+// bandwidth-shaped: [B,K,K] is tiny next to A).  Workgroups past the first B combine the X' slabs, which
+// would otherwise be a launch of their own.  Every sum keeps the order of the multi-kernel path.
+constexpr int POST_LDS_MAX_K = 176;  // K*K*4 + partials <= 160 KB
+
+struct XCombineArgs {
+  const float* src; int splits; long s_split, s_batch, total; float* dst; int blocks_per_graph;
+};
+
+__global__ __launch_bounds__(1024) void post_lds_kernel(PostArgs p, int B, XCombineArgs xc) {
+  extern __shared__ __attribute__((aligned(16))) float m[];
+  const int tid = threadIdx.x;
+  if (static_cast<int>(blockIdx.x) >= B) {  // ---- X' slab combine ------------------------------------------
+    const int xb = blockIdx.x - B;
+    const int b = xb / xc.blocks_per_graph, part = xb - b * xc.blocks_per_graph;
+    const float* sb = xc.src + static_cast<long>(b) * xc.s_batch;
+    for (long e = static_cast<long>(part) * 1024 + tid; e < xc.total; e += static_cast<long>(xc.blocks_per_graph) * 1024) {
+      float v = sb[e];
+      for (int sp = 1; sp < xc.splits; ++sp) v = __fadd_rn(v, sb[sp * xc.s_split + e]);
+      xc.dst[static_cast<long>(b) * xc.total + e] = v;
+    }
+    return;
+  }
+  const int b = blockIdx.x, K = p.K, lane = tid & 63, w = tid >> 6;
+  const int kk = K * K;
+  float* dv = m + kk;            // [K]
+  float* s_part = dv + K;        // [16][64]
+  float* s_max = s_part + 1024;  // [16]
+  const float* sb = p.src + static_cast<long>(b) * p.s_batch;
+  float* rawb = p.raw ? p.raw + static_cast<long>(b) * kk : nullptr;
+  float* dstb = p.dst ? p.dst + static_cast<long>(b) * kk : nullptr;
+  const bool rsl = p.flags & TGP_REMOVE_SELF_LOOPS;
+  // pass 1: fixed-order slab sum -> raw output, diag-cleared copy in LDS  (K % 4 == 0, ld_src == K here)
+  for (int e = tid * 4; e < kk; e += 4096) {
+    float4 t = *reinterpret_cast<const float4*>(sb + e);
+    for (int sp = 1; sp < p.splits; ++sp) {
+      const float4 u = *reinterpret_cast<const float4*>(sb + sp * p.s_split + e);
+      t.x = __fadd_rn(t.x, u.x); t.y = __fadd_rn(t.y, u.y); t.z = __fadd_rn(t.z, u.z); t.w = __fadd_rn(t.w, u.w);
+    }
+    if (rawb) *reinterpret_cast<float4*>(rawb + e) = t;
+    if (rsl) {
+      const int i = e / K, j = e - i * K;
+      if (i == j) t.x = 0.f;
+      if (i == j + 1) t.y = 0.f;
+      if (i == j + 2) t.z = 0.f;
+      if (i == j + 3) t.w = 0.f;
+    }
+    *reinterpret_cast<float4*>(m + e) = t;
+  }
+  if (!dstb) return;
+  __syncthreads();
+  if (p.flags & TGP_DEGREE_NORM) {
+    if (p.flags & TGP_SUM_AXIS_ROWS) {  // column sums: wave w adds rows w, w+16, ...; partials added in order
+      for (int base = 0; base < K; base += 64) {
+        const int j = base + lane;
+        float sacc = 0.f;
+        if (j < K)
+          for (int i = w; i < K; i += 16) sacc = __fadd_rn(sacc, m[i * K + j]);
+        s_part[w * 64 + lane] = sacc;
+        __syncthreads();
+        if (w == 0 && j < K) {
+          float t = 0.f;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) t = __fadd_rn(t, s_part[q * 64 + lane]);
+          dv[j] = sqrtf(fmaxf(t, TGP_EPS));
+        }
+        __syncthreads();
+      }
+    } else {                            // row sums: lanes stride over the columns, fixed shuffle tree
+      for (int i = w; i < K; i += 16) {
+        float sacc = 0.f;
+        for (int j = lane; j < K; j += 64) sacc = __fadd_rn(sacc, m[i * K + j]);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) sacc = __fadd_rn(sacc, __shfl_down(sacc, d, WAVE));
+        if (lane == 0) dv[i] = sqrtf(fmaxf(sacc, TGP_EPS));
+      }
+      __syncthreads();
+    }
+  }
+  const bool by_cols = p.flags & TGP_SUM_AXIS_ROWS, ewn = p.flags & TGP_EDGE_WEIGHT_NORM;
+  float mx = 0.f;
+  for (int e = tid * 4; e < kk; e += 4096) {
+    float4 t = *reinterpret_cast<const float4*>(m + e);
+    if (p.flags & TGP_DEGREE_NORM) {
+      const int i = e / K, j = e - i * K;
+      const float di = dv[i];
+      const float4 dj = *reinterpret_cast<const float4*>(dv + j);
+      if (by_cols) {  // (adj / d[1,K]) / d[K,1]
+        t.x = (t.x / dj.x) / di; t.y = (t.y / dj.y) / di; t.z = (t.z / dj.z) / di; t.w = (t.w / dj.w) / di;
+      } else {
+        t.x = (t.x / di) / dj.x; t.y = (t.y / di) / dj.y; t.z = (t.z / di) / dj.z; t.w = (t.w / di) / dj.w;
+      }
+    }
+    if (ewn) {
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(t.x), fabsf(t.y))), fmaxf(fabsf(t.z), fabsf(t.w)));
+      *reinterpret_cast<float4*>(m + e) = t;
+    } else {
+      *reinterpret_cast<float4*>(dstb + e) = t;
+    }
+  }
+  if (!ewn) return;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, WAVE));
+  if (lane == 0) s_max[w] = mx;
+  __syncthreads();
+  float gm = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) gm = fmaxf(gm, s_max[q]);
+  if (gm == 0.f) gm = 1.f;
+  for (int e = tid * 4; e < kk; e += 4096) {
+    float4 t = *reinterpret_cast<const float4*>(m + e);
+    t.x = t.x / gm; t.y = t.y / gm; t.z = t.z / gm; t.w = t.w / gm;
+    *reinterpret_cast<float4*>(dstb + e) = t;
+  }
+}
+
 static size_t post_ws_floats(int64_t B, int64_t K) { return static_cast<size_t>(B * K + B * POST_BLOCKS); }
 
-static void launch_post(PostArgs p, int64_t B, float* ws, hipStream_t stream) {
+// Returns true when the X' slab combine described by xc (if any) was folded into the launch.
+static bool launch_post(PostArgs p, int64_t B, float* ws, hipStream_t stream, const XCombineArgs* xc = nullptr) {
   const int K = p.K;
   if (K <= 64) {  // one wave per graph: one launch instead of three or four
     const dim3 grid(static_cast<unsigned>((B + 3) / 4));
     if (K <= 32) hipLaunchKernelGGL(post_tiny_kernel, grid, dim3(256), 0, stream, p, static_cast<int>(B));
     else hipLaunchKernelGGL(post_small_kernel, grid, dim3(256), 0, stream, p, static_cast<int>(B));
-    return;
+    return false;
+  }
+  static const int no_lds = getenv("TGP_NO_POST_LDS") ? 1 : 0;
+  if (!no_lds && K <= POST_LDS_MAX_K && K % 4 == 0 && p.ld_src == K && p.s_split % 4 == 0 && p.s_batch % 4 == 0 &&
+      reinterpret_cast<uintptr_t>(p.src) % 16 == 0 && (!p.raw || reinterpret_cast<uintptr_t>(p.raw) % 16 == 0) &&
+      (!p.dst || reinterpret_cast<uintptr_t>(p.dst) % 16 == 0)) {
+    XCombineArgs x{};
+    if (xc) {
+      x = *xc;
+      x.blocks_per_graph = static_cast<int>((x.total + 4095) / 4096);
+      if (x.blocks_per_graph < 1) x.blocks_per_graph = 1;
+      if (x.blocks_per_graph > 8) x.blocks_per_graph = 8;
+    }
+    const size_t lds = (static_cast<size_t>(K) * K + K + 1024 + 16) * sizeof(float);
+    const unsigned grid = static_cast<unsigned>(B + (xc ? B * x.blocks_per_graph : 0));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(post_lds_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(post_lds_kernel, dim3(grid), dim3(1024), lds, stream, p, static_cast<int>(B), x);
+    return xc != nullptr;
   }
   p.dvec = ws;
   p.maxpart = ws + static_cast<size_t>(B) * K;
@@ -664,13 +803,14 @@ static void launch_post(PostArgs p, int64_t B, float* ws, hipStream_t stream) {
   const dim3 gridc(gx, static_cast<unsigned>(B));
   if (vec) hipLaunchKernelGGL(post_combine_kernel<4>, gridc, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(post_combine_kernel<1>, gridc, dim3(256), 0, stream, p);
-  if (!p.dst) return;
+  if (!p.dst) return false;
   const dim3 gride(POST_BLOCKS, static_cast<unsigned>(B));
   if (p.flags & TGP_DEGREE_NORM)
     hipLaunchKernelGGL(post_degree_kernel, dim3((K + 63) / 64, static_cast<unsigned>(B)), dim3(1024), 0, stream, p);
   if (p.flags & (TGP_DEGREE_NORM | TGP_EDGE_WEIGHT_NORM))
     hipLaunchKernelGGL(post_scale_kernel, gride, dim3(256), 0, stream, p);
   if (p.flags & TGP_EDGE_WEIGHT_NORM) hipLaunchKernelGGL(post_maxnorm_kernel, gride, dim3(256), 0, stream, p);
+  return false;
 }
 
 // x_pool slabs -> x_pool (fixed-order combine); src [B][splits][K][F]
@@ -890,16 +1030,21 @@ __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
   }
 }
 
+static const int kStage2Tile = getenv("TGP_STAGE2_TILE") ? atoi(getenv("TGP_STAGE2_TILE")) : 0;
 struct DensePlan {
-  int splits;
+  int splits, tile;
   int k_per_split;
   size_t u_floats, aslab_floats, xslab_floats, post_floats;
 };
 
 static DensePlan dense_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
   DensePlan p;
-  // second product: output is only K x (K+F) per graph -> split N so the chip is filled
-  const int64_t tiles = ((K + 127) / 128) * (((K + 127) / 128) + ((F + 127) / 128));
+  // second product: output is only K x (K+F) per graph -> split N so the chip is filled.  Small K: 64 x 64
+  // tiles (256-thread workgroups) need fewer splits for the same number of workgroups, i.e. longer k-loops
+  // per workgroup and less slab traffic.
+  p.tile = (kStage2Tile == 64 || kStage2Tile == 128) ? kStage2Tile : 64;
+  const int64_t T = p.tile;
+  const int64_t tiles = ((K + T - 1) / T) * (((K + T - 1) / T) + ((F + T - 1) / T));
   const int64_t base = B * (tiles > 0 ? tiles : 1);
   int64_t splits = (2 * 256 + base - 1) / base;  // aim for ~2 workgroups per CU
   const int64_t max_splits = (N + 4 * BK - 1) / (4 * BK);  // keep >= 4 k-steps per workgroup
@@ -985,6 +1130,7 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
     h.A = S; h.lda = K; h.sA = N * K;
     h.M = static_cast<int>(K); h.Kd = static_cast<int>(N);
     h.splits = p.splits; h.k_per_split = p.k_per_split;
+    h.force_bm = h.force_bn = p.tile;
     const GemmRhs ra{U, aslab, static_cast<int>(K), K, K, N * K, static_cast<long>(p.splits) * K * K, K * K};
     const GemmRhs rx{X, xslab, static_cast<int>(F), F, F, N * F, static_cast<long>(p.splits) * K * F, K * F};
     if (want_a && want_x) {
@@ -996,18 +1142,20 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
     }
     launch_gemm<true>(h, static_cast<int>(B), stream);
   }
-  if (want_x) {
+  bool x_done = !want_x;
+  if (want_a) {
+    PostArgs q{};
+    q.src = aslab; q.splits = p.splits; q.s_split = K * K; q.s_batch = static_cast<long>(p.splits) * K * K;
+    q.ld_src = K; q.K = static_cast<int>(K); q.flags = flags; q.raw = adj_raw; q.dst = adj_pool;
+    const XCombineArgs xc{xslab, p.splits, K * F, static_cast<long>(p.splits) * K * F, K * F, x_pool, 0};
+    if (launch_post(q, B, postws, stream, want_x ? &xc : nullptr)) x_done = true;
+  }
+  if (!x_done) {
     const long total = K * F;
     int gx = static_cast<int>((total + 255) / 256);
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(combine_slabs_kernel, dim3(gx, static_cast<unsigned>(B)), dim3(256), 0, stream, xslab,
                        p.splits, K * F, static_cast<long>(p.splits) * K * F, total, x_pool);
-  }
-  if (want_a) {
-    PostArgs q{};
-    q.src = aslab; q.splits = p.splits; q.s_split = K * K; q.s_batch = static_cast<long>(p.splits) * K * K;
-    q.ld_src = K; q.K = static_cast<int>(K); q.flags = flags; q.raw = adj_raw; q.dst = adj_pool;
-    launch_post(q, B, postws, stream);
   }
   return check_launch("tgp_dense_pool_f32");
 }
