@@ -55,6 +55,14 @@ struct GemmArgs {
   int force_bm, force_bn;  // 0 = pick_tile decides
 };
 
+// Row of a [rows][BK+1] LDS tile served by slot t = 8*g + r (8 lanes per slot, slot = one 128-byte row segment).
+// The 8 rows one wave instruction touches are {4g..4g+3} u {4g+32..4g+35}: with the odd row stride their
+// ds_write banks (33*row + 4*q + c) mod 64 are all distinct, where 8 consecutive rows would collide 2-way.
+__device__ __forceinline__ int tile_row(int t) {
+  const int g = t >> 3, r = t & 7;
+  return 4 * (g & 7) + (r & 3) + 32 * (r >> 2) + 64 * (g >> 3);
+}
+
 __device__ __forceinline__ float4 ld4_guarded(const float* p, bool ok) {
   return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
     for (int i = 0; i < A_VECS; ++i) {
       int m, k;
       if constexpr (!A_KMAJOR) {  // [BM m][32 k]: 8 lanes cover one 128-byte row segment
-        m = m0 + (tid >> 3) + i * (THREADS / 8);
+        m = m0 + tile_row((tid >> 3) + i * (THREADS / 8));
         k = k0 + (tid & 7) * 4;
       } else {                    // [32 k][BM m]: AK_LANES lanes cover one row
         k = k0 + tid / AK_LANES + i * (THREADS / AK_LANES);
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < B_VECS; ++i) {
       if constexpr (MODE == 1) {        // [BN n][32 k]: 8 lanes cover one 128-byte row segment
-        const int n = n0 + (tid >> 3) + i * (THREADS / 8), k = k0 + (tid & 7) * 4;
+        const int n = n0 + tile_row((tid >> 3) + i * (THREADS / 8)), k = k0 + (tid & 7) * 4;
         const float* p = Bm + static_cast<long>(n) * ldb + k;
         if constexpr (ALIGNED) {
           rb[i] = ld4_guarded(p, n < Nc && k < k_end);
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < A_VECS; ++i) {
       if constexpr (!A_KMAJOR) {
-        float* d = As + ((tid >> 3) + i * (THREADS / 8)) * LDA_ROWMAJOR + (tid & 7) * 4;
+        float* d = As + tile_row((tid >> 3) + i * (THREADS / 8)) * LDA_ROWMAJOR + (tid & 7) * 4;
         d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
       } else {
         *reinterpret_cast<float4*>(As + (tid / AK_LANES + i * (THREADS / AK_LANES)) * BM + (tid % AK_LANES) * 4) = ra[i];
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < B_VECS; ++i) {
       if constexpr (MODE == 1) {
-        float* d = Bs + ((tid >> 3) + i * (THREADS / 8)) * LDA_ROWMAJOR + (tid & 7) * 4;
+        float* d = Bs + tile_row((tid >> 3) + i * (THREADS / 8)) * LDA_ROWMAJOR + (tid & 7) * 4;
         d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w;
       } else {
         *reinterpret_cast<float4*>(Bs + (tid / BN_LANES + i * (THREADS / BN_LANES)) * BN + (tid % BN_LANES) * 4) = rb[i];
