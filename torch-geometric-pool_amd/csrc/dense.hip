@@ -28,6 +28,9 @@ namespace tgp {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
+#ifndef TGP_OPERAND_PREFETCH
+#define TGP_OPERAND_PREFETCH 1
+#endif
 constexpr int LDA_ROWMAJOR = BK + 1;
 
 // One right-hand side / output pair.  A launch may carry two (column tiles >= tiles_n0 use the
@@ -63,6 +66,20 @@ __device__ __forceinline__ int tile_row(int t) {
   return 4 * (g & 7) + (r & 3) + 32 * (r >> 2) + 64 * (g >> 3);
 }
 
+#ifdef TGP_GEMM_STAMPS
+// Diagnostic build only (make stamps): per-workgroup wall-clock stamps (100 MHz) at kernel entry, after the
+// prologue, after the k-loop and after the epilogue, plus the hardware id (XCC / SE / CU) the workgroup ran on.
+__device__ unsigned long long* g_gemm_stamps = nullptr;
+__device__ int g_gemm_reverse = 0;  // experiment: hand the tiles out in reverse dispatch order
+#define TGP_STAMP(slot)                                                                        \
+  do {                                                                                          \
+    if (g_gemm_stamps && threadIdx.x == 0)                                                      \
+      g_gemm_stamps[static_cast<long>(blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define TGP_STAMP(slot) do {} while (0)
+#endif
+
 __device__ __forceinline__ float4 ld4_guarded(const float* p, bool ok) {
   return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -91,9 +108,22 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  TGP_STAMP(0);
+#ifdef TGP_GEMM_STAMPS
+  if (g_gemm_stamps && threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_gemm_stamps[static_cast<long>(blockIdx.x) * 8 + 4] = hw;
+    g_gemm_stamps[static_cast<long>(blockIdx.x) * 8 + 5] = xcc;
+  }
+#endif
 
   // logical block id, XCD-aware: tiles of one batch element share S / U through one L2
   int bid = xcd_remap(blockIdx.x, gridDim.x);
+#ifdef TGP_GEMM_STAMPS
+  if (g_gemm_reverse) bid = gridDim.x - 1 - bid;
+#endif
   const int tn_all = bid % g.tiles_n; bid /= g.tiles_n;
   const int tm = bid % g.tiles_m; bid /= g.tiles_m;
   const int split = bid % g.splits;
@@ -220,27 +250,25 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
   const int b_off = MODE == 1 ? (wn * (BN / 2) + lm) * LDA_ROWMAJOR + lk : lk * BN + wn * (BN / 2) + lm;
   constexpr int b_step = MODE == 1 ? 2 : 2 * BN;               // one k-pair
   constexpr int b_tile = MODE == 1 ? 32 * LDA_ROWMAJOR : 32;   // next 32 output columns
-  // MFMAs of k-pairs [p0, p1) of one LDS stage; the LDS operands of pair p+1 are requested before the
-  // MFMAs of pair p are issued (sched_group_barrier pins that order).
-  float a_cur, b_cur[NT];
+  // MFMAs of k-pairs [p0, p1) of one LDS stage.
+  // LDS operand ring: the operands of k-pair p + PD are requested before the MFMAs of pair p are issued
+  // (sched_group_barrier pins that order), so PD MFMA slots of latency are covered.
+  constexpr int PD = TGP_OPERAND_PREFETCH;
+  float a_r[PD + 1], b_r[PD + 1][NT];
+  auto fetch_pair = [&](const float* As, const float* Bs, int p) {
+    a_r[p % (PD + 1)] = As[a_off + p * a_step];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b_r[p % (PD + 1)][j] = Bs[b_off + p * b_step + b_tile * j];
+  };
   auto mfma_pairs = [&](const float* As, const float* Bs, int p0, int p1) {
 #pragma unroll
     for (int p = p0; p < p1; ++p) {
-      float a_nxt = 0.f, b_nxt[NT];
+      if (p + PD < BK / 2) fetch_pair(As, Bs, p + PD);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b_nxt[j] = 0.f;
-      if (p + 1 < BK / 2) {
-        a_nxt = As[a_off + (p + 1) * a_step];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b_nxt[j] = Bs[b_off + (p + 1) * b_step + b_tile * j];
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 x ds_read (a, b)
-      __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);  // NT x MFMA
-      a_cur = a_nxt;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) b_cur[j] = b_nxt[j];
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_r[p % (PD + 1)], b_r[p % (PD + 1)][j], acc[j], 0, 0, 0);
+      if (p + PD < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NT, 0);  // ds_reads of pair p+PD
+      __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);                            // NT x MFMA
     }
   };
 
@@ -257,13 +285,17 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
   }
   if (nk > 1) load_tiles(ra0, rb0, kof(1));
   __syncthreads();
+  TGP_STAMP(1);
   for (int t = 0; t < nk; ++t) {
+#ifdef TGP_GEMM_STAMPS
+    if (t == nk / 2) TGP_STAMP(6);
+    if (t == (3 * nk) / 4) TGP_STAMP(7);
+#endif
     const float* As = (t & 1) ? L1 : L0;
     const float* Bs = As + A_TILE_FLOATS;
     float* Ln = (t & 1) ? L0 : L1;
-    a_cur = As[a_off];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) b_cur[j] = Bs[b_off + b_tile * j];
+    for (int p = 0; p < PD; ++p) fetch_pair(As, Bs, p);
     mfma_pairs(As, Bs, 0, 4);
     __builtin_amdgcn_sched_barrier(0);
     if (t + 1 < nk) store_stage(ra0, rb0, Ln, Ln + A_TILE_FLOATS);
@@ -275,6 +307,7 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
     mfma_pairs(As, Bs, 8, 16);
     __syncthreads();
   }
+  TGP_STAMP(2);
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -----------
   if constexpr (MODE == 1) {
@@ -309,6 +342,7 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
       if (row < g.M && col < Nc) C[static_cast<long>(row) * R.ldc + col] = acc[j][r];
     }
   }
+  TGP_STAMP(3);
 }
 
 static bool gemm_aligned(const GemmArgs& g) {
@@ -346,7 +380,8 @@ static TileCfg pick_tile(int64_t M, int64_t max_nc, int64_t batches_x_splits, co
 }
 
 template <bool A_KMAJOR, int BM, int BN, int MODE = 0>
-static void launch_gemm_cfg(const GemmArgs& g, int batches, hipStream_t stream) {
+static void launch_gemm_cfg(const GemmArgs& g_in, int batches, hipStream_t stream) {
+  const GemmArgs& g = g_in;
   const int nwg = batches * g.splits * g.tiles_m * g.tiles_n;
   const size_t lds = 2 * (BM * LDA_ROWMAJOR + (MODE == 1 ? BN * LDA_ROWMAJOR : BK * BN)) * sizeof(float);
   if (gemm_aligned(g))
@@ -1290,3 +1325,12 @@ extern "C" int tgp_link_loss_f32(const float* S, const float* A, int64_t B, int6
   hipLaunchKernelGGL(sum_partials_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, g.partial, tiles, sq);
   return tgp::check_launch("tgp_link_loss_f32");
 }
+
+#ifdef TGP_GEMM_STAMPS
+extern "C" int tgp_debug_set_gemm_reverse(int on) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(tgp::g_gemm_reverse), &on, sizeof(on)) == hipSuccess ? 0 : -3;
+}
+extern "C" int tgp_debug_set_gemm_stamps(unsigned long long* device_buffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(tgp::g_gemm_stamps), &device_buffer, sizeof(device_buffer)) == hipSuccess ? 0 : -3;
+}
+#endif

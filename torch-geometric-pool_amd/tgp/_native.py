@@ -15,7 +15,8 @@ import torch
 from torch import Tensor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtgp_hip.so")
+# TGP_HIP_LIB: load another build of the same library (kernel experiments); never a different implementation
+LIB_PATH = os.environ.get("TGP_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libtgp_hip.so")
 
 # flag bits / enums, mirrored from include/tgp_hip.h
 REMOVE_SELF_LOOPS = 1
