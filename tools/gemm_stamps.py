@@ -30,14 +30,14 @@ def run():
 for _ in range(3):
     run()
 nwg_max = B * ((N + 63) // 64) * ((K + 63) // 64)
-stamps = torch.zeros(nwg_max * 8, dtype=torch.int64, device=dev)
+stamps = torch.zeros(nwg_max * 16, dtype=torch.int64, device=dev)
 assert lib.tgp_debug_set_gemm_stamps(stamps.data_ptr()) == 0
 if os.environ.get("REVERSE"):
     assert lib.tgp_debug_set_gemm_reverse(1) == 0
 torch.cuda.synchronize()
 run()
 torch.cuda.synchronize()
-st = stamps.view(-1, 8).cpu()
+st = stamps.view(-1, 16).cpu()
 st = st[st[:, 0] > 0]
 t = st[:, :4].double() / 100.0  # us (100 MHz counter)
 t0 = t[:, 0].min()
@@ -93,3 +93,11 @@ for name, m in (("gen1 (id < 256)", ids < 256), ("gen2 (id >= 256)", ids >= 256)
     print(f"{name}: first half {float(half[m].mean()):.2f}  third quarter {float(q3[m].mean()):.2f}  last quarter {float(q4[m].mean()):.2f} us")
 pairs = [v for v in groups.values() if len(v) == 2]
 print("sample CU pairs (block ids, loop us):", [(p_[0], p_[1], round(float(loop[p_[0]]), 1), round(float(loop[p_[1]]), 1)) for p_ in pairs[:6]])
+
+# phases of one k-step (t = nk/2), wave 0 of every workgroup: durations in ns
+phs = st[:, 8:15].double() * 10.0
+names = ["4 MFMA (+first operand fetch)", "vmcnt wait + LDS stage store", "4 MFMA", "global loads issue", "8 MFMA", "barrier wait"]
+for name, m in (("gen1", ids < 256), ("gen2", ids >= 256)):
+    print(name, "k-step phases (mean ns):", ", ".join(f"{n}: {float((phs[m, i + 1] - phs[m, i]).mean()):.0f}" for i, n in enumerate(names)),
+          f"| total {float((phs[m, 6] - phs[m, 0]).mean()):.0f}",
+          f"| of the second phase, waiting for the tile to land: {float((st[m, 15].double() * 10.0 - phs[m, 1]).mean()):.0f}")

@@ -22,6 +22,7 @@
 //   * k-major operand tile    (S, U, X, A^T): LDS [BK][128]    (lanes read consecutive floats)
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace tgp {
 
@@ -30,6 +31,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 #ifndef TGP_OPERAND_PREFETCH
 #define TGP_OPERAND_PREFETCH 1
+#endif
+#ifndef TGP_LOAD_AT
+#define TGP_LOAD_AT 7
+#endif
+#ifndef TGP_STORE_AT
+#define TGP_STORE_AT 3
+#endif
+#ifndef TGP_SPREAD
+#define TGP_SPREAD 0
+#endif
+#ifndef TGP_ACC_CHAINS
+#define TGP_ACC_CHAINS 1
 #endif
 constexpr int LDA_ROWMAJOR = BK + 1;
 
@@ -74,7 +87,7 @@ __device__ int g_gemm_reverse = 0;  // experiment: hand the tiles out in reverse
 #define TGP_STAMP(slot)                                                                        \
   do {                                                                                          \
     if (g_gemm_stamps && threadIdx.x == 0)                                                      \
-      g_gemm_stamps[static_cast<long>(blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+      g_gemm_stamps[static_cast<long>(blockIdx.x) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
 #define TGP_STAMP(slot) do {} while (0)
@@ -114,8 +127,8 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    g_gemm_stamps[static_cast<long>(blockIdx.x) * 8 + 4] = hw;
-    g_gemm_stamps[static_cast<long>(blockIdx.x) * 8 + 5] = xcc;
+    g_gemm_stamps[static_cast<long>(blockIdx.x) * 16 + 4] = hw;
+    g_gemm_stamps[static_cast<long>(blockIdx.x) * 16 + 5] = xcc;
   }
 #endif
 
@@ -148,12 +161,64 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
   const int k_end = min(k_hi, k_begin + g.k_per_split);
   const int nk = k_end > k_begin ? (k_end - k_begin + BK - 1) / BK : 0;
 
-  // register staging: the global loads of tile t+1 are in flight while tile t is multiplied
-  float4 ra0[A_VECS], rb0[B_VECS];
+  // register staging, two sets: tile t+2 is being loaded into one while tile t+1 is written to LDS from the other
+  float4 ra[2][A_VECS], rb[2][B_VECS];
 
-  auto load_tiles = [&](float4 (&ra)[A_VECS], float4 (&rb)[B_VECS], int k0) {
+  // ALIGNED path: buffer loads.  Each operand gets a 128-bit resource descriptor (base of this batch element,
+  // valid bytes) held in SGPRs, a per-lane byte offset computed ONCE (rows / columns outside the problem get an
+  // offset past the end, which the hardware range check turns into zeros), and a scalar offset that advances
+  // with the k-step.  The steady-state loop then issues its global loads without a single vector-ALU
+  // instruction: measured per-wave time stamps showed ~0.5 us per k-step going to the address / predicate
+  // arithmetic of plain global loads, which has to squeeze in between other waves' MFMAs.
+  constexpr int OOB = static_cast<int>(0x80000000u);  // >= any valid size (matrices are < 2^31 bytes here)
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+  [[maybe_unused]] int voff_a[A_VECS], voff_b[B_VECS];
+  [[maybe_unused]] int kloc_a[A_VECS], kloc_b[B_VECS];  // this lane's k offset inside a stage (for the tail)
+  if constexpr (ALIGNED) {
+    const int a_bytes = A_KMAJOR ? (static_cast<int>(g.Kd - 1) * static_cast<int>(lda) + g.M) * 4
+                                 : (static_cast<int>(g.M - 1) * static_cast<int>(lda) + g.Kd) * 4;
+    const int b_bytes = MODE == 1 ? (static_cast<int>(Nc - 1) * static_cast<int>(ldb) + g.Kd) * 4
+                                  : (static_cast<int>(g.Kd - 1) * static_cast<int>(ldb) + Nc) * 4;
+    rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, a_bytes, 0x00020000);
+    rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bm), 0, b_bytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < A_VECS; ++i) {
+      if constexpr (!A_KMAJOR) {
+        const int m = m0 + tile_row((tid >> 3) + i * (THREADS / 8));
+        kloc_a[i] = (tid & 7) * 4;
+        voff_a[i] = m < g.M ? (m * static_cast<int>(lda) + kloc_a[i]) * 4 : OOB;
+      } else {
+        const int m = m0 + (tid % AK_LANES) * 4;
+        kloc_a[i] = tid / AK_LANES + i * (THREADS / AK_LANES);
+        voff_a[i] = m < g.M ? (kloc_a[i] * static_cast<int>(lda) + m) * 4 : OOB;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_VECS; ++i) {
+      if constexpr (MODE == 1) {
+        const int n = n0 + tile_row((tid >> 3) + i * (THREADS / 8));
+        kloc_b[i] = (tid & 7) * 4;
+        voff_b[i] = n < Nc ? (n * static_cast<int>(ldb) + kloc_b[i]) * 4 : OOB;
+      } else {
+        const int n = n0 + (tid % BN_LANES) * 4;
+        kloc_b[i] = tid / BN_LANES + i * (THREADS / BN_LANES);
+        voff_b[i] = n < Nc ? (kloc_b[i] * static_cast<int>(ldb) + n) * 4 : OOB;
+      }
+    }
+  }
+  auto buf_ld4 = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  };
+
+  // one float4 of the A / B stage starting at k0 (tail = this stage is cut short by k_end)
+  auto load_a = [&](int i, int k0, bool tail) -> float4 {
+    if constexpr (ALIGNED) {
+      const int soff = A_KMAJOR ? k0 * static_cast<int>(lda) * 4 : k0 * 4;
+      if (!tail) return buf_ld4(rsrc_a, voff_a[i], soff);  // steady state: no per-lane arithmetic at all
+      return buf_ld4(rsrc_a, k0 + kloc_a[i] < k_end ? voff_a[i] : OOB, soff);
+    } else {
       int m, k;
       if constexpr (!A_KMAJOR) {  // [BM m][32 k]: 8 lanes cover one 128-byte row segment
         m = m0 + tile_row((tid >> 3) + i * (THREADS / 8));
@@ -163,71 +228,61 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
         m = m0 + (tid % AK_LANES) * 4;
       }
       const float* p = A_KMAJOR ? A + static_cast<long>(k) * lda + m : A + static_cast<long>(m) * lda + k;
-      if constexpr (ALIGNED) {
-        ra[i] = ld4_guarded(p, m < g.M && k < k_end);
-      } else {
-        float t[4];
+      float t[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bool ok = A_KMAJOR ? (k < k_end && m + j < g.M) : (m < g.M && k + j < k_end);
-          t[j] = ok ? p[j] : 0.f;
-        }
-        ra[i] = make_float4(t[0], t[1], t[2], t[3]);
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = A_KMAJOR ? (k < k_end && m + j < g.M) : (m < g.M && k + j < k_end);
+        t[j] = ok ? p[j] : 0.f;
       }
+      return make_float4(t[0], t[1], t[2], t[3]);
     }
-#pragma unroll
-    for (int i = 0; i < B_VECS; ++i) {
+  };
+  auto load_b = [&](int i, int k0, bool tail) -> float4 {
+    if constexpr (ALIGNED) {
+      const int soff = MODE == 1 ? k0 * 4 : k0 * static_cast<int>(ldb) * 4;
+      if (!tail) return buf_ld4(rsrc_b, voff_b[i], soff);
+      return buf_ld4(rsrc_b, k0 + kloc_b[i] < k_end ? voff_b[i] : OOB, soff);
+    } else {
+      float t[4];
       if constexpr (MODE == 1) {        // [BN n][32 k]: 8 lanes cover one 128-byte row segment
         const int n = n0 + tile_row((tid >> 3) + i * (THREADS / 8)), k = k0 + (tid & 7) * 4;
         const float* p = Bm + static_cast<long>(n) * ldb + k;
-        if constexpr (ALIGNED) {
-          rb[i] = ld4_guarded(p, n < Nc && k < k_end);
-        } else {
-          float t[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) t[j] = (n < Nc && k + j < k_end) ? p[j] : 0.f;
-          rb[i] = make_float4(t[0], t[1], t[2], t[3]);
-        }
+        for (int j = 0; j < 4; ++j) t[j] = (n < Nc && k + j < k_end) ? p[j] : 0.f;
       } else {                          // [32 k][BN n]: BN_LANES lanes cover one row
         const int k = k0 + tid / BN_LANES + i * (THREADS / BN_LANES), n = n0 + (tid % BN_LANES) * 4;
         const float* p = Bm + static_cast<long>(k) * ldb + n;
-        if constexpr (ALIGNED) {
-          rb[i] = ld4_guarded(p, k < k_end && n < Nc);
-        } else {
-          float t[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) t[j] = (k < k_end && n + j < Nc) ? p[j] : 0.f;
-          rb[i] = make_float4(t[0], t[1], t[2], t[3]);
-        }
+        for (int j = 0; j < 4; ++j) t[j] = (k < k_end && n + j < Nc) ? p[j] : 0.f;
       }
+      return make_float4(t[0], t[1], t[2], t[3]);
     }
   };
-  auto store_stage = [&](const float4 (&ra)[A_VECS], const float4 (&rb)[B_VECS], float* As, float* Bs) {
-#pragma unroll
-    for (int i = 0; i < A_VECS; ++i) {
-      if constexpr (!A_KMAJOR) {
-        float* d = As + tile_row((tid >> 3) + i * (THREADS / 8)) * LDA_ROWMAJOR + (tid & 7) * 4;
-        d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
-      } else {
-        *reinterpret_cast<float4*>(As + (tid / AK_LANES + i * (THREADS / AK_LANES)) * BM + (tid % AK_LANES) * 4) = ra[i];
-      }
+  auto store_a = [&](int i, const float4& v, float* As) {
+    if constexpr (!A_KMAJOR) {
+      float* d = As + tile_row((tid >> 3) + i * (THREADS / 8)) * LDA_ROWMAJOR + (tid & 7) * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    } else {
+      *reinterpret_cast<float4*>(As + (tid / AK_LANES + i * (THREADS / AK_LANES)) * BM + (tid % AK_LANES) * 4) = v;
     }
-#pragma unroll
-    for (int i = 0; i < B_VECS; ++i) {
-      if constexpr (MODE == 1) {
-        float* d = Bs + tile_row((tid >> 3) + i * (THREADS / 8)) * LDA_ROWMAJOR + (tid & 7) * 4;
-        d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w;
-      } else {
-        *reinterpret_cast<float4*>(Bs + (tid / BN_LANES + i * (THREADS / BN_LANES)) * BN + (tid % BN_LANES) * 4) = rb[i];
-      }
+  };
+  auto store_b = [&](int i, const float4& v, float* Bs) {
+    if constexpr (MODE == 1) {
+      float* d = Bs + tile_row((tid >> 3) + i * (THREADS / 8)) * LDA_ROWMAJOR + (tid & 7) * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    } else {
+      *reinterpret_cast<float4*>(Bs + (tid / BN_LANES + i * (THREADS / BN_LANES)) * BN + (tid % BN_LANES) * 4) = v;
     }
   };
 
-  f32x16 acc[NT];
+  // NC independent accumulator chains per MFMA tile (even / odd k-pairs): with a single chain every MFMA of a
+  // wave waits for the previous one to retire, and the other waves on the SIMD do not fill those gaps.
+  constexpr int NC = (NT == 1) ? TGP_ACC_CHAINS : 1;
+  f32x16 acc[NT], acc_b[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; acc_b[j][r] = 0.f; }
 
   const int lm = lane & 31, lk = lane >> 5;
   // MODE 1: the residual tile is requested before the first k-step and consumed in the epilogue, so its
@@ -260,54 +315,97 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) b_r[p % (PD + 1)][j] = Bs[b_off + p * b_step + b_tile * j];
   };
-  auto mfma_pairs = [&](const float* As, const float* Bs, int p0, int p1) {
+  auto mfma_pair = [&](int p) {
 #pragma unroll
-    for (int p = p0; p < p1; ++p) {
-      if (p + PD < BK / 2) fetch_pair(As, Bs, p + PD);
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NT; ++j) {
+      if (NC == 2 && (p & 1))
+        acc_b[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_r[p % (PD + 1)], b_r[p % (PD + 1)][j], acc_b[j], 0, 0, 0);
+      else
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_r[p % (PD + 1)], b_r[p % (PD + 1)][j], acc[j], 0, 0, 0);
-      if (p + PD < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NT, 0);  // ds_reads of pair p+PD
-      __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);                            // NT x MFMA
     }
   };
 
-  // Stage schedule.  Everything that is not an MFMA rides in the shadow of the matrix pipe:
-  //   MFMAs 0-7 | LDS <- registers (tile t+1, loaded during stage t-1) | MFMAs 8-15 |
-  //   global loads of tile t+2 -> the same registers | MFMAs 16-31 | barrier
-  // The tile being written (t+1) lives in the other LDS buffer than the one being read (t).
+  // Stage schedule.  Per-wave time stamps (tools/gemm_stamps.py) showed that a wave loses most of a k-step not
+  // in the MFMAs but queueing behind the other 15 waves of the CU whenever all of them issue their global loads
+  // or their LDS stores at the same point of the step (the texture-address path takes 16 clk per 1 KB load and a
+  // wave cannot issue its next MFMA while it is stuck in that queue).  So the memory work of a stage is dealt
+  // out ONE instruction at a time between MFMA pairs:
+  //   pair 1: load A0(t+2) | 2: store A0(t+1) | 3: load A1 | 4: store A1 | 5: load B0 | 6: store B0 | ...
+  // Tile t+2 is loaded into register set t&1 during stage t, written to LDS from there during stage t+1 (the
+  // other LDS buffer than the one being read) and multiplied in stage t+2, so a load has a whole stage to land.
   float* L0 = smem;
   float* L1 = smem + STAGE_FLOATS;
   auto kof = [&](int t) { return k_begin + t * BK; };
-  if (nk > 0) {
-    load_tiles(ra0, rb0, kof(0));
-    store_stage(ra0, rb0, L0, L0 + A_TILE_FLOATS);
-  }
-  if (nk > 1) load_tiles(ra0, rb0, kof(1));
-  __syncthreads();
-  TGP_STAMP(1);
-  for (int t = 0; t < nk; ++t) {
-#ifdef TGP_GEMM_STAMPS
-    if (t == nk / 2) TGP_STAMP(6);
-    if (t == (3 * nk) / 4) TGP_STAMP(7);
-#endif
-    const float* As = (t & 1) ? L1 : L0;
+  auto stage = [&](auto par_c, int t) {
+    constexpr int PAR = decltype(par_c)::value;
+    const float* As = PAR ? L1 : L0;
     const float* Bs = As + A_TILE_FLOATS;
-    float* Ln = (t & 1) ? L0 : L1;
+    float* An = PAR ? L0 : L1;
+    float* Bn = An + A_TILE_FLOATS;
+    const bool do_store = t + 1 < nk, do_load = t + 2 < nk;
+    const int k2 = kof(t + 2);
+    const bool tail = k2 + BK > k_end;
 #pragma unroll
     for (int p = 0; p < PD; ++p) fetch_pair(As, Bs, p);
-    mfma_pairs(As, Bs, 0, 4);
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < nk) store_stage(ra0, rb0, Ln, Ln + A_TILE_FLOATS);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_pairs(As, Bs, 4, 8);
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 2 < nk) load_tiles(ra0, rb0, kof(t + 2));
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_pairs(As, Bs, 8, 16);
+#pragma unroll
+    for (int p = 0; p < BK / 2; ++p) {
+      if (p + PD < BK / 2) fetch_pair(As, Bs, p + PD);
+      mfma_pair(p);
+      if (p + PD < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NT, 0);  // ds_reads of pair p+PD
+      __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);                            // NT x MFMA
+      // memory work of the stage: loads of tile t+2 behind pair LOAD_AT, LDS stores of tile t+1 behind STORE_AT
+      // (SPREAD: one vector per pair starting there, instead of all at once)
+      constexpr int LOAD_AT = TGP_LOAD_AT, STORE_AT = TGP_STORE_AT, SPREAD = TGP_SPREAD;
+#pragma unroll
+      for (int v = 0; v < A_VECS + B_VECS; ++v) {
+        if (p == LOAD_AT + (SPREAD ? v : 0) && do_load) {
+          if (v < A_VECS) ra[PAR][v] = load_a(v, k2, tail);
+          else rb[PAR][v - A_VECS] = load_b(v - A_VECS, k2, tail);
+        }
+        if (p == STORE_AT + (SPREAD ? v : 0) && do_store) {
+          if (v < A_VECS) store_a(v, ra[1 - PAR][v], An);
+          else store_b(v - A_VECS, rb[1 - PAR][v - A_VECS], Bn);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
+  };
+  if (nk > 0) {
+#pragma unroll
+    for (int i = 0; i < A_VECS; ++i) ra[0][i] = load_a(i, kof(0), kof(0) + BK > k_end);
+#pragma unroll
+    for (int i = 0; i < B_VECS; ++i) rb[0][i] = load_b(i, kof(0), kof(0) + BK > k_end);
+  }
+  if (nk > 1) {
+#pragma unroll
+    for (int i = 0; i < A_VECS; ++i) ra[1][i] = load_a(i, kof(1), kof(1) + BK > k_end);
+#pragma unroll
+    for (int i = 0; i < B_VECS; ++i) rb[1][i] = load_b(i, kof(1), kof(1) + BK > k_end);
+  }
+  if (nk > 0) {
+#pragma unroll
+    for (int i = 0; i < A_VECS; ++i) store_a(i, ra[0][i], L0);
+#pragma unroll
+    for (int i = 0; i < B_VECS; ++i) store_b(i, rb[0][i], L0 + A_TILE_FLOATS);
+  }
+  __syncthreads();
+  TGP_STAMP(1);
+  for (int t = 0; t < nk; t += 2) {
+#ifdef TGP_GEMM_STAMPS
+    if (t == (nk / 2 & ~1)) TGP_STAMP(6);
+    if (t == ((3 * nk) / 4 & ~1)) TGP_STAMP(7);
+#endif
+    stage(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nk) stage(std::integral_constant<int, 1>{}, t + 1);
   }
   TGP_STAMP(2);
+  if constexpr (NC == 2) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] += acc_b[j][r];
+  }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -----------
   if constexpr (MODE == 1) {
@@ -350,8 +448,13 @@ static bool gemm_aligned(const GemmArgs& g) {
     return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 4 == 0) && (s % 4 == 0);
   };
   bool a = ok(g.A, g.lda, g.sA) && (g.M % 4 == 0) && (g.Kd % 4 == 0) && (g.k_per_split % 4 == 0) && !g.k_ptr;
+  // the aligned path addresses each batch element through a buffer descriptor with 32-bit byte offsets
+  const long lim = (1l << 31) - 4096;
+  a = a && (static_cast<long>(g.M) * g.lda * 4 < lim) && (static_cast<long>(g.Kd) * g.lda * 4 < lim);
   for (int w = 0; w < 2; ++w)
-    if (w == 0 || g.tiles_n > g.tiles_n0) a = a && ok(g.rhs[w].Bm, g.rhs[w].ldb, g.rhs[w].sB) && (g.rhs[w].Nc % 4 == 0);
+    if (w == 0 || g.tiles_n > g.tiles_n0)
+      a = a && ok(g.rhs[w].Bm, g.rhs[w].ldb, g.rhs[w].sB) && (g.rhs[w].Nc % 4 == 0) &&
+          (static_cast<long>(g.Kd) * g.rhs[w].ldb * 4 < lim) && (static_cast<long>(g.rhs[w].Nc) * g.rhs[w].ldb * 4 < lim);
   return a;
 }
 
