@@ -646,3 +646,32 @@ def greedy_matching(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes
             lab[best] = u
     _, inv = torch.unique(torch.tensor(lab), sorted=True, return_inverse=True)
     return inv
+
+
+# ------------------------------------------------------------------ A0: SelectOutput.assign_all_nodes
+def get_assignments(kept, edge_index, max_iter, num_nodes):  # utils/ops.py:1222-1440 (deterministic part)
+    """Plain-loop restatement: kept nodes label themselves 1..K; in every round each unassigned node takes the
+    label most of its already-labelled in-neighbours carry (smallest label on ties), all updates of a round
+    being computed from the labels of the previous round.  Raises if nodes are left for the reference's random
+    fallback (unpinned).  Returns [2, N]: node ids, consecutive supernode ids (rank of the kept node's id)."""
+    kept = [int(k) for k in kept]
+    label = [0] * num_nodes
+    for i, k in enumerate(kept):
+        label[k] = i + 1
+    src, dst = edge_index[0].tolist(), edge_index[1].tolist()
+    for _ in range(max_iter):
+        if all(label):
+            break
+        votes = {}
+        for s_, d_ in zip(src, dst):
+            if label[s_] > 0 and label[d_] == 0:
+                votes.setdefault(d_, {}).setdefault(label[s_], 0)
+                votes[d_][label[s_]] += 1
+        for d_, v in votes.items():
+            best = max(v.values())
+            label[d_] = min(c for c, n in v.items() if n == best)
+    if not all(label):
+        raise ValueError("nodes left for the random fallback: parity unpinned")
+    target = [kept[c - 1] for c in label]            # node id of the supernode's kept node
+    rank = {k: i for i, k in enumerate(sorted(set(target)))}
+    return torch.tensor([list(range(num_nodes)), [rank[v] for v in target]], dtype=torch.long)

@@ -450,12 +450,48 @@ def gen_operators():
     add("dense_connect_unbatched_grid", dict(edge_index=eib, edge_weight=ewb, batch=bb, S=S3), exp)
 
 
+# ----------------------------------------------------------------------------- assign_all_nodes
+def gen_assign_all():
+    """SelectOutput.assign_all_nodes / utils.ops.get_assignments (base_select.py:381-486, ops.py:1222-1440) on
+    graphs where every node is reached by propagation, so no random fallback is involved."""
+    from tgp.utils.ops import get_assignments
+    gen = torch.Generator().manual_seed(11)
+    # two chains of 9 and 7 nodes with a few chords; kept nodes on both
+    def chain(n, off):
+        a = torch.arange(n - 1) + off
+        ei = torch.stack([torch.cat([a, a + 1]), torch.cat([a + 1, a])])
+        return ei
+    ei = torch.cat([chain(9, 0), chain(7, 9), torch.tensor([[2, 6, 11, 14], [6, 2, 14, 11]])], 1)
+    batch = torch.cat([torch.zeros(9, dtype=torch.long), torch.ones(7, dtype=torch.long)])
+    kept = torch.tensor([1, 7, 10, 15])
+    for it in (1, 2, 5):
+        if it < 5:
+            continue  # fewer rounds leave nodes to the random fallback: unpinned
+        a = get_assignments(kept, edge_index=ei, max_iter=it, batch=batch)
+        add(f"get_assignments_chains_it{it}", dict(kept=kept, edge_index=ei, batch=batch), {"assignments": t(a)},
+            cfg=dict(max_iter=it))
+    # vote counting + tie break: node 4 hears cluster 1 twice and cluster 2 twice -> smallest id wins
+    ei2 = torch.tensor([[0, 0, 1, 1, 2, 3, 0, 1, 4], [4, 4, 4, 4, 5, 5, 2, 3, 6]])
+    a2 = get_assignments(torch.tensor([0, 1]), edge_index=ei2, max_iter=3, num_nodes=7)
+    add("get_assignments_votes", dict(kept=torch.tensor([0, 1]), edge_index=ei2), {"assignments": t(a2)},
+        cfg=dict(max_iter=3, num_nodes=7))
+    # through SelectOutput, with per-node weights and an extra attribute
+    g = torch.Generator().manual_seed(12)
+    w = torch.rand(16, generator=g)
+    so = SelectOutput(cluster_index=torch.arange(4), node_index=kept, num_nodes=16, num_supernodes=4, tag="kept")
+    full = so.assign_all_nodes(adj=ei, weight=w, batch=batch, closest_node_assignment=True)
+    add("assign_all_nodes_chains", dict(kept=kept, edge_index=ei, batch=batch, weight=w),
+        {"so": so_dict(full), "tag": full.tag})
+
+
 def main():
+    gen_assign_all_last = gen_assign_all
     gen_topk()
     gen_cluster_connect()
     gen_ndp()
     gen_dense()
     gen_operators()
+    gen_assign_all_last()
     out = os.path.join(HERE, "golden_v1.pt")
     torch.save({"tgp_version": tgp.__version__, "torch": str(torch.__version__),
                 "numpy": str(np.__version__), "cases": CASES}, out)

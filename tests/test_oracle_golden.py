@@ -292,3 +292,39 @@ def test_golden_dense_connect_unbatched_grid(golden):
         ei, ew = O.postprocess_sparse(ei, ew, raw.size(0) * raw.size(1), True, True, ewn, bp)
         exact(ei, e[f"sp1_ewn{int(ewn)}_adj"])
         close(ew, e[f"sp1_ewn{int(ewn)}_w"])
+
+
+def test_get_assignments_and_assign_all_nodes(golden):
+    """A0 `SelectOutput.assign_all_nodes` (base_select.py:381-486): oracle loops == reference dump == product
+    (host-side torch logic, runs on any device)."""
+    import tgp_oracle as O
+    from tgp.select import SelectOutput
+    from tgp.utils.ops import get_assignments
+    for name in ("get_assignments_chains_it5", "get_assignments_votes"):
+        c = golden[name]
+        n = c["cfg"].get("num_nodes") or c["inputs"]["batch"].numel()
+        want = c["expected"]["assignments"]
+        assert torch.equal(O.get_assignments(c["inputs"]["kept"], c["inputs"]["edge_index"], c["cfg"]["max_iter"], n), want)
+        got = get_assignments(c["inputs"]["kept"], edge_index=c["inputs"]["edge_index"], max_iter=c["cfg"]["max_iter"],
+                              batch=c["inputs"].get("batch"), num_nodes=c["cfg"].get("num_nodes"))
+        assert torch.equal(got, want)
+    c = golden["assign_all_nodes_chains"]
+    i = c["inputs"]
+    so = SelectOutput(cluster_index=torch.arange(4), node_index=i["kept"], num_nodes=16, num_supernodes=4, tag="kept")
+    full = so.assign_all_nodes(adj=i["edge_index"], weight=i["weight"], batch=i["batch"])
+    e = c["expected"]["so"]
+    assert torch.equal(full.cluster_index, e["cluster_index"]) and torch.equal(full.node_index, e["node_index"])
+    assert torch.equal(full.weight, e["weight"]) and full.tag == c["expected"]["tag"]
+    assert (full.num_nodes, full.num_supernodes) == (e["num_nodes"], e["num_supernodes"])
+    # reference tests/selection/test_base_select.py:380-405, 442-466, 469-494
+    small = SelectOutput(cluster_index=torch.tensor([0, 1]), node_index=torch.tensor([0, 2]), num_nodes=4, num_supernodes=2)
+    ei = torch.tensor([[0, 1, 2, 3], [1, 0, 3, 2]])
+    with pytest.raises(ValueError, match=r"Weight tensor size \(3\) must match the number of nodes \(4\)"):
+        small.assign_all_nodes(adj=ei, weight=torch.ones(3))
+    out = small.assign_all_nodes(adj=ei)
+    assert (out.num_nodes, out.num_supernodes) == (4, 2) and out.cluster_index.tolist() == [0, 0, 1, 1]
+    coo = torch.sparse_coo_tensor(ei, torch.ones(4), size=(4, 4)).coalesce()
+    assert small.assign_all_nodes(adj=coo).cluster_index.tolist() == [0, 0, 1, 1]
+    with pytest.raises(AssertionError):
+        small.assign_all_nodes(adj=None)
+    assert small.assign_all_nodes(adj=ei) is not small and out.assign_all_nodes(adj=ei) is out  # all kept: unchanged

@@ -95,7 +95,8 @@ class SparseConnect(Connect):
                                  "required for per-graph normalization in SparseConnect.")
         # every node assigned (one-over-K poolers): hand over the supernode->member index (cached on `so`,
         # shared with Reduce) so the sort-free row-local coalesce can be used
-        all_assigned = so.node_index.numel() == so.num_nodes and so.node_index.is_cuda
+        ni = so.node_index  # None for a dense assignment: sparse_connect then raises the reference's RuntimeError
+        all_assigned = ni is not None and ni.numel() == so.num_nodes and ni.is_cuda
         return sparse_connect(edge_index, edge_weight, node_index=so.node_index, cluster_index=so.cluster_index,
                               num_nodes=so.num_nodes, num_supernodes=so.num_supernodes,
                               remove_self_loops=self.remove_self_loops, reduce_op=self.reduce_op,
@@ -184,6 +185,9 @@ class DenseConnect(Connect):
     @staticmethod
     def _dense_connect_unbatched(edge_index, edge_weight, batch, s, num_nodes, num_clusters, batch_size):
         """[B,K,K] = per-graph S_b^T A_b S_b from a sparse A (reference dense_conn.py:140-208)."""
+        if batch_size == 1 and not isinstance(edge_index, Tensor) and not is_sparsetensor(edge_index):
+            # the reference's single-graph path converts with connectivity_to_torch_coo (dense_conn.py:158-160)
+            raise ValueError(f"Edge index must be of type Tensor or SparseTensor, got {type(edge_index)}")
         ei, ew = connectivity_to_edge_index(edge_index, edge_weight)
         if ei.size(1) == 0:
             return s.new_zeros((batch_size, num_clusters, num_clusters))

@@ -244,9 +244,36 @@ class SelectOutput:
     def requires_grad_(self, requires_grad: bool = True) -> "SelectOutput":
         return self.apply(lambda t: t.requires_grad_(requires_grad=requires_grad))
 
-    def assign_all_nodes(self, *args, **kwargs):
-        raise NotImplementedError("assign_all_nodes belongs to the KMIS/MaxCut poolers, which are outside the "
-                                  "scope of this build (SURVEY.md section 2).")
+    def assign_all_nodes(self, adj=None, weight: Optional[Tensor] = None, max_iter: int = 5,
+                         batch: Optional[Tensor] = None, closest_node_assignment: bool = True) -> "SelectOutput":
+        """Extend a sparse selection (e.g. top-k) to an assignment of ALL nodes to the selected supernodes
+        (reference base_select.py:381-486): graph-aware label propagation for ``closest_node_assignment``,
+        random otherwise; ``weight`` are per-node assignment weights."""
+        from ..utils.ops import connectivity_to_edge_index, get_assignments
+        kept = self.node_index
+        if len(kept) == self.num_nodes:
+            return self
+        edge_index = None
+        if closest_node_assignment:
+            assert adj is not None, "adj must be provided for closest_node_assignment"
+            assert max_iter > 0, "max_iter must be greater than 0 for closest_node_assignment"
+            if is_sparsetensor(adj) or (isinstance(adj, Tensor) and adj.is_sparse):
+                edge_index, _ = connectivity_to_edge_index(adj)
+            elif isinstance(adj, Tensor):
+                edge_index = adj
+            else:
+                raise ValueError(f"Invalid adjacency type: {type(adj)}")
+            if weight is not None and weight.size(0) != self.num_nodes:
+                raise ValueError(f"Weight tensor size ({weight.size(0)}) must match the number of nodes "
+                                 f"({self.num_nodes})")
+        assignments = get_assignments(kept, edge_index=edge_index if closest_node_assignment else None,
+                                      max_iter=max_iter if closest_node_assignment else 0, batch=batch)
+        out = SelectOutput(cluster_index=assignments[1], s_inv_op=getattr(self, "s_inv_op", "transpose"),
+                           weight=weight)
+        for name in self._extra_args:
+            if hasattr(self, name):
+                setattr(out, name, getattr(self, name))
+        return out
 
 
 class Select(torch.nn.Module):

@@ -119,6 +119,8 @@ def connectivity_to_torch_coo(edge_index, edge_weight: Optional[Tensor] = None,
         if w is None:
             w = torch.ones(edge_index.size(1), device=edge_index.device)
         return torch.sparse_coo_tensor(edge_index, w, (n, n)).coalesce()
+    if not is_sparsetensor(edge_index):  # defensive (reference ops.py: final else of the type dispatch)
+        raise ValueError("Edge index must be a Tensor or SparseTensor.")
     row, col, value = edge_index.coo()
     n = maybe_num_nodes(edge_index, num_nodes)
     if value is None:
@@ -261,3 +263,98 @@ def dense_to_block_diag(adj_pool: Tensor) -> Tuple[Tensor, Tensor]:
     if adj_pool.dim() != 3:
         raise ValueError("adj_pool must have shape [B, K, K] or [K, K].")
     return K.block_diag_edges(adj_pool)
+
+
+# --------------------------------------------------------------------------------------------------
+# SelectOutput.assign_all_nodes support (reference utils/ops.py:1177-1440).  Host-side selector logic
+# (device torch ops, outside the timed Reduce + Connect path): every node that a sparse selection left
+# out joins the supernode most of its already-assigned in-neighbours belong to; leftovers are dealt out
+# at random inside their own graph.
+# --------------------------------------------------------------------------------------------------
+def get_random_map_mask(kept_nodes: Tensor, mask: Tensor, batch: Optional[Tensor] = None) -> Tensor:
+    """[2, #unassigned]: unassigned node -> randomly drawn kept node (same graph when ``batch`` is given;
+    kept nodes must then be grouped by graph, reference ops.py:1177-1219)."""
+    todo = (~mask).nonzero().view(-1)
+    pick = torch.randint(0, kept_nodes.size(0), (todo.size(0),), device=kept_nodes.device)
+    if batch is not None:
+        per_graph = torch.bincount(batch[kept_nodes])
+        first = torch.cumsum(per_graph, 0) - per_graph  # offset of each graph's kept nodes
+        g = batch[todo]
+        pick = kept_nodes[pick % per_graph[g] + first[g]]
+    return torch.stack([todo, pick])
+
+
+def propagate_assignments_sparse(assignments: Tensor, edge_index: Tensor, kept_node_tensor: Tensor, mask: Tensor,
+                                 num_clusters: int):
+    """One round of label propagation over the COO edge list (reference ops.py:1222-1314): an unassigned
+    destination takes the cluster (1..K, 0 = none) that most of its assigned sources carry, the smallest
+    cluster id on ties.  Returns (assignments, [2, #new] node -> kept-node map, mask)."""
+    src, dst = edge_index[0], edge_index[1]
+    label = assignments[src]
+    live = (label > 0) & ~mask[dst]
+    none = torch.empty((2, 0), device=assignments.device, dtype=torch.long)
+    if not bool(live.any()):
+        return assignments, none, mask
+    # (dst, label) pairs with multiplicities; `unique` returns them sorted by dst, then label
+    pair, votes = torch.unique(dst[live] * (num_clusters + 1) + label[live], return_counts=True)
+    p_dst, p_label = pair // (num_clusters + 1), pair % (num_clusters + 1)
+    # stable sort by (dst, votes descending): the first entry of every dst run is its winner, and among equal
+    # vote counts the smaller label stays in front
+    top = int(votes.max()) + 1
+    order = torch.sort(p_dst * top + (top - 1 - votes), stable=True)[1]
+    p_dst, p_label = p_dst[order], p_label[order]
+    first = torch.ones_like(p_dst, dtype=torch.bool)
+    first[1:] = p_dst[1:] != p_dst[:-1]
+    new_nodes, new_labels = p_dst[first], p_label[first]
+    real = new_labels > 0  # labels beyond num_clusters alias to 0 in the packed key: nothing to assign
+    if not bool(real.any()):
+        return assignments, none, mask
+    new_nodes, new_labels = new_nodes[real], new_labels[real]
+    assignments = assignments.clone()
+    assignments[new_nodes] = new_labels
+    mask = mask.clone()
+    mask[new_nodes] = True
+    return assignments, torch.stack([new_nodes, kept_node_tensor[new_labels - 1]]), mask
+
+
+def get_assignments(kept_node_indices, edge_index: Optional[Tensor] = None, max_iter: int = 5,
+                    batch: Optional[Tensor] = None, num_nodes: Optional[int] = None) -> Tensor:
+    """[2, N] map node -> consecutive supernode id: kept nodes are their own supernode, the others join through
+    up to ``max_iter`` propagation rounds, the rest at random (reference ops.py:1317-1440)."""
+    if isinstance(kept_node_indices, Tensor):
+        kept = torch.squeeze(kept_node_indices).to(torch.long)
+    else:
+        kept = torch.tensor(kept_node_indices, dtype=torch.long)
+    if num_nodes is None:
+        if batch is not None:
+            num_nodes = batch.size(0)
+        elif edge_index is not None:
+            num_nodes = int(edge_index.max()) + 1
+        else:
+            raise ValueError("Either num_nodes, batch, or edge_index must be provided to determine the number "
+                             "of nodes")
+    device = edge_index.device if edge_index is not None else (batch.device if batch is not None else kept.device)
+    kept = kept.to(device)
+    mask = torch.zeros(num_nodes, device=device, dtype=torch.bool)
+    mask[kept] = True
+    maps = [torch.stack([kept, kept])]
+    if max_iter > 0:
+        if edge_index is None:
+            raise ValueError("edge_index must be provided when max_iter > 0")
+        ei = edge_index.coalesce().indices() if (isinstance(edge_index, Tensor) and edge_index.is_sparse) \
+            else edge_index
+        k = kept.size(0)
+        labels = torch.zeros(num_nodes, device=device, dtype=torch.long)
+        labels[kept] = torch.arange(1, k + 1, device=device)
+        for _ in range(max_iter):
+            if bool(mask.all()):
+                break
+            labels, new_map, mask = propagate_assignments_sparse(labels, ei, kept, mask, k)
+            if new_map.size(1) > 0:
+                maps.append(new_map)
+    if not bool(mask.all()):
+        maps.append(get_random_map_mask(kept, mask, batch))
+    out = torch.cat(maps, dim=1)
+    out = out[:, out[0].argsort()]
+    out[1] = torch.unique(out[1], return_inverse=True)[1]
+    return out
