@@ -1,24 +1,25 @@
 // A4 + A6 fast path: coalesce Connect WITHOUT a global sort, for row-sorted edge lists.
 //
 // PyG edge lists are row-sorted almost everywhere (coalesced inputs, to_undirected, dataset loaders).
-// Then the edges of one supernode r are the union of the contiguous edge ranges of its member nodes, so
-// grouping the relabelled edges by supernode row needs no sort: every edge computes its own slot
-//     raw_off[r] + member_off[node] + (e - node_ptr[node])
-// (stable: members ascending, input order inside a member), and only the short per-row segments
-// (~E/K entries) have to be ordered by column.  Pipeline, all edge- or row-parallel:
-//   K1 check rows sorted + CSR of the input (node_ptr)            read E*8 B
+// Then the edges of one supernode r are the union of the contiguous edge ranges of its member nodes, in the
+// stable order (members ascending, input order inside a member) at slot
+//     raw_off[r] + member_off[node] + (e - node_ptr[node]),
+// so grouping the relabelled edges by supernode row needs no sort, and only the short per-row segments
+// (~E/K entries) have to be ordered by column.  Pipeline:
+//   K1 check rows sorted + CSR of the input (node_ptr)            read E*8 B twice
 //   K2 per supernode: raw row length T_r, per-member offsets      K-sized
-//   K3 scan T_r -> raw_off                                          K-sized
-//   K4 scatter (cluster[col], w) into supernode-major order       read E*20 B, write E*8 B
-//   K5 per row segment: stable sort by column (half-wave bitonic network in registers for rows of <= 32
-//      entries, one workgroup + LDS bitonic for rows of 33..1024), merge duplicates with reduce_op in
-//      input order, fused self-loop / eps filters, survivors compacted per row          read+write E*8 B
-//   K6 scan survivors -> output offsets, total                    K-sized            [host reads total]
-//   K7 fill                                                        read E'*8 B, write E'*20 B
+//   K3 scan T_r -> raw_off; per-node slot base                    K-, N-sized
+//   K4 gather-sort-merge (cr_gather_sort_kernel): one workgroup per 64 supernode rows gathers the rows' edges
+//      through the cluster table straight into LDS, sorts every row there (half-wave bitonic network in
+//      registers for rows of <= 32 entries, workgroup LDS bitonic for 33..1024), merges duplicates with
+//      reduce_op in input order, fused self-loop / eps filters, survivors compacted per row
+//                                                                  read E*12 B + gathers, write E'*8 B
+//   K5 scan survivors -> output offsets, total                    K-sized            [host reads total]
+//   K6 fill                                                        read E'*8 B, write E'*20 B
 // vs. five radix passes of 32 B/edge each in the general path (sparse_connect.hip).  The result is
 // identical to the general path (row-major sorted, unique, duplicates reduced in input order).
-// Preconditions are checked on the device (rows sorted; no supernode row longer than 1024 raw entries);
-// if they fail *d_count is set to -1 and the caller falls back to the sort-based path.
+// Preconditions are checked on the device (rows sorted; no supernode row longer than 1024 raw entries or with
+// more than 1024 members); if they fail *d_count is set to -1 and the caller falls back to the sort-based path.
 #include "primitives.h"
 
 namespace tgp {
@@ -116,25 +117,31 @@ __global__ __launch_bounds__(256) void cr_row_len_kernel(const int32_t* __restri
 }
 
 // ------------------------------------------------------------------ K4
-__global__ __launch_bounds__(256) void cr_scatter_kernel(const int64_t* __restrict__ row,
-                                                         const int64_t* __restrict__ col,
-                                                         const float* __restrict__ w, int64_t E,
-                                                         const int32_t* __restrict__ table,
-                                                         const uint32_t* __restrict__ node_ptr,
-                                                         const uint32_t* __restrict__ member_off,
-                                                         const uint32_t* __restrict__ raw_off,
-                                                         const int* __restrict__ bad, uint32_t* __restrict__ tmp_c,
-                                                         float* __restrict__ tmp_w) {
+// (first edge, first slot) of every member, in inverted-index order: the gather kernel below then reads the
+// segments of its rows as two coalesced runs instead of chasing a_perm -> node_ptr per member
+__global__ __launch_bounds__(256) void cr_segments_kernel(const int32_t* __restrict__ a_perm, int64_t nnz,
+                                                          const int32_t* __restrict__ table,
+                                                          const uint32_t* __restrict__ node_ptr,
+                                                          const uint32_t* __restrict__ member_off,
+                                                          const uint32_t* __restrict__ raw_off,
+                                                          const int* __restrict__ bad, uint32_t* __restrict__ seg_src,
+                                                          uint32_t* __restrict__ seg_dst) {
   if (*bad) return;
-  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (e >= E) return;
-  const int64_t node = row[e];
-  const uint32_t pos = raw_off[table[node]] + member_off[node] + (static_cast<uint32_t>(e) - node_ptr[node]);
-  tmp_c[pos] = static_cast<uint32_t>(table[col[e]]);
-  if (tmp_w) tmp_w[pos] = w[e];
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (p >= nnz) return;
+  const int32_t node = a_perm[p];
+  seg_src[p] = node_ptr[node];
+  seg_dst[p] = raw_off[table[node]] + member_off[node];
 }
 
 // ------------------------------------------------------------------ K5
+// value of lane (lane ^ J) within the 32-lane half: one ds_swizzle (bit-mask mode: and 0x1F, xor J) - no address
+// arithmetic and no LDS access, where __shfl_xor costs two VALU instructions plus a ds_bpermute
+template <int J>
+__device__ __forceinline__ uint32_t xor_lane(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), 0x1F | (J << 10)));
+}
+
 __device__ __forceinline__ float cr_reduce(float acc, float v, int op) {
   switch (op) {
     case TGP_MIN: return fminf(acc, v);
@@ -144,77 +151,224 @@ __device__ __forceinline__ float cr_reduce(float acc, float v, int op) {
   }
 }
 
-// Rows of <= 32 raw entries: one HALF-WAVE per row, one entry per lane, bitonic network on the key
-// (column << 5 | input position) => stable; requires K < 2^27 (checked by the host wrapper).
-__global__ __launch_bounds__(256) void cr_rows_short_kernel(uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w,
-                                                            const uint32_t* __restrict__ raw_off, int64_t K,
-                                                            int64_t E, int reduce_op, int flags,
-                                                            const int* __restrict__ bad,
-                                                            uint32_t* __restrict__ n_out) {
+// ------------------------------------------------------------------ K4 + K5 fused: gather, sort, merge
+// One workgroup owns GS_ROWS consecutive supernode rows.  Their members are consecutive in the inverted index
+// and every member's edges are one contiguous range of the (row-sorted) input, so the workgroup
+//   (a) turns its members into (first edge, first slot) segments in LDS,
+//   (b) gathers slot-parallel: thread t finds its segment by binary search, reads (col, w) of its edge, maps
+//       the column through the cluster table and drops (cluster, w) into LDS slot t - no scatter through HBM,
+//   (c) sorts every row inside LDS (half-wave register bitonic for <= 32 entries, workgroup bitonic up to
+//       CR_LONG), merges duplicates in input order with the A6 filters fused, and writes the survivors of row r
+//       compacted at tmp[raw_off[r] ...] with their count in n_out[r].
+// Every dependent-load level (row offsets -> members -> node ranges -> edges -> table) is one block-wide,
+// coalesced-as-possible request, so the latency chain is paid once per ~1000 edges instead of once per row.
+constexpr int GS_ROWS = 32;
+constexpr int GS_CAP = 1024;   // raw entries staged per pass (>= CR_LONG)
+constexpr int GS_MEM = 512;    // members per pass
+
+__global__ __launch_bounds__(256) void cr_gather_sort_kernel(
+    const int64_t* __restrict__ col, const float* __restrict__ w, int64_t E, const int32_t* __restrict__ table,
+    const int32_t* __restrict__ a_row_ptr, const uint32_t* __restrict__ seg_src, const uint32_t* __restrict__ seg_dst,
+    const uint32_t* __restrict__ raw_off, int64_t K, int reduce_op, int flags,
+    int* __restrict__ bad, uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w, uint32_t* __restrict__ n_out) {
+  __shared__ uint32_t s_key[GS_CAP];
+  __shared__ float s_val[GS_CAP];
+  __shared__ uint32_t s_seg_dst[GS_MEM], s_seg_src[GS_MEM];
+  __shared__ uint32_t s_roff[GS_ROWS + 1];
+  __shared__ int32_t s_rp[GS_ROWS + 1];
+  __shared__ int s_mid[GS_ROWS];
+  __shared__ int s_nmid;
   if (*bad) return;
-  const int l = threadIdx.x & 31;
-  const unsigned long long half_mask = 0xFFFFFFFFull << (threadIdx.x & 32);
-  const int64_t nhalf = static_cast<int64_t>(gridDim.x) * 8;
-  for (int64_t r0 = static_cast<int64_t>(blockIdx.x) * 8; r0 < K; r0 += nhalf) {
-    const int64_t r = r0 + (threadIdx.x >> 5);
-    uint32_t b = 0, T = 0;
-    if (r < K) {
-      b = raw_off[r];
-      T = (r + 1 < K ? raw_off[r + 1] : static_cast<uint32_t>(E)) - b;
+  const int tid = threadIdx.x;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * GS_ROWS;
+  const int nrows = static_cast<int>(K - r0 < GS_ROWS ? K - r0 : GS_ROWS);
+  if (tid <= nrows) {
+    s_roff[tid] = r0 + tid < K ? raw_off[r0 + tid] : static_cast<uint32_t>(E);
+    s_rp[tid] = a_row_ptr[r0 + tid];
+  }
+  __syncthreads();
+  const bool has_w = tmp_w != nullptr;
+  int rs = 0;
+  while (rs < nrows) {
+    if (s_rp[rs + 1] - s_rp[rs] > GS_MEM) {  // one supernode with too many members for a pass: decline
+      if (tid == 0) *bad = 3;
+      return;
     }
-    const bool mine = r < K && T <= 32;  // longer rows belong to cr_rows_long_kernel
-    const uint32_t Tm = mine ? T : 0;
-    uint32_t key = 0xFFFFFFFFu;
-    float w = 0.f;
-    if (static_cast<uint32_t>(l) < Tm) {
-      key = (tmp_c[b + l] << 5) | static_cast<uint32_t>(l);
-      if (tmp_w) w = tmp_w[b + l];
+    int re = rs + 1;
+    while (re < nrows && s_roff[re + 1] - s_roff[rs] <= static_cast<uint32_t>(GS_CAP) && s_rp[re + 1] - s_rp[rs] <= GS_MEM) ++re;
+    const uint32_t base = s_roff[rs];
+    const int cnt = static_cast<int>(s_roff[re] - base);
+    const int p_lo = s_rp[rs], M = s_rp[re] - p_lo;
+    if (tid == 0) s_nmid = 0;
+    // (a) members -> (first edge, first slot)
+    for (int m = tid; m < M; m += 256) {
+      s_seg_src[m] = seg_src[p_lo + m];
+      s_seg_dst[m] = seg_dst[p_lo + m] - base;
     }
-    // bitonic sort of 32 (key, w) pairs across the half-wave
+    __syncthreads();
+    // (b) slot-parallel gather through the cluster table
+    {  // all GS_CAP / 256 slots of a thread are requested before any is consumed: one round trip per level
+      constexpr int U = GS_CAP / 256;
+      uint32_t eidx[U];
+      int64_t cc[U];
+      float wv[U];
 #pragma unroll
-    for (int k = 2; k <= 32; k <<= 1) {
+      for (int u = 0; u < U; ++u) {
+        const int t = tid + u * 256;
+        eidx[u] = 0;
+        if (t < cnt) {
+          int lo = 0, hi = M;  // last member with dst <= t (zero-length members share their successor's dst)
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_seg_dst[mid] <= static_cast<uint32_t>(t)) lo = mid; else hi = mid;
+          }
+          eidx[u] = s_seg_src[lo] + (static_cast<uint32_t>(t) - s_seg_dst[lo]);
+        }
+      }
 #pragma unroll
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        const uint32_t ok = __shfl_xor(key, j, 32);
-        const float ow = __shfl_xor(w, j, 32);
-        const bool up = ((l & k) == 0);            // ascending block
-        const bool lower = ((l & j) == 0);         // this lane keeps the smaller one in an ascending block
-        const bool take = (key > ok) == (up == lower);
-        if (take) { key = ok; w = ow; }
+      for (int u = 0; u < U; ++u) {
+        const bool ok = tid + u * 256 < cnt;
+        cc[u] = ok ? col[eidx[u]] : 0;
+        wv[u] = (ok && has_w) ? w[eidx[u]] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = tid + u * 256;
+        if (t < cnt) {
+          s_key[t] = static_cast<uint32_t>(table[cc[u]]);
+          s_val[t] = wv[u];
+        }
       }
     }
-    const bool valid = key != 0xFFFFFFFFu;
-    const uint32_t c = key >> 5;
-    const uint32_t pc = __shfl_up(c, 1, 32);
-    const bool pvalid = __shfl_up(valid ? 1 : 0, 1, 32) != 0;
-    const bool head = valid && (l == 0 || !pvalid || pc != c);
-    // every head folds its run in sorted (= input) order
-    float acc = w;
-    uint32_t cnt = 1;
-    bool open = head;
-    for (int d = 1; d < 32; ++d) {
-      const uint32_t nc = __shfl_down(c, d, 32);
-      const float nw = __shfl_down(w, d, 32);
-      const bool nvalid = __shfl_down(valid ? 1 : 0, d, 32) != 0;
-      open = open && (l + d < 32) && nvalid && nc == c;
-      if (open) { acc = cr_reduce(acc, nw, reduce_op); ++cnt; }
-      if (!__any(open)) break;
+    __syncthreads();
+    // (c1) rows of <= 32 entries: one half-wave each
+    {
+      const int l = tid & 31, hw = tid >> 5;
+      const unsigned long long half_mask = 0xFFFFFFFFull << (tid & 32);
+      for (int i0 = rs; i0 < re; i0 += 8) {
+        const int i = i0 + hw;
+        uint32_t b = 0, T = 0;
+        if (i < re) {
+          b = s_roff[i] - base;
+          T = s_roff[i + 1] - s_roff[i];
+        }
+        const bool mine = i < re && T <= 32;
+        if (i < re && T > 32) {
+          if (T <= 64) {
+            if (l == 0) s_mid[atomicAdd(&s_nmid, 1)] = i;
+          } else {  // longer rows: hand the raw (cluster, weight) entries to cr_rows_long_kernel through tmp
+            for (uint32_t j = l; j < T; j += 32) {
+              tmp_c[base + b + j] = s_key[b + j];
+              if (has_w) tmp_w[base + b + j] = s_val[b + j];
+            }
+          }
+        }
+        const uint32_t Tm = mine ? T : 0;
+        uint32_t key = 0xFFFFFFFFu;
+        if (static_cast<uint32_t>(l) < Tm) key = (s_key[b + l] << 5) | static_cast<uint32_t>(l);
+        // only the keys travel through the network (the input position rides in their low 5 bits, which also
+        // makes the sort stable); the weight is fetched from LDS by that position afterwards
+#define TGP_CE(KK, JJ)                                                           \
+  {                                                                              \
+    const uint32_t ok = xor_lane<JJ>(key);                                       \
+    if ((key > ok) == (((l & KK) == 0) == ((l & JJ) == 0))) key = ok;            \
+  }
+        TGP_CE(2, 1) TGP_CE(4, 2) TGP_CE(4, 1) TGP_CE(8, 4) TGP_CE(8, 2) TGP_CE(8, 1)
+        TGP_CE(16, 8) TGP_CE(16, 4) TGP_CE(16, 2) TGP_CE(16, 1)
+        TGP_CE(32, 16) TGP_CE(32, 8) TGP_CE(32, 4) TGP_CE(32, 2) TGP_CE(32, 1)
+#undef TGP_CE
+        const bool valid = key != 0xFFFFFFFFu;
+        const uint32_t c = key >> 5;
+        const float wv = valid ? s_val[b + (key & 31u)] : 0.f;
+        const uint32_t pc = __shfl_up(c, 1, 32);
+        const bool pvalid = __shfl_up(valid ? 1 : 0, 1, 32) != 0;
+        const bool head = valid && (l == 0 || !pvalid || pc != c);
+        float acc = wv;
+        uint32_t ncnt = 1;
+        bool open = head;
+        const int dmax = __any(valid && !head) ? 32 : 1;  // no duplicate column anywhere in this wave: nothing to fold
+        for (int d = 1; d < dmax; ++d) {
+          const uint32_t nc = __shfl_down(c, d, 32);
+          const float nw = __shfl_down(wv, d, 32);
+          const bool nvalid = __shfl_down(valid ? 1 : 0, d, 32) != 0;
+          open = open && (l + d < 32) && nvalid && nc == c;
+          if (open) { acc = cr_reduce(acc, nw, reduce_op); ++ncnt; }
+          if (!__any(open)) break;
+        }
+        if (has_w && reduce_op == TGP_MEAN) acc = acc / static_cast<float>(ncnt);
+        bool keep = head;
+        if ((flags & TGP_REMOVE_SELF_LOOPS) && c == static_cast<uint32_t>(r0 + i)) keep = false;
+        if (has_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > TGP_EPS)) keep = false;
+        const unsigned long long km = __ballot(keep) & half_mask;
+        const uint32_t rank = __popcll(km & lanemask_lt());
+        if (keep) {
+          tmp_c[base + b + rank] = c;
+          if (has_w) tmp_w[base + b + rank] = acc;
+        }
+        if (mine && l == 0) n_out[r0 + i] = __popcll(km);
+      }
     }
-    if (tmp_w && reduce_op == TGP_MEAN) acc = acc / static_cast<float>(cnt);
-    bool keep = head;
-    if ((flags & TGP_REMOVE_SELF_LOOPS) && c == static_cast<uint32_t>(r)) keep = false;
-    if (tmp_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > TGP_EPS)) keep = false;
-    const unsigned long long km = __ballot(keep) & half_mask;
-    const uint32_t rank = __popcll(km & lanemask_lt());
-    if (keep) {
-      tmp_c[b + rank] = c;
-      if (tmp_w) tmp_w[b + rank] = acc;
+    __syncthreads();
+    // (c1b) rows of 33 .. 64 entries: one wave each, the same register network over 64 lanes (position in 6 bits)
+    {
+      const int lane = tid & 63;
+      const int nmid = s_nmid;
+      for (int li = tid >> 6; li < nmid; li += 4) {
+        const int i = s_mid[li];
+        const uint32_t b = s_roff[i] - base, T = s_roff[i + 1] - s_roff[i];
+        uint32_t key = static_cast<uint32_t>(lane) < T ? (s_key[b + lane] << 6) | static_cast<uint32_t>(lane) : 0xFFFFFFFFu;
+#define TGP_CE(KK, JJ)                                                                 \
+  {                                                                                    \
+    const uint32_t ok = xor_lane<JJ>(key);                                             \
+    if ((key > ok) == (((lane & KK) == 0) == ((lane & JJ) == 0))) key = ok;            \
+  }
+        TGP_CE(2, 1) TGP_CE(4, 2) TGP_CE(4, 1) TGP_CE(8, 4) TGP_CE(8, 2) TGP_CE(8, 1)
+        TGP_CE(16, 8) TGP_CE(16, 4) TGP_CE(16, 2) TGP_CE(16, 1)
+        TGP_CE(32, 16) TGP_CE(32, 8) TGP_CE(32, 4) TGP_CE(32, 2) TGP_CE(32, 1)
+        {
+          const uint32_t ok = __shfl_xor(key, 32, 64);  // the one exchange across the two 32-lane halves
+          if ((key > ok) == ((lane & 32) == 0)) key = ok;
+        }
+        TGP_CE(64, 16) TGP_CE(64, 8) TGP_CE(64, 4) TGP_CE(64, 2) TGP_CE(64, 1)
+#undef TGP_CE
+        const bool valid = key != 0xFFFFFFFFu;
+        const uint32_t c = key >> 6;
+        const float wv = valid ? s_val[b + (key & 63u)] : 0.f;
+        const uint32_t pc = __shfl_up(c, 1, 64);
+        const bool pvalid = __shfl_up(valid ? 1 : 0, 1, 64) != 0;
+        const bool head = valid && (lane == 0 || !pvalid || pc != c);
+        float acc = wv;
+        uint32_t ncnt = 1;
+        bool open = head;
+        const int dmax = __any(valid && !head) ? 64 : 1;
+        for (int d = 1; d < dmax; ++d) {
+          const uint32_t nc = __shfl_down(c, d, 64);
+          const float nw = __shfl_down(wv, d, 64);
+          const bool nvalid = __shfl_down(valid ? 1 : 0, d, 64) != 0;
+          open = open && (lane + d < 64) && nvalid && nc == c;
+          if (open) { acc = cr_reduce(acc, nw, reduce_op); ++ncnt; }
+          if (!__any(open)) break;
+        }
+        if (has_w && reduce_op == TGP_MEAN) acc = acc / static_cast<float>(ncnt);
+        bool keep = head;
+        if ((flags & TGP_REMOVE_SELF_LOOPS) && c == static_cast<uint32_t>(r0 + i)) keep = false;
+        if (has_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > TGP_EPS)) keep = false;
+        const unsigned long long km = __ballot(keep);
+        const uint32_t rank = __popcll(km & lanemask_lt());
+        if (keep) {
+          tmp_c[base + b + rank] = c;
+          if (has_w) tmp_w[base + b + rank] = acc;
+        }
+        if (lane == 0) n_out[r0 + i] = __popcll(km);
+      }
     }
-    if (mine && l == 0) n_out[r] = __popcll(km);
+    rs = re;
+    __syncthreads();
   }
 }
 
-// Rows of 33..1024 raw entries: one workgroup per row, bitonic sort of (column << 32 | position) in LDS.
+// Rows of 65..1024 raw entries (rare: hub supernodes), left raw in tmp by the gather kernel: one workgroup per
+// row, bitonic sort of (column << 32 | position) in LDS, sorted + merged in place.
 __global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w,
                                                            const uint32_t* __restrict__ raw_off, int64_t K,
                                                            int64_t E, int reduce_op, int flags,
@@ -235,7 +389,7 @@ __global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict_
     if (rr < K) {
       const uint32_t tb = raw_off[rr];
       const uint32_t tt = (rr + 1 < K ? raw_off[rr + 1] : static_cast<uint32_t>(E)) - tb;
-      if (tt > 32 && tt <= CR_LONG) s_list[atomicAdd(&s_nlist, 1)] = tid;
+      if (tt > 64 && tt <= CR_LONG) s_list[atomicAdd(&s_nlist, 1)] = tid;
     }
   }
   __syncthreads();
@@ -334,6 +488,8 @@ struct CrWs {
   int32_t* table;        // [N]
   uint32_t* node_ptr;    // [N+1]
   uint32_t* member_off;  // [N]
+  uint32_t* seg_src;     // [N] first edge of every member (inverted-index order)
+  uint32_t* seg_dst;     // [N] first slot of every member
   uint32_t* T;           // [K]
   uint32_t* raw_off;     // [K]
   uint32_t* n_out;       // [K]
@@ -353,6 +509,8 @@ static size_t cr_layout(void* ws, int64_t E, int64_t N, int64_t K, CrWs* out) {
   s.table = cv.take<int32_t>(n);
   s.node_ptr = cv.take<uint32_t>(n + 1);
   s.member_off = cv.take<uint32_t>(n);
+  s.seg_src = cv.take<uint32_t>(n);
+  s.seg_dst = cv.take<uint32_t>(n);
   s.T = cv.take<uint32_t>(k);
   s.raw_off = cv.take<uint32_t>(k);
   s.n_out = cv.take<uint32_t>(k);
@@ -391,8 +549,8 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
               "tgp_connect_coalesce_rows_count: null pointer");
   TGP_REQUIRE(reduce_op >= TGP_SUM && reduce_op <= TGP_MUL, TGP_ERR_INVALID,
               "tgp_connect_coalesce_rows_count: unknown reduce_op %d", reduce_op);
-  TGP_REQUIRE(E < (1ll << 31) && K < (1ll << 27) && N < (1ll << 31), TGP_ERR_RANGE,
-              "tgp_connect_coalesce_rows_count: E/N >= 2^31 or K >= 2^27");
+  TGP_REQUIRE(E < (1ll << 31) && K < (1ll << 26) && N < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_connect_coalesce_rows_count: E/N >= 2^31 or K >= 2^26");
   TGP_REQUIRE(ws && ws_bytes >= tgp_connect_coalesce_rows_workspace_bytes(E, N, K), TGP_ERR_WORKSPACE,
               "tgp_connect_coalesce_rows_count: workspace too small");
   if (E == 0 || K == 0) {
@@ -409,17 +567,13 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
   hipLaunchKernelGGL(cr_row_len_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, assign_row_ptr, assign_perm,
                      s.node_ptr, K, s.bad, s.T, s.member_off);
   device_scan_u32(s.T, K, s.raw_off, s.total, s.scan_scratch, stream);
-  hipLaunchKernelGGL(cr_scatter_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, E, s.table, s.node_ptr,
-                     s.member_off, s.raw_off, s.bad, s.tmp_c, tmp_w);
-  (void)hipMemsetAsync(s.n_out, 0, static_cast<size_t>(K) * sizeof(uint32_t), stream);
-  {
-    int64_t gs = (K + 7) / 8;
-    if (gs > 256 * 16) gs = 256 * 16;
-    hipLaunchKernelGGL(cr_rows_short_kernel, dim3(static_cast<unsigned>(gs)), dim3(256), 0, stream, s.tmp_c, tmp_w,
-                       s.raw_off, K, E, reduce_op, flags, s.bad, s.n_out);
-    hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, s.tmp_c, tmp_w,
-                       s.raw_off, K, E, reduce_op, flags, s.bad, s.n_out);
-  }
+  hipLaunchKernelGGL(cr_segments_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, assign_perm, N, s.table, s.node_ptr,
+                     s.member_off, s.raw_off, s.bad, s.seg_src, s.seg_dst);
+  hipLaunchKernelGGL(cr_gather_sort_kernel, dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, col, w, E, s.table,
+                     assign_row_ptr, s.seg_src, s.seg_dst, s.raw_off, K, reduce_op, flags, s.bad, s.tmp_c, tmp_w,
+                     s.n_out);
+  hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
+                     reduce_op, flags, s.bad, s.n_out);
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream);
   hipLaunchKernelGGL(cr_finish_count_kernel, dim3(1), dim3(1), 0, stream, s.bad, s.total, d_count);
   return check_launch("tgp_connect_coalesce_rows_count");

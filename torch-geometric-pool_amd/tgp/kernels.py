@@ -130,7 +130,7 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if (w is not None and eps_filter) else 0)
     L = N.lib()
     if (assign_index is not None and assign_index.nnz == cl.numel() and assign_index.num_targets == num_supernodes
-            and num_supernodes < (1 << 27)):
+            and num_supernodes < (1 << 26)):
         ws = N.workspace(L.tgp_connect_coalesce_rows_workspace_bytes(E, cl.numel(), num_supernodes), dev)
         d_count = torch.empty(1, dtype=torch.int64, device=dev)
         st = N.stream_ptr(dev)
