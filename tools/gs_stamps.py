@@ -18,7 +18,7 @@ k = so.num_supernodes
 idx = so.assign_index()
 for _ in range(2):
     kernels.coalesce_edges(ei, ew, so.cluster_index, k, "sum", True, assign_index=idx)
-nwg = (k + 63) // 64
+nwg = (k + 31) // 32
 st = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
 lib = _native.lib()
 lib.tgp_debug_set_gs_stamps.argtypes = [ctypes.c_void_p]
@@ -27,9 +27,9 @@ torch.cuda.synchronize()
 kernels.coalesce_edges(ei, ew, so.cluster_index, k, "sum", True, assign_index=idx)
 torch.cuda.synchronize()
 s = st.view(-1, 8).cpu().double() / 100.0
-names = ["(a) members", "(b) gather", "(c1) rows<=32", "(c1b) rows 33..64", "(c2) rows>64 + tail"]
+names = ["(a) segments -> LDS", "(b) gather", "(c1) rows<=32", "(c1b) rows 33..64 + tail", "-", "row offsets"]
 print("workgroups", nwg, "mean us per workgroup:")
 for i, nm in enumerate(names):
     print(f"  {nm:22s} {float(s[:, i].mean()):7.2f}  (max {float(s[:, i].max()):7.2f})")
 t0 = s[:, 7].min()
-print("start spread", float((s[:, 7] - t0).max()), "us; total per WG", float(s[:, :5].sum(1).mean()))
+print("start spread", float((s[:, 7] - t0).max()), "us; total per WG", float(s[:, :6].sum(1).mean()))

@@ -138,39 +138,35 @@ static __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t* __res
   if (tid == 0) digit_total[blockIdx.x] = tot;
 }
 
-// digit_total[BINS] -> exclusive prefix in place (one 256-thread workgroup)
-template <int DB>
-static __global__ __launch_bounds__(256) void radix_digit_base_kernel(uint32_t* __restrict__ digit_total) {
-  constexpr int BINS = 1 << DB;
-  constexpr int PER = BINS / 256;
-  __shared__ uint32_t s_w[4];
-  uint32_t v[PER], sum = 0;
-#pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    v[q] = digit_total[threadIdx.x * PER + q];
-    sum += v[q];
-  }
-  uint32_t run = block_excl_scan_256(sum, s_w, nullptr);
-#pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    digit_total[threadIdx.x * PER + q] = run;
-    run += v[q];
-  }
-}
-
 template <typename KeyT, typename ValT, int DB>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in, KeyT* __restrict__ keys_out,
     ValT* __restrict__ vals_out, const uint32_t* __restrict__ hist_scanned,
-    const uint32_t* __restrict__ digit_base, int64_t n, int64_t chunk, int shift, int nblocks) {
+    const uint32_t* __restrict__ digit_total, int64_t n, int64_t chunk, int shift, int nblocks) {
   constexpr int BINS = 1 << DB;
   constexpr int PER = BINS / kSortThreads;
   __shared__ uint32_t s_base[BINS];
   __shared__ uint32_t s_whist[4][BINS];
+  __shared__ uint32_t s_scan[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
-  for (int d = tid; d < BINS; d += kSortThreads)
-    s_base[d] = digit_base[d] + hist_scanned[static_cast<size_t>(d) * nblocks + blockIdx.x];
+  {  // first output slot of every digit = exclusive prefix of the digit totals (every workgroup redoes this tiny
+     // scan instead of a launch of its own) + what earlier chunks hold of that digit
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      v[q] = digit_total[tid * PER + q];
+      sum += v[q];
+    }
+    uint32_t run = block_excl_scan_256(sum, s_scan, nullptr);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int d = tid * PER + q;
+      s_base[d] = run + hist_scanned[static_cast<size_t>(d) * nblocks + blockIdx.x];
+      run += v[q];
+    }
+  }
+  __syncthreads();
 
   const int64_t begin = static_cast<int64_t>(blockIdx.x) * chunk;
   const int64_t end = begin + chunk < n ? begin + chunk : n;
@@ -275,7 +271,6 @@ static void radix_pass(const KeyT* ki, const ValT* vi, KeyT* ko, ValT* vo, int64
   hipLaunchKernelGGL((radix_hist_kernel<KeyT, DB>), dim3(p.nblocks), dim3(kSortThreads), 0, stream, ki, n,
                      p.chunk, shift, p.nblocks, hist);
   hipLaunchKernelGGL(radix_scan_kernel, dim3(BINS), dim3(1024), 0, stream, hist, p.nblocks, digit_total);
-  hipLaunchKernelGGL(radix_digit_base_kernel<DB>, dim3(1), dim3(256), 0, stream, digit_total);
   hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT, DB>), dim3(p.nblocks), dim3(kSortThreads), 0, stream,
                      ki, vi, ko, vo, hist, digit_total, n, p.chunk, shift, p.nblocks);
 }
