@@ -529,7 +529,7 @@ static int launch_gemm_residual(GemmArgs g, int batches, hipStream_t stream, boo
 //   pass 3  post_scale_kernel   : (a / d) / d^T, per-block max|.|
 //   pass 4  post_maxnorm_kernel : divide by the per-graph max                   (edge_weight_norm)
 // ------------------------------------------------------------------------------------------
-constexpr int POST_BLOCKS = 8;  // workgroups per graph in the elementwise passes
+constexpr int POST_BLOCKS = 64; // workgroups per graph in the elementwise passes
 
 struct PostArgs {
   const float* src;  // [B][splits][K][ld_src]
@@ -621,22 +621,23 @@ __global__ __launch_bounds__(256) void post_scale_kernel(PostArgs p) {
   const int b = blockIdx.y, K = p.K, tid = threadIdx.x;
   float* a = p.dst + static_cast<long>(b) * K * K;
   const float* dv = p.dvec + static_cast<long>(b) * K;
-  const long kk = static_cast<long>(K) * K;
-  const long per = (kk + POST_BLOCKS - 1) / POST_BLOCKS;
-  const long lo = blockIdx.x * per, hi = min(kk, lo + per);
+  const int rows_per = (K + POST_BLOCKS - 1) / POST_BLOCKS;  // a contiguous band of rows per workgroup
+  const int r_lo = blockIdx.x * rows_per, r_hi = min(K, r_lo + rows_per);
   const bool by_cols = p.flags & TGP_SUM_AXIS_ROWS;
   float mx = 0.f;
-  for (long e = lo + tid; e < hi; e += 256) {
-    float v = a[e];
-    if (p.flags & TGP_DEGREE_NORM) {
-      const int i = static_cast<int>(e / K), j = static_cast<int>(e - static_cast<long>(i) * K);
-      // (adj / d) / d^T with d shaped [1,K] (axis -2) or [K,1] (axis -1): ops.py:319
-      const float first = by_cols ? dv[j] : dv[i];
-      const float second = by_cols ? dv[i] : dv[j];
-      v = (v / first) / second;
-      a[e] = v;
+  for (int i = r_lo; i < r_hi; ++i) {
+    float* row = a + static_cast<long>(i) * K;
+    const float di = dv[i];
+    for (int j = tid; j < K; j += 256) {
+      float v = row[j];
+      if (p.flags & TGP_DEGREE_NORM) {
+        // (adj / d) / d^T with d shaped [1,K] (axis -2) or [K,1] (axis -1): ops.py:319
+        const float dj = dv[j];
+        v = by_cols ? (v / dj) / di : (v / di) / dj;
+        row[j] = v;
+      }
+      mx = fmaxf(mx, fabsf(v));
     }
-    mx = fmaxf(mx, fabsf(v));
   }
   if (p.flags & TGP_EDGE_WEIGHT_NORM) {
 #pragma unroll
@@ -1177,8 +1178,9 @@ __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
 }
 
 static const int kStage2Tile = getenv("TGP_STAGE2_TILE") ? atoi(getenv("TGP_STAGE2_TILE")) : 0;
+static const int kStage2TileM = getenv("TGP_STAGE2_TILE_M") ? atoi(getenv("TGP_STAGE2_TILE_M")) : 0;
 struct DensePlan {
-  int splits, tile;
+  int splits, tile, tile_m;
   int k_per_split;
   size_t u_floats, aslab_floats, xslab_floats, post_floats;
 };
@@ -1189,8 +1191,9 @@ static DensePlan dense_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
   // tiles (256-thread workgroups) need fewer splits for the same number of workgroups, i.e. longer k-loops
   // per workgroup and less slab traffic.
   p.tile = (kStage2Tile == 64 || kStage2Tile == 128) ? kStage2Tile : 64;
-  const int64_t T = p.tile;
-  const int64_t tiles = ((K + T - 1) / T) * (((K + T - 1) / T) + ((F + T - 1) / T));
+  p.tile_m = (kStage2TileM == 64 || kStage2TileM == 128) ? kStage2TileM : p.tile;
+  const int64_t T = p.tile, TM = p.tile_m;
+  const int64_t tiles = ((K + TM - 1) / TM) * (((K + T - 1) / T) + ((F + T - 1) / T));
   const int64_t base = B * (tiles > 0 ? tiles : 1);
   int64_t splits = (2 * 256 + base - 1) / base;  // aim for ~2 workgroups per CU
   const int64_t max_splits = (N + 4 * BK - 1) / (4 * BK);  // keep >= 4 k-steps per workgroup
@@ -1276,7 +1279,7 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
     h.A = S; h.lda = K; h.sA = N * K;
     h.M = static_cast<int>(K); h.Kd = static_cast<int>(N);
     h.splits = p.splits; h.k_per_split = p.k_per_split;
-    h.force_bm = h.force_bn = p.tile;
+    h.force_bm = p.tile_m; h.force_bn = p.tile;
     const GemmRhs ra{U, aslab, static_cast<int>(K), K, K, N * K, static_cast<long>(p.splits) * K * K, K * K};
     const GemmRhs rx{X, xslab, static_cast<int>(F), F, F, N * F, static_cast<long>(p.splits) * K * F, K * F};
     if (want_a && want_x) {
