@@ -16,15 +16,26 @@ lib.tgp_debug_set_gemm_stamps.argtypes = [p]
 B, N, K = (32, 1024, 128) if len(sys.argv) < 4 else (int(v) for v in sys.argv[1:4])
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-A = (torch.rand(B, N, N, device=dev) < 0.01).float()
-S = torch.softmax(torch.randn(B, N, K, device=dev), -1)
-U = torch.empty(B, N, K, device=dev)
 stream = torch.cuda.current_stream(dev).cuda_stream
+if os.environ.get("STAGE2"):
+    # the second product of the dense path, S^T [U | X] over a slice of N: C[b] = A[b]^T Bm[b], A stored [Kd, M]
+    Kd, M, Nc = (int(v) for v in os.environ["STAGE2"].split(","))
+    A = torch.rand(B, Kd, M, device=dev)
+    S = torch.rand(B, Kd, Nc, device=dev)
+    U = torch.empty(B, M, Nc, device=dev)
 
+    def run():
+        rc = lib.tgp_bmm_f32(A.data_ptr(), S.data_ptr(), U.data_ptr(), B, M, Nc, Kd, 1, M, Nc, Nc, Kd * M, Kd * Nc, M * Nc, stream)
+        assert rc == 0
+    N, K = M, Nc
+else:
+    A = (torch.rand(B, N, N, device=dev) < 0.01).float()
+    S = torch.softmax(torch.randn(B, N, K, device=dev), -1)
+    U = torch.empty(B, N, K, device=dev)
 
-def run():
-    rc = lib.tgp_bmm_f32(A.data_ptr(), S.data_ptr(), U.data_ptr(), B, N, K, N, 0, N, K, K, N * N, N * K, N * K, stream)
-    assert rc == 0
+    def run():
+        rc = lib.tgp_bmm_f32(A.data_ptr(), S.data_ptr(), U.data_ptr(), B, N, K, N, 0, N, K, K, N * N, N * K, N * K, stream)
+        assert rc == 0
 
 
 for _ in range(3):
@@ -94,10 +105,3 @@ for name, m in (("gen1 (id < 256)", ids < 256), ("gen2 (id >= 256)", ids >= 256)
 pairs = [v for v in groups.values() if len(v) == 2]
 print("sample CU pairs (block ids, loop us):", [(p_[0], p_[1], round(float(loop[p_[0]]), 1), round(float(loop[p_[1]]), 1)) for p_ in pairs[:6]])
 
-# phases of one k-step (t = nk/2), wave 0 of every workgroup: durations in ns
-phs = st[:, 8:15].double() * 10.0
-names = ["4 MFMA (+first operand fetch)", "vmcnt wait + LDS stage store", "4 MFMA", "global loads issue", "8 MFMA", "barrier wait"]
-for name, m in (("gen1", ids < 256), ("gen2", ids >= 256)):
-    print(name, "k-step phases (mean ns):", ", ".join(f"{n}: {float((phs[m, i + 1] - phs[m, i]).mean()):.0f}" for i, n in enumerate(names)),
-          f"| total {float((phs[m, 6] - phs[m, 0]).mean()):.0f}",
-          f"| of the second phase, waiting for the tile to land: {float((st[m, 15].double() * 10.0 - phs[m, 1]).mean()):.0f}")

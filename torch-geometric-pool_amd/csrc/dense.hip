@@ -1195,11 +1195,24 @@ static DensePlan dense_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
   const int64_t T = p.tile, TM = p.tile_m;
   const int64_t tiles = ((K + TM - 1) / TM) * (((K + T - 1) / T) + ((F + T - 1) / T));
   const int64_t base = B * (tiles > 0 ? tiles : 1);
-  int64_t splits = (2 * 256 + base - 1) / base;  // aim for ~2 workgroups per CU
+  // Split count: every workgroup of this grid is resident at once (<= 4 per CU), so the launch ends with the
+  // busiest CU.  Cost model: (k-steps per workgroup + ~3 steps of prologue and epilogue) x (time of a k-step with n
+  // co-resident workgroups).
+  // E.g. C2: 192 tiles -> 4 splits = 768 workgroups = exactly 3 per CU (3 splits = 576 leaves a quarter of
+  // the CUs with 3 and the rest with 2).  Slabs cost traffic too, hence the small bias against more splits.
   const int64_t max_splits = (N + 4 * BK - 1) / (4 * BK);  // keep >= 4 k-steps per workgroup
-  if (splits > max_splits) splits = max_splits;
-  if (splits > 32) splits = 32;
-  if (splits < 1) splits = 1;
+  const int64_t cus = 256;
+  int64_t splits = 1;
+  double best = 1e30;
+  for (int64_t sp = 1; sp <= 32 && sp <= (max_splits > 0 ? max_splits : 1); ++sp) {
+    const int64_t wgs = base * sp;
+    const int64_t ksteps = ((N + sp - 1) / sp + BK - 1) / BK;
+    const int64_t per_cu = (wgs + cus - 1) / cus, resident = per_cu < 4 ? per_cu : 4;
+    // measured with the stamps build: a k-step takes ~(0.8 + 0.4 n) us when n workgroups share a CU
+    const double cost = static_cast<double>((per_cu + 3) / 4) * static_cast<double>(ksteps + 3) *
+                        static_cast<double>(2 + resident) * (1.0 + 0.01 * sp);
+    if (cost < best) { best = cost; splits = sp; }
+  }
   int64_t kps = (N + splits - 1) / splits;
   kps = (kps + BK - 1) / BK * BK;
   splits = (N + kps - 1) / kps;
