@@ -413,3 +413,40 @@ def test_dense_src_preprocessing_and_finalize(dev):  # :105-144, 199-256
                                                adj_pool=torch.tensor([[[1.0, 0.5], [0.5, 1.0]]], device=dev),
                                                batch=None, batch_pooled=None, so=so_sp)
     assert bp is None and xo.shape == (2, 2) and eo.shape[0] == 2 and wo.numel() == eo.shape[1]
+
+
+def test_kron_connect_device_solve_matches_scipy_route(dev):
+    """A9 / N4: the dense fp64 Kron reduction on the GPU gives the edge set and weights of the reference's scipy
+    route (connect/kron_conn.py:117-146) - with and without a selector-provided Laplacian, COO in / COO out, a
+    single kept node, and the MIS error path of tests/connect/test_kron_conn.py:230-255."""
+    import warnings
+    from tgp.connect import KronConnect
+    from tgp.select import NDPSelect, SelectOutput
+    x, ei, ew, _ = sparse_graph(dev, n=120, e=500, seed=7)
+    n = x.size(0)
+    dense, host = KronConnect(), KronConnect(dense_solve_max_nodes=0)
+    so_ndp = NDPSelect()(edge_index=ei, edge_weight=ew, num_nodes=n)
+    kept = torch.arange(0, n, 2, device=dev)
+    so_plain = SelectOutput(node_index=kept, cluster_index=torch.arange(kept.numel(), device=dev), num_nodes=n,
+                            num_supernodes=kept.numel())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for so in (so_ndp, so_plain):
+            a1, w1 = dense(edge_index=ei, so=so, edge_weight=ew)
+            a2, w2 = host(edge_index=ei, so=so, edge_weight=ew)
+            assert a1.device.type == "cuda" and torch.equal(a1, a2) and w1.dtype == torch.float32
+            torch.testing.assert_close(w1, w2, rtol=1e-5, atol=1e-6)
+        coo = torch.sparse_coo_tensor(ei, ew, size=(n, n)).coalesce()
+        ac, wc = dense(edge_index=coo, so=so_plain, edge_weight=None)
+        assert ac.is_sparse and wc is None and ac.shape == (kept.numel(), kept.numel())
+        one = SelectOutput(node_index=torch.tensor([3], device=dev), cluster_index=torch.tensor([0], device=dev),
+                           num_nodes=n, num_supernodes=1)
+        a_one, w_one = dense(edge_index=ei, so=one, edge_weight=ew)
+        assert a_one.size(0) == 2 and a_one.size(1) == 0  # the 1x1 "-1" Laplacian leaves no off-diagonal edge
+        lo, _ = KronConnect(sparse_threshold=0.0)(edge_index=ei, so=so_plain, edge_weight=ew)
+        hi, _ = KronConnect(sparse_threshold=10.0)(edge_index=ei, so=so_plain, edge_weight=ew)
+        assert lo.size(1) >= hi.size(1)
+        bad = SelectOutput(num_nodes=3, num_supernodes=2, node_index=torch.arange(3, device=dev),
+                           cluster_index=torch.tensor([0, 0, 1], device=dev), mis=torch.tensor([0, 5], device=dev))
+        with pytest.raises(ValueError, match="MIS indices out of range"):
+            dense(edge_index=torch.tensor([[0, 1, 1, 2], [1, 0, 2, 1]], device=dev), so=bad, edge_weight=None)
