@@ -41,9 +41,7 @@ constexpr int BK = 32;
 #ifndef TGP_SPREAD
 #define TGP_SPREAD 0
 #endif
-#ifndef TGP_ACC_CHAINS
-#define TGP_ACC_CHAINS 1
-#endif
+
 constexpr int LDA_ROWMAJOR = BK + 1;
 
 // One right-hand side / output pair.  A launch may carry two (column tiles >= tiles_n0 use the
@@ -275,14 +273,11 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
     }
   };
 
-  // NC independent accumulator chains per MFMA tile (even / odd k-pairs): with a single chain every MFMA of a
-  // wave waits for the previous one to retire, and the other waves on the SIMD do not fill those gaps.
-  constexpr int NC = (NT == 1) ? TGP_ACC_CHAINS : 1;
-  f32x16 acc[NT], acc_b[NT];
+  f32x16 acc[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; acc_b[j][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int lm = lane & 31, lk = lane >> 5;
   // MODE 1: the residual tile is requested before the first k-step and consumed in the epilogue, so its
@@ -317,12 +312,8 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
   };
   auto mfma_pair = [&](int p) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      if (NC == 2 && (p & 1))
-        acc_b[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_r[p % (PD + 1)], b_r[p % (PD + 1)][j], acc_b[j], 0, 0, 0);
-      else
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_r[p % (PD + 1)], b_r[p % (PD + 1)][j], acc[j], 0, 0, 0);
-    }
+    for (int j = 0; j < NT; ++j)
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_r[p % (PD + 1)], b_r[p % (PD + 1)][j], acc[j], 0, 0, 0);
   };
 
   // Stage schedule.  Per-wave time stamps (tools/gemm_stamps.py) showed that a wave loses most of a k-step not
@@ -400,12 +391,6 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
     if (t + 1 < nk) stage(std::integral_constant<int, 1>{}, t + 1);
   }
   TGP_STAMP(2);
-  if constexpr (NC == 2) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] += acc_b[j][r];
-  }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -----------
   if constexpr (MODE == 1) {
