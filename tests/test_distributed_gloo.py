@@ -61,8 +61,22 @@ def _worker(rank, world, port, out_dir):
         pg = D.PackedGather()
         pg.start([xp[:2], ap[:2]])
         pxp, pap = pg.wait()
+        # bucketed variant: 5 steps, 3 per collective -> one full bucket + one flushed partial bucket; step j
+        # sends (j + 1) * its tensors so that steps cannot be confused
+        pb = D.PackedGather(bucket_steps=3)
+        handed = []
+        for j in range(5):
+            pb.start([xp[:2] * (j + 1), ap[:2] * (j + 1)])
+            r = pb.wait() if j == 3 else None  # the full bucket is in flight from step 2 on
+            if r:
+                handed.extend(r)
+        handed.extend(pb.flush())
+        bucket_ok = len(handed) == 5 and all(
+            torch.allclose(h[0], pxp * (j + 1)) and torch.allclose(h[1], pap * (j + 1)) for j, h in enumerate(handed))
+        assert pb.flush() == [] and pb.wait() is None
         if rank == 0:
-            torch.save(dict(gx=gx, gei=gei, gew=gew, gb=gb, gxp=gxp, gap=gap, pxp=pxp, pap=pap),
+            torch.save(dict(gx=gx, gei=gei, gew=gew, gb=gb, gxp=gxp, gap=gap, pxp=pxp, pap=pap,
+                            bucket_ok=torch.tensor(bucket_ok)),
                        os.path.join(out_dir, "gathered.pt"))
         dist.barrier()
     finally:
@@ -108,3 +122,4 @@ def test_two_rank_gather_matches_single_process(tmp_path):
     # packed gather took graphs [0,1] of rank 0 (global 0,1) and [0,1] of rank 1 (global 3,4)
     torch.testing.assert_close(got["pxp"], O.reduce_dense(s, xd)[[0, 1, 3, 4]], rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(got["pap"], ap_full[[0, 1, 3, 4]], rtol=1e-6, atol=1e-6)
+    assert bool(got["bucket_ok"])  # bucketed gather: five steps, three per collective, order and values kept

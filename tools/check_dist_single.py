@@ -27,5 +27,19 @@ assert torch.equal(buf, x)
 t = torch.tensor([1.5], device=dev, dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 dist.barrier()
+# bucketed, asynchronous PackedGather through RCCL (one rank, collective forced), interleaved with compute
+os.environ["TGP_FORCE_COLLECTIVE"] = "1"
+pg = D.PackedGather(bucket_steps=4)
+got = []
+for j in range(10):
+    y = (torch.full((32, 128, 64), float(j), device=dev), torch.full((32, 128, 128), float(-j), device=dev))
+    pg.start(list(y))
+    torch.mm(torch.randn(512, 512, device=dev), torch.randn(512, 512, device=dev))  # something to overlap with
+    got.extend(pg.take_ready())
+got.extend(pg.flush())
+torch.cuda.synchronize()
+assert len(got) == 10 and all(float(g[0][0, 0, 0]) == j and float(g[1][-1, -1, -1]) == -j for j, g in enumerate(got))
+assert got[3][0].shape == (32, 128, 64) and got[3][1].shape == (32, 128, 128)
+print("bucketed PackedGather over RCCL ok")
 print("rccl collectives ok on", torch.cuda.get_device_name(dev))
 dist.destroy_process_group()
