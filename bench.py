@@ -187,9 +187,13 @@ def run_other_workload(args, dev):
         idx = so.assign_index()
         alg = nnz * (4.0 * f + 8 + 8 + 4) + k * 4.0 * f
         kern_ms = event_time_ms(lambda: kernels.reduce_sparse(x, so.node_index, so.weight, idx), 20, dev)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(f"reduce_sparse_vec4_kernel:{args.workload}")
         roof = {"kernel": "tgp::reduce_sparse_vec4_kernel (gather-sum, index cached)", "bound": "hbm",
                 "achieved": round(alg / (kern_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": round(alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                "frac": round(alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": alg, "avg_launch_ms": round(kern_ms, 4)}
     dt = timed(step, args.steps, args.warmup, lambda: torch.cuda.synchronize(dev), lambda: None)
     cfg = {"workload": name, "nodes_counted": "input nodes per step"}
