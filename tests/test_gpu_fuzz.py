@@ -1,0 +1,170 @@
+"""Seeded randomised differential tests: every native path against the CPU oracle on many small random shapes
+(sizes, alignments, flag combinations, duplicate / self-loop / isolated-node patterns, sorted and unsorted
+edge lists).  Indices must be bit-exact, fp32 within rtol = atol = 1e-5 (north_star)."""
+import itertools
+import random
+
+import pytest
+import torch
+
+import tgp_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def rand_graph(rng, g, n, e, sort_rows, with_loops, with_dups):
+    if e == 0 or n == 0:
+        return torch.zeros(2, 0, dtype=torch.long)
+    r = torch.randint(0, n, (e,), generator=g)
+    c = torch.randint(0, n, (e,), generator=g)
+    if not with_loops:
+        c = torch.where(r == c, (c + 1) % n, c)
+    ei = torch.stack([r, c])
+    if with_dups and e > 4:
+        ei = torch.cat([ei, ei[:, : e // 3]], 1)  # repeated directed entries
+    if sort_rows:  # stable sort by row only: columns stay in insertion order (what PyG loaders hand out)
+        ei = ei[:, torch.sort(ei[0], stable=True)[1]]
+    return ei
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_sparse_connect_fuzz(dev, seed):
+    from tgp.connect import sparse_connect
+    rng = random.Random(seed)
+    g = torch.Generator().manual_seed(1000 + seed)
+    n = rng.choice([1, 2, 7, 33, 150, 1000, 5000])
+    e = rng.choice([0, 1, 5, 40, 700, 20_000])
+    ei = rand_graph(rng, g, n, e, sort_rows=rng.random() < 0.6, with_loops=rng.random() < 0.5, with_dups=rng.random() < 0.5)
+    weighted = rng.random() < 0.7
+    ew = None
+    if weighted:
+        ew = torch.rand(ei.size(1), generator=g) + 0.05
+        ew[torch.rand(ei.size(1), generator=g) < 0.1] = 0.0  # eps filter
+    op = rng.choice(["sum", "mean", "min", "max", "mul"])
+    flags = dict(remove_self_loops=rng.random() < 0.5, degree_norm=rng.random() < 0.4, edge_weight_norm=rng.random() < 0.4)
+    # coalesce branch: every node in some supernode; clusters of very different sizes
+    k = max(1, rng.choice([1, 2, n // 3 + 1, n]))
+    cluster = torch.randint(0, k, (n,), generator=g)
+    if rng.random() < 0.5:  # one hub supernode
+        cluster[torch.rand(n, generator=g) < 0.3] = 0
+    batch_pooled = torch.sort(torch.randint(0, 3, (k,), generator=g))[0]
+    ref_ei, ref_ew = O.sparse_connect(ei, ew, torch.arange(n), cluster, n, k, reduce_op=op, batch_pooled=batch_pooled, **flags)
+    got_ei, got_ew = sparse_connect(ei.to(dev), None if ew is None else ew.to(dev), node_index=torch.arange(n, device=dev),
+                                    cluster_index=cluster.to(dev), num_nodes=n, num_supernodes=k, reduce_op=op,
+                                    batch_pooled=batch_pooled.to(dev), **flags)
+    assert torch.equal(got_ei.cpu(), ref_ei), (seed, "coalesce", op, flags)
+    if ref_ew is None:
+        assert got_ew is None
+    else:
+        torch.testing.assert_close(got_ew.cpu(), ref_ew, **TOL)
+    # subgraph branch: a strict subset of the nodes is kept
+    if n >= 2:
+        kept = torch.sort(torch.randperm(n, generator=g)[: max(1, n // 2)])[0]
+        kk = kept.numel()
+        bp = torch.sort(torch.randint(0, 3, (kk,), generator=g))[0]
+        ref_ei, ref_ew = O.sparse_connect(ei, ew, kept, torch.arange(kk), n, kk, batch_pooled=bp, **flags)
+        got_ei, got_ew = sparse_connect(ei.to(dev), None if ew is None else ew.to(dev), node_index=kept.to(dev),
+                                        cluster_index=torch.arange(kk, device=dev), num_nodes=n, num_supernodes=kk,
+                                        batch_pooled=bp.to(dev), **flags)
+        assert torch.equal(got_ei.cpu(), ref_ei), (seed, "subgraph", flags)
+        if ref_ew is None:
+            assert got_ew is None
+        else:
+            torch.testing.assert_close(got_ew.cpu(), ref_ew, **TOL)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_sparse_reduce_fuzz(dev, seed):
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    rng = random.Random(seed)
+    g = torch.Generator().manual_seed(2000 + seed)
+    n = rng.choice([1, 3, 64, 500, 4000])
+    f = rng.choice([1, 3, 4, 16, 33, 128, 200])
+    x = torch.randn(n, f, generator=g)
+    if rng.random() < 0.5:   # one-over-K style: every node assigned, clusters of any size
+        k = max(1, rng.choice([1, n // 4 + 1, n]))
+        ci = torch.randint(0, k, (n,), generator=g)
+        ni = torch.arange(n)
+    else:                    # TopK style: a subset of nodes, one per supernode, arbitrary supernode order
+        k = max(1, n // 2)
+        ni = torch.sort(torch.randperm(n, generator=g)[:k])[0]
+        ci = torch.randperm(k, generator=g)
+    w = torch.randn(ni.numel(), generator=g)
+    # graph ids: members of one supernode share a graph (scatter_ with disagreeing duplicates is order-dependent
+    # in torch itself), so graphs are assigned per supernode and handed down to the nodes
+    graph_of_cluster = torch.randint(0, 3, (k,), generator=g)
+    batch = torch.zeros(n, dtype=torch.long)
+    batch[ni] = graph_of_cluster[ci]
+    so = SelectOutput(node_index=ni.to(dev), cluster_index=ci.to(dev), num_nodes=n, num_supernodes=k, weight=w.to(dev))
+    xp, bp = BaseReduce()(x.to(dev), so, batch=batch.to(dev))
+    # ordering of the COO entries inside SelectOutput is node-sorted; the oracle takes the same views
+    ref = O.reduce_sparse(x, so.node_index.cpu(), so.cluster_index.cpu(), so.weight.cpu(), k)
+    assert torch.equal(xp.cpu(), ref), seed  # same summation order as the sequential CPU scatter: bit-identical
+    assert torch.equal(bp.cpu(), O.reduce_batch_sparse(batch, so.node_index.cpu(), so.cluster_index.cpu(), k))
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_dense_pool_fuzz(dev, seed):
+    from tgp.connect import DenseConnect
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    rng = random.Random(seed)
+    g = torch.Generator().manual_seed(3000 + seed)
+    B = rng.choice([1, 2, 5, 70])
+    N = rng.choice([1, 5, 31, 60, 64, 100, 257]) if B < 70 else rng.choice([8, 40, 60, 64])
+    K = rng.choice([1, 3, 8, 20, 32, 33, 70])
+    F = rng.choice([1, 4, 7, 32, 65])
+    adj = (torch.rand(B, N, N, generator=g) < 0.3).float() * torch.rand(B, N, N, generator=g)
+    x = torch.randn(B, N, F, generator=g)
+    s = torch.softmax(torch.randn(B, N, K, generator=g), -1)
+    if rng.random() < 0.5:  # padded graphs
+        nb = torch.randint(1, N + 1, (B,), generator=g)
+        mask = torch.arange(N).unsqueeze(0) < nb.unsqueeze(1)
+        s, x = s * mask.unsqueeze(-1), x * mask.unsqueeze(-1)
+        adj = adj * mask.unsqueeze(1) * mask.unsqueeze(2)
+    flags = [rng.random() < 0.5 for _ in range(4)]  # remove_self_loops, degree_norm, adj_transpose, edge_weight_norm
+    so = SelectOutput(s=s.to(dev))
+    xp, _ = BaseReduce()(x.to(dev), so)
+    torch.testing.assert_close(xp.cpu(), O.reduce_dense(s, x), **TOL)
+    conn = DenseConnect(*flags)
+    raw_ref = O.dense_connect(s, adj)
+    torch.testing.assert_close(conn.dense_connect(adj=adj.to(dev), s=s.to(dev)).cpu(), raw_ref, **TOL)
+    out, _ = conn(adj.to(dev), so)
+    torch.testing.assert_close(out.cpu(), O.postprocess_dense(raw_ref.clone(), *flags), **TOL)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_densify_and_block_diag_fuzz(dev, seed):
+    from tgp.src import to_dense_adj, to_dense_batch
+    from tgp.utils.ops import dense_to_block_diag
+    rng = random.Random(seed)
+    g = torch.Generator().manual_seed(4000 + seed)
+    sizes = [rng.choice([1, 2, 9, 30]) for _ in range(rng.choice([1, 2, 5]))]
+    n = sum(sizes)
+    batch = torch.cat([torch.full((m,), i, dtype=torch.long) for i, m in enumerate(sizes)])
+    off = 0
+    eis = []
+    for m in sizes:
+        e = rng.choice([0, 3, 40])
+        eis.append(rand_graph(rng, g, m, e, sort_rows=False, with_loops=True, with_dups=True) + off)
+        off += m
+    ei = torch.cat(eis, 1)
+    ew = torch.rand(ei.size(1), generator=g)
+    x = torch.randn(n, 5, generator=g)
+    xd_ref, mask_ref = O.to_dense_batch(x, batch)
+    xd, mask = to_dense_batch(x.to(dev), batch.to(dev))
+    assert torch.equal(xd.cpu(), xd_ref) and torch.equal(mask.cpu(), mask_ref)
+    ad_ref = O.to_dense_adj(ei, ew, batch)
+    torch.testing.assert_close(to_dense_adj(ei.to(dev), batch.to(dev), ew.to(dev)).cpu(), ad_ref, **TOL)
+    k = rng.choice([1, 4, 9])
+    pooled = (torch.rand(len(sizes), k, k, generator=g) < 0.5).float() * torch.randn(len(sizes), k, k, generator=g)
+    ref_ei, ref_ew = O.dense_to_block_diag(pooled)
+    got_ei, got_ew = dense_to_block_diag(pooled.to(dev))
+    assert torch.equal(got_ei.cpu(), ref_ei) and torch.equal(got_ew.cpu(), ref_ew)
