@@ -168,3 +168,112 @@ def test_densify_and_block_diag_fuzz(dev, seed):
     ref_ei, ref_ew = O.dense_to_block_diag(pooled)
     got_ei, got_ew = dense_to_block_diag(pooled.to(dev))
     assert torch.equal(got_ei.cpu(), ref_ei) and torch.equal(got_ew.cpu(), ref_ew)
+
+
+def rand_batch(rng, g, feat):
+    """A PyG-style batch of small random undirected graphs (row-sorted, no duplicates), positive weights."""
+    sizes = [rng.choice([3, 7, 12, 25]) for _ in range(rng.choice([1, 2, 4]))]
+    xs, eis, ews, bs, off = [], [], [], [], 0
+    for gi, m in enumerate(sizes):
+        a = torch.triu(torch.rand(m, m, generator=g) < rng.choice([0.15, 0.4, 0.8]), 1)
+        a = a | a.t()
+        ei = a.nonzero().t() + off
+        w = torch.rand(m, m, generator=g)
+        w = (w + w.t())[a] + 0.1
+        eis.append(ei)
+        ews.append(w)
+        xs.append(torch.randn(m, feat, generator=g))
+        bs.append(torch.full((m,), gi, dtype=torch.long))
+        off += m
+    return torch.cat(xs), torch.cat(eis, 1), torch.cat(ews), torch.cat(bs)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_topk_and_cluster_poolers_end_to_end_fuzz(dev, seed):
+    """get_pooler("topk") and the Graclus-style reduce/connect pipeline on random batches == oracle pooler functions
+    (poolers/topk.py:120-190, poolers/graclus.py:91-156) including batch vectors and every Connect flag."""
+    from tgp.connect import SparseConnect
+    from tgp.poolers import get_pooler
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    rng = random.Random(seed)
+    g = torch.Generator().manual_seed(5000 + seed)
+    feat = rng.choice([1, 4, 9])
+    x, ei, ew, batch = rand_batch(rng, g, feat)
+    use_w = rng.random() < 0.7
+    cfg = dict(ratio=rng.choice([0.3, 0.5, 0.9, 2]), remove_self_loops=rng.random() < 0.7,
+               degree_norm=rng.random() < 0.4, edge_weight_norm=rng.random() < 0.4,
+               connect_red_op=rng.choice(["sum", "mean", "max"]))
+    torch.manual_seed(seed)
+    pooler = get_pooler("topk", in_channels=feat, **cfg).to(dev).eval()
+    p = pooler.selector.weight.detach().cpu() if feat > 1 else None
+    with torch.no_grad():
+        out = pooler(x=x.to(dev), adj=ei.to(dev), edge_weight=ew.to(dev) if use_w else None, batch=batch.to(dev))
+    ref = O.topk_pool(x, ei, ew if use_w else None, batch, p, ratio=cfg["ratio"], remove_self_loops=cfg["remove_self_loops"],
+                      degree_norm=cfg["degree_norm"], edge_weight_norm=cfg["edge_weight_norm"], reduce_op=cfg["connect_red_op"])
+    assert torch.equal(out.so.node_index.cpu(), ref["node_index"]) and torch.equal(out.so.cluster_index.cpu(), ref["cluster_index"])
+    torch.testing.assert_close(out.x.cpu(), ref["x"], **TOL)
+    assert torch.equal(out.edge_index.cpu(), ref["edge_index"]) and torch.equal(out.batch.cpu(), ref["batch"])
+    if ref["edge_weight"] is None:
+        assert out.edge_weight is None
+    else:
+        torch.testing.assert_close(out.edge_weight.cpu(), ref["edge_weight"], **TOL)
+    # cluster pipeline: the oracle's greedy matching as the selector output
+    cluster = O.greedy_matching(ei, ew if use_w else None, x.size(0))
+    k = int(cluster.max()) + 1
+    so = SelectOutput(cluster_index=cluster.to(dev), num_nodes=x.size(0), num_supernodes=k)
+    xp, bp = BaseReduce()(x.to(dev), so, batch=batch.to(dev))
+    conn = SparseConnect(reduce_op=cfg["connect_red_op"], remove_self_loops=cfg["remove_self_loops"],
+                         degree_norm=cfg["degree_norm"], edge_weight_norm=cfg["edge_weight_norm"])
+    ce, cw = conn(ei.to(dev), so, edge_weight=ew.to(dev) if use_w else None, batch_pooled=bp)
+    refc = O.cluster_pool(x, ei, ew if use_w else None, batch, cluster, k, reduce_op=cfg["connect_red_op"],
+                          remove_self_loops=cfg["remove_self_loops"], degree_norm=cfg["degree_norm"],
+                          edge_weight_norm=cfg["edge_weight_norm"])
+    assert torch.equal(xp.cpu(), refc["x"]) and torch.equal(bp.cpu(), refc["batch"]) and torch.equal(ce.cpu(), refc["edge_index"])
+    if refc["edge_weight"] is None:
+        assert cw is None
+    else:
+        torch.testing.assert_close(cw.cpu(), refc["edge_weight"], **TOL)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_dense_poolers_end_to_end_fuzz(dev, seed):
+    """get_pooler("diff" | "mincut" [+ "_u"]) from sparse inputs on random batches == the oracle's dense_pool
+    (poolers/diffpool.py:145-260, poolers/mincut.py:150-289): assignments, pooled features, adjacency in every
+    output format, losses."""
+    from tgp.poolers import get_pooler
+    rng = random.Random(seed)
+    g = torch.Generator().manual_seed(6000 + seed)
+    feat, k = rng.choice([3, 8]), rng.choice([2, 5])
+    x, ei, ew, batch = rand_batch(rng, g, feat)
+    alias = rng.choice(["diff", "mincut"])
+    batched = rng.random() < 0.5
+    cfg = dict(remove_self_loops=rng.random() < 0.7, degree_norm=rng.random() < 0.6, edge_weight_norm=rng.random() < 0.4,
+               adj_transpose=rng.random() < 0.6, sparse_output=rng.random() < 0.5)
+    if alias == "diff":
+        cfg["normalize_loss"] = rng.random() < 0.5
+    torch.manual_seed(seed)
+    pooler = get_pooler(alias if batched else alias + "_u", in_channels=feat, k=k, **cfg).to(dev).eval()
+    sd = pooler.state_dict()
+    weights = [sd[n].cpu() for n in sd if n.endswith("weight")]
+    biases = [sd[n].cpu() for n in sd if n.endswith("bias")]
+    with torch.no_grad():
+        out = pooler(x=x.to(dev), adj=ei.to(dev), edge_weight=ew.to(dev), batch=batch.to(dev))
+    ref = O.dense_pool(alias, x, ei, ew, batch, weights, biases, batched=batched,
+                       remove_self_loops=cfg["remove_self_loops"], degree_norm=cfg["degree_norm"],
+                       edge_weight_norm=cfg["edge_weight_norm"], adj_transpose=cfg["adj_transpose"],
+                       sparse_output=cfg["sparse_output"], normalize_loss=cfg.get("normalize_loss", False))
+    torch.testing.assert_close(out.so.s.cpu(), ref["s"], **TOL)
+    torch.testing.assert_close(out.x.cpu(), ref["x"], **TOL)
+    if ref["edge_weight"] is not None:   # [2, E'] output: same edges, same order
+        assert torch.equal(out.edge_index.cpu(), ref["edge_index"]), (alias, batched, cfg)
+        torch.testing.assert_close(out.edge_weight.cpu(), ref["edge_weight"], **TOL)
+    else:
+        torch.testing.assert_close(out.edge_index.cpu(), ref["edge_index"], **TOL)
+    if ref["batch"] is None:
+        assert out.batch is None
+    else:
+        assert torch.equal(out.batch.cpu(), ref["batch"])
+    assert set(out.loss) == set(ref["loss"])
+    for key in ref["loss"]:
+        torch.testing.assert_close(out.loss[key].cpu(), ref["loss"][key], **TOL)
