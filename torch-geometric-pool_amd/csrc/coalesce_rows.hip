@@ -496,6 +496,10 @@ __global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict_
 }
 
 // ------------------------------------------------------------------ K7: one wave per 64 rows, lane per row
+#ifndef TGP_FILL_LANES
+#define TGP_FILL_LANES 16
+#endif
+constexpr int FILL_LANES = TGP_FILL_LANES;
 __global__ __launch_bounds__(256) void cr_fill_kernel(const uint32_t* __restrict__ tmp_c,
                                                       const float* __restrict__ tmp_w,
                                                       const uint32_t* __restrict__ raw_off,
@@ -503,12 +507,12 @@ __global__ __launch_bounds__(256) void cr_fill_kernel(const uint32_t* __restrict
                                                       const uint32_t* __restrict__ out_off, int64_t K,
                                                       int64_t* __restrict__ out_row, int64_t* __restrict__ out_col,
                                                       float* __restrict__ out_w) {
-  // a group of 8 lanes copies one row (rows hold ~E'/K entries): consecutive lanes -> consecutive outputs
-  const int64_t g = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 3;
-  const int l = threadIdx.x & 7;
+  // a group of FILL_LANES lanes copies one row (rows hold ~E'/K entries): consecutive lanes -> consecutive outputs
+  const int64_t g = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) / FILL_LANES;
+  const int l = threadIdx.x % FILL_LANES;
   if (g >= K) return;
   const uint32_t n = n_out[g], src = raw_off[g], dst = out_off[g];
-  for (uint32_t i = l; i < n; i += 8) {
+  for (uint32_t i = l; i < n; i += FILL_LANES) {
     out_row[dst + i] = g;
     out_col[dst + i] = tmp_c[src + i];
     if (out_w) out_w[dst + i] = tmp_w[src + i];
@@ -619,7 +623,7 @@ extern "C" int tgp_connect_coalesce_rows_fill(const void* ws, int64_t E, int64_t
               "tgp_connect_coalesce_rows_fill: null output");
   CrWs s;
   cr_layout(const_cast<void*>(ws), E, N, K, &s);
-  hipLaunchKernelGGL(cr_fill_kernel, dim3(cdiv(K * 8, 256)), dim3(256), 0, stream, s.tmp_c,
+  hipLaunchKernelGGL(cr_fill_kernel, dim3(cdiv(K * FILL_LANES, 256)), dim3(256), 0, stream, s.tmp_c,
                      has_weight ? s.tmp_w : nullptr, s.raw_off, s.n_out, s.out_off, K, out_row, out_col,
                      has_weight ? out_w : nullptr);
   return check_launch("tgp_connect_coalesce_rows_fill");
