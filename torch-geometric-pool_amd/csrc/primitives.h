@@ -148,6 +148,9 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
   __shared__ uint32_t s_base[BINS];
   __shared__ uint32_t s_whist[4][BINS];
   __shared__ uint32_t s_scan[4];
+  __shared__ uint32_t s_toff[BINS];          // first tile-local slot of every digit
+  __shared__ KeyT s_key[kSortTile];          // the tile, reordered by digit, before it goes out
+  __shared__ ValT s_val[kSortTile];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
   {  // first output slot of every digit = exclusive prefix of the digit totals (every workgroup redoes this tiny
@@ -220,13 +223,36 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
       }
       tot[q] = run;
     }
+    {  // tile-local exclusive offsets of the digits
+      uint32_t sum = 0;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) sum += tot[q];
+      // digits are dealt out as d = tid + q * 256, so a plain scan over threads is only digit order for PER == 1
+      static_assert(PER == 1, "LDS-staged scatter assumes 8-bit digits (one digit per thread)");
+      s_toff[tid] = block_excl_scan_256(sum, s_scan, nullptr);
+    }
     __syncthreads();
+    // stage the tile in LDS in digit order (stable: wave order, then rank inside the wave) ...
 #pragma unroll
     for (int it = 0; it < kSortItems; ++it) {
       if (dg[it] < BINS) {
-        const uint32_t pos = s_base[dg[it]] + s_whist[w][dg[it]] + r[it];
-        keys_out[pos] = k[it];
-        vals_out[pos] = v[it];
+        const uint32_t lpos = s_toff[dg[it]] + s_whist[w][dg[it]] + r[it];
+        s_key[lpos] = k[it];
+        s_val[lpos] = v[it];
+      }
+    }
+    __syncthreads();
+    // ... and write it out so that consecutive threads write consecutive addresses inside every digit's run
+    const int ntile = static_cast<int>(end - tile < kSortTile ? end - tile : kSortTile);
+#pragma unroll
+    for (int it = 0; it < kSortItems; ++it) {
+      const int i = it * kSortThreads + tid;
+      if (i < ntile) {
+        const KeyT kk = s_key[i];
+        const uint32_t d = static_cast<uint32_t>(kk >> shift) & (BINS - 1);
+        const uint32_t pos = s_base[d] + (static_cast<uint32_t>(i) - s_toff[d]);
+        keys_out[pos] = kk;
+        vals_out[pos] = s_val[i];
       }
     }
     __syncthreads();
@@ -290,8 +316,8 @@ int radix_sort_pairs(KeyT* k0, ValT* v0, KeyT* k1, ValT* v1, int64_t n, int key_
   KeyT *ki = k0, *ko = k1;
   ValT *vi = v0, *vo = v1;
   for (int pass = 0; pass < passes; ++pass) {
-    if (db == 11) radix_pass<KeyT, ValT, 11>(ki, vi, ko, vo, n, pass * 11, p, hist, digit_total, stream);
-    else radix_pass<KeyT, ValT, 8>(ki, vi, ko, vo, n, pass * 8, p, hist, digit_total, stream);
+    (void)db;  // 8-bit digits only (11-bit digits measured slower, see sort_digit_bits)
+    radix_pass<KeyT, ValT, 8>(ki, vi, ko, vo, n, pass * 8, p, hist, digit_total, stream);
     KeyT* tk = ki; ki = ko; ko = tk;
     ValT* tv = vi; vi = vo; vo = tv;
   }
