@@ -129,6 +129,17 @@ int tgp_connect_coalesce_rows_fill(const void* ws, int64_t num_edges, int64_t nu
                                    int has_weight, int64_t num_out, int64_t* out_row, int64_t* out_col,
                                    float* out_weight, void* stream);
 
+/* A4 for edge lists in ANY order, two-level: a stable radix sort by supernode row only (log2 K bits instead of the
+ * 2 log2 K bits of the (row, col) key above) carrying (cluster column, weight) as payload, then the same in-row
+ * sort / merge as the row-sorted path.  Same output as the other two pairs.  *d_count = -1 if a supernode row
+ * exceeds the in-LDS sort (1024 raw entries): use tgp_connect_coalesce_{count,fill} then.  The fill half is
+ * tgp_connect_coalesce_rows_fill with this workspace. */
+size_t tgp_connect_coalesce_grouped_workspace_bytes(int64_t num_edges, int64_t num_nodes, int64_t num_supernodes);
+int tgp_connect_coalesce_grouped_count(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
+                                       int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,
+                                       int64_t num_supernodes, int reduce_op, int flags, void* ws, size_t ws_bytes,
+                                       int64_t* d_count, void* stream);
+
 /* A6 (rest)  degree / per-graph max normalisation of a pooled edge list, in place
  * (utils/ops.py:383-417).  edge_weight must be initialised (ones when the list was
  * unweighted, ops.py:384-385).  ws: tgp_postprocess_sparse_workspace_bytes().           */

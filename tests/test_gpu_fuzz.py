@@ -277,3 +277,32 @@ def test_dense_poolers_end_to_end_fuzz(dev, seed):
     assert set(out.loss) == set(ref["loss"])
     for key in ref["loss"]:
         torch.testing.assert_close(out.loss[key].cpu(), ref["loss"][key], **TOL)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_grouped_coalesce_path_vs_oracle(dev, seed):
+    """Unsorted edge lists with more than 65536 supernodes take the two-level path (radix sort by supernode row +
+    in-row LDS sort); a hub supernode whose row exceeds the LDS sort makes it decline to the general path.  Both
+    must equal the oracle (connect/base_conn.py:83-89 + utils/ops.py:338-419)."""
+    from tgp.connect import sparse_connect
+    rng = random.Random(seed)
+    g = torch.Generator().manual_seed(7000 + seed)
+    n, k = 180_000, rng.choice([70_000, 100_000, 180_000])
+    e = 300_000
+    ei = rand_graph(rng, g, n, e, sort_rows=False, with_loops=True, with_dups=True)
+    ew = (torch.rand(ei.size(1), generator=g) + 0.05) if rng.random() < 0.7 else None
+    if ew is not None:
+        ew[torch.rand(ei.size(1), generator=g) < 0.05] = 0.0
+    cluster = torch.randint(0, k, (n,), generator=g)
+    if seed % 3 == 2:  # hub: one supernode row with far more than 1024 raw entries
+        cluster[: n // 20] = 7
+    op = rng.choice(["sum", "mean", "min", "max", "mul"])
+    flags = dict(remove_self_loops=rng.random() < 0.5, degree_norm=rng.random() < 0.3)
+    ref_ei, ref_ew = O.sparse_connect(ei, ew, torch.arange(n), cluster, n, k, reduce_op=op, **flags)
+    got_ei, got_ew = sparse_connect(ei.to(dev), None if ew is None else ew.to(dev), node_index=torch.arange(n, device=dev),
+                                    cluster_index=cluster.to(dev), num_nodes=n, num_supernodes=k, reduce_op=op, **flags)
+    assert torch.equal(got_ei.cpu(), ref_ei), (seed, op, flags)
+    if ref_ew is None:
+        assert got_ew is None
+    else:
+        torch.testing.assert_close(got_ew.cpu(), ref_ew, **TOL)

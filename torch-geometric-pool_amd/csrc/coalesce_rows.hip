@@ -203,10 +203,15 @@ constexpr int GS_ROWS = 32;
 constexpr int GS_CAP = 1024;   // raw entries staged per pass (>= CR_LONG)
 constexpr int GS_MEM = 512;    // members per pass
 
+// DIRECT = false: rows are assembled from the members' edge ranges (row-sorted input, above).
+// DIRECT = true : `grouped` already holds the (cluster column | weight bits << 32) entries in supernode-row order
+//                 (the output of the 3-pass radix sort by supernode row, below); slot t of a row is grouped[...+t].
+template <bool DIRECT>
 __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
     const int64_t* __restrict__ col, const float* __restrict__ w, int64_t E, const int32_t* __restrict__ table,
     const int32_t* __restrict__ a_row_ptr, const uint32_t* __restrict__ seg_src, const uint32_t* __restrict__ seg_dst,
-    const uint32_t* __restrict__ raw_off, int64_t K, int reduce_op, int flags,
+    const unsigned long long* __restrict__ grouped, const uint32_t* __restrict__ raw_off, int64_t K, int reduce_op,
+    int flags,
     int* __restrict__ bad, uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w, uint32_t* __restrict__ n_out) {
   __shared__ uint32_t s_key[GS_CAP];
   __shared__ float s_val[GS_CAP];
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
   const int nrows = static_cast<int>(K - r0 < GS_ROWS ? K - r0 : GS_ROWS);
   if (tid <= nrows) {
     s_roff[tid] = r0 + tid < K ? raw_off[r0 + tid] : static_cast<uint32_t>(E);
-    s_rp[tid] = a_row_ptr[r0 + tid];
+    s_rp[tid] = DIRECT ? 0 : a_row_ptr[r0 + tid];
   }
   __syncthreads();
   const bool has_w = tmp_w != nullptr;
@@ -231,12 +236,23 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
       if (tid == 0) *bad = 3;
       return;
     }
+    if (s_roff[rs + 1] - s_roff[rs] > static_cast<uint32_t>(CR_LONG)) {  // a supernode row too long for the LDS sort
+      if (tid == 0) *bad = 2;
+      return;
+    }
     int re = rs + 1;
     while (re < nrows && s_roff[re + 1] - s_roff[rs] <= static_cast<uint32_t>(GS_CAP) && s_rp[re + 1] - s_rp[rs] <= GS_MEM) ++re;
     const uint32_t base = s_roff[rs];
     const int cnt = static_cast<int>(s_roff[re] - base);
     const int p_lo = s_rp[rs], M = s_rp[re] - p_lo;
     if (tid == 0) s_nmid = 0;
+    if constexpr (DIRECT) {
+      for (int t = tid; t < cnt; t += 256) {
+        const unsigned long long v = grouped[base + t];
+        s_key[t] = static_cast<uint32_t>(v);
+        s_val[t] = __uint_as_float(static_cast<uint32_t>(v >> 32));
+      }
+    } else {
     // (a) members -> (first edge, first slot)
     for (int m = tid; m < M; m += 256) {
       s_seg_src[m] = seg_src[p_lo + m];
@@ -276,6 +292,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
           s_val[t] = wv[u];
         }
       }
+    }
     }
     __syncthreads();
     // (c1) rows of <= 32 entries: one half-wave each
@@ -604,13 +621,113 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
   device_scan_u32(s.T, K, s.raw_off, s.total, s.scan_scratch, stream);
   hipLaunchKernelGGL(cr_segments_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, assign_perm, N, s.table, s.node_ptr,
                      s.member_off, s.raw_off, s.bad, s.seg_src, s.seg_dst);
-  hipLaunchKernelGGL(cr_gather_sort_kernel, dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, col, w, E, s.table,
-                     assign_row_ptr, s.seg_src, s.seg_dst, s.raw_off, K, reduce_op, flags, s.bad, s.tmp_c, tmp_w,
-                     s.n_out);
+  hipLaunchKernelGGL(cr_gather_sort_kernel<false>, dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, col, w, E, s.table,
+                     assign_row_ptr, s.seg_src, s.seg_dst, static_cast<const unsigned long long*>(nullptr), s.raw_off, K,
+                     reduce_op, flags, s.bad, s.tmp_c, tmp_w, s.n_out);
   hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
                      reduce_op, flags, s.bad, s.n_out);
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);
   return check_launch("tgp_connect_coalesce_rows_count");
+}
+
+// ------------------------------------------------------------------ grouped path (any edge order)
+// Two-level sort for inputs whose rows are NOT sorted: a stable LSD radix sort by SUPERNODE ROW only (log2 K bits:
+// 3 passes for K = 550 000, where the (row, col) key of the general path needs 5), carrying (cluster column,
+// weight) as one 64-bit payload, then the in-row sort / merge of the row-local path above.  Stable => duplicates
+// keep their input order, so the result equals the other two paths bit for bit.
+namespace tgp {
+__global__ __launch_bounds__(256) void cg_keys_kernel(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                                                      const float* __restrict__ w, const int32_t* __restrict__ table,
+                                                      int64_t E, uint32_t* __restrict__ keys,
+                                                      unsigned long long* __restrict__ vals) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= E) return;
+  keys[e] = static_cast<uint32_t>(table[row[e]]);
+  vals[e] = static_cast<unsigned long long>(static_cast<uint32_t>(table[col[e]])) |
+            (static_cast<unsigned long long>(__float_as_uint(w ? w[e] : 1.0f)) << 32);
+}
+
+// first slot of every supernode row from the sorted keys (rows without edges get the next row's slot)
+__global__ __launch_bounds__(256) void cg_row_off_kernel(const uint32_t* __restrict__ keys, int64_t E, int64_t K,
+                                                         uint32_t* __restrict__ raw_off) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (p > E) return;
+  if (p == E) {
+    for (int64_t c = E > 0 ? static_cast<int64_t>(keys[E - 1]) + 1 : 0; c < K; ++c) raw_off[c] = static_cast<uint32_t>(E);
+    return;
+  }
+  const int64_t cur = keys[p], prev = p > 0 ? static_cast<int64_t>(keys[p - 1]) : -1;
+  for (int64_t c = prev + 1; c <= cur; ++c) raw_off[c] = static_cast<uint32_t>(p);
+}
+
+struct CgWs {
+  uint32_t *k0, *k1;
+  unsigned long long *v0, *v1;
+  uint32_t* scratch;
+};
+static size_t cg_layout(void* ws, int64_t E, int64_t N, int64_t K, CrWs* cr, CgWs* cg) {
+  const size_t head = cr_layout(ws, E, N, K, cr);  // same prefix as the row-local path: its fill entry is reused
+  Carver cv(ws);
+  cv.off = align_up(head);
+  const size_t e = static_cast<size_t>(E > 0 ? E : 1);
+  CgWs g;
+  g.v0 = cv.take<unsigned long long>(e);
+  g.v1 = cv.take<unsigned long long>(e);
+  g.k0 = cv.take<uint32_t>(e);
+  g.k1 = cv.take<uint32_t>(e);
+  g.scratch = cv.take<uint32_t>(sort_scratch_words());
+  if (cg) *cg = g;
+  return cv.off;
+}
+}  // namespace tgp
+
+extern "C" size_t tgp_connect_coalesce_grouped_workspace_bytes(int64_t E, int64_t N, int64_t K) {
+  return cg_layout(nullptr, E, N, K, nullptr, nullptr) + 256;
+}
+
+// Counting half; the fill half is tgp_connect_coalesce_rows_fill with the same workspace.
+extern "C" int tgp_connect_coalesce_grouped_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                                  const int64_t* cluster_index, int64_t N, int64_t K, int reduce_op,
+                                                  int flags, void* ws, size_t ws_bytes, int64_t* d_count,
+                                                  void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && d_count, TGP_ERR_INVALID, "tgp_connect_coalesce_grouped_count: bad argument");
+  TGP_REQUIRE(E == 0 || (row && col && cluster_index), TGP_ERR_INVALID,
+              "tgp_connect_coalesce_grouped_count: null pointer");
+  TGP_REQUIRE(reduce_op >= TGP_SUM && reduce_op <= TGP_MUL, TGP_ERR_INVALID,
+              "tgp_connect_coalesce_grouped_count: unknown reduce_op %d", reduce_op);
+  TGP_REQUIRE(E < (1ll << 31) && K < (1ll << 26) && N < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_connect_coalesce_grouped_count: E/N >= 2^31 or K >= 2^26");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_connect_coalesce_grouped_workspace_bytes(E, N, K), TGP_ERR_WORKSPACE,
+              "tgp_connect_coalesce_grouped_count: workspace too small");
+  if (E == 0 || K == 0) {
+    (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
+    return check_launch("tgp_connect_coalesce_grouped_count");
+  }
+  CrWs s;
+  CgWs g;
+  cg_layout(ws, E, N, K, &s, &g);
+  float* tmp_w = w ? s.tmp_w : nullptr;
+  (void)hipMemsetAsync(s.bad, 0, sizeof(int), stream);
+  hipLaunchKernelGGL(cr_table_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, cluster_index, N, s.table);
+  hipLaunchKernelGGL(cg_keys_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, s.table, E, g.k0, g.v0);
+  bool first = true;
+  const int rc = radix_sort_pairs<uint32_t, unsigned long long>(g.k0, g.v0, g.k1, g.v1, E,
+                                                                bits_for(static_cast<uint64_t>(K - 1)), g.scratch,
+                                                                stream, &first);
+  if (rc != TGP_OK) return rc;
+  const uint32_t* keys = first ? g.k0 : g.k1;
+  const unsigned long long* vals = first ? g.v0 : g.v1;
+  hipLaunchKernelGGL(cg_row_off_kernel, dim3(cdiv(E + 1, 256)), dim3(256), 0, stream, keys, E, K, s.raw_off);
+  hipLaunchKernelGGL(cr_gather_sort_kernel<true>, dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream,
+                     static_cast<const int64_t*>(nullptr), static_cast<const float*>(nullptr), E,
+                     static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr),
+                     static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), vals, s.raw_off, K,
+                     reduce_op, flags, s.bad, s.tmp_c, tmp_w, s.n_out);
+  hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
+                     reduce_op, flags, s.bad, s.n_out);
+  device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);
+  return check_launch("tgp_connect_coalesce_grouped_count");
 }
 
 extern "C" int tgp_connect_coalesce_rows_fill(const void* ws, int64_t E, int64_t N, int64_t K, int has_weight,

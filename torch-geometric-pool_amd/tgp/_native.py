@@ -55,6 +55,9 @@ SIGNATURES = {
                                                  _c_int, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_connect_coalesce_rows_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_p, _c_p, _c_p,
                                                 _c_p]),
+    "tgp_connect_coalesce_grouped_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "tgp_connect_coalesce_grouped_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_int,
+                                                    _c_p, _c_sz, _c_p, _c_p]),
     "tgp_postprocess_sparse_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tgp_postprocess_sparse_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64,
                                                  _c_p, _c_sz, _c_p]),

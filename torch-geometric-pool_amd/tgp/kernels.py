@@ -148,6 +148,25 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
                     "tgp_connect_coalesce_rows_fill")
             return out_ei, out_w
         del ws  # declined: fall through to the sort-based path
+    if 65536 < num_supernodes < (1 << 26):
+        # more than 32 bits of (row, col) key: sort by supernode row only (half the radix passes) and order the short
+        # rows in LDS; declines (count = -1) when a supernode row is too long for that
+        ws = N.workspace(L.tgp_connect_coalesce_grouped_workspace_bytes(E, cl.numel(), num_supernodes), dev)
+        d_count = torch.empty(1, dtype=torch.int64, device=dev)
+        st = N.stream_ptr(dev)
+        N.check(L.tgp_connect_coalesce_grouped_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
+                                                     num_supernodes, N.REDUCE_OPS[reduce_op], flags, N.ptr(ws),
+                                                     ws.numel(), N.ptr(d_count), st), "tgp_connect_coalesce_grouped_count")
+        n_out = _read_count(d_count)
+        if n_out >= 0:
+            out_ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
+            out_w = None if w is None else torch.empty(n_out, dtype=torch.float32, device=dev)
+            N.check(L.tgp_connect_coalesce_rows_fill(N.ptr(ws), E, cl.numel(), num_supernodes, 0 if w is None else 1,
+                                                     n_out, N.ptr(out_ei[0]) if n_out else None,
+                                                     N.ptr(out_ei[1]) if n_out else None, N.ptr(out_w), st),
+                    "tgp_connect_coalesce_rows_fill")
+            return out_ei, out_w
+        del ws
     ws = N.workspace(L.tgp_connect_coalesce_workspace_bytes(E, cl.numel(), num_supernodes), dev)
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
     st = N.stream_ptr(dev)
