@@ -1,8 +1,8 @@
-"""Diagnostic: phase times inside cr_gather_sort_kernel (needs a -DTGP_GS_STAMPS build as lib/libtgp_gs.so)."""
+"""Diagnostic: phase times inside cr_gather_sort_kernel (needs `make -C torch-geometric-pool_amd/csrc stamps`)."""
 import ctypes, os, sys
 import torch
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-os.environ["TGP_HIP_LIB"] = os.path.join(ROOT, "torch-geometric-pool_amd", "lib", "libtgp_gs.so")
+os.environ["TGP_HIP_LIB"] = os.path.join(ROOT, "torch-geometric-pool_amd", "lib", "libtgp_hip_stamps.so")
 sys.path.insert(0, os.path.join(ROOT, "torch-geometric-pool_amd"))
 from tgp import _native, kernels
 from tgp.select import GraclusSelect

@@ -199,6 +199,19 @@ __device__ __forceinline__ float cr_reduce(float acc, float v, int op) {
 //       compacted at tmp[raw_off[r] ...] with their count in n_out[r].
 // Every dependent-load level (row offsets -> members -> node ranges -> edges -> table) is one block-wide,
 // coalesced-as-possible request, so the latency chain is paid once per ~1000 edges instead of once per row.
+#ifdef TGP_GEMM_STAMPS  // diagnostic build only (make stamps): time per phase of cr_gather_sort_kernel, per workgroup
+__device__ unsigned long long* g_gs_stamps = nullptr;
+#define GS_STAMP(slot)                                                                              \
+  do {                                                                                              \
+    if (g_gs_stamps && threadIdx.x == 0) {                                                          \
+      const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();                             \
+      g_gs_stamps[static_cast<long>(blockIdx.x) * 8 + (slot)] += now_ - t_prev;                     \
+      t_prev = now_;                                                                                \
+    }                                                                                               \
+  } while (0)
+#else
+#define GS_STAMP(slot) do {} while (0)
+#endif
 constexpr int GS_ROWS = 32;
 constexpr int GS_CAP = 1024;   // raw entries staged per pass (>= CR_LONG)
 constexpr int GS_MEM = 512;    // members per pass
@@ -221,6 +234,10 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
   __shared__ int s_mid[GS_ROWS];
   __shared__ int s_nmid;
   if (*bad) return;
+#ifdef TGP_GEMM_STAMPS
+  unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
+  if (g_gs_stamps && threadIdx.x == 0) g_gs_stamps[static_cast<long>(blockIdx.x) * 8 + 7] = t_prev;
+#endif
   const int tid = threadIdx.x;
   const int64_t r0 = static_cast<int64_t>(blockIdx.x) * GS_ROWS;
   const int nrows = static_cast<int>(K - r0 < GS_ROWS ? K - r0 : GS_ROWS);
@@ -229,6 +246,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
     s_rp[tid] = DIRECT ? 0 : a_row_ptr[r0 + tid];
   }
   __syncthreads();
+  GS_STAMP(5);
   const bool has_w = tmp_w != nullptr;
   int rs = 0;
   while (rs < nrows) {
@@ -259,6 +277,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
       s_seg_dst[m] = seg_dst[p_lo + m] - base;
     }
     __syncthreads();
+    GS_STAMP(0);
     // (b) slot-parallel gather through the cluster table
     {  // all GS_CAP / 256 slots of a thread are requested before any is consumed: one round trip per level
       constexpr int U = GS_CAP / 256;
@@ -295,6 +314,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
     }
     }
     __syncthreads();
+    GS_STAMP(1);
     // (c1) rows of <= 32 entries: one half-wave each
     {
       const int l = tid & 31, hw = tid >> 5;
@@ -363,6 +383,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
       }
     }
     __syncthreads();
+    GS_STAMP(2);
     // (c1b) rows of 33 .. 64 entries: one wave each, the same register network over 64 lanes (position in 6 bits)
     {
       const int lane = tid & 63;
@@ -418,6 +439,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
     }
     rs = re;
     __syncthreads();
+    GS_STAMP(3);
   }
 }
 
@@ -745,3 +767,9 @@ extern "C" int tgp_connect_coalesce_rows_fill(const void* ws, int64_t E, int64_t
                      has_weight ? out_w : nullptr);
   return check_launch("tgp_connect_coalesce_rows_fill");
 }
+
+#ifdef TGP_GEMM_STAMPS
+extern "C" int tgp_debug_set_gs_stamps(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(tgp::g_gs_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#endif
