@@ -105,3 +105,13 @@ for name, m in (("gen1 (id < 256)", ids < 256), ("gen2 (id >= 256)", ids >= 256)
 pairs = [v for v in groups.values() if len(v) == 2]
 print("sample CU pairs (block ids, loop us):", [(p_[0], p_[1], round(float(loop[p_[0]]), 1), round(float(loop[p_[1]]), 1)) for p_ in pairs[:6]])
 
+
+# phases of one k-step (t = nk/2), wave 0 of every workgroup: durations in ns
+phs = st[:, 8:15].double() * 10.0
+names = ["MFMA pairs 0..STORE_AT (+ first operand fetch)", "LDS stage stores (incl. wait for the tile)", "MFMA pairs ..LOAD_AT",
+         "global loads issue", "MFMA pairs ..15", "barrier wait"]
+for name, m in (("gen1", ids < 256), ("gen2", ids >= 256)):
+    if int(m.sum()) == 0:
+        continue
+    print(name, "k-step phases (mean ns):", ", ".join(f"{n}: {float((phs[m, i + 1] - phs[m, i]).mean()):.0f}" for i, n in enumerate(names)),
+          f"| total {float((phs[m, 6] - phs[m, 0]).mean()):.0f}")

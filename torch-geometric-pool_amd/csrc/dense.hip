@@ -95,20 +95,20 @@ __device__ __forceinline__ float4 ld4_guarded(const float* p, bool ok) {
   return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// Output tile BM x 128 per workgroup of (BM/32)*2 waves laid out (BM/32)(M) x 2(N); each wave owns a
-// 32 x 64 strip = two 32x32 MFMA tiles.  BM = 128: 512 threads, one workgroup per CU (big problems);
-// BM = 64: 256 threads, two workgroups per CU whose barriers / prologues / epilogues interleave (used
-// when the 128-row tiling would leave fewer than two workgroups per CU).
+// Output tile BM x BN per workgroup of (BM/32) x WN waves; each wave owns a 32 x BN/WN strip = NT 32x32 MFMA
+// tiles.  Shapes in use: 128 x 128 with 16 waves (4 x 4, NT = 1: 51 VGPRs, two workgroups per CU, A and B tiles
+// loaded once per 128 x 128 of output - measured 143 TFLOP/s at C5 against 137 for the 8-wave NT = 2 form),
+// 128 x 64 and 64 x 128 with 8 waves, 64 x 64 with 4 waves (when the bigger tiles would leave CUs idle).
 // A_KMAJOR = false: A stored [M][Kd] (k contiguous).  true: stored [Kd][M] (m contiguous).
 // ALIGNED: every leading dimension / extent is a multiple of 4 floats and every base is 16-byte
 // aligned, so all traffic is float4 with one predicate per vector.  Otherwise: scalar guarded path.
 // MODE 0: C = op(A) Bm.  MODE 1 (link-prediction residual, utils/losses.py:644-708): Bm is stored
 // [Nc][Kd] (n-major, i.e. the product is A Bm^T), and instead of storing C the epilogue accumulates
 // sum((resid - C)^2) over the tile, so S S^T never exists in memory.
-template <bool A_KMAJOR, bool ALIGNED, int BM, int BN, int MODE>
-__global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
-  constexpr int THREADS = BM * 4;
-  constexpr int NT = BN / 64;                       // 32x32 MFMA tiles per wave (wave strip = 32 x BN/2)
+template <bool A_KMAJOR, bool ALIGNED, int BM, int BN, int MODE, int WN = 2>
+__global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) {
+  constexpr int THREADS = BM * 2 * WN;              // (BM/32) x WN waves
+  constexpr int NT = BN / (32 * WN);                // 32x32 MFMA tiles per wave (wave strip = 32 x BN/WN)
   constexpr int B_TILE_FLOATS = MODE == 1 ? BN * LDA_ROWMAJOR : BK * BN;
   constexpr int BN_LANES = BN / 4;                  // lanes per k-row of the B tile
   constexpr int A_TILE_FLOATS = BM * LDA_ROWMAJOR;  // >= BK*BM, used for both A layouts
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
   constexpr int AK_LANES = BM / 4;                  // lanes per k-row of a k-major A tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   TGP_STAMP(0);
 #ifdef TGP_GEMM_STAMPS
   if (g_gemm_stamps && threadIdx.x == 0) {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
     const float* __restrict__ Rm = g.resid + static_cast<long>(batch) * g.sR;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int col = n0 + wn * (BN / 2) + j * 32 + lm;
+      const int col = n0 + wn * (BN / WN) + j * 32 + lm;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
   }
   const int a_off = A_KMAJOR ? lk * BM + wm * 32 + lm : (wm * 32 + lm) * LDA_ROWMAJOR + lk;
   const int a_step = A_KMAJOR ? 2 * BM : 2;
-  const int b_off = MODE == 1 ? (wn * (BN / 2) + lm) * LDA_ROWMAJOR + lk : lk * BN + wn * (BN / 2) + lm;
+  const int b_off = MODE == 1 ? (wn * (BN / WN) + lm) * LDA_ROWMAJOR + lk : lk * BN + wn * (BN / WN) + lm;
   constexpr int b_step = MODE == 1 ? 2 : 2 * BN;               // one k-pair
   constexpr int b_tile = MODE == 1 ? 32 * LDA_ROWMAJOR : 32;   // next 32 output columns
   // MFMAs of k-pairs [p0, p1) of one LDS stage.
@@ -336,6 +336,15 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
     const bool do_store = t + 1 < nk, do_load = t + 2 < nk;
     const int k2 = kof(t + 2);
     const bool tail = k2 + BK > k_end;
+#ifdef TGP_GEMM_STAMPS
+    // phase clock of one k-step in the middle of the loop (wave 0 of every workgroup): slots 8.. hold the time at
+    // step start, before / after the LDS stores, before / after the global loads, before / after the barrier
+    const bool probe = g_gemm_stamps && t == (nk / 2) && threadIdx.x == 0;
+#define TGP_PHASE(i) do { if (probe) g_gemm_stamps[static_cast<long>(blockIdx.x) * 16 + 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TGP_PHASE(i) do {} while (0)
+#endif
+    TGP_PHASE(0);
 #pragma unroll
     for (int p = 0; p < PD; ++p) fetch_pair(As, Bs, p);
 #pragma unroll
@@ -347,6 +356,8 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
       // memory work of the stage: loads of tile t+2 behind pair LOAD_AT, LDS stores of tile t+1 behind STORE_AT
       // (SPREAD: one vector per pair starting there, instead of all at once)
       constexpr int LOAD_AT = TGP_LOAD_AT, STORE_AT = TGP_STORE_AT, SPREAD = TGP_SPREAD;
+      if (p == STORE_AT) TGP_PHASE(1);
+      if (p == LOAD_AT) TGP_PHASE(3);
 #pragma unroll
       for (int v = 0; v < A_VECS + B_VECS; ++v) {
         if (p == LOAD_AT + (SPREAD ? v : 0) && do_load) {
@@ -359,8 +370,12 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (p == STORE_AT) TGP_PHASE(2);
+      if (p == LOAD_AT) TGP_PHASE(4);
     }
+    TGP_PHASE(5);
     __syncthreads();
+    TGP_PHASE(6);
   };
   if (nk > 0) {
 #pragma unroll
@@ -418,7 +433,7 @@ __global__ __launch_bounds__(BM * 4) void gemm_f32_mfma_kernel(GemmArgs g) {
   }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int col = n0 + wn * (BN / 2) + j * 32 + lm;
+    const int col = n0 + wn * (BN / WN) + j * 32 + lm;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -467,15 +482,15 @@ static TileCfg pick_tile(int64_t M, int64_t max_nc, int64_t batches_x_splits, co
   return t;
 }
 
-template <bool A_KMAJOR, int BM, int BN, int MODE = 0>
+template <bool A_KMAJOR, int BM, int BN, int MODE = 0, int WN = 2>
 static void launch_gemm_cfg(const GemmArgs& g_in, int batches, hipStream_t stream) {
   const GemmArgs& g = g_in;
   const int nwg = batches * g.splits * g.tiles_m * g.tiles_n;
   const size_t lds = 2 * (BM * LDA_ROWMAJOR + (MODE == 1 ? BN * LDA_ROWMAJOR : BK * BN)) * sizeof(float);
   if (gemm_aligned(g))
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, true, BM, BN, MODE>), dim3(nwg), dim3(BM * 4), lds, stream, g);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, true, BM, BN, MODE, WN>), dim3(nwg), dim3(BM * 2 * WN), lds, stream, g);
   else
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, false, BM, BN, MODE>), dim3(nwg), dim3(BM * 4), lds, stream, g);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, false, BM, BN, MODE, WN>), dim3(nwg), dim3(BM * 2 * WN), lds, stream, g);
 }
 
 // g.tiles_* are filled in here: they follow from the tile shape chosen for this problem.
@@ -489,7 +504,7 @@ static void launch_gemm(GemmArgs g, int batches, hipStream_t stream) {
   if (t.bm == 64 && t.bn == 64) launch_gemm_cfg<A_KMAJOR, 64, 64>(g, batches, stream);
   else if (t.bm == 64) launch_gemm_cfg<A_KMAJOR, 64, 128>(g, batches, stream);
   else if (t.bn == 64) launch_gemm_cfg<A_KMAJOR, 128, 64>(g, batches, stream);
-  else launch_gemm_cfg<A_KMAJOR, 128, 128>(g, batches, stream);
+  else launch_gemm_cfg<A_KMAJOR, 128, 128, 0, 4>(g, batches, stream);  // 16 waves (4 x 4), one 32x32 tile each
 }
 
 // MODE 1 launch: sum((resid - A Bm^T)^2) per tile into g.partial; returns tiles per batch element.
@@ -501,7 +516,7 @@ static int launch_gemm_residual(GemmArgs g, int batches, hipStream_t stream, boo
   if (t.bm == 64 && t.bn == 64) launch_gemm_cfg<false, 64, 64, 1>(g, batches, stream);
   else if (t.bm == 64) launch_gemm_cfg<false, 64, 128, 1>(g, batches, stream);
   else if (t.bn == 64) launch_gemm_cfg<false, 128, 64, 1>(g, batches, stream);
-  else launch_gemm_cfg<false, 128, 128, 1>(g, batches, stream);
+  else launch_gemm_cfg<false, 128, 128, 1, 4>(g, batches, stream);
   return g.tiles_m * g.tiles_n;
 }
 
