@@ -163,7 +163,8 @@ def test_coalesce_properties_full_size(dev):
 
 
 # ----------------------------------------------------------------------------------- dense
-@pytest.mark.parametrize("B,N,K,F", [(32, 1024, 128, 64), (3, 333, 37, 19), (2, 2048, 512, 128), (64, 60, 20, 32)])
+@pytest.mark.parametrize("B,N,K,F", [(32, 1024, 128, 64), (3, 333, 37, 19), (2, 2048, 512, 128), (64, 60, 20, 32),
+                                     (64, 521, 258, 7), (48, 640, 256, 64)])  # the last two: 128x128 / 16-wave tiles, ragged and aligned
 def test_dense_pool_vs_oracle(dev, B, N, K, F):
     import tgp_oracle as O
     from tgp.connect import DenseConnect
