@@ -14,25 +14,40 @@ constexpr int kCompactTile = 256 * kCompactItems;
 // =====================================================================================
 // A5 + A6 filters: induced subgraph with relabelling (connect/base_conn.py:79-82)
 // =====================================================================================
+// relabel[node] = position in node_index, and a 1-bit-per-node membership map.  The predicate of both passes
+// tests the bitmap (N/8 bytes: 125 KB for a million nodes, cache resident) instead of gathering from the 4 N-byte
+// relabel table; the table is read only for the edges that survive (fill pass).
 __global__ __launch_bounds__(256) void relabel_scatter_kernel(const int64_t* __restrict__ node_index, int64_t k,
                                                               int32_t* __restrict__ relabel) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (j < k) relabel[node_index[j]] = static_cast<int32_t>(j);
 }
 
+// one ballot per 64 nodes: lane = node, the wave's two result words are the membership bits (no atomics)
+__global__ __launch_bounds__(256) void member_bits_kernel(const int32_t* __restrict__ relabel, int64_t n,
+                                                          uint32_t* __restrict__ member_bits) {
+  const int64_t v = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const unsigned long long m = __ballot(v < n && relabel[v] >= 0);
+  if ((threadIdx.x & 63) == 0 && v < n) {
+    member_bits[v >> 5] = static_cast<uint32_t>(m);
+    if (v + 32 < n || ((n + 31) >> 5) > ((v >> 5) + 1)) member_bits[(v >> 5) + 1] = static_cast<uint32_t>(m >> 32);
+  }
+}
+
 struct SubgraphPred {
   const int64_t* row;
   const int64_t* col;
   const float* w;
-  const int32_t* relabel;  // nullptr = no node filter
+  const int32_t* relabel;       // nullptr = no node filter
+  const uint32_t* member_bits;  // set with relabel
   int flags;
+  // keep / drop only; r, c are the ORIGINAL endpoints (relabelling is injective, so r == c decides self loops)
   __device__ __forceinline__ bool operator()(int64_t e, int64_t& r, int64_t& c) const {
     r = row[e];
     c = col[e];
     if (relabel) {
-      r = relabel[r];
-      c = relabel[c];
-      if ((r | c) < 0) return false;
+      const uint32_t br = member_bits[r >> 5] >> (r & 31), bc = member_bits[c >> 5] >> (c & 31);
+      if (!(br & bc & 1u)) return false;
     }
     if ((flags & TGP_REMOVE_SELF_LOOPS) && r == c) return false;
     if (w && (flags & TGP_EPS_FILTER) && !(fabsf(w[e]) > TGP_EPS)) return false;
@@ -40,48 +55,147 @@ struct SubgraphPred {
   }
 };
 
-__global__ __launch_bounds__(256) void subgraph_count_kernel(SubgraphPred pred, int64_t E,
-                                                             uint32_t* __restrict__ block_counts) {
-  __shared__ uint32_t s_cnt[4];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kCompactTile;
-  uint32_t mine = 0;
+// Both passes walk the edge list in chunks of SG_CHUNK = 4096 edges with persistent 1024-thread workgroups (one per
+// CU).  A thread owns 4 CONSECUTIVE edges of a chunk, so row / col arrive as 16-byte loads, and the
+// order-preserving rank of an edge is (survivors of earlier chunks) + (survivors of earlier threads) + (survivors
+// among the thread's earlier edges).  The node-membership bitmap is copied into LDS once per workgroup when it fits
+// (N <= 1.2 M nodes): the two membership tests per edge are then LDS reads instead of 64 scattered L2 requests per
+// wave instruction, which is what bounded the first version of these kernels.
+constexpr int SG_PER = 4;
+constexpr int SG_THREADS = 1024;
+constexpr int SG_CHUNK = SG_THREADS * SG_PER;
+constexpr int SG_LDS_WORDS_MAX = 38 * 1024;  // 152 KB of the 160 KB LDS
+
+struct SgEdges {
+  int64_t r[SG_PER], c[SG_PER];
+  bool keep[SG_PER];
+};
+
+// the streaming part: the thread's 4 consecutive (row, col) pairs; keep[] = "edge exists"
+__device__ __forceinline__ void sg_fetch(const SubgraphPred& pred, int64_t e0, int64_t E, SgEdges& t) {
+  if (e0 >= E) {
 #pragma unroll
-  for (int it = 0; it < kCompactItems; ++it) {
-    const int64_t e = base + it * 256 + threadIdx.x;
-    int64_t r, c;
-    const bool keep = e < E && pred(e, r, c);
-    mine += __popcll(__ballot(keep));
+    for (int j = 0; j < SG_PER; ++j) { t.keep[j] = false; t.r[j] = 0; t.c[j] = 0; }
+    return;
   }
-  if (lane_id() == 0) s_cnt[wave_id()] = mine;
-  __syncthreads();
-  if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  if (e0 + SG_PER <= E && ((reinterpret_cast<uintptr_t>(pred.row + e0) | reinterpret_cast<uintptr_t>(pred.col + e0)) & 15) == 0) {
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    const ll2 r01 = *reinterpret_cast<const ll2*>(pred.row + e0), r23 = *reinterpret_cast<const ll2*>(pred.row + e0 + 2);
+    const ll2 c01 = *reinterpret_cast<const ll2*>(pred.col + e0), c23 = *reinterpret_cast<const ll2*>(pred.col + e0 + 2);
+    t.r[0] = r01.x; t.r[1] = r01.y; t.r[2] = r23.x; t.r[3] = r23.y;
+    t.c[0] = c01.x; t.c[1] = c01.y; t.c[2] = c23.x; t.c[3] = c23.y;
+#pragma unroll
+    for (int j = 0; j < SG_PER; ++j) t.keep[j] = true;
+  } else {
+#pragma unroll
+    for (int j = 0; j < SG_PER; ++j) {
+      t.keep[j] = e0 + j < E;
+      t.r[j] = t.keep[j] ? pred.row[e0 + j] : 0;
+      t.c[j] = t.keep[j] ? pred.col[e0 + j] : 0;
+    }
+  }
 }
 
-__global__ __launch_bounds__(256) void subgraph_fill_kernel(SubgraphPred pred, int64_t E,
-                                                            const uint32_t* __restrict__ block_offsets,
-                                                            int64_t* __restrict__ out_row,
-                                                            int64_t* __restrict__ out_col,
-                                                            float* __restrict__ out_w) {
-  __shared__ uint32_t s_cnt[kCompactItems * 4];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kCompactTile;
-  bool keep[kCompactItems];
-  int64_t r[kCompactItems], c[kCompactItems];
-  uint32_t rank[kCompactItems];
+// the predicate: membership of both endpoints (bitmap), self loops, |w| > eps
+template <bool LDSB>
+__device__ __forceinline__ void sg_eval(const SubgraphPred& pred, const uint32_t* s_bits, int64_t e0, SgEdges& t) {
+  if (pred.relabel) {  // all bitmap words are requested before any is tested
+    uint32_t br[SG_PER], bc[SG_PER];
 #pragma unroll
-  for (int it = 0; it < kCompactItems; ++it) {
-    const int64_t e = base + it * 256 + threadIdx.x;
-    keep[it] = e < E && pred(e, r[it], c[it]);
+    for (int j = 0; j < SG_PER; ++j) {
+      if constexpr (LDSB) {
+        br[j] = s_bits[t.r[j] >> 5];
+        bc[j] = s_bits[t.c[j] >> 5];
+      } else {
+        br[j] = pred.member_bits[t.r[j] >> 5];
+        bc[j] = pred.member_bits[t.c[j] >> 5];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < SG_PER; ++j)
+      t.keep[j] = t.keep[j] && (((br[j] >> (t.r[j] & 31)) & (bc[j] >> (t.c[j] & 31)) & 1u) != 0);
   }
-  uint32_t total;
-  block_compact_ranks<kCompactItems>(keep, rank, total, s_cnt);
-  const int64_t off = block_offsets[blockIdx.x];
 #pragma unroll
-  for (int it = 0; it < kCompactItems; ++it) {
-    if (keep[it]) {
-      const int64_t e = base + it * 256 + threadIdx.x;
-      out_row[off + rank[it]] = r[it];
-      out_col[off + rank[it]] = c[it];
-      if (out_w) out_w[off + rank[it]] = pred.w[e];
+  for (int j = 0; j < SG_PER; ++j) {
+    if ((pred.flags & TGP_REMOVE_SELF_LOOPS) && t.r[j] == t.c[j]) t.keep[j] = false;
+    if (t.keep[j] && pred.w && (pred.flags & TGP_EPS_FILTER) && !(fabsf(pred.w[e0 + j]) > TGP_EPS)) t.keep[j] = false;
+  }
+}
+
+// exclusive scan of one value per thread over a 1024-thread workgroup (16 waves); s_w: 16 words
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s_w, uint32_t* total) {
+  const uint32_t inc = wave_incl_scan(v);
+  if (lane_id() == WAVE - 1) s_w[wave_id()] = inc;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const uint32_t c = s_w[w];
+    if (w < wave_id()) off += c;
+    tot += c;
+  }
+  if (total) *total = tot;
+  __syncthreads();
+  return off + inc - v;
+}
+
+template <bool LDSB>
+__global__ __launch_bounds__(SG_THREADS) void subgraph_count_kernel(SubgraphPred pred, int64_t E, int nchunks,
+                                                                    int nwords, uint32_t* __restrict__ block_counts) {
+  extern __shared__ uint32_t s_dyn[];
+  __shared__ uint32_t s_w[16];
+  if constexpr (LDSB) {
+    for (int i = threadIdx.x; i < nwords; i += SG_THREADS) s_dyn[i] = pred.member_bits[i];
+    __syncthreads();
+  }
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int64_t e0 = static_cast<int64_t>(chunk) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER;
+    uint32_t mine = 0;
+    SgEdges t;
+    sg_fetch(pred, e0, E, t);
+    sg_eval<LDSB>(pred, s_dyn, e0, t);
+#pragma unroll
+    for (int j = 0; j < SG_PER; ++j) mine += t.keep[j] ? 1u : 0u;
+    uint32_t total;
+    block_excl_scan_1024(mine, s_w, &total);
+    if (threadIdx.x == 0) block_counts[chunk] = total;
+  }
+}
+
+template <bool LDSB>
+__global__ __launch_bounds__(SG_THREADS) void subgraph_fill_kernel(SubgraphPred pred, int64_t E, int nchunks, int nwords,
+                                                                   const uint32_t* __restrict__ block_offsets,
+                                                                   int64_t* __restrict__ out_row,
+                                                                   int64_t* __restrict__ out_col,
+                                                                   float* __restrict__ out_w) {
+  extern __shared__ uint32_t s_dyn[];
+  __shared__ uint32_t s_w[16];
+  if constexpr (LDSB) {
+    for (int i = threadIdx.x; i < nwords; i += SG_THREADS) s_dyn[i] = pred.member_bits[i];
+    __syncthreads();
+  }
+  // the (row, col) stream of the next chunk is requested before this chunk's dependent work (relabel gathers,
+  // weight loads, stores) starts: a persistent workgroup would otherwise pay every round trip back to back
+  SgEdges nxt;
+  sg_fetch(pred, static_cast<int64_t>(blockIdx.x) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER, E, nxt);
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int64_t e0 = static_cast<int64_t>(chunk) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER;
+    SgEdges t = nxt;
+    if (chunk + static_cast<int>(gridDim.x) < nchunks)
+      sg_fetch(pred, e0 + static_cast<int64_t>(gridDim.x) * SG_CHUNK, E, nxt);
+    sg_eval<LDSB>(pred, s_dyn, e0, t);
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < SG_PER; ++j) mine += t.keep[j] ? 1u : 0u;
+    int64_t pos = static_cast<int64_t>(block_offsets[chunk]) + block_excl_scan_1024(mine, s_w, nullptr);
+#pragma unroll
+    for (int j = 0; j < SG_PER; ++j) {
+      if (t.keep[j]) {
+        out_row[pos] = pred.relabel ? pred.relabel[t.r[j]] : t.r[j];
+        out_col[pos] = pred.relabel ? pred.relabel[t.c[j]] : t.c[j];
+        if (out_w) out_w[pos] = pred.w[e0 + j];
+        ++pos;
+      }
     }
   }
 }
@@ -381,20 +495,23 @@ using namespace tgp;
 
 // ------------------------------------------------------------------------------------- subgraph
 extern "C" size_t tgp_connect_subgraph_workspace_bytes(int64_t E, int64_t N) {
-  const size_t nb = static_cast<size_t>(cdiv(E > 0 ? E : 1, kCompactTile));
-  return align_up((N > 0 ? N : 1) * sizeof(int32_t)) + 2 * align_up(nb * sizeof(uint32_t)) + 256;
+  const size_t nb = static_cast<size_t>(cdiv(E > 0 ? E : 1, SG_CHUNK));
+  return align_up((N > 0 ? N : 1) * sizeof(int32_t)) + align_up(((N > 0 ? N : 1) / 32 + 1) * sizeof(uint32_t)) +
+         2 * align_up(nb * sizeof(uint32_t)) + 256;
 }
 
 struct SubgraphWs {
   int32_t* relabel;
+  uint32_t* member_bits;
   uint32_t* counts;
   uint32_t* offsets;
 };
 static SubgraphWs carve_subgraph(void* ws, int64_t E, int64_t N) {
   Carver cv(ws);
-  const size_t nb = static_cast<size_t>(cdiv(E > 0 ? E : 1, kCompactTile));
+  const size_t nb = static_cast<size_t>(cdiv(E > 0 ? E : 1, SG_CHUNK));
   SubgraphWs s;
   s.relabel = cv.take<int32_t>(N > 0 ? N : 1);
+  s.member_bits = cv.take<uint32_t>((N > 0 ? N : 1) / 32 + 1);
   s.counts = cv.take<uint32_t>(nb);
   s.offsets = cv.take<uint32_t>(nb);
   return s;
@@ -413,12 +530,23 @@ extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col
   if (node_index) {
     (void)hipMemsetAsync(s.relabel, 0xFF, static_cast<size_t>(N > 0 ? N : 1) * sizeof(int32_t), stream);
     if (k > 0)
-      hipLaunchKernelGGL(relabel_scatter_kernel, dim3(cdiv(k, 256)), dim3(256), 0, stream, node_index, k,
-                         s.relabel);
+      hipLaunchKernelGGL(relabel_scatter_kernel, dim3(cdiv(k, 256)), dim3(256), 0, stream, node_index, k, s.relabel);
+    hipLaunchKernelGGL(member_bits_kernel, dim3(cdiv(N > 0 ? N : 1, 256)), dim3(256), 0, stream, s.relabel, N,
+                       s.member_bits);
   }
-  const int nb = cdiv(E > 0 ? E : 1, kCompactTile);
-  SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, flags};
-  hipLaunchKernelGGL(subgraph_count_kernel, dim3(nb), dim3(256), 0, stream, pred, E, s.counts);
+  const int nb = cdiv(E > 0 ? E : 1, SG_CHUNK);
+  SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, flags};
+  const int nwords = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
+  const int grid = nb < 256 ? nb : 256;  // persistent: one 1024-thread workgroup per CU
+  if (node_index && nwords <= SG_LDS_WORDS_MAX) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_count_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_WORDS_MAX * 4);
+    hipLaunchKernelGGL(subgraph_count_kernel<true>, dim3(grid), dim3(SG_THREADS), nwords * sizeof(uint32_t), stream,
+                       pred, E, nb, nwords, s.counts);
+  } else {
+    hipLaunchKernelGGL(subgraph_count_kernel<false>, dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords,
+                       s.counts);
+  }
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nb, s.offsets, d_count);
   return check_launch("tgp_connect_subgraph_count");
 }
@@ -431,11 +559,19 @@ extern "C" int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col,
   if (num_out == 0 || E == 0) return TGP_OK;
   TGP_REQUIRE(out_row && out_col && (!w || out_w), TGP_ERR_INVALID, "tgp_connect_subgraph_fill: null output");
   SubgraphWs s = carve_subgraph(const_cast<void*>(ws), E, N);
-  const int nb = cdiv(E, kCompactTile);
-  SubgraphPred pred{row, col, w, (flags & TGP_NODE_FILTER) ? s.relabel : nullptr,
-                    flags};
-  hipLaunchKernelGGL(subgraph_fill_kernel, dim3(nb), dim3(256), 0, stream, pred, E, s.offsets, out_row, out_col,
-                     w ? out_w : nullptr);
+  const int nb = cdiv(E, SG_CHUNK);
+  SubgraphPred pred{row, col, w, (flags & TGP_NODE_FILTER) ? s.relabel : nullptr, s.member_bits, flags};
+  const int nwords = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
+  const int grid = nb < 256 ? nb : 256;
+  if ((flags & TGP_NODE_FILTER) && nwords <= SG_LDS_WORDS_MAX) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_fill_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_WORDS_MAX * 4);
+    hipLaunchKernelGGL(subgraph_fill_kernel<true>, dim3(grid), dim3(SG_THREADS), nwords * sizeof(uint32_t), stream, pred,
+                       E, nb, nwords, s.offsets, out_row, out_col, w ? out_w : nullptr);
+  } else {
+    hipLaunchKernelGGL(subgraph_fill_kernel<false>, dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords,
+                       s.offsets, out_row, out_col, w ? out_w : nullptr);
+  }
   return check_launch("tgp_connect_subgraph_fill");
 }
 
