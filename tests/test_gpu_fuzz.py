@@ -66,6 +66,8 @@ def test_sparse_connect_fuzz(dev, seed):
     # subgraph branch: a strict subset of the nodes is kept
     if n >= 2:
         kept = torch.sort(torch.randperm(n, generator=g)[: max(1, n // 2)])[0]
+        if seed % 4 == 1:  # a subset in arbitrary order: new ids are positions in node_index, not ranks
+            kept = kept[torch.randperm(kept.numel(), generator=g)]
         kk = kept.numel()
         bp = torch.sort(torch.randint(0, 3, (kk,), generator=g))[0]
         ref_ei, ref_ew = O.sparse_connect(ei, ew, kept, torch.arange(kk), n, kk, batch_pooled=bp, **flags)

@@ -18,9 +18,50 @@ constexpr int kCompactTile = 256 * kCompactItems;
 // tests the bitmap (N/8 bytes: 125 KB for a million nodes, cache resident) instead of gathering from the 4 N-byte
 // relabel table; the table is read only for the edges that survive (fill pass).
 __global__ __launch_bounds__(256) void relabel_scatter_kernel(const int64_t* __restrict__ node_index, int64_t k,
-                                                              int32_t* __restrict__ relabel) {
+                                                              int32_t* __restrict__ relabel,
+                                                              int* __restrict__ unsorted) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (j < k) relabel[node_index[j]] = static_cast<int32_t>(j);
+  if (j < k) {
+    const int64_t v = node_index[j];
+    relabel[v] = static_cast<int32_t>(j);
+    if (j > 0 && node_index[j - 1] >= v) *unsorted = 1;  // then position != rank: the table is the only way
+  }
+}
+
+// rank128[b] = number of member nodes with id < 128 b (exclusive scan of the bitmap's popcounts, one workgroup):
+// with an ascending node_index the new id of node v is its rank among the members,
+//   rank128[v >> 7] + popcount(bitmap words of the block before v's word) + popcount(v's word below bit v),
+// so the fill pass needs no gather from the 4 N-byte relabel table at all.
+__global__ __launch_bounds__(1024) void member_rank_kernel(const uint32_t* __restrict__ member_bits, int nwords,
+                                                           int nblocks, uint32_t* __restrict__ rank128) {
+  __shared__ uint32_t s_w[16];
+  __shared__ uint32_t s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int b = base + tid;
+    uint32_t v = 0;
+    if (b < nblocks) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (4 * b + q < nwords) v += __popc(member_bits[4 * b + q]);
+    }
+    const uint32_t inc = wave_incl_scan(v);
+    if (lane == WAVE - 1) s_w[w] = inc;
+    __syncthreads();
+    uint32_t off = s_carry, tot = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t c = s_w[j];
+      if (j < w) off += c;
+      tot += c;
+    }
+    if (b < nblocks) rank128[b] = off + inc - v;
+    __syncthreads();
+    if (tid == 0) s_carry += tot;
+    __syncthreads();
+  }
 }
 
 // one ballot per 64 nodes: lane = node, the wave's two result words are the membership bits (no atomics)
@@ -40,6 +81,8 @@ struct SubgraphPred {
   const float* w;
   const int32_t* relabel;       // nullptr = no node filter
   const uint32_t* member_bits;  // set with relabel
+  const uint32_t* rank128;      // set with relabel
+  const int* unsorted;          // set with relabel: node_index is not ascending
   int flags;
   // keep / drop only; r, c are the ORIGINAL endpoints (relabelling is injective, so r == c decides self loops)
   __device__ __forceinline__ bool operator()(int64_t e, int64_t& r, int64_t& c) const {
@@ -68,6 +111,7 @@ constexpr int SG_LDS_WORDS_MAX = 38 * 1024;  // 152 KB of the 160 KB LDS
 
 struct SgEdges {
   int64_t r[SG_PER], c[SG_PER];
+  float w[SG_PER];
   bool keep[SG_PER];
 };
 
@@ -75,8 +119,17 @@ struct SgEdges {
 __device__ __forceinline__ void sg_fetch(const SubgraphPred& pred, int64_t e0, int64_t E, SgEdges& t) {
   if (e0 >= E) {
 #pragma unroll
-    for (int j = 0; j < SG_PER; ++j) { t.keep[j] = false; t.r[j] = 0; t.c[j] = 0; }
+    for (int j = 0; j < SG_PER; ++j) { t.keep[j] = false; t.r[j] = 0; t.c[j] = 0; t.w[j] = 0.f; }
     return;
+  }
+  if (pred.w) {  // streamed with the indices (one 16-byte load) rather than fetched sparsely for the survivors
+    if (e0 + SG_PER <= E && (reinterpret_cast<uintptr_t>(pred.w + e0) & 15) == 0) {
+      const float4 wv = *reinterpret_cast<const float4*>(pred.w + e0);
+      t.w[0] = wv.x; t.w[1] = wv.y; t.w[2] = wv.z; t.w[3] = wv.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < SG_PER; ++j) t.w[j] = e0 + j < E ? pred.w[e0 + j] : 0.f;
+    }
   }
   if (e0 + SG_PER <= E && ((reinterpret_cast<uintptr_t>(pred.row + e0) | reinterpret_cast<uintptr_t>(pred.col + e0)) & 15) == 0) {
     typedef long long ll2 __attribute__((ext_vector_type(2)));
@@ -118,7 +171,7 @@ __device__ __forceinline__ void sg_eval(const SubgraphPred& pred, const uint32_t
 #pragma unroll
   for (int j = 0; j < SG_PER; ++j) {
     if ((pred.flags & TGP_REMOVE_SELF_LOOPS) && t.r[j] == t.c[j]) t.keep[j] = false;
-    if (t.keep[j] && pred.w && (pred.flags & TGP_EPS_FILTER) && !(fabsf(pred.w[e0 + j]) > TGP_EPS)) t.keep[j] = false;
+    if (pred.w && (pred.flags & TGP_EPS_FILTER) && !(fabsf(t.w[j]) > TGP_EPS)) t.keep[j] = false;
   }
 }
 
@@ -162,7 +215,8 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_count_kernel(SubgraphPred
   }
 }
 
-template <bool LDSB>
+// LDSB: 0 = bitmap in global memory, 1 = bitmap in LDS, 2 = bitmap + rank128 in LDS (relabel by rank)
+template <int LDSB>
 __global__ __launch_bounds__(SG_THREADS) void subgraph_fill_kernel(SubgraphPred pred, int64_t E, int nchunks, int nwords,
                                                                    const uint32_t* __restrict__ block_offsets,
                                                                    int64_t* __restrict__ out_row,
@@ -170,10 +224,28 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_fill_kernel(SubgraphPred 
                                                                    float* __restrict__ out_w) {
   extern __shared__ uint32_t s_dyn[];
   __shared__ uint32_t s_w[16];
-  if constexpr (LDSB) {
+  const uint32_t* s_rank = s_dyn + nwords;
+  bool by_rank = false;
+  if constexpr (LDSB >= 1) {
     for (int i = threadIdx.x; i < nwords; i += SG_THREADS) s_dyn[i] = pred.member_bits[i];
+    if constexpr (LDSB == 2) {
+      const int nblocks = (nwords + 3) / 4;
+      for (int i = threadIdx.x; i < nblocks; i += SG_THREADS) s_dyn[nwords + i] = pred.rank128[i];
+      by_rank = *pred.unsorted == 0;
+    }
     __syncthreads();
   }
+  auto new_id = [&](int64_t v) -> int64_t {
+    if constexpr (LDSB == 2) {
+      if (by_rank) {
+        const int word = static_cast<int>(v >> 5);
+        uint32_t r = s_rank[word >> 2];
+        for (int q = word & ~3; q < word; ++q) r += __popc(s_dyn[q]);
+        return r + __popc(s_dyn[word] & ((1u << (v & 31)) - 1u));
+      }
+    }
+    return pred.relabel[v];
+  };
   // the (row, col) stream of the next chunk is requested before this chunk's dependent work (relabel gathers,
   // weight loads, stores) starts: a persistent workgroup would otherwise pay every round trip back to back
   SgEdges nxt;
@@ -183,7 +255,7 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_fill_kernel(SubgraphPred 
     SgEdges t = nxt;
     if (chunk + static_cast<int>(gridDim.x) < nchunks)
       sg_fetch(pred, e0 + static_cast<int64_t>(gridDim.x) * SG_CHUNK, E, nxt);
-    sg_eval<LDSB>(pred, s_dyn, e0, t);
+    sg_eval<(LDSB >= 1)>(pred, s_dyn, e0, t);
     uint32_t mine = 0;
 #pragma unroll
     for (int j = 0; j < SG_PER; ++j) mine += t.keep[j] ? 1u : 0u;
@@ -191,9 +263,9 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_fill_kernel(SubgraphPred 
 #pragma unroll
     for (int j = 0; j < SG_PER; ++j) {
       if (t.keep[j]) {
-        out_row[pos] = pred.relabel ? pred.relabel[t.r[j]] : t.r[j];
-        out_col[pos] = pred.relabel ? pred.relabel[t.c[j]] : t.c[j];
-        if (out_w) out_w[pos] = pred.w[e0 + j];
+        out_row[pos] = pred.relabel ? new_id(t.r[j]) : t.r[j];
+        out_col[pos] = pred.relabel ? new_id(t.c[j]) : t.c[j];
+        if (out_w) out_w[pos] = t.w[j];
         ++pos;
       }
     }
@@ -497,12 +569,14 @@ using namespace tgp;
 extern "C" size_t tgp_connect_subgraph_workspace_bytes(int64_t E, int64_t N) {
   const size_t nb = static_cast<size_t>(cdiv(E > 0 ? E : 1, SG_CHUNK));
   return align_up((N > 0 ? N : 1) * sizeof(int32_t)) + align_up(((N > 0 ? N : 1) / 32 + 1) * sizeof(uint32_t)) +
-         2 * align_up(nb * sizeof(uint32_t)) + 256;
+         align_up(((N > 0 ? N : 1) / 128 + 2) * sizeof(uint32_t)) + 2 * align_up(nb * sizeof(uint32_t)) + 512;
 }
 
 struct SubgraphWs {
   int32_t* relabel;
   uint32_t* member_bits;
+  uint32_t* rank128;
+  int* unsorted;
   uint32_t* counts;
   uint32_t* offsets;
 };
@@ -512,6 +586,8 @@ static SubgraphWs carve_subgraph(void* ws, int64_t E, int64_t N) {
   SubgraphWs s;
   s.relabel = cv.take<int32_t>(N > 0 ? N : 1);
   s.member_bits = cv.take<uint32_t>((N > 0 ? N : 1) / 32 + 1);
+  s.rank128 = cv.take<uint32_t>((N > 0 ? N : 1) / 128 + 2);
+  s.unsorted = cv.take<int>(4);
   s.counts = cv.take<uint32_t>(nb);
   s.offsets = cv.take<uint32_t>(nb);
   return s;
@@ -529,13 +605,17 @@ extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col
   SubgraphWs s = carve_subgraph(ws, E, N);
   if (node_index) {
     (void)hipMemsetAsync(s.relabel, 0xFF, static_cast<size_t>(N > 0 ? N : 1) * sizeof(int32_t), stream);
+    (void)hipMemsetAsync(s.unsorted, 0, sizeof(int), stream);
     if (k > 0)
-      hipLaunchKernelGGL(relabel_scatter_kernel, dim3(cdiv(k, 256)), dim3(256), 0, stream, node_index, k, s.relabel);
+      hipLaunchKernelGGL(relabel_scatter_kernel, dim3(cdiv(k, 256)), dim3(256), 0, stream, node_index, k, s.relabel,
+                         s.unsorted);
     hipLaunchKernelGGL(member_bits_kernel, dim3(cdiv(N > 0 ? N : 1, 256)), dim3(256), 0, stream, s.relabel, N,
                        s.member_bits);
+    const int nw = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
+    hipLaunchKernelGGL(member_rank_kernel, dim3(1), dim3(1024), 0, stream, s.member_bits, nw, (nw + 3) / 4, s.rank128);
   }
   const int nb = cdiv(E > 0 ? E : 1, SG_CHUNK);
-  SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, flags};
+  SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.rank128, s.unsorted, flags};
   const int nwords = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
   const int grid = nb < 256 ? nb : 256;  // persistent: one 1024-thread workgroup per CU
   if (node_index && nwords <= SG_LDS_WORDS_MAX) {
@@ -560,16 +640,23 @@ extern "C" int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col,
   TGP_REQUIRE(out_row && out_col && (!w || out_w), TGP_ERR_INVALID, "tgp_connect_subgraph_fill: null output");
   SubgraphWs s = carve_subgraph(const_cast<void*>(ws), E, N);
   const int nb = cdiv(E, SG_CHUNK);
-  SubgraphPred pred{row, col, w, (flags & TGP_NODE_FILTER) ? s.relabel : nullptr, s.member_bits, flags};
+  SubgraphPred pred{row, col, w, (flags & TGP_NODE_FILTER) ? s.relabel : nullptr, s.member_bits, s.rank128, s.unsorted,
+                    flags};
   const int nwords = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
   const int grid = nb < 256 ? nb : 256;
-  if ((flags & TGP_NODE_FILTER) && nwords <= SG_LDS_WORDS_MAX) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_fill_kernel<true>),
+  const int nblocks = (nwords + 3) / 4;
+  if ((flags & TGP_NODE_FILTER) && nwords + nblocks <= SG_LDS_WORDS_MAX + 1984) {  // bitmap + rank128 <= 159.75 KB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_fill_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (SG_LDS_WORDS_MAX + 1984) * 4);
+    hipLaunchKernelGGL(subgraph_fill_kernel<2>, dim3(grid), dim3(SG_THREADS), (nwords + nblocks) * sizeof(uint32_t),
+                       stream, pred, E, nb, nwords, s.offsets, out_row, out_col, w ? out_w : nullptr);
+  } else if ((flags & TGP_NODE_FILTER) && nwords <= SG_LDS_WORDS_MAX) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_fill_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_WORDS_MAX * 4);
-    hipLaunchKernelGGL(subgraph_fill_kernel<true>, dim3(grid), dim3(SG_THREADS), nwords * sizeof(uint32_t), stream, pred,
+    hipLaunchKernelGGL(subgraph_fill_kernel<1>, dim3(grid), dim3(SG_THREADS), nwords * sizeof(uint32_t), stream, pred,
                        E, nb, nwords, s.offsets, out_row, out_col, w ? out_w : nullptr);
   } else {
-    hipLaunchKernelGGL(subgraph_fill_kernel<false>, dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords,
+    hipLaunchKernelGGL(subgraph_fill_kernel<0>, dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords,
                        s.offsets, out_row, out_col, w ? out_w : nullptr);
   }
   return check_launch("tgp_connect_subgraph_fill");
