@@ -394,20 +394,100 @@ __global__ __launch_bounds__(256) void check_sorted_rows_kernel(const int64_t* _
   if (e + 1 < E && row[e] > row[e + 1]) *unsorted = 1;
 }
 
-// Sorted rows: the first edge of every row adds up its run sequentially (same order as the CPU
-// scatter_add_).  Skipped (no-op) when *unsorted is set.
+// Sorted rows: segmented sums without atomics.  One wave owns a slab of kDegSlab consecutive edges
+// and walks it in 64-edge chunks: a segmented inclusive scan over the lanes (rows are sorted, so
+// "same row `off` lanes back" implies the whole span is that row) plus a carry from the previous
+// chunk.  A run that lies inside the slab is written by its last edge.  Runs cut by a slab boundary
+// leave partial sums in head[] / tail[] and degree_stitch_kernel adds them up in slab order, so the
+// result is deterministic.  Skipped (no-op) when *unsorted is set.
+constexpr int kDegChunks = 16;
+constexpr int kDegSlab = 64 * kDegChunks;
+constexpr int kDegEndsLeft = 1;   // the slab's leading run started in an earlier slab and ends here
+constexpr int kDegThrough = 2;    // the whole slab is the middle of one run
 __global__ __launch_bounds__(256) void degree_sorted_kernel(const int64_t* __restrict__ row,
                                                             const float* __restrict__ w, int64_t E,
                                                             const int* __restrict__ unsorted,
+                                                            float* __restrict__ deg, float* __restrict__ head,
+                                                            float* __restrict__ tail, int* __restrict__ slab_flags) {
+  if (*unsorted) return;
+  const int64_t slab = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int64_t start = slab * kDegSlab;
+  if (start >= E) return;
+  const int64_t row_first = row[start];
+  const bool open_left = start > 0 && row[start - 1] == row_first;
+  float carry_sum = 0.f;
+  int64_t carry_row = -1;
+  int flags = 0;
+  for (int c = 0; c < kDegChunks; ++c) {
+    const int64_t e = start + c * 64 + lane;
+    if (start + c * 64 >= E) break;  // wave-uniform
+    const bool valid = e < E;
+    const int64_t r = valid ? row[e] : -2;
+    const int64_t rn = (e + 1 < E) ? row[e + 1] : -3;
+    float v = valid ? w[e] : 0.f;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float pv = __shfl_up(v, off);
+      const int64_t pr = __shfl_up(r, off);
+      if (lane >= off && pr == r) v = __fadd_rn(pv, v);
+    }
+    if (r == carry_row) v = __fadd_rn(carry_sum, v);
+    if (valid && rn != r) {
+      if (open_left && r == row_first) {
+        head[slab] = v;
+        flags = kDegEndsLeft;
+      } else {
+        deg[r] = v;
+      }
+    }
+    carry_sum = __shfl(v, 63);
+    carry_row = __shfl(r, 63);
+  }
+  // The run still open at the slab's right edge (carry_row == -2 when the list ended inside it).
+  const int64_t end = start + kDegSlab;
+  const bool open_right = end < E && row[end] == carry_row;
+  if (open_right) {
+    if (open_left && carry_row == row_first) {
+      head[slab] = carry_sum;
+      flags = kDegThrough;
+    } else {
+      tail[slab] = carry_sum;
+    }
+  }
+  if (__any(flags & kDegEndsLeft)) flags |= kDegEndsLeft;
+  if (lane == 0) slab_flags[slab] = flags;
+}
+
+// One wave per slab whose leading run ends there: walk back over the "through" slabs to the slab
+// the run started in and add the partial sums (fixed reduction tree -> deterministic).
+__global__ __launch_bounds__(256) void degree_stitch_kernel(const int64_t* __restrict__ row, int64_t E,
+                                                            const int* __restrict__ unsorted,
+                                                            const float* __restrict__ head,
+                                                            const float* __restrict__ tail,
+                                                            const int* __restrict__ slab_flags,
                                                             float* __restrict__ deg) {
   if (*unsorted) return;
-  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (e >= E) return;
-  const int64_t r = row[e];
-  if (e > 0 && row[e - 1] == r) return;
+  const int64_t slab = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (slab * kDegSlab >= E || !(slab_flags[slab] & kDegEndsLeft)) return;
   float acc = 0.f;
-  for (int64_t j = e; j < E && row[j] == r; ++j) acc = __fadd_rn(acc, w[j]);
-  deg[r] = acc;
+  int64_t t = slab - 1;
+  for (;;) {
+    const int64_t mine = t - lane;
+    const bool through = mine >= 0 && (slab_flags[mine] & kDegThrough);
+    const unsigned long long stop = __ballot(!through);
+    const int first_stop = stop ? __ffsll(static_cast<long long>(stop)) - 1 : 64;
+    float part = 0.f;
+    if (lane < first_stop) part = head[mine];
+    else if (lane == first_stop) part = tail[mine];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part = __fadd_rn(part, __shfl_xor(part, off));
+    acc = __fadd_rn(part, acc);
+    if (stop) break;
+    t -= 64;
+  }
+  if (lane == 0) deg[row[slab * kDegSlab]] = __fadd_rn(acc, head[slab]);
 }
 
 __global__ __launch_bounds__(256) void degree_fallback_kernel(const int64_t* __restrict__ row,
@@ -415,8 +495,9 @@ __global__ __launch_bounds__(256) void degree_fallback_kernel(const int64_t* __r
                                                               const int* __restrict__ unsorted,
                                                               float* __restrict__ deg) {
   if (!*unsorted) return;
-  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (e < E) atomicAdd(&deg[row[e]], w[e]);
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < E;
+       e += static_cast<int64_t>(gridDim.x) * 256)
+    atomicAdd(&deg[row[e]], w[e]);
 }
 
 __global__ __launch_bounds__(256) void degree_scale_kernel(const int64_t* __restrict__ row,
@@ -433,12 +514,77 @@ __global__ __launch_bounds__(256) void degree_scale_kernel(const int64_t* __rest
 }
 
 // |w| is non-negative, so its IEEE bit pattern orders like an unsigned int: exact, order-free max.
+// A batch has few graphs, so one atomic per edge would serialise on a handful of addresses
+// (113 ms at E = 10M, 8 graphs).  Each thread instead walks a contiguous slice of the list keeping a
+// running (graph, max) pair -- rows are normally sorted, so the graph id changes a few times per
+// slice at most -- and a wave whose lanes all ended on the same graph issues a single atomic.
+constexpr int kGraphMaxPerThread = 16;
 __global__ __launch_bounds__(256) void graph_max_kernel(const int64_t* __restrict__ row,
                                                         const float* __restrict__ w, int64_t E,
                                                         const int64_t* __restrict__ batch_pooled,
                                                         uint32_t* __restrict__ gmax) {
-  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (e < E) atomicMax(&gmax[batch_pooled[row[e]]], __float_as_uint(fabsf(w[e])));
+  __shared__ int64_t s_g[4];
+  __shared__ uint32_t s_m[4];
+  // Lane-interleaved inside a wave-sized slab so loads stay coalesced.
+  const int wave_in_block = threadIdx.x >> 6;
+  const int64_t wave = static_cast<int64_t>(blockIdx.x) * 4 + wave_in_block;
+  const int lane = threadIdx.x & 63;
+  const int64_t base = wave * (64 * kGraphMaxPerThread) + lane;
+  // All loads first (independent), then the running (graph, max) fold.
+  int64_t g[kGraphMaxPerThread];
+  uint32_t v[kGraphMaxPerThread];
+#pragma unroll
+  for (int i = 0; i < kGraphMaxPerThread; ++i) {
+    const int64_t e = base + static_cast<int64_t>(i) * 64;
+    g[i] = e < E ? row[e] : -1;
+    v[i] = e < E ? __float_as_uint(fabsf(w[e])) : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < kGraphMaxPerThread; ++i) g[i] = g[i] >= 0 ? batch_pooled[g[i]] : -1;
+  int64_t g_cur = -1;
+  uint32_t m_cur = 0;
+#pragma unroll
+  for (int i = 0; i < kGraphMaxPerThread; ++i) {
+    if (g[i] < 0) continue;
+    if (g[i] != g_cur) {
+      if (g_cur >= 0 && m_cur > gmax[g_cur]) atomicMax(&gmax[g_cur], m_cur);
+      g_cur = g[i];
+      m_cur = v[i];
+    } else {
+      m_cur = m_cur > v[i] ? m_cur : v[i];
+    }
+  }
+  // Wave, then block: when everyone ended on the same graph a single atomic covers 4096 edges.
+  // gmax only grows, so a (possibly stale) plain read that already covers the candidate lets us
+  // skip the atomic altogether.
+  const int64_t g0 = __shfl(g_cur, 0);
+  const bool wave_uniform = __all(g_cur == g0 || g_cur < 0);
+  if (wave_uniform) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint32_t o = __shfl_xor(m_cur, off);
+      m_cur = m_cur > o ? m_cur : o;
+    }
+  } else if (g_cur >= 0 && m_cur > gmax[g_cur]) {
+    atomicMax(&gmax[g_cur], m_cur);
+  }
+  if (lane == 0) {
+    s_g[wave_in_block] = wave_uniform ? g0 : -1;
+    s_m[wave_in_block] = wave_uniform ? m_cur : 0u;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool block_uniform = s_g[0] >= 0 && (s_g[1] == s_g[0] || s_g[1] < 0) &&
+                               (s_g[2] == s_g[0] || s_g[2] < 0) && (s_g[3] == s_g[0] || s_g[3] < 0);
+    if (block_uniform) {
+      uint32_t m = s_m[0];
+      for (int k = 1; k < 4; ++k) m = m > s_m[k] ? m : s_m[k];
+      if (m > gmax[s_g[0]]) atomicMax(&gmax[s_g[0]], m);
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (s_g[k] >= 0 && s_m[k] > gmax[s_g[k]]) atomicMax(&gmax[s_g[k]], s_m[k]);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void graph_max_scale_kernel(const int64_t* __restrict__ row,
@@ -748,9 +894,10 @@ extern "C" int tgp_connect_coalesce_fill(const void* ws, int64_t E, int64_t N, i
 }
 
 // ------------------------------------------------------------------------------------- norms
-extern "C" size_t tgp_postprocess_sparse_workspace_bytes(int64_t /*E*/, int64_t num_nodes, int64_t num_graphs) {
+extern "C" size_t tgp_postprocess_sparse_workspace_bytes(int64_t E, int64_t num_nodes, int64_t num_graphs) {
+  const size_t slabs = static_cast<size_t>(cdiv(E > 0 ? E : 1, kDegSlab));
   return align_up((num_nodes > 0 ? num_nodes : 1) * sizeof(float)) +
-         align_up((num_graphs > 0 ? num_graphs : 1) * sizeof(uint32_t)) + 512;
+         align_up((num_graphs > 0 ? num_graphs : 1) * sizeof(uint32_t)) + 3 * align_up(slabs * sizeof(float)) + 512;
 }
 
 extern "C" int tgp_postprocess_sparse_norm_f32(const int64_t* row, const int64_t* col, float* w, int64_t E,
@@ -765,21 +912,31 @@ extern "C" int tgp_postprocess_sparse_norm_f32(const int64_t* row, const int64_t
   Carver cv(ws);
   float* deg = cv.take<float>(num_nodes > 0 ? num_nodes : 1);
   uint32_t* gmax = cv.take<uint32_t>(num_graphs > 0 ? num_graphs : 1);
+  const int64_t slabs = cdiv(E, kDegSlab);
+  float* head = cv.take<float>(slabs);
+  float* tail = cv.take<float>(slabs);
+  int* slab_flags = cv.take<int>(slabs);
   int* unsorted = cv.take<int>(4);
   const int nb = cdiv(E, 256);
   if (flags & TGP_DEGREE_NORM) {
     (void)hipMemsetAsync(deg, 0, static_cast<size_t>(num_nodes) * sizeof(float), stream);
     (void)hipMemsetAsync(unsorted, 0, sizeof(int), stream);
     hipLaunchKernelGGL(check_sorted_rows_kernel, dim3(nb), dim3(256), 0, stream, row, E, unsorted);
-    hipLaunchKernelGGL(degree_sorted_kernel, dim3(nb), dim3(256), 0, stream, row, w, E, unsorted, deg);
-    hipLaunchKernelGGL(degree_fallback_kernel, dim3(nb), dim3(256), 0, stream, row, w, E, unsorted, deg);
+    const int slab_blocks = cdiv(slabs, 4);
+    hipLaunchKernelGGL(degree_sorted_kernel, dim3(slab_blocks), dim3(256), 0, stream, row, w, E, unsorted, deg, head,
+                       tail, slab_flags);
+    hipLaunchKernelGGL(degree_stitch_kernel, dim3(slab_blocks), dim3(256), 0, stream, row, E, unsorted, head, tail,
+                       slab_flags, deg);
+    hipLaunchKernelGGL(degree_fallback_kernel, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, stream, row, w, E,
+                       unsorted, deg);
     hipLaunchKernelGGL(degree_scale_kernel, dim3(nb), dim3(256), 0, stream, row, col, w, E, deg);
   }
   if (flags & TGP_EDGE_WEIGHT_NORM) {
     TGP_REQUIRE(batch_pooled && num_graphs > 0, TGP_ERR_INVALID,
                 "tgp_postprocess_sparse_norm_f32: batch_pooled required for edge_weight_norm");
     (void)hipMemsetAsync(gmax, 0, static_cast<size_t>(num_graphs) * sizeof(uint32_t), stream);
-    hipLaunchKernelGGL(graph_max_kernel, dim3(nb), dim3(256), 0, stream, row, w, E, batch_pooled, gmax);
+    hipLaunchKernelGGL(graph_max_kernel, dim3(cdiv(E, 256 * kGraphMaxPerThread)), dim3(256), 0, stream, row, w, E,
+                       batch_pooled, gmax);
     hipLaunchKernelGGL(graph_max_scale_kernel, dim3(nb), dim3(256), 0, stream, row, w, E, batch_pooled, gmax);
   }
   return check_launch("tgp_postprocess_sparse_norm_f32");
