@@ -173,9 +173,13 @@ int tgp_bmm_f32(const float* A, const float* Bm, float* C, int64_t batch, int64_
 
 /* A3' / A7'  un-padded batch (reduce/base_reduce.py:170-182, connect/dense_conn.py:195-206):
  * C[b] = S_b^T Y_b where graph b owns node rows ptr[b]..ptr[b+1] of S [Ntot,K] and Y [Ntot,F].
- * One launch instead of the reference's Python loop over graphs. max_nodes = max_b (ptr[b+1]-ptr[b]). */
+ * One launch instead of the reference's Python loop over graphs. max_nodes = max_b (ptr[b+1]-ptr[b]).
+ * Long graphs are split along their node range across workgroups; the partial products live in the
+ * workspace and are added in a fixed order. */
+size_t tgp_segment_gemm_tn_workspace_bytes(int64_t B, int64_t K, int64_t F, int64_t max_nodes);
 int tgp_segment_gemm_tn_f32(const float* S, const float* Y, const int64_t* ptr, float* C, int64_t B,
-                            int64_t Ntot, int64_t K, int64_t F, int64_t max_nodes, void* stream);
+                            int64_t Ntot, int64_t K, int64_t F, int64_t max_nodes, void* ws, size_t ws_bytes,
+                            void* stream);
 
 /* ----------------------------------------------------------------------------------
  * N3  auxiliary losses of the dense poolers, fused.

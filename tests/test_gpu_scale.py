@@ -427,3 +427,21 @@ def test_postprocess_dense_flag_grid(dev, K):
         want = O.postprocess_dense(raw.clone(), rsl, deg, tr, ewn)
         got = postprocess_adj_pool_dense(raw.to(dev), rsl, deg, tr, ewn).cpu()
         torch.testing.assert_close(got, want, rtol=RTOL, atol=ATOL, msg=lambda m: f"flags {rsl, deg, tr, ewn}: {m}")
+
+
+@pytest.mark.parametrize("K,F", [(128, 64), (16, 32), (13, 7), (64, 130)])
+def test_segment_gemm_long_ragged_graphs(dev, K, F):
+    """A3'/A7' (reduce/base_reduce.py:170-182): per-graph S_b^T Y_b when graphs are few, long and ragged, so the
+    node range is split across workgroups (some splits of the short graphs are empty)."""
+    from tgp import kernels as KK
+    g = torch.Generator().manual_seed(K * 1000 + F)
+    sizes = torch.tensor([5000, 3, 1, 2047, 8192, 129])
+    ptr = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)])
+    n = int(sizes.sum())
+    s = torch.softmax(torch.randn(n, K, generator=g), -1)
+    y = torch.randn(n, F, generator=g)
+    got = KK.segment_gemm_tn(s.to(dev), y.to(dev), ptr.to(dev), int(sizes.max())).cpu()
+    for b in range(sizes.numel()):
+        lo, hi = int(ptr[b]), int(ptr[b + 1])
+        ref = (s[lo:hi].double().t() @ y[lo:hi].double()).float()
+        torch.testing.assert_close(got[b], ref, rtol=1e-5, atol=2e-5)

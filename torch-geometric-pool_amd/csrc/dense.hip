@@ -443,11 +443,14 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
   TGP_STAMP(3);
 }
 
-static bool gemm_aligned(const GemmArgs& g) {
+// k_rows: both operands are stored one k per row (A k-major, Bm [Kd][Nc]); then a k range may start and
+// end anywhere (segment products over ptr[b]..ptr[b+1]) without breaking 16-byte alignment.
+static bool gemm_aligned(const GemmArgs& g, bool k_rows) {
   auto ok = [](const void* p, long ld, long s) {
     return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 4 == 0) && (s % 4 == 0);
   };
-  bool a = ok(g.A, g.lda, g.sA) && (g.M % 4 == 0) && (g.Kd % 4 == 0) && (g.k_per_split % 4 == 0) && !g.k_ptr;
+  bool a = ok(g.A, g.lda, g.sA) && (g.M % 4 == 0);
+  if (!k_rows) a = a && (g.Kd % 4 == 0) && (g.k_per_split % 4 == 0) && !g.k_ptr;
   // the aligned path addresses each batch element through a buffer descriptor with 32-bit byte offsets
   const long lim = (1l << 31) - 4096;
   a = a && (static_cast<long>(g.M) * g.lda * 4 < lim) && (static_cast<long>(g.Kd) * g.lda * 4 < lim);
@@ -487,7 +490,7 @@ static void launch_gemm_cfg(const GemmArgs& g_in, int batches, hipStream_t strea
   const GemmArgs& g = g_in;
   const int nwg = batches * g.splits * g.tiles_m * g.tiles_n;
   const size_t lds = 2 * (BM * LDA_ROWMAJOR + (MODE == 1 ? BN * LDA_ROWMAJOR : BK * BN)) * sizeof(float);
-  if (gemm_aligned(g))
+  if (gemm_aligned(g, A_KMAJOR && MODE == 0))
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, true, BM, BN, MODE, WN>), dim3(nwg), dim3(BM * 2 * WN), lds, stream, g);
   else
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, false, BM, BN, MODE, WN>), dim3(nwg), dim3(BM * 2 * WN), lds, stream, g);
@@ -1366,24 +1369,58 @@ extern "C" int tgp_bmm_f32(const float* A, const float* Bm, float* C, int64_t ba
 // A3' / A7' (reduce/base_reduce.py:170-182, connect/dense_conn.py:195-206): per-graph S_b^T Y_b for an
 // un-padded batch.  Graph b owns node rows ptr[b]..ptr[b+1] of S [Ntot,K] and Y [Ntot,F]; C is [B,K,F].
 // Replaces the reference's Python loop over graphs with one launch (no padding, no densification).
+// Graphs are few and long in the unbatched modes (e.g. 2 graphs of 8192 nodes), so the node range of a graph
+// is split across workgroups like the batched path does; the partial products go to slabs [B][splits][K][F]
+// and are added in split order (deterministic).
+static int segment_splits(int64_t B, int64_t K, int64_t F, int64_t span) {
+  const int64_t tiles = ((K + 63) / 64) * ((F + 63) / 64);
+  const int64_t wgs = (B > 0 ? B : 1) * tiles;
+  int64_t splits = (3 * 256 + wgs - 1) / wgs;                       // aim at ~3 workgroups per CU
+  const int64_t max_splits = (span + 4 * BK - 1) / (4 * BK);        // keep >= 4 k-steps per workgroup
+  if (splits > max_splits) splits = max_splits;
+  if (splits > 64) splits = 64;
+  return splits < 1 ? 1 : static_cast<int>(splits);
+}
+
+extern "C" size_t tgp_segment_gemm_tn_workspace_bytes(int64_t B, int64_t K, int64_t F, int64_t max_nodes) {
+  if (B <= 0 || K <= 0 || F <= 0) return 256;
+  const int splits = segment_splits(B, K, F, max_nodes);
+  return (splits > 1 ? align_up(static_cast<size_t>(B) * splits * K * F * sizeof(float)) : 0) + 256;
+}
+
 extern "C" int tgp_segment_gemm_tn_f32(const float* S, const float* Y, const int64_t* ptr, float* C, int64_t B,
-                                       int64_t Ntot, int64_t K, int64_t F, int64_t max_nodes, void* stream_) {
+                                       int64_t Ntot, int64_t K, int64_t F, int64_t max_nodes, void* ws,
+                                       size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && Ntot >= 0 && K >= 0 && F >= 0, TGP_ERR_INVALID, "tgp_segment_gemm_tn_f32: negative size");
   if (B == 0 || K == 0 || F == 0) return TGP_OK;
   TGP_REQUIRE(C && ptr && (Ntot == 0 || (S && Y)), TGP_ERR_INVALID, "tgp_segment_gemm_tn_f32: null pointer");
   TGP_REQUIRE(Ntot < (1ll << 31) && K < (1ll << 31) && F < (1ll << 31), TGP_ERR_RANGE,
               "tgp_segment_gemm_tn_f32: too large");
+  const int64_t span = max_nodes > 0 ? max_nodes : Ntot;
+  const int splits = segment_splits(B, K, F, span);
+  TGP_REQUIRE(splits == 1 || (ws && ws_bytes >= tgp_segment_gemm_tn_workspace_bytes(B, K, F, max_nodes)),
+              TGP_ERR_WORKSPACE, "tgp_segment_gemm_tn_f32: workspace too small");
+  TGP_REQUIRE(B * splits * ((K + 63) / 64) * ((F + 63) / 64) < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_segment_gemm_tn_f32: grid too large");
+  float* slab = splits > 1 ? static_cast<float*>(ws) : C;
   GemmArgs g{};
   g.A = S; g.lda = K; g.sA = 0;
   g.M = static_cast<int>(K); g.Kd = static_cast<int>(Ntot);
-  g.rhs[0] = GemmRhs{Y, C, static_cast<int>(F), F, F, 0, K * F, 0};
-  g.splits = 1;
-  const int64_t span = max_nodes > 0 ? max_nodes : Ntot;
-  g.k_per_split = static_cast<int>((span + BK - 1) / BK * BK);
-  if (g.k_per_split < BK) g.k_per_split = BK;
+  g.rhs[0] = GemmRhs{Y, slab, static_cast<int>(F), F, F, 0, static_cast<long>(splits) * K * F, K * F};
+  g.splits = splits;
+  int64_t kps = ((span + splits - 1) / splits + BK - 1) / BK * BK;
+  if (kps < BK) kps = BK;
+  g.k_per_split = static_cast<int>(kps);
   g.k_ptr = ptr;
   launch_gemm<true>(g, static_cast<int>(B), stream);
+  if (splits > 1) {
+    const long total = K * F;
+    int gx = static_cast<int>((total + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(combine_slabs_kernel, dim3(gx, static_cast<unsigned>(B)), dim3(256), 0, stream, slab, splits,
+                       K * F, static_cast<long>(splits) * K * F, total, C);
+  }
   return check_launch("tgp_segment_gemm_tn_f32");
 }
 

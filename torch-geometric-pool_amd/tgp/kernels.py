@@ -337,8 +337,10 @@ def segment_gemm_tn(s: Tensor, y: Tensor, ptr: Tensor, max_nodes: int) -> Tensor
     B = ptr.numel() - 1
     K, F = s.size(1), y.size(1)
     out = torch.empty(B, K, F, dtype=torch.float32, device=dev)
-    N.check(N.lib().tgp_segment_gemm_tn_f32(N.ptr(s), N.ptr(y), N.ptr(ptr), N.ptr(out), B, s.size(0), K, F,
-                                            max_nodes, N.stream_ptr(dev)), "tgp_segment_gemm_tn_f32")
+    L = N.lib()
+    ws = N.workspace(L.tgp_segment_gemm_tn_workspace_bytes(B, K, F, max_nodes), dev)
+    N.check(L.tgp_segment_gemm_tn_f32(N.ptr(s), N.ptr(y), N.ptr(ptr), N.ptr(out), B, s.size(0), K, F,
+                                      max_nodes, N.ptr(ws), ws.numel(), N.stream_ptr(dev)), "tgp_segment_gemm_tn_f32")
     return out
 
 
