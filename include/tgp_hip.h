@@ -181,6 +181,13 @@ int tgp_segment_gemm_tn_f32(const float* S, const float* Y, const int64_t* ptr, 
                             int64_t Ntot, int64_t K, int64_t F, int64_t max_nodes, void* ws, size_t ws_bytes,
                             void* stream);
 
+/* Row-side counterpart on the same un-padded batch: C[rows of graph b] = A[rows of graph b] Bm[b] with
+ * A [Ntot,Kd], Bm [B,Kd,Nc], C [Ntot,Nc].  BaseLift on dense [N,K] assignments with a batch vector
+ * (lift/base_lift.py:138-247 loops over graphs) and the backward of tgp_segment_gemm_tn_f32
+ * (dS_b = Y_b G_b^T, dY_b = S_b G_b). */
+int tgp_segment_gemm_nn_f32(const float* A, const float* Bm, const int64_t* ptr, float* C, int64_t B,
+                            int64_t Ntot, int64_t Kd, int64_t Nc, int64_t max_nodes, void* stream);
+
 /* ----------------------------------------------------------------------------------
  * N3  auxiliary losses of the dense poolers, fused.
  *

@@ -79,3 +79,191 @@ def test_topk_pooler_trains(dev):
     out.x.pow(2).sum().backward()
     grad = pool.selector.weight.grad
     assert grad is not None and torch.isfinite(grad).all() and grad.abs().sum() > 0
+
+
+# --------------------------------------------------------------------------- un-padded (unbatched) mode
+def _ragged_batch(dev, sizes):
+    sizes = torch.tensor(sizes)
+    batch = torch.repeat_interleave(torch.arange(sizes.numel()), sizes).to(dev)
+    ptr = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)]).to(dev)
+    return sizes, batch, ptr
+
+
+@pytest.mark.parametrize("Kd,Nc", [(12, 8), (13, 7), (128, 64)])
+def test_segment_gemm_nn_forward(dev, Kd, Nc):
+    """C[rows of b] = A[rows of b] M_b against a per-graph loop (lift/base_lift.py:205-215)."""
+    from tgp import kernels as KK
+    g = torch.Generator(device=dev).manual_seed(Kd)
+    sizes, batch, ptr = _ragged_batch(dev, [70, 1, 300, 64, 129])
+    a = torch.randn(int(sizes.sum()), Kd, device=dev, generator=g)
+    m = torch.randn(sizes.numel(), Kd, Nc, device=dev, generator=g)
+    got = KK.segment_gemm_nn(a, m, ptr, int(sizes.max()))
+    ref = torch.cat([(a[int(ptr[b]):int(ptr[b + 1])].double() @ m[b].double()).float() for b in range(sizes.numel())])
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-4)
+
+
+def test_unbatched_reduce_connect_gradients(dev):
+    """S [N,K] + batch vector + sparse (non-symmetric, weighted, duplicated) A: X' = S_b^T X_b,
+    A' = S_b^T A_b S_b (reduce/base_reduce.py:170-182, connect/dense_conn.py:140-208) and their gradients
+    w.r.t. S, X and the edge weights against torch autograd on the densified problem."""
+    from tgp.connect import DenseConnect
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    g = torch.Generator(device=dev).manual_seed(3)
+    sizes, batch, ptr = _ragged_batch(dev, [40, 7, 65, 33])
+    n, K, F, B = int(sizes.sum()), 6, 5, sizes.numel()
+    rows, cols = [], []
+    for b in range(B):
+        lo, nb = int(ptr[b]), int(sizes[b])
+        e = 4 * nb
+        rows.append(lo + torch.randint(0, nb, (e,), device=dev, generator=g))
+        cols.append(lo + torch.randint(0, nb, (e,), device=dev, generator=g))
+    ei = torch.stack([torch.cat(rows), torch.cat(cols)])
+    ei = torch.cat([ei, ei[:, :50]], 1)  # duplicates are summed
+    ei = ei[:, torch.randperm(ei.size(1), device=dev, generator=g)]
+    w0 = torch.rand(ei.size(1), device=dev, generator=g) + 0.1
+    S0 = torch.softmax(torch.randn(n, K, device=dev, generator=g), -1)
+    X0 = torch.randn(n, F, device=dev, generator=g)
+    wx = torch.randn(B * K, F, device=dev, generator=g)
+    wa = torch.randn(B, K, K, device=dev, generator=g)
+
+    def run(native):
+        S, X, w = (t.clone().requires_grad_(True) for t in (S0, X0, w0))
+        if native:
+            so = SelectOutput(s=S, batch=batch)
+            xp, _ = BaseReduce()(X, so, batch=batch)
+            ap, _ = DenseConnect(remove_self_loops=True, degree_norm=True, adj_transpose=False)(
+                ei, so, edge_weight=w, batch=batch)
+        else:
+            A = torch.zeros(n, n, device=dev).index_put((ei[0], ei[1]), w, accumulate=True)
+            xs, as_ = [], []
+            for b in range(B):
+                lo, hi = int(ptr[b]), int(ptr[b + 1])
+                xs.append(S[lo:hi].t() @ X[lo:hi])
+                as_.append(S[lo:hi].t() @ A[lo:hi, lo:hi] @ S[lo:hi])
+            xp, raw = torch.cat(xs), torch.stack(as_)
+            raw = raw * (1 - torch.eye(K, device=dev))
+            d = torch.sqrt(raw.sum(-1, keepdim=True).clamp(min=1e-8))
+            ap = (raw / d) / d.transpose(-2, -1)
+        ((xp * wx).sum() + (ap * wa).sum()).backward()
+        return xp.detach(), ap.detach(), S.grad, X.grad, w.grad
+
+    got, ref = run(True), run(False)
+    for a, b, name in zip(got, ref, ("x_pool", "adj_pool", "dS", "dX", "dw")):
+        torch.testing.assert_close(a, b, msg=lambda m: f"{name}: {m}", **TOL)
+
+
+def test_unbatched_sparse_output_gradients(dev):
+    """DenseConnect(sparse_output=True) on unbatched inputs: the block-diagonal edge weights carry gradients
+    back to S through the export and the sparse normalisations (connect/dense_conn.py:329-354)."""
+    from tgp.connect import DenseConnect
+    from tgp.select import SelectOutput
+    g = torch.Generator(device=dev).manual_seed(4)
+    sizes, batch, ptr = _ragged_batch(dev, [20, 31])
+    n, K, B = int(sizes.sum()), 4, 2
+    A = torch.zeros(n, n, device=dev)
+    for b in range(B):
+        lo, hi = int(ptr[b]), int(ptr[b + 1])
+        blk = (torch.rand(hi - lo, hi - lo, device=dev, generator=g) < 0.2).float()
+        A[lo:hi, lo:hi] = torch.triu(blk, 1) + torch.triu(blk, 1).t()
+    ei = A.nonzero().t().contiguous()
+    S0 = torch.softmax(torch.randn(n, K, device=dev, generator=g), -1)
+    bp = torch.arange(B, device=dev).repeat_interleave(K)
+
+    S = S0.clone().requires_grad_(True)
+    out_ei, out_w = DenseConnect(remove_self_loops=True, degree_norm=True, edge_weight_norm=True, sparse_output=True)(
+        ei, SelectOutput(s=S, batch=batch), batch=batch, batch_pooled=bp)
+    coef = torch.randn(out_w.numel(), device=dev, generator=g)
+    (out_w * coef).sum().backward()
+
+    S2 = S0.clone().requires_grad_(True)
+    raw = torch.stack([S2[int(ptr[b]):int(ptr[b + 1])].t() @ A[int(ptr[b]):int(ptr[b + 1]), int(ptr[b]):int(ptr[b + 1])]
+                       @ S2[int(ptr[b]):int(ptr[b + 1])] for b in range(B)])
+    raw = raw * (1 - torch.eye(K, device=dev))
+    d = raw.sum(-1, keepdim=True).clamp(min=1e-8).pow(-0.5)  # row sums of the block-diagonal list
+    nrm = raw * d * d.transpose(-2, -1)
+    nrm = nrm / nrm.abs().amax(dim=(1, 2), keepdim=True)
+    b_i, r_i, c_i = out_ei[0] // K, out_ei[0] % K, out_ei[1] % K
+    ref_w = nrm[b_i, r_i, c_i]
+    (ref_w * coef).sum().backward()
+    torch.testing.assert_close(out_w.detach(), ref_w.detach(), **TOL)
+    torch.testing.assert_close(S.grad, S2.grad, **TOL)
+
+
+def test_lift_gradients(dev):
+    """BaseLift in its three layouts (lift/base_lift.py:102-111, 138-247): sparse S, dense batched S, dense
+    [N,K] S with a multi-graph batch vector; gradients w.r.t. x_pool (and the assignment where it is dense)."""
+    from tgp.lift import BaseLift
+    from tgp.select import SelectOutput
+    g = torch.Generator(device=dev).manual_seed(5)
+    # sparse
+    n, k, f = 300, 70, 6
+    cluster = torch.randint(0, k, (n,), device=dev, generator=g)
+    cluster[:k] = torch.arange(k, device=dev)
+    w = torch.rand(n, device=dev, generator=g) + 0.5
+    so = SelectOutput(cluster_index=cluster, num_nodes=n, num_supernodes=k, weight=w)
+    xp = torch.randn(k, f, device=dev, generator=g, requires_grad=True)
+    go = torch.randn(n, f, device=dev, generator=g)
+    out = BaseLift(matrix_op="transpose")(xp, so)
+    (out * go).sum().backward()
+    xp2 = xp.detach().clone().requires_grad_(True)
+    ref = xp2[cluster] * w.view(-1, 1)
+    (ref * go).sum().backward()
+    torch.testing.assert_close(out.detach(), ref.detach(), **TOL)
+    torch.testing.assert_close(xp.grad, xp2.grad, **TOL)
+    # dense batched
+    B, N, K = 3, 50, 7
+    S = torch.softmax(torch.randn(B, N, K, device=dev, generator=g), -1).requires_grad_(True)
+    xp = torch.randn(B, K, f, device=dev, generator=g, requires_grad=True)
+    go = torch.randn(B, N, f, device=dev, generator=g)
+    out = BaseLift(matrix_op="transpose")(xp, SelectOutput(s=S))
+    (out * go).sum().backward()
+    S2, xp2 = S.detach().clone().requires_grad_(True), xp.detach().clone().requires_grad_(True)
+    ((S2 @ xp2) * go).sum().backward()
+    torch.testing.assert_close(out.detach(), (S2 @ xp2).detach(), **TOL)
+    torch.testing.assert_close(S.grad, S2.grad, **TOL)
+    torch.testing.assert_close(xp.grad, xp2.grad, **TOL)
+    # dense [N,K] with a batch vector
+    sizes, batch, ptr = _ragged_batch(dev, [40, 3, 66])
+    n, Bn = int(sizes.sum()), 3
+    S = torch.softmax(torch.randn(n, K, device=dev, generator=g), -1).requires_grad_(True)
+    xp = torch.randn(Bn * K, f, device=dev, generator=g, requires_grad=True)
+    go = torch.randn(n, f, device=dev, generator=g)
+    out = BaseLift(matrix_op="transpose")(xp, SelectOutput(s=S, batch=batch), batch=batch)
+    (out * go).sum().backward()
+    S2, xp2 = S.detach().clone().requires_grad_(True), xp.detach().clone().requires_grad_(True)
+    ref = torch.cat([S2[int(ptr[b]):int(ptr[b + 1])] @ xp2.view(Bn, K, f)[b] for b in range(Bn)])
+    (ref * go).sum().backward()
+    torch.testing.assert_close(out.detach(), ref.detach(), **TOL)
+    torch.testing.assert_close(S.grad, S2.grad, **TOL)
+    torch.testing.assert_close(xp.grad, xp2.grad, **TOL)
+
+
+@pytest.mark.parametrize("alias", ["diff", "mincut"])
+def test_unbatched_pooler_parameter_gradients_match_batched(dev, alias):
+    """The `_u` poolers train like the batched ones: same parameters, same graphs => same parameter gradients
+    through Select -> Reduce -> Connect -> losses (reference pin 11 compares the forward values only)."""
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(6)
+    sizes = [30, 45, 38]
+    xs, eis, bs, off = [], [], [], 0
+    for gi, n in enumerate(sizes):
+        a = torch.triu(torch.rand(n, n, generator=g) < 0.15, 1)
+        a = a | a.t()
+        eis.append(a.nonzero().t() + off)
+        xs.append(torch.randn(n, 16, generator=g))
+        bs.append(torch.full((n,), gi))
+        off += n
+    x, ei, b = torch.cat(xs).to(dev), torch.cat(eis, 1).to(dev), torch.cat(bs).to(dev)
+    pb = get_pooler(alias, in_channels=16, k=8).to(dev)
+    pu = get_pooler(alias + "_u", in_channels=16, k=8).to(dev)
+    pu.load_state_dict(pb.state_dict())
+    grads = []
+    for p in (pb, pu):
+        out = p(x=x, adj=ei, batch=b)
+        adj = out.edge_index
+        loss = out.x.pow(2).sum() + adj.pow(2).sum() + sum(out.loss.values())
+        loss.backward()
+        grads.append([q.grad.clone() for q in p.parameters()])
+    for ga, gb in zip(*grads):
+        torch.testing.assert_close(ga, gb, rtol=1e-3, atol=1e-4)

@@ -1,0 +1,78 @@
+"""End-to-end pooler calls (Select + Reduce + Connect [+ losses, + backward]) at scale: wall time per call.
+Finds host overhead / syncs / slow helper ops around the native kernels."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "torch-geometric-pool_amd"))
+from tgp.poolers import get_pooler  # noqa: E402
+
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+only = sys.argv[1:] or None
+
+
+def wall(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def sparse_graph(n, deg, graphs):
+    src = torch.arange(n, device=dev).repeat_interleave(deg // 2)
+    per = n // graphs
+    dst = (src // per) * per + torch.randint(0, per, (src.numel(),), device=dev, generator=g)
+    ei = torch.cat([torch.stack([src, dst]), torch.stack([dst, src])], 1)
+    ei = ei[:, torch.argsort(ei[0] * n + ei[1])]
+    batch = torch.arange(n, device=dev) // per
+    return ei, batch
+
+
+def run(name, pooler, x, ei, ew, batch, train):
+    pooler = pooler.to(dev)
+    params = [p for p in pooler.parameters()]
+
+    def step():
+        xx = x.detach().requires_grad_(train)
+        if train:
+            out = pooler(x=xx, adj=ei, edge_weight=ew, batch=batch)
+            loss = out.x.sum()
+            if out.loss:
+                loss = loss + sum(out.loss.values())
+            loss.backward()
+            for p in params:
+                p.grad = None
+        else:
+            with torch.no_grad():
+                pooler(x=xx, adj=ei, edge_weight=ew, batch=batch)
+    print(f"{name:58s} {'fwd+bwd' if train else 'fwd    '} {wall(step):9.3f} ms", flush=True)
+
+
+cases = []
+n, F = 1_000_000, 128
+ei, batch = sparse_graph(n, 10, 8)
+x = torch.randn(n, F, device=dev, generator=g)
+ew = torch.rand(ei.size(1), device=dev, generator=g) + 0.1
+cases.append(("topk N=1M E=10M F=128", lambda: get_pooler("topk", in_channels=F, ratio=0.5), x, ei, ew, batch))
+cases.append(("graclus N=1M E=10M F=128", lambda: get_pooler("graclus"), x, ei, ew, batch))
+n2, F2 = 32 * 1024, 64
+ei2, batch2 = sparse_graph(n2, 16, 32)
+x2 = torch.randn(n2, F2, device=dev, generator=g)
+for nm in ("diff", "mincut", "diff_u", "mincut_u"):
+    cases.append((f"{nm} B=32 N=1024 K=128 F=64 (sparse input)", (lambda nm=nm: get_pooler(nm, in_channels=F2, k=128)),
+                  x2, ei2, None, batch2))
+for name, mk, xx, e, w, b in cases:
+    if only and not any(o in name for o in only):
+        continue
+    for train in (False, True):
+        try:
+            run(name, mk(), xx, e, w, b, train)
+        except Exception as ex:  # noqa: BLE001
+            print(f"{name:58s} {'fwd+bwd' if train else 'fwd    '} FAILED: {type(ex).__name__}: {ex}", flush=True)

@@ -62,6 +62,8 @@ struct GemmArgs {
   int splits;              // split of Kd across workgroups
   int k_per_split;         // multiple of BK
   const int64_t* k_ptr;    // optional [batches+1]: batch b reduces over rows k_ptr[b]..k_ptr[b+1]
+  const int64_t* m_ptr;    // optional [batches+1] (row-major A only): batch b owns rows m_ptr[b]..m_ptr[b+1] of
+                           // A and C (M = the longest range; sA = sC = 0) -- per-graph products on an un-padded batch
   // MODE 1 only (residual epilogue): nothing is stored; each workgroup writes sum((resid - C)^2) of its tile
   const float* resid;
   long ldr, sR;
@@ -150,6 +152,14 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
   const long lda = g.lda, ldb = R.ldb;
 
   const int m0 = tm * BM, n0 = tn * BN;
+  int M = g.M;
+  if (g.m_ptr) {
+    const long m_lo = g.m_ptr[batch];
+    M = static_cast<int>(g.m_ptr[batch + 1] - m_lo);
+    if (m0 >= M) return;  // workgroup-uniform: this graph is shorter than the longest one
+    A += m_lo * lda;
+    C += m_lo * R.ldc;
+  }
   int k_lo = 0, k_hi = g.Kd;
   if (g.k_ptr) {
     k_lo = static_cast<int>(g.k_ptr[batch]);
@@ -173,8 +183,8 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
   [[maybe_unused]] int voff_a[A_VECS], voff_b[B_VECS];
   [[maybe_unused]] int kloc_a[A_VECS], kloc_b[B_VECS];  // this lane's k offset inside a stage (for the tail)
   if constexpr (ALIGNED) {
-    const int a_bytes = A_KMAJOR ? (static_cast<int>(g.Kd - 1) * static_cast<int>(lda) + g.M) * 4
-                                 : (static_cast<int>(g.M - 1) * static_cast<int>(lda) + g.Kd) * 4;
+    const int a_bytes = A_KMAJOR ? (static_cast<int>(g.Kd - 1) * static_cast<int>(lda) + M) * 4
+                                 : (static_cast<int>(M - 1) * static_cast<int>(lda) + g.Kd) * 4;
     const int b_bytes = MODE == 1 ? (static_cast<int>(Nc - 1) * static_cast<int>(ldb) + g.Kd) * 4
                                   : (static_cast<int>(g.Kd - 1) * static_cast<int>(ldb) + Nc) * 4;
     rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, a_bytes, 0x00020000);
@@ -184,11 +194,11 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
       if constexpr (!A_KMAJOR) {
         const int m = m0 + tile_row((tid >> 3) + i * (THREADS / 8));
         kloc_a[i] = (tid & 7) * 4;
-        voff_a[i] = m < g.M ? (m * static_cast<int>(lda) + kloc_a[i]) * 4 : OOB;
+        voff_a[i] = m < M ? (m * static_cast<int>(lda) + kloc_a[i]) * 4 : OOB;
       } else {
         const int m = m0 + (tid % AK_LANES) * 4;
         kloc_a[i] = tid / AK_LANES + i * (THREADS / AK_LANES);
-        voff_a[i] = m < g.M ? (kloc_a[i] * static_cast<int>(lda) + m) * 4 : OOB;
+        voff_a[i] = m < M ? (kloc_a[i] * static_cast<int>(lda) + m) * 4 : OOB;
       }
     }
 #pragma unroll
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
       float t[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bool ok = A_KMAJOR ? (k < k_end && m + j < g.M) : (m < g.M && k + j < k_end);
+        const bool ok = A_KMAJOR ? (k < k_end && m + j < M) : (m < M && k + j < k_end);
         t[j] = ok ? p[j] : 0.f;
       }
       return make_float4(t[0], t[1], t[2], t[3]);
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        rres[j][r] = (row < g.M && col < Nc) ? Rm[static_cast<long>(row) * g.ldr + col] : 0.f;
+        rres[j][r] = (row < M && col < Nc) ? Rm[static_cast<long>(row) * g.ldr + col] : 0.f;
       }
     }
   }
@@ -437,7 +447,7 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (row < g.M && col < Nc) C[static_cast<long>(row) * R.ldc + col] = acc[j][r];
+      if (row < M && col < Nc) C[static_cast<long>(row) * R.ldc + col] = acc[j][r];
     }
   }
   TGP_STAMP(3);
@@ -449,7 +459,8 @@ static bool gemm_aligned(const GemmArgs& g, bool k_rows) {
   auto ok = [](const void* p, long ld, long s) {
     return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 4 == 0) && (s % 4 == 0);
   };
-  bool a = ok(g.A, g.lda, g.sA) && (g.M % 4 == 0);
+  // row-major A (m_ptr mode) is only ever read along k, so ragged row ranges keep every vector aligned
+  bool a = ok(g.A, g.lda, g.sA) && (g.M % 4 == 0 || g.m_ptr);
   if (!k_rows) a = a && (g.Kd % 4 == 0) && (g.k_per_split % 4 == 0) && !g.k_ptr;
   // the aligned path addresses each batch element through a buffer descriptor with 32-bit byte offsets
   const long lim = (1l << 31) - 4096;
@@ -1422,6 +1433,30 @@ extern "C" int tgp_segment_gemm_tn_f32(const float* S, const float* Y, const int
                        K * F, static_cast<long>(splits) * K * F, total, C);
   }
   return check_launch("tgp_segment_gemm_tn_f32");
+}
+
+// Row-side counterpart (lift/base_lift.py:138-247 on an un-padded batch; backward of the products above):
+// C[rows of graph b] = A[rows of graph b] Bm[b], A [Ntot,Kd], Bm [B,Kd,Nc], C [Ntot,Nc]; one launch.
+extern "C" int tgp_segment_gemm_nn_f32(const float* A, const float* Bm, const int64_t* ptr, float* C, int64_t B,
+                                       int64_t Ntot, int64_t Kd, int64_t Nc, int64_t max_nodes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && Ntot >= 0 && Kd >= 0 && Nc >= 0, TGP_ERR_INVALID, "tgp_segment_gemm_nn_f32: negative size");
+  if (B == 0 || Ntot == 0 || Nc == 0) return TGP_OK;
+  TGP_REQUIRE(C && ptr && (Kd == 0 || (A && Bm)), TGP_ERR_INVALID, "tgp_segment_gemm_nn_f32: null pointer");
+  TGP_REQUIRE(Ntot < (1ll << 31) && Kd < (1ll << 31) && Nc < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_segment_gemm_nn_f32: too large");
+  const int64_t span = max_nodes > 0 ? max_nodes : Ntot;
+  TGP_REQUIRE(B * ((span + 63) / 64) * ((Nc + 63) / 64) < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_segment_gemm_nn_f32: grid too large");
+  GemmArgs g{};
+  g.A = A; g.lda = Kd; g.sA = 0;
+  g.M = static_cast<int>(span); g.Kd = static_cast<int>(Kd);
+  g.rhs[0] = GemmRhs{Bm, C, static_cast<int>(Nc), Nc, Nc, Kd * Nc, 0, 0};
+  g.splits = 1; g.k_per_split = static_cast<int>((Kd + BK - 1) / BK * BK);
+  if (g.k_per_split < BK) g.k_per_split = BK;
+  g.m_ptr = ptr;
+  launch_gemm<false>(g, static_cast<int>(B), stream);
+  return check_launch("tgp_segment_gemm_nn_f32");
 }
 
 // N3: DiffPool's link-prediction residual ||A - S S^T||_F^2 per graph (utils/losses.py:644-708 computes

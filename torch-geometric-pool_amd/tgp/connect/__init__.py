@@ -7,6 +7,7 @@ from typing import Optional, Tuple
 import torch
 from torch import Tensor
 
+from .. import functions as Fn
 from .. import kernels as K
 from ..imports import is_sparsetensor
 from ..select import SelectOutput
@@ -194,13 +195,12 @@ class DenseConnect(Connect):
         # duplicates are SUMMED by the reference's per-graph `.coalesce()`, also for unweighted input
         ew = torch.ones(ei.size(1), device=ei.device) if ew is None else ew.view(-1)
         # sorted + duplicate-summed A (what `.coalesce()` does per graph), then T = A S, then S_b^T T_b
-        ident = torch.arange(num_nodes, device=ei.device)
-        ei, ew = K.coalesce_edges(ei, ew, ident, num_nodes, "sum", remove_self_loops=False, eps_filter=False)
-        t = K.spmm_sorted(ei, ew, num_nodes, s)
+        ei, ew = Fn.coalesce_sum(ei, ew, num_nodes)
+        t = Fn.spmm_sorted(ei, ew, num_nodes, s)
         if batch_size == 1:
-            return K.bmm(s, t, trans_a=True).unsqueeze(0)
+            return Fn.bmm(s, t, trans_a=True).unsqueeze(0)
         sizes, ptr = graph_ptr(batch, batch_size)
-        return K.segment_gemm_tn(s, t, ptr, int(sizes.max()))
+        return Fn.segment_gemm_tn(s, t, ptr, int(sizes.max()))
 
     def forward(self, edge_index, so: SelectOutput, *, edge_weight: Optional[Tensor] = None,
                 batch: Optional[Tensor] = None, batch_pooled: Optional[Tensor] = None, **kwargs):
@@ -235,7 +235,7 @@ class DenseConnect(Connect):
             raise AssertionError("edge_weight_norm=True but batch_pooled=None. batch_pooled parameter is "
                                  "required for per-graph normalization in DenseConnect.")
         num_supernodes = batch_size * num_clusters
-        ei, ew = K.block_diag_edges(adj_dense, None, self.remove_self_loops)
+        ei, ew = Fn.block_diag_edges(adj_dense, None, self.remove_self_loops)
         ei, ew = _normalize_pooled_edges(ei, ew, num_supernodes, self.degree_norm, self.edge_weight_norm,
                                          batch_pooled)
         return _restore_format(edge_index, ei, ew, num_supernodes)

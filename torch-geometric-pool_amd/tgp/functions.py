@@ -1,0 +1,239 @@
+"""Differentiable wrappers of the native products that the operators compose.
+
+The reference gets its gradients from ATen autograd over ``matmul`` / ``scatter`` / sparse ``mm``; the native
+kernels are opaque to autograd, so each product used on a trainable path has an explicit backward here, itself
+made of the same native kernels.  Every wrapper calls the kernel directly when nothing requires grad.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import kernels as K
+
+
+def _needs_grad(*ts) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(t, Tensor) and t.requires_grad for t in ts)
+
+
+# --------------------------------------------------------------------------------------- batched GEMM
+class _BmmFn(torch.autograd.Function):
+    """C = op(A) B.  trans_a False: dA = dC B^T, dB = A^T dC.  trans_a True (A stored [Kd,M]): dA = B dC^T, dB = A dC."""
+
+    @staticmethod
+    def forward(ctx, a, b, trans_a):
+        ctx.save_for_backward(a, b)
+        ctx.trans_a = trans_a
+        return K.bmm(a, b, trans_a)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            if ctx.trans_a:
+                ga = K.bmm(b, g.transpose(-1, -2).contiguous())
+            else:
+                ga = K.bmm(g, b.transpose(-1, -2).contiguous())
+            ga = _unbroadcast(ga, a)
+        if ctx.needs_input_grad[1]:
+            gb = K.bmm(a, g) if ctx.trans_a else K.bmm(a, g, trans_a=True)
+            gb = _unbroadcast(gb, b)
+        return ga, gb, None
+
+
+def _unbroadcast(grad: Tensor, like: Tensor) -> Tensor:
+    """Undo K.bmm's batch broadcasting (a 2-D or batch-1 operand against a batched one)."""
+    if grad.dim() == 3 and like.dim() == 2:
+        return grad.sum(0)
+    if grad.dim() == 3 and like.dim() == 3 and like.size(0) == 1 and grad.size(0) != 1:
+        return grad.sum(0, keepdim=True)
+    return grad
+
+
+def bmm(a: Tensor, b: Tensor, trans_a: bool = False) -> Tensor:
+    return _BmmFn.apply(a, b, trans_a) if _needs_grad(a, b) else K.bmm(a, b, trans_a)
+
+
+# ------------------------------------------------------------------------- products on an un-padded batch
+class _SegmentGemmTnFn(torch.autograd.Function):
+    """C[b] = S_b^T Y_b (reduce/base_reduce.py:170-182, connect/dense_conn.py:195-206).
+    dS_b = Y_b dC_b^T, dY_b = S_b dC_b: two row-side segment products."""
+
+    @staticmethod
+    def forward(ctx, s, y, ptr, max_nodes):
+        ctx.save_for_backward(s, y, ptr)
+        ctx.max_nodes = max_nodes
+        return K.segment_gemm_tn(s, y, ptr, max_nodes)
+
+    @staticmethod
+    def backward(ctx, g):
+        s, y, ptr = ctx.saved_tensors
+        g = g.contiguous()
+        gs = gy = None
+        if ctx.needs_input_grad[0]:
+            gs = K.segment_gemm_nn(y, g.transpose(1, 2).contiguous(), ptr, ctx.max_nodes)
+        if ctx.needs_input_grad[1]:
+            gy = K.segment_gemm_nn(s, g, ptr, ctx.max_nodes)
+        return gs, gy, None, None
+
+
+def segment_gemm_tn(s: Tensor, y: Tensor, ptr: Tensor, max_nodes: int) -> Tensor:
+    if _needs_grad(s, y):
+        return _SegmentGemmTnFn.apply(s, y, ptr, max_nodes)
+    return K.segment_gemm_tn(s, y, ptr, max_nodes)
+
+
+class _SegmentGemmNnFn(torch.autograd.Function):
+    """C[rows of b] = A[rows of b] M_b (lift/base_lift.py:138-247).  dA = dC M_b^T (row side again),
+    dM_b = A_b^T dC_b (the reduction-side product)."""
+
+    @staticmethod
+    def forward(ctx, a, m, ptr, max_nodes):
+        ctx.save_for_backward(a, m, ptr)
+        ctx.max_nodes = max_nodes
+        return K.segment_gemm_nn(a, m, ptr, max_nodes)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, m, ptr = ctx.saved_tensors
+        g = g.contiguous()
+        ga = gm = None
+        if ctx.needs_input_grad[0]:
+            ga = K.segment_gemm_nn(g, m.transpose(1, 2).contiguous(), ptr, ctx.max_nodes)
+        if ctx.needs_input_grad[1]:
+            gm = K.segment_gemm_tn(a, g, ptr, ctx.max_nodes)
+        return ga, gm, None, None
+
+
+def segment_gemm_nn(a: Tensor, m: Tensor, ptr: Tensor, max_nodes: int) -> Tensor:
+    if _needs_grad(a, m):
+        return _SegmentGemmNnFn.apply(a, m, ptr, max_nodes)
+    return K.segment_gemm_nn(a, m, ptr, max_nodes)
+
+
+# --------------------------------------------------------------------------------------------- CSR SpMM
+class _SpmmFn(torch.autograd.Function):
+    """T = A S for a coalesced, row-sorted edge list (connect/dense_conn.py:165,204).
+    dS = A^T dT (the same kernel on the column-sorted list), dw_e = <dT[row_e], S[col_e]>."""
+
+    @staticmethod
+    def forward(ctx, edge_index, edge_weight, num_rows, s):
+        ctx.save_for_backward(edge_index, edge_weight, s)
+        ctx.num_rows = num_rows
+        return K.spmm_sorted(edge_index, edge_weight, num_rows, s)
+
+    @staticmethod
+    def backward(ctx, g):
+        edge_index, edge_weight, s = ctx.saved_tensors
+        g = g.contiguous()
+        gw = gs = None
+        if ctx.needs_input_grad[1]:
+            gw = (g[edge_index[0]] * s[edge_index[1]]).sum(-1)
+        if ctx.needs_input_grad[3]:
+            n = max(ctx.num_rows, s.size(0))
+            ident = torch.arange(n, device=s.device)
+            w = edge_weight if edge_weight is not None else torch.ones(edge_index.size(1), device=s.device)
+            # transpose = re-sort by column; the list is coalesced, so nothing merges
+            ei_t, w_t = K.coalesce_edges(edge_index.flip(0), w, ident, n, "sum", remove_self_loops=False,
+                                         eps_filter=False)
+            gs = K.spmm_sorted(ei_t, w_t, s.size(0), g)
+        return None, gw, None, gs
+
+
+def spmm_sorted(edge_index: Tensor, edge_weight: Optional[Tensor], num_rows: int, s: Tensor) -> Tensor:
+    if _needs_grad(edge_weight, s):
+        return _SpmmFn.apply(edge_index, edge_weight, num_rows, s)
+    return K.spmm_sorted(edge_index, edge_weight, num_rows, s)
+
+
+# ------------------------------------------------------------------------ duplicate-summing coalesce
+class _CoalescedWeightsFn(torch.autograd.Function):
+    """Weights of a sum-coalesced list as a function of the input weights: out[j] = sum of the inputs that
+    landed on entry j, so dw_e = dout[slot(e)].  The forward values come from the native kernel."""
+
+    @staticmethod
+    def forward(ctx, edge_weight, slot, out_values):
+        ctx.save_for_backward(slot)
+        return out_values.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (slot,) = ctx.saved_tensors
+        return g[slot], None, None
+
+
+def coalesce_sum(edge_index: Tensor, edge_weight: Tensor, num_nodes: int):
+    """Row-sorted, duplicate-summed copy of the list (what ``.coalesce()`` does, connect/dense_conn.py:163,202)."""
+    ident = torch.arange(num_nodes, device=edge_index.device)
+    ei, ew = K.coalesce_edges(edge_index, edge_weight, ident, num_nodes, "sum", remove_self_loops=False,
+                              eps_filter=False)
+    if _needs_grad(edge_weight) and ei.size(1) > 0:
+        slot = torch.searchsorted(ei[0] * num_nodes + ei[1], edge_index[0] * num_nodes + edge_index[1])
+        ew = _CoalescedWeightsFn.apply(edge_weight, slot, ew)
+    return ei, ew
+
+
+# ------------------------------------------------------------------------------------ block-diagonal export
+class _BlockDiagWeightsFn(torch.autograd.Function):
+    """Values of dense_to_block_diag (utils/ops.py:53-82) as a function of the dense tensor: a gather at the
+    positions the native compaction reported; backward scatters the edge gradients back."""
+
+    @staticmethod
+    def forward(ctx, adj, b, r, c):
+        ctx.save_for_backward(b, r, c)
+        ctx.shape = adj.shape
+        return adj[b, r, c]
+
+    @staticmethod
+    def backward(ctx, g):
+        b, r, c = ctx.saved_tensors
+        ga = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        ga[b, r, c] = g
+        return ga, None, None, None
+
+
+def block_diag_edges(adj_pool: Tensor, relabel: Optional[Tensor] = None, remove_self_loops: bool = False,
+                     inverse: Optional[Tensor] = None):
+    """``inverse``: new id -> flat supernode id b*K + k (needed with ``relabel`` to find the dense positions)."""
+    ei, ew = K.block_diag_edges(adj_pool, relabel, remove_self_loops)
+    if _needs_grad(adj_pool) and ei.size(1) > 0 and (relabel is None or inverse is not None):
+        a = adj_pool if adj_pool.dim() == 3 else adj_pool.unsqueeze(0)
+        k = a.size(1)
+        r, c = (ei[0], ei[1]) if relabel is None else (inverse[ei[0]], inverse[ei[1]])
+        b = torch.div(r, k, rounding_mode="floor")
+        ew = _BlockDiagWeightsFn.apply(a, b, r - b * k, c - b * k)
+    return ei, ew
+
+
+# ------------------------------------------------------------------------------------------ sparse Lift
+class _SparseLiftFn(torch.autograd.Function):
+    """X_lift[row] += v * X_pool[col] (lift/base_lift.py:102-111) = the sparse Reduce kernel with the roles of
+    node and supernode swapped; dX_pool is the Reduce itself, dv a row-dot."""
+
+    @staticmethod
+    def forward(ctx, x_pool, values, row, col, index, back_index_fn):
+        ctx.save_for_backward(x_pool, values, row, col)
+        ctx.back_index_fn = back_index_fn
+        return K.reduce_sparse(x_pool, col, values, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        x_pool, values, row, col = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gv = None
+        if ctx.needs_input_grad[0]:
+            gx = K.reduce_sparse(g, row, values, ctx.back_index_fn())
+        if ctx.needs_input_grad[1]:
+            gv = (g[row] * x_pool[col]).sum(-1)
+        return gx, gv, None, None, None, None
+
+
+def sparse_lift(x_pool: Tensor, values: Tensor, row: Tensor, col: Tensor, index, back_index_fn) -> Tensor:
+    """``index``: inverted index over ``row`` (output nodes); ``back_index_fn()``: the one over ``col``."""
+    if _needs_grad(x_pool, values):
+        return _SparseLiftFn.apply(x_pool, values, row, col, index, back_index_fn)
+    return K.reduce_sparse(x_pool, col, values, index)

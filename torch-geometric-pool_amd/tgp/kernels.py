@@ -344,6 +344,20 @@ def segment_gemm_tn(s: Tensor, y: Tensor, ptr: Tensor, max_nodes: int) -> Tensor
     return out
 
 
+def segment_gemm_nn(a: Tensor, bm: Tensor, ptr: Tensor, max_nodes: int) -> Tensor:
+    """C[rows of graph b] = A[rows of graph b] @ Bm[b] (lift/base_lift.py:138-247 on an un-padded batch; the
+    backward of :func:`segment_gemm_tn`) in one launch.  a: [Ntot,Kd], bm: [B,Kd,Nc]."""
+    dev = N.require_device(a, bm, ptr)
+    a, bm, ptr = N.f32c(a), N.f32c(bm), N.i64c(ptr)
+    B = ptr.numel() - 1
+    if bm.dim() != 3 or bm.size(0) != B or bm.size(1) != a.size(1):
+        raise ValueError(f"segment_gemm_nn: a {tuple(a.shape)} x bm {tuple(bm.shape)} with {B} graphs")
+    out = torch.empty(a.size(0), bm.size(2), dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_segment_gemm_nn_f32(N.ptr(a), N.ptr(bm), N.ptr(ptr), N.ptr(out), B, a.size(0), a.size(1),
+                                            bm.size(2), max_nodes, N.stream_ptr(dev)), "tgp_segment_gemm_nn_f32")
+    return out
+
+
 def spmm_sorted(edge_index: Tensor, edge_weight: Optional[Tensor], num_rows: int, s: Tensor) -> Tensor:
     """T = A S for a row-sorted (coalesced) edge list (connect/dense_conn.py:165,204)."""
     dev = N.require_device(edge_index, edge_weight, s)

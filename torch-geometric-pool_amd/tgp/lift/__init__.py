@@ -6,6 +6,7 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
+from .. import functions as Fn
 from .. import kernels as K
 from ..select import SelectOutput
 from ..utils.ops import build_pooled_batch, expand_compacted_rows, graph_ptr, is_multi_graph_batch, pseudo_inverse
@@ -60,7 +61,8 @@ class BaseLift(Lift):
         same = lift_matrix.size() == so.s.size() and row.numel() == so.node_index.numel() and (
             row.data_ptr() == so.node_index.data_ptr() or torch.equal(row, so.node_index))
         index = lift_index_of(so) if same else K.build_assign_index(row, lift_matrix.size(0))
-        return K.reduce_sparse(x_pool, col, lift_matrix.values(), index)
+        back = so.assign_index if same else (lambda: K.build_assign_index(col, lift_matrix.size(1)))
+        return Fn.sparse_lift(x_pool, lift_matrix.values(), row, col, index, back)
 
     @staticmethod
     def _lift_dense_multi_graph(lift_matrix, x_pool_flat, batch, batch_pooled) -> Tensor:
@@ -73,11 +75,8 @@ class BaseLift(Lift):
                              f"got {nb} assignment blocks and pooled blocks of sizes {counts.tolist()}.")
         xp = x_pool_flat.view(nb, k, -1)
         sizes, ptr = graph_ptr(batch, nb)
-        out = torch.empty(lift_matrix.size(0), xp.size(-1), dtype=torch.float32, device=lift_matrix.device)
-        for g, (lo, hi) in enumerate(zip(ptr[:-1].tolist(), ptr[1:].tolist())):  # one GEMM launch per graph
-            if hi > lo:
-                out[lo:hi] = K.bmm(lift_matrix[lo:hi], xp[g])
-        return out
+        # one launch over all graphs (the reference loops over them, base_lift.py:205-215)
+        return Fn.segment_gemm_nn(lift_matrix, xp, ptr, int(sizes.max()))
 
     def forward(self, x_pool: Tensor, so: SelectOutput = None, batch: Optional[Tensor] = None,
                 batch_pooled: Optional[Tensor] = None, **kwargs) -> Tensor:
@@ -91,7 +90,7 @@ class BaseLift(Lift):
         if m.dim() == 2 and x_pool.dim() == 2 and multi:
             nb = int(batch.max().item()) + 1
             if x_pool.size(0) == k:
-                return K.bmm(m, x_pool)
+                return Fn.bmm(m, x_pool)
             if x_pool.size(0) != nb * k:
                 raise ValueError("Unexpected pooled feature shape for dense [N, K] lifting with a multi-graph "
                                  f"batch: got x_pool.size(0)={x_pool.size(0)}, expected {k} or {nb * k}.")
@@ -103,7 +102,7 @@ class BaseLift(Lift):
             return self._lift_dense_multi_graph(m, x_pool, batch, batch_pooled)
         if m.dim() == 2 and x_pool.dim() == 3:
             if not multi:
-                return K.bmm(m, x_pool.squeeze(0))
+                return Fn.bmm(m, x_pool.squeeze(0))
             nb = x_pool.size(0)
             flat = x_pool.reshape(nb * k, x_pool.size(-1))
             if batch_pooled is None:
@@ -117,7 +116,7 @@ class BaseLift(Lift):
             if x_pool.size(0) != nb * k:
                 x_pool = expand_compacted_rows(x_pool, so.out_mask, nb * k)
             x_pool = x_pool.view(nb, k, x_pool.size(-1))
-        return K.bmm(m, x_pool)
+        return Fn.bmm(m, x_pool)
 
     def __repr__(self) -> str:
         return f"{self.__class__.__name__}(matrix_op={self.matrix_op}, reduce_op={self.reduce_op})"

@@ -6,6 +6,7 @@ from typing import Optional, Tuple
 import torch
 from torch import Tensor, nn
 
+from .. import functions as Fn
 from .. import kernels as K
 from ..select import SelectOutput
 from ..utils.ops import build_pooled_batch, graph_ptr, is_multi_graph_batch
@@ -59,11 +60,11 @@ class BaseReduce(Reduce):
             raise ValueError(f"Dense SelectOutput.s must be 2D [N, K] or 3D [B, N, K], got ndim={s.dim()}.")
         if is_multi_graph_batch(batch):
             sizes, ptr = graph_ptr(batch)
-            x_pool = K.segment_gemm_tn(s, x, ptr, int(sizes.max()))  # [B,K,F]
+            x_pool = Fn.segment_gemm_tn(s, x, ptr, int(sizes.max()))  # [B,K,F]
             if not return_batched:
                 x_pool = x_pool.reshape(-1, x_pool.size(-1))
             return x_pool, self.reduce_batch(so, batch)
-        x_pool = K.bmm(s, x, trans_a=True)  # [K,F]
+        x_pool = Fn.bmm(s, x, trans_a=True)  # [K,F]
         if return_batched:
             x_pool = x_pool.unsqueeze(0)
         return x_pool, self.reduce_batch(so, batch)

@@ -9,6 +9,7 @@ from typing import Dict, Iterator, List, Optional, Tuple, Union
 import torch
 from torch import Tensor
 
+from . import functions as Fn
 from . import kernels as K
 from .connect import Connect
 from .imports import HAS_PYG
@@ -321,13 +322,13 @@ class DenseSRCPooling(SRCPooling):
         if batch_pooled is None and out_mask is not None:
             batch_pooled = torch.zeros(B * Kc, dtype=torch.long, device=x_pool.device)
         if out_mask is None:
-            ei, ew = K.block_diag_edges(adj_pool)
+            ei, ew = Fn.block_diag_edges(adj_pool)
             return x_flat, ei, ew, batch_pooled
         valid = out_mask.reshape(-1)
         idx = valid.nonzero(as_tuple=True)[0]
         relabel = torch.full((B * Kc,), -1, dtype=torch.long, device=x_pool.device)
         relabel[idx] = torch.arange(idx.numel(), device=x_pool.device)
-        ei, ew = K.block_diag_edges(adj_pool, relabel)
+        ei, ew = Fn.block_diag_edges(adj_pool, relabel, inverse=idx)
         return x_flat[idx], ei, ew, batch_pooled[valid]
 
 

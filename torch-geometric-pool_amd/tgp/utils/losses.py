@@ -15,6 +15,7 @@ import torch
 from torch import Tensor
 
 from .. import eps
+from .. import functions as Fn
 from .. import kernels as K
 from .ops import check_and_filter_edge_weights
 
@@ -155,8 +156,9 @@ def sparse_mincut_loss(edge_index: Tensor, S: Tensor, edge_weight: Optional[Tens
 
 def _per_graph_gram(S: Tensor, batch: Tensor, nb: int) -> Tensor:
     """[B,K,K] stack of S_g^T S_g (batch is sorted, as everywhere in PyG-style batching)."""
-    sizes = torch.bincount(batch, minlength=nb).tolist()
-    return torch.stack([p.t().matmul(p) for p in S.split(sizes)])
+    sizes = torch.bincount(batch, minlength=nb)
+    ptr = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)])
+    return Fn.segment_gemm_tn(S, S, ptr, int(sizes.max()))  # one launch, no per-graph loop
 
 
 def unbatched_orthogonality_loss(S: Tensor, batch: Optional[Tensor] = None,

@@ -246,6 +246,20 @@ def _normalize_pooled_edges(edge_index, edge_weight, num_nodes, degree_norm, edg
     if degree_norm and edge_weight is None:
         edge_weight = torch.ones(edge_index.size(1), device=edge_index.device)
     do_ewn = edge_weight_norm and edge_weight is not None
+    if (degree_norm or do_ewn) and edge_index.size(1) > 0 and edge_weight.requires_grad and torch.is_grad_enabled():
+        # training through the pooled weights: differentiable torch form of the same arithmetic
+        w = edge_weight
+        if degree_norm:
+            deg = torch.zeros(num_nodes, dtype=w.dtype, device=w.device).index_add(0, edge_index[0], w)
+            dis = deg.clamp(min=eps).pow(-0.5)
+            w = w * dis[edge_index[0]] * dis[edge_index[1]]
+        if do_ewn:
+            eb = batch_pooled[edge_index[0]]
+            ng = int(eb.max()) + 1
+            mx = torch.zeros(ng, dtype=w.dtype, device=w.device).scatter_reduce(0, eb, w.abs(), "amax")
+            mx = torch.where(mx == 0, torch.ones_like(mx), mx)
+            w = w / mx[eb]
+        return edge_index, w
     if (degree_norm or do_ewn) and edge_index.size(1) > 0:
         if not edge_weight.is_contiguous() or edge_weight.dtype != torch.float32:
             edge_weight = edge_weight.to(torch.float32).contiguous()
