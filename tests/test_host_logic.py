@@ -181,3 +181,33 @@ def test_connect_argument_errors():
         so4.s = torch.rand(1, 1, 4, 2)
         BaseReduce()(torch.rand(4, 3), so4)
     assert so_dense.num_supernodes == 2
+
+
+def test_batch_info_memo_is_keyed_by_object_and_version():
+    """The per-batch-vector memo (graph count, sizes, offsets, longest graph) must never serve stale facts:
+    a different tensor object or an in-place write misses; trailing empty graphs are honoured."""
+    import gc
+
+    import torch
+    from tgp.utils.ops import batch_info, graph_ptr, is_multi_graph_batch, max_graph_size, num_graphs_of
+
+    b = torch.tensor([0, 0, 1, 1, 1, 3])
+    info = batch_info(b)
+    assert (info.num_graphs, info.max_nodes, info.distinct) == (4, 3, 3)
+    assert batch_info(b) is info  # same object, same version: memo hit
+    assert info.sizes.tolist() == [2, 3, 0, 1] and info.ptr.tolist() == [0, 2, 5, 5, 6]
+    b[5] = 1  # in-place write bumps the version counter
+    info2 = batch_info(b)
+    assert info2 is not info and (info2.num_graphs, info2.max_nodes, info2.distinct) == (2, 4, 2)
+    sizes, ptr = graph_ptr(b, 5)  # caller-supplied batch_size beyond max + 1
+    assert sizes.tolist() == [2, 4, 0, 0, 0] and ptr.tolist() == [0, 2, 6, 6, 6, 6]
+    # a new tensor that happens to reuse the Python id of a dead one must miss
+    for _ in range(50):
+        t = torch.randint(0, 7, (11,))
+        got = batch_info(t)
+        assert got.num_graphs == int(t.max()) + 1 and got.max_nodes == int(torch.bincount(t).max())
+        del t, got
+        gc.collect()
+    assert not is_multi_graph_batch(torch.tensor([2, 2, 2])) and num_graphs_of(torch.tensor([2, 2, 2])) == 3
+    assert is_multi_graph_batch(torch.tensor([0, 2])) and max_graph_size(torch.tensor([0, 2, 2])) == 2
+    assert num_graphs_of(None) == 1 and num_graphs_of(torch.zeros(0, dtype=torch.long)) == 1

@@ -71,7 +71,7 @@ for nm in ("diff", "mincut", "diff_u", "mincut_u"):
 for name, mk, xx, e, w, b in cases:
     if only and not any(o in name for o in only):
         continue
-    for train in (False, True):
+    for train in ((False, True) if not os.environ.get("E2E_MODE") else (os.environ["E2E_MODE"] == "train",)):
         try:
             run(name, mk(), xx, e, w, b, train)
         except Exception as ex:  # noqa: BLE001

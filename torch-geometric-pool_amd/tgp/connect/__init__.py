@@ -17,6 +17,8 @@ from ..utils.ops import (
     connectivity_to_sparsetensor,
     connectivity_to_torch_coo,
     graph_ptr,
+    max_graph_size,
+    num_graphs_of,
     is_dense_adj,
     maybe_num_nodes,
     postprocess_adj_pool_dense,
@@ -200,7 +202,7 @@ class DenseConnect(Connect):
         if batch_size == 1:
             return Fn.bmm(s, t, trans_a=True).unsqueeze(0)
         sizes, ptr = graph_ptr(batch, batch_size)
-        return Fn.segment_gemm_tn(s, t, ptr, int(sizes.max()))
+        return Fn.segment_gemm_tn(s, t, ptr, max_graph_size(batch))
 
     def forward(self, edge_index, so: SelectOutput, *, edge_weight: Optional[Tensor] = None,
                 batch: Optional[Tensor] = None, batch_pooled: Optional[Tensor] = None, **kwargs):
@@ -219,7 +221,7 @@ class DenseConnect(Connect):
         return K.dense_pool(s, adj, None, flags)[2], None
 
     def _forward_unbatched_inputs(self, edge_index, edge_weight, batch, s, batch_pooled):
-        batch_size = 1 if batch is None else int(batch.max().item()) + 1
+        batch_size = num_graphs_of(batch)
         if s.dim() == 3 and s.size(0) == 1:
             s = s.squeeze(0)
         elif s.dim() != 2:

@@ -9,7 +9,8 @@ from torch import Tensor, nn
 from .. import functions as Fn
 from .. import kernels as K
 from ..select import SelectOutput
-from ..utils.ops import build_pooled_batch, expand_compacted_rows, graph_ptr, is_multi_graph_batch, pseudo_inverse
+from ..utils.ops import (build_pooled_batch, expand_compacted_rows, graph_ptr, is_multi_graph_batch, max_graph_size,
+                         num_graphs_of, pseudo_inverse)
 
 
 def lift_index_of(so: SelectOutput):
@@ -67,7 +68,7 @@ class BaseLift(Lift):
     @staticmethod
     def _lift_dense_multi_graph(lift_matrix, x_pool_flat, batch, batch_pooled) -> Tensor:
         """Per-graph M_b X_pool_b for an un-padded batch: rows of graph b use the K pooled rows of b."""
-        nb = int(batch.max()) + 1
+        nb = num_graphs_of(batch)
         k = lift_matrix.size(-1)
         counts = torch.bincount(batch_pooled, minlength=nb)
         if counts.numel() != nb or not bool((counts == k).all()):
@@ -76,7 +77,7 @@ class BaseLift(Lift):
         xp = x_pool_flat.view(nb, k, -1)
         sizes, ptr = graph_ptr(batch, nb)
         # one launch over all graphs (the reference loops over them, base_lift.py:205-215)
-        return Fn.segment_gemm_nn(lift_matrix, xp, ptr, int(sizes.max()))
+        return Fn.segment_gemm_nn(lift_matrix, xp, ptr, max_graph_size(batch))
 
     def forward(self, x_pool: Tensor, so: SelectOutput = None, batch: Optional[Tensor] = None,
                 batch_pooled: Optional[Tensor] = None, **kwargs) -> Tensor:
@@ -88,7 +89,7 @@ class BaseLift(Lift):
         k = m.size(-1)
         multi = is_multi_graph_batch(batch)
         if m.dim() == 2 and x_pool.dim() == 2 and multi:
-            nb = int(batch.max().item()) + 1
+            nb = num_graphs_of(batch)
             if x_pool.size(0) == k:
                 return Fn.bmm(m, x_pool)
             if x_pool.size(0) != nb * k:

@@ -204,11 +204,11 @@ class DiffPool(_DenseMLPPooling):
     def _batched_connect_and_loss(self, x, adj, so, mask, edge_weight, batch, batch_pooled):
         adj_pool, _ = self.connect(edge_index=adj, so=so, edge_weight=edge_weight, batch=batch,
                                    batch_pooled=batch_pooled)
-        loss = self.compute_loss(adj=adj, S=so.s, num_nodes=mask.sum().item())
+        loss = self.compute_loss(adj=adj, S=so.s, num_nodes=mask.sum())  # 0-dim tensor: no host round trip
         return adj_pool, loss
 
     def _loss_from_fused(self, adj, so, mask, raw) -> dict:
-        return self.compute_loss(adj=adj, S=so.s, num_nodes=mask.sum().item())
+        return self.compute_loss(adj=adj, S=so.s, num_nodes=mask.sum())  # 0-dim tensor: no host round trip
 
     def compute_loss(self, adj: Tensor, S: Tensor, num_nodes: int) -> dict:
         return {"link_loss": link_pred_loss(S, adj, normalize_loss=self.normalize_loss) * self.link_loss_coeff,

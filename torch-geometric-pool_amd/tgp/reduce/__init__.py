@@ -9,7 +9,7 @@ from torch import Tensor, nn
 from .. import functions as Fn
 from .. import kernels as K
 from ..select import SelectOutput
-from ..utils.ops import build_pooled_batch, graph_ptr, is_multi_graph_batch
+from ..utils.ops import build_pooled_batch, graph_ptr, is_multi_graph_batch, max_graph_size, num_graphs_of
 
 
 class Reduce(nn.Module):
@@ -25,7 +25,7 @@ class Reduce(nn.Module):
                                          select_output.num_supernodes)
         if batch.numel() == 0:
             return batch.new_empty((0,), dtype=batch.dtype)
-        return build_pooled_batch(int(batch.max().item()) + 1, select_output.num_supernodes, batch.device,
+        return build_pooled_batch(num_graphs_of(batch), select_output.num_supernodes, batch.device,
                                   dtype=batch.dtype)
 
     def reset_parameters(self):
@@ -60,7 +60,7 @@ class BaseReduce(Reduce):
             raise ValueError(f"Dense SelectOutput.s must be 2D [N, K] or 3D [B, N, K], got ndim={s.dim()}.")
         if is_multi_graph_batch(batch):
             sizes, ptr = graph_ptr(batch)
-            x_pool = Fn.segment_gemm_tn(s, x, ptr, int(sizes.max()))  # [B,K,F]
+            x_pool = Fn.segment_gemm_tn(s, x, ptr, max_graph_size(batch))  # [B,K,F]
             if not return_batched:
                 x_pool = x_pool.reshape(-1, x_pool.size(-1))
             return x_pool, self.reduce_batch(so, batch)

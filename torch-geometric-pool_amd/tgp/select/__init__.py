@@ -20,6 +20,7 @@ from ..utils.ops import (
     connectivity_to_edge_index,
     get_mask_from_dense_s,
     graph_ptr,
+    num_graphs_of,
     maybe_num_nodes,
     pseudo_inverse,
 )
@@ -301,7 +302,7 @@ def topk(x: Tensor, ratio, batch: Tensor, min_score: Optional[float] = None, tol
     """Per-graph top-k node indices, graph-major and score-descending (the algorithm of PyG 2.6
     ``torch_geometric.nn.pool.select.topk.topk``, which the reference calls at
     select/topk_select.py:194)."""
-    nb = int(batch.max()) + 1 if batch.numel() else 0
+    nb = num_graphs_of(batch) if batch.numel() else 0
     if min_score is not None:
         floor = (_segment_max(x, batch, nb)[batch] - tol).clamp(max=min_score)
         return (x > floor).nonzero().view(-1)
@@ -372,7 +373,7 @@ class TopkSelect(Select):
         if self.min_score is None:
             score = self.act(score)
         else:  # segment softmax, +1e-16 in the denominator as PyG's utils.softmax
-            nb = int(batch.max()) + 1
+            nb = num_graphs_of(batch)
             e = (score - _segment_max(score.detach(), batch, nb)[batch]).exp()
             score = e / (e.new_zeros(nb).index_add_(0, batch, e) + 1e-16)[batch]
         node_index = topk(score, self.ratio, batch, self.min_score)

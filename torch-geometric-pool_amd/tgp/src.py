@@ -17,7 +17,7 @@ from .lift import Lift
 from .reduce import Reduce
 from .select import Select, SelectOutput
 from .utils import Signature, connectivity_to_edge_index, foo_signature
-from .utils.ops import build_pooled_batch, graph_ptr, is_dense_adj
+from .utils.ops import build_pooled_batch, graph_ptr, is_dense_adj, max_graph_size, num_graphs_of
 
 
 @dataclass
@@ -186,10 +186,10 @@ def to_dense_batch(x: Tensor, batch: Optional[Tensor] = None, max_num_nodes: Opt
     if batch is None:
         batch = x.new_zeros(x.size(0), dtype=torch.long)
     if batch_size is None:
-        batch_size = int(batch.max()) + 1
+        batch_size = num_graphs_of(batch)
     sizes, ptr = graph_ptr(batch, batch_size)
     if max_num_nodes is None:
-        max_num_nodes = int(sizes.max())
+        max_num_nodes = max_graph_size(batch)
     if x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad):
         return K.to_dense_batch(x, batch, ptr, batch_size, max_num_nodes)  # one HIP kernel
     local = torch.arange(batch.numel(), device=x.device) - ptr[batch]
@@ -211,17 +211,17 @@ def to_dense_adj(edge_index: Tensor, batch: Optional[Tensor] = None, edge_attr: 
         n = int(edge_index.max()) + 1 if edge_index.numel() > 0 else 0
         batch = edge_index.new_zeros(n)
     if batch_size is None:
-        batch_size = int(batch.max()) + 1 if batch.numel() > 0 else 1
+        batch_size = num_graphs_of(batch)
     sizes, ptr = graph_ptr(batch, batch_size)
     if (edge_index.is_cuda and (edge_attr is None or (edge_attr.dim() == 1 and edge_attr.dtype == torch.float32
                                                       and not (torch.is_grad_enabled() and edge_attr.requires_grad)))):
-        nmax = max_num_nodes if max_num_nodes is not None else (int(sizes.max()) if sizes.numel() else 0)
+        nmax = max_num_nodes if max_num_nodes is not None else max_graph_size(batch)
         return K.to_dense_adj(edge_index, edge_attr, batch, ptr, batch_size, nmax, transposed)  # one HIP kernel
     g = batch[edge_index[0]]
     r = edge_index[0] - ptr[g]
     c = edge_index[1] - ptr[batch[edge_index[1]]]
     if max_num_nodes is None:
-        max_num_nodes = int(sizes.max()) if sizes.numel() else 0
+        max_num_nodes = max_graph_size(batch)
     else:
         ok = (r < max_num_nodes) & (c < max_num_nodes)
         g, r, c = g[ok], r[ok], c[ok]

@@ -17,7 +17,7 @@ from torch import Tensor
 from .. import eps
 from .. import functions as Fn
 from .. import kernels as K
-from .ops import check_and_filter_edge_weights
+from .ops import check_and_filter_edge_weights, graph_ptr, max_graph_size, num_graphs_of
 
 
 def _reduce(loss: Tensor, how: str) -> Tensor:
@@ -145,8 +145,8 @@ def sparse_mincut_loss(edge_index: Tensor, S: Tensor, edge_weight: Optional[Tens
                        batch: Optional[Tensor] = None, batch_reduction: str = "mean") -> Tensor:
     n = S.size(0)
     w = _edge_weights(edge_index, edge_weight, S)
+    nb = num_graphs_of(batch)
     batch = _batch_or_zeros(batch, n, S.device)
-    nb = int(batch.max()) + 1
     deg = _seg_sum(w, edge_index[0], n)
     den = _seg_sum(deg * (S * S).sum(-1), batch, nb)
     contrib = w * (S[edge_index[0]] * S[edge_index[1]]).sum(-1)
@@ -154,18 +154,18 @@ def sparse_mincut_loss(edge_index: Tensor, S: Tensor, edge_weight: Optional[Tens
     return _reduce(-(num / (den + eps)), batch_reduction)
 
 
-def _per_graph_gram(S: Tensor, batch: Tensor, nb: int) -> Tensor:
-    """[B,K,K] stack of S_g^T S_g (batch is sorted, as everywhere in PyG-style batching)."""
-    sizes = torch.bincount(batch, minlength=nb)
-    ptr = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)])
-    return Fn.segment_gemm_tn(S, S, ptr, int(sizes.max()))  # one launch, no per-graph loop
+def _per_graph_gram(S: Tensor, batch: Optional[Tensor], nb: int) -> Tensor:
+    """[B,K,K] stack of S_g^T S_g (batch is sorted, as everywhere in PyG-style batching): one launch."""
+    if batch is None or nb == 1:
+        return Fn.bmm(S, S, trans_a=True).unsqueeze(0)
+    _, ptr = graph_ptr(batch, nb)
+    return Fn.segment_gemm_tn(S, S, ptr, max_graph_size(batch))
 
 
 def unbatched_orthogonality_loss(S: Tensor, batch: Optional[Tensor] = None,
                                  batch_reduction: str = "mean") -> Tensor:
     n, k = S.shape
-    batch = _batch_or_zeros(batch, n, S.device)
-    nb = int(batch.max()) + 1
+    nb = num_graphs_of(batch)
     gram = _per_graph_gram(S, batch, nb)
     gram = gram / torch.norm(gram, dim=(-2, -1), keepdim=True)
     target = torch.eye(k, device=S.device, dtype=S.dtype) / math.sqrt(k)
@@ -176,13 +176,15 @@ def sparse_link_pred_loss(S: Tensor, edge_index: Tensor, edge_weight: Optional[T
                           batch: Optional[Tensor] = None, normalize_loss: bool = True) -> Tensor:
     n = S.size(0)
     w = _edge_weights(edge_index, edge_weight, S)
-    batch = _batch_or_zeros(batch, n, S.device)
-    nb = int(batch.max()) + 1
+    nb = num_graphs_of(batch)
     ss = (S[edge_index[0]] * S[edge_index[1]]).sum(-1)
     gram = _per_graph_gram(S, batch, nb)
     # ||A - S S^T||_F^2 = sum_E (w - ss)^2 + sum_g ||S_g^T S_g||_F^2 - sum_E ss^2
     sq = ((w - ss) ** 2).sum() + (gram * gram).sum() - (ss ** 2).sum()
     loss = torch.sqrt(torch.clamp(sq, min=0.0))
-    sizes = torch.bincount(batch, minlength=nb)
-    numel = int((sizes * sizes).sum())
-    return loss / numel if normalize_loss and numel > 0 else loss
+    if not normalize_loss:
+        return loss
+    if batch is None:
+        return loss / (n * n) if n > 0 else loss
+    sizes, _ = graph_ptr(batch, nb)
+    return loss / (sizes * sizes).sum().clamp(min=1)  # stays on the device: no host round trip

@@ -34,15 +34,57 @@ def is_dense_adj(edge_index) -> bool:
     return edge_index.dim() == 2 and edge_index.size(0) == edge_index.size(1) and edge_index.is_floating_point()
 
 
+class BatchInfo:
+    """Host-side facts about a batch vector (number of graphs, graph sizes, CSR offsets, longest graph).
+    Reading them costs two device round trips; one pooler call asks for them in half a dozen places (dense
+    preprocessing, Reduce, Connect, Lift, the losses), so they are memoised per tensor OBJECT: the entry is
+    valid only while the weak reference still resolves to the very same tensor and its version counter has
+    not moved (an in-place write bumps it), which rules out stale hits from recycled memory."""
+
+    __slots__ = ("ref", "version", "num_graphs", "sizes", "ptr", "max_nodes", "distinct")
+
+
+_BATCH_INFO: dict = {}
+
+
+def batch_info(batch: Tensor) -> BatchInfo:
+    import weakref
+    hit = _BATCH_INFO.get(id(batch))
+    if hit is not None and hit.ref() is batch and hit.version == batch._version:
+        return hit
+    info = BatchInfo()
+    info.ref, info.version = weakref.ref(batch), batch._version
+    if batch.numel() == 0:
+        info.sizes = torch.zeros(0, dtype=torch.long, device=batch.device)
+        info.num_graphs, info.max_nodes, info.distinct = 0, 0, 0
+    else:
+        info.sizes = torch.bincount(batch)  # sync 1: the output length is max(batch) + 1
+        info.num_graphs = info.sizes.numel()
+        info.max_nodes, info.distinct = torch.stack([info.sizes.max(), (info.sizes > 0).sum()]).tolist()  # sync 2
+    info.ptr = torch.zeros(info.num_graphs + 1, dtype=torch.long, device=batch.device)
+    if info.num_graphs:
+        torch.cumsum(info.sizes, 0, out=info.ptr[1:])
+    if len(_BATCH_INFO) >= 16:  # a handful of live batch vectors at most; drop dead and old entries
+        for key in [k for k, v in _BATCH_INFO.items() if v.ref() is None]:
+            del _BATCH_INFO[key]
+        while len(_BATCH_INFO) >= 16:
+            del _BATCH_INFO[next(iter(_BATCH_INFO))]
+    _BATCH_INFO[id(batch)] = info
+    return info
+
+
 def is_multi_graph_batch(batch: Optional[Tensor]) -> bool:
     if batch is None or batch.numel() == 0:
         return False
-    lo, hi = torch.aminmax(batch)
-    return int(lo) != int(hi)
+    return batch_info(batch).distinct > 1
 
 
 def num_graphs_of(batch: Optional[Tensor]) -> int:
-    return 1 if batch is None or batch.numel() == 0 else int(batch.max()) + 1
+    return 1 if batch is None or batch.numel() == 0 else batch_info(batch).num_graphs
+
+
+def max_graph_size(batch: Tensor) -> int:
+    return batch_info(batch).max_nodes
 
 
 def build_pooled_batch(batch_size: int, num_supernodes: int, device, dtype: torch.dtype = torch.long) -> Tensor:
@@ -50,10 +92,12 @@ def build_pooled_batch(batch_size: int, num_supernodes: int, device, dtype: torc
 
 
 def graph_ptr(batch: Tensor, batch_size: Optional[int] = None) -> Tuple[Tensor, Tensor]:
-    """(sizes [B], ptr [B+1]) of a sorted batch vector."""
-    if batch_size is None:
-        batch_size = num_graphs_of(batch)
-    sizes = torch.bincount(batch, minlength=batch_size)
+    """(sizes [B], ptr [B+1]) of a sorted batch vector (``batch_size`` may exceed max(batch)+1: trailing
+    empty graphs)."""
+    info = batch_info(batch)
+    if batch_size is None or batch_size == info.num_graphs:
+        return info.sizes, info.ptr
+    sizes = torch.bincount(batch, minlength=batch_size)[:batch_size]
     ptr = torch.zeros(batch_size + 1, dtype=torch.long, device=batch.device)
     torch.cumsum(sizes, 0, out=ptr[1:])
     return sizes, ptr
@@ -155,7 +199,7 @@ def get_mask_from_dense_s(s: Tensor, batch: Optional[Tensor] = None) -> Tensor:
         return s.sum(dim=-2) > 0
     if batch is None:
         return (s.sum(dim=-2) > 0).unsqueeze(0)
-    nb = int(batch.max()) + 1
+    nb = num_graphs_of(batch)
     acc = s.new_zeros(nb, s.size(-1)).index_add_(0, batch, s)
     return acc > 0
 
