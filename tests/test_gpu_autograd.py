@@ -267,3 +267,40 @@ def test_unbatched_pooler_parameter_gradients_match_batched(dev, alias):
         grads.append([q.grad.clone() for q in p.parameters()])
     for ga, gb in zip(*grads):
         torch.testing.assert_close(ga, gb, rtol=1e-3, atol=1e-4)
+
+
+def test_to_dense_batch_and_linear_gradients(dev):
+    """Sparse -> padded-dense preprocessing (src.py:448-450) and the selector's Linear layer
+    (select/mlp_select.py:67) under autograd: native forward, gather / split-range backward."""
+    from tgp import functions as Fn
+    from tgp.src import to_dense_batch
+    g = torch.Generator(device=dev).manual_seed(7)
+    sizes, batch, ptr = _ragged_batch(dev, [5, 1, 9, 4])
+    n, f = int(sizes.sum()), 6
+    x0 = torch.randn(n, f, device=dev, generator=g)
+    for max_nodes in (None, 6):  # 6 truncates the 9-node graph: dropped nodes get zero gradient
+        x = x0.clone().requires_grad_(True)
+        out, mask = to_dense_batch(x, batch, max_num_nodes=max_nodes)
+        go = torch.randn(out.shape, device=dev, generator=g)
+        (out * go).sum().backward()
+        nmax = out.size(1)
+        local = torch.arange(n, device=dev) - ptr[batch]
+        keep = local < nmax
+        ref = torch.zeros(n, f, device=dev)
+        ref[keep] = go[batch[keep], local[keep]]
+        assert out.grad_fn is not None and not mask.requires_grad
+        torch.testing.assert_close(x.grad, ref, **TOL)
+        assert torch.equal(out[batch[keep], local[keep]], x0[keep])
+    # linear: [B,N,F] input, weight [K,F], bias
+    X0 = torch.randn(3, 700, 10, device=dev, generator=g)
+    W0 = torch.randn(12, 10, device=dev, generator=g)
+    b0 = torch.randn(12, device=dev, generator=g)
+    go = torch.randn(3, 700, 12, device=dev, generator=g)
+    res = []
+    for native in (True, False):
+        X, W, b = (t.clone().requires_grad_(True) for t in (X0, W0, b0))
+        y = Fn.linear(X, W, b) if native else torch.nn.functional.linear(X, W, b)
+        (y * go).sum().backward()
+        res.append((y.detach(), X.grad, W.grad, b.grad))
+    for a, r in zip(*res):
+        torch.testing.assert_close(a, r, rtol=1e-4, atol=1e-4)

@@ -168,6 +168,12 @@ class _CoalescedWeightsFn(torch.autograd.Function):
 
 def coalesce_sum(edge_index: Tensor, edge_weight: Tensor, num_nodes: int):
     """Row-sorted, duplicate-summed copy of the list (what ``.coalesce()`` does, connect/dense_conn.py:163,202)."""
+    if edge_index.size(1) > 0:
+        # PyG hands out coalesced lists; one fused comparison + the same single host round trip the count -> fill
+        # pair would cost tells us the sort can be skipped altogether
+        key = edge_index[0] * num_nodes + edge_index[1]
+        if bool((key[1:] > key[:-1]).all()):
+            return edge_index, edge_weight
     ident = torch.arange(num_nodes, device=edge_index.device)
     ei, ew = K.coalesce_edges(edge_index, edge_weight, ident, num_nodes, "sum", remove_self_loops=False,
                               eps_filter=False)
@@ -237,3 +243,79 @@ def sparse_lift(x_pool: Tensor, values: Tensor, row: Tensor, col: Tensor, index,
     if _needs_grad(x_pool, values):
         return _SparseLiftFn.apply(x_pool, values, row, col, index, back_index_fn)
     return K.reduce_sparse(x_pool, col, values, index)
+
+
+# ------------------------------------------------------------------------------- sparse -> padded dense
+class _ToDenseBatchFn(torch.autograd.Function):
+    """to_dense_batch (src.py:448-450) with the native scatter forward; the backward is the matching gather
+    (torch's own backward of the indexed assignment sorts the indices first)."""
+
+    @staticmethod
+    def forward(ctx, x, batch, ptr, num_graphs, max_nodes):
+        out, mask = K.to_dense_batch(x, batch, ptr, num_graphs, max_nodes)
+        ctx.save_for_backward(batch, ptr)
+        ctx.max_nodes = max_nodes
+        ctx.mark_non_differentiable(mask)
+        return out, mask
+
+    @staticmethod
+    def backward(ctx, g, _gmask):
+        batch, ptr = ctx.saved_tensors
+        local = torch.arange(batch.numel(), device=batch.device) - ptr[batch]
+        flat = g.reshape((-1,) + tuple(g.shape[2:]))
+        keep = local < ctx.max_nodes  # nodes beyond a caller-imposed max_num_nodes were dropped in the forward
+        gx = flat[(batch * ctx.max_nodes + local).clamp(max=flat.size(0) - 1)]
+        gx = gx * keep.view((-1,) + (1,) * (gx.dim() - 1)).to(gx.dtype)
+        return gx, None, None, None, None
+
+
+def to_dense_batch(x: Tensor, batch: Tensor, ptr: Tensor, num_graphs: int, max_nodes: int):
+    if _needs_grad(x):
+        return _ToDenseBatchFn.apply(x, batch, ptr, num_graphs, max_nodes)
+    return K.to_dense_batch(x, batch, ptr, num_graphs, max_nodes)
+
+
+# ---------------------------------------------------------------------------------------- Linear layer
+_WHOLE_RANGE: dict = {}
+
+
+def _whole_range(n: int, device) -> Tensor:
+    key = (n, str(device))
+    if key not in _WHOLE_RANGE:
+        if len(_WHOLE_RANGE) > 64:
+            _WHOLE_RANGE.clear()
+        _WHOLE_RANGE[key] = torch.tensor([0, n], dtype=torch.long, device=device)
+    return _WHOLE_RANGE[key]
+
+
+class _LinearFn(torch.autograd.Function):
+    """Y = X W^T + b of the selector MLP (select/mlp_select.py:67).  Forward and dX are plain library GEMMs;
+    dW = dY^T X reduces over every node of the batch into a tiny [out,in] matrix, which the library runs as a
+    handful of workgroups (136 us at 32768 x 64 -> 128) -- here it is the node-range-split segment product."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        g2 = g.reshape(-1, g.size(-1))
+        if ctx.needs_input_grad[0]:
+            gx = g.matmul(weight)
+        if ctx.needs_input_grad[1]:
+            x2 = x.reshape(-1, x.size(-1))
+            n = x2.size(0)
+            gw = K.segment_gemm_tn(g2, x2, _whole_range(n, x.device), n)[0]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    if x.is_cuda and x.dtype == torch.float32 and _needs_grad(x, weight, bias):
+        return _LinearFn.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)

@@ -15,6 +15,7 @@ from typing import Any, Callable, List, Optional, Union
 import torch
 from torch import Tensor
 
+from .. import functions as Fn
 from ..imports import is_sparsetensor
 from ..utils.ops import (
     connectivity_to_edge_index,
@@ -408,7 +409,7 @@ class MLP(torch.nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         for i, lin in enumerate(self.lins):
-            x = lin(x)
+            x = Fn.linear(x, lin.weight, lin.bias)
             if i + 1 < len(self.lins):
                 if self.act is not None:
                     x = self.act(x)

@@ -190,8 +190,8 @@ def to_dense_batch(x: Tensor, batch: Optional[Tensor] = None, max_num_nodes: Opt
     sizes, ptr = graph_ptr(batch, batch_size)
     if max_num_nodes is None:
         max_num_nodes = max_graph_size(batch)
-    if x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad):
-        return K.to_dense_batch(x, batch, ptr, batch_size, max_num_nodes)  # one HIP kernel
+    if x.is_cuda and x.dtype == torch.float32:
+        return Fn.to_dense_batch(x, batch, ptr, batch_size, max_num_nodes)  # one HIP kernel (+ gather backward)
     local = torch.arange(batch.numel(), device=x.device) - ptr[batch]
     keep = local < max_num_nodes
     slot = (local + batch * max_num_nodes)[keep]
