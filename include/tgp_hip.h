@@ -188,6 +188,12 @@ int tgp_segment_gemm_tn_f32(const float* S, const float* Y, const int64_t* ptr, 
 int tgp_segment_gemm_nn_f32(const float* A, const float* Bm, const int64_t* ptr, float* C, int64_t B,
                             int64_t Ntot, int64_t Kd, int64_t Nc, int64_t max_nodes, void* stream);
 
+/* ss[e] = <S[row_e,:], S[col_e,:]> for every edge: the entries of S S^T that the sparse (unbatched) losses
+ * read (utils/losses.py:73-127 sparse_mincut_loss, :661-708 sparse_link_pred_loss: (S[src] * S[dst]).sum(-1)),
+ * without the two [E,K] gathers.  Any edge order; S [N,K] row-major. */
+int tgp_edge_dot_f32(const int64_t* row, const int64_t* col, int64_t E, const float* S, int64_t N, int64_t K,
+                     float* out, void* stream);
+
 /* ----------------------------------------------------------------------------------
  * N3  auxiliary losses of the dense poolers, fused.
  *

@@ -132,3 +132,27 @@ def test_diffpool_trains_with_fused_losses(dev):
     total.backward()
     grads = [p.grad for p in pooler.parameters()]
     assert grads and all(g is not None and torch.isfinite(g).all() and g.abs().sum() > 0 for g in grads)
+
+
+@pytest.mark.parametrize("K", [1, 3, 4, 20, 64, 128, 130, 300])
+def test_edge_dot_and_gradient(dev, K):
+    """ss[e] = <S[row_e], S[col_e]> (utils/losses.py:73-127, 661-708) and dS against the torch gathers, for
+    unsorted edges with duplicates and self loops, every lane-group width of the kernel."""
+    from tgp import functions as Fn
+    g = torch.Generator(device=dev).manual_seed(K)
+    n, E = 500, 7001
+    ei = torch.randint(0, n, (2, E), device=dev, generator=g)
+    ei[:, :40] = ei[:, 40:80]          # duplicates
+    ei[1, 100:140] = ei[0, 100:140]    # self loops
+    S0 = torch.softmax(torch.randn(n, K, device=dev, generator=g), -1)
+    go = torch.randn(E, device=dev, generator=g)
+    S = S0.clone().requires_grad_(True)
+    out = Fn.edge_dot(S, ei)
+    (out * go).sum().backward()
+    S2 = S0.clone().requires_grad_(True)
+    ref = (S2[ei[0]] * S2[ei[1]]).sum(-1)
+    (ref * go).sum().backward()
+    torch.testing.assert_close(out.detach(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(S.grad, S2.grad, rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        torch.testing.assert_close(Fn.edge_dot(S0, ei), ref.detach(), rtol=1e-5, atol=1e-6)

@@ -30,7 +30,8 @@ def sparse_graph(n, deg, graphs):
     per = n // graphs
     dst = (src // per) * per + torch.randint(0, per, (src.numel(),), device=dev, generator=g)
     ei = torch.cat([torch.stack([src, dst]), torch.stack([dst, src])], 1)
-    ei = ei[:, torch.argsort(ei[0] * n + ei[1])]
+    key = torch.unique(ei[0] * n + ei[1])  # sorted, duplicate-free: what PyG datasets hand out
+    ei = torch.stack([key // n, key % n])
     batch = torch.arange(n, device=dev) // per
     return ei, batch
 

@@ -90,6 +90,53 @@ __global__ __launch_bounds__(256) void cut_den_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) den[blockIdx.x] = t;
 }
 
+
+// ss[e] = <S[row_e,:], S[col_e,:]>: the per-edge entries of S S^T that the sparse (unbatched) losses need
+// (utils/losses.py:73-127 sparse_mincut_loss, :661-708 sparse_link_pred_loss compute (S[src] * S[dst]).sum(-1),
+// which materialises two [E,K] gathers and their product).  G lanes share an edge (float4 each when VEC),
+// so a wave covers 64/G edges per step; S rows are re-read through L2 (S is N*K*4 bytes, far smaller than
+// the 2*E*K*4 bytes of the gathers).
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void edge_dot_kernel(const int64_t* __restrict__ row,
+                                                       const int64_t* __restrict__ col, int64_t E,
+                                                       const float* __restrict__ S, int K,
+                                                       float* __restrict__ out) {
+  constexpr int PER_WAVE = 64 / G;
+  const int lane = threadIdx.x & 63, sub = lane % G, slot = lane / G;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * 4;
+  for (int64_t base = wave * PER_WAVE; base < E; base += nwaves * PER_WAVE) {
+    const int64_t e = base + slot;
+    float acc = 0.f;
+    if (e < E) {
+      const float* a = S + row[e] * K;
+      const float* b = S + col[e] * K;
+      if constexpr (VEC) {
+        for (int k = sub * 4; k < K; k += G * 4) {
+          const float4 x = *reinterpret_cast<const float4*>(a + k);
+          const float4 y = *reinterpret_cast<const float4*>(b + k);
+          acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc);
+          acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+        }
+      } else {
+        for (int k = sub; k < K; k += G) acc = fmaf(a[k], b[k], acc);
+      }
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (e < E && sub == 0) out[e] = acc;
+  }
+}
+
+template <int G, bool VEC>
+static void launch_edge_dot(const int64_t* row, const int64_t* col, int64_t E, const float* S, int K, float* out,
+                            hipStream_t stream) {
+  int64_t blocks = cdiv(E, static_cast<int64_t>(4) * (64 / G));
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL((edge_dot_kernel<G, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, row, col, E,
+                     S, K, out);
+}
+
 }  // namespace tgp
 
 using namespace tgp;
@@ -137,4 +184,30 @@ extern "C" int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int6
                      static_cast<int>(K), deg, q);
   hipLaunchKernelGGL(cut_den_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, deg, q, static_cast<int>(N), den);
   return check_launch("tgp_cut_terms_f32");
+}
+
+extern "C" int tgp_edge_dot_f32(const int64_t* row, const int64_t* col, int64_t E, const float* S, int64_t N,
+                                int64_t K, float* out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_edge_dot_f32: negative size");
+  if (E == 0) return TGP_OK;
+  TGP_REQUIRE(row && col && out && (K == 0 || S), TGP_ERR_INVALID, "tgp_edge_dot_f32: null pointer");
+  TGP_REQUIRE(K < (1ll << 31), TGP_ERR_RANGE, "tgp_edge_dot_f32: K too large");
+  const int k = static_cast<int>(K);
+  const bool vec = (K % 4 == 0) && (reinterpret_cast<uintptr_t>(S) % 16 == 0);
+  const int64_t units = vec ? K / 4 : K;  // work items per edge
+  if (vec) {
+    if (units <= 1) launch_edge_dot<1, true>(row, col, E, S, k, out, stream);
+    else if (units <= 2) launch_edge_dot<2, true>(row, col, E, S, k, out, stream);
+    else if (units <= 4) launch_edge_dot<4, true>(row, col, E, S, k, out, stream);
+    else if (units <= 8) launch_edge_dot<8, true>(row, col, E, S, k, out, stream);
+    else if (units <= 16) launch_edge_dot<16, true>(row, col, E, S, k, out, stream);
+    else if (units <= 32) launch_edge_dot<32, true>(row, col, E, S, k, out, stream);
+    else launch_edge_dot<64, true>(row, col, E, S, k, out, stream);
+  } else {
+    if (units <= 4) launch_edge_dot<4, false>(row, col, E, S, k, out, stream);
+    else if (units <= 16) launch_edge_dot<16, false>(row, col, E, S, k, out, stream);
+    else launch_edge_dot<64, false>(row, col, E, S, k, out, stream);
+  }
+  return check_launch("tgp_edge_dot_f32");
 }

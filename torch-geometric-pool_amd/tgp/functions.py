@@ -319,3 +319,29 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
     if x.is_cuda and x.dtype == torch.float32 and _needs_grad(x, weight, bias):
         return _LinearFn.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------ per-edge <S_i, S_j>
+class _EdgeDotFn(torch.autograd.Function):
+    """ss[e] = <S[row_e], S[col_e]>.  dS[i] = sum_{e: row_e = i} g_e S[col_e] + sum_{e: col_e = i} g_e S[row_e]:
+    two runs of the segmented gather-sum kernel of the sparse Reduce over inverted indices of the edge list
+    (deterministic; torch's backward of the two gathers is a pair of sort-based index_add's over [E,K])."""
+
+    @staticmethod
+    def forward(ctx, s, edge_index):
+        ctx.save_for_backward(s, edge_index)
+        return K.edge_dot(s, edge_index)
+
+    @staticmethod
+    def backward(ctx, g):
+        s, edge_index = ctx.saved_tensors
+        g = g.contiguous()
+        n = s.size(0)
+        row, col = edge_index[0], edge_index[1]
+        gs = K.reduce_sparse(s, col, g, K.build_assign_index(row, n))
+        gs = gs + K.reduce_sparse(s, row, g, K.build_assign_index(col, n))
+        return gs, None
+
+
+def edge_dot(s: Tensor, edge_index: Tensor) -> Tensor:
+    return _EdgeDotFn.apply(s, edge_index) if _needs_grad(s) else K.edge_dot(s, edge_index)

@@ -307,6 +307,17 @@ def cut_terms(adj: Tensor, s: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     return deg, q, den
 
 
+def edge_dot(s: Tensor, edge_index: Tensor) -> Tensor:
+    """ss[e] = <S[row_e], S[col_e]> (utils/losses.py:73-127, 661-708: ``(S[src] * S[dst]).sum(-1)``) in one pass."""
+    dev = N.require_device(s, edge_index)
+    row, col = _edge_rows(edge_index)
+    s = N.f32c(s)
+    out = torch.empty(row.numel(), dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_edge_dot_f32(N.ptr(row), N.ptr(col), row.numel(), N.ptr(s), s.size(0), s.size(1), N.ptr(out),
+                                     N.stream_ptr(dev)), "tgp_edge_dot_f32")
+    return out
+
+
 def bmm(a: Tensor, b: Tensor, trans_a: bool = False) -> Tensor:
     """C[g] = op(A[g]) @ B[g] on the fp32 matrix cores.  a: [G,M,Kd] (or [G,Kd,M] when trans_a),
     b: [G,Kd,Nc]; 2-D operands are treated as G = 1."""

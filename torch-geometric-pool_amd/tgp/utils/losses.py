@@ -149,7 +149,7 @@ def sparse_mincut_loss(edge_index: Tensor, S: Tensor, edge_weight: Optional[Tens
     batch = _batch_or_zeros(batch, n, S.device)
     deg = _seg_sum(w, edge_index[0], n)
     den = _seg_sum(deg * (S * S).sum(-1), batch, nb)
-    contrib = w * (S[edge_index[0]] * S[edge_index[1]]).sum(-1)
+    contrib = w * Fn.edge_dot(S, edge_index)
     num = _seg_sum(contrib, batch[edge_index[0]], nb)
     return _reduce(-(num / (den + eps)), batch_reduction)
 
@@ -177,7 +177,7 @@ def sparse_link_pred_loss(S: Tensor, edge_index: Tensor, edge_weight: Optional[T
     n = S.size(0)
     w = _edge_weights(edge_index, edge_weight, S)
     nb = num_graphs_of(batch)
-    ss = (S[edge_index[0]] * S[edge_index[1]]).sum(-1)
+    ss = Fn.edge_dot(S, edge_index)
     gram = _per_graph_gram(S, batch, nb)
     # ||A - S S^T||_F^2 = sum_E (w - ss)^2 + sum_g ||S_g^T S_g||_F^2 - sum_E ss^2
     sq = ((w - ss) ** 2).sum() + (gram * gram).sum() - (ss ** 2).sum()
