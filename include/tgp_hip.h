@@ -188,6 +188,20 @@ int tgp_segment_gemm_tn_f32(const float* S, const float* Y, const int64_t* ptr, 
 int tgp_segment_gemm_nn_f32(const float* A, const float* Bm, const int64_t* ptr, float* C, int64_t B,
                             int64_t Ntot, int64_t Kd, int64_t Nc, int64_t max_nodes, void* stream);
 
+/* ----------------------------------------------------------------------------------
+ * A12  TopkSelect, ratio mode (select/topk_select.py:163-203 -> PyG topk(score, ratio, batch), then the
+ * row sort of SelectOutput, select/base_select.py:58).  Graph g keeps its k[g] highest-scoring nodes; kept
+ * node i becomes supernode koff[g] + (its rank in the graph's descending score order), ties by lower node id.
+ *   ptr  [B+1] exclusive prefix sums of the graph sizes,  k [B],  koff [B+1] exclusive prefix sums of k.
+ * Outputs (k_total = koff[B] entries, ordered by ascending node id = the reference's row-sorted COO):
+ *   node_index, cluster_index (int64) and assign_perm (int32): assign_perm[c] = position of supernode c's
+ *   single assignment, i.e. the inverted index the sparse Reduce consumes (tgp_assign_index_build's perm).
+ * batch may be NULL when B == 1. */
+size_t tgp_topk_select_workspace_bytes(int64_t N);
+int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t B, const int64_t* ptr,
+                    const int64_t* k, const int64_t* koff, void* ws, size_t ws_bytes, int64_t* node_index,
+                    int64_t* cluster_index, int32_t* assign_perm, void* stream);
+
 /* ss[e] = <S[row_e,:], S[col_e,:]> for every edge: the entries of S S^T that the sparse (unbatched) losses
  * read (utils/losses.py:73-127 sparse_mincut_loss, :661-708 sparse_link_pred_loss: (S[src] * S[dst]).sum(-1)),
  * without the two [E,K] gathers.  Any edge order; S [N,K] row-major. */

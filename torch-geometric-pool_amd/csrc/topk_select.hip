@@ -1,0 +1,157 @@
+// A12: per-graph top-k node selection (reference select/topk_select.py:163-203 -> PyG
+// nn/pool/select/topk.py `topk(score, ratio, batch)`), ratio mode.
+//
+// PyG sorts all scores descending, then stable-sorts by graph id and keeps the first k_g entries of every
+// graph; the reference's SelectOutput then sorts the kept node ids once more to build a row-sorted COO
+// assignment (select/base_select.py:58).  That is three device-wide comparison sorts of N (or k) elements.
+// Here:  one stable LSD radix sort of the composite key (graph id : descending score bits) with the node id
+// as payload  ->  a rank pass that hands every kept node its supernode id (= its position in PyG's
+// graph-major, score-descending order)  ->  an order-preserving compaction over the node ids, which yields
+// the row-sorted assignment directly, together with the supernode -> assignment inverted index the sparse
+// Reduce kernel wants.  Ties keep the lower node id first (what a stable descending sort does).
+#include "common.h"
+#include "primitives.h"
+
+namespace tgp {
+
+constexpr int kTopkItems = 8;
+constexpr int kTopkTile = 256 * kTopkItems;
+
+// Bit pattern that orders like the float, descending, under an unsigned ascending sort.  -0 == +0 and every
+// NaN sorts first (torch.sort's descending order treats NaN as the largest value).
+__device__ __forceinline__ uint32_t descending_key(float f) {
+  uint32_t b = __float_as_uint(f);
+  if (f == 0.f) b = 0u;
+  if (f != f) b = 0x7FC00000u;
+  const uint32_t asc = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  return ~asc;
+}
+
+__global__ __launch_bounds__(256) void topk_keys_kernel(const float* __restrict__ score,
+                                                        const int64_t* __restrict__ batch, int64_t n,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t g = batch ? static_cast<uint64_t>(batch[i]) : 0ull;
+  keys[i] = (g << 32) | descending_key(score[i]);
+  vals[i] = static_cast<uint32_t>(i);
+}
+
+// Sorted position p belongs to graph g = key >> 32 at local rank q = p - ptr[g]; the first k[g] of a graph are
+// kept and become supernode koff[g] + q.
+__global__ __launch_bounds__(256) void topk_rank_kernel(const uint64_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ vals, int64_t n,
+                                                        const int64_t* __restrict__ ptr,
+                                                        const int64_t* __restrict__ k,
+                                                        const int64_t* __restrict__ koff,
+                                                        int32_t* __restrict__ rank_of) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (p >= n) return;
+  const int64_t g = static_cast<int64_t>(keys[p] >> 32);
+  const int64_t q = p - ptr[g];
+  if (q < k[g]) rank_of[vals[p]] = static_cast<int32_t>(koff[g] + q);
+}
+
+__global__ __launch_bounds__(256) void topk_count_kernel(const int32_t* __restrict__ rank_of, int64_t n,
+                                                         uint32_t* __restrict__ counts) {
+  __shared__ uint32_t s_w[4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTopkTile;
+  uint32_t c = 0;
+#pragma unroll
+  for (int it = 0; it < kTopkItems; ++it) {
+    const int64_t i = base + it * 256 + threadIdx.x;
+    c += __popcll(__ballot(i < n && rank_of[i] >= 0));
+  }
+  if (lane_id() == 0) s_w[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void topk_fill_kernel(const int32_t* __restrict__ rank_of, int64_t n,
+                                                        const uint32_t* __restrict__ offsets,
+                                                        int64_t* __restrict__ node_index,
+                                                        int64_t* __restrict__ cluster_index,
+                                                        int32_t* __restrict__ assign_perm) {
+  __shared__ uint32_t s_cnt[kTopkItems * 4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTopkTile;
+  bool flag[kTopkItems];
+  int32_t r[kTopkItems];
+  uint32_t rank[kTopkItems];
+#pragma unroll
+  for (int it = 0; it < kTopkItems; ++it) {
+    const int64_t i = base + it * 256 + threadIdx.x;
+    r[it] = i < n ? rank_of[i] : -1;
+    flag[it] = r[it] >= 0;
+  }
+  uint32_t total;
+  block_compact_ranks<kTopkItems>(flag, rank, total, s_cnt);
+  const uint32_t off = offsets[blockIdx.x];
+#pragma unroll
+  for (int it = 0; it < kTopkItems; ++it) {
+    if (!flag[it]) continue;
+    const uint32_t j = off + rank[it];
+    node_index[j] = base + it * 256 + threadIdx.x;
+    cluster_index[j] = r[it];
+    assign_perm[r[it]] = static_cast<int32_t>(j);
+  }
+}
+
+struct TopkLayout {
+  uint64_t *k0, *k1;
+  uint32_t *v0, *v1, *scratch, *counts, *offsets;
+  int32_t* rank_of;
+  int64_t* total;
+  size_t bytes;
+};
+
+static TopkLayout topk_layout(void* ws, int64_t n) {
+  Carver cv(ws);
+  TopkLayout s;
+  const size_t m = static_cast<size_t>(n > 0 ? n : 1);
+  const size_t nb = static_cast<size_t>(cdiv(n > 0 ? n : 1, kTopkTile));
+  s.k0 = cv.take<uint64_t>(m);
+  s.k1 = cv.take<uint64_t>(m);
+  s.v0 = cv.take<uint32_t>(m);
+  s.v1 = cv.take<uint32_t>(m);
+  s.scratch = cv.take<uint32_t>(sort_scratch_words());
+  s.rank_of = cv.take<int32_t>(m);
+  s.counts = cv.take<uint32_t>(nb);
+  s.offsets = cv.take<uint32_t>(nb);
+  s.total = cv.take<int64_t>(1);
+  s.bytes = cv.off;
+  return s;
+}
+
+}  // namespace tgp
+
+using namespace tgp;
+
+extern "C" size_t tgp_topk_select_workspace_bytes(int64_t N) { return topk_layout(nullptr, N).bytes + 256; }
+
+extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t B, const int64_t* ptr,
+                               const int64_t* k, const int64_t* koff, void* ws, size_t ws_bytes,
+                               int64_t* node_index, int64_t* cluster_index, int32_t* assign_perm, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(N >= 0 && B >= 0, TGP_ERR_INVALID, "tgp_topk_select: negative size");
+  if (N == 0 || B == 0) return TGP_OK;
+  TGP_REQUIRE(N < (1ll << 31), TGP_ERR_RANGE, "tgp_topk_select: more than 2^31 nodes");
+  TGP_REQUIRE(score && ptr && k && koff && (batch || B == 1), TGP_ERR_INVALID, "tgp_topk_select: null pointer");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_topk_select_workspace_bytes(N), TGP_ERR_WORKSPACE,
+              "tgp_topk_select: workspace too small");
+  const TopkLayout s = topk_layout(ws, N);
+  const int nb256 = cdiv(N, 256), nbt = cdiv(N, kTopkTile);
+  hipLaunchKernelGGL(topk_keys_kernel, dim3(nb256), dim3(256), 0, stream, score, batch, N, s.k0, s.v0);
+  bool first = true;
+  const int key_bits = 32 + (B > 1 ? bits_for(static_cast<uint64_t>(B - 1)) : 0);
+  const int rc = radix_sort_pairs<uint64_t, uint32_t>(s.k0, s.v0, s.k1, s.v1, N, key_bits, s.scratch, stream, &first);
+  if (rc != TGP_OK) return rc;
+  (void)hipMemsetAsync(s.rank_of, 0xFF, static_cast<size_t>(N) * sizeof(int32_t), stream);
+  hipLaunchKernelGGL(topk_rank_kernel, dim3(nb256), dim3(256), 0, stream, first ? s.k0 : s.k1, first ? s.v0 : s.v1,
+                     N, ptr, k, koff, s.rank_of);
+  hipLaunchKernelGGL(topk_count_kernel, dim3(nbt), dim3(256), 0, stream, s.rank_of, N, s.counts);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nbt, s.offsets, s.total);
+  if (node_index)
+    hipLaunchKernelGGL(topk_fill_kernel, dim3(nbt), dim3(256), 0, stream, s.rank_of, N, s.offsets, node_index,
+                       cluster_index, assign_perm);
+  return check_launch("tgp_topk_select");
+}

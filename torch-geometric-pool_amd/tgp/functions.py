@@ -345,3 +345,26 @@ class _EdgeDotFn(torch.autograd.Function):
 
 def edge_dot(s: Tensor, edge_index: Tensor) -> Tensor:
     return _EdgeDotFn.apply(s, edge_index) if _needs_grad(s) else K.edge_dot(s, edge_index)
+
+
+# ------------------------------------------------------------------ gather at unique positions
+class _TakeUniqueFn(torch.autograd.Function):
+    """x[index] for an index without repeats (the kept nodes of a top-k selection): the backward is a plain
+    scatter into zeros, where torch's generic indexing backward sorts the indices to merge duplicates."""
+
+    @staticmethod
+    def forward(ctx, x, index):
+        ctx.save_for_backward(index)
+        ctx.n = x.size(0)
+        return x[index]
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        out = torch.zeros((ctx.n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        out[index] = g
+        return out, None
+
+
+def take_unique(x: Tensor, index: Tensor) -> Tensor:
+    return _TakeUniqueFn.apply(x, index) if _needs_grad(x) else x[index]

@@ -307,6 +307,26 @@ def cut_terms(adj: Tensor, s: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     return deg, q, den
 
 
+def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Tensor, k: Tensor, koff: Tensor,
+                k_total: int) -> Tuple[Tensor, Tensor, AssignIndex]:
+    """Per-graph top-k (select/topk_select.py:194 -> PyG ``topk``) fused with the row sort of SelectOutput
+    (select/base_select.py:58): (node_index ascending, cluster_index, supernode -> assignment index)."""
+    dev = N.require_device(score, batch, ptr, k, koff)
+    score = N.f32c(score.reshape(-1))
+    n = score.numel()
+    node_index = torch.empty(k_total, dtype=torch.int64, device=dev)
+    cluster_index = torch.empty(k_total, dtype=torch.int64, device=dev)
+    perm = torch.empty(max(k_total, 1), dtype=torch.int32, device=dev)
+    L = N.lib()
+    ws = N.workspace(L.tgp_topk_select_workspace_bytes(n), dev)
+    N.check(L.tgp_topk_select(N.ptr(score), N.ptr(None if batch is None else N.i64c(batch)), n, num_graphs,
+                              N.ptr(N.i64c(ptr)), N.ptr(N.i64c(k)), N.ptr(N.i64c(koff)), N.ptr(ws), ws.numel(),
+                              N.ptr(node_index), N.ptr(cluster_index), N.ptr(perm), N.stream_ptr(dev)),
+            "tgp_topk_select")
+    row_ptr = torch.arange(k_total + 1, dtype=torch.int32, device=dev)
+    return node_index, cluster_index, AssignIndex(row_ptr, perm, k_total, k_total)
+
+
 def edge_dot(s: Tensor, edge_index: Tensor) -> Tensor:
     """ss[e] = <S[row_e], S[col_e]> (utils/losses.py:73-127, 661-708: ``(S[src] * S[dst]).sum(-1)``) in one pass."""
     dev = N.require_device(s, edge_index)

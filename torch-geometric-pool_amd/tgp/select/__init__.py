@@ -360,6 +360,7 @@ class TopkSelect(Select):
             self.weight.data.uniform_(-bound, bound)
 
     def forward(self, x: Tensor, *, batch: Optional[Tensor] = None, **kwargs) -> SelectOutput:
+        have_batch = batch is not None
         if batch is None:
             batch = x.new_zeros(x.size(0), dtype=torch.long)
         if self.weight is None:
@@ -377,12 +378,49 @@ class TopkSelect(Select):
             nb = num_graphs_of(batch)
             e = (score - _segment_max(score.detach(), batch, nb)[batch]).exp()
             score = e / (e.new_zeros(nb).index_add_(0, batch, e) + 1e-16)[batch]
+        if score.is_cuda and self.min_score is None and self.ratio is not None and score.dtype == torch.float32:
+            return self._native_select(score, batch if have_batch else None, x.size(0))
         node_index = topk(score, self.ratio, batch, self.min_score)
         so = SelectOutput(node_index=node_index, num_nodes=x.size(0),
                           cluster_index=torch.arange(node_index.size(0), device=x.device),
                           num_supernodes=node_index.size(0), weight=score[node_index],
                           s_inv_op=self.s_inv_op)
         so._set_one_to_one_index()
+        return so
+
+    def _native_select(self, score: Tensor, batch: Optional[Tensor], n: int) -> SelectOutput:
+        """Ratio mode on the device: one radix sort + rank + compaction (csrc/topk_select.hip) instead of the two
+        sorts of PyG's ``topk`` and the row sort of ``cluster_to_s``; the result is the same SelectOutput."""
+        from .. import kernels
+        from ..utils.ops import batch_info
+        dev = score.device
+        if batch is None or n == 0:
+            sizes_host, nb = [n], 1
+            sizes = torch.tensor(sizes_host, dtype=torch.long, device=dev) if n else torch.zeros(1, dtype=torch.long,
+                                                                                                 device=dev)
+            ptr = torch.zeros(2, dtype=torch.long, device=dev)
+            ptr[1] = n
+        else:
+            info = batch_info(batch)
+            sizes, sizes_host, nb, ptr = info.sizes, info.sizes_host, info.num_graphs, info.ptr
+        # k_g exactly as PyG computes it (float32 product, ceil), on the host for the total and on the device
+        # for the kernel -- no round trip
+        hs = torch.tensor(sizes_host, dtype=torch.long)
+        if self.ratio >= 1:
+            k_host = torch.minimum(torch.full_like(hs, int(self.ratio)), hs)
+            k = torch.minimum(torch.full_like(sizes, int(self.ratio)), sizes)
+        else:
+            k_host = (float(self.ratio) * hs.to(torch.float32)).ceil().to(torch.long)
+            k = (float(self.ratio) * sizes.to(torch.float32)).ceil().to(torch.long)
+        k_total = int(k_host.sum())
+        koff = torch.zeros(nb + 1, dtype=torch.long, device=dev)
+        torch.cumsum(k, 0, out=koff[1:])
+        node_index, cluster_index, assign = kernels.topk_select(score.detach(), batch, nb, ptr, k, koff, k_total)
+        values = Fn.take_unique(score, node_index)
+        s = torch.sparse_coo_tensor(torch.stack([node_index, cluster_index]), values, size=(n, k_total),
+                                    is_coalesced=True)
+        so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
+        so._assign_index = assign
         return so
 
     def __repr__(self) -> str:

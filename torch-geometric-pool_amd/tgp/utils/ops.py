@@ -41,7 +41,7 @@ class BatchInfo:
     valid only while the weak reference still resolves to the very same tensor and its version counter has
     not moved (an in-place write bumps it), which rules out stale hits from recycled memory."""
 
-    __slots__ = ("ref", "version", "num_graphs", "sizes", "ptr", "max_nodes", "distinct")
+    __slots__ = ("ref", "version", "num_graphs", "sizes", "sizes_host", "ptr", "max_nodes", "distinct")
 
 
 _BATCH_INFO: dict = {}
@@ -56,11 +56,13 @@ def batch_info(batch: Tensor) -> BatchInfo:
     info.ref, info.version = weakref.ref(batch), batch._version
     if batch.numel() == 0:
         info.sizes = torch.zeros(0, dtype=torch.long, device=batch.device)
-        info.num_graphs, info.max_nodes, info.distinct = 0, 0, 0
+        info.num_graphs, info.max_nodes, info.distinct, info.sizes_host = 0, 0, 0, []
     else:
         info.sizes = torch.bincount(batch)  # sync 1: the output length is max(batch) + 1
         info.num_graphs = info.sizes.numel()
-        info.max_nodes, info.distinct = torch.stack([info.sizes.max(), (info.sizes > 0).sum()]).tolist()  # sync 2
+        info.sizes_host = info.sizes.tolist()  # sync 2 (B integers)
+        info.max_nodes = max(info.sizes_host)
+        info.distinct = sum(1 for v in info.sizes_host if v > 0)
     info.ptr = torch.zeros(info.num_graphs + 1, dtype=torch.long, device=batch.device)
     if info.num_graphs:
         torch.cumsum(info.sizes, 0, out=info.ptr[1:])
