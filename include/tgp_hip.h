@@ -202,6 +202,14 @@ int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t
                     const int64_t* k, const int64_t* koff, void* ws, size_t ws_bytes, int64_t* node_index,
                     int64_t* cluster_index, int32_t* assign_perm, void* stream);
 
+/* TopkSelect scoring (select/topk_select.py:176, score = (x * w).sum(-1)): out[i] = <x[i,:], w>, one pass over
+ * x [N,F] (row stride ldx); and the matching weight gradient out[f] = sum_i g[i] x[i,f] (fixed-order two-level
+ * sum, deterministic). */
+int tgp_row_dot_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const float* w, float* out, void* stream);
+size_t tgp_weighted_colsum_workspace_bytes(int64_t F);
+int tgp_weighted_colsum_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const float* g, float* out, void* ws,
+                            size_t ws_bytes, void* stream);
+
 /* ss[e] = <S[row_e,:], S[col_e,:]> for every edge: the entries of S S^T that the sparse (unbatched) losses
  * read (utils/losses.py:73-127 sparse_mincut_loss, :661-708 sparse_link_pred_loss: (S[src] * S[dst]).sum(-1)),
  * without the two [E,K] gathers.  Any edge order; S [N,K] row-major. */

@@ -304,3 +304,26 @@ def test_to_dense_batch_and_linear_gradients(dev):
         res.append((y.detach(), X.grad, W.grad, b.grad))
     for a, r in zip(*res):
         torch.testing.assert_close(a, r, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("F", [1, 3, 4, 64, 128, 130, 300, 2100])
+def test_row_dot_and_gradients(dev, F):
+    """TopkSelect scoring x.w (select/topk_select.py:176) and its two gradients against torch."""
+    from tgp import functions as Fn
+    g = torch.Generator(device=dev).manual_seed(F)
+    n = 3001
+    x0 = torch.randn(n, F, device=dev, generator=g)
+    w0 = torch.randn(1, F, device=dev, generator=g)
+    go = torch.randn(n, device=dev, generator=g)
+    x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    out = Fn.row_dot(x, w)
+    (out * go).sum().backward()
+    x2, w2 = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    ref = (x2 * w2).sum(-1)
+    (ref * go).sum().backward()
+    torch.testing.assert_close(out.detach(), ref.detach(), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(x.grad, x2.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(w.grad, w2.grad, rtol=1e-4, atol=1e-3)
+    xs = x0[:, : max(1, F // 2)]  # strided rows
+    torch.testing.assert_close(Fn.row_dot(xs, w0[:, : xs.size(1)]), (xs * w0[:, : xs.size(1)]).sum(-1), rtol=1e-5,
+                               atol=1e-4)

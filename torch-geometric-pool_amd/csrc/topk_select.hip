@@ -96,6 +96,102 @@ __global__ __launch_bounds__(256) void topk_fill_kernel(const int32_t* __restric
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Scoring (select/topk_select.py:176: score = (x * w).sum(-1)): one pass over x instead of an [N,F] product
+// written and re-read; and its weight gradient dw[f] = sum_i g[i] x[i,f].  Both are pure HBM streams over x.
+// G lanes share a row (float4 each when VEC); w lives in registers.
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void row_dot_kernel(const float* __restrict__ x, int64_t n, int F, int64_t ldx,
+                                                      const float* __restrict__ w, float* __restrict__ out) {
+  constexpr int PER_WAVE = 64 / G;
+  constexpr int MAXC = 8;  // column chunks per lane kept in registers (covers F <= G*4*8)
+  const int lane = threadIdx.x & 63, sub = lane % G, slot = lane / G;
+  const int64_t wave = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * 4;
+  constexpr int STEP = VEC ? G * 4 : G;
+  float wr[MAXC][VEC ? 4 : 1];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int k = (VEC ? sub * 4 : sub) + c * STEP;
+#pragma unroll
+    for (int j = 0; j < (VEC ? 4 : 1); ++j) wr[c][j] = (k + j < F) ? w[k + j] : 0.f;
+  }
+  for (int64_t base = wave * PER_WAVE; base < n; base += nwaves * PER_WAVE) {
+    const int64_t i = base + slot;
+    float acc = 0.f;
+    if (i < n) {
+      const float* a = x + i * ldx;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        const int k = (VEC ? sub * 4 : sub) + c * STEP;
+        if (k >= F) break;
+        if constexpr (VEC) {
+          const float4 v = *reinterpret_cast<const float4*>(a + k);
+          acc = fmaf(v.x, wr[c][0], acc); acc = fmaf(v.y, wr[c][1], acc);
+          acc = fmaf(v.z, wr[c][2], acc); acc = fmaf(v.w, wr[c][3], acc);
+        } else {
+          acc = fmaf(a[k], wr[c][0], acc);
+        }
+      }
+      for (int k = (VEC ? sub * 4 : sub) + MAXC * STEP; k < F; k += STEP) {  // very wide rows
+#pragma unroll
+        for (int j = 0; j < (VEC ? 4 : 1); ++j) acc = fmaf(a[k + j], w[k + j], acc);
+      }
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (i < n && sub == 0) out[i] = acc;
+  }
+}
+
+constexpr int kColsumBlocks = 1024;
+// partial[b][f] = sum over the rows of block b of g[i] * x[i][f]; a thread owns column f = tid % F-chunk and
+// every (256 / chunk)-th row of the block's slab, LDS folds the row phases in a fixed order.
+__global__ __launch_bounds__(256) void weighted_colsum_partial_kernel(const float* __restrict__ x, int64_t n, int F,
+                                                                      int64_t ldx, const float* __restrict__ g,
+                                                                      float* __restrict__ partial) {
+  extern __shared__ float s_acc[];  // [phases][F]
+  const int64_t rows_per_block = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  const int cols = F < 256 ? F : 256;          // columns handled per sweep
+  const int phases = 256 / cols;               // rows in flight per sweep
+  const int col = threadIdx.x % cols, phase = threadIdx.x / cols;
+  for (int f0 = 0; f0 < F; f0 += cols) {
+    const int f = f0 + col;
+    float acc = 0.f;
+    if (phase < phases && f < F)
+      for (int64_t i = r0 + phase; i < r1; i += phases) acc = fmaf(g[i], x[i * ldx + f], acc);
+    if (phase < phases) s_acc[phase * cols + col] = acc;
+    __syncthreads();
+    if (threadIdx.x < cols && f0 + threadIdx.x < F) {
+      float t = 0.f;
+      for (int p = 0; p < phases; ++p) t += s_acc[p * cols + threadIdx.x];
+      partial[static_cast<int64_t>(blockIdx.x) * F + f0 + threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int blocks, int F,
+                                                           float* __restrict__ out) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  float t = 0.f;
+  for (int b = 0; b < blocks; ++b) t += partial[static_cast<int64_t>(b) * F + f];
+  out[f] = t;
+}
+
+template <int G, bool VEC>
+static void launch_row_dot(const float* x, int64_t n, int F, int64_t ldx, const float* w, float* out,
+                           hipStream_t stream) {
+  int64_t blocks = cdiv(n, static_cast<int64_t>(4) * (64 / G));
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL((row_dot_kernel<G, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, x, n, F, ldx,
+                     w, out);
+}
+
 struct TopkLayout {
   uint64_t *k0, *k1;
   uint32_t *v0, *v1, *scratch, *counts, *offsets;
@@ -154,4 +250,59 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
     hipLaunchKernelGGL(topk_fill_kernel, dim3(nbt), dim3(256), 0, stream, s.rank_of, N, s.offsets, node_index,
                        cluster_index, assign_perm);
   return check_launch("tgp_topk_select");
+}
+
+extern "C" int tgp_row_dot_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const float* w, float* out,
+                               void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(N >= 0 && F >= 0 && ldx >= F, TGP_ERR_INVALID, "tgp_row_dot_f32: bad size");
+  if (N == 0) return TGP_OK;
+  TGP_REQUIRE(out && (F == 0 || (x && w)), TGP_ERR_INVALID, "tgp_row_dot_f32: null pointer");
+  TGP_REQUIRE(F < (1ll << 31), TGP_ERR_RANGE, "tgp_row_dot_f32: F too large");
+  const int f = static_cast<int>(F);
+  const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+  const int64_t units = vec ? F / 4 : F;
+  if (vec) {
+    if (units <= 1) launch_row_dot<1, true>(x, N, f, ldx, w, out, stream);
+    else if (units <= 2) launch_row_dot<2, true>(x, N, f, ldx, w, out, stream);
+    else if (units <= 4) launch_row_dot<4, true>(x, N, f, ldx, w, out, stream);
+    else if (units <= 8) launch_row_dot<8, true>(x, N, f, ldx, w, out, stream);
+    else if (units <= 16) launch_row_dot<16, true>(x, N, f, ldx, w, out, stream);
+    else if (units <= 32) launch_row_dot<32, true>(x, N, f, ldx, w, out, stream);
+    else launch_row_dot<64, true>(x, N, f, ldx, w, out, stream);
+  } else {
+    if (units <= 4) launch_row_dot<4, false>(x, N, f, ldx, w, out, stream);
+    else if (units <= 16) launch_row_dot<16, false>(x, N, f, ldx, w, out, stream);
+    else launch_row_dot<64, false>(x, N, f, ldx, w, out, stream);
+  }
+  return check_launch("tgp_row_dot_f32");
+}
+
+extern "C" size_t tgp_weighted_colsum_workspace_bytes(int64_t F) {
+  return align_up(static_cast<size_t>(kColsumBlocks) * (F > 0 ? F : 1) * sizeof(float)) + 256;
+}
+
+extern "C" int tgp_weighted_colsum_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const float* g, float* out,
+                                       void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(N >= 0 && F >= 0 && ldx >= F, TGP_ERR_INVALID, "tgp_weighted_colsum_f32: bad size");
+  if (F == 0) return TGP_OK;
+  TGP_REQUIRE(out, TGP_ERR_INVALID, "tgp_weighted_colsum_f32: null output");
+  if (N == 0) {
+    (void)hipMemsetAsync(out, 0, static_cast<size_t>(F) * sizeof(float), stream);
+    return check_launch("tgp_weighted_colsum_f32");
+  }
+  TGP_REQUIRE(x && g, TGP_ERR_INVALID, "tgp_weighted_colsum_f32: null pointer");
+  TGP_REQUIRE(F < (1ll << 24), TGP_ERR_RANGE, "tgp_weighted_colsum_f32: F too large");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_weighted_colsum_workspace_bytes(F), TGP_ERR_WORKSPACE,
+              "tgp_weighted_colsum_f32: workspace too small");
+  int blocks = cdiv(N, 256);
+  if (blocks > kColsumBlocks) blocks = kColsumBlocks;
+  float* partial = static_cast<float*>(ws);
+  const int cols = F < 256 ? static_cast<int>(F) : 256;
+  hipLaunchKernelGGL(weighted_colsum_partial_kernel, dim3(blocks), dim3(256), (256 / cols) * cols * sizeof(float),
+                     stream, x, N, static_cast<int>(F), ldx, g, partial);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(F, 256)), dim3(256), 0, stream, partial, blocks,
+                     static_cast<int>(F), out);
+  return check_launch("tgp_weighted_colsum_f32");
 }

@@ -368,3 +368,27 @@ class _TakeUniqueFn(torch.autograd.Function):
 
 def take_unique(x: Tensor, index: Tensor) -> Tensor:
     return _TakeUniqueFn.apply(x, index) if _needs_grad(x) else x[index]
+
+
+# --------------------------------------------------------------------------------- TopK scoring x.w
+class _RowDotFn(torch.autograd.Function):
+    """score = x w (select/topk_select.py:176): one pass over x; dx = g w^T, dw = x^T g (one more pass)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return K.row_dot(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = g.unsqueeze(1) * w.reshape(1, -1)
+        if ctx.needs_input_grad[1]:
+            gw = K.weighted_colsum(x, g.contiguous()).view_as(w)
+        return gx, gw
+
+
+def row_dot(x: Tensor, w: Tensor) -> Tensor:
+    return _RowDotFn.apply(x, w) if _needs_grad(x, w) else K.row_dot(x, w)

@@ -327,6 +327,33 @@ def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Te
     return node_index, cluster_index, AssignIndex(row_ptr, perm, k_total, k_total)
 
 
+def _rows_f32(x: Tensor) -> Tensor:
+    x = x.to(torch.float32) if x.dtype != torch.float32 else x
+    return x if x.stride(1) == 1 else x.contiguous()
+
+
+def row_dot(x: Tensor, w: Tensor) -> Tensor:
+    """out[i] = <x[i,:], w> (select/topk_select.py:176) in one pass over x."""
+    dev = N.require_device(x, w)
+    x, w = _rows_f32(x), N.f32c(w.reshape(-1))
+    out = torch.empty(x.size(0), dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_row_dot_f32(N.ptr(x), x.size(0), x.size(1), x.stride(0), N.ptr(w), N.ptr(out),
+                                    N.stream_ptr(dev)), "tgp_row_dot_f32")
+    return out
+
+
+def weighted_colsum(x: Tensor, g: Tensor) -> Tensor:
+    """out[f] = sum_i g[i] x[i,f]: the weight gradient of :func:`row_dot`."""
+    dev = N.require_device(x, g)
+    x, g = _rows_f32(x), N.f32c(g.reshape(-1))
+    out = torch.empty(x.size(1), dtype=torch.float32, device=dev)
+    L = N.lib()
+    ws = N.workspace(L.tgp_weighted_colsum_workspace_bytes(x.size(1)), dev)
+    N.check(L.tgp_weighted_colsum_f32(N.ptr(x), x.size(0), x.size(1), x.stride(0), N.ptr(g), N.ptr(out), N.ptr(ws),
+                                      ws.numel(), N.stream_ptr(dev)), "tgp_weighted_colsum_f32")
+    return out
+
+
 def edge_dot(s: Tensor, edge_index: Tensor) -> Tensor:
     """ss[e] = <S[row_e], S[col_e]> (utils/losses.py:73-127, 661-708: ``(S[src] * S[dst]).sum(-1)``) in one pass."""
     dev = N.require_device(s, edge_index)

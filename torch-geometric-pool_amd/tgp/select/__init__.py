@@ -369,7 +369,9 @@ class TopkSelect(Select):
             score = x.reshape(-1)
         else:
             feats = x.view(-1, 1) if x.dim() == 1 else x
-            score = (feats * self.weight).sum(dim=-1)
+            # x.w in a single native pass over x (the elementwise product + row sum of the reference,
+            # topk_select.py:176, writes and re-reads an [N,F] temporary)
+            score = Fn.row_dot(feats, self.weight) if feats.is_cuda else (feats * self.weight).sum(dim=-1)
             if self.min_score is None:
                 score = score / self.weight.norm(p=2, dim=-1)
         if self.min_score is None:
