@@ -215,6 +215,10 @@ int tgp_weighted_colsum_f32(const float* x, int64_t N, int64_t F, int64_t ldx, c
  * without the two [E,K] gathers.  Any edge order; S [N,K] row-major. */
 int tgp_edge_dot_f32(const int64_t* row, const int64_t* col, int64_t E, const float* S, int64_t N, int64_t K,
                      float* out, void* stream);
+/* Two-matrix form, out[e] = <A[ia_e,:], Bm[ib_e,:]> (both [*,K] row-major): the assignment-weight gradient of the
+ * sparse Reduce, dw_i = <x[node_i], dX'[cluster_i]> (autograd of reduce/base_reduce.py:146-153). */
+int tgp_pair_dot_f32(const int64_t* ia, const int64_t* ib, int64_t E, const float* A, const float* Bm, int64_t K,
+                     float* out, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * N3  auxiliary losses of the dense poolers, fused.

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void cut_den_kernel(const float* __restrict__ 
 template <int G, bool VEC>
 __global__ __launch_bounds__(256) void edge_dot_kernel(const int64_t* __restrict__ row,
                                                        const int64_t* __restrict__ col, int64_t E,
-                                                       const float* __restrict__ S, int K,
+                                                       const float* __restrict__ S,
+                                                       const float* __restrict__ S2, int K,
                                                        float* __restrict__ out) {
   constexpr int PER_WAVE = 64 / G;
   const int lane = threadIdx.x & 63, sub = lane % G, slot = lane / G;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void edge_dot_kernel(const int64_t* __restrict
     float acc = 0.f;
     if (e < E) {
       const float* a = S + row[e] * K;
-      const float* b = S + col[e] * K;
+      const float* b = S2 + col[e] * K;
       if constexpr (VEC) {
         for (int k = sub * 4; k < K; k += G * 4) {
           const float4 x = *reinterpret_cast<const float4*>(a + k);
@@ -129,12 +130,12 @@ __global__ __launch_bounds__(256) void edge_dot_kernel(const int64_t* __restrict
 }
 
 template <int G, bool VEC>
-static void launch_edge_dot(const int64_t* row, const int64_t* col, int64_t E, const float* S, int K, float* out,
-                            hipStream_t stream) {
+static void launch_edge_dot(const int64_t* row, const int64_t* col, int64_t E, const float* S, const float* S2, int K,
+                            float* out, hipStream_t stream) {
   int64_t blocks = cdiv(E, static_cast<int64_t>(4) * (64 / G));
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL((edge_dot_kernel<G, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, row, col, E,
-                     S, K, out);
+                     S, S2, K, out);
 }
 
 }  // namespace tgp
@@ -186,6 +187,27 @@ extern "C" int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int6
   return check_launch("tgp_cut_terms_f32");
 }
 
+static int pair_dot(const int64_t* row, const int64_t* col, int64_t E, const float* S, const float* S2, int64_t K,
+                    float* out, hipStream_t stream, const char* what) {
+  const int k = static_cast<int>(K);
+  const bool vec = (K % 4 == 0) && (reinterpret_cast<uintptr_t>(S) % 16 == 0) && (reinterpret_cast<uintptr_t>(S2) % 16 == 0);
+  const int64_t units = vec ? K / 4 : K;  // work items per edge
+  if (vec) {
+    if (units <= 1) launch_edge_dot<1, true>(row, col, E, S, S2, k, out, stream);
+    else if (units <= 2) launch_edge_dot<2, true>(row, col, E, S, S2, k, out, stream);
+    else if (units <= 4) launch_edge_dot<4, true>(row, col, E, S, S2, k, out, stream);
+    else if (units <= 8) launch_edge_dot<8, true>(row, col, E, S, S2, k, out, stream);
+    else if (units <= 16) launch_edge_dot<16, true>(row, col, E, S, S2, k, out, stream);
+    else if (units <= 32) launch_edge_dot<32, true>(row, col, E, S, S2, k, out, stream);
+    else launch_edge_dot<64, true>(row, col, E, S, S2, k, out, stream);
+  } else {
+    if (units <= 4) launch_edge_dot<4, false>(row, col, E, S, S2, k, out, stream);
+    else if (units <= 16) launch_edge_dot<16, false>(row, col, E, S, S2, k, out, stream);
+    else launch_edge_dot<64, false>(row, col, E, S, S2, k, out, stream);
+  }
+  return check_launch(what);
+}
+
 extern "C" int tgp_edge_dot_f32(const int64_t* row, const int64_t* col, int64_t E, const float* S, int64_t N,
                                 int64_t K, float* out, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -193,21 +215,15 @@ extern "C" int tgp_edge_dot_f32(const int64_t* row, const int64_t* col, int64_t 
   if (E == 0) return TGP_OK;
   TGP_REQUIRE(row && col && out && (K == 0 || S), TGP_ERR_INVALID, "tgp_edge_dot_f32: null pointer");
   TGP_REQUIRE(K < (1ll << 31), TGP_ERR_RANGE, "tgp_edge_dot_f32: K too large");
-  const int k = static_cast<int>(K);
-  const bool vec = (K % 4 == 0) && (reinterpret_cast<uintptr_t>(S) % 16 == 0);
-  const int64_t units = vec ? K / 4 : K;  // work items per edge
-  if (vec) {
-    if (units <= 1) launch_edge_dot<1, true>(row, col, E, S, k, out, stream);
-    else if (units <= 2) launch_edge_dot<2, true>(row, col, E, S, k, out, stream);
-    else if (units <= 4) launch_edge_dot<4, true>(row, col, E, S, k, out, stream);
-    else if (units <= 8) launch_edge_dot<8, true>(row, col, E, S, k, out, stream);
-    else if (units <= 16) launch_edge_dot<16, true>(row, col, E, S, k, out, stream);
-    else if (units <= 32) launch_edge_dot<32, true>(row, col, E, S, k, out, stream);
-    else launch_edge_dot<64, true>(row, col, E, S, k, out, stream);
-  } else {
-    if (units <= 4) launch_edge_dot<4, false>(row, col, E, S, k, out, stream);
-    else if (units <= 16) launch_edge_dot<16, false>(row, col, E, S, k, out, stream);
-    else launch_edge_dot<64, false>(row, col, E, S, k, out, stream);
-  }
-  return check_launch("tgp_edge_dot_f32");
+  return pair_dot(row, col, E, S, S, K, out, stream, "tgp_edge_dot_f32");
+}
+
+extern "C" int tgp_pair_dot_f32(const int64_t* ia, const int64_t* ib, int64_t E, const float* A, const float* Bm,
+                                int64_t K, float* out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_pair_dot_f32: negative size");
+  if (E == 0) return TGP_OK;
+  TGP_REQUIRE(ia && ib && out && (K == 0 || (A && Bm)), TGP_ERR_INVALID, "tgp_pair_dot_f32: null pointer");
+  TGP_REQUIRE(K < (1ll << 31), TGP_ERR_RANGE, "tgp_pair_dot_f32: K too large");
+  return pair_dot(ia, ib, E, A, Bm, K, out, stream, "tgp_pair_dot_f32");
 }

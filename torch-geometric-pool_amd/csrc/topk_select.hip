@@ -146,41 +146,84 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const float* __restrict__ 
 }
 
 constexpr int kColsumBlocks = 1024;
-// partial[b][f] = sum over the rows of block b of g[i] * x[i][f]; a thread owns column f = tid % F-chunk and
-// every (256 / chunk)-th row of the block's slab, LDS folds the row phases in a fixed order.
+// partial[b][f] = sum over the rows of block b of g[i] * x[i][f].  A thread owns one column chunk (a float4 when
+// VEC) and every `phases`-th row of the block's slab, four rows in flight; LDS folds the row phases in a fixed
+// order.  Columns beyond 256 chunks are covered by an outer sweep.
+template <bool VEC>
 __global__ __launch_bounds__(256) void weighted_colsum_partial_kernel(const float* __restrict__ x, int64_t n, int F,
                                                                       int64_t ldx, const float* __restrict__ g,
                                                                       float* __restrict__ partial) {
-  extern __shared__ float s_acc[];  // [phases][F]
+  constexpr int W = VEC ? 4 : 1;
+  extern __shared__ float s_acc[];  // [phases][cols * W]
   const int64_t rows_per_block = (n + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
-  const int cols = F < 256 ? F : 256;          // columns handled per sweep
-  const int phases = 256 / cols;               // rows in flight per sweep
+  const int chunks = F / W;
+  const int cols = chunks < 256 ? chunks : 256;  // chunks handled per sweep
+  const int phases = 256 / cols;                 // rows in flight per sweep
   const int col = threadIdx.x % cols, phase = threadIdx.x / cols;
-  for (int f0 = 0; f0 < F; f0 += cols) {
-    const int f = f0 + col;
-    float acc = 0.f;
-    if (phase < phases && f < F)
-      for (int64_t i = r0 + phase; i < r1; i += phases) acc = fmaf(g[i], x[i * ldx + f], acc);
-    if (phase < phases) s_acc[phase * cols + col] = acc;
+  for (int c0 = 0; c0 < chunks; c0 += cols) {
+    const int c = c0 + col;
+    float acc[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] = 0.f;
+    if (phase < phases && c < chunks) {
+      const float* xc = x + static_cast<int64_t>(c) * W;
+      int64_t i = r0 + phase;
+      for (; i + 3 * phases < r1; i += 4 * phases) {
+        float gv[4], xv[4][W];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t r = i + static_cast<int64_t>(u) * phases;
+          gv[u] = g[r];
+          if constexpr (VEC) {
+            const float4 v = *reinterpret_cast<const float4*>(xc + r * ldx);
+            xv[u][0] = v.x; xv[u][1] = v.y; xv[u][2] = v.z; xv[u][3] = v.w;
+          } else {
+            xv[u][0] = xc[r * ldx];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < W; ++j) acc[j] = fmaf(gv[u], xv[u][j], acc[j]);
+      }
+      for (; i < r1; i += phases) {
+        const float gv = g[i];
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[j] = fmaf(gv, xc[i * ldx + j], acc[j]);
+      }
+    }
+    if (phase < phases) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) s_acc[(phase * cols + col) * W + j] = acc[j];
+    }
     __syncthreads();
-    if (threadIdx.x < cols && f0 + threadIdx.x < F) {
-      float t = 0.f;
-      for (int p = 0; p < phases; ++p) t += s_acc[p * cols + threadIdx.x];
-      partial[static_cast<int64_t>(blockIdx.x) * F + f0 + threadIdx.x] = t;
+    for (int e = threadIdx.x; e < cols * W; e += 256) {
+      if (c0 * W + e < F) {
+        float t = 0.f;
+        for (int p = 0; p < phases; ++p) t += s_acc[p * cols * W + e];
+        partial[static_cast<int64_t>(blockIdx.x) * F + c0 * W + e] = t;
+      }
     }
     __syncthreads();
   }
 }
 
+// out[f] = sum_b partial[b][f]: one workgroup per column, 256 partial sums in flight, fixed-order tree.
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int blocks, int F,
                                                            float* __restrict__ out) {
-  const int f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= F) return;
+  __shared__ float s_t[256];
+  const int f = blockIdx.x;
   float t = 0.f;
-  for (int b = 0; b < blocks; ++b) t += partial[static_cast<int64_t>(b) * F + f];
-  out[f] = t;
+  for (int b = threadIdx.x; b < blocks; b += 256) t += partial[static_cast<int64_t>(b) * F + f];
+  s_t[threadIdx.x] = t;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) s_t[threadIdx.x] += s_t[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[f] = s_t[0];
 }
 
 template <int G, bool VEC>
@@ -299,10 +342,17 @@ extern "C" int tgp_weighted_colsum_f32(const float* x, int64_t N, int64_t F, int
   int blocks = cdiv(N, 256);
   if (blocks > kColsumBlocks) blocks = kColsumBlocks;
   float* partial = static_cast<float*>(ws);
-  const int cols = F < 256 ? static_cast<int>(F) : 256;
-  hipLaunchKernelGGL(weighted_colsum_partial_kernel, dim3(blocks), dim3(256), (256 / cols) * cols * sizeof(float),
-                     stream, x, N, static_cast<int>(F), ldx, g, partial);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(F, 256)), dim3(256), 0, stream, partial, blocks,
+  const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+  const int chunks = static_cast<int>(vec ? F / 4 : F);
+  const int cols = chunks < 256 ? chunks : 256;
+  const size_t lds = static_cast<size_t>(256 / cols) * cols * (vec ? 4 : 1) * sizeof(float);
+  if (vec)
+    hipLaunchKernelGGL(weighted_colsum_partial_kernel<true>, dim3(blocks), dim3(256), lds, stream, x, N,
+                       static_cast<int>(F), ldx, g, partial);
+  else
+    hipLaunchKernelGGL(weighted_colsum_partial_kernel<false>, dim3(blocks), dim3(256), lds, stream, x, N,
+                       static_cast<int>(F), ldx, g, partial);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(F)), dim3(256), 0, stream, partial, blocks,
                      static_cast<int>(F), out);
   return check_launch("tgp_weighted_colsum_f32");
 }

@@ -234,7 +234,7 @@ class _SparseLiftFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = K.reduce_sparse(g, row, values, ctx.back_index_fn())
         if ctx.needs_input_grad[1]:
-            gv = (g[row] * x_pool[col]).sum(-1)
+            gv = K.pair_dot(g, row, x_pool, col) if g.dim() == 2 else (g[row] * x_pool[col]).sum(-1)
         return gx, gv, None, None, None, None
 
 

@@ -354,6 +354,18 @@ def weighted_colsum(x: Tensor, g: Tensor) -> Tensor:
     return out
 
 
+def pair_dot(a: Tensor, ia: Tensor, b: Tensor, ib: Tensor) -> Tensor:
+    """out[e] = <a[ia_e,:], b[ib_e,:]>: the assignment-weight gradient of the sparse Reduce / Lift."""
+    dev = N.require_device(a, ia, b, ib)
+    a, b, ia, ib = N.f32c(a), N.f32c(b), N.i64c(ia), N.i64c(ib)
+    if a.dim() != 2 or b.dim() != 2 or a.size(1) != b.size(1) or ia.numel() != ib.numel():
+        raise ValueError(f"pair_dot: a {tuple(a.shape)}, b {tuple(b.shape)}, {ia.numel()} / {ib.numel()} indices")
+    out = torch.empty(ia.numel(), dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_pair_dot_f32(N.ptr(ia), N.ptr(ib), ia.numel(), N.ptr(a), N.ptr(b), a.size(1), N.ptr(out),
+                                     N.stream_ptr(dev)), "tgp_pair_dot_f32")
+    return out
+
+
 def edge_dot(s: Tensor, edge_index: Tensor) -> Tensor:
     """ss[e] = <S[row_e], S[col_e]> (utils/losses.py:73-127, 661-708: ``(S[src] * S[dst]).sum(-1)``) in one pass."""
     dev = N.require_device(s, edge_index)

@@ -91,7 +91,10 @@ class _SparseReduceFn(torch.autograd.Function):
             from ..lift import lift_index_of
             gx = K.reduce_sparse(grad_out, so.cluster_index, weight, lift_index_of(so))
         if ctx.needs_input_grad[1]:
-            gw = (x[so.node_index] * grad_out[so.cluster_index]).sum(-1)
+            if x.dim() == 2 and x.is_cuda:
+                gw = K.pair_dot(x, so.node_index, grad_out, so.cluster_index)
+            else:
+                gw = (x[so.node_index] * grad_out[so.cluster_index]).reshape(so.node_index.numel(), -1).sum(-1)
         return gx, gw, None
 
 
