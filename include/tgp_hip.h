@@ -202,6 +202,20 @@ int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t
                     const int64_t* k, const int64_t* koff, void* ws, size_t ws_bytes, int64_t* node_index,
                     int64_t* cluster_index, int32_t* assign_perm, void* stream);
 
+/* ----------------------------------------------------------------------------------
+ * A14  GraclusSelect's matching (select/graclus_select.py:62-81 -> torch_cluster 1.6.3 graclus_cluster, absent
+ * from the reference tree; its published algorithm: pair every node with its heaviest unmatched neighbour).
+ * Data-parallel handshake rounds over the CSR of the edge list (row_ptr / perm = tgp_assign_index_build of the
+ * source ids); label[i] = min(i, partner) or i.  _start gathers the CSR and resets the state, _rounds runs
+ * `rounds` propose/match rounds and reports the nodes matched per round in matched[rounds] (device memory):
+ * the matching is maximal once a round matches nothing. */
+size_t tgp_graclus_match_workspace_bytes(int64_t num_nodes, int64_t num_edges);
+int tgp_graclus_match_start(const int64_t* col, const float* weight /* NULL = ones */, const int32_t* row_ptr,
+                            const int32_t* perm, int64_t num_nodes, int64_t num_edges, void* ws, size_t ws_bytes,
+                            int64_t* label, void* stream);
+int tgp_graclus_match_rounds(const int32_t* row_ptr, int64_t num_nodes, int64_t num_edges, void* ws, int rounds,
+                             unsigned int* matched, int64_t* label, void* stream);
+
 /* TopkSelect scoring (select/topk_select.py:176, score = (x * w).sum(-1)): out[i] = <x[i,:], w>, one pass over
  * x [N,F] (row stride ldx); and the matching weight gradient out[f] = sum_i g[i] x[i,f] (fixed-order two-level
  * sum, deterministic). */

@@ -398,3 +398,51 @@ def test_native_topk_select_vs_oracle(dev, seed):
     torch.testing.assert_close(so.weight.cpu(), score[ref_node], rtol=0, atol=0)
     ai = so.assign_index()                                     # supernode -> position of its assignment
     assert torch.equal(ai.perm[:k].cpu().long(), torch.argsort(ref_cluster))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_native_graclus_matching_contract(dev, seed):
+    """A14 (select/graclus_select.py:62-81): the native handshake matching must be a valid MAXIMAL matching over
+    the non-loop edges, label = smaller id of the pair, consecutive cluster ids in representative order; on
+    distinct weights it must equal the sequential greedy heavy-edge matching (unique answer)."""
+    from tgp import kernels as KK
+    from tgp.select import GraclusSelect
+    rng = random.Random(seed)
+    g = torch.Generator().manual_seed(9000 + seed)
+    n = rng.choice([1, 2, 9, 200, 5000])
+    e = rng.choice([0, 3, 50, 4 * n])
+    r = torch.randint(0, n, (e,), generator=g)
+    c = torch.randint(0, n, (e,), generator=g)
+    if seed == 0:  # a path: smallest-id tie-breaking would need n/2 rounds here
+        n = 4000
+        r, c = torch.arange(n - 1), torch.arange(1, n)
+    ei = torch.cat([torch.stack([r, c]), torch.stack([c, r])], 1)  # symmetric, maybe with loops / duplicates
+    und_w = torch.rand(r.numel(), generator=g) + 0.1 if seed % 2 else None
+    w = None if und_w is None else torch.cat([und_w, und_w])
+    label = KK.graclus_match(ei.to(dev), None if w is None else w.to(dev), n).cpu()
+    idx = torch.arange(n)
+    partner_count = torch.bincount(label, minlength=n)
+    assert partner_count.max() <= 2 and torch.all(label <= idx)
+    assert torch.equal(label[label], label)                      # representatives label themselves
+    matched = partner_count[label] == 2
+    nl = ei[:, ei[0] != ei[1]]
+    pairs = set(map(tuple, nl.t().tolist()))
+    for i in (matched & (label != idx)).nonzero().view(-1).tolist():
+        assert (i, int(label[i])) in pairs                        # partners are adjacent
+    both_free = ~matched[nl[0]] & ~matched[nl[1]]
+    assert not bool(both_free.any())                              # maximal: no edge between two free nodes
+    if w is not None and n <= 200 and nl.size(1):                 # distinct weights: unique greedy answer
+        order = torch.argsort(w[ei[0] != ei[1]], descending=True)
+        ref = idx.clone()
+        free = torch.ones(n, dtype=torch.bool)
+        for k in order.tolist():
+            a, b = int(nl[0, k]), int(nl[1, k])
+            if free[a] and free[b]:
+                free[a] = free[b] = False
+                ref[a] = ref[b] = min(a, b)
+        assert torch.equal(label, ref)
+    so = GraclusSelect()(ei.to(dev), None if w is None else w.to(dev), num_nodes=n)
+    ids = torch.unique(label)
+    assert so.num_supernodes == ids.numel()
+    assert torch.equal(so.cluster_index.cpu(), torch.searchsorted(ids, label))
+    assert torch.equal(so.node_index.cpu(), idx)

@@ -327,6 +327,33 @@ def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Te
     return node_index, cluster_index, AssignIndex(row_ptr, perm, k_total, k_total)
 
 
+def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int, max_rounds: int = 64) -> Tensor:
+    """label[i] = min(i, partner) of a heavy-edge maximal matching (select/graclus_select.py:66 ->
+    torch_cluster.graclus_cluster): handshake rounds on the device until a round matches nothing."""
+    dev = N.require_device(edge_index, edge_weight)
+    row, col = _edge_rows(edge_index)
+    E = row.numel()
+    w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
+    index = build_assign_index(row, num_nodes)
+    label = torch.empty(num_nodes, dtype=torch.int64, device=dev)
+    L = N.lib()
+    st = N.stream_ptr(dev)
+    ws = N.workspace(L.tgp_graclus_match_workspace_bytes(num_nodes, E), dev)
+    N.check(L.tgp_graclus_match_start(N.ptr(col), N.ptr(w), N.ptr(index.row_ptr), N.ptr(index.perm), num_nodes, E,
+                                      N.ptr(ws), ws.numel(), N.ptr(label), st), "tgp_graclus_match_start")
+    done, step = 0, 6
+    while done < max_rounds and num_nodes > 0 and E > 0:
+        step = min(step, max_rounds - done)
+        matched = torch.empty(step, dtype=torch.int32, device=dev)
+        N.check(L.tgp_graclus_match_rounds(N.ptr(index.row_ptr), num_nodes, E, N.ptr(ws), step, N.ptr(matched),
+                                           N.ptr(label), st), "tgp_graclus_match_rounds")
+        done += step
+        if int(matched[-1].item()) == 0:  # one round trip per batch of rounds
+            break
+        step = 4
+    return label
+
+
 def _rows_f32(x: Tensor) -> Tensor:
     x = x.to(torch.float32) if x.dtype != torch.float32 else x
     return x if x.stride(1) == 1 else x.contiguous()

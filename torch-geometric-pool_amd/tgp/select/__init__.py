@@ -547,6 +547,17 @@ class GraclusSelect(Select):
                 num_nodes: Optional[int] = None, **kwargs) -> SelectOutput:
         edge_index, edge_weight = connectivity_to_edge_index(edge_index, edge_weight)
         num_nodes = maybe_num_nodes(edge_index, num_nodes)
+        if edge_index.is_cuda:
+            # native matching + scan-based relabelling (no sort): representatives keep their relative order
+            from .. import kernels
+            pair = kernels.graclus_match(edge_index, edge_weight, num_nodes)
+            nodes = torch.arange(num_nodes, device=pair.device)
+            rank = torch.cumsum(pair == nodes, 0) - 1
+            assignment = rank[pair]
+            k = int(rank[-1]) + 1 if num_nodes else 0
+            s = torch.sparse_coo_tensor(torch.stack([nodes, assignment]), torch.ones(num_nodes, device=pair.device),
+                                        size=(num_nodes, k), is_coalesced=True)
+            return SelectOutput(s=s, s_inv_op=self.s_inv_op)
         pair = graclus_cluster(edge_index[0], edge_index[1], edge_weight, num_nodes)
         ids, assignment = torch.unique(pair, sorted=True, return_inverse=True)
         return SelectOutput(node_index=torch.arange(num_nodes, device=assignment.device), num_nodes=num_nodes,
