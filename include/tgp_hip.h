@@ -206,8 +206,9 @@ int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t
  * A14  GraclusSelect's matching (select/graclus_select.py:62-81 -> torch_cluster 1.6.3 graclus_cluster, absent
  * from the reference tree; its published algorithm: pair every node with its heaviest unmatched neighbour).
  * Data-parallel handshake rounds over the CSR of the edge list (row_ptr / perm = tgp_assign_index_build of the
- * source ids); label[i] = min(i, partner) or i.  _start gathers the CSR and resets the state, _rounds runs
- * `rounds` propose/match rounds and reports the nodes matched per round in matched[rounds] (device memory):
+ * source ids; perm may be NULL when the list is already sorted by source, with row_ptr from
+ * tgp_rowptr_from_sorted_i64); label[i] = min(i, partner) or i.  _start gathers the CSR and resets the state,
+ * _rounds runs `rounds` propose/match rounds and sets matched[r] = 1 if round r formed a pair (device memory):
  * the matching is maximal once a round matches nothing. */
 size_t tgp_graclus_match_workspace_bytes(int64_t num_nodes, int64_t num_edges);
 int tgp_graclus_match_start(const int64_t* col, const float* weight /* NULL = ones */, const int32_t* row_ptr,

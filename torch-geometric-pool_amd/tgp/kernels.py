@@ -334,23 +334,29 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
     row, col = _edge_rows(edge_index)
     E = row.numel()
     w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
-    index = build_assign_index(row, num_nodes)
     label = torch.empty(num_nodes, dtype=torch.int64, device=dev)
     L = N.lib()
     st = N.stream_ptr(dev)
+    # PyG lists are sorted by source: one comparison pass + round trip decides whether the CSR needs a sort at all
+    if E > 1 and bool((row[1:] >= row[:-1]).all()):
+        row_ptr, perm = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev), None
+        N.check(L.tgp_rowptr_from_sorted_i64(N.ptr(row), E, num_nodes, N.ptr(row_ptr), st), "tgp_rowptr_from_sorted_i64")
+    else:
+        index = build_assign_index(row, num_nodes)
+        row_ptr, perm = index.row_ptr, index.perm
     ws = N.workspace(L.tgp_graclus_match_workspace_bytes(num_nodes, E), dev)
-    N.check(L.tgp_graclus_match_start(N.ptr(col), N.ptr(w), N.ptr(index.row_ptr), N.ptr(index.perm), num_nodes, E,
+    N.check(L.tgp_graclus_match_start(N.ptr(col), N.ptr(w), N.ptr(row_ptr), N.ptr(perm), num_nodes, E,
                                       N.ptr(ws), ws.numel(), N.ptr(label), st), "tgp_graclus_match_start")
-    done, step = 0, 6
+    done, step = 0, 3
     while done < max_rounds and num_nodes > 0 and E > 0:
         step = min(step, max_rounds - done)
         matched = torch.empty(step, dtype=torch.int32, device=dev)
-        N.check(L.tgp_graclus_match_rounds(N.ptr(index.row_ptr), num_nodes, E, N.ptr(ws), step, N.ptr(matched),
+        N.check(L.tgp_graclus_match_rounds(N.ptr(row_ptr), num_nodes, E, N.ptr(ws), step, N.ptr(matched),
                                            N.ptr(label), st), "tgp_graclus_match_rounds")
         done += step
         if int(matched[-1].item()) == 0:  # one round trip per batch of rounds
             break
-        step = 4
+        step = 2
     return label
 
 
