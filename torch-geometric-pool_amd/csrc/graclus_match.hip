@@ -56,20 +56,36 @@ __global__ __launch_bounds__(256) void gm_propose_kernel(const int32_t* __restri
     float bw = 0.f;
     uint32_t bh = 0;
     const int32_t lo = row_ptr[i], hi = row_ptr[i + 1];
-    for (int32_t p = lo; p < hi; ++p) {
-      const int32_t j = nbr[p];
-      if (j == i || !is_free[j]) continue;
-      const float wj = wt[p];
-      if (wj != wj) continue;  // NaN weights never match
-      const uint32_t a = static_cast<uint32_t>(i < j ? i : j), b = static_cast<uint32_t>(i < j ? j : i);
-      const uint32_t h = pair_hash(a, b);
-      // lexicographic (w, hash, min, max); min/max only matter for hash collisions between different pairs
-      bool better = best < 0 || wj > bw || (wj == bw && h > bh);
-      if (!better && best >= 0 && wj == bw && h == bh && j != best) {
-        const uint32_t ca = static_cast<uint32_t>(i < best ? i : best), cb = static_cast<uint32_t>(i < best ? best : i);
-        better = a > ca || (a == ca && b > cb);
+    // A wave is as slow as its slowest lane and a lane's scan is a chain of dependent loads (neighbour id ->
+    // its free flag), so the neighbours are taken eight at a time: ids first, then flags and weights together.
+    constexpr int U = 8;
+    for (int32_t p0 = lo; p0 < hi; p0 += U) {
+      int32_t js[U];
+      float ws[U];
+      uint8_t fs[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) js[u] = p0 + u < hi ? nbr[p0 + u] : -1;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        fs[u] = js[u] >= 0 ? is_free[js[u]] : 0;
+        ws[u] = js[u] >= 0 ? wt[p0 + u] : 0.f;
       }
-      if (better) { best = j; bw = wj; bh = h; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int32_t j = js[u];
+        if (j < 0 || j == i || !fs[u]) continue;
+        const float wj = ws[u];
+        if (wj != wj) continue;  // NaN weights never match
+        const uint32_t a = static_cast<uint32_t>(i < j ? i : j), b = static_cast<uint32_t>(i < j ? j : i);
+        const uint32_t h = pair_hash(a, b);
+        // lexicographic (w, hash, min, max); min/max only matter for hash collisions between different pairs
+        bool better = best < 0 || wj > bw || (wj == bw && h > bh);
+        if (!better && best >= 0 && wj == bw && h == bh && j != best) {
+          const uint32_t ca = static_cast<uint32_t>(i < best ? i : best), cb = static_cast<uint32_t>(i < best ? best : i);
+          better = a > ca || (a == ca && b > cb);
+        }
+        if (better) { best = j; bw = wj; bh = h; }
+      }
     }
     // No free neighbour left: the free set only shrinks, so this node stays single -- retire it, later rounds
     // skip its scan.  (No free node is adjacent to it, so nobody's proposal depends on this flag.)
