@@ -445,3 +445,25 @@ def test_segment_gemm_long_ragged_graphs(dev, K, F):
         lo, hi = int(ptr[b]), int(ptr[b + 1])
         ref = (s[lo:hi].double().t() @ y[lo:hi].double()).float()
         torch.testing.assert_close(got[b], ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("trans_a", [False, True])
+def test_bmm_every_small_odd_shape(dev, trans_a):
+    """The buffer-load GEMM path with dword-aligned (not 16-byte-aligned) rows: every vector that runs past a row
+    end, a k range or the end of the matrix must contribute exactly the in-range elements (lift/base_lift.py:138-247
+    and the backward products run through this entry point with arbitrary N, K, F)."""
+    from tgp import kernels as KK
+    g = torch.Generator(device=dev).manual_seed(11)
+    for M in (1, 2, 3, 5, 33, 66):
+        for Kd in (1, 2, 3, 5, 7, 31, 33, 65):
+            for Nc in (1, 2, 3, 5, 7, 34):
+                a = torch.randn(3, Kd, M, device=dev, generator=g) if trans_a else torch.randn(3, M, Kd, device=dev, generator=g)
+                b = torch.randn(3, Kd, Nc, device=dev, generator=g)
+                got = KK.bmm(a, b, trans_a=trans_a)
+                ref = (a.transpose(1, 2) if trans_a else a).double() @ b.double()
+                torch.testing.assert_close(got, ref.float(), rtol=1e-5, atol=1e-4, msg=lambda m: f"M={M} Kd={Kd} Nc={Nc}: {m}")
+    # a sub-view whose base pointer is only dword-aligned
+    base = torch.randn(3 * 37 * 29 + 1, device=dev, generator=g)
+    a = base[1:].view(3, 37, 29)
+    b = torch.randn(3, 29, 11, device=dev, generator=g)
+    torch.testing.assert_close(KK.bmm(a, b), (a.double() @ b.double()).float(), rtol=1e-5, atol=1e-4)

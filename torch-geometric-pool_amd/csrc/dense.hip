@@ -102,8 +102,9 @@ __device__ __forceinline__ float4 ld4_guarded(const float* p, bool ok) {
 // loaded once per 128 x 128 of output - measured 143 TFLOP/s at C5 against 137 for the 8-wave NT = 2 form),
 // 128 x 64 and 64 x 128 with 8 waves, 64 x 64 with 4 waves (when the bigger tiles would leave CUs idle).
 // A_KMAJOR = false: A stored [M][Kd] (k contiguous).  true: stored [Kd][M] (m contiguous).
-// ALIGNED: every leading dimension / extent is a multiple of 4 floats and every base is 16-byte
-// aligned, so all traffic is float4 with one predicate per vector.  Otherwise: scalar guarded path.
+// ALIGNED: buffer-descriptor path, all traffic is 16-byte vectors with one predicate per vector; bases and
+// leading dimensions need dword alignment only (see gemm_aligned).  Otherwise: scalar guarded path (matrices too
+// large for 32-bit descriptor offsets).
 // MODE 0: C = op(A) Bm.  MODE 1 (link-prediction residual, utils/losses.py:644-708): Bm is stored
 // [Nc][Kd] (n-major, i.e. the product is A Bm^T), and instead of storing C the epilogue accumulates
 // sum((resid - C)^2) over the tile, so S S^T never exists in memory.
@@ -225,7 +226,12 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
     if constexpr (ALIGNED) {
       const int soff = A_KMAJOR ? k0 * static_cast<int>(lda) * 4 : k0 * 4;
       if (!tail) return buf_ld4(rsrc_a, voff_a[i], soff);  // steady state: no per-lane arithmetic at all
-      return buf_ld4(rsrc_a, k0 + kloc_a[i] < k_end ? voff_a[i] : OOB, soff);
+      float4 v = buf_ld4(rsrc_a, k0 + kloc_a[i] < k_end ? voff_a[i] : OOB, soff);
+      if constexpr (!A_KMAJOR) {  // k runs along the vector: a range that is not a multiple of 4 ends inside one
+        const int rem = k_end - (k0 + kloc_a[i]);
+        if (rem < 4) { v.w = 0.f; if (rem < 3) v.z = 0.f; if (rem < 2) v.y = 0.f; }
+      }
+      return v;
     } else {
       int m, k;
       if constexpr (!A_KMAJOR) {  // [BM m][32 k]: 8 lanes cover one 128-byte row segment
@@ -249,7 +255,12 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
     if constexpr (ALIGNED) {
       const int soff = MODE == 1 ? k0 * 4 : k0 * static_cast<int>(ldb) * 4;
       if (!tail) return buf_ld4(rsrc_b, voff_b[i], soff);
-      return buf_ld4(rsrc_b, k0 + kloc_b[i] < k_end ? voff_b[i] : OOB, soff);
+      float4 v = buf_ld4(rsrc_b, k0 + kloc_b[i] < k_end ? voff_b[i] : OOB, soff);
+      if constexpr (MODE == 1) {
+        const int rem = k_end - (k0 + kloc_b[i]);
+        if (rem < 4) { v.w = 0.f; if (rem < 3) v.z = 0.f; if (rem < 2) v.y = 0.f; }
+      }
+      return v;
     } else {
       float t[4];
       if constexpr (MODE == 1) {        // [BN n][32 k]: 8 lanes cover one 128-byte row segment
@@ -453,21 +464,22 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
   TGP_STAMP(3);
 }
 
-// k_rows: both operands are stored one k per row (A k-major, Bm [Kd][Nc]); then a k range may start and
-// end anywhere (segment products over ptr[b]..ptr[b+1]) without breaking 16-byte alignment.
-static bool gemm_aligned(const GemmArgs& g, bool k_rows) {
-  auto ok = [](const void* p, long ld, long s) {
-    return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && (ld % 4 == 0) && (s % 4 == 0);
-  };
-  // row-major A (m_ptr mode) is only ever read along k, so ragged row ranges keep every vector aligned
-  bool a = ok(g.A, g.lda, g.sA) && (g.M % 4 == 0 || g.m_ptr);
-  if (!k_rows) a = a && (g.Kd % 4 == 0) && (g.k_per_split % 4 == 0) && !g.k_ptr;
-  // the aligned path addresses each batch element through a buffer descriptor with 32-bit byte offsets
+// The buffer-load path needs dword alignment only (compute queues run in unaligned-access mode, so a 16-byte
+// load may start on any dword): a vector that runs past the end of its row picks up the head of the next row,
+// which is either masked (k tail, see load_a / load_b) or lands in output rows / columns that are never stored;
+// past the end of the matrix the descriptor's per-dword range check returns zeros.  What remains a requirement
+// is that every matrix fits the 32-bit byte offsets of a descriptor.  TGP_GEMM_SCALAR=1 forces the guarded
+// scalar path (diagnostic).
+static bool gemm_aligned(const GemmArgs& g, bool /*k_rows*/) {
+  static const bool force_scalar = getenv("TGP_GEMM_SCALAR") && atoi(getenv("TGP_GEMM_SCALAR"));
+  if (force_scalar) return false;
+  auto ok = [](const void* p, long, long) { return reinterpret_cast<uintptr_t>(p) % 4 == 0; };
+  bool a = ok(g.A, g.lda, g.sA);
   const long lim = (1l << 31) - 4096;
   a = a && (static_cast<long>(g.M) * g.lda * 4 < lim) && (static_cast<long>(g.Kd) * g.lda * 4 < lim);
   for (int w = 0; w < 2; ++w)
     if (w == 0 || g.tiles_n > g.tiles_n0)
-      a = a && ok(g.rhs[w].Bm, g.rhs[w].ldb, g.rhs[w].sB) && (g.rhs[w].Nc % 4 == 0) &&
+      a = a && ok(g.rhs[w].Bm, g.rhs[w].ldb, g.rhs[w].sB) &&
           (static_cast<long>(g.Kd) * g.rhs[w].ldb * 4 < lim) && (static_cast<long>(g.rhs[w].Nc) * g.rhs[w].ldb * 4 < lim);
   return a;
 }
