@@ -251,17 +251,20 @@ def test_lift_roundtrip(dev):
     torch.testing.assert_close(lifted, ref, rtol=RTOL, atol=ATOL)
 
 
-def test_small_graph_kernel_flag_grid(dev):
-    """One-wave-per-graph path (N <= 64, K <= 32, F <= 32, B >= 64): every post-processing flag
-    combination, ragged graph sizes (zero-padded rows as MLPSelect leaves them) and both A layouts."""
+@pytest.mark.parametrize("shape", [(96, 60, 20, 32), (70, 61, 19, 31), (64, 63, 32, 5), (65, 33, 1, 1), (80, 64, 7, 30),
+                                   (66, 100, 20, 32), (64, 126, 40, 64), (70, 200, 50, 37), (64, 257, 64, 128)])
+def test_small_graph_kernel_flag_grid(dev, shape):
+    """One-wave-per-graph path (N <= 64, K <= 32, F <= 32, B >= 64) and the one-workgroup-per-graph path above it:
+    every post-processing flag combination, ragged graph sizes (zero-padded rows as MLPSelect leaves them), both A
+    layouts, and N, K, F that are not multiples of 4 (a padded batch takes its N from the longest graph)."""
     import tgp_oracle as O
     from tgp import kernels
     from tgp.connect import DenseConnect
     from tgp.reduce import BaseReduce
     from tgp.select import SelectOutput
     g = torch.Generator().manual_seed(11)
-    B, N, K, F = 96, 60, 20, 32
-    n_b = torch.randint(20, 61, (B,), generator=g)
+    B, N, K, F = shape
+    n_b = torch.randint(max(1, N // 3), N + 1, (B,), generator=g)
     mask = torch.arange(N).unsqueeze(0) < n_b.unsqueeze(1)
     A = (torch.rand(B, N, N, generator=g) < 0.15).float() * torch.rand(B, N, N, generator=g)
     A = A * mask.unsqueeze(1) * mask.unsqueeze(2)

@@ -1044,13 +1044,20 @@ __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
     if (p.A) {  // 16 lanes per row (64 floats), 4 rows per wave-instruction, 16 instructions
       const float* Ab = p.A + static_cast<long>(b) * N * N;
       const int q = lane & 15;
-      const bool qok = 4 * q < N;
+      const bool qfull = 4 * q + 3 < N;   // whole vector inside the row (rows need dword alignment only)
+      const int qrem = N - 4 * q;         // 1..3 on the lane that holds a row's ragged tail (N % 4 != 0)
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int i = (lane >> 4) + 4 * t;
-        const bool ok = qok && i < N;
+        const bool ok = qfull && i < N;
         const float4 r = *reinterpret_cast<const float4*>(byte_off(Ab, ok ? (i * N + 4 * q) * 4 : 0));
         v[t] = ok ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!qfull && qrem > 0 && i < N) {  // never read past the end of the row (= of the tensor for the last one)
+          const float* tail = byte_off(Ab, (i * N + 4 * q) * 4);
+          v[t].x = tail[0];
+          if (qrem > 1) v[t].y = tail[1];
+          if (qrem > 2) v[t].z = tail[2];
+        }
       }
     }
     // step q of every product contracts node rows node(q) = 32*(q>>4) + rho(q&15) + 4*lk
@@ -1281,9 +1288,7 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
     return check_launch("tgp_dense_pool_f32");
   }
   static const int no_small = getenv("TGP_NO_SMALL_GRAPH_KERNEL") ? 1 : 0;
-  const bool small_ok = N <= SG_N && K <= SG_K && F <= SG_K && B >= 64 && N % 4 == 0 && K % 4 == 0 && F % 4 == 0 &&
-                        reinterpret_cast<uintptr_t>(S) % 16 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 &&
-                        reinterpret_cast<uintptr_t>(X) % 16 == 0;
+  const bool small_ok = N <= SG_N && K <= SG_K && F <= SG_K && B >= 64;  // any N, K, F: padded batches are ragged
   if (!no_small && small_ok) {
     SmallArgs q{S, want_a ? A : nullptr, want_x ? X : nullptr, static_cast<int>(B), static_cast<int>(N),
                 static_cast<int>(K), static_cast<int>(F), flags, want_x ? x_pool : nullptr,
