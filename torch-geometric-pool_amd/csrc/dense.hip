@@ -1210,6 +1210,224 @@ __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Medium graphs (TU-dataset-sized batches: N up to a few hundred, K <= 64): one WORKGROUP (4 waves) owns one
+// graph, every byte of A / X crosses HBM once and nothing intermediate leaves the CU.
+//   * S [N,K] is copied to LDS once (zero padded to 32-row / 32-column multiples); every MFMA reads one of its
+//     operands from there (lane = cluster: consecutive words, conflict-free).
+//   * A and X are read straight from HBM into the MFMA B-operand registers: lane = column, so a half-wave
+//     reads 128 contiguous bytes of one row per k-step -- the operand layout IS the memory layout, no staging
+//     (that is why the product is associated as (S^T A) S here; (A S) would need A transposed through LDS).
+//     Buffer-descriptor loads: rows / columns outside the graph come back as zeros from the range check.
+//   * work items = 32-column strips of A (then of X), dealt round-robin to the waves.  An A strip gives
+//     P = (S^T A)^T restricted to the strip, [32 nodes x K], with the strip as the MFMA A operand; register r
+//     of the C/D layout holds strip rows (rho(r), rho(r)+4) on the two half-waves = a k-pair of a B operand,
+//     so P goes straight from the accumulators into A'[c1][c2] += sum_n P[n][c1] S[n][c2] (no LDS round trip).
+//     The four waves' partial A' are added in wave order (deterministic), then the workgroup post-processes
+//     the K x K result in LDS (utils/ops.py:282-335) and stores it.
+// If memory holds A^T (TGP_ADJ_TRANSPOSED) the same program yields (A')^T, which is transposed on the way
+// into the post-processing buffer.
+// ------------------------------------------------------------------------------------------
+struct MediumArgs {
+  const float* S; const float* A; const float* X;
+  int B, N, K, F, flags;
+  float* x_pool; float* adj_raw; float* adj_pool;
+  int npad;  // N rounded up to 32
+};
+
+template <int MT>
+static size_t medium_lds_bytes(int64_t npad) {
+  constexpr int KP = 32 * MT;
+  return (static_cast<size_t>(npad) * KP + KP * (KP + 1) + KP) * sizeof(float);
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel(MediumArgs p) {
+  constexpr int KP = 32 * MT;          // padded K
+  constexpr int UNROLL = 8;            // k-pairs whose B operands are requested together
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, lm = lane & 31, lk = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = p.N, K = p.K, F = p.F, NP = p.npad;
+  const int b = blockIdx.x;
+  float* Ss = smem;                       // [NP][KP]
+  float* Rs = Ss + NP * KP;               // [KP][KP+1]
+  float* ds = Rs + KP * (KP + 1);         // [KP] degrees
+  const bool want_a = p.A && (p.adj_raw || p.adj_pool);
+  const bool want_x = p.X && p.x_pool;
+
+  // ---- S -> LDS (zero padded) ------------------------------------------------------------
+  {
+    const float* Sb = p.S + static_cast<long>(b) * N * K;
+    for (int e = tid; e < NP * KP; e += 256) {
+      const int r = e / KP, c = e - r * KP;
+      Ss[e] = (r < N && c < K) ? Sb[r * K + c] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  f32x16 racc[MT][MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) racc[i][j][r] = 0.f;
+
+  const int nt_a = want_a ? (N + 31) / 32 : 0;
+  const int nt_x = want_x ? (F + 31) / 32 : 0;
+  constexpr int OOB = static_cast<int>(0x80000000u);
+  for (int job = w; job < nt_a + nt_x; job += 4) {
+    const bool is_a = job < nt_a;
+    const int n0 = (is_a ? job : job - nt_a) * 32;
+    const int ld = is_a ? N : F;
+    const float* src = is_a ? p.A + static_cast<long>(b) * N * N : p.X + static_cast<long>(b) * N * F;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, N * ld * 4, 0x00020000);
+    const int voff = (n0 + lm < ld) ? (lk * ld + n0 + lm) * 4 : OOB;
+    // strip element (node row k + lk, column n0 + lm) of A or X; two register sets: the next batch of k-pairs
+    // is requested before the MFMAs of the current one
+    float gv[2][UNROLL];
+    auto request = [&](int set, int k0) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+        gv[set][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (k0 + 2 * u) * ld * 4, 0));
+    };
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // X strip:  X'[c][f]  = sum_k S[k][c] X[k][f]    (S = A operand from LDS, the strip = B operand)
+    // A strip:  P [n][c]  = sum_k A[k][n] S[k][c]    (the strip = A operand, S = B operand from LDS) = T^T
+    auto consume = [&](auto is_a_c, int set, int k0) {
+      constexpr bool IS_A = decltype(is_a_c)::value;
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int k = k0 + 2 * u + lk;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const float sv = Ss[k * KP + i * 32 + lm];
+          if constexpr (IS_A) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[set][u], sv, acc[i], 0, 0, 0);
+          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, gv[set][u], acc[i], 0, 0, 0);
+        }
+      }
+    };
+    auto k_loop = [&](auto is_a_c) {
+      request(0, 0);
+      for (int k0 = 0; k0 < NP; k0 += 4 * UNROLL) {  // NP is a multiple of 32 = 4 * UNROLL node rows
+        request(1, k0 + 2 * UNROLL);
+        consume(is_a_c, 0, k0);
+        if (k0 + 4 * UNROLL < NP) request(0, k0 + 4 * UNROLL);
+        consume(is_a_c, 1, k0 + 2 * UNROLL);
+      }
+    };
+    if (is_a) k_loop(std::true_type{});   // wave-uniform branch: one operand order per loop body
+    else k_loop(std::false_type{});
+    if (!is_a) {  // X' strip: rows = clusters, cols = features n0 .. n0+31
+      if (n0 + lm < F) {
+        float* o = p.x_pool + static_cast<long>(b) * K * F;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = i * 32 + rho(r) + 4 * lk;
+            if (c < K) o[c * F + n0 + lm] = acc[i][r];
+          }
+      }
+      continue;
+    }
+    // R[c1][c2] = sum_n P[n][c1] S[n][c2]: register r of the C/D layout holds strip rows (rho(r), rho(r)+4) on the
+    // two half-waves, which is exactly a k-pair of a B operand, so P never leaves the accumulators:
+    //   D[row = c2][col = c1] += S[n0 + rho(r) + 4 lk][c2]  x  P_r[c1]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float sv[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) sv[i] = Ss[(n0 + rho(r) + 4 * lk) * KP + i * 32 + lm];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+          racc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[i], acc[j][r], racc[i][j], 0, 0, 0);
+    }
+  }
+  if (!want_a) return;
+
+  // ---- A' = sum of the four partial products, in wave order ---------------------------------
+  const bool at = p.flags & TGP_ADJ_TRANSPOSED;
+  for (int turn = 0; turn < 4; ++turn) {
+    if (w == turn) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c2 = i * 32 + rho(r) + 4 * lk, c1 = j * 32 + lm;  // the accumulators hold R[c1][c2]
+            float* d = at ? &Rs[c2 * (KP + 1) + c1] : &Rs[c1 * (KP + 1) + c2];
+            *d = turn == 0 ? racc[i][j][r] : __fadd_rn(*d, racc[i][j][r]);
+          }
+    }
+    __syncthreads();
+  }
+
+  // ---- post-processing on the K x K result (utils/ops.py:282-335) ---------------------------
+  // element loops run over the padded [K][KP] index space: row / column come from shifts, not divisions
+  const long obase = static_cast<long>(b) * K * K;
+  if (p.adj_raw) {
+    for (int e = tid; e < K * KP; e += 256) {
+      const int i = e / KP, j = e % KP;
+      if (j < K) p.adj_raw[obase + i * K + j] = Rs[i * (KP + 1) + j];
+    }
+    __syncthreads();  // the diagonal is cleared next
+  }
+  if (!p.adj_pool) return;
+  if (p.flags & TGP_REMOVE_SELF_LOOPS) {
+    if (tid < K) Rs[tid * (KP + 1) + tid] = 0.f;
+    __syncthreads();
+  }
+  if (p.flags & TGP_DEGREE_NORM) {
+    const bool rows = p.flags & TGP_SUM_AXIS_ROWS;
+    if (tid < K) {
+      float t = 0.f;
+      for (int q = 0; q < K; ++q) t = __fadd_rn(t, rows ? Rs[q * (KP + 1) + tid] : Rs[tid * (KP + 1) + q]);
+      ds[tid] = sqrtf(fmaxf(t, TGP_EPS));
+    }
+    __syncthreads();
+    for (int e = tid; e < K * KP; e += 256) {
+      const int i = e / KP, j = e % KP;
+      if (j < K) {
+        const float first = rows ? ds[j] : ds[i], second = rows ? ds[i] : ds[j];
+        Rs[i * (KP + 1) + j] = (Rs[i * (KP + 1) + j] / first) / second;
+      }
+    }
+    __syncthreads();
+  }
+  float scale = 1.f;
+  if (p.flags & TGP_EDGE_WEIGHT_NORM) {
+    float m = 0.f;
+    for (int e = tid; e < K * KP; e += 256) {
+      const int i = e / KP, j = e % KP;
+      if (j < K) m = fmaxf(m, fabsf(Rs[i * (KP + 1) + j]));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, WAVE));
+    __syncthreads();
+    if (lane == 0) ds[w] = m;
+    __syncthreads();
+    scale = fmaxf(fmaxf(ds[0], ds[1]), fmaxf(ds[2], ds[3]));
+    if (scale == 0.f) scale = 1.f;
+  }
+  for (int e = tid; e < K * KP; e += 256) {
+    const int i = e / KP, j = e % KP;
+    if (j < K) {
+      const float v = Rs[i * (KP + 1) + j];
+      p.adj_pool[obase + i * K + j] = (p.flags & TGP_EDGE_WEIGHT_NORM) ? v / scale : v;
+    }
+  }
+}
+
 static const int kStage2Tile = getenv("TGP_STAGE2_TILE") ? atoi(getenv("TGP_STAGE2_TILE")) : 0;
 static const int kStage2TileM = getenv("TGP_STAGE2_TILE_M") ? atoi(getenv("TGP_STAGE2_TILE_M")) : 0;
 struct DensePlan {
@@ -1296,6 +1514,26 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
     const int grid = static_cast<int>((B + 3) / 4);
     hipLaunchKernelGGL(dense_pool_small_kernel, dim3(grid), dim3(256), 4 * SG_WAVE_FLOATS * sizeof(float), stream, q);
     return check_launch("tgp_dense_pool_f32(small)");
+  }
+  // One workgroup per graph while S and the K x K result fit LDS (measured faster than the tiled path from 8 graphs
+  // up, also with a single resident workgroup per CU; below that the tiled GEMM path splits the work finer).
+  static const int no_medium = getenv("TGP_NO_MEDIUM_GRAPH_KERNEL") ? 1 : 0;
+  static const int kMediumMinGraphs = getenv("TGP_MEDIUM_MIN_GRAPHS") ? atoi(getenv("TGP_MEDIUM_MIN_GRAPHS")) : 8;
+  static const int kMediumMaxLds = getenv("TGP_MEDIUM_MAX_LDS") ? atoi(getenv("TGP_MEDIUM_MAX_LDS")) : 152 * 1024;
+  if (!no_medium && K <= 64 && B >= kMediumMinGraphs && reinterpret_cast<uintptr_t>(S) % 4 == 0) {
+    const int64_t npad = (N + 31) / 32 * 32;
+    const size_t lds = K <= 32 ? medium_lds_bytes<1>(npad) : medium_lds_bytes<2>(npad);
+    const bool fits32 = static_cast<int64_t>(N) * (N > F ? N : F) * 4 < (1ll << 31) - 4096;
+    if (lds <= static_cast<size_t>(kMediumMaxLds) && fits32) {
+      MediumArgs q{S, want_a ? A : nullptr, want_x ? X : nullptr, static_cast<int>(B), static_cast<int>(N),
+                   static_cast<int>(K), static_cast<int>(F), flags, want_x ? x_pool : nullptr,
+                   want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr, static_cast<int>(npad)};
+      if (K <= 32)
+        hipLaunchKernelGGL(dense_pool_medium_kernel<1>, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, q);
+      else
+        hipLaunchKernelGGL(dense_pool_medium_kernel<2>, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, q);
+      return check_launch("tgp_dense_pool_f32(medium)");
+    }
   }
   TGP_REQUIRE(ws && ws_bytes >= tgp_dense_pool_workspace_bytes(B, N, K, F), TGP_ERR_WORKSPACE,
               "tgp_dense_pool_f32: workspace too small");
