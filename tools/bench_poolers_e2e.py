@@ -69,6 +69,19 @@ x2 = torch.randn(n2, F2, device=dev, generator=g)
 for nm in ("diff", "mincut", "diff_u", "mincut_u"):
     cases.append((f"{nm} B=32 N=1024 K=128 F=64 (sparse input)", (lambda nm=nm: get_pooler(nm, in_channels=F2, k=128)),
                   x2, ei2, None, batch2))
+# PROTEINS-like batch: 2048 graphs of 20..60 nodes, K=20, F=32 (BASELINE configs[2] shape)
+sizes3 = torch.randint(20, 61, (2048,), device=dev, generator=g)
+batch3 = torch.repeat_interleave(torch.arange(2048, device=dev), sizes3)
+ptr3 = torch.cat([sizes3.new_zeros(1), sizes3.cumsum(0)])
+n3 = batch3.numel()
+src3 = torch.arange(n3, device=dev).repeat_interleave(2)
+dst3 = ptr3[batch3[src3]] + (torch.rand(src3.numel(), device=dev, generator=g) * sizes3[batch3[src3]]).long()
+key3 = torch.unique(torch.cat([src3 * n3 + dst3, dst3 * n3 + src3]))
+ei3 = torch.stack([key3 // n3, key3 % n3])
+x3 = torch.randn(n3, 32, device=dev, generator=g)
+for nm in ("mincut", "diff", "mincut_u"):
+    cases.append((f"{nm} small graphs B=2048 n~40 K=20 F=32", (lambda nm=nm: get_pooler(nm, in_channels=32, k=20)),
+                  x3, ei3, None, batch3))
 for name, mk, xx, e, w, b in cases:
     if only and not any(o in name for o in only):
         continue
