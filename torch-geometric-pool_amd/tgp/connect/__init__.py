@@ -114,12 +114,20 @@ class SparseConnect(Connect):
 
 
 class _DenseConnectFn(torch.autograd.Function):
-    """R = S^T A S on the matrix cores.  dS = A S dR^T + A^T S dR, dA = S dR S^T."""
+    """R = S^T A S on the matrix cores.  dS = A S dR^T + A^T S dR, dA = S dR S^T.  For graphs too large for the
+    one-workgroup-per-graph kernels U = A S is a tensor of its own here, shared with the backward and with the
+    link-prediction loss (functions.ASProducts)."""
 
     @staticmethod
     def forward(ctx, s, adj):
         ctx.save_for_backward(s, adj)
-        return K.dense_pool(s, adj, None, 0, want_raw=True, want_post=False)[1]
+        ctx.products = Fn.shared_products(s, adj)
+        B, n, k = s.shape
+        if n <= 512 and k <= 64:  # small / medium graphs: the fused kernel; U is cheap to redo in the backward
+            return K.dense_pool(s, adj, None, 0, want_raw=True, want_post=False)[1]
+        u = ctx.products.get_u(s, adj)
+        ptr = Fn._uniform_ptr(B, n, s.device)
+        return K.segment_gemm_tn(s.detach().reshape(B * n, k), u.reshape(B * n, k), ptr, n)
 
     @staticmethod
     def backward(ctx, g):
@@ -127,8 +135,8 @@ class _DenseConnectFn(torch.autograd.Function):
         g = g.contiguous()
         gs = ga = None
         if ctx.needs_input_grad[0]:
-            u = K.bmm(adj, s)                     # A S
-            v = K.bmm(adj, s, trans_a=True)       # A^T S
+            u = ctx.products.get_u(s, adj)   # A S
+            v = ctx.products.get_v(s, adj)   # A^T S
             gs = K.bmm(u, g.transpose(-1, -2).contiguous()) + K.bmm(v, g)
         if ctx.needs_input_grad[1]:
             ga = K.bmm(K.bmm(s, g), s.transpose(-1, -2).contiguous())

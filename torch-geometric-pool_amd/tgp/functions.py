@@ -279,6 +279,16 @@ def to_dense_batch(x: Tensor, batch: Tensor, ptr: Tensor, num_graphs: int, max_n
 _WHOLE_RANGE: dict = {}
 
 
+def _uniform_ptr(num_graphs: int, n: int, device) -> Tensor:
+    """[0, n, 2n, ...]: a padded batch seen as an un-padded one (segment products with split node ranges)."""
+    key = ("u", num_graphs, n, str(device))
+    if key not in _WHOLE_RANGE:
+        if len(_WHOLE_RANGE) > 64:
+            _WHOLE_RANGE.clear()
+        _WHOLE_RANGE[key] = torch.arange(num_graphs + 1, dtype=torch.long, device=device) * n
+    return _WHOLE_RANGE[key]
+
+
 def _whole_range(n: int, device) -> Tensor:
     key = (n, str(device))
     if key not in _WHOLE_RANGE:
@@ -392,3 +402,52 @@ class _RowDotFn(torch.autograd.Function):
 
 def row_dot(x: Tensor, w: Tensor) -> Tensor:
     return _RowDotFn.apply(x, w) if _needs_grad(x, w) else K.row_dot(x, w)
+
+
+# ------------------------------------------------- A S and A^T S shared between Connect and the link loss
+class ASProducts:
+    """U = A S and V = A^T S of one (S, A) pair, computed at most once.  DiffPool's training step needs U in the
+    Connect forward, U and V in its backward and both again in the link-prediction loss' backward
+    (poolers/diffpool.py:208-218): five N^2 K products where two suffice.  The object is found again in the forward
+    by the identity of the two live tensors and carried into the backward by the autograd contexts."""
+
+    __slots__ = ("s_ref", "adj_ref", "versions", "u", "v", "__weakref__")
+
+    def __init__(self, s: Tensor, adj: Tensor):
+        import weakref
+        self.s_ref, self.adj_ref = weakref.ref(s), weakref.ref(adj)
+        self.versions = (s._version, adj._version)
+        self.u = self.v = None
+
+    def matches(self, s: Tensor, adj: Tensor) -> bool:
+        return self.s_ref() is s and self.adj_ref() is adj and self.versions == (s._version, adj._version)
+
+    @staticmethod
+    def _product(s: Tensor, adj: Tensor, transposed: bool) -> Tensor:
+        mem, tflag = K._dense_adj_layout(adj)  # adj may be the transposed view of contiguous memory (src.py:442-443)
+        return K.bmm(mem, s, trans_a=bool(tflag) != transposed)
+
+    def get_u(self, s: Tensor, adj: Tensor) -> Tensor:
+        if self.u is None:
+            self.u = self._product(s.detach(), adj.detach(), False)
+        return self.u
+
+    def get_v(self, s: Tensor, adj: Tensor) -> Tensor:
+        if self.v is None:
+            self.v = self._product(s.detach(), adj.detach(), True)
+        return self.v
+
+
+import weakref as _weakref
+
+_PRODUCTS: "_weakref.WeakValueDictionary" = _weakref.WeakValueDictionary()
+
+
+def shared_products(s: Tensor, adj: Tensor) -> ASProducts:
+    key = (id(s), id(adj))
+    hit = _PRODUCTS.get(key)
+    if hit is not None and hit.matches(s, adj):
+        return hit
+    fresh = ASProducts(s, adj)
+    _PRODUCTS[key] = fresh
+    return fresh

@@ -75,6 +75,7 @@ class _LinkNormFn(torch.autograd.Function):
     def forward(ctx, S, adj):
         norm = torch.sqrt(K.link_loss_sq(S, adj).sum())
         ctx.save_for_backward(S, adj, norm)
+        ctx.products = Fn.shared_products(S, adj)  # A S, A^T S: shared with DenseConnect's backward
         return norm
 
     @staticmethod
@@ -84,7 +85,7 @@ class _LinkNormFn(torch.autograd.Function):
         g_s = g_adj = None
         if ctx.needs_input_grad[0]:
             gram = K.dense_pool(S, None, S)[0]
-            g_s = (2.0 * K.bmm(S, gram) - K.bmm(adj, S) - K.bmm(adj, S, trans_a=True)) * coef
+            g_s = (2.0 * K.bmm(S, gram) - ctx.products.get_u(S, adj) - ctx.products.get_v(S, adj)) * coef
         if ctx.needs_input_grad[1]:
             g_adj = (adj - torch.matmul(S, S.transpose(1, 2))) * coef
         return g_s, g_adj
