@@ -327,3 +327,41 @@ def test_row_dot_and_gradients(dev, F):
     xs = x0[:, : max(1, F // 2)]  # strided rows
     torch.testing.assert_close(Fn.row_dot(xs, w0[:, : xs.size(1)]), (xs * w0[:, : xs.size(1)]).sum(-1), rtol=1e-5,
                                atol=1e-4)
+
+
+@pytest.mark.parametrize("rsl,dn,at", [(True, True, True), (True, True, False), (False, True, True), (True, False, False),
+                                       (False, True, False)])
+def test_postprocess_dense_closed_form_backward(dev, rsl, dn, at):
+    """A8 (utils/ops.py:282-335) under autograd: native forward + closed-form backward against torch autograd of the
+    elementwise form, including a graph whose degree sums sit below eps (clamped: zero gradient through the sum)."""
+    from tgp.utils.ops import _postprocess_dense_autograd, postprocess_adj_pool_dense
+    g = torch.Generator(device=dev).manual_seed(3)
+    a0 = torch.rand(5, 9, 9, device=dev, generator=g) + 0.05
+    a0[2] = 0.0                      # empty graph: every degree is clamped at eps
+    a0[3, :, 4] = 0.0
+    a0[3, 4, :] = 0.0                # an isolated supernode
+    go = torch.randn(5, 9, 9, device=dev, generator=g)
+    a = a0.clone().requires_grad_(True)
+    out = postprocess_adj_pool_dense(a, rsl, dn, at, False)
+    (out * go).sum().backward()
+    b = a0.clone().requires_grad_(True)
+    ref = _postprocess_dense_autograd(b, rsl, dn, at, False)
+    (ref * go).sum().backward()
+    torch.testing.assert_close(out.detach(), ref.detach(), **TOL)
+    torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_orthogonality_loss_closed_form_backward(dev):
+    from tgp.utils.losses import orthogonality_loss
+    g = torch.Generator(device=dev).manual_seed(4)
+    S0 = torch.softmax(torch.randn(6, 40, 7, device=dev, generator=g), -1)
+    S = S0.clone().requires_grad_(True)
+    loss = orthogonality_loss(S)
+    loss.backward()
+    S2 = S0.clone().requires_grad_(True)
+    sts = S2.transpose(1, 2) @ S2
+    sts = sts / torch.norm(sts, dim=(-2, -1), keepdim=True)
+    ref = torch.norm(sts - torch.eye(7, device=dev) / 7 ** 0.5, dim=(-2, -1)).mean()
+    ref.backward()
+    torch.testing.assert_close(loss.detach(), ref.detach(), **TOL)
+    torch.testing.assert_close(S.grad, S2.grad, rtol=1e-4, atol=1e-6)

@@ -471,3 +471,37 @@ def test_bmm_every_small_odd_shape(dev, trans_a):
     a = base[1:].view(3, 37, 29)
     b = torch.randn(3, 29, 11, device=dev, generator=g)
     torch.testing.assert_close(KK.bmm(a, b), (a.double() @ b.double()).float(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("alias,shape", [("mincut", (256, 60, 20, 32)), ("diff", (16, 200, 40, 24)), ("diff", (4, 1024, 128, 64))])
+def test_dense_pooler_forward_is_hip_graph_capturable(dev, alias, shape):
+    """The native entry points neither synchronise nor allocate behind torch's back, so a whole dense pooler call on
+    pre-batched inputs (Select + fused Reduce/Connect + losses) can be captured once and replayed as a HIP graph."""
+    from tgp.poolers import get_pooler
+    B, N, K, F = shape
+    g = torch.Generator(device=dev).manual_seed(21)
+    pooler = get_pooler(alias, in_channels=F, k=K).to(dev).eval()
+    x = torch.randn(B, N, F, device=dev, generator=g)
+    adj = (torch.rand(B, N, N, device=dev, generator=g) < 0.1).float()
+    adj = torch.maximum(adj, adj.transpose(1, 2)).contiguous()
+    with torch.no_grad():
+        ref = pooler(x=x, adj=adj)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            pooler(x=x, adj=adj)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = pooler(x=x, adj=adj)
+        # new inputs in the captured buffers, then replay
+        x2 = torch.randn(B, N, F, device=dev, generator=g)
+        x.copy_(x2)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref2 = pooler(x=x, adj=adj)
+    assert not torch.allclose(ref.x, ref2.x)
+    torch.testing.assert_close(out.x, ref2.x, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(out.edge_index, ref2.edge_index, rtol=RTOL, atol=ATOL)
+    for k in ref2.loss:
+        torch.testing.assert_close(out.loss[k], ref2.loss[k], rtol=1e-4, atol=1e-6)

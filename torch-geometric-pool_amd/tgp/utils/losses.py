@@ -109,8 +109,32 @@ def mincut_loss(adj: Tensor, S: Tensor, adj_pooled: Tensor, batch_reduction: str
     return _reduce(-(num / (den + eps)), batch_reduction)
 
 
+class _OrthoFromGramFn(torch.autograd.Function):
+    """l = || G / ||G||_F - I / sqrt(K) ||_F per graph (losses.py:59-70) with its closed-form gradient
+    dl/dG = (Y - <Y, G> G / n^2) / (n l),  Y = G / n - I / sqrt(K),  n = ||G||_F."""
+
+    @staticmethod
+    def forward(ctx, gram):
+        k = gram.size(-1)
+        n = torch.linalg.matrix_norm(gram, keepdim=True)
+        y = gram / n
+        y.diagonal(dim1=-2, dim2=-1).sub_(1.0 / math.sqrt(k))
+        l = torch.linalg.matrix_norm(y)
+        ctx.save_for_backward(gram, n, y, l)
+        return l
+
+    @staticmethod
+    def backward(ctx, g):
+        gram, n, y, l = ctx.saved_tensors
+        yg = (y * gram).sum(dim=(-2, -1), keepdim=True)
+        coef = (g / l).view(-1, 1, 1) / n
+        return coef * (y - yg * gram / (n * n))
+
+
 def orthogonality_loss(S: Tensor, batch_reduction: str = "mean") -> Tensor:
     sts = _GramFn.apply(S)
+    if sts.is_cuda and torch.is_grad_enabled() and sts.requires_grad:
+        return _reduce(_OrthoFromGramFn.apply(sts), batch_reduction)
     sts = sts / torch.norm(sts, dim=(-2, -1), keepdim=True)
     k = S.size(-1)
     target = torch.eye(k, device=S.device, dtype=S.dtype) / math.sqrt(k)

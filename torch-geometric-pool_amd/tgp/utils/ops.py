@@ -253,13 +253,54 @@ def postprocess_adj_pool_dense(adj_pool: Tensor, remove_self_loops: bool = False
     squeeze = adj_pool.dim() == 2
     a = adj_pool.unsqueeze(0) if squeeze else adj_pool
     if adj_pool.requires_grad and torch.is_grad_enabled():
-        out = _postprocess_dense_autograd(a, remove_self_loops, degree_norm, adj_transpose, edge_weight_norm)
+        if a.is_cuda and a.dtype == torch.float32 and not edge_weight_norm:
+            out = _PostprocessDenseFn.apply(a, remove_self_loops, degree_norm, adj_transpose)
+        else:
+            out = _postprocess_dense_autograd(a, remove_self_loops, degree_norm, adj_transpose, edge_weight_norm)
         return out.squeeze(0) if squeeze else out
     flags = K.dense_flags(remove_self_loops, degree_norm, adj_transpose, edge_weight_norm)
     # NB the reference also clears the diagonal of its *input* in place (ops.py:308); every caller passes a
     # freshly computed S^T A S, so that side effect is not reproduced (it would cost an extra pass).
     out = K.postprocess_dense(a, flags)
     return out.squeeze(0) if squeeze else out
+
+
+class _PostprocessDenseFn(torch.autograd.Function):
+    """A8 under autograd: the native kernel forward, a closed-form backward (a dozen [B,K,K] ops where autograd
+    over the elementwise form records ~45 tiny kernels per step).
+        R1 = R (1 - I);  c = sum_axis(R1);  d = sqrt(max(c, eps));  out_ij = R1_ij / (d_i d_j)
+        dR1_ij = G_ij / (d_i d_j) + dc_[axis index],   dc_k = -[c_k > eps] (rowsum_k(G out) + colsum_k(G out)) / (2 d_k^2)
+    """
+
+    @staticmethod
+    def forward(ctx, a, remove_self_loops, degree_norm, adj_transpose):
+        flags = K.dense_flags(remove_self_loops, degree_norm, adj_transpose, False)
+        out = K.postprocess_dense(a, flags)
+        ctx.cfg = (remove_self_loops, degree_norm, adj_transpose)
+        ctx.save_for_backward(a, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, out = ctx.saved_tensors
+        rsl, dn, at = ctx.cfg
+        k = a.size(-1)
+        keep = None
+        if rsl:
+            keep = 1.0 - torch.eye(k, device=a.device, dtype=a.dtype)
+        ga = g
+        if dn:
+            r1 = a * keep if rsl else a
+            c = r1.sum(-2 if at else -1)                        # [B,K]
+            d = torch.sqrt(c.clamp(min=eps))
+            inv = 1.0 / (d.unsqueeze(-1) * d.unsqueeze(-2))     # 1 / (d_i d_j)
+            go = g * out
+            dc = -(go.sum(-1) + go.sum(-2)) / (2.0 * d * d)
+            dc = torch.where(c >= eps, dc, torch.zeros_like(dc))  # clamp passes the gradient where c >= eps
+            ga = g * inv + (dc.unsqueeze(-2) if at else dc.unsqueeze(-1))
+        if rsl:
+            ga = ga * keep
+        return ga, None, None, None
 
 
 def _postprocess_dense_autograd(a, remove_self_loops, degree_norm, adj_transpose, edge_weight_norm):
