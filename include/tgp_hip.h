@@ -196,11 +196,13 @@ int tgp_segment_gemm_nn_f32(const float* A, const float* Bm, const int64_t* ptr,
  * Outputs (k_total = koff[B] entries, ordered by ascending node id = the reference's row-sorted COO):
  *   node_index, cluster_index (int64) and assign_perm (int32): assign_perm[c] = position of supernode c's
  *   single assignment, i.e. the inverted index the sparse Reduce consumes (tgp_assign_index_build's perm).
- * batch may be NULL when B == 1. */
+ * batch may be NULL when B == 1.  segments_max_nodes > 0 promises that the batch vector is sorted (graph g owns nodes
+ * ptr[g] .. ptr[g+1]) and that no graph has more nodes than that: graphs are then sorted one per wave / workgroup
+ * instead of by a device-wide radix sort (0 = no promise). */
 size_t tgp_topk_select_workspace_bytes(int64_t N);
 int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t B, const int64_t* ptr,
-                    const int64_t* k, const int64_t* koff, void* ws, size_t ws_bytes, int64_t* node_index,
-                    int64_t* cluster_index, int32_t* assign_perm, void* stream);
+                    const int64_t* k, const int64_t* koff, int64_t segments_max_nodes, void* ws, size_t ws_bytes,
+                    int64_t* node_index, int64_t* cluster_index, int32_t* assign_perm, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * A14  GraclusSelect's matching (select/graclus_select.py:62-81 -> torch_cluster 1.6.3 graclus_cluster, absent

@@ -355,15 +355,16 @@ def test_sparse_norm_long_rows_vs_oracle(dev, seed):
             torch.testing.assert_close(got_ew.cpu(), ref_ew, **TOL)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(16))
 def test_native_topk_select_vs_oracle(dev, seed):
     """A12 ratio mode (select/topk_select.py:163-203): the radix-sort selection against the oracle's two-sort
     restatement of PyG's topk + the row sort of SelectOutput; ragged graphs, empty graph ids, ties, +-0, int ratio."""
     from tgp.select import TopkSelect
     rng = random.Random(seed)
     g = torch.Generator().manual_seed(7000 + seed)
-    nb = rng.choice([1, 2, 5, 40])
-    sizes = [rng.choice([0, 1, 2, 3, 17, 100, 2500]) for _ in range(nb)]
+    nb = rng.choice([1, 2, 5, 40, 80, 300])  # >= 64 graphs: one workgroup (or wave, if all <= 64 nodes) per graph
+    pool = [0, 1, 2, 3, 17, 64] if seed % 4 == 2 else [0, 1, 2, 3, 17, 100, 700, 2500 if nb < 64 else 2048]
+    sizes = [rng.choice(pool) for _ in range(nb)]
     if sum(sizes) == 0:
         sizes[0] = 5
     batch = torch.repeat_interleave(torch.arange(nb), torch.tensor(sizes))
@@ -374,6 +375,9 @@ def test_native_topk_select_vs_oracle(dev, seed):
         score[score == 0] = torch.where(torch.rand(int((score == 0).sum()), generator=g) < 0.5, 0.0, -0.0)
     ratio = rng.choice([0.5, 0.3, 0.999, 1, 3, 7])
     sel = TopkSelect(in_channels=None, ratio=ratio, act="linear").to(dev)
+    if seed % 5 == 4 and n > 1:  # unsorted batch vector: graphs are not contiguous segments (radix path)
+        perm = torch.randperm(n, generator=g)
+        batch, score = batch[perm], score[perm]
     use_batch = None if nb == 1 and seed % 2 else batch.to(dev)
     so = sel(score.view(-1, 1).to(dev), batch=use_batch)
     if seed % 3 == 0:

@@ -82,6 +82,8 @@ x3 = torch.randn(n3, 32, device=dev, generator=g)
 for nm in ("mincut", "diff", "mincut_u"):
     cases.append((f"{nm} small graphs B=2048 n~40 K=20 F=32", (lambda nm=nm: get_pooler(nm, in_channels=32, k=20)),
                   x3, ei3, None, batch3))
+cases.append(("topk small graphs B=2048 n~40 F=32", lambda: get_pooler("topk", in_channels=32, ratio=0.5), x3, ei3, None, batch3))
+cases.append(("graclus small graphs B=2048 n~40 F=32", lambda: get_pooler("graclus"), x3, ei3, None, batch3))
 for name, mk, xx, e, w, b in cases:
     if only and not any(o in name for o in only):
         continue

@@ -52,6 +52,78 @@ __global__ __launch_bounds__(256) void topk_rank_kernel(const uint64_t* __restri
   if (q < k[g]) rank_of[vals[p]] = static_cast<int32_t>(koff[g] + q);
 }
 
+// Batches of many small graphs (sorted batch vector: graph g owns nodes ptr[g] .. ptr[g+1]): the composite-key
+// radix sort needs 32 + log2(B) bits = 5-6 passes of three launches each, all of them launch-bound on a few
+// hundred KB.  Instead every graph is sorted on its own: one WAVE per graph when it has at most 64 nodes
+// (bitonic network over the lanes, 64-bit (descending score bits : local index) keys, so ties keep the lower
+// node id), one WORKGROUP per graph up to kSegSortMax nodes (the same network through LDS).  The q-th element of
+// a graph's order gets supernode koff[g] + q if q < k[g] -- exactly what topk_rank_kernel writes.
+constexpr int kSegSortMax = 2048;
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+  const unsigned lo = __shfl_xor(static_cast<unsigned>(v), mask, WAVE);
+  const unsigned hi = __shfl_xor(static_cast<unsigned>(v >> 32), mask, WAVE);
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
+__global__ __launch_bounds__(256) void topk_segsort_wave_kernel(const float* __restrict__ score,
+                                                                const int64_t* __restrict__ ptr,
+                                                                const int64_t* __restrict__ k,
+                                                                const int64_t* __restrict__ koff, int64_t B,
+                                                                int32_t* __restrict__ rank_of) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave_id();
+  if (g >= B) return;
+  const int lane = lane_id();
+  const int64_t lo = ptr[g];
+  const int n = static_cast<int>(ptr[g + 1] - lo);
+  unsigned long long v = ~0ull;  // sentinel: sorts last
+  if (lane < n) v = (static_cast<unsigned long long>(descending_key(score[lo + lane])) << 32) | static_cast<unsigned>(lane);
+#pragma unroll
+  for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const unsigned long long o = shfl_xor_u64(v, stride);
+      const bool up = (lane & size) == 0;          // ascending block
+      const bool lower = (lane & stride) == 0;     // this lane keeps the smaller of the pair in an ascending block
+      const bool take_min = up == lower;
+      v = take_min ? (v < o ? v : o) : (v > o ? v : o);
+    }
+  }
+  if (lane < n && lane < k[g]) rank_of[lo + static_cast<int64_t>(v & 0xFFFFFFFFull)] = static_cast<int32_t>(koff[g] + lane);
+}
+
+__global__ __launch_bounds__(256) void topk_segsort_block_kernel(const float* __restrict__ score,
+                                                                 const int64_t* __restrict__ ptr,
+                                                                 const int64_t* __restrict__ k,
+                                                                 const int64_t* __restrict__ koff,
+                                                                 int32_t* __restrict__ rank_of) {
+  __shared__ unsigned long long s_v[kSegSortMax];
+  const int64_t g = blockIdx.x;
+  const int64_t lo = ptr[g];
+  const int n = static_cast<int>(ptr[g + 1] - lo);
+  if (n == 0) return;
+  int m = 64;
+  while (m < n) m <<= 1;  // padded power of two (<= kSegSortMax by dispatch)
+  for (int i = threadIdx.x; i < m; i += 256)
+    s_v[i] = i < n ? (static_cast<unsigned long long>(descending_key(score[lo + i])) << 32) | static_cast<unsigned>(i) : ~0ull;
+  __syncthreads();
+  for (int size = 2; size <= m; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < m / 2; t += 256) {
+        const int i = 2 * t - (t & (stride - 1));   // lower index of the pair
+        const int j = i + stride;
+        const bool up = (i & size) == 0;
+        const unsigned long long a = s_v[i], b = s_v[j];
+        if ((a > b) == up) { s_v[i] = b; s_v[j] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  const int kg = static_cast<int>(k[g] < n ? k[g] : n);
+  for (int q = threadIdx.x; q < kg; q += 256)
+    rank_of[lo + static_cast<int64_t>(s_v[q] & 0xFFFFFFFFull)] = static_cast<int32_t>(koff[g] + q);
+}
+
 __global__ __launch_bounds__(256) void topk_count_kernel(const int32_t* __restrict__ rank_of, int64_t n,
                                                          uint32_t* __restrict__ counts) {
   __shared__ uint32_t s_w[4];
@@ -268,7 +340,8 @@ using namespace tgp;
 extern "C" size_t tgp_topk_select_workspace_bytes(int64_t N) { return topk_layout(nullptr, N).bytes + 256; }
 
 extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t B, const int64_t* ptr,
-                               const int64_t* k, const int64_t* koff, void* ws, size_t ws_bytes,
+                               const int64_t* k, const int64_t* koff, int64_t segments_max_nodes, void* ws,
+                               size_t ws_bytes,
                                int64_t* node_index, int64_t* cluster_index, int32_t* assign_perm, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(N >= 0 && B >= 0, TGP_ERR_INVALID, "tgp_topk_select: negative size");
@@ -279,14 +352,22 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
               "tgp_topk_select: workspace too small");
   const TopkLayout s = topk_layout(ws, N);
   const int nb256 = cdiv(N, 256), nbt = cdiv(N, kTopkTile);
-  hipLaunchKernelGGL(topk_keys_kernel, dim3(nb256), dim3(256), 0, stream, score, batch, N, s.k0, s.v0);
-  bool first = true;
-  const int key_bits = 32 + (B > 1 ? bits_for(static_cast<uint64_t>(B - 1)) : 0);
-  const int rc = radix_sort_pairs<uint64_t, uint32_t>(s.k0, s.v0, s.k1, s.v1, N, key_bits, s.scratch, stream, &first);
-  if (rc != TGP_OK) return rc;
   (void)hipMemsetAsync(s.rank_of, 0xFF, static_cast<size_t>(N) * sizeof(int32_t), stream);
-  hipLaunchKernelGGL(topk_rank_kernel, dim3(nb256), dim3(256), 0, stream, first ? s.k0 : s.k1, first ? s.v0 : s.v1,
-                     N, ptr, k, koff, s.rank_of);
+  if (segments_max_nodes > 0 && segments_max_nodes <= 64) {
+    hipLaunchKernelGGL(topk_segsort_wave_kernel, dim3(cdiv(B, 4)), dim3(256), 0, stream, score, ptr, k, koff, B,
+                       s.rank_of);
+  } else if (segments_max_nodes > 0 && segments_max_nodes <= kSegSortMax && B >= 64) {
+    hipLaunchKernelGGL(topk_segsort_block_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, score, ptr, k,
+                       koff, s.rank_of);
+  } else {
+    hipLaunchKernelGGL(topk_keys_kernel, dim3(nb256), dim3(256), 0, stream, score, batch, N, s.k0, s.v0);
+    bool first = true;
+    const int key_bits = 32 + (B > 1 ? bits_for(static_cast<uint64_t>(B - 1)) : 0);
+    const int rc = radix_sort_pairs<uint64_t, uint32_t>(s.k0, s.v0, s.k1, s.v1, N, key_bits, s.scratch, stream, &first);
+    if (rc != TGP_OK) return rc;
+    hipLaunchKernelGGL(topk_rank_kernel, dim3(nb256), dim3(256), 0, stream, first ? s.k0 : s.k1, first ? s.v0 : s.v1,
+                       N, ptr, k, koff, s.rank_of);
+  }
   hipLaunchKernelGGL(topk_count_kernel, dim3(nbt), dim3(256), 0, stream, s.rank_of, N, s.counts);
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nbt, s.offsets, s.total);
   if (node_index)

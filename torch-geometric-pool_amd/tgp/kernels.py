@@ -308,7 +308,7 @@ def cut_terms(adj: Tensor, s: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
 
 
 def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Tensor, k: Tensor, koff: Tensor,
-                k_total: int) -> Tuple[Tensor, Tensor, AssignIndex]:
+                k_total: int, segments_max_nodes: int = 0) -> Tuple[Tensor, Tensor, AssignIndex]:
     """Per-graph top-k (select/topk_select.py:194 -> PyG ``topk``) fused with the row sort of SelectOutput
     (select/base_select.py:58): (node_index ascending, cluster_index, supernode -> assignment index)."""
     dev = N.require_device(score, batch, ptr, k, koff)
@@ -320,7 +320,8 @@ def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Te
     L = N.lib()
     ws = N.workspace(L.tgp_topk_select_workspace_bytes(n), dev)
     N.check(L.tgp_topk_select(N.ptr(score), N.ptr(None if batch is None else N.i64c(batch)), n, num_graphs,
-                              N.ptr(N.i64c(ptr)), N.ptr(N.i64c(k)), N.ptr(N.i64c(koff)), N.ptr(ws), ws.numel(),
+                              N.ptr(N.i64c(ptr)), N.ptr(N.i64c(k)), N.ptr(N.i64c(koff)), segments_max_nodes, N.ptr(ws),
+                              ws.numel(),
                               N.ptr(node_index), N.ptr(cluster_index), N.ptr(perm), N.stream_ptr(dev)),
             "tgp_topk_select")
     row_ptr = torch.arange(k_total + 1, dtype=torch.int32, device=dev)

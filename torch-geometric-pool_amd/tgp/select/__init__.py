@@ -396,8 +396,10 @@ class TopkSelect(Select):
         from .. import kernels
         from ..utils.ops import batch_info
         dev = score.device
+        seg_max = 0
         if batch is None or n == 0:
             sizes_host, nb = [n], 1
+            seg_max = n  # a single graph is trivially one sorted segment
             sizes = torch.tensor(sizes_host, dtype=torch.long, device=dev) if n else torch.zeros(1, dtype=torch.long,
                                                                                                  device=dev)
             ptr = torch.zeros(2, dtype=torch.long, device=dev)
@@ -405,6 +407,7 @@ class TopkSelect(Select):
         else:
             info = batch_info(batch)
             sizes, sizes_host, nb, ptr = info.sizes, info.sizes_host, info.num_graphs, info.ptr
+            seg_max = info.max_nodes if info.is_sorted else 0
         # k_g exactly as PyG computes it (float32 product, ceil), on the host for the total and on the device
         # for the kernel -- no round trip
         hs = torch.tensor(sizes_host, dtype=torch.long)
@@ -417,7 +420,8 @@ class TopkSelect(Select):
         k_total = int(k_host.sum())
         koff = torch.zeros(nb + 1, dtype=torch.long, device=dev)
         torch.cumsum(k, 0, out=koff[1:])
-        node_index, cluster_index, assign = kernels.topk_select(score.detach(), batch, nb, ptr, k, koff, k_total)
+        node_index, cluster_index, assign = kernels.topk_select(score.detach(), batch, nb, ptr, k, koff, k_total,
+                                                                segments_max_nodes=seg_max)
         values = Fn.take_unique(score, node_index)
         s = torch.sparse_coo_tensor(torch.stack([node_index, cluster_index]), values, size=(n, k_total),
                                     is_coalesced=True)

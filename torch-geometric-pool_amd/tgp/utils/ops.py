@@ -41,7 +41,7 @@ class BatchInfo:
     valid only while the weak reference still resolves to the very same tensor and its version counter has
     not moved (an in-place write bumps it), which rules out stale hits from recycled memory."""
 
-    __slots__ = ("ref", "version", "num_graphs", "sizes", "sizes_host", "ptr", "max_nodes", "distinct")
+    __slots__ = ("ref", "version", "num_graphs", "sizes", "sizes_host", "ptr", "max_nodes", "distinct", "is_sorted")
 
 
 _BATCH_INFO: dict = {}
@@ -56,11 +56,13 @@ def batch_info(batch: Tensor) -> BatchInfo:
     info.ref, info.version = weakref.ref(batch), batch._version
     if batch.numel() == 0:
         info.sizes = torch.zeros(0, dtype=torch.long, device=batch.device)
-        info.num_graphs, info.max_nodes, info.distinct, info.sizes_host = 0, 0, 0, []
+        info.num_graphs, info.max_nodes, info.distinct, info.sizes_host, info.is_sorted = 0, 0, 0, [], True
     else:
         info.sizes = torch.bincount(batch)  # sync 1: the output length is max(batch) + 1
         info.num_graphs = info.sizes.numel()
-        info.sizes_host = info.sizes.tolist()  # sync 2 (B integers)
+        unsorted = (batch[1:] < batch[:-1]).any().to(info.sizes.dtype).view(1)
+        host = torch.cat([info.sizes, unsorted]).tolist()  # sync 2 (B + 1 integers)
+        info.sizes_host, info.is_sorted = host[:-1], host[-1] == 0
         info.max_nodes = max(info.sizes_host)
         info.distinct = sum(1 for v in info.sizes_host if v > 0)
     info.ptr = torch.zeros(info.num_graphs + 1, dtype=torch.long, device=batch.device)
