@@ -85,6 +85,7 @@ class SelectOutput:
                              "assignment vector must be provided thorough 'cluster_index'.")
         self.s = s
         self.s_inv = s_inv
+        self._auto_s_inv = None
         if s_inv is None:
             self.set_s_inv(s_inv_op)
         self.batch = batch
@@ -162,6 +163,7 @@ class SelectOutput:
     def set_s_inv(self, method) -> None:
         if method == "transpose":
             self.s_inv = self.s.t() if self.is_sparse else self.s.transpose(-1, -2)
+            self._auto_s_inv = self.s_inv  # lets Lift recognise S_inv^T == S without re-coalescing the transpose
         elif method == "inverse":
             self.s_inv = pseudo_inverse(self.s)
         else:
