@@ -1026,6 +1026,17 @@ __device__ __forceinline__ const float* byte_off(const float* base, int bytes) {
   return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + static_cast<unsigned>(bytes));
 }
 
+#ifdef TGP_GEMM_STAMPS
+// per-WAVE stamps of the small-graph kernel (slot s of graph b at stamps[b*16 + s])
+#define TGP_WSTAMP(slot)                                                                                  \
+  do {                                                                                                    \
+    if (g_gemm_stamps && lane_id() == 0)                                                                  \
+      g_gemm_stamps[static_cast<long>(blockIdx.x * 4 + wave_id()) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define TGP_WSTAMP(slot) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = lane_id();
@@ -1036,6 +1047,7 @@ __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
   const bool at = p.flags & TGP_ADJ_TRANSPOSED;
   const int b = blockIdx.x * 4 + w;  // one graph per wave, no loop (keeps the 64 + 64 load offsets transient)
   if (b >= p.B) return;
+  TGP_WSTAMP(0);
   {
     // ---- request everything up front: A (float4 rows), then S and X in operand order ------------
     // out-of-range elements read element 0 of the graph (always valid) and are replaced by 0 afterwards, so
@@ -1100,6 +1112,7 @@ __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
     }
     // the tile belongs to this wave alone and LDS serves a wave's requests in order: no workgroup barrier
     __builtin_amdgcn_wave_barrier();
+    TGP_WSTAMP(1);
 
     // ---- X' = S^T X ---------------------------------------------------------------------
     if (p.X && p.x_pool) {
@@ -1118,6 +1131,7 @@ __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
       }
     }
 
+    TGP_WSTAMP(2);
     // ---- U = A S (kept in accumulators), A' = S^T U -----------------------------------------
     if (p.A && (p.adj_raw || p.adj_pool)) {
       f32x16 u[2], aa;
@@ -1135,6 +1149,7 @@ __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
         for (int r = 0; r < 16; ++r)
           aa = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[mt * 16 + r], u[mt][r], aa, 0, 0, 0);
 
+      TGP_WSTAMP(3);
       // aa[r] = A'[row = rho(r) + 4*lk][col = lm]
       if (p.adj_raw && lm < K) {
         float* o = p.adj_raw + static_cast<long>(b) * K * K;
@@ -1197,6 +1212,7 @@ __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) aa[r] = aa[r] / m;
         }
+        TGP_WSTAMP(4);
         if (lm < K) {
           float* o = p.adj_pool + static_cast<long>(b) * K * K;
 #pragma unroll
@@ -1208,6 +1224,7 @@ __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
       }
     }
   }
+  TGP_WSTAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------
