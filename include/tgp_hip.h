@@ -211,9 +211,10 @@ int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t
  * source ids; perm may be NULL when the list is already sorted by source, with row_ptr from
  * tgp_rowptr_from_sorted_i64); label[i] = min(i, partner) or i.  _start gathers the CSR and resets the state,
  * _rounds runs `rounds` propose/match rounds and sets matched[r] = 1 if round r formed a pair (device memory):
- * the matching is maximal once a round matches nothing. */
+ * the matching is maximal once a round matches nothing.  _start also symmetrises the list (a pair weighs the larger
+ * of its two directions, entries without a reverse are ignored): pairs form by mutual proposal. */
 size_t tgp_graclus_match_workspace_bytes(int64_t num_nodes, int64_t num_edges);
-int tgp_graclus_match_start(const int64_t* col, const float* weight /* NULL = ones */, const int32_t* row_ptr,
+int tgp_graclus_match_start(const int64_t* row, const int64_t* col, const float* weight /* NULL = ones */, const int32_t* row_ptr,
                             const int32_t* perm, int64_t num_nodes, int64_t num_edges, void* ws, size_t ws_bytes,
                             int64_t* label, void* stream);
 int tgp_graclus_match_rounds(const int32_t* row_ptr, int64_t num_nodes, int64_t num_edges, void* ws, int rounds,

@@ -450,3 +450,36 @@ def test_native_graclus_matching_contract(dev, seed):
     assert so.num_supernodes == ids.numel()
     assert torch.equal(so.cluster_index.cpu(), torch.searchsorted(ids, label))
     assert torch.equal(so.node_index.cpu(), idx)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_native_graclus_matching_directed_and_asymmetric_input(dev, seed):
+    """Edge lists that are not the symmetric, symmetrically weighted lists Graclus is defined on: entries without a
+    reverse are ignored, a pair's weight is the larger of its two directions; the result must be the greedy
+    heavy-edge matching of that symmetrised graph (distinct weights => unique) and maximal on it."""
+    from tgp import kernels as KK
+    g = torch.Generator().manual_seed(9500 + seed)
+    n = [30, 200, 200, 3000][seed]
+    e = 5 * n
+    r = torch.randint(0, n, (e,), generator=g)
+    c = torch.randint(0, n, (e,), generator=g)
+    keep_rev = torch.rand(e, generator=g) < 0.7                       # 30 % of the pairs are one-directional
+    ei = torch.cat([torch.stack([r, c]), torch.stack([c[keep_rev], r[keep_rev]])], 1)
+    ei = torch.unique(ei, dim=1)                                       # coalesced: sorted by (row, col)
+    if seed == 2:
+        ei = ei[:, torch.randperm(ei.size(1), generator=g)]           # unsorted list: CSR rows in arbitrary column order
+    w = torch.rand(ei.size(1), generator=g) + 0.1                      # a different weight on every directed entry
+    label = KK.graclus_match(ei.to(dev), w.to(dev), n).cpu()
+    # reference: symmetrise (max over the two directions, drop entries without reverse), sequential greedy
+    key = {(int(a), int(b)): float(x) for a, b, x in zip(ei[0], ei[1], w)}
+    und = {}
+    for (a, b), x in key.items():
+        if a != b and (b, a) in key:
+            und[(min(a, b), max(a, b))] = max(x, key[(b, a)])
+    ref = torch.arange(n)
+    free = [True] * n
+    for (a, b), _ in sorted(und.items(), key=lambda kv: -kv[1]):
+        if free[a] and free[b]:
+            free[a] = free[b] = False
+            ref[a] = ref[b] = a
+    assert torch.equal(label, ref)

@@ -60,7 +60,7 @@ cases = []
 n, F = 1_000_000, 128
 ei, batch = sparse_graph(n, 10, 8)
 x = torch.randn(n, F, device=dev, generator=g)
-ew = torch.rand(ei.size(1), device=dev, generator=g) + 0.1
+ew = ((ei[0] * ei[1] + ei[0] + ei[1]) % 1000).float() / 1000 + 0.1  # symmetric: w(i,j) = w(j,i), an undirected graph
 cases.append(("topk N=1M E=10M F=128", lambda: get_pooler("topk", in_channels=F, ratio=0.5), x, ei, ew, batch))
 cases.append(("graclus N=1M E=10M F=128", lambda: get_pooler("graclus"), x, ei, ew, batch))
 n2, F2 = 32 * 1024, 64

@@ -14,6 +14,7 @@
 // of `row` (any edge order), gathered once into CSR arrays (int32 neighbour, fp32 weight); per-node state is one
 // byte (free) + one int32 (proposal) + the int64 label.  A round streams the CSR once: HBM-bound, E * 8 bytes.
 #include "common.h"
+#include "primitives.h"
 
 namespace tgp {
 
@@ -23,15 +24,94 @@ __device__ __forceinline__ uint32_t pair_hash(uint32_t a, uint32_t b) {  // symm
   return h;
 }
 
-__global__ __launch_bounds__(256) void gm_csr_gather_kernel(const int64_t* __restrict__ col,
+__device__ __forceinline__ unsigned long long entry_hash64(uint32_t a, uint32_t b, uint32_t wbits) {
+  unsigned long long h = (static_cast<unsigned long long>(a) << 32 | b) * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 29; h += wbits; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32; h *= 0x94D049BB133111EBull; h ^= h >> 29;
+  return h;
+}
+
+// Gathers the CSR (source, neighbour, weight per entry) and, on the way, a fingerprint of the list's symmetry:
+// sum over the entries of sign(i - j) * hash(min, max, weight bits) in 64-bit wrap-around arithmetic.  Every
+// entry that has a reverse with the same weight cancels exactly, so the sum is 0 for an undirected, symmetrically
+// weighted list (what PyG hands out) and non-zero otherwise except with probability 2^-64 -- which lets the
+// common case skip the reverse-edge search of gm_symmetrise_kernel.
+__global__ __launch_bounds__(256) void gm_csr_gather_kernel(const int64_t* __restrict__ row,
+                                                            const int64_t* __restrict__ col,
                                                             const float* __restrict__ w,
                                                             const int32_t* __restrict__ perm, int64_t E,
-                                                            int32_t* __restrict__ nbr, float* __restrict__ wt) {
+                                                            int32_t* __restrict__ src, int32_t* __restrict__ nbr,
+                                                            float* __restrict__ wt,
+                                                            unsigned long long* __restrict__ partial) {
+  __shared__ unsigned long long s_sum[4];
   const int64_t p = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  unsigned long long term = 0;
+  if (p < E) {
+    const int64_t e = perm ? perm[p] : p;  // perm == NULL: the list is already grouped by source
+    const int32_t i = static_cast<int32_t>(row[e]), j = static_cast<int32_t>(col[e]);
+    const float x = w ? w[e] : 1.0f;
+    src[p] = i;
+    nbr[p] = j;
+    wt[p] = x;
+    if (i != j) {
+      const unsigned long long h = entry_hash64(static_cast<uint32_t>(i < j ? i : j), static_cast<uint32_t>(i < j ? j : i),
+                                                __float_as_uint(x));
+      term = i < j ? h : 0ull - h;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned lo = __shfl_xor(static_cast<unsigned>(term), off, WAVE);
+    const unsigned hi = __shfl_xor(static_cast<unsigned>(term >> 32), off, WAVE);
+    term += (static_cast<unsigned long long>(hi) << 32) | lo;
+  }
+  if (lane_id() == 0) s_sum[wave_id()] = term;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+
+// *asymmetric = (sum of the per-block fingerprints != 0)
+__global__ __launch_bounds__(1024) void gm_fingerprint_kernel(const unsigned long long* __restrict__ partial, int nb,
+                                                              int* __restrict__ asymmetric) {
+  __shared__ unsigned long long s_sum[16];
+  unsigned long long t = 0;
+  for (int b = threadIdx.x; b < nb; b += 1024) t += partial[b];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned lo = __shfl_xor(static_cast<unsigned>(t), off, WAVE);
+    const unsigned hi = __shfl_xor(static_cast<unsigned>(t >> 32), off, WAVE);
+    t += (static_cast<unsigned long long>(hi) << 32) | lo;
+  }
+  if (lane_id() == 0) s_sum[wave_id()] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long all = 0;
+    for (int q = 0; q < 16; ++q) all += s_sum[q];
+    *asymmetric = all != 0ull;
+  }
+}
+
+__global__ __launch_bounds__(256) void gm_symmetrise_kernel(const int32_t* __restrict__ row_ptr,
+                                                            const int32_t* __restrict__ src, int64_t E,
+                                                            const int* __restrict__ asymmetric,
+                                                            int32_t* __restrict__ nbr, float* __restrict__ wt) {
+  if (!*asymmetric) return;  // fingerprint says every entry has an equal-weight reverse: nothing to do
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;  // one thread per CSR entry
   if (p >= E) return;
-  const int64_t e = perm ? perm[p] : p;  // perm == NULL: the list is already grouped by source
-  nbr[p] = static_cast<int32_t>(col[e]);
-  wt[p] = w ? w[e] : 1.0f;
+  const int32_t i = src[p], j = nbr[p];
+  if (j < 0 || j == i) return;
+  const int32_t lo = row_ptr[j], hi = row_ptr[j + 1];
+  int32_t a = lo, b = hi, q = -1;
+  while (a < b) {
+    const int32_t mid = (a + b) >> 1;
+    const int32_t v = nbr[mid];
+    if (v == i) { q = mid; break; }
+    if (v >= 0 && v < i) a = mid + 1; else b = mid;
+  }
+  if (q < 0)
+    for (int32_t t = lo; t < hi; ++t)
+      if (nbr[t] == i) { q = t; break; }
+  if (q < 0) nbr[p] = -1;
+  else wt[p] = fmaxf(wt[p], wt[q]);
 }
 
 __global__ __launch_bounds__(256) void gm_init_kernel(int64_t n, int64_t* __restrict__ label,
@@ -94,6 +174,92 @@ __global__ __launch_bounds__(256) void gm_propose_kernel(const int32_t* __restri
   cand[i] = best;
 }
 
+// Same proposal step with the free flags as a 1-bit-per-node map held in LDS (N <= kGmLdsNodes): the per-neighbour
+// flag test is what bounds the byte-array version (10 M random one-byte reads = 10 M 64-byte L2 -> L1 sectors per
+// round); from LDS it costs nothing next to the CSR stream.  Persistent 1024-thread workgroups, one per CU.
+constexpr int kGmLdsWords = 36 * 1024;            // 144 KB of LDS (+ 4 KB of work list)
+constexpr int64_t kGmLdsNodes = static_cast<int64_t>(kGmLdsWords) * 32;
+
+__global__ __launch_bounds__(256) void gm_pack_free_kernel(const uint8_t* __restrict__ is_free, int64_t n,
+                                                           uint32_t* __restrict__ bits) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const unsigned long long m = __ballot(i < n && is_free[i]);
+  if (lane_id() == 0 && (i >> 5) < ((n + 31) >> 5)) {
+    bits[i >> 5] = static_cast<uint32_t>(m);
+    if (((i >> 5) + 1) < ((n + 31) >> 5)) bits[(i >> 5) + 1] = static_cast<uint32_t>(m >> 32);
+  }
+}
+
+__global__ __launch_bounds__(1024) void gm_propose_lds_kernel(const int32_t* __restrict__ row_ptr,
+                                                              const int32_t* __restrict__ nbr,
+                                                              const float* __restrict__ wt, int64_t n,
+                                                              const uint32_t* __restrict__ bits,
+                                                              uint8_t* __restrict__ is_free,
+                                                              int32_t* __restrict__ cand) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
+  lds_copy_words<1024>(s_bits, bits, static_cast<int>((n + 31) >> 5));  // 128 KB at 1 M nodes
+  __syncthreads();
+  auto free_bit = [&](int32_t j) { return (s_bits[j >> 5] >> (j & 31)) & 1u; };
+  __shared__ int32_t s_list[1024];
+  __shared__ int s_cnt[16];
+  const int w = threadIdx.x >> 6;
+  // A wave pays the full scan latency as soon as ONE of its lanes holds a free node, and after a few rounds
+  // nearly every wave still has one (5 % free nodes: 96 % of the waves).  So each 1024-node chunk first packs
+  // its free nodes to the front (ballot ranks + a 16-entry scan) and only the packed prefix is scanned.
+  for (int64_t c0 = static_cast<int64_t>(blockIdx.x) * 1024; c0 < n; c0 += static_cast<int64_t>(gridDim.x) * 1024) {
+    const int64_t own = c0 + threadIdx.x;
+    const bool is_f = own < n && free_bit(static_cast<int32_t>(own));
+    if (own < n && !is_f) cand[own] = -1;
+    const unsigned long long m = __ballot(is_f);
+    if (lane_id() == 0) s_cnt[w] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = s_cnt[q];
+      if (q < w) before += c;
+      total += c;
+    }
+    if (is_f) s_list[before + __popcll(m & lanemask_lt())] = static_cast<int32_t>(own);
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < total) {
+      const int64_t i = s_list[threadIdx.x];
+      int32_t best = -1;
+      float bw = 0.f;
+      uint32_t bh = 0;
+      const int32_t lo = row_ptr[i], hi = row_ptr[i + 1];
+      constexpr int U = 8;
+      for (int32_t p0 = lo; p0 < hi; p0 += U) {
+        int32_t js[U];
+        float ws[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          js[u] = p0 + u < hi ? nbr[p0 + u] : -1;
+          ws[u] = p0 + u < hi ? wt[p0 + u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int32_t j = js[u];
+          if (j < 0 || j == i || !free_bit(j)) continue;
+          const float wj = ws[u];
+          if (wj != wj) continue;
+          const uint32_t a = static_cast<uint32_t>(i < j ? i : j), b = static_cast<uint32_t>(i < j ? j : i);
+          const uint32_t h = pair_hash(a, b);
+          bool better = best < 0 || wj > bw || (wj == bw && h > bh);
+          if (!better && best >= 0 && wj == bw && h == bh && j != best) {
+            const uint32_t ca = static_cast<uint32_t>(i < best ? i : best), cb = static_cast<uint32_t>(i < best ? best : i);
+            better = a > ca || (a == ca && b > cb);
+          }
+          if (better) { best = j; bw = wj; bh = h; }
+        }
+      }
+      if (best < 0) is_free[i] = 0;  // retire (see gm_propose_kernel)
+      cand[i] = best;
+    }
+    __syncthreads();  // s_list / s_cnt are reused by the next chunk
+  }
+}
+
 // Mutual proposals become pairs.  Each endpoint writes only its own slots; *matched is set when any pair formed.
 __global__ __launch_bounds__(256) void gm_match_kernel(const int32_t* __restrict__ cand, int64_t n,
                                                        int64_t* __restrict__ label, uint8_t* __restrict__ is_free,
@@ -119,20 +285,22 @@ using namespace tgp;
 
 extern "C" size_t tgp_graclus_match_workspace_bytes(int64_t num_nodes, int64_t num_edges) {
   const size_t n = static_cast<size_t>(num_nodes > 0 ? num_nodes : 1), e = static_cast<size_t>(num_edges > 0 ? num_edges : 1);
-  return align_up(e * sizeof(int32_t)) + align_up(e * sizeof(float)) + align_up(n) + align_up(n * sizeof(int32_t)) + 256;
+  return align_up(e * sizeof(int32_t)) + align_up(e * sizeof(float)) + align_up(n) + align_up(n * sizeof(int32_t)) +
+         align_up((n / 32 + 8) * sizeof(uint32_t)) + align_up(e * sizeof(int32_t)) +
+         align_up((e / 256 + 2) * sizeof(unsigned long long)) + 512;
 }
 
 // Start: gathers the CSR and resets the state.  Rounds: runs `rounds` propose/match rounds; matched[r] becomes 1 if
 // round r matched anything (device memory, uint32[rounds], zeroed here).  The host reads the last
 // entries to decide whether to run more rounds (0 = the matching is maximal).
-extern "C" int tgp_graclus_match_start(const int64_t* col, const float* weight, const int32_t* row_ptr,
+extern "C" int tgp_graclus_match_start(const int64_t* row, const int64_t* col, const float* weight, const int32_t* row_ptr,
                                        const int32_t* perm, int64_t num_nodes, int64_t num_edges, void* ws,
                                        size_t ws_bytes, int64_t* label, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(num_nodes >= 0 && num_edges >= 0, TGP_ERR_INVALID, "tgp_graclus_match_start: negative size");
   if (num_nodes == 0) return TGP_OK;
   TGP_REQUIRE(num_nodes < (1ll << 31) && num_edges < (1ll << 31), TGP_ERR_RANGE, "tgp_graclus_match_start: too large");
-  TGP_REQUIRE(label && row_ptr && (num_edges == 0 || col), TGP_ERR_INVALID,
+  TGP_REQUIRE(label && row_ptr && (num_edges == 0 || (row && col)), TGP_ERR_INVALID,
               "tgp_graclus_match_start: null pointer");
   TGP_REQUIRE(ws && ws_bytes >= tgp_graclus_match_workspace_bytes(num_nodes, num_edges), TGP_ERR_WORKSPACE,
               "tgp_graclus_match_start: workspace too small");
@@ -140,9 +308,19 @@ extern "C" int tgp_graclus_match_start(const int64_t* col, const float* weight, 
   int32_t* nbr = cv.take<int32_t>(num_edges > 0 ? num_edges : 1);
   float* wt = cv.take<float>(num_edges > 0 ? num_edges : 1);
   uint8_t* is_free = cv.take<uint8_t>(num_nodes);
-  if (num_edges > 0)
-    hipLaunchKernelGGL(gm_csr_gather_kernel, dim3(cdiv(num_edges, 256)), dim3(256), 0, stream, col, weight, perm,
-                       num_edges, nbr, wt);
+  (void)cv.take<int32_t>(num_nodes);                 // cand   (used by the rounds)
+  (void)cv.take<uint32_t>(num_nodes / 32 + 8);       // bitmap (used by the rounds)
+  int32_t* src = cv.take<int32_t>(num_edges > 0 ? num_edges : 1);
+  unsigned long long* partial = cv.take<unsigned long long>(num_edges / 256 + 2);
+  int* asymmetric = cv.take<int>(4);
+  if (num_edges > 0) {
+    const int nbe = cdiv(num_edges, 256);
+    hipLaunchKernelGGL(gm_csr_gather_kernel, dim3(nbe), dim3(256), 0, stream, row, col, weight, perm, num_edges, src,
+                       nbr, wt, partial);
+    hipLaunchKernelGGL(gm_fingerprint_kernel, dim3(1), dim3(1024), 0, stream, partial, nbe, asymmetric);
+    hipLaunchKernelGGL(gm_symmetrise_kernel, dim3(nbe), dim3(256), 0, stream, row_ptr, src, num_edges, asymmetric, nbr,
+                       wt);
+  }
   hipLaunchKernelGGL(gm_init_kernel, dim3(cdiv(num_nodes, 256)), dim3(256), 0, stream, num_nodes, label, is_free);
   return check_launch("tgp_graclus_match_start");
 }
@@ -159,8 +337,17 @@ extern "C" int tgp_graclus_match_rounds(const int32_t* row_ptr, int64_t num_node
   uint8_t* is_free = cv.take<uint8_t>(num_nodes);
   int32_t* cand = cv.take<int32_t>(num_nodes);
   (void)hipMemsetAsync(matched, 0, static_cast<size_t>(rounds) * sizeof(unsigned int), stream);
+  uint32_t* bits = cv.take<uint32_t>(num_nodes / 32 + 8);
   const int nb = cdiv(num_nodes, 256);
+  static const int cus = [] { int v = tgp_device_cu_count(); return v > 0 ? v : 256; }();
+  const bool lds_map = num_nodes <= kGmLdsNodes && num_nodes >= 65536;
+  const size_t lds_bytes = align_up(static_cast<size_t>((num_nodes + 31) / 32) * sizeof(uint32_t), 16);
   for (int r = 0; r < rounds; ++r) {
+    if (lds_map) {
+      hipLaunchKernelGGL(gm_pack_free_kernel, dim3(cdiv(num_nodes, 256)), dim3(256), 0, stream, is_free, num_nodes, bits);
+      hipLaunchKernelGGL(gm_propose_lds_kernel, dim3(cus), dim3(1024), lds_bytes, stream, row_ptr, nbr, wt, num_nodes,
+                         bits, is_free, cand);
+    } else
     hipLaunchKernelGGL(gm_propose_kernel, dim3(nb), dim3(256), 0, stream, row_ptr, nbr, wt, num_nodes, is_free, cand);
     hipLaunchKernelGGL(gm_match_kernel, dim3(nb), dim3(256), 0, stream, cand, num_nodes, label, is_free, matched + r);
   }

@@ -87,6 +87,31 @@ static __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t
   if (tid == 0) *total = static_cast<int64_t>(s_carry);
 }
 
+// Workgroup-wide copy of `nwords` 32-bit words from global memory into LDS (both 16-byte aligned): 16-byte
+// loads, eight in flight per thread.  A one-word-per-iteration loop exposes the full load latency on every
+// iteration (~1 us each: 30 us for the 128 KB node bitmap of a 1 M-node graph, paid by every workgroup).
+template <int THREADS>
+__device__ __forceinline__ void lds_copy_words(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src,
+                                               int nwords) {
+  const int n4 = nwords >> 2;
+  const uint4* src4 = reinterpret_cast<const uint4*>(src);
+  uint4* dst4 = reinterpret_cast<uint4*>(dst);
+  for (int base = 0; base < n4; base += 8 * THREADS) {
+    uint4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = base + u * THREADS + static_cast<int>(threadIdx.x);
+      v[u] = t < n4 ? src4[t] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = base + u * THREADS + static_cast<int>(threadIdx.x);
+      if (t < n4) dst4[t] = v[u];
+    }
+  }
+  for (int t = (n4 << 2) + static_cast<int>(threadIdx.x); t < nwords; t += THREADS) dst[t] = src[t];
+}
+
 // ------------------------------------------------------------------ LSD radix sort
 // Pass structure (per DB-bit digit):  histogram per workgroup chunk -> per-digit scan over
 // chunks -> stable scatter.  A workgroup owns one contiguous chunk of the input, so block

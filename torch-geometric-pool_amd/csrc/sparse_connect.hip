@@ -195,10 +195,10 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s
 template <bool LDSB>
 __global__ __launch_bounds__(SG_THREADS) void subgraph_count_kernel(SubgraphPred pred, int64_t E, int nchunks,
                                                                     int nwords, uint32_t* __restrict__ block_counts) {
-  extern __shared__ uint32_t s_dyn[];
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   __shared__ uint32_t s_w[16];
   if constexpr (LDSB) {
-    for (int i = threadIdx.x; i < nwords; i += SG_THREADS) s_dyn[i] = pred.member_bits[i];
+    lds_copy_words<SG_THREADS>(s_dyn, pred.member_bits, nwords);
     __syncthreads();
   }
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
@@ -222,12 +222,12 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_fill_kernel(SubgraphPred 
                                                                    int64_t* __restrict__ out_row,
                                                                    int64_t* __restrict__ out_col,
                                                                    float* __restrict__ out_w) {
-  extern __shared__ uint32_t s_dyn[];
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   __shared__ uint32_t s_w[16];
   const uint32_t* s_rank = s_dyn + nwords;
   bool by_rank = false;
   if constexpr (LDSB >= 1) {
-    for (int i = threadIdx.x; i < nwords; i += SG_THREADS) s_dyn[i] = pred.member_bits[i];
+    lds_copy_words<SG_THREADS>(s_dyn, pred.member_bits, nwords);
     if constexpr (LDSB == 2) {
       const int nblocks = (nwords + 3) / 4;
       for (int i = threadIdx.x; i < nblocks; i += SG_THREADS) s_dyn[nwords + i] = pred.rank128[i];

@@ -76,7 +76,7 @@ SIGNATURES = {
     "tgp_topk_select": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_sz, _c_p, _c_p, _c_p,
                                  _c_p]),
     "tgp_graclus_match_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
-    "tgp_graclus_match_start": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_sz, _c_p, _c_p]),
+    "tgp_graclus_match_start": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_graclus_match_rounds": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_p, _c_p]),
     "tgp_row_dot_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_weighted_colsum_workspace_bytes": (_c_sz, [_c_i64]),

@@ -346,9 +346,9 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
         index = build_assign_index(row, num_nodes)
         row_ptr, perm = index.row_ptr, index.perm
     ws = N.workspace(L.tgp_graclus_match_workspace_bytes(num_nodes, E), dev)
-    N.check(L.tgp_graclus_match_start(N.ptr(col), N.ptr(w), N.ptr(row_ptr), N.ptr(perm), num_nodes, E,
+    N.check(L.tgp_graclus_match_start(N.ptr(row), N.ptr(col), N.ptr(w), N.ptr(row_ptr), N.ptr(perm), num_nodes, E,
                                       N.ptr(ws), ws.numel(), N.ptr(label), st), "tgp_graclus_match_start")
-    done, step = 0, 3
+    done, step = 0, 6  # late rounds are cheap (free nodes are packed before scanning): prefer fewer round trips
     while done < max_rounds and num_nodes > 0 and E > 0:
         step = min(step, max_rounds - done)
         matched = torch.empty(step, dtype=torch.int32, device=dev)
@@ -357,7 +357,7 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
         done += step
         if int(matched[-1].item()) == 0:  # one round trip per batch of rounds
             break
-        step = 2
+        step = 4
     return label
 
 
