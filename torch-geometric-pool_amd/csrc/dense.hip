@@ -1261,7 +1261,8 @@ static size_t medium_lds_bytes(int64_t npad) {
 template <int MT>
 __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel(MediumArgs p) {
   constexpr int KP = 32 * MT;          // padded K
-  constexpr int UNROLL = 8;            // k-pairs whose B operands are requested together
+  constexpr int UNROLL = 8;            // k-pairs whose operands are requested together (two such sets in flight;
+                                       // 16 measured no faster for K <= 32 and spills for K <= 64)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, lm = lane & 31, lk = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1294,7 +1295,9 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel
   const int nt_a = want_a ? (N + 31) / 32 : 0;
   const int nt_x = want_x ? (F + 31) / 32 : 0;
   constexpr int OOB = static_cast<int>(0x80000000u);
-  for (int job = w; job < nt_a + nt_x; job += 4) {
+  // Strips are dealt round-robin, starting at a wave that rotates with the graph index: wave w always runs on SIMD
+  // w, so a fixed start would pile every graph's extra strip onto the same SIMD of the CU.
+  for (int job = (w + 4 - (b & 3)) & 3; job < nt_a + nt_x; job += 4) {
     const bool is_a = job < nt_a;
     const int n0 = (is_a ? job : job - nt_a) * 32;
     const int ld = is_a ? N : F;
@@ -1332,9 +1335,10 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel
     };
     auto k_loop = [&](auto is_a_c) {
       request(0, 0);
-      for (int k0 = 0; k0 < NP; k0 += 4 * UNROLL) {  // NP is a multiple of 32 = 4 * UNROLL node rows
-        request(1, k0 + 2 * UNROLL);
+      for (int k0 = 0; k0 < NP; k0 += 4 * UNROLL) {  // NP is a multiple of 32 = 2 * UNROLL node rows
+        if (k0 + 2 * UNROLL < NP) request(1, k0 + 2 * UNROLL);
         consume(is_a_c, 0, k0);
+        if (k0 + 2 * UNROLL >= NP) break;
         if (k0 + 4 * UNROLL < NP) request(0, k0 + 4 * UNROLL);
         consume(is_a_c, 1, k0 + 2 * UNROLL);
       }
