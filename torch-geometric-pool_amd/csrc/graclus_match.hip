@@ -123,7 +123,50 @@ __global__ __launch_bounds__(256) void gm_init_kernel(int64_t n, int64_t* __rest
   }
 }
 
-// cand[i] = best free neighbour of free node i, or -1.
+// Best free neighbour of free node i under the edge key (w, hash, min, max), or -1.  `is_free_of(j)` tests a
+// neighbour's flag (global byte array or LDS bitmap).  A wave is as slow as its slowest lane and a lane's scan is
+// a chain of dependent loads, so the neighbours are taken eight at a time: ids and weights first, flags second.
+template <typename FreeFn>
+__device__ __forceinline__ int32_t gm_best_neighbour(int64_t i, const int32_t* __restrict__ row_ptr,
+                                                     const int32_t* __restrict__ nbr, const float* __restrict__ wt,
+                                                     FreeFn is_free_of) {
+  int32_t best = -1;
+  float bw = 0.f;
+  uint32_t bh = 0;
+  const int32_t lo = row_ptr[i], hi = row_ptr[i + 1];
+  constexpr int U = 8;
+  for (int32_t p0 = lo; p0 < hi; p0 += U) {
+    int32_t js[U];
+    float ws[U];
+    bool fs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      js[u] = p0 + u < hi ? nbr[p0 + u] : -1;
+      ws[u] = p0 + u < hi ? wt[p0 + u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) fs[u] = js[u] >= 0 && is_free_of(js[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int32_t j = js[u];
+      if (!fs[u] || j == i) continue;
+      const float wj = ws[u];
+      if (wj != wj) continue;  // NaN weights never match
+      const uint32_t a = static_cast<uint32_t>(i < j ? i : j), b = static_cast<uint32_t>(i < j ? j : i);
+      const uint32_t h = pair_hash(a, b);
+      // lexicographic (w, hash, min, max); min/max only matter for hash collisions between different pairs
+      bool better = best < 0 || wj > bw || (wj == bw && h > bh);
+      if (!better && wj == bw && h == bh && j != best) {
+        const uint32_t ca = static_cast<uint32_t>(i < best ? i : best), cb = static_cast<uint32_t>(i < best ? best : i);
+        better = a > ca || (a == ca && b > cb);
+      }
+      if (better) { best = j; bw = wj; bh = h; }
+    }
+  }
+  return best;
+}
+
+// cand[i] = best free neighbour of free node i, or -1 (free flags read from the global byte array).
 __global__ __launch_bounds__(256) void gm_propose_kernel(const int32_t* __restrict__ row_ptr,
                                                          const int32_t* __restrict__ nbr,
                                                          const float* __restrict__ wt, int64_t n,
@@ -133,40 +176,7 @@ __global__ __launch_bounds__(256) void gm_propose_kernel(const int32_t* __restri
   if (i >= n) return;
   int32_t best = -1;
   if (is_free[i]) {
-    float bw = 0.f;
-    uint32_t bh = 0;
-    const int32_t lo = row_ptr[i], hi = row_ptr[i + 1];
-    // A wave is as slow as its slowest lane and a lane's scan is a chain of dependent loads (neighbour id ->
-    // its free flag), so the neighbours are taken eight at a time: ids first, then flags and weights together.
-    constexpr int U = 8;
-    for (int32_t p0 = lo; p0 < hi; p0 += U) {
-      int32_t js[U];
-      float ws[U];
-      uint8_t fs[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) js[u] = p0 + u < hi ? nbr[p0 + u] : -1;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        fs[u] = js[u] >= 0 ? is_free[js[u]] : 0;
-        ws[u] = js[u] >= 0 ? wt[p0 + u] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int32_t j = js[u];
-        if (j < 0 || j == i || !fs[u]) continue;
-        const float wj = ws[u];
-        if (wj != wj) continue;  // NaN weights never match
-        const uint32_t a = static_cast<uint32_t>(i < j ? i : j), b = static_cast<uint32_t>(i < j ? j : i);
-        const uint32_t h = pair_hash(a, b);
-        // lexicographic (w, hash, min, max); min/max only matter for hash collisions between different pairs
-        bool better = best < 0 || wj > bw || (wj == bw && h > bh);
-        if (!better && best >= 0 && wj == bw && h == bh && j != best) {
-          const uint32_t ca = static_cast<uint32_t>(i < best ? i : best), cb = static_cast<uint32_t>(i < best ? best : i);
-          better = a > ca || (a == ca && b > cb);
-        }
-        if (better) { best = j; bw = wj; bh = h; }
-      }
-    }
+    best = gm_best_neighbour(i, row_ptr, nbr, wt, [&](int32_t j) { return is_free[j] != 0; });
     // No free neighbour left: the free set only shrinks, so this node stays single -- retire it, later rounds
     // skip its scan.  (No free node is adjacent to it, so nobody's proposal depends on this flag.)
     if (best < 0) is_free[i] = 0;
@@ -197,11 +207,11 @@ __global__ __launch_bounds__(1024) void gm_propose_lds_kernel(const int32_t* __r
                                                               uint8_t* __restrict__ is_free,
                                                               int32_t* __restrict__ cand) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
-  lds_copy_words<1024>(s_bits, bits, static_cast<int>((n + 31) >> 5));  // 128 KB at 1 M nodes
-  __syncthreads();
-  auto free_bit = [&](int32_t j) { return (s_bits[j >> 5] >> (j & 31)) & 1u; };
   __shared__ int32_t s_list[1024];
   __shared__ int s_cnt[16];
+  lds_copy_words<1024>(s_bits, bits, static_cast<int>((n + 31) >> 5));  // 128 KB at 1 M nodes
+  __syncthreads();
+  auto free_bit = [&](int32_t j) { return ((s_bits[j >> 5] >> (j & 31)) & 1u) != 0; };
   const int w = threadIdx.x >> 6;
   // A wave pays the full scan latency as soon as ONE of its lanes holds a free node, and after a few rounds
   // nearly every wave still has one (5 % free nodes: 96 % of the waves).  So each 1024-node chunk first packs
@@ -224,35 +234,7 @@ __global__ __launch_bounds__(1024) void gm_propose_lds_kernel(const int32_t* __r
     __syncthreads();
     if (static_cast<int>(threadIdx.x) < total) {
       const int64_t i = s_list[threadIdx.x];
-      int32_t best = -1;
-      float bw = 0.f;
-      uint32_t bh = 0;
-      const int32_t lo = row_ptr[i], hi = row_ptr[i + 1];
-      constexpr int U = 8;
-      for (int32_t p0 = lo; p0 < hi; p0 += U) {
-        int32_t js[U];
-        float ws[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          js[u] = p0 + u < hi ? nbr[p0 + u] : -1;
-          ws[u] = p0 + u < hi ? wt[p0 + u] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int32_t j = js[u];
-          if (j < 0 || j == i || !free_bit(j)) continue;
-          const float wj = ws[u];
-          if (wj != wj) continue;
-          const uint32_t a = static_cast<uint32_t>(i < j ? i : j), b = static_cast<uint32_t>(i < j ? j : i);
-          const uint32_t h = pair_hash(a, b);
-          bool better = best < 0 || wj > bw || (wj == bw && h > bh);
-          if (!better && best >= 0 && wj == bw && h == bh && j != best) {
-            const uint32_t ca = static_cast<uint32_t>(i < best ? i : best), cb = static_cast<uint32_t>(i < best ? best : i);
-            better = a > ca || (a == ca && b > cb);
-          }
-          if (better) { best = j; bw = wj; bh = h; }
-        }
-      }
+      const int32_t best = gm_best_neighbour(i, row_ptr, nbr, wt, free_bit);
       if (best < 0) is_free[i] = 0;  // retire (see gm_propose_kernel)
       cand[i] = best;
     }
