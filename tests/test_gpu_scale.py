@@ -505,3 +505,21 @@ def test_dense_pooler_forward_is_hip_graph_capturable(dev, alias, shape):
     torch.testing.assert_close(out.edge_index, ref2.edge_index, rtol=RTOL, atol=ATOL)
     for k in ref2.loss:
         torch.testing.assert_close(out.loss[k], ref2.loss[k], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("trans_a", [False, True])
+@pytest.mark.parametrize("shape", [(2048, 60, 32, 20), (2048, 60, 60, 20), (600, 126, 20, 64), (70, 300, 300, 33), (513, 1, 7, 1),
+                                   (128, 512, 512, 64)])
+def test_bmm_many_small_matrices(dev, shape, trans_a):
+    """The one-wave-per-strip batched product used by the backward of the dense poolers on small graphs
+    (tgp_bmm_f32 with M, Kd <= 512, Nc <= 64 and many batch elements), including broadcast operands."""
+    from tgp import kernels as KK
+    B, M, Kd, Nc = shape
+    g = torch.Generator(device=dev).manual_seed(M * 7 + Nc)
+    a = torch.randn(B, Kd, M, device=dev, generator=g) if trans_a else torch.randn(B, M, Kd, device=dev, generator=g)
+    b = torch.randn(B, Kd, Nc, device=dev, generator=g)
+    ref = ((a.transpose(1, 2) if trans_a else a).double() @ b.double()).float()
+    torch.testing.assert_close(KK.bmm(a, b, trans_a=trans_a), ref, rtol=1e-5, atol=2e-4)
+    b1 = b[:1]  # one right-hand side shared by the whole batch (stride 0)
+    ref1 = ((a.transpose(1, 2) if trans_a else a).double() @ b1.double()).float()
+    torch.testing.assert_close(KK.bmm(a, b1, trans_a=trans_a), ref1, rtol=1e-5, atol=2e-4)

@@ -1633,6 +1633,69 @@ extern "C" int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B
   return check_launch("tgp_postprocess_dense_f32");
 }
 
+namespace tgp {
+// Batched products of SMALL matrices (the backward of the dense poolers on TU-dataset-sized graphs: [N x F][F x K],
+// [N x N][N x K], ... with N up to a few hundred and at most 64 output columns): the LDS-tiled kernel above spends
+// such a launch on 64 / 128-wide tiles that are mostly padding.  Here one WAVE owns a 32-row strip of one batch
+// element and keeps 32 x Nc of C in its accumulators; both operands go straight from memory into the MFMA operand
+// registers (B: lane = column, coalesced; A: lane = row, each lane walks its own row, so every 64-byte line is
+// fetched once and serves 16 k-steps from L1), eight k-pairs requested at a time.  No LDS, no barriers.
+struct SmallBmmArgs {
+  const float* A; const float* Bm; float* C;
+  int M, Nc, Kd, trans_a;
+  long lda, ldb, ldc, sA, sB, sC;
+  int strips;  // 32-row strips per batch element
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void small_bmm_kernel(SmallBmmArgs p, long total_strips) {
+  const long strip = static_cast<long>(blockIdx.x) * 4 + wave_id();
+  if (strip >= total_strips) return;
+  const int lane = lane_id(), lm = lane & 31, lk = lane >> 5;
+  const long b = strip / p.strips;
+  const int m0 = static_cast<int>(strip - b * p.strips) * 32;
+  const float* A = p.A + b * p.sA;
+  const float* Bm = p.Bm + b * p.sB;
+  float* C = p.C + b * p.sC;
+  const bool row_ok = m0 + lm < p.M;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  constexpr int U = 8;
+  for (int k0 = 0; k0 < p.Kd; k0 += 2 * U) {
+    float av[U], bv[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 2 * u + lk;
+      const bool k_ok = k < p.Kd;
+      const long a_off = p.trans_a ? static_cast<long>(k) * p.lda + m0 + lm : static_cast<long>(m0 + lm) * p.lda + k;
+      av[u] = (k_ok && row_ok) ? A[a_off] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + lm;
+        bv[u][j] = (k_ok && n < p.Nc) ? Bm[static_cast<long>(k) * p.ldb + n] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][j], acc[j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = j * 32 + lm;
+    if (n >= p.Nc) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + rho(r) + 4 * lk;
+      if (m < p.M) C[static_cast<long>(m) * p.ldc + n] = acc[j][r];
+    }
+  }
+}
+}  // namespace tgp
+
 // Generic batched fp32 GEMM on the matrix cores (used by Lift and by the unbatched dense paths).
 extern "C" int tgp_bmm_f32(const float* A, const float* Bm, float* C, int64_t batch, int64_t M, int64_t Nc,
                            int64_t Kd, int trans_a, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA,
@@ -1648,6 +1711,19 @@ extern "C" int tgp_bmm_f32(const float* A, const float* Bm, float* C, int64_t ba
   g.rhs[0] = GemmRhs{Bm, C, static_cast<int>(Nc), ldb, ldc, sB, sC, 0};
   g.splits = 1; g.k_per_split = static_cast<int>((Kd + BK - 1) / BK * BK);
   TGP_REQUIRE(batch * ((M + 63) / 64) * ((Nc + 63) / 64) < (1ll << 31), TGP_ERR_RANGE, "tgp_bmm_f32: grid too large");
+  // many small matrices: one wave per 32-row strip, operands straight from memory (see small_bmm_kernel)
+  static const int no_small_bmm = getenv("TGP_NO_SMALL_BMM") ? 1 : 0;
+  const int64_t strips = (M + 31) / 32;
+  if (!no_small_bmm && Nc <= 64 && M <= 512 && Kd <= 512 && batch * strips >= 512) {
+    SmallBmmArgs q{A, Bm, C, static_cast<int>(M), static_cast<int>(Nc), static_cast<int>(Kd), trans_a ? 1 : 0,
+                   lda, ldb, ldc, sA, sB, sC, static_cast<int>(strips)};
+    const long total = batch * strips;
+    if (Nc <= 32)
+      hipLaunchKernelGGL(small_bmm_kernel<1>, dim3(static_cast<unsigned>((total + 3) / 4)), dim3(256), 0, stream, q, total);
+    else
+      hipLaunchKernelGGL(small_bmm_kernel<2>, dim3(static_cast<unsigned>((total + 3) / 4)), dim3(256), 0, stream, q, total);
+    return check_launch("tgp_bmm_f32(small)");
+  }
   if (trans_a) launch_gemm<true>(g, static_cast<int>(batch), stream);
   else launch_gemm<false>(g, static_cast<int>(batch), stream);
   return check_launch("tgp_bmm_f32");
