@@ -483,3 +483,34 @@ def test_native_graclus_matching_directed_and_asymmetric_input(dev, seed):
             free[a] = free[b] = False
             ref[a] = ref[b] = a
     assert torch.equal(label, ref)
+
+
+def test_native_selectors_degenerate_inputs(dev):
+    """Empty and degenerate inputs through the native selectors: no nodes, no edges, only self loops, scores with
+    +-inf / NaN, a ratio that keeps everything, one-node graphs."""
+    from tgp.poolers import get_pooler
+    from tgp.select import GraclusSelect, TopkSelect
+    # TopK: scores with infinities and NaN (torch.sort's descending order puts NaN first, then +inf)
+    score = torch.tensor([0.5, float("inf"), -1.0, float("nan"), float("-inf"), 0.5, 2.0, -0.0, 0.0])
+    batch = torch.tensor([0, 0, 0, 0, 0, 1, 1, 1, 1])
+    so = TopkSelect(in_channels=None, ratio=0.5, act="linear").to(dev)(score.view(-1, 1).to(dev), batch=batch.to(dev))
+    kept = set(so.node_index.cpu().tolist())
+    assert kept == {3, 1, 0, 6, 5}, kept                                  # ceil(0.5*5)=3 of graph 0, 2 of graph 1
+    assert so.cluster_index.cpu().tolist() == [2, 1, 0, 4, 3]             # rows sorted by node id; rank in score order
+    # ratio >= number of nodes keeps everything; single-node graphs
+    so = TopkSelect(in_channels=None, ratio=7, act="linear").to(dev)(torch.randn(3, 1, device=dev),
+                                                                      batch=torch.tensor([0, 1, 2], device=dev))
+    assert so.num_supernodes == 3 and so.node_index.cpu().tolist() == [0, 1, 2]
+    # zero nodes
+    so = TopkSelect(in_channels=4, ratio=0.5).to(dev)(torch.zeros(0, 4, device=dev),
+                                                     batch=torch.zeros(0, dtype=torch.long, device=dev))
+    assert so.num_nodes == 0 and so.num_supernodes == 0
+    # Graclus: no edges / only self loops -> every node is its own cluster
+    for ei in (torch.zeros(2, 0, dtype=torch.long), torch.tensor([[0, 1, 2], [0, 1, 2]])):
+        so = GraclusSelect()(ei.to(dev), None, num_nodes=5)
+        assert so.num_supernodes == 5 and so.cluster_index.cpu().tolist() == [0, 1, 2, 3, 4]
+    # a two-node graph with one undirected edge collapses to one supernode; pooling it end to end works
+    x = torch.randn(2, 3, device=dev)
+    out = get_pooler("graclus")(x=x, adj=torch.tensor([[0, 1], [1, 0]], device=dev))
+    assert out.x.shape == (1, 3) and out.edge_index.size(1) == 0
+    torch.testing.assert_close(out.x[0], x.sum(0))
