@@ -199,6 +199,8 @@ int tgp_segment_gemm_nn_f32(const float* A, const float* Bm, const int64_t* ptr,
  * batch may be NULL when B == 1.  segments_max_nodes > 0 promises that the batch vector is sorted (graph g owns nodes
  * ptr[g] .. ptr[g+1]) and that no graph has more nodes than that: graphs are then sorted one per wave / workgroup
  * instead of by a device-wide radix sort (0 = no promise). */
+int tgp_topk_plan(const int64_t* sizes, int64_t B, double ratio, int64_t* k /* [B] */, int64_t* koff /* [B+1] */,
+                  void* stream); /* k[g] = ceil(fp32(ratio) * n_g) (ratio < 1) or min(ratio, n_g); koff = prefix sums */
 size_t tgp_topk_select_workspace_bytes(int64_t N);
 int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t B, const int64_t* ptr,
                     const int64_t* k, const int64_t* koff, int64_t segments_max_nodes, void* ws, size_t ws_bytes,

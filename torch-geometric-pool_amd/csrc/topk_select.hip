@@ -307,6 +307,51 @@ static void launch_row_dot(const float* x, int64_t n, int F, int64_t ldx, const 
                      w, out);
 }
 
+// k[g] = ceil(ratio * n_g) in fp32 (ratio < 1; exactly PyG's `(ratio * num_nodes.to(float)).ceil()`) or
+// min(ratio, n_g) (ratio >= 1), and koff = its exclusive prefix sums: one launch instead of eight tiny tensor ops.
+__global__ __launch_bounds__(1024) void topk_plan_kernel(const int64_t* __restrict__ sizes, int64_t B, float ratio,
+                                                         int64_t* __restrict__ k, int64_t* __restrict__ koff) {
+  __shared__ long long s_w[16];
+  __shared__ long long s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < B; base += 1024) {
+    const int64_t g = base + tid;
+    long long v = 0;
+    if (g < B) {
+      const long long n = sizes[g];
+      if (ratio >= 1.0f) {
+        const long long r = static_cast<long long>(ratio);
+        v = r < n ? r : n;
+      } else {
+        v = static_cast<long long>(ceilf(__fmul_rn(ratio, static_cast<float>(n))));
+      }
+      k[g] = v;
+    }
+    long long inc = v;  // inclusive scan over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const long long o = __shfl_up(inc, off, WAVE);
+      if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    long long before = s_carry, tot = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const long long c = s_w[q];
+      if (q < w) before += c;
+      tot += c;
+    }
+    if (g < B) koff[g] = before + inc - v;
+    __syncthreads();
+    if (tid == 0) s_carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) koff[B] = s_carry;
+}
+
 struct TopkLayout {
   uint64_t *k0, *k1;
   uint32_t *v0, *v1, *scratch, *counts, *offsets;
@@ -436,4 +481,12 @@ extern "C" int tgp_weighted_colsum_f32(const float* x, int64_t N, int64_t F, int
   hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(F)), dim3(256), 0, stream, partial, blocks,
                      static_cast<int>(F), out);
   return check_launch("tgp_weighted_colsum_f32");
+}
+
+extern "C" int tgp_topk_plan(const int64_t* sizes, int64_t B, double ratio, int64_t* k, int64_t* koff, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && ratio > 0.0, TGP_ERR_INVALID, "tgp_topk_plan: bad argument");
+  TGP_REQUIRE(koff && (B == 0 || (sizes && k)), TGP_ERR_INVALID, "tgp_topk_plan: null pointer");
+  hipLaunchKernelGGL(topk_plan_kernel, dim3(1), dim3(1024), 0, stream, sizes, B, static_cast<float>(ratio), k, koff);
+  return check_launch("tgp_topk_plan");
 }

@@ -72,6 +72,7 @@ SIGNATURES = {
     "tgp_segment_gemm_tn_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
                                          _c_p, _c_sz, _c_p]),
     "tgp_segment_gemm_nn_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+    "tgp_topk_plan": (_c_int, [_c_p, _c_i64, ctypes.c_double, _c_p, _c_p, _c_p]),
     "tgp_topk_select_workspace_bytes": (_c_sz, [_c_i64]),
     "tgp_topk_select": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_sz, _c_p, _c_p, _c_p,
                                  _c_p]),

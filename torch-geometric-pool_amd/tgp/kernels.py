@@ -307,6 +307,19 @@ def cut_terms(adj: Tensor, s: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     return deg, q, den
 
 
+def topk_plan(sizes: Tensor, ratio: float) -> Tuple[Tensor, Tensor]:
+    """(k [B], koff [B+1]): nodes kept per graph (PyG topk: ceil(ratio * n) in fp32, or min(ratio, n)) and their
+    exclusive prefix sums, in one launch."""
+    dev = N.require_device(sizes)
+    sizes = N.i64c(sizes)
+    B = sizes.numel()
+    k = torch.empty(B, dtype=torch.int64, device=dev)
+    koff = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    N.check(N.lib().tgp_topk_plan(N.ptr(sizes), B, float(ratio), N.ptr(k), N.ptr(koff), N.stream_ptr(dev)),
+            "tgp_topk_plan")
+    return k, koff
+
+
 def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Tensor, k: Tensor, koff: Tensor,
                 k_total: int, segments_max_nodes: int = 0) -> Tuple[Tensor, Tensor, AssignIndex]:
     """Per-graph top-k (select/topk_select.py:194 -> PyG ``topk``) fused with the row sort of SelectOutput

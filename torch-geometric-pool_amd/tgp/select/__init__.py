@@ -415,13 +415,10 @@ class TopkSelect(Select):
         hs = torch.tensor(sizes_host, dtype=torch.long)
         if self.ratio >= 1:
             k_host = torch.minimum(torch.full_like(hs, int(self.ratio)), hs)
-            k = torch.minimum(torch.full_like(sizes, int(self.ratio)), sizes)
         else:
             k_host = (float(self.ratio) * hs.to(torch.float32)).ceil().to(torch.long)
-            k = (float(self.ratio) * sizes.to(torch.float32)).ceil().to(torch.long)
         k_total = int(k_host.sum())
-        koff = torch.zeros(nb + 1, dtype=torch.long, device=dev)
-        torch.cumsum(k, 0, out=koff[1:])
+        k, koff = kernels.topk_plan(sizes, self.ratio)  # the same arithmetic on the device, one launch
         node_index, cluster_index, assign = kernels.topk_select(score.detach(), batch, nb, ptr, k, koff, k_total,
                                                                 segments_max_nodes=seg_max)
         values = Fn.take_unique(score, node_index)
