@@ -211,3 +211,28 @@ def test_batch_info_memo_is_keyed_by_object_and_version():
     assert not is_multi_graph_batch(torch.tensor([2, 2, 2])) and num_graphs_of(torch.tensor([2, 2, 2])) == 3
     assert is_multi_graph_batch(torch.tensor([0, 2])) and max_graph_size(torch.tensor([0, 2, 2])) == 2
     assert num_graphs_of(None) == 1 and num_graphs_of(torch.zeros(0, dtype=torch.long)) == 1
+
+
+def test_select_output_s_inv_is_lazy_but_behaves_like_the_eager_attribute():
+    """S_inv (reference base_select.py:290-300) is materialised on first access; assignment, .apply() and clone()
+    keep the reference's observable behaviour."""
+    import torch
+    from tgp.select import SelectOutput
+
+    so = SelectOutput(cluster_index=torch.tensor([0, 1, 1, 2]), num_nodes=4, num_supernodes=3)
+    assert so._s_inv is None and so.s_inv_is_transpose_of_s          # nothing built yet
+    t = so.s_inv
+    assert torch.equal(t.to_dense(), so.s.to_dense().t()) and so.s_inv is t and so.s_inv_is_transpose_of_s
+    so2 = so.clone()
+    assert so2.s_inv is not t and torch.equal(so2.s_inv.to_dense(), t.to_dense()) and so2.s_inv_is_transpose_of_s
+    so.apply(lambda v: v * 2)                                         # S changed: S_inv follows it
+    assert torch.equal(so.s_inv.to_dense(), so.s.to_dense().t())
+    custom = torch.ones(3, 4).to_sparse()
+    so.s_inv = custom                                                 # a user-provided inverse is kept as is
+    assert so.s_inv is custom and not so.s_inv_is_transpose_of_s
+    so.apply(lambda v: v * 3)
+    assert torch.equal(so.s_inv.to_dense(), torch.full((3, 4), 3.0))
+    dense = SelectOutput(s=torch.rand(2, 5, 3), s_inv_op="inverse")
+    assert not dense.s_inv_is_transpose_of_s and dense.s_inv.shape == (2, 3, 5)
+    dense.set_s_inv("transpose")
+    assert dense.s_inv_is_transpose_of_s and torch.equal(dense.s_inv, dense.s.transpose(-1, -2))

@@ -45,8 +45,8 @@ class BaseLift(Lift):
         if self.matrix_op == "transpose":
             return so.s
         if self.matrix_op == "precomputed":
-            if so.s_inv is not None and getattr(so, "_auto_s_inv", None) is so.s_inv:
-                return so.s  # S_inv was built as S^T: its transpose is S itself (already coalesced, node-sorted)
+            if getattr(so, "s_inv_is_transpose_of_s", False):
+                return so.s  # S_inv is S^T: its transpose is S itself (already coalesced, node-sorted)
             matrix = so.s_inv
         elif self.matrix_op == "inverse":
             matrix = pseudo_inverse(so.s)

@@ -84,10 +84,13 @@ class SelectOutput:
             raise ValueError("Either a sparse or dense assignment matrix is provided through 's' or a cluster "
                              "assignment vector must be provided thorough 'cluster_index'.")
         self.s = s
-        self.s_inv = s_inv
+        self._s_inv = s_inv
         self._auto_s_inv = None
-        if s_inv is None:
-            self.set_s_inv(s_inv_op)
+        # S_inv is materialised on first access: only Lift (and user code) reads it, and for a sparse S the transpose
+        # costs several device copies per SelectOutput (reference base_select.py:290-300 builds it eagerly)
+        self._s_inv_method = None if s_inv is not None else s_inv_op
+        if s_inv is None and s_inv_op not in ("transpose", "inverse"):
+            raise ValueError()
         self.batch = batch
         self.in_mask = self._validate_in_mask(in_mask)
         self._extra_args = set()
@@ -160,14 +163,39 @@ class SelectOutput:
         return bool(torch.allclose(row_sum, first.expand_as(row_sum))) and not bool(
             torch.allclose(first, torch.zeros((), dtype=first.dtype, device=first.device)))
 
-    def set_s_inv(self, method) -> None:
+    @property
+    def s_inv(self):
+        if self._s_inv is None and self._s_inv_method is not None:
+            method, self._s_inv_method = self._s_inv_method, None
+            self._materialise_s_inv(method)
+        return self._s_inv
+
+    @s_inv.setter
+    def s_inv(self, value) -> None:
+        self._s_inv = value
+        self._s_inv_method = None
+        self._auto_s_inv = None
+
+    @property
+    def s_inv_is_transpose_of_s(self) -> bool:
+        """True while S_inv is (or, not yet materialised, will be) exactly S^T: Lift then multiplies by S itself."""
+        if self._s_inv is None:
+            return self._s_inv_method == "transpose"
+        return self._auto_s_inv is not None and self._auto_s_inv is self._s_inv
+
+    def _materialise_s_inv(self, method) -> None:
         if method == "transpose":
-            self.s_inv = self.s.t() if self.is_sparse else self.s.transpose(-1, -2)
-            self._auto_s_inv = self.s_inv  # lets Lift recognise S_inv^T == S without re-coalescing the transpose
+            self._s_inv = self.s.t() if self.is_sparse else self.s.transpose(-1, -2)
+            self._auto_s_inv = self._s_inv
         elif method == "inverse":
-            self.s_inv = pseudo_inverse(self.s)
+            self._s_inv = pseudo_inverse(self.s)
         else:
             raise ValueError()
+
+    def set_s_inv(self, method) -> None:
+        if method not in ("transpose", "inverse"):
+            raise ValueError()
+        self._s_inv, self._auto_s_inv, self._s_inv_method = None, None, method
 
     # ---- native-kernel caches ---------------------------------------------------------
     def assign_index(self):
@@ -212,9 +240,12 @@ class SelectOutput:
         return value
 
     def apply(self, func: Callable) -> "SelectOutput":
+        derived = self.s_inv_is_transpose_of_s
         self.s = func(self.s)
-        if self.s_inv is not None:
-            self.s_inv = func(self.s_inv)
+        if derived:  # S_inv follows S: rebuild it lazily from the new S
+            self._s_inv, self._auto_s_inv, self._s_inv_method = None, None, "transpose"
+        elif self._s_inv is not None:
+            self._s_inv = func(self._s_inv)
         for name in self._extra_args:
             if hasattr(self, name):
                 setattr(self, name, self._apply_to_value(getattr(self, name), func))
