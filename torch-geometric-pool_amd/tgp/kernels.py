@@ -341,6 +341,26 @@ def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Te
     return node_index, cluster_index, AssignIndex(row_ptr, perm, k_total, k_total)
 
 
+_ROWS_SORTED: dict = {}
+
+
+def _rows_sorted(edge_index: Tensor, row: Tensor) -> bool:
+    """Is the list grouped by ascending source node?  Memoised per tensor object (weak reference + version counter,
+    like utils.ops.batch_info), so an unchanged edge_index costs one host round trip in total, not one per call."""
+    import weakref
+    hit = _ROWS_SORTED.get(id(edge_index))
+    if hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version:
+        return hit[2]
+    flag = bool((row[1:] >= row[:-1]).all())
+    if len(_ROWS_SORTED) >= 16:
+        for key in [k for k, v in _ROWS_SORTED.items() if v[0]() is None]:
+            del _ROWS_SORTED[key]
+        while len(_ROWS_SORTED) >= 16:
+            del _ROWS_SORTED[next(iter(_ROWS_SORTED))]
+    _ROWS_SORTED[id(edge_index)] = (weakref.ref(edge_index), edge_index._version, flag)
+    return flag
+
+
 def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int, max_rounds: int = 64) -> Tensor:
     """label[i] = min(i, partner) of a heavy-edge maximal matching (select/graclus_select.py:66 ->
     torch_cluster.graclus_cluster): handshake rounds on the device until a round matches nothing."""
@@ -352,7 +372,8 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
     L = N.lib()
     st = N.stream_ptr(dev)
     # PyG lists are sorted by source: one comparison pass + round trip decides whether the CSR needs a sort at all
-    if E > 1 and bool((row[1:] >= row[:-1]).all()):
+    # (remembered per edge_index object: full-batch training pools the same graph every epoch)
+    if E > 1 and _rows_sorted(edge_index, row):
         row_ptr, perm = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev), None
         N.check(L.tgp_rowptr_from_sorted_i64(N.ptr(row), E, num_nodes, N.ptr(row_ptr), st), "tgp_rowptr_from_sorted_i64")
     else:
