@@ -1274,16 +1274,31 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel
   const bool want_a = p.A && (p.adj_raw || p.adj_pool);
   const bool want_x = p.X && p.x_pool;
 
+  TGP_WSTAMP(0);
   // ---- S -> LDS (zero padded) ------------------------------------------------------------
   {
+    // eight independent loads in flight per thread: a one-element-per-iteration loop exposes the full load latency
+    // NP * KP / 256 times (measured: 22 us of a 92 us workgroup at N = 200, K = 50)
     const float* Sb = p.S + static_cast<long>(b) * N * K;
-    for (int e = tid; e < NP * KP; e += 256) {
-      const int r = e / KP, c = e - r * KP;
-      Ss[e] = (r < N && c < K) ? Sb[r * K + c] : 0.f;
+    constexpr int UB = 8;
+    for (int base = 0; base < NP * KP; base += 256 * UB) {
+      float v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int e = base + u * 256 + tid;
+        const int r = e / KP, c = e - r * KP;
+        v[u] = (r < N && c < K) ? Sb[r * K + c] : 0.f;  // r < N also covers e beyond the tile (NP >= N)
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int e = base + u * 256 + tid;
+        if (e < NP * KP) Ss[e] = v[u];
+      }
     }
   }
   __syncthreads();
 
+  TGP_WSTAMP(1);
   f32x16 racc[MT][MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -1373,6 +1388,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel
           racc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[i], acc[j][r], racc[i][j], 0, 0, 0);
     }
   }
+  TGP_WSTAMP(2);
   if (!want_a) return;
 
   // ---- A' = sum of the four partial products, in wave order ---------------------------------
@@ -1393,6 +1409,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel
     __syncthreads();
   }
 
+  TGP_WSTAMP(3);
   // ---- post-processing on the K x K result (utils/ops.py:282-335) ---------------------------
   // element loops run over the padded [K][KP] index space: row / column come from shifts, not divisions
   const long obase = static_cast<long>(b) * K * K;
@@ -1447,6 +1464,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel
       p.adj_pool[obase + i * K + j] = (p.flags & TGP_EDGE_WEIGHT_NORM) ? v / scale : v;
     }
   }
+  TGP_WSTAMP(4);
 }
 
 static const int kStage2Tile = getenv("TGP_STAGE2_TILE") ? atoi(getenv("TGP_STAGE2_TILE")) : 0;
