@@ -837,7 +837,13 @@ __global__ __launch_bounds__(1024) void post_lds_kernel(PostArgs p, int B, XComb
     const float* sb = xc.src + static_cast<long>(b) * xc.s_batch;
     for (long e = static_cast<long>(part) * 1024 + tid; e < xc.total; e += static_cast<long>(xc.blocks_per_graph) * 1024) {
       float v = sb[e];
-      for (int sp = 1; sp < xc.splits; ++sp) v = __fadd_rn(v, sb[sp * xc.s_split + e]);
+      int sp = 1;
+      for (; sp + 3 < xc.splits; sp += 4) {  // four slab loads in flight, added in slab order
+        const float u0 = sb[sp * xc.s_split + e], u1 = sb[(sp + 1) * xc.s_split + e];
+        const float u2 = sb[(sp + 2) * xc.s_split + e], u3 = sb[(sp + 3) * xc.s_split + e];
+        v = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(v, u0), u1), u2), u3);
+      }
+      for (; sp < xc.splits; ++sp) v = __fadd_rn(v, sb[sp * xc.s_split + e]);
       xc.dst[static_cast<long>(b) * xc.total + e] = v;
     }
     return;
@@ -854,10 +860,17 @@ __global__ __launch_bounds__(1024) void post_lds_kernel(PostArgs p, int B, XComb
   // pass 1: fixed-order slab sum -> raw output, diag-cleared copy in LDS  (K % 4 == 0, ld_src == K here)
   for (int e = tid * 4; e < kk; e += 4096) {
     float4 t = *reinterpret_cast<const float4*>(sb + e);
-    for (int sp = 1; sp < p.splits; ++sp) {
-      const float4 u = *reinterpret_cast<const float4*>(sb + sp * p.s_split + e);
-      t.x = __fadd_rn(t.x, u.x); t.y = __fadd_rn(t.y, u.y); t.z = __fadd_rn(t.z, u.z); t.w = __fadd_rn(t.w, u.w);
+    auto add4 = [](float4& a, const float4& u) {
+      a.x = __fadd_rn(a.x, u.x); a.y = __fadd_rn(a.y, u.y); a.z = __fadd_rn(a.z, u.z); a.w = __fadd_rn(a.w, u.w);
+    };
+    int sp = 1;
+    for (; sp + 2 < p.splits; sp += 3) {  // three slab loads in flight, added in slab order
+      const float4 u0 = *reinterpret_cast<const float4*>(sb + sp * p.s_split + e);
+      const float4 u1 = *reinterpret_cast<const float4*>(sb + (sp + 1) * p.s_split + e);
+      const float4 u2 = *reinterpret_cast<const float4*>(sb + (sp + 2) * p.s_split + e);
+      add4(t, u0); add4(t, u1); add4(t, u2);
     }
+    for (; sp < p.splits; ++sp) add4(t, *reinterpret_cast<const float4*>(sb + sp * p.s_split + e));
     if (rawb) *reinterpret_cast<float4*>(rawb + e) = t;
     if (rsl) {
       const int i = e / K, j = e - i * K;
