@@ -1516,6 +1516,8 @@ static DensePlan dense_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
                         static_cast<double>(2 + resident) * (1.0 + 0.01 * sp);
     if (cost < best) { best = cost; splits = sp; }
   }
+  static const int force_splits = getenv("TGP_STAGE2_SPLITS") ? atoi(getenv("TGP_STAGE2_SPLITS")) : 0;
+  if (force_splits > 0 && force_splits <= max_splits) splits = force_splits;
   int64_t kps = (N + splits - 1) / splits;
   kps = (kps + BK - 1) / BK * BK;
   splits = (N + kps - 1) / kps;
