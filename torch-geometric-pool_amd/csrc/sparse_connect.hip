@@ -201,11 +201,15 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_count_kernel(SubgraphPred
     lds_copy_words<SG_THREADS>(s_dyn, pred.member_bits, nwords);
     __syncthreads();
   }
+  // the next chunk's edges are requested before the current one is evaluated and counted (as in the fill pass)
+  SgEdges nxt;
+  sg_fetch(pred, static_cast<int64_t>(blockIdx.x) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER, E, nxt);
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const int64_t e0 = static_cast<int64_t>(chunk) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER;
     uint32_t mine = 0;
-    SgEdges t;
-    sg_fetch(pred, e0, E, t);
+    SgEdges t = nxt;
+    if (chunk + static_cast<int>(gridDim.x) < nchunks)
+      sg_fetch(pred, e0 + static_cast<int64_t>(gridDim.x) * SG_CHUNK, E, nxt);
     sg_eval<LDSB>(pred, s_dyn, e0, t);
 #pragma unroll
     for (int j = 0; j < SG_PER; ++j) mine += t.keep[j] ? 1u : 0u;
