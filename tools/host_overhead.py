@@ -1,5 +1,6 @@
+"""Host-side cost (us per call, GPU work negligible) of the native wrappers next to a plain torch op."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "torch-geometric-pool_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "torch-geometric-pool_amd"))
 from tgp import kernels as K
 from tgp import _native as N
 dev = torch.device("cuda:0")

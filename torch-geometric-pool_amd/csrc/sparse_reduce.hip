@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void reduce_sparse_vec4_kernel(
         const float* src[U];
         float4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = m < len[u] ? perm[beg[u] + m] : -1;
+        for (int u = 0; u < U; ++u) a[u] = m < len[u] ? (perm ? perm[beg[u] + m] : beg[u] + m) : -1;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           w[u] = 1.0f;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void reduce_sparse_scalar_kernel(
     const int64_t c = o / F, f = o - c * F;
     float acc = 0.f;
     for (int32_t p = row_ptr[c]; p < row_ptr[c + 1]; ++p) {
-      const int32_t a = perm[p];
+      const int32_t a = perm ? perm[p] : p;
       const float w = weight ? weight[a] : 1.0f;
       acc = __fadd_rn(acc, __fmul_rn(x[node_index[a] * x_stride + f], w));
     }
@@ -206,7 +206,7 @@ extern "C" int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t 
   TGP_REQUIRE(num_nodes >= 0 && F >= 0 && K >= 0 && nnz >= 0 && row_ptr, TGP_ERR_INVALID,
               "tgp_reduce_sparse_f32: bad argument");
   if (K == 0 || F == 0) return TGP_OK;
-  TGP_REQUIRE(x_pool && (nnz == 0 || (x && node_index && perm)), TGP_ERR_INVALID,
+  TGP_REQUIRE(x_pool && (nnz == 0 || (x && node_index)), TGP_ERR_INVALID,  // perm == NULL: identity order
               "tgp_reduce_sparse_f32: null pointer");
   const bool vec = (F % 4 == 0) && (x_stride % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                    (reinterpret_cast<uintptr_t>(x_pool) % 16 == 0);
