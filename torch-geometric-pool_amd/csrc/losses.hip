@@ -48,32 +48,35 @@ __global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict_
   if (threadIdx.x == 0) out[0] = t;
 }
 
-// One wave per node row: deg (row sum of A), q (squared norm of the S row); 4 rows per workgroup.
+// G lanes per node row: deg (row sum of A), q (squared norm of the S row); 256 / G rows per workgroup.  G = 64 for
+// long rows; batches of small graphs (N <= 64: a row is at most 16 float4) use G = 16, i.e. four rows per wave.
+template <int G>
 __global__ __launch_bounds__(256) void cut_rows_kernel(const float* __restrict__ A, const float* __restrict__ S,
                                                        int64_t rows, int N, int K, float* __restrict__ deg,
                                                        float* __restrict__ q) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float* a = A + row * N;
-  const float* s = S + row * K;
+  const int sub = threadIdx.x % G;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * (256 / G) + threadIdx.x / G;
   float d = 0.f, qq = 0.f;
-  if ((N & 3) == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0) {
-    const nt_f32x4* a4 = reinterpret_cast<const nt_f32x4*>(a);
-    for (int j = lane; j < N / 4; j += 64) {
-      const nt_f32x4 v = __builtin_nontemporal_load(a4 + j);
-      d += (v.x + v.y) + (v.z + v.w);
+  if (row < rows) {
+    const float* a = A + row * N;
+    const float* s = S + row * K;
+    if ((N & 3) == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0) {
+      const nt_f32x4* a4 = reinterpret_cast<const nt_f32x4*>(a);
+      for (int j = sub; j < N / 4; j += G) {
+        const nt_f32x4 v = __builtin_nontemporal_load(a4 + j);
+        d += (v.x + v.y) + (v.z + v.w);
+      }
+    } else {
+      for (int j = sub; j < N; j += G) d += a[j];
     }
-  } else {
-    for (int j = lane; j < N; j += 64) d += a[j];
+    for (int k = sub; k < K; k += G) qq = fmaf(s[k], s[k], qq);
   }
-  for (int k = lane; k < K; k += 64) qq = fmaf(s[k], s[k], qq);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
+  for (int o = G / 2; o > 0; o >>= 1) {
     d += __shfl_xor(d, o, 64);
     qq += __shfl_xor(qq, o, 64);
   }
-  if (lane == 0) {
+  if (row < rows && sub == 0) {
     deg[row] = d;
     q[row] = qq;
   }
@@ -181,8 +184,12 @@ extern "C" int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int6
   TGP_REQUIRE(A && deg && q && (K == 0 || S), TGP_ERR_INVALID, "tgp_cut_terms_f32: null pointer");
   TGP_REQUIRE(N < (1ll << 31) && K < (1ll << 31) && B * N < (1ll << 33), TGP_ERR_RANGE, "tgp_cut_terms_f32: too large");
   const int64_t rows = B * N;
-  hipLaunchKernelGGL(cut_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, A, S, rows, static_cast<int>(N),
-                     static_cast<int>(K), deg, q);
+  if (N <= 64)
+    hipLaunchKernelGGL(cut_rows_kernel<16>, dim3(cdiv(rows, 16)), dim3(256), 0, stream, A, S, rows, static_cast<int>(N),
+                       static_cast<int>(K), deg, q);
+  else
+    hipLaunchKernelGGL(cut_rows_kernel<64>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, A, S, rows, static_cast<int>(N),
+                       static_cast<int>(K), deg, q);
   hipLaunchKernelGGL(cut_den_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, deg, q, static_cast<int>(N), den);
   return check_launch("tgp_cut_terms_f32");
 }
