@@ -1,0 +1,540 @@
+// Whole graphs per wave / workgroup (small and medium graph batches) and batched products of small matrices.
+#pragma once
+#include <stdlib.h>
+#include <type_traits>
+
+#include "common.h"
+#include "gemm_mfma.h"  // f32x16, stamps
+
+namespace tgp {
+
+// ------------------------------------------------------------------------------------------
+// Small graphs (N <= 64, K <= 32, F <= 32; e.g. the PROTEINS-shaped batch of BASELINE configs[2]):
+// one WAVE owns one graph.  S and X go straight from HBM into the MFMA operand registers (row-coalesced:
+// lane = column, one node row per half-wave); only A, whose operand layout is the transpose of its
+// memory layout, is staged through LDS (zero padded 64 x 65 per wave, so two workgroups fit a CU).
+// Then X' = S^T X (32 MFMAs), U = A S (64) and A' = S^T U (32) run back to back.  U never leaves the
+// accumulators: register r of the 32x32 C/D layout holds rows (rho(r), rho(r)+4) for the two half-waves,
+// which is exactly a k-pair of the next MFMA's B operand, so every product walks the node dimension in
+// that order (node(q) below) and all three share one register copy of S.  The post-processing
+// (utils/ops.py:282-335) happens in registers + wave shuffles.  Each graph crosses HBM once: HBM-bound.
+// ------------------------------------------------------------------------------------------
+constexpr int SG_N = 64, SG_K = 32, SG_LDA = 65;
+constexpr int SG_WAVE_FLOATS = SG_N * SG_LDA;  // A only
+
+struct SmallArgs {
+  const float* S; const float* A; const float* X;
+  int B, N, K, F, flags;
+  float* x_pool; float* adj_raw; float* adj_pool;
+};
+
+__device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
+// uniform base + 32-bit per-lane byte offset: lets the load use the SGPR-base addressing form
+__device__ __forceinline__ const float* byte_off(const float* base, int bytes) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + static_cast<unsigned>(bytes));
+}
+
+#ifdef TGP_GEMM_STAMPS
+// per-WAVE stamps of the small-graph kernel (slot s of graph b at stamps[b*16 + s])
+#define TGP_WSTAMP(slot)                                                                                  \
+  do {                                                                                                    \
+    if (g_gemm_stamps && lane_id() == 0)                                                                  \
+      g_gemm_stamps[static_cast<long>(blockIdx.x * 4 + wave_id()) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define TGP_WSTAMP(slot) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = lane_id();
+  const int w = __builtin_amdgcn_readfirstlane(wave_id());  // wave-uniform => graph bases stay in SGPRs
+  const int lm = lane & 31, lk = lane >> 5;
+  float* As = smem + w * SG_WAVE_FLOATS;
+  const int N = p.N, K = p.K, F = p.F;
+  const bool at = p.flags & TGP_ADJ_TRANSPOSED;
+  const int b = blockIdx.x * 4 + w;  // one graph per wave, no loop (keeps the 64 + 64 load offsets transient)
+  if (b >= p.B) return;
+  TGP_WSTAMP(0);
+  {
+    // ---- request everything up front: A (float4 rows), then S and X in operand order ------------
+    // out-of-range elements read element 0 of the graph (always valid) and are replaced by 0 afterwards, so
+    // the loads stay unconditional and are issued back to back
+    float4 v[16];
+    if (p.A) {  // 16 lanes per row (64 floats), 4 rows per wave-instruction, 16 instructions
+      const float* Ab = p.A + static_cast<long>(b) * N * N;
+      const int q = lane & 15;
+      const bool qfull = 4 * q + 3 < N;   // whole vector inside the row (rows need dword alignment only)
+      const int qrem = N - 4 * q;         // 1..3 on the lane that holds a row's ragged tail (N % 4 != 0)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = (lane >> 4) + 4 * t;
+        const bool ok = qfull && i < N;
+        const float4 r = *reinterpret_cast<const float4*>(byte_off(Ab, ok ? (i * N + 4 * q) * 4 : 0));
+        v[t] = ok ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!qfull && qrem > 0 && i < N) {  // never read past the end of the row (= of the tensor for the last one)
+          const float* tail = byte_off(Ab, (i * N + 4 * q) * 4);
+          v[t].x = tail[0];
+          if (qrem > 1) v[t].y = tail[1];
+          if (qrem > 2) v[t].z = tail[2];
+        }
+      }
+    }
+    // step q of every product contracts node rows node(q) = 32*(q>>4) + rho(q&15) + 4*lk
+    float sr[32], xr[32];
+    {
+      const float* Sb = p.S + static_cast<long>(b) * N * K;
+      const bool cok = lm < K;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
+        const bool ok = cok && node < N;
+        const float r = *byte_off(Sb, ok ? (node * K + lm) * 4 : 0);
+        sr[q] = ok ? r : 0.f;
+      }
+    }
+    if (p.X) {
+      const float* Xb = p.X + static_cast<long>(b) * N * F;
+      const bool cok = lm < F;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
+        const bool ok = cok && node < N;
+        const float r = *byte_off(Xb, ok ? (node * F + lm) * 4 : 0);
+        xr[q] = ok ? r : 0.f;
+      }
+    }
+    if (p.A) {
+      const int q = lane & 15;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = (lane >> 4) + 4 * t;
+        if (!at) {
+          float* d = As + i * SG_LDA + 4 * q;
+          d[0] = v[t].x; d[1] = v[t].y; d[2] = v[t].z; d[3] = v[t].w;
+        } else {  // memory holds A^T: element (row i, cols 4q..4q+3) of memory is A[4q+j][i]
+          As[(4 * q + 0) * SG_LDA + i] = v[t].x; As[(4 * q + 1) * SG_LDA + i] = v[t].y;
+          As[(4 * q + 2) * SG_LDA + i] = v[t].z; As[(4 * q + 3) * SG_LDA + i] = v[t].w;
+        }
+      }
+    }
+    // the tile belongs to this wave alone and LDS serves a wave's requests in order: no workgroup barrier
+    __builtin_amdgcn_wave_barrier();
+    TGP_WSTAMP(1);
+
+    // ---- X' = S^T X ---------------------------------------------------------------------
+    if (p.X && p.x_pool) {
+      f32x16 ax;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ax[r] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) ax = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[q], xr[q], ax, 0, 0, 0);
+      if (lm < F) {
+        float* o = p.x_pool + static_cast<long>(b) * K * F;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = rho(r) + 4 * lk;
+          if (c < K) o[c * F + lm] = ax[r];
+        }
+      }
+    }
+
+    TGP_WSTAMP(2);
+    // ---- U = A S (kept in accumulators), A' = S^T U -----------------------------------------
+    if (p.A && (p.adj_raw || p.adj_pool)) {
+      f32x16 u[2], aa;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { u[0][r] = 0.f; u[1][r] = 0.f; aa[r] = 0.f; }
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
+        u[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[lm * SG_LDA + node], sr[q], u[0], 0, 0, 0);
+        u[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(32 + lm) * SG_LDA + node], sr[q], u[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          aa = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[mt * 16 + r], u[mt][r], aa, 0, 0, 0);
+
+      TGP_WSTAMP(3);
+      // aa[r] = A'[row = rho(r) + 4*lk][col = lm]
+      if (p.adj_raw && lm < K) {
+        float* o = p.adj_raw + static_cast<long>(b) * K * K;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = rho(r) + 4 * lk;
+          if (i < K) o[i * K + lm] = aa[r];
+        }
+      }
+      if (p.adj_pool) {
+        if (p.flags & TGP_REMOVE_SELF_LOOPS) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (rho(r) + 4 * lk == lm) aa[r] = 0.f;
+        }
+        if (p.flags & TGP_DEGREE_NORM) {
+          float dcol;  // degree of index `lm`, identical on both half-waves
+          if (p.flags & TGP_SUM_AXIS_ROWS) {  // sum over rows (axis -2): per-lane column sum
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += aa[r];
+            s += __shfl_xor(s, 32, WAVE);
+            dcol = s;
+          } else {                            // sum over columns (axis -1): reduce each row over lanes
+            float mine = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float s = aa[r];
+#pragma unroll
+              for (int d = 16; d > 0; d >>= 1) s += __shfl_xor(s, d, WAVE);
+              // row (rho(r) + 4*lk) total now on every lane of this half-wave; hand it to lane = row
+              const int row = rho(r) + 4 * lk;
+              if (lm == row) mine = s;
+            }
+            // lanes of the other half-wave own the other 16 rows: merge
+            const float other = __shfl_xor(mine, 32, WAVE);
+            bool own = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) own |= (rho(r) + 4 * lk == lm);
+            dcol = own ? mine : other;
+          }
+          const float d = sqrtf(fmaxf(dcol, TGP_EPS));  // d[lm]
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rho(r) + 4 * lk;
+            const float drow = __shfl(d, row, WAVE);      // d[row]
+            const float first = (p.flags & TGP_SUM_AXIS_ROWS) ? d : drow;
+            const float second = (p.flags & TGP_SUM_AXIS_ROWS) ? drow : d;
+            aa[r] = (aa[r] / first) / second;
+          }
+        }
+        if (p.flags & TGP_EDGE_WEIGHT_NORM) {
+          float m = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (lm < K && rho(r) + 4 * lk < K) m = fmaxf(m, fabsf(aa[r]));
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, WAVE));
+          if (m == 0.f) m = 1.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) aa[r] = aa[r] / m;
+        }
+        TGP_WSTAMP(4);
+        if (lm < K) {
+          float* o = p.adj_pool + static_cast<long>(b) * K * K;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = rho(r) + 4 * lk;
+            if (i < K) o[i * K + lm] = aa[r];
+          }
+        }
+      }
+    }
+  }
+  TGP_WSTAMP(5);
+}
+
+// ------------------------------------------------------------------------------------------
+// Medium graphs (TU-dataset-sized batches: N up to a few hundred, K <= 64): one WORKGROUP (4 waves) owns one
+// graph, every byte of A / X crosses HBM once and nothing intermediate leaves the CU.
+//   * S [N,K] is copied to LDS once (zero padded to 32-row / 32-column multiples); every MFMA reads one of its
+//     operands from there (lane = cluster: consecutive words, conflict-free).
+//   * A and X are read straight from HBM into the MFMA B-operand registers: lane = column, so a half-wave
+//     reads 128 contiguous bytes of one row per k-step -- the operand layout IS the memory layout, no staging
+//     (that is why the product is associated as (S^T A) S here; (A S) would need A transposed through LDS).
+//     Buffer-descriptor loads: rows / columns outside the graph come back as zeros from the range check.
+//   * work items = 32-column strips of A (then of X), dealt round-robin to the waves.  An A strip gives
+//     P = (S^T A)^T restricted to the strip, [32 nodes x K], with the strip as the MFMA A operand; register r
+//     of the C/D layout holds strip rows (rho(r), rho(r)+4) on the two half-waves = a k-pair of a B operand,
+//     so P goes straight from the accumulators into A'[c1][c2] += sum_n P[n][c1] S[n][c2] (no LDS round trip).
+//     The four waves' partial A' are added in wave order (deterministic), then the workgroup post-processes
+//     the K x K result in LDS (utils/ops.py:282-335) and stores it.
+// If memory holds A^T (TGP_ADJ_TRANSPOSED) the same program yields (A')^T, which is transposed on the way
+// into the post-processing buffer.
+// ------------------------------------------------------------------------------------------
+struct MediumArgs {
+  const float* S; const float* A; const float* X;
+  int B, N, K, F, flags;
+  float* x_pool; float* adj_raw; float* adj_pool;
+  int npad;  // N rounded up to 32
+};
+
+template <int MT>
+static size_t medium_lds_bytes(int64_t npad) {
+  constexpr int KP = 32 * MT;
+  return (static_cast<size_t>(npad) * KP + KP * (KP + 1) + KP) * sizeof(float);
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel(MediumArgs p) {
+  constexpr int KP = 32 * MT;          // padded K
+  constexpr int UNROLL = 8;            // k-pairs whose operands are requested together (two such sets in flight;
+                                       // 16 measured no faster for K <= 32 and spills for K <= 64)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, lm = lane & 31, lk = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int N = p.N, K = p.K, F = p.F, NP = p.npad;
+  const int b = blockIdx.x;
+  float* Ss = smem;                       // [NP][KP]
+  float* Rs = Ss + NP * KP;               // [KP][KP+1]
+  float* ds = Rs + KP * (KP + 1);         // [KP] degrees
+  const bool want_a = p.A && (p.adj_raw || p.adj_pool);
+  const bool want_x = p.X && p.x_pool;
+
+  TGP_WSTAMP(0);
+  // ---- S -> LDS (zero padded) ------------------------------------------------------------
+  {
+    // eight independent loads in flight per thread: a one-element-per-iteration loop exposes the full load latency
+    // NP * KP / 256 times (measured: 22 us of a 92 us workgroup at N = 200, K = 50)
+    const float* Sb = p.S + static_cast<long>(b) * N * K;
+    constexpr int UB = 8;
+    for (int base = 0; base < NP * KP; base += 256 * UB) {
+      float v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int e = base + u * 256 + tid;
+        const int r = e / KP, c = e - r * KP;
+        v[u] = (r < N && c < K) ? Sb[r * K + c] : 0.f;  // r < N also covers e beyond the tile (NP >= N)
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int e = base + u * 256 + tid;
+        if (e < NP * KP) Ss[e] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+
+  TGP_WSTAMP(1);
+  f32x16 racc[MT][MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) racc[i][j][r] = 0.f;
+
+  const int nt_a = want_a ? (N + 31) / 32 : 0;
+  const int nt_x = want_x ? (F + 31) / 32 : 0;
+  constexpr int OOB = static_cast<int>(0x80000000u);
+  // Strips are dealt round-robin, starting at a wave that rotates with the graph index: wave w always runs on SIMD
+  // w, so a fixed start would pile every graph's extra strip onto the same SIMD of the CU.
+  for (int job = (w + 4 - (b & 3)) & 3; job < nt_a + nt_x; job += 4) {
+    const bool is_a = job < nt_a;
+    const int n0 = (is_a ? job : job - nt_a) * 32;
+    const int ld = is_a ? N : F;
+    const float* src = is_a ? p.A + static_cast<long>(b) * N * N : p.X + static_cast<long>(b) * N * F;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, N * ld * 4, 0x00020000);
+    const int voff = (n0 + lm < ld) ? (lk * ld + n0 + lm) * 4 : OOB;
+    // strip element (node row k + lk, column n0 + lm) of A or X; two register sets: the next batch of k-pairs
+    // is requested before the MFMAs of the current one
+    float gv[2][UNROLL];
+    auto request = [&](int set, int k0) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+        gv[set][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (k0 + 2 * u) * ld * 4, 0));
+    };
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // X strip:  X'[c][f]  = sum_k S[k][c] X[k][f]    (S = A operand from LDS, the strip = B operand)
+    // A strip:  P [n][c]  = sum_k A[k][n] S[k][c]    (the strip = A operand, S = B operand from LDS) = T^T
+    auto consume = [&](auto is_a_c, int set, int k0) {
+      constexpr bool IS_A = decltype(is_a_c)::value;
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int k = k0 + 2 * u + lk;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const float sv = Ss[k * KP + i * 32 + lm];
+          if constexpr (IS_A) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[set][u], sv, acc[i], 0, 0, 0);
+          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, gv[set][u], acc[i], 0, 0, 0);
+        }
+      }
+    };
+    auto k_loop = [&](auto is_a_c) {
+      request(0, 0);
+      for (int k0 = 0; k0 < NP; k0 += 4 * UNROLL) {  // NP is a multiple of 32 = 2 * UNROLL node rows
+        if (k0 + 2 * UNROLL < NP) request(1, k0 + 2 * UNROLL);
+        consume(is_a_c, 0, k0);
+        if (k0 + 2 * UNROLL >= NP) break;
+        if (k0 + 4 * UNROLL < NP) request(0, k0 + 4 * UNROLL);
+        consume(is_a_c, 1, k0 + 2 * UNROLL);
+      }
+    };
+    if (is_a) k_loop(std::true_type{});   // wave-uniform branch: one operand order per loop body
+    else k_loop(std::false_type{});
+    if (!is_a) {  // X' strip: rows = clusters, cols = features n0 .. n0+31
+      if (n0 + lm < F) {
+        float* o = p.x_pool + static_cast<long>(b) * K * F;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = i * 32 + rho(r) + 4 * lk;
+            if (c < K) o[c * F + n0 + lm] = acc[i][r];
+          }
+      }
+      continue;
+    }
+    // R[c1][c2] = sum_n P[n][c1] S[n][c2]: register r of the C/D layout holds strip rows (rho(r), rho(r)+4) on the
+    // two half-waves, which is exactly a k-pair of a B operand, so P never leaves the accumulators:
+    //   D[row = c2][col = c1] += S[n0 + rho(r) + 4 lk][c2]  x  P_r[c1]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float sv[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) sv[i] = Ss[(n0 + rho(r) + 4 * lk) * KP + i * 32 + lm];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+          racc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[i], acc[j][r], racc[i][j], 0, 0, 0);
+    }
+  }
+  TGP_WSTAMP(2);
+  if (!want_a) return;
+
+  // ---- A' = sum of the four partial products, in wave order ---------------------------------
+  const bool at = p.flags & TGP_ADJ_TRANSPOSED;
+  for (int turn = 0; turn < 4; ++turn) {
+    if (w == turn) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c2 = i * 32 + rho(r) + 4 * lk, c1 = j * 32 + lm;  // the accumulators hold R[c1][c2]
+            float* d = at ? &Rs[c2 * (KP + 1) + c1] : &Rs[c1 * (KP + 1) + c2];
+            *d = turn == 0 ? racc[i][j][r] : __fadd_rn(*d, racc[i][j][r]);
+          }
+    }
+    __syncthreads();
+  }
+
+  TGP_WSTAMP(3);
+  // ---- post-processing on the K x K result (utils/ops.py:282-335) ---------------------------
+  // element loops run over the padded [K][KP] index space: row / column come from shifts, not divisions
+  const long obase = static_cast<long>(b) * K * K;
+  if (p.adj_raw) {
+    for (int e = tid; e < K * KP; e += 256) {
+      const int i = e / KP, j = e % KP;
+      if (j < K) p.adj_raw[obase + i * K + j] = Rs[i * (KP + 1) + j];
+    }
+    __syncthreads();  // the diagonal is cleared next
+  }
+  if (!p.adj_pool) return;
+  if (p.flags & TGP_REMOVE_SELF_LOOPS) {
+    if (tid < K) Rs[tid * (KP + 1) + tid] = 0.f;
+    __syncthreads();
+  }
+  if (p.flags & TGP_DEGREE_NORM) {
+    const bool rows = p.flags & TGP_SUM_AXIS_ROWS;
+    if (tid < K) {
+      float t = 0.f;
+      for (int q = 0; q < K; ++q) t = __fadd_rn(t, rows ? Rs[q * (KP + 1) + tid] : Rs[tid * (KP + 1) + q]);
+      ds[tid] = sqrtf(fmaxf(t, TGP_EPS));
+    }
+    __syncthreads();
+    for (int e = tid; e < K * KP; e += 256) {
+      const int i = e / KP, j = e % KP;
+      if (j < K) {
+        const float first = rows ? ds[j] : ds[i], second = rows ? ds[i] : ds[j];
+        Rs[i * (KP + 1) + j] = (Rs[i * (KP + 1) + j] / first) / second;
+      }
+    }
+    __syncthreads();
+  }
+  float scale = 1.f;
+  if (p.flags & TGP_EDGE_WEIGHT_NORM) {
+    float m = 0.f;
+    for (int e = tid; e < K * KP; e += 256) {
+      const int i = e / KP, j = e % KP;
+      if (j < K) m = fmaxf(m, fabsf(Rs[i * (KP + 1) + j]));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, WAVE));
+    __syncthreads();
+    if (lane == 0) ds[w] = m;
+    __syncthreads();
+    scale = fmaxf(fmaxf(ds[0], ds[1]), fmaxf(ds[2], ds[3]));
+    if (scale == 0.f) scale = 1.f;
+  }
+  for (int e = tid; e < K * KP; e += 256) {
+    const int i = e / KP, j = e % KP;
+    if (j < K) {
+      const float v = Rs[i * (KP + 1) + j];
+      p.adj_pool[obase + i * K + j] = (p.flags & TGP_EDGE_WEIGHT_NORM) ? v / scale : v;
+    }
+  }
+  TGP_WSTAMP(4);
+}
+
+
+// Batched products of SMALL matrices (the backward of the dense poolers on TU-dataset-sized graphs: [N x F][F x K],
+// [N x N][N x K], ... with N up to a few hundred and at most 64 output columns): the LDS-tiled kernel above spends
+// such a launch on 64 / 128-wide tiles that are mostly padding.  Here one WAVE owns a 32-row strip of one batch
+// element and keeps 32 x Nc of C in its accumulators; both operands go straight from memory into the MFMA operand
+// registers (B: lane = column, coalesced; A: lane = row, each lane walks its own row, so every 64-byte line is
+// fetched once and serves 16 k-steps from L1), eight k-pairs requested at a time.  No LDS, no barriers.
+struct SmallBmmArgs {
+  const float* A; const float* Bm; float* C;
+  int M, Nc, Kd, trans_a;
+  long lda, ldb, ldc, sA, sB, sC;
+  int strips;  // 32-row strips per batch element
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void small_bmm_kernel(SmallBmmArgs p, long total_strips) {
+  const long strip = static_cast<long>(blockIdx.x) * 4 + wave_id();
+  if (strip >= total_strips) return;
+  const int lane = lane_id(), lm = lane & 31, lk = lane >> 5;
+  const long b = strip / p.strips;
+  const int m0 = static_cast<int>(strip - b * p.strips) * 32;
+  const float* A = p.A + b * p.sA;
+  const float* Bm = p.Bm + b * p.sB;
+  float* C = p.C + b * p.sC;
+  const bool row_ok = m0 + lm < p.M;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  constexpr int U = 8;
+  for (int k0 = 0; k0 < p.Kd; k0 += 2 * U) {
+    float av[U], bv[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 2 * u + lk;
+      const bool k_ok = k < p.Kd;
+      const long a_off = p.trans_a ? static_cast<long>(k) * p.lda + m0 + lm : static_cast<long>(m0 + lm) * p.lda + k;
+      av[u] = (k_ok && row_ok) ? A[a_off] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + lm;
+        bv[u][j] = (k_ok && n < p.Nc) ? Bm[static_cast<long>(k) * p.ldb + n] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][j], acc[j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = j * 32 + lm;
+    if (n >= p.Nc) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + rho(r) + 4 * lk;
+      if (m < p.M) C[static_cast<long>(m) * p.ldc + n] = acc[j][r];
+    }
+  }
+}
+
+}  // namespace tgp
