@@ -102,3 +102,32 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     assert b"workspace too small" in lib.tgp_last_error()
     assert lib.tgp_dense_pool_f32(p, p, p, 1, 1 << 31, 4, 4, 0, p, None, p, p, 1 << 20, None) == -4  # TGP_ERR_RANGE
     assert lib.tgp_block_diag_count(p, 70000, 70000, None, 0, p, 1 << 20, p, None) == -4
+
+
+def test_ctypes_signatures_match_the_header_parameter_by_parameter():
+    """Every binding in tgp/_native.py must take exactly the parameters the header declares, in kind: pointer /
+    int64 / int / size_t / double.  (A drifted argtypes list would otherwise only show up as a wrong answer or a
+    crash on the GPU box.)"""
+    from tgp import _native
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    decls = dict(re.findall(r"\b(tgp_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S))
+
+    def kind(param: str):
+        p = " ".join(param.split())
+        if "*" in p:
+            return ctypes.c_void_p
+        if p.startswith("int64_t"):
+            return ctypes.c_int64
+        if p.startswith("size_t"):
+            return ctypes.c_size_t
+        if p.startswith("double"):
+            return ctypes.c_double
+        if p.startswith("int") or p.startswith("unsigned"):
+            return ctypes.c_int
+        raise AssertionError(f"unrecognised parameter '{p}'")
+
+    for name, (_, argtypes) in _native.SIGNATURES.items():
+        params = [q for q in decls[name].split(",") if q.strip() and q.strip() != "void"]
+        want = [kind(q) for q in params]
+        got = [ctypes.c_void_p if a is ctypes.c_char_p else a for a in argtypes]
+        assert got == want, f"{name}: header {[w.__name__ for w in want]} vs binding {[g.__name__ for g in got]}"
