@@ -365,3 +365,39 @@ def test_orthogonality_loss_closed_form_backward(dev):
     ref.backward()
     torch.testing.assert_close(loss.detach(), ref.detach(), **TOL)
     torch.testing.assert_close(S.grad, S2.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("transposed_view", [False, True])
+def test_dense_connect_gradients_large_graph_path(dev, transposed_view):
+    """DenseConnect under autograd on graphs too large for the one-workgroup-per-graph kernels (N > 512 or K > 64):
+    U = A S is a tensor shared between the forward, its backward and the link loss (functions.ASProducts); A may be
+    the transposed view the dense preprocessing hands over (src.py:442-443)."""
+    from tgp.connect import DenseConnect
+    from tgp.select import SelectOutput
+    from tgp.utils.losses import link_pred_loss
+    g = torch.Generator(device=dev).manual_seed(8)
+    B, N, K = 2, 600, 70
+    S0 = torch.softmax(torch.randn(B, N, K, device=dev, generator=g), -1)
+    A0 = (torch.rand(B, N, N, device=dev, generator=g) < 0.05).float() * torch.rand(B, N, N, device=dev, generator=g)
+    wa = torch.randn(B, K, K, device=dev, generator=g)
+
+    def run(native):
+        S = S0.clone().requires_grad_(True)
+        A = A0.transpose(1, 2).contiguous().transpose(1, 2) if transposed_view else A0.clone()
+        assert A.is_contiguous() != transposed_view
+        if native:
+            ap, _ = DenseConnect(remove_self_loops=True, degree_norm=True, adj_transpose=True)(A, SelectOutput(s=S))
+            ll = link_pred_loss(S, A, normalize_loss=False)
+        else:
+            raw = S.transpose(1, 2) @ A @ S
+            raw = raw * (1 - torch.eye(K, device=dev))
+            d = torch.sqrt(raw.sum(-2, keepdim=True).clamp(min=1e-8))
+            ap = (raw / d) / d.transpose(-2, -1)
+            ll = torch.norm(A - S @ S.transpose(1, 2), p=2)
+        ((ap * wa).sum() + ll).backward()
+        return ap.detach(), ll.detach(), S.grad
+
+    got, ref = run(True), run(False)
+    torch.testing.assert_close(got[0], ref[0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(got[1], ref[1], rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(got[2], ref[2], rtol=1e-3, atol=1e-4)
