@@ -1,5 +1,6 @@
 """End-to-end pooler calls (Select + Reduce + Connect [+ losses, + backward]) at scale: wall time per call.
 Finds host overhead / syncs / slow helper ops around the native kernels."""
+import gc
 import os
 import sys
 import time
@@ -17,6 +18,8 @@ only = sys.argv[1:] or None
 def wall(fn, iters=10):
     for _ in range(3):
         fn()
+    gc.collect()  # keep CPython's full collections (~40 ms with torch imported) out of a 10-iteration window
+    gc.freeze()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):

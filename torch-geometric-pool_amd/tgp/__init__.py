@@ -16,6 +16,18 @@ __version__ = "1.0.1+mi355x"
 _submodules = ["poolers", "src", "select", "reduce", "lift", "connect", "utils", "kernels", "distributed"]
 
 
+def freeze_gc() -> None:
+    """Move every object alive now (the imported torch / numpy / scipy modules: ~10^6 containers) into the collector's
+    permanent generation.  A training step of a pooler allocates ~1500 tracked containers (autograd nodes, tuples), so
+    CPython runs a full generation-2 collection every ~50 steps, and with torch imported that pass takes ~40 ms on the
+    host -- 0.8 ms per step amortised, next to ~1.2 ms of actual work (measured, MI355X box).  Calling this once
+    after start-up (model built, first batch seen) makes those passes scan only what was allocated afterwards.  Opt-in:
+    the collector's policy belongs to the application."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def __getattr__(name):
     if name in _submodules:
         module = importlib.import_module(f".{name}", __name__)
