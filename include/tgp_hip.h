@@ -158,11 +158,14 @@ int tgp_postprocess_sparse_norm_f32(const int64_t* row, const int64_t* col, floa
  * TGP_ADJ_TRANSPOSED is set (then element (b,i,j) is read from A[b*N*N + j*N + i]).
  * x / x_pool, adj_raw, adj_pool may each be NULL to skip that product.  MinCut
  * (poolers/mincut.py:226-237) asks for adj_raw AND adj_pool; DiffPool only adj_pool.
+ * graph_sizes (optional): graph b's real nodes are its first graph_sizes[b] rows and everything beyond them in
+ * S, A, X is zero (the layout of to_dense_batch / to_dense_adj, src.py:434-450); kernels then stop at the real
+ * size instead of the padded one.  NULL = every row may be non-zero.
  * ---------------------------------------------------------------------------------- */
 size_t tgp_dense_pool_workspace_bytes(int64_t B, int64_t N, int64_t K, int64_t F);
 int tgp_dense_pool_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K,
-                       int64_t F, int flags, float* x_pool, float* adj_raw, float* adj_pool, void* ws,
-                       size_t ws_bytes, void* stream);
+                       int64_t F, int flags, const int64_t* graph_sizes /* [B] or NULL */, float* x_pool,
+                       float* adj_raw, float* adj_pool, void* ws, size_t ws_bytes, void* stream);
 
 /* Generic batched fp32 GEMM on the matrix cores, C[b] = op(A[b]) B[b] with B[b] [Kd,Nc] row-major.
  * trans_a = 0: A[b] is [M,Kd] row-major; 1: A[b] is stored [Kd,M] (C = A^T B).  Used by

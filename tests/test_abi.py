@@ -100,7 +100,7 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     # valid pointers but a workspace that is too small -> TGP_ERR_WORKSPACE, message names the call
     assert lib.tgp_connect_subgraph_count(p, p, None, 10, None, 0, 10, 0, p, 8, p, None) == -2
     assert b"workspace too small" in lib.tgp_last_error()
-    assert lib.tgp_dense_pool_f32(p, p, p, 1, 1 << 31, 4, 4, 0, p, None, p, p, 1 << 20, None) == -4  # TGP_ERR_RANGE
+    assert lib.tgp_dense_pool_f32(p, p, p, 1, 1 << 31, 4, 4, 0, None, p, None, p, p, 1 << 20, None) == -4  # TGP_ERR_RANGE
     assert lib.tgp_block_diag_count(p, 70000, 70000, None, 0, p, 1 << 20, p, None) == -4
 
 

@@ -523,3 +523,28 @@ def test_bmm_many_small_matrices(dev, shape, trans_a):
     b1 = b[:1]  # one right-hand side shared by the whole batch (stride 0)
     ref1 = ((a.transpose(1, 2) if trans_a else a).double() @ b1.double()).float()
     torch.testing.assert_close(KK.bmm(a, b1, trans_a=trans_a), ref1, rtol=1e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("K,F", [(20, 32), (50, 7), (64, 64)])
+def test_dense_pool_with_graph_sizes_matches_padded_run(dev, K, F):
+    """Ragged padded batch (to_dense_batch layout: real nodes first, zeros after): telling the kernels the real size of
+    every graph must not change a single output, including empty graphs and graphs that fill the padded size."""
+    from tgp import kernels as KK
+    g = torch.Generator(device=dev).manual_seed(K + F)
+    sizes = torch.tensor([300, 5, 0, 17, 128, 33, 1, 299, 64, 31, 32, 250], device=dev)
+    B, N = sizes.numel(), 300
+    mask = torch.arange(N, device=dev).unsqueeze(0) < sizes.unsqueeze(1)
+    A = (torch.rand(B, N, N, device=dev, generator=g) < 0.1).float() * torch.rand(B, N, N, device=dev, generator=g)
+    A = A * mask.unsqueeze(1) * mask.unsqueeze(2)
+    X = torch.randn(B, N, F, device=dev, generator=g) * mask.unsqueeze(-1)
+    S = torch.softmax(torch.randn(B, N, K, device=dev, generator=g), -1) * mask.unsqueeze(-1)
+    flags = KK.dense_flags(True, True, True, True)
+    ref = KK.dense_pool(S, A, X, flags, want_raw=True)
+    got = KK.dense_pool(S, A, X, flags, want_raw=True, graph_sizes=sizes)
+    for a, b, name in zip(got, ref, ("x_pool", "adj_raw", "adj_pool")):
+        torch.testing.assert_close(a, b, rtol=RTOL, atol=ATOL, msg=lambda m: f"{name}: {m}")
+    dense_ref = (S.double().transpose(1, 2) @ A.double() @ S.double()).float()
+    torch.testing.assert_close(got[1], dense_ref, rtol=1e-4, atol=1e-4)
+    At = A.transpose(1, 2).contiguous().transpose(1, 2)  # transposed memory layout
+    got_t = KK.dense_pool(S, At, X, flags, want_raw=True, graph_sizes=sizes)
+    torch.testing.assert_close(got_t[1], ref[1], rtol=RTOL, atol=ATOL)

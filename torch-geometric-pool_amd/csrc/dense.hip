@@ -87,8 +87,8 @@ extern "C" size_t tgp_dense_pool_workspace_bytes(int64_t B, int64_t N, int64_t K
 }
 
 extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N,
-                                  int64_t K, int64_t F, int flags, float* x_pool, float* adj_raw,
-                                  float* adj_pool, void* ws, size_t ws_bytes, void* stream_) {
+                                  int64_t K, int64_t F, int flags, const int64_t* graph_sizes, float* x_pool,
+                                  float* adj_raw, float* adj_pool, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0 && F >= 0, TGP_ERR_INVALID, "tgp_dense_pool_f32: negative size");
   if (B == 0 || K == 0) return TGP_OK;
@@ -125,7 +125,7 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
     if (lds <= static_cast<size_t>(kMediumMaxLds) && fits32) {
       MediumArgs q{S, want_a ? A : nullptr, want_x ? X : nullptr, static_cast<int>(B), static_cast<int>(N),
                    static_cast<int>(K), static_cast<int>(F), flags, want_x ? x_pool : nullptr,
-                   want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr, static_cast<int>(npad)};
+                   want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr, static_cast<int>(npad), graph_sizes};
       if (K <= 32)
         hipLaunchKernelGGL(dense_pool_medium_kernel<1>, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, q);
       else

@@ -258,6 +258,10 @@ struct MediumArgs {
   int B, N, K, F, flags;
   float* x_pool; float* adj_raw; float* adj_pool;
   int npad;  // N rounded up to 32
+  // optional [B]: graph b's real nodes are its first sizes[b] rows (to_dense_batch layout, src.py:448-450); the rest
+  // of the padded tensors is zero by construction, so the loops stop there.  A real batch pads every graph to the
+  // longest one (PROTEINS: 39 nodes on average, 620 at most), which is where most of the padded work goes.
+  const int64_t* sizes;
 };
 
 template <int MT>
@@ -276,6 +280,12 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int N = p.N, K = p.K, F = p.F, NP = p.npad;
   const int b = blockIdx.x;
+  int NV = N;  // valid node rows of this graph
+  if (p.sizes) {
+    const int64_t sz = p.sizes[b];
+    NV = sz < N ? (sz > 0 ? static_cast<int>(sz) : 0) : N;
+  }
+  const int NPV = (NV + 31) & ~31;
   float* Ss = smem;                       // [NP][KP]
   float* Rs = Ss + NP * KP;               // [KP][KP+1]
   float* ds = Rs + KP * (KP + 1);         // [KP] degrees
@@ -289,18 +299,18 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel
     // NP * KP / 256 times (measured: 22 us of a 92 us workgroup at N = 200, K = 50)
     const float* Sb = p.S + static_cast<long>(b) * N * K;
     constexpr int UB = 8;
-    for (int base = 0; base < NP * KP; base += 256 * UB) {
+    for (int base = 0; base < NPV * KP; base += 256 * UB) {
       float v[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int e = base + u * 256 + tid;
         const int r = e / KP, c = e - r * KP;
-        v[u] = (r < N && c < K) ? Sb[r * K + c] : 0.f;  // r < N also covers e beyond the tile (NP >= N)
+        v[u] = (r < NV && c < K) ? Sb[r * K + c] : 0.f;  // r < NV also covers e beyond the tile (NPV >= NV)
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int e = base + u * 256 + tid;
-        if (e < NP * KP) Ss[e] = v[u];
+        if (e < NPV * KP) Ss[e] = v[u];
       }
     }
   }
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) racc[i][j][r] = 0.f;
 
-  const int nt_a = want_a ? (N + 31) / 32 : 0;
+  const int nt_a = want_a ? (NV + 31) / 32 : 0;
   const int nt_x = want_x ? (F + 31) / 32 : 0;
   constexpr int OOB = static_cast<int>(0x80000000u);
   // Strips are dealt round-robin, starting at a wave that rotates with the graph index: wave w always runs on SIMD
@@ -358,11 +368,11 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel
     };
     auto k_loop = [&](auto is_a_c) {
       request(0, 0);
-      for (int k0 = 0; k0 < NP; k0 += 4 * UNROLL) {  // NP is a multiple of 32 = 2 * UNROLL node rows
-        if (k0 + 2 * UNROLL < NP) request(1, k0 + 2 * UNROLL);
+      for (int k0 = 0; k0 < NPV; k0 += 4 * UNROLL) {  // NPV is a multiple of 32 = 4 * UNROLL node rows
+        if (k0 + 2 * UNROLL < NPV) request(1, k0 + 2 * UNROLL);
         consume(is_a_c, 0, k0);
-        if (k0 + 2 * UNROLL >= NP) break;
-        if (k0 + 4 * UNROLL < NP) request(0, k0 + 4 * UNROLL);
+        if (k0 + 2 * UNROLL >= NPV) break;
+        if (k0 + 4 * UNROLL < NPV) request(0, k0 + 4 * UNROLL);
         consume(is_a_c, 1, k0 + 2 * UNROLL);
       }
     };

@@ -62,7 +62,7 @@ SIGNATURES = {
     "tgp_postprocess_sparse_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64,
                                                  _c_p, _c_sz, _c_p]),
     "tgp_dense_pool_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64]),
-    "tgp_dense_pool_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p,
+    "tgp_dense_pool_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p,
                                     _c_p, _c_p, _c_sz, _c_p]),
     "tgp_postprocess_dense_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
     "tgp_postprocess_dense_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_sz, _c_p]),

@@ -119,12 +119,12 @@ class _DenseConnectFn(torch.autograd.Function):
     link-prediction loss (functions.ASProducts)."""
 
     @staticmethod
-    def forward(ctx, s, adj):
+    def forward(ctx, s, adj, graph_sizes=None):
         ctx.save_for_backward(s, adj)
         ctx.products = Fn.shared_products(s, adj)
         B, n, k = s.shape
         if n <= 512 and k <= 64:  # small / medium graphs: the fused kernel; U is cheap to redo in the backward
-            return K.dense_pool(s, adj, None, 0, want_raw=True, want_post=False)[1]
+            return K.dense_pool(s, adj, None, 0, want_raw=True, want_post=False, graph_sizes=graph_sizes)[1]
         u = ctx.products.get_u(s, adj)
         ptr = Fn._uniform_ptr(B, n, s.device)
         return K.segment_gemm_tn(s.detach().reshape(B * n, k), u.reshape(B * n, k), ptr, n)
@@ -140,7 +140,7 @@ class _DenseConnectFn(torch.autograd.Function):
             gs = K.bmm(u, g.transpose(-1, -2).contiguous()) + K.bmm(v, g)
         if ctx.needs_input_grad[1]:
             ga = K.bmm(K.bmm(s, g), s.transpose(-1, -2).contiguous())
-        return gs, ga
+        return gs, ga, None
 
 
 class DenseConnect(Connect):
@@ -185,8 +185,8 @@ class DenseConnect(Connect):
         return so.s
 
     @staticmethod
-    def _dense_connect(s: Tensor, adj: Tensor) -> Tensor:
-        return _DenseConnectFn.apply(s, adj)
+    def _dense_connect(s: Tensor, adj: Tensor, graph_sizes: Optional[Tensor] = None) -> Tensor:
+        return _DenseConnectFn.apply(s, adj, graph_sizes)
 
     def dense_connect(self, adj: Tensor, s: Tensor) -> Tensor:
         """Raw S^T A S (MinCut needs it for its loss before post-processing, poolers/mincut.py:226)."""
@@ -216,17 +216,19 @@ class DenseConnect(Connect):
                 batch: Optional[Tensor] = None, batch_pooled: Optional[Tensor] = None, **kwargs):
         s = self._validate_select_output(so)
         if is_dense_adj(edge_index):
-            return self._forward_batched_inputs(edge_index, s)
+            return self._forward_batched_inputs(edge_index, s, getattr(so, "_graph_sizes", None))
         return self._forward_unbatched_inputs(edge_index, edge_weight, batch, s, batch_pooled)
 
-    def _forward_batched_inputs(self, adj: Tensor, s: Tensor):
+    def _forward_batched_inputs(self, adj: Tensor, s: Tensor, graph_sizes: Optional[Tensor] = None):
         s, adj = self._prepare_batched_dense_inputs(s, adj)
+        if graph_sizes is not None and graph_sizes.numel() != s.size(0):
+            graph_sizes = None
         if torch.is_grad_enabled() and (s.requires_grad or adj.requires_grad):
-            raw = self._dense_connect(s, adj)
+            raw = self._dense_connect(s, adj, graph_sizes)
             return postprocess_adj_pool_dense(raw, self.remove_self_loops, self.degree_norm, self.adj_transpose,
                                               self.edge_weight_norm), None
         flags = K.dense_flags(self.remove_self_loops, self.degree_norm, self.adj_transpose, self.edge_weight_norm)
-        return K.dense_pool(s, adj, None, flags)[2], None
+        return K.dense_pool(s, adj, None, flags, graph_sizes=graph_sizes)[2], None
 
     def _forward_unbatched_inputs(self, edge_index, edge_weight, batch, s, batch_pooled):
         batch_size = num_graphs_of(batch)

@@ -220,9 +220,11 @@ def _dense_adj_layout(adj: Tensor) -> Tuple[Tensor, int]:
 
 
 def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int = 0, want_raw: bool = False,
-               want_post: bool = True) -> Tuple[Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
+               want_post: bool = True, graph_sizes: Optional[Tensor] = None
+               ) -> Tuple[Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
     """(x_pool, adj_raw, adj_pool) = (S^T X, S^T A S, postprocess(S^T A S)) for a padded batch
-    (reduce/base_reduce.py:158-161, connect/dense_conn.py:111-122, utils/ops.py:282-335)."""
+    (reduce/base_reduce.py:158-161, connect/dense_conn.py:111-122, utils/ops.py:282-335).  ``graph_sizes`` [B]
+    (optional): real nodes per graph when they are the leading rows and the padding is zero (to_dense_batch layout)."""
     dev = N.require_device(s, adj, x)
     s = N.f32c(s)
     B, Nn, K = s.shape
@@ -246,8 +248,14 @@ def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int
             adj_pool = torch.empty(B, K, K, dtype=torch.float32, device=dev)
     L = N.lib()
     ws = N.workspace(L.tgp_dense_pool_workspace_bytes(B, Nn, K, F), dev)
-    N.check(L.tgp_dense_pool_f32(N.ptr(s), N.ptr(a), N.ptr(x), B, Nn, K, F, flags, N.ptr(x_pool), N.ptr(adj_raw),
-                                 N.ptr(adj_pool), N.ptr(ws), ws.numel(), N.stream_ptr(dev)), "tgp_dense_pool_f32")
+    gs = None
+    if graph_sizes is not None:
+        gs = N.i64c(graph_sizes)
+        if gs.numel() != B or gs.device != dev:
+            raise ValueError(f"graph_sizes must hold one count per graph on {dev}, got {tuple(gs.shape)} on {gs.device}")
+    N.check(L.tgp_dense_pool_f32(N.ptr(s), N.ptr(a), N.ptr(x), B, Nn, K, F, flags, N.ptr(gs), N.ptr(x_pool),
+                                 N.ptr(adj_raw), N.ptr(adj_pool), N.ptr(ws), ws.numel(), N.stream_ptr(dev)),
+            "tgp_dense_pool_f32")
     return x_pool, adj_raw, adj_pool
 
 

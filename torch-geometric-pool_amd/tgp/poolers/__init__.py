@@ -18,7 +18,7 @@ from ..lift import BaseLift
 from ..reduce import BaseReduce
 from ..select import GraclusSelect, MLPSelect, NDPSelect, SelectOutput, TopkSelect
 from ..src import BasePrecoarseningMixin, DenseSRCPooling, PoolingOutput, SRCPooling
-from ..utils.ops import is_dense_adj
+from ..utils.ops import batch_info, is_dense_adj
 from ..utils.losses import (
     entropy_loss,
     link_pred_loss,
@@ -171,13 +171,18 @@ class _DenseMLPPooling(DenseSRCPooling):
             # number of real nodes behind the padded batch, when the host already knows it (a reduction over the mask
             # costs ~25 us on the device for any mask size)
             self._known_nodes = None
+            graph_sizes = None
             if not is_dense_adj(adj) and isinstance(x, Tensor) and x.dim() == 2:
                 self._known_nodes = x.size(0)
+                if batch is not None and batch.numel() > 0 and x.is_cuda:
+                    graph_sizes = batch_info(batch).sizes  # memoised: the densification below asks for it anyway
             elif mask is None and isinstance(x, Tensor) and x.dim() == 3:
                 self._known_nodes = x.size(0) * x.size(1)
             x, adj, mask = self._ensure_batched_inputs(x=x, edge_index=adj, edge_weight=edge_weight, batch=batch,
                                                        mask=mask)
             so = self.select(x=x, mask=mask)
+            if graph_sizes is not None and graph_sizes.numel() == x.size(0):
+                so._graph_sizes = graph_sizes
             fused = self.reduce_connect(x, adj, so, want_raw=self._loss_needs_raw)
             if fused is not None:  # inference: Reduce + Connect in one native call
                 x_pool, raw, adj_pool = fused

@@ -55,7 +55,7 @@ class BaseReduce(Reduce):
             return x_pool, self.reduce_batch(so, batch)
         s = so.s
         if s.dim() == 3:
-            return _DenseReduceFn.apply(s, x), self.reduce_batch(so, batch)
+            return _DenseReduceFn.apply(s, x, getattr(so, "_graph_sizes", None)), self.reduce_batch(so, batch)
         if s.dim() != 2:
             raise ValueError(f"Dense SelectOutput.s must be 2D [N, K] or 3D [B, N, K], got ndim={s.dim()}.")
         if is_multi_graph_batch(batch):
@@ -102,9 +102,9 @@ class _DenseReduceFn(torch.autograd.Function):
     """X' = S^T X on the matrix cores; dS = X dX'^T, dX = S dX'."""
 
     @staticmethod
-    def forward(ctx, s, x):
+    def forward(ctx, s, x, graph_sizes=None):
         ctx.save_for_backward(s, x)
-        return K.dense_pool(s, None, x)[0]
+        return K.dense_pool(s, None, x, graph_sizes=graph_sizes)[0]
 
     @staticmethod
     def backward(ctx, g):
@@ -115,7 +115,7 @@ class _DenseReduceFn(torch.autograd.Function):
             gs = K.bmm(x, g.transpose(-1, -2).contiguous())
         if ctx.needs_input_grad[1]:
             gx = K.bmm(s, g)
-        return gs, gx
+        return gs, gx, None
 
 
 __all__ = ["Reduce", "BaseReduce"]

@@ -101,6 +101,9 @@ class SelectOutput:
             self._extra_args.add(key)
         self._assign_index = None
         self._lift_index = None
+        # dense padded batches: real nodes per graph (leading rows), set by the pooler that densified the batch; lets
+        # the dense kernels stop at a graph's real size instead of the padded one
+        self._graph_sizes = None
 
     # ---- validation / derived views -------------------------------------------------
     def _validate_in_mask(self, in_mask: Optional[Tensor]) -> Optional[Tensor]:
@@ -208,6 +211,7 @@ class SelectOutput:
     def _drop_caches(self) -> None:
         self._assign_index = None
         self._lift_index = None
+        self._graph_sizes = None
 
     def _set_one_to_one_index(self) -> None:
         """Selectors whose supernodes own exactly one node (TopK, NDP) know the inverted index in

@@ -305,7 +305,8 @@ class DenseSRCPooling(SRCPooling):
             raise ValueError("Assignment and adjacency batch sizes do not match: "
                              f"got s.size(0)={s.size(0)} and adj.size(0)={adj.size(0)}.")
         flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
-        return K.dense_pool(s, adj, x, flags, want_raw=want_raw, want_post=True)
+        return K.dense_pool(s, adj, x, flags, want_raw=want_raw, want_post=True,
+                            graph_sizes=getattr(so, "_graph_sizes", None))
 
     def _finalize_sparse_output(self, x_pool: Tensor, adj_pool: Tensor, batch: Optional[Tensor],
                                 batch_pooled: Optional[Tensor], so: SelectOutput):
