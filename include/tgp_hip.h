@@ -257,12 +257,13 @@ int tgp_pair_dot_f32(const int64_t* ia, const int64_t* ib, int64_t E, const floa
  *   returned because the backward pass needs them.
  * ---------------------------------------------------------------------------------- */
 size_t tgp_link_loss_workspace_bytes(int64_t B, int64_t N, int64_t K);
-int tgp_link_loss_f32(const float* S, const float* A, int64_t B, int64_t N, int64_t K, float* sq, void* ws,
+int tgp_link_loss_f32(const float* S, const float* A, int64_t B, int64_t N, int64_t K,
+                      const int64_t* graph_sizes /* [B] or NULL, as in tgp_dense_pool_f32 */, float* sq, void* ws,
                       size_t ws_bytes, void* stream);
 size_t tgp_entropy_sum_workspace_bytes(int64_t n);
 int tgp_entropy_sum_f32(const float* S, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
-int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int64_t N, int64_t K, float* deg, float* q,
-                      float* den, void* stream);
+int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int64_t N, int64_t K,
+                      const int64_t* graph_sizes /* [B] or NULL */, float* deg, float* q, float* den, void* stream);
 
 /* A7'  sparse A times dense S (connect/dense_conn.py:165,204: torch.sparse.mm), A in CSR built from a
  * row-sorted coalesced edge list: T[i,:] = sum_{e in row i} w[e] * S[col[e],:].  w may be NULL. */

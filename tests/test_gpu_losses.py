@@ -156,3 +156,20 @@ def test_edge_dot_and_gradient(dev, K):
     torch.testing.assert_close(S.grad, S2.grad, rtol=1e-4, atol=1e-5)
     with torch.no_grad():
         torch.testing.assert_close(Fn.edge_dot(S0, ei), ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_losses_with_graph_sizes_match_padded_run(dev):
+    """Link-prediction residual and MinCut denominator on a ragged zero-padded batch: skipping the padding by the
+    per-graph sizes must give the same numbers (utils/losses.py:39-56, 644-652)."""
+    from tgp import kernels as KK
+    g = torch.Generator(device=dev).manual_seed(31)
+    sizes = torch.tensor([200, 5, 0, 17, 128, 33, 1, 199, 64, 130], device=dev)
+    B, N, K = sizes.numel(), 200, 12
+    mask = torch.arange(N, device=dev).unsqueeze(0) < sizes.unsqueeze(1)
+    A = (torch.rand(B, N, N, device=dev, generator=g) < 0.1).float() * mask.unsqueeze(1) * mask.unsqueeze(2)
+    S = torch.softmax(torch.randn(B, N, K, device=dev, generator=g), -1) * mask.unsqueeze(-1)
+    torch.testing.assert_close(KK.link_loss_sq(S, A, sizes), KK.link_loss_sq(S, A), rtol=1e-6, atol=1e-4)
+    for a, b in zip(KK.cut_terms(A, S, sizes), KK.cut_terms(A, S)):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+    ref = torch.stack([torch.norm(A[b] - S[b] @ S[b].t()) ** 2 for b in range(B)])
+    torch.testing.assert_close(KK.link_loss_sq(S, A, sizes), ref, rtol=1e-4, atol=1e-3)

@@ -362,8 +362,8 @@ extern "C" size_t tgp_link_loss_workspace_bytes(int64_t B, int64_t N, int64_t K)
   return tgp::align_up(static_cast<size_t>(B) * tiles * sizeof(float)) + 256;
 }
 
-extern "C" int tgp_link_loss_f32(const float* S, const float* A, int64_t B, int64_t N, int64_t K, float* sq,
-                                 void* ws, size_t ws_bytes, void* stream_) {
+extern "C" int tgp_link_loss_f32(const float* S, const float* A, int64_t B, int64_t N, int64_t K,
+                                 const int64_t* graph_sizes, float* sq, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_link_loss_f32: negative size");
   if (B == 0) return TGP_OK;
@@ -379,6 +379,7 @@ extern "C" int tgp_link_loss_f32(const float* S, const float* A, int64_t B, int6
   TGP_REQUIRE(B * ((N + 63) / 64) * ((N + 63) / 64) < (1ll << 31), TGP_ERR_RANGE, "tgp_link_loss_f32: grid too large");
   tgp::GemmArgs g = link_loss_args(S, A, N, K);
   g.partial = static_cast<float*>(ws);
+  g.sizes = graph_sizes;
   const int tiles = tgp::launch_gemm_residual(g, static_cast<int>(B), stream);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, g.partial, tiles, sq);
   return tgp::check_launch("tgp_link_loss_f32");

@@ -60,6 +60,9 @@ struct GemmArgs {
   long ldr, sR;
   float* partial;          // [batches][tiles_m * tiles_n]
   int force_bm, force_bn;  // 0 = pick_tile decides
+  // MODE 1 only, optional [batches]: rows / columns >= sizes[batch] of resid and op(A) Bm^T are zero (padded batch),
+  // so tiles that lie entirely beyond them contribute nothing and are skipped
+  const int64_t* sizes;
 };
 
 // Row of a [rows][BK+1] LDS tile served by slot t = 8*g + r (8 lanes per slot, slot = one 128-byte row segment).
@@ -144,6 +147,16 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
   const long lda = g.lda, ldb = R.ldb;
 
   const int m0 = tm * BM, n0 = tn * BN;
+  if constexpr (MODE == 1) {
+    if (g.sizes) {
+      const int64_t nb = g.sizes[batch];
+      if (m0 >= nb || n0 >= nb) {  // workgroup-uniform
+        if (threadIdx.x == 0)
+          g.partial[static_cast<long>(batch) * (g.tiles_m * g.tiles_n) + tm * g.tiles_n + tn_all] = 0.f;
+        return;
+      }
+    }
+  }
   int M = g.M;
   if (g.m_ptr) {
     const long m_lo = g.m_ptr[batch];

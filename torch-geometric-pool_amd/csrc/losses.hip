@@ -52,12 +52,15 @@ __global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict_
 // long rows; batches of small graphs (N <= 64: a row is at most 16 float4) use G = 16, i.e. four rows per wave.
 template <int G>
 __global__ __launch_bounds__(256) void cut_rows_kernel(const float* __restrict__ A, const float* __restrict__ S,
-                                                       int64_t rows, int N, int K, float* __restrict__ deg,
+                                                       int64_t rows, int N, int K,
+                                                       const int64_t* __restrict__ sizes, float* __restrict__ deg,
                                                        float* __restrict__ q) {
   const int sub = threadIdx.x % G;
   const int64_t row = static_cast<int64_t>(blockIdx.x) * (256 / G) + threadIdx.x / G;
   float d = 0.f, qq = 0.f;
-  if (row < rows) {
+  // padded rows (beyond the graph's real size) are zero in A and S: nothing to read
+  const bool real = row < rows && (!sizes || row % N < sizes[row / N]);
+  if (real) {
     const float* a = A + row * N;
     const float* s = S + row * K;
     if ((N & 3) == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0) {
@@ -171,8 +174,8 @@ extern "C" int tgp_entropy_sum_f32(const float* S, int64_t n, float* out, void* 
   return check_launch("tgp_entropy_sum_f32");
 }
 
-extern "C" int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int64_t N, int64_t K, float* deg,
-                                 float* q, float* den, void* stream_) {
+extern "C" int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int64_t N, int64_t K,
+                                 const int64_t* graph_sizes, float* deg, float* q, float* den, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_cut_terms_f32: negative size");
   if (B == 0) return TGP_OK;
@@ -186,10 +189,10 @@ extern "C" int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int6
   const int64_t rows = B * N;
   if (N <= 64)
     hipLaunchKernelGGL(cut_rows_kernel<16>, dim3(cdiv(rows, 16)), dim3(256), 0, stream, A, S, rows, static_cast<int>(N),
-                       static_cast<int>(K), deg, q);
+                       static_cast<int>(K), graph_sizes, deg, q);
   else
     hipLaunchKernelGGL(cut_rows_kernel<64>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, A, S, rows, static_cast<int>(N),
-                       static_cast<int>(K), deg, q);
+                       static_cast<int>(K), graph_sizes, deg, q);
   hipLaunchKernelGGL(cut_den_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, deg, q, static_cast<int>(N), den);
   return check_launch("tgp_cut_terms_f32");
 }

@@ -85,10 +85,10 @@ SIGNATURES = {
     "tgp_pair_dot_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "tgp_edge_dot_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_link_loss_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
-    "tgp_link_loss_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_sz, _c_p]),
+    "tgp_link_loss_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_sz, _c_p]),
     "tgp_entropy_sum_workspace_bytes": (_c_sz, [_c_i64]),
     "tgp_entropy_sum_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_sz, _c_p]),
-    "tgp_cut_terms_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p]),
+    "tgp_cut_terms_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "tgp_rowptr_from_sorted_i64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_spmm_csr_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
     "tgp_to_dense_adj_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p]),

@@ -248,11 +248,7 @@ def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int
             adj_pool = torch.empty(B, K, K, dtype=torch.float32, device=dev)
     L = N.lib()
     ws = N.workspace(L.tgp_dense_pool_workspace_bytes(B, Nn, K, F), dev)
-    gs = None
-    if graph_sizes is not None:
-        gs = N.i64c(graph_sizes)
-        if gs.numel() != B or gs.device != dev:
-            raise ValueError(f"graph_sizes must hold one count per graph on {dev}, got {tuple(gs.shape)} on {gs.device}")
+    gs = _sizes_arg(graph_sizes, B, dev)
     N.check(L.tgp_dense_pool_f32(N.ptr(s), N.ptr(a), N.ptr(x), B, Nn, K, F, flags, N.ptr(gs), N.ptr(x_pool),
                                  N.ptr(adj_raw), N.ptr(adj_pool), N.ptr(ws), ws.numel(), N.stream_ptr(dev)),
             "tgp_dense_pool_f32")
@@ -272,7 +268,16 @@ def postprocess_dense(adj_pool: Tensor, flags: int, inplace: bool = False) -> Te
     return dst
 
 
-def link_loss_sq(s: Tensor, adj: Tensor) -> Tensor:
+def _sizes_arg(graph_sizes: Optional[Tensor], num_graphs: int, dev) -> Optional[Tensor]:
+    if graph_sizes is None:
+        return None
+    gs = N.i64c(graph_sizes)
+    if gs.numel() != num_graphs or gs.device != dev:
+        raise ValueError(f"graph_sizes must hold one count per graph on {dev}, got {tuple(gs.shape)} on {gs.device}")
+    return gs
+
+
+def link_loss_sq(s: Tensor, adj: Tensor, graph_sizes: Optional[Tensor] = None) -> Tensor:
     """sq[b] = ||adj[b] - s[b] s[b]^T||_F^2 without materialising s s^T (utils/losses.py:644-708)."""
     dev = N.require_device(s, adj)
     s, adj = N.f32c(s), N.f32c(adj)
@@ -282,8 +287,8 @@ def link_loss_sq(s: Tensor, adj: Tensor) -> Tensor:
     sq = torch.empty(B, dtype=torch.float32, device=dev)
     L = N.lib()
     ws = N.workspace(L.tgp_link_loss_workspace_bytes(B, Nn, K), dev)
-    N.check(L.tgp_link_loss_f32(N.ptr(s), N.ptr(adj), B, Nn, K, N.ptr(sq), N.ptr(ws), ws.numel(), N.stream_ptr(dev)),
-            "tgp_link_loss_f32")
+    N.check(L.tgp_link_loss_f32(N.ptr(s), N.ptr(adj), B, Nn, K, N.ptr(_sizes_arg(graph_sizes, B, dev)), N.ptr(sq),
+                                N.ptr(ws), ws.numel(), N.stream_ptr(dev)), "tgp_link_loss_f32")
     return sq
 
 
@@ -299,7 +304,7 @@ def entropy_sum(s: Tensor) -> Tensor:
     return out
 
 
-def cut_terms(adj: Tensor, s: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+def cut_terms(adj: Tensor, s: Tensor, graph_sizes: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """(deg [B,N], q [B,N], den [B]): row sums of adj, squared row norms of s, trace(s^T D s)
     (utils/losses.py:39-81)."""
     dev = N.require_device(adj, s)
@@ -310,8 +315,8 @@ def cut_terms(adj: Tensor, s: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     deg = torch.empty(B, Nn, dtype=torch.float32, device=dev)
     q = torch.empty(B, Nn, dtype=torch.float32, device=dev)
     den = torch.empty(B, dtype=torch.float32, device=dev)
-    N.check(N.lib().tgp_cut_terms_f32(N.ptr(adj), N.ptr(s), B, Nn, K, N.ptr(deg), N.ptr(q), N.ptr(den),
-                                      N.stream_ptr(dev)), "tgp_cut_terms_f32")
+    N.check(N.lib().tgp_cut_terms_f32(N.ptr(adj), N.ptr(s), B, Nn, K, N.ptr(_sizes_arg(graph_sizes, B, dev)), N.ptr(deg),
+                                      N.ptr(q), N.ptr(den), N.stream_ptr(dev)), "tgp_cut_terms_f32")
     return deg, q, den
 
 

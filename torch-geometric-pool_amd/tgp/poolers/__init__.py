@@ -8,6 +8,7 @@ Only the five poolers named by the hot path are built: ``topk``, ``graclus``, ``
 from __future__ import annotations
 
 import inspect
+import weakref
 from typing import Callable, List, Optional, Union
 
 import torch
@@ -155,6 +156,11 @@ class _DenseMLPPooling(DenseSRCPooling):
     def _lift(self, x, so, batch, batch_pooled):
         return self.lift(x_pool=x, so=so, batch=batch, batch_pooled=batch_pooled)
 
+    def _sizes_for(self, adj):
+        """Real nodes per graph of the zero-padded batch ``adj`` belongs to, if forward() densified it itself."""
+        hint = getattr(self, "_sizes_hint", None)
+        return hint[1] if hint is not None and hint[0]() is adj else None
+
     def _real_nodes(self, mask):
         """Valid nodes of the padded batch: the host-side count when forward() had one, else a 0-dim device tensor
         (no host round trip either way)."""
@@ -181,8 +187,10 @@ class _DenseMLPPooling(DenseSRCPooling):
             x, adj, mask = self._ensure_batched_inputs(x=x, edge_index=adj, edge_weight=edge_weight, batch=batch,
                                                        mask=mask)
             so = self.select(x=x, mask=mask)
+            self._sizes_hint = None
             if graph_sizes is not None and graph_sizes.numel() == x.size(0):
                 so._graph_sizes = graph_sizes
+                self._sizes_hint = (weakref.ref(adj), graph_sizes)  # valid for exactly this adjacency tensor
             fused = self.reduce_connect(x, adj, so, want_raw=self._loss_needs_raw)
             if fused is not None:  # inference: Reduce + Connect in one native call
                 x_pool, raw, adj_pool = fused
@@ -230,7 +238,8 @@ class DiffPool(_DenseMLPPooling):
         return self.compute_loss(adj=adj, S=so.s, num_nodes=self._real_nodes(mask))
 
     def compute_loss(self, adj: Tensor, S: Tensor, num_nodes: int) -> dict:
-        return {"link_loss": link_pred_loss(S, adj, normalize_loss=self.normalize_loss) * self.link_loss_coeff,
+        return {"link_loss": link_pred_loss(S, adj, normalize_loss=self.normalize_loss,
+                                            graph_sizes=self._sizes_for(adj)) * self.link_loss_coeff,
                 "entropy_loss": entropy_loss(S, num_nodes) * self.ent_loss_coeff}
 
     def compute_sparse_loss(self, edge_index, edge_weight, S, batch) -> dict:
@@ -277,7 +286,8 @@ class MinCutPooling(_DenseMLPPooling):
         return self.compute_loss(adj, so.s, raw)
 
     def compute_loss(self, adj: Tensor, S: Tensor, adj_pooled: Tensor) -> dict:
-        return {"cut_loss": mincut_loss(adj, S, adj_pooled, batch_reduction="mean") * self.cut_loss_coeff,
+        return {"cut_loss": mincut_loss(adj, S, adj_pooled, batch_reduction="mean",
+                                        graph_sizes=self._sizes_for(adj)) * self.cut_loss_coeff,
                 "ortho_loss": orthogonality_loss(S, batch_reduction="mean") * self.ortho_loss_coeff}
 
     def compute_sparse_loss(self, edge_index, edge_weight, S, batch) -> dict:

@@ -36,8 +36,8 @@ class _CutDenFn(torch.autograd.Function):
     """den[b] = trace(S^T D S) = sum_i deg_i ||S_i||^2 with deg = row sums of adj, one pass over adj."""
 
     @staticmethod
-    def forward(ctx, adj, S):
-        deg, q, den = K.cut_terms(adj, S)
+    def forward(ctx, adj, S, graph_sizes=None):
+        deg, q, den = K.cut_terms(adj, S, graph_sizes)
         ctx.save_for_backward(S, deg, q)
         return den
 
@@ -50,7 +50,7 @@ class _CutDenFn(torch.autograd.Function):
             g_adj = (g * q.unsqueeze(-1)).expand(-1, -1, q.size(1)).contiguous()
         if ctx.needs_input_grad[1]:
             g_s = 2.0 * g * deg.unsqueeze(-1) * S
-        return g_adj, g_s
+        return g_adj, g_s, None
 
 
 class _GramFn(torch.autograd.Function):
@@ -72,8 +72,8 @@ class _LinkNormFn(torch.autograd.Function):
     accumulators (forward) and the backward uses d/dS = (4 S S^T S - 2 (A + A^T) S) / (2 norm)."""
 
     @staticmethod
-    def forward(ctx, S, adj):
-        norm = torch.sqrt(K.link_loss_sq(S, adj).sum())
+    def forward(ctx, S, adj, graph_sizes=None):
+        norm = torch.sqrt(K.link_loss_sq(S, adj, graph_sizes).sum())
         ctx.save_for_backward(S, adj, norm)
         ctx.products = Fn.shared_products(S, adj)  # A S, A^T S: shared with DenseConnect's backward
         return norm
@@ -88,7 +88,7 @@ class _LinkNormFn(torch.autograd.Function):
             g_s = (2.0 * K.bmm(S, gram) - ctx.products.get_u(S, adj) - ctx.products.get_v(S, adj)) * coef
         if ctx.needs_input_grad[1]:
             g_adj = (adj - torch.matmul(S, S.transpose(1, 2))) * coef
-        return g_s, g_adj
+        return g_s, g_adj, None
 
 
 class _EntropySumFn(torch.autograd.Function):
@@ -103,9 +103,12 @@ class _EntropySumFn(torch.autograd.Function):
         return -(torch.log(S + eps) + S / (S + eps)) * g
 
 
-def mincut_loss(adj: Tensor, S: Tensor, adj_pooled: Tensor, batch_reduction: str = "mean") -> Tensor:
+def mincut_loss(adj: Tensor, S: Tensor, adj_pooled: Tensor, batch_reduction: str = "mean",
+                graph_sizes: Optional[Tensor] = None) -> Tensor:
+    """``graph_sizes`` (this build only): real nodes per graph of a zero-padded batch, lets the pass over adj skip the
+    padding."""
     num = torch.diagonal(adj_pooled, dim1=-2, dim2=-1).sum(-1)
-    den = _CutDenFn.apply(adj, S)  # trace(S^T D S) without forming D
+    den = _CutDenFn.apply(adj, S, graph_sizes)  # trace(S^T D S) without forming D
     return _reduce(-(num / (den + eps)), batch_reduction)
 
 
@@ -141,8 +144,9 @@ def orthogonality_loss(S: Tensor, batch_reduction: str = "mean") -> Tensor:
     return _reduce(torch.norm(sts - target, dim=(-2, -1)), batch_reduction)
 
 
-def link_pred_loss(S: Tensor, adj: Tensor, normalize_loss: bool = True) -> Tensor:
-    loss = _LinkNormFn.apply(S, adj)
+def link_pred_loss(S: Tensor, adj: Tensor, normalize_loss: bool = True,
+                   graph_sizes: Optional[Tensor] = None) -> Tensor:
+    loss = _LinkNormFn.apply(S, adj, graph_sizes)
     return loss / adj.numel() if normalize_loss is True else loss
 
 
