@@ -288,7 +288,8 @@ class MinCutPooling(_DenseMLPPooling):
     def compute_loss(self, adj: Tensor, S: Tensor, adj_pooled: Tensor) -> dict:
         return {"cut_loss": mincut_loss(adj, S, adj_pooled, batch_reduction="mean",
                                         graph_sizes=self._sizes_for(adj)) * self.cut_loss_coeff,
-                "ortho_loss": orthogonality_loss(S, batch_reduction="mean") * self.ortho_loss_coeff}
+                "ortho_loss": orthogonality_loss(S, batch_reduction="mean",
+                                                 graph_sizes=self._sizes_for(adj)) * self.ortho_loss_coeff}
 
     def compute_sparse_loss(self, edge_index, edge_weight, S, batch) -> dict:
         ei, ew = connectivity_to_edge_index(edge_index, edge_weight)

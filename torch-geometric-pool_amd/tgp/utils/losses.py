@@ -57,14 +57,14 @@ class _GramFn(torch.autograd.Function):
     """G = S^T S on the matrix cores (split over the node dimension); dS = S (g + g^T)."""
 
     @staticmethod
-    def forward(ctx, S):
+    def forward(ctx, S, graph_sizes=None):
         ctx.save_for_backward(S)
-        return K.dense_pool(S, None, S)[0]
+        return K.dense_pool(S, None, S, graph_sizes=graph_sizes)[0]
 
     @staticmethod
     def backward(ctx, g):
         (S,) = ctx.saved_tensors
-        return K.bmm(S, (g + g.transpose(-1, -2)).contiguous())
+        return K.bmm(S, (g + g.transpose(-1, -2)).contiguous()), None
 
 
 class _LinkNormFn(torch.autograd.Function):
@@ -134,8 +134,8 @@ class _OrthoFromGramFn(torch.autograd.Function):
         return coef * (y - yg * gram / (n * n))
 
 
-def orthogonality_loss(S: Tensor, batch_reduction: str = "mean") -> Tensor:
-    sts = _GramFn.apply(S)
+def orthogonality_loss(S: Tensor, batch_reduction: str = "mean", graph_sizes: Optional[Tensor] = None) -> Tensor:
+    sts = _GramFn.apply(S, graph_sizes if S.dim() == 3 else None)
     if sts.is_cuda and torch.is_grad_enabled() and sts.requires_grad:
         return _reduce(_OrthoFromGramFn.apply(sts), batch_reduction)
     sts = sts / torch.norm(sts, dim=(-2, -1), keepdim=True)
