@@ -401,3 +401,26 @@ def test_dense_connect_gradients_large_graph_path(dev, transposed_view):
     torch.testing.assert_close(got[0], ref[0], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(got[1], ref[1], rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(got[2], ref[2], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(2048, 60, 32, 20), (64, 1024, 64, 128), (700, 50, 7, 3)])
+def test_linear_weight_gradient_tall_skinny(dev, shape):
+    """dW = dY^T X of the selector's Linear over many node rows (select/mlp_select.py:67): the slab-wise path for
+    narrow layers and the split-range segment product otherwise, against torch."""
+    from tgp import functions as Fn
+    B, N, F, K = shape
+    g = torch.Generator(device=dev).manual_seed(B + K)
+    X0 = torch.randn(B, N, F, device=dev, generator=g)
+    W0 = torch.randn(K, F, device=dev, generator=g) / F ** 0.5
+    b0 = torch.randn(K, device=dev, generator=g)
+    go = torch.randn(B, N, K, device=dev, generator=g)
+    res = []
+    for native in (True, False):
+        X, W, b = (t.clone().requires_grad_(True) for t in (X0, W0, b0))
+        y = Fn.linear(X, W, b) if native else torch.nn.functional.linear(X, W, b)
+        (y * go).sum().backward()
+        res.append((X.grad, W.grad, b.grad))
+    scale = float(res[1][1].abs().max())
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-5 * max(scale, 1.0) * 10)
+    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-4, atol=1e-2)

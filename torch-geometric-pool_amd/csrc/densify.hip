@@ -40,6 +40,22 @@ __global__ __launch_bounds__(256) void dense_batch_kernel(const float* __restric
   }
 }
 
+// The inverse gather (backward of to_dense_batch): x[i,:] = dense[batch[i], i - ptr[batch[i]], :], zero for nodes that
+// a caller-imposed max_num_nodes dropped.
+__global__ __launch_bounds__(256) void from_dense_batch_kernel(const float* __restrict__ dense, int64_t N, int64_t F,
+                                                               const int64_t* __restrict__ batch,
+                                                               const int64_t* __restrict__ ptr, int64_t Nmax,
+                                                               float* __restrict__ x) {
+  const int64_t total = N * F;
+  for (int64_t o = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; o < total;
+       o += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t i = o / F, f = o - i * F;
+    const int64_t b = batch[i];
+    const int64_t li = i - ptr[b];
+    x[o] = li < Nmax ? dense[(b * Nmax + li) * F + f] : 0.f;
+  }
+}
+
 }  // namespace tgp
 
 using namespace tgp;
@@ -74,4 +90,22 @@ extern "C" int tgp_to_dense_batch_f32(const float* x, int64_t N, int64_t F, cons
                        ptr, Nmax, out, mask);
   }
   return check_launch("tgp_to_dense_batch_f32");
+}
+
+extern "C" int tgp_from_dense_batch_f32(const float* dense, int64_t N, int64_t F, const int64_t* batch,
+                                        const int64_t* ptr, int64_t B, int64_t Nmax, float* x, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(N >= 0 && F >= 0 && B >= 0 && Nmax >= 0, TGP_ERR_INVALID, "tgp_from_dense_batch_f32: negative size");
+  if (N == 0 || F == 0) return TGP_OK;
+  TGP_REQUIRE(x && batch && ptr && (dense || B == 0 || Nmax == 0), TGP_ERR_INVALID,
+              "tgp_from_dense_batch_f32: null pointer");
+  if (B == 0 || Nmax == 0) {
+    (void)hipMemsetAsync(x, 0, sizeof(float) * N * F, stream);
+    return check_launch("tgp_from_dense_batch_f32");
+  }
+  int64_t blocks = (N * F + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(from_dense_batch_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, dense, N, F,
+                     batch, ptr, Nmax, x);
+  return check_launch("tgp_from_dense_batch_f32");
 }

@@ -261,12 +261,8 @@ class _ToDenseBatchFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gmask):
         batch, ptr = ctx.saved_tensors
-        local = torch.arange(batch.numel(), device=batch.device) - ptr[batch]
-        flat = g.reshape((-1,) + tuple(g.shape[2:]))
-        keep = local < ctx.max_nodes  # nodes beyond a caller-imposed max_num_nodes were dropped in the forward
-        gx = flat[(batch * ctx.max_nodes + local).clamp(max=flat.size(0) - 1)]
-        gx = gx * keep.view((-1,) + (1,) * (gx.dim() - 1)).to(gx.dtype)
-        return gx, None, None, None, None
+        # one gather kernel; nodes beyond a caller-imposed max_num_nodes were dropped in the forward: zero gradient
+        return K.from_dense_batch(g, batch, ptr, ctx.max_nodes), None, None, None, None
 
 
 def to_dense_batch(x: Tensor, batch: Tensor, ptr: Tensor, num_graphs: int, max_nodes: int):
@@ -318,11 +314,26 @@ class _LinearFn(torch.autograd.Function):
             gx = g.matmul(weight)
         if ctx.needs_input_grad[1]:
             x2 = x.reshape(-1, x.size(-1))
-            n = x2.size(0)
-            gw = K.segment_gemm_tn(g2, x2, _whole_range(n, x.device), n)[0]
+            gw = _tall_skinny_tn(g2, x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum(0)
         return gx, gw, gb
+
+
+def _tall_skinny_tn(a: Tensor, b: Tensor) -> Tensor:
+    """a^T b for a [n, p], b [n, q] with n >> p, q (a weight gradient: every node row contributes to a tiny matrix).
+    Narrow operands: the rows are cut into slabs of 64, every slab is one batch element of the one-wave-per-strip
+    product (both operands read in MFMA layout, no LDS) and the slab results are added -- thousands of waves where
+    the tiled GEMM would run a single mostly-padded 64 x 128 tile per split (83 -> ~15 us at n = 122880, 20 x 32)."""
+    n, p, q = a.size(0), a.size(1), b.size(1)
+    slab = 64
+    if p <= 512 and q <= 64 and n >= 512 * slab:
+        full = (n // slab) * slab
+        out = K.bmm(a[:full].view(-1, slab, p), b[:full].view(-1, slab, q), trans_a=True).sum(0)
+        if full < n:
+            out = out + K.bmm(a[full:].unsqueeze(0), b[full:].unsqueeze(0), trans_a=True)[0]
+        return out
+    return K.segment_gemm_tn(a, b, _whole_range(n, a.device), n)[0]
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:

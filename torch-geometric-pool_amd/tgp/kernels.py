@@ -566,6 +566,18 @@ def to_dense_adj(edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tenso
     return adj
 
 
+def from_dense_batch(dense: Tensor, batch: Tensor, ptr: Tensor, max_nodes: int) -> Tensor:
+    """[B,Nmax,F] -> [N,F]: the rows that to_dense_batch scattered, gathered back (its backward)."""
+    dev = N.require_device(dense, batch, ptr)
+    d = N.f32c(dense.reshape(dense.size(0), dense.size(1), -1))
+    batch, ptr = N.i64c(batch), N.i64c(ptr)
+    n, F = batch.numel(), d.size(2)
+    out = torch.empty(n, F, dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_from_dense_batch_f32(N.ptr(d), n, F, N.ptr(batch), N.ptr(ptr), d.size(0), max_nodes, N.ptr(out),
+                                             N.stream_ptr(dev)), "tgp_from_dense_batch_f32")
+    return out.view((n,) + tuple(dense.shape[2:]))
+
+
 def to_dense_batch(x: Tensor, batch: Tensor, ptr: Tensor, num_graphs: int, max_nodes: int) -> Tuple[Tensor, Tensor]:
     """PyG to_dense_batch (src.py:448-450): ([B,Nmax,F], mask [B,Nmax])."""
     dev = N.require_device(x, batch, ptr)
