@@ -181,11 +181,16 @@ def run_other_workload(args, dev):
 
             def step():
                 so._drop_caches()
+                so._set_one_to_one_index()  # what TopkSelect / NDPSelect attach: one node per supernode, no sort
                 red(x, so, batch=batch)
+            so._set_one_to_one_index()
             nnz = k
         # roofline of the gather-sum kernel alone (index cached), SURVEY 8(d) A1 byte count
         idx = so.assign_index()
-        alg = nnz * (4.0 * f + 8 + 8 + 4) + k * 4.0 * f
+        if idx.one_to_one:  # row + node_index + perm (+ weight) per assignment; no row_ptr table to read
+            alg = nnz * (4.0 * f + 8 + 4 + (4 if so.weight is not None else 0)) + k * 4.0 * f
+        else:
+            alg = nnz * (4.0 * f + 8 + 8 + 4) + k * 4.0 * f
         kern_ms = event_time_ms(lambda: kernels.reduce_sparse(x, so.node_index, so.weight, idx), 20, dev)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")

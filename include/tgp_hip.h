@@ -73,7 +73,8 @@ int tgp_assign_index_build(const int64_t* cluster_index, int64_t nnz, int64_t nu
                            void* ws, size_t ws_bytes, void* stream);
 int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t num_features, int64_t x_row_stride,
                           const int64_t* node_index, const float* weight /* may be NULL = ones */,
-                          const int32_t* row_ptr, const int32_t* perm /* NULL = identity */, int64_t nnz,
+                          const int32_t* row_ptr /* NULL = one assignment per supernode (nnz == K): TopK, NDP */,
+                          const int32_t* perm /* NULL = identity */, int64_t nnz,
                           int64_t num_supernodes, float* x_pool /* [K,F] contiguous */, void* stream);
 
 /* A2  Reduce.reduce_batch, sparse branch (reduce/base_reduce.py:37-41):

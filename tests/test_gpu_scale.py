@@ -68,6 +68,42 @@ def test_sparse_reduce_vs_oracle_bitexact(dev, n, f):
     assert torch.equal(BaseReduce()(x.to(dev), so)[0].cpu(), ref)
 
 
+@pytest.mark.parametrize("n,f", [(40_000, 128), (5_000, 20), (3_001, 7), (1, 4)])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_one_to_one_reduce_vs_oracle_bitexact(dev, n, f, weighted):
+    """TopK / NDP assignments (one node per supernode): the index without a row_ptr table gives the bits of the
+    oracle and of the general index, through both the vector and the scalar kernel."""
+    import tgp_oracle as O
+    import tgp.kernels as KK
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    g = torch.Generator().manual_seed(n * 7 + f)
+    k = (n + 1) // 2
+    keep = torch.sort(torch.randperm(n, generator=g)[:k])[0]
+    cluster = torch.randperm(k, generator=g)
+    w = (torch.rand(k, generator=g) + 0.5) if weighted else None
+    x = torch.randn(n, f, generator=g)
+    so = SelectOutput(node_index=keep.to(dev), cluster_index=cluster.to(dev), num_nodes=n, num_supernodes=k,
+                      weight=None if w is None else w.to(dev))
+    general = BaseReduce()(x.to(dev), so)[0]
+    assert not so.assign_index().one_to_one
+    so._drop_caches()
+    so._set_one_to_one_index()
+    assert so.assign_index().one_to_one
+    direct = BaseReduce()(x.to(dev), so)[0]
+    ref = O.reduce_sparse(x, keep, cluster, w if w is not None else torch.ones(k), k)
+    assert torch.equal(direct.cpu(), ref) and torch.equal(general, direct)
+    # a consumer that asks for the table gets arange
+    assert torch.equal(so.assign_index().row_ptr.cpu(), torch.arange(k + 1, dtype=torch.int32))
+    # the ABI refuses a missing table when the assignment is not one-to-one
+    from tgp._native import TgpNativeError
+    if k > 1:
+        bad = KK.AssignIndex(None, so.assign_index().perm, k, k)
+        bad.nnz = k - 1
+        with pytest.raises(TgpNativeError):
+            KK.reduce_sparse(x.to(dev), so.node_index, so.weight, bad)
+
+
 def test_sparse_reduce_linearity_full_size(dev):
     """C4 size (N = 1M, F = 128): S^T(aX + bY) == a S^T X + b S^T Y up to fp32 rounding, and column sums
     are conserved for unit weights."""

@@ -28,6 +28,7 @@ elif which == "reduce_topk":
     k = keep.numel()
     so = SelectOutput(node_index=keep, num_nodes=n, cluster_index=torch.randperm(k, device=dev, generator=g),
                       num_supernodes=k, weight=torch.rand(k, device=dev, generator=g))
+    so._set_one_to_one_index()  # as TopkSelect attaches it
     idx = so.assign_index()
     for _ in range(reps):
         kernels.reduce_sparse(x, so.node_index, so.weight, idx)

@@ -65,8 +65,13 @@ __global__ __launch_bounds__(256) void reduce_sparse_vec4_kernel(
       beg[u] = 0;
       len[u] = -1;
       if (c < K) {
-        beg[u] = row_ptr[c];
-        len[u] = row_ptr[c + 1] - beg[u];
+        if (row_ptr) {
+          beg[u] = row_ptr[c];
+          len[u] = row_ptr[c + 1] - beg[u];
+        } else {  // one assignment per supernode (TopK, NDP): the table is the identity
+          beg[u] = static_cast<int32_t>(c);
+          len[u] = 1;
+        }
       }
       maxlen = len[u] > maxlen ? len[u] : maxlen;
     }
@@ -139,7 +144,9 @@ __global__ __launch_bounds__(256) void reduce_sparse_scalar_kernel(
        o += static_cast<int64_t>(gridDim.x) * 256) {
     const int64_t c = o / F, f = o - c * F;
     float acc = 0.f;
-    for (int32_t p = row_ptr[c]; p < row_ptr[c + 1]; ++p) {
+    const int32_t p_beg = row_ptr ? row_ptr[c] : static_cast<int32_t>(c);
+    const int32_t p_end = row_ptr ? row_ptr[c + 1] : p_beg + 1;
+    for (int32_t p = p_beg; p < p_end; ++p) {
       const int32_t a = perm ? perm[p] : p;
       const float w = weight ? weight[a] : 1.0f;
       acc = __fadd_rn(acc, __fmul_rn(x[node_index[a] * x_stride + f], w));
@@ -203,8 +210,8 @@ extern "C" int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t 
                                      const int32_t* perm, int64_t nnz, int64_t K, float* x_pool,
                                      void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  TGP_REQUIRE(num_nodes >= 0 && F >= 0 && K >= 0 && nnz >= 0 && row_ptr, TGP_ERR_INVALID,
-              "tgp_reduce_sparse_f32: bad argument");
+  TGP_REQUIRE(num_nodes >= 0 && F >= 0 && K >= 0 && nnz >= 0 && (row_ptr || nnz == K), TGP_ERR_INVALID,
+              "tgp_reduce_sparse_f32: bad argument");  // row_ptr == NULL: one assignment per supernode
   if (K == 0 || F == 0) return TGP_OK;
   TGP_REQUIRE(x_pool && (nnz == 0 || (x && node_index)), TGP_ERR_INVALID,  // perm == NULL: identity order
               "tgp_reduce_sparse_f32: null pointer");

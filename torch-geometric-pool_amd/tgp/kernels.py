@@ -19,10 +19,24 @@ class AssignIndex:
     """Inverted index of a sparse assignment (supernode -> its assignments, in ascending
     assignment order).  A function of the SelectOutput only, so SelectOutput caches it."""
 
-    __slots__ = ("row_ptr", "perm", "nnz", "num_targets")
+    __slots__ = ("_row_ptr", "perm", "nnz", "num_targets")
 
-    def __init__(self, row_ptr: Tensor, perm: Tensor, nnz: int, num_targets: int):
-        self.row_ptr, self.perm, self.nnz, self.num_targets = row_ptr, perm, nnz, num_targets
+    def __init__(self, row_ptr: Optional[Tensor], perm: Tensor, nnz: int, num_targets: int):
+        # row_ptr None: exactly one assignment per target (TopK, NDP) -- the table is arange and the Reduce kernel
+        # skips reading it; it is materialised only for a consumer that wants the general form
+        if row_ptr is None and nnz != num_targets:
+            raise ValueError("an AssignIndex without row_ptr must be one-to-one")
+        self._row_ptr, self.perm, self.nnz, self.num_targets = row_ptr, perm, nnz, num_targets
+
+    @property
+    def one_to_one(self) -> bool:
+        return self._row_ptr is None
+
+    @property
+    def row_ptr(self) -> Tensor:
+        if self._row_ptr is None:
+            self._row_ptr = torch.arange(self.num_targets + 1, dtype=torch.int32, device=self.perm.device)
+        return self._row_ptr
 
 
 def build_assign_index(target_index: Tensor, num_targets: int) -> AssignIndex:
@@ -55,7 +69,7 @@ def reduce_sparse(x: Tensor, source_index: Tensor, weight: Optional[Tensor], ind
     F = x2.size(1)
     out = torch.empty(index.num_targets, F, dtype=torch.float32, device=dev)
     N.check(N.lib().tgp_reduce_sparse_f32(N.ptr(x2), x2.size(0), F, x2.stride(0), N.ptr(source_index), N.ptr(w),
-                                          N.ptr(index.row_ptr), N.ptr(index.perm), index.nnz,
+                                          N.ptr(index._row_ptr), N.ptr(index.perm), index.nnz,
                                           index.num_targets, N.ptr(out), N.stream_ptr(dev)),
             "tgp_reduce_sparse_f32")
     return out.view(-1) if squeeze else out
@@ -350,8 +364,7 @@ def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Te
                               ws.numel(),
                               N.ptr(node_index), N.ptr(cluster_index), N.ptr(perm), N.stream_ptr(dev)),
             "tgp_topk_select")
-    row_ptr = torch.arange(k_total + 1, dtype=torch.int32, device=dev)
-    return node_index, cluster_index, AssignIndex(row_ptr, perm, k_total, k_total)
+    return node_index, cluster_index, AssignIndex(None, perm, k_total, k_total)
 
 
 _ROWS_SORTED: dict = {}

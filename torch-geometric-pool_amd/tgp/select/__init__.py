@@ -223,8 +223,7 @@ class SelectOutput:
             return
         perm = torch.empty(max(k, 1), dtype=torch.int32, device=ci.device)
         perm[ci] = torch.arange(k, dtype=torch.int32, device=ci.device)
-        row_ptr = torch.arange(k + 1, dtype=torch.int32, device=ci.device)
-        self._assign_index = kernels.AssignIndex(row_ptr, perm, k, k)
+        self._assign_index = kernels.AssignIndex(None, perm, k, k)
 
     # ---- tensor plumbing (reference base_select.py:313-379) ---------------------------
     def __repr__(self) -> str:
