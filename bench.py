@@ -86,14 +86,32 @@ def cpu_baseline_dense(B, N, K, F, budget_s=12.0):
         O.reduce_dense(S, X)
         O.postprocess_dense(O.dense_connect(S, A), True, True, True, False)
 
-    step()
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
+    def rate(seconds):
         step()
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": bs * N * n / dt, "unit": "nodes/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{bs} of {B} graphs (N={N},K={K},F={F}) x {n} passes of the CPU oracle, {dt:.1f}s"}
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            step()
+            n += 1
+        dt = time.perf_counter() - t0
+        return bs * N * n / dt, n, dt
+
+    threads = torch.get_num_threads()
+    value, n, dt = rate(budget_s)
+    torch.set_num_threads(1)  # all host cores, and again with one thread
+    try:
+        one, n1, dt1 = rate(budget_s / 3)
+    finally:
+        torch.set_num_threads(threads)
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": value, "unit": "nodes/s", "cores": threads, "kind": "port",
+            "sample": f"{bs} of {B} graphs (N={N},K={K},F={F}) x {n} passes of the CPU oracle, {dt:.1f}s",
+            "one_thread": {"value": one, "passes": n1, "seconds": round(dt1, 1)},
+            "host": {"cpu_count": os.cpu_count(), "model": model}}
 
 
 def run_other_workload(args, dev):
