@@ -244,7 +244,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # TGP_BENCH_FORCE_DIST=1: run the RCCL path with a one-rank group (a 1-GPU box can then exercise it)
+    distributed = world > 1 or os.environ.get("TGP_BENCH_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
     dev = torch.device(f"cuda:{local_rank}")
