@@ -514,3 +514,52 @@ def test_native_selectors_degenerate_inputs(dev):
     out = get_pooler("graclus")(x=x, adj=torch.tensor([[0, 1], [1, 0]], device=dev))
     assert out.x.shape == (1, 3) and out.edge_index.size(1) == 0
     torch.testing.assert_close(out.x[0], x.sum(0))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.bfloat16])
+def test_operator_outputs_carry_the_input_dtype(dev, dtype):
+    """The kernels compute in fp32; a float64 / bf16 caller gets tensors of its own dtype back (as from the
+    reference's ATen ops), equal to the fp32 result rounded to that dtype, and gradients of the input dtype."""
+    from tgp.connect import DenseConnect, SparseConnect
+    from tgp.lift import BaseLift
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    g = torch.Generator().manual_seed(3)
+    n, f, k = 40, 6, 9
+    x = torch.randn(n, f, generator=g)
+    cluster = torch.randint(0, k, (n,), generator=g)
+    cluster[:k] = torch.arange(k)
+    w = torch.rand(n, generator=g) + 0.5
+    so = SelectOutput(cluster_index=cluster.to(dev), num_nodes=n, num_supernodes=k, weight=w.to(dev))
+    ref = BaseReduce()(x.to(dev), so)[0]
+    xt = x.to(dev).to(dtype).requires_grad_(True)
+    out = BaseReduce()(xt, so)[0]
+    assert out.dtype == dtype
+    ref_t = BaseReduce()(xt.detach().float(), so)[0]
+    torch.testing.assert_close(out.float(), ref_t.to(dtype).float(), rtol=0, atol=0)
+    if dtype == torch.float64:
+        torch.testing.assert_close(out.float(), ref, rtol=1e-6, atol=1e-6)
+    out.sum().backward()
+    assert xt.grad.dtype == dtype
+    lifted = BaseLift(matrix_op="transpose")(out.detach(), so)
+    assert lifted.dtype == dtype and lifted.shape == (n, f)
+    # sparse Connect: pooled weights follow the input weights
+    ei = torch.randint(0, n, (2, 200), generator=g).to(dev)
+    ew = (torch.rand(200, generator=g) + 0.5).to(dev)
+    e32, w32 = SparseConnect()(ei, so, edge_weight=ew)
+    e_t, w_t = SparseConnect()(ei, so, edge_weight=ew.to(dtype))
+    assert w_t.dtype == dtype and torch.equal(e_t, e32)
+    if dtype == torch.float64:
+        torch.testing.assert_close(w_t.float(), w32, rtol=0, atol=0)
+    # dense Connect / Reduce: results follow S
+    s = torch.softmax(torch.randn(2, 12, 4, generator=g), -1).to(dev)
+    a = (torch.rand(2, 12, 12, generator=g) < 0.3).float().to(dev)
+    sd = SelectOutput(s=s.to(dtype))
+    ap, _ = DenseConnect()(a.to(dtype), sd)
+    assert ap.dtype == dtype
+    assert DenseConnect().dense_connect(a.to(dtype), s.to(dtype)).dtype == dtype
+    xd = torch.randn(2, 12, 5, generator=g).to(dev).to(dtype)
+    assert BaseReduce()(xd, sd)[0].dtype == dtype
+    if dtype == torch.float64:
+        ap32, _ = DenseConnect()(a, SelectOutput(s=s))
+        torch.testing.assert_close(ap.float(), ap32, rtol=1e-6, atol=1e-6)

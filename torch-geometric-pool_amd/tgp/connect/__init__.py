@@ -12,6 +12,7 @@ from .. import kernels as K
 from ..imports import is_sparsetensor
 from ..select import SelectOutput
 from ..utils.ops import (
+    as_compute_dtype, like_input_dtype,
     _normalize_pooled_edges,
     connectivity_to_edge_index,
     connectivity_to_sparsetensor,
@@ -100,12 +101,14 @@ class SparseConnect(Connect):
         # shared with Reduce) so the sort-free row-local coalesce can be used
         ni = so.node_index  # None for a dense assignment: sparse_connect then raises the reference's RuntimeError
         all_assigned = ni is not None and ni.numel() == so.num_nodes and ni.is_cuda
-        return sparse_connect(edge_index, edge_weight, node_index=so.node_index, cluster_index=so.cluster_index,
-                              num_nodes=so.num_nodes, num_supernodes=so.num_supernodes,
-                              remove_self_loops=self.remove_self_loops, reduce_op=self.reduce_op,
-                              edge_weight_norm=self.edge_weight_norm, batch_pooled=batch_pooled,
-                              degree_norm=self.degree_norm,
-                              assign_index=so.assign_index() if all_assigned else None)
+        w32 = as_compute_dtype(edge_weight)  # fp32 arithmetic; pooled weights carry the dtype of the input weights
+        adj_pool, w_pool = sparse_connect(edge_index, w32, node_index=so.node_index, cluster_index=so.cluster_index,
+                                          num_nodes=so.num_nodes, num_supernodes=so.num_supernodes,
+                                          remove_self_loops=self.remove_self_loops, reduce_op=self.reduce_op,
+                                          edge_weight_norm=self.edge_weight_norm, batch_pooled=batch_pooled,
+                                          degree_norm=self.degree_norm,
+                                          assign_index=so.assign_index() if all_assigned else None)
+        return adj_pool, like_input_dtype(w_pool, edge_weight)
 
     def __repr__(self) -> str:
         return (f"{self.__class__.__name__}(reduce_op={self.reduce_op}, "
@@ -190,8 +193,8 @@ class DenseConnect(Connect):
 
     def dense_connect(self, adj: Tensor, s: Tensor) -> Tensor:
         """Raw S^T A S (MinCut needs it for its loss before post-processing, poolers/mincut.py:226)."""
-        s, adj = self._prepare_batched_dense_inputs(s, adj)
-        return self._dense_connect(s, adj)
+        s32, adj32 = self._prepare_batched_dense_inputs(as_compute_dtype(s), as_compute_dtype(adj))
+        return like_input_dtype(self._dense_connect(s32, adj32), s)
 
     @staticmethod
     def _dense_connect_unbatched(edge_index, edge_weight, batch, s, num_nodes, num_clusters, batch_size):
@@ -215,9 +218,15 @@ class DenseConnect(Connect):
     def forward(self, edge_index, so: SelectOutput, *, edge_weight: Optional[Tensor] = None,
                 batch: Optional[Tensor] = None, batch_pooled: Optional[Tensor] = None, **kwargs):
         s = self._validate_select_output(so)
+        s32 = as_compute_dtype(s)  # fp32 arithmetic; the pooled adjacency carries the dtype of S
         if is_dense_adj(edge_index):
-            return self._forward_batched_inputs(edge_index, s, getattr(so, "_graph_sizes", None))
-        return self._forward_unbatched_inputs(edge_index, edge_weight, batch, s, batch_pooled)
+            adj_pool, w = self._forward_batched_inputs(as_compute_dtype(edge_index), s32, getattr(so, "_graph_sizes", None))
+        else:
+            adj_pool, w = self._forward_unbatched_inputs(edge_index, as_compute_dtype(edge_weight), batch, s32,
+                                                         batch_pooled)
+        if w is None:
+            return like_input_dtype(adj_pool, s), None
+        return adj_pool, like_input_dtype(w, s)
 
     def _forward_batched_inputs(self, adj: Tensor, s: Tensor, graph_sizes: Optional[Tensor] = None):
         s, adj = self._prepare_batched_dense_inputs(s, adj)

@@ -9,7 +9,7 @@ from torch import Tensor, nn
 from .. import functions as Fn
 from .. import kernels as K
 from ..select import SelectOutput
-from ..utils.ops import (build_pooled_batch, expand_compacted_rows, graph_ptr, is_multi_graph_batch, max_graph_size,
+from ..utils.ops import (as_compute_dtype, like_input_dtype, build_pooled_batch, expand_compacted_rows, graph_ptr, is_multi_graph_batch, max_graph_size,
                          num_graphs_of, pseudo_inverse)
 
 
@@ -65,7 +65,7 @@ class BaseLift(Lift):
             row.data_ptr() == so.node_index.data_ptr() or torch.equal(row, so.node_index))
         index = lift_index_of(so) if same else K.build_assign_index(row, lift_matrix.size(0))
         back = so.assign_index if same else (lambda: K.build_assign_index(col, lift_matrix.size(1)))
-        return Fn.sparse_lift(x_pool, lift_matrix.values(), row, col, index, back)
+        return Fn.sparse_lift(x_pool, as_compute_dtype(lift_matrix.values()), row, col, index, back)
 
     @staticmethod
     def _lift_dense_multi_graph(lift_matrix, x_pool_flat, batch, batch_pooled) -> Tensor:
@@ -83,11 +83,18 @@ class BaseLift(Lift):
 
     def forward(self, x_pool: Tensor, so: SelectOutput = None, batch: Optional[Tensor] = None,
                 batch_pooled: Optional[Tensor] = None, **kwargs) -> Tensor:
+        # fp32 arithmetic; the result carries the dtype of x_pool like the reference's ATen ops would
+        out = self._forward_f32(as_compute_dtype(x_pool), so, batch, batch_pooled)
+        return like_input_dtype(out, x_pool)
+
+    def _forward_f32(self, x_pool: Tensor, so: SelectOutput, batch: Optional[Tensor],
+                     batch_pooled: Optional[Tensor]) -> Tensor:
         if batch is None and so.batch is not None:
             batch = so.batch
         m = self._get_lift_matrix(so)
         if m.is_sparse:
             return self._lift_sparse(m, x_pool, so)
+        m = as_compute_dtype(m)
         k = m.size(-1)
         multi = is_multi_graph_batch(batch)
         if m.dim() == 2 and x_pool.dim() == 2 and multi:

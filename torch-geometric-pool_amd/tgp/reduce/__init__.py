@@ -9,7 +9,8 @@ from torch import Tensor, nn
 from .. import functions as Fn
 from .. import kernels as K
 from ..select import SelectOutput
-from ..utils.ops import build_pooled_batch, graph_ptr, is_multi_graph_batch, max_graph_size, num_graphs_of
+from ..utils.ops import (as_compute_dtype, build_pooled_batch, graph_ptr, is_multi_graph_batch, like_input_dtype,
+                         max_graph_size, num_graphs_of)
 
 
 class Reduce(nn.Module):
@@ -46,14 +47,20 @@ class BaseReduce(Reduce):
 
     def forward(self, x: Tensor, so: SelectOutput, *, batch: Optional[Tensor] = None,
                 return_batched: bool = False, **kwargs) -> Tuple[Tensor, Optional[Tensor]]:
+        # fp32 arithmetic; the result carries the dtype of x like the reference's ATen ops would
+        x_pool, batch_pool = self._forward_f32(as_compute_dtype(x), so, batch=batch, return_batched=return_batched)
+        return like_input_dtype(x_pool, x), batch_pool
+
+    def _forward_f32(self, x: Tensor, so: SelectOutput, *, batch: Optional[Tensor] = None,
+                     return_batched: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
         if batch is None and so.batch is not None:
             batch = so.batch
         if so.s.is_sparse:
             if return_batched:
                 raise ValueError("return_batched=True is only supported for dense assignment matrices.")
-            x_pool = _SparseReduceFn.apply(x, so.weight, so)
+            x_pool = _SparseReduceFn.apply(x, as_compute_dtype(so.weight), so)
             return x_pool, self.reduce_batch(so, batch)
-        s = so.s
+        s = as_compute_dtype(so.s)
         if s.dim() == 3:
             return _DenseReduceFn.apply(s, x, getattr(so, "_graph_sizes", None)), self.reduce_batch(so, batch)
         if s.dim() != 2:

@@ -17,7 +17,8 @@ from .lift import Lift
 from .reduce import Reduce
 from .select import Select, SelectOutput
 from .utils import Signature, connectivity_to_edge_index, foo_signature
-from .utils.ops import build_pooled_batch, graph_ptr, is_dense_adj, max_graph_size, num_graphs_of
+from .utils.ops import (build_pooled_batch, graph_ptr, is_dense_adj, like_input_dtype, max_graph_size,
+                        num_graphs_of)
 
 
 @dataclass
@@ -305,8 +306,10 @@ class DenseSRCPooling(SRCPooling):
             raise ValueError("Assignment and adjacency batch sizes do not match: "
                              f"got s.size(0)={s.size(0)} and adj.size(0)={adj.size(0)}.")
         flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
-        return K.dense_pool(s, adj, x, flags, want_raw=want_raw, want_post=True,
-                            graph_sizes=getattr(so, "_graph_sizes", None))
+        x_pool, raw, adj_pool = K.dense_pool(s, adj, x, flags, want_raw=want_raw, want_post=True,
+                                             graph_sizes=getattr(so, "_graph_sizes", None))
+        # fp32 arithmetic; results carry the dtypes the reference's ATen ops would return
+        return like_input_dtype(x_pool, x), like_input_dtype(raw, s), like_input_dtype(adj_pool, s)
 
     def _finalize_sparse_output(self, x_pool: Tensor, adj_pool: Tensor, batch: Optional[Tensor],
                                 batch_pooled: Optional[Tensor], so: SelectOutput):

@@ -34,6 +34,22 @@ def is_dense_adj(edge_index) -> bool:
     return edge_index.dim() == 2 and edge_index.size(0) == edge_index.size(1) and edge_index.is_floating_point()
 
 
+def as_compute_dtype(t):
+    """The kernels compute in fp32.  Floating tensors of another dtype (a ``model.double()`` run, bf16 / half
+    features) are converted on the way in -- differentiably -- and :func:`like_input_dtype` converts results back, so
+    the dtype a caller sees is the one the reference's ATen ops would return; the arithmetic stays fp32."""
+    if isinstance(t, Tensor) and not t.is_sparse and t.is_floating_point() and t.dtype != torch.float32:
+        return t.float()
+    return t
+
+
+def like_input_dtype(out, like):
+    if (isinstance(out, Tensor) and isinstance(like, Tensor) and like.is_floating_point()
+            and out.is_floating_point() and out.dtype != like.dtype):
+        return out.to(like.dtype)
+    return out
+
+
 class BatchInfo:
     """Host-side facts about a batch vector (number of graphs, graph sizes, CSR offsets, longest graph).
     Reading them costs two device round trips; one pooler call asks for them in half a dozen places (dense
