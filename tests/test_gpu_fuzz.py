@@ -563,3 +563,39 @@ def test_operator_outputs_carry_the_input_dtype(dev, dtype):
     if dtype == torch.float64:
         ap32, _ = DenseConnect()(a, SelectOutput(s=s))
         torch.testing.assert_close(ap.float(), ap32, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,e,ratio", [(50, 0, 0.5), (50, 7, 0.5), (300, 4096, 0.5), (300, 4097, 0.9), (5_000, 70_000, 0.3),
+                                       (200_000, 1_500_000, 0.5), (1_500_000, 3_000_000, 0.6), (2_000, 2_500_000, 1.0)])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_subgraph_filter_matches_torch_across_chunk_counts(dev, n, e, ratio, weighted):
+    """Induced subgraph + relabel + filters against the same selection written with torch ops, from an empty list
+    and a single chunk to hundreds of chunks per workgroup, with the node bitmap in LDS or (N > 1.2 M) in global
+    memory, sorted and unsorted node_index, all edges or none surviving."""
+    import tgp.kernels as KK
+    g = torch.Generator(device=dev).manual_seed(n + e)
+    ei = torch.randint(0, n, (2, e), device=dev, generator=g)
+    w = (torch.rand(e, device=dev, generator=g) - 0.2) if weighted else None
+    if weighted and e:
+        w[torch.rand(e, device=dev, generator=g) < 0.05] = 0.0  # eps filter
+    k = max(1, int(n * ratio))
+    keep = torch.sort(torch.randperm(n, device=dev, generator=g)[:k])[0]
+    for node_index in (keep, None, keep.flip(0)):
+        for rsl in (True, False):
+            got_ei, got_w = KK.filter_edges(ei, w, node_index, n, rsl)
+            mask = torch.ones(e, dtype=torch.bool, device=dev)
+            src, dst = ei[0], ei[1]
+            if node_index is not None:
+                relabel = torch.full((n,), -1, dtype=torch.long, device=dev)
+                relabel[node_index] = torch.arange(node_index.numel(), device=dev)
+                mask &= (relabel[src] >= 0) & (relabel[dst] >= 0)
+                src, dst = relabel[src], relabel[dst]
+            if rsl:
+                mask &= ei[0] != ei[1]
+            if w is not None:
+                mask &= w.abs() > 1e-8
+            assert torch.equal(got_ei, torch.stack([src[mask], dst[mask]]))
+            assert (got_w is None) == (w is None) and (w is None or torch.equal(got_w, w[mask]))
+    # nothing survives
+    none_ei, none_w = KK.filter_edges(ei, w, keep[:0], n, True)
+    assert none_ei.shape == (2, 0) and (none_w is None or none_w.numel() == 0)

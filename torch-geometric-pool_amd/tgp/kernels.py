@@ -109,6 +109,9 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if w is not None else 0)
     if ni is not None:
         flags |= N.NODE_FILTER
+        if ni.numel() == 0:  # no node kept: no edge survives (an empty tensor has no device pointer to hand over)
+            return (torch.empty(2, 0, dtype=torch.int64, device=dev),
+                    None if w is None else torch.empty(0, dtype=torch.float32, device=dev))
     L = N.lib()
     ws = N.workspace(L.tgp_connect_subgraph_workspace_bytes(E, num_nodes), dev)
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
