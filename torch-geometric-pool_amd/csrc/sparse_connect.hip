@@ -32,35 +32,47 @@ __global__ __launch_bounds__(256) void relabel_scatter_kernel(const int64_t* __r
 // with an ascending node_index the new id of node v is its rank among the members,
 //   rank128[v >> 7] + popcount(bitmap words of the block before v's word) + popcount(v's word below bit v),
 // so the fill pass needs no gather from the 4 N-byte relabel table at all.
-__global__ __launch_bounds__(1024) void member_rank_kernel(const uint32_t* __restrict__ member_bits, int nwords,
-                                                           int nblocks, uint32_t* __restrict__ rank128) {
+__global__ __launch_bounds__(1024) void member_rank_kernel(const uint32_t* member_bits, int nwords, int nblocks,
+                                                           uint32_t* __restrict__ rank128, int in_lds) {
+  // a thread owns a contiguous run of blocks: one streaming pass for the run totals, ONE workgroup scan, and a
+  // second pass (from L2) that writes the ranks -- instead of a scan with three barriers per 1024 blocks
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
   __shared__ uint32_t s_w[16];
-  __shared__ uint32_t s_carry;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int base = 0; base < nblocks; base += 1024) {
-    const int b = base + tid;
+  const int run = (nblocks + 1023) / 1024;
+  const int b0 = tid * run;
+  if (in_lds) {  // coalesced copy with several loads in flight; the per-thread runs are then read from LDS
+    lds_copy_words<1024>(s_bits, member_bits, nwords);
+    __syncthreads();
+    member_bits = s_bits;
+  }
+  auto block_pop = [&](int b) -> uint32_t {
     uint32_t v = 0;
-    if (b < nblocks) {
-#pragma unroll
+    if (4 * b + 3 < nwords) {
+      const uint4 q = *reinterpret_cast<const uint4*>(member_bits + 4 * b);
+      v = __popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w);
+    } else {
       for (int q = 0; q < 4; ++q)
         if (4 * b + q < nwords) v += __popc(member_bits[4 * b + q]);
     }
-    const uint32_t inc = wave_incl_scan(v);
-    if (lane == WAVE - 1) s_w[w] = inc;
-    __syncthreads();
-    uint32_t off = s_carry, tot = 0;
+    return v;
+  };
+  uint32_t mine = 0;
+#pragma unroll 8
+  for (int r = 0; r < run; ++r)
+    if (b0 + r < nblocks) mine += block_pop(b0 + r);
+  const uint32_t inc = wave_incl_scan(mine);
+  if (lane == WAVE - 1) s_w[w] = inc;
+  __syncthreads();
+  uint32_t off = inc - mine;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const uint32_t c = s_w[j];
-      if (j < w) off += c;
-      tot += c;
+  for (int j = 0; j < 16; ++j)
+    if (j < w) off += s_w[j];
+  for (int r = 0; r < run; ++r) {
+    if (b0 + r < nblocks) {
+      rank128[b0 + r] = off;
+      off += block_pop(b0 + r);
     }
-    if (b < nblocks) rank128[b] = off + inc - v;
-    __syncthreads();
-    if (tid == 0) s_carry += tot;
-    __syncthreads();
   }
 }
 
@@ -762,7 +774,12 @@ extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col
     hipLaunchKernelGGL(member_bits_kernel, dim3(cdiv(N > 0 ? N : 1, 256)), dim3(256), 0, stream, s.relabel, N,
                        s.member_bits);
     const int nw = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
-    hipLaunchKernelGGL(member_rank_kernel, dim3(1), dim3(1024), 0, stream, s.member_bits, nw, (nw + 3) / 4, s.rank128);
+    const int in_lds = nw <= SG_LDS_WORDS_MAX ? 1 : 0;
+  if (in_lds)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(member_rank_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_WORDS_MAX * 4);
+  hipLaunchKernelGGL(member_rank_kernel, dim3(1), dim3(1024), in_lds ? nw * sizeof(uint32_t) : 0, stream,
+                     s.member_bits, nw, (nw + 3) / 4, s.rank128, in_lds);
   }
   const int nb = cdiv(E > 0 ? E : 1, SG_CHUNK);
   SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.rank128, s.unsorted, flags};
