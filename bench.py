@@ -2,25 +2,35 @@
 """Headline benchmark: pooled nodes/sec of Reduce + Connect on batched graphs (BASELINE.json).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 ...                       # starts 8 ranks itself (child processes, before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A *step* is one pass of the hot path (BaseReduce + DenseConnect, i.e. S^T X and post-processed
-S^T A S) over one resident synthetic batch.  N = 1 workload = BASELINE.json configs[1]:
-DiffPool dense, B = 32 graphs, N = 1024, K = 128, F = 64 (fp32, the precision the reference computes
-in).  Select and the sparse->dense preprocessing are excluded; inputs are resident in
-HBM when the timed region starts.  With N > 1 every rank pools its own B graphs (weak scaling, seed =
-rank) and the pooled outputs are all-gathered over RCCL inside the timed region.
+A *step* is one pass of the hot path (BaseReduce + DenseConnect, i.e. S^T X and post-processed S^T A S) over one
+resident synthetic batch.  Headline workload = BASELINE.json configs[1]: DiffPool dense, B = 32 graphs, N = 1024,
+K = 128, F = 64 (fp32, the precision the reference computes in).  Select and the sparse->dense preprocessing are
+excluded; inputs are resident in HBM when the timed region starts.  With N > 1 every rank pools its
+own B graphs (weak scaling, seed = rank) and the pooled outputs are all-gathered over RCCL inside the timed region.
 
-Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     fp32-MFMA roofline of the dominant kernel (U = A S, 2*B*N*N*K flop per launch), timed
-                  live with HIP events on the launch stream,
-  "cpu_baseline": the CPU oracle (port of the reference algorithm) on a bounded sample of the same
-                  workload on this box's host cores (rank 0, N = 1 only).
-Other workloads (--workload c3|c4|c5) are for DESIGN.md tables, not the driver's line.
+Rank 0 prints ONE JSON line:
+  contract fields  `value` / `ms_per_step` come from ONE window of EXACTLY --steps steps after --warmup warm-up steps,
+                   bracketed by barrier + device synchronise on both sides, MAX over ranks;
+  "windows"        the same step re-timed as the median of 5 windows of >= 200 steps (tens of ms per window);
+  "roofline"       fp32-MFMA roofline of the dominant kernel (U = A S, 2*B*N*N*K flop per launch), timed live with HIP
+                   events on the launch stream;
+  "cpu_baseline"   the CPU oracle (port of the reference algorithm) on a bounded sample of the same workload on this
+                   box's host cores (rank 0, N = 1 only);
+  "secondary"      the other north_star workloads, each with its own median-window timing and roofline:
+                   c5 (N=8192,K=512,F=128: fp32 MFMA), topk1m (TopK scatter-reduce: HBM), topk_connect (TopK subgraph
+                   Connect: HBM), c4_graclus (Reduce + coalesce Connect, both rooflines: HBM), c3 (MinCut small graphs:
+                   HBM).  With N > 1 only the graph-sharded ones (c5, c3) run; one giant graph (C4) does not shard.
+`--workload X` makes X the headline of the line instead; the driver's line is the default c2.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -31,8 +41,128 @@ sys.path.insert(0, os.path.join(ROOT, "torch-geometric-pool_amd"))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+METRIC = "pooled nodes/sec (Reduce+Connect) on batched graphs"
+WINDOWS, WINDOW_STEPS = 5, 200
 
 
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int) -> int:
+    """`bench.py --gpus N` without a launcher: start N ranks as CHILD processes (one per GPU) and wait for them.
+    Runs before this process has made any GPU call (a process that has initialised the GPU must never exec or fork
+    GPU work); `torch.cuda.device_count()` does not initialise the device on this image."""
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} but this node exposes {have} GPU(s)", file=sys.stderr)
+        return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:  # a rank died: the others would wait in a collective forever
+                    q.terminate()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ timing
+class Ctx:
+    """Per-process timing context: device, ranks, barrier, max-over-ranks."""
+
+    def __init__(self, dev, rank, world, dist):
+        self.dev, self.rank, self.world, self.dist = dev, rank, world, dist
+
+    def sync(self):
+        torch.cuda.synchronize(self.dev)
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, seconds: float) -> float:
+        if self.dist is None:
+            return seconds
+        t = torch.tensor([seconds], device=self.dev, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t)
+
+
+def timed_window(ctx: Ctx, step, steps: int, drain=None) -> float:
+    """EXACTLY `steps` steps bracketed by barrier + device synchronise on both sides; MAX over ranks (seconds)."""
+    ctx.barrier()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    if drain is not None:
+        drain()  # e.g. the last, partly filled all-gather bucket: it belongs to the timed region
+    ctx.sync()
+    ctx.barrier()
+    return ctx.max_over_ranks(time.perf_counter() - t0)
+
+
+def median_windows(ctx: Ctx, step, drain=None, steps=WINDOW_STEPS, windows=WINDOWS) -> dict:
+    ms = [timed_window(ctx, step, steps, drain) / steps * 1e3 for _ in range(windows)]
+    return {"steps_per_window": steps, "windows": windows, "ms_per_step_median": round(statistics.median(ms), 5),
+            "ms_per_step_min": round(min(ms), 5), "ms_per_step_max": round(max(ms), 5)}
+
+
+def event_time_ms(fn, reps, dev):
+    """Average duration of `fn` (the launches of one kernel / one operator) measured with HIP events on the launch
+    stream (torch's current stream: the library launches on the stream handle it is given)."""
+    stream = torch.cuda.current_stream(dev)
+    for _ in range(3):
+        fn()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record(stream)
+    for _ in range(reps):
+        fn()
+    stop.record(stream)
+    stop.synchronize()
+    return start.elapsed_time(stop) / reps
+
+
+def _traffic(key):
+    """HBM bytes per launch from this round's PMC passes (profiles/roofline_traffic.json), or None."""
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            return json.load(fh).get(key)
+    return None
+
+
+def roof_mfma(kernel, flops, ms, traffic_key=None):
+    a = flops / (ms * 1e-3) / 1e12
+    return {"kernel": kernel, "bound": "mfma", "achieved": round(a, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(a / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": _traffic(traffic_key),
+            "flops_per_launch": flops, "avg_launch_ms": round(ms, 5)}
+
+
+def roof_hbm(kernel, nbytes, ms, traffic_key=None):
+    a = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": kernel, "bound": "hbm", "achieved": round(a, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(a / PEAK_HBM_GBS, 4), "traffic": _traffic(traffic_key), "bytes_per_launch": nbytes,
+            "avg_launch_ms": round(ms, 5)}
+
+
+# ------------------------------------------------------------------------------------------------ workloads
 def dense_inputs(B, N, K, F, seed, dev):
     """A = (rand < 0.01) symmetrised, zero diagonal; X ~ N(0,1); S = softmax(randn)."""
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -44,35 +174,308 @@ def dense_inputs(B, N, K, F, seed, dev):
     return S, A, X
 
 
-def timed(fn, steps, warmup, sync, barrier):
-    for _ in range(warmup):
-        fn()
-    barrier()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
-    sync()
-    barrier()
-    return time.perf_counter() - t0
+class Workload:
+    """name, step(), drain() (or None), nodes per step on this rank, rooflines() -> dict or list, extra config."""
+    name = ""
+    nodes = 0
+    shards = False
+    drain = None
+    extra = None
+
+    def step(self):
+        raise NotImplementedError
+
+    def rooflines(self, dev):
+        raise NotImplementedError
 
 
-def event_time_ms(fn, reps, dev):
-    """Average duration of `fn` (one kernel launch) measured with HIP events on the launch stream."""
-    stream = torch.cuda.current_stream(dev)
-    fn()
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record(stream)
-    for _ in range(reps):
-        fn()
-    stop.record(stream)
-    stop.synchronize()
-    return start.elapsed_time(stop) / reps
+class DenseDiffPool(Workload):
+    """C2 / C5: fused A3 + A7 + A8 with DiffPool defaults (diffpool.py:98-115)."""
+    shards = True
+
+    def __init__(self, which, ctx, unfused=False, force_collective=False):
+        from tgp.connect import DenseConnect
+        from tgp.distributed import PackedGather
+        from tgp.reduce import BaseReduce
+        from tgp.select import SelectOutput
+        from tgp.src import DenseSRCPooling
+        if which == "c2":
+            self.B, self.N, self.K, self.F = 32, 1024, 128, 64
+            self.name = "DiffPool dense S^T X / S^T A S, batch=32 graphs N=1024 K=128 F=64 (BASELINE configs[1])"
+        else:
+            self.B, self.N, self.K, self.F = 2, 8192, 512, 128
+            self.name = "DiffPool N=8192 K=512 F=128, 2 graphs per GPU (BASELINE configs[4] shape)"
+        self.which, self.unfused = which, unfused
+        self.S, self.A, self.X = dense_inputs(self.B, self.N, self.K, self.F, seed=ctx.rank, dev=ctx.dev)
+        self.so = SelectOutput(s=self.S)
+        self.reducer, self.connector = BaseReduce(), DenseConnect()
+        self.pool = DenseSRCPooling(reducer=self.reducer, connector=self.connector, adj_transpose=True)
+        # pooled outputs of every step are all-gathered; four steps share one collective (fewer, larger RCCL calls)
+        self.gather = (PackedGather(bucket_steps=4, force_collective=force_collective)
+                       if ctx.dist is not None else None)
+        self.nodes = self.B * self.N
+        if self.gather is not None:
+            self.drain = self.gather.flush
+        self.extra = {"graphs_per_gpu": self.B, "nodes_per_graph": self.N, "clusters": self.K, "features": self.F,
+                      "nodes_counted": "input nodes (B*N per GPU per step)",
+                      "step": ("BaseReduce (S^T X) then DenseConnect (S^T A S + diag/degree post-processing)"
+                               if unfused else
+                               "fused Reduce+Connect (S^T X, S^T A S, diag/degree post-processing) as the dense "
+                               "poolers' forward calls it: DenseSRCPooling.reduce_connect")
+                              + (" + RCCL all-gather of every step's pooled outputs (4 steps per collective)"
+                                 if self.gather is not None else "")}
+
+    def step(self):
+        with torch.no_grad():
+            if self.unfused:
+                x_pool, _ = self.reducer(self.X, self.so)
+                adj_pool, _ = self.connector(self.A, self.so)
+            else:
+                x_pool, _, adj_pool = self.pool.reduce_connect(self.X, self.A, self.so)
+            if self.gather is not None:
+                # asynchronous on RCCL's stream: overlaps the next steps' kernels (one collective in flight)
+                self.gather.start([x_pool, adj_pool])
+                self.gather.take_ready()  # a consumer would use these; the bench only must not accumulate them
+
+    def rooflines(self, dev):
+        from tgp import kernels
+        flops = 2.0 * self.B * self.N * self.N * self.K
+        ms = event_time_ms(lambda: kernels.bmm(self.A, self.S), 50 if self.which == "c2" else 10, dev)
+        r = roof_mfma("tgp::gemm_f32_mfma_kernel<false> (U = A S)", flops, ms,
+                      f"gemm_f32_mfma_kernel<false>:{self.which}")
+        step_flops = flops + 2.0 * self.B * self.K * self.N * (self.K + self.F)
+        r["whole_step_flops"] = step_flops
+        return r
 
 
-def cpu_baseline_dense(B, N, K, F, budget_s=12.0):
+class SmallGraphsMinCut(Workload):
+    """C3: MinCut order on the PROTEINS-shape padded batch: x_pool, raw S^T A S, post-processed A' (one launch)."""
+    shards = True
+
+    def __init__(self, ctx, unfused=False):
+        from tgp.connect import DenseConnect
+        from tgp.reduce import BaseReduce
+        from tgp.select import SelectOutput
+        from tgp.src import DenseSRCPooling
+        dev = ctx.dev
+        g = torch.Generator(device=dev).manual_seed(ctx.rank)
+        B, Nmax, K, F = 2048, 60, 20, 32
+        n_b = torch.randint(20, 61, (B,), device=dev, generator=g)
+        mask = torch.arange(Nmax, device=dev).unsqueeze(0) < n_b.unsqueeze(1)
+        A = (torch.rand(B, Nmax, Nmax, device=dev, generator=g) < (3.7 / 40)).float()
+        A = torch.maximum(A, A.transpose(1, 2)) * mask.unsqueeze(1) * mask.unsqueeze(2)
+        A.diagonal(dim1=1, dim2=2).zero_()
+        self.A = A.contiguous()
+        self.X = torch.randn(B, Nmax, F, device=dev, generator=g) * mask.unsqueeze(-1)
+        self.S = torch.softmax(torch.randn(B, Nmax, K, device=dev, generator=g), -1) * mask.unsqueeze(-1)
+        self.so, self.conn, self.red = SelectOutput(s=self.S, in_mask=mask), DenseConnect(), BaseReduce()
+        self.pool = DenseSRCPooling(reducer=self.red, connector=self.conn, adj_transpose=True)
+        self.unfused = unfused
+        self.nodes = int(n_b.sum())
+        self.dims = (B, Nmax, K, F)
+        self.name = "MinCut PROTEINS-shape batch: B=2048, n~U[20,60] padded to 60, K=20, F=32 (BASELINE configs[2])"
+        self.extra = {"nodes_counted": "real (un-padded) input nodes per step"}
+
+    def step(self):
+        from tgp.utils.ops import postprocess_adj_pool_dense
+        with torch.no_grad():
+            if self.unfused:
+                self.red(self.X, self.so)
+                raw = self.conn.dense_connect(adj=self.A, s=self.S)  # MinCut order: raw -> (loss) -> post-process
+                postprocess_adj_pool_dense(raw, True, True, True, False)
+            else:
+                self.pool.reduce_connect(self.X, self.A, self.so, want_raw=True)
+
+    def rooflines(self, dev):
+        B, Nmax, K, F = self.dims
+        alg = 4.0 * B * (Nmax * Nmax + Nmax * K + Nmax * F + K * K + K * F)  # SURVEY 8(d), padded shapes
+        ms = event_time_ms(self.step, 100, dev)
+        return roof_hbm("tgp::dense_pool_small_kernel (whole step, one launch: graphs fit in LDS)", alg, ms,
+                        "dense_pool_small_kernel:c3")
+
+
+def _big_graph(dev, g, sort_rows=True):
+    n = 1_000_000
+    a = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    b = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+    if sort_rows:
+        # PyG hands out row-major sorted edge lists (to_undirected / coalesce); sort once at set-up
+        ei = ei[:, torch.argsort(ei[0] * n + ei[1])]
+    return n, ei.contiguous()
+
+
+class SparseReduceOnly(Workload):
+    """topk1m / c4_ndp: the sparse Reduce (A1 + A2) with a one-to-one assignment (TopK, NDP)."""
+
+    def __init__(self, which, ctx):
+        from tgp.reduce import BaseReduce
+        from tgp.select import SelectOutput
+        dev = ctx.dev
+        g = torch.Generator(device=dev).manual_seed(0)
+        n, f = 1_000_000, 128
+        self.which, self.f = which, f
+        self.x = torch.randn(n, f, device=dev, generator=g)
+        self.batch = torch.zeros(n, dtype=torch.long, device=dev)
+        if which == "c4_ndp":
+            keep_nodes = (torch.rand(n, device=dev, generator=g) < 0.5).nonzero().view(-1)
+            wts = None
+            self.name = "NDP-shaped S (random +-1 partition) on N=1M, F=128: Reduce only (Kron excluded, SURVEY 8(d))"
+        else:
+            keep_nodes = torch.sort(torch.randperm(n, device=dev, generator=g)[: n // 2])[0]
+            wts = torch.rand(keep_nodes.numel(), device=dev, generator=g)
+            self.name = "TopK-shaped S (ratio 0.5, score weights) on N=1M, F=128: scatter-reduce only"
+        k = keep_nodes.numel()
+        # NDPSelect numbers supernodes in node order (ndp_select.py:128-144); TopK numbers them by score
+        ci = torch.arange(k, device=dev) if which == "c4_ndp" else torch.randperm(k, device=dev, generator=g)
+        self.so = SelectOutput(node_index=keep_nodes, num_nodes=n, cluster_index=ci, num_supernodes=k, weight=wts)
+        self.so._set_one_to_one_index()
+        self.red = BaseReduce()
+        self.nodes, self.k = n, k
+        self.extra = {"num_supernodes": k, "nodes_counted": "input nodes per step"}
+
+    def step(self):
+        so = self.so
+        so._drop_caches()
+        so._set_one_to_one_index()  # what TopkSelect / NDPSelect attach: one node per supernode, no sort
+        self.red(self.x, so, batch=self.batch)
+
+    def rooflines(self, dev):
+        from tgp import kernels
+        so, f, k = self.so, self.f, self.k
+        idx = so.assign_index()
+        # row + node_index + perm (+ weight) per assignment; no row_ptr table to read (one-to-one)
+        alg = k * (4.0 * f + 8 + 4 + (4 if so.weight is not None else 0)) + k * 4.0 * f
+        ms = event_time_ms(lambda: kernels.reduce_sparse(self.x, so.node_index, so.weight, idx), 50, dev)
+        return roof_hbm("tgp::reduce_sparse_vec4_kernel (gather-sum, index cached)", alg, ms,
+                        f"reduce_sparse_vec4_kernel:{self.which}")
+
+
+class TopkConnect(Workload):
+    """A5 + A6: TopK subgraph Connect on N = 1M, E = 10M, ratio 0.5 (count, one sync, fill)."""
+
+    def __init__(self, ctx):
+        from tgp.connect import SparseConnect
+        from tgp.select import SelectOutput
+        dev = ctx.dev
+        g = torch.Generator(device=dev).manual_seed(0)
+        n, self.ei = _big_graph(dev, g)
+        self.ew = torch.ones(self.ei.size(1), device=dev)
+        keep_nodes = torch.sort(torch.randperm(n, device=dev, generator=g)[: n // 2])[0]
+        k = keep_nodes.numel()
+        self.so = SelectOutput(node_index=keep_nodes, num_nodes=n, cluster_index=torch.arange(k, device=dev),
+                               num_supernodes=k, weight=torch.rand(k, device=dev, generator=g))
+        self.conn = SparseConnect()
+        self.nodes, self.n, self.k = n, n, k
+        self.name = "TopK subgraph Connect (ratio 0.5) on one N=1M E=10M graph: induced subgraph + relabel + filters"
+        self.extra = {"edges": int(self.ei.size(1)), "num_supernodes": k, "nodes_counted": "input nodes per step"}
+
+    def step(self):
+        return self.conn(self.ei, self.so, edge_weight=self.ew)
+
+    def rooflines(self, dev):
+        ei_out, _ = self.step()
+        E, E2 = self.ei.size(1), ei_out.size(1)
+        alg = E * 20.0 + self.n + self.k * 8.0 + E2 * 20.0  # SURVEY 8(d) A5+A6
+        ms = event_time_ms(self.step, 30, dev)
+        r = roof_hbm("tgp::subgraph_{count,fill}_kernel (whole Connect call incl. its one host read-back)", alg, ms,
+                     "subgraph_connect:topk1m")
+        r["edges_out"] = E2
+        return r
+
+
+class GraclusC4(Workload):
+    """C4: Graclus-shaped many-to-one S on one N=1M E=10M graph: Reduce (A1+A2) + coalesce Connect (A4+A6)."""
+
+    def __init__(self, ctx, unsorted_edges=False):
+        from tgp.connect import SparseConnect
+        from tgp.reduce import BaseReduce
+        from tgp.select import GraclusSelect
+        dev = ctx.dev
+        g = torch.Generator(device=dev).manual_seed(0)
+        n, self.ei = _big_graph(dev, g, sort_rows=not unsorted_edges)
+        self.f = 128
+        self.ew = torch.ones(self.ei.size(1), device=dev)
+        self.x = torch.randn(n, self.f, device=dev, generator=g)
+        self.batch = torch.zeros(n, dtype=torch.long, device=dev)
+        self.so = GraclusSelect()(self.ei, self.ew, num_nodes=n)
+        self.red, self.conn = BaseReduce(), SparseConnect()
+        self.nodes, self.n, self.k = n, n, self.so.num_supernodes
+        self.name = ("Graclus precoarsening on one N=1M E=10M graph, F=128: Reduce + coalesce Connect "
+                     "(BASELINE configs[3])")
+        self.extra = {"num_supernodes": self.k, "edges": int(self.ei.size(1)),
+                      "edge_order": "random" if unsorted_edges else "row-major sorted (PyG convention)",
+                      "nodes_counted": "input nodes per step"}
+
+    def step(self):
+        so = self.so
+        so._drop_caches()  # rebuild the inverted index every step (no cross-step caching)
+        xp, bp = self.red(self.x, so, batch=self.batch)
+        return self.conn(self.ei, so, edge_weight=self.ew, batch_pooled=bp)
+
+    def rooflines(self, dev):
+        from tgp import kernels
+        so, f, n, k = self.so, self.f, self.n, self.k
+        idx = so.assign_index()
+        alg_r = n * (4.0 * f + 8 + 8 + 4) + k * 4.0 * f  # SURVEY 8(d) A1
+        ms_r = event_time_ms(lambda: kernels.reduce_sparse(self.x, so.node_index, so.weight, idx), 50, dev)
+        ei_out, _ = self.conn(self.ei, so, edge_weight=self.ew)
+        E, E2 = self.ei.size(1), ei_out.size(1)
+        alg_c = E * 20.0 + n * 8.0 + E2 * 20.0  # SURVEY 8(d) A4+A6
+        ms_c = event_time_ms(lambda: self.conn(self.ei, so, edge_weight=self.ew), 30, dev)
+        rc = roof_hbm("coalesce Connect (every kernel of the call + its one host read-back; index cached)", alg_c,
+                      ms_c, "coalesce_connect:c4_graclus")
+        rc["edges_out"] = E2
+        return [rc, roof_hbm("tgp::reduce_sparse_vec4_kernel (gather-sum, index cached)", alg_r, ms_r,
+                             "reduce_sparse_vec4_kernel:c4_graclus")]
+
+
+def make_workload(which, ctx, args):
+    if which in ("c2", "c5"):
+        return DenseDiffPool(which, ctx, unfused=args.unfused,
+                             force_collective=os.environ.get("TGP_BENCH_FORCE_DIST") == "1")
+    if which == "c3":
+        return SmallGraphsMinCut(ctx, unfused=args.unfused)
+    if which in ("topk1m", "c4_ndp"):
+        return SparseReduceOnly(which, ctx)
+    if which == "topk_connect":
+        return TopkConnect(ctx)
+    if which == "c4_graclus":
+        return GraclusC4(ctx, unsorted_edges=args.unsorted_edges)
+    raise ValueError(which)
+
+
+def run_secondary(which, ctx, args):
+    """One secondary workload: warm-up, median of 5 windows of 200 steps, rooflines (first = the one that bounds it)."""
+    wl = make_workload(which, ctx, args)
+    for _ in range(5):
+        wl.step()
+    steps = WINDOW_STEPS if which != "c5" else 50  # c5: 1.1 ms per step, 50 steps = 55 ms per window
+    win = median_windows(ctx, wl.step, wl.drain, steps=steps)
+    roofs = wl.rooflines(ctx.dev)
+    roofs = roofs if isinstance(roofs, list) else [roofs]
+    ms = win["ms_per_step_median"]
+    out = {"workload": which, "name": wl.name, "ms_per_step": ms,
+           "value": round(wl.nodes * ctx.world / (ms * 1e-3), 1), "unit": "nodes/s", "windows": win,
+           "roofline": roofs[0], "config": wl.extra}
+    if len(roofs) > 1:
+        out["roofline_other"] = roofs[1:]
+    if which in ("c2", "c5"):
+        fl = roofs[0]["whole_step_flops"]
+        out["whole_step"] = {"flops": fl, "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                             "frac_of_fp32_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline_dense(B, N, K, F, budget_s=10.0):
     """CPU oracle (plain torch port of reference base_reduce.py:158-161 + dense_conn.py:111-122 +
-    ops.py:282-335) on a bounded sample: B_s graphs of the same shape, repeated for ~budget_s seconds."""
+    ops.py:282-335) on a bounded sample: B_s graphs of the same shape; per-pass times, MEDIAN reported (a shared
+    host's scheduling noise moved a mean by 1.7x between two runs of round 1)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import tgp_oracle as O
     bs = min(B, 8)
@@ -82,24 +485,25 @@ def cpu_baseline_dense(B, N, K, F, budget_s=12.0):
     X = torch.randn(bs, N, F, generator=g)
     S = torch.softmax(torch.randn(bs, N, K, generator=g), -1)
 
-    def step():
+    def one_pass():
+        t0 = time.perf_counter()
         O.reduce_dense(S, X)
         O.postprocess_dense(O.dense_connect(S, A), True, True, True, False)
+        return time.perf_counter() - t0
 
     def rate(seconds):
-        step()
-        n, t0 = 0, time.perf_counter()
+        for _ in range(3):
+            one_pass()
+        ts, t0 = [], time.perf_counter()
         while time.perf_counter() - t0 < seconds:
-            step()
-            n += 1
-        dt = time.perf_counter() - t0
-        return bs * N * n / dt, n, dt
+            ts.append(one_pass())
+        return bs * N / statistics.median(ts), len(ts), time.perf_counter() - t0, bs * N * len(ts) / sum(ts)
 
     threads = torch.get_num_threads()
-    value, n, dt = rate(budget_s)
+    value, n, dt, mean_rate = rate(budget_s)
     torch.set_num_threads(1)  # all host cores, and again with one thread
     try:
-        one, n1, dt1 = rate(budget_s / 3)
+        one, n1, dt1, _ = rate(budget_s / 3)
     finally:
         torch.set_num_threads(threads)
     model = ""
@@ -109,131 +513,25 @@ def cpu_baseline_dense(B, N, K, F, budget_s=12.0):
     except OSError:
         pass
     return {"value": value, "unit": "nodes/s", "cores": threads, "kind": "port",
-            "sample": f"{bs} of {B} graphs (N={N},K={K},F={F}) x {n} passes of the CPU oracle, {dt:.1f}s",
+            "sample": f"{bs} of {B} graphs (N={N},K={K},F={F}), median of {n} passes of the CPU oracle in {dt:.1f}s",
+            "mean_value": mean_rate,  # passes / total time: includes the host's scheduling outliers
             "one_thread": {"value": one, "passes": n1, "seconds": round(dt1, 1)},
             "host": {"cpu_count": os.cpu_count(), "model": model}}
 
 
-def run_other_workload(args, dev):
-    """Secondary workloads for the DESIGN.md / BASELINE.md tables (single GPU, same JSON layout)."""
-    from tgp import kernels
-    from tgp.connect import DenseConnect, SparseConnect
-    from tgp.reduce import BaseReduce
-    from tgp.select import GraclusSelect, SelectOutput
-    from tgp.utils.ops import postprocess_adj_pool_dense
-    from tgp.src import DenseSRCPooling
-    g = torch.Generator(device=dev).manual_seed(0)
-    red = BaseReduce()
-    extra = {}
-    if args.workload == "c3":
-        B, Nmax, K, F = 2048, 60, 20, 32
-        n_b = torch.randint(20, 61, (B,), device=dev, generator=g)
-        mask = torch.arange(Nmax, device=dev).unsqueeze(0) < n_b.unsqueeze(1)
-        A = (torch.rand(B, Nmax, Nmax, device=dev, generator=g) < (3.7 / 40)).float()
-        A = torch.maximum(A, A.transpose(1, 2)) * mask.unsqueeze(1) * mask.unsqueeze(2)
-        A.diagonal(dim1=1, dim2=2).zero_()
-        A = A.contiguous()
-        X = torch.randn(B, Nmax, F, device=dev, generator=g) * mask.unsqueeze(-1)
-        S = torch.softmax(torch.randn(B, Nmax, K, device=dev, generator=g), -1) * mask.unsqueeze(-1)
-        so, conn = SelectOutput(s=S, in_mask=mask), DenseConnect()
-        nodes = int(n_b.sum())
-
-        fused_pool = DenseSRCPooling(reducer=red, connector=conn, adj_transpose=True)
-
-        def step():
-            with torch.no_grad():
-                if args.unfused:
-                    red(X, so)
-                    raw = conn.dense_connect(adj=A, s=S)  # MinCut order: raw -> (loss) -> post-process
-                    postprocess_adj_pool_dense(raw, True, True, True, False)
-                else:  # MinCut forward: x_pool, raw S^T A S (for the cut loss) and post-processed A' at once
-                    fused_pool.reduce_connect(X, A, so, want_raw=True)
-        name = "MinCut PROTEINS-shape batch: B=2048, n~U[20,60] padded to 60, K=20, F=32 (BASELINE configs[2])"
-        alg = 4.0 * B * (Nmax * Nmax + Nmax * K + Nmax * F + K * K + K * F)
-        kern_ms = event_time_ms(step, 20, dev)
-        roof = {"kernel": "whole step (graphs fit in LDS: HBM-bound)", "bound": "hbm",
-                "achieved": round(alg / (kern_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": round(alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
-                "bytes_per_launch": alg, "avg_launch_ms": round(kern_ms, 4)}
-    else:
-        n, f = 1_000_000, 128
-        a = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
-        b = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
-        keep = a != b
-        a, b = a[keep], b[keep]
-        ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
-        if not args.unsorted_edges:
-            # PyG hands out row-major sorted edge lists (to_undirected / coalesce); sort once at set-up
-            ei = ei[:, torch.argsort(ei[0] * n + ei[1])]
-        ew = torch.ones(ei.size(1), device=dev)
-        x = torch.randn(n, f, device=dev, generator=g)
-        batch = torch.zeros(n, dtype=torch.long, device=dev)
-        nodes = n
-        if args.workload == "c4_graclus":
-            so = GraclusSelect()(ei, ew, num_nodes=n)
-            conn = SparseConnect()
-            k = so.num_supernodes
-            extra = {"num_supernodes": k, "edges": int(ei.size(1)),
-                     "edge_order": "random" if args.unsorted_edges else "row-major sorted (PyG convention)"}
-
-            def step():
-                so._drop_caches()  # rebuild the inverted index every step (no cross-step caching)
-                xp, bp = red(x, so, batch=batch)
-                conn(ei, so, edge_weight=ew, batch_pooled=bp)
-            name = "Graclus precoarsening on one N=1M E=10M graph, F=128: Reduce + coalesce Connect (BASELINE configs[3])"
-            nnz = n
-        else:
-            if args.workload == "c4_ndp":
-                keep_nodes = (torch.rand(n, device=dev, generator=g) < 0.5).nonzero().view(-1)
-                wts = None
-                name = "NDP-shaped S (random +-1 partition) on N=1M, F=128: Reduce only (Kron excluded, SURVEY 8(d))"
-            else:
-                keep_nodes = torch.sort(torch.randperm(n, device=dev, generator=g)[: n // 2])[0]
-                wts = torch.rand(keep_nodes.numel(), device=dev, generator=g)
-                name = "TopK-shaped S (ratio 0.5, score weights) on N=1M, F=128: scatter-reduce only"
-            k = keep_nodes.numel()
-            # NDPSelect numbers supernodes in node order (ndp_select.py:128-144); TopK numbers them by score
-            ci = torch.arange(k, device=dev) if args.workload == "c4_ndp" else torch.randperm(k, device=dev, generator=g)
-            so = SelectOutput(node_index=keep_nodes, num_nodes=n, cluster_index=ci, num_supernodes=k, weight=wts)
-            extra = {"num_supernodes": k}
-
-            def step():
-                so._drop_caches()
-                so._set_one_to_one_index()  # what TopkSelect / NDPSelect attach: one node per supernode, no sort
-                red(x, so, batch=batch)
-            so._set_one_to_one_index()
-            nnz = k
-        # roofline of the gather-sum kernel alone (index cached), SURVEY 8(d) A1 byte count
-        idx = so.assign_index()
-        if idx.one_to_one:  # row + node_index + perm (+ weight) per assignment; no row_ptr table to read
-            alg = nnz * (4.0 * f + 8 + 4 + (4 if so.weight is not None else 0)) + k * 4.0 * f
-        else:
-            alg = nnz * (4.0 * f + 8 + 8 + 4) + k * 4.0 * f
-        kern_ms = event_time_ms(lambda: kernels.reduce_sparse(x, so.node_index, so.weight, idx), 20, dev)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(f"reduce_sparse_vec4_kernel:{args.workload}")
-        roof = {"kernel": "tgp::reduce_sparse_vec4_kernel (gather-sum, index cached)", "bound": "hbm",
-                "achieved": round(alg / (kern_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": round(alg / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": traffic,
-                "bytes_per_launch": alg, "avg_launch_ms": round(kern_ms, 4)}
-    dt = timed(step, args.steps, args.warmup, lambda: torch.cuda.synchronize(dev), lambda: None)
-    cfg = {"workload": name, "nodes_counted": "input nodes per step"}
-    cfg.update(extra)
-    print(json.dumps({
-        "metric": "pooled nodes/sec (Reduce+Connect) on batched graphs", "value": round(nodes * args.steps / dt, 1),
-        "unit": "nodes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg, "roofline": roof}))
+# ------------------------------------------------------------------------------------------------ main
+ALL = ["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect"]
+SECONDARY_DEFAULT = ["c5", "topk1m", "topk_connect", "c4_graclus", "c3"]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m"])
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="c2", choices=ALL)
+    ap.add_argument("--secondary", default=None,
+                    help="comma-separated secondary workloads ('none' to skip); default: all five on the c2 line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true",
                     help="dense workloads: call the Reduce and Connect operators one after the other")
@@ -241,111 +539,85 @@ def main():
                     help="c4_graclus: leave the synthetic edge list in random order (forces the sort-based coalesce)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))  # no GPU call has been made in this process
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # TGP_BENCH_FORCE_DIST=1: run the RCCL path with a one-rank group (a 1-GPU box can then exercise it)
     distributed = world > 1 or os.environ.get("TGP_BENCH_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
+    dist = None
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: RCCL world size {dist.get_world_size()} != --gpus {args.gpus}")
+    ctx = Ctx(dev, rank, world, dist)
 
-    from tgp import _native, kernels
-    from tgp.connect import DenseConnect
-    from tgp.distributed import PackedGather
-    from tgp.reduce import BaseReduce
-    from tgp.select import SelectOutput
-    from tgp.src import DenseSRCPooling
-    _native.lib()
+    from tgp import _native
+    _native.lib()  # fails loudly when the HIP library is missing
 
-    if args.workload not in ("c2", "c5"):
-        if distributed:
-            raise SystemExit("secondary workloads are single-GPU (C4 does not shard: replicas only)")
-        run_other_workload(args, dev)
-        return
-    if args.workload == "c2":
-        B, N, K, F = 32, 1024, 128, 64
-        name = "DiffPool dense S^T X / S^T A S, batch=32 graphs N=1024 K=128 F=64 (BASELINE configs[1])"
+    wl = make_workload(args.workload, ctx, args)
+    if world > 1 and not wl.shards:
+        raise SystemExit(f"workload {args.workload} is single-GPU (one giant graph does not shard: replicas only)")
+    for _ in range(args.warmup):
+        wl.step()
+    dt = timed_window(ctx, wl.step, args.steps, wl.drain)  # THE contract window: exactly --steps steps
+    win = median_windows(ctx, wl.step, wl.drain, steps=max(WINDOW_STEPS if args.workload != "c5" else 50, 1))
+    roofs = wl.rooflines(dev)
+    roofs = roofs if isinstance(roofs, list) else [roofs]
+    value = wl.nodes * world * args.steps / dt
+
+    if args.secondary is None:
+        sec = SECONDARY_DEFAULT if args.workload == "c2" else []
     else:
-        B, N, K, F = 2, 8192, 512, 128
-        name = "DiffPool N=8192 K=512 F=128, 2 graphs per GPU (BASELINE configs[4] shape)"
-    S, A, X = dense_inputs(B, N, K, F, seed=rank, dev=dev)
-    so = SelectOutput(s=S)
-    reducer, connector = BaseReduce(), DenseConnect()  # DiffPool defaults (diffpool.py:98-115)
-    # what the dense poolers' forward runs after Select: Reduce + Connect as one native call (SURVEY 8(d) C2:
-    # "time fused A3+A7+A8"); --unfused times the two operators called one after the other instead
-    fused_pool = DenseSRCPooling(reducer=reducer, connector=connector, adj_transpose=True)
-
-    # pooled outputs of every step are all-gathered; four steps share one collective (fewer, larger RCCL calls)
-    gather = PackedGather(bucket_steps=4) if distributed else None
-
-    def step():
-        with torch.no_grad():
-            if args.unfused:
-                x_pool, _ = reducer(X, so)
-                adj_pool, _ = connector(A, so)
-            else:
-                x_pool, _, adj_pool = fused_pool.reduce_connect(X, A, so)
-            if distributed:
-                # asynchronous on RCCL's stream: overlaps the next steps' kernels (at most one collective in flight)
-                gather.start([x_pool, adj_pool])
-                gather.take_ready()  # a consumer would use these; the bench only has to not accumulate them
-        return x_pool, adj_pool
-
-    def sync():
-        if distributed:
-            gather.flush()  # every step's gather, including a partly filled last bucket, belongs to the timed region
-        torch.cuda.synchronize(dev)
-
-    def barrier():
-        if distributed:
-            dist.barrier()
-
-    dt = timed(step, args.steps, args.warmup, sync, barrier)
-    if distributed:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
-    nodes_per_step = world * B * N
-    value = nodes_per_step * args.steps / dt
-
-    # ---- roofline of the dominant kernel: U = A S on the fp32 matrix cores --------------------
-    flops = 2.0 * B * N * N * K
-    gemm_ms = event_time_ms(lambda: kernels.bmm(A, S), max(args.steps, 10), dev)
-    achieved = flops / (gemm_ms * 1e-3) / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(f"gemm_f32_mfma_kernel<false>:{args.workload}")
-    roofline = {"kernel": "tgp::gemm_f32_mfma_kernel<false> (U = A S)", "bound": "mfma",
-                "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "flops_per_launch": flops, "avg_launch_ms": round(gemm_ms, 4)}
+        sec = [s for s in args.secondary.split(",") if s and s != "none"]
+    if world > 1:
+        sec = [s for s in sec if s in ("c5", "c3")]  # the graph-sharded ones
+    headline_cfg = dict(workload=wl.name, **(wl.extra or {}), parallelism=f"graph-sharded x{world}")
+    dims = (wl.B, wl.N, wl.K, wl.F) if isinstance(wl, DenseDiffPool) else None
+    del wl
+    torch.cuda.empty_cache()
+    secondary = []
+    for s in sec:
+        try:
+            secondary.append(run_secondary(s, ctx, args))
+        except Exception as exc:  # a failing secondary must not lose the headline; it is reported, not hidden
+            secondary.append({"workload": s, "error": f"{type(exc).__name__}: {exc}"})
+            torch.cuda.empty_cache()
 
     if rank == 0:
         line = {
-            "metric": "pooled nodes/sec (Reduce+Connect) on batched graphs",
-            "value": round(value, 1), "unit": "nodes/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC, "value": round(value, 1), "unit": "nodes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": name, "graphs_per_gpu": B, "nodes_per_graph": N, "clusters": K,
-                       "features": F, "nodes_counted": "input nodes (B*N per GPU per step)",
-                       "step": ("BaseReduce (S^T X) then DenseConnect (S^T A S + diag/degree post-processing)"
-                                if args.unfused else
-                                "fused Reduce+Connect (S^T X, S^T A S, diag/degree post-processing) as the dense "
-                                "poolers' forward calls it: DenseSRCPooling.reduce_connect")
-                               + (" + RCCL all-gather of every step's pooled outputs (4 steps per collective)" if distributed else ""),
-                       "parallelism": f"graph-sharded x{world}"},
-            "roofline": roofline,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": headline_cfg,
+            "windows": win, "roofline": roofs[0],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_dense(B, N, K, F)
-        print(json.dumps(line))
-    if distributed:
+        if len(roofs) > 1:
+            line["roofline_other"] = roofs[1:]
+        if dims is not None:
+            fl = roofs[0]["whole_step_flops"]
+            ms = win["ms_per_step_median"]
+            line["whole_step"] = {"flops": fl, "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                                  "frac_of_fp32_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+        if world == 1 and not args.no_cpu_baseline and dims is not None:
+            line["cpu_baseline"] = cpu_baseline_dense(*dims)
+        if secondary:
+            line["secondary"] = secondary
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -69,14 +69,15 @@ class PackedGather:
     yet handed out.  A result is the list
     of gathered tensors of one step; with ``bucket_steps == 1`` ``wait()`` returns that list directly."""
 
-    def __init__(self, group=None, bucket_steps: int = 1):
+    def __init__(self, group=None, bucket_steps: int = 1, force_collective: bool = False):
         if bucket_steps < 1:
             raise ValueError("bucket_steps must be >= 1")
         self.group = group
         self.world = _world(group)
-        # a one-rank process group still goes through the collective when asked to (single-GPU test of the RCCL path)
+        # a one-rank process group still goes through the collective when asked to (single-GPU test of the RCCL
+        # path: ``force_collective=True``, which bench.py passes under TGP_BENCH_FORCE_DIST=1, or TGP_FORCE_COLLECTIVE)
         self._collective = self.world > 1 or (dist.is_available() and dist.is_initialized()
-                                              and bool(os.environ.get("TGP_FORCE_COLLECTIVE")))
+                                              and (force_collective or bool(os.environ.get("TGP_FORCE_COLLECTIVE"))))
         self.bucket = bucket_steps
         self._send = [None, None]   # double-buffered [bucket, B, total]
         self._cur = 0
