@@ -301,6 +301,32 @@ int tgp_block_diag_fill(const float* adj_pool, int64_t B, int64_t K, const int64
                         float* out_weight, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * A9  KronConnect.forward (connect/kron_conn.py:117-165), block-batched: the batch Laplacian is block diagonal, so
+ *     every graph's Kron reduction  L' = L[+,+] - L[+,-] L[-,-]^-1 L[-,+]  is independent.  One workgroup per graph
+ *     forms the graph's dense Laplacian in fp64 (LDS up to 128 nodes, a workspace slab up to
+ *     tgp_kron_batched_max_graph_nodes()), eliminates the dropped nodes, then A = -L', |A| > threshold, zero diagonal,
+ *     fp32 cast; edges come out in row-major order of the pooled batch (what the reference's CSR -> COO gives).
+ *     Entries: CSR over ALL nodes of the batch (`indptr` [N+1], `col` [nnz], values fp32 or fp64 or NULL = ones,
+ *     optional `perm` = CSR slot -> entry).  from_adjacency = 0: the entries ARE the Laplacian (SelectOutput.L);
+ *     from_adjacency = 1: they are edge weights and L = D - A is formed in the kernel (get_laplacian,
+ *     kron_conn.py:88-92; self loops skipped, duplicates summed).  `graph_ptr` [B+1]: node offsets of the graphs
+ *     (sorted batch vector); `node_index`: kept nodes, ascending (pooled id = position).  An exactly singular
+ *     L[-,-] block is redone with the reference's 1e-6 I damping (kron_conn.py:131-135), per graph.
+ *     *d_count = -1: declined (node_index not ascending, a graph beyond the size limit, or an entry that couples two
+ *     graphs) - the caller keeps its generic route.
+ * ---------------------------------------------------------------------------------- */
+size_t tgp_kron_batched_workspace_bytes(int64_t num_nodes, int64_t num_graphs, int64_t max_graph_nodes);
+int tgp_kron_batched_max_graph_nodes(void);
+int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col, const float* val_f32 /* NULL ok */,
+                           const double* val_f64 /* NULL ok */, const int32_t* perm /* NULL ok */, int from_adjacency,
+                           int64_t num_nodes, int64_t nnz, const int64_t* graph_ptr, int64_t num_graphs,
+                           int64_t max_graph_nodes, const int64_t* node_index, int64_t num_kept, double threshold,
+                           void* ws, size_t ws_bytes, int64_t* d_count, void* stream);
+int tgp_kron_batched_fill(const void* ws, int64_t num_nodes, int64_t num_graphs, int64_t max_graph_nodes,
+                          const int64_t* graph_ptr, int64_t num_out, int64_t* out_row, int64_t* out_col,
+                          float* out_weight, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * test hooks for the shared primitives (device-wide stable LSD radix sort, block scan)
  * ---------------------------------------------------------------------------------- */
 size_t tgp_debug_sort_workspace_bytes(int64_t n);

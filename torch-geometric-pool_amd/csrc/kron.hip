@@ -1,0 +1,418 @@
+// A9: KronConnect (connect/kron_conn.py:117-165) as a block-batched Schur complement.
+//
+// The reference builds ONE sparse Laplacian for the whole batch and calls scipy's sparse LU on L[-,-].  L is block
+// diagonal (one block per graph), so the Kron reduction of every graph is independent:
+//     L'_g = L_g[+,+] - L_g[+,-] L_g[-,-]^-1 L_g[-,+]
+// One workgroup per graph holds the graph's dense n x n Laplacian in fp64, ordered (dropped nodes, kept nodes), and
+// eliminates the dropped nodes by Gaussian elimination without pivoting (L[-,-] is a principal block of a Laplacian:
+// a symmetric, weakly diagonally dominant M-matrix, for which elimination in any order is stable); what is left in the
+// trailing k x k block IS the Schur complement.  Graphs up to KRON_LDS_MAX_N nodes keep the matrix in LDS; larger ones
+// (up to KRON_MAX_N) use a slab of the workspace (same code, L2-resident); beyond that the call declines
+// (*d_count = -1) and the host keeps its library / scipy route for that batch.
+//
+// Update rule M[i][j] -= (M[i][p] * M[p][j]) * (1 / M[p][p]): the product commutes, so a symmetric L gives a bitwise
+// symmetric result and the reference's "symmetrise if nearly symmetric" step (kron_conn.py:137-139) is the identity.
+// Exactly singular L[-,-] (a component made of dropped nodes only): the block is redone with the reference's
+// Marquardt-Levenberg damping 1e-6 I (kron_conn.py:131-135).
+#include "primitives.h"
+
+namespace tgp {
+
+constexpr int KRON_LDS_MAX_N = 128;  // 128 x 129 doubles = 132 KB of the 160 KB LDS
+constexpr int KRON_MAX_N = 1024;
+constexpr int KRON_THREADS = 256;
+constexpr int KRON_BIG_THREADS = 1024;
+
+enum KronStatus { KRON_UNSORTED = 1, KRON_BAD_INDEX = 2, KRON_TOO_LARGE = 4, KRON_CROSS_GRAPH = 8 };
+
+__global__ __launch_bounds__(256) void kron_flags_kernel(const int64_t* __restrict__ node_index, int64_t k, int64_t n,
+                                                         uint32_t* __restrict__ flags, int* __restrict__ status) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (j >= k) return;
+  const int64_t v = node_index[j];
+  if (v < 0 || v >= n) {
+    atomicOr(status, KRON_BAD_INDEX);
+    return;
+  }
+  flags[v] = 1u;
+  // pooled id of a kept node = its position in node_index = its rank among the kept nodes only when ascending
+  if (j > 0 && node_index[j - 1] >= v) atomicOr(status, KRON_UNSORTED);
+}
+
+__device__ __forceinline__ int64_t wave_incl_scan64(int64_t v) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const int64_t t = __shfl_up(v, d, WAVE);
+    if (lane_id() >= d) v += t;
+  }
+  return v;
+}
+
+// per graph: offset of its k x k result in the dense buffer, offset of its n x (n|1) scratch matrix (graphs that do
+// not fit LDS), and the size checks.  One 1024-thread workgroup.
+__global__ __launch_bounds__(1024) void kron_plan_kernel(const int64_t* __restrict__ graph_ptr, int B,
+                                                         const uint32_t* __restrict__ rank,
+                                                         int64_t* __restrict__ sq_off, int64_t* __restrict__ big_off,
+                                                         int64_t cap_dense, int64_t cap_big, int* __restrict__ status) {
+  __shared__ int64_t s_w[2][16];
+  __shared__ int64_t s_carry[2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid < 2) s_carry[tid] = 0;
+  __syncthreads();
+  for (int base = 0; base < B; base += 1024) {
+    const int g = base + tid;
+    int64_t sq = 0, big = 0;
+    if (g < B) {
+      const int64_t p0 = graph_ptr[g], p1 = graph_ptr[g + 1];
+      const int64_t n = p1 - p0;
+      const int64_t k = static_cast<int64_t>(rank[p1]) - static_cast<int64_t>(rank[p0]);
+      if (n < 0 || n > KRON_MAX_N) atomicOr(status, KRON_TOO_LARGE);
+      sq = k * k;
+      if (n > KRON_LDS_MAX_N && k > 0) big = n * (n | 1);
+    }
+    const int64_t isq = wave_incl_scan64(sq), ibig = wave_incl_scan64(big);
+    if (lane == WAVE - 1) { s_w[0][w] = isq; s_w[1][w] = ibig; }
+    __syncthreads();
+    int64_t osq = s_carry[0], obig = s_carry[1], tsq = 0, tbig = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < w) { osq += s_w[0][j]; obig += s_w[1][j]; }
+      tsq += s_w[0][j];
+      tbig += s_w[1][j];
+    }
+    if (g < B) {
+      sq_off[g] = osq + isq - sq;
+      big_off[g] = obig + ibig - big;
+    }
+    __syncthreads();
+    if (tid == 0) { s_carry[0] += tsq; s_carry[1] += tbig; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    sq_off[B] = s_carry[0];
+    big_off[B] = s_carry[1];
+    if (s_carry[0] > cap_dense || s_carry[1] > cap_big) atomicOr(status, KRON_TOO_LARGE);
+  }
+}
+
+struct KronArgs {
+  const int32_t* indptr;   // [N+1] CSR row offsets of the entry list
+  const int64_t* col;      // [nnz]
+  const float* val32;      // one of val32 / val64, or neither (= ones)
+  const double* val64;
+  const int32_t* perm;     // optional indirection: CSR slot -> entry
+  int from_adj;            // entries are adjacency weights: L = D - A is formed here (self loops skipped)
+  const int64_t* graph_ptr;
+  const uint32_t* rank;    // [N+1] exclusive prefix sums of the keep flags
+  const int64_t* sq_off;
+  const int64_t* big_off;
+  float* dense;
+  double* big;
+  uint32_t* counts;
+  int* status;
+  double threshold;
+  int lds_cap;             // graphs up to this many nodes use LDS
+};
+
+template <int THREADS>
+__device__ __forceinline__ void kron_build(const KronArgs& a, double* M, int ld, int64_t p0, int n, int m, uint32_t r0,
+                                           double damp) {
+  for (int e = threadIdx.x; e < n * ld; e += THREADS) M[e] = 0.0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < n; t += THREADS) {
+    const int64_t v = p0 + t;
+    const uint32_t rv = a.rank[v] - r0;
+    const bool keep_v = a.rank[v + 1] - a.rank[v] != 0;
+    const int lr = keep_v ? m + static_cast<int>(rv) : t - static_cast<int>(rv);
+    if (damp != 0.0 && !keep_v) atomicAdd(&M[lr * ld + lr], damp);
+    for (int e = a.indptr[v]; e < a.indptr[v + 1]; ++e) {
+      const int idx = a.perm ? a.perm[e] : e;
+      const int64_t c = a.col[idx];
+      if (c < p0 || c >= p0 + n) {  // an entry that couples two graphs: L is not block diagonal
+        atomicOr(a.status, KRON_CROSS_GRAPH);
+        continue;
+      }
+      const double val = a.val64 ? a.val64[idx] : (a.val32 ? static_cast<double>(a.val32[idx]) : 1.0);
+      const uint32_t rc = a.rank[c] - r0;
+      const bool keep_c = a.rank[c + 1] - a.rank[c] != 0;
+      const int lc = keep_c ? m + static_cast<int>(rc) : static_cast<int>(c - p0) - static_cast<int>(rc);
+      if (a.from_adj) {
+        if (c != v) {
+          atomicAdd(&M[lr * ld + lc], -val);
+          atomicAdd(&M[lr * ld + lr], val);
+        }
+      } else {
+        atomicAdd(&M[lr * ld + lc], val);
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// eliminate pivots 0..m-1; returns (uniformly) whether an exactly zero pivot was met
+template <int THREADS>
+__device__ __forceinline__ bool kron_eliminate(double* M, int ld, int n, int m, int* s_flag) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int NW = THREADS / 64;
+  for (int p = 0; p < m; ++p) {
+    const double piv = M[p * ld + p];
+    if (piv == 0.0 || !(piv == piv)) {
+      if (threadIdx.x == 0) *s_flag = 1;
+      // a zero pivot with a zero column below it contributes nothing; anything else is the singular case
+    }
+    const double inv = piv != 0.0 ? 1.0 / piv : 0.0;
+    for (int i = p + 1 + w; i < n; i += NW) {
+      const double cip = M[i * ld + p];
+      if (cip != 0.0) {
+        for (int j = p + 1 + lane; j < n; j += 64) M[i * ld + j] -= (cip * M[p * ld + j]) * inv;
+      }
+    }
+    __syncthreads();
+  }
+  const bool bad = *s_flag != 0;
+  __syncthreads();
+  return bad;
+}
+
+template <int THREADS>
+__device__ __forceinline__ void kron_graph(const KronArgs& a, double* M, int g, int64_t p0, int n, int k, uint32_t r0,
+                                           int* s_flag, uint32_t* s_cnt) {
+  const int m = n - k, ld = n | 1;
+  if (threadIdx.x == 0) { *s_flag = 0; *s_cnt = 0; }
+  kron_build<THREADS>(a, M, ld, p0, n, m, r0, 0.0);
+  if (kron_eliminate<THREADS>(M, ld, n, m, s_flag)) {
+    if (threadIdx.x == 0) *s_flag = 0;
+    kron_build<THREADS>(a, M, ld, p0, n, m, r0, 1e-6);  // Marquardt-Levenberg damping (kron_conn.py:131-135)
+    (void)kron_eliminate<THREADS>(M, ld, n, m, s_flag);
+  }
+  // A = -L', |A| > threshold, zero diagonal, explicit zeros dropped (kron_conn.py:141-146); 0.f marks "no edge"
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int NW = THREADS / 64;
+  float* out = a.dense + a.sq_off[g];
+  uint32_t mine = 0;
+  for (int i = w; i < k; i += NW) {
+    for (int j0 = 0; j0 < k; j0 += 64) {
+      const int j = j0 + lane;
+      bool keep = false;
+      float f = 0.f;
+      if (j < k) {
+        const double v = -M[(m + i) * ld + m + j];
+        keep = i != j && v != 0.0 && (a.threshold > 0.0 ? fabs(v) > a.threshold : v == v);
+        f = keep ? static_cast<float>(v) : 0.f;
+        keep = keep && f != 0.f;
+        out[static_cast<int64_t>(i) * k + j] = f;
+      }
+      mine += __popcll(__ballot(keep));
+    }
+  }
+  if (lane == 0 && mine) atomicAdd(s_cnt, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) a.counts[g] = *s_cnt;
+}
+
+// LDS-resident graphs: one 256-thread workgroup per graph
+__global__ __launch_bounds__(KRON_THREADS) void kron_schur_lds_kernel(KronArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double s_M[];
+  __shared__ int s_flag;
+  __shared__ uint32_t s_cnt;
+  const int g = blockIdx.x;
+  const int64_t p0 = a.graph_ptr[g], p1 = a.graph_ptr[g + 1];
+  const int64_t n64 = p1 - p0;
+  if (n64 <= 0 || n64 > a.lds_cap) {
+    if (n64 <= 0 && threadIdx.x == 0) a.counts[g] = 0;
+    return;  // empty, or handled by the big-graph kernel
+  }
+  const uint32_t r0 = a.rank[p0];
+  const int k = static_cast<int>(a.rank[p1] - r0);
+  if (k == 0) {
+    if (threadIdx.x == 0) a.counts[g] = 0;
+    return;
+  }
+  kron_graph<KRON_THREADS>(a, s_M, g, p0, static_cast<int>(n64), k, r0, &s_flag, &s_cnt);
+}
+
+// graphs beyond the LDS capacity: the same elimination on a slab of the workspace, one 1024-thread workgroup each
+__global__ __launch_bounds__(KRON_BIG_THREADS) void kron_schur_big_kernel(KronArgs a) {
+  __shared__ int s_flag;
+  __shared__ uint32_t s_cnt;
+  const int g = blockIdx.x;
+  const int64_t p0 = a.graph_ptr[g], p1 = a.graph_ptr[g + 1];
+  const int64_t n64 = p1 - p0;
+  if (n64 <= a.lds_cap || n64 > KRON_MAX_N) return;
+  const uint32_t r0 = a.rank[p0];
+  const int k = static_cast<int>(a.rank[p1] - r0);
+  if (k == 0) {
+    if (threadIdx.x == 0) a.counts[g] = 0;
+    return;
+  }
+  kron_graph<KRON_BIG_THREADS>(a, a.big + a.big_off[g], g, p0, static_cast<int>(n64), k, r0, &s_flag, &s_cnt);
+}
+
+__global__ void kron_finish_count_kernel(const int* __restrict__ status, int64_t* __restrict__ d_count) {
+  if (*status != 0) *d_count = -1;  // declined: see KronStatus
+}
+
+// edge list of the surviving entries in (graph, row, col) order = row-major order of the whole pooled batch
+__global__ __launch_bounds__(KRON_THREADS) void kron_fill_kernel(const int64_t* __restrict__ graph_ptr,
+                                                                 const uint32_t* __restrict__ rank,
+                                                                 const int64_t* __restrict__ sq_off,
+                                                                 const float* __restrict__ dense,
+                                                                 const uint32_t* __restrict__ out_off,
+                                                                 int64_t* __restrict__ out_row,
+                                                                 int64_t* __restrict__ out_col,
+                                                                 float* __restrict__ out_w) {
+  __shared__ uint32_t s_row[KRON_MAX_N + 1];
+  const int g = blockIdx.x;
+  const int64_t p0 = graph_ptr[g], p1 = graph_ptr[g + 1];
+  if (p1 <= p0) return;
+  const uint32_t r0 = rank[p0];
+  const int k = static_cast<int>(rank[p1] - r0);
+  if (k == 0) return;
+  const float* d = dense + sq_off[g];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = w; i < k; i += KRON_THREADS / 64) {
+    uint32_t c = 0;
+    for (int j0 = 0; j0 < k; j0 += 64) {
+      const int j = j0 + lane;
+      c += __popcll(__ballot(j < k && d[static_cast<int64_t>(i) * k + j] != 0.f));
+    }
+    if (lane == 0) s_row[i] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // k <= 1024 row counts: a serial scan is a few hundred cycles
+    uint32_t run = out_off[g];
+    for (int i = 0; i < k; ++i) {
+      const uint32_t c = s_row[i];
+      s_row[i] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  for (int i = w; i < k; i += KRON_THREADS / 64) {
+    uint32_t pos = s_row[i];
+    for (int j0 = 0; j0 < k; j0 += 64) {
+      const int j = j0 + lane;
+      const float v = j < k ? d[static_cast<int64_t>(i) * k + j] : 0.f;
+      const unsigned long long mk = __ballot(v != 0.f);
+      if (v != 0.f) {
+        const uint32_t q = pos + __popcll(mk & lanemask_lt());
+        out_row[q] = static_cast<int64_t>(r0) + i;
+        out_col[q] = static_cast<int64_t>(r0) + j;
+        out_w[q] = v;
+      }
+      pos += __popcll(mk);
+    }
+  }
+}
+
+struct KronWs {
+  uint32_t* flags;   // [N+2] keep flags
+  uint32_t* rank;    // [N+2] exclusive prefix sums
+  int64_t* scan_total;
+  int* status;
+  int64_t* sq_off;   // [B+1]
+  int64_t* big_off;  // [B+1]
+  uint32_t* counts;  // [B]
+  uint32_t* out_off; // [B]
+  float* dense;
+  double* big;
+  int64_t cap_dense, cap_big;
+};
+
+static void kron_caps(int64_t N, int64_t max_nodes, int64_t* cap_dense, int64_t* cap_big) {
+  // sum_g k_g^2 <= sum_g n_g * max_nodes = N * max_nodes; scratch matrices only for graphs beyond the LDS capacity
+  *cap_dense = N * (max_nodes > 0 ? max_nodes : 1);
+  *cap_big = max_nodes > KRON_LDS_MAX_N ? N * ((max_nodes | 1) + 1) : 0;
+}
+
+static KronWs carve_kron(void* ws, int64_t N, int64_t B, int64_t max_nodes) {
+  Carver c(ws);
+  KronWs s;
+  kron_caps(N, max_nodes, &s.cap_dense, &s.cap_big);
+  s.flags = c.take<uint32_t>(N + 2);
+  s.rank = c.take<uint32_t>(N + 2);
+  s.scan_total = c.take<int64_t>(1);
+  s.status = c.take<int>(1);
+  s.sq_off = c.take<int64_t>(B + 1);
+  s.big_off = c.take<int64_t>(B + 1);
+  s.counts = c.take<uint32_t>(B + 1);
+  s.out_off = c.take<uint32_t>(B + 1);
+  s.dense = c.take<float>(s.cap_dense);
+  s.big = c.take<double>(s.cap_big);
+  return s;
+}
+
+}  // namespace tgp
+
+using namespace tgp;
+
+extern "C" size_t tgp_kron_batched_workspace_bytes(int64_t N, int64_t B, int64_t max_graph_nodes) {
+  if (N < 0 || B < 0 || max_graph_nodes < 0) return 0;
+  int64_t cd, cb;
+  kron_caps(N, max_graph_nodes, &cd, &cb);
+  return align_up((N + 2) * sizeof(uint32_t)) * 2 + align_up(sizeof(int64_t)) + align_up(sizeof(int)) +
+         align_up((B + 1) * sizeof(int64_t)) * 2 + align_up((B + 1) * sizeof(uint32_t)) * 2 +
+         align_up(static_cast<size_t>(cd) * sizeof(float)) + align_up(static_cast<size_t>(cb) * sizeof(double)) + 256;
+}
+
+extern "C" int tgp_kron_batched_max_graph_nodes(void) { return KRON_MAX_N; }
+
+extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col, const float* val32,
+                                      const double* val64, const int32_t* perm, int from_adjacency, int64_t N,
+                                      int64_t nnz, const int64_t* graph_ptr, int64_t B, int64_t max_graph_nodes,
+                                      const int64_t* node_index, int64_t num_kept, double threshold, void* ws,
+                                      size_t ws_bytes, int64_t* d_count, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(N >= 0 && B >= 0 && nnz >= 0 && num_kept >= 0 && d_count && graph_ptr && indptr && (col || nnz == 0) &&
+                  (node_index || num_kept == 0),
+              TGP_ERR_INVALID, "tgp_kron_batched_count: bad argument");
+  TGP_REQUIRE(!(val32 && val64), TGP_ERR_INVALID, "tgp_kron_batched_count: give fp32 or fp64 values, not both");
+  TGP_REQUIRE(N < (1ll << 31) - 2 && nnz < (1ll << 31) && B < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_kron_batched_count: N / nnz / B >= 2^31");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_kron_batched_workspace_bytes(N, B, max_graph_nodes), TGP_ERR_WORKSPACE,
+              "tgp_kron_batched_count: workspace too small");
+  KronWs s = carve_kron(ws, N, B, max_graph_nodes);
+  (void)hipMemsetAsync(s.flags, 0, (N + 2) * sizeof(uint32_t), stream);
+  (void)hipMemsetAsync(s.status, 0, sizeof(int), stream);
+  (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
+  if (B == 0 || N == 0) return check_launch("tgp_kron_batched_count");
+  if (num_kept > 0)
+    hipLaunchKernelGGL(kron_flags_kernel, dim3(cdiv(num_kept, 256)), dim3(256), 0, stream, node_index, num_kept, N,
+                       s.flags, s.status);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.flags, static_cast<int>(N + 1), s.rank,
+                     s.scan_total);
+  hipLaunchKernelGGL(kron_plan_kernel, dim3(1), dim3(1024), 0, stream, graph_ptr, static_cast<int>(B), s.rank, s.sq_off,
+                     s.big_off, s.cap_dense, s.cap_big, s.status);
+  KronArgs a{};
+  a.indptr = indptr; a.col = col; a.val32 = val32; a.val64 = val64; a.perm = perm; a.from_adj = from_adjacency;
+  a.graph_ptr = graph_ptr; a.rank = s.rank; a.sq_off = s.sq_off; a.big_off = s.big_off; a.dense = s.dense;
+  a.big = s.big; a.counts = s.counts; a.status = s.status; a.threshold = threshold;
+  const int cap = static_cast<int>(max_graph_nodes < KRON_LDS_MAX_N ? max_graph_nodes : KRON_LDS_MAX_N);
+  a.lds_cap = cap;
+  const size_t lds = static_cast<size_t>(cap) * (cap | 1) * sizeof(double) + 16;
+  (void)hipMemsetAsync(s.counts, 0, (B + 1) * sizeof(uint32_t), stream);
+  // the kernel also has a few static LDS words: ask for what this launch needs, not for the whole 160 KB
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kron_schur_lds_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  hipLaunchKernelGGL(kron_schur_lds_kernel, dim3(static_cast<unsigned>(B)), dim3(KRON_THREADS), lds, stream, a);
+  if (max_graph_nodes > KRON_LDS_MAX_N)
+    hipLaunchKernelGGL(kron_schur_big_kernel, dim3(static_cast<unsigned>(B)), dim3(KRON_BIG_THREADS), 0, stream, a);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, static_cast<int>(B), s.out_off,
+                     d_count);
+  hipLaunchKernelGGL(kron_finish_count_kernel, dim3(1), dim3(1), 0, stream, s.status, d_count);
+  return check_launch("tgp_kron_batched_count");
+}
+
+extern "C" int tgp_kron_batched_fill(const void* ws, int64_t N, int64_t B, int64_t max_graph_nodes,
+                                     const int64_t* graph_ptr, int64_t num_out, int64_t* out_row, int64_t* out_col,
+                                     float* out_weight, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(ws && N >= 0 && B >= 0 && num_out >= 0 && graph_ptr, TGP_ERR_INVALID,
+              "tgp_kron_batched_fill: bad argument");
+  if (num_out == 0 || B == 0) return TGP_OK;
+  TGP_REQUIRE(out_row && out_col && out_weight, TGP_ERR_INVALID, "tgp_kron_batched_fill: null output");
+  KronWs s = carve_kron(const_cast<void*>(ws), N, B, max_graph_nodes);
+  hipLaunchKernelGGL(kron_fill_kernel, dim3(static_cast<unsigned>(B)), dim3(KRON_THREADS), 0, stream, graph_ptr, s.rank,
+                     s.sq_off, s.dense, s.out_off, out_row, out_col, out_weight);
+  return check_launch("tgp_kron_batched_fill");
+}

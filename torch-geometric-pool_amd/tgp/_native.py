@@ -98,6 +98,11 @@ SIGNATURES = {
     "tgp_block_diag_count": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_block_diag_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_i64, _c_p, _c_p, _c_p,
                                      _c_p]),
+    "tgp_kron_batched_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "tgp_kron_batched_max_graph_nodes": (_c_int, []),
+    "tgp_kron_batched_count": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p,
+                                        _c_i64, ctypes.c_double, _c_p, _c_sz, _c_p, _c_p]),
+    "tgp_kron_batched_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p]),
     "tgp_debug_sort_workspace_bytes": (_c_sz, [_c_i64]),
     "tgp_debug_sort_pairs_u64": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_sz, _c_p]),
 }

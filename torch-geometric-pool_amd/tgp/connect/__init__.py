@@ -17,6 +17,7 @@ from ..utils.ops import (
     connectivity_to_edge_index,
     connectivity_to_sparsetensor,
     connectivity_to_torch_coo,
+    batch_info,
     graph_ptr,
     max_graph_size,
     num_graphs_of,
@@ -271,21 +272,77 @@ class KronConnect(Connect):
     r"""Kron reduction L' = L[+,+] - L[+,-] L[-,-]^{-1} L[-,+] of the graph Laplacian, used by NDP
     (reference connect/kron_conn.py:26-168).
 
-    The reference solves on the host with scipy's sparse LU.  Here, when the graph lives on the GPU and has at
-    most ``dense_solve_max_nodes`` nodes, the same Schur complement is taken densely in fp64 on the device
-    (``torch.linalg.solve`` -> rocSOLVER LU, then one GEMM): the fill-in that makes the sparse factorisation
-    superlinear is irrelevant at this size and nothing crosses PCIe but the selector's Laplacian.  Larger graphs
-    (or host tensors) take the reference's scipy route unchanged.  Both give the same edge set; weights agree to
-    solver round-off before the fp32 cast."""
+    The reference builds one sparse Laplacian for the whole batch and calls scipy's sparse LU on the host.  The batch
+    Laplacian is block diagonal, so on the GPU every graph's Schur complement is taken independently by
+    ``tgp_kron_batched_{count,fill}``: one workgroup per graph, dense fp64 elimination of the dropped nodes in LDS
+    (graphs up to 128 nodes) or in a workspace slab (up to 1024 nodes), threshold / zero-diagonal / fp32 cast fused,
+    edges emitted in the row-major order the reference's CSR -> COO conversion gives.  Nothing but the selector's
+    Laplacian (uploaded once per SelectOutput) crosses PCIe.  Batches with a graph beyond that size, or without a
+    usable graph partition, take the dense fp64 library solve on the device (``torch.linalg.solve`` -> rocSOLVER) up to
+    ``dense_solve_max_nodes`` nodes in total, else the reference's scipy route unchanged.  All routes give the same
+    edge set; weights agree to solver round-off before the fp32 cast."""
 
     def __init__(self, sparse_threshold: float = 1e-2, dense_solve_max_nodes: int = 8192):
         super().__init__()
         self.sparse_threshold = sparse_threshold
         self.dense_solve_max_nodes = dense_solve_max_nodes
 
+    # ---------------------------------------------------------------- native block-batched route
+    @staticmethod
+    def _laplacian_csr_on_device(so: SelectOutput, device):
+        """(indptr int32, col int64, val fp64) of ``so.L`` on the device; uploaded once per SelectOutput."""
+        import numpy as np
+        import scipy.sparse as sp
+        hit = getattr(so, "_kron_csr", None)
+        if hit is not None and hit[0] is so.L and hit[1] == device:
+            return hit[2]
+        dev_csr = getattr(so, "_L_device_csr", None)  # NDPSelect's device-built Laplacian, when it has one
+        if dev_csr is not None and dev_csr[0].device == device:
+            return dev_csr
+        L = sp.csr_matrix(so.L)
+        L.sum_duplicates()
+        csr = (torch.from_numpy(L.indptr.astype(np.int32)).to(device),
+               torch.from_numpy(L.indices.astype(np.int64)).to(device),
+               torch.from_numpy(L.data.astype(np.float64)).to(device))
+        so._kron_csr = (so.L, device, csr)
+        return csr
+
+    def _kron_native(self, edge_index: Tensor, edge_weight: Optional[Tensor], so: SelectOutput, idx_pos: Tensor,
+                     has_laplacian: bool, batch: Optional[Tensor]):
+        n = so.num_nodes
+        dev = edge_index.device
+        if n == 0 or idx_pos.device != dev:
+            return None
+        if batch is None:
+            batch = getattr(so, "_node_batch", None)  # NDPSelect remembers the batch vector it partitioned by
+        if batch is not None and batch.numel() == n and batch.device == dev:
+            info = batch_info(batch)
+            if not info.is_sorted:
+                return None
+            ptr, max_nodes = info.ptr, info.max_nodes
+        else:
+            ptr, max_nodes = torch.tensor([0, n], dtype=torch.long, device=dev), n
+        if max_nodes > K.kron_max_graph_nodes():
+            return None
+        if has_laplacian:
+            indptr, col, val = self._laplacian_csr_on_device(so, dev)
+            if indptr.numel() != n + 1:
+                return None
+            return K.kron_batched(indptr, col, val, None, False, n, ptr, max_nodes, idx_pos, self.sparse_threshold)
+        row = edge_index[0]
+        if row.numel() > 1 and K._rows_sorted(edge_index, row):
+            indptr, perm = torch.empty(n + 1, dtype=torch.int32, device=dev), None
+            K.rowptr_from_sorted(row, n, indptr)
+        else:
+            index = K.build_assign_index(row, n)
+            indptr, perm = index.row_ptr, index.perm
+        return K.kron_batched(indptr, edge_index[1], edge_weight, perm, True, n, ptr, max_nodes, idx_pos,
+                              self.sparse_threshold)
+
+    # ---------------------------------------------------------------- library route (one dense solve)
     def _kron_on_device(self, L: Tensor, idx_pos: Tensor) -> Tuple[Tensor, Tensor]:
-        """Dense fp64 Kron reduction on the GPU; returns the pooled (edge_index, fp32 weights), row-major sorted
-        like the scipy route's CSR -> COO conversion."""
+        """Dense fp64 Kron reduction of the WHOLE batch Laplacian on the GPU; returns the pooled (edge_index, fp32
+        weights), row-major sorted like the scipy route's CSR -> COO conversion."""
         n = L.size(0)
         if idx_pos.numel() <= 1:
             l_new = -torch.ones((1, 1), dtype=torch.float64, device=L.device)
@@ -322,26 +379,35 @@ class KronConnect(Connect):
         edge_index, edge_weight = connectivity_to_edge_index(edge_index, edge_weight)
         device = edge_index.device
         n = so.num_nodes
-        if hasattr(so, "L"):
-            L = sp.csr_matrix(so.L)
-            idx_pos = so.node_index.cpu().numpy()
+        has_laplacian = hasattr(so, "L")
+        if has_laplacian:
+            idx_pos_t = so.node_index
         else:
             warnings.warn("Laplacian not provided. The SelectOutput is not computed with NDPSelect.")
+            if len(so.node_index) == so.num_supernodes:
+                idx_pos_t = so.node_index
+            elif getattr(so, "mis", None) is not None:
+                idx_pos_t = so.mis
+                if bool((idx_pos_t >= n).any()):
+                    raise ValueError(f"MIS indices out of range: max idx={int(idx_pos_t.max())}, but graph has only "
+                                     f"{n} nodes.")
+            else:
+                raise ValueError("Inconsistent number of clusters and node indices.")
+        if device.type == "cuda":
+            w = None if edge_weight is None else edge_weight.detach().reshape(-1)
+            out = self._kron_native(edge_index, w, so, idx_pos_t, has_laplacian, kwargs.get("batch"))
+            if out is not None:
+                return _restore_format(template, out[0], out[1], so.num_supernodes)
+        idx_pos = idx_pos_t.cpu().numpy()
+        if has_laplacian:
+            L = sp.csr_matrix(so.L)
+        else:
             ei = edge_index.cpu().numpy()
             w = np.ones(ei.shape[1], dtype=np.float32) if edge_weight is None else \
                 edge_weight.detach().reshape(-1).cpu().numpy()
             off = ei[0] != ei[1]
             A = sp.coo_matrix((w[off], (ei[0][off], ei[1][off])), shape=(n, n)).tocsr()
             L = (sp.diags(np.asarray(A.sum(1)).reshape(-1).astype(w.dtype)) - A).tocsr()
-            if len(so.node_index) == so.num_supernodes:
-                idx_pos = so.node_index.cpu().numpy()
-            elif getattr(so, "mis", None) is not None:
-                idx_pos = so.mis.cpu().numpy()
-                if (idx_pos >= n).any():
-                    raise ValueError(f"MIS indices out of range: max idx={idx_pos.max()}, but graph has only "
-                                     f"{n} nodes.")
-            else:
-                raise ValueError("Inconsistent number of clusters and node indices.")
         if device.type == "cuda" and 0 < L.shape[0] <= self.dense_solve_max_nodes:
             l_dev = torch.from_numpy(L.toarray().astype(np.float64)).to(device)
             ei_out, ew_out = self._kron_on_device(l_dev, torch.as_tensor(idx_pos, dtype=torch.long, device=device))

@@ -525,6 +525,15 @@ def segment_gemm_nn(a: Tensor, bm: Tensor, ptr: Tensor, max_nodes: int) -> Tenso
     return out
 
 
+def rowptr_from_sorted(row: Tensor, num_rows: int, out: Tensor) -> Tensor:
+    """CSR offsets (int32 [num_rows+1]) of an ascending int64 row vector."""
+    dev = N.require_device(row, out)
+    row = N.i64c(row)
+    N.check(N.lib().tgp_rowptr_from_sorted_i64(N.ptr(row), row.numel(), num_rows, N.ptr(out), N.stream_ptr(dev)),
+            "tgp_rowptr_from_sorted_i64")
+    return out
+
+
 def spmm_sorted(edge_index: Tensor, edge_weight: Optional[Tensor], num_rows: int, s: Tensor) -> Tensor:
     """T = A S for a row-sorted (coalesced) edge list (connect/dense_conn.py:165,204)."""
     dev = N.require_device(edge_index, edge_weight, s)
@@ -540,6 +549,49 @@ def spmm_sorted(edge_index: Tensor, edge_weight: Optional[Tensor], num_rows: int
     N.check(L.tgp_spmm_csr_f32(N.ptr(row_ptr), N.ptr(col), N.ptr(w), num_rows, row.numel(), N.ptr(s), s.size(1),
                                N.ptr(out), st), "tgp_spmm_csr_f32")
     return out
+
+
+# ------------------------------------------------------------------------- A9
+def kron_max_graph_nodes() -> int:
+    return int(N.lib().tgp_kron_batched_max_graph_nodes())
+
+
+def kron_batched(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optional[Tensor], from_adjacency: bool,
+                 num_nodes: int, graph_ptr: Tensor, max_graph_nodes: int, node_index: Tensor,
+                 threshold: float) -> Optional[Tuple[Tensor, Tensor]]:
+    """Block-batched Kron reduction (connect/kron_conn.py:117-165): one workgroup per graph, fp64 elimination of the
+    dropped nodes, thresholded fp32 edge list in row-major order.  ``indptr`` int32 [N+1] / ``col`` int64 / ``val``
+    fp32 or fp64 (None = ones) / ``perm`` int32 (None = identity) describe the Laplacian entries, or the edge weights
+    when ``from_adjacency``.  Returns None when the library declines (see include/tgp_hip.h)."""
+    dev = N.require_device(indptr, col, val, perm, graph_ptr, node_index)
+    if indptr.dtype != torch.int32 or (perm is not None and perm.dtype != torch.int32):
+        raise ValueError("kron_batched: indptr / perm must be int32")
+    col, graph_ptr, node_index = N.i64c(col), N.i64c(graph_ptr), N.i64c(node_index)
+    v32 = v64 = None
+    if val is not None:
+        if val.dtype == torch.float64:
+            v64 = val.contiguous()
+        else:
+            v32 = N.f32c(val.reshape(-1))
+    B = graph_ptr.numel() - 1
+    L = N.lib()
+    ws = N.workspace(L.tgp_kron_batched_workspace_bytes(num_nodes, B, max_graph_nodes), dev)
+    d_count = torch.empty(1, dtype=torch.int64, device=dev)
+    st = N.stream_ptr(dev)
+    N.check(L.tgp_kron_batched_count(N.ptr(indptr.contiguous()), N.ptr(col), N.ptr(v32), N.ptr(v64),
+                                     N.ptr(None if perm is None else perm.contiguous()), 1 if from_adjacency else 0,
+                                     num_nodes, col.numel(), N.ptr(graph_ptr), B, max_graph_nodes, N.ptr(node_index),
+                                     node_index.numel(), float(threshold), N.ptr(ws), ws.numel(), N.ptr(d_count), st),
+            "tgp_kron_batched_count")
+    n_out = _read_count(d_count)
+    if n_out < 0:
+        return None
+    ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
+    ew = torch.empty(n_out, dtype=torch.float32, device=dev)
+    N.check(L.tgp_kron_batched_fill(N.ptr(ws), num_nodes, B, max_graph_nodes, N.ptr(graph_ptr), n_out,
+                                    N.ptr(ei[0]) if n_out else None, N.ptr(ei[1]) if n_out else None,
+                                    N.ptr(ew) if n_out else None, st), "tgp_kron_batched_fill")
+    return ei, ew
 
 
 # ------------------------------------------------------------------------- A10

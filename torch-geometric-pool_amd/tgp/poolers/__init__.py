@@ -116,7 +116,8 @@ class NDPPooling(BasePrecoarseningMixin, SRCPooling):
             return self.lift(x_pool=x, so=so)
         so = self.select(edge_index=adj, edge_weight=edge_weight, batch=batch, num_nodes=x.size(0))
         x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch)
-        ei, ew = self.connect(edge_index=adj, so=so, edge_weight=edge_weight)
+        # batch: the Kron reduction is taken per graph (block-batched kernel); the reference's connector ignores it
+        ei, ew = self.connect(edge_index=adj, so=so, edge_weight=edge_weight, batch=batch)
         return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so)
 
     def extra_repr_args(self) -> dict:

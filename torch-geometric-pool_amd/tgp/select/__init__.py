@@ -674,6 +674,7 @@ class NDPSelect(Select):
                                     torch.ones(k, device=dev), size=(num_nodes, k)).coalesce()
         so = SelectOutput(s=s, s_inv_op=self.s_inv_op, L=L.astype(np.float32))
         so._set_one_to_one_index()
+        so._node_batch = batch  # the partition KronConnect's block-batched kernel works on
         return so
 
     def __repr__(self) -> str:
