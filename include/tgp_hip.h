@@ -19,6 +19,9 @@
  *     surviving edges in `*d_count` (device int64); the caller reads it (the one host
  *     sync the reference's own `.item()` calls also pay), allocates exact outputs and
  *     calls *_fill with the SAME workspace.
+ *   - `eps` arguments: the reference reads its module-level `eps` (tgp/__init__.py:6, 1e-8) at CALL time
+ *     (utils/ops.py:72,318,377,395; utils/losses.py:498; tests monkeypatch it), so it is an argument of every
+ *     entry point that filters or clamps with it, never a compiled-in constant.
  *   - return value 0 = ok; otherwise a negative tgp_status and tgp_last_error() holds a
  *     thread-local message.  No exceptions cross the boundary; no global mutable state.
  */
@@ -32,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10001 /* 1.0.1: tracks the reference version it mirrors */
+#define TGP_ABI_VERSION 10002 /* 1.0.1 of the reference, ABI revision 2 (eps arguments, Kron entries) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -92,11 +95,13 @@ int tgp_reduce_batch_i64(const int64_t* batch, const int64_t* node_index, const 
 size_t tgp_connect_subgraph_workspace_bytes(int64_t num_edges, int64_t num_nodes);
 int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
                                int64_t num_edges, const int64_t* node_index /* NULL ok */, int64_t num_kept,
-                               int64_t num_nodes, int flags, void* ws, size_t ws_bytes,
+                               int64_t num_nodes, int flags, float eps, void* ws, size_t ws_bytes,
                                int64_t* d_count, void* stream);
 int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col, const float* edge_weight,
-                              int64_t num_edges, int64_t num_nodes, int flags, const void* ws,
+                              int64_t num_edges, int64_t num_nodes, int flags, float eps, const void* ws,
                               int64_t num_out, int64_t* out_row, int64_t* out_col, float* out_weight,
+                              int64_t* out_edge_id /* NULL ok: input position of every kept edge (the map the
+                                                      backward of the weight pass-through needs) */,
                               void* stream);
 
 /* ------------------------------------------------------------------------------------
@@ -108,7 +113,7 @@ int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col, const floa
 size_t tgp_connect_coalesce_workspace_bytes(int64_t num_edges, int64_t num_nodes, int64_t num_supernodes);
 int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
                                int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,
-                               int64_t num_supernodes, int reduce_op, int flags, void* ws, size_t ws_bytes,
+                               int64_t num_supernodes, int reduce_op, int flags, float eps, void* ws, size_t ws_bytes,
                                int64_t* d_count, void* stream);
 int tgp_connect_coalesce_fill(const void* ws, int64_t num_edges, int64_t num_nodes, int64_t num_supernodes, int has_weight,
                               int flags, int64_t num_out, int64_t* out_row, int64_t* out_col,
@@ -124,7 +129,7 @@ size_t tgp_connect_coalesce_rows_workspace_bytes(int64_t num_edges, int64_t num_
 int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
                                     int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,
                                     int64_t num_supernodes, const int32_t* assign_row_ptr,
-                                    const int32_t* assign_perm, int reduce_op, int flags, void* ws,
+                                    const int32_t* assign_perm, int reduce_op, int flags, float eps, void* ws,
                                     size_t ws_bytes, int64_t* d_count, void* stream);
 int tgp_connect_coalesce_rows_fill(const void* ws, int64_t num_edges, int64_t num_nodes, int64_t num_supernodes,
                                    int has_weight, int64_t num_out, int64_t* out_row, int64_t* out_col,
@@ -138,15 +143,15 @@ int tgp_connect_coalesce_rows_fill(const void* ws, int64_t num_edges, int64_t nu
 size_t tgp_connect_coalesce_grouped_workspace_bytes(int64_t num_edges, int64_t num_nodes, int64_t num_supernodes);
 int tgp_connect_coalesce_grouped_count(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
                                        int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,
-                                       int64_t num_supernodes, int reduce_op, int flags, void* ws, size_t ws_bytes,
-                                       int64_t* d_count, void* stream);
+                                       int64_t num_supernodes, int reduce_op, int flags, float eps, void* ws,
+                                       size_t ws_bytes, int64_t* d_count, void* stream);
 
 /* A6 (rest)  degree / per-graph max normalisation of a pooled edge list, in place
  * (utils/ops.py:383-417).  edge_weight must be initialised (ones when the list was
  * unweighted, ops.py:384-385).  ws: tgp_postprocess_sparse_workspace_bytes().           */
 size_t tgp_postprocess_sparse_workspace_bytes(int64_t num_edges, int64_t num_nodes, int64_t num_graphs);
 int tgp_postprocess_sparse_norm_f32(const int64_t* row, const int64_t* col, float* edge_weight,
-                                    int64_t num_edges, int64_t num_nodes, int flags,
+                                    int64_t num_edges, int64_t num_nodes, int flags, float eps,
                                     const int64_t* batch_pooled /* needed for EDGE_WEIGHT_NORM */,
                                     int64_t num_graphs, void* ws, size_t ws_bytes, void* stream);
 
@@ -165,7 +170,7 @@ int tgp_postprocess_sparse_norm_f32(const int64_t* row, const int64_t* col, floa
  * ---------------------------------------------------------------------------------- */
 size_t tgp_dense_pool_workspace_bytes(int64_t B, int64_t N, int64_t K, int64_t F);
 int tgp_dense_pool_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K,
-                       int64_t F, int flags, const int64_t* graph_sizes /* [B] or NULL */, float* x_pool,
+                       int64_t F, int flags, float eps, const int64_t* graph_sizes /* [B] or NULL */, float* x_pool,
                        float* adj_raw, float* adj_pool, void* ws, size_t ws_bytes, void* stream);
 
 /* Generic batched fp32 GEMM on the matrix cores, C[b] = op(A[b]) B[b] with B[b] [Kd,Nc] row-major.
@@ -262,7 +267,7 @@ int tgp_link_loss_f32(const float* S, const float* A, int64_t B, int64_t N, int6
                       const int64_t* graph_sizes /* [B] or NULL, as in tgp_dense_pool_f32 */, float* sq, void* ws,
                       size_t ws_bytes, void* stream);
 size_t tgp_entropy_sum_workspace_bytes(int64_t n);
-int tgp_entropy_sum_f32(const float* S, int64_t n, float* out, void* ws, size_t ws_bytes, void* stream);
+int tgp_entropy_sum_f32(const float* S, int64_t n, float eps, float* out, void* ws, size_t ws_bytes, void* stream);
 int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int64_t N, int64_t K,
                       const int64_t* graph_sizes /* [B] or NULL */, float* deg, float* q, float* den, void* stream);
 
@@ -274,7 +279,7 @@ int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, const float* w,
 
 /* A8 alone: post-process a [B,K,K] pooled adjacency (src may equal dst).                */
 size_t tgp_postprocess_dense_workspace_bytes(int64_t B, int64_t K);
-int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K, int flags, void* ws,
+int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K, int flags, float eps, void* ws,
                               size_t ws_bytes, void* stream);
 
 /* A11  DenseSRCPooling.preprocessing (src.py:374-452 -> PyG to_dense_adj / to_dense_batch): the step
@@ -295,9 +300,9 @@ int tgp_to_dense_batch_f32(const float* x, int64_t num_nodes, int64_t num_featur
  * renumbers supernodes (relabel[B*K] int64: new id or -1, NULL = keep all).             */
 size_t tgp_block_diag_workspace_bytes(int64_t B, int64_t K);
 int tgp_block_diag_count(const float* adj_pool, int64_t B, int64_t K, const int64_t* relabel /* NULL ok */,
-                         int flags, void* ws, size_t ws_bytes, int64_t* d_count, void* stream);
+                         int flags, float eps, void* ws, size_t ws_bytes, int64_t* d_count, void* stream);
 int tgp_block_diag_fill(const float* adj_pool, int64_t B, int64_t K, const int64_t* relabel, int flags,
-                        const void* ws, int64_t num_out, int64_t* out_row, int64_t* out_col,
+                        float eps, const void* ws, int64_t num_out, int64_t* out_row, int64_t* out_col,
                         float* out_weight, void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -39,7 +39,7 @@ def test_ctypes_table_matches_header():
     from tgp import _native
     assert sorted(_native.SIGNATURES) == declared_symbols()
     lib = _native.lib()
-    assert lib.tgp_version() == 10001
+    assert lib.tgp_version() == 10002
     assert lib.tgp_last_error() is not None
 
 
@@ -93,15 +93,18 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     lib = _native.lib()
     assert lib.tgp_reduce_sparse_f32(None, -1, 4, 4, None, None, None, None, 0, 1, None, None) == -1  # TGP_ERR_INVALID
     assert b"tgp_reduce_sparse_f32" in lib.tgp_last_error()
-    assert lib.tgp_connect_coalesce_count(None, None, None, 5, None, 4, 2, 99, 0, None, 0, None, None) == -1
-    assert lib.tgp_connect_coalesce_count(None, None, None, 1 << 31, None, 4, 2, 0, 0, None, 0, None, None) == -1
+    assert lib.tgp_connect_coalesce_count(None, None, None, 5, None, 4, 2, 99, 0, 1e-8, None, 0, None, None) == -1
+    assert lib.tgp_connect_coalesce_count(None, None, None, 1 << 31, None, 4, 2, 0, 0, 1e-8, None, 0, None, None) == -1
     dummy = ctypes.c_int64(0)
     p = ctypes.addressof(dummy)
     # valid pointers but a workspace that is too small -> TGP_ERR_WORKSPACE, message names the call
-    assert lib.tgp_connect_subgraph_count(p, p, None, 10, None, 0, 10, 0, p, 8, p, None) == -2
+    assert lib.tgp_connect_subgraph_count(p, p, None, 10, None, 0, 10, 0, 1e-8, p, 8, p, None) == -2
     assert b"workspace too small" in lib.tgp_last_error()
-    assert lib.tgp_dense_pool_f32(p, p, p, 1, 1 << 31, 4, 4, 0, None, p, None, p, p, 1 << 20, None) == -4  # TGP_ERR_RANGE
-    assert lib.tgp_block_diag_count(p, 70000, 70000, None, 0, p, 1 << 20, p, None) == -4
+    assert lib.tgp_dense_pool_f32(p, p, p, 1, 1 << 31, 4, 4, 0, 1e-8, None, p, None, p, p, 1 << 20, None) == -4  # TGP_ERR_RANGE
+    assert lib.tgp_block_diag_count(p, 70000, 70000, None, 0, 1e-8, p, 1 << 20, p, None) == -4
+    # Kron: fp32 and fp64 values at once is a caller error; sizes beyond the int32 internals are refused
+    assert lib.tgp_kron_batched_count(p, p, p, p, None, 0, 4, 4, p, 1, 4, p, 2, 1e-2, p, 1 << 20, p, None) == -1
+    assert lib.tgp_kron_batched_count(p, p, None, None, None, 0, 1 << 31, 4, p, 1, 4, p, 2, 1e-2, p, 1 << 20, p, None) == -4
 
 
 def test_ctypes_signatures_match_the_header_parameter_by_parameter():
@@ -122,6 +125,8 @@ def test_ctypes_signatures_match_the_header_parameter_by_parameter():
             return ctypes.c_size_t
         if p.startswith("double"):
             return ctypes.c_double
+        if p.startswith("float"):
+            return ctypes.c_float
         if p.startswith("int") or p.startswith("unsigned"):
             return ctypes.c_int
         raise AssertionError(f"unrecognised parameter '{p}'")

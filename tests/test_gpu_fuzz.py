@@ -452,6 +452,32 @@ def test_native_graclus_matching_contract(dev, seed):
     assert torch.equal(so.node_index.cpu(), idx)
 
 
+def test_native_graclus_matching_monotone_path_is_maximal(dev):
+    """a path with strictly increasing weights matches ONE pair per handshake round (n/2 rounds); the
+    matching must still come out maximal -- here the unique greedy answer, a perfect matching -- not stop at a cap."""
+    from tgp import kernels as KK
+    from tgp.select import GraclusSelect, graclus_cluster
+    n = 3000
+    r, c = torch.arange(n - 1), torch.arange(1, n)
+    w = torch.arange(1, n, dtype=torch.float32)
+    ei = torch.cat([torch.stack([r, c]), torch.stack([c, r])], 1)
+    ww = torch.cat([w, w])
+    label = KK.graclus_match(ei.to(dev), ww.to(dev), n).cpu()
+    ref = torch.arange(n)
+    ref[1::2] = ref[0::2]  # pairs (0,1), (2,3), ...: the heaviest edge (n-2, n-1) first, then every second one
+    assert torch.equal(label, ref)
+    assert GraclusSelect()(ei.to(dev), ww.to(dev), num_nodes=n).num_supernodes == n // 2
+    with pytest.warns(RuntimeWarning, match="not maximal"):
+        capped = KK.graclus_match(ei.to(dev), ww.to(dev), n, max_rounds=10).cpu()
+    assert int((capped != torch.arange(n)).sum()) < n // 2
+    # the host-tensor stand-in has the same contract
+    m = 400
+    rm, cm = torch.arange(m - 1), torch.arange(1, m)
+    em = torch.cat([torch.stack([rm, cm]), torch.stack([cm, rm])], 1)
+    wm = torch.arange(1, m, dtype=torch.float32).repeat(2)
+    assert torch.equal(graclus_cluster(em[0], em[1], wm, m), ref[:m])
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_native_graclus_matching_directed_and_asymmetric_input(dev, seed):
     """Edge lists that are not the symmetric, symmetrically weighted lists Graclus is defined on: entries without a

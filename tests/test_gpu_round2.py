@@ -1,0 +1,210 @@
+"""Round-2 behaviour tests on the GPU: runtime eps (reference tests/connect/test_dense_conn.py:444-463), gradients
+through SparseConnect's edge weights (the reference's subgraph / coalesce / scatter path is differentiable), the 2-D
+orthogonality loss, the float64 notice."""
+import math
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------- runtime eps
+def test_dense_connect_unbatched_filters_small_edges_with_patched_eps(dev, monkeypatch):
+    """Mirror of reference tests/connect/test_dense_conn.py:444-463: ops.eps is read at call time."""
+    from tgp.connect import DenseConnect
+    from tgp.select import SelectOutput
+    from tgp.utils import ops as ops_module
+    ei = torch.tensor([[0, 1, 1], [1, 0, 2]], device=dev)
+    ew = torch.tensor([0.5, 0.5, 2.0], device=dev)
+    so = SelectOutput(s=torch.eye(3, device=dev))
+    conn = DenseConnect(sparse_output=True, remove_self_loops=False, degree_norm=False)
+    adj0, w0 = conn(edge_index=ei, edge_weight=ew, so=so)
+    assert w0.numel() == 3
+    monkeypatch.setattr(ops_module, "eps", 1.0)
+    adj, w = conn(edge_index=ei, edge_weight=ew, so=so)
+    assert adj.size(0) == 2 and w.numel() == 1 and bool(torch.all(w > 1.0))
+
+
+def test_eps_reaches_every_kernel_that_uses_it(dev, monkeypatch):
+    """|w| > eps filters of the sparse Connect (ops.py:377), the degree clamp of both post-processings (ops.py:318,
+    395) and the entropy term (losses.py:498) follow the patched module globals, against the oracle with the same eps."""
+    import tgp_oracle as O
+    from tgp.connect import SparseConnect
+    from tgp.select import SelectOutput
+    from tgp.utils import losses as losses_module
+    from tgp.utils import ops as ops_module
+    from tgp.utils.ops import postprocess_adj_pool_dense, postprocess_adj_pool_sparse
+    g = torch.Generator().manual_seed(0)
+    n, e = 60, 400
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ew = torch.rand(e, generator=g)
+    cl = torch.randint(0, 12, (n,), generator=g)
+    so = SelectOutput(cluster_index=cl.to(dev), num_supernodes=12)
+    monkeypatch.setattr(ops_module, "eps", 2.5)
+    monkeypatch.setattr(O, "EPS", 2.5)
+    out_ei, out_w = SparseConnect(degree_norm=True)(ei.to(dev), so, edge_weight=ew.to(dev))
+    ref_ei, ref_w = O.sparse_connect(ei, ew, torch.arange(n), cl, n, 12, degree_norm=True)
+    assert 0 < ref_ei.size(1) < 12 * 12 - 12  # the patched eps really dropped merged edges
+    assert torch.equal(out_ei.cpu(), ref_ei)
+    torch.testing.assert_close(out_w.cpu(), ref_w, rtol=1e-5, atol=1e-6)
+    # plain filter pass on an arbitrary list
+    f_ei, f_w = postprocess_adj_pool_sparse(ei.to(dev), (ew * 5).to(dev), n, remove_self_loops=True)
+    keep = (ei[0] != ei[1]) & ((ew * 5).abs() > 2.5)
+    assert torch.equal(f_ei.cpu(), ei[:, keep])
+    # dense degree clamp: rows with tiny degree are clamped at eps
+    for K in (8, 40, 100, 200):  # tiny / small / LDS / multi-kernel post-processing
+        a = torch.rand(3, K, K, generator=g) * 0.05
+        got = postprocess_adj_pool_dense(a.to(dev).clone(), True, True, True, False)
+        ref = O.postprocess_dense(a.clone(), True, True, True, False)
+        torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-6)
+    monkeypatch.setattr(losses_module, "eps", 0.5)
+    s = torch.softmax(torch.randn(4, 50, 6, generator=g), -1)
+    got = losses_module.entropy_loss(s.to(dev), num_nodes=200)
+    ref = (-(s * torch.log(s + 0.5)).sum(-1)).sum() / 200
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+# --------------------------------------------------------------------------- SparseConnect weight gradients
+def _dense_ref_coalesce(ei, w, cl, k, op, remove_self_loops, eps=1e-8):
+    """Differentiable torch restatement of cluster -> coalesce(reduce=op) -> filters, returning the pooled weights in
+    row-major order (what PyG's scatter-based coalesce + postprocess_adj_pool_sparse compute)."""
+    key = cl[ei[0]] * k + cl[ei[1]]
+    uniq, inv = torch.unique(key, return_inverse=True)
+    if op in ("sum", "mean"):
+        out = torch.zeros(uniq.numel(), dtype=w.dtype).index_add(0, inv, w)
+        if op == "mean":
+            out = out / torch.bincount(inv, minlength=uniq.numel()).to(w.dtype)
+    elif op == "mul":
+        out = torch.ones(uniq.numel(), dtype=w.dtype).scatter_reduce(0, inv, w, "prod", include_self=True)
+    else:
+        out = torch.zeros(uniq.numel(), dtype=w.dtype).scatter_reduce(0, inv, w, "amax" if op == "max" else "amin",
+                                                                     include_self=False)
+    r, c = uniq // k, uniq % k
+    keep = out.abs() > eps
+    if remove_self_loops:
+        keep = keep & (r != c)
+    return torch.stack([r[keep], c[keep]]), out[keep]
+
+
+@pytest.mark.parametrize("op", ["sum", "mean", "max", "min", "mul"])
+def test_sparse_connect_coalesce_edge_weight_gradient(dev, op):
+    from tgp.connect import SparseConnect
+    from tgp.select import SelectOutput
+    g = torch.Generator().manual_seed(5)
+    n, e, k = 40, 300, 9
+    ei = torch.randint(0, n, (2, e), generator=g)
+    w = (torch.rand(e, generator=g) + 0.5)
+    if op in ("max", "min"):  # ties share the gradient: make a few exact ties
+        w[10:20] = w[0]
+    cl = torch.randint(0, k, (n,), generator=g)
+    so = SelectOutput(cluster_index=cl.to(dev), num_supernodes=k)
+    wd = w.to(dev).requires_grad_(True)
+    out_ei, out_w = SparseConnect(reduce_op=op)(ei.to(dev), so, edge_weight=wd)
+    assert out_w.requires_grad
+    wr = w.clone().requires_grad_(True)
+    ref_ei, ref_w = _dense_ref_coalesce(ei, wr, cl, k, op, True)
+    assert torch.equal(out_ei.cpu(), ref_ei)
+    torch.testing.assert_close(out_w.detach().cpu(), ref_w.detach(), rtol=1e-5, atol=1e-6)
+    coef = torch.randn(ref_w.numel(), generator=g)
+    (out_w * coef.to(dev)).sum().backward()
+    (ref_w * coef).sum().backward()
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_sparse_connect_topk_edge_weight_gradient_and_normalisations(dev):
+    """Filter path (kept-node subgraph): kept edges pass their gradient through, dropped edges get zero; with
+    degree_norm / edge_weight_norm the differentiable normalisation sits on top (ops.py:383-417)."""
+    from tgp.connect import SparseConnect
+    from tgp.select import SelectOutput
+    g = torch.Generator().manual_seed(6)
+    n, e = 50, 400
+    ei = torch.randint(0, n, (2, e), generator=g)
+    w = torch.rand(e, generator=g) + 0.1
+    kept = torch.sort(torch.randperm(n, generator=g)[:25])[0]
+    so = SelectOutput(node_index=kept.to(dev), cluster_index=torch.arange(25, device=dev), num_nodes=n, num_supernodes=25)
+    member = torch.zeros(n, dtype=torch.bool)
+    member[kept] = True
+    keep = member[ei[0]] & member[ei[1]] & (ei[0] != ei[1])
+    relabel = torch.full((n,), -1, dtype=torch.long)
+    relabel[kept] = torch.arange(25)
+    for dn, ewn in ((False, False), (True, False), (True, True)):
+        wd = w.to(dev).requires_grad_(True)
+        bp = torch.zeros(25, dtype=torch.long, device=dev)
+        out_ei, out_w = SparseConnect(degree_norm=dn, edge_weight_norm=ewn)(ei.to(dev), so, edge_weight=wd,
+                                                                            batch_pooled=bp)
+        wr = w.clone().requires_grad_(True)
+        r, c, ww = relabel[ei[0][keep]], relabel[ei[1][keep]], wr[keep]
+        if dn:
+            deg = torch.zeros(25).index_add(0, r, ww)
+            dis = deg.clamp(min=1e-8).pow(-0.5)
+            ww = ww * dis[r] * dis[c]
+        if ewn:
+            ww = ww / ww.abs().max()
+        assert torch.equal(out_ei.cpu(), torch.stack([r, c]))
+        torch.testing.assert_close(out_w.detach().cpu(), ww.detach(), rtol=1e-5, atol=1e-6)
+        coef = torch.randn(ww.numel(), generator=g)
+        (out_w * coef.to(dev)).sum().backward()
+        (ww * coef).sum().backward()
+        torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=1e-4, atol=1e-6)
+        assert bool((wd.grad.cpu()[~keep] == 0).all())
+
+
+def test_hierarchy_dense_sparse_output_into_topk_trains_edge_weights(dev):
+    """a dense pooler with sparse_output=True feeding a TopK level -- the second level's pooled weights
+    must carry a gradient back to the first level's parameters."""
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(7)
+    n = 30
+    a = torch.triu(torch.rand(n, n, generator=g) < 0.2, 1)
+    ei = (a | a.t()).nonzero().t().to(dev)
+    x = torch.randn(n, 8, generator=g).to(dev)
+    p1 = get_pooler("mincut", in_channels=8, k=10, sparse_output=True).to(dev)
+    p2 = get_pooler("topk", in_channels=8, ratio=0.5).to(dev)
+    o1 = p1(x=x, adj=ei, batch=torch.zeros(n, dtype=torch.long, device=dev))
+    assert o1.edge_weight.requires_grad
+    o2 = p2(x=o1.x, adj=o1.edge_index, edge_weight=o1.edge_weight, batch=o1.batch)
+    assert o2.edge_weight.requires_grad
+    o2.edge_weight.sum().backward()
+    grads = [p.grad for p in p1.parameters() if p.grad is not None]
+    assert grads and any(float(gr.abs().sum()) > 0 for gr in grads)
+
+
+# ------------------------------------------------------------------------------------------- small fixes
+def test_orthogonality_loss_accepts_a_single_2d_assignment(dev):
+    """reference utils/losses.py:59-70 uses transpose(-2,-1) and norm(dim=(-2,-1)): S [N,K] is valid input."""
+    from tgp.utils.losses import orthogonality_loss
+    g = torch.Generator().manual_seed(1)
+    s = torch.softmax(torch.randn(37, 5, generator=g), -1)
+    sts = s.t() @ s
+    ref = torch.norm(sts / torch.norm(sts) - torch.eye(5) / math.sqrt(5))
+    got = orthogonality_loss(s.to(dev))
+    assert got.dim() == 0
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-6)
+    sd = s.to(dev).requires_grad_(True)
+    orthogonality_loss(sd).backward()
+    sr = s.clone().requires_grad_(True)
+    t = sr.t() @ sr
+    torch.norm(t / torch.norm(t) - torch.eye(5) / math.sqrt(5)).backward()
+    torch.testing.assert_close(sd.grad.cpu(), sr.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_float64_inputs_are_announced_as_fp32_arithmetic(dev):
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    from tgp.utils import ops as ops_module
+    ops_module._WARNED_F64 = False
+    so = SelectOutput(cluster_index=torch.tensor([0, 0, 1, 1], device=dev))
+    x = torch.randn(4, 3, dtype=torch.float64, device=dev)
+    with pytest.warns(UserWarning, match="float64 inputs are computed in float32"):
+        out, _ = BaseReduce()(x, so)
+    assert out.dtype == torch.float64
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # once per process
+        BaseReduce()(x, so)

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
     const int64_t* __restrict__ col, const float* __restrict__ w, int64_t E, const int32_t* __restrict__ table,
     const int32_t* __restrict__ a_row_ptr, const uint32_t* __restrict__ seg_src, const uint32_t* __restrict__ seg_dst,
     const unsigned long long* __restrict__ grouped, const uint32_t* __restrict__ raw_off, int64_t K, int reduce_op,
-    int flags,
+    int flags, float eps,
     int* __restrict__ bad, uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w, uint32_t* __restrict__ n_out) {
   __shared__ uint32_t s_key[GS_CAP];
   __shared__ float s_val[GS_CAP];
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
         if (has_w && reduce_op == TGP_MEAN) acc = acc / static_cast<float>(ncnt);
         bool keep = head;
         if ((flags & TGP_REMOVE_SELF_LOOPS) && c == static_cast<uint32_t>(r0 + i)) keep = false;
-        if (has_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > TGP_EPS)) keep = false;
+        if (has_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > eps)) keep = false;
         const unsigned long long km = __ballot(keep) & half_mask;
         const uint32_t rank = __popcll(km & lanemask_lt());
         if (keep) {
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
         if (has_w && reduce_op == TGP_MEAN) acc = acc / static_cast<float>(ncnt);
         bool keep = head;
         if ((flags & TGP_REMOVE_SELF_LOOPS) && c == static_cast<uint32_t>(r0 + i)) keep = false;
-        if (has_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > TGP_EPS)) keep = false;
+        if (has_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > eps)) keep = false;
         const unsigned long long km = __ballot(keep);
         const uint32_t rank = __popcll(km & lanemask_lt());
         if (keep) {
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
 // row, bitonic sort of (column << 32 | position) in LDS, sorted + merged in place.
 __global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w,
                                                            const uint32_t* __restrict__ raw_off, int64_t K,
-                                                           int64_t E, int reduce_op, int flags,
+                                                           int64_t E, int reduce_op, int flags, float eps,
                                                            const int* __restrict__ bad,
                                                            uint32_t* __restrict__ n_out) {
   __shared__ unsigned long long s_key[CR_LONG];
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict_
           if (tmp_w && reduce_op == TGP_MEAN) acc = acc / static_cast<float>(cnt);
           bool k2 = true;
           if ((flags & TGP_REMOVE_SELF_LOOPS) && c == static_cast<uint32_t>(r)) k2 = false;
-          if (tmp_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > TGP_EPS)) k2 = false;
+          if (tmp_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > eps)) k2 = false;
           keep[it] = k2; col[it] = c; val[it] = acc;
         }
       }
@@ -615,7 +615,7 @@ extern "C" size_t tgp_connect_coalesce_rows_workspace_bytes(int64_t E, int64_t N
 extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
                                                const int64_t* cluster_index, int64_t N, int64_t K,
                                                const int32_t* assign_row_ptr, const int32_t* assign_perm,
-                                               int reduce_op, int flags, void* ws, size_t ws_bytes,
+                                               int reduce_op, int flags, float eps, void* ws, size_t ws_bytes,
                                                int64_t* d_count, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && d_count, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_count: bad argument");
@@ -645,9 +645,9 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
                      s.member_off, s.raw_off, s.bad, s.seg_src, s.seg_dst);
   hipLaunchKernelGGL(cr_gather_sort_kernel<false>, dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, col, w, E, s.table,
                      assign_row_ptr, s.seg_src, s.seg_dst, static_cast<const unsigned long long*>(nullptr), s.raw_off, K,
-                     reduce_op, flags, s.bad, s.tmp_c, tmp_w, s.n_out);
+                     reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out);
   hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
-                     reduce_op, flags, s.bad, s.n_out);
+                     reduce_op, flags, eps, s.bad, s.n_out);
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);
   return check_launch("tgp_connect_coalesce_rows_count");
 }
@@ -710,7 +710,7 @@ extern "C" size_t tgp_connect_coalesce_grouped_workspace_bytes(int64_t E, int64_
 // Counting half; the fill half is tgp_connect_coalesce_rows_fill with the same workspace.
 extern "C" int tgp_connect_coalesce_grouped_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
                                                   const int64_t* cluster_index, int64_t N, int64_t K, int reduce_op,
-                                                  int flags, void* ws, size_t ws_bytes, int64_t* d_count,
+                                                  int flags, float eps, void* ws, size_t ws_bytes, int64_t* d_count,
                                                   void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && d_count, TGP_ERR_INVALID, "tgp_connect_coalesce_grouped_count: bad argument");
@@ -745,9 +745,9 @@ extern "C" int tgp_connect_coalesce_grouped_count(const int64_t* row, const int6
                      static_cast<const int64_t*>(nullptr), static_cast<const float*>(nullptr), E,
                      static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr),
                      static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), vals, s.raw_off, K,
-                     reduce_op, flags, s.bad, s.tmp_c, tmp_w, s.n_out);
+                     reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out);
   hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
-                     reduce_op, flags, s.bad, s.n_out);
+                     reduce_op, flags, eps, s.bad, s.n_out);
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);
   return check_launch("tgp_connect_coalesce_grouped_count");
 }

@@ -7,7 +7,8 @@
 
 #include "../../include/tgp_hip.h"
 
-#define TGP_EPS 1e-8f  // reference: tgp/__init__.py:6
+// eps (reference tgp/__init__.py:6, 1e-8) is an ARGUMENT of every entry point that uses it: the reference reads the
+// module global at call time (utils/ops.py:72,318,377,395; utils/losses.py:498), so a caller may have changed it.
 #define WAVE 64
 
 namespace tgp {

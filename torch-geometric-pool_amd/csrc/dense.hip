@@ -87,7 +87,8 @@ extern "C" size_t tgp_dense_pool_workspace_bytes(int64_t B, int64_t N, int64_t K
 }
 
 extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N,
-                                  int64_t K, int64_t F, int flags, const int64_t* graph_sizes, float* x_pool,
+                                  int64_t K, int64_t F, int flags, float eps, const int64_t* graph_sizes,
+                                  float* x_pool,
                                   float* adj_raw, float* adj_pool, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0 && F >= 0, TGP_ERR_INVALID, "tgp_dense_pool_f32: negative size");
@@ -107,7 +108,7 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
   const bool small_ok = N <= SG_N && K <= SG_K && F <= SG_K && B >= 64;  // any N, K, F: padded batches are ragged
   if (!no_small && small_ok) {
     SmallArgs q{S, want_a ? A : nullptr, want_x ? X : nullptr, static_cast<int>(B), static_cast<int>(N),
-                static_cast<int>(K), static_cast<int>(F), flags, want_x ? x_pool : nullptr,
+                static_cast<int>(K), static_cast<int>(F), flags, eps, want_x ? x_pool : nullptr,
                 want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr};
     const int grid = static_cast<int>((B + 3) / 4);
     hipLaunchKernelGGL(dense_pool_small_kernel, dim3(grid), dim3(256), 4 * SG_WAVE_FLOATS * sizeof(float), stream, q);
@@ -124,7 +125,7 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
     const bool fits32 = static_cast<int64_t>(N) * (N > F ? N : F) * 4 < (1ll << 31) - 4096;
     if (lds <= static_cast<size_t>(kMediumMaxLds) && fits32) {
       MediumArgs q{S, want_a ? A : nullptr, want_x ? X : nullptr, static_cast<int>(B), static_cast<int>(N),
-                   static_cast<int>(K), static_cast<int>(F), flags, want_x ? x_pool : nullptr,
+                   static_cast<int>(K), static_cast<int>(F), flags, eps, want_x ? x_pool : nullptr,
                    want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr, static_cast<int>(npad), graph_sizes};
       if (K <= 32)
         hipLaunchKernelGGL(dense_pool_medium_kernel<1>, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, q);
@@ -175,7 +176,7 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
   if (want_a) {
     PostArgs q{};
     q.src = aslab; q.splits = p.splits; q.s_split = K * K; q.s_batch = static_cast<long>(p.splits) * K * K;
-    q.ld_src = K; q.K = static_cast<int>(K); q.flags = flags; q.raw = adj_raw; q.dst = adj_pool;
+    q.ld_src = K; q.K = static_cast<int>(K); q.flags = flags; q.eps = eps; q.raw = adj_raw; q.dst = adj_pool;
     const XCombineArgs xc{xslab, p.splits, K * F, static_cast<long>(p.splits) * K * F, K * F, x_pool, 0};
     if (launch_post(q, B, postws, stream, want_x ? &xc : nullptr)) x_done = true;
   }
@@ -194,7 +195,7 @@ extern "C" size_t tgp_postprocess_dense_workspace_bytes(int64_t B, int64_t K) {
   return align_up(post_ws_floats(B, K) * 4) + 256;
 }
 
-extern "C" int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K, int flags, void* ws,
+extern "C" int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K, int flags, float eps, void* ws,
                                          size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_postprocess_dense_f32: negative size");
@@ -205,7 +206,7 @@ extern "C" int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B
               "tgp_postprocess_dense_f32: workspace too small");
   PostArgs q{};
   q.src = src; q.splits = 1; q.s_split = 0; q.s_batch = K * K; q.ld_src = K;
-  q.K = static_cast<int>(K); q.flags = flags; q.raw = nullptr; q.dst = dst;
+  q.K = static_cast<int>(K); q.flags = flags; q.eps = eps; q.raw = nullptr; q.dst = dst;
   launch_post(q, B, static_cast<float*>(ws), stream);
   return check_launch("tgp_postprocess_dense_f32");
 }

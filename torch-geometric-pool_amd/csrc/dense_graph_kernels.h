@@ -25,6 +25,7 @@ constexpr int SG_WAVE_FLOATS = SG_N * SG_LDA;  // A only
 struct SmallArgs {
   const float* S; const float* A; const float* X;
   int B, N, K, F, flags;
+  float eps;
   float* x_pool; float* adj_raw; float* adj_pool;
 };
 
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
             for (int r = 0; r < 16; ++r) own |= (rho(r) + 4 * lk == lm);
             dcol = own ? mine : other;
           }
-          const float d = sqrtf(fmaxf(dcol, TGP_EPS));  // d[lm]
+          const float d = sqrtf(fmaxf(dcol, p.eps));  // d[lm]
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = rho(r) + 4 * lk;
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
 struct MediumArgs {
   const float* S; const float* A; const float* X;
   int B, N, K, F, flags;
+  float eps;
   float* x_pool; float* adj_raw; float* adj_pool;
   int npad;  // N rounded up to 32
   // optional [B]: graph b's real nodes are its first sizes[b] rows (to_dense_batch layout, src.py:448-450); the rest
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel
     if (tid < K) {
       float t = 0.f;
       for (int q = 0; q < K; ++q) t = __fadd_rn(t, rows ? Rs[q * (KP + 1) + tid] : Rs[tid * (KP + 1) + q]);
-      ds[tid] = sqrtf(fmaxf(t, TGP_EPS));
+      ds[tid] = sqrtf(fmaxf(t, p.eps));
     }
     __syncthreads();
     for (int e = tid; e < K * KP; e += 256) {

@@ -22,6 +22,7 @@ struct PostArgs {
   int splits;
   long s_split, s_batch, ld_src;
   int K, flags;
+  float eps;         // clamp of the degree vector: the caller's eps at call time (ops.py:318)
   float* raw;        // optional [B][K][K]
   float* dst;        // optional [B][K][K]
   float* dvec;       // [B][K]
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(1024) void post_degree_kernel(PostArgs p) {
       float t = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) t = __fadd_rn(t, s_part[q][lane]);
-      p.dvec[static_cast<long>(b) * K + j] = sqrtf(fmaxf(t, TGP_EPS));  // sqrt(clamp(d, eps)): ops.py:318
+      p.dvec[static_cast<long>(b) * K + j] = sqrtf(fmaxf(t, p.eps));  // sqrt(clamp(d, eps)): ops.py:318
     }
   } else {
     for (int r = w; r < 64; r += 16) {
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(1024) void post_degree_kernel(PostArgs p) {
       for (int j = lane; j < K; j += 64) s = __fadd_rn(s, a[static_cast<long>(i) * K + j]);
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) s = __fadd_rn(s, __shfl_down(s, d, WAVE));
-      if (lane == 0) p.dvec[static_cast<long>(b) * K + i] = sqrtf(fmaxf(s, TGP_EPS));
+      if (lane == 0) p.dvec[static_cast<long>(b) * K + i] = sqrtf(fmaxf(s, p.eps));
     }
   }
 }
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void post_small_kernel(PostArgs p, int B) {
           mine = __fadd_rn(mine, t);
         }
     }
-    d = sqrtf(fmaxf(mine, TGP_EPS));  // d[lane]
+    d = sqrtf(fmaxf(mine, p.eps));  // d[lane]
   }
   const bool by_cols = p.flags & TGP_SUM_AXIS_ROWS;
   float m = 0.f;
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void post_tiny_kernel(PostArgs p, int B) {
 #pragma unroll
     for (int j = 0; j < 32; ++j) sum = __fadd_rn(sum, t[j]);  // lanes < 32: column sums; >= 32: row sums
     const bool by_cols = p.flags & TGP_SUM_AXIS_ROWS;
-    const float d = sqrtf(fmaxf(__shfl(sum, by_cols ? idx : 32 + idx, WAVE), TGP_EPS));  // d[idx] on every lane
+    const float d = sqrtf(fmaxf(__shfl(sum, by_cols ? idx : 32 + idx, WAVE), p.eps));  // d[idx] on every lane
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       const float dj = __shfl(d, j, WAVE);
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(1024) void post_lds_kernel(PostArgs p, int B, XComb
           float t = 0.f;
 #pragma unroll
           for (int q = 0; q < 16; ++q) t = __fadd_rn(t, s_part[q * 64 + lane]);
-          dv[j] = sqrtf(fmaxf(t, TGP_EPS));
+          dv[j] = sqrtf(fmaxf(t, p.eps));
         }
         __syncthreads();
       }
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(1024) void post_lds_kernel(PostArgs p, int B, XComb
         for (int j = lane; j < K; j += 64) sacc = __fadd_rn(sacc, m[i * K + j]);
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) sacc = __fadd_rn(sacc, __shfl_down(sacc, d, WAVE));
-        if (lane == 0) dv[i] = sqrtf(fmaxf(sacc, TGP_EPS));
+        if (lane == 0) dv[i] = sqrtf(fmaxf(sacc, p.eps));
       }
       __syncthreads();
     }

@@ -21,9 +21,9 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-__device__ __forceinline__ float ent_term(float s) { return -s * logf(s + TGP_EPS); }
+__device__ __forceinline__ float ent_term(float s, float eps) { return -s * logf(s + eps); }
 
-__global__ __launch_bounds__(256) void entropy_partial_kernel(const float* __restrict__ S, int64_t n,
+__global__ __launch_bounds__(256) void entropy_partial_kernel(const float* __restrict__ S, int64_t n, float eps,
                                                               float* __restrict__ partial) {
   __shared__ float sh[4];
   float acc = 0.f;
@@ -31,10 +31,10 @@ __global__ __launch_bounds__(256) void entropy_partial_kernel(const float* __res
   const nt_f32x4* S4 = reinterpret_cast<const nt_f32x4*>(S);
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += 256ll * gridDim.x) {
     const nt_f32x4 v = __builtin_nontemporal_load(S4 + i);
-    acc += (ent_term(v.x) + ent_term(v.y)) + (ent_term(v.z) + ent_term(v.w));
+    acc += (ent_term(v.x, eps) + ent_term(v.y, eps)) + (ent_term(v.z, eps) + ent_term(v.w, eps));
   }
   for (int64_t i = n4 * 4 + static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += 256ll * gridDim.x)
-    acc += ent_term(S[i]);
+    acc += ent_term(S[i], eps);
   const float t = block_sum_256(acc, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
@@ -153,7 +153,7 @@ extern "C" size_t tgp_entropy_sum_workspace_bytes(int64_t n) {
   return RED_BLOCKS * sizeof(float);
 }
 
-extern "C" int tgp_entropy_sum_f32(const float* S, int64_t n, float* out, void* ws, size_t ws_bytes,
+extern "C" int tgp_entropy_sum_f32(const float* S, int64_t n, float eps, float* out, void* ws, size_t ws_bytes,
                                    void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(n >= 0, TGP_ERR_INVALID, "tgp_entropy_sum_f32: negative size");
@@ -169,7 +169,7 @@ extern "C" int tgp_entropy_sum_f32(const float* S, int64_t n, float* out, void* 
   if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
   if (blocks < 1) blocks = 1;
   float* partial = static_cast<float*>(ws);
-  hipLaunchKernelGGL(entropy_partial_kernel, dim3(blocks), dim3(256), 0, stream, S, n, partial);
+  hipLaunchKernelGGL(entropy_partial_kernel, dim3(blocks), dim3(256), 0, stream, S, n, eps, partial);
   hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, out);
   return check_launch("tgp_entropy_sum_f32");
 }

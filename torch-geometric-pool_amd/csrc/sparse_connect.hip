@@ -96,6 +96,7 @@ struct SubgraphPred {
   const uint32_t* rank128;      // set with relabel
   const int* unsorted;          // set with relabel: node_index is not ascending
   int flags;
+  float eps;                    // the caller's eps at call time (reference ops.py:377 reads the module global)
   // keep / drop only; r, c are the ORIGINAL endpoints (relabelling is injective, so r == c decides self loops)
   __device__ __forceinline__ bool operator()(int64_t e, int64_t& r, int64_t& c) const {
     r = row[e];
@@ -105,7 +106,7 @@ struct SubgraphPred {
       if (!(br & bc & 1u)) return false;
     }
     if ((flags & TGP_REMOVE_SELF_LOOPS) && r == c) return false;
-    if (w && (flags & TGP_EPS_FILTER) && !(fabsf(w[e]) > TGP_EPS)) return false;
+    if (w && (flags & TGP_EPS_FILTER) && !(fabsf(w[e]) > eps)) return false;
     return true;
   }
 };
@@ -183,7 +184,7 @@ __device__ __forceinline__ void sg_eval(const SubgraphPred& pred, const uint32_t
 #pragma unroll
   for (int j = 0; j < SG_PER; ++j) {
     if ((pred.flags & TGP_REMOVE_SELF_LOOPS) && t.r[j] == t.c[j]) t.keep[j] = false;
-    if (pred.w && (pred.flags & TGP_EPS_FILTER) && !(fabsf(t.w[j]) > TGP_EPS)) t.keep[j] = false;
+    if (pred.w && (pred.flags & TGP_EPS_FILTER) && !(fabsf(t.w[j]) > pred.eps)) t.keep[j] = false;
   }
 }
 
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_fill_kernel(SubgraphPred 
                                                                    const uint32_t* __restrict__ block_offsets,
                                                                    int64_t* __restrict__ out_row,
                                                                    int64_t* __restrict__ out_col,
-                                                                   float* __restrict__ out_w) {
+                                                                   float* __restrict__ out_w,
+                                                                   int64_t* __restrict__ out_eid) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   __shared__ uint32_t s_w[16];
   const uint32_t* s_rank = s_dyn + nwords;
@@ -282,6 +284,7 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_fill_kernel(SubgraphPred 
         out_row[pos] = pred.relabel ? new_id(t.r[j]) : t.r[j];
         out_col[pos] = pred.relabel ? new_id(t.c[j]) : t.c[j];
         if (out_w) out_w[pos] = t.w[j];
+        if (out_eid) out_eid[pos] = e0 + j;  // which input edge this is: the backward of the weight pass-through
         ++pos;
       }
     }
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(256) void coalesce_keys_kernel(const int64_t* __res
 __global__ __launch_bounds__(256) void coalesce_segment_kernel(const uint64_t* __restrict__ keys,
                                                                const float* __restrict__ vals, int64_t E,
                                                                uint64_t K, int has_weight, int reduce_op,
-                                                               int flags, float* __restrict__ seg,
+                                                               int flags, float eps, float* __restrict__ seg,
                                                                uint8_t* __restrict__ keepflag,
                                                                uint32_t* __restrict__ block_counts) {
   __shared__ uint32_t s_cnt[4];
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256) void coalesce_segment_kernel(const uint64_t* _
           }
           if (reduce_op == TGP_MEAN) acc = acc / static_cast<float>(n);
           seg[i] = acc;
-          if ((flags & TGP_EPS_FILTER) && !(fabsf(acc) > TGP_EPS)) keep = false;
+          if ((flags & TGP_EPS_FILTER) && !(fabsf(acc) > eps)) keep = false;
         }
       }
       keepflag[i] = keep ? 1 : 0;
@@ -519,12 +522,12 @@ __global__ __launch_bounds__(256) void degree_fallback_kernel(const int64_t* __r
 __global__ __launch_bounds__(256) void degree_scale_kernel(const int64_t* __restrict__ row,
                                                            const int64_t* __restrict__ col,
                                                            float* __restrict__ w, int64_t E,
-                                                           const float* __restrict__ deg) {
+                                                           const float* __restrict__ deg, float eps) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (e < E) {
     // deg.clamp(min=eps).pow(-0.5); w * dis[row] * dis[col]  (ops.py:395-401)
-    const float dr = 1.0f / sqrtf(fmaxf(deg[row[e]], TGP_EPS));
-    const float dc = 1.0f / sqrtf(fmaxf(deg[col[e]], TGP_EPS));
+    const float dr = 1.0f / sqrtf(fmaxf(deg[row[e]], eps));
+    const float dc = 1.0f / sqrtf(fmaxf(deg[col[e]], eps));
     w[e] = __fmul_rn(__fmul_rn(w[e], dr), dc);
   }
 }
@@ -623,6 +626,7 @@ struct BlockDiagPred {
   const int64_t* relabel;  // [B*K] new id or -1; nullptr = identity
   int64_t K;
   int flags;
+  float eps;
   __device__ __forceinline__ bool operator()(int64_t i, int64_t& r, int64_t& c, float& v) const {
     v = adj[i];
     const int64_t kk = K * K;
@@ -630,7 +634,7 @@ struct BlockDiagPred {
     const int64_t rr = rem / K;
     r = b * K + rr;
     c = b * K + (rem - rr * K);
-    if (!(fabsf(v) > TGP_EPS)) return false;
+    if (!(fabsf(v) > eps)) return false;
     if (relabel) {
       r = relabel[r];
       c = relabel[c];
@@ -756,8 +760,8 @@ static SubgraphWs carve_subgraph(void* ws, int64_t E, int64_t N) {
 }
 
 extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
-                                          const int64_t* node_index, int64_t k, int64_t N, int flags, void* ws,
-                                          size_t ws_bytes, int64_t* d_count, void* stream_) {
+                                          const int64_t* node_index, int64_t k, int64_t N, int flags, float eps,
+                                          void* ws, size_t ws_bytes, int64_t* d_count, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(E >= 0 && N >= 0 && k >= 0 && d_count && (E == 0 || (row && col)), TGP_ERR_INVALID,
               "tgp_connect_subgraph_count: bad argument");
@@ -782,7 +786,7 @@ extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col
                      s.member_bits, nw, (nw + 3) / 4, s.rank128, in_lds);
   }
   const int nb = cdiv(E > 0 ? E : 1, SG_CHUNK);
-  SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.rank128, s.unsorted, flags};
+  SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.rank128, s.unsorted, flags, eps};
   const int nwords = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
   const int grid = nb < 256 ? nb : 256;  // persistent: one 1024-thread workgroup per CU
   if (node_index && nwords <= SG_LDS_WORDS_MAX) {
@@ -799,8 +803,9 @@ extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col
 }
 
 extern "C" int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col, const float* w, int64_t E,
-                                         int64_t N, int flags, const void* ws, int64_t num_out,
-                                         int64_t* out_row, int64_t* out_col, float* out_w, void* stream_) {
+                                         int64_t N, int flags, float eps, const void* ws, int64_t num_out,
+                                         int64_t* out_row, int64_t* out_col, float* out_w, int64_t* out_edge_id,
+                                         void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(E >= 0 && num_out >= 0 && ws, TGP_ERR_INVALID, "tgp_connect_subgraph_fill: bad argument");
   if (num_out == 0 || E == 0) return TGP_OK;
@@ -808,7 +813,7 @@ extern "C" int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col,
   SubgraphWs s = carve_subgraph(const_cast<void*>(ws), E, N);
   const int nb = cdiv(E, SG_CHUNK);
   SubgraphPred pred{row, col, w, (flags & TGP_NODE_FILTER) ? s.relabel : nullptr, s.member_bits, s.rank128, s.unsorted,
-                    flags};
+                    flags, eps};
   const int nwords = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
   const int grid = nb < 256 ? nb : 256;
   const int nblocks = (nwords + 3) / 4;
@@ -816,15 +821,15 @@ extern "C" int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_fill_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (SG_LDS_WORDS_MAX + 1984) * 4);
     hipLaunchKernelGGL(subgraph_fill_kernel<2>, dim3(grid), dim3(SG_THREADS), (nwords + nblocks) * sizeof(uint32_t),
-                       stream, pred, E, nb, nwords, s.offsets, out_row, out_col, w ? out_w : nullptr);
+                       stream, pred, E, nb, nwords, s.offsets, out_row, out_col, w ? out_w : nullptr, out_edge_id);
   } else if ((flags & TGP_NODE_FILTER) && nwords <= SG_LDS_WORDS_MAX) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_fill_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_WORDS_MAX * 4);
     hipLaunchKernelGGL(subgraph_fill_kernel<1>, dim3(grid), dim3(SG_THREADS), nwords * sizeof(uint32_t), stream, pred,
-                       E, nb, nwords, s.offsets, out_row, out_col, w ? out_w : nullptr);
+                       E, nb, nwords, s.offsets, out_row, out_col, w ? out_w : nullptr, out_edge_id);
   } else {
     hipLaunchKernelGGL(subgraph_fill_kernel<0>, dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords,
-                       s.offsets, out_row, out_col, w ? out_w : nullptr);
+                       s.offsets, out_row, out_col, w ? out_w : nullptr, out_edge_id);
   }
   return check_launch("tgp_connect_subgraph_fill");
 }
@@ -863,7 +868,7 @@ extern "C" size_t tgp_connect_coalesce_workspace_bytes(int64_t E, int64_t N, int
 
 extern "C" int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
                                           const int64_t* cluster_index, int64_t N, int64_t K, int reduce_op,
-                                          int flags, void* ws, size_t ws_bytes, int64_t* d_count,
+                                          int flags, float eps, void* ws, size_t ws_bytes, int64_t* d_count,
                                           void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && d_count && (E == 0 || (row && col && cluster_index)),
@@ -890,7 +895,7 @@ extern "C" int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col
   if (rc != TGP_OK) return rc;
   const int nb = cdiv(E, kCompactTile);
   hipLaunchKernelGGL(coalesce_segment_kernel, dim3(nb), dim3(256), 0, stream, first ? s.k0 : s.k1,
-                     first ? s.v0 : s.v1, E, Ku, w ? 1 : 0, reduce_op, flags, s.seg, s.keep, s.counts);
+                     first ? s.v0 : s.v1, E, Ku, w ? 1 : 0, reduce_op, flags, eps, s.seg, s.keep, s.counts);
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nb, s.offsets, d_count);
   return check_launch("tgp_connect_coalesce_count");
 }
@@ -922,7 +927,7 @@ extern "C" size_t tgp_postprocess_sparse_workspace_bytes(int64_t E, int64_t num_
 }
 
 extern "C" int tgp_postprocess_sparse_norm_f32(const int64_t* row, const int64_t* col, float* w, int64_t E,
-                                               int64_t num_nodes, int flags, const int64_t* batch_pooled,
+                                               int64_t num_nodes, int flags, float eps, const int64_t* batch_pooled,
                                                int64_t num_graphs, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(E >= 0 && num_nodes >= 0, TGP_ERR_INVALID, "tgp_postprocess_sparse_norm_f32: bad size");
@@ -950,7 +955,7 @@ extern "C" int tgp_postprocess_sparse_norm_f32(const int64_t* row, const int64_t
                        slab_flags, deg);
     hipLaunchKernelGGL(degree_fallback_kernel, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, stream, row, w, E,
                        unsorted, deg);
-    hipLaunchKernelGGL(degree_scale_kernel, dim3(nb), dim3(256), 0, stream, row, col, w, E, deg);
+    hipLaunchKernelGGL(degree_scale_kernel, dim3(nb), dim3(256), 0, stream, row, col, w, E, deg, eps);
   }
   if (flags & TGP_EDGE_WEIGHT_NORM) {
     TGP_REQUIRE(batch_pooled && num_graphs > 0, TGP_ERR_INVALID,
@@ -971,7 +976,7 @@ extern "C" size_t tgp_block_diag_workspace_bytes(int64_t B, int64_t K) {
 }
 
 extern "C" int tgp_block_diag_count(const float* adj, int64_t B, int64_t K, const int64_t* relabel, int flags,
-                                    void* ws, size_t ws_bytes, int64_t* d_count, void* stream_) {
+                                    float eps, void* ws, size_t ws_bytes, int64_t* d_count, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && K >= 0 && d_count, TGP_ERR_INVALID, "tgp_block_diag_count: bad argument");
   const int64_t total = B * K * K;
@@ -987,14 +992,14 @@ extern "C" int tgp_block_diag_count(const float* adj, int64_t B, int64_t K, cons
   const int nb = cdiv(total, kCompactTile);
   uint32_t* counts = cv.take<uint32_t>(nb);
   uint32_t* offsets = cv.take<uint32_t>(nb);
-  BlockDiagPred pred{adj, relabel, K, flags};
+  BlockDiagPred pred{adj, relabel, K, flags, eps};
   hipLaunchKernelGGL(blockdiag_count_kernel, dim3(nb), dim3(256), 0, stream, pred, total, counts);
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts, nb, offsets, d_count);
   return check_launch("tgp_block_diag_count");
 }
 
 extern "C" int tgp_block_diag_fill(const float* adj, int64_t B, int64_t K, const int64_t* relabel, int flags,
-                                   const void* ws, int64_t num_out, int64_t* out_row, int64_t* out_col,
+                                   float eps, const void* ws, int64_t num_out, int64_t* out_row, int64_t* out_col,
                                    float* out_w, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int64_t total = B * K * K;
@@ -1005,7 +1010,7 @@ extern "C" int tgp_block_diag_fill(const float* adj, int64_t B, int64_t K, const
   const int nb = cdiv(total, kCompactTile);
   cv.take<uint32_t>(nb);
   uint32_t* offsets = cv.take<uint32_t>(nb);
-  BlockDiagPred pred{adj, relabel, K, flags};
+  BlockDiagPred pred{adj, relabel, K, flags, eps};
   hipLaunchKernelGGL(blockdiag_fill_kernel, dim3(nb), dim3(256), 0, stream, pred, total, offsets, out_row,
                      out_col, out_w);
   return check_launch("tgp_block_diag_fill");

@@ -28,7 +28,7 @@ ADJ_TRANSPOSED = 32
 NODE_FILTER = 64
 REDUCE_OPS = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3, "mul": 4}
 
-_c_i64, _c_int, _c_sz, _c_p = ctypes.c_int64, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
+_c_i64, _c_int, _c_sz, _c_p, _c_f = ctypes.c_int64, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float
 
 # name -> (restype, argtypes); must list every symbol the header declares
 SIGNATURES = {
@@ -41,31 +41,31 @@ SIGNATURES = {
                                        _c_i64, _c_p, _c_p]),
     "tgp_reduce_batch_i64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_connect_subgraph_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
-    "tgp_connect_subgraph_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_p,
+    "tgp_connect_subgraph_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_f, _c_p,
                                             _c_sz, _c_p, _c_p]),
-    "tgp_connect_subgraph_fill": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64, _c_p,
-                                           _c_p, _c_p, _c_p]),
+    "tgp_connect_subgraph_fill": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_i64, _c_p,
+                                           _c_p, _c_p, _c_p, _c_p]),
     "tgp_connect_coalesce_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
-    "tgp_connect_coalesce_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_int,
+    "tgp_connect_coalesce_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_int, _c_f,
                                             _c_p, _c_sz, _c_p, _c_p]),
     "tgp_connect_coalesce_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_i64, _c_p, _c_p,
                                            _c_p, _c_p]),
     "tgp_connect_coalesce_rows_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tgp_connect_coalesce_rows_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_int,
-                                                 _c_int, _c_p, _c_sz, _c_p, _c_p]),
+                                                 _c_int, _c_f, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_connect_coalesce_rows_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_p, _c_p, _c_p,
                                                 _c_p]),
     "tgp_connect_coalesce_grouped_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tgp_connect_coalesce_grouped_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_int,
-                                                    _c_p, _c_sz, _c_p, _c_p]),
+                                                    _c_f, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_postprocess_sparse_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
-    "tgp_postprocess_sparse_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_i64,
+    "tgp_postprocess_sparse_norm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_i64,
                                                  _c_p, _c_sz, _c_p]),
     "tgp_dense_pool_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64]),
-    "tgp_dense_pool_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_p, _c_p,
+    "tgp_dense_pool_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_p, _c_p,
                                     _c_p, _c_p, _c_sz, _c_p]),
     "tgp_postprocess_dense_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
-    "tgp_postprocess_dense_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_sz, _c_p]),
+    "tgp_postprocess_dense_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_sz, _c_p]),
     "tgp_bmm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_i64,
                              _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "tgp_segment_gemm_tn_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64]),
@@ -87,7 +87,7 @@ SIGNATURES = {
     "tgp_link_loss_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tgp_link_loss_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_sz, _c_p]),
     "tgp_entropy_sum_workspace_bytes": (_c_sz, [_c_i64]),
-    "tgp_entropy_sum_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_sz, _c_p]),
+    "tgp_entropy_sum_f32": (_c_int, [_c_p, _c_i64, _c_f, _c_p, _c_p, _c_sz, _c_p]),
     "tgp_cut_terms_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "tgp_rowptr_from_sorted_i64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_spmm_csr_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
@@ -95,8 +95,8 @@ SIGNATURES = {
     "tgp_from_dense_batch_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_to_dense_batch_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_block_diag_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
-    "tgp_block_diag_count": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_sz, _c_p, _c_p]),
-    "tgp_block_diag_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_i64, _c_p, _c_p, _c_p,
+    "tgp_block_diag_count": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_f, _c_p, _c_sz, _c_p, _c_p]),
+    "tgp_block_diag_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_f, _c_p, _c_i64, _c_p, _c_p, _c_p,
                                      _c_p]),
     "tgp_kron_batched_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tgp_kron_batched_max_graph_nodes": (_c_int, []),

@@ -70,11 +70,12 @@ def sparse_connect(edge_index, edge_weight: Optional[Tensor] = None, node_index:
     if edge_weight is not None:
         edge_weight = edge_weight.view(-1)
     num_nodes = maybe_num_nodes(edge_index, num_nodes)
+    # Fn.*: the native kernels, with the pooled weights kept differentiable w.r.t. edge_weight when it needs a gradient
     if node_index is not None and len(node_index) < num_nodes:
-        ei, ew = K.filter_edges(edge_index, edge_weight, node_index, num_nodes, remove_self_loops)
+        ei, ew = Fn.filter_edges(edge_index, edge_weight, node_index, num_nodes, remove_self_loops)
     elif cluster_index is not None and len(cluster_index) == num_nodes:
-        ei, ew = K.coalesce_edges(edge_index, edge_weight, cluster_index, num_supernodes, reduce_op,
-                                  remove_self_loops, assign_index=assign_index)
+        ei, ew = Fn.coalesce_edges(edge_index, edge_weight, cluster_index, num_supernodes, reduce_op,
+                                   remove_self_loops, assign_index=assign_index)
     else:
         raise RuntimeError
     ei, ew = _normalize_pooled_edges(ei, ew, num_supernodes, degree_norm, edge_weight_norm, batch_pooled)

@@ -183,6 +183,92 @@ def coalesce_sum(edge_index: Tensor, edge_weight: Tensor, num_nodes: int):
     return ei, ew
 
 
+# ------------------------------------------------------------------- edge weights through sparse Connect
+class _FilteredWeightsFn(torch.autograd.Function):
+    """Weights of the edges that survive the subgraph / self-loop / eps filters (connect/base_conn.py:79-82,
+    utils/ops.py:370-380): a pass-through of the kept inputs, so dw_e = dout[position of e] for kept edges and 0
+    for dropped ones.  ``edge_id`` (input position of every kept edge) comes from the native fill kernel."""
+
+    @staticmethod
+    def forward(ctx, edge_weight, edge_id, holder):
+        ctx.save_for_backward(edge_id)
+        ctx.shape = edge_weight.shape
+        return holder[0]  # the values the kernel compacted (handed over in a tuple: not an input tensor)
+
+    @staticmethod
+    def backward(ctx, g):
+        (edge_id,) = ctx.saved_tensors
+        n = 1
+        for d in ctx.shape:
+            n *= d
+        gi = torch.zeros(n, dtype=g.dtype, device=g.device)
+        gi[edge_id] = g  # kept edges are distinct inputs: a plain scatter
+        return gi.view(ctx.shape), None, None
+
+
+def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: Optional[Tensor], num_nodes: int,
+                 remove_self_loops: bool):
+    """K.filter_edges whose pooled weights stay differentiable w.r.t. ``edge_weight``."""
+    if not _needs_grad(edge_weight):
+        return K.filter_edges(edge_index, edge_weight, node_index, num_nodes, remove_self_loops)
+    ei, ew, eid = K.filter_edges(edge_index, edge_weight.detach(), node_index, num_nodes, remove_self_loops,
+                                 want_edge_id=True)
+    w32 = edge_weight if edge_weight.dtype == torch.float32 else edge_weight.float()
+    return ei, _FilteredWeightsFn.apply(w32.reshape(-1), eid, (ew,))
+
+
+class _CoalescedEdgeWeightsFn(torch.autograd.Function):
+    """Weights of ``coalesce(cluster_index[edge_index], w, reduce=op)`` (connect/base_conn.py:86-89) as a function of
+    the input weights; the values come from the native kernel, the backward is the one of PyG's ``scatter``:
+    sum: dw_e = g[slot e]; mean: / group size; min / max: split evenly among the group's extremal entries
+    (torch ``scatter_reduce`` amax / amin rule); mul: g out / w_e.  Entries whose merged edge was filtered out (self
+    loop, |w| <= eps) get no gradient -- the reference's masks are not differentiable either."""
+
+    @staticmethod
+    def forward(ctx, edge_weight, slot, valid, op, holder):
+        out = holder[0]
+        ctx.save_for_backward(edge_weight, slot, valid, out)
+        ctx.op = op
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, slot, valid, out = ctx.saved_tensors
+        op = ctx.op
+        gs = g[slot]
+        if op in ("sum", "add"):
+            gi = gs
+        elif op == "mean":
+            cnt = torch.bincount(slot[valid], minlength=out.numel()).to(g.dtype)
+            gi = gs / cnt[slot].clamp(min=1)
+        elif op in ("min", "max"):
+            sel = valid & (w == out[slot])
+            cnt = torch.bincount(slot[sel], minlength=out.numel()).to(g.dtype)
+            gi = torch.where(sel, gs / cnt[slot].clamp(min=1), torch.zeros_like(gs))
+        else:  # mul: surviving groups have |prod| > eps, so no factor is zero
+            gi = gs * out[slot] / w
+        return torch.where(valid, gi, torch.zeros_like(gi)), None, None, None, None
+
+
+def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_index: Tensor, num_supernodes: int,
+                   reduce_op: str, remove_self_loops: bool, assign_index=None):
+    """K.coalesce_edges whose pooled weights stay differentiable w.r.t. ``edge_weight``."""
+    if not _needs_grad(edge_weight):
+        return K.coalesce_edges(edge_index, edge_weight, cluster_index, num_supernodes, reduce_op, remove_self_loops,
+                                assign_index=assign_index)
+    w = edge_weight.reshape(-1)
+    w32 = w if w.dtype == torch.float32 else w.float()
+    ei, ew = K.coalesce_edges(edge_index, w32.detach(), cluster_index, num_supernodes, reduce_op, remove_self_loops,
+                              assign_index=assign_index)
+    if ei.size(1) == 0:
+        return ei, ew
+    key_in = cluster_index[edge_index[0]] * num_supernodes + cluster_index[edge_index[1]]
+    key_out = ei[0] * num_supernodes + ei[1]  # row-major sorted and unique
+    slot = torch.searchsorted(key_out, key_in).clamp_(max=key_out.numel() - 1)
+    valid = key_out[slot] == key_in
+    return ei, _CoalescedEdgeWeightsFn.apply(w32, slot, valid, reduce_op, (ew,))
+
+
 # ------------------------------------------------------------------------------------ block-diagonal export
 class _BlockDiagWeightsFn(torch.autograd.Function):
     """Values of dense_to_block_diag (utils/ops.py:53-82) as a function of the dense tensor: a gather at the

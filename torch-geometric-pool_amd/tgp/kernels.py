@@ -14,6 +14,18 @@ from torch import Tensor
 from . import _native as N
 
 
+def ops_eps() -> float:
+    """``tgp.utils.ops.eps`` read at CALL time, as the reference's ops functions read their module global
+    (utils/ops.py:21,72,318,377,395; reference tests monkeypatch it: tests/connect/test_dense_conn.py:444-463)."""
+    from .utils import ops
+    return float(ops.eps)
+
+
+def losses_eps() -> float:
+    from .utils import losses
+    return float(losses.eps)
+
+
 # ------------------------------------------------------------------------- A1 / A2
 class AssignIndex:
     """Inverted index of a sparse assignment (supernode -> its assignments, in ascending
@@ -98,9 +110,11 @@ def _read_count(d_count: Tensor) -> int:
 
 
 def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: Optional[Tensor],
-                 num_nodes: int, remove_self_loops: bool) -> Tuple[Tensor, Optional[Tensor]]:
+                 num_nodes: int, remove_self_loops: bool, want_edge_id: bool = False):
     """Induced subgraph + relabel (connect/base_conn.py:79-82) fused with remove_self_loops and the
-    |w| > eps filter (utils/ops.py:370-380).  node_index=None: filters only.  Keeps input order."""
+    |w| > eps filter (utils/ops.py:370-380).  node_index=None: filters only.  Keeps input order.
+    ``want_edge_id``: also return the input position of every kept edge (what the backward of the weight
+    pass-through scatters by)."""
     dev = N.require_device(edge_index, edge_weight, node_index)
     row, col = _edge_rows(edge_index)
     E = row.numel()
@@ -110,23 +124,27 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
     if ni is not None:
         flags |= N.NODE_FILTER
         if ni.numel() == 0:  # no node kept: no edge survives (an empty tensor has no device pointer to hand over)
-            return (torch.empty(2, 0, dtype=torch.int64, device=dev),
-                    None if w is None else torch.empty(0, dtype=torch.float32, device=dev))
+            out = (torch.empty(2, 0, dtype=torch.int64, device=dev),
+                   None if w is None else torch.empty(0, dtype=torch.float32, device=dev))
+            return out + (torch.empty(0, dtype=torch.int64, device=dev),) if want_edge_id else out
     L = N.lib()
     ws = N.workspace(L.tgp_connect_subgraph_workspace_bytes(E, num_nodes), dev)
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
     st = N.stream_ptr(dev)
+    eps = ops_eps()
     N.check(L.tgp_connect_subgraph_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(ni),
-                                         0 if ni is None else ni.numel(), num_nodes, flags, N.ptr(ws),
+                                         0 if ni is None else ni.numel(), num_nodes, flags, eps, N.ptr(ws),
                                          ws.numel(), N.ptr(d_count), st), "tgp_connect_subgraph_count")
     n_out = _read_count(d_count)
     out_ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
     out_w = None if w is None else torch.empty(n_out, dtype=torch.float32, device=dev)
-    N.check(L.tgp_connect_subgraph_fill(N.ptr(row), N.ptr(col), N.ptr(w), E, num_nodes, flags, N.ptr(ws), n_out,
+    out_id = torch.empty(n_out, dtype=torch.int64, device=dev) if want_edge_id else None
+    N.check(L.tgp_connect_subgraph_fill(N.ptr(row), N.ptr(col), N.ptr(w), E, num_nodes, flags, eps, N.ptr(ws), n_out,
                                         N.ptr(out_ei[0]) if n_out else None,
-                                        N.ptr(out_ei[1]) if n_out else None, N.ptr(out_w), st),
+                                        N.ptr(out_ei[1]) if n_out else None, N.ptr(out_w),
+                                        N.ptr(out_id) if n_out else None, st),
             "tgp_connect_subgraph_fill")
-    return out_ei, out_w
+    return (out_ei, out_w, out_id) if want_edge_id else (out_ei, out_w)
 
 
 def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_index: Tensor,
@@ -146,6 +164,7 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
     cl = N.i64c(cluster_index)
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if (w is not None and eps_filter) else 0)
     L = N.lib()
+    eps = ops_eps()
     if (assign_index is not None and assign_index.nnz == cl.numel() and assign_index.num_targets == num_supernodes
             and num_supernodes < (1 << 26)):
         ws = N.workspace(L.tgp_connect_coalesce_rows_workspace_bytes(E, cl.numel(), num_supernodes), dev)
@@ -153,7 +172,7 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
         st = N.stream_ptr(dev)
         N.check(L.tgp_connect_coalesce_rows_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
                                                   num_supernodes, N.ptr(assign_index.row_ptr),
-                                                  N.ptr(assign_index.perm), N.REDUCE_OPS[reduce_op], flags, N.ptr(ws),
+                                                  N.ptr(assign_index.perm), N.REDUCE_OPS[reduce_op], flags, eps, N.ptr(ws),
                                                   ws.numel(), N.ptr(d_count), st), "tgp_connect_coalesce_rows_count")
         n_out = _read_count(d_count)
         if n_out >= 0:
@@ -172,7 +191,7 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
         d_count = torch.empty(1, dtype=torch.int64, device=dev)
         st = N.stream_ptr(dev)
         N.check(L.tgp_connect_coalesce_grouped_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
-                                                     num_supernodes, N.REDUCE_OPS[reduce_op], flags, N.ptr(ws),
+                                                     num_supernodes, N.REDUCE_OPS[reduce_op], flags, eps, N.ptr(ws),
                                                      ws.numel(), N.ptr(d_count), st), "tgp_connect_coalesce_grouped_count")
         n_out = _read_count(d_count)
         if n_out >= 0:
@@ -188,7 +207,7 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
     st = N.stream_ptr(dev)
     N.check(L.tgp_connect_coalesce_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
-                                         num_supernodes, N.REDUCE_OPS[reduce_op], flags, N.ptr(ws), ws.numel(),
+                                         num_supernodes, N.REDUCE_OPS[reduce_op], flags, eps, N.ptr(ws), ws.numel(),
                                          N.ptr(d_count), st), "tgp_connect_coalesce_count")
     n_out = _read_count(d_count)
     out_ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
@@ -212,7 +231,7 @@ def normalize_edges_(edge_index: Tensor, edge_weight: Tensor, num_nodes: int, de
     L = N.lib()
     ws = N.workspace(L.tgp_postprocess_sparse_workspace_bytes(row.numel(), num_nodes, num_graphs), dev)
     N.check(L.tgp_postprocess_sparse_norm_f32(N.ptr(row), N.ptr(col), N.ptr(edge_weight), row.numel(), num_nodes,
-                                              flags, N.ptr(bp), num_graphs, N.ptr(ws), ws.numel(),
+                                              flags, ops_eps(), N.ptr(bp), num_graphs, N.ptr(ws), ws.numel(),
                                               N.stream_ptr(dev)), "tgp_postprocess_sparse_norm_f32")
     return edge_weight
 
@@ -266,7 +285,7 @@ def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int
     L = N.lib()
     ws = N.workspace(L.tgp_dense_pool_workspace_bytes(B, Nn, K, F), dev)
     gs = _sizes_arg(graph_sizes, B, dev)
-    N.check(L.tgp_dense_pool_f32(N.ptr(s), N.ptr(a), N.ptr(x), B, Nn, K, F, flags, N.ptr(gs), N.ptr(x_pool),
+    N.check(L.tgp_dense_pool_f32(N.ptr(s), N.ptr(a), N.ptr(x), B, Nn, K, F, flags, ops_eps(), N.ptr(gs), N.ptr(x_pool),
                                  N.ptr(adj_raw), N.ptr(adj_pool), N.ptr(ws), ws.numel(), N.stream_ptr(dev)),
             "tgp_dense_pool_f32")
     return x_pool, adj_raw, adj_pool
@@ -280,7 +299,7 @@ def postprocess_dense(adj_pool: Tensor, flags: int, inplace: bool = False) -> Te
     B, K = src.size(0), src.size(1)
     L = N.lib()
     ws = N.workspace(L.tgp_postprocess_dense_workspace_bytes(B, K), dev)
-    N.check(L.tgp_postprocess_dense_f32(N.ptr(src), N.ptr(dst), B, K, flags, N.ptr(ws), ws.numel(),
+    N.check(L.tgp_postprocess_dense_f32(N.ptr(src), N.ptr(dst), B, K, flags, ops_eps(), N.ptr(ws), ws.numel(),
                                         N.stream_ptr(dev)), "tgp_postprocess_dense_f32")
     return dst
 
@@ -316,7 +335,8 @@ def entropy_sum(s: Tensor) -> Tensor:
     out = torch.empty((), dtype=torch.float32, device=dev)
     L = N.lib()
     ws = N.workspace(L.tgp_entropy_sum_workspace_bytes(s.numel()), dev)
-    N.check(L.tgp_entropy_sum_f32(N.ptr(s), s.numel(), N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(dev)),
+    N.check(L.tgp_entropy_sum_f32(N.ptr(s), s.numel(), losses_eps(), N.ptr(out), N.ptr(ws), ws.numel(),
+                                  N.stream_ptr(dev)),
             "tgp_entropy_sum_f32")
     return out
 
@@ -390,9 +410,13 @@ def _rows_sorted(edge_index: Tensor, row: Tensor) -> bool:
     return flag
 
 
-def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int, max_rounds: int = 64) -> Tensor:
+def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
+                  max_rounds: Optional[int] = None) -> Tensor:
     """label[i] = min(i, partner) of a heavy-edge maximal matching (select/graclus_select.py:66 ->
-    torch_cluster.graclus_cluster): handshake rounds on the device until a round matches nothing."""
+    torch_cluster.graclus_cluster): handshake rounds on the device until a round matches nothing, however many that
+    takes (a path with monotone weights matches one pair per round: n/2 rounds; torch_cluster iterates until done
+    too).  ``max_rounds`` bounds the loop for callers that accept a non-maximal matching; if it is hit a
+    RuntimeWarning says so."""
     dev = N.require_device(edge_index, edge_weight)
     row, col = _edge_rows(edge_index)
     E = row.numel()
@@ -412,15 +436,22 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
     N.check(L.tgp_graclus_match_start(N.ptr(row), N.ptr(col), N.ptr(w), N.ptr(row_ptr), N.ptr(perm), num_nodes, E,
                                       N.ptr(ws), ws.numel(), N.ptr(label), st), "tgp_graclus_match_start")
     done, step = 0, 6  # late rounds are cheap (free nodes are packed before scanning): prefer fewer round trips
-    while done < max_rounds and num_nodes > 0 and E > 0:
-        step = min(step, max_rounds - done)
+    finished = num_nodes == 0 or E == 0
+    while not finished and (max_rounds is None or done < max_rounds):
+        if max_rounds is not None:
+            step = min(step, max_rounds - done)
         matched = torch.empty(step, dtype=torch.int32, device=dev)
         N.check(L.tgp_graclus_match_rounds(N.ptr(row_ptr), num_nodes, E, N.ptr(ws), step, N.ptr(matched),
                                            N.ptr(label), st), "tgp_graclus_match_rounds")
         done += step
-        if int(matched[-1].item()) == 0:  # one round trip per batch of rounds
-            break
-        step = 4
+        finished = int(matched[-1].item()) == 0  # one round trip per batch of rounds
+        # random-like graphs finish in a handful of rounds; a long tail means chain-like structure: batch more
+        # rounds per round trip (4, then doubling up to 256) so that n/2 rounds cost n/512 host synchronisations
+        step = 4 if done <= 6 else min(2 * step, 256)
+    if not finished:
+        import warnings
+        warnings.warn(f"graclus_match stopped after max_rounds={max_rounds} rounds: the matching is not maximal",
+                      RuntimeWarning)
     return label
 
 
@@ -608,12 +639,13 @@ def block_diag_edges(adj_pool: Tensor, relabel: Optional[Tensor] = None,
     ws = N.workspace(L.tgp_block_diag_workspace_bytes(B, K), dev)
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
     st = N.stream_ptr(dev)
-    N.check(L.tgp_block_diag_count(N.ptr(a), B, K, N.ptr(rl), flags, N.ptr(ws), ws.numel(), N.ptr(d_count), st),
+    eps = ops_eps()
+    N.check(L.tgp_block_diag_count(N.ptr(a), B, K, N.ptr(rl), flags, eps, N.ptr(ws), ws.numel(), N.ptr(d_count), st),
             "tgp_block_diag_count")
     n_out = _read_count(d_count)
     ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
     ew = torch.empty(n_out, dtype=torch.float32, device=dev)
-    N.check(L.tgp_block_diag_fill(N.ptr(a), B, K, N.ptr(rl), flags, N.ptr(ws), n_out,
+    N.check(L.tgp_block_diag_fill(N.ptr(a), B, K, N.ptr(rl), flags, eps, N.ptr(ws), n_out,
                                   N.ptr(ei[0]) if n_out else None, N.ptr(ei[1]) if n_out else None,
                                   N.ptr(ew) if n_out else None, st), "tgp_block_diag_fill")
     return ei, ew

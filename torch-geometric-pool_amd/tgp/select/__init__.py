@@ -47,6 +47,21 @@ def cluster_to_s(cluster_index: Tensor, node_index: Optional[Tensor] = None, wei
                                    size=(num_nodes, num_supernodes), is_coalesced=True)
 
 
+def _check_assignment_ranges(cluster_index: Tensor, node_index: Optional[Tensor], num_nodes: Optional[int],
+                             num_supernodes: Optional[int]) -> None:
+    if cluster_index.numel() == 0:
+        return
+    probes = [cluster_index.min(), cluster_index.max()]
+    if node_index is not None and node_index.numel():
+        probes += [node_index.min(), node_index.max()]
+    vals = torch.stack(probes).tolist()
+    if vals[0] < 0 or (num_supernodes is not None and vals[1] >= num_supernodes):
+        raise IndexError(f"cluster_index out of range: values in [{vals[0]}, {vals[1]}] with num_supernodes="
+                         f"{num_supernodes}")
+    if len(vals) == 4 and (vals[2] < 0 or (num_nodes is not None and vals[3] >= num_nodes)):
+        raise IndexError(f"node_index out of range: values in [{vals[2]}, {vals[3]}] with num_nodes={num_nodes}")
+
+
 class SelectOutput:
     r"""Assignment of nodes to supernodes: ``s`` is a sparse COO ``[N,K]`` or a dense ``[N,K]`` /
     ``[B,N,K]`` tensor (reference select/base_select.py:76-486).
@@ -78,6 +93,10 @@ class SelectOutput:
                     assert val is None, f"'{name}' cannot be set if 's' is a dense Tensor"
         elif s is None:
             assert cluster_index is not None, "'cluster_index' cannot be None if 's' is None"
+            if not extra_args.pop("_trusted", False):
+                # caller-supplied vectors: the kernels index [K] / [N] tables with them unchecked (the reference's
+                # scatter / index ops would raise); one host read here, never on a selector's own output
+                _check_assignment_ranges(cluster_index, node_index, num_nodes, num_supernodes)
             s = cluster_to_s(cluster_index, node_index=node_index, num_supernodes=num_supernodes,
                              num_nodes=num_nodes, weight=weight)
         else:
@@ -307,7 +326,7 @@ class SelectOutput:
         assignments = get_assignments(kept, edge_index=edge_index if closest_node_assignment else None,
                                       max_iter=max_iter if closest_node_assignment else 0, batch=batch)
         out = SelectOutput(cluster_index=assignments[1], s_inv_op=getattr(self, "s_inv_op", "transpose"),
-                           weight=weight)
+                           weight=weight, _trusted=True)
         for name in self._extra_args:
             if hasattr(self, name):
                 setattr(out, name, getattr(self, name))
@@ -422,7 +441,7 @@ class TopkSelect(Select):
         so = SelectOutput(node_index=node_index, num_nodes=x.size(0),
                           cluster_index=torch.arange(node_index.size(0), device=x.device),
                           num_supernodes=node_index.size(0), weight=score[node_index],
-                          s_inv_op=self.s_inv_op)
+                          s_inv_op=self.s_inv_op, _trusted=True)
         so._set_one_to_one_index()
         return so
 
@@ -531,7 +550,7 @@ class MLPSelect(Select):
 
 # =============================================================================== Graclus
 def graclus_cluster(row: Tensor, col: Tensor, weight: Optional[Tensor] = None,
-                    num_nodes: Optional[int] = None, max_rounds: int = 64) -> Tensor:
+                    num_nodes: Optional[int] = None, max_rounds: Optional[int] = None) -> Tensor:
     """Greedy heavy-edge matching; each node is labelled with the smaller id of its pair.
 
     torch_cluster's ``graclus_cluster`` (what the reference calls, select/graclus_select.py:66) is a
@@ -539,7 +558,8 @@ def graclus_cluster(row: Tensor, col: Tensor, weight: Optional[Tensor] = None,
     matching is a valid stand-in.  This one is deterministic: in every round each free node proposes
     to its heaviest free neighbour (smallest id on ties) and mutual proposals are matched; the
     rounds are data-parallel device ops.  (The globally heaviest free edge with the smallest endpoint
-    ids is always a mutual proposal, so every round makes progress.)
+    ids is always a mutual proposal, so every round makes progress.)  Runs until no free edge is left
+    (``max_rounds=None``): a path with monotone weights needs n/2 rounds.
     """
     n = int(num_nodes) if num_nodes is not None else (int(max(row.max(), col.max())) + 1 if row.numel() else 0)
     dev = row.device
@@ -548,7 +568,9 @@ def graclus_cluster(row: Tensor, col: Tensor, weight: Optional[Tensor] = None,
     row, col = row[keep], col[keep]
     w = torch.ones(row.numel(), device=dev) if weight is None else weight.reshape(-1)[keep].to(torch.float32)
     free = torch.ones(n, dtype=torch.bool, device=dev)
-    for _ in range(max_rounds):
+    rounds = 0
+    while max_rounds is None or rounds < max_rounds:
+        rounds += 1
         live = free[row] & free[col]
         if not bool(live.any()):
             break
@@ -598,7 +620,8 @@ class GraclusSelect(Select):
         pair = graclus_cluster(edge_index[0], edge_index[1], edge_weight, num_nodes)
         ids, assignment = torch.unique(pair, sorted=True, return_inverse=True)
         return SelectOutput(node_index=torch.arange(num_nodes, device=assignment.device), num_nodes=num_nodes,
-                            cluster_index=assignment, num_supernodes=ids.size(0), s_inv_op=self.s_inv_op)
+                            cluster_index=assignment, num_supernodes=ids.size(0), s_inv_op=self.s_inv_op,
+                            _trusted=True)
 
     def __repr__(self) -> str:
         return f"{self.__class__.__name__}(s_inv_op={self.s_inv_op})"

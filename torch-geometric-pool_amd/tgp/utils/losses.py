@@ -135,6 +135,8 @@ class _OrthoFromGramFn(torch.autograd.Function):
 
 
 def orthogonality_loss(S: Tensor, batch_reduction: str = "mean", graph_sizes: Optional[Tensor] = None) -> Tensor:
+    if S.dim() == 2:  # a single graph [N,K]: the reference's transpose(-2,-1) / norm(dim=(-2,-1)) accept it (losses.py:59-70)
+        return orthogonality_loss(S.unsqueeze(0), batch_reduction, None).reshape(())
     sts = _GramFn.apply(S, graph_sizes if S.dim() == 3 else None)
     if sts.is_cuda and torch.is_grad_enabled() and sts.requires_grad:
         return _reduce(_OrthoFromGramFn.apply(sts), batch_reduction)

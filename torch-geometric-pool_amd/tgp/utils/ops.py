@@ -39,8 +39,25 @@ def as_compute_dtype(t):
     features) are converted on the way in -- differentiably -- and :func:`like_input_dtype` converts results back, so
     the dtype a caller sees is the one the reference's ATen ops would return; the arithmetic stays fp32."""
     if isinstance(t, Tensor) and not t.is_sparse and t.is_floating_point() and t.dtype != torch.float32:
+        if t.dtype == torch.float64:
+            _warn_float64_once()
         return t.float()
     return t
+
+
+_WARNED_F64 = False
+
+
+def _warn_float64_once() -> None:
+    """The reference computes ``model.double()`` inputs in true fp64 (ATen); this build's kernels are fp32.  Said out
+    loud, once per process, instead of silently narrowing (``torch.autograd.gradcheck`` in fp64 will not pass)."""
+    global _WARNED_F64
+    if not _WARNED_F64:
+        _WARNED_F64 = True
+        import warnings
+        warnings.warn("tgp (MI355X build): float64 inputs are computed in float32 by the HIP kernels and the results "
+                      "cast back to float64; the reference computes them in float64.  Precision is fp32's.",
+                      UserWarning, stacklevel=3)
 
 
 def like_input_dtype(out, like):
@@ -343,7 +360,8 @@ def postprocess_adj_pool_sparse(edge_index: Tensor, edge_weight: Optional[Tensor
     if edge_weight is not None:
         edge_weight = edge_weight.view(-1)
     if remove_self_loops or edge_weight is not None:
-        edge_index, edge_weight = K.filter_edges(edge_index, edge_weight, None, num_nodes, remove_self_loops)
+        from .. import functions as Fn  # (imports this module)
+        edge_index, edge_weight = Fn.filter_edges(edge_index, edge_weight, None, num_nodes, remove_self_loops)
     return _normalize_pooled_edges(edge_index, edge_weight, num_nodes, degree_norm, edge_weight_norm, batch_pooled)
 
 
