@@ -388,7 +388,7 @@ def test_rowlocal_coalesce_declines_and_falls_back(dev):
         cnt = torch.empty(1, dtype=torch.int64, device=dev)
         N.check(L.tgp_connect_coalesce_rows_count(row.data_ptr(), col.data_ptr(), None, row.numel(), cl.data_ptr(),
                                                   cl.numel(), kk, index.row_ptr.data_ptr(), index.perm.data_ptr(), 0, 1,
-                                                  ws.data_ptr(), ws.numel(), cnt.data_ptr(), N.stream_ptr(dev)), "rows")
+                                                  1e-8, ws.data_ptr(), ws.numel(), cnt.data_ptr(), N.stream_ptr(dev)), "rows")
         return int(cnt.item())
 
     assert raw_count(ei.to(dev), cl_d, k, idx) == -1           # unsorted rows -> declined

@@ -11,7 +11,7 @@ lib = ctypes.CDLL(os.path.join(ROOT, "torch-geometric-pool_amd", "lib", "libtgp_
 p, i64, ci, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 lib.tgp_dense_pool_workspace_bytes.restype = sz
 lib.tgp_dense_pool_workspace_bytes.argtypes = [i64] * 4
-lib.tgp_dense_pool_f32.argtypes = [p, p, p, i64, i64, i64, i64, ci, p, p, p, p, p, sz, p]
+lib.tgp_dense_pool_f32.argtypes = [p, p, p, i64, i64, i64, i64, ci, ctypes.c_float, p, p, p, p, p, sz, p]
 lib.tgp_debug_set_gemm_stamps.argtypes = [p]
 B, N, K, F = (int(v) for v in sys.argv[1:5]) if len(sys.argv) >= 5 else (1024, 200, 50, 64)
 dev = torch.device("cuda:0")
@@ -25,7 +25,7 @@ stream = torch.cuda.current_stream(dev).cuda_stream
 
 
 def run():
-    rc = lib.tgp_dense_pool_f32(S.data_ptr(), A.data_ptr(), X.data_ptr(), B, N, K, F, 1 | 2 | 8, None, xp.data_ptr(), None,
+    rc = lib.tgp_dense_pool_f32(S.data_ptr(), A.data_ptr(), X.data_ptr(), B, N, K, F, 1 | 2 | 8, 1e-8, None, xp.data_ptr(), None,
                                 ap.data_ptr(), ws.data_ptr(), ws.numel(), stream)
     assert rc == 0
 
