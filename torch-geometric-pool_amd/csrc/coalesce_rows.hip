@@ -6,16 +6,16 @@
 //     raw_off[r] + member_off[node] + (e - node_ptr[node]),
 // so grouping the relabelled edges by supernode row needs no sort, and only the short per-row segments
 // (~E/K entries) have to be ordered by column.  Pipeline:
-//   K1 check rows sorted + CSR of the input (node_ptr)            read E*8 B twice
+//   K1 CSR of the input (node_ptr) + sortedness check, one pass     read E*8 B once
 //   K2 per supernode: raw row length T_r, per-member offsets      K-sized
 //   K3 scan T_r -> raw_off; per-node slot base                    K-, N-sized
-//   K4 gather-sort-merge (cr_gather_sort_kernel): one workgroup per 64 supernode rows gathers the rows' edges
-//      through the cluster table straight into LDS, sorts every row there (half-wave bitonic network in
-//      registers for rows of <= 32 entries, workgroup LDS bitonic for 33..1024), merges duplicates with
+//   K4 gather-sort-merge (cr_gather_sort_kernel): one workgroup per 32 supernode rows gathers the rows' edges
+//      through the cluster table straight into LDS, sorts every row there (8 lanes x 4 keys per row of <= 32
+//      entries, 16 x 4 for 33..64: cr_sort_rows; workgroup LDS bitonic for 65..1024), merges duplicates with
 //      reduce_op in input order, fused self-loop / eps filters, survivors compacted per row
 //                                                                  read E*12 B + gathers, write E'*8 B
 //   K5 scan survivors -> output offsets, total                    K-sized            [host reads total]
-//   K6 fill                                                        read E'*8 B, write E'*20 B
+//   K6 fill (output-parallel per 64-row block)                     read E'*8 B, write E'*20 B
 // vs. five radix passes of 32 B/edge each in the general path (sparse_connect.hip).  The result is
 // identical to the general path (row-major sorted, unique, duplicates reduced in input order).
 // Preconditions are checked on the device (rows sorted; no supernode row longer than 1024 raw entries or with
@@ -110,25 +110,31 @@ static void device_scan_u32(const uint32_t* in, int64_t n, uint32_t* out, int64_
 }
 
 // ------------------------------------------------------------------ K1 / K2
-__global__ __launch_bounds__(256) void cr_check_sorted_kernel(const int64_t* __restrict__ row, int64_t E,
-                                                              int* __restrict__ bad) {
-  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (e + 1 < E && row[e] > row[e + 1]) *bad = 1;
-}
-
+// CSR offsets of the (row-sorted) input AND the sortedness check in one pass over the row array: thread p owns
+// edge p and fills node_ptr for the nodes that start between its predecessor's row and its own.  An inversion (or a
+// node id outside [0, num_rows)) sets *bad = 1; fill loops are only entered on an ascending step, re-read the flag
+// now and then, and are bounded by num_rows, so unsorted input costs a few microseconds, not an unbounded walk.
 __global__ __launch_bounds__(256) void cr_node_ptr_kernel(const int64_t* __restrict__ rows, int64_t n,
-                                                          int64_t num_rows, const int* __restrict__ bad,
+                                                          int64_t num_rows, int* __restrict__ bad,
                                                           uint32_t* __restrict__ node_ptr) {
-  if (*bad) return;  // unsorted rows: the gap loops below would be unbounded garbage
   const int64_t p = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (p > n) return;
+  volatile int* vbad = bad;
   if (p == n) {
-    const int64_t first = n > 0 ? rows[n - 1] + 1 : 0;
+    int64_t first = n > 0 ? rows[n - 1] + 1 : 0;
+    if (first < 0) first = 0;
     for (int64_t c = first; c <= num_rows; ++c) node_ptr[c] = static_cast<uint32_t>(n);
     return;
   }
   const int64_t cur = rows[p], prev = p > 0 ? rows[p - 1] : -1;
-  for (int64_t c = prev + 1; c <= cur; ++c) node_ptr[c] = static_cast<uint32_t>(p);
+  if (cur < prev || cur < 0 || cur >= num_rows) {
+    if (*vbad == 0) atomicOr(bad, 1);  // the atomic drops the line from this XCD's L2: later plain reads see it
+    return;
+  }
+  for (int64_t c = prev + 1; c <= cur; ++c) {
+    node_ptr[c] = static_cast<uint32_t>(p);
+    if (((c - prev) & 63) == 0 && *vbad) return;
+  }
 }
 
 // one thread per supernode: raw row length + offset of each member's edge range inside the row
@@ -216,6 +222,127 @@ constexpr int GS_ROWS = 32;
 constexpr int GS_CAP = 1024;   // raw entries staged per pass (>= CR_LONG)
 constexpr int GS_MEM = 512;    // members per pass
 
+// ------------------------------------------------------------------ in-row sort + merge, LPR lanes per row
+// A row of up to 4 * LPR entries is sorted by LPR lanes holding 4 keys each (element e of the row lives in lane e / 4,
+// register e % 4): the two lowest index bits are lane-local, so 9 of the 15 compare-exchange levels of a 32-element
+// bitonic network are plain v_min / v_max on registers and only 6 cross lanes (ds_swizzle inside the 32-lane half).
+// Flip formulation (first level of every merge pairs e with e ^ (k - 1), then half-cleaners e ^ j): every exchange
+// is ascending, the lower element keeps the minimum - no per-level direction logic.  Only keys travel: key =
+// column << PB | input position, which also makes the sort stable; weights are fetched from LDS by position after.
+// A wave sorts 64 / LPR rows at once: 8 rows of <= 32 entries instead of the 2 of a lane-per-entry network.
+template <int M>
+__device__ __forceinline__ uint32_t cr_swz(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), 0x1F | (M << 10)));
+}
+__device__ __forceinline__ void cr_ce(uint32_t& a, uint32_t& b) {
+  const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+  a = lo;
+  b = hi;
+}
+// partner lane = lane ^ M, partner register = 3 - q (FLIP) or q; the lower lane keeps the minima
+template <int M, bool FLIP>
+__device__ __forceinline__ void cr_xlane(uint32_t (&k)[4], int l) {
+  constexpr int HB = M & ~(M >> 1);  // highest set bit of M (M is 2^n or 2^n - 1)
+  const bool lower = (l & HB) == 0;
+  uint32_t o[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) o[q] = cr_swz<M>(k[FLIP ? 3 - q : q]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t mn = k[q] < o[q] ? k[q] : o[q], mx = k[q] < o[q] ? o[q] : k[q];
+    k[q] = lower ? mn : mx;
+  }
+}
+__device__ __forceinline__ void cr_intra21(uint32_t (&k)[4]) {
+  cr_ce(k[0], k[2]); cr_ce(k[1], k[3]);  // j = 2
+  cr_ce(k[0], k[1]); cr_ce(k[2], k[3]);  // j = 1
+}
+
+template <int LPR>
+__device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, const float* s_val, uint32_t b, uint32_t T, bool mine,
+                                             uint32_t row_id, uint32_t base, bool has_w, int reduce_op, int flags,
+                                             float eps, uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w,
+                                             uint32_t* __restrict__ n_out_row) {
+  constexpr int PB = LPR == 8 ? 5 : 6;          // position bits: 32 or 64 entries per row
+  constexpr uint32_t PM = (1u << PB) - 1u;
+  const int l = threadIdx.x & (LPR - 1);
+  uint32_t k[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t e = static_cast<uint32_t>(l) * 4 + q;
+    k[q] = e < T ? (s_key[b + e] << PB) | e : 0xFFFFFFFFu;
+  }
+  cr_ce(k[0], k[1]); cr_ce(k[2], k[3]);                              // k = 2
+  cr_ce(k[0], k[3]); cr_ce(k[1], k[2]); cr_ce(k[0], k[1]); cr_ce(k[2], k[3]);  // k = 4: flip, j = 1
+  cr_xlane<1, true>(k, l); cr_intra21(k);                             // k = 8
+  cr_xlane<3, true>(k, l); cr_xlane<1, false>(k, l); cr_intra21(k);   // k = 16
+  cr_xlane<7, true>(k, l); cr_xlane<2, false>(k, l); cr_xlane<1, false>(k, l); cr_intra21(k);  // k = 32
+  if constexpr (LPR == 16) {
+    cr_xlane<15, true>(k, l); cr_xlane<4, false>(k, l); cr_xlane<2, false>(k, l); cr_xlane<1, false>(k, l);
+    cr_intra21(k);                                                     // k = 64
+  }
+  // sorted order = (lane, register); invalid keys (0xFFFFFFFF) are last
+  uint32_t c[4];
+  bool valid[4], head[4];
+  float acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    valid[q] = k[q] != 0xFFFFFFFFu;
+    c[q] = k[q] >> PB;
+    acc[q] = (valid[q] && has_w) ? s_val[b + (k[q] & PM)] : 0.f;
+  }
+  const uint32_t pc = __shfl_up(c[3], 1, LPR);  // an earlier element of a valid one is valid
+  head[0] = valid[0] && (l == 0 || pc != c[0]);
+#pragma unroll
+  for (int q = 1; q < 4; ++q) head[q] = valid[q] && c[q] != c[q - 1];
+  const bool dup_here = (valid[0] && !head[0]) || (valid[1] && !head[1]) || (valid[2] && !head[2]) || (valid[3] && !head[3]);
+  uint32_t ncnt[4] = {1, 1, 1, 1};
+  if (__any(dup_here)) {  // duplicate columns somewhere in this wave (rare): heads fold their run from LDS
+    // the sorted keys go back to the row's own slots (every lane of the row has its keys in registers by now)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (valid[q]) s_key[b + static_cast<uint32_t>(l) * 4 + q] = k[q];
+    __threadfence_block();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (head[q]) {
+        for (uint32_t p = static_cast<uint32_t>(l) * 4 + q + 1; p < T; ++p) {
+          const uint32_t kk = s_key[b + p];
+          if ((kk >> PB) != c[q]) break;
+          if (has_w) acc[q] = cr_reduce(acc[q], s_val[b + (kk & PM)], reduce_op);
+          ++ncnt[q];
+        }
+      }
+    }
+  }
+  uint32_t cnt_lane = 0;
+  bool keep[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (has_w && reduce_op == TGP_MEAN) acc[q] = acc[q] / static_cast<float>(ncnt[q]);
+    keep[q] = head[q];
+    if ((flags & TGP_REMOVE_SELF_LOOPS) && c[q] == row_id) keep[q] = false;
+    if (has_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc[q]) > eps)) keep[q] = false;
+    cnt_lane += keep[q] ? 1u : 0u;
+  }
+  uint32_t incl = cnt_lane;  // inclusive scan over the LPR lanes of the row
+#pragma unroll
+  for (int d = 1; d < LPR; d <<= 1) {
+    const uint32_t t = __shfl_up(incl, d, LPR);
+    if (l >= d) incl += t;
+  }
+  uint32_t rank = incl - cnt_lane;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (keep[q]) {
+      tmp_c[base + b + rank] = c[q];
+      if (has_w) tmp_w[base + b + rank] = acc[q];
+      ++rank;
+    }
+  }
+  if (mine && l == LPR - 1) *n_out_row = incl;
+}
+
 // DIRECT = false: rows are assembled from the members' edge ranges (row-sorted input, above).
 // DIRECT = true : `grouped` already holds the (cluster column | weight bits << 32) entries in supernode-row order
 //                 (the output of the 3-pass radix sort by supernode row, below); slot t of a row is grouped[...+t].
@@ -259,7 +386,11 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
       return;
     }
     int re = rs + 1;
-    while (re < nrows && s_roff[re + 1] - s_roff[rs] <= static_cast<uint32_t>(GS_CAP) && s_rp[re + 1] - s_rp[rs] <= GS_MEM) ++re;
+    if (s_roff[nrows] - s_roff[rs] <= static_cast<uint32_t>(GS_CAP) && s_rp[nrows] - s_rp[rs] <= GS_MEM) {
+      re = nrows;  // the usual case: all remaining rows fit one pass (no serial walk over the rows)
+    } else {
+      while (re < nrows && s_roff[re + 1] - s_roff[rs] <= static_cast<uint32_t>(GS_CAP) && s_rp[re + 1] - s_rp[rs] <= GS_MEM) ++re;
+    }
     const uint32_t base = s_roff[rs];
     const int cnt = static_cast<int>(s_roff[re] - base);
     const int p_lo = s_rp[rs], M = s_rp[re] - p_lo;
@@ -315,126 +446,46 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
     }
     __syncthreads();
     GS_STAMP(1);
-    // (c1) rows of <= 32 entries: one half-wave each
+    // (c1) rows of <= 32 entries: 8 lanes x 4 keys each, all 32 rows of the pass at once (cr_sort_rows)
     {
-      const int l = tid & 31, hw = tid >> 5;
-      const unsigned long long half_mask = 0xFFFFFFFFull << (tid & 32);
-      for (int i0 = rs; i0 < re; i0 += 8) {
-        const int i = i0 + hw;
+      constexpr int LPR = 8;
+      const int grp = tid / LPR;
+      for (int i0 = rs; i0 < re; i0 += 256 / LPR) {
+        const int i = i0 + grp;
         uint32_t b = 0, T = 0;
         if (i < re) {
           b = s_roff[i] - base;
           T = s_roff[i + 1] - s_roff[i];
         }
-        const bool mine = i < re && T <= 32;
         if (i < re && T > 32) {
+          const int l = tid & (LPR - 1);
           if (T <= 64) {
             if (l == 0) s_mid[atomicAdd(&s_nmid, 1)] = i;
           } else {  // longer rows: hand the raw (cluster, weight) entries to cr_rows_long_kernel through tmp
-            for (uint32_t j = l; j < T; j += 32) {
+            for (uint32_t j = l; j < T; j += LPR) {
               tmp_c[base + b + j] = s_key[b + j];
               if (has_w) tmp_w[base + b + j] = s_val[b + j];
             }
           }
         }
-        const uint32_t Tm = mine ? T : 0;
-        uint32_t key = 0xFFFFFFFFu;
-        if (static_cast<uint32_t>(l) < Tm) key = (s_key[b + l] << 5) | static_cast<uint32_t>(l);
-        // only the keys travel through the network (the input position rides in their low 5 bits, which also
-        // makes the sort stable); the weight is fetched from LDS by that position afterwards
-#define TGP_CE(KK, JJ)                                                           \
-  {                                                                              \
-    const uint32_t ok = xor_lane<JJ>(key);                                       \
-    if ((key > ok) == (((l & KK) == 0) == ((l & JJ) == 0))) key = ok;            \
-  }
-        TGP_CE(2, 1) TGP_CE(4, 2) TGP_CE(4, 1) TGP_CE(8, 4) TGP_CE(8, 2) TGP_CE(8, 1)
-        TGP_CE(16, 8) TGP_CE(16, 4) TGP_CE(16, 2) TGP_CE(16, 1)
-        TGP_CE(32, 16) TGP_CE(32, 8) TGP_CE(32, 4) TGP_CE(32, 2) TGP_CE(32, 1)
-#undef TGP_CE
-        const bool valid = key != 0xFFFFFFFFu;
-        const uint32_t c = key >> 5;
-        const float wv = valid ? s_val[b + (key & 31u)] : 0.f;
-        const uint32_t pc = __shfl_up(c, 1, 32);
-        const bool pvalid = __shfl_up(valid ? 1 : 0, 1, 32) != 0;
-        const bool head = valid && (l == 0 || !pvalid || pc != c);
-        float acc = wv;
-        uint32_t ncnt = 1;
-        bool open = head;
-        const int dmax = __any(valid && !head) ? 32 : 1;  // no duplicate column anywhere in this wave: nothing to fold
-        for (int d = 1; d < dmax; ++d) {
-          const uint32_t nc = __shfl_down(c, d, 32);
-          const float nw = __shfl_down(wv, d, 32);
-          const bool nvalid = __shfl_down(valid ? 1 : 0, d, 32) != 0;
-          open = open && (l + d < 32) && nvalid && nc == c;
-          if (open) { acc = cr_reduce(acc, nw, reduce_op); ++ncnt; }
-          if (!__any(open)) break;
-        }
-        if (has_w && reduce_op == TGP_MEAN) acc = acc / static_cast<float>(ncnt);
-        bool keep = head;
-        if ((flags & TGP_REMOVE_SELF_LOOPS) && c == static_cast<uint32_t>(r0 + i)) keep = false;
-        if (has_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > eps)) keep = false;
-        const unsigned long long km = __ballot(keep) & half_mask;
-        const uint32_t rank = __popcll(km & lanemask_lt());
-        if (keep) {
-          tmp_c[base + b + rank] = c;
-          if (has_w) tmp_w[base + b + rank] = acc;
-        }
-        if (mine && l == 0) n_out[r0 + i] = __popcll(km);
+        const bool mine = i < re && T <= 32;
+        cr_sort_rows<LPR>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), base, has_w, reduce_op,
+                          flags, eps, tmp_c, tmp_w, n_out + r0 + i);
       }
     }
     __syncthreads();
     GS_STAMP(2);
-    // (c1b) rows of 33 .. 64 entries: one wave each, the same register network over 64 lanes (position in 6 bits)
+    // (c1b) rows of 33 .. 64 entries: 16 lanes x 4 keys each
     {
-      const int lane = tid & 63;
+      constexpr int LPR = 16;
       const int nmid = s_nmid;
-      for (int li = tid >> 6; li < nmid; li += 4) {
-        const int i = s_mid[li];
+      for (int li0 = 0; li0 < nmid; li0 += 256 / LPR) {
+        const int li = li0 + tid / LPR;
+        const bool mine = li < nmid;
+        const int i = mine ? s_mid[li] : rs;
         const uint32_t b = s_roff[i] - base, T = s_roff[i + 1] - s_roff[i];
-        uint32_t key = static_cast<uint32_t>(lane) < T ? (s_key[b + lane] << 6) | static_cast<uint32_t>(lane) : 0xFFFFFFFFu;
-#define TGP_CE(KK, JJ)                                                                 \
-  {                                                                                    \
-    const uint32_t ok = xor_lane<JJ>(key);                                             \
-    if ((key > ok) == (((lane & KK) == 0) == ((lane & JJ) == 0))) key = ok;            \
-  }
-        TGP_CE(2, 1) TGP_CE(4, 2) TGP_CE(4, 1) TGP_CE(8, 4) TGP_CE(8, 2) TGP_CE(8, 1)
-        TGP_CE(16, 8) TGP_CE(16, 4) TGP_CE(16, 2) TGP_CE(16, 1)
-        TGP_CE(32, 16) TGP_CE(32, 8) TGP_CE(32, 4) TGP_CE(32, 2) TGP_CE(32, 1)
-        {
-          const uint32_t ok = __shfl_xor(key, 32, 64);  // the one exchange across the two 32-lane halves
-          if ((key > ok) == ((lane & 32) == 0)) key = ok;
-        }
-        TGP_CE(64, 16) TGP_CE(64, 8) TGP_CE(64, 4) TGP_CE(64, 2) TGP_CE(64, 1)
-#undef TGP_CE
-        const bool valid = key != 0xFFFFFFFFu;
-        const uint32_t c = key >> 6;
-        const float wv = valid ? s_val[b + (key & 63u)] : 0.f;
-        const uint32_t pc = __shfl_up(c, 1, 64);
-        const bool pvalid = __shfl_up(valid ? 1 : 0, 1, 64) != 0;
-        const bool head = valid && (lane == 0 || !pvalid || pc != c);
-        float acc = wv;
-        uint32_t ncnt = 1;
-        bool open = head;
-        const int dmax = __any(valid && !head) ? 64 : 1;
-        for (int d = 1; d < dmax; ++d) {
-          const uint32_t nc = __shfl_down(c, d, 64);
-          const float nw = __shfl_down(wv, d, 64);
-          const bool nvalid = __shfl_down(valid ? 1 : 0, d, 64) != 0;
-          open = open && (lane + d < 64) && nvalid && nc == c;
-          if (open) { acc = cr_reduce(acc, nw, reduce_op); ++ncnt; }
-          if (!__any(open)) break;
-        }
-        if (has_w && reduce_op == TGP_MEAN) acc = acc / static_cast<float>(ncnt);
-        bool keep = head;
-        if ((flags & TGP_REMOVE_SELF_LOOPS) && c == static_cast<uint32_t>(r0 + i)) keep = false;
-        if (has_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > eps)) keep = false;
-        const unsigned long long km = __ballot(keep);
-        const uint32_t rank = __popcll(km & lanemask_lt());
-        if (keep) {
-          tmp_c[base + b + rank] = c;
-          if (has_w) tmp_w[base + b + rank] = acc;
-        }
-        if (lane == 0) n_out[r0 + i] = __popcll(km);
+        cr_sort_rows<LPR>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), base, has_w, reduce_op,
+                          flags, eps, tmp_c, tmp_w, n_out + r0 + i);
       }
     }
     rs = re;
@@ -534,27 +585,38 @@ __global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict_
   }
 }
 
-// ------------------------------------------------------------------ K7: one wave per 64 rows, lane per row
-#ifndef TGP_FILL_LANES
-#define TGP_FILL_LANES 16
-#endif
-constexpr int FILL_LANES = TGP_FILL_LANES;
+// ------------------------------------------------------------------ K7: fill
+// One workgroup per FILL_ROWS consecutive rows: their survivors are one contiguous run of the output, so the
+// workgroup walks that run output-parallel (thread t -> output slot o0 + t: fully coalesced stores), finds each
+// slot's row by binary search over the rows' output offsets in LDS, and reads the survivor from the row's
+// compacted run in tmp (contiguous up to the gaps the merge left).
+constexpr int FILL_ROWS = 64;
 __global__ __launch_bounds__(256) void cr_fill_kernel(const uint32_t* __restrict__ tmp_c,
                                                       const float* __restrict__ tmp_w,
                                                       const uint32_t* __restrict__ raw_off,
-                                                      const uint32_t* __restrict__ n_out,
-                                                      const uint32_t* __restrict__ out_off, int64_t K,
+                                                      const uint32_t* __restrict__ out_off,
+                                                      const int64_t* __restrict__ total, int64_t K,
                                                       int64_t* __restrict__ out_row, int64_t* __restrict__ out_col,
                                                       float* __restrict__ out_w) {
-  // a group of FILL_LANES lanes copies one row (rows hold ~E'/K entries): consecutive lanes -> consecutive outputs
-  const int64_t g = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) / FILL_LANES;
-  const int l = threadIdx.x % FILL_LANES;
-  if (g >= K) return;
-  const uint32_t n = n_out[g], src = raw_off[g], dst = out_off[g];
-  for (uint32_t i = l; i < n; i += FILL_LANES) {
-    out_row[dst + i] = g;
-    out_col[dst + i] = tmp_c[src + i];
-    if (out_w) out_w[dst + i] = tmp_w[src + i];
+  __shared__ uint32_t s_out[FILL_ROWS + 1], s_raw[FILL_ROWS];
+  const int tid = threadIdx.x;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * FILL_ROWS;
+  const int nr = static_cast<int>(K - r0 < FILL_ROWS ? K - r0 : FILL_ROWS);
+  if (tid <= nr) s_out[tid] = r0 + tid < K ? out_off[r0 + tid] : static_cast<uint32_t>(*total);
+  if (tid < nr) s_raw[tid] = raw_off[r0 + tid];
+  __syncthreads();
+  const uint32_t o0 = s_out[0], cnt = s_out[nr] - o0;
+  for (uint32_t t = tid; t < cnt; t += 256) {
+    const uint32_t o = o0 + t;
+    int lo = 0, hi = nr;  // last row i with s_out[i] <= o (rows without survivors share their successor's offset)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_out[mid] <= o) lo = mid; else hi = mid;
+    }
+    const uint32_t src = s_raw[lo] + (o - s_out[lo]);
+    out_row[o] = r0 + lo;
+    out_col[o] = tmp_c[src];
+    if (out_w) out_w[o] = tmp_w[src];
   }
 }
 
@@ -635,12 +697,13 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
   cr_layout(ws, E, N, K, &s);
   float* tmp_w = w ? s.tmp_w : nullptr;
   (void)hipMemsetAsync(s.bad, 0, sizeof(int), stream);
-  hipLaunchKernelGGL(cr_check_sorted_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, E, s.bad);
   hipLaunchKernelGGL(cr_node_ptr_kernel, dim3(cdiv(E + 1, 256)), dim3(256), 0, stream, row, E, N, s.bad, s.node_ptr);
   hipLaunchKernelGGL(cr_table_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, cluster_index, N, s.table);
   hipLaunchKernelGGL(cr_row_len_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, assign_row_ptr, assign_perm,
                      s.node_ptr, K, s.bad, s.T, s.member_off);
   device_scan_u32(s.T, K, s.raw_off, s.total, s.scan_scratch, stream);
+  // (measured r2: splitting this into an edge-parallel permute pass + the DIRECT sort kernel costs 114 + 103 us against
+  //  185 us for the fused gather: the 10 M random 4-byte table look-ups take ~50 us wherever they run)
   hipLaunchKernelGGL(cr_segments_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, assign_perm, N, s.table, s.node_ptr,
                      s.member_off, s.raw_off, s.bad, s.seg_src, s.seg_dst);
   hipLaunchKernelGGL(cr_gather_sort_kernel<false>, dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, col, w, E, s.table,
@@ -762,8 +825,8 @@ extern "C" int tgp_connect_coalesce_rows_fill(const void* ws, int64_t E, int64_t
               "tgp_connect_coalesce_rows_fill: null output");
   CrWs s;
   cr_layout(const_cast<void*>(ws), E, N, K, &s);
-  hipLaunchKernelGGL(cr_fill_kernel, dim3(cdiv(K * FILL_LANES, 256)), dim3(256), 0, stream, s.tmp_c,
-                     has_weight ? s.tmp_w : nullptr, s.raw_off, s.n_out, s.out_off, K, out_row, out_col,
+  hipLaunchKernelGGL(cr_fill_kernel, dim3(cdiv(K, FILL_ROWS)), dim3(256), 0, stream, s.tmp_c,
+                     has_weight ? s.tmp_w : nullptr, s.raw_off, s.out_off, s.total, K, out_row, out_col,
                      has_weight ? out_w : nullptr);
   return check_launch("tgp_connect_coalesce_rows_fill");
 }

@@ -166,7 +166,7 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
     L = N.lib()
     eps = ops_eps()
     if (assign_index is not None and assign_index.nnz == cl.numel() and assign_index.num_targets == num_supernodes
-            and num_supernodes < (1 << 26)):
+            and num_supernodes < (1 << 26) and _rows_sorted_memo(edge_index) is not False):
         ws = N.workspace(L.tgp_connect_coalesce_rows_workspace_bytes(E, cl.numel(), num_supernodes), dev)
         d_count = torch.empty(1, dtype=torch.int64, device=dev)
         st = N.stream_ptr(dev)
@@ -184,6 +184,10 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
                     "tgp_connect_coalesce_rows_fill")
             return out_ei, out_w
         del ws  # declined: fall through to the sort-based path
+        if E > 1 and _rows_sorted_memo(edge_index) is None:
+            # remember WHY for this tensor object (one comparison pass, once): an unsorted list skips the row-local
+            # attempt (~50 us + a host round trip) on every later call
+            _rows_sorted(edge_index, row)
     if 65536 < num_supernodes < (1 << 26):
         # more than 32 bits of (row, col) key: sort by supernode row only (half the radix passes) and order the short
         # rows in LDS; declines (count = -1) when a supernode row is too long for that
@@ -391,6 +395,14 @@ def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Te
 
 
 _ROWS_SORTED: dict = {}
+
+
+def _rows_sorted_memo(edge_index: Tensor) -> Optional[bool]:
+    """What is already known about this tensor object: True / False, or None when it has not been looked at."""
+    hit = _ROWS_SORTED.get(id(edge_index))
+    if hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version:
+        return hit[2]
+    return None
 
 
 def _rows_sorted(edge_index: Tensor, row: Tensor) -> bool:
