@@ -306,6 +306,22 @@ int tgp_block_diag_fill(const float* adj_pool, int64_t B, int64_t K, const int64
                         float* out_weight, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * A14  NDPSelect._spectral_partition (select/ndp_select.py:187-256) for every graph of a batch, one workgroup each:
+ *      largest eigenvector of Ls = I - D^-1/2 A D^-1/2 by power iteration (fp64, vectors in LDS), sign partition,
+ *      cut = z^T L z / (2 vol), random +-1 partition (node 0 kept, node 1 dropped, rest from `seed`) when cut < 0.5.
+ *      Input: CSR over all nodes (`indptr` [N+1], `col`, `w` or NULL = ones) of the SYMMETRIC adjacency without self
+ *      loops (the caller symmetrises with max: to_undirected(reduce="max"), ndp_select.py:198-202); `graph_ptr` [B+1].
+ *      Output: keep[v] = 1 for the positive side; info[g] = iterations used, -1 = random fallback;
+ *      *d_status: 0 ok, bit 0 = a graph beyond tgp_ndp_max_graph_nodes() (caller keeps its host route), bit 1 = an
+ *      entry that couples two graphs.
+ * ---------------------------------------------------------------------------------- */
+int tgp_ndp_max_graph_nodes(void);
+int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, const float* w /* NULL ok */, int64_t num_nodes,
+                      int64_t nnz, const int64_t* graph_ptr, int64_t num_graphs, int64_t max_graph_nodes,
+                      uint64_t seed, int max_iter, double tol, uint8_t* keep, int32_t* info, int* d_status,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------
  * A9  KronConnect.forward (connect/kron_conn.py:117-165), block-batched: the batch Laplacian is block diagonal, so
  *     every graph's Kron reduction  L' = L[+,+] - L[+,-] L[-,-]^-1 L[-,+]  is independent.  One workgroup per graph
  *     forms the graph's dense Laplacian in fp64 (LDS up to 128 nodes, a workspace slab up to

@@ -45,6 +45,42 @@ def oracle_kron(ei, ew, n, idx_pos, thr=1e-2):
     return L, O.kron_connect(L, idx_pos, thr)
 
 
+
+def blockwise_kron(ei, ew, batch, idx_pos, thr=1e-2):
+    """The same Kron reduction graph by graph in dense fp64 (mathematically what the reference's whole-batch sparse LU
+    computes on a block-diagonal Laplacian; scipy takes ~70 s on a 2048-graph batch, this takes a second)."""
+    n = batch.numel()
+    sizes = torch.bincount(batch).tolist()
+    keep = torch.zeros(n, dtype=torch.bool)
+    keep[idx_pos] = True
+    rank = torch.cumsum(keep.long(), 0) - keep.long()
+    order = torch.argsort(batch[ei[0]], stable=True)
+    eis, ews = ei[:, order], ew[order].double()
+    ecount = torch.bincount(batch[ei[0]], minlength=len(sizes)).tolist()
+    rows, cols, vals, off, eoff = [], [], [], 0, 0
+    for m, ne in zip(sizes, ecount):
+        e = eis[:, eoff:eoff + ne] - off
+        w = ews[eoff:eoff + ne]
+        nl = e[0] != e[1]
+        A = torch.zeros(m, m, dtype=torch.float64).index_put_((e[0][nl], e[1][nl]), w[nl], accumulate=True)
+        L = torch.diag(A.sum(1)) - A
+        kp = keep[off:off + m]
+        pos, neg = kp.nonzero().view(-1), (~kp).nonzero().view(-1)
+        if pos.numel() > 1:
+            Ln = L[pos][:, pos]
+            if neg.numel():
+                Ln = Ln - L[pos][:, neg] @ torch.linalg.solve(L[neg][:, neg], L[neg][:, pos])
+            a = -Ln
+            a = a * (a.abs() > thr) if thr > 0 else a
+            a.fill_diagonal_(0)
+            nz = a.nonzero()
+            base = int(rank[off])
+            rows.append(nz[:, 0] + base); cols.append(nz[:, 1] + base); vals.append(a[nz[:, 0], nz[:, 1]].float())
+        off += m
+        eoff += ne
+    return torch.stack([torch.cat(rows), torch.cat(cols)]), torch.cat(vals)
+
+
 def so_of(idx_pos, n, dev, L=None):
     from tgp.select import SelectOutput
     k = idx_pos.numel()
@@ -196,8 +232,99 @@ def test_ndp_pooler_2048_graph_batch_connect_stays_on_device(dev, monkeypatch):
     ei_p, ew_p = pool.connect(edge_index=ei.to(dev), so=so, edge_weight=ew.to(dev), batch=batch.to(dev))
     out = pool(x=x.to(dev), adj=ei.to(dev), edge_weight=ew.to(dev), batch=batch.to(dev))  # whole call, fresh selection
     monkeypatch.undo()
-    import tgp_oracle as O
-    ref = O.kron_connect(so.L.astype(np.float64), so.node_index.cpu())
+    ref = blockwise_kron(ei, ew, batch, so.node_index.cpu())
     check(ei_p, ew_p, ref, dev)
     k = out.so.num_supernodes
     assert out.x.shape == (k, 8) and out.batch.numel() == k and int(out.edge_index.max()) < k
+
+
+# ------------------------------------------------------------------------------------------ NDPSelect on the device
+def test_ndp_select_device_partition_contract(dev, monkeypatch):
+    """A14: tgp_ndp_partition vs a dense eigen-decomposition of every graph's Ls.  The reference's partition is only
+    defined up to the eigenvector's sign and lobpcg's tolerance (and is random under the cut < 0.5 rule), so the
+    contract checked per graph is: info >= 0 -> keep is the sign pattern (or its complement) of the largest
+    eigenvector and the partition's cut is >= 0.5; info == -1 -> the eigenvector's cut really is < 0.5 (or the graph
+    has no edges), node 0 is kept and node 1 dropped (ndp_select.py:171-185, 250-252)."""
+    import scipy.sparse.linalg as spla
+    from tgp.select import NDPSelect
+
+    def boom(*a, **k):
+        raise AssertionError("host eigen-solver called: NDPSelect left the device route")
+    monkeypatch.setattr(spla, "eigsh", boom)
+    g = torch.Generator().manual_seed(12)
+    sizes = torch.randint(2, 61, (150,), generator=g).tolist() + [1, 2, 3, 90, 200, 301]
+    ei, ew, batch, _ = make_batch(sizes, seed=33, density=0.15, connected=False)
+    n = batch.numel()
+    so = NDPSelect()(edge_index=ei.to(dev), edge_weight=ew.to(dev), batch=batch.to(dev), num_nodes=n)
+    keep = torch.zeros(n, dtype=torch.bool)
+    keep[so.node_index.cpu()] = True
+    info = so._partition_info.cpu()
+    A = torch.zeros(n, n, dtype=torch.float64)
+    A[ei[0], ei[1]] = ew.double()
+    checked = fallback = 0
+    off = 0
+    for gi, m in enumerate(sizes):
+        a = A[off:off + m, off:off + m]
+        kp = keep[off:off + m]
+        if m == 1:
+            assert bool(kp[0])
+            off += m
+            continue
+        deg = a.sum(1)
+        dis = torch.where(deg > 0, deg.clamp(min=1e-300).rsqrt(), torch.zeros_like(deg))
+        Ls = torch.eye(m, dtype=torch.float64) - dis[:, None] * a * dis[None, :]
+        vals, vecs = torch.linalg.eigh(Ls)
+        v = vecs[:, -1]
+        L = torch.diag(deg) - a
+        vol = float(deg.sum())
+
+        def cut_of(mask):
+            z = torch.where(mask, 1.0, -1.0).double()
+            return float(z @ (L @ z)) / (2 * vol) if vol > 0 else 0.0
+        if int(info[gi]) == -1:
+            fallback += 1
+            assert bool(kp[0]) and not bool(kp[1])
+            if vol > 0 and float(vals[-1] - vals[-2]) > 1e-6 and float(v.abs().min()) > 1e-6:
+                assert cut_of(v >= 0) < 0.5 + 1e-9
+        else:
+            assert cut_of(kp) >= 0.5 - 1e-9
+            if float(vals[-1] - vals[-2]) > 1e-3 and float(v.abs().min()) > 1e-5:
+                checked += 1
+                assert torch.equal(kp, v >= 0) or torch.equal(kp, v < 0), (gi, m)
+        off += m
+    assert checked > 40 and so.num_supernodes == int(keep.sum())
+    # the reference's host-side Laplacian appears on demand and equals get_laplacian of the symmetrised graph
+    import tgp_oracle as O
+    assert so._has_laplacian() and "L" not in so.__dict__
+    Lref = O.laplacian_scipy(ei, ew, n)
+    assert abs(so.L - Lref).max() < 1e-5 and "L" in so.__dict__ and hasattr(so, "L")
+
+
+def test_ndp_pooler_end_to_end_stays_on_device(dev, monkeypatch):
+    """get_pooler("ndp") on a 2048-graph batch: neither the selector's eigen-solver nor the connector's sparse LU is
+    called on the host; Reduce / Connect of the result equal the oracle's for the SelectOutput the pooler produced."""
+    import scipy.sparse.linalg as spla
+    import tgp_oracle as O
+    from tgp.poolers import get_pooler
+
+    def boom(*a, **k):
+        raise AssertionError("host solver called")
+    for name in ("eigsh", "spsolve"):
+        monkeypatch.setattr(spla, name, boom)
+    monkeypatch.setattr(torch.linalg, "solve", boom)
+    g = torch.Generator().manual_seed(3)
+    sizes = torch.randint(20, 61, (2048,), generator=g).tolist()
+    ei, ew, batch, _ = make_batch(sizes, seed=8)
+    n = batch.numel()
+    x = torch.randn(n, 16, generator=g)
+    out = get_pooler("ndp").to(dev)(x=x.to(dev), adj=ei.to(dev), edge_weight=ew.to(dev), batch=batch.to(dev))
+    monkeypatch.undo()
+    so = out.so
+    idx = so.node_index.cpu()
+    assert torch.equal(out.x.cpu(), x[idx]) and torch.equal(out.batch.cpu(), batch[idx])
+    ref = blockwise_kron(ei, ew, batch, idx)
+    check(out.edge_index, out.edge_weight, ref, dev)
+    # 2-level precoarsening through the same route
+    levels = get_pooler("ndp").to(dev).multi_level_precoarsening(levels=2, edge_index=ei.to(dev), edge_weight=ew.to(dev),
+                                                                 batch=batch.to(dev), num_nodes=n)
+    assert len(levels) == 2 and levels[1].so.num_nodes == levels[0].so.num_supernodes

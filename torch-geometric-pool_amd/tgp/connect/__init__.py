@@ -325,6 +325,11 @@ class KronConnect(Connect):
             ptr, max_nodes = torch.tensor([0, n], dtype=torch.long, device=dev), n
         if max_nodes > K.kron_max_graph_nodes():
             return None
+        adj_csr = so.__dict__.get("_adj_device_csr")
+        if has_laplacian and adj_csr is not None and adj_csr[0].device == dev and adj_csr[0].numel() == n + 1:
+            # NDPSelect's device route left the symmetrised adjacency on the GPU: L = D - A is formed in the kernel
+            return K.kron_batched(adj_csr[0], adj_csr[1], adj_csr[2], None, True, n, ptr, max_nodes, idx_pos,
+                                  self.sparse_threshold)
         if has_laplacian:
             indptr, col, val = self._laplacian_csr_on_device(so, dev)
             if indptr.numel() != n + 1:
@@ -380,7 +385,7 @@ class KronConnect(Connect):
         edge_index, edge_weight = connectivity_to_edge_index(edge_index, edge_weight)
         device = edge_index.device
         n = so.num_nodes
-        has_laplacian = hasattr(so, "L")
+        has_laplacian = so._has_laplacian() if hasattr(so, "_has_laplacian") else hasattr(so, "L")
         if has_laplacian:
             idx_pos_t = so.node_index
         else:

@@ -594,6 +594,32 @@ def spmm_sorted(edge_index: Tensor, edge_weight: Optional[Tensor], num_rows: int
     return out
 
 
+# ------------------------------------------------------------------------- A14 (NDP)
+def ndp_max_graph_nodes() -> int:
+    return int(N.lib().tgp_ndp_max_graph_nodes())
+
+
+def ndp_partition(indptr: Tensor, col: Tensor, weight: Optional[Tensor], num_nodes: int, graph_ptr: Tensor,
+                  max_graph_nodes: int, seed: int, max_iter: int = 4000, tol: float = 1e-9):
+    """(keep [N] bool, info [B] int32, status int): NDPSelect's per-graph spectral +-1 partition
+    (select/ndp_select.py:187-256) on a symmetric, self-loop-free CSR adjacency.  info[g] = power iterations used, -1 =
+    the reference's random fallback (cut < 0.5); status != 0: declined, see include/tgp_hip.h."""
+    dev = N.require_device(indptr, col, weight, graph_ptr)
+    if indptr.dtype != torch.int32:
+        raise ValueError("ndp_partition: indptr must be int32")
+    col, graph_ptr = N.i64c(col), N.i64c(graph_ptr)
+    w = None if weight is None else N.f32c(weight.reshape(-1))
+    B = graph_ptr.numel() - 1
+    keep = torch.empty(max(num_nodes, 1), dtype=torch.uint8, device=dev)
+    info = torch.empty(max(B, 1), dtype=torch.int32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    N.check(N.lib().tgp_ndp_partition(N.ptr(indptr.contiguous()), N.ptr(col), N.ptr(w), num_nodes, col.numel(),
+                                      N.ptr(graph_ptr), B, max_graph_nodes, int(seed) & ((1 << 64) - 1), max_iter,
+                                      float(tol), N.ptr(keep), N.ptr(info), N.ptr(status), N.stream_ptr(dev)),
+            "tgp_ndp_partition")
+    return keep[:num_nodes].bool(), info[:B], status
+
+
 # ------------------------------------------------------------------------- A9
 def kron_max_graph_nodes() -> int:
     return int(N.lib().tgp_kron_batched_max_graph_nodes())

@@ -124,6 +124,21 @@ class SelectOutput:
         # the dense kernels stop at a graph's real size instead of the padded one
         self._graph_sizes = None
 
+    # ---- lazily materialised extra attribute ------------------------------------------
+    def __getattr__(self, name):
+        # only reached when normal lookup fails.  NDPSelect's device path keeps the Laplacian on the GPU; the
+        # reference's host-side scipy ``so.L`` (select/ndp_select.py:146-152) is built the first time it is asked for
+        if name == "L":
+            factory = self.__dict__.get("_L_factory")
+            if factory is not None:
+                value = factory()
+                self.__dict__["L"] = value
+                return value
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
+    def _has_laplacian(self) -> bool:
+        return "L" in self.__dict__ or self.__dict__.get("_L_factory") is not None
+
     # ---- validation / derived views -------------------------------------------------
     def _validate_in_mask(self, in_mask: Optional[Tensor]) -> Optional[Tensor]:
         if in_mask is None:
@@ -269,7 +284,7 @@ class SelectOutput:
         elif self._s_inv is not None:
             self._s_inv = func(self._s_inv)
         for name in self._extra_args:
-            if hasattr(self, name):
+            if name in self.__dict__:  # (a lazily built attribute that was never asked for stays lazy)
                 setattr(self, name, self._apply_to_value(getattr(self, name), func))
         self._drop_caches()
         return self
@@ -647,6 +662,10 @@ class NDPSelect(Select):
             num_nodes = maybe_num_nodes(edge_index)
         edge_index, edge_weight = connectivity_to_edge_index(edge_index, edge_weight)
         dev = edge_index.device
+        if dev.type == "cuda" and num_nodes > 0:
+            so = self._forward_device(edge_index, edge_weight, batch, num_nodes)
+            if so is not None:
+                return so
         ei = edge_index.cpu().numpy()
         w = np.ones(ei.shape[1], dtype=np.float64) if edge_weight is None else \
             edge_weight.detach().cpu().numpy().astype(np.float64).reshape(-1)
@@ -698,6 +717,56 @@ class NDPSelect(Select):
         so = SelectOutput(s=s, s_inv_op=self.s_inv_op, L=L.astype(np.float32))
         so._set_one_to_one_index()
         so._node_batch = batch  # the partition KronConnect's block-batched kernel works on
+        return so
+
+    def _forward_device(self, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Optional[Tensor],
+                        num_nodes: int) -> Optional[SelectOutput]:
+        """The whole selection on the GPU (tgp_ndp_partition: one workgroup per graph); None when the batch has a
+        graph beyond the kernel's size limit or an unsorted batch vector (the host route below then runs)."""
+        from .. import kernels as K
+        from ..utils.ops import batch_info
+        dev = edge_index.device
+        n = num_nodes
+        if batch is not None and batch.numel() == n:
+            info = batch_info(batch)
+            if not info.is_sorted:
+                return None
+            ptr, max_nodes = info.ptr, info.max_nodes
+        else:
+            ptr, max_nodes = torch.tensor([0, n], dtype=torch.long, device=dev), n
+        if max_nodes > K.ndp_max_graph_nodes():
+            return None
+        ident = torch.arange(n, device=dev)
+        w0 = torch.ones(edge_index.size(1), device=dev) if edge_weight is None else edge_weight.detach().reshape(-1).float()
+        # self loops out, duplicates summed (get_laplacian + COO -> CSR), then max with the transpose
+        # (to_undirected(reduce="max"), ndp_select.py:198-202): a row-sorted, symmetric, coalesced list
+        ei1, w1 = K.coalesce_edges(edge_index, w0, ident, n, "sum", remove_self_loops=True, eps_filter=False)
+        ei2, w2 = K.coalesce_edges(torch.cat([ei1, ei1.flip(0)], 1), torch.cat([w1, w1]), ident, n, "max",
+                                   remove_self_loops=False, eps_filter=False)
+        indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        K.rowptr_from_sorted(ei2[0], n, indptr)
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        keep, part_info, status = K.ndp_partition(indptr, ei2[1], w2, n, ptr, max_nodes, seed)
+        idx_pos = keep.nonzero().view(-1)  # (host round trip: the size of S; also orders the status read below)
+        if int(status.item()) != 0:
+            return None
+        k = idx_pos.numel()
+        s = torch.sparse_coo_tensor(torch.stack([idx_pos, torch.arange(k, device=dev)]), torch.ones(k, device=dev),
+                                    size=(n, k), is_coalesced=True)
+        so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
+        so._extra_args.add("L")
+
+        def laplacian_on_host():  # the reference's so.L: scipy CSR, float32 (ndp_select.py:254-255)
+            import numpy as np
+            import scipy.sparse as sp
+            r, c, w = ei2[0].cpu().numpy(), ei2[1].cpu().numpy(), w2.cpu().numpy().astype(np.float64)
+            A = sp.coo_matrix((w, (r, c)), shape=(n, n)).tocsr()
+            return (sp.diags(np.asarray(A.sum(1)).reshape(-1)) - A).tocsr().astype(np.float32)
+        so.__dict__["_L_factory"] = laplacian_on_host
+        so._adj_device_csr = (indptr, ei2[1], w2)  # KronConnect's kernel forms L = D - A from these directly
+        so._partition_info = part_info
+        so._set_one_to_one_index()
+        so._node_batch = batch
         return so
 
     def __repr__(self) -> str:
