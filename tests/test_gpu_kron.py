@@ -49,6 +49,15 @@ def oracle_kron(ei, ew, n, idx_pos, thr=1e-2):
 def blockwise_kron(ei, ew, batch, idx_pos, thr=1e-2):
     """The same Kron reduction graph by graph in dense fp64 (mathematically what the reference's whole-batch sparse LU
     computes on a block-diagonal Laplacian; scipy takes ~70 s on a 2048-graph batch, this takes a second)."""
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)  # thousands of 40 x 40 solves: a 128-thread pool costs more than the arithmetic
+    try:
+        return _blockwise_kron(ei, ew, batch, idx_pos, thr)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _blockwise_kron(ei, ew, batch, idx_pos, thr):
     n = batch.numel()
     sizes = torch.bincount(batch).tolist()
     keep = torch.zeros(n, dtype=torch.bool)
