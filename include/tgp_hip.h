@@ -289,6 +289,11 @@ int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K
 int tgp_to_dense_adj_f32(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL = ones */,
                          int64_t num_edges, const int64_t* batch, const int64_t* ptr, int64_t B, int64_t Nmax,
                          int transposed, float* adj, void* stream);
+/* inverse gather of tgp_to_dense_adj_f32 (its backward w.r.t. the edge weights, which the reference gets from ATen
+ * autograd over PyG's scatter, src.py:434): grad_weight[e] = grad_adj[slot of e], 0 for dropped entries */
+int tgp_from_dense_adj_f32(const float* grad_adj, const int64_t* row, const int64_t* col, int64_t num_edges,
+                           const int64_t* batch, const int64_t* ptr, int64_t B, int64_t Nmax, int transposed,
+                           float* grad_weight, void* stream);
 /* inverse gather of tgp_to_dense_batch_f32 (its backward): x[i,:] = dense[batch[i], i - ptr[batch[i]], :] */
 int tgp_from_dense_batch_f32(const float* dense, int64_t N, int64_t F, const int64_t* batch, const int64_t* ptr,
                              int64_t B, int64_t Nmax, float* x, void* stream);

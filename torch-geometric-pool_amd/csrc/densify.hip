@@ -24,6 +24,25 @@ __global__ __launch_bounds__(256) void dense_adj_kernel(const int64_t* __restric
   atomicAdd(adj + o, w ? w[e] : 1.0f);
 }
 
+// The inverse gather (backward of to_dense_adj w.r.t. the edge weights): dw[e] = g[b, r, c] at the slot edge e was
+// added to; 0 for entries a caller-imposed max_num_nodes dropped.  Duplicates each receive the slot's gradient.
+__global__ __launch_bounds__(256) void from_dense_adj_kernel(const float* __restrict__ g, const int64_t* __restrict__ row,
+                                                             const int64_t* __restrict__ col, int64_t E,
+                                                             const int64_t* __restrict__ batch,
+                                                             const int64_t* __restrict__ ptr, int64_t Nmax,
+                                                             int transposed, float* __restrict__ dw) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int64_t r = row[e], c = col[e];
+  const int64_t b = batch[r];
+  const int64_t lr = r - ptr[b], lc = c - ptr[batch[c]];
+  if (lr >= Nmax || lc >= Nmax) {
+    dw[e] = 0.f;
+    return;
+  }
+  dw[e] = g[transposed ? (b * Nmax + lc) * Nmax + lr : (b * Nmax + lr) * Nmax + lc];
+}
+
 __global__ __launch_bounds__(256) void dense_batch_kernel(const float* __restrict__ x, int64_t N, int64_t F,
                                                           const int64_t* __restrict__ batch,
                                                           const int64_t* __restrict__ ptr, int64_t Nmax,
@@ -90,6 +109,19 @@ extern "C" int tgp_to_dense_batch_f32(const float* x, int64_t N, int64_t F, cons
                        ptr, Nmax, out, mask);
   }
   return check_launch("tgp_to_dense_batch_f32");
+}
+
+extern "C" int tgp_from_dense_adj_f32(const float* grad_adj, const int64_t* row, const int64_t* col, int64_t E,
+                                      const int64_t* batch, const int64_t* ptr, int64_t B, int64_t Nmax,
+                                      int transposed, float* grad_weight, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E >= 0 && B >= 0 && Nmax >= 0, TGP_ERR_INVALID, "tgp_from_dense_adj_f32: negative size");
+  if (E == 0) return TGP_OK;
+  TGP_REQUIRE(grad_adj && row && col && batch && ptr && grad_weight, TGP_ERR_INVALID,
+              "tgp_from_dense_adj_f32: null pointer");
+  hipLaunchKernelGGL(from_dense_adj_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, grad_adj, row, col, E, batch, ptr,
+                     Nmax, transposed, grad_weight);
+  return check_launch("tgp_from_dense_adj_f32");
 }
 
 extern "C" int tgp_from_dense_batch_f32(const float* dense, int64_t N, int64_t F, const int64_t* batch,

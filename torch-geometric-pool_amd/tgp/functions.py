@@ -357,6 +357,30 @@ def to_dense_batch(x: Tensor, batch: Tensor, ptr: Tensor, num_graphs: int, max_n
     return K.to_dense_batch(x, batch, ptr, num_graphs, max_nodes)
 
 
+class _ToDenseAdjFn(torch.autograd.Function):
+    """to_dense_adj (src.py:434-443) with the native scatter-add forward; the gradient of the edge weights is the
+    matching gather (the reference gets it from ATen autograd over PyG's scatter)."""
+
+    @staticmethod
+    def forward(ctx, edge_weight, edge_index, batch, ptr, num_graphs, max_nodes, transposed):
+        ctx.save_for_backward(edge_index, batch, ptr)
+        ctx.max_nodes, ctx.transposed, ctx.shape = max_nodes, transposed, edge_weight.shape
+        return K.to_dense_adj(edge_index, edge_weight, batch, ptr, num_graphs, max_nodes, transposed)
+
+    @staticmethod
+    def backward(ctx, g):
+        edge_index, batch, ptr = ctx.saved_tensors
+        gw = K.from_dense_adj(g.contiguous(), edge_index, batch, ptr, ctx.max_nodes, ctx.transposed)
+        return gw.view(ctx.shape), None, None, None, None, None, None
+
+
+def to_dense_adj(edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor, ptr: Tensor, num_graphs: int,
+                 max_nodes: int, transposed: bool) -> Tensor:
+    if _needs_grad(edge_weight):
+        return _ToDenseAdjFn.apply(edge_weight, edge_index, batch, ptr, num_graphs, max_nodes, transposed)
+    return K.to_dense_adj(edge_index, edge_weight, batch, ptr, num_graphs, max_nodes, transposed)
+
+
 # ---------------------------------------------------------------------------------------- Linear layer
 _WHOLE_RANGE: dict = {}
 

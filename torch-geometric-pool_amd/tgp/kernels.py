@@ -704,6 +704,20 @@ def to_dense_adj(edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tenso
     return adj
 
 
+def from_dense_adj(grad_adj: Tensor, edge_index: Tensor, batch: Tensor, ptr: Tensor, max_nodes: int,
+                   transposed: bool) -> Tensor:
+    """grad of :func:`to_dense_adj` w.r.t. the edge weights: one gather kernel."""
+    dev = N.require_device(grad_adj, edge_index, batch, ptr)
+    row, col = _edge_rows(edge_index)
+    g = N.f32c(grad_adj)
+    batch, ptr = N.i64c(batch), N.i64c(ptr)
+    out = torch.empty(row.numel(), dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_from_dense_adj_f32(N.ptr(g), N.ptr(row), N.ptr(col), row.numel(), N.ptr(batch), N.ptr(ptr),
+                                           g.size(0), max_nodes, 1 if transposed else 0, N.ptr(out),
+                                           N.stream_ptr(dev)), "tgp_from_dense_adj_f32")
+    return out
+
+
 def from_dense_batch(dense: Tensor, batch: Tensor, ptr: Tensor, max_nodes: int) -> Tensor:
     """[B,Nmax,F] -> [N,F]: the rows that to_dense_batch scattered, gathered back (its backward)."""
     dev = N.require_device(dense, batch, ptr)

@@ -214,10 +214,11 @@ def to_dense_adj(edge_index: Tensor, batch: Optional[Tensor] = None, edge_attr: 
     if batch_size is None:
         batch_size = num_graphs_of(batch)
     sizes, ptr = graph_ptr(batch, batch_size)
-    if (edge_index.is_cuda and (edge_attr is None or (edge_attr.dim() == 1 and edge_attr.dtype == torch.float32
-                                                      and not (torch.is_grad_enabled() and edge_attr.requires_grad)))):
+    if edge_index.is_cuda and (edge_attr is None or (edge_attr.dim() == 1 and edge_attr.dtype == torch.float32)):
         nmax = max_num_nodes if max_num_nodes is not None else max_graph_size(batch)
-        return K.to_dense_adj(edge_index, edge_attr, batch, ptr, batch_size, nmax, transposed)  # one HIP kernel
+        # one HIP kernel; differentiable w.r.t. the edge weights through the matching gather kernel
+        return Fn.to_dense_adj(edge_index, edge_attr, batch, ptr, batch_size, nmax, transposed)
+    # what is left for the torch form below: host tensors (CPU-side data preparation) and multi-channel edge attributes
     g = batch[edge_index[0]]
     r = edge_index[0] - ptr[g]
     c = edge_index[1] - ptr[batch[edge_index[1]]]
