@@ -110,8 +110,12 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
     SmallArgs q{S, want_a ? A : nullptr, want_x ? X : nullptr, static_cast<int>(B), static_cast<int>(N),
                 static_cast<int>(K), static_cast<int>(F), flags, eps, want_x ? x_pool : nullptr,
                 want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr};
-    const int grid = static_cast<int>((B + 3) / 4);
-    hipLaunchKernelGGL(dense_pool_small_kernel, dim3(grid), dim3(256), 4 * SG_WAVE_FLOATS * sizeof(float), stream, q);
+    const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(SG_WAVES * SG_WAVE_FLOATS * sizeof(float)));
+    hipLaunchKernelGGL(dense_pool_small_kernel, dim3(grid), dim3(64 * SG_WAVES),
+                       SG_WAVES * SG_WAVE_FLOATS * sizeof(float), stream, q);
     return check_launch("tgp_dense_pool_f32(small)");
   }
   // One workgroup per graph while S and the K x K result fit LDS (measured faster than the tiled path from 8 graphs

@@ -40,22 +40,38 @@ __device__ __forceinline__ const float* byte_off(const float* base, int bytes) {
 #define TGP_WSTAMP(slot)                                                                                  \
   do {                                                                                                    \
     if (g_gemm_stamps && lane_id() == 0)                                                                  \
-      g_gemm_stamps[static_cast<long>(blockIdx.x * 4 + wave_id()) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+      g_gemm_stamps[static_cast<long>(blockIdx.x * 8 + wave_id()) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
 #define TGP_WSTAMP(slot) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
+// Workgroup = 8 waves = 8 graphs.  Waves w and w + 4 share a SIMD (a workgroup's waves are dealt to the SIMDs
+// cyclically).  Waves 4-7 queue their load requests BEHIND those of waves 0-3 (an LDS counter the first group bumps
+// once its loads are issued), so that the first group's operands land first and its MFMA phases overlap the tail of
+// the second group's loads.  Measured (r2 stamps): a wave cannot keep more than ~3.8 GB/s of these loads in flight and
+// a CU needs ~7 loading waves to reach its ~26 GB/s, so with 8 resident waves (187 VGPRs) the overlap is small:
+// 22.0 -> 21.3 us.  Real overlap needs 16 lighter waves per CU (two waves per graph); see DESIGN.md known gaps.
+constexpr int SG_WAVES = 8;
+__global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(SmallArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_issued;
   const int lane = lane_id();
   const int w = __builtin_amdgcn_readfirstlane(wave_id());  // wave-uniform => graph bases stay in SGPRs
   const int lm = lane & 31, lk = lane >> 5;
   float* As = smem + w * SG_WAVE_FLOATS;
   const int N = p.N, K = p.K, F = p.F;
   const bool at = p.flags & TGP_ADJ_TRANSPOSED;
-  const int b = blockIdx.x * 4 + w;  // one graph per wave, no loop (keeps the 64 + 64 load offsets transient)
+  const int b = blockIdx.x * SG_WAVES + w;  // one graph per wave, no loop (keeps the 64 + 64 load offsets transient)
+  if (threadIdx.x == 0) s_issued = 0;
+  __syncthreads();
   if (b >= p.B) return;
+  if (w >= SG_WAVES / 2) {  // second group: wait until the first group's requests are in the queue
+    int first = p.B - static_cast<int>(blockIdx.x) * SG_WAVES;
+    first = first < SG_WAVES / 2 ? first : SG_WAVES / 2;
+    while (__hip_atomic_load(&s_issued, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < first)
+      __builtin_amdgcn_s_sleep(2);
+  }
   TGP_WSTAMP(0);
   {
     // ---- request everything up front: A (float4 rows), then S and X in operand order ------------
@@ -105,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void dense_pool_small_kernel(SmallArgs p) {
         xr[q] = ok ? r : 0.f;
       }
     }
+    if (w < SG_WAVES / 2 && lane == 0) atomicAdd(&s_issued, 1);  // this wave's loads are all issued
     if (p.A) {
       const int q = lane & 15;
 #pragma unroll
