@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch one hot kernel repeatedly (for rocprofv3 --pmc / --kernel-trace runs).
-usage: python tools/run_kernel.py {gemm_c2|gemm_c5|reduce_topk|coalesce_c4} [reps]"""
+usage: python tools/run_kernel.py {gemm_c2|gemm_c5|reduce_topk|coalesce_c4|coalesce_c4_sorted|subgraph_topk|c3} [reps]"""
 import os
 import sys
 
@@ -43,5 +43,43 @@ elif which == "coalesce_c4":
     cluster[pair] = torch.arange(n, device=dev) // 2
     for _ in range(reps):
         kernels.coalesce_edges(ei, ew, cluster, n // 2, "sum", True)
+elif which == "coalesce_c4_sorted":  # bench.py's c4_graclus Connect: row-sorted edges, Graclus assignment, index cached
+    from tgp.connect import SparseConnect
+    from tgp.select import GraclusSelect
+    n = 1_000_000
+    a = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    b = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+    ei = ei[:, torch.argsort(ei[0] * n + ei[1])].contiguous()
+    ew = torch.ones(ei.size(1), device=dev)
+    so = GraclusSelect()(ei, ew, num_nodes=n)
+    conn = SparseConnect()
+    for _ in range(reps):
+        conn(ei, so, edge_weight=ew)
+elif which == "subgraph_topk":
+    from tgp.connect import SparseConnect
+    n = 1_000_000
+    a = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    b = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+    ei = ei[:, torch.argsort(ei[0] * n + ei[1])].contiguous()
+    ew = torch.ones(ei.size(1), device=dev)
+    kept = torch.sort(torch.randperm(n, device=dev, generator=g)[: n // 2])[0]
+    so = SelectOutput(node_index=kept, num_nodes=n, cluster_index=torch.arange(kept.numel(), device=dev),
+                      num_supernodes=kept.numel())
+    conn = SparseConnect()
+    for _ in range(reps):
+        conn(ei, so, edge_weight=ew)
+elif which == "c3":
+    B, N, K, F = 2048, 60, 20, 32
+    S = torch.softmax(torch.randn(B, N, K, device=dev, generator=g), -1)
+    A = (torch.rand(B, N, N, device=dev, generator=g) < 0.1).float()
+    X = torch.randn(B, N, F, device=dev, generator=g)
+    for _ in range(reps):
+        kernels.dense_pool(S, A, X, kernels.dense_flags(True, True, True, False), want_raw=True)
 torch.cuda.synchronize()
 print("done", which, reps)
