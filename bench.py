@@ -26,6 +26,7 @@ Rank 0 prints ONE JSON line:
 `--workload X` makes X the headline of the line instead; the driver's line is the default c2.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -230,6 +231,10 @@ class DenseDiffPool(Workload):
             if self.unfused:
                 x_pool, _ = self.reducer(self.X, self.so)
                 adj_pool, _ = self.connector(self.A, self.so)
+            elif self.gather is not None:
+                # the kernels write the pooled outputs straight into the next slot of the all-gather send buffer
+                ox, oa = self.gather.slots([(self.B, self.K, self.F), (self.B, self.K, self.K)], device=self.S.device)
+                x_pool, _, adj_pool = self.pool.reduce_connect(self.X, self.A, self.so, out_x=ox, out_adj=oa)
             else:
                 x_pool, _, adj_pool = self.pool.reduce_connect(self.X, self.A, self.so)
             if self.gather is not None:
@@ -571,8 +576,20 @@ def main():
     wl = make_workload(args.workload, ctx, args)
     if world > 1 and not wl.shards:
         raise SystemExit(f"workload {args.workload} is single-GPU (one giant graph does not shard: replicas only)")
+    for _ in range(2):  # the barrier's own first calls set up RCCL state: not part of any step
+        ctx.barrier()
+        ctx.sync()
+    wl.step()
+    # CPython's generation-2 collection takes ~40 ms with torch imported and lands in whichever window crosses the
+    # allocation threshold (seen: a 20-step window of 2.4 ms reported as 42 ms); collect now, keep start-up objects
+    # out of later passes (tgp.freeze_gc()).  Done BEFORE the warm-up steps so that the timed window
+    # follows them without a host-side pause in which the GPU would clock down.
+    gc.collect()
+    gc.freeze()
     for _ in range(args.warmup):
         wl.step()
+    if wl.drain is not None:
+        wl.drain()  # warm-up ends with an empty gather bucket, its collective done (communicator set-up is not a step)
     dt = timed_window(ctx, wl.step, args.steps, wl.drain)  # THE contract window: exactly --steps steps
     win = median_windows(ctx, wl.step, wl.drain, steps=max(WINDOW_STEPS if args.workload != "c5" else 50, 1))
     roofs = wl.rooflines(dev)

@@ -74,6 +74,20 @@ def _worker(rank, world, port, out_dir):
         bucket_ok = len(handed) == 5 and all(
             torch.allclose(h[0], pxp * (j + 1)) and torch.allclose(h[1], pap * (j + 1)) for j, h in enumerate(handed))
         assert pb.flush() == [] and pb.wait() is None
+        # in-place mode: the producer writes into the slots the gather hands out (what bench.py does with the
+        # kernels' out_x / out_adj); no pack copy, same results
+        pi = D.PackedGather(bucket_steps=2)
+        inplace = []
+        for j in range(3):
+            sx, sa = pi.slots([xp[:2].shape, ap[:2].shape], dtype=xp.dtype, device=xp.device)
+            sx.copy_(xp[:2] * (j + 1))
+            sa.copy_(ap[:2] * (j + 1))
+            ptrs = (sx.data_ptr(), sa.data_ptr())
+            pi.start([sx, sa])
+            assert (sx.data_ptr(), sa.data_ptr()) == ptrs
+        inplace.extend(pi.flush())
+        bucket_ok = bucket_ok and len(inplace) == 3 and all(
+            torch.allclose(h[0], pxp * (j + 1)) and torch.allclose(h[1], pap * (j + 1)) for j, h in enumerate(inplace))
         if rank == 0:
             torch.save(dict(gx=gx, gei=gei, gew=gew, gb=gb, gxp=gxp, gap=gap, pxp=pxp, pap=pap,
                             bucket_ok=torch.tensor(bucket_ok)),

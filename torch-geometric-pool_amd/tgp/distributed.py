@@ -55,19 +55,21 @@ def _world(group=None) -> int:
 
 
 class PackedGather:
-    """RCCL all-gather of fixed-shape pooled outputs, packed and bucketed.
+    """RCCL all-gather of fixed-shape pooled outputs, bucketed, without pack copies.
 
-    Every step's per-graph tensors ([B,K,F], [B,K,K], ...) are packed into one [B, total] row block; the blocks
-    of ``bucket_steps`` consecutive steps share one send buffer and go out as ONE ``all_gather_into_tensor``
-    (fewer, larger collectives: at 8 GPUs a 3 MB-per-rank gather is latency-bound on xGMI, four steps' worth is
-    not).  The collective is asynchronous on RCCL's own stream, so it overlaps the next steps' kernels; at most
-    one is in flight, and the send buffers are double-buffered so packing never waits for it.  Every rank must
-    hold the same number of graphs.
+    The per-graph tensors of a step ([B,K,F], [B,K,K], ...) live in one flat send buffer, every tensor a contiguous
+    slice of its step's region; the regions of ``bucket_steps`` consecutive steps go out as ONE
+    ``all_gather_into_tensor`` (fewer, larger collectives: at 8 GPUs a 3 MB-per-rank gather is latency-bound on xGMI,
+    four steps' worth is not).  ``slots(shapes)`` hands out the next step's slices so that the pooling kernels write
+    their outputs straight into the send buffer (``DenseSRCPooling.reduce_connect(out_x=, out_adj=)``); ``start``
+    then only books the step (tensors that are not those slices are copied in).  The collective is asynchronous on
+    RCCL's own stream, so it overlaps the next steps' kernels; at most one is in flight and the send buffers are
+    double-buffered, so a step never waits for it.  Every rank must hold the same number of graphs.
 
     ``start(tensors)`` once per step; ``take_ready()`` -> finished results without waiting; ``wait()`` -> also
     waits for the collective in flight; ``flush()`` -> sends a partly filled bucket and returns everything not
-    yet handed out.  A result is the list
-    of gathered tensors of one step; with ``bucket_steps == 1`` ``wait()`` returns that list directly."""
+    yet handed out.  A result is the list of gathered tensors of one step (rank-major along the graph dimension, like
+    ``torch.cat`` of the shards); with ``bucket_steps == 1`` ``wait()`` returns that list directly."""
 
     def __init__(self, group=None, bucket_steps: int = 1, force_collective: bool = False):
         if bucket_steps < 1:
@@ -79,72 +81,92 @@ class PackedGather:
         self._collective = self.world > 1 or (dist.is_available() and dist.is_initialized()
                                               and (force_collective or bool(os.environ.get("TGP_FORCE_COLLECTIVE"))))
         self.bucket = bucket_steps
-        self._send = [None, None]   # double-buffered [bucket, B, total]
+        self._send = [None, None]   # double-buffered flat [bucket * per_step]
         self._cur = 0
         self._fill = 0
-        self._shapes = None
-        self._pending = None        # (work, out, nsteps, shapes)
+        self._shapes = None         # full shapes [B, ...] of one step's tensors
+        self._per_step = 0
+        self._pending = None        # (work, out, nsteps, shapes, per_step)
         self._ready: List[List[Tensor]] = []
 
-    def _unpack(self, out: Tensor, nsteps: int, shapes) -> List[List[Tensor]]:
-        # out: [world, nsteps, B, total]
+    # ---- layout ---------------------------------------------------------------------------------
+    def _ensure(self, shapes, dtype, device) -> None:
+        shapes = [tuple(int(d) for d in shp) for shp in shapes]
+        per_step = 0
+        for shp in shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            per_step += n
+        buf = self._send[self._cur]
+        if (buf is None or self._shapes != shapes or buf.dtype != dtype or buf.device != device):
+            if self._fill:
+                raise ValueError("PackedGather: shapes changed inside an open bucket")
+            self._collect()  # nothing of the old layout may still be in flight
+            self._send = [torch.empty(self.bucket * per_step, dtype=dtype, device=device) for _ in range(2)]
+            self._shapes, self._per_step = shapes, per_step
+
+    def _views(self, flat: Tensor, step: int, lead=None) -> List[Tensor]:
+        out, off = [], step * self._per_step
+        for shp in self._shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            out.append(flat[off: off + n].view(shp))
+            off += n
+        return out
+
+    def slots(self, shapes, dtype=torch.float32, device=None) -> List[Tensor]:
+        """Contiguous views of the NEXT step's region of the send buffer, one per tensor shape [B, ...]: write the
+        step's outputs there, then call ``start`` with exactly these tensors."""
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu"
+        self._ensure(shapes, dtype, torch.device(device))
+        return self._views(self._send[self._cur], self._fill)
+
+    # ---- collective -----------------------------------------------------------------------------
+    def _unpack(self, out: Tensor, nsteps: int, shapes, per_step: int) -> List[List[Tensor]]:
+        # out: [world, nsteps * per_step]
         res = []
         for j in range(nsteps):
-            block = out[:, j].reshape(-1, out.size(-1))  # [world * B, total], rank-major like torch.cat of shards
-            tensors, col = [], 0
+            tensors, off = [], j * per_step
             for shp in shapes:
                 n = 1
                 for d in shp:
                     n *= d
-                tensors.append(block[:, col: col + n].reshape((block.size(0),) + shp))
-                col += n
+                tensors.append(out[:, off: off + n].reshape((out.size(0) * shp[0],) + tuple(shp[1:])))
+                off += n
             res.append(tensors)
         return res
 
     def _collect(self) -> None:
         if self._pending is None:
             return
-        work, out, nsteps, shapes = self._pending
+        work, out, nsteps, shapes, per_step = self._pending
         self._pending = None
         if work is not None:
             work.wait()
-        self._ready.extend(self._unpack(out, nsteps, shapes))
+        self._ready.extend(self._unpack(out, nsteps, shapes, per_step))
 
     def _launch(self) -> None:
         self._collect()  # at most one collective in flight; its send buffer becomes free here
         n = self._fill
-        send = self._send[self._cur][:n]
-        out = torch.empty((self.world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+        send = self._send[self._cur][: n * self._per_step]
+        out = torch.empty((self.world, send.numel()), dtype=send.dtype, device=send.device)
         work = None
         if self._collective:
-            work = dist.all_gather_into_tensor(out.view(self.world * n * send.size(1), send.size(2)),
-                                               send.reshape(n * send.size(1), send.size(2)), group=self.group,
-                                               async_op=True)
+            work = dist.all_gather_into_tensor(out.view(-1), send, group=self.group, async_op=True)
         else:
             out[0].copy_(send)
-        self._pending = (work, out, n, self._shapes)
+        self._pending = (work, out, n, self._shapes, self._per_step)
         self._cur ^= 1
         self._fill = 0
 
     def start(self, tensors: Sequence[Tensor]) -> None:
-        b = tensors[0].size(0)
-        shapes = [tuple(t.shape[1:]) for t in tensors]
-        total = sum(int(t[0].numel()) if b else 0 for t in tensors)
-        buf = self._send[self._cur]
-        if buf is None or buf.size(1) != b or buf.size(2) != total or buf.dtype != tensors[0].dtype \
-                or buf.device != tensors[0].device:
-            if self._fill:
-                raise ValueError("PackedGather: shapes changed inside an open bucket")
-            self._send = [torch.empty((self.bucket, b, total), dtype=tensors[0].dtype, device=tensors[0].device)
-                          for _ in range(2)]
-            buf = self._send[self._cur]
-        self._shapes = shapes
-        col = 0
-        row = buf[self._fill]
-        for t in tensors:
-            n = int(t[0].numel()) if b else 0
-            row[:, col: col + n].copy_(t.reshape(b, -1))
-            col += n
+        self._ensure([t.shape for t in tensors], tensors[0].dtype, tensors[0].device)
+        for dst, t in zip(self._views(self._send[self._cur], self._fill), tensors):
+            if t.data_ptr() != dst.data_ptr() or not t.is_contiguous():
+                dst.copy_(t)  # not produced in place: pack
         self._fill += 1
         if self._fill == self.bucket:
             self._launch()

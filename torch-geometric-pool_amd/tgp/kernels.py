@@ -259,9 +259,18 @@ def _dense_adj_layout(adj: Tensor) -> Tuple[Tensor, int]:
     return adj.contiguous(), 0
 
 
+def _out_buffer(out: Optional[Tensor], shape, dev) -> Tensor:
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or out.device != dev or not out.is_contiguous():
+        raise ValueError(f"output buffer must be a contiguous float32 {tuple(shape)} tensor on {dev}, got "
+                         f"{tuple(out.shape)} {out.dtype} on {out.device}")
+    return out
+
+
 def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int = 0, want_raw: bool = False,
-               want_post: bool = True, graph_sizes: Optional[Tensor] = None
-               ) -> Tuple[Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
+               want_post: bool = True, graph_sizes: Optional[Tensor] = None, out_x: Optional[Tensor] = None,
+               out_adj: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
     """(x_pool, adj_raw, adj_pool) = (S^T X, S^T A S, postprocess(S^T A S)) for a padded batch
     (reduce/base_reduce.py:158-161, connect/dense_conn.py:111-122, utils/ops.py:282-335).  ``graph_sizes`` [B]
     (optional): real nodes per graph when they are the leading rows and the padding is zero (to_dense_batch layout)."""
@@ -275,7 +284,7 @@ def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int
         if x.shape[:2] != (B, Nn):
             raise ValueError(f"x {tuple(x.shape)} does not match s {tuple(s.shape)}")
         F = x.size(2)
-        x_pool = torch.empty(B, K, F, dtype=torch.float32, device=dev)
+        x_pool = _out_buffer(out_x, (B, K, F), dev)  # caller-provided: e.g. a slot of an all-gather send buffer
     a = None
     if adj is not None:
         if adj.shape != (B, Nn, Nn):
@@ -285,7 +294,7 @@ def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int
         if want_raw:
             adj_raw = torch.empty(B, K, K, dtype=torch.float32, device=dev)
         if want_post:
-            adj_pool = torch.empty(B, K, K, dtype=torch.float32, device=dev)
+            adj_pool = _out_buffer(out_adj, (B, K, K), dev)
     L = N.lib()
     ws = N.workspace(L.tgp_dense_pool_workspace_bytes(B, Nn, K, F), dev)
     gs = _sizes_arg(graph_sizes, B, dev)

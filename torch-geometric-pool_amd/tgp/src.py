@@ -286,7 +286,8 @@ class DenseSRCPooling(SRCPooling):
         super().clear_cache()
         self.preprocessing_cache = None
 
-    def reduce_connect(self, x: Tensor, adj: Tensor, so: SelectOutput, want_raw: bool = False):
+    def reduce_connect(self, x: Tensor, adj: Tensor, so: SelectOutput, want_raw: bool = False,
+                       out_x: Optional[Tensor] = None, out_adj: Optional[Tensor] = None):
         """Reduce + Connect of a padded dense batch as ONE native call (fused A3 + A7 + A8):
         ``(x_pool [B,K,F], raw S^T A S or None, adj_pool [B,K,K])``.  ``U = A S`` is formed once and
         ``S^T [U | X]`` runs as a single grid (one wave per graph when the graphs fit in LDS), so S is read
@@ -307,8 +308,11 @@ class DenseSRCPooling(SRCPooling):
             raise ValueError("Assignment and adjacency batch sizes do not match: "
                              f"got s.size(0)={s.size(0)} and adj.size(0)={adj.size(0)}.")
         flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
+        # out_x / out_adj (optional, float32 [B,K,F] / [B,K,K]): the kernels write the pooled outputs straight into
+        # caller memory, e.g. the next slot of distributed.PackedGather's send buffer (no pack copy before the RCCL call)
         x_pool, raw, adj_pool = K.dense_pool(s, adj, x, flags, want_raw=want_raw, want_post=True,
-                                             graph_sizes=getattr(so, "_graph_sizes", None))
+                                             graph_sizes=getattr(so, "_graph_sizes", None), out_x=out_x,
+                                             out_adj=out_adj)
         # fp32 arithmetic; results carry the dtypes the reference's ATen ops would return
         return like_input_dtype(x_pool, x), like_input_dtype(raw, s), like_input_dtype(adj_pool, s)
 
