@@ -56,7 +56,8 @@ enum tgp_flags {
   TGP_SUM_AXIS_ROWS = 8,     /* dense: degree = sum over axis -2 (adj_transpose=True, ops.py:312-314) */
   TGP_EPS_FILTER = 16,       /* sparse: drop |w| <= 1e-8 when weights are given (ops.py:374-380) */
   TGP_ADJ_TRANSPOSED = 32,   /* dense: A is handed over as the transposed view (src.py:442-443) */
-  TGP_NODE_FILTER = 64       /* subgraph_fill: node_index was given to the matching _count call */
+  TGP_NODE_FILTER = 64,      /* subgraph_fill: node_index was given to the matching _count call */
+  TGP_WANT_EDGE_ID = 128     /* subgraph_count + _fill: also stage / emit the input position of every kept edge */
 };
 
 int tgp_version(void);
@@ -101,7 +102,8 @@ int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col, const floa
                               int64_t num_edges, int64_t num_nodes, int flags, float eps, const void* ws,
                               int64_t num_out, int64_t* out_row, int64_t* out_col, float* out_weight,
                               int64_t* out_edge_id /* NULL ok: input position of every kept edge (the map the
-                                                      backward of the weight pass-through needs) */,
+                                                      backward of the weight pass-through needs); requires
+                                                      TGP_WANT_EDGE_ID in `flags` of _count and _fill */,
                               void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -19,13 +19,30 @@ constexpr int kCompactTile = 256 * kCompactItems;
 // relabel table; the table is read only for the edges that survive (fill pass).
 __global__ __launch_bounds__(256) void relabel_scatter_kernel(const int64_t* __restrict__ node_index, int64_t k,
                                                               int32_t* __restrict__ relabel,
+                                                              uint32_t* __restrict__ member_bits,
                                                               int* __restrict__ unsorted) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (j < k) {
-    const int64_t v = node_index[j];
-    relabel[v] = static_cast<int32_t>(j);
+  const bool live = j < k;
+  const int64_t v = live ? node_index[j] : -1;
+  if (live) {
+    relabel[v] = static_cast<int32_t>(j);  // only ever read for member nodes: no fill of the other N - k entries
     if (j > 0 && node_index[j - 1] >= v) *unsorted = 1;  // then position != rank: the table is the only way
   }
+  // membership bitmap (zeroed by the caller).  An ascending node_index puts the ~16 members of a 32-node word on
+  // neighbouring lanes: fold their bits with a segmented suffix-OR over the wave and let the first lane of every run
+  // issue ONE atomicOr (one atomic per lane onto a handful of words measured 28 us for 500 k nodes).  Runs are only
+  // an optimisation: for an unsorted list equal words need not be adjacent, and every run head still ORs its bits in.
+  const int lane = lane_id();
+  const int64_t word = live ? (v >> 5) : -1 - lane;  // dead lanes: distinct keys, no bits
+  uint32_t acc = live ? 1u << (v & 31) : 0u;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const uint32_t t = __shfl_down(acc, d, WAVE);
+    const int64_t tw = __shfl_down(word, d, WAVE);
+    if (lane + d < WAVE && tw == word) acc |= t;
+  }
+  const int64_t pw = __shfl_up(word, 1, WAVE);
+  if (live && (lane == 0 || pw != word)) atomicOr(member_bits + word, acc);
 }
 
 // rank128[b] = number of member nodes with id < 128 b (exclusive scan of the bitmap's popcounts, one workgroup):
@@ -76,17 +93,6 @@ __global__ __launch_bounds__(1024) void member_rank_kernel(const uint32_t* membe
   }
 }
 
-// one ballot per 64 nodes: lane = node, the wave's two result words are the membership bits (no atomics)
-__global__ __launch_bounds__(256) void member_bits_kernel(const int32_t* __restrict__ relabel, int64_t n,
-                                                          uint32_t* __restrict__ member_bits) {
-  const int64_t v = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  const unsigned long long m = __ballot(v < n && relabel[v] >= 0);
-  if ((threadIdx.x & 63) == 0 && v < n) {
-    member_bits[v >> 5] = static_cast<uint32_t>(m);
-    if (v + 32 < n || ((n + 31) >> 5) > ((v >> 5) + 1)) member_bits[(v >> 5) + 1] = static_cast<uint32_t>(m >> 32);
-  }
-}
-
 struct SubgraphPred {
   const int64_t* row;
   const int64_t* col;
@@ -111,7 +117,7 @@ struct SubgraphPred {
   }
 };
 
-// Both passes walk the edge list in chunks of SG_CHUNK = 4096 edges with persistent 1024-thread workgroups (one per
+// The edge list is walked ONCE, in chunks of SG_CHUNK = 4096 edges, by persistent 1024-thread workgroups (one per
 // CU).  A thread owns 4 CONSECUTIVE edges of a chunk, so row / col arrive as 16-byte loads, and the
 // order-preserving rank of an edge is (survivors of earlier chunks) + (survivors of earlier threads) + (survivors
 // among the thread's earlier edges).  The node-membership bitmap is copied into LDS once per workgroup when it fits
@@ -205,41 +211,23 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s
   return off + inc - v;
 }
 
-template <bool LDSB>
-__global__ __launch_bounds__(SG_THREADS) void subgraph_count_kernel(SubgraphPred pred, int64_t E, int nchunks,
-                                                                    int nwords, uint32_t* __restrict__ block_counts) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-  __shared__ uint32_t s_w[16];
-  if constexpr (LDSB) {
-    lds_copy_words<SG_THREADS>(s_dyn, pred.member_bits, nwords);
-    __syncthreads();
-  }
-  // the next chunk's edges are requested before the current one is evaluated and counted (as in the fill pass)
-  SgEdges nxt;
-  sg_fetch(pred, static_cast<int64_t>(blockIdx.x) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER, E, nxt);
-  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const int64_t e0 = static_cast<int64_t>(chunk) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER;
-    uint32_t mine = 0;
-    SgEdges t = nxt;
-    if (chunk + static_cast<int>(gridDim.x) < nchunks)
-      sg_fetch(pred, e0 + static_cast<int64_t>(gridDim.x) * SG_CHUNK, E, nxt);
-    sg_eval<LDSB>(pred, s_dyn, e0, t);
-#pragma unroll
-    for (int j = 0; j < SG_PER; ++j) mine += t.keep[j] ? 1u : 0u;
-    uint32_t total;
-    block_excl_scan_1024(mine, s_w, &total);
-    if (threadIdx.x == 0) block_counts[chunk] = total;
-  }
-}
-
+// Pass 1 ("count"): ONE pass over the edge list.  Per chunk of 4096 edges a persistent 1024-thread workgroup evaluates
+// the predicate, ranks the survivors (workgroup scan) and writes them -- already relabelled -- compacted at the
+// chunk's own base in a staging area (new ids as int32, weight, offset inside the chunk as uint16), plus the chunk's
+// survivor count.  Pass 2 ("fill", after the host has read the total and allocated the outputs) only moves the
+// staged survivors to their final places: it reads 14 bytes and writes 20 per SURVIVOR instead of streaming the
+// whole edge list a second time (at ratio 0.5 three quarters of the edges die: 200 MB -> 35 MB of reads).
 // LDSB: 0 = bitmap in global memory, 1 = bitmap in LDS, 2 = bitmap + rank128 in LDS (relabel by rank)
+struct SgStage {
+  int32_t* r;
+  int32_t* c;
+  float* w;
+  uint16_t* off;
+};
+
 template <int LDSB>
-__global__ __launch_bounds__(SG_THREADS) void subgraph_fill_kernel(SubgraphPred pred, int64_t E, int nchunks, int nwords,
-                                                                   const uint32_t* __restrict__ block_offsets,
-                                                                   int64_t* __restrict__ out_row,
-                                                                   int64_t* __restrict__ out_col,
-                                                                   float* __restrict__ out_w,
-                                                                   int64_t* __restrict__ out_eid) {
+__global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred pred, int64_t E, int nchunks, int nwords,
+                                                                    SgStage st, uint32_t* __restrict__ block_counts) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   __shared__ uint32_t s_w[16];
   const uint32_t* s_rank = s_dyn + nwords;
@@ -253,19 +241,18 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_fill_kernel(SubgraphPred 
     }
     __syncthreads();
   }
-  auto new_id = [&](int64_t v) -> int64_t {
+  auto new_id = [&](int64_t v) -> int32_t {
     if constexpr (LDSB == 2) {
       if (by_rank) {
         const int word = static_cast<int>(v >> 5);
         uint32_t r = s_rank[word >> 2];
         for (int q = word & ~3; q < word; ++q) r += __popc(s_dyn[q]);
-        return r + __popc(s_dyn[word] & ((1u << (v & 31)) - 1u));
+        return static_cast<int32_t>(r + __popc(s_dyn[word] & ((1u << (v & 31)) - 1u)));
       }
     }
     return pred.relabel[v];
   };
-  // the (row, col) stream of the next chunk is requested before this chunk's dependent work (relabel gathers,
-  // weight loads, stores) starts: a persistent workgroup would otherwise pay every round trip back to back
+  // the (row, col) stream of the next chunk is requested before this chunk's dependent work starts
   SgEdges nxt;
   sg_fetch(pred, static_cast<int64_t>(blockIdx.x) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER, E, nxt);
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
@@ -277,16 +264,36 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_fill_kernel(SubgraphPred 
     uint32_t mine = 0;
 #pragma unroll
     for (int j = 0; j < SG_PER; ++j) mine += t.keep[j] ? 1u : 0u;
-    int64_t pos = static_cast<int64_t>(block_offsets[chunk]) + block_excl_scan_1024(mine, s_w, nullptr);
+    uint32_t total;
+    int64_t pos = static_cast<int64_t>(chunk) * SG_CHUNK + block_excl_scan_1024(mine, s_w, &total);
+    if (threadIdx.x == 0) block_counts[chunk] = total;
+    // (computing the new ids ahead of the scan, to overlap their LDS look-ups with its barriers, measured 68 vs 64 us)
 #pragma unroll
     for (int j = 0; j < SG_PER; ++j) {
       if (t.keep[j]) {
-        out_row[pos] = pred.relabel ? new_id(t.r[j]) : t.r[j];
-        out_col[pos] = pred.relabel ? new_id(t.c[j]) : t.c[j];
-        if (out_w) out_w[pos] = t.w[j];
-        if (out_eid) out_eid[pos] = e0 + j;  // which input edge this is: the backward of the weight pass-through
+        st.r[pos] = pred.relabel ? new_id(t.r[j]) : static_cast<int32_t>(t.r[j]);
+        st.c[pos] = pred.relabel ? new_id(t.c[j]) : static_cast<int32_t>(t.c[j]);
+        if (st.w) st.w[pos] = t.w[j];
+        if (st.off) st.off[pos] = static_cast<uint16_t>(threadIdx.x * SG_PER + j);
         ++pos;
       }
+    }
+  }
+}
+
+// Pass 2: staged survivors of chunk c (counts[c] entries at c * SG_CHUNK) -> outputs at offsets[c]
+__global__ __launch_bounds__(256) void subgraph_copy_kernel(SgStage st, const uint32_t* __restrict__ counts,
+                                                            const uint32_t* __restrict__ offsets, int nchunks,
+                                                            int64_t* __restrict__ out_row, int64_t* __restrict__ out_col,
+                                                            float* __restrict__ out_w, int64_t* __restrict__ out_eid) {
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint32_t n = counts[chunk];
+    const int64_t dst = offsets[chunk], src = static_cast<int64_t>(chunk) * SG_CHUNK;
+    for (uint32_t t = threadIdx.x; t < n; t += 256) {
+      out_row[dst + t] = st.r[src + t];
+      out_col[dst + t] = st.c[src + t];
+      if (out_w) out_w[dst + t] = st.w[src + t];
+      if (out_eid) out_eid[dst + t] = src + st.off[src + t];  // (staged only under TGP_WANT_EDGE_ID)
     }
   }
 }
@@ -732,12 +739,6 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict
 using namespace tgp;
 
 // ------------------------------------------------------------------------------------- subgraph
-extern "C" size_t tgp_connect_subgraph_workspace_bytes(int64_t E, int64_t N) {
-  const size_t nb = static_cast<size_t>(cdiv(E > 0 ? E : 1, SG_CHUNK));
-  return align_up((N > 0 ? N : 1) * sizeof(int32_t)) + align_up(((N > 0 ? N : 1) / 32 + 1) * sizeof(uint32_t)) +
-         align_up(((N > 0 ? N : 1) / 128 + 2) * sizeof(uint32_t)) + 2 * align_up(nb * sizeof(uint32_t)) + 512;
-}
-
 struct SubgraphWs {
   int32_t* relabel;
   uint32_t* member_bits;
@@ -745,10 +746,12 @@ struct SubgraphWs {
   int* unsorted;
   uint32_t* counts;
   uint32_t* offsets;
+  SgStage st;
 };
-static SubgraphWs carve_subgraph(void* ws, int64_t E, int64_t N) {
+static size_t subgraph_layout(void* ws, int64_t E, int64_t N, SubgraphWs* out) {
   Carver cv(ws);
   const size_t nb = static_cast<size_t>(cdiv(E > 0 ? E : 1, SG_CHUNK));
+  const size_t cap = nb * SG_CHUNK;  // staging capacity: every chunk compacts at its own base
   SubgraphWs s;
   s.relabel = cv.take<int32_t>(N > 0 ? N : 1);
   s.member_bits = cv.take<uint32_t>((N > 0 ? N : 1) / 32 + 1);
@@ -756,7 +759,21 @@ static SubgraphWs carve_subgraph(void* ws, int64_t E, int64_t N) {
   s.unsorted = cv.take<int>(4);
   s.counts = cv.take<uint32_t>(nb);
   s.offsets = cv.take<uint32_t>(nb);
+  s.st.r = cv.take<int32_t>(cap);
+  s.st.c = cv.take<int32_t>(cap);
+  s.st.w = cv.take<float>(cap);
+  s.st.off = cv.take<uint16_t>(cap);
+  if (out) *out = s;
+  return cv.off;
+}
+static SubgraphWs carve_subgraph(void* ws, int64_t E, int64_t N) {
+  SubgraphWs s;
+  subgraph_layout(ws, E, N, &s);
   return s;
+}
+
+extern "C" size_t tgp_connect_subgraph_workspace_bytes(int64_t E, int64_t N) {
+  return subgraph_layout(nullptr, E, N, nullptr) + 512;
 }
 
 extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
@@ -769,68 +786,59 @@ extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col
   TGP_REQUIRE(ws && ws_bytes >= tgp_connect_subgraph_workspace_bytes(E, N), TGP_ERR_WORKSPACE,
               "tgp_connect_subgraph_count: workspace too small");
   SubgraphWs s = carve_subgraph(ws, E, N);
+  const int nwords = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
   if (node_index) {
-    (void)hipMemsetAsync(s.relabel, 0xFF, static_cast<size_t>(N > 0 ? N : 1) * sizeof(int32_t), stream);
+    (void)hipMemsetAsync(s.member_bits, 0, static_cast<size_t>(nwords) * sizeof(uint32_t), stream);
     (void)hipMemsetAsync(s.unsorted, 0, sizeof(int), stream);
     if (k > 0)
       hipLaunchKernelGGL(relabel_scatter_kernel, dim3(cdiv(k, 256)), dim3(256), 0, stream, node_index, k, s.relabel,
-                         s.unsorted);
-    hipLaunchKernelGGL(member_bits_kernel, dim3(cdiv(N > 0 ? N : 1, 256)), dim3(256), 0, stream, s.relabel, N,
-                       s.member_bits);
-    const int nw = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
-    const int in_lds = nw <= SG_LDS_WORDS_MAX ? 1 : 0;
-  if (in_lds)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(member_rank_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_WORDS_MAX * 4);
-  hipLaunchKernelGGL(member_rank_kernel, dim3(1), dim3(1024), in_lds ? nw * sizeof(uint32_t) : 0, stream,
-                     s.member_bits, nw, (nw + 3) / 4, s.rank128, in_lds);
+                         s.member_bits, s.unsorted);
+    const int in_lds = nwords <= SG_LDS_WORDS_MAX ? 1 : 0;
+    if (in_lds)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(member_rank_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_WORDS_MAX * 4);
+    hipLaunchKernelGGL(member_rank_kernel, dim3(1), dim3(1024), in_lds ? nwords * sizeof(uint32_t) : 0, stream,
+                       s.member_bits, nwords, (nwords + 3) / 4, s.rank128, in_lds);
   }
   const int nb = cdiv(E > 0 ? E : 1, SG_CHUNK);
   SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.rank128, s.unsorted, flags, eps};
-  const int nwords = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
+  SgStage st = s.st;
+  if (!w) st.w = nullptr;
+  if (!(flags & TGP_WANT_EDGE_ID)) st.off = nullptr;  // input positions are only staged for callers that will ask for them
   const int grid = nb < 256 ? nb : 256;  // persistent: one 1024-thread workgroup per CU
-  if (node_index && nwords <= SG_LDS_WORDS_MAX) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_count_kernel<true>),
+  const int nblocks = (nwords + 3) / 4;
+  if (node_index && nwords + nblocks <= SG_LDS_WORDS_MAX + 1984) {  // bitmap + rank128 <= 159.75 KB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (SG_LDS_WORDS_MAX + 1984) * 4);
+    hipLaunchKernelGGL(subgraph_stage_kernel<2>, dim3(grid), dim3(SG_THREADS), (nwords + nblocks) * sizeof(uint32_t),
+                       stream, pred, E, nb, nwords, st, s.counts);
+  } else if (node_index && nwords <= SG_LDS_WORDS_MAX) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_WORDS_MAX * 4);
-    hipLaunchKernelGGL(subgraph_count_kernel<true>, dim3(grid), dim3(SG_THREADS), nwords * sizeof(uint32_t), stream,
-                       pred, E, nb, nwords, s.counts);
+    hipLaunchKernelGGL(subgraph_stage_kernel<1>, dim3(grid), dim3(SG_THREADS), nwords * sizeof(uint32_t), stream, pred,
+                       E, nb, nwords, st, s.counts);
   } else {
-    hipLaunchKernelGGL(subgraph_count_kernel<false>, dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords,
+    hipLaunchKernelGGL(subgraph_stage_kernel<0>, dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords, st,
                        s.counts);
   }
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nb, s.offsets, d_count);
   return check_launch("tgp_connect_subgraph_count");
 }
 
-extern "C" int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col, const float* w, int64_t E,
-                                         int64_t N, int flags, float eps, const void* ws, int64_t num_out,
+extern "C" int tgp_connect_subgraph_fill(const int64_t* /*row*/, const int64_t* /*col*/, const float* w, int64_t E,
+                                         int64_t N, int flags, float /*eps*/, const void* ws, int64_t num_out,
                                          int64_t* out_row, int64_t* out_col, float* out_w, int64_t* out_edge_id,
                                          void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(E >= 0 && num_out >= 0 && ws, TGP_ERR_INVALID, "tgp_connect_subgraph_fill: bad argument");
   if (num_out == 0 || E == 0) return TGP_OK;
   TGP_REQUIRE(out_row && out_col && (!w || out_w), TGP_ERR_INVALID, "tgp_connect_subgraph_fill: null output");
+  TGP_REQUIRE(!out_edge_id || (flags & TGP_WANT_EDGE_ID), TGP_ERR_INVALID,
+              "tgp_connect_subgraph_fill: out_edge_id needs TGP_WANT_EDGE_ID in the flags of BOTH calls");
   SubgraphWs s = carve_subgraph(const_cast<void*>(ws), E, N);
   const int nb = cdiv(E, SG_CHUNK);
-  SubgraphPred pred{row, col, w, (flags & TGP_NODE_FILTER) ? s.relabel : nullptr, s.member_bits, s.rank128, s.unsorted,
-                    flags, eps};
-  const int nwords = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
-  const int grid = nb < 256 ? nb : 256;
-  const int nblocks = (nwords + 3) / 4;
-  if ((flags & TGP_NODE_FILTER) && nwords + nblocks <= SG_LDS_WORDS_MAX + 1984) {  // bitmap + rank128 <= 159.75 KB
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_fill_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (SG_LDS_WORDS_MAX + 1984) * 4);
-    hipLaunchKernelGGL(subgraph_fill_kernel<2>, dim3(grid), dim3(SG_THREADS), (nwords + nblocks) * sizeof(uint32_t),
-                       stream, pred, E, nb, nwords, s.offsets, out_row, out_col, w ? out_w : nullptr, out_edge_id);
-  } else if ((flags & TGP_NODE_FILTER) && nwords <= SG_LDS_WORDS_MAX) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_fill_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_WORDS_MAX * 4);
-    hipLaunchKernelGGL(subgraph_fill_kernel<1>, dim3(grid), dim3(SG_THREADS), nwords * sizeof(uint32_t), stream, pred,
-                       E, nb, nwords, s.offsets, out_row, out_col, w ? out_w : nullptr, out_edge_id);
-  } else {
-    hipLaunchKernelGGL(subgraph_fill_kernel<0>, dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords,
-                       s.offsets, out_row, out_col, w ? out_w : nullptr, out_edge_id);
-  }
+  hipLaunchKernelGGL(subgraph_copy_kernel, dim3(nb < 4096 ? nb : 4096), dim3(256), 0, stream, s.st, s.counts, s.offsets,
+                     nb, out_row, out_col, w ? out_w : nullptr, out_edge_id);
   return check_launch("tgp_connect_subgraph_fill");
 }
 

@@ -26,6 +26,7 @@ SUM_AXIS_ROWS = 8
 EPS_FILTER = 16
 ADJ_TRANSPOSED = 32
 NODE_FILTER = 64
+WANT_EDGE_ID = 128
 REDUCE_OPS = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3, "mul": 4}
 
 _c_i64, _c_int, _c_sz, _c_p, _c_f = ctypes.c_int64, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float

@@ -121,6 +121,8 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
     w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
     ni = None if node_index is None else N.i64c(node_index)
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if w is not None else 0)
+    if want_edge_id:
+        flags |= N.WANT_EDGE_ID
     if ni is not None:
         flags |= N.NODE_FILTER
         if ni.numel() == 0:  # no node kept: no edge survives (an empty tensor has no device pointer to hand over)
