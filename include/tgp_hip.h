@@ -22,6 +22,9 @@
  *   - `eps` arguments: the reference reads its module-level `eps` (tgp/__init__.py:6, 1e-8) at CALL time
  *     (utils/ops.py:72,318,377,395; utils/losses.py:498; tests monkeypatch it), so it is an argument of every
  *     entry point that filters or clamps with it, never a compiled-in constant.
+ *   - *d_count < 0 is a refusal, not a size: -1 = this fast path declines (preconditions not met: the caller
+ *     takes its general route), -2 = bad input (a node id outside [0, num_nodes) or a cluster id outside
+ *     [0, num_supernodes): never dereferenced; the reference's index ops raise for it too).
  *   - return value 0 = ok; otherwise a negative tgp_status and tgp_last_error() holds a
  *     thread-local message.  No exceptions cross the boundary; no global mutable state.
  */

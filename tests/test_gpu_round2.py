@@ -251,3 +251,44 @@ def test_to_dense_adj_edge_weight_gradient_is_native(dev, monkeypatch):
     out = pool(x=x, adj=ei.to(dev), edge_weight=wd, batch=batch.to(dev))
     (out.edge_index.sum() + sum(out.loss.values())).backward()
     assert wd.grad is not None and float(wd.grad.abs().sum()) > 0
+
+
+def test_out_of_range_node_ids_are_refused_not_dereferenced(dev):
+    """node ids in edge_index beyond num_nodes (and cluster ids beyond num_supernodes) used to index
+    the kernels' tables unchecked.  Now every Connect path guards them and the call raises, as the reference's
+    `cluster_index[edge_index]` / `subgraph` would."""
+    from tgp import kernels as K
+    from tgp.connect import SparseConnect
+    from tgp.select import SelectOutput
+    n = 50
+    g = torch.Generator().manual_seed(0)
+    ei = torch.randint(0, n, (2, 300), generator=g)
+    bad = ei.clone()
+    bad[1, 17] = n + 3
+    neg = ei.clone()
+    neg[0, 5] = -1
+    w = torch.rand(300, generator=g)
+    kept = torch.arange(0, n, 2)
+    so_topk = SelectOutput(node_index=kept.to(dev), cluster_index=torch.arange(kept.numel(), device=dev), num_nodes=n,
+                           num_supernodes=kept.numel())
+    so_cl = SelectOutput(cluster_index=(torch.arange(n) // 2).to(dev), num_supernodes=n // 2)
+    for e in (bad, neg):
+        with pytest.raises(IndexError, match="node ids outside"):
+            SparseConnect()(e.to(dev), so_topk, edge_weight=w.to(dev))
+        with pytest.raises(IndexError, match="node ids outside"):
+            SparseConnect()(e.to(dev), so_cl, edge_weight=w.to(dev))          # row-local attempt declines, general path reports
+        with pytest.raises(IndexError, match="node ids outside"):
+            srt = e[:, torch.argsort(e[0].clamp(min=0), stable=True)]
+            SparseConnect()(srt.to(dev), so_cl, edge_weight=w.to(dev))
+    # a large-K clustering takes the grouped path first: same refusal
+    big_n = 140_000
+    eb = torch.randint(0, big_n, (2, 1000), generator=g)
+    eb[1, 3] = big_n + 1
+    so_big = SelectOutput(cluster_index=torch.arange(big_n, device=dev), num_supernodes=big_n)
+    with pytest.raises(IndexError, match="node ids outside"):
+        SparseConnect()(eb.to(dev), so_big, edge_weight=None)
+    # valid inputs still work afterwards (no sticky device state)
+    out_ei, out_w = SparseConnect()(ei.to(dev), so_cl, edge_weight=w.to(dev))
+    assert out_ei.size(1) > 0 and int(out_ei.max()) < n // 2
+    with pytest.raises(IndexError):
+        SelectOutput(cluster_index=torch.tensor([0, 3, 1], device=dev), num_supernodes=3)

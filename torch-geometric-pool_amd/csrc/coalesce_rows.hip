@@ -104,7 +104,7 @@ static void device_scan_u32(const uint32_t* in, int64_t n, uint32_t* out, int64_
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nt), dim3(256), 0, stream, in, n, sums, 1, out, total, bad, d_count);
     return;
   }
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, sums, nt, offs, total);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, sums, nt, offs, total, static_cast<const int*>(nullptr));
   hipLaunchKernelGGL(scan_apply_kernel, dim3(nt), dim3(256), 0, stream, in, n, offs, 0, out, nullptr, nullptr, nullptr);
   if (d_count) hipLaunchKernelGGL(cr_finish_count_kernel, dim3(1), dim3(1), 0, stream, bad, total, d_count);
 }
@@ -352,7 +352,8 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
     const int32_t* __restrict__ a_row_ptr, const uint32_t* __restrict__ seg_src, const uint32_t* __restrict__ seg_dst,
     const unsigned long long* __restrict__ grouped, const uint32_t* __restrict__ raw_off, int64_t K, int reduce_op,
     int flags, float eps,
-    int* __restrict__ bad, uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w, uint32_t* __restrict__ n_out) {
+    int* __restrict__ bad, uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w, uint32_t* __restrict__ n_out,
+    int64_t n_nodes) {
   __shared__ uint32_t s_key[GS_CAP];
   __shared__ float s_val[GS_CAP];
   __shared__ uint32_t s_seg_dst[GS_MEM], s_seg_src[GS_MEM];
@@ -438,7 +439,10 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
       for (int u = 0; u < U; ++u) {
         const int t = tid + u * 256;
         if (t < cnt) {
-          s_key[t] = static_cast<uint32_t>(table[cc[u]]);
+          // a column outside [0, n_nodes): decline (the general path reports it); never used as an index
+          const bool inr = static_cast<uint64_t>(cc[u]) < static_cast<uint64_t>(n_nodes);
+          if (!inr) *bad = 4;
+          s_key[t] = inr ? static_cast<uint32_t>(table[cc[u]]) : 0u;
           s_val[t] = wv[u];
         }
       }
@@ -708,7 +712,7 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
                      s.member_off, s.raw_off, s.bad, s.seg_src, s.seg_dst);
   hipLaunchKernelGGL(cr_gather_sort_kernel<false>, dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, col, w, E, s.table,
                      assign_row_ptr, s.seg_src, s.seg_dst, static_cast<const unsigned long long*>(nullptr), s.raw_off, K,
-                     reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out);
+                     reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out, N);
   hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
                      reduce_op, flags, eps, s.bad, s.n_out);
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);
@@ -723,12 +727,22 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
 namespace tgp {
 __global__ __launch_bounds__(256) void cg_keys_kernel(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
                                                       const float* __restrict__ w, const int32_t* __restrict__ table,
-                                                      int64_t E, uint32_t* __restrict__ keys,
+                                                      int64_t E, int64_t n_nodes, int64_t K, int* __restrict__ bad,
+                                                      uint32_t* __restrict__ keys,
                                                       unsigned long long* __restrict__ vals) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (e >= E) return;
-  keys[e] = static_cast<uint32_t>(table[row[e]]);
-  vals[e] = static_cast<unsigned long long>(static_cast<uint32_t>(table[col[e]])) |
+  const int64_t r = row[e], c = col[e];
+  uint32_t kr = 0, kc = 0;
+  if (static_cast<uint64_t>(r) >= static_cast<uint64_t>(n_nodes) || static_cast<uint64_t>(c) >= static_cast<uint64_t>(n_nodes)) {
+    *bad = 4;  // node id outside [0, n): decline, the general path reports it
+  } else {
+    kr = static_cast<uint32_t>(table[r]);
+    kc = static_cast<uint32_t>(table[c]);
+    if (kr >= static_cast<uint64_t>(K) || kc >= static_cast<uint64_t>(K)) { *bad = 4; kr = kc = 0; }
+  }
+  keys[e] = kr;
+  vals[e] = static_cast<unsigned long long>(kc) |
             (static_cast<unsigned long long>(__float_as_uint(w ? w[e] : 1.0f)) << 32);
 }
 
@@ -795,7 +809,8 @@ extern "C" int tgp_connect_coalesce_grouped_count(const int64_t* row, const int6
   float* tmp_w = w ? s.tmp_w : nullptr;
   (void)hipMemsetAsync(s.bad, 0, sizeof(int), stream);
   hipLaunchKernelGGL(cr_table_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, cluster_index, N, s.table);
-  hipLaunchKernelGGL(cg_keys_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, s.table, E, g.k0, g.v0);
+  hipLaunchKernelGGL(cg_keys_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, s.table, E, N, K, s.bad, g.k0,
+                     g.v0);
   bool first = true;
   const int rc = radix_sort_pairs<uint32_t, unsigned long long>(g.k0, g.v0, g.k1, g.v1, E,
                                                                 bits_for(static_cast<uint64_t>(K - 1)), g.scratch,
@@ -808,7 +823,7 @@ extern "C" int tgp_connect_coalesce_grouped_count(const int64_t* row, const int6
                      static_cast<const int64_t*>(nullptr), static_cast<const float*>(nullptr), E,
                      static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr),
                      static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), vals, s.raw_off, K,
-                     reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out);
+                     reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out, N);
   hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
                      reduce_op, flags, eps, s.bad, s.n_out);
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);

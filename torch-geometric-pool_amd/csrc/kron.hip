@@ -457,7 +457,7 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
     hipLaunchKernelGGL(kron_flags_kernel, dim3(cdiv(num_kept, 256)), dim3(256), 0, stream, node_index, num_kept, N,
                        s.flags, s.status);
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.flags, static_cast<int>(N + 1), s.rank,
-                     s.scan_total);
+                     s.scan_total, static_cast<const int*>(nullptr));
   hipLaunchKernelGGL(kron_plan_kernel, dim3(1), dim3(1024), 0, stream, graph_ptr, static_cast<int>(B), s.rank, s.sq_off,
                      s.big_off, s.cap_dense, s.cap_big, s.status);
   KronArgs a{};
@@ -480,7 +480,7 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
     hipLaunchKernelGGL(kron_schur_big_kernel, dim3(static_cast<unsigned>(B)), dim3(KRON_BIG_THREADS), plds, stream, a);
   }
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, static_cast<int>(B), s.out_off,
-                     d_count);
+                     d_count, static_cast<const int*>(nullptr));
   hipLaunchKernelGGL(kron_finish_count_kernel, dim3(1), dim3(1), 0, stream, s.status, d_count);
   return check_launch("tgp_kron_batched_count");
 }

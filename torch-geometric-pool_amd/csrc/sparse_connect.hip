@@ -18,12 +18,16 @@ constexpr int kCompactTile = 256 * kCompactItems;
 // tests the bitmap (N/8 bytes: 125 KB for a million nodes, cache resident) instead of gathering from the 4 N-byte
 // relabel table; the table is read only for the edges that survive (fill pass).
 __global__ __launch_bounds__(256) void relabel_scatter_kernel(const int64_t* __restrict__ node_index, int64_t k,
-                                                              int32_t* __restrict__ relabel,
+                                                              int64_t n, int32_t* __restrict__ relabel,
                                                               uint32_t* __restrict__ member_bits,
                                                               int* __restrict__ unsorted) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  const bool live = j < k;
+  bool live = j < k;
   const int64_t v = live ? node_index[j] : -1;
+  if (live && static_cast<uint64_t>(v) >= static_cast<uint64_t>(n)) {  // a kept node outside [0, n)
+    unsorted[1] = 1;
+    live = false;
+  }
   if (live) {
     relabel[v] = static_cast<int32_t>(j);  // only ever read for member nodes: no fill of the other N - k entries
     if (j > 0 && node_index[j - 1] >= v) *unsorted = 1;  // then position != rank: the table is the only way
@@ -103,10 +107,16 @@ struct SubgraphPred {
   const int* unsorted;          // set with relabel: node_index is not ascending
   int flags;
   float eps;                    // the caller's eps at call time (reference ops.py:377 reads the module global)
+  int64_t n;                    // number of nodes: endpoints outside [0, n) set *bad_ids (the reference's index ops raise)
+  int* bad_ids;
   // keep / drop only; r, c are the ORIGINAL endpoints (relabelling is injective, so r == c decides self loops)
   __device__ __forceinline__ bool operator()(int64_t e, int64_t& r, int64_t& c) const {
     r = row[e];
     c = col[e];
+    if (static_cast<uint64_t>(r) >= static_cast<uint64_t>(n) || static_cast<uint64_t>(c) >= static_cast<uint64_t>(n)) {
+      *bad_ids = 1;
+      return false;
+    }
     if (relabel) {
       const uint32_t br = member_bits[r >> 5] >> (r & 31), bc = member_bits[c >> 5] >> (c & 31);
       if (!(br & bc & 1u)) return false;
@@ -171,6 +181,16 @@ __device__ __forceinline__ void sg_fetch(const SubgraphPred& pred, int64_t e0, i
 // the predicate: membership of both endpoints (bitmap), self loops, |w| > eps
 template <bool LDSB>
 __device__ __forceinline__ void sg_eval(const SubgraphPred& pred, const uint32_t* s_bits, int64_t e0, SgEdges& t) {
+#pragma unroll
+  for (int j = 0; j < SG_PER; ++j) {  // endpoints outside [0, n): flagged, never used as an index
+    if (t.keep[j] && (static_cast<uint64_t>(t.r[j]) >= static_cast<uint64_t>(pred.n) ||
+                      static_cast<uint64_t>(t.c[j]) >= static_cast<uint64_t>(pred.n))) {
+      *pred.bad_ids = 1;
+      t.keep[j] = false;
+      t.r[j] = 0;
+      t.c[j] = 0;
+    }
+  }
   if (pred.relabel) {  // all bitmap words are requested before any is tested
     uint32_t br[SG_PER], bc[SG_PER];
 #pragma unroll
@@ -313,11 +333,20 @@ __global__ __launch_bounds__(256) void coalesce_keys_kernel(const int64_t* __res
                                                             const int64_t* __restrict__ col,
                                                             const float* __restrict__ w,
                                                             const int32_t* __restrict__ cluster, int64_t E,
-                                                            uint64_t K, uint64_t* __restrict__ keys,
-                                                            float* __restrict__ vals) {
+                                                            int64_t n, uint64_t K, uint64_t* __restrict__ keys,
+                                                            float* __restrict__ vals, int* __restrict__ bad_ids) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (e < E) {
-    keys[e] = static_cast<uint64_t>(cluster[row[e]]) * K + static_cast<uint64_t>(cluster[col[e]]);
+    const int64_t r = row[e], c = col[e];
+    uint64_t key = 0;
+    if (static_cast<uint64_t>(r) >= static_cast<uint64_t>(n) || static_cast<uint64_t>(c) >= static_cast<uint64_t>(n)) {
+      *bad_ids = 1;  // node id outside [0, n): the reference's cluster_index[edge_index] would raise
+    } else {
+      const uint64_t cr = static_cast<uint32_t>(cluster[r]), cc = static_cast<uint32_t>(cluster[c]);
+      if (cr >= K || cc >= K) *bad_ids = 1;  // cluster id outside [0, K)
+      else key = cr * K + cc;
+    }
+    keys[e] = key;
     vals[e] = w ? w[e] : 1.0f;
   }
 }
@@ -787,11 +816,11 @@ extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col
               "tgp_connect_subgraph_count: workspace too small");
   SubgraphWs s = carve_subgraph(ws, E, N);
   const int nwords = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
+  (void)hipMemsetAsync(s.unsorted, 0, 4 * sizeof(int), stream);  // [0] node_index not ascending, [1] bad node ids
   if (node_index) {
     (void)hipMemsetAsync(s.member_bits, 0, static_cast<size_t>(nwords) * sizeof(uint32_t), stream);
-    (void)hipMemsetAsync(s.unsorted, 0, sizeof(int), stream);
     if (k > 0)
-      hipLaunchKernelGGL(relabel_scatter_kernel, dim3(cdiv(k, 256)), dim3(256), 0, stream, node_index, k, s.relabel,
+      hipLaunchKernelGGL(relabel_scatter_kernel, dim3(cdiv(k, 256)), dim3(256), 0, stream, node_index, k, N, s.relabel,
                          s.member_bits, s.unsorted);
     const int in_lds = nwords <= SG_LDS_WORDS_MAX ? 1 : 0;
     if (in_lds)
@@ -801,7 +830,8 @@ extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col
                        s.member_bits, nwords, (nwords + 3) / 4, s.rank128, in_lds);
   }
   const int nb = cdiv(E > 0 ? E : 1, SG_CHUNK);
-  SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.rank128, s.unsorted, flags, eps};
+  SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.rank128, s.unsorted, flags, eps,
+                    N, s.unsorted + 1};
   SgStage st = s.st;
   if (!w) st.w = nullptr;
   if (!(flags & TGP_WANT_EDGE_ID)) st.off = nullptr;  // input positions are only staged for callers that will ask for them
@@ -821,7 +851,8 @@ extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col
     hipLaunchKernelGGL(subgraph_stage_kernel<0>, dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords, st,
                        s.counts);
   }
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nb, s.offsets, d_count);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nb, s.offsets, d_count,
+                     static_cast<const int*>(s.unsorted + 1));
   return check_launch("tgp_connect_subgraph_count");
 }
 
@@ -850,6 +881,7 @@ struct CoalesceWs {
   uint8_t* keep;
   uint32_t *counts, *offsets, *scratch;
   int32_t* table;
+  int* bad_ids;
 };
 static size_t coalesce_layout(void* ws, int64_t E, int64_t N, CoalesceWs* out) {
   Carver cv(ws);
@@ -866,6 +898,7 @@ static size_t coalesce_layout(void* ws, int64_t E, int64_t N, CoalesceWs* out) {
   s.offsets = cv.take<uint32_t>(nb);
   s.scratch = cv.take<uint32_t>(sort_scratch_words());
   s.table = cv.take<int32_t>(static_cast<size_t>(N > 0 ? N : 1));
+  s.bad_ids = cv.take<int>(4);
   if (out) *out = s;
   return cv.off;
 }
@@ -895,8 +928,10 @@ extern "C" int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col
   }
   const uint64_t Ku = static_cast<uint64_t>(K > 0 ? K : 1);
   hipLaunchKernelGGL(cluster_table_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, cluster_index, N, s.table);
-  hipLaunchKernelGGL(coalesce_keys_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, s.table, E, Ku,
-                     s.k0, s.v0);
+  int* bad_ids = s.bad_ids;
+  (void)hipMemsetAsync(bad_ids, 0, sizeof(int), stream);
+  hipLaunchKernelGGL(coalesce_keys_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, s.table, E, N, Ku,
+                     s.k0, s.v0, bad_ids);
   bool first = true;
   const int rc = radix_sort_pairs<uint64_t, float>(s.k0, s.v0, s.k1, s.v1, E, bits_for(Ku * Ku - 1), s.scratch,
                                                    stream, &first);
@@ -904,7 +939,8 @@ extern "C" int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col
   const int nb = cdiv(E, kCompactTile);
   hipLaunchKernelGGL(coalesce_segment_kernel, dim3(nb), dim3(256), 0, stream, first ? s.k0 : s.k1,
                      first ? s.v0 : s.v1, E, Ku, w ? 1 : 0, reduce_op, flags, eps, s.seg, s.keep, s.counts);
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nb, s.offsets, d_count);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nb, s.offsets, d_count,
+                     static_cast<const int*>(bad_ids));
   return check_launch("tgp_connect_coalesce_count");
 }
 
@@ -1002,7 +1038,8 @@ extern "C" int tgp_block_diag_count(const float* adj, int64_t B, int64_t K, cons
   uint32_t* offsets = cv.take<uint32_t>(nb);
   BlockDiagPred pred{adj, relabel, K, flags, eps};
   hipLaunchKernelGGL(blockdiag_count_kernel, dim3(nb), dim3(256), 0, stream, pred, total, counts);
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts, nb, offsets, d_count);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts, nb, offsets, d_count,
+                     static_cast<const int*>(nullptr));
   return check_launch("tgp_block_diag_count");
 }
 

@@ -414,7 +414,8 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
                        N, ptr, k, koff, s.rank_of);
   }
   hipLaunchKernelGGL(topk_count_kernel, dim3(nbt), dim3(256), 0, stream, s.rank_of, N, s.counts);
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nbt, s.offsets, s.total);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nbt, s.offsets, s.total,
+                     static_cast<const int*>(nullptr));
   if (node_index)
     hipLaunchKernelGGL(topk_fill_kernel, dim3(nbt), dim3(256), 0, stream, s.rank_of, N, s.offsets, node_index,
                        cluster_index, assign_perm);

@@ -106,7 +106,11 @@ def _edge_rows(edge_index: Tensor) -> Tuple[Tensor, Tensor]:
 
 def _read_count(d_count: Tensor) -> int:
     # the single host sync of a count -> fill pair (the reference pays `.item()` syncs too)
-    return int(d_count.item())
+    n = int(d_count.item())
+    if n == -2:  # refusal code of the count kernels: an endpoint (or cluster id) outside its table
+        raise IndexError("edge_index holds node ids outside [0, num_nodes) (or cluster ids outside [0, num_supernodes)): "
+                         "the reference's index ops raise for these inputs too")
+    return n
 
 
 def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: Optional[Tensor],
