@@ -87,6 +87,13 @@ for nm in ("mincut", "diff", "mincut_u"):
                   x3, ei3, None, batch3))
 cases.append(("topk small graphs B=2048 n~40 F=32", lambda: get_pooler("topk", in_channels=32, ratio=0.5), x3, ei3, None, batch3))
 cases.append(("graclus small graphs B=2048 n~40 F=32", lambda: get_pooler("graclus"), x3, ei3, None, batch3))
+# NDP: spectral partition (tgp_ndp_partition) + Reduce + block-batched Kron reduction, all on the device; and its
+# two-level precoarsening (what NDP is normally used for: a transform applied once per dataset)
+cases.append(("ndp small graphs B=2048 n~40 F=32", lambda: get_pooler("ndp"), x3, ei3, None, batch3))
+if not only or any("precoarsen" in o for o in only):
+    ndp = get_pooler("ndp").to(dev)
+    ms = wall(lambda: ndp.multi_level_precoarsening(levels=2, edge_index=ei3, batch=batch3, num_nodes=n3), iters=5)
+    print(f"{'ndp 2-level precoarsening, small graphs B=2048 n~40':58s} {'fwd    '} {ms:9.3f} ms", flush=True)
 for name, mk, xx, e, w, b in cases:
     if only and not any(o in name for o in only):
         continue

@@ -4,9 +4,11 @@
 // its largest eigenvector by torch.lobpcg, sign partition z, cut size z^T L z / (2 vol), random +-1 partition when the
 // cut is below 0.5 (or the eigen-solve fails).  The partition is only defined up to the eigenvector's sign and solver
 // tolerance, so the contract is: z is the sign pattern of a (converged) largest eigenvector of Ls, or the random
-// fallback under the reference's rule.  Here every graph runs a power iteration on Ls (positive semi-definite with
-// spectrum in [0, 2]: the dominant eigenvector IS the largest one) in fp64, vectors in LDS, the graph's CSR rows read
-// from L2; per iteration one sparse mat-vec and one workgroup reduction.
+// fallback under the reference's rule.  Here every graph runs the method the reference names -- LOBPCG with one vector:
+// every step maximises the Rayleigh quotient over span{x, residual, previous direction} (a 3 x 3 symmetric eigenproblem
+// solved redundantly by every thread) -- in fp64 with the six work vectors and the graph's matrix in LDS; one sparse
+// mat-vec and four workgroup reductions per step, a few dozen steps per graph (a plain power iteration needed a
+// median of 400 and up to thousands when the two largest eigenvalues are close).
 #include "primitives.h"
 
 namespace tgp {
@@ -48,6 +50,46 @@ __device__ __forceinline__ double ndp_block_max(double v, double* s_red) {
   return t;
 }
 
+// largest eigenpair of a symmetric 3 x 3 matrix (cyclic Jacobi, fixed sweeps; every thread runs it on the same numbers)
+__device__ __forceinline__ void ndp_eig3_largest(double a[3][3], int dim, double& theta, double c[3]) {
+  double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 8; ++sweep) {
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+      if (q >= dim) continue;
+      const double apq = a[p][q];
+      if (fabs(apq) < 1e-300) continue;
+      const double tau = (a[q][q] - a[p][p]) / (2.0 * apq);
+      const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+      const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {  // A <- A J
+        const double akp = a[k][p], akq = a[k][q];
+        a[k][p] = cs * akp - sn * akq;
+        a[k][q] = sn * akp + cs * akq;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {  // A <- J^T A
+        const double apk = a[p][k], aqk = a[q][k];
+        a[p][k] = cs * apk - sn * aqk;
+        a[q][k] = sn * apk + cs * aqk;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double vkp = v[k][p], vkq = v[k][q];
+        v[k][p] = cs * vkp - sn * vkq;
+        v[k][q] = sn * vkp + cs * vkq;
+      }
+    }
+  }
+  int best = 0;
+  for (int k = 1; k < dim; ++k)
+    if (a[k][k] > a[best][best]) best = k;
+  theta = a[best][best];
+  for (int k = 0; k < 3; ++k) c[k] = k < dim ? v[k][best] : 0.0;
+}
+
 // indptr / col / w: CSR over all nodes of the batch of a SYMMETRIC adjacency without self loops (the caller
 // symmetrises with max, as to_undirected(reduce="max") does, ndp_select.py:198-202).
 template <int THREADS>
@@ -56,6 +98,7 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
                                                                 const float* __restrict__ w,
                                                                 const int64_t* __restrict__ graph_ptr,
                                                                 unsigned long long seed, int max_iter, double tol,
+                                                                int ncap, int ecap,
                                                                 uint8_t* __restrict__ keep, int32_t* __restrict__ info,
                                                                 int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
@@ -73,9 +116,21 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
     if (tid == 0) { keep[p0] = 1; info[g] = 0; }
     return;
   }
-  double* x = s_dyn;
-  double* y = s_dyn + n;
-  float* dis = reinterpret_cast<float*>(s_dyn + 2 * n);
+  // LDS: six fp64 work vectors [ncap], then the graph's matrix M = D^-1/2 A D^-1/2 as a local CSR when it fits
+  // (values [ecap] fp64, row offsets [ncap + 1], columns [ecap] uint16), dis [ncap] fp32: the iteration then never
+  // leaves the CU (reading indptr / col / w from L2 every iteration cost ~2 us per iteration)
+  double* x = s_dyn;              // iterate (unit length)
+  double* ax = s_dyn + ncap;      // Ls x
+  double* wv = s_dyn + 2 * ncap;  // normalised residual
+  double* aw = s_dyn + 3 * ncap;
+  double* pv = s_dyn + 4 * ncap;  // previous search direction, orthonormalised against x and wv
+  double* ap = s_dyn + 5 * ncap;
+  double* mval = s_dyn + 6 * ncap;
+  int* mptr = reinterpret_cast<int*>(mval + ecap);
+  float* dis = reinterpret_cast<float*>(mptr + ncap + 1);
+  unsigned short* mcol = reinterpret_cast<unsigned short*>(dis + ncap);
+  const int e_lo = indptr[p0], nnz_g = indptr[p1] - e_lo;
+  const bool cached = nnz_g <= ecap && n <= 65535;
   // degrees, volume
   double vol_part = 0.0;
   for (int i = tid; i < n; i += THREADS) {
@@ -91,37 +146,135 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
   }
   const double vol = ndp_block_sum<THREADS>(vol_part, s_red);
   __syncthreads();
+  if (cached) {
+    for (int i = tid; i <= n; i += THREADS) mptr[i] = indptr[p0 + i] - e_lo;
+    for (int i = tid; i < n; i += THREADS) {
+      for (int e = indptr[p0 + i]; e < indptr[p0 + i + 1]; ++e) {
+        const int64_t c = col[e];
+        const bool in = c >= p0 && c < p1;
+        const int j = in ? static_cast<int>(c - p0) : 0;
+        mcol[e - e_lo] = static_cast<unsigned short>(j);
+        mval[e - e_lo] = in ? (w ? static_cast<double>(w[e]) : 1.0) * static_cast<double>(dis[i]) *
+                                  static_cast<double>(dis[j]) : 0.0;
+      }
+    }
+    __syncthreads();
+  }
   int it = 0;
   bool random_part = !(vol > 0.0);
-  if (!random_part) {
-    for (; it < max_iter; ++it) {
-      double sq = 0.0;
-      for (int i = tid; i < n; i += THREADS) {
+  auto matvec = [&](const double* src, double* dst) {  // dst = Ls src on this thread's rows
+    for (int i = tid; i < n; i += THREADS) {
+      double v;
+      if (cached) {
+        double acc = 0.0;
+        for (int e = mptr[i]; e < mptr[i + 1]; ++e) acc += mval[e] * src[mcol[e]];
+        v = src[i] - acc;
+      } else {
         double acc = 0.0;
         for (int e = indptr[p0 + i]; e < indptr[p0 + i + 1]; ++e) {
           const int64_t c = col[e];
           if (c < p0 || c >= p1) continue;
           const int j = static_cast<int>(c - p0);
-          acc += (w ? static_cast<double>(w[e]) : 1.0) * static_cast<double>(dis[j]) * x[j];
+          acc += (w ? static_cast<double>(w[e]) : 1.0) * static_cast<double>(dis[j]) * src[j];
         }
-        const double v = x[i] - static_cast<double>(dis[i]) * acc;  // (Ls x)_i
-        y[i] = v;
-        sq += v * v;
+        v = src[i] - static_cast<double>(dis[i]) * acc;
       }
-      const double nrm2 = ndp_block_sum<THREADS>(sq, s_red);
-      if (!(nrm2 > 0.0)) { random_part = true; break; }  // x fell into the null space (cannot happen for vol > 0)
-      const double inv = 1.0 / sqrt(nrm2);
-      double diff = 0.0;
+      dst[i] = v;
+    }
+  };
+  if (!random_part) {
+    // x <- x / |x|, ax = Ls x, lambda = x . ax
+    double sq = 0.0;
+    for (int i = tid; i < n; i += THREADS) sq += x[i] * x[i];
+    const double x2 = ndp_block_sum<THREADS>(sq, s_red);
+    __syncthreads();
+    for (int i = tid; i < n; i += THREADS) { x[i] *= 1.0 / sqrt(x2); pv[i] = 0.0; ap[i] = 0.0; }
+    __syncthreads();
+    matvec(x, ax);
+    double dt = 0.0;
+    for (int i = tid; i < n; i += THREADS) dt += x[i] * ax[i];
+    double lam = ndp_block_sum<THREADS>(dt, s_red);
+    bool has_p = false;
+    for (; it < max_iter; ++it) {
+      // residual r = ax - lambda x (orthogonal to x), w = r / |r|
+      double r2 = 0.0;
+      for (int i = tid; i < n; i += THREADS) {
+        const double r = ax[i] - lam * x[i];
+        wv[i] = r;
+        r2 += r * r;
+      }
+      const double rn2 = ndp_block_sum<THREADS>(r2, s_red);
+      if (!(rn2 > tol * tol * lam * lam)) break;  // |Ls x - lambda x| <= tol * lambda: converged
+      const double xw_scale = 1.0 / sqrt(rn2);
+      __syncthreads();
+      // re-orthogonalise against x (round-off) while normalising
+      double xw = 0.0;
+      for (int i = tid; i < n; i += THREADS) { wv[i] *= xw_scale; xw += x[i] * wv[i]; }
+      const double cxw = ndp_block_sum<THREADS>(xw, s_red);
+      double w2 = 0.0;
+      for (int i = tid; i < n; i += THREADS) { wv[i] -= cxw * x[i]; w2 += wv[i] * wv[i]; }
+      const double wn2 = ndp_block_sum<THREADS>(w2, s_red);
+      if (!(wn2 > 1e-30)) break;
+      __syncthreads();
+      for (int i = tid; i < n; i += THREADS) wv[i] *= 1.0 / sqrt(wn2);
+      __syncthreads();
+      matvec(wv, aw);
+      // previous direction: orthonormalise against x and w (ap follows by linearity)
+      double h[3][3] = {{lam, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      int dim = 2;
+      if (has_p) {
+        double d0 = 0.0, d1 = 0.0;
+        for (int i = tid; i < n; i += THREADS) { d0 += x[i] * pv[i]; d1 += wv[i] * pv[i]; }
+        const double cxp = ndp_block_sum<THREADS>(d0, s_red);
+        const double cwp = ndp_block_sum<THREADS>(d1, s_red);
+        double p2 = 0.0;
+        for (int i = tid; i < n; i += THREADS) {
+          pv[i] -= cxp * x[i] + cwp * wv[i];
+          ap[i] -= cxp * ax[i] + cwp * aw[i];
+          p2 += pv[i] * pv[i];
+        }
+        const double pn2 = ndp_block_sum<THREADS>(p2, s_red);
+        if (pn2 > 1e-24) {
+          const double ip = 1.0 / sqrt(pn2);
+          for (int i = tid; i < n; i += THREADS) { pv[i] *= ip; ap[i] *= ip; }
+          dim = 3;
+        }
+      }
+      double q01 = 0.0, q11 = 0.0, q02 = 0.0, q12 = 0.0, q22 = 0.0;
+      for (int i = tid; i < n; i += THREADS) {
+        q01 += x[i] * aw[i];
+        q11 += wv[i] * aw[i];
+        if (dim == 3) { q02 += x[i] * ap[i]; q12 += wv[i] * ap[i]; q22 += pv[i] * ap[i]; }
+      }
+      h[0][1] = h[1][0] = ndp_block_sum<THREADS>(q01, s_red);
+      h[1][1] = ndp_block_sum<THREADS>(q11, s_red);
+      if (dim == 3) {
+        h[0][2] = h[2][0] = ndp_block_sum<THREADS>(q02, s_red);
+        h[1][2] = h[2][1] = ndp_block_sum<THREADS>(q12, s_red);
+        h[2][2] = ndp_block_sum<THREADS>(q22, s_red);
+      }
+      double theta, c[3];
+      ndp_eig3_largest(h, dim, theta, c);
+      if (c[0] < 0.0) { c[0] = -c[0]; c[1] = -c[1]; c[2] = -c[2]; }
+      // x <- c0 x + c1 w + c2 p, p <- c1 w + c2 p (and the same combinations of ax, aw, ap)
+      double nx = 0.0;
       __syncthreads();
       for (int i = tid; i < n; i += THREADS) {
-        const double v = y[i] * inv;
-        diff = fmax(diff, fabs(v - x[i]));
-        x[i] = v;
+        const double pn = c[1] * wv[i] + c[2] * pv[i], apn = c[1] * aw[i] + c[2] * ap[i];
+        const double xn = c[0] * x[i] + pn, axn = c[0] * ax[i] + apn;
+        pv[i] = pn; ap[i] = apn; x[i] = xn; ax[i] = axn;
+        nx += xn * xn;
       }
-      const double dmax = ndp_block_max<THREADS>(diff, s_red);
+      const double xn2 = ndp_block_sum<THREADS>(nx, s_red);
+      const double ix = 1.0 / sqrt(xn2);
+      double ld = 0.0;
       __syncthreads();
-      if (dmax < tol) { ++it; break; }
+      for (int i = tid; i < n; i += THREADS) { x[i] *= ix; ax[i] *= ix; ld += x[i] * ax[i]; }
+      lam = ndp_block_sum<THREADS>(ld, s_red);
+      has_p = true;
+      __syncthreads();
     }
+    if (!(lam > 0.0)) random_part = true;  // cannot happen for vol > 0 (Ls has trace n > 0)
   }
   // sign partition and its cut: z^T L z / (2 vol) = (weight of the directed entries that cross the cut) / vol
   if (!random_part) {
@@ -173,12 +326,25 @@ extern "C" int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, cons
   (void)hipMemsetAsync(info, 0, static_cast<size_t>(B) * sizeof(int32_t), stream);
   int64_t cap = max_graph_nodes < NDP_MAX_N ? max_graph_nodes : NDP_MAX_N;
   if (cap < 2) cap = 2;
-  const size_t lds = static_cast<size_t>(cap) * (2 * sizeof(double) + sizeof(float)) + 16;
-  if (cap <= 64)
+  // entries of a graph's matrix kept in LDS: four times the batch average (graph sizes are not known on the host),
+  // at most what one workgroup may take; larger graphs iterate out of L2
+  int64_t ecap = 4 * (nnz / B + 1);
+  if (ecap < 256) ecap = 256;
+  const int64_t fixed = cap * (6 * sizeof(double) + sizeof(float) + sizeof(int)) + 64;
+  const int64_t budget = cap <= 64 ? 12 * 1024 : 150 * 1024;  // 64-thread workgroups: keep ~12 of them on a CU
+  if (fixed + ecap * 10 > budget) ecap = (budget - fixed) / 10 > 0 ? (budget - fixed) / 10 : 0;
+  ecap &= ~static_cast<int64_t>(3);  // keeps the arrays behind the fp64 values 4-byte aligned
+  const size_t lds = static_cast<size_t>(fixed + ecap * 10);
+  const int ncap = static_cast<int>(cap), ec = static_cast<int>(ecap);
+  if (cap <= 64) {
     hipLaunchKernelGGL(ndp_partition_kernel<64>, dim3(static_cast<unsigned>(B)), dim3(64), lds, stream, indptr, col, w,
-                       graph_ptr, static_cast<unsigned long long>(seed), max_iter, tol, keep, info, d_status);
-  else
+                       graph_ptr, static_cast<unsigned long long>(seed), max_iter, tol, ncap, ec, keep, info, d_status);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ndp_partition_kernel<256>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     hipLaunchKernelGGL(ndp_partition_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, indptr, col,
-                       w, graph_ptr, static_cast<unsigned long long>(seed), max_iter, tol, keep, info, d_status);
+                       w, graph_ptr, static_cast<unsigned long long>(seed), max_iter, tol, ncap, ec, keep, info,
+                       d_status);
+  }
   return check_launch("tgp_ndp_partition");
 }

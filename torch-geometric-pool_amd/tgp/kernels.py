@@ -615,10 +615,11 @@ def ndp_max_graph_nodes() -> int:
 
 
 def ndp_partition(indptr: Tensor, col: Tensor, weight: Optional[Tensor], num_nodes: int, graph_ptr: Tensor,
-                  max_graph_nodes: int, seed: int, max_iter: int = 4000, tol: float = 1e-9):
+                  max_graph_nodes: int, seed: int, max_iter: int = 500, tol: float = 1e-6):
     """(keep [N] bool, info [B] int32, status int): NDPSelect's per-graph spectral +-1 partition
-    (select/ndp_select.py:187-256) on a symmetric, self-loop-free CSR adjacency.  info[g] = power iterations used, -1 =
-    the reference's random fallback (cut < 0.5); status != 0: declined, see include/tgp_hip.h."""
+    (select/ndp_select.py:187-256) on a symmetric, self-loop-free CSR adjacency.  info[g] = LOBPCG steps used, -1 =
+    the reference's random fallback (cut < 0.5); status != 0: declined, see include/tgp_hip.h.  ``tol``: relative
+    eigen-residual |Ls x - lambda x| <= tol * lambda at which the iteration stops."""
     dev = N.require_device(indptr, col, weight, graph_ptr)
     if indptr.dtype != torch.int32:
         raise ValueError("ndp_partition: indptr must be int32")
