@@ -31,5 +31,19 @@ names = ["(a) segments -> LDS", "(b) gather", "(c1) rows<=32", "(c1b) rows 33..6
 print("workgroups", nwg, "mean us per workgroup:")
 for i, nm in enumerate(names):
     print(f"  {nm:22s} {float(s[:, i].mean()):7.2f}  (max {float(s[:, i].max()):7.2f})")
+def timed(mode):
+    assert lib.tgp_debug_set_gs_ablate(mode) == 0
+    for _ in range(3):
+        kernels.coalesce_edges(ei, ew, so.cluster_index, k, "sum", True, assign_index=idx)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(20):
+        kernels.coalesce_edges(ei, ew, so.cluster_index, k, "sum", True, assign_index=idx)
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / 20 * 1e3
+assert lib.tgp_debug_set_gs_stamps(0) == 0
+base = timed(0)
+print(f"whole call us: full {base:.1f}; no sort {timed(1):.1f}; no edge/table loads {timed(2):.1f}; neither {timed(3):.1f}; no table {timed(4):.1f}; no col/w {timed(8):.1f}; nt table {timed(16):.1f}")
+lib.tgp_debug_set_gs_ablate(0)
 t0 = s[:, 7].min()
 print("start spread", float((s[:, 7] - t0).max()), "us; total per WG", float(s[:, :6].sum(1).mean()))

@@ -137,44 +137,134 @@ __global__ __launch_bounds__(256) void cr_node_ptr_kernel(const int64_t* __restr
   }
 }
 
-// one thread per supernode: raw row length + offset of each member's edge range inside the row
-__global__ __launch_bounds__(256) void cr_row_len_kernel(const int32_t* __restrict__ a_row_ptr,
-                                                         const int32_t* __restrict__ a_perm,
-                                                         const uint32_t* __restrict__ node_ptr, int64_t K,
-                                                         int* __restrict__ bad, uint32_t* __restrict__ T,
-                                                         uint32_t* __restrict__ member_off) {
-  const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (r >= K) return;
-  if (*bad == 1) {
-    T[r] = 0;
-    return;
+// The same pass with four consecutive edges per thread (two 16-byte loads): a quarter of the waves to launch for a
+// kernel that only streams 8 bytes per edge.  `rows` must be 16-byte aligned (the host picks the variant).
+__global__ __launch_bounds__(256) void cr_node_ptr_vec_kernel(const int64_t* __restrict__ rows, int64_t n,
+                                                              int64_t num_rows, int* __restrict__ bad,
+                                                              uint32_t* __restrict__ node_ptr) {
+  const int64_t p0 = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  volatile int* vbad = bad;
+  if (p0 == 0) {  // the tail [last row + 1, num_rows] (one thread, it also covers n == 0)
+    int64_t first = n > 0 ? rows[n - 1] + 1 : 0;
+    if (first < 0) first = 0;
+    for (int64_t c = first; c <= num_rows; ++c) node_ptr[c] = static_cast<uint32_t>(n);
   }
-  uint32_t run = 0;
-  for (int32_t p = a_row_ptr[r]; p < a_row_ptr[r + 1]; ++p) {
-    const int32_t node = a_perm[p];  // members ascending (the inverted index is stable)
-    member_off[node] = run;
-    run += node_ptr[node + 1] - node_ptr[node];
+  if (p0 >= n) return;
+  int64_t v[4];
+  if (p0 + 4 <= n) {
+    const longlong2 a = *reinterpret_cast<const longlong2*>(rows + p0);
+    const longlong2 b = *reinterpret_cast<const longlong2*>(rows + p0 + 2);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = p0 + i < n ? rows[p0 + i] : num_rows - 1;  // padded with a valid, final id
   }
-  T[r] = run;
-  if (run > CR_LONG) *bad = 2;  // a supernode row too long for the LDS sort: decline
+  int64_t prev = p0 > 0 ? rows[p0 - 1] : -1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (p0 + i >= n) break;
+    const int64_t cur = v[i];
+    if (cur < prev || cur < 0 || cur >= num_rows) {
+      if (*vbad == 0) atomicOr(bad, 1);
+      return;
+    }
+    for (int64_t c = prev + 1; c <= cur; ++c) {
+      node_ptr[c] = static_cast<uint32_t>(p0 + i);
+      if (((c - prev) & 63) == 0 && *vbad) return;
+    }
+    prev = cur;
+  }
 }
 
-// ------------------------------------------------------------------ K4
-// (first edge, first slot) of every member, in inverted-index order: the gather kernel below then reads the
-// segments of its rows as two coalesced runs instead of chasing a_perm -> node_ptr per member
-__global__ __launch_bounds__(256) void cr_segments_kernel(const int32_t* __restrict__ a_perm, int64_t nnz,
-                                                          const int32_t* __restrict__ table,
-                                                          const uint32_t* __restrict__ node_ptr,
-                                                          const uint32_t* __restrict__ member_off,
-                                                          const uint32_t* __restrict__ raw_off,
-                                                          const int* __restrict__ bad, uint32_t* __restrict__ seg_src,
-                                                          uint32_t* __restrict__ seg_dst) {
+// ------------------------------------------------------------------ K2 / K3: member segments
+// Every member p of the inverted index (members of supernode 0, then of supernode 1, ...) contributes one contiguous
+// range of the row-sorted input: seg_src[p] = its first edge, and its first slot in the supernode-row-major raw
+// layout is the exclusive prefix of the member degrees, seg_dst[p] (seg_dst[nnz] = E).  Two kernels: degree sums per
+// tile of MS_TILE members (+ the int32 cluster table, an independent N-sized copy that rides along), then the scan.
+constexpr int MS_ITEMS = 8;
+constexpr int MS_TILE = 256 * MS_ITEMS;
+__global__ __launch_bounds__(256) void cr_member_sums_kernel(const int32_t* __restrict__ a_perm, int64_t nnz,
+                                                             const uint32_t* __restrict__ node_ptr,
+                                                             const int64_t* __restrict__ cluster, int64_t n_nodes,
+                                                             const int* __restrict__ bad, int32_t* __restrict__ table,
+                                                             uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t s_w[4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * MS_TILE + static_cast<int64_t>(threadIdx.x) * MS_ITEMS;
+#pragma unroll
+  for (int i = 0; i < MS_ITEMS; ++i)
+    if (base + i < n_nodes) table[base + i] = static_cast<int32_t>(cluster[base + i]);
+  if (static_cast<int64_t>(blockIdx.x) * MS_TILE >= nnz) return;
+  uint32_t sum = 0;
+  if (*bad == 0) {  // rows not sorted: node_ptr is not a CSR, the call declines
+    int32_t node[MS_ITEMS];
+#pragma unroll
+    for (int i = 0; i < MS_ITEMS; ++i) node[i] = base + i < nnz ? a_perm[base + i] : -1;
+#pragma unroll
+    for (int i = 0; i < MS_ITEMS; ++i)
+      if (node[i] >= 0) sum += node_ptr[node[i] + 1] - node_ptr[node[i]];
+  }
+  uint32_t total;
+  block_excl_scan_256(sum, s_w, &total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// self_offsets: tile_sums are raw sums (every workgroup adds up the ones before it); else exclusive offsets
+__global__ __launch_bounds__(256) void cr_member_scan_kernel(const int32_t* __restrict__ a_perm, int64_t nnz,
+                                                             const uint32_t* __restrict__ node_ptr,
+                                                             const uint32_t* __restrict__ tile_sums, int self_offsets,
+                                                             const int* __restrict__ bad,
+                                                             uint32_t* __restrict__ seg_src,
+                                                             uint32_t* __restrict__ seg_dst) {
+  __shared__ uint32_t s_w[4];
+  __shared__ uint32_t s_off;
   if (*bad) return;
-  const int64_t p = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (p >= nnz) return;
-  const int32_t node = a_perm[p];
-  seg_src[p] = node_ptr[node];
-  seg_dst[p] = raw_off[table[node]] + member_off[node];
+  uint32_t tile_off;
+  if (self_offsets) {
+    uint32_t acc = 0;
+    for (int i = threadIdx.x; i < static_cast<int>(blockIdx.x); i += 256) acc += tile_sums[i];
+    uint32_t tot;
+    block_excl_scan_256(acc, s_w, &tot);
+    if (threadIdx.x == 0) s_off = tot;
+    __syncthreads();
+    tile_off = s_off;
+    __syncthreads();
+  } else {
+    tile_off = tile_sums[blockIdx.x];
+  }
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * MS_TILE + static_cast<int64_t>(threadIdx.x) * MS_ITEMS;
+  int32_t node[MS_ITEMS];
+  uint32_t first[MS_ITEMS], len[MS_ITEMS], sum = 0;
+#pragma unroll
+  for (int i = 0; i < MS_ITEMS; ++i) node[i] = base + i < nnz ? a_perm[base + i] : -1;
+#pragma unroll
+  for (int i = 0; i < MS_ITEMS; ++i) {
+    first[i] = node[i] >= 0 ? node_ptr[node[i]] : 0u;
+    len[i] = node[i] >= 0 ? node_ptr[node[i] + 1] - first[i] : 0u;
+    sum += len[i];
+  }
+  uint32_t tile_total;
+  uint32_t run = tile_off + block_excl_scan_256(sum, s_w, &tile_total);
+#pragma unroll
+  for (int i = 0; i < MS_ITEMS; ++i) {
+    if (base + i < nnz) {
+      seg_src[base + i] = first[i];
+      seg_dst[base + i] = run;
+    }
+    run += len[i];
+    if (base + i == nnz - 1) seg_dst[nnz] = run;
+  }
+}
+
+// raw_off[r] = first slot of supernode row r = first slot of its first member (an empty row shares its successor's);
+// a row longer than the LDS sort takes declines the call before the heavy kernel runs.
+__global__ __launch_bounds__(256) void cr_raw_off_kernel(const int32_t* __restrict__ a_row_ptr, int64_t K,
+                                                         const uint32_t* __restrict__ seg_dst, int* __restrict__ bad,
+                                                         uint32_t* __restrict__ raw_off) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (r >= K || *bad == 1) return;
+  const uint32_t lo = seg_dst[a_row_ptr[r]], hi = seg_dst[a_row_ptr[r + 1]];
+  raw_off[r] = lo;
+  if (hi - lo > static_cast<uint32_t>(CR_LONG)) *bad = 2;
 }
 
 // ------------------------------------------------------------------ K5
@@ -207,6 +297,7 @@ __device__ __forceinline__ float cr_reduce(float acc, float v, int op) {
 // coalesced-as-possible request, so the latency chain is paid once per ~1000 edges instead of once per row.
 #ifdef TGP_GEMM_STAMPS  // diagnostic build only (make stamps): time per phase of cr_gather_sort_kernel, per workgroup
 __device__ unsigned long long* g_gs_stamps = nullptr;
+__device__ int g_gs_ablate = 0;  // 1: no in-row sort, 2: no edge / table loads (synthetic keys), 3: neither
 #define GS_STAMP(slot)                                                                              \
   do {                                                                                              \
     if (g_gs_stamps && threadIdx.x == 0) {                                                          \
@@ -220,7 +311,6 @@ __device__ unsigned long long* g_gs_stamps = nullptr;
 #endif
 constexpr int GS_ROWS = 32;
 constexpr int GS_CAP = 1024;   // raw entries staged per pass (>= CR_LONG)
-constexpr int GS_MEM = 512;    // members per pass
 
 // ------------------------------------------------------------------ in-row sort + merge, LPR lanes per row
 // A row of up to 4 * LPR entries is sorted by LPR lanes holding 4 keys each (element e of the row lives in lane e / 4,
@@ -258,6 +348,12 @@ __device__ __forceinline__ void cr_intra21(uint32_t (&k)[4]) {
   cr_ce(k[0], k[1]); cr_ce(k[2], k[3]);  // j = 1
 }
 
+// DPP move (row_shr:n = 0x110 + n, row_shl:n = 0x100 + n, inside a 16-lane row; lanes shifted in from outside read 0)
+template <int CTRL>
+__device__ __forceinline__ uint32_t cr_dpp(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, true));
+}
+
 template <int LPR>
 __device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, const float* s_val, uint32_t b, uint32_t T, bool mine,
                                              uint32_t row_id, uint32_t base, bool has_w, int reduce_op, int flags,
@@ -291,13 +387,45 @@ __device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, const float* s_val
     c[q] = k[q] >> PB;
     acc[q] = (valid[q] && has_w) ? s_val[b + (k[q] & PM)] : 0.f;
   }
-  const uint32_t pc = __shfl_up(c[3], 1, LPR);  // an earlier element of a valid one is valid
+  const uint32_t pc = cr_dpp<0x111>(c[3]);  // row_shr:1; an earlier element of a valid one is valid
   head[0] = valid[0] && (l == 0 || pc != c[0]);
 #pragma unroll
   for (int q = 1; q < 4; ++q) head[q] = valid[q] && c[q] != c[q - 1];
-  const bool dup_here = (valid[0] && !head[0]) || (valid[1] && !head[1]) || (valid[2] && !head[2]) || (valid[3] && !head[3]);
+  // Duplicates of a column that the self-loop filter drops anyway need no folding (a Graclus row always holds its
+  // own column twice: the matched pair's edge, seen from both ends).
+  const bool drop_self = (flags & TGP_REMOVE_SELF_LOOPS) != 0;
+  bool nonhead[4], fold_here = false;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    nonhead[q] = valid[q] && !head[q];
+    fold_here = fold_here || (nonhead[q] && !(drop_self && c[q] == row_id));
+  }
   uint32_t ncnt[4] = {1, 1, 1, 1};
-  if (__any(dup_here)) {  // duplicate columns somewhere in this wave (rare): heads fold their run from LDS
+  const bool any_fold = __any(fold_here);
+  bool long_run = false;
+  if (any_fold) {  // a run of three or more equal columns anywhere in the wave?
+    // (DPP reads 0 from lanes that are switched off: move first, with every lane on, then mask)
+    const uint32_t prev_nh = cr_dpp<0x111>(nonhead[3] ? 1u : 0u);
+    const bool prev_nonhead = (l > 0) & (prev_nh != 0u);
+    long_run = __any((nonhead[0] && prev_nonhead) || (nonhead[1] && nonhead[0]) || (nonhead[2] && nonhead[1]) ||
+                     (nonhead[3] && nonhead[2]));
+  }
+  if (any_fold && !long_run) {  // runs of two: the head takes its successor's weight, in registers
+    const uint32_t next_nh = cr_dpp<0x101>(nonhead[0] ? 1u : 0u);  // row_shl:1
+    const bool next_nonhead = (l < LPR - 1) & (next_nh != 0u);
+    const float next_acc = __uint_as_float(cr_dpp<0x101>(__float_as_uint(acc[0])));
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (head[q] && nonhead[q + 1]) {
+        acc[q] = cr_reduce(acc[q], acc[q + 1], reduce_op);
+        ncnt[q] = 2;
+      }
+    }
+    if (head[3] && next_nonhead) {
+      acc[3] = cr_reduce(acc[3], next_acc, reduce_op);
+      ncnt[3] = 2;
+    }
+  } else if (any_fold) {  // longer runs (rare): heads fold their run from LDS, in input order
     // the sorted keys go back to the row's own slots (every lane of the row has its keys in registers by now)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -326,10 +454,17 @@ __device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, const float* s_val
     cnt_lane += keep[q] ? 1u : 0u;
   }
   uint32_t incl = cnt_lane;  // inclusive scan over the LPR lanes of the row
-#pragma unroll
-  for (int d = 1; d < LPR; d <<= 1) {
-    const uint32_t t = __shfl_up(incl, d, LPR);
-    if (l >= d) incl += t;
+  {
+    uint32_t t = cr_dpp<0x111>(incl);  // row_shr:d inside the 16-lane row; the l >= d guard keeps it inside the LPR group
+    if (l >= 1) incl += t;
+    t = cr_dpp<0x112>(incl);
+    if (l >= 2) incl += t;
+    t = cr_dpp<0x114>(incl);
+    if (l >= 4) incl += t;
+    if constexpr (LPR == 16) {
+      t = cr_dpp<0x118>(incl);
+      if (l >= 8) incl += t;
+    }
   }
   uint32_t rank = incl - cnt_lane;
 #pragma unroll
@@ -356,7 +491,6 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
     int64_t n_nodes) {
   __shared__ uint32_t s_key[GS_CAP];
   __shared__ float s_val[GS_CAP];
-  __shared__ uint32_t s_seg_dst[GS_MEM], s_seg_src[GS_MEM];
   __shared__ uint32_t s_roff[GS_ROWS + 1];
   __shared__ int32_t s_rp[GS_ROWS + 1];
   __shared__ int s_mid[GS_ROWS];
@@ -378,19 +512,15 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
   const bool has_w = tmp_w != nullptr;
   int rs = 0;
   while (rs < nrows) {
-    if (s_rp[rs + 1] - s_rp[rs] > GS_MEM) {  // one supernode with too many members for a pass: decline
-      if (tid == 0) *bad = 3;
-      return;
-    }
     if (s_roff[rs + 1] - s_roff[rs] > static_cast<uint32_t>(CR_LONG)) {  // a supernode row too long for the LDS sort
       if (tid == 0) *bad = 2;
       return;
     }
     int re = rs + 1;
-    if (s_roff[nrows] - s_roff[rs] <= static_cast<uint32_t>(GS_CAP) && s_rp[nrows] - s_rp[rs] <= GS_MEM) {
+    if (s_roff[nrows] - s_roff[rs] <= static_cast<uint32_t>(GS_CAP)) {
       re = nrows;  // the usual case: all remaining rows fit one pass (no serial walk over the rows)
     } else {
-      while (re < nrows && s_roff[re + 1] - s_roff[rs] <= static_cast<uint32_t>(GS_CAP) && s_rp[re + 1] - s_rp[rs] <= GS_MEM) ++re;
+      while (re < nrows && s_roff[re + 1] - s_roff[rs] <= static_cast<uint32_t>(GS_CAP)) ++re;
     }
     const uint32_t base = s_roff[rs];
     const int cnt = static_cast<int>(s_roff[re] - base);
@@ -403,54 +533,104 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
         s_val[t] = __uint_as_float(static_cast<uint32_t>(v >> 32));
       }
     } else {
-    // (a) members -> (first edge, first slot)
-    for (int m = tid; m < M; m += 256) {
-      s_seg_src[m] = seg_src[p_lo + m];
-      s_seg_dst[m] = seg_dst[p_lo + m] - base;
-    }
-    __syncthreads();
-    GS_STAMP(0);
-    // (b) slot-parallel gather through the cluster table
-    {  // all GS_CAP / 256 slots of a thread are requested before any is consumed: one round trip per level
-      constexpr int U = GS_CAP / 256;
-      uint32_t eidx[U];
-      int64_t cc[U];
-      float wv[U];
+    // (a+b) member-parallel gather: 8 lanes walk one member's edge range (a contiguous run of the row-sorted
+    // input), map the columns through the cluster table and drop (cluster, w) into the member's LDS slots.  Two
+    // rounds of 32 members x two steps of 8 edges are requested before any is consumed: one round trip per level
+    // (segments -> edges -> table) for the usual 64 members of <= 16 edges; longer members finish in the tail loop.
+    {
+      const int grp = tid >> 3, l = tid & 7;
+      const uint32_t end_all = base + static_cast<uint32_t>(cnt);
+      constexpr int GR = GS_CAP / 512;  // rounds of 32 members in flight
+      for (int m0 = 0; m0 < M; m0 += 32 * GR) {
+        uint32_t src[GR], dst[GR], len[GR];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int t = tid + u * 256;
-        eidx[u] = 0;
-        if (t < cnt) {
-          int lo = 0, hi = M;  // last member with dst <= t (zero-length members share their successor's dst)
-          while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_seg_dst[mid] <= static_cast<uint32_t>(t)) lo = mid; else hi = mid;
+        for (int r = 0; r < GR; ++r) {
+          const int m = m0 + r * 32 + grp;
+          const bool v = m < M;
+          src[r] = v ? seg_src[p_lo + m] : 0u;
+          const uint32_t d = v ? seg_dst[p_lo + m] : 0u;
+          const uint32_t nx = m + 1 < M ? seg_dst[p_lo + m + 1] : end_all;  // zero-length members share a slot
+          len[r] = v ? nx - d : 0u;
+          dst[r] = d - base;
+        }
+        int64_t cc[GR][2];
+        float wv[GR][2];
+#pragma unroll
+        for (int r = 0; r < GR; ++r)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint32_t j = static_cast<uint32_t>(l + 8 * q);
+            bool ok = j < len[r];
+#ifdef TGP_GEMM_STAMPS
+            if (g_gs_ablate & 2) ok = false;
+#endif
+#ifdef TGP_GEMM_STAMPS
+            if (g_gs_ablate & 8) {  // no col / w loads: synthetic node ids, table lookups stay
+              cc[r][q] = static_cast<int64_t>(((src[r] + j) * 2654435761u) % static_cast<uint32_t>(n_nodes));
+              wv[r][q] = 1.f;
+              continue;
+            }
+#endif
+            cc[r][q] = ok ? col[src[r] + j] : 0;
+            wv[r][q] = (ok && has_w) ? w[src[r] + j] : 0.f;
           }
-          eidx[u] = s_seg_src[lo] + (static_cast<uint32_t>(t) - s_seg_dst[lo]);
-        }
-      }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool ok = tid + u * 256 < cnt;
-        cc[u] = ok ? col[eidx[u]] : 0;
-        wv[u] = (ok && has_w) ? w[eidx[u]] : 0.f;
-      }
+        for (int r = 0; r < GR; ++r)
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int t = tid + u * 256;
-        if (t < cnt) {
-          // a column outside [0, n_nodes): decline (the general path reports it); never used as an index
-          const bool inr = static_cast<uint64_t>(cc[u]) < static_cast<uint64_t>(n_nodes);
-          if (!inr) *bad = 4;
-          s_key[t] = inr ? static_cast<uint32_t>(table[cc[u]]) : 0u;
-          s_val[t] = wv[u];
-        }
+          for (int q = 0; q < 2; ++q) {
+            const uint32_t j = static_cast<uint32_t>(l + 8 * q);
+            if (j < len[r]) {
+              // a column outside [0, n_nodes): decline (the general path reports it); never used as an index
+              const bool inr = static_cast<uint64_t>(cc[r][q]) < static_cast<uint64_t>(n_nodes);
+              if (!inr) *bad = 4;
+#ifdef TGP_GEMM_STAMPS
+              if (g_gs_ablate & 2) {
+                s_key[dst[r] + j] = ((src[r] + j) * 2654435761u) >> 13;
+                s_val[dst[r] + j] = 1.f;
+                continue;
+              }
+#endif
+#ifdef TGP_GEMM_STAMPS
+              if (g_gs_ablate & 4) {  // no table lookups
+                s_key[dst[r] + j] = static_cast<uint32_t>(cc[r][q]) >> 1;
+                s_val[dst[r] + j] = wv[r][q];
+                continue;
+              }
+#endif
+#ifdef TGP_GEMM_STAMPS
+              if (g_gs_ablate & 16) {  // nontemporal table lookups
+                s_key[dst[r] + j] = inr ? static_cast<uint32_t>(__builtin_nontemporal_load(table + cc[r][q])) : 0u;
+                s_val[dst[r] + j] = wv[r][q];
+                continue;
+              }
+#endif
+              s_key[dst[r] + j] = inr ? static_cast<uint32_t>(table[cc[r][q]]) : 0u;
+              s_val[dst[r] + j] = wv[r][q];
+            }
+          }
+#pragma unroll
+        for (int r = 0; r < GR; ++r)
+          for (uint32_t j = static_cast<uint32_t>(l) + 16; j < len[r]; j += 8) {
+            const int64_t c = col[src[r] + j];
+            const bool inr = static_cast<uint64_t>(c) < static_cast<uint64_t>(n_nodes);
+            if (!inr) *bad = 4;
+            s_key[dst[r] + j] = inr ? static_cast<uint32_t>(table[c]) : 0u;
+            s_val[dst[r] + j] = has_w ? w[src[r] + j] : 0.f;
+          }
       }
     }
     }
     __syncthreads();
     GS_STAMP(1);
     // (c1) rows of <= 32 entries: 8 lanes x 4 keys each, all 32 rows of the pass at once (cr_sort_rows)
+#ifdef TGP_GEMM_STAMPS
+    if (g_gs_ablate & 1) {
+      if (tid < re - rs) n_out[r0 + rs + tid] = s_key[tid] & 1;
+      rs = re;
+      __syncthreads();
+      continue;
+    }
+#endif
     {
       constexpr int LPR = 8;
       const int grp = tid / LPR;
@@ -627,10 +807,8 @@ __global__ __launch_bounds__(256) void cr_fill_kernel(const uint32_t* __restrict
 struct CrWs {
   int32_t* table;        // [N]
   uint32_t* node_ptr;    // [N+1]
-  uint32_t* member_off;  // [N]
   uint32_t* seg_src;     // [N] first edge of every member (inverted-index order)
-  uint32_t* seg_dst;     // [N] first slot of every member
-  uint32_t* T;           // [K]
+  uint32_t* seg_dst;     // [N + 1] first slot of every member, then E
   uint32_t* raw_off;     // [K]
   uint32_t* n_out;       // [K]
   uint32_t* out_off;     // [K]
@@ -648,16 +826,14 @@ static size_t cr_layout(void* ws, int64_t E, int64_t N, int64_t K, CrWs* out) {
   CrWs s;
   s.table = cv.take<int32_t>(n);
   s.node_ptr = cv.take<uint32_t>(n + 1);
-  s.member_off = cv.take<uint32_t>(n);
   s.seg_src = cv.take<uint32_t>(n);
-  s.seg_dst = cv.take<uint32_t>(n);
-  s.T = cv.take<uint32_t>(k);
+  s.seg_dst = cv.take<uint32_t>(n + 1);
   s.raw_off = cv.take<uint32_t>(k);
   s.n_out = cv.take<uint32_t>(k);
   s.out_off = cv.take<uint32_t>(k);
   s.tmp_c = cv.take<uint32_t>(e);
   s.tmp_w = cv.take<float>(e);
-  s.scan_scratch = cv.take<uint32_t>(2 * static_cast<size_t>(cdiv(k, SCAN_TILE)) + 16);
+  s.scan_scratch = cv.take<uint32_t>(2 * static_cast<size_t>(cdiv(k, SCAN_TILE) + cdiv(n, MS_TILE)) + 16);
   s.total = cv.take<int64_t>(2);
   s.bad = cv.take<int>(4);
   if (out) *out = s;
@@ -701,15 +877,32 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
   cr_layout(ws, E, N, K, &s);
   float* tmp_w = w ? s.tmp_w : nullptr;
   (void)hipMemsetAsync(s.bad, 0, sizeof(int), stream);
-  hipLaunchKernelGGL(cr_node_ptr_kernel, dim3(cdiv(E + 1, 256)), dim3(256), 0, stream, row, E, N, s.bad, s.node_ptr);
-  hipLaunchKernelGGL(cr_table_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, cluster_index, N, s.table);
-  hipLaunchKernelGGL(cr_row_len_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, assign_row_ptr, assign_perm,
-                     s.node_ptr, K, s.bad, s.T, s.member_off);
-  device_scan_u32(s.T, K, s.raw_off, s.total, s.scan_scratch, stream);
-  // (measured r2: splitting this into an edge-parallel permute pass + the DIRECT sort kernel costs 114 + 103 us against
-  //  185 us for the fused gather: the 10 M random 4-byte table look-ups take ~50 us wherever they run)
-  hipLaunchKernelGGL(cr_segments_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, assign_perm, N, s.table, s.node_ptr,
-                     s.member_off, s.raw_off, s.bad, s.seg_src, s.seg_dst);
+  if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+    hipLaunchKernelGGL(cr_node_ptr_vec_kernel, dim3(cdiv(cdiv(E, 4) + 1, 256)), dim3(256), 0, stream, row, E, N, s.bad,
+                       s.node_ptr);
+  } else {
+    hipLaunchKernelGGL(cr_node_ptr_kernel, dim3(cdiv(E + 1, 256)), dim3(256), 0, stream, row, E, N, s.bad, s.node_ptr);
+  }
+  {  // member segments: degree sums per tile (+ cluster table), scan, row offsets
+    const int nt = cdiv(N, MS_TILE);
+    uint32_t* sums = s.scan_scratch;
+    uint32_t* offs = s.scan_scratch + nt;
+    hipLaunchKernelGGL(cr_member_sums_kernel, dim3(nt), dim3(256), 0, stream, assign_perm, N, s.node_ptr, cluster_index,
+                       N, s.bad, s.table, sums);
+    if (nt <= SCAN_SELF_TILES) {
+      hipLaunchKernelGGL(cr_member_scan_kernel, dim3(nt), dim3(256), 0, stream, assign_perm, N, s.node_ptr, sums, 1, s.bad,
+                         s.seg_src, s.seg_dst);
+    } else {
+      hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, sums, nt, offs, s.total,
+                         static_cast<const int*>(nullptr));
+      hipLaunchKernelGGL(cr_member_scan_kernel, dim3(nt), dim3(256), 0, stream, assign_perm, N, s.node_ptr, offs, 0, s.bad,
+                         s.seg_src, s.seg_dst);
+    }
+    hipLaunchKernelGGL(cr_raw_off_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, assign_row_ptr, K, s.seg_dst, s.bad,
+                       s.raw_off);
+  }
+  // (measured r2: splitting the gather into an edge-parallel permute pass + the DIRECT sort kernel costs 114 + 103 us
+  //  against 185 us for the fused gather: the 10 M random 4-byte table look-ups take ~50 us wherever they run)
   hipLaunchKernelGGL(cr_gather_sort_kernel<false>, dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, col, w, E, s.table,
                      assign_row_ptr, s.seg_src, s.seg_dst, static_cast<const unsigned long long*>(nullptr), s.raw_off, K,
                      reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out, N);
@@ -847,6 +1040,9 @@ extern "C" int tgp_connect_coalesce_rows_fill(const void* ws, int64_t E, int64_t
 }
 
 #ifdef TGP_GEMM_STAMPS
+extern "C" int tgp_debug_set_gs_ablate(int mode) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(tgp::g_gs_ablate), &mode, sizeof(mode)) == hipSuccess ? 0 : -3;
+}
 extern "C" int tgp_debug_set_gs_stamps(unsigned long long* p) {
   return hipMemcpyToSymbol(HIP_SYMBOL(tgp::g_gs_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
 }
