@@ -292,3 +292,39 @@ def test_out_of_range_node_ids_are_refused_not_dereferenced(dev):
     assert out_ei.size(1) > 0 and int(out_ei.max()) < n // 2
     with pytest.raises(IndexError):
         SelectOutput(cluster_index=torch.tensor([0, 3, 1], device=dev), num_supernodes=3)
+
+
+@pytest.mark.parametrize("case", ["pairs", "upto8", "medium", "hub", "mostly_singletons_one_giant"])
+def test_counting_assign_index_equals_stable_sort(dev, case):
+    """The inverted assignment index (supernode -> its assignments, ascending) must be the stable sort by supernode
+    whatever route builds it (reduce/base_reduce.py:146-153 reduces in that order): the counting route (few members
+    per supernode) handles supernodes of 2, <= 8, <= 8192 and > 8192 members by four different code paths."""
+    from tgp import kernels
+    g = torch.Generator().manual_seed(11)
+    n = 300_000
+    if case == "pairs":
+        k = n // 2
+        cluster = torch.randperm(n, generator=g) // 2
+    elif case == "upto8":
+        k = n // 4
+        cluster = torch.randint(0, k, (n,), generator=g)
+    elif case == "medium":
+        k = n // 3
+        cluster = torch.randint(0, k, (n,), generator=g)
+        cluster[torch.randperm(n, generator=g)[:5000]] = 17      # one supernode of ~5000 members (LDS bitonic)
+        cluster[torch.randperm(n, generator=g)[:300]] = 4242     # and one of ~300
+    elif case == "hub":
+        k = n // 3
+        cluster = torch.randint(0, k, (n,), generator=g)
+        cluster[torch.randperm(n, generator=g)[:20000]] = 5      # > 8192 members: stable-compaction route
+    else:
+        k = n // 2
+        cluster = torch.arange(n) % k
+        cluster[: n // 4] = k - 1
+    idx = kernels.build_assign_index(cluster.to(dev), k)
+    order = torch.argsort(cluster, stable=True)
+    counts = torch.bincount(cluster, minlength=k)
+    row_ptr = torch.zeros(k + 1, dtype=torch.int64)
+    row_ptr[1:] = torch.cumsum(counts, 0)
+    assert torch.equal(idx._row_ptr.cpu().long(), row_ptr)
+    assert torch.equal(idx.perm.cpu().long()[:n], order)

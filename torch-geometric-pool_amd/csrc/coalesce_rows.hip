@@ -25,90 +25,6 @@
 namespace tgp {
 
 constexpr int CR_LONG = 1024;    // longest supernode row (raw entries) the LDS kernel sorts
-constexpr int SCAN_ITEMS = 16;
-constexpr int SCAN_TILE = 256 * SCAN_ITEMS;
-
-// total survivors -> d_count, or -1 when a precondition failed
-__global__ void cr_finish_count_kernel(const int* __restrict__ bad, const int64_t* __restrict__ total,
-                                       int64_t* __restrict__ d_count) {
-  *d_count = *bad ? -1 : *total;
-}
-
-// ------------------------------------------------------------------ multi-block exclusive scan (u32)
-__global__ __launch_bounds__(256) void scan_tile_sums_kernel(const uint32_t* __restrict__ in, int64_t n,
-                                                             uint32_t* __restrict__ tile_sums) {
-  __shared__ uint32_t s_w[4];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * SCAN_TILE + static_cast<int64_t>(threadIdx.x) * SCAN_ITEMS;
-  uint32_t s = 0;
-#pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; ++i)
-    if (base + i < n) s += in[base + i];
-  uint32_t total;
-  block_excl_scan_256(s, s_w, &total);
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
-}
-
-// Second (and last) pass: every workgroup adds up the sums of the tiles before it (<= SCAN_SELF_TILES of them, a
-// few hundred words) instead of waiting for a separate scan-of-sums launch; the last one also publishes the
-// total and, if asked, the caller-visible count (-1 when a precondition flag is set).
-constexpr int SCAN_SELF_TILES = 4096;
-__global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t* __restrict__ in, int64_t n,
-                                                         const uint32_t* __restrict__ tile_sums, int self_offsets,
-                                                         uint32_t* __restrict__ out, int64_t* __restrict__ total,
-                                                         const int* __restrict__ bad, int64_t* __restrict__ d_count) {
-  __shared__ uint32_t s_w[4];
-  __shared__ uint32_t s_off;
-  uint32_t tile_off;
-  if (self_offsets) {
-    uint32_t acc = 0;
-    for (int i = threadIdx.x; i < static_cast<int>(blockIdx.x); i += 256) acc += tile_sums[i];
-    uint32_t tot;
-    block_excl_scan_256(acc, s_w, &tot);
-    if (threadIdx.x == 0) s_off = tot;
-    __syncthreads();
-    tile_off = s_off;
-    __syncthreads();
-  } else {
-    tile_off = tile_sums[blockIdx.x];  // already exclusive offsets
-  }
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * SCAN_TILE + static_cast<int64_t>(threadIdx.x) * SCAN_ITEMS;
-  uint32_t v[SCAN_ITEMS], sacc = 0;
-#pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; ++i) {
-    v[i] = base + i < n ? in[base + i] : 0u;
-    sacc += v[i];
-  }
-  uint32_t tile_total;
-  uint32_t run = tile_off + block_excl_scan_256(sacc, s_w, &tile_total);
-#pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; ++i) {
-    if (base + i < n) out[base + i] = run;
-    run += v[i];
-  }
-  if (self_offsets && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-    const int64_t t = static_cast<int64_t>(tile_off) + tile_total;
-    if (total) *total = t;
-    if (d_count) *d_count = (bad && *bad) ? -1 : t;
-  }
-}
-
-// out[0..n) = exclusive prefix of in, *total = sum.  tile scratch: 2 * ceil(n / SCAN_TILE) words.
-// d_count (optional): also receives the total, or -1 if *bad is set.
-static void device_scan_u32(const uint32_t* in, int64_t n, uint32_t* out, int64_t* total, uint32_t* tile_scratch,
-                            hipStream_t stream, const int* bad = nullptr, int64_t* d_count = nullptr) {
-  const int nt = cdiv(n > 0 ? n : 1, SCAN_TILE);
-  uint32_t* sums = tile_scratch;
-  uint32_t* offs = tile_scratch + nt;
-  hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(nt), dim3(256), 0, stream, in, n, sums);
-  if (nt <= SCAN_SELF_TILES) {
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nt), dim3(256), 0, stream, in, n, sums, 1, out, total, bad, d_count);
-    return;
-  }
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, sums, nt, offs, total, static_cast<const int*>(nullptr));
-  hipLaunchKernelGGL(scan_apply_kernel, dim3(nt), dim3(256), 0, stream, in, n, offs, 0, out, nullptr, nullptr, nullptr);
-  if (d_count) hipLaunchKernelGGL(cr_finish_count_kernel, dim3(1), dim3(1), 0, stream, bad, total, d_count);
-}
-
 // ------------------------------------------------------------------ K1 / K2
 // CSR offsets of the (row-sorted) input AND the sortedness check in one pass over the row array: thread p owns
 // edge p and fills node_ptr for the nodes that start between its predecessor's row and its own.  An inversion (or a

@@ -41,6 +41,117 @@ __global__ __launch_bounds__(256) void assign_rowptr_kernel(const uint32_t* __re
   for (int64_t c = prev + 1; c <= cur; ++c) row_ptr[c] = static_cast<int32_t>(p);
 }
 
+// ------------------------------------------------------------------ counting index (few members per supernode)
+// The radix route above is three launch-bound passes (nine kernels) for a 20-bit key.  When supernodes hold only a
+// few assignments each (matchings, k-MIS, partitions: nnz <= 8 K) a counting sort does it in four kernels:
+// count with returning atomics (slot of each assignment inside its supernode, in arrival order), scan, scatter,
+// and then every supernode's few members are put in ascending order - which is exactly what the stable sort yields.
+__global__ __launch_bounds__(256) void assign_count_kernel(const int64_t* __restrict__ cluster_index, int64_t nnz,
+                                                           int64_t K, uint32_t* __restrict__ cnt,
+                                                           uint32_t* __restrict__ slot) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= nnz) return;
+  const int64_t c = cluster_index[i];
+  // an id outside [0, K) has no row: the assignment is left out (callers validate ids; this only keeps the
+  // counters in bounds)
+  slot[i] = static_cast<uint64_t>(c) < static_cast<uint64_t>(K) ? atomicAdd(&cnt[c], 1u) : 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(256) void assign_scatter_kernel(const int64_t* __restrict__ cluster_index, int64_t nnz,
+                                                             int64_t K, const uint32_t* __restrict__ slot,
+                                                             const int64_t* __restrict__ total,
+                                                             int32_t* __restrict__ row_ptr,
+                                                             int32_t* __restrict__ perm) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i == 0) row_ptr[K] = static_cast<int32_t>(*total);
+  if (i >= nnz) return;
+  const uint32_t sl = slot[i];
+  if (sl != 0xFFFFFFFFu) perm[row_ptr[cluster_index[i]] + static_cast<int32_t>(sl)] = static_cast<int32_t>(i);
+}
+
+constexpr int AO_SMALL = 8;     // members sorted by the supernode's own thread
+constexpr int AO_MED = 8192;    // members sorted by the workgroup in LDS
+__global__ __launch_bounds__(256) void assign_order_kernel(const int64_t* __restrict__ cluster_index, int64_t nnz,
+                                                           const int32_t* __restrict__ row_ptr, int64_t K,
+                                                           int32_t* __restrict__ perm) {
+  __shared__ int32_t s_buf[AO_MED];
+  __shared__ int s_list[256];
+  __shared__ int s_nlist;
+  __shared__ uint32_t s_cnt[8 * 4];
+  const int tid = threadIdx.x;
+  if (tid == 0) s_nlist = 0;
+  __syncthreads();
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + tid;
+  if (c < K) {
+    const int32_t b = row_ptr[c], n = row_ptr[c + 1] - b;
+    if (n == 2) {
+      const int32_t a0 = perm[b], a1 = perm[b + 1];
+      if (a0 > a1) {
+        perm[b] = a1;
+        perm[b + 1] = a0;
+      }
+    } else if (n > 2 && n <= AO_SMALL) {  // insertion sort in place (the segment is this thread's alone)
+      for (int i = 1; i < n; ++i) {
+        const int32_t key = perm[b + i];
+        int j = i - 1;
+        while (j >= 0 && perm[b + j] > key) {
+          perm[b + j + 1] = perm[b + j];
+          --j;
+        }
+        perm[b + j + 1] = key;
+      }
+    } else if (n > AO_SMALL) {
+      s_list[atomicAdd(&s_nlist, 1)] = tid;
+    }
+  }
+  __syncthreads();
+  const int nlist = s_nlist;
+  for (int li = 0; li < nlist; ++li) {
+    const int64_t cc = static_cast<int64_t>(blockIdx.x) * 256 + s_list[li];
+    const int32_t b = row_ptr[cc], n = row_ptr[cc + 1] - b;
+    if (n <= AO_MED) {  // bitonic sort in LDS
+      int P = 16;
+      while (P < n) P <<= 1;
+      for (int i = tid; i < P; i += 256) s_buf[i] = i < n ? perm[b + i] : 0x7FFFFFFF;
+      __syncthreads();
+      for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int i = tid; i < P; i += 256) {
+            const int x = i ^ j;
+            if (x > i) {
+              const int32_t a0 = s_buf[i], a1 = s_buf[x];
+              if ((a0 > a1) == ((i & k) == 0)) {
+                s_buf[i] = a1;
+                s_buf[x] = a0;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      for (int i = tid; i < n; i += 256) perm[b + i] = s_buf[i];
+      __syncthreads();
+    } else {  // a very large supernode: its members in ascending order = a stable compaction of all assignments
+      uint32_t run = 0;
+      for (int64_t base = 0; base < nnz; base += 2048) {
+        bool flag[8];
+        uint32_t rank[8], block_total;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int64_t i = base + it * 256 + tid;
+          flag[it] = i < nnz && cluster_index[i] == cc;
+        }
+        block_compact_ranks<8>(flag, rank, block_total, s_cnt);
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+          if (flag[it]) perm[b + run + rank[it]] = static_cast<int32_t>(base + it * 256 + tid);
+        run += block_total;
+        __syncthreads();
+      }
+    }
+  }
+}
+
 // One group of G lanes per supernode; lane g owns features [4g,4g+4) (+ 4G strides).  Every group
 // works on U supernodes at once: the (row_ptr -> perm -> node_index/weight -> x row) chains of the U
 // supernodes are issued side by side, so U row gathers are in flight per group instead of one
@@ -172,9 +283,22 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(const int64_t* __rest
 
 using namespace tgp;
 
-extern "C" size_t tgp_assign_index_workspace_bytes(int64_t nnz, int64_t /*num_supernodes*/) {
+// counting route: cnt [K], slot [nnz], scan tiles, total
+static size_t assign_counting_bytes(int64_t nnz, int64_t K) {
+  const size_t n = nnz > 0 ? static_cast<size_t>(nnz) : 1, k = K > 0 ? static_cast<size_t>(K) : 1;
+  return align_up(k * sizeof(uint32_t)) + align_up(n * sizeof(uint32_t)) +
+         align_up((2 * static_cast<size_t>(cdiv(static_cast<int64_t>(k), SCAN_TILE)) + 16) * sizeof(uint32_t)) +
+         align_up(2 * sizeof(int64_t));
+}
+static bool assign_use_counting(int64_t nnz, int64_t K) {
+  return nnz >= 4096 && nnz <= 8 * K && K <= 4 * nnz;  // few members per supernode, and not mostly empty rows
+}
+
+extern "C" size_t tgp_assign_index_workspace_bytes(int64_t nnz, int64_t num_supernodes) {
   const size_t n = nnz > 0 ? static_cast<size_t>(nnz) : 1;
-  return 4 * align_up(n * sizeof(uint32_t)) + align_up(sort_scratch_words() * sizeof(uint32_t));
+  const size_t radix = 4 * align_up(n * sizeof(uint32_t)) + align_up(sort_scratch_words() * sizeof(uint32_t));
+  const size_t counting = assign_use_counting(nnz, num_supernodes) ? assign_counting_bytes(nnz, num_supernodes) : 0;
+  return radix > counting ? radix : counting;
 }
 
 extern "C" int tgp_assign_index_build(const int64_t* cluster_index, int64_t nnz, int64_t K, int32_t* row_ptr,
@@ -187,6 +311,20 @@ extern "C" int tgp_assign_index_build(const int64_t* cluster_index, int64_t nnz,
               "tgp_assign_index_build: workspace too small");
   Carver cv(ws);
   const size_t n = nnz > 0 ? static_cast<size_t>(nnz) : 1;
+  if (assign_use_counting(nnz, K)) {
+    uint32_t* cnt = cv.take<uint32_t>(static_cast<size_t>(K));
+    uint32_t* slot = cv.take<uint32_t>(n);
+    uint32_t* tiles = cv.take<uint32_t>(2 * static_cast<size_t>(cdiv(K, SCAN_TILE)) + 16);
+    int64_t* total = cv.take<int64_t>(2);
+    (void)hipMemsetAsync(cnt, 0, static_cast<size_t>(K) * sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(assign_count_kernel, dim3(cdiv(nnz, 256)), dim3(256), 0, stream, cluster_index, nnz, K, cnt, slot);
+    device_scan_u32(cnt, K, reinterpret_cast<uint32_t*>(row_ptr), total, tiles, stream);
+    hipLaunchKernelGGL(assign_scatter_kernel, dim3(cdiv(nnz, 256)), dim3(256), 0, stream, cluster_index, nnz, K, slot,
+                       total, row_ptr, perm);
+    hipLaunchKernelGGL(assign_order_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, cluster_index, nnz, row_ptr, K,
+                       perm);
+    return check_launch("tgp_assign_index_build");
+  }
   uint32_t* k0 = cv.take<uint32_t>(n);
   uint32_t* v0 = cv.take<uint32_t>(n);
   uint32_t* k1 = cv.take<uint32_t>(n);
