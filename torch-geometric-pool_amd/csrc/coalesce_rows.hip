@@ -271,9 +271,8 @@ __device__ __forceinline__ uint32_t cr_dpp(uint32_t v) {
 }
 
 template <int LPR>
-__device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, const float* s_val, uint32_t b, uint32_t T, bool mine,
-                                             uint32_t row_id, uint32_t base, bool has_w, int reduce_op, int flags,
-                                             float eps, uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w,
+__device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, float* s_val, uint32_t b, uint32_t T, bool mine,
+                                             uint32_t row_id, bool has_w, int reduce_op, int flags, float eps,
                                              uint32_t* __restrict__ n_out_row) {
   constexpr int PB = LPR == 8 ? 5 : 6;          // position bits: 32 or 64 entries per row
   constexpr uint32_t PM = (1u << PB) - 1u;
@@ -385,9 +384,9 @@ __device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, const float* s_val
   uint32_t rank = incl - cnt_lane;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    if (keep[q]) {
-      tmp_c[base + b + rank] = c[q];
-      if (has_w) tmp_w[base + b + rank] = acc[q];
+    if (keep[q]) {  // survivors stay in LDS, compacted at the head of the row's slots (every lane of the row holds
+      s_key[b + rank] = c[q];  // its keys and weights in registers by now, and the row's lanes share a wave);
+      if (has_w) s_val[b + rank] = acc[q];  // the workgroup copies its whole slot range out afterwards, coalesced
       ++rank;
     }
   }
@@ -557,20 +556,11 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
           b = s_roff[i] - base;
           T = s_roff[i + 1] - s_roff[i];
         }
-        if (i < re && T > 32) {
-          const int l = tid & (LPR - 1);
-          if (T <= 64) {
-            if (l == 0) s_mid[atomicAdd(&s_nmid, 1)] = i;
-          } else {  // longer rows: hand the raw (cluster, weight) entries to cr_rows_long_kernel through tmp
-            for (uint32_t j = l; j < T; j += LPR) {
-              tmp_c[base + b + j] = s_key[b + j];
-              if (has_w) tmp_w[base + b + j] = s_val[b + j];
-            }
-          }
-        }
+        // rows of 33..64 entries wait for (c1b); longer ones go out raw with the copy below, for cr_rows_long_kernel
+        if (i < re && T > 32 && T <= 64 && (tid & (LPR - 1)) == 0) s_mid[atomicAdd(&s_nmid, 1)] = i;
         const bool mine = i < re && T <= 32;
-        cr_sort_rows<LPR>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), base, has_w, reduce_op,
-                          flags, eps, tmp_c, tmp_w, n_out + r0 + i);
+        cr_sort_rows<LPR>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), has_w, reduce_op, flags,
+                          eps, n_out + r0 + i);
       }
     }
     __syncthreads();
@@ -584,9 +574,16 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
         const bool mine = li < nmid;
         const int i = mine ? s_mid[li] : rs;
         const uint32_t b = s_roff[i] - base, T = s_roff[i + 1] - s_roff[i];
-        cr_sort_rows<LPR>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), base, has_w, reduce_op,
-                          flags, eps, tmp_c, tmp_w, n_out + r0 + i);
+        cr_sort_rows<LPR>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), has_w, reduce_op, flags,
+                          eps, n_out + r0 + i);
       }
+    }
+    __syncthreads();
+    // the pass's slot range goes out in one coalesced sweep: survivors at the head of every row's slots (what is
+    // behind them is never read: the fill kernel takes n_out[r] entries from raw_off[r]), long rows still raw
+    for (int t = tid; t < cnt; t += 256) {
+      tmp_c[base + t] = s_key[t];
+      if (has_w) tmp_w[base + t] = s_val[t];
     }
     rs = re;
     __syncthreads();
