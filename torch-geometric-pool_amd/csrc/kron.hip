@@ -391,6 +391,7 @@ struct KronWs {
   int64_t* big_off;  // [B+1]
   uint32_t* counts;  // [B]
   uint32_t* out_off; // [B]
+  uint32_t* scan_tiles;  // multi-block scan scratch
   float* dense;
   double* big;
   int64_t cap_dense, cap_big;
@@ -414,6 +415,7 @@ static KronWs carve_kron(void* ws, int64_t N, int64_t B, int64_t max_nodes) {
   s.big_off = c.take<int64_t>(B + 1);
   s.counts = c.take<uint32_t>(B + 1);
   s.out_off = c.take<uint32_t>(B + 1);
+  s.scan_tiles = c.take<uint32_t>(2 * static_cast<size_t>(cdiv(N + 2, SCAN_TILE)) + 16);
   s.dense = c.take<float>(s.cap_dense);
   s.big = c.take<double>(s.cap_big);
   return s;
@@ -429,6 +431,7 @@ extern "C" size_t tgp_kron_batched_workspace_bytes(int64_t N, int64_t B, int64_t
   kron_caps(N, max_graph_nodes, &cd, &cb);
   return align_up((N + 2) * sizeof(uint32_t)) * 2 + align_up(sizeof(int64_t)) + align_up(sizeof(int)) +
          align_up((B + 1) * sizeof(int64_t)) * 2 + align_up((B + 1) * sizeof(uint32_t)) * 2 +
+         align_up((2 * static_cast<size_t>(cdiv(N + 2, SCAN_TILE)) + 16) * sizeof(uint32_t)) +
          align_up(static_cast<size_t>(cd) * sizeof(float)) + align_up(static_cast<size_t>(cb) * sizeof(double)) + 256;
 }
 
@@ -456,8 +459,7 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
   if (num_kept > 0)
     hipLaunchKernelGGL(kron_flags_kernel, dim3(cdiv(num_kept, 256)), dim3(256), 0, stream, node_index, num_kept, N,
                        s.flags, s.status);
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.flags, static_cast<int>(N + 1), s.rank,
-                     s.scan_total, static_cast<const int*>(nullptr));
+  device_scan_u32(s.flags, N + 1, s.rank, s.scan_total, s.scan_tiles, stream);  // (one workgroup took 73 us at N = 82 k)
   hipLaunchKernelGGL(kron_plan_kernel, dim3(1), dim3(1024), 0, stream, graph_ptr, static_cast<int>(B), s.rank, s.sq_off,
                      s.big_off, s.cap_dense, s.cap_big, s.status);
   KronArgs a{};

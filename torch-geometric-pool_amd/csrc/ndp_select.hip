@@ -23,10 +23,34 @@ __device__ __forceinline__ uint32_t ndp_hash(uint64_t seed, uint64_t v) {
   return static_cast<uint32_t>(x);
 }
 
+// Sum over the 64 lanes of a wave, the same value in every lane: four rotate-and-add steps inside the 16-lane rows
+// (DPP row_ror: register moves, no trip through the LDS pipe that a shuffle takes), then the four row sums are read
+// through scalar registers.  The iteration below does a dozen of these per step, back to back.
+template <int CTRL>
+__device__ __forceinline__ double ndp_dpp_f64(double v) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(u), CTRL, 0xF, 0xF, false));
+  const unsigned hi =
+      static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(u >> 32), CTRL, 0xF, 0xF, false));
+  return __longlong_as_double((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+__device__ __forceinline__ double ndp_readlane_f64(double v, int lane) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(u), lane));
+  const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(u >> 32), lane));
+  return __longlong_as_double((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+__device__ __forceinline__ double ndp_wave_sum(double v) {
+  v += ndp_dpp_f64<0x121>(v);  // row_ror:1
+  v += ndp_dpp_f64<0x122>(v);  // row_ror:2
+  v += ndp_dpp_f64<0x124>(v);  // row_ror:4
+  v += ndp_dpp_f64<0x128>(v);  // row_ror:8 -> every lane holds its row's sum
+  return (ndp_readlane_f64(v, 0) + ndp_readlane_f64(v, 16)) + (ndp_readlane_f64(v, 32) + ndp_readlane_f64(v, 48));
+}
+
 template <int THREADS>
 __device__ __forceinline__ double ndp_block_sum(double v, double* s_red) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+  v = ndp_wave_sum(v);
   if constexpr (THREADS == 64) return v;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
@@ -36,6 +60,29 @@ __device__ __forceinline__ double ndp_block_sum(double v, double* s_red) {
   for (int w = 0; w < THREADS / 64; ++w) t += s_red[w];
   return t;
 }
+// K sums at once: the K wave reductions are independent instruction chains (they overlap), and a 256-thread
+// workgroup pays its two barriers once for all of them.  s_red: K * (THREADS / 64) doubles.
+template <int THREADS, int K>
+__device__ __forceinline__ void ndp_block_sums(double (&v)[K], double* s_red) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = ndp_wave_sum(v[k]);
+  if constexpr (THREADS == 64) return;
+  constexpr int NW = THREADS / 64;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) s_red[k * NW + (threadIdx.x >> 6)] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += s_red[k * NW + w];
+    v[k] = t;
+  }
+}
+
 template <int THREADS>
 __device__ __forceinline__ double ndp_block_max(double v, double* s_red) {
 #pragma unroll
@@ -54,12 +101,17 @@ __device__ __forceinline__ double ndp_block_max(double v, double* s_red) {
 __device__ __forceinline__ void ndp_eig3_largest(double a[3][3], int dim, double& theta, double c[3]) {
   double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
   for (int sweep = 0; sweep < 8; ++sweep) {
+    // every lane holds the same numbers, so the exits below are wave-uniform; near convergence the matrix is
+    // already almost diagonal (a[0][1] is the residual norm) and one or two sweeps finish it
+    const double off = fabs(a[0][1]) + (dim == 3 ? fabs(a[0][2]) + fabs(a[1][2]) : 0.0);
+    const double dia = fabs(a[0][0]) + fabs(a[1][1]) + (dim == 3 ? fabs(a[2][2]) : 0.0);
+    if (!(off > 1e-17 * dia)) break;
 #pragma unroll
     for (int pq = 0; pq < 3; ++pq) {
       const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
       if (q >= dim) continue;
       const double apq = a[p][q];
-      if (fabs(apq) < 1e-300) continue;
+      if (!(fabs(apq) > 1e-18 * (fabs(a[p][p]) + fabs(a[q][q])))) continue;
       const double tau = (a[q][q] - a[p][p]) / (2.0 * apq);
       const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
       const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
@@ -102,7 +154,7 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
                                                                 uint8_t* __restrict__ keep, int32_t* __restrict__ info,
                                                                 int* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-  __shared__ double s_red[THREADS / 64 + 1];
+  __shared__ double s_red[6 * (THREADS / 64) + 1];
   const int g = blockIdx.x, tid = threadIdx.x;
   const int64_t p0 = graph_ptr[g], p1 = graph_ptr[g + 1];
   const int64_t n64 = p1 - p0;
@@ -194,84 +246,76 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
     double dt = 0.0;
     for (int i = tid; i < n; i += THREADS) dt += x[i] * ax[i];
     double lam = ndp_block_sum<THREADS>(dt, s_red);
+    // One step = three rounds of reductions (the basis {x, w, p} is orthonormalised with coefficients that ride
+    // along with sums needed anyway, and |x| = 1 is restored together with the new Rayleigh quotient):
+    //   A: |r|^2, x.p, r.p            r = Ls x - lambda x, w = r / |r|, p' = p - (x.p) x - (w.p) w
+    //   B: |p'|^2, x.Aw, w.Aw, x.Ap', w.Ap', p'.Ap'   -> 3 x 3 Rayleigh-Ritz on {x, w, p' / |p'|}
+    //   C: |x_new|^2, x_new.A x_new
     bool has_p = false;
     for (; it < max_iter; ++it) {
-      // residual r = ax - lambda x (orthogonal to x), w = r / |r|
-      double r2 = 0.0;
+      double sa[3] = {0.0, 0.0, 0.0};
       for (int i = tid; i < n; i += THREADS) {
         const double r = ax[i] - lam * x[i];
         wv[i] = r;
-        r2 += r * r;
+        sa[0] += r * r;
+        sa[1] += x[i] * pv[i];
+        sa[2] += r * pv[i];
       }
-      const double rn2 = ndp_block_sum<THREADS>(r2, s_red);
+      ndp_block_sums<THREADS, 3>(sa, s_red);
+      const double rn2 = sa[0];
       if (!(rn2 > tol * tol * lam * lam)) break;  // |Ls x - lambda x| <= tol * lambda: converged
-      const double xw_scale = 1.0 / sqrt(rn2);
+      const double inv_r = 1.0 / sqrt(rn2);
+      const double cxp = sa[1], cwp = sa[2] * inv_r;
       __syncthreads();
-      // re-orthogonalise against x (round-off) while normalising
-      double xw = 0.0;
-      for (int i = tid; i < n; i += THREADS) { wv[i] *= xw_scale; xw += x[i] * wv[i]; }
-      const double cxw = ndp_block_sum<THREADS>(xw, s_red);
-      double w2 = 0.0;
-      for (int i = tid; i < n; i += THREADS) { wv[i] -= cxw * x[i]; w2 += wv[i] * wv[i]; }
-      const double wn2 = ndp_block_sum<THREADS>(w2, s_red);
-      if (!(wn2 > 1e-30)) break;
-      __syncthreads();
-      for (int i = tid; i < n; i += THREADS) wv[i] *= 1.0 / sqrt(wn2);
+      for (int i = tid; i < n; i += THREADS) wv[i] *= inv_r;
       __syncthreads();
       matvec(wv, aw);
-      // previous direction: orthonormalise against x and w (ap follows by linearity)
-      double h[3][3] = {{lam, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-      int dim = 2;
-      if (has_p) {
-        double d0 = 0.0, d1 = 0.0;
-        for (int i = tid; i < n; i += THREADS) { d0 += x[i] * pv[i]; d1 += wv[i] * pv[i]; }
-        const double cxp = ndp_block_sum<THREADS>(d0, s_red);
-        const double cwp = ndp_block_sum<THREADS>(d1, s_red);
-        double p2 = 0.0;
-        for (int i = tid; i < n; i += THREADS) {
-          pv[i] -= cxp * x[i] + cwp * wv[i];
-          ap[i] -= cxp * ax[i] + cwp * aw[i];
-          p2 += pv[i] * pv[i];
-        }
-        const double pn2 = ndp_block_sum<THREADS>(p2, s_red);
-        if (pn2 > 1e-24) {
-          const double ip = 1.0 / sqrt(pn2);
-          for (int i = tid; i < n; i += THREADS) { pv[i] *= ip; ap[i] *= ip; }
-          dim = 3;
-        }
-      }
-      double q01 = 0.0, q11 = 0.0, q02 = 0.0, q12 = 0.0, q22 = 0.0;
+      double sb[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       for (int i = tid; i < n; i += THREADS) {
-        q01 += x[i] * aw[i];
-        q11 += wv[i] * aw[i];
-        if (dim == 3) { q02 += x[i] * ap[i]; q12 += wv[i] * ap[i]; q22 += pv[i] * ap[i]; }
+        double pi = 0.0, api = 0.0;
+        if (has_p) {
+          pi = pv[i] - cxp * x[i] - cwp * wv[i];
+          api = ap[i] - cxp * ax[i] - cwp * aw[i];
+          pv[i] = pi;
+          ap[i] = api;
+        }
+        sb[0] += pi * pi;
+        sb[1] += x[i] * aw[i];
+        sb[2] += wv[i] * aw[i];
+        sb[3] += x[i] * api;
+        sb[4] += wv[i] * api;
+        sb[5] += pi * api;
       }
-      h[0][1] = h[1][0] = ndp_block_sum<THREADS>(q01, s_red);
-      h[1][1] = ndp_block_sum<THREADS>(q11, s_red);
-      if (dim == 3) {
-        h[0][2] = h[2][0] = ndp_block_sum<THREADS>(q02, s_red);
-        h[1][2] = h[2][1] = ndp_block_sum<THREADS>(q12, s_red);
-        h[2][2] = ndp_block_sum<THREADS>(q22, s_red);
-      }
+      ndp_block_sums<THREADS, 6>(sb, s_red);
+      const int dim = (has_p && sb[0] > 1e-24) ? 3 : 2;  // p was unit length: what is left of it outside span{x, w}
+      const double ip = dim == 3 ? 1.0 / sqrt(sb[0]) : 0.0;
+      double h[3][3] = {{lam, sb[1], sb[3] * ip}, {sb[1], sb[2], sb[4] * ip}, {sb[3] * ip, sb[4] * ip, sb[5] * ip * ip}};
       double theta, c[3];
       ndp_eig3_largest(h, dim, theta, c);
       if (c[0] < 0.0) { c[0] = -c[0]; c[1] = -c[1]; c[2] = -c[2]; }
-      // x <- c0 x + c1 w + c2 p, p <- c1 w + c2 p (and the same combinations of ax, aw, ap)
-      double nx = 0.0;
-      __syncthreads();
+      // x <- c0 x + c1 w + c2 p^, p <- (c1 w + c2 p^) / |.| (the same combinations of Ls x, Ls w, Ls p^)
+      const double c2p = c[2] * ip;
+      const double pn2 = c[1] * c[1] + c[2] * c[2];
+      const double sp = pn2 > 1e-300 ? 1.0 / sqrt(pn2) : 0.0;
+      double sc[2] = {0.0, 0.0};
       for (int i = tid; i < n; i += THREADS) {
-        const double pn = c[1] * wv[i] + c[2] * pv[i], apn = c[1] * aw[i] + c[2] * ap[i];
+        const double pn = c[1] * wv[i] + c2p * pv[i], apn = c[1] * aw[i] + c2p * ap[i];
         const double xn = c[0] * x[i] + pn, axn = c[0] * ax[i] + apn;
-        pv[i] = pn; ap[i] = apn; x[i] = xn; ax[i] = axn;
-        nx += xn * xn;
+        pv[i] = pn * sp;
+        ap[i] = apn * sp;
+        x[i] = xn;
+        ax[i] = axn;
+        sc[0] += xn * xn;
+        sc[1] += xn * axn;
       }
-      const double xn2 = ndp_block_sum<THREADS>(nx, s_red);
-      const double ix = 1.0 / sqrt(xn2);
-      double ld = 0.0;
-      __syncthreads();
-      for (int i = tid; i < n; i += THREADS) { x[i] *= ix; ax[i] *= ix; ld += x[i] * ax[i]; }
-      lam = ndp_block_sum<THREADS>(ld, s_red);
-      has_p = true;
+      ndp_block_sums<THREADS, 2>(sc, s_red);
+      const double ix = 1.0 / sqrt(sc[0]);
+      for (int i = tid; i < n; i += THREADS) {
+        x[i] *= ix;
+        ax[i] *= ix;
+      }
+      lam = sc[1] / sc[0];
+      has_p = sp > 0.0;
       __syncthreads();
     }
     if (!(lam > 0.0)) random_part = true;  // cannot happen for vol > 0 (Ls has trace n > 0)
