@@ -153,8 +153,11 @@ __device__ __forceinline__ void sg_fetch(const SubgraphPred& pred, int64_t e0, i
   }
   if (pred.w) {  // streamed with the indices (one 16-byte load) rather than fetched sparsely for the survivors
     if (e0 + SG_PER <= E && (reinterpret_cast<uintptr_t>(pred.w + e0) & 15) == 0) {
-      const float4 wv = *reinterpret_cast<const float4*>(pred.w + e0);
-      t.w[0] = wv.x; t.w[1] = wv.y; t.w[2] = wv.z; t.w[3] = wv.w;
+#pragma unroll
+      for (int g = 0; g < SG_PER; g += 4) {
+        const float4 wv = *reinterpret_cast<const float4*>(pred.w + e0 + g);
+        t.w[g] = wv.x; t.w[g + 1] = wv.y; t.w[g + 2] = wv.z; t.w[g + 3] = wv.w;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < SG_PER; ++j) t.w[j] = e0 + j < E ? pred.w[e0 + j] : 0.f;
@@ -162,10 +165,12 @@ __device__ __forceinline__ void sg_fetch(const SubgraphPred& pred, int64_t e0, i
   }
   if (e0 + SG_PER <= E && ((reinterpret_cast<uintptr_t>(pred.row + e0) | reinterpret_cast<uintptr_t>(pred.col + e0)) & 15) == 0) {
     typedef long long ll2 __attribute__((ext_vector_type(2)));
-    const ll2 r01 = *reinterpret_cast<const ll2*>(pred.row + e0), r23 = *reinterpret_cast<const ll2*>(pred.row + e0 + 2);
-    const ll2 c01 = *reinterpret_cast<const ll2*>(pred.col + e0), c23 = *reinterpret_cast<const ll2*>(pred.col + e0 + 2);
-    t.r[0] = r01.x; t.r[1] = r01.y; t.r[2] = r23.x; t.r[3] = r23.y;
-    t.c[0] = c01.x; t.c[1] = c01.y; t.c[2] = c23.x; t.c[3] = c23.y;
+#pragma unroll
+    for (int g = 0; g < SG_PER; g += 2) {
+      const ll2 rr = *reinterpret_cast<const ll2*>(pred.row + e0 + g), cc = *reinterpret_cast<const ll2*>(pred.col + e0 + g);
+      t.r[g] = rr.x; t.r[g + 1] = rr.y;
+      t.c[g] = cc.x; t.c[g + 1] = cc.y;
+    }
 #pragma unroll
     for (int j = 0; j < SG_PER; ++j) t.keep[j] = true;
   } else {
@@ -263,11 +268,16 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred
   }
   auto new_id = [&](int64_t v) -> int32_t {
     if constexpr (LDSB == 2) {
-      if (by_rank) {
-        const int word = static_cast<int>(v >> 5);
-        uint32_t r = s_rank[word >> 2];
-        for (int q = word & ~3; q < word; ++q) r += __popc(s_dyn[q]);
-        return static_cast<int32_t>(r + __popc(s_dyn[word] & ((1u << (v & 31)) - 1u)));
+      if (by_rank) {  // rank of the 128-node block + the set bits below v inside it: one 16-byte LDS read, no loop
+        const int word = static_cast<int>(v >> 5), sub = word & 3;
+        const uint4 b = *reinterpret_cast<const uint4*>(s_dyn + (word & ~3));
+        const uint32_t below = (1u << (v & 31)) - 1u;
+        const uint32_t m0 = sub > 0 ? 0xFFFFFFFFu : (sub == 0 ? below : 0u);
+        const uint32_t m1 = sub > 1 ? 0xFFFFFFFFu : (sub == 1 ? below : 0u);
+        const uint32_t m2 = sub > 2 ? 0xFFFFFFFFu : (sub == 2 ? below : 0u);
+        const uint32_t m3 = sub == 3 ? below : 0u;
+        return static_cast<int32_t>(s_rank[word >> 2] + __popc(b.x & m0) + __popc(b.y & m1) + __popc(b.z & m2) +
+                                    __popc(b.w & m3));
       }
     }
     return pred.relabel[v];
@@ -839,8 +849,9 @@ extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col
   const int nblocks = (nwords + 3) / 4;
   if (node_index && nwords + nblocks <= SG_LDS_WORDS_MAX + 1984) {  // bitmap + rank128 <= 159.75 KB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (SG_LDS_WORDS_MAX + 1984) * 4);
-    hipLaunchKernelGGL(subgraph_stage_kernel<2>, dim3(grid), dim3(SG_THREADS), (nwords + nblocks) * sizeof(uint32_t),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (SG_LDS_WORDS_MAX + 1984 + 4) * 4);
+    // (+ 4 words: new_id reads the bitmap in aligned 16-byte pieces, the last one may reach past nwords + nblocks)
+    hipLaunchKernelGGL(subgraph_stage_kernel<2>, dim3(grid), dim3(SG_THREADS), (nwords + nblocks + 4) * sizeof(uint32_t),
                        stream, pred, E, nb, nwords, st, s.counts);
   } else if (node_index && nwords <= SG_LDS_WORDS_MAX) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<1>),
