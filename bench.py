@@ -12,8 +12,9 @@ excluded; inputs are resident in HBM when the timed region star
 own B graphs (weak scaling, seed = rank) and the pooled outputs are all-gathered over RCCL inside the timed region.
 
 Rank 0 prints ONE JSON line:
-  contract fields  `value` / `ms_per_step` come from ONE window of EXACTLY --steps steps after --warmup warm-up steps,
-                   bracketed by barrier + device synchronise on both sides, MAX over ranks;
+  contract fields  `value` / `ms_per_step` come from ONE window of EXACTLY --steps steps after --warmup warm-up steps
+                   (+ "settle_steps" more untimed steps: ~50 ms of the same workload, so that the window does not sit
+                   on the device's clock ramp), bracketed by barrier + device synchronise on both sides, MAX over ranks;
   "windows"        the same step re-timed as the median of 5 windows of >= 200 steps (tens of ms per window);
   "roofline"       fp32-MFMA roofline of the dominant kernel (U = A S, 2*B*N*N*K flop per launch), timed live with HIP
                    events on the launch stream;
@@ -43,6 +44,7 @@ sys.path.insert(0, os.path.join(ROOT, "torch-geometric-pool_amd"))
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = "pooled nodes/sec (Reduce+Connect) on batched graphs"
+SETTLE_SECONDS = 0.05  # untimed run-in of the workload before the contract window (see main)
 WINDOWS, WINDOW_STEPS = 5, 200
 
 
@@ -586,7 +588,20 @@ def main():
     # follows them without a host-side pause in which the GPU would clock down.
     gc.collect()
     gc.freeze()
+    ctx.sync()
+    t0 = time.perf_counter()
     for _ in range(args.warmup):
+        wl.step()
+    ctx.sync()
+    # Settle: the first ~50 ms of device work after the idle start-up phase run 5-10 % slow (clock / power ramp; a
+    # 20-step window right after 5 warm-up steps read 0.111 ms per step against 0.098 in every later window).  The
+    # W warm-up steps are therefore followed by more UNTIMED steps of the same workload until ~50 ms of it have run;
+    # the count is agreed across ranks (every step may hold a collective) and reported as "settle_steps".
+    est = torch.tensor([(time.perf_counter() - t0) / max(args.warmup, 1)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(est, op=dist.ReduceOp.MAX)
+    settle_steps = max(0, min(2000, int(SETTLE_SECONDS / max(float(est.item()), 1e-6)) - args.warmup))
+    for _ in range(settle_steps):
         wl.step()
     if wl.drain is not None:
         wl.drain()  # warm-up ends with an empty gather bucket, its collective done (communicator set-up is not a step)
@@ -617,7 +632,7 @@ def main():
     if rank == 0:
         line = {
             "metric": METRIC, "value": round(value, 1), "unit": "nodes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "warmup": args.warmup, "settle_steps": settle_steps, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": headline_cfg,
             "windows": win, "roofline": roofs[0],
         }
