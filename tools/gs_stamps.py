@@ -43,7 +43,7 @@ def timed(mode):
     return a.elapsed_time(b) / 20 * 1e3
 assert lib.tgp_debug_set_gs_stamps(0) == 0
 base = timed(0)
-print(f"whole call us: full {base:.1f}; no sort {timed(1):.1f}; no edge/table loads {timed(2):.1f}; neither {timed(3):.1f}; no table {timed(4):.1f}; no col/w {timed(8):.1f}; nt table {timed(16):.1f}")
+print(f"whole call us: full {base:.1f}; no sort {timed(1):.1f}; no edge/table loads {timed(2):.1f}; neither {timed(3):.1f}; no table {timed(4):.1f}; no col/w {timed(8):.1f}; nt table {timed(16):.1f}; dummy 4-byte {timed(256):.1f}; dummy 2-byte {timed(512):.1f}; dummy 1-byte {timed(1024):.1f}")
 lib.tgp_debug_set_gs_ablate(0)
 t0 = s[:, 7].min()
 print("start spread", float((s[:, 7] - t0).max()), "us; total per WG", float(s[:, :6].sum(1).mean()))

@@ -486,8 +486,9 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
               continue;
             }
 #endif
-            cc[r][q] = ok ? col[src[r] + j] : 0;
-            wv[r][q] = (ok && has_w) ? w[src[r] + j] : 0.f;
+            // streamed once: non-temporal, so that the edge list does not push the cluster table out of the L2
+            cc[r][q] = ok ? __builtin_nontemporal_load(col + src[r] + j) : 0;
+            wv[r][q] = (ok && has_w) ? __builtin_nontemporal_load(w + src[r] + j) : 0.f;
           }
 #pragma unroll
         for (int r = 0; r < GR; ++r)
@@ -513,6 +514,16 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
               }
 #endif
 #ifdef TGP_GEMM_STAMPS
+              if (g_gs_ablate & (256 | 512 | 1024)) {  // key = node id / 2 (as mode 4) + a look-up whose value is dropped:
+                uint32_t v;                             // 4-, 2- or 1-byte table entries (footprint 4 / 2 / 1 MB)
+                if (g_gs_ablate & 256) v = static_cast<uint32_t>(table[cc[r][q]]);
+                else if (g_gs_ablate & 512) v = reinterpret_cast<const uint16_t*>(table)[cc[r][q]];
+                else v = reinterpret_cast<const uint8_t*>(table)[cc[r][q]];
+                asm volatile("" ::"v"(v));
+                s_key[dst[r] + j] = static_cast<uint32_t>(cc[r][q]) >> 1;
+                s_val[dst[r] + j] = wv[r][q];
+                continue;
+              }
               if (g_gs_ablate & 16) {  // nontemporal table lookups
                 s_key[dst[r] + j] = inr ? static_cast<uint32_t>(__builtin_nontemporal_load(table + cc[r][q])) : 0u;
                 s_val[dst[r] + j] = wv[r][q];
@@ -582,8 +593,8 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
     // the pass's slot range goes out in one coalesced sweep: survivors at the head of every row's slots (what is
     // behind them is never read: the fill kernel takes n_out[r] entries from raw_off[r]), long rows still raw
     for (int t = tid; t < cnt; t += 256) {
-      tmp_c[base + t] = s_key[t];
-      if (has_w) tmp_w[base + t] = s_val[t];
+      __builtin_nontemporal_store(s_key[t], tmp_c + base + t);
+      if (has_w) __builtin_nontemporal_store(s_val[t], tmp_w + base + t);
     }
     rs = re;
     __syncthreads();
