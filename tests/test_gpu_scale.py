@@ -406,6 +406,44 @@ def test_rowlocal_coalesce_declines_and_falls_back(dev):
     assert torch.equal(got[0].cpu(), ref[0]) and torch.equal(got[1].cpu(), ref[1])
 
 
+def test_rowlocal_coalesce_many_members_empty_rows_and_hub_nodes(dev):
+    """Shapes the member-parallel gather has to get right: supernodes with > 1000 members of which most have no edge at
+    all (zero-length members share a slot), supernodes without any member (empty rows in the middle and at the end),
+    and nodes of degree > 16 (the gather's tail loop) - still through the row-local path, bit-identical to the
+    sort-based one (connect/base_conn.py:83-89 + utils/ops.py:338-419)."""
+    import tgp_oracle as O
+    from tgp import kernels
+    g = torch.Generator().manual_seed(77)
+    n, k = 60_000, 64
+    src = torch.randint(0, n // 8, (14_000,), generator=g) * 8        # only every 8th node has edges
+    dst = torch.randint(0, n, (14_000,), generator=g)
+    hub = torch.full((40,), 8 * 123), torch.randint(0, n, (40,), generator=g)   # one node of degree > 40
+    ei = torch.stack([torch.cat([src, hub[0]]), torch.cat([dst, hub[1]])])
+    ei = ei[:, torch.argsort(ei[0], stable=True)]
+    ew = torch.rand(ei.size(1), generator=g) + 0.1
+    cluster = torch.randint(0, 40, (n,), generator=g)                   # supernodes 40..63 have no member
+    cluster[cluster == 17] = 18                                         # ... and neither has 17
+    cl_d = cluster.to(dev)
+    idx = kernels.build_assign_index(cl_d, k)
+    for rsl in (True, False):
+        got_ei, got_ew = kernels.coalesce_edges(ei.to(dev), ew.to(dev), cl_d, k, "sum", rsl, assign_index=idx)
+        ref_ei, ref_ew = O.sparse_connect(ei, ew, torch.arange(n), cluster, n, k, remove_self_loops=rsl)
+        assert torch.equal(got_ei.cpu(), ref_ei)
+        torch.testing.assert_close(got_ew.cpu(), ref_ew, rtol=RTOL, atol=ATOL)
+        gen_ei, gen_ew = kernels.coalesce_edges(ei.to(dev), ew.to(dev), cl_d, k, "sum", rsl)
+        assert torch.equal(gen_ei, got_ei) and torch.equal(gen_ew, got_ew)
+    # the fast path is the one that ran: its count call does not decline on this input
+    from tgp import _native as N
+    L = N.lib()
+    row, col = ei[0].to(dev).contiguous(), ei[1].to(dev).contiguous()
+    ws = N.workspace(L.tgp_connect_coalesce_rows_workspace_bytes(row.numel(), n, k), dev)
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    N.check(L.tgp_connect_coalesce_rows_count(row.data_ptr(), col.data_ptr(), None, row.numel(), cl_d.data_ptr(), n, k,
+                                              idx.row_ptr.data_ptr(), idx.perm.data_ptr(), 0, 1, 1e-8, ws.data_ptr(),
+                                              ws.numel(), cnt.data_ptr(), N.stream_ptr(dev)), "rows")
+    assert int(cnt.item()) > 0
+
+
 def test_rowlocal_coalesce_long_rows(dev):
     """Supernode rows of 33..1024 raw entries take the LDS bitonic kernel (hub supernodes)."""
     import tgp_oracle as O
