@@ -863,6 +863,50 @@ __global__ __launch_bounds__(256) void cg_keys_kernel(const int64_t* __restrict_
             (static_cast<unsigned long long>(__float_as_uint(w ? w[e] : 1.0f)) << 32);
 }
 
+// Four consecutive edges per thread: row / col / w arrive as 16-byte loads, the eight table look-ups of a thread are
+// in flight together, keys and payloads leave as 16-byte stores (all arrays 16-byte aligned: the host checks).
+__global__ __launch_bounds__(256) void cg_keys4_kernel(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                                                       const float* __restrict__ w, const int32_t* __restrict__ table,
+                                                       int64_t groups, int64_t n_nodes, int64_t K,
+                                                       int* __restrict__ bad, uint32_t* __restrict__ keys,
+                                                       unsigned long long* __restrict__ vals) {
+  const int64_t gi = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (gi >= groups) return;
+  const int64_t e = gi * 4;
+  typedef long long ll2 __attribute__((ext_vector_type(2)));
+  typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+  const ll2 r01 = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(row + e));
+  const ll2 r23 = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(row + e + 2));
+  const ll2 c01 = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(col + e));
+  const ll2 c23 = __builtin_nontemporal_load(reinterpret_cast<const ll2*>(col + e + 2));
+  float4 wv = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (w) wv = *reinterpret_cast<const float4*>(w + e);
+  const int64_t r[4] = {r01.x, r01.y, r23.x, r23.y}, c[4] = {c01.x, c01.y, c23.x, c23.y};
+  const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+  uint32_t kr[4], kc[4];
+  bool ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    ok[j] = static_cast<uint64_t>(r[j]) < static_cast<uint64_t>(n_nodes) &&
+            static_cast<uint64_t>(c[j]) < static_cast<uint64_t>(n_nodes);
+    kr[j] = static_cast<uint32_t>(table[ok[j] ? r[j] : 0]);
+    kc[j] = static_cast<uint32_t>(table[ok[j] ? c[j] : 0]);
+  }
+  unsigned long long v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (!ok[j] || kr[j] >= static_cast<uint64_t>(K) || kc[j] >= static_cast<uint64_t>(K)) {
+      *bad = 4;  // node / cluster id out of range: decline, the general path reports it
+      kr[j] = kc[j] = 0;
+    }
+    v[j] = static_cast<unsigned long long>(kc[j]) | (static_cast<unsigned long long>(__float_as_uint(ww[j])) << 32);
+  }
+  *reinterpret_cast<uint4*>(keys + e) = make_uint4(kr[0], kr[1], kr[2], kr[3]);
+  ull2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+  *reinterpret_cast<ull2*>(vals + e) = v01;
+  *reinterpret_cast<ull2*>(vals + e + 2) = v23;
+}
+
 // first slot of every supernode row from the sorted keys (rows without edges get the next row's slot)
 __global__ __launch_bounds__(256) void cg_row_off_kernel(const uint32_t* __restrict__ keys, int64_t E, int64_t K,
                                                          uint32_t* __restrict__ raw_off) {
@@ -926,8 +970,17 @@ extern "C" int tgp_connect_coalesce_grouped_count(const int64_t* row, const int6
   float* tmp_w = w ? s.tmp_w : nullptr;
   (void)hipMemsetAsync(s.bad, 0, sizeof(int), stream);
   hipLaunchKernelGGL(cr_table_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, cluster_index, N, s.table);
-  hipLaunchKernelGGL(cg_keys_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, s.table, E, N, K, s.bad, g.k0,
-                     g.v0);
+  {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const int64_t groups = (al16(row) && al16(col) && (!w || al16(w))) ? E / 4 : 0;
+    if (groups > 0)
+      hipLaunchKernelGGL(cg_keys4_kernel, dim3(cdiv(groups, 256)), dim3(256), 0, stream, row, col, w, s.table, groups, N,
+                         K, s.bad, g.k0, g.v0);
+    const int64_t done = groups * 4;
+    if (done < E)
+      hipLaunchKernelGGL(cg_keys_kernel, dim3(cdiv(E - done, 256)), dim3(256), 0, stream, row + done, col + done,
+                         w ? w + done : nullptr, s.table, E - done, N, K, s.bad, g.k0 + done, g.v0 + done);
+  }
   bool first = true;
   const int rc = radix_sort_pairs<uint32_t, unsigned long long>(g.k0, g.v0, g.k1, g.v1, E,
                                                                 bits_for(static_cast<uint64_t>(K - 1)), g.scratch,
