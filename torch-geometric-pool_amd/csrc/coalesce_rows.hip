@@ -3,12 +3,12 @@
 // PyG edge lists are row-sorted almost everywhere (coalesced inputs, to_undirected, dataset loaders).
 // Then the edges of one supernode r are the union of the contiguous edge ranges of its member nodes, in the
 // stable order (members ascending, input order inside a member) at slot
-//     raw_off[r] + member_off[node] + (e - node_ptr[node]),
+//     seg_dst[p] + (e - node_ptr[node])     (p = position of the member in the inverted index),
 // so grouping the relabelled edges by supernode row needs no sort, and only the short per-row segments
 // (~E/K entries) have to be ordered by column.  Pipeline:
 //   K1 CSR of the input (node_ptr) + sortedness check, one pass     read E*8 B once
-//   K2 per supernode: raw row length T_r, per-member offsets      K-sized
-//   K3 scan T_r -> raw_off; per-node slot base                    K-, N-sized
+//   K2 member degrees: tile sums (+ the int32 cluster table)       N-sized
+//   K3 scan -> seg_src / seg_dst per member; raw_off per row      N-, K-sized
 //   K4 gather-sort-merge (cr_gather_sort_kernel): one workgroup per 32 supernode rows gathers the rows' edges
 //      through the cluster table straight into LDS, sorts every row there (8 lanes x 4 keys per row of <= 32
 //      entries, 16 x 4 for 33..64: cr_sort_rows; workgroup LDS bitonic for 65..1024), merges duplicates with
@@ -18,8 +18,7 @@
 //   K6 fill (output-parallel per 64-row block)                     read E'*8 B, write E'*20 B
 // vs. five radix passes of 32 B/edge each in the general path (sparse_connect.hip).  The result is
 // identical to the general path (row-major sorted, unique, duplicates reduced in input order).
-// Preconditions are checked on the device (rows sorted; no supernode row longer than 1024 raw entries or with
-// more than 1024 members); if they fail *d_count is set to -1 and the caller falls back to the sort-based path.
+// Preconditions are checked on the device (rows sorted; no supernode row longer than 1024 raw entries); if they fail *d_count is set to -1 and the caller falls back to the sort-based path.
 #include "primitives.h"
 
 namespace tgp {
@@ -203,14 +202,14 @@ __device__ __forceinline__ float cr_reduce(float acc, float v, int op) {
 // ------------------------------------------------------------------ K4 + K5 fused: gather, sort, merge
 // One workgroup owns GS_ROWS consecutive supernode rows.  Their members are consecutive in the inverted index
 // and every member's edges are one contiguous range of the (row-sorted) input, so the workgroup
-//   (a) turns its members into (first edge, first slot) segments in LDS,
-//   (b) gathers slot-parallel: thread t finds its segment by binary search, reads (col, w) of its edge, maps
-//       the column through the cluster table and drops (cluster, w) into LDS slot t - no scatter through HBM,
-//   (c) sorts every row inside LDS (half-wave register bitonic for <= 32 entries, workgroup bitonic up to
-//       CR_LONG), merges duplicates in input order with the A6 filters fused, and writes the survivors of row r
-//       compacted at tmp[raw_off[r] ...] with their count in n_out[r].
-// Every dependent-load level (row offsets -> members -> node ranges -> edges -> table) is one block-wide,
-// coalesced-as-possible request, so the latency chain is paid once per ~1000 edges instead of once per row.
+//   (a) reads its members' (first edge, first slot) segments, 8 lanes per member,
+//   (b) gathers member-parallel: the 8 lanes walk the member's edge range, map the columns through the cluster
+//       table and drop (cluster, w) into the member's LDS slots - no scatter through HBM,
+//   (c) sorts every row inside LDS / registers (8 or 16 lanes x 4 keys for <= 64 entries; longer rows go out raw
+//       for the workgroup bitonic of cr_rows_long_kernel), merges duplicates in input order with the A6 filters
+//       fused, and writes the survivors of row r compacted at tmp[raw_off[r] ...] with their count in n_out[r].
+// Every dependent-load level (row offsets -> segments -> edges -> table) is one block-wide request with all of a
+// thread's loads in flight together, so the latency chain is paid once per ~1000 edges instead of once per row.
 #ifdef TGP_GEMM_STAMPS  // diagnostic build only (make stamps): time per phase of cr_gather_sort_kernel, per workgroup
 __device__ unsigned long long* g_gs_stamps = nullptr;
 __device__ int g_gs_ablate = 0;  // 1: no in-row sort, 2: no edge / table loads (synthetic keys), 3: neither
