@@ -49,61 +49,16 @@ __global__ __launch_bounds__(256) void relabel_scatter_kernel(const int64_t* __r
   if (live && (lane == 0 || pw != word)) atomicOr(member_bits + word, acc);
 }
 
-// rank128[b] = number of member nodes with id < 128 b (exclusive scan of the bitmap's popcounts, one workgroup):
-// with an ascending node_index the new id of node v is its rank among the members,
-//   rank128[v >> 7] + popcount(bitmap words of the block before v's word) + popcount(v's word below bit v),
-// so the fill pass needs no gather from the 4 N-byte relabel table at all.
-__global__ __launch_bounds__(1024) void member_rank_kernel(const uint32_t* member_bits, int nwords, int nblocks,
-                                                           uint32_t* __restrict__ rank128, int in_lds) {
-  // a thread owns a contiguous run of blocks: one streaming pass for the run totals, ONE workgroup scan, and a
-  // second pass (from L2) that writes the ranks -- instead of a scan with three barriers per 1024 blocks
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
-  __shared__ uint32_t s_w[16];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int run = (nblocks + 1023) / 1024;
-  const int b0 = tid * run;
-  if (in_lds) {  // coalesced copy with several loads in flight; the per-thread runs are then read from LDS
-    lds_copy_words<1024>(s_bits, member_bits, nwords);
-    __syncthreads();
-    member_bits = s_bits;
-  }
-  auto block_pop = [&](int b) -> uint32_t {
-    uint32_t v = 0;
-    if (4 * b + 3 < nwords) {
-      const uint4 q = *reinterpret_cast<const uint4*>(member_bits + 4 * b);
-      v = __popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w);
-    } else {
-      for (int q = 0; q < 4; ++q)
-        if (4 * b + q < nwords) v += __popc(member_bits[4 * b + q]);
-    }
-    return v;
-  };
-  uint32_t mine = 0;
-#pragma unroll 8
-  for (int r = 0; r < run; ++r)
-    if (b0 + r < nblocks) mine += block_pop(b0 + r);
-  const uint32_t inc = wave_incl_scan(mine);
-  if (lane == WAVE - 1) s_w[w] = inc;
-  __syncthreads();
-  uint32_t off = inc - mine;
-#pragma unroll
-  for (int j = 0; j < 16; ++j)
-    if (j < w) off += s_w[j];
-  for (int r = 0; r < run; ++r) {
-    if (b0 + r < nblocks) {
-      rank128[b0 + r] = off;
-      off += block_pop(b0 + r);
-    }
-  }
-}
-
+// Relabelling by rank: with an ascending node_index the new id of node v is its rank among the members,
+//   rank128[v >> 7] + popcount(bitmap words of the 128-node block before v's word) + popcount(v's word below bit v),
+// so the staging pass needs no gather from the 4 N-byte relabel table; the directory rank128 (exclusive scan of the
+// blocks' popcounts) is built by the stage kernel itself from its LDS copy of the bitmap.
 struct SubgraphPred {
   const int64_t* row;
   const int64_t* col;
   const float* w;
   const int32_t* relabel;       // nullptr = no node filter
   const uint32_t* member_bits;  // set with relabel
-  const uint32_t* rank128;      // set with relabel
   const int* unsorted;          // set with relabel: node_index is not ascending
   int flags;
   float eps;                    // the caller's eps at call time (reference ops.py:377 reads the module global)
@@ -255,14 +210,32 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred
                                                                     SgStage st, uint32_t* __restrict__ block_counts) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   __shared__ uint32_t s_w[16];
-  const uint32_t* s_rank = s_dyn + nwords;
+  uint32_t* s_rank = s_dyn + 4 * ((nwords + 3) / 4);  // behind the bitmap, padded to whole 128-node blocks
   bool by_rank = false;
   if constexpr (LDSB >= 1) {
     lds_copy_words<SG_THREADS>(s_dyn, pred.member_bits, nwords);
     if constexpr (LDSB == 2) {
-      const int nblocks = (nwords + 3) / 4;
-      for (int i = threadIdx.x; i < nblocks; i += SG_THREADS) s_dyn[nwords + i] = pred.rank128[i];
+      // rank directory rank128[b] = members with id < 128 b, computed here from the LDS copy of the bitmap by every
+      // workgroup for itself, in parallel on every CU, instead of a 10 us single-workgroup kernel in front of this one
       by_rank = *pred.unsorted == 0;
+      __syncthreads();
+      const int nblocks = (nwords + 3) / 4;
+      // rounds of 1024 consecutive blocks, one block per thread (a 16-byte LDS read: conflict-free; a run of blocks
+      // per thread would put all lanes on one bank), carry between rounds
+      uint32_t carry = 0;
+      for (int base = 0; base < nblocks; base += SG_THREADS) {
+        const int bb = base + static_cast<int>(threadIdx.x);
+        uint32_t v = 0;
+        if (bb < nblocks) {  // (words past nwords in the last block are padding: masked)
+          const uint4 q = *reinterpret_cast<const uint4*>(s_dyn + 4 * bb);
+          const int left = nwords - 4 * bb;
+          v = __popc(q.x) + (left > 1 ? __popc(q.y) : 0) + (left > 2 ? __popc(q.z) : 0) + (left > 3 ? __popc(q.w) : 0);
+        }
+        uint32_t total;
+        const uint32_t off = block_excl_scan_1024(v, s_w, &total);
+        if (bb < nblocks) s_rank[bb] = carry + off;
+        carry += total;
+      }
     }
     __syncthreads();
   }
@@ -781,7 +754,6 @@ using namespace tgp;
 struct SubgraphWs {
   int32_t* relabel;
   uint32_t* member_bits;
-  uint32_t* rank128;
   int* unsorted;
   uint32_t* counts;
   uint32_t* offsets;
@@ -794,7 +766,6 @@ static size_t subgraph_layout(void* ws, int64_t E, int64_t N, SubgraphWs* out) {
   SubgraphWs s;
   s.relabel = cv.take<int32_t>(N > 0 ? N : 1);
   s.member_bits = cv.take<uint32_t>((N > 0 ? N : 1) / 32 + 1);
-  s.rank128 = cv.take<uint32_t>((N > 0 ? N : 1) / 128 + 2);
   s.unsorted = cv.take<int>(4);
   s.counts = cv.take<uint32_t>(nb);
   s.offsets = cv.take<uint32_t>(nb);
@@ -832,26 +803,21 @@ extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col
     if (k > 0)
       hipLaunchKernelGGL(relabel_scatter_kernel, dim3(cdiv(k, 256)), dim3(256), 0, stream, node_index, k, N, s.relabel,
                          s.member_bits, s.unsorted);
-    const int in_lds = nwords <= SG_LDS_WORDS_MAX ? 1 : 0;
-    if (in_lds)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(member_rank_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_WORDS_MAX * 4);
-    hipLaunchKernelGGL(member_rank_kernel, dim3(1), dim3(1024), in_lds ? nwords * sizeof(uint32_t) : 0, stream,
-                       s.member_bits, nwords, (nwords + 3) / 4, s.rank128, in_lds);
+    // (the rank directory of the relabel-by-rank route is computed inside the stage kernel from its LDS bitmap; the
+    //  other routes relabel through the table and need none)
   }
   const int nb = cdiv(E > 0 ? E : 1, SG_CHUNK);
-  SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.rank128, s.unsorted, flags, eps,
+  SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.unsorted, flags, eps,
                     N, s.unsorted + 1};
   SgStage st = s.st;
   if (!w) st.w = nullptr;
   if (!(flags & TGP_WANT_EDGE_ID)) st.off = nullptr;  // input positions are only staged for callers that will ask for them
   const int grid = nb < 256 ? nb : 256;  // persistent: one 1024-thread workgroup per CU
   const int nblocks = (nwords + 3) / 4;
-  if (node_index && nwords + nblocks <= SG_LDS_WORDS_MAX + 1984) {  // bitmap + rank128 <= 159.75 KB
+  if (node_index && 5 * nblocks <= SG_LDS_WORDS_MAX + 1984) {  // bitmap (whole blocks) + rank128 <= 159.75 KB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (SG_LDS_WORDS_MAX + 1984 + 4) * 4);
-    // (+ 4 words: new_id reads the bitmap in aligned 16-byte pieces, the last one may reach past nwords + nblocks)
-    hipLaunchKernelGGL(subgraph_stage_kernel<2>, dim3(grid), dim3(SG_THREADS), (nwords + nblocks + 4) * sizeof(uint32_t),
+    hipLaunchKernelGGL(subgraph_stage_kernel<2>, dim3(grid), dim3(SG_THREADS), (5 * nblocks + 4) * sizeof(uint32_t),
                        stream, pred, E, nb, nwords, st, s.counts);
   } else if (node_index && nwords <= SG_LDS_WORDS_MAX) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<1>),
