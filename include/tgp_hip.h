@@ -344,9 +344,13 @@ int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, const float* w 
  *     (sorted batch vector); `node_index`: kept nodes, ascending (pooled id = position).  An exactly singular
  *     L[-,-] block is redone with the reference's 1e-6 I damping (kron_conn.py:131-135), per graph.
  *     *d_count = -1: declined (node_index not ascending, a graph beyond the size limit, or an entry that couples two
- *     graphs) - the caller keeps its generic route.
+ *     graphs) - the caller keeps its generic route.  from_adjacency bit 1 (value 2, TGP_KRON_SKIP_OVERSIZE): graphs
+ *     beyond the size limit do not decline the call, they are left out (no scratch, no edges) and the caller reduces
+ *     those few graphs itself (pass max_graph_nodes = min(longest graph, tgp_kron_batched_max_graph_nodes())).
  * ---------------------------------------------------------------------------------- */
 size_t tgp_kron_batched_workspace_bytes(int64_t num_nodes, int64_t num_graphs, int64_t max_graph_nodes);
+#define TGP_KRON_FROM_ADJACENCY 1
+#define TGP_KRON_SKIP_OVERSIZE 2
 int tgp_kron_batched_max_graph_nodes(void);
 int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col, const float* val_f32 /* NULL ok */,
                            const double* val_f64 /* NULL ok */, const int32_t* perm /* NULL ok */, int from_adjacency,

@@ -221,6 +221,35 @@ def test_kron_declines_oversized_graph_and_falls_back(dev):
     check(out[0], out[1], ref, dev)
 
 
+@pytest.mark.parametrize("source", ["laplacian", "edge_list", "edge_list_unsorted"])
+def test_kron_mixed_batch_keeps_oversize_graphs_on_the_device(dev, monkeypatch, source):
+    """A few graphs beyond the kernel's size limit in a batch of small ones: the kernel skips them
+    (TGP_KRON_SKIP_OVERSIZE), each is reduced by the dense fp64 library solve on its own block on the device, the edge
+    lists are merged in row-major order - and the host's scipy solver is never entered (kron_conn.py:117-165)."""
+    import scipy.sparse.linalg as spla
+    import tgp_oracle as O
+    from tgp import kernels as K
+    from tgp.connect import KronConnect
+
+    def boom(*a, **k):
+        raise AssertionError("KronConnect went to the host sparse solver")
+    big = K.kron_max_graph_nodes() + 60
+    sizes = [30, 45, big, 25, 200, big + 333, 40, 1]
+    ei, ew, batch, idx_pos = make_batch(sizes, seed=9)
+    n = batch.numel()
+    if source == "edge_list_unsorted":
+        perm = torch.randperm(ei.size(1), generator=torch.Generator().manual_seed(3))
+        ei, ew = ei[:, perm], ew[perm]
+    ref = blockwise_kron(ei, ew, batch, idx_pos)
+    L = O.laplacian_scipy(ei, ew.double(), n).astype(np.float64) if source == "laplacian" else None
+    monkeypatch.setattr(spla, "spsolve", boom)
+    conn = KronConnect()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = conn(ei.to(dev), so_of(idx_pos, n, dev, L=L), edge_weight=ew.to(dev), batch=batch.to(dev))
+    check(out[0], out[1], ref, dev)
+
+
 def test_ndp_pooler_2048_graph_batch_connect_stays_on_device(dev, monkeypatch):
     """get_pooler("ndp") on a PROTEINS-sized batch (2048 graphs, n ~ 40): Connect never touches
     the host solvers; result equals the oracle's Kron reduction of the same SelectOutput."""

@@ -53,7 +53,8 @@ __device__ __forceinline__ int64_t wave_incl_scan64(int64_t v) {
 __global__ __launch_bounds__(1024) void kron_plan_kernel(const int64_t* __restrict__ graph_ptr, int B,
                                                          const uint32_t* __restrict__ rank,
                                                          int64_t* __restrict__ sq_off, int64_t* __restrict__ big_off,
-                                                         int64_t cap_dense, int64_t cap_big, int* __restrict__ status) {
+                                                         int64_t cap_dense, int64_t cap_big, int skip_oversize,
+                                                         int* __restrict__ status) {
   __shared__ int64_t s_w[2][16];
   __shared__ int64_t s_carry[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -66,9 +67,12 @@ __global__ __launch_bounds__(1024) void kron_plan_kernel(const int64_t* __restri
       const int64_t p0 = graph_ptr[g], p1 = graph_ptr[g + 1];
       const int64_t n = p1 - p0;
       const int64_t k = static_cast<int64_t>(rank[p1]) - static_cast<int64_t>(rank[p0]);
-      if (n < 0 || n > KRON_MAX_N) atomicOr(status, KRON_TOO_LARGE);
-      sq = k * k;
-      if (n > KRON_LDS_MAX_N && k > 0) big = n * (n | 1);
+      const bool oversize = n > KRON_MAX_N;
+      if (n < 0 || (oversize && !skip_oversize)) atomicOr(status, KRON_TOO_LARGE);
+      if (!oversize) {  // (skipped graphs take no scratch and emit nothing: the caller reduces them itself)
+        sq = k * k;
+        if (n > KRON_LDS_MAX_N && k > 0) big = n * (n | 1);
+      }
     }
     const int64_t isq = wave_incl_scan64(sq), ibig = wave_incl_scan64(big);
     if (lane == WAVE - 1) { s_w[0][w] = isq; s_w[1][w] = ibig; }
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(KRON_THREADS) void kron_fill_kernel(const int64_t* 
   __shared__ uint32_t s_row[KRON_MAX_N + 1];
   const int g = blockIdx.x;
   const int64_t p0 = graph_ptr[g], p1 = graph_ptr[g + 1];
-  if (p1 <= p0) return;
+  if (p1 <= p0 || p1 - p0 > KRON_MAX_N) return;  // (an oversize graph was skipped by the count pass: it has no block)
   const uint32_t r0 = rank[p0];
   const int k = static_cast<int>(rank[p1] - r0);
   if (k == 0) return;
@@ -461,9 +465,9 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
                        s.flags, s.status);
   device_scan_u32(s.flags, N + 1, s.rank, s.scan_total, s.scan_tiles, stream);  // (one workgroup took 73 us at N = 82 k)
   hipLaunchKernelGGL(kron_plan_kernel, dim3(1), dim3(1024), 0, stream, graph_ptr, static_cast<int>(B), s.rank, s.sq_off,
-                     s.big_off, s.cap_dense, s.cap_big, s.status);
+                     s.big_off, s.cap_dense, s.cap_big, (from_adjacency & 2) ? 1 : 0, s.status);
   KronArgs a{};
-  a.indptr = indptr; a.col = col; a.val32 = val32; a.val64 = val64; a.perm = perm; a.from_adj = from_adjacency;
+  a.indptr = indptr; a.col = col; a.val32 = val32; a.val64 = val64; a.perm = perm; a.from_adj = from_adjacency & 1;
   a.graph_ptr = graph_ptr; a.rank = s.rank; a.sq_off = s.sq_off; a.big_off = s.big_off; a.dense = s.dense;
   a.big = s.big; a.counts = s.counts; a.status = s.status; a.threshold = threshold;
   const int cap = static_cast<int>(max_graph_nodes < KRON_LDS_MAX_N ? max_graph_nodes : KRON_LDS_MAX_N);

@@ -278,9 +278,11 @@ class KronConnect(Connect):
     ``tgp_kron_batched_{count,fill}``: one workgroup per graph, dense fp64 elimination of the dropped nodes in LDS
     (graphs up to 128 nodes) or in a workspace slab (up to 1024 nodes), threshold / zero-diagonal / fp32 cast fused,
     edges emitted in the row-major order the reference's CSR -> COO conversion gives.  Nothing but the selector's
-    Laplacian (uploaded once per SelectOutput) crosses PCIe.  Batches with a graph beyond that size, or without a
-    usable graph partition, take the dense fp64 library solve on the device (``torch.linalg.solve`` -> rocSOLVER) up to
-    ``dense_solve_max_nodes`` nodes in total, else the reference's scipy route unchanged.  All routes give the same
+    Laplacian (uploaded once per SelectOutput) crosses PCIe.  Graphs beyond that size are skipped by the kernel and
+    reduced one by one with the dense fp64 library solve on the device (``torch.linalg.solve`` -> rocSOLVER, up to
+    ``dense_solve_max_nodes`` nodes per graph), the edge lists merged; a batch without a usable graph partition takes
+    that library solve as a whole (up to ``dense_solve_max_nodes`` nodes in total), else the reference's scipy route
+    unchanged.  All routes give the same
     edge set; weights agree to solver round-off before the fp32 cast."""
 
     def __init__(self, sparse_threshold: float = 1e-2, dense_solve_max_nodes: int = 8192):
@@ -323,27 +325,77 @@ class KronConnect(Connect):
             ptr, max_nodes = info.ptr, info.max_nodes
         else:
             ptr, max_nodes = torch.tensor([0, n], dtype=torch.long, device=dev), n
-        if max_nodes > K.kron_max_graph_nodes():
-            return None
+        limit = K.kron_max_graph_nodes()
+        oversize = None
+        if max_nodes > limit:
+            # A few graphs beyond the kernel's size limit must not send the whole batch to the host (one 1500-node
+            # graph among 2000 small ones did): the kernel skips them, each is reduced by the dense fp64 library solve
+            # on ITS block, and the edge lists are merged.  Only when such a graph is itself beyond the library route
+            # (or the batch is one single graph) does the call fall back as a whole.
+            sizes = ptr[1:] - ptr[:-1]
+            oversize = (sizes > limit).nonzero().view(-1).tolist()
+            if ptr.numel() <= 2 or int(sizes.max()) > self.dense_solve_max_nodes:
+                return None
         adj_csr = so.__dict__.get("_adj_device_csr")
         if has_laplacian and adj_csr is not None and adj_csr[0].device == dev and adj_csr[0].numel() == n + 1:
             # NDPSelect's device route left the symmetrised adjacency on the GPU: L = D - A is formed in the kernel
-            return K.kron_batched(adj_csr[0], adj_csr[1], adj_csr[2], None, True, n, ptr, max_nodes, idx_pos,
-                                  self.sparse_threshold)
-        if has_laplacian:
+            indptr, col, val, perm, from_adj = adj_csr[0], adj_csr[1], adj_csr[2], None, True
+        elif has_laplacian:
             indptr, col, val = self._laplacian_csr_on_device(so, dev)
             if indptr.numel() != n + 1:
                 return None
-            return K.kron_batched(indptr, col, val, None, False, n, ptr, max_nodes, idx_pos, self.sparse_threshold)
-        row = edge_index[0]
-        if row.numel() > 1 and K._rows_sorted(edge_index, row):
-            indptr, perm = torch.empty(n + 1, dtype=torch.int32, device=dev), None
-            K.rowptr_from_sorted(row, n, indptr)
+            perm, from_adj = None, False
         else:
-            index = K.build_assign_index(row, n)
-            indptr, perm = index.row_ptr, index.perm
-        return K.kron_batched(indptr, edge_index[1], edge_weight, perm, True, n, ptr, max_nodes, idx_pos,
-                              self.sparse_threshold)
+            row = edge_index[0]
+            if row.numel() > 1 and K._rows_sorted(edge_index, row):
+                indptr, perm = torch.empty(n + 1, dtype=torch.int32, device=dev), None
+                K.rowptr_from_sorted(row, n, indptr)
+            else:
+                index = K.build_assign_index(row, n)
+                indptr, perm = index.row_ptr, index.perm
+            col, val, from_adj = edge_index[1], edge_weight, True
+        out = K.kron_batched(indptr, col, val, perm, from_adj, n, ptr, min(max_nodes, limit), idx_pos,
+                             self.sparse_threshold, skip_oversize=oversize is not None)
+        if out is None or not oversize:
+            return out
+        eis, ews = [out[0]], [out[1]]
+        for g in oversize:
+            p0, p1 = int(ptr[g]), int(ptr[g + 1])
+            lap = self._dense_laplacian_block(indptr, col, val, perm, from_adj, p0, p1)
+            if lap is None:
+                return None  # an entry couples this graph to another one: not a block-diagonal batch
+            lo, hi = torch.searchsorted(idx_pos, torch.tensor([p0, p1], device=dev)).tolist()
+            if hi == lo:
+                continue
+            ei_g, ew_g = self._kron_on_device(lap, idx_pos[lo:hi] - p0)
+            eis.append(ei_g + lo)
+            ews.append(ew_g)
+        ei_all, ew_all = torch.cat(eis, 1), torch.cat(ews)
+        order = torch.sort(ei_all[0], stable=True).indices  # every block is row-major already; rows of one graph only
+        return ei_all[:, order].contiguous(), ew_all[order]
+
+    @staticmethod
+    def _dense_laplacian_block(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optional[Tensor],
+                               from_adjacency: bool, p0: int, p1: int) -> Optional[Tensor]:
+        """Dense fp64 Laplacian of the graph that owns nodes [p0, p1), from the same CSR the kernel reads
+        (from_adjacency: entries are edge weights, self loops skipped, duplicates summed, L = D - A)."""
+        n = p1 - p0
+        e0, e1 = int(indptr[p0]), int(indptr[p1])
+        counts = (indptr[p0 + 1: p1 + 1] - indptr[p0: p1]).long()
+        rows = torch.repeat_interleave(torch.arange(n, device=indptr.device), counts)
+        slots = torch.arange(e0, e1, device=indptr.device)
+        entries = slots if perm is None else perm[slots].long()
+        c = col[entries] - p0
+        if c.numel() and (int(c.min()) < 0 or int(c.max()) >= n):
+            return None
+        v = torch.ones(entries.numel(), dtype=torch.float64, device=indptr.device) if val is None else \
+            val[entries].to(torch.float64)
+        m = torch.zeros(n, n, dtype=torch.float64, device=indptr.device)
+        m.index_put_((rows, c), v, accumulate=True)
+        if not from_adjacency:
+            return m
+        m.fill_diagonal_(0)
+        return torch.diag(m.sum(1)) - m
 
     # ---------------------------------------------------------------- library route (one dense solve)
     def _kron_on_device(self, L: Tensor, idx_pos: Tensor) -> Tuple[Tensor, Tensor]:

@@ -643,7 +643,7 @@ def kron_max_graph_nodes() -> int:
 
 def kron_batched(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optional[Tensor], from_adjacency: bool,
                  num_nodes: int, graph_ptr: Tensor, max_graph_nodes: int, node_index: Tensor,
-                 threshold: float) -> Optional[Tuple[Tensor, Tensor]]:
+                 threshold: float, skip_oversize: bool = False) -> Optional[Tuple[Tensor, Tensor]]:
     """Block-batched Kron reduction (connect/kron_conn.py:117-165): one workgroup per graph, fp64 elimination of the
     dropped nodes, thresholded fp32 edge list in row-major order.  ``indptr`` int32 [N+1] / ``col`` int64 / ``val``
     fp32 or fp64 (None = ones) / ``perm`` int32 (None = identity) describe the Laplacian entries, or the edge weights
@@ -664,7 +664,8 @@ def kron_batched(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optio
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
     st = N.stream_ptr(dev)
     N.check(L.tgp_kron_batched_count(N.ptr(indptr.contiguous()), N.ptr(col), N.ptr(v32), N.ptr(v64),
-                                     N.ptr(None if perm is None else perm.contiguous()), 1 if from_adjacency else 0,
+                                     N.ptr(None if perm is None else perm.contiguous()),
+                                     (1 if from_adjacency else 0) | (2 if skip_oversize else 0),
                                      num_nodes, col.numel(), N.ptr(graph_ptr), B, max_graph_nodes, N.ptr(node_index),
                                      node_index.numel(), float(threshold), N.ptr(ws), ws.numel(), N.ptr(d_count), st),
             "tgp_kron_batched_count")
