@@ -317,13 +317,14 @@ int tgp_block_diag_fill(const float* adj_pool, int64_t B, int64_t K, const int64
 
 /* ------------------------------------------------------------------------------------
  * A14  NDPSelect._spectral_partition (select/ndp_select.py:187-256) for every graph of a batch, one workgroup each:
- *      largest eigenvector of Ls = I - D^-1/2 A D^-1/2 by power iteration (fp64, vectors in LDS), sign partition,
+ *      largest eigenvector of Ls = I - D^-1/2 A D^-1/2 by a one-vector LOBPCG iteration (fp64, vectors and matrix in LDS), sign partition,
  *      cut = z^T L z / (2 vol), random +-1 partition (node 0 kept, node 1 dropped, rest from `seed`) when cut < 0.5.
  *      Input: CSR over all nodes (`indptr` [N+1], `col`, `w` or NULL = ones) of the SYMMETRIC adjacency without self
  *      loops (the caller symmetrises with max: to_undirected(reduce="max"), ndp_select.py:198-202); `graph_ptr` [B+1].
- *      Output: keep[v] = 1 for the positive side; info[g] = iterations used, -1 = random fallback;
- *      *d_status: 0 ok, bit 0 = a graph beyond tgp_ndp_max_graph_nodes() (caller keeps its host route), bit 1 = an
- *      entry that couples two graphs.
+ *      Output: keep[v] = 1 for the positive side; info[g] = iterations used, -1 = random fallback, -2 = the graph is
+ *      beyond tgp_ndp_max_graph_nodes(): left unpartitioned (keep = 0 on its nodes), the caller partitions those few
+ *      graphs itself (pass max_graph_nodes = min(longest graph, tgp_ndp_max_graph_nodes()));
+ *      *d_status: 0 ok, bit 1 = an entry that couples two graphs.
  * ---------------------------------------------------------------------------------- */
 int tgp_ndp_max_graph_nodes(void);
 int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, const float* w /* NULL ok */, int64_t num_nodes,

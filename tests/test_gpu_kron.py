@@ -338,6 +338,53 @@ def test_ndp_select_device_partition_contract(dev, monkeypatch):
     assert abs(so.L - Lref).max() < 1e-5 and "L" in so.__dict__ and hasattr(so, "L")
 
 
+def test_ndp_mixed_batch_oversize_graph_does_not_send_the_batch_to_the_host(dev, monkeypatch):
+    """A graph beyond tgp_ndp_max_graph_nodes() (and beyond the Kron kernel's limit) among small ones: the kernels
+    leave it out, NDPSelect partitions THAT graph with the reference's scipy code on its sub-matrix, KronConnect
+    reduces it with the dense library solve on the device; the host's per-graph loop over the whole batch and the
+    host's sparse LU never run.  Result: every small graph satisfies the device contract, the big graph's partition
+    is the sign pattern of its largest eigenvector, the pooled edges equal the block-wise Kron reduction."""
+    import scipy.sparse.linalg as spla
+    from tgp import kernels as K
+    from tgp.poolers import get_pooler
+    from tgp.select import NDPSelect
+
+    big = K.ndp_max_graph_nodes() + 150
+    sizes = [30, 50, big, 41, 2, 60]
+    ei, ew, batch, _ = make_batch(sizes, seed=21, density=None, connected=True)
+    n = batch.numel()
+    calls = []
+    real_eigsh = spla.eigsh
+
+    def counting_eigsh(m, *a, **k):
+        calls.append(m.shape[0])
+        return real_eigsh(m, *a, **k)
+    monkeypatch.setattr(spla, "eigsh", counting_eigsh)
+    monkeypatch.setattr(spla, "spsolve", lambda *a, **k: (_ for _ in ()).throw(AssertionError("host sparse LU")))
+    pooler = get_pooler("ndp").to(dev)
+    x = torch.randn(n, 8, generator=torch.Generator().manual_seed(1)).to(dev)
+    with torch.no_grad():
+        out = pooler(x=x, adj=ei.to(dev), edge_weight=ew.to(dev), batch=batch.to(dev))
+    assert calls == [big], calls  # the host eigen-solver saw the oversize graph and nothing else
+    so = out.so
+    keep = torch.zeros(n, dtype=torch.bool)
+    keep[so.node_index.cpu()] = True
+    off = sum(sizes[:2])
+    a = torch.zeros(big, big, dtype=torch.float64)
+    sel = (batch[ei[0]] == 2)
+    a[ei[0][sel] - off, ei[1][sel] - off] = ew[sel].double()
+    deg = a.sum(1)
+    dis = deg.rsqrt()
+    vals, vecs = torch.linalg.eigh(torch.eye(big, dtype=torch.float64) - dis[:, None] * a * dis[None, :])
+    v = vecs[:, -1]
+    kp = keep[off:off + big]
+    if float(vals[-1] - vals[-2]) > 1e-6 and float(v.abs().min()) > 1e-7:
+        assert torch.equal(kp, v >= 0) or torch.equal(kp, v < 0)
+    assert 0 < int(kp.sum()) < big
+    ref = blockwise_kron(ei, ew, batch, so.node_index.cpu())
+    check(out.edge_index, out.edge_weight, ref, dev)
+
+
 def test_ndp_pooler_end_to_end_stays_on_device(dev, monkeypatch):
     """get_pooler("ndp") on a 2048-graph batch: neither the selector's eigen-solver nor the connector's sparse LU is
     called on the host; Reduce / Connect of the result equal the oracle's for the SelectOutput the pooler produced."""

@@ -159,8 +159,8 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
   const int64_t p0 = graph_ptr[g], p1 = graph_ptr[g + 1];
   const int64_t n64 = p1 - p0;
   if (n64 <= 0) return;
-  if (n64 > NDP_MAX_N) {
-    if (tid == 0) atomicOr(status, 1);
+  if (n64 > NDP_MAX_N) {  // left unpartitioned (keep stays 0): the caller handles the few oversize graphs itself
+    if (tid == 0) info[g] = -2;
     return;
   }
   const int n = static_cast<int>(n64);

@@ -684,31 +684,7 @@ class NDPSelect(Select):
             if nodes.size == 1:
                 keep.append(nodes)
                 continue
-            Ag = A[nodes][:, nodes]
-            dg = np.asarray(Ag.sum(1)).reshape(-1)
-            dis = np.where(dg > 0, 1.0 / np.sqrt(np.maximum(dg, 1e-300)), 0.0)
-            Ls = sp.eye(nodes.size) - sp.diags(dis) @ Ag @ sp.diags(dis)
-            Lg = sp.diags(dg) - Ag
-
-            def random_sign():
-                v = rng.integers(0, 2, nodes.size) * 2 - 1
-                v[0], v[1] = 1, -1
-                return v
-
-            try:
-                if nodes.size <= 3:
-                    vals, vecs = np.linalg.eigh(Ls.toarray())
-                    vec = vecs[:, -1]
-                else:
-                    _, vecs = spla.eigsh(Ls.tocsc(), k=1, which="LA", v0=np.ones(nodes.size))
-                    vec = vecs[:, 0]
-                z = np.where(vec >= 0, 1.0, -1.0)
-            except Exception:
-                z = random_sign().astype(np.float64)
-            vol = Ag.sum() if edge_weight is not None else Ag.nnz
-            cut = float(z @ (Lg @ z)) / (2.0 * vol) if vol > 0 else 0.0
-            if cut < 0.5:
-                z = random_sign().astype(np.float64)
+            z = self._partition_graph_on_host(A[nodes][:, nodes], edge_weight is not None, rng)
             keep.append(nodes[z >= 0])
         idx_pos = torch.from_numpy(np.sort(np.concatenate(keep)) if keep else np.zeros(0, dtype=np.int64)).to(dev)
         k = idx_pos.numel()
@@ -719,10 +695,46 @@ class NDPSelect(Select):
         so._node_batch = batch  # the partition KronConnect's block-batched kernel works on
         return so
 
+    @staticmethod
+    def _partition_graph_on_host(Ag, weighted: bool, rng):
+        """Sign partition of ONE graph (symmetric scipy CSR adjacency without self loops) exactly as the reference
+        does it (ndp_select.py:187-256): scipy eigsh, cut test, random +-1 fallback.  Returns z in {-1, +1}^n."""
+        import numpy as np
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spla
+        n = Ag.shape[0]
+        dg = np.asarray(Ag.sum(1)).reshape(-1)
+        dis = np.where(dg > 0, 1.0 / np.sqrt(np.maximum(dg, 1e-300)), 0.0)
+        Ls = sp.eye(n) - sp.diags(dis) @ Ag @ sp.diags(dis)
+        Lg = sp.diags(dg) - Ag
+
+        def random_sign():
+            v = rng.integers(0, 2, n) * 2 - 1
+            v[0], v[1] = 1, -1
+            return v
+
+        try:
+            if n <= 3:
+                vals, vecs = np.linalg.eigh(Ls.toarray())
+                vec = vecs[:, -1]
+            else:
+                _, vecs = spla.eigsh(Ls.tocsc(), k=1, which="LA", v0=np.ones(n))
+                vec = vecs[:, 0]
+            z = np.where(vec >= 0, 1.0, -1.0)
+        except Exception:
+            z = random_sign().astype(np.float64)
+        vol = Ag.sum() if weighted else Ag.nnz
+        cut = float(z @ (Lg @ z)) / (2.0 * vol) if vol > 0 else 0.0
+        if cut < 0.5:
+            z = random_sign().astype(np.float64)
+        return z
+
     def _forward_device(self, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Optional[Tensor],
                         num_nodes: int) -> Optional[SelectOutput]:
-        """The whole selection on the GPU (tgp_ndp_partition: one workgroup per graph); None when the batch has a
-        graph beyond the kernel's size limit or an unsorted batch vector (the host route below then runs)."""
+        """The whole selection on the GPU (tgp_ndp_partition: one workgroup per graph); graphs beyond the kernel's
+        size limit are left out by the kernel and partitioned one by one with the reference's own scipy code on THEIR
+        sub-matrix (a 5000-node graph among 2000 small ones must not send the whole batch through the host loop).
+        None for an unsorted batch vector or a single oversize graph (the host route below then runs)."""
         from .. import kernels as K
         from ..utils.ops import batch_info
         dev = edge_index.device
@@ -731,10 +743,12 @@ class NDPSelect(Select):
             info = batch_info(batch)
             if not info.is_sorted:
                 return None
-            ptr, max_nodes = info.ptr, info.max_nodes
+            ptr, max_nodes, sizes_host = info.ptr, info.max_nodes, info.sizes_host
         else:
-            ptr, max_nodes = torch.tensor([0, n], dtype=torch.long, device=dev), n
-        if max_nodes > K.ndp_max_graph_nodes():
+            ptr, max_nodes, sizes_host = torch.tensor([0, n], dtype=torch.long, device=dev), n, [n]
+        limit = K.ndp_max_graph_nodes()
+        oversize = [g for g, m in enumerate(sizes_host) if m > limit]
+        if oversize and len(sizes_host) == 1:
             return None
         ident = torch.arange(n, device=dev)
         w0 = torch.ones(edge_index.size(1), device=dev) if edge_weight is None else edge_weight.detach().reshape(-1).float()
@@ -746,7 +760,24 @@ class NDPSelect(Select):
         indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         K.rowptr_from_sorted(ei2[0], n, indptr)
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-        keep, part_info, status = K.ndp_partition(indptr, ei2[1], w2, n, ptr, max_nodes, seed)
+        keep, part_info, status = K.ndp_partition(indptr, ei2[1], w2, n, ptr, min(max_nodes, limit), seed)
+        if oversize:
+            import numpy as np
+            import scipy.sparse as sp
+            rng = np.random.default_rng(seed)
+            offs = [0]
+            for m in sizes_host:
+                offs.append(offs[-1] + m)
+            for g in oversize:
+                p0, p1 = offs[g], offs[g + 1]
+                e0, e1 = int(indptr[p0]), int(indptr[p1])
+                ip = (indptr[p0: p1 + 1] - e0).cpu().numpy()
+                cg = (ei2[1][e0:e1] - p0).cpu().numpy()
+                if cg.size and (cg.min() < 0 or cg.max() >= p1 - p0):
+                    return None  # an edge couples this graph to another one
+                Ag = sp.csr_matrix((w2[e0:e1].double().cpu().numpy(), cg, ip), shape=(p1 - p0, p1 - p0))
+                z = self._partition_graph_on_host(Ag, edge_weight is not None, rng)
+                keep[p0:p1] = torch.from_numpy(z >= 0).to(dev)
         idx_pos = keep.nonzero().view(-1)  # (host round trip: the size of S; also orders the status read below)
         if int(status.item()) != 0:
             return None
