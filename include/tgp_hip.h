@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10002 /* 1.0.1 of the reference, ABI revision 2 (eps arguments, Kron entries) */
+#define TGP_ABI_VERSION 10003 /* 1.0.1 of the reference, ABI revision 3 (r2: eps arguments, Kron / NDP entries; oversize graphs are skipped, not declined: TGP_KRON_SKIP_OVERSIZE, info[g] = -2) */
 
 enum tgp_status {
   TGP_OK = 0,

@@ -39,7 +39,7 @@ def test_ctypes_table_matches_header():
     from tgp import _native
     assert sorted(_native.SIGNATURES) == declared_symbols()
     lib = _native.lib()
-    assert lib.tgp_version() == 10002
+    assert lib.tgp_version() == 10003
     assert lib.tgp_last_error() is not None
 
 
