@@ -44,7 +44,7 @@ sys.path.insert(0, os.path.join(ROOT, "torch-geometric-pool_amd"))
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = "pooled nodes/sec (Reduce+Connect) on batched graphs"
-SETTLE_SECONDS = 0.05  # untimed run-in of the workload before the contract window (see main)
+SETTLE_SECONDS = 0.1  # untimed run-in of the workload before the contract window (see main)
 WINDOWS, WINDOW_STEPS = 5, 200
 
 
@@ -93,6 +93,12 @@ class Ctx:
         self.dev, self.rank, self.world, self.dist = dev, rank, world, dist
 
     def sync(self):
+        # torch.cuda.synchronize() alone returns tens of microseconds after the device went idle (the runtime's wait
+        # yields the CPU); on a 2 ms window that is percents.  Poll an event first, then synchronise for real.
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        while not ev.query():
+            pass
         torch.cuda.synchronize(self.dev)
 
     def barrier(self):
@@ -606,9 +612,13 @@ def main():
     est = torch.tensor([(time.perf_counter() - t0) / max(args.warmup, 1)], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(est, op=dist.ReduceOp.MAX)
-    settle_steps = max(0, min(2000, int(SETTLE_SECONDS / max(float(est.item()), 1e-6)) - args.warmup))
-    for _ in range(settle_steps):
-        wl.step()
+    settle_steps = max(0, min(4000, int(SETTLE_SECONDS / max(float(est.item()), 1e-6)) - args.warmup))
+    done = 0
+    while done < settle_steps:  # in bursts of 50 with a synchronise in between: the host must not run hundreds of
+        for _ in range(min(50, settle_steps - done)):  # launches ahead (the first submission after such a backlog
+            wl.step()                                  # takes ~100 us instead of ~40, inside the window that follows)
+        done += 50
+        ctx.sync()
     if wl.drain is not None:
         wl.drain()  # warm-up ends with an empty gather bucket, its collective done (communicator set-up is not a step)
     dt = timed_window(ctx, wl.step, args.steps, wl.drain)  # THE contract window: exactly --steps steps
