@@ -164,7 +164,14 @@ def ptr(t: Optional[Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(dev: torch.device) -> int:
+    """Handle of torch's CURRENT stream on ``dev`` (what the library launches on).  The raw accessor costs ~0.3 us;
+    building a torch.cuda.Stream object per call cost ~6 us, a quarter of the whole launch path of a 21 us kernel."""
+    if _raw_stream is not None:
+        return _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(dev).cuda_stream
 
 
