@@ -39,7 +39,8 @@ def test_ctypes_table_matches_header():
     from tgp import _native
     assert sorted(_native.SIGNATURES) == declared_symbols()
     lib = _native.lib()
-    assert lib.tgp_version() == 10003
+    m = re.search(r"#define\s+TGP_ABI_VERSION\s+(\d+)", open(HEADER).read())
+    assert m and lib.tgp_version() == int(m.group(1))
     assert lib.tgp_last_error() is not None
 
 
@@ -138,3 +139,19 @@ def test_ctypes_signatures_match_the_header_parameter_by_parameter():
         want = [kind(q) for q in params]
         got = [ctypes.c_void_p if a is ctypes.c_char_p else a for a in argtypes]
         assert got == want, f"{name}: header {[w.__name__ for w in want]} vs binding {[g.__name__ for g in got]}"
+
+
+def test_graft_entry_build_from_a_clean_tree(tmp_path):
+    """``__graft_entry__.build()`` on a scratch copy without ``lib/``: clean checkout -> make -> bind every symbol
+    -> version check against the header.  (r2 shipped a stale version literal in build() that no test reached.)"""
+    import shutil
+    import subprocess
+    import sys
+    dst = tmp_path / "tree"
+    ignore = shutil.ignore_patterns(".git", "gpurun_out", "lib", "__pycache__", "profiles", "golden", ".pytest_cache")
+    shutil.copytree(ROOT, dst, ignore=ignore)
+    assert not (dst / "torch-geometric-pool_amd" / "lib").exists()
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); print('BUILD-OK')"],
+                       cwd=dst, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "BUILD-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert (dst / "torch-geometric-pool_amd" / "lib" / "libtgp_hip.so").exists()
