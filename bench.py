@@ -23,7 +23,10 @@ Rank 0 prints ONE JSON line:
   "secondary"      the other north_star workloads, each with its own median-window timing and roofline:
                    c5 (N=8192,K=512,F=128: fp32 MFMA), topk1m (TopK scatter-reduce: HBM), topk_connect (TopK subgraph
                    Connect: HBM), c4_graclus (Reduce + coalesce Connect, both rooflines: HBM), c3 (MinCut small graphs:
-                   HBM).  With N > 1 only the graph-sharded ones (c5, c3) run; one giant graph (C4) does not shard.
+                   HBM), c4_ndp (NDP-shaped Reduce), topk_batch (batched sparse TopK Reduce + Connect; with ranks: +
+                   variable-size RCCL all-gather), e2e_diff_c2 / e2e_mincut_c3 (WHOLE pooler forwards on sparse
+                   inputs, eager and HIP-graph replayed, launches per forward).  With N > 1 only the graph-sharded
+                   ones run; one giant graph (C4) does not shard.
 `--workload X` makes X the headline of the line instead; the driver's line is the default c2.
 """
 import argparse
@@ -43,6 +46,7 @@ sys.path.insert(0, os.path.join(ROOT, "torch-geometric-pool_amd"))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+COPY_RATE_GBS = 6290.0         # MI355X_MICROARCH.md: measured float4 copy (79 % of spec): the achievable streaming rate
 METRIC = "pooled nodes/sec (Reduce+Connect) on batched graphs"
 SETTLE_SECONDS = 0.1  # untimed run-in of the workload before the contract window (see main)
 WINDOWS, WINDOW_STEPS = 5, 200
@@ -155,26 +159,31 @@ def event_time_ms(fn, reps, dev):
 
 
 def _traffic(key):
-    """HBM bytes per launch from this round's PMC passes (profiles/roofline_traffic.json), or None."""
+    """(HBM bytes per launch, source) from the committed PMC passes (profiles/roofline_traffic.json; counters cannot
+    be collected from inside the run), or (None, None)."""
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-    if os.path.exists(tpath):
+    if key and os.path.exists(tpath):
         with open(tpath) as fh:
-            return json.load(fh).get(key)
-    return None
+            blob = json.load(fh)
+        if blob.get(key) is not None:
+            return blob[key], blob.get("_source", "profiles/roofline_traffic.json")
+    return None, None
 
 
 def roof_mfma(kernel, flops, ms, traffic_key=None):
     a = flops / (ms * 1e-3) / 1e12
+    traffic, src = _traffic(traffic_key)
     return {"kernel": kernel, "bound": "mfma", "achieved": round(a, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(a / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": _traffic(traffic_key),
-            "flops_per_launch": flops, "avg_launch_ms": round(ms, 5)}
+            "unit": "TFLOP/s", "frac": round(a / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": src, "flops_per_launch": flops, "avg_launch_ms": round(ms, 5)}
 
 
 def roof_hbm(kernel, nbytes, ms, traffic_key=None):
     a = nbytes / (ms * 1e-3) / 1e9
+    traffic, src = _traffic(traffic_key)
     return {"kernel": kernel, "bound": "hbm", "achieved": round(a, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(a / PEAK_HBM_GBS, 4), "traffic": _traffic(traffic_key), "bytes_per_launch": nbytes,
-            "avg_launch_ms": round(ms, 5)}
+            "frac": round(a / PEAK_HBM_GBS, 4), "frac_of_measured_copy_rate": round(a / COPY_RATE_GBS, 4),
+            "traffic": traffic, "traffic_source": src, "bytes_per_launch": nbytes, "avg_launch_ms": round(ms, 5)}
 
 
 # ------------------------------------------------------------------------------------------------ workloads
@@ -311,6 +320,164 @@ class SmallGraphsMinCut(Workload):
         ms = event_time_ms(self.step, 100, dev)
         return roof_hbm("tgp::dense_pool_small_kernel (whole step, one launch: graphs fit in LDS)", alg, ms,
                         "dense_pool_small_kernel:c3")
+
+
+def sparse_batch(sizes, deg, f, dev, seed=0):
+    """PyG-style batch: x [Ntot,F], sorted duplicate-free undirected edge_index [2,E], sorted batch vector."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    sizes = torch.as_tensor(sizes, device=dev)
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(sizes.numel(), device=dev), sizes)
+    start = torch.cumsum(sizes, 0) - sizes
+    src = torch.arange(n, device=dev).repeat_interleave(max(deg // 2, 1))
+    dst = start[batch[src]] + (torch.rand(src.numel(), device=dev, generator=g) * sizes[batch[src]]).long()
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    key = torch.unique(torch.cat([src * n + dst, dst * n + src]))
+    ei = torch.stack([key // n, key % n])
+    x = torch.randn(n, f, device=dev, generator=g)
+    return x, ei, batch
+
+
+def _proteins_sizes(seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(20, 61, (2048,), generator=g).tolist()
+
+
+def count_kernels(fn):
+    """Device kernels (and memsets) one call of `fn` launches, from torch.profiler; None when the profiler is not
+    available."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        fn()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            fn()
+            torch.cuda.synchronize()
+        return sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
+    except Exception:
+        return None
+
+
+class PoolerForward(Workload):
+    """e2e_diff_c2 / e2e_mincut_c3: the WHOLE forward of ``get_pooler(alias)(x, adj=edge_index, batch=batch)`` on
+    sparse PyG-style inputs -- sparse->dense preprocessing, MLPSelect, Reduce, Connect, auxiliary losses -- eager,
+    and replayed from a HIP graph.  Not the contract metric (that excludes Select and preprocessing):
+    it is what a user's call costs."""
+    shards = True
+
+    def __init__(self, which, ctx):
+        from tgp.poolers import get_pooler
+        dev = ctx.dev
+        torch.manual_seed(ctx.rank)
+        if which == "e2e_diff_c2":
+            self.B, self.N, self.K, self.F = 32, 1024, 128, 64
+            sizes, deg, alias = [1024] * 32, 10, "diff"
+            self.name = "get_pooler('diff') whole forward on sparse inputs: 32 graphs x 1024 nodes, K=128, F=64"
+        else:
+            self.B, self.N, self.K, self.F = 2048, 60, 20, 32
+            sizes, deg, alias = _proteins_sizes(ctx.rank), 4, "mincut"
+            self.name = "get_pooler('mincut') whole forward on sparse inputs: 2048 graphs n~U[20,60], K=20, F=32"
+        self.which = which
+        self.x, self.ei, self.batch = sparse_batch(sizes, deg, self.F, dev, seed=ctx.rank)
+        self.pooler = get_pooler(alias, in_channels=self.F, k=self.K).to(dev).eval()
+        self.nodes = self.x.size(0)
+        self.graph = None
+        self.extra = {"nodes_counted": "real input nodes per forward", "edges": int(self.ei.size(1)),
+                      "step": "whole pooler forward, eager (preprocessing + Select + Reduce + Connect + losses)"}
+
+    def step(self):
+        with torch.no_grad():
+            return self.pooler(x=self.x, adj=self.ei, batch=self.batch)
+
+    def rooflines(self, dev):
+        B, N, K, F = self.B, self.N, self.K, self.F
+        ms = event_time_ms(self.step, 50, dev)
+        if self.which == "e2e_diff_c2":
+            # Select 2MFK + Reduce/Connect 2BN^2K + 2BKN(K+F) + link-prediction residual 2BN^2K
+            flops = 2.0 * B * N * F * K + 4.0 * B * N * N * K + 2.0 * B * K * N * (K + F)
+            r = roof_mfma("whole forward (all kernels of the call, eager)", flops, ms)
+        else:
+            # edge list + x in; dense A written and read once; X, S written and read once; pooled outputs
+            alg = (self.ei.size(1) * 16.0 + self.nodes * F * 4.0 + 2 * 4.0 * B * N * N + 2 * 4.0 * B * N * (F + K)
+                   + 4.0 * B * (2 * K * K + K * F))
+            r = roof_hbm("whole forward (all kernels of the call, eager)", alg, ms)
+        r["launches_per_forward"] = count_kernels(self.step)
+        try:  # the same forward replayed from a HIP graph (inputs resident, sizes memoised per batch vector)
+            gph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.step()
+            torch.cuda.current_stream().wait_stream(side)
+            with torch.cuda.graph(gph):
+                self.step()
+            r["hip_graph_replay_ms"] = round(event_time_ms(gph.replay, 50, dev), 5)
+        except Exception as exc:
+            r["hip_graph_replay_ms"] = None
+            r["hip_graph_error"] = f"{type(exc).__name__}: {str(exc)[:120]}"
+        return r
+
+
+class TopkBatch(Workload):
+    """topk_batch: TopK (ratio 0.5) Reduce + subgraph Connect on 2048 PROTEINS-shaped graphs, Select excluded.  The
+    batched SPARSE path of SURVEY 8(e): graphs shard by id, and with more than one rank (or TGP_BENCH_FORCE_DIST=1)
+    the variable-size pooled outputs are all-gathered over RCCL inside the timed region (counts, then padded
+    payloads, then node-id / graph-id offsets: the merge rule of tgp/data/collate.py:144-153)."""
+    shards = True
+
+    def __init__(self, ctx, force_collective=False):
+        from tgp.connect import SparseConnect
+        from tgp.reduce import BaseReduce
+        from tgp.select import TopkSelect
+        dev = ctx.dev
+        torch.manual_seed(ctx.rank)
+        self.f = 32
+        self.x, self.ei, self.batch = sparse_batch(_proteins_sizes(ctx.rank), 4, self.f, dev, seed=ctx.rank)
+        self.ew = torch.rand(self.ei.size(1), device=dev) + 0.5
+        with torch.no_grad():
+            self.so = TopkSelect(in_channels=self.f, ratio=0.5).to(dev)(x=self.x, batch=self.batch)
+        self.red, self.conn = BaseReduce(), SparseConnect()
+        self.gather = ctx.dist is not None
+        self.dist_world = ctx.world
+        self.force = force_collective
+        self.nodes = self.x.size(0)
+        self.num_graphs = 2048
+        self.name = ("TopK (ratio 0.5) Reduce + subgraph Connect on 2048 PROTEINS-shaped graphs (n~U[20,60], F=32), "
+                     "graph-sharded" + (", pooled outputs all-gathered over RCCL (variable-size)" if self.gather else ""))
+        self.extra = {"edges": int(self.ei.size(1)), "num_supernodes": int(self.so.num_supernodes),
+                      "nodes_counted": "input nodes per step per GPU",
+                      "step": "BaseReduce + SparseConnect (subgraph)" + (" + all_gather_sparse" if self.gather else "")}
+
+    def compute(self):
+        with torch.no_grad():
+            xp, bp = self.red(self.x, self.so, batch=self.batch)
+            ei, ew = self.conn(self.ei, self.so, edge_weight=self.ew, batch_pooled=bp)
+        return xp, ei, ew, bp
+
+    def step(self):
+        xp, ei, ew, bp = self.compute()
+        if self.gather:
+            from tgp.distributed import all_gather_sparse
+            return all_gather_sparse(xp, ei, ew, bp, self.num_graphs, force_collective=self.force)
+        return xp, ei, ew, bp
+
+    def rooflines(self, dev):
+        xp, ei, ew, bp = self.compute()
+        E, E2, k = self.ei.size(1), ei.size(1), xp.size(0)
+        alg = (k * (4.0 * self.f + 8 + 4 + 4) + k * 4.0 * self.f          # A1 one-to-one
+               + E * 20.0 + self.nodes + k * 8.0 + E2 * 20.0)              # A5 + A6
+        ms_c = event_time_ms(self.compute, 50, dev)
+        r = roof_hbm("Reduce + subgraph Connect (all kernels of both calls + the Connect's host read-back)", alg, ms_c)
+        r["compute_only_ms"] = round(ms_c, 5)
+        if self.gather:
+            ms_g = event_time_ms(self.step, 50, dev)
+            r["compute_plus_gather_ms"] = round(ms_g, 5)
+            merged = self.step()
+            if self.dist_world == 1:  # one-rank group: the merged result must be the local one, bit for bit
+                r["gather_equals_local"] = bool(torch.equal(merged[0], xp) and torch.equal(merged[1], ei)
+                                                and torch.equal(merged[2], ew) and torch.equal(merged[3], bp))
+        return r
 
 
 def _big_graph(dev, g, sort_rows=True):
@@ -463,6 +630,10 @@ def make_workload(which, ctx, args):
         return TopkConnect(ctx)
     if which == "c4_graclus":
         return GraclusC4(ctx, unsorted_edges=args.unsorted_edges)
+    if which in ("e2e_diff_c2", "e2e_mincut_c3"):
+        return PoolerForward(which, ctx)
+    if which == "topk_batch":
+        return TopkBatch(ctx, force_collective=os.environ.get("TGP_BENCH_FORCE_DIST") == "1")
     raise ValueError(which)
 
 
@@ -539,8 +710,10 @@ def cpu_baseline_dense(B, N, K, F, budget_s=10.0):
 
 
 # ------------------------------------------------------------------------------------------------ main
-ALL = ["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect"]
-SECONDARY_DEFAULT = ["c5", "topk1m", "topk_connect", "c4_graclus", "c3"]
+ALL = ["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect", "topk_batch", "e2e_diff_c2", "e2e_mincut_c3"]
+SECONDARY_DEFAULT = ["c5", "topk1m", "topk_connect", "c4_graclus", "c4_ndp", "c3", "topk_batch", "e2e_diff_c2",
+                     "e2e_mincut_c3"]
+SHARDED = ("c5", "c3", "topk_batch", "e2e_diff_c2", "e2e_mincut_c3")
 
 
 def main():
@@ -550,7 +723,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=ALL)
     ap.add_argument("--secondary", default=None,
-                    help="comma-separated secondary workloads ('none' to skip); default: all five on the c2 line")
+                    help="comma-separated secondary workloads ('none' to skip); default: all of them on the c2 line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true",
                     help="dense workloads: call the Reduce and Connect operators one after the other")
@@ -632,7 +805,7 @@ def main():
     else:
         sec = [s for s in args.secondary.split(",") if s and s != "none"]
     if world > 1:
-        sec = [s for s in sec if s in ("c5", "c3")]  # the graph-sharded ones
+        sec = [s for s in sec if s in SHARDED]  # the graph-sharded ones
     headline_cfg = dict(workload=wl.name, **(wl.extra or {}), parallelism=f"graph-sharded x{world}")
     dims = (wl.B, wl.N, wl.K, wl.F) if isinstance(wl, DenseDiffPool) else None
     del wl

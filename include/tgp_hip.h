@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10003 /* 1.0.1 of the reference, ABI revision 3 (r2: eps arguments, Kron / NDP entries; oversize graphs are skipped, not declined: TGP_KRON_SKIP_OVERSIZE, info[g] = -2) */
+#define TGP_ABI_VERSION 10004 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -275,6 +275,10 @@ size_t tgp_entropy_sum_workspace_bytes(int64_t n);
 int tgp_entropy_sum_f32(const float* S, int64_t n, float eps, float* out, void* ws, size_t ws_bytes, void* stream);
 int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int64_t N, int64_t K,
                       const int64_t* graph_sizes /* [B] or NULL */, float* deg, float* q, float* den, void* stream);
+/* Per-graph tails of MinCut's losses in one launch: out[0,b] = -trace(raw[b]) / (den[b] + eps) (utils/losses.py:39-56),
+ * out[1,b] = || G_b / ||G_b||_F - I / sqrt(K) ||_F (utils/losses.py:59-70); raw, gram [B,K,K], den [B], out [2,B]. */
+int tgp_mincut_loss_terms_f32(const float* raw, const float* den, const float* gram, int64_t B, int64_t K, float eps,
+                              float* out, void* stream);
 
 /* A7'  sparse A times dense S (connect/dense_conn.py:165,204: torch.sparse.mm), A in CSR built from a
  * row-sorted coalesced edge list: T[i,:] = sum_{e in row i} w[e] * S[col[e],:].  w may be NULL. */
@@ -361,6 +365,20 @@ int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col, const floa
 int tgp_kron_batched_fill(const void* ws, int64_t num_nodes, int64_t num_graphs, int64_t max_graph_nodes,
                           const int64_t* graph_ptr, int64_t num_out, int64_t* out_row, int64_t* out_col,
                           float* out_weight, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * A13  MLPSelect's last layer, one pass over the node features
+ *   S[m,:] = softmax(X[m,:] W^T + b) * mask[m]       (select/mlp_select.py:139-145; single Linear(F,K): :67)
+ * x [M,F], weight [K,F] (torch.nn.Linear layout), bias [K] or NULL, mask [M] bytes (0 = padded row) or NULL,
+ * s_out [M,K]; all contiguous fp32.  K <= tgp_mlp_select_max_fused_k() (256: eight 32-column accumulator tiles per
+ * wave); wider selectors run tgp_bmm_f32 for the logits and tgp_softmax_rows_f32 (bias + softmax + mask, in place).
+ * tgp_softmax_bwd_f32: dY = S * (dS - <dS,S>_row), the gradient w.r.t. the logits (0 on masked rows, whose S is 0).
+ * ---------------------------------------------------------------------------------- */
+int tgp_mlp_select_max_fused_k(void);
+int tgp_mlp_select_f32(const float* x, const float* weight, const float* bias, const unsigned char* mask, int64_t M,
+                       int64_t F, int64_t K, float* s_out, void* stream);
+int tgp_softmax_rows_f32(float* y, const float* bias, const unsigned char* mask, int64_t M, int64_t K, void* stream);
+int tgp_softmax_bwd_f32(const float* s, const float* ds, float* dy, int64_t M, int64_t K, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * test hooks for the shared primitives (device-wide stable LSD radix sort, block scan)

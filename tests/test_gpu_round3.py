@@ -1,0 +1,172 @@
+"""Round-3 GPU parity tests: the native MLPSelect (select/mlp_select.py:105-147) against the
+oracle's restatement, its gradients against torch autograd, and the selectors through ``get_pooler``."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+SHAPES = [  # (leading shape, F, K)
+    ((2048, 60), 32, 20),      # C3: PROTEINS-shaped MinCut batch
+    ((32, 1024), 64, 128),     # C2
+    ((3, 50), 16, 8), ((1, 37), 7, 5), ((5, 33), 33, 31), ((2, 100), 130, 65), ((4, 64), 96, 256),
+    ((2, 40), 300, 200),       # F * K beyond the LDS budget: W walks through LDS in slices
+    ((777,), 12, 10),          # unbatched [N, F]
+    ((2, 70), 24, 300),        # K > 256: tiled GEMM + softmax kernel
+]
+
+
+@pytest.mark.parametrize("lead,F,K", SHAPES)
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_mlp_select_kernel_vs_oracle(dev, lead, F, K, with_mask):
+    """S = softmax(X W^T + b) * mask, rtol = atol = 1e-5 (north_star: 1e-5 rel for fp32 outputs) and rows sum to 1."""
+    import tgp_oracle as O
+    from tgp import kernels as Kn
+    g = torch.Generator().manual_seed(hash((lead, F, K)) % 1000)
+    x = torch.randn(*lead, F, generator=g)
+    w = torch.randn(K, F, generator=g) * (2.0 / F ** 0.5)
+    b = torch.randn(K, generator=g)
+    mask = (torch.rand(*lead, generator=g) < 0.8) if with_mask else None
+    want = O.mlp_select(x, [w], [b], mask)
+    got = Kn.mlp_select(x.to(dev), w.to(dev), b.to(dev), None if mask is None else mask.to(dev)).cpu()
+    assert got.shape == want.shape
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    rel = ((got - want).abs() / want.abs().clamp_min(1e-30))[want > 1e-6]
+    assert rel.numel() == 0 or float(rel.max()) < 2e-5, float(rel.max())
+    if with_mask:
+        assert bool((got[~mask] == 0).all())
+    # no bias
+    got = Kn.mlp_select(x.to(dev), w.to(dev), None, None).cpu()
+    torch.testing.assert_close(got, O.mlp_select(x, [w], [torch.zeros(K)], None), rtol=1e-5, atol=1e-5)
+
+
+def test_mlp_select_large_logits_and_misaligned_views(dev):
+    """Logits of +-80 (softmax saturates: the max-subtraction must hold), and x / weight handed over as
+    non-contiguous views (made contiguous at the boundary)."""
+    import tgp_oracle as O
+    from tgp import kernels as Kn
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(200, 40, generator=g) * 20
+    w = torch.randn(24, 40, generator=g)
+    b = torch.randn(24, generator=g) * 5
+    torch.testing.assert_close(Kn.mlp_select(x.to(dev), w.to(dev), b.to(dev), None).cpu(),
+                               O.mlp_select(x, [w], [b]), rtol=1e-5, atol=1e-5)
+    xb = torch.randn(200, 80, generator=g)
+    wb = torch.randn(24, 80, generator=g)
+    got = Kn.mlp_select(xb.to(dev)[:, ::2], wb.to(dev)[:, 1::2], None, None).cpu()
+    torch.testing.assert_close(got, O.mlp_select(xb[:, ::2], [wb[:, 1::2]], [torch.zeros(24)]), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("lead,F,K", [((6, 50), 16, 8), ((2, 64), 64, 128), ((300,), 20, 300)])
+def test_mlp_select_gradients_vs_torch(dev, lead, F, K):
+    """Backward of the one-pass selector (softmax gradient kernel + native GEMMs) against torch autograd of
+    linear -> softmax -> mask."""
+    from tgp import functions as Fn
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(*lead, F, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(K, F, generator=g) * 0.3).to(dev).requires_grad_(True)
+    b = torch.randn(K, generator=g).to(dev).requires_grad_(True)
+    mask = (torch.rand(*lead, generator=g) < 0.7).to(dev)
+    up = torch.randn(*lead, K, generator=g).to(dev)
+    s = Fn.mlp_select(x, w, b, mask)
+    (s * up).sum().backward()
+    got = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    ref = torch.softmax(torch.nn.functional.linear(x, w, b), -1) * mask.unsqueeze(-1)
+    (ref * up).sum().backward()
+    for a, t in zip(got, (x, w, b)):
+        torch.testing.assert_close(a, t.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_mlp_select_module_uses_the_native_kernel(dev, monkeypatch):
+    """MLPSelect.forward on a device batch never calls torch.softmax / F.linear for a single-Linear selector, and a
+    multi-layer selector only for its hidden layers; outputs equal the oracle."""
+    import tgp_oracle as O
+    from tgp.select import MLPSelect
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 30, 12, generator=g)
+    mask = torch.rand(4, 30, generator=g) < 0.9
+    sel = MLPSelect(in_channels=12, k=6).to(dev)
+    calls = []
+    real_softmax = torch.softmax
+    monkeypatch.setattr(torch, "softmax", lambda *a, **k: (calls.append("softmax"), real_softmax(*a, **k))[1])
+    so = sel(x=x.to(dev), mask=mask.to(dev))
+    assert calls == []
+    lin = sel.mlp.lins[0]
+    want = O.mlp_select(x, [lin.weight.detach().cpu()], [lin.bias.detach().cpu()], mask)
+    torch.testing.assert_close(so.s.cpu(), want, rtol=1e-5, atol=1e-5)
+    sel2 = MLPSelect(in_channels=[12, 16], k=6, act="relu").to(dev)
+    so2 = sel2(x=x.to(dev), mask=mask.to(dev))
+    assert calls == []
+    ws = [l.weight.detach().cpu() for l in sel2.mlp.lins]
+    bs = [l.bias.detach().cpu() for l in sel2.mlp.lins]
+    torch.testing.assert_close(so2.s.cpu(), O.mlp_select(x, ws, bs, mask, act="relu"), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,N,K", [(7, 40, 6), (3, 200, 33), (64, 60, 20), (2, 300, 130)])
+def test_mincut_loss_tail_kernel_vs_oracle(dev, B, N, K):
+    """Both MinCut losses through the one-launch tail (inference path) equal the oracle's restatement of
+    utils/losses.py:39-70 and the autograd-path values."""
+    import tgp_oracle as O
+    from tgp.utils import losses as L
+    g = torch.Generator().manual_seed(B * 1000 + K)
+    a = (torch.rand(B, N, N, generator=g) < 0.1).float()
+    a = torch.maximum(a, a.transpose(1, 2))
+    s = torch.softmax(torch.randn(B, N, K, generator=g), -1)
+    raw = O.dense_connect(s, a)
+    want_cut, want_ortho = O.mincut_loss(a, s, raw), O.orthogonality_loss(s)
+    both = L.mincut_loss_terms(a.to(dev), s.to(dev), raw.to(dev)).mean(dim=1).cpu()
+    torch.testing.assert_close(both[0], want_cut, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(both[1], want_ortho, rtol=1e-5, atol=1e-6)
+    sg = s.to(dev).requires_grad_(True)
+    torch.testing.assert_close(L.mincut_loss(a.to(dev), sg, raw.to(dev)).detach().cpu(), both[0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(L.orthogonality_loss(sg).detach().cpu(), both[1], rtol=1e-5, atol=1e-6)
+
+
+def test_all_gather_sparse_over_rccl_one_rank_group(dev):
+    """The variable-size gather of pooled sparse outputs (merge rule tgp/data/collate.py:144-153) through
+    REAL RCCL collectives on the device: a one-rank process group with ``force_collective`` runs the count exchange, the
+    padded payload gathers and the offset merge; the merged result must equal the local one bit for bit."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from tgp.connect import SparseConnect
+    from tgp.distributed import all_gather_sparse
+    from tgp.reduce import BaseReduce
+    from tgp.select import TopkSelect
+    created = False
+    if not dist.is_initialized():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        g = torch.Generator().manual_seed(0)
+        sizes = torch.randint(20, 61, (300,), generator=g)
+        n = int(sizes.sum())
+        batch = torch.repeat_interleave(torch.arange(300), sizes).to(dev)
+        start = (torch.cumsum(sizes, 0) - sizes).to(dev)
+        src = torch.arange(n, device=dev).repeat_interleave(2)
+        dst = start[batch[src]] + (torch.rand(src.numel(), device=dev) * sizes.to(dev)[batch[src]]).long()
+        key = torch.unique(torch.cat([src * n + dst, dst * n + src]))
+        ei = torch.stack([key // n, key % n])
+        x = torch.randn(n, 16, device=dev)
+        ew = torch.rand(ei.size(1), device=dev) + 0.5
+        with torch.no_grad():
+            so = TopkSelect(in_channels=16, ratio=0.5).to(dev)(x=x, batch=batch)
+            xp, bp = BaseReduce()(x, so, batch=batch)
+            pe, pw = SparseConnect()(ei, so, edge_weight=ew, batch_pooled=bp)
+        mx, me, mw, mb = all_gather_sparse(xp, pe, pw, bp, 300, force_collective=True)
+        assert mx.data_ptr() != xp.data_ptr()  # went through the gather buffers, not the early return
+        assert torch.equal(mx, xp) and torch.equal(me, pe) and torch.equal(mw, pw) and torch.equal(mb, bp)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -719,3 +719,81 @@ def test_dense_path_max_relative_error_vs_fp64_oracle(dev, B, N, K, F, capsys):
     with capsys.disabled():
         print(f"\n[max relative error vs fp64 oracle, B={B} N={N} K={K} F={F}] "
               + ", ".join(f"{k}: {v:.2e}" for k, v in report.items()))
+
+
+# ------------------------------------------------------------------ full-size bit-exact cross-checks (r3)
+def _torch_coalesce(ei, ew, cluster, k, remove_self_loops=True):
+    """connect/base_conn.py:83-89 + utils/ops.py:370-380 restated with torch device ops that share no code with the
+    kernels: relabel, stable sort of the u64 key, unique_consecutive, index_add_ of the weights, self-loop filter."""
+    r, c = cluster[ei[0]], cluster[ei[1]]
+    key = r * k + c
+    skey, order = torch.sort(key, stable=True)
+    uk, inv = torch.unique_consecutive(skey, return_inverse=True)
+    w = torch.zeros(uk.numel(), dtype=torch.float32, device=ei.device).index_add_(0, inv, ew[order])
+    keep = torch.ones_like(uk, dtype=torch.bool)
+    if remove_self_loops:
+        keep &= (uk // k) != (uk % k)
+    keep &= w.abs() > 1e-8
+    uk, w = uk[keep], w[keep]
+    return torch.stack([uk // k, uk % k]), w
+
+
+@pytest.mark.parametrize("sorted_rows", [True, False])
+def test_coalesce_full_size_vs_torch_bitexact(dev, sorted_rows):
+    """C4 at full size (N = 1M, E = 10M, Graclus assignment from the native matcher, unit weights): every coalesce
+    route -- row-local (sorted input), grouped, general radix -- gives the edge_index and the (integer-valued) weights
+    of an independent torch restatement on the device, bit for bit."""
+    from tgp import kernels
+    from tgp.select import GraclusSelect
+    n = 1_000_000
+    g = torch.Generator(device=dev).manual_seed(0)
+    a = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    b = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+    if sorted_rows:
+        ei = ei[:, torch.argsort(ei[0] * n + ei[1])].contiguous()
+    ew = torch.ones(ei.size(1), device=dev)
+    so = GraclusSelect()(ei, ew, num_nodes=n)
+    cluster, k = so.cluster_index, so.num_supernodes
+    assert 400_000 < k < 700_000
+    want_ei, want_w = _torch_coalesce(ei, ew, cluster, k)
+    routes = ["rows", "grouped", "general"] if sorted_rows else ["grouped", "general"]
+    for route in routes:
+        got_ei, got_w = kernels.coalesce_edges(ei, ew, cluster, k, "sum", True, route=route)
+        assert torch.equal(got_ei, want_ei), route
+        assert torch.equal(got_w, want_w), route  # sums of ones: exact in fp32 whatever the order
+    # the public operator (whatever route it picks) as well
+    from tgp.connect import SparseConnect
+    oi, ow = SparseConnect()(ei, so, edge_weight=ew)
+    assert torch.equal(oi, want_ei) and torch.equal(ow, want_w)
+
+
+def test_subgraph_connect_full_size_vs_torch_bitexact(dev):
+    """TopK branch (connect/base_conn.py:79-82) at N = 1M, E = 10M, ratio 0.5: kept edges in INPUT order, relabelled
+    by position in the ascending node_index, weights passed through -- against torch boolean indexing on the device."""
+    from tgp.connect import SparseConnect
+    from tgp.select import SelectOutput
+    n = 1_000_000
+    g = torch.Generator(device=dev).manual_seed(1)
+    a = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    b = torch.randint(0, n, (5_000_000,), device=dev, generator=g)
+    ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])  # self loops and duplicates stay in
+    ew = torch.rand(ei.size(1), device=dev, generator=g)
+    ew[::13] = 0.0
+    kept = torch.sort(torch.randperm(n, device=dev, generator=g)[: n // 2])[0]
+    kk = kept.numel()
+    so = SelectOutput(node_index=kept, num_nodes=n, cluster_index=torch.arange(kk, device=dev), num_supernodes=kk)
+    for sort_rows in (False, True):
+        e = ei[:, torch.argsort(ei[0] * n + ei[1])].contiguous() if sort_rows else ei
+        w = ew
+        member = torch.zeros(n, dtype=torch.bool, device=dev)
+        member[kept] = True
+        relabel = torch.full((n,), -1, dtype=torch.long, device=dev)
+        relabel[kept] = torch.arange(kk, device=dev)
+        m = member[e[0]] & member[e[1]] & (e[0] != e[1]) & (w.abs() > 1e-8)
+        want_ei, want_w = relabel[e[:, m]], w[m]
+        got_ei, got_w = SparseConnect()(e, so, edge_weight=w)
+        assert torch.equal(got_ei, want_ei), sort_rows
+        assert torch.equal(got_w, want_w), sort_rows

@@ -97,6 +97,36 @@ __global__ __launch_bounds__(256) void cut_den_kernel(const float* __restrict__ 
 }
 
 
+// Per-graph tails of MinCut's two losses in ONE launch (utils/losses.py:39-56 and :59-70):
+//   cut[b]   = -trace(raw[b]) / (den[b] + eps)                    raw = S^T A S, den = trace(S^T D S)
+//   ortho[b] = || G_b / ||G_b||_F - I / sqrt(K) ||_F              G = S^T S
+// (as torch ops these are ~14 launches of a few hundred bytes each).  One workgroup per graph; out[0,b], out[1,b].
+__global__ __launch_bounds__(256) void mincut_tail_kernel(const float* __restrict__ raw, const float* __restrict__ den,
+                                                          const float* __restrict__ gram, int K, float eps,
+                                                          int B, float* __restrict__ out) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  const float* R = raw + static_cast<int64_t>(b) * K * K;
+  const float* G = gram + static_cast<int64_t>(b) * K * K;
+  float tr = 0.f, sq = 0.f;
+  for (int i = threadIdx.x; i < K; i += 256) tr += R[static_cast<int64_t>(i) * K + i];
+  for (int i = threadIdx.x; i < K * K; i += 256) sq = fmaf(G[i], G[i], sq);
+  tr = block_sum_256(tr, sh);
+  sq = block_sum_256(sq, sh);
+  const float n = sqrtf(sq);
+  const float t = 1.0f / sqrtf(static_cast<float>(K));
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < K * K; i += 256) {
+    const float y = G[i] / n - ((i / K == i % K) ? t : 0.f);
+    acc = fmaf(y, y, acc);
+  }
+  acc = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) {
+    out[b] = -(tr / (den[b] + eps));
+    out[B + b] = sqrtf(acc);
+  }
+}
+
 // ss[e] = <S[row_e,:], S[col_e,:]>: the per-edge entries of S S^T that the sparse (unbatched) losses need
 // (utils/losses.py:73-127 sparse_mincut_loss, :661-708 sparse_link_pred_loss compute (S[src] * S[dst]).sum(-1),
 // which materialises two [E,K] gathers and their product).  G lanes share an edge (float4 each when VEC),
@@ -195,6 +225,17 @@ extern "C" int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int6
                        static_cast<int>(K), graph_sizes, deg, q);
   hipLaunchKernelGGL(cut_den_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, deg, q, static_cast<int>(N), den);
   return check_launch("tgp_cut_terms_f32");
+}
+
+extern "C" int tgp_mincut_loss_terms_f32(const float* raw, const float* den, const float* gram, int64_t B, int64_t K,
+                                         float eps, float* out, void* stream_) {
+  TGP_REQUIRE(B >= 0 && K >= 1 && K < 32768, TGP_ERR_INVALID, "tgp_mincut_loss_terms_f32: bad shape");
+  if (B == 0) return TGP_OK;
+  TGP_REQUIRE(raw && den && gram && out, TGP_ERR_INVALID, "tgp_mincut_loss_terms_f32: null pointer");
+  TGP_REQUIRE(B < (1ll << 31), TGP_ERR_RANGE, "tgp_mincut_loss_terms_f32: too many graphs");
+  hipLaunchKernelGGL(mincut_tail_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), raw, den, gram, static_cast<int>(K), eps, static_cast<int>(B), out);
+  return check_launch("tgp_mincut_loss_terms_f32");
 }
 
 static int pair_dot(const int64_t* row, const int64_t* col, int64_t E, const float* S, const float* S2, int64_t K,

@@ -1,0 +1,323 @@
+// A13: MLPSelect's last layer as ONE pass over the node features.
+//
+//   S[m, :] = softmax(X[m, :] W^T + b) * mask[m]          reference select/mlp_select.py:139-145
+//
+// (single Linear(F, K) with bias when in_channels is an int, mlp_select.py:67).  The reference runs F.linear, a softmax
+// and a mask multiply: the [M, K] logits cross HBM three times and S twice.  Here every node row is read once and S is
+// written once: HBM-bound, algorithmic bytes M * 4 * (F + K) (+ M mask bytes, + K * (F + 1) * 4 of parameters).
+//
+// mlp_select_mfma_kernel: a wave owns 32 node rows and all K columns.  The product is taken TRANSPOSED on the fp32
+// matrix cores (v_mfma_f32_32x32x2_f32): A operand = a 32-column tile of W (LDS), B operand = X^T, so that in the C/D
+// layout (col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) a lane holds ONE node row's logits in its
+// registers -- 16 per 32-column tile, the other half of the row on lane ^ 32 -- and the softmax is register arithmetic
+// plus two cross-half exchanges per row (the natural orientation would need 16 rows x 5-step lane reductions).  The
+// order of k inside the dot product is free as long as both operands agree: half-wave h takes k = 32 c + 16 h + j
+// (chunk c, j = 0..15), so a lane's X operand is 64 contiguous bytes per chunk (four 16-byte loads, a node row's
+// 128-byte chunk shared by lanes l and l ^ 32) and its W operand four ds_read_b128 of a padded LDS row.
+// W stays in LDS for the life of the workgroup when it fits 64 KB; otherwise the workgroup's four waves walk F in
+// slices between barriers (W then comes from L2 once per 128 node rows).
+//
+// K > 256 (more than 8 accumulator tiles): the caller runs tgp_bmm_f32 and softmax_rows_kernel (in place).
+// tgp_softmax_bwd_f32: dY = S * (dS - <dS, S>) per row -- with S = softmax * mask this is the gradient w.r.t. the
+// logits for kept rows and 0 for masked rows (their S is 0).
+#include "common.h"
+
+namespace tgp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MS_WAVES = 4;
+constexpr int MS_LDS_BYTES = 64 * 1024;
+
+struct MlpSelArgs {
+  const float* x; const float* w; const float* bias; const unsigned char* mask;
+  float* s;
+  long M;
+  int F, K;
+  int fc;      // k's per LDS slice (multiple of 32); >= Fpad: W resident
+  int ldw;     // LDS row stride in floats (fc + 4)
+  long tiles;  // ceil(M / 32)
+};
+
+__device__ __forceinline__ float half_swap(float v) { return __shfl_xor(v, 32, 64); }
+
+// exp(x) for x <= 0 on v_exp_f32 with the rounding error of x * log2(e) carried along (the library expf keeps two
+// compare masks per call alive: 128 calls per lane spilled > 200 SGPRs).  Relative error ~2e-7; results below
+// 2^-126 come out as 0.
+__device__ __forceinline__ float exp_neg(float x) {
+  const float L = 1.44269504088896341f, Llo = 1.92596299112661746e-8f;
+  x = fmaxf(x, -104.f);  // 2^-150 = 0 in fp32; keeps -inf (padded columns) out of the error term (inf - inf)
+  const float y = x * L;
+  float r = fmaf(x, L, -y);
+  r = fmaf(x, Llo, r);
+  const float e = __builtin_amdgcn_exp2f(y);
+  return fmaf(e, r * 0.693147180559945309f, e);
+}
+
+template <int KT, bool VEC>
+__global__ __launch_bounds__(64 * MS_WAVES, KT > 6 ? 1 : 2) void mlp_select_mfma_kernel(MlpSelArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wl = smem;                       // [KT * 32][ldw]
+  float* bl = smem + KT * 32 * p.ldw;     // [KT * 32] bias; -inf beyond K: padded columns drop out of the softmax
+  const int lane = lane_id(), w = wave_id();
+  const int lm = lane & 31, h = lane >> 5;
+  const int F = p.F, K = p.K, fc = p.fc, ldw = p.ldw;
+  const int Fpad = (F + 31) & ~31;
+  const bool resident = fc >= Fpad;
+  const int nslices = resident ? 1 : (Fpad + fc - 1) / fc;
+
+  auto stage_w = [&](int k0) {  // W[:, k0 : k0 + fc] -> LDS, zero beyond K rows / F columns
+    const int width = fc < Fpad - k0 ? fc : Fpad - k0;
+    const int q4 = width >> 2;
+    for (int i = threadIdx.x; i < KT * 32 * q4; i += 64 * MS_WAVES) {
+      const int n = i / q4, q = i - n * q4;
+      const int k = k0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < K) {
+        const float* src = p.w + static_cast<long>(n) * F + k;
+        if (VEC && k + 3 < F) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (k < F) v.x = src[0];
+          if (k + 1 < F) v.y = src[1];
+          if (k + 2 < F) v.z = src[2];
+          if (k + 3 < F) v.w = src[3];
+        }
+      }
+      *reinterpret_cast<float4*>(Wl + n * ldw + 4 * q) = v;
+    }
+  };
+
+  for (int i = threadIdx.x; i < KT * 32; i += 64 * MS_WAVES) bl[i] = i < K ? (p.bias ? p.bias[i] : 0.f) : -INFINITY;
+  if (resident) stage_w(0);
+  __syncthreads();
+
+  // rounds: MS_WAVES consecutive row tiles per workgroup per round (all waves take part in the barriers of the
+  // sliced mode, so the loop bound is workgroup-uniform)
+  const long rounds = (p.tiles + MS_WAVES - 1) / MS_WAVES;
+  for (long r = blockIdx.x; r < rounds; r += gridDim.x) {
+    const long tile = r * MS_WAVES + w;
+    const long m = tile * 32 + lm;
+    const bool row_ok = m < p.M;
+    const float* xrow = p.x + (row_ok ? m : 0) * F;
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = bl[32 * t + (i & 3) + 8 * (i >> 2) + 4 * h];  // bias (-inf: padding)
+
+    for (int sl = 0; sl < nslices; ++sl) {
+      const int k0 = sl * fc;
+      if (!resident) {
+        __syncthreads();  // every wave is done with the previous slice
+        stage_w(k0);
+        __syncthreads();
+      }
+      const int width = fc < Fpad - k0 ? fc : Fpad - k0;
+      for (int c = 0; c < width; c += 32) {
+        // X operand: k = k0 + c + 16 h + j
+        float xb[16];
+        const int kb = k0 + c + 16 * h;
+        // unconditional loads from clamped addresses, zeroed afterwards (guards would put every load in a branch of
+        // its own): with F % 4 == 0 a 16-byte vector is wholly inside or wholly outside the row
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = kb + 4 * q;
+          float4 v;
+          if (VEC) {
+            v = *reinterpret_cast<const float4*>(xrow + (k < F ? k : F - 4));
+          } else {
+            v.x = xrow[k < F ? k : F - 1];
+            v.y = xrow[k + 1 < F ? k + 1 : F - 1];
+            v.z = xrow[k + 2 < F ? k + 2 : F - 1];
+            v.w = xrow[k + 3 < F ? k + 3 : F - 1];
+          }
+          const bool in = row_ok && k < F;
+          xb[4 * q] = in ? v.x : 0.f;
+          xb[4 * q + 1] = (VEC ? in : row_ok && k + 1 < F) ? v.y : 0.f;
+          xb[4 * q + 2] = (VEC ? in : row_ok && k + 2 < F) ? v.z : 0.f;
+          xb[4 * q + 3] = (VEC ? in : row_ok && k + 3 < F) ? v.w : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          const float* wr = Wl + (32 * t + lm) * ldw + c + 16 * h;
+          float wa[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(wr + 4 * q);
+            wa[4 * q] = v.x; wa[4 * q + 1] = v.y; wa[4 * q + 2] = v.z; wa[4 * q + 3] = v.w;
+          }
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xb[j], acc[t], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- softmax over the row held by lanes (lm, h = 0/1): column n = 32 t + (i & 3) + 8 (i >> 2) + 4 h
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        mx = fmaxf(mx, acc[t][i]);
+      }
+    mx = fmaxf(mx, half_swap(mx));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float e = exp_neg(acc[t][i] - mx);  // exp(-inf) = 0 on the padded columns
+        acc[t][i] = e;
+        sum += e;
+      }
+    sum += half_swap(sum);
+    const float keep = (p.mask && row_ok) ? static_cast<float>(p.mask[m] != 0) : 1.f;
+    if (row_ok) {
+      float* srow = p.s + m * K;
+      const float scale = keep / sum;  // one division per row (64 of them per lane spilled ~100 SGPRs of masks)
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        const bool full = VEC && 32 * t + 32 <= K;  // wave-uniform: whole tile inside the row
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = 32 * t + 8 * g + 4 * h;
+          float4 v;
+          v.x = acc[t][4 * g] * scale;
+          v.y = acc[t][4 * g + 1] * scale;
+          v.z = acc[t][4 * g + 2] * scale;
+          v.w = acc[t][4 * g + 3] * scale;
+          if (full) {
+            *reinterpret_cast<float4*>(srow + n) = v;
+          } else {
+            int rem = K - n;  // opaque to the optimiser: the 16 KT loop-invariant store masks would otherwise be
+            asm volatile("" : "+v"(rem));  // hoisted out of the row loop and spilled (92 SGPRs at KT = 4)
+            if (rem > 0) srow[n] = v.x;
+            if (rem > 1) srow[n + 1] = v.y;
+            if (rem > 2) srow[n + 2] = v.z;
+            if (rem > 3) srow[n + 3] = v.w;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // scale-and-store tile by tile (else all 16 KT products are formed first)
+      }
+    }
+  }
+}
+
+// One wave per row, any K: softmax(y + b) * mask in place (fallback behind tgp_bmm_f32 for K > 256).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                           const unsigned char* __restrict__ mask, long M, int K) {
+  const long m = static_cast<long>(blockIdx.x) * 4 + wave_id();
+  if (m >= M) return;
+  const int lane = lane_id();
+  float* row = y + m * K;
+  float mx = -INFINITY;
+  for (int k = lane; k < K; k += 64) mx = fmaxf(mx, row[k] + (bias ? bias[k] : 0.f));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int k = lane; k < K; k += 64) sum += expf(row[k] + (bias ? bias[k] : 0.f) - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float keep = mask ? static_cast<float>(mask[m] != 0) : 1.f;
+  for (int k = lane; k < K; k += 64) row[k] = expf(row[k] + (bias ? bias[k] : 0.f) - mx) / sum * keep;
+}
+
+// dY[m, :] = S[m, :] * (dS[m, :] - sum_k dS[m, k] S[m, k]); G lanes per row.
+template <int G>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ s, const float* __restrict__ ds,
+                                                          float* __restrict__ dy, long M, int K) {
+  const int sub = threadIdx.x % G;
+  const long m = static_cast<long>(blockIdx.x) * (256 / G) + threadIdx.x / G;
+  const bool ok = m < M;
+  const float* sr = s + (ok ? m : 0) * K;
+  const float* dr = ds + (ok ? m : 0) * K;
+  float dot = 0.f;
+  if (ok)
+    for (int k = sub; k < K; k += G) dot = fmaf(dr[k], sr[k], dot);
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+  if (ok) {
+    float* out = dy + m * K;
+    for (int k = sub; k < K; k += G) out[k] = sr[k] * (dr[k] - dot);
+  }
+}
+
+template <int KT>
+static int launch_mlp_select(const MlpSelArgs& a, bool vec, int grid, size_t lds, hipStream_t st) {
+  if (vec)
+    hipLaunchKernelGGL((mlp_select_mfma_kernel<KT, true>), dim3(grid), dim3(64 * MS_WAVES), lds, st, a);
+  else
+    hipLaunchKernelGGL((mlp_select_mfma_kernel<KT, false>), dim3(grid), dim3(64 * MS_WAVES), lds, st, a);
+  return check_launch("mlp_select_mfma_kernel");
+}
+
+}  // namespace tgp
+
+using namespace tgp;
+
+extern "C" int tgp_mlp_select_max_fused_k(void) { return 256; }
+
+extern "C" int tgp_mlp_select_f32(const float* x, const float* weight, const float* bias, const unsigned char* mask,
+                                  int64_t M, int64_t F, int64_t K, float* s_out, void* stream) {
+  TGP_REQUIRE(M >= 0 && F >= 1 && K >= 1, TGP_ERR_INVALID, "tgp_mlp_select_f32: bad shape M=%lld F=%lld K=%lld",
+              (long long)M, (long long)F, (long long)K);
+  TGP_REQUIRE(K <= 256, TGP_ERR_INVALID, "tgp_mlp_select_f32: K=%lld > 256: use tgp_bmm_f32 + tgp_softmax_rows_f32",
+              (long long)K);
+  TGP_REQUIRE(F < (1 << 24), TGP_ERR_RANGE, "tgp_mlp_select_f32: F too large");
+  if (M == 0) return TGP_OK;
+  TGP_REQUIRE(x && weight && s_out, TGP_ERR_INVALID, "tgp_mlp_select_f32: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int KT = static_cast<int>((K + 31) / 32);
+  const int Fpad = static_cast<int>((F + 31) & ~31ll);
+  // slice width: the largest multiple of 32 whose [KT*32][fc+4] image (+ bias) fits MS_LDS_BYTES
+  const int budget = (MS_LDS_BYTES - KT * 32 * 4) / (KT * 32 * 4) - 4;
+  int fc = budget / 32 * 32;
+  if (fc >= Fpad) fc = Fpad;
+  TGP_REQUIRE(fc >= 32, TGP_ERR_INVALID, "tgp_mlp_select_f32: LDS budget");
+  MlpSelArgs a;
+  a.x = x; a.w = weight; a.bias = bias; a.mask = mask; a.s = s_out;
+  a.M = M; a.F = static_cast<int>(F); a.K = static_cast<int>(K);
+  a.fc = fc; a.ldw = fc + 4;
+  a.tiles = (M + 31) / 32;
+  const size_t lds = static_cast<size_t>(KT) * 32 * (a.ldw + 1) * sizeof(float);
+  const long rounds = (a.tiles + MS_WAVES - 1) / MS_WAVES;
+  const int cus = tgp_device_cu_count();
+  long grid = static_cast<long>(cus > 0 ? cus : 256) * (KT <= 2 ? 4 : KT <= 6 ? 2 : 1);  // workgroups resident per CU (registers)
+  if (grid > rounds) grid = rounds;
+  const bool vec = (F % 4 == 0) && (K % 4 == 0) && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(weight) % 16 == 0 && reinterpret_cast<uintptr_t>(s_out) % 16 == 0;
+  switch (KT) {
+    case 1: return launch_mlp_select<1>(a, vec, (int)grid, lds, st);
+    case 2: return launch_mlp_select<2>(a, vec, (int)grid, lds, st);
+    case 3: return launch_mlp_select<3>(a, vec, (int)grid, lds, st);
+    case 4: return launch_mlp_select<4>(a, vec, (int)grid, lds, st);
+    case 5: return launch_mlp_select<5>(a, vec, (int)grid, lds, st);
+    case 6: return launch_mlp_select<6>(a, vec, (int)grid, lds, st);
+    case 7: return launch_mlp_select<7>(a, vec, (int)grid, lds, st);
+    default: return launch_mlp_select<8>(a, vec, (int)grid, lds, st);
+  }
+}
+
+extern "C" int tgp_softmax_rows_f32(float* y, const float* bias, const unsigned char* mask, int64_t M, int64_t K,
+                                    void* stream) {
+  TGP_REQUIRE(M >= 0 && K >= 1 && K < (1ll << 31), TGP_ERR_INVALID, "tgp_softmax_rows_f32: bad shape");
+  if (M == 0) return TGP_OK;
+  TGP_REQUIRE(y, TGP_ERR_INVALID, "tgp_softmax_rows_f32: null pointer");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), y, bias,
+                     mask, static_cast<long>(M), static_cast<int>(K));
+  return check_launch("softmax_rows_kernel");
+}
+
+extern "C" int tgp_softmax_bwd_f32(const float* s, const float* ds, float* dy, int64_t M, int64_t K, void* stream) {
+  TGP_REQUIRE(M >= 0 && K >= 1 && K < (1ll << 31), TGP_ERR_INVALID, "tgp_softmax_bwd_f32: bad shape");
+  if (M == 0) return TGP_OK;
+  TGP_REQUIRE(s && ds && dy, TGP_ERR_INVALID, "tgp_softmax_bwd_f32: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (K <= 32)
+    hipLaunchKernelGGL((softmax_bwd_kernel<16>), dim3(cdiv(M, 16)), dim3(256), 0, st, s, ds, dy, (long)M, (int)K);
+  else
+    hipLaunchKernelGGL((softmax_bwd_kernel<64>), dim3(cdiv(M, 4)), dim3(256), 0, st, s, ds, dy, (long)M, (int)K);
+  return check_launch("softmax_bwd_kernel");
+}

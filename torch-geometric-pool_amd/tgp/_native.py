@@ -90,6 +90,7 @@ SIGNATURES = {
     "tgp_entropy_sum_workspace_bytes": (_c_sz, [_c_i64]),
     "tgp_entropy_sum_f32": (_c_int, [_c_p, _c_i64, _c_f, _c_p, _c_p, _c_sz, _c_p]),
     "tgp_cut_terms_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "tgp_mincut_loss_terms_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_f, _c_p, _c_p]),
     "tgp_rowptr_from_sorted_i64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_spmm_csr_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
     "tgp_to_dense_adj_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p]),
@@ -108,6 +109,10 @@ SIGNATURES = {
     "tgp_kron_batched_count": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p,
                                         _c_i64, ctypes.c_double, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_kron_batched_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p]),
+    "tgp_mlp_select_max_fused_k": (_c_int, []),
+    "tgp_mlp_select_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
+    "tgp_softmax_rows_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p]),
+    "tgp_softmax_bwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p]),
     "tgp_debug_sort_workspace_bytes": (_c_sz, [_c_i64]),
     "tgp_debug_sort_pairs_u64": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_sz, _c_p]),
 }

@@ -163,7 +163,13 @@ class PackedGather:
         self._fill = 0
 
     def start(self, tensors: Sequence[Tensor]) -> None:
-        self._ensure([t.shape for t in tensors], tensors[0].dtype, tensors[0].device)
+        shapes = [tuple(int(d) for d in t.shape) for t in tensors]
+        buf = self._send[self._cur]
+        # a layout that slots() set up keeps its dtype (the kernels' fp32): outputs cast back to a caller's half /
+        # double dtype are converted by the pack copy instead of re-allocating the send buffers every step
+        dtype = buf.dtype if (buf is not None and self._shapes == shapes and buf.device == tensors[0].device) \
+            else tensors[0].dtype
+        self._ensure(shapes, dtype, tensors[0].device)
         for dst, t in zip(self._views(self._send[self._cur], self._fill), tensors):
             if t.data_ptr() != dst.data_ptr() or not t.is_contiguous():
                 dst.copy_(t)  # not produced in place: pack
@@ -218,11 +224,15 @@ def all_gather_dense(tensors: Sequence[Tensor], group=None) -> List[Tensor]:
 
 
 def all_gather_sparse(x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor,
-                      num_graphs_local: int, group=None):
+                      num_graphs_local: int, group=None, force_collective: bool = False):
     """Gather variable-size pooled graphs: counts first, then max-padded payloads, then shift the
-    pooled node ids / graph ids of rank r by the totals of ranks < r."""
+    pooled node ids / graph ids of rank r by the totals of ranks < r.  ``force_collective`` (or
+    ``TGP_FORCE_COLLECTIVE``): a one-rank process group still runs the collectives (single-GPU exercise of the
+    variable-size RCCL path)."""
     world = _world(group)
-    if world == 1:
+    forced = (dist.is_available() and dist.is_initialized()
+              and (force_collective or bool(os.environ.get("TGP_FORCE_COLLECTIVE"))))
+    if world == 1 and not forced:
         return x, edge_index, edge_weight, batch
     dev = x.device
     mine = torch.tensor([x.size(0), edge_index.size(1), num_graphs_local], dtype=torch.long, device=dev)

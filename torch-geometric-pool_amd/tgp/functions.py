@@ -446,6 +446,39 @@ def _tall_skinny_tn(a: Tensor, b: Tensor) -> Tensor:
     return K.segment_gemm_tn(a, b, _whole_range(n, a.device), n)[0]
 
 
+class _MlpSelectFn(torch.autograd.Function):
+    """S = softmax(X W^T + b) * mask (select/mlp_select.py:139-145) in one native pass; backward: dY = S (dS - <dS,S>)
+    (one kernel), dX = dY W (fp32-MFMA GEMM), dW = dY^T X (node-range-split product), db = column sums of dY."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mask):
+        s = K.mlp_select(x, weight, bias, mask)
+        ctx.save_for_backward(x, weight, s)
+        ctx.has_bias = bias is not None
+        return s
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, s = ctx.saved_tensors
+        dy = K.softmax_bwd(s, g)
+        dy2 = dy.reshape(-1, dy.size(-1))
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = K.bmm(dy2, weight).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            gw = _tall_skinny_tn(dy2, x.reshape(-1, x.size(-1)))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = dy2.sum(0)
+        return gx, gw, gb, None
+
+
+def mlp_select(x: Tensor, weight: Tensor, bias: Optional[Tensor], mask: Optional[Tensor]) -> Tensor:
+    """Last layer of MLPSelect: softmax(linear(x)) * mask, one kernel."""
+    if _needs_grad(x, weight, bias):
+        return _MlpSelectFn.apply(x, weight, bias, mask)
+    return K.mlp_select(x, weight, bias, mask)
+
+
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
     if x.is_cuda and x.dtype == torch.float32 and _needs_grad(x, weight, bias):
         return _LinearFn.apply(x, weight, bias)

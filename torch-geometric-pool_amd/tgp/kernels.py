@@ -155,12 +155,16 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
 
 def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_index: Tensor,
                    num_supernodes: int, reduce_op: str, remove_self_loops: bool,
-                   eps_filter: bool = True, assign_index: Optional[AssignIndex] = None) -> Tuple[Tensor, Optional[Tensor]]:
+                   eps_filter: bool = True, assign_index: Optional[AssignIndex] = None,
+                   route: Optional[str] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """cluster_index[edge_index] + PyG coalesce (connect/base_conn.py:86-89) fused with
     remove_self_loops and the |w| > eps filter (utils/ops.py:370-380).
 
     With the supernode->member index of the assignment at hand (``assign_index``) the sort-free row-local
-    path is tried first; it declines (count = -1) for unsorted rows or very long supernode rows."""
+    path is tried first; it declines (count = -1) for unsorted rows or very long supernode rows.
+    ``route`` ("rows" / "grouped" / "general"; tests): take exactly that route, raise if it declines."""
+    if route not in (None, "rows", "grouped", "general"):
+        raise ValueError(f"unknown route {route!r}")
     if reduce_op not in N.REDUCE_OPS:
         raise ValueError(f"unknown reduce_op '{reduce_op}', expected one of {sorted(N.REDUCE_OPS)}")
     dev = N.require_device(edge_index, edge_weight, cluster_index)
@@ -171,8 +175,11 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if (w is not None and eps_filter) else 0)
     L = N.lib()
     eps = ops_eps()
-    if (assign_index is not None and assign_index.nnz == cl.numel() and assign_index.num_targets == num_supernodes
-            and num_supernodes < (1 << 26) and _rows_sorted_memo(edge_index) is not False):
+    if route == "rows" and assign_index is None:
+        assign_index = build_assign_index(cl, num_supernodes)
+    if (route in (None, "rows") and assign_index is not None and assign_index.nnz == cl.numel()
+            and assign_index.num_targets == num_supernodes
+            and num_supernodes < (1 << 26) and (route == "rows" or _rows_sorted_memo(edge_index) is not False)):
         ws = N.workspace(L.tgp_connect_coalesce_rows_workspace_bytes(E, cl.numel(), num_supernodes), dev)
         d_count = torch.empty(1, dtype=torch.int64, device=dev)
         st = N.stream_ptr(dev)
@@ -190,11 +197,15 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
                     "tgp_connect_coalesce_rows_fill")
             return out_ei, out_w
         del ws  # declined: fall through to the sort-based path
+        if route == "rows":
+            raise RuntimeError("row-local coalesce route declined (unsorted rows or a supernode row too long)")
         if E > 1 and _rows_sorted_memo(edge_index) is None:
             # remember WHY for this tensor object (one comparison pass, once): an unsorted list skips the row-local
             # attempt (~50 us + a host round trip) on every later call
             _rows_sorted(edge_index, row)
-    if 65536 < num_supernodes < (1 << 26):
+    if route == "rows":
+        raise RuntimeError("row-local coalesce route not applicable")
+    if route == "grouped" or (route is None and 65536 < num_supernodes < (1 << 26)):
         # more than 32 bits of (row, col) key: sort by supernode row only (half the radix passes) and order the short
         # rows in LDS; declines (count = -1) when a supernode row is too long for that
         ws = N.workspace(L.tgp_connect_coalesce_grouped_workspace_bytes(E, cl.numel(), num_supernodes), dev)
@@ -213,6 +224,8 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
                     "tgp_connect_coalesce_rows_fill")
             return out_ei, out_w
         del ws
+        if route == "grouped":
+            raise RuntimeError("grouped coalesce route declined (a supernode row too long for the in-LDS sort)")
     ws = N.workspace(L.tgp_connect_coalesce_workspace_bytes(E, cl.numel(), num_supernodes), dev)
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
     st = N.stream_ptr(dev)
@@ -374,6 +387,17 @@ def cut_terms(adj: Tensor, s: Tensor, graph_sizes: Optional[Tensor] = None) -> T
     N.check(N.lib().tgp_cut_terms_f32(N.ptr(adj), N.ptr(s), B, Nn, K, N.ptr(_sizes_arg(graph_sizes, B, dev)), N.ptr(deg),
                                       N.ptr(q), N.ptr(den), N.stream_ptr(dev)), "tgp_cut_terms_f32")
     return deg, q, den
+
+
+def mincut_loss_terms(raw: Tensor, den: Tensor, gram: Tensor) -> Tensor:
+    """[2,B]: per-graph -trace(raw)/(den + eps) and ||G/||G|| - I/sqrt(K)||_F (utils/losses.py:39-70), one launch."""
+    dev = N.require_device(raw, den, gram)
+    raw, den, gram = N.f32c(raw), N.f32c(den), N.f32c(gram)
+    B, Kc = raw.size(0), raw.size(-1)
+    out = torch.empty(2, B, dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_mincut_loss_terms_f32(N.ptr(raw), N.ptr(den), N.ptr(gram), B, Kc, losses_eps(), N.ptr(out),
+                                              N.stream_ptr(dev)), "tgp_mincut_loss_terms_f32")
+    return out
 
 
 def topk_plan(sizes: Tensor, ratio: float) -> Tuple[Tensor, Tensor]:
@@ -552,6 +576,47 @@ def bmm(a: Tensor, b: Tensor, trans_a: bool = False) -> Tensor:
     N.check(N.lib().tgp_bmm_f32(N.ptr(a3), N.ptr(b3), N.ptr(out), G, M, Nc, Kd, 1 if trans_a else 0, a3.stride(1),
                                 b3.stride(1), Nc, sA, sB, M * Nc, N.stream_ptr(dev)), "tgp_bmm_f32")
     return out if (a.dim() == 3 or b.dim() == 3) else out[0]
+
+
+# ------------------------------------------------------------------------- A13
+def mlp_select(x: Tensor, weight: Tensor, bias: Optional[Tensor], mask: Optional[Tensor]) -> Tensor:
+    """S = softmax(x W^T + b) * mask[..., None] (select/mlp_select.py:139-145, single Linear: :67) in one pass over
+    x.  x [..., F], weight [K, F], bias [K] or None, mask broadcastable to x.shape[:-1] (bool) or None."""
+    dev = N.require_device(x, weight)
+    lead = x.shape[:-1]
+    x2 = N.f32c(x).reshape(-1, x.size(-1))
+    w, b = N.f32c(weight), (None if bias is None else N.f32c(bias))
+    M, F, Kc = x2.size(0), x2.size(1), w.size(0)
+    if w.size(1) != F:
+        raise ValueError(f"mlp_select: weight {tuple(weight.shape)} does not match features {F}")
+    m8 = None
+    if mask is not None:
+        m8 = mask.reshape(-1)
+        if m8.numel() != M:
+            raise ValueError(f"mlp_select: mask {tuple(mask.shape)} does not match x {tuple(x.shape)}")
+        if m8.dtype != torch.bool and m8.dtype != torch.uint8:
+            m8 = m8 != 0
+        m8 = m8.contiguous().view(torch.uint8)
+    L = N.lib()
+    st = N.stream_ptr(dev)
+    if Kc <= L.tgp_mlp_select_max_fused_k():
+        out = torch.empty(M, Kc, dtype=torch.float32, device=dev)
+        N.check(L.tgp_mlp_select_f32(N.ptr(x2), N.ptr(w), N.ptr(b), N.ptr(m8), M, F, Kc, N.ptr(out), st),
+                "tgp_mlp_select_f32")
+    else:  # wider than eight accumulator tiles: tiled GEMM for the logits, then bias + softmax + mask in place
+        out = bmm(x2, w.t().contiguous())
+        N.check(L.tgp_softmax_rows_f32(N.ptr(out), N.ptr(b), N.ptr(m8), M, Kc, st), "tgp_softmax_rows_f32")
+    return out.view(*lead, Kc)
+
+
+def softmax_bwd(s: Tensor, ds: Tensor) -> Tensor:
+    """dY = S * (dS - <dS, S>_row): gradient of S = softmax(Y) * mask w.r.t. Y (masked rows have S = 0)."""
+    dev = N.require_device(s, ds)
+    s2, d2 = N.f32c(s).reshape(-1, s.size(-1)), N.f32c(ds).reshape(-1, s.size(-1))
+    out = torch.empty_like(s2)
+    N.check(N.lib().tgp_softmax_bwd_f32(N.ptr(s2), N.ptr(d2), N.ptr(out), s2.size(0), s2.size(1),
+                                        N.stream_ptr(dev)), "tgp_softmax_bwd_f32")
+    return out.view(s.shape)
 
 
 def segment_gemm_tn(s: Tensor, y: Tensor, ptr: Tensor, max_nodes: int) -> Tensor:

@@ -518,14 +518,18 @@ class MLP(torch.nn.Module):
         for lin in self.lins:
             lin.reset_parameters()
 
-    def forward(self, x: Tensor) -> Tensor:
-        for i, lin in enumerate(self.lins):
+    def hidden(self, x: Tensor) -> Tensor:
+        """Every layer but the last (with activation and dropout); the identity for a single Linear."""
+        for lin in self.lins[:-1]:
             x = Fn.linear(x, lin.weight, lin.bias)
-            if i + 1 < len(self.lins):
-                if self.act is not None:
-                    x = self.act(x)
-                x = torch.nn.functional.dropout(x, p=self.dropout, training=self.training)
+            if self.act is not None:
+                x = self.act(x)
+            x = torch.nn.functional.dropout(x, p=self.dropout, training=self.training)
         return x
+
+    def forward(self, x: Tensor) -> Tensor:
+        last = self.lins[-1]
+        return Fn.linear(self.hidden(x), last.weight, last.bias)
 
 
 class MLPSelect(Select):
@@ -551,10 +555,19 @@ class MLPSelect(Select):
             x = x.unsqueeze(0) if x.dim() == 2 else x
         else:
             assert x.dim() == 2, "x must be of shape [N, F] for unbatched mode"
-        s = torch.softmax(self.mlp(x), dim=-1)
+        use_mask = mask if self.batched_representation else None
+        if x.is_cuda and x.dtype in (torch.float32, torch.float16, torch.bfloat16):
+            # last Linear + softmax + mask in ONE native pass over the features (tgp_mlp_select_f32); hidden layers
+            # of a multi-layer selector (with activations) stay separate launches
+            last = self.mlp.lins[-1]
+            s = Fn.mlp_select(self.mlp.hidden(x), last.weight, last.bias, use_mask)
+            if s.dtype != x.dtype:
+                s = s.to(x.dtype)
+        else:  # host tensors (data preparation) and float64 callers: torch ops, like the reference
+            s = torch.softmax(self.mlp(x), dim=-1)
+            if use_mask is not None:
+                s = s * use_mask.unsqueeze(-1)
         if self.batched_representation:
-            if mask is not None:
-                s = s * mask.unsqueeze(-1)
             return SelectOutput(s=s, s_inv_op=self.s_inv_op, in_mask=mask)
         return SelectOutput(s=s, s_inv_op=self.s_inv_op, batch=batch)
 

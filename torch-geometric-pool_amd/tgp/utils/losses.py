@@ -112,6 +112,14 @@ def mincut_loss(adj: Tensor, S: Tensor, adj_pooled: Tensor, batch_reduction: str
     return _reduce(-(num / (den + eps)), batch_reduction)
 
 
+def mincut_loss_terms(adj: Tensor, S: Tensor, adj_pooled: Tensor, graph_sizes: Optional[Tensor] = None) -> Tensor:
+    """[2,B] per-graph values of :func:`mincut_loss` and :func:`orthogonality_loss` (before the batch reduction) for
+    a device batch outside autograd: den and S^T S from their kernels, both tails in ONE launch."""
+    _, _, den = K.cut_terms(adj, S, graph_sizes)
+    gram = K.dense_pool(S, None, S, graph_sizes=graph_sizes)[0]
+    return K.mincut_loss_terms(adj_pooled, den, gram)
+
+
 class _OrthoFromGramFn(torch.autograd.Function):
     """l = || G / ||G||_F - I / sqrt(K) ||_F per graph (losses.py:59-70) with its closed-form gradient
     dl/dG = (Y - <Y, G> G / n^2) / (n l),  Y = G / n - I / sqrt(K),  n = ||G||_F."""

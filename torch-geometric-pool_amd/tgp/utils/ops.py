@@ -124,8 +124,20 @@ def max_graph_size(batch: Tensor) -> int:
     return batch_info(batch).max_nodes
 
 
+_pooled_batch_memo: dict = {}
+
+
 def build_pooled_batch(batch_size: int, num_supernodes: int, device, dtype: torch.dtype = torch.long) -> Tensor:
-    return torch.arange(batch_size, dtype=dtype, device=device).repeat_interleave(num_supernodes)
+    """arange(B).repeat_interleave(K) (reference utils/ops.py:152-169).  A pure function of (B, K): the last few
+    results are kept and handed out as a fresh copy (one launch instead of three per pooler call)."""
+    key = (int(batch_size), int(num_supernodes), torch.device(device), dtype)
+    hit = _pooled_batch_memo.get(key)
+    if hit is None:
+        if len(_pooled_batch_memo) >= 8:
+            _pooled_batch_memo.clear()
+        hit = torch.arange(batch_size, dtype=dtype, device=device).repeat_interleave(num_supernodes)
+        _pooled_batch_memo[key] = hit
+    return hit.clone()
 
 
 def graph_ptr(batch: Tensor, batch_size: Optional[int] = None) -> Tuple[Tensor, Tensor]:
