@@ -134,11 +134,34 @@ size_t tgp_connect_coalesce_rows_workspace_bytes(int64_t num_edges, int64_t num_
 int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
                                     int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,
                                     int64_t num_supernodes, const int32_t* assign_row_ptr,
-                                    const int32_t* assign_perm, int reduce_op, int flags, float eps, void* ws,
+                                    const int32_t* assign_perm,
+                                    const int32_t* csr_ptr /* NULL, or CSR offsets [N+1] of this row-sorted list */,
+                                    int reduce_op, int flags, float eps, void* ws,
                                     size_t ws_bytes, int64_t* d_count, void* stream);
 int tgp_connect_coalesce_rows_fill(const void* ws, int64_t num_edges, int64_t num_nodes, int64_t num_supernodes,
                                    int has_weight, int64_t num_out, int64_t* out_row, int64_t* out_col,
                                    float* out_weight, void* stream);
+
+/* A4 + A6, row-sorted input, as ONE heavy kernel + a widening fill (r3).  Every workgroup derives its rows' member
+ * edge ranges, LDS slots and survivor counts locally; the survivors in front of it come from a decoupled look-back, so
+ * weights are written once, at their final place, into `out_weight_cap` (capacity num_edges: the first *d_count
+ * entries are the result), and tgp_connect_coalesce_fused_fill only widens the columns and generates the rows.
+ * Optional CSR of the SAME edge list (csr_ptr [N+1], csr_col [E], int32; e.g. the one GraclusSelect builds of a
+ * symmetric input): the pass over `row` (CSR offsets + sortedness check) is skipped and 4-byte columns are streamed;
+ * row / col may then be NULL.  *d_count: >= 0 the output size; -1 declined (unsorted rows, a supernode row of more
+ * than 1024 raw entries, ...: use the radix routes); -3 declined by this kernel's tile limit only (more than 256
+ * members in a tile of rows): tgp_connect_coalesce_rows_{count,fill} takes the call.  Output identical to the other
+ * coalesce routes. */
+size_t tgp_connect_coalesce_fused_workspace_bytes(int64_t num_edges, int64_t num_nodes, int64_t num_supernodes);
+int tgp_connect_coalesce_fused_count(const int64_t* row, const int64_t* col, const int32_t* csr_ptr /* NULL ok */,
+                                     const int32_t* csr_col /* NULL ok */, const float* edge_weight /* NULL ok */,
+                                     int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,
+                                     int64_t num_supernodes, const int32_t* assign_row_ptr,
+                                     const int32_t* assign_perm, int reduce_op, int flags, float eps,
+                                     float* out_weight_cap /* [num_edges] when weighted */, void* ws, size_t ws_bytes,
+                                     int64_t* d_count, void* stream);
+int tgp_connect_coalesce_fused_fill(const void* ws, int64_t num_edges, int64_t num_nodes, int64_t num_supernodes,
+                                    int64_t num_out, int64_t* out_row, int64_t* out_col, void* stream);
 
 /* A4 for edge lists in ANY order, two-level: a stable radix sort by supernode row only (log2 K bits instead of the
  * 2 log2 K bits of the (row, col) key above) carrying (cluster column, weight) as payload, then the same in-row

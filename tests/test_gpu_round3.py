@@ -46,16 +46,21 @@ def test_mlp_select_kernel_vs_oracle(dev, lead, F, K, with_mask):
 
 
 def test_mlp_select_large_logits_and_misaligned_views(dev):
-    """Logits of +-80 (softmax saturates: the max-subtraction must hold), and x / weight handed over as
-    non-contiguous views (made contiguous at the boundary)."""
+    """Logits of several hundred (softmax saturates: the max-subtraction must hold; one fp32 ulp of such a logit is
+    3e-5, which is the relative accuracy ANY fp32 evaluation of the softmax can have -- the oracle is evaluated in
+    float64 and the bound is 2e-4), and x / weight handed over as non-contiguous views (made contiguous at the
+    boundary)."""
     import tgp_oracle as O
     from tgp import kernels as Kn
     g = torch.Generator().manual_seed(3)
     x = torch.randn(200, 40, generator=g) * 20
     w = torch.randn(24, 40, generator=g)
     b = torch.randn(24, generator=g) * 5
-    torch.testing.assert_close(Kn.mlp_select(x.to(dev), w.to(dev), b.to(dev), None).cpu(),
-                               O.mlp_select(x, [w], [b]), rtol=1e-5, atol=1e-5)
+    want = O.mlp_select(x.double(), [w.double()], [b.double()]).float()
+    got = Kn.mlp_select(x.to(dev), w.to(dev), b.to(dev), None).cpu()
+    assert bool(torch.isfinite(got).all())
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=1e-6)
+    torch.testing.assert_close(got.sum(-1), torch.ones(200), rtol=1e-5, atol=1e-5)
     xb = torch.randn(200, 80, generator=g)
     wb = torch.randn(24, 80, generator=g)
     got = Kn.mlp_select(xb.to(dev)[:, ::2], wb.to(dev)[:, 1::2], None, None).cpu()
@@ -98,12 +103,15 @@ def test_mlp_select_module_uses_the_native_kernel(dev, monkeypatch):
     monkeypatch.setattr(torch, "softmax", lambda *a, **k: (calls.append("softmax"), real_softmax(*a, **k))[1])
     so = sel(x=x.to(dev), mask=mask.to(dev))
     assert calls == []
+    monkeypatch.setattr(torch, "softmax", real_softmax)  # (the oracle below uses it)
     lin = sel.mlp.lins[0]
     want = O.mlp_select(x, [lin.weight.detach().cpu()], [lin.bias.detach().cpu()], mask)
     torch.testing.assert_close(so.s.cpu(), want, rtol=1e-5, atol=1e-5)
     sel2 = MLPSelect(in_channels=[12, 16], k=6, act="relu").to(dev)
+    monkeypatch.setattr(torch, "softmax", lambda *a, **k: (calls.append("softmax"), real_softmax(*a, **k))[1])
     so2 = sel2(x=x.to(dev), mask=mask.to(dev))
     assert calls == []
+    monkeypatch.setattr(torch, "softmax", real_softmax)
     ws = [l.weight.detach().cpu() for l in sel2.mlp.lins]
     bs = [l.bias.detach().cpu() for l in sel2.mlp.lins]
     torch.testing.assert_close(so2.s.cpu(), O.mlp_select(x, ws, bs, mask, act="relu"), rtol=1e-5, atol=1e-5)
@@ -170,3 +178,127 @@ def test_all_gather_sparse_over_rccl_one_rank_group(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------ fused coalesce route (r3)
+def _coalesce_case(case):
+    import random
+    rng = random.Random(case)
+    g = torch.Generator().manual_seed(case)
+    n = rng.choice([3, 50, 700, 5_000, 40_000, 200_000])
+    e = rng.choice([0, 1, 7, n, 4 * n, 12 * n, 40 * n if n <= 5_000 else 6 * n])
+    shape = rng.choice(["pairs", "pairs", "random", "few_big", "many_empty", "triples"])
+    if shape == "pairs":
+        k = max(1, n // 2)
+        cluster = (torch.randperm(n, generator=g) // 2).clamp(max=k - 1)
+    elif shape == "triples":
+        k = max(1, n // 3)
+        cluster = (torch.randperm(n, generator=g) // 3).clamp(max=k - 1)
+    elif shape == "random":
+        k = max(1, rng.choice([n // 3, n // 10, n]))
+        cluster = torch.randint(0, k, (n,), generator=g)
+    elif shape == "few_big":
+        k = max(1, min(n, rng.choice([2, 5, 40, 300])))
+        cluster = torch.randint(0, k, (n,), generator=g)
+    else:
+        k = 2 * n + 5
+        cluster = torch.randint(0, max(1, n // 4), (n,), generator=g) * 3
+    ei = torch.randint(0, n, (2, e), generator=g)
+    if e > 0 and rng.random() < 0.2:  # a hub node: one long supernode row
+        ei[0, : e // 3] = int(torch.randint(0, n, (1,), generator=g))
+    sorted_rows = rng.random() < 0.8 and e > 0
+    if sorted_rows:
+        ei = ei[:, torch.argsort(ei[0], stable=True)]
+    ew = (torch.rand(e, generator=g) - 0.3) if rng.random() < 0.7 else None
+    if ew is not None and e:
+        ew[torch.rand(e, generator=g) < 0.1] = 0.0
+    op = rng.choice(["sum", "sum", "mean", "min", "max", "mul"])
+    return n, k, cluster, ei, ew, op, rng.random() < 0.5, sorted_rows
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_fused_coalesce_route_equals_the_other_routes(dev, block):
+    """The one-kernel row-local route (decoupled look-back, survivors at final offsets, long rows in-kernel) against
+    the general radix route bit for bit -- edge_index AND weights (same reduction order) -- over random shapes: pair /
+    triple / random / few-big / sparse-id clusterings, hub rows, unsorted lists (must decline), all reduce ops."""
+    from tgp import kernels
+    took = 0
+    for case in range(block * 25, block * 25 + 25):
+        n, k, cluster, ei, ew, op, rsl, sorted_rows = _coalesce_case(case)
+        cl, eid, ewd = cluster.to(dev), ei.to(dev), None if ew is None else ew.to(dev)
+        ref = kernels.coalesce_edges(eid, ewd, cl, k, op, rsl, route="general")
+        try:
+            got = kernels.coalesce_edges(eid, ewd, cl, k, op, rsl, route="fused")
+        except RuntimeError as exc:
+            assert "declined" in str(exc)
+            continue
+        took += 1
+        assert sorted_rows or ei.size(1) <= 1 or bool((ei[0, 1:] >= ei[0, :-1]).all()), case
+        assert torch.equal(got[0], ref[0]), case
+        assert (got[1] is None and ref[1] is None) or torch.equal(got[1], ref[1]), case
+        auto = kernels.coalesce_edges(eid, ewd, cl, k, op, rsl, assign_index=kernels.build_assign_index(cl, k))
+        assert torch.equal(auto[0], ref[0]) and ((auto[1] is None) or torch.equal(auto[1], ref[1])), case
+    assert took >= 5
+
+
+def test_fused_coalesce_long_rows_and_many_tiles(dev):
+    """Hub supernodes (rows of 65..1024 raw entries sorted by the whole workgroup), multi-pass tiles (32 rows of more
+    than 1024 entries together) and a tile count far beyond the look-back window (64)."""
+    from tgp import kernels
+    g = torch.Generator().manual_seed(11)
+    n = 60_000   # 30 000 supernode rows = 938 tiles: the most one launch takes (FZ_MAX_TILES = 1024)
+    k = n // 2
+    cluster = torch.randperm(n, generator=g) // 2
+    deg = torch.randint(1, 40, (n,), generator=g)
+    deg[torch.randint(0, n, (300,), generator=g)] = 400      # hubs: long rows
+    row = torch.repeat_interleave(torch.arange(n), deg)
+    col = torch.randint(0, n, (row.numel(),), generator=g)
+    ei = torch.stack([row, col])
+    ew = torch.rand(row.numel(), generator=g) + 0.1
+    cl, eid, ewd = cluster.to(dev), ei.to(dev), ew.to(dev)
+    ref = kernels.coalesce_edges(eid, ewd, cl, k, "sum", True, route="general")
+    got = kernels.coalesce_edges(eid, ewd, cl, k, "sum", True, route="fused")
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    got = kernels.coalesce_edges(eid, None, cl, k, "sum", False, route="fused")
+    ref = kernels.coalesce_edges(eid, None, cl, k, "sum", False, route="general")
+    assert torch.equal(got[0], ref[0]) and got[1] is None
+
+
+def test_graclus_select_hands_its_csr_offsets_to_sparse_connect(dev):
+    """GraclusSelect attaches the CSR offsets of the row-sorted list it walked; SparseConnect uses them only for that
+    very tensor object, unmodified; results equal the route without them; a list with ids outside [0, N) still raises."""
+    from tgp import kernels
+    from tgp.connect import SparseConnect
+    from tgp.select import GraclusSelect
+    g = torch.Generator().manual_seed(2)
+    n = 50_000
+    a, b = torch.randint(0, n, (2, 200_000), generator=g)
+    ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+    ei = ei[:, torch.argsort(ei[0] * n + ei[1])].contiguous().to(dev)
+    ew = torch.rand(ei.size(1), generator=g).to(dev) + 0.1
+    so = GraclusSelect()(ei, ew, num_nodes=n)
+    ptr = so.edge_csr_for(ei)
+    assert ptr is not None and ptr.dtype == torch.int32 and ptr.numel() == n + 1
+    assert so.edge_csr_for(ei.clone()) is None            # another object: not trusted
+    want = kernels.coalesce_edges(ei, ew, so.cluster_index, so.num_supernodes, "sum", True, route="general")
+    for route in ("staged", "fused"):
+        got = kernels.coalesce_edges(ei, ew, so.cluster_index, so.num_supernodes, "sum", True, route=route,
+                                     csr=(ptr, None))
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), route
+    oi, ow = SparseConnect()(ei, so, edge_weight=ew)
+    assert torch.equal(oi, want[0]) and torch.equal(ow, want[1])
+    ei[0, 0] = ei[0, 0]                                   # in-place write bumps the version counter
+    assert so.edge_csr_for(ei) is None
+    import pickle
+    pickle.loads(pickle.dumps(so))                        # (a weak reference would not pickle)
+    # stale / wrong offsets (ids outside [0, N) clamp into them): refused, and the general route reports the ids
+    bad = ei.clone()
+    bad[0, -1] = n + 5
+    bad_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    from tgp import _native as N
+    N.check(N.lib().tgp_rowptr_from_sorted_i64(N.ptr(bad[0].contiguous()), bad.size(1), n, N.ptr(bad_ptr),
+                                               N.stream_ptr(dev)), "rowptr")
+    assert int(bad_ptr[n]) == bad.size(1) - 1             # clamped: no out-of-bounds write, visibly incomplete
+    with pytest.raises(IndexError):
+        kernels.coalesce_edges(bad, ew, so.cluster_index, so.num_supernodes, "sum", True, csr=(bad_ptr, None),
+                               assign_index=kernels.build_assign_index(so.cluster_index, so.num_supernodes))

@@ -387,7 +387,7 @@ def test_rowlocal_coalesce_declines_and_falls_back(dev):
         ws = N.workspace(L.tgp_connect_coalesce_rows_workspace_bytes(row.numel(), cl.numel(), kk), dev)
         cnt = torch.empty(1, dtype=torch.int64, device=dev)
         N.check(L.tgp_connect_coalesce_rows_count(row.data_ptr(), col.data_ptr(), None, row.numel(), cl.data_ptr(),
-                                                  cl.numel(), kk, index.row_ptr.data_ptr(), index.perm.data_ptr(), 0, 1,
+                                                  cl.numel(), kk, index.row_ptr.data_ptr(), index.perm.data_ptr(), None, 0, 1,
                                                   1e-8, ws.data_ptr(), ws.numel(), cnt.data_ptr(), N.stream_ptr(dev)), "rows")
         return int(cnt.item())
 
@@ -439,7 +439,7 @@ def test_rowlocal_coalesce_many_members_empty_rows_and_hub_nodes(dev):
     ws = N.workspace(L.tgp_connect_coalesce_rows_workspace_bytes(row.numel(), n, k), dev)
     cnt = torch.empty(1, dtype=torch.int64, device=dev)
     N.check(L.tgp_connect_coalesce_rows_count(row.data_ptr(), col.data_ptr(), None, row.numel(), cl_d.data_ptr(), n, k,
-                                              idx.row_ptr.data_ptr(), idx.perm.data_ptr(), 0, 1, 1e-8, ws.data_ptr(),
+                                              idx.row_ptr.data_ptr(), idx.perm.data_ptr(), None, 0, 1, 1e-8, ws.data_ptr(),
                                               ws.numel(), cnt.data_ptr(), N.stream_ptr(dev)), "rows")
     assert int(cnt.item()) > 0
 

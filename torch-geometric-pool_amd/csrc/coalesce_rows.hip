@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void cr_raw_off_kernel(const int32_t* __restri
                                                          const uint32_t* __restrict__ seg_dst, int* __restrict__ bad,
                                                          uint32_t* __restrict__ raw_off) {
   const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (r >= K || *bad == 1) return;
+  if (r >= K || (*bad & 1)) return;
   const uint32_t lo = seg_dst[a_row_ptr[r]], hi = seg_dst[a_row_ptr[r + 1]];
   raw_off[r] = lo;
   if (hi - lo > static_cast<uint32_t>(CR_LONG)) *bad = 2;
@@ -727,6 +727,424 @@ __global__ __launch_bounds__(256) void cr_fill_kernel(const uint32_t* __restrict
   }
 }
 
+// ======================================================================================================
+// r3: the row-sorted path as ONE heavy kernel (cr_fused_kernel) + a widening fill.
+//
+// What the staged pipeline above spends outside its gather-sort kernel -- member degree sums + scan + row offsets
+// (30 us at C4), the survivor scan (15-19 us), the long-row kernel's launch, and a fill that re-reads weights it only
+// copies -- comes from handing positions between kernels through global arrays.  Here a workgroup derives all of it
+// locally and the only cross-workgroup quantity, the number of survivors in front of it, comes from a decoupled
+// look-back over 8-byte {state, value} granules (agent-scope relaxed atomics: the data IS the flag, R2 of the
+// programming guide's Guideline 16).  A tile waits for the tiles in front of it, so the kernel is only launched with
+// at most FZ_MAX_TILES tiles -- one launch wave, every workgroup resident -- and every spin is bounded (a timeout
+// declines the call to the staged pipeline, so no result depends on dispatch order or placement).  Measured r3 at
+// C4 (17 k tiles): the waiting costs 95 us of a 288 us kernel and a ticket counter for arrival-order tiles 600 us more
+// (one word takes ~88 atomics per us), against 186 us for the staged kernels it replaces: large lists stay on the
+// staged pipeline, batches of small graphs (where ten launches of a few us each dominate) take this one:
+//   * rows r0 .. r0 + R of the tile -> their members (inverted index) -> each member's edge range (node_ptr) ->
+//     block scan of the member degrees = LDS slots.  No seg_src / seg_dst / raw_off arrays.
+//   * gather through the int32 cluster table into LDS, in-row sort + merge + filters exactly as above
+//     (cr_sort_rows); rows of 65..1024 entries are sorted by the whole workgroup in LDS (solo pass) instead of a
+//     second kernel.
+//   * survivors leave at their FINAL offsets: weights straight into the caller's output buffer, columns as uint32
+//     into tmp (the int64 [2, n] tensor can only be allocated once n is known), per-row output offsets for the fill.
+// The fill then reads 4 bytes and writes 16 per survivor (28 + 4 before).  Declines: unsorted rows / a row longer
+// than 1024 entries / K >= 2^22 with a long row (d_count = -1: radix routes), more than 256 members in a tile
+// (d_count = -3: the staged row-local pipeline above takes any member count).
+constexpr int FZ_MEMBERS = 256;
+constexpr int FZ_MAX_TILES = 1024;  // all tiles of a call are resident together (256 CUs x 6 workgroups): see below
+constexpr uint32_t FZ_POS_BITS = 10;  // long rows: key = column << 10 | position
+
+__device__ __forceinline__ unsigned long long fz_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void fz_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr unsigned long long FZ_AGG = 1ull << 32, FZ_PRE = 2ull << 32;
+
+// Exclusive prefix of tile `tile` (survivors of all earlier tiles); called by every lane of ONE wave.  Returns false
+// when the call was declined meanwhile (a predecessor may then never publish).
+__device__ __forceinline__ bool fz_lookback(const unsigned long long* __restrict__ status, int64_t tile,
+                                            int* __restrict__ bad, uint32_t* excl_out) {
+  const int lane = lane_id();
+  uint32_t excl = 0;
+  int64_t j = tile - 1;
+  while (j >= 0) {
+    const int64_t idx = j - lane;
+    unsigned long long st = idx >= 0 ? fz_load(status + idx) : FZ_PRE;
+    int spins = 0;
+    while (__any((st >> 32) == 0)) {
+      ++spins;
+      if ((spins & 15) == 0) {
+        int b = 0;
+        if (lane == 0) b = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__shfl(b, 0, 64) != 0) return false;
+        if (spins > (1 << 20)) {  // every spin is bounded: give the call back to the staged pipeline
+          if (lane == 0) atomicOr(bad, 16);
+          return false;
+        }
+      }
+      if (spins > 4) __builtin_amdgcn_s_sleep(2);
+      if ((st >> 32) == 0) st = fz_load(status + idx);
+    }
+    const unsigned long long pre = __ballot((st >> 32) == 2);
+    const int first = pre ? __builtin_ctzll(pre) : 64;  // nearest predecessor that already knows its prefix
+    uint32_t v = lane <= first ? static_cast<uint32_t>(st) : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    excl += v;
+    if (pre) break;
+    j -= 64;
+  }
+  *excl_out = excl;
+  return true;
+}
+
+// One row of 65 .. 1024 entries, alone in LDS at slots [0, T): workgroup-wide bitonic on (column << 10 | position),
+// duplicates folded by the run heads in input order, filters, survivors compacted back to slots [0, n).
+__device__ __forceinline__ uint32_t fz_sort_long(uint32_t* s_key, float* s_val, uint32_t* s_cnt, uint32_t T,
+                                                 uint32_t row_id, bool has_w, int reduce_op, int flags, float eps) {
+  const int tid = threadIdx.x;
+  uint32_t P = 128;
+  while (P < T) P <<= 1;
+  for (uint32_t i = tid; i < P; i += 256) s_key[i] = i < T ? (s_key[i] << FZ_POS_BITS) | i : 0xFFFFFFFFu;
+  __syncthreads();
+  for (uint32_t k = 2; k <= P; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = tid; i < P; i += 256) {
+        const uint32_t x = i ^ j;
+        if (x > i) {
+          const bool up = (i & k) == 0;
+          const uint32_t a = s_key[i], c2 = s_key[x];
+          if ((a > c2) == up) { s_key[i] = c2; s_key[x] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  bool keep[4];
+  uint32_t rank[4], colv[4];
+  float val[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const uint32_t i = it * 256 + tid;
+    keep[it] = false; colv[it] = 0; val[it] = 0.f;
+    if (i < T) {
+      const uint32_t kk = s_key[i], c = kk >> FZ_POS_BITS;
+      const bool head = i == 0 || (s_key[i - 1] >> FZ_POS_BITS) != c;
+      if (head) {
+        float acc = has_w ? s_val[kk & 1023u] : 0.f;
+        uint32_t cnt = 1;
+        for (uint32_t q = i + 1; q < T; ++q, ++cnt) {
+          const uint32_t k2 = s_key[q];
+          if ((k2 >> FZ_POS_BITS) != c) break;
+          if (has_w) acc = cr_reduce(acc, s_val[k2 & 1023u], reduce_op);
+        }
+        if (has_w && reduce_op == TGP_MEAN) acc = acc / static_cast<float>(cnt);
+        bool k3 = true;
+        if ((flags & TGP_REMOVE_SELF_LOOPS) && c == row_id) k3 = false;
+        if (has_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > eps)) k3 = false;
+        keep[it] = k3; colv[it] = c; val[it] = acc;
+      }
+    }
+  }
+  uint32_t total;
+  block_compact_ranks<4>(keep, rank, total, s_cnt);  // (two barriers: every read of the sorted keys is done)
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+    if (keep[it]) {
+      s_key[rank[it]] = colv[it];
+      if (has_w) s_val[rank[it]] = val[it];
+    }
+  __syncthreads();
+  return total;
+}
+
+template <typename ColT>
+__global__ __launch_bounds__(256, 6) void cr_fused_kernel(
+    const ColT* __restrict__ col, const float* __restrict__ w, int64_t E, const int32_t* __restrict__ table,
+    const int32_t* __restrict__ a_row_ptr, const int32_t* __restrict__ a_perm, const uint32_t* __restrict__ node_ptr,
+    int64_t K, int rows_per_wg, int reduce_op, int flags, float eps, int* __restrict__ bad,
+    unsigned long long* __restrict__ status, uint32_t* __restrict__ tmp_c,
+    float* __restrict__ out_w, uint32_t* __restrict__ out_off, int64_t* __restrict__ total, int64_t n_nodes) {
+  __shared__ uint32_t s_key[GS_CAP];
+  __shared__ float s_val[GS_CAP];
+  __shared__ uint32_t s_src[FZ_MEMBERS + 1], s_dst[FZ_MEMBERS + 1];
+  __shared__ uint32_t s_roff[GS_ROWS + 1], s_nout[GS_ROWS], s_ooff[GS_ROWS + 1];
+  __shared__ int32_t s_rp[GS_ROWS + 1];
+  __shared__ int s_mid[GS_ROWS];
+  __shared__ uint32_t s_w4[16];
+  __shared__ int s_nmid, s_anylong;
+  __shared__ uint32_t s_base;
+  __shared__ int s_ok;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_anylong = 0;
+    // one lane reads the decline flag for the workgroup (per-thread reads could disagree and split a barrier)
+    s_ok = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+  }
+  __syncthreads();
+  const int64_t tile = blockIdx.x;
+  const int64_t ntiles = gridDim.x;
+  const int64_t r0 = tile * rows_per_wg;
+  const int nrows = static_cast<int>(K - r0 < rows_per_wg ? K - r0 : rows_per_wg);
+  const bool has_w = w != nullptr;
+  if (!s_ok) return;  // declined already (its successors leave their look-back through the same flag)
+  if (tid <= nrows) s_rp[tid] = a_row_ptr[r0 + tid];
+  __syncthreads();
+  const int p_lo = s_rp[0], M = s_rp[nrows] - p_lo;
+  if (M > FZ_MEMBERS) {
+    if (tid == 0) atomicOr(bad, 8);
+    return;
+  }
+  {  // member degrees -> LDS slots
+    uint32_t src = 0, len = 0;
+    if (tid < M) {
+      const int32_t node = a_perm[p_lo + tid];
+      src = node_ptr[node];
+      len = node_ptr[node + 1] - src;
+    }
+    uint32_t cnt_all;
+    const uint32_t dst = block_excl_scan_256(len, s_w4, &cnt_all);
+    s_src[tid] = src;
+    s_dst[tid] = dst;
+    if (tid == 0) s_dst[FZ_MEMBERS] = cnt_all;
+  }
+  __syncthreads();
+  if (tid <= nrows) {
+    const int m = s_rp[tid] - p_lo;
+    s_roff[tid] = m < FZ_MEMBERS ? s_dst[m] : s_dst[FZ_MEMBERS];
+    // (member M of a full tile: s_dst[256] holds the total; for M < 256 thread M's scan value is the total too)
+  }
+  __syncthreads();
+  if (tid < nrows) {
+    const uint32_t T = s_roff[tid + 1] - s_roff[tid];
+    if (T > 64) s_anylong = 1;
+    if (T > static_cast<uint32_t>(CR_LONG) || (T > 64 && K >= (1ll << 22))) {
+      atomicOr(bad, 2);
+      s_ok = 0;
+    }
+  }
+  __syncthreads();
+  if (!s_ok) return;
+
+  const bool single = !s_anylong && s_roff[nrows] <= static_cast<uint32_t>(GS_CAP);
+  bool have_base = false;
+  uint32_t out_base = 0, wg_total = 0;
+  int rs = 0;
+  while (rs < nrows) {
+    int re = rs + 1;
+    if (single) {
+      re = nrows;
+    } else if (s_roff[rs + 1] - s_roff[rs] <= 64) {
+      while (re < nrows && s_roff[re + 1] - s_roff[re] <= 64 &&
+             s_roff[re + 1] - s_roff[rs] <= static_cast<uint32_t>(GS_CAP))
+        ++re;
+    }
+    const uint32_t base = s_roff[rs];
+    const int cnt = static_cast<int>(s_roff[re] - base);
+    const int m_lo = s_rp[rs] - p_lo, Mp = s_rp[re] - s_rp[rs];
+    if (tid == 0) s_nmid = 0;
+    {  // gather: 8 lanes per member, two rounds of 32 members x two steps of 8 edges requested before any is used
+      const int grp = tid >> 3, l = tid & 7;
+      constexpr int GR = 2;
+      for (int m0 = 0; m0 < Mp; m0 += 32 * GR) {
+        uint32_t src[GR], dst[GR], len[GR];
+#pragma unroll
+        for (int r = 0; r < GR; ++r) {
+          const int m = m0 + r * 32 + grp;
+          const bool v = m < Mp;
+          src[r] = v ? s_src[m_lo + m] : 0u;
+          const uint32_t d = v ? s_dst[m_lo + m] : 0u;
+          len[r] = v ? s_dst[m_lo + m + 1] - d : 0u;  // s_dst[M .. 256] all hold the tile's total
+          dst[r] = d - base;
+        }
+        ColT cc[GR][2];
+        float wv[GR][2];
+#pragma unroll
+        for (int r = 0; r < GR; ++r)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint32_t j = static_cast<uint32_t>(l + 8 * q);
+            const bool ok = j < len[r];
+            cc[r][q] = ok ? __builtin_nontemporal_load(col + src[r] + j) : 0;
+            wv[r][q] = (ok && has_w) ? __builtin_nontemporal_load(w + src[r] + j) : 0.f;
+          }
+#pragma unroll
+        for (int r = 0; r < GR; ++r)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint32_t j = static_cast<uint32_t>(l + 8 * q);
+            if (j < len[r]) {
+              const bool inr = static_cast<uint64_t>(static_cast<int64_t>(cc[r][q])) < static_cast<uint64_t>(n_nodes);
+              if (!inr) atomicOr(bad, 4);
+              s_key[dst[r] + j] = inr ? static_cast<uint32_t>(table[cc[r][q]]) : 0u;
+              s_val[dst[r] + j] = wv[r][q];
+            }
+          }
+#pragma unroll
+        for (int r = 0; r < GR; ++r)
+          for (uint32_t j = static_cast<uint32_t>(l) + 16; j < len[r]; j += 8) {
+            const int64_t c = static_cast<int64_t>(col[src[r] + j]);
+            const bool inr = static_cast<uint64_t>(c) < static_cast<uint64_t>(n_nodes);
+            if (!inr) atomicOr(bad, 4);
+            s_key[dst[r] + j] = inr ? static_cast<uint32_t>(table[c]) : 0u;
+            s_val[dst[r] + j] = has_w ? w[src[r] + j] : 0.f;
+          }
+      }
+    }
+    __syncthreads();
+    if (cnt > 64 && re == rs + 1 && s_roff[rs + 1] - s_roff[rs] > 64) {
+      const uint32_t n = fz_sort_long(s_key, s_val, s_w4, static_cast<uint32_t>(cnt), static_cast<uint32_t>(r0 + rs),
+                                      has_w, reduce_op, flags, eps);
+      if (tid == 0) s_nout[rs] = n;
+    } else {
+      {
+        constexpr int LPR = 8;
+        const int grp = tid / LPR;
+        for (int i0 = rs; i0 < re; i0 += 256 / LPR) {
+          const int i = i0 + grp;
+          uint32_t b = 0, T = 0;
+          if (i < re) {
+            b = s_roff[i] - base;
+            T = s_roff[i + 1] - s_roff[i];
+          }
+          if (i < re && T > 32 && (tid & (LPR - 1)) == 0) s_mid[atomicAdd(&s_nmid, 1)] = i;
+          const bool mine = i < re && T <= 32;
+          cr_sort_rows<LPR>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), has_w, reduce_op, flags,
+                            eps, s_nout + (mine ? i : 0));
+        }
+      }
+      __syncthreads();
+      {
+        constexpr int LPR = 16;
+        const int nmid = s_nmid;
+        for (int li0 = 0; li0 < nmid; li0 += 256 / LPR) {
+          const int li = li0 + tid / LPR;
+          const bool mine = li < nmid;
+          const int i = mine ? s_mid[li] : rs;
+          const uint32_t b = s_roff[i] - base, T = s_roff[i + 1] - s_roff[i];
+          cr_sort_rows<LPR>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), has_w, reduce_op, flags,
+                            eps, s_nout + i);
+        }
+      }
+    }
+    __syncthreads();
+    // output offsets of the pass's rows (<= 32 rows: one wave scans them)
+    if (tid < 64) {
+      const int i = rs + tid;
+      const uint32_t v = i < re ? s_nout[i] : 0u;
+      const uint32_t inc = wave_incl_scan(v);
+      if (i < re) s_ooff[i] = inc - v;
+      if (tid == 63) s_ooff[re] = inc;  // rows beyond re contributed 0
+    }
+    __syncthreads();
+    const uint32_t pass_total = s_ooff[re];
+    if (!have_base) {
+      if (tid < 64) {
+        if (single && tid == 0) fz_store(status + tile, FZ_AGG | pass_total);
+        uint32_t excl = 0;
+        const bool ok = fz_lookback(status, tile, bad, &excl);
+        if (tid == 0) {
+          s_base = excl;
+          s_ok = ok ? 1 : 0;
+          if (single && ok) fz_store(status + tile, FZ_PRE | (excl + pass_total));
+        }
+      }
+      __syncthreads();
+      if (!s_ok) return;
+      out_base = s_base;
+      have_base = true;
+    }
+    const uint32_t o0 = out_base + wg_total;
+    if (tid < re - rs) out_off[r0 + rs + tid] = o0 + s_ooff[rs + tid];
+    for (uint32_t t = tid; t < pass_total; t += 256) {
+      int lo = rs, hi = re;  // last row i of the pass with s_ooff[i] <= t
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_ooff[mid] <= t) lo = mid; else hi = mid;
+      }
+      const uint32_t slot = (s_roff[lo] - base) + (t - s_ooff[lo]);
+      __builtin_nontemporal_store(s_key[slot], tmp_c + o0 + t);
+      if (has_w) __builtin_nontemporal_store(s_val[slot], out_w + o0 + t);
+    }
+    wg_total += pass_total;
+    rs = re;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (!single) fz_store(status + tile, FZ_PRE | (out_base + wg_total));
+    if (tile == ntiles - 1) {
+      *total = static_cast<int64_t>(out_base) + wg_total;
+      out_off[K] = out_base + wg_total;
+    }
+  }
+}
+
+static __global__ void fz_decline_kernel(int64_t* __restrict__ d_count) { *d_count = -3; }
+
+// d_count = total, or the decline code: -2 an id out of range (the general path reports it), -3 only the fused
+// kernel's member limit (the staged row-local pipeline can take the call), -1 unsorted rows / a row too long.
+static __global__ void fz_finish_kernel(const int* __restrict__ bad, const int64_t* __restrict__ total,
+                                        int64_t* __restrict__ d_count) {
+  const int b = *bad;
+  *d_count = b == 0 ? *total : ((b & 4) ? -1 : ((b & 3) ? -1 : -3));
+}
+
+// out_col[o] = tmp_c[o] widened, out_row[o] = the row whose output range holds o: one workgroup per 64 rows.
+__global__ __launch_bounds__(256) void fz_fill_kernel(const uint32_t* __restrict__ tmp_c,
+                                                      const uint32_t* __restrict__ out_off, int64_t K,
+                                                      int64_t* __restrict__ out_row, int64_t* __restrict__ out_col) {
+  __shared__ uint32_t s_out[FILL_ROWS + 1];
+  const int tid = threadIdx.x;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * FILL_ROWS;
+  const int nr = static_cast<int>(K - r0 < FILL_ROWS ? K - r0 : FILL_ROWS);
+  if (tid <= nr) s_out[tid] = out_off[r0 + tid];
+  __syncthreads();
+  const uint32_t o0 = s_out[0], cnt = s_out[nr] - o0;
+  for (uint32_t t = tid; t < cnt; t += 256) {
+    const uint32_t o = o0 + t;
+    int lo = 0, hi = nr;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_out[mid] <= o) lo = mid; else hi = mid;
+    }
+    out_row[o] = r0 + lo;
+    out_col[o] = tmp_c[o];
+  }
+}
+
+struct FzWs {
+  int32_t* table;            // [N]
+  uint32_t* node_ptr;        // [N + 1]
+  uint32_t* out_off;         // [K + 1]
+  uint32_t* tmp_c;           // [E]
+  unsigned long long* status;  // [tiles] + control words behind it (one memset)
+  int* bad;
+  int64_t* total;
+  size_t zero_bytes;
+};
+
+static size_t fz_layout(void* ws, int64_t E, int64_t N, int64_t K, FzWs* out) {
+  Carver cv(ws);
+  const size_t n = static_cast<size_t>(N > 0 ? N : 1), k = static_cast<size_t>(K > 0 ? K : 1);
+  const size_t e = static_cast<size_t>(E > 0 ? E : 1);
+  FzWs s;
+  // the zeroed block comes first (Guideline 16: a block of its own at the allocation's start, a multiple of 16 bytes)
+  const size_t tiles = k + 2;  // rows_per_wg >= 1
+  s.status = cv.take<unsigned long long>(tiles + 6);
+  s.bad = reinterpret_cast<int*>(s.status + tiles + 1);
+  s.total = reinterpret_cast<int64_t*>(s.status + tiles + 2);
+  s.zero_bytes = (tiles + 6) * sizeof(unsigned long long) / 16 * 16;
+  s.table = cv.take<int32_t>(n);
+  s.node_ptr = cv.take<uint32_t>(n + 1);
+  s.out_off = cv.take<uint32_t>(k + 1);
+  s.tmp_c = cv.take<uint32_t>(e);
+  if (out) *out = s;
+  return cv.off;
+}
+
 struct CrWs {
   int32_t* table;        // [N]
   uint32_t* node_ptr;    // [N+1]
@@ -777,11 +1195,17 @@ extern "C" size_t tgp_connect_coalesce_rows_workspace_bytes(int64_t E, int64_t N
   return cr_layout(nullptr, E, N, K, nullptr) + 256;
 }
 
+// a handed-over CSR covers the whole list: offsets start at 0 and end at E (a list with ids outside [0, N) does not)
+static __global__ void cr_check_csr_kernel(const int32_t* __restrict__ csr_ptr, int64_t N, int64_t E,
+                                           int* __restrict__ bad) {
+  if (csr_ptr[0] != 0 || static_cast<int64_t>(csr_ptr[N]) != E) *bad = 4;
+}
+
 extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
                                                const int64_t* cluster_index, int64_t N, int64_t K,
                                                const int32_t* assign_row_ptr, const int32_t* assign_perm,
-                                               int reduce_op, int flags, float eps, void* ws, size_t ws_bytes,
-                                               int64_t* d_count, void* stream_) {
+                                               const int32_t* csr_ptr, int reduce_op, int flags, float eps, void* ws,
+                                               size_t ws_bytes, int64_t* d_count, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && d_count, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_count: bad argument");
   TGP_REQUIRE(E == 0 || (row && col && cluster_index && assign_row_ptr && assign_perm), TGP_ERR_INVALID,
@@ -800,7 +1224,11 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
   cr_layout(ws, E, N, K, &s);
   float* tmp_w = w ? s.tmp_w : nullptr;
   (void)hipMemsetAsync(s.bad, 0, sizeof(int), stream);
-  if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+  if (csr_ptr) {
+    // CSR offsets of this very list from the caller (GraclusSelect builds them): no pass over the row array
+    s.node_ptr = reinterpret_cast<uint32_t*>(const_cast<int32_t*>(csr_ptr));  // non-negative: same bits; read only
+    hipLaunchKernelGGL(cr_check_csr_kernel, dim3(1), dim3(1), 0, stream, csr_ptr, N, E, s.bad);
+  } else if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
     hipLaunchKernelGGL(cr_node_ptr_vec_kernel, dim3(cdiv(cdiv(E, 4) + 1, 256)), dim3(256), 0, stream, row, E, N, s.bad,
                        s.node_ptr);
   } else {
@@ -833,6 +1261,80 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
                      reduce_op, flags, eps, s.bad, s.n_out);
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);
   return check_launch("tgp_connect_coalesce_rows_count");
+}
+
+// ------------------------------------------------------------------ fused row-sorted path (r3), see cr_fused_kernel
+extern "C" size_t tgp_connect_coalesce_fused_workspace_bytes(int64_t E, int64_t N, int64_t K) {
+  return fz_layout(nullptr, E, N, K, nullptr) + 256;
+}
+
+extern "C" int tgp_connect_coalesce_fused_count(const int64_t* row, const int64_t* col, const int32_t* csr_ptr,
+                                                const int32_t* csr_col, const float* w, int64_t E,
+                                                const int64_t* cluster_index, int64_t N, int64_t K,
+                                                const int32_t* assign_row_ptr, const int32_t* assign_perm,
+                                                int reduce_op, int flags, float eps, float* out_w, void* ws,
+                                                size_t ws_bytes, int64_t* d_count, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const bool csr = csr_ptr && csr_col;  // int32 columns are only usable with the offsets of the same list
+  TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && d_count, TGP_ERR_INVALID, "tgp_connect_coalesce_fused_count: bad argument");
+  TGP_REQUIRE(E == 0 || (((csr_ptr || row) && (col || csr)) && cluster_index && assign_row_ptr && assign_perm),
+              TGP_ERR_INVALID, "tgp_connect_coalesce_fused_count: null pointer");
+  TGP_REQUIRE(!w || out_w || E == 0, TGP_ERR_INVALID, "tgp_connect_coalesce_fused_count: weights without an output buffer");
+  TGP_REQUIRE(reduce_op >= TGP_SUM && reduce_op <= TGP_MUL, TGP_ERR_INVALID,
+              "tgp_connect_coalesce_fused_count: unknown reduce_op %d", reduce_op);
+  TGP_REQUIRE(E < (1ll << 31) && K < (1ll << 26) && N < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_connect_coalesce_fused_count: E/N >= 2^31 or K >= 2^26");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_connect_coalesce_fused_workspace_bytes(E, N, K), TGP_ERR_WORKSPACE,
+              "tgp_connect_coalesce_fused_count: workspace too small");
+  if (E == 0 || K == 0) {
+    (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
+    return check_launch("tgp_connect_coalesce_fused_count");
+  }
+  FzWs s;
+  fz_layout(ws, E, N, K, &s);
+  (void)hipMemsetAsync(s.status, 0, s.zero_bytes, stream);
+  const uint32_t* node_ptr = s.node_ptr;
+  if (csr_ptr) {
+    node_ptr = reinterpret_cast<const uint32_t*>(csr_ptr);  // offsets are non-negative: same bits
+    hipLaunchKernelGGL(cr_check_csr_kernel, dim3(1), dim3(1), 0, stream, csr_ptr, N, E, s.bad);
+  } else if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+    hipLaunchKernelGGL(cr_node_ptr_vec_kernel, dim3(cdiv(cdiv(E, 4) + 1, 256)), dim3(256), 0, stream, row, E, N, s.bad,
+                       s.node_ptr);
+  } else {
+    hipLaunchKernelGGL(cr_node_ptr_kernel, dim3(cdiv(E + 1, 256)), dim3(256), 0, stream, row, E, N, s.bad, s.node_ptr);
+  }
+  hipLaunchKernelGGL(cr_table_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, cluster_index, N, s.table);
+  // rows per tile: ~100 members on average (the kernel takes at most 256), at most 32 rows
+  int64_t rows = N > 0 ? 100 * K / N : GS_ROWS;
+  rows = rows < 1 ? 1 : (rows > GS_ROWS ? GS_ROWS : rows);
+  const unsigned tiles = static_cast<unsigned>(cdiv(K, rows));
+  if (tiles > static_cast<unsigned>(FZ_MAX_TILES)) {  // more tiles than one launch wave holds: the staged pipeline
+    hipLaunchKernelGGL(fz_decline_kernel, dim3(1), dim3(1), 0, stream, d_count);
+    return check_launch("tgp_connect_coalesce_fused_count");
+  }
+  if (csr)
+    hipLaunchKernelGGL(cr_fused_kernel<int32_t>, dim3(tiles), dim3(256), 0, stream, csr_col, w, E, s.table,
+                       assign_row_ptr, assign_perm, node_ptr, K, static_cast<int>(rows), reduce_op, flags, eps, s.bad,
+                       s.status, s.tmp_c, w ? out_w : nullptr, s.out_off, s.total, N);
+  else
+    hipLaunchKernelGGL(cr_fused_kernel<int64_t>, dim3(tiles), dim3(256), 0, stream, col, w, E, s.table,
+                       assign_row_ptr, assign_perm, node_ptr, K, static_cast<int>(rows), reduce_op, flags, eps, s.bad,
+                       s.status, s.tmp_c, w ? out_w : nullptr, s.out_off, s.total, N);
+  hipLaunchKernelGGL(fz_finish_kernel, dim3(1), dim3(1), 0, stream, s.bad, s.total, d_count);
+  return check_launch("tgp_connect_coalesce_fused_count");
+}
+
+extern "C" int tgp_connect_coalesce_fused_fill(const void* ws, int64_t E, int64_t N, int64_t K, int64_t num_out,
+                                               int64_t* out_row, int64_t* out_col, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(ws && num_out >= 0, TGP_ERR_INVALID, "tgp_connect_coalesce_fused_fill: bad argument");
+  if (num_out == 0 || E == 0 || K == 0) return TGP_OK;
+  TGP_REQUIRE(out_row && out_col, TGP_ERR_INVALID, "tgp_connect_coalesce_fused_fill: null output");
+  FzWs s;
+  fz_layout(const_cast<void*>(ws), E, N, K, &s);
+  hipLaunchKernelGGL(fz_fill_kernel, dim3(cdiv(K, FILL_ROWS)), dim3(256), 0, stream, s.tmp_c, s.out_off, K, out_row,
+                     out_col);
+  return check_launch("tgp_connect_coalesce_fused_fill");
 }
 
 // ------------------------------------------------------------------ grouped path (any edge order)

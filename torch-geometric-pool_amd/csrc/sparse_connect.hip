@@ -718,16 +718,20 @@ __global__ __launch_bounds__(256) void blockdiag_fill_kernel(BlockDiagPred pred,
 // =====================================================================================
 __global__ __launch_bounds__(256) void rowptr_from_sorted_kernel(const int64_t* __restrict__ rows, int64_t n,
                                                                  int64_t num_rows, int32_t* __restrict__ row_ptr) {
+  // Ids are CLAMPED to [-1, num_rows]: a list with ids outside [0, num_rows) never writes outside row_ptr[0 ..
+  // num_rows]; it shows as row_ptr[0] != 0 (negative ids in front) or row_ptr[num_rows] != n (ids >= num_rows behind),
+  // which the consumers check before they trust the offsets.
   const int64_t p = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (p > n) return;
+  auto clamp = [num_rows](int64_t v) { return v < -1 ? -1 : (v > num_rows ? num_rows : v); };
   if (p == n) {
-    const int64_t first = n > 0 ? rows[n - 1] + 1 : 0;
+    const int64_t first = n > 0 ? clamp(rows[n - 1]) + 1 : 0;
     for (int64_t c = first; c <= num_rows; ++c) row_ptr[c] = static_cast<int32_t>(n);
     return;
   }
-  const int64_t cur = rows[p];
-  const int64_t prev = p > 0 ? rows[p - 1] : -1;
-  for (int64_t c = prev + 1; c <= cur; ++c) row_ptr[c] = static_cast<int32_t>(p);
+  const int64_t cur = clamp(rows[p]);
+  const int64_t prev = p > 0 ? clamp(rows[p - 1]) : -1;
+  for (int64_t c = prev + 1; c <= cur && c <= num_rows; ++c) row_ptr[c] = static_cast<int32_t>(p);
 }
 
 __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict__ row_ptr,

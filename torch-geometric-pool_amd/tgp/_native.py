@@ -52,10 +52,14 @@ SIGNATURES = {
     "tgp_connect_coalesce_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_i64, _c_p, _c_p,
                                            _c_p, _c_p]),
     "tgp_connect_coalesce_rows_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
-    "tgp_connect_coalesce_rows_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_int,
-                                                 _c_int, _c_f, _c_p, _c_sz, _c_p, _c_p]),
+    "tgp_connect_coalesce_rows_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p,
+                                                 _c_int, _c_int, _c_f, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_connect_coalesce_rows_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_p, _c_p, _c_p,
                                                 _c_p]),
+    "tgp_connect_coalesce_fused_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "tgp_connect_coalesce_fused_count": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p,
+                                                  _c_p, _c_int, _c_int, _c_f, _c_p, _c_p, _c_sz, _c_p, _c_p]),
+    "tgp_connect_coalesce_fused_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_connect_coalesce_grouped_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tgp_connect_coalesce_grouped_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_int,
                                                     _c_f, _c_p, _c_sz, _c_p, _c_p]),

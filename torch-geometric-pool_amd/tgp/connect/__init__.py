@@ -53,7 +53,8 @@ def _restore_format(template, edge_index, edge_weight, num_supernodes):
 def sparse_connect(edge_index, edge_weight: Optional[Tensor] = None, node_index: Tensor = None,
                    cluster_index: Optional[Tensor] = None, num_nodes: int = None, num_supernodes: int = None,
                    remove_self_loops: bool = True, reduce_op: str = "sum", edge_weight_norm: bool = False,
-                   batch_pooled: Optional[Tensor] = None, degree_norm: bool = False, assign_index=None):
+                   batch_pooled: Optional[Tensor] = None, degree_norm: bool = False, assign_index=None,
+                   edge_csr: Optional[Tensor] = None):
     r"""Coarsen an edge list (reference connect/base_conn.py:57-112).
 
     * kept-node selection (TopK): induced subgraph, endpoints relabelled to their position in the
@@ -75,7 +76,8 @@ def sparse_connect(edge_index, edge_weight: Optional[Tensor] = None, node_index:
         ei, ew = Fn.filter_edges(edge_index, edge_weight, node_index, num_nodes, remove_self_loops)
     elif cluster_index is not None and len(cluster_index) == num_nodes:
         ei, ew = Fn.coalesce_edges(edge_index, edge_weight, cluster_index, num_supernodes, reduce_op,
-                                   remove_self_loops, assign_index=assign_index)
+                                   remove_self_loops, assign_index=assign_index,
+                                   csr=None if edge_csr is None else (edge_csr, None))
     else:
         raise RuntimeError
     ei, ew = _normalize_pooled_edges(ei, ew, num_supernodes, degree_norm, edge_weight_norm, batch_pooled)
@@ -109,7 +111,8 @@ class SparseConnect(Connect):
                                           remove_self_loops=self.remove_self_loops, reduce_op=self.reduce_op,
                                           edge_weight_norm=self.edge_weight_norm, batch_pooled=batch_pooled,
                                           degree_norm=self.degree_norm,
-                                          assign_index=so.assign_index() if all_assigned else None)
+                                          assign_index=so.assign_index() if all_assigned else None,
+                                          edge_csr=so.edge_csr_for(edge_index) if all_assigned else None)
         return adj_pool, like_input_dtype(w_pool, edge_weight)
 
     def __repr__(self) -> str:

@@ -251,15 +251,15 @@ class _CoalescedEdgeWeightsFn(torch.autograd.Function):
 
 
 def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_index: Tensor, num_supernodes: int,
-                   reduce_op: str, remove_self_loops: bool, assign_index=None):
+                   reduce_op: str, remove_self_loops: bool, assign_index=None, csr=None):
     """K.coalesce_edges whose pooled weights stay differentiable w.r.t. ``edge_weight``."""
     if not _needs_grad(edge_weight):
         return K.coalesce_edges(edge_index, edge_weight, cluster_index, num_supernodes, reduce_op, remove_self_loops,
-                                assign_index=assign_index)
+                                assign_index=assign_index, csr=csr)
     w = edge_weight.reshape(-1)
     w32 = w if w.dtype == torch.float32 else w.float()
     ei, ew = K.coalesce_edges(edge_index, w32.detach(), cluster_index, num_supernodes, reduce_op, remove_self_loops,
-                              assign_index=assign_index)
+                              assign_index=assign_index, csr=csr)
     if ei.size(1) == 0:
         return ei, ew
     key_in = cluster_index[edge_index[0]] * num_supernodes + cluster_index[edge_index[1]]

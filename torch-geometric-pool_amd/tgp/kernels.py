@@ -153,17 +153,26 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
     return (out_ei, out_w, out_id) if want_edge_id else (out_ei, out_w)
 
 
+FUSED_MAX_SUPERNODES = 32 * 1024  # 1024 tiles of 32 supernode rows
+
+
 def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_index: Tensor,
                    num_supernodes: int, reduce_op: str, remove_self_loops: bool,
                    eps_filter: bool = True, assign_index: Optional[AssignIndex] = None,
-                   route: Optional[str] = None) -> Tuple[Tensor, Optional[Tensor]]:
+                   route: Optional[str] = None, csr: Optional[Tuple[Tensor, Tensor]] = None
+                   ) -> Tuple[Tensor, Optional[Tensor]]:
     """cluster_index[edge_index] + PyG coalesce (connect/base_conn.py:86-89) fused with
     remove_self_loops and the |w| > eps filter (utils/ops.py:370-380).
 
     With the supernode->member index of the assignment at hand (``assign_index``) the sort-free row-local
     path is tried first; it declines (count = -1) for unsorted rows or very long supernode rows.
-    ``route`` ("rows" / "grouped" / "general"; tests): take exactly that route, raise if it declines."""
-    if route not in (None, "rows", "grouped", "general"):
+    The row-local path is first tried as ONE fused kernel (``tgp_connect_coalesce_fused_*``: survivors written at
+    their final offsets through a decoupled look-back), then as the staged pipeline (any member count per supernode).
+    ``csr`` = (row_ptr int32 [N+1], col int32 [E] or None) of exactly this row-sorted edge list (GraclusSelect builds
+    the offsets): the pass over the row array is skipped; the fused kernel can also stream the 4-byte columns.
+    ``route`` ("fused" / "staged" / "rows" / "grouped" / "general"; tests): take exactly that route, raise if it
+    declines ("rows" = fused, then staged)."""
+    if route not in (None, "fused", "staged", "rows", "grouped", "general"):
         raise ValueError(f"unknown route {route!r}")
     if reduce_op not in N.REDUCE_OPS:
         raise ValueError(f"unknown reduce_op '{reduce_op}', expected one of {sorted(N.REDUCE_OPS)}")
@@ -175,17 +184,60 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if (w is not None and eps_filter) else 0)
     L = N.lib()
     eps = ops_eps()
-    if route == "rows" and assign_index is None:
+    if csr is not None:
+        cptr, ccol = csr
+        if (cptr.dtype != torch.int32 or cptr.numel() != cl.numel() + 1 or not cptr.is_contiguous()
+                or (ccol is not None and (ccol.dtype != torch.int32 or ccol.numel() != E or not ccol.is_contiguous()))):
+            raise ValueError("csr must be (int32 [N+1], int32 [E] or None) contiguous tensors of this edge list")
+    rowish = route in ("fused", "staged", "rows")
+    if rowish and assign_index is None:
         assign_index = build_assign_index(cl, num_supernodes)
-    if (route in (None, "rows") and assign_index is not None and assign_index.nnz == cl.numel()
-            and assign_index.num_targets == num_supernodes
-            and num_supernodes < (1 << 26) and (route == "rows" or _rows_sorted_memo(edge_index) is not False)):
+    rows_ok = (route is None or rowish) and assign_index is not None and assign_index.nnz == cl.numel() \
+        and assign_index.num_targets == num_supernodes and num_supernodes < (1 << 26) \
+        and (rowish or csr is not None or _rows_sorted_memo(edge_index) is not False)
+    staged_ok = rows_ok
+    # the fused kernel's workgroups wait for their predecessors: it is used while all tiles are resident at once
+    # (<= 1024 of them: one launch wave), i.e. for batches of small graphs, where the staged pipeline's ten launches
+    # dominate; large lists take the staged pipeline, whose kernels never wait for each other
+    fused_ok = rows_ok and (route == "fused" or num_supernodes <= FUSED_MAX_SUPERNODES)
+    if fused_ok and route != "staged":
+        ws = N.workspace(L.tgp_connect_coalesce_fused_workspace_bytes(E, cl.numel(), num_supernodes), dev)
+        d_count = torch.empty(1, dtype=torch.int64, device=dev)
+        cap_w = None if w is None else torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+        st = N.stream_ptr(dev)
+        cptr = ccol = None
+        if csr is not None:
+            cptr, ccol = csr
+        N.check(L.tgp_connect_coalesce_fused_count(N.ptr(row), N.ptr(col), N.ptr(cptr), N.ptr(ccol), N.ptr(w), E,
+                                                   N.ptr(cl), cl.numel(), num_supernodes,
+                                                   N.ptr(assign_index.row_ptr), N.ptr(assign_index.perm),
+                                                   N.REDUCE_OPS[reduce_op], flags, eps, N.ptr(cap_w), N.ptr(ws),
+                                                   ws.numel(), N.ptr(d_count), st), "tgp_connect_coalesce_fused_count")
+        n_out = _read_count(d_count)
+        if n_out >= 0:
+            out_ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
+            N.check(L.tgp_connect_coalesce_fused_fill(N.ptr(ws), E, cl.numel(), num_supernodes, n_out,
+                                                      N.ptr(out_ei[0]) if n_out else None,
+                                                      N.ptr(out_ei[1]) if n_out else None, st),
+                    "tgp_connect_coalesce_fused_fill")
+            out_w = None
+            if w is not None:  # the kernel wrote the weights at their final offsets of the capacity-E buffer
+                out_w = cap_w[:n_out] if 2 * n_out >= E else cap_w[:n_out].clone()
+            return out_ei, out_w
+        del ws, cap_w
+        if route == "fused":
+            raise RuntimeError(f"fused coalesce route declined (code {n_out})")
+        staged_ok = n_out == -3  # only the fused kernel's tile limit: the staged pipeline takes the call
+        if not staged_ok and E > 1 and _rows_sorted_memo(edge_index) is None:
+            _rows_sorted(edge_index, row)
+    if staged_ok:
         ws = N.workspace(L.tgp_connect_coalesce_rows_workspace_bytes(E, cl.numel(), num_supernodes), dev)
         d_count = torch.empty(1, dtype=torch.int64, device=dev)
         st = N.stream_ptr(dev)
         N.check(L.tgp_connect_coalesce_rows_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
                                                   num_supernodes, N.ptr(assign_index.row_ptr),
-                                                  N.ptr(assign_index.perm), N.REDUCE_OPS[reduce_op], flags, eps, N.ptr(ws),
+                                                  N.ptr(assign_index.perm), N.ptr(csr[0]) if csr is not None else None,
+                                                  N.REDUCE_OPS[reduce_op], flags, eps, N.ptr(ws),
                                                   ws.numel(), N.ptr(d_count), st), "tgp_connect_coalesce_rows_count")
         n_out = _read_count(d_count)
         if n_out >= 0:
@@ -197,14 +249,14 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
                     "tgp_connect_coalesce_rows_fill")
             return out_ei, out_w
         del ws  # declined: fall through to the sort-based path
-        if route == "rows":
+        if rowish:
             raise RuntimeError("row-local coalesce route declined (unsorted rows or a supernode row too long)")
         if E > 1 and _rows_sorted_memo(edge_index) is None:
             # remember WHY for this tensor object (one comparison pass, once): an unsorted list skips the row-local
             # attempt (~50 us + a host round trip) on every later call
             _rows_sorted(edge_index, row)
-    if route == "rows":
-        raise RuntimeError("row-local coalesce route not applicable")
+    if rowish:
+        raise RuntimeError("row-local coalesce route declined or not applicable")
     if route == "grouped" or (route is None and 65536 < num_supernodes < (1 << 26)):
         # more than 32 bits of (row, col) key: sort by supernode row only (half the radix passes) and order the short
         # rows in LDS; declines (count = -1) when a supernode row is too long for that
@@ -462,17 +514,19 @@ def _rows_sorted(edge_index: Tensor, row: Tensor) -> bool:
 
 
 def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
-                  max_rounds: Optional[int] = None) -> Tensor:
+                  max_rounds: Optional[int] = None, return_row_ptr: bool = False):
     """label[i] = min(i, partner) of a heavy-edge maximal matching (select/graclus_select.py:66 ->
     torch_cluster.graclus_cluster): handshake rounds on the device until a round matches nothing, however many that
     takes (a path with monotone weights matches one pair per round: n/2 rounds; torch_cluster iterates until done
     too).  ``max_rounds`` bounds the loop for callers that accept a non-maximal matching; if it is hit a
-    RuntimeWarning says so."""
+    RuntimeWarning says so.  ``return_row_ptr``: also return the int32 CSR offsets [num_nodes + 1] of the list when
+    it is row-sorted (else None) -- the matcher builds them anyway and SparseConnect can reuse them."""
     dev = N.require_device(edge_index, edge_weight)
     row, col = _edge_rows(edge_index)
     E = row.numel()
     w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
     label = torch.empty(num_nodes, dtype=torch.int64, device=dev)
+    sorted_ptr = None
     L = N.lib()
     st = N.stream_ptr(dev)
     # PyG lists are sorted by source: one comparison pass + round trip decides whether the CSR needs a sort at all
@@ -480,6 +534,7 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
     if E > 1 and _rows_sorted(edge_index, row):
         row_ptr, perm = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev), None
         N.check(L.tgp_rowptr_from_sorted_i64(N.ptr(row), E, num_nodes, N.ptr(row_ptr), st), "tgp_rowptr_from_sorted_i64")
+        sorted_ptr = row_ptr
     else:
         index = build_assign_index(row, num_nodes)
         row_ptr, perm = index.row_ptr, index.perm
@@ -503,7 +558,7 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
         import warnings
         warnings.warn(f"graclus_match stopped after max_rounds={max_rounds} rounds: the matching is not maximal",
                       RuntimeWarning)
-    return label
+    return (label, sorted_ptr) if return_row_ptr else label
 
 
 def _rows_f32(x: Tensor) -> Tensor:

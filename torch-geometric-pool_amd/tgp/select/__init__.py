@@ -242,6 +242,21 @@ class SelectOutput:
             self._assign_index = kernels.build_assign_index(self.cluster_index, self.num_supernodes)
         return self._assign_index
 
+    _edge_csr = None  # (weakref to an edge_index tensor, its version, int32 CSR offsets): set by GraclusSelect
+
+    def edge_csr_for(self, edge_index) -> Optional[Tensor]:
+        """CSR offsets a selector attached for exactly this edge_index tensor (same object, unmodified), else None."""
+        hit = self._edge_csr
+        if (hit is not None and isinstance(edge_index, Tensor) and hit[0]() is edge_index
+                and hit[1] == edge_index._version and hit[2].device == edge_index.device):
+            return hit[2]
+        return None
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_edge_csr", None)  # holds a weak reference (not picklable) to a tensor the copy does not share
+        return state
+
     def _drop_caches(self) -> None:
         self._assign_index = None
         self._lift_index = None
@@ -287,6 +302,7 @@ class SelectOutput:
             if name in self.__dict__:  # (a lazily built attribute that was never asked for stays lazy)
                 setattr(self, name, self._apply_to_value(getattr(self, name), func))
         self._drop_caches()
+        self._edge_csr = None  # belongs to a tensor on the old device
         return self
 
     def clone(self) -> "SelectOutput":
@@ -637,14 +653,20 @@ class GraclusSelect(Select):
         if edge_index.is_cuda:
             # native matching + scan-based relabelling (no sort): representatives keep their relative order
             from .. import kernels
-            pair = kernels.graclus_match(edge_index, edge_weight, num_nodes)
+            pair, row_ptr = kernels.graclus_match(edge_index, edge_weight, num_nodes, return_row_ptr=True)
             nodes = torch.arange(num_nodes, device=pair.device)
             rank = torch.cumsum(pair == nodes, 0) - 1
             assignment = rank[pair]
             k = int(rank[-1]) + 1 if num_nodes else 0
             s = torch.sparse_coo_tensor(torch.stack([nodes, assignment]), torch.ones(num_nodes, device=pair.device),
                                         size=(num_nodes, k), is_coalesced=True)
-            return SelectOutput(s=s, s_inv_op=self.s_inv_op)
+            so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
+            if row_ptr is not None:
+                # CSR offsets of the (row-sorted) list the matcher walked: SparseConnect skips its own pass over the
+                # row array when it is handed this very edge_index object, unchanged (identity + version counter)
+                import weakref
+                so._edge_csr = (weakref.ref(edge_index), edge_index._version, row_ptr)
+            return so
         pair = graclus_cluster(edge_index[0], edge_index[1], edge_weight, num_nodes)
         ids, assignment = torch.unique(pair, sorted=True, return_inverse=True)
         return SelectOutput(node_index=torch.arange(num_nodes, device=assignment.device), num_nodes=num_nodes,
