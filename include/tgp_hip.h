@@ -361,9 +361,10 @@ int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, const float* w 
 
 /* ------------------------------------------------------------------------------------
  * A9  KronConnect.forward (connect/kron_conn.py:117-165), block-batched: the batch Laplacian is block diagonal, so
- *     every graph's Kron reduction  L' = L[+,+] - L[+,-] L[-,-]^-1 L[-,+]  is independent.  One workgroup per graph
- *     forms the graph's dense Laplacian in fp64 (LDS up to 128 nodes, a workspace slab up to
- *     tgp_kron_batched_max_graph_nodes()), eliminates the dropped nodes, then A = -L', |A| > threshold, zero diagonal,
+ *     every graph's Kron reduction  L' = L[+,+] - L[+,-] L[-,-]^-1 L[-,+]  is independent.  The graph's dense
+ *     Laplacian is formed in fp64 -- in LDS by one workgroup per graph up to 128 nodes; in a workspace slab, reduced
+ *     panel by panel by many workgroups per graph, up to tgp_kron_batched_max_graph_nodes() -- the dropped nodes are
+ *     eliminated, then A = -L', |A| > threshold, zero diagonal,
  *     fp32 cast; edges come out in row-major order of the pooled batch (what the reference's CSR -> COO gives).
  *     Entries: CSR over ALL nodes of the batch (`indptr` [N+1], `col` [nnz], values fp32 or fp64 or NULL = ones,
  *     optional `perm` = CSR slot -> entry).  from_adjacency = 0: the entries ARE the Laplacian (SelectOutput.L);
@@ -376,18 +377,23 @@ int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, const float* w 
  *     beyond the size limit do not decline the call, they are left out (no scratch, no edges) and the caller reduces
  *     those few graphs itself (pass max_graph_nodes = min(longest graph, tgp_kron_batched_max_graph_nodes())).
  * ---------------------------------------------------------------------------------- */
-size_t tgp_kron_batched_workspace_bytes(int64_t num_nodes, int64_t num_graphs, int64_t max_graph_nodes);
-#define TGP_KRON_FROM_ADJACENCY 1
-#define TGP_KRON_SKIP_OVERSIZE 2
+size_t tgp_kron_batched_workspace_bytes(int64_t num_nodes, int64_t num_graphs, int64_t max_graph_nodes,
+                                        int64_t cap_dense, int64_t cap_big);
 int tgp_kron_batched_max_graph_nodes(void);
-int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col, const float* val_f32 /* NULL ok */,
-                           const double* val_f64 /* NULL ok */, const int32_t* perm /* NULL ok */, int from_adjacency,
-                           int64_t num_nodes, int64_t nnz, const int64_t* graph_ptr, int64_t num_graphs,
-                           int64_t max_graph_nodes, const int64_t* node_index, int64_t num_kept, double threshold,
-                           void* ws, size_t ws_bytes, int64_t* d_count, void* stream);
+/* cap_dense / cap_big: sizes (elements) of the k x k result buffer and of the fp64 scratch for graphs beyond the LDS
+ * capacity.  Exact figures from the caller (sum over graphs of n_g^2; sum of n_g * (n_g | 1) over the graphs of more
+ * than 128 nodes) keep the workspace at what the batch needs; -1 = the worst case from max_graph_nodes alone
+ * (num_nodes * max_graph_nodes).  The real totals are checked on the device (too small: *d_count = -1).
+ * num_big: how many graphs have more than 128 (and at most tgp_kron_batched_max_graph_nodes()) nodes, an upper
+ * bound, -1 = unknown (num_graphs): it sizes the launches of the multi-workgroup elimination those graphs take. */
+int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col, const float* val32, const double* val64,
+                           const int32_t* perm, int from_adjacency, int64_t num_nodes, int64_t nnz,
+                           const int64_t* graph_ptr, int64_t num_graphs, int64_t max_graph_nodes, int64_t cap_dense,
+                           int64_t cap_big, int64_t num_big, const int64_t* node_index, int64_t num_kept,
+                           double threshold, void* ws, size_t ws_bytes, int64_t* d_count, void* stream);
 int tgp_kron_batched_fill(const void* ws, int64_t num_nodes, int64_t num_graphs, int64_t max_graph_nodes,
-                          const int64_t* graph_ptr, int64_t num_out, int64_t* out_row, int64_t* out_col,
-                          float* out_weight, void* stream);
+                          int64_t cap_dense, int64_t cap_big, int64_t num_big, const int64_t* graph_ptr,
+                          int64_t num_out, int64_t* out_row, int64_t* out_col, float* out_weight, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * A13  MLPSelect's last layer, one pass over the node features

@@ -104,8 +104,8 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.tgp_dense_pool_f32(p, p, p, 1, 1 << 31, 4, 4, 0, 1e-8, None, p, None, p, p, 1 << 20, None) == -4  # TGP_ERR_RANGE
     assert lib.tgp_block_diag_count(p, 70000, 70000, None, 0, 1e-8, p, 1 << 20, p, None) == -4
     # Kron: fp32 and fp64 values at once is a caller error; sizes beyond the int32 internals are refused
-    assert lib.tgp_kron_batched_count(p, p, p, p, None, 0, 4, 4, p, 1, 4, p, 2, 1e-2, p, 1 << 20, p, None) == -1
-    assert lib.tgp_kron_batched_count(p, p, None, None, None, 0, 1 << 31, 4, p, 1, 4, p, 2, 1e-2, p, 1 << 20, p, None) == -4
+    assert lib.tgp_kron_batched_count(p, p, p, p, None, 0, 4, 4, p, 1, 4, -1, -1, -1, p, 2, 1e-2, p, 1 << 20, p, None) == -1
+    assert lib.tgp_kron_batched_count(p, p, None, None, None, 0, 1 << 31, 4, p, 1, 4, -1, -1, -1, p, 2, 1e-2, p, 1 << 20, p, None) == -4
 
 
 def test_ctypes_signatures_match_the_header_parameter_by_parameter():

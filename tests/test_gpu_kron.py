@@ -413,3 +413,43 @@ def test_ndp_pooler_end_to_end_stays_on_device(dev, monkeypatch):
     levels = get_pooler("ndp").to(dev).multi_level_precoarsening(levels=2, edge_index=ei.to(dev), edge_weight=ew.to(dev),
                                                                  batch=batch.to(dev), num_nodes=n)
     assert len(levels) == 2 and levels[1].so.num_nodes == levels[0].so.num_supernodes
+
+
+def test_kron_singular_block_in_a_mid_size_graph_is_damped(dev):
+    """r3: graphs of 129..1024 nodes are reduced panel by panel by many workgroups; one with an exactly singular
+    L[-,-] (a dropped-only component) is flagged by the panel kernels and redone with the reference's 1e-6 damping
+    (kron_conn.py:131-135), while its neighbours in the batch keep the fast route."""
+    from tgp.connect import KronConnect
+    import tgp_oracle as O
+    ei, ew, batch, idx_pos = make_batch([300, 50, 200], seed=21)
+    n = batch.numel()
+    # two extra dropped nodes forming their own component inside graph 2 (appended: graph 2 is the last one)
+    a, b = n, n + 1
+    ei = torch.cat([ei, torch.tensor([[a, b], [b, a]])], 1)
+    ew = torch.cat([ew, torch.tensor([0.7, 0.7])])
+    batch = torch.cat([batch, torch.tensor([2, 2])])
+    n += 2
+    L = torch.from_numpy(O.laplacian_scipy(ei, ew.double(), n).toarray())
+    keep = torch.zeros(n, dtype=torch.bool)
+    keep[idx_pos] = True
+    rows, cols, vals = [], [], []
+    base = 0
+    for gi in range(3):
+        nodes = (batch == gi).nonzero().view(-1)
+        pos, neg = nodes[keep[nodes]], nodes[~keep[nodes]]
+        lnn = L[neg][:, neg]
+        if gi == 2:
+            lnn = lnn + 1e-6 * torch.eye(neg.numel(), dtype=torch.float64)
+        lnew = L[pos][:, pos] - L[pos][:, neg] @ torch.linalg.solve(lnn, L[neg][:, pos])
+        am = -lnew
+        am = am * (am.abs() > 1e-2)
+        am.fill_diagonal_(0)
+        nz = am.nonzero()
+        rows.append(nz[:, 0] + base); cols.append(nz[:, 1] + base); vals.append(am[nz[:, 0], nz[:, 1]].float())
+        base += pos.numel()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = native_only(KronConnect())(ei.to(dev), so_of(idx_pos, n, dev), edge_weight=ew.to(dev),
+                                         batch=batch.to(dev))
+    assert torch.equal(out[0].cpu(), torch.stack([torch.cat(rows), torch.cat(cols)]))
+    torch.testing.assert_close(out[1].cpu(), torch.cat(vals), rtol=1e-5, atol=1e-7)

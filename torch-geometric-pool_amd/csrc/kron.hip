@@ -7,7 +7,8 @@
 // eliminates the dropped nodes by Gaussian elimination without pivoting (L[-,-] is a principal block of a Laplacian:
 // a symmetric, weakly diagonally dominant M-matrix, for which elimination in any order is stable); what is left in the
 // trailing k x k block IS the Schur complement.  Graphs up to KRON_LDS_MAX_N nodes keep the matrix in LDS; larger ones
-// (up to KRON_MAX_N) use a slab of the workspace (the same arithmetic, blocked: kron_eliminate_blocked); beyond that the call declines
+// (up to KRON_MAX_N) use a slab of the workspace and MANY workgroups (one launch per panel: kron_big_panel_kernel / kron_big_trail_kernel, the same
+// arithmetic); beyond that the call declines
 // (*d_count = -1) and the host keeps its library / scipy route for that batch.
 //
 // Update rule M[i][j] -= (M[i][p] * M[p][j]) * (1 / M[p][p]): the product commutes, so a symmetric L gives a bitwise
@@ -54,11 +55,16 @@ __global__ __launch_bounds__(1024) void kron_plan_kernel(const int64_t* __restri
                                                          const uint32_t* __restrict__ rank,
                                                          int64_t* __restrict__ sq_off, int64_t* __restrict__ big_off,
                                                          int64_t cap_dense, int64_t cap_big, int skip_oversize,
+                                                         int lds_cap, int64_t declared_max,
+                                                         int* __restrict__ big_list,
+                                                         int* __restrict__ big_count, int big_cap,
                                                          int* __restrict__ status) {
   __shared__ int64_t s_w[2][16];
   __shared__ int64_t s_carry[2];
+  __shared__ int s_nbig;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid < 2) s_carry[tid] = 0;
+  if (tid == 0) s_nbig = 0;
   __syncthreads();
   for (int base = 0; base < B; base += 1024) {
     const int g = base + tid;
@@ -71,7 +77,12 @@ __global__ __launch_bounds__(1024) void kron_plan_kernel(const int64_t* __restri
       if (n < 0 || (oversize && !skip_oversize)) atomicOr(status, KRON_TOO_LARGE);
       if (!oversize) {  // (skipped graphs take no scratch and emit nothing: the caller reduces them itself)
         sq = k * k;
-        if (n > KRON_LDS_MAX_N && k > 0) big = n * (n | 1);
+        if (n > lds_cap && k > 0) big = n * (n | 1);
+        if (n > declared_max) atomicOr(status, KRON_TOO_LARGE);  // the caller's max_graph_nodes sized the launches
+        if (n > lds_cap && k > 0) {  // reduced by the multi-workgroup kernels: any order in the list will do
+          const int slot = atomicAdd(&s_nbig, 1);
+          if (slot < big_cap) big_list[slot] = g; else atomicOr(status, KRON_TOO_LARGE);
+        }
       }
     }
     const int64_t isq = wave_incl_scan64(sq), ibig = wave_incl_scan64(big);
@@ -95,6 +106,7 @@ __global__ __launch_bounds__(1024) void kron_plan_kernel(const int64_t* __restri
   if (tid == 0) {
     sq_off[B] = s_carry[0];
     big_off[B] = s_carry[1];
+    *big_count = s_nbig < big_cap ? s_nbig : big_cap;
     if (s_carry[0] > cap_dense || s_carry[1] > cap_big) atomicOr(status, KRON_TOO_LARGE);
   }
 }
@@ -116,6 +128,13 @@ struct KronArgs {
   int* status;
   double threshold;
   int lds_cap;             // graphs up to this many nodes use LDS
+  int lds_lo;              // this launch of the LDS kernel takes graphs of lds_lo < n <= lds_hi nodes
+  int lds_hi;
+  const int* big_list;     // graphs beyond it (and up to KRON_MAX_N), kept nodes > 0
+  const int* big_count;
+  int* sing;               // [B] exactly singular L[-,-] met: the graph is redone with damping
+  double* big_inv;         // [num_big][KRON_SNB] reciprocal pivots of the step in flight
+  uint32_t* rowcnt;        // [num_kept] survivors per pooled row (big graphs only; NULL: not wanted)
 };
 
 template <int THREADS>
@@ -268,6 +287,7 @@ __device__ __forceinline__ void kron_graph(const KronArgs& a, double* M, int g, 
   float* out = a.dense + a.sq_off[g];
   uint32_t mine = 0;
   for (int i = w; i < k; i += NW) {
+    uint32_t rowc = 0;
     for (int j0 = 0; j0 < k; j0 += 64) {
       const int j = j0 + lane;
       bool keep = false;
@@ -279,8 +299,10 @@ __device__ __forceinline__ void kron_graph(const KronArgs& a, double* M, int g, 
         keep = keep && f != 0.f;
         out[static_cast<int64_t>(i) * k + j] = f;
       }
-      mine += __popcll(__ballot(keep));
+      rowc += __popcll(__ballot(keep));
     }
+    mine += rowc;
+    if (a.rowcnt && lane == 0) a.rowcnt[r0 + i] = rowc;
   }
   if (lane == 0 && mine) atomicAdd(s_cnt, mine);
   __syncthreads();
@@ -295,9 +317,9 @@ __global__ __launch_bounds__(KRON_THREADS) void kron_schur_lds_kernel(KronArgs a
   const int g = blockIdx.x;
   const int64_t p0 = a.graph_ptr[g], p1 = a.graph_ptr[g + 1];
   const int64_t n64 = p1 - p0;
-  if (n64 <= 0 || n64 > a.lds_cap) {
-    if (n64 <= 0 && threadIdx.x == 0) a.counts[g] = 0;
-    return;  // empty, or handled by the big-graph kernel
+  if (n64 <= a.lds_lo || n64 > a.lds_hi) {
+    if (n64 <= 0 && a.lds_lo == 0 && threadIdx.x == 0) a.counts[g] = 0;
+    return;  // empty, another size class of this kernel, or handled by the big-graph kernels
   }
   const uint32_t r0 = a.rank[p0];
   const int k = static_cast<int>(a.rank[p1] - r0);
@@ -308,25 +330,283 @@ __global__ __launch_bounds__(KRON_THREADS) void kron_schur_lds_kernel(KronArgs a
   kron_graph<KRON_THREADS, false>(a, s_M, g, p0, static_cast<int>(n64), k, r0, &s_flag, &s_cnt);
 }
 
-// graphs beyond the LDS capacity: the same elimination on a slab of the workspace, one 1024-thread workgroup each
-__global__ __launch_bounds__(KRON_BIG_THREADS) void kron_schur_big_kernel(KronArgs a) {
+// ------------------------------------------------------------------------------------------------------------
+// r3: graphs of 129 .. 1024 nodes on MANY workgroups.  One workgroup walking a 1000-node matrix through 62 panels
+// pulled ~1 GB through a single CU: 10 ms for a batch whose 2048 small graphs take 0.25 ms (profiles/r02_kron.txt).
+// The same blocked elimination is now one launch per panel of KRON_SNB pivots over every big graph of the batch, a
+// 64 x 64 tile of the trailing matrix per workgroup: the tile's workgroup factors the panel's diagonal block and its
+// own slices of the pivot rows U and pivot columns C redundantly in LDS, then applies the panel to its tile, each
+// element receiving the pivots' updates in order with the same (c * u) * (1 / pivot) arithmetic as the single-
+// workgroup loops above (bit-identical; the launch boundary is the only synchronisation: no spin, no fence).
+// A graph with an exactly singular L[-,-] is flagged and redone (build + damped elimination) by the one-workgroup
+// kernel; it is the rare case (a connected component made of dropped nodes only).
+constexpr int KRON_SNB = 32;   // pivots per launch
+constexpr int KRON_TILE = 64;
+
+struct BigGraph {
+  int g, n, k, m, ld;
+  int64_t p0;
+  uint32_t r0;
+  double* M;
+};
+
+__device__ __forceinline__ bool kron_big_graph(const KronArgs& a, int b, BigGraph* out) {
+  if (b >= *a.big_count) return false;
+  BigGraph q;
+  q.g = a.big_list[b];
+  q.p0 = a.graph_ptr[q.g];
+  q.n = static_cast<int>(a.graph_ptr[q.g + 1] - q.p0);
+  q.r0 = a.rank[q.p0];
+  q.k = static_cast<int>(a.rank[q.p0 + q.n] - q.r0);
+  q.m = q.n - q.k;
+  q.ld = q.n | 1;
+  q.M = a.big + a.big_off[q.g];
+  *out = q;
+  return true;
+}
+
+// M (zeroed by a memset) += the graph's Laplacian entries, ordered (dropped nodes, kept nodes): 256 nodes per workgroup
+__global__ __launch_bounds__(256) void kron_big_build_kernel(KronArgs a) {
+  BigGraph q;
+  if (!kron_big_graph(a, blockIdx.y, &q)) return;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= q.n) return;
+  const int64_t v = q.p0 + t;
+  const uint32_t rv = a.rank[v] - q.r0;
+  const bool keep_v = a.rank[v + 1] - a.rank[v] != 0;
+  const int lr = keep_v ? q.m + static_cast<int>(rv) : t - static_cast<int>(rv);
+  for (int e = a.indptr[v]; e < a.indptr[v + 1]; ++e) {
+    const int idx = a.perm ? a.perm[e] : e;
+    const int64_t c = a.col[idx];
+    if (c < q.p0 || c >= q.p0 + q.n) {
+      atomicOr(a.status, KRON_CROSS_GRAPH);
+      continue;
+    }
+    const double val = a.val64 ? a.val64[idx] : (a.val32 ? static_cast<double>(a.val32[idx]) : 1.0);
+    const uint32_t rc = a.rank[c] - q.r0;
+    const bool keep_c = a.rank[c + 1] - a.rank[c] != 0;
+    const int lc = keep_c ? q.m + static_cast<int>(rc) : static_cast<int>(c - q.p0) - static_cast<int>(rc);
+    if (a.from_adj) {
+      if (c != v) {
+        atomicAdd(&q.M[static_cast<long>(lr) * q.ld + lc], -val);
+        atomicAdd(&q.M[static_cast<long>(lr) * q.ld + lr], val);
+      }
+    } else {
+      atomicAdd(&q.M[static_cast<long>(lr) * q.ld + lc], val);
+    }
+  }
+}
+
+// Panel kernel: workgroup (slice, graph) factors the diagonal block D of the step's KRON_SNB pivots (redundantly: it is
+// 32 x 32) and ITS 64-column slice of the pivot rows U and 64-row slice of the pivot columns C, and writes the updated
+// slices back in place; slice 0 also stores the reciprocal pivots.  Register ownership (dependent LDS read-modify-
+// write loops took ~30 us per tile; with every thread's elements in registers a pivot costs one barrier and a handful
+// of independent fp64 operations):
+//   U slice [32][64]: thread (j = tid & 63, g = tid >> 6) holds rows g, g + 4, ... of column j      (8 values)
+//   C slice [64][32]: thread (i = tid & 63, g = tid >> 6) holds columns g, g + 4, ... of row i       (8 values)
+//   D block [32][32]: thread (r = tid >> 3, h = tid & 7) holds columns h, h + 8, h + 16, h + 24      (4 values)
+// Row p of U, column p of C and the D block live in LDS as well: a pivot step reads only them.
+// (Measured r3, 1000-node graph: this form 20 us per launch; one thread per U column / C row doing the whole forward
+//  substitution in registers, no barriers: 41 us -- 496 dependent steps on two waves lose to 32 wide ones.)
+__global__ __launch_bounds__(256) void kron_big_panel_kernel(KronArgs a, int step) {
+  __shared__ double sD[KRON_SNB][KRON_SNB + 1];
+  __shared__ double sU[KRON_SNB][KRON_TILE];
+  __shared__ double sC[KRON_TILE][KRON_SNB + 1];
+  __shared__ double s_inv[KRON_SNB + 1];
+  __shared__ int s_bad;
+  BigGraph q;
+  if (!kron_big_graph(a, blockIdx.y, &q)) return;
+  const int p0 = step * KRON_SNB;
+  if (p0 >= q.m) return;
+  const int nb = q.m - p0 < KRON_SNB ? q.m - p0 : KRON_SNB;
+  const int T0 = p0 + nb;
+  const int S0 = T0 + blockIdx.x * KRON_TILE;  // this slice: columns S0.. of U, rows S0.. of C
+  if (S0 >= q.n) return;
+  const int width = q.n - S0 < KRON_TILE ? q.n - S0 : KRON_TILE;
+  const int tid = threadIdx.x;
+  const long ld = q.ld;
+  double* M = q.M;
+  const int j = tid & 63, g = tid >> 6;
+  double u[8], c[8], d[4];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int r = g + 4 * t;
+    u[t] = (r < nb && j < width) ? M[(p0 + r) * ld + S0 + j] : 0.0;
+    c[t] = (r < nb && j < width) ? M[(S0 + j) * ld + p0 + r] : 0.0;  // (row j of the C slice, column r)
+    sU[r][j] = u[t];
+    sC[j][r] = c[t];
+  }
+  const int dr = tid >> 3, dh = tid & 7;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int cc = dh + 8 * t;
+    d[t] = (dr < nb && cc < nb) ? M[(p0 + dr) * ld + p0 + cc] : 0.0;
+    sD[dr][cc] = d[t];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double piv = sD[0][0];
+    s_inv[0] = piv != 0.0 ? 1.0 / piv : 0.0;
+    s_bad = (piv == 0.0 || !(piv == piv)) ? 1 : 0;
+  }
+  __syncthreads();
+  // One barrier per pivot: step p READS row p / column p of the LDS images (and 1 / pivot), and WRITES only rows and
+  // columns beyond p (the D entries, row p + 1 of U, column p + 1 of C, the next reciprocal), so the write-backs of step
+  // p need no barrier against its own reads.  The owner of D[p+1][p+1] takes the reciprocal as soon as that entry is
+  // final, off the other threads' critical path.
+  for (int p = 0; p < nb; ++p) {
+    const double inv = s_inv[p];
+    {  // D: rows / columns beyond the pivot
+      const double crp = sD[dr][p];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int cc = dh + 8 * t;
+        const double upd = d[t] - (crp * sD[p][cc]) * inv;
+        if (dr > p && cc > p && crp != 0.0) d[t] = upd;
+        if (dr > p && cc > p) sD[dr][cc] = d[t];
+        if (dr == p + 1 && cc == p + 1) {
+          const double piv = d[t];
+          s_inv[p + 1] = piv != 0.0 ? 1.0 / piv : 0.0;
+          if ((piv == 0.0 || !(piv == piv)) && p + 1 < nb) s_bad = 1;
+        }
+      }
+    }
+    {  // U slice: rows beyond the pivot; C slice: columns beyond the pivot
+      const double up = sU[p][j], cip = sC[j][p];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int r = g + 4 * t;
+        const double crp = sD[r][p];
+        const double nu = u[t] - (crp * up) * inv;
+        if (r > p && crp != 0.0) u[t] = nu;
+        const double nc = c[t] - (cip * sD[p][r]) * inv;
+        if (r > p && cip != 0.0) c[t] = nc;
+      }
+    }
+    if (((p + 1) & 3) == g && p + 1 < KRON_SNB) {  // the owners of row / column p + 1 publish it for the next pivot
+      const int t = (p + 1) >> 2;
+      double uv = 0.0, cv = 0.0;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        uv = x == t ? u[x] : uv;
+        cv = x == t ? c[x] : cv;
+      }
+      sU[p + 1][j] = uv;
+      sC[j][p + 1] = cv;
+    }
+    __syncthreads();
+  }
+  // the factored slices go back in place: the trailing kernel (next launch) reads them
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int r = g + 4 * t;
+    if (r < nb && j < width) {
+      M[(p0 + r) * ld + S0 + j] = u[t];
+      M[(S0 + j) * ld + p0 + r] = c[t];
+    }
+  }
+  if (blockIdx.x == 0) {
+    if (tid < nb) a.big_inv[static_cast<long>(blockIdx.y) * KRON_SNB + tid] = s_inv[tid];
+    if (tid == 0 && s_bad) a.sing[q.g] = 1;
+  }
+}
+
+// Trailing kernel: one 64 x 64 tile per workgroup, M[i][j] -= sum over the step's pivots of (C[i][p] * U[p][j]) * inv_p, in
+// pivot order (the arithmetic of the single-workgroup loops); thread = (column j, rows g, g + 4, ...).
+// (64 x 128 tiles with two columns per thread measured slower: 16 vs 11.6 us per launch.)
+__global__ __launch_bounds__(256) void kron_big_trail_kernel(KronArgs a, int step) {
+  __shared__ double sU[KRON_SNB][KRON_TILE];
+  __shared__ double sC[KRON_TILE][KRON_SNB + 1];
+  __shared__ double s_inv[KRON_SNB];
+  BigGraph q;
+  if (!kron_big_graph(a, blockIdx.y, &q)) return;
+  const int p0 = step * KRON_SNB;
+  if (p0 >= q.m) return;
+  const int nb = q.m - p0 < KRON_SNB ? q.m - p0 : KRON_SNB;
+  const int T0 = p0 + nb, rem = q.n - T0;
+  const int nt = (rem + KRON_TILE - 1) / KRON_TILE;
+  const int tile = blockIdx.x;
+  if (tile >= nt * nt) return;
+  const int R0 = T0 + (tile / nt) * KRON_TILE, C0 = T0 + (tile % nt) * KRON_TILE;
+  const int rows = q.n - R0 < KRON_TILE ? q.n - R0 : KRON_TILE, cols = q.n - C0 < KRON_TILE ? q.n - C0 : KRON_TILE;
+  const int tid = threadIdx.x;
+  const long ld = q.ld;
+  double* M = q.M;
+  const int j = tid & 63, g = tid >> 6;
+  double v[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int i = g + 4 * t;
+    v[t] = (i < rows && j < cols) ? M[(R0 + i) * ld + C0 + j] : 0.0;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int r = g + 4 * t;
+    sU[r][j] = (r < nb && j < cols) ? M[(p0 + r) * ld + C0 + j] : 0.0;
+  }
+  for (int e = tid; e < KRON_TILE * KRON_SNB; e += 256) {  // a thread reads 32 contiguous bytes of a C row
+    const int i = e / KRON_SNB, c = e % KRON_SNB;
+    sC[i][c] = (i < rows && c < nb) ? M[(R0 + i) * ld + p0 + c] : 0.0;
+  }
+  if (tid < KRON_SNB) s_inv[tid] = a.big_inv[static_cast<long>(blockIdx.y) * KRON_SNB + tid];
+  __syncthreads();
+  for (int p = 0; p < nb; ++p) {
+    const double up = sU[p][j], inv = s_inv[p];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      // (no c != 0 test here: (0 * u) * inv is 0 unless a pivot was singular, and such a graph is redone anyway;
+      //  v - 0 differs from v at most in the sign of a zero, which no later comparison sees)
+      v[t] = v[t] - (sC[g + 4 * t][p] * up) * inv;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int i = g + 4 * t;
+    if (i < rows && j < cols) M[(R0 + i) * ld + C0 + j] = v[t];
+  }
+}
+
+// flagged graphs only: build + elimination with the reference's damping, threshold and count, on one workgroup
+__global__ __launch_bounds__(KRON_BIG_THREADS) void kron_big_redo_kernel(KronArgs a) {
   extern __shared__ __attribute__((aligned(16))) double s_panel[];  // U [NB][n] | C [n][NB]
   __shared__ int s_flag;
   __shared__ uint32_t s_cnt;
   __shared__ double s_inv[KRON_NB];
-  const int g = blockIdx.x;
-  const int64_t p0 = a.graph_ptr[g], p1 = a.graph_ptr[g + 1];
-  const int64_t n64 = p1 - p0;
-  if (n64 <= a.lds_cap || n64 > KRON_MAX_N) return;
-  const uint32_t r0 = a.rank[p0];
-  const int k = static_cast<int>(a.rank[p1] - r0);
-  if (k == 0) {
-    if (threadIdx.x == 0) a.counts[g] = 0;
-    return;
+  BigGraph q;
+  if (!kron_big_graph(a, blockIdx.x, &q)) return;
+  if (a.sing[q.g] == 0) return;
+  kron_graph<KRON_BIG_THREADS, true>(a, q.M, q.g, q.p0, q.n, q.k, q.r0, &s_flag, &s_cnt, s_panel,
+                                     s_panel + static_cast<size_t>(KRON_NB) * q.n, s_inv);
+}
+
+// A = -L', |A| > threshold, zero diagonal, fp32 (kron_conn.py:141-146) for the graphs the step kernels reduced:
+// 16 rows of the k x k block per workgroup
+__global__ __launch_bounds__(256) void kron_big_finish_kernel(KronArgs a) {
+  BigGraph q;
+  if (!kron_big_graph(a, blockIdx.y, &q)) return;
+  if (a.sing[q.g] != 0) return;  // redone (and counted) by kron_big_redo_kernel
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* out = a.dense + a.sq_off[q.g];
+  uint32_t mine = 0;
+  const int i1 = (blockIdx.x + 1) * 16 < q.k ? (blockIdx.x + 1) * 16 : q.k;
+  for (int i = blockIdx.x * 16 + w; i < i1; i += 4) {
+    uint32_t rowc = 0;
+    for (int j0 = 0; j0 < q.k; j0 += 64) {
+      const int j = j0 + lane;
+      bool keep = false;
+      if (j < q.k) {
+        const double v = -q.M[static_cast<long>(q.m + i) * q.ld + q.m + j];
+        keep = i != j && v != 0.0 && (a.threshold > 0.0 ? fabs(v) > a.threshold : v == v);
+        const float f = keep ? static_cast<float>(v) : 0.f;
+        keep = keep && f != 0.f;
+        out[static_cast<int64_t>(i) * q.k + j] = f;
+      }
+      rowc += __popcll(__ballot(keep));
+    }
+    mine += rowc;
+    if (lane == 0) a.rowcnt[q.r0 + i] = rowc;
   }
-  const int n = static_cast<int>(n64);
-  kron_graph<KRON_BIG_THREADS, true>(a, a.big + a.big_off[g], g, p0, n, k, r0, &s_flag, &s_cnt, s_panel,
-                                     s_panel + static_cast<size_t>(KRON_NB) * n, s_inv);
+  if (lane == 0 && mine) atomicAdd(&a.counts[q.g], mine);
 }
 
 __global__ void kron_finish_count_kernel(const int* __restrict__ status, int64_t* __restrict__ d_count) {
@@ -338,14 +618,14 @@ __global__ __launch_bounds__(KRON_THREADS) void kron_fill_kernel(const int64_t* 
                                                                  const uint32_t* __restrict__ rank,
                                                                  const int64_t* __restrict__ sq_off,
                                                                  const float* __restrict__ dense,
-                                                                 const uint32_t* __restrict__ out_off,
+                                                                 const uint32_t* __restrict__ out_off, int lds_cap,
                                                                  int64_t* __restrict__ out_row,
                                                                  int64_t* __restrict__ out_col,
                                                                  float* __restrict__ out_w) {
-  __shared__ uint32_t s_row[KRON_MAX_N + 1];
+  __shared__ uint32_t s_row[KRON_LDS_MAX_N + 1];
   const int g = blockIdx.x;
   const int64_t p0 = graph_ptr[g], p1 = graph_ptr[g + 1];
-  if (p1 <= p0 || p1 - p0 > KRON_MAX_N) return;  // (an oversize graph was skipped by the count pass: it has no block)
+  if (p1 <= p0 || p1 - p0 > lds_cap) return;  // (graphs beyond the LDS capacity: kron_big_fill_kernel; oversize: no block)
   const uint32_t r0 = rank[p0];
   const int k = static_cast<int>(rank[p1] - r0);
   if (k == 0) return;
@@ -386,6 +666,49 @@ __global__ __launch_bounds__(KRON_THREADS) void kron_fill_kernel(const int64_t* 
   }
 }
 
+// The same for a graph of 129 .. 1024 nodes, 16 rows of its k x k block per workgroup (one workgroup walking 500 rows
+// took 0.58 ms): the rows' survivor counts come from the finish pass, the workgroup adds up those in front of its own
+// block, then its four waves emit four rows each.
+__global__ __launch_bounds__(256) void kron_big_fill_kernel(KronArgs a, const uint32_t* __restrict__ out_off,
+                                                            int64_t* __restrict__ out_row,
+                                                            int64_t* __restrict__ out_col,
+                                                            float* __restrict__ out_w) {
+  __shared__ uint32_t s_w[4];
+  __shared__ uint32_t s_rowcnt[16];
+  BigGraph q;
+  if (!kron_big_graph(a, blockIdx.y, &q)) return;
+  const int i0 = blockIdx.x * 16;
+  if (i0 >= q.k) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* d = a.dense + a.sq_off[q.g];
+  uint32_t before = 0;  // survivors of the graph's rows in front of this block (per-row counts from the finish pass)
+  for (int i = threadIdx.x; i < i0; i += 256) before += a.rowcnt[q.r0 + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  if (lane == 0) s_w[w] = before;
+  if (threadIdx.x < 16) s_rowcnt[threadIdx.x] = i0 + threadIdx.x < q.k ? a.rowcnt[q.r0 + i0 + threadIdx.x] : 0u;
+  __syncthreads();
+  uint32_t base = out_off[q.g] + s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  for (int rr = w; rr < 16; rr += 4) {
+    const int i = i0 + rr;
+    if (i >= q.k) break;
+    uint32_t pos = base;
+    for (int x = 0; x < rr; ++x) pos += s_rowcnt[x];
+    for (int j0 = 0; j0 < q.k; j0 += 64) {
+      const int j = j0 + lane;
+      const float v = j < q.k ? d[static_cast<int64_t>(i) * q.k + j] : 0.f;
+      const unsigned long long mk = __ballot(v != 0.f);
+      if (v != 0.f) {
+        const uint32_t o = pos + __popcll(mk & lanemask_lt());
+        out_row[o] = static_cast<int64_t>(q.r0) + i;
+        out_col[o] = static_cast<int64_t>(q.r0) + j;
+        out_w[o] = v;
+      }
+      pos += __popcll(mk);
+    }
+  }
+}
+
 struct KronWs {
   uint32_t* flags;   // [N+2] keep flags
   uint32_t* rank;    // [N+2] exclusive prefix sums
@@ -395,22 +718,31 @@ struct KronWs {
   int64_t* big_off;  // [B+1]
   uint32_t* counts;  // [B]
   uint32_t* out_off; // [B]
+  int* big_list;     // [B] graphs beyond the LDS capacity
+  int* big_count;
+  int* sing;         // [B]
+  double* big_inv;   // [B][32]
   uint32_t* scan_tiles;  // multi-block scan scratch
   float* dense;
   double* big;
   int64_t cap_dense, cap_big;
 };
 
-static void kron_caps(int64_t N, int64_t max_nodes, int64_t* cap_dense, int64_t* cap_big) {
-  // sum_g k_g^2 <= sum_g n_g * max_nodes = N * max_nodes; scratch matrices only for graphs beyond the LDS capacity
-  *cap_dense = N * (max_nodes > 0 ? max_nodes : 1);
-  *cap_big = max_nodes > KRON_LDS_MAX_N ? N * ((max_nodes | 1) + 1) : 0;
+// Sizes of the two big buffers: the caller's exact figures when it has them (sum over graphs of n_g^2 bounds the
+// k_g x k_g results; sum of n_g * (n_g | 1) over the graphs beyond the LDS capacity is the scratch), else the
+// worst case from the longest graph alone (N * max_nodes: one 1000-node graph among 80 k nodes of small ones made that
+// 1 GB where 12 MB are needed).  The plan kernel checks the real totals against them and declines when they do not fit.
+static void kron_caps(int64_t N, int64_t max_nodes, int64_t want_dense, int64_t want_big, int64_t* cap_dense,
+                      int64_t* cap_big) {
+  *cap_dense = want_dense >= 0 ? want_dense : N * (max_nodes > 0 ? max_nodes : 1);
+  *cap_big = want_big >= 0 ? want_big : (max_nodes > KRON_LDS_MAX_N ? N * ((max_nodes | 1) + 1) : 0);
 }
 
-static KronWs carve_kron(void* ws, int64_t N, int64_t B, int64_t max_nodes) {
+static size_t kron_layout(void* ws, int64_t N, int64_t B, int64_t max_nodes, int64_t want_dense, int64_t want_big,
+                          KronWs* out) {
   Carver c(ws);
   KronWs s;
-  kron_caps(N, max_nodes, &s.cap_dense, &s.cap_big);
+  kron_caps(N, max_nodes, want_dense, want_big, &s.cap_dense, &s.cap_big);
   s.flags = c.take<uint32_t>(N + 2);
   s.rank = c.take<uint32_t>(N + 2);
   s.scan_total = c.take<int64_t>(1);
@@ -419,24 +751,25 @@ static KronWs carve_kron(void* ws, int64_t N, int64_t B, int64_t max_nodes) {
   s.big_off = c.take<int64_t>(B + 1);
   s.counts = c.take<uint32_t>(B + 1);
   s.out_off = c.take<uint32_t>(B + 1);
+  s.big_list = c.take<int>(B + 1);
+  s.big_count = c.take<int>(4);
+  s.sing = c.take<int>(B + 1);
+  s.big_inv = c.take<double>(static_cast<size_t>(B + 1) * 32);
   s.scan_tiles = c.take<uint32_t>(2 * static_cast<size_t>(cdiv(N + 2, SCAN_TILE)) + 16);
-  s.dense = c.take<float>(s.cap_dense);
-  s.big = c.take<double>(s.cap_big);
-  return s;
+  s.dense = c.take<float>(s.cap_dense > 0 ? s.cap_dense : 1);
+  s.big = c.take<double>(s.cap_big > 0 ? s.cap_big : 1);
+  if (out) *out = s;
+  return c.off;
 }
 
 }  // namespace tgp
 
 using namespace tgp;
 
-extern "C" size_t tgp_kron_batched_workspace_bytes(int64_t N, int64_t B, int64_t max_graph_nodes) {
+extern "C" size_t tgp_kron_batched_workspace_bytes(int64_t N, int64_t B, int64_t max_graph_nodes, int64_t cap_dense,
+                                                   int64_t cap_big) {
   if (N < 0 || B < 0 || max_graph_nodes < 0) return 0;
-  int64_t cd, cb;
-  kron_caps(N, max_graph_nodes, &cd, &cb);
-  return align_up((N + 2) * sizeof(uint32_t)) * 2 + align_up(sizeof(int64_t)) + align_up(sizeof(int)) +
-         align_up((B + 1) * sizeof(int64_t)) * 2 + align_up((B + 1) * sizeof(uint32_t)) * 2 +
-         align_up((2 * static_cast<size_t>(cdiv(N + 2, SCAN_TILE)) + 16) * sizeof(uint32_t)) +
-         align_up(static_cast<size_t>(cd) * sizeof(float)) + align_up(static_cast<size_t>(cb) * sizeof(double)) + 256;
+  return kron_layout(nullptr, N, B, max_graph_nodes, cap_dense, cap_big, nullptr) + 256;
 }
 
 extern "C" int tgp_kron_batched_max_graph_nodes(void) { return KRON_MAX_N; }
@@ -444,6 +777,7 @@ extern "C" int tgp_kron_batched_max_graph_nodes(void) { return KRON_MAX_N; }
 extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col, const float* val32,
                                       const double* val64, const int32_t* perm, int from_adjacency, int64_t N,
                                       int64_t nnz, const int64_t* graph_ptr, int64_t B, int64_t max_graph_nodes,
+                                      int64_t cap_dense, int64_t cap_big, int64_t num_big,
                                       const int64_t* node_index, int64_t num_kept, double threshold, void* ws,
                                       size_t ws_bytes, int64_t* d_count, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -453,9 +787,11 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
   TGP_REQUIRE(!(val32 && val64), TGP_ERR_INVALID, "tgp_kron_batched_count: give fp32 or fp64 values, not both");
   TGP_REQUIRE(N < (1ll << 31) - 2 && nnz < (1ll << 31) && B < (1ll << 31), TGP_ERR_RANGE,
               "tgp_kron_batched_count: N / nnz / B >= 2^31");
-  TGP_REQUIRE(ws && ws_bytes >= tgp_kron_batched_workspace_bytes(N, B, max_graph_nodes), TGP_ERR_WORKSPACE,
-              "tgp_kron_batched_count: workspace too small");
-  KronWs s = carve_kron(ws, N, B, max_graph_nodes);
+  TGP_REQUIRE(ws && ws_bytes >= tgp_kron_batched_workspace_bytes(N, B, max_graph_nodes, cap_dense, cap_big),
+              TGP_ERR_WORKSPACE, "tgp_kron_batched_count: workspace too small");
+  KronWs s;
+  kron_layout(ws, N, B, max_graph_nodes, cap_dense, cap_big, &s);
+  if (num_big < 0 || num_big > B) num_big = B;
   (void)hipMemsetAsync(s.flags, 0, (N + 2) * sizeof(uint32_t), stream);
   (void)hipMemsetAsync(s.status, 0, sizeof(int), stream);
   (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
@@ -464,26 +800,51 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
     hipLaunchKernelGGL(kron_flags_kernel, dim3(cdiv(num_kept, 256)), dim3(256), 0, stream, node_index, num_kept, N,
                        s.flags, s.status);
   device_scan_u32(s.flags, N + 1, s.rank, s.scan_total, s.scan_tiles, stream);  // (one workgroup took 73 us at N = 82 k)
+  const int cap = static_cast<int>(max_graph_nodes < KRON_LDS_MAX_N ? max_graph_nodes : KRON_LDS_MAX_N);
   hipLaunchKernelGGL(kron_plan_kernel, dim3(1), dim3(1024), 0, stream, graph_ptr, static_cast<int>(B), s.rank, s.sq_off,
-                     s.big_off, s.cap_dense, s.cap_big, (from_adjacency & 2) ? 1 : 0, s.status);
+                     s.big_off, s.cap_dense, s.cap_big, (from_adjacency & 2) ? 1 : 0, cap, max_graph_nodes, s.big_list, s.big_count,
+                     static_cast<int>(num_big), s.status);
   KronArgs a{};
   a.indptr = indptr; a.col = col; a.val32 = val32; a.val64 = val64; a.perm = perm; a.from_adj = from_adjacency & 1;
   a.graph_ptr = graph_ptr; a.rank = s.rank; a.sq_off = s.sq_off; a.big_off = s.big_off; a.dense = s.dense;
   a.big = s.big; a.counts = s.counts; a.status = s.status; a.threshold = threshold;
-  const int cap = static_cast<int>(max_graph_nodes < KRON_LDS_MAX_N ? max_graph_nodes : KRON_LDS_MAX_N);
   a.lds_cap = cap;
-  const size_t lds = static_cast<size_t>(cap) * (cap | 1) * sizeof(double) + 16;
+  a.big_list = s.big_list; a.big_count = s.big_count; a.sing = s.sing; a.big_inv = s.big_inv;
+  a.rowcnt = nullptr;
   (void)hipMemsetAsync(s.counts, 0, (B + 1) * sizeof(uint32_t), stream);
-  // the kernel also has a few static LDS words: ask for what this launch needs, not for the whole 160 KB
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kron_schur_lds_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  hipLaunchKernelGGL(kron_schur_lds_kernel, dim3(static_cast<unsigned>(B)), dim3(KRON_THREADS), lds, stream, a);
-  if (max_graph_nodes > KRON_LDS_MAX_N) {
-    const int64_t nmax = max_graph_nodes < KRON_MAX_N ? max_graph_nodes : KRON_MAX_N;
+  // One workgroup per graph with the graph's matrix in LDS: the allocation decides how many graphs a CU works on at
+  // once (128 nodes = 132 KB = one; 64 nodes = 33 KB = four), so a batch whose longest LDS graph has more than 64
+  // nodes runs the kernel twice, small graphs first with the small allocation (2048 graphs of 20..60 nodes beside one
+  // 100-node graph: 320 -> ~100 us).  The kernel also has a few static LDS words: ask for what a launch needs.
+  const int cuts[3] = {0, cap > 64 ? 64 : cap, cap};
+  for (int cls = 0; cls < 2; ++cls) {
+    if (cuts[cls + 1] <= cuts[cls]) continue;
+    a.lds_lo = cuts[cls];
+    a.lds_hi = cuts[cls + 1];
+    const size_t lds = static_cast<size_t>(a.lds_hi) * (a.lds_hi | 1) * sizeof(double) + 16;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kron_schur_lds_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL(kron_schur_lds_kernel, dim3(static_cast<unsigned>(B)), dim3(KRON_THREADS), lds, stream, a);
+  }
+  if (max_graph_nodes > cap && num_big > 0) {
+    // graphs of 129 .. 1024 nodes: one launch per panel of KRON_SNB pivots over all of them (see kron_big_panel_kernel / kron_big_trail_kernel)
+    const int nmax = static_cast<int>(max_graph_nodes < KRON_MAX_N ? max_graph_nodes : KRON_MAX_N);
+    const unsigned nbig = static_cast<unsigned>(num_big);
+    a.rowcnt = s.flags;  // the keep flags are spent once the ranks exist: [N + 2] words, indexed by pooled row
+    (void)hipMemsetAsync(s.sing, 0, (B + 1) * sizeof(int), stream);
+    (void)hipMemsetAsync(s.big, 0, static_cast<size_t>(s.cap_big) * sizeof(double), stream);
+    hipLaunchKernelGGL(kron_big_build_kernel, dim3(cdiv(nmax, 256), nbig), dim3(256), 0, stream, a);
+    for (int step = 0; step * KRON_SNB < nmax - 1; ++step) {  // at least one node is kept: m <= n - 1
+      const int rem = nmax - step * KRON_SNB - 1;             // trailing rows at most (the panel holds >= 1 pivot)
+      const int nt = cdiv(rem, KRON_TILE);
+      hipLaunchKernelGGL(kron_big_panel_kernel, dim3(static_cast<unsigned>(nt), nbig), dim3(256), 0, stream, a, step);
+      hipLaunchKernelGGL(kron_big_trail_kernel, dim3(static_cast<unsigned>(nt * nt), nbig), dim3(256), 0, stream, a, step);
+    }
+    hipLaunchKernelGGL(kron_big_finish_kernel, dim3(cdiv(nmax, 16), nbig), dim3(256), 0, stream, a);
     const size_t plds = static_cast<size_t>(2 * KRON_NB) * nmax * sizeof(double);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kron_schur_big_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kron_big_redo_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plds));
-    hipLaunchKernelGGL(kron_schur_big_kernel, dim3(static_cast<unsigned>(B)), dim3(KRON_BIG_THREADS), plds, stream, a);
+    hipLaunchKernelGGL(kron_big_redo_kernel, dim3(nbig), dim3(KRON_BIG_THREADS), plds, stream, a);
   }
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, static_cast<int>(B), s.out_off,
                      d_count, static_cast<const int*>(nullptr));
@@ -491,16 +852,27 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
   return check_launch("tgp_kron_batched_count");
 }
 
-extern "C" int tgp_kron_batched_fill(const void* ws, int64_t N, int64_t B, int64_t max_graph_nodes,
-                                     const int64_t* graph_ptr, int64_t num_out, int64_t* out_row, int64_t* out_col,
-                                     float* out_weight, void* stream_) {
+extern "C" int tgp_kron_batched_fill(const void* ws, int64_t N, int64_t B, int64_t max_graph_nodes, int64_t cap_dense,
+                                     int64_t cap_big, int64_t num_big, const int64_t* graph_ptr, int64_t num_out,
+                                     int64_t* out_row, int64_t* out_col, float* out_weight, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(ws && N >= 0 && B >= 0 && num_out >= 0 && graph_ptr, TGP_ERR_INVALID,
               "tgp_kron_batched_fill: bad argument");
   if (num_out == 0 || B == 0) return TGP_OK;
   TGP_REQUIRE(out_row && out_col && out_weight, TGP_ERR_INVALID, "tgp_kron_batched_fill: null output");
-  KronWs s = carve_kron(const_cast<void*>(ws), N, B, max_graph_nodes);
+  KronWs s;
+  kron_layout(const_cast<void*>(ws), N, B, max_graph_nodes, cap_dense, cap_big, &s);
+  const int cap = static_cast<int>(max_graph_nodes < KRON_LDS_MAX_N ? max_graph_nodes : KRON_LDS_MAX_N);
   hipLaunchKernelGGL(kron_fill_kernel, dim3(static_cast<unsigned>(B)), dim3(KRON_THREADS), 0, stream, graph_ptr, s.rank,
-                     s.sq_off, s.dense, s.out_off, out_row, out_col, out_weight);
+                     s.sq_off, s.dense, s.out_off, cap, out_row, out_col, out_weight);
+  if (num_big < 0 || num_big > B) num_big = B;
+  if (max_graph_nodes > cap && num_big > 0) {
+    KronArgs a{};
+    a.graph_ptr = graph_ptr; a.rank = s.rank; a.sq_off = s.sq_off; a.big_off = s.big_off; a.dense = s.dense;
+    a.big = s.big; a.big_list = s.big_list; a.big_count = s.big_count; a.rowcnt = s.flags;
+    const int nmax = static_cast<int>(max_graph_nodes < KRON_MAX_N ? max_graph_nodes : KRON_MAX_N);
+    hipLaunchKernelGGL(kron_big_fill_kernel, dim3(cdiv(nmax, 16), static_cast<unsigned>(num_big)), dim3(256), 0, stream, a,
+                       s.out_off, out_row, out_col, out_weight);
+  }
   return check_launch("tgp_kron_batched_fill");
 }

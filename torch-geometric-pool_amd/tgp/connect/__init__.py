@@ -325,9 +325,9 @@ class KronConnect(Connect):
             info = batch_info(batch)
             if not info.is_sorted:
                 return None
-            ptr, max_nodes = info.ptr, info.max_nodes
+            ptr, max_nodes, sizes_host = info.ptr, info.max_nodes, info.sizes_host
         else:
-            ptr, max_nodes = torch.tensor([0, n], dtype=torch.long, device=dev), n
+            ptr, max_nodes, sizes_host = torch.tensor([0, n], dtype=torch.long, device=dev), n, [n]
         limit = K.kron_max_graph_nodes()
         oversize = None
         if max_nodes > limit:
@@ -358,7 +358,7 @@ class KronConnect(Connect):
                 indptr, perm = index.row_ptr, index.perm
             col, val, from_adj = edge_index[1], edge_weight, True
         out = K.kron_batched(indptr, col, val, perm, from_adj, n, ptr, min(max_nodes, limit), idx_pos,
-                             self.sparse_threshold, skip_oversize=oversize is not None)
+                             self.sparse_threshold, skip_oversize=oversize is not None, graph_sizes_host=sizes_host)
         if out is None or not oversize:
             return out
         eis, ews = [out[0]], [out[1]]

@@ -6,7 +6,7 @@ on the CPU and nothing falls back to ATen kernels.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor
@@ -763,12 +763,22 @@ def kron_max_graph_nodes() -> int:
 
 def kron_batched(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optional[Tensor], from_adjacency: bool,
                  num_nodes: int, graph_ptr: Tensor, max_graph_nodes: int, node_index: Tensor,
-                 threshold: float, skip_oversize: bool = False) -> Optional[Tuple[Tensor, Tensor]]:
+                 threshold: float, skip_oversize: bool = False,
+                 graph_sizes_host: Optional[Sequence[int]] = None) -> Optional[Tuple[Tensor, Tensor]]:
     """Block-batched Kron reduction (connect/kron_conn.py:117-165): one workgroup per graph, fp64 elimination of the
     dropped nodes, thresholded fp32 edge list in row-major order.  ``indptr`` int32 [N+1] / ``col`` int64 / ``val``
     fp32 or fp64 (None = ones) / ``perm`` int32 (None = identity) describe the Laplacian entries, or the edge weights
-    when ``from_adjacency``.  Returns None when the library declines (see include/tgp_hip.h)."""
+    when ``from_adjacency``.  ``graph_sizes_host``: the graphs' node counts on the host (the caller's memoised
+    batch info): the workspace is then sized from the real graphs instead of num_nodes x longest graph.
+    Returns None when the library declines (see include/tgp_hip.h)."""
     dev = N.require_device(indptr, col, val, perm, graph_ptr, node_index)
+    cap_dense = cap_big = num_big = -1
+    if graph_sizes_host is not None:
+        lim, lds = kron_max_graph_nodes(), 128
+        inside = [int(v) for v in graph_sizes_host if v <= lim]
+        cap_dense = sum(v * v for v in inside)
+        cap_big = sum(v * (v | 1) for v in inside if v > lds)
+        num_big = sum(1 for v in inside if v > lds)
     if indptr.dtype != torch.int32 or (perm is not None and perm.dtype != torch.int32):
         raise ValueError("kron_batched: indptr / perm must be int32")
     col, graph_ptr, node_index = N.i64c(col), N.i64c(graph_ptr), N.i64c(node_index)
@@ -780,13 +790,14 @@ def kron_batched(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optio
             v32 = N.f32c(val.reshape(-1))
     B = graph_ptr.numel() - 1
     L = N.lib()
-    ws = N.workspace(L.tgp_kron_batched_workspace_bytes(num_nodes, B, max_graph_nodes), dev)
+    ws = N.workspace(L.tgp_kron_batched_workspace_bytes(num_nodes, B, max_graph_nodes, cap_dense, cap_big), dev)
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
     st = N.stream_ptr(dev)
     N.check(L.tgp_kron_batched_count(N.ptr(indptr.contiguous()), N.ptr(col), N.ptr(v32), N.ptr(v64),
                                      N.ptr(None if perm is None else perm.contiguous()),
                                      (1 if from_adjacency else 0) | (2 if skip_oversize else 0),
-                                     num_nodes, col.numel(), N.ptr(graph_ptr), B, max_graph_nodes, N.ptr(node_index),
+                                     num_nodes, col.numel(), N.ptr(graph_ptr), B, max_graph_nodes, cap_dense, cap_big,
+                                     num_big, N.ptr(node_index),
                                      node_index.numel(), float(threshold), N.ptr(ws), ws.numel(), N.ptr(d_count), st),
             "tgp_kron_batched_count")
     n_out = _read_count(d_count)
@@ -794,7 +805,8 @@ def kron_batched(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optio
         return None
     ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
     ew = torch.empty(n_out, dtype=torch.float32, device=dev)
-    N.check(L.tgp_kron_batched_fill(N.ptr(ws), num_nodes, B, max_graph_nodes, N.ptr(graph_ptr), n_out,
+    N.check(L.tgp_kron_batched_fill(N.ptr(ws), num_nodes, B, max_graph_nodes, cap_dense, cap_big, num_big,
+                                    N.ptr(graph_ptr), n_out,
                                     N.ptr(ei[0]) if n_out else None, N.ptr(ei[1]) if n_out else None,
                                     N.ptr(ew) if n_out else None, st), "tgp_kron_batched_fill")
     return ei, ew
