@@ -359,6 +359,25 @@ int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, const float* w 
                       uint64_t seed, int max_iter, double tol, uint8_t* keep, int32_t* info, int* d_status,
                       void* stream);
 
+/* One LARGE graph (beyond tgp_ndp_max_graph_nodes(); e.g. N = 1M, E = 10M of BASELINE configs[3]) on the whole
+ * chip: the same LOBPCG iteration with every vector pass as a grid-wide kernel over fp64 work vectors in `ws`
+ * (tgp_ndp_large_workspace_bytes(n): seven fp64 vectors + one fp32), scalars handed from kernel to kernel in device
+ * memory.  The graph is the node range [p0, p1) of the same symmetric, self-loop-free CSR.
+ *   start : degrees, start vector, first product.
+ *   steps : `steps` LOBPCG steps (no-ops once |Ls x - lambda x| <= tol * lambda or max_iter steps are done);
+ *           d_progress[0] = done flag, [1] = steps taken so far: the host reads it once per batch of steps.
+ *   finish: sign partition, cut test, the reference's random fallback (ndp_select.py:171-185, 250-252);
+ *           keep[p0 .. p1) is written, *info = steps used or -1 (random fallback).
+ *   state : (diagnostics; synchronises the stream) lambda, |residual|^2, steps, random flag, cut. */
+size_t tgp_ndp_large_workspace_bytes(int64_t num_graph_nodes);
+int tgp_ndp_large_start(const int32_t* indptr, const int64_t* col, const float* w /* NULL ok */, int64_t p0,
+                        int64_t p1, int max_iter, void* ws, size_t ws_bytes, int* d_status, void* stream);
+int tgp_ndp_large_steps(const int32_t* indptr, const int64_t* col, const float* w, int64_t p0, int64_t p1, int steps,
+                        double tol, void* ws, size_t ws_bytes, int32_t* d_progress, int* d_status, void* stream);
+int tgp_ndp_large_finish(const int32_t* indptr, const int64_t* col, const float* w, int64_t p0, int64_t p1,
+                         uint64_t seed, void* ws, size_t ws_bytes, uint8_t* keep, int32_t* info, void* stream);
+int tgp_ndp_large_state(const void* ws, int64_t num_graph_nodes, double* out5, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * A9  KronConnect.forward (connect/kron_conn.py:117-165), block-batched: the batch Laplacian is block diagonal, so
  *     every graph's Kron reduction  L' = L[+,+] - L[+,-] L[-,-]^-1 L[-,+]  is independent.  The graph's dense

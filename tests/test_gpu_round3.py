@@ -302,3 +302,83 @@ def test_graclus_select_hands_its_csr_offsets_to_sparse_connect(dev):
     with pytest.raises(IndexError):
         kernels.coalesce_edges(bad, ew, so.cluster_index, so.num_supernodes, "sum", True, csr=(bad_ptr, None),
                                assign_index=kernels.build_assign_index(so.cluster_index, so.num_supernodes))
+
+
+# ------------------------------------------------------------------------------ NDPSelect, one large graph (r3)
+def _undirected(n, m, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randint(0, n, (m,), generator=g)
+    b = torch.randint(0, n, (m,), generator=g)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    key = torch.unique(torch.cat([a * n + b, b * n + a]))
+    return torch.stack([key // n, key % n])
+
+
+def test_ndp_large_graph_partition_contract_vs_scipy(dev):
+    """A 50 000-node graph (beyond the one-workgroup kernel) is partitioned by the chip-wide LOBPCG (tgp_ndp_large_*):
+    its Rayleigh quotient equals scipy's largest eigenvalue of Ls = I - D^-1/2 A D^-1/2 within 1e-6, the residual meets
+    the tolerance, and the partition is the sign pattern of the iterate (or the reference's random fallback when the
+    cut test says so), with both sides non-empty."""
+    import numpy as np
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from tgp import kernels as K
+    n = 50_000
+    ei = _undirected(n, 250_000, 3)
+    w = torch.rand(ei.size(1) // 1, generator=torch.Generator().manual_seed(4)) + 0.5
+    # symmetric weights: w(u,v) = w(v,u)
+    key = torch.minimum(ei[0], ei[1]) * n + torch.maximum(ei[0], ei[1])
+    w = ((key * 2654435761) % 1000).float() / 1000 + 0.5
+    A = sp.coo_matrix((w.double().numpy(), (ei[0].numpy(), ei[1].numpy())), shape=(n, n)).tocsr()
+    deg = np.asarray(A.sum(1)).reshape(-1)
+    dis = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1e-300)), 0.0)
+    Ls = sp.eye(n) - sp.diags(dis) @ A @ sp.diags(dis)
+    lam_ref = float(spla.eigsh(Ls.tocsc(), k=1, which="LA", tol=1e-10, return_eigenvectors=False)[0])
+    eid, wd = ei.to(dev), w.to(dev)
+    indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    K.rowptr_from_sorted(eid[0], n, indptr)
+    keep = torch.zeros(n, dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    info, state = K.ndp_partition_large(indptr, eid[1], wd, 0, n, 7, keep, status, want_state=True)
+    assert int(status.item()) == 0
+    assert abs(state["lambda"] - lam_ref) <= 1e-6 * lam_ref, (state, lam_ref)
+    assert state["residual_sq"] <= (1e-6 * state["lambda"]) ** 2 * 1.0001
+    kb = keep.bool().cpu()
+    assert 0 < int(kb.sum()) < n
+    z = np.where(kb.numpy(), 1.0, -1.0)
+    L = sp.diags(deg) - A
+    cut = float(z @ (L @ z)) / (2.0 * A.sum())
+    if int(info.item()) >= 0:   # spectral partition kept: its cut passed the reference's test
+        assert cut >= 0.5 and abs(cut - state["cut"]) < 1e-9
+    else:                       # random fallback (ndp_select.py:171-185): node 0 kept, node 1 dropped
+        assert bool(kb[0]) and not bool(kb[1])
+
+
+def test_ndp_select_single_large_graph_stays_on_device(dev, monkeypatch):
+    """NDPSelect on one 30 000-node graph: no scipy eigen-solver is called (r2 sent such graphs to eigsh on the host);
+    the selector's outputs have the reference's structure (kept nodes ascending, one-to-one S, weights 1)."""
+    import scipy.sparse.linalg as spla
+    from tgp.select import NDPSelect
+
+    def boom(*a, **k):
+        raise AssertionError("host eigen-solver called")
+    monkeypatch.setattr(spla, "eigsh", boom)
+    n = 30_000
+    ei = _undirected(n, 120_000, 5).to(dev)
+    so = NDPSelect()(ei, None, num_nodes=n)
+    ni = so.node_index
+    assert ni.is_cuda and 0 < ni.numel() < n and bool((ni[1:] > ni[:-1]).all())
+    assert torch.equal(so.cluster_index, torch.arange(ni.numel(), device=dev))
+    assert bool((so.weight == 1).all())
+    # a batch that mixes small graphs with one large graph: the small ones keep the one-workgroup kernel
+    sizes = [30, 45, 5000, 20]
+    eis, bs, off = [], [], 0
+    for gi, m in enumerate(sizes):
+        eis.append(_undirected(m, 3 * m, 10 + gi) + off)
+        bs.append(torch.full((m,), gi))
+        off += m
+    ei2, batch = torch.cat(eis, 1).to(dev), torch.cat(bs).to(dev)
+    so2 = NDPSelect()(ei2, None, batch=batch, num_nodes=off)
+    kept_per_graph = torch.bincount(batch[so2.node_index], minlength=len(sizes))
+    assert bool((kept_per_graph > 0).all()) and bool((kept_per_graph < torch.tensor(sizes, device=dev)).all())

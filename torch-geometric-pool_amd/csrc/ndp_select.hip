@@ -159,7 +159,9 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
   const int64_t p0 = graph_ptr[g], p1 = graph_ptr[g + 1];
   const int64_t n64 = p1 - p0;
   if (n64 <= 0) return;
-  if (n64 > NDP_MAX_N) {  // left unpartitioned (keep stays 0): the caller handles the few oversize graphs itself
+  if (n64 > NDP_MAX_N || n64 > ncap) {
+    // beyond the kernel's limit, or beyond the max_graph_nodes the caller declared (which sized the LDS arrays): left
+    // unpartitioned (keep stays 0, info = -2): the caller handles those graphs itself (tgp_ndp_large_*)
     if (tid == 0) info[g] = -2;
     return;
   }
@@ -346,6 +348,339 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
   if (tid == 0) info[g] = random_part ? -1 : it;
 }
 
+
+// ====================================================================================================================
+// r3: ONE LARGE GRAPH on the whole chip (graphs beyond NDP_MAX_N nodes; the N = 1M, E = 10M graph of BASELINE configs[3]).
+// The same iteration as ndp_partition_kernel above -- LOBPCG with one vector on Ls = I - D^-1/2 A D^-1/2, orthonormalised
+// basis {x, w = r / |r|, p' = p - (x.p) x - (w.p) w}, 3 x 3 Rayleigh-Ritz, sign partition, cut test, the reference's
+// random fallback -- with every vector pass as a grid-wide kernel: fp64 vectors in the workspace, block partial sums in a
+// fixed layout reduced in a fixed order by one small workgroup (deterministic), scalars handed from kernel to kernel
+// through a device-side state record, so that the host launches steps in batches and reads one flag per batch.
+// Per step: round A (residual, 3 sums), sparse mat-vec of the residual, round B (6 sums), update (2 sums); 32 MB-48 MB
+// of vector traffic per round at N = 1M plus one pass over the CSR.
+constexpr int NL_BLOCKS = 512;      // partial-sum slots (grid of every reducing kernel)
+constexpr int NL_THREADS = 256;
+
+struct NlState {        // device-resident scalars of the iteration
+  double lam, rn2, inv_r, cxp, cwp, c0, c1, c2p, sp, scale, vol, x2, cut;
+  int has_p, done, it, random_part, max_iter, pad;
+};
+
+struct NlVecs {
+  double *x, *ax, *pv, *ap, *wv, *aw, *raw;
+  float* dis;
+  double* partial;     // [NL_BLOCKS][8]
+  NlState* st;
+};
+
+static size_t nl_layout(void* ws, int64_t n, NlVecs* out) {
+  Carver c(ws);
+  NlVecs v;
+  const size_t m = static_cast<size_t>(n > 0 ? n : 1);
+  v.st = c.take<NlState>(1);
+  v.partial = c.take<double>(NL_BLOCKS * 8);
+  v.x = c.take<double>(m); v.ax = c.take<double>(m); v.pv = c.take<double>(m); v.ap = c.take<double>(m);
+  v.wv = c.take<double>(m); v.aw = c.take<double>(m); v.raw = c.take<double>(m);
+  v.dis = c.take<float>(m);
+  if (out) *out = v;
+  return c.off;
+}
+
+template <int K>
+__device__ __forceinline__ void nl_store_partials(double (&v)[K], double* __restrict__ partial) {
+  __shared__ double s_red[K * (NL_THREADS / 64)];
+  ndp_block_sums<NL_THREADS, K>(v, s_red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) partial[blockIdx.x * 8 + k] = v[k];
+  }
+}
+
+// sums of the first K columns of partial[NL_BLOCKS][8], in slot order (one workgroup; every thread gets them)
+template <int K>
+__device__ __forceinline__ void nl_reduce_partials(const double* __restrict__ partial, double (&out)[K]) {
+  __shared__ double s_red[K * (NL_THREADS / 64)];
+  double v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = 0.0;
+  for (int b = threadIdx.x; b < NL_BLOCKS; b += NL_THREADS) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += partial[b * 8 + k];
+  }
+  ndp_block_sums<NL_THREADS, K>(v, s_red);
+#pragma unroll
+  for (int k = 0; k < K; ++k) out[k] = v[k];
+}
+
+// row i of  M src  with M = D^-1/2 A D^-1/2 restricted to the graph's nodes [p0, p1)
+__device__ __forceinline__ double nl_row_matvec(const int32_t* __restrict__ indptr, const int64_t* __restrict__ col,
+                                                const float* __restrict__ w, const float* __restrict__ dis,
+                                                const double* __restrict__ src, int64_t p0, int64_t p1, int64_t i,
+                                                int* __restrict__ status) {
+  double acc = 0.0;
+  for (int e = indptr[p0 + i]; e < indptr[p0 + i + 1]; ++e) {
+    const int64_t c = col[e];
+    if (c < p0 || c >= p1) { atomicOr(status, 2); continue; }
+    const int64_t j = c - p0;
+    acc += (w ? static_cast<double>(w[e]) : 1.0) * static_cast<double>(dis[j]) * src[j];
+  }
+  return static_cast<double>(dis[i]) * acc;
+}
+
+// degrees -> dis, volume; pseudo-random start vector (raw) and its squared norm
+__global__ __launch_bounds__(NL_THREADS) void nl_init_kernel(const int32_t* __restrict__ indptr,
+                                                             const float* __restrict__ w, int64_t p0, int64_t n,
+                                                             NlVecs v) {
+  double s[2] = {0.0, 0.0};
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
+       i += static_cast<int64_t>(NL_BLOCKS) * NL_THREADS) {
+    double d = 0.0;
+    for (int e = indptr[p0 + i]; e < indptr[p0 + i + 1]; ++e) d += w ? static_cast<double>(w[e]) : 1.0;
+    v.dis[i] = d > 0.0 ? static_cast<float>(1.0 / sqrt(d)) : 0.f;
+    const double x0 =
+        (static_cast<double>(ndp_hash(0x5EEDull, static_cast<uint64_t>(i) + 977ull * static_cast<uint64_t>(n)) >> 8) /
+         8388608.0) - 1.0;
+    v.raw[i] = x0;
+    s[0] += d;
+    s[1] += x0 * x0;
+  }
+  nl_store_partials<2>(s, v.partial);
+}
+
+__global__ __launch_bounds__(NL_THREADS) void nl_init_reduce_kernel(NlVecs v, int max_iter) {
+  double s[2];
+  nl_reduce_partials<2>(v.partial, s);
+  if (threadIdx.x == 0) {
+    NlState* st = v.st;
+    st->vol = s[0];
+    st->x2 = s[1];
+    st->random_part = !(s[0] > 0.0);
+    st->done = st->random_part;
+    st->has_p = 0;
+    st->it = 0;
+    st->scale = 1.0;
+    st->max_iter = max_iter;
+    st->cut = 0.0;
+  }
+}
+
+// x = raw / |raw|, ax = Ls x, p = ap = 0; partial of x . ax
+__global__ __launch_bounds__(NL_THREADS) void nl_first_matvec_kernel(const int32_t* __restrict__ indptr,
+                                                                     const int64_t* __restrict__ col,
+                                                                     const float* __restrict__ w, int64_t p0,
+                                                                     int64_t p1, NlVecs v, int* __restrict__ status) {
+  const int64_t n = p1 - p0;
+  const double inv = v.st->x2 > 0.0 ? 1.0 / sqrt(v.st->x2) : 0.0;
+  double s[1] = {0.0};
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
+       i += static_cast<int64_t>(NL_BLOCKS) * NL_THREADS) {
+    const double xi = v.raw[i] * inv;
+    const double axi = xi - inv * nl_row_matvec(indptr, col, w, v.dis, v.raw, p0, p1, i, status);
+    v.x[i] = xi;
+    v.ax[i] = axi;
+    v.pv[i] = 0.0;
+    v.ap[i] = 0.0;
+    s[0] += xi * axi;
+  }
+  nl_store_partials<1>(s, v.partial);
+}
+
+__global__ __launch_bounds__(NL_THREADS) void nl_first_reduce_kernel(NlVecs v) {
+  double s[1];
+  nl_reduce_partials<1>(v.partial, s);
+  if (threadIdx.x == 0) v.st->lam = s[0];
+}
+
+// round A: x, ax rescaled by the previous step's 1 / |x_new|; raw = ax - lam x; sums |r|^2, x.p, r.p
+__global__ __launch_bounds__(NL_THREADS) void nl_round_a_kernel(int64_t n, NlVecs v) {
+  const NlState* st = v.st;
+  if (st->done) return;
+  const double sc = st->scale, lam = st->lam;
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
+       i += static_cast<int64_t>(NL_BLOCKS) * NL_THREADS) {
+    const double xi = v.x[i] * sc, axi = v.ax[i] * sc, pi = v.pv[i];
+    v.x[i] = xi;
+    v.ax[i] = axi;
+    const double r = axi - lam * xi;
+    v.raw[i] = r;
+    s[0] += r * r;
+    s[1] += xi * pi;
+    s[2] += r * pi;
+  }
+  nl_store_partials<3>(s, v.partial);
+}
+
+__global__ __launch_bounds__(NL_THREADS) void nl_reduce_a_kernel(NlVecs v, double tol) {
+  NlState* st = v.st;
+  if (st->done) return;
+  double s[3];
+  nl_reduce_partials<3>(v.partial, s);
+  if (threadIdx.x == 0) {
+    st->scale = 1.0;
+    st->rn2 = s[0];
+    if (!(s[0] > tol * tol * st->lam * st->lam) || st->it >= st->max_iter) {
+      st->done = 1;  // |Ls x - lambda x| <= tol * lambda (or the step budget is spent: the caller decides what then)
+    } else {
+      st->inv_r = 1.0 / sqrt(s[0]);
+      st->cxp = s[1];
+      st->cwp = s[2] * st->inv_r;
+    }
+  }
+}
+
+// w = r / |r|, aw = Ls w
+__global__ __launch_bounds__(NL_THREADS) void nl_matvec_kernel(const int32_t* __restrict__ indptr,
+                                                               const int64_t* __restrict__ col,
+                                                               const float* __restrict__ w, int64_t p0, int64_t p1,
+                                                               NlVecs v, int* __restrict__ status) {
+  const NlState* st = v.st;
+  if (st->done) return;
+  const int64_t n = p1 - p0;
+  const double inv_r = st->inv_r;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * NL_THREADS) {
+    const double ri = v.raw[i];
+    v.wv[i] = ri * inv_r;
+    v.aw[i] = inv_r * (ri - nl_row_matvec(indptr, col, w, v.dis, v.raw, p0, p1, i, status));
+  }
+}
+
+// round B: p' = p - (x.p) x - (w.p) w (and the same combination of the products); six sums
+__global__ __launch_bounds__(NL_THREADS) void nl_round_b_kernel(int64_t n, NlVecs v) {
+  const NlState* st = v.st;
+  if (st->done) return;
+  const bool has_p = st->has_p != 0;
+  const double cxp = st->cxp, cwp = st->cwp;
+  double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
+       i += static_cast<int64_t>(NL_BLOCKS) * NL_THREADS) {
+    const double xi = v.x[i], wi = v.wv[i], axi = v.ax[i], awi = v.aw[i];
+    double pi = 0.0, api = 0.0;
+    if (has_p) {
+      pi = v.pv[i] - cxp * xi - cwp * wi;
+      api = v.ap[i] - cxp * axi - cwp * awi;
+      v.pv[i] = pi;
+      v.ap[i] = api;
+    }
+    s[0] += pi * pi;
+    s[1] += xi * awi;
+    s[2] += wi * awi;
+    s[3] += xi * api;
+    s[4] += wi * api;
+    s[5] += pi * api;
+  }
+  nl_store_partials<6>(s, v.partial);
+}
+
+__global__ __launch_bounds__(NL_THREADS) void nl_reduce_b_kernel(NlVecs v) {
+  NlState* st = v.st;
+  if (st->done) return;
+  double sb[6];
+  nl_reduce_partials<6>(v.partial, sb);
+  if (threadIdx.x == 0) {
+    const bool has_p = st->has_p != 0;
+    const int dim = (has_p && sb[0] > 1e-24) ? 3 : 2;
+    const double ip = dim == 3 ? 1.0 / sqrt(sb[0]) : 0.0;
+    const double lam = st->lam;
+    double h[3][3] = {{lam, sb[1], sb[3] * ip}, {sb[1], sb[2], sb[4] * ip}, {sb[3] * ip, sb[4] * ip, sb[5] * ip * ip}};
+    double theta, c[3];
+    ndp_eig3_largest(h, dim, theta, c);
+    if (c[0] < 0.0) { c[0] = -c[0]; c[1] = -c[1]; c[2] = -c[2]; }
+    const double pn2 = c[1] * c[1] + c[2] * c[2];
+    st->c0 = c[0];
+    st->c1 = c[1];
+    st->c2p = c[2] * ip;
+    st->sp = pn2 > 1e-300 ? 1.0 / sqrt(pn2) : 0.0;
+  }
+}
+
+// x <- c0 x + c1 w + c2 p^, p <- (c1 w + c2 p^) / |.| (the same combinations of the products); sums |x|^2, x.Ax
+__global__ __launch_bounds__(NL_THREADS) void nl_update_kernel(int64_t n, NlVecs v) {
+  const NlState* st = v.st;
+  if (st->done) return;
+  const double c0 = st->c0, c1 = st->c1, c2p = st->c2p, sp = st->sp;
+  double s[2] = {0.0, 0.0};
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
+       i += static_cast<int64_t>(NL_BLOCKS) * NL_THREADS) {
+    const double pn = c1 * v.wv[i] + c2p * v.pv[i], apn = c1 * v.aw[i] + c2p * v.ap[i];
+    const double xn = c0 * v.x[i] + pn, axn = c0 * v.ax[i] + apn;
+    v.pv[i] = pn * sp;
+    v.ap[i] = apn * sp;
+    v.x[i] = xn;
+    v.ax[i] = axn;
+    s[0] += xn * xn;
+    s[1] += xn * axn;
+  }
+  nl_store_partials<2>(s, v.partial);
+}
+
+__global__ __launch_bounds__(NL_THREADS) void nl_reduce_update_kernel(NlVecs v, int32_t* __restrict__ d_progress) {
+  NlState* st = v.st;
+  if (!st->done) {
+    double s[2];
+    nl_reduce_partials<2>(v.partial, s);
+    if (threadIdx.x == 0) {
+      st->scale = 1.0 / sqrt(s[0]);  // applied to x, ax by the next round A (or by the finish kernel)
+      st->lam = s[1] / s[0];
+      st->has_p = st->sp > 0.0;
+      st->it += 1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && d_progress) {
+    d_progress[0] = st->done;
+    d_progress[1] = st->it;
+  }
+}
+
+// weight of the directed entries that cross the sign partition
+__global__ __launch_bounds__(NL_THREADS) void nl_cut_kernel(const int32_t* __restrict__ indptr,
+                                                            const int64_t* __restrict__ col,
+                                                            const float* __restrict__ w, int64_t p0, int64_t p1,
+                                                            NlVecs v) {
+  const int64_t n = p1 - p0;
+  double s[1] = {0.0};
+  if (!v.st->random_part) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
+         i += static_cast<int64_t>(NL_BLOCKS) * NL_THREADS) {
+      const bool zi = v.x[i] >= 0.0;
+      for (int e = indptr[p0 + i]; e < indptr[p0 + i + 1]; ++e) {
+        const int64_t c = col[e];
+        if (c < p0 || c >= p1) continue;
+        if ((v.x[c - p0] >= 0.0) != zi) s[0] += w ? static_cast<double>(w[e]) : 1.0;
+      }
+    }
+  }
+  nl_store_partials<1>(s, v.partial);
+}
+
+__global__ __launch_bounds__(NL_THREADS) void nl_cut_reduce_kernel(NlVecs v, int32_t* __restrict__ info) {
+  double s[1];
+  nl_reduce_partials<1>(v.partial, s);
+  if (threadIdx.x == 0) {
+    NlState* st = v.st;
+    if (!(st->lam > 0.0)) st->random_part = 1;
+    if (!st->random_part) {
+      st->cut = s[0] / st->vol;
+      if (st->cut < 0.5) st->random_part = 1;  // ndp_select.py:250-252
+    }
+    if (info) *info = st->random_part ? -1 : st->it;
+  }
+}
+
+__global__ __launch_bounds__(NL_THREADS) void nl_keep_kernel(int64_t p0, int64_t n, unsigned long long seed, NlVecs v,
+                                                             uint8_t* __restrict__ keep) {
+  const bool random_part = v.st->random_part != 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * NL_THREADS) {
+    bool pos;
+    if (random_part) pos = i == 0 ? true : (i == 1 ? false : (ndp_hash(seed, static_cast<uint64_t>(p0 + i)) & 1u) != 0);
+    else pos = v.x[i] >= 0.0;  // (the pending 1 / |x| factor is positive: signs are final)
+    keep[p0 + i] = pos ? 1 : 0;
+  }
+}
+
 }  // namespace tgp
 
 using namespace tgp;
@@ -391,4 +726,88 @@ extern "C" int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, cons
                        d_status);
   }
   return check_launch("tgp_ndp_partition");
+}
+
+// ------------------------------------------------------------------ one large graph, chip-wide (see nl_* kernels)
+extern "C" size_t tgp_ndp_large_workspace_bytes(int64_t n) { return nl_layout(nullptr, n, nullptr) + 256; }
+
+static int nl_check(const int32_t* indptr, int64_t p0, int64_t p1, const void* ws, size_t ws_bytes, const char* what) {
+  TGP_REQUIRE(indptr && ws && p0 >= 0 && p1 > p0, TGP_ERR_INVALID, "%s: bad argument", what);
+  TGP_REQUIRE(p1 < (1ll << 31), TGP_ERR_RANGE, "%s: node ids >= 2^31", what);
+  TGP_REQUIRE(ws_bytes >= tgp_ndp_large_workspace_bytes(p1 - p0), TGP_ERR_WORKSPACE, "%s: workspace too small", what);
+  return TGP_OK;
+}
+
+extern "C" int tgp_ndp_large_start(const int32_t* indptr, const int64_t* col, const float* w, int64_t p0, int64_t p1,
+                                   int max_iter, void* ws, size_t ws_bytes, int* d_status, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int rc = nl_check(indptr, p0, p1, ws, ws_bytes, "tgp_ndp_large_start");
+  if (rc != TGP_OK) return rc;
+  TGP_REQUIRE(col && d_status && max_iter > 0, TGP_ERR_INVALID, "tgp_ndp_large_start: bad argument");
+  NlVecs v;
+  nl_layout(ws, p1 - p0, &v);
+  const int64_t n = p1 - p0;
+  hipLaunchKernelGGL(nl_init_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, indptr, w, p0, n, v);
+  hipLaunchKernelGGL(nl_init_reduce_kernel, dim3(1), dim3(NL_THREADS), 0, stream, v, max_iter);
+  hipLaunchKernelGGL(nl_first_matvec_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, indptr, col, w, p0, p1, v,
+                     d_status);
+  hipLaunchKernelGGL(nl_first_reduce_kernel, dim3(1), dim3(NL_THREADS), 0, stream, v);
+  return check_launch("tgp_ndp_large_start");
+}
+
+extern "C" int tgp_ndp_large_steps(const int32_t* indptr, const int64_t* col, const float* w, int64_t p0, int64_t p1,
+                                   int steps, double tol, void* ws, size_t ws_bytes, int32_t* d_progress,
+                                   int* d_status, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int rc = nl_check(indptr, p0, p1, ws, ws_bytes, "tgp_ndp_large_steps");
+  if (rc != TGP_OK) return rc;
+  TGP_REQUIRE(col && d_status && steps > 0 && tol >= 0.0, TGP_ERR_INVALID, "tgp_ndp_large_steps: bad argument");
+  NlVecs v;
+  nl_layout(ws, p1 - p0, &v);
+  const int64_t n = p1 - p0;
+  const unsigned mv_blocks = static_cast<unsigned>(cdiv(n, NL_THREADS) < 8192 ? cdiv(n, NL_THREADS) : 8192);
+  for (int s = 0; s < steps; ++s) {
+    hipLaunchKernelGGL(nl_round_a_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, n, v);
+    hipLaunchKernelGGL(nl_reduce_a_kernel, dim3(1), dim3(NL_THREADS), 0, stream, v, tol);
+    hipLaunchKernelGGL(nl_matvec_kernel, dim3(mv_blocks), dim3(NL_THREADS), 0, stream, indptr, col, w, p0, p1, v,
+                       d_status);
+    hipLaunchKernelGGL(nl_round_b_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, n, v);
+    hipLaunchKernelGGL(nl_reduce_b_kernel, dim3(1), dim3(NL_THREADS), 0, stream, v);
+    hipLaunchKernelGGL(nl_update_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, n, v);
+    hipLaunchKernelGGL(nl_reduce_update_kernel, dim3(1), dim3(NL_THREADS), 0, stream, v,
+                       s + 1 == steps ? d_progress : static_cast<int32_t*>(nullptr));
+  }
+  return check_launch("tgp_ndp_large_steps");
+}
+
+extern "C" int tgp_ndp_large_finish(const int32_t* indptr, const int64_t* col, const float* w, int64_t p0, int64_t p1,
+                                    uint64_t seed, void* ws, size_t ws_bytes, uint8_t* keep, int32_t* info,
+                                    void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int rc = nl_check(indptr, p0, p1, ws, ws_bytes, "tgp_ndp_large_finish");
+  if (rc != TGP_OK) return rc;
+  TGP_REQUIRE(col && keep, TGP_ERR_INVALID, "tgp_ndp_large_finish: null pointer");
+  NlVecs v;
+  nl_layout(ws, p1 - p0, &v);
+  const int64_t n = p1 - p0;
+  hipLaunchKernelGGL(nl_cut_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, indptr, col, w, p0, p1, v);
+  hipLaunchKernelGGL(nl_cut_reduce_kernel, dim3(1), dim3(NL_THREADS), 0, stream, v, info);
+  hipLaunchKernelGGL(nl_keep_kernel, dim3(static_cast<unsigned>(cdiv(n, NL_THREADS) < 4096 ? cdiv(n, NL_THREADS) : 4096)),
+                     dim3(NL_THREADS), 0, stream, p0, n, static_cast<unsigned long long>(seed), v, keep);
+  return check_launch("tgp_ndp_large_finish");
+}
+
+// lambda (Rayleigh quotient), |residual|^2, steps, random-fallback flag, cut: diagnostics / tests
+extern "C" int tgp_ndp_large_state(const void* ws, int64_t n, double* out5, void* stream_) {
+  TGP_REQUIRE(ws && out5, TGP_ERR_INVALID, "tgp_ndp_large_state: null pointer");
+  NlVecs v;
+  nl_layout(const_cast<void*>(ws), n, &v);
+  NlState h;
+  if (hipMemcpyAsync(&h, v.st, sizeof(NlState), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream_)) != hipSuccess ||
+      hipStreamSynchronize(static_cast<hipStream_t>(stream_)) != hipSuccess) {
+    set_error("tgp_ndp_large_state: copy failed");
+    return TGP_ERR_LAUNCH;
+  }
+  out5[0] = h.lam; out5[1] = h.rn2; out5[2] = h.it; out5[3] = h.random_part; out5[4] = h.cut;
+  return TGP_OK;
 }

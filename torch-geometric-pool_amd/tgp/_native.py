@@ -108,6 +108,13 @@ SIGNATURES = {
     "tgp_ndp_max_graph_nodes": (_c_int, []),
     "tgp_ndp_partition": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, ctypes.c_uint64, _c_int,
                                    ctypes.c_double, _c_p, _c_p, _c_p, _c_p]),
+    "tgp_ndp_large_workspace_bytes": (_c_sz, [_c_i64]),
+    "tgp_ndp_large_start": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_sz, _c_p, _c_p]),
+    "tgp_ndp_large_steps": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, ctypes.c_double, _c_p, _c_sz, _c_p,
+                                     _c_p, _c_p]),
+    "tgp_ndp_large_finish": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, ctypes.c_uint64, _c_p, _c_sz, _c_p, _c_p,
+                                      _c_p]),
+    "tgp_ndp_large_state": (_c_int, [_c_p, _c_i64, _c_p, _c_p]),
     "tgp_kron_batched_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
     "tgp_kron_batched_max_graph_nodes": (_c_int, []),
     "tgp_kron_batched_count": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_i64, _c_i64, _c_p, _c_i64, _c_i64,

@@ -735,7 +735,7 @@ def ndp_max_graph_nodes() -> int:
 
 
 def ndp_partition(indptr: Tensor, col: Tensor, weight: Optional[Tensor], num_nodes: int, graph_ptr: Tensor,
-                  max_graph_nodes: int, seed: int, max_iter: int = 500, tol: float = 1e-6):
+                  max_graph_nodes: int, seed: int, max_iter: int = 500, tol: float = 1e-6, raw_keep: bool = False):
     """(keep [N] bool, info [B] int32, status int): NDPSelect's per-graph spectral +-1 partition
     (select/ndp_select.py:187-256) on a symmetric, self-loop-free CSR adjacency.  info[g] = LOBPCG steps used, -1 =
     the reference's random fallback (cut < 0.5); status != 0: declined, see include/tgp_hip.h.  ``tol``: relative
@@ -753,7 +753,45 @@ def ndp_partition(indptr: Tensor, col: Tensor, weight: Optional[Tensor], num_nod
                                       N.ptr(graph_ptr), B, max_graph_nodes, int(seed) & ((1 << 64) - 1), max_iter,
                                       float(tol), N.ptr(keep), N.ptr(info), N.ptr(status), N.stream_ptr(dev)),
             "tgp_ndp_partition")
-    return keep[:num_nodes].bool(), info[:B], status
+    return (keep[:num_nodes] if raw_keep else keep[:num_nodes].bool()), info[:B], status
+
+
+def ndp_partition_large(indptr: Tensor, col: Tensor, weight: Optional[Tensor], p0: int, p1: int, seed: int,
+                        keep: Tensor, status: Tensor, max_iter: int = 2000, tol: float = 1e-6,
+                        steps_per_batch: int = 16, want_state: bool = False):
+    """NDPSelect's spectral +-1 partition (select/ndp_select.py:187-256) of ONE large graph -- the nodes [p0, p1) of a
+    symmetric, self-loop-free CSR -- on the whole chip: the LOBPCG iteration of :func:`ndp_partition` with grid-wide
+    vector kernels (tgp_ndp_large_*).  Writes keep[p0:p1] (uint8 view of the caller's mask); returns the steps used
+    (-1: the reference's random fallback).  One host read per ``steps_per_batch`` steps (the done flag)."""
+    dev = N.require_device(indptr, col, weight, keep, status)
+    if indptr.dtype != torch.int32 or keep.dtype != torch.uint8 or status.dtype != torch.int32:
+        raise ValueError("ndp_partition_large: indptr / status must be int32, keep uint8")
+    col = N.i64c(col)
+    w = None if weight is None else N.f32c(weight.reshape(-1))
+    L = N.lib()
+    n = p1 - p0
+    ws = N.workspace(L.tgp_ndp_large_workspace_bytes(n), dev)
+    st = N.stream_ptr(dev)
+    N.check(L.tgp_ndp_large_start(N.ptr(indptr), N.ptr(col), N.ptr(w), p0, p1, max_iter, N.ptr(ws), ws.numel(),
+                                  N.ptr(status), st), "tgp_ndp_large_start")
+    progress = torch.zeros(2, dtype=torch.int32, device=dev)
+    done = False
+    while not done:
+        N.check(L.tgp_ndp_large_steps(N.ptr(indptr), N.ptr(col), N.ptr(w), p0, p1, steps_per_batch, float(tol),
+                                      N.ptr(ws), ws.numel(), N.ptr(progress), N.ptr(status), st),
+                "tgp_ndp_large_steps")
+        flag, it = progress.tolist()  # one round trip per batch of steps
+        done = flag != 0 or it >= max_iter
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    N.check(L.tgp_ndp_large_finish(N.ptr(indptr), N.ptr(col), N.ptr(w), p0, p1, int(seed) & ((1 << 64) - 1),
+                                   N.ptr(ws), ws.numel(), N.ptr(keep), N.ptr(info), st), "tgp_ndp_large_finish")
+    if want_state:
+        import ctypes as _ct
+        out = (_ct.c_double * 5)()
+        N.check(L.tgp_ndp_large_state(N.ptr(ws), n, _ct.addressof(out), st), "tgp_ndp_large_state")
+        return info, {"lambda": out[0], "residual_sq": out[1], "steps": int(out[2]), "random": bool(out[3]),
+                      "cut": out[4]}
+    return info
 
 
 # ------------------------------------------------------------------------- A9

@@ -255,6 +255,11 @@ class SelectOutput:
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop("_edge_csr", None)  # holds a weak reference (not picklable) to a tensor the copy does not share
+        factory = state.pop("_L_factory", None)  # a closure over device tensors: the pickle carries the Laplacian itself
+        if factory is not None and "L" not in state:
+            state["L"] = factory()
+        for helper in ("_adj_device_csr", "_kron_csr", "_node_batch", "_partition_info"):
+            state.pop(helper, None)  # device-side shortcuts of this process; KronConnect rebuilds what it needs from L
         return state
 
     def _drop_caches(self) -> None:
@@ -303,6 +308,11 @@ class SelectOutput:
                 setattr(self, name, self._apply_to_value(getattr(self, name), func))
         self._drop_caches()
         self._edge_csr = None  # belongs to a tensor on the old device
+        for helper in ("_adj_device_csr", "_kron_csr"):  # device-side shortcuts built for the old placement
+            self.__dict__.pop(helper, None)
+        nb = self.__dict__.get("_node_batch")
+        if isinstance(nb, Tensor):
+            self.__dict__["_node_batch"] = func(nb)
         return self
 
     def clone(self) -> "SelectOutput":
@@ -359,7 +369,10 @@ class SelectOutput:
         out = SelectOutput(cluster_index=assignments[1], s_inv_op=getattr(self, "s_inv_op", "transpose"),
                            weight=weight, _trusted=True)
         for name in self._extra_args:
-            if hasattr(self, name):
+            if name == "L" and "L" not in self.__dict__ and self.__dict__.get("_L_factory") is not None:
+                out.__dict__["_L_factory"] = self.__dict__["_L_factory"]  # stays lazy (hasattr would build it on the host)
+                out._extra_args.add("L")
+            elif hasattr(self, name):
                 setattr(out, name, getattr(self, name))
         return out
 
@@ -767,9 +780,8 @@ class NDPSelect(Select):
     def _forward_device(self, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Optional[Tensor],
                         num_nodes: int) -> Optional[SelectOutput]:
         """The whole selection on the GPU (tgp_ndp_partition: one workgroup per graph); graphs beyond the kernel's
-        size limit are left out by the kernel and partitioned one by one with the reference's own scipy code on THEIR
-        sub-matrix (a 5000-node graph among 2000 small ones must not send the whole batch through the host loop).
-        None for an unsorted batch vector or a single oversize graph (the host route below then runs)."""
+        size limit are left out by that kernel and partitioned one by one by the chip-wide form of the same iteration
+        (tgp_ndp_large_*).  None for an unsorted batch vector (the host route below then runs)."""
         from .. import kernels as K
         from ..utils.ops import batch_info
         dev = edge_index.device
@@ -783,8 +795,6 @@ class NDPSelect(Select):
             ptr, max_nodes, sizes_host = torch.tensor([0, n], dtype=torch.long, device=dev), n, [n]
         limit = K.ndp_max_graph_nodes()
         oversize = [g for g, m in enumerate(sizes_host) if m > limit]
-        if oversize and len(sizes_host) == 1:
-            return None
         ident = torch.arange(n, device=dev)
         w0 = torch.ones(edge_index.size(1), device=dev) if edge_weight is None else edge_weight.detach().reshape(-1).float()
         # self loops out, duplicates summed (get_laplacian + COO -> CSR), then max with the transpose
@@ -795,24 +805,19 @@ class NDPSelect(Select):
         indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         K.rowptr_from_sorted(ei2[0], n, indptr)
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-        keep, part_info, status = K.ndp_partition(indptr, ei2[1], w2, n, ptr, min(max_nodes, limit), seed)
+        keep8, part_info, status = K.ndp_partition(indptr, ei2[1], w2, n, ptr, min(max_nodes, limit), seed,
+                                                   raw_keep=True)
         if oversize:
-            import numpy as np
-            import scipy.sparse as sp
-            rng = np.random.default_rng(seed)
+            # graphs beyond the one-workgroup kernel (it leaves them out): the same LOBPCG iteration chip-wide, one
+            # graph after the other (tgp_ndp_large_*): the N = 1M, E = 10M graph of BASELINE configs[3] never
+            # touches the host (r2 handed such graphs to scipy's eigsh)
             offs = [0]
             for m in sizes_host:
                 offs.append(offs[-1] + m)
             for g in oversize:
-                p0, p1 = offs[g], offs[g + 1]
-                e0, e1 = int(indptr[p0]), int(indptr[p1])
-                ip = (indptr[p0: p1 + 1] - e0).cpu().numpy()
-                cg = (ei2[1][e0:e1] - p0).cpu().numpy()
-                if cg.size and (cg.min() < 0 or cg.max() >= p1 - p0):
-                    return None  # an edge couples this graph to another one
-                Ag = sp.csr_matrix((w2[e0:e1].double().cpu().numpy(), cg, ip), shape=(p1 - p0, p1 - p0))
-                z = self._partition_graph_on_host(Ag, edge_weight is not None, rng)
-                keep[p0:p1] = torch.from_numpy(z >= 0).to(dev)
+                info_g = K.ndp_partition_large(indptr, ei2[1], w2, offs[g], offs[g + 1], seed, keep8, status)
+                part_info[g: g + 1] = info_g
+        keep = keep8.bool()
         idx_pos = keep.nonzero().view(-1)  # (host round trip: the size of S; also orders the status read below)
         if int(status.item()) != 0:
             return None
