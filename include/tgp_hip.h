@@ -12,6 +12,13 @@
  *   - every pointer is a DEVICE pointer (hipMalloc / PyTorch caching allocator) unless
  *     the name ends in `_host`; index tensors are int64 (reference: utils/ops.py:472-476),
  *     features / weights are fp32; `[2,E]` edge lists are given as two row pointers.
+ *   - THE ABI IS fp32-ONLY (decision, r3).  Every floating-point argument is fp32 and every kernel accumulates in fp32
+ *     -- the reference's default dtype (torch.ones(E) at ops.py:385,547; base_select.py:64) and the precision
+ *     north_star's 1e-5 tolerance is stated in.  There are no `_f64` variants of Reduce / Connect: a caller holding
+ *     float64 tensors (model.double()) converts at the boundary, and the host mirror does exactly that with a
+ *     one-time UserWarning saying the arithmetic is fp32's.  Two algorithms whose RESULT depends on wider arithmetic
+ *     run in fp64 inside their kernels regardless of the I/O type: the Kron reduction (tgp_kron_batched_*) and
+ *     NDPSelect's eigen-iteration (tgp_ndp_*); KronConnect also accepts fp64 Laplacian values (`val64`).
  *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it and
  *     never synchronises, allocates or frees.  Scratch memory comes from the caller
  *     (`ws`, sized by the matching *_workspace_bytes()).
@@ -413,6 +420,17 @@ int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col, const floa
 int tgp_kron_batched_fill(const void* ws, int64_t num_nodes, int64_t num_graphs, int64_t max_graph_nodes,
                           int64_t cap_dense, int64_t cap_big, int64_t num_big, const int64_t* graph_ptr,
                           int64_t num_out, int64_t* out_row, int64_t* out_col, float* out_weight, void* stream);
+
+/* A12, min_score mode (select/topk_select.py:186-194): prob = per-graph softmax of `score` (PyG utils.softmax: max
+ * subtraction, +1e-16 in the denominator), kept = prob > min(max_g(prob) - tol, min_score) (PyG topk; tol 1e-7), kept
+ * nodes in ascending order (nonzero()).  `ptr` [B+1]: node offsets of the graphs of the SORTED batch vector.  count
+ * writes prob [N] and leaves the number of kept nodes in *d_count; fill writes node_index [num_out]. */
+size_t tgp_topk_minscore_workspace_bytes(int64_t num_nodes, int64_t num_graphs);
+int tgp_topk_minscore_count(const float* score, const int64_t* ptr, int64_t num_nodes, int64_t num_graphs,
+                            float min_score, float tol, float* prob, void* ws, size_t ws_bytes, int64_t* d_count,
+                            void* stream);
+int tgp_topk_minscore_fill(const void* ws, const int64_t* ptr, int64_t num_nodes, int64_t num_graphs, int64_t num_out,
+                           int64_t* node_index, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * A13  MLPSelect's last layer, one pass over the node features

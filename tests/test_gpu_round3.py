@@ -382,3 +382,59 @@ def test_ndp_select_single_large_graph_stays_on_device(dev, monkeypatch):
     so2 = NDPSelect()(ei2, None, batch=batch, num_nodes=off)
     kept_per_graph = torch.bincount(batch[so2.node_index], minlength=len(sizes))
     assert bool((kept_per_graph > 0).all()) and bool((kept_per_graph < torch.tensor(sizes, device=dev)).all())
+
+
+# ------------------------------------------------------------------------------ TopkSelect, min_score mode (r3)
+@pytest.mark.parametrize("seed", range(6))
+def test_topk_min_score_mode_native_vs_oracle(dev, seed, monkeypatch):
+    """min_score mode (select/topk_select.py:186-194): per-graph softmax + threshold + nonzero() as native kernels;
+    node_index / cluster_index bit-exact vs the oracle, weights within 1e-5, no torch scatter / nonzero in the path."""
+    import tgp_oracle as O
+    from tgp.select import TopkSelect
+    g = torch.Generator().manual_seed(seed)
+    sizes = torch.randint(1, 90, (int(torch.randint(1, 40, (1,), generator=g)),), generator=g)
+    if seed == 5:
+        sizes = torch.tensor([5000, 3, 1])
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(sizes.numel()), sizes)
+    f = 9
+    x = torch.randn(n, f, generator=g)
+    min_score = [0.02, 0.05, 0.5, 1e-4, 0.9, 2e-4][seed]
+    sel = TopkSelect(in_channels=f, ratio=None, min_score=min_score).to(dev)
+    calls = []
+    real_nonzero = torch.Tensor.nonzero
+    monkeypatch.setattr(torch.Tensor, "nonzero", lambda self, *a, **k: (calls.append("nonzero"), real_nonzero(self, *a, **k))[1])
+    so = sel(x=x.to(dev), batch=batch.to(dev))
+    monkeypatch.setattr(torch.Tensor, "nonzero", real_nonzero)
+    assert calls == []
+    ni, ci, w = O.topk_select(x, sel.weight.detach().cpu(), None, batch, min_score, "tanh")
+    assert torch.equal(so.node_index.cpu(), ni) and torch.equal(so.cluster_index.cpu(), ci)
+    torch.testing.assert_close(so.weight.cpu(), w, rtol=1e-5, atol=1e-7)
+    # no batch vector: one graph
+    so1 = sel(x=x.to(dev))
+    ni1, _, w1 = O.topk_select(x, sel.weight.detach().cpu(), None, None, min_score, "tanh")
+    assert torch.equal(so1.node_index.cpu(), ni1)
+    torch.testing.assert_close(so1.weight.cpu(), w1, rtol=1e-5, atol=1e-7)
+
+
+def test_topk_min_score_mode_gradients(dev):
+    """The selection weights stay differentiable w.r.t. x and the projection (softmax Jacobian per graph)."""
+    from tgp.select import TopkSelect
+    g = torch.Generator().manual_seed(0)
+    sizes = torch.tensor([30, 12, 47])
+    batch = torch.repeat_interleave(torch.arange(3), sizes).to(dev)
+    x = torch.randn(int(sizes.sum()), 6, generator=g).to(dev).requires_grad_(True)
+    sel = TopkSelect(in_channels=6, ratio=None, min_score=0.02).to(dev)
+    so = sel(x=x, batch=batch)
+    up = torch.randn(so.weight.numel(), generator=g).to(dev)
+    (so.weight * up).sum().backward()
+    gx, gw = x.grad.clone(), sel.weight.grad.clone()
+    x.grad = None
+    sel.weight.grad = None
+    score = (x * sel.weight).sum(-1)
+    mx = torch.zeros(3, device=dev).scatter_reduce_(0, batch, score.detach(), "amax", include_self=False)
+    e = (score - mx[batch]).exp()
+    p = e / (torch.zeros(3, device=dev).index_add_(0, batch, e) + 1e-16)[batch]
+    (p[so.node_index] * up).sum().backward()
+    torch.testing.assert_close(gx, x.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(gw, sel.weight.grad, rtol=1e-4, atol=1e-6)

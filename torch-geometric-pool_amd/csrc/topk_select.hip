@@ -378,6 +378,98 @@ static TopkLayout topk_layout(void* ws, int64_t n) {
   return s;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// min_score mode (select/topk_select.py:186-194): score = per-graph softmax of x.w (PyG utils.softmax: max
+// subtraction, +1e-16 in the denominator), kept = score > min(max_g(score) - tol, min_score) (PyG topk, tol 1e-7),
+// in ascending node order (nonzero()).  One workgroup per graph of the sorted batch walks its nodes three times (max,
+// sum of exponentials, probabilities + keep flags; the scores stay in L2): batches of small graphs are one launch,
+// a single large graph is one workgroup's stream.  Sums are taken in a fixed order (strided partial sums, then waves).
+__device__ __forceinline__ float ms_block_max(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__device__ __forceinline__ float ms_block_sum(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void topk_minscore_kernel(const float* __restrict__ score,
+                                                            const int64_t* __restrict__ ptr, float min_score,
+                                                            float tol, float* __restrict__ prob,
+                                                            uint8_t* __restrict__ keep,
+                                                            uint32_t* __restrict__ counts) {
+  __shared__ float sh[4];
+  const int g = blockIdx.x;
+  const int64_t p0 = ptr[g], p1 = ptr[g + 1];
+  if (p1 <= p0) {
+    if (threadIdx.x == 0) counts[g] = 0;
+    return;
+  }
+  float mx = -INFINITY;
+  for (int64_t i = p0 + threadIdx.x; i < p1; i += 256) mx = fmaxf(mx, score[i]);
+  mx = ms_block_max(mx, sh);
+  float sum = 0.f;
+  for (int64_t i = p0 + threadIdx.x; i < p1; i += 256) sum += expf(score[i] - mx);
+  sum = ms_block_sum(sum, sh);
+  const float den = sum + 1e-16f;
+  const float floor_ = fminf(1.0f / den - tol, min_score);  // max probability = exp(0) / den
+  uint32_t mine = 0;
+  for (int64_t i = p0 + threadIdx.x; i < p1; i += 256) {
+    const float pr = expf(score[i] - mx) / den;
+    prob[i] = pr;
+    const bool k = pr > floor_;
+    keep[i] = k ? 1 : 0;
+    mine += k ? 1u : 0u;
+  }
+  const float total = ms_block_sum(static_cast<float>(mine), sh);  // (< 2^24 per graph: exact; larger graphs below)
+  if (p1 - p0 < (1 << 24)) {
+    if (threadIdx.x == 0) counts[g] = static_cast<uint32_t>(total);
+  } else {
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[g] = s_cnt;
+  }
+}
+
+// kept nodes of graph g, ascending, at out[off[g] ..]
+__global__ __launch_bounds__(256) void topk_minscore_fill_kernel(const uint8_t* __restrict__ keep,
+                                                                 const int64_t* __restrict__ ptr,
+                                                                 const uint32_t* __restrict__ off,
+                                                                 int64_t* __restrict__ node_index) {
+  __shared__ uint32_t s_w[4];
+  const int g = blockIdx.x;
+  const int64_t p0 = ptr[g], p1 = ptr[g + 1];
+  uint32_t base = off[g];
+  for (int64_t c0 = p0; c0 < p1; c0 += 256) {
+    const int64_t i = c0 + threadIdx.x;
+    const bool k = i < p1 && keep[i] != 0;
+    const unsigned long long m = __ballot(k);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_w[w] = __popcll(m);
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < w) before += s_w[q];
+      all += s_w[q];
+    }
+    if (k) node_index[base + before + __popcll(m & lanemask_lt())] = i;
+    base += all;
+  }
+}
+
 }  // namespace tgp
 
 using namespace tgp;
@@ -490,4 +582,48 @@ extern "C" int tgp_topk_plan(const int64_t* sizes, int64_t B, double ratio, int6
   TGP_REQUIRE(koff && (B == 0 || (sizes && k)), TGP_ERR_INVALID, "tgp_topk_plan: null pointer");
   hipLaunchKernelGGL(topk_plan_kernel, dim3(1), dim3(1024), 0, stream, sizes, B, static_cast<float>(ratio), k, koff);
   return check_launch("tgp_topk_plan");
+}
+
+// ---------------------------------------------------------------------------- min_score mode
+extern "C" size_t tgp_topk_minscore_workspace_bytes(int64_t N, int64_t B) {
+  return align_up(static_cast<size_t>(N > 0 ? N : 1)) + 2 * align_up(static_cast<size_t>(B + 1) * sizeof(uint32_t)) + 256;
+}
+
+extern "C" int tgp_topk_minscore_count(const float* score, const int64_t* ptr, int64_t N, int64_t B, float min_score,
+                                       float tol, float* prob, void* ws, size_t ws_bytes, int64_t* d_count,
+                                       void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(N >= 0 && B >= 0 && d_count, TGP_ERR_INVALID, "tgp_topk_minscore_count: bad argument");
+  if (N == 0 || B == 0) {
+    (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
+    return check_launch("tgp_topk_minscore_count");
+  }
+  TGP_REQUIRE(score && ptr && prob && ws, TGP_ERR_INVALID, "tgp_topk_minscore_count: null pointer");
+  TGP_REQUIRE(N < (1ll << 32) && B < (1ll << 31), TGP_ERR_RANGE, "tgp_topk_minscore_count: too large");
+  TGP_REQUIRE(ws_bytes >= tgp_topk_minscore_workspace_bytes(N, B), TGP_ERR_WORKSPACE,
+              "tgp_topk_minscore_count: workspace too small");
+  Carver cv(ws);
+  uint8_t* keep = cv.take<uint8_t>(N);
+  uint32_t* counts = cv.take<uint32_t>(B + 1);
+  uint32_t* off = cv.take<uint32_t>(B + 1);
+  hipLaunchKernelGGL(topk_minscore_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, score, ptr, min_score,
+                     tol, prob, keep, counts);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts, static_cast<int>(B), off, d_count,
+                     static_cast<const int*>(nullptr));
+  return check_launch("tgp_topk_minscore_count");
+}
+
+extern "C" int tgp_topk_minscore_fill(const void* ws, const int64_t* ptr, int64_t N, int64_t B, int64_t num_out,
+                                      int64_t* node_index, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(ws && ptr && N >= 0 && B >= 0 && num_out >= 0, TGP_ERR_INVALID, "tgp_topk_minscore_fill: bad argument");
+  if (num_out == 0 || B == 0) return TGP_OK;
+  TGP_REQUIRE(node_index, TGP_ERR_INVALID, "tgp_topk_minscore_fill: null output");
+  Carver cv(const_cast<void*>(ws));
+  const uint8_t* keep = cv.take<uint8_t>(N);
+  (void)cv.take<uint32_t>(B + 1);
+  const uint32_t* off = cv.take<uint32_t>(B + 1);
+  hipLaunchKernelGGL(topk_minscore_fill_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, keep, ptr, off,
+                     node_index);
+  return check_launch("tgp_topk_minscore_fill");
 }

@@ -81,6 +81,9 @@ SIGNATURES = {
     "tgp_topk_select_workspace_bytes": (_c_sz, [_c_i64]),
     "tgp_topk_select": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_sz, _c_p, _c_p, _c_p,
                                  _c_p]),
+    "tgp_topk_minscore_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
+    "tgp_topk_minscore_count": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_f, _c_f, _c_p, _c_p, _c_sz, _c_p, _c_p]),
+    "tgp_topk_minscore_fill": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_graclus_match_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
     "tgp_graclus_match_start": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_graclus_match_rounds": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_p, _c_p]),

@@ -511,6 +511,33 @@ def edge_dot(s: Tensor, edge_index: Tensor) -> Tensor:
     return _EdgeDotFn.apply(s, edge_index) if _needs_grad(s) else K.edge_dot(s, edge_index)
 
 
+# ------------------------------------------------------------------ TopkSelect, min_score mode
+class _SegmentSoftmaxSelectFn(torch.autograd.Function):
+    """(prob, node_index) of TopkSelect's min_score mode (select/topk_select.py:186-194) from the native kernels;
+    d prob / d score is the per-graph softmax Jacobian: g_in = p * (g - sum_graph(g * p))."""
+
+    @staticmethod
+    def forward(ctx, score, ptr, batch, min_score):
+        prob, node_index = K.topk_minscore(score, ptr, min_score)
+        ctx.save_for_backward(prob, batch)
+        ctx.num_graphs = ptr.numel() - 1
+        ctx.mark_non_differentiable(node_index)
+        return prob, node_index
+
+    @staticmethod
+    def backward(ctx, g, _unused):
+        prob, batch = ctx.saved_tensors
+        gp = g * prob
+        seg = gp.new_zeros(ctx.num_graphs).index_add_(0, batch, gp)
+        return gp - prob * seg[batch], None, None, None
+
+
+def segment_softmax_select(score: Tensor, ptr: Tensor, batch: Tensor, min_score: float):
+    if _needs_grad(score):
+        return _SegmentSoftmaxSelectFn.apply(score, ptr, batch, min_score)
+    return K.topk_minscore(score, ptr, min_score)
+
+
 # ------------------------------------------------------------------ gather at unique positions
 class _TakeUniqueFn(torch.autograd.Function):
     """x[index] for an index without repeats (the kept nodes of a top-k selection): the backward is a plain

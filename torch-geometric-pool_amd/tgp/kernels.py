@@ -452,6 +452,26 @@ def mincut_loss_terms(raw: Tensor, den: Tensor, gram: Tensor) -> Tensor:
     return out
 
 
+def topk_minscore(score: Tensor, ptr: Tensor, min_score: float, tol: float = 1e-7) -> Tuple[Tensor, Tensor]:
+    """(prob [N], node_index [k]): per-graph softmax of ``score`` and the nodes above the min_score threshold, ascending
+    (select/topk_select.py:186-194 with PyG's softmax / topk); ``ptr`` = node offsets of the sorted batch."""
+    dev = N.require_device(score, ptr)
+    score, ptr = N.f32c(score.reshape(-1)), N.i64c(ptr)
+    n, B = score.numel(), ptr.numel() - 1
+    prob = torch.empty(n, dtype=torch.float32, device=dev)
+    L = N.lib()
+    ws = N.workspace(L.tgp_topk_minscore_workspace_bytes(n, B), dev)
+    d_count = torch.empty(1, dtype=torch.int64, device=dev)
+    st = N.stream_ptr(dev)
+    N.check(L.tgp_topk_minscore_count(N.ptr(score), N.ptr(ptr), n, B, float(min_score), float(tol), N.ptr(prob),
+                                      N.ptr(ws), ws.numel(), N.ptr(d_count), st), "tgp_topk_minscore_count")
+    k = _read_count(d_count)
+    node_index = torch.empty(k, dtype=torch.int64, device=dev)
+    N.check(L.tgp_topk_minscore_fill(N.ptr(ws), N.ptr(ptr), n, B, k, N.ptr(node_index) if k else None, st),
+            "tgp_topk_minscore_fill")
+    return prob, node_index
+
+
 def topk_plan(sizes: Tensor, ratio: float) -> Tuple[Tensor, Tensor]:
     """(k [B], koff [B+1]): nodes kept per graph (PyG topk: ceil(ratio * n) in fp32, or min(ratio, n)) and their
     exclusive prefix sums, in one launch."""

@@ -475,7 +475,17 @@ class TopkSelect(Select):
                 score = score / self.weight.norm(p=2, dim=-1)
         if self.min_score is None:
             score = self.act(score)
-        else:  # segment softmax, +1e-16 in the denominator as PyG's utils.softmax
+        elif score.is_cuda and score.dtype == torch.float32 and score.numel() > 0 and self._sorted_ptr(batch, have_batch) is not None:
+            # min_score mode on the device: per-graph softmax + threshold + ordered compaction (csrc/topk_select.hip)
+            ptr = self._sorted_ptr(batch, have_batch)
+            prob, node_index = Fn.segment_softmax_select(score, ptr, batch, float(self.min_score))
+            so = SelectOutput(node_index=node_index, num_nodes=x.size(0),
+                              cluster_index=torch.arange(node_index.size(0), device=x.device),
+                              num_supernodes=node_index.size(0), weight=Fn.take_unique(prob, node_index),
+                              s_inv_op=self.s_inv_op, _trusted=True)
+            so._set_one_to_one_index()
+            return so
+        else:  # segment softmax, +1e-16 in the denominator as PyG's utils.softmax (host tensors, unsorted batches)
             nb = num_graphs_of(batch)
             e = (score - _segment_max(score.detach(), batch, nb)[batch]).exp()
             score = e / (e.new_zeros(nb).index_add_(0, batch, e) + 1e-16)[batch]
@@ -488,6 +498,15 @@ class TopkSelect(Select):
                           s_inv_op=self.s_inv_op, _trusted=True)
         so._set_one_to_one_index()
         return so
+
+    @staticmethod
+    def _sorted_ptr(batch: Tensor, have_batch: bool) -> Optional[Tensor]:
+        """Node offsets of the graphs when the batch vector is sorted (memoised batch facts), else None."""
+        from ..utils.ops import batch_info
+        if not have_batch:
+            return torch.tensor([0, batch.numel()], dtype=torch.long, device=batch.device)
+        info = batch_info(batch)
+        return info.ptr if info.is_sorted else None
 
     def _native_select(self, score: Tensor, batch: Optional[Tensor], n: int) -> SelectOutput:
         """Ratio mode on the device: one radix sort + rank + compaction (csrc/topk_select.hip) instead of the two
