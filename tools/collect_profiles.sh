@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box into gpurun_out/<tag>/ (copy what is to be judged into profiles/).
 # usage: tools/collect_profiles.sh <tag>
-tag=${1:-r02}
+tag=${1:-r03}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/$tag
 mkdir -p $out
@@ -15,13 +15,21 @@ pmc() {  # name, counter, command...
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_${name}_$ctr -o run -- "$@" > /dev/null 2> $out/pmc_${name}_$ctr.err
   cp $(find $out/pmc_${name}_$ctr -name "*counter_collection.csv" | head -1) $out/pmc_${name}_$ctr.csv 2>/dev/null
 }
-stats bench python3 bench.py --steps 20 --warmup 5
+python3 bench.py --steps 20 --warmup 5 > $out/bench_line.json 2> $out/bench_line.err
+TGP_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29617 python3 bench.py --workload topk_batch --secondary none --no-cpu-baseline --steps 50 > $out/bench_topk_batch_rccl.json 2> $out/bench_topk_batch_rccl.err
+stats bench python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
 stats c4_graclus_sorted python3 bench.py --workload c4_graclus --secondary none --no-cpu-baseline --steps 50
 stats c4_graclus_unsorted python3 bench.py --workload c4_graclus --unsorted-edges --secondary none --no-cpu-baseline --steps 50
-stats kron python3 tools/bench_kron.py
+stats topk_connect python3 bench.py --workload topk_connect --secondary none --no-cpu-baseline --steps 50
+stats kron python3 tools/bench_kron.py --no-reference
+python3 tools/bench_kron.py > $out/kron.txt 2>&1
+python3 tools/e2e_launches.py > $out/e2e_launches.txt 2>&1
+python3 tools/bench_poolers_e2e.py > $out/e2e_poolers.txt 2>&1
+python3 tools/bench_ndp_large.py > $out/ndp_large.txt 2>&1
 for k in coalesce_c4_sorted subgraph_topk c3 reduce_topk gemm_c2; do
   pmc $k FETCH_SIZE python3 tools/run_kernel.py $k 4
   pmc $k WRITE_SIZE python3 tools/run_kernel.py $k 4
 done
 python3 tools/pmc_summary.py $out > $out/pmc_summary.md
-ls $out | head -50
+rm -rf $out/pmc_*_FETCH_SIZE $out/pmc_*_WRITE_SIZE $out/bench $out/c4_graclus_sorted $out/c4_graclus_unsorted $out/topk_connect $out/kron
+ls $out | head -60
