@@ -208,6 +208,16 @@ int tgp_dense_pool_f32(const float* S, const float* A, const float* X, int64_t B
                        int64_t F, int flags, float eps, const int64_t* graph_sizes /* [B] or NULL */, float* x_pool,
                        float* adj_raw, float* adj_pool, void* ws, size_t ws_bytes, void* stream);
 
+/* The same call for batches the one-wave-per-graph kernel takes (tgp_dense_pool_is_small(B,N,K,F) != 0: N <= 64,
+ * K, F <= 32, B >= 64), which can also leave the per-graph tails of MinCut's two auxiliary losses in
+ * mincut_terms [2,B] while S, A and the raw S^T A S sit in registers / LDS (poolers/mincut.py:226-237 computes them
+ * between Reduce and Connect): [0,b] = -trace(S^T A S) / (trace(S^T D S) + loss_eps) (utils/losses.py:39-56),
+ * [1,b] = || S^T S / ||S^T S||_F - I / sqrt(K) ||_F (utils/losses.py:59-70). */
+int tgp_dense_pool_is_small(int64_t B, int64_t N, int64_t K, int64_t F);
+int tgp_dense_pool_mincut_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K,
+                              int64_t F, int flags, float eps, float loss_eps, float* x_pool, float* adj_raw,
+                              float* adj_pool, float* mincut_terms, void* ws, size_t ws_bytes, void* stream);
+
 /* Generic batched fp32 GEMM on the matrix cores, C[b] = op(A[b]) B[b] with B[b] [Kd,Nc] row-major.
  * trans_a = 0: A[b] is [M,Kd] row-major; 1: A[b] is stored [Kd,M] (C = A^T B).  Used by
  * BaseLift (lift/base_lift.py:138-247: S_inv^T X_pool) and exposed for callers' own products. */

@@ -438,3 +438,63 @@ def test_topk_min_score_mode_gradients(dev):
     (p[so.node_index] * up).sum().backward()
     torch.testing.assert_close(gx, x.grad, rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(gw, sel.weight.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+def test_mincut_terms_from_inside_the_small_graph_kernel(dev, transposed):
+    """Batches of small graphs: the pooling kernel itself leaves the per-graph tails of MinCut's losses (trace of the raw
+    S^T A S, trace(S^T D S), the orthogonality norm); equal to the separate loss kernels and to the oracle, and the
+    pooled outputs are unchanged by asking for them."""
+    import tgp_oracle as O
+    from tgp import kernels as Kn
+    from tgp.utils import losses as L
+    g = torch.Generator().manual_seed(7)
+    B, N, K, F = 100, 57, 19, 30
+    n_b = torch.randint(10, N + 1, (B,), generator=g)
+    mask = torch.arange(N).unsqueeze(0) < n_b.unsqueeze(1)
+    a = (torch.rand(B, N, N, generator=g) < 0.1).float() * torch.rand(B, N, N, generator=g)
+    a = a * mask.unsqueeze(1) * mask.unsqueeze(2)           # directed, weighted, zero padding
+    s = torch.softmax(torch.randn(B, N, K, generator=g), -1) * mask.unsqueeze(-1)
+    x = torch.randn(B, N, F, generator=g) * mask.unsqueeze(-1)
+    ad = a.to(dev)
+    adj_arg = ad.transpose(1, 2).contiguous().transpose(1, 2) if transposed else ad  # same values, transposed memory
+    flags = Kn.dense_flags(True, True, True, False)
+    xp, raw, ap, terms = Kn.dense_pool(s.to(dev), adj_arg, x.to(dev), flags, want_raw=True, mincut_terms=True)
+    assert terms is not None and terms.shape == (2, B)
+    xp0, raw0, ap0 = Kn.dense_pool(s.to(dev), adj_arg, x.to(dev), flags, want_raw=True)
+    assert torch.equal(xp, xp0) and torch.equal(raw, raw0) and torch.equal(ap, ap0)
+    want = L.mincut_loss_terms(ad, s.to(dev), raw0)
+    torch.testing.assert_close(terms, want, rtol=1e-5, atol=1e-6)
+    rawc = O.dense_connect(s, a)
+    torch.testing.assert_close(terms.mean(1).cpu(), torch.stack([O.mincut_loss(a, s, rawc), O.orthogonality_loss(s)]),
+                               rtol=1e-5, atol=1e-6)
+
+
+def test_mincut_pooler_small_graph_batch_losses_vs_oracle(dev):
+    """get_pooler('mincut') forward (no grad) on 128 small graphs: the losses that come out of the fused path equal the
+    autograd path's and the oracle's."""
+    import tgp_oracle as O
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(3)
+    sizes = torch.randint(12, 50, (128,), generator=g)
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(128), sizes)
+    start = torch.cumsum(sizes, 0) - sizes
+    src = torch.arange(n).repeat_interleave(2)
+    dst = start[batch[src]] + (torch.rand(src.numel(), generator=g) * sizes[batch[src]]).long()
+    key = torch.unique(torch.cat([src * n + dst, dst * n + src]))
+    ei = torch.stack([key // n, key % n])
+    ei = ei[:, ei[0] != ei[1]]
+    x = torch.randn(n, 16, generator=g)
+    pooler = get_pooler("mincut", in_channels=16, k=7).to(dev).eval()
+    with torch.no_grad():
+        out = pooler(x=x.to(dev), adj=ei.to(dev), batch=batch.to(dev))
+    lin = pooler.selector.mlp.lins[0]
+    ref = O.dense_pool("mincut", x, ei, None, batch, [lin.weight.detach().cpu()], [lin.bias.detach().cpu()])
+    torch.testing.assert_close(out.x.cpu(), ref["x"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out.edge_index.cpu(), ref["edge_index"], rtol=1e-5, atol=1e-5)
+    for name in ("cut_loss", "ortho_loss"):
+        torch.testing.assert_close(out.loss[name].cpu(), ref["loss"][name], rtol=1e-5, atol=1e-6)
+    out_g = pooler(x=x.to(dev).requires_grad_(True), adj=ei.to(dev), batch=batch.to(dev))
+    for name in ("cut_loss", "ortho_loss"):
+        torch.testing.assert_close(out_g.loss[name].detach(), out.loss[name], rtol=1e-5, atol=1e-6)

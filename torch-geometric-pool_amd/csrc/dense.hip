@@ -86,10 +86,43 @@ extern "C" size_t tgp_dense_pool_workspace_bytes(int64_t B, int64_t N, int64_t K
          align_up(p.post_floats * 4) + 256;
 }
 
+static bool dense_pool_small_ok(int64_t B, int64_t N, int64_t K, int64_t F) {
+  static const int no_small = getenv("TGP_NO_SMALL_GRAPH_KERNEL") ? 1 : 0;
+  return !no_small && N <= SG_N && K <= SG_K && F <= SG_K && B >= 64;  // any N, K, F: padded batches are ragged
+}
+
+extern "C" int tgp_dense_pool_is_small(int64_t B, int64_t N, int64_t K, int64_t F) {
+  return dense_pool_small_ok(B, N, K, F) ? 1 : 0;
+}
+
+static int dense_pool_impl(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K, int64_t F,
+                           int flags, float eps, const int64_t* graph_sizes, float* x_pool, float* adj_raw,
+                           float* adj_pool, float* mincut_terms, float loss_eps, void* ws, size_t ws_bytes,
+                           void* stream_);
+
 extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N,
                                   int64_t K, int64_t F, int flags, float eps, const int64_t* graph_sizes,
                                   float* x_pool,
                                   float* adj_raw, float* adj_pool, void* ws, size_t ws_bytes, void* stream_) {
+  return dense_pool_impl(S, A, X, B, N, K, F, flags, eps, graph_sizes, x_pool, adj_raw, adj_pool, nullptr, 0.f, ws,
+                         ws_bytes, stream_);
+}
+
+extern "C" int tgp_dense_pool_mincut_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N,
+                                         int64_t K, int64_t F, int flags, float eps, float loss_eps, float* x_pool,
+                                         float* adj_raw, float* adj_pool, float* mincut_terms, void* ws,
+                                         size_t ws_bytes, void* stream_) {
+  TGP_REQUIRE(mincut_terms && A, TGP_ERR_INVALID, "tgp_dense_pool_mincut_f32: mincut_terms / A is null");
+  TGP_REQUIRE(dense_pool_small_ok(B, N, K, F), TGP_ERR_INVALID,
+              "tgp_dense_pool_mincut_f32: only batches the one-wave-per-graph kernel takes (tgp_dense_pool_is_small)");
+  return dense_pool_impl(S, A, X, B, N, K, F, flags, eps, nullptr, x_pool, adj_raw, adj_pool, mincut_terms, loss_eps,
+                         ws, ws_bytes, stream_);
+}
+
+static int dense_pool_impl(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K, int64_t F,
+                           int flags, float eps, const int64_t* graph_sizes, float* x_pool, float* adj_raw,
+                           float* adj_pool, float* mincut_terms, float loss_eps, void* ws, size_t ws_bytes,
+                           void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0 && F >= 0, TGP_ERR_INVALID, "tgp_dense_pool_f32: negative size");
   if (B == 0 || K == 0) return TGP_OK;
@@ -104,12 +137,10 @@ extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X
     if (adj_pool) (void)hipMemsetAsync(adj_pool, 0, sizeof(float) * B * K * K, stream);
     return check_launch("tgp_dense_pool_f32");
   }
-  static const int no_small = getenv("TGP_NO_SMALL_GRAPH_KERNEL") ? 1 : 0;
-  const bool small_ok = N <= SG_N && K <= SG_K && F <= SG_K && B >= 64;  // any N, K, F: padded batches are ragged
-  if (!no_small && small_ok) {
+  if (dense_pool_small_ok(B, N, K, F)) {
     SmallArgs q{S, want_a ? A : nullptr, want_x ? X : nullptr, static_cast<int>(B), static_cast<int>(N),
                 static_cast<int>(K), static_cast<int>(F), flags, eps, want_x ? x_pool : nullptr,
-                want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr};
+                want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr, want_a ? mincut_terms : nullptr, loss_eps};
     const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize,

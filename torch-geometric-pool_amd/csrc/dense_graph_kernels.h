@@ -20,14 +20,26 @@ namespace tgp {
 // (utils/ops.py:282-335) happens in registers + wave shuffles.  Each graph crosses HBM once: HBM-bound.
 // ------------------------------------------------------------------------------------------
 constexpr int SG_N = 64, SG_K = 32, SG_LDA = 65;
-constexpr int SG_WAVE_FLOATS = SG_N * SG_LDA;  // A only
+constexpr int SG_WAVE_FLOATS = SG_N * SG_LDA + SG_N;  // the A tile, then the node degrees of the fused MinCut terms
 
 struct SmallArgs {
   const float* S; const float* A; const float* X;
   int B, N, K, F, flags;
   float eps;
   float* x_pool; float* adj_raw; float* adj_pool;
+  // optional [2,B] (r3): the per-graph tails of MinCut's two auxiliary losses (utils/losses.py:39-70), taken where S,
+  // A and the raw S^T A S already sit in registers / LDS: terms[b] = -trace(S^T A S) / (trace(S^T D S) + loss_eps),
+  // terms[B + b] = || S^T S / ||S^T S||_F - I / sqrt(K) ||_F  (five more launches and a second pass over A and S when
+  // computed behind the pooling kernel)
+  float* mincut_terms;
+  float loss_eps;
 };
+
+__device__ __forceinline__ float sg_wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+  return v;
+}
 
 __device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 // uniform base + 32-bit per-lane byte offset: lets the load use the SGPR-base addressing form
@@ -177,6 +189,54 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
 
       TGP_WSTAMP(3);
       // aa[r] = A'[row = rho(r) + 4*lk][col = lm]
+      if (p.mincut_terms) {
+        float tr = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rho(r) + 4 * lk == lm) tr += aa[r];
+        tr = sg_wave_sum(tr);
+        // degrees: lane i sums row i of the (logical) adjacency tile; rows / columns beyond N are zero
+        float* s_deg = As + SG_N * SG_LDA;
+        {
+          float dsum = 0.f;
+          const float* rowp = As + lane * SG_LDA;
+#pragma unroll 16
+          for (int j = 0; j < SG_N; ++j) dsum += rowp[j];
+          s_deg[lane] = dsum;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float den = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+          const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
+          den = fmaf(s_deg[node], sr[q] * sr[q], den);
+        }
+        den = sg_wave_sum(den);
+        f32x16 gg;  // S^T S: lane = column, register r = row rho(r) + 4 lk
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gg[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) gg = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[q], sr[q], gg, 0, 0, 0);
+        float fro = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fro = fmaf(gg[r], gg[r], fro);
+        const float nrm = sqrtf(sg_wave_sum(fro));
+        const float tdiag = 1.0f / sqrtf(static_cast<float>(K));
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rho(r) + 4 * lk;
+          if (row < K && lm < K) {
+            const float y = gg[r] / nrm - (row == lm ? tdiag : 0.f);
+            acc = fmaf(y, y, acc);
+          }
+        }
+        acc = sg_wave_sum(acc);
+        if (lane == 0) {
+          p.mincut_terms[b] = -(tr / (den + p.loss_eps));
+          p.mincut_terms[p.B + b] = sqrtf(acc);
+        }
+      }
       if (p.adj_raw && lm < K) {
         float* o = p.adj_raw + static_cast<long>(b) * K * K;
 #pragma unroll

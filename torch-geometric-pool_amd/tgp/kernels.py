@@ -341,10 +341,12 @@ def _out_buffer(out: Optional[Tensor], shape, dev) -> Tensor:
 
 def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int = 0, want_raw: bool = False,
                want_post: bool = True, graph_sizes: Optional[Tensor] = None, out_x: Optional[Tensor] = None,
-               out_adj: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
+               out_adj: Optional[Tensor] = None, mincut_terms: bool = False):
     """(x_pool, adj_raw, adj_pool) = (S^T X, S^T A S, postprocess(S^T A S)) for a padded batch
     (reduce/base_reduce.py:158-161, connect/dense_conn.py:111-122, utils/ops.py:282-335).  ``graph_sizes`` [B]
-    (optional): real nodes per graph when they are the leading rows and the padding is zero (to_dense_batch layout)."""
+    (optional): real nodes per graph when they are the leading rows and the padding is zero (to_dense_batch layout).
+    ``mincut_terms``: return a fourth value, the [2,B] per-graph tails of MinCut's losses taken inside the pooling
+    kernel (batches of small graphs only; None when the batch takes another kernel)."""
     dev = N.require_device(s, adj, x)
     s = N.f32c(s)
     B, Nn, K = s.shape
@@ -368,11 +370,20 @@ def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int
             adj_pool = _out_buffer(out_adj, (B, K, K), dev)
     L = N.lib()
     ws = N.workspace(L.tgp_dense_pool_workspace_bytes(B, Nn, K, F), dev)
+    if mincut_terms:
+        terms = None
+        if a is not None and L.tgp_dense_pool_is_small(B, Nn, K, F):
+            terms = torch.empty(2, B, dtype=torch.float32, device=dev)
+            N.check(L.tgp_dense_pool_mincut_f32(N.ptr(s), N.ptr(a), N.ptr(x), B, Nn, K, F, flags, ops_eps(),
+                                                losses_eps(), N.ptr(x_pool), N.ptr(adj_raw), N.ptr(adj_pool),
+                                                N.ptr(terms), N.ptr(ws), ws.numel(), N.stream_ptr(dev)),
+                    "tgp_dense_pool_mincut_f32")
+            return x_pool, adj_raw, adj_pool, terms
     gs = _sizes_arg(graph_sizes, B, dev)
     N.check(L.tgp_dense_pool_f32(N.ptr(s), N.ptr(a), N.ptr(x), B, Nn, K, F, flags, ops_eps(), N.ptr(gs), N.ptr(x_pool),
                                  N.ptr(adj_raw), N.ptr(adj_pool), N.ptr(ws), ws.numel(), N.stream_ptr(dev)),
             "tgp_dense_pool_f32")
-    return x_pool, adj_raw, adj_pool
+    return (x_pool, adj_raw, adj_pool, None) if mincut_terms else (x_pool, adj_raw, adj_pool)
 
 
 def postprocess_dense(adj_pool: Tensor, flags: int, inplace: bool = False) -> Tensor:

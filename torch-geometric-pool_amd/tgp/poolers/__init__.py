@@ -152,7 +152,7 @@ class _DenseMLPPooling(DenseSRCPooling):
 
     _loss_needs_raw = False  # MinCut's cut loss reads the raw S^T A S
 
-    def _loss_from_fused(self, adj, so, mask, raw) -> dict:
+    def _loss_from_fused(self, adj, so, mask, raw, terms=None) -> dict:
         raise NotImplementedError
 
     def _lift(self, x, so, batch, batch_pooled):
@@ -193,11 +193,12 @@ class _DenseMLPPooling(DenseSRCPooling):
             if graph_sizes is not None and graph_sizes.numel() == x.size(0):
                 so._graph_sizes = graph_sizes
                 self._sizes_hint = (weakref.ref(adj), graph_sizes)  # valid for exactly this adjacency tensor
-            fused = self.reduce_connect(x, adj, so, want_raw=self._loss_needs_raw)
+            fused = self.reduce_connect(x, adj, so, want_raw=self._loss_needs_raw,
+                                        want_mincut_terms=self._loss_needs_raw)
             if fused is not None:  # inference: Reduce + Connect in one native call
-                x_pool, raw, adj_pool = fused
+                x_pool, raw, adj_pool = fused[:3]
                 batch_pool = self.reducer.reduce_batch(so, batch if batch is not None else so.batch)
-                loss = self._loss_from_fused(adj, so, mask, raw)
+                loss = self._loss_from_fused(adj, so, mask, raw, fused[3] if len(fused) > 3 else None)
             else:
                 x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch)
                 adj_pool, loss = self._batched_connect_and_loss(x, adj, so, mask, edge_weight, batch, batch_pool)
@@ -236,7 +237,7 @@ class DiffPool(_DenseMLPPooling):
         loss = self.compute_loss(adj=adj, S=so.s, num_nodes=self._real_nodes(mask))
         return adj_pool, loss
 
-    def _loss_from_fused(self, adj, so, mask, raw) -> dict:
+    def _loss_from_fused(self, adj, so, mask, raw, terms=None) -> dict:
         return self.compute_loss(adj=adj, S=so.s, num_nodes=self._real_nodes(mask))
 
     def compute_loss(self, adj: Tensor, S: Tensor, num_nodes: int) -> dict:
@@ -284,7 +285,12 @@ class MinCutPooling(_DenseMLPPooling):
 
     _loss_needs_raw = True
 
-    def _loss_from_fused(self, adj, so, mask, raw) -> dict:
+    def _loss_from_fused(self, adj, so, mask, raw, terms=None) -> dict:
+        if terms is not None and so.s.dtype == torch.float32:
+            # both per-graph loss tails came out of the pooling kernel itself (batches of small graphs)
+            both = terms.mean(dim=1)
+            return {"cut_loss": both[0] if self.cut_loss_coeff == 1 else both[0] * self.cut_loss_coeff,
+                    "ortho_loss": both[1] if self.ortho_loss_coeff == 1 else both[1] * self.ortho_loss_coeff}
         return self.compute_loss(adj, so.s, raw)
 
     def compute_loss(self, adj: Tensor, S: Tensor, adj_pooled: Tensor) -> dict:
@@ -293,7 +299,8 @@ class MinCutPooling(_DenseMLPPooling):
                                                        or adj_pooled.requires_grad))):
             # inference: both losses' per-graph tails in one launch (as torch ops: ~14 launches of a few hundred bytes)
             both = mincut_loss_terms(adj, S, adj_pooled, graph_sizes=self._sizes_for(adj)).mean(dim=1)
-            return {"cut_loss": both[0] * self.cut_loss_coeff, "ortho_loss": both[1] * self.ortho_loss_coeff}
+            return {"cut_loss": both[0] if self.cut_loss_coeff == 1 else both[0] * self.cut_loss_coeff,
+                    "ortho_loss": both[1] if self.ortho_loss_coeff == 1 else both[1] * self.ortho_loss_coeff}
         return {"cut_loss": mincut_loss(adj, S, adj_pooled, batch_reduction="mean",
                                         graph_sizes=self._sizes_for(adj)) * self.cut_loss_coeff,
                 "ortho_loss": orthogonality_loss(S, batch_reduction="mean",

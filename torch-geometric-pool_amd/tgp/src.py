@@ -287,7 +287,8 @@ class DenseSRCPooling(SRCPooling):
         self.preprocessing_cache = None
 
     def reduce_connect(self, x: Tensor, adj: Tensor, so: SelectOutput, want_raw: bool = False,
-                       out_x: Optional[Tensor] = None, out_adj: Optional[Tensor] = None):
+                       out_x: Optional[Tensor] = None, out_adj: Optional[Tensor] = None,
+                       want_mincut_terms: bool = False):
         """Reduce + Connect of a padded dense batch as ONE native call (fused A3 + A7 + A8):
         ``(x_pool [B,K,F], raw S^T A S or None, adj_pool [B,K,K])``.  ``U = A S`` is formed once and
         ``S^T [U | X]`` runs as a single grid (one wave per graph when the graphs fit in LDS), so S is read
@@ -310,11 +311,15 @@ class DenseSRCPooling(SRCPooling):
         flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
         # out_x / out_adj (optional, float32 [B,K,F] / [B,K,K]): the kernels write the pooled outputs straight into
         # caller memory, e.g. the next slot of distributed.PackedGather's send buffer (no pack copy before the RCCL call)
-        x_pool, raw, adj_pool = K.dense_pool(s, adj, x, flags, want_raw=want_raw, want_post=True,
-                                             graph_sizes=getattr(so, "_graph_sizes", None), out_x=out_x,
-                                             out_adj=out_adj)
+        out = K.dense_pool(s, adj, x, flags, want_raw=want_raw, want_post=True,
+                           graph_sizes=getattr(so, "_graph_sizes", None), out_x=out_x, out_adj=out_adj,
+                           mincut_terms=want_mincut_terms)
+        x_pool, raw, adj_pool = out[:3]
         # fp32 arithmetic; results carry the dtypes the reference's ATen ops would return
-        return like_input_dtype(x_pool, x), like_input_dtype(raw, s), like_input_dtype(adj_pool, s)
+        res = (like_input_dtype(x_pool, x), like_input_dtype(raw, s), like_input_dtype(adj_pool, s))
+        # want_mincut_terms: a fourth value, the [2,B] loss tails from inside the pooling kernel (None when the batch
+        # does not take the one-wave-per-graph kernel)
+        return res + (out[3],) if want_mincut_terms else res
 
     def _finalize_sparse_output(self, x_pool: Tensor, adj_pool: Tensor, batch: Optional[Tensor],
                                 batch_pooled: Optional[Tensor], so: SelectOutput):
