@@ -313,6 +313,13 @@ int tgp_link_loss_f32(const float* S, const float* A, int64_t B, int64_t N, int6
                       size_t ws_bytes, void* stream);
 size_t tgp_entropy_sum_workspace_bytes(int64_t n);
 int tgp_entropy_sum_f32(const float* S, int64_t n, float eps, float* out, void* ws, size_t ws_bytes, void* stream);
+/* DiffPool's losses (poolers/diffpool.py:262-284) from the native partial results in one launch:
+ * out2[0] = sqrt(sum_b sq[b]) * link_scale (sq from tgp_link_loss_f32), out2[1] = (sum of ent_partial) * ent_scale
+ * (ent_partial from tgp_entropy_partials_f32: *n_partial_out block sums of -S log(S + eps) in `ws`). */
+int tgp_entropy_partials_f32(const float* S, int64_t n, float eps, void* ws, size_t ws_bytes, int* n_partial_out,
+                             void* stream);
+int tgp_diffpool_loss_tail_f32(const float* sq, int64_t B, const float* ent_partial, int n_partial, float link_scale,
+                               float ent_scale, float* out2, void* stream);
 int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int64_t N, int64_t K,
                       const int64_t* graph_sizes /* [B] or NULL */, float* deg, float* q, float* den, void* stream);
 /* Per-graph tails of MinCut's losses in one launch: out[0,b] = -trace(raw[b]) / (den[b] + eps) (utils/losses.py:39-56),
@@ -346,6 +353,10 @@ int tgp_from_dense_adj_f32(const float* grad_adj, const int64_t* row, const int6
 /* inverse gather of tgp_to_dense_batch_f32 (its backward): x[i,:] = dense[batch[i], i - ptr[batch[i]], :] */
 int tgp_from_dense_batch_f32(const float* dense, int64_t N, int64_t F, const int64_t* batch, const int64_t* ptr,
                              int64_t B, int64_t Nmax, float* x, void* stream);
+/* to_dense_batch for a SORTED batch vector (graph b = nodes ptr[b] .. ptr[b+1]): output-parallel, padding and mask
+ * written by the same kernel (no memsets in front). */
+int tgp_to_dense_batch_sorted_f32(const float* x, int64_t num_nodes, int64_t F, const int64_t* ptr, int64_t B,
+                                  int64_t Nmax, float* out, uint8_t* mask, void* stream);
 int tgp_to_dense_batch_f32(const float* x, int64_t num_nodes, int64_t num_features, const int64_t* batch,
                            const int64_t* ptr, int64_t B, int64_t Nmax, float* out, uint8_t* mask, void* stream);
 

@@ -498,3 +498,32 @@ def test_mincut_pooler_small_graph_batch_losses_vs_oracle(dev):
     out_g = pooler(x=x.to(dev).requires_grad_(True), adj=ei.to(dev), batch=batch.to(dev))
     for name in ("cut_loss", "ortho_loss"):
         torch.testing.assert_close(out_g.loss[name].detach(), out.loss[name], rtol=1e-5, atol=1e-6)
+
+
+def test_diffpool_loss_tail_and_sorted_dense_batch(dev):
+    """DiffPool's inference losses through the one-launch tail equal the autograd path and the oracle; to_dense_batch
+    for a sorted batch vector (no memsets) equals the scatter form, padding and mask included."""
+    import tgp_oracle as O
+    from tgp import kernels as Kn
+    from tgp.utils import losses as L
+    g = torch.Generator().manual_seed(9)
+    B, N, K = 20, 33, 6
+    a = (torch.rand(B, N, N, generator=g) < 0.15).float()
+    a = torch.maximum(a, a.transpose(1, 2))
+    s = torch.softmax(torch.randn(B, N, K, generator=g), -1)
+    for normalize, coeff in ((False, 1.0), (True, 0.3)):
+        scale = coeff / a.numel() if normalize else coeff
+        both = Kn.diffpool_loss_tail(s.to(dev), a.to(dev), None, scale, 2.0 / (B * N)).cpu()
+        torch.testing.assert_close(both[0], O.link_pred_loss(s, a, normalize) * coeff, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(both[1], O.entropy_loss(s, B * N) * 2.0, rtol=1e-5, atol=1e-7)
+    sg = s.to(dev).requires_grad_(True)
+    torch.testing.assert_close(L.link_pred_loss(sg, a.to(dev), False).detach().cpu(),
+                               Kn.diffpool_loss_tail(s.to(dev), a.to(dev), None, 1.0, 1.0).cpu()[0], rtol=1e-5, atol=1e-7)
+    # sorted to_dense_batch vs the oracle (ragged sizes, an empty graph in the middle)
+    sizes = torch.tensor([5, 0, 17, 1, 9])
+    batch = torch.repeat_interleave(torch.arange(5), sizes)
+    x = torch.randn(int(sizes.sum()), 7, generator=g)
+    from tgp.src import to_dense_batch
+    got, mask = to_dense_batch(x.to(dev), batch.to(dev), batch_size=5)
+    want, wmask = O.to_dense_batch(x, batch)
+    assert got.shape[0] == 5 and torch.equal(got.cpu()[:, : want.size(1)], want) and torch.equal(mask.cpu()[:, : want.size(1)], wmask)

@@ -127,6 +127,26 @@ __global__ __launch_bounds__(256) void mincut_tail_kernel(const float* __restric
   }
 }
 
+// DiffPool's two losses from their native partial results in ONE launch (poolers/diffpool.py:262-284):
+//   out[0] = sqrt(sum_b sq[b]) * link_scale     (link_scale = link_loss_coeff, / adj.numel() when normalize_loss)
+//   out[1] = (sum of the entropy partial sums) * ent_scale   (ent_scale = ent_loss_coeff / num_nodes)
+// (as torch ops behind the kernels: sum, sqrt, two multiplications, a final-sum kernel and a division)
+__global__ __launch_bounds__(256) void diffpool_tail_kernel(const float* __restrict__ sq, int B,
+                                                            const float* __restrict__ ent_partial, int n_partial,
+                                                            float link_scale, float ent_scale,
+                                                            float* __restrict__ out) {
+  __shared__ float sh[4];
+  float a = 0.f, e = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) a += sq[i];
+  for (int i = threadIdx.x; i < n_partial; i += 256) e += ent_partial[i];
+  a = block_sum_256(a, sh);
+  e = block_sum_256(e, sh);
+  if (threadIdx.x == 0) {
+    out[0] = sqrtf(a) * link_scale;
+    out[1] = e * ent_scale;
+  }
+}
+
 // ss[e] = <S[row_e,:], S[col_e,:]>: the per-edge entries of S S^T that the sparse (unbatched) losses need
 // (utils/losses.py:73-127 sparse_mincut_loss, :661-708 sparse_link_pred_loss compute (S[src] * S[dst]).sum(-1),
 // which materialises two [E,K] gathers and their product).  G lanes share an edge (float4 each when VEC),
@@ -202,6 +222,30 @@ extern "C" int tgp_entropy_sum_f32(const float* S, int64_t n, float eps, float* 
   hipLaunchKernelGGL(entropy_partial_kernel, dim3(blocks), dim3(256), 0, stream, S, n, eps, partial);
   hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, out);
   return check_launch("tgp_entropy_sum_f32");
+}
+
+// entropy partial sums only (ws: RED_BLOCKS floats; *n_partial_out slots are written), for tgp_diffpool_loss_tail_f32
+extern "C" int tgp_entropy_partials_f32(const float* S, int64_t n, float eps, void* ws, size_t ws_bytes,
+                                        int* n_partial_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(n >= 0 && ws && n_partial_out && (n == 0 || S), TGP_ERR_INVALID, "tgp_entropy_partials_f32: bad argument");
+  TGP_REQUIRE(ws_bytes >= tgp_entropy_sum_workspace_bytes(n), TGP_ERR_WORKSPACE,
+              "tgp_entropy_partials_f32: workspace too small");
+  int blocks = cdiv(n, 256 * 4 * 4);
+  if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  *n_partial_out = blocks;
+  hipLaunchKernelGGL(entropy_partial_kernel, dim3(blocks), dim3(256), 0, stream, S, n, eps, static_cast<float*>(ws));
+  return check_launch("tgp_entropy_partials_f32");
+}
+
+extern "C" int tgp_diffpool_loss_tail_f32(const float* sq, int64_t B, const float* ent_partial, int n_partial,
+                                          float link_scale, float ent_scale, float* out2, void* stream_) {
+  TGP_REQUIRE(B >= 0 && B < (1ll << 31) && n_partial >= 0 && out2 && (B == 0 || sq) && (n_partial == 0 || ent_partial),
+              TGP_ERR_INVALID, "tgp_diffpool_loss_tail_f32: bad argument");
+  hipLaunchKernelGGL(diffpool_tail_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), sq,
+                     static_cast<int>(B), ent_partial, n_partial, link_scale, ent_scale, out2);
+  return check_launch("tgp_diffpool_loss_tail_f32");
 }
 
 extern "C" int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int64_t N, int64_t K,

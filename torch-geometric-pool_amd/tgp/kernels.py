@@ -423,6 +423,27 @@ def link_loss_sq(s: Tensor, adj: Tensor, graph_sizes: Optional[Tensor] = None) -
     return sq
 
 
+def diffpool_loss_tail(s: Tensor, adj: Tensor, graph_sizes: Optional[Tensor], link_scale: float,
+                       ent_scale: float) -> Tensor:
+    """[2]: DiffPool's link-prediction loss sqrt(sum_b ||adj_b - s_b s_b^T||^2) * link_scale and entropy loss
+    sum(-s log(s + eps)) * ent_scale (poolers/diffpool.py:262-284) -- the two native partial reductions and ONE tail
+    launch (outside autograd)."""
+    dev = N.require_device(s, adj)
+    sq = link_loss_sq(s, adj, graph_sizes)
+    s32 = N.f32c(s)
+    L = N.lib()
+    ws = N.workspace(L.tgp_entropy_sum_workspace_bytes(s32.numel()), dev)
+    import ctypes as _ct
+    n_partial = _ct.c_int(0)
+    st = N.stream_ptr(dev)
+    N.check(L.tgp_entropy_partials_f32(N.ptr(s32), s32.numel(), losses_eps(), N.ptr(ws), ws.numel(),
+                                       _ct.addressof(n_partial), st), "tgp_entropy_partials_f32")
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    N.check(L.tgp_diffpool_loss_tail_f32(N.ptr(sq), sq.numel(), N.ptr(ws), n_partial.value, float(link_scale),
+                                         float(ent_scale), N.ptr(out), st), "tgp_diffpool_loss_tail_f32")
+    return out
+
+
 def entropy_sum(s: Tensor) -> Tensor:
     """0-d tensor sum(-s log(s + eps)) over every element (utils/losses.py:476-483 before / num_nodes)."""
     dev = N.require_device(s)
@@ -956,6 +977,13 @@ def to_dense_batch(x: Tensor, batch: Tensor, ptr: Tensor, num_graphs: int, max_n
     F = x2.size(1)
     out = torch.empty(num_graphs, max_nodes, F, dtype=torch.float32, device=dev)
     mask = torch.empty(num_graphs, max_nodes, dtype=torch.bool, device=dev)
+    from .utils.ops import batch_info
+    if F > 0 and ptr.numel() == num_graphs + 1 and batch_info(batch).is_sorted:
+        # sorted batch vector (memoised fact): one output-parallel kernel writes rows, padding and mask -- no memsets
+        N.check(N.lib().tgp_to_dense_batch_sorted_f32(N.ptr(x2), x2.size(0), F, N.ptr(ptr), num_graphs, max_nodes,
+                                                      N.ptr(out), N.ptr(mask), N.stream_ptr(dev)),
+                "tgp_to_dense_batch_sorted_f32")
+        return out.view((num_graphs, max_nodes) + tuple(x.shape[1:])), mask
     N.check(N.lib().tgp_to_dense_batch_f32(N.ptr(x2), x2.size(0), F, N.ptr(batch), N.ptr(ptr), num_graphs, max_nodes,
                                            N.ptr(out), N.ptr(mask), N.stream_ptr(dev)), "tgp_to_dense_batch_f32")
     return out.view((num_graphs, max_nodes) + tuple(x.shape[1:])), mask

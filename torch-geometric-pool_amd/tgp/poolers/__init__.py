@@ -241,6 +241,15 @@ class DiffPool(_DenseMLPPooling):
         return self.compute_loss(adj=adj, S=so.s, num_nodes=self._real_nodes(mask))
 
     def compute_loss(self, adj: Tensor, S: Tensor, num_nodes: int) -> dict:
+        if (S.is_cuda and S.dim() == 3 and S.dtype == torch.float32 and adj.dim() == 3 and adj.is_contiguous()
+                and isinstance(num_nodes, int) and num_nodes > 0
+                and not (torch.is_grad_enabled() and (S.requires_grad or adj.requires_grad))):
+            # inference: both losses from their native partial reductions and one tail launch (as torch ops behind
+            # the kernels: sum, sqrt, a final-sum kernel, a division and two multiplications)
+            from .. import kernels as K
+            link_scale = self.link_loss_coeff / adj.numel() if self.normalize_loss is True else self.link_loss_coeff
+            both = K.diffpool_loss_tail(S, adj, self._sizes_for(adj), link_scale, self.ent_loss_coeff / num_nodes)
+            return {"link_loss": both[0], "entropy_loss": both[1]}
         return {"link_loss": link_pred_loss(S, adj, normalize_loss=self.normalize_loss,
                                             graph_sizes=self._sizes_for(adj)) * self.link_loss_coeff,
                 "entropy_loss": entropy_loss(S, num_nodes) * self.ent_loss_coeff}
