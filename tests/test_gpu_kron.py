@@ -339,10 +339,10 @@ def test_ndp_select_device_partition_contract(dev, monkeypatch):
 
 
 def test_ndp_mixed_batch_oversize_graph_does_not_send_the_batch_to_the_host(dev, monkeypatch):
-    """A graph beyond tgp_ndp_max_graph_nodes() (and beyond the Kron kernel's limit) among small ones: the kernels
-    leave it out, NDPSelect partitions THAT graph with the reference's scipy code on its sub-matrix, KronConnect
-    reduces it with the dense library solve on the device; the host's per-graph loop over the whole batch and the
-    host's sparse LU never run.  Result: every small graph satisfies the device contract, the big graph's partition
+    """A graph beyond tgp_ndp_max_graph_nodes() (and beyond the Kron kernel's limit) among small ones: the one-workgroup
+    kernels leave it out, NDPSelect partitions THAT graph with the chip-wide form of the same iteration (r3; r2 used
+    scipy's eigsh on its sub-matrix), KronConnect reduces it with the dense library solve on the device; neither the
+    host eigen-solver nor the host's sparse LU ever run.  Result: every small graph satisfies the device contract, the big graph's partition
     is the sign pattern of its largest eigenvector, the pooled edges equal the block-wise Kron reduction."""
     import scipy.sparse.linalg as spla
     from tgp import kernels as K
@@ -365,7 +365,7 @@ def test_ndp_mixed_batch_oversize_graph_does_not_send_the_batch_to_the_host(dev,
     x = torch.randn(n, 8, generator=torch.Generator().manual_seed(1)).to(dev)
     with torch.no_grad():
         out = pooler(x=x, adj=ei.to(dev), edge_weight=ew.to(dev), batch=batch.to(dev))
-    assert calls == [big], calls  # the host eigen-solver saw the oversize graph and nothing else
+    assert calls == [], calls  # no graph reached the host eigen-solver
     so = out.so
     keep = torch.zeros(n, dtype=torch.bool)
     keep[so.node_index.cpu()] = True
