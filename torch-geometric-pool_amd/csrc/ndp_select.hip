@@ -529,7 +529,10 @@ __global__ __launch_bounds__(NL_THREADS) void nl_reduce_a_kernel(NlVecs v, doubl
   }
 }
 
-// w = r / |r|, aw = Ls w
+// w = r / |r|, aw = Ls w.  NL_G lanes share a row (rows of ~10 entries: one lane per row leaves the 64 lanes of a
+// load instruction on 64 different cache lines of col / w; with 8 lanes per row consecutive lanes read consecutive
+// entries), partial sums folded inside the lane group in a fixed order.
+constexpr int NL_G = 8;
 __global__ __launch_bounds__(NL_THREADS) void nl_matvec_kernel(const int32_t* __restrict__ indptr,
                                                                const int64_t* __restrict__ col,
                                                                const float* __restrict__ w, int64_t p0, int64_t p1,
@@ -538,11 +541,25 @@ __global__ __launch_bounds__(NL_THREADS) void nl_matvec_kernel(const int32_t* __
   if (st->done) return;
   const int64_t n = p1 - p0;
   const double inv_r = st->inv_r;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
-       i += static_cast<int64_t>(gridDim.x) * NL_THREADS) {
-    const double ri = v.raw[i];
-    v.wv[i] = ri * inv_r;
-    v.aw[i] = inv_r * (ri - nl_row_matvec(indptr, col, w, v.dis, v.raw, p0, p1, i, status));
+  const int sub = threadIdx.x % NL_G;
+  const int64_t rows_per_pass = static_cast<int64_t>(gridDim.x) * (NL_THREADS / NL_G);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * (NL_THREADS / NL_G) + threadIdx.x / NL_G; i < n;
+       i += rows_per_pass) {
+    double acc = 0.0;
+    const int e1 = indptr[p0 + i + 1];
+    for (int e = indptr[p0 + i] + sub; e < e1; e += NL_G) {
+      const int64_t c = col[e];
+      if (c < p0 || c >= p1) { atomicOr(status, 2); continue; }
+      const int64_t j = c - p0;
+      acc += (w ? static_cast<double>(w[e]) : 1.0) * static_cast<double>(v.dis[j]) * v.raw[j];
+    }
+#pragma unroll
+    for (int o = NL_G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
+    if (sub == 0) {
+      const double ri = v.raw[i];
+      v.wv[i] = ri * inv_r;
+      v.aw[i] = inv_r * (ri - static_cast<double>(v.dis[i]) * acc);
+    }
   }
 }
 
@@ -765,7 +782,7 @@ extern "C" int tgp_ndp_large_steps(const int32_t* indptr, const int64_t* col, co
   NlVecs v;
   nl_layout(ws, p1 - p0, &v);
   const int64_t n = p1 - p0;
-  const unsigned mv_blocks = static_cast<unsigned>(cdiv(n, NL_THREADS) < 8192 ? cdiv(n, NL_THREADS) : 8192);
+  const unsigned mv_blocks = static_cast<unsigned>(cdiv(n, NL_THREADS / NL_G) < 16384 ? cdiv(n, NL_THREADS / NL_G) : 16384);
   for (int s = 0; s < steps; ++s) {
     hipLaunchKernelGGL(nl_round_a_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, n, v);
     hipLaunchKernelGGL(nl_reduce_a_kernel, dim3(1), dim3(NL_THREADS), 0, stream, v, tol);
