@@ -16,8 +16,15 @@
 // Exactly singular L[-,-] (a component made of dropped nodes only): the block is redone with the reference's
 // Marquardt-Levenberg damping 1e-6 I (kron_conn.py:131-135).
 #include "primitives.h"
+#include <utility>
 
 namespace tgp {
+
+// THE update of every elimination loop in this file: m - (c * u) / pivot as fma(-(c * u), 1 / pivot, m) -- the product is
+// rounded, the rest is one rounding.  c * u commutes, so a symmetric L gives a bitwise symmetric result and the
+// reference's "symmetrise if nearly symmetric" step (kron_conn.py:137-139) is the identity.  (r3: was (c * u) * inv and a
+// subtraction; fp64 multiplies and adds issue at 8 cycles per wave here, the fused form is a third less work.)
+__device__ __forceinline__ double kron_upd(double m, double c, double u, double inv) { return __fma_rn(-(c * u), inv, m); }
 
 constexpr int KRON_LDS_MAX_N = 128;  // 128 x 129 doubles = 132 KB of the 160 KB LDS
 constexpr int KRON_MAX_N = 1024;
@@ -49,6 +56,16 @@ __device__ __forceinline__ int64_t wave_incl_scan64(int64_t v) {
   return v;
 }
 
+// what the multi-workgroup kernels need to know about one of their graphs: ONE 40-byte record read per workgroup
+// (graph_ptr -> rank -> big_off was a chain of three dependent global reads in front of every panel launch)
+struct BigDesc {
+  int g, n, k, m;
+  int64_t p0;   // first node of the graph
+  int64_t off;  // of its n x (n | 1) matrix in the scratch buffer
+  uint32_t r0;  // rank of its first node = first pooled row
+  int pad;
+};
+
 // per graph: offset of its k x k result in the dense buffer, offset of its n x (n|1) scratch matrix (graphs that do
 // not fit LDS), and the size checks.  One 1024-thread workgroup.
 __global__ __launch_bounds__(1024) void kron_plan_kernel(const int64_t* __restrict__ graph_ptr, int B,
@@ -56,7 +73,7 @@ __global__ __launch_bounds__(1024) void kron_plan_kernel(const int64_t* __restri
                                                          int64_t* __restrict__ sq_off, int64_t* __restrict__ big_off,
                                                          int64_t cap_dense, int64_t cap_big, int skip_oversize,
                                                          int lds_cap, int64_t declared_max,
-                                                         int* __restrict__ big_list,
+                                                         BigDesc* __restrict__ big_desc,
                                                          int* __restrict__ big_count, int big_cap,
                                                          int* __restrict__ status) {
   __shared__ int64_t s_w[2][16];
@@ -69,10 +86,14 @@ __global__ __launch_bounds__(1024) void kron_plan_kernel(const int64_t* __restri
   for (int base = 0; base < B; base += 1024) {
     const int g = base + tid;
     int64_t sq = 0, big = 0;
+    int slot = -1;
+    BigDesc desc{};
     if (g < B) {
       const int64_t p0 = graph_ptr[g], p1 = graph_ptr[g + 1];
       const int64_t n = p1 - p0;
       const int64_t k = static_cast<int64_t>(rank[p1]) - static_cast<int64_t>(rank[p0]);
+      desc.g = g; desc.n = static_cast<int>(n); desc.k = static_cast<int>(k); desc.m = static_cast<int>(n - k);
+      desc.p0 = p0; desc.r0 = rank[p0];
       const bool oversize = n > KRON_MAX_N;
       if (n < 0 || (oversize && !skip_oversize)) atomicOr(status, KRON_TOO_LARGE);
       if (!oversize) {  // (skipped graphs take no scratch and emit nothing: the caller reduces them itself)
@@ -80,8 +101,8 @@ __global__ __launch_bounds__(1024) void kron_plan_kernel(const int64_t* __restri
         if (n > lds_cap && k > 0) big = n * (n | 1);
         if (n > declared_max) atomicOr(status, KRON_TOO_LARGE);  // the caller's max_graph_nodes sized the launches
         if (n > lds_cap && k > 0) {  // reduced by the multi-workgroup kernels: any order in the list will do
-          const int slot = atomicAdd(&s_nbig, 1);
-          if (slot < big_cap) big_list[slot] = g; else atomicOr(status, KRON_TOO_LARGE);
+          slot = atomicAdd(&s_nbig, 1);
+          if (slot >= big_cap) { slot = -1; atomicOr(status, KRON_TOO_LARGE); }
         }
       }
     }
@@ -98,6 +119,10 @@ __global__ __launch_bounds__(1024) void kron_plan_kernel(const int64_t* __restri
     if (g < B) {
       sq_off[g] = osq + isq - sq;
       big_off[g] = obig + ibig - big;
+      if (slot >= 0) {
+        desc.off = obig + ibig - big;
+        big_desc[slot] = desc;
+      }
     }
     __syncthreads();
     if (tid == 0) { s_carry[0] += tsq; s_carry[1] += tbig; }
@@ -130,7 +155,7 @@ struct KronArgs {
   int lds_cap;             // graphs up to this many nodes use LDS
   int lds_lo;              // this launch of the LDS kernel takes graphs of lds_lo < n <= lds_hi nodes
   int lds_hi;
-  const int* big_list;     // graphs beyond it (and up to KRON_MAX_N), kept nodes > 0
+  const BigDesc* big_desc; // graphs beyond it (and up to KRON_MAX_N), kept nodes > 0
   const int* big_count;
   int* sing;               // [B] exactly singular L[-,-] met: the graph is redone with damping
   double* big_inv;         // [num_big][KRON_SNB] reciprocal pivots of the step in flight
@@ -187,7 +212,7 @@ __device__ __forceinline__ bool kron_eliminate(double* M, int ld, int n, int m, 
     for (int i = p + 1 + w; i < n; i += NW) {
       const double cip = M[i * ld + p];
       if (cip != 0.0) {
-        for (int j = p + 1 + lane; j < n; j += 64) M[i * ld + j] -= (cip * M[p * ld + j]) * inv;
+        for (int j = p + 1 + lane; j < n; j += 64) M[i * ld + j] = kron_upd(M[i * ld + j], cip, M[p * ld + j], inv);
       }
     }
     __syncthreads();
@@ -230,12 +255,12 @@ __device__ __forceinline__ bool kron_eliminate_blocked(double* M, int ld, int n,
       for (int r = q + 1 + w; r < nb; r += NW) {
         const double crq = pc[r * KRON_NB + q];
         if (crq != 0.0)
-          for (int j = q + 1 + lane; j < rem; j += 64) pu[r * n + j] -= (crq * pu[q * n + j]) * inv;
+          for (int j = q + 1 + lane; j < rem; j += 64) pu[r * n + j] = kron_upd(pu[r * n + j], crq, pu[q * n + j], inv);
       }
       for (int e = threadIdx.x; e < (rem - q - 1) * (nb - q - 1); e += THREADS) {
         const int i = q + 1 + e / (nb - q - 1), c = q + 1 + e % (nb - q - 1);
         const double ciq = pc[i * KRON_NB + q];
-        if (ciq != 0.0) pc[i * KRON_NB + c] -= (ciq * pu[q * n + c]) * inv;
+        if (ciq != 0.0) pc[i * KRON_NB + c] = kron_upd(pc[i * KRON_NB + c], ciq, pu[q * n + c], inv);
       }
       __syncthreads();
     }
@@ -352,15 +377,11 @@ struct BigGraph {
 
 __device__ __forceinline__ bool kron_big_graph(const KronArgs& a, int b, BigGraph* out) {
   if (b >= *a.big_count) return false;
+  const BigDesc d = a.big_desc[b];
   BigGraph q;
-  q.g = a.big_list[b];
-  q.p0 = a.graph_ptr[q.g];
-  q.n = static_cast<int>(a.graph_ptr[q.g + 1] - q.p0);
-  q.r0 = a.rank[q.p0];
-  q.k = static_cast<int>(a.rank[q.p0 + q.n] - q.r0);
-  q.m = q.n - q.k;
+  q.g = d.g; q.p0 = d.p0; q.n = d.n; q.r0 = d.r0; q.k = d.k; q.m = d.m;
   q.ld = q.n | 1;
-  q.M = a.big + a.big_off[q.g];
+  q.M = a.big + d.off;
   *out = q;
   return true;
 }
@@ -398,122 +419,236 @@ __global__ __launch_bounds__(256) void kron_big_build_kernel(KronArgs a) {
 }
 
 // Panel kernel: workgroup (slice, graph) factors the diagonal block D of the step's KRON_SNB pivots (redundantly: it is
-// 32 x 32) and ITS 64-column slice of the pivot rows U and 64-row slice of the pivot columns C, and writes the updated
-// slices back in place; slice 0 also stores the reciprocal pivots.  Register ownership (dependent LDS read-modify-
-// write loops took ~30 us per tile; with every thread's elements in registers a pivot costs one barrier and a handful
-// of independent fp64 operations):
-//   U slice [32][64]: thread (j = tid & 63, g = tid >> 6) holds rows g, g + 4, ... of column j      (8 values)
-//   C slice [64][32]: thread (i = tid & 63, g = tid >> 6) holds columns g, g + 4, ... of row i       (8 values)
-//   D block [32][32]: thread (r = tid >> 3, h = tid & 7) holds columns h, h + 8, h + 16, h + 24      (4 values)
-// Row p of U, column p of C and the D block live in LDS as well: a pivot step reads only them.
-// (Measured r3, 1000-node graph: this form 20 us per launch; one thread per U column / C row doing the whole forward
-//  substitution in registers, no barriers: 41 us -- 496 dependent steps on two waves lose to 32 wide ones.)
-__global__ __launch_bounds__(256) void kron_big_panel_kernel(KronArgs a, int step) {
-  __shared__ double sD[KRON_SNB][KRON_SNB + 1];
-  __shared__ double sU[KRON_SNB][KRON_TILE];
-  __shared__ double sC[KRON_TILE][KRON_SNB + 1];
-  __shared__ double s_inv[KRON_SNB + 1];
-  __shared__ int s_bad;
+// 32 x 32) and ITS slice of KRON_PW columns of the pivot rows U and KRON_PW rows of the pivot columns C, and writes the
+// updated slices back in place; slice 0 also stores the reciprocal pivots.
+//   1. the workgroup stages D and its C rows in LDS with coalesced reads (a C row is 256 contiguous bytes: one thread
+//      per row is 64 cache lines per load instruction, the same in the write-back: 4.6 us of stores per launch); every
+//      thread then holds ONE line in registers: thread t < 128 column S0 + t of U, thread 128 + t row S0 + t of C;
+//   2. wave 0 factors D with no barrier and no LDS traffic: lane r owns row r (32 registers), the pivot row reaches the
+//      other lanes through v_readlane, the next reciprocal is started as soon as its pivot is final; the factored block
+//      is then published twice, sUp[p][r] = D[p][r] and sLo[p][r] = D[r][p] (as they stood at pivot p for r > p; the
+//      other triangle of each copy is never read);
+//   3. ONE barrier, then every thread runs the forward substitution of its own line out of registers (the U columns
+//      against sLo, the C rows against sUp: the same code): x[r] -= (tab[p][r] * x[p]) * inv_p, p ascending.
+// Every element receives the pivots' updates in order with the (c * u) * (1 / pivot) arithmetic of the one-workgroup
+// loops.  (No "multiplier != 0" test: (0 * u) * inv is a zero unless a pivot was singular, and such a graph is redone;
+// x - 0 differs from x at most in the sign of a zero, which nothing downstream looks at.  Rows at or above the pivot
+// are frozen by zeroing their multiplier, the same argument; and a last panel of fewer than 32 pivots is padded with
+// identity pivots and zero lines, for which every update subtracts a zero.)  The updates are written in groups of 8 independent
+// products: left to itself the compiler chained mul -> mul -> sub through one temporary, 42 cycles per element.
+// Measured r3 on the 1000-node graph of profiles/r03_kron.txt: one barrier per pivot with the slices spread over the
+// workgroup's registers took ~37 us per launch (0.9 us per pivot).
+constexpr int KRON_PW = 128;
+constexpr int KRON_CH = 8;
+
+__device__ __forceinline__ double kron_bcast(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// one pivot of the D factorisation / of a line's forward substitution, the pivot a template parameter: with a run-time
+// p the compiler declined to unroll the 32 steps, indexed the register arrays dynamically and put them in scratch
+template <int P>
+__device__ __forceinline__ void kron_dfac_step(double (&d)[KRON_SNB], int row, int lane, double& inv, bool& bad,
+                                               double* s_inv) {
+  if (lane == 0) s_inv[P] = inv;
+  const double crp = row > P ? d[P] : 0.0;  // rows at or above the pivot are final: a zero multiplier freezes them
+  double inv_next = 0.0;
+  if constexpr (P + 1 < KRON_SNB) {  // the next pivot first: its reciprocal is taken while the other columns are updated
+    const double up1 = kron_bcast(d[P + 1], P);
+    d[P + 1] = kron_upd(d[P + 1], crp, up1, inv);
+    const double pn = kron_bcast(d[P + 1], P + 1);
+    inv_next = pn != 0.0 ? 1.0 / pn : 0.0;
+    bad = bad || pn == 0.0 || !(pn == pn);
+  }
+#pragma unroll
+  for (int c0 = P + 2; c0 < KRON_SNB; c0 += KRON_CH) {
+    double t[KRON_CH];
+#pragma unroll
+    for (int i = 0; i < KRON_CH; ++i)
+      if (c0 + i < KRON_SNB) t[i] = kron_bcast(d[c0 + i], P);
+#pragma unroll
+    for (int i = 0; i < KRON_CH; ++i)
+      if (c0 + i < KRON_SNB) t[i] = crp * t[i];
+#pragma unroll
+    for (int i = 0; i < KRON_CH; ++i)
+      if (c0 + i < KRON_SNB) d[c0 + i] = __fma_rn(-t[i], inv, d[c0 + i]);
+  }
+  inv = inv_next;
+}
+
+template <int P>
+__device__ __forceinline__ void kron_subst_step(double (&x)[KRON_SNB], const double* tab, const double* s_inv) {
+  const double t = x[P], ip = s_inv[P];
+#pragma unroll
+  for (int r0 = P + 1; r0 < KRON_SNB; r0 += KRON_CH) {
+    double v[KRON_CH];
+#pragma unroll
+    for (int i = 0; i < KRON_CH; ++i)
+      if (r0 + i < KRON_SNB) v[i] = tab[P * KRON_SNB + r0 + i];
+#pragma unroll
+    for (int i = 0; i < KRON_CH; ++i)
+      if (r0 + i < KRON_SNB) v[i] = v[i] * t;
+#pragma unroll
+    for (int i = 0; i < KRON_CH; ++i)
+      if (r0 + i < KRON_SNB) x[r0 + i] = __fma_rn(-v[i], ip, x[r0 + i]);
+  }
+}
+
+template <int... P>
+__device__ __forceinline__ void kron_dfac_all(double (&d)[KRON_SNB], int row, int lane, double& inv, bool& bad,
+                                              double* s_inv, std::integer_sequence<int, P...>) {
+  (kron_dfac_step<P>(d, row, lane, inv, bad, s_inv), ...);
+}
+
+template <int... P>
+__device__ __forceinline__ void kron_subst_all(double (&x)[KRON_SNB], const double* tab, const double* s_inv,
+                                               std::integer_sequence<int, P...>) {
+  (kron_subst_step<P>(x, tab, s_inv), ...);
+}
+
+// diagnostic build (-DKRON_STAMPS, never shipped): cycle stamps of the panel kernel's phases, printed by one workgroup
+#ifdef KRON_STAMPS
+#define KRON_STAMP(i) st[i] = clock64()
+#define KRON_STAMP_PRINT()                                                                                            \
+  if (q.n == 1000 && slice == 0 && (tid == 0 || tid == 192) && p0 == 0)                                               \
+  printf("panel tid %d cycles: issue-loads %lld wait+bar %lld read-lds %lld dfac %lld publish %lld bar %lld subst %lld " \
+         "to-lds %lld bar %lld store %lld\n", tid, st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], \
+         0ll, st[6] - st[5], st[7] - st[6], st[8] - st[7], st[9] - st[8])
+#else
+#define KRON_STAMP(i)
+#define KRON_STAMP_PRINT()
+#endif
+
+__device__ __forceinline__ void kron_panel_body(const KronArgs& a, const BigGraph& q, int p0, int nb, int slice,
+                                                int graph_slot, double (*sT)[KRON_SNB + 1],
+                                                double (*sDin)[KRON_SNB + 1], double* sF, double* s_inv) {
+  const int T0 = p0 + nb;
+  const int S0 = T0 + slice * KRON_PW;  // this slice: columns S0.. of U, rows S0.. of C
+  const int tid = threadIdx.x, lane = tid & 63;
+  const long ld = q.ld;
+  double* M = q.M;
+  const bool is_u = tid < KRON_PW;
+  const int li = tid & (KRON_PW - 1);
+  const int line = S0 + li;
+  const bool live = line < q.n;
+  double x[KRON_SNB];
+#ifdef KRON_STAMPS
+  long long st[10] = {};
+#endif
+  KRON_STAMP(0);
+  // every load is issued unconditionally from a clamped address and masked afterwards: a branch per guarded load made
+  // the compiler wait for each one in turn (7 us of this kernel's 22)
+  const int lc = line < q.n ? line : q.n - 1;
+  if (is_u) {
+#pragma unroll
+    for (int r = 0; r < KRON_SNB; ++r) x[r] = M[(p0 + (r < nb ? r : nb - 1)) * ld + lc];
+#pragma unroll
+    for (int r = 0; r < KRON_SNB; ++r) x[r] = (live && r < nb) ? x[r] : 0.0;
+  }
+  {
+    double tv[KRON_PW * KRON_SNB / 256], dv[KRON_SNB * KRON_SNB / 256];
+    const int cc = tid & 31, cq = cc < nb ? cc : nb - 1;
+#pragma unroll
+    for (int i = 0; i < KRON_PW * KRON_SNB / 256; ++i) {
+      const int rr = (tid >> 5) + 8 * i, gr = S0 + rr < q.n ? S0 + rr : q.n - 1;
+      tv[i] = M[static_cast<long>(gr) * ld + p0 + cq];
+    }
+#pragma unroll
+    for (int i = 0; i < KRON_SNB * KRON_SNB / 256; ++i) {
+      const int rr = (tid >> 5) + 8 * i;
+      dv[i] = M[(p0 + (rr < nb ? rr : nb - 1)) * ld + p0 + cq];
+    }
+#pragma unroll
+    for (int i = 0; i < KRON_PW * KRON_SNB / 256; ++i) {
+      const int rr = (tid >> 5) + 8 * i;
+      sT[rr][cc] = (S0 + rr < q.n && cc < nb) ? tv[i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < KRON_SNB * KRON_SNB / 256; ++i) {
+      const int rr = (tid >> 5) + 8 * i;
+      sDin[rr][cc] = (rr < nb && cc < nb) ? dv[i] : (rr == cc ? 1.0 : 0.0);
+    }
+  }
+  KRON_STAMP(1);
+  __syncthreads();
+  KRON_STAMP(2);
+  if (!is_u) {
+#pragma unroll
+    for (int r = 0; r < KRON_SNB; ++r) x[r] = sT[li][r];
+  }
+  if (tid < 64) {
+    double d[KRON_SNB];
+    const int row = lane & 31;  // (lanes 32..63 mirror lanes 0..31: their results are never read)
+#pragma unroll
+    for (int c = 0; c < KRON_SNB; ++c) d[c] = sDin[row][c];
+    double piv = kron_bcast(d[0], 0);
+    double inv = piv != 0.0 ? 1.0 / piv : 0.0;
+    bool bad = piv == 0.0 || !(piv == piv);
+    KRON_STAMP(3);
+    kron_dfac_all(d, row, lane, inv, bad, s_inv, std::make_integer_sequence<int, KRON_SNB>{});
+    KRON_STAMP(4);
+    if (lane < KRON_SNB) {
+#pragma unroll
+      for (int c = 0; c < KRON_SNB; ++c) {
+        sF[KRON_SNB * KRON_SNB + row * KRON_SNB + c] = d[c];  // sUp
+        sF[c * KRON_SNB + row] = d[c];                        // sLo
+      }
+    }
+    if (slice == 0 && lane == 0 && bad) a.sing[q.g] = 1;
+  }
+  __syncthreads();
+  KRON_STAMP(5);
+  {
+    const double* tab = sF + __builtin_amdgcn_readfirstlane(is_u ? 0 : KRON_SNB * KRON_SNB);
+    kron_subst_all(x, tab, s_inv, std::make_integer_sequence<int, KRON_SNB>{});
+  }
+  KRON_STAMP(6);
+  // the factored slices go back in place: the trailing kernel (next launch) reads them
+  if (is_u) {
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < KRON_SNB; ++r)
+        if (r < nb) M[(p0 + r) * ld + line] = x[r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < KRON_SNB; ++r) sT[li][r] = x[r];
+  }
+  KRON_STAMP(7);
+  __syncthreads();
+  KRON_STAMP(8);
+#pragma unroll
+  for (int i = 0; i < KRON_PW * KRON_SNB / 256; ++i) {
+    const int e = tid + 256 * i, rr = e >> 5, cc = e & 31;
+    if (S0 + rr < q.n && cc < nb) M[static_cast<long>(S0 + rr) * ld + p0 + cc] = sT[rr][cc];
+  }
+  KRON_STAMP(9);
+  KRON_STAMP_PRINT();
+  if (slice == 0 && tid < nb) a.big_inv[static_cast<long>(graph_slot) * KRON_SNB + tid] = s_inv[tid];
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void kron_big_panel_kernel(KronArgs a,
+                                                                                                       int step) {
+  __shared__ double sT[KRON_PW][KRON_SNB + 1];
+  __shared__ double sDin[KRON_SNB][KRON_SNB + 1];
+  __shared__ double sF[2 * KRON_SNB * KRON_SNB];  // sLo | sUp
+  __shared__ double s_inv[KRON_SNB];
   BigGraph q;
   if (!kron_big_graph(a, blockIdx.y, &q)) return;
   const int p0 = step * KRON_SNB;
   if (p0 >= q.m) return;
   const int nb = q.m - p0 < KRON_SNB ? q.m - p0 : KRON_SNB;
-  const int T0 = p0 + nb;
-  const int S0 = T0 + blockIdx.x * KRON_TILE;  // this slice: columns S0.. of U, rows S0.. of C
-  if (S0 >= q.n) return;
-  const int width = q.n - S0 < KRON_TILE ? q.n - S0 : KRON_TILE;
-  const int tid = threadIdx.x;
-  const long ld = q.ld;
-  double* M = q.M;
-  const int j = tid & 63, g = tid >> 6;
-  double u[8], c[8], d[4];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int r = g + 4 * t;
-    u[t] = (r < nb && j < width) ? M[(p0 + r) * ld + S0 + j] : 0.0;
-    c[t] = (r < nb && j < width) ? M[(S0 + j) * ld + p0 + r] : 0.0;  // (row j of the C slice, column r)
-    sU[r][j] = u[t];
-    sC[j][r] = c[t];
-  }
-  const int dr = tid >> 3, dh = tid & 7;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int cc = dh + 8 * t;
-    d[t] = (dr < nb && cc < nb) ? M[(p0 + dr) * ld + p0 + cc] : 0.0;
-    sD[dr][cc] = d[t];
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const double piv = sD[0][0];
-    s_inv[0] = piv != 0.0 ? 1.0 / piv : 0.0;
-    s_bad = (piv == 0.0 || !(piv == piv)) ? 1 : 0;
-  }
-  __syncthreads();
-  // One barrier per pivot: step p READS row p / column p of the LDS images (and 1 / pivot), and WRITES only rows and
-  // columns beyond p (the D entries, row p + 1 of U, column p + 1 of C, the next reciprocal), so the write-backs of step
-  // p need no barrier against its own reads.  The owner of D[p+1][p+1] takes the reciprocal as soon as that entry is
-  // final, off the other threads' critical path.
-  for (int p = 0; p < nb; ++p) {
-    const double inv = s_inv[p];
-    {  // D: rows / columns beyond the pivot
-      const double crp = sD[dr][p];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int cc = dh + 8 * t;
-        const double upd = d[t] - (crp * sD[p][cc]) * inv;
-        if (dr > p && cc > p && crp != 0.0) d[t] = upd;
-        if (dr > p && cc > p) sD[dr][cc] = d[t];
-        if (dr == p + 1 && cc == p + 1) {
-          const double piv = d[t];
-          s_inv[p + 1] = piv != 0.0 ? 1.0 / piv : 0.0;
-          if ((piv == 0.0 || !(piv == piv)) && p + 1 < nb) s_bad = 1;
-        }
-      }
-    }
-    {  // U slice: rows beyond the pivot; C slice: columns beyond the pivot
-      const double up = sU[p][j], cip = sC[j][p];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int r = g + 4 * t;
-        const double crp = sD[r][p];
-        const double nu = u[t] - (crp * up) * inv;
-        if (r > p && crp != 0.0) u[t] = nu;
-        const double nc = c[t] - (cip * sD[p][r]) * inv;
-        if (r > p && cip != 0.0) c[t] = nc;
-      }
-    }
-    if (((p + 1) & 3) == g && p + 1 < KRON_SNB) {  // the owners of row / column p + 1 publish it for the next pivot
-      const int t = (p + 1) >> 2;
-      double uv = 0.0, cv = 0.0;
-#pragma unroll
-      for (int x = 0; x < 8; ++x) {
-        uv = x == t ? u[x] : uv;
-        cv = x == t ? c[x] : cv;
-      }
-      sU[p + 1][j] = uv;
-      sC[j][p + 1] = cv;
-    }
-    __syncthreads();
-  }
-  // the factored slices go back in place: the trailing kernel (next launch) reads them
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int r = g + 4 * t;
-    if (r < nb && j < width) {
-      M[(p0 + r) * ld + S0 + j] = u[t];
-      M[(S0 + j) * ld + p0 + r] = c[t];
-    }
-  }
-  if (blockIdx.x == 0) {
-    if (tid < nb) a.big_inv[static_cast<long>(blockIdx.y) * KRON_SNB + tid] = s_inv[tid];
-    if (tid == 0 && s_bad) a.sing[q.g] = 1;
-  }
+  if (p0 + nb + static_cast<int>(blockIdx.x) * KRON_PW >= q.n) return;
+  kron_panel_body(a, q, p0, nb, blockIdx.x, blockIdx.y, sT, sDin, sF, s_inv);
 }
 
-// Trailing kernel: one 64 x 64 tile per workgroup, M[i][j] -= sum over the step's pivots of (C[i][p] * U[p][j]) * inv_p, in
-// pivot order (the arithmetic of the single-workgroup loops); thread = (column j, rows g, g + 4, ...).
-// (64 x 128 tiles with two columns per thread measured slower: 16 vs 11.6 us per launch.)
+// Trailing kernel: one 64 x 64 tile per workgroup, M[i][j] = kron_upd(M[i][j], C[i][p], U[p][j], inv_p) over the step's
+// pivots in order (the arithmetic of the single-workgroup loops).  16 x 16 threads with a 4 x 4 register tile each (rows
+// ti + 16 a, columns tj + 16 b): a pivot costs 8 LDS reads for 16 updates (one column per thread: 17 reads for 16, and the
+// LDS reads were a third of the loop).  Loads are issued from clamped addresses and masked afterwards (a branch per
+// guarded load serialised them).  (64 x 128 tiles measured slower in r3: 16 vs 11.6 us per launch.)
 __global__ __launch_bounds__(256) void kron_big_trail_kernel(KronArgs a, int step) {
   __shared__ double sU[KRON_SNB][KRON_TILE];
   __shared__ double sC[KRON_TILE][KRON_SNB + 1];
@@ -532,38 +667,82 @@ __global__ __launch_bounds__(256) void kron_big_trail_kernel(KronArgs a, int ste
   const int tid = threadIdx.x;
   const long ld = q.ld;
   double* M = q.M;
-  const int j = tid & 63, g = tid >> 6;
-  double v[16];
+  const int tj = tid & 15, ti = tid >> 4;
+#ifdef KRON_STAMPS
+  long long tt[5] = {};
+  tt[0] = clock64();
+#endif
+  double v[4][4];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int i = g + 4 * t;
-    v[t] = (i < rows && j < cols) ? M[(R0 + i) * ld + C0 + j] : 0.0;
-  }
+  for (int x = 0; x < 4; ++x) {
+    const int i = ti + 16 * x, gi = R0 + (i < rows ? i : rows - 1);
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int r = g + 4 * t;
-    sU[r][j] = (r < nb && j < cols) ? M[(p0 + r) * ld + C0 + j] : 0.0;
+    for (int y = 0; y < 4; ++y) {
+      const int j = tj + 16 * y;
+      v[x][y] = M[gi * ld + C0 + (j < cols ? j : cols - 1)];
+    }
   }
-  for (int e = tid; e < KRON_TILE * KRON_SNB; e += 256) {  // a thread reads 32 contiguous bytes of a C row
-    const int i = e / KRON_SNB, c = e % KRON_SNB;
-    sC[i][c] = (i < rows && c < nb) ? M[(R0 + i) * ld + p0 + c] : 0.0;
+  {
+    double uv[KRON_SNB * KRON_TILE / 256], cv[KRON_TILE * KRON_SNB / 256];
+    const int uj = tid & 63, cc = tid & 31;
+#pragma unroll
+    for (int x = 0; x < KRON_SNB * KRON_TILE / 256; ++x) {
+      const int r = (tid >> 6) + 4 * x;
+      uv[x] = M[(p0 + (r < nb ? r : nb - 1)) * ld + C0 + (uj < cols ? uj : cols - 1)];
+    }
+#pragma unroll
+    for (int x = 0; x < KRON_TILE * KRON_SNB / 256; ++x) {  // 32 lanes read 256 contiguous bytes of a C row
+      const int i = (tid >> 5) + 8 * x;
+      cv[x] = M[(R0 + (i < rows ? i : rows - 1)) * ld + p0 + (cc < nb ? cc : nb - 1)];
+    }
+#pragma unroll
+    for (int x = 0; x < KRON_SNB * KRON_TILE / 256; ++x) {
+      const int r = (tid >> 6) + 4 * x;
+      sU[r][uj] = (r < nb && uj < cols) ? uv[x] : 0.0;
+    }
+#pragma unroll
+    for (int x = 0; x < KRON_TILE * KRON_SNB / 256; ++x) {
+      const int i = (tid >> 5) + 8 * x;
+      sC[i][cc] = (i < rows && cc < nb) ? cv[x] : 0.0;
+    }
   }
   if (tid < KRON_SNB) s_inv[tid] = a.big_inv[static_cast<long>(blockIdx.y) * KRON_SNB + tid];
   __syncthreads();
+#ifdef KRON_STAMPS
+  tt[1] = clock64();
+#endif
+  // (no c != 0 test here: (0 * u) * inv is 0 unless a pivot was singular, and such a graph is redone anyway; v - 0
+  //  differs from v at most in the sign of a zero, which no later comparison sees)
+#pragma unroll 2
   for (int p = 0; p < nb; ++p) {
-    const double up = sU[p][j], inv = s_inv[p];
+    const double inv = s_inv[p];
+    double cu[4], uu[4];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      // (no c != 0 test here: (0 * u) * inv is 0 unless a pivot was singular, and such a graph is redone anyway;
-      //  v - 0 differs from v at most in the sign of a zero, which no later comparison sees)
-      v[t] = v[t] - (sC[g + 4 * t][p] * up) * inv;
+    for (int x = 0; x < 4; ++x) cu[x] = sC[ti + 16 * x][p];
+#pragma unroll
+    for (int y = 0; y < 4; ++y) uu[y] = sU[p][tj + 16 * y];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) v[x][y] = kron_upd(v[x][y], cu[x], uu[y], inv);
+  }
+#ifdef KRON_STAMPS
+  tt[2] = clock64();
+#endif
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const int i = ti + 16 * x;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const int j = tj + 16 * y;
+      if (i < rows && j < cols) M[(R0 + i) * ld + C0 + j] = v[x][y];
     }
   }
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int i = g + 4 * t;
-    if (i < rows && j < cols) M[(R0 + i) * ld + C0 + j] = v[t];
-  }
+#ifdef KRON_STAMPS
+  tt[3] = clock64();
+  if (q.n == 1000 && (tile == 0 || tile == 200) && tid == 0 && p0 == 0)
+    printf("trail tile %d cycles: load+lds %lld compute %lld store %lld\n", tile, tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2]);
+#endif
 }
 
 // flagged graphs only: build + elimination with the reference's damping, threshold and count, on one workgroup
@@ -718,7 +897,7 @@ struct KronWs {
   int64_t* big_off;  // [B+1]
   uint32_t* counts;  // [B]
   uint32_t* out_off; // [B]
-  int* big_list;     // [B] graphs beyond the LDS capacity
+  BigDesc* big_desc; // [B] graphs beyond the LDS capacity
   int* big_count;
   int* sing;         // [B]
   double* big_inv;   // [B][32]
@@ -751,7 +930,7 @@ static size_t kron_layout(void* ws, int64_t N, int64_t B, int64_t max_nodes, int
   s.big_off = c.take<int64_t>(B + 1);
   s.counts = c.take<uint32_t>(B + 1);
   s.out_off = c.take<uint32_t>(B + 1);
-  s.big_list = c.take<int>(B + 1);
+  s.big_desc = c.take<BigDesc>(B + 1);
   s.big_count = c.take<int>(4);
   s.sing = c.take<int>(B + 1);
   s.big_inv = c.take<double>(static_cast<size_t>(B + 1) * 32);
@@ -802,14 +981,14 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
   device_scan_u32(s.flags, N + 1, s.rank, s.scan_total, s.scan_tiles, stream);  // (one workgroup took 73 us at N = 82 k)
   const int cap = static_cast<int>(max_graph_nodes < KRON_LDS_MAX_N ? max_graph_nodes : KRON_LDS_MAX_N);
   hipLaunchKernelGGL(kron_plan_kernel, dim3(1), dim3(1024), 0, stream, graph_ptr, static_cast<int>(B), s.rank, s.sq_off,
-                     s.big_off, s.cap_dense, s.cap_big, (from_adjacency & 2) ? 1 : 0, cap, max_graph_nodes, s.big_list, s.big_count,
+                     s.big_off, s.cap_dense, s.cap_big, (from_adjacency & 2) ? 1 : 0, cap, max_graph_nodes, s.big_desc, s.big_count,
                      static_cast<int>(num_big), s.status);
   KronArgs a{};
   a.indptr = indptr; a.col = col; a.val32 = val32; a.val64 = val64; a.perm = perm; a.from_adj = from_adjacency & 1;
   a.graph_ptr = graph_ptr; a.rank = s.rank; a.sq_off = s.sq_off; a.big_off = s.big_off; a.dense = s.dense;
   a.big = s.big; a.counts = s.counts; a.status = s.status; a.threshold = threshold;
   a.lds_cap = cap;
-  a.big_list = s.big_list; a.big_count = s.big_count; a.sing = s.sing; a.big_inv = s.big_inv;
+  a.big_desc = s.big_desc; a.big_count = s.big_count; a.sing = s.sing; a.big_inv = s.big_inv;
   a.rowcnt = nullptr;
   (void)hipMemsetAsync(s.counts, 0, (B + 1) * sizeof(uint32_t), stream);
   // One workgroup per graph with the graph's matrix in LDS: the allocation decides how many graphs a CU works on at
@@ -834,11 +1013,19 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
     (void)hipMemsetAsync(s.sing, 0, (B + 1) * sizeof(int), stream);
     (void)hipMemsetAsync(s.big, 0, static_cast<size_t>(s.cap_big) * sizeof(double), stream);
     hipLaunchKernelGGL(kron_big_build_kernel, dim3(cdiv(nmax, 256), nbig), dim3(256), 0, stream, a);
+    // Unused dynamic LDS on top of the kernels' static arrays: ONE workgroup per CU.  A launch has a few hundred busy
+    // workgroups at most and the dispatcher packs them four to a CU (33 KB of LDS each) while other CUs get none: the
+    // trailing update of the first panels took 28 us where its arithmetic is 5 us per workgroup.
+    constexpr int KRON_LDS_PAD = 56 * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kron_big_panel_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, KRON_LDS_PAD);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kron_big_trail_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, KRON_LDS_PAD);
     for (int step = 0; step * KRON_SNB < nmax - 1; ++step) {  // at least one node is kept: m <= n - 1
       const int rem = nmax - step * KRON_SNB - 1;             // trailing rows at most (the panel holds >= 1 pivot)
       const int nt = cdiv(rem, KRON_TILE);
-      hipLaunchKernelGGL(kron_big_panel_kernel, dim3(static_cast<unsigned>(nt), nbig), dim3(256), 0, stream, a, step);
-      hipLaunchKernelGGL(kron_big_trail_kernel, dim3(static_cast<unsigned>(nt * nt), nbig), dim3(256), 0, stream, a, step);
+      hipLaunchKernelGGL(kron_big_panel_kernel, dim3(static_cast<unsigned>(cdiv(rem, KRON_PW)), nbig), dim3(256), KRON_LDS_PAD, stream, a, step);
+      hipLaunchKernelGGL(kron_big_trail_kernel, dim3(static_cast<unsigned>(nt * nt), nbig), dim3(256), KRON_LDS_PAD, stream, a, step);
     }
     hipLaunchKernelGGL(kron_big_finish_kernel, dim3(cdiv(nmax, 16), nbig), dim3(256), 0, stream, a);
     const size_t plds = static_cast<size_t>(2 * KRON_NB) * nmax * sizeof(double);
@@ -869,7 +1056,7 @@ extern "C" int tgp_kron_batched_fill(const void* ws, int64_t N, int64_t B, int64
   if (max_graph_nodes > cap && num_big > 0) {
     KronArgs a{};
     a.graph_ptr = graph_ptr; a.rank = s.rank; a.sq_off = s.sq_off; a.big_off = s.big_off; a.dense = s.dense;
-    a.big = s.big; a.big_list = s.big_list; a.big_count = s.big_count; a.rowcnt = s.flags;
+    a.big = s.big; a.big_desc = s.big_desc; a.big_count = s.big_count; a.rowcnt = s.flags;
     const int nmax = static_cast<int>(max_graph_nodes < KRON_MAX_N ? max_graph_nodes : KRON_MAX_N);
     hipLaunchKernelGGL(kron_big_fill_kernel, dim3(cdiv(nmax, 16), static_cast<unsigned>(num_big)), dim3(256), 0, stream, a,
                        s.out_off, out_row, out_col, out_weight);
