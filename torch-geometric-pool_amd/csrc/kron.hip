@@ -16,6 +16,7 @@
 // Exactly singular L[-,-] (a component made of dropped nodes only): the block is redone with the reference's
 // Marquardt-Levenberg damping 1e-6 I (kron_conn.py:131-135).
 #include "primitives.h"
+#include <mutex>
 #include <utility>
 
 namespace tgp {
@@ -941,6 +942,31 @@ static size_t kron_layout(void* ws, int64_t N, int64_t B, int64_t max_nodes, int
   return c.off;
 }
 
+// A second stream per device for the LDS-resident graphs of a batch that also holds mid-size graphs: the panel chain of
+// the latter is ~50 dependent launches that keep a few dozen CUs busy, the 2048 small graphs of a PROTEINS-like batch
+// are 100 us of work for the whole chip -- run one beside the other (fork after the plan kernel, join before the
+// counts are scanned; a plain fork / join of events, so a captured caller stream captures the side stream with it).
+struct KronSide {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false, tried = false;
+};
+static KronSide g_kron_side[64];
+static std::mutex g_kron_side_mutex;
+
+static KronSide* kron_side() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  KronSide& k = g_kron_side[dev];
+  if (!k.tried) {
+    k.tried = true;
+    k.ok = hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&k.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&k.join, hipEventDisableTiming) == hipSuccess;
+  }
+  return k.ok ? &k : nullptr;
+}
+
 }  // namespace tgp
 
 using namespace tgp;
@@ -991,6 +1017,19 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
   a.big_desc = s.big_desc; a.big_count = s.big_count; a.sing = s.sing; a.big_inv = s.big_inv;
   a.rowcnt = nullptr;
   (void)hipMemsetAsync(s.counts, 0, (B + 1) * sizeof(uint32_t), stream);
+  const bool has_big = max_graph_nodes > cap && num_big > 0;
+  std::unique_lock<std::mutex> side_lock(g_kron_side_mutex, std::defer_lock);
+  KronSide* side = nullptr;
+  hipStream_t lds_stream = stream;
+  if (has_big) {
+    side_lock.lock();  // (the fork / join events are shared by the callers of one device)
+    side = kron_side();
+    if (side && hipEventRecord(side->fork, stream) == hipSuccess &&
+        hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess)
+      lds_stream = side->stream;
+    else
+      side = nullptr;
+  }
   // One workgroup per graph with the graph's matrix in LDS: the allocation decides how many graphs a CU works on at
   // once (128 nodes = 132 KB = one; 64 nodes = 33 KB = four), so a batch whose longest LDS graph has more than 64
   // nodes runs the kernel twice, small graphs first with the small allocation (2048 graphs of 20..60 nodes beside one
@@ -1003,9 +1042,11 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
     const size_t lds = static_cast<size_t>(a.lds_hi) * (a.lds_hi | 1) * sizeof(double) + 16;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kron_schur_lds_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    hipLaunchKernelGGL(kron_schur_lds_kernel, dim3(static_cast<unsigned>(B)), dim3(KRON_THREADS), lds, stream, a);
+    hipLaunchKernelGGL(kron_schur_lds_kernel, dim3(static_cast<unsigned>(B)), dim3(KRON_THREADS), lds, lds_stream, a);
   }
-  if (max_graph_nodes > cap && num_big > 0) {
+  bool joined = true;
+  if (side) joined = hipEventRecord(side->join, side->stream) == hipSuccess;
+  if (has_big) {
     // graphs of 129 .. 1024 nodes: one launch per panel of KRON_SNB pivots over all of them (see kron_big_panel_kernel / kron_big_trail_kernel)
     const int nmax = static_cast<int>(max_graph_nodes < KRON_MAX_N ? max_graph_nodes : KRON_MAX_N);
     const unsigned nbig = static_cast<unsigned>(num_big);
@@ -1032,6 +1073,10 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kron_big_redo_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plds));
     hipLaunchKernelGGL(kron_big_redo_kernel, dim3(nbig), dim3(KRON_BIG_THREADS), plds, stream, a);
+  }
+  if (side) {
+    if (!joined || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) (void)hipStreamSynchronize(side->stream);
+    side_lock.unlock();
   }
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, static_cast<int>(B), s.out_off,
                      d_count, static_cast<const int*>(nullptr));
