@@ -245,6 +245,52 @@ __global__ __launch_bounds__(256) void reduce_sparse_vec4_kernel(
   }
 }
 
+// One assignment per supernode (row_ptr == NULL: TopK, NDP) with every load unconditional and the U chains issued level
+// by level: U table entries, then U node ids + U weights, then the U rows.  In the general kernel above each guarded
+// load sits in its own branch and the compiler waits for it before the next one is issued (four serial round trips in
+// front of the two row requests, and the rows leave as FLAT loads); here a group has U rows in flight after three.
+// Supernodes past the end re-read the last one and are not stored.  Same products as the general kernel: 0 + x * w.
+template <int G, int U, bool HAS_W, bool HAS_PERM>
+__global__ __launch_bounds__(256) void reduce_one_to_one_kernel(
+    const float* __restrict__ x, int64_t F, int64_t x_stride, const int64_t* __restrict__ node_index,
+    const float* __restrict__ weight, const int32_t* __restrict__ perm, int64_t K, float* __restrict__ x_pool) {
+  constexpr int GROUPS = 256 / G;
+  const int g = threadIdx.x % G;
+  const int64_t group = static_cast<int64_t>(blockIdx.x) * GROUPS + threadIdx.x / G;
+  const int64_t ngroups = static_cast<int64_t>(gridDim.x) * GROUPS;
+  for (int64_t c0 = group; c0 < K; c0 += ngroups * U) {
+    int64_t c[U];
+    int32_t a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      c[u] = c0 + u * ngroups;
+      const int64_t cc = c[u] < K ? c[u] : K - 1;
+      a[u] = HAS_PERM ? perm[cc] : static_cast<int32_t>(cc);
+    }
+    int64_t n[U];
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      n[u] = node_index[a[u]];
+      w[u] = HAS_W ? weight[a[u]] : 1.0f;
+    }
+    for (int64_t f = 4 * g; f < F; f += 4 * G) {
+      nt_f32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        v[u] = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(x + n[u] * x_stride + f));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (c[u] < K) {  // product rounded before the add, as the reference's two-step form
+          nt_f32x4 t = {__fadd_rn(0.f, __fmul_rn(v[u].x, w[u])), __fadd_rn(0.f, __fmul_rn(v[u].y, w[u])),
+                        __fadd_rn(0.f, __fmul_rn(v[u].z, w[u])), __fadd_rn(0.f, __fmul_rn(v[u].w, w[u]))};
+          __builtin_nontemporal_store(t, reinterpret_cast<nt_f32x4*>(x_pool + c[u] * F + f));
+        }
+      }
+    }
+  }
+}
+
 // Fallback for feature counts / strides that are not 16-byte friendly: one lane per feature.
 __global__ __launch_bounds__(256) void reduce_sparse_scalar_kernel(
     const float* __restrict__ x, int64_t F, int64_t x_stride, const int64_t* __restrict__ node_index,
@@ -372,6 +418,45 @@ extern "C" int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t 
     if (blocks > cus * kBlocksPerCu) blocks = cus * kBlocksPerCu;
     if (blocks < 1) blocks = 1;
     grid = dim3(static_cast<unsigned>(blocks));
+    static const int kO2O = getenv("TGP_REDUCE_O2O") ? atoi(getenv("TGP_REDUCE_O2O")) : 2;  // 0: general kernel
+    if (!row_ptr && kO2O > 0 && G >= 8) {
+      const int uu = kO2O >= 8 ? 8 : (kO2O >= 4 ? 4 : (kO2O >= 2 ? 2 : 1));
+      blocks = (K + groups_per_block * uu - 1) / (groups_per_block * uu);
+      if (blocks > cus * kBlocksPerCu) blocks = cus * kBlocksPerCu;
+      if (blocks < 1) blocks = 1;
+      grid = dim3(static_cast<unsigned>(blocks));
+#define TGP_LAUNCH_O(GG, UU)                                                                                     \
+  do {                                                                                                            \
+    if (weight && perm)                                                                                           \
+      hipLaunchKernelGGL((reduce_one_to_one_kernel<GG, UU, true, true>), grid, block, 0, stream, x, F, x_stride,  \
+                         node_index, weight, perm, K, x_pool);                                                    \
+    else if (weight)                                                                                              \
+      hipLaunchKernelGGL((reduce_one_to_one_kernel<GG, UU, true, false>), grid, block, 0, stream, x, F, x_stride, \
+                         node_index, weight, perm, K, x_pool);                                                    \
+    else if (perm)                                                                                                \
+      hipLaunchKernelGGL((reduce_one_to_one_kernel<GG, UU, false, true>), grid, block, 0, stream, x, F, x_stride, \
+                         node_index, weight, perm, K, x_pool);                                                    \
+    else                                                                                                          \
+      hipLaunchKernelGGL((reduce_one_to_one_kernel<GG, UU, false, false>), grid, block, 0, stream, x, F,          \
+                         x_stride, node_index, weight, perm, K, x_pool);                                          \
+  } while (0)
+#define TGP_LAUNCH_OG(GG)                   \
+  do {                                      \
+    if (uu == 1) TGP_LAUNCH_O(GG, 1);       \
+    else if (uu == 2) TGP_LAUNCH_O(GG, 2);  \
+    else if (uu == 4) TGP_LAUNCH_O(GG, 4);  \
+    else TGP_LAUNCH_O(GG, 8);               \
+  } while (0)
+      switch (G) {
+        case 8: TGP_LAUNCH_OG(8); break;
+        case 16: TGP_LAUNCH_OG(16); break;
+        case 32: TGP_LAUNCH_OG(32); break;
+        default: TGP_LAUNCH_OG(64); break;
+      }
+#undef TGP_LAUNCH_OG
+#undef TGP_LAUNCH_O
+      return check_launch("tgp_reduce_sparse_f32");
+    }
 #define TGP_LAUNCH_GU(GG, UU)                                                                                  \
   do {                                                                                                          \
     if (kNT)                                                                                                    \
