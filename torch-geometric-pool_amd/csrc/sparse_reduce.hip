@@ -162,28 +162,30 @@ template <int G, int U, bool NT>
 __global__ __launch_bounds__(256) void reduce_sparse_vec4_kernel(
     const float* __restrict__ x, int64_t F, int64_t x_stride, const int64_t* __restrict__ node_index,
     const float* __restrict__ weight, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ perm,
-    int64_t K, float* __restrict__ x_pool) {
+    int64_t nnz, int64_t K, float* __restrict__ x_pool) {
   constexpr int GROUPS = 256 / G;
   const int g = threadIdx.x % G;
   const int64_t group = static_cast<int64_t>(blockIdx.x) * GROUPS + threadIdx.x / G;
   const int64_t ngroups = static_cast<int64_t>(gridDim.x) * GROUPS;
+  const int32_t last = static_cast<int32_t>(nnz > 0 ? nnz - 1 : 0);
+  // Every load is unconditional, from a clamped index, and the U chains are issued level by level (a guarded load in
+  // its own branch is waited for before the next one is issued: r3 found four serial round trips in front of the row
+  // requests); what a clamped load returned is dropped by the select in front of the add.
   for (int64_t c0 = group; c0 < K; c0 += ngroups * U) {
     int32_t beg[U], len[U];
     int32_t maxlen = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t c = c0 + u * ngroups;
-      beg[u] = 0;
-      len[u] = -1;
-      if (c < K) {
-        if (row_ptr) {
-          beg[u] = row_ptr[c];
-          len[u] = row_ptr[c + 1] - beg[u];
-        } else {  // one assignment per supernode (TopK, NDP): the table is the identity
-          beg[u] = static_cast<int32_t>(c);
-          len[u] = 1;
-        }
+      const int64_t cc = c < K ? c : K - 1;
+      if (row_ptr) {
+        beg[u] = row_ptr[cc];
+        len[u] = row_ptr[cc + 1] - beg[u];
+      } else {  // one assignment per supernode: the table is the identity (reduce_one_to_one_kernel is the fast path)
+        beg[u] = static_cast<int32_t>(cc);
+        len[u] = 1;
       }
+      if (c >= K) len[u] = -1;
       maxlen = len[u] > maxlen ? len[u] : maxlen;
     }
     for (int64_t f = 4 * g; f < F; f += 4 * G) {
@@ -193,40 +195,38 @@ __global__ __launch_bounds__(256) void reduce_sparse_vec4_kernel(
       for (int32_t m = 0; m < maxlen; ++m) {
         int32_t a[U];
         float w[U];
-        const float* src[U];
+        int64_t n[U];
         float4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = m < len[u] ? (perm ? perm[beg[u] + m] : beg[u] + m) : -1;
-#pragma unroll
         for (int u = 0; u < U; ++u) {
-          w[u] = 1.0f;
-          src[u] = x;
-          if (a[u] >= 0) {
-            if (weight) w[u] = weight[a[u]];
-            src[u] = x + node_index[a[u]] * x_stride + f;
-          }
+          int32_t slot = beg[u] + (m < len[u] ? m : 0);
+          slot = slot < last ? slot : last;
+          a[u] = perm ? perm[slot] : slot;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-        {
-          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (a[u] >= 0) {
-            if constexpr (NT) {  // rows are read exactly once: keep them out of the way of the index tables
-              const nt_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(src[u]));
-              v[u] = make_float4(t.x, t.y, t.z, t.w);
-            } else {
-              v[u] = *reinterpret_cast<const float4*>(src[u]);
-            }
+        for (int u = 0; u < U; ++u) {
+          w[u] = weight ? weight[a[u]] : 1.0f;
+          n[u] = node_index[a[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float* src = x + n[u] * x_stride + f;
+          if constexpr (NT) {  // rows are read exactly once: keep them out of the way of the index tables
+            const nt_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(src));
+            v[u] = make_float4(t.x, t.y, t.z, t.w);
+          } else {
+            v[u] = *reinterpret_cast<const float4*>(src);
           }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          if (a[u] >= 0) {  // product rounded before the add, as the reference's two-step form
-            acc[u].x = __fadd_rn(acc[u].x, __fmul_rn(v[u].x, w[u]));
-            acc[u].y = __fadd_rn(acc[u].y, __fmul_rn(v[u].y, w[u]));
-            acc[u].z = __fadd_rn(acc[u].z, __fmul_rn(v[u].z, w[u]));
-            acc[u].w = __fadd_rn(acc[u].w, __fmul_rn(v[u].w, w[u]));
-          }
+          const bool on = m < len[u];  // product rounded before the add, as the reference's two-step form
+          const float px = __fadd_rn(acc[u].x, __fmul_rn(v[u].x, w[u])), py = __fadd_rn(acc[u].y, __fmul_rn(v[u].y, w[u]));
+          const float pz = __fadd_rn(acc[u].z, __fmul_rn(v[u].z, w[u])), pw = __fadd_rn(acc[u].w, __fmul_rn(v[u].w, w[u]));
+          acc[u].x = on ? px : acc[u].x;
+          acc[u].y = on ? py : acc[u].y;
+          acc[u].z = on ? pz : acc[u].z;
+          acc[u].w = on ? pw : acc[u].w;
         }
       }
 #pragma unroll
@@ -461,10 +461,10 @@ extern "C" int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t 
   do {                                                                                                          \
     if (kNT)                                                                                                    \
       hipLaunchKernelGGL((reduce_sparse_vec4_kernel<GG, UU, true>), grid, block, 0, stream, x, F, x_stride,     \
-                         node_index, weight, row_ptr, perm, K, x_pool);                                         \
+                         node_index, weight, row_ptr, perm, nnz, K, x_pool);                                       \
     else                                                                                                        \
       hipLaunchKernelGGL((reduce_sparse_vec4_kernel<GG, UU, false>), grid, block, 0, stream, x, F, x_stride,    \
-                         node_index, weight, row_ptr, perm, K, x_pool);                                         \
+                         node_index, weight, row_ptr, perm, nnz, K, x_pool);                                       \
   } while (0)
 #define TGP_LAUNCH_G(GG)                  \
   do {                                    \
