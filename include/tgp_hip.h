@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10004 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10005 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -217,6 +217,20 @@ int tgp_dense_pool_is_small(int64_t B, int64_t N, int64_t K, int64_t F);
 int tgp_dense_pool_mincut_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K,
                               int64_t F, int flags, float eps, float loss_eps, float* x_pool, float* adj_raw,
                               float* adj_pool, float* mincut_terms, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of that call for the same batches (what autograd derives operator by operator from base_reduce.py:158-161,
+ * dense_conn.py:111-122, utils/ops.py:282-335 and utils/losses.py:39-70: ~80 launches in a MinCut training step), ONE
+ * launch: from the upstream gradients of x_pool [B,K,F], of the post-processed adj_pool [B,K,K], of the raw S^T A S
+ * [B,K,K] and of the two per-graph terms [2,B] (each may be NULL = zero) it writes gS [B,N,K] and, when gX is given,
+ * gX [B,N,F].  flags as in the forward call (TGP_EDGE_WEIGHT_NORM is refused); A receives no gradient.
+ * DiffPool's two batch-wide losses (utils/losses.py:644-658) ride along when g_diff [2] (upstream gradients of
+ * link = link_scale * ||A - S S^T||_F and ent = ent_scale * sum(-S log(S + ent_eps))) and diff_losses [2] (their forward
+ * values, tgp_diffpool_loss_tail_f32's output) are given; both NULL otherwise. */
+int tgp_dense_pool_small_bwd_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K,
+                                 int64_t F, int flags, float eps, float loss_eps, const float* g_x_pool,
+                                 const float* g_adj_pool, const float* g_adj_raw, const float* g_terms,
+                                 const float* g_diff, const float* diff_losses, float link_scale, float ent_scale,
+                                 float ent_eps, float* gS, float* gX, void* stream);
 
 /* Generic batched fp32 GEMM on the matrix cores, C[b] = op(A[b]) B[b] with B[b] [Kd,Nc] row-major.
  * trans_a = 0: A[b] is [M,Kd] row-major; 1: A[b] is stored [Kd,M] (C = A^T B).  Used by

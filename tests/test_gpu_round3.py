@@ -574,3 +574,161 @@ def test_round3_entry_points_on_empty_and_degenerate_inputs(dev):
     ei = torch.stack([torch.cat([a, a + 1]), torch.cat([a + 1, a])]).to(dev)    # a path on nodes 0..1999, rest isolated
     so = NDPSelect()(ei, None, num_nodes=n)
     assert 0 < so.num_supernodes < n and bool((so.node_index[1:] > so.node_index[:-1]).all())
+
+
+# ----------------------------------------------------------------------------- fused backward of the small-graph kernel
+def _ragged_dense_batch(B, Nmax, K, F, seed, dev, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    n_b = torch.randint(max(2, Nmax // 3), Nmax + 1, (B,), generator=g)
+    n_b[0] = Nmax
+    mask = torch.arange(Nmax).unsqueeze(0) < n_b.unsqueeze(1)
+    A = (torch.rand(B, Nmax, Nmax, generator=g) < 0.15).float() * torch.rand(B, Nmax, Nmax, generator=g)
+    A = A * mask.unsqueeze(1) * mask.unsqueeze(2)
+    X = torch.randn(B, Nmax, F, generator=g) * mask.unsqueeze(-1)
+    logits = torch.randn(B, Nmax, K, generator=g)
+    return A.to(dev, dtype), X.to(dev, dtype), logits.to(dev, dtype), mask.to(dev)
+
+
+def _dense_pool_reference(S, A, X, rsl, dn, at, eps_ops, eps_loss):
+    """Plain torch restatement (differentiable) of Reduce, Connect, post-processing and MinCut's per-graph terms:
+    base_reduce.py:158-161, dense_conn.py:111-122, utils/ops.py:282-335, utils/losses.py:39-70."""
+    xp = S.transpose(1, 2) @ X
+    raw = S.transpose(1, 2) @ A @ S
+    ap = raw
+    if rsl:
+        ap = ap * (1 - torch.eye(ap.size(-1), device=ap.device, dtype=ap.dtype))
+    if dn:
+        d = ap.sum(-2 if at else -1, keepdim=True)
+        d = torch.sqrt(d.clamp(min=eps_ops))
+        ap = (ap / d) / d.transpose(-2, -1)
+    num = torch.einsum("bii->b", raw)
+    den = torch.einsum("bnk,bn,bnk->b", S, A.sum(-1), S)
+    cut = -(num / (den + eps_loss))
+    sts = S.transpose(1, 2) @ S
+    sts = sts / torch.norm(sts, dim=(-2, -1), keepdim=True)
+    k = S.size(-1)
+    ortho = torch.norm(sts - torch.eye(k, device=S.device, dtype=S.dtype) / k ** 0.5, dim=(-2, -1))
+    return xp, raw, ap, torch.stack([cut, ortho])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Nmax,K,F", [(17, 5, 8), (40, 20, 32), (64, 32, 32), (60, 20, 3)])
+@pytest.mark.parametrize("rsl,dn,at", [(True, True, True), (True, True, False), (False, True, True),
+                                       (True, False, False), (False, False, True)])
+@pytest.mark.parametrize("transposed_view", [False, True])
+def test_small_graph_fused_backward_vs_autograd(dev, Nmax, K, F, rsl, dn, at, transposed_view):
+    """tgp_dense_pool_small_bwd_f32 (one launch) against torch autograd of the fp64 restatement: gradients of S and X
+    from random upstream gradients of x_pool, adj_pool, the raw S^T A S and both per-graph MinCut terms."""
+    from tgp import functions as Fn, kernels as K_
+    from tgp.utils import losses, ops
+    B = 70
+    A, X, logits, mask = _ragged_dense_batch(B, Nmax, K, F, seed=Nmax * 131 + K, dev=dev)
+    flags = K_.dense_flags(rsl, dn, at, False)
+    g = torch.Generator().manual_seed(7)
+    w_x, w_a = torch.randn(B, K, F, generator=g).to(dev), torch.randn(B, K, K, generator=g).to(dev)
+    w_r, w_t = torch.randn(B, K, K, generator=g).to(dev), torch.randn(2, B, generator=g).to(dev)
+
+    # fp64 reference
+    l64 = logits.double().requires_grad_(True)
+    x64 = X.double().requires_grad_(True)
+    S64 = torch.softmax(l64, -1) * mask.unsqueeze(-1)
+    out = _dense_pool_reference(S64, A.double(), x64, rsl, dn, at, float(ops.eps), float(losses.eps))
+    # DiffPool's two losses (utils/losses.py:644-658), scaled as poolers/diffpool.py:262-284 scales them
+    w_d = torch.tensor([1.3, -0.7], device=dev)
+    ref_diff = [0.37 * torch.norm(A.double() - S64 @ S64.transpose(1, 2), p=2),
+                (-(S64 * torch.log(S64 + float(losses.eps))).sum()) / int(mask.sum())]
+    ref_loss = sum((o * w.double()).sum() for o, w in zip(out, (w_x, w_r, w_a, w_t)))
+    ref_loss = ref_loss + ref_diff[0] * w_d[0].double() + ref_diff[1] * w_d[1].double()
+    ref_loss.backward()
+
+    l32 = logits.clone().requires_grad_(True)
+    x32 = X.clone().requires_grad_(True)
+    S32 = torch.softmax(l32, -1) * mask.unsqueeze(-1)
+    adj = A.transpose(1, 2).contiguous().transpose(1, 2) if transposed_view else A
+    link_scale, ent_scale = 0.37, 1.0 / int(mask.sum())
+    xp, raw, ap, terms, diff = Fn.dense_pool_small(S32, adj, x32, flags, True, True, (link_scale, ent_scale))
+    for got, want, name in zip((xp, raw, ap, terms), out, ("x_pool", "raw", "adj_pool", "terms")):
+        torch.testing.assert_close(got, want.float(), rtol=2e-4, atol=2e-5, msg=lambda m, n=name: f"{n}: {m}")
+    torch.testing.assert_close(diff, torch.stack(ref_diff).float(), rtol=2e-4, atol=1e-5)
+    loss = (xp * w_x).sum() + (raw * w_r).sum() + (ap * w_a).sum() + (terms * w_t).sum() + (diff * w_d).sum()
+    loss.backward()
+    scale_s = l64.grad.abs().max().item()
+    torch.testing.assert_close(l32.grad, l64.grad.float(), rtol=2e-3, atol=2e-4 * max(scale_s, 1.0))
+    torch.testing.assert_close(x32.grad, x64.grad.float(), rtol=2e-4, atol=2e-5 * max(x64.grad.abs().max().item(), 1.0))
+    assert x32.grad[~mask].abs().max().item() == 0.0  # padded rows of X get exact zeros
+
+
+@pytest.mark.gpu
+def test_small_graph_fused_backward_partial_upstreams(dev):
+    """Only some outputs feed the loss (x_pool alone; adj_pool alone; terms alone): the missing upstream gradients are
+    NULL in the C call, the result equals autograd's."""
+    from tgp import functions as Fn, kernels as K_
+    from tgp.utils import losses, ops
+    B, Nmax, K, F = 80, 33, 7, 16
+    A, X, logits, mask = _ragged_dense_batch(B, Nmax, K, F, seed=5, dev=dev)
+    flags = K_.dense_flags(True, True, True, False)
+    for pick in ("x", "adj", "terms"):
+        l64 = logits.double().requires_grad_(True)
+        x64 = X.double().requires_grad_(True)
+        out = _dense_pool_reference(torch.softmax(l64, -1) * mask.unsqueeze(-1), A.double(), x64, True, True, True,
+                                    float(ops.eps), float(losses.eps))
+        ref = {"x": out[0].square().sum(), "adj": out[2].square().sum(), "terms": out[3].mean(dim=1).sum()}[pick]
+        ref.backward()
+        l32 = logits.clone().requires_grad_(True)
+        x32 = X.clone().requires_grad_(True)
+        xp, raw, ap, terms, _ = Fn.dense_pool_small(torch.softmax(l32, -1) * mask.unsqueeze(-1), A, x32, flags,
+                                                    False, pick == "terms")
+        got = {"x": xp.square().sum(), "adj": ap.square().sum(), "terms": terms.mean(dim=1).sum()}[pick]
+        got.backward()
+        torch.testing.assert_close(l32.grad, l64.grad.float(), rtol=2e-3, atol=2e-4 * max(l64.grad.abs().max().item(), 1))
+        if pick == "x":
+            torch.testing.assert_close(x32.grad, x64.grad.float(), rtol=2e-4, atol=1e-4)
+        else:
+            assert x32.grad is None or x32.grad.abs().max().item() == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alias", ["mincut", "diff"])
+def test_dense_pooler_training_step_uses_the_fused_backward(dev, alias, monkeypatch):
+    """get_pooler('mincut' / 'diff') on a PROTEINS-shaped sparse batch in training mode: the forward goes through the
+    fused small-graph kernel, the backward through tgp_dense_pool_small_bwd_f32, and parameter / input gradients equal
+    the operator-by-operator autograd path's (TGP_NO_SMALL_GRAPH_KERNEL-free check: the fused Function is switched off
+    by patching dense_pool_is_small)."""
+    from tgp import kernels as K_
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(3)
+    sizes = torch.randint(20, 61, (96,), generator=g)
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(96), sizes).to(dev)
+    start = (torch.cumsum(sizes, 0) - sizes).to(dev)
+    src = torch.arange(n, device=dev).repeat_interleave(2)
+    dst = start[batch[src]] + (torch.rand(src.numel(), device=dev) * sizes.to(dev)[batch[src]]).long()
+    keep = src != dst
+    key = torch.unique(torch.cat([src[keep] * n + dst[keep], dst[keep] * n + src[keep]]))
+    ei = torch.stack([key // n, key % n])
+    x0 = torch.randn(n, 32, device=dev)
+    torch.manual_seed(0)
+    pooler = get_pooler(alias, in_channels=32, k=20).to(dev).train()
+
+    calls = []
+    real_bwd = K_.dense_pool_small_bwd
+    monkeypatch.setattr(K_, "dense_pool_small_bwd", lambda *a, **k: (calls.append(1), real_bwd(*a, **k))[1])
+
+    def step():
+        pooler.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        out = pooler(x=x, adj=ei, batch=batch)
+        loss = out.x.square().sum() + out.edge_index.square().sum() + sum(out.loss.values())
+        loss.backward()
+        return loss.detach(), x.grad, [p.grad.clone() for p in pooler.parameters()]
+
+    fused = step()
+    assert calls, "the fused backward did not run"
+    monkeypatch.setattr(K_, "dense_pool_is_small", lambda *a: False)
+    calls.clear()
+    plain = step()
+    assert not calls
+    torch.testing.assert_close(fused[0], plain[0], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(fused[1], plain[1], rtol=2e-3, atol=2e-4 * max(plain[1].abs().max().item(), 1.0))
+    for a, b in zip(fused[2], plain[2]):
+        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-4 * max(b.abs().max().item(), 1.0))

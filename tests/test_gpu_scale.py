@@ -488,7 +488,17 @@ def test_fused_reduce_connect_equals_operators(dev):
                 ap3 = postprocess_adj_pool_dense(raw2, *flags)
             assert torch.equal(xp, xp2) and torch.equal(raw, raw2) and torch.equal(ap, ap2)
             torch.testing.assert_close(ap, ap3, rtol=1e-5, atol=1e-5)
-    assert pool.reduce_connect(X, A, SelectOutput(s=S.clone().requires_grad_(True))) is None
+    # under autograd: None (the caller takes the operator path) unless the batch is one of small graphs, which keeps the
+    # fused kernel and its one-launch backward -- not with edge_weight_norm (this connector), not when A needs a gradient
+    Sg = S.clone().requires_grad_(True)
+    assert pool.reduce_connect(X, A, SelectOutput(s=Sg)) is None
+    pool2 = DenseSRCPooling(reducer=BaseReduce(), connector=DenseConnect(True, True, True, False), adj_transpose=True)
+    assert pool2.reduce_connect(X, A.clone().requires_grad_(True), SelectOutput(s=Sg)) is None
+    got = pool2.reduce_connect(X, A, SelectOutput(s=Sg), want_raw=True)
+    assert got is not None and got[0].requires_grad and got[2].requires_grad
+    big = torch.softmax(torch.randn(3, 200, 12, device=dev), -1).requires_grad_(True)
+    assert pool2.reduce_connect(torch.randn(3, 200, 9, device=dev), torch.rand(3, 200, 200, device=dev),
+                                SelectOutput(s=big)) is None
 
 
 @pytest.mark.parametrize("K", [20, 32, 48, 68, 100, 128, 176, 180, 256])

@@ -119,6 +119,34 @@ extern "C" int tgp_dense_pool_mincut_f32(const float* S, const float* A, const f
                          ws, ws_bytes, stream_);
 }
 
+extern "C" int tgp_dense_pool_small_bwd_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N,
+                                            int64_t K, int64_t F, int flags, float eps, float loss_eps,
+                                            const float* g_x_pool, const float* g_adj_pool, const float* g_adj_raw,
+                                            const float* g_terms, const float* g_diff, const float* diff_losses,
+                                            float link_scale, float ent_scale, float ent_eps, float* gS, float* gX,
+                                            void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0 && F >= 0, TGP_ERR_INVALID, "tgp_dense_pool_small_bwd_f32: negative size");
+  if (B == 0 || N == 0 || K == 0) return TGP_OK;
+  TGP_REQUIRE(S && A && gS, TGP_ERR_INVALID, "tgp_dense_pool_small_bwd_f32: S, A and gS are required");
+  TGP_REQUIRE(dense_pool_small_ok(B, N, K, F), TGP_ERR_INVALID,
+              "tgp_dense_pool_small_bwd_f32: only batches the one-wave-per-graph kernel takes (tgp_dense_pool_is_small)");
+  TGP_REQUIRE(!(flags & TGP_EDGE_WEIGHT_NORM), TGP_ERR_INVALID,
+              "tgp_dense_pool_small_bwd_f32: edge_weight_norm is not differentiated by this entry");
+  TGP_REQUIRE(!gX || X || !g_x_pool, TGP_ERR_INVALID, "tgp_dense_pool_small_bwd_f32: gX needs X");
+  TGP_REQUIRE(!g_diff || diff_losses, TGP_ERR_INVALID, "tgp_dense_pool_small_bwd_f32: g_diff needs diff_losses");
+  SmallBwdArgs q{S, A, X, static_cast<int>(B), static_cast<int>(N), static_cast<int>(K), static_cast<int>(F), flags,
+                 eps, loss_eps, X ? g_x_pool : nullptr, g_adj_pool, g_adj_raw, g_terms, g_diff, diff_losses, link_scale,
+                 ent_scale, ent_eps, gS, F > 0 ? gX : nullptr};
+  const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_bwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(SG_WAVES * SG_WAVE_FLOATS * sizeof(float)));
+  hipLaunchKernelGGL(dense_pool_small_bwd_kernel, dim3(grid), dim3(64 * SG_WAVES),
+                     SG_WAVES * SG_WAVE_FLOATS * sizeof(float), stream, q);
+  return check_launch("tgp_dense_pool_small_bwd_f32");
+}
+
 static int dense_pool_impl(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K, int64_t F,
                            int flags, float eps, const int64_t* graph_sizes, float* x_pool, float* adj_raw,
                            float* adj_pool, float* mincut_terms, float loss_eps, void* ws, size_t ws_bytes,

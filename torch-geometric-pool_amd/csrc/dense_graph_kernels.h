@@ -314,6 +314,415 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward of the small-graph kernel (r3): ONE launch for the gradients of everything dense_pool_small_kernel produces.
+// Given the upstream gradients of X' = S^T X, of the post-processed A' (utils/ops.py:282-335), optionally of the raw
+// R = S^T A S and of the two per-graph MinCut terms (utils/losses.py:39-70), a wave recomputes R, the node degrees and
+// S^T S from S and A in registers / LDS exactly as the forward kernel does and forms
+//     gR  = d post / d R (gA')  +  gRaw  -  g_cut / (den + eps) * I
+//     gS  = A S gR^T + A^T S gR + X gX'^T + g_cut * 2 tr(R) / (den + eps)^2 * D S + 2 S gG ,     gX = S gX'
+// with gG the gradient of || S^T S / ||S^T S|| - I / sqrt(K) || with respect to S^T S (symmetric); DiffPool's link and
+// entropy losses add  g_link * link_scale / ||A - S S^T|| * (2 S S^T S - (A + A^T) S)  and
+// -g_ent * ent_scale * (log(S + eps) + S / (S + eps)).  Every product with a
+// node dimension is computed TRANSPOSED (clusters / features as the MFMA row index, nodes as the column index = lane),
+// so that the accumulators of one product are the B operand of the next, as in the forward kernel:
+//     U^T = S^T A^T, V^T = S^T A   (lane = node; B operand = the LDS tile of A read by row, resp. by column)
+//     gS^T = gR U^T + gR^T V^T + 2 gG S^T + gX' X^T ,   gX^T = gX'^T S^T
+// The adjacency gets no gradient here (callers whose A requires one keep the operator-by-operator path), and
+// edge_weight_norm is not differentiated here either.  Under autograd the reference runs ~110 launches for a MinCut
+// training step on a PROTEINS-shaped batch (profiles/r02_e2e_poolers.txt); this is the Reduce + Connect + loss share of
+// the backward in one.
+// ------------------------------------------------------------------------------------------
+struct SmallBwdArgs {
+  const float* S; const float* A; const float* X;
+  int B, N, K, F, flags;
+  float eps, loss_eps;
+  const float* g_x_pool;    // [B,K,F] or NULL
+  const float* g_adj_pool;  // [B,K,K] or NULL
+  const float* g_adj_raw;   // [B,K,K] or NULL
+  const float* g_terms;     // [2,B] or NULL: upstream gradients of the per-graph cut / orthogonality terms
+  // DiffPool's two batch-wide losses (utils/losses.py:644-658; both NULL = not part of this backward):
+  //   link = link_scale * || A - S S^T ||_F over the whole batch,  ent = ent_scale * sum(-S log(S + ent_eps))
+  const float* g_diff;      // [2] upstream gradients of (link, ent)
+  const float* diff_losses; // [2] the forward values (link = link_scale * norm gives the norm back)
+  float link_scale, ent_scale, ent_eps;
+  float* gS;                // [B,N,K]
+  float* gX;                // [B,N,F] or NULL
+};
+
+__global__ __launch_bounds__(64 * SG_WAVES) void dense_pool_small_bwd_kernel(SmallBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = lane_id();
+  const int w = __builtin_amdgcn_readfirstlane(wave_id());
+  const int lm = lane & 31, lk = lane >> 5;
+  float* As = smem + w * SG_WAVE_FLOATS;
+  float* s_deg = As + SG_N * SG_LDA;
+  const int N = p.N, K = p.K, F = p.F;
+  const bool at = p.flags & TGP_ADJ_TRANSPOSED;
+  const int b = blockIdx.x * SG_WAVES + w;
+  if (b >= p.B) return;  // (no workgroup barrier below: waves are independent)
+  // ---- A -> LDS (logical orientation), S in the operand order of the node contraction (as the forward kernel) -------
+  float sr[32];
+  {
+    float4 v[16];
+    const float* Ab = p.A + static_cast<long>(b) * N * N;
+    const int q4 = lane & 15;
+    const bool qfull = 4 * q4 + 3 < N;
+    const int qrem = N - 4 * q4;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int i = (lane >> 4) + 4 * t;
+      const bool ok = qfull && i < N;
+      const float4 r = *reinterpret_cast<const float4*>(byte_off(Ab, ok ? (i * N + 4 * q4) * 4 : 0));
+      v[t] = ok ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!qfull && qrem > 0 && i < N) {
+        const float* tail = byte_off(Ab, (i * N + 4 * q4) * 4);
+        v[t].x = tail[0];
+        if (qrem > 1) v[t].y = tail[1];
+        if (qrem > 2) v[t].z = tail[2];
+      }
+    }
+    const float* Sb = p.S + static_cast<long>(b) * N * K;
+    const bool cok = lm < K;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
+      const bool ok = cok && node < N;
+      const float r = *byte_off(Sb, ok ? (node * K + lm) * 4 : 0);
+      sr[q] = ok ? r : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int i = (lane >> 4) + 4 * t;
+      if (!at) {
+        float* d = As + i * SG_LDA + 4 * q4;
+        d[0] = v[t].x; d[1] = v[t].y; d[2] = v[t].z; d[3] = v[t].w;
+      } else {
+        As[(4 * q4 + 0) * SG_LDA + i] = v[t].x; As[(4 * q4 + 1) * SG_LDA + i] = v[t].y;
+        As[(4 * q4 + 2) * SG_LDA + i] = v[t].z; As[(4 * q4 + 3) * SG_LDA + i] = v[t].w;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- forward recomputation: R = S^T (A S); C/D layout: lane = column lm, register r = row rho(r) + 4 lk ------------
+  f32x16 R;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) R[r] = 0.f;
+  {
+    f32x16 u0, u1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { u0[r] = 0.f; u1[r] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
+      u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(As[lm * SG_LDA + node], sr[q], u0, 0, 0, 0);
+      u1 = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(32 + lm) * SG_LDA + node], sr[q], u1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[r], u0[r], R, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[16 + r], u1[r], R, 0, 0, 0);
+  }
+  // ---- the loss terms' coefficients: gR[i][i] += cdiag, gS[n][j] += c1 deg[n] S[n][j], gS += S W (W = 2 gG) ---------
+  float cdiag = 0.f, c1 = 0.f;
+  f32x16 W;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) W[r] = 0.f;
+  bool have_w = false;
+  {
+    // degrees of the logical adjacency: lane i sums row i (rows / columns beyond N are zero)
+    float dsum = 0.f;
+    const float* rowp = As + lane * SG_LDA;
+#pragma unroll 16
+    for (int j = 0; j < SG_N; ++j) dsum += rowp[j];
+    s_deg[lane] = dsum;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float c_link = 0.f, c_ent = 0.f;
+  if (p.g_diff) {
+    const float lv = p.diff_losses[0];
+    c_link = lv != 0.f ? p.g_diff[0] * p.link_scale * p.link_scale / lv : 0.f;  // g * link_scale / ||A - S S^T||
+    c_ent = p.g_diff[1] * p.ent_scale;
+  }
+  const float gt_cut = p.g_terms ? p.g_terms[b] : 0.f, gt_ortho = p.g_terms ? p.g_terms[p.B + b] : 0.f;
+  if (p.g_terms) {
+    float tr = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (rho(r) + 4 * lk == lm) tr += R[r];
+    tr = sg_wave_sum(tr);
+    float den = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
+      den = fmaf(s_deg[node], sr[q] * sr[q], den);
+    }
+    den = sg_wave_sum(den) + p.loss_eps;
+    cdiag = -gt_cut / den;
+    c1 = 2.0f * gt_cut * tr / (den * den);
+  }
+  if (gt_ortho != 0.f || c_link != 0.f) {  // (uniform) both need S^T S
+    f32x16 gg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gg[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) gg = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[q], sr[q], gg, 0, 0, 0);
+    if (gt_ortho != 0.f) {
+      float fro = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) fro = fmaf(gg[r], gg[r], fro);
+      const float ng2 = sg_wave_sum(fro), ng = sqrtf(ng2);
+      const float tdiag = 1.0f / sqrtf(static_cast<float>(K));
+      float y[16], ny2 = 0.f, gy = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rho(r) + 4 * lk;
+        y[r] = (row < K && lm < K) ? gg[r] / ng - (row == lm ? tdiag : 0.f) : 0.f;
+        ny2 = fmaf(y[r], y[r], ny2);
+        gy = fmaf(gg[r], y[r], gy);
+      }
+      ny2 = sg_wave_sum(ny2);
+      gy = sg_wave_sum(gy);
+      const float ny = sqrtf(ny2);
+      const float coef = ny > 0.f ? 2.0f * gt_ortho / (ny * ng) : 0.f;  // (the factor 2: gG + gG^T, gG symmetric)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) W[r] = coef * (y[r] - gg[r] * (gy / ng2));
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) W[r] = fmaf(2.0f * c_link, gg[r], W[r]);
+    have_w = true;
+  }
+
+  // ---- U^T = S^T A^T and V^T = S^T A: lane = node (two tiles of 32), register r = cluster rho(r) + 4 lk -------------
+  f32x16 ut0, ut1, vt0, vt1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { ut0[r] = 0.f; ut1[r] = 0.f; vt0[r] = 0.f; vt1[r] = 0.f; }
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
+    ut0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[q], As[lm * SG_LDA + node], ut0, 0, 0, 0);
+    ut1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[q], As[(32 + lm) * SG_LDA + node], ut1, 0, 0, 0);
+    vt0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[q], As[node * SG_LDA + lm], vt0, 0, 0, 0);
+    vt1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[q], As[node * SG_LDA + 32 + lm], vt1, 0, 0, 0);
+  }
+  const float deg0 = s_deg[lm], deg1 = s_deg[32 + lm];
+  __builtin_amdgcn_wave_barrier();  // the A tile is spent: its LDS is the transposition scratch from here on
+
+  // ---- gR (C/D layout) -------------------------------------------------------------------------------------------
+  f32x16 gR;
+  {
+    float gP[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = rho(r) + 4 * lk;
+      const bool ok = p.g_adj_pool && i < K && lm < K;
+      const float t = *byte_off(p.g_adj_pool ? p.g_adj_pool + static_cast<long>(b) * K * K : p.S, ok ? (i * K + lm) * 4 : 0);
+      gP[r] = ok ? t : 0.f;
+    }
+    if (p.g_adj_pool && (p.flags & TGP_DEGREE_NORM)) {
+      float r0[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        r0[r] = R[r];
+        if ((p.flags & TGP_REMOVE_SELF_LOOPS) && rho(r) + 4 * lk == lm) r0[r] = 0.f;
+      }
+      // degree of index lm, identical on both half-waves (the forward kernel's code)
+      float dcol;
+      if (p.flags & TGP_SUM_AXIS_ROWS) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += r0[r];
+        s += __shfl_xor(s, 32, WAVE);
+        dcol = s;
+      } else {
+        float mine = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float s = r0[r];
+#pragma unroll
+          for (int d = 16; d > 0; d >>= 1) s += __shfl_xor(s, d, WAVE);
+          if (lm == rho(r) + 4 * lk) mine = s;
+        }
+        const float other = __shfl_xor(mine, 32, WAVE);
+        bool own = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) own |= (rho(r) + 4 * lk == lm);
+        dcol = own ? mine : other;
+      }
+      const float d = sqrtf(fmaxf(dcol, p.eps));
+      const bool pass = dcol >= p.eps;  // clamp(min = eps) lets the gradient through where the sum is not below eps
+      float qv[16], colq = 0.f, rowmine = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rho(r) + 4 * lk;
+        const float drow = __shfl(d, row, WAVE);
+        const float first = (p.flags & TGP_SUM_AXIS_ROWS) ? d : drow;
+        const float second = (p.flags & TGP_SUM_AXIS_ROWS) ? drow : d;
+        const float pv = (r0[r] / first) / second;
+        qv[r] = gP[r] * pv;
+        colq += qv[r];
+        float s = qv[r];
+#pragma unroll
+        for (int dd = 16; dd > 0; dd >>= 1) s += __shfl_xor(s, dd, WAVE);
+        if (lm == row) rowmine = s;
+        gP[r] = gP[r] / (drow * d);
+      }
+      colq += __shfl_xor(colq, 32, WAVE);
+      {
+        const float other = __shfl_xor(rowmine, 32, WAVE);
+        bool own = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) own |= (rho(r) + 4 * lk == lm);
+        rowmine = own ? rowmine : other;
+      }
+      const float gs = pass ? -(rowmine + colq) / (2.0f * d * d) : 0.f;  // d loss / d (degree sum of index lm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rho(r) + 4 * lk;
+        const float gsrow = __shfl(gs, row, WAVE);
+        const float add = (p.flags & TGP_SUM_AXIS_ROWS) ? gs : gsrow;
+        gP[r] = (row < K && lm < K) ? gP[r] + add : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = rho(r) + 4 * lk;
+      float g = gP[r];
+      if ((p.flags & TGP_REMOVE_SELF_LOOPS) && i == lm) g = 0.f;  // the diagonal of R never reaches A'
+      const bool ok = p.g_adj_raw && i < K && lm < K;
+      const float t = *byte_off(p.g_adj_raw ? p.g_adj_raw + static_cast<long>(b) * K * K : p.S, ok ? (i * K + lm) * 4 : 0);
+      g += ok ? t : 0.f;
+      if (i == lm && i < K) g += cdiag;
+      gR[r] = g;
+    }
+  }
+  // gRt[r] = gR[lm][rho(r) + 4 lk]: through LDS ([row][col], 33 floats per row)
+  f32x16 gRt;
+  {
+    float* sT = As;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sT[(rho(r) + 4 * lk) * 33 + lm] = gR[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gRt[r] = sT[lm * 33 + rho(r) + 4 * lk];
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- S and X with lane = node, the upstream gradient of X' ---------------------------------------------------------
+  float sn0[16], sn1[16];
+  {
+    const float* Sb = p.S + static_cast<long>(b) * N * K;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = rho(r) + 4 * lk;
+      const bool ok0 = lm < N && j < K, ok1 = 32 + lm < N && j < K;
+      const float a0 = *byte_off(Sb, ok0 ? (lm * K + j) * 4 : 0), a1 = *byte_off(Sb, ok1 ? ((32 + lm) * K + j) * 4 : 0);
+      sn0[r] = ok0 ? a0 : 0.f;
+      sn1[r] = ok1 ? a1 : 0.f;
+    }
+  }
+  f32x16 gs0, gs1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    gs0[r] = c1 * deg0 * sn0[r] - c_link * (ut0[r] + vt0[r]);
+    gs1[r] = c1 * deg1 * sn1[r] - c_link * (ut1[r] + vt1[r]);
+  }
+  if (c_ent != 0.f) {  // every stored element of S, padded rows included (autograd's gradient of -s log(s + eps) at 0)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool jok = rho(r) + 4 * lk < K;
+      if (jok && lm < N) gs0[r] -= c_ent * (__logf(sn0[r] + p.ent_eps) + sn0[r] / (sn0[r] + p.ent_eps));
+      if (jok && 32 + lm < N) gs1[r] -= c_ent * (__logf(sn1[r] + p.ent_eps) + sn1[r] / (sn1[r] + p.ent_eps));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    gs0 = __builtin_amdgcn_mfma_f32_32x32x2f32(gRt[r], ut0[r], gs0, 0, 0, 0);
+    gs1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gRt[r], ut1[r], gs1, 0, 0, 0);
+    gs0 = __builtin_amdgcn_mfma_f32_32x32x2f32(gR[r], vt0[r], gs0, 0, 0, 0);
+    gs1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gR[r], vt1[r], gs1, 0, 0, 0);
+  }
+  if (have_w) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      gs0 = __builtin_amdgcn_mfma_f32_32x32x2f32(W[r], sn0[r], gs0, 0, 0, 0);
+      gs1 = __builtin_amdgcn_mfma_f32_32x32x2f32(W[r], sn1[r], gs1, 0, 0, 0);
+    }
+  }
+  if (p.g_x_pool && p.X) {
+    const float* Xb = p.X + static_cast<long>(b) * N * F;
+    const float* Gb = p.g_x_pool + static_cast<long>(b) * K * F;
+    float ga[16], xn0[16], xn1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = rho(r) + 4 * lk;
+      const bool okg = lm < K && f < F, ok0 = lm < N && f < F, ok1 = 32 + lm < N && f < F;
+      const float tg = *byte_off(Gb, okg ? (lm * F + f) * 4 : 0);
+      const float t0 = *byte_off(Xb, ok0 ? (lm * F + f) * 4 : 0), t1 = *byte_off(Xb, ok1 ? ((32 + lm) * F + f) * 4 : 0);
+      ga[r] = okg ? tg : 0.f;
+      xn0[r] = ok0 ? t0 : 0.f;
+      xn1[r] = ok1 ? t1 : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      gs0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[r], xn0[r], gs0, 0, 0, 0);
+      gs1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[r], xn1[r], gs1, 0, 0, 0);
+    }
+  }
+  // ---- gS out: accumulators hold gS^T (lane = node): through LDS so that a row leaves as one contiguous run -----------
+  {
+    float* sT = As;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sT[lm * 33 + rho(r) + 4 * lk] = gs0[r];
+      sT[(32 + lm) * 33 + rho(r) + 4 * lk] = gs1[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* o = p.gS + static_cast<long>(b) * N * K;
+#pragma unroll 4
+    for (int t = 0; t < 32; ++t) {
+      const int n = 2 * t + lk;
+      if (n < N && lm < K) o[n * K + lm] = sT[n * 33 + lm];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- gX^T = gX'^T S^T (lane = node, register = feature) ----------------------------------------------------------
+  if (p.gX) {
+    f32x16 gx0, gx1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { gx0[r] = 0.f; gx1[r] = 0.f; }
+    if (p.g_x_pool) {
+      const float* Gb = p.g_x_pool + static_cast<long>(b) * K * F;
+      float gb[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = rho(r) + 4 * lk;
+        const bool ok = j < K && lm < F;
+        const float t = *byte_off(Gb, ok ? (j * F + lm) * 4 : 0);
+        gb[r] = ok ? t : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        gx0 = __builtin_amdgcn_mfma_f32_32x32x2f32(gb[r], sn0[r], gx0, 0, 0, 0);
+        gx1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gb[r], sn1[r], gx1, 0, 0, 0);
+      }
+    }
+    float* sT = As;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sT[lm * 33 + rho(r) + 4 * lk] = gx0[r];
+      sT[(32 + lm) * 33 + rho(r) + 4 * lk] = gx1[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* o = p.gX + static_cast<long>(b) * N * F;
+#pragma unroll 4
+    for (int t = 0; t < 32; ++t) {
+      const int n = 2 * t + lk;
+      if (n < N && lm < F) o[n * F + lm] = sT[n * 33 + lm];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Medium graphs (TU-dataset-sized batches: N up to a few hundred, K <= 64): one WORKGROUP (4 waves) owns one
 // graph, every byte of A / X crosses HBM once and nothing intermediate leaves the CU.
 //   * S [N,K] is copied to LDS once (zero padded to 32-row / 32-column multiples); every MFMA reads one of its

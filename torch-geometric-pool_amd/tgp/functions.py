@@ -586,6 +586,58 @@ def row_dot(x: Tensor, w: Tensor) -> Tensor:
 
 
 # ------------------------------------------------- A S and A^T S shared between Connect and the link loss
+class _DensePoolSmallFn(torch.autograd.Function):
+    """Reduce + Connect (+ MinCut's two loss tails, + DiffPool's two losses) of a batch of small graphs as ONE kernel in
+    each direction (csrc/dense_graph_kernels.h: dense_pool_small_kernel / dense_pool_small_bwd_kernel).  Outputs:
+    x_pool, raw S^T A S, post-processed adj_pool, terms [2,B], diff [2]; raw / terms / diff are only differentiated
+    when they were asked for."""
+
+    @staticmethod
+    def forward(ctx, s, adj, x, flags, want_raw, want_terms, diff_scales, graph_sizes):
+        from . import kernels as K
+        sd, ad = s.detach(), adj.detach()
+        x_pool, raw, adj_pool, terms = K.dense_pool(sd, ad, x.detach(), flags, want_raw=want_raw, want_post=True,
+                                                    mincut_terms=True)
+        if terms is None:
+            raise RuntimeError("_DensePoolSmallFn: the batch does not take the one-wave-per-graph kernel")
+        diff = s.new_empty(0)
+        if diff_scales is not None:
+            diff = K.diffpool_loss_tail(sd, ad, graph_sizes, diff_scales[0], diff_scales[1])
+        ctx.save_for_backward(s, adj, x, diff)
+        ctx.flags = flags
+        ctx.want_gx = x.requires_grad
+        ctx.diff_scales = diff_scales
+        if raw is None:
+            raw = s.new_empty(0)
+        if not want_terms:
+            terms = terms.detach()
+        ctx.mark_non_differentiable(*([] if want_raw else [raw]), *([] if want_terms else [terms]),
+                                    *([] if diff_scales is not None else [diff]))
+        return x_pool, raw, adj_pool, terms, diff
+
+    @staticmethod
+    def backward(ctx, g_x, g_raw, g_adj, g_terms, g_diff):
+        from . import kernels as K
+        s, adj, x, diff = ctx.saved_tensors
+        if g_raw is not None and g_raw.numel() == 0:
+            g_raw = None
+        ds = ctx.diff_scales
+        if ds is None or g_diff is None or g_diff.numel() == 0:
+            g_diff, ds = None, (0.0, 0.0)
+        gs, gx = K.dense_pool_small_bwd(s, adj, x, ctx.flags, g_x, g_adj, g_raw, g_terms, want_gx=ctx.want_gx,
+                                        g_diff=g_diff, diff_losses=diff if g_diff is not None else None,
+                                        link_scale=ds[0], ent_scale=ds[1])
+        return gs.to(s.dtype), None, (gx.to(x.dtype) if gx is not None else None), None, None, None, None, None
+
+
+def dense_pool_small(s: Tensor, adj: Tensor, x: Tensor, flags: int, want_raw: bool, want_terms: bool,
+                     diff_scales=None, graph_sizes: Optional[Tensor] = None):
+    """Differentiable fused Reduce + Connect for batches ``kernels.dense_pool_is_small`` accepts (adj gets no gradient:
+    callers check ``adj.requires_grad`` first).  ``diff_scales = (link_scale, ent_scale)``: also DiffPool's link and
+    entropy losses [2], differentiated by the same backward launch."""
+    return _DensePoolSmallFn.apply(s, adj, x, flags, want_raw, want_terms, diff_scales, graph_sizes)
+
+
 class ASProducts:
     """U = A S and V = A^T S of one (S, A) pair, computed at most once.  DiffPool's training step needs U in the
     Connect forward, U and V in its backward and both again in the link-prediction loss' backward

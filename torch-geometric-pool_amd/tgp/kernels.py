@@ -386,6 +386,50 @@ def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int
     return (x_pool, adj_raw, adj_pool, None) if mincut_terms else (x_pool, adj_raw, adj_pool)
 
 
+def dense_pool_is_small(B: int, Nn: int, K: int, F: int) -> bool:
+    """Does the one-wave-per-graph kernel take this padded batch (and so its fused backward)?"""
+    return bool(N.lib().tgp_dense_pool_is_small(B, Nn, K, F))
+
+
+def dense_pool_small_bwd(s: Tensor, adj: Tensor, x: Optional[Tensor], flags: int, g_x_pool: Optional[Tensor],
+                         g_adj_pool: Optional[Tensor], g_adj_raw: Optional[Tensor], g_terms: Optional[Tensor],
+                         want_gx: bool = True, g_diff: Optional[Tensor] = None, diff_losses: Optional[Tensor] = None,
+                         link_scale: float = 0.0, ent_scale: float = 0.0):
+    """Gradients (gS, gX) of ``dense_pool`` (with its in-kernel MinCut terms) for a batch of small graphs, one launch:
+    base_reduce.py:158-161, dense_conn.py:111-122, utils/ops.py:282-335, utils/losses.py:39-70 under autograd."""
+    dev = N.require_device(s, adj, x)
+    s = N.f32c(s)
+    B, Nn, K = s.shape
+    a, tflag = _dense_adj_layout(adj)
+    F = 0
+    if x is not None:
+        x = N.f32c(x)
+        F = x.size(2)
+
+    def grad(t, shape):
+        if t is None:
+            return None
+        t = N.f32c(t)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"upstream gradient {tuple(t.shape)} does not match {tuple(shape)}")
+        return t
+
+    g_x_pool = grad(g_x_pool, (B, K, F)) if x is not None else None
+    g_adj_pool, g_adj_raw = grad(g_adj_pool, (B, K, K)), grad(g_adj_raw, (B, K, K))
+    g_terms = grad(g_terms, (2, B))
+    g_diff = grad(g_diff, (2,))
+    diff_losses = grad(diff_losses, (2,)) if g_diff is not None else None
+    gs = torch.empty(B, Nn, K, dtype=torch.float32, device=dev)
+    gx = torch.empty(B, Nn, F, dtype=torch.float32, device=dev) if (want_gx and x is not None) else None
+    N.check(N.lib().tgp_dense_pool_small_bwd_f32(N.ptr(s), N.ptr(a), N.ptr(x), B, Nn, K, F, flags | tflag, ops_eps(),
+                                                 losses_eps(), N.ptr(g_x_pool), N.ptr(g_adj_pool), N.ptr(g_adj_raw),
+                                                 N.ptr(g_terms), N.ptr(g_diff), N.ptr(diff_losses), float(link_scale),
+                                                 float(ent_scale), losses_eps(), N.ptr(gs), N.ptr(gx),
+                                                 N.stream_ptr(dev)),
+            "tgp_dense_pool_small_bwd_f32")
+    return gs, gx
+
+
 def postprocess_dense(adj_pool: Tensor, flags: int, inplace: bool = False) -> Tensor:
     """utils/ops.py:282-335 on a [B,K,K] tensor."""
     dev = N.require_device(adj_pool)

@@ -152,7 +152,11 @@ class _DenseMLPPooling(DenseSRCPooling):
 
     _loss_needs_raw = False  # MinCut's cut loss reads the raw S^T A S
 
-    def _loss_from_fused(self, adj, so, mask, raw, terms=None) -> dict:
+    def _fused_diff_scales(self, adj, mask):
+        """(link_scale, ent_scale) when the pooler's two losses can ride on the fused training call (DiffPool)."""
+        return None
+
+    def _loss_from_fused(self, adj, so, mask, raw, terms=None, diff=None) -> dict:
         raise NotImplementedError
 
     def _lift(self, x, so, batch, batch_pooled):
@@ -193,12 +197,15 @@ class _DenseMLPPooling(DenseSRCPooling):
             if graph_sizes is not None and graph_sizes.numel() == x.size(0):
                 so._graph_sizes = graph_sizes
                 self._sizes_hint = (weakref.ref(adj), graph_sizes)  # valid for exactly this adjacency tensor
+            diff_scales = self._fused_diff_scales(adj, mask)
             fused = self.reduce_connect(x, adj, so, want_raw=self._loss_needs_raw,
-                                        want_mincut_terms=self._loss_needs_raw)
-            if fused is not None:  # inference: Reduce + Connect in one native call
+                                        want_mincut_terms=self._loss_needs_raw, want_diff_losses=diff_scales)
+            if fused is not None:  # Reduce + Connect in one native call (training: batches of small graphs only)
                 x_pool, raw, adj_pool = fused[:3]
                 batch_pool = self.reducer.reduce_batch(so, batch if batch is not None else so.batch)
-                loss = self._loss_from_fused(adj, so, mask, raw, fused[3] if len(fused) > 3 else None)
+                terms = fused[3] if self._loss_needs_raw else None
+                diff = fused[-1] if diff_scales is not None else None
+                loss = self._loss_from_fused(adj, so, mask, raw, terms, diff)
             else:
                 x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch)
                 adj_pool, loss = self._batched_connect_and_loss(x, adj, so, mask, edge_weight, batch, batch_pool)
@@ -237,7 +244,16 @@ class DiffPool(_DenseMLPPooling):
         loss = self.compute_loss(adj=adj, S=so.s, num_nodes=self._real_nodes(mask))
         return adj_pool, loss
 
-    def _loss_from_fused(self, adj, so, mask, raw, terms=None) -> dict:
+    def _fused_diff_scales(self, adj, mask):
+        num_nodes = self._real_nodes(mask)
+        if not (isinstance(num_nodes, int) and num_nodes > 0 and torch.is_grad_enabled()):
+            return None
+        link_scale = self.link_loss_coeff / adj.numel() if self.normalize_loss is True else self.link_loss_coeff
+        return (float(link_scale), float(self.ent_loss_coeff) / num_nodes)
+
+    def _loss_from_fused(self, adj, so, mask, raw, terms=None, diff=None) -> dict:
+        if diff is not None:  # both losses came with the fused training call (and are differentiated by its backward)
+            return {"link_loss": diff[0], "entropy_loss": diff[1]}
         return self.compute_loss(adj=adj, S=so.s, num_nodes=self._real_nodes(mask))
 
     def compute_loss(self, adj: Tensor, S: Tensor, num_nodes: int) -> dict:
@@ -294,7 +310,7 @@ class MinCutPooling(_DenseMLPPooling):
 
     _loss_needs_raw = True
 
-    def _loss_from_fused(self, adj, so, mask, raw, terms=None) -> dict:
+    def _loss_from_fused(self, adj, so, mask, raw, terms=None, diff=None) -> dict:
         if terms is not None and so.s.dtype == torch.float32:
             # both per-graph loss tails came out of the pooling kernel itself (batches of small graphs)
             both = terms.mean(dim=1)

@@ -288,7 +288,7 @@ class DenseSRCPooling(SRCPooling):
 
     def reduce_connect(self, x: Tensor, adj: Tensor, so: SelectOutput, want_raw: bool = False,
                        out_x: Optional[Tensor] = None, out_adj: Optional[Tensor] = None,
-                       want_mincut_terms: bool = False):
+                       want_mincut_terms: bool = False, want_diff_losses=None):
         """Reduce + Connect of a padded dense batch as ONE native call (fused A3 + A7 + A8):
         ``(x_pool [B,K,F], raw S^T A S or None, adj_pool [B,K,K])``.  ``U = A S`` is formed once and
         ``S^T [U | X]`` runs as a single grid (one wave per graph when the graphs fit in LDS), so S is read
@@ -303,12 +303,24 @@ class DenseSRCPooling(SRCPooling):
         if not (type(c) is DenseConnect and type(self.reducer) is BaseReduce and isinstance(s, Tensor)
                 and not s.is_sparse and s.dim() == 3 and adj.dim() == 3 and x.dim() == 3 and s.is_cuda):
             return None
-        if torch.is_grad_enabled() and (s.requires_grad or adj.requires_grad or x.requires_grad):
-            return None
         if s.size(0) != adj.size(0):
             raise ValueError("Assignment and adjacency batch sizes do not match: "
                              f"got s.size(0)={s.size(0)} and adj.size(0)={adj.size(0)}.")
         flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
+        if torch.is_grad_enabled() and (s.requires_grad or adj.requires_grad or x.requires_grad):
+            # training: batches of small graphs keep the fused kernel and get its one-launch backward (the adjacency
+            # gets no gradient there, edge_weight_norm is not differentiated there: those keep the operator path)
+            if (adj.requires_grad or c.edge_weight_norm or out_x is not None or out_adj is not None
+                    or s.dtype != torch.float32 or x.dtype != torch.float32 or adj.dtype != torch.float32
+                    or not K.dense_pool_is_small(s.size(0), s.size(1), s.size(2), x.size(2))):
+                return None
+            # want_diff_losses = (link_scale, ent_scale): DiffPool's two losses ride along as a last value [2]
+            x_pool, raw, adj_pool, terms, diff = Fn.dense_pool_small(
+                s, adj, x, flags, want_raw, want_mincut_terms, want_diff_losses, getattr(so, "_graph_sizes", None))
+            res = (x_pool, raw if want_raw else None, adj_pool)
+            if want_mincut_terms:
+                res = res + (terms,)
+            return res + (diff,) if want_diff_losses is not None else res
         # out_x / out_adj (optional, float32 [B,K,F] / [B,K,K]): the kernels write the pooled outputs straight into
         # caller memory, e.g. the next slot of distributed.PackedGather's send buffer (no pack copy before the RCCL call)
         out = K.dense_pool(s, adj, x, flags, want_raw=want_raw, want_post=True,
@@ -318,8 +330,11 @@ class DenseSRCPooling(SRCPooling):
         # fp32 arithmetic; results carry the dtypes the reference's ATen ops would return
         res = (like_input_dtype(x_pool, x), like_input_dtype(raw, s), like_input_dtype(adj_pool, s))
         # want_mincut_terms: a fourth value, the [2,B] loss tails from inside the pooling kernel (None when the batch
-        # does not take the one-wave-per-graph kernel)
-        return res + (out[3],) if want_mincut_terms else res
+        # does not take the one-wave-per-graph kernel); want_diff_losses: a last value, None on this (no-grad) path --
+        # the caller's own inference tail computes the two losses
+        if want_mincut_terms:
+            res = res + (out[3],)
+        return res + (None,) if want_diff_losses is not None else res
 
     def _finalize_sparse_output(self, x_pool: Tensor, adj_pool: Tensor, batch: Optional[Tensor],
                                 batch_pooled: Optional[Tensor], so: SelectOutput):
