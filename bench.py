@@ -25,7 +25,8 @@ Rank 0 prints ONE JSON line:
                    Connect: HBM), c4_graclus (Reduce + coalesce Connect, both rooflines: HBM), c3 (MinCut small graphs:
                    HBM), c4_ndp (NDP-shaped Reduce), topk_batch (batched sparse TopK Reduce + Connect; with ranks: +
                    variable-size RCCL all-gather), e2e_diff_c2 / e2e_mincut_c3 (WHOLE pooler forwards on sparse
-                   inputs, eager and HIP-graph replayed, launches per forward).  With N > 1 only the graph-sharded
+                   inputs, eager and HIP-graph replayed, launches per forward), e2e_train_mincut_c3 (a whole MinCut
+                   training step, forward + backward, launches per step).  With N > 1 only the graph-sharded
                    ones run; one giant graph (C4) does not shard.
 `--workload X` makes X the headline of the line instead; the driver's line is the default c2.
 """
@@ -419,6 +420,47 @@ class PoolerForward(Workload):
         return r
 
 
+class PoolerTrainStep(Workload):
+    """e2e_train_mincut_c3: a WHOLE training step of ``get_pooler('mincut')`` on the PROTEINS-shaped sparse batch --
+    forward (preprocessing, MLPSelect, fused Reduce + Connect + loss terms), a scalar loss over the pooled outputs and
+    both auxiliary losses, backward to the input features and the selector's parameters (the fused one-launch backward of
+    csrc/dense_graph_kernels.h for Reduce + Connect + losses).  Eager, and launches per step; what a user's step costs."""
+    shards = True
+
+    def __init__(self, ctx):
+        from tgp.poolers import get_pooler
+        dev = ctx.dev
+        torch.manual_seed(ctx.rank)
+        self.B, self.N, self.K, self.F = 2048, 60, 20, 32
+        self.x, self.ei, self.batch = sparse_batch(_proteins_sizes(ctx.rank), 4, self.F, dev, seed=ctx.rank)
+        self.x.requires_grad_(True)
+        self.pooler = get_pooler("mincut", in_channels=self.F, k=self.K).to(dev).train()
+        self.nodes = self.x.size(0)
+        self.name = ("get_pooler('mincut') whole TRAINING step (forward + backward) on sparse inputs: 2048 graphs "
+                     "n~U[20,60], K=20, F=32")
+        self.extra = {"nodes_counted": "real input nodes per step", "edges": int(self.ei.size(1)),
+                      "step": "forward + loss + backward to x and the selector's parameters, eager"}
+
+    def step(self):
+        self.pooler.zero_grad(set_to_none=True)
+        self.x.grad = None
+        out = self.pooler(x=self.x, adj=self.ei, batch=self.batch)
+        loss = out.x.sum() + out.edge_index.sum() + out.loss["cut_loss"] + out.loss["ortho_loss"]
+        loss.backward()
+        return loss
+
+    def rooflines(self, dev):
+        B, N, K, F = self.B, self.N, self.K, self.F
+        ms = event_time_ms(self.step, 50, dev)
+        # forward traffic (as e2e_mincut_c3) + backward: A, S, X read again, gS, gX and the dense gradients written / read
+        fwd = (self.ei.size(1) * 16.0 + self.nodes * F * 4.0 + 2 * 4.0 * B * N * N + 2 * 4.0 * B * N * (F + K)
+               + 4.0 * B * (2 * K * K + K * F))
+        bwd = 4.0 * B * N * N + 3 * 4.0 * B * N * (F + K) + 4.0 * B * (K * K + K * F) + 2 * self.nodes * F * 4.0
+        r = roof_hbm("whole training step (all kernels of forward + backward, eager)", fwd + bwd, ms)
+        r["launches_per_step"] = count_kernels(self.step)
+        return r
+
+
 class TopkBatch(Workload):
     """topk_batch: TopK (ratio 0.5) Reduce + subgraph Connect on 2048 PROTEINS-shaped graphs, Select excluded.  The
     batched SPARSE path of SURVEY 8(e): graphs shard by id, and with more than one rank (or TGP_BENCH_FORCE_DIST=1)
@@ -632,6 +674,8 @@ def make_workload(which, ctx, args):
         return GraclusC4(ctx, unsorted_edges=args.unsorted_edges)
     if which in ("e2e_diff_c2", "e2e_mincut_c3"):
         return PoolerForward(which, ctx)
+    if which == "e2e_train_mincut_c3":
+        return PoolerTrainStep(ctx)
     if which == "topk_batch":
         return TopkBatch(ctx, force_collective=os.environ.get("TGP_BENCH_FORCE_DIST") == "1")
     raise ValueError(which)
@@ -710,10 +754,11 @@ def cpu_baseline_dense(B, N, K, F, budget_s=10.0):
 
 
 # ------------------------------------------------------------------------------------------------ main
-ALL = ["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect", "topk_batch", "e2e_diff_c2", "e2e_mincut_c3"]
+ALL = ["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect", "topk_batch", "e2e_diff_c2", "e2e_mincut_c3",
+       "e2e_train_mincut_c3"]
 SECONDARY_DEFAULT = ["c5", "topk1m", "topk_connect", "c4_graclus", "c4_ndp", "c3", "topk_batch", "e2e_diff_c2",
-                     "e2e_mincut_c3"]
-SHARDED = ("c5", "c3", "topk_batch", "e2e_diff_c2", "e2e_mincut_c3")
+                     "e2e_mincut_c3", "e2e_train_mincut_c3"]
+SHARDED = ("c5", "c3", "topk_batch", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3")
 
 
 def main():
