@@ -56,11 +56,12 @@ def count_kernels(fn, list_kernels=False):
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
         fn()
         torch.cuda.synchronize()
-    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
     if list_kernels:
-        for nm in names:
-            print("    ", nm[:110])
-    return len(names)
+        for e in sorted(evs, key=lambda e: e.time_range.start):
+            print(f"     {e.device_time:8.1f} us  {e.name[:110]}")
+        print(f"     GPU-busy {sum(e.device_time for e in evs) / 1e3:.3f} ms")
+    return len(evs)
 
 
 CASES = {

@@ -1,0 +1,59 @@
+"""NDPSelect on a PROTEINS-shaped batch: the one-wave kernel against the LDS-vector kernel (TGP_NDP_GENERIC_KERNEL=1 in a
+child process) -- same partitions (up to the eigenvector's global sign per graph), iteration counts, kernel time."""
+import os
+import subprocess
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "torch-geometric-pool_amd"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def run():
+    from e2e_launches import batch_graphs
+    from tgp import kernels as K
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    sizes = torch.randint(20, 61, (2048,), generator=g).tolist()
+    x, ei, batch = batch_graphs(sizes, 4, 8)
+    n = x.size(0)
+    indptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    indptr[1:] = torch.cumsum(torch.bincount(ei[0], minlength=n), 0).int()
+    ptr = torch.zeros(2049, dtype=torch.long, device=dev)
+    ptr[1:] = torch.cumsum(torch.tensor(sizes, device=dev), 0)
+    for _ in range(3):
+        keep, info, status = K.ndp_partition(indptr, ei[1], None, n, ptr, 64, seed=1)
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(20):
+        keep, info, status = K.ndp_partition(indptr, ei[1], None, n, ptr, 64, seed=1)
+    t1.record()
+    torch.cuda.synchronize()
+    return keep.cpu(), info.cpu(), t0.elapsed_time(t1) / 20, ptr.cpu()
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "child":
+        keep, info, ms, ptr = run()
+        torch.save((keep, info, ms), sys.argv[2])
+        sys.exit(0)
+    keep, info, ms, ptr = run()
+    out = "/tmp/ndp_generic.pt"
+    env = dict(os.environ, TGP_NDP_GENERIC_KERNEL="1")
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), "child", out], env=env)
+    keep_g, info_g, ms_g = torch.load(out)
+    same = flipped = differ = 0
+    for b in range(2048):
+        a, c = keep[ptr[b]:ptr[b + 1]], keep_g[ptr[b]:ptr[b + 1]]
+        if torch.equal(a, c):
+            same += 1
+        elif torch.equal(a, ~c):
+            flipped += 1
+        else:
+            differ += 1
+    print(f"one-wave kernel {ms:.3f} ms per call (steps: median {int(info[info >= 0].median())}, max {int(info.max())}, "
+          f"random fallbacks {int((info < 0).sum())});  LDS-vector kernel {ms_g:.3f} ms (median "
+          f"{int(info_g[info_g >= 0].median())}, max {int(info_g.max())}, random {int((info_g < 0).sum())})")
+    print(f"partitions: identical {same}, globally sign-flipped {flipped}, different {differ} of 2048 graphs")

@@ -142,6 +142,111 @@ __device__ __forceinline__ void ndp_eig3_largest(double a[3][3], int dim, double
   for (int k = 0; k < 3; ++k) c[k] = k < dim ? v[k][best] : 0.0;
 }
 
+// The same in fp32, for the one-workgroup kernel below.  The 3 x 3 Rayleigh-Ritz only picks the next search direction:
+// the iterate is renormalised and its Rayleigh quotient and residual are re-evaluated in fp64 every step, so the
+// coefficients need a few digits, not sixteen.  The fp64 sweeps (two divisions and two square roots per rotation, each a
+// sequence of ~30 dependent instructions) were 55 % of a step: 7.1 k of 13 k cycles per step on a 49-node graph (r3
+// stamps), 1.03 ms for the 2048 graphs of a PROTEINS-shaped batch.
+__device__ __forceinline__ void ndp_eig3_largest_f32(const double ad[3][3], int dim, double c[3]) {
+  float a[3][3], v[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a[i][j] = static_cast<float>(ad[i][j]);
+  for (int sweep = 0; sweep < 4; ++sweep) {
+    const float off = fabsf(a[0][1]) + (dim == 3 ? fabsf(a[0][2]) + fabsf(a[1][2]) : 0.f);
+    const float dia = fabsf(a[0][0]) + fabsf(a[1][1]) + (dim == 3 ? fabsf(a[2][2]) : 0.f);
+    if (!(off > 1e-6f * dia)) break;  // (wave-uniform: every lane holds the same numbers; fp32 cannot go much lower)
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+      if (q >= dim) continue;
+      const float apq = a[p][q];
+      if (!(fabsf(apq) > 1e-9f * (fabsf(a[p][p]) + fabsf(a[q][q])))) continue;
+      const float tau = (a[q][q] - a[p][p]) / (2.0f * apq);
+      const float t = (tau >= 0.f ? 1.0f : -1.0f) / (fabsf(tau) + sqrtf(1.0f + tau * tau));
+      const float cs = 1.0f / sqrtf(1.0f + t * t), sn = t * cs;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {  // A <- A J
+        const float akp = a[k][p], akq = a[k][q];
+        a[k][p] = cs * akp - sn * akq;
+        a[k][q] = sn * akp + cs * akq;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {  // A <- J^T A
+        const float apk = a[p][k], aqk = a[q][k];
+        a[p][k] = cs * apk - sn * aqk;
+        a[q][k] = sn * apk + cs * aqk;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float vkp = v[k][p], vkq = v[k][q];
+        v[k][p] = cs * vkp - sn * vkq;
+        v[k][q] = sn * vkp + cs * vkq;
+      }
+    }
+  }
+  int best = 0;
+  for (int k = 1; k < dim; ++k)
+    if (a[k][k] > a[best][best]) best = k;
+  for (int k = 0; k < 3; ++k) c[k] = k < dim ? static_cast<double>(v[k][best]) : 0.0;
+}
+
+// Largest eigenpair of the 3 x 3 (or 2 x 2) Rayleigh-Ritz matrix in closed form, fp32: the eigenvalue from the
+// trigonometric solution of the characteristic cubic, the eigenvector as the largest of the three cross products of rows
+// of H - theta I.  ~100 instructions where four Jacobi sweeps are ~1000 (5.6 k cycles per step of the one-wave kernel,
+// more than half of it).  When the largest eigenvalue is (nearly) double the cross products vanish: the Jacobi sweeps
+// take over (rare: two coinciding Ritz values).  c comes back with unit length.
+__device__ __forceinline__ void ndp_rr_largest_f32(const double ad[3][3], int dim, double c[3]) {
+  const float a00 = static_cast<float>(ad[0][0]), a11 = static_cast<float>(ad[1][1]), a01 = static_cast<float>(ad[0][1]);
+  if (dim == 2) {
+    const float t = 0.5f * (a00 - a11), sr = sqrtf(t * t + a01 * a01);
+    const float theta = 0.5f * (a00 + a11) + sr;
+    // rows of H - theta I: (a00 - theta, a01) and (a01, a11 - theta); eigenvector orthogonal to the larger one
+    const float u0 = theta - a11, u1 = a01;      // from the second row
+    const float v0 = a01, v1 = theta - a00;      // from the first row
+    const float nu = u0 * u0 + u1 * u1, nv = v0 * v0 + v1 * v1;
+    const float x0 = nu >= nv ? u0 : v0, x1 = nu >= nv ? u1 : v1, nn = nu >= nv ? nu : nv;
+    if (nn > 0.f) {
+      const float inv = 1.0f / sqrtf(nn);
+      c[0] = static_cast<double>(x0 * inv); c[1] = static_cast<double>(x1 * inv); c[2] = 0.0;
+    } else {  // a multiple of the identity
+      c[0] = 1.0; c[1] = 0.0; c[2] = 0.0;
+    }
+    return;
+  }
+  const float a22 = static_cast<float>(ad[2][2]), a02 = static_cast<float>(ad[0][2]), a12 = static_cast<float>(ad[1][2]);
+  const float p1 = a01 * a01 + a02 * a02 + a12 * a12;
+  const float q = (a00 + a11 + a22) * (1.0f / 3.0f);
+  const float b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+  const float p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0f * p1;
+  bool ok = p2 > 0.f;
+  if (ok) {
+    const float pp = sqrtf(p2 * (1.0f / 6.0f)), ip = 1.0f / pp;
+    const float c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
+    float r = 0.5f * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+    r = fminf(1.0f, fmaxf(-1.0f, r));
+    const float theta = q + 2.0f * pp * cosf(acosf(r) * (1.0f / 3.0f));
+    const float m00 = a00 - theta, m11 = a11 - theta, m22 = a22 - theta;
+    // cross products of the rows (m00, a01, a02), (a01, m11, a12), (a02, a12, m22)
+    const float x12[3] = {m11 * m22 - a12 * a12, a12 * a02 - a01 * m22, a01 * a12 - m11 * a02};
+    const float x02[3] = {a01 * m22 - a02 * a12, a02 * a02 - m00 * m22, m00 * a12 - a01 * a02};
+    const float x01[3] = {a01 * a12 - a02 * m11, a02 * a01 - m00 * a12, m00 * m11 - a01 * a01};
+    const float n12 = x12[0] * x12[0] + x12[1] * x12[1] + x12[2] * x12[2];
+    const float n02 = x02[0] * x02[0] + x02[1] * x02[1] + x02[2] * x02[2];
+    const float n01 = x01[0] * x01[0] + x01[1] * x01[1] + x01[2] * x01[2];
+    float best = n12, y0 = x12[0], y1 = x12[1], y2 = x12[2];
+    if (n02 > best) { best = n02; y0 = x02[0]; y1 = x02[1]; y2 = x02[2]; }
+    if (n01 > best) { best = n01; y0 = x01[0]; y1 = x01[1]; y2 = x01[2]; }
+    ok = best > 1e-6f * p2 * p2;  // (gap to the other eigenvalues) x (spread) well above fp32 noise
+    if (ok) {
+      const float inv = 1.0f / sqrtf(best);
+      c[0] = static_cast<double>(y0 * inv); c[1] = static_cast<double>(y1 * inv); c[2] = static_cast<double>(y2 * inv);
+    }
+  }
+  if (!ok) ndp_eig3_largest_f32(ad, dim, c);  // (wave-uniform)
+}
+
 // indptr / col / w: CSR over all nodes of the batch of a SYMMETRIC adjacency without self loops (the caller
 // symmetrises with max, as to_undirected(reduce="max") does, ndp_select.py:198-202).
 template <int THREADS>
@@ -292,8 +397,8 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
       const int dim = (has_p && sb[0] > 1e-24) ? 3 : 2;  // p was unit length: what is left of it outside span{x, w}
       const double ip = dim == 3 ? 1.0 / sqrt(sb[0]) : 0.0;
       double h[3][3] = {{lam, sb[1], sb[3] * ip}, {sb[1], sb[2], sb[4] * ip}, {sb[3] * ip, sb[4] * ip, sb[5] * ip * ip}};
-      double theta, c[3];
-      ndp_eig3_largest(h, dim, theta, c);
+      double c[3];
+      ndp_rr_largest_f32(h, dim, c);
       if (c[0] < 0.0) { c[0] = -c[0]; c[1] = -c[1]; c[2] = -c[2]; }
       // x <- c0 x + c1 w + c2 p^, p <- (c1 w + c2 p^) / |.| (the same combinations of Ls x, Ls w, Ls p^)
       const double c2p = c[2] * ip;
@@ -348,6 +453,158 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
   if (tid == 0) info[g] = random_part ? -1 : it;
 }
 
+
+// The same iteration for graphs of at most 64 nodes, ONE WAVE per graph with the six work vectors in REGISTERS (lane =
+// node): the loops over "this thread's rows" and their LDS round trips are gone, a step is ~40 vector instructions, one
+// LDS exchange for the sparse mat-vec, eleven DPP reductions and the 3 x 3 Rayleigh-Ritz.  r3, 2048 graphs of 20..60
+// nodes: ndp_partition_kernel<64> took 1.03 ms (13 k cycles per step, 7 k of them fp64 Jacobi sweeps); same arithmetic,
+// same stopping rule, same outputs up to the solver tolerance.
+__global__ __launch_bounds__(64) void ndp_partition_wave_kernel(const int32_t* __restrict__ indptr,
+                                                                const int64_t* __restrict__ col,
+                                                                const float* __restrict__ w,
+                                                                const int64_t* __restrict__ graph_ptr,
+                                                                unsigned long long seed, int max_iter, double tol,
+                                                                int ncap, int ecap, uint8_t* __restrict__ keep,
+                                                                int32_t* __restrict__ info, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const int64_t p0 = graph_ptr[g], p1 = graph_ptr[g + 1];
+  const int64_t n64 = p1 - p0;
+  if (n64 <= 0) return;
+  if (n64 > 64 || n64 > ncap) {
+    if (lane == 0) info[g] = -2;
+    return;
+  }
+  const int n = static_cast<int>(n64);
+  if (n == 1) {
+    if (lane == 0) { keep[p0] = 1; info[g] = 0; }
+    return;
+  }
+  double* xs = s_dyn;  // [ncap] the vector a mat-vec reads through the column indices
+  double* mval = s_dyn + 6 * ncap;
+  int* mptr = reinterpret_cast<int*>(mval + ecap);
+  float* dis = reinterpret_cast<float*>(mptr + ncap + 1);
+  unsigned short* mcol = reinterpret_cast<unsigned short*>(dis + ncap);
+  const bool on = lane < n;
+  const int e_beg = on ? indptr[p0 + lane] : 0, e_end = on ? indptr[p0 + lane + 1] : 0;
+  const int e_lo = indptr[p0], nnz_g = indptr[p1] - e_lo;
+  const bool cached = nnz_g <= ecap;
+  double deg = 0.0;
+  for (int e = e_beg; e < e_end; ++e) {
+    const int64_t c = col[e];
+    if (c < p0 || c >= p1) { atomicOr(status, 2); continue; }
+    deg += w ? static_cast<double>(w[e]) : 1.0;
+  }
+  const float my_dis = deg > 0.0 ? static_cast<float>(1.0 / sqrt(deg)) : 0.f;
+  if (on) dis[lane] = my_dis;
+  const double vol = ndp_wave_sum(deg);
+  __builtin_amdgcn_wave_barrier();
+  if (cached && on) {
+    for (int e = e_beg; e < e_end; ++e) {
+      const int64_t c = col[e];
+      const bool in = c >= p0 && c < p1;
+      const int j = in ? static_cast<int>(c - p0) : 0;
+      mcol[e - e_lo] = static_cast<unsigned short>(j);
+      mval[e - e_lo] = in ? (w ? static_cast<double>(w[e]) : 1.0) * static_cast<double>(my_dis) *
+                                static_cast<double>(dis[j]) : 0.0;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int r_beg = e_beg - e_lo, r_end = e_end - e_lo;
+  auto matvec = [&](double src) -> double {  // (Ls src)[lane]
+    xs[lane] = src;
+    __builtin_amdgcn_wave_barrier();
+    double acc = 0.0;
+    if (cached) {
+      for (int e = r_beg; e < r_end; ++e) acc += mval[e] * xs[mcol[e]];
+    } else {
+      for (int e = e_beg; e < e_end; ++e) {
+        const int64_t c = col[e];
+        if (c < p0 || c >= p1) continue;
+        const int j = static_cast<int>(c - p0);
+        acc += (w ? static_cast<double>(w[e]) : 1.0) * static_cast<double>(dis[j]) * xs[j];
+      }
+      acc *= static_cast<double>(my_dis);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return on ? src - acc : 0.0;
+  };
+  int it = 0;
+  bool random_part = !(vol > 0.0);
+  double x = on ? (static_cast<double>(ndp_hash(0x5EEDull, static_cast<uint64_t>(lane) + 977ull * n) >> 8) / 8388608.0) - 1.0
+                : 0.0;
+  if (!random_part) {
+    const double x2 = ndp_wave_sum(x * x);
+    x *= 1.0 / sqrt(x2);
+    double ax = matvec(x), pv = 0.0, ap = 0.0;
+    double lam = ndp_wave_sum(x * ax);
+    bool has_p = false;
+    for (; it < max_iter; ++it) {
+      const double r = ax - lam * x;
+      double sa[3] = {r * r, x * pv, r * pv};
+      ndp_block_sums<64, 3>(sa, nullptr);
+      const double rn2 = sa[0];
+      if (!(rn2 > tol * tol * lam * lam)) break;  // |Ls x - lambda x| <= tol * lambda: converged
+      const double inv_r = 1.0 / sqrt(rn2);
+      const double cxp = sa[1], cwp = sa[2] * inv_r;
+      const double wv = r * inv_r;
+      const double aw = matvec(wv);
+      if (has_p) {
+        pv = pv - cxp * x - cwp * wv;
+        ap = ap - cxp * ax - cwp * aw;
+      } else {
+        pv = 0.0;
+        ap = 0.0;
+      }
+      double sb[6] = {pv * pv, x * aw, wv * aw, x * ap, wv * ap, pv * ap};
+      ndp_block_sums<64, 6>(sb, nullptr);
+      const int dim = (has_p && sb[0] > 1e-24) ? 3 : 2;
+      const double ip = dim == 3 ? 1.0 / sqrt(sb[0]) : 0.0;
+      const double h[3][3] = {{lam, sb[1], sb[3] * ip}, {sb[1], sb[2], sb[4] * ip}, {sb[3] * ip, sb[4] * ip, sb[5] * ip * ip}};
+      double c[3];
+      ndp_rr_largest_f32(h, dim, c);
+      if (c[0] < 0.0) { c[0] = -c[0]; c[1] = -c[1]; c[2] = -c[2]; }
+      const double c2p = c[2] * ip;
+      const double pn2 = c[1] * c[1] + c[2] * c[2];
+      const double sp = pn2 > 1e-300 ? 1.0 / sqrt(pn2) : 0.0;
+      const double pn = c[1] * wv + c2p * pv, apn = c[1] * aw + c2p * ap;
+      const double xn = c[0] * x + pn, axn = c[0] * ax + apn;
+      pv = pn * sp;
+      ap = apn * sp;
+      double sc[2] = {xn * xn, xn * axn};
+      ndp_block_sums<64, 2>(sc, nullptr);
+      const double ix = 1.0 / sqrt(sc[0]);
+      x = xn * ix;
+      ax = axn * ix;
+      lam = sc[1] / sc[0];
+      has_p = sp > 0.0;
+    }
+    if (!(lam > 0.0)) random_part = true;
+  }
+  if (!random_part) {
+    xs[lane] = x;
+    __builtin_amdgcn_wave_barrier();
+    double cross = 0.0;
+    const bool zi = x >= 0.0;
+    for (int e = e_beg; e < e_end; ++e) {
+      const int64_t c = col[e];
+      if (c < p0 || c >= p1) continue;
+      if ((xs[c - p0] >= 0.0) != zi) cross += w ? static_cast<double>(w[e]) : 1.0;
+    }
+    const double cut = ndp_wave_sum(cross) / vol;
+    if (cut < 0.5) random_part = true;  // ndp_select.py:250-252
+  }
+  if (on) {
+    bool pos;
+    if (random_part) {
+      pos = lane == 0 ? true : (lane == 1 ? false : (ndp_hash(seed, static_cast<uint64_t>(p0 + lane)) & 1u) != 0);
+    } else {
+      pos = x >= 0.0;
+    }
+    keep[p0 + lane] = pos ? 1 : 0;
+  }
+  if (lane == 0) info[g] = random_part ? -1 : it;
+}
 
 // ====================================================================================================================
 // r3: ONE LARGE GRAPH on the whole chip (graphs beyond NDP_MAX_N nodes; the N = 1M, E = 10M graph of BASELINE configs[3]).
@@ -733,8 +990,14 @@ extern "C" int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, cons
   const size_t lds = static_cast<size_t>(fixed + ecap * 10);
   const int ncap = static_cast<int>(cap), ec = static_cast<int>(ecap);
   if (cap <= 64) {
-    hipLaunchKernelGGL(ndp_partition_kernel<64>, dim3(static_cast<unsigned>(B)), dim3(64), lds, stream, indptr, col, w,
-                       graph_ptr, static_cast<unsigned long long>(seed), max_iter, tol, ncap, ec, keep, info, d_status);
+    static const int generic = getenv("TGP_NDP_GENERIC_KERNEL") ? 1 : 0;  // (A/B switch: the LDS-vector kernel)
+    if (generic)
+      hipLaunchKernelGGL(ndp_partition_kernel<64>, dim3(static_cast<unsigned>(B)), dim3(64), lds, stream, indptr, col, w,
+                         graph_ptr, static_cast<unsigned long long>(seed), max_iter, tol, ncap, ec, keep, info, d_status);
+    else
+      hipLaunchKernelGGL(ndp_partition_wave_kernel, dim3(static_cast<unsigned>(B)), dim3(64), lds, stream, indptr, col,
+                         w, graph_ptr, static_cast<unsigned long long>(seed), max_iter, tol, ncap, ec, keep, info,
+                         d_status);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ndp_partition_kernel<256>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
