@@ -458,6 +458,30 @@ class PoolerTrainStep(Workload):
         bwd = 4.0 * B * N * N + 3 * 4.0 * B * N * (F + K) + 4.0 * B * (K * K + K * F) + 2 * self.nodes * F * 4.0
         r = roof_hbm("whole training step (all kernels of forward + backward, eager)", fwd + bwd, ms)
         r["launches_per_step"] = count_kernels(self.step)
+        try:  # the same step with forward and backward replayed from HIP graphs (torch.cuda.make_graphed_callables)
+            pooler, ei, batch = self.pooler, self.ei, self.batch
+
+            class Step(torch.nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.pooler = pooler
+
+                def forward(self, x):
+                    out = self.pooler(x=x, adj=ei, batch=batch)
+                    return out.x.sum() + out.edge_index.sum() + out.loss["cut_loss"] + out.loss["ortho_loss"]
+
+            xg = self.x.detach().clone().requires_grad_(True)
+            graphed = torch.cuda.make_graphed_callables(Step(), (xg,), num_warmup_iters=3)
+
+            def replay():
+                self.pooler.zero_grad(set_to_none=True)
+                xg.grad = None
+                graphed(xg).backward()
+
+            r["hip_graph_replay_ms"] = round(event_time_ms(replay, 50, dev), 5)
+        except Exception as exc:
+            r["hip_graph_replay_ms"] = None
+            r["hip_graph_error"] = f"{type(exc).__name__}: {str(exc)[:120]}"
         return r
 
 

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10005 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10006 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -395,6 +395,12 @@ int tgp_block_diag_fill(const float* adj_pool, int64_t B, int64_t K, const int64
  *      graphs itself (pass max_graph_nodes = min(longest graph, tgp_ndp_max_graph_nodes()));
  *      *d_status: 0 ok, bit 1 = an entry that couples two graphs.
  * ---------------------------------------------------------------------------------- */
+/* The symmetrisation in front of it (ndp_select.py:198-202: duplicates summed, self loops dropped, max with the
+ * transpose) when the list already is row-major sorted, duplicate-free, loop-free and pattern-symmetric: w_out[e] =
+ * max(w[e], w[reverse of e]) and *d_flag = 0; any violation (checked per entry; `indptr` = tgp_rowptr_from_sorted_i64 of
+ * `row`) sets *d_flag = 1 and the caller takes the general coalesce route. */
+int tgp_ndp_symmetric_max_f32(const int64_t* row, const int64_t* col, const float* w /* NULL = ones */, int64_t E,
+                              int64_t num_nodes, const int32_t* indptr, float* w_out, int* d_flag, void* stream);
 int tgp_ndp_max_graph_nodes(void);
 int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, const float* w /* NULL ok */, int64_t num_nodes,
                       int64_t nnz, const int64_t* graph_ptr, int64_t num_graphs, int64_t max_graph_nodes,

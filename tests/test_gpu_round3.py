@@ -732,3 +732,74 @@ def test_dense_pooler_training_step_uses_the_fused_backward(dev, alias, monkeypa
     torch.testing.assert_close(fused[1], plain[1], rtol=2e-3, atol=2e-4 * max(plain[1].abs().max().item(), 1.0))
     for a, b in zip(fused[2], plain[2]):
         torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-4 * max(b.abs().max().item(), 1.0))
+
+
+# ----------------------------------------------------------------------------- NDPSelect: the list that needs no symmetrising
+@pytest.mark.gpu
+def test_ndp_symmetric_max_recognises_a_clean_list_and_refuses_the_rest(dev):
+    """tgp_ndp_symmetric_max_f32: flag 0 and w = max(w, w_reverse) for a sorted, duplicate-free, loop-free, symmetric
+    list; flag 1 for an unsorted list, a duplicate, a self loop, a missing reverse entry, an id out of range."""
+    from tgp import kernels as K_
+    g = torch.Generator().manual_seed(11)
+    n = 500
+    src = torch.randint(0, n, (3000,), generator=g)
+    dst = torch.randint(0, n, (3000,), generator=g)
+    keep = src != dst
+    key = torch.unique(torch.cat([src[keep] * n + dst[keep], dst[keep] * n + src[keep]]))
+    ei = torch.stack([key // n, key % n]).to(dev)
+    w = torch.rand(ei.size(1), generator=g).to(dev)
+
+    def run(e, ww):
+        indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        K_.rowptr_from_sorted(e[0], n, indptr)
+        out, flag = K_.ndp_symmetric_max(e, ww, n, indptr)
+        return out, int(flag.item())
+
+    out, flag = run(ei, w)
+    assert flag == 0
+    dense = torch.zeros(n, n, device=dev)
+    dense[ei[0], ei[1]] = w
+    torch.testing.assert_close(out, torch.maximum(dense, dense.t())[ei[0], ei[1]], rtol=0, atol=0)
+    out1, flag1 = run(ei, None)
+    assert flag1 == 0 and bool((out1 == 1).all())
+    perm = torch.randperm(ei.size(1), generator=g).to(dev)
+    assert run(ei[:, perm], w[perm])[1] == 1                                     # unsorted
+    assert run(torch.cat([ei[:, :1], ei], 1), torch.cat([w[:1], w]))[1] == 1      # a duplicate
+    loop = torch.tensor([[0], [0]], device=dev)
+    assert run(torch.cat([loop, ei[:, ei[0] > 0]], 1), torch.cat([w[:1], w[ei[0] > 0]]))[1] == 1   # a self loop
+    drop = torch.ones(ei.size(1), dtype=torch.bool, device=dev)
+    drop[7] = False
+    assert run(ei[:, drop], w[drop])[1] == 1                                     # reverse entry missing
+    bad = ei.clone()
+    bad[1, -1] = n + 3
+    assert run(bad, w)[1] == 1                                                   # id out of range
+
+
+@pytest.mark.gpu
+def test_ndp_select_fast_and_general_preparation_agree(dev, monkeypatch):
+    """NDPSelect on a batch of undirected graphs: the recognised-clean-list route and the two-coalesce route give the
+    same SelectOutput (same kept nodes, same device adjacency for KronConnect)."""
+    from tgp import kernels as K_
+    from tgp.select import NDPSelect
+    g = torch.Generator().manual_seed(4)
+    sizes = torch.randint(10, 50, (40,), generator=g)
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(40), sizes)
+    start = torch.cumsum(sizes, 0) - sizes
+    src = torch.arange(n).repeat_interleave(2)
+    dst = start[batch[src]] + (torch.rand(src.numel(), generator=g) * sizes[batch[src]]).long()
+    keep = src != dst
+    key = torch.unique(torch.cat([src[keep] * n + dst[keep], dst[keep] * n + src[keep]]))
+    ei = torch.stack([key // n, key % n]).to(dev)
+    w = torch.rand(ei.size(1), generator=g).to(dev)
+    batch = batch.to(dev)
+    sel = NDPSelect()
+    torch.manual_seed(1)
+    fast = sel(edge_index=ei, edge_weight=w, batch=batch, num_nodes=n)
+    real = K_.ndp_symmetric_max
+    monkeypatch.setattr(K_, "ndp_symmetric_max", lambda *a, **k: (real(*a, **k)[0], torch.ones(1, dtype=torch.int32, device=dev)))
+    torch.manual_seed(1)
+    general = sel(edge_index=ei, edge_weight=w, batch=batch, num_nodes=n)
+    assert torch.equal(fast.node_index, general.node_index)
+    for a, b in zip(fast._adj_device_csr, general._adj_device_csr):
+        assert torch.equal(a, b)

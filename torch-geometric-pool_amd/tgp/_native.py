@@ -116,6 +116,7 @@ SIGNATURES = {
     "tgp_block_diag_count": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_f, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_block_diag_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_f, _c_p, _c_i64, _c_p, _c_p, _c_p,
                                      _c_p]),
+    "tgp_ndp_symmetric_max_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p]),
     "tgp_ndp_max_graph_nodes": (_c_int, []),
     "tgp_ndp_partition": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, ctypes.c_uint64, _c_int,
                                    ctypes.c_double, _c_p, _c_p, _c_p, _c_p]),

@@ -830,6 +830,20 @@ def ndp_max_graph_nodes() -> int:
     return int(N.lib().tgp_ndp_max_graph_nodes())
 
 
+def ndp_symmetric_max(edge_index: Tensor, weight: Optional[Tensor], num_nodes: int, indptr: Tensor):
+    """(w_max [E], flag [1] int32): for a list that already is row-major sorted, duplicate-free, loop-free and
+    pattern-symmetric, the weights NDPSelect's symmetrisation would produce (max with the reverse entry) and flag = 0;
+    flag = 1 when the list is anything else (ndp_select.py:198-202 then needs the general route)."""
+    dev = N.require_device(edge_index, weight, indptr)
+    row, col = _edge_rows(edge_index)
+    w = None if weight is None else N.f32c(weight.reshape(-1))
+    out = torch.empty(row.numel(), dtype=torch.float32, device=dev)
+    flag = torch.empty(1, dtype=torch.int32, device=dev)
+    N.check(N.lib().tgp_ndp_symmetric_max_f32(N.ptr(row), N.ptr(col), N.ptr(w), row.numel(), num_nodes, N.ptr(indptr),
+                                              N.ptr(out), N.ptr(flag), N.stream_ptr(dev)), "tgp_ndp_symmetric_max_f32")
+    return out, flag
+
+
 def ndp_partition(indptr: Tensor, col: Tensor, weight: Optional[Tensor], num_nodes: int, graph_ptr: Tensor,
                   max_graph_nodes: int, seed: int, max_iter: int = 500, tol: float = 1e-6, raw_keep: bool = False):
     """(keep [N] bool, info [B] int32, status int): NDPSelect's per-graph spectral +-1 partition

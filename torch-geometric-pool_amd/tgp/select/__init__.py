@@ -818,11 +818,20 @@ class NDPSelect(Select):
         w0 = torch.ones(edge_index.size(1), device=dev) if edge_weight is None else edge_weight.detach().reshape(-1).float()
         # self loops out, duplicates summed (get_laplacian + COO -> CSR), then max with the transpose
         # (to_undirected(reduce="max"), ndp_select.py:198-202): a row-sorted, symmetric, coalesced list
-        ei1, w1 = K.coalesce_edges(edge_index, w0, ident, n, "sum", remove_self_loops=True, eps_filter=False)
-        ei2, w2 = K.coalesce_edges(torch.cat([ei1, ei1.flip(0)], 1), torch.cat([w1, w1]), ident, n, "max",
-                                   remove_self_loops=False, eps_filter=False)
+        # A list that already is that (the usual PyG dataset of undirected graphs) is recognised by one kernel and used
+        # as it is (r3: the two coalesce calls were two dozen launches and two host read-backs of the NDP forward).
         indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
-        K.rowptr_from_sorted(ei2[0], n, indptr)
+        ei2 = None
+        if edge_index.size(1) > 0:
+            K.rowptr_from_sorted(edge_index[0], n, indptr)
+            w_sym, flag = K.ndp_symmetric_max(edge_index, None if edge_weight is None else w0, n, indptr)
+            if int(flag.item()) == 0:
+                ei2, w2 = edge_index, w_sym
+        if ei2 is None:
+            ei1, w1 = K.coalesce_edges(edge_index, w0, ident, n, "sum", remove_self_loops=True, eps_filter=False)
+            ei2, w2 = K.coalesce_edges(torch.cat([ei1, ei1.flip(0)], 1), torch.cat([w1, w1]), ident, n, "max",
+                                       remove_self_loops=False, eps_filter=False)
+            K.rowptr_from_sorted(ei2[0], n, indptr)
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         keep8, part_info, status = K.ndp_partition(indptr, ei2[1], w2, n, ptr, min(max_nodes, limit), seed,
                                                    raw_keep=True)
