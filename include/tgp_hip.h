@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10006 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10007 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -327,6 +327,9 @@ int tgp_link_loss_f32(const float* S, const float* A, int64_t B, int64_t N, int6
                       size_t ws_bytes, void* stream);
 size_t tgp_entropy_sum_workspace_bytes(int64_t n);
 int tgp_entropy_sum_f32(const float* S, int64_t n, float eps, float* out, void* ws, size_t ws_bytes, void* stream);
+/* Backward of that sum (utils/losses.py:476-483 under autograd): out[i] = -(log(S[i] + eps) + S[i] / (S[i] + eps)) *
+ * g[0] * scale, g a device scalar (the upstream gradient), one elementwise pass. */
+int tgp_entropy_bwd_f32(const float* S, int64_t n, float eps, const float* g, float scale, float* out, void* stream);
 /* DiffPool's losses (poolers/diffpool.py:262-284) from the native partial results in one launch:
  * out2[0] = sqrt(sum_b sq[b]) * link_scale (sq from tgp_link_loss_f32), out2[1] = (sum of ent_partial) * ent_scale
  * (ent_partial from tgp_entropy_partials_f32: *n_partial_out block sums of -S log(S + eps) in `ws`). */
@@ -351,6 +354,10 @@ int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, const float* w,
 size_t tgp_postprocess_dense_workspace_bytes(int64_t B, int64_t K);
 int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K, int flags, float eps, void* ws,
                               size_t ws_bytes, void* stream);
+/* Its backward (what autograd derives from utils/ops.py:282-335): g_raw [B,K,K] from the raw S^T A S and the upstream
+ * gradient of the post-processed tensor; one launch, K <= 4096, TGP_EDGE_WEIGHT_NORM refused (not differentiated here). */
+int tgp_postprocess_dense_bwd_f32(const float* raw, const float* g_post, int64_t B, int64_t K, int flags, float eps,
+                                  float* g_raw, void* stream);
 
 /* A11  DenseSRCPooling.preprocessing (src.py:374-452 -> PyG to_dense_adj / to_dense_batch): the step
  * right before the timed path.  batch must be sorted; ptr[B+1] = exclusive prefix of the graph sizes.

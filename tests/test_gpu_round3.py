@@ -803,3 +803,46 @@ def test_ndp_select_fast_and_general_preparation_agree(dev, monkeypatch):
     assert torch.equal(fast.node_index, general.node_index)
     for a, b in zip(fast._adj_device_csr, general._adj_device_csr):
         assert torch.equal(a, b)
+
+
+# ----------------------------------------------------------------------------- native backwards of A8 and the entropy loss
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [7, 20, 128, 200, 513])
+@pytest.mark.parametrize("rsl,dn,at", [(True, True, True), (True, True, False), (False, True, True),
+                                       (False, True, False), (True, False, False)])
+def test_postprocess_dense_backward_kernel_vs_autograd(dev, K, rsl, dn, at):
+    """tgp_postprocess_dense_bwd_f32 against torch autograd of the elementwise form (utils/ops.py:282-335), including
+    rows whose degree sum is below eps (the clamp blocks their gradient) and negative sums."""
+    from tgp.utils import ops
+    g = torch.Generator().manual_seed(K)
+    B = 5
+    raw = torch.rand(B, K, K, generator=g)
+    raw[1] *= 0.0                       # a graph of all-zero sums
+    raw[2, 0] = -raw[2, 0]              # a negative row
+    raw[3, :, 1] = 0.0
+    raw[3, 1, :] = 0.0                  # one isolated index
+    w = torch.randn(B, K, K, generator=g).to(dev)
+    r64 = raw.to(dev).double().requires_grad_(True)
+    ref = ops._postprocess_dense_autograd(r64, rsl, dn, at, False)
+    (ref * w.double()).sum().backward()
+    r32 = raw.to(dev).requires_grad_(True)
+    out = ops.postprocess_adj_pool_dense(r32, rsl, dn, at, False)
+    torch.testing.assert_close(out, ref.float(), rtol=1e-5, atol=1e-5)
+    (out * w).sum().backward()
+    torch.testing.assert_close(r32.grad, r64.grad.float(), rtol=2e-4, atol=2e-5 * max(r64.grad.abs().max().item(), 1.0))
+
+
+@pytest.mark.gpu
+def test_entropy_loss_backward_kernel_vs_autograd(dev):
+    from tgp.utils import losses
+    g = torch.Generator().manual_seed(2)
+    S = torch.softmax(torch.randn(6, 50, 9, generator=g), -1)
+    S[0, 40:] = 0.0                      # padded rows
+    s64 = S.to(dev).double().requires_grad_(True)
+    ref = (-(s64 * torch.log(s64 + float(losses.eps))).sum()) / 123 * 0.7
+    ref.backward()
+    s32 = S.to(dev).requires_grad_(True)
+    out = losses.entropy_loss(s32, 123) * 0.7
+    out.backward()
+    torch.testing.assert_close(out, ref.float(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(s32.grad, s64.grad.float(), rtol=1e-5, atol=1e-6)

@@ -258,6 +258,102 @@ extern "C" size_t tgp_postprocess_dense_workspace_bytes(int64_t B, int64_t K) {
   return align_up(post_ws_floats(B, K) * 4) + 256;
 }
 
+// Backward of the post-processing (utils/ops.py:282-335 under autograd), one workgroup per graph, any K up to 4096:
+//   R1 = R (1 - I);  c = sum_axis(R1);  d = sqrt(max(c, eps));  P_ij = (R1_ij / first) / second
+//   gR_ij = G_ij / (d_i d_j) + gc_[axis index],  gc_t = -[c_t >= eps] (rowsum_t(G P) + colsum_t(G P)) / (2 d_t^2)
+// and the diagonal of gR cleared when the self loops were.  Three sweeps over the graph's K x K pair (L2-resident), the
+// per-index vectors in LDS.  As torch ops this was ~20 launches of a few KB each per training step.
+namespace tgp {
+__global__ __launch_bounds__(256) void post_bwd_kernel(const float* __restrict__ R, const float* __restrict__ G, int K,
+                                                       int flags, float eps, float* __restrict__ out) {
+  extern __shared__ float sm[];
+  float* s_d = sm;
+  float* s_gs = sm + K;
+  float* s_rowq = sm + 2 * K;
+  float* s_colq = sm + 3 * K;
+  const long off = static_cast<long>(blockIdx.x) * K * K;
+  const float* Rb = R + off;
+  const float* Gb = G + off;
+  float* ob = out + off;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool rsl = flags & TGP_REMOVE_SELF_LOOPS, dn = flags & TGP_DEGREE_NORM, cols = flags & TGP_SUM_AXIS_ROWS;
+  if (!dn) {
+    for (long e = tid; e < static_cast<long>(K) * K; e += 256) {
+      const int i = static_cast<int>(e / K), j = static_cast<int>(e - static_cast<long>(i) * K);
+      ob[e] = (rsl && i == j) ? 0.f : Gb[e];
+    }
+    return;
+  }
+  if (!cols) {  // c_i = sum_j R1_ij: a wave per row
+    for (int i = wave; i < K; i += 4) {
+      float acc = 0.f;
+      for (int j = lane; j < K; j += 64) acc += (rsl && i == j) ? 0.f : Rb[static_cast<long>(i) * K + j];
+#pragma unroll
+      for (int dd = 32; dd > 0; dd >>= 1) acc += __shfl_xor(acc, dd, WAVE);
+      if (lane == 0) s_d[i] = acc;
+    }
+  } else {      // c_j = sum_i R1_ij: a thread per column
+    for (int j = tid; j < K; j += 256) {
+      float acc = 0.f;
+      for (int i = 0; i < K; ++i) acc += (rsl && i == j) ? 0.f : Rb[static_cast<long>(i) * K + j];
+      s_d[j] = acc;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < K; t += 256) {
+    const float c = s_d[t];
+    s_gs[t] = c >= eps ? 1.f : 0.f;  // clamp(min = eps) passes the gradient where c >= eps
+    s_d[t] = sqrtf(fmaxf(c, eps));
+  }
+  __syncthreads();
+  auto pval = [&](int i, int j) -> float {  // the forward's P_ij, same arithmetic
+    const float r1 = (rsl && i == j) ? 0.f : Rb[static_cast<long>(i) * K + j];
+    const float di = s_d[i], dj = s_d[j];
+    return cols ? (r1 / dj) / di : (r1 / di) / dj;
+  };
+  for (int i = wave; i < K; i += 4) {  // rowsum_i(G P)
+    float acc = 0.f;
+    for (int j = lane; j < K; j += 64) acc += Gb[static_cast<long>(i) * K + j] * pval(i, j);
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) acc += __shfl_xor(acc, dd, WAVE);
+    if (lane == 0) s_rowq[i] = acc;
+  }
+  for (int j = tid; j < K; j += 256) {  // colsum_j(G P)
+    float acc = 0.f;
+    for (int i = 0; i < K; ++i) acc += Gb[static_cast<long>(i) * K + j] * pval(i, j);
+    s_colq[j] = acc;
+  }
+  __syncthreads();
+  for (int t = tid; t < K; t += 256) {
+    const float d = s_d[t];
+    s_gs[t] = s_gs[t] != 0.f ? -(s_rowq[t] + s_colq[t]) / (2.0f * d * d) : 0.f;
+  }
+  __syncthreads();
+  for (long e = tid; e < static_cast<long>(K) * K; e += 256) {
+    const int i = static_cast<int>(e / K), j = static_cast<int>(e - static_cast<long>(i) * K);
+    const float v = Gb[e] * (1.0f / (s_d[i] * s_d[j])) + (cols ? s_gs[j] : s_gs[i]);
+    ob[e] = (rsl && i == j) ? 0.f : v;
+  }
+}
+}  // namespace tgp
+
+extern "C" int tgp_postprocess_dense_bwd_f32(const float* raw, const float* g_post, int64_t B, int64_t K, int flags,
+                                             float eps, float* g_raw, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_postprocess_dense_bwd_f32: negative size");
+  if (B == 0 || K == 0) return TGP_OK;
+  TGP_REQUIRE(raw && g_post && g_raw, TGP_ERR_INVALID, "tgp_postprocess_dense_bwd_f32: null pointer");
+  TGP_REQUIRE(!(flags & TGP_EDGE_WEIGHT_NORM), TGP_ERR_INVALID,
+              "tgp_postprocess_dense_bwd_f32: edge_weight_norm is not differentiated by this entry");
+  TGP_REQUIRE(K <= 4096 && B < (1ll << 31), TGP_ERR_RANGE, "tgp_postprocess_dense_bwd_f32: K > 4096");
+  const size_t lds = static_cast<size_t>(4 * K) * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(post_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds));
+  hipLaunchKernelGGL(post_bwd_kernel, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, raw, g_post,
+                     static_cast<int>(K), flags, eps, g_raw);
+  return check_launch("tgp_postprocess_dense_bwd_f32");
+}
+
 extern "C" int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K, int flags, float eps, void* ws,
                                          size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);

@@ -203,6 +203,34 @@ extern "C" size_t tgp_entropy_sum_workspace_bytes(int64_t n) {
   return RED_BLOCKS * sizeof(float);
 }
 
+// d/dS of sum(-S log(S + eps)), times the upstream gradient (a device scalar) and a host scale: one elementwise pass
+// (utils/losses.py:476-483 under autograd: log, add, div, add, neg, mul as six launches)
+namespace tgp {
+__global__ __launch_bounds__(256) void entropy_bwd_kernel(const float* __restrict__ S, int64_t n, float eps,
+                                                          const float* __restrict__ g, float scale,
+                                                          float* __restrict__ out) {
+  const float gs = g[0] * scale;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    const float s = S[i];
+    out[i] = -(logf(s + eps) + s / (s + eps)) * gs;
+  }
+}
+}  // namespace tgp
+
+extern "C" int tgp_entropy_bwd_f32(const float* S, int64_t n, float eps, const float* g, float scale, float* out,
+                                   void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(n >= 0, TGP_ERR_INVALID, "tgp_entropy_bwd_f32: negative size");
+  if (n == 0) return TGP_OK;
+  TGP_REQUIRE(S && g && out, TGP_ERR_INVALID, "tgp_entropy_bwd_f32: null pointer");
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(entropy_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, S, n, eps, g, scale,
+                     out);
+  return check_launch("tgp_entropy_bwd_f32");
+}
+
 extern "C" int tgp_entropy_sum_f32(const float* S, int64_t n, float eps, float* out, void* ws, size_t ws_bytes,
                                    void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);

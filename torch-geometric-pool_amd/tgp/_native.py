@@ -75,6 +75,7 @@ SIGNATURES = {
     "tgp_dense_pool_small_bwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_f, _c_f, _c_p,
                                               _c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_p, _c_p, _c_p]),
     "tgp_postprocess_dense_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
+    "tgp_postprocess_dense_bwd_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_p]),
     "tgp_postprocess_dense_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_sz, _c_p]),
     "tgp_bmm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_i64,
                              _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
@@ -100,6 +101,7 @@ SIGNATURES = {
     "tgp_link_loss_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tgp_link_loss_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_sz, _c_p]),
     "tgp_entropy_sum_workspace_bytes": (_c_sz, [_c_i64]),
+    "tgp_entropy_bwd_f32": (_c_int, [_c_p, _c_i64, _c_f, _c_p, _c_f, _c_p, _c_p]),
     "tgp_entropy_sum_f32": (_c_int, [_c_p, _c_i64, _c_f, _c_p, _c_p, _c_sz, _c_p]),
     "tgp_cut_terms_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "tgp_mincut_loss_terms_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_f, _c_p, _c_p]),

@@ -443,6 +443,30 @@ def postprocess_dense(adj_pool: Tensor, flags: int, inplace: bool = False) -> Te
     return dst
 
 
+def postprocess_dense_bwd(raw: Tensor, g_post: Tensor, flags: int) -> Optional[Tensor]:
+    """Gradient of :func:`postprocess_dense` with respect to its input (utils/ops.py:282-335 under autograd), one
+    launch; None when the kernel does not take the case (K > 4096)."""
+    dev = N.require_device(raw, g_post)
+    raw, g_post = N.f32c(raw), N.f32c(g_post)
+    B, K = raw.size(0), raw.size(1)
+    if K > 4096 or tuple(g_post.shape) != tuple(raw.shape):
+        return None
+    out = torch.empty_like(raw)
+    N.check(N.lib().tgp_postprocess_dense_bwd_f32(N.ptr(raw), N.ptr(g_post), B, K, flags, ops_eps(), N.ptr(out),
+                                                  N.stream_ptr(dev)), "tgp_postprocess_dense_bwd_f32")
+    return out
+
+
+def entropy_bwd(s: Tensor, g: Tensor, scale: float = 1.0) -> Tensor:
+    """-(log(s + eps) + s / (s + eps)) * g * scale, g a 0-d device tensor (utils/losses.py:476-483 under autograd)."""
+    dev = N.require_device(s, g)
+    s32 = N.f32c(s)
+    out = torch.empty_like(s32)
+    N.check(N.lib().tgp_entropy_bwd_f32(N.ptr(s32), s32.numel(), losses_eps(), N.ptr(N.f32c(g.reshape(1))), float(scale),
+                                        N.ptr(out), N.stream_ptr(dev)), "tgp_entropy_bwd_f32")
+    return out
+
+
 def _sizes_arg(graph_sizes: Optional[Tensor], num_graphs: int, dev) -> Optional[Tensor]:
     if graph_sizes is None:
         return None

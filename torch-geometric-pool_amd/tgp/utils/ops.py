@@ -331,6 +331,9 @@ class _PostprocessDenseFn(torch.autograd.Function):
     def backward(ctx, g):
         a, out = ctx.saved_tensors
         rsl, dn, at = ctx.cfg
+        native = K.postprocess_dense_bwd(a, g, K.dense_flags(rsl, dn, at, False))  # one launch (K <= 4096)
+        if native is not None:
+            return native, None, None, None
         k = a.size(-1)
         keep = None
         if rsl:
