@@ -264,6 +264,10 @@ extern "C" size_t tgp_postprocess_dense_workspace_bytes(int64_t B, int64_t K) {
 // and the diagonal of gR cleared when the self loops were.  Three sweeps over the graph's K x K pair (L2-resident), the
 // per-index vectors in LDS.  As torch ops this was ~20 launches of a few KB each per training step.
 namespace tgp {
+// IN_LDS: the graph's R1 and G tiles are staged in LDS first ([K][K + 1] each: K <= 128) -- every sweep below is then
+// LDS-local; from global memory (L2-resident, but ~0.6 us per dependent access) the serial column sweeps of one workgroup
+// per graph took 98 us at B = 32, K = 128.
+template <bool IN_LDS>
 __global__ __launch_bounds__(256) void post_bwd_kernel(const float* __restrict__ R, const float* __restrict__ G, int K,
                                                        int flags, float eps, float* __restrict__ out) {
   extern __shared__ float sm[];
@@ -271,6 +275,9 @@ __global__ __launch_bounds__(256) void post_bwd_kernel(const float* __restrict__
   float* s_gs = sm + K;
   float* s_rowq = sm + 2 * K;
   float* s_colq = sm + 3 * K;
+  float* sR = sm + 4 * K;
+  float* sG = sR + (IN_LDS ? K * (K + 1) : 0);
+  const int ld = IN_LDS ? K + 1 : K;
   const long off = static_cast<long>(blockIdx.x) * K * K;
   const float* Rb = R + off;
   const float* Gb = G + off;
@@ -284,10 +291,26 @@ __global__ __launch_bounds__(256) void post_bwd_kernel(const float* __restrict__
     }
     return;
   }
+  if constexpr (IN_LDS) {
+    for (int i = wave; i < K; i += 4)
+      for (int j = lane; j < K; j += 64) {
+        sR[i * ld + j] = (rsl && i == j) ? 0.f : Rb[static_cast<long>(i) * K + j];
+        sG[i * ld + j] = Gb[static_cast<long>(i) * K + j];
+      }
+    __syncthreads();
+  }
+  auto r1 = [&](int i, int j) -> float {
+    if constexpr (IN_LDS) return sR[i * ld + j];
+    return (rsl && i == j) ? 0.f : Rb[static_cast<long>(i) * K + j];
+  };
+  auto gv = [&](int i, int j) -> float {
+    if constexpr (IN_LDS) return sG[i * ld + j];
+    return Gb[static_cast<long>(i) * K + j];
+  };
   if (!cols) {  // c_i = sum_j R1_ij: a wave per row
     for (int i = wave; i < K; i += 4) {
       float acc = 0.f;
-      for (int j = lane; j < K; j += 64) acc += (rsl && i == j) ? 0.f : Rb[static_cast<long>(i) * K + j];
+      for (int j = lane; j < K; j += 64) acc += r1(i, j);
 #pragma unroll
       for (int dd = 32; dd > 0; dd >>= 1) acc += __shfl_xor(acc, dd, WAVE);
       if (lane == 0) s_d[i] = acc;
@@ -295,7 +318,8 @@ __global__ __launch_bounds__(256) void post_bwd_kernel(const float* __restrict__
   } else {      // c_j = sum_i R1_ij: a thread per column
     for (int j = tid; j < K; j += 256) {
       float acc = 0.f;
-      for (int i = 0; i < K; ++i) acc += (rsl && i == j) ? 0.f : Rb[static_cast<long>(i) * K + j];
+#pragma unroll 8
+      for (int i = 0; i < K; ++i) acc += r1(i, j);
       s_d[j] = acc;
     }
   }
@@ -307,20 +331,20 @@ __global__ __launch_bounds__(256) void post_bwd_kernel(const float* __restrict__
   }
   __syncthreads();
   auto pval = [&](int i, int j) -> float {  // the forward's P_ij, same arithmetic
-    const float r1 = (rsl && i == j) ? 0.f : Rb[static_cast<long>(i) * K + j];
     const float di = s_d[i], dj = s_d[j];
-    return cols ? (r1 / dj) / di : (r1 / di) / dj;
+    return cols ? (r1(i, j) / dj) / di : (r1(i, j) / di) / dj;
   };
   for (int i = wave; i < K; i += 4) {  // rowsum_i(G P)
     float acc = 0.f;
-    for (int j = lane; j < K; j += 64) acc += Gb[static_cast<long>(i) * K + j] * pval(i, j);
+    for (int j = lane; j < K; j += 64) acc += gv(i, j) * pval(i, j);
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) acc += __shfl_xor(acc, dd, WAVE);
     if (lane == 0) s_rowq[i] = acc;
   }
   for (int j = tid; j < K; j += 256) {  // colsum_j(G P)
     float acc = 0.f;
-    for (int i = 0; i < K; ++i) acc += Gb[static_cast<long>(i) * K + j] * pval(i, j);
+#pragma unroll 4
+    for (int i = 0; i < K; ++i) acc += gv(i, j) * pval(i, j);
     s_colq[j] = acc;
   }
   __syncthreads();
@@ -329,11 +353,11 @@ __global__ __launch_bounds__(256) void post_bwd_kernel(const float* __restrict__
     s_gs[t] = s_gs[t] != 0.f ? -(s_rowq[t] + s_colq[t]) / (2.0f * d * d) : 0.f;
   }
   __syncthreads();
-  for (long e = tid; e < static_cast<long>(K) * K; e += 256) {
-    const int i = static_cast<int>(e / K), j = static_cast<int>(e - static_cast<long>(i) * K);
-    const float v = Gb[e] * (1.0f / (s_d[i] * s_d[j])) + (cols ? s_gs[j] : s_gs[i]);
-    ob[e] = (rsl && i == j) ? 0.f : v;
-  }
+  for (int i = wave; i < K; i += 4)
+    for (int j = lane; j < K; j += 64) {
+      const float v = gv(i, j) * (1.0f / (s_d[i] * s_d[j])) + (cols ? s_gs[j] : s_gs[i]);
+      ob[static_cast<long>(i) * K + j] = (rsl && i == j) ? 0.f : v;
+    }
 }
 }  // namespace tgp
 
@@ -346,11 +370,19 @@ extern "C" int tgp_postprocess_dense_bwd_f32(const float* raw, const float* g_po
   TGP_REQUIRE(!(flags & TGP_EDGE_WEIGHT_NORM), TGP_ERR_INVALID,
               "tgp_postprocess_dense_bwd_f32: edge_weight_norm is not differentiated by this entry");
   TGP_REQUIRE(K <= 4096 && B < (1ll << 31), TGP_ERR_RANGE, "tgp_postprocess_dense_bwd_f32: K > 4096");
-  const size_t lds = static_cast<size_t>(4 * K) * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(post_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(lds));
-  hipLaunchKernelGGL(post_bwd_kernel, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, raw, g_post,
-                     static_cast<int>(K), flags, eps, g_raw);
+  if (K <= 128) {
+    const size_t lds = (static_cast<size_t>(4 * K) + 2 * static_cast<size_t>(K) * (K + 1)) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(post_bwd_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL(post_bwd_kernel<true>, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, raw, g_post,
+                       static_cast<int>(K), flags, eps, g_raw);
+  } else {
+    const size_t lds = static_cast<size_t>(4 * K) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(post_bwd_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL(post_bwd_kernel<false>, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, raw, g_post,
+                       static_cast<int>(K), flags, eps, g_raw);
+  }
   return check_launch("tgp_postprocess_dense_bwd_f32");
 }
 
