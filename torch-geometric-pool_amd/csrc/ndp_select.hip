@@ -625,6 +625,7 @@ struct NlState {        // device-resident scalars of the iteration
 
 struct NlVecs {
   double *x, *ax, *pv, *ap, *wv, *aw, *raw;
+  double* ts;          // dis * raw: the vector the sparse mat-vec gathers (ONE random 8-byte read per entry, not two)
   float* dis;
   double* partial;     // [NL_BLOCKS][8]
   NlState* st;
@@ -638,6 +639,7 @@ static size_t nl_layout(void* ws, int64_t n, NlVecs* out) {
   v.partial = c.take<double>(NL_BLOCKS * 8);
   v.x = c.take<double>(m); v.ax = c.take<double>(m); v.pv = c.take<double>(m); v.ap = c.take<double>(m);
   v.wv = c.take<double>(m); v.aw = c.take<double>(m); v.raw = c.take<double>(m);
+  v.ts = c.take<double>(m);
   v.dis = c.take<float>(m);
   if (out) *out = v;
   return c.off;
@@ -761,6 +763,7 @@ __global__ __launch_bounds__(NL_THREADS) void nl_round_a_kernel(int64_t n, NlVec
     v.ax[i] = axi;
     const double r = axi - lam * xi;
     v.raw[i] = r;
+    v.ts[i] = static_cast<double>(v.dis[i]) * r;
     s[0] += r * r;
     s[1] += xi * pi;
     s[2] += r * pi;
@@ -788,8 +791,13 @@ __global__ __launch_bounds__(NL_THREADS) void nl_reduce_a_kernel(NlVecs v, doubl
 
 // w = r / |r|, aw = Ls w.  NL_G lanes share a row (rows of ~10 entries: one lane per row leaves the 64 lanes of a
 // load instruction on 64 different cache lines of col / w; with 8 lanes per row consecutive lanes read consecutive
-// entries), partial sums folded inside the lane group in a fixed order.
-constexpr int NL_G = 8;
+// entries; 16 since r3), partial sums folded inside the lane group in a fixed order.  r3: a group works on NL_U rows at once with
+// every load unconditional (clamped) and issued level by level -- row offsets, then columns, then ONE gather per entry
+// from ts = dis * r (round A writes it) instead of dis[j] and r[j]: 242 us per call at N = 1M, E = 10M before (72 % of a
+// LOBPCG step; a dependent chain of three loads per row with one row in flight per group).  Now ~120 us: 10 M random
+// 8-byte reads are 10 M L2 sectors whatever the group shape (8 x 4, 8 x 8, 16 x 4, 16 x 2 lanes x rows measured within 8 %).
+constexpr int NL_G = 16;
+constexpr int NL_U = 2;
 __global__ __launch_bounds__(NL_THREADS) void nl_matvec_kernel(const int32_t* __restrict__ indptr,
                                                                const int64_t* __restrict__ col,
                                                                const float* __restrict__ w, int64_t p0, int64_t p1,
@@ -799,23 +807,63 @@ __global__ __launch_bounds__(NL_THREADS) void nl_matvec_kernel(const int32_t* __
   const int64_t n = p1 - p0;
   const double inv_r = st->inv_r;
   const int sub = threadIdx.x % NL_G;
-  const int64_t rows_per_pass = static_cast<int64_t>(gridDim.x) * (NL_THREADS / NL_G);
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * (NL_THREADS / NL_G) + threadIdx.x / NL_G; i < n;
-       i += rows_per_pass) {
-    double acc = 0.0;
-    const int e1 = indptr[p0 + i + 1];
-    for (int e = indptr[p0 + i] + sub; e < e1; e += NL_G) {
-      const int64_t c = col[e];
-      if (c < p0 || c >= p1) { atomicOr(status, 2); continue; }
-      const int64_t j = c - p0;
-      acc += (w ? static_cast<double>(w[e]) : 1.0) * static_cast<double>(v.dis[j]) * v.raw[j];
+  const int64_t ngroups = static_cast<int64_t>(gridDim.x) * (NL_THREADS / NL_G);
+  const int e_first = indptr[p0];  // a valid entry index whenever any loop below runs
+  for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * (NL_THREADS / NL_G) + threadIdx.x / NL_G; i0 < n;
+       i0 += ngroups * NL_U) {
+    int e[NL_U], e1[NL_U];
+    double acc[NL_U];
+#pragma unroll
+    for (int u = 0; u < NL_U; ++u) {
+      const int64_t i = i0 + u * ngroups;
+      const int64_t ic = i < n ? i : n - 1;
+      const int a = indptr[p0 + ic], b = indptr[p0 + ic + 1];
+      e[u] = a + sub;
+      e1[u] = i < n ? b : a;
+      acc[u] = 0.0;
+    }
+    bool more = false;
+#pragma unroll
+    for (int u = 0; u < NL_U; ++u) more = more || e[u] < e1[u];
+    while (__any(more)) {
+      int64_t c[NL_U];
+      float ww[NL_U];
+      double g[NL_U];
+      bool ok[NL_U];
+#pragma unroll
+      for (int u = 0; u < NL_U; ++u) {
+        ok[u] = e[u] < e1[u];
+        const int idx = ok[u] ? e[u] : e_first;
+        c[u] = col[idx];
+        ww[u] = w ? w[idx] : 1.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < NL_U; ++u) {
+        const int64_t j = c[u] - p0;
+        const bool inr = static_cast<uint64_t>(j) < static_cast<uint64_t>(n);
+        if (ok[u] && !inr) atomicOr(status, 2);
+        ok[u] = ok[u] && inr;
+        g[u] = v.ts[inr ? j : 0];
+      }
+      more = false;
+#pragma unroll
+      for (int u = 0; u < NL_U; ++u) {
+        acc[u] += ok[u] ? static_cast<double>(ww[u]) * g[u] : 0.0;
+        e[u] += NL_G;
+        more = more || e[u] < e1[u];
+      }
     }
 #pragma unroll
-    for (int o = NL_G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
-    if (sub == 0) {
-      const double ri = v.raw[i];
-      v.wv[i] = ri * inv_r;
-      v.aw[i] = inv_r * (ri - static_cast<double>(v.dis[i]) * acc);
+    for (int u = 0; u < NL_U; ++u) {
+      double a = acc[u];
+#pragma unroll
+      for (int o = NL_G / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
+      const int64_t i = i0 + u * ngroups;
+      if (sub == 0 && i < n) {
+        const double ri = v.raw[i];
+        v.wv[i] = ri * inv_r;
+        v.aw[i] = inv_r * (ri - static_cast<double>(v.dis[i]) * a);
+      }
     }
   }
 }
@@ -1020,7 +1068,7 @@ __global__ __launch_bounds__(256) void ndp_symmetric_max_kernel(const int64_t* _
                                                                 const int32_t* __restrict__ indptr,
                                                                 float* __restrict__ w_out, int* __restrict__ flag) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (e >= E) return;
+  if (e >= E || *flag) return;  // (a violation found by an earlier workgroup: the caller takes the general route anyway)
   const int64_t i = row[e], j = col[e];
   bool ok = static_cast<uint64_t>(i) < static_cast<uint64_t>(n) && static_cast<uint64_t>(j) < static_cast<uint64_t>(n) &&
             i != j;
@@ -1097,7 +1145,8 @@ extern "C" int tgp_ndp_large_steps(const int32_t* indptr, const int64_t* col, co
   NlVecs v;
   nl_layout(ws, p1 - p0, &v);
   const int64_t n = p1 - p0;
-  const unsigned mv_blocks = static_cast<unsigned>(cdiv(n, NL_THREADS / NL_G) < 16384 ? cdiv(n, NL_THREADS / NL_G) : 16384);
+  const int64_t mv_rows = static_cast<int64_t>(NL_THREADS / NL_G) * NL_U;  // rows a workgroup takes per pass
+  const unsigned mv_blocks = static_cast<unsigned>(cdiv(n, mv_rows) < 16384 ? cdiv(n, mv_rows) : 16384);
   for (int s = 0; s < steps; ++s) {
     hipLaunchKernelGGL(nl_round_a_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, n, v);
     hipLaunchKernelGGL(nl_reduce_a_kernel, dim3(1), dim3(NL_THREADS), 0, stream, v, tol);
