@@ -72,6 +72,8 @@ CASES = {
     "topk_c3": ("topk", dict(in_channels=32, ratio=0.5), None, 4, 32),
     "graclus_c3": ("graclus", dict(), None, 4, 32),
     "ndp_c3": ("ndp", dict(), None, 4, 32),
+    "topk_c4": ("topk", dict(in_channels=128, ratio=0.5), [1_000_000], 10, 128),
+    "graclus_c4": ("graclus", dict(), [1_000_000], 10, 128),
 }
 
 

@@ -198,7 +198,11 @@ __device__ __forceinline__ void kron_build(const KronArgs& a, double* M, int ld,
   __syncthreads();
 }
 
-// eliminate pivots 0..m-1; returns (uniformly) whether an exactly zero pivot was met
+// eliminate pivots 0..m-1; returns (uniformly) whether an exactly zero pivot was met.  A wave takes KRON_RU rows of the
+// pivot step at once, every read issued before the first update (r3: one row at a time behind a "multiplier != 0" branch
+// made a pivot step a chain of dependent LDS round trips -- 94 us for 2048 graphs of 20..60 nodes; a zero multiplier now
+// simply subtracts a zero, which changes nothing but, at most, the sign of a zero).
+constexpr int KRON_RU = 4;
 template <int THREADS>
 __device__ __forceinline__ bool kron_eliminate(double* M, int ld, int n, int m, int* s_flag) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -210,10 +214,23 @@ __device__ __forceinline__ bool kron_eliminate(double* M, int ld, int n, int m, 
       // a zero pivot with a zero column below it contributes nothing; anything else is the singular case
     }
     const double inv = piv != 0.0 ? 1.0 / piv : 0.0;
-    for (int i = p + 1 + w; i < n; i += NW) {
-      const double cip = M[i * ld + p];
-      if (cip != 0.0) {
-        for (int j = p + 1 + lane; j < n; j += 64) M[i * ld + j] = kron_upd(M[i * ld + j], cip, M[p * ld + j], inv);
+    for (int i0 = p + 1 + w; i0 < n; i0 += NW * KRON_RU) {
+      double c[KRON_RU];
+      int row[KRON_RU];
+#pragma unroll
+      for (int t = 0; t < KRON_RU; ++t) {
+        const int i = i0 + NW * t;
+        row[t] = i < n ? i : p;  // (a row past the end re-reads the pivot row with a zero multiplier and is not stored)
+        c[t] = i < n ? M[i * ld + p] : 0.0;
+      }
+      for (int j = p + 1 + lane; j < n; j += 64) {
+        const double up = M[p * ld + j];
+        double v[KRON_RU];
+#pragma unroll
+        for (int t = 0; t < KRON_RU; ++t) v[t] = M[row[t] * ld + j];
+#pragma unroll
+        for (int t = 0; t < KRON_RU; ++t)
+          if (i0 + NW * t < n) M[row[t] * ld + j] = kron_upd(v[t], c[t], up, inv);
       }
     }
     __syncthreads();
