@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10007 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10008 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -343,6 +343,12 @@ int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int64_t N, int6
  * out[1,b] = || G_b / ||G_b||_F - I / sqrt(K) ||_F (utils/losses.py:59-70); raw, gram [B,K,K], den [B], out [2,B]. */
 int tgp_mincut_loss_terms_f32(const float* raw, const float* den, const float* gram, int64_t B, int64_t K, float eps,
                               float* out, void* stream);
+/* Backward of those two tails in one launch: from the upstream gradients g_terms [2,B] it writes g_raw [B,K,K] (the
+ * gradient with respect to raw: -(g_cut / (den + eps)) on the diagonal), c1 [B] (the gradient with respect to den:
+ * g_cut trace(raw) / (den + eps)^2; d den / dS = 2 D S) and W [B,K,K] (the gradient with respect to gram = S^T S;
+ * dS = S (W + W^T)). */
+int tgp_mincut_loss_terms_bwd_f32(const float* raw, const float* den, const float* gram, const float* g_terms, int64_t B,
+                                  int64_t K, float eps, float* g_raw, float* c1, float* W, void* stream);
 
 /* A7'  sparse A times dense S (connect/dense_conn.py:165,204: torch.sparse.mm), A in CSR built from a
  * row-sorted coalesced edge list: T[i,:] = sum_{e in row i} w[e] * S[col[e],:].  w may be NULL. */

@@ -846,3 +846,33 @@ def test_entropy_loss_backward_kernel_vs_autograd(dev):
     out.backward()
     torch.testing.assert_close(out, ref.float(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(s32.grad, s64.grad.float(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,K", [(6, 150, 12), (32, 300, 128), (3, 90, 33)])
+def test_mincut_terms_function_vs_autograd(dev, B, N, K):
+    """_MinCutTermsFn (three forward kernels, one native backward tail) against fp64 autograd of utils/losses.py:39-70:
+    values, and gradients with respect to S and to the raw S^T A S."""
+    from tgp.utils import losses
+    g = torch.Generator().manual_seed(B * 7 + K)
+    A = (torch.rand(B, N, N, generator=g) < 0.1).float()
+    A = torch.maximum(A, A.transpose(1, 2)).to(dev)
+    S0 = torch.softmax(torch.randn(B, N, K, generator=g), -1).to(dev)
+    wt = torch.randn(2, B, generator=g).to(dev)
+    s64 = S0.double().requires_grad_(True)
+    raw64 = (s64.transpose(1, 2) @ A.double() @ s64).detach().requires_grad_(True)
+    num = torch.einsum("bii->b", raw64)
+    den = torch.einsum("bnk,bn,bnk->b", s64, A.double().sum(-1), s64)
+    cut = -(num / (den + float(losses.eps)))
+    sts = s64.transpose(1, 2) @ s64
+    sts = sts / torch.norm(sts, dim=(-2, -1), keepdim=True)
+    ortho = torch.norm(sts - torch.eye(K, device=dev, dtype=torch.float64) / K ** 0.5, dim=(-2, -1))
+    ref = torch.stack([cut, ortho])
+    (ref * wt.double()).sum().backward()
+    s32 = S0.clone().requires_grad_(True)
+    raw32 = raw64.detach().float().requires_grad_(True)
+    got = losses._MinCutTermsFn.apply(A, s32, raw32, None)
+    torch.testing.assert_close(got, ref.float(), rtol=1e-5, atol=1e-6)
+    (got * wt).sum().backward()
+    torch.testing.assert_close(s32.grad, s64.grad.float(), rtol=2e-4, atol=2e-5 * max(s64.grad.abs().max().item(), 1.0))
+    torch.testing.assert_close(raw32.grad, raw64.grad.float(), rtol=1e-5, atol=1e-7)

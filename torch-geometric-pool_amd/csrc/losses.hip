@@ -127,6 +127,49 @@ __global__ __launch_bounds__(256) void mincut_tail_kernel(const float* __restric
   }
 }
 
+// Backward of those two tails, one launch (what autograd derives from utils/losses.py:39-70 behind S^T A S, trace(S^T D S)
+// and S^T S: ~25 launches of a few hundred bytes each).  Given the upstream gradients g[0,b], g[1,b] of the two terms:
+//   g_raw[b] = -(g_cut / (den + eps)) I                    (gradient with respect to raw = S^T A S)
+//   c1[b]    = g_cut * trace(raw) / (den + eps)^2          (gradient with respect to den; dden/dS = 2 D S)
+//   W[b]     = d ortho / d G = g_ortho / (|Y| |G|) (Y - G <G,Y> / |G|^2),  Y = G / |G| - I / sqrt(K)   (dS = S (W + W^T))
+__global__ __launch_bounds__(256) void mincut_tail_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ den,
+                                                              const float* __restrict__ gram, const float* __restrict__ g,
+                                                              int K, float eps, int B, float* __restrict__ g_raw,
+                                                              float* __restrict__ c1, float* __restrict__ W) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  const int64_t off = static_cast<int64_t>(b) * K * K;
+  const float* R = raw + off;
+  const float* G = gram + off;
+  float tr = 0.f, sq = 0.f;
+  for (int i = threadIdx.x; i < K; i += 256) tr += R[static_cast<int64_t>(i) * K + i];
+  for (int i = threadIdx.x; i < K * K; i += 256) sq = fmaf(G[i], G[i], sq);
+  tr = block_sum_256(tr, sh);
+  sq = block_sum_256(sq, sh);
+  const float n = sqrtf(sq);
+  const float t = 1.0f / sqrtf(static_cast<float>(K));
+  float ny2 = 0.f, gy = 0.f;
+  for (int i = threadIdx.x; i < K * K; i += 256) {
+    const float y = G[i] / n - ((i / K == i % K) ? t : 0.f);
+    ny2 = fmaf(y, y, ny2);
+    gy = fmaf(G[i], y, gy);
+  }
+  ny2 = block_sum_256(ny2, sh);
+  gy = block_sum_256(gy, sh);
+  const float ny = sqrtf(ny2);
+  const float g_cut = g[b], g_ortho = g[B + b];
+  const float dd = den[b] + eps;
+  const float cdiag = -g_cut / dd;
+  const float coef = ny > 0.f ? g_ortho / (ny * n) : 0.f;
+  for (int i = threadIdx.x; i < K * K; i += 256) {
+    const bool diag = i / K == i % K;
+    const float y = G[i] / n - (diag ? t : 0.f);
+    W[off + i] = coef * (y - G[i] * (gy / sq));
+    g_raw[off + i] = diag ? cdiag : 0.f;
+  }
+  if (threadIdx.x == 0) c1[b] = g_cut * tr / (dd * dd);
+}
+
 // DiffPool's two losses from their native partial results in ONE launch (poolers/diffpool.py:262-284):
 //   out[0] = sqrt(sum_b sq[b]) * link_scale     (link_scale = link_loss_coeff, / adj.numel() when normalize_loss)
 //   out[1] = (sum of the entropy partial sums) * ent_scale   (ent_scale = ent_loss_coeff / num_nodes)
@@ -308,6 +351,20 @@ extern "C" int tgp_mincut_loss_terms_f32(const float* raw, const float* den, con
   hipLaunchKernelGGL(mincut_tail_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0,
                      static_cast<hipStream_t>(stream_), raw, den, gram, static_cast<int>(K), eps, static_cast<int>(B), out);
   return check_launch("tgp_mincut_loss_terms_f32");
+}
+
+extern "C" int tgp_mincut_loss_terms_bwd_f32(const float* raw, const float* den, const float* gram, const float* g_terms,
+                                            int64_t B, int64_t K, float eps, float* g_raw, float* c1, float* W,
+                                            void* stream_) {
+  TGP_REQUIRE(B >= 0 && K >= 1 && K < 32768, TGP_ERR_INVALID, "tgp_mincut_loss_terms_bwd_f32: bad shape");
+  if (B == 0) return TGP_OK;
+  TGP_REQUIRE(raw && den && gram && g_terms && g_raw && c1 && W, TGP_ERR_INVALID,
+              "tgp_mincut_loss_terms_bwd_f32: null pointer");
+  TGP_REQUIRE(B < (1ll << 31), TGP_ERR_RANGE, "tgp_mincut_loss_terms_bwd_f32: too many graphs");
+  hipLaunchKernelGGL(mincut_tail_bwd_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_), raw, den, gram, g_terms, static_cast<int>(K), eps,
+                     static_cast<int>(B), g_raw, c1, W);
+  return check_launch("tgp_mincut_loss_terms_bwd_f32");
 }
 
 static int pair_dot(const int64_t* row, const int64_t* col, int64_t E, const float* S, const float* S2, int64_t K,

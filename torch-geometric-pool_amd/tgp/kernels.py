@@ -552,6 +552,21 @@ def mincut_loss_terms(raw: Tensor, den: Tensor, gram: Tensor) -> Tensor:
     return out
 
 
+def mincut_loss_terms_bwd(raw: Tensor, den: Tensor, gram: Tensor, g_terms: Tensor):
+    """(g_raw [B,K,K], c1 [B], W [B,K,K]): gradients of :func:`mincut_loss_terms` with respect to raw, den and gram from
+    the upstream gradients [2,B] (utils/losses.py:39-70 under autograd), one launch."""
+    dev = N.require_device(raw, den, gram, g_terms)
+    raw, den, gram, g_terms = N.f32c(raw), N.f32c(den), N.f32c(gram), N.f32c(g_terms)
+    B, Kc = raw.size(0), raw.size(-1)
+    g_raw = torch.empty_like(raw)
+    W = torch.empty_like(raw)
+    c1 = torch.empty(B, dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_mincut_loss_terms_bwd_f32(N.ptr(raw), N.ptr(den), N.ptr(gram), N.ptr(g_terms), B, Kc, losses_eps(),
+                                                  N.ptr(g_raw), N.ptr(c1), N.ptr(W), N.stream_ptr(dev)),
+            "tgp_mincut_loss_terms_bwd_f32")
+    return g_raw, c1, W
+
+
 def topk_minscore(score: Tensor, ptr: Tensor, min_score: float, tol: float = 1e-7) -> Tuple[Tensor, Tensor]:
     """(prob [N], node_index [k]): per-graph softmax of ``score`` and the nodes above the min_score threshold, ascending
     (select/topk_select.py:186-194 with PyG's softmax / topk); ``ptr`` = node offsets of the sorted batch."""

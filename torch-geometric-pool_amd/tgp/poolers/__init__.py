@@ -21,6 +21,7 @@ from ..select import GraclusSelect, MLPSelect, NDPSelect, SelectOutput, TopkSele
 from ..src import BasePrecoarseningMixin, DenseSRCPooling, PoolingOutput, SRCPooling
 from ..utils.ops import batch_info, is_dense_adj
 from ..utils.losses import (
+    _MinCutTermsFn,
     entropy_loss,
     link_pred_loss,
     mincut_loss,
@@ -324,6 +325,12 @@ class MinCutPooling(_DenseMLPPooling):
                                                        or adj_pooled.requires_grad))):
             # inference: both losses' per-graph tails in one launch (as torch ops: ~14 launches of a few hundred bytes)
             both = mincut_loss_terms(adj, S, adj_pooled, graph_sizes=self._sizes_for(adj)).mean(dim=1)
+            return {"cut_loss": both[0] if self.cut_loss_coeff == 1 else both[0] * self.cut_loss_coeff,
+                    "ortho_loss": both[1] if self.ortho_loss_coeff == 1 else both[1] * self.ortho_loss_coeff}
+        if (S.is_cuda and S.dim() == 3 and S.dtype == torch.float32 and adj.dim() == 3 and not adj.requires_grad
+                and adj_pooled.dtype == torch.float32 and adj_pooled.dim() == 3):
+            # training: both losses as one Function with a native backward tail (the adjacency gets no gradient there)
+            both = _MinCutTermsFn.apply(adj, S, adj_pooled, self._sizes_for(adj)).mean(dim=1)
             return {"cut_loss": both[0] if self.cut_loss_coeff == 1 else both[0] * self.cut_loss_coeff,
                     "ortho_loss": both[1] if self.ortho_loss_coeff == 1 else both[1] * self.ortho_loss_coeff}
         return {"cut_loss": mincut_loss(adj, S, adj_pooled, batch_reduction="mean",

@@ -114,6 +114,28 @@ def mincut_loss(adj: Tensor, S: Tensor, adj_pooled: Tensor, batch_reduction: str
     return _reduce(-(num / (den + eps)), batch_reduction)
 
 
+class _MinCutTermsFn(torch.autograd.Function):
+    """[2,B] per-graph values of :func:`mincut_loss` and :func:`orthogonality_loss` under autograd with a native backward
+    tail: forward = the three kernels of :func:`mincut_loss_terms`; backward = one launch for the K x K parts
+    (tgp_mincut_loss_terms_bwd_f32), one product S (W + W^T) and one fused multiply-add for 2 c1 D S.  The adjacency gets
+    no gradient here (callers whose adj requires one keep the composed Functions above)."""
+
+    @staticmethod
+    def forward(ctx, adj, S, raw, graph_sizes):
+        deg, _, den = K.cut_terms(adj, S, graph_sizes)
+        gram = K.dense_pool(S, None, S, graph_sizes=graph_sizes)[0]
+        ctx.save_for_backward(S, raw, deg, den, gram)
+        return K.mincut_loss_terms(raw, den, gram)
+
+    @staticmethod
+    def backward(ctx, g):
+        S, raw, deg, den, gram = ctx.saved_tensors
+        g_raw, c1, W = K.mincut_loss_terms_bwd(raw, den, gram, g)
+        g_s = K.bmm(S, W + W.transpose(1, 2))
+        g_s.addcmul_((2.0 * c1).view(-1, 1, 1) * deg.unsqueeze(-1), S)
+        return None, g_s.to(S.dtype), g_raw.to(raw.dtype), None
+
+
 def mincut_loss_terms(adj: Tensor, S: Tensor, adj_pooled: Tensor, graph_sizes: Optional[Tensor] = None) -> Tensor:
     """[2,B] per-graph values of :func:`mincut_loss` and :func:`orthogonality_loss` (before the batch reduction) for
     a device batch outside autograd: den and S^T S from their kernels, both tails in ONE launch."""
