@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10008 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10009 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -217,6 +217,14 @@ int tgp_dense_pool_is_small(int64_t B, int64_t N, int64_t K, int64_t F);
 int tgp_dense_pool_mincut_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K,
                               int64_t F, int flags, float eps, float loss_eps, float* x_pool, float* adj_raw,
                               float* adj_pool, float* mincut_terms, void* ws, size_t ws_bytes, void* stream);
+
+/* The same call with the selector folded in (A13 + A3 + A7 + A8 in ONE launch, same batches): S = softmax(X W^T + b) * mask
+ * (select/mlp_select.py:105-147 for a single Linear; W [K,F], bias [K] or NULL, mask [B,N] bytes or NULL) is formed by the
+ * graph's wave from the X it has just loaded, written once to S_out [B,N,K] (SelectOutput.s) and used from registers. */
+int tgp_dense_pool_select_f32(const float* X, const float* A, const float* W, const float* bias,
+                              const unsigned char* mask, int64_t B, int64_t N, int64_t K, int64_t F, int flags,
+                              float eps, float loss_eps, float* S_out, float* x_pool, float* adj_raw, float* adj_pool,
+                              float* mincut_terms /* [2,B] or NULL */, void* stream);
 
 /* Backward of that call for the same batches (what autograd derives operator by operator from base_reduce.py:158-161,
  * dense_conn.py:111-122, utils/ops.py:282-335 and utils/losses.py:39-70: ~80 launches in a MinCut training step), ONE

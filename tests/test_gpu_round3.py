@@ -876,3 +876,67 @@ def test_mincut_terms_function_vs_autograd(dev, B, N, K):
     (got * wt).sum().backward()
     torch.testing.assert_close(s32.grad, s64.grad.float(), rtol=2e-4, atol=2e-5 * max(s64.grad.abs().max().item(), 1.0))
     torch.testing.assert_close(raw32.grad, raw64.grad.float(), rtol=1e-5, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------- the selector folded into the small-graph kernel
+@pytest.mark.gpu
+@pytest.mark.parametrize("Nmax,K,F", [(17, 5, 8), (40, 20, 32), (64, 32, 32), (60, 20, 3)])
+@pytest.mark.parametrize("with_mask,with_bias,transposed_view", [(True, True, False), (False, False, True), (True, False, True)])
+def test_dense_pool_select_fold_vs_separate_kernels(dev, Nmax, K, F, with_mask, with_bias, transposed_view):
+    """tgp_dense_pool_select_f32 (MLPSelect's Linear + softmax + mask inside the pooling kernel): S against the oracle's
+    mlp_select in fp64, pooled outputs and MinCut terms against the two-launch path fed with that S."""
+    import tgp_oracle as O
+    from tgp import kernels as K_
+    B = 70
+    A, X, _, mask = _ragged_dense_batch(B, Nmax, K, F, seed=Nmax + 3 * K, dev=dev)
+    g = torch.Generator().manual_seed(K)
+    W = (torch.randn(K, F, generator=g) * 0.7).to(dev)
+    bias = torch.randn(K, generator=g).to(dev) if with_bias else None
+    m = mask if with_mask else None
+    adj = A.transpose(1, 2).contiguous().transpose(1, 2) if transposed_view else A
+    flags = K_.dense_flags(True, True, True, False)
+    s, xp, raw, ap, terms = K_.dense_pool_select(X, adj, W, bias, m, flags, want_raw=True, mincut_terms=True)
+    ref_mask = m.cpu() if m is not None else torch.ones(B, Nmax, dtype=torch.bool)
+    want = O.mlp_select(X.cpu().double(), [W.cpu().double()], [None if bias is None else bias.cpu().double()], ref_mask)
+    torch.testing.assert_close(s.cpu(), want.float(), rtol=1e-5, atol=1e-6)
+    xp2, raw2, ap2, terms2 = K_.dense_pool(s, adj, X, flags, want_raw=True, mincut_terms=True)
+    torch.testing.assert_close(xp, xp2, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(raw, raw2, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ap, ap2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(terms, terms2, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alias", ["mincut", "diff"])
+def test_pooler_inference_with_the_folded_selector_equals_the_separate_path(dev, alias, monkeypatch):
+    """get_pooler('mincut' / 'diff') in eval mode on a PROTEINS-shaped sparse batch: Select + Reduce + Connect as one
+    launch gives the same PoolingOutput (so.s, x, adjacency, losses) as MLPSelect's kernel followed by the pooling kernel."""
+    from tgp import kernels as K_
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(9)
+    sizes = torch.randint(20, 61, (80,), generator=g)
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(80), sizes).to(dev)
+    start = (torch.cumsum(sizes, 0) - sizes).to(dev)
+    src = torch.arange(n, device=dev).repeat_interleave(2)
+    dst = start[batch[src]] + (torch.rand(src.numel(), device=dev) * sizes.to(dev)[batch[src]]).long()
+    keep = src != dst
+    key = torch.unique(torch.cat([src[keep] * n + dst[keep], dst[keep] * n + src[keep]]))
+    ei = torch.stack([key // n, key % n])
+    x = torch.randn(n, 32, device=dev)
+    torch.manual_seed(0)
+    pooler = get_pooler(alias, in_channels=32, k=20).to(dev).eval()
+    calls = []
+    real = K_.dense_pool_select
+    monkeypatch.setattr(K_, "dense_pool_select", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        folded = pooler(x=x, adj=ei, batch=batch)
+    assert calls, "the folded kernel did not run"
+    monkeypatch.setattr(type(pooler), "_select_reduce_connect", lambda self, *a: None)
+    with torch.no_grad():
+        plain = pooler(x=x, adj=ei, batch=batch)
+    torch.testing.assert_close(folded.so.s, plain.so.s, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(folded.x, plain.x, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(folded.edge_index, plain.edge_index, rtol=1e-5, atol=1e-5)
+    for k in plain.loss:
+        torch.testing.assert_close(folded.loss[k], plain.loss[k], rtol=1e-5, atol=1e-6)

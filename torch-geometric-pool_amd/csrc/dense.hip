@@ -119,6 +119,30 @@ extern "C" int tgp_dense_pool_mincut_f32(const float* S, const float* A, const f
                          ws, ws_bytes, stream_);
 }
 
+extern "C" int tgp_dense_pool_select_f32(const float* X, const float* A, const float* W, const float* bias,
+                                         const unsigned char* mask, int64_t B, int64_t N, int64_t K, int64_t F,
+                                         int flags, float eps, float loss_eps, float* S_out, float* x_pool,
+                                         float* adj_raw, float* adj_pool, float* mincut_terms, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0 && F >= 0, TGP_ERR_INVALID, "tgp_dense_pool_select_f32: negative size");
+  if (B == 0 || N == 0 || K == 0) return TGP_OK;
+  TGP_REQUIRE(X && W && S_out && F > 0, TGP_ERR_INVALID, "tgp_dense_pool_select_f32: X, W and S_out are required");
+  TGP_REQUIRE(dense_pool_small_ok(B, N, K, F), TGP_ERR_INVALID,
+              "tgp_dense_pool_select_f32: only batches the one-wave-per-graph kernel takes (tgp_dense_pool_is_small)");
+  TGP_REQUIRE(!mincut_terms || A, TGP_ERR_INVALID, "tgp_dense_pool_select_f32: mincut_terms needs A");
+  const bool want_a = A && (adj_raw || adj_pool);
+  SmallArgs q{nullptr, want_a ? A : nullptr, X, static_cast<int>(B), static_cast<int>(N), static_cast<int>(K),
+              static_cast<int>(F), flags, eps, x_pool, want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr,
+              want_a ? mincut_terms : nullptr, loss_eps, W, bias, mask, S_out};
+  const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(SG_WAVES * SG_WAVE_FLOATS * sizeof(float)));
+  hipLaunchKernelGGL(dense_pool_small_kernel, dim3(grid), dim3(64 * SG_WAVES),
+                     SG_WAVES * SG_WAVE_FLOATS * sizeof(float), stream, q);
+  return check_launch("tgp_dense_pool_select_f32");
+}
+
 extern "C" int tgp_dense_pool_small_bwd_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N,
                                             int64_t K, int64_t F, int flags, float eps, float loss_eps,
                                             const float* g_x_pool, const float* g_adj_pool, const float* g_adj_raw,
@@ -168,7 +192,8 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
   if (dense_pool_small_ok(B, N, K, F)) {
     SmallArgs q{S, want_a ? A : nullptr, want_x ? X : nullptr, static_cast<int>(B), static_cast<int>(N),
                 static_cast<int>(K), static_cast<int>(F), flags, eps, want_x ? x_pool : nullptr,
-                want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr, want_a ? mincut_terms : nullptr, loss_eps};
+                want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr, want_a ? mincut_terms : nullptr, loss_eps,
+                nullptr, nullptr, nullptr, nullptr};
     const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -33,6 +33,11 @@ struct SmallArgs {
   // computed behind the pooling kernel)
   float* mincut_terms;
   float loss_eps;
+  // optional (r3): the selector folded in -- S = softmax(X W^T + b) * mask (select/mlp_select.py:105-147 for a single
+  // Linear) is formed by the wave from the X it has just loaded, written ONCE to s_out [B,N,K] (it is an output:
+  // SelectOutput.s) and used from registers; p.S is ignored then.  sel_w [K,F], sel_b [K] or NULL, sel_mask [B,N] bytes
+  // or NULL.
+  const float* sel_w; const float* sel_b; const unsigned char* sel_mask; float* s_out;
 };
 
 __device__ __forceinline__ float sg_wave_sum(float v) {
@@ -42,6 +47,41 @@ __device__ __forceinline__ float sg_wave_sum(float v) {
 }
 
 __device__ __forceinline__ int rho(int r) { return (r & 3) + 8 * (r >> 2); }
+// Reductions over the 32 lanes of a half-wave, the result in every lane: four DPP rotations inside the 16-lane rows
+// (register moves) and ONE ds_swizzle across the two rows (a __shfl_xor ladder is five trips through the LDS pipe: 320
+// of them per wave made the folded selector cost 20 us instead of 3)
+template <int CTRL>
+__device__ __forceinline__ float sg_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float sg_swz16(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x1F | (16 << 10)));
+}
+__device__ __forceinline__ float sg_half_sum(float v) {
+  v += sg_dpp<0x121>(v);  // row_ror:1
+  v += sg_dpp<0x122>(v);
+  v += sg_dpp<0x124>(v);
+  v += sg_dpp<0x128>(v);
+  return v + sg_swz16(v);
+}
+__device__ __forceinline__ float sg_half_max(float v) {
+  v = fmaxf(v, sg_dpp<0x121>(v));
+  v = fmaxf(v, sg_dpp<0x122>(v));
+  v = fmaxf(v, sg_dpp<0x124>(v));
+  v = fmaxf(v, sg_dpp<0x128>(v));
+  return fmaxf(v, sg_swz16(v));
+}
+// exp(x) for x <= 0 on v_exp_f32 with the rounding error of x * log2(e) carried along (as csrc/mlp_select.hip: relative
+// error ~2e-7; -inf and anything below 2^-150 give 0)
+__device__ __forceinline__ float sg_exp_neg(float x) {
+  const float L = 1.44269504088896341f, Llo = 1.92596299112661746e-8f;
+  x = fmaxf(x, -104.f);
+  const float y = x * L;
+  float r = fmaf(x, L, -y);
+  r = fmaf(x, Llo, r);
+  const float e = __builtin_amdgcn_exp2f(y);
+  return fmaf(e, r * 0.693147180559945309f, e);
+}
 // uniform base + 32-bit per-lane byte offset: lets the load use the SGPR-base addressing form
 __device__ __forceinline__ const float* byte_off(const float* base, int bytes) {
   return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + static_cast<unsigned>(bytes));
@@ -111,7 +151,7 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
     }
     // step q of every product contracts node rows node(q) = 32*(q>>4) + rho(q&15) + 4*lk
     float sr[32], xr[32];
-    {
+    if (!p.sel_w) {
       const float* Sb = p.S + static_cast<long>(b) * N * K;
       const bool cok = lm < K;
 #pragma unroll
@@ -133,7 +173,63 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
         xr[q] = ok ? r : 0.f;
       }
     }
+    float wl[16];
+    if (p.sel_w) {  // W [K,F] row by row (lane = feature: coalesced), two rows per load instruction; staged in LDS below
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int kr = 2 * t + lk;
+        const bool ok = kr < K && lm < F;
+        const float v0 = *byte_off(p.sel_w, ok ? (kr * F + lm) * 4 : 0);
+        wl[t] = ok ? v0 : 0.f;
+      }
+    }
     if (w < SG_WAVES / 2 && lane == 0) atomicAdd(&s_issued, 1);  // this wave's loads are all issued
+    if (p.sel_w) {
+      // ---- S = softmax(X W^T + b) * mask, straight into the operand registers sr[] ------------------------------
+      // X is in registers with lane = feature; the product needs it with lane = node: through the (still unused) A tile
+      // in LDS.  The accumulators of Z_T = X_T W^T (lane = cluster, register r = node 32 T + rho(r) + 4 lk) ARE the
+      // layout sr[16 T + r] of every product below; the softmax of a node is a reduction over the 32 lanes of a half.
+      float* Xs = As;            // [node][33]
+      float* Ws = As + 64 * 33;  // [cluster][33]
+#pragma unroll
+      for (int q = 0; q < 32; ++q) Xs[(32 * (q >> 4) + rho(q & 15) + 4 * lk) * 33 + lm] = xr[q];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) Ws[(2 * t + lk) * 33 + lm] = wl[t];
+      __builtin_amdgcn_wave_barrier();
+      float wr[16];  // W as the B operand of Z = X W^T: lane = cluster, k-step r = features rho(r) + 4 lk
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wr[r] = Ws[lm * 33 + rho(r) + 4 * lk];
+      const float bz = lm < K ? (p.sel_b ? p.sel_b[lm] : 0.f) : -__builtin_inff();
+      const unsigned char* mk = p.sel_mask ? p.sel_mask + static_cast<long>(b) * N : nullptr;
+      float* So = p.s_out ? p.s_out + static_cast<long>(b) * N * K : nullptr;
+#pragma unroll
+      for (int T = 0; T < 2; ++T) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = bz;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          z = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[(32 * T + lm) * 33 + rho(r) + 4 * lk], wr[r], z, 0, 0, 0);
+        // (the 16 reductions of a pass are written side by side: one after the other they are 16 dependent chains of
+        //  four DPP moves and an LDS swizzle each)
+        float mx[16], ex[16], sm[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx[r] = sg_half_max(z[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ex[r] = sg_exp_neg(z[r] - mx[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm[r] = sg_half_sum(ex[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int node = 32 * T + rho(r) + 4 * lk;
+          const bool on = node < N && (!mk || mk[node < N ? node : 0] != 0);
+          const float sv = on ? ex[r] * __builtin_amdgcn_rcpf(sm[r]) : 0.f;  // (1 ulp reciprocal: far inside 1e-5)
+          sr[16 * T + r] = sv;
+          if (So && node < N && lm < K) So[node * K + lm] = sv;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // (the A tile overwrites Xs below)
+    }
     if (p.A) {
       const int q = lane & 15;
 #pragma unroll

@@ -72,6 +72,8 @@ SIGNATURES = {
     "tgp_dense_pool_is_small": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64]),
     "tgp_dense_pool_mincut_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_f, _c_f, _c_p,
                                            _c_p, _c_p, _c_p, _c_p, _c_sz, _c_p]),
+    "tgp_dense_pool_select_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_f, _c_f,
+                                           _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "tgp_dense_pool_small_bwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_f, _c_f, _c_p,
                                               _c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_p, _c_p, _c_p]),
     "tgp_postprocess_dense_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),

@@ -386,6 +386,37 @@ def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int
     return (x_pool, adj_raw, adj_pool, None) if mincut_terms else (x_pool, adj_raw, adj_pool)
 
 
+def dense_pool_select(x: Tensor, adj: Tensor, weight: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], flags: int,
+                      want_raw: bool = False, mincut_terms: bool = False):
+    """(s, x_pool, adj_raw, adj_pool, terms): MLPSelect's last Linear + softmax + mask, Reduce, Connect and the
+    post-processing of a batch of small graphs in ONE launch (select/mlp_select.py:105-147, base_reduce.py:158-161,
+    dense_conn.py:111-122, utils/ops.py:282-335); callers check :func:`dense_pool_is_small` first."""
+    dev = N.require_device(x, adj, weight, bias, mask)
+    x, weight = N.f32c(x), N.f32c(weight)
+    B, Nn, F = x.shape
+    K = weight.size(0)
+    if weight.shape != (K, F) or adj.shape != (B, Nn, Nn):
+        raise ValueError(f"dense_pool_select: shapes x {tuple(x.shape)}, adj {tuple(adj.shape)}, weight {tuple(weight.shape)}")
+    a, tflag = _dense_adj_layout(adj)
+    b = None if bias is None else N.f32c(bias)
+    m = None
+    if mask is not None:
+        m = mask.to(torch.uint8) if mask.dtype != torch.uint8 and mask.dtype != torch.bool else mask
+        m = m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.contiguous()
+        if tuple(m.shape) != (B, Nn):
+            raise ValueError(f"dense_pool_select: mask {tuple(mask.shape)} does not match x {tuple(x.shape)}")
+    s = torch.empty(B, Nn, K, dtype=torch.float32, device=dev)
+    x_pool = torch.empty(B, K, F, dtype=torch.float32, device=dev)
+    adj_pool = torch.empty(B, K, K, dtype=torch.float32, device=dev)
+    adj_raw = torch.empty(B, K, K, dtype=torch.float32, device=dev) if want_raw else None
+    terms = torch.empty(2, B, dtype=torch.float32, device=dev) if mincut_terms else None
+    N.check(N.lib().tgp_dense_pool_select_f32(N.ptr(x), N.ptr(a), N.ptr(weight), N.ptr(b), N.ptr(m), B, Nn, K, F,
+                                              flags | tflag, ops_eps(), losses_eps(), N.ptr(s), N.ptr(x_pool),
+                                              N.ptr(adj_raw), N.ptr(adj_pool), N.ptr(terms), N.stream_ptr(dev)),
+            "tgp_dense_pool_select_f32")
+    return s, x_pool, adj_raw, adj_pool, terms
+
+
 def dense_pool_is_small(B: int, Nn: int, K: int, F: int) -> bool:
     """Does the one-wave-per-graph kernel take this padded batch (and so its fused backward)?"""
     return bool(N.lib().tgp_dense_pool_is_small(B, Nn, K, F))

@@ -163,6 +163,35 @@ class _DenseMLPPooling(DenseSRCPooling):
     def _lift(self, x, so, batch, batch_pooled):
         return self.lift(x_pool=x, so=so, batch=batch, batch_pooled=batch_pooled)
 
+    def _select_reduce_connect(self, x, adj, mask):
+        """Inference on a batch of small graphs with a single-Linear selector: Select + Reduce + Connect as ONE launch
+        (tgp_dense_pool_select_f32: S is formed in the pooling kernel's registers and written once).  Returns
+        ``(SelectOutput, (x_pool, raw, adj_pool[, terms]))`` or None when the case is not that one."""
+        from .. import kernels as K
+        sel, c = self.selector, self.connector
+        lins = getattr(getattr(sel, "mlp", None), "lins", None)
+        if (type(sel) is not MLPSelect or lins is None or len(lins) != 1 or type(c) is not DenseConnect
+                or type(self.reducer) is not BaseReduce or not (isinstance(x, Tensor) and isinstance(adj, Tensor))
+                or x.dim() != 3 or adj.dim() != 3 or not x.is_cuda or x.dtype != torch.float32
+                or adj.dtype != torch.float32 or (mask is not None and mask.dtype != torch.bool)):
+            return None
+        last = lins[0]
+        if torch.is_grad_enabled() and (x.requires_grad or adj.requires_grad or last.weight.requires_grad
+                                        or (last.bias is not None and last.bias.requires_grad)):
+            return None
+        if (last.weight.dtype != torch.float32 or adj.shape != (x.size(0), x.size(1), x.size(1))
+                or not K.dense_pool_is_small(x.size(0), x.size(1), last.weight.size(0), x.size(2))):
+            return None
+        flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
+        s, x_pool, raw, adj_pool, terms = K.dense_pool_select(
+            x, adj, last.weight.detach(), None if last.bias is None else last.bias.detach(), mask, flags,
+            want_raw=self._loss_needs_raw, mincut_terms=self._loss_needs_raw)
+        so = SelectOutput(s=s, s_inv_op=sel.s_inv_op, in_mask=mask)
+        fused = (x_pool, raw, adj_pool) + ((terms,) if self._loss_needs_raw else ())
+        if self._fused_diff_scales(adj, mask) is not None:
+            fused = fused + (None,)
+        return so, fused
+
     def _sizes_for(self, adj):
         """Real nodes per graph of the zero-padded batch ``adj`` belongs to, if forward() densified it itself."""
         hint = getattr(self, "_sizes_hint", None)
@@ -193,14 +222,16 @@ class _DenseMLPPooling(DenseSRCPooling):
                 self._known_nodes = x.size(0) * x.size(1)
             x, adj, mask = self._ensure_batched_inputs(x=x, edge_index=adj, edge_weight=edge_weight, batch=batch,
                                                        mask=mask)
-            so = self.select(x=x, mask=mask)
+            folded = self._select_reduce_connect(x, adj, mask)
+            so = folded[0] if folded is not None else self.select(x=x, mask=mask)
             self._sizes_hint = None
             if graph_sizes is not None and graph_sizes.numel() == x.size(0):
                 so._graph_sizes = graph_sizes
                 self._sizes_hint = (weakref.ref(adj), graph_sizes)  # valid for exactly this adjacency tensor
             diff_scales = self._fused_diff_scales(adj, mask)
-            fused = self.reduce_connect(x, adj, so, want_raw=self._loss_needs_raw,
-                                        want_mincut_terms=self._loss_needs_raw, want_diff_losses=diff_scales)
+            fused = folded[1] if folded is not None else self.reduce_connect(
+                x, adj, so, want_raw=self._loss_needs_raw, want_mincut_terms=self._loss_needs_raw,
+                want_diff_losses=diff_scales)
             if fused is not None:  # Reduce + Connect in one native call (training: batches of small graphs only)
                 x_pool, raw, adj_pool = fused[:3]
                 batch_pool = self.reducer.reduce_batch(so, batch if batch is not None else so.batch)
