@@ -28,7 +28,8 @@ namespace tgp {
 __device__ __forceinline__ double kron_upd(double m, double c, double u, double inv) { return __fma_rn(-(c * u), inv, m); }
 
 constexpr int KRON_LDS_MAX_N = 128;  // 128 x 129 doubles = 132 KB of the 160 KB LDS
-constexpr int KRON_MAX_N = 1024;
+constexpr int KRON_MAX_N = 4096;       // r3: was 1024 (the multi-workgroup panel kernels do not care; 4096^2 doubles = 134 MB per graph)
+constexpr int KRON_REDO_MAX_N = 1024;  // what the one-workgroup damped redo of a singular graph can hold in LDS
 constexpr int KRON_THREADS = 256;
 constexpr int KRON_BIG_THREADS = 1024;
 
@@ -772,6 +773,10 @@ __global__ __launch_bounds__(KRON_BIG_THREADS) void kron_big_redo_kernel(KronArg
   BigGraph q;
   if (!kron_big_graph(a, blockIdx.x, &q)) return;
   if (a.sing[q.g] == 0) return;
+  if (q.n > KRON_REDO_MAX_N) {  // a singular graph beyond this kernel's LDS panels: decline, the caller has its own route
+    if (threadIdx.x == 0) atomicOr(a.status, KRON_TOO_LARGE);
+    return;
+  }
   kron_graph<KRON_BIG_THREADS, true>(a, q.M, q.g, q.p0, q.n, q.k, q.r0, &s_flag, &s_cnt, s_panel,
                                      s_panel + static_cast<size_t>(KRON_NB) * q.n, s_inv);
 }
@@ -1086,7 +1091,7 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
       hipLaunchKernelGGL(kron_big_trail_kernel, dim3(static_cast<unsigned>(nt * nt), nbig), dim3(256), KRON_LDS_PAD, stream, a, step);
     }
     hipLaunchKernelGGL(kron_big_finish_kernel, dim3(cdiv(nmax, 16), nbig), dim3(256), 0, stream, a);
-    const size_t plds = static_cast<size_t>(2 * KRON_NB) * nmax * sizeof(double);
+    const size_t plds = static_cast<size_t>(2 * KRON_NB) * (nmax < KRON_REDO_MAX_N ? nmax : KRON_REDO_MAX_N) * sizeof(double);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kron_big_redo_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plds));
     hipLaunchKernelGGL(kron_big_redo_kernel, dim3(nbig), dim3(KRON_BIG_THREADS), plds, stream, a);
