@@ -154,6 +154,10 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
 
 
 FUSED_MAX_SUPERNODES = 32 * 1024  # 1024 tiles of 32 supernode rows
+# ... and while supernode rows are short on average: a row of more than 64 raw entries is sorted by the whole workgroup,
+# one such row at a time, with its successors waiting in their look-back (a batch of denser mid-size graphs -- the
+# reference's own timing harness, 27 entries per row on average -- took 1.45 ms in the fused kernel, 0.1 ms staged)
+FUSED_MAX_AVG_ROW = 16
 
 
 def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_index: Tensor,
@@ -199,7 +203,8 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
     # the fused kernel's workgroups wait for their predecessors: it is used while all tiles are resident at once
     # (<= 1024 of them: one launch wave), i.e. for batches of small graphs, where the staged pipeline's ten launches
     # dominate; large lists take the staged pipeline, whose kernels never wait for each other
-    fused_ok = rows_ok and (route == "fused" or num_supernodes <= FUSED_MAX_SUPERNODES)
+    fused_ok = rows_ok and (route == "fused" or (num_supernodes <= FUSED_MAX_SUPERNODES
+                                                  and E <= FUSED_MAX_AVG_ROW * num_supernodes))
     if fused_ok and route != "staged":
         ws = N.workspace(L.tgp_connect_coalesce_fused_workspace_bytes(E, cl.numel(), num_supernodes), dev)
         d_count = torch.empty(1, dtype=torch.int64, device=dev)
