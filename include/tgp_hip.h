@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10009 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10010 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -376,10 +376,11 @@ int tgp_postprocess_dense_bwd_f32(const float* raw, const float* g_post, int64_t
 /* A11  DenseSRCPooling.preprocessing (src.py:374-452 -> PyG to_dense_adj / to_dense_batch): the step
  * right before the timed path.  batch must be sorted; ptr[B+1] = exclusive prefix of the graph sizes.
  * adj [B,Nmax,Nmax] / out [B,Nmax,F] / mask [B,Nmax] are zero-filled inside.  transposed != 0 writes
- * A^T (what src.py:442-443 produces as a view).  Duplicated edges are summed (float atomics). */
+ * A^T (what src.py:442-443 produces as a view).  Duplicated edges are summed (float atomics).  adj_is_zeroed != 0: the
+ * caller has zero-filled adj already (tgp_to_dense_batch_sorted_f32 can do it in its own launch). */
 int tgp_to_dense_adj_f32(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL = ones */,
                          int64_t num_edges, const int64_t* batch, const int64_t* ptr, int64_t B, int64_t Nmax,
-                         int transposed, float* adj, void* stream);
+                         int transposed, int adj_is_zeroed, float* adj, void* stream);
 /* inverse gather of tgp_to_dense_adj_f32 (its backward w.r.t. the edge weights, which the reference gets from ATen
  * autograd over PyG's scatter, src.py:434): grad_weight[e] = grad_adj[slot of e], 0 for dropped entries */
 int tgp_from_dense_adj_f32(const float* grad_adj, const int64_t* row, const int64_t* col, int64_t num_edges,
@@ -389,9 +390,11 @@ int tgp_from_dense_adj_f32(const float* grad_adj, const int64_t* row, const int6
 int tgp_from_dense_batch_f32(const float* dense, int64_t N, int64_t F, const int64_t* batch, const int64_t* ptr,
                              int64_t B, int64_t Nmax, float* x, void* stream);
 /* to_dense_batch for a SORTED batch vector (graph b = nodes ptr[b] .. ptr[b+1]): output-parallel, padding and mask
- * written by the same kernel (no memsets in front). */
+ * written by the same kernel (no memsets in front).  zero_buf / zero_count (optional): a second float buffer to zero-fill
+ * in the same launch (the adjacency tgp_to_dense_adj_f32 scatters into next). */
 int tgp_to_dense_batch_sorted_f32(const float* x, int64_t num_nodes, int64_t F, const int64_t* ptr, int64_t B,
-                                  int64_t Nmax, float* out, uint8_t* mask, void* stream);
+                                  int64_t Nmax, float* out, uint8_t* mask, float* zero_buf /* NULL ok */,
+                                  int64_t zero_count, void* stream);
 int tgp_to_dense_batch_f32(const float* x, int64_t num_nodes, int64_t num_features, const int64_t* batch,
                            const int64_t* ptr, int64_t B, int64_t Nmax, float* out, uint8_t* mask, void* stream);
 

@@ -940,3 +940,38 @@ def test_pooler_inference_with_the_folded_selector_equals_the_separate_path(dev,
     torch.testing.assert_close(folded.edge_index, plain.edge_index, rtol=1e-5, atol=1e-5)
     for k in plain.loss:
         torch.testing.assert_close(folded.loss[k], plain.loss[k], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transposed", [False, True])
+def test_densify_together_equals_the_separate_functions(dev, transposed):
+    """to_dense_batch zero-filling the adjacency buffer in its own launch + to_dense_adj scattering into it (what the
+    dense poolers' preprocessing runs) against the two stand-alone functions: same x, mask, adjacency (duplicates
+    summed), gradients of x and of the edge weights."""
+    from tgp.connect import DenseConnect
+    from tgp.reduce import BaseReduce
+    from tgp.src import DenseSRCPooling, to_dense_adj, to_dense_batch
+    g = torch.Generator().manual_seed(6)
+    sizes = torch.tensor([5, 1, 17, 3, 9])
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(5), sizes).to(dev)
+    start = (torch.cumsum(sizes, 0) - sizes).to(dev)
+    src = torch.arange(n, device=dev).repeat_interleave(3)
+    dst = start[batch[src]] + (torch.rand(src.numel(), device=dev) * sizes.to(dev)[batch[src]]).long()
+    ei = torch.stack([src, dst])                       # duplicates and self loops included
+    ew = torch.rand(ei.size(1), generator=g).to(dev).requires_grad_(True)
+    x = torch.randn(n, 7, generator=g).to(dev).requires_grad_(True)
+    pool = DenseSRCPooling(reducer=BaseReduce(), connector=DenseConnect(), adj_transpose=transposed)
+    xd, adj, mask = pool.preprocessing(x=x, edge_index=ei, edge_weight=ew, batch=batch)
+    wx, wa = torch.randn_like(xd), torch.randn_like(adj)
+    ((xd * wx).sum() + (adj * wa).sum()).backward()
+    gx, gw = x.grad.clone(), ew.grad.clone()
+    x.grad = None
+    ew.grad = None
+    adj2 = to_dense_adj(ei, batch, ew, None, None, transposed=transposed)
+    xd2, mask2 = to_dense_batch(x, batch, None, None)
+    ((xd2 * wx).sum() + (adj2 * wa).sum()).backward()
+    assert torch.equal(xd, xd2) and torch.equal(mask, mask2)
+    torch.testing.assert_close(adj, adj2, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(gx, x.grad, rtol=0, atol=0)
+    torch.testing.assert_close(gw, ew.grad, rtol=1e-6, atol=1e-6)

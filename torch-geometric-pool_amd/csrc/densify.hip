@@ -65,7 +65,19 @@ __global__ __launch_bounds__(256) void dense_batch_kernel(const float* __restric
 __global__ __launch_bounds__(256) void dense_batch_sorted_kernel(const float* __restrict__ x, int64_t F,
                                                                  const int64_t* __restrict__ ptr, int64_t B,
                                                                  int64_t Nmax, float* __restrict__ out,
-                                                                 uint8_t* __restrict__ mask) {
+                                                                 uint8_t* __restrict__ mask,
+                                                                 float* __restrict__ zero_buf, int64_t zero_count) {
+  // (r3) the same launch zero-fills a second buffer, the [B,Nmax,Nmax] adjacency the edge scatter adds into next: both
+  // are pure streaming writes, and a dependent launch costs ~5 us on this part whatever it does
+  {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t n4 = zero_count / 4;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<int64_t>(gridDim.x) * 256)
+      reinterpret_cast<float4*>(zero_buf)[i] = z;
+    for (int64_t i = n4 * 4 + static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < zero_count;
+         i += static_cast<int64_t>(gridDim.x) * 256)
+      zero_buf[i] = 0.f;
+  }
   const int64_t total = B * Nmax * F;
   for (int64_t o = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; o < total;
        o += static_cast<int64_t>(gridDim.x) * 256) {
@@ -100,12 +112,12 @@ using namespace tgp;
 
 extern "C" int tgp_to_dense_adj_f32(const int64_t* row, const int64_t* col, const float* w, int64_t E,
                                     const int64_t* batch, const int64_t* ptr, int64_t B, int64_t Nmax,
-                                    int transposed, float* adj, void* stream_) {
+                                    int transposed, int adj_is_zeroed, float* adj, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(E >= 0 && B >= 0 && Nmax >= 0, TGP_ERR_INVALID, "tgp_to_dense_adj_f32: negative size");
   if (B == 0 || Nmax == 0) return TGP_OK;
   TGP_REQUIRE(adj && (E == 0 || (row && col && batch && ptr)), TGP_ERR_INVALID, "tgp_to_dense_adj_f32: null pointer");
-  (void)hipMemsetAsync(adj, 0, sizeof(float) * B * Nmax * Nmax, stream);
+  if (!adj_is_zeroed) (void)hipMemsetAsync(adj, 0, sizeof(float) * B * Nmax * Nmax, stream);
   if (E > 0)
     hipLaunchKernelGGL(dense_adj_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, E, batch, ptr, Nmax,
                        transposed, adj);
@@ -131,19 +143,24 @@ extern "C" int tgp_to_dense_batch_f32(const float* x, int64_t N, int64_t F, cons
 }
 
 extern "C" int tgp_to_dense_batch_sorted_f32(const float* x, int64_t N, int64_t F, const int64_t* ptr, int64_t B,
-                                             int64_t Nmax, float* out, uint8_t* mask, void* stream_) {
+                                             int64_t Nmax, float* out, uint8_t* mask, float* zero_buf,
+                                             int64_t zero_count, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(N >= 0 && F >= 0 && B >= 0 && Nmax >= 0, TGP_ERR_INVALID, "tgp_to_dense_batch_sorted_f32: negative size");
   if (B == 0 || Nmax == 0) return TGP_OK;
   TGP_REQUIRE(out && ptr && (N == 0 || x), TGP_ERR_INVALID, "tgp_to_dense_batch_sorted_f32: null pointer");
+  TGP_REQUIRE(zero_count >= 0 && (zero_count == 0 || (zero_buf && reinterpret_cast<uintptr_t>(zero_buf) % 16 == 0)),
+              TGP_ERR_INVALID, "tgp_to_dense_batch_sorted_f32: zero_buf must be 16-byte aligned");
   if (F == 0) {
     if (mask) (void)hipMemsetAsync(mask, 0, static_cast<size_t>(B) * Nmax, stream);  // (no feature column to ride on)
+    if (zero_count) (void)hipMemsetAsync(zero_buf, 0, sizeof(float) * zero_count, stream);
     return check_launch("tgp_to_dense_batch_sorted_f32");
   }
-  int64_t blocks = (B * Nmax * F + 255) / 256;
+  const int64_t work = B * Nmax * F > zero_count / 4 ? B * Nmax * F : zero_count / 4;
+  int64_t blocks = (work + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(dense_batch_sorted_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, x, F, ptr, B,
-                     Nmax, out, mask);
+                     Nmax, out, mask, zero_buf, zero_count);
   return check_launch("tgp_to_dense_batch_sorted_f32");
 }
 

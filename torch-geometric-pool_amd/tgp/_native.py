@@ -110,10 +110,10 @@ SIGNATURES = {
     "tgp_mincut_loss_terms_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_f, _c_p, _c_p]),
     "tgp_rowptr_from_sorted_i64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_spmm_csr_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
-    "tgp_to_dense_adj_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p]),
+    "tgp_to_dense_adj_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_int, _c_p, _c_p]),
     "tgp_from_dense_adj_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p]),
     "tgp_from_dense_batch_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
-    "tgp_to_dense_batch_sorted_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
+    "tgp_to_dense_batch_sorted_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p]),
     "tgp_entropy_partials_f32": (_c_int, [_c_p, _c_i64, _c_f, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_diffpool_loss_tail_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_int, _c_f, _c_f, _c_p, _c_p]),
     "tgp_to_dense_batch_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),

@@ -337,8 +337,8 @@ class _ToDenseBatchFn(torch.autograd.Function):
     (torch's own backward of the indexed assignment sorts the indices first)."""
 
     @staticmethod
-    def forward(ctx, x, batch, ptr, num_graphs, max_nodes):
-        out, mask = K.to_dense_batch(x, batch, ptr, num_graphs, max_nodes)
+    def forward(ctx, x, batch, ptr, num_graphs, max_nodes, also_zero=None):
+        out, mask = K.to_dense_batch(x, batch, ptr, num_graphs, max_nodes, also_zero)
         ctx.save_for_backward(batch, ptr)
         ctx.max_nodes = max_nodes
         ctx.mark_non_differentiable(mask)
@@ -348,13 +348,14 @@ class _ToDenseBatchFn(torch.autograd.Function):
     def backward(ctx, g, _gmask):
         batch, ptr = ctx.saved_tensors
         # one gather kernel; nodes beyond a caller-imposed max_num_nodes were dropped in the forward: zero gradient
-        return K.from_dense_batch(g, batch, ptr, ctx.max_nodes), None, None, None, None
+        return K.from_dense_batch(g, batch, ptr, ctx.max_nodes), None, None, None, None, None
 
 
-def to_dense_batch(x: Tensor, batch: Tensor, ptr: Tensor, num_graphs: int, max_nodes: int):
+def to_dense_batch(x: Tensor, batch: Tensor, ptr: Tensor, num_graphs: int, max_nodes: int,
+                   also_zero: Optional[Tensor] = None):
     if _needs_grad(x):
-        return _ToDenseBatchFn.apply(x, batch, ptr, num_graphs, max_nodes)
-    return K.to_dense_batch(x, batch, ptr, num_graphs, max_nodes)
+        return _ToDenseBatchFn.apply(x, batch, ptr, num_graphs, max_nodes, also_zero)
+    return K.to_dense_batch(x, batch, ptr, num_graphs, max_nodes, also_zero)
 
 
 class _ToDenseAdjFn(torch.autograd.Function):
@@ -362,23 +363,23 @@ class _ToDenseAdjFn(torch.autograd.Function):
     matching gather (the reference gets it from ATen autograd over PyG's scatter)."""
 
     @staticmethod
-    def forward(ctx, edge_weight, edge_index, batch, ptr, num_graphs, max_nodes, transposed):
+    def forward(ctx, edge_weight, edge_index, batch, ptr, num_graphs, max_nodes, transposed, zeroed_out=None):
         ctx.save_for_backward(edge_index, batch, ptr)
         ctx.max_nodes, ctx.transposed, ctx.shape = max_nodes, transposed, edge_weight.shape
-        return K.to_dense_adj(edge_index, edge_weight, batch, ptr, num_graphs, max_nodes, transposed)
+        return K.to_dense_adj(edge_index, edge_weight, batch, ptr, num_graphs, max_nodes, transposed, zeroed_out)
 
     @staticmethod
     def backward(ctx, g):
         edge_index, batch, ptr = ctx.saved_tensors
         gw = K.from_dense_adj(g.contiguous(), edge_index, batch, ptr, ctx.max_nodes, ctx.transposed)
-        return gw.view(ctx.shape), None, None, None, None, None, None
+        return gw.view(ctx.shape), None, None, None, None, None, None, None
 
 
 def to_dense_adj(edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor, ptr: Tensor, num_graphs: int,
-                 max_nodes: int, transposed: bool) -> Tensor:
+                 max_nodes: int, transposed: bool, zeroed_out: Optional[Tensor] = None) -> Tensor:
     if _needs_grad(edge_weight):
-        return _ToDenseAdjFn.apply(edge_weight, edge_index, batch, ptr, num_graphs, max_nodes, transposed)
-    return K.to_dense_adj(edge_index, edge_weight, batch, ptr, num_graphs, max_nodes, transposed)
+        return _ToDenseAdjFn.apply(edge_weight, edge_index, batch, ptr, num_graphs, max_nodes, transposed, zeroed_out)
+    return K.to_dense_adj(edge_index, edge_weight, batch, ptr, num_graphs, max_nodes, transposed, zeroed_out)
 
 
 # ---------------------------------------------------------------------------------------- Linear layer

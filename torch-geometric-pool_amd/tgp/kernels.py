@@ -1063,16 +1063,20 @@ def block_diag_edges(adj_pool: Tensor, relabel: Optional[Tensor] = None,
 
 # ------------------------------------------------------------------------- A11
 def to_dense_adj(edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor, ptr: Tensor, num_graphs: int,
-                 max_nodes: int, transposed: bool) -> Tensor:
-    """PyG to_dense_adj (src.py:434-443): [B,Nmax,Nmax], duplicates summed; optionally written transposed."""
+                 max_nodes: int, transposed: bool, zeroed_out: Optional[Tensor] = None) -> Tensor:
+    """PyG to_dense_adj (src.py:434-443): [B,Nmax,Nmax], duplicates summed; optionally written transposed.
+    ``zeroed_out``: a zero-filled [B,Nmax,Nmax] buffer to add into (:func:`to_dense_batch` can zero it in its launch)."""
     dev = N.require_device(edge_index, edge_weight, batch, ptr)
     row, col = _edge_rows(edge_index)
     w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
     batch, ptr = N.i64c(batch), N.i64c(ptr)
-    adj = torch.empty(num_graphs, max_nodes, max_nodes, dtype=torch.float32, device=dev)
+    adj = zeroed_out if zeroed_out is not None else torch.empty(num_graphs, max_nodes, max_nodes, dtype=torch.float32,
+                                                                device=dev)
+    if tuple(adj.shape) != (num_graphs, max_nodes, max_nodes) or adj.dtype != torch.float32 or not adj.is_contiguous():
+        raise ValueError("to_dense_adj: zeroed_out must be a contiguous float32 [B,Nmax,Nmax] tensor")
     N.check(N.lib().tgp_to_dense_adj_f32(N.ptr(row), N.ptr(col), N.ptr(w), row.numel(), N.ptr(batch), N.ptr(ptr),
-                                         num_graphs, max_nodes, 1 if transposed else 0, N.ptr(adj),
-                                         N.stream_ptr(dev)), "tgp_to_dense_adj_f32")
+                                         num_graphs, max_nodes, 1 if transposed else 0, 1 if zeroed_out is not None else 0,
+                                         N.ptr(adj), N.stream_ptr(dev)), "tgp_to_dense_adj_f32")
     return adj
 
 
@@ -1102,8 +1106,10 @@ def from_dense_batch(dense: Tensor, batch: Tensor, ptr: Tensor, max_nodes: int) 
     return out.view((n,) + tuple(dense.shape[2:]))
 
 
-def to_dense_batch(x: Tensor, batch: Tensor, ptr: Tensor, num_graphs: int, max_nodes: int) -> Tuple[Tensor, Tensor]:
-    """PyG to_dense_batch (src.py:448-450): ([B,Nmax,F], mask [B,Nmax])."""
+def to_dense_batch(x: Tensor, batch: Tensor, ptr: Tensor, num_graphs: int, max_nodes: int,
+                   also_zero: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """PyG to_dense_batch (src.py:448-450): ([B,Nmax,F], mask [B,Nmax]).  ``also_zero``: a contiguous float32 buffer to
+    zero-fill on the way (in the same launch when the batch vector is sorted)."""
     dev = N.require_device(x, batch, ptr)
     x2 = N.f32c(x if x.dim() == 2 else x.reshape(x.size(0), -1))
     batch, ptr = N.i64c(batch), N.i64c(ptr)
@@ -1114,9 +1120,13 @@ def to_dense_batch(x: Tensor, batch: Tensor, ptr: Tensor, num_graphs: int, max_n
     if F > 0 and ptr.numel() == num_graphs + 1 and batch_info(batch).is_sorted:
         # sorted batch vector (memoised fact): one output-parallel kernel writes rows, padding and mask -- no memsets
         N.check(N.lib().tgp_to_dense_batch_sorted_f32(N.ptr(x2), x2.size(0), F, N.ptr(ptr), num_graphs, max_nodes,
-                                                      N.ptr(out), N.ptr(mask), N.stream_ptr(dev)),
+                                                      N.ptr(out), N.ptr(mask), N.ptr(also_zero),
+                                                      also_zero.numel() if also_zero is not None else 0,
+                                                      N.stream_ptr(dev)),
                 "tgp_to_dense_batch_sorted_f32")
         return out.view((num_graphs, max_nodes) + tuple(x.shape[1:])), mask
+    if also_zero is not None:
+        also_zero.zero_()
     N.check(N.lib().tgp_to_dense_batch_f32(N.ptr(x2), x2.size(0), F, N.ptr(batch), N.ptr(ptr), num_graphs, max_nodes,
                                            N.ptr(out), N.ptr(mask), N.stream_ptr(dev)), "tgp_to_dense_batch_f32")
     return out.view((num_graphs, max_nodes) + tuple(x.shape[1:])), mask

@@ -256,6 +256,12 @@ class DenseSRCPooling(SRCPooling):
             adj = self.preprocessing_cache
         else:
             ei, ew = connectivity_to_edge_index(edge_index, edge_weight)
+            fused = self._densify_together(x, ei, ew, batch, max_num_nodes, batch_size)
+            if fused is not None:  # x, mask and the zero-filled adjacency in one launch, the edge scatter behind it
+                x, adj, mask = fused
+                if use_cache:
+                    self.preprocessing_cache = adj
+                return x, adj, mask
             # adj_transpose (src.py:442-443): the HIP kernel writes A^T directly; the torch path (host
             # tensors / autograd through edge weights) returns the transposed view the reference builds
             adj = to_dense_adj(ei, batch, ew, max_num_nodes, batch_size, transposed=self.adj_transpose)
@@ -263,6 +269,27 @@ class DenseSRCPooling(SRCPooling):
                 self.preprocessing_cache = adj
         x, mask = to_dense_batch(x, batch, max_num_nodes, batch_size)
         return x, adj, mask
+
+    def _densify_together(self, x, ei, ew, batch, max_num_nodes, batch_size):
+        """Device batches with a sorted batch vector: to_dense_batch's launch also zero-fills the [B,Nmax,Nmax] buffer
+        that to_dense_adj's edge scatter then adds into (three launches -> two in front of every dense pooler call;
+        a dependent launch costs ~5 us here whatever it does).  None: the general functions above take the case."""
+        if not (isinstance(x, Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and batch is not None
+                and batch.numel() == x.size(0) and x.size(0) > 0 and x.size(1) > 0 and isinstance(ei, Tensor)
+                and ei.is_cuda and (ew is None or (ew.dim() == 1 and ew.dtype == torch.float32))):
+            return None
+        from .utils.ops import batch_info
+        info = batch_info(batch)
+        if not info.is_sorted:
+            return None
+        if batch_size is None:
+            batch_size = num_graphs_of(batch)
+        _, ptr = graph_ptr(batch, batch_size)
+        nmax = max_num_nodes if max_num_nodes is not None else max_graph_size(batch)
+        adj0 = torch.empty(batch_size, nmax, nmax, dtype=torch.float32, device=x.device)
+        xd, mask = Fn.to_dense_batch(x, batch, ptr, batch_size, nmax, also_zero=adj0)
+        adj = Fn.to_dense_adj(ei, ew, batch, ptr, batch_size, nmax, self.adj_transpose, zeroed_out=adj0)
+        return xd, adj, mask
 
     def _ensure_batched_inputs(self, x, edge_index, edge_weight, batch, mask, use_cache: Optional[bool] = None):
         if edge_index is None:
