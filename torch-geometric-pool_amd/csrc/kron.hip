@@ -1043,7 +1043,10 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
   std::unique_lock<std::mutex> side_lock(g_kron_side_mutex, std::defer_lock);
   KronSide* side = nullptr;
   hipStream_t lds_stream = stream;
-  if (has_big) {
+  // Off unless TGP_KRON_SIDE_STREAM=1: measured 0.89 -> 0.86 ms when it works, but in some processes the second hardware
+  // queue makes the whole call 3-4 ms (queue-to-queue hand-offs of hundreds of microseconds): not worth the risk.
+  static const int use_side = getenv("TGP_KRON_SIDE_STREAM") ? atoi(getenv("TGP_KRON_SIDE_STREAM")) : 0;
+  if (has_big && use_side) {
     side_lock.lock();  // (the fork / join events are shared by the callers of one device)
     side = kron_side();
     if (side && hipEventRecord(side->fork, stream) == hipSuccess &&
