@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10010 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10013 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -297,6 +297,24 @@ int tgp_graclus_match_start(const int64_t* row, const int64_t* col, const float*
                             int64_t* label, void* stream);
 int tgp_graclus_match_rounds(const int32_t* row_ptr, int64_t num_nodes, int64_t num_edges, void* ws, int rounds,
                              unsigned int* matched, int64_t* label, void* stream);
+/* All rounds of every graph in ONE launch (instead of tgp_graclus_match_rounds, after tgp_graclus_match_start) for a
+ * batch whose graphs own contiguous node ranges graph_ptr[b] .. graph_ptr[b+1] of at most
+ * tgp_graclus_match_max_graph_nodes() nodes: one workgroup per graph, the matching the device-wide rounds give.
+ * max_graph_nodes: the caller's bound on the longest graph (64 or less: one wave per graph).
+ * *d_status != 0: not applicable (1: a graph longer than the bound, 2: an entry that leaves its graph); the caller
+ * then runs tgp_graclus_match_start + _rounds again. */
+int tgp_graclus_match_max_graph_nodes(void);
+int tgp_graclus_match_graphs(const int32_t* row_ptr, int64_t num_nodes, int64_t num_edges, void* ws,
+                             const int64_t* graph_ptr, int64_t num_graphs, int64_t max_graph_nodes, int64_t* label,
+                             int* d_status, void* stream);
+/* Matching labels -> consecutive cluster ids, the torch.unique(cluster, return_inverse=True) of the reference's
+ * select/graclus_select.py:66-70 without a sort (representatives label[r] == r keep their order, which is the order
+ * unique() gives: the label of a pair is its smaller node id).  index_out [2, N] int64: row 0 = 0..N-1, row 1 = ids;
+ * *d_k = number of ids.  N <= tgp_graclus_relabel_max_nodes(). */
+int64_t tgp_graclus_relabel_max_nodes(void);
+size_t tgp_graclus_relabel_workspace_bytes(int64_t num_nodes);
+int tgp_graclus_relabel_i64(const int64_t* label, int64_t num_nodes, void* ws, size_t ws_bytes, int64_t* index_out,
+                            int64_t* d_k, void* stream);
 
 /* TopkSelect scoring (select/topk_select.py:176, score = (x * w).sum(-1)): out[i] = <x[i,:], w>, one pass over
  * x [N,F] (row stride ldx); and the matching weight gradient out[f] = sum_i g[i] x[i,f] (fixed-order two-level

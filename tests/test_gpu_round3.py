@@ -975,3 +975,129 @@ def test_densify_together_equals_the_separate_functions(dev, transposed):
     torch.testing.assert_close(adj, adj2, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(gx, x.grad, rtol=0, atol=0)
     torch.testing.assert_close(gw, ew.grad, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------ Graclus: all rounds of a batch in one launch
+def _graph_batch(sizes, deg, seed, dev, weights="rand"):
+    g = torch.Generator().manual_seed(seed)
+    rows, cols, off = [], [], 0
+    for n in sizes:
+        if n >= 2:
+            m = max(1, int(n * deg / 2))
+            a = torch.randint(0, n, (m,), generator=g)
+            b = torch.randint(0, n, (m,), generator=g)
+            keep = a != b
+            a, b = a[keep] + off, b[keep] + off
+            rows += [a, b]
+            cols += [b, a]
+        off += n
+    if rows:
+        ei = torch.stack([torch.cat(rows), torch.cat(cols)])
+        ei = torch.unique(ei[0] * off + ei[1])
+        ei = torch.stack([ei // off, ei % off])
+    else:
+        ei = torch.zeros(2, 0, dtype=torch.long)
+    if weights == "rand":
+        half = torch.rand(off * off if off < 300 else 1, generator=g)
+        lo, hi = torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])
+        ew = (torch.sin((lo * 7919 + hi * 104729).double()) * 0.5 + 0.6).float()   # symmetric, many distinct values
+        del half
+    elif weights == "ties":
+        ew = torch.ones(ei.size(1))
+    else:
+        ew = None
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    ptr = torch.zeros(len(sizes) + 1, dtype=torch.long)
+    ptr[1:] = torch.cumsum(torch.tensor(sizes), 0)
+    return ei.to(dev), (ew.to(dev) if ew is not None else None), batch.to(dev), ptr.to(dev), off
+
+
+@pytest.mark.parametrize("sizes,deg,weights", [
+    ([39] * 64, 3.7, "rand"), ([5, 1, 0, 17, 300, 2, 1024, 64, 1, 1], 4.0, "rand"), ([620, 7, 1000], 12.0, "ties"),
+    ([30] * 200, 2.0, None), ([1, 1, 1], 1.0, "rand"), ([900], 30.0, "rand"),
+])
+def test_graclus_per_graph_rounds_equal_the_device_wide_rounds(dev, sizes, deg, weights):
+    """tgp_graclus_match_graphs (one workgroup per graph, every round in one launch) gives the very labels the
+    device-wide propose / match rounds give (graphs do not interact; same edge key)."""
+    from tgp import kernels
+    ei, ew, batch, ptr, n = _graph_batch(sizes, deg, 11, dev, weights)
+    want = kernels.graclus_match(ei, ew, n)
+    got = kernels.graclus_match(ei, ew, n, graph_ptr=ptr, max_graph_nodes=max(sizes))
+    assert torch.equal(got, want)
+    # maximal matching, in range, symmetric (the contract test_native_graclus_matching_contract states)
+    lab = got.cpu()
+    pair_free = torch.bincount(lab, minlength=n)[lab] == 1
+    r, c = ei.cpu()
+    assert not bool((pair_free[r] & pair_free[c] & (r != c)).any())
+
+
+def test_graclus_per_graph_rounds_refuse_what_they_cannot_do(dev, monkeypatch):
+    """An entry that leaves its graph, or a graph longer than the declared bound, raises the status word and the
+    device-wide rounds run from a fresh start: same labels as without the graph offsets."""
+    from tgp import kernels, _native as N
+    ei, ew, batch, ptr, n = _graph_batch([40, 50, 60], 4.0, 5, dev)
+    cross = torch.tensor([[3, 95], [95, 3]], device=dev)
+    ei2 = torch.cat([ei, cross], 1)
+    ew2 = torch.cat([ew, torch.tensor([9.0, 9.0], device=dev)])
+    want = kernels.graclus_match(ei2, ew2, n)
+    got = kernels.graclus_match(ei2, ew2, n, graph_ptr=ptr, max_graph_nodes=60)
+    assert torch.equal(got, want) and int(got[95]) == 3
+    # a wrong (too small) declared bound is caught by the kernel itself
+    big = N.lib().tgp_graclus_match_max_graph_nodes()
+    ei3, ew3, _, ptr3, n3 = _graph_batch([big + 1, 10], 3.0, 6, dev)
+    want = kernels.graclus_match(ei3, ew3, n3)
+    got = kernels.graclus_match(ei3, ew3, n3, graph_ptr=ptr3, max_graph_nodes=10)
+    assert torch.equal(got, want)
+    # and a batch with such a graph never reaches the per-graph entry when the bound is honest
+    called = []
+    real = N.lib().tgp_graclus_match_graphs
+    monkeypatch.setattr(N.lib(), "tgp_graclus_match_graphs", lambda *a: called.append(1) or real(*a))
+    kernels.graclus_match(ei3, ew3, n3, graph_ptr=ptr3, max_graph_nodes=big + 1)
+    assert not called
+
+
+def test_graclus_pooler_with_a_batch_vector_takes_the_per_graph_rounds(dev, monkeypatch):
+    from tgp import _native as N
+    from tgp.poolers import get_pooler
+    ei, ew, batch, ptr, n = _graph_batch([39] * 32, 3.7, 3, dev)
+    x = torch.randn(n, 8, device=dev)
+    pooler = get_pooler("graclus").to(dev)
+    called = []
+    real = N.lib().tgp_graclus_match_graphs
+    monkeypatch.setattr(N.lib(), "tgp_graclus_match_graphs", lambda *a: called.append(1) or real(*a))
+    out_b = pooler(x=x, adj=ei, edge_weight=ew, batch=batch)
+    assert called
+    so_plain = pooler.select(edge_index=ei, edge_weight=ew, num_nodes=n)
+    assert torch.equal(out_b.so.cluster_index, so_plain.cluster_index)
+    # an unsorted batch vector keeps the device-wide rounds
+    called.clear()
+    perm = torch.randperm(n, device=dev)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n, device=dev)
+    pooler(x=x[perm], adj=inv[ei], edge_weight=ew, batch=batch[perm])
+    assert not called
+
+
+@pytest.mark.parametrize("n", [0, 1, 31, 1024, 1025, 70_001, 2_100_000])
+def test_graclus_relabel_kernel_equals_unique_inverse(dev, n):
+    """tgp_graclus_relabel_i64 = torch.unique(label, return_inverse=True) (graclus_select.py:68) for matching labels
+    (label[i] = min(i, partner))."""
+    from tgp import _native as N
+    g = torch.Generator().manual_seed(n)
+    perm = torch.randperm(n, generator=g)
+    label = torch.arange(n)
+    m = (n // 3) * 2
+    a, b = perm[:m:2], perm[1:m:2]
+    lo = torch.minimum(a, b)
+    label[a] = lo
+    label[b] = lo
+    ids, inverse = torch.unique(label, sorted=True, return_inverse=True)
+    label = label.to(dev)
+    L = N.lib()
+    index = torch.full((2, n), -1, dtype=torch.int64, device=dev)
+    k = torch.full((1,), -1, dtype=torch.int64, device=dev)
+    ws = N.workspace(L.tgp_graclus_relabel_workspace_bytes(n), dev)
+    N.check(L.tgp_graclus_relabel_i64(N.ptr(label), n, N.ptr(ws), ws.numel(), N.ptr(index), N.ptr(k),
+                                      N.stream_ptr(dev)), "relabel")
+    assert int(k) == ids.numel()
+    assert torch.equal(index[0].cpu(), torch.arange(n)) and torch.equal(index[1].cpu(), inverse)

@@ -261,9 +261,234 @@ __global__ __launch_bounds__(256) void gm_match_kernel(const int32_t* __restrict
   if (__ballot(hit) && lane_id() == 0) *matched = 1u;
 }
 
+// Batches of graphs of at most GM_GRAPH_MAX nodes with a sorted batch vector: ONE workgroup per graph runs ALL the
+// propose / match rounds of its graph in one launch (graphs do not interact, so the matching is the one the device-wide
+// rounds give; the workgroup barrier replaces the launch boundary).  A PROTEINS-shaped batch took 6 rounds x 3 launches
+// and two host read-backs of the "anything matched" flags; an entry that leaves the graph raises *status (the caller
+// takes the device-wide rounds then).
+constexpr int GM_GRAPH_MAX = 1024;
+constexpr int GM_GRAPH_LDS_E = 2048;  // entries of a graph's CSR kept in LDS (16 KB: six workgroups per CU)
+
+// The rounds of one graph.  `ptr`, `nb`, `wv` are indexed with GLOBAL node ids / entry offsets (LDS copies come shifted),
+// free flags and candidates live in LDS under local ids.
+template <int T, typename P, typename NB, typename WV>
+__device__ __forceinline__ void gm_graph_rounds(P ptr, NB nb, WV wv, int64_t p0, int n, uint8_t* s_free, int32_t* s_cand,
+                                                int64_t* __restrict__ label) {
+  for (int t = threadIdx.x; t < n; t += T) s_free[t] = 1;
+  __syncthreads();
+  for (int round = 0; round < 2 * GM_GRAPH_MAX; ++round) {  // (a round matches at least one pair while a free edge exists)
+    for (int t = threadIdx.x; t < n; t += T) {
+      int32_t c = -1;
+      if (s_free[t]) {
+        c = gm_best_neighbour(p0 + t, ptr, nb, wv, [&](int32_t j) { return s_free[j - p0] != 0; });
+        if (c < 0) s_free[t] = 0;  // retire (see gm_propose_kernel); nobody adjacent is free, so nobody reads this flag
+      }
+      s_cand[t] = c;
+    }
+    __syncthreads();
+    bool hit = false;
+    for (int t = threadIdx.x; t < n; t += T) {
+      const int32_t j = s_cand[t];
+      const int32_t i = static_cast<int32_t>(p0) + t;
+      if (j >= 0 && s_cand[j - p0] == i) {
+        label[p0 + t] = i < j ? i : j;
+        s_free[t] = 0;  // (own flag; this step reads candidates only, the barrier below orders it before the next scan)
+        hit = true;
+      }
+    }
+    if (!__syncthreads_or(hit ? 1 : 0)) break;
+  }
+}
+
+// T threads per graph (64 when the batch's longest graph fits one wave: the barriers cost nothing and a CU holds 32
+// graphs); LDS: offsets [cap_n + 1], candidates [cap_n], CSR entries 2 x [cap_e], flags [cap_n] bytes.
+template <int T>
+__global__ __launch_bounds__(T) void gm_graph_rounds_kernel(const int32_t* __restrict__ row_ptr,
+                                                            const int32_t* __restrict__ nbr,
+                                                            const float* __restrict__ wt,
+                                                            const int64_t* __restrict__ graph_ptr, int cap_n, int cap_e,
+                                                            int64_t* __restrict__ label, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) int32_t gm_lds[];
+  int32_t* s_ptr = gm_lds;
+  int32_t* s_cand = s_ptr + cap_n + 1;
+  int32_t* s_nbr = s_cand + cap_n;
+  float* s_wt = reinterpret_cast<float*>(s_nbr + cap_e);
+  uint8_t* s_free = reinterpret_cast<uint8_t*>(s_wt + cap_e);
+  const int64_t p0 = graph_ptr[blockIdx.x], p1 = graph_ptr[blockIdx.x + 1];
+  const int n = static_cast<int>(p1 - p0);
+  if (n <= 0) return;
+  if (n > cap_n) {
+    if (threadIdx.x == 0) atomicOr(status, 1);
+    return;
+  }
+  for (int t = threadIdx.x; t <= n; t += T) s_ptr[t] = row_ptr[p0 + t];
+  const int32_t e0 = row_ptr[p0], e1 = row_ptr[p1];
+  const bool in_lds = e1 - e0 <= cap_e;
+  bool out = false;  // entries must stay inside the graph (the rounds read the neighbours' flags without a range test)
+  for (int32_t e = e0 + threadIdx.x; e < e1; e += T) {
+    const int32_t j = nbr[e];
+    out = out || (j >= 0 && (j < p0 || j >= p1));  // (-1: an entry the symmetrisation dropped)
+    if (in_lds) {
+      s_nbr[e - e0] = j;
+      s_wt[e - e0] = wt[e];
+    }
+  }
+  if (__syncthreads_or(out ? 1 : 0)) {
+    if (threadIdx.x == 0) atomicOr(status, 2);
+    return;
+  }
+  if (in_lds) gm_graph_rounds<T>(s_ptr - p0, s_nbr - e0, s_wt - e0, p0, n, s_free, s_cand, label);
+  else gm_graph_rounds<T>(s_ptr - p0, nbr, wt, p0, n, s_free, s_cand, label);
+}
+
+// ---- labels -> consecutive cluster ids (the torch.unique(return_inverse=True) of select/graclus_select.py:68) -------
+// A representative is a node with label[i] == i; its id is the number of representatives before it, and every node takes
+// the id of its label.  Two launches, no sort: 1024-node tiles write their flag words, the running popcount of the words
+// inside the tile and the tile total; the second launch scans the (few) tile totals in LDS in every workgroup and looks
+// the rank of label[i] up as tile prefix + word prefix + popcount of the lower bits.
+constexpr int RL_TILE = 1024;
+constexpr int RL_MAX_TILES = 8192;  // tile prefixes held in LDS (32 KB): 8.4 M nodes
+__global__ __launch_bounds__(256) void rl_flags_kernel(const int64_t* __restrict__ label, int64_t n,
+                                                       uint32_t* __restrict__ bits, uint32_t* __restrict__ wprefix,
+                                                       uint32_t* __restrict__ tile_sum) {
+  __shared__ uint32_t pc[32];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * RL_TILE;
+  const int w = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    const unsigned long long m = __ballot(i < n && label[i] == i);
+    if (lane_id() == 0) {
+      const int q = r * 8 + w * 2;
+      const uint32_t lo = static_cast<uint32_t>(m), hi = static_cast<uint32_t>(m >> 32);
+      bits[(base >> 5) + q] = lo;
+      bits[(base >> 5) + q + 1] = hi;
+      pc[q] = __popc(lo);
+      pc[q + 1] = __popc(hi);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    uint32_t before = 0;
+    for (int q = 0; q < static_cast<int>(threadIdx.x); ++q) before += pc[q];
+    wprefix[(base >> 5) + threadIdx.x] = before;
+    if (threadIdx.x == 31) tile_sum[blockIdx.x] = before + pc[31];
+  }
+}
+
+__global__ __launch_bounds__(256) void rl_assign_kernel(const int64_t* __restrict__ label, int64_t n,
+                                                        const uint32_t* __restrict__ bits,
+                                                        const uint32_t* __restrict__ wprefix,
+                                                        const uint32_t* __restrict__ tile_sum, int tiles,
+                                                        int64_t* __restrict__ index_out, int64_t* __restrict__ d_k) {
+  __shared__ uint32_t s_tp[RL_MAX_TILES];
+  __shared__ uint32_t s_part[256];
+  // exclusive scan of the tile totals: thread t owns a contiguous run of `per` tiles
+  const int per = (tiles + 255) / 256;
+  uint32_t mine = 0;
+  for (int q = 0; q < per; ++q) {
+    const int t = threadIdx.x * per + q;
+    mine += t < tiles ? tile_sum[t] : 0u;
+  }
+  s_part[threadIdx.x] = mine;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const uint32_t v = static_cast<int>(threadIdx.x) >= d ? s_part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    s_part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = s_part[threadIdx.x] - mine;
+  for (int q = 0; q < per; ++q) {
+    const int t = threadIdx.x * per + q;
+    if (t < tiles) {
+      s_tp[t] = run;
+      run += tile_sum[t];
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d_k = static_cast<int64_t>(s_part[255]);
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * RL_TILE;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i >= n) continue;
+    int64_t j = label[i];
+    j = j < 0 ? 0 : (j >= n ? n - 1 : j);  // (the matcher's labels are in range; a caller's might not be)
+    const uint32_t word = bits[j >> 5];
+    const uint32_t rank = s_tp[j >> 10] + wprefix[j >> 5] + __popc(word & ((1u << (j & 31)) - 1u));
+    index_out[i] = i;
+    index_out[n + i] = static_cast<int64_t>(rank);
+  }
+}
+
 }  // namespace tgp
 
 using namespace tgp;
+
+extern "C" int64_t tgp_graclus_relabel_max_nodes(void) { return static_cast<int64_t>(RL_TILE) * RL_MAX_TILES; }
+
+extern "C" size_t tgp_graclus_relabel_workspace_bytes(int64_t num_nodes) {
+  const size_t tiles = static_cast<size_t>(cdiv(num_nodes > 0 ? num_nodes : 1, RL_TILE));
+  return 2 * align_up(tiles * 32 * sizeof(uint32_t)) + align_up(tiles * sizeof(uint32_t)) + 256;
+}
+
+// index_out[0][i] = i, index_out[1][i] = consecutive id of label[i] (ids in the order of the representatives
+// label[r] == r), *d_k = number of ids: the indices of the [N, K] assignment the selector returns.
+extern "C" int tgp_graclus_relabel_i64(const int64_t* label, int64_t num_nodes, void* ws, size_t ws_bytes,
+                                       int64_t* index_out, int64_t* d_k, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(num_nodes >= 0 && d_k, TGP_ERR_INVALID, "tgp_graclus_relabel_i64: bad argument");
+  if (num_nodes == 0) {
+    (void)hipMemsetAsync(d_k, 0, sizeof(int64_t), stream);
+    return check_launch("tgp_graclus_relabel_i64");
+  }
+  TGP_REQUIRE(num_nodes <= tgp_graclus_relabel_max_nodes(), TGP_ERR_RANGE, "tgp_graclus_relabel_i64: too many nodes");
+  TGP_REQUIRE(label && index_out && ws && ws_bytes >= tgp_graclus_relabel_workspace_bytes(num_nodes),
+              TGP_ERR_WORKSPACE, "tgp_graclus_relabel_i64: null pointer / workspace too small");
+  const int tiles = static_cast<int>(cdiv(num_nodes, RL_TILE));
+  Carver cv(ws);
+  uint32_t* bits = cv.take<uint32_t>(static_cast<int64_t>(tiles) * 32);
+  uint32_t* wprefix = cv.take<uint32_t>(static_cast<int64_t>(tiles) * 32);
+  uint32_t* tile_sum = cv.take<uint32_t>(tiles);
+  hipLaunchKernelGGL(rl_flags_kernel, dim3(tiles), dim3(256), 0, stream, label, num_nodes, bits, wprefix, tile_sum);
+  hipLaunchKernelGGL(rl_assign_kernel, dim3(tiles), dim3(256), 0, stream, label, num_nodes, bits, wprefix, tile_sum,
+                     tiles, index_out, d_k);
+  return check_launch("tgp_graclus_relabel_i64");
+}
+
+extern "C" int tgp_graclus_match_max_graph_nodes(void) { return GM_GRAPH_MAX; }
+
+// All rounds of every graph in one launch (after tgp_graclus_match_start, instead of tgp_graclus_match_rounds), for a
+// batch whose graphs own contiguous node ranges graph_ptr[b] .. graph_ptr[b+1] of at most
+// tgp_graclus_match_max_graph_nodes() nodes (max_graph_nodes: the caller's bound on the longest graph, which picks
+// the workgroup size).  *d_status != 0: not applicable (a graph longer than the bound: 1, an entry that leaves
+// its graph: 2) -- the labels are then partial and the caller runs tgp_graclus_match_rounds from a fresh start.
+extern "C" int tgp_graclus_match_graphs(const int32_t* row_ptr, int64_t num_nodes, int64_t num_edges, void* ws,
+                                        const int64_t* graph_ptr, int64_t B, int64_t max_graph_nodes, int64_t* label,
+                                        int* d_status, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(num_nodes >= 0 && num_edges >= 0 && B >= 0 && d_status, TGP_ERR_INVALID,
+              "tgp_graclus_match_graphs: bad argument");
+  TGP_REQUIRE(max_graph_nodes <= GM_GRAPH_MAX, TGP_ERR_RANGE, "tgp_graclus_match_graphs: graphs too long");
+  (void)hipMemsetAsync(d_status, 0, sizeof(int), stream);
+  if (num_nodes == 0 || B == 0) return check_launch("tgp_graclus_match_graphs");
+  TGP_REQUIRE(row_ptr && ws && graph_ptr && label && B < (1ll << 31), TGP_ERR_INVALID,
+              "tgp_graclus_match_graphs: null pointer");
+  Carver cv(ws);
+  int32_t* nbr = cv.take<int32_t>(num_edges > 0 ? num_edges : 1);
+  float* wt = cv.take<float>(num_edges > 0 ? num_edges : 1);
+  const bool one_wave = max_graph_nodes <= 64;
+  const int cap_n = one_wave ? 64 : GM_GRAPH_MAX, cap_e = one_wave ? 512 : GM_GRAPH_LDS_E;
+  const size_t lds = (static_cast<size_t>(cap_n) * 2 + 1 + 2 * cap_e) * 4 + cap_n;
+  if (one_wave)
+    hipLaunchKernelGGL(gm_graph_rounds_kernel<64>, dim3(static_cast<unsigned>(B)), dim3(64), lds, stream, row_ptr, nbr,
+                       wt, graph_ptr, cap_n, cap_e, label, d_status);
+  else
+    hipLaunchKernelGGL(gm_graph_rounds_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, row_ptr, nbr,
+                       wt, graph_ptr, cap_n, cap_e, label, d_status);
+  return check_launch("tgp_graclus_match_graphs");
+}
 
 extern "C" size_t tgp_graclus_match_workspace_bytes(int64_t num_nodes, int64_t num_edges) {
   const size_t n = static_cast<size_t>(num_nodes > 0 ? num_nodes : 1), e = static_cast<size_t>(num_edges > 0 ? num_edges : 1);

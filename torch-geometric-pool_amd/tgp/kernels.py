@@ -685,13 +685,20 @@ def _rows_sorted(edge_index: Tensor, row: Tensor) -> bool:
 
 
 def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
-                  max_rounds: Optional[int] = None, return_row_ptr: bool = False):
+                  max_rounds: Optional[int] = None, return_row_ptr: bool = False,
+                  graph_ptr: Optional[Tensor] = None, max_graph_nodes: Optional[int] = None,
+                  relabel: bool = False):
     """label[i] = min(i, partner) of a heavy-edge maximal matching (select/graclus_select.py:66 ->
     torch_cluster.graclus_cluster): handshake rounds on the device until a round matches nothing, however many that
     takes (a path with monotone weights matches one pair per round: n/2 rounds; torch_cluster iterates until done
     too).  ``max_rounds`` bounds the loop for callers that accept a non-maximal matching; if it is hit a
     RuntimeWarning says so.  ``return_row_ptr``: also return the int32 CSR offsets [num_nodes + 1] of the list when
-    it is row-sorted (else None) -- the matcher builds them anyway and SparseConnect can reuse them."""
+    it is row-sorted (else None) -- the matcher builds them anyway and SparseConnect can reuse them.
+    ``graph_ptr`` [B+1] / ``max_graph_nodes``: node offsets of the graphs of a sorted batch and its longest graph; when
+    every graph fits one workgroup all rounds of all graphs run as ONE launch (same matching).
+    ``relabel``: return ``(index [2, N], K)`` instead of the labels -- row 0 = 0..N-1, row 1 = the consecutive cluster id
+    of every node (``torch.unique(label, return_inverse=True)[1]``, graclus_select.py:68) from two more launches, its
+    count read back together with the matcher's status word."""
     dev = N.require_device(edge_index, edge_weight)
     row, col = _edge_rows(edge_index)
     E = row.numel()
@@ -710,10 +717,41 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
         index = build_assign_index(row, num_nodes)
         row_ptr, perm = index.row_ptr, index.perm
     ws = N.workspace(L.tgp_graclus_match_workspace_bytes(num_nodes, E), dev)
-    N.check(L.tgp_graclus_match_start(N.ptr(row), N.ptr(col), N.ptr(w), N.ptr(row_ptr), N.ptr(perm), num_nodes, E,
-                                      N.ptr(ws), ws.numel(), N.ptr(label), st), "tgp_graclus_match_start")
-    done, step = 0, 6  # late rounds are cheap (free nodes are packed before scanning): prefer fewer round trips
     finished = num_nodes == 0 or E == 0
+    words = torch.empty(4, dtype=torch.int32, device=dev)  # [status, -, K (int64)]
+
+    def relabelled():
+        index = torch.empty(2, num_nodes, dtype=torch.int64, device=dev)
+        rws = N.workspace(L.tgp_graclus_relabel_workspace_bytes(num_nodes), dev)
+        N.check(L.tgp_graclus_relabel_i64(N.ptr(label), num_nodes, N.ptr(rws), rws.numel(), N.ptr(index),
+                                          N.ptr(words[2:]), st), "tgp_graclus_relabel_i64")
+        return index
+
+    def finish(index=None, k=None):
+        out = label
+        if relabel:
+            if index is None:
+                index = relabelled()
+                k = words.tolist()[2]
+            out = (index, int(k))
+        return (out, sorted_ptr) if return_row_ptr else out
+
+    def start():
+        N.check(L.tgp_graclus_match_start(N.ptr(row), N.ptr(col), N.ptr(w), N.ptr(row_ptr), N.ptr(perm), num_nodes, E,
+                                          N.ptr(ws), ws.numel(), N.ptr(label), st), "tgp_graclus_match_start")
+    start()
+    if (not finished and max_rounds is None and graph_ptr is not None and max_graph_nodes is not None
+            and max_graph_nodes <= L.tgp_graclus_match_max_graph_nodes() and graph_ptr.numel() >= 2):
+        gp = N.i64c(graph_ptr)
+        N.check(L.tgp_graclus_match_graphs(N.ptr(row_ptr), num_nodes, E, N.ptr(ws), N.ptr(gp), gp.numel() - 1,
+                                           int(max_graph_nodes), N.ptr(label), N.ptr(words), st),
+                "tgp_graclus_match_graphs")
+        index = relabelled() if relabel else None  # (optimistic: one round trip for the status word and the count)
+        got = words.tolist()
+        if got[0] == 0:
+            return finish(index, got[2])
+        start()  # an entry that leaves its graph (or a longer graph than declared): the device-wide rounds, from scratch
+    done, step = 0, 6  # late rounds are cheap (free nodes are packed before scanning): prefer fewer round trips
     while not finished and (max_rounds is None or done < max_rounds):
         if max_rounds is not None:
             step = min(step, max_rounds - done)
@@ -729,7 +767,7 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
         import warnings
         warnings.warn(f"graclus_match stopped after max_rounds={max_rounds} rounds: the matching is not maximal",
                       RuntimeWarning)
-    return (label, sorted_ptr) if return_row_ptr else label
+    return finish()
 
 
 def _rows_f32(x: Tensor) -> Tensor:

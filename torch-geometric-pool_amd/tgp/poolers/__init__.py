@@ -91,7 +91,7 @@ class GraclusPooling(BasePrecoarseningMixin, SRCPooling):
                 **kwargs):
         if lifting:
             return self.lift(x_pool=x, so=so)
-        so = self.select(edge_index=adj, edge_weight=edge_weight, num_nodes=x.size(0))
+        so = self.select(edge_index=adj, edge_weight=edge_weight, num_nodes=x.size(0), batch=batch)
         x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch)
         ei, ew = self.connect(edge_index=adj, so=so, edge_weight=edge_weight, batch_pooled=batch_pool)
         return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so)

@@ -684,14 +684,26 @@ class GraclusSelect(Select):
         num_nodes = maybe_num_nodes(edge_index, num_nodes)
         if edge_index.is_cuda:
             # native matching + scan-based relabelling (no sort): representatives keep their relative order
-            from .. import kernels
-            pair, row_ptr = kernels.graclus_match(edge_index, edge_weight, num_nodes, return_row_ptr=True)
-            nodes = torch.arange(num_nodes, device=pair.device)
-            rank = torch.cumsum(pair == nodes, 0) - 1
-            assignment = rank[pair]
-            k = int(rank[-1]) + 1 if num_nodes else 0
-            s = torch.sparse_coo_tensor(torch.stack([nodes, assignment]), torch.ones(num_nodes, device=pair.device),
-                                        size=(num_nodes, k), is_coalesced=True)
+            from .. import kernels, _native as N
+            gptr = gmax = None
+            batch = kwargs.get("batch")
+            if isinstance(batch, Tensor) and batch.is_cuda and batch.numel() == num_nodes and num_nodes > 0:
+                from ..utils.ops import batch_info
+                info = batch_info(batch)  # (memoised per batch vector)
+                if info.is_sorted:
+                    gptr, gmax = info.ptr, info.max_nodes
+            if num_nodes <= N.lib().tgp_graclus_relabel_max_nodes():
+                (index, k), row_ptr = kernels.graclus_match(edge_index, edge_weight, num_nodes, return_row_ptr=True,
+                                                            graph_ptr=gptr, max_graph_nodes=gmax, relabel=True)
+            else:
+                pair, row_ptr = kernels.graclus_match(edge_index, edge_weight, num_nodes, return_row_ptr=True,
+                                                      graph_ptr=gptr, max_graph_nodes=gmax)
+                nodes = torch.arange(num_nodes, device=pair.device)
+                rank = torch.cumsum(pair == nodes, 0) - 1
+                index = torch.stack([nodes, rank[pair]])
+                k = int(rank[-1]) + 1 if num_nodes else 0
+            s = torch.sparse_coo_tensor(index, torch.ones(num_nodes, device=index.device), size=(num_nodes, k),
+                                        is_coalesced=True)
             so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
             if row_ptr is not None:
                 # CSR offsets of the (row-sorted) list the matcher walked: SparseConnect skips its own pass over the
