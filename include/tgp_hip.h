@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10013 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10014 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -320,6 +320,10 @@ int tgp_graclus_relabel_i64(const int64_t* label, int64_t num_nodes, void* ws, s
  * x [N,F] (row stride ldx); and the matching weight gradient out[f] = sum_i g[i] x[i,f] (fixed-order two-level
  * sum, deterministic). */
 int tgp_row_dot_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const float* w, float* out, void* stream);
+/* The whole ratio-mode score of select/topk_select.py:176-184 in that one pass, for callers that need no gradient:
+ * out[i] = act(<x[i,:], w> / ||w||_2), act 0 = identity ("linear"), 1 = tanh. */
+int tgp_topk_score_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const float* w, int act, float* out,
+                       void* stream);
 size_t tgp_weighted_colsum_workspace_bytes(int64_t F);
 int tgp_weighted_colsum_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const float* g, float* out, void* ws,
                             size_t ws_bytes, void* stream);

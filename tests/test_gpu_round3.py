@@ -1101,3 +1101,32 @@ def test_graclus_relabel_kernel_equals_unique_inverse(dev, n):
                                       N.stream_ptr(dev)), "relabel")
     assert int(k) == ids.numel()
     assert torch.equal(index[0].cpu(), torch.arange(n)) and torch.equal(index[1].cpu(), inverse)
+
+
+@pytest.mark.parametrize("n,F", [(1, 4), (100, 16), (3000, 32), (777, 7), (50, 300), (4096, 128), (20, 1024)])
+@pytest.mark.parametrize("act", ["tanh", "linear"])
+def test_topk_score_kernel_vs_torch(dev, n, F, act):
+    """tgp_topk_score_f32 = act(x.w / ||w||) (topk_select.py:176-184) within 1e-6 of the torch expression; TopkSelect
+    under no_grad takes it and selects the very nodes the differentiable route selects."""
+    from tgp import kernels
+    from tgp.select import TopkSelect
+    g = torch.Generator().manual_seed(n * 31 + F)
+    x = torch.randn(n, F, generator=g).to(dev)
+    sel = TopkSelect(in_channels=F, ratio=0.5, act=act).to(dev)
+    w = sel.weight.detach()
+    want = (x.double() * w.double()).sum(-1) / w.double().norm(p=2, dim=-1)
+    want = torch.tanh(want) if act == "tanh" else want
+    got = kernels.topk_score(x, w, act == "tanh")
+    assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-6)
+    batch = torch.sort(torch.randint(0, 5, (n,), generator=g)).values.to(dev)
+    with torch.no_grad():
+        fused = sel(x, batch=batch)
+    x2 = x.clone().requires_grad_(True)
+    plain = sel(x2, batch=batch)
+    assert plain.s.values().requires_grad
+    a = torch.stack([fused.node_index, fused.cluster_index])
+    b = torch.stack([plain.node_index, plain.cluster_index])
+    if torch.equal(a, b):
+        assert torch.allclose(fused.s.values(), plain.s.values().detach(), rtol=1e-5, atol=1e-6)
+    else:  # a last-place difference may swap two nodes whose scores agree to rounding: same scores, sorted per graph
+        assert torch.allclose(fused.s.values().sort().values, plain.s.values().detach().sort().values, rtol=1e-5, atol=1e-6)

@@ -1,6 +1,8 @@
 """Where the HOST time of a pooler training step goes (cProfile over 300 steps, GPU work left asynchronous).
 
-    python tools/profile_host_step.py [mincut_c3|diff_c3|...] [--forward]
+    python tools/profile_host_step.py [mincut_c3|diff_c3|...] [--forward] [--infer] [--tottime]
+
+--infer: the pooler's forward alone under no_grad, eval mode (any alias of e2e_launches.CASES, sparse poolers included).
 """
 import cProfile
 import os
@@ -23,9 +25,15 @@ if sizes is None:
 x, ei, batch = batch_graphs(sizes, deg, f)
 x.requires_grad_(True)
 pooler = get_pooler(alias, **kw).to(dev).train()
+if "--infer" in sys.argv:
+    pooler.eval()
 
 
 def step():
+    if "--infer" in sys.argv:
+        with torch.no_grad():
+            pooler(x=x, adj=ei, batch=batch)
+        return
     pooler.zero_grad(set_to_none=True)
     x.grad = None
     out = pooler(x=x, adj=ei, batch=batch)

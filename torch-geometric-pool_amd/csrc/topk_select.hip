@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void topk_fill_kernel(const int32_t* __restric
 // G lanes share a row (float4 each when VEC); w lives in registers.
 template <int G, bool VEC>
 __global__ __launch_bounds__(256) void row_dot_kernel(const float* __restrict__ x, int64_t n, int F, int64_t ldx,
-                                                      const float* __restrict__ w, float* __restrict__ out) {
+                                                      const float* __restrict__ w, float* __restrict__ out,
+                                                      int post) {
   constexpr int PER_WAVE = 64 / G;
   constexpr int MAXC = 8;  // column chunks per lane kept in registers (covers F <= G*4*8)
   const int lane = threadIdx.x & 63, sub = lane % G, slot = lane / G;
@@ -188,6 +189,20 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const float* __restrict__ 
     const int k = (VEC ? sub * 4 : sub) + c * STEP;
 #pragma unroll
     for (int j = 0; j < (VEC ? 4 : 1); ++j) wr[c][j] = (k + j < F) ? w[k + j] : 0.f;
+  }
+  float nrm = 1.f;
+  if (post) {  // TopkSelect's score: act(x.w / ||w||_2), act = identity (1) or tanh (2); every lane group sums all of w
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+      for (int j = 0; j < (VEC ? 4 : 1); ++j) sq = fmaf(wr[c][j], wr[c][j], sq);
+    for (int k = (VEC ? sub * 4 : sub) + MAXC * STEP; k < F; k += STEP)
+#pragma unroll
+      for (int j = 0; j < (VEC ? 4 : 1); ++j) sq = fmaf(w[k + j], w[k + j], sq);
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    nrm = sqrtf(sq);
   }
   for (int64_t base = wave * PER_WAVE; base < n; base += nwaves * PER_WAVE) {
     const int64_t i = base + slot;
@@ -213,6 +228,10 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const float* __restrict__ 
     }
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (post) {
+      acc = acc / nrm;
+      if (post == 2) acc = tanhf(acc);
+    }
     if (i < n && sub == 0) out[i] = acc;
   }
 }
@@ -300,11 +319,11 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 
 template <int G, bool VEC>
 static void launch_row_dot(const float* x, int64_t n, int F, int64_t ldx, const float* w, float* out,
-                           hipStream_t stream) {
+                           hipStream_t stream, int post = 0) {
   int64_t blocks = cdiv(n, static_cast<int64_t>(4) * (64 / G));
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL((row_dot_kernel<G, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, x, n, F, ldx,
-                     w, out);
+                     w, out, post);
 }
 
 // k[g] = ceil(ratio * n_g) in fp32 (ratio < 1; exactly PyG's `(ratio * num_nodes.to(float)).ceil()`) or
@@ -514,30 +533,42 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
   return check_launch("tgp_topk_select");
 }
 
-extern "C" int tgp_row_dot_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const float* w, float* out,
-                               void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  TGP_REQUIRE(N >= 0 && F >= 0 && ldx >= F, TGP_ERR_INVALID, "tgp_row_dot_f32: bad size");
+static int row_dot_dispatch(const float* x, int64_t N, int64_t F, int64_t ldx, const float* w, float* out, int post,
+                            hipStream_t stream, const char* who) {
+  TGP_REQUIRE(N >= 0 && F >= 0 && ldx >= F, TGP_ERR_INVALID, "row dot: bad size");
   if (N == 0) return TGP_OK;
-  TGP_REQUIRE(out && (F == 0 || (x && w)), TGP_ERR_INVALID, "tgp_row_dot_f32: null pointer");
-  TGP_REQUIRE(F < (1ll << 31), TGP_ERR_RANGE, "tgp_row_dot_f32: F too large");
+  TGP_REQUIRE(out && (F == 0 || (x && w)), TGP_ERR_INVALID, "row dot: null pointer");
+  TGP_REQUIRE(F < (1ll << 31), TGP_ERR_RANGE, "row dot: F too large");
   const int f = static_cast<int>(F);
   const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
   const int64_t units = vec ? F / 4 : F;
   if (vec) {
-    if (units <= 1) launch_row_dot<1, true>(x, N, f, ldx, w, out, stream);
-    else if (units <= 2) launch_row_dot<2, true>(x, N, f, ldx, w, out, stream);
-    else if (units <= 4) launch_row_dot<4, true>(x, N, f, ldx, w, out, stream);
-    else if (units <= 8) launch_row_dot<8, true>(x, N, f, ldx, w, out, stream);
-    else if (units <= 16) launch_row_dot<16, true>(x, N, f, ldx, w, out, stream);
-    else if (units <= 32) launch_row_dot<32, true>(x, N, f, ldx, w, out, stream);
-    else launch_row_dot<64, true>(x, N, f, ldx, w, out, stream);
+    if (units <= 1) launch_row_dot<1, true>(x, N, f, ldx, w, out, stream, post);
+    else if (units <= 2) launch_row_dot<2, true>(x, N, f, ldx, w, out, stream, post);
+    else if (units <= 4) launch_row_dot<4, true>(x, N, f, ldx, w, out, stream, post);
+    else if (units <= 8) launch_row_dot<8, true>(x, N, f, ldx, w, out, stream, post);
+    else if (units <= 16) launch_row_dot<16, true>(x, N, f, ldx, w, out, stream, post);
+    else if (units <= 32) launch_row_dot<32, true>(x, N, f, ldx, w, out, stream, post);
+    else launch_row_dot<64, true>(x, N, f, ldx, w, out, stream, post);
   } else {
-    if (units <= 4) launch_row_dot<4, false>(x, N, f, ldx, w, out, stream);
-    else if (units <= 16) launch_row_dot<16, false>(x, N, f, ldx, w, out, stream);
-    else launch_row_dot<64, false>(x, N, f, ldx, w, out, stream);
+    if (units <= 4) launch_row_dot<4, false>(x, N, f, ldx, w, out, stream, post);
+    else if (units <= 16) launch_row_dot<16, false>(x, N, f, ldx, w, out, stream, post);
+    else launch_row_dot<64, false>(x, N, f, ldx, w, out, stream, post);
   }
-  return check_launch("tgp_row_dot_f32");
+  return check_launch(who);
+}
+
+extern "C" int tgp_row_dot_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const float* w, float* out,
+                               void* stream_) {
+  return row_dot_dispatch(x, N, F, ldx, w, out, 0, static_cast<hipStream_t>(stream_), "tgp_row_dot_f32");
+}
+
+// TopkSelect's whole score in the same pass (select/topk_select.py:176-184, ratio mode): out[i] = act(<x[i,:], w> /
+// ||w||_2), act = identity (0) or tanh (1); the norm is summed by every wave from the copy of w it holds in registers.
+extern "C" int tgp_topk_score_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const float* w, int act,
+                                  float* out, void* stream_) {
+  TGP_REQUIRE(act == 0 || act == 1, TGP_ERR_INVALID, "tgp_topk_score_f32: act must be 0 (identity) or 1 (tanh)");
+  return row_dot_dispatch(x, N, F, ldx, w, out, 1 + act, static_cast<hipStream_t>(stream_), "tgp_topk_score_f32");
 }
 
 extern "C" size_t tgp_weighted_colsum_workspace_bytes(int64_t F) {

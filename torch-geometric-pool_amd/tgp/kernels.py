@@ -785,6 +785,17 @@ def row_dot(x: Tensor, w: Tensor) -> Tensor:
     return out
 
 
+def topk_score(x: Tensor, w: Tensor, tanh: bool) -> Tensor:
+    """act(x.w / ||w||_2), act = tanh or identity: TopkSelect's ratio-mode score (select/topk_select.py:176-184) in
+    the one pass over x (no gradient: inference and detached inputs)."""
+    dev = N.require_device(x, w)
+    x, w = _rows_f32(x), N.f32c(w.reshape(-1))
+    out = torch.empty(x.size(0), dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_topk_score_f32(N.ptr(x), x.size(0), x.size(1), x.stride(0), N.ptr(w), 1 if tanh else 0,
+                                       N.ptr(out), N.stream_ptr(dev)), "tgp_topk_score_f32")
+    return out
+
+
 def weighted_colsum(x: Tensor, g: Tensor) -> Tensor:
     """out[f] = sum_i g[i] x[i,f]: the weight gradient of :func:`row_dot`."""
     dev = N.require_device(x, g)

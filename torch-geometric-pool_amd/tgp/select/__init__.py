@@ -447,6 +447,9 @@ class TopkSelect(Select):
                              f"'{self.__class__.__name__}'")
         self.in_channels, self.ratio, self.min_score, self.s_inv_op = in_channels, ratio, min_score, s_inv_op
         self.act = (lambda v: v) if act in ("linear", "identity", "none", None) else _resolve_activation(act)
+        # which of the two activations the score kernel knows (None: any other callable / module)
+        self._fused_act = ("linear" if act in ("linear", "identity", "none", None) else
+                           "tanh" if isinstance(act, str) and act.lower() == "tanh" else None)
         if in_channels is None or in_channels <= 1:
             self.register_parameter("weight", None)
         else:
@@ -468,6 +471,13 @@ class TopkSelect(Select):
             score = x.reshape(-1)
         else:
             feats = x.view(-1, 1) if x.dim() == 1 else x
+            if (feats.is_cuda and self.min_score is None and self.ratio is not None and self._fused_act is not None
+                    and feats.dtype == torch.float32 and feats.dim() == 2 and feats.size(0) > 0
+                    and not (torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad))):
+                # nothing to differentiate: dot, norm, division and activation in the one pass over x
+                from .. import kernels
+                score = kernels.topk_score(feats, self.weight.detach(), self._fused_act == "tanh")
+                return self._native_select(score, batch if have_batch else None, x.size(0))
             # x.w in a single native pass over x (the elementwise product + row sum of the reference,
             # topk_select.py:176, writes and re-reads an [N,F] temporary)
             score = Fn.row_dot(feats, self.weight) if feats.is_cuda else (feats * self.weight).sum(dim=-1)
@@ -527,14 +537,19 @@ class TopkSelect(Select):
             sizes, sizes_host, nb, ptr = info.sizes, info.sizes_host, info.num_graphs, info.ptr
             seg_max = info.max_nodes if info.is_sorted else 0
         # k_g exactly as PyG computes it (float32 product, ceil), on the host for the total and on the device
-        # for the kernel -- no round trip
-        hs = torch.tensor(sizes_host, dtype=torch.long)
-        if self.ratio >= 1:
-            k_host = torch.minimum(torch.full_like(hs, int(self.ratio)), hs)
-        else:
-            k_host = (float(self.ratio) * hs.to(torch.float32)).ceil().to(torch.long)
-        k_total = int(k_host.sum())
-        k, koff = kernels.topk_plan(sizes, self.ratio)  # the same arithmetic on the device, one launch
+        # for the kernel -- no round trip; remembered with the batch facts (a loader's batch vector is pooled every epoch
+        # with the same ratio; the host list -> tensor conversion alone was 50 us at 2048 graphs)
+        memo = info.memo if (batch is not None and n) else {}
+        plan = memo.get(("topk", float(self.ratio)))
+        if plan is None:
+            hs = torch.tensor(sizes_host, dtype=torch.long)
+            if self.ratio >= 1:
+                k_host = torch.minimum(torch.full_like(hs, int(self.ratio)), hs)
+            else:
+                k_host = (float(self.ratio) * hs.to(torch.float32)).ceil().to(torch.long)
+            plan = (int(k_host.sum()),) + tuple(kernels.topk_plan(sizes, self.ratio))  # same arithmetic on the device
+            memo[("topk", float(self.ratio))] = plan
+        k_total, k, koff = plan
         node_index, cluster_index, assign = kernels.topk_select(score.detach(), batch, nb, ptr, k, koff, k_total,
                                                                 segments_max_nodes=seg_max)
         values = Fn.take_unique(score, node_index)

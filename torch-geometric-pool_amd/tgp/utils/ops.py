@@ -74,7 +74,8 @@ class BatchInfo:
     valid only while the weak reference still resolves to the very same tensor and its version counter has
     not moved (an in-place write bumps it), which rules out stale hits from recycled memory."""
 
-    __slots__ = ("ref", "version", "num_graphs", "sizes", "sizes_host", "ptr", "max_nodes", "distinct", "is_sorted")
+    __slots__ = ("ref", "version", "num_graphs", "sizes", "sizes_host", "ptr", "max_nodes", "distinct", "is_sorted",
+                 "memo")  # memo: facts derived from the sizes by a caller (e.g. TopkSelect's per-graph k for a ratio)
 
 
 _BATCH_INFO: dict = {}
@@ -86,7 +87,7 @@ def batch_info(batch: Tensor) -> BatchInfo:
     if hit is not None and hit.ref() is batch and hit.version == batch._version:
         return hit
     info = BatchInfo()
-    info.ref, info.version = weakref.ref(batch), batch._version
+    info.ref, info.version, info.memo = weakref.ref(batch), batch._version, {}
     if batch.numel() == 0:
         info.sizes = torch.zeros(0, dtype=torch.long, device=batch.device)
         info.num_graphs, info.max_nodes, info.distinct, info.sizes_host, info.is_sorted = 0, 0, 0, [], True
