@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10014 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10015 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -280,7 +280,8 @@ int tgp_topk_plan(const int64_t* sizes, int64_t B, double ratio, int64_t* k /* [
 size_t tgp_topk_select_workspace_bytes(int64_t N);
 int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t B, const int64_t* ptr,
                     const int64_t* k, const int64_t* koff, int64_t segments_max_nodes, void* ws, size_t ws_bytes,
-                    int64_t* node_index, int64_t* cluster_index, int32_t* assign_perm, void* stream);
+                    int64_t* node_index, int64_t* cluster_index, int32_t* assign_perm,
+                    float* values /* optional [k_total]: score[node_index], the weights of S */, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * A14  GraclusSelect's matching (select/graclus_select.py:62-81 -> torch_cluster 1.6.3 graclus_cluster, absent

@@ -143,7 +143,9 @@ __global__ __launch_bounds__(256) void topk_fill_kernel(const int32_t* __restric
                                                         const uint32_t* __restrict__ offsets,
                                                         int64_t* __restrict__ node_index,
                                                         int64_t* __restrict__ cluster_index,
-                                                        int32_t* __restrict__ assign_perm) {
+                                                        int32_t* __restrict__ assign_perm,
+                                                        const float* __restrict__ score,
+                                                        float* __restrict__ values) {
   __shared__ uint32_t s_cnt[kTopkItems * 4];
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kTopkTile;
   bool flag[kTopkItems];
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(256) void topk_fill_kernel(const int32_t* __restric
     node_index[j] = base + it * 256 + threadIdx.x;
     cluster_index[j] = r[it];
     assign_perm[r[it]] = static_cast<int32_t>(j);
+    if (values) values[j] = score[base + it * 256 + threadIdx.x];
   }
 }
 
@@ -498,7 +501,8 @@ extern "C" size_t tgp_topk_select_workspace_bytes(int64_t N) { return topk_layou
 extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t B, const int64_t* ptr,
                                const int64_t* k, const int64_t* koff, int64_t segments_max_nodes, void* ws,
                                size_t ws_bytes,
-                               int64_t* node_index, int64_t* cluster_index, int32_t* assign_perm, void* stream_) {
+                               int64_t* node_index, int64_t* cluster_index, int32_t* assign_perm, float* values,
+                               void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(N >= 0 && B >= 0, TGP_ERR_INVALID, "tgp_topk_select: negative size");
   if (N == 0 || B == 0) return TGP_OK;
@@ -529,7 +533,7 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
                      static_cast<const int*>(nullptr));
   if (node_index)
     hipLaunchKernelGGL(topk_fill_kernel, dim3(nbt), dim3(256), 0, stream, s.rank_of, N, s.offsets, node_index,
-                       cluster_index, assign_perm);
+                       cluster_index, assign_perm, score, values);
   return check_launch("tgp_topk_select");
 }
 

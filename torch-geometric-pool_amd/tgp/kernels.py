@@ -637,23 +637,24 @@ def topk_plan(sizes: Tensor, ratio: float) -> Tuple[Tensor, Tensor]:
 
 
 def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Tensor, k: Tensor, koff: Tensor,
-                k_total: int, segments_max_nodes: int = 0) -> Tuple[Tensor, Tensor, AssignIndex]:
+                k_total: int, segments_max_nodes: int = 0, with_values: bool = False):
     """Per-graph top-k (select/topk_select.py:194 -> PyG ``topk``) fused with the row sort of SelectOutput
-    (select/base_select.py:58): (node_index ascending, cluster_index, supernode -> assignment index)."""
+    (select/base_select.py:58): (index [2, k_total] = node_index ascending over cluster_index, supernode -> assignment
+    index[, values = score[node_index] when ``with_values``: no gradient])."""
     dev = N.require_device(score, batch, ptr, k, koff)
     score = N.f32c(score.reshape(-1))
     n = score.numel()
-    node_index = torch.empty(k_total, dtype=torch.int64, device=dev)
-    cluster_index = torch.empty(k_total, dtype=torch.int64, device=dev)
+    index = torch.empty(2, k_total, dtype=torch.int64, device=dev)  # the indices of the sparse S, written in place
+    values = torch.empty(k_total, dtype=torch.float32, device=dev) if with_values else None
     perm = torch.empty(max(k_total, 1), dtype=torch.int32, device=dev)
     L = N.lib()
     ws = N.workspace(L.tgp_topk_select_workspace_bytes(n), dev)
     N.check(L.tgp_topk_select(N.ptr(score), N.ptr(None if batch is None else N.i64c(batch)), n, num_graphs,
                               N.ptr(N.i64c(ptr)), N.ptr(N.i64c(k)), N.ptr(N.i64c(koff)), segments_max_nodes, N.ptr(ws),
-                              ws.numel(),
-                              N.ptr(node_index), N.ptr(cluster_index), N.ptr(perm), N.stream_ptr(dev)),
-            "tgp_topk_select")
-    return node_index, cluster_index, AssignIndex(None, perm, k_total, k_total)
+                              ws.numel(), N.ptr(index[0]), N.ptr(index[1]), N.ptr(perm), N.ptr(values),
+                              N.stream_ptr(dev)), "tgp_topk_select")
+    assign = AssignIndex(None, perm, k_total, k_total)
+    return (index, assign, values) if with_values else (index, assign)
 
 
 _ROWS_SORTED: dict = {}

@@ -550,11 +550,15 @@ class TopkSelect(Select):
             plan = (int(k_host.sum()),) + tuple(kernels.topk_plan(sizes, self.ratio))  # same arithmetic on the device
             memo[("topk", float(self.ratio))] = plan
         k_total, k, koff = plan
-        node_index, cluster_index, assign = kernels.topk_select(score.detach(), batch, nb, ptr, k, koff, k_total,
-                                                                segments_max_nodes=seg_max)
-        values = Fn.take_unique(score, node_index)
-        s = torch.sparse_coo_tensor(torch.stack([node_index, cluster_index]), values, size=(n, k_total),
-                                    is_coalesced=True)
+        if torch.is_grad_enabled() and score.requires_grad:
+            index, assign = kernels.topk_select(score.detach(), batch, nb, ptr, k, koff, k_total,
+                                                segments_max_nodes=seg_max)
+            values = Fn.take_unique(score, index[0])
+        else:  # the weights of S come out of the compaction kernel
+            index, assign, values = kernels.topk_select(score, batch, nb, ptr, k, koff, k_total,
+                                                        segments_max_nodes=seg_max, with_values=True)
+            values = values.to(score.dtype)
+        s = torch.sparse_coo_tensor(index, values, size=(n, k_total), is_coalesced=True)
         so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
         so._assign_index = assign
         return so
