@@ -620,7 +620,8 @@ constexpr int NL_THREADS = 256;
 
 struct NlState {        // device-resident scalars of the iteration
   double lam, rn2, inv_r, cxp, cwp, c0, c1, c2p, sp, scale, vol, x2, cut;
-  int has_p, done, it, random_part, max_iter, pad;
+  int has_p, done, it, random_part, max_iter;
+  int done_seen;  // `done` as of the end of the previous step (fused steps: written by the update / start kernels only)
 };
 
 struct NlVecs {
@@ -628,6 +629,8 @@ struct NlVecs {
   double* ts;          // dis * raw: the vector the sparse mat-vec gathers (ONE random 8-byte read per entry, not two)
   float* dis;
   double* partial;     // [NL_BLOCKS][8]
+  double* part_a;      // [NL_BLOCKS][4]   sums of the residual round  (fused steps: nl_update_a_kernel -> nl_matvec2_kernel)
+  double* part_b;      // [NL_BLOCKS][16]  Gram sums of the basis      (nl_round_b2_kernel -> nl_update_a_kernel)
   NlState* st;
 };
 
@@ -637,6 +640,8 @@ static size_t nl_layout(void* ws, int64_t n, NlVecs* out) {
   const size_t m = static_cast<size_t>(n > 0 ? n : 1);
   v.st = c.take<NlState>(1);
   v.partial = c.take<double>(NL_BLOCKS * 8);
+  v.part_a = c.take<double>(NL_BLOCKS * 4);
+  v.part_b = c.take<double>(NL_BLOCKS * 16);
   v.x = c.take<double>(m); v.ax = c.take<double>(m); v.pv = c.take<double>(m); v.ap = c.take<double>(m);
   v.wv = c.take<double>(m); v.aw = c.take<double>(m); v.raw = c.take<double>(m);
   v.ts = c.take<double>(m);
@@ -665,6 +670,32 @@ __device__ __forceinline__ void nl_reduce_partials(const double* __restrict__ pa
   for (int b = threadIdx.x; b < NL_BLOCKS; b += NL_THREADS) {
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] += partial[b * 8 + k];
+  }
+  ndp_block_sums<NL_THREADS, K>(v, s_red);
+#pragma unroll
+  for (int k = 0; k < K; ++k) out[k] = v[k];
+}
+
+// the same with a slot stride / slot count of the caller's choice (fused steps below)
+template <int K, int STRIDE>
+__device__ __forceinline__ void nl_store_slots(double (&v)[K], double* __restrict__ partial) {
+  __shared__ double s_red[K * (NL_THREADS / 64)];
+  ndp_block_sums<NL_THREADS, K>(v, s_red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) partial[blockIdx.x * STRIDE + k] = v[k];
+  }
+}
+
+template <int K, int STRIDE>
+__device__ __forceinline__ void nl_reduce_slots(const double* __restrict__ partial, int nslots, double (&out)[K]) {
+  __shared__ double s_red[K * (NL_THREADS / 64)];
+  double v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = 0.0;
+  for (int b = threadIdx.x; b < nslots; b += NL_THREADS) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += partial[b * STRIDE + k];
   }
   ndp_block_sums<NL_THREADS, K>(v, s_red);
 #pragma unroll
@@ -720,6 +751,7 @@ __global__ __launch_bounds__(NL_THREADS) void nl_init_reduce_kernel(NlVecs v, in
     st->scale = 1.0;
     st->max_iter = max_iter;
     st->cut = 0.0;
+    st->done_seen = st->random_part;
   }
 }
 
@@ -798,14 +830,54 @@ __global__ __launch_bounds__(NL_THREADS) void nl_reduce_a_kernel(NlVecs v, doubl
 // 8-byte reads are 10 M L2 sectors whatever the group shape (8 x 4, 8 x 8, 16 x 4, 16 x 2 lanes x rows measured within 8 %).
 constexpr int NL_G = 16;
 constexpr int NL_U = 2;
+// FUSED: the residual round's sums are reduced here (what nl_reduce_a_kernel did in front).  FOLD_B (graphs of at most
+// NL_FOLD_MAX_N nodes, where the step is launch latency): the lane that finishes a row also does round B for it, so the
+// step is two launches; the grid is capped at NL_BLOCKS workgroups (= partial-sum slots).
+constexpr int64_t NL_FOLD_MAX_N = 131072;
+template <bool FUSED, bool FOLD_B>
 __global__ __launch_bounds__(NL_THREADS) void nl_matvec_kernel(const int32_t* __restrict__ indptr,
                                                                const int64_t* __restrict__ col,
                                                                const float* __restrict__ w, int64_t p0, int64_t p1,
-                                                               NlVecs v, int* __restrict__ status) {
-  const NlState* st = v.st;
-  if (st->done) return;
+                                                               NlVecs v, int nslots, double tol,
+                                                               int* __restrict__ status) {
+  NlState* st = v.st;
   const int64_t n = p1 - p0;
-  const double inv_r = st->inv_r;
+  double inv_r, cxp = 0.0, cwp = 0.0;
+  bool has_p = false;
+  if constexpr (FUSED) {
+    // every field read here was written by an EARLIER launch (done_seen by the update kernel), so the loads go out
+    // together with the partial sums' and the exit below is uniform over the grid
+    const int seen = st->done_seen, it = st->it, max_iter = st->max_iter;
+    const double lam = st->lam, sp_prev = st->sp;
+    double sa[3];
+    nl_reduce_slots<3, 4>(v.part_a, nslots, sa);
+    if (seen) return;
+    const bool stop = !(sa[0] > tol * tol * lam * lam) || it >= max_iter;
+    inv_r = stop ? 0.0 : 1.0 / sqrt(sa[0]);
+    has_p = sp_prev > 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      st->rn2 = sa[0];
+      if (stop) {
+        st->done = 1;  // |Ls x - lambda x| <= tol * lambda (or the step budget is spent: the caller decides what then)
+      } else {
+        st->inv_r = inv_r;
+        st->cxp = sa[1];
+        st->cwp = sa[2] * inv_r;
+        st->has_p = has_p;
+      }
+    }
+    if (stop) return;
+    if constexpr (FOLD_B) {
+      cxp = sa[1];
+      cwp = sa[2] * inv_r;
+    }
+  } else {
+    if (st->done) return;
+    inv_r = st->inv_r;
+  }
+  double sb[FOLD_B ? 12 : 1];
+#pragma unroll
+  for (int k = 0; k < (FOLD_B ? 12 : 1); ++k) sb[k] = 0.0;
   const int sub = threadIdx.x % NL_G;
   const int64_t ngroups = static_cast<int64_t>(gridDim.x) * (NL_THREADS / NL_G);
   const int e_first = indptr[p0];  // a valid entry index whenever any loop below runs
@@ -813,11 +885,21 @@ __global__ __launch_bounds__(NL_THREADS) void nl_matvec_kernel(const int32_t* __
        i0 += ngroups * NL_U) {
     int e[NL_U], e1[NL_U];
     double acc[NL_U];
+    double r_i[NL_U], x_i[NL_U], ax_i[NL_U], p_i[NL_U], ap_i[NL_U];  // the row's own entries, requested with its offsets
+    float d_i[NL_U];
 #pragma unroll
     for (int u = 0; u < NL_U; ++u) {
       const int64_t i = i0 + u * ngroups;
       const int64_t ic = i < n ? i : n - 1;
       const int a = indptr[p0 + ic], b = indptr[p0 + ic + 1];
+      r_i[u] = v.raw[ic];
+      d_i[u] = v.dis[ic];
+      if constexpr (FOLD_B) {
+        x_i[u] = v.x[ic];
+        ax_i[u] = v.ax[ic];
+        p_i[u] = v.pv[ic];
+        ap_i[u] = v.ap[ic];
+      }
       e[u] = a + sub;
       e1[u] = i < n ? b : a;
       acc[u] = 0.0;
@@ -860,12 +942,36 @@ __global__ __launch_bounds__(NL_THREADS) void nl_matvec_kernel(const int32_t* __
       for (int o = NL_G / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
       const int64_t i = i0 + u * ngroups;
       if (sub == 0 && i < n) {
-        const double ri = v.raw[i];
-        v.wv[i] = ri * inv_r;
-        v.aw[i] = inv_r * (ri - static_cast<double>(v.dis[i]) * a);
+        const double ri = r_i[u];
+        const double wi = ri * inv_r, awi = inv_r * (ri - static_cast<double>(d_i[u]) * a);
+        v.wv[i] = wi;
+        v.aw[i] = awi;
+        if constexpr (FOLD_B) {  // round B of this row (nl_round_b2_kernel)
+          const double xi = x_i[u], axi = ax_i[u];
+          double pi = 0.0, api = 0.0;
+          if (has_p) {
+            pi = p_i[u] - cxp * xi - cwp * wi;
+            api = ap_i[u] - cxp * axi - cwp * awi;
+            v.pv[i] = pi;
+            v.ap[i] = api;
+          }
+          sb[0] += pi * pi;
+          sb[1] += xi * awi;
+          sb[2] += wi * awi;
+          sb[3] += xi * api;
+          sb[4] += wi * api;
+          sb[5] += pi * api;
+          sb[6] += xi * xi;
+          sb[7] += xi * wi;
+          sb[8] += xi * pi;
+          sb[9] += wi * wi;
+          sb[10] += wi * pi;
+          sb[11] += xi * axi;
+        }
       }
     }
   }
+  if constexpr (FOLD_B) nl_store_slots<12, 16>(sb, v.part_b);
 }
 
 // round B: p' = p - (x.p) x - (w.p) w (and the same combination of the products); six sums
@@ -953,6 +1059,159 @@ __global__ __launch_bounds__(NL_THREADS) void nl_reduce_update_kernel(NlVecs v, 
   if (threadIdx.x == 0 && d_progress) {
     d_progress[0] = st->done;
     d_progress[1] = st->it;
+  }
+}
+
+// ---- r3 (late): the step as THREE launches instead of seven.  A mid-size graph (2 k .. 50 k nodes) spends its step in
+// launch latency (~5 us per dependent kernel, seven of them), so (1) every one-workgroup "reduce" kernel is folded into
+// the grid kernel that consumes its result: each workgroup sums the producer's partial slots itself (same slots, same
+// order in every workgroup: bitwise the same scalars everywhere) and workgroup 0 records what later kernels need; a
+// kernel never reads a state field it writes (`done` excepted: reading the value written by this very launch leads to
+// the decision the reader would take anyway).  (2) The update's own sums go: with the twelve Gram sums of the basis
+// {x, w, p'} from round B, |x_new|^2 = c^T G c and x_new . A x_new = c^T H c are known BEFORE x_new is formed, so update,
+// normalisation, the new residual, ts = dis * r and the residual's three sums are one pass (17 vector streams -> 12).
+// first residual round of the fused steps (start): raw = ax - lam x, ts, the three sums -> part_a
+__global__ __launch_bounds__(NL_THREADS) void nl_round_a2_kernel(int64_t n, NlVecs v) {
+  const NlState* st = v.st;
+  const double lam = st->lam;
+  double s[3] = {0.0, 0.0, 0.0};
+  if (!st->done) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * NL_THREADS) {
+      const double xi = v.x[i], pi = v.pv[i];
+      const double r = v.ax[i] - lam * xi;
+      v.raw[i] = r;
+      v.ts[i] = static_cast<double>(v.dis[i]) * r;
+      s[0] += r * r;
+      s[1] += xi * pi;
+      s[2] += r * pi;
+    }
+  }
+  nl_store_slots<3, 4>(s, v.part_a);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    v.st->sp = 0.0;
+    v.st->done_seen = st->done;
+  }
+}
+
+// round B with the full Gram matrices: G = {xx, xw, xp, ww, wp, pp}, H = {x.ax, x.aw, w.aw, x.ap, w.ap, p.ap}
+__global__ __launch_bounds__(NL_THREADS) void nl_round_b2_kernel(int64_t n, NlVecs v) {
+  const NlState* st = v.st;
+  if (st->done) return;  // (written by the mat-vec launch before this one)
+  const bool has_p = st->has_p != 0;
+  const double cxp = st->cxp, cwp = st->cwp;
+  double s[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) s[k] = 0.0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * NL_THREADS) {
+    const double xi = v.x[i], wi = v.wv[i], axi = v.ax[i], awi = v.aw[i];
+    double pi = 0.0, api = 0.0;
+    if (has_p) {
+      pi = v.pv[i] - cxp * xi - cwp * wi;
+      api = v.ap[i] - cxp * axi - cwp * awi;
+      v.pv[i] = pi;
+      v.ap[i] = api;
+    }
+    s[0] += pi * pi;
+    s[1] += xi * awi;
+    s[2] += wi * awi;
+    s[3] += xi * api;
+    s[4] += wi * api;
+    s[5] += pi * api;
+    s[6] += xi * xi;
+    s[7] += xi * wi;
+    s[8] += xi * pi;
+    s[9] += wi * wi;
+    s[10] += wi * pi;
+    s[11] += xi * axi;
+  }
+  nl_store_slots<12, 16>(s, v.part_b);
+}
+
+// Rayleigh-Ritz from round B's sums, then in ONE pass: x <- (c0 x + c1 w + c2 p^) / |.|, p <- (c1 w + c2 p^) / |.| (and
+// the same combinations of the products), raw = ax - lam x with the new lam = c^T H c / c^T G c, ts = dis * raw, and the
+// residual round's three sums.
+__global__ __launch_bounds__(NL_THREADS) void nl_update_a_kernel(int64_t n, NlVecs v, int nslots,
+                                                                 int32_t* __restrict__ d_progress) {
+  NlState* st = v.st;
+  // the first element's operands are requested before the sums arrive (a mid-size graph has one element per thread)
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * NL_THREADS;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x;
+  int64_t ic = i < n ? i : 0;
+  double wi = v.wv[ic], pi = v.pv[ic], awi = v.aw[ic], api = v.ap[ic], xi = v.x[ic], axi = v.ax[ic];
+  float di = v.dis[ic];
+  const int done = st->done, has_p_i = st->has_p;  // (written by the mat-vec launch of this step or an earlier one)
+  double sb[12];
+  nl_reduce_slots<12, 16>(v.part_b, nslots, sb);
+  if (done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      st->done_seen = 1;
+      if (d_progress) {
+        d_progress[0] = 1;
+        d_progress[1] = st->it;
+      }
+    }
+    return;
+  }
+  __shared__ double s_c[6];
+  if (threadIdx.x == 0) {
+    const bool has_p = has_p_i != 0;
+    const int dim = (has_p && sb[0] > 1e-24) ? 3 : 2;
+    const double ip = dim == 3 ? 1.0 / sqrt(sb[0]) : 0.0;
+    const double hxx = sb[11], hxw = sb[1], hww = sb[2], hxp = sb[3] * ip, hwp = sb[4] * ip, hpp = sb[5] * ip * ip;
+    double h[3][3] = {{hxx, hxw, hxp}, {hxw, hww, hwp}, {hxp, hwp, hpp}};
+    double c[3];
+    ndp_rr_largest_f32(h, dim, c);  // (as the one-workgroup kernels: the Gram sums below make the normalisation exact)
+    if (c[0] < 0.0) { c[0] = -c[0]; c[1] = -c[1]; c[2] = -c[2]; }
+    const double pn2 = c[1] * c[1] + c[2] * c[2];
+    const double gxp = sb[8] * ip, gwp = sb[10] * ip, gpp = dim == 3 ? 1.0 : 0.0;
+    const double x2 = c[0] * c[0] * sb[6] + c[1] * c[1] * sb[9] + c[2] * c[2] * gpp +
+                      2.0 * (c[0] * c[1] * sb[7] + c[0] * c[2] * gxp + c[1] * c[2] * gwp);
+    const double xax = c[0] * c[0] * hxx + c[1] * c[1] * hww + c[2] * c[2] * hpp +
+                       2.0 * (c[0] * c[1] * hxw + c[0] * c[2] * hxp + c[1] * c[2] * hwp);
+    s_c[0] = c[0];
+    s_c[1] = c[1];
+    s_c[2] = c[2] * ip;
+    s_c[3] = pn2 > 1e-300 ? 1.0 / sqrt(pn2) : 0.0;
+    s_c[4] = 1.0 / sqrt(x2);
+    s_c[5] = xax / x2;
+  }
+  __syncthreads();
+  const double c0 = s_c[0], c1 = s_c[1], c2p = s_c[2], sp = s_c[3], sc = s_c[4], lam = s_c[5];
+  double s[3] = {0.0, 0.0, 0.0};
+  while (i < n) {
+    const double pn = c1 * wi + c2p * pi, apn = c1 * awi + c2p * api;
+    const double xn = (c0 * xi + pn) * sc, axn = (c0 * axi + apn) * sc;
+    const double pnew = pn * sp;
+    const double r = axn - lam * xn;
+    const int64_t at = i;
+    const double ts = static_cast<double>(di) * r;
+    i += stride;
+    if (i < n) {  // next element's operands before this one's stores
+      wi = v.wv[i]; pi = v.pv[i]; awi = v.aw[i]; api = v.ap[i]; xi = v.x[i]; axi = v.ax[i];
+      di = v.dis[i];
+    }
+    v.pv[at] = pnew;
+    v.ap[at] = apn * sp;
+    v.x[at] = xn;
+    v.ax[at] = axn;
+    v.raw[at] = r;
+    v.ts[at] = ts;
+    s[0] += r * r;
+    s[1] += xn * pnew;
+    s[2] += r * pnew;
+  }
+  nl_store_slots<3, 4>(s, v.part_a);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->lam = lam;
+    st->sp = sp;
+    const int it = st->it + 1;
+    st->it = it;
+    if (d_progress) {
+      d_progress[0] = 0;
+      d_progress[1] = it;
+    }
   }
 }
 
@@ -1111,6 +1370,20 @@ extern "C" int tgp_ndp_symmetric_max_f32(const int64_t* row, const int64_t* col,
 // ------------------------------------------------------------------ one large graph, chip-wide (see nl_* kernels)
 extern "C" size_t tgp_ndp_large_workspace_bytes(int64_t n) { return nl_layout(nullptr, n, nullptr) + 256; }
 
+// TGP_NDP_LARGE_CLASSIC=1: the seven-launch step of the first r3 version (A/B measurements; start and steps must agree,
+// so the switch is read once per process)
+static bool nl_classic_steps() {
+  static const bool classic = [] {
+    const char* e = getenv("TGP_NDP_LARGE_CLASSIC");
+    return e && e[0] == '1';
+  }();
+  return classic;
+}
+static unsigned nl_grid(int64_t n) {  // workgroups (= partial-sum slots) of the fused steps' vector kernels
+  const int64_t b = cdiv(n, static_cast<int64_t>(NL_THREADS));
+  return static_cast<unsigned>(b < NL_BLOCKS ? (b > 0 ? b : 1) : NL_BLOCKS);
+}
+
 static int nl_check(const int32_t* indptr, int64_t p0, int64_t p1, const void* ws, size_t ws_bytes, const char* what) {
   TGP_REQUIRE(indptr && ws && p0 >= 0 && p1 > p0, TGP_ERR_INVALID, "%s: bad argument", what);
   TGP_REQUIRE(p1 < (1ll << 31), TGP_ERR_RANGE, "%s: node ids >= 2^31", what);
@@ -1132,6 +1405,8 @@ extern "C" int tgp_ndp_large_start(const int32_t* indptr, const int64_t* col, co
   hipLaunchKernelGGL(nl_first_matvec_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, indptr, col, w, p0, p1, v,
                      d_status);
   hipLaunchKernelGGL(nl_first_reduce_kernel, dim3(1), dim3(NL_THREADS), 0, stream, v);
+  if (!nl_classic_steps())
+    hipLaunchKernelGGL(nl_round_a2_kernel, dim3(nl_grid(n)), dim3(NL_THREADS), 0, stream, n, v);
   return check_launch("tgp_ndp_large_start");
 }
 
@@ -1147,11 +1422,32 @@ extern "C" int tgp_ndp_large_steps(const int32_t* indptr, const int64_t* col, co
   const int64_t n = p1 - p0;
   const int64_t mv_rows = static_cast<int64_t>(NL_THREADS / NL_G) * NL_U;  // rows a workgroup takes per pass
   const unsigned mv_blocks = static_cast<unsigned>(cdiv(n, mv_rows) < 16384 ? cdiv(n, mv_rows) : 16384);
+  if (!nl_classic_steps()) {
+    const unsigned nb = nl_grid(n);
+    const bool fold = n <= NL_FOLD_MAX_N;
+    const unsigned fb = mv_blocks < static_cast<unsigned>(NL_BLOCKS) ? mv_blocks : static_cast<unsigned>(NL_BLOCKS);
+    for (int s = 0; s < steps; ++s) {
+      int32_t* progress = s + 1 == steps ? d_progress : static_cast<int32_t*>(nullptr);
+      if (fold) {
+        hipLaunchKernelGGL((nl_matvec_kernel<true, true>), dim3(fb), dim3(NL_THREADS), 0, stream, indptr, col, w, p0, p1,
+                           v, static_cast<int>(nb), tol, d_status);
+        hipLaunchKernelGGL(nl_update_a_kernel, dim3(nb), dim3(NL_THREADS), 0, stream, n, v, static_cast<int>(fb),
+                           progress);
+      } else {
+        hipLaunchKernelGGL((nl_matvec_kernel<true, false>), dim3(mv_blocks), dim3(NL_THREADS), 0, stream, indptr, col, w,
+                           p0, p1, v, static_cast<int>(nb), tol, d_status);
+        hipLaunchKernelGGL(nl_round_b2_kernel, dim3(nb), dim3(NL_THREADS), 0, stream, n, v);
+        hipLaunchKernelGGL(nl_update_a_kernel, dim3(nb), dim3(NL_THREADS), 0, stream, n, v, static_cast<int>(nb),
+                           progress);
+      }
+    }
+    return check_launch("tgp_ndp_large_steps");
+  }
   for (int s = 0; s < steps; ++s) {
     hipLaunchKernelGGL(nl_round_a_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, n, v);
     hipLaunchKernelGGL(nl_reduce_a_kernel, dim3(1), dim3(NL_THREADS), 0, stream, v, tol);
-    hipLaunchKernelGGL(nl_matvec_kernel, dim3(mv_blocks), dim3(NL_THREADS), 0, stream, indptr, col, w, p0, p1, v,
-                       d_status);
+    hipLaunchKernelGGL((nl_matvec_kernel<false, false>), dim3(mv_blocks), dim3(NL_THREADS), 0, stream, indptr, col, w, p0, p1, v,
+                       0, tol, d_status);
     hipLaunchKernelGGL(nl_round_b_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, n, v);
     hipLaunchKernelGGL(nl_reduce_b_kernel, dim3(1), dim3(NL_THREADS), 0, stream, v);
     hipLaunchKernelGGL(nl_update_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, n, v);
