@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10015 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10016 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -298,6 +298,11 @@ int tgp_graclus_match_start(const int64_t* row, const int64_t* col, const float*
                             int64_t* label, void* stream);
 int tgp_graclus_match_rounds(const int32_t* row_ptr, int64_t num_nodes, int64_t num_edges, void* ws, int rounds,
                              unsigned int* matched, int64_t* label, void* stream);
+/* The remaining rounds in two launches once at most 16384 free nodes are left (after tgp_graclus_match_rounds, same
+ * workspace): one workgroup runs them over the list of those nodes (same pairs: a proposal depends on the free set
+ * only).  *d_status = 1: the matching is now maximal; 0: too many free nodes, nothing was changed. */
+int tgp_graclus_match_tail(const int32_t* row_ptr, int64_t num_nodes, int64_t num_edges, void* ws, int64_t* label,
+                           int* d_status, void* stream);
 /* All rounds of every graph in ONE launch (instead of tgp_graclus_match_rounds, after tgp_graclus_match_start) for a
  * batch whose graphs own contiguous node ranges graph_ptr[b] .. graph_ptr[b+1] of at most
  * tgp_graclus_match_max_graph_nodes() nodes: one workgroup per graph, the matching the device-wide rounds give.

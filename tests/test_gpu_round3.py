@@ -1130,3 +1130,23 @@ def test_topk_score_kernel_vs_torch(dev, n, F, act):
         assert torch.allclose(fused.s.values(), plain.s.values().detach(), rtol=1e-5, atol=1e-6)
     else:  # a last-place difference may swap two nodes whose scores agree to rounding: same scores, sorted per graph
         assert torch.allclose(fused.s.values().sort().values, plain.s.values().detach().sort().values, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,m,weights", [(200_000, 1_000_000, "unit"), (200_000, 600_000, "rand"), (5000, 20_000, "unit"),
+                                         (70_000, 70_000, "rand")])
+def test_graclus_tail_rounds_equal_the_device_wide_rounds(dev, n, m, weights, monkeypatch):
+    """tgp_graclus_match_tail (the last rounds over a list of the free nodes, one workgroup) gives the labels the
+    device-wide rounds give; it is actually taken on these graphs."""
+    from tgp import kernels, _native as N
+    ei = _undirected(n, m, n + m).to(dev)
+    if weights == "rand":
+        lo, hi = torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])
+        ew = (torch.sin((lo * 7919 + hi * 104729).double()) * 0.5 + 0.6).float()
+    else:
+        ew = torch.ones(ei.size(1), device=dev)
+    want = kernels.graclus_match(ei, ew, n, max_rounds=1 << 20)      # (a bounded loop never takes the tail)
+    seen = []
+    real = N.lib().tgp_graclus_match_tail
+    monkeypatch.setattr(N.lib(), "tgp_graclus_match_tail", lambda *a: seen.append(1) or real(*a))
+    got = kernels.graclus_match(ei, ew, n)
+    assert seen and torch.equal(got, want)

@@ -341,6 +341,88 @@ __global__ __launch_bounds__(T) void gm_graph_rounds_kernel(const int32_t* __res
   else gm_graph_rounds<T>(s_ptr - p0, nbr, wt, p0, n, s_free, s_cand, label);
 }
 
+// ---- the tail of the device-wide rounds ---------------------------------------------------------------------------------
+// After a few rounds a random-like graph has a few thousand free nodes left that still have a free neighbour, and every
+// further round costs three launches over all N nodes (15 us at N = 1M) to match a handful of pairs.  The tail gathers
+// those nodes into a list (at most GM_TAIL_CAP, else it declines) and ONE workgroup runs all remaining rounds over the
+// list: same proposals, same pairs (a proposal depends only on the free set), the workgroup barrier is the round boundary.
+constexpr int GM_TAIL_CAP = 16384;
+__global__ __launch_bounds__(256) void gm_tail_list_kernel(const uint8_t* __restrict__ is_free, int64_t n,
+                                                           int32_t* __restrict__ list, unsigned int* __restrict__ count) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const bool f = i < n && is_free[i];
+  const unsigned long long m = __ballot(f);
+  if (m == 0) return;
+  unsigned int base = 0;
+  if (lane_id() == 0) base = atomicAdd(count, static_cast<unsigned int>(__popcll(m)));
+  base = __shfl(base, 0, WAVE);
+  const unsigned int at = base + static_cast<unsigned int>(__popcll(m & lanemask_lt()));
+  if (f && at < static_cast<unsigned int>(GM_TAIL_CAP)) list[at] = static_cast<int32_t>(i);
+}
+
+__global__ __launch_bounds__(1024) void gm_tail_rounds_kernel(const int32_t* __restrict__ row_ptr,
+                                                              const int32_t* __restrict__ nbr,
+                                                              const float* __restrict__ wt,
+                                                              const int32_t* __restrict__ list,
+                                                              const unsigned int* __restrict__ count,
+                                                              int64_t* __restrict__ label, uint8_t* __restrict__ is_free,
+                                                              int32_t* __restrict__ cand, int* __restrict__ status) {
+  __shared__ int32_t s_list[GM_TAIL_CAP];
+  __shared__ unsigned int s_cnt[16];
+  unsigned int m = *count;
+  if (m > static_cast<unsigned int>(GM_TAIL_CAP)) {
+    if (threadIdx.x == 0) *status = 0;  // too many: the caller goes on with device-wide rounds
+    return;
+  }
+  for (unsigned int t = threadIdx.x; t < m; t += 1024) s_list[t] = list[t];
+  __syncthreads();
+  for (int round = 0; round < (1 << 30); ++round) {
+    for (unsigned int t = threadIdx.x; t < m; t += 1024) {
+      const int32_t i = s_list[t];
+      int32_t c = -1;
+      if (is_free[i]) {
+        c = gm_best_neighbour(i, row_ptr, nbr, wt, [&](int32_t j) { return is_free[j] != 0; });
+        if (c < 0) is_free[i] = 0;  // retire (see gm_propose_kernel)
+      }
+      cand[i] = c;
+    }
+    __syncthreads();
+    bool hit = false;
+    for (unsigned int t = threadIdx.x; t < m; t += 1024) {
+      const int32_t i = s_list[t];
+      const int32_t j = cand[i];
+      if (j >= 0 && cand[j] == i) {  // (j is free and has a free neighbour, so it is on the list and proposed this round)
+        label[i] = i < j ? i : j;
+        is_free[i] = 0;
+        hit = true;
+      }
+    }
+    if (!__syncthreads_or(hit ? 1 : 0)) break;
+    // keep only the nodes that are still free (matched and retired ones drop out: later rounds are one node per thread)
+    unsigned int kept = 0;
+    for (unsigned int base = 0; base < m; base += 1024) {
+      const unsigned int t = base + threadIdx.x;
+      const int32_t i = t < m ? s_list[t] : 0;
+      const bool f = t < m && is_free[i] != 0;
+      const unsigned long long bm = __ballot(f);
+      if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = __popcll(bm);
+      __syncthreads();  // (also: every entry of this chunk has been read)
+      unsigned int before = 0, total = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const unsigned int c = s_cnt[q];
+        if (q < static_cast<int>(threadIdx.x >> 6)) before += c;
+        total += c;
+      }
+      if (f) s_list[kept + before + __popcll(bm & lanemask_lt())] = i;
+      kept += total;
+      __syncthreads();
+    }
+    m = kept;
+  }
+  if (threadIdx.x == 0) *status = 1;
+}
+
 // ---- labels -> consecutive cluster ids (the torch.unique(return_inverse=True) of select/graclus_select.py:68) -------
 // A representative is a node with label[i] == i; its id is the number of representatives before it, and every node takes
 // the id of its label.  Two launches, no sort: 1024-node tiles write their flag words, the running popcount of the words
@@ -494,7 +576,7 @@ extern "C" size_t tgp_graclus_match_workspace_bytes(int64_t num_nodes, int64_t n
   const size_t n = static_cast<size_t>(num_nodes > 0 ? num_nodes : 1), e = static_cast<size_t>(num_edges > 0 ? num_edges : 1);
   return align_up(e * sizeof(int32_t)) + align_up(e * sizeof(float)) + align_up(n) + align_up(n * sizeof(int32_t)) +
          align_up((n / 32 + 8) * sizeof(uint32_t)) + align_up(e * sizeof(int32_t)) +
-         align_up((e / 256 + 2) * sizeof(unsigned long long)) + 512;
+         align_up((e / 256 + 2) * sizeof(unsigned long long)) + align_up((GM_TAIL_CAP + 16) * sizeof(int32_t)) + 512;
 }
 
 // Start: gathers the CSR and resets the state.  Rounds: runs `rounds` propose/match rounds; matched[r] becomes 1 if
@@ -559,4 +641,34 @@ extern "C" int tgp_graclus_match_rounds(const int32_t* row_ptr, int64_t num_node
     hipLaunchKernelGGL(gm_match_kernel, dim3(nb), dim3(256), 0, stream, cand, num_nodes, label, is_free, matched + r);
   }
   return check_launch("tgp_graclus_match_rounds");
+}
+
+// Every remaining round in two launches when at most 16384 free nodes are left (after tgp_graclus_match_rounds, same
+// workspace).  *d_status = 1: the matching is now maximal; 0: too many free nodes, nothing was changed.
+extern "C" int tgp_graclus_match_tail(const int32_t* row_ptr, int64_t num_nodes, int64_t num_edges, void* ws,
+                                      int64_t* label, int* d_status, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(num_nodes >= 0 && num_edges >= 0 && d_status, TGP_ERR_INVALID, "tgp_graclus_match_tail: bad argument");
+  if (num_nodes == 0) {
+    (void)hipMemsetAsync(d_status, 0, sizeof(int), stream);
+    return check_launch("tgp_graclus_match_tail");
+  }
+  TGP_REQUIRE(row_ptr && ws && label, TGP_ERR_INVALID, "tgp_graclus_match_tail: null pointer");
+  Carver cv(ws);
+  int32_t* nbr = cv.take<int32_t>(num_edges > 0 ? num_edges : 1);
+  float* wt = cv.take<float>(num_edges > 0 ? num_edges : 1);
+  uint8_t* is_free = cv.take<uint8_t>(num_nodes);
+  int32_t* cand = cv.take<int32_t>(num_nodes);
+  (void)cv.take<uint32_t>(num_nodes / 32 + 8);
+  (void)cv.take<int32_t>(num_edges > 0 ? num_edges : 1);
+  (void)cv.take<unsigned long long>(num_edges / 256 + 2);
+  (void)cv.take<int>(4);
+  int32_t* list = cv.take<int32_t>(GM_TAIL_CAP + 16);
+  unsigned int* count = reinterpret_cast<unsigned int*>(list + GM_TAIL_CAP);
+  (void)hipMemsetAsync(count, 0, sizeof(unsigned int), stream);
+  hipLaunchKernelGGL(gm_tail_list_kernel, dim3(cdiv(num_nodes, 256)), dim3(256), 0, stream, is_free, num_nodes, list,
+                     count);
+  hipLaunchKernelGGL(gm_tail_rounds_kernel, dim3(1), dim3(1024), 0, stream, row_ptr, nbr, wt, list, count, label,
+                     is_free, cand, d_status);
+  return check_launch("tgp_graclus_match_tail");
 }

@@ -756,11 +756,19 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
     while not finished and (max_rounds is None or done < max_rounds):
         if max_rounds is not None:
             step = min(step, max_rounds - done)
-        matched = torch.empty(step, dtype=torch.int32, device=dev)
+        matched = torch.empty(step + 1, dtype=torch.int32, device=dev)  # [round flags ..., tail status]
         N.check(L.tgp_graclus_match_rounds(N.ptr(row_ptr), num_nodes, E, N.ptr(ws), step, N.ptr(matched),
                                            N.ptr(label), st), "tgp_graclus_match_rounds")
         done += step
-        finished = int(matched[-1].item()) == 0  # one round trip per batch of rounds
+        if max_rounds is None:
+            # the few thousand nodes that are still free after these rounds: all their remaining rounds in one workgroup
+            # (declines when there are more than that), read back with the round flags
+            N.check(L.tgp_graclus_match_tail(N.ptr(row_ptr), num_nodes, E, N.ptr(ws), N.ptr(label),
+                                             N.ptr(matched[step:]), st), "tgp_graclus_match_tail")
+            last, tail = matched[step - 1:].tolist()
+            finished = last == 0 or tail == 1
+        else:
+            finished = int(matched[step - 1].item()) == 0  # one round trip per batch of rounds
         # random-like graphs finish in a handful of rounds; a long tail means chain-like structure: batch more
         # rounds per round trip (4, then doubling up to 256) so that n/2 rounds cost n/512 host synchronisations
         step = 4 if done <= 6 else min(2 * step, 256)
