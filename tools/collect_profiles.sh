@@ -28,6 +28,8 @@ python3 tools/bench_poolers_e2e.py > $out/e2e_poolers.txt 2>&1
 python3 tools/bench_ndp_large.py > $out/ndp_large.txt 2>&1
 python3 tools/e2e_train_step.py mincut_c3 diff_c3 mincut_c2 diff_c2 --top 8 2>&1 | grep -v -i "warn" > $out/e2e_train_steps.txt
 python3 tools/ndp_small_ab.py 2>&1 | grep -v -i "warn" > $out/ndp_small.txt
+bash tools/ndp_large_ab.sh 2>&1 | grep -v -i "warn\|amdgpu.ids" > $out/ndp_mid_ab.txt
+python3 tools/bench_reference_harness.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $out/reference_harness.txt
 python3 tools/kron_timeline.py $(find $out/kron -name "*kernel_trace.csv" | head -1) > $out/kron_timeline.txt 2>&1
 for k in coalesce_c4_sorted subgraph_topk c3 reduce_topk gemm_c2; do
   pmc $k FETCH_SIZE python3 tools/run_kernel.py $k 4
