@@ -292,9 +292,14 @@ namespace tgp {
 // IN_LDS: the graph's R1 and G tiles are staged in LDS first ([K][K + 1] each: K <= 128) -- every sweep below is then
 // LDS-local; from global memory (L2-resident, but ~0.6 us per dependent access) the serial column sweeps of one workgroup
 // per graph took 98 us at B = 32, K = 128.
+// r3 (late): the LDS form runs 1024 threads (the workgroup owns its CU anyway: 2 K^2 floats of LDS), stores the forward's
+// P in place of R1 once (the two divisions per element were evaluated in both sweeps) and splits every column sweep over
+// 8 row phases folded in a fixed order: 55 -> 15 us at B = 32, K = 128.
 template <bool IN_LDS>
-__global__ __launch_bounds__(256) void post_bwd_kernel(const float* __restrict__ R, const float* __restrict__ G, int K,
-                                                       int flags, float eps, float* __restrict__ out) {
+__global__ __launch_bounds__(IN_LDS ? 1024 : 256) void post_bwd_kernel(const float* __restrict__ R,
+                                                                       const float* __restrict__ G, int K, int flags,
+                                                                       float eps, float* __restrict__ out) {
+  constexpr int T = IN_LDS ? 1024 : 256, NW = T / 64, PARTS = 8;
   extern __shared__ float sm[];
   float* s_d = sm;
   float* s_gs = sm + K;
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(256) void post_bwd_kernel(const float* __restrict__
   float* s_colq = sm + 3 * K;
   float* sR = sm + 4 * K;
   float* sG = sR + (IN_LDS ? K * (K + 1) : 0);
+  float* s_part = sG + (IN_LDS ? K * (K + 1) : 0);  // [PARTS][K] (IN_LDS only)
   const int ld = IN_LDS ? K + 1 : K;
   const long off = static_cast<long>(blockIdx.x) * K * K;
   const float* Rb = R + off;
@@ -310,14 +316,14 @@ __global__ __launch_bounds__(256) void post_bwd_kernel(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool rsl = flags & TGP_REMOVE_SELF_LOOPS, dn = flags & TGP_DEGREE_NORM, cols = flags & TGP_SUM_AXIS_ROWS;
   if (!dn) {
-    for (long e = tid; e < static_cast<long>(K) * K; e += 256) {
+    for (long e = tid; e < static_cast<long>(K) * K; e += T) {
       const int i = static_cast<int>(e / K), j = static_cast<int>(e - static_cast<long>(i) * K);
       ob[e] = (rsl && i == j) ? 0.f : Gb[e];
     }
     return;
   }
   if constexpr (IN_LDS) {
-    for (int i = wave; i < K; i += 4)
+    for (int i = wave; i < K; i += NW)
       for (int j = lane; j < K; j += 64) {
         sR[i * ld + j] = (rsl && i == j) ? 0.f : Rb[static_cast<long>(i) * K + j];
         sG[i * ld + j] = Gb[static_cast<long>(i) * K + j];
@@ -332,53 +338,77 @@ __global__ __launch_bounds__(256) void post_bwd_kernel(const float* __restrict__
     if constexpr (IN_LDS) return sG[i * ld + j];
     return Gb[static_cast<long>(i) * K + j];
   };
+  // column sums of f(i, j) into dst[j]: a thread per column, or (IN_LDS) 8 row phases per column folded in phase order
+  auto col_sweep = [&](auto f, float* dst) {
+    if constexpr (IN_LDS) {
+      for (int idx = tid; idx < K * PARTS; idx += T) {
+        const int j = idx % K, part = idx / K;
+        float acc = 0.f;
+        for (int i = part; i < K; i += PARTS) acc += f(i, j);
+        s_part[part * K + j] = acc;
+      }
+      __syncthreads();
+      for (int j = tid; j < K; j += T) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) acc += s_part[q * K + j];
+        dst[j] = acc;
+      }
+    } else {
+      for (int j = tid; j < K; j += T) {
+        float acc = 0.f;
+#pragma unroll 4
+        for (int i = 0; i < K; ++i) acc += f(i, j);
+        dst[j] = acc;
+      }
+    }
+  };
   if (!cols) {  // c_i = sum_j R1_ij: a wave per row
-    for (int i = wave; i < K; i += 4) {
+    for (int i = wave; i < K; i += NW) {
       float acc = 0.f;
       for (int j = lane; j < K; j += 64) acc += r1(i, j);
 #pragma unroll
       for (int dd = 32; dd > 0; dd >>= 1) acc += __shfl_xor(acc, dd, WAVE);
       if (lane == 0) s_d[i] = acc;
     }
-  } else {      // c_j = sum_i R1_ij: a thread per column
-    for (int j = tid; j < K; j += 256) {
-      float acc = 0.f;
-#pragma unroll 8
-      for (int i = 0; i < K; ++i) acc += r1(i, j);
-      s_d[j] = acc;
-    }
+  } else {      // c_j = sum_i R1_ij
+    col_sweep(r1, s_d);
   }
   __syncthreads();
-  for (int t = tid; t < K; t += 256) {
+  for (int t = tid; t < K; t += T) {
     const float c = s_d[t];
     s_gs[t] = c >= eps ? 1.f : 0.f;  // clamp(min = eps) passes the gradient where c >= eps
     s_d[t] = sqrtf(fmaxf(c, eps));
   }
   __syncthreads();
-  auto pval = [&](int i, int j) -> float {  // the forward's P_ij, same arithmetic
+  auto pdiv = [&](int i, int j) -> float {  // the forward's P_ij, same arithmetic
     const float di = s_d[i], dj = s_d[j];
     return cols ? (r1(i, j) / dj) / di : (r1(i, j) / di) / dj;
   };
-  for (int i = wave; i < K; i += 4) {  // rowsum_i(G P)
+  if constexpr (IN_LDS) {  // P in place of R1 (each element read and written by one thread)
+    for (int i = wave; i < K; i += NW)
+      for (int j = lane; j < K; j += 64) sR[i * ld + j] = pdiv(i, j);
+    __syncthreads();
+  }
+  auto pval = [&](int i, int j) -> float {
+    if constexpr (IN_LDS) return sR[i * ld + j];
+    return pdiv(i, j);
+  };
+  for (int i = wave; i < K; i += NW) {  // rowsum_i(G P)
     float acc = 0.f;
     for (int j = lane; j < K; j += 64) acc += gv(i, j) * pval(i, j);
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) acc += __shfl_xor(acc, dd, WAVE);
     if (lane == 0) s_rowq[i] = acc;
   }
-  for (int j = tid; j < K; j += 256) {  // colsum_j(G P)
-    float acc = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < K; ++i) acc += gv(i, j) * pval(i, j);
-    s_colq[j] = acc;
-  }
+  col_sweep([&](int i, int j) { return gv(i, j) * pval(i, j); }, s_colq);  // colsum_j(G P)
   __syncthreads();
-  for (int t = tid; t < K; t += 256) {
+  for (int t = tid; t < K; t += T) {
     const float d = s_d[t];
     s_gs[t] = s_gs[t] != 0.f ? -(s_rowq[t] + s_colq[t]) / (2.0f * d * d) : 0.f;
   }
   __syncthreads();
-  for (int i = wave; i < K; i += 4)
+  for (int i = wave; i < K; i += NW)
     for (int j = lane; j < K; j += 64) {
       const float v = gv(i, j) * (1.0f / (s_d[i] * s_d[j])) + (cols ? s_gs[j] : s_gs[i]);
       ob[static_cast<long>(i) * K + j] = (rsl && i == j) ? 0.f : v;
@@ -396,10 +426,10 @@ extern "C" int tgp_postprocess_dense_bwd_f32(const float* raw, const float* g_po
               "tgp_postprocess_dense_bwd_f32: edge_weight_norm is not differentiated by this entry");
   TGP_REQUIRE(K <= 4096 && B < (1ll << 31), TGP_ERR_RANGE, "tgp_postprocess_dense_bwd_f32: K > 4096");
   if (K <= 128) {
-    const size_t lds = (static_cast<size_t>(4 * K) + 2 * static_cast<size_t>(K) * (K + 1)) * sizeof(float);
+    const size_t lds = (static_cast<size_t>(12 * K) + 2 * static_cast<size_t>(K) * (K + 1)) * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(post_bwd_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    hipLaunchKernelGGL(post_bwd_kernel<true>, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, raw, g_post,
+    hipLaunchKernelGGL(post_bwd_kernel<true>, dim3(static_cast<unsigned>(B)), dim3(1024), lds, stream, raw, g_post,
                        static_cast<int>(K), flags, eps, g_raw);
   } else {
     const size_t lds = static_cast<size_t>(4 * K) * sizeof(float);
