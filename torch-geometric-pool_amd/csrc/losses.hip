@@ -21,6 +21,19 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+template <int T>
+__device__ __forceinline__ float block_sum_t(float v, float* sh) {  // sh: T / 64 floats; fixed order
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < T / 64; ++w) t += sh[w];
+  return t;
+}
+
 __device__ __forceinline__ float ent_term(float s, float eps) { return -s * logf(s + eps); }
 
 __global__ __launch_bounds__(256) void entropy_partial_kernel(const float* __restrict__ S, int64_t n, float eps,
@@ -101,26 +114,27 @@ __global__ __launch_bounds__(256) void cut_den_kernel(const float* __restrict__ 
 //   cut[b]   = -trace(raw[b]) / (den[b] + eps)                    raw = S^T A S, den = trace(S^T D S)
 //   ortho[b] = || G_b / ||G_b||_F - I / sqrt(K) ||_F              G = S^T S
 // (as torch ops these are ~14 launches of a few hundred bytes each).  One workgroup per graph; out[0,b], out[1,b].
-__global__ __launch_bounds__(256) void mincut_tail_kernel(const float* __restrict__ raw, const float* __restrict__ den,
+template <int T>  // threads: 1024 for K >= 64 (few graphs, K^2 elements each: the 256-thread form took 28 us at B = 32, K = 128)
+__global__ __launch_bounds__(T) void mincut_tail_kernel(const float* __restrict__ raw, const float* __restrict__ den,
                                                           const float* __restrict__ gram, int K, float eps,
                                                           int B, float* __restrict__ out) {
-  __shared__ float sh[4];
+  __shared__ float sh[T / 64];
   const int b = blockIdx.x;
   const float* R = raw + static_cast<int64_t>(b) * K * K;
   const float* G = gram + static_cast<int64_t>(b) * K * K;
   float tr = 0.f, sq = 0.f;
-  for (int i = threadIdx.x; i < K; i += 256) tr += R[static_cast<int64_t>(i) * K + i];
-  for (int i = threadIdx.x; i < K * K; i += 256) sq = fmaf(G[i], G[i], sq);
-  tr = block_sum_256(tr, sh);
-  sq = block_sum_256(sq, sh);
+  for (int i = threadIdx.x; i < K; i += T) tr += R[static_cast<int64_t>(i) * K + i];
+  for (int i = threadIdx.x; i < K * K; i += T) sq = fmaf(G[i], G[i], sq);
+  tr = block_sum_t<T>(tr, sh);
+  sq = block_sum_t<T>(sq, sh);
   const float n = sqrtf(sq);
   const float t = 1.0f / sqrtf(static_cast<float>(K));
   float acc = 0.f;
-  for (int i = threadIdx.x; i < K * K; i += 256) {
+  for (int i = threadIdx.x; i < K * K; i += T) {
     const float y = G[i] / n - ((i / K == i % K) ? t : 0.f);
     acc = fmaf(y, y, acc);
   }
-  acc = block_sum_256(acc, sh);
+  acc = block_sum_t<T>(acc, sh);
   if (threadIdx.x == 0) {
     out[b] = -(tr / (den[b] + eps));
     out[B + b] = sqrtf(acc);
@@ -132,36 +146,37 @@ __global__ __launch_bounds__(256) void mincut_tail_kernel(const float* __restric
 //   g_raw[b] = -(g_cut / (den + eps)) I                    (gradient with respect to raw = S^T A S)
 //   c1[b]    = g_cut * trace(raw) / (den + eps)^2          (gradient with respect to den; dden/dS = 2 D S)
 //   W[b]     = d ortho / d G = g_ortho / (|Y| |G|) (Y - G <G,Y> / |G|^2),  Y = G / |G| - I / sqrt(K)   (dS = S (W + W^T))
-__global__ __launch_bounds__(256) void mincut_tail_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ den,
+template <int T>
+__global__ __launch_bounds__(T) void mincut_tail_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ den,
                                                               const float* __restrict__ gram, const float* __restrict__ g,
                                                               int K, float eps, int B, float* __restrict__ g_raw,
                                                               float* __restrict__ c1, float* __restrict__ W) {
-  __shared__ float sh[4];
+  __shared__ float sh[T / 64];
   const int b = blockIdx.x;
   const int64_t off = static_cast<int64_t>(b) * K * K;
   const float* R = raw + off;
   const float* G = gram + off;
   float tr = 0.f, sq = 0.f;
-  for (int i = threadIdx.x; i < K; i += 256) tr += R[static_cast<int64_t>(i) * K + i];
-  for (int i = threadIdx.x; i < K * K; i += 256) sq = fmaf(G[i], G[i], sq);
-  tr = block_sum_256(tr, sh);
-  sq = block_sum_256(sq, sh);
+  for (int i = threadIdx.x; i < K; i += T) tr += R[static_cast<int64_t>(i) * K + i];
+  for (int i = threadIdx.x; i < K * K; i += T) sq = fmaf(G[i], G[i], sq);
+  tr = block_sum_t<T>(tr, sh);
+  sq = block_sum_t<T>(sq, sh);
   const float n = sqrtf(sq);
   const float t = 1.0f / sqrtf(static_cast<float>(K));
   float ny2 = 0.f, gy = 0.f;
-  for (int i = threadIdx.x; i < K * K; i += 256) {
+  for (int i = threadIdx.x; i < K * K; i += T) {
     const float y = G[i] / n - ((i / K == i % K) ? t : 0.f);
     ny2 = fmaf(y, y, ny2);
     gy = fmaf(G[i], y, gy);
   }
-  ny2 = block_sum_256(ny2, sh);
-  gy = block_sum_256(gy, sh);
+  ny2 = block_sum_t<T>(ny2, sh);
+  gy = block_sum_t<T>(gy, sh);
   const float ny = sqrtf(ny2);
   const float g_cut = g[b], g_ortho = g[B + b];
   const float dd = den[b] + eps;
   const float cdiag = -g_cut / dd;
   const float coef = ny > 0.f ? g_ortho / (ny * n) : 0.f;
-  for (int i = threadIdx.x; i < K * K; i += 256) {
+  for (int i = threadIdx.x; i < K * K; i += T) {
     const bool diag = i / K == i % K;
     const float y = G[i] / n - (diag ? t : 0.f);
     W[off + i] = coef * (y - G[i] * (gy / sq));
@@ -348,8 +363,12 @@ extern "C" int tgp_mincut_loss_terms_f32(const float* raw, const float* den, con
   if (B == 0) return TGP_OK;
   TGP_REQUIRE(raw && den && gram && out, TGP_ERR_INVALID, "tgp_mincut_loss_terms_f32: null pointer");
   TGP_REQUIRE(B < (1ll << 31), TGP_ERR_RANGE, "tgp_mincut_loss_terms_f32: too many graphs");
-  hipLaunchKernelGGL(mincut_tail_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream_), raw, den, gram, static_cast<int>(K), eps, static_cast<int>(B), out);
+  if (K >= 64)
+    hipLaunchKernelGGL(mincut_tail_kernel<1024>, dim3(static_cast<unsigned>(B)), dim3(1024), 0,
+                       static_cast<hipStream_t>(stream_), raw, den, gram, static_cast<int>(K), eps, static_cast<int>(B), out);
+  else
+    hipLaunchKernelGGL(mincut_tail_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), raw, den, gram, static_cast<int>(K), eps, static_cast<int>(B), out);
   return check_launch("tgp_mincut_loss_terms_f32");
 }
 
@@ -361,9 +380,14 @@ extern "C" int tgp_mincut_loss_terms_bwd_f32(const float* raw, const float* den,
   TGP_REQUIRE(raw && den && gram && g_terms && g_raw && c1 && W, TGP_ERR_INVALID,
               "tgp_mincut_loss_terms_bwd_f32: null pointer");
   TGP_REQUIRE(B < (1ll << 31), TGP_ERR_RANGE, "tgp_mincut_loss_terms_bwd_f32: too many graphs");
-  hipLaunchKernelGGL(mincut_tail_bwd_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream_), raw, den, gram, g_terms, static_cast<int>(K), eps,
-                     static_cast<int>(B), g_raw, c1, W);
+  if (K >= 64)
+    hipLaunchKernelGGL(mincut_tail_bwd_kernel<1024>, dim3(static_cast<unsigned>(B)), dim3(1024), 0,
+                       static_cast<hipStream_t>(stream_), raw, den, gram, g_terms, static_cast<int>(K), eps,
+                       static_cast<int>(B), g_raw, c1, W);
+  else
+    hipLaunchKernelGGL(mincut_tail_bwd_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), raw, den, gram, g_terms, static_cast<int>(K), eps,
+                       static_cast<int>(B), g_raw, c1, W);
   return check_launch("tgp_mincut_loss_terms_bwd_f32");
 }
 
