@@ -1150,3 +1150,46 @@ def test_graclus_tail_rounds_equal_the_device_wide_rounds(dev, n, m, weights, mo
     monkeypatch.setattr(N.lib(), "tgp_graclus_match_tail", lambda *a: seen.append(1) or real(*a))
     got = kernels.graclus_match(ei, ew, n)
     assert seen and torch.equal(got, want)
+
+
+# ------------------------------------------------------------------------------ batch facts in one read-back
+def _batch_info_torch(batch):
+    sizes = torch.bincount(batch)
+    return dict(num_graphs=sizes.numel(), sizes=sizes.tolist(), is_sorted=bool((batch[1:] >= batch[:-1]).all()),
+                max_nodes=int(sizes.max()), distinct=int((sizes > 0).sum()))
+
+
+@pytest.mark.parametrize("case", ["sorted", "unsorted", "gaps", "one", "single_node", "long_runs", "big"])
+def test_batch_facts_kernel_equals_the_torch_ops(dev, case):
+    """utils.ops.batch_info through tgp_batch_facts_i64 (one read-back) = bincount / comparison / max on the same vector;
+    ids beyond N or negative ids decline to the torch route."""
+    from tgp.utils.ops import batch_info
+    g = torch.Generator().manual_seed(3)
+    if case == "sorted":
+        batch = torch.repeat_interleave(torch.arange(300), torch.randint(1, 70, (300,), generator=g))
+    elif case == "unsorted":
+        batch = torch.randint(0, 50, (5000,), generator=g)
+    elif case == "gaps":      # empty graphs in the middle and a sorted vector
+        batch = torch.sort(torch.randint(0, 40, (200,), generator=g) * 3).values
+    elif case == "one":
+        batch = torch.zeros(1000, dtype=torch.long)
+    elif case == "single_node":
+        batch = torch.tensor([0])
+    elif case == "long_runs":  # runs longer than a wave and crossing workgroup boundaries
+        batch = torch.repeat_interleave(torch.arange(7), torch.tensor([1, 63, 64, 65, 700, 256, 1]))
+    else:
+        batch = torch.repeat_interleave(torch.arange(20000), torch.randint(20, 61, (20000,), generator=g))
+    want = _batch_info_torch(batch)
+    info = batch_info(batch.to(dev))
+    assert info.num_graphs == want["num_graphs"] and info.is_sorted == want["is_sorted"]
+    assert info.max_nodes == want["max_nodes"] and info.distinct == want["distinct"]
+    assert info.sizes.tolist() == want["sizes"] and info.sizes_host == want["sizes"]
+    assert info.ptr.tolist() == [0] + torch.cumsum(torch.tensor(want["sizes"]), 0).tolist()
+
+
+def test_batch_facts_kernel_declines_ids_it_cannot_count(dev):
+    from tgp.utils.ops import batch_info
+    info = batch_info(torch.tensor([0, 7], device=dev))     # more graph ids than nodes: legal, torch route
+    assert info.num_graphs == 8 and info.sizes.tolist() == [1, 0, 0, 0, 0, 0, 0, 1] and info.distinct == 2
+    with pytest.raises(RuntimeError):
+        batch_info(torch.tensor([0, -1], device=dev))       # (bincount's own error, as before)

@@ -106,9 +106,89 @@ __global__ __launch_bounds__(256) void from_dense_batch_kernel(const float* __re
   }
 }
 
+// Facts about a batch vector in one pass + a small second launch, for ONE host read (utils/ops.py batch_info; as torch
+// ops: bincount -- which synchronises for its output length --, a comparison, any, cat, a second synchronising copy).
+// sizes [N + 1] must be zero; facts = {max id, unsorted flag | 2 * (an id outside [0, N]), longest graph, non-empty graphs}.
+// Runs of equal ids inside a wave add their length with ONE atomic (a sorted batch of 40-node graphs: 2-3 per wave).
+__global__ __launch_bounds__(256) void batch_facts_kernel(const int64_t* __restrict__ batch, int64_t n,
+                                                          unsigned long long* __restrict__ sizes,
+                                                          unsigned long long* __restrict__ facts) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t base = (static_cast<int64_t>(blockIdx.x) * 256 + (threadIdx.x & ~63)); base < n;
+       base += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t i = base + lane;
+    const bool in = i < n;
+    const int64_t b = in ? batch[i] : 0;
+    const int64_t prev = (in && i > 0) ? batch[i - 1] : b;
+    const bool bad = in && (b < 0 || b > n);
+    const bool head = in && (lane == 0 || b != prev);
+    const unsigned long long heads = __ballot(head), valid = __ballot(in);
+    if (__ballot(in && b < prev) && lane == 0) atomicOr(facts + 1, 1ull);
+    if (__ballot(bad)) {
+      if (lane == 0) atomicOr(facts + 1, 2ull);
+      continue;
+    }
+    if (head) {
+      const unsigned long long above = heads & ~((2ull << lane) - 1ull);  // heads after this lane
+      const int end = above ? __ffsll(static_cast<long long>(above)) - 1 : __popcll(valid);
+      atomicAdd(sizes + b, static_cast<unsigned long long>(end - lane));
+    }
+    long long mx = in ? b : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const long long t = __shfl_xor(mx, o, 64);
+      mx = t > mx ? t : mx;
+    }
+    if (lane == 0) atomicMax(facts, static_cast<unsigned long long>(mx));
+  }
+}
+
+__global__ __launch_bounds__(256) void batch_facts_finish_kernel(const unsigned long long* __restrict__ sizes, int64_t n,
+                                                                 unsigned long long* __restrict__ facts) {
+  if (facts[1] & 2ull) return;
+  const int64_t B = static_cast<int64_t>(facts[0]) + 1;  // (written by the launch before this one)
+  unsigned long long mx = 0, cnt = 0;
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; g < B && g <= n;
+       g += static_cast<int64_t>(gridDim.x) * 256) {
+    const unsigned long long v = sizes[g];
+    mx = v > mx ? v : mx;
+    cnt += v > 0 ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_xor(mx, o, 64);
+    mx = t > mx ? t : mx;
+    cnt += __shfl_xor(cnt, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && (mx | cnt)) {
+    atomicMax(facts + 2, mx);
+    atomicAdd(facts + 3, cnt);
+  }
+}
+
 }  // namespace tgp
 
 using namespace tgp;
+
+// batch [N] int64 -> sizes [N + 1] int64 (graph g's node count at sizes[g]; the caller keeps sizes[:B]) and
+// facts int64[4] = {B - 1, bit 0: not sorted / bit 1: an id outside [0, N] (sizes are then meaningless), longest graph,
+// number of non-empty graphs}: everything utils/ops.py batch_info reads back, in one copy.
+extern "C" int tgp_batch_facts_i64(const int64_t* batch, int64_t N, int64_t* sizes, int64_t* facts, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(N >= 0 && sizes && facts, TGP_ERR_INVALID, "tgp_batch_facts_i64: bad argument");
+  (void)hipMemsetAsync(sizes, 0, sizeof(int64_t) * static_cast<size_t>(N + 1), stream);
+  (void)hipMemsetAsync(facts, 0, sizeof(int64_t) * 4, stream);
+  if (N == 0) return check_launch("tgp_batch_facts_i64");
+  TGP_REQUIRE(batch, TGP_ERR_INVALID, "tgp_batch_facts_i64: null pointer");
+  int64_t blocks = (N + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(batch_facts_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, batch, N,
+                     reinterpret_cast<unsigned long long*>(sizes), reinterpret_cast<unsigned long long*>(facts));
+  hipLaunchKernelGGL(batch_facts_finish_kernel, dim3(static_cast<unsigned>(blocks < 256 ? blocks : 256)), dim3(256), 0,
+                     stream, reinterpret_cast<const unsigned long long*>(sizes), N,
+                     reinterpret_cast<unsigned long long*>(facts));
+  return check_launch("tgp_batch_facts_i64");
+}
 
 extern "C" int tgp_to_dense_adj_f32(const int64_t* row, const int64_t* col, const float* w, int64_t E,
                                     const int64_t* batch, const int64_t* ptr, int64_t B, int64_t Nmax,

@@ -526,28 +526,23 @@ class TopkSelect(Select):
         dev = score.device
         seg_max = 0
         if batch is None or n == 0:
-            sizes_host, nb = [n], 1
+            nb = 1
             seg_max = n  # a single graph is trivially one sorted segment
-            sizes = torch.tensor(sizes_host, dtype=torch.long, device=dev) if n else torch.zeros(1, dtype=torch.long,
-                                                                                                 device=dev)
+            sizes = torch.full((1,), n, dtype=torch.long, device=dev)
             ptr = torch.zeros(2, dtype=torch.long, device=dev)
             ptr[1] = n
         else:
             info = batch_info(batch)
-            sizes, sizes_host, nb, ptr = info.sizes, info.sizes_host, info.num_graphs, info.ptr
+            sizes, nb, ptr = info.sizes, info.num_graphs, info.ptr
             seg_max = info.max_nodes if info.is_sorted else 0
-        # k_g exactly as PyG computes it (float32 product, ceil), on the host for the total and on the device
-        # for the kernel -- no round trip; remembered with the batch facts (a loader's batch vector is pooled every epoch
-        # with the same ratio; the host list -> tensor conversion alone was 50 us at 2048 graphs)
+        # k_g exactly as PyG computes it (float32 product, ceil) and its prefix sums: one launch; the total is the
+        # last prefix sum (one 8-byte read).  Remembered with the batch facts: a loader's batch vector that is pooled
+        # again (full-batch training, several poolers with one ratio) pays neither.
         memo = info.memo if (batch is not None and n) else {}
         plan = memo.get(("topk", float(self.ratio)))
         if plan is None:
-            hs = torch.tensor(sizes_host, dtype=torch.long)
-            if self.ratio >= 1:
-                k_host = torch.minimum(torch.full_like(hs, int(self.ratio)), hs)
-            else:
-                k_host = (float(self.ratio) * hs.to(torch.float32)).ceil().to(torch.long)
-            plan = (int(k_host.sum()),) + tuple(kernels.topk_plan(sizes, self.ratio))  # same arithmetic on the device
+            k, koff = kernels.topk_plan(sizes, self.ratio)
+            plan = (int(koff[-1]), k, koff)
             memo[("topk", float(self.ratio))] = plan
         k_total, k, koff = plan
         if torch.is_grad_enabled() and score.requires_grad:
@@ -840,11 +835,12 @@ class NDPSelect(Select):
             info = batch_info(batch)
             if not info.is_sorted:
                 return None
-            ptr, max_nodes, sizes_host = info.ptr, info.max_nodes, info.sizes_host
+            ptr, max_nodes = info.ptr, info.max_nodes
+            sizes_host = info.sizes_host if max_nodes > K.ndp_max_graph_nodes() else None  # (read back only when needed)
         else:
             ptr, max_nodes, sizes_host = torch.tensor([0, n], dtype=torch.long, device=dev), n, [n]
         limit = K.ndp_max_graph_nodes()
-        oversize = [g for g, m in enumerate(sizes_host) if m > limit]
+        oversize = [g for g, m in enumerate(sizes_host) if m > limit] if max_nodes > limit else []
         ident = torch.arange(n, device=dev)
         w0 = torch.ones(edge_index.size(1), device=dev) if edge_weight is None else edge_weight.detach().reshape(-1).float()
         # self loops out, duplicates summed (get_laplacian + COO -> CSR), then max with the transpose

@@ -74,11 +74,39 @@ class BatchInfo:
     valid only while the weak reference still resolves to the very same tensor and its version counter has
     not moved (an in-place write bumps it), which rules out stale hits from recycled memory."""
 
-    __slots__ = ("ref", "version", "num_graphs", "sizes", "sizes_host", "ptr", "max_nodes", "distinct", "is_sorted",
+    __slots__ = ("ref", "version", "num_graphs", "sizes", "_sizes_host", "ptr", "max_nodes", "distinct", "is_sorted",
                  "memo")  # memo: facts derived from the sizes by a caller (e.g. TopkSelect's per-graph k for a ratio)
+
+    @property
+    def sizes_host(self):
+        """The graph sizes as a Python list: read back on first use (the device route of batch_info needs only four
+        numbers on the host; KronConnect / NDPSelect ask for the list when they size per-graph work)."""
+        if self._sizes_host is None:
+            self._sizes_host = self.sizes.tolist()
+        return self._sizes_host
 
 
 _BATCH_INFO: dict = {}
+
+
+def _batch_facts_device(batch: Tensor, info: "BatchInfo") -> bool:
+    """Graph sizes, count, longest graph, sortedness from csrc/densify.hip's tgp_batch_facts_i64 (one read-back instead
+    of bincount's and a second one).  False: an id outside [0, N] (more graph ids than nodes, or a negative id) -- the
+    caller takes the torch route, which raises / sizes its output as the reference's ops do."""
+    from .. import _native as N
+    n = batch.numel()
+    sizes = torch.empty(n + 1, dtype=torch.long, device=batch.device)
+    facts = torch.empty(4, dtype=torch.long, device=batch.device)
+    N.check(N.lib().tgp_batch_facts_i64(N.ptr(batch), n, N.ptr(sizes), N.ptr(facts), N.stream_ptr(batch.device)),
+            "tgp_batch_facts_i64")
+    max_id, flags, longest, distinct = facts.tolist()
+    if flags & 2:
+        return False
+    info.num_graphs = max_id + 1
+    info.sizes = sizes[:info.num_graphs]
+    info.is_sorted = (flags & 1) == 0
+    info.max_nodes, info.distinct = longest, distinct
+    return True
 
 
 def batch_info(batch: Tensor) -> BatchInfo:
@@ -88,17 +116,20 @@ def batch_info(batch: Tensor) -> BatchInfo:
         return hit
     info = BatchInfo()
     info.ref, info.version, info.memo = weakref.ref(batch), batch._version, {}
+    info._sizes_host = None
     if batch.numel() == 0:
         info.sizes = torch.zeros(0, dtype=torch.long, device=batch.device)
-        info.num_graphs, info.max_nodes, info.distinct, info.sizes_host, info.is_sorted = 0, 0, 0, [], True
+        info.num_graphs, info.max_nodes, info.distinct, info._sizes_host, info.is_sorted = 0, 0, 0, [], True
+    elif batch.is_cuda and batch.dtype == torch.long and batch.is_contiguous() and _batch_facts_device(batch, info):
+        pass  # two launches, ONE host read of four numbers
     else:
         info.sizes = torch.bincount(batch)  # sync 1: the output length is max(batch) + 1
         info.num_graphs = info.sizes.numel()
         unsorted = (batch[1:] < batch[:-1]).any().to(info.sizes.dtype).view(1)
         host = torch.cat([info.sizes, unsorted]).tolist()  # sync 2 (B + 1 integers)
-        info.sizes_host, info.is_sorted = host[:-1], host[-1] == 0
-        info.max_nodes = max(info.sizes_host)
-        info.distinct = sum(1 for v in info.sizes_host if v > 0)
+        info._sizes_host, info.is_sorted = host[:-1], host[-1] == 0
+        info.max_nodes = max(info._sizes_host)
+        info.distinct = info.num_graphs - info._sizes_host.count(0)  # (list.count: a generator over 2048 sizes was 60 us)
     info.ptr = torch.zeros(info.num_graphs + 1, dtype=torch.long, device=batch.device)
     if info.num_graphs:
         torch.cumsum(info.sizes, 0, out=info.ptr[1:])
