@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10017 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10018 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -389,6 +389,11 @@ int tgp_mincut_loss_terms_bwd_f32(const float* raw, const float* den, const floa
 /* A7'  sparse A times dense S (connect/dense_conn.py:165,204: torch.sparse.mm), A in CSR built from a
  * row-sorted coalesced edge list: T[i,:] = sum_{e in row i} w[e] * S[col[e],:].  w may be NULL. */
 int tgp_rowptr_from_sorted_i64(const int64_t* rows, int64_t n, int64_t num_rows, int32_t* row_ptr, void* stream);
+/* the same for a list whose order has not been checked: *d_unsorted (zeroed by the entry) = 1 when a row id descends;
+ * the offsets of such a list are meaningless but stay in [0, n] (callers go on and read the flag with their next
+ * read-back instead of synchronising for the check first) */
+int tgp_rowptr_from_sorted_flag_i64(const int64_t* rows, int64_t n, int64_t num_rows, int32_t* row_ptr, int* d_unsorted,
+                                    void* stream);
 int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows, int64_t nnz,
                      const float* S, int64_t K, float* T, void* stream);
 

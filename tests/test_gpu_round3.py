@@ -1193,3 +1193,24 @@ def test_batch_facts_kernel_declines_ids_it_cannot_count(dev):
     assert info.num_graphs == 8 and info.sizes.tolist() == [1, 0, 0, 0, 0, 0, 0, 1] and info.distinct == 2
     with pytest.raises(RuntimeError):
         batch_info(torch.tensor([0, -1], device=dev))       # (bincount's own error, as before)
+
+
+def test_graclus_per_graph_route_with_an_unchecked_unsorted_edge_list(dev):
+    """The one-launch route goes on before the row order of a NEW edge_index object is known (the check rides on the
+    offsets kernel); a list that turns out not to be sorted is redone on the general route: same labels as ever, and the
+    memo remembers the answer for the object."""
+    from tgp import kernels
+    ei, ew, batch, ptr, n = _graph_batch([39] * 64, 3.7, 21, dev)
+    perm = torch.randperm(ei.size(1), device=dev)
+    ei_u, ew_u = ei[:, perm].contiguous(), ew[perm].contiguous()
+    want = kernels.graclus_match(ei, ew, n)
+    assert kernels._rows_sorted_memo(ei_u) is None
+    got = kernels.graclus_match(ei_u, ew_u, n, graph_ptr=ptr, max_graph_nodes=39)
+    assert torch.equal(got, want) and kernels._rows_sorted_memo(ei_u) is False
+    fresh = ei.clone()
+    assert kernels._rows_sorted_memo(fresh) is None
+    (index, k), row_ptr = kernels.graclus_match(fresh, ew, n, graph_ptr=ptr, max_graph_nodes=39, relabel=True,
+                                                return_row_ptr=True)
+    assert kernels._rows_sorted_memo(fresh) is True and row_ptr is not None
+    ids, inverse = torch.unique(want, return_inverse=True)
+    assert k == ids.numel() and torch.equal(index[1], inverse)

@@ -1,6 +1,6 @@
 """Where the HOST time of a pooler training step goes (cProfile over 300 steps, GPU work left asynchronous).
 
-    python tools/profile_host_step.py [mincut_c3|diff_c3|...] [--forward] [--infer] [--tottime]
+    python tools/profile_host_step.py [mincut_c3|diff_c3|...] [--forward] [--infer [--fresh]] [--tottime]
 
 --infer: the pooler's forward alone under no_grad, eval mode (any alias of e2e_launches.CASES, sparse poolers included).
 """
@@ -32,7 +32,10 @@ if "--infer" in sys.argv:
 def step():
     if "--infer" in sys.argv:
         with torch.no_grad():
-            pooler(x=x, adj=ei, batch=batch)
+            if "--fresh" in sys.argv:  # new tensor objects per call: the per-tensor memos miss (a DataLoader's batches)
+                pooler(x=x, adj=ei.clone(), batch=batch.clone())
+            else:
+                pooler(x=x, adj=ei, batch=batch)
         return
     pooler.zero_grad(set_to_none=True)
     x.grad = None

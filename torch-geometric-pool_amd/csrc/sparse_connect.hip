@@ -717,7 +717,8 @@ __global__ __launch_bounds__(256) void blockdiag_fill_kernel(BlockDiagPred pred,
 // one group of G lanes per row, float4 per lane; rows are summed in CSR (= sorted) order
 // =====================================================================================
 __global__ __launch_bounds__(256) void rowptr_from_sorted_kernel(const int64_t* __restrict__ rows, int64_t n,
-                                                                 int64_t num_rows, int32_t* __restrict__ row_ptr) {
+                                                                 int64_t num_rows, int32_t* __restrict__ row_ptr,
+                                                                 int* __restrict__ unsorted = nullptr) {
   // Ids are CLAMPED to [-1, num_rows]: a list with ids outside [0, num_rows) never writes outside row_ptr[0 ..
   // num_rows]; it shows as row_ptr[0] != 0 (negative ids in front) or row_ptr[num_rows] != n (ids >= num_rows behind),
   // which the consumers check before they trust the offsets.
@@ -732,6 +733,9 @@ __global__ __launch_bounds__(256) void rowptr_from_sorted_kernel(const int64_t* 
   const int64_t cur = clamp(rows[p]);
   const int64_t prev = p > 0 ? clamp(rows[p - 1]) : -1;
   for (int64_t c = prev + 1; c <= cur && c <= num_rows; ++c) row_ptr[c] = static_cast<int32_t>(p);
+  // (a list that is NOT sorted still gets every entry of row_ptr written, with values in [0, n]: any id is crossed by
+  //  an ascent, or lies below the first / above the last row -- offsets a kernel can walk without leaving the arrays)
+  if (unsorted && p > 0 && rows[p] < rows[p - 1]) *unsorted = 1;
 }
 
 __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict__ row_ptr,
@@ -1073,6 +1077,21 @@ extern "C" int tgp_debug_sort_pairs_u64(const uint64_t* keys_in, const uint32_t*
   return check_launch("tgp_debug_sort_pairs_u64");
 }
 
+// The same offsets for a list whose order has not been checked yet: *d_unsorted (zeroed here) becomes 1 when a row id
+// descends.  The caller goes on optimistically and reads the flag with its next read-back (the offsets of an unsorted
+// list are meaningless but in range).
+extern "C" int tgp_rowptr_from_sorted_flag_i64(const int64_t* rows, int64_t n, int64_t num_rows, int32_t* row_ptr,
+                                               int* d_unsorted, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(n >= 0 && num_rows >= 0 && row_ptr && d_unsorted && (n == 0 || rows), TGP_ERR_INVALID,
+              "tgp_rowptr_from_sorted_flag_i64: bad argument");
+  TGP_REQUIRE(n < (1ll << 31), TGP_ERR_RANGE, "tgp_rowptr_from_sorted_flag_i64: n >= 2^31");
+  (void)hipMemsetAsync(d_unsorted, 0, sizeof(int), stream);
+  hipLaunchKernelGGL(rowptr_from_sorted_kernel, dim3(cdiv(n + 1, 256)), dim3(256), 0, stream, rows, n, num_rows,
+                     row_ptr, d_unsorted);
+  return check_launch("tgp_rowptr_from_sorted_flag_i64");
+}
+
 // ------------------------------------------------------------------------------------- SpMM (A7')
 extern "C" int tgp_rowptr_from_sorted_i64(const int64_t* rows, int64_t n, int64_t num_rows, int32_t* row_ptr,
                                           void* stream_) {
@@ -1081,7 +1100,7 @@ extern "C" int tgp_rowptr_from_sorted_i64(const int64_t* rows, int64_t n, int64_
               "tgp_rowptr_from_sorted_i64: bad argument");
   TGP_REQUIRE(n < (1ll << 31), TGP_ERR_RANGE, "tgp_rowptr_from_sorted_i64: n >= 2^31");
   hipLaunchKernelGGL(rowptr_from_sorted_kernel, dim3(cdiv(n + 1, 256)), dim3(256), 0, stream, rows, n, num_rows,
-                     row_ptr);
+                     row_ptr, static_cast<int*>(nullptr));
   return check_launch("tgp_rowptr_from_sorted_i64");
 }
 

@@ -116,6 +116,7 @@ SIGNATURES = {
     "tgp_cut_terms_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "tgp_mincut_loss_terms_bwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_f, _c_p, _c_p, _c_p, _c_p]),
     "tgp_mincut_loss_terms_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_f, _c_p, _c_p]),
+    "tgp_rowptr_from_sorted_flag_i64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_rowptr_from_sorted_i64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_spmm_csr_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
     "tgp_to_dense_adj_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_int, _c_p, _c_p]),

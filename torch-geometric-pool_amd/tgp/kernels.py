@@ -676,13 +676,18 @@ def _rows_sorted(edge_index: Tensor, row: Tensor) -> bool:
     if hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version:
         return hit[2]
     flag = bool((row[1:] >= row[:-1]).all())
+    _remember_rows_sorted(edge_index, flag)
+    return flag
+
+
+def _remember_rows_sorted(edge_index: Tensor, flag: bool) -> None:
+    import weakref
     if len(_ROWS_SORTED) >= 16:
         for key in [k for k, v in _ROWS_SORTED.items() if v[0]() is None]:
             del _ROWS_SORTED[key]
         while len(_ROWS_SORTED) >= 16:
             del _ROWS_SORTED[next(iter(_ROWS_SORTED))]
     _ROWS_SORTED[id(edge_index)] = (weakref.ref(edge_index), edge_index._version, flag)
-    return flag
 
 
 def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: int,
@@ -710,16 +715,27 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
     st = N.stream_ptr(dev)
     # PyG lists are sorted by source: one comparison pass + round trip decides whether the CSR needs a sort at all
     # (remembered per edge_index object: full-batch training pools the same graph every epoch)
-    if E > 1 and _rows_sorted(edge_index, row):
+    words = torch.empty(4, dtype=torch.int32, device=dev)  # [status, rows-not-sorted flag, K (int64)]
+    per_graph = (max_rounds is None and graph_ptr is not None and max_graph_nodes is not None and E > 0
+                 and num_nodes > 0 and max_graph_nodes <= L.tgp_graclus_match_max_graph_nodes()
+                 and graph_ptr.numel() >= 2)
+    # a list nobody has looked at yet, on the one-launch route: go on as if it were sorted, the check rides on the
+    # offsets kernel and its flag is read with the status word (no round trip of its own)
+    optimistic = per_graph and E > 1 and _rows_sorted_memo(edge_index) is None
+    if optimistic or (E > 1 and _rows_sorted(edge_index, row)):
         row_ptr, perm = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev), None
-        N.check(L.tgp_rowptr_from_sorted_i64(N.ptr(row), E, num_nodes, N.ptr(row_ptr), st), "tgp_rowptr_from_sorted_i64")
+        if optimistic:
+            N.check(L.tgp_rowptr_from_sorted_flag_i64(N.ptr(row), E, num_nodes, N.ptr(row_ptr), N.ptr(words[1:]), st),
+                    "tgp_rowptr_from_sorted_flag_i64")
+        else:
+            N.check(L.tgp_rowptr_from_sorted_i64(N.ptr(row), E, num_nodes, N.ptr(row_ptr), st),
+                    "tgp_rowptr_from_sorted_i64")
         sorted_ptr = row_ptr
     else:
         index = build_assign_index(row, num_nodes)
         row_ptr, perm = index.row_ptr, index.perm
     ws = N.workspace(L.tgp_graclus_match_workspace_bytes(num_nodes, E), dev)
     finished = num_nodes == 0 or E == 0
-    words = torch.empty(4, dtype=torch.int32, device=dev)  # [status, -, K (int64)]
 
     def relabelled():
         index = torch.empty(2, num_nodes, dtype=torch.int64, device=dev)
@@ -741,14 +757,18 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
         N.check(L.tgp_graclus_match_start(N.ptr(row), N.ptr(col), N.ptr(w), N.ptr(row_ptr), N.ptr(perm), num_nodes, E,
                                           N.ptr(ws), ws.numel(), N.ptr(label), st), "tgp_graclus_match_start")
     start()
-    if (not finished and max_rounds is None and graph_ptr is not None and max_graph_nodes is not None
-            and max_graph_nodes <= L.tgp_graclus_match_max_graph_nodes() and graph_ptr.numel() >= 2):
+    if not finished and per_graph:
         gp = N.i64c(graph_ptr)
         N.check(L.tgp_graclus_match_graphs(N.ptr(row_ptr), num_nodes, E, N.ptr(ws), N.ptr(gp), gp.numel() - 1,
                                            int(max_graph_nodes), N.ptr(label), N.ptr(words), st),
                 "tgp_graclus_match_graphs")
         index = relabelled() if relabel else None  # (optimistic: one round trip for the status word and the count)
         got = words.tolist()
+        if optimistic:
+            _remember_rows_sorted(edge_index, got[1] == 0)
+            if got[1] != 0:  # not sorted after all: everything above walked meaningless offsets -- again, knowing it
+                return graclus_match(edge_index, edge_weight, num_nodes, max_rounds, return_row_ptr, graph_ptr,
+                                     max_graph_nodes, relabel)
         if got[0] == 0:
             return finish(index, got[2])
         start()  # an entry that leaves its graph (or a longer graph than declared): the device-wide rounds, from scratch
