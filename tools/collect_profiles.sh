@@ -24,6 +24,7 @@ stats topk_connect python3 bench.py --workload topk_connect --secondary none --n
 stats kron python3 tools/bench_kron.py --no-reference
 python3 tools/bench_kron.py > $out/kron.txt 2>&1
 python3 tools/e2e_launches.py > $out/e2e_launches.txt 2>&1
+python3 tools/e2e_fresh_batch.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $out/e2e_fresh_batch.txt
 python3 tools/bench_poolers_e2e.py > $out/e2e_poolers.txt 2>&1
 python3 tools/bench_ndp_large.py > $out/ndp_large.txt 2>&1
 python3 tools/e2e_train_step.py mincut_c3 diff_c3 mincut_c2 diff_c2 --top 8 2>&1 | grep -v -i "warn" > $out/e2e_train_steps.txt
