@@ -1214,3 +1214,24 @@ def test_graclus_per_graph_route_with_an_unchecked_unsorted_edge_list(dev):
     assert kernels._rows_sorted_memo(fresh) is True and row_ptr is not None
     ids, inverse = torch.unique(want, return_inverse=True)
     assert k == ids.numel() and torch.equal(index[1], inverse)
+
+
+@pytest.mark.parametrize("act", ["tanh", "linear"])
+@pytest.mark.parametrize("n,F", [(500, 16), (37, 7), (4096, 128)])
+def test_topk_score_function_gradients_vs_torch(dev, act, n, F):
+    """Fn.topk_score (forward: the fused kernel; backward in closed form) against autograd on the reference's expression
+    act((x * w).sum(-1) / w.norm()) (topk_select.py:176-184), fp64."""
+    from tgp import functions as Fn
+    g = torch.Generator().manual_seed(n + F)
+    x = torch.randn(n, F, generator=g).to(dev).requires_grad_(True)
+    w = (torch.rand(1, F, generator=g) - 0.5).to(dev).requires_grad_(True)
+    up = torch.randn(n, generator=g).to(dev)
+    s = Fn.topk_score(x, w, act == "tanh")
+    s.backward(up)
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    t = (xd * wd).sum(-1) / wd.norm(p=2, dim=-1)
+    sd = torch.tanh(t) if act == "tanh" else t
+    sd.backward(up.double())
+    assert torch.allclose(s.detach().double(), sd.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(x.grad.double(), xd.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(w.grad.double(), wd.grad, rtol=1e-4, atol=1e-4 * float(wd.grad.abs().max()))

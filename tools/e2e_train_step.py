@@ -34,10 +34,12 @@ def main():
             with torch.no_grad():
                 return pooler(x=x, adj=ei, batch=batch)
 
+        fresh = "--fresh" in sys.argv  # new edge_index / batch objects every step (mini-batch training: memos miss)
+
         def step():
             pooler.zero_grad(set_to_none=True)
             x.grad = None
-            out = pooler(x=x, adj=ei, batch=batch)
+            out = pooler(x=x, adj=ei.clone(), batch=batch.clone()) if fresh else pooler(x=x, adj=ei, batch=batch)
             loss = out.x.square().sum()
             if out.edge_weight is not None and out.edge_weight.requires_grad:
                 loss = loss + out.edge_weight.square().sum()

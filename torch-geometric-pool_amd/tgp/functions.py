@@ -586,6 +586,37 @@ def row_dot(x: Tensor, w: Tensor) -> Tensor:
     return _RowDotFn.apply(x, w) if _needs_grad(x, w) else K.row_dot(x, w)
 
 
+class _TopkScoreFn(torch.autograd.Function):
+    """TopkSelect's ratio-mode score act(x w / ||w||_2), act = tanh or identity (select/topk_select.py:176-184), as one
+    node of the graph: forward = the one pass over x (+ tanh), backward from t = x w / ||w||:
+    dx = (g_t / ||w||) w^T,  dw = x^T (g_t / ||w||) - (sum_i g_t[i] t[i]) w / ||w||^2,  g_t = g (1 - s^2) for tanh."""
+
+    @staticmethod
+    def forward(ctx, x, w, use_tanh):
+        t = K.topk_score(x, w, False)
+        s = torch.tanh(t) if use_tanh else t
+        ctx.save_for_backward(x, w, t, s)
+        ctx.use_tanh = use_tanh
+        return s
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, t, s = ctx.saved_tensors
+        gt = torch.ops.aten.tanh_backward(g, s) if ctx.use_tanh else g
+        inv = w.norm(p=2).reciprocal()
+        gtn = (gt * inv).contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = gtn.unsqueeze(1) * w.reshape(1, -1)
+        if ctx.needs_input_grad[1]:
+            gw = K.weighted_colsum(x, gtn).view_as(w) - (torch.dot(gtn, t) * inv) * w
+        return gx, gw, None
+
+
+def topk_score(x: Tensor, w: Tensor, use_tanh: bool) -> Tensor:
+    return _TopkScoreFn.apply(x, w, use_tanh) if _needs_grad(x, w) else K.topk_score(x, w, use_tanh)
+
+
 # ------------------------------------------------- A S and A^T S shared between Connect and the link loss
 class _DensePoolSmallFn(torch.autograd.Function):
     """Reduce + Connect (+ MinCut's two loss tails, + DiffPool's two losses) of a batch of small graphs as ONE kernel in

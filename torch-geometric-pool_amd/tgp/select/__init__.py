@@ -179,7 +179,19 @@ class SelectOutput:
 
     @property
     def weight(self) -> Optional[Tensor]:
-        return self.s.values() if self.is_sparse else None
+        if not self.is_sparse:
+            return None
+        # the selector's own values tensor while `s` is still the tensor it built: under autograd `s.values()` is
+        # differentiated through sparse_mask machinery (half a dozen launches per backward) for the same numbers
+        held = self.__dict__.get("_values_of")
+        if held is not None and held[0] is self.s:
+            return held[1]
+        return self.s.values()
+
+    def _hold_values(self, values: Tensor) -> None:
+        """Remember the (autograd-tracked) tensor the sparse ``s`` was built from: ``weight`` hands it out directly."""
+        if self.is_sparse and values.shape == (self.s._nnz(),):
+            self.__dict__["_values_of"] = (self.s, values)
 
     @property
     def out_mask(self) -> Optional[Tensor]:
@@ -258,7 +270,7 @@ class SelectOutput:
         factory = state.pop("_L_factory", None)  # a closure over device tensors: the pickle carries the Laplacian itself
         if factory is not None and "L" not in state:
             state["L"] = factory()
-        for helper in ("_adj_device_csr", "_kron_csr", "_node_batch", "_partition_info"):
+        for helper in ("_adj_device_csr", "_kron_csr", "_node_batch", "_partition_info", "_values_of"):
             state.pop(helper, None)  # device-side shortcuts of this process; KronConnect rebuilds what it needs from L
         return state
 
@@ -473,10 +485,10 @@ class TopkSelect(Select):
             feats = x.view(-1, 1) if x.dim() == 1 else x
             if (feats.is_cuda and self.min_score is None and self.ratio is not None and self._fused_act is not None
                     and feats.dtype == torch.float32 and feats.dim() == 2 and feats.size(0) > 0
-                    and not (torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad))):
-                # nothing to differentiate: dot, norm, division and activation in the one pass over x
-                from .. import kernels
-                score = kernels.topk_score(feats, self.weight.detach(), self._fused_act == "tanh")
+                    and self.weight.dtype == torch.float32):
+                # dot, norm, division (and, with nothing to differentiate, the activation) in the one pass over x;
+                # under autograd the whole score is one graph node (Fn.topk_score)
+                score = Fn.topk_score(feats, self.weight, self._fused_act == "tanh")
                 return self._native_select(score, batch if have_batch else None, x.size(0))
             # x.w in a single native pass over x (the elementwise product + row sum of the reference,
             # topk_select.py:176, writes and re-reads an [N,F] temporary)
@@ -556,6 +568,8 @@ class TopkSelect(Select):
         s = torch.sparse_coo_tensor(index, values, size=(n, k_total), is_coalesced=True)
         so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
         so._assign_index = assign
+        if values.requires_grad:
+            so._hold_values(values)
         return so
 
     def __repr__(self) -> str:
