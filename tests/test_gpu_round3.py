@@ -1235,3 +1235,22 @@ def test_topk_score_function_gradients_vs_torch(dev, act, n, F):
     assert torch.allclose(s.detach().double(), sd.detach(), rtol=1e-5, atol=1e-6)
     assert torch.allclose(x.grad.double(), xd.grad, rtol=1e-4, atol=1e-6)
     assert torch.allclose(w.grad.double(), wd.grad, rtol=1e-4, atol=1e-4 * float(wd.grad.abs().max()))
+
+
+def test_graclus_reduce_backward_with_the_identity_lift_index(dev):
+    """GraclusSelect's SelectOutput needs no transposed index for the backward of Reduce (node i owns assignment i):
+    dX = S dX' equals the gather it is, and Lift gives the same rows."""
+    from tgp.lift import lift_index_of
+    from tgp.poolers import get_pooler
+    ei, ew, batch, ptr, n = _graph_batch([33] * 20, 3.5, 8, dev)
+    x = torch.randn(n, 12, device=dev, requires_grad=True)
+    pooler = get_pooler("graclus").to(dev)
+    out = pooler(x=x, adj=ei, edge_weight=ew, batch=batch)
+    idx = lift_index_of(out.so)
+    assert idx.one_to_one and idx.perm is None
+    up = torch.randn_like(out.x)
+    out.x.backward(up)
+    want = up[out.so.cluster_index] * out.so.weight.unsqueeze(1)
+    assert torch.allclose(x.grad, want, rtol=1e-6, atol=1e-6)
+    lifted = pooler(x=out.x.detach(), so=out.so, lifting=True)
+    assert torch.allclose(lifted, out.x.detach()[out.so.cluster_index], rtol=1e-6, atol=1e-6)

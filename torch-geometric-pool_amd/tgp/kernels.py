@@ -31,14 +31,19 @@ class AssignIndex:
     """Inverted index of a sparse assignment (supernode -> its assignments, in ascending
     assignment order).  A function of the SelectOutput only, so SelectOutput caches it."""
 
-    __slots__ = ("_row_ptr", "perm", "nnz", "num_targets")
+    __slots__ = ("_row_ptr", "perm", "nnz", "num_targets", "_device")
 
-    def __init__(self, row_ptr: Optional[Tensor], perm: Tensor, nnz: int, num_targets: int):
+    def __init__(self, row_ptr: Optional[Tensor], perm: Optional[Tensor], nnz: int, num_targets: int, device=None):
         # row_ptr None: exactly one assignment per target (TopK, NDP) -- the table is arange and the Reduce kernel
-        # skips reading it; it is materialised only for a consumer that wants the general form
+        # skips reading it; it is materialised only for a consumer that wants the general form.  perm None (with
+        # row_ptr None): target t owns assignment t -- the transposed index of a one-over-K assignment whose
+        # node_index is 0..N-1 (Graclus): nothing to build, the kernel reads no table at all
         if row_ptr is None and nnz != num_targets:
             raise ValueError("an AssignIndex without row_ptr must be one-to-one")
+        if perm is None and (row_ptr is not None or device is None):
+            raise ValueError("an AssignIndex without perm must be one-to-one and name its device")
         self._row_ptr, self.perm, self.nnz, self.num_targets = row_ptr, perm, nnz, num_targets
+        self._device = perm.device if perm is not None else torch.device(device)
 
     @property
     def one_to_one(self) -> bool:
@@ -47,7 +52,7 @@ class AssignIndex:
     @property
     def row_ptr(self) -> Tensor:
         if self._row_ptr is None:
-            self._row_ptr = torch.arange(self.num_targets + 1, dtype=torch.int32, device=self.perm.device)
+            self._row_ptr = torch.arange(self.num_targets + 1, dtype=torch.int32, device=self._device)
         return self._row_ptr
 
 

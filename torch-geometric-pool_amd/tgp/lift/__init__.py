@@ -16,7 +16,11 @@ from ..utils.ops import (as_compute_dtype, like_input_dtype, build_pooled_batch,
 def lift_index_of(so: SelectOutput):
     """node -> assignments inverted index (the transpose of SelectOutput.assign_index), cached."""
     if so._lift_index is None:
-        so._lift_index = K.build_assign_index(so.node_index, so.num_nodes)
+        if so.__dict__.get("_identity_nodes") and so.s.is_cuda and so.s._nnz() == so.num_nodes:
+            # node i owns assignment i (one-over-K selectors whose node_index is 0..N-1): no table to build
+            so._lift_index = K.AssignIndex(None, None, so.num_nodes, so.num_nodes, device=so.s.device)
+        else:
+            so._lift_index = K.build_assign_index(so.node_index, so.num_nodes)
     return so._lift_index
 
 

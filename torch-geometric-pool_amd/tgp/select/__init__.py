@@ -733,6 +733,7 @@ class GraclusSelect(Select):
             s = torch.sparse_coo_tensor(index, torch.ones(num_nodes, device=index.device), size=(num_nodes, k),
                                         is_coalesced=True)
             so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
+            so.__dict__["_identity_nodes"] = True  # row 0 of the indices is 0..N-1: the transposed index is the identity
             if row_ptr is not None:
                 # CSR offsets of the (row-sorted) list the matcher walked: SparseConnect skips its own pass over the
                 # row array when it is handed this very edge_index object, unchanged (identity + version counter)
