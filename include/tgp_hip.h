@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10018 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10019 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -281,7 +281,10 @@ size_t tgp_topk_select_workspace_bytes(int64_t N);
 int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t B, const int64_t* ptr,
                     const int64_t* k, const int64_t* koff, int64_t segments_max_nodes, void* ws, size_t ws_bytes,
                     int64_t* node_index, int64_t* cluster_index, int32_t* assign_perm,
-                    float* values /* optional [k_total]: score[node_index], the weights of S */, void* stream);
+                    float* values /* optional [k_total]: score[node_index], the weights of S */,
+                    int32_t* lift_row_ptr /* optional [N+1]: CSR offsets of the node -> assignment index (the
+                                             transposed index Reduce's backward and Lift walk; its perm is the identity) */,
+                    void* stream);
 
 /* ----------------------------------------------------------------------------------
  * A14  GraclusSelect's matching (select/graclus_select.py:62-81 -> torch_cluster 1.6.3 graclus_cluster, absent

@@ -1254,3 +1254,28 @@ def test_graclus_reduce_backward_with_the_identity_lift_index(dev):
     assert torch.allclose(x.grad, want, rtol=1e-6, atol=1e-6)
     lifted = pooler(x=out.x.detach(), so=out.so, lifting=True)
     assert torch.allclose(lifted, out.x.detach()[out.so.cluster_index], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("sizes", [[50] * 40, [1, 2, 3, 700, 5], [5000]])
+def test_topk_select_hands_reduce_its_transposed_index(dev, sizes):
+    """Under autograd TopkSelect's compaction also emits the node -> assignment CSR offsets (perm = identity): equal to
+    the index build_assign_index derives from node_index, and x.grad through the pooler equals the reference expression."""
+    from tgp import kernels
+    from tgp.poolers import get_pooler
+    ei, ew, batch, ptr, n = _graph_batch(sizes, 3.0, 13, dev)
+    x = torch.randn(n, 9, device=dev, requires_grad=True)
+    pooler = get_pooler("topk", in_channels=9, ratio=0.4).to(dev)
+    out = pooler(x=x, adj=ei, edge_weight=ew, batch=batch)
+    lift = out.so._lift_index
+    assert lift is not None and lift.perm is None
+    want = kernels.build_assign_index(out.so.node_index, n)
+    assert torch.equal(lift.row_ptr, want.row_ptr) and torch.equal(want.perm, torch.arange(want.nnz, device=dev, dtype=torch.int32))
+    up = torch.randn_like(out.x)
+    out.x.backward(up)
+    # reference: x_pool = x[node_index] * score[node_index, None]; score = tanh(x w / |w|)
+    xd = x.detach().double().requires_grad_(True)
+    wd = pooler.selector.weight.detach().double()
+    score = torch.tanh((xd * wd).sum(-1) / wd.norm(p=2, dim=-1))
+    ni, ci = out.so.node_index, out.so.cluster_index      # row ci[j] of x_pool is node ni[j]
+    (xd[ni] * score[ni].unsqueeze(1)).backward(up.double()[ci])
+    assert torch.allclose(x.grad.double(), xd.grad, rtol=1e-4, atol=1e-5)

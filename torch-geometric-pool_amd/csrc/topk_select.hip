@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void topk_fill_kernel(const int32_t* __restric
                                                         int64_t* __restrict__ cluster_index,
                                                         int32_t* __restrict__ assign_perm,
                                                         const float* __restrict__ score,
-                                                        float* __restrict__ values) {
+                                                        float* __restrict__ values,
+                                                        int32_t* __restrict__ lift_ptr) {
   __shared__ uint32_t s_cnt[kTopkItems * 4];
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kTopkTile;
   bool flag[kTopkItems];
@@ -160,6 +161,17 @@ __global__ __launch_bounds__(256) void topk_fill_kernel(const int32_t* __restric
   uint32_t total;
   block_compact_ranks<kTopkItems>(flag, rank, total, s_cnt);
   const uint32_t off = offsets[blockIdx.x];
+  if (lift_ptr) {  // CSR offsets of the node -> assignment index: kept nodes are written in node order, so node i's
+                   // (at most one) assignment is the number of kept nodes in front of it; perm is the identity
+#pragma unroll
+    for (int it = 0; it < kTopkItems; ++it) {
+      const int64_t i = base + it * 256 + threadIdx.x;
+      if (i < n) {
+        lift_ptr[i] = static_cast<int32_t>(off + rank[it]);
+        if (i == n - 1) lift_ptr[n] = static_cast<int32_t>(off + rank[it] + (flag[it] ? 1u : 0u));
+      }
+    }
+  }
 #pragma unroll
   for (int it = 0; it < kTopkItems; ++it) {
     if (!flag[it]) continue;
@@ -502,7 +514,7 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
                                const int64_t* k, const int64_t* koff, int64_t segments_max_nodes, void* ws,
                                size_t ws_bytes,
                                int64_t* node_index, int64_t* cluster_index, int32_t* assign_perm, float* values,
-                               void* stream_) {
+                               int32_t* lift_row_ptr, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(N >= 0 && B >= 0, TGP_ERR_INVALID, "tgp_topk_select: negative size");
   if (N == 0 || B == 0) return TGP_OK;
@@ -533,7 +545,7 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
                      static_cast<const int*>(nullptr));
   if (node_index)
     hipLaunchKernelGGL(topk_fill_kernel, dim3(nbt), dim3(256), 0, stream, s.rank_of, N, s.offsets, node_index,
-                       cluster_index, assign_perm, score, values);
+                       cluster_index, assign_perm, score, values, lift_row_ptr);
   return check_launch("tgp_topk_select");
 }
 

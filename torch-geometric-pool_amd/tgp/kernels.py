@@ -40,10 +40,11 @@ class AssignIndex:
         # node_index is 0..N-1 (Graclus): nothing to build, the kernel reads no table at all
         if row_ptr is None and nnz != num_targets:
             raise ValueError("an AssignIndex without row_ptr must be one-to-one")
-        if perm is None and (row_ptr is not None or device is None):
-            raise ValueError("an AssignIndex without perm must be one-to-one and name its device")
+        if perm is None and device is None and row_ptr is None:
+            raise ValueError("an AssignIndex without perm and row_ptr must name its device")
         self._row_ptr, self.perm, self.nnz, self.num_targets = row_ptr, perm, nnz, num_targets
-        self._device = perm.device if perm is not None else torch.device(device)
+        self._device = perm.device if perm is not None else (row_ptr.device if row_ptr is not None else
+                                                              torch.device(device))
 
     @property
     def one_to_one(self) -> bool:
@@ -642,24 +643,28 @@ def topk_plan(sizes: Tensor, ratio: float) -> Tuple[Tensor, Tensor]:
 
 
 def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Tensor, k: Tensor, koff: Tensor,
-                k_total: int, segments_max_nodes: int = 0, with_values: bool = False):
+                k_total: int, segments_max_nodes: int = 0, with_values: bool = False, with_lift: bool = False):
     """Per-graph top-k (select/topk_select.py:194 -> PyG ``topk``) fused with the row sort of SelectOutput
     (select/base_select.py:58): (index [2, k_total] = node_index ascending over cluster_index, supernode -> assignment
-    index[, values = score[node_index] when ``with_values``: no gradient])."""
+    index[, values = score[node_index] when ``with_values``: no gradient][, the node -> assignment index when
+    ``with_lift``: what Reduce's backward and Lift walk, from the same compaction])."""
     dev = N.require_device(score, batch, ptr, k, koff)
     score = N.f32c(score.reshape(-1))
     n = score.numel()
     index = torch.empty(2, k_total, dtype=torch.int64, device=dev)  # the indices of the sparse S, written in place
     values = torch.empty(k_total, dtype=torch.float32, device=dev) if with_values else None
     perm = torch.empty(max(k_total, 1), dtype=torch.int32, device=dev)
+    lift_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev) if with_lift and n > 0 else None
+    with_lift = lift_ptr is not None
     L = N.lib()
     ws = N.workspace(L.tgp_topk_select_workspace_bytes(n), dev)
     N.check(L.tgp_topk_select(N.ptr(score), N.ptr(None if batch is None else N.i64c(batch)), n, num_graphs,
                               N.ptr(N.i64c(ptr)), N.ptr(N.i64c(k)), N.ptr(N.i64c(koff)), segments_max_nodes, N.ptr(ws),
                               ws.numel(), N.ptr(index[0]), N.ptr(index[1]), N.ptr(perm), N.ptr(values),
-                              N.stream_ptr(dev)), "tgp_topk_select")
+                              N.ptr(lift_ptr), N.stream_ptr(dev)), "tgp_topk_select")
     assign = AssignIndex(None, perm, k_total, k_total)
-    return (index, assign, values) if with_values else (index, assign)
+    out = (index, assign) + ((values,) if with_values else ())
+    return out + ((AssignIndex(lift_ptr, None, k_total, n),) if with_lift else ())
 
 
 _ROWS_SORTED: dict = {}

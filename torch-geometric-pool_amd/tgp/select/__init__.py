@@ -557,9 +557,12 @@ class TopkSelect(Select):
             plan = (int(koff[-1]), k, koff)
             memo[("topk", float(self.ratio))] = plan
         k_total, k, koff = plan
+        lift = None
         if torch.is_grad_enabled() and score.requires_grad:
-            index, assign = kernels.topk_select(score.detach(), batch, nb, ptr, k, koff, k_total,
-                                                segments_max_nodes=seg_max)
+            got = kernels.topk_select(score.detach(), batch, nb, ptr, k, koff, k_total, segments_max_nodes=seg_max,
+                                      with_lift=True)  # (the backward of Reduce walks the transposed index)
+            index, assign = got[0], got[1]
+            lift = got[2] if len(got) > 2 else None
             values = Fn.take_unique(score, index[0])
         else:  # the weights of S come out of the compaction kernel
             index, assign, values = kernels.topk_select(score, batch, nb, ptr, k, koff, k_total,
@@ -568,6 +571,7 @@ class TopkSelect(Select):
         s = torch.sparse_coo_tensor(index, values, size=(n, k_total), is_coalesced=True)
         so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
         so._assign_index = assign
+        so._lift_index = lift
         if values.requires_grad:
             so._hold_values(values)
         return so
