@@ -609,7 +609,7 @@ class _TopkScoreFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = gtn.unsqueeze(1) * w.reshape(1, -1)
         if ctx.needs_input_grad[1]:
-            gw = K.weighted_colsum(x, gtn).view_as(w) - (torch.dot(gtn, t) * inv) * w
+            gw = K.weighted_colsum(x, gtn).view_as(w) - ((gtn * t).sum() * inv) * w
         return gx, gw, None
 
 
