@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
     const unsigned long long* __restrict__ grouped, const uint32_t* __restrict__ raw_off, int64_t K, int reduce_op,
     int flags, float eps,
     int* __restrict__ bad, uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w, uint32_t* __restrict__ n_out,
-    int64_t n_nodes) {
+    int64_t n_nodes, uint32_t* __restrict__ long_list) {
   __shared__ uint32_t s_key[GS_CAP];
   __shared__ float s_val[GS_CAP];
   __shared__ uint32_t s_roff[GS_ROWS + 1];
@@ -568,6 +568,11 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
         }
         // rows of 33..64 entries wait for (c1b); longer ones go out raw with the copy below, for cr_rows_long_kernel
         if (i < re && T > 32 && T <= 64 && (tid & (LPR - 1)) == 0) s_mid[atomicAdd(&s_nmid, 1)] = i;
+        // (long rows are listed for cr_rows_long_kernel, which spreads the list over its workgroups: hub supernodes sit
+        //  next to each other -- the first nodes of a preferential-attachment graph -- and a workgroup per 256 rows that
+        //  sorted its own long rows one after the other took 150 us for a 4500-node batch with a dozen hubs)
+        if (i < re && T > 64 && (tid & (LPR - 1)) == 0)
+          long_list[atomicAdd(bad + 1, 1)] = static_cast<uint32_t>(r0 + i);
         const bool mine = i < re && T <= 32;
         cr_sort_rows<LPR>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), has_w, reduce_op, flags,
                           eps, n_out + r0 + i);
@@ -601,35 +606,22 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
   }
 }
 
-// Rows of 65..1024 raw entries (rare: hub supernodes), left raw in tmp by the gather kernel: one workgroup per
-// row, bitonic sort of (column << 32 | position) in LDS, sorted + merged in place.
+// Rows of 65..1024 raw entries (rare: hub supernodes), left raw in tmp and listed by the gather kernel: a workgroup
+// takes every gridDim.x-th row of the list; bitonic sort of (column << 32 | position) in LDS, sorted + merged in place.
 __global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w,
                                                            const uint32_t* __restrict__ raw_off, int64_t K,
                                                            int64_t E, int reduce_op, int flags, float eps,
                                                            const int* __restrict__ bad,
+                                                           const uint32_t* __restrict__ long_list,
                                                            uint32_t* __restrict__ n_out) {
   __shared__ unsigned long long s_key[CR_LONG];
   __shared__ float s_w[CR_LONG];
   __shared__ uint32_t s_cnt[4 * 4];
-  __shared__ int s_list[256];
-  __shared__ int s_nlist;
   if (*bad) return;
   const int tid = threadIdx.x;
-  // each workgroup owns 256 consecutive rows: find the long ones with one coalesced look, then sort them
-  if (tid == 0) s_nlist = 0;
-  __syncthreads();
-  {
-    const int64_t rr = static_cast<int64_t>(blockIdx.x) * 256 + tid;
-    if (rr < K) {
-      const uint32_t tb = raw_off[rr];
-      const uint32_t tt = (rr + 1 < K ? raw_off[rr + 1] : static_cast<uint32_t>(E)) - tb;
-      if (tt > 64 && tt <= CR_LONG) s_list[atomicAdd(&s_nlist, 1)] = tid;
-    }
-  }
-  __syncthreads();
-  const int nlist = s_nlist;
-  for (int li = 0; li < nlist; ++li) {
-    const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + s_list[li];
+  const int nlist = bad[1];
+  for (int li = blockIdx.x; li < nlist; li += gridDim.x) {
+    const int64_t r = long_list[li];
     const uint32_t b = raw_off[r];
     const uint32_t T = (r + 1 < K ? raw_off[r + 1] : static_cast<uint32_t>(E)) - b;
     uint32_t P = 64;
@@ -1157,7 +1149,8 @@ struct CrWs {
   float* tmp_w;          // [E]
   uint32_t* scan_scratch;
   int64_t* total;
-  int* bad;
+  int* bad;              // [0] status, [1] number of long rows (65 .. CR_LONG raw entries) listed in long_list
+  uint32_t* long_list;   // [E / 64 + 2] long rows in the order the gather kernel met them
 };
 
 static size_t cr_layout(void* ws, int64_t E, int64_t N, int64_t K, CrWs* out) {
@@ -1177,8 +1170,13 @@ static size_t cr_layout(void* ws, int64_t E, int64_t N, int64_t K, CrWs* out) {
   s.scan_scratch = cv.take<uint32_t>(2 * static_cast<size_t>(cdiv(k, SCAN_TILE) + cdiv(n, MS_TILE)) + 16);
   s.total = cv.take<int64_t>(2);
   s.bad = cv.take<int>(4);
+  s.long_list = cv.take<uint32_t>(e / 64 + 2);
   if (out) *out = s;
   return cv.off;
+}
+
+static unsigned cr_long_grid(int64_t K) {  // workgroups of cr_rows_long_kernel (each takes every grid-th listed row)
+  return static_cast<unsigned>(K < 1024 ? (K > 0 ? K : 1) : 1024);
 }
 
 __global__ __launch_bounds__(256) void cr_table_kernel(const int64_t* __restrict__ cluster, int64_t n,
@@ -1223,7 +1221,7 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
   CrWs s;
   cr_layout(ws, E, N, K, &s);
   float* tmp_w = w ? s.tmp_w : nullptr;
-  (void)hipMemsetAsync(s.bad, 0, sizeof(int), stream);
+  (void)hipMemsetAsync(s.bad, 0, 2 * sizeof(int), stream);
   if (csr_ptr) {
     // CSR offsets of this very list from the caller (GraclusSelect builds them): no pass over the row array
     s.node_ptr = reinterpret_cast<uint32_t*>(const_cast<int32_t*>(csr_ptr));  // non-negative: same bits; read only
@@ -1256,9 +1254,9 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
   //  against 185 us for the fused gather: the 10 M random 4-byte table look-ups take ~50 us wherever they run)
   hipLaunchKernelGGL(cr_gather_sort_kernel<false>, dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, col, w, E, s.table,
                      assign_row_ptr, s.seg_src, s.seg_dst, static_cast<const unsigned long long*>(nullptr), s.raw_off, K,
-                     reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out, N);
-  hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
-                     reduce_op, flags, eps, s.bad, s.n_out);
+                     reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out, N, s.long_list);
+  hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cr_long_grid(K)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
+                     reduce_op, flags, eps, s.bad, s.long_list, s.n_out);
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);
   return check_launch("tgp_connect_coalesce_rows_count");
 }
@@ -1469,7 +1467,7 @@ extern "C" int tgp_connect_coalesce_grouped_count(const int64_t* row, const int6
   CgWs g;
   cg_layout(ws, E, N, K, &s, &g);
   float* tmp_w = w ? s.tmp_w : nullptr;
-  (void)hipMemsetAsync(s.bad, 0, sizeof(int), stream);
+  (void)hipMemsetAsync(s.bad, 0, 2 * sizeof(int), stream);
   hipLaunchKernelGGL(cr_table_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, cluster_index, N, s.table);
   {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -1494,9 +1492,9 @@ extern "C" int tgp_connect_coalesce_grouped_count(const int64_t* row, const int6
                      static_cast<const int64_t*>(nullptr), static_cast<const float*>(nullptr), E,
                      static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr),
                      static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), vals, s.raw_off, K,
-                     reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out, N);
-  hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
-                     reduce_op, flags, eps, s.bad, s.n_out);
+                     reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out, N, s.long_list);
+  hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cr_long_grid(K)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
+                     reduce_op, flags, eps, s.bad, s.long_list, s.n_out);
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);
   return check_launch("tgp_connect_coalesce_grouped_count");
 }
