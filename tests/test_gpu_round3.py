@@ -1279,3 +1279,23 @@ def test_topk_select_hands_reduce_its_transposed_index(dev, sizes):
     ni, ci = out.so.node_index, out.so.cluster_index      # row ci[j] of x_pool is node ni[j]
     (xd[ni] * score[ni].unsqueeze(1)).backward(up.double()[ci])
     assert torch.allclose(x.grad.double(), xd.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("sizes", [[3000, 100, 8192, 2049], [2669, 506, 152, 1176], [5000]])
+def test_topk_large_segment_sort_equals_the_device_wide_sort(dev, sizes):
+    """Graphs of 2049 .. 8192 nodes are ranked one workgroup per graph (1024 threads, LDS bitonic network) instead of by
+    the device-wide radix sort: identical node_index / cluster_index, ties included (lower node id first)."""
+    from tgp import kernels
+    from tgp.utils.ops import batch_info
+    g = torch.Generator().manual_seed(sum(sizes))
+    n = sum(sizes)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(dev)
+    score = torch.randn(n, generator=g)
+    score[torch.randint(0, n, (n // 10,), generator=g)] = 0.25      # ties
+    score = score.to(dev)
+    info = batch_info(batch)
+    k, koff = kernels.topk_plan(info.sizes, 0.3)
+    k_total = int(koff[-1])
+    seg = kernels.topk_select(score, batch, info.num_graphs, info.ptr, k, koff, k_total, segments_max_nodes=max(sizes))
+    rad = kernels.topk_select(score, batch, info.num_graphs, info.ptr, k, koff, k_total, segments_max_nodes=0)
+    assert torch.equal(seg[0], rad[0]) and torch.equal(seg[1].perm, rad[1].perm)

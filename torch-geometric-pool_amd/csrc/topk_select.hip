@@ -92,24 +92,29 @@ __global__ __launch_bounds__(256) void topk_segsort_wave_kernel(const float* __r
   if (lane < n && lane < k[g]) rank_of[lo + static_cast<int64_t>(v & 0xFFFFFFFFull)] = static_cast<int32_t>(koff[g] + lane);
 }
 
-__global__ __launch_bounds__(256) void topk_segsort_block_kernel(const float* __restrict__ score,
-                                                                 const int64_t* __restrict__ ptr,
-                                                                 const int64_t* __restrict__ k,
-                                                                 const int64_t* __restrict__ koff,
-                                                                 int32_t* __restrict__ rank_of) {
-  __shared__ unsigned long long s_v[kSegSortMax];
+// T = 256 threads for graphs up to kSegSortMax nodes, 1024 threads (dynamic LDS) up to kSegSortLarge: a handful of
+// graphs of a few thousand nodes (the reference harness's batches) took the device-wide radix sort before -- 15 launches
+// for 4500 keys.
+constexpr int kSegSortLarge = 8192;
+template <int T>
+__global__ __launch_bounds__(T) void topk_segsort_block_kernel(const float* __restrict__ score,
+                                                               const int64_t* __restrict__ ptr,
+                                                               const int64_t* __restrict__ k,
+                                                               const int64_t* __restrict__ koff,
+                                                               int32_t* __restrict__ rank_of) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_v[];
   const int64_t g = blockIdx.x;
   const int64_t lo = ptr[g];
   const int n = static_cast<int>(ptr[g + 1] - lo);
   if (n == 0) return;
   int m = 64;
   while (m < n) m <<= 1;  // padded power of two (<= kSegSortMax by dispatch)
-  for (int i = threadIdx.x; i < m; i += 256)
+  for (int i = threadIdx.x; i < m; i += T)
     s_v[i] = i < n ? (static_cast<unsigned long long>(descending_key(score[lo + i])) << 32) | static_cast<unsigned>(i) : ~0ull;
   __syncthreads();
   for (int size = 2; size <= m; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = threadIdx.x; t < m / 2; t += 256) {
+      for (int t = threadIdx.x; t < m / 2; t += T) {
         const int i = 2 * t - (t & (stride - 1));   // lower index of the pair
         const int j = i + stride;
         const bool up = (i & size) == 0;
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256) void topk_segsort_block_kernel(const float* __
     }
   }
   const int kg = static_cast<int>(k[g] < n ? k[g] : n);
-  for (int q = threadIdx.x; q < kg; q += 256)
+  for (int q = threadIdx.x; q < kg; q += T)
     rank_of[lo + static_cast<int64_t>(s_v[q] & 0xFFFFFFFFull)] = static_cast<int32_t>(koff[g] + q);
 }
 
@@ -528,9 +533,17 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
   if (segments_max_nodes > 0 && segments_max_nodes <= 64) {
     hipLaunchKernelGGL(topk_segsort_wave_kernel, dim3(cdiv(B, 4)), dim3(256), 0, stream, score, ptr, k, koff, B,
                        s.rank_of);
-  } else if (segments_max_nodes > 0 && segments_max_nodes <= kSegSortMax && B >= 64) {
-    hipLaunchKernelGGL(topk_segsort_block_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, score, ptr, k,
-                       koff, s.rank_of);
+  } else if (segments_max_nodes > 0 && segments_max_nodes <= kSegSortMax) {
+    hipLaunchKernelGGL(topk_segsort_block_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256),
+                       kSegSortMax * sizeof(unsigned long long), stream, score, ptr, k, koff, s.rank_of);
+  } else if (segments_max_nodes > 0 && segments_max_nodes <= kSegSortLarge) {
+    int m = 64;
+    while (m < segments_max_nodes) m <<= 1;
+    const size_t lds = static_cast<size_t>(m) * sizeof(unsigned long long);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_segsort_block_kernel<1024>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    hipLaunchKernelGGL(topk_segsort_block_kernel<1024>, dim3(static_cast<unsigned>(B)), dim3(1024), lds, stream, score,
+                       ptr, k, koff, s.rank_of);
   } else {
     hipLaunchKernelGGL(topk_keys_kernel, dim3(nb256), dim3(256), 0, stream, score, batch, N, s.k0, s.v0);
     bool first = true;
