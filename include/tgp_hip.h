@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10019 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10020 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -323,7 +323,13 @@ int tgp_graclus_match_graphs(const int32_t* row_ptr, int64_t num_nodes, int64_t 
 int64_t tgp_graclus_relabel_max_nodes(void);
 size_t tgp_graclus_relabel_workspace_bytes(int64_t num_nodes);
 int tgp_graclus_relabel_i64(const int64_t* label, int64_t num_nodes, void* ws, size_t ws_bytes, int64_t* index_out,
-                            int64_t* d_k, void* stream);
+                            int64_t* d_k,
+                            int32_t* assign_row_ptr /* optional [N + 1] (the first K + 1 entries are written) */,
+                            int32_t* assign_perm /* optional [N]; both or neither: the supernode -> members index the
+                                                    sparse Reduce and the coalesce Connect walk (what
+                                                    tgp_assign_index_build derives from the ids), valid when every
+                                                    label is shared by at most two nodes -- a matching */,
+                            void* stream);
 
 /* TopkSelect scoring (select/topk_select.py:176, score = (x * w).sum(-1)): out[i] = <x[i,:], w>, one pass over
  * x [N,F] (row stride ldx); and the matching weight gradient out[f] = sum_i g[i] x[i,f] (fixed-order two-level

@@ -1097,10 +1097,21 @@ def test_graclus_relabel_kernel_equals_unique_inverse(dev, n):
     index = torch.full((2, n), -1, dtype=torch.int64, device=dev)
     k = torch.full((1,), -1, dtype=torch.int64, device=dev)
     ws = N.workspace(L.tgp_graclus_relabel_workspace_bytes(n), dev)
-    N.check(L.tgp_graclus_relabel_i64(N.ptr(label), n, N.ptr(ws), ws.numel(), N.ptr(index), N.ptr(k),
+    N.check(L.tgp_graclus_relabel_i64(N.ptr(label), n, N.ptr(ws), ws.numel(), N.ptr(index), N.ptr(k), None, None,
                                       N.stream_ptr(dev)), "relabel")
     assert int(k) == ids.numel()
     assert torch.equal(index[0].cpu(), torch.arange(n)) and torch.equal(index[1].cpu(), inverse)
+    # the same call with the supernode -> members index of the matching: equal to what the general builder derives
+    from tgp import kernels
+    row_ptr = torch.full((n + 1,), -7, dtype=torch.int32, device=dev)
+    perm = torch.full((max(n, 1),), -7, dtype=torch.int32, device=dev)
+    index2 = torch.empty_like(index)
+    N.check(L.tgp_graclus_relabel_i64(N.ptr(label), n, N.ptr(ws), ws.numel(), N.ptr(index2), N.ptr(k), N.ptr(row_ptr),
+                                      N.ptr(perm), N.stream_ptr(dev)), "relabel")
+    assert torch.equal(index2, index)
+    if n:
+        want = kernels.build_assign_index(index[1], int(k))
+        assert torch.equal(row_ptr[:int(k) + 1], want.row_ptr) and torch.equal(perm[:n], want.perm)
 
 
 @pytest.mark.parametrize("n,F", [(1, 4), (100, 16), (3000, 32), (777, 7), (50, 300), (4096, 128), (20, 1024)])
@@ -1209,8 +1220,8 @@ def test_graclus_per_graph_route_with_an_unchecked_unsorted_edge_list(dev):
     assert torch.equal(got, want) and kernels._rows_sorted_memo(ei_u) is False
     fresh = ei.clone()
     assert kernels._rows_sorted_memo(fresh) is None
-    (index, k), row_ptr = kernels.graclus_match(fresh, ew, n, graph_ptr=ptr, max_graph_nodes=39, relabel=True,
-                                                return_row_ptr=True)
+    (index, k, _), row_ptr = kernels.graclus_match(fresh, ew, n, graph_ptr=ptr, max_graph_nodes=39, relabel=True,
+                                                   return_row_ptr=True)
     assert kernels._rows_sorted_memo(fresh) is True and row_ptr is not None
     ids, inverse = torch.unique(want, return_inverse=True)
     assert k == ids.numel() and torch.equal(index[1], inverse)

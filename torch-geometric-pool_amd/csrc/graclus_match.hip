@@ -429,17 +429,21 @@ __global__ __launch_bounds__(1024) void gm_tail_rounds_kernel(const int32_t* __r
 // inside the tile and the tile total; the second launch scans the (few) tile totals in LDS in every workgroup and looks
 // the rank of label[i] up as tile prefix + word prefix + popcount of the lower bits.
 constexpr int RL_TILE = 1024;
-constexpr int RL_MAX_TILES = 8192;  // tile prefixes held in LDS (32 KB): 8.4 M nodes
+constexpr int RL_MAX_TILES = 4096;  // tile prefixes held in LDS (two tables of 16 KB): 4.2 M nodes
 __global__ __launch_bounds__(256) void rl_flags_kernel(const int64_t* __restrict__ label, int64_t n,
                                                        uint32_t* __restrict__ bits, uint32_t* __restrict__ wprefix,
-                                                       uint32_t* __restrict__ tile_sum) {
+                                                       uint32_t* __restrict__ tile_sum,
+                                                       uint32_t* __restrict__ paired) {
   __shared__ uint32_t pc[32];
   const int64_t base = static_cast<int64_t>(blockIdx.x) * RL_TILE;
   const int w = threadIdx.x >> 6;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t i = base + r * 256 + threadIdx.x;
-    const unsigned long long m = __ballot(i < n && label[i] == i);
+    const int64_t li = i < n ? label[i] : i;
+    if (paired && i < n && li != i && li >= 0 && li < n)  // the partner marks its representative (zeroed bitmap)
+      atomicOr(paired + (li >> 5), 1u << (li & 31));
+    const unsigned long long m = __ballot(i < n && li == i);
     if (lane_id() == 0) {
       const int q = r * 8 + w * 2;
       const uint32_t lo = static_cast<uint32_t>(m), hi = static_cast<uint32_t>(m >> 32);
@@ -458,20 +462,33 @@ __global__ __launch_bounds__(256) void rl_flags_kernel(const int64_t* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void rl_assign_kernel(const int64_t* __restrict__ label, int64_t n,
-                                                        const uint32_t* __restrict__ bits,
-                                                        const uint32_t* __restrict__ wprefix,
-                                                        const uint32_t* __restrict__ tile_sum, int tiles,
-                                                        int64_t* __restrict__ index_out, int64_t* __restrict__ d_k) {
-  __shared__ uint32_t s_tp[RL_MAX_TILES];
-  __shared__ uint32_t s_part[256];
-  // exclusive scan of the tile totals: thread t owns a contiguous run of `per` tiles
-  const int per = (tiles + 255) / 256;
+// word prefixes and tile totals of the "has a partner" bitmap (complete only after rl_flags_kernel has finished)
+__global__ __launch_bounds__(256) void rl_paired_prefix_kernel(const uint32_t* __restrict__ paired, int tiles,
+                                                               uint32_t* __restrict__ wprefix2,
+                                                               uint32_t* __restrict__ tile_sum2) {
+  const int t = blockIdx.x * 8 + (threadIdx.x >> 5), q = threadIdx.x & 31;  // 32 lanes per tile, 8 tiles per workgroup
+  if (t >= tiles) return;
+  const uint32_t c = __popc(paired[static_cast<int64_t>(t) * 32 + q]);
+  uint32_t inc = c;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const uint32_t v = __shfl_up(inc, o, 32);
+    if (q >= o) inc += v;
+  }
+  wprefix2[static_cast<int64_t>(t) * 32 + q] = inc - c;
+  if (q == 31) tile_sum2[t] = inc;
+}
+
+// exclusive scan of `tiles` totals into s_tp (every workgroup does it for itself); returns the grand total
+__device__ __forceinline__ uint32_t rl_scan_tiles(const uint32_t* __restrict__ tile_sum, int tiles, uint32_t* s_tp,
+                                                  uint32_t* s_part) {
+  const int per = (tiles + 255) / 256;  // thread t owns a contiguous run of `per` tiles
   uint32_t mine = 0;
   for (int q = 0; q < per; ++q) {
     const int t = threadIdx.x * per + q;
     mine += t < tiles ? tile_sum[t] : 0u;
   }
+  __syncthreads();  // (s_part may still be read from a previous call)
   s_part[threadIdx.x] = mine;
   __syncthreads();
   for (int d = 1; d < 256; d <<= 1) {
@@ -489,7 +506,31 @@ __global__ __launch_bounds__(256) void rl_assign_kernel(const int64_t* __restric
     }
   }
   __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) *d_k = static_cast<int64_t>(s_part[255]);
+  return s_part[255];
+}
+
+// PAIRS: also the supernode -> members index of a MATCHING (every label shared by at most two nodes): cluster c of
+// representative r starts at c + (paired representatives before r) and holds r, then its partner -- ascending node
+// order, what tgp_assign_index_build derives from the cluster ids with five launches.
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void rl_assign_kernel(const int64_t* __restrict__ label, int64_t n,
+                                                        const uint32_t* __restrict__ bits,
+                                                        const uint32_t* __restrict__ wprefix,
+                                                        const uint32_t* __restrict__ tile_sum,
+                                                        const uint32_t* __restrict__ paired,
+                                                        const uint32_t* __restrict__ wprefix2,
+                                                        const uint32_t* __restrict__ tile_sum2, int tiles,
+                                                        int64_t* __restrict__ index_out, int64_t* __restrict__ d_k,
+                                                        int32_t* __restrict__ a_row_ptr, int32_t* __restrict__ a_perm) {
+  __shared__ uint32_t s_tp[RL_MAX_TILES];
+  __shared__ uint32_t s_tp2[PAIRS ? RL_MAX_TILES : 1];
+  __shared__ uint32_t s_part[256];
+  const uint32_t total = rl_scan_tiles(tile_sum, tiles, s_tp, s_part);
+  if constexpr (PAIRS) rl_scan_tiles(tile_sum2, tiles, s_tp2, s_part);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *d_k = static_cast<int64_t>(total);
+    if constexpr (PAIRS) a_row_ptr[total] = static_cast<int32_t>(n);
+  }
   const int64_t base = static_cast<int64_t>(blockIdx.x) * RL_TILE;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -497,10 +538,19 @@ __global__ __launch_bounds__(256) void rl_assign_kernel(const int64_t* __restric
     if (i >= n) continue;
     int64_t j = label[i];
     j = j < 0 ? 0 : (j >= n ? n - 1 : j);  // (the matcher's labels are in range; a caller's might not be)
-    const uint32_t word = bits[j >> 5];
-    const uint32_t rank = s_tp[j >> 10] + wprefix[j >> 5] + __popc(word & ((1u << (j & 31)) - 1u));
+    const uint32_t below = (1u << (j & 31)) - 1u;
+    const uint32_t rank = s_tp[j >> 10] + wprefix[j >> 5] + __popc(bits[j >> 5] & below);
     index_out[i] = i;
     index_out[n + i] = static_cast<int64_t>(rank);
+    if constexpr (PAIRS) {
+      const uint32_t slot = rank + s_tp2[j >> 10] + wprefix2[j >> 5] + __popc(paired[j >> 5] & below);
+      if (i == j) {
+        a_row_ptr[rank] = static_cast<int32_t>(slot);
+        a_perm[slot] = static_cast<int32_t>(i);
+      } else {
+        a_perm[slot + 1] = static_cast<int32_t>(i);
+      }
+    }
   }
 }
 
@@ -512,17 +562,21 @@ extern "C" int64_t tgp_graclus_relabel_max_nodes(void) { return static_cast<int6
 
 extern "C" size_t tgp_graclus_relabel_workspace_bytes(int64_t num_nodes) {
   const size_t tiles = static_cast<size_t>(cdiv(num_nodes > 0 ? num_nodes : 1, RL_TILE));
-  return 2 * align_up(tiles * 32 * sizeof(uint32_t)) + align_up(tiles * sizeof(uint32_t)) + 256;
+  return 4 * align_up(tiles * 32 * sizeof(uint32_t)) + 2 * align_up(tiles * sizeof(uint32_t)) + 256;
 }
 
 // index_out[0][i] = i, index_out[1][i] = consecutive id of label[i] (ids in the order of the representatives
 // label[r] == r), *d_k = number of ids: the indices of the [N, K] assignment the selector returns.
 extern "C" int tgp_graclus_relabel_i64(const int64_t* label, int64_t num_nodes, void* ws, size_t ws_bytes,
-                                       int64_t* index_out, int64_t* d_k, void* stream_) {
+                                       int64_t* index_out, int64_t* d_k, int32_t* assign_row_ptr,
+                                       int32_t* assign_perm, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(num_nodes >= 0 && d_k, TGP_ERR_INVALID, "tgp_graclus_relabel_i64: bad argument");
+  TGP_REQUIRE((assign_row_ptr == nullptr) == (assign_perm == nullptr), TGP_ERR_INVALID,
+              "tgp_graclus_relabel_i64: assign_row_ptr and assign_perm come together");
   if (num_nodes == 0) {
     (void)hipMemsetAsync(d_k, 0, sizeof(int64_t), stream);
+    if (assign_row_ptr) (void)hipMemsetAsync(assign_row_ptr, 0, sizeof(int32_t), stream);
     return check_launch("tgp_graclus_relabel_i64");
   }
   TGP_REQUIRE(num_nodes <= tgp_graclus_relabel_max_nodes(), TGP_ERR_RANGE, "tgp_graclus_relabel_i64: too many nodes");
@@ -533,9 +587,23 @@ extern "C" int tgp_graclus_relabel_i64(const int64_t* label, int64_t num_nodes, 
   uint32_t* bits = cv.take<uint32_t>(static_cast<int64_t>(tiles) * 32);
   uint32_t* wprefix = cv.take<uint32_t>(static_cast<int64_t>(tiles) * 32);
   uint32_t* tile_sum = cv.take<uint32_t>(tiles);
-  hipLaunchKernelGGL(rl_flags_kernel, dim3(tiles), dim3(256), 0, stream, label, num_nodes, bits, wprefix, tile_sum);
-  hipLaunchKernelGGL(rl_assign_kernel, dim3(tiles), dim3(256), 0, stream, label, num_nodes, bits, wprefix, tile_sum,
-                     tiles, index_out, d_k);
+  uint32_t* paired = cv.take<uint32_t>(static_cast<int64_t>(tiles) * 32);
+  uint32_t* wprefix2 = cv.take<uint32_t>(static_cast<int64_t>(tiles) * 32);
+  uint32_t* tile_sum2 = cv.take<uint32_t>(tiles);
+  if (assign_row_ptr) {
+    (void)hipMemsetAsync(paired, 0, static_cast<size_t>(tiles) * 32 * sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(rl_flags_kernel, dim3(tiles), dim3(256), 0, stream, label, num_nodes, bits, wprefix, tile_sum,
+                       paired);
+    hipLaunchKernelGGL(rl_paired_prefix_kernel, dim3(cdiv(tiles, 8)), dim3(256), 0, stream, paired, tiles, wprefix2,
+                       tile_sum2);
+    hipLaunchKernelGGL(rl_assign_kernel<true>, dim3(tiles), dim3(256), 0, stream, label, num_nodes, bits, wprefix,
+                       tile_sum, paired, wprefix2, tile_sum2, tiles, index_out, d_k, assign_row_ptr, assign_perm);
+  } else {
+    hipLaunchKernelGGL(rl_flags_kernel, dim3(tiles), dim3(256), 0, stream, label, num_nodes, bits, wprefix, tile_sum,
+                       static_cast<uint32_t*>(nullptr));
+    hipLaunchKernelGGL(rl_assign_kernel<false>, dim3(tiles), dim3(256), 0, stream, label, num_nodes, bits, wprefix,
+                       tile_sum, paired, wprefix2, tile_sum2, tiles, index_out, d_k, assign_row_ptr, assign_perm);
+  }
   return check_launch("tgp_graclus_relabel_i64");
 }
 

@@ -712,7 +712,7 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
     it is row-sorted (else None) -- the matcher builds them anyway and SparseConnect can reuse them.
     ``graph_ptr`` [B+1] / ``max_graph_nodes``: node offsets of the graphs of a sorted batch and its longest graph; when
     every graph fits one workgroup all rounds of all graphs run as ONE launch (same matching).
-    ``relabel``: return ``(index [2, N], K)`` instead of the labels -- row 0 = 0..N-1, row 1 = the consecutive cluster id
+    ``relabel``: return ``(index [2, N], K, assign_index)`` instead of the labels -- row 0 = 0..N-1, row 1 = the consecutive cluster id
     of every node (``torch.unique(label, return_inverse=True)[1]``, graclus_select.py:68) from two more launches, its
     count read back together with the matcher's status word."""
     dev = N.require_device(edge_index, edge_weight)
@@ -747,11 +747,18 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
     ws = N.workspace(L.tgp_graclus_match_workspace_bytes(num_nodes, E), dev)
     finished = num_nodes == 0 or E == 0
 
+    pairs = {}
+
     def relabelled():
         index = torch.empty(2, num_nodes, dtype=torch.int64, device=dev)
         rws = N.workspace(L.tgp_graclus_relabel_workspace_bytes(num_nodes), dev)
+        # the supernode -> members index comes out of the same kernels (a matching: a representative and at most one
+        # partner per cluster), so Reduce / Connect do not build it from the ids
+        pairs["row_ptr"] = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+        pairs["perm"] = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=dev)
         N.check(L.tgp_graclus_relabel_i64(N.ptr(label), num_nodes, N.ptr(rws), rws.numel(), N.ptr(index),
-                                          N.ptr(words[2:]), st), "tgp_graclus_relabel_i64")
+                                          N.ptr(words[2:]), N.ptr(pairs["row_ptr"]), N.ptr(pairs["perm"]), st),
+                "tgp_graclus_relabel_i64")
         return index
 
     def finish(index=None, k=None):
@@ -760,7 +767,8 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
             if index is None:
                 index = relabelled()
                 k = words.tolist()[2]
-            out = (index, int(k))
+            k = int(k)
+            out = (index, k, AssignIndex(pairs["row_ptr"][:k + 1], pairs["perm"], num_nodes, k))
         return (out, sorted_ptr) if return_row_ptr else out
 
     def start():
