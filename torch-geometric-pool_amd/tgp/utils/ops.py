@@ -120,7 +120,8 @@ def batch_info(batch: Tensor) -> BatchInfo:
     if batch.numel() == 0:
         info.sizes = torch.zeros(0, dtype=torch.long, device=batch.device)
         info.num_graphs, info.max_nodes, info.distinct, info._sizes_host, info.is_sorted = 0, 0, 0, [], True
-    elif batch.is_cuda and batch.dtype == torch.long and batch.is_contiguous() and _batch_facts_device(batch, info):
+    elif (batch.is_cuda and batch.dtype == torch.long and batch.is_contiguous() and batch.numel() <= (1 << 24)
+          and _batch_facts_device(batch, info)):  # (its size table has one slot per NODE: 128 MB at the cap)
         pass  # two launches, ONE host read of four numbers
     else:
         info.sizes = torch.bincount(batch)  # sync 1: the output length is max(batch) + 1
