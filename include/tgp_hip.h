@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10020 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10021 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -433,9 +433,10 @@ int tgp_from_dense_batch_f32(const float* dense, int64_t N, int64_t F, const int
                              int64_t B, int64_t Nmax, float* x, void* stream);
 /* Facts about a batch vector for ONE host read (what PyG's to_dense_batch / the reference's src.py:434-450 obtain with
  * batch.max().item() and a bincount): sizes [N + 1] int64 = node count per graph id (the caller keeps sizes[:B]),
- * facts int64[4] = {B - 1, bit 0: not sorted | bit 1: an id outside [0, N] (sizes are then meaningless), nodes of the
- * longest graph, number of non-empty graphs}. */
-int tgp_batch_facts_i64(const int64_t* batch, int64_t N, int64_t* sizes, int64_t* facts, void* stream);
+ * facts int64[5] = {B - 1, bit 0: not sorted | bit 1: an id outside [0, N] (sizes are then meaningless), nodes of the
+ * longest graph, number of non-empty graphs, sum over graphs of TopkSelect's k_g for topk_ratio (tgp_topk_plan's
+ * arithmetic; 0 when topk_ratio <= 0)}. */
+int tgp_batch_facts_i64(const int64_t* batch, int64_t N, int64_t* sizes, int64_t* facts, double topk_ratio, void* stream);
 /* to_dense_batch for a SORTED batch vector (graph b = nodes ptr[b] .. ptr[b+1]): output-parallel, padding and mask
  * written by the same kernel (no memsets in front).  zero_buf / zero_count (optional): a second float buffer to zero-fill
  * in the same launch (the adjacency tgp_to_dense_adj_f32 scatters into next). */

@@ -1310,3 +1310,16 @@ def test_topk_large_segment_sort_equals_the_device_wide_sort(dev, sizes):
     seg = kernels.topk_select(score, batch, info.num_graphs, info.ptr, k, koff, k_total, segments_max_nodes=max(sizes))
     rad = kernels.topk_select(score, batch, info.num_graphs, info.ptr, k, koff, k_total, segments_max_nodes=0)
     assert torch.equal(seg[0], rad[0]) and torch.equal(seg[1].perm, rad[1].perm)
+
+
+@pytest.mark.parametrize("ratio", [0.5, 0.1, 0.37, 3, 1.0])
+def test_batch_facts_carry_the_topk_total(dev, ratio):
+    """A TopK selector that reads the batch facts first gets sum_g k_g with them: equal to the plan kernel's last prefix sum
+    (PyG's ceil(fp32(ratio) * n_g) / min(ratio, n_g))."""
+    from tgp import kernels
+    from tgp.utils.ops import batch_info
+    g = torch.Generator().manual_seed(17)
+    batch = torch.repeat_interleave(torch.arange(500), torch.randint(1, 90, (500,), generator=g)).to(dev)
+    info = batch_info(batch, topk_ratio=float(ratio))
+    k, koff = kernels.topk_plan(info.sizes, ratio)
+    assert info.memo[("topk_total", float(ratio))] == int(koff[-1]) == int(k.sum())

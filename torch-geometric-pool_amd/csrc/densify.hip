@@ -144,25 +144,35 @@ __global__ __launch_bounds__(256) void batch_facts_kernel(const int64_t* __restr
 }
 
 __global__ __launch_bounds__(256) void batch_facts_finish_kernel(const unsigned long long* __restrict__ sizes, int64_t n,
-                                                                 unsigned long long* __restrict__ facts) {
+                                                                 unsigned long long* __restrict__ facts, float ratio) {
   if (facts[1] & 2ull) return;
   const int64_t B = static_cast<int64_t>(facts[0]) + 1;  // (written by the launch before this one)
-  unsigned long long mx = 0, cnt = 0;
+  unsigned long long mx = 0, cnt = 0, keep = 0;
   for (int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; g < B && g <= n;
        g += static_cast<int64_t>(gridDim.x) * 256) {
     const unsigned long long v = sizes[g];
     mx = v > mx ? v : mx;
     cnt += v > 0 ? 1 : 0;
+    if (ratio > 0.f) {  // TopkSelect's k_g, the arithmetic of topk_plan_kernel (PyG: ceil(fp32(ratio) * n_g) / min)
+      if (ratio >= 1.0f) {
+        const unsigned long long r = static_cast<unsigned long long>(ratio);
+        keep += r < v ? r : v;
+      } else {
+        keep += static_cast<unsigned long long>(ceilf(__fmul_rn(ratio, static_cast<float>(v))));
+      }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned long long t = __shfl_xor(mx, o, 64);
     mx = t > mx ? t : mx;
     cnt += __shfl_xor(cnt, o, 64);
+    keep += __shfl_xor(keep, o, 64);
   }
   if ((threadIdx.x & 63) == 0 && (mx | cnt)) {
     atomicMax(facts + 2, mx);
     atomicAdd(facts + 3, cnt);
+    if (keep) atomicAdd(facts + 4, keep);
   }
 }
 
@@ -171,13 +181,15 @@ __global__ __launch_bounds__(256) void batch_facts_finish_kernel(const unsigned 
 using namespace tgp;
 
 // batch [N] int64 -> sizes [N + 1] int64 (graph g's node count at sizes[g]; the caller keeps sizes[:B]) and
-// facts int64[4] = {B - 1, bit 0: not sorted / bit 1: an id outside [0, N] (sizes are then meaningless), longest graph,
-// number of non-empty graphs}: everything utils/ops.py batch_info reads back, in one copy.
-extern "C" int tgp_batch_facts_i64(const int64_t* batch, int64_t N, int64_t* sizes, int64_t* facts, void* stream_) {
+// facts int64[5] = {B - 1, bit 0: not sorted / bit 1: an id outside [0, N] (sizes are then meaningless), longest graph,
+// number of non-empty graphs, sum_g k_g of TopkSelect for `topk_ratio` (0: not asked)}: everything utils/ops.py batch_info
+// and a TopK selector behind it read back, in one copy.
+extern "C" int tgp_batch_facts_i64(const int64_t* batch, int64_t N, int64_t* sizes, int64_t* facts, double topk_ratio,
+                                   void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(N >= 0 && sizes && facts, TGP_ERR_INVALID, "tgp_batch_facts_i64: bad argument");
   (void)hipMemsetAsync(sizes, 0, sizeof(int64_t) * static_cast<size_t>(N + 1), stream);
-  (void)hipMemsetAsync(facts, 0, sizeof(int64_t) * 4, stream);
+  (void)hipMemsetAsync(facts, 0, sizeof(int64_t) * 5, stream);
   if (N == 0) return check_launch("tgp_batch_facts_i64");
   TGP_REQUIRE(batch, TGP_ERR_INVALID, "tgp_batch_facts_i64: null pointer");
   int64_t blocks = (N + 255) / 256;
@@ -186,7 +198,7 @@ extern "C" int tgp_batch_facts_i64(const int64_t* batch, int64_t N, int64_t* siz
                      reinterpret_cast<unsigned long long*>(sizes), reinterpret_cast<unsigned long long*>(facts));
   hipLaunchKernelGGL(batch_facts_finish_kernel, dim3(static_cast<unsigned>(blocks < 256 ? blocks : 256)), dim3(256), 0,
                      stream, reinterpret_cast<const unsigned long long*>(sizes), N,
-                     reinterpret_cast<unsigned long long*>(facts));
+                     reinterpret_cast<unsigned long long*>(facts), static_cast<float>(topk_ratio > 0.0 ? topk_ratio : 0.0));
   return check_launch("tgp_batch_facts_i64");
 }
 

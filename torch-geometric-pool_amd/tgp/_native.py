@@ -101,7 +101,7 @@ SIGNATURES = {
     "tgp_graclus_match_max_graph_nodes": (_c_int, []),
     "tgp_graclus_match_graphs": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_graclus_match_rounds": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_p, _c_p]),
-    "tgp_batch_facts_i64": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "tgp_batch_facts_i64": (_c_int, [_c_p, _c_i64, _c_p, _c_p, ctypes.c_double, _c_p]),
     "tgp_topk_score_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_p]),
     "tgp_row_dot_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_weighted_colsum_workspace_bytes": (_c_sz, [_c_i64]),

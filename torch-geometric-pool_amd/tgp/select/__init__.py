@@ -544,7 +544,7 @@ class TopkSelect(Select):
             ptr = torch.zeros(2, dtype=torch.long, device=dev)
             ptr[1] = n
         else:
-            info = batch_info(batch)
+            info = batch_info(batch, topk_ratio=float(self.ratio))
             sizes, nb, ptr = info.sizes, info.num_graphs, info.ptr
             seg_max = info.max_nodes if info.is_sorted else 0
         # k_g exactly as PyG computes it (float32 product, ceil) and its prefix sums: one launch; the total is the
@@ -554,7 +554,8 @@ class TopkSelect(Select):
         plan = memo.get(("topk", float(self.ratio)))
         if plan is None:
             k, koff = kernels.topk_plan(sizes, self.ratio)
-            plan = (int(koff[-1]), k, koff)
+            total = memo.get(("topk_total", float(self.ratio)))  # (came with the batch facts when this call read them)
+            plan = (int(koff[-1]) if total is None else int(total), k, koff)
             memo[("topk", float(self.ratio))] = plan
         k_total, k, koff = plan
         lift = None

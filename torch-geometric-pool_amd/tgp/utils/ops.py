@@ -89,19 +89,21 @@ class BatchInfo:
 _BATCH_INFO: dict = {}
 
 
-def _batch_facts_device(batch: Tensor, info: "BatchInfo") -> bool:
+def _batch_facts_device(batch: Tensor, info: "BatchInfo", topk_ratio: float = 0.0) -> bool:
     """Graph sizes, count, longest graph, sortedness from csrc/densify.hip's tgp_batch_facts_i64 (one read-back instead
     of bincount's and a second one).  False: an id outside [0, N] (more graph ids than nodes, or a negative id) -- the
     caller takes the torch route, which raises / sizes its output as the reference's ops do."""
     from .. import _native as N
     n = batch.numel()
     sizes = torch.empty(n + 1, dtype=torch.long, device=batch.device)
-    facts = torch.empty(4, dtype=torch.long, device=batch.device)
-    N.check(N.lib().tgp_batch_facts_i64(N.ptr(batch), n, N.ptr(sizes), N.ptr(facts), N.stream_ptr(batch.device)),
-            "tgp_batch_facts_i64")
-    max_id, flags, longest, distinct = facts.tolist()
+    facts = torch.empty(5, dtype=torch.long, device=batch.device)
+    N.check(N.lib().tgp_batch_facts_i64(N.ptr(batch), n, N.ptr(sizes), N.ptr(facts), float(topk_ratio or 0.0),
+                                        N.stream_ptr(batch.device)), "tgp_batch_facts_i64")
+    max_id, flags, longest, distinct, keep = facts.tolist()
     if flags & 2:
         return False
+    if topk_ratio and topk_ratio > 0:
+        info.memo[("topk_total", float(topk_ratio))] = keep  # (TopkSelect's sum of k_g: no read-back of its own)
     info.num_graphs = max_id + 1
     info.sizes = sizes[:info.num_graphs]
     info.is_sorted = (flags & 1) == 0
@@ -109,7 +111,8 @@ def _batch_facts_device(batch: Tensor, info: "BatchInfo") -> bool:
     return True
 
 
-def batch_info(batch: Tensor) -> BatchInfo:
+def batch_info(batch: Tensor, topk_ratio: float = 0.0) -> BatchInfo:
+    """``topk_ratio``: a TopK selector asking first also gets its total number of kept nodes from the same read-back."""
     import weakref
     hit = _BATCH_INFO.get(id(batch))
     if hit is not None and hit.ref() is batch and hit.version == batch._version:
@@ -121,7 +124,7 @@ def batch_info(batch: Tensor) -> BatchInfo:
         info.sizes = torch.zeros(0, dtype=torch.long, device=batch.device)
         info.num_graphs, info.max_nodes, info.distinct, info._sizes_host, info.is_sorted = 0, 0, 0, [], True
     elif (batch.is_cuda and batch.dtype == torch.long and batch.is_contiguous() and batch.numel() <= (1 << 24)
-          and _batch_facts_device(batch, info)):  # (its size table has one slot per NODE: 128 MB at the cap)
+          and _batch_facts_device(batch, info, topk_ratio)):  # (its size table has one slot per NODE: 128 MB at the cap)
         pass  # two launches, ONE host read of four numbers
     else:
         info.sizes = torch.bincount(batch)  # sync 1: the output length is max(batch) + 1
