@@ -126,10 +126,16 @@ __global__ __launch_bounds__(256) void gm_init_kernel(int64_t n, int64_t* __rest
 // Best free neighbour of free node i under the edge key (w, hash, min, max), or -1.  `is_free_of(j)` tests a
 // neighbour's flag (global byte array or LDS bitmap).  A wave is as slow as its slowest lane and a lane's scan is
 // a chain of dependent loads, so the neighbours are taken eight at a time: ids and weights first, flags second.
-template <typename FreeFn>
-__device__ __forceinline__ int32_t gm_best_neighbour(int64_t i, const int32_t* __restrict__ row_ptr,
-                                                     const int32_t* __restrict__ nbr, const float* __restrict__ wt,
-                                                     FreeFn is_free_of) {
+// a table addressed with GLOBAL indices whose storage starts at index `off` (an LDS copy of a graph's slice)
+template <typename T>
+struct GmShifted {
+  const T* base;
+  int64_t off;
+  __device__ __forceinline__ T operator[](int64_t k) const { return base[k - off]; }
+};
+
+template <typename FreeFn, typename PtrT = const int32_t*, typename NbrT = const int32_t*, typename WtT = const float*>
+__device__ __forceinline__ int32_t gm_best_neighbour(int64_t i, PtrT row_ptr, NbrT nbr, WtT wt, FreeFn is_free_of) {
   int32_t best = -1;
   float bw = 0.f;
   uint32_t bh = 0;
@@ -337,8 +343,11 @@ __global__ __launch_bounds__(T) void gm_graph_rounds_kernel(const int32_t* __res
     if (threadIdx.x == 0) atomicOr(status, 2);
     return;
   }
-  if (in_lds) gm_graph_rounds<T>(s_ptr - p0, s_nbr - e0, s_wt - e0, p0, n, s_free, s_cand, label);
-  else gm_graph_rounds<T>(s_ptr - p0, nbr, wt, p0, n, s_free, s_cand, label);
+  const GmShifted<int32_t> ptr_g{s_ptr, p0};
+  if (in_lds)
+    gm_graph_rounds<T>(ptr_g, GmShifted<int32_t>{s_nbr, e0}, GmShifted<float>{s_wt, e0}, p0, n, s_free, s_cand, label);
+  else
+    gm_graph_rounds<T>(ptr_g, nbr, wt, p0, n, s_free, s_cand, label);
 }
 
 // ---- the tail of the device-wide rounds ---------------------------------------------------------------------------------
