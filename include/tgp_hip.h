@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10021 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10022 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -298,7 +298,9 @@ int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t
 size_t tgp_graclus_match_workspace_bytes(int64_t num_nodes, int64_t num_edges);
 int tgp_graclus_match_start(const int64_t* row, const int64_t* col, const float* weight /* NULL = ones */, const int32_t* row_ptr,
                             const int32_t* perm, int64_t num_nodes, int64_t num_edges, void* ws, size_t ws_bytes,
-                            int64_t* label, void* stream);
+                            int64_t* label, int init_state /* 1; 0 only in front of tgp_graclus_match_graphs, which sets
+                                                              the labels itself and keeps its free flags in LDS */,
+                            void* stream);
 int tgp_graclus_match_rounds(const int32_t* row_ptr, int64_t num_nodes, int64_t num_edges, void* ws, int rounds,
                              unsigned int* matched, int64_t* label, void* stream);
 /* The remaining rounds in two launches once at most 16384 free nodes are left (after tgp_graclus_match_rounds, same
@@ -329,6 +331,7 @@ int tgp_graclus_relabel_i64(const int64_t* label, int64_t num_nodes, void* ws, s
                                                     sparse Reduce and the coalesce Connect walk (what
                                                     tgp_assign_index_build derives from the ids), valid when every
                                                     label is shared by at most two nodes -- a matching */,
+                            float* ones /* optional [N]: filled with 1.0f, the values of the assignment matrix */,
                             void* stream);
 
 /* TopkSelect scoring (select/topk_select.py:176, score = (x * w).sum(-1)): out[i] = <x[i,:], w>, one pass over

@@ -1098,7 +1098,7 @@ def test_graclus_relabel_kernel_equals_unique_inverse(dev, n):
     k = torch.full((1,), -1, dtype=torch.int64, device=dev)
     ws = N.workspace(L.tgp_graclus_relabel_workspace_bytes(n), dev)
     N.check(L.tgp_graclus_relabel_i64(N.ptr(label), n, N.ptr(ws), ws.numel(), N.ptr(index), N.ptr(k), None, None,
-                                      N.stream_ptr(dev)), "relabel")
+                                      None, N.stream_ptr(dev)), "relabel")
     assert int(k) == ids.numel()
     assert torch.equal(index[0].cpu(), torch.arange(n)) and torch.equal(index[1].cpu(), inverse)
     # the same call with the supernode -> members index of the matching: equal to what the general builder derives
@@ -1107,7 +1107,7 @@ def test_graclus_relabel_kernel_equals_unique_inverse(dev, n):
     perm = torch.full((max(n, 1),), -7, dtype=torch.int32, device=dev)
     index2 = torch.empty_like(index)
     N.check(L.tgp_graclus_relabel_i64(N.ptr(label), n, N.ptr(ws), ws.numel(), N.ptr(index2), N.ptr(k), N.ptr(row_ptr),
-                                      N.ptr(perm), N.stream_ptr(dev)), "relabel")
+                                      N.ptr(perm), None, N.stream_ptr(dev)), "relabel")
     assert torch.equal(index2, index)
     if n:
         want = kernels.build_assign_index(index[1], int(k))
@@ -1220,8 +1220,9 @@ def test_graclus_per_graph_route_with_an_unchecked_unsorted_edge_list(dev):
     assert torch.equal(got, want) and kernels._rows_sorted_memo(ei_u) is False
     fresh = ei.clone()
     assert kernels._rows_sorted_memo(fresh) is None
-    (index, k, _), row_ptr = kernels.graclus_match(fresh, ew, n, graph_ptr=ptr, max_graph_nodes=39, relabel=True,
-                                                   return_row_ptr=True)
+    (index, k, _, ones), row_ptr = kernels.graclus_match(fresh, ew, n, graph_ptr=ptr, max_graph_nodes=39,
+                                                         relabel=True, return_row_ptr=True)
+    assert torch.equal(ones, torch.ones(n, device=dev))
     assert kernels._rows_sorted_memo(fresh) is True and row_ptr is not None
     ids, inverse = torch.unique(want, return_inverse=True)
     assert k == ids.numel() and torch.equal(index[1], inverse)

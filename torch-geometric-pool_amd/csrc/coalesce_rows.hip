@@ -1194,9 +1194,16 @@ extern "C" size_t tgp_connect_coalesce_rows_workspace_bytes(int64_t E, int64_t N
 }
 
 // a handed-over CSR covers the whole list: offsets start at 0 and end at E (a list with ids outside [0, N) does not)
+// (reset: this one-thread launch also clears the status words, saving the memset in front of it)
 static __global__ void cr_check_csr_kernel(const int32_t* __restrict__ csr_ptr, int64_t N, int64_t E,
-                                           int* __restrict__ bad) {
-  if (csr_ptr[0] != 0 || static_cast<int64_t>(csr_ptr[N]) != E) *bad = 4;
+                                           int* __restrict__ bad, int reset) {
+  const bool broken = csr_ptr[0] != 0 || static_cast<int64_t>(csr_ptr[N]) != E;
+  if (reset) {
+    bad[0] = broken ? 4 : 0;
+    bad[1] = 0;
+  } else if (broken) {
+    *bad = 4;
+  }
 }
 
 extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
@@ -1221,11 +1228,11 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
   CrWs s;
   cr_layout(ws, E, N, K, &s);
   float* tmp_w = w ? s.tmp_w : nullptr;
-  (void)hipMemsetAsync(s.bad, 0, 2 * sizeof(int), stream);
+  if (!csr_ptr) (void)hipMemsetAsync(s.bad, 0, 2 * sizeof(int), stream);
   if (csr_ptr) {
     // CSR offsets of this very list from the caller (GraclusSelect builds them): no pass over the row array
     s.node_ptr = reinterpret_cast<uint32_t*>(const_cast<int32_t*>(csr_ptr));  // non-negative: same bits; read only
-    hipLaunchKernelGGL(cr_check_csr_kernel, dim3(1), dim3(1), 0, stream, csr_ptr, N, E, s.bad);
+    hipLaunchKernelGGL(cr_check_csr_kernel, dim3(1), dim3(1), 0, stream, csr_ptr, N, E, s.bad, 1);
   } else if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
     hipLaunchKernelGGL(cr_node_ptr_vec_kernel, dim3(cdiv(cdiv(E, 4) + 1, 256)), dim3(256), 0, stream, row, E, N, s.bad,
                        s.node_ptr);
@@ -1294,7 +1301,7 @@ extern "C" int tgp_connect_coalesce_fused_count(const int64_t* row, const int64_
   const uint32_t* node_ptr = s.node_ptr;
   if (csr_ptr) {
     node_ptr = reinterpret_cast<const uint32_t*>(csr_ptr);  // offsets are non-negative: same bits
-    hipLaunchKernelGGL(cr_check_csr_kernel, dim3(1), dim3(1), 0, stream, csr_ptr, N, E, s.bad);
+    hipLaunchKernelGGL(cr_check_csr_kernel, dim3(1), dim3(1), 0, stream, csr_ptr, N, E, s.bad, 0);
   } else if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
     hipLaunchKernelGGL(cr_node_ptr_vec_kernel, dim3(cdiv(cdiv(E, 4) + 1, 256)), dim3(256), 0, stream, row, E, N, s.bad,
                        s.node_ptr);

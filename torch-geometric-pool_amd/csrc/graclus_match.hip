@@ -280,7 +280,10 @@ constexpr int GM_GRAPH_LDS_E = 2048;  // entries of a graph's CSR kept in LDS (1
 template <int T, typename P, typename NB, typename WV>
 __device__ __forceinline__ void gm_graph_rounds(P ptr, NB nb, WV wv, int64_t p0, int n, uint8_t* s_free, int32_t* s_cand,
                                                 int64_t* __restrict__ label) {
-  for (int t = threadIdx.x; t < n; t += T) s_free[t] = 1;
+  for (int t = threadIdx.x; t < n; t += T) {
+    s_free[t] = 1;
+    label[p0 + t] = p0 + t;  // (pairs overwrite it below, after a barrier)
+  }
   __syncthreads();
   for (int round = 0; round < 2 * GM_GRAPH_MAX; ++round) {  // (a round matches at least one pair while a free edge exists)
     for (int t = threadIdx.x; t < n; t += T) {
@@ -530,7 +533,8 @@ __global__ __launch_bounds__(256) void rl_assign_kernel(const int64_t* __restric
                                                         const uint32_t* __restrict__ wprefix2,
                                                         const uint32_t* __restrict__ tile_sum2, int tiles,
                                                         int64_t* __restrict__ index_out, int64_t* __restrict__ d_k,
-                                                        int32_t* __restrict__ a_row_ptr, int32_t* __restrict__ a_perm) {
+                                                        int32_t* __restrict__ a_row_ptr, int32_t* __restrict__ a_perm,
+                                                        float* __restrict__ ones) {
   __shared__ uint32_t s_tp[RL_MAX_TILES];
   __shared__ uint32_t s_tp2[PAIRS ? RL_MAX_TILES : 1];
   __shared__ uint32_t s_part[256];
@@ -551,6 +555,7 @@ __global__ __launch_bounds__(256) void rl_assign_kernel(const int64_t* __restric
     const uint32_t rank = s_tp[j >> 10] + wprefix[j >> 5] + __popc(bits[j >> 5] & below);
     index_out[i] = i;
     index_out[n + i] = static_cast<int64_t>(rank);
+    if (ones) ones[i] = 1.0f;  // (the values of the one-over-K assignment matrix)
     if constexpr (PAIRS) {
       const uint32_t slot = rank + s_tp2[j >> 10] + wprefix2[j >> 5] + __popc(paired[j >> 5] & below);
       if (i == j) {
@@ -578,7 +583,7 @@ extern "C" size_t tgp_graclus_relabel_workspace_bytes(int64_t num_nodes) {
 // label[r] == r), *d_k = number of ids: the indices of the [N, K] assignment the selector returns.
 extern "C" int tgp_graclus_relabel_i64(const int64_t* label, int64_t num_nodes, void* ws, size_t ws_bytes,
                                        int64_t* index_out, int64_t* d_k, int32_t* assign_row_ptr,
-                                       int32_t* assign_perm, void* stream_) {
+                                       int32_t* assign_perm, float* ones, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(num_nodes >= 0 && d_k, TGP_ERR_INVALID, "tgp_graclus_relabel_i64: bad argument");
   TGP_REQUIRE((assign_row_ptr == nullptr) == (assign_perm == nullptr), TGP_ERR_INVALID,
@@ -606,12 +611,12 @@ extern "C" int tgp_graclus_relabel_i64(const int64_t* label, int64_t num_nodes, 
     hipLaunchKernelGGL(rl_paired_prefix_kernel, dim3(cdiv(tiles, 8)), dim3(256), 0, stream, paired, tiles, wprefix2,
                        tile_sum2);
     hipLaunchKernelGGL(rl_assign_kernel<true>, dim3(tiles), dim3(256), 0, stream, label, num_nodes, bits, wprefix,
-                       tile_sum, paired, wprefix2, tile_sum2, tiles, index_out, d_k, assign_row_ptr, assign_perm);
+                       tile_sum, paired, wprefix2, tile_sum2, tiles, index_out, d_k, assign_row_ptr, assign_perm, ones);
   } else {
     hipLaunchKernelGGL(rl_flags_kernel, dim3(tiles), dim3(256), 0, stream, label, num_nodes, bits, wprefix, tile_sum,
                        static_cast<uint32_t*>(nullptr));
     hipLaunchKernelGGL(rl_assign_kernel<false>, dim3(tiles), dim3(256), 0, stream, label, num_nodes, bits, wprefix,
-                       tile_sum, paired, wprefix2, tile_sum2, tiles, index_out, d_k, assign_row_ptr, assign_perm);
+                       tile_sum, paired, wprefix2, tile_sum2, tiles, index_out, d_k, assign_row_ptr, assign_perm, ones);
   }
   return check_launch("tgp_graclus_relabel_i64");
 }
@@ -661,7 +666,7 @@ extern "C" size_t tgp_graclus_match_workspace_bytes(int64_t num_nodes, int64_t n
 // entries to decide whether to run more rounds (0 = the matching is maximal).
 extern "C" int tgp_graclus_match_start(const int64_t* row, const int64_t* col, const float* weight, const int32_t* row_ptr,
                                        const int32_t* perm, int64_t num_nodes, int64_t num_edges, void* ws,
-                                       size_t ws_bytes, int64_t* label, void* stream_) {
+                                       size_t ws_bytes, int64_t* label, int init_state, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(num_nodes >= 0 && num_edges >= 0, TGP_ERR_INVALID, "tgp_graclus_match_start: negative size");
   if (num_nodes == 0) return TGP_OK;
@@ -687,7 +692,10 @@ extern "C" int tgp_graclus_match_start(const int64_t* row, const int64_t* col, c
     hipLaunchKernelGGL(gm_symmetrise_kernel, dim3(nbe), dim3(256), 0, stream, row_ptr, src, num_edges, asymmetric, nbr,
                        wt);
   }
-  hipLaunchKernelGGL(gm_init_kernel, dim3(cdiv(num_nodes, 256)), dim3(256), 0, stream, num_nodes, label, is_free);
+  // init_state == 0: the caller goes on with tgp_graclus_match_graphs, which sets every label itself and keeps its free
+  // flags in LDS (the device-wide rounds need the state: 1)
+  if (init_state)
+    hipLaunchKernelGGL(gm_init_kernel, dim3(cdiv(num_nodes, 256)), dim3(256), 0, stream, num_nodes, label, is_free);
   return check_launch("tgp_graclus_match_start");
 }
 

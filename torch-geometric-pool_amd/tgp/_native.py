@@ -93,10 +93,10 @@ SIGNATURES = {
     "tgp_topk_minscore_count": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_f, _c_f, _c_p, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_topk_minscore_fill": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_graclus_match_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
-    "tgp_graclus_match_start": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_sz, _c_p, _c_p]),
+    "tgp_graclus_match_start": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_sz, _c_p, _c_int, _c_p]),
     "tgp_graclus_relabel_max_nodes": (_c_i64, []),
     "tgp_graclus_relabel_workspace_bytes": (_c_sz, [_c_i64]),
-    "tgp_graclus_relabel_i64": (_c_int, [_c_p, _c_i64, _c_p, _c_sz, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "tgp_graclus_relabel_i64": (_c_int, [_c_p, _c_i64, _c_p, _c_sz, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "tgp_graclus_match_tail": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p]),
     "tgp_graclus_match_max_graph_nodes": (_c_int, []),
     "tgp_graclus_match_graphs": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),

@@ -712,7 +712,7 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
     it is row-sorted (else None) -- the matcher builds them anyway and SparseConnect can reuse them.
     ``graph_ptr`` [B+1] / ``max_graph_nodes``: node offsets of the graphs of a sorted batch and its longest graph; when
     every graph fits one workgroup all rounds of all graphs run as ONE launch (same matching).
-    ``relabel``: return ``(index [2, N], K, assign_index)`` instead of the labels -- row 0 = 0..N-1, row 1 = the consecutive cluster id
+    ``relabel``: return ``(index [2, N], K, assign_index, ones [N])`` instead of the labels -- row 0 = 0..N-1, row 1 = the consecutive cluster id
     of every node (``torch.unique(label, return_inverse=True)[1]``, graclus_select.py:68) from two more launches, its
     count read back together with the matcher's status word."""
     dev = N.require_device(edge_index, edge_weight)
@@ -756,9 +756,10 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
         # partner per cluster), so Reduce / Connect do not build it from the ids
         pairs["row_ptr"] = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
         pairs["perm"] = torch.empty(max(num_nodes, 1), dtype=torch.int32, device=dev)
+        pairs["ones"] = torch.empty(num_nodes, dtype=torch.float32, device=dev)  # the values of S, same launch
         N.check(L.tgp_graclus_relabel_i64(N.ptr(label), num_nodes, N.ptr(rws), rws.numel(), N.ptr(index),
-                                          N.ptr(words[2:]), N.ptr(pairs["row_ptr"]), N.ptr(pairs["perm"]), st),
-                "tgp_graclus_relabel_i64")
+                                          N.ptr(words[2:]), N.ptr(pairs["row_ptr"]), N.ptr(pairs["perm"]),
+                                          N.ptr(pairs["ones"]), st), "tgp_graclus_relabel_i64")
         return index
 
     def finish(index=None, k=None):
@@ -768,13 +769,14 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
                 index = relabelled()
                 k = words.tolist()[2]
             k = int(k)
-            out = (index, k, AssignIndex(pairs["row_ptr"][:k + 1], pairs["perm"], num_nodes, k))
+            out = (index, k, AssignIndex(pairs["row_ptr"][:k + 1], pairs["perm"], num_nodes, k), pairs["ones"])
         return (out, sorted_ptr) if return_row_ptr else out
 
-    def start():
+    def start(init_state=1):
         N.check(L.tgp_graclus_match_start(N.ptr(row), N.ptr(col), N.ptr(w), N.ptr(row_ptr), N.ptr(perm), num_nodes, E,
-                                          N.ptr(ws), ws.numel(), N.ptr(label), st), "tgp_graclus_match_start")
-    start()
+                                          N.ptr(ws), ws.numel(), N.ptr(label), init_state, st),
+                "tgp_graclus_match_start")
+    start(0 if (per_graph and not finished) else 1)  # (the one-launch route sets the labels itself)
     if not finished and per_graph:
         gp = N.i64c(graph_ptr)
         N.check(L.tgp_graclus_match_graphs(N.ptr(row_ptr), num_nodes, E, N.ptr(ws), N.ptr(gp), gp.numel() - 1,

@@ -726,9 +726,9 @@ class GraclusSelect(Select):
                 if info.is_sorted:
                     gptr, gmax = info.ptr, info.max_nodes
             if num_nodes <= N.lib().tgp_graclus_relabel_max_nodes():
-                (index, k, assign), row_ptr = kernels.graclus_match(edge_index, edge_weight, num_nodes,
-                                                                    return_row_ptr=True, graph_ptr=gptr,
-                                                                    max_graph_nodes=gmax, relabel=True)
+                (index, k, assign, ones), row_ptr = kernels.graclus_match(edge_index, edge_weight, num_nodes,
+                                                                          return_row_ptr=True, graph_ptr=gptr,
+                                                                          max_graph_nodes=gmax, relabel=True)
             else:
                 pair, row_ptr = kernels.graclus_match(edge_index, edge_weight, num_nodes, return_row_ptr=True,
                                                       graph_ptr=gptr, max_graph_nodes=gmax)
@@ -736,9 +736,8 @@ class GraclusSelect(Select):
                 rank = torch.cumsum(pair == nodes, 0) - 1
                 index = torch.stack([nodes, rank[pair]])
                 k = int(rank[-1]) + 1 if num_nodes else 0
-                assign = None
-            s = torch.sparse_coo_tensor(index, torch.ones(num_nodes, device=index.device), size=(num_nodes, k),
-                                        is_coalesced=True)
+                assign, ones = None, torch.ones(num_nodes, device=index.device)
+            s = torch.sparse_coo_tensor(index, ones, size=(num_nodes, k), is_coalesced=True)
             so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
             so.__dict__["_identity_nodes"] = True  # row 0 of the indices is 0..N-1: the transposed index is the identity
             so._assign_index = assign
