@@ -1324,3 +1324,22 @@ def test_batch_facts_carry_the_topk_total(dev, ratio):
     info = batch_info(batch, topk_ratio=float(ratio))
     k, koff = kernels.topk_plan(info.sizes, ratio)
     assert info.memo[("topk_total", float(ratio))] == int(koff[-1]) == int(k.sum())
+
+
+@pytest.mark.parametrize("max_iter", [1, 5, 37])
+def test_ndp_large_steps_stop_at_the_step_budget(dev, max_iter):
+    """The fused LOBPCG step (tgp_ndp_large_steps) honours max_iter when the tolerance is out of reach: exactly that
+    many updates, the host loop ends, the partition is still a sign split of the current iterate (or the reference's
+    random fallback when its cut is below 0.5)."""
+    from tgp import kernels as K
+    n = 3000
+    ei = _undirected(n, 12000, 5).to(dev)
+    indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    K.rowptr_from_sorted(ei[0], n, indptr)
+    keep = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    info, state = K.ndp_partition_large(indptr, ei[1], None, 0, n, 3, keep, status, max_iter=max_iter, tol=1e-12,
+                                        want_state=True)
+    assert int(status) == 0 and state["steps"] == max_iter
+    assert set(keep.unique().tolist()) <= {0, 1} and 0 < int(keep.sum()) < n
+    assert state["random"] or int(info) == max_iter
