@@ -367,3 +367,18 @@ def test_precoarsening_plumbing():  # :259-318
     out = pooler._precoarsening_from_select_output(so=so, edge_index=torch.tensor([[0, 1], [1, 2]]),
                                                    edge_weight=torch.ones(2), batch=None)
     assert so.batch.tolist() == [1, 1, 1] and int(out.batch[0]) == 0
+
+
+def test_ndp_select_public_helpers():
+    """NDPSelect.sign_partition / eval_cut (reference select/ndp_select.py:154-185)."""
+    import torch
+    from tgp.select import NDPSelect
+    pos, neg = NDPSelect.sign_partition(torch.tensor([0.5, -1.0, 0.0, -0.1]))
+    assert pos.tolist() == [0, 2] and neg.tolist() == [1, 3]
+    pos, neg = NDPSelect.sign_partition(7)
+    assert 0 in pos.tolist() and 1 in neg.tolist() and len(pos) + len(neg) == 7
+    # a path 0-1-2: L = D - A, z = (+1, -1, +1): both edges are cut, volume 4 -> z^T L z / (2 vol) = 8 / 8
+    L = torch.tensor([[1.0, -1.0, 0.0], [-1.0, 2.0, -1.0], [0.0, -1.0, 1.0]])
+    z = torch.tensor([[1.0], [-1.0], [1.0]])
+    assert float(NDPSelect.eval_cut(4.0, L, z)) == 1.0
+    assert float(NDPSelect.eval_cut(4.0, L.to_sparse(), z)) == 1.0

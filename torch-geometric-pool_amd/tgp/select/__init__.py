@@ -767,6 +767,27 @@ class NDPSelect(Select):
         super().__init__()
         self.s_inv_op = s_inv_op
 
+    # the two public helpers of the reference class (select/ndp_select.py:154-185), for callers that use them directly
+    @staticmethod
+    def eval_cut(total_volume, L, z):
+        """Normalised size of the cut of a +-1 partition vector ``z``: ``z^T L z / (2 * total_volume)`` (``L``: the
+        unnormalised Laplacian as a torch (sparse) tensor, a scipy matrix or an array)."""
+        Lz = L.matmul(z) if hasattr(L, "matmul") else L @ z
+        zt = z.T if hasattr(z, "T") else z
+        cut = zt.matmul(Lz) if hasattr(zt, "matmul") else zt @ Lz
+        return cut / (2 * total_volume)
+
+    @staticmethod
+    def sign_partition(vec_or_size: Union[Tensor, int]) -> Tuple[Tensor, Tensor]:
+        """Indices of the non-negative and of the negative entries of a vector; for an integer ``n >= 2`` a random +-1
+        vector whose first two entries are +1 and -1 (both sides non-empty) is split instead."""
+        if isinstance(vec_or_size, int):
+            vec = torch.randint(0, 2, (vec_or_size,), dtype=torch.long) * 2 - 1
+            vec[0], vec[1] = 1, -1
+        else:
+            vec = vec_or_size
+        return torch.where(vec >= 0)[0], torch.where(vec < 0)[0]
+
     def forward(self, edge_index, edge_weight: Optional[Tensor] = None, *, batch: Optional[Tensor] = None,
                 num_nodes: Optional[int] = None, **kwargs) -> SelectOutput:
         import numpy as np
