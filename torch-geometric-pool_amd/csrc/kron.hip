@@ -1091,7 +1091,11 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
       const int rem = nmax - step * KRON_SNB - 1;             // trailing rows at most (the panel holds >= 1 pivot)
       const int nt = cdiv(rem, KRON_TILE);
       hipLaunchKernelGGL(kron_big_panel_kernel, dim3(static_cast<unsigned>(cdiv(rem, KRON_PW)), nbig), dim3(256), KRON_LDS_PAD, stream, a, step);
-      hipLaunchKernelGGL(kron_big_trail_kernel, dim3(static_cast<unsigned>(nt * nt), nbig), dim3(256), KRON_LDS_PAD, stream, a, step);
+      // (a launch with several workgroups per CU anyway -- the early panels of a graph of a few thousand nodes -- is better
+      //  off packed: 4 workgroups per CU hide each other's load latency: the harness batch's 2669-node graph, whole ndp forward 10.6 -> 9.8 ms)
+      static const int cus = [] { int v = tgp_device_cu_count(); return v > 0 ? v : 256; }();
+      const size_t trail_pad = static_cast<long>(nt) * nt * nbig >= 3l * cus ? 0 : KRON_LDS_PAD;
+      hipLaunchKernelGGL(kron_big_trail_kernel, dim3(static_cast<unsigned>(nt * nt), nbig), dim3(256), trail_pad, stream, a, step);
     }
     hipLaunchKernelGGL(kron_big_finish_kernel, dim3(cdiv(nmax, 16), nbig), dim3(256), 0, stream, a);
     const size_t plds = static_cast<size_t>(2 * KRON_NB) * (nmax < KRON_REDO_MAX_N ? nmax : KRON_REDO_MAX_N) * sizeof(double);
