@@ -1306,6 +1306,17 @@ extern "C" int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, cons
                          w, graph_ptr, static_cast<unsigned long long>(seed), max_iter, tol, ncap, ec, keep, info,
                          d_status);
   } else {
+    // graphs of 513 .. 2048 nodes: 512 threads per graph (64 graphs of 600 .. 2000 nodes 10.7 -> 7.1 ms; 1024 threads
+    // were measured slower than 256: profiles/r03_c3_small_kernel_experiments.md).  TGP_NDP_THREADS=256: A/B switch
+    static const int wide = getenv("TGP_NDP_THREADS") ? atoi(getenv("TGP_NDP_THREADS")) : 512;
+    if (wide == 512 && cap > 512) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ndp_partition_kernel<512>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      hipLaunchKernelGGL(ndp_partition_kernel<512>, dim3(static_cast<unsigned>(B)), dim3(512), lds, stream, indptr, col,
+                         w, graph_ptr, static_cast<unsigned long long>(seed), max_iter, tol, ncap, ec, keep, info,
+                         d_status);
+      return check_launch("tgp_ndp_partition");
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ndp_partition_kernel<256>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     hipLaunchKernelGGL(ndp_partition_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, indptr, col,
