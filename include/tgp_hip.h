@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10022 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10023 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -94,7 +94,10 @@ int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t num_feature
 /* A2  Reduce.reduce_batch, sparse branch (reduce/base_reduce.py:37-41):
  *     out = arange(K); out[cluster_index[i]] = batch[node_index[i]]                      */
 int tgp_reduce_batch_i64(const int64_t* batch, const int64_t* node_index, const int64_t* cluster_index,
-                         int64_t nnz, int64_t num_supernodes, int64_t* batch_pool, void* stream);
+                         int64_t nnz, int64_t num_supernodes,
+                         int every_cluster_has_a_node /* 1: the arange is never visible (selectors that create a
+                                                         supernode per kept node / matched pair): one launch */,
+                         int64_t* batch_pool, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * A5 + A6  sparse_connect, TopK branch (connect/base_conn.py:79-82 -> PyG subgraph with

@@ -492,14 +492,16 @@ extern "C" int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t 
 }
 
 extern "C" int tgp_reduce_batch_i64(const int64_t* batch, const int64_t* node_index,
-                                    const int64_t* cluster_index, int64_t nnz, int64_t K, int64_t* batch_pool,
-                                    void* stream_) {
+                                    const int64_t* cluster_index, int64_t nnz, int64_t K, int every_cluster_has_a_node,
+                                    int64_t* batch_pool, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(nnz >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_reduce_batch_i64: bad size");
   if (K == 0) return TGP_OK;
   TGP_REQUIRE(batch_pool && (nnz == 0 || (batch && node_index && cluster_index)), TGP_ERR_INVALID,
               "tgp_reduce_batch_i64: null pointer");
-  hipLaunchKernelGGL(arange_i64_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, batch_pool, K);
+  // (the arange only shows through for supernodes without a node: a caller that knows there is none skips the launch)
+  if (!every_cluster_has_a_node || nnz == 0)
+    hipLaunchKernelGGL(arange_i64_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, batch_pool, K);
   if (nnz > 0)
     hipLaunchKernelGGL(reduce_batch_kernel, dim3(cdiv(nnz, 256)), dim3(256), 0, stream, batch, node_index,
                        cluster_index, nnz, batch_pool);

@@ -40,7 +40,7 @@ SIGNATURES = {
     "tgp_assign_index_build": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_sz, _c_p]),
     "tgp_reduce_sparse_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64,
                                        _c_i64, _c_p, _c_p]),
-    "tgp_reduce_batch_i64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
+    "tgp_reduce_batch_i64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p]),
     "tgp_connect_subgraph_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
     "tgp_connect_subgraph_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_f, _c_p,
                                             _c_sz, _c_p, _c_p]),

@@ -23,7 +23,8 @@ class Reduce(nn.Module):
             return None
         if select_output.s.is_sparse:
             return K.reduce_batch_sparse(batch, select_output.node_index, select_output.cluster_index,
-                                         select_output.num_supernodes)
+                                         select_output.num_supernodes,
+                                         every_cluster_has_a_node=bool(select_output.__dict__.get("_no_empty_cluster")))
         if batch.numel() == 0:
             return batch.new_empty((0,), dtype=batch.dtype)
         return build_pooled_batch(num_graphs_of(batch), select_output.num_supernodes, batch.device,

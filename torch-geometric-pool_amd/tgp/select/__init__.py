@@ -573,6 +573,7 @@ class TopkSelect(Select):
         so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
         so._assign_index = assign
         so._lift_index = lift
+        so.__dict__["_no_empty_cluster"] = True  # one supernode per kept node
         if values.requires_grad:
             so._hold_values(values)
         return so
@@ -740,6 +741,7 @@ class GraclusSelect(Select):
             s = torch.sparse_coo_tensor(index, ones, size=(num_nodes, k), is_coalesced=True)
             so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
             so.__dict__["_identity_nodes"] = True  # row 0 of the indices is 0..N-1: the transposed index is the identity
+            so.__dict__["_no_empty_cluster"] = True  # ids are the ranks of the representatives: every id has its node
             so._assign_index = assign
             if row_ptr is not None:
                 # CSR offsets of the (row-sorted) list the matcher walked: SparseConnect skips its own pass over the
@@ -944,6 +946,7 @@ class NDPSelect(Select):
         s = torch.sparse_coo_tensor(torch.stack([idx_pos, torch.arange(k, device=dev)]), torch.ones(k, device=dev),
                                     size=(n, k), is_coalesced=True)
         so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
+        so.__dict__["_no_empty_cluster"] = True  # one supernode per kept node
         so._extra_args.add("L")
 
         def laplacian_on_host():  # the reference's so.L: scipy CSR, float32 (ndp_select.py:254-255)
