@@ -92,6 +92,58 @@ __global__ __launch_bounds__(256) void topk_segsort_wave_kernel(const float* __r
   if (lane < n && lane < k[g]) rank_of[lo + static_cast<int64_t>(v & 0xFFFFFFFFull)] = static_cast<int32_t>(koff[g] + lane);
 }
 
+// The same sort with the outputs written by the wave itself (r3, late): a sorted batch puts graph g's kept nodes at
+// [koff[g], koff[g] + k_g) of the ascending node_index, so the position of a kept node is koff[g] + (kept nodes of ITS
+// graph in front of it) -- a ballot -- and the device-wide rank table, its memset, the count, the scan and the fill
+// launch are not needed: TopkSelect on a batch of small graphs is the score kernel + this one.
+__global__ __launch_bounds__(256) void topk_segsort_wave_fill_kernel(
+    const float* __restrict__ score, const int64_t* __restrict__ ptr, const int64_t* __restrict__ k,
+    const int64_t* __restrict__ koff, int64_t B, int64_t N, int64_t* __restrict__ node_index,
+    int64_t* __restrict__ cluster_index, int32_t* __restrict__ assign_perm, float* __restrict__ values,
+    int32_t* __restrict__ lift_ptr) {
+  __shared__ int s_inv[4][64];
+  const int w = wave_id();
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + w;
+  if (g >= B) return;
+  const int lane = lane_id();
+  const int64_t lo = ptr[g];
+  const int n = static_cast<int>(ptr[g + 1] - lo);
+  const float sc = lane < n ? score[lo + lane] : 0.f;
+  unsigned long long v = ~0ull;  // sentinel: sorts last
+  if (lane < n) v = (static_cast<unsigned long long>(descending_key(sc)) << 32) | static_cast<unsigned>(lane);
+#pragma unroll
+  for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const unsigned long long o = shfl_xor_u64(v, stride);
+      const bool up = (lane & size) == 0;
+      const bool lower = (lane & stride) == 0;
+      const bool take_min = up == lower;
+      v = take_min ? (v < o ? v : o) : (v > o ? v : o);
+    }
+  }
+  // lane q holds the node with rank q; every node looks its rank up (one LDS exchange inside the wave)
+  if (lane < n) s_inv[w][static_cast<int>(v & 0xFFFFFFFFull)] = lane;
+  __builtin_amdgcn_wave_barrier();
+  const int q_of = lane < n ? s_inv[w][lane] : 64;
+  const int64_t kg64 = k[g];
+  const int kg = static_cast<int>(kg64 < n ? kg64 : n);
+  const bool kept = lane < n && q_of < kg;
+  const unsigned long long mask = __ballot(kept);
+  const int64_t base = koff[g];
+  const int64_t pos = base + __popcll(mask & lanemask_lt());
+  if (lift_ptr) {
+    if (lane < n) lift_ptr[lo + lane] = static_cast<int32_t>(pos);
+    if (g == B - 1 && lane == 0) lift_ptr[N] = static_cast<int32_t>(koff[B]);
+  }
+  if (kept) {
+    node_index[pos] = lo + lane;
+    cluster_index[pos] = base + q_of;
+    assign_perm[base + q_of] = static_cast<int32_t>(pos);
+    if (values) values[pos] = sc;
+  }
+}
+
 // T = 256 threads for graphs up to kSegSortMax nodes, 1024 threads (dynamic LDS) up to kSegSortLarge: a handful of
 // graphs of a few thousand nodes (the reference harness's batches) took the device-wide radix sort before -- 15 launches
 // for 4500 keys.
@@ -529,6 +581,11 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
               "tgp_topk_select: workspace too small");
   const TopkLayout s = topk_layout(ws, N);
   const int nb256 = cdiv(N, 256), nbt = cdiv(N, kTopkTile);
+  if (segments_max_nodes > 0 && segments_max_nodes <= 64 && node_index) {
+    hipLaunchKernelGGL(topk_segsort_wave_fill_kernel, dim3(cdiv(B, 4)), dim3(256), 0, stream, score, ptr, k, koff, B, N,
+                       node_index, cluster_index, assign_perm, values, lift_row_ptr);
+    return check_launch("tgp_topk_select");
+  }
   (void)hipMemsetAsync(s.rank_of, 0xFF, static_cast<size_t>(N) * sizeof(int32_t), stream);
   if (segments_max_nodes > 0 && segments_max_nodes <= 64) {
     hipLaunchKernelGGL(topk_segsort_wave_kernel, dim3(cdiv(B, 4)), dim3(256), 0, stream, score, ptr, k, koff, B,
