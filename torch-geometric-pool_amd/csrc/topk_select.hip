@@ -148,16 +148,26 @@ __global__ __launch_bounds__(256) void topk_segsort_wave_fill_kernel(
 // graphs of a few thousand nodes (the reference harness's batches) took the device-wide radix sort before -- 15 launches
 // for 4500 keys.
 constexpr int kSegSortLarge = 8192;
-template <int T>
+// FILL: the workgroup also writes the final outputs (see topk_segsort_wave_fill_kernel): kept flags by local node id in
+// LDS behind the keys ([m] ints), positions from a workgroup scan in node order.
+template <int T, bool FILL>
 __global__ __launch_bounds__(T) void topk_segsort_block_kernel(const float* __restrict__ score,
                                                                const int64_t* __restrict__ ptr,
                                                                const int64_t* __restrict__ k,
                                                                const int64_t* __restrict__ koff,
-                                                               int32_t* __restrict__ rank_of) {
+                                                               int32_t* __restrict__ rank_of, int64_t B, int64_t N,
+                                                               int64_t* __restrict__ node_index,
+                                                               int64_t* __restrict__ cluster_index,
+                                                               int32_t* __restrict__ assign_perm,
+                                                               float* __restrict__ values,
+                                                               int32_t* __restrict__ lift_ptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_v[];
   const int64_t g = blockIdx.x;
   const int64_t lo = ptr[g];
   const int n = static_cast<int>(ptr[g + 1] - lo);
+  if constexpr (FILL) {
+    if (lift_ptr && g == B - 1 && threadIdx.x == 0) lift_ptr[N] = static_cast<int32_t>(koff[B]);
+  }
   if (n == 0) return;
   int m = 64;
   while (m < n) m <<= 1;  // padded power of two (<= kSegSortMax by dispatch)
@@ -177,8 +187,46 @@ __global__ __launch_bounds__(T) void topk_segsort_block_kernel(const float* __re
     }
   }
   const int kg = static_cast<int>(k[g] < n ? k[g] : n);
-  for (int q = threadIdx.x; q < kg; q += T)
-    rank_of[lo + static_cast<int64_t>(s_v[q] & 0xFFFFFFFFull)] = static_cast<int32_t>(koff[g] + q);
+  if constexpr (!FILL) {
+    for (int q = threadIdx.x; q < kg; q += T)
+      rank_of[lo + static_cast<int64_t>(s_v[q] & 0xFFFFFFFFull)] = static_cast<int32_t>(koff[g] + q);
+  } else {
+    __shared__ uint32_t s_w[T / 64];
+    int* s_q = reinterpret_cast<int*>(s_v + m);  // rank of every node of the graph, -1 = not kept
+    for (int i = threadIdx.x; i < n; i += T) s_q[i] = -1;
+    __syncthreads();
+    for (int q = threadIdx.x; q < kg; q += T) s_q[static_cast<int>(s_v[q] & 0xFFFFFFFFull)] = q;
+    __syncthreads();
+    const int64_t base = koff[g];
+    uint32_t carry = 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i0 = 0; i0 < n; i0 += T) {
+      const int i = i0 + static_cast<int>(threadIdx.x);
+      const int q = i < n ? s_q[i] : -1;
+      const unsigned long long mk = __ballot(q >= 0);
+      if (lane == 0) s_w[w] = __popcll(mk);
+      __syncthreads();
+      uint32_t before = 0, total = 0;
+#pragma unroll
+      for (int ww = 0; ww < T / 64; ++ww) {
+        const uint32_t c = s_w[ww];
+        if (ww < w) before += c;
+        total += c;
+      }
+      const int64_t pos = base + carry + before + __popcll(mk & lanemask_lt());
+      if (i < n) {
+        if (lift_ptr) lift_ptr[lo + i] = static_cast<int32_t>(pos);
+        if (q >= 0) {
+          node_index[pos] = lo + i;
+          cluster_index[pos] = base + q;
+          assign_perm[base + q] = static_cast<int32_t>(pos);
+          if (values) values[pos] = score[lo + i];
+        }
+      }
+      carry += total;
+      __syncthreads();
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void topk_count_kernel(const int32_t* __restrict__ rank_of, int64_t n,
@@ -586,21 +634,40 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
                        node_index, cluster_index, assign_perm, values, lift_row_ptr);
     return check_launch("tgp_topk_select");
   }
+  if (segments_max_nodes > 64 && segments_max_nodes <= kSegSortLarge && node_index) {  // the same, one workgroup per graph
+    int m = 64;
+    while (m < segments_max_nodes) m <<= 1;
+    const size_t lds = static_cast<size_t>(m) * (sizeof(unsigned long long) + sizeof(int));
+    if (segments_max_nodes <= kSegSortMax) {
+      hipLaunchKernelGGL((topk_segsort_block_kernel<256, true>), dim3(static_cast<unsigned>(B)), dim3(256), lds, stream,
+                         score, ptr, k, koff, s.rank_of, B, N, node_index, cluster_index, assign_perm, values,
+                         lift_row_ptr);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_segsort_block_kernel<1024, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      hipLaunchKernelGGL((topk_segsort_block_kernel<1024, true>), dim3(static_cast<unsigned>(B)), dim3(1024), lds, stream,
+                         score, ptr, k, koff, s.rank_of, B, N, node_index, cluster_index, assign_perm, values,
+                         lift_row_ptr);
+    }
+    return check_launch("tgp_topk_select");
+  }
   (void)hipMemsetAsync(s.rank_of, 0xFF, static_cast<size_t>(N) * sizeof(int32_t), stream);
   if (segments_max_nodes > 0 && segments_max_nodes <= 64) {
     hipLaunchKernelGGL(topk_segsort_wave_kernel, dim3(cdiv(B, 4)), dim3(256), 0, stream, score, ptr, k, koff, B,
                        s.rank_of);
   } else if (segments_max_nodes > 0 && segments_max_nodes <= kSegSortMax) {
-    hipLaunchKernelGGL(topk_segsort_block_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256),
-                       kSegSortMax * sizeof(unsigned long long), stream, score, ptr, k, koff, s.rank_of);
+    hipLaunchKernelGGL((topk_segsort_block_kernel<256, false>), dim3(static_cast<unsigned>(B)), dim3(256),
+                       kSegSortMax * sizeof(unsigned long long), stream, score, ptr, k, koff, s.rank_of, B, N,
+                       node_index, cluster_index, assign_perm, values, lift_row_ptr);
   } else if (segments_max_nodes > 0 && segments_max_nodes <= kSegSortLarge) {
     int m = 64;
     while (m < segments_max_nodes) m <<= 1;
     const size_t lds = static_cast<size_t>(m) * sizeof(unsigned long long);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_segsort_block_kernel<1024>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_segsort_block_kernel<1024, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    hipLaunchKernelGGL(topk_segsort_block_kernel<1024>, dim3(static_cast<unsigned>(B)), dim3(1024), lds, stream, score,
-                       ptr, k, koff, s.rank_of);
+    hipLaunchKernelGGL((topk_segsort_block_kernel<1024, false>), dim3(static_cast<unsigned>(B)), dim3(1024), lds, stream,
+                       score, ptr, k, koff, s.rank_of, B, N, node_index, cluster_index, assign_perm, values,
+                       lift_row_ptr);
   } else {
     hipLaunchKernelGGL(topk_keys_kernel, dim3(nb256), dim3(256), 0, stream, score, batch, N, s.k0, s.v0);
     bool first = true;
