@@ -1343,3 +1343,40 @@ def test_ndp_large_steps_stop_at_the_step_budget(dev, max_iter):
     assert int(status) == 0 and state["steps"] == max_iter
     assert set(keep.unique().tolist()) <= {0, 1} and 0 < int(keep.sum()) < n
     assert state["random"] or int(info) == max_iter
+
+
+@pytest.mark.parametrize("n,hubs,deg,lds", [(3000, 3, 900, False), (70_000, 5, 4000, True), (3000, 70, 400, False)])
+def test_graclus_matching_with_hub_rows(dev, n, hubs, deg, lds):
+    """Rows beyond 256 entries are scanned by whole waves taken from a list (work stealing): the matching is still valid
+    and maximal, and on distinct weights it is the sequential greedy heavy-edge matching (unique), hubs next to each
+    other included (70 hubs = more long rows than one wave has lanes); n >= 65536 takes the LDS-bitmap kernel."""
+    from tgp import kernels as KK
+    g = torch.Generator().manual_seed(n + hubs)
+    a = torch.randint(0, n, (2 * n,), generator=g)
+    b = torch.randint(0, n, (2 * n,), generator=g)
+    h = torch.arange(hubs).repeat_interleave(deg)
+    t = torch.randint(hubs, n, (hubs * deg,), generator=g)
+    r, c = torch.cat([a, h]), torch.cat([b, t])
+    keep = r != c
+    key = torch.unique(torch.minimum(r, c)[keep] * n + torch.maximum(r, c)[keep])
+    lo, hi = key // n, key % n
+    und_w = torch.rand(lo.numel(), generator=g) + 0.1
+    und_w = und_w + torch.arange(lo.numel()) * 1e-9       # distinct
+    ei = torch.cat([torch.stack([lo, hi]), torch.stack([hi, lo])], 1)
+    w = torch.cat([und_w, und_w])
+    order = torch.argsort(ei[0] * n + ei[1])
+    ei, w = ei[:, order].contiguous(), w[order].contiguous()
+    label = KK.graclus_match(ei.to(dev), w.to(dev), n).cpu()
+    idx = torch.arange(n)
+    cnt = torch.bincount(label, minlength=n)
+    assert cnt.max() <= 2 and torch.all(label <= idx) and torch.equal(label[label], label)
+    matched = cnt[label] == 2
+    assert not bool((~matched[ei[0]] & ~matched[ei[1]]).any())      # maximal
+    ref = idx.clone()
+    free = torch.ones(n, dtype=torch.bool)
+    for k in torch.argsort(und_w, descending=True).tolist():        # sequential greedy on the undirected pairs
+        x, y = int(lo[k]), int(hi[k])
+        if free[x] and free[y]:
+            free[x] = free[y] = False
+            ref[x] = ref[y] = min(x, y)
+    assert torch.equal(label, ref)

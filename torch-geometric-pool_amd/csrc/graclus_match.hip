@@ -114,12 +114,16 @@ __global__ __launch_bounds__(256) void gm_symmetrise_kernel(const int32_t* __res
   else wt[p] = fmaxf(wt[p], wt[q]);
 }
 
+constexpr int GM_LONG_ROW = 256;  // rows beyond this many entries are scanned by a whole wave (see gm_best_neighbour_wave)
 __global__ __launch_bounds__(256) void gm_init_kernel(int64_t n, int64_t* __restrict__ label,
-                                                      uint8_t* __restrict__ is_free) {
+                                                      uint8_t* __restrict__ is_free,
+                                                      const int32_t* __restrict__ row_ptr,
+                                                      int32_t* __restrict__ long_list, unsigned int* __restrict__ long_ctr) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i < n) {
     label[i] = i;
     is_free[i] = 1;
+    if (row_ptr[i + 1] - row_ptr[i] > GM_LONG_ROW) long_list[atomicAdd(long_ctr, 1u)] = static_cast<int32_t>(i);
   }
 }
 
@@ -172,22 +176,104 @@ __device__ __forceinline__ int32_t gm_best_neighbour(int64_t i, PtrT row_ptr, Nb
   return best;
 }
 
+// The same for ONE long row by the whole wave (every lane calls it with the same i): lane l takes entries lo + l,
+// lo + l + 64, ... and the lanes' bests are folded under the same lexicographic key, so the result is the one the
+// sequential scan gives.  Rows beyond GM_LONG_ROW entries take this: a hub of a power-law graph scanned by one lane
+// held its whole wave (and the round) for degree / 8 dependent trips -- ten hubs of degree 100 000 in a 1M-node graph
+// made the matching 27.6 ms instead of 0.32 ms.
+__device__ __forceinline__ bool gm_key_better(bool have, float bw, uint32_t bh, uint32_t ca, uint32_t cb, bool ohave,
+                                              float ow, uint32_t oh, uint32_t oa, uint32_t ob) {
+  if (!ohave) return false;
+  if (!have) return true;
+  if (ow != bw) return ow > bw;
+  if (oh != bh) return oh > bh;
+  if (oa != ca) return oa > ca;
+  return ob > cb;
+}
+template <typename FreeFn>
+__device__ __forceinline__ int32_t gm_best_neighbour_wave(int64_t i, const int32_t* __restrict__ row_ptr,
+                                                          const int32_t* __restrict__ nbr,
+                                                          const float* __restrict__ wt, FreeFn is_free_of) {
+  const int32_t lo = row_ptr[i], hi = row_ptr[i + 1];
+  int32_t best = -1;
+  float bw = 0.f;
+  uint32_t bh = 0, ba = 0, bb = 0;
+  for (int32_t p = lo + lane_id(); p < hi; p += 64) {
+    const int32_t j = nbr[p];
+    const float wj = wt[p];
+    if (j < 0 || j == i || wj != wj || !is_free_of(j)) continue;
+    const uint32_t a = static_cast<uint32_t>(i < j ? i : j), b = static_cast<uint32_t>(i < j ? j : i);
+    const uint32_t h = pair_hash(a, b);
+    if (gm_key_better(best >= 0, bw, bh, ba, bb, true, wj, h, a, b)) { best = j; bw = wj; bh = h; ba = a; bb = b; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int32_t oj = __shfl_xor(best, o, 64);
+    const float ow = __shfl_xor(bw, o, 64);
+    const uint32_t oh = __shfl_xor(bh, o, 64), oa = __shfl_xor(ba, o, 64), ob = __shfl_xor(bb, o, 64);
+    if (gm_key_better(best >= 0, bw, bh, ba, bb, oj >= 0, ow, oh, oa, ob)) { best = oj; bw = ow; bh = oh; ba = oa; bb = ob; }
+  }
+  return best;
+}
+
+// Proposal of a wave's nodes: short rows lane by lane; long rows are left to gm_steal_long_rows.  `mine`: this lane
+// holds a free node i.  *is_long: the lane's row is long (its candidate is written by whoever takes it from the list).
+template <typename FreeFn>
+__device__ __forceinline__ int32_t gm_propose_short(bool mine, int64_t i, const int32_t* __restrict__ row_ptr,
+                                                    const int32_t* __restrict__ nbr, const float* __restrict__ wt,
+                                                    FreeFn is_free_of, bool* is_long) {
+  *is_long = mine && row_ptr[i + 1] - row_ptr[i] > GM_LONG_ROW;
+  return (mine && !*is_long) ? gm_best_neighbour(i, row_ptr, nbr, wt, is_free_of) : -1;
+}
+
+// Every wave of the launch takes long rows from the list until it is empty (a ticket counter: hubs sit next to each
+// other -- the first nodes of a preferential-attachment graph -- and one wave owning 64 of them would scan them one
+// after the other).  `owner_free(i)`: node i is free at the start of this round.
+template <typename FreeFn, typename OwnFn>
+__device__ __forceinline__ void gm_steal_long_rows(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ nbr,
+                                                   const float* __restrict__ wt, const int32_t* __restrict__ long_list,
+                                                   unsigned int* __restrict__ long_ctr, FreeFn is_free_of,
+                                                   OwnFn owner_free, uint8_t* __restrict__ is_free,
+                                                   int32_t* __restrict__ cand) {
+  const unsigned int count = long_ctr[0];
+  if (count == 0) return;
+  for (;;) {
+    unsigned int t = 0;
+    if (lane_id() == 0) t = atomicAdd(long_ctr + 1, 1u);
+    t = __shfl(t, 0, 64);
+    if (t >= count) return;
+    const int32_t i = long_list[t];
+    if (!owner_free(i)) continue;  // (its candidate is already -1)
+    const int32_t r = gm_best_neighbour_wave(i, row_ptr, nbr, wt, is_free_of);
+    if (lane_id() == 0) {
+      if (r < 0) is_free[i] = 0;  // retire (see gm_propose_kernel)
+      cand[i] = r;
+    }
+  }
+}
+
 // cand[i] = best free neighbour of free node i, or -1 (free flags read from the global byte array).
 __global__ __launch_bounds__(256) void gm_propose_kernel(const int32_t* __restrict__ row_ptr,
                                                          const int32_t* __restrict__ nbr,
                                                          const float* __restrict__ wt, int64_t n,
                                                          uint8_t* __restrict__ is_free,
-                                                         int32_t* __restrict__ cand) {
+                                                         int32_t* __restrict__ cand,
+                                                         const int32_t* __restrict__ long_list,
+                                                         unsigned int* __restrict__ long_ctr) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (i >= n) return;
-  int32_t best = -1;
-  if (is_free[i]) {
-    best = gm_best_neighbour(i, row_ptr, nbr, wt, [&](int32_t j) { return is_free[j] != 0; });
+  const bool mine = i < n && is_free[i] != 0;
+  auto free_of = [&](int32_t j) { return is_free[j] != 0; };
+  bool is_long;
+  const int32_t best = gm_propose_short(mine, mine ? i : 0, row_ptr, nbr, wt, free_of, &is_long);
+  if (i < n && !is_long) {
     // No free neighbour left: the free set only shrinks, so this node stays single -- retire it, later rounds
     // skip its scan.  (No free node is adjacent to it, so nobody's proposal depends on this flag.)
-    if (best < 0) is_free[i] = 0;
+    if (mine && best < 0) is_free[i] = 0;
+    cand[i] = best;
   }
-  cand[i] = best;
+  // (a long row's flag is only cleared by the wave that scans it, after its scan: nobody reads it as "retired" early;
+  //  a neighbour reading it as free while it is being retired is the benign race described above)
+  gm_steal_long_rows(row_ptr, nbr, wt, long_list, long_ctr, free_of, free_of, is_free, cand);
 }
 
 // Same proposal step with the free flags as a 1-bit-per-node map held in LDS (N <= kGmLdsNodes): the per-neighbour
@@ -211,7 +297,9 @@ __global__ __launch_bounds__(1024) void gm_propose_lds_kernel(const int32_t* __r
                                                               const float* __restrict__ wt, int64_t n,
                                                               const uint32_t* __restrict__ bits,
                                                               uint8_t* __restrict__ is_free,
-                                                              int32_t* __restrict__ cand) {
+                                                              int32_t* __restrict__ cand,
+                                                              const int32_t* __restrict__ long_list,
+                                                              unsigned int* __restrict__ long_ctr) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
   __shared__ int32_t s_list[1024];
   __shared__ int s_cnt[16];
@@ -238,20 +326,26 @@ __global__ __launch_bounds__(1024) void gm_propose_lds_kernel(const int32_t* __r
     }
     if (is_f) s_list[before + __popcll(m & lanemask_lt())] = static_cast<int32_t>(own);
     __syncthreads();
-    if (static_cast<int>(threadIdx.x) < total) {
-      const int64_t i = s_list[threadIdx.x];
-      const int32_t best = gm_best_neighbour(i, row_ptr, nbr, wt, free_bit);
-      if (best < 0) is_free[i] = 0;  // retire (see gm_propose_kernel)
-      cand[i] = best;
+    {
+      const bool mine = static_cast<int>(threadIdx.x) < total;
+      const int64_t i = mine ? s_list[threadIdx.x] : 0;
+      bool is_long;
+      const int32_t best = gm_propose_short(mine, i, row_ptr, nbr, wt, free_bit, &is_long);
+      if (mine && !is_long) {
+        if (best < 0) is_free[i] = 0;  // retire (see gm_propose_kernel)
+        cand[i] = best;
+      }
     }
     __syncthreads();  // s_list / s_cnt are reused by the next chunk
   }
+  gm_steal_long_rows(row_ptr, nbr, wt, long_list, long_ctr, free_bit, free_bit, is_free, cand);
 }
 
 // Mutual proposals become pairs.  Each endpoint writes only its own slots; *matched is set when any pair formed.
 __global__ __launch_bounds__(256) void gm_match_kernel(const int32_t* __restrict__ cand, int64_t n,
                                                        int64_t* __restrict__ label, uint8_t* __restrict__ is_free,
-                                                       unsigned int* __restrict__ matched) {
+                                                       unsigned int* __restrict__ matched,
+                                                       unsigned int* __restrict__ long_ctr) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   bool hit = false;
   if (i < n) {
@@ -265,6 +359,7 @@ __global__ __launch_bounds__(256) void gm_match_kernel(const int32_t* __restrict
   // "did this round match anything": a plain store of 1 (one atomic per wave onto a single counter serialised
   // into 150 us at 1M nodes)
   if (__ballot(hit) && lane_id() == 0) *matched = 1u;
+  if (i == 0 && long_ctr) long_ctr[1] = 0;  // the long rows' ticket counter of the next round's proposal kernel
 }
 
 // Batches of graphs of at most GM_GRAPH_MAX nodes with a sorted batch vector: ONE workgroup per graph runs ALL the
@@ -389,14 +484,22 @@ __global__ __launch_bounds__(1024) void gm_tail_rounds_kernel(const int32_t* __r
   for (unsigned int t = threadIdx.x; t < m; t += 1024) s_list[t] = list[t];
   __syncthreads();
   for (int round = 0; round < (1 << 30); ++round) {
-    for (unsigned int t = threadIdx.x; t < m; t += 1024) {
-      const int32_t i = s_list[t];
-      int32_t c = -1;
-      if (is_free[i]) {
-        c = gm_best_neighbour(i, row_ptr, nbr, wt, [&](int32_t j) { return is_free[j] != 0; });
-        if (c < 0) is_free[i] = 0;  // retire (see gm_propose_kernel)
+    for (unsigned int t0 = 0; t0 < m; t0 += 1024) {  // (same trip count for every lane: long rows are scanned by the wave)
+      const unsigned int t = t0 + threadIdx.x;
+      const int32_t i = t < m ? s_list[t] : 0;
+      const bool mine = t < m && is_free[i] != 0;
+      auto free_of = [&](int32_t j) { return is_free[j] != 0; };
+      bool is_long;
+      int32_t c = gm_propose_short(mine, i, row_ptr, nbr, wt, free_of, &is_long);
+      unsigned long long lm = __ballot(is_long);  // (a hub that is still free this late: its wave scans it)
+      while (lm) {
+        const int l = __ffsll(static_cast<long long>(lm)) - 1;
+        lm &= lm - 1;
+        const int32_t r = gm_best_neighbour_wave(__shfl(i, l, 64), row_ptr, nbr, wt, free_of);
+        if (lane_id() == l) c = r;
       }
-      cand[i] = c;
+      if (mine && c < 0) is_free[i] = 0;  // retire (see gm_propose_kernel)
+      if (t < m) cand[i] = c;
     }
     __syncthreads();
     bool hit = false;
@@ -658,7 +761,26 @@ extern "C" size_t tgp_graclus_match_workspace_bytes(int64_t num_nodes, int64_t n
   const size_t n = static_cast<size_t>(num_nodes > 0 ? num_nodes : 1), e = static_cast<size_t>(num_edges > 0 ? num_edges : 1);
   return align_up(e * sizeof(int32_t)) + align_up(e * sizeof(float)) + align_up(n) + align_up(n * sizeof(int32_t)) +
          align_up((n / 32 + 8) * sizeof(uint32_t)) + align_up(e * sizeof(int32_t)) +
-         align_up((e / 256 + 2) * sizeof(unsigned long long)) + align_up((GM_TAIL_CAP + 16) * sizeof(int32_t)) + 512;
+         align_up((e / 256 + 2) * sizeof(unsigned long long)) + align_up((GM_TAIL_CAP + 16) * sizeof(int32_t)) +
+         align_up((e / GM_LONG_ROW + 8) * sizeof(int32_t)) + 512;
+}
+
+// rows of more than GM_LONG_ROW entries (listed by the init kernel) and {count, next ticket}: behind everything else
+static void gm_long_ptrs(void* ws, int64_t num_nodes, int64_t num_edges, int32_t** list, unsigned int** ctr) {
+  Carver cv(ws);
+  const int64_t e = num_edges > 0 ? num_edges : 1;
+  (void)cv.take<int32_t>(e);
+  (void)cv.take<float>(e);
+  (void)cv.take<uint8_t>(num_nodes);
+  (void)cv.take<int32_t>(num_nodes);
+  (void)cv.take<uint32_t>(num_nodes / 32 + 8);
+  (void)cv.take<int32_t>(e);
+  (void)cv.take<unsigned long long>(num_edges / 256 + 2);
+  (void)cv.take<int>(4);
+  (void)cv.take<int32_t>(GM_TAIL_CAP + 16);
+  int32_t* l = cv.take<int32_t>(e / GM_LONG_ROW + 8);
+  *ctr = reinterpret_cast<unsigned int*>(l);  // [0] count, [1] next ticket; the list starts at l + 4
+  *list = l + 4;
 }
 
 // Start: gathers the CSR and resets the state.  Rounds: runs `rounds` propose/match rounds; matched[r] becomes 1 if
@@ -694,8 +816,14 @@ extern "C" int tgp_graclus_match_start(const int64_t* row, const int64_t* col, c
   }
   // init_state == 0: the caller goes on with tgp_graclus_match_graphs, which sets every label itself and keeps its free
   // flags in LDS (the device-wide rounds need the state: 1)
-  if (init_state)
-    hipLaunchKernelGGL(gm_init_kernel, dim3(cdiv(num_nodes, 256)), dim3(256), 0, stream, num_nodes, label, is_free);
+  if (init_state) {
+    int32_t* long_list;
+    unsigned int* long_ctr;
+    gm_long_ptrs(ws, num_nodes, num_edges, &long_list, &long_ctr);
+    (void)hipMemsetAsync(long_ctr, 0, 2 * sizeof(unsigned int), stream);
+    hipLaunchKernelGGL(gm_init_kernel, dim3(cdiv(num_nodes, 256)), dim3(256), 0, stream, num_nodes, label, is_free,
+                       row_ptr, long_list, long_ctr);
+  }
   return check_launch("tgp_graclus_match_start");
 }
 
@@ -713,6 +841,9 @@ extern "C" int tgp_graclus_match_rounds(const int32_t* row_ptr, int64_t num_node
   (void)hipMemsetAsync(matched, 0, static_cast<size_t>(rounds) * sizeof(unsigned int), stream);
   uint32_t* bits = cv.take<uint32_t>(num_nodes / 32 + 8);
   const int nb = cdiv(num_nodes, 256);
+  int32_t* long_list;
+  unsigned int* long_ctr;
+  gm_long_ptrs(ws, num_nodes, num_edges, &long_list, &long_ctr);
   static const int cus = [] { int v = tgp_device_cu_count(); return v > 0 ? v : 256; }();
   const bool lds_map = num_nodes <= kGmLdsNodes && num_nodes >= 65536;
   const size_t lds_bytes = align_up(static_cast<size_t>((num_nodes + 31) / 32) * sizeof(uint32_t), 16);
@@ -720,10 +851,12 @@ extern "C" int tgp_graclus_match_rounds(const int32_t* row_ptr, int64_t num_node
     if (lds_map) {
       hipLaunchKernelGGL(gm_pack_free_kernel, dim3(cdiv(num_nodes, 256)), dim3(256), 0, stream, is_free, num_nodes, bits);
       hipLaunchKernelGGL(gm_propose_lds_kernel, dim3(cus), dim3(1024), lds_bytes, stream, row_ptr, nbr, wt, num_nodes,
-                         bits, is_free, cand);
+                         bits, is_free, cand, long_list, long_ctr);
     } else
-    hipLaunchKernelGGL(gm_propose_kernel, dim3(nb), dim3(256), 0, stream, row_ptr, nbr, wt, num_nodes, is_free, cand);
-    hipLaunchKernelGGL(gm_match_kernel, dim3(nb), dim3(256), 0, stream, cand, num_nodes, label, is_free, matched + r);
+    hipLaunchKernelGGL(gm_propose_kernel, dim3(nb), dim3(256), 0, stream, row_ptr, nbr, wt, num_nodes, is_free, cand,
+                       long_list, long_ctr);
+    hipLaunchKernelGGL(gm_match_kernel, dim3(nb), dim3(256), 0, stream, cand, num_nodes, label, is_free, matched + r,
+                       long_ctr);
   }
   return check_launch("tgp_graclus_match_rounds");
 }
