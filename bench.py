@@ -266,6 +266,19 @@ class DenseDiffPool(Workload):
                 self.gather.start([x_pool, adj_pool])
                 self.gather.take_ready()  # a consumer would use these; the bench only must not accumulate them
 
+    def cpu_pass(self):
+        """reference base_reduce.py:158-161 + dense_conn.py:111-122 + ops.py:282-335 on the first graphs of THIS batch."""
+        O = _oracle()
+        bs = min(self.B, 8 if self.which == "c2" else 1)
+        S, A, X = self.S[:bs].cpu(), self.A[:bs].cpu(), self.X[:bs].cpu()
+
+        def one_pass():
+            O.reduce_dense(S, X)
+            O.postprocess_dense(O.dense_connect(S, A), True, True, True, False)
+
+        return one_pass, bs * self.N, (f"the first {bs} of the {self.B} graphs of the measured batch "
+                                       f"(N={self.N},K={self.K},F={self.F})"), (10.0 if self.which == "c2" else 6.0)
+
     def rooflines(self, dev):
         from tgp import kernels
         flops = 2.0 * self.B * self.N * self.N * self.K
@@ -314,6 +327,17 @@ class SmallGraphsMinCut(Workload):
                 postprocess_adj_pool_dense(raw, True, True, True, False)
             else:
                 self.pool.reduce_connect(self.X, self.A, self.so, want_raw=True)
+
+    def cpu_pass(self):
+        """MinCut order on the CPU: S^T X, raw S^T A S, post-processing (mincut.py:220-237 over the dense operators)."""
+        O = _oracle()
+        S, A, X = self.S.cpu(), self.A.cpu(), self.X.cpu()
+
+        def one_pass():
+            O.reduce_dense(S, X)
+            O.postprocess_dense(O.dense_connect(S, A), True, True, True, False)
+
+        return one_pass, self.nodes, "the whole measured batch (2048 padded graphs)", 4.0
 
     def rooflines(self, dev):
         B, Nmax, K, F = self.dims
@@ -528,6 +552,19 @@ class TopkBatch(Workload):
             return all_gather_sparse(xp, ei, ew, bp, self.num_graphs, force_collective=self.force)
         return xp, ei, ew, bp
 
+    def cpu_pass(self):
+        O = _oracle()
+        so = self.so
+        x, ei, ew, batch = self.x.cpu(), self.ei.cpu(), self.ew.cpu(), self.batch.cpu()
+        ni, ci, w, n, k = so.node_index.cpu(), so.cluster_index.cpu(), so.weight.cpu(), self.nodes, int(so.num_supernodes)
+
+        def one_pass():
+            O.reduce_sparse(x, ni, ci, w, k)
+            bp = O.reduce_batch_sparse(batch, ni, ci, k)
+            O.sparse_connect(ei, ew, ni, ci, n, k, batch_pooled=bp)
+
+        return one_pass, n, "the whole measured batch (2048 graphs): Reduce + subgraph Connect", 3.0
+
     def rooflines(self, dev):
         xp, ei, ew, bp = self.compute()
         E, E2, k = self.ei.size(1), ei.size(1), xp.size(0)
@@ -594,6 +631,19 @@ class SparseReduceOnly(Workload):
         so._set_one_to_one_index()  # what TopkSelect / NDPSelect attach: one node per supernode, no sort
         self.red(self.x, so, batch=self.batch)
 
+    def cpu_pass(self):
+        """reference base_reduce.py:14-53,141-155 (gather x weight, scatter-add, reduce_batch) on the measured inputs."""
+        O = _oracle()
+        so, k = self.so, self.k
+        x, batch, ni, ci = self.x.cpu(), self.batch.cpu(), so.node_index.cpu(), so.cluster_index.cpu()
+        w = so.weight.cpu() if so.weight is not None else torch.ones(ni.numel())
+
+        def one_pass():
+            O.reduce_sparse(x, ni, ci, w, k)
+            O.reduce_batch_sparse(batch, ni, ci, k)
+
+        return one_pass, self.nodes, "the whole measured input (N=1M, F=128)", 5.0
+
     def rooflines(self, dev):
         from tgp import kernels
         so, f, k = self.so, self.f, self.k
@@ -601,8 +651,8 @@ class SparseReduceOnly(Workload):
         # row + node_index + perm (+ weight) per assignment; no row_ptr table to read (one-to-one)
         alg = k * (4.0 * f + 8 + 4 + (4 if so.weight is not None else 0)) + k * 4.0 * f
         ms = event_time_ms(lambda: kernels.reduce_sparse(self.x, so.node_index, so.weight, idx), 50, dev)
-        return roof_hbm("tgp::reduce_sparse_vec4_kernel (gather-sum, index cached)", alg, ms,
-                        f"reduce_sparse_vec4_kernel:{self.which}")
+        return roof_hbm("tgp::reduce_one_to_one_kernel (gather-scale, one assignment per supernode)", alg, ms,
+                        f"reduce_one_to_one_kernel:{self.which}")
 
 
 class TopkConnect(Workload):
@@ -626,6 +676,16 @@ class TopkConnect(Workload):
 
     def step(self):
         return self.conn(self.ei, self.so, edge_weight=self.ew)
+
+    def cpu_pass(self):
+        """reference base_conn.py:79-82 + ops.py:338-419 on the measured inputs."""
+        O = _oracle()
+        ei, ew, ni, n, k = self.ei.cpu(), self.ew.cpu(), self.so.node_index.cpu(), self.n, self.k
+
+        def one_pass():
+            O.sparse_connect(ei, ew, ni, None, n, k)
+
+        return one_pass, n, "the whole measured input (N=1M, E=10M)", 5.0
 
     def rooflines(self, dev):
         ei_out, _ = self.step()
@@ -666,6 +726,21 @@ class GraclusC4(Workload):
         so._drop_caches()  # rebuild the inverted index every step (no cross-step caching)
         xp, bp = self.red(self.x, so, batch=self.batch)
         return self.conn(self.ei, so, edge_weight=self.ew, batch_pooled=bp)
+
+    def cpu_pass(self):
+        """reference base_reduce.py:14-53,141-155 + base_conn.py:83-89 (relabel + coalesce) + ops.py:338-419."""
+        O = _oracle()
+        so, n, k = self.so, self.n, self.k
+        x, batch, ei, ew = self.x.cpu(), self.batch.cpu(), self.ei.cpu(), self.ew.cpu()
+        ni, ci = so.node_index.cpu(), so.cluster_index.cpu()
+        w = so.weight.cpu() if so.weight is not None else torch.ones(ni.numel())
+
+        def one_pass():
+            O.reduce_sparse(x, ni, ci, w, k)
+            bp = O.reduce_batch_sparse(batch, ni, ci, k)
+            O.sparse_connect(ei, ew, ni, ci, n, k, batch_pooled=bp)
+
+        return one_pass, n, "the whole measured input (N=1M, E=10M, F=128): Reduce + coalesce Connect", 8.0
 
     def rooflines(self, dev):
         from tgp import kernels
@@ -710,6 +785,14 @@ def run_secondary(which, ctx, args):
     wl = make_workload(which, ctx, args)
     for _ in range(5):
         wl.step()
+    # the previous workload's CPU-baseline leg left the device idle for seconds: run in until ~50 ms of this workload
+    # have gone by (clock ramp), synchronising every 50 steps as the headline's settle phase does
+    ctx.sync()
+    t0 = time.perf_counter()
+    while ctx.dist is None and time.perf_counter() - t0 < SETTLE_SECONDS / 2:
+        for _ in range(50):
+            wl.step()
+        ctx.sync()
     steps = WINDOW_STEPS if which != "c5" else 50  # c5: 1.1 ms per step, 50 steps = 55 ms per window
     win = median_windows(ctx, wl.step, wl.drain, steps=steps)
     roofs = wl.rooflines(ctx.dev)
@@ -724,57 +807,63 @@ def run_secondary(which, ctx, args):
         fl = roofs[0]["whole_step_flops"]
         out["whole_step"] = {"flops": fl, "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
                              "frac_of_fp32_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    if ctx.world == 1 and ctx.rank == 0 and not args.no_cpu_baseline and hasattr(wl, "cpu_pass"):
+        out["cpu_baseline"] = cpu_baseline(*wl.cpu_pass())
     del wl
     torch.cuda.empty_cache()
     return out
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline_dense(B, N, K, F, budget_s=10.0):
-    """CPU oracle (plain torch port of reference base_reduce.py:158-161 + dense_conn.py:111-122 +
-    ops.py:282-335) on a bounded sample: B_s graphs of the same shape; per-pass times, MEDIAN reported (a shared
-    host's scheduling noise moved a mean by 1.7x between two runs of round 1)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+def _oracle():
+    """The CPU oracle: imported by this leg only, as the reported baseline (never by the measured path)."""
+    p = os.path.join(ROOT, "oracle")
+    if p not in sys.path:
+        sys.path.insert(0, p)
     import tgp_oracle as O
-    bs = min(B, 8)
-    g = torch.Generator().manual_seed(0)
-    A = (torch.rand(bs, N, N, generator=g) < 0.01).float()
-    A = torch.maximum(A, A.transpose(1, 2))
-    X = torch.randn(bs, N, F, generator=g)
-    S = torch.softmax(torch.randn(bs, N, K, generator=g), -1)
+    return O
 
-    def one_pass():
-        t0 = time.perf_counter()
-        O.reduce_dense(S, X)
-        O.postprocess_dense(O.dense_connect(S, A), True, True, True, False)
-        return time.perf_counter() - t0
 
-    def rate(seconds):
-        for _ in range(3):
-            one_pass()
-        ts, t0 = [], time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
-            ts.append(one_pass())
-        return bs * N / statistics.median(ts), len(ts), time.perf_counter() - t0, bs * N * len(ts) / sum(ts)
-
-    threads = torch.get_num_threads()
-    value, n, dt, mean_rate = rate(budget_s)
-    torch.set_num_threads(1)  # SURVEY 8(d): all host cores, and again with one thread
-    try:
-        one, n1, dt1, _ = rate(budget_s / 3)
-    finally:
-        torch.set_num_threads(threads)
-    model = ""
+def _host_model():
     try:
         with open("/proc/cpuinfo") as fh:
-            model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "")
+            return next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "")
     except OSError:
-        pass
+        return ""
+
+
+def cpu_baseline(one_pass, nodes, sample, budget_s=10.0, min_passes=2):
+    """`one_pass()` = the CPU oracle (plain torch port of the reference algorithm) over `nodes` input
+    nodes of the same workload; timed per pass on this box's host cores, all torch threads and again with one
+    (the pattern of /root/reference/examples/time_and_mem_test.py:335-440: warm-up, then timed repetitions).
+    `value` = nodes / MEDIAN pass time: the number to quote (a shared host's scheduling outliers moved a mean by
+    1.7x between two runs of round 1; the median is the CPU's undisturbed rate, i.e. the figure that flatters the
+    CPU); `mean_value` = all nodes / all time is kept beside it for the record."""
+    def rate(seconds, warm):
+        for _ in range(warm):
+            one_pass()
+        ts, t0 = [], time.perf_counter()
+        while len(ts) < min_passes or time.perf_counter() - t0 < seconds:
+            t1 = time.perf_counter()
+            one_pass()
+            ts.append(time.perf_counter() - t1)
+            if len(ts) >= min_passes and time.perf_counter() - t0 >= seconds:
+                break
+        return nodes / statistics.median(ts), len(ts), time.perf_counter() - t0, nodes * len(ts) / sum(ts)
+
+    threads = torch.get_num_threads()
+    value, n, dt, mean_rate = rate(budget_s, 1)
+    torch.set_num_threads(1)  # SURVEY 8(d): all host cores, and again with one thread
+    try:
+        one, n1, dt1, _ = rate(budget_s / 3, 0)
+    finally:
+        torch.set_num_threads(threads)
     return {"value": value, "unit": "nodes/s", "cores": threads, "kind": "port",
-            "sample": f"{bs} of {B} graphs (N={N},K={K},F={F}), median of {n} passes of the CPU oracle in {dt:.1f}s",
+            "sample": f"{sample}; median of {n} passes of the CPU oracle in {dt:.1f}s",
+            "quote": "value (nodes / median pass time, all torch threads)",
             "mean_value": mean_rate,  # passes / total time: includes the host's scheduling outliers
             "one_thread": {"value": one, "passes": n1, "seconds": round(dt1, 1)},
-            "host": {"cpu_count": os.cpu_count(), "model": model}}
+            "host": {"cpu_count": os.cpu_count(), "model": _host_model()}}
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -877,6 +966,9 @@ def main():
         sec = [s for s in sec if s in SHARDED]  # the graph-sharded ones
     headline_cfg = dict(workload=wl.name, **(wl.extra or {}), parallelism=f"graph-sharded x{world}")
     dims = (wl.B, wl.N, wl.K, wl.F) if isinstance(wl, DenseDiffPool) else None
+    cpu_job = None  # host copies of the measured inputs now; the CPU passes run after the GPU work of the line
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and hasattr(wl, "cpu_pass"):
+        cpu_job = wl.cpu_pass()
     del wl
     torch.cuda.empty_cache()
     secondary = []
@@ -901,8 +993,8 @@ def main():
             ms = win["ms_per_step_median"]
             line["whole_step"] = {"flops": fl, "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
                                   "frac_of_fp32_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
-        if world == 1 and not args.no_cpu_baseline and dims is not None:
-            line["cpu_baseline"] = cpu_baseline_dense(*dims)
+        if cpu_job is not None:
+            line["cpu_baseline"] = cpu_baseline(*cpu_job)
         if secondary:
             line["secondary"] = secondary
         print(json.dumps(line), flush=True)

@@ -289,7 +289,8 @@ def test_lift_roundtrip(dev):
 
 @pytest.mark.parametrize("shape", [(96, 60, 20, 32), (70, 61, 19, 31), (64, 63, 32, 5), (65, 33, 1, 1), (80, 64, 7, 30),
                                    (130, 100, 20, 32), (128, 126, 40, 64), (129, 200, 50, 37), (128, 257, 64, 128), (128, 97, 33, 1),
-                                   (128, 65, 64, 65), (9, 500, 33, 20), (8, 40, 64, 3)])
+                                   (128, 65, 64, 65), (9, 500, 33, 20), (8, 40, 64, 3),
+                                   (2048, 60, 20, 32)])  # the last one: C3 at its stated size (BASELINE configs[2])
 def test_small_graph_kernel_flag_grid(dev, shape):
     """One-wave-per-graph path (N <= 64, K <= 32, F <= 32, B >= 64) and the one-workgroup-per-graph path above it:
     every post-processing flag combination, ragged graph sizes (zero-padded rows as MLPSelect leaves them), both A

@@ -236,3 +236,30 @@ def test_select_output_s_inv_is_lazy_but_behaves_like_the_eager_attribute():
     assert not dense.s_inv_is_transpose_of_s and dense.s_inv.shape == (2, 3, 5)
     dense.set_s_inv("transpose")
     assert dense.s_inv_is_transpose_of_s and torch.equal(dense.s_inv, dense.s.transpose(-1, -2))
+
+
+def test_roofline_traffic_json_is_the_pmc_summary_it_names():
+    """profiles/roofline_traffic.json (what bench.py reports as roofline.traffic) is generated by tools/pmc_summary.py
+    from the same PMC pass as the markdown summary it names in `_source`: every value must be that file's per-call
+    total, and every key must be one bench.py asks for."""
+    import json
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blob = json.load(open(os.path.join(root, "profiles", "roofline_traffic.json")))
+    md = open(os.path.join(root, blob["_source"])).read()
+    totals = {m.group(1): float(m.group(2)) for m in
+              re.finditer(r"^\| (\S+) \| \*\*kernels of one measured call.*\*\*([0-9.]+)\*\* \|$", md, re.M)}
+    assert totals, "no per-call totals found in " + blob["_source"]
+    src = open(os.path.join(root, "tools", "pmc_summary.py")).read()
+    keys = dict(re.findall(r'^    "(\w+)": "([^"]+)",$', src, re.M))
+    bench_src = open(os.path.join(root, "bench.py")).read()
+    seen = 0
+    for work, total_mb in totals.items():
+        key = keys.get(work, work)
+        assert key in blob, f"{key} (workload {work}) missing from roofline_traffic.json"
+        assert round(blob[key] / 1e6, 1) == pytest.approx(total_mb, abs=0.051), (key, blob[key], total_mb)
+        stem = key.split(":")[0]
+        assert stem in bench_src, f"bench.py never asks for traffic key {key}"
+        seen += 1
+    assert seen == len([k for k in blob if not k.startswith("_")])

@@ -279,7 +279,8 @@ class KronConnect(Connect):
     The reference builds one sparse Laplacian for the whole batch and calls scipy's sparse LU on the host.  The batch
     Laplacian is block diagonal, so on the GPU every graph's Schur complement is taken independently by
     ``tgp_kron_batched_{count,fill}``: one workgroup per graph, dense fp64 elimination of the dropped nodes in LDS
-    (graphs up to 128 nodes) or in a workspace slab (up to 1024 nodes), threshold / zero-diagonal / fp32 cast fused,
+    (graphs up to 128 nodes) or panel by panel in a workspace slab (up to ``tgp_kron_batched_max_graph_nodes`` = 4096
+    nodes), threshold / zero-diagonal / fp32 cast fused,
     edges emitted in the row-major order the reference's CSR -> COO conversion gives.  Nothing but the selector's
     Laplacian (uploaded once per SelectOutput) crosses PCIe.  Graphs beyond that size are skipped by the kernel and
     reduced one by one with the dense fp64 library solve on the device (``torch.linalg.solve`` -> rocSOLVER, up to
