@@ -516,7 +516,7 @@ class TopkBatch(Workload):
     payloads, then node-id / graph-id offsets: the merge rule of tgp/data/collate.py:144-153)."""
     shards = True
 
-    def __init__(self, ctx, force_collective=False):
+    def __init__(self, ctx, force_collective=False, unfused=False):
         from tgp.connect import SparseConnect
         from tgp.reduce import BaseReduce
         from tgp.select import TopkSelect
@@ -528,6 +528,9 @@ class TopkBatch(Workload):
         with torch.no_grad():
             self.so = TopkSelect(in_channels=self.f, ratio=0.5).to(dev)(x=self.x, batch=self.batch)
         self.red, self.conn = BaseReduce(), SparseConnect()
+        from tgp.src import SRCPooling
+        self.pool = SRCPooling(reducer=self.red, connector=self.conn)
+        self.unfused = unfused
         self.gather = ctx.dist is not None
         self.dist_world = ctx.world
         self.force = force_collective
@@ -537,13 +540,25 @@ class TopkBatch(Workload):
                      "graph-sharded" + (", pooled outputs all-gathered over RCCL (variable-size)" if self.gather else ""))
         self.extra = {"edges": int(self.ei.size(1)), "num_supernodes": int(self.so.num_supernodes),
                       "nodes_counted": "input nodes per step per GPU",
-                      "step": "BaseReduce + SparseConnect (subgraph)" + (" + all_gather_sparse" if self.gather else "")}
+                      "step": ("BaseReduce then SparseConnect (subgraph), operator by operator" if unfused else
+                               "fused Reduce + Connect as the sparse poolers' forward calls it on a batch of small "
+                               "graphs: SRCPooling.reduce_connect (one launch + the count read-back)")
+                              + (" + all_gather_sparse" if self.gather else "")}
 
-    def compute(self):
+    def staged(self):
         with torch.no_grad():
             xp, bp = self.red(self.x, self.so, batch=self.batch)
             ei, ew = self.conn(self.ei, self.so, edge_weight=self.ew, batch_pooled=bp)
         return xp, ei, ew, bp
+
+    def compute(self):
+        if not self.unfused:
+            with torch.no_grad():
+                fused = self.pool.reduce_connect(self.x, self.ei, self.ew, self.so, self.batch)
+            if fused is not None:
+                xp, bp, ei, ew = fused
+                return xp, ei, ew, bp
+        return self.staged()
 
     def step(self):
         xp, ei, ew, bp = self.compute()
@@ -571,8 +586,15 @@ class TopkBatch(Workload):
         alg = (k * (4.0 * self.f + 8 + 4 + 4) + k * 4.0 * self.f          # A1 one-to-one
                + E * 20.0 + self.nodes + k * 8.0 + E2 * 20.0)              # A5 + A6
         ms_c = event_time_ms(self.compute, 50, dev)
-        r = roof_hbm("Reduce + subgraph Connect (all kernels of both calls + the Connect's host read-back)", alg, ms_c)
+        r = roof_hbm("tgp::sparse_pool_small_kernel<0> (Reduce + subgraph Connect: one launch + the count read-back)"
+                     if not self.unfused else
+                     "Reduce + subgraph Connect (all kernels of both calls + the Connect's host read-back)", alg, ms_c,
+                     "sparse_pool_small:topk_batch")
         r["compute_only_ms"] = round(ms_c, 5)
+        if not self.unfused:
+            r["staged_operators_ms"] = round(event_time_ms(self.staged, 50, dev), 5)
+            a, b = self.compute(), self.staged()
+            r["fused_equals_staged"] = bool(all(torch.equal(u, v) for u, v in zip(a, b)))
         if self.gather:
             ms_g = event_time_ms(self.step, 50, dev)
             r["compute_plus_gather_ms"] = round(ms_g, 5)
@@ -776,7 +798,7 @@ def make_workload(which, ctx, args):
     if which == "e2e_train_mincut_c3":
         return PoolerTrainStep(ctx)
     if which == "topk_batch":
-        return TopkBatch(ctx, force_collective=os.environ.get("TGP_BENCH_FORCE_DIST") == "1")
+        return TopkBatch(ctx, force_collective=os.environ.get("TGP_BENCH_FORCE_DIST") == "1", unfused=args.unfused)
     raise ValueError(which)
 
 

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10023 /* 1.0.1 of the reference, ABI revision 4 (r3: MLPSelect entry points) */
+#define TGP_ABI_VERSION 10024 /* 1.0.1 of the reference, ABI revision 5 (r4: one-launch sparse pooling of small graphs) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -172,6 +172,35 @@ int tgp_connect_coalesce_fused_count(const int64_t* row, const int64_t* col, con
                                      int64_t* d_count, void* stream);
 int tgp_connect_coalesce_fused_fill(const void* ws, int64_t num_edges, int64_t num_nodes, int64_t num_supernodes,
                                     int64_t num_out, int64_t* out_row, int64_t* out_col, void* stream);
+
+/* A1 + A2 + (A5 | A4) + A6 filters for a BATCH OF SMALL GRAPHS in ONE launch (r4): sparse Reduce
+ * (reduce/base_reduce.py:14-53,141-155) and sparse Connect (connect/base_conn.py:79-89 + the self-loop / |w| > eps
+ * filters of utils/ops.py:370-380) of a PyG-style batch whose `batch` vector is sorted and whose graphs have at most
+ * tgp_sparse_pool_small_max_graph_nodes() nodes: one wave per graph.  `graph_ptr` [B+1] = node offsets of the graphs.
+ *   mode 0 (kept-node selection: TopK, NDP-shaped S): node_index ascending, one supernode per kept node, numbered
+ *          graph-major; induced subgraph, endpoints relabelled to their position in node_index, input edge order kept.
+ *   mode 1 (every node in exactly one cluster: Graclus, ...): node_index = 0..N-1, cluster ids contiguous per graph and
+ *          ascending over the graphs; endpoints mapped through cluster_index, duplicates merged with `reduce_op` in input
+ *          order, output in (row, col) order (PyG coalesce).
+ * Outputs: x_pool [K,F], batch_pool [K] (NULL ok), and the surviving edges written ONCE at their final offsets of the
+ * capacity-E buffers out_row / out_col / out_weight (NULL iff edge_weight is NULL): the first `total` entries are the
+ * result, identical to tgp_reduce_sparse_f32 + tgp_reduce_batch_i64 + tgp_connect_{subgraph,coalesce_*}_{count,fill}.
+ * `status` (>= tgp_sparse_pool_small_status_words(B, mode) 64-bit words, caller-owned, kept between calls on ONE
+ * stream, never cleared: every word carries `epoch` in its bits 34.., 0 < epoch < 2^30, a different value for every
+ * call on that buffer): status[0] = refusal (current epoch and low 32 bits != 0: a precondition above does not hold,
+ * checked on the device -- an edge leaving its graph, unsorted rows, a graph too large, more than 512 edges in a mode-1
+ * graph, ... -- outputs are then unspecified and the caller takes the staged entry points), status[1] = total.  The
+ * caller reads both words after the launch (the call's one host sync). */
+int tgp_sparse_pool_small_max_graph_nodes(void);
+int64_t tgp_sparse_pool_small_status_words(int64_t num_graphs, int mode);
+int tgp_sparse_pool_small_f32(const float* x, int64_t num_nodes, int64_t num_features, int64_t x_row_stride,
+                              const int64_t* graph_ptr /* [B+1] */, int64_t num_graphs, const int64_t* row,
+                              const int64_t* col, const float* edge_weight /* NULL ok */, int64_t num_edges,
+                              const int64_t* node_index, const int64_t* cluster_index,
+                              const float* weight /* NULL = ones */, int64_t nnz, int64_t num_supernodes, int mode,
+                              int reduce_op, int flags, float eps, float* x_pool, int64_t* batch_pool /* NULL ok */,
+                              int64_t* out_row, int64_t* out_col, float* out_weight, uint64_t* status,
+                              int64_t status_words, uint32_t epoch, void* stream);
 
 /* A4 for edge lists in ANY order, two-level: a stable radix sort by supernode row only (log2 K bits instead of the
  * 2 log2 K bits of the (row, col) key above) carrying (cluster column, weight) as payload, then the same in-row

@@ -65,3 +65,152 @@ def test_packed_gather_in_place_over_rccl_one_rank_group(dev, one_rank_rccl):
     for (xw, aw), (xg, ag) in zip(want, got):
         assert xg.data_ptr() != xw.data_ptr()
         assert torch.equal(xg, xw) and torch.equal(ag, aw)
+
+
+# ------------------------------------------------------------------------------ one-launch sparse pooling of small graphs
+def _small_batch(num_graphs, lo, hi, f, seed, dev, deg=4, dup=False):
+    """PyG-style batch: sorted batch vector, row-major sorted undirected edge list (optionally with duplicate entries)."""
+    g = torch.Generator().manual_seed(seed)
+    sizes = torch.randint(lo, hi + 1, (num_graphs,), generator=g)
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(num_graphs), sizes)
+    start = torch.cumsum(sizes, 0) - sizes
+    src = torch.arange(n).repeat_interleave(max(deg // 2, 1))
+    dst = start[batch[src]] + (torch.rand(src.numel(), generator=g) * sizes[batch[src]]).long()
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    key = torch.cat([src * n + dst, dst * n + src])
+    key = torch.sort(key)[0] if dup else torch.unique(key)
+    ei = torch.stack([key // n, key % n])
+    x = torch.randn(n, f, generator=g)
+    ew = torch.rand(ei.size(1), generator=g) + 0.25
+    ew[torch.rand(ei.size(1), generator=g) < 0.05] = 0.0  # some weights the eps filter drops
+    return x.to(dev), ei.to(dev), ew.to(dev), batch.to(dev), sizes
+
+
+def _staged_reduce_connect(pooler, x, ei, ew, so, batch):
+    xp, bp = pooler.reducer(x, so, batch=batch)
+    pe, pw = pooler.connector(ei, so, edge_weight=ew, batch_pooled=bp)
+    return xp, bp, pe, pw
+
+
+def _same(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    return a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("weighted", [True, False])
+@pytest.mark.parametrize("f", [32, 7, 128])
+@pytest.mark.parametrize("kw", [dict(), dict(remove_self_loops=False), dict(degree_norm=True, edge_weight_norm=True)])
+def test_sparse_pool_small_topk_equals_staged_operators(dev, weighted, f, kw):
+    """TopK: the one-launch Reduce + Connect of a batch of small graphs (tgp_sparse_pool_small_f32, mode 0) against
+    BaseReduce + SparseConnect (reduce/base_reduce.py:141-155, connect/base_conn.py:79-82, utils/ops.py:338-419):
+    x_pool, batch, edge_index and weights bit for bit, and against the oracle end to end."""
+    import tgp_oracle as O
+    from tgp.poolers import get_pooler
+    x, ei, ew, batch, sizes = _small_batch(300, 1, 64, f, 5, dev)
+    if not weighted:
+        ew = None
+    pooler = get_pooler("topk", in_channels=f, ratio=0.5, **kw).to(dev).eval()
+    with torch.no_grad():
+        so = pooler.selector(x=x, batch=batch)
+        fused = pooler.reduce_connect(x, ei, ew, so, batch)
+        assert fused is not None, "the one-launch path declined a sorted batch of small graphs"
+        staged = _staged_reduce_connect(pooler, x, ei, ew, so, batch)
+        out = pooler(x=x, adj=ei, edge_weight=ew, batch=batch)
+    for a, b in zip(fused, staged):
+        assert _same(a, b)
+    assert _same(out.edge_index, staged[2]) and _same(out.x, staged[0])
+    ref = O.topk_pool(x.cpu(), ei.cpu(), None if ew is None else ew.cpu(), batch.cpu(),
+                      pooler.selector.weight.detach().cpu(), ratio=0.5, **kw)
+    assert torch.equal(out.edge_index.cpu(), ref["edge_index"]) and torch.equal(out.batch.cpu(), ref["batch"])
+    torch.testing.assert_close(out.x.cpu(), ref["x"], rtol=1e-5, atol=1e-5)
+    if ref["edge_weight"] is not None:
+        torch.testing.assert_close(out.edge_weight.cpu(), ref["edge_weight"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("op", ["sum", "mean", "min", "max", "mul"])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_sparse_pool_small_cluster_equals_staged_operators(dev, op, weighted):
+    """Graclus-style clusterings (mode 1): relabel + coalesce with every reduce op, duplicate input entries included,
+    against BaseReduce + SparseConnect's coalesce routes (connect/base_conn.py:83-89), bit for bit; and the oracle."""
+    import tgp_oracle as O
+    from tgp.poolers import get_pooler
+    x, ei, ew, batch, sizes = _small_batch(257, 1, 64, 20, 11, dev, dup=True)
+    if not weighted:
+        ew = None
+    pooler = get_pooler("graclus", connect_red_op=op).to(dev).eval()
+    with torch.no_grad():
+        so = pooler.selector(edge_index=ei, edge_weight=ew, num_nodes=x.size(0), batch=batch)
+        fused = pooler.reduce_connect(x, ei, ew, so, batch)
+        assert fused is not None, "the one-launch path declined a sorted batch of small graphs"
+        staged = _staged_reduce_connect(pooler, x, ei, ew, so, batch)
+    for a, b in zip(fused, staged):
+        assert _same(a, b)
+    ref = O.cluster_pool(x.cpu(), ei.cpu(), None if ew is None else ew.cpu(), batch.cpu(), so.cluster_index.cpu(),
+                         so.num_supernodes, reduce_op=op)
+    assert torch.equal(fused[2].cpu(), ref["edge_index"]) and torch.equal(fused[1].cpu(), ref["batch"])
+    torch.testing.assert_close(fused[0].cpu(), ref["x"], rtol=1e-5, atol=1e-5)
+    if ref["edge_weight"] is not None:
+        torch.testing.assert_close(fused[3].cpu(), ref["edge_weight"], rtol=1e-5, atol=1e-5)
+
+
+def test_sparse_pool_small_refuses_what_it_cannot_check_off(dev):
+    """The kernel's on-device checks: an edge between two graphs, unsorted rows, a cluster spanning two graphs -> it
+    declines (None) and the pooler's staged operators give the reference's result; a graph beyond 64 nodes is not
+    offered to it at all."""
+    import tgp_oracle as O
+    from tgp import kernels as K
+    from tgp.poolers import get_pooler
+    from tgp.select import SelectOutput
+    x, ei, ew, batch, sizes = _small_batch(50, 5, 40, 8, 3, dev)
+    pooler = get_pooler("topk", in_channels=8, ratio=0.5).to(dev).eval()
+    with torch.no_grad():
+        so = pooler.selector(x=x, batch=batch)
+        # (a) an edge that leaves its graph (legal for the reference: both endpoints kept or not decides)
+        cross = torch.tensor([[0], [x.size(0) - 1]], device=dev)
+        ei_a = torch.cat([cross, ei], 1)
+        ew_a = torch.cat([torch.ones(1, device=dev), ew])
+        assert pooler.reduce_connect(x, ei_a, ew_a, so, batch) is None
+        assert K.sparse_pool_small_declined(ei_a)
+        out = pooler(x=x, adj=ei_a, edge_weight=ew_a, batch=batch)
+        ref = O.topk_pool(x.cpu(), ei_a.cpu(), ew_a.cpu(), batch.cpu(), pooler.selector.weight.detach().cpu(), ratio=0.5)
+        assert torch.equal(out.edge_index.cpu(), ref["edge_index"])
+        # (b) rows in random order
+        perm = torch.randperm(ei.size(1), device=dev)
+        ei_b, ew_b = ei[:, perm].contiguous(), ew[perm]
+        assert pooler.reduce_connect(x, ei_b, ew_b, so, batch) is None
+        out = pooler(x=x, adj=ei_b, edge_weight=ew_b, batch=batch)
+        ref = O.topk_pool(x.cpu(), ei_b.cpu(), ew_b.cpu(), batch.cpu(), pooler.selector.weight.detach().cpu(), ratio=0.5)
+        assert torch.equal(out.edge_index.cpu(), ref["edge_index"])
+        torch.testing.assert_close(out.edge_weight.cpu(), ref["edge_weight"], rtol=1e-5, atol=1e-5)
+        # (c) a clustering whose ids are not contiguous per graph (random labels over the whole batch)
+        gp = get_pooler("graclus").to(dev).eval()
+        g = torch.Generator().manual_seed(0)
+        cl = torch.randint(0, 40, (x.size(0),), generator=g).to(dev)
+        so_c = SelectOutput(cluster_index=cl, num_nodes=x.size(0), num_supernodes=40)
+        assert gp.reduce_connect(x, ei, ew, so_c, batch) is None
+        # (d) one graph of 65 nodes in the batch: never offered
+        x2, ei2, ew2, batch2, _ = _small_batch(20, 65, 65, 8, 4, dev)
+        so2 = pooler.selector(x=x2, batch=batch2)
+        assert pooler.reduce_connect(x2, ei2, ew2, so2, batch2) is None
+
+
+def test_sparse_pool_small_c3_sized_batch_and_empty_graphs(dev):
+    """2048 PROTEINS-shaped graphs (the bench's topk_batch workload) and a batch with graphs that own no edge and no
+    kept node: fused == staged, bit for bit; repeated calls reuse the epoch-tagged status buffer."""
+    from tgp.poolers import get_pooler
+    for num_graphs, lo, hi in ((2048, 20, 60), (700, 1, 3)):
+        x, ei, ew, batch, sizes = _small_batch(num_graphs, lo, hi, 32, 9, dev, deg=2 if hi <= 3 else 4)
+        for alias in ("topk", "graclus"):
+            pooler = (get_pooler("topk", in_channels=32, ratio=0.5) if alias == "topk" else get_pooler("graclus")).to(dev).eval()
+            with torch.no_grad():
+                so = (pooler.selector(x=x, batch=batch) if alias == "topk" else
+                      pooler.selector(edge_index=ei, edge_weight=ew, num_nodes=x.size(0), batch=batch))
+                staged = _staged_reduce_connect(pooler, x, ei, ew, so, batch)
+                for _ in range(3):
+                    fused = pooler.reduce_connect(x, ei, ew, so, batch)
+                    assert fused is not None
+                    for a, b in zip(fused, staged):
+                        assert _same(a, b)

@@ -1,0 +1,567 @@
+// r4: sparse Reduce + Connect of a BATCH OF SMALL GRAPHS in ONE launch -- the sparse twin of dense_pool_small_kernel.
+//
+// The staged operators (sparse_reduce.hip, sparse_connect.hip, coalesce_rows.hip) are built for one large graph:
+// device-wide bitmaps, sorts and scans, six to ten launches per Reduce + Connect.  On 2048 PROTEINS-sized graphs
+// (80 k nodes, 300 k edges) each of those launches moves a few megabytes and the call is bound by their dispatch
+// latency (0.093 ms, 0.026 of the HBM roofline).  Here ONE WAVE owns one graph of a sorted batch (<= 64 nodes):
+//   * its node range comes from the batch offsets; its edge range and its slice of the (node-sorted) assignment from
+//     64-ary searches over the row / node_index arrays (three or four dependent probes instead of a log2 chain);
+//   * A1 + A2 (reduce/base_reduce.py:14-53,141-155): the graph's pooled rows are gathered, scaled, summed and
+//     written by the wave (products rounded before the add, members in ascending order: the bits of
+//     reduce_sparse_*_kernel and of the reference's sequential scatter);
+//   * A5 + A6 (connect/base_conn.py:79-82, utils/ops.py:370-380; TopK): membership = a 64-bit mask in registers, new id
+//     = first assignment of the graph + popcount below; survivors keep input order;
+//   * A4 + A6 (connect/base_conn.py:83-89; Graclus-style clusterings): the graph's edges are staged in LDS, LANE =
+//     supernode ROW walks the edge ranges of its member nodes in input order and keeps a sorted, duplicate-merged
+//     list of (column, weight) in its own LDS slots (rows of a small graph hold a handful of entries: insertion beats a
+//     sorting network), filters fused; rows leave in (row, column) order = PyG coalesce's;
+//   * the only cross-wave quantity, the number of surviving edges in front of a graph, comes from a workgroup sum and a
+//     decoupled look-back over the workgroups (WAVES graphs each: 128 tiles for 2048 graphs, two hops).  Survivors are
+//     written ONCE, in their final int64 form at their final offsets of capacity-E buffers; the host reads the total
+//     (the one sync the reference's own .item() pays) and narrows the buffers: no fill launch.
+// Every structural assumption is CHECKED on the device (graph sizes, ranges that tile the arrays, edges that stay
+// inside their graph, ascending assignment / rows, cluster ids contiguous per graph): a violation raises a status word
+// and the caller takes the staged operators, so no result depends on an unchecked property of the input.
+//
+// The look-back state lives in a caller-owned status buffer whose words carry the call's EPOCH: stale words of
+// earlier calls read as "not ready", so the buffer is never cleared (no memset launch in front of the kernel).
+#include "primitives.h"
+
+namespace tgp {
+
+constexpr int SPS_EPOCH_SHIFT = 34;
+constexpr unsigned long long SPS_AGG = 1ull << 32, SPS_PRE = 2ull << 32;
+constexpr int SPS_CAP = 512;  // cluster mode: edges of one graph staged in LDS
+
+struct SpsArgs {
+  const float* x;
+  int64_t N, F, x_stride;
+  const int64_t* gptr;
+  int64_t B;
+  const int64_t* row;
+  const int64_t* col;
+  const float* w;
+  int64_t E;
+  const int64_t* node_index;
+  const int64_t* cluster_index;
+  const float* weight;
+  int64_t nnz, K;
+  int reduce_op, flags;
+  float eps;
+  float* x_pool;
+  int64_t* batch_pool;
+  int64_t* out_row;
+  int64_t* out_col;
+  float* out_w;
+  unsigned long long* status;  // [0] refusal word, [1] total, [2 + tile] look-back state; all epoch-tagged
+  unsigned long long tag;      // epoch << SPS_EPOCH_SHIFT
+};
+
+__device__ __forceinline__ unsigned long long sps_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sps_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool sps_current(unsigned long long word, unsigned long long tag) {
+  return (word >> SPS_EPOCH_SHIFT) == (tag >> SPS_EPOCH_SHIFT);
+}
+
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ int64_t wave_min64(int64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int64_t t = __shfl_xor(v, o, WAVE);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int64_t wave_max64(int64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int64_t t = __shfl_xor(v, o, WAVE);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+// lower_bound(arr, k0) and lower_bound(arr, k1) by ONE wave: 64 probes per round and key (the two searches' loads are
+// in flight together).  On an array that is not ascending the result is still a deterministic function of (arr, key),
+// which is all the tiling check of the caller needs.
+__device__ __forceinline__ void wave_lower_bound2(const int64_t* __restrict__ arr, int64_t n, int64_t k0, int64_t k1,
+                                                  int64_t& r0, int64_t& r1) {
+  const int lane = lane_id();
+  int64_t lo0 = 0, hi0 = n, lo1 = 0, hi1 = n;
+  while (lo0 < hi0 || lo1 < hi1) {
+    const int64_t s0 = (hi0 - lo0 + 63) >> 6, s1 = (hi1 - lo1 + 63) >> 6;
+    const int64_t i0 = lo0 + lane * s0, i1 = lo1 + lane * s1;
+    const bool v0 = i0 < hi0, v1 = i1 < hi1;
+    const int64_t a0 = arr[v0 ? i0 : (n - 1)], a1 = arr[v1 ? i1 : (n - 1)];  // unconditional, clamped (n > 0 here)
+    const int c0 = __popcll(__ballot(v0 && a0 < k0)), c1 = __popcll(__ballot(v1 && a1 < k1));
+    if (lo0 < hi0) {
+      if (c0 == 0) {
+        hi0 = lo0;
+      } else {
+        const int64_t last = lo0 + static_cast<int64_t>(c0 - 1) * s0;
+        lo0 = last + 1;
+        hi0 = last + s0 < hi0 ? last + s0 : hi0;
+      }
+    }
+    if (lo1 < hi1) {
+      if (c1 == 0) {
+        hi1 = lo1;
+      } else {
+        const int64_t last = lo1 + static_cast<int64_t>(c1 - 1) * s1;
+        lo1 = last + 1;
+        hi1 = last + s1 < hi1 ? last + s1 : hi1;
+      }
+    }
+  }
+  r0 = lo0;
+  r1 = lo1;
+}
+
+// Exclusive prefix of `tile` over the tiles' survivor counts; every lane of ONE wave calls it.  false: the call was
+// refused meanwhile (a predecessor may never publish) or a spin bound was hit (refusal raised here).
+__device__ __forceinline__ bool sps_lookback(unsigned long long* status, int tile, unsigned long long tag,
+                                             uint32_t* excl_out) {
+  const int lane = lane_id();
+  uint32_t excl = 0;
+  int j = tile - 1;
+  while (j >= 0) {
+    const int idx = j - lane;
+    unsigned long long st = idx >= 0 ? sps_load(status + 2 + idx) : (tag | SPS_PRE);
+    int spins = 0;
+    while (__any(!sps_current(st, tag) || ((st >> 32) & 3ull) == 0)) {
+      ++spins;
+      if ((spins & 15) == 0) {
+        unsigned long long b = 0;
+        if (lane == 0) b = sps_load(status);
+        b = __shfl(b, 0, WAVE);
+        if (sps_current(b, tag) && (b & 0xFFFFFFFFull) != 0) return false;
+        if (spins > (1 << 20)) {
+          if (lane == 0) sps_store(status, tag | 16ull);
+          return false;
+        }
+      }
+      if (spins > 4) __builtin_amdgcn_s_sleep(2);
+      if (idx >= 0 && (!sps_current(st, tag) || ((st >> 32) & 3ull) == 0)) st = sps_load(status + 2 + idx);
+    }
+    const unsigned long long pre = __ballot(((st >> 32) & 3ull) == 2);
+    const int first = pre ? __builtin_ctzll(pre) : 64;  // nearest predecessor that already knows its prefix
+    excl += wave_sum32(lane <= first ? static_cast<uint32_t>(st) : 0u);
+    if (pre) break;
+    j -= 64;
+  }
+  *excl_out = excl;
+  return true;
+}
+
+__device__ __forceinline__ float sps_reduce(float acc, float v, int op) {
+  switch (op) {
+    case TGP_MIN: return fminf(acc, v);
+    case TGP_MAX: return fmaxf(acc, v);
+    case TGP_MUL: return __fmul_rn(acc, v);
+    default: return __fadd_rn(acc, v);
+  }
+}
+
+// per-wave LDS of the cluster mode
+struct SpsClusterLds {
+  unsigned long long mem[64];  // members (local node bits) of local cluster r
+  uint32_t deg[64];            // edges per local node, then (first staged edge << 16 | edges)
+  uint8_t cl[64];              // local cluster of local node j
+  uint8_t ecol[SPS_CAP];       // staged edges: local column
+  float ew[SPS_CAP];           // staged edges: weight
+  uint8_t lkey[SPS_CAP];       // row lists: local cluster column, ascending inside a row's slots
+  uint16_t lcnt[SPS_CAP];      // row lists: merged entries (mean)
+  float lval[SPS_CAP];         // row lists: merged weight
+};
+
+template <int MODE, int WAVES>  // MODE 0: kept-node selection (TopK, NDP-shaped); 1: every node in one cluster (Graclus)
+__global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p) {
+  __shared__ uint32_t s_cnt[WAVES];
+  __shared__ uint32_t s_base;
+  __shared__ int s_ok;
+  __shared__ SpsClusterLds s_cl_all[MODE == 1 ? WAVES : 1];
+  const int lane = lane_id(), wv = wave_id();
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * WAVES + wv;
+  const bool live = g < p.B;
+  int64_t n0 = 0, n1 = 0;
+  if (live) {
+    n0 = p.gptr[g];
+    n1 = p.gptr[g + 1];
+  }
+  bool bad = false;
+  if (n1 < n0 || n1 - n0 > 64 || n0 < 0 || n1 > p.N) {
+    bad = true;
+    n0 = n1 = 0;
+  }
+  if (live && ((g == 0 && n0 != 0) || (g == p.B - 1 && n1 != p.N))) bad = true;
+  int64_t e0 = 0, e1 = 0;
+  if (live && p.E > 0) wave_lower_bound2(p.row, p.E, n0, n1, e0, e1);
+  if (live && (e1 < e0 || (g == 0 && e0 != 0) || (g == p.B - 1 && e1 != p.E))) bad = true;
+  const bool has_w = p.w != nullptr;
+  const bool rsl = (p.flags & TGP_REMOVE_SELF_LOOPS) != 0, epsf = has_w && (p.flags & TGP_EPS_FILTER) != 0;
+  const bool vec = (p.F & 3) == 0 && (p.x_stride & 3) == 0;
+  const int F4 = static_cast<int>(p.F >> 2);
+  uint32_t cnt = 0;
+
+  // ---------------------------------------------------------------------------------------------- MODE 0 state
+  unsigned long long M = 0;   // membership of the graph's nodes
+  int64_t a0 = 0;             // first assignment of the graph = new id of its first kept node
+  // ---------------------------------------------------------------------------------------------- MODE 1 state
+  int64_t cmin = 0;
+  int nrow_keep = 0, row_lo = 0;  // lane = supernode row: survivors, first LDS slot
+  uint32_t row_base = 0;          // survivors of the wave's earlier rows
+  SpsClusterLds& L = s_cl_all[MODE == 1 ? wv : 0];
+
+  if constexpr (MODE == 0) {
+    int64_t a1 = 0;
+    if (live && p.nnz > 0) wave_lower_bound2(p.node_index, p.nnz, n0, n1, a0, a1);
+    if (live && (a1 < a0 || a1 - a0 > 64 || (g == 0 && a0 != 0) || (g == p.B - 1 && a1 != p.nnz))) bad = true;
+    const int ka = bad ? 0 : static_cast<int>(a1 - a0);
+    const bool act = lane < ka;
+    const int64_t v = act ? p.node_index[a0 + lane] : n0;
+    const int64_t ci = act ? p.cluster_index[a0 + lane] : a0;
+    const float wa = (act && p.weight) ? p.weight[a0 + lane] : 1.0f;
+    const int64_t vprev = __shfl_up(v, 1, WAVE);
+    const bool okv = !act || (v >= n0 && v < n1 && (lane == 0 || vprev < v));
+    const int64_t cl = ci - a0;  // one supernode per kept node, numbered graph-major: a permutation of the slice
+    const bool okc = !act || (cl >= 0 && cl < ka);
+    if (__any(!okv || !okc)) bad = true;
+    M = wave_or64((act && okv) ? 1ull << (v - n0) : 0ull);
+    const unsigned long long CM = wave_or64((act && okc) ? 1ull << cl : 0ull);
+    if (__popcll(CM) != ka) bad = true;
+    if (!bad && ka > 0) {
+      // A1: x_pool[cluster] = 0 + weight * x[node] (one member per supernode); A2: batch_pool[cluster] = graph id
+      if (p.batch_pool && act) p.batch_pool[ci] = g;
+      if (vec) {
+        const int total = ka * F4;
+        for (int base = 0; base < total; base += WAVE) {
+          const int idx = base + lane;
+          const bool on = idx < total;
+          const int a = on ? idx / F4 : 0;
+          const int f = (idx - a * F4) * 4;
+          const int64_t vv = __shfl(v, a, WAVE), cc = __shfl(ci, a, WAVE);
+          const float ww = __shfl(wa, a, WAVE);
+          if (on) {
+            const float4 t = *reinterpret_cast<const float4*>(p.x + vv * p.x_stride + f);
+            float4 o;
+            o.x = __fadd_rn(0.f, __fmul_rn(t.x, ww));
+            o.y = __fadd_rn(0.f, __fmul_rn(t.y, ww));
+            o.z = __fadd_rn(0.f, __fmul_rn(t.z, ww));
+            o.w = __fadd_rn(0.f, __fmul_rn(t.w, ww));
+            *reinterpret_cast<float4*>(p.x_pool + cc * p.F + f) = o;
+          }
+        }
+      } else {
+        const int Fi = static_cast<int>(p.F);
+        const int total = ka * Fi;
+        for (int base = 0; base < total; base += WAVE) {
+          const int idx = base + lane;
+          const bool on = idx < total;
+          const int a = on ? idx / Fi : 0;
+          const int f = idx - a * Fi;
+          const int64_t vv = __shfl(v, a, WAVE), cc = __shfl(ci, a, WAVE);
+          const float ww = __shfl(wa, a, WAVE);
+          if (on) p.x_pool[cc * p.F + f] = __fadd_rn(0.f, __fmul_rn(p.x[vv * p.x_stride + f], ww));
+        }
+      }
+    }
+    // A5 + A6, pass 1: survivors of the graph
+    if (!bad) {
+      for (int64_t e = e0; e < e1; e += WAVE) {
+        const int64_t ee = e + lane;
+        const bool on = ee < e1;
+        const int64_t r = on ? p.row[ee] : n0, c = on ? p.col[ee] : n0;
+        const float wt = (on && has_w) ? p.w[ee] : 1.0f;
+        const bool inb = r >= n0 && r < n1 && c >= n0 && c < n1;
+        if (__any(on && !inb)) bad = true;
+        bool keep = on && inb && (((M >> ((r - n0) & 63)) & (M >> ((c - n0) & 63)) & 1ull) != 0);
+        if (rsl && r == c) keep = false;
+        if (epsf && !(fabsf(wt) > p.eps)) keep = false;
+        cnt += __popcll(__ballot(keep));
+      }
+      if (bad) cnt = 0;
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------ MODE 1
+    const int n = static_cast<int>(n1 - n0);
+    const bool nact = lane < n;
+    const int64_t ni = nact ? p.node_index[n0 + lane] : n0 + lane;
+    const int64_t cj = nact ? p.cluster_index[n0 + lane] : 0;
+    const float wj = (nact && p.weight) ? p.weight[n0 + lane] : 1.0f;
+    if (__any(nact && ni != n0 + lane)) bad = true;  // every node assigned, in node order (base_select.py:58)
+    cmin = wave_min64(nact ? cj : INT64_MAX);
+    const int64_t cmax = wave_max64(nact ? cj : -1);
+    int kc = 0;
+    if (n > 0) {
+      if (cmin < 0 || cmax >= p.K || cmax - cmin + 1 > 64) bad = true;
+      else kc = static_cast<int>(cmax - cmin + 1);
+      // cluster ids are contiguous per graph and ascending over the graphs (what a per-graph selector's unique()
+      // relabelling gives): no cluster spans two graphs and the graph-major output is PyG coalesce's global order
+      int64_t want = 0;
+      int64_t gp = g - 1;
+      while (gp >= 0 && p.gptr[gp + 1] == p.gptr[gp]) --gp;
+      if (gp >= 0) {
+        const int64_t q0 = p.gptr[gp], q1 = p.gptr[gp + 1];
+        const bool qa = q0 + lane < q1 && lane < 64;
+        const int64_t pc = qa ? p.cluster_index[q0 + lane] : -1;
+        want = wave_max64(pc) + 1;
+      }
+      if (cmin != want) bad = true;
+      if (n1 == p.N && cmax != p.K - 1) bad = true;
+    } else {
+      cmin = 0;
+    }
+    if (bad) kc = 0;
+    const int nn = bad ? 0 : n;
+    // members of every local cluster
+    L.mem[lane] = 0ull;
+    L.deg[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < nn) {
+      atomicOr(&L.mem[cj - cmin], 1ull << lane);
+      L.cl[lane] = static_cast<uint8_t>(cj - cmin);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long mymem = lane < kc ? L.mem[lane] : 0ull;
+    if (__any(lane < kc && mymem == 0ull)) bad = true;  // an id without a node would keep reduce_batch's arange value
+    if (!bad && kc > 0) {
+      // A2 + A1
+      if (p.batch_pool && lane < kc) p.batch_pool[cmin + lane] = g;
+      const int per = vec ? F4 : static_cast<int>(p.F);
+      const int total = kc * per;
+      for (int base = 0; base < total; base += WAVE) {
+        const int idx = base + lane;
+        const bool on = idx < total;
+        const int rr = on ? idx / per : 0;
+        const int f = (idx - rr * per) * (vec ? 4 : 1);
+        unsigned long long mask = on ? L.mem[rr] : 0ull;
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        while (__any(mask != 0ull)) {
+          const int j = mask ? __builtin_ctzll(mask) : 0;
+          const float ww = __shfl(wj, j, WAVE);
+          if (mask) {
+            mask &= mask - 1;
+            const float* src = p.x + (n0 + j) * p.x_stride + f;
+            if (vec) {
+              const float4 t = *reinterpret_cast<const float4*>(src);
+              acc.x = __fadd_rn(acc.x, __fmul_rn(t.x, ww));
+              acc.y = __fadd_rn(acc.y, __fmul_rn(t.y, ww));
+              acc.z = __fadd_rn(acc.z, __fmul_rn(t.z, ww));
+              acc.w = __fadd_rn(acc.w, __fmul_rn(t.w, ww));
+            } else {
+              acc.x = __fadd_rn(acc.x, __fmul_rn(*src, ww));
+            }
+          }
+        }
+        if (on) {
+          float* dst = p.x_pool + (cmin + rr) * p.F + f;
+          if (vec) *reinterpret_cast<float4*>(dst) = acc;
+          else *dst = acc.x;
+        }
+      }
+    }
+    // A4: stage the graph's edges (local column, weight) in LDS, count per local row node
+    int ne = static_cast<int>(e1 - e0);
+    if (bad || e1 - e0 > SPS_CAP) {
+      if (e1 - e0 > SPS_CAP) bad = true;
+      ne = 0;
+    }
+    int64_t carry = n0;
+    for (int base = 0; base < ne; base += WAVE) {
+      const int t = base + lane;
+      const bool on = t < ne;
+      const int64_t r = on ? p.row[e0 + t] : n1, c = on ? p.col[e0 + t] : n0;
+      const float wt = (on && has_w) ? p.w[e0 + t] : 1.0f;
+      const bool inb = !on || (r >= n0 && r < n1 && c >= n0 && c < n1);
+      int64_t rp = __shfl_up(r, 1, WAVE);
+      if (lane == 0) rp = carry;
+      if (__any(!inb || (on && r < rp))) bad = true;  // rows ascending inside the graph: a node's edges are one range
+      carry = __shfl(r, WAVE - 1, WAVE);
+      if (on && inb) {
+        atomicAdd(&L.deg[r - n0], 1u);
+        L.ecol[t] = static_cast<uint8_t>(c - n0);
+        L.ew[t] = wt;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (bad) ne = 0;
+    {
+      const uint32_t d = ne > 0 ? L.deg[lane] : 0u;
+      const uint32_t ps = wave_incl_scan(d) - d;
+      __builtin_amdgcn_wave_barrier();
+      L.deg[lane] = (ps << 16) | d;
+      __builtin_amdgcn_wave_barrier();
+    }
+    // lane = supernode row: raw entries of the row = edges of its members; LDS slots by exclusive scan
+    uint32_t raw = 0;
+    if (ne > 0 && lane < kc) {
+      unsigned long long mask = mymem;
+      while (mask) {
+        const int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        raw += L.deg[j] & 0xFFFFu;
+      }
+    }
+    row_lo = static_cast<int>(wave_incl_scan(raw) - raw);
+    int len = 0;
+    if (raw > 0) {
+      unsigned long long mask = mymem;
+      while (mask) {
+        const int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const uint32_t pd = L.deg[j];
+        const int t0 = static_cast<int>(pd >> 16), t1 = t0 + static_cast<int>(pd & 0xFFFFu);
+        for (int t = t0; t < t1; ++t) {  // input order: ascending member, then position
+          const int cc = L.cl[L.ecol[t]];
+          if (rsl && cc == lane) continue;  // (self loops are their own key: dropping them first changes nothing else)
+          const float wt = L.ew[t];
+          int q = 0;
+          while (q < len && L.lkey[row_lo + q] < cc) ++q;
+          if (q < len && L.lkey[row_lo + q] == cc) {
+            if (has_w) L.lval[row_lo + q] = sps_reduce(L.lval[row_lo + q], wt, p.reduce_op);
+            L.lcnt[row_lo + q] = static_cast<uint16_t>(L.lcnt[row_lo + q] + 1);
+          } else {
+            for (int u = len; u > q; --u) {
+              L.lkey[row_lo + u] = L.lkey[row_lo + u - 1];
+              L.lval[row_lo + u] = L.lval[row_lo + u - 1];
+              L.lcnt[row_lo + u] = L.lcnt[row_lo + u - 1];
+            }
+            L.lkey[row_lo + q] = static_cast<uint8_t>(cc);
+            L.lval[row_lo + q] = wt;
+            L.lcnt[row_lo + q] = 1;
+            ++len;
+          }
+        }
+      }
+      // mean, |w| > eps; survivors compacted at the head of the row's slots
+      int m = 0;
+      for (int q = 0; q < len; ++q) {
+        float val = L.lval[row_lo + q];
+        if (has_w && p.reduce_op == TGP_MEAN) val = val / static_cast<float>(L.lcnt[row_lo + q]);
+        if (epsf && !(fabsf(val) > p.eps)) continue;
+        L.lkey[row_lo + m] = L.lkey[row_lo + q];
+        L.lval[row_lo + m] = val;
+        ++m;
+      }
+      nrow_keep = m;
+    }
+    const uint32_t incl = wave_incl_scan(static_cast<uint32_t>(nrow_keep));
+    row_base = incl - static_cast<uint32_t>(nrow_keep);
+    cnt = __shfl(incl, WAVE - 1, WAVE);
+    if (bad) cnt = 0;
+  }
+
+  // ------------------------------------------------------------------------------ survivors in front of this graph
+  if (bad && lane == 0) sps_store(p.status, p.tag | 1ull);
+  if (lane == 0) s_cnt[wv] = cnt;
+  __syncthreads();
+  if (wv == 0) {
+    const uint32_t tot = wave_sum32(lane < WAVES ? s_cnt[lane] : 0u);
+    const int tile = blockIdx.x;
+    if (lane == 0) sps_store(p.status + 2 + tile, p.tag | (tile == 0 ? SPS_PRE : SPS_AGG) | tot);
+    uint32_t excl = 0;
+    bool ok = true;
+    if (tile > 0) {
+      ok = sps_lookback(p.status, tile, p.tag, &excl);
+      if (ok && lane == 0) sps_store(p.status + 2 + tile, p.tag | SPS_PRE | static_cast<unsigned long long>(excl + tot));
+    }
+    if (lane == 0) {
+      s_base = excl;
+      s_ok = ok ? 1 : 0;
+      if (ok && tile == static_cast<int>(gridDim.x) - 1)
+        sps_store(p.status + 1, p.tag | static_cast<unsigned long long>(excl + tot));
+    }
+  }
+  __syncthreads();
+  if (!s_ok || bad) return;
+  uint32_t base = s_base;
+  for (int w2 = 0; w2 < wv; ++w2) base += s_cnt[w2];
+
+  if constexpr (MODE == 0) {
+    // pass 2: the same predicate, survivors written once at their final offsets (input order kept)
+    uint32_t pos = base;
+    for (int64_t e = e0; e < e1; e += WAVE) {
+      const int64_t ee = e + lane;
+      const bool on = ee < e1;
+      const int64_t r = on ? p.row[ee] : n0, c = on ? p.col[ee] : n0;
+      const float wt = (on && has_w) ? p.w[ee] : 1.0f;
+      const int lr = static_cast<int>(r - n0) & 63, lc = static_cast<int>(c - n0) & 63;
+      bool keep = on && (((M >> lr) & (M >> lc) & 1ull) != 0);
+      if (rsl && r == c) keep = false;
+      if (epsf && !(fabsf(wt) > p.eps)) keep = false;
+      const unsigned long long km = __ballot(keep);
+      if (keep) {
+        const uint32_t o = pos + __popcll(km & lanemask_lt());
+        p.out_row[o] = a0 + __popcll(M & ((1ull << lr) - 1ull));
+        p.out_col[o] = a0 + __popcll(M & ((1ull << lc) - 1ull));
+        if (has_w) p.out_w[o] = wt;
+      }
+      pos += __popcll(km);
+    }
+  } else {
+    const uint32_t o0 = base + row_base;
+    for (int q = 0; q < nrow_keep; ++q) {
+      p.out_row[o0 + q] = cmin + lane;
+      p.out_col[o0 + q] = cmin + L.lkey[row_lo + q];
+      if (has_w) p.out_w[o0 + q] = L.lval[row_lo + q];
+    }
+  }
+}
+
+}  // namespace tgp
+
+using namespace tgp;
+
+constexpr int SPS_WAVES_TOPK = 16, SPS_WAVES_CLUSTER = 8;
+
+/* graphs of at most this many nodes are pooled by one wave */
+extern "C" int tgp_sparse_pool_small_max_graph_nodes(void) { return 64; }
+
+extern "C" int64_t tgp_sparse_pool_small_status_words(int64_t num_graphs, int mode) {
+  const int waves = mode == 0 ? SPS_WAVES_TOPK : SPS_WAVES_CLUSTER;
+  return 2 + (num_graphs + waves - 1) / waves;
+}
+
+extern "C" int tgp_sparse_pool_small_f32(const float* x, int64_t N, int64_t F, int64_t x_stride, const int64_t* graph_ptr,
+                                         int64_t B, const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                         const int64_t* node_index, const int64_t* cluster_index, const float* weight,
+                                         int64_t nnz, int64_t K, int mode, int reduce_op, int flags, float eps,
+                                         float* x_pool, int64_t* batch_pool, int64_t* out_row, int64_t* out_col,
+                                         float* out_w, uint64_t* status, int64_t status_words, uint32_t epoch,
+                                         void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(x && graph_ptr && node_index && cluster_index && x_pool && status && N > 0 && F > 0 && B > 0 && E >= 0 &&
+                  nnz >= 0 && K >= 0 && x_stride >= F && (mode == 0 || mode == 1),
+              TGP_ERR_INVALID, "tgp_sparse_pool_small_f32: bad argument");
+  TGP_REQUIRE(E == 0 || (row && col && out_row && out_col && (!w || out_w)), TGP_ERR_INVALID,
+              "tgp_sparse_pool_small_f32: null edge pointer");
+  TGP_REQUIRE(reduce_op >= TGP_SUM && reduce_op <= TGP_MUL, TGP_ERR_INVALID, "tgp_sparse_pool_small_f32: reduce_op");
+  TGP_REQUIRE(E < (1ll << 31) && N < (1ll << 31) && B < (1ll << 24) && epoch != 0 && epoch < (1u << 30), TGP_ERR_RANGE,
+              "tgp_sparse_pool_small_f32: size or epoch out of range");
+  TGP_REQUIRE(status_words >= tgp_sparse_pool_small_status_words(B, mode), TGP_ERR_WORKSPACE,
+              "tgp_sparse_pool_small_f32: status buffer too small");
+  SpsArgs a{x, N, F, x_stride, graph_ptr, B, row, col, w, E, node_index, cluster_index, weight, nnz, K, reduce_op, flags,
+            eps, x_pool, batch_pool, out_row, out_col, out_w, reinterpret_cast<unsigned long long*>(status),
+            static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT};
+  if (mode == 0) {
+    hipLaunchKernelGGL((sparse_pool_small_kernel<0, SPS_WAVES_TOPK>), dim3(cdiv(B, SPS_WAVES_TOPK)),
+                       dim3(SPS_WAVES_TOPK * 64), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((sparse_pool_small_kernel<1, SPS_WAVES_CLUSTER>), dim3(cdiv(B, SPS_WAVES_CLUSTER)),
+                       dim3(SPS_WAVES_CLUSTER * 64), 0, stream, a);
+  }
+  return check_launch("tgp_sparse_pool_small_f32");
+}

@@ -109,8 +109,100 @@ def reduce_batch_sparse(batch: Tensor, node_index: Tensor, cluster_index: Tensor
 
 # ------------------------------------------------------------------------- A4 / A5 / A6
 def _edge_rows(edge_index: Tensor) -> Tuple[Tensor, Tensor]:
-    ei = N.i64c(edge_index)
+    """The two rows of a [2, E] list as contiguous int64 vectors.  The C ABI takes them as two pointers, so a list whose
+    ROWS are contiguous (e.g. the narrowed capacity buffers of ``sparse_pool_small``) needs no copy."""
+    ei = edge_index
+    if ei.dtype != torch.int64:
+        ei = ei.to(torch.int64)
+    if not (ei.dim() == 2 and ei.size(0) == 2 and (ei.stride(1) == 1 or ei.size(1) <= 1)):
+        ei = ei.contiguous()
     return ei[0], ei[1]
+
+
+# ------------------------------------------------------------------------- A1 + A2 + A4/A5 + A6, batches of small graphs
+_SPS_STATUS: dict = {}  # (device index, stream handle) -> [status words (never cleared: epoch-tagged), last epoch]
+_SPS_DECLINED: dict = {}
+SPS_COMPACT_BYTES = 64 << 20  # capacity buffers above this are replaced by exact copies when mostly empty
+
+
+def _sps_status(dev: torch.device, stream: int, words: int):
+    key = (dev.index, stream)
+    ent = _SPS_STATUS.get(key)
+    if ent is None or ent[0].numel() < words:
+        ent = [torch.zeros(max(int(words), 4096), dtype=torch.int64, device=dev), 0]
+        _SPS_STATUS[key] = ent
+    ent[1] += 1
+    if ent[1] >= (1 << 29):  # epochs of a buffer never repeat: start over on a cleared buffer
+        ent[0].zero_()
+        ent[1] = 1
+    return ent[0], ent[1]
+
+
+def sparse_pool_small_declined(edge_index: Tensor) -> bool:
+    """Did the one-launch kernel refuse this very edge list before (unsorted rows, an edge between two graphs, ...)?
+    Remembered per tensor object + version, like the row-order memo, so that a refusal costs one launch once."""
+    hit = _SPS_DECLINED.get(id(edge_index))
+    return hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version
+
+
+def _sps_remember_declined(edge_index: Tensor) -> None:
+    import weakref
+    if len(_SPS_DECLINED) >= 16:
+        for key in [k for k, v in _SPS_DECLINED.items() if v[0]() is None]:
+            del _SPS_DECLINED[key]
+        while len(_SPS_DECLINED) >= 16:
+            del _SPS_DECLINED[next(iter(_SPS_DECLINED))]
+    _SPS_DECLINED[id(edge_index)] = (weakref.ref(edge_index), edge_index._version)
+
+
+def sparse_pool_small_max_graph_nodes() -> int:
+    return int(N.lib().tgp_sparse_pool_small_max_graph_nodes())
+
+
+def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor],
+                      node_index: Tensor, cluster_index: Tensor, weight: Optional[Tensor], num_supernodes: int,
+                      mode: int, reduce_op: str = "sum", remove_self_loops: bool = True, want_batch: bool = True):
+    """Sparse Reduce + Connect of a sorted batch of graphs of at most 64 nodes in ONE launch
+    (reduce/base_reduce.py:14-53,141-155; connect/base_conn.py:79-89; the filters of utils/ops.py:370-380):
+    ``(x_pool [K,F], batch_pool [K] or None, edge_index' [2,E'], edge_weight' [E'] or None)``, bit-identical to
+    ``reduce_sparse`` + ``reduce_batch_sparse`` + ``filter_edges`` (mode 0) / ``coalesce_edges`` (mode 1).  The pooled
+    edges are written once at their final offsets of capacity-E buffers, which are then narrowed: ``edge_index'`` is a
+    view whose two rows are contiguous.  None: a precondition checked on the device does not hold (the caller takes
+    the staged operators)."""
+    dev = N.require_device(x, graph_ptr, edge_index, edge_weight, node_index, cluster_index, weight)
+    if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
+        raise ValueError("sparse_pool_small expects float32 x [N, F] with unit feature stride")
+    row, col = _edge_rows(edge_index)
+    E = row.numel()
+    w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
+    ni, ci, gp = N.i64c(node_index), N.i64c(cluster_index), N.i64c(graph_ptr)
+    wt = None if weight is None else N.f32c(weight.reshape(-1))
+    n, F, K, B = x.size(0), x.size(1), int(num_supernodes), gp.numel() - 1
+    x_pool = torch.empty(K, F, dtype=torch.float32, device=dev)
+    batch_pool = torch.empty(K, dtype=torch.int64, device=dev) if want_batch else None
+    cap = torch.empty(2, max(E, 1), dtype=torch.int64, device=dev)
+    cap_w = None if w is None else torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+    L = N.lib()
+    st = N.stream_ptr(dev)
+    status, epoch = _sps_status(dev, st, L.tgp_sparse_pool_small_status_words(B, mode))
+    flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if w is not None else 0)
+    N.check(L.tgp_sparse_pool_small_f32(N.ptr(x), n, F, x.stride(0), N.ptr(gp), B, N.ptr(row) if E else None,
+                                        N.ptr(col) if E else None, N.ptr(w), E, N.ptr(ni), N.ptr(ci), N.ptr(wt),
+                                        ni.numel(), K, mode, N.REDUCE_OPS[reduce_op], flags, ops_eps(), N.ptr(x_pool),
+                                        N.ptr(batch_pool), N.ptr(cap[0]), N.ptr(cap[1]), N.ptr(cap_w), N.ptr(status),
+                                        status.numel(), epoch, st), "tgp_sparse_pool_small_f32")
+    refusal, total = status[:2].tolist()  # the call's one host sync
+    if (refusal >> 34) == epoch and (refusal & 0xFFFFFFFF):
+        _sps_remember_declined(edge_index)
+        return None
+    if (total >> 34) != epoch:
+        raise N.TgpNativeError("tgp_sparse_pool_small_f32 finished without publishing its edge count")
+    n_out = total & 0xFFFFFFFF
+    ei = cap[:, :n_out]
+    ew = None if cap_w is None else cap_w[:n_out]
+    if E * 16 > SPS_COMPACT_BYTES and 2 * n_out < E:
+        ei, ew = ei.contiguous(), None if ew is None else ew.clone()
+    return x_pool, batch_pool, ei, ew
 
 
 def _read_count(d_count: Tensor) -> int:

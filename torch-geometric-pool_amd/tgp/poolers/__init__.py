@@ -60,6 +60,12 @@ class TopkPooling(SRCPooling):
         if lifting:
             return self.lift(x_pool=x, so=so)
         so = self.select(x=x if attn is None else attn, batch=batch)
+        fused = self.reduce_connect(x, adj, edge_weight, so, batch)  # batches of small graphs, inference: ONE launch
+        if fused is not None:
+            x_pool, batch_pool, ei, ew = fused
+            if self.multiplier != 1:
+                x_pool = self.multiplier * x_pool
+            return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so)
         x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch)
         if self.multiplier != 1:
             x_pool = self.multiplier * x_pool
@@ -92,6 +98,10 @@ class GraclusPooling(BasePrecoarseningMixin, SRCPooling):
         if lifting:
             return self.lift(x_pool=x, so=so)
         so = self.select(edge_index=adj, edge_weight=edge_weight, num_nodes=x.size(0), batch=batch)
+        fused = self.reduce_connect(x, adj, edge_weight, so, batch)  # batches of small graphs, inference: ONE launch
+        if fused is not None:
+            x_pool, batch_pool, ei, ew = fused
+            return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so)
         x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch)
         ei, ew = self.connect(edge_index=adj, so=so, edge_weight=edge_weight, batch_pooled=batch_pool)
         return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so)

@@ -123,6 +123,59 @@ class SRCPooling(torch.nn.Module):
             self._pooled_edge_index, self._pooled_edge_weight = ei, ew
         return ei, ew
 
+    def reduce_connect(self, x: Tensor, edge_index, edge_weight: Optional[Tensor], so: SelectOutput,
+                       batch: Optional[Tensor]):
+        """Sparse Reduce + Connect of a batch of SMALL graphs as ONE native launch (fused A1 + A2 +
+        A4/A5 + A6; ``tgp_sparse_pool_small_f32``): ``(x_pool, batch_pool, edge_index_pool, edge_weight_pool)`` with the
+        values ``self.reduce`` + ``self.connect`` return, or None when the call is not that case -- host tensors, a
+        gradient is required (the operators below are the differentiable path), no or an unsorted batch vector, a graph
+        of more than 64 nodes, non-tensor connectivity, caching -- or when the kernel's on-device checks refuse the
+        input (an edge between two graphs, unsorted rows, ...).  The pooled ``edge_index`` is a [2, E'] view of a
+        capacity buffer: both rows contiguous, values and order those of the staged operators."""
+        from .connect import SparseConnect, _normalize_pooled_edges
+        from .reduce import BaseReduce
+        from . import kernels as K
+        from .utils.ops import batch_info
+        c = self.connector
+        if (self.cached or type(c) is not SparseConnect or type(self.reducer) is not BaseReduce or batch is None
+                or not isinstance(x, Tensor) or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32
+                or x.size(0) == 0 or x.size(1) == 0 or x.stride(1) != 1 or not isinstance(edge_index, Tensor)
+                or edge_index.is_sparse or edge_index.dim() != 2 or edge_index.size(0) != 2
+                or edge_index.dtype != torch.int64 or edge_index.size(1) == 0 or not so.is_sparse
+                or batch.dtype != torch.int64 or batch.numel() != x.size(0) or so.num_nodes != x.size(0)):
+            return None
+        ew = edge_weight
+        if ew is not None:
+            if ew.dtype != torch.float32 or ew.numel() != edge_index.size(1):
+                return None
+            ew = ew.reshape(-1)
+        weight = so.weight
+        if torch.is_grad_enabled() and (x.requires_grad or (ew is not None and ew.requires_grad)
+                                        or (weight is not None and weight.requires_grad)):
+            return None
+        info = batch_info(batch)
+        if (not info.is_sorted or info.num_graphs < 2 or info.max_nodes > K.sparse_pool_small_max_graph_nodes()
+                or K.sparse_pool_small_declined(edge_index)):
+            return None
+        ni, ci = so.node_index, so.cluster_index
+        nnz, n = ni.numel(), so.num_nodes
+        if nnz < n:
+            mode = 0  # sparse_connect's first branch: kept-node selection (base_conn.py:79-82)
+        elif ci.numel() == n:
+            mode = 1  # one-over-K clustering (base_conn.py:83-89)
+        else:
+            return None
+        if weight is not None and weight.dtype != torch.float32:
+            return None
+        out = K.sparse_pool_small(x, info.ptr, edge_index, ew, ni, ci, weight, so.num_supernodes, mode,
+                                  reduce_op=c.reduce_op, remove_self_loops=c.remove_self_loops)
+        if out is None:
+            return None
+        x_pool, batch_pool, ei, w_pool = out
+        ei, w_pool = _normalize_pooled_edges(ei, w_pool, so.num_supernodes, c.degree_norm, c.edge_weight_norm,
+                                             batch_pool)
+        return x_pool, batch_pool, ei, w_pool
+
     def preprocessing(self, x: Tensor, edge_index, **kwargs):
         return x, edge_index, None
 
