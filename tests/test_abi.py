@@ -130,6 +130,8 @@ def test_ctypes_signatures_match_the_header_parameter_by_parameter():
             return ctypes.c_float
         if p.startswith("uint64_t"):
             return ctypes.c_uint64
+        if p.startswith("uint32_t"):
+            return ctypes.c_uint32
         if p.startswith("int") or p.startswith("unsigned"):
             return ctypes.c_int
         raise AssertionError(f"unrecognised parameter '{p}'")
