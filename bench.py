@@ -516,17 +516,21 @@ class TopkBatch(Workload):
     payloads, then node-id / graph-id offsets: the merge rule of tgp/data/collate.py:144-153)."""
     shards = True
 
-    def __init__(self, ctx, force_collective=False, unfused=False):
+    def __init__(self, ctx, force_collective=False, unfused=False, which="topk_batch"):
         from tgp.connect import SparseConnect
         from tgp.reduce import BaseReduce
-        from tgp.select import TopkSelect
+        from tgp.select import GraclusSelect, TopkSelect
         dev = ctx.dev
         torch.manual_seed(ctx.rank)
         self.f = 32
+        self.which = which
         self.x, self.ei, self.batch = sparse_batch(_proteins_sizes(ctx.rank), 4, self.f, dev, seed=ctx.rank)
         self.ew = torch.rand(self.ei.size(1), device=dev) + 0.5
         with torch.no_grad():
-            self.so = TopkSelect(in_channels=self.f, ratio=0.5).to(dev)(x=self.x, batch=self.batch)
+            if which == "topk_batch":
+                self.so = TopkSelect(in_channels=self.f, ratio=0.5).to(dev)(x=self.x, batch=self.batch)
+            else:  # Graclus matching of every graph: many-to-one S, relabel + coalesce Connect
+                self.so = GraclusSelect()(self.ei, self.ew, num_nodes=self.x.size(0), batch=self.batch)
         self.red, self.conn = BaseReduce(), SparseConnect()
         from tgp.src import SRCPooling
         self.pool = SRCPooling(reducer=self.red, connector=self.conn)
@@ -536,11 +540,13 @@ class TopkBatch(Workload):
         self.force = force_collective
         self.nodes = self.x.size(0)
         self.num_graphs = 2048
-        self.name = ("TopK (ratio 0.5) Reduce + subgraph Connect on 2048 PROTEINS-shaped graphs (n~U[20,60], F=32), "
-                     "graph-sharded" + (", pooled outputs all-gathered over RCCL (variable-size)" if self.gather else ""))
+        self.name = (("TopK (ratio 0.5) Reduce + subgraph Connect" if which == "topk_batch" else
+                      "Graclus Reduce + coalesce Connect") +
+                     " on 2048 PROTEINS-shaped graphs (n~U[20,60], F=32), graph-sharded"
+                     + (", pooled outputs all-gathered over RCCL (variable-size)" if self.gather else ""))
         self.extra = {"edges": int(self.ei.size(1)), "num_supernodes": int(self.so.num_supernodes),
                       "nodes_counted": "input nodes per step per GPU",
-                      "step": ("BaseReduce then SparseConnect (subgraph), operator by operator" if unfused else
+                      "step": ("BaseReduce then SparseConnect, operator by operator" if unfused else
                                "fused Reduce + Connect as the sparse poolers' forward calls it on a batch of small "
                                "graphs: SRCPooling.reduce_connect (one launch + the count read-back)")
                               + (" + all_gather_sparse" if self.gather else "")}
@@ -578,18 +584,23 @@ class TopkBatch(Workload):
             bp = O.reduce_batch_sparse(batch, ni, ci, k)
             O.sparse_connect(ei, ew, ni, ci, n, k, batch_pooled=bp)
 
-        return one_pass, n, "the whole measured batch (2048 graphs): Reduce + subgraph Connect", 3.0
+        return one_pass, n, "the whole measured batch (2048 graphs): Reduce + Connect", 3.0
 
     def rooflines(self, dev):
         xp, ei, ew, bp = self.compute()
         E, E2, k = self.ei.size(1), ei.size(1), xp.size(0)
-        alg = (k * (4.0 * self.f + 8 + 4 + 4) + k * 4.0 * self.f          # A1 one-to-one
-               + E * 20.0 + self.nodes + k * 8.0 + E2 * 20.0)              # A5 + A6
+        if self.which == "topk_batch":
+            alg = (k * (4.0 * self.f + 8 + 4 + 4) + k * 4.0 * self.f          # A1 one-to-one
+                   + E * 20.0 + self.nodes + k * 8.0 + E2 * 20.0)              # A5 + A6
+        else:
+            alg = (self.nodes * (4.0 * self.f + 8 + 8 + 4) + k * 4.0 * self.f  # A1
+                   + E * 20.0 + self.nodes * 8.0 + E2 * 20.0)                   # A4 + A6
         ms_c = event_time_ms(self.compute, 50, dev)
-        r = roof_hbm("tgp::sparse_pool_small_kernel<0> (Reduce + subgraph Connect: one launch + the count read-back)"
+        mode = 0 if self.which == "topk_batch" else 1
+        r = roof_hbm(f"tgp::sparse_pool_small_kernel<{mode}> (Reduce + Connect: one launch + the count read-back)"
                      if not self.unfused else
-                     "Reduce + subgraph Connect (all kernels of both calls + the Connect's host read-back)", alg, ms_c,
-                     "sparse_pool_small:topk_batch")
+                     "Reduce + Connect (all kernels of both calls + the Connect's host read-back)", alg, ms_c,
+                     f"sparse_pool_small:{self.which}")
         r["compute_only_ms"] = round(ms_c, 5)
         if not self.unfused:
             r["staged_operators_ms"] = round(event_time_ms(self.staged, 50, dev), 5)
@@ -797,8 +808,9 @@ def make_workload(which, ctx, args):
         return PoolerForward(which, ctx)
     if which == "e2e_train_mincut_c3":
         return PoolerTrainStep(ctx)
-    if which == "topk_batch":
-        return TopkBatch(ctx, force_collective=os.environ.get("TGP_BENCH_FORCE_DIST") == "1", unfused=args.unfused)
+    if which in ("topk_batch", "graclus_batch"):
+        return TopkBatch(ctx, force_collective=os.environ.get("TGP_BENCH_FORCE_DIST") == "1", unfused=args.unfused,
+                         which=which)
     raise ValueError(which)
 
 
@@ -889,11 +901,11 @@ def cpu_baseline(one_pass, nodes, sample, budget_s=10.0, min_passes=2):
 
 
 # ------------------------------------------------------------------------------------------------ main
-ALL = ["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect", "topk_batch", "e2e_diff_c2", "e2e_mincut_c3",
-       "e2e_train_mincut_c3"]
-SECONDARY_DEFAULT = ["c5", "topk1m", "topk_connect", "c4_graclus", "c4_ndp", "c3", "topk_batch", "e2e_diff_c2",
-                     "e2e_mincut_c3", "e2e_train_mincut_c3"]
-SHARDED = ("c5", "c3", "topk_batch", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3")
+ALL = ["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect", "topk_batch", "graclus_batch", "e2e_diff_c2",
+       "e2e_mincut_c3", "e2e_train_mincut_c3"]
+SECONDARY_DEFAULT = ["c5", "topk1m", "topk_connect", "c4_graclus", "c4_ndp", "c3", "topk_batch", "graclus_batch",
+                     "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3"]
+SHARDED = ("c5", "c3", "topk_batch", "graclus_batch", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3")
 
 
 def main():

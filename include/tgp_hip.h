@@ -185,12 +185,14 @@ int tgp_connect_coalesce_fused_fill(const void* ws, int64_t num_edges, int64_t n
  * Outputs: x_pool [K,F], batch_pool [K] (NULL ok), and the surviving edges written ONCE at their final offsets of the
  * capacity-E buffers out_row / out_col / out_weight (NULL iff edge_weight is NULL): the first `total` entries are the
  * result, identical to tgp_reduce_sparse_f32 + tgp_reduce_batch_i64 + tgp_connect_{subgraph,coalesce_*}_{count,fill}.
- * `status` (>= tgp_sparse_pool_small_status_words(B, mode) 64-bit words, caller-owned, kept between calls on ONE
- * stream, never cleared: every word carries `epoch` in its bits 34.., 0 < epoch < 2^30, a different value for every
- * call on that buffer): status[0] = refusal (current epoch and low 32 bits != 0: a precondition above does not hold,
- * checked on the device -- an edge leaving its graph, unsorted rows, a graph too large, more than 512 edges in a mode-1
- * graph, ... -- outputs are then unspecified and the caller takes the staged entry points), status[1] = total.  The
- * caller reads both words after the launch (the call's one host sync). */
+ * `status` (>= tgp_sparse_pool_small_status_words(B, mode) 64-bit words of device memory, caller-owned, kept between
+ * calls on ONE stream, never cleared: every word carries `epoch` in its bits 34.., 0 < epoch < 2^29, a different value
+ * for every call on that buffer) holds the look-back state.  `*result` receives ONE word when the last graph is done:
+ * bits 34.. = epoch, bit 31 = refused (a precondition above does not hold, checked on the device -- an edge leaving its
+ * graph, unsorted rows, a graph too large, more than 512 edges in a mode-1 graph, ...: outputs are then unspecified
+ * and the caller takes the staged entry points), bits 0..30 = total.  It is stored with system scope, so `result` may
+ * point into pinned host memory that the caller polls for the call's epoch (the call's one host wait: no copy kernel,
+ * no stream synchronise); with a device pointer the caller copies the word back after the launch. */
 int tgp_sparse_pool_small_max_graph_nodes(void);
 int64_t tgp_sparse_pool_small_status_words(int64_t num_graphs, int mode);
 int tgp_sparse_pool_small_f32(const float* x, int64_t num_nodes, int64_t num_features, int64_t x_row_stride,
@@ -200,7 +202,8 @@ int tgp_sparse_pool_small_f32(const float* x, int64_t num_nodes, int64_t num_fea
                               const float* weight /* NULL = ones */, int64_t nnz, int64_t num_supernodes, int mode,
                               int reduce_op, int flags, float eps, float* x_pool, int64_t* batch_pool /* NULL ok */,
                               int64_t* out_row, int64_t* out_col, float* out_weight, uint64_t* status,
-                              int64_t status_words, uint32_t epoch, void* stream);
+                              int64_t status_words, uint64_t* result /* device-ACCESSIBLE: may be pinned host memory */,
+                              uint32_t epoch, void* stream);
 
 /* A4 for edge lists in ANY order, two-level: a stable radix sort by supernode row only (log2 K bits instead of the
  * 2 log2 K bits of the (row, col) key above) carrying (cluster column, weight) as payload, then the same in-row

@@ -24,7 +24,11 @@
 // and the caller takes the staged operators, so no result depends on an unchecked property of the input.
 //
 // The look-back state lives in a caller-owned status buffer whose words carry the call's EPOCH: stale words of
-// earlier calls read as "not ready", so the buffer is never cleared (no memset launch in front of the kernel).
+// earlier calls read as "not ready", so the buffer is never cleared (no memset launch in front of the kernel).  A
+// refusal travels INSIDE those words (bit 31 of the value: a tile that saw a violation, or whose predecessors did, says
+// so in what it publishes), so the last tile knows the verdict of the whole call and leaves ONE result word
+// {epoch, refused, total}, stored with system scope: the caller may point it at pinned host memory and poll it instead
+// of paying a device-to-host copy kernel and a stream synchronise for eight bytes.
 #include "primitives.h"
 
 namespace tgp {
@@ -53,7 +57,8 @@ struct SpsArgs {
   int64_t* out_row;
   int64_t* out_col;
   float* out_w;
-  unsigned long long* status;  // [0] refusal word, [1] total, [2 + tile] look-back state; all epoch-tagged
+  unsigned long long* status;  // [2 + tile] look-back state, epoch-tagged ([0], [1] reserved)
+  unsigned long long* result;  // ONE word {epoch, refused (bit 31), total}; may live in pinned host memory
   unsigned long long tag;      // epoch << SPS_EPOCH_SHIFT
 };
 
@@ -94,76 +99,85 @@ __device__ __forceinline__ int64_t wave_max64(int64_t v) {
   return v;
 }
 
-// lower_bound(arr, k0) and lower_bound(arr, k1) by ONE wave: 64 probes per round and key (the two searches' loads are
-// in flight together).  On an array that is not ascending the result is still a deterministic function of (arr, key),
-// which is all the tiling check of the caller needs.
-__device__ __forceinline__ void wave_lower_bound2(const int64_t* __restrict__ arr, int64_t n, int64_t k0, int64_t k1,
-                                                  int64_t& r0, int64_t& r1) {
+// NK lower bounds by ONE wave, together: 128 probes per round and key (two per lane), the loads of all keys in
+// flight at once -- three dependent rounds for 300 k entries instead of a log2 chain of nineteen.  On an array that is
+// not ascending the result is still a deterministic function of (array, key), which is all the tiling check of the
+// caller needs.
+template <int NK>
+__device__ __forceinline__ void wave_lower_bounds(const int64_t* const (&arr)[NK], const int64_t (&n)[NK],
+                                                  const int64_t (&key)[NK], int64_t (&res)[NK]) {
   const int lane = lane_id();
-  int64_t lo0 = 0, hi0 = n, lo1 = 0, hi1 = n;
-  while (lo0 < hi0 || lo1 < hi1) {
-    const int64_t s0 = (hi0 - lo0 + 63) >> 6, s1 = (hi1 - lo1 + 63) >> 6;
-    const int64_t i0 = lo0 + lane * s0, i1 = lo1 + lane * s1;
-    const bool v0 = i0 < hi0, v1 = i1 < hi1;
-    const int64_t a0 = arr[v0 ? i0 : (n - 1)], a1 = arr[v1 ? i1 : (n - 1)];  // unconditional, clamped (n > 0 here)
-    const int c0 = __popcll(__ballot(v0 && a0 < k0)), c1 = __popcll(__ballot(v1 && a1 < k1));
-    if (lo0 < hi0) {
-      if (c0 == 0) {
-        hi0 = lo0;
-      } else {
-        const int64_t last = lo0 + static_cast<int64_t>(c0 - 1) * s0;
-        lo0 = last + 1;
-        hi0 = last + s0 < hi0 ? last + s0 : hi0;
-      }
+  int64_t lo[NK], hi[NK];
+#pragma unroll
+  for (int q = 0; q < NK; ++q) {
+    lo[q] = 0;
+    hi[q] = n[q];
+  }
+  for (;;) {
+    bool more = false;
+#pragma unroll
+    for (int q = 0; q < NK; ++q) more = more || lo[q] < hi[q];
+    if (!more) break;
+    int64_t step[NK], va[NK], vb[NK];
+    bool oa[NK], ob[NK];
+#pragma unroll
+    for (int q = 0; q < NK; ++q) {  // unconditional, clamped loads (a finished key re-reads its last element)
+      step[q] = (hi[q] - lo[q] + 127) >> 7;
+      const int64_t ia = lo[q] + lane * step[q], ib = lo[q] + (lane + 64) * step[q];
+      oa[q] = ia < hi[q];
+      ob[q] = ib < hi[q];
+      const int64_t last = n[q] > 0 ? n[q] - 1 : 0;
+      va[q] = n[q] > 0 ? arr[q][oa[q] ? ia : last] : 0;
+      vb[q] = n[q] > 0 ? arr[q][ob[q] ? ib : last] : 0;
     }
-    if (lo1 < hi1) {
-      if (c1 == 0) {
-        hi1 = lo1;
-      } else {
-        const int64_t last = lo1 + static_cast<int64_t>(c1 - 1) * s1;
-        lo1 = last + 1;
-        hi1 = last + s1 < hi1 ? last + s1 : hi1;
+#pragma unroll
+    for (int q = 0; q < NK; ++q) {
+      const int c = __popcll(__ballot(oa[q] && va[q] < key[q])) + __popcll(__ballot(ob[q] && vb[q] < key[q]));
+      if (lo[q] < hi[q]) {
+        if (c == 0) {
+          hi[q] = lo[q];
+        } else {
+          const int64_t last = lo[q] + static_cast<int64_t>(c - 1) * step[q];
+          lo[q] = last + 1;
+          hi[q] = last + step[q] < hi[q] ? last + step[q] : hi[q];
+        }
       }
     }
   }
-  r0 = lo0;
-  r1 = lo1;
+#pragma unroll
+  for (int q = 0; q < NK; ++q) res[q] = lo[q];
 }
 
-// Exclusive prefix of `tile` over the tiles' survivor counts; every lane of ONE wave calls it.  false: the call was
-// refused meanwhile (a predecessor may never publish) or a spin bound was hit (refusal raised here).
-__device__ __forceinline__ bool sps_lookback(unsigned long long* status, int tile, unsigned long long tag,
-                                             uint32_t* excl_out) {
+// Exclusive prefix of `tile` over the tiles' survivor counts (bits 0..30 of the published values) and whether any of
+// them refused (bit 31); every lane of ONE wave calls it.  A spin bound turns a tile that never shows up into a refusal.
+__device__ __forceinline__ void sps_lookback(unsigned long long* status, int tile, unsigned long long tag,
+                                             uint32_t* excl_out, bool* refused) {
   const int lane = lane_id();
   uint32_t excl = 0;
+  bool bad = false;
   int j = tile - 1;
   while (j >= 0) {
     const int idx = j - lane;
     unsigned long long st = idx >= 0 ? sps_load(status + 2 + idx) : (tag | SPS_PRE);
     int spins = 0;
     while (__any(!sps_current(st, tag) || ((st >> 32) & 3ull) == 0)) {
-      ++spins;
-      if ((spins & 15) == 0) {
-        unsigned long long b = 0;
-        if (lane == 0) b = sps_load(status);
-        b = __shfl(b, 0, WAVE);
-        if (sps_current(b, tag) && (b & 0xFFFFFFFFull) != 0) return false;
-        if (spins > (1 << 20)) {
-          if (lane == 0) sps_store(status, tag | 16ull);
-          return false;
-        }
+      if (++spins > (1 << 20)) {  // every spin is bounded
+        *excl_out = 0;
+        *refused = true;
+        return;
       }
-      if (spins > 4) __builtin_amdgcn_s_sleep(2);
+      if (spins > 4) __builtin_amdgcn_s_sleep(1);
       if (idx >= 0 && (!sps_current(st, tag) || ((st >> 32) & 3ull) == 0)) st = sps_load(status + 2 + idx);
     }
     const unsigned long long pre = __ballot(((st >> 32) & 3ull) == 2);
     const int first = pre ? __builtin_ctzll(pre) : 64;  // nearest predecessor that already knows its prefix
-    excl += wave_sum32(lane <= first ? static_cast<uint32_t>(st) : 0u);
+    excl += wave_sum32(lane <= first ? static_cast<uint32_t>(st) & 0x7FFFFFFFu : 0u);
+    bad = bad || __any(lane <= first && ((st >> 31) & 1ull));
     if (pre) break;
     j -= 64;
   }
   *excl_out = excl;
-  return true;
+  *refused = bad;
 }
 
 __device__ __forceinline__ float sps_reduce(float acc, float v, int op) {
@@ -207,9 +221,26 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
     n0 = n1 = 0;
   }
   if (live && ((g == 0 && n0 != 0) || (g == p.B - 1 && n1 != p.N))) bad = true;
-  int64_t e0 = 0, e1 = 0;
-  if (live && p.E > 0) wave_lower_bound2(p.row, p.E, n0, n1, e0, e1);
-  if (live && (e1 < e0 || (g == 0 && e0 != 0) || (g == p.B - 1 && e1 != p.E))) bad = true;
+  // the graph's edge range and (mode 0) its slice of the node-sorted assignment: four lower bounds, searched together
+  int64_t e0 = 0, e1 = 0, a0 = 0, a1 = 0;
+  if (live) {
+    if constexpr (MODE == 0) {
+      const int64_t* const arrs[4] = {p.row, p.row, p.node_index, p.node_index};
+      const int64_t ns[4] = {p.E, p.E, p.nnz, p.nnz}, keys[4] = {n0, n1, n0, n1};
+      int64_t res[4];
+      wave_lower_bounds<4>(arrs, ns, keys, res);
+      e0 = res[0]; e1 = res[1]; a0 = res[2]; a1 = res[3];
+      if (a1 < a0 || a1 - a0 > 64 || (g == 0 && a0 != 0) || (g == p.B - 1 && a1 != p.nnz)) bad = true;
+    } else {
+      const int64_t* const arrs[2] = {p.row, p.row};
+      const int64_t ns[2] = {p.E, p.E}, keys[2] = {n0, n1};
+      int64_t res[2];
+      wave_lower_bounds<2>(arrs, ns, keys, res);
+      e0 = res[0]; e1 = res[1];
+    }
+    if (e1 < e0 || (g == 0 && e0 != 0) || (g == p.B - 1 && e1 != p.E)) bad = true;
+  }
+  if (bad) e0 = e1 = a0 = a1 = 0;
   const bool has_w = p.w != nullptr;
   const bool rsl = (p.flags & TGP_REMOVE_SELF_LOOPS) != 0, epsf = has_w && (p.flags & TGP_EPS_FILTER) != 0;
   const bool vec = (p.F & 3) == 0 && (p.x_stride & 3) == 0;
@@ -217,8 +248,11 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
   uint32_t cnt = 0;
 
   // ---------------------------------------------------------------------------------------------- MODE 0 state
-  unsigned long long M = 0;   // membership of the graph's nodes
-  int64_t a0 = 0;             // first assignment of the graph = new id of its first kept node
+  unsigned long long M = 0;   // membership of the graph's nodes; a0 = new id of its first kept node
+  constexpr int CI = 4;       // edge iterations kept in registers between the count and the write pass
+  int64_t er[CI], ec[CI];
+  float ewt[CI];
+  unsigned long long ekeep[CI];
   // ---------------------------------------------------------------------------------------------- MODE 1 state
   int64_t cmin = 0;
   int nrow_keep = 0, row_lo = 0;  // lane = supernode row: survivors, first LDS slot
@@ -226,14 +260,21 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
   SpsClusterLds& L = s_cl_all[MODE == 1 ? wv : 0];
 
   if constexpr (MODE == 0) {
-    int64_t a1 = 0;
-    if (live && p.nnz > 0) wave_lower_bound2(p.node_index, p.nnz, n0, n1, a0, a1);
-    if (live && (a1 < a0 || a1 - a0 > 64 || (g == 0 && a0 != 0) || (g == p.B - 1 && a1 != p.nnz))) bad = true;
-    const int ka = bad ? 0 : static_cast<int>(a1 - a0);
+    const int ka = static_cast<int>(a1 - a0);
     const bool act = lane < ka;
-    const int64_t v = act ? p.node_index[a0 + lane] : n0;
-    const int64_t ci = act ? p.cluster_index[a0 + lane] : a0;
-    const float wa = (act && p.weight) ? p.weight[a0 + lane] : 1.0f;
+    // one round trip: the graph's slice of the assignment and its first CI * 64 edges, all requested before any is used
+    const int64_t ai = act ? a0 + lane : 0;
+    const int64_t v = p.nnz > 0 ? p.node_index[ai] : 0;
+    const int64_t ci = p.nnz > 0 ? p.cluster_index[ai] : 0;
+    const float wa = (p.weight && p.nnz > 0) ? p.weight[ai] : 1.0f;
+#pragma unroll
+    for (int it = 0; it < CI; ++it) {
+      const int64_t ee = e0 + it * WAVE + lane;
+      const int64_t es = ee < e1 ? ee : 0;
+      er[it] = p.E > 0 ? p.row[es] : 0;
+      ec[it] = p.E > 0 ? p.col[es] : 0;
+      ewt[it] = has_w ? p.w[es] : 1.0f;
+    }
     const int64_t vprev = __shfl_up(v, 1, WAVE);
     const bool okv = !act || (v >= n0 && v < n1 && (lane == 0 || vprev < v));
     const int64_t cl = ci - a0;  // one supernode per kept node, numbered graph-major: a permutation of the slice
@@ -278,22 +319,29 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
         }
       }
     }
-    // A5 + A6, pass 1: survivors of the graph
-    if (!bad) {
-      for (int64_t e = e0; e < e1; e += WAVE) {
-        const int64_t ee = e + lane;
-        const bool on = ee < e1;
-        const int64_t r = on ? p.row[ee] : n0, c = on ? p.col[ee] : n0;
-        const float wt = (on && has_w) ? p.w[ee] : 1.0f;
-        const bool inb = r >= n0 && r < n1 && c >= n0 && c < n1;
-        if (__any(on && !inb)) bad = true;
-        bool keep = on && inb && (((M >> ((r - n0) & 63)) & (M >> ((c - n0) & 63)) & 1ull) != 0);
-        if (rsl && r == c) keep = false;
-        if (epsf && !(fabsf(wt) > p.eps)) keep = false;
-        cnt += __popcll(__ballot(keep));
-      }
-      if (bad) cnt = 0;
+    // A5 + A6, pass 1: survivors of the graph (the predicate of utils/ops.py:370-380 on the induced subgraph)
+    auto survives = [&](bool on, int64_t r, int64_t c, float wt) -> bool {
+      const bool inb = r >= n0 && r < n1 && c >= n0 && c < n1;
+      if (__any(on && !inb)) bad = true;  // an edge that leaves its graph (or rows that are not grouped by graph)
+      bool keep = on && inb && (((M >> ((r - n0) & 63)) & (M >> ((c - n0) & 63)) & 1ull) != 0);
+      if (rsl && r == c) keep = false;
+      if (epsf && !(fabsf(wt) > p.eps)) keep = false;
+      return keep;
+    };
+#pragma unroll
+    for (int it = 0; it < CI; ++it) {
+      const bool on = e0 + it * WAVE + lane < e1;
+      ekeep[it] = __ballot(survives(on, er[it], ec[it], ewt[it]));
+      cnt += __popcll(ekeep[it]);
     }
+    for (int64_t e = e0 + CI * WAVE; e < e1; e += WAVE) {  // (graphs of more than CI * 64 edges: re-read in pass 2)
+      const int64_t ee = e + lane;
+      const bool on = ee < e1;
+      const int64_t r = on ? p.row[ee] : n0, c = on ? p.col[ee] : n0;
+      const float wt = (on && has_w) ? p.w[ee] : 1.0f;
+      cnt += __popcll(__ballot(survives(on, r, c, wt)));
+    }
+    if (bad) cnt = 0;
   } else {
     // ------------------------------------------------------------------------------------------------ MODE 1
     const int n = static_cast<int>(n1 - n0);
@@ -465,51 +513,62 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
   }
 
   // ------------------------------------------------------------------------------ survivors in front of this graph
-  if (bad && lane == 0) sps_store(p.status, p.tag | 1ull);
-  if (lane == 0) s_cnt[wv] = cnt;
+  if (lane == 0) s_cnt[wv] = cnt | (bad ? 0x80000000u : 0u);
   __syncthreads();
   if (wv == 0) {
-    const uint32_t tot = wave_sum32(lane < WAVES ? s_cnt[lane] : 0u);
+    const uint32_t mine = lane < WAVES ? s_cnt[lane] : 0u;
+    const uint32_t tot = wave_sum32(mine & 0x7FFFFFFFu);
+    bool refused = __any((mine >> 31) != 0u);
     const int tile = blockIdx.x;
-    if (lane == 0) sps_store(p.status + 2 + tile, p.tag | (tile == 0 ? SPS_PRE : SPS_AGG) | tot);
+    const unsigned long long flag = refused ? 0x80000000ull : 0ull;
+    if (lane == 0) sps_store(p.status + 2 + tile, p.tag | (tile == 0 ? SPS_PRE : SPS_AGG) | flag | tot);
     uint32_t excl = 0;
-    bool ok = true;
     if (tile > 0) {
-      ok = sps_lookback(p.status, tile, p.tag, &excl);
-      if (ok && lane == 0) sps_store(p.status + 2 + tile, p.tag | SPS_PRE | static_cast<unsigned long long>(excl + tot));
+      bool before = false;
+      sps_lookback(p.status, tile, p.tag, &excl, &before);
+      refused = refused || before;
+      if (lane == 0)
+        sps_store(p.status + 2 + tile, p.tag | SPS_PRE | (refused ? 0x80000000ull : 0ull) |
+                                           static_cast<unsigned long long>((excl + tot) & 0x7FFFFFFFu));
     }
     if (lane == 0) {
       s_base = excl;
-      s_ok = ok ? 1 : 0;
-      if (ok && tile == static_cast<int>(gridDim.x) - 1)
-        sps_store(p.status + 1, p.tag | static_cast<unsigned long long>(excl + tot));
+      s_ok = refused ? 0 : 1;
+      if (tile == static_cast<int>(gridDim.x) - 1)  // the verdict and the size of the whole call, in one word
+        __hip_atomic_store(p.result, p.tag | (refused ? 0x80000000ull : 0ull) |
+                                         static_cast<unsigned long long>((excl + tot) & 0x7FFFFFFFu),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   __syncthreads();
-  if (!s_ok || bad) return;
+  if (!s_ok || bad) return;  // (a refusal seen so far: the outputs will be discarded anyway)
   uint32_t base = s_base;
-  for (int w2 = 0; w2 < wv; ++w2) base += s_cnt[w2];
+  for (int w2 = 0; w2 < wv; ++w2) base += s_cnt[w2] & 0x7FFFFFFFu;
 
   if constexpr (MODE == 0) {
-    // pass 2: the same predicate, survivors written once at their final offsets (input order kept)
+    // pass 2: survivors written once at their final offsets (input order kept); the first CI iterations from registers
     uint32_t pos = base;
-    for (int64_t e = e0; e < e1; e += WAVE) {
-      const int64_t ee = e + lane;
-      const bool on = ee < e1;
-      const int64_t r = on ? p.row[ee] : n0, c = on ? p.col[ee] : n0;
-      const float wt = (on && has_w) ? p.w[ee] : 1.0f;
-      const int lr = static_cast<int>(r - n0) & 63, lc = static_cast<int>(c - n0) & 63;
-      bool keep = on && (((M >> lr) & (M >> lc) & 1ull) != 0);
-      if (rsl && r == c) keep = false;
-      if (epsf && !(fabsf(wt) > p.eps)) keep = false;
-      const unsigned long long km = __ballot(keep);
-      if (keep) {
+    auto emit = [&](unsigned long long km, int64_t r, int64_t c, float wt) {
+      if ((km >> lane) & 1ull) {
+        const int lr = static_cast<int>(r - n0) & 63, lc = static_cast<int>(c - n0) & 63;
         const uint32_t o = pos + __popcll(km & lanemask_lt());
         p.out_row[o] = a0 + __popcll(M & ((1ull << lr) - 1ull));
         p.out_col[o] = a0 + __popcll(M & ((1ull << lc) - 1ull));
         if (has_w) p.out_w[o] = wt;
       }
       pos += __popcll(km);
+    };
+#pragma unroll
+    for (int it = 0; it < CI; ++it) emit(ekeep[it], er[it], ec[it], ewt[it]);
+    for (int64_t e = e0 + CI * WAVE; e < e1; e += WAVE) {
+      const int64_t ee = e + lane;
+      const bool on = ee < e1;
+      const int64_t r = on ? p.row[ee] : n0, c = on ? p.col[ee] : n0;
+      const float wt = (on && has_w) ? p.w[ee] : 1.0f;
+      bool keep = on && (((M >> ((r - n0) & 63)) & (M >> ((c - n0) & 63)) & 1ull) != 0);
+      if (rsl && r == c) keep = false;
+      if (epsf && !(fabsf(wt) > p.eps)) keep = false;
+      emit(__ballot(keep), r, c, wt);
     }
   } else {
     const uint32_t o0 = base + row_base;
@@ -540,22 +599,22 @@ extern "C" int tgp_sparse_pool_small_f32(const float* x, int64_t N, int64_t F, i
                                          const int64_t* node_index, const int64_t* cluster_index, const float* weight,
                                          int64_t nnz, int64_t K, int mode, int reduce_op, int flags, float eps,
                                          float* x_pool, int64_t* batch_pool, int64_t* out_row, int64_t* out_col,
-                                         float* out_w, uint64_t* status, int64_t status_words, uint32_t epoch,
-                                         void* stream_) {
+                                         float* out_w, uint64_t* status, int64_t status_words, uint64_t* result,
+                                         uint32_t epoch, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  TGP_REQUIRE(x && graph_ptr && node_index && cluster_index && x_pool && status && N > 0 && F > 0 && B > 0 && E >= 0 &&
+  TGP_REQUIRE(x && graph_ptr && node_index && cluster_index && x_pool && status && result && N > 0 && F > 0 && B > 0 && E >= 0 &&
                   nnz >= 0 && K >= 0 && x_stride >= F && (mode == 0 || mode == 1),
               TGP_ERR_INVALID, "tgp_sparse_pool_small_f32: bad argument");
   TGP_REQUIRE(E == 0 || (row && col && out_row && out_col && (!w || out_w)), TGP_ERR_INVALID,
               "tgp_sparse_pool_small_f32: null edge pointer");
   TGP_REQUIRE(reduce_op >= TGP_SUM && reduce_op <= TGP_MUL, TGP_ERR_INVALID, "tgp_sparse_pool_small_f32: reduce_op");
-  TGP_REQUIRE(E < (1ll << 31) && N < (1ll << 31) && B < (1ll << 24) && epoch != 0 && epoch < (1u << 30), TGP_ERR_RANGE,
+  TGP_REQUIRE(E < (1ll << 31) && N < (1ll << 31) && B < (1ll << 24) && epoch != 0 && epoch < (1u << 29), TGP_ERR_RANGE,
               "tgp_sparse_pool_small_f32: size or epoch out of range");
   TGP_REQUIRE(status_words >= tgp_sparse_pool_small_status_words(B, mode), TGP_ERR_WORKSPACE,
               "tgp_sparse_pool_small_f32: status buffer too small");
   SpsArgs a{x, N, F, x_stride, graph_ptr, B, row, col, w, E, node_index, cluster_index, weight, nnz, K, reduce_op, flags,
             eps, x_pool, batch_pool, out_row, out_col, out_w, reinterpret_cast<unsigned long long*>(status),
-            static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT};
+            reinterpret_cast<unsigned long long*>(result), static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT};
   if (mode == 0) {
     hipLaunchKernelGGL((sparse_pool_small_kernel<0, SPS_WAVES_TOPK>), dim3(cdiv(B, SPS_WAVES_TOPK)),
                        dim3(SPS_WAVES_TOPK * 64), 0, stream, a);

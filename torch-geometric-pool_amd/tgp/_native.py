@@ -64,7 +64,7 @@ SIGNATURES = {
     "tgp_sparse_pool_small_status_words": (_c_i64, [_c_i64, _c_int]),
     "tgp_sparse_pool_small_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p,
                                            _c_p, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p,
-                                           _c_p, _c_i64, ctypes.c_uint32, _c_p]),
+                                           _c_p, _c_i64, _c_p, ctypes.c_uint32, _c_p]),
     "tgp_connect_coalesce_grouped_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tgp_connect_coalesce_grouped_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_int,
                                                     _c_f, _c_p, _c_sz, _c_p, _c_p]),

@@ -120,22 +120,57 @@ def _edge_rows(edge_index: Tensor) -> Tuple[Tensor, Tensor]:
 
 
 # ------------------------------------------------------------------------- A1 + A2 + A4/A5 + A6, batches of small graphs
-_SPS_STATUS: dict = {}  # (device index, stream handle) -> [status words (never cleared: epoch-tagged), last epoch]
+_SPS_STATE: dict = {}  # (device index, stream handle) -> _SpsState
 _SPS_DECLINED: dict = {}
 SPS_COMPACT_BYTES = 64 << 20  # capacity buffers above this are replaced by exact copies when mostly empty
 
 
-def _sps_status(dev: torch.device, stream: int, words: int):
+class _SpsState:
+    """Per (device, stream): the look-back words of ``tgp_sparse_pool_small_f32`` (device memory, never cleared: every
+    word carries the epoch of the call that wrote it), the epoch counter, and ONE pinned host word the kernel's last
+    workgroup stores {epoch, refused, total} into -- the host polls it instead of paying a device-to-host copy kernel
+    and a stream synchronise for eight bytes."""
+
+    __slots__ = ("status", "epoch", "pinned", "host")
+
+    def __init__(self, dev, words):
+        self.status = torch.zeros(max(int(words), 4096), dtype=torch.int64, device=dev)
+        self.epoch = 0
+        self.pinned = torch.zeros(8, dtype=torch.int64).pin_memory()
+        self.host = self.pinned.numpy()  # the same memory
+
+    def next_epoch(self) -> int:
+        self.epoch += 1
+        if self.epoch >= (1 << 29) - 1:  # epochs of a buffer never repeat: start over on a cleared buffer
+            torch.cuda.synchronize(self.status.device)
+            self.status.zero_()
+            self.host[0] = 0
+            self.epoch = 1
+        return self.epoch
+
+    def wait(self, epoch: int) -> int:
+        """The result word of call ``epoch`` (spins on the pinned word; a stuck device is turned into an error)."""
+        host, spins = self.host, 0
+        while True:
+            word = int(host[0])
+            if (word >> 34) == epoch:
+                return word
+            spins += 1
+            if spins > 4_000_000:
+                torch.cuda.synchronize(self.status.device)  # surfaces a device fault, if that is what happened
+                word = int(host[0])
+                if (word >> 34) == epoch:
+                    return word
+                raise N.TgpNativeError("tgp_sparse_pool_small_f32 finished without publishing its result word")
+
+
+def _sps_state(dev: torch.device, stream: int, words: int) -> "_SpsState":
     key = (dev.index, stream)
-    ent = _SPS_STATUS.get(key)
-    if ent is None or ent[0].numel() < words:
-        ent = [torch.zeros(max(int(words), 4096), dtype=torch.int64, device=dev), 0]
-        _SPS_STATUS[key] = ent
-    ent[1] += 1
-    if ent[1] >= (1 << 29):  # epochs of a buffer never repeat: start over on a cleared buffer
-        ent[0].zero_()
-        ent[1] = 1
-    return ent[0], ent[1]
+    ent = _SPS_STATE.get(key)
+    if ent is None or ent.status.numel() < words:
+        ent = _SpsState(dev, words)
+        _SPS_STATE[key] = ent
+    return ent
 
 
 def sparse_pool_small_declined(edge_index: Tensor) -> bool:
@@ -184,20 +219,20 @@ def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_wei
     cap_w = None if w is None else torch.empty(max(E, 1), dtype=torch.float32, device=dev)
     L = N.lib()
     st = N.stream_ptr(dev)
-    status, epoch = _sps_status(dev, st, L.tgp_sparse_pool_small_status_words(B, mode))
+    state = _sps_state(dev, st, L.tgp_sparse_pool_small_status_words(B, mode))
+    epoch = state.next_epoch()
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if w is not None else 0)
     N.check(L.tgp_sparse_pool_small_f32(N.ptr(x), n, F, x.stride(0), N.ptr(gp), B, N.ptr(row) if E else None,
                                         N.ptr(col) if E else None, N.ptr(w), E, N.ptr(ni), N.ptr(ci), N.ptr(wt),
                                         ni.numel(), K, mode, N.REDUCE_OPS[reduce_op], flags, ops_eps(), N.ptr(x_pool),
-                                        N.ptr(batch_pool), N.ptr(cap[0]), N.ptr(cap[1]), N.ptr(cap_w), N.ptr(status),
-                                        status.numel(), epoch, st), "tgp_sparse_pool_small_f32")
-    refusal, total = status[:2].tolist()  # the call's one host sync
-    if (refusal >> 34) == epoch and (refusal & 0xFFFFFFFF):
+                                        N.ptr(batch_pool), N.ptr(cap[0]), N.ptr(cap[1]), N.ptr(cap_w),
+                                        N.ptr(state.status), state.status.numel(), state.pinned.data_ptr(), epoch, st),
+            "tgp_sparse_pool_small_f32")
+    total = state.wait(epoch)  # the call's one host wait (the reference's .item() syncs)
+    if total & 0x80000000:
         _sps_remember_declined(edge_index)
         return None
-    if (total >> 34) != epoch:
-        raise N.TgpNativeError("tgp_sparse_pool_small_f32 finished without publishing its edge count")
-    n_out = total & 0xFFFFFFFF
+    n_out = total & 0x7FFFFFFF
     ei = cap[:, :n_out]
     ew = None if cap_w is None else cap_w[:n_out]
     if E * 16 > SPS_COMPACT_BYTES and 2 * n_out < E:
