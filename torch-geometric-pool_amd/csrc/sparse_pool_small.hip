@@ -4,17 +4,20 @@
 // device-wide bitmaps, sorts and scans, six to ten launches per Reduce + Connect.  On 2048 PROTEINS-sized graphs
 // (80 k nodes, 300 k edges) each of those launches moves a few megabytes and the call is bound by their dispatch
 // latency (0.093 ms, 0.026 of the HBM roofline).  Here ONE WAVE owns one graph of a sorted batch (<= 64 nodes):
-//   * its node range comes from the batch offsets; its edge range and its slice of the (node-sorted) assignment from
-//     64-ary searches over the row / node_index arrays (three or four dependent probes instead of a log2 chain);
+//   * its node range comes from the batch offsets.  The graphs of a workgroup are consecutive, so ONE wave finds the
+//     workgroup's edge range and its slice of the (node-sorted) assignment with 128-ary searches (three dependent rounds;
+//     r4 stamps: every wave searching for itself kept the CU's address unit busy for 8 us with stride-N probes), and
+//     the per-graph boundaries inside come from one coalesced pass over the workgroup's rows;
 //   * A1 + A2 (reduce/base_reduce.py:14-53,141-155): the graph's pooled rows are gathered, scaled, summed and
 //     written by the wave (products rounded before the add, members in ascending order: the bits of
 //     reduce_sparse_*_kernel and of the reference's sequential scatter);
 //   * A5 + A6 (connect/base_conn.py:79-82, utils/ops.py:370-380; TopK): membership = a 64-bit mask in registers, new id
 //     = first assignment of the graph + popcount below; survivors keep input order;
-//   * A4 + A6 (connect/base_conn.py:83-89; Graclus-style clusterings): the graph's edges are staged in LDS, LANE =
-//     supernode ROW walks the edge ranges of its member nodes in input order and keeps a sorted, duplicate-merged
-//     list of (column, weight) in its own LDS slots (rows of a small graph hold a handful of entries: insertion beats a
-//     sorting network), filters fused; rows leave in (row, column) order = PyG coalesce's;
+//   * A4 + A6 (connect/base_conn.py:83-89; Graclus-style clusterings): the graph's edges are staged in LDS with their
+//     column already mapped to its cluster; LANE = supernode ROW walks the edge ranges of its member nodes in input
+//     order.  A graph has at most 64 clusters, so a row's set of columns is a 64-bit mask: the slot of column c in the
+//     sorted row is a popcount below c -- no sorting network, no searching; weights of duplicates are folded into
+//     their slot in input order; filters fused; rows leave in (row, column) order = PyG coalesce's;
 //   * the only cross-wave quantity, the number of surviving edges in front of a graph, comes from a workgroup sum and a
 //     decoupled look-back over the workgroups (WAVES graphs each: 128 tiles for 2048 graphs, two hops).  Survivors are
 //     written ONCE, in their final int64 form at their final offsets of capacity-E buffers; the host reads the total
@@ -152,29 +155,50 @@ __device__ __forceinline__ void wave_lower_bounds(const int64_t* const (&arr)[NK
 // them refused (bit 31); every lane of ONE wave calls it.  A spin bound turns a tile that never shows up into a refusal.
 __device__ __forceinline__ void sps_lookback(unsigned long long* status, int tile, unsigned long long tag,
                                              uint32_t* excl_out, bool* refused) {
+  // 256 predecessors per round (four words per lane, all requested at once): the words live behind the fabric (agent
+  // scope across XCDs), a round trip costs ~1 us, and everybody publishes at about the same time -- r4 stamps: 64 per
+  // round made the last of 256 tiles wait four dependent rounds
   const int lane = lane_id();
   uint32_t excl = 0;
   bool bad = false;
   int j = tile - 1;
   while (j >= 0) {
-    const int idx = j - lane;
-    unsigned long long st = idx >= 0 ? sps_load(status + 2 + idx) : (tag | SPS_PRE);
+    unsigned long long st[4];
+    int idx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      idx[k] = j - lane - 64 * k;
+      st[k] = idx[k] >= 0 ? sps_load(status + 2 + idx[k]) : (tag | SPS_PRE);
+    }
     int spins = 0;
-    while (__any(!sps_current(st, tag) || ((st >> 32) & 3ull) == 0)) {
+    for (;;) {
+      bool wait = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wait = wait || !sps_current(st[k], tag) || ((st[k] >> 32) & 3ull) == 0;
+      if (!__any(wait)) break;
       if (++spins > (1 << 20)) {  // every spin is bounded
         *excl_out = 0;
         *refused = true;
         return;
       }
       if (spins > 4) __builtin_amdgcn_s_sleep(1);
-      if (idx >= 0 && (!sps_current(st, tag) || ((st >> 32) & 3ull) == 0)) st = sps_load(status + 2 + idx);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (idx[k] >= 0 && (!sps_current(st[k], tag) || ((st[k] >> 32) & 3ull) == 0)) st[k] = sps_load(status + 2 + idx[k]);
     }
-    const unsigned long long pre = __ballot(((st >> 32) & 3ull) == 2);
-    const int first = pre ? __builtin_ctzll(pre) : 64;  // nearest predecessor that already knows its prefix
-    excl += wave_sum32(lane <= first ? static_cast<uint32_t>(st) & 0x7FFFFFFFu : 0u);
-    bad = bad || __any(lane <= first && ((st >> 31) & 1ull));
-    if (pre) break;
-    j -= 64;
+    bool done = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!done) {  // (uniform: `done` comes from ballots)
+        const unsigned long long pre = __ballot(((st[k] >> 32) & 3ull) == 2);
+        const int first = pre ? __builtin_ctzll(pre) : 64;  // nearest predecessor that already knows its prefix
+        excl += wave_sum32(lane <= first ? static_cast<uint32_t>(st[k]) & 0x7FFFFFFFu : 0u);
+        bad = bad || __any(lane <= first && ((st[k] >> 31) & 1ull));
+        done = pre != 0ull;
+      }
+    }
+    if (done) break;
+    j -= 256;
   }
   *excl_out = excl;
   *refused = bad;
@@ -193,54 +217,112 @@ __device__ __forceinline__ float sps_reduce(float acc, float v, int op) {
 struct SpsClusterLds {
   unsigned long long mem[64];  // members (local node bits) of local cluster r
   uint32_t deg[64];            // edges per local node, then (first staged edge << 16 | edges)
-  uint8_t cl[64];              // local cluster of local node j
-  uint8_t ecol[SPS_CAP];       // staged edges: local column
+  uint8_t ecc[SPS_CAP];        // staged edges: local cluster of the column
   float ew[SPS_CAP];           // staged edges: weight
-  uint8_t lkey[SPS_CAP];       // row lists: local cluster column, ascending inside a row's slots
-  uint16_t lcnt[SPS_CAP];      // row lists: merged entries (mean)
-  float lval[SPS_CAP];         // row lists: merged weight
+  uint16_t lcnt[SPS_CAP];      // row slots: merged entries (mean)
+  float lval[SPS_CAP];         // row slots: merged weight
 };
+
+// diagnostic build (make stamps): wave 0 of every workgroup leaves the constant-rate clock at its phase boundaries in
+// status[2 + tiles + 8 * tile + k] (tools/sps_stamps.py reads them)
+#ifdef TGP_GEMM_STAMPS
+#define SPS_STAMP(k)                                                                                                   \
+  do {                                                                                                                 \
+    if (threadIdx.x == 0) p.status[2 + gridDim.x + 8 * blockIdx.x + (k)] = wall_clock64();                             \
+  } while (0)
+#else
+#define SPS_STAMP(k) do { } while (0)
+#endif
+
+// boundaries of WAVES + 1 ascending keys s_key[] inside arr[lo, lo + len): s_out[t] = first i with arr[lo + i] >= key
+// (left at INT_MAX when no element is that large).  One coalesced pass by the whole workgroup; on an array that is not
+// ascending the minimum of the candidates is taken (deterministic; the caller's range checks then refuse the input).
+template <int WAVES>
+__device__ __forceinline__ void sps_boundaries(const int64_t* __restrict__ arr, int64_t lo, int64_t len,
+                                               const int64_t* s_key, int* s_out) {
+  for (int64_t i = threadIdx.x; i < len; i += WAVES * WAVE) {
+    const int64_t r = arr[lo + i];
+    const int64_t rp = i > 0 ? arr[lo + i - 1] : INT64_MIN;
+    if (r != rp) {
+      for (int t = 0; t <= WAVES; ++t) {
+        const int64_t nb = s_key[t];
+        if (rp < nb && nb <= r) atomicMin(&s_out[t], static_cast<int>(i));
+      }
+    }
+  }
+}
 
 template <int MODE, int WAVES>  // MODE 0: kept-node selection (TopK, NDP-shaped); 1: every node in one cluster (Graclus)
 __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p) {
   __shared__ uint32_t s_cnt[WAVES];
   __shared__ uint32_t s_base;
   __shared__ int s_ok;
+  __shared__ int64_t s_nb[WAVES + 1];  // node offsets of the workgroup's graphs
+  __shared__ int s_eb[WAVES + 1], s_ab[WAVES + 1];
+  __shared__ int64_t s_rng[4];  // the workgroup's edge range and assignment slice
   __shared__ SpsClusterLds s_cl_all[MODE == 1 ? WAVES : 1];
   const int lane = lane_id(), wv = wave_id();
-  const int64_t g = static_cast<int64_t>(blockIdx.x) * WAVES + wv;
+  SPS_STAMP(0);
+  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * WAVES;
+  const int64_t g = g0 + wv;
   const bool live = g < p.B;
-  int64_t n0 = 0, n1 = 0;
-  if (live) {
-    n0 = p.gptr[g];
-    n1 = p.gptr[g + 1];
+  if (threadIdx.x <= WAVES) {
+    const int64_t gi = g0 + threadIdx.x < p.B ? g0 + threadIdx.x : p.B;
+    s_nb[threadIdx.x] = p.gptr[gi];
+    s_eb[threadIdx.x] = INT_MAX;
+    s_ab[threadIdx.x] = INT_MAX;
   }
+  if (wv == 0) {
+    const int64_t N0 = p.gptr[g0], N1 = p.gptr[g0 + WAVES < p.B ? g0 + WAVES : p.B];
+    if constexpr (MODE == 0) {
+      const int64_t* const arrs[4] = {p.row, p.row, p.node_index, p.node_index};
+      const int64_t ns[4] = {p.E, p.E, p.nnz, p.nnz}, keys[4] = {N0, N1, N0, N1};
+      int64_t res[4];
+      wave_lower_bounds<4>(arrs, ns, keys, res);
+      if (lane < 4) s_rng[lane] = lane == 0 ? res[0] : (lane == 1 ? res[1] : (lane == 2 ? res[2] : res[3]));
+    } else {
+      const int64_t* const arrs[2] = {p.row, p.row};
+      const int64_t ns[2] = {p.E, p.E}, keys[2] = {N0, N1};
+      int64_t res[2];
+      wave_lower_bounds<2>(arrs, ns, keys, res);
+      if (lane < 4) s_rng[lane] = lane == 0 ? res[0] : (lane == 1 ? res[1] : 0);
+    }
+  }
+  __syncthreads();
+  const int64_t E0 = s_rng[0], E1 = s_rng[1], A0 = s_rng[2], A1 = s_rng[3];
+  const int64_t LE = E1 - E0, LA = A1 - A0;
   bool bad = false;
+  // the workgroups' ranges tile the arrays: consecutive workgroups search for the same key (a deterministic function of
+  // array and key, sorted or not), the first range starts at 0, the last one ends at the end
+  if (LE < 0 || LA < 0 || (blockIdx.x == 0 && (E0 != 0 || A0 != 0 || s_nb[0] != 0)) ||
+      (blockIdx.x == gridDim.x - 1 && (E1 != p.E || (MODE == 0 && A1 != p.nnz) || s_nb[WAVES] != p.N)))
+    bad = true;
+  if (!bad) {
+    sps_boundaries<WAVES>(p.row, E0, LE, s_nb, s_eb);
+    if constexpr (MODE == 0) sps_boundaries<WAVES>(p.node_index, A0, LA, s_nb, s_ab);
+  }
+  __syncthreads();
+  SPS_STAMP(1);
+  int64_t n0 = s_nb[wv], n1 = s_nb[wv + 1];
   if (n1 < n0 || n1 - n0 > 64 || n0 < 0 || n1 > p.N) {
     bad = true;
     n0 = n1 = 0;
   }
-  if (live && ((g == 0 && n0 != 0) || (g == p.B - 1 && n1 != p.N))) bad = true;
-  // the graph's edge range and (mode 0) its slice of the node-sorted assignment: four lower bounds, searched together
   int64_t e0 = 0, e1 = 0, a0 = 0, a1 = 0;
-  if (live) {
+  if (!bad) {
+    const int64_t b0 = s_eb[wv] < LE ? s_eb[wv] : LE, b1 = s_eb[wv + 1] < LE ? s_eb[wv + 1] : LE;
+    e0 = E0 + b0;
+    e1 = E0 + b1;
+    if (b1 < b0 || (wv == 0 && b0 != 0) || (wv == WAVES - 1 && b1 != LE)) bad = true;
     if constexpr (MODE == 0) {
-      const int64_t* const arrs[4] = {p.row, p.row, p.node_index, p.node_index};
-      const int64_t ns[4] = {p.E, p.E, p.nnz, p.nnz}, keys[4] = {n0, n1, n0, n1};
-      int64_t res[4];
-      wave_lower_bounds<4>(arrs, ns, keys, res);
-      e0 = res[0]; e1 = res[1]; a0 = res[2]; a1 = res[3];
-      if (a1 < a0 || a1 - a0 > 64 || (g == 0 && a0 != 0) || (g == p.B - 1 && a1 != p.nnz)) bad = true;
-    } else {
-      const int64_t* const arrs[2] = {p.row, p.row};
-      const int64_t ns[2] = {p.E, p.E}, keys[2] = {n0, n1};
-      int64_t res[2];
-      wave_lower_bounds<2>(arrs, ns, keys, res);
-      e0 = res[0]; e1 = res[1];
+      const int64_t c0 = s_ab[wv] < LA ? s_ab[wv] : LA, c1 = s_ab[wv + 1] < LA ? s_ab[wv + 1] : LA;
+      a0 = A0 + c0;
+      a1 = A0 + c1;
+      if (c1 < c0 || c1 - c0 > 64 || (wv == 0 && c0 != 0) || (wv == WAVES - 1 && c1 != LA)) bad = true;
     }
-    if (e1 < e0 || (g == 0 && e0 != 0) || (g == p.B - 1 && e1 != p.E)) bad = true;
   }
   if (bad) e0 = e1 = a0 = a1 = 0;
+  (void)live;
   const bool has_w = p.w != nullptr;
   const bool rsl = (p.flags & TGP_REMOVE_SELF_LOOPS) != 0, epsf = has_w && (p.flags & TGP_EPS_FILTER) != 0;
   const bool vec = (p.F & 3) == 0 && (p.x_stride & 3) == 0;
@@ -255,18 +337,24 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
   unsigned long long ekeep[CI];
   // ---------------------------------------------------------------------------------------------- MODE 1 state
   int64_t cmin = 0;
-  int nrow_keep = 0, row_lo = 0;  // lane = supernode row: survivors, first LDS slot
-  uint32_t row_base = 0;          // survivors of the wave's earlier rows
+  unsigned long long colmask = 0;  // lane = supernode row: its surviving columns
+  int row_lo = 0;                  // first LDS slot of the row
+  uint32_t row_base = 0;           // survivors of the wave's earlier rows
   SpsClusterLds& L = s_cl_all[MODE == 1 ? wv : 0];
 
+  int ka = 0;            // MODE 0: the graph's kept nodes, one per lane
+  int64_t v = 0, ci = 0;
+  float wa = 1.0f;
+  int kc = 0;            // MODE 1: the graph's clusters; lane = node: its weight
+  float wj = 1.0f;
   if constexpr (MODE == 0) {
-    const int ka = static_cast<int>(a1 - a0);
+    ka = static_cast<int>(a1 - a0);
     const bool act = lane < ka;
     // one round trip: the graph's slice of the assignment and its first CI * 64 edges, all requested before any is used
     const int64_t ai = act ? a0 + lane : 0;
-    const int64_t v = p.nnz > 0 ? p.node_index[ai] : 0;
-    const int64_t ci = p.nnz > 0 ? p.cluster_index[ai] : 0;
-    const float wa = (p.weight && p.nnz > 0) ? p.weight[ai] : 1.0f;
+    v = p.nnz > 0 ? p.node_index[ai] : 0;
+    ci = p.nnz > 0 ? p.cluster_index[ai] : 0;
+    wa = (p.weight && p.nnz > 0) ? p.weight[ai] : 1.0f;
 #pragma unroll
     for (int it = 0; it < CI; ++it) {
       const int64_t ee = e0 + it * WAVE + lane;
@@ -283,42 +371,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
     M = wave_or64((act && okv) ? 1ull << (v - n0) : 0ull);
     const unsigned long long CM = wave_or64((act && okc) ? 1ull << cl : 0ull);
     if (__popcll(CM) != ka) bad = true;
-    if (!bad && ka > 0) {
-      // A1: x_pool[cluster] = 0 + weight * x[node] (one member per supernode); A2: batch_pool[cluster] = graph id
-      if (p.batch_pool && act) p.batch_pool[ci] = g;
-      if (vec) {
-        const int total = ka * F4;
-        for (int base = 0; base < total; base += WAVE) {
-          const int idx = base + lane;
-          const bool on = idx < total;
-          const int a = on ? idx / F4 : 0;
-          const int f = (idx - a * F4) * 4;
-          const int64_t vv = __shfl(v, a, WAVE), cc = __shfl(ci, a, WAVE);
-          const float ww = __shfl(wa, a, WAVE);
-          if (on) {
-            const float4 t = *reinterpret_cast<const float4*>(p.x + vv * p.x_stride + f);
-            float4 o;
-            o.x = __fadd_rn(0.f, __fmul_rn(t.x, ww));
-            o.y = __fadd_rn(0.f, __fmul_rn(t.y, ww));
-            o.z = __fadd_rn(0.f, __fmul_rn(t.z, ww));
-            o.w = __fadd_rn(0.f, __fmul_rn(t.w, ww));
-            *reinterpret_cast<float4*>(p.x_pool + cc * p.F + f) = o;
-          }
-        }
-      } else {
-        const int Fi = static_cast<int>(p.F);
-        const int total = ka * Fi;
-        for (int base = 0; base < total; base += WAVE) {
-          const int idx = base + lane;
-          const bool on = idx < total;
-          const int a = on ? idx / Fi : 0;
-          const int f = idx - a * Fi;
-          const int64_t vv = __shfl(v, a, WAVE), cc = __shfl(ci, a, WAVE);
-          const float ww = __shfl(wa, a, WAVE);
-          if (on) p.x_pool[cc * p.F + f] = __fadd_rn(0.f, __fmul_rn(p.x[vv * p.x_stride + f], ww));
-        }
-      }
-    }
+    SPS_STAMP(2);
     // A5 + A6, pass 1: survivors of the graph (the predicate of utils/ops.py:370-380 on the induced subgraph)
     auto survives = [&](bool on, int64_t r, int64_t c, float wt) -> bool {
       const bool inb = r >= n0 && r < n1 && c >= n0 && c < n1;
@@ -346,25 +399,31 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
     // ------------------------------------------------------------------------------------------------ MODE 1
     const int n = static_cast<int>(n1 - n0);
     const bool nact = lane < n;
+    // one round trip: the graph's nodes and the previous graph's cluster ids (the usual case: it is not empty)
+    const int64_t q1 = n0, q0 = wv > 0 ? s_nb[wv - 1] : (g > 0 ? p.gptr[g - 1] : 0);
     const int64_t ni = nact ? p.node_index[n0 + lane] : n0 + lane;
     const int64_t cj = nact ? p.cluster_index[n0 + lane] : 0;
-    const float wj = (nact && p.weight) ? p.weight[n0 + lane] : 1.0f;
+    wj = (nact && p.weight) ? p.weight[n0 + lane] : 1.0f;
+    int64_t pc = (q0 + lane < q1) ? p.cluster_index[q0 + lane] : -1;
     if (__any(nact && ni != n0 + lane)) bad = true;  // every node assigned, in node order (base_select.py:58)
     cmin = wave_min64(nact ? cj : INT64_MAX);
     const int64_t cmax = wave_max64(nact ? cj : -1);
-    int kc = 0;
     if (n > 0) {
       if (cmin < 0 || cmax >= p.K || cmax - cmin + 1 > 64) bad = true;
       else kc = static_cast<int>(cmax - cmin + 1);
       // cluster ids are contiguous per graph and ascending over the graphs (what a per-graph selector's unique()
       // relabelling gives): no cluster spans two graphs and the graph-major output is PyG coalesce's global order
       int64_t want = 0;
-      int64_t gp = g - 1;
-      while (gp >= 0 && p.gptr[gp + 1] == p.gptr[gp]) --gp;
-      if (gp >= 0) {
-        const int64_t q0 = p.gptr[gp], q1 = p.gptr[gp + 1];
-        const bool qa = q0 + lane < q1 && lane < 64;
-        const int64_t pc = qa ? p.cluster_index[q0 + lane] : -1;
+      if (g > 0) {
+        if (q1 == q0) {  // the previous graph is empty: walk back to the last graph that is not
+          int64_t gp = g - 1;
+          while (gp >= 0 && p.gptr[gp + 1] == p.gptr[gp]) --gp;
+          pc = -1;
+          if (gp >= 0) {
+            const int64_t r0 = p.gptr[gp], r1 = p.gptr[gp + 1];
+            pc = (r0 + lane < r1) ? p.cluster_index[r0 + lane] : -1;
+          }
+        }
         want = wave_max64(pc) + 1;
       }
       if (cmin != want) bad = true;
@@ -378,55 +437,17 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
     L.mem[lane] = 0ull;
     L.deg[lane] = 0u;
     __builtin_amdgcn_wave_barrier();
-    if (lane < nn) {
-      atomicOr(&L.mem[cj - cmin], 1ull << lane);
-      L.cl[lane] = static_cast<uint8_t>(cj - cmin);
-    }
+    if (lane < nn) atomicOr(&L.mem[cj - cmin], 1ull << lane);
     __builtin_amdgcn_wave_barrier();
     const unsigned long long mymem = lane < kc ? L.mem[lane] : 0ull;
     if (__any(lane < kc && mymem == 0ull)) bad = true;  // an id without a node would keep reduce_batch's arange value
-    if (!bad && kc > 0) {
-      // A2 + A1
-      if (p.batch_pool && lane < kc) p.batch_pool[cmin + lane] = g;
-      const int per = vec ? F4 : static_cast<int>(p.F);
-      const int total = kc * per;
-      for (int base = 0; base < total; base += WAVE) {
-        const int idx = base + lane;
-        const bool on = idx < total;
-        const int rr = on ? idx / per : 0;
-        const int f = (idx - rr * per) * (vec ? 4 : 1);
-        unsigned long long mask = on ? L.mem[rr] : 0ull;
-        float4 acc = {0.f, 0.f, 0.f, 0.f};
-        while (__any(mask != 0ull)) {
-          const int j = mask ? __builtin_ctzll(mask) : 0;
-          const float ww = __shfl(wj, j, WAVE);
-          if (mask) {
-            mask &= mask - 1;
-            const float* src = p.x + (n0 + j) * p.x_stride + f;
-            if (vec) {
-              const float4 t = *reinterpret_cast<const float4*>(src);
-              acc.x = __fadd_rn(acc.x, __fmul_rn(t.x, ww));
-              acc.y = __fadd_rn(acc.y, __fmul_rn(t.y, ww));
-              acc.z = __fadd_rn(acc.z, __fmul_rn(t.z, ww));
-              acc.w = __fadd_rn(acc.w, __fmul_rn(t.w, ww));
-            } else {
-              acc.x = __fadd_rn(acc.x, __fmul_rn(*src, ww));
-            }
-          }
-        }
-        if (on) {
-          float* dst = p.x_pool + (cmin + rr) * p.F + f;
-          if (vec) *reinterpret_cast<float4*>(dst) = acc;
-          else *dst = acc.x;
-        }
-      }
-    }
-    // A4: stage the graph's edges (local column, weight) in LDS, count per local row node
+    // A4, first half: the graph's edges into LDS (cluster of the column, weight), edges per local row node
     int ne = static_cast<int>(e1 - e0);
     if (bad || e1 - e0 > SPS_CAP) {
       if (e1 - e0 > SPS_CAP) bad = true;
       ne = 0;
     }
+    const int clj = static_cast<int>(cj - cmin) & 63;
     int64_t carry = n0;
     for (int base = 0; base < ne; base += WAVE) {
       const int t = base + lane;
@@ -438,14 +459,19 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
       if (lane == 0) rp = carry;
       if (__any(!inb || (on && r < rp))) bad = true;  // rows ascending inside the graph: a node's edges are one range
       carry = __shfl(r, WAVE - 1, WAVE);
+      const int cc = __shfl(clj, static_cast<int>(c - n0) & 63, WAVE);  // the column's cluster sits in lane (c - n0)
       if (on && inb) {
         atomicAdd(&L.deg[r - n0], 1u);
-        L.ecol[t] = static_cast<uint8_t>(c - n0);
+        L.ecc[t] = static_cast<uint8_t>(cc);
         L.ew[t] = wt;
       }
     }
+    if (bad) {
+      ne = 0;
+      kc = 0;
+    }
+    SPS_STAMP(2);
     __builtin_amdgcn_wave_barrier();
-    if (bad) ne = 0;
     {
       const uint32_t d = ne > 0 ? L.deg[lane] : 0u;
       const uint32_t ps = wave_incl_scan(d) - d;
@@ -453,94 +479,187 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
       L.deg[lane] = (ps << 16) | d;
       __builtin_amdgcn_wave_barrier();
     }
-    // lane = supernode row: raw entries of the row = edges of its members; LDS slots by exclusive scan
-    uint32_t raw = 0;
+    // A4, second half.  lane = supernode row.  First walk: the row's set of columns (a mask) and its raw length.
     if (ne > 0 && lane < kc) {
-      unsigned long long mask = mymem;
-      while (mask) {
-        const int j = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        raw += L.deg[j] & 0xFFFFu;
-      }
-    }
-    row_lo = static_cast<int>(wave_incl_scan(raw) - raw);
-    int len = 0;
-    if (raw > 0) {
       unsigned long long mask = mymem;
       while (mask) {
         const int j = __builtin_ctzll(mask);
         mask &= mask - 1;
         const uint32_t pd = L.deg[j];
         const int t0 = static_cast<int>(pd >> 16), t1 = t0 + static_cast<int>(pd & 0xFFFFu);
-        for (int t = t0; t < t1; ++t) {  // input order: ascending member, then position
-          const int cc = L.cl[L.ecol[t]];
-          if (rsl && cc == lane) continue;  // (self loops are their own key: dropping them first changes nothing else)
+        for (int t = t0; t < t1; ++t) colmask |= 1ull << L.ecc[t];
+      }
+      if (rsl) colmask &= ~(1ull << lane);  // (self loops are their own key: dropping them first changes nothing else)
+    }
+    const uint32_t width = __popcll(colmask);  // merged entries of the row (<= raw): its LDS slots
+    row_lo = static_cast<int>(wave_incl_scan(width) - width);
+    if (has_w && width > 0) {
+      // second walk, input order (ascending member, then position): the slot of column c is the number of the row's
+      // columns below c; the first entry of a slot sets it, later ones fold in
+      unsigned long long seen = 0, mask = mymem;
+      while (mask) {
+        const int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const uint32_t pd = L.deg[j];
+        const int t0 = static_cast<int>(pd >> 16), t1 = t0 + static_cast<int>(pd & 0xFFFFu);
+        for (int t = t0; t < t1; ++t) {
+          const int cc = L.ecc[t];
+          const unsigned long long bit = 1ull << cc;
+          if (!(colmask & bit)) continue;
+          const int slot = row_lo + __popcll(colmask & (bit - 1ull));
           const float wt = L.ew[t];
-          int q = 0;
-          while (q < len && L.lkey[row_lo + q] < cc) ++q;
-          if (q < len && L.lkey[row_lo + q] == cc) {
-            if (has_w) L.lval[row_lo + q] = sps_reduce(L.lval[row_lo + q], wt, p.reduce_op);
-            L.lcnt[row_lo + q] = static_cast<uint16_t>(L.lcnt[row_lo + q] + 1);
+          if (seen & bit) {
+            L.lval[slot] = sps_reduce(L.lval[slot], wt, p.reduce_op);
+            L.lcnt[slot] = static_cast<uint16_t>(L.lcnt[slot] + 1);
           } else {
-            for (int u = len; u > q; --u) {
-              L.lkey[row_lo + u] = L.lkey[row_lo + u - 1];
-              L.lval[row_lo + u] = L.lval[row_lo + u - 1];
-              L.lcnt[row_lo + u] = L.lcnt[row_lo + u - 1];
-            }
-            L.lkey[row_lo + q] = static_cast<uint8_t>(cc);
-            L.lval[row_lo + q] = wt;
-            L.lcnt[row_lo + q] = 1;
-            ++len;
+            seen |= bit;
+            L.lval[slot] = wt;
+            L.lcnt[slot] = 1;
           }
         }
       }
-      // mean, |w| > eps; survivors compacted at the head of the row's slots
-      int m = 0;
-      for (int q = 0; q < len; ++q) {
-        float val = L.lval[row_lo + q];
-        if (has_w && p.reduce_op == TGP_MEAN) val = val / static_cast<float>(L.lcnt[row_lo + q]);
-        if (epsf && !(fabsf(val) > p.eps)) continue;
-        L.lkey[row_lo + m] = L.lkey[row_lo + q];
-        L.lval[row_lo + m] = val;
-        ++m;
+      // mean, |w| > eps: columns that fall out leave the mask (their slots stay where they are)
+      unsigned long long cm = colmask;
+      int slot = row_lo;
+      while (cm) {
+        const int cc = __builtin_ctzll(cm);
+        cm &= cm - 1;
+        float val = L.lval[slot];
+        if (p.reduce_op == TGP_MEAN) {
+          val = val / static_cast<float>(L.lcnt[slot]);
+          L.lval[slot] = val;
+        }
+        if (epsf && !(fabsf(val) > p.eps)) {
+          colmask &= ~(1ull << cc);
+          L.lcnt[slot] = 0;  // marks the slot as dropped for the write pass
+        }
+        ++slot;
       }
-      nrow_keep = m;
     }
-    const uint32_t incl = wave_incl_scan(static_cast<uint32_t>(nrow_keep));
-    row_base = incl - static_cast<uint32_t>(nrow_keep);
+    const uint32_t keepn = __popcll(colmask);
+    const uint32_t incl = wave_incl_scan(keepn);
+    row_base = incl - keepn;
     cnt = __shfl(incl, WAVE - 1, WAVE);
     if (bad) cnt = 0;
   }
 
   // ------------------------------------------------------------------------------ survivors in front of this graph
+  SPS_STAMP(3);
   if (lane == 0) s_cnt[wv] = cnt | (bad ? 0x80000000u : 0u);
   __syncthreads();
-  if (wv == 0) {
+  SPS_STAMP(4);
+  uint32_t tile_tot = 0;
+  bool tile_refused = false;
+  if (wv == 0) {  // the tile's count goes out first: successors only need this word
     const uint32_t mine = lane < WAVES ? s_cnt[lane] : 0u;
-    const uint32_t tot = wave_sum32(mine & 0x7FFFFFFFu);
-    bool refused = __any((mine >> 31) != 0u);
+    tile_tot = wave_sum32(mine & 0x7FFFFFFFu);
+    tile_refused = __any((mine >> 31) != 0u);
+    if (lane == 0)
+      sps_store(p.status + 2 + blockIdx.x, p.tag | (blockIdx.x == 0 ? SPS_PRE : SPS_AGG) |
+                                               (tile_refused ? 0x80000000ull : 0ull) | tile_tot);
+  }
+  // ------------------------------------------------------------------- A1 + A2, while the look-back words travel
+  if (!bad) {
+    if constexpr (MODE == 0) {
+      const bool act = lane < ka;
+      if (ka > 0) {
+        // A1: x_pool[cluster] = 0 + weight * x[node] (one member per supernode); A2: batch_pool[cluster] = graph id
+        if (p.batch_pool && act) p.batch_pool[ci] = g;
+        if (vec) {
+          const int total = ka * F4;
+          for (int base = 0; base < total; base += WAVE) {
+            const int idx = base + lane;
+            const bool on = idx < total;
+            const int a = on ? idx / F4 : 0;
+            const int f = (idx - a * F4) * 4;
+            const int64_t vv = __shfl(v, a, WAVE), cc = __shfl(ci, a, WAVE);
+            const float ww = __shfl(wa, a, WAVE);
+            if (on) {
+              const float4 t = *reinterpret_cast<const float4*>(p.x + vv * p.x_stride + f);
+              float4 o;
+              o.x = __fadd_rn(0.f, __fmul_rn(t.x, ww));
+              o.y = __fadd_rn(0.f, __fmul_rn(t.y, ww));
+              o.z = __fadd_rn(0.f, __fmul_rn(t.z, ww));
+              o.w = __fadd_rn(0.f, __fmul_rn(t.w, ww));
+              *reinterpret_cast<float4*>(p.x_pool + cc * p.F + f) = o;
+            }
+          }
+        } else {
+          const int Fi = static_cast<int>(p.F);
+          const int total = ka * Fi;
+          for (int base = 0; base < total; base += WAVE) {
+            const int idx = base + lane;
+            const bool on = idx < total;
+            const int a = on ? idx / Fi : 0;
+            const int f = idx - a * Fi;
+            const int64_t vv = __shfl(v, a, WAVE), cc = __shfl(ci, a, WAVE);
+            const float ww = __shfl(wa, a, WAVE);
+            if (on) p.x_pool[cc * p.F + f] = __fadd_rn(0.f, __fmul_rn(p.x[vv * p.x_stride + f], ww));
+          }
+        }
+      }
+    } else {
+      if (kc > 0) {
+        // A2 + A1: members in ascending node order, products rounded before the add
+        if (p.batch_pool && lane < kc) p.batch_pool[cmin + lane] = g;
+        const int per = vec ? F4 : static_cast<int>(p.F);
+        const int total = kc * per;
+        for (int base = 0; base < total; base += WAVE) {
+          const int idx = base + lane;
+          const bool on = idx < total;
+          const int rr = on ? idx / per : 0;
+          const int f = (idx - rr * per) * (vec ? 4 : 1);
+          unsigned long long mask = on ? L.mem[rr] : 0ull;
+          float4 acc = {0.f, 0.f, 0.f, 0.f};
+          while (__any(mask != 0ull)) {
+            const int j = mask ? __builtin_ctzll(mask) : 0;
+            const float ww = __shfl(wj, j, WAVE);
+            if (mask) {
+              mask &= mask - 1;
+              const float* src = p.x + (n0 + j) * p.x_stride + f;
+              if (vec) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                acc.x = __fadd_rn(acc.x, __fmul_rn(t.x, ww));
+                acc.y = __fadd_rn(acc.y, __fmul_rn(t.y, ww));
+                acc.z = __fadd_rn(acc.z, __fmul_rn(t.z, ww));
+                acc.w = __fadd_rn(acc.w, __fmul_rn(t.w, ww));
+              } else {
+                acc.x = __fadd_rn(acc.x, __fmul_rn(*src, ww));
+              }
+            }
+          }
+          if (on) {
+            float* dst = p.x_pool + (cmin + rr) * p.F + f;
+            if (vec) *reinterpret_cast<float4*>(dst) = acc;
+            else *dst = acc.x;
+          }
+        }
+      }
+    }
+  }
+  if (wv == 0) {
     const int tile = blockIdx.x;
-    const unsigned long long flag = refused ? 0x80000000ull : 0ull;
-    if (lane == 0) sps_store(p.status + 2 + tile, p.tag | (tile == 0 ? SPS_PRE : SPS_AGG) | flag | tot);
     uint32_t excl = 0;
+    bool refused = tile_refused;
     if (tile > 0) {
       bool before = false;
       sps_lookback(p.status, tile, p.tag, &excl, &before);
       refused = refused || before;
       if (lane == 0)
         sps_store(p.status + 2 + tile, p.tag | SPS_PRE | (refused ? 0x80000000ull : 0ull) |
-                                           static_cast<unsigned long long>((excl + tot) & 0x7FFFFFFFu));
+                                           static_cast<unsigned long long>((excl + tile_tot) & 0x7FFFFFFFu));
     }
     if (lane == 0) {
       s_base = excl;
       s_ok = refused ? 0 : 1;
       if (tile == static_cast<int>(gridDim.x) - 1)  // the verdict and the size of the whole call, in one word
         __hip_atomic_store(p.result, p.tag | (refused ? 0x80000000ull : 0ull) |
-                                         static_cast<unsigned long long>((excl + tot) & 0x7FFFFFFFu),
+                                         static_cast<unsigned long long>((excl + tile_tot) & 0x7FFFFFFFu),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   __syncthreads();
+  SPS_STAMP(5);
   if (!s_ok || bad) return;  // (a refusal seen so far: the outputs will be discarded anyway)
   uint32_t base = s_base;
   for (int w2 = 0; w2 < wv; ++w2) base += s_cnt[w2] & 0x7FFFFFFFu;
@@ -571,27 +690,43 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
       emit(__ballot(keep), r, c, wt);
     }
   } else {
-    const uint32_t o0 = base + row_base;
-    for (int q = 0; q < nrow_keep; ++q) {
-      p.out_row[o0 + q] = cmin + lane;
-      p.out_col[o0 + q] = cmin + L.lkey[row_lo + q];
-      if (has_w) p.out_w[o0 + q] = L.lval[row_lo + q];
+    // the row's surviving columns in ascending order; a weighted row skips the slots the filters emptied
+    uint32_t o = base + row_base;
+    int slot = row_lo;
+    unsigned long long cm = colmask;
+    while (cm) {
+      const int cc = __builtin_ctzll(cm);
+      cm &= cm - 1;
+      if (has_w) {
+        while (L.lcnt[slot] == 0) ++slot;
+        p.out_w[o] = L.lval[slot];
+        ++slot;
+      }
+      p.out_row[o] = cmin + lane;
+      p.out_col[o] = cmin + cc;
+      ++o;
     }
   }
+  SPS_STAMP(6);
 }
 
 }  // namespace tgp
 
 using namespace tgp;
 
-constexpr int SPS_WAVES_TOPK = 16, SPS_WAVES_CLUSTER = 8;
+constexpr int SPS_WAVES_TOPK = 8, SPS_WAVES_CLUSTER = 8;
 
 /* graphs of at most this many nodes are pooled by one wave */
 extern "C" int tgp_sparse_pool_small_max_graph_nodes(void) { return 64; }
 
 extern "C" int64_t tgp_sparse_pool_small_status_words(int64_t num_graphs, int mode) {
   const int waves = mode == 0 ? SPS_WAVES_TOPK : SPS_WAVES_CLUSTER;
-  return 2 + (num_graphs + waves - 1) / waves;
+  const int64_t tiles = (num_graphs + waves - 1) / waves;
+#ifdef TGP_GEMM_STAMPS
+  return 2 + 9 * tiles;
+#else
+  return 2 + tiles;
+#endif
 }
 
 extern "C" int tgp_sparse_pool_small_f32(const float* x, int64_t N, int64_t F, int64_t x_stride, const int64_t* graph_ptr,

@@ -195,39 +195,53 @@ def sparse_pool_small_max_graph_nodes() -> int:
 
 
 def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor],
-                      node_index: Tensor, cluster_index: Tensor, weight: Optional[Tensor], num_supernodes: int,
+                      assign_index: Tensor, weight: Optional[Tensor], num_supernodes: int,
                       mode: int, reduce_op: str = "sum", remove_self_loops: bool = True, want_batch: bool = True):
     """Sparse Reduce + Connect of a sorted batch of graphs of at most 64 nodes in ONE launch
     (reduce/base_reduce.py:14-53,141-155; connect/base_conn.py:79-89; the filters of utils/ops.py:370-380):
     ``(x_pool [K,F], batch_pool [K] or None, edge_index' [2,E'], edge_weight' [E'] or None)``, bit-identical to
     ``reduce_sparse`` + ``reduce_batch_sparse`` + ``filter_edges`` (mode 0) / ``coalesce_edges`` (mode 1).  The pooled
     edges are written once at their final offsets of capacity-E buffers, which are then narrowed: ``edge_index'`` is a
-    view whose two rows are contiguous.  None: a precondition checked on the device does not hold (the caller takes
-    the staged operators)."""
-    dev = N.require_device(x, graph_ptr, edge_index, edge_weight, node_index, cluster_index, weight)
+    view whose two rows are contiguous.  ``assign_index`` [2, nnz] = (node_index, cluster_index), the indices of the
+    sparse S.  None: a precondition checked on the device does not hold (the caller takes the staged operators)."""
+    dev = N.require_device(x, graph_ptr, edge_index, edge_weight, assign_index, weight)
     if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
         raise ValueError("sparse_pool_small expects float32 x [N, F] with unit feature stride")
-    row, col = _edge_rows(edge_index)
-    E = row.numel()
+    # (this wrapper sits in front of a ~10 us kernel: pointers by arithmetic instead of row views, no re-validation of
+    #  what SRCPooling.reduce_connect has checked)
+    ei = edge_index
+    if not (ei.dtype == torch.int64 and ei.dim() == 2 and ei.size(0) == 2 and (ei.stride(1) == 1 or ei.size(1) <= 1)):
+        ei = N.i64c(ei)
+    E = ei.size(1)
+    row_p = ei.data_ptr()
+    col_p = row_p + 8 * ei.stride(0)
     w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
-    ni, ci, gp = N.i64c(node_index), N.i64c(cluster_index), N.i64c(graph_ptr)
+    ai = assign_index
+    if not (ai.dtype == torch.int64 and ai.dim() == 2 and ai.size(0) == 2 and (ai.stride(1) == 1 or ai.size(1) <= 1)):
+        ai = N.i64c(ai)
+    nnz = ai.size(1)
+    ni_p = ai.data_ptr()
+    ci_p = ni_p + 8 * ai.stride(0)
+    gp = N.i64c(graph_ptr)
     wt = None if weight is None else N.f32c(weight.reshape(-1))
     n, F, K, B = x.size(0), x.size(1), int(num_supernodes), gp.numel() - 1
     x_pool = torch.empty(K, F, dtype=torch.float32, device=dev)
     batch_pool = torch.empty(K, dtype=torch.int64, device=dev) if want_batch else None
-    cap = torch.empty(2, max(E, 1), dtype=torch.int64, device=dev)
-    cap_w = None if w is None else torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+    ecap = max(E, 1)
+    cap = torch.empty(2, ecap, dtype=torch.int64, device=dev)
+    cap_w = None if w is None else torch.empty(ecap, dtype=torch.float32, device=dev)
+    cap_p = cap.data_ptr()
     L = N.lib()
     st = N.stream_ptr(dev)
     state = _sps_state(dev, st, L.tgp_sparse_pool_small_status_words(B, mode))
     epoch = state.next_epoch()
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if w is not None else 0)
-    N.check(L.tgp_sparse_pool_small_f32(N.ptr(x), n, F, x.stride(0), N.ptr(gp), B, N.ptr(row) if E else None,
-                                        N.ptr(col) if E else None, N.ptr(w), E, N.ptr(ni), N.ptr(ci), N.ptr(wt),
-                                        ni.numel(), K, mode, N.REDUCE_OPS[reduce_op], flags, ops_eps(), N.ptr(x_pool),
-                                        N.ptr(batch_pool), N.ptr(cap[0]), N.ptr(cap[1]), N.ptr(cap_w),
-                                        N.ptr(state.status), state.status.numel(), state.pinned.data_ptr(), epoch, st),
-            "tgp_sparse_pool_small_f32")
+    N.check(L.tgp_sparse_pool_small_f32(x.data_ptr(), n, F, x.stride(0), gp.data_ptr(), B, row_p if E else None,
+                                        col_p if E else None, N.ptr(w), E, ni_p, ci_p, N.ptr(wt),
+                                        nnz, K, mode, N.REDUCE_OPS[reduce_op], flags, ops_eps(),
+                                        x_pool.data_ptr(), N.ptr(batch_pool), cap_p, cap_p + 8 * ecap, N.ptr(cap_w),
+                                        state.status.data_ptr(), state.status.numel(), state.pinned.data_ptr(), epoch,
+                                        st), "tgp_sparse_pool_small_f32")
     total = state.wait(epoch)  # the call's one host wait (the reference's .item() syncs)
     if total & 0x80000000:
         _sps_remember_declined(edge_index)

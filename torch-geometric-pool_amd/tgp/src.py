@@ -157,17 +157,17 @@ class SRCPooling(torch.nn.Module):
         if (not info.is_sorted or info.num_graphs < 2 or info.max_nodes > K.sparse_pool_small_max_graph_nodes()
                 or K.sparse_pool_small_declined(edge_index)):
             return None
-        ni, ci = so.node_index, so.cluster_index
-        nnz, n = ni.numel(), so.num_nodes
+        index = so.s.indices()  # [2, nnz]: (node_index, cluster_index)
+        nnz, n = index.size(1), so.num_nodes
         if nnz < n:
             mode = 0  # sparse_connect's first branch: kept-node selection (base_conn.py:79-82)
-        elif ci.numel() == n:
+        elif nnz == n:
             mode = 1  # one-over-K clustering (base_conn.py:83-89)
         else:
             return None
         if weight is not None and weight.dtype != torch.float32:
             return None
-        out = K.sparse_pool_small(x, info.ptr, edge_index, ew, ni, ci, weight, so.num_supernodes, mode,
+        out = K.sparse_pool_small(x, info.ptr, edge_index, ew, index, weight, so.num_supernodes, mode,
                                   reduce_op=c.reduce_op, remove_self_loops=c.remove_self_loops)
         if out is None:
             return None
