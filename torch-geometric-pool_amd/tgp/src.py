@@ -153,6 +153,8 @@ class SRCPooling(torch.nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or (ew is not None and ew.requires_grad)
                                         or (weight is not None and weight.requires_grad)):
             return None
+        if torch.cuda.is_current_stream_capturing():
+            return None  # the call waits for its edge count on the host (the staged operators raise for the same reason)
         info = batch_info(batch)
         if (not info.is_sorted or info.num_graphs < 2 or info.max_nodes > K.sparse_pool_small_max_graph_nodes()
                 or K.sparse_pool_small_declined(edge_index)):
