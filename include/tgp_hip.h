@@ -91,6 +91,18 @@ int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t num_feature
                           const int32_t* perm /* NULL = identity */, int64_t nnz,
                           int64_t num_supernodes, float* x_pool /* [K,F] contiguous */, void* stream);
 
+/* A1 for selectors whose supernodes own exactly ONE node (TopK, NDP; r4), with the PACKED index: pack[c] = low word the
+ * int32 source row node_index[a], high word the fp32 weight[a] of supernode c's single assignment a -- one streamed
+ * 8-byte load per supernode instead of perm[c] + two random gathers.  x_pool[c,:] = 0 + weight * x[row,:], the bits of
+ * tgp_reduce_sparse_f32.  tgp_one_to_one_index_build derives perm and pack from (node_index, cluster_index, weight) in
+ * one launch (cluster_index a permutation of 0..k-1); tgp_topk_select emits the pack itself.  F % 4 == 0, F >= 32 and
+ * 16-byte aligned rows (other shapes: tgp_reduce_sparse_f32). */
+int tgp_one_to_one_index_build(const int64_t* node_index, const int64_t* cluster_index,
+                               const float* weight /* NULL = ones */, int64_t k, int32_t* perm /* [k] */,
+                               uint64_t* pack /* [k] */, void* stream);
+int tgp_reduce_one_to_one_f32(const float* x, int64_t num_nodes, int64_t num_features, int64_t x_row_stride,
+                              const uint64_t* pack, int has_weight, int64_t num_supernodes, float* x_pool, void* stream);
+
 /* A2  Reduce.reduce_batch, sparse branch (reduce/base_reduce.py:37-41):
  *     out = arange(K); out[cluster_index[i]] = batch[node_index[i]]                      */
 int tgp_reduce_batch_i64(const int64_t* batch, const int64_t* node_index, const int64_t* cluster_index,
@@ -319,6 +331,8 @@ int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t
                     float* values /* optional [k_total]: score[node_index], the weights of S */,
                     int32_t* lift_row_ptr /* optional [N+1]: CSR offsets of the node -> assignment index (the
                                              transposed index Reduce's backward and Lift walk; its perm is the identity) */,
+                    uint64_t* assign_pack /* optional [k_total]: the packed one-to-one index of
+                                             tgp_reduce_one_to_one_f32, {node id, score} of supernode c */,
                     void* stream);
 
 /* ----------------------------------------------------------------------------------

@@ -291,6 +291,58 @@ __global__ __launch_bounds__(256) void reduce_one_to_one_kernel(
   }
 }
 
+// r4: the same with the PACKED one-to-one index: pack[c] = {int32 source row, fp32 weight} of supernode c's single
+// assignment, written by the selector next to its own outputs (TopkSelect) or by one_to_one_index_kernel.  The kernel
+// above reads perm[c] and then gathers an 8-byte node id and a 4-byte weight at perm[c]: two random 64-byte sectors
+// per supernode (PMC, r3: 70 MB of the 590 MB the TopK Reduce moved at N = 1M) and one more dependent load level in
+// front of the row requests.  Here the index is ONE streamed 8-byte load per supernode.
+template <int G, int U, bool HAS_W>
+__global__ __launch_bounds__(256) void reduce_one_to_one_packed_kernel(
+    const float* __restrict__ x, int64_t F, int64_t x_stride, const uint2* __restrict__ pack, int64_t K,
+    float* __restrict__ x_pool) {
+  constexpr int GROUPS = 256 / G;
+  const int g = threadIdx.x % G;
+  const int64_t group = static_cast<int64_t>(blockIdx.x) * GROUPS + threadIdx.x / G;
+  const int64_t ngroups = static_cast<int64_t>(gridDim.x) * GROUPS;
+  for (int64_t c0 = group; c0 < K; c0 += ngroups * U) {
+    int64_t c[U];
+    uint2 pk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      c[u] = c0 + u * ngroups;
+      pk[u] = pack[c[u] < K ? c[u] : K - 1];
+    }
+    for (int64_t f = 4 * g; f < F; f += 4 * G) {
+      nt_f32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        v[u] = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(x + static_cast<int64_t>(pk[u].x) * x_stride + f));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (c[u] < K) {  // product rounded before the add, as the reference's two-step form
+          const float w = HAS_W ? __uint_as_float(pk[u].y) : 1.0f;
+          nt_f32x4 t = {__fadd_rn(0.f, __fmul_rn(v[u].x, w)), __fadd_rn(0.f, __fmul_rn(v[u].y, w)),
+                        __fadd_rn(0.f, __fmul_rn(v[u].z, w)), __fadd_rn(0.f, __fmul_rn(v[u].w, w))};
+          __builtin_nontemporal_store(t, reinterpret_cast<nt_f32x4*>(x_pool + c[u] * F + f));
+        }
+      }
+    }
+  }
+}
+
+// perm[c] = a, pack[c] = {node_index[a], weight[a]} for the single assignment a of supernode c = cluster_index[a]
+__global__ __launch_bounds__(256) void one_to_one_index_kernel(const int64_t* __restrict__ node_index,
+                                                               const int64_t* __restrict__ cluster_index,
+                                                               const float* __restrict__ weight, int64_t k,
+                                                               int32_t* __restrict__ perm, uint2* __restrict__ pack) {
+  const int64_t a = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (a >= k) return;
+  const int64_t c = cluster_index[a];
+  if (static_cast<uint64_t>(c) >= static_cast<uint64_t>(k)) return;  // (callers validate ids; this keeps the stores in bounds)
+  perm[c] = static_cast<int32_t>(a);
+  pack[c] = make_uint2(static_cast<uint32_t>(node_index[a]), weight ? __float_as_uint(weight[a]) : 0x3F800000u);
+}
+
 // Fallback for feature counts / strides that are not 16-byte friendly: one lane per feature.
 __global__ __launch_bounds__(256) void reduce_sparse_scalar_kernel(
     const float* __restrict__ x, int64_t F, int64_t x_stride, const int64_t* __restrict__ node_index,
@@ -489,6 +541,66 @@ extern "C" int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t 
                        F, x_stride, node_index, weight, row_ptr, perm, K, x_pool);
   }
   return check_launch("tgp_reduce_sparse_f32");
+}
+
+extern "C" int tgp_one_to_one_index_build(const int64_t* node_index, const int64_t* cluster_index, const float* weight,
+                                          int64_t k, int32_t* perm, uint64_t* pack, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(k >= 0, TGP_ERR_INVALID, "tgp_one_to_one_index_build: negative size");
+  if (k == 0) return TGP_OK;
+  TGP_REQUIRE(node_index && cluster_index && perm && pack, TGP_ERR_INVALID, "tgp_one_to_one_index_build: null pointer");
+  TGP_REQUIRE(k < (1ll << 31), TGP_ERR_RANGE, "tgp_one_to_one_index_build: k >= 2^31");
+  hipLaunchKernelGGL(one_to_one_index_kernel, dim3(cdiv(k, 256)), dim3(256), 0, stream, node_index, cluster_index, weight,
+                     k, perm, reinterpret_cast<uint2*>(pack));
+  return check_launch("tgp_one_to_one_index_build");
+}
+
+extern "C" int tgp_reduce_one_to_one_f32(const float* x, int64_t num_nodes, int64_t F, int64_t x_stride,
+                                         const uint64_t* pack, int has_weight, int64_t K, float* x_pool, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(num_nodes >= 0 && F >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_reduce_one_to_one_f32: bad argument");
+  if (K == 0 || F == 0) return TGP_OK;
+  TGP_REQUIRE(x && pack && x_pool, TGP_ERR_INVALID, "tgp_reduce_one_to_one_f32: null pointer");
+  TGP_REQUIRE((F % 4 == 0) && (x_stride % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
+                  (reinterpret_cast<uintptr_t>(x_pool) % 16 == 0) && F >= 32 && num_nodes < (1ll << 32),
+              TGP_ERR_INVALID, "tgp_reduce_one_to_one_f32: needs 16-byte friendly rows of at least 32 features "
+                               "(tgp_reduce_sparse_f32 takes every shape)");
+  const uint2* pk = reinterpret_cast<const uint2*>(pack);
+  const int64_t lanes = F / 4;
+  int G = 8;
+  while (G < lanes && G < 64) G <<= 1;
+  static const int kBlocksPerCu = getenv("TGP_REDUCE_BPC") ? atoi(getenv("TGP_REDUCE_BPC")) : 8;
+  static const int kU = getenv("TGP_REDUCE_O2O") ? atoi(getenv("TGP_REDUCE_O2O")) : 2;
+  const int uu = kU >= 4 ? 4 : (kU >= 2 ? 2 : 1);
+  const int64_t groups_per_block = 256 / G;
+  int64_t blocks = (K + groups_per_block * uu - 1) / (groups_per_block * uu);
+  if (blocks > 256 * kBlocksPerCu) blocks = 256 * kBlocksPerCu;
+  if (blocks < 1) blocks = 1;
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+#define TGP_LAUNCH_P(GG, UU)                                                                                        \
+  do {                                                                                                               \
+    if (has_weight)                                                                                                  \
+      hipLaunchKernelGGL((reduce_one_to_one_packed_kernel<GG, UU, true>), grid, block, 0, stream, x, F, x_stride, pk, \
+                         K, x_pool);                                                                                 \
+    else                                                                                                             \
+      hipLaunchKernelGGL((reduce_one_to_one_packed_kernel<GG, UU, false>), grid, block, 0, stream, x, F, x_stride,   \
+                         pk, K, x_pool);                                                                             \
+  } while (0)
+#define TGP_LAUNCH_PG(GG)                 \
+  do {                                    \
+    if (uu == 1) TGP_LAUNCH_P(GG, 1);     \
+    else if (uu == 2) TGP_LAUNCH_P(GG, 2); \
+    else TGP_LAUNCH_P(GG, 4);             \
+  } while (0)
+  switch (G) {
+    case 8: TGP_LAUNCH_PG(8); break;
+    case 16: TGP_LAUNCH_PG(16); break;
+    case 32: TGP_LAUNCH_PG(32); break;
+    default: TGP_LAUNCH_PG(64); break;
+  }
+#undef TGP_LAUNCH_PG
+#undef TGP_LAUNCH_P
+  return check_launch("tgp_reduce_one_to_one_f32");
 }
 
 extern "C" int tgp_reduce_batch_i64(const int64_t* batch, const int64_t* node_index,

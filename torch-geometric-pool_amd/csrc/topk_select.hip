@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void topk_segsort_wave_fill_kernel(
     const float* __restrict__ score, const int64_t* __restrict__ ptr, const int64_t* __restrict__ k,
     const int64_t* __restrict__ koff, int64_t B, int64_t N, int64_t* __restrict__ node_index,
     int64_t* __restrict__ cluster_index, int32_t* __restrict__ assign_perm, float* __restrict__ values,
-    int32_t* __restrict__ lift_ptr) {
+    int32_t* __restrict__ lift_ptr, uint2* __restrict__ assign_pack) {
   __shared__ int s_inv[4][64];
   const int w = wave_id();
   const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + w;
@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void topk_segsort_wave_fill_kernel(
     node_index[pos] = lo + lane;
     cluster_index[pos] = base + q_of;
     assign_perm[base + q_of] = static_cast<int32_t>(pos);
+    if (assign_pack) assign_pack[base + q_of] = make_uint2(static_cast<uint32_t>(lo + lane), __float_as_uint(sc));
     if (values) values[pos] = sc;
   }
 }
@@ -160,7 +161,8 @@ __global__ __launch_bounds__(T) void topk_segsort_block_kernel(const float* __re
                                                                int64_t* __restrict__ cluster_index,
                                                                int32_t* __restrict__ assign_perm,
                                                                float* __restrict__ values,
-                                                               int32_t* __restrict__ lift_ptr) {
+                                                               int32_t* __restrict__ lift_ptr,
+                                                               uint2* __restrict__ assign_pack) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_v[];
   const int64_t g = blockIdx.x;
   const int64_t lo = ptr[g];
@@ -220,7 +222,11 @@ __global__ __launch_bounds__(T) void topk_segsort_block_kernel(const float* __re
           node_index[pos] = lo + i;
           cluster_index[pos] = base + q;
           assign_perm[base + q] = static_cast<int32_t>(pos);
-          if (values) values[pos] = score[lo + i];
+          if (assign_pack || values) {
+            const float sc = score[lo + i];
+            if (assign_pack) assign_pack[base + q] = make_uint2(static_cast<uint32_t>(lo + i), __float_as_uint(sc));
+            if (values) values[pos] = sc;
+          }
         }
       }
       carry += total;
@@ -251,7 +257,8 @@ __global__ __launch_bounds__(256) void topk_fill_kernel(const int32_t* __restric
                                                         int32_t* __restrict__ assign_perm,
                                                         const float* __restrict__ score,
                                                         float* __restrict__ values,
-                                                        int32_t* __restrict__ lift_ptr) {
+                                                        int32_t* __restrict__ lift_ptr,
+                                                        uint2* __restrict__ assign_pack) {
   __shared__ uint32_t s_cnt[kTopkItems * 4];
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kTopkTile;
   bool flag[kTopkItems];
@@ -284,7 +291,12 @@ __global__ __launch_bounds__(256) void topk_fill_kernel(const int32_t* __restric
     node_index[j] = base + it * 256 + threadIdx.x;
     cluster_index[j] = r[it];
     assign_perm[r[it]] = static_cast<int32_t>(j);
-    if (values) values[j] = score[base + it * 256 + threadIdx.x];
+    if (assign_pack || values) {
+      const float sc = score[base + it * 256 + threadIdx.x];
+      if (assign_pack)
+        assign_pack[r[it]] = make_uint2(static_cast<uint32_t>(base + it * 256 + threadIdx.x), __float_as_uint(sc));
+      if (values) values[j] = sc;
+    }
   }
 }
 
@@ -619,8 +631,9 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
                                const int64_t* k, const int64_t* koff, int64_t segments_max_nodes, void* ws,
                                size_t ws_bytes,
                                int64_t* node_index, int64_t* cluster_index, int32_t* assign_perm, float* values,
-                               int32_t* lift_row_ptr, void* stream_) {
+                               int32_t* lift_row_ptr, uint64_t* assign_pack_, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  uint2* assign_pack = reinterpret_cast<uint2*>(assign_pack_);
   TGP_REQUIRE(N >= 0 && B >= 0, TGP_ERR_INVALID, "tgp_topk_select: negative size");
   if (N == 0 || B == 0) return TGP_OK;
   TGP_REQUIRE(N < (1ll << 31), TGP_ERR_RANGE, "tgp_topk_select: more than 2^31 nodes");
@@ -631,7 +644,7 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
   const int nb256 = cdiv(N, 256), nbt = cdiv(N, kTopkTile);
   if (segments_max_nodes > 0 && segments_max_nodes <= 64 && node_index) {
     hipLaunchKernelGGL(topk_segsort_wave_fill_kernel, dim3(cdiv(B, 4)), dim3(256), 0, stream, score, ptr, k, koff, B, N,
-                       node_index, cluster_index, assign_perm, values, lift_row_ptr);
+                       node_index, cluster_index, assign_perm, values, lift_row_ptr, assign_pack);
     return check_launch("tgp_topk_select");
   }
   if (segments_max_nodes > 64 && segments_max_nodes <= kSegSortLarge && node_index) {  // the same, one workgroup per graph
@@ -641,13 +654,13 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
     if (segments_max_nodes <= kSegSortMax) {
       hipLaunchKernelGGL((topk_segsort_block_kernel<256, true>), dim3(static_cast<unsigned>(B)), dim3(256), lds, stream,
                          score, ptr, k, koff, s.rank_of, B, N, node_index, cluster_index, assign_perm, values,
-                         lift_row_ptr);
+                         lift_row_ptr, assign_pack);
     } else {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_segsort_block_kernel<1024, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
       hipLaunchKernelGGL((topk_segsort_block_kernel<1024, true>), dim3(static_cast<unsigned>(B)), dim3(1024), lds, stream,
                          score, ptr, k, koff, s.rank_of, B, N, node_index, cluster_index, assign_perm, values,
-                         lift_row_ptr);
+                         lift_row_ptr, assign_pack);
     }
     return check_launch("tgp_topk_select");
   }
@@ -658,7 +671,7 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
   } else if (segments_max_nodes > 0 && segments_max_nodes <= kSegSortMax) {
     hipLaunchKernelGGL((topk_segsort_block_kernel<256, false>), dim3(static_cast<unsigned>(B)), dim3(256),
                        kSegSortMax * sizeof(unsigned long long), stream, score, ptr, k, koff, s.rank_of, B, N,
-                       node_index, cluster_index, assign_perm, values, lift_row_ptr);
+                       node_index, cluster_index, assign_perm, values, lift_row_ptr, assign_pack);
   } else if (segments_max_nodes > 0 && segments_max_nodes <= kSegSortLarge) {
     int m = 64;
     while (m < segments_max_nodes) m <<= 1;
@@ -667,7 +680,7 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     hipLaunchKernelGGL((topk_segsort_block_kernel<1024, false>), dim3(static_cast<unsigned>(B)), dim3(1024), lds, stream,
                        score, ptr, k, koff, s.rank_of, B, N, node_index, cluster_index, assign_perm, values,
-                       lift_row_ptr);
+                       lift_row_ptr, assign_pack);
   } else {
     hipLaunchKernelGGL(topk_keys_kernel, dim3(nb256), dim3(256), 0, stream, score, batch, N, s.k0, s.v0);
     bool first = true;
@@ -682,7 +695,7 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
                      static_cast<const int*>(nullptr));
   if (node_index)
     hipLaunchKernelGGL(topk_fill_kernel, dim3(nbt), dim3(256), 0, stream, s.rank_of, N, s.offsets, node_index,
-                       cluster_index, assign_perm, score, values, lift_row_ptr);
+                       cluster_index, assign_perm, score, values, lift_row_ptr, assign_pack);
   return check_launch("tgp_topk_select");
 }
 

@@ -93,7 +93,9 @@ SIGNATURES = {
     "tgp_topk_plan": (_c_int, [_c_p, _c_i64, ctypes.c_double, _c_p, _c_p, _c_p]),
     "tgp_topk_select_workspace_bytes": (_c_sz, [_c_i64]),
     "tgp_topk_select": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_sz, _c_p, _c_p, _c_p,
-                                 _c_p, _c_p, _c_p]),
+                                 _c_p, _c_p, _c_p, _c_p]),
+    "tgp_one_to_one_index_build": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p]),
+    "tgp_reduce_one_to_one_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_int, _c_i64, _c_p, _c_p]),
     "tgp_topk_minscore_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
     "tgp_topk_minscore_count": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_f, _c_f, _c_p, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_topk_minscore_fill": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),

@@ -31,7 +31,7 @@ class AssignIndex:
     """Inverted index of a sparse assignment (supernode -> its assignments, in ascending
     assignment order).  A function of the SelectOutput only, so SelectOutput caches it."""
 
-    __slots__ = ("_row_ptr", "perm", "nnz", "num_targets", "_device")
+    __slots__ = ("_row_ptr", "perm", "nnz", "num_targets", "_device", "pack", "pack_key")
 
     def __init__(self, row_ptr: Optional[Tensor], perm: Optional[Tensor], nnz: int, num_targets: int, device=None):
         # row_ptr None: exactly one assignment per target (TopK, NDP) -- the table is arange and the Reduce kernel
@@ -43,6 +43,11 @@ class AssignIndex:
         if perm is None and device is None and row_ptr is None:
             raise ValueError("an AssignIndex without perm and row_ptr must name its device")
         self._row_ptr, self.perm, self.nnz, self.num_targets = row_ptr, perm, nnz, num_targets
+        # one-to-one indices (TopK, NDP) may carry the PACKED form: pack[c] = {int32 source row, fp32 weight} of target
+        # c's single assignment (int64 words), valid for exactly the (source_index, weight) storage named by pack_key =
+        # (source_index.data_ptr(), weight.data_ptr() or 0).  It is a snapshot of the selector's own output: like the
+        # inverted index itself it is not refreshed if a caller edits S's indices / values in place afterwards.
+        self.pack, self.pack_key = None, None
         self._device = perm.device if perm is not None else (row_ptr.device if row_ptr is not None else
                                                               torch.device(device))
 
@@ -86,11 +91,35 @@ def reduce_sparse(x: Tensor, source_index: Tensor, weight: Optional[Tensor], ind
     w = None if weight is None else N.f32c(weight.reshape(-1))
     F = x2.size(1)
     out = torch.empty(index.num_targets, F, dtype=torch.float32, device=dev)
+    if (index.pack is not None and index.pack_key == (source_index.data_ptr(), 0 if w is None else w.data_ptr())
+            and F % 4 == 0 and F >= 32 and x2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0):
+        # one node per target (TopK, NDP): the packed index, one streamed 8-byte load per pooled row
+        N.check(N.lib().tgp_reduce_one_to_one_f32(N.ptr(x2), x2.size(0), F, x2.stride(0), N.ptr(index.pack),
+                                                  0 if w is None else 1, index.num_targets, N.ptr(out),
+                                                  N.stream_ptr(dev)), "tgp_reduce_one_to_one_f32")
+        return out.view(-1) if squeeze else out
     N.check(N.lib().tgp_reduce_sparse_f32(N.ptr(x2), x2.size(0), F, x2.stride(0), N.ptr(source_index), N.ptr(w),
                                           N.ptr(index._row_ptr), N.ptr(index.perm), index.nnz,
                                           index.num_targets, N.ptr(out), N.stream_ptr(dev)),
             "tgp_reduce_sparse_f32")
     return out.view(-1) if squeeze else out
+
+
+def one_to_one_index(node_index: Tensor, cluster_index: Tensor, weight: Optional[Tensor]) -> AssignIndex:
+    """Inverted index of an assignment whose supernodes own exactly one node each (cluster_index a permutation of
+    0..k-1: TopK, NDP): perm = the inverse permutation, plus the packed {source row, weight} form the Reduce kernel
+    streams -- one launch, no sort (select/base_select.py:58 keeps the assignment node-sorted)."""
+    dev = N.require_device(node_index, cluster_index, weight)
+    ni, ci = N.i64c(node_index), N.i64c(cluster_index)
+    w = None if weight is None else N.f32c(weight.reshape(-1))
+    k = ci.numel()
+    perm = torch.empty(max(k, 1), dtype=torch.int32, device=dev)
+    pack = torch.empty(max(k, 1), dtype=torch.int64, device=dev)
+    N.check(N.lib().tgp_one_to_one_index_build(N.ptr(ni), N.ptr(ci), N.ptr(w), k, N.ptr(perm), N.ptr(pack),
+                                               N.stream_ptr(dev)), "tgp_one_to_one_index_build")
+    index = AssignIndex(None, perm, k, k)
+    index.pack, index.pack_key = pack, (ni.data_ptr(), 0 if w is None else w.data_ptr())
+    return index
 
 
 def reduce_batch_sparse(batch: Tensor, node_index: Tensor, cluster_index: Tensor, num_supernodes: int,
@@ -798,6 +827,8 @@ def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Te
     index = torch.empty(2, k_total, dtype=torch.int64, device=dev)  # the indices of the sparse S, written in place
     values = torch.empty(k_total, dtype=torch.float32, device=dev) if with_values else None
     perm = torch.empty(max(k_total, 1), dtype=torch.int32, device=dev)
+    # the packed one-to-one index {node, score} the sparse Reduce streams (when the scores ARE the weights of S)
+    pack = torch.empty(max(k_total, 1), dtype=torch.int64, device=dev) if with_values else None
     lift_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev) if with_lift and n > 0 else None
     with_lift = lift_ptr is not None
     L = N.lib()
@@ -805,8 +836,10 @@ def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Te
     N.check(L.tgp_topk_select(N.ptr(score), N.ptr(None if batch is None else N.i64c(batch)), n, num_graphs,
                               N.ptr(N.i64c(ptr)), N.ptr(N.i64c(k)), N.ptr(N.i64c(koff)), segments_max_nodes, N.ptr(ws),
                               ws.numel(), N.ptr(index[0]), N.ptr(index[1]), N.ptr(perm), N.ptr(values),
-                              N.ptr(lift_ptr), N.stream_ptr(dev)), "tgp_topk_select")
+                              N.ptr(lift_ptr), N.ptr(pack), N.stream_ptr(dev)), "tgp_topk_select")
     assign = AssignIndex(None, perm, k_total, k_total)
+    if pack is not None and k_total > 0 and n < (1 << 31):
+        assign.pack, assign.pack_key = pack, (index.data_ptr(), values.data_ptr())
     out = (index, assign) + ((values,) if with_values else ())
     return out + ((AssignIndex(lift_ptr, None, k_total, n),) if with_lift else ())
 

@@ -287,9 +287,14 @@ class SelectOutput:
         k = self.num_supernodes
         if not ci.is_cuda or ci.numel() != k:
             return
-        perm = torch.empty(max(k, 1), dtype=torch.int32, device=ci.device)
-        perm[ci] = torch.arange(k, dtype=torch.int32, device=ci.device)
-        self._assign_index = kernels.AssignIndex(None, perm, k, k)
+        w = self.weight
+        if w is not None and (w.dtype != torch.float32 or w.requires_grad):
+            w = None  # (the packed form snapshots the weights: only for the plain fp32 values of S)
+            perm = torch.empty(max(k, 1), dtype=torch.int32, device=ci.device)
+            perm[ci] = torch.arange(k, dtype=torch.int32, device=ci.device)
+            self._assign_index = kernels.AssignIndex(None, perm, k, k)
+            return
+        self._assign_index = kernels.one_to_one_index(self.node_index, ci, w)  # perm + packed {row, weight}: one launch
 
     # ---- tensor plumbing (reference base_select.py:313-379) ---------------------------
     def __repr__(self) -> str:
