@@ -684,7 +684,7 @@ class SparseReduceOnly(Workload):
         # row + node_index + perm (+ weight) per assignment; no row_ptr table to read (one-to-one)
         alg = k * (4.0 * f + 8 + 4 + (4 if so.weight is not None else 0)) + k * 4.0 * f
         ms = event_time_ms(lambda: kernels.reduce_sparse(self.x, so.node_index, so.weight, idx), 50, dev)
-        return roof_hbm("tgp::reduce_one_to_one_kernel (gather-scale, one assignment per supernode)", alg, ms,
+        return roof_hbm("tgp::reduce_one_to_one_packed_kernel (gather-scale, one assignment per supernode, packed index)", alg, ms,
                         f"reduce_one_to_one_kernel:{self.which}")
 
 

@@ -30,7 +30,7 @@
  *     (utils/ops.py:72,318,377,395; utils/losses.py:498; tests monkeypatch it), so it is an argument of every
  *     entry point that filters or clamps with it, never a compiled-in constant.
  *   - *d_count < 0 is a refusal, not a size: -1 = this fast path declines (preconditions not met: the caller
- *     takes its general route), -2 = bad input (a node id outside [0, num_nodes) or a cluster id outside
+ *     takes its general route; -3 / -5: declines that name the entry point to call instead, see there), -2 = bad input (a node id outside [0, num_nodes) or a cluster id outside
  *     [0, num_supernodes): never dereferenced; the reference's index ops raise for it too).
  *   - return value 0 = ok; otherwise a negative tgp_status and tgp_last_error() holds a
  *     thread-local message.  No exceptions cross the boundary; no global mutable state.
@@ -67,7 +67,9 @@ enum tgp_flags {
   TGP_EPS_FILTER = 16,       /* sparse: drop |w| <= 1e-8 when weights are given (ops.py:374-380) */
   TGP_ADJ_TRANSPOSED = 32,   /* dense: A is handed over as the transposed view (src.py:442-443) */
   TGP_NODE_FILTER = 64,      /* subgraph_fill: node_index was given to the matching _count call */
-  TGP_WANT_EDGE_ID = 128     /* subgraph_count + _fill: also stage / emit the input position of every kept edge */
+  TGP_WANT_EDGE_ID = 128,    /* subgraph_count + _fill: also stage / emit the input position of every kept edge */
+  TGP_HUGE_ROWS = 256        /* coalesce_rows_count: supernode rows beyond 1024 raw entries (hubs) are sorted device-wide
+                                instead of declining the call (workspace: ..._rows_huge_workspace_bytes) */
 };
 
 int tgp_version(void);
@@ -150,9 +152,13 @@ int tgp_connect_coalesce_fill(const void* ws, int64_t num_edges, int64_t num_nod
  * supernode row through the CSR of the input and the supernode->member index of the assignment
  * (assign_row_ptr / assign_perm = what tgp_assign_index_build returns for cluster_index), then every short
  * row segment is ordered by column, merged and filtered inside LDS.  Same output as the sort-based pair
- * above.  If the rows are not sorted, or a block of 256 supernode rows exceeds the LDS budget, *d_count is
- * set to -1 and the caller uses tgp_connect_coalesce_{count,fill} instead. */
+ * above.  If the rows are not sorted *d_count is set to -1 and the caller uses tgp_connect_coalesce_{count,fill}
+ * instead.  A supernode row of more than 1024 raw entries (a hub of a power-law graph): *d_count = -5 unless
+ * TGP_HUGE_ROWS is in `flags` (r4) -- then the entries of such rows alone go through a device-wide stable sort (at most
+ * 4096 of them per call, else -1) while every other row stays in LDS, and `ws` must hold
+ * tgp_connect_coalesce_rows_huge_workspace_bytes(); the matching _fill call takes the same workspace. */
 size_t tgp_connect_coalesce_rows_workspace_bytes(int64_t num_edges, int64_t num_nodes, int64_t num_supernodes);
+size_t tgp_connect_coalesce_rows_huge_workspace_bytes(int64_t num_edges, int64_t num_nodes, int64_t num_supernodes);
 int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
                                     int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,
                                     int64_t num_supernodes, const int32_t* assign_row_ptr,

@@ -214,3 +214,78 @@ def test_sparse_pool_small_c3_sized_batch_and_empty_graphs(dev):
                     assert fused is not None
                     for a, b in zip(fused, staged):
                         assert _same(a, b)
+
+
+# ------------------------------------------------------------------------------ hub rows in the row-local coalesce
+def _hub_graph(n, pairs, hubs, hub_deg, seed):
+    """Undirected, row-major sorted, duplicate-free edge list with `hubs` nodes of ~hub_deg neighbours each."""
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randint(0, n, (pairs,), generator=g)
+    b = torch.randint(0, n, (pairs,), generator=g)
+    hub_ids = torch.randperm(n, generator=g)[:hubs]
+    ha = hub_ids.repeat_interleave(hub_deg)
+    hb = torch.randint(0, n, (hubs * hub_deg,), generator=g)
+    a, b = torch.cat([a, ha]), torch.cat([b, hb])
+    keep = a != b
+    a, b = a[keep], b[keep]
+    key = torch.unique(torch.cat([a * n + b, b * n + a]))
+    return torch.stack([key // n, key % n]), hub_ids
+
+
+@pytest.mark.parametrize("weighted", [True, False])
+@pytest.mark.parametrize("op", ["sum", "mean", "min", "max", "mul"])
+def test_rowlocal_coalesce_hub_rows_equal_the_radix_route(dev, weighted, op):
+    """Supernode rows of 100 000 raw entries (hubs) inside a row-sorted list: the row-local route sorts those rows
+    device-wide (TGP_HUGE_ROWS) and keeps every other row in LDS -- same edges, same weights (bit for bit: duplicates are
+    folded in input order on both routes) as the general radix route and the oracle (connect/base_conn.py:83-89)."""
+    import tgp_oracle as O
+    from tgp import kernels
+    n = 120_000
+    ei, hub_ids = _hub_graph(n, 200_000, 5, 100_000, 41)
+    g = torch.Generator().manual_seed(42)
+    # pairs (Graclus-shaped) + a few clusters of many nodes; hubs are paired with each other -> rows of ~2 x 100 000
+    perm = torch.randperm(n, generator=g)
+    cluster = torch.empty(n, dtype=torch.long)
+    cluster[perm] = torch.arange(n) // 2
+    cluster[perm[:3000]] = 7          # one cluster of 3000 ordinary nodes: a long row made of many short members
+    cluster[hub_ids[:2]] = 11         # two hubs in one supernode
+    k = int(cluster.max()) + 1
+    ew = (torch.rand(ei.size(1), generator=g) - 0.3) if weighted else None
+    ei_d, cl_d = ei.to(dev), cluster.to(dev)
+    ew_d = None if ew is None else ew.to(dev)
+    idx = kernels.build_assign_index(cl_d, k)
+    got_ei, got_ew = kernels.coalesce_edges(ei_d, ew_d, cl_d, k, op, True, assign_index=idx, route="staged")
+    ref_ei, ref_ew = kernels.coalesce_edges(ei_d, ew_d, cl_d, k, op, True, route="general")
+    assert torch.equal(got_ei, ref_ei)
+    assert (got_ew is None) == (ref_ew is None)
+    if got_ew is not None:
+        assert torch.equal(got_ew, ref_ew)
+    # a second call on the same edge_index object asks for the hub kernels at once (no -5 round trip) and agrees
+    again_ei, again_ew = kernels.coalesce_edges(ei_d, ew_d, cl_d, k, op, True, assign_index=idx)
+    assert torch.equal(again_ei, ref_ei) and (again_ew is None or torch.equal(again_ew, ref_ew))
+    if op == "sum":
+        o_ei, o_ew = O.sparse_connect(ei, ew, torch.arange(n), cluster, n, k, reduce_op=op)
+        assert torch.equal(got_ei.cpu(), o_ei)
+        if o_ew is not None:
+            torch.testing.assert_close(got_ew.cpu(), o_ew, rtol=1e-5, atol=1e-5)
+
+
+def test_graclus_pooler_on_a_hub_graph_stays_on_the_rowlocal_route(dev):
+    """Whole `graclus` forward on a graph with hub nodes: the Connect no longer falls to the radix route for one long
+    supernode row, and the result equals the oracle's Reduce + Connect given the same clustering."""
+    import tgp_oracle as O
+    from tgp import kernels
+    from tgp.poolers import get_pooler
+    n = 60_000
+    ei, _ = _hub_graph(n, 150_000, 4, 30_000, 7)
+    x = torch.randn(n, 16, generator=torch.Generator().manual_seed(1))
+    pooler = get_pooler("graclus").to(dev).eval()
+    calls = []
+    orig = kernels.N.lib().tgp_connect_coalesce_count
+    with torch.no_grad():
+        out = pooler(x=x.to(dev), adj=ei.to(dev))
+    assert id(ei) not in kernels._HUB_ROWS  # (the memo is keyed by the DEVICE tensor the pooler saw)
+    ref = O.cluster_pool(x, ei, None, None, out.so.cluster_index.cpu(), out.so.num_supernodes)
+    assert torch.equal(out.edge_index.cpu(), ref["edge_index"])
+    torch.testing.assert_close(out.x.cpu(), ref["x"], rtol=1e-5, atol=1e-5)
+    del calls, orig

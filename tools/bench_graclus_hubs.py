@@ -21,3 +21,14 @@ for hubs, deg in ((0, 0), (10, 100_000), (100, 10_000)):
     ew = torch.ones(ei.size(1), device=dev)
     f = lambda: K.graclus_match(ei, ew, n)
     print(f"hubs {hubs} x deg {deg}: E = {ei.size(1)}, graclus_match {wall(f, 5):.3f} ms", flush=True)
+    # whole `graclus` forward (GraclusSelect + Reduce + coalesce Connect): r3 sent the whole list to the radix route for
+    # one supernode row beyond 1024 entries (3.2 ms with ten hubs against 0.92 ms without); r4 sorts those rows alone
+    from tgp.poolers import get_pooler
+    x = torch.randn(n, 128, device=dev, generator=g)
+    pooler = get_pooler("graclus").to(dev).eval()
+    def fwd():
+        with torch.no_grad():
+            return pooler(x=x, adj=ei, edge_weight=ew)
+    out = fwd()
+    print(f"    whole graclus forward {wall(fwd, 5):.3f} ms, pooled edges {out.edge_index.size(1)}, "
+          f"hub kernels {'on' if id(ei) in K._HUB_ROWS else 'off'}", flush=True)

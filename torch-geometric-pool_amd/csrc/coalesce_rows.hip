@@ -172,14 +172,28 @@ __global__ __launch_bounds__(256) void cr_member_scan_kernel(const int32_t* __re
 
 // raw_off[r] = first slot of supernode row r = first slot of its first member (an empty row shares its successor's);
 // a row longer than the LDS sort takes declines the call before the heavy kernel runs.
+// A row beyond CR_LONG entries (a hub): listed for the huge-row kernels below when the caller asked for them
+// (huge_list != NULL: TGP_HUGE_ROWS), else the call declines with status 8 (d_count = -5).
+constexpr int HUGE_MAX = 4096;  // huge rows per call (beyond: decline to the radix routes)
 __global__ __launch_bounds__(256) void cr_raw_off_kernel(const int32_t* __restrict__ a_row_ptr, int64_t K,
                                                          const uint32_t* __restrict__ seg_dst, int* __restrict__ bad,
-                                                         uint32_t* __restrict__ raw_off) {
+                                                         uint32_t* __restrict__ raw_off,
+                                                         uint32_t* __restrict__ huge_list,
+                                                         uint32_t* __restrict__ n_out) {
   const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (r >= K || (*bad & 1)) return;
   const uint32_t lo = seg_dst[a_row_ptr[r]], hi = seg_dst[a_row_ptr[r + 1]];
   raw_off[r] = lo;
-  if (hi - lo > static_cast<uint32_t>(CR_LONG)) *bad = 2;
+  if (hi - lo > static_cast<uint32_t>(CR_LONG)) {
+    if (!huge_list) {
+      atomicOr(bad, 8);
+    } else {
+      const int idx = atomicAdd(bad + 2, 1);
+      if (idx < HUGE_MAX) huge_list[idx] = static_cast<uint32_t>(r);
+      else atomicOr(bad, 2);
+      n_out[r] = 0;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ K5
@@ -427,8 +441,12 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
   int rs = 0;
   while (rs < nrows) {
     if (s_roff[rs + 1] - s_roff[rs] > static_cast<uint32_t>(CR_LONG)) {  // a supernode row too long for the LDS sort
-      if (tid == 0) *bad = 2;
-      return;
+      if constexpr (DIRECT) {  // the grouped route has no huge-row kernels: decline to the general route
+        if (tid == 0) *bad = 2;
+        return;
+      }
+      ++rs;      // listed by cr_raw_off_kernel for the huge-row kernels (or the call has declined already: status 8);
+      continue;  // its slots of tmp and its n_out entry are theirs
     }
     int re = rs + 1;
     if (s_roff[nrows] - s_roff[rs] <= static_cast<uint32_t>(GS_CAP)) {
@@ -571,7 +589,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
         // (long rows are listed for cr_rows_long_kernel, which spreads the list over its workgroups: hub supernodes sit
         //  next to each other -- the first nodes of a preferential-attachment graph -- and a workgroup per 256 rows that
         //  sorted its own long rows one after the other took 150 us for a 4500-node batch with a dozen hubs)
-        if (i < re && T > 64 && (tid & (LPR - 1)) == 0)
+        if (i < re && T > 64 && T <= static_cast<uint32_t>(CR_LONG) && (tid & (LPR - 1)) == 0)
           long_list[atomicAdd(bad + 1, 1)] = static_cast<uint32_t>(r0 + i);
         const bool mine = i < re && T <= 32;
         cr_sort_rows<LPR>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), has_w, reduce_op, flags,
@@ -681,6 +699,156 @@ __global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict_
     }
     if (tid == 0) n_out[r] = total;
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ huge rows (r4)
+// Supernode rows beyond CR_LONG raw entries -- the hubs of a power-law graph -- used to send the WHOLE list to the radix
+// routes (r3: `graclus` forward on a 1M-node graph with ten 100 000-entry hubs 3.2 ms against 0.92 ms without).  Now
+// only THEIR entries are sorted device-wide: the rows are listed, their raw entries gathered as (row rank : cluster
+// column) keys with the input position as payload, sorted by the stable LSD radix sort of primitives.h (element count
+// on the device), run heads fold their run in input order with the A6 filters fused, a scan ranks the survivors inside
+// their row, and they land compacted at the head of the row's slots of tmp with n_out[r] set -- exactly what the LDS
+// kernels leave for every other row, so the survivor scan and the fill take it from there.  Same output as the radix
+// routes (tests compare both).
+struct HugeWs {
+  uint32_t* list;    // [HUGE_MAX] rows
+  uint32_t* hoff;    // [HUGE_MAX + 1] first sub-list entry of every listed row; hoff[nh] = H
+  uint64_t *k0, *k1;
+  uint32_t *v0, *v1;
+  float* sub_w;      // weights by sub-list position
+  uint32_t* flags;   // keep flags of the sorted entries (zero behind H)
+  uint32_t* ranks;   // their exclusive scan
+  float* mval;       // merged weight of every run head
+  uint32_t* sort_scratch;
+  uint32_t* scan_scratch;
+  int64_t* total;
+};
+
+__global__ __launch_bounds__(1024) void cr_huge_offsets_kernel(const uint32_t* __restrict__ list,
+                                                               const uint32_t* __restrict__ raw_off, int64_t K,
+                                                               int64_t E, int* __restrict__ bad,
+                                                               uint32_t* __restrict__ hoff) {
+  __shared__ uint32_t s_w[16];
+  __shared__ uint32_t s_carry;
+  if (bad[0] & ~8) return;
+  const int nh = bad[2] < HUGE_MAX ? bad[2] : HUGE_MAX;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nh; base += 1024) {
+    const int li = base + static_cast<int>(threadIdx.x);
+    uint32_t T = 0;
+    if (li < nh) {
+      const int64_t r = list[li];
+      T = (r + 1 < K ? raw_off[r + 1] : static_cast<uint32_t>(E)) - raw_off[r];
+    }
+    const uint32_t inc = wave_incl_scan(T);
+    if (lane_id() == WAVE - 1) s_w[wave_id()] = inc;
+    __syncthreads();
+    uint32_t off = s_carry, tot = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t c = s_w[j];
+      if (j < wave_id()) off += c;
+      tot += c;
+    }
+    if (li < nh) hoff[li] = off + inc - T;
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    hoff[nh] = s_carry;
+    bad[3] = static_cast<int>(s_carry);  // H: the sort's element count
+  }
+}
+
+// (raw_off[r + 1] is not the end of row r when r + 1 is an EMPTY row's shared offset -- it is: an empty row shares its
+//  successor's first slot, so the difference is still row r's length)
+__global__ __launch_bounds__(256) void cr_huge_gather_kernel(
+    const int64_t* __restrict__ col, const float* __restrict__ w, const int32_t* __restrict__ table,
+    const int32_t* __restrict__ a_row_ptr, const uint32_t* __restrict__ seg_src, const uint32_t* __restrict__ seg_dst,
+    const uint32_t* __restrict__ raw_off, const uint32_t* __restrict__ list, const uint32_t* __restrict__ hoff,
+    int64_t n_nodes, int colbits, int* __restrict__ bad, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+    float* __restrict__ sub_w) {
+  if (bad[0] & ~8) return;
+  const int nh = bad[2] < HUGE_MAX ? bad[2] : HUGE_MAX;
+  for (int li = 0; li < nh; ++li) {
+    const int64_t r = list[li];
+    const uint32_t b = raw_off[r], h0 = hoff[li], T = hoff[li + 1] - h0;
+    const int p0 = a_row_ptr[r], p1 = a_row_ptr[r + 1];
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < T; t += gridDim.x * 256) {
+      const uint32_t slot = b + t;
+      int lo = p0, hi = p1;  // last member p with seg_dst[p] <= slot (members without edges share their successor's)
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (seg_dst[mid] <= slot) lo = mid; else hi = mid;
+      }
+      const uint32_t e = seg_src[lo] + (slot - seg_dst[lo]);
+      const int64_t c = col[e];
+      const bool inr = static_cast<uint64_t>(c) < static_cast<uint64_t>(n_nodes);
+      if (!inr) *bad = 4;
+      const uint64_t cl = inr ? static_cast<uint32_t>(table[c]) : 0u;
+      keys[h0 + t] = (static_cast<uint64_t>(li) << colbits) | cl;
+      vals[h0 + t] = h0 + t;
+      sub_w[h0 + t] = w ? w[e] : 0.f;
+    }
+  }
+}
+
+// run heads of the sorted sub-list fold their run (input order: the sort is stable and the payload is the position)
+__global__ __launch_bounds__(256) void cr_huge_merge_kernel(const uint64_t* __restrict__ keys,
+                                                            const uint32_t* __restrict__ vals,
+                                                            const float* __restrict__ sub_w, int has_w,
+                                                            const uint32_t* __restrict__ list, int colbits,
+                                                            int reduce_op, int flags, float eps,
+                                                            const int* __restrict__ bad, int64_t n_max,
+                                                            uint32_t* __restrict__ keep, float* __restrict__ mval) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n_max) return;
+  const int64_t H = (bad[0] & ~8) ? 0 : bad[3];
+  uint32_t k = 0;
+  if (i < H) {
+    const uint64_t key = keys[i];
+    if (i == 0 || keys[i - 1] != key) {
+      float acc = has_w ? sub_w[vals[i]] : 0.f;
+      uint32_t cnt = 1;
+      for (int64_t q = i + 1; q < H && keys[q] == key; ++q, ++cnt)
+        if (has_w) acc = cr_reduce(acc, sub_w[vals[q]], reduce_op);
+      if (has_w && reduce_op == TGP_MEAN) acc = acc / static_cast<float>(cnt);
+      const uint32_t c = static_cast<uint32_t>(key & ((1ull << colbits) - 1ull));
+      const uint32_t r = list[key >> colbits];
+      k = 1;
+      if ((flags & TGP_REMOVE_SELF_LOOPS) && c == r) k = 0;
+      if (has_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > eps)) k = 0;
+      mval[i] = acc;
+    }
+  }
+  keep[i] = k;
+}
+
+__global__ __launch_bounds__(256) void cr_huge_write_kernel(const uint64_t* __restrict__ keys,
+                                                            const uint32_t* __restrict__ keep,
+                                                            const uint32_t* __restrict__ ranks,
+                                                            const float* __restrict__ mval,
+                                                            const uint32_t* __restrict__ list,
+                                                            const uint32_t* __restrict__ hoff,
+                                                            const uint32_t* __restrict__ raw_off, int colbits,
+                                                            const int* __restrict__ bad, const int64_t* __restrict__ total,
+                                                            int64_t n_max, uint32_t* __restrict__ tmp_c,
+                                                            float* __restrict__ tmp_w, uint32_t* __restrict__ n_out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if ((bad[0] & ~8) || i >= bad[3]) return;
+  const uint64_t key = keys[i];
+  const uint32_t li = static_cast<uint32_t>(key >> colbits);
+  const uint32_t h0 = hoff[li], h1 = hoff[li + 1];
+  const uint32_t first = ranks[h0];
+  const int64_t r = list[li];
+  if (i == h0) n_out[r] = (h1 < n_max ? ranks[h1] : static_cast<uint32_t>(*total)) - first;
+  if (keep[i]) {
+    const uint32_t dst = raw_off[r] + (ranks[i] - first);
+    tmp_c[dst] = static_cast<uint32_t>(key & ((1ull << colbits) - 1ull));
+    if (tmp_w) tmp_w[dst] = mval[i];
   }
 }
 
@@ -1175,6 +1343,28 @@ static size_t cr_layout(void* ws, int64_t E, int64_t N, int64_t K, CrWs* out) {
   return cv.off;
 }
 
+static size_t huge_layout(void* ws, size_t off0, int64_t E, HugeWs* out) {
+  Carver cv(ws);
+  cv.off = off0;
+  const size_t e = static_cast<size_t>(E > 0 ? E : 1);
+  HugeWs h;
+  h.list = cv.take<uint32_t>(HUGE_MAX);
+  h.hoff = cv.take<uint32_t>(HUGE_MAX + 1);
+  h.k0 = cv.take<uint64_t>(e);
+  h.k1 = cv.take<uint64_t>(e);
+  h.v0 = cv.take<uint32_t>(e);
+  h.v1 = cv.take<uint32_t>(e);
+  h.sub_w = cv.take<float>(e);
+  h.flags = cv.take<uint32_t>(e);
+  h.ranks = cv.take<uint32_t>(e);
+  h.mval = cv.take<float>(e);
+  h.sort_scratch = cv.take<uint32_t>(sort_scratch_words());
+  h.scan_scratch = cv.take<uint32_t>(2 * static_cast<size_t>(cdiv(e, SCAN_TILE)) + 16);
+  h.total = cv.take<int64_t>(2);
+  if (out) *out = h;
+  return cv.off;
+}
+
 static unsigned cr_long_grid(int64_t K) {  // workgroups of cr_rows_long_kernel (each takes every grid-th listed row)
   return static_cast<unsigned>(K < 1024 ? (K > 0 ? K : 1) : 1024);
 }
@@ -1192,6 +1382,10 @@ using namespace tgp;
 extern "C" size_t tgp_connect_coalesce_rows_workspace_bytes(int64_t E, int64_t N, int64_t K) {
   return cr_layout(nullptr, E, N, K, nullptr) + 256;
 }
+// with TGP_HUGE_ROWS in the flags of tgp_connect_coalesce_rows_count: room for the device-wide sort of the hub rows
+extern "C" size_t tgp_connect_coalesce_rows_huge_workspace_bytes(int64_t E, int64_t N, int64_t K) {
+  return huge_layout(nullptr, align_up(cr_layout(nullptr, E, N, K, nullptr)), E, nullptr) + 256;
+}
 
 // a handed-over CSR covers the whole list: offsets start at 0 and end at E (a list with ids outside [0, N) does not)
 // (reset: this one-thread launch also clears the status words, saving the memset in front of it)
@@ -1201,6 +1395,8 @@ static __global__ void cr_check_csr_kernel(const int32_t* __restrict__ csr_ptr, 
   if (reset) {
     bad[0] = broken ? 4 : 0;
     bad[1] = 0;
+    bad[2] = 0;
+    bad[3] = 0;
   } else if (broken) {
     *bad = 4;
   }
@@ -1219,16 +1415,20 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
               "tgp_connect_coalesce_rows_count: unknown reduce_op %d", reduce_op);
   TGP_REQUIRE(E < (1ll << 31) && K < (1ll << 26) && N < (1ll << 31), TGP_ERR_RANGE,
               "tgp_connect_coalesce_rows_count: E/N >= 2^31 or K >= 2^26");
-  TGP_REQUIRE(ws && ws_bytes >= tgp_connect_coalesce_rows_workspace_bytes(E, N, K), TGP_ERR_WORKSPACE,
-              "tgp_connect_coalesce_rows_count: workspace too small");
+  const bool huge = (flags & TGP_HUGE_ROWS) != 0;
+  TGP_REQUIRE(ws && ws_bytes >= (huge ? tgp_connect_coalesce_rows_huge_workspace_bytes(E, N, K)
+                                      : tgp_connect_coalesce_rows_workspace_bytes(E, N, K)),
+              TGP_ERR_WORKSPACE, "tgp_connect_coalesce_rows_count: workspace too small");
   if (E == 0 || K == 0) {
     (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
     return check_launch("tgp_connect_coalesce_rows_count");
   }
   CrWs s;
-  cr_layout(ws, E, N, K, &s);
+  const size_t cr_end = cr_layout(ws, E, N, K, &s);
+  HugeWs h{};
+  if (huge) huge_layout(ws, align_up(cr_end), E, &h);
   float* tmp_w = w ? s.tmp_w : nullptr;
-  if (!csr_ptr) (void)hipMemsetAsync(s.bad, 0, 2 * sizeof(int), stream);
+  if (!csr_ptr) (void)hipMemsetAsync(s.bad, 0, 4 * sizeof(int), stream);
   if (csr_ptr) {
     // CSR offsets of this very list from the caller (GraclusSelect builds them): no pass over the row array
     s.node_ptr = reinterpret_cast<uint32_t*>(const_cast<int32_t*>(csr_ptr));  // non-negative: same bits; read only
@@ -1255,7 +1455,25 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
                          s.seg_src, s.seg_dst);
     }
     hipLaunchKernelGGL(cr_raw_off_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, assign_row_ptr, K, s.seg_dst, s.bad,
-                       s.raw_off);
+                       s.raw_off, huge ? h.list : static_cast<uint32_t*>(nullptr), s.n_out);
+  }
+  if (huge) {  // rows beyond CR_LONG entries (hubs): their entries alone are sorted device-wide (see cr_huge_*_kernel)
+    const int colbits = bits_for(static_cast<uint64_t>(K - 1));
+    const uint32_t* n_dev = reinterpret_cast<const uint32_t*>(s.bad + 3);
+    hipLaunchKernelGGL(cr_huge_offsets_kernel, dim3(1), dim3(1024), 0, stream, h.list, s.raw_off, K, E, s.bad, h.hoff);
+    hipLaunchKernelGGL(cr_huge_gather_kernel, dim3(1024), dim3(256), 0, stream, col, w, s.table, assign_row_ptr, s.seg_src,
+                       s.seg_dst, s.raw_off, h.list, h.hoff, N, colbits, s.bad, h.k0, h.v0, h.sub_w);
+    bool first = true;
+    const int rc = radix_sort_pairs<uint64_t, uint32_t>(h.k0, h.v0, h.k1, h.v1, E, colbits + 12, h.sort_scratch, stream,
+                                                        &first, n_dev);
+    if (rc != TGP_OK) return rc;
+    const uint64_t* ks = first ? h.k0 : h.k1;
+    const uint32_t* vs = first ? h.v0 : h.v1;
+    hipLaunchKernelGGL(cr_huge_merge_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, ks, vs, h.sub_w, w ? 1 : 0, h.list,
+                       colbits, reduce_op, flags, eps, s.bad, E, h.flags, h.mval);
+    device_scan_u32(h.flags, E, h.ranks, h.total, h.scan_scratch, stream);
+    hipLaunchKernelGGL(cr_huge_write_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, ks, h.flags, h.ranks, h.mval,
+                       h.list, h.hoff, s.raw_off, colbits, s.bad, h.total, E, s.tmp_c, tmp_w, s.n_out);
   }
   // (measured r2: splitting the gather into an edge-parallel permute pass + the DIRECT sort kernel costs 114 + 103 us
   //  against 185 us for the fused gather: the 10 M random 4-byte table look-ups take ~50 us wherever they run)

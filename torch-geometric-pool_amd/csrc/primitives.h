@@ -94,7 +94,8 @@ constexpr int SCAN_TILE = 256 * SCAN_ITEMS;
 // total survivors -> d_count, or -1 when a precondition failed
 static __global__ void cr_finish_count_kernel(const int* __restrict__ bad, const int64_t* __restrict__ total,
                                        int64_t* __restrict__ d_count) {
-  *d_count = *bad ? -1 : *total;
+  const int b = *bad;  // 8 alone: the row-local coalesce met a supernode row beyond its LDS sort and was not asked to
+  *d_count = b == 0 ? *total : (b == 8 ? -5 : -1);  // handle such rows (-5: call again with TGP_HUGE_ROWS)
 }
 
 // ------------------------------------------------------------------ multi-block exclusive scan (u32)
@@ -151,7 +152,7 @@ static __global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t* 
   if (self_offsets && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     const int64_t t = static_cast<int64_t>(tile_off) + tile_total;
     if (total) *total = t;
-    if (d_count) *d_count = (bad && *bad) ? -1 : t;
+    if (d_count) *d_count = (bad && *bad) ? (*bad == 8 ? -5 : -1) : t;
   }
 }
 
@@ -212,10 +213,12 @@ constexpr int kSortMaxBins = 2048;
 template <typename KeyT, int DB>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const KeyT* __restrict__ keys, int64_t n,
                                                                    int64_t chunk, int shift, int nblocks,
-                                                                   uint32_t* __restrict__ hist) {
+                                                                   uint32_t* __restrict__ hist,
+                                                                   const uint32_t* __restrict__ n_dev = nullptr) {
   constexpr int BINS = 1 << DB;
   __shared__ uint32_t s_h[BINS];
   const int tid = threadIdx.x;
+  if (n_dev) n = *n_dev < n ? *n_dev : n;  // element count known on the device only (<= the n the launch was sized for)
   for (int d = tid; d < BINS; d += kSortThreads) s_h[d] = 0;
   __syncthreads();
   const int64_t begin = static_cast<int64_t>(blockIdx.x) * chunk;
@@ -253,9 +256,11 @@ template <typename KeyT, typename ValT, int DB>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const KeyT* __restrict__ keys_in, const ValT* __restrict__ vals_in, KeyT* __restrict__ keys_out,
     ValT* __restrict__ vals_out, const uint32_t* __restrict__ hist_scanned,
-    const uint32_t* __restrict__ digit_total, int64_t n, int64_t chunk, int shift, int nblocks) {
+    const uint32_t* __restrict__ digit_total, int64_t n, int64_t chunk, int shift, int nblocks,
+    const uint32_t* __restrict__ n_dev = nullptr) {
   constexpr int BINS = 1 << DB;
   constexpr int PER = BINS / kSortThreads;
+  if (n_dev) n = *n_dev < n ? *n_dev : n;
   __shared__ uint32_t s_base[BINS];
   __shared__ uint32_t s_whist[4][BINS];
   __shared__ uint32_t s_scan[4];
@@ -403,20 +408,22 @@ inline int sort_passes(int64_t n, int key_bits) {
 
 template <typename KeyT, typename ValT, int DB>
 static void radix_pass(const KeyT* ki, const ValT* vi, KeyT* ko, ValT* vo, int64_t n, int shift, const SortPlan& p,
-                       uint32_t* hist, uint32_t* digit_total, hipStream_t stream) {
+                       uint32_t* hist, uint32_t* digit_total, hipStream_t stream, const uint32_t* n_dev = nullptr) {
   constexpr int BINS = 1 << DB;
   hipLaunchKernelGGL((radix_hist_kernel<KeyT, DB>), dim3(p.nblocks), dim3(kSortThreads), 0, stream, ki, n,
-                     p.chunk, shift, p.nblocks, hist);
+                     p.chunk, shift, p.nblocks, hist, n_dev);
   hipLaunchKernelGGL(radix_scan_kernel, dim3(BINS), dim3(1024), 0, stream, hist, p.nblocks, digit_total);
   hipLaunchKernelGGL((radix_scatter_kernel<KeyT, ValT, DB>), dim3(p.nblocks), dim3(kSortThreads), 0, stream,
-                     ki, vi, ko, vo, hist, digit_total, n, p.chunk, shift, p.nblocks);
+                     ki, vi, ko, vo, hist, digit_total, n, p.chunk, shift, p.nblocks, n_dev);
 }
 
 // Sorts (keys, vals) by the low `key_bits` bits of the key.  Buffers ping-pong between
 // (k0,v0) and (k1,v1); returns in *result_in_first whether the sorted data ended in (k0,v0).
+// `n_dev` (optional): the real element count lives on the device (*n_dev <= n); the launches are sized for n, chunks
+// past *n_dev are empty.
 template <typename KeyT, typename ValT>
 int radix_sort_pairs(KeyT* k0, ValT* v0, KeyT* k1, ValT* v1, int64_t n, int key_bits, uint32_t* scratch,
-                     hipStream_t stream, bool* result_in_first) {
+                     hipStream_t stream, bool* result_in_first, const uint32_t* n_dev = nullptr) {
   *result_in_first = true;
   const int passes = sort_passes(n, key_bits);
   if (passes == 0) return TGP_OK;
@@ -428,7 +435,7 @@ int radix_sort_pairs(KeyT* k0, ValT* v0, KeyT* k1, ValT* v1, int64_t n, int key_
   ValT *vi = v0, *vo = v1;
   for (int pass = 0; pass < passes; ++pass) {
     (void)db;  // 8-bit digits only (11-bit digits measured slower, see sort_digit_bits)
-    radix_pass<KeyT, ValT, 8>(ki, vi, ko, vo, n, pass * 8, p, hist, digit_total, stream);
+    radix_pass<KeyT, ValT, 8>(ki, vi, ko, vo, n, pass * 8, p, hist, digit_total, stream, n_dev);
     KeyT* tk = ki; ki = ko; ko = tk;
     ValT* tv = vi; vi = vo; vo = tv;
   }

@@ -27,6 +27,7 @@ EPS_FILTER = 16
 ADJ_TRANSPOSED = 32
 NODE_FILTER = 64
 WANT_EDGE_ID = 128
+HUGE_ROWS = 256
 REDUCE_OPS = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3, "mul": 4}
 
 _c_i64, _c_int, _c_sz, _c_p, _c_f = ctypes.c_int64, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float
@@ -52,6 +53,7 @@ SIGNATURES = {
     "tgp_connect_coalesce_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_i64, _c_p, _c_p,
                                            _c_p, _c_p]),
     "tgp_connect_coalesce_rows_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "tgp_connect_coalesce_rows_huge_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tgp_connect_coalesce_rows_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p,
                                                  _c_int, _c_int, _c_f, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_connect_coalesce_rows_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_p, _c_p, _c_p,

@@ -411,19 +411,34 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
         del ws, cap_w
         if route == "fused":
             raise RuntimeError(f"fused coalesce route declined (code {n_out})")
-        staged_ok = n_out == -3  # only the fused kernel's tile limit: the staged pipeline takes the call
-        if not staged_ok and E > 1 and _rows_sorted_memo(edge_index) is None:
+        # -3: only the fused kernel's tile limit; -1 on a list whose rows ARE sorted: a supernode row too long for the
+        # fused kernel -- the staged pipeline takes both (it sorts hub rows device-wide)
+        if n_out != -3 and E > 1 and csr is None and _rows_sorted_memo(edge_index) is None:
             _rows_sorted(edge_index, row)
+        staged_ok = n_out == -3 or (n_out == -1 and (csr is not None or _rows_sorted_memo(edge_index) is True))
     if staged_ok:
-        ws = N.workspace(L.tgp_connect_coalesce_rows_workspace_bytes(E, cl.numel(), num_supernodes), dev)
-        d_count = torch.empty(1, dtype=torch.int64, device=dev)
-        st = N.stream_ptr(dev)
-        N.check(L.tgp_connect_coalesce_rows_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
-                                                  num_supernodes, N.ptr(assign_index.row_ptr),
-                                                  N.ptr(assign_index.perm), N.ptr(csr[0]) if csr is not None else None,
-                                                  N.REDUCE_OPS[reduce_op], flags, eps, N.ptr(ws),
-                                                  ws.numel(), N.ptr(d_count), st), "tgp_connect_coalesce_rows_count")
-        n_out = _read_count(d_count)
+        # a list known to hold hub rows (a supernode row beyond 1024 raw entries) asks for the huge-row kernels at once;
+        # any other list finds out from the count (-5), once per edge_index object
+        hub = _HUB_ROWS.get(id(edge_index))
+        hub = hub is not None and hub[0]() is edge_index and hub[1] == edge_index._version
+        for attempt in range(2):
+            fl = flags | (N.HUGE_ROWS if hub else 0)
+            nbytes = (L.tgp_connect_coalesce_rows_huge_workspace_bytes if hub else
+                      L.tgp_connect_coalesce_rows_workspace_bytes)(E, cl.numel(), num_supernodes)
+            ws = N.workspace(nbytes, dev)
+            d_count = torch.empty(1, dtype=torch.int64, device=dev)
+            st = N.stream_ptr(dev)
+            N.check(L.tgp_connect_coalesce_rows_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
+                                                      num_supernodes, N.ptr(assign_index.row_ptr),
+                                                      N.ptr(assign_index.perm), N.ptr(csr[0]) if csr is not None else None,
+                                                      N.REDUCE_OPS[reduce_op], fl, eps, N.ptr(ws),
+                                                      ws.numel(), N.ptr(d_count), st), "tgp_connect_coalesce_rows_count")
+            n_out = _read_count(d_count)
+            if n_out != -5 or hub:
+                break
+            hub = True
+            _remember_hub_rows(edge_index)
+            del ws
         if n_out >= 0:
             out_ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
             out_w = None if w is None else torch.empty(n_out, dtype=torch.float32, device=dev)
@@ -845,6 +860,17 @@ def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Te
 
 
 _ROWS_SORTED: dict = {}
+_HUB_ROWS: dict = {}  # edge lists on which the row-local coalesce met a supernode row beyond its LDS sort
+
+
+def _remember_hub_rows(edge_index: Tensor) -> None:
+    import weakref
+    if len(_HUB_ROWS) >= 16:
+        for key in [k for k, v in _HUB_ROWS.items() if v[0]() is None]:
+            del _HUB_ROWS[key]
+        while len(_HUB_ROWS) >= 16:
+            del _HUB_ROWS[next(iter(_HUB_ROWS))]
+    _HUB_ROWS[id(edge_index)] = (weakref.ref(edge_index), edge_index._version)
 
 
 def _rows_sorted_memo(edge_index: Tensor) -> Optional[bool]:
