@@ -167,7 +167,8 @@ int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t* col, cons
                                     int reduce_op, int flags, float eps, void* ws,
                                     size_t ws_bytes, int64_t* d_count, void* stream);
 int tgp_connect_coalesce_rows_fill(const void* ws, int64_t num_edges, int64_t num_nodes, int64_t num_supernodes,
-                                   int has_weight, int64_t num_out, int64_t* out_row, int64_t* out_col,
+                                   int has_weight /* bit 0: weights; bit 1: the count call ran with TGP_HUGE_ROWS */,
+                                   int64_t num_out, int64_t* out_row, int64_t* out_col,
                                    float* out_weight, void* stream);
 
 /* A4 + A6, row-sorted input, as ONE heavy kernel + a widening fill (r3).  Every workgroup derives its rows' member

@@ -396,11 +396,12 @@ def test_rowlocal_coalesce_declines_and_falls_back(dev):
     got = kernels.coalesce_edges(ei.to(dev), ew.to(dev), cl_d, k, "sum", True, assign_index=idx)
     ref = O.sparse_connect(ei, ew, torch.arange(n), cluster, n, k)
     assert torch.equal(got[0].cpu(), ref[0]) and torch.equal(got[1].cpu(), ref[1])
-    # very long supernode rows (few clusters, > 1024 raw entries each) -> declined, general path still right
+    # very long supernode rows (few clusters, > 1024 raw entries each): declined with the code that asks for the
+    # huge-row kernels (r4; -1 before), which coalesce_edges then runs -- same result as the oracle
     es = _sorted_graph(n, 40_000, 6)
     cl2 = torch.arange(n) % 3
     idx2 = kernels.build_assign_index(cl2.to(dev), 3)
-    assert raw_count(es.to(dev), cl2.to(dev), 3, idx2) == -1
+    assert raw_count(es.to(dev), cl2.to(dev), 3, idx2) == -5
     got = kernels.coalesce_edges(es.to(dev), torch.ones(es.size(1), device=dev), cl2.to(dev), 3, "sum", False,
                                  assign_index=idx2)
     ref = O.sparse_connect(es, torch.ones(es.size(1)), torch.arange(n), cl2, n, 3, remove_self_loops=False)

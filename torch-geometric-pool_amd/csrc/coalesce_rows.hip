@@ -858,6 +858,10 @@ __global__ __launch_bounds__(256) void cr_huge_write_kernel(const uint64_t* __re
 // slot's row by binary search over the rows' output offsets in LDS, and reads the survivor from the row's
 // compacted run in tmp (contiguous up to the gaps the merge left).
 constexpr int FILL_ROWS = 64;
+// rows with more survivors than this (only a hub row can have them: a row the LDS kernels sorted holds <= CR_LONG) are
+// left to cr_fill_huge_kernel, which spreads each over the whole grid -- one workgroup walking a 200 000-entry row slot
+// by slot took 3.5 ms (r4, ten hubs)
+constexpr uint32_t FILL_LONG = CR_LONG;
 __global__ __launch_bounds__(256) void cr_fill_kernel(const uint32_t* __restrict__ tmp_c,
                                                       const float* __restrict__ tmp_w,
                                                       const uint32_t* __restrict__ raw_off,
@@ -866,24 +870,64 @@ __global__ __launch_bounds__(256) void cr_fill_kernel(const uint32_t* __restrict
                                                       int64_t* __restrict__ out_row, int64_t* __restrict__ out_col,
                                                       float* __restrict__ out_w) {
   __shared__ uint32_t s_out[FILL_ROWS + 1], s_raw[FILL_ROWS];
+  __shared__ unsigned long long s_hub;
   const int tid = threadIdx.x;
   const int64_t r0 = static_cast<int64_t>(blockIdx.x) * FILL_ROWS;
   const int nr = static_cast<int>(K - r0 < FILL_ROWS ? K - r0 : FILL_ROWS);
   if (tid <= nr) s_out[tid] = r0 + tid < K ? out_off[r0 + tid] : static_cast<uint32_t>(*total);
   if (tid < nr) s_raw[tid] = raw_off[r0 + tid];
   __syncthreads();
-  const uint32_t o0 = s_out[0], cnt = s_out[nr] - o0;
-  for (uint32_t t = tid; t < cnt; t += 256) {
-    const uint32_t o = o0 + t;
-    int lo = 0, hi = nr;  // last row i with s_out[i] <= o (rows without survivors share their successor's offset)
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (s_out[mid] <= o) lo = mid; else hi = mid;
+  if (tid < 64) {
+    const unsigned long long m = __ballot(tid < nr && s_out[tid + 1] - s_out[tid] > FILL_LONG);
+    if (tid == 0) s_hub = m;
+  }
+  __syncthreads();
+  unsigned long long hub = s_hub;
+  int i0 = 0;
+  while (i0 < nr) {  // maximal runs [i0, i1) of rows without a hub row (one run, the whole block, almost always)
+    if ((hub >> i0) & 1ull) {
+      ++i0;
+      continue;
     }
-    const uint32_t src = s_raw[lo] + (o - s_out[lo]);
-    out_row[o] = r0 + lo;
-    out_col[o] = tmp_c[src];
-    if (out_w) out_w[o] = tmp_w[src];
+    const unsigned long long rest = hub >> i0;
+    const int i1 = rest ? i0 + __builtin_ctzll(rest) : nr;
+    const uint32_t o0 = s_out[i0], cnt = s_out[i1] - o0;
+    for (uint32_t t = tid; t < cnt; t += 256) {
+      const uint32_t o = o0 + t;
+      int lo = i0, hi = i1;  // last row i with s_out[i] <= o (rows without survivors share their successor's offset)
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_out[mid] <= o) lo = mid; else hi = mid;
+      }
+      const uint32_t src = s_raw[lo] + (o - s_out[lo]);
+      out_row[o] = r0 + lo;
+      out_col[o] = tmp_c[src];
+      if (out_w) out_w[o] = tmp_w[src];
+    }
+    i0 = i1;
+  }
+}
+
+// the listed hub rows with more than FILL_LONG survivors: every row a grid-wide strided copy
+__global__ __launch_bounds__(256) void cr_fill_huge_kernel(const uint32_t* __restrict__ tmp_c,
+                                                           const float* __restrict__ tmp_w,
+                                                           const uint32_t* __restrict__ raw_off,
+                                                           const uint32_t* __restrict__ out_off,
+                                                           const int64_t* __restrict__ total, int64_t K,
+                                                           const uint32_t* __restrict__ list, const int* __restrict__ bad,
+                                                           int64_t* __restrict__ out_row, int64_t* __restrict__ out_col,
+                                                           float* __restrict__ out_w) {
+  const int nh = bad[2] < HUGE_MAX ? bad[2] : HUGE_MAX;
+  for (int li = 0; li < nh; ++li) {
+    const int64_t r = list[li];
+    const uint32_t o0 = out_off[r], n = (r + 1 < K ? out_off[r + 1] : static_cast<uint32_t>(*total)) - o0;
+    if (n <= FILL_LONG) continue;  // cr_fill_kernel wrote it
+    const uint32_t b = raw_off[r];
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
+      out_row[o0 + t] = r;
+      out_col[o0 + t] = tmp_c[b + t];
+      if (out_w) out_w[o0 + t] = tmp_w[b + t];
+    }
   }
 }
 
@@ -1730,13 +1774,20 @@ extern "C" int tgp_connect_coalesce_rows_fill(const void* ws, int64_t E, int64_t
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(ws && num_out >= 0, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_fill: bad argument");
   if (num_out == 0 || E == 0 || K == 0) return TGP_OK;
-  TGP_REQUIRE(out_row && out_col && (!has_weight || out_w), TGP_ERR_INVALID,
+  TGP_REQUIRE(out_row && out_col && (!(has_weight & 1) || out_w), TGP_ERR_INVALID,
               "tgp_connect_coalesce_rows_fill: null output");
   CrWs s;
-  cr_layout(const_cast<void*>(ws), E, N, K, &s);
+  const size_t cr_end = cr_layout(const_cast<void*>(ws), E, N, K, &s);
+  const bool weights = (has_weight & 1) != 0;
   hipLaunchKernelGGL(cr_fill_kernel, dim3(cdiv(K, FILL_ROWS)), dim3(256), 0, stream, s.tmp_c,
-                     has_weight ? s.tmp_w : nullptr, s.raw_off, s.out_off, s.total, K, out_row, out_col,
-                     has_weight ? out_w : nullptr);
+                     weights ? s.tmp_w : nullptr, s.raw_off, s.out_off, s.total, K, out_row, out_col,
+                     weights ? out_w : nullptr);
+  if (has_weight & 2) {  // the count call ran with TGP_HUGE_ROWS: hub rows are copied by the whole grid
+    HugeWs h;
+    huge_layout(const_cast<void*>(ws), align_up(cr_end), E, &h);
+    hipLaunchKernelGGL(cr_fill_huge_kernel, dim3(1024), dim3(256), 0, stream, s.tmp_c, weights ? s.tmp_w : nullptr,
+                       s.raw_off, s.out_off, s.total, K, h.list, s.bad, out_row, out_col, weights ? out_w : nullptr);
+  }
   return check_launch("tgp_connect_coalesce_rows_fill");
 }
 

@@ -238,8 +238,13 @@ __device__ __forceinline__ void gm_steal_long_rows(const int32_t* __restrict__ r
   const unsigned int count = long_ctr[0];
   if (count == 0) return;
   for (;;) {
+    // a plain look first: once the list is empty the ~15 k waves of a launch must not each queue an atomic on the one
+    // ticket word (it takes ~88 atomics per us: 150 us per launch for nothing)
     unsigned int t = 0;
-    if (lane_id() == 0) t = atomicAdd(long_ctr + 1, 1u);
+    if (lane_id() == 0) {
+      t = __hip_atomic_load(long_ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t < count) t = atomicAdd(long_ctr + 1, 1u);
+    }
     t = __shfl(t, 0, 64);
     if (t >= count) return;
     const int32_t i = long_list[t];

@@ -218,7 +218,11 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const KeyT* __
   constexpr int BINS = 1 << DB;
   __shared__ uint32_t s_h[BINS];
   const int tid = threadIdx.x;
-  if (n_dev) n = *n_dev < n ? *n_dev : n;  // element count known on the device only (<= the n the launch was sized for)
+  if (n_dev) {  // element count known on the device only (<= the n the launch was sized for): the chunks are re-cut so
+    n = *n_dev < n ? *n_dev : n;  // that every workgroup of the launch gets a share
+    const int64_t tiles = (n + kSortTile - 1) / kSortTile;
+    chunk = ((tiles + nblocks - 1) / nblocks) * kSortTile;
+  }
   for (int d = tid; d < BINS; d += kSortThreads) s_h[d] = 0;
   __syncthreads();
   const int64_t begin = static_cast<int64_t>(blockIdx.x) * chunk;
@@ -260,7 +264,11 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const uint32_t* __restrict__ n_dev = nullptr) {
   constexpr int BINS = 1 << DB;
   constexpr int PER = BINS / kSortThreads;
-  if (n_dev) n = *n_dev < n ? *n_dev : n;
+  if (n_dev) {
+    n = *n_dev < n ? *n_dev : n;
+    const int64_t tiles = (n + kSortTile - 1) / kSortTile;
+    chunk = ((tiles + nblocks - 1) / nblocks) * kSortTile;
+  }
   __shared__ uint32_t s_base[BINS];
   __shared__ uint32_t s_whist[4][BINS];
   __shared__ uint32_t s_scan[4];

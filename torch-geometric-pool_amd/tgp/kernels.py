@@ -442,7 +442,8 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
         if n_out >= 0:
             out_ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
             out_w = None if w is None else torch.empty(n_out, dtype=torch.float32, device=dev)
-            N.check(L.tgp_connect_coalesce_rows_fill(N.ptr(ws), E, cl.numel(), num_supernodes, 0 if w is None else 1,
+            N.check(L.tgp_connect_coalesce_rows_fill(N.ptr(ws), E, cl.numel(), num_supernodes,
+                                                     (0 if w is None else 1) | (2 if hub else 0),
                                                      n_out, N.ptr(out_ei[0]) if n_out else None,
                                                      N.ptr(out_ei[1]) if n_out else None, N.ptr(out_w), st),
                     "tgp_connect_coalesce_rows_fill")
