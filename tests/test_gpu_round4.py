@@ -280,12 +280,11 @@ def test_graclus_pooler_on_a_hub_graph_stays_on_the_rowlocal_route(dev):
     ei, _ = _hub_graph(n, 150_000, 4, 30_000, 7)
     x = torch.randn(n, 16, generator=torch.Generator().manual_seed(1))
     pooler = get_pooler("graclus").to(dev).eval()
-    calls = []
-    orig = kernels.N.lib().tgp_connect_coalesce_count
+    ei_d = ei.to(dev)
     with torch.no_grad():
-        out = pooler(x=x.to(dev), adj=ei.to(dev))
-    assert id(ei) not in kernels._HUB_ROWS  # (the memo is keyed by the DEVICE tensor the pooler saw)
+        out = pooler(x=x.to(dev), adj=ei_d)
+    hub = kernels._HUB_ROWS.get(id(ei_d))
+    assert hub is not None and hub[0]() is ei_d  # the row-local route met the hub rows and took them itself
     ref = O.cluster_pool(x, ei, None, None, out.so.cluster_index.cpu(), out.so.num_supernodes)
     assert torch.equal(out.edge_index.cpu(), ref["edge_index"])
     torch.testing.assert_close(out.x.cpu(), ref["x"], rtol=1e-5, atol=1e-5)
-    del calls, orig
