@@ -133,6 +133,24 @@ int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col, const floa
                                                       TGP_WANT_EDGE_ID in `flags` of _count and _fill */,
                               void* stream);
 
+/* The same operator in ONE pass (r4): survivors are written once, in their final int64 form at their final offsets of
+ * CAPACITY-num_edges outputs (out_row / out_col / out_weight / out_edge_id: the first `total` entries are the result,
+ * identical to the count -> fill pair above), through an epoch-tagged decoupled look-back over the 4096-edge chunks
+ * (`status`: >= tgp_connect_subgraph_single_status_words(E) 64-bit words of device memory, caller-owned, never
+ * cleared, one buffer per stream; 0 < epoch < 2^29 different for every call on it).  `*result` (device-accessible, e.g.
+ * pinned host memory the caller polls) receives {epoch << 34 | refused << 31 | total} when the last chunk is done;
+ * refused = an endpoint outside [0, num_nodes) was met (the count -> fill pair reports -2 for it), or a look-back
+ * spin bound was hit (the device is shared: use the pair).  num_edges > 0. */
+size_t tgp_connect_subgraph_single_workspace_bytes(int64_t num_nodes);
+int64_t tgp_connect_subgraph_single_status_words(int64_t num_edges);
+/* byte offset in `ws` of the int32 flag "an endpoint outside [0, num_nodes) was met": tells the two refusals apart */
+int64_t tgp_connect_subgraph_single_bad_ids_offset(int64_t num_nodes);
+int tgp_connect_subgraph_single(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
+                                int64_t num_edges, const int64_t* node_index /* NULL = filters only */, int64_t k,
+                                int64_t num_nodes, int flags, float eps, void* ws, size_t ws_bytes, int64_t* out_row,
+                                int64_t* out_col, float* out_weight, int64_t* out_edge_id /* NULL ok */,
+                                uint64_t* status, int64_t status_words, uint64_t* result, uint32_t epoch, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * A4 + A6  sparse_connect, one-over-K branch (connect/base_conn.py:83-89 -> PyG coalesce):
  * relabel endpoints by cluster_index, sort by (row, col) (stable), merge duplicates with

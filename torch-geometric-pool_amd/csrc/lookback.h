@@ -1,0 +1,84 @@
+// Epoch-tagged decoupled look-back, shared by the one-launch kernels that write their survivors at FINAL offsets
+// (sparse_pool_small.hip, the single-pass subgraph Connect of sparse_connect.hip).
+//
+// A tile publishes {epoch, state, refused, count} in one 64-bit word of a caller-owned status buffer: state AGG = the
+// tile's own count, PRE = the inclusive prefix up to it.  Words of earlier calls carry another epoch and read as "not
+// ready", so the buffer is never cleared (no memset launch in front of the kernel).  A refusal (bit 31) travels inside
+// the words: the last tile knows the verdict of the whole call and leaves ONE result word {epoch, refused, total},
+// stored with system scope -- the caller may point it at pinned host memory and poll it.
+#pragma once
+#include "primitives.h"
+
+namespace tgp {
+
+constexpr int SPS_EPOCH_SHIFT = 34;
+constexpr unsigned long long SPS_AGG = 1ull << 32, SPS_PRE = 2ull << 32;
+__device__ __forceinline__ unsigned long long sps_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sps_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool sps_current(unsigned long long word, unsigned long long tag) {
+  return (word >> SPS_EPOCH_SHIFT) == (tag >> SPS_EPOCH_SHIFT);
+}
+
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+// Exclusive prefix of `tile` over the tiles' survivor counts (bits 0..30 of the published values) and whether any of
+// them refused (bit 31); every lane of ONE wave calls it.  A spin bound turns a tile that never shows up into a refusal.
+__device__ __forceinline__ void sps_lookback(unsigned long long* status, int tile, unsigned long long tag,
+                                             uint32_t* excl_out, bool* refused) {
+  // 256 predecessors per round (four words per lane, all requested at once): the words live behind the fabric (agent
+  // scope across XCDs), a round trip costs ~1 us, and everybody publishes at about the same time -- r4 stamps: 64 per
+  // round made the last of 256 tiles wait four dependent rounds
+  const int lane = lane_id();
+  uint32_t excl = 0;
+  bool bad = false;
+  int j = tile - 1;
+  while (j >= 0) {
+    unsigned long long st[4];
+    int idx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      idx[k] = j - lane - 64 * k;
+      st[k] = idx[k] >= 0 ? sps_load(status + 2 + idx[k]) : (tag | SPS_PRE);
+    }
+    int spins = 0;
+    for (;;) {
+      bool wait = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wait = wait || !sps_current(st[k], tag) || ((st[k] >> 32) & 3ull) == 0;
+      if (!__any(wait)) break;
+      if (++spins > (1 << 20)) {  // every spin is bounded
+        *excl_out = 0;
+        *refused = true;
+        return;
+      }
+      if (spins > 4) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (idx[k] >= 0 && (!sps_current(st[k], tag) || ((st[k] >> 32) & 3ull) == 0)) st[k] = sps_load(status + 2 + idx[k]);
+    }
+    bool done = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!done) {  // (uniform: `done` comes from ballots)
+        const unsigned long long pre = __ballot(((st[k] >> 32) & 3ull) == 2);
+        const int first = pre ? __builtin_ctzll(pre) : 64;  // nearest predecessor that already knows its prefix
+        excl += wave_sum32(lane <= first ? static_cast<uint32_t>(st[k]) & 0x7FFFFFFFu : 0u);
+        bad = bad || __any(lane <= first && ((st[k] >> 31) & 1ull));
+        done = pre != 0ull;
+      }
+    }
+    if (done) break;
+    j -= 256;
+  }
+  *excl_out = excl;
+  *refused = bad;
+}
+
+}  // namespace tgp

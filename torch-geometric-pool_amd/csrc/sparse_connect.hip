@@ -4,7 +4,7 @@
 // contract (SURVEY.md 7 "ordering contracts"): PyG `subgraph` keeps input edge order, PyG
 // `coalesce` returns row-major sorted unique edges, `nonzero` returns (b,row,col) order — so all
 // compactions are scan-based (ballot ranks + block offsets), never atomic-append.
-#include "primitives.h"
+#include "lookback.h"
 
 namespace tgp {
 
@@ -140,12 +140,14 @@ __device__ __forceinline__ void sg_fetch(const SubgraphPred& pred, int64_t e0, i
 
 // the predicate: membership of both endpoints (bitmap), self loops, |w| > eps
 template <bool LDSB>
-__device__ __forceinline__ void sg_eval(const SubgraphPred& pred, const uint32_t* s_bits, int64_t e0, SgEdges& t) {
+__device__ __forceinline__ bool sg_eval(const SubgraphPred& pred, const uint32_t* s_bits, int64_t e0, SgEdges& t) {
+  bool met_bad = false;
 #pragma unroll
   for (int j = 0; j < SG_PER; ++j) {  // endpoints outside [0, n): flagged, never used as an index
     if (t.keep[j] && (static_cast<uint64_t>(t.r[j]) >= static_cast<uint64_t>(pred.n) ||
                       static_cast<uint64_t>(t.c[j]) >= static_cast<uint64_t>(pred.n))) {
       *pred.bad_ids = 1;
+      met_bad = true;
       t.keep[j] = false;
       t.r[j] = 0;
       t.c[j] = 0;
@@ -172,6 +174,7 @@ __device__ __forceinline__ void sg_eval(const SubgraphPred& pred, const uint32_t
     if ((pred.flags & TGP_REMOVE_SELF_LOOPS) && t.r[j] == t.c[j]) t.keep[j] = false;
     if (pred.w && (pred.flags & TGP_EPS_FILTER) && !(fabsf(t.w[j]) > pred.eps)) t.keep[j] = false;
   }
+  return met_bad;
 }
 
 // exclusive scan of one value per thread over a 1024-thread workgroup (16 waves); s_w: 16 words
@@ -205,11 +208,31 @@ struct SgStage {
   uint16_t* off;
 };
 
-template <int LDSB>
+// r4, SINGLE = true: the same pass writes the survivors ONCE, in their final int64 form at their final offsets of
+// capacity-E outputs -- no staging area, no count kernel, no copy pass behind the host read (r3: 12 B read + 20 B written
+// per survivor, a quarter of the call with its launch and the device-to-host copy).  The number of survivors in front of
+// a chunk comes from the epoch-tagged decoupled look-back of lookback.h: the persistent workgroups take chunks in
+// increasing order (chunk = workgroup + round * grid), so the predecessors of a chunk belong to the same round of
+// workgroups that are all resident, and the next chunk's loads are already in flight while the words travel.  Edge ids
+// outside [0, n) ride along as the refusal bit; the last chunk leaves {epoch, refused, total} in *result (pinned host
+// memory: the caller polls it).
+struct SgSingle {
+  int64_t* out_row;
+  int64_t* out_col;
+  float* out_w;
+  int64_t* out_eid;
+  unsigned long long* status;
+  unsigned long long* result;
+  unsigned long long tag;
+};
+
+template <int LDSB, bool SINGLE>
 __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred pred, int64_t E, int nchunks, int nwords,
-                                                                    SgStage st, uint32_t* __restrict__ block_counts) {
+                                                                    SgStage st, uint32_t* __restrict__ block_counts,
+                                                                    SgSingle sg) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   __shared__ uint32_t s_w[16];
+  __shared__ uint32_t s_base;
   uint32_t* s_rank = s_dyn + 4 * ((nwords + 3) / 4);  // behind the bitmap, padded to whole 128-node blocks
   bool by_rank = false;
   if constexpr (LDSB >= 1) {
@@ -263,22 +286,62 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred
     SgEdges t = nxt;
     if (chunk + static_cast<int>(gridDim.x) < nchunks)
       sg_fetch(pred, e0 + static_cast<int64_t>(gridDim.x) * SG_CHUNK, E, nxt);
-    sg_eval<(LDSB >= 1)>(pred, s_dyn, e0, t);
+    const bool met_bad = sg_eval<(LDSB >= 1)>(pred, s_dyn, e0, t);
     uint32_t mine = 0;
 #pragma unroll
     for (int j = 0; j < SG_PER; ++j) mine += t.keep[j] ? 1u : 0u;
+    if constexpr (SINGLE) mine |= met_bad ? 0x10000u : 0u;  // (survivors of a chunk fit 13 bits: the flag rides above)
     uint32_t total;
-    int64_t pos = static_cast<int64_t>(chunk) * SG_CHUNK + block_excl_scan_1024(mine, s_w, &total);
-    if (threadIdx.x == 0) block_counts[chunk] = total;
-    // (computing the new ids ahead of the scan, to overlap their LDS look-ups with its barriers, measured 68 vs 64 us)
+    const uint32_t rank0 = block_excl_scan_1024(mine, s_w, &total);
+    if constexpr (!SINGLE) {
+      int64_t pos = static_cast<int64_t>(chunk) * SG_CHUNK + rank0;
+      if (threadIdx.x == 0) block_counts[chunk] = total;
+      // (computing the new ids ahead of the scan, to overlap their LDS look-ups with its barriers, measured 68 vs 64 us)
 #pragma unroll
-    for (int j = 0; j < SG_PER; ++j) {
-      if (t.keep[j]) {
-        st.r[pos] = pred.relabel ? new_id(t.r[j]) : static_cast<int32_t>(t.r[j]);
-        st.c[pos] = pred.relabel ? new_id(t.c[j]) : static_cast<int32_t>(t.c[j]);
-        if (st.w) st.w[pos] = t.w[j];
-        if (st.off) st.off[pos] = static_cast<uint16_t>(threadIdx.x * SG_PER + j);
-        ++pos;
+      for (int j = 0; j < SG_PER; ++j) {
+        if (t.keep[j]) {
+          st.r[pos] = pred.relabel ? new_id(t.r[j]) : static_cast<int32_t>(t.r[j]);
+          st.c[pos] = pred.relabel ? new_id(t.c[j]) : static_cast<int32_t>(t.c[j]);
+          if (st.w) st.w[pos] = t.w[j];
+          if (st.off) st.off[pos] = static_cast<uint16_t>(threadIdx.x * SG_PER + j);
+          ++pos;
+        }
+      }
+    } else {
+      if (wave_id() == 0) {
+        const uint32_t tot = total & 0xFFFFu;
+        bool refused = (total >> 16) != 0u;
+        const int lane = lane_id();
+        if (lane == 0)
+          sps_store(sg.status + 2 + chunk, sg.tag | (chunk == 0 ? SPS_PRE : SPS_AGG) | (refused ? 0x80000000ull : 0ull) | tot);
+        uint32_t excl = 0;
+        if (chunk > 0) {
+          bool before = false;
+          sps_lookback(sg.status, chunk, sg.tag, &excl, &before);
+          refused = refused || before;
+          if (lane == 0)
+            sps_store(sg.status + 2 + chunk, sg.tag | SPS_PRE | (refused ? 0x80000000ull : 0ull) |
+                                                 static_cast<unsigned long long>((excl + tot) & 0x7FFFFFFFu));
+        }
+        if (lane == 0) {
+          s_base = excl;
+          if (chunk == nchunks - 1)
+            __hip_atomic_store(sg.result, sg.tag | (refused ? 0x80000000ull : 0ull) |
+                                              static_cast<unsigned long long>((excl + tot) & 0x7FFFFFFFu),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      __syncthreads();
+      int64_t pos = static_cast<int64_t>(s_base) + (rank0 & 0xFFFFu);
+#pragma unroll
+      for (int j = 0; j < SG_PER; ++j) {
+        if (t.keep[j]) {
+          sg.out_row[pos] = pred.relabel ? static_cast<int64_t>(new_id(t.r[j])) : t.r[j];
+          sg.out_col[pos] = pred.relabel ? static_cast<int64_t>(new_id(t.c[j])) : t.c[j];
+          if (sg.out_w) sg.out_w[pos] = t.w[j];
+          if (sg.out_eid) sg.out_eid[pos] = e0 + j;
+          ++pos;
+        }
       }
     }
   }
@@ -823,18 +886,18 @@ extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col
   const int grid = nb < 256 ? nb : 256;  // persistent: one 1024-thread workgroup per CU
   const int nblocks = (nwords + 3) / 4;
   if (node_index && 5 * nblocks <= SG_LDS_WORDS_MAX + 1984) {  // bitmap (whole blocks) + rank128 <= 159.75 KB
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<2, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (SG_LDS_WORDS_MAX + 1984 + 4) * 4);
-    hipLaunchKernelGGL(subgraph_stage_kernel<2>, dim3(grid), dim3(SG_THREADS), (5 * nblocks + 4) * sizeof(uint32_t),
-                       stream, pred, E, nb, nwords, st, s.counts);
+    hipLaunchKernelGGL((subgraph_stage_kernel<2, false>), dim3(grid), dim3(SG_THREADS),
+                       (5 * nblocks + 4) * sizeof(uint32_t), stream, pred, E, nb, nwords, st, s.counts, SgSingle{});
   } else if (node_index && nwords <= SG_LDS_WORDS_MAX) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<1>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<1, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_WORDS_MAX * 4);
-    hipLaunchKernelGGL(subgraph_stage_kernel<1>, dim3(grid), dim3(SG_THREADS), nwords * sizeof(uint32_t), stream, pred,
-                       E, nb, nwords, st, s.counts);
+    hipLaunchKernelGGL((subgraph_stage_kernel<1, false>), dim3(grid), dim3(SG_THREADS), nwords * sizeof(uint32_t), stream,
+                       pred, E, nb, nwords, st, s.counts, SgSingle{});
   } else {
-    hipLaunchKernelGGL(subgraph_stage_kernel<0>, dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords, st,
-                       s.counts);
+    hipLaunchKernelGGL((subgraph_stage_kernel<0, false>), dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords,
+                       st, s.counts, SgSingle{});
   }
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nb, s.offsets, d_count,
                      static_cast<const int*>(s.unsorted + 1));
@@ -856,6 +919,85 @@ extern "C" int tgp_connect_subgraph_fill(const int64_t* /*row*/, const int64_t* 
   hipLaunchKernelGGL(subgraph_copy_kernel, dim3(nb < 4096 ? nb : 4096), dim3(256), 0, stream, s.st, s.counts, s.offsets,
                      nb, out_row, out_col, w ? out_w : nullptr, out_edge_id);
   return check_launch("tgp_connect_subgraph_fill");
+}
+
+// ------------------------------------------------------------------------------------- subgraph, single pass (r4)
+static size_t subgraph_single_layout(void* ws, int64_t N, SubgraphWs* out) {
+  Carver cv(ws);
+  SubgraphWs s{};
+  s.relabel = cv.take<int32_t>(N > 0 ? N : 1);
+  s.member_bits = cv.take<uint32_t>((N > 0 ? N : 1) / 32 + 1);
+  s.unsorted = cv.take<int>(4);
+  if (out) *out = s;
+  return cv.off;
+}
+
+extern "C" size_t tgp_connect_subgraph_single_workspace_bytes(int64_t N) {
+  return subgraph_single_layout(nullptr, N, nullptr) + 512;
+}
+
+extern "C" int64_t tgp_connect_subgraph_single_status_words(int64_t E) { return 2 + cdiv(E > 0 ? E : 1, SG_CHUNK); }
+
+// byte offset, inside the workspace, of the int32 flag "an endpoint outside [0, N) was met" (what a refusal means
+// unless a spin bound was hit: the caller reads it only after a refused call)
+extern "C" int64_t tgp_connect_subgraph_single_bad_ids_offset(int64_t N) {
+  SubgraphWs s;
+  char base[1];
+  subgraph_single_layout(base, N, &s);
+  return reinterpret_cast<char*>(s.unsorted + 1) - base;
+}
+
+extern "C" int tgp_connect_subgraph_single(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                           const int64_t* node_index, int64_t k, int64_t N, int flags, float eps,
+                                           void* ws, size_t ws_bytes, int64_t* out_row, int64_t* out_col, float* out_w,
+                                           int64_t* out_edge_id, uint64_t* status, int64_t status_words,
+                                           uint64_t* result, uint32_t epoch, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E > 0 && N >= 0 && k >= 0 && row && col && out_row && out_col && (!w || out_w) && status && result,
+              TGP_ERR_INVALID, "tgp_connect_subgraph_single: bad argument");
+  TGP_REQUIRE(E < (1ll << 31) && N < (1ll << 31) && epoch != 0 && epoch < (1u << 29), TGP_ERR_RANGE,
+              "tgp_connect_subgraph_single: E/N >= 2^31 or epoch out of range");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_connect_subgraph_single_workspace_bytes(N), TGP_ERR_WORKSPACE,
+              "tgp_connect_subgraph_single: workspace too small");
+  TGP_REQUIRE(status_words >= tgp_connect_subgraph_single_status_words(E), TGP_ERR_WORKSPACE,
+              "tgp_connect_subgraph_single: status buffer too small");
+  TGP_REQUIRE(!out_edge_id || (flags & TGP_WANT_EDGE_ID), TGP_ERR_INVALID,
+              "tgp_connect_subgraph_single: out_edge_id needs TGP_WANT_EDGE_ID");
+  SubgraphWs s;
+  subgraph_single_layout(ws, N, &s);
+  const int nwords = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
+  (void)hipMemsetAsync(s.unsorted, 0, 4 * sizeof(int), stream);  // [0] node_index not ascending, [1] bad node ids
+  if (node_index) {
+    (void)hipMemsetAsync(s.member_bits, 0, static_cast<size_t>(nwords) * sizeof(uint32_t), stream);
+    if (k > 0)
+      hipLaunchKernelGGL(relabel_scatter_kernel, dim3(cdiv(k, 256)), dim3(256), 0, stream, node_index, k, N, s.relabel,
+                         s.member_bits, s.unsorted);
+  }
+  const int nb = cdiv(E, SG_CHUNK);
+  SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.unsorted, flags, eps,
+                    N, s.unsorted + 1};
+  SgSingle sg{out_row, out_col, w ? out_w : nullptr, out_edge_id, reinterpret_cast<unsigned long long*>(status),
+              reinterpret_cast<unsigned long long*>(result), static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT};
+  // persistent, every workgroup resident (the look-back waits for chunks of the same round): one per CU
+  int cus = tgp_device_cu_count();
+  if (cus <= 0) cus = 256;
+  const int grid = nb < cus ? nb : cus;
+  const int nblocks = (nwords + 3) / 4;
+  if (node_index && 5 * nblocks <= SG_LDS_WORDS_MAX + 1984) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<2, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (SG_LDS_WORDS_MAX + 1984 + 4) * 4);
+    hipLaunchKernelGGL((subgraph_stage_kernel<2, true>), dim3(grid), dim3(SG_THREADS),
+                       (5 * nblocks + 4) * sizeof(uint32_t), stream, pred, E, nb, nwords, SgStage{}, nullptr, sg);
+  } else if (node_index && nwords <= SG_LDS_WORDS_MAX) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_WORDS_MAX * 4);
+    hipLaunchKernelGGL((subgraph_stage_kernel<1, true>), dim3(grid), dim3(SG_THREADS), nwords * sizeof(uint32_t), stream,
+                       pred, E, nb, nwords, SgStage{}, nullptr, sg);
+  } else {
+    hipLaunchKernelGGL((subgraph_stage_kernel<0, true>), dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords,
+                       SgStage{}, nullptr, sg);
+  }
+  return check_launch("tgp_connect_subgraph_single");
 }
 
 // ------------------------------------------------------------------------------------- coalesce

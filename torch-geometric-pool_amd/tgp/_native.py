@@ -47,6 +47,11 @@ SIGNATURES = {
                                             _c_sz, _c_p, _c_p]),
     "tgp_connect_subgraph_fill": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_i64, _c_p,
                                            _c_p, _c_p, _c_p, _c_p]),
+    "tgp_connect_subgraph_single_workspace_bytes": (_c_sz, [_c_i64]),
+    "tgp_connect_subgraph_single_status_words": (_c_i64, [_c_i64]),
+    "tgp_connect_subgraph_single_bad_ids_offset": (_c_i64, [_c_i64]),
+    "tgp_connect_subgraph_single": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_sz, _c_p,
+                                             _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, ctypes.c_uint32, _c_p]),
     "tgp_connect_coalesce_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tgp_connect_coalesce_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_int, _c_f,
                                             _c_p, _c_sz, _c_p, _c_p]),

@@ -313,10 +313,16 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
                    None if w is None else torch.empty(0, dtype=torch.float32, device=dev))
             return out + (torch.empty(0, dtype=torch.int64, device=dev),) if want_edge_id else out
     L = N.lib()
-    ws = N.workspace(L.tgp_connect_subgraph_workspace_bytes(E, num_nodes), dev)
-    d_count = torch.empty(1, dtype=torch.int64, device=dev)
     st = N.stream_ptr(dev)
     eps = ops_eps()
+    if E > 0 and not torch.cuda.is_current_stream_capturing():
+        # ONE pass (r4): survivors written once at their final offsets of capacity-E buffers, which are then narrowed
+        # (edge_index' is a view whose two rows are contiguous); the count arrives in a pinned host word
+        got = _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id)
+        if got is not None:
+            return got
+    ws = N.workspace(L.tgp_connect_subgraph_workspace_bytes(E, num_nodes), dev)
+    d_count = torch.empty(1, dtype=torch.int64, device=dev)
     N.check(L.tgp_connect_subgraph_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(ni),
                                          0 if ni is None else ni.numel(), num_nodes, flags, eps, N.ptr(ws),
                                          ws.numel(), N.ptr(d_count), st), "tgp_connect_subgraph_count")
@@ -329,6 +335,40 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
                                         N.ptr(out_ei[1]) if n_out else None, N.ptr(out_w),
                                         N.ptr(out_id) if n_out else None, st),
             "tgp_connect_subgraph_fill")
+    return (out_ei, out_w, out_id) if want_edge_id else (out_ei, out_w)
+
+
+def _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id):
+    """``tgp_connect_subgraph_single``; None when the kernel refused for a reason other than bad node ids (a look-back
+    spin bound on a shared device): the caller takes the count -> fill pair."""
+    ws = N.workspace(L.tgp_connect_subgraph_single_workspace_bytes(num_nodes), dev)
+    cap = torch.empty(2, E, dtype=torch.int64, device=dev)
+    cap_w = None if w is None else torch.empty(E, dtype=torch.float32, device=dev)
+    cap_id = torch.empty(E, dtype=torch.int64, device=dev) if want_edge_id else None
+    state = _sps_state(dev, st, L.tgp_connect_subgraph_single_status_words(E))
+    epoch = state.next_epoch()
+    cap_p = cap.data_ptr()
+    N.check(L.tgp_connect_subgraph_single(row.data_ptr(), col.data_ptr(), N.ptr(w), E, N.ptr(ni),
+                                          0 if ni is None else ni.numel(), num_nodes, flags, eps, ws.data_ptr(),
+                                          ws.numel(), cap_p, cap_p + 8 * E, N.ptr(cap_w), N.ptr(cap_id),
+                                          state.status.data_ptr(), state.status.numel(), state.pinned.data_ptr(), epoch,
+                                          st), "tgp_connect_subgraph_single")
+    total = state.wait(epoch)
+    if total & 0x80000000:
+        # refused: node ids outside [0, num_nodes) (flag word [1] of the workspace's status ints, behind the relabel
+        # table and the bitmap) -- the reference's index ops raise for these inputs too -- or a spin bound
+        off = L.tgp_connect_subgraph_single_bad_ids_offset(num_nodes)
+        if int(ws[off: off + 4].view(torch.int32)[0]) != 0:
+            raise IndexError("edge_index holds node ids outside [0, num_nodes) (or cluster ids outside "
+                             "[0, num_supernodes)): the reference's index ops raise for these inputs too")
+        return None
+    n_out = total & 0x7FFFFFFF
+    out_ei, out_w = cap[:, :n_out], None if cap_w is None else cap_w[:n_out]
+    out_id = None if cap_id is None else cap_id[:n_out]
+    if E * 16 > SPS_COMPACT_BYTES and 4 * n_out < E:  # mostly empty capacity buffers of a large list: exact copies
+        out_ei = out_ei.contiguous()
+        out_w = None if out_w is None else out_w.clone()
+        out_id = None if out_id is None else out_id.clone()
     return (out_ei, out_w, out_id) if want_edge_id else (out_ei, out_w)
 
 
