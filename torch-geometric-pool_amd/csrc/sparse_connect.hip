@@ -281,20 +281,18 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred
   // the (row, col) stream of the next chunk is requested before this chunk's dependent work starts
   SgEdges nxt;
   sg_fetch(pred, static_cast<int64_t>(blockIdx.x) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER, E, nxt);
-  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const int64_t e0 = static_cast<int64_t>(chunk) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER;
-    SgEdges t = nxt;
-    if (chunk + static_cast<int>(gridDim.x) < nchunks)
-      sg_fetch(pred, e0 + static_cast<int64_t>(gridDim.x) * SG_CHUNK, E, nxt);
-    const bool met_bad = sg_eval<(LDSB >= 1)>(pred, s_dyn, e0, t);
-    uint32_t mine = 0;
+  if constexpr (!SINGLE) {
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+      const int64_t e0 = static_cast<int64_t>(chunk) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER;
+      SgEdges t = nxt;
+      if (chunk + static_cast<int>(gridDim.x) < nchunks)
+        sg_fetch(pred, e0 + static_cast<int64_t>(gridDim.x) * SG_CHUNK, E, nxt);
+      sg_eval<(LDSB >= 1)>(pred, s_dyn, e0, t);
+      uint32_t mine = 0;
 #pragma unroll
-    for (int j = 0; j < SG_PER; ++j) mine += t.keep[j] ? 1u : 0u;
-    if constexpr (SINGLE) mine |= met_bad ? 0x10000u : 0u;  // (survivors of a chunk fit 13 bits: the flag rides above)
-    uint32_t total;
-    const uint32_t rank0 = block_excl_scan_1024(mine, s_w, &total);
-    if constexpr (!SINGLE) {
-      int64_t pos = static_cast<int64_t>(chunk) * SG_CHUNK + rank0;
+      for (int j = 0; j < SG_PER; ++j) mine += t.keep[j] ? 1u : 0u;
+      uint32_t total;
+      int64_t pos = static_cast<int64_t>(chunk) * SG_CHUNK + block_excl_scan_1024(mine, s_w, &total);
       if (threadIdx.x == 0) block_counts[chunk] = total;
       // (computing the new ids ahead of the scan, to overlap their LDS look-ups with its barriers, measured 68 vs 64 us)
 #pragma unroll
@@ -307,41 +305,85 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred
           ++pos;
         }
       }
-    } else {
-      if (wave_id() == 0) {
-        const uint32_t tot = total & 0xFFFFu;
-        bool refused = (total >> 16) != 0u;
-        const int lane = lane_id();
-        if (lane == 0)
-          sps_store(sg.status + 2 + chunk, sg.tag | (chunk == 0 ? SPS_PRE : SPS_AGG) | (refused ? 0x80000000ull : 0ull) | tot);
-        uint32_t excl = 0;
-        if (chunk > 0) {
-          bool before = false;
-          sps_lookback(sg.status, chunk, sg.tag, &excl, &before);
-          refused = refused || before;
-          if (lane == 0)
-            sps_store(sg.status + 2 + chunk, sg.tag | SPS_PRE | (refused ? 0x80000000ull : 0ull) |
-                                                 static_cast<unsigned long long>((excl + tot) & 0x7FFFFFFFu));
-        }
-        if (lane == 0) {
-          s_base = excl;
-          if (chunk == nchunks - 1)
-            __hip_atomic_store(sg.result, sg.tag | (refused ? 0x80000000ull : 0ull) |
-                                              static_cast<unsigned long long>((excl + tot) & 0x7FFFFFFFu),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-      }
-      __syncthreads();
-      int64_t pos = static_cast<int64_t>(s_base) + (rank0 & 0xFFFFu);
+    }
+  } else {
+    // Software pipeline over the workgroup's chunks: chunk k + 1 is evaluated and its count PUBLISHED before chunk k
+    // waits for its prefix, so the words chunk k needs (chunks of the same round, on other CUs) have had a whole chunk's
+    // time to arrive -- with one workgroup per CU nothing else would hide that round trip (r4: 100 us with the wait
+    // in line against 64 us for the staging pass of the count -> fill pair).
+    const int G = static_cast<int>(gridDim.x);
+    auto eval_publish = [&](int chunk, SgEdges& t, uint32_t& rank, uint32_t& tot, bool& refused) {
+      const int64_t e0 = static_cast<int64_t>(chunk) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER;
+      const bool met_bad = sg_eval<(LDSB >= 1)>(pred, s_dyn, e0, t);
+      uint32_t mine = met_bad ? 0x10000u : 0u;  // (survivors of a chunk fit 13 bits: the flag rides above)
 #pragma unroll
-      for (int j = 0; j < SG_PER; ++j) {
-        if (t.keep[j]) {
-          sg.out_row[pos] = pred.relabel ? static_cast<int64_t>(new_id(t.r[j])) : t.r[j];
-          sg.out_col[pos] = pred.relabel ? static_cast<int64_t>(new_id(t.c[j])) : t.c[j];
-          if (sg.out_w) sg.out_w[pos] = t.w[j];
-          if (sg.out_eid) sg.out_eid[pos] = e0 + j;
-          ++pos;
+      for (int j = 0; j < SG_PER; ++j) mine += t.keep[j] ? 1u : 0u;
+      uint32_t total;
+      rank = block_excl_scan_1024(mine, s_w, &total) & 0xFFFFu;
+      tot = total & 0xFFFFu;
+      refused = (total >> 16) != 0u;
+      if (threadIdx.x == 0)
+        sps_store(sg.status + 2 + chunk, sg.tag | (chunk == 0 ? SPS_PRE : SPS_AGG) | (refused ? 0x80000000ull : 0ull) | tot);
+    };
+    int chunk = blockIdx.x;
+    if (chunk < nchunks) {
+      SgEdges cur = nxt;
+      if (chunk + G < nchunks)
+        sg_fetch(pred, static_cast<int64_t>(chunk + G) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER, E, nxt);
+      uint32_t rank_c, tot_c;
+      bool ref_c;
+      eval_publish(chunk, cur, rank_c, tot_c, ref_c);
+      for (;;) {
+        const bool has_next = chunk + G < nchunks;
+        SgEdges tn;
+        uint32_t rank_n = 0, tot_n = 0;
+        bool ref_n = false;
+        if (has_next) {
+          tn = nxt;
+          if (chunk + 2 * G < nchunks)
+            sg_fetch(pred, static_cast<int64_t>(chunk + 2 * G) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER, E,
+                     nxt);
+          eval_publish(chunk + G, tn, rank_n, tot_n, ref_n);
         }
+        if (wave_id() == 0) {  // the prefix of `chunk`
+          const int lane = lane_id();
+          uint32_t excl = 0;
+          bool refused = ref_c;
+          if (chunk > 0) {
+            bool before = false;
+            sps_lookback(sg.status, chunk, sg.tag, &excl, &before);
+            refused = refused || before;
+            if (lane == 0)
+              sps_store(sg.status + 2 + chunk, sg.tag | SPS_PRE | (refused ? 0x80000000ull : 0ull) |
+                                                   static_cast<unsigned long long>((excl + tot_c) & 0x7FFFFFFFu));
+          }
+          if (lane == 0) {
+            s_base = excl;
+            if (chunk == nchunks - 1)
+              __hip_atomic_store(sg.result, sg.tag | (refused ? 0x80000000ull : 0ull) |
+                                                static_cast<unsigned long long>((excl + tot_c) & 0x7FFFFFFFu),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+        __syncthreads();
+        int64_t pos = static_cast<int64_t>(s_base) + rank_c;
+        const int64_t e0 = static_cast<int64_t>(chunk) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER;
+#pragma unroll
+        for (int j = 0; j < SG_PER; ++j) {
+          if (cur.keep[j]) {
+            sg.out_row[pos] = pred.relabel ? static_cast<int64_t>(new_id(cur.r[j])) : cur.r[j];
+            sg.out_col[pos] = pred.relabel ? static_cast<int64_t>(new_id(cur.c[j])) : cur.c[j];
+            if (sg.out_w) sg.out_w[pos] = cur.w[j];
+            if (sg.out_eid) sg.out_eid[pos] = e0 + j;
+            ++pos;
+          }
+        }
+        if (!has_next) break;
+        cur = tn;
+        rank_c = rank_n;
+        tot_c = tot_n;
+        ref_c = ref_n;
+        chunk += G;
       }
     }
   }

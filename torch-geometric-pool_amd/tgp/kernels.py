@@ -151,7 +151,7 @@ def _edge_rows(edge_index: Tensor) -> Tuple[Tensor, Tensor]:
 # ------------------------------------------------------------------------- A1 + A2 + A4/A5 + A6, batches of small graphs
 _SPS_STATE: dict = {}  # (device index, stream handle) -> _SpsState
 _SPS_DECLINED: dict = {}
-SPS_COMPACT_BYTES = 64 << 20  # capacity buffers above this are replaced by exact copies when mostly empty
+SPS_COMPACT_BYTES = 1 << 30  # capacity buffers above this are replaced by exact copies when mostly empty
 
 
 class _SpsState:
