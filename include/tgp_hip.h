@@ -643,6 +643,25 @@ size_t tgp_debug_sort_workspace_bytes(int64_t n);
 int tgp_debug_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, int64_t n, int key_bits,
                              uint64_t* keys_out, uint32_t* vals_out, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * pack / unpack of the variable-size all-gather of pooled sparse outputs (r4).  A rank's pooled graphs
+ * (x [K,F] fp32, batch [K] int64 or NULL, edge_index rows [E] int64, edge_weight [E] fp32 or NULL) go into one byte
+ * buffer of `capacity` bytes behind a 128-byte header {magic, K, E, B, F, has_w, needed_bytes}; when needed_bytes >
+ * capacity only the header is written (every rank then sees how much room the largest rank needs).  The buffers of all
+ * ranks are all-gathered as they are; tgp_gather_unpack_f32 reads `world` of them ([world, capacity] bytes) and writes
+ * the merged tensors, node ids of rank r shifted by the supernodes, graph ids by the graphs of the ranks before it
+ * (tgp/data/collate.py:144-153).  Output sizes = sums over the headers (the caller reads them once).
+ * ---------------------------------------------------------------------------------- */
+int64_t tgp_gather_pack_bytes(int64_t num_supernodes, int64_t num_edges, int64_t num_features, int has_weight);
+int tgp_gather_pack_f32(const float* x, int64_t x_row_stride, const int64_t* batch /* NULL ok */, const int64_t* row,
+                        const int64_t* col, const float* edge_weight /* NULL ok */, int64_t num_supernodes,
+                        int64_t num_edges, int64_t num_graphs, int64_t num_features, int64_t capacity, void* out,
+                        void* stream);
+int tgp_gather_unpack_f32(const void* gathered, int64_t capacity, int world,
+                          int64_t max_words /* 4-byte words of the largest payload: sizes the grid */, float* x_out,
+                          int64_t* batch_out /* NULL ok */, int64_t* row_out, int64_t* col_out,
+                          float* weight_out /* NULL ok */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,9 +88,26 @@ def _worker(rank, world, port, out_dir):
         inplace.extend(pi.flush())
         bucket_ok = bucket_ok and len(inplace) == 3 and all(
             torch.allclose(h[0], pxp * (j + 1)) and torch.allclose(h[1], pap * (j + 1)) for j, h in enumerate(inplace))
+        # asynchronous variable-size gather: three steps in flight two deep, a capacity that is too small at first (the
+        # ranks grow it from the headers, alike, and repeat the step) -- every step's merged result must be the
+        # synchronous one scaled by its step number
+        sg = D.SparseGather(depth=2, capacity=256)
+        outs = []
+        for j in range(3):
+            sg.start(loc["x"] * (j + 1), loc["edge_index"], loc["edge_weight"] * (j + 1), loc["batch"], hi - lo)
+            outs.extend(sg.take_ready())
+        outs.extend(sg.flush())
+        sparse_ok = len(outs) == 3 and sg.capacity > 256 and all(
+            torch.allclose(o[0], gx * (j + 1)) and torch.equal(o[1], gei) and torch.allclose(o[2], gew * (j + 1))
+            and torch.equal(o[3], gb) for j, o in enumerate(outs))
+        # unweighted lists and 1-D features travel too
+        sg2 = D.SparseGather(depth=1)
+        sg2.start(loc["x"][:, 0].contiguous(), loc["edge_index"], None, loc["batch"], hi - lo)
+        o2 = sg2.wait()
+        sparse_ok = sparse_ok and o2[2] is None and torch.equal(o2[1], gei) and torch.allclose(o2[0], gx[:, 0])
         if rank == 0:
             torch.save(dict(gx=gx, gei=gei, gew=gew, gb=gb, gxp=gxp, gap=gap, pxp=pxp, pap=pap,
-                            bucket_ok=torch.tensor(bucket_ok)),
+                            bucket_ok=torch.tensor(bucket_ok), sparse_ok=torch.tensor(sparse_ok)),
                        os.path.join(out_dir, "gathered.pt"))
         dist.barrier()
     finally:
@@ -139,3 +156,4 @@ def test_two_rank_gather_matches_single_process(tmp_path):
     torch.testing.assert_close(got["pxp"], O.reduce_dense(s, xd)[[0, 1, 3, 4]], rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(got["pap"], ap_full[[0, 1, 3, 4]], rtol=1e-6, atol=1e-6)
     assert bool(got["bucket_ok"])  # bucketed gather: five steps, three per collective, order and values kept
+    assert bool(got["sparse_ok"])  # SparseGather: async steps, capacity growth agreed from the headers, no weights, 1-D x

@@ -1,0 +1,133 @@
+// the variable-size all-gather of pooled SPARSE outputs as ONE payload collective.
+//
+// A rank's pooled graphs -- x [K,F] fp32, batch [K] int64, edge_index [2,E] int64, edge_weight [E] fp32 -- are packed
+// by one launch into one byte buffer behind a 128-byte header {magic, K, E, B, F, has_w, needed_bytes}; the buffers of
+// all ranks travel in ONE all_gather_into_tensor (capacity-padded: the capacity is agreed between the ranks from the
+// headers themselves, no count exchange in front of the payload), and one launch unpacks the gathered buffer into the
+// merged tensors, shifting the node ids / graph ids of rank r by the totals of the ranks before it -- the merge rule the
+// reference uses when it collates pooled graphs on the CPU (tgp/data/collate.py:144-153).  (r3: a count exchange with
+// a host read + four padded collectives + torch offset ops: 0.35 ms on a one-rank group against 0.09 ms of compute.)
+#include "primitives.h"
+
+namespace tgp {
+
+constexpr int64_t GP_MAGIC = 0x7467705f67617468ll;  // "tgp_gath"
+constexpr int GP_HEADER_WORDS = 16;                 // int64 words: 128 bytes
+
+struct GpLayout {
+  int64_t x, batch, row, col, w, end;  // byte offsets of the segments (16-byte aligned)
+};
+__host__ __device__ inline int64_t gp_align(int64_t v) { return (v + 15) & ~int64_t(15); }
+__host__ __device__ inline GpLayout gp_layout(int64_t K, int64_t E, int64_t F, int has_w) {
+  GpLayout l;
+  l.x = GP_HEADER_WORDS * 8;
+  l.batch = gp_align(l.x + K * F * 4);
+  l.row = gp_align(l.batch + K * 8);
+  l.col = gp_align(l.row + E * 8);
+  l.w = gp_align(l.col + E * 8);
+  l.end = gp_align(l.w + (has_w ? E * 4 : 0));
+  return l;
+}
+
+__global__ __launch_bounds__(256) void gp_pack_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                      const int64_t* __restrict__ batch, const int64_t* __restrict__ row,
+                                                      const int64_t* __restrict__ col, const float* __restrict__ w,
+                                                      int64_t K, int64_t E, int64_t B, int64_t F, int64_t capacity,
+                                                      char* __restrict__ out) {
+  const GpLayout l = gp_layout(K, E, F, w != nullptr);
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x, nthr = static_cast<int64_t>(gridDim.x) * 256;
+  if (tid < GP_HEADER_WORDS) {
+    const int64_t h[GP_HEADER_WORDS] = {GP_MAGIC, K, E, B, F, w ? 1 : 0, l.end, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    reinterpret_cast<int64_t*>(out)[tid] = h[tid];
+  }
+  if (l.end > capacity) return;  // does not fit: the header alone tells every rank how much room is needed
+  float* ox = reinterpret_cast<float*>(out + l.x);
+  for (int64_t i = tid; i < K * F; i += nthr) ox[i] = x[(i / F) * x_stride + (i % F)];
+  int64_t* ob = reinterpret_cast<int64_t*>(out + l.batch);
+  for (int64_t i = tid; i < K; i += nthr) ob[i] = batch ? batch[i] : 0;
+  int64_t* orow = reinterpret_cast<int64_t*>(out + l.row);
+  int64_t* ocol = reinterpret_cast<int64_t*>(out + l.col);
+  for (int64_t i = tid; i < E; i += nthr) {
+    orow[i] = row[i];
+    ocol[i] = col[i];
+  }
+  if (w) {
+    float* ow = reinterpret_cast<float*>(out + l.w);
+    for (int64_t i = tid; i < E; i += nthr) ow[i] = w[i];
+  }
+}
+
+// blockIdx.y = source rank; node ids += supernodes of the ranks before it, graph ids += their graphs
+__global__ __launch_bounds__(256) void gp_unpack_kernel(const char* __restrict__ gathered, int64_t capacity, int world,
+                                                        float* __restrict__ x_out, int64_t* __restrict__ batch_out,
+                                                        int64_t* __restrict__ row_out, int64_t* __restrict__ col_out,
+                                                        float* __restrict__ w_out) {
+  const int r = blockIdx.y;
+  int64_t koff = 0, eoff = 0, goff = 0;
+  for (int q = 0; q < r; ++q) {
+    const int64_t* h = reinterpret_cast<const int64_t*>(gathered + static_cast<int64_t>(q) * capacity);
+    koff += h[1];
+    eoff += h[2];
+    goff += h[3];
+  }
+  const char* src = gathered + static_cast<int64_t>(r) * capacity;
+  const int64_t* h = reinterpret_cast<const int64_t*>(src);
+  const int64_t K = h[1], E = h[2], F = h[4];
+  const int has_w = static_cast<int>(h[5]);
+  const GpLayout l = gp_layout(K, E, F, has_w);
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x, nthr = static_cast<int64_t>(gridDim.x) * 256;
+  const float* sx = reinterpret_cast<const float*>(src + l.x);
+  for (int64_t i = tid; i < K * F; i += nthr) x_out[koff * F + i] = sx[i];
+  const int64_t* sb = reinterpret_cast<const int64_t*>(src + l.batch);
+  if (batch_out)
+    for (int64_t i = tid; i < K; i += nthr) batch_out[koff + i] = sb[i] + goff;
+  const int64_t* sr = reinterpret_cast<const int64_t*>(src + l.row);
+  const int64_t* sc = reinterpret_cast<const int64_t*>(src + l.col);
+  for (int64_t i = tid; i < E; i += nthr) {
+    row_out[eoff + i] = sr[i] + koff;
+    col_out[eoff + i] = sc[i] + koff;
+  }
+  if (w_out && has_w) {
+    const float* sw = reinterpret_cast<const float*>(src + l.w);
+    for (int64_t i = tid; i < E; i += nthr) w_out[eoff + i] = sw[i];
+  }
+}
+
+}  // namespace tgp
+
+using namespace tgp;
+
+extern "C" int64_t tgp_gather_pack_bytes(int64_t K, int64_t E, int64_t F, int has_weight) {
+  return gp_layout(K, E, F, has_weight).end;
+}
+
+extern "C" int tgp_gather_pack_f32(const float* x, int64_t x_stride, const int64_t* batch, const int64_t* row,
+                                   const int64_t* col, const float* w, int64_t K, int64_t E, int64_t B, int64_t F,
+                                   int64_t capacity, void* out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(K >= 0 && E >= 0 && B >= 0 && F >= 0 && capacity >= GP_HEADER_WORDS * 8 && out, TGP_ERR_INVALID,
+              "tgp_gather_pack_f32: bad argument");
+  TGP_REQUIRE((K == 0 || F == 0 || x) && (E == 0 || (row && col)), TGP_ERR_INVALID, "tgp_gather_pack_f32: null pointer");
+  const int64_t words = K * F + 2 * K + 5 * E + GP_HEADER_WORDS;
+  int64_t blocks = (words + 256 * 8 - 1) / (256 * 8);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gp_pack_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, x, x_stride, batch, row,
+                     col, w, K, E, B, F, capacity, static_cast<char*>(out));
+  return check_launch("tgp_gather_pack_f32");
+}
+
+extern "C" int tgp_gather_unpack_f32(const void* gathered, int64_t capacity, int world, int64_t max_words,
+                                     float* x_out, int64_t* batch_out, int64_t* row_out, int64_t* col_out,
+                                     float* w_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(gathered && capacity >= GP_HEADER_WORDS * 8 && world >= 1 && world <= 65535, TGP_ERR_INVALID,
+              "tgp_gather_unpack_f32: bad argument");
+  int64_t blocks = (max_words + 256 * 8 - 1) / (256 * 8);  // max_words: 4-byte words of the largest rank's payload
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(gp_unpack_kernel, dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(world)), dim3(256), 0,
+                     stream, static_cast<const char*>(gathered), capacity, world, x_out, batch_out, row_out, col_out,
+                     w_out);
+  return check_launch("tgp_gather_unpack_f32");
+}

@@ -223,44 +223,197 @@ def all_gather_dense(tensors: Sequence[Tensor], group=None) -> List[Tensor]:
     return out
 
 
+_GP_MAGIC = 0x7467705F67617468
+_GP_HEADER = 16  # int64 words
+
+
+def _gp_align(v: int) -> int:
+    return (v + 15) & ~15
+
+
+def _gp_layout(K: int, E: int, F: int, has_w: bool):
+    x = _GP_HEADER * 8
+    batch = _gp_align(x + K * F * 4)
+    row = _gp_align(batch + K * 8)
+    col = _gp_align(row + E * 8)
+    w = _gp_align(col + E * 8)
+    end = _gp_align(w + (E * 4 if has_w else 0))
+    return x, batch, row, col, w, end
+
+
+class SparseGather:
+    """All-gather of VARIABLE-SIZE pooled sparse outputs (x [K,F], edge_index [2,E], edge_weight [E] or None, batch [K])
+    as ONE payload collective per step, asynchronous like :class:`PackedGather`.
+
+    ``start`` packs the rank's outputs behind a 128-byte header {K, E, B, F, has_w, needed bytes} into one byte buffer
+    (one native launch on a device, ``tgp_gather_pack_f32``) and issues ONE ``all_gather_into_tensor`` of capacity-padded
+    buffers on the collective's own stream.  There is no count exchange in front of it: the capacity is agreed FROM the
+    headers -- every rank sees every header, so when some rank needs more room than the current capacity all ranks
+    reach the same verdict, grow to the same size and repeat that step's collective (a payload that did not fit is a
+    header only).  The result is finalised when it is asked for (``take_ready`` / ``wait`` / ``flush``): one read of
+    the headers (world x 16 integers: the output shapes live on the host), one native launch that unpacks and shifts
+    node ids / graph ids of rank r by the totals of the ranks before it (``tgp_gather_unpack_f32``; the merge rule of
+    tgp/data/collate.py:144-153).  At most ``depth`` collectives are in flight, so a step's gather overlaps the next
+    steps' kernels.  Every rank must call ``start`` the same number of times.
+
+    A result is ``(x, edge_index, edge_weight, batch)`` of ALL ranks' graphs, rank-major, as a single process would
+    have produced them for the concatenated batch."""
+
+    INITIAL_CAPACITY = 64 * 1024  # bytes; the SAME on every rank (a collective needs equal buffer sizes): it only grows,
+                                  # and only by the rule below, which every rank applies to the same headers
+
+    def __init__(self, group=None, force_collective: bool = False, depth: int = 2, capacity: Optional[int] = None):
+        self.group = group
+        self.world = _world(group)
+        self._collective = self.world > 1 or (dist.is_available() and dist.is_initialized()
+                                              and (force_collective or bool(os.environ.get("TGP_FORCE_COLLECTIVE"))))
+        self.depth = max(int(depth), 1)
+        # ``capacity``: a caller that knows its payloads may start larger (the same value on every rank!)
+        self.capacity = max(int(capacity if capacity is not None else self.INITIAL_CAPACITY), _GP_HEADER * 8)
+        self._inflight: List[tuple] = []   # (work, gathered, send, capacity, inputs)
+        self._ready: List[tuple] = []
+
+    # ---- packing --------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _pack(x, edge_index, edge_weight, batch, num_graphs, capacity) -> Tensor:
+        K, F = (x.size(0), x.size(1)) if x.dim() == 2 else (x.size(0), 1)
+        E = edge_index.size(1)
+        send = torch.empty(capacity, dtype=torch.uint8, device=x.device)
+        if x.is_cuda:
+            from . import _native as N
+            x2 = x.reshape(K, F)
+            x2 = x2 if x2.dtype == torch.float32 and x2.stride(1) == 1 else x2.to(torch.float32).contiguous()
+            ei = edge_index
+            if not (ei.dtype == torch.int64 and (ei.stride(1) == 1 or E <= 1)):
+                ei = ei.to(torch.int64).contiguous()
+            w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
+            b = None if batch is None else N.i64c(batch)
+            N.check(N.lib().tgp_gather_pack_f32(N.ptr(x2) if K * F else None, x2.stride(0) if K else F, N.ptr(b),
+                                                ei.data_ptr() if E else None,
+                                                ei.data_ptr() + 8 * ei.stride(0) if E else None, N.ptr(w), K, E,
+                                                int(num_graphs), F, capacity, send.data_ptr(),
+                                                N.stream_ptr(x.device)), "tgp_gather_pack_f32")
+            return send
+        # host tensors (the gloo tests of the N > 1 logic): the same layout with torch ops
+        ox, ob, orow, ocol, ow, end = _gp_layout(K, E, F, edge_weight is not None)
+        head = torch.zeros(_GP_HEADER, dtype=torch.int64)
+        head[:7] = torch.tensor([_GP_MAGIC, K, E, int(num_graphs), F, int(edge_weight is not None), end])
+        send[: _GP_HEADER * 8] = head.view(torch.uint8)
+        if end <= capacity:
+            send[ox: ox + K * F * 4] = x.reshape(-1).to(torch.float32).contiguous().view(torch.uint8)
+            bb = torch.zeros(K, dtype=torch.int64) if batch is None else batch.to(torch.int64)
+            send[ob: ob + K * 8] = bb.contiguous().view(torch.uint8)
+            send[orow: orow + E * 8] = edge_index[0].contiguous().view(torch.uint8)
+            send[ocol: ocol + E * 8] = edge_index[1].contiguous().view(torch.uint8)
+            if edge_weight is not None:
+                send[ow: ow + E * 4] = edge_weight.reshape(-1).to(torch.float32).contiguous().view(torch.uint8)
+        return send
+
+    def _issue(self, inputs) -> None:
+        x, edge_index, edge_weight, batch, num_graphs = inputs
+        send = self._pack(x, edge_index, edge_weight, batch, num_graphs, self.capacity)
+        gathered = torch.empty(self.world * self.capacity, dtype=torch.uint8, device=x.device)
+        work = None
+        if self._collective:
+            work = dist.all_gather_into_tensor(gathered, send, group=self.group, async_op=True)
+        else:
+            gathered.copy_(send)
+        self._inflight.append((work, gathered, send, self.capacity, inputs))
+
+    # ---- public ---------------------------------------------------------------------------------------------------
+    def start(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Optional[Tensor],
+              num_graphs_local: int) -> None:
+        while len(self._inflight) >= self.depth:
+            self._finalise_oldest()
+        self._issue((x, edge_index, edge_weight, batch, int(num_graphs_local)))
+
+    def _finalise_oldest(self) -> None:
+        work, gathered, send, capacity, inputs = self._inflight.pop(0)
+        if work is not None:
+            work.wait()
+        heads = gathered.view(self.world, capacity)[:, : _GP_HEADER * 8].contiguous().view(torch.int64)
+        heads = heads.view(self.world, _GP_HEADER).cpu()  # the one host read of a step: output shapes
+        if not bool((heads[:, 0] == _GP_MAGIC).all()):
+            raise RuntimeError("SparseGather: a gathered buffer does not start with a pack header")
+        need = int(heads[:, 6].max())
+        if need > capacity:
+            # some rank's payload did not fit: every rank sees the same headers, grows alike and repeats this step's
+            # collective (and, in order, those issued behind it with the old capacity)
+            redo = [inputs] + [it[4] for it in self._inflight]
+            for it in self._inflight:
+                if it[0] is not None:
+                    it[0].wait()
+            self._inflight = []
+            self.capacity = max(self.capacity, ((need + need // 4 + 4095) // 4096) * 4096)
+            for inp in redo:
+                self._issue(inp)
+            return self._finalise_oldest()
+        Ks, Es, F = heads[:, 1], heads[:, 2], int(heads[0, 4])
+        has_w = bool(heads[0, 5])
+        Kt, Et = int(Ks.sum()), int(Es.sum())
+        dev = gathered.device
+        x_in, _, _, b_in, _ = inputs
+        x_out = torch.empty(Kt, F, dtype=torch.float32, device=dev)
+        b_out = torch.empty(Kt, dtype=torch.int64, device=dev)
+        ei_out = torch.empty(2, Et, dtype=torch.int64, device=dev)
+        w_out = torch.empty(Et, dtype=torch.float32, device=dev) if has_w else None
+        if gathered.is_cuda:
+            from . import _native as N
+            max_words = int((Ks * F + 2 * Ks + 5 * Es).max())
+            N.check(N.lib().tgp_gather_unpack_f32(gathered.data_ptr(), capacity, self.world, max_words,
+                                                  N.ptr(x_out) if Kt * F else None, N.ptr(b_out) if Kt else None,
+                                                  ei_out.data_ptr() if Et else None,
+                                                  ei_out.data_ptr() + 8 * Et if Et else None, N.ptr(w_out),
+                                                  N.stream_ptr(dev)), "tgp_gather_unpack_f32")
+        else:
+            g2 = gathered.view(self.world, capacity)
+            koff = eoff = goff = 0
+            for r in range(self.world):
+                K, E, B = int(heads[r, 1]), int(heads[r, 2]), int(heads[r, 3])
+                ox, ob, orow, ocol, ow, _ = _gp_layout(K, E, F, has_w)
+                x_out[koff: koff + K] = g2[r, ox: ox + K * F * 4].contiguous().view(torch.float32).view(K, F)
+                b_out[koff: koff + K] = g2[r, ob: ob + K * 8].contiguous().view(torch.int64) + goff
+                ei_out[0, eoff: eoff + E] = g2[r, orow: orow + E * 8].contiguous().view(torch.int64) + koff
+                ei_out[1, eoff: eoff + E] = g2[r, ocol: ocol + E * 8].contiguous().view(torch.int64) + koff
+                if has_w:
+                    w_out[eoff: eoff + E] = g2[r, ow: ow + E * 4].contiguous().view(torch.float32)
+                koff, eoff, goff = koff + K, eoff + E, goff + B
+        if x_in.dim() == 1:
+            x_out = x_out.view(-1)
+        if x_in.dtype != torch.float32 and x_in.is_floating_point():
+            x_out = x_out.to(x_in.dtype)
+        self._ready.append((x_out, ei_out, w_out, b_out if b_in is not None else None))
+
+    def take_ready(self) -> List[tuple]:
+        """Results whose collective has already completed (never blocks on a collective still in flight)."""
+        while self._inflight and (self._inflight[0][0] is None or self._inflight[0][0].is_completed()):
+            self._finalise_oldest()
+        res, self._ready = self._ready, []
+        return res
+
+    def wait(self):
+        """The oldest result not yet handed out (waits for its collective), or None."""
+        if not self._ready and self._inflight:
+            self._finalise_oldest()
+        return self._ready.pop(0) if self._ready else None
+
+    def flush(self) -> List[tuple]:
+        while self._inflight:
+            self._finalise_oldest()
+        res, self._ready = self._ready, []
+        return res
+
+
 def all_gather_sparse(x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor,
                       num_graphs_local: int, group=None, force_collective: bool = False):
-    """Gather variable-size pooled graphs: counts first, then max-padded payloads, then shift the
-    pooled node ids / graph ids of rank r by the totals of ranks < r.  ``force_collective`` (or
-    ``TGP_FORCE_COLLECTIVE``): a one-rank process group still runs the collectives (single-GPU exercise of the
-    variable-size RCCL path)."""
+    """Gather variable-size pooled graphs from every rank, synchronously: one :class:`SparseGather` step (one payload
+    collective; node ids / graph ids of rank r shifted by the totals of ranks < r).  ``force_collective`` (or
+    ``TGP_FORCE_COLLECTIVE``): a one-rank process group still runs the collective."""
     world = _world(group)
     forced = (dist.is_available() and dist.is_initialized()
               and (force_collective or bool(os.environ.get("TGP_FORCE_COLLECTIVE"))))
     if world == 1 and not forced:
         return x, edge_index, edge_weight, batch
-    dev = x.device
-    mine = torch.tensor([x.size(0), edge_index.size(1), num_graphs_local], dtype=torch.long, device=dev)
-    allc = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(allc, mine, group=group)
-    allc = torch.stack(allc).cpu()
-    k_max, e_max = int(allc[:, 0].max()), int(allc[:, 1].max())
-
-    def gather_rows(t: Tensor, n_max: int) -> Tensor:
-        pad = t.new_zeros((n_max,) + tuple(t.shape[1:]))
-        pad[: t.size(0)] = t
-        buf = torch.empty((world * n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-        dist.all_gather_into_tensor(buf, pad, group=group)
-        return buf.view((world, n_max) + tuple(t.shape[1:]))
-
-    gx = gather_rows(x, k_max)
-    gb = gather_rows(batch, k_max)
-    ge = gather_rows(edge_index.t().contiguous(), e_max)
-    gw = None if edge_weight is None else gather_rows(edge_weight, e_max)
-    xs, bs, es, ws = [], [], [], []
-    node_off = graph_off = 0
-    for r in range(world):
-        k, e, g = (int(v) for v in allc[r])
-        xs.append(gx[r, :k])
-        bs.append(gb[r, :k] + graph_off)
-        es.append(ge[r, :e] + node_off)
-        if gw is not None:
-            ws.append(gw[r, :e])
-        node_off += k
-        graph_off += g
-    return (torch.cat(xs), torch.cat(es).t().contiguous(), None if gw is None else torch.cat(ws), torch.cat(bs))
+    g = SparseGather(group=group, force_collective=force_collective, depth=1)
+    g.start(x, edge_index, edge_weight, batch, num_graphs_local)
+    return g.wait()
