@@ -657,10 +657,18 @@ int tgp_gather_pack_f32(const float* x, int64_t x_row_stride, const int64_t* bat
                         const int64_t* col, const float* edge_weight /* NULL ok */, int64_t num_supernodes,
                         int64_t num_edges, int64_t num_graphs, int64_t num_features, int64_t capacity, void* out,
                         void* stream);
-int tgp_gather_unpack_f32(const void* gathered, int64_t capacity, int world,
-                          int64_t max_words /* 4-byte words of the largest payload: sizes the grid */, float* x_out,
+int tgp_gather_unpack_f32(const void* gathered, int64_t capacity,
+                          int64_t rank_stride /* bytes between two ranks' buffers (>= capacity: several steps' slots may be
+                                                 gathered as one bucket) */,
+                          int world, int64_t max_words /* 4-byte words of the largest payload: sizes the grid */,
+                          int64_t k_cap, int64_t e_cap /* rows the outputs can hold */, float* x_out,
                           int64_t* batch_out /* NULL ok */, int64_t* row_out, int64_t* col_out,
-                          float* weight_out /* NULL ok */, void* stream);
+                          float* weight_out /* NULL ok */,
+                          uint64_t* result /* NULL, or 5 words of device-accessible (pinned host) memory: {tag, K total,
+                                              E total, largest needed_bytes, headers valid}, word 0 stored last; a
+                                              payload that does not fit capacity / k_cap / e_cap makes the launch a no-op
+                                              apart from this report */,
+                          uint64_t tag, void* stream);
 
 #ifdef __cplusplus
 }

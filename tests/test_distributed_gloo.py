@@ -91,7 +91,7 @@ def _worker(rank, world, port, out_dir):
         # asynchronous variable-size gather: three steps in flight two deep, a capacity that is too small at first (the
         # ranks grow it from the headers, alike, and repeat the step) -- every step's merged result must be the
         # synchronous one scaled by its step number
-        sg = D.SparseGather(depth=2, capacity=256)
+        sg = D.SparseGather(depth=2, capacity=256, bucket_steps=2)
         outs = []
         for j in range(3):
             sg.start(loc["x"] * (j + 1), loc["edge_index"], loc["edge_weight"] * (j + 1), loc["batch"], hi - lo)

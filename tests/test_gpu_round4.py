@@ -288,3 +288,32 @@ def test_graclus_pooler_on_a_hub_graph_stays_on_the_rowlocal_route(dev):
     ref = O.cluster_pool(x, ei, None, None, out.so.cluster_index.cpu(), out.so.num_supernodes)
     assert torch.equal(out.edge_index.cpu(), ref["edge_index"])
     torch.testing.assert_close(out.x.cpu(), ref["x"], rtol=1e-5, atol=1e-5)
+
+
+def test_sparse_gather_async_buckets_over_rccl_one_rank_group(dev, one_rank_rccl):
+    """SURVEY 8(e), sparse outputs: SparseGather on a one-rank RCCL group with REAL collectives -- five steps, two per
+    payload collective, two buckets in flight, a first capacity that is too small (grown from the headers, the steps
+    repeated), totals through pinned host words.  Every merged result equals the local one bit for bit (one rank: no
+    offsets), in step order; the pooled edge_index of the one-launch kernel (a strided view) travels unchanged."""
+    from tgp.distributed import SparseGather
+    from tgp.poolers import get_pooler
+    x, ei, ew, batch, sizes = _small_batch(300, 5, 60, 16, 21, dev)
+    pooler = get_pooler("topk", in_channels=16, ratio=0.5).to(dev).eval()
+    with torch.no_grad():
+        out = pooler(x=x, adj=ei, edge_weight=ew, batch=batch)
+    assert not out.edge_index.is_contiguous()  # the capacity-buffer view of tgp_sparse_pool_small_f32
+    sg = SparseGather(force_collective=True, depth=2, bucket_steps=2, capacity=1024)
+    got = []
+    for j in range(5):
+        sg.start(out.x * (j + 1), out.edge_index, out.edge_weight * (j + 1), out.batch, 300)
+        got.extend(sg.take_ready())
+    got.extend(sg.flush())
+    assert len(got) == 5 and sg.capacity > 1024
+    for j, (gx, gei, gw, gb) in enumerate(got):
+        assert torch.equal(gx, out.x * (j + 1)) and torch.equal(gei, out.edge_index)
+        assert torch.equal(gw, out.edge_weight * (j + 1)) and torch.equal(gb, out.batch)
+    # unweighted, no batch vector
+    sg2 = SparseGather(force_collective=True)
+    sg2.start(out.x, out.edge_index, None, None, 300)
+    gx, gei, gw, gb = sg2.wait()
+    assert gw is None and gb is None and torch.equal(gx, out.x) and torch.equal(gei, out.edge_index)

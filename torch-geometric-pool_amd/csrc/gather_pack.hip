@@ -58,19 +58,48 @@ __global__ __launch_bounds__(256) void gp_pack_kernel(const float* __restrict__ 
 }
 
 // blockIdx.y = source rank; node ids += supernodes of the ranks before it, graph ids += their graphs
-__global__ __launch_bounds__(256) void gp_unpack_kernel(const char* __restrict__ gathered, int64_t capacity, int world,
+// `rank_stride`: bytes between two ranks' buffers in `gathered` (a bucket of several steps is gathered at once: the
+// slot of this step sits at the same offset of every rank's bucket).  `result` (optional, pinned host memory): block
+// (0, 0) leaves {tag, K total, E total, largest needed_bytes, all headers valid} there -- the caller polls word 0 for
+// its tag instead of copying the headers back; a payload that did not fit (needed > capacity) or a bad header makes the
+// whole launch a no-op apart from that report.
+__global__ __launch_bounds__(256) void gp_unpack_kernel(const char* __restrict__ gathered, int64_t capacity,
+                                                        int64_t rank_stride, int world, int64_t k_cap, int64_t e_cap,
                                                         float* __restrict__ x_out, int64_t* __restrict__ batch_out,
                                                         int64_t* __restrict__ row_out, int64_t* __restrict__ col_out,
-                                                        float* __restrict__ w_out) {
+                                                        float* __restrict__ w_out,
+                                                        unsigned long long* __restrict__ result,
+                                                        unsigned long long tag) {
   const int r = blockIdx.y;
+  {
+    int64_t kt = 0, et = 0, need = 0;
+    bool ok = true;
+    for (int q = 0; q < world; ++q) {
+      const int64_t* hq = reinterpret_cast<const int64_t*>(gathered + static_cast<int64_t>(q) * rank_stride);
+      ok = ok && hq[0] == GP_MAGIC;
+      kt += hq[1];
+      et += hq[2];
+      need = hq[6] > need ? hq[6] : need;
+    }
+    const bool fits = ok && need <= capacity && kt <= k_cap && et <= e_cap;
+    if (result && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+      result[1] = static_cast<unsigned long long>(kt);
+      result[2] = static_cast<unsigned long long>(et);
+      result[3] = static_cast<unsigned long long>(need);
+      result[4] = ok ? 1ull : 0ull;
+      __threadfence_system();
+      __hip_atomic_store(result, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (!fits) return;
+  }
   int64_t koff = 0, eoff = 0, goff = 0;
   for (int q = 0; q < r; ++q) {
-    const int64_t* h = reinterpret_cast<const int64_t*>(gathered + static_cast<int64_t>(q) * capacity);
+    const int64_t* h = reinterpret_cast<const int64_t*>(gathered + static_cast<int64_t>(q) * rank_stride);
     koff += h[1];
     eoff += h[2];
     goff += h[3];
   }
-  const char* src = gathered + static_cast<int64_t>(r) * capacity;
+  const char* src = gathered + static_cast<int64_t>(r) * rank_stride;
   const int64_t* h = reinterpret_cast<const int64_t*>(src);
   const int64_t K = h[1], E = h[2], F = h[4];
   const int has_w = static_cast<int>(h[5]);
@@ -117,17 +146,20 @@ extern "C" int tgp_gather_pack_f32(const float* x, int64_t x_stride, const int64
   return check_launch("tgp_gather_pack_f32");
 }
 
-extern "C" int tgp_gather_unpack_f32(const void* gathered, int64_t capacity, int world, int64_t max_words,
-                                     float* x_out, int64_t* batch_out, int64_t* row_out, int64_t* col_out,
-                                     float* w_out, void* stream_) {
+extern "C" int tgp_gather_unpack_f32(const void* gathered, int64_t capacity, int64_t rank_stride, int world,
+                                     int64_t max_words, int64_t k_cap, int64_t e_cap, float* x_out, int64_t* batch_out,
+                                     int64_t* row_out, int64_t* col_out, float* w_out, uint64_t* result, uint64_t tag,
+                                     void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  TGP_REQUIRE(gathered && capacity >= GP_HEADER_WORDS * 8 && world >= 1 && world <= 65535, TGP_ERR_INVALID,
-              "tgp_gather_unpack_f32: bad argument");
+  TGP_REQUIRE(gathered && capacity >= GP_HEADER_WORDS * 8 && rank_stride >= capacity && world >= 1 && world <= 65535 &&
+                  k_cap >= 0 && e_cap >= 0,
+              TGP_ERR_INVALID, "tgp_gather_unpack_f32: bad argument");
   int64_t blocks = (max_words + 256 * 8 - 1) / (256 * 8);  // max_words: 4-byte words of the largest rank's payload
   if (blocks < 1) blocks = 1;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(gp_unpack_kernel, dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(world)), dim3(256), 0,
-                     stream, static_cast<const char*>(gathered), capacity, world, x_out, batch_out, row_out, col_out,
-                     w_out);
+                     stream, static_cast<const char*>(gathered), capacity, rank_stride, world, k_cap, e_cap, x_out,
+                     batch_out, row_out, col_out, w_out, reinterpret_cast<unsigned long long*>(result),
+                     static_cast<unsigned long long>(tag));
   return check_launch("tgp_gather_unpack_f32");
 }

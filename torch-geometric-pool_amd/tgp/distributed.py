@@ -243,42 +243,55 @@ def _gp_layout(K: int, E: int, F: int, has_w: bool):
 
 class SparseGather:
     """All-gather of VARIABLE-SIZE pooled sparse outputs (x [K,F], edge_index [2,E], edge_weight [E] or None, batch [K])
-    as ONE payload collective per step, asynchronous like :class:`PackedGather`.
+    as ONE payload collective per bucket of steps, asynchronous like :class:`PackedGather`.
 
-    ``start`` packs the rank's outputs behind a 128-byte header {K, E, B, F, has_w, needed bytes} into one byte buffer
-    (one native launch on a device, ``tgp_gather_pack_f32``) and issues ONE ``all_gather_into_tensor`` of capacity-padded
-    buffers on the collective's own stream.  There is no count exchange in front of it: the capacity is agreed FROM the
-    headers -- every rank sees every header, so when some rank needs more room than the current capacity all ranks
-    reach the same verdict, grow to the same size and repeat that step's collective (a payload that did not fit is a
-    header only).  The result is finalised when it is asked for (``take_ready`` / ``wait`` / ``flush``): one read of
-    the headers (world x 16 integers: the output shapes live on the host), one native launch that unpacks and shifts
-    node ids / graph ids of rank r by the totals of the ranks before it (``tgp_gather_unpack_f32``; the merge rule of
-    tgp/data/collate.py:144-153).  At most ``depth`` collectives are in flight, so a step's gather overlaps the next
-    steps' kernels.  Every rank must call ``start`` the same number of times.
+    ``start`` packs the rank's outputs behind a 128-byte header {K, E, B, F, has_w, needed bytes} into the next slot of
+    a byte buffer (one native launch on a device, ``tgp_gather_pack_f32``); ``bucket_steps`` slots go out as ONE
+    ``all_gather_into_tensor`` on the collective's own stream.  There is no count exchange in front of it: the slot
+    capacity is agreed FROM the headers -- every rank sees every header, so when some rank needs more room than the
+    current capacity all ranks reach the same verdict, grow to the same size and repeat the steps concerned (a
+    payload that does not fit travels as a header only).  On a device nothing of this blocks the host: behind the
+    collective (a stream dependency) one native launch per step unpacks into capacity-sized outputs, shifting node ids
+    / graph ids of rank r by the totals of the ranks before it (``tgp_gather_unpack_f32``; the merge rule of
+    tgp/data/collate.py:144-153), and leaves the totals in a pinned host word that ``take_ready`` polls; the merged
+    tensors are views of the capacity buffers (``edge_index``: both rows contiguous).  At most ``depth`` buckets are in
+    flight, so a bucket's gather overlaps the next steps' kernels.  Every rank must call ``start`` (and ``flush``) the
+    same number of times.
 
     A result is ``(x, edge_index, edge_weight, batch)`` of ALL ranks' graphs, rank-major, as a single process would
     have produced them for the concatenated batch."""
 
-    INITIAL_CAPACITY = 64 * 1024  # bytes; the SAME on every rank (a collective needs equal buffer sizes): it only grows,
-                                  # and only by the rule below, which every rank applies to the same headers
+    INITIAL_CAPACITY = 64 * 1024  # bytes per step; the SAME on every rank (a collective needs equal buffer sizes): it
+                                  # only grows, and only by the rule below, which every rank applies to the same headers
 
-    def __init__(self, group=None, force_collective: bool = False, depth: int = 2, capacity: Optional[int] = None):
+    def __init__(self, group=None, force_collective: bool = False, depth: int = 2, capacity: Optional[int] = None,
+                 bucket_steps: int = 1):
         self.group = group
         self.world = _world(group)
         self._collective = self.world > 1 or (dist.is_available() and dist.is_initialized()
                                               and (force_collective or bool(os.environ.get("TGP_FORCE_COLLECTIVE"))))
         self.depth = max(int(depth), 1)
+        self.bucket = max(int(bucket_steps), 1)
         # ``capacity``: a caller that knows its payloads may start larger (the same value on every rank!)
         self.capacity = max(int(capacity if capacity is not None else self.INITIAL_CAPACITY), _GP_HEADER * 8)
-        self._inflight: List[tuple] = []   # (work, gathered, send, capacity, inputs)
+        self._send: Optional[Tensor] = None
+        self._open: List[tuple] = []       # inputs of the steps packed into the open bucket
+        self._inflight: List[dict] = []    # buckets whose collective has been issued
         self._ready: List[tuple] = []
+        self._pin = None                   # pinned result words (device path), 8 per step slot
+        self._host = None
+        self._tick = 0
 
     # ---- packing --------------------------------------------------------------------------------------------------
     @staticmethod
-    def _pack(x, edge_index, edge_weight, batch, num_graphs, capacity) -> Tensor:
+    def _dims(x, edge_index):
         K, F = (x.size(0), x.size(1)) if x.dim() == 2 else (x.size(0), 1)
-        E = edge_index.size(1)
-        send = torch.empty(capacity, dtype=torch.uint8, device=x.device)
+        return K, F, edge_index.size(1)
+
+    def _pack(self, inputs, dst: Tensor) -> None:
+        x, edge_index, edge_weight, batch, num_graphs = inputs
+        K, F, E = self._dims(x, edge_index)
+        cap = dst.numel()
         if x.is_cuda:
             from . import _native as N
             x2 = x.reshape(K, F)
@@ -288,118 +301,231 @@ class SparseGather:
                 ei = ei.to(torch.int64).contiguous()
             w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
             b = None if batch is None else N.i64c(batch)
-            N.check(N.lib().tgp_gather_pack_f32(N.ptr(x2) if K * F else None, x2.stride(0) if K else F, N.ptr(b),
+            N.check(N.lib().tgp_gather_pack_f32(x2.data_ptr() if K * F else None, x2.stride(0) if K else F, N.ptr(b),
                                                 ei.data_ptr() if E else None,
                                                 ei.data_ptr() + 8 * ei.stride(0) if E else None, N.ptr(w), K, E,
-                                                int(num_graphs), F, capacity, send.data_ptr(),
-                                                N.stream_ptr(x.device)), "tgp_gather_pack_f32")
-            return send
+                                                int(num_graphs), F, cap, dst.data_ptr(), N.stream_ptr(x.device)),
+                    "tgp_gather_pack_f32")
+            return
         # host tensors (the gloo tests of the N > 1 logic): the same layout with torch ops
         ox, ob, orow, ocol, ow, end = _gp_layout(K, E, F, edge_weight is not None)
         head = torch.zeros(_GP_HEADER, dtype=torch.int64)
         head[:7] = torch.tensor([_GP_MAGIC, K, E, int(num_graphs), F, int(edge_weight is not None), end])
-        send[: _GP_HEADER * 8] = head.view(torch.uint8)
-        if end <= capacity:
-            send[ox: ox + K * F * 4] = x.reshape(-1).to(torch.float32).contiguous().view(torch.uint8)
+        dst[: _GP_HEADER * 8] = head.view(torch.uint8)
+        if end <= cap:
+            dst[ox: ox + K * F * 4] = x.reshape(-1).to(torch.float32).contiguous().view(torch.uint8)
             bb = torch.zeros(K, dtype=torch.int64) if batch is None else batch.to(torch.int64)
-            send[ob: ob + K * 8] = bb.contiguous().view(torch.uint8)
-            send[orow: orow + E * 8] = edge_index[0].contiguous().view(torch.uint8)
-            send[ocol: ocol + E * 8] = edge_index[1].contiguous().view(torch.uint8)
+            dst[ob: ob + K * 8] = bb.contiguous().view(torch.uint8)
+            dst[orow: orow + E * 8] = edge_index[0].contiguous().view(torch.uint8)
+            dst[ocol: ocol + E * 8] = edge_index[1].contiguous().view(torch.uint8)
             if edge_weight is not None:
-                send[ow: ow + E * 4] = edge_weight.reshape(-1).to(torch.float32).contiguous().view(torch.uint8)
-        return send
+                dst[ow: ow + E * 4] = edge_weight.reshape(-1).to(torch.float32).contiguous().view(torch.uint8)
 
-    def _issue(self, inputs) -> None:
-        x, edge_index, edge_weight, batch, num_graphs = inputs
-        send = self._pack(x, edge_index, edge_weight, batch, num_graphs, self.capacity)
-        gathered = torch.empty(self.world * self.capacity, dtype=torch.uint8, device=x.device)
-        work = None
-        if self._collective:
-            work = dist.all_gather_into_tensor(gathered, send, group=self.group, async_op=True)
-        else:
-            gathered.copy_(send)
-        self._inflight.append((work, gathered, send, self.capacity, inputs))
+    @staticmethod
+    def _grown(need: int) -> int:
+        return ((need + need // 4 + 4095) // 4096) * 4096
 
     # ---- public ---------------------------------------------------------------------------------------------------
     def start(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Optional[Tensor],
               num_graphs_local: int) -> None:
-        while len(self._inflight) >= self.depth:
-            self._finalise_oldest()
-        self._issue((x, edge_index, edge_weight, batch, int(num_graphs_local)))
+        inputs = (x, edge_index, edge_weight, batch, int(num_graphs_local))
+        if self._send is None:
+            self._send = torch.empty(self.bucket * self.capacity, dtype=torch.uint8, device=x.device)
+        j = len(self._open)
+        self._pack(inputs, self._send[j * self.capacity: (j + 1) * self.capacity])
+        self._open.append(inputs)
+        if len(self._open) == self.bucket:
+            self._launch()
 
-    def _finalise_oldest(self) -> None:
-        work, gathered, send, capacity, inputs = self._inflight.pop(0)
-        if work is not None:
-            work.wait()
-        heads = gathered.view(self.world, capacity)[:, : _GP_HEADER * 8].contiguous().view(torch.int64)
-        heads = heads.view(self.world, _GP_HEADER).cpu()  # the one host read of a step: output shapes
-        if not bool((heads[:, 0] == _GP_MAGIC).all()):
-            raise RuntimeError("SparseGather: a gathered buffer does not start with a pack header")
-        need = int(heads[:, 6].max())
-        if need > capacity:
-            # some rank's payload did not fit: every rank sees the same headers, grows alike and repeats this step's
-            # collective (and, in order, those issued behind it with the old capacity)
-            redo = [inputs] + [it[4] for it in self._inflight]
-            for it in self._inflight:
-                if it[0] is not None:
-                    it[0].wait()
-            self._inflight = []
-            self.capacity = max(self.capacity, ((need + need // 4 + 4095) // 4096) * 4096)
-            for inp in redo:
-                self._issue(inp)
-            return self._finalise_oldest()
-        Ks, Es, F = heads[:, 1], heads[:, 2], int(heads[0, 4])
-        has_w = bool(heads[0, 5])
-        Kt, Et = int(Ks.sum()), int(Es.sum())
-        dev = gathered.device
-        x_in, _, _, b_in, _ = inputs
-        x_out = torch.empty(Kt, F, dtype=torch.float32, device=dev)
-        b_out = torch.empty(Kt, dtype=torch.int64, device=dev)
-        ei_out = torch.empty(2, Et, dtype=torch.int64, device=dev)
-        w_out = torch.empty(Et, dtype=torch.float32, device=dev) if has_w else None
-        if gathered.is_cuda:
-            from . import _native as N
-            max_words = int((Ks * F + 2 * Ks + 5 * Es).max())
-            N.check(N.lib().tgp_gather_unpack_f32(gathered.data_ptr(), capacity, self.world, max_words,
-                                                  N.ptr(x_out) if Kt * F else None, N.ptr(b_out) if Kt else None,
-                                                  ei_out.data_ptr() if Et else None,
-                                                  ei_out.data_ptr() + 8 * Et if Et else None, N.ptr(w_out),
-                                                  N.stream_ptr(dev)), "tgp_gather_unpack_f32")
+    def _launch(self, partial: bool = False) -> None:
+        # The sequence of collectives must be the same on every rank, so a capacity change (which re-issues steps) may
+        # only be decided at points every rank reaches at the same place of that sequence: here, before bucket
+        # b + depth goes out (bucket b is finalised, blocking), and in wait / flush.  take_ready hands out finished
+        # results early but never re-issues anything.
+        while len(self._inflight) >= self.depth:
+            self._finalise_oldest(block=True, allow_redo=True)
+        if not self._open or (len(self._open) < self.bucket and not partial):
+            return
+        n, cap = len(self._open), self.capacity
+        send = self._send[: n * cap]
+        dev = send.device
+        if self._collective:
+            gathered = torch.empty(self.world * n * cap, dtype=torch.uint8, device=dev)
+            work = dist.all_gather_into_tensor(gathered, send, group=self.group, async_op=True)
         else:
-            g2 = gathered.view(self.world, capacity)
+            gathered, work = send, None
+        bucket = dict(work=work, gathered=gathered, send=send, n=n, cap=cap, inputs=self._open, steps=None)
+        self._send, self._open = None, []
+        self._inflight.append(bucket)
+        if dev.type == "cuda":
+            self._enqueue_unpack(bucket)
+
+    def _enqueue_unpack(self, bucket) -> None:
+        """Device path: everything behind the collective is enqueued NOW (stream dependency, no host wait): one unpack
+        launch per step into capacity-sized outputs, totals into pinned words."""
+        from . import _native as N
+        if bucket["work"] is not None:
+            bucket["work"].wait()  # the current stream waits for the collective; the host does not
+        n, cap, gathered = bucket["n"], bucket["cap"], bucket["gathered"]
+        dev = gathered.device
+        nslots = (self.depth + 2) * self.bucket
+        if self._pin is None:
+            self._pin = torch.zeros(nslots * 8, dtype=torch.int64).pin_memory()
+            self._host = self._pin.numpy()
+        L, st = N.lib(), N.stream_ptr(dev)
+        steps = []
+        for j, inputs in enumerate(bucket["inputs"]):
+            x, edge_index, edge_weight, batch, _ = inputs
+            K, F, E = self._dims(x, edge_index)
+            has_w = edge_weight is not None
+            k_cap = self.world * (cap // (4 * F + 8) + 1)
+            e_cap = self.world * (cap // (20 if has_w else 16) + 1)
+            x_out = torch.empty(k_cap, F, dtype=torch.float32, device=dev)
+            b_out = torch.empty(k_cap, dtype=torch.int64, device=dev)
+            ei_out = torch.empty(2, e_cap, dtype=torch.int64, device=dev)
+            w_out = torch.empty(e_cap, dtype=torch.float32, device=dev) if has_w else None
+            self._tick += 1
+            slot, tag = self._tick % nslots, self._tick
+            max_words = cap // 4
+            N.check(L.tgp_gather_unpack_f32(gathered.data_ptr() + j * cap, cap, n * cap, self.world, max_words, k_cap,
+                                            e_cap, x_out.data_ptr(), b_out.data_ptr(), ei_out.data_ptr(),
+                                            ei_out.data_ptr() + 8 * e_cap, N.ptr(w_out),
+                                            self._pin.data_ptr() + slot * 64, tag, st), "tgp_gather_unpack_f32")
+            steps.append((slot, tag, x_out, b_out, ei_out, w_out))
+        bucket["steps"] = steps
+
+    def _poll(self, slot: int, tag: int, block: bool) -> bool:
+        host, spins = self._host, 0
+        while int(host[slot * 8]) != tag:
+            if not block:
+                return False
+            spins += 1
+            if spins > 4_000_000:
+                torch.cuda.synchronize()
+                if int(host[slot * 8]) != tag:
+                    raise RuntimeError("SparseGather: the unpack launch never reported (device fault?)")
+        return True
+
+    def _redo_with(self, need: int, first_bucket: dict) -> None:
+        """A payload did not fit: every rank sees the same headers, grows alike and repeats, in order, the steps of this
+        bucket, of the buckets issued behind it, and of the open one."""
+        redo = list(first_bucket["inputs"])
+        for bk in self._inflight:
+            if bk["work"] is not None:
+                bk["work"].wait()
+            redo.extend(bk["inputs"])
+        redo.extend(self._open)
+        if first_bucket["gathered"].is_cuda:
+            torch.cuda.synchronize(first_bucket["gathered"].device)  # nothing of the old layout may still be running
+        self._inflight, self._open, self._send = [], [], None
+        self.capacity = max(self.capacity, self._grown(need))
+        for inp in redo:
+            self.start(*inp)
+
+    def _finalise_oldest(self, block: bool, allow_redo: bool = False) -> bool:
+        if not self._inflight:
+            return False
+        bucket = self._inflight[0]
+        if bucket["steps"] is not None:  # device path: totals arrive in the pinned words
+            for (slot, tag, *_rest) in bucket["steps"]:
+                if not self._poll(slot, tag, block):
+                    return False
+            results, need, valid = [], 0, True
+            for inputs, (slot, tag, x_out, b_out, ei_out, w_out) in zip(bucket["inputs"], bucket["steps"]):
+                h = self._host[slot * 8: slot * 8 + 8]
+                kt, et, nd, ok = int(h[1]), int(h[2]), int(h[3]), int(h[4])
+                need, valid = max(need, nd), valid and ok == 1
+                results.append((inputs, kt, et, x_out, b_out, ei_out, w_out))
+            if not valid:
+                raise RuntimeError("SparseGather: a gathered buffer does not start with a pack header")
+            if need > bucket["cap"]:
+                if not allow_redo:
+                    return False
+                self._inflight.pop(0)
+                self._redo_with(need, bucket)
+                return self._finalise_oldest(block, allow_redo)
+            self._inflight.pop(0)
+            for inputs, kt, et, x_out, b_out, ei_out, w_out in results:
+                x_in, _, _, b_in, _ = inputs
+                xo = x_out[:kt]
+                if x_in.dim() == 1:
+                    xo = xo.view(-1)
+                if x_in.dtype != torch.float32 and x_in.is_floating_point():
+                    xo = xo.to(x_in.dtype)
+                self._ready.append((xo, ei_out[:, :et], None if w_out is None else w_out[:et],
+                                    b_out[:kt] if b_in is not None else None))
+            return True
+        # host tensors (gloo): synchronous, with torch ops
+        if bucket["work"] is not None:
+            bucket["work"].wait()
+        n, cap = bucket["n"], bucket["cap"]
+        g3 = bucket["gathered"].view(self.world if self._collective else 1, n, cap)
+        world = g3.size(0)
+        heads = g3[:, :, : _GP_HEADER * 8].contiguous().view(torch.int64).view(world, n, _GP_HEADER)
+        if not bool((heads[..., 0] == _GP_MAGIC).all()):
+            raise RuntimeError("SparseGather: a gathered buffer does not start with a pack header")
+        need = int(heads[..., 6].max())
+        if need > cap:
+            if not allow_redo:
+                return False
+            self._inflight.pop(0)
+            self._redo_with(need, bucket)
+            return self._finalise_oldest(block, allow_redo)
+        self._inflight.pop(0)
+        for j, inputs in enumerate(bucket["inputs"]):
+            x_in, _, _, b_in, _ = inputs
+            hj = heads[:, j]
+            F, has_w = int(hj[0, 4]), bool(hj[0, 5])
+            Kt, Et = int(hj[:, 1].sum()), int(hj[:, 2].sum())
+            x_out = torch.empty(Kt, F, dtype=torch.float32)
+            b_out = torch.empty(Kt, dtype=torch.int64)
+            ei_out = torch.empty(2, Et, dtype=torch.int64)
+            w_out = torch.empty(Et, dtype=torch.float32) if has_w else None
             koff = eoff = goff = 0
-            for r in range(self.world):
-                K, E, B = int(heads[r, 1]), int(heads[r, 2]), int(heads[r, 3])
+            for r in range(world):
+                K, E, B = int(hj[r, 1]), int(hj[r, 2]), int(hj[r, 3])
                 ox, ob, orow, ocol, ow, _ = _gp_layout(K, E, F, has_w)
-                x_out[koff: koff + K] = g2[r, ox: ox + K * F * 4].contiguous().view(torch.float32).view(K, F)
-                b_out[koff: koff + K] = g2[r, ob: ob + K * 8].contiguous().view(torch.int64) + goff
-                ei_out[0, eoff: eoff + E] = g2[r, orow: orow + E * 8].contiguous().view(torch.int64) + koff
-                ei_out[1, eoff: eoff + E] = g2[r, ocol: ocol + E * 8].contiguous().view(torch.int64) + koff
+                buf = g3[r, j]
+                x_out[koff: koff + K] = buf[ox: ox + K * F * 4].contiguous().view(torch.float32).view(K, F)
+                b_out[koff: koff + K] = buf[ob: ob + K * 8].contiguous().view(torch.int64) + goff
+                ei_out[0, eoff: eoff + E] = buf[orow: orow + E * 8].contiguous().view(torch.int64) + koff
+                ei_out[1, eoff: eoff + E] = buf[ocol: ocol + E * 8].contiguous().view(torch.int64) + koff
                 if has_w:
-                    w_out[eoff: eoff + E] = g2[r, ow: ow + E * 4].contiguous().view(torch.float32)
+                    w_out[eoff: eoff + E] = buf[ow: ow + E * 4].contiguous().view(torch.float32)
                 koff, eoff, goff = koff + K, eoff + E, goff + B
-        if x_in.dim() == 1:
-            x_out = x_out.view(-1)
-        if x_in.dtype != torch.float32 and x_in.is_floating_point():
-            x_out = x_out.to(x_in.dtype)
-        self._ready.append((x_out, ei_out, w_out, b_out if b_in is not None else None))
+            if x_in.dim() == 1:
+                x_out = x_out.view(-1)
+            if x_in.dtype != torch.float32 and x_in.is_floating_point():
+                x_out = x_out.to(x_in.dtype)
+            self._ready.append((x_out, ei_out, w_out, b_out if b_in is not None else None))
+        return True
 
     def take_ready(self) -> List[tuple]:
-        """Results whose collective has already completed (never blocks on a collective still in flight)."""
-        while self._inflight and (self._inflight[0][0] is None or self._inflight[0][0].is_completed()):
-            self._finalise_oldest()
+        """Results of buckets whose unpack has already reported (never waits for a collective still in flight)."""
+        while self._inflight:
+            bk = self._inflight[0]
+            if bk["steps"] is None and bk["work"] is not None and not bk["work"].is_completed():
+                break
+            if not self._finalise_oldest(block=False, allow_redo=False):
+                break
         res, self._ready = self._ready, []
         return res
 
     def wait(self):
-        """The oldest result not yet handed out (waits for its collective), or None."""
-        if not self._ready and self._inflight:
-            self._finalise_oldest()
+        """The oldest result not yet handed out (sends a partly filled bucket and waits if it has to), or None.  Like
+        ``start`` / ``flush``, every rank must call it at the same place."""
+        if not self._ready:
+            if not self._inflight:
+                self._launch(partial=True)
+            self._finalise_oldest(block=True, allow_redo=True)
         return self._ready.pop(0) if self._ready else None
 
     def flush(self) -> List[tuple]:
+        while self._inflight:  # (first what is in flight: a capacity change re-issues the open steps with it)
+            self._finalise_oldest(block=True, allow_redo=True)
+        self._launch(partial=True)
         while self._inflight:
-            self._finalise_oldest()
+            self._finalise_oldest(block=True, allow_redo=True)
         res, self._ready = self._ready, []
         return res
 
@@ -414,6 +540,6 @@ def all_gather_sparse(x: Tensor, edge_index: Tensor, edge_weight: Optional[Tenso
               and (force_collective or bool(os.environ.get("TGP_FORCE_COLLECTIVE"))))
     if world == 1 and not forced:
         return x, edge_index, edge_weight, batch
-    g = SparseGather(group=group, force_collective=force_collective, depth=1)
+    g = SparseGather(group=group, force_collective=force_collective, depth=1, bucket_steps=1)
     g.start(x, edge_index, edge_weight, batch, num_graphs_local)
     return g.wait()
