@@ -374,24 +374,31 @@ class SparseGather:
             self._host = self._pin.numpy()
         L, st = N.lib(), N.stream_ptr(dev)
         steps = []
-        for j, inputs in enumerate(bucket["inputs"]):
+        # ONE allocation per bucket for all capacity outputs (the merged tensors are carved out of it when they are
+        # handed out; at enqueue time only addresses are needed): per step just the unpack launch
+        plan, total = [], 0
+        for inputs in bucket["inputs"]:
             x, edge_index, edge_weight, batch, _ = inputs
             K, F, E = self._dims(x, edge_index)
             has_w = edge_weight is not None
             k_cap = self.world * (cap // (4 * F + 8) + 1)
             e_cap = self.world * (cap // (20 if has_w else 16) + 1)
-            x_out = torch.empty(k_cap, F, dtype=torch.float32, device=dev)
-            b_out = torch.empty(k_cap, dtype=torch.int64, device=dev)
-            ei_out = torch.empty(2, e_cap, dtype=torch.int64, device=dev)
-            w_out = torch.empty(e_cap, dtype=torch.float32, device=dev) if has_w else None
+            ox = total
+            ob = _gp_align(ox + k_cap * F * 4)
+            oe = _gp_align(ob + k_cap * 8)
+            ow = _gp_align(oe + 2 * e_cap * 8)
+            total = _gp_align(ow + (e_cap * 4 if has_w else 0))
+            plan.append((F, has_w, k_cap, e_cap, ox, ob, oe, ow))
+        out = torch.empty(total, dtype=torch.uint8, device=dev)
+        base, gbase = out.data_ptr(), gathered.data_ptr()
+        max_words = cap // 4
+        for j, (F, has_w, k_cap, e_cap, ox, ob, oe, ow) in enumerate(plan):
             self._tick += 1
             slot, tag = self._tick % nslots, self._tick
-            max_words = cap // 4
-            N.check(L.tgp_gather_unpack_f32(gathered.data_ptr() + j * cap, cap, n * cap, self.world, max_words, k_cap,
-                                            e_cap, x_out.data_ptr(), b_out.data_ptr(), ei_out.data_ptr(),
-                                            ei_out.data_ptr() + 8 * e_cap, N.ptr(w_out),
+            N.check(L.tgp_gather_unpack_f32(gbase + j * cap, cap, n * cap, self.world, max_words, k_cap, e_cap, base + ox,
+                                            base + ob, base + oe, base + oe + 8 * e_cap, base + ow if has_w else None,
                                             self._pin.data_ptr() + slot * 64, tag, st), "tgp_gather_unpack_f32")
-            steps.append((slot, tag, x_out, b_out, ei_out, w_out))
+            steps.append((slot, tag, out, plan[j]))
         bucket["steps"] = steps
 
     def _poll(self, slot: int, tag: int, block: bool) -> bool:
@@ -431,11 +438,11 @@ class SparseGather:
                 if not self._poll(slot, tag, block):
                     return False
             results, need, valid = [], 0, True
-            for inputs, (slot, tag, x_out, b_out, ei_out, w_out) in zip(bucket["inputs"], bucket["steps"]):
+            for inputs, (slot, tag, out, plan) in zip(bucket["inputs"], bucket["steps"]):
                 h = self._host[slot * 8: slot * 8 + 8]
                 kt, et, nd, ok = int(h[1]), int(h[2]), int(h[3]), int(h[4])
                 need, valid = max(need, nd), valid and ok == 1
-                results.append((inputs, kt, et, x_out, b_out, ei_out, w_out))
+                results.append((inputs, kt, et, out, plan))
             if not valid:
                 raise RuntimeError("SparseGather: a gathered buffer does not start with a pack header")
             if need > bucket["cap"]:
@@ -445,15 +452,17 @@ class SparseGather:
                 self._redo_with(need, bucket)
                 return self._finalise_oldest(block, allow_redo)
             self._inflight.pop(0)
-            for inputs, kt, et, x_out, b_out, ei_out, w_out in results:
+            for inputs, kt, et, out, (F, has_w, k_cap, e_cap, ox, ob, oe, ow) in results:
                 x_in, _, _, b_in, _ = inputs
-                xo = x_out[:kt]
+                xo = out[ox: ox + kt * F * 4].view(torch.float32).view(kt, F)
+                eo = out[oe: oe + 2 * e_cap * 8].view(torch.int64).view(2, e_cap)[:, :et]
+                wo = out[ow: ow + et * 4].view(torch.float32) if has_w else None
+                bo = out[ob: ob + kt * 8].view(torch.int64) if b_in is not None else None
                 if x_in.dim() == 1:
                     xo = xo.view(-1)
                 if x_in.dtype != torch.float32 and x_in.is_floating_point():
                     xo = xo.to(x_in.dtype)
-                self._ready.append((xo, ei_out[:, :et], None if w_out is None else w_out[:et],
-                                    b_out[:kt] if b_in is not None else None))
+                self._ready.append((xo, eo, wo, bo))
             return True
         # host tensors (gloo): synchronous, with torch ops
         if bucket["work"] is not None:
