@@ -12,13 +12,15 @@
  *   - every pointer is a DEVICE pointer (hipMalloc / PyTorch caching allocator) unless
  *     the name ends in `_host`; index tensors are int64 (reference: utils/ops.py:472-476),
  *     features / weights are fp32; `[2,E]` edge lists are given as two row pointers.
- *   - THE ABI IS fp32-ONLY (decision, r3).  Every floating-point argument is fp32 and every kernel accumulates in fp32
- *     -- the reference's default dtype (torch.ones(E) at ops.py:385,547; base_select.py:64) and the precision
- *     north_star's 1e-5 tolerance is stated in.  There are no `_f64` variants of Reduce / Connect: a caller holding
- *     float64 tensors (model.double()) converts at the boundary, and the host mirror does exactly that with a
- *     one-time UserWarning saying the arithmetic is fp32's.  Two algorithms whose RESULT depends on wider arithmetic
- *     run in fp64 inside their kernels regardless of the I/O type: the Kron reduction (tgp_kron_batched_*) and
- *     NDPSelect's eigen-iteration (tgp_ndp_*); KronConnect also accepts fp64 Laplacian values (`val64`).
+ *   - fp32 is the default value type (the reference's default dtype: torch.ones(E) at ops.py:385,547;
+ *     base_select.py:64; north_star's 1e-5 tolerance is stated in it).  r4: the HBM-bound operators also exist for
+ *     float64 values (`*_f64`: sparse Reduce, subgraph / coalesce Connect, block-diagonal export, sparse and dense
+ *     post-processing; see the section near the end), because the reference's ATen ops compute model.double() inputs
+ *     in fp64.  The dense GEMM path (S^T X, S^T A S, the fused small-graph kernels, the losses) is fp32 only: a caller
+ *     holding float64 tensors converts at that boundary, and the host mirror does exactly that with a one-time
+ *     UserWarning saying the arithmetic is fp32's.  Two algorithms whose RESULT depends on wider arithmetic run in fp64
+ *     inside their kernels regardless of the I/O type: the Kron reduction (tgp_kron_batched_*) and NDPSelect's
+ *     eigen-iteration (tgp_ndp_*); KronConnect also accepts fp64 Laplacian values (`val64`).
  *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it and
  *     never synchronises, allocates or frees.  Scratch memory comes from the caller
  *     (`ws`, sized by the matching *_workspace_bytes()).
@@ -642,6 +644,48 @@ int tgp_softmax_bwd_f32(const float* s, const float* ds, float* dy, int64_t M, i
 size_t tgp_debug_sort_workspace_bytes(int64_t n);
 int tgp_debug_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, int64_t n, int key_bits,
                              uint64_t* keys_out, uint32_t* vals_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * float64 value types of the HBM-bound operators (r4).  The reference's ATen ops compute model.double() inputs in fp64
+ * (reduce/base_reduce.py:141-155, utils/ops.py:282-419); these entry points do the same for the operators that only
+ * move and add values -- sparse Reduce, the edge-list Connect (subgraph / coalesce / block-diagonal export) and both
+ * post-processings -- with the argument meaning of their fp32 twins above (`eps` as a double).  Same summation orders,
+ * products rounded before the add.  The dense GEMM path (S^T X, S^T A S) has no fp64 form: the host mirror converts
+ * there and says so.
+ * ---------------------------------------------------------------------------------- */
+int tgp_reduce_sparse_f64(const double* x, int64_t num_nodes, int64_t num_features, int64_t x_row_stride,
+                          const int64_t* node_index, const double* weight /* NULL = ones */,
+                          const int32_t* row_ptr /* NULL = one assignment per supernode */,
+                          const int32_t* perm /* NULL = identity */, int64_t nnz, int64_t num_supernodes, double* x_pool,
+                          void* stream);
+int tgp_connect_subgraph_single_f64(const int64_t* row, const int64_t* col, const double* edge_weight /* NULL ok */,
+                                    int64_t num_edges, const int64_t* node_index, int64_t k, int64_t num_nodes, int flags,
+                                    double eps, void* ws /* tgp_connect_subgraph_single_workspace_bytes */,
+                                    size_t ws_bytes, int64_t* out_row, int64_t* out_col, double* out_weight,
+                                    int64_t* out_edge_id, uint64_t* status, int64_t status_words, uint64_t* result,
+                                    uint32_t epoch, void* stream);
+size_t tgp_connect_coalesce_workspace_bytes_f64(int64_t num_edges, int64_t num_nodes, int64_t num_supernodes);
+int tgp_connect_coalesce_count_f64(const int64_t* row, const int64_t* col, const double* edge_weight /* NULL ok */,
+                                   int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,
+                                   int64_t num_supernodes, int reduce_op, int flags, double eps, void* ws,
+                                   size_t ws_bytes, int64_t* d_count, void* stream);
+int tgp_connect_coalesce_fill_f64(const void* ws, int64_t num_edges, int64_t num_nodes, int64_t num_supernodes,
+                                  int has_weight, int flags, int64_t num_out, int64_t* out_row, int64_t* out_col,
+                                  double* out_weight, void* stream);
+size_t tgp_postprocess_sparse_workspace_bytes_f64(int64_t num_edges, int64_t num_nodes, int64_t num_graphs);
+int tgp_postprocess_sparse_norm_f64(const int64_t* row, const int64_t* col, double* edge_weight /* in place */,
+                                    int64_t num_edges, int64_t num_nodes, int flags, double eps,
+                                    const int64_t* batch_pooled, int64_t num_graphs, void* ws, size_t ws_bytes,
+                                    void* stream);
+int tgp_block_diag_count_f64(const double* adj, int64_t B, int64_t K, const int64_t* relabel, int flags, double eps,
+                             void* ws /* tgp_block_diag_workspace_bytes */, size_t ws_bytes, int64_t* d_count,
+                             void* stream);
+int tgp_block_diag_fill_f64(const double* adj, int64_t B, int64_t K, const int64_t* relabel, int flags, double eps,
+                            const void* ws, int64_t num_out, int64_t* out_row, int64_t* out_col, double* out_weight,
+                            void* stream);
+size_t tgp_postprocess_dense_workspace_bytes_f64(int64_t B, int64_t K);
+int tgp_postprocess_dense_f64(const double* src, double* dst /* may alias src */, int64_t B, int64_t K, int flags,
+                              double eps, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * pack / unpack of the variable-size all-gather of pooled sparse outputs (r4).  A rank's pooled graphs

@@ -317,3 +317,117 @@ def test_sparse_gather_async_buckets_over_rccl_one_rank_group(dev, one_rank_rccl
     sg2.start(out.x, out.edge_index, None, None, 300)
     gx, gei, gw, gb = sg2.wait()
     assert gw is None and gb is None and torch.equal(gx, out.x) and torch.equal(gei, out.edge_index)
+
+
+# ------------------------------------------------------------------------------ float64 value types (r4)
+def _f64_graph(n, pairs, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randint(0, n, (pairs,), generator=g)
+    b = torch.randint(0, n, (pairs,), generator=g)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    key = torch.sort(torch.cat([a * n + b, b * n + a]))[0]       # duplicates stay: coalesce has something to merge
+    ei = torch.stack([key // n, key % n])
+    ew = torch.rand(ei.size(1), generator=g, dtype=torch.float64) - 0.2
+    ew[torch.rand(ei.size(1), generator=g) < 0.05] = 1e-9        # below eps in fp64, and in fp32
+    return ei, ew, g
+
+
+def _oracle64(fn, *a, **k):
+    """The oracle evaluated in float64 (its `torch.ones` defaults follow the default dtype)."""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        return fn(*a, **k)
+    finally:
+        torch.set_default_dtype(old)
+
+
+def test_float64_sparse_reduce_and_connect_run_in_fp64(dev):
+    """model.double() inputs: sparse Reduce (base_reduce.py:141-155) and SparseConnect (base_conn.py:79-89 +
+    utils/ops.py:338-419) compute in fp64 like the reference's ATen ops -- against the oracle evaluated in fp64 at
+    1e-12 (fp32 arithmetic would miss by 1e-7), indices bit-exact, float64 outputs, and NO fp32-narrowing warning."""
+    import warnings
+    import tgp_oracle as O
+    from tgp.connect import SparseConnect
+    from tgp.reduce import BaseReduce
+    from tgp.select import SelectOutput
+    import tgp.utils.ops as ops
+    n, f = 3000, 24
+    ei, ew, g = _f64_graph(n, 12_000, 51)
+    x = torch.randn(n, f, generator=g, dtype=torch.float64)
+    batch = torch.sort(torch.randint(0, 7, (n,), generator=g))[0]
+    ops._WARNED_F64 = False
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # the fp32-narrowing UserWarning must not fire on these paths
+        # (a) kept-node selection with fp64 scores (TopK-shaped)
+        kept = torch.sort(torch.randperm(n, generator=g)[: n // 2])[0]
+        ci = torch.randperm(kept.numel(), generator=g)
+        sw = torch.rand(kept.numel(), generator=g, dtype=torch.float64)
+        so = SelectOutput(node_index=kept.to(dev), num_nodes=n, cluster_index=ci.to(dev), num_supernodes=kept.numel(),
+                          weight=sw.to(dev))
+        xp, bp = BaseReduce()(x.to(dev), so, batch=batch.to(dev))
+        assert xp.dtype == torch.float64
+        nis, cis, ws = O.sort_assignment(kept, ci, sw)
+        ref = _oracle64(O.reduce_sparse, x, nis, cis, ws, kept.numel())
+        torch.testing.assert_close(xp.cpu(), ref, rtol=1e-12, atol=1e-12)
+        for kw in (dict(), dict(degree_norm=True, edge_weight_norm=True), dict(remove_self_loops=False)):
+            pe, pw = SparseConnect(**kw)(ei.to(dev), so, edge_weight=ew.to(dev), batch_pooled=bp)
+            r_ei, r_ew = _oracle64(O.sparse_connect, ei, ew, nis, cis, n, kept.numel(), batch_pooled=bp.cpu(), **kw)
+            assert pw.dtype == torch.float64 and torch.equal(pe.cpu(), r_ei)
+            torch.testing.assert_close(pw.cpu(), r_ew, rtol=1e-12, atol=1e-12)
+        # (b) clustering (Graclus-shaped), every reduce op
+        cl = torch.randint(0, n // 3, (n,), generator=g)
+        cl[: n // 3] = torch.arange(n // 3)
+        so2 = SelectOutput(cluster_index=cl.to(dev), num_nodes=n, num_supernodes=n // 3)
+        xp2, _ = BaseReduce()(x.to(dev), so2)
+        ref2 = _oracle64(O.reduce_sparse, x, torch.arange(n), cl, torch.ones(n, dtype=torch.float64), n // 3)
+        assert xp2.dtype == torch.float64
+        torch.testing.assert_close(xp2.cpu(), ref2, rtol=1e-12, atol=1e-12)
+        for op in ("sum", "mean", "min", "max", "mul"):
+            pe, pw = SparseConnect(reduce_op=op, degree_norm=(op == "sum"))(ei.to(dev), so2, edge_weight=ew.to(dev))
+            r_ei, r_ew = _oracle64(O.sparse_connect, ei, ew, torch.arange(n), cl, n, n // 3, reduce_op=op,
+                                   degree_norm=(op == "sum"))
+            assert pw.dtype == torch.float64 and torch.equal(pe.cpu(), r_ei)
+            torch.testing.assert_close(pw.cpu(), r_ew, rtol=1e-12, atol=1e-12)
+        # fp32 features with fp64 assignment weights promote, as the reference's x[node_index] * weight does
+        xp3, _ = BaseReduce()(x.float().to(dev), so)
+        assert xp3.dtype == torch.float64
+        torch.testing.assert_close(xp3.cpu(), _oracle64(O.reduce_sparse, x.float().double(), nis, cis, ws, kept.numel()),
+                                   rtol=1e-12, atol=1e-12)
+
+
+def test_float64_dense_postprocessing_and_block_diag_run_in_fp64(dev):
+    """postprocess_adj_pool_dense on a float64 [B,K,K] tensor (utils/ops.py:282-335), all 16 flag combinations, and
+    dense_to_block_diag (utils/ops.py:53-82) in fp64: 1e-12 against the oracle in fp64."""
+    import tgp_oracle as O
+    from tgp import functions as Fn
+    from tgp.utils.ops import postprocess_adj_pool_dense
+    g = torch.Generator().manual_seed(77)
+    for (B, K) in ((5, 17), (2, 130)):
+        a = torch.rand(B, K, K, generator=g, dtype=torch.float64) * (torch.rand(B, K, K, generator=g) < 0.4)
+        a[0, :, 3] = 0.0  # an empty column: the clamp(min=eps) branch
+        for rsl in (True, False):
+            for dn in (True, False):
+                for at in (True, False):
+                    for ewn in (True, False):
+                        got = postprocess_adj_pool_dense(a.to(dev), rsl, dn, at, ewn)
+                        ref = O.postprocess_dense(a, rsl, dn, at, ewn)
+                        assert got.dtype == torch.float64
+                        torch.testing.assert_close(got.cpu(), ref, rtol=1e-12, atol=1e-12)
+        ei, w = Fn.block_diag_edges(a.to(dev))
+        r_ei, r_w = O.dense_to_block_diag(a)
+        assert w.dtype == torch.float64 and torch.equal(ei.cpu(), r_ei) and torch.equal(w.cpu(), r_w)
+
+
+def test_float64_dense_gemm_path_still_announces_fp32(dev):
+    """The dense GEMM path has no fp64 form: a float64 DiffPool input is computed in fp32, and says so (once)."""
+    import tgp.utils.ops as ops
+    from tgp.poolers import get_pooler
+    ops._WARNED_F64 = False
+    x, ei, ew, batch, _ = _small_batch(8, 20, 40, 8, 1, dev)
+    pooler = get_pooler("diff", in_channels=8, k=4).to(dev).double().eval()
+    with pytest.warns(UserWarning, match="float64 inputs are computed in float32"):
+        with torch.no_grad():
+            out = pooler(x=x.double(), adj=ei, batch=batch)
+    assert out.x.dtype == torch.float64

@@ -53,15 +53,18 @@ __global__ __launch_bounds__(256) void relabel_scatter_kernel(const int64_t* __r
 //   rank128[v >> 7] + popcount(bitmap words of the 128-node block before v's word) + popcount(v's word below bit v),
 // so the staging pass needs no gather from the 4 N-byte relabel table; the directory rank128 (exclusive scan of the
 // blocks' popcounts) is built by the stage kernel itself from its LDS copy of the bitmap.
-struct SubgraphPred {
+// WT: the weight type of the list (float, or double for model.double() inputs: r4) -- weights only pass through and
+// meet the |w| > eps test, in their own precision
+template <typename WT>
+struct SubgraphPredT {
   const int64_t* row;
   const int64_t* col;
-  const float* w;
+  const WT* w;
   const int32_t* relabel;       // nullptr = no node filter
   const uint32_t* member_bits;  // set with relabel
   const int* unsorted;          // set with relabel: node_index is not ascending
   int flags;
-  float eps;                    // the caller's eps at call time (reference ops.py:377 reads the module global)
+  WT eps;                       // the caller's eps at call time (reference ops.py:377 reads the module global)
   int64_t n;                    // number of nodes: endpoints outside [0, n) set *bad_ids (the reference's index ops raise)
   int* bad_ids;
   // keep / drop only; r, c are the ORIGINAL endpoints (relabelling is injective, so r == c decides self loops)
@@ -77,10 +80,11 @@ struct SubgraphPred {
       if (!(br & bc & 1u)) return false;
     }
     if ((flags & TGP_REMOVE_SELF_LOOPS) && r == c) return false;
-    if (w && (flags & TGP_EPS_FILTER) && !(fabsf(w[e]) > eps)) return false;
+    if (w && (flags & TGP_EPS_FILTER) && !(fabs(w[e]) > eps)) return false;
     return true;
   }
 };
+using SubgraphPred = SubgraphPredT<float>;
 
 // The edge list is walked ONCE, in chunks of SG_CHUNK = 4096 edges, by persistent 1024-thread workgroups (one per
 // CU).  A thread owns 4 CONSECUTIVE edges of a chunk, so row / col arrive as 16-byte loads, and the
@@ -93,29 +97,40 @@ constexpr int SG_THREADS = 1024;
 constexpr int SG_CHUNK = SG_THREADS * SG_PER;
 constexpr int SG_LDS_WORDS_MAX = 38 * 1024;  // 152 KB of the 160 KB LDS
 
-struct SgEdges {
+template <typename WT>
+struct SgEdgesT {
   int64_t r[SG_PER], c[SG_PER];
-  float w[SG_PER];
+  WT w[SG_PER];
   bool keep[SG_PER];
 };
+using SgEdges = SgEdgesT<float>;
 
 // the streaming part: the thread's 4 consecutive (row, col) pairs; keep[] = "edge exists"
-__device__ __forceinline__ void sg_fetch(const SubgraphPred& pred, int64_t e0, int64_t E, SgEdges& t) {
+template <typename WT>
+__device__ __forceinline__ void sg_fetch(const SubgraphPredT<WT>& pred, int64_t e0, int64_t E, SgEdgesT<WT>& t) {
   if (e0 >= E) {
 #pragma unroll
-    for (int j = 0; j < SG_PER; ++j) { t.keep[j] = false; t.r[j] = 0; t.c[j] = 0; t.w[j] = 0.f; }
+    for (int j = 0; j < SG_PER; ++j) { t.keep[j] = false; t.r[j] = 0; t.c[j] = 0; t.w[j] = WT(0); }
     return;
   }
-  if (pred.w) {  // streamed with the indices (one 16-byte load) rather than fetched sparsely for the survivors
+  if (pred.w) {  // streamed with the indices (16-byte loads) rather than fetched sparsely for the survivors
     if (e0 + SG_PER <= E && (reinterpret_cast<uintptr_t>(pred.w + e0) & 15) == 0) {
+      if constexpr (sizeof(WT) == 4) {
 #pragma unroll
-      for (int g = 0; g < SG_PER; g += 4) {
-        const float4 wv = *reinterpret_cast<const float4*>(pred.w + e0 + g);
-        t.w[g] = wv.x; t.w[g + 1] = wv.y; t.w[g + 2] = wv.z; t.w[g + 3] = wv.w;
+        for (int g = 0; g < SG_PER; g += 4) {
+          const float4 wv = *reinterpret_cast<const float4*>(pred.w + e0 + g);
+          t.w[g] = wv.x; t.w[g + 1] = wv.y; t.w[g + 2] = wv.z; t.w[g + 3] = wv.w;
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < SG_PER; g += 2) {
+          const double2 wv = *reinterpret_cast<const double2*>(pred.w + e0 + g);
+          t.w[g] = wv.x; t.w[g + 1] = wv.y;
+        }
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < SG_PER; ++j) t.w[j] = e0 + j < E ? pred.w[e0 + j] : 0.f;
+      for (int j = 0; j < SG_PER; ++j) t.w[j] = e0 + j < E ? pred.w[e0 + j] : WT(0);
     }
   }
   if (e0 + SG_PER <= E && ((reinterpret_cast<uintptr_t>(pred.row + e0) | reinterpret_cast<uintptr_t>(pred.col + e0)) & 15) == 0) {
@@ -139,8 +154,9 @@ __device__ __forceinline__ void sg_fetch(const SubgraphPred& pred, int64_t e0, i
 }
 
 // the predicate: membership of both endpoints (bitmap), self loops, |w| > eps
-template <bool LDSB>
-__device__ __forceinline__ bool sg_eval(const SubgraphPred& pred, const uint32_t* s_bits, int64_t e0, SgEdges& t) {
+template <bool LDSB, typename WT>
+__device__ __forceinline__ bool sg_eval(const SubgraphPredT<WT>& pred, const uint32_t* s_bits, int64_t e0,
+                                        SgEdgesT<WT>& t) {
   bool met_bad = false;
 #pragma unroll
   for (int j = 0; j < SG_PER; ++j) {  // endpoints outside [0, n): flagged, never used as an index
@@ -172,7 +188,7 @@ __device__ __forceinline__ bool sg_eval(const SubgraphPred& pred, const uint32_t
 #pragma unroll
   for (int j = 0; j < SG_PER; ++j) {
     if ((pred.flags & TGP_REMOVE_SELF_LOOPS) && t.r[j] == t.c[j]) t.keep[j] = false;
-    if (pred.w && (pred.flags & TGP_EPS_FILTER) && !(fabsf(t.w[j]) > pred.eps)) t.keep[j] = false;
+    if (pred.w && (pred.flags & TGP_EPS_FILTER) && !(fabs(t.w[j]) > pred.eps)) t.keep[j] = false;
   }
   return met_bad;
 }
@@ -201,12 +217,14 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s
 // staged survivors to their final places: it reads 14 bytes and writes 20 per SURVIVOR instead of streaming the
 // whole edge list a second time (at ratio 0.5 three quarters of the edges die: 200 MB -> 35 MB of reads).
 // LDSB: 0 = bitmap in global memory, 1 = bitmap in LDS, 2 = bitmap + rank128 in LDS (relabel by rank)
-struct SgStage {
+template <typename WT>
+struct SgStageT {
   int32_t* r;
   int32_t* c;
-  float* w;
+  WT* w;
   uint16_t* off;
 };
+using SgStage = SgStageT<float>;
 
 // r4, SINGLE = true: the same pass writes the survivors ONCE, in their final int64 form at their final offsets of
 // capacity-E outputs -- no staging area, no count kernel, no copy pass behind the host read (r3: 12 B read + 20 B written
@@ -216,20 +234,24 @@ struct SgStage {
 // workgroups that are all resident, and the next chunk's loads are already in flight while the words travel.  Edge ids
 // outside [0, n) ride along as the refusal bit; the last chunk leaves {epoch, refused, total} in *result (pinned host
 // memory: the caller polls it).
-struct SgSingle {
+template <typename WT>
+struct SgSingleT {
   int64_t* out_row;
   int64_t* out_col;
-  float* out_w;
+  WT* out_w;
   int64_t* out_eid;
   unsigned long long* status;
   unsigned long long* result;
   unsigned long long tag;
 };
+using SgSingle = SgSingleT<float>;
 
-template <int LDSB, bool SINGLE>
-__global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred pred, int64_t E, int nchunks, int nwords,
-                                                                    SgStage st, uint32_t* __restrict__ block_counts,
-                                                                    SgSingle sg) {
+template <int LDSB, bool SINGLE, typename WT = float>
+__global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPredT<WT> pred, int64_t E, int nchunks,
+                                                                    int nwords, SgStageT<WT> st,
+                                                                    uint32_t* __restrict__ block_counts,
+                                                                    SgSingleT<WT> sg) {
+  using SgEdges = SgEdgesT<WT>;
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   __shared__ uint32_t s_w[16];
   __shared__ uint32_t s_base;
@@ -287,7 +309,7 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred
       SgEdges t = nxt;
       if (chunk + static_cast<int>(gridDim.x) < nchunks)
         sg_fetch(pred, e0 + static_cast<int64_t>(gridDim.x) * SG_CHUNK, E, nxt);
-      sg_eval<(LDSB >= 1)>(pred, s_dyn, e0, t);
+      sg_eval<(LDSB >= 1), WT>(pred, s_dyn, e0, t);
       uint32_t mine = 0;
 #pragma unroll
       for (int j = 0; j < SG_PER; ++j) mine += t.keep[j] ? 1u : 0u;
@@ -314,7 +336,7 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred
     const int G = static_cast<int>(gridDim.x);
     auto eval_publish = [&](int chunk, SgEdges& t, uint32_t& rank, uint32_t& tot, bool& refused) {
       const int64_t e0 = static_cast<int64_t>(chunk) * SG_CHUNK + static_cast<int64_t>(threadIdx.x) * SG_PER;
-      const bool met_bad = sg_eval<(LDSB >= 1)>(pred, s_dyn, e0, t);
+      const bool met_bad = sg_eval<(LDSB >= 1), WT>(pred, s_dyn, e0, t);
       uint32_t mine = met_bad ? 0x10000u : 0u;  // (survivors of a chunk fit 13 bits: the flag rides above)
 #pragma unroll
       for (int j = 0; j < SG_PER; ++j) mine += t.keep[j] ? 1u : 0u;
@@ -417,12 +439,28 @@ __global__ __launch_bounds__(256) void cluster_table_kernel(const int64_t* __res
   if (i < n) table[i] = static_cast<int32_t>(cluster[i]);
 }
 
+// arithmetic of the weight type VT (float; double for model.double() inputs, r4): products / sums rounded one by one
+__device__ __forceinline__ float vt_add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double vt_add(double a, double b) { return __dadd_rn(a, b); }
+__device__ __forceinline__ float vt_mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double vt_mul(double a, double b) { return __dmul_rn(a, b); }
+template <typename VT>
+__device__ __forceinline__ VT vt_reduce(VT acc, VT v, int op) {
+  switch (op) {
+    case TGP_MIN: return fmin(acc, v);
+    case TGP_MAX: return fmax(acc, v);
+    case TGP_MUL: return vt_mul(acc, v);
+    default: return vt_add(acc, v);
+  }
+}
+
+template <typename VT>
 __global__ __launch_bounds__(256) void coalesce_keys_kernel(const int64_t* __restrict__ row,
                                                             const int64_t* __restrict__ col,
-                                                            const float* __restrict__ w,
+                                                            const VT* __restrict__ w,
                                                             const int32_t* __restrict__ cluster, int64_t E,
                                                             int64_t n, uint64_t K, uint64_t* __restrict__ keys,
-                                                            float* __restrict__ vals, int* __restrict__ bad_ids) {
+                                                            VT* __restrict__ vals, int* __restrict__ bad_ids) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (e < E) {
     const int64_t r = row[e], c = col[e];
@@ -435,17 +473,18 @@ __global__ __launch_bounds__(256) void coalesce_keys_kernel(const int64_t* __res
       else key = cr * K + cc;
     }
     keys[e] = key;
-    vals[e] = w ? w[e] : 1.0f;
+    vals[e] = w ? w[e] : VT(1);
   }
 }
 
 // Head of every run of equal keys reduces its run in sorted (= stable input) order, decides
 // whether the merged edge survives the filters, and the block counts survivors.
 // seg[i] holds the merged weight at run heads; keepflag[i] = 1 at surviving heads.
+template <typename VT>
 __global__ __launch_bounds__(256) void coalesce_segment_kernel(const uint64_t* __restrict__ keys,
-                                                               const float* __restrict__ vals, int64_t E,
+                                                               const VT* __restrict__ vals, int64_t E,
                                                                uint64_t K, int has_weight, int reduce_op,
-                                                               int flags, float eps, float* __restrict__ seg,
+                                                               int flags, VT eps, VT* __restrict__ seg,
                                                                uint8_t* __restrict__ keepflag,
                                                                uint32_t* __restrict__ block_counts) {
   __shared__ uint32_t s_cnt[4];
@@ -463,20 +502,12 @@ __global__ __launch_bounds__(256) void coalesce_segment_kernel(const uint64_t* _
         const uint64_t r = key / K, c = key - r * K;
         if ((flags & TGP_REMOVE_SELF_LOOPS) && r == c) keep = false;
         if (has_weight) {
-          float acc = vals[i];
+          VT acc = vals[i];
           int64_t n = 1;
-          for (int64_t j = i + 1; j < E && keys[j] == key; ++j, ++n) {
-            const float v = vals[j];
-            switch (reduce_op) {
-              case TGP_MIN: acc = fminf(acc, v); break;
-              case TGP_MAX: acc = fmaxf(acc, v); break;
-              case TGP_MUL: acc = __fmul_rn(acc, v); break;
-              default: acc = __fadd_rn(acc, v); break;
-            }
-          }
-          if (reduce_op == TGP_MEAN) acc = acc / static_cast<float>(n);
+          for (int64_t j = i + 1; j < E && keys[j] == key; ++j, ++n) acc = vt_reduce(acc, vals[j], reduce_op);
+          if (reduce_op == TGP_MEAN) acc = acc / static_cast<VT>(n);
           seg[i] = acc;
-          if ((flags & TGP_EPS_FILTER) && !(fabsf(acc) > eps)) keep = false;
+          if ((flags & TGP_EPS_FILTER) && !(fabs(acc) > eps)) keep = false;
         }
       }
       keepflag[i] = keep ? 1 : 0;
@@ -488,13 +519,14 @@ __global__ __launch_bounds__(256) void coalesce_segment_kernel(const uint64_t* _
   if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
+template <typename VT>
 __global__ __launch_bounds__(256) void coalesce_fill_kernel(const uint64_t* __restrict__ keys,
-                                                            const float* __restrict__ seg,
+                                                            const VT* __restrict__ seg,
                                                             const uint8_t* __restrict__ keepflag, int64_t E,
                                                             uint64_t K, const uint32_t* __restrict__ block_offsets,
                                                             int64_t* __restrict__ out_row,
                                                             int64_t* __restrict__ out_col,
-                                                            float* __restrict__ out_w) {
+                                                            VT* __restrict__ out_w) {
   __shared__ uint32_t s_cnt[kCompactItems * 4];
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kCompactTile;
   bool keep[kCompactItems];
@@ -745,20 +777,21 @@ __global__ __launch_bounds__(256) void graph_max_scale_kernel(const int64_t* __r
 // =====================================================================================
 // A10: dense [B,K,K] -> block-diagonal edge list (utils/ops.py:53-82, src.py:526-552)
 // =====================================================================================
-struct BlockDiagPred {
-  const float* adj;
+template <typename VT>
+struct BlockDiagPredT {
+  const VT* adj;
   const int64_t* relabel;  // [B*K] new id or -1; nullptr = identity
   int64_t K;
   int flags;
-  float eps;
-  __device__ __forceinline__ bool operator()(int64_t i, int64_t& r, int64_t& c, float& v) const {
+  VT eps;
+  __device__ __forceinline__ bool operator()(int64_t i, int64_t& r, int64_t& c, VT& v) const {
     v = adj[i];
     const int64_t kk = K * K;
     const int64_t b = i / kk, rem = i - b * kk;
     const int64_t rr = rem / K;
     r = b * K + rr;
     c = b * K + (rem - rr * K);
-    if (!(fabsf(v) > eps)) return false;
+    if (!(fabs(v) > eps)) return false;
     if (relabel) {
       r = relabel[r];
       c = relabel[c];
@@ -769,7 +802,10 @@ struct BlockDiagPred {
   }
 };
 
-__global__ __launch_bounds__(256) void blockdiag_count_kernel(BlockDiagPred pred, int64_t total,
+using BlockDiagPred = BlockDiagPredT<float>;
+
+template <typename VT>
+__global__ __launch_bounds__(256) void blockdiag_count_kernel(BlockDiagPredT<VT> pred, int64_t total,
                                                               uint32_t* __restrict__ block_counts) {
   __shared__ uint32_t s_cnt[4];
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kCompactTile;
@@ -778,7 +814,7 @@ __global__ __launch_bounds__(256) void blockdiag_count_kernel(BlockDiagPred pred
   for (int it = 0; it < kCompactItems; ++it) {
     const int64_t i = base + it * 256 + threadIdx.x;
     int64_t r, c;
-    float v;
+    VT v;
     const bool keep = i < total && pred(i, r, c, v);
     mine += __popcll(__ballot(keep));
   }
@@ -787,16 +823,17 @@ __global__ __launch_bounds__(256) void blockdiag_count_kernel(BlockDiagPred pred
   if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-__global__ __launch_bounds__(256) void blockdiag_fill_kernel(BlockDiagPred pred, int64_t total,
+template <typename VT>
+__global__ __launch_bounds__(256) void blockdiag_fill_kernel(BlockDiagPredT<VT> pred, int64_t total,
                                                              const uint32_t* __restrict__ block_offsets,
                                                              int64_t* __restrict__ out_row,
                                                              int64_t* __restrict__ out_col,
-                                                             float* __restrict__ out_w) {
+                                                             VT* __restrict__ out_w) {
   __shared__ uint32_t s_cnt[kCompactItems * 4];
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kCompactTile;
   bool keep[kCompactItems];
   int64_t r[kCompactItems], c[kCompactItems];
-  float v[kCompactItems];
+  VT v[kCompactItems];
   uint32_t rank[kCompactItems];
 #pragma unroll
   for (int it = 0; it < kCompactItems; ++it) {
@@ -989,11 +1026,12 @@ extern "C" int64_t tgp_connect_subgraph_single_bad_ids_offset(int64_t N) {
   return reinterpret_cast<char*>(s.unsorted + 1) - base;
 }
 
-extern "C" int tgp_connect_subgraph_single(const int64_t* row, const int64_t* col, const float* w, int64_t E,
-                                           const int64_t* node_index, int64_t k, int64_t N, int flags, float eps,
-                                           void* ws, size_t ws_bytes, int64_t* out_row, int64_t* out_col, float* out_w,
-                                           int64_t* out_edge_id, uint64_t* status, int64_t status_words,
-                                           uint64_t* result, uint32_t epoch, void* stream_) {
+template <typename WT>
+static int subgraph_single_impl(const int64_t* row, const int64_t* col, const WT* w, int64_t E,
+                                const int64_t* node_index, int64_t k, int64_t N, int flags, WT eps, void* ws,
+                                size_t ws_bytes, int64_t* out_row, int64_t* out_col, WT* out_w, int64_t* out_edge_id,
+                                uint64_t* status, int64_t status_words, uint64_t* result, uint32_t epoch,
+                                void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(E > 0 && N >= 0 && k >= 0 && row && col && out_row && out_col && (!w || out_w) && status && result,
               TGP_ERR_INVALID, "tgp_connect_subgraph_single: bad argument");
@@ -1016,9 +1054,9 @@ extern "C" int tgp_connect_subgraph_single(const int64_t* row, const int64_t* co
                          s.member_bits, s.unsorted);
   }
   const int nb = cdiv(E, SG_CHUNK);
-  SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.unsorted, flags, eps,
-                    N, s.unsorted + 1};
-  SgSingle sg{out_row, out_col, w ? out_w : nullptr, out_edge_id, reinterpret_cast<unsigned long long*>(status),
+  SubgraphPredT<WT> pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.unsorted, flags, eps,
+                         N, s.unsorted + 1};
+  SgSingleT<WT> sg{out_row, out_col, w ? out_w : nullptr, out_edge_id, reinterpret_cast<unsigned long long*>(status),
               reinterpret_cast<unsigned long long*>(result), static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT};
   // persistent, every workgroup resident (the look-back waits for chunks of the same round): one per CU
   int cus = tgp_device_cu_count();
@@ -1026,42 +1064,65 @@ extern "C" int tgp_connect_subgraph_single(const int64_t* row, const int64_t* co
   const int grid = nb < cus ? nb : cus;
   const int nblocks = (nwords + 3) / 4;
   if (node_index && 5 * nblocks <= SG_LDS_WORDS_MAX + 1984) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<2, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<2, true, WT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (SG_LDS_WORDS_MAX + 1984 + 4) * 4);
-    hipLaunchKernelGGL((subgraph_stage_kernel<2, true>), dim3(grid), dim3(SG_THREADS),
-                       (5 * nblocks + 4) * sizeof(uint32_t), stream, pred, E, nb, nwords, SgStage{}, nullptr, sg);
+    hipLaunchKernelGGL((subgraph_stage_kernel<2, true, WT>), dim3(grid), dim3(SG_THREADS),
+                       (5 * nblocks + 4) * sizeof(uint32_t), stream, pred, E, nb, nwords, SgStageT<WT>{}, nullptr, sg);
   } else if (node_index && nwords <= SG_LDS_WORDS_MAX) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<1, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<1, true, WT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS_WORDS_MAX * 4);
-    hipLaunchKernelGGL((subgraph_stage_kernel<1, true>), dim3(grid), dim3(SG_THREADS), nwords * sizeof(uint32_t), stream,
-                       pred, E, nb, nwords, SgStage{}, nullptr, sg);
+    hipLaunchKernelGGL((subgraph_stage_kernel<1, true, WT>), dim3(grid), dim3(SG_THREADS), nwords * sizeof(uint32_t), stream,
+                       pred, E, nb, nwords, SgStageT<WT>{}, nullptr, sg);
   } else {
-    hipLaunchKernelGGL((subgraph_stage_kernel<0, true>), dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords,
-                       SgStage{}, nullptr, sg);
+    hipLaunchKernelGGL((subgraph_stage_kernel<0, true, WT>), dim3(grid), dim3(SG_THREADS), 0, stream, pred, E, nb, nwords,
+                       SgStageT<WT>{}, nullptr, sg);
   }
   return check_launch("tgp_connect_subgraph_single");
 }
 
+extern "C" int tgp_connect_subgraph_single(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                           const int64_t* node_index, int64_t k, int64_t N, int flags, float eps,
+                                           void* ws, size_t ws_bytes, int64_t* out_row, int64_t* out_col, float* out_w,
+                                           int64_t* out_edge_id, uint64_t* status, int64_t status_words,
+                                           uint64_t* result, uint32_t epoch, void* stream_) {
+  return subgraph_single_impl<float>(row, col, w, E, node_index, k, N, flags, eps, ws, ws_bytes, out_row, out_col, out_w,
+                                     out_edge_id, status, status_words, result, epoch, stream_);
+}
+
+// float64 weights (model.double(): the reference's ATen ops keep them in fp64): they pass through and meet the
+// |w| > eps test in double, eps as a double
+extern "C" int tgp_connect_subgraph_single_f64(const int64_t* row, const int64_t* col, const double* w, int64_t E,
+                                               const int64_t* node_index, int64_t k, int64_t N, int flags, double eps,
+                                               void* ws, size_t ws_bytes, int64_t* out_row, int64_t* out_col,
+                                               double* out_w, int64_t* out_edge_id, uint64_t* status,
+                                               int64_t status_words, uint64_t* result, uint32_t epoch, void* stream_) {
+  return subgraph_single_impl<double>(row, col, w, E, node_index, k, N, flags, eps, ws, ws_bytes, out_row, out_col,
+                                      out_w, out_edge_id, status, status_words, result, epoch, stream_);
+}
+
 // ------------------------------------------------------------------------------------- coalesce
-struct CoalesceWs {
+template <typename VT>
+struct CoalesceWsT {
   uint64_t *k0, *k1;
-  float *v0, *v1;
-  float* seg;
+  VT *v0, *v1;
+  VT* seg;
   uint8_t* keep;
   uint32_t *counts, *offsets, *scratch;
   int32_t* table;
   int* bad_ids;
 };
-static size_t coalesce_layout(void* ws, int64_t E, int64_t N, CoalesceWs* out) {
+using CoalesceWs = CoalesceWsT<float>;
+template <typename VT>
+static size_t coalesce_layout(void* ws, int64_t E, int64_t N, CoalesceWsT<VT>* out) {
   Carver cv(ws);
   const size_t n = static_cast<size_t>(E > 0 ? E : 1);
   const size_t nb = static_cast<size_t>(cdiv(E > 0 ? E : 1, kCompactTile));
-  CoalesceWs s;
+  CoalesceWsT<VT> s;
   s.k0 = cv.take<uint64_t>(n);
   s.k1 = cv.take<uint64_t>(n);
-  s.v0 = cv.take<float>(n);
-  s.v1 = cv.take<float>(n);
-  s.seg = cv.take<float>(n);
+  s.v0 = cv.take<VT>(n);
+  s.v1 = cv.take<VT>(n);
+  s.seg = cv.take<VT>(n);
   s.keep = cv.take<uint8_t>(n);
   s.counts = cv.take<uint32_t>(nb);
   s.offsets = cv.take<uint32_t>(nb);
@@ -1073,13 +1134,16 @@ static size_t coalesce_layout(void* ws, int64_t E, int64_t N, CoalesceWs* out) {
 }
 
 extern "C" size_t tgp_connect_coalesce_workspace_bytes(int64_t E, int64_t N, int64_t /*K*/) {
-  return coalesce_layout(nullptr, E, N, nullptr) + 256;
+  return coalesce_layout<float>(nullptr, E, N, nullptr) + 256;
+}
+extern "C" size_t tgp_connect_coalesce_workspace_bytes_f64(int64_t E, int64_t N, int64_t /*K*/) {
+  return coalesce_layout<double>(nullptr, E, N, nullptr) + 256;
 }
 
-extern "C" int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
-                                          const int64_t* cluster_index, int64_t N, int64_t K, int reduce_op,
-                                          int flags, float eps, void* ws, size_t ws_bytes, int64_t* d_count,
-                                          void* stream_) {
+template <typename VT>
+static int coalesce_count_impl(const int64_t* row, const int64_t* col, const VT* w, int64_t E,
+                               const int64_t* cluster_index, int64_t N, int64_t K, int reduce_op, int flags, VT eps,
+                               void* ws, size_t ws_bytes, int64_t* d_count, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && d_count && (E == 0 || (row && col && cluster_index)),
               TGP_ERR_INVALID, "tgp_connect_coalesce_count: bad argument");
@@ -1087,10 +1151,10 @@ extern "C" int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col
               "tgp_connect_coalesce_count: unknown reduce_op %d", reduce_op);
   TGP_REQUIRE(E < (1ll << 31) && K < (1ll << 31) && N < (1ll << 31), TGP_ERR_RANGE,
               "tgp_connect_coalesce_count: E/N/K >= 2^31");
-  TGP_REQUIRE(ws && ws_bytes >= tgp_connect_coalesce_workspace_bytes(E, N, K), TGP_ERR_WORKSPACE,
+  TGP_REQUIRE(ws && ws_bytes >= coalesce_layout<VT>(nullptr, E, N, nullptr) + 256, TGP_ERR_WORKSPACE,
               "tgp_connect_coalesce_count: workspace too small");
-  CoalesceWs s;
-  coalesce_layout(ws, E, N, &s);
+  CoalesceWsT<VT> s;
+  coalesce_layout<VT>(ws, E, N, &s);
   if (E == 0) {
     (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
     return check_launch("tgp_connect_coalesce_count");
@@ -1099,37 +1163,64 @@ extern "C" int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col
   hipLaunchKernelGGL(cluster_table_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, cluster_index, N, s.table);
   int* bad_ids = s.bad_ids;
   (void)hipMemsetAsync(bad_ids, 0, sizeof(int), stream);
-  hipLaunchKernelGGL(coalesce_keys_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, s.table, E, N, Ku,
-                     s.k0, s.v0, bad_ids);
+  hipLaunchKernelGGL(coalesce_keys_kernel<VT>, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, s.table, E, N,
+                     Ku, s.k0, s.v0, bad_ids);
   bool first = true;
-  const int rc = radix_sort_pairs<uint64_t, float>(s.k0, s.v0, s.k1, s.v1, E, bits_for(Ku * Ku - 1), s.scratch,
-                                                   stream, &first);
+  const int rc = radix_sort_pairs<uint64_t, VT>(s.k0, s.v0, s.k1, s.v1, E, bits_for(Ku * Ku - 1), s.scratch, stream,
+                                                &first);
   if (rc != TGP_OK) return rc;
   const int nb = cdiv(E, kCompactTile);
-  hipLaunchKernelGGL(coalesce_segment_kernel, dim3(nb), dim3(256), 0, stream, first ? s.k0 : s.k1,
+  hipLaunchKernelGGL(coalesce_segment_kernel<VT>, dim3(nb), dim3(256), 0, stream, first ? s.k0 : s.k1,
                      first ? s.v0 : s.v1, E, Ku, w ? 1 : 0, reduce_op, flags, eps, s.seg, s.keep, s.counts);
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nb, s.offsets, d_count,
                      static_cast<const int*>(bad_ids));
   return check_launch("tgp_connect_coalesce_count");
 }
 
-extern "C" int tgp_connect_coalesce_fill(const void* ws, int64_t E, int64_t N, int64_t K, int has_weight, int /*flags*/,
-                                         int64_t num_out, int64_t* out_row, int64_t* out_col, float* out_w,
-                                         void* stream_) {
+extern "C" int tgp_connect_coalesce_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                          const int64_t* cluster_index, int64_t N, int64_t K, int reduce_op,
+                                          int flags, float eps, void* ws, size_t ws_bytes, int64_t* d_count,
+                                          void* stream_) {
+  return coalesce_count_impl<float>(row, col, w, E, cluster_index, N, K, reduce_op, flags, eps, ws, ws_bytes, d_count,
+                                    stream_);
+}
+// float64 weights: merged in fp64 (products / sums rounded one by one, input order), eps as a double
+extern "C" int tgp_connect_coalesce_count_f64(const int64_t* row, const int64_t* col, const double* w, int64_t E,
+                                              const int64_t* cluster_index, int64_t N, int64_t K, int reduce_op,
+                                              int flags, double eps, void* ws, size_t ws_bytes, int64_t* d_count,
+                                              void* stream_) {
+  return coalesce_count_impl<double>(row, col, w, E, cluster_index, N, K, reduce_op, flags, eps, ws, ws_bytes, d_count,
+                                     stream_);
+}
+
+template <typename VT>
+static int coalesce_fill_impl(const void* ws, int64_t E, int64_t N, int64_t K, int has_weight, int64_t num_out,
+                              int64_t* out_row, int64_t* out_col, VT* out_w, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(ws && E >= 0 && num_out >= 0, TGP_ERR_INVALID, "tgp_connect_coalesce_fill: bad argument");
   if (num_out == 0 || E == 0) return TGP_OK;
   TGP_REQUIRE(out_row && out_col && (!has_weight || out_w), TGP_ERR_INVALID,
               "tgp_connect_coalesce_fill: null output");
-  CoalesceWs s;
-  coalesce_layout(const_cast<void*>(ws), E, N, &s);
+  CoalesceWsT<VT> s;
+  coalesce_layout<VT>(const_cast<void*>(ws), E, N, &s);
   const uint64_t Ku = static_cast<uint64_t>(K > 0 ? K : 1);
   // The ping-pong parity is a pure function of (E, K): recompute it instead of reading it back.
   const bool first = (sort_passes(E, bits_for(Ku * Ku - 1)) % 2) == 0;
   const int nb = cdiv(E, kCompactTile);
-  hipLaunchKernelGGL(coalesce_fill_kernel, dim3(nb), dim3(256), 0, stream, first ? s.k0 : s.k1, s.seg, s.keep, E,
-                     Ku, s.offsets, out_row, out_col, has_weight ? out_w : nullptr);
+  hipLaunchKernelGGL(coalesce_fill_kernel<VT>, dim3(nb), dim3(256), 0, stream, first ? s.k0 : s.k1, s.seg, s.keep, E,
+                     Ku, s.offsets, out_row, out_col, has_weight ? out_w : static_cast<VT*>(nullptr));
   return check_launch("tgp_connect_coalesce_fill");
+}
+
+extern "C" int tgp_connect_coalesce_fill(const void* ws, int64_t E, int64_t N, int64_t K, int has_weight, int /*flags*/,
+                                         int64_t num_out, int64_t* out_row, int64_t* out_col, float* out_w,
+                                         void* stream_) {
+  return coalesce_fill_impl<float>(ws, E, N, K, has_weight, num_out, out_row, out_col, out_w, stream_);
+}
+extern "C" int tgp_connect_coalesce_fill_f64(const void* ws, int64_t E, int64_t N, int64_t K, int has_weight,
+                                             int /*flags*/, int64_t num_out, int64_t* out_row, int64_t* out_col,
+                                             double* out_w, void* stream_) {
+  return coalesce_fill_impl<double>(ws, E, N, K, has_weight, num_out, out_row, out_col, out_w, stream_);
 }
 
 // ------------------------------------------------------------------------------------- norms
@@ -1188,8 +1279,9 @@ extern "C" size_t tgp_block_diag_workspace_bytes(int64_t B, int64_t K) {
   return 2 * align_up(nb * sizeof(uint32_t)) + 256;
 }
 
-extern "C" int tgp_block_diag_count(const float* adj, int64_t B, int64_t K, const int64_t* relabel, int flags,
-                                    float eps, void* ws, size_t ws_bytes, int64_t* d_count, void* stream_) {
+template <typename VT>
+static int block_diag_count_impl(const VT* adj, int64_t B, int64_t K, const int64_t* relabel, int flags, VT eps, void* ws,
+                                 size_t ws_bytes, int64_t* d_count, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && K >= 0 && d_count, TGP_ERR_INVALID, "tgp_block_diag_count: bad argument");
   const int64_t total = B * K * K;
@@ -1205,16 +1297,25 @@ extern "C" int tgp_block_diag_count(const float* adj, int64_t B, int64_t K, cons
   const int nb = cdiv(total, kCompactTile);
   uint32_t* counts = cv.take<uint32_t>(nb);
   uint32_t* offsets = cv.take<uint32_t>(nb);
-  BlockDiagPred pred{adj, relabel, K, flags, eps};
-  hipLaunchKernelGGL(blockdiag_count_kernel, dim3(nb), dim3(256), 0, stream, pred, total, counts);
+  BlockDiagPredT<VT> pred{adj, relabel, K, flags, eps};
+  hipLaunchKernelGGL(blockdiag_count_kernel<VT>, dim3(nb), dim3(256), 0, stream, pred, total, counts);
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts, nb, offsets, d_count,
                      static_cast<const int*>(nullptr));
   return check_launch("tgp_block_diag_count");
 }
+extern "C" int tgp_block_diag_count(const float* adj, int64_t B, int64_t K, const int64_t* relabel, int flags,
+                                    float eps, void* ws, size_t ws_bytes, int64_t* d_count, void* stream_) {
+  return block_diag_count_impl<float>(adj, B, K, relabel, flags, eps, ws, ws_bytes, d_count, stream_);
+}
+extern "C" int tgp_block_diag_count_f64(const double* adj, int64_t B, int64_t K, const int64_t* relabel, int flags,
+                                        double eps, void* ws, size_t ws_bytes, int64_t* d_count, void* stream_) {
+  return block_diag_count_impl<double>(adj, B, K, relabel, flags, eps, ws, ws_bytes, d_count, stream_);
+}
 
-extern "C" int tgp_block_diag_fill(const float* adj, int64_t B, int64_t K, const int64_t* relabel, int flags,
-                                   float eps, const void* ws, int64_t num_out, int64_t* out_row, int64_t* out_col,
-                                   float* out_w, void* stream_) {
+template <typename VT>
+static int block_diag_fill_impl(const VT* adj, int64_t B, int64_t K, const int64_t* relabel, int flags, VT eps,
+                                const void* ws, int64_t num_out, int64_t* out_row, int64_t* out_col, VT* out_w,
+                                void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int64_t total = B * K * K;
   TGP_REQUIRE(ws && num_out >= 0, TGP_ERR_INVALID, "tgp_block_diag_fill: bad argument");
@@ -1224,10 +1325,20 @@ extern "C" int tgp_block_diag_fill(const float* adj, int64_t B, int64_t K, const
   const int nb = cdiv(total, kCompactTile);
   cv.take<uint32_t>(nb);
   uint32_t* offsets = cv.take<uint32_t>(nb);
-  BlockDiagPred pred{adj, relabel, K, flags, eps};
-  hipLaunchKernelGGL(blockdiag_fill_kernel, dim3(nb), dim3(256), 0, stream, pred, total, offsets, out_row,
+  BlockDiagPredT<VT> pred{adj, relabel, K, flags, eps};
+  hipLaunchKernelGGL(blockdiag_fill_kernel<VT>, dim3(nb), dim3(256), 0, stream, pred, total, offsets, out_row,
                      out_col, out_w);
   return check_launch("tgp_block_diag_fill");
+}
+extern "C" int tgp_block_diag_fill(const float* adj, int64_t B, int64_t K, const int64_t* relabel, int flags,
+                                   float eps, const void* ws, int64_t num_out, int64_t* out_row, int64_t* out_col,
+                                   float* out_w, void* stream_) {
+  return block_diag_fill_impl<float>(adj, B, K, relabel, flags, eps, ws, num_out, out_row, out_col, out_w, stream_);
+}
+extern "C" int tgp_block_diag_fill_f64(const double* adj, int64_t B, int64_t K, const int64_t* relabel, int flags,
+                                       double eps, const void* ws, int64_t num_out, int64_t* out_row, int64_t* out_col,
+                                       double* out_w, void* stream_) {
+  return block_diag_fill_impl<double>(adj, B, K, relabel, flags, eps, ws, num_out, out_row, out_col, out_w, stream_);
 }
 
 // ------------------------------------------------------------------------------------- debug sort

@@ -165,6 +165,23 @@ SIGNATURES = {
     "tgp_mlp_select_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_softmax_rows_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p]),
     "tgp_softmax_bwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p]),
+    "tgp_reduce_sparse_f64": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
+    "tgp_connect_subgraph_single_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, ctypes.c_double,
+                                                 _c_p, _c_sz, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, ctypes.c_uint32,
+                                                 _c_p]),
+    "tgp_connect_coalesce_workspace_bytes_f64": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "tgp_connect_coalesce_count_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_int,
+                                                ctypes.c_double, _c_p, _c_sz, _c_p, _c_p]),
+    "tgp_connect_coalesce_fill_f64": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_i64, _c_p, _c_p, _c_p,
+                                               _c_p]),
+    "tgp_postprocess_sparse_workspace_bytes_f64": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "tgp_postprocess_sparse_norm_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_int, ctypes.c_double, _c_p, _c_i64,
+                                                 _c_p, _c_sz, _c_p]),
+    "tgp_block_diag_count_f64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, ctypes.c_double, _c_p, _c_sz, _c_p, _c_p]),
+    "tgp_block_diag_fill_f64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, ctypes.c_double, _c_p, _c_i64, _c_p, _c_p,
+                                         _c_p, _c_p]),
+    "tgp_postprocess_dense_workspace_bytes_f64": (_c_sz, [_c_i64, _c_i64]),
+    "tgp_postprocess_dense_f64": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_int, ctypes.c_double, _c_p, _c_sz, _c_p]),
     "tgp_gather_pack_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64, _c_int]),
     "tgp_gather_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_gather_unpack_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p,
@@ -238,6 +255,13 @@ def stream_ptr(dev: torch.device) -> int:
 
 def workspace(nbytes: int, dev: torch.device) -> Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+def f64c(t: Tensor) -> Tensor:
+    """fp64 + contiguous view/copy (the float64 value type of the HBM-bound operators)."""
+    if t.dtype != torch.float64:
+        t = t.to(torch.float64)
+    return t if t.is_contiguous() else t.contiguous()
 
 
 def f32c(t: Tensor) -> Tensor:

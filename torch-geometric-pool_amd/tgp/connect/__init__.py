@@ -105,7 +105,10 @@ class SparseConnect(Connect):
         # shared with Reduce) so the sort-free row-local coalesce can be used
         ni = so.node_index  # None for a dense assignment: sparse_connect then raises the reference's RuntimeError
         all_assigned = ni is not None and ni.numel() == so.num_nodes and ni.is_cuda
-        w32 = as_compute_dtype(edge_weight)  # fp32 arithmetic; pooled weights carry the dtype of the input weights
+        # fp32 arithmetic for fp32 / half weights (pooled weights carry the dtype of the input weights); float64 weights
+        # stay float64 through the edge-list kernels (r4: the reference's coalesce / scatter keep them in fp64)
+        w32 = edge_weight if (isinstance(edge_weight, Tensor) and edge_weight.dtype == torch.float64
+                              and edge_weight.is_cuda) else as_compute_dtype(edge_weight)
         adj_pool, w_pool = sparse_connect(edge_index, w32, node_index=so.node_index, cluster_index=so.cluster_index,
                                           num_nodes=so.num_nodes, num_supernodes=so.num_supernodes,
                                           remove_self_loops=self.remove_self_loops, reduce_op=self.reduce_op,

@@ -213,7 +213,7 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
         return K.filter_edges(edge_index, edge_weight, node_index, num_nodes, remove_self_loops)
     ei, ew, eid = K.filter_edges(edge_index, edge_weight.detach(), node_index, num_nodes, remove_self_loops,
                                  want_edge_id=True)
-    w32 = edge_weight if edge_weight.dtype == torch.float32 else edge_weight.float()
+    w32 = edge_weight if edge_weight.dtype in (torch.float32, torch.float64) else edge_weight.float()
     return ei, _FilteredWeightsFn.apply(w32.reshape(-1), eid, (ew,))
 
 
@@ -257,7 +257,7 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
         return K.coalesce_edges(edge_index, edge_weight, cluster_index, num_supernodes, reduce_op, remove_self_loops,
                                 assign_index=assign_index, csr=csr)
     w = edge_weight.reshape(-1)
-    w32 = w if w.dtype == torch.float32 else w.float()
+    w32 = w if w.dtype in (torch.float32, torch.float64) else w.float()
     ei, ew = K.coalesce_edges(edge_index, w32.detach(), cluster_index, num_supernodes, reduce_op, remove_self_loops,
                               assign_index=assign_index, csr=csr)
     if ei.size(1) == 0:

@@ -84,6 +84,17 @@ def reduce_sparse(x: Tensor, source_index: Tensor, weight: Optional[Tensor], ind
     x2 = x.view(-1, 1) if squeeze else x
     if x2.dim() != 2:
         raise ValueError(f"sparse reduce expects x of shape [N, F], got {tuple(x.shape)}")
+    if x2.dtype == torch.float64 or (weight is not None and weight.dtype == torch.float64):
+        # float64 features or weights: the product promotes to fp64 in the reference (base_reduce.py:146-153) -- fp64
+        # kernel, same summation order
+        x2 = N.f64c(x2) if x2.stride(1) == 1 and x2.dtype == torch.float64 else x2.to(torch.float64).contiguous()
+        src64 = N.i64c(source_index)
+        w64 = None if weight is None else N.f64c(weight.reshape(-1))
+        out = torch.empty(index.num_targets, x2.size(1), dtype=torch.float64, device=dev)
+        N.check(N.lib().tgp_reduce_sparse_f64(N.ptr(x2), x2.size(0), x2.size(1), x2.stride(0), N.ptr(src64), N.ptr(w64),
+                                              N.ptr(index._row_ptr), N.ptr(index.perm), index.nnz, index.num_targets,
+                                              N.ptr(out), N.stream_ptr(dev)), "tgp_reduce_sparse_f64")
+        return out.view(-1) if squeeze else out
     x2 = x2.to(torch.float32) if x2.dtype != torch.float32 else x2
     if x2.stride(1) != 1:
         x2 = x2.contiguous()
@@ -301,7 +312,8 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
     dev = N.require_device(edge_index, edge_weight, node_index)
     row, col = _edge_rows(edge_index)
     E = row.numel()
-    w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
+    f64 = edge_weight is not None and edge_weight.dtype == torch.float64  # fp64 weights pass through as they are
+    w = None if edge_weight is None else (N.f64c if f64 else N.f32c)(edge_weight.reshape(-1))
     ni = None if node_index is None else N.i64c(node_index)
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if w is not None else 0)
     if want_edge_id:
@@ -310,17 +322,24 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
         flags |= N.NODE_FILTER
         if ni.numel() == 0:  # no node kept: no edge survives (an empty tensor has no device pointer to hand over)
             out = (torch.empty(2, 0, dtype=torch.int64, device=dev),
-                   None if w is None else torch.empty(0, dtype=torch.float32, device=dev))
+                   None if w is None else torch.empty(0, dtype=w.dtype, device=dev))
             return out + (torch.empty(0, dtype=torch.int64, device=dev),) if want_edge_id else out
     L = N.lib()
     st = N.stream_ptr(dev)
     eps = ops_eps()
-    if E > 0 and not torch.cuda.is_current_stream_capturing():
+    if E > 0 and (f64 or not torch.cuda.is_current_stream_capturing()):
         # ONE pass (r4): survivors written once at their final offsets of capacity-E buffers, which are then narrowed
         # (edge_index' is a view whose two rows are contiguous); the count arrives in a pinned host word
         got = _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id)
+        if got is None and f64:  # (a look-back spin bound on a shared device: once more; fp64 has no count -> fill pair)
+            got = _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id)
         if got is not None:
             return got
+        if f64:
+            raise N.TgpNativeError("tgp_connect_subgraph_single_f64 refused twice (is the device shared?)")
+    if f64:  # E == 0
+        out = (torch.empty(2, 0, dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.float64, device=dev))
+        return out + (torch.empty(0, dtype=torch.int64, device=dev),) if want_edge_id else out
     ws = N.workspace(L.tgp_connect_subgraph_workspace_bytes(E, num_nodes), dev)
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
     N.check(L.tgp_connect_subgraph_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(ni),
@@ -343,12 +362,14 @@ def _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, 
     spin bound on a shared device): the caller takes the count -> fill pair."""
     ws = N.workspace(L.tgp_connect_subgraph_single_workspace_bytes(num_nodes), dev)
     cap = torch.empty(2, E, dtype=torch.int64, device=dev)
-    cap_w = None if w is None else torch.empty(E, dtype=torch.float32, device=dev)
+    cap_w = None if w is None else torch.empty(E, dtype=w.dtype, device=dev)
     cap_id = torch.empty(E, dtype=torch.int64, device=dev) if want_edge_id else None
     state = _sps_state(dev, st, L.tgp_connect_subgraph_single_status_words(E))
     epoch = state.next_epoch()
     cap_p = cap.data_ptr()
-    N.check(L.tgp_connect_subgraph_single(row.data_ptr(), col.data_ptr(), N.ptr(w), E, N.ptr(ni),
+    entry = (L.tgp_connect_subgraph_single_f64 if (w is not None and w.dtype == torch.float64)
+             else L.tgp_connect_subgraph_single)
+    N.check(entry(row.data_ptr(), col.data_ptr(), N.ptr(w), E, N.ptr(ni),
                                           0 if ni is None else ni.numel(), num_nodes, flags, eps, ws.data_ptr(),
                                           ws.numel(), cap_p, cap_p + 8 * E, N.ptr(cap_w), N.ptr(cap_id),
                                           state.status.data_ptr(), state.status.numel(), state.pinned.data_ptr(), epoch,
@@ -402,6 +423,28 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
     dev = N.require_device(edge_index, edge_weight, cluster_index)
     row, col = _edge_rows(edge_index)
     E = row.numel()
+    if edge_weight is not None and edge_weight.dtype == torch.float64:
+        # fp64 weights are merged in fp64 (the reference's coalesce / scatter do): the sort-based route, in double
+        if route not in (None, "general"):
+            raise RuntimeError("float64 edge weights take the general coalesce route")
+        w = N.f64c(edge_weight.reshape(-1))
+        cl = N.i64c(cluster_index)
+        flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if eps_filter else 0)
+        L = N.lib()
+        ws = N.workspace(L.tgp_connect_coalesce_workspace_bytes_f64(E, cl.numel(), num_supernodes), dev)
+        d_count = torch.empty(1, dtype=torch.int64, device=dev)
+        st = N.stream_ptr(dev)
+        N.check(L.tgp_connect_coalesce_count_f64(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
+                                                 num_supernodes, N.REDUCE_OPS[reduce_op], flags, ops_eps(), N.ptr(ws),
+                                                 ws.numel(), N.ptr(d_count), st), "tgp_connect_coalesce_count_f64")
+        n_out = _read_count(d_count)
+        out_ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
+        out_w = torch.empty(n_out, dtype=torch.float64, device=dev)
+        N.check(L.tgp_connect_coalesce_fill_f64(N.ptr(ws), E, cl.numel(), num_supernodes, 1, flags, n_out,
+                                                N.ptr(out_ei[0]) if n_out else None,
+                                                N.ptr(out_ei[1]) if n_out else None, N.ptr(out_w) if n_out else None, st),
+                "tgp_connect_coalesce_fill_f64")
+        return out_ei, out_w
     w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
     cl = N.i64c(cluster_index)
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if (w is not None and eps_filter) else 0)
@@ -544,6 +587,12 @@ def normalize_edges_(edge_index: Tensor, edge_weight: Tensor, num_nodes: int, de
         return edge_weight
     bp = None if batch_pooled is None else N.i64c(batch_pooled)
     L = N.lib()
+    if edge_weight.dtype == torch.float64:
+        ws = N.workspace(L.tgp_postprocess_sparse_workspace_bytes_f64(row.numel(), num_nodes, num_graphs), dev)
+        N.check(L.tgp_postprocess_sparse_norm_f64(N.ptr(row), N.ptr(col), N.ptr(edge_weight), row.numel(), num_nodes,
+                                                  flags, ops_eps(), N.ptr(bp), num_graphs, N.ptr(ws), ws.numel(),
+                                                  N.stream_ptr(dev)), "tgp_postprocess_sparse_norm_f64")
+        return edge_weight
     ws = N.workspace(L.tgp_postprocess_sparse_workspace_bytes(row.numel(), num_nodes, num_graphs), dev)
     N.check(L.tgp_postprocess_sparse_norm_f32(N.ptr(row), N.ptr(col), N.ptr(edge_weight), row.numel(), num_nodes,
                                               flags, ops_eps(), N.ptr(bp), num_graphs, N.ptr(ws), ws.numel(),
@@ -704,6 +753,15 @@ def dense_pool_small_bwd(s: Tensor, adj: Tensor, x: Optional[Tensor], flags: int
 def postprocess_dense(adj_pool: Tensor, flags: int, inplace: bool = False) -> Tensor:
     """utils/ops.py:282-335 on a [B,K,K] tensor."""
     dev = N.require_device(adj_pool)
+    if adj_pool.dtype == torch.float64:  # a float64 pooled adjacency is post-processed in fp64 (utils/ops.py:282-335)
+        src = N.f64c(adj_pool)
+        dst = src if inplace else torch.empty_like(src)
+        B, K = src.size(0), src.size(1)
+        L = N.lib()
+        ws = N.workspace(L.tgp_postprocess_dense_workspace_bytes_f64(B, K), dev)
+        N.check(L.tgp_postprocess_dense_f64(N.ptr(src), N.ptr(dst), B, K, flags, ops_eps(), N.ptr(ws), ws.numel(),
+                                            N.stream_ptr(dev)), "tgp_postprocess_dense_f64")
+        return dst
     src = N.f32c(adj_pool)
     dst = src if inplace else torch.empty_like(src)
     B, K = src.size(0), src.size(1)
@@ -1383,7 +1441,8 @@ def block_diag_edges(adj_pool: Tensor, relabel: Optional[Tensor] = None,
     """dense_to_block_diag (utils/ops.py:53-82) with the optional valid-supernode renumbering of
     DenseSRCPooling._finalize_sparse_output (src.py:526-552)."""
     dev = N.require_device(adj_pool, relabel)
-    a = N.f32c(adj_pool if adj_pool.dim() == 3 else adj_pool.unsqueeze(0))
+    f64 = adj_pool.dtype == torch.float64
+    a = (N.f64c if f64 else N.f32c)(adj_pool if adj_pool.dim() == 3 else adj_pool.unsqueeze(0))
     B, K = a.size(0), a.size(1)
     rl = None if relabel is None else N.i64c(relabel)
     flags = N.REMOVE_SELF_LOOPS if remove_self_loops else 0
@@ -1392,12 +1451,14 @@ def block_diag_edges(adj_pool: Tensor, relabel: Optional[Tensor] = None,
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
     st = N.stream_ptr(dev)
     eps = ops_eps()
-    N.check(L.tgp_block_diag_count(N.ptr(a), B, K, N.ptr(rl), flags, eps, N.ptr(ws), ws.numel(), N.ptr(d_count), st),
+    count, fill = ((L.tgp_block_diag_count_f64, L.tgp_block_diag_fill_f64) if f64 else
+                   (L.tgp_block_diag_count, L.tgp_block_diag_fill))
+    N.check(count(N.ptr(a), B, K, N.ptr(rl), flags, eps, N.ptr(ws), ws.numel(), N.ptr(d_count), st),
             "tgp_block_diag_count")
     n_out = _read_count(d_count)
     ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
-    ew = torch.empty(n_out, dtype=torch.float32, device=dev)
-    N.check(L.tgp_block_diag_fill(N.ptr(a), B, K, N.ptr(rl), flags, eps, N.ptr(ws), n_out,
+    ew = torch.empty(n_out, dtype=a.dtype, device=dev)
+    N.check(fill(N.ptr(a), B, K, N.ptr(rl), flags, eps, N.ptr(ws), n_out,
                                   N.ptr(ei[0]) if n_out else None, N.ptr(ei[1]) if n_out else None,
                                   N.ptr(ew) if n_out else None, st), "tgp_block_diag_fill")
     return ei, ew

@@ -48,7 +48,16 @@ class BaseReduce(Reduce):
 
     def forward(self, x: Tensor, so: SelectOutput, *, batch: Optional[Tensor] = None,
                 return_batched: bool = False, **kwargs) -> Tuple[Tensor, Optional[Tensor]]:
-        # fp32 arithmetic; the result carries the dtype of x like the reference's ATen ops would
+        if so.s.is_sparse and (x.dtype == torch.float64 or so.s.dtype == torch.float64) and x.is_cuda:
+            # float64 features / assignment weights: the sparse Reduce runs in fp64 like the reference's scatter
+            # (base_reduce.py:146-153; r4) -- the result has the promoted dtype, no fp32 narrowing, no warning
+            if return_batched:
+                raise ValueError("return_batched=True is only supported for dense assignment matrices.")
+            if batch is None and so.batch is not None:
+                batch = so.batch
+            return _SparseReduceFn.apply(x, so.weight, so), self.reduce_batch(so, batch)
+        # fp32 arithmetic (the GEMM paths; sparse fp32 / half inputs); the result carries the dtype of x like the
+        # reference's ATen ops would
         x_pool, batch_pool = self._forward_f32(as_compute_dtype(x), so, batch=batch, return_batched=return_batched)
         return like_input_dtype(x_pool, x), batch_pool
 
@@ -99,7 +108,7 @@ class _SparseReduceFn(torch.autograd.Function):
             from ..lift import lift_index_of
             gx = K.reduce_sparse(grad_out, so.cluster_index, weight, lift_index_of(so))
         if ctx.needs_input_grad[1]:
-            if x.dim() == 2 and x.is_cuda:
+            if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and grad_out.dtype == torch.float32:
                 gw = K.pair_dot(x, so.node_index, grad_out, so.cluster_index)
             else:
                 gw = (x[so.node_index] * grad_out[so.cluster_index]).reshape(so.node_index.numel(), -1).sum(-1)

@@ -418,7 +418,7 @@ def postprocess_adj_pool_sparse(edge_index: Tensor, edge_weight: Optional[Tensor
 
 def _normalize_pooled_edges(edge_index, edge_weight, num_nodes, degree_norm, edge_weight_norm, batch_pooled):
     if degree_norm and edge_weight is None:
-        edge_weight = torch.ones(edge_index.size(1), device=edge_index.device)
+        edge_weight = torch.ones(edge_index.size(1), device=edge_index.device)  # (default dtype, as ops.py:385)
     do_ewn = edge_weight_norm and edge_weight is not None
     if (degree_norm or do_ewn) and edge_index.size(1) > 0 and edge_weight.requires_grad and torch.is_grad_enabled():
         # training through the pooled weights: differentiable torch form of the same arithmetic
@@ -435,8 +435,10 @@ def _normalize_pooled_edges(edge_index, edge_weight, num_nodes, degree_norm, edg
             w = w / mx[eb]
         return edge_index, w
     if (degree_norm or do_ewn) and edge_index.size(1) > 0:
-        if not edge_weight.is_contiguous() or edge_weight.dtype != torch.float32:
-            edge_weight = edge_weight.to(torch.float32).contiguous()
+        if edge_weight.dtype not in (torch.float32, torch.float64):
+            edge_weight = edge_weight.to(torch.float32)
+        if not edge_weight.is_contiguous():
+            edge_weight = edge_weight.contiguous()
         ng = 0
         if do_ewn:
             ng = int(batch_pooled.max()) + 1 if batch_pooled.numel() else 0
