@@ -199,9 +199,11 @@ def test_float64_inputs_are_announced_as_fp32_arithmetic(dev):
     from tgp.reduce import BaseReduce
     from tgp.select import SelectOutput
     from tgp.utils import ops as ops_module
+    # (r4: the sparse Reduce / Connect have fp64 kernels and do NOT warn -- tests/test_gpu_round4.py; the dense GEMM
+    #  path still computes in fp32 and says so)
     ops_module._WARNED_F64 = False
-    so = SelectOutput(cluster_index=torch.tensor([0, 0, 1, 1], device=dev))
-    x = torch.randn(4, 3, dtype=torch.float64, device=dev)
+    so = SelectOutput(s=torch.softmax(torch.randn(1, 4, 2, device=dev), -1))
+    x = torch.randn(1, 4, 3, dtype=torch.float64, device=dev)
     with pytest.warns(UserWarning, match="float64 inputs are computed in float32"):
         out, _ = BaseReduce()(x, so)
     assert out.dtype == torch.float64

@@ -389,6 +389,9 @@ class DenseSRCPooling(SRCPooling):
             raise ValueError("Assignment and adjacency batch sizes do not match: "
                              f"got s.size(0)={s.size(0)} and adj.size(0)={adj.size(0)}.")
         flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
+        if torch.float64 in (s.dtype, adj.dtype, x.dtype):
+            from .utils.ops import _warn_float64_once
+            _warn_float64_once()  # the GEMM path below is fp32 arithmetic: said once per process
         if torch.is_grad_enabled() and (s.requires_grad or adj.requires_grad or x.requires_grad):
             # training: batches of small graphs keep the fused kernel and get its one-launch backward (the adjacency
             # gets no gradient there, edge_weight_norm is not differentiated there: those keep the operator path)
