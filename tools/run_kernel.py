@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Launch one hot kernel repeatedly (for rocprofv3 --pmc / --kernel-trace runs).
-usage: python tools/run_kernel.py {gemm_c2|gemm_c5|reduce_topk|coalesce_c4|coalesce_c4_sorted|subgraph_topk|c3} [reps]"""
+usage: python tools/run_kernel.py {gemm_c2|gemm_c5|reduce_topk|reduce_ndp|reduce_graclus|coalesce_c4|coalesce_c4_sorted|
+                                   subgraph_topk|c3|topk_batch|graclus_batch} [reps]"""
 import os
 import sys
 
@@ -40,6 +41,31 @@ elif which == "reduce_topk":
     marker()
     for _ in range(reps):
         kernels.reduce_sparse(x, so.node_index, so.weight, idx)
+elif which in ("reduce_ndp", "reduce_graclus"):
+    n, f = 1_000_000, 128
+    x = torch.randn(n, f, device=dev, generator=g)
+    if which == "reduce_ndp":
+        keep = (torch.rand(n, device=dev, generator=g) < 0.5).nonzero().view(-1)
+        so = SelectOutput(node_index=keep, num_nodes=n, cluster_index=torch.arange(keep.numel(), device=dev),
+                          num_supernodes=keep.numel())
+        so._set_one_to_one_index()
+    else:
+        pair = torch.randperm(n, device=dev, generator=g)
+        cluster = torch.empty(n, dtype=torch.long, device=dev)
+        cluster[pair] = torch.arange(n, device=dev) // 2
+        so = SelectOutput(cluster_index=cluster, num_nodes=n, num_supernodes=n // 2)
+    idx = so.assign_index()
+    marker()
+    for _ in range(reps):
+        kernels.reduce_sparse(x, so.node_index, so.weight, idx)
+elif which in ("topk_batch", "graclus_batch"):  # bench.py's batched sparse workloads: the one-launch kernel
+    sys.path.insert(0, ROOT)
+    import bench
+    wl = bench.TopkBatch(bench.Ctx(dev, 0, 1, None), which=which)
+    wl.compute()
+    marker()
+    for _ in range(reps):
+        wl.compute()
 elif which == "coalesce_c4":
     n = 1_000_000
     a = torch.randint(0, n, (5_000_000,), device=dev, generator=g)

@@ -28,30 +28,45 @@ __device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
   return v;
 }
-// Exclusive prefix of `tile` over the tiles' survivor counts (bits 0..30 of the published values) and whether any of
-// them refused (bit 31); every lane of ONE wave calls it.  A spin bound turns a tile that never shows up into a refusal.
-__device__ __forceinline__ void sps_lookback(unsigned long long* status, int tile, unsigned long long tag,
-                                             uint32_t* excl_out, bool* refused) {
-  // 256 predecessors per round (four words per lane, all requested at once): the words live behind the fabric (agent
-  // scope across XCDs), a round trip costs ~1 us, and everybody publishes at about the same time -- r4 stamps: 64 per
-  // round made the last of 256 tiles wait four dependent rounds
+// The look-back in two halves, so that the words' round trip (~1 us: they live behind the fabric) overlaps work that does
+// not depend on them: `issue` requests the 256 nearest predecessor words, `finish` consumes them (re-reading only those
+// that were not published yet) and walks further back if none of them held a prefix.
+struct SpsLook {
+  unsigned long long st[4];
+  int idx[4];
+};
+
+__device__ __forceinline__ void sps_lookback_issue(const unsigned long long* status, int tile, unsigned long long tag,
+                                                   SpsLook& lk) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    lk.idx[k] = tile - 1 - lane - 64 * k;
+    lk.st[k] = lk.idx[k] >= 0 ? sps_load(status + 2 + lk.idx[k]) : (tag | SPS_PRE);
+  }
+}
+
+__device__ __forceinline__ void sps_lookback_finish(unsigned long long* status, int tile, unsigned long long tag,
+                                                    SpsLook& lk, uint32_t* excl_out, bool* refused) {
   const int lane = lane_id();
   uint32_t excl = 0;
   bool bad = false;
   int j = tile - 1;
+  bool first_window = true;
   while (j >= 0) {
-    unsigned long long st[4];
-    int idx[4];
+    if (!first_window) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      idx[k] = j - lane - 64 * k;
-      st[k] = idx[k] >= 0 ? sps_load(status + 2 + idx[k]) : (tag | SPS_PRE);
+      for (int k = 0; k < 4; ++k) {
+        lk.idx[k] = j - lane - 64 * k;
+        lk.st[k] = lk.idx[k] >= 0 ? sps_load(status + 2 + lk.idx[k]) : (tag | SPS_PRE);
+      }
     }
+    first_window = false;
     int spins = 0;
     for (;;) {
       bool wait = false;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) wait = wait || !sps_current(st[k], tag) || ((st[k] >> 32) & 3ull) == 0;
+      for (int k = 0; k < 4; ++k) wait = wait || !sps_current(lk.st[k], tag) || ((lk.st[k] >> 32) & 3ull) == 0;
       if (!__any(wait)) break;
       if (++spins > (1 << 20)) {  // every spin is bounded
         *excl_out = 0;
@@ -61,16 +76,17 @@ __device__ __forceinline__ void sps_lookback(unsigned long long* status, int til
       if (spins > 4) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (idx[k] >= 0 && (!sps_current(st[k], tag) || ((st[k] >> 32) & 3ull) == 0)) st[k] = sps_load(status + 2 + idx[k]);
+        if (lk.idx[k] >= 0 && (!sps_current(lk.st[k], tag) || ((lk.st[k] >> 32) & 3ull) == 0))
+          lk.st[k] = sps_load(status + 2 + lk.idx[k]);
     }
     bool done = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (!done) {  // (uniform: `done` comes from ballots)
-        const unsigned long long pre = __ballot(((st[k] >> 32) & 3ull) == 2);
+        const unsigned long long pre = __ballot(((lk.st[k] >> 32) & 3ull) == 2);
         const int first = pre ? __builtin_ctzll(pre) : 64;  // nearest predecessor that already knows its prefix
-        excl += wave_sum32(lane <= first ? static_cast<uint32_t>(st[k]) & 0x7FFFFFFFu : 0u);
-        bad = bad || __any(lane <= first && ((st[k] >> 31) & 1ull));
+        excl += wave_sum32(lane <= first ? static_cast<uint32_t>(lk.st[k]) & 0x7FFFFFFFu : 0u);
+        bad = bad || __any(lane <= first && ((lk.st[k] >> 31) & 1ull));
         done = pre != 0ull;
       }
     }
@@ -79,6 +95,17 @@ __device__ __forceinline__ void sps_lookback(unsigned long long* status, int til
   }
   *excl_out = excl;
   *refused = bad;
+}
+
+// Exclusive prefix of `tile` over the tiles' survivor counts (bits 0..30 of the published values) and whether any of
+// them refused (bit 31); every lane of ONE wave calls it.  A spin bound turns a tile that never shows up into a refusal.
+// (256 predecessors per round, four words per lane, all requested at once: everybody publishes at about the same time --
+// r4 stamps: 64 per round made the last of 256 tiles wait four dependent rounds.)
+__device__ __forceinline__ void sps_lookback(unsigned long long* status, int tile, unsigned long long tag,
+                                             uint32_t* excl_out, bool* refused) {
+  SpsLook lk;
+  sps_lookback_issue(status, tile, tag, lk);
+  sps_lookback_finish(status, tile, tag, lk, excl_out, refused);
 }
 
 }  // namespace tgp

@@ -360,6 +360,10 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred
         SgEdges tn;
         uint32_t rank_n = 0, tot_n = 0;
         bool ref_n = false;
+        // the words of `chunk`'s predecessors (published one chunk ago, like its own) are requested now and consumed
+        // behind the evaluation of the next chunk: their ~1 us round trip is not on the critical path
+        SpsLook look;
+        if (wave_id() == 0 && chunk > 0) sps_lookback_issue(sg.status, chunk, sg.tag, look);
         if (has_next) {
           tn = nxt;
           if (chunk + 2 * G < nchunks)
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred
           bool refused = ref_c;
           if (chunk > 0) {
             bool before = false;
-            sps_lookback(sg.status, chunk, sg.tag, &excl, &before);
+            sps_lookback_finish(sg.status, chunk, sg.tag, look, &excl, &before);
             refused = refused || before;
             if (lane == 0)
               sps_store(sg.status + 2 + chunk, sg.tag | SPS_PRE | (refused ? 0x80000000ull : 0ull) |

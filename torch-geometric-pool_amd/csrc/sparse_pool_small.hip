@@ -488,6 +488,8 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
       sps_store(p.status + 2 + blockIdx.x, p.tag | (blockIdx.x == 0 ? SPS_PRE : SPS_AGG) |
                                                (tile_refused ? 0x80000000ull : 0ull) | tile_tot);
   }
+  SpsLook look;  // the predecessors' words are requested now and consumed behind the Reduce part
+  if (wv == 0 && blockIdx.x > 0) sps_lookback_issue(p.status, blockIdx.x, p.tag, look);
   // ------------------------------------------------------------------- A1 + A2, while the look-back words travel
   if (!bad) {
     if constexpr (MODE == 0) {
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
     bool refused = tile_refused;
     if (tile > 0) {
       bool before = false;
-      sps_lookback(p.status, tile, p.tag, &excl, &before);
+      sps_lookback_finish(p.status, tile, p.tag, look, &excl, &before);
       refused = refused || before;
       if (lane == 0)
         sps_store(p.status + 2 + tile, p.tag | SPS_PRE | (refused ? 0x80000000ull : 0ull) |
