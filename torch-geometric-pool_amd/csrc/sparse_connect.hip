@@ -4,6 +4,8 @@
 // contract (SURVEY.md 7 "ordering contracts"): PyG `subgraph` keeps input edge order, PyG
 // `coalesce` returns row-major sorted unique edges, `nonzero` returns (b,row,col) order — so all
 // compactions are scan-based (ballot ranks + block offsets), never atomic-append.
+#include <stdlib.h>
+
 #include "lookback.h"
 
 namespace tgp {
@@ -375,6 +377,11 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred
           const int lane = lane_id();
           uint32_t excl = 0;
           bool refused = ref_c;
+#ifdef TGP_GEMM_STAMPS  // diagnostic build: TGP_SG_ABLATE=1 skips the wait (wrong offsets, timing only)
+          if (chunk > 0 && (pred.flags & (1 << 30))) {
+            excl = static_cast<uint32_t>(chunk) * 1024u;
+          } else
+#endif
           if (chunk > 0) {
             bool before = false;
             sps_lookback_finish(sg.status, chunk, sg.tag, look, &excl, &before);
@@ -1058,6 +1065,9 @@ static int subgraph_single_impl(const int64_t* row, const int64_t* col, const WT
                          s.member_bits, s.unsorted);
   }
   const int nb = cdiv(E, SG_CHUNK);
+#ifdef TGP_GEMM_STAMPS
+  if (getenv("TGP_SG_ABLATE")) flags |= (1 << 30);
+#endif
   SubgraphPredT<WT> pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.unsorted, flags, eps,
                          N, s.unsorted + 1};
   SgSingleT<WT> sg{out_row, out_col, w ? out_w : nullptr, out_edge_id, reinterpret_cast<unsigned long long*>(status),
