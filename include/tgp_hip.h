@@ -320,6 +320,11 @@ int tgp_dense_pool_small_bwd_f32(const float* S, const float* A, const float* X,
 int tgp_bmm_f32(const float* A, const float* Bm, float* C, int64_t batch, int64_t M, int64_t Nc, int64_t Kd,
                 int trans_a, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
                 void* stream);
+/* C += op(A) Bm, same arguments (r4): a second product accumulates in the GEMM epilogue into the buffer the first one
+ * wrote (two-term gradients of the dense Connect under autograd) */
+int tgp_bmm_accumulate_f32(const float* A, const float* Bm, float* C, int64_t batch, int64_t M, int64_t Nc, int64_t Kd,
+                int trans_a, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
+                void* stream);
 
 /* A3' / A7'  un-padded batch (reduce/base_reduce.py:170-182, connect/dense_conn.py:195-206):
  * C[b] = S_b^T Y_b where graph b owns node rows ptr[b]..ptr[b+1] of S [Ntot,K] and Y [Ntot,F].

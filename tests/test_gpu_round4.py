@@ -431,3 +431,17 @@ def test_float64_dense_gemm_path_still_announces_fp32(dev):
         with torch.no_grad():
             out = pooler(x=x.double(), adj=ei, batch=batch)
     assert out.x.dtype == torch.float64
+
+
+def test_bmm_accumulate_in_the_epilogue(dev):
+    """C += op(A) B in the GEMM epilogue (tgp_bmm_accumulate_f32): the bits of the separate product + add, for both
+    operand layouts, ragged shapes and the big-tile path; DenseConnect's two-term dS uses it."""
+    from tgp import kernels as K
+    g = torch.Generator(device=dev).manual_seed(0)
+    for (G, M, Kd, Nc, ta) in ((3, 70, 33, 20, False), (2, 1024, 1024, 128, False), (4, 100, 257, 65, True)):
+        a = torch.randn((G, Kd, M) if ta else (G, M, Kd), device=dev, generator=g)
+        b = torch.randn(G, Kd, Nc, device=dev, generator=g)
+        c0 = torch.randn(G, M, Nc, device=dev, generator=g)
+        want = c0 + K.bmm(a, b, trans_a=ta)
+        got = K.bmm(a, b, trans_a=ta, accumulate_into=c0.clone())
+        assert torch.equal(got, want)

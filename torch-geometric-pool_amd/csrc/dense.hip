@@ -459,9 +459,27 @@ extern "C" int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B
 
 
 // Generic batched fp32 GEMM on the matrix cores (used by Lift and by the unbatched dense paths).
+static int bmm_impl(const float* A, const float* Bm, float* C, int64_t batch, int64_t M, int64_t Nc, int64_t Kd,
+                    int trans_a, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
+                    int accumulate, void* stream_);
+
 extern "C" int tgp_bmm_f32(const float* A, const float* Bm, float* C, int64_t batch, int64_t M, int64_t Nc,
                            int64_t Kd, int trans_a, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA,
                            int64_t sB, int64_t sC, void* stream_) {
+  return bmm_impl(A, Bm, C, batch, M, Nc, Kd, trans_a, lda, ldb, ldc, sA, sB, sC, 0, stream_);
+}
+
+// C += op(A) Bm: the second term of a two-term gradient (dS = U dR^T + V dR, connect/dense_conn.py:111-122 under
+// autograd) accumulates in the GEMM epilogue into the buffer the first term wrote, instead of a separate elementwise add
+extern "C" int tgp_bmm_accumulate_f32(const float* A, const float* Bm, float* C, int64_t batch, int64_t M, int64_t Nc,
+                                      int64_t Kd, int trans_a, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA,
+                                      int64_t sB, int64_t sC, void* stream_) {
+  return bmm_impl(A, Bm, C, batch, M, Nc, Kd, trans_a, lda, ldb, ldc, sA, sB, sC, 1, stream_);
+}
+
+static int bmm_impl(const float* A, const float* Bm, float* C, int64_t batch, int64_t M, int64_t Nc, int64_t Kd,
+                    int trans_a, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC,
+                    int accumulate, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(batch >= 0 && M >= 0 && Nc >= 0 && Kd >= 0, TGP_ERR_INVALID, "tgp_bmm_f32: negative size");
   if (batch == 0 || M == 0 || Nc == 0) return TGP_OK;
@@ -472,11 +490,12 @@ extern "C" int tgp_bmm_f32(const float* A, const float* Bm, float* C, int64_t ba
   g.M = static_cast<int>(M); g.Kd = static_cast<int>(Kd);
   g.rhs[0] = GemmRhs{Bm, C, static_cast<int>(Nc), ldb, ldc, sB, sC, 0};
   g.splits = 1; g.k_per_split = static_cast<int>((Kd + BK - 1) / BK * BK);
+  g.accumulate = accumulate;
   TGP_REQUIRE(batch * ((M + 63) / 64) * ((Nc + 63) / 64) < (1ll << 31), TGP_ERR_RANGE, "tgp_bmm_f32: grid too large");
   // many small matrices: one wave per 32-row strip, operands straight from memory (see small_bmm_kernel)
   static const int no_small_bmm = getenv("TGP_NO_SMALL_BMM") ? 1 : 0;
   const int64_t strips = (M + 31) / 32;
-  if (!no_small_bmm && Nc <= 64 && M <= 512 && Kd <= 512 && batch * strips >= 512) {
+  if (!no_small_bmm && !accumulate && Nc <= 64 && M <= 512 && Kd <= 512 && batch * strips >= 512) {
     SmallBmmArgs q{A, Bm, C, static_cast<int>(M), static_cast<int>(Nc), static_cast<int>(Kd), trans_a ? 1 : 0,
                    lda, ldb, ldc, sA, sB, sC, static_cast<int>(strips)};
     const long total = batch * strips;

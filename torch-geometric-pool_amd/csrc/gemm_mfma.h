@@ -63,6 +63,8 @@ struct GemmArgs {
   // MODE 1 only, optional [batches]: rows / columns >= sizes[batch] of resid and op(A) Bm^T are zero (padded batch),
   // so tiles that lie entirely beyond them contribute nothing and are skipped
   const int64_t* sizes;
+  // MODE 0, splits == 1: C += op(A) Bm (the second term of a two-term gradient lands in the first term's buffer: r4)
+  int accumulate;
 };
 
 // Row of a [rows][BK+1] LDS tile served by slot t = 8*g + r (8 lanes per slot, slot = one 128-byte row segment).
@@ -462,7 +464,10 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (row < M && col < Nc) C[static_cast<long>(row) * R.ldc + col] = acc[j][r];
+      if (row < M && col < Nc) {
+        float* dst = C + static_cast<long>(row) * R.ldc + col;
+        *dst = g.accumulate ? __fadd_rn(*dst, acc[j][r]) : acc[j][r];
+      }
     }
   }
   TGP_STAMP(3);

@@ -93,6 +93,8 @@ SIGNATURES = {
     "tgp_postprocess_dense_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_sz, _c_p]),
     "tgp_bmm_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_i64,
                              _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+    "tgp_bmm_accumulate_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_i64,
+                                        _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "tgp_segment_gemm_tn_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64]),
     "tgp_segment_gemm_tn_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
                                          _c_p, _c_sz, _c_p]),

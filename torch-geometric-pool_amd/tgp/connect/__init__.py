@@ -148,7 +148,8 @@ class _DenseConnectFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             u = ctx.products.get_u(s, adj)   # A S
             v = ctx.products.get_v(s, adj)   # A^T S
-            gs = K.bmm(u, g.transpose(-1, -2).contiguous()) + K.bmm(v, g)
+            gs = K.bmm(u, g.transpose(-1, -2).contiguous())
+            gs = K.bmm(v, g, accumulate_into=gs)  # second term in the GEMM epilogue (no elementwise add launch)
         if ctx.needs_input_grad[1]:
             ga = K.bmm(K.bmm(s, g), s.transpose(-1, -2).contiguous())
         return gs, ga, None

@@ -1182,9 +1182,10 @@ def edge_dot(s: Tensor, edge_index: Tensor) -> Tensor:
     return out
 
 
-def bmm(a: Tensor, b: Tensor, trans_a: bool = False) -> Tensor:
+def bmm(a: Tensor, b: Tensor, trans_a: bool = False, accumulate_into: Optional[Tensor] = None) -> Tensor:
     """C[g] = op(A[g]) @ B[g] on the fp32 matrix cores.  a: [G,M,Kd] (or [G,Kd,M] when trans_a),
-    b: [G,Kd,Nc]; 2-D operands are treated as G = 1."""
+    b: [G,Kd,Nc]; 2-D operands are treated as G = 1.  ``accumulate_into`` (contiguous fp32 [G,M,Nc]): C += product in
+    the GEMM epilogue, returned as that tensor."""
     dev = N.require_device(a, b)
     a3 = N.f32c(a if a.dim() == 3 else a.unsqueeze(0))
     b3 = N.f32c(b if b.dim() == 3 else b.unsqueeze(0))
@@ -1196,9 +1197,17 @@ def bmm(a: Tensor, b: Tensor, trans_a: bool = False) -> Tensor:
     if b3.size(1) != Kd:
         raise ValueError(f"bmm inner dimensions differ: {tuple(a.shape)} x {tuple(b.shape)}")
     Nc = b3.size(2)
-    out = torch.empty(G, M, Nc, dtype=torch.float32, device=dev)
     sA = 0 if a3.size(0) == 1 else a3.stride(0)
     sB = 0 if b3.size(0) == 1 else b3.stride(0)
+    if accumulate_into is not None:
+        out = accumulate_into
+        if (out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != G * M * Nc or out.device != dev):
+            raise ValueError("bmm: accumulate_into must be a contiguous float32 tensor of the product's shape")
+        N.check(N.lib().tgp_bmm_accumulate_f32(N.ptr(a3), N.ptr(b3), N.ptr(out), G, M, Nc, Kd, 1 if trans_a else 0,
+                                               a3.stride(1), b3.stride(1), Nc, sA, sB, M * Nc, N.stream_ptr(dev)),
+                "tgp_bmm_accumulate_f32")
+        return out
+    out = torch.empty(G, M, Nc, dtype=torch.float32, device=dev)
     N.check(N.lib().tgp_bmm_f32(N.ptr(a3), N.ptr(b3), N.ptr(out), G, M, Nc, Kd, 1 if trans_a else 0, a3.stride(1),
                                 b3.stride(1), Nc, sA, sB, M * Nc, N.stream_ptr(dev)), "tgp_bmm_f32")
     return out if (a.dim() == 3 or b.dim() == 3) else out[0]
