@@ -445,3 +445,31 @@ def test_bmm_accumulate_in_the_epilogue(dev):
         want = c0 + K.bmm(a, b, trans_a=ta)
         got = K.bmm(a, b, trans_a=ta, accumulate_into=c0.clone())
         assert torch.equal(got, want)
+
+
+def test_graclus_optimistic_route_with_unsorted_rows(dev):
+    """A batch of small graphs whose edge list nobody has looked at yet takes the one-launch matching optimistically
+    (the row-order check rides on the offsets kernel).  With UNSORTED rows the offsets are no CSR: the per-graph kernel
+    must refuse before reading through them (status 4) and the call must still return a valid maximal matching."""
+    from tgp import kernels as K
+    x, ei, ew, batch, sizes = _small_batch(200, 10, 60, 4, 33, dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    perm = torch.randperm(ei.size(1), device=dev, generator=g)
+    ei_u, ew_u = ei[:, perm].contiguous(), ew[perm].abs() + 0.1  # a fresh tensor object: no row-order memo yet
+    n = x.size(0)
+    ptr = torch.zeros(sizes.numel() + 1, dtype=torch.long)
+    ptr[1:] = torch.cumsum(sizes, 0)
+    assert K._rows_sorted_memo(ei_u) is None
+    label = K.graclus_match(ei_u, ew_u, n, graph_ptr=ptr.to(dev), max_graph_nodes=int(sizes.max()))
+    assert K._rows_sorted_memo(ei_u) is False  # found out on the way, remembered
+    lab = label.cpu()
+    cnt = torch.bincount(lab, minlength=n)
+    assert int(cnt.max()) <= 2 and bool((lab <= torch.arange(n)).all())
+    r, c = ei_u.cpu()
+    paired = cnt[lab] == 2
+    partner_ok = torch.zeros(n, dtype=torch.bool)
+    same = lab[r] == lab[c]
+    partner_ok[r[same & (r != c)]] = True
+    assert bool((partner_ok | ~paired).all())            # every pair is an edge
+    free = ~paired
+    assert not bool((free[r] & free[c] & (r != c)).any())  # maximal: no edge between two single nodes

@@ -434,6 +434,18 @@ __global__ __launch_bounds__(T) void gm_graph_rounds_kernel(const int32_t* __res
   const int32_t e0 = row_ptr[p0], e1 = row_ptr[p1];
   const bool in_lds = e1 - e0 <= cap_e;
   bool out = false;  // entries must stay inside the graph (the rounds read the neighbours' flags without a range test)
+  // ... and the graph's offsets must BE a CSR slice: ascending, inside [e0, e1].  On the optimistic route (a list nobody
+  // has checked for row order yet) an unsorted list leaves in-range but non-monotonic offsets behind; the rounds would
+  // then index their LDS views outside the graph's slice.  Refused here, before anything is read through them.
+  bool broken = e1 < e0;
+  for (int t = threadIdx.x; t < n; t += T) {
+    const int32_t a = row_ptr[p0 + t], b = row_ptr[p0 + t + 1];
+    broken = broken || a > b || a < e0 || b > e1;
+  }
+  if (__syncthreads_or(broken ? 1 : 0)) {
+    if (threadIdx.x == 0) atomicOr(status, 4);
+    return;
+  }
   for (int32_t e = e0 + threadIdx.x; e < e1; e += T) {
     const int32_t j = nbr[e];
     out = out || (j >= 0 && (j < p0 || j >= p1));  // (-1: an entry the symmetrisation dropped)

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void topk_segsort_wave_fill_kernel(
   const int lane = lane_id();
   const int64_t lo = ptr[g];
   const int n = static_cast<int>(ptr[g + 1] - lo);
+  if (n > 64) return;  // beyond the promised segments_max_nodes <= 64: left out (see topk_segsort_block_kernel)
   const float sc = lane < n ? score[lo + lane] : 0.f;
   unsigned long long v = ~0ull;  // sentinel: sorts last
   if (lane < n) v = (static_cast<unsigned long long>(descending_key(sc)) << 32) | static_cast<unsigned>(lane);
@@ -162,11 +163,14 @@ __global__ __launch_bounds__(T) void topk_segsort_block_kernel(const float* __re
                                                                int32_t* __restrict__ assign_perm,
                                                                float* __restrict__ values,
                                                                int32_t* __restrict__ lift_ptr,
-                                                               uint2* __restrict__ assign_pack) {
+                                                               uint2* __restrict__ assign_pack, int cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_v[];
   const int64_t g = blockIdx.x;
   const int64_t lo = ptr[g];
   const int n = static_cast<int>(ptr[g + 1] - lo);
+  if (n > cap) return;  // a graph beyond the promised segments_max_nodes: the LDS tile is sized for `cap` keys -- left
+                        // out rather than written past it (the caller broke its promise; the host mirror passes the
+                        // exact maximum from the batch facts)
   if constexpr (FILL) {
     if (lift_ptr && g == B - 1 && threadIdx.x == 0) lift_ptr[N] = static_cast<int32_t>(koff[B]);
   }
@@ -654,15 +658,19 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
     if (segments_max_nodes <= kSegSortMax) {
       hipLaunchKernelGGL((topk_segsort_block_kernel<256, true>), dim3(static_cast<unsigned>(B)), dim3(256), lds, stream,
                          score, ptr, k, koff, s.rank_of, B, N, node_index, cluster_index, assign_perm, values,
-                         lift_row_ptr, assign_pack);
-    } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_segsort_block_kernel<1024, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+                         lift_row_ptr, assign_pack, m);
+      return check_launch("tgp_topk_select");
+    }
+    // 96 KB of dynamic LDS at 8192 nodes: above the default limit -- if the device does not grant it, the rank-table
+    // route below takes the call (its sort tile is 64 KB)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(topk_segsort_block_kernel<1024, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) == hipSuccess) {
       hipLaunchKernelGGL((topk_segsort_block_kernel<1024, true>), dim3(static_cast<unsigned>(B)), dim3(1024), lds, stream,
                          score, ptr, k, koff, s.rank_of, B, N, node_index, cluster_index, assign_perm, values,
-                         lift_row_ptr, assign_pack);
+                         lift_row_ptr, assign_pack, m);
+      return check_launch("tgp_topk_select");
     }
-    return check_launch("tgp_topk_select");
+    (void)hipGetLastError();
   }
   (void)hipMemsetAsync(s.rank_of, 0xFF, static_cast<size_t>(N) * sizeof(int32_t), stream);
   if (segments_max_nodes > 0 && segments_max_nodes <= 64) {
@@ -671,16 +679,17 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
   } else if (segments_max_nodes > 0 && segments_max_nodes <= kSegSortMax) {
     hipLaunchKernelGGL((topk_segsort_block_kernel<256, false>), dim3(static_cast<unsigned>(B)), dim3(256),
                        kSegSortMax * sizeof(unsigned long long), stream, score, ptr, k, koff, s.rank_of, B, N,
-                       node_index, cluster_index, assign_perm, values, lift_row_ptr, assign_pack);
+                       node_index, cluster_index, assign_perm, values, lift_row_ptr, assign_pack, kSegSortMax);
   } else if (segments_max_nodes > 0 && segments_max_nodes <= kSegSortLarge) {
     int m = 64;
     while (m < segments_max_nodes) m <<= 1;
     const size_t lds = static_cast<size_t>(m) * sizeof(unsigned long long);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_segsort_block_kernel<1024, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    TGP_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_segsort_block_kernel<1024, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) == hipSuccess,
+                TGP_ERR_LAUNCH, "tgp_topk_select: the device does not grant %zu bytes of dynamic LDS", lds);
     hipLaunchKernelGGL((topk_segsort_block_kernel<1024, false>), dim3(static_cast<unsigned>(B)), dim3(1024), lds, stream,
                        score, ptr, k, koff, s.rank_of, B, N, node_index, cluster_index, assign_perm, values,
-                       lift_row_ptr, assign_pack);
+                       lift_row_ptr, assign_pack, m);
   } else {
     hipLaunchKernelGGL(topk_keys_kernel, dim3(nb256), dim3(256), 0, stream, score, batch, N, s.k0, s.v0);
     bool first = true;

@@ -765,6 +765,20 @@ class GraclusSelect(Select):
 
 
 # =============================================================================== NDP
+import os as _os
+
+_NDP_SIDE_STREAM = _os.environ.get("TGP_NDP_SIDE_STREAM", "1") != "0"  # read once
+_NDP_SIDE_STREAMS: dict = {}
+
+
+def _ndp_side_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _NDP_SIDE_STREAMS.get(key)
+    if st is None:
+        st = _NDP_SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class NDPSelect(Select):
     r"""Node Decimation Pooling selection: keep the positive side of the sign partition of the largest
     eigenvector of the symmetric normalised Laplacian of every graph; random +-1 partition when the cut
@@ -910,13 +924,12 @@ class NDPSelect(Select):
                                        remove_self_loops=False, eps_filter=False)
             K.rowptr_from_sorted(ei2[0], n, indptr)
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-        import os
         side = None
-        if oversize and len(sizes_host) > len(oversize) and os.environ.get("TGP_NDP_SIDE_STREAM", "1") != "0":
+        if oversize and len(sizes_host) > len(oversize) and _NDP_SIDE_STREAM:
             # the one-workgroup-per-graph kernel of the smaller graphs runs on a second stream, next to the chip-wide
             # steps of the large ones: they share nothing but read-only inputs (one long launch beside ~700 short ones:
             # the reference harness batch 11.6 -> 10.4 ms; TGP_NDP_SIDE_STREAM=0 keeps everything on one stream)
-            side = torch.cuda.Stream(device=dev)
+            side = _ndp_side_stream(dev)  # one per device, made once
             side.wait_stream(torch.cuda.current_stream(dev))
         if side is not None:
             with torch.cuda.stream(side):
@@ -938,7 +951,12 @@ class NDPSelect(Select):
             infos = [(g, K.ndp_partition_large(indptr, ei2[1], w2, offs[g], offs[g + 1], seed, keep_l, status_l))
                      for g in oversize]
             if side is not None:
-                torch.cuda.current_stream(dev).wait_stream(side)
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_stream(side)
+                # allocated under the side stream, used (and freed) from here on under the caller's stream: tell the
+                # caching allocator, or their memory could be handed out again while this stream's work is pending
+                for t in (keep8, part_info, status):
+                    t.record_stream(cur)
                 keep8 = keep8 | keep_l
                 status = status | status_l
             for g, info_g in infos:
