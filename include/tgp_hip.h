@@ -191,6 +191,24 @@ int tgp_connect_coalesce_rows_fill(const void* ws, int64_t num_edges, int64_t nu
                                    int64_t num_out, int64_t* out_row, int64_t* out_col,
                                    float* out_weight, void* stream);
 
+/* The row-sorted pipeline WITHOUT the survivor scan, the host read and the separate fill call (r4): same arguments as
+ * tgp_connect_coalesce_rows_count (incl. TGP_HUGE_ROWS and its workspace), then the fill in the same call -- its offsets
+ * come from an epoch-tagged decoupled look-back over blocks of 64 supernode rows (`status`: >=
+ * tgp_connect_coalesce_rows_single_status_words(K) 64-bit words of device memory, caller-owned, never cleared, one
+ * buffer per stream; 0 < epoch < 2^29 different for every call on it) and it writes into CAPACITY-num_edges outputs: the
+ * first `total` entries are the result of the count -> fill pair.  `*result` (device-accessible, e.g. pinned host
+ * memory the caller polls) receives {epoch << 34 | total}, or {epoch << 34 | 1 << 31 | code} when the pipeline
+ * declined: code 8 = hub rows (call again with TGP_HUGE_ROWS), anything else: take another route (the pair's -1).
+ * num_edges > 0, num_supernodes > 0. */
+int64_t tgp_connect_coalesce_rows_single_status_words(int64_t num_supernodes);
+int tgp_connect_coalesce_rows_single(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
+                                     int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,
+                                     int64_t num_supernodes, const int32_t* assign_row_ptr, const int32_t* assign_perm,
+                                     const int32_t* csr_ptr /* NULL ok */, int reduce_op, int flags, float eps, void* ws,
+                                     size_t ws_bytes, int64_t* out_row, int64_t* out_col, float* out_weight,
+                                     uint64_t* status, int64_t status_words, uint64_t* result, uint32_t epoch,
+                                     void* stream);
+
 /* A4 + A6, row-sorted input, as ONE heavy kernel + a widening fill (r3).  Every workgroup derives its rows' member
  * edge ranges, LDS slots and survivor counts locally; the survivors in front of it come from a decoupled look-back, so
  * weights are written once, at their final place, into `out_weight_cap` (capacity num_edges: the first *d_count

@@ -19,7 +19,7 @@
 // vs. five radix passes of 32 B/edge each in the general path (sparse_connect.hip).  The result is
 // identical to the general path (row-major sorted, unique, duplicates reduced in input order).
 // Preconditions are checked on the device (rows sorted; no supernode row longer than 1024 raw entries); if they fail *d_count is set to -1 and the caller falls back to the sort-based path.
-#include "primitives.h"
+#include "lookback.h"
 
 namespace tgp {
 
@@ -913,14 +913,14 @@ __global__ __launch_bounds__(256) void cr_fill_huge_kernel(const uint32_t* __res
                                                            const float* __restrict__ tmp_w,
                                                            const uint32_t* __restrict__ raw_off,
                                                            const uint32_t* __restrict__ out_off,
-                                                           const int64_t* __restrict__ total, int64_t K,
+                                                           const uint32_t* __restrict__ n_out, int64_t K,
                                                            const uint32_t* __restrict__ list, const int* __restrict__ bad,
                                                            int64_t* __restrict__ out_row, int64_t* __restrict__ out_col,
                                                            float* __restrict__ out_w) {
   const int nh = bad[2] < HUGE_MAX ? bad[2] : HUGE_MAX;
   for (int li = 0; li < nh; ++li) {
     const int64_t r = list[li];
-    const uint32_t o0 = out_off[r], n = (r + 1 < K ? out_off[r + 1] : static_cast<uint32_t>(*total)) - o0;
+    const uint32_t o0 = out_off[r], n = n_out[r];
     if (n <= FILL_LONG) continue;  // cr_fill_kernel wrote it
     const uint32_t b = raw_off[r];
     for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) {
@@ -928,6 +928,89 @@ __global__ __launch_bounds__(256) void cr_fill_huge_kernel(const uint32_t* __res
       out_col[o0 + t] = tmp_c[b + t];
       if (out_w) out_w[o0 + t] = tmp_w[b + t];
     }
+  }
+}
+
+// r4: the fill WITHOUT a survivor scan and WITHOUT a host read in front of it.  A workgroup owns FILL_ROWS rows; the
+// number of survivors in front of them comes from the epoch-tagged decoupled look-back of lookback.h -- and because a
+// workgroup publishes its count from 64 loads at its very start, every predecessor's word is there almost at once
+// (nothing heavy sits in front of the publish: no skew to wait out).  Survivors go to CAPACITY-E outputs; the last
+// workgroup leaves {epoch, refused, total} in *result (pinned host memory: the caller polls it), refused carrying the
+// count kernels' verdict (*bad).  Replaces scan_tile_sums + scan_apply (19 us at C4), the device-to-host copy of the
+// count and the idle gap before the fill launch.  Also writes out_off for cr_fill_huge_kernel.
+__global__ __launch_bounds__(256) void cr_fill_single_kernel(const uint32_t* __restrict__ tmp_c,
+                                                             const float* __restrict__ tmp_w,
+                                                             const uint32_t* __restrict__ raw_off,
+                                                             const uint32_t* __restrict__ n_out,
+                                                             uint32_t* __restrict__ out_off, int64_t K,
+                                                             const int* __restrict__ bad, unsigned long long* status,
+                                                             unsigned long long* result, unsigned long long tag,
+                                                             int64_t* __restrict__ out_row, int64_t* __restrict__ out_col,
+                                                             float* __restrict__ out_w) {
+  __shared__ uint32_t s_out[FILL_ROWS + 1], s_raw[FILL_ROWS];
+  __shared__ unsigned long long s_hub;
+  __shared__ uint32_t s_base;
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int64_t r0 = static_cast<int64_t>(tile) * FILL_ROWS;
+  const int nr = static_cast<int>(K - r0 < FILL_ROWS ? K - r0 : FILL_ROWS);
+  const int declined = *bad;  // the count kernels' verdict: rides along as the refusal bit (outputs are then not written)
+  if (tid < 64) {  // wave 0: the tile's row counts, their scan, the publish and the look-back
+    const uint32_t c = (tid < nr && !declined) ? n_out[r0 + tid] : 0u;
+    const uint32_t inc = wave_incl_scan(c);
+    s_out[tid] = inc - c;
+    if (tid == 63) s_out[64] = inc;
+    const uint32_t tot = __shfl(inc, 63, WAVE);
+    const unsigned long long flag = declined ? 0x80000000ull : 0ull;
+    if (tid == 0) sps_store(status + 2 + tile, tag | (tile == 0 ? SPS_PRE : SPS_AGG) | flag | tot);
+    const unsigned long long m = __ballot(tid < nr && c > FILL_LONG);
+    uint32_t excl = 0;
+    bool refused = declined != 0;
+    if (tile > 0) {
+      bool before = false;
+      sps_lookback(status, tile, tag, &excl, &before);
+      refused = refused || before;
+      if (tid == 0)
+        sps_store(status + 2 + tile, tag | SPS_PRE | (refused ? 0x80000000ull : 0ull) |
+                                         static_cast<unsigned long long>((excl + tot) & 0x7FFFFFFFu));
+    }
+    if (tid == 0) {
+      s_hub = m;
+      s_base = excl;
+      if (tile == static_cast<int>(gridDim.x) - 1)
+        __hip_atomic_store(result, tag | (refused ? (0x80000000ull | static_cast<unsigned>(declined & 0xFF)) :
+                                                    static_cast<unsigned long long>((excl + tot) & 0x7FFFFFFFu)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (tid < nr) s_raw[tid] = raw_off[r0 + tid];
+  __syncthreads();
+  if (declined) return;
+  const uint32_t base = s_base;
+  if (tid <= nr && r0 + tid < K) out_off[r0 + tid] = base + s_out[tid];
+  const unsigned long long hub = s_hub;
+  int i0 = 0;
+  while (i0 < nr) {  // maximal runs [i0, i1) of rows without a hub row (one run, the whole block, almost always)
+    if ((hub >> i0) & 1ull) {
+      ++i0;
+      continue;
+    }
+    const unsigned long long rest = hub >> i0;
+    const int i1 = rest ? i0 + __builtin_ctzll(rest) : nr;
+    const uint32_t o0 = s_out[i0], cnt = s_out[i1] - o0;
+    for (uint32_t t = tid; t < cnt; t += 256) {
+      const uint32_t o = o0 + t;
+      int lo = i0, hi = i1;  // last row i with s_out[i] <= o (rows without survivors share their successor's offset)
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_out[mid] <= o) lo = mid; else hi = mid;
+      }
+      const uint32_t src = s_raw[lo] + (o - s_out[lo]);
+      out_row[base + o] = r0 + lo;
+      out_col[base + o] = tmp_c[src];
+      if (out_w) out_w[base + o] = tmp_w[src];
+    }
+    i0 = i1;
   }
 }
 
@@ -1446,13 +1529,22 @@ static __global__ void cr_check_csr_kernel(const int32_t* __restrict__ csr_ptr, 
   }
 }
 
-extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
-                                               const int64_t* cluster_index, int64_t N, int64_t K,
-                                               const int32_t* assign_row_ptr, const int32_t* assign_perm,
-                                               const int32_t* csr_ptr, int reduce_op, int flags, float eps, void* ws,
-                                               size_t ws_bytes, int64_t* d_count, void* stream_) {
+struct CrSingle {  // non-null status: no survivor scan, no d_count -- the single-pass fill follows in the same call
+  int64_t* out_row;
+  int64_t* out_col;
+  float* out_w;
+  uint64_t* status;
+  uint64_t* result;
+  uint32_t epoch;
+};
+
+static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                              const int64_t* cluster_index, int64_t N, int64_t K, const int32_t* assign_row_ptr,
+                              const int32_t* assign_perm, const int32_t* csr_ptr, int reduce_op, int flags, float eps,
+                              void* ws, size_t ws_bytes, int64_t* d_count, const CrSingle* single, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && d_count, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_count: bad argument");
+  TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && (d_count || single), TGP_ERR_INVALID,
+              "tgp_connect_coalesce_rows_count: bad argument");
   TGP_REQUIRE(E == 0 || (row && col && cluster_index && assign_row_ptr && assign_perm), TGP_ERR_INVALID,
               "tgp_connect_coalesce_rows_count: null pointer");
   TGP_REQUIRE(reduce_op >= TGP_SUM && reduce_op <= TGP_MUL, TGP_ERR_INVALID,
@@ -1464,6 +1556,7 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
                                       : tgp_connect_coalesce_rows_workspace_bytes(E, N, K)),
               TGP_ERR_WORKSPACE, "tgp_connect_coalesce_rows_count: workspace too small");
   if (E == 0 || K == 0) {
+    TGP_REQUIRE(!single, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_single: empty input");
     (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
     return check_launch("tgp_connect_coalesce_rows_count");
   }
@@ -1526,8 +1619,52 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
                      reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out, N, s.long_list);
   hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cr_long_grid(K)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
                      reduce_op, flags, eps, s.bad, s.long_list, s.n_out);
+  if (single) {
+    const int tiles = cdiv(K, FILL_ROWS);
+    hipLaunchKernelGGL(cr_fill_single_kernel, dim3(tiles), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, s.n_out,
+                       s.out_off, K, s.bad, reinterpret_cast<unsigned long long*>(single->status),
+                       reinterpret_cast<unsigned long long*>(single->result),
+                       static_cast<unsigned long long>(single->epoch) << SPS_EPOCH_SHIFT, single->out_row,
+                       single->out_col, w ? single->out_w : nullptr);
+    if (huge)
+      hipLaunchKernelGGL(cr_fill_huge_kernel, dim3(1024), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, s.out_off,
+                         s.n_out, K, h.list, s.bad, single->out_row, single->out_col, w ? single->out_w : nullptr);
+    return check_launch("tgp_connect_coalesce_rows_single");
+  }
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);
   return check_launch("tgp_connect_coalesce_rows_count");
+}
+
+extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                               const int64_t* cluster_index, int64_t N, int64_t K,
+                                               const int32_t* assign_row_ptr, const int32_t* assign_perm,
+                                               const int32_t* csr_ptr, int reduce_op, int flags, float eps, void* ws,
+                                               size_t ws_bytes, int64_t* d_count, void* stream_) {
+  return cr_rows_count_impl(row, col, w, E, cluster_index, N, K, assign_row_ptr, assign_perm, csr_ptr, reduce_op, flags,
+                            eps, ws, ws_bytes, d_count, nullptr, stream_);
+}
+
+// The same pipeline WITHOUT the survivor scan, the host read and the separate fill call (r4): the fill follows in the
+// same call, takes its offsets from a decoupled look-back and writes into capacity-E outputs; *result (pinned host
+// memory) receives {epoch << 34 | total}, or {epoch << 34 | 1 << 31 | status} when the pipeline declined (status 8:
+// hub rows, call again with TGP_HUGE_ROWS; anything else: use the other routes).
+extern "C" int64_t tgp_connect_coalesce_rows_single_status_words(int64_t K) { return 2 + cdiv(K > 0 ? K : 1, FILL_ROWS); }
+
+extern "C" int tgp_connect_coalesce_rows_single(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                                const int64_t* cluster_index, int64_t N, int64_t K,
+                                                const int32_t* assign_row_ptr, const int32_t* assign_perm,
+                                                const int32_t* csr_ptr, int reduce_op, int flags, float eps, void* ws,
+                                                size_t ws_bytes, int64_t* out_row, int64_t* out_col, float* out_w,
+                                                uint64_t* status, int64_t status_words, uint64_t* result,
+                                                uint32_t epoch, void* stream_) {
+  TGP_REQUIRE(E > 0 && K > 0 && out_row && out_col && (!w || out_w) && status && result, TGP_ERR_INVALID,
+              "tgp_connect_coalesce_rows_single: bad argument");
+  TGP_REQUIRE(status_words >= tgp_connect_coalesce_rows_single_status_words(K), TGP_ERR_WORKSPACE,
+              "tgp_connect_coalesce_rows_single: status buffer too small");
+  TGP_REQUIRE(epoch != 0 && epoch < (1u << 29), TGP_ERR_RANGE, "tgp_connect_coalesce_rows_single: epoch out of range");
+  const CrSingle single{out_row, out_col, out_w, status, result, epoch};
+  return cr_rows_count_impl(row, col, w, E, cluster_index, N, K, assign_row_ptr, assign_perm, csr_ptr, reduce_op, flags,
+                            eps, ws, ws_bytes, nullptr, &single, stream_);
 }
 
 // ------------------------------------------------------------------ fused row-sorted path (r3), see cr_fused_kernel
@@ -1786,7 +1923,7 @@ extern "C" int tgp_connect_coalesce_rows_fill(const void* ws, int64_t E, int64_t
     HugeWs h;
     huge_layout(const_cast<void*>(ws), align_up(cr_end), E, &h);
     hipLaunchKernelGGL(cr_fill_huge_kernel, dim3(1024), dim3(256), 0, stream, s.tmp_c, weights ? s.tmp_w : nullptr,
-                       s.raw_off, s.out_off, s.total, K, h.list, s.bad, out_row, out_col, weights ? out_w : nullptr);
+                       s.raw_off, s.out_off, s.n_out, K, h.list, s.bad, out_row, out_col, weights ? out_w : nullptr);
   }
   return check_launch("tgp_connect_coalesce_rows_fill");
 }

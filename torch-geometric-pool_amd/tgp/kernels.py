@@ -504,19 +504,49 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
         # any other list finds out from the count (-5), once per edge_index object
         hub = _HUB_ROWS.get(id(edge_index))
         hub = hub is not None and hub[0]() is edge_index and hub[1] == edge_index._version
+        single = not torch.cuda.is_current_stream_capturing()
         for attempt in range(2):
             fl = flags | (N.HUGE_ROWS if hub else 0)
             nbytes = (L.tgp_connect_coalesce_rows_huge_workspace_bytes if hub else
                       L.tgp_connect_coalesce_rows_workspace_bytes)(E, cl.numel(), num_supernodes)
             ws = N.workspace(nbytes, dev)
-            d_count = torch.empty(1, dtype=torch.int64, device=dev)
             st = N.stream_ptr(dev)
-            N.check(L.tgp_connect_coalesce_rows_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
-                                                      num_supernodes, N.ptr(assign_index.row_ptr),
-                                                      N.ptr(assign_index.perm), N.ptr(csr[0]) if csr is not None else None,
-                                                      N.REDUCE_OPS[reduce_op], fl, eps, N.ptr(ws),
-                                                      ws.numel(), N.ptr(d_count), st), "tgp_connect_coalesce_rows_count")
-            n_out = _read_count(d_count)
+            if single:
+                # r4: no survivor scan, no host read in front of the fill: the fill takes its offsets from a decoupled
+                # look-back and writes into capacity-E buffers, which are then narrowed (edge_index': a view whose two
+                # rows are contiguous); the count arrives in a pinned host word
+                cap = torch.empty(2, E, dtype=torch.int64, device=dev)
+                cap_w = None if w is None else torch.empty(E, dtype=torch.float32, device=dev)
+                state = _sps_state(dev, st, L.tgp_connect_coalesce_rows_single_status_words(num_supernodes))
+                epoch = state.next_epoch()
+                cap_p = cap.data_ptr()
+                N.check(L.tgp_connect_coalesce_rows_single(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
+                                                           num_supernodes, N.ptr(assign_index.row_ptr),
+                                                           N.ptr(assign_index.perm),
+                                                           N.ptr(csr[0]) if csr is not None else None,
+                                                           N.REDUCE_OPS[reduce_op], fl, eps, N.ptr(ws), ws.numel(), cap_p,
+                                                           cap_p + 8 * E, N.ptr(cap_w), state.status.data_ptr(),
+                                                           state.status.numel(), state.pinned.data_ptr(), epoch, st),
+                        "tgp_connect_coalesce_rows_single")
+                word = state.wait(epoch)
+                if word & 0x80000000:
+                    code = word & 0xFF  # 8: hub rows; else decline (an id outside its table is reported by the general
+                    n_out = -5 if code == 8 else -1  # route, which the caller takes next)
+                else:
+                    n_out = word & 0x7FFFFFFF
+                    out_ei, out_w = cap[:, :n_out], None if cap_w is None else cap_w[:n_out]
+                    if E * 16 > SPS_COMPACT_BYTES and 4 * n_out < E:
+                        out_ei, out_w = out_ei.contiguous(), None if out_w is None else out_w.clone()
+                    return out_ei, out_w
+            else:
+                d_count = torch.empty(1, dtype=torch.int64, device=dev)
+                N.check(L.tgp_connect_coalesce_rows_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
+                                                          num_supernodes, N.ptr(assign_index.row_ptr),
+                                                          N.ptr(assign_index.perm),
+                                                          N.ptr(csr[0]) if csr is not None else None,
+                                                          N.REDUCE_OPS[reduce_op], fl, eps, N.ptr(ws),
+                                                          ws.numel(), N.ptr(d_count), st), "tgp_connect_coalesce_rows_count")
+                n_out = _read_count(d_count)
             if n_out != -5 or hub:
                 break
             hub = True
