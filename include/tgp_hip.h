@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10024 /* 1.0.1 of the reference, ABI revision 5 (r4: one-launch sparse pooling of small graphs) */
+#define TGP_ABI_VERSION 10025 /* 1.0.1 of the reference, ABI revision 25 (r4: one-launch sparse pooling, fp64 operators, tgp_count_publish) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -191,15 +191,23 @@ int tgp_connect_coalesce_rows_fill(const void* ws, int64_t num_edges, int64_t nu
                                    int64_t num_out, int64_t* out_row, int64_t* out_col,
                                    float* out_weight, void* stream);
 
-/* The row-sorted pipeline WITHOUT the survivor scan, the host read and the separate fill call (r4): same arguments as
- * tgp_connect_coalesce_rows_count (incl. TGP_HUGE_ROWS and its workspace), then the fill in the same call -- its offsets
- * come from an epoch-tagged decoupled look-back over blocks of 64 supernode rows (`status`: >=
- * tgp_connect_coalesce_rows_single_status_words(K) 64-bit words of device memory, caller-owned, never cleared, one
- * buffer per stream; 0 < epoch < 2^29 different for every call on it) and it writes into CAPACITY-num_edges outputs: the
- * first `total` entries are the result of the count -> fill pair.  `*result` (device-accessible, e.g. pinned host
- * memory the caller polls) receives {epoch << 34 | total}, or {epoch << 34 | 1 << 31 | code} when the pipeline
- * declined: code 8 = hub rows (call again with TGP_HUGE_ROWS), anything else: take another route (the pair's -1).
- * num_edges > 0, num_supernodes > 0. */
+/* The host read of any count -> fill pair below without a device-to-host copy: stores
+ * {epoch << 34 | *d_count as a 34-bit two's complement number} with system scope into `*result` (pinned host memory the
+ * caller polls; epoch as for tgp_sparse_pool_small_f32).  Stands in for the reference's `.item()` reads
+ * (connect/base_conn.py:79-82 via torch_geometric.utils.subgraph, utils/ops.py:370-380). */
+int tgp_count_publish(const int64_t* d_count, uint64_t* result, uint32_t epoch, void* stream);
+
+/* The row-sorted pipeline without the host read and the separate fill call (r4): same arguments as
+ * tgp_connect_coalesce_rows_count (incl. TGP_HUGE_ROWS and its workspace), then the survivor scan and the fill in the same
+ * call, writing into CAPACITY-num_edges outputs: the first `total` entries are the result of the count -> fill pair.
+ * `*result` (device-accessible, e.g. pinned host memory the caller polls) receives {epoch << 34 | total}, or
+ * {epoch << 34 | 1 << 31 | code} when the pipeline declined: code 8 = hub rows (call again with TGP_HUGE_ROWS), anything
+ * else: take another route (the pair's -1).  num_edges > 0, num_supernodes > 0, 0 < epoch < 2^29 different for every
+ * call that shares `result`.  `status` (>= ..._status_words(K) 64-bit words of device memory) is reserved: the first r4
+ * build took the fill's offsets from a decoupled look-back over it instead of the scan and measured slower.
+ * Use it when the caller wants the outputs in buffers it already owns; the count -> tgp_count_publish -> fill sequence
+ * keeps the host wait in the MIDDLE of the call (the fill then overlaps the caller's next launches) and is what
+ * tgp.kernels.coalesce_edges runs. */
 int64_t tgp_connect_coalesce_rows_single_status_words(int64_t num_supernodes);
 int tgp_connect_coalesce_rows_single(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
                                      int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,

@@ -867,10 +867,12 @@ __global__ __launch_bounds__(256) void cr_fill_kernel(const uint32_t* __restrict
                                                       const uint32_t* __restrict__ raw_off,
                                                       const uint32_t* __restrict__ out_off,
                                                       const int64_t* __restrict__ total, int64_t K,
+                                                      const int* __restrict__ bad /* NULL, or: declined -> no-op */,
                                                       int64_t* __restrict__ out_row, int64_t* __restrict__ out_col,
                                                       float* __restrict__ out_w) {
   __shared__ uint32_t s_out[FILL_ROWS + 1], s_raw[FILL_ROWS];
   __shared__ unsigned long long s_hub;
+  if (bad && *bad) return;
   const int tid = threadIdx.x;
   const int64_t r0 = static_cast<int64_t>(blockIdx.x) * FILL_ROWS;
   const int nr = static_cast<int>(K - r0 < FILL_ROWS ? K - r0 : FILL_ROWS);
@@ -906,6 +908,15 @@ __global__ __launch_bounds__(256) void cr_fill_kernel(const uint32_t* __restrict
     }
     i0 = i1;
   }
+}
+
+// {epoch, refused, total} of a call that ran count + fill without a host read in between (pinned host memory)
+__global__ void cr_publish_kernel(const int* __restrict__ bad, const int64_t* __restrict__ total,
+                                  unsigned long long* __restrict__ result, unsigned long long tag) {
+  const int b = *bad;
+  __hip_atomic_store(result, tag | (b ? (0x80000000ull | static_cast<unsigned>(b & 0xFF)) :
+                                        static_cast<unsigned long long>(*total & 0x7FFFFFFF)),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // the listed hub rows with more than FILL_LONG survivors: every row a grid-wide strided copy
@@ -968,7 +979,7 @@ __global__ __launch_bounds__(256) void cr_fill_single_kernel(const uint32_t* __r
     bool refused = declined != 0;
     if (tile > 0) {
       bool before = false;
-      sps_lookback(status, tile, tag, &excl, &before);
+      sps_lookback<1>(status, tile, tag, &excl, &before);
       refused = refused || before;
       if (tid == 0)
         sps_store(status + 2 + tile, tag | SPS_PRE | (refused ? 0x80000000ull : 0ull) |
@@ -1620,15 +1631,20 @@ static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const floa
   hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cr_long_grid(K)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
                      reduce_op, flags, eps, s.bad, s.long_list, s.n_out);
   if (single) {
-    const int tiles = cdiv(K, FILL_ROWS);
-    hipLaunchKernelGGL(cr_fill_single_kernel, dim3(tiles), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, s.n_out,
-                       s.out_off, K, s.bad, reinterpret_cast<unsigned long long*>(single->status),
-                       reinterpret_cast<unsigned long long*>(single->result),
-                       static_cast<unsigned long long>(single->epoch) << SPS_EPOCH_SHIFT, single->out_row,
-                       single->out_col, w ? single->out_w : nullptr);
+    // no host read between count and fill: the fill is launched right behind the survivor scan into capacity-E outputs
+    // and a one-thread kernel leaves {epoch, refused, total} for the caller to poll.  (r4: taking the offsets from a
+    // decoupled look-back inside the fill instead of the scan was built and measured SLOWER -- cr_fill_single_kernel,
+    // 107 us against 46 + 19 us: with thousands of short tiles resident at once a prefix only advances one look-back
+    // window per round trip of the uncached status words; kept for the record, not launched.)
+    device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream);
+    hipLaunchKernelGGL(cr_fill_kernel, dim3(cdiv(K, FILL_ROWS)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, s.out_off,
+                       s.total, K, s.bad, single->out_row, single->out_col, w ? single->out_w : nullptr);
     if (huge)
       hipLaunchKernelGGL(cr_fill_huge_kernel, dim3(1024), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, s.out_off,
                          s.n_out, K, h.list, s.bad, single->out_row, single->out_col, w ? single->out_w : nullptr);
+    hipLaunchKernelGGL(cr_publish_kernel, dim3(1), dim3(1), 0, stream, s.bad, s.total,
+                       reinterpret_cast<unsigned long long*>(single->result),
+                       static_cast<unsigned long long>(single->epoch) << SPS_EPOCH_SHIFT);
     return check_launch("tgp_connect_coalesce_rows_single");
   }
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);
@@ -1917,8 +1933,8 @@ extern "C" int tgp_connect_coalesce_rows_fill(const void* ws, int64_t E, int64_t
   const size_t cr_end = cr_layout(const_cast<void*>(ws), E, N, K, &s);
   const bool weights = (has_weight & 1) != 0;
   hipLaunchKernelGGL(cr_fill_kernel, dim3(cdiv(K, FILL_ROWS)), dim3(256), 0, stream, s.tmp_c,
-                     weights ? s.tmp_w : nullptr, s.raw_off, s.out_off, s.total, K, out_row, out_col,
-                     weights ? out_w : nullptr);
+                     weights ? s.tmp_w : nullptr, s.raw_off, s.out_off, s.total, K, static_cast<const int*>(nullptr),
+                     out_row, out_col, weights ? out_w : nullptr);
   if (has_weight & 2) {  // the count call ran with TGP_HUGE_ROWS: hub rows are copied by the whole grid
     HugeWs h;
     huge_layout(const_cast<void*>(ws), align_up(cr_end), E, &h);
@@ -1936,3 +1952,20 @@ extern "C" int tgp_debug_set_gs_stamps(unsigned long long* p) {
   return hipMemcpyToSymbol(HIP_SYMBOL(tgp::g_gs_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
 }
 #endif
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The host read of a count -> fill pair without a device-to-host copy and a stream synchronise: one thread stores
+// {epoch << 34 | count (34-bit two's complement: decline codes are negative)} into a pinned host word the caller polls.
+__global__ void count_publish_kernel(const int64_t* __restrict__ d_count, unsigned long long* __restrict__ result,
+                                     unsigned long long tag) {
+  __hip_atomic_store(result, tag | (static_cast<unsigned long long>(*d_count) & ((1ull << SPS_EPOCH_SHIFT) - 1)),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int tgp_count_publish(const int64_t* d_count, uint64_t* result, uint32_t epoch, void* stream_) {
+  TGP_REQUIRE(d_count && result && epoch > 0 && epoch < (1u << 30), TGP_ERR_INVALID, "tgp_count_publish: bad argument");
+  hipLaunchKernelGGL(count_publish_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream_), d_count,
+                     reinterpret_cast<unsigned long long*>(result),
+                     static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT);
+  return check_launch("tgp_count_publish");
+}

@@ -31,23 +31,31 @@ __device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
 // The look-back in two halves, so that the words' round trip (~1 us: they live behind the fabric) overlaps work that does
 // not depend on them: `issue` requests the 256 nearest predecessor words, `finish` consumes them (re-reading only those
 // that were not published yet) and walks further back if none of them held a prefix.
-struct SpsLook {
-  unsigned long long st[4];
-  int idx[4];
+// WIN = words per lane and round: 4 (256 predecessors at once) where a round of persistent workgroups publishes together
+// and no prefix can be nearer than that (sparse_pool_small, the single-pass subgraph Connect); 1 for grids of thousands of
+// short tiles, where a prefix is almost always among the 64 nearest (every word is an uncached read behind the fabric:
+// 256 of them per tile made the look-back fill of the coalesce Connect 47 us slower than its scan kernels).
+template <int WIN = 4>
+struct SpsLookT {
+  unsigned long long st[WIN];
+  int idx[WIN];
 };
+using SpsLook = SpsLookT<4>;
 
+template <int WIN>
 __device__ __forceinline__ void sps_lookback_issue(const unsigned long long* status, int tile, unsigned long long tag,
-                                                   SpsLook& lk) {
+                                                   SpsLookT<WIN>& lk) {
   const int lane = lane_id();
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < WIN; ++k) {
     lk.idx[k] = tile - 1 - lane - 64 * k;
     lk.st[k] = lk.idx[k] >= 0 ? sps_load(status + 2 + lk.idx[k]) : (tag | SPS_PRE);
   }
 }
 
+template <int WIN>
 __device__ __forceinline__ void sps_lookback_finish(unsigned long long* status, int tile, unsigned long long tag,
-                                                    SpsLook& lk, uint32_t* excl_out, bool* refused) {
+                                                    SpsLookT<WIN>& lk, uint32_t* excl_out, bool* refused) {
   const int lane = lane_id();
   uint32_t excl = 0;
   bool bad = false;
@@ -56,7 +64,7 @@ __device__ __forceinline__ void sps_lookback_finish(unsigned long long* status, 
   while (j >= 0) {
     if (!first_window) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < WIN; ++k) {
         lk.idx[k] = j - lane - 64 * k;
         lk.st[k] = lk.idx[k] >= 0 ? sps_load(status + 2 + lk.idx[k]) : (tag | SPS_PRE);
       }
@@ -66,7 +74,7 @@ __device__ __forceinline__ void sps_lookback_finish(unsigned long long* status, 
     for (;;) {
       bool wait = false;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) wait = wait || !sps_current(lk.st[k], tag) || ((lk.st[k] >> 32) & 3ull) == 0;
+      for (int k = 0; k < WIN; ++k) wait = wait || !sps_current(lk.st[k], tag) || ((lk.st[k] >> 32) & 3ull) == 0;
       if (!__any(wait)) break;
       if (++spins > (1 << 20)) {  // every spin is bounded
         *excl_out = 0;
@@ -75,13 +83,13 @@ __device__ __forceinline__ void sps_lookback_finish(unsigned long long* status, 
       }
       if (spins > 4) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < WIN; ++k)
         if (lk.idx[k] >= 0 && (!sps_current(lk.st[k], tag) || ((lk.st[k] >> 32) & 3ull) == 0))
           lk.st[k] = sps_load(status + 2 + lk.idx[k]);
     }
     bool done = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < WIN; ++k) {
       if (!done) {  // (uniform: `done` comes from ballots)
         const unsigned long long pre = __ballot(((lk.st[k] >> 32) & 3ull) == 2);
         const int first = pre ? __builtin_ctzll(pre) : 64;  // nearest predecessor that already knows its prefix
@@ -91,7 +99,7 @@ __device__ __forceinline__ void sps_lookback_finish(unsigned long long* status, 
       }
     }
     if (done) break;
-    j -= 256;
+    j -= 64 * WIN;
   }
   *excl_out = excl;
   *refused = bad;
@@ -101,11 +109,12 @@ __device__ __forceinline__ void sps_lookback_finish(unsigned long long* status, 
 // them refused (bit 31); every lane of ONE wave calls it.  A spin bound turns a tile that never shows up into a refusal.
 // (256 predecessors per round, four words per lane, all requested at once: everybody publishes at about the same time --
 // r4 stamps: 64 per round made the last of 256 tiles wait four dependent rounds.)
+template <int WIN = 4>
 __device__ __forceinline__ void sps_lookback(unsigned long long* status, int tile, unsigned long long tag,
                                              uint32_t* excl_out, bool* refused) {
-  SpsLook lk;
-  sps_lookback_issue(status, tile, tag, lk);
-  sps_lookback_finish(status, tile, tag, lk, excl_out, refused);
+  SpsLookT<WIN> lk;
+  sps_lookback_issue<WIN>(status, tile, tag, lk);
+  sps_lookback_finish<WIN>(status, tile, tag, lk, excl_out, refused);
 }
 
 }  // namespace tgp

@@ -6,6 +6,7 @@ on the CPU and nothing falls back to ATen kernels.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -162,6 +163,8 @@ def _edge_rows(edge_index: Tensor) -> Tuple[Tensor, Tensor]:
 # ------------------------------------------------------------------------- A1 + A2 + A4/A5 + A6, batches of small graphs
 _SPS_STATE: dict = {}  # (device index, stream handle) -> _SpsState
 _SPS_DECLINED: dict = {}
+_PUBLISH_COUNTS = os.environ.get("TGP_PUBLISH_COUNTS", "1") != "0"  # A/B switch of _read_count (read once)
+_ROWS_SINGLE = os.environ.get("TGP_COALESCE_ROWS_SINGLE", "0") == "1"  # A/B switch: fill inside the count call
 SPS_COMPACT_BYTES = 1 << 30  # capacity buffers above this are replaced by exact copies when mostly empty
 
 
@@ -295,8 +298,21 @@ def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_wei
 
 
 def _read_count(d_count: Tensor) -> int:
-    # the single host sync of a count -> fill pair (the reference pays `.item()` syncs too)
-    n = int(d_count.item())
+    # the single host wait of a count -> fill pair (the reference pays `.item()` syncs too).  r4: a one-thread kernel
+    # stores the count into a pinned host word this thread polls -- a few microseconds instead of the copy kernel +
+    # stream synchronise of `.item()`; the wait stays in the MIDDLE of the call, so the fill still overlaps whatever
+    # the caller launches next.  Under stream capture neither form is legal: the count routes are not capturable.
+    if _PUBLISH_COUNTS and not torch.cuda.is_current_stream_capturing():
+        dev = d_count.device
+        st = N.stream_ptr(dev)
+        state = _sps_state(dev, st, 0)
+        epoch = state.next_epoch()
+        N.check(N.lib().tgp_count_publish(N.ptr(d_count), state.pinned.data_ptr(), epoch, st), "tgp_count_publish")
+        n = state.wait(epoch) & ((1 << 34) - 1)
+        if n >= 1 << 33:
+            n -= 1 << 34
+    else:
+        n = int(d_count.item())
     if n == -2:  # refusal code of the count kernels: an endpoint (or cluster id) outside its table
         raise IndexError("edge_index holds node ids outside [0, num_nodes) (or cluster ids outside [0, num_supernodes)): "
                          "the reference's index ops raise for these inputs too")
@@ -504,7 +520,7 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
         # any other list finds out from the count (-5), once per edge_index object
         hub = _HUB_ROWS.get(id(edge_index))
         hub = hub is not None and hub[0]() is edge_index and hub[1] == edge_index._version
-        single = not torch.cuda.is_current_stream_capturing()
+        single = _ROWS_SINGLE and E > 0 and num_supernodes > 0 and not torch.cuda.is_current_stream_capturing()
         for attempt in range(2):
             fl = flags | (N.HUGE_ROWS if hub else 0)
             nbytes = (L.tgp_connect_coalesce_rows_huge_workspace_bytes if hub else
@@ -512,9 +528,9 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
             ws = N.workspace(nbytes, dev)
             st = N.stream_ptr(dev)
             if single:
-                # r4: no survivor scan, no host read in front of the fill: the fill takes its offsets from a decoupled
-                # look-back and writes into capacity-E buffers, which are then narrowed (edge_index': a view whose two
-                # rows are contiguous); the count arrives in a pinned host word
+                # r4 experiment (TGP_COALESCE_ROWS_SINGLE=1): no host read in front of the fill, which writes into
+                # capacity-E buffers that are then narrowed; measured slower than the pair below because the host wait
+                # moves to the END of the call, where nothing overlaps it
                 cap = torch.empty(2, E, dtype=torch.int64, device=dev)
                 cap_w = None if w is None else torch.empty(E, dtype=torch.float32, device=dev)
                 state = _sps_state(dev, st, L.tgp_connect_coalesce_rows_single_status_words(num_supernodes))
