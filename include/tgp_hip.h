@@ -197,25 +197,24 @@ int tgp_connect_coalesce_rows_fill(const void* ws, int64_t num_edges, int64_t nu
  * (connect/base_conn.py:79-82 via torch_geometric.utils.subgraph, utils/ops.py:370-380). */
 int tgp_count_publish(const int64_t* d_count, uint64_t* result, uint32_t epoch, void* stream);
 
-/* The row-sorted pipeline without the host read and the separate fill call (r4): same arguments as
- * tgp_connect_coalesce_rows_count (incl. TGP_HUGE_ROWS and its workspace), then the survivor scan and the fill in the same
- * call, writing into CAPACITY-num_edges outputs: the first `total` entries are the result of the count -> fill pair.
- * `*result` (device-accessible, e.g. pinned host memory the caller polls) receives {epoch << 34 | total}, or
- * {epoch << 34 | 1 << 31 | code} when the pipeline declined: code 8 = hub rows (call again with TGP_HUGE_ROWS), anything
- * else: take another route (the pair's -1).  num_edges > 0, num_supernodes > 0, 0 < epoch < 2^29 different for every
- * call that shares `result`.  `status` (>= ..._status_words(K) 64-bit words of device memory) is reserved: the first r4
- * build took the fill's offsets from a decoupled look-back over it instead of the scan and measured slower.
- * Use it when the caller wants the outputs in buffers it already owns; the count -> tgp_count_publish -> fill sequence
- * keeps the host wait in the MIDDLE of the call (the fill then overlaps the caller's next launches) and is what
- * tgp.kernels.coalesce_edges runs. */
-int64_t tgp_connect_coalesce_rows_single_status_words(int64_t num_supernodes);
-int tgp_connect_coalesce_rows_single(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
-                                     int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,
-                                     int64_t num_supernodes, const int32_t* assign_row_ptr, const int32_t* assign_perm,
-                                     const int32_t* csr_ptr /* NULL ok */, int reduce_op, int flags, float eps, void* ws,
-                                     size_t ws_bytes, int64_t* out_row, int64_t* out_col, float* out_weight,
-                                     uint64_t* status, int64_t status_words, uint64_t* result, uint32_t epoch,
-                                     void* stream);
+/* tgp_connect_coalesce_rows_count with its survivor scan as ONE launch that also hands the count to the host (r4):
+ * the scan takes the survivors in front of every block of 4096 supernode rows from an epoch-tagged decoupled look-back
+ * (`status`: >= ..._status_words(K) 64-bit words of device memory, caller-owned, never cleared, one buffer per stream;
+ * 0 < epoch < 2^29 different for every call on it) and its last workgroup stores {epoch << 34 | *d_count as a 34-bit
+ * two's complement number} with system scope into `*result` (pinned host memory the caller polls; same word format as
+ * tgp_count_publish).  *d_count is written as well; tgp_connect_coalesce_rows_fill follows as for the plain count.
+ * `csr_col` (NULL ok, only with csr_ptr): the int32 copy of `col` that GraclusSelect's CSR holds for this very list --
+ * half the column stream of the gather kernel; `col` is still needed (hub rows).
+ * Measured alternatives (profiles/r04_coalesce_tail_experiments.md): the look-back inside the FILL (64-row tiles) and the
+ * fill inside the count call (host wait at the end) are both slower. */
+int64_t tgp_connect_coalesce_rows_count_status_words(int64_t num_supernodes);
+int tgp_connect_coalesce_rows_count_published(const int64_t* row, const int64_t* col, const int32_t* csr_col /* NULL ok */,
+                                              const float* edge_weight /* NULL ok */, int64_t num_edges,
+                                              const int64_t* cluster_index, int64_t num_nodes, int64_t num_supernodes,
+                                              const int32_t* assign_row_ptr, const int32_t* assign_perm,
+                                              const int32_t* csr_ptr /* NULL ok */, int reduce_op, int flags, float eps,
+                                              void* ws, size_t ws_bytes, int64_t* d_count, uint64_t* status,
+                                              int64_t status_words, uint64_t* result, uint32_t epoch, void* stream);
 
 /* A4 + A6, row-sorted input, as ONE heavy kernel + a widening fill (r3).  Every workgroup derives its rows' member
  * edge ranges, LDS slots and survivor counts locally; the survivors in front of it come from a decoupled look-back, so

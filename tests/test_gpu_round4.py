@@ -473,3 +473,42 @@ def test_graclus_optimistic_route_with_unsorted_rows(dev):
     assert bool((partner_ok | ~paired).all())            # every pair is an edge
     free = ~paired
     assert not bool((free[r] & free[c] & (r != c)).any())  # maximal: no edge between two single nodes
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("n,deg", [(5000, 6), (300_000, 10)])
+def test_published_count_and_int32_columns_equal_the_plain_count_route(dev, weighted, n, deg, monkeypatch):
+    """Row-sorted coalesce Connect (connect/base_conn.py:83-89): the survivor scan as one look-back launch that hands
+    the count over in a pinned host word, with and without the int32 column copy of the list's CSR, against the
+    count -> `.item()` -> fill pair and the general radix route -- same edges, same weights, bit for bit."""
+    from tgp import kernels
+    g = torch.Generator().manual_seed(n + deg)
+    src = torch.randint(0, n, (n * deg,), generator=g)
+    dst = torch.randint(0, n, (n * deg,), generator=g)
+    ei = torch.stack([torch.cat([src, dst]), torch.cat([dst, src])])
+    key = torch.unique(ei[0] * n + ei[1])
+    ei = torch.stack([key // n, key % n])  # row-major sorted, no duplicates (PyG convention)
+    perm = torch.randperm(n, generator=g)
+    cluster = torch.empty(n, dtype=torch.long)
+    cluster[perm] = torch.arange(n) // 2
+    k = int(cluster.max()) + 1
+    ew = (torch.rand(ei.size(1), generator=g) - 0.3) if weighted else None
+    ei_d, cl_d = ei.to(dev), cluster.to(dev)
+    ew_d = None if ew is None else ew.to(dev)
+    idx = kernels.build_assign_index(cl_d, k)
+    ptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    ptr[1:] = torch.bincount(ei_d[0], minlength=n).cumsum(0).to(torch.int32)
+    csr = (ptr, ei_d[1].to(torch.int32).contiguous())
+    ref_ei, ref_ew = kernels.coalesce_edges(ei_d, ew_d, cl_d, k, "sum", True, route="general")
+    monkeypatch.setattr(kernels, "_PUBLISH_COUNTS", False)
+    plain_ei, plain_ew = kernels.coalesce_edges(ei_d, ew_d, cl_d, k, "sum", True, assign_index=idx, route="staged")
+    monkeypatch.setattr(kernels, "_PUBLISH_COUNTS", True)
+    for kw in ({}, {"csr": csr}, {"csr": (ptr, None)}):
+        for _ in range(3):  # the status words of the previous calls are stale, never cleared
+            got_ei, got_ew = kernels.coalesce_edges(ei_d, ew_d, cl_d, k, "sum", True, assign_index=idx, route="staged",
+                                                    **kw)
+            assert torch.equal(got_ei, ref_ei) and torch.equal(got_ei, plain_ei)
+            if weighted:
+                assert torch.equal(got_ew, plain_ew) and torch.equal(got_ew, ref_ew)
+            else:
+                assert got_ew is None

@@ -409,9 +409,10 @@ __device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, float* s_val, uint
 // DIRECT = false: rows are assembled from the members' edge ranges (row-sorted input, above).
 // DIRECT = true : `grouped` already holds the (cluster column | weight bits << 32) entries in supernode-row order
 //                 (the output of the 3-pass radix sort by supernode row, below); slot t of a row is grouped[...+t].
-template <bool DIRECT>
+// CT: int64 columns of the caller's list, or the int32 copy GraclusSelect's CSR already holds (half the column stream).
+template <bool DIRECT, typename CT = int64_t>
 __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
-    const int64_t* __restrict__ col, const float* __restrict__ w, int64_t E, const int32_t* __restrict__ table,
+    const CT* __restrict__ col, const float* __restrict__ w, int64_t E, const int32_t* __restrict__ table,
     const int32_t* __restrict__ a_row_ptr, const uint32_t* __restrict__ seg_src, const uint32_t* __restrict__ seg_dst,
     const unsigned long long* __restrict__ grouped, const uint32_t* __restrict__ raw_off, int64_t K, int reduce_op,
     int flags, float eps,
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
           len[r] = v ? nx - d : 0u;
           dst[r] = d - base;
         }
-        int64_t cc[GR][2];
+        CT cc[GR][2];
         float wv[GR][2];
 #pragma unroll
         for (int r = 0; r < GR; ++r)
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
 #endif
 #ifdef TGP_GEMM_STAMPS
             if (g_gs_ablate & 8) {  // no col / w loads: synthetic node ids, table lookups stay
-              cc[r][q] = static_cast<int64_t>(((src[r] + j) * 2654435761u) % static_cast<uint32_t>(n_nodes));
+              cc[r][q] = static_cast<CT>(((src[r] + j) * 2654435761u) % static_cast<uint32_t>(n_nodes));
               wv[r][q] = 1.f;
               continue;
             }
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
             const uint32_t j = static_cast<uint32_t>(l + 8 * q);
             if (j < len[r]) {
               // a column outside [0, n_nodes): decline (the general path reports it); never used as an index
-              const bool inr = static_cast<uint64_t>(cc[r][q]) < static_cast<uint64_t>(n_nodes);
+              const bool inr = static_cast<uint64_t>(static_cast<int64_t>(cc[r][q])) < static_cast<uint64_t>(n_nodes);
               if (!inr) *bad = 4;
 #ifdef TGP_GEMM_STAMPS
               if (g_gs_ablate & 2) {
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
 #pragma unroll
         for (int r = 0; r < GR; ++r)
           for (uint32_t j = static_cast<uint32_t>(l) + 16; j < len[r]; j += 8) {
-            const int64_t c = col[src[r] + j];
+            const int64_t c = static_cast<int64_t>(col[src[r] + j]);
             const bool inr = static_cast<uint64_t>(c) < static_cast<uint64_t>(n_nodes);
             if (!inr) *bad = 4;
             s_key[dst[r] + j] = inr ? static_cast<uint32_t>(table[c]) : 0u;
@@ -910,15 +911,6 @@ __global__ __launch_bounds__(256) void cr_fill_kernel(const uint32_t* __restrict
   }
 }
 
-// {epoch, refused, total} of a call that ran count + fill without a host read in between (pinned host memory)
-__global__ void cr_publish_kernel(const int* __restrict__ bad, const int64_t* __restrict__ total,
-                                  unsigned long long* __restrict__ result, unsigned long long tag) {
-  const int b = *bad;
-  __hip_atomic_store(result, tag | (b ? (0x80000000ull | static_cast<unsigned>(b & 0xFF)) :
-                                        static_cast<unsigned long long>(*total & 0x7FFFFFFF)),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // the listed hub rows with more than FILL_LONG survivors: every row a grid-wide strided copy
 __global__ __launch_bounds__(256) void cr_fill_huge_kernel(const uint32_t* __restrict__ tmp_c,
                                                            const float* __restrict__ tmp_w,
@@ -942,86 +934,72 @@ __global__ __launch_bounds__(256) void cr_fill_huge_kernel(const uint32_t* __res
   }
 }
 
-// r4: the fill WITHOUT a survivor scan and WITHOUT a host read in front of it.  A workgroup owns FILL_ROWS rows; the
-// number of survivors in front of them comes from the epoch-tagged decoupled look-back of lookback.h -- and because a
-// workgroup publishes its count from 64 loads at its very start, every predecessor's word is there almost at once
-// (nothing heavy sits in front of the publish: no skew to wait out).  Survivors go to CAPACITY-E outputs; the last
-// workgroup leaves {epoch, refused, total} in *result (pinned host memory: the caller polls it), refused carrying the
-// count kernels' verdict (*bad).  Replaces scan_tile_sums + scan_apply (19 us at C4), the device-to-host copy of the
-// count and the idle gap before the fill launch.  Also writes out_off for cr_fill_huge_kernel.
-__global__ __launch_bounds__(256) void cr_fill_single_kernel(const uint32_t* __restrict__ tmp_c,
-                                                             const float* __restrict__ tmp_w,
-                                                             const uint32_t* __restrict__ raw_off,
-                                                             const uint32_t* __restrict__ n_out,
-                                                             uint32_t* __restrict__ out_off, int64_t K,
-                                                             const int* __restrict__ bad, unsigned long long* status,
-                                                             unsigned long long* result, unsigned long long tag,
-                                                             int64_t* __restrict__ out_row, int64_t* __restrict__ out_col,
-                                                             float* __restrict__ out_w) {
-  __shared__ uint32_t s_out[FILL_ROWS + 1], s_raw[FILL_ROWS];
-  __shared__ unsigned long long s_hub;
+// r4: the survivor scan as ONE launch that also hands the count to the host.  A workgroup owns SCAN_TILE rows; the
+// survivors in front of them come from the epoch-tagged decoupled look-back of lookback.h (a few hundred tiles, all
+// published within a microsecond of each other: 256 predecessor words per round), and the last workgroup leaves the
+// total in *total, the caller-visible count in *d_count and {epoch << 34 | count as a 34-bit two's complement number} in
+// *result -- pinned host memory the caller polls: no device-to-host copy, no stream synchronise.  Replaces
+// scan_tile_sums + scan_apply + the count's copy kernel (r4, C4: 4.8 + 7.8 us + the `.item()` round trip).
+// (The look-back does NOT pay inside the fill -- thousands of 64-row tiles, 107 us against 46 + 19 -- nor does running
+// the fill inside the count call with the host wait at its end: profiles/r04_coalesce_tail_experiments.md.)
+__global__ __launch_bounds__(256) void cr_scan_publish_kernel(const uint32_t* __restrict__ n_out, int64_t K,
+                                                              uint32_t* __restrict__ out_off,
+                                                              int64_t* __restrict__ total, const int* __restrict__ bad,
+                                                              int64_t* __restrict__ d_count,
+                                                              unsigned long long* status, unsigned long long* result,
+                                                              unsigned long long tag) {
+  __shared__ uint32_t s_w[4];
   __shared__ uint32_t s_base;
   const int tid = threadIdx.x;
   const int tile = blockIdx.x;
-  const int64_t r0 = static_cast<int64_t>(tile) * FILL_ROWS;
-  const int nr = static_cast<int>(K - r0 < FILL_ROWS ? K - r0 : FILL_ROWS);
-  const int declined = *bad;  // the count kernels' verdict: rides along as the refusal bit (outputs are then not written)
-  if (tid < 64) {  // wave 0: the tile's row counts, their scan, the publish and the look-back
-    const uint32_t c = (tid < nr && !declined) ? n_out[r0 + tid] : 0u;
-    const uint32_t inc = wave_incl_scan(c);
-    s_out[tid] = inc - c;
-    if (tid == 63) s_out[64] = inc;
-    const uint32_t tot = __shfl(inc, 63, WAVE);
-    const unsigned long long flag = declined ? 0x80000000ull : 0ull;
-    if (tid == 0) sps_store(status + 2 + tile, tag | (tile == 0 ? SPS_PRE : SPS_AGG) | flag | tot);
-    const unsigned long long m = __ballot(tid < nr && c > FILL_LONG);
+  const int64_t base = static_cast<int64_t>(tile) * SCAN_TILE + static_cast<int64_t>(tid) * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS], sacc = 0;
+  if (base + SCAN_ITEMS <= K) {  // (the workspace carves 256-byte aligned arrays)
+    const uint4* p = reinterpret_cast<const uint4*>(n_out + base);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS / 4; ++i) {
+      const uint4 q = p[i];
+      v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) v[i] = base + i < K ? n_out[base + i] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) sacc += v[i];
+  uint32_t tile_total;
+  const uint32_t local = block_excl_scan_256(sacc, s_w, &tile_total);
+  if (tid < WAVE) {  // wave 0: publish, look back, publish the prefix
+    if (tid == 0)
+      sps_store(status + 2 + tile, tag | (tile == 0 ? SPS_PRE : SPS_AGG) | static_cast<unsigned long long>(tile_total));
     uint32_t excl = 0;
-    bool refused = declined != 0;
+    bool refused = false;
     if (tile > 0) {
-      bool before = false;
-      sps_lookback<1>(status, tile, tag, &excl, &before);
-      refused = refused || before;
+      sps_lookback<4>(status, tile, tag, &excl, &refused);
       if (tid == 0)
         sps_store(status + 2 + tile, tag | SPS_PRE | (refused ? 0x80000000ull : 0ull) |
-                                         static_cast<unsigned long long>((excl + tot) & 0x7FFFFFFFu));
+                                         static_cast<unsigned long long>((excl + tile_total) & 0x7FFFFFFFu));
     }
     if (tid == 0) {
-      s_hub = m;
       s_base = excl;
-      if (tile == static_cast<int>(gridDim.x) - 1)
-        __hip_atomic_store(result, tag | (refused ? (0x80000000ull | static_cast<unsigned>(declined & 0xFF)) :
-                                                    static_cast<unsigned long long>((excl + tot) & 0x7FFFFFFFu)),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (tile == static_cast<int>(gridDim.x) - 1) {
+        const int64_t t = static_cast<int64_t>(excl) + tile_total;
+        const int b = *bad;  // a look-back that ran into its spin bound declines the call like an unmet precondition
+        const int64_t count = (b || refused) ? (b == 8 ? -5 : -1) : t;
+        *total = t;
+        if (d_count) *d_count = count;
+        if (result)
+          __hip_atomic_store(result, tag | (static_cast<unsigned long long>(count) & ((1ull << SPS_EPOCH_SHIFT) - 1)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
-  if (tid < nr) s_raw[tid] = raw_off[r0 + tid];
   __syncthreads();
-  if (declined) return;
-  const uint32_t base = s_base;
-  if (tid <= nr && r0 + tid < K) out_off[r0 + tid] = base + s_out[tid];
-  const unsigned long long hub = s_hub;
-  int i0 = 0;
-  while (i0 < nr) {  // maximal runs [i0, i1) of rows without a hub row (one run, the whole block, almost always)
-    if ((hub >> i0) & 1ull) {
-      ++i0;
-      continue;
-    }
-    const unsigned long long rest = hub >> i0;
-    const int i1 = rest ? i0 + __builtin_ctzll(rest) : nr;
-    const uint32_t o0 = s_out[i0], cnt = s_out[i1] - o0;
-    for (uint32_t t = tid; t < cnt; t += 256) {
-      const uint32_t o = o0 + t;
-      int lo = i0, hi = i1;  // last row i with s_out[i] <= o (rows without survivors share their successor's offset)
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (s_out[mid] <= o) lo = mid; else hi = mid;
-      }
-      const uint32_t src = s_raw[lo] + (o - s_out[lo]);
-      out_row[base + o] = r0 + lo;
-      out_col[base + o] = tmp_c[src];
-      if (out_w) out_w[base + o] = tmp_w[src];
-    }
-    i0 = i1;
+  uint32_t run = s_base + local;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    if (base + i < K) out_off[base + i] = run;
+    run += v[i];
   }
 }
 
@@ -1525,6 +1503,15 @@ extern "C" size_t tgp_connect_coalesce_rows_huge_workspace_bytes(int64_t E, int6
   return huge_layout(nullptr, align_up(cr_layout(nullptr, E, N, K, nullptr)), E, nullptr) + 256;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The host read of a count -> fill pair without a device-to-host copy and a stream synchronise: one thread stores
+// {epoch << 34 | count (34-bit two's complement: decline codes are negative)} into a pinned host word the caller polls.
+__global__ void count_publish_kernel(const int64_t* __restrict__ d_count, unsigned long long* __restrict__ result,
+                                     unsigned long long tag) {
+  __hip_atomic_store(result, tag | (static_cast<unsigned long long>(*d_count) & ((1ull << SPS_EPOCH_SHIFT) - 1)),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // a handed-over CSR covers the whole list: offsets start at 0 and end at E (a list with ids outside [0, N) does not)
 // (reset: this one-thread launch also clears the status words, saving the memset in front of it)
 static __global__ void cr_check_csr_kernel(const int32_t* __restrict__ csr_ptr, int64_t N, int64_t E,
@@ -1540,10 +1527,8 @@ static __global__ void cr_check_csr_kernel(const int32_t* __restrict__ csr_ptr, 
   }
 }
 
-struct CrSingle {  // non-null status: no survivor scan, no d_count -- the single-pass fill follows in the same call
-  int64_t* out_row;
-  int64_t* out_col;
-  float* out_w;
+struct CrPublish {  // the single-launch survivor scan with the count handed to the host through *result
+  const int32_t* csr_col;  // NULL, or the int32 columns of this very list (only with csr_ptr)
   uint64_t* status;
   uint64_t* result;
   uint32_t epoch;
@@ -1552,10 +1537,9 @@ struct CrSingle {  // non-null status: no survivor scan, no d_count -- the singl
 static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const float* w, int64_t E,
                               const int64_t* cluster_index, int64_t N, int64_t K, const int32_t* assign_row_ptr,
                               const int32_t* assign_perm, const int32_t* csr_ptr, int reduce_op, int flags, float eps,
-                              void* ws, size_t ws_bytes, int64_t* d_count, const CrSingle* single, void* stream_) {
+                              void* ws, size_t ws_bytes, int64_t* d_count, const CrPublish* pub, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && (d_count || single), TGP_ERR_INVALID,
-              "tgp_connect_coalesce_rows_count: bad argument");
+  TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && d_count, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_count: bad argument");
   TGP_REQUIRE(E == 0 || (row && col && cluster_index && assign_row_ptr && assign_perm), TGP_ERR_INVALID,
               "tgp_connect_coalesce_rows_count: null pointer");
   TGP_REQUIRE(reduce_op >= TGP_SUM && reduce_op <= TGP_MUL, TGP_ERR_INVALID,
@@ -1567,8 +1551,11 @@ static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const floa
                                       : tgp_connect_coalesce_rows_workspace_bytes(E, N, K)),
               TGP_ERR_WORKSPACE, "tgp_connect_coalesce_rows_count: workspace too small");
   if (E == 0 || K == 0) {
-    TGP_REQUIRE(!single, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_single: empty input");
     (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
+    if (pub)
+      hipLaunchKernelGGL(count_publish_kernel, dim3(1), dim3(1), 0, stream, d_count,
+                         reinterpret_cast<unsigned long long*>(pub->result),
+                         static_cast<unsigned long long>(pub->epoch) << SPS_EPOCH_SHIFT);
     return check_launch("tgp_connect_coalesce_rows_count");
   }
   CrWs s;
@@ -1625,27 +1612,23 @@ static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const floa
   }
   // (measured r2: splitting the gather into an edge-parallel permute pass + the DIRECT sort kernel costs 114 + 103 us
   //  against 185 us for the fused gather: the 10 M random 4-byte table look-ups take ~50 us wherever they run)
-  hipLaunchKernelGGL(cr_gather_sort_kernel<false>, dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, col, w, E, s.table,
-                     assign_row_ptr, s.seg_src, s.seg_dst, static_cast<const unsigned long long*>(nullptr), s.raw_off, K,
-                     reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out, N, s.long_list);
+  if (pub && pub->csr_col && csr_ptr)
+    hipLaunchKernelGGL((cr_gather_sort_kernel<false, int32_t>), dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, pub->csr_col,
+                       w, E, s.table, assign_row_ptr, s.seg_src, s.seg_dst,
+                       static_cast<const unsigned long long*>(nullptr), s.raw_off, K, reduce_op, flags, eps, s.bad,
+                       s.tmp_c, tmp_w, s.n_out, N, s.long_list);
+  else
+    hipLaunchKernelGGL((cr_gather_sort_kernel<false, int64_t>), dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, col, w, E,
+                       s.table, assign_row_ptr, s.seg_src, s.seg_dst, static_cast<const unsigned long long*>(nullptr),
+                       s.raw_off, K, reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out, N, s.long_list);
   hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cr_long_grid(K)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
                      reduce_op, flags, eps, s.bad, s.long_list, s.n_out);
-  if (single) {
-    // no host read between count and fill: the fill is launched right behind the survivor scan into capacity-E outputs
-    // and a one-thread kernel leaves {epoch, refused, total} for the caller to poll.  (r4: taking the offsets from a
-    // decoupled look-back inside the fill instead of the scan was built and measured SLOWER -- cr_fill_single_kernel,
-    // 107 us against 46 + 19 us: with thousands of short tiles resident at once a prefix only advances one look-back
-    // window per round trip of the uncached status words; kept for the record, not launched.)
-    device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream);
-    hipLaunchKernelGGL(cr_fill_kernel, dim3(cdiv(K, FILL_ROWS)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, s.out_off,
-                       s.total, K, s.bad, single->out_row, single->out_col, w ? single->out_w : nullptr);
-    if (huge)
-      hipLaunchKernelGGL(cr_fill_huge_kernel, dim3(1024), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, s.out_off,
-                         s.n_out, K, h.list, s.bad, single->out_row, single->out_col, w ? single->out_w : nullptr);
-    hipLaunchKernelGGL(cr_publish_kernel, dim3(1), dim3(1), 0, stream, s.bad, s.total,
-                       reinterpret_cast<unsigned long long*>(single->result),
-                       static_cast<unsigned long long>(single->epoch) << SPS_EPOCH_SHIFT);
-    return check_launch("tgp_connect_coalesce_rows_single");
+  if (pub) {
+    hipLaunchKernelGGL(cr_scan_publish_kernel, dim3(cdiv(K, SCAN_TILE)), dim3(256), 0, stream, s.n_out, K, s.out_off,
+                       s.total, s.bad, d_count, reinterpret_cast<unsigned long long*>(pub->status),
+                       reinterpret_cast<unsigned long long*>(pub->result),
+                       static_cast<unsigned long long>(pub->epoch) << SPS_EPOCH_SHIFT);
+    return check_launch("tgp_connect_coalesce_rows_count_published");
   }
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);
   return check_launch("tgp_connect_coalesce_rows_count");
@@ -1660,27 +1643,28 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
                             eps, ws, ws_bytes, d_count, nullptr, stream_);
 }
 
-// The same pipeline WITHOUT the survivor scan, the host read and the separate fill call (r4): the fill follows in the
-// same call, takes its offsets from a decoupled look-back and writes into capacity-E outputs; *result (pinned host
-// memory) receives {epoch << 34 | total}, or {epoch << 34 | 1 << 31 | status} when the pipeline declined (status 8:
-// hub rows, call again with TGP_HUGE_ROWS; anything else: use the other routes).
-extern "C" int64_t tgp_connect_coalesce_rows_single_status_words(int64_t K) { return 2 + cdiv(K > 0 ? K : 1, FILL_ROWS); }
+// The same pipeline with the survivor scan as one launch (decoupled look-back over `status`, epoch-tagged: caller-owned,
+// never cleared) that also stores {epoch << 34 | count} into *result -- pinned host memory the caller polls instead of
+// copying *d_count back; `csr_col`: the int32 columns GraclusSelect's CSR holds for this very list (with csr_ptr).
+extern "C" int64_t tgp_connect_coalesce_rows_count_status_words(int64_t K) { return 2 + cdiv(K > 0 ? K : 1, SCAN_TILE); }
 
-extern "C" int tgp_connect_coalesce_rows_single(const int64_t* row, const int64_t* col, const float* w, int64_t E,
-                                                const int64_t* cluster_index, int64_t N, int64_t K,
-                                                const int32_t* assign_row_ptr, const int32_t* assign_perm,
-                                                const int32_t* csr_ptr, int reduce_op, int flags, float eps, void* ws,
-                                                size_t ws_bytes, int64_t* out_row, int64_t* out_col, float* out_w,
-                                                uint64_t* status, int64_t status_words, uint64_t* result,
-                                                uint32_t epoch, void* stream_) {
-  TGP_REQUIRE(E > 0 && K > 0 && out_row && out_col && (!w || out_w) && status && result, TGP_ERR_INVALID,
-              "tgp_connect_coalesce_rows_single: bad argument");
-  TGP_REQUIRE(status_words >= tgp_connect_coalesce_rows_single_status_words(K), TGP_ERR_WORKSPACE,
-              "tgp_connect_coalesce_rows_single: status buffer too small");
-  TGP_REQUIRE(epoch != 0 && epoch < (1u << 29), TGP_ERR_RANGE, "tgp_connect_coalesce_rows_single: epoch out of range");
-  const CrSingle single{out_row, out_col, out_w, status, result, epoch};
+extern "C" int tgp_connect_coalesce_rows_count_published(const int64_t* row, const int64_t* col, const int32_t* csr_col,
+                                                         const float* w, int64_t E, const int64_t* cluster_index,
+                                                         int64_t N, int64_t K, const int32_t* assign_row_ptr,
+                                                         const int32_t* assign_perm, const int32_t* csr_ptr,
+                                                         int reduce_op, int flags, float eps, void* ws, size_t ws_bytes,
+                                                         int64_t* d_count, uint64_t* status, int64_t status_words,
+                                                         uint64_t* result, uint32_t epoch, void* stream_) {
+  TGP_REQUIRE(status && result && d_count, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_count_published: bad argument");
+  TGP_REQUIRE(status_words >= tgp_connect_coalesce_rows_count_status_words(K), TGP_ERR_WORKSPACE,
+              "tgp_connect_coalesce_rows_count_published: status buffer too small");
+  TGP_REQUIRE(epoch != 0 && epoch < (1u << 29), TGP_ERR_RANGE,
+              "tgp_connect_coalesce_rows_count_published: epoch out of range");
+  TGP_REQUIRE(!csr_col || csr_ptr, TGP_ERR_INVALID,
+              "tgp_connect_coalesce_rows_count_published: int32 columns without the offsets of the same list");
+  const CrPublish pub{csr_col, status, result, epoch};
   return cr_rows_count_impl(row, col, w, E, cluster_index, N, K, assign_row_ptr, assign_perm, csr_ptr, reduce_op, flags,
-                            eps, ws, ws_bytes, nullptr, &single, stream_);
+                            eps, ws, ws_bytes, d_count, &pub, stream_);
 }
 
 // ------------------------------------------------------------------ fused row-sorted path (r3), see cr_fused_kernel
@@ -1952,15 +1936,6 @@ extern "C" int tgp_debug_set_gs_stamps(unsigned long long* p) {
   return hipMemcpyToSymbol(HIP_SYMBOL(tgp::g_gs_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
 }
 #endif
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The host read of a count -> fill pair without a device-to-host copy and a stream synchronise: one thread stores
-// {epoch << 34 | count (34-bit two's complement: decline codes are negative)} into a pinned host word the caller polls.
-__global__ void count_publish_kernel(const int64_t* __restrict__ d_count, unsigned long long* __restrict__ result,
-                                     unsigned long long tag) {
-  __hip_atomic_store(result, tag | (static_cast<unsigned long long>(*d_count) & ((1ull << SPS_EPOCH_SHIFT) - 1)),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 extern "C" int tgp_count_publish(const int64_t* d_count, uint64_t* result, uint32_t epoch, void* stream_) {
   TGP_REQUIRE(d_count && result && epoch > 0 && epoch < (1u << 30), TGP_ERR_INVALID, "tgp_count_publish: bad argument");

@@ -62,10 +62,10 @@ SIGNATURES = {
     "tgp_connect_coalesce_rows_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p,
                                                  _c_int, _c_int, _c_f, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_count_publish": (_c_int, [_c_p, _c_p, ctypes.c_uint32, _c_p]),
-    "tgp_connect_coalesce_rows_single_status_words": (_c_i64, [_c_i64]),
-    "tgp_connect_coalesce_rows_single": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p,
-                                                  _c_int, _c_int, _c_f, _c_p, _c_sz, _c_p, _c_p, _c_p, _c_p, _c_i64,
-                                                  _c_p, ctypes.c_uint32, _c_p]),
+    "tgp_connect_coalesce_rows_count_status_words": (_c_i64, [_c_i64]),
+    "tgp_connect_coalesce_rows_count_published": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p,
+                                                           _c_p, _c_p, _c_int, _c_int, _c_f, _c_p, _c_sz, _c_p, _c_p,
+                                                           _c_i64, _c_p, ctypes.c_uint32, _c_p]),
     "tgp_connect_coalesce_rows_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_p, _c_p, _c_p,
                                                 _c_p]),
     "tgp_connect_coalesce_fused_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),

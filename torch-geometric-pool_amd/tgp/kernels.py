@@ -164,7 +164,6 @@ def _edge_rows(edge_index: Tensor) -> Tuple[Tensor, Tensor]:
 _SPS_STATE: dict = {}  # (device index, stream handle) -> _SpsState
 _SPS_DECLINED: dict = {}
 _PUBLISH_COUNTS = os.environ.get("TGP_PUBLISH_COUNTS", "1") != "0"  # A/B switch of _read_count (read once)
-_ROWS_SINGLE = os.environ.get("TGP_COALESCE_ROWS_SINGLE", "0") == "1"  # A/B switch: fill inside the count call
 SPS_COMPACT_BYTES = 1 << 30  # capacity buffers above this are replaced by exact copies when mostly empty
 
 
@@ -297,6 +296,12 @@ def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_wei
     return x_pool, batch_pool, ei, ew
 
 
+def _decode_count(word: int) -> int:
+    """The count of a published result word: bits 0..33, two's complement (decline codes are negative)."""
+    n = word & ((1 << 34) - 1)
+    return n - (1 << 34) if n >= 1 << 33 else n
+
+
 def _read_count(d_count: Tensor) -> int:
     # the single host wait of a count -> fill pair (the reference pays `.item()` syncs too).  r4: a one-thread kernel
     # stores the count into a pinned host word this thread polls -- a few microseconds instead of the copy kernel +
@@ -308,9 +313,7 @@ def _read_count(d_count: Tensor) -> int:
         state = _sps_state(dev, st, 0)
         epoch = state.next_epoch()
         N.check(N.lib().tgp_count_publish(N.ptr(d_count), state.pinned.data_ptr(), epoch, st), "tgp_count_publish")
-        n = state.wait(epoch) & ((1 << 34) - 1)
-        if n >= 1 << 33:
-            n -= 1 << 34
+        n = _decode_count(state.wait(epoch))
     else:
         n = int(d_count.item())
     if n == -2:  # refusal code of the count kernels: an endpoint (or cluster id) outside its table
@@ -520,42 +523,27 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
         # any other list finds out from the count (-5), once per edge_index object
         hub = _HUB_ROWS.get(id(edge_index))
         hub = hub is not None and hub[0]() is edge_index and hub[1] == edge_index._version
-        single = _ROWS_SINGLE and E > 0 and num_supernodes > 0 and not torch.cuda.is_current_stream_capturing()
+        published = _PUBLISH_COUNTS and not torch.cuda.is_current_stream_capturing()
         for attempt in range(2):
             fl = flags | (N.HUGE_ROWS if hub else 0)
             nbytes = (L.tgp_connect_coalesce_rows_huge_workspace_bytes if hub else
                       L.tgp_connect_coalesce_rows_workspace_bytes)(E, cl.numel(), num_supernodes)
             ws = N.workspace(nbytes, dev)
             st = N.stream_ptr(dev)
-            if single:
-                # r4 experiment (TGP_COALESCE_ROWS_SINGLE=1): no host read in front of the fill, which writes into
-                # capacity-E buffers that are then narrowed; measured slower than the pair below because the host wait
-                # moves to the END of the call, where nothing overlaps it
-                cap = torch.empty(2, E, dtype=torch.int64, device=dev)
-                cap_w = None if w is None else torch.empty(E, dtype=torch.float32, device=dev)
-                state = _sps_state(dev, st, L.tgp_connect_coalesce_rows_single_status_words(num_supernodes))
+            d_count = torch.empty(1, dtype=torch.int64, device=dev)
+            if published:
+                # r4: the survivor scan is one look-back launch whose last workgroup stores the count into a pinned host
+                # word: no scan pair, no copy kernel, no stream synchronise; int32 columns when Select's CSR holds them
+                state = _sps_state(dev, st, L.tgp_connect_coalesce_rows_count_status_words(num_supernodes))
                 epoch = state.next_epoch()
-                cap_p = cap.data_ptr()
-                N.check(L.tgp_connect_coalesce_rows_single(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
-                                                           num_supernodes, N.ptr(assign_index.row_ptr),
-                                                           N.ptr(assign_index.perm),
-                                                           N.ptr(csr[0]) if csr is not None else None,
-                                                           N.REDUCE_OPS[reduce_op], fl, eps, N.ptr(ws), ws.numel(), cap_p,
-                                                           cap_p + 8 * E, N.ptr(cap_w), state.status.data_ptr(),
-                                                           state.status.numel(), state.pinned.data_ptr(), epoch, st),
-                        "tgp_connect_coalesce_rows_single")
-                word = state.wait(epoch)
-                if word & 0x80000000:
-                    code = word & 0xFF  # 8: hub rows; else decline (an id outside its table is reported by the general
-                    n_out = -5 if code == 8 else -1  # route, which the caller takes next)
-                else:
-                    n_out = word & 0x7FFFFFFF
-                    out_ei, out_w = cap[:, :n_out], None if cap_w is None else cap_w[:n_out]
-                    if E * 16 > SPS_COMPACT_BYTES and 4 * n_out < E:
-                        out_ei, out_w = out_ei.contiguous(), None if out_w is None else out_w.clone()
-                    return out_ei, out_w
+                N.check(L.tgp_connect_coalesce_rows_count_published(
+                    N.ptr(row), N.ptr(col), N.ptr(csr[1]) if csr is not None else None, N.ptr(w), E, N.ptr(cl),
+                    cl.numel(), num_supernodes, N.ptr(assign_index.row_ptr), N.ptr(assign_index.perm),
+                    N.ptr(csr[0]) if csr is not None else None, N.REDUCE_OPS[reduce_op], fl, eps, N.ptr(ws),
+                    ws.numel(), N.ptr(d_count), state.status.data_ptr(), state.status.numel(),
+                    state.pinned.data_ptr(), epoch, st), "tgp_connect_coalesce_rows_count_published")
+                n_out = _decode_count(state.wait(epoch))
             else:
-                d_count = torch.empty(1, dtype=torch.int64, device=dev)
                 N.check(L.tgp_connect_coalesce_rows_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(cl), cl.numel(),
                                                           num_supernodes, N.ptr(assign_index.row_ptr),
                                                           N.ptr(assign_index.perm),
