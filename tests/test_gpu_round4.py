@@ -512,3 +512,63 @@ def test_published_count_and_int32_columns_equal_the_plain_count_route(dev, weig
                 assert torch.equal(got_ew, plain_ew) and torch.equal(got_ew, ref_ew)
             else:
                 assert got_ew is None
+
+
+@pytest.mark.parametrize("n,weighted", [(50_000, True), (50_000, False), (200_000, True)])
+def test_ndp_large_partition_with_hub_rows_vs_scipy(dev, n, weighted):
+    """NDPSelect's chip-wide LOBPCG (select/ndp_select.py:187-256) on a graph with hub nodes: rows beyond 1024 entries
+    are listed and reduced by whole workgroups in the start, mat-vec and cut kernels (n <= 131072: the two-launch step
+    with round B folded into the mat-vec; beyond: the three-launch step).  Same contract as the hub-free test: the
+    Rayleigh quotient equals scipy's largest eigenvalue of Ls within 1e-6, the residual meets the tolerance, the cut
+    of the returned partition is the one the kernels report."""
+    import numpy as np
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from tgp import kernels as K
+    g = torch.Generator().manual_seed(n + int(weighted))
+    a = torch.randint(0, n, (4 * n,), generator=g)
+    b = torch.randint(0, n, (4 * n,), generator=g)
+    hubs = [0, 1, 2, n // 2, n - 1]                      # neighbouring hubs + two elsewhere
+    degs = [30_000, 5_000, 1_500, 12_000, 2_000]         # one barely beyond the threshold
+    ha = torch.cat([torch.full((d,), h) for h, d in zip(hubs, degs)])
+    hb = torch.cat([torch.randint(0, n, (d,), generator=g) for d in degs])
+    a, b = torch.cat([a, ha]), torch.cat([b, hb])
+    keep = a != b
+    a, b = a[keep], b[keep]
+    key = torch.unique(torch.cat([a * n + b, b * n + a]))
+    ei = torch.stack([key // n, key % n])
+    if weighted:
+        k2 = torch.minimum(ei[0], ei[1]) * n + torch.maximum(ei[0], ei[1])
+        w = ((k2 * 2654435761) % 1000).float() / 1000 + 0.5
+    else:
+        w = None
+    vals = np.ones(ei.size(1)) if w is None else w.double().numpy()
+    A = sp.coo_matrix((vals, (ei[0].numpy(), ei[1].numpy())), shape=(n, n)).tocsr()
+    deg = np.asarray(A.sum(1)).reshape(-1)
+    assert int((np.diff(A.indptr) > 1024).sum()) == len(hubs)
+    dis = np.where(deg > 0, 1.0 / np.sqrt(np.maximum(deg, 1e-300)), 0.0)
+    Ls = sp.eye(n) - sp.diags(dis) @ A @ sp.diags(dis)
+    lam_ref = float(spla.eigsh(Ls.tocsc(), k=1, which="LA", tol=1e-10, return_eigenvectors=False)[0])
+    eid = ei.to(dev)
+    wd = None if w is None else w.to(dev)
+    indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    K.rowptr_from_sorted(eid[0], n, indptr)
+    keepv = torch.zeros(n, dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    info, state = K.ndp_partition_large(indptr, eid[1], wd, 0, n, 7, keepv, status, want_state=True)
+    assert int(status.item()) == 0
+    assert abs(state["lambda"] - lam_ref) <= 1e-6 * lam_ref, (state, lam_ref)
+    assert state["residual_sq"] <= (1e-6 * state["lambda"]) ** 2 * 1.0001
+    kb = keepv.bool().cpu()
+    assert 0 < int(kb.sum()) < n
+    z = np.where(kb.numpy(), 1.0, -1.0)
+    L = sp.diags(deg) - A
+    cut = float(z @ (L @ z)) / (2.0 * A.sum())
+    if int(info.item()) >= 0:
+        assert cut >= 0.5 and abs(cut - state["cut"]) < 1e-9
+    else:
+        assert bool(kb[0]) and not bool(kb[1])
+    # the same call again gives the same partition bit for bit (the hub list is sorted: fixed summation order)
+    keep2 = torch.zeros(n, dtype=torch.uint8, device=dev)
+    info2, state2 = K.ndp_partition_large(indptr, eid[1], wd, 0, n, 7, keep2, status, want_state=True)
+    assert torch.equal(keep2, keepv) and state2["lambda"] == state["lambda"] and state2["steps"] == state["steps"]

@@ -617,6 +617,15 @@ __global__ __launch_bounds__(64) void ndp_partition_wave_kernel(const int32_t* _
 // of vector traffic per round at N = 1M plus one pass over the CSR.
 constexpr int NL_BLOCKS = 512;      // partial-sum slots (grid of every reducing kernel)
 constexpr int NL_THREADS = 256;
+// r4: HUB ROWS.  Every kernel that walks the CSR gives a row to one thread (start, cut) or one 16-lane group (mat-vec):
+// a 100 000-entry row -- the hub of a power-law graph -- was then 6 000 dependent trips per LOBPCG step for one group
+// while the chip idled (ten such hubs in a 1M-node graph: 7.4 ms per step against 0.15; 200 ms per partition against 5).
+// Rows beyond NL_HUB entries are listed once per call (sorted: every sum keeps a fixed order) and each is reduced by a
+// WHOLE WORKGROUP, four entries per thread in flight, in a second phase of the same kernels; workgroup h % grid takes
+// listed row h, so neighbouring hubs (the first nodes of a preferential-attachment graph) spread over the chip.  More
+// than NL_HUB_CAP such rows: the surplus is not listed and keeps the in-line path (a row is a hub iff it is LISTED).
+constexpr int NL_HUB = 1024;
+constexpr int NL_HUB_CAP = 4096;
 
 struct NlState {        // device-resident scalars of the iteration
   double lam, rn2, inv_r, cxp, cwp, c0, c1, c2p, sp, scale, vol, x2, cut;
@@ -632,6 +641,10 @@ struct NlVecs {
   double* part_a;      // [NL_BLOCKS][4]   sums of the residual round  (fused steps: nl_update_a_kernel -> nl_matvec2_kernel)
   double* part_b;      // [NL_BLOCKS][16]  Gram sums of the basis      (nl_round_b2_kernel -> nl_update_a_kernel)
   NlState* st;
+  int32_t* hub;        // [NL_HUB_CAP] listed hub rows, ascending (nl_hub_setup_kernel)
+  int32_t* hub_raw;    // [NL_HUB_CAP] the same in arrival order (nl_init_kernel)
+  int* hub_cnt;        // [0] rows that asked for a place in the list, [1] rows listed
+  double* hub_part;    // [NL_HUB_CAP][2] degree and start-vector square of every listed row (start only)
 };
 
 static size_t nl_layout(void* ws, int64_t n, NlVecs* out) {
@@ -646,8 +659,60 @@ static size_t nl_layout(void* ws, int64_t n, NlVecs* out) {
   v.wv = c.take<double>(m); v.aw = c.take<double>(m); v.raw = c.take<double>(m);
   v.ts = c.take<double>(m);
   v.dis = c.take<float>(m);
+  v.hub = c.take<int32_t>(NL_HUB_CAP);
+  v.hub_raw = c.take<int32_t>(NL_HUB_CAP);
+  v.hub_cnt = c.take<int>(4);
+  v.hub_part = c.take<double>(NL_HUB_CAP * 2);
   if (out) *out = v;
   return c.off;
+}
+
+// is row i (more than NL_HUB entries) one of the nh listed rows?  (binary search; only rows that long ever ask)
+__device__ __forceinline__ bool nl_listed(const int32_t* __restrict__ hub, int nh, int64_t i) {
+  int lo = 0, hi = nh;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (hub[mid] < i) lo = mid + 1; else hi = mid;
+  }
+  return lo < nh && hub[lo] == i;
+}
+
+// sum over the entries e of a hub row [a, b) of  w[e] * g(col[e] - p0)  by the WHOLE workgroup: four entries per thread
+// in flight, every load unconditional (clamped), level by level; fixed order (thread-strided, then the workgroup tree).
+// Entries that leave [p0, p0 + n) are dropped (and flagged when `status` is given).  Every thread gets the sum.
+template <typename G>
+__device__ __forceinline__ double nl_hub_row(const int64_t* __restrict__ col, const float* __restrict__ w, int a, int b,
+                                             int64_t p0, int64_t n, int* __restrict__ status, G g, double* s_red) {
+  constexpr int U = 4;
+  double acc = 0.0;
+  for (int e0 = a + static_cast<int>(threadIdx.x); e0 < b; e0 += U * NL_THREADS) {
+    int64_t c[U];
+    float ww[U];
+    bool ok[U];
+    double t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = e0 + u * NL_THREADS;
+      ok[u] = idx < b;
+      const int ci = ok[u] ? idx : a;
+      c[u] = col[ci];
+      ww[u] = w ? w[ci] : 1.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = c[u] - p0;
+      const bool inr = static_cast<uint64_t>(j) < static_cast<uint64_t>(n);
+      if (ok[u] && !inr && status) atomicOr(status, 2);
+      ok[u] = ok[u] && inr;
+      t[u] = g(inr ? j : 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += ok[u] ? static_cast<double>(ww[u]) * t[u] : 0.0;
+  }
+  double sv[1] = {acc};
+  __syncthreads();  // s_red may still be read by the previous row's tree
+  ndp_block_sums<NL_THREADS, 1>(sv, s_red);
+  return sv[0];
 }
 
 template <int K>
@@ -725,7 +790,17 @@ __global__ __launch_bounds__(NL_THREADS) void nl_init_kernel(const int32_t* __re
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
        i += static_cast<int64_t>(NL_BLOCKS) * NL_THREADS) {
     double d = 0.0;
-    for (int e = indptr[p0 + i]; e < indptr[p0 + i + 1]; ++e) d += w ? static_cast<double>(w[e]) : 1.0;
+    const int ra = indptr[p0 + i], rb = indptr[p0 + i + 1];
+    if (rb - ra > NL_HUB) {  // a hub row: listed, its degree / start entry / sums come from nl_hub_setup_kernel
+      const int pos = atomicAdd(v.hub_cnt, 1);
+      if (pos < NL_HUB_CAP) {
+        v.hub_raw[pos] = static_cast<int32_t>(i);
+        continue;
+      }
+    }
+    if (!w) d = static_cast<double>(rb - ra);
+    else
+      for (int e = ra; e < rb; ++e) d += static_cast<double>(w[e]);
     v.dis[i] = d > 0.0 ? static_cast<float>(1.0 / sqrt(d)) : 0.f;
     const double x0 =
         (static_cast<double>(ndp_hash(0x5EEDull, static_cast<uint64_t>(i) + 977ull * static_cast<uint64_t>(n)) >> 8) /
@@ -737,9 +812,83 @@ __global__ __launch_bounds__(NL_THREADS) void nl_init_kernel(const int32_t* __re
   nl_store_partials<2>(s, v.partial);
 }
 
+// The listed hub rows in ascending order (every workgroup sorts the few of them in LDS; workgroup 0 writes the list),
+// then what nl_init_kernel does for a row, one workgroup per hub row.
+__global__ __launch_bounds__(NL_THREADS) void nl_hub_setup_kernel(const int32_t* __restrict__ indptr,
+                                                                  const float* __restrict__ w, int64_t p0, int64_t n,
+                                                                  NlVecs v) {
+  __shared__ int32_t s_list[NL_HUB_CAP];
+  __shared__ double s_red[NL_THREADS / 64];
+  const int asked = v.hub_cnt[0];
+  const int nh = asked < NL_HUB_CAP ? asked : NL_HUB_CAP;
+  if (nh == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) v.hub_cnt[1] = 0;
+    return;
+  }
+  int P = 1;
+  while (P < nh) P <<= 1;
+  for (int t = threadIdx.x; t < P; t += NL_THREADS) s_list[t] = t < nh ? v.hub_raw[t] : 0x7FFFFFFF;
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < P; t += NL_THREADS) {
+        const int x = t ^ j;
+        if (x > t) {
+          const int32_t lo = s_list[t], hi = s_list[x];
+          if ((lo > hi) == ((t & k) == 0)) {
+            s_list[t] = hi;
+            s_list[x] = lo;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (int t = threadIdx.x; t < nh; t += NL_THREADS) v.hub[t] = s_list[t];
+    if (threadIdx.x == 0) v.hub_cnt[1] = nh;
+  }
+  for (int h = blockIdx.x; h < nh; h += gridDim.x) {
+    const int64_t i = s_list[h];
+    const int a = indptr[p0 + i], b = indptr[p0 + i + 1];
+    double d;
+    if (!w) {
+      d = static_cast<double>(b - a);
+    } else {
+      double sv[1] = {0.0};
+      for (int e = a + static_cast<int>(threadIdx.x); e < b; e += NL_THREADS) sv[0] += static_cast<double>(w[e]);
+      __syncthreads();
+      ndp_block_sums<NL_THREADS, 1>(sv, s_red);
+      d = sv[0];
+    }
+    if (threadIdx.x == 0) {
+      v.dis[i] = d > 0.0 ? static_cast<float>(1.0 / sqrt(d)) : 0.f;
+      const double x0 =
+          (static_cast<double>(ndp_hash(0x5EEDull, static_cast<uint64_t>(i) + 977ull * static_cast<uint64_t>(n)) >> 8) /
+           8388608.0) - 1.0;
+      v.raw[i] = x0;
+      v.hub_part[2 * h] = d;
+      v.hub_part[2 * h + 1] = x0 * x0;
+    }
+  }
+}
+
 __global__ __launch_bounds__(NL_THREADS) void nl_init_reduce_kernel(NlVecs v, int max_iter) {
   double s[2];
   nl_reduce_partials<2>(v.partial, s);
+  {  // the hub rows' share, in list (= row) order
+    __shared__ double s_hub[2 * (NL_THREADS / 64)];
+    const int nh = v.hub_cnt[1];
+    double hv[2] = {0.0, 0.0};
+    for (int h = threadIdx.x; h < nh; h += NL_THREADS) {
+      hv[0] += v.hub_part[2 * h];
+      hv[1] += v.hub_part[2 * h + 1];
+    }
+    __syncthreads();
+    ndp_block_sums<NL_THREADS, 2>(hv, s_hub);
+    s[0] += hv[0];
+    s[1] += hv[1];
+  }
   if (threadIdx.x == 0) {
     NlState* st = v.st;
     st->vol = s[0];
@@ -762,9 +911,11 @@ __global__ __launch_bounds__(NL_THREADS) void nl_first_matvec_kernel(const int32
                                                                      int64_t p1, NlVecs v, int* __restrict__ status) {
   const int64_t n = p1 - p0;
   const double inv = v.st->x2 > 0.0 ? 1.0 / sqrt(v.st->x2) : 0.0;
+  const int nh = v.hub_cnt[1];
   double s[1] = {0.0};
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
        i += static_cast<int64_t>(NL_BLOCKS) * NL_THREADS) {
+    if (indptr[p0 + i + 1] - indptr[p0 + i] > NL_HUB && nl_listed(v.hub, nh, i)) continue;  // second phase
     const double xi = v.raw[i] * inv;
     const double axi = xi - inv * nl_row_matvec(indptr, col, w, v.dis, v.raw, p0, p1, i, status);
     v.x[i] = xi;
@@ -772,6 +923,25 @@ __global__ __launch_bounds__(NL_THREADS) void nl_first_matvec_kernel(const int32
     v.pv[i] = 0.0;
     v.ap[i] = 0.0;
     s[0] += xi * axi;
+  }
+  {  // hub rows: one workgroup each
+    __shared__ double s_hub[NL_THREADS / 64];
+    const float* dis = v.dis;
+    const double* raw = v.raw;
+    for (int h = blockIdx.x; h < nh; h += gridDim.x) {
+      const int64_t i = v.hub[h];
+      const double acc = nl_hub_row(col, w, indptr[p0 + i], indptr[p0 + i + 1], p0, n, status,
+                                    [=](int64_t j) { return static_cast<double>(dis[j]) * raw[j]; }, s_hub);
+      if (threadIdx.x == 0) {
+        const double xi = v.raw[i] * inv;
+        const double axi = xi - inv * (static_cast<double>(v.dis[i]) * acc);
+        v.x[i] = xi;
+        v.ax[i] = axi;
+        v.pv[i] = 0.0;
+        v.ap[i] = 0.0;
+        s[0] += xi * axi;
+      }
+    }
   }
   nl_store_partials<1>(s, v.partial);
 }
@@ -881,17 +1051,20 @@ __global__ __launch_bounds__(NL_THREADS) void nl_matvec_kernel(const int32_t* __
   const int sub = threadIdx.x % NL_G;
   const int64_t ngroups = static_cast<int64_t>(gridDim.x) * (NL_THREADS / NL_G);
   const int e_first = indptr[p0];  // a valid entry index whenever any loop below runs
+  const int nh = v.hub_cnt[1];
   for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * (NL_THREADS / NL_G) + threadIdx.x / NL_G; i0 < n;
        i0 += ngroups * NL_U) {
     int e[NL_U], e1[NL_U];
     double acc[NL_U];
     double r_i[NL_U], x_i[NL_U], ax_i[NL_U], p_i[NL_U], ap_i[NL_U];  // the row's own entries, requested with its offsets
     float d_i[NL_U];
+    bool hub_i[NL_U];
 #pragma unroll
     for (int u = 0; u < NL_U; ++u) {
       const int64_t i = i0 + u * ngroups;
       const int64_t ic = i < n ? i : n - 1;
       const int a = indptr[p0 + ic], b = indptr[p0 + ic + 1];
+      hub_i[u] = b - a > NL_HUB && nl_listed(v.hub, nh, ic);  // a listed hub row: the second phase below takes it
       r_i[u] = v.raw[ic];
       d_i[u] = v.dis[ic];
       if constexpr (FOLD_B) {
@@ -901,7 +1074,7 @@ __global__ __launch_bounds__(NL_THREADS) void nl_matvec_kernel(const int32_t* __
         ap_i[u] = v.ap[ic];
       }
       e[u] = a + sub;
-      e1[u] = i < n ? b : a;
+      e1[u] = (i < n && !hub_i[u]) ? b : a;
       acc[u] = 0.0;
     }
     bool more = false;
@@ -941,7 +1114,7 @@ __global__ __launch_bounds__(NL_THREADS) void nl_matvec_kernel(const int32_t* __
 #pragma unroll
       for (int o = NL_G / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, WAVE);
       const int64_t i = i0 + u * ngroups;
-      if (sub == 0 && i < n) {
+      if (sub == 0 && i < n && !hub_i[u]) {
         const double ri = r_i[u];
         const double wi = ri * inv_r, awi = inv_r * (ri - static_cast<double>(d_i[u]) * a);
         v.wv[i] = wi;
@@ -952,6 +1125,43 @@ __global__ __launch_bounds__(NL_THREADS) void nl_matvec_kernel(const int32_t* __
           if (has_p) {
             pi = p_i[u] - cxp * xi - cwp * wi;
             api = ap_i[u] - cxp * axi - cwp * awi;
+            v.pv[i] = pi;
+            v.ap[i] = api;
+          }
+          sb[0] += pi * pi;
+          sb[1] += xi * awi;
+          sb[2] += wi * awi;
+          sb[3] += xi * api;
+          sb[4] += wi * api;
+          sb[5] += pi * api;
+          sb[6] += xi * xi;
+          sb[7] += xi * wi;
+          sb[8] += xi * pi;
+          sb[9] += wi * wi;
+          sb[10] += wi * pi;
+          sb[11] += xi * axi;
+        }
+      }
+    }
+  }
+  {  // hub rows: one workgroup each, what the loop above does for a row done by thread 0 behind the workgroup's sum
+    __shared__ double s_hub[NL_THREADS / 64];
+    const double* ts = v.ts;
+    for (int h = blockIdx.x; h < nh; h += gridDim.x) {
+      const int64_t i = v.hub[h];
+      const double a = nl_hub_row(col, w, indptr[p0 + i], indptr[p0 + i + 1], p0, n, status,
+                                  [=](int64_t j) { return ts[j]; }, s_hub);
+      if (threadIdx.x == 0) {
+        const double ri = v.raw[i];
+        const double wi = ri * inv_r, awi = inv_r * (ri - static_cast<double>(v.dis[i]) * a);
+        v.wv[i] = wi;
+        v.aw[i] = awi;
+        if constexpr (FOLD_B) {
+          const double xi = v.x[i], axi = v.ax[i];
+          double pi = 0.0, api = 0.0;
+          if (has_p) {
+            pi = v.pv[i] - cxp * xi - cwp * wi;
+            api = v.ap[i] - cxp * axi - cwp * awi;
             v.pv[i] = pi;
             v.ap[i] = api;
           }
@@ -1223,14 +1433,25 @@ __global__ __launch_bounds__(NL_THREADS) void nl_cut_kernel(const int32_t* __res
   const int64_t n = p1 - p0;
   double s[1] = {0.0};
   if (!v.st->random_part) {
+    const int nh = v.hub_cnt[1];
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * NL_THREADS + threadIdx.x; i < n;
          i += static_cast<int64_t>(NL_BLOCKS) * NL_THREADS) {
+      if (indptr[p0 + i + 1] - indptr[p0 + i] > NL_HUB && nl_listed(v.hub, nh, i)) continue;  // second phase
       const bool zi = v.x[i] >= 0.0;
       for (int e = indptr[p0 + i]; e < indptr[p0 + i + 1]; ++e) {
         const int64_t c = col[e];
         if (c < p0 || c >= p1) continue;
         if ((v.x[c - p0] >= 0.0) != zi) s[0] += w ? static_cast<double>(w[e]) : 1.0;
       }
+    }
+    __shared__ double s_hub[NL_THREADS / 64];
+    const double* x = v.x;
+    for (int h = blockIdx.x; h < nh; h += gridDim.x) {  // hub rows: one workgroup each
+      const int64_t i = v.hub[h];
+      const bool zi = v.x[i] >= 0.0;
+      const double acc = nl_hub_row(col, w, indptr[p0 + i], indptr[p0 + i + 1], p0, n, static_cast<int*>(nullptr),
+                                    [=](int64_t j) { return (x[j] >= 0.0) != zi ? 1.0 : 0.0; }, s_hub);
+      if (threadIdx.x == 0) s[0] += acc;
     }
   }
   nl_store_partials<1>(s, v.partial);
@@ -1411,7 +1632,9 @@ extern "C" int tgp_ndp_large_start(const int32_t* indptr, const int64_t* col, co
   NlVecs v;
   nl_layout(ws, p1 - p0, &v);
   const int64_t n = p1 - p0;
+  (void)hipMemsetAsync(v.hub_cnt, 0, 4 * sizeof(int), stream);
   hipLaunchKernelGGL(nl_init_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, indptr, w, p0, n, v);
+  hipLaunchKernelGGL(nl_hub_setup_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, indptr, w, p0, n, v);
   hipLaunchKernelGGL(nl_init_reduce_kernel, dim3(1), dim3(NL_THREADS), 0, stream, v, max_iter);
   hipLaunchKernelGGL(nl_first_matvec_kernel, dim3(NL_BLOCKS), dim3(NL_THREADS), 0, stream, indptr, col, w, p0, p1, v,
                      d_status);
