@@ -114,7 +114,13 @@ __global__ __launch_bounds__(256) void gm_symmetrise_kernel(const int32_t* __res
   else wt[p] = fmaxf(wt[p], wt[q]);
 }
 
-constexpr int GM_LONG_ROW = 256;  // rows beyond this many entries are scanned by a whole wave (see gm_best_neighbour_wave)
+constexpr int GM_LONG_ROW = 256;  // rows beyond this many entries are scanned by whole waves (see gm_best_neighbour_wave)
+// r4: a long row is dealt out in CHUNKS of GM_CHUNK entries -- one ticket (an 8-word record {row, chunk, best j, w, hash,
+// min, max, arrivals}) per chunk -- so that a 100 000-entry hub is scanned by 25 waves at once instead of one; the wave
+// that brings a row's last chunk folds the chunk bests (the key is a total order: any dealing gives the sequential
+// scan's answer) and writes the candidate.  Rows of at most GM_CHUNK entries have one ticket and no fold.
+constexpr int GM_CHUNK = 4096;
+constexpr int GM_REC = 8;  // int32 words per ticket record
 __global__ __launch_bounds__(256) void gm_init_kernel(int64_t n, int64_t* __restrict__ label,
                                                       uint8_t* __restrict__ is_free,
                                                       const int32_t* __restrict__ row_ptr,
@@ -123,7 +129,17 @@ __global__ __launch_bounds__(256) void gm_init_kernel(int64_t n, int64_t* __rest
   if (i < n) {
     label[i] = i;
     is_free[i] = 1;
-    if (row_ptr[i + 1] - row_ptr[i] > GM_LONG_ROW) long_list[atomicAdd(long_ctr, 1u)] = static_cast<int32_t>(i);
+    const int32_t deg = row_ptr[i + 1] - row_ptr[i];
+    if (deg > GM_LONG_ROW) {
+      const int nch = (deg + GM_CHUNK - 1) / GM_CHUNK;
+      const unsigned int base = atomicAdd(long_ctr, static_cast<unsigned int>(nch));
+      for (int c = 0; c < nch; ++c) {
+        int32_t* rec = long_list + static_cast<size_t>(base + c) * GM_REC;
+        rec[0] = static_cast<int32_t>(i);
+        rec[1] = c;
+        rec[7] = 0;
+      }
+    }
   }
 }
 
@@ -190,30 +206,66 @@ __device__ __forceinline__ bool gm_key_better(bool have, float bw, uint32_t bh, 
   if (oa != ca) return oa > ca;
   return ob > cb;
 }
-template <typename FreeFn>
-__device__ __forceinline__ int32_t gm_best_neighbour_wave(int64_t i, const int32_t* __restrict__ row_ptr,
-                                                          const int32_t* __restrict__ nbr,
-                                                          const float* __restrict__ wt, FreeFn is_free_of) {
-  const int32_t lo = row_ptr[i], hi = row_ptr[i + 1];
-  int32_t best = -1;
-  float bw = 0.f;
-  uint32_t bh = 0, ba = 0, bb = 0;
-  for (int32_t p = lo + lane_id(); p < hi; p += 64) {
-    const int32_t j = nbr[p];
-    const float wj = wt[p];
-    if (j < 0 || j == i || wj != wj || !is_free_of(j)) continue;
-    const uint32_t a = static_cast<uint32_t>(i < j ? i : j), b = static_cast<uint32_t>(i < j ? j : i);
-    const uint32_t h = pair_hash(a, b);
-    if (gm_key_better(best >= 0, bw, bh, ba, bb, true, wj, h, a, b)) { best = j; bw = wj; bh = h; ba = a; bb = b; }
-  }
+struct GmBest {  // a candidate under the edge key (w, hash, min, max); j < 0: none
+  int32_t j;
+  float w;
+  uint32_t h, a, b;
+};
+__device__ __forceinline__ void gm_fold(GmBest& x, const GmBest& o) {
+  if (gm_key_better(x.j >= 0, x.w, x.h, x.a, x.b, o.j >= 0, o.w, o.h, o.a, o.b)) x = o;
+}
+__device__ __forceinline__ GmBest gm_wave_fold(GmBest x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const int32_t oj = __shfl_xor(best, o, 64);
-    const float ow = __shfl_xor(bw, o, 64);
-    const uint32_t oh = __shfl_xor(bh, o, 64), oa = __shfl_xor(ba, o, 64), ob = __shfl_xor(bb, o, 64);
-    if (gm_key_better(best >= 0, bw, bh, ba, bb, oj >= 0, ow, oh, oa, ob)) { best = oj; bw = ow; bh = oh; ba = oa; bb = ob; }
+    GmBest y;
+    y.j = __shfl_xor(x.j, o, 64);
+    y.w = __shfl_xor(x.w, o, 64);
+    y.h = __shfl_xor(x.h, o, 64);
+    y.a = __shfl_xor(x.a, o, 64);
+    y.b = __shfl_xor(x.b, o, 64);
+    gm_fold(x, y);
   }
-  return best;
+  return x;
+}
+// entries [lo, hi) of row i by the whole wave; every lane returns the wave's best
+template <typename FreeFn>
+__device__ __forceinline__ GmBest gm_best_neighbour_wave(int64_t i, int32_t lo, int32_t hi,
+                                                         const int32_t* __restrict__ nbr,
+                                                         const float* __restrict__ wt, FreeFn is_free_of) {
+  GmBest x{-1, 0.f, 0u, 0u, 0u};
+  // r4: eight entries per lane in flight (512 per wave and trip), every load unconditional from a clamped position,
+  // level by level -- entries, then their free flags: one entry per lane and trip made a 100 000-entry row 1 563
+  // dependent round trips (1.5 ms; ten such hubs were 1.5 of the 1.8 ms the whole matching of a 1M-node graph took).
+  // The key is a total order, so the fold does not depend on how the entries are dealt to the lanes.
+  constexpr int U = 8;
+  for (int32_t p0 = lo + lane_id(); p0 < hi; p0 += 64 * U) {
+    int32_t js[U];
+    float ws[U];
+    bool fs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int32_t p = p0 + 64 * u;
+      const bool in = p < hi;
+      const int32_t pc = in ? p : lo;
+      const int32_t j = nbr[pc];
+      js[u] = in ? j : -1;
+      ws[u] = wt[pc];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool f = is_free_of(js[u] >= 0 ? js[u] : static_cast<int32_t>(i));  // (a valid node id either way)
+      fs[u] = f && js[u] >= 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int32_t j = js[u];
+      const float wj = ws[u];
+      if (!fs[u] || j == i || wj != wj) continue;
+      const uint32_t a = static_cast<uint32_t>(i < j ? i : j), b = static_cast<uint32_t>(i < j ? j : i);
+      gm_fold(x, GmBest{j, wj, pair_hash(a, b), a, b});
+    }
+  }
+  return gm_wave_fold(x);
 }
 
 // Proposal of a wave's nodes: short rows lane by lane; long rows are left to gm_steal_long_rows.  `mine`: this lane
@@ -247,12 +299,44 @@ __device__ __forceinline__ void gm_steal_long_rows(const int32_t* __restrict__ r
     }
     t = __shfl(t, 0, 64);
     if (t >= count) return;
-    const int32_t i = long_list[t];
-    if (!owner_free(i)) continue;  // (its candidate is already -1)
-    const int32_t r = gm_best_neighbour_wave(i, row_ptr, nbr, wt, is_free_of);
+    int32_t* rec = const_cast<int32_t*>(long_list) + static_cast<size_t>(t) * GM_REC;
+    const int32_t i = rec[0], c = rec[1];
+    if (!owner_free(i)) continue;  // (its candidate is already -1; every chunk of the row sees the same flag: it is only
+                                   //  cleared by the wave that folds the row, after all chunks have arrived)
+    const int32_t lo = row_ptr[i], hi = row_ptr[i + 1];
+    const int nch = (hi - lo + GM_CHUNK - 1) / GM_CHUNK;
+    const int32_t clo = lo + c * GM_CHUNK;
+    GmBest r = gm_best_neighbour_wave(i, clo, clo + GM_CHUNK < hi ? clo + GM_CHUNK : hi, nbr, wt, is_free_of);
+    if (nch > 1) {
+      int32_t* rec0 = rec - static_cast<size_t>(c) * GM_REC;  // a row's tickets are consecutive, chunk 0 first
+      int last = 0;
+      if (lane_id() == 0) {
+        __hip_atomic_store(rec + 2, r.j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + 3, static_cast<int32_t>(__float_as_uint(r.w)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + 4, static_cast<int32_t>(r.h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + 5, static_cast<int32_t>(r.a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + 6, static_cast<int32_t>(r.b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = __hip_atomic_fetch_add(rec0 + 7, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nch - 1;
+      }
+      last = __shfl(last, 0, 64);
+      if (!last) continue;
+      GmBest x{-1, 0.f, 0u, 0u, 0u};
+      for (int k = lane_id(); k < nch; k += 64) {
+        const int32_t* q = rec0 + static_cast<size_t>(k) * GM_REC;
+        GmBest y;
+        y.j = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        y.w = __uint_as_float(static_cast<uint32_t>(__hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        y.h = static_cast<uint32_t>(__hip_atomic_load(q + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        y.a = static_cast<uint32_t>(__hip_atomic_load(q + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        y.b = static_cast<uint32_t>(__hip_atomic_load(q + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        gm_fold(x, y);
+      }
+      r = gm_wave_fold(x);
+      if (lane_id() == 0) __hip_atomic_store(rec0 + 7, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next round
+    }
     if (lane_id() == 0) {
-      if (r < 0) is_free[i] = 0;  // retire (see gm_propose_kernel)
-      cand[i] = r;
+      if (r.j < 0) is_free[i] = 0;  // retire (see gm_propose_kernel)
+      cand[i] = r.j;
     }
   }
 }
@@ -512,7 +596,8 @@ __global__ __launch_bounds__(1024) void gm_tail_rounds_kernel(const int32_t* __r
       while (lm) {
         const int l = __ffsll(static_cast<long long>(lm)) - 1;
         lm &= lm - 1;
-        const int32_t r = gm_best_neighbour_wave(__shfl(i, l, 64), row_ptr, nbr, wt, free_of);
+        const int32_t il = __shfl(i, l, 64);
+        const int32_t r = gm_best_neighbour_wave(il, row_ptr[il], row_ptr[il + 1], nbr, wt, free_of).j;
         if (lane_id() == l) c = r;
       }
       if (mine && c < 0) is_free[i] = 0;  // retire (see gm_propose_kernel)
@@ -779,7 +864,7 @@ extern "C" size_t tgp_graclus_match_workspace_bytes(int64_t num_nodes, int64_t n
   return align_up(e * sizeof(int32_t)) + align_up(e * sizeof(float)) + align_up(n) + align_up(n * sizeof(int32_t)) +
          align_up((n / 32 + 8) * sizeof(uint32_t)) + align_up(e * sizeof(int32_t)) +
          align_up((e / 256 + 2) * sizeof(unsigned long long)) + align_up((GM_TAIL_CAP + 16) * sizeof(int32_t)) +
-         align_up((e / GM_LONG_ROW + 8) * sizeof(int32_t)) + 512;
+         align_up((4 + GM_REC * (e / GM_LONG_ROW + e / GM_CHUNK + 8)) * sizeof(int32_t)) + 512;
 }
 
 // rows of more than GM_LONG_ROW entries (listed by the init kernel) and {count, next ticket}: behind everything else
@@ -795,8 +880,8 @@ static void gm_long_ptrs(void* ws, int64_t num_nodes, int64_t num_edges, int32_t
   (void)cv.take<unsigned long long>(num_edges / 256 + 2);
   (void)cv.take<int>(4);
   (void)cv.take<int32_t>(GM_TAIL_CAP + 16);
-  int32_t* l = cv.take<int32_t>(e / GM_LONG_ROW + 8);
-  *ctr = reinterpret_cast<unsigned int*>(l);  // [0] count, [1] next ticket; the list starts at l + 4
+  int32_t* l = cv.take<int32_t>(4 + GM_REC * (e / GM_LONG_ROW + e / GM_CHUNK + 8));
+  *ctr = reinterpret_cast<unsigned int*>(l);  // [0] tickets, [1] next ticket; the ticket records start at l + 4
   *list = l + 4;
 }
 
