@@ -424,6 +424,21 @@ int tgp_graclus_match_max_graph_nodes(void);
 int tgp_graclus_match_graphs(const int32_t* row_ptr, int64_t num_nodes, int64_t num_edges, void* ws,
                              const int64_t* graph_ptr, int64_t num_graphs, int64_t max_graph_nodes, int64_t* label,
                              int* d_status, void* stream);
+/* r4: the whole GraclusSelect of a sorted batch of SMALL graphs in ONE launch -- matching (select/graclus_select.py:66, the
+ * pairs of tgp_graclus_match_graphs), consecutive cluster ids (`:68-70`, as tgp_graclus_relabel_i64) and the supernode ->
+ * members index -- from the row-sorted edge list itself (no CSR, no workspace): one wave per graph of at most
+ * tgp_graclus_match_graphs_fused_max_graph_nodes() (= 64) nodes and 512 entries.  index [2, N] int64 (row 0 = 0..N-1, row
+ * 1 = cluster id), assign_row_ptr [N + 1] / assign_perm [N] int32 (the first K + 1 offsets are written), ones [N] fp32,
+ * label [N] int64 (NULL ok: the pair's smaller node id).  `status` / `epoch` / `*result` as for tgp_sparse_pool_small_f32:
+ * *result = {epoch << 34 | K}, or {epoch << 34 | 1 << 31 | ...} when the kernel refused (a graph beyond 64 nodes or 512
+ * entries, an entry that leaves its graph, rows not ascending): run tgp_graclus_match_start + _graphs / _rounds then. */
+int tgp_graclus_match_graphs_fused_max_graph_nodes(void);
+int64_t tgp_graclus_match_graphs_fused_status_words(int64_t num_graphs);
+int tgp_graclus_match_graphs_fused(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
+                                   int64_t num_nodes, int64_t num_edges, const int64_t* graph_ptr, int64_t num_graphs,
+                                   int64_t* label /* NULL ok */, int64_t* index, int32_t* assign_row_ptr,
+                                   int32_t* assign_perm, float* ones, uint64_t* status, int64_t status_words,
+                                   uint64_t* result, uint32_t epoch, void* stream);
 /* Matching labels -> consecutive cluster ids, the torch.unique(cluster, return_inverse=True) of the reference's
  * select/graclus_select.py:66-70 without a sort (representatives label[r] == r keep their order, which is the order
  * unique() gives: the label of a pair is its smaller node id).  index_out [2, N] int64: row 0 = 0..N-1, row 1 = ids;

@@ -1064,9 +1064,11 @@ def test_graclus_pooler_with_a_batch_vector_takes_the_per_graph_rounds(dev, monk
     pooler = get_pooler("graclus").to(dev)
     called = []
     real = N.lib().tgp_graclus_match_graphs
+    real_fused = N.lib().tgp_graclus_match_graphs_fused  # r4: graphs of at most 64 nodes take the one-launch selector
     monkeypatch.setattr(N.lib(), "tgp_graclus_match_graphs", lambda *a: called.append(1) or real(*a))
+    monkeypatch.setattr(N.lib(), "tgp_graclus_match_graphs_fused", lambda *a: called.append(2) or real_fused(*a))
     out_b = pooler(x=x, adj=ei, edge_weight=ew, batch=batch)
-    assert called
+    assert called == [2]
     so_plain = pooler.select(edge_index=ei, edge_weight=ew, num_nodes=n)
     assert torch.equal(out_b.so.cluster_index, so_plain.cluster_index)
     # an unsorted batch vector keeps the device-wide rounds
@@ -1223,7 +1225,9 @@ def test_graclus_per_graph_route_with_an_unchecked_unsorted_edge_list(dev):
     (index, k, _, ones), row_ptr = kernels.graclus_match(fresh, ew, n, graph_ptr=ptr, max_graph_nodes=39,
                                                          relabel=True, return_row_ptr=True)
     assert torch.equal(ones, torch.ones(n, device=dev))
-    assert kernels._rows_sorted_memo(fresh) is True and row_ptr is not None
+    # r4: graphs of at most 64 nodes take the one-launch selector, which validates the row order itself and builds no
+    # offsets (row_ptr None); the staged per-graph route (TGP_GRACLUS_FUSED=0) returns them
+    assert kernels._rows_sorted_memo(fresh) is True and (row_ptr is None or row_ptr.numel() == n + 1)
     ids, inverse = torch.unique(want, return_inverse=True)
     assert k == ids.numel() and torch.equal(index[1], inverse)
 

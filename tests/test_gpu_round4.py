@@ -572,3 +572,75 @@ def test_ndp_large_partition_with_hub_rows_vs_scipy(dev, n, weighted):
     keep2 = torch.zeros(n, dtype=torch.uint8, device=dev)
     info2, state2 = K.ndp_partition_large(indptr, eid[1], wd, 0, n, 7, keep2, status, want_state=True)
     assert torch.equal(keep2, keepv) and state2["lambda"] == state["lambda"] and state2["steps"] == state["steps"]
+
+
+def _graclus_select_outputs(ei, ew, n, gptr, gmax):
+    from tgp import kernels
+    (index, k, assign, ones), _ = kernels.graclus_match(ei, ew, n, return_row_ptr=True, graph_ptr=gptr,
+                                                        max_graph_nodes=gmax, relabel=True)
+    return index, k, assign.row_ptr[:k + 1].clone(), assign.perm[:n].clone(), ones
+
+
+@pytest.mark.parametrize("weighted", [True, False])
+@pytest.mark.parametrize("shape", [(300, 5, 64, 4, False), (2048, 20, 60, 4, False), (257, 1, 30, 6, True),
+                                   (64, 40, 64, 16, False)])
+def test_one_launch_graclus_select_equals_the_staged_route(dev, weighted, shape, monkeypatch):
+    """GraclusSelect of a sorted batch of small graphs (select/graclus_select.py:62-81) as ONE launch -- matching, consecutive
+    cluster ids, supernode -> members index -- against the staged route (offsets, CSR gather, symmetrise, one-launch rounds,
+    relabel kernels): the same pairs (both use the key on global ids), hence the same index / K / members index, bit for
+    bit.  Ragged sizes incl. one-node graphs, isolated nodes, duplicate entries, weight ties (unweighted)."""
+    from tgp import kernels
+    from tgp.utils.ops import batch_info
+    B, lo, hi, deg, dup = shape
+    x, ei, ew, batch, sizes = _small_batch(B, lo, hi, 8, 100 + B, dev, deg=deg, dup=dup)
+    ew = ew if weighted else None
+    n = x.size(0)
+    info = batch_info(batch)
+    monkeypatch.setattr(kernels, "_GRACLUS_FUSED", False)
+    ref = _graclus_select_outputs(ei, ew, n, info.ptr, info.max_nodes)
+    monkeypatch.setattr(kernels, "_GRACLUS_FUSED", True)
+    for _ in range(3):  # stale status words of earlier calls must read as "not ready"
+        got = _graclus_select_outputs(ei, ew, n, info.ptr, info.max_nodes)
+        assert got[1] == ref[1]
+        for a, b in zip((got[0], got[2], got[3], got[4]), (ref[0], ref[2], ref[3], ref[4])):
+            assert torch.equal(a, b)
+    # the cluster ids describe a maximal matching: every cluster has one or two members, two members share an edge
+    idx, k = got[0], got[1]
+    sizes_c = torch.bincount(idx[1], minlength=k)
+    assert int(sizes_c.min()) >= 1 and int(sizes_c.max()) <= 2
+
+
+def test_one_launch_graclus_select_refusals_fall_back(dev, monkeypatch):
+    """What the one-launch kernel refuses still gives the staged route's answer through the same call: a directed list
+    (entries without a reverse are dropped by both), an UNSORTED list (refused: rows not ascending), a batch with a graph
+    beyond 64 nodes (not attempted), an edge that leaves its graph (refused by both per-graph kernels: device-wide rounds)."""
+    from tgp import kernels
+    from tgp.utils.ops import batch_info
+    x, ei, ew, batch, sizes = _small_batch(200, 10, 50, 8, 7, dev)
+    n = x.size(0)
+    info = batch_info(batch)
+
+    def both(e, w, gptr, gmax):
+        monkeypatch.setattr(kernels, "_GRACLUS_FUSED", False)
+        ref = _graclus_select_outputs(e.clone(), w, n, gptr, gmax)
+        monkeypatch.setattr(kernels, "_GRACLUS_FUSED", True)
+        got = _graclus_select_outputs(e.clone(), w, n, gptr, gmax)
+        assert got[1] == ref[1]
+        for a, b in zip((got[0], got[2], got[3], got[4]), (ref[0], ref[2], ref[3], ref[4])):
+            assert torch.equal(a, b)
+        return got
+
+    keep = torch.rand(ei.size(1), generator=torch.Generator().manual_seed(3)).to(dev) < 0.8   # directed: reverses missing
+    both(ei[:, keep].contiguous(), ew[keep].contiguous(), info.ptr, info.max_nodes)
+    perm = torch.randperm(ei.size(1), generator=torch.Generator().manual_seed(4)).to(dev)       # unsorted rows
+    both(ei[:, perm].contiguous(), ew[perm].contiguous(), info.ptr, info.max_nodes)
+    leak = ei.clone()
+    leak[1, 0] = n - 1                                                                         # leaves its graph
+    both(leak, ew, info.ptr, info.max_nodes)
+    x2, ei2, ew2, batch2, _ = _small_batch(40, 30, 100, 8, 9, dev)                             # graphs beyond 64 nodes
+    info2 = batch_info(batch2)
+    n2 = x2.size(0)
+    monkeypatch.setattr(kernels, "_GRACLUS_FUSED", True)
+    (index, k, assign, ones), _ = kernels.graclus_match(ei2, ew2, n2, return_row_ptr=True, graph_ptr=info2.ptr,
+                                                        max_graph_nodes=info2.max_nodes, relabel=True)
+    assert index.shape == (2, n2) and 0 < k <= n2

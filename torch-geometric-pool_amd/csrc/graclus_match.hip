@@ -15,6 +15,7 @@
 // byte (free) + one int32 (proposal) + the int64 label.  A round streams the CSR once: HBM-bound, E * 8 bytes.
 #include "common.h"
 #include "primitives.h"
+#include "lookback.h"
 
 namespace tgp {
 
@@ -549,6 +550,240 @@ __global__ __launch_bounds__(T) void gm_graph_rounds_kernel(const int32_t* __res
     gm_graph_rounds<T>(ptr_g, nbr, wt, p0, n, s_free, s_cand, label);
 }
 
+// ---- r4: matching + relabelling + members index of a sorted batch of SMALL graphs in ONE launch -------------------------
+// What `graclus` on a PROTEINS-shaped batch spent around the rounds kernel above: offsets of the list (1 launch), CSR
+// gather + symmetry fingerprint + symmetrise (3), a status memset, the rounds (1), a bitmap memset + three relabel
+// launches, a device-to-host copy -- eleven launches for 80 us of GPU time.  Here ONE WAVE PER GRAPH (<= 64 nodes,
+// <= GF_CAP entries; lane = node) does all of it out of LDS:
+//   * its graph's entry range from the row array itself (128-ary lower bounds + one boundary pass per workgroup, as
+//     sparse_pool_small.hip: no offsets kernel), validated -- rows ascending, ranges tiling [0, E), entries inside the graph;
+//   * symmetrisation by looking the reverse entry up in LDS (pair weight = the larger direction, entries without a
+//     reverse dropped: gm_symmetrise_kernel's rule, applied always -- max(w, w) = w on a symmetric list);
+//   * the handshake rounds with the free set as ONE 64-bit ballot and the candidates exchanged by `__shfl` (same key on
+//     GLOBAL ids, so the pairs are those of the device-wide rounds);
+//   * cluster ids = rank of the representative among the representatives (popcounts of a ballot) + the clusters of all
+//     earlier graphs from the epoch-tagged look-back of lookback.h; the members index needs no second prefix: a graph's
+//     clusters cover exactly its nodes, so its slots start at its first node.
+// {epoch, refused, K} lands in *result (pinned host memory).  Refuses (the caller takes the staged route): a graph beyond
+// 64 nodes or GF_CAP entries, an entry that leaves its graph, rows not ascending.
+constexpr int GF_WAVES = 4;
+constexpr int GF_CAP = 512;
+struct GfWaveLds {
+  int32_t ptr[65];
+  uint8_t row[GF_CAP];
+  uint8_t nbr[GF_CAP];  // local column; 255: dropped by the symmetrisation
+  float wt[GF_CAP];
+};
+struct GfArgs {
+  const int64_t *row, *col;
+  const float* w;
+  int64_t N, E;
+  const int64_t* gptr;
+  int64_t B;
+  int64_t* label;  // NULL ok
+  int64_t* index;  // [2, N]
+  int32_t *a_row_ptr, *a_perm;
+  float* ones;
+  unsigned long long *status, *result;
+  unsigned long long tag;
+};
+
+__global__ __launch_bounds__(GF_WAVES * 64) void gm_graph_fused_kernel(GfArgs p) {
+  __shared__ uint32_t s_cnt[GF_WAVES];
+  __shared__ uint32_t s_base;
+  __shared__ int s_ok;
+  __shared__ int64_t s_nb[GF_WAVES + 1];
+  __shared__ int s_eb[GF_WAVES + 1];
+  __shared__ int64_t s_rng[2];
+  __shared__ GfWaveLds s_all[GF_WAVES];
+  const int lane = lane_id(), wv = wave_id();
+  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * GF_WAVES;
+  if (threadIdx.x <= GF_WAVES) {
+    const int64_t gi = g0 + threadIdx.x < p.B ? g0 + threadIdx.x : p.B;
+    s_nb[threadIdx.x] = p.gptr[gi];
+    s_eb[threadIdx.x] = INT_MAX;
+  }
+  if (wv == 0) {
+    const int64_t N0 = p.gptr[g0], N1 = p.gptr[g0 + GF_WAVES < p.B ? g0 + GF_WAVES : p.B];
+    const int64_t* const arrs[2] = {p.row, p.row};
+    const int64_t ns[2] = {p.E, p.E}, keys[2] = {N0, N1};
+    int64_t res[2];
+    wave_lower_bounds<2>(arrs, ns, keys, res);
+    if (lane < 2) s_rng[lane] = lane == 0 ? res[0] : res[1];
+  }
+  __syncthreads();
+  const int64_t E0 = s_rng[0], E1 = s_rng[1], LE = E1 - E0;
+  bool bad = false;
+  // the workgroups' ranges tile the list (see sparse_pool_small_kernel): the first starts at 0, the last ends at E
+  if (LE < 0 || (blockIdx.x == 0 && (E0 != 0 || s_nb[0] != 0)) ||
+      (blockIdx.x == gridDim.x - 1 && (E1 != p.E || s_nb[GF_WAVES] != p.N)))
+    bad = true;
+  if (!bad) sps_boundaries<GF_WAVES>(p.row, E0, LE, s_nb, s_eb);
+  __syncthreads();
+  int64_t n0 = s_nb[wv], n1 = s_nb[wv + 1];
+  if (n1 < n0 || n1 - n0 > 64 || n0 < 0 || n1 > p.N) {
+    bad = true;
+    n0 = n1 = 0;
+  }
+  int64_t e0 = 0;
+  int m = 0;
+  if (!bad) {
+    const int64_t b0 = s_eb[wv] < LE ? s_eb[wv] : LE, b1 = s_eb[wv + 1] < LE ? s_eb[wv + 1] : LE;
+    if (b1 < b0 || (wv == 0 && b0 != 0) || (wv == GF_WAVES - 1 && b1 != LE) || b1 - b0 > GF_CAP) bad = true;
+    else {
+      e0 = E0 + b0;
+      m = static_cast<int>(b1 - b0);
+    }
+  }
+  const int n = bad ? 0 : static_cast<int>(n1 - n0);
+  GfWaveLds& L = s_all[wv];
+  L.ptr[lane] = m;
+  if (lane == 0) L.ptr[64] = m;
+  __builtin_amdgcn_wave_barrier();
+  // stage the entries; ptr[t] = first entry of local row t (entries are grouped by ascending row, or the wave refuses)
+  for (int e = lane; e < m; e += 64) {
+    const int64_t r = p.row[e0 + e] - n0, rp = e > 0 ? p.row[e0 + e - 1] - n0 : -1;
+    const int64_t c = p.col[e0 + e] - n0;
+    const bool okr = r >= 0 && r < n && rp <= r && rp >= -1, okc = c >= 0 && c < n;
+    if (!okr || !okc) bad = true;
+    L.row[e] = static_cast<uint8_t>(okr ? r : 0);
+    L.nbr[e] = static_cast<uint8_t>(okc ? c : 0);
+    L.wt[e] = p.w ? p.w[e0 + e] : 1.0f;
+    if (okr && r != rp)
+      for (int64_t t = rp + 1; t <= r; ++t) L.ptr[t] = e;
+  }
+  bad = __any(bad);
+  __builtin_amdgcn_wave_barrier();
+  // symmetrise (reverse entry looked up in LDS); two phases: all reads, then all writes
+  constexpr int PER = GF_CAP / 64;
+  float nw[PER];
+  bool drop[PER];
+  const int mm = bad ? 0 : m;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int e = lane + 64 * k;
+    nw[k] = 0.f;
+    drop[k] = false;
+    if (e < mm) {
+      const int i = L.row[e], j = L.nbr[e];
+      const float w = L.wt[e];
+      nw[k] = w;
+      if (j != i) {
+        // (the probe order of gm_symmetrise_kernel -- bisection over the row, then a linear scan -- so that a list with
+        //  DUPLICATE entries of different weights picks the same reverse entry and the two routes give the same pairs)
+        const int lo = L.ptr[j], hi = L.ptr[j + 1];
+        int a = lo, b = hi, q = -1;
+        while (a < b) {
+          const int mid = (a + b) >> 1;
+          const int v = L.nbr[mid];
+          if (v == i) { q = mid; break; }
+          if (v < i) a = mid + 1; else b = mid;
+        }
+        if (q < 0)
+          for (int t = lo; t < hi; ++t)
+            if (L.nbr[t] == i) { q = t; break; }
+        drop[k] = q < 0;
+        if (q >= 0) nw[k] = fmaxf(w, L.wt[q]);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int e = lane + 64 * k;
+    if (e < mm) {
+      if (drop[k]) L.nbr[e] = 255;
+      else L.wt[e] = nw[k];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // the rounds: lane = node, free set = one ballot, candidates exchanged by shuffle
+  const int nn = bad ? 0 : n;
+  bool isfree = lane < nn;
+  int partner = -1;
+  const uint32_t gi = static_cast<uint32_t>(n0) + static_cast<uint32_t>(lane);
+  for (int round = 0; round < 2 * 64 + 2; ++round) {
+    const unsigned long long free_mask = __ballot(isfree);
+    GmBest best{-1, 0.f, 0u, 0u, 0u};
+    if (isfree) {
+      for (int e = L.ptr[lane]; e < L.ptr[lane + 1]; ++e) {
+        const int j = L.nbr[e];
+        if (j == 255 || j == lane || !((free_mask >> j) & 1ull)) continue;
+        const float wj = L.wt[e];
+        if (wj != wj) continue;  // NaN weights never match
+        const uint32_t gj = static_cast<uint32_t>(n0) + static_cast<uint32_t>(j);
+        const uint32_t a = gi < gj ? gi : gj, b = gi < gj ? gj : gi;
+        gm_fold(best, GmBest{j, wj, pair_hash(a, b), a, b});
+      }
+      if (best.j < 0) isfree = false;  // no free neighbour left: retire (see gm_propose_kernel)
+    }
+    const int c = best.j;
+    const int cj = __shfl(c, c >= 0 ? c : 0, 64);
+    const bool hit = c >= 0 && cj == lane;
+    if (hit) {
+      partner = c;
+      isfree = false;
+    }
+    if (!__any(hit)) break;
+  }
+  const bool valid = lane < nn;
+  const int lab = partner >= 0 && partner < lane ? partner : lane;  // local id of the pair's smaller node
+  const bool rep = valid && lab == lane;
+  const unsigned long long repmask = __ballot(rep), pairmask = __ballot(rep && partner >= 0);
+  const uint32_t cnt = static_cast<uint32_t>(__popcll(repmask));
+  if (lane == 0) s_cnt[wv] = cnt | (bad ? 0x80000000u : 0u);
+  __syncthreads();
+  if (wv == 0) {
+    const int tile = blockIdx.x;
+    uint32_t tile_tot = 0;
+    bool refused = false;
+#pragma unroll
+    for (int w2 = 0; w2 < GF_WAVES; ++w2) {
+      tile_tot += s_cnt[w2] & 0x7FFFFFFFu;
+      refused = refused || (s_cnt[w2] >> 31) != 0u;
+    }
+    if (lane == 0)
+      sps_store(p.status + 2 + tile, p.tag | (tile == 0 ? SPS_PRE : SPS_AGG) | (refused ? 0x80000000ull : 0ull) | tile_tot);
+    uint32_t excl = 0;
+    if (tile > 0) {
+      bool before = false;
+      sps_lookback<4>(p.status, tile, p.tag, &excl, &before);
+      refused = refused || before;
+      if (lane == 0)
+        sps_store(p.status + 2 + tile, p.tag | SPS_PRE | (refused ? 0x80000000ull : 0ull) |
+                                           static_cast<unsigned long long>((excl + tile_tot) & 0x7FFFFFFFu));
+    }
+    if (lane == 0) {
+      s_base = excl;
+      s_ok = refused ? 0 : 1;
+      if (tile == static_cast<int>(gridDim.x) - 1) {
+        if (!refused) p.a_row_ptr[excl + tile_tot] = static_cast<int32_t>(p.N);
+        __hip_atomic_store(p.result, p.tag | (refused ? 0x80000000ull : 0ull) |
+                                         static_cast<unsigned long long>((excl + tile_tot) & 0x7FFFFFFFu),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+  __syncthreads();
+  if (!s_ok || !valid) return;
+  uint32_t base = s_base;
+  for (int w2 = 0; w2 < wv; ++w2) base += s_cnt[w2] & 0x7FFFFFFFu;
+  const unsigned long long below = (1ull << lab) - 1ull;
+  const uint32_t lr = static_cast<uint32_t>(__popcll(repmask & below));
+  const int64_t slot = n0 + lr + __popcll(pairmask & below);  // members of this graph's earlier clusters
+  const int64_t i = n0 + lane;
+  p.index[i] = i;
+  p.index[p.N + i] = static_cast<int64_t>(base + lr);
+  p.ones[i] = 1.0f;
+  if (p.label) p.label[i] = n0 + lab;
+  if (rep) {
+    p.a_row_ptr[base + lr] = static_cast<int32_t>(slot);
+    p.a_perm[slot] = static_cast<int32_t>(i);
+  } else {
+    p.a_perm[slot + 1] = static_cast<int32_t>(i);
+  }
+}
+
 // ---- the tail of the device-wide rounds ---------------------------------------------------------------------------------
 // After a few rounds a random-like graph has a few thousand free nodes left that still have a free neighbour, and every
 // further round costs three launches over all N nodes (15 us at N = 1M) to match a handful of pairs.  The tail gathers
@@ -824,6 +1059,32 @@ extern "C" int tgp_graclus_relabel_i64(const int64_t* label, int64_t num_nodes, 
                        tile_sum, paired, wprefix2, tile_sum2, tiles, index_out, d_k, assign_row_ptr, assign_perm, ones);
   }
   return check_launch("tgp_graclus_relabel_i64");
+}
+
+extern "C" int tgp_graclus_match_graphs_fused_max_graph_nodes(void) { return 64; }
+extern "C" int64_t tgp_graclus_match_graphs_fused_status_words(int64_t B) { return 2 + cdiv(B > 0 ? B : 1, GF_WAVES); }
+
+// r4: matching + consecutive cluster ids + supernode -> members index of a sorted batch of graphs of at most 64 nodes in
+// ONE launch (gm_graph_fused_kernel).  row / col / w: the row-sorted edge list itself (no CSR needed).
+extern "C" int tgp_graclus_match_graphs_fused(const int64_t* row, const int64_t* col, const float* w, int64_t N, int64_t E,
+                                              const int64_t* graph_ptr, int64_t B, int64_t* label, int64_t* index,
+                                              int32_t* assign_row_ptr, int32_t* assign_perm, float* ones,
+                                              uint64_t* status, int64_t status_words, uint64_t* result, uint32_t epoch,
+                                              void* stream_) {
+  TGP_REQUIRE(N > 0 && E >= 0 && B > 0 && graph_ptr && index && assign_row_ptr && assign_perm && ones && status &&
+                  result && (E == 0 || (row && col)),
+              TGP_ERR_INVALID, "tgp_graclus_match_graphs_fused: bad argument");
+  TGP_REQUIRE(N < (1ll << 31) && E < (1ll << 31) && B < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_graclus_match_graphs_fused: N / E / B >= 2^31");
+  TGP_REQUIRE(status_words >= tgp_graclus_match_graphs_fused_status_words(B), TGP_ERR_WORKSPACE,
+              "tgp_graclus_match_graphs_fused: status buffer too small");
+  TGP_REQUIRE(epoch != 0 && epoch < (1u << 29), TGP_ERR_RANGE, "tgp_graclus_match_graphs_fused: epoch out of range");
+  const GfArgs a{row, col, w, N, E, graph_ptr, B, label, index, assign_row_ptr, assign_perm, ones,
+                 reinterpret_cast<unsigned long long*>(status), reinterpret_cast<unsigned long long*>(result),
+                 static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT};
+  hipLaunchKernelGGL(gm_graph_fused_kernel, dim3(static_cast<unsigned>(cdiv(B, GF_WAVES))), dim3(GF_WAVES * 64), 0,
+                     static_cast<hipStream_t>(stream_), a);
+  return check_launch("tgp_graclus_match_graphs_fused");
 }
 
 extern "C" int tgp_graclus_match_max_graph_nodes(void) { return GM_GRAPH_MAX; }

@@ -63,77 +63,6 @@ struct SpsArgs {
   unsigned long long tag;      // epoch << SPS_EPOCH_SHIFT
 };
 
-__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, WAVE);
-  return v;
-}
-__device__ __forceinline__ int64_t wave_min64(int64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const int64_t t = __shfl_xor(v, o, WAVE);
-    v = t < v ? t : v;
-  }
-  return v;
-}
-__device__ __forceinline__ int64_t wave_max64(int64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const int64_t t = __shfl_xor(v, o, WAVE);
-    v = t > v ? t : v;
-  }
-  return v;
-}
-
-// NK lower bounds by ONE wave, together: 128 probes per round and key (two per lane), the loads of all keys in
-// flight at once -- three dependent rounds for 300 k entries instead of a log2 chain of nineteen.  On an array that is
-// not ascending the result is still a deterministic function of (array, key), which is all the tiling check of the
-// caller needs.
-template <int NK>
-__device__ __forceinline__ void wave_lower_bounds(const int64_t* const (&arr)[NK], const int64_t (&n)[NK],
-                                                  const int64_t (&key)[NK], int64_t (&res)[NK]) {
-  const int lane = lane_id();
-  int64_t lo[NK], hi[NK];
-#pragma unroll
-  for (int q = 0; q < NK; ++q) {
-    lo[q] = 0;
-    hi[q] = n[q];
-  }
-  for (;;) {
-    bool more = false;
-#pragma unroll
-    for (int q = 0; q < NK; ++q) more = more || lo[q] < hi[q];
-    if (!more) break;
-    int64_t step[NK], va[NK], vb[NK];
-    bool oa[NK], ob[NK];
-#pragma unroll
-    for (int q = 0; q < NK; ++q) {  // unconditional, clamped loads (a finished key re-reads its last element)
-      step[q] = (hi[q] - lo[q] + 127) >> 7;
-      const int64_t ia = lo[q] + lane * step[q], ib = lo[q] + (lane + 64) * step[q];
-      oa[q] = ia < hi[q];
-      ob[q] = ib < hi[q];
-      const int64_t last = n[q] > 0 ? n[q] - 1 : 0;
-      va[q] = n[q] > 0 ? arr[q][oa[q] ? ia : last] : 0;
-      vb[q] = n[q] > 0 ? arr[q][ob[q] ? ib : last] : 0;
-    }
-#pragma unroll
-    for (int q = 0; q < NK; ++q) {
-      const int c = __popcll(__ballot(oa[q] && va[q] < key[q])) + __popcll(__ballot(ob[q] && vb[q] < key[q]));
-      if (lo[q] < hi[q]) {
-        if (c == 0) {
-          hi[q] = lo[q];
-        } else {
-          const int64_t last = lo[q] + static_cast<int64_t>(c - 1) * step[q];
-          lo[q] = last + 1;
-          hi[q] = last + step[q] < hi[q] ? last + step[q] : hi[q];
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < NK; ++q) res[q] = lo[q];
-}
-
 __device__ __forceinline__ float sps_reduce(float acc, float v, int op) {
   switch (op) {
     case TGP_MIN: return fminf(acc, v);
@@ -163,24 +92,6 @@ struct SpsClusterLds {
 #else
 #define SPS_STAMP(k) do { } while (0)
 #endif
-
-// boundaries of WAVES + 1 ascending keys s_key[] inside arr[lo, lo + len): s_out[t] = first i with arr[lo + i] >= key
-// (left at INT_MAX when no element is that large).  One coalesced pass by the whole workgroup; on an array that is not
-// ascending the minimum of the candidates is taken (deterministic; the caller's range checks then refuse the input).
-template <int WAVES>
-__device__ __forceinline__ void sps_boundaries(const int64_t* __restrict__ arr, int64_t lo, int64_t len,
-                                               const int64_t* s_key, int* s_out) {
-  for (int64_t i = threadIdx.x; i < len; i += WAVES * WAVE) {
-    const int64_t r = arr[lo + i];
-    const int64_t rp = i > 0 ? arr[lo + i - 1] : INT64_MIN;
-    if (r != rp) {
-      for (int t = 0; t <= WAVES; ++t) {
-        const int64_t nb = s_key[t];
-        if (rp < nb && nb <= r) atomicMin(&s_out[t], static_cast<int>(i));
-      }
-    }
-  }
-}
 
 template <int MODE, int WAVES>  // MODE 0: kept-node selection (TopK, NDP-shaped); 1: every node in one cluster (Graclus)
 __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p) {

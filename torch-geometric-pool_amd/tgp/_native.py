@@ -120,6 +120,10 @@ SIGNATURES = {
     "tgp_graclus_relabel_i64": (_c_int, [_c_p, _c_i64, _c_p, _c_sz, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "tgp_graclus_match_tail": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p]),
     "tgp_graclus_match_max_graph_nodes": (_c_int, []),
+    "tgp_graclus_match_graphs_fused_max_graph_nodes": (_c_int, []),
+    "tgp_graclus_match_graphs_fused_status_words": (_c_i64, [_c_i64]),
+    "tgp_graclus_match_graphs_fused": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p,
+                                                _c_p, _c_p, _c_i64, _c_p, ctypes.c_uint32, _c_p]),
     "tgp_graclus_match_graphs": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_graclus_match_rounds": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_p, _c_p]),
     "tgp_batch_facts_i64": (_c_int, [_c_p, _c_i64, _c_p, _c_p, ctypes.c_double, _c_p]),

@@ -163,6 +163,7 @@ def _edge_rows(edge_index: Tensor) -> Tuple[Tensor, Tensor]:
 # ------------------------------------------------------------------------- A1 + A2 + A4/A5 + A6, batches of small graphs
 _SPS_STATE: dict = {}  # (device index, stream handle) -> _SpsState
 _SPS_DECLINED: dict = {}
+_GRACLUS_FUSED = os.environ.get("TGP_GRACLUS_FUSED", "1") != "0"  # A/B switch: one-launch GraclusSelect of small graphs
 _PUBLISH_COUNTS = os.environ.get("TGP_PUBLISH_COUNTS", "1") != "0"  # A/B switch of _read_count (read once)
 SPS_COMPACT_BYTES = 1 << 30  # capacity buffers above this are replaced by exact copies when mostly empty
 
@@ -1055,10 +1056,35 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
     row, col = _edge_rows(edge_index)
     E = row.numel()
     w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
-    label = torch.empty(num_nodes, dtype=torch.int64, device=dev)
-    sorted_ptr = None
     L = N.lib()
     st = N.stream_ptr(dev)
+    if (relabel and max_rounds is None and graph_ptr is not None and max_graph_nodes is not None and E > 0
+            and num_nodes > 0 and graph_ptr.numel() >= 2 and max_graph_nodes <= 64 and _GRACLUS_FUSED
+            and _rows_sorted_memo(edge_index) is not False and not torch.cuda.is_current_stream_capturing()):
+        # r4: matching + relabelling + members index of a batch of small graphs in ONE launch, straight from the edge list
+        # (no CSR); the kernel validates row order itself, so a list nobody has looked at yet needs no check pass
+        gp = N.i64c(graph_ptr)
+        B = gp.numel() - 1
+        state = _sps_state(dev, st, L.tgp_graclus_match_graphs_fused_status_words(B))
+        epoch = state.next_epoch()
+        index = torch.empty(2, num_nodes, dtype=torch.int64, device=dev)
+        a_ptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+        a_perm = torch.empty(num_nodes, dtype=torch.int32, device=dev)
+        ones = torch.empty(num_nodes, dtype=torch.float32, device=dev)
+        N.check(L.tgp_graclus_match_graphs_fused(N.ptr(row), N.ptr(col), N.ptr(w), num_nodes, E, N.ptr(gp), B, None,
+                                                 N.ptr(index), N.ptr(a_ptr), N.ptr(a_perm), N.ptr(ones),
+                                                 state.status.data_ptr(), state.status.numel(),
+                                                 state.pinned.data_ptr(), epoch, st), "tgp_graclus_match_graphs_fused")
+        word = state.wait(epoch)
+        if not word & 0x80000000:
+            k = word & 0x7FFFFFFF
+            if E > 1 and _rows_sorted_memo(edge_index) is None:
+                _remember_rows_sorted(edge_index, True)  # (the kernel refuses lists whose rows are not ascending)
+            out = (index, k, AssignIndex(a_ptr[:k + 1], a_perm, num_nodes, k), ones)
+            return (out, None) if return_row_ptr else out
+        del index, a_ptr, a_perm, ones  # refused: the staged route below decides why
+    label = torch.empty(num_nodes, dtype=torch.int64, device=dev)
+    sorted_ptr = None
     # PyG lists are sorted by source: one comparison pass + round trip decides whether the CSR needs a sort at all
     # (remembered per edge_index object: full-batch training pools the same graph every epoch)
     words = torch.empty(4, dtype=torch.int32, device=dev)  # [status, rows-not-sorted flag, K (int64)]
