@@ -19,6 +19,7 @@ python3 bench.py --steps 20 --warmup 5 > $out/bench_line.json 2> $out/bench_line
 TGP_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29617 python3 bench.py --workload topk_batch --secondary none --no-cpu-baseline --steps 50 2> $out/bench_topk_batch_rccl.err | grep '^{' > $out/bench_topk_batch_rccl.json
 TGP_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29618 python3 bench.py --workload c2 --secondary none --no-cpu-baseline --steps 50 2> $out/bench_c2_rccl.err | grep '^{' > $out/bench_c2_rccl.json
 python3 tools/bench_graclus_hubs.py 2>&1 | grep -v -i 'warn\|amdgpu.ids' > $out/graclus_hubs.txt
+python3 tools/bench_ndp_hubs.py 2>&1 | grep -v -i 'warn\|amdgpu.ids' > $out/ndp_hubs_after.txt
 stats bench python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
 stats c4_graclus_sorted python3 bench.py --workload c4_graclus --secondary none --no-cpu-baseline --steps 50
 stats c4_graclus_unsorted python3 bench.py --workload c4_graclus --unsorted-edges --secondary none --no-cpu-baseline --steps 50
@@ -34,7 +35,7 @@ python3 tools/ndp_small_ab.py 2>&1 | grep -v -i "warn" > $out/ndp_small.txt
 bash tools/ndp_large_ab.sh 2>&1 | grep -v -i "warn\|amdgpu.ids" > $out/ndp_mid_ab.txt
 python3 tools/bench_reference_harness.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $out/reference_harness.txt
 python3 tools/kron_timeline.py $(find $out/kron -name "*kernel_trace.csv" | head -1) > $out/kron_timeline.txt 2>&1
-for k in coalesce_c4_sorted subgraph_topk c3 reduce_topk reduce_ndp reduce_graclus topk_batch gemm_c2; do
+for k in coalesce_c4_sorted subgraph_topk c3 reduce_topk reduce_ndp reduce_graclus topk_batch graclus_batch gemm_c2; do
   pmc $k FETCH_SIZE python3 tools/run_kernel.py $k 4
   pmc $k WRITE_SIZE python3 tools/run_kernel.py $k 4
 done

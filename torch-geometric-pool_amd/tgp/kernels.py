@@ -15,11 +15,17 @@ from torch import Tensor
 from . import _native as N
 
 
+_OPS_MODULE = None
+
+
 def ops_eps() -> float:
     """``tgp.utils.ops.eps`` read at CALL time, as the reference's ops functions read their module global
     (utils/ops.py:21,72,318,377,395; reference tests monkeypatch it: tests/connect/test_dense_conn.py:444-463)."""
-    from .utils import ops
-    return float(ops.eps)
+    global _OPS_MODULE
+    if _OPS_MODULE is None:
+        from .utils import ops
+        _OPS_MODULE = ops
+    return float(_OPS_MODULE.eps)
 
 
 def losses_eps() -> float:

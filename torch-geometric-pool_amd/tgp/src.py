@@ -11,13 +11,13 @@ from torch import Tensor
 
 from . import functions as Fn
 from . import kernels as K
-from .connect import Connect
+from .connect import Connect, SparseConnect, _normalize_pooled_edges
 from .imports import HAS_PYG
 from .lift import Lift
-from .reduce import Reduce
+from .reduce import BaseReduce, Reduce
 from .select import Select, SelectOutput
 from .utils import Signature, connectivity_to_edge_index, foo_signature
-from .utils.ops import (build_pooled_batch, graph_ptr, is_dense_adj, like_input_dtype, max_graph_size,
+from .utils.ops import (batch_info, build_pooled_batch, graph_ptr, is_dense_adj, like_input_dtype, max_graph_size,
                         num_graphs_of)
 
 
@@ -132,10 +132,6 @@ class SRCPooling(torch.nn.Module):
         of more than 64 nodes, non-tensor connectivity, caching -- or when the kernel's on-device checks refuse the
         input (an edge between two graphs, unsorted rows, ...).  The pooled ``edge_index`` is a [2, E'] view of a
         capacity buffer: both rows contiguous, values and order those of the staged operators."""
-        from .connect import SparseConnect, _normalize_pooled_edges
-        from .reduce import BaseReduce
-        from . import kernels as K
-        from .utils.ops import batch_info
         c = self.connector
         if (self.cached or type(c) is not SparseConnect or type(self.reducer) is not BaseReduce or batch is None
                 or not isinstance(x, Tensor) or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32
@@ -333,7 +329,6 @@ class DenseSRCPooling(SRCPooling):
                 and batch.numel() == x.size(0) and x.size(0) > 0 and x.size(1) > 0 and isinstance(ei, Tensor)
                 and ei.is_cuda and (ew is None or (ew.dim() == 1 and ew.dtype == torch.float32))):
             return None
-        from .utils.ops import batch_info
         info = batch_info(batch)
         if not info.is_sorted:
             return None
