@@ -644,3 +644,53 @@ def test_one_launch_graclus_select_refusals_fall_back(dev, monkeypatch):
     (index, k, assign, ones), _ = kernels.graclus_match(ei2, ew2, n2, return_row_ptr=True, graph_ptr=info2.ptr,
                                                         max_graph_nodes=info2.max_nodes, relabel=True)
     assert index.shape == (2, n2) and 0 < k <= n2
+
+
+def test_ndp_select_with_an_unsorted_batch_vector_stays_on_device(dev, monkeypatch):
+    """NDPSelect (select/ndp_select.py:187-256) on a batch whose nodes are NOT grouped by graph: r3 handed such batches to
+    the host (scipy eigsh per graph); now the nodes are renumbered graph by graph on the device, partitioned by the same
+    kernels and the kept set mapped back -- equal to the sorted batch's selection under the node permutation."""
+    import scipy.sparse.linalg as spla
+    from tgp.select import NDPSelect
+
+    def boom(*a, **k):
+        raise AssertionError("host eigen-solver called")
+    monkeypatch.setattr(spla, "eigsh", boom)
+    x, ei, ew, batch, sizes = _small_batch(60, 8, 50, 4, 33, dev)
+    n = x.size(0)
+    sel = NDPSelect()
+    torch.manual_seed(5)                          # (the random-fallback seed is drawn from torch's generator)
+    so_sorted = sel(ei, ew, batch=batch, num_nodes=n)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(6)).to(dev)   # new id of node i: perm[i]
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n, device=dev)
+    ei_u = perm[ei]
+    order = torch.argsort(ei_u[0] * n + ei_u[1])
+    ei_u, ew_u = ei_u[:, order].contiguous(), ew[order].contiguous()
+    batch_u = batch[inv].contiguous()
+    assert not bool((batch_u[1:] >= batch_u[:-1]).all())
+    torch.manual_seed(5)
+    so_u = sel(ei_u, ew_u, batch=batch_u, num_nodes=n)
+    ni = so_u.node_index
+    assert ni.is_cuda and bool((ni[1:] > ni[:-1]).all())
+    assert torch.equal(so_u.cluster_index, torch.arange(ni.numel(), device=dev))
+    # graph by graph the same nodes are kept.  The stable renumbering keeps the order of a graph's nodes as they appear
+    # in the unsorted numbering, which differs from the sorted batch's order: the spectral partition is the same SET up
+    # to the eigenvector's sign, the random fallback (cut < 0.5) is not comparable -- compare the graphs that kept it
+    kept_sorted = torch.zeros(n, dtype=torch.bool, device=dev)
+    kept_sorted[so_sorted.node_index] = True
+    kept_u = torch.zeros(n, dtype=torch.bool, device=dev)
+    kept_u[ni] = True
+    kept_u_in_sorted_ids = kept_u[perm]
+    spectral = (so_sorted._partition_info >= 0) & (so_u._partition_info >= 0)
+    assert int(spectral.sum()) > 0
+    same = 0
+    for g in spectral.nonzero().view(-1).tolist():
+        m = batch == g
+        a, b = kept_sorted[m], kept_u_in_sorted_ids[m]
+        assert torch.equal(a, b) or torch.equal(a, ~b)   # the sign of an eigenvector is a convention
+        same += 1
+    assert same == int(spectral.sum())
+    # the reference's so.L in the caller's numbering (built lazily on the host)
+    L = so_u.L
+    assert L.shape == (n, n) and abs(L.sum()) < 1e-3

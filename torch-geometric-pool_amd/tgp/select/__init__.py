@@ -898,7 +898,7 @@ class NDPSelect(Select):
         if batch is not None and batch.numel() == n:
             info = batch_info(batch)
             if not info.is_sorted:
-                return None
+                return self._forward_device_unsorted(edge_index, edge_weight, batch, n)
             ptr, max_nodes = info.ptr, info.max_nodes
             sizes_host = info.sizes_host if max_nodes > K.ndp_max_graph_nodes() else None  # (read back only when needed)
         else:
@@ -981,6 +981,51 @@ class NDPSelect(Select):
         so.__dict__["_L_factory"] = laplacian_on_host
         so._adj_device_csr = (indptr, ei2[1], w2)  # KronConnect's kernel forms L = D - A from these directly
         so._partition_info = part_info
+        so._set_one_to_one_index()
+        so._node_batch = batch
+        return so
+
+    def _forward_device_unsorted(self, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor,
+                                 num_nodes: int) -> Optional[SelectOutput]:
+        """An UNSORTED batch vector (r4; the host route before): the nodes are renumbered graph by graph (stable sort of
+        the batch vector, so the order inside a graph is kept), the sorted problem is partitioned on the device as above
+        and the kept set is mapped back.  A graph's partition does not depend on how its nodes are numbered beyond the
+        eigenvector's sign convention, which the kernels fix by the iterate itself -- same contract as the sorted route."""
+        dev = edge_index.device
+        n = num_nodes
+        order = torch.sort(batch, stable=True)[1]          # sorted position -> original node
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(n, device=dev)          # original node -> sorted position
+        ei_s = rank[edge_index]
+        # the device route wants a row-sorted list to recognise "already symmetric and coalesced"; any order is accepted
+        # (it coalesces otherwise), so the list is only re-sorted by its new rows, stably
+        perm = torch.sort(ei_s[0], stable=True)[1]
+        ei_s = ei_s[:, perm].contiguous()
+        ew_s = None if edge_weight is None else edge_weight.reshape(-1)[perm]
+        so_s = self._forward_device(ei_s, ew_s, batch[order].contiguous(), n)
+        if so_s is None:
+            return None
+        keep_s = torch.zeros(n, dtype=torch.bool, device=dev)
+        keep_s[so_s.node_index] = True
+        idx_pos = keep_s[rank].nonzero().view(-1)          # kept nodes, original numbering, ascending
+        k = idx_pos.numel()
+        s = torch.sparse_coo_tensor(torch.stack([idx_pos, torch.arange(k, device=dev)]), torch.ones(k, device=dev),
+                                    size=(n, k), is_coalesced=True)
+        so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
+        so.__dict__["_no_empty_cluster"] = True
+        so._extra_args.add("L")
+        indptr_s, col_s, w_s = so_s._adj_device_csr
+
+        def laplacian_on_host():  # the reference's so.L in the caller's numbering (ndp_select.py:254-255)
+            import numpy as np
+            import scipy.sparse as sp
+            cnt = (indptr_s[1:] - indptr_s[:-1]).long()
+            r = order[torch.repeat_interleave(torch.arange(n, device=dev), cnt)].cpu().numpy()
+            c, w = order[col_s].cpu().numpy(), w_s.cpu().numpy().astype(np.float64)
+            A = sp.coo_matrix((w, (r, c)), shape=(n, n)).tocsr()
+            return (sp.diags(np.asarray(A.sum(1)).reshape(-1)) - A).tocsr().astype(np.float32)
+        so.__dict__["_L_factory"] = laplacian_on_host
+        so._partition_info = so_s._partition_info
         so._set_one_to_one_index()
         so._node_batch = batch
         return so
