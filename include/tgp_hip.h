@@ -199,15 +199,16 @@ int tgp_count_publish(const int64_t* d_count, uint64_t* result, uint32_t epoch, 
 
 /* tgp_connect_coalesce_rows_count with its survivor scan as ONE launch that also hands the count to the host (r4):
  * the scan takes the survivors in front of every block of 4096 supernode rows from an epoch-tagged decoupled look-back
- * (`status`: >= ..._status_words(K) 64-bit words of device memory, caller-owned, never cleared, one buffer per stream;
- * 0 < epoch < 2^29 different for every call on it) and its last workgroup stores {epoch << 34 | *d_count as a 34-bit
+ * (`status`: >= ..._status_words(K, N) 64-bit words of device memory, caller-owned, never cleared, one buffer per stream;
+ * 0 < epoch < 2^29 different for every call on it; the member segments of the front end take their offsets from a second
+ * look-back over the same buffer -- member degree sums, their scan and the CSR check are ONE launch on this route) and its last workgroup stores {epoch << 34 | *d_count as a 34-bit
  * two's complement number} with system scope into `*result` (pinned host memory the caller polls; same word format as
  * tgp_count_publish).  *d_count is written as well; tgp_connect_coalesce_rows_fill follows as for the plain count.
  * `csr_col` (NULL ok, only with csr_ptr): the int32 copy of `col` that GraclusSelect's CSR holds for this very list --
  * half the column stream of the gather kernel; `col` is still needed (hub rows).
  * Measured alternatives (profiles/r04_coalesce_tail_experiments.md): the look-back inside the FILL (64-row tiles) and the
  * fill inside the count call (host wait at the end) are both slower. */
-int64_t tgp_connect_coalesce_rows_count_status_words(int64_t num_supernodes);
+int64_t tgp_connect_coalesce_rows_count_status_words(int64_t num_supernodes, int64_t num_nodes);
 int tgp_connect_coalesce_rows_count_published(const int64_t* row, const int64_t* col, const int32_t* csr_col /* NULL ok */,
                                               const float* edge_weight /* NULL ok */, int64_t num_edges,
                                               const int64_t* cluster_index, int64_t num_nodes, int64_t num_supernodes,

@@ -170,6 +170,83 @@ __global__ __launch_bounds__(256) void cr_member_scan_kernel(const int32_t* __re
   }
 }
 
+// r4: the two kernels above as ONE launch (the published count route, which has an epoch-tagged status buffer): a tile's
+// degree sum is published, the sums in front of it come from the decoupled look-back of lookback.h (a few hundred tiles,
+// all resident), and the tile writes its members' segments at once -- the member ids and their CSR offsets are loaded
+// once instead of twice.  csr_ptr != NULL: the handed-over CSR is checked here too (offsets start at 0 and end at E: what
+// cr_check_csr_kernel did in a launch of its own) and workgroup 0 resets the status words for the kernels behind.
+__global__ __launch_bounds__(256) void cr_member_single_kernel(const int32_t* __restrict__ a_perm, int64_t nnz,
+                                                               const uint32_t* __restrict__ node_ptr,
+                                                               const int64_t* __restrict__ cluster, int64_t n_nodes,
+                                                               int64_t E, int csr_given, int* __restrict__ bad,
+                                                               int32_t* __restrict__ table,
+                                                               uint32_t* __restrict__ seg_src,
+                                                               uint32_t* __restrict__ seg_dst,
+                                                               unsigned long long* status, unsigned long long tag) {
+  __shared__ uint32_t s_w[4];
+  __shared__ uint32_t s_off;
+  __shared__ int s_refused;
+  const int tile = blockIdx.x;
+  const int64_t base = static_cast<int64_t>(tile) * MS_TILE + static_cast<int64_t>(threadIdx.x) * MS_ITEMS;
+#pragma unroll
+  for (int i = 0; i < MS_ITEMS; ++i)
+    if (base + i < n_nodes) table[base + i] = static_cast<int32_t>(cluster[base + i]);
+  int declined;
+  if (csr_given) {  // (every workgroup looks for itself: nobody may rely on workgroup 0's reset inside this launch)
+    declined = (node_ptr[0] != 0u || static_cast<int64_t>(node_ptr[n_nodes]) != E) ? 4 : 0;
+    if (tile == 0 && threadIdx.x == 0) {
+      bad[0] = declined;
+      bad[1] = 0;
+      bad[2] = 0;
+      bad[3] = 0;
+    }
+  } else {
+    declined = *bad;  // written by the CSR pass in front (rows not sorted: node_ptr is not a CSR)
+  }
+  if (declined || static_cast<int64_t>(tile) * MS_TILE >= nnz) return;  // (uniform over the tiles that take part)
+  int32_t node[MS_ITEMS];
+  uint32_t first[MS_ITEMS], len[MS_ITEMS], sum = 0;
+#pragma unroll
+  for (int i = 0; i < MS_ITEMS; ++i) node[i] = base + i < nnz ? a_perm[base + i] : -1;
+#pragma unroll
+  for (int i = 0; i < MS_ITEMS; ++i) {
+    first[i] = node[i] >= 0 ? node_ptr[node[i]] : 0u;
+    len[i] = node[i] >= 0 ? node_ptr[node[i] + 1] - first[i] : 0u;
+    sum += len[i];
+  }
+  uint32_t tile_total;
+  const uint32_t local = block_excl_scan_256(sum, s_w, &tile_total);
+  if (threadIdx.x < WAVE) {
+    if (threadIdx.x == 0)
+      sps_store(status + 2 + tile, tag | (tile == 0 ? SPS_PRE : SPS_AGG) | static_cast<unsigned long long>(tile_total));
+    uint32_t excl = 0;
+    bool refused = false;
+    if (tile > 0) {
+      sps_lookback<4>(status, tile, tag, &excl, &refused);
+      if (threadIdx.x == 0)
+        sps_store(status + 2 + tile, tag | SPS_PRE | (refused ? 0x80000000ull : 0ull) |
+                                         static_cast<unsigned long long>((excl + tile_total) & 0x7FFFFFFFu));
+    }
+    if (threadIdx.x == 0) {
+      s_off = excl;
+      s_refused = refused ? 1 : 0;
+      if (refused) atomicOr(bad, 1);  // a look-back that ran into its spin bound declines the call
+    }
+  }
+  __syncthreads();
+  if (s_refused) return;
+  uint32_t run = s_off + local;
+#pragma unroll
+  for (int i = 0; i < MS_ITEMS; ++i) {
+    if (base + i < nnz) {
+      seg_src[base + i] = first[i];
+      seg_dst[base + i] = run;
+    }
+    run += len[i];
+    if (base + i == nnz - 1) seg_dst[nnz] = run;
+  }
+}
+
 // raw_off[r] = first slot of supernode row r = first slot of its first member (an empty row shares its successor's);
 // a row longer than the LDS sort takes declines the call before the heavy kernel runs.
 // A row beyond CR_LONG entries (a hub): listed for the huge-row kernels below when the caller asked for them
@@ -1567,15 +1644,22 @@ static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const floa
   if (csr_ptr) {
     // CSR offsets of this very list from the caller (GraclusSelect builds them): no pass over the row array
     s.node_ptr = reinterpret_cast<uint32_t*>(const_cast<int32_t*>(csr_ptr));  // non-negative: same bits; read only
-    hipLaunchKernelGGL(cr_check_csr_kernel, dim3(1), dim3(1), 0, stream, csr_ptr, N, E, s.bad, 1);
+    if (!pub) hipLaunchKernelGGL(cr_check_csr_kernel, dim3(1), dim3(1), 0, stream, csr_ptr, N, E, s.bad, 1);
   } else if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
     hipLaunchKernelGGL(cr_node_ptr_vec_kernel, dim3(cdiv(cdiv(E, 4) + 1, 256)), dim3(256), 0, stream, row, E, N, s.bad,
                        s.node_ptr);
   } else {
     hipLaunchKernelGGL(cr_node_ptr_kernel, dim3(cdiv(E + 1, 256)), dim3(256), 0, stream, row, E, N, s.bad, s.node_ptr);
   }
-  {  // member segments: degree sums per tile (+ cluster table), scan, row offsets
-    const int nt = cdiv(N, MS_TILE);
+  const int nt = cdiv(N, MS_TILE);
+  if (pub) {  // member segments in one launch: look-back over the second region of the status buffer
+    unsigned long long* st2 = reinterpret_cast<unsigned long long*>(pub->status) + 2 + cdiv(K > 0 ? K : 1, SCAN_TILE);
+    hipLaunchKernelGGL(cr_member_single_kernel, dim3(nt), dim3(256), 0, stream, assign_perm, N, s.node_ptr,
+                       cluster_index, N, E, csr_ptr ? 1 : 0, s.bad, s.table, s.seg_src, s.seg_dst, st2,
+                       static_cast<unsigned long long>(pub->epoch) << SPS_EPOCH_SHIFT);
+    hipLaunchKernelGGL(cr_raw_off_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, assign_row_ptr, K, s.seg_dst, s.bad,
+                       s.raw_off, huge ? h.list : static_cast<uint32_t*>(nullptr), s.n_out);
+  } else {  // member segments: degree sums per tile (+ cluster table), scan, row offsets
     uint32_t* sums = s.scan_scratch;
     uint32_t* offs = s.scan_scratch + nt;
     hipLaunchKernelGGL(cr_member_sums_kernel, dim3(nt), dim3(256), 0, stream, assign_perm, N, s.node_ptr, cluster_index,
@@ -1646,7 +1730,10 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
 // The same pipeline with the survivor scan as one launch (decoupled look-back over `status`, epoch-tagged: caller-owned,
 // never cleared) that also stores {epoch << 34 | count} into *result -- pinned host memory the caller polls instead of
 // copying *d_count back; `csr_col`: the int32 columns GraclusSelect's CSR holds for this very list (with csr_ptr).
-extern "C" int64_t tgp_connect_coalesce_rows_count_status_words(int64_t K) { return 2 + cdiv(K > 0 ? K : 1, SCAN_TILE); }
+// [2 + survivor-scan tiles] then [2 + member tiles]: the two look-backs of a call share the buffer, not their words
+extern "C" int64_t tgp_connect_coalesce_rows_count_status_words(int64_t K, int64_t N) {
+  return 4 + cdiv(K > 0 ? K : 1, SCAN_TILE) + cdiv(N > 0 ? N : 1, MS_TILE);
+}
 
 extern "C" int tgp_connect_coalesce_rows_count_published(const int64_t* row, const int64_t* col, const int32_t* csr_col,
                                                          const float* w, int64_t E, const int64_t* cluster_index,
@@ -1656,7 +1743,7 @@ extern "C" int tgp_connect_coalesce_rows_count_published(const int64_t* row, con
                                                          int64_t* d_count, uint64_t* status, int64_t status_words,
                                                          uint64_t* result, uint32_t epoch, void* stream_) {
   TGP_REQUIRE(status && result && d_count, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_count_published: bad argument");
-  TGP_REQUIRE(status_words >= tgp_connect_coalesce_rows_count_status_words(K), TGP_ERR_WORKSPACE,
+  TGP_REQUIRE(status_words >= tgp_connect_coalesce_rows_count_status_words(K, N), TGP_ERR_WORKSPACE,
               "tgp_connect_coalesce_rows_count_published: status buffer too small");
   TGP_REQUIRE(epoch != 0 && epoch < (1u << 29), TGP_ERR_RANGE,
               "tgp_connect_coalesce_rows_count_published: epoch out of range");

@@ -62,7 +62,7 @@ SIGNATURES = {
     "tgp_connect_coalesce_rows_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p,
                                                  _c_int, _c_int, _c_f, _c_p, _c_sz, _c_p, _c_p]),
     "tgp_count_publish": (_c_int, [_c_p, _c_p, ctypes.c_uint32, _c_p]),
-    "tgp_connect_coalesce_rows_count_status_words": (_c_i64, [_c_i64]),
+    "tgp_connect_coalesce_rows_count_status_words": (_c_i64, [_c_i64, _c_i64]),
     "tgp_connect_coalesce_rows_count_published": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p,
                                                            _c_p, _c_p, _c_int, _c_int, _c_f, _c_p, _c_sz, _c_p, _c_p,
                                                            _c_i64, _c_p, ctypes.c_uint32, _c_p]),

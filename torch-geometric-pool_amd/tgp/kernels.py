@@ -541,7 +541,7 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
             if published:
                 # r4: the survivor scan is one look-back launch whose last workgroup stores the count into a pinned host
                 # word: no scan pair, no copy kernel, no stream synchronise; int32 columns when Select's CSR holds them
-                state = _sps_state(dev, st, L.tgp_connect_coalesce_rows_count_status_words(num_supernodes))
+                state = _sps_state(dev, st, L.tgp_connect_coalesce_rows_count_status_words(num_supernodes, cl.numel()))
                 epoch = state.next_epoch()
                 N.check(L.tgp_connect_coalesce_rows_count_published(
                     N.ptr(row), N.ptr(col), N.ptr(csr[1]) if csr is not None else None, N.ptr(w), E, N.ptr(cl),
