@@ -540,9 +540,9 @@ class TopkBatch(Workload):
         self.force = force_collective
         self.sg = None
         if self.gather:
-            # ONE payload collective per bucket of four steps, asynchronous, two deep: a gather overlaps the next steps' kernels
+            # ONE payload collective per bucket of eight steps, asynchronous, two deep: a gather overlaps the next steps' kernels
             from tgp.distributed import SparseGather
-            self.sg = SparseGather(force_collective=force_collective, depth=2, bucket_steps=4)
+            self.sg = SparseGather(force_collective=force_collective, depth=2, bucket_steps=8)
             self.drain = self.sg.flush
         self.nodes = self.x.size(0)
         self.num_graphs = 2048
@@ -555,7 +555,7 @@ class TopkBatch(Workload):
                       "step": ("BaseReduce then SparseConnect, operator by operator" if unfused else
                                "fused Reduce + Connect as the sparse poolers' forward calls it on a batch of small "
                                "graphs: SRCPooling.reduce_connect (one launch + the count read-back)")
-                              + (" + SparseGather (one asynchronous payload collective per 4 steps)" if self.gather else "")}
+                              + (" + SparseGather (one asynchronous payload collective per 8 steps)" if self.gather else "")}
 
     def staged(self):
         with torch.no_grad():
@@ -616,8 +616,9 @@ class TopkBatch(Workload):
             ms_g = event_time_ms(self.step, 50, dev)
             self.sg.flush()
             r["compute_plus_gather_ms"] = round(ms_g, 5)
-            r["gather"] = ("SparseGather: one payload collective per 4 steps, asynchronous (two in flight), unpack + id offsets "
-                           "in one launch per step, totals through pinned host words (no host wait)")
+            r["gather"] = ("SparseGather: one pack launch, one payload collective and one unpack (+ id offsets) launch per "
+                           "bucket of 8 steps, asynchronous (two buckets in flight), totals through pinned host words (no "
+                           "host wait)")
             from tgp.distributed import all_gather_sparse
             merged = all_gather_sparse(xp, ei, ew, bp, self.num_graphs, force_collective=self.force)
             if self.dist_world == 1:  # one-rank group: the merged result must be the local one, bit for bit

@@ -759,6 +759,18 @@ int tgp_gather_unpack_f32(const void* gathered, int64_t capacity,
                                               payload that does not fit capacity / k_cap / e_cap makes the launch a no-op
                                               apart from this report */,
                           uint64_t tag, void* stream);
+/* The same for a whole BUCKET of steps in one launch each (r4): step j of at most tgp_gather_max_bucket_steps() (= 8) is
+ * packed into out + j * capacity; after the single collective over the bucket ([world][n * capacity] bytes, rank_stride =
+ * n * capacity or more) one launch unpacks all its steps.  ptrs / dims are HOST arrays read during the call:
+ *   pack:   ptrs [n][5] = {x, batch (NULL ok), row, col, edge_weight (NULL ok)}, dims [n][5] = {x_row_stride,
+ *           num_supernodes, num_edges, num_graphs, num_features};
+ *   unpack: ptrs [n][6] = {x_out, batch_out (NULL ok), row_out, col_out, weight_out (NULL ok), result (NULL ok)},
+ *           dims [n][3] = {k_cap, e_cap, tag}. */
+int tgp_gather_max_bucket_steps(void);
+int tgp_gather_pack_bucket_f32(const void* const* ptrs, const int64_t* dims, int num_steps, int64_t capacity, void* out,
+                               void* stream);
+int tgp_gather_unpack_bucket_f32(const void* gathered, int64_t capacity, int64_t rank_stride, int world,
+                                 int64_t max_words, int num_steps, void* const* ptrs, const int64_t* dims, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,11 +29,10 @@ __host__ __device__ inline GpLayout gp_layout(int64_t K, int64_t E, int64_t F, i
   return l;
 }
 
-__global__ __launch_bounds__(256) void gp_pack_kernel(const float* __restrict__ x, int64_t x_stride,
-                                                      const int64_t* __restrict__ batch, const int64_t* __restrict__ row,
-                                                      const int64_t* __restrict__ col, const float* __restrict__ w,
-                                                      int64_t K, int64_t E, int64_t B, int64_t F, int64_t capacity,
-                                                      char* __restrict__ out) {
+__device__ __forceinline__ void gp_pack_body(const float* __restrict__ x, int64_t x_stride,
+                                             const int64_t* __restrict__ batch, const int64_t* __restrict__ row,
+                                             const int64_t* __restrict__ col, const float* __restrict__ w, int64_t K,
+                                             int64_t E, int64_t B, int64_t F, int64_t capacity, char* __restrict__ out) {
   const GpLayout l = gp_layout(K, E, F, w != nullptr);
   const int64_t tid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x, nthr = static_cast<int64_t>(gridDim.x) * 256;
   if (tid < GP_HEADER_WORDS) {
@@ -57,19 +56,44 @@ __global__ __launch_bounds__(256) void gp_pack_kernel(const float* __restrict__ 
   }
 }
 
+__global__ __launch_bounds__(256) void gp_pack_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                      const int64_t* __restrict__ batch, const int64_t* __restrict__ row,
+                                                      const int64_t* __restrict__ col, const float* __restrict__ w,
+                                                      int64_t K, int64_t E, int64_t B, int64_t F, int64_t capacity,
+                                                      char* __restrict__ out) {
+  gp_pack_body(x, x_stride, batch, row, col, w, K, E, B, F, capacity, out);
+}
+
+// r4, late: a whole BUCKET of steps in one launch (blockIdx.y = step): on a one-rank group, where nothing hides host time,
+// the per-step pack and unpack launches were a third of what the gather added to a step.
+constexpr int GP_MAX_STEPS = 8;
+struct GpPackStep {
+  const float* x;
+  const int64_t *batch, *row, *col;
+  const float* w;
+  int64_t x_stride, K, E, B, F;
+};
+struct GpPackArgs {
+  GpPackStep s[GP_MAX_STEPS];
+};
+__global__ __launch_bounds__(256) void gp_pack_bucket_kernel(GpPackArgs a, int64_t capacity, char* __restrict__ out) {
+  const GpPackStep& t = a.s[blockIdx.y];
+  gp_pack_body(t.x, t.x_stride, t.batch, t.row, t.col, t.w, t.K, t.E, t.B, t.F, capacity,
+               out + static_cast<int64_t>(blockIdx.y) * capacity);
+}
+
 // blockIdx.y = source rank; node ids += supernodes of the ranks before it, graph ids += their graphs
 // `rank_stride`: bytes between two ranks' buffers in `gathered` (a bucket of several steps is gathered at once: the
 // slot of this step sits at the same offset of every rank's bucket).  `result` (optional, pinned host memory): block
 // (0, 0) leaves {tag, K total, E total, largest needed_bytes, all headers valid} there -- the caller polls word 0 for
 // its tag instead of copying the headers back; a payload that did not fit (needed > capacity) or a bad header makes the
 // whole launch a no-op apart from that report.
-__global__ __launch_bounds__(256) void gp_unpack_kernel(const char* __restrict__ gathered, int64_t capacity,
-                                                        int64_t rank_stride, int world, int64_t k_cap, int64_t e_cap,
-                                                        float* __restrict__ x_out, int64_t* __restrict__ batch_out,
-                                                        int64_t* __restrict__ row_out, int64_t* __restrict__ col_out,
-                                                        float* __restrict__ w_out,
-                                                        unsigned long long* __restrict__ result,
-                                                        unsigned long long tag) {
+__device__ __forceinline__ void gp_unpack_body(const char* __restrict__ gathered, int64_t capacity,
+                                               int64_t rank_stride, int world, int64_t k_cap, int64_t e_cap,
+                                               float* __restrict__ x_out, int64_t* __restrict__ batch_out,
+                                               int64_t* __restrict__ row_out, int64_t* __restrict__ col_out,
+                                               float* __restrict__ w_out, unsigned long long* __restrict__ result,
+                                               unsigned long long tag) {
   const int r = blockIdx.y;
   {
     int64_t kt = 0, et = 0, need = 0;
@@ -122,6 +146,36 @@ __global__ __launch_bounds__(256) void gp_unpack_kernel(const char* __restrict__
   }
 }
 
+__global__ __launch_bounds__(256) void gp_unpack_kernel(const char* __restrict__ gathered, int64_t capacity,
+                                                        int64_t rank_stride, int world, int64_t k_cap, int64_t e_cap,
+                                                        float* __restrict__ x_out, int64_t* __restrict__ batch_out,
+                                                        int64_t* __restrict__ row_out, int64_t* __restrict__ col_out,
+                                                        float* __restrict__ w_out,
+                                                        unsigned long long* __restrict__ result,
+                                                        unsigned long long tag) {
+  gp_unpack_body(gathered, capacity, rank_stride, world, k_cap, e_cap, x_out, batch_out, row_out, col_out, w_out, result,
+                 tag);
+}
+
+struct GpUnpackStep {
+  float* x;
+  int64_t *batch, *row, *col;
+  float* w;
+  unsigned long long* result;
+  int64_t k_cap, e_cap;
+  unsigned long long tag;
+};
+struct GpUnpackArgs {
+  GpUnpackStep s[GP_MAX_STEPS];
+};
+// blockIdx.z = step of the bucket (its slot sits at z * capacity of every rank's bucket)
+__global__ __launch_bounds__(256) void gp_unpack_bucket_kernel(const char* __restrict__ gathered, int64_t capacity,
+                                                               int64_t rank_stride, int world, GpUnpackArgs a) {
+  const GpUnpackStep& t = a.s[blockIdx.z];
+  gp_unpack_body(gathered + static_cast<int64_t>(blockIdx.z) * capacity, capacity, rank_stride, world, t.k_cap, t.e_cap,
+                 t.x, t.batch, t.row, t.col, t.w, t.result, t.tag);
+}
+
 }  // namespace tgp
 
 using namespace tgp;
@@ -162,4 +216,73 @@ extern "C" int tgp_gather_unpack_f32(const void* gathered, int64_t capacity, int
                      batch_out, row_out, col_out, w_out, reinterpret_cast<unsigned long long*>(result),
                      static_cast<unsigned long long>(tag));
   return check_launch("tgp_gather_unpack_f32");
+}
+
+extern "C" int tgp_gather_max_bucket_steps(void) { return GP_MAX_STEPS; }
+
+// ptrs [n][5] = {x, batch, row, col, w} (batch / w: NULL ok), dims [n][5] = {x_stride, K, E, B, F}; step j is packed into
+// out + j * capacity.
+extern "C" int tgp_gather_pack_bucket_f32(const void* const* ptrs, const int64_t* dims, int n, int64_t capacity,
+                                          void* out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(ptrs && dims && n >= 1 && n <= GP_MAX_STEPS && capacity >= GP_HEADER_WORDS * 8 && out, TGP_ERR_INVALID,
+              "tgp_gather_pack_bucket_f32: bad argument");
+  GpPackArgs a{};
+  int64_t words = 0;
+  for (int j = 0; j < n; ++j) {
+    GpPackStep& t = a.s[j];
+    t.x = static_cast<const float*>(ptrs[5 * j]);
+    t.batch = static_cast<const int64_t*>(ptrs[5 * j + 1]);
+    t.row = static_cast<const int64_t*>(ptrs[5 * j + 2]);
+    t.col = static_cast<const int64_t*>(ptrs[5 * j + 3]);
+    t.w = static_cast<const float*>(ptrs[5 * j + 4]);
+    t.x_stride = dims[5 * j];
+    t.K = dims[5 * j + 1];
+    t.E = dims[5 * j + 2];
+    t.B = dims[5 * j + 3];
+    t.F = dims[5 * j + 4];
+    TGP_REQUIRE(t.K >= 0 && t.E >= 0 && t.B >= 0 && t.F >= 0 && (t.K == 0 || t.F == 0 || t.x) &&
+                    (t.E == 0 || (t.row && t.col)),
+                TGP_ERR_INVALID, "tgp_gather_pack_bucket_f32: bad step %d", j);
+    const int64_t wj = t.K * t.F + 2 * t.K + 5 * t.E + GP_HEADER_WORDS;
+    words = wj > words ? wj : words;
+  }
+  int64_t blocks = (words + 256 * 8 - 1) / (256 * 8);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gp_pack_bucket_kernel, dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(n)), dim3(256), 0,
+                     stream, a, capacity, static_cast<char*>(out));
+  return check_launch("tgp_gather_pack_bucket_f32");
+}
+
+// ptrs [n][6] = {x, batch, row, col, w, result} outputs of step j (batch / w / result: NULL ok), dims [n][3] = {k_cap,
+// e_cap, tag}; `rank_stride`: bytes between two ranks' buckets in `gathered`.
+extern "C" int tgp_gather_unpack_bucket_f32(const void* gathered, int64_t capacity, int64_t rank_stride, int world,
+                                            int64_t max_words, int n, void* const* ptrs, const int64_t* dims,
+                                            void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(gathered && ptrs && dims && n >= 1 && n <= GP_MAX_STEPS && capacity >= GP_HEADER_WORDS * 8 &&
+                  rank_stride >= static_cast<int64_t>(n) * capacity && world >= 1 && world <= 65535,
+              TGP_ERR_INVALID, "tgp_gather_unpack_bucket_f32: bad argument");
+  GpUnpackArgs a{};
+  for (int j = 0; j < n; ++j) {
+    GpUnpackStep& t = a.s[j];
+    t.x = static_cast<float*>(ptrs[6 * j]);
+    t.batch = static_cast<int64_t*>(ptrs[6 * j + 1]);
+    t.row = static_cast<int64_t*>(ptrs[6 * j + 2]);
+    t.col = static_cast<int64_t*>(ptrs[6 * j + 3]);
+    t.w = static_cast<float*>(ptrs[6 * j + 4]);
+    t.result = static_cast<unsigned long long*>(ptrs[6 * j + 5]);
+    t.k_cap = dims[3 * j];
+    t.e_cap = dims[3 * j + 1];
+    t.tag = static_cast<unsigned long long>(dims[3 * j + 2]);
+    TGP_REQUIRE(t.k_cap >= 0 && t.e_cap >= 0, TGP_ERR_INVALID, "tgp_gather_unpack_bucket_f32: bad step %d", j);
+  }
+  int64_t blocks = (max_words + 256 * 8 - 1) / (256 * 8);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(gp_unpack_bucket_kernel,
+                     dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(world), static_cast<unsigned>(n)),
+                     dim3(256), 0, stream, static_cast<const char*>(gathered), capacity, rank_stride, world, a);
+  return check_launch("tgp_gather_unpack_bucket_f32");
 }

@@ -197,6 +197,9 @@ SIGNATURES = {
     "tgp_gather_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_gather_unpack_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p,
                                        _c_p, ctypes.c_uint64, _c_p]),
+    "tgp_gather_max_bucket_steps": (_c_int, []),
+    "tgp_gather_pack_bucket_f32": (_c_int, [_c_p, _c_p, _c_int, _c_i64, _c_p, _c_p]),
+    "tgp_gather_unpack_bucket_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_i64, _c_int, _c_p, _c_p, _c_p]),
     "tgp_debug_sort_workspace_bytes": (_c_sz, [_c_i64]),
     "tgp_debug_sort_pairs_u64": (_c_int, [_c_p, _c_p, _c_i64, _c_int, _c_p, _c_p, _c_p, _c_sz, _c_p]),
 }

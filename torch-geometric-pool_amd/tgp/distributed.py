@@ -271,7 +271,7 @@ class SparseGather:
         self._collective = self.world > 1 or (dist.is_available() and dist.is_initialized()
                                               and (force_collective or bool(os.environ.get("TGP_FORCE_COLLECTIVE"))))
         self.depth = max(int(depth), 1)
-        self.bucket = max(int(bucket_steps), 1)
+        self.bucket = min(max(int(bucket_steps), 1), 8)  # (tgp_gather_max_bucket_steps)
         # ``capacity``: a caller that knows its payloads may start larger (the same value on every rank!)
         self.capacity = max(int(capacity if capacity is not None else self.INITIAL_CAPACITY), _GP_HEADER * 8)
         self._send: Optional[Tensor] = None
@@ -321,6 +321,42 @@ class SparseGather:
             if edge_weight is not None:
                 dst[ow: ow + E * 4] = edge_weight.reshape(-1).to(torch.float32).contiguous().view(torch.uint8)
 
+    def _pack_bucket(self, steps, cap: int) -> Tensor:
+        """Device path: every step of the bucket into its slot of a fresh send buffer, ONE launch."""
+        import ctypes
+        from . import _native as N
+        n = len(steps)
+        dev = steps[0][0].device
+        send = torch.empty(n * cap, dtype=torch.uint8, device=dev)
+        ptrs = (ctypes.c_void_p * (5 * n))()
+        dims = (ctypes.c_int64 * (5 * n))()
+        keep = []  # converted copies must outlive the launch (stream order: the allocator recycles them after it)
+        for j, (x, edge_index, edge_weight, batch, num_graphs) in enumerate(steps):
+            K, F, E = self._dims(x, edge_index)
+            x2 = x if x.dim() == 2 else x.reshape(K, F)
+            if not (x2.dtype == torch.float32 and (F <= 1 or x2.stride(1) == 1)):
+                x2 = x2.to(torch.float32).contiguous()
+            ei = edge_index
+            if not (ei.dtype == torch.int64 and (E <= 1 or ei.stride(1) == 1)):
+                ei = ei.to(torch.int64).contiguous()
+            w = edge_weight
+            if w is not None and not (w.dtype == torch.float32 and w.dim() == 1 and (E <= 1 or w.stride(0) == 1)):
+                w = N.f32c(w.reshape(-1))
+            b = batch
+            if b is not None and not (b.dtype == torch.int64 and b.dim() == 1 and (K <= 1 or b.stride(0) == 1)):
+                b = N.i64c(b)
+            keep.append((x2, ei, w, b))
+            o = 5 * j
+            ptrs[o] = x2.data_ptr() if K * F else None
+            ptrs[o + 1] = None if b is None else b.data_ptr()
+            ptrs[o + 2] = ei.data_ptr() if E else None
+            ptrs[o + 3] = ei.data_ptr() + 8 * ei.stride(0) if E else None
+            ptrs[o + 4] = None if w is None else w.data_ptr()
+            dims[o], dims[o + 1], dims[o + 2], dims[o + 3], dims[o + 4] = (x2.stride(0) if K else F), K, E, num_graphs, F
+        N.check(N.lib().tgp_gather_pack_bucket_f32(ptrs, dims, n, cap, send.data_ptr(), N.stream_ptr(dev)),
+                "tgp_gather_pack_bucket_f32")
+        return send
+
     @staticmethod
     def _grown(need: int) -> int:
         return ((need + need // 4 + 4095) // 4096) * 4096
@@ -329,11 +365,16 @@ class SparseGather:
     def start(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Optional[Tensor],
               num_graphs_local: int) -> None:
         inputs = (x, edge_index, edge_weight, batch, int(num_graphs_local))
-        if self._send is None:
-            self._send = torch.empty(self.bucket * self.capacity, dtype=torch.uint8, device=x.device)
-        j = len(self._open)
-        self._pack(inputs, self._send[j * self.capacity: (j + 1) * self.capacity])
-        self._open.append(inputs)
+        if x.is_cuda:
+            # device path: the whole bucket is packed by ONE launch when it goes out (`_launch`); until then the tensors
+            # handed over must not be written to (the pooled outputs of a step are fresh tensors)
+            self._open.append(inputs)
+        else:
+            if self._send is None:
+                self._send = torch.empty(self.bucket * self.capacity, dtype=torch.uint8, device=x.device)
+            j = len(self._open)
+            self._pack(inputs, self._send[j * self.capacity: (j + 1) * self.capacity])
+            self._open.append(inputs)
         if len(self._open) == self.bucket:
             self._launch()
 
@@ -347,7 +388,10 @@ class SparseGather:
         if not self._open or (len(self._open) < self.bucket and not partial):
             return
         n, cap = len(self._open), self.capacity
-        send = self._send[: n * cap]
+        if self._open[0][0].is_cuda:
+            send = self._pack_bucket(self._open, cap)
+        else:
+            send = self._send[: n * cap]
         dev = send.device
         if self._collective:
             gathered = torch.empty(self.world * n * cap, dtype=torch.uint8, device=dev)
@@ -389,16 +433,27 @@ class SparseGather:
             ow = _gp_align(oe + 2 * e_cap * 8)
             total = _gp_align(ow + (e_cap * 4 if has_w else 0))
             plan.append((F, has_w, k_cap, e_cap, ox, ob, oe, ow))
-        out = torch.empty(total, dtype=torch.uint8, device=dev)
-        base, gbase = out.data_ptr(), gathered.data_ptr()
+        import ctypes
+        out8 = torch.empty(total, dtype=torch.uint8, device=dev)
+        # two typed views of the bucket's output buffer, made once: every merged tensor is then ONE as_strided away
+        out = (out8.view(torch.float32), out8.view(torch.int64))
+        base, gbase = out8.data_ptr(), gathered.data_ptr()
         max_words = cap // 4
+        ptrs = (ctypes.c_void_p * (6 * n))()
+        dims = (ctypes.c_int64 * (3 * n))()
+        pin = self._pin.data_ptr()
         for j, (F, has_w, k_cap, e_cap, ox, ob, oe, ow) in enumerate(plan):
             self._tick += 1
             slot, tag = self._tick % nslots, self._tick
-            N.check(L.tgp_gather_unpack_f32(gbase + j * cap, cap, n * cap, self.world, max_words, k_cap, e_cap, base + ox,
-                                            base + ob, base + oe, base + oe + 8 * e_cap, base + ow if has_w else None,
-                                            self._pin.data_ptr() + slot * 64, tag, st), "tgp_gather_unpack_f32")
+            o = 6 * j
+            ptrs[o], ptrs[o + 1], ptrs[o + 2], ptrs[o + 3] = base + ox, base + ob, base + oe, base + oe + 8 * e_cap
+            ptrs[o + 4] = base + ow if has_w else None
+            ptrs[o + 5] = pin + slot * 64
+            dims[3 * j], dims[3 * j + 1], dims[3 * j + 2] = k_cap, e_cap, tag
             steps.append((slot, tag, out, plan[j]))
+        # ONE launch for the whole bucket (grid z = step)
+        N.check(L.tgp_gather_unpack_bucket_f32(gbase, cap, n * cap, self.world, max_words, n, ptrs, dims, st),
+                "tgp_gather_unpack_bucket_f32")
         bucket["steps"] = steps
 
     def _poll(self, slot: int, tag: int, block: bool) -> bool:
@@ -454,10 +509,11 @@ class SparseGather:
             self._inflight.pop(0)
             for inputs, kt, et, out, (F, has_w, k_cap, e_cap, ox, ob, oe, ow) in results:
                 x_in, _, _, b_in, _ = inputs
-                xo = out[ox: ox + kt * F * 4].view(torch.float32).view(kt, F)
-                eo = out[oe: oe + 2 * e_cap * 8].view(torch.int64).view(2, e_cap)[:, :et]
-                wo = out[ow: ow + et * 4].view(torch.float32) if has_w else None
-                bo = out[ob: ob + kt * 8].view(torch.int64) if b_in is not None else None
+                f32, i64 = out
+                xo = torch.as_strided(f32, (kt, F), (F, 1), ox >> 2)
+                eo = torch.as_strided(i64, (2, et), (e_cap, 1), oe >> 3)
+                wo = torch.as_strided(f32, (et,), (1,), ow >> 2) if has_w else None
+                bo = torch.as_strided(i64, (kt,), (1,), ob >> 3) if b_in is not None else None
                 if x_in.dim() == 1:
                     xo = xo.view(-1)
                 if x_in.dtype != torch.float32 and x_in.is_floating_point():
