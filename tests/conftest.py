@@ -31,3 +31,16 @@ def golden():
     blob = torch.load(path, weights_only=True)
     assert blob["tgp_version"] == "1.0.1"
     return blob["cases"]
+
+
+@pytest.fixture(autouse=True)
+def _seeded(request):
+    """Every test starts from its own fixed seed (a CRC of its id): this build of torch seeds the default generators from
+    the clock, and a pooler's randomly initialised score weights decide near-ties between two nodes -- a comparison with
+    the CPU oracle (different summation order) must not depend on the run."""
+    import zlib
+    seed = zlib.crc32(request.node.nodeid.encode())
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    yield
