@@ -791,7 +791,10 @@ class GraclusC4(Workload):
         so, f, n, k = self.so, self.f, self.n, self.k
         idx = so.assign_index()
         alg_r = n * (4.0 * f + 8 + 8 + 4) + k * 4.0 * f
-        ms_r = event_time_ms(lambda: kernels.reduce_sparse(self.x, so.node_index, so.weight, idx), 50, dev)
+        # (as BaseReduce calls it: a clustering's S has row index 0..N-1 and unit values, which the SelectOutput knows)
+        ident, unit = bool(so.__dict__.get("_identity_nodes", False)), bool(so.__dict__.get("_unit_values", False))
+        ms_r = event_time_ms(lambda: kernels.reduce_sparse(self.x, so.node_index, so.weight, idx, identity_source=ident,
+                                                           unit_weight=unit), 50, dev)
         ei_out, _ = self.conn(self.ei, so, edge_weight=self.ew)
         E, E2 = self.ei.size(1), ei_out.size(1)
         alg_c = E * 20.0 + n * 8.0 + E2 * 20.0  # SURVEY 8(d) A4+A6

@@ -192,42 +192,56 @@ __global__ __launch_bounds__(256) void reduce_sparse_vec4_kernel(
       float4 acc[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int32_t m = 0; m < maxlen; ++m) {
-        int32_t a[U];
-        float w[U];
-        int64_t n[U];
-        float4 v[U];
+      // r4: TWO members of every supernode per round, level by level (slots, then node ids + weights, then rows): a
+      // Graclus supernode (one or two members) is row offsets -> slots -> [ids] -> rows, three or four dependent round
+      // trips where the one-member-at-a-time loop paid seven; the adds keep the member order.  node_index == NULL: the
+      // source row IS the assignment id (S's row index is 0..N-1: GraclusSelect, a cluster vector), one level less.
+      constexpr int MP = 2;
+      for (int32_t m0 = 0; m0 < maxlen; m0 += MP) {
+        int32_t a[U][MP];
+        float w[U][MP];
+        int64_t n[U][MP];
+        float4 v[U][MP];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          int32_t slot = beg[u] + (m < len[u] ? m : 0);
-          slot = slot < last ? slot : last;
-          a[u] = perm ? perm[slot] : slot;
-        }
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          w[u] = weight ? weight[a[u]] : 1.0f;
-          n[u] = node_index[a[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const float* src = x + n[u] * x_stride + f;
-          if constexpr (NT) {  // rows are read exactly once: keep them out of the way of the index tables
-            const nt_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(src));
-            v[u] = make_float4(t.x, t.y, t.z, t.w);
-          } else {
-            v[u] = *reinterpret_cast<const float4*>(src);
+          for (int q = 0; q < MP; ++q) {
+            int32_t slot = beg[u] + (m0 + q < len[u] ? m0 + q : 0);
+            slot = slot < last ? slot : last;
+            a[u][q] = perm ? perm[slot] : slot;
           }
-        }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const bool on = m < len[u];  // product rounded before the add, as the reference's two-step form
-          const float px = __fadd_rn(acc[u].x, __fmul_rn(v[u].x, w[u])), py = __fadd_rn(acc[u].y, __fmul_rn(v[u].y, w[u]));
-          const float pz = __fadd_rn(acc[u].z, __fmul_rn(v[u].z, w[u])), pw = __fadd_rn(acc[u].w, __fmul_rn(v[u].w, w[u]));
-          acc[u].x = on ? px : acc[u].x;
-          acc[u].y = on ? py : acc[u].y;
-          acc[u].z = on ? pz : acc[u].z;
-          acc[u].w = on ? pw : acc[u].w;
-        }
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int q = 0; q < MP; ++q) {
+            w[u][q] = weight ? weight[a[u][q]] : 1.0f;
+            n[u][q] = node_index ? node_index[a[u][q]] : static_cast<int64_t>(a[u][q]);
+          }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int q = 0; q < MP; ++q) {
+            const float* src = x + n[u][q] * x_stride + f;
+            if constexpr (NT) {  // rows are read exactly once: keep them out of the way of the index tables
+              const nt_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(src));
+              v[u][q] = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+              v[u][q] = *reinterpret_cast<const float4*>(src);
+            }
+          }
+#pragma unroll
+        for (int q = 0; q < MP; ++q)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const bool on = m0 + q < len[u];  // product rounded before the add, as the reference's two-step form
+            const float wq = w[u][q];
+            const float px = __fadd_rn(acc[u].x, __fmul_rn(v[u][q].x, wq)), py = __fadd_rn(acc[u].y, __fmul_rn(v[u][q].y, wq));
+            const float pz = __fadd_rn(acc[u].z, __fmul_rn(v[u][q].z, wq)), pw = __fadd_rn(acc[u].w, __fmul_rn(v[u][q].w, wq));
+            acc[u].x = on ? px : acc[u].x;
+            acc[u].y = on ? py : acc[u].y;
+            acc[u].z = on ? pz : acc[u].z;
+            acc[u].w = on ? pw : acc[u].w;
+          }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -358,7 +372,7 @@ __global__ __launch_bounds__(256) void reduce_sparse_scalar_kernel(
     for (int32_t p = p_beg; p < p_end; ++p) {
       const int32_t a = perm ? perm[p] : p;
       const float w = weight ? weight[a] : 1.0f;
-      acc = __fadd_rn(acc, __fmul_rn(x[node_index[a] * x_stride + f], w));
+      acc = __fadd_rn(acc, __fmul_rn(x[(node_index ? node_index[a] : static_cast<int64_t>(a)) * x_stride + f], w));
     }
     x_pool[o] = acc;
   }
@@ -449,8 +463,11 @@ extern "C" int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t 
   TGP_REQUIRE(num_nodes >= 0 && F >= 0 && K >= 0 && nnz >= 0 && (row_ptr || nnz == K), TGP_ERR_INVALID,
               "tgp_reduce_sparse_f32: bad argument");  // row_ptr == NULL: one assignment per supernode
   if (K == 0 || F == 0) return TGP_OK;
-  TGP_REQUIRE(x_pool && (nnz == 0 || (x && node_index)), TGP_ERR_INVALID,  // perm == NULL: identity order
+  TGP_REQUIRE(x_pool && (nnz == 0 || x), TGP_ERR_INVALID,  // perm == NULL: identity order
               "tgp_reduce_sparse_f32: null pointer");
+  // node_index == NULL (r4): assignment i reads row i (S's row index is 0..nnz-1); only the vectorised general kernel
+  TGP_REQUIRE(node_index || (row_ptr && nnz <= num_nodes), TGP_ERR_INVALID,
+              "tgp_reduce_sparse_f32: node_index may only be omitted with a supernode index over nnz <= num_nodes rows");
   const bool vec = (F % 4 == 0) && (x_stride % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
                    (reinterpret_cast<uintptr_t>(x_pool) % 16 == 0);
   const int cus = 256;
@@ -463,7 +480,12 @@ extern "C" int tgp_reduce_sparse_f32(const float* x, int64_t num_nodes, int64_t 
     if (blocks > cus * 8) blocks = cus * 8;
     if (blocks < 1) blocks = 1;
     dim3 grid(static_cast<unsigned>(blocks)), block(256);
-    static const int kU = getenv("TGP_REDUCE_U") ? atoi(getenv("TGP_REDUCE_U")) : 2;
+    // supernodes in flight per lane group: with two MEMBERS of a supernode requested per round (r4) a Graclus-shaped
+    // assignment (at most two members: nnz <= 2 K) has its rows in flight from ONE supernode per group and a second one
+    // only costs registers (C4 Reduce, MI355X: U = 1 0.134 ms = 0.755 of HBM, U = 2 0.142, U = 4 0.155); longer member
+    // lists keep two supernodes per group as before.  TGP_REDUCE_U overrides (A/B measurements).
+    static const int kUenv = getenv("TGP_REDUCE_U") ? atoi(getenv("TGP_REDUCE_U")) : 0;
+    const int kU = kUenv > 0 ? kUenv : (row_ptr && nnz <= 2 * K ? 1 : 2);
     static const int kNT = getenv("TGP_REDUCE_NT") ? atoi(getenv("TGP_REDUCE_NT")) : 1;
     static const int kBlocksPerCu = getenv("TGP_REDUCE_BPC") ? atoi(getenv("TGP_REDUCE_BPC")) : 8;
     blocks = (K + groups_per_block * kU - 1) / (groups_per_block * kU);

@@ -83,9 +83,12 @@ def build_assign_index(target_index: Tensor, num_targets: int) -> AssignIndex:
     return AssignIndex(row_ptr, perm, nnz, num_targets)
 
 
-def reduce_sparse(x: Tensor, source_index: Tensor, weight: Optional[Tensor], index: AssignIndex) -> Tensor:
+def reduce_sparse(x: Tensor, source_index: Tensor, weight: Optional[Tensor], index: AssignIndex,
+                  identity_source: bool = False, unit_weight: bool = False) -> Tensor:
     """out[t,:] = sum_{i: target[i]==t} weight[i] * x[source_index[i],:]
-    (reduce/base_reduce.py:146-153; lift/base_lift.py:102-111 with the roles swapped)."""
+    (reduce/base_reduce.py:146-153; lift/base_lift.py:102-111 with the roles swapped).
+    ``identity_source`` / ``unit_weight``: the caller KNOWS that source_index is 0..nnz-1 / that every weight is 1.0 (a
+    clustering: GraclusSelect, a cluster vector) -- the fp32 kernel then skips those two loads per assignment; same bits."""
     dev = N.require_device(x, source_index, weight)
     squeeze = x.dim() == 1
     x2 = x.view(-1, 1) if squeeze else x
@@ -116,7 +119,10 @@ def reduce_sparse(x: Tensor, source_index: Tensor, weight: Optional[Tensor], ind
                                                   0 if w is None else 1, index.num_targets, N.ptr(out),
                                                   N.stream_ptr(dev)), "tgp_reduce_one_to_one_f32")
         return out.view(-1) if squeeze else out
-    N.check(N.lib().tgp_reduce_sparse_f32(N.ptr(x2), x2.size(0), F, x2.stride(0), N.ptr(source_index), N.ptr(w),
+    fast = index._row_ptr is not None and index.nnz <= x2.size(0)
+    N.check(N.lib().tgp_reduce_sparse_f32(N.ptr(x2), x2.size(0), F, x2.stride(0),
+                                          None if (identity_source and fast) else N.ptr(source_index),
+                                          None if unit_weight else N.ptr(w),
                                           N.ptr(index._row_ptr), N.ptr(index.perm), index.nnz,
                                           index.num_targets, N.ptr(out), N.stream_ptr(dev)),
             "tgp_reduce_sparse_f32")

@@ -93,7 +93,10 @@ class _SparseReduceFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, so):
-        out = K.reduce_sparse(x, so.node_index, weight, so.assign_index())
+        # a clustering whose S has row index 0..N-1 and unit values (GraclusSelect; a cluster vector): known, not probed
+        out = K.reduce_sparse(x, so.node_index, weight, so.assign_index(),
+                              identity_source=bool(so.__dict__.get("_identity_nodes", False)),
+                              unit_weight=bool(so.__dict__.get("_unit_values", False)))
         ctx.so = so
         ctx.save_for_backward(x, weight)
         return out

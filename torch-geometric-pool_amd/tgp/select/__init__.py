@@ -99,6 +99,10 @@ class SelectOutput:
                 _check_assignment_ranges(cluster_index, node_index, num_nodes, num_supernodes)
             s = cluster_to_s(cluster_index, node_index=node_index, num_supernodes=num_supernodes,
                              num_nodes=num_nodes, weight=weight)
+            if node_index is None:
+                self.__dict__["_identity_nodes"] = True  # cluster_to_s numbered the rows 0..N-1 itself ...
+            if weight is None:
+                self.__dict__["_unit_values"] = True  # ... and filled the values with ones
         else:
             raise ValueError("Either a sparse or dense assignment matrix is provided through 's' or a cluster "
                              "assignment vector must be provided thorough 'cluster_index'.")
@@ -746,6 +750,7 @@ class GraclusSelect(Select):
             s = torch.sparse_coo_tensor(index, ones, size=(num_nodes, k), is_coalesced=True)
             so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
             so.__dict__["_identity_nodes"] = True  # row 0 of the indices is 0..N-1: the transposed index is the identity
+            so.__dict__["_unit_values"] = True  # S's values are the ones the kernels wrote
             so.__dict__["_no_empty_cluster"] = True  # ids are the ranks of the representatives: every id has its node
             so._assign_index = assign
             if row_ptr is not None:
