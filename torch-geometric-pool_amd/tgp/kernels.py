@@ -181,10 +181,11 @@ SPS_COMPACT_BYTES = 1 << 30  # capacity buffers above this are replaced by exact
 
 
 class _SpsState:
-    """Per (device, stream): the look-back words of ``tgp_sparse_pool_small_f32`` (device memory, never cleared: every
+    """Per (device, stream): the look-back words of the one-launch kernels (``tgp_sparse_pool_small_f32``, the single-pass
+    subgraph Connect, the coalesce Connect's scans, the one-launch GraclusSelect; device memory, never cleared: every
     word carries the epoch of the call that wrote it), the epoch counter, and ONE pinned host word the kernel's last
     workgroup stores {epoch, refused, total} into -- the host polls it instead of paying a device-to-host copy kernel
-    and a stream synchronise for eight bytes."""
+    and a stream synchronise for eight bytes (``tgp_count_publish`` gives every count -> fill pair the same read)."""
 
     __slots__ = ("status", "epoch", "pinned", "host")
 
@@ -216,7 +217,7 @@ class _SpsState:
                 word = int(host[0])
                 if (word >> 34) == epoch:
                     return word
-                raise N.TgpNativeError("tgp_sparse_pool_small_f32 finished without publishing its result word")
+                raise N.TgpNativeError("a kernel that hands its count over in a pinned host word finished without storing it")
 
 
 def _sps_state(dev: torch.device, stream: int, words: int) -> "_SpsState":
