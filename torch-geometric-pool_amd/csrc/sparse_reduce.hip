@@ -592,7 +592,9 @@ extern "C" int tgp_reduce_one_to_one_f32(const float* x, int64_t num_nodes, int6
   int G = 8;
   while (G < lanes && G < 64) G <<= 1;
   static const int kBlocksPerCu = getenv("TGP_REDUCE_BPC") ? atoi(getenv("TGP_REDUCE_BPC")) : 8;
-  static const int kU = getenv("TGP_REDUCE_O2O") ? atoi(getenv("TGP_REDUCE_O2O")) : 2;
+  // supernodes in flight per lane group: one (r4 sweep on MI355X, topk1m / c4_ndp: U = 1 0.760 / 0.787-0.793 of HBM,
+  // U = 2 0.751 / 0.781, U = 4 0.68: the packed index made the chain short enough that occupancy wins)
+  static const int kU = getenv("TGP_REDUCE_O2O") ? atoi(getenv("TGP_REDUCE_O2O")) : 1;
   const int uu = kU >= 4 ? 4 : (kU >= 2 ? 2 : 1);
   const int64_t groups_per_block = 256 / G;
   int64_t blocks = (K + groups_per_block * uu - 1) / (groups_per_block * uu);
