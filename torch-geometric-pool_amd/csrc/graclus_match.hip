@@ -580,6 +580,7 @@ struct GfArgs {
   int64_t N, E;
   const int64_t* gptr;
   int64_t B;
+  const int64_t* edge_ptr;  // NULL, or [B + 1]: first entry of every graph (the caller's memo; re-checked)
   int64_t* label;  // NULL ok
   int64_t* index;  // [2, N]
   int32_t *a_row_ptr, *a_perm;
@@ -603,7 +604,17 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gm_graph_fused_kernel(GfArgs p)
     s_nb[threadIdx.x] = p.gptr[gi];
     s_eb[threadIdx.x] = INT_MAX;
   }
-  if (wv == 0) {
+  const bool given = p.edge_ptr != nullptr;  // (as sparse_pool_small_kernel: one round trip instead of the searches)
+  if (given) {
+    if (threadIdx.x <= GF_WAVES) {
+      const int64_t gi = g0 + threadIdx.x < p.B ? g0 + threadIdx.x : p.B;
+      const int64_t eg = p.edge_ptr[gi], e_first = p.edge_ptr[g0 < p.B ? g0 : p.B];
+      if (threadIdx.x == 0) s_rng[0] = eg;
+      if (threadIdx.x == GF_WAVES) s_rng[1] = eg;
+      const int64_t de = eg - e_first;
+      s_eb[threadIdx.x] = (de < 0 || de > INT_MAX - 1) ? -1 : static_cast<int>(de);
+    }
+  } else if (wv == 0) {
     const int64_t N0 = p.gptr[g0], N1 = p.gptr[g0 + GF_WAVES < p.B ? g0 + GF_WAVES : p.B];
     const int64_t* const arrs[2] = {p.row, p.row};
     const int64_t ns[2] = {p.E, p.E}, keys[2] = {N0, N1};
@@ -618,8 +629,9 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gm_graph_fused_kernel(GfArgs p)
   if (LE < 0 || (blockIdx.x == 0 && (E0 != 0 || s_nb[0] != 0)) ||
       (blockIdx.x == gridDim.x - 1 && (E1 != p.E || s_nb[GF_WAVES] != p.N)))
     bad = true;
-  if (!bad) sps_boundaries<GF_WAVES>(p.row, E0, LE, s_nb, s_eb);
-  __syncthreads();
+  if (!bad && !given) sps_boundaries<GF_WAVES>(p.row, E0, LE, s_nb, s_eb);
+  if (!given) __syncthreads();
+  if (given && (s_eb[wv] < 0 || s_eb[wv + 1] < 0)) bad = true;  // a corrupt table
   int64_t n0 = s_nb[wv], n1 = s_nb[wv + 1];
   if (n1 < n0 || n1 - n0 > 64 || n0 < 0 || n1 > p.N) {
     bad = true;
@@ -1067,7 +1079,8 @@ extern "C" int64_t tgp_graclus_match_graphs_fused_status_words(int64_t B) { retu
 // r4: matching + consecutive cluster ids + supernode -> members index of a sorted batch of graphs of at most 64 nodes in
 // ONE launch (gm_graph_fused_kernel).  row / col / w: the row-sorted edge list itself (no CSR needed).
 extern "C" int tgp_graclus_match_graphs_fused(const int64_t* row, const int64_t* col, const float* w, int64_t N, int64_t E,
-                                              const int64_t* graph_ptr, int64_t B, int64_t* label, int64_t* index,
+                                              const int64_t* graph_ptr, int64_t B, const int64_t* edge_ptr,
+                                              int64_t* label, int64_t* index,
                                               int32_t* assign_row_ptr, int32_t* assign_perm, float* ones,
                                               uint64_t* status, int64_t status_words, uint64_t* result, uint32_t epoch,
                                               void* stream_) {
@@ -1079,7 +1092,7 @@ extern "C" int tgp_graclus_match_graphs_fused(const int64_t* row, const int64_t*
   TGP_REQUIRE(status_words >= tgp_graclus_match_graphs_fused_status_words(B), TGP_ERR_WORKSPACE,
               "tgp_graclus_match_graphs_fused: status buffer too small");
   TGP_REQUIRE(epoch != 0 && epoch < (1u << 29), TGP_ERR_RANGE, "tgp_graclus_match_graphs_fused: epoch out of range");
-  const GfArgs a{row, col, w, N, E, graph_ptr, B, label, index, assign_row_ptr, assign_perm, ones,
+  const GfArgs a{row, col, w, N, E, graph_ptr, B, edge_ptr, label, index, assign_row_ptr, assign_perm, ones,
                  reinterpret_cast<unsigned long long*>(status), reinterpret_cast<unsigned long long*>(result),
                  static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT};
   hipLaunchKernelGGL(gm_graph_fused_kernel, dim3(static_cast<unsigned>(cdiv(B, GF_WAVES))), dim3(GF_WAVES * 64), 0,

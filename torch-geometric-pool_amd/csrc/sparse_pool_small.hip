@@ -58,6 +58,8 @@ struct SpsArgs {
   int64_t* out_row;
   int64_t* out_col;
   float* out_w;
+  const int64_t* edge_ptr;     // NULL, or [B + 1]: first edge of every graph (lower bounds of gptr in `row`)
+  const int64_t* assign_ptr;   // NULL, or [B + 1] (MODE 0): first assignment of every graph
   unsigned long long* status;  // [2 + tile] look-back state, epoch-tagged ([0], [1] reserved)
   unsigned long long* result;  // ONE word {epoch, refused (bit 31), total}; may live in pinned host memory
   unsigned long long tag;      // epoch << SPS_EPOCH_SHIFT
@@ -113,7 +115,31 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
     s_eb[threadIdx.x] = INT_MAX;
     s_ab[threadIdx.x] = INT_MAX;
   }
-  if (wv == 0) {
+  // r4, late: the caller may hand over the per-graph offsets it already has (the edge offsets memoised per edge list and
+  // batch vector, TopkSelect's keep-count prefix): the graph's ranges are then ONE round trip instead of the three
+  // dependent search rounds + the boundary pass below (5.8 of the kernel's 13.4 us on 2048 PROTEINS-shaped graphs).
+  // Nothing is trusted: the ranges must tile [0, E) / [0, nnz) and every edge / kept node is range-checked as before.
+  const bool given = p.edge_ptr != nullptr && (MODE == 1 || p.assign_ptr != nullptr);
+  if (given) {
+    if (threadIdx.x <= WAVES) {
+      const int64_t gi = g0 + threadIdx.x < p.B ? g0 + threadIdx.x : p.B;
+      const int64_t eg = p.edge_ptr[gi], ag = MODE == 0 ? p.assign_ptr[gi] : 0;
+      if (threadIdx.x == 0) {
+        s_rng[0] = eg;
+        s_rng[2] = ag;
+      }
+      if (threadIdx.x == WAVES) {
+        s_rng[1] = eg;
+        s_rng[3] = ag;
+      }
+      // offsets relative to the workgroup's first graph, as the boundary pass leaves them (clamped: a corrupt table
+      // must fail the checks below, not overflow an int)
+      const int64_t e_first = p.edge_ptr[g0 < p.B ? g0 : p.B], a_first = MODE == 0 ? p.assign_ptr[g0 < p.B ? g0 : p.B] : 0;
+      const int64_t de = eg - e_first, da = ag - a_first;
+      s_eb[threadIdx.x] = (de < 0 || de > INT_MAX - 1) ? -1 : static_cast<int>(de);  // -1: refused below
+      s_ab[threadIdx.x] = (da < 0 || da > INT_MAX - 1) ? -1 : static_cast<int>(da);
+    }
+  } else if (wv == 0) {
     const int64_t N0 = p.gptr[g0], N1 = p.gptr[g0 + WAVES < p.B ? g0 + WAVES : p.B];
     if constexpr (MODE == 0) {
       const int64_t* const arrs[4] = {p.row, p.row, p.node_index, p.node_index};
@@ -138,11 +164,11 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
   if (LE < 0 || LA < 0 || (blockIdx.x == 0 && (E0 != 0 || A0 != 0 || s_nb[0] != 0)) ||
       (blockIdx.x == gridDim.x - 1 && (E1 != p.E || (MODE == 0 && A1 != p.nnz) || s_nb[WAVES] != p.N)))
     bad = true;
-  if (!bad) {
+  if (!bad && !given) {
     sps_boundaries<WAVES>(p.row, E0, LE, s_nb, s_eb);
     if constexpr (MODE == 0) sps_boundaries<WAVES>(p.node_index, A0, LA, s_nb, s_ab);
   }
-  __syncthreads();
+  if (!given) __syncthreads();
   SPS_STAMP(1);
   int64_t n0 = s_nb[wv], n1 = s_nb[wv + 1];
   if (n1 < n0 || n1 - n0 > 64 || n0 < 0 || n1 > p.N) {
@@ -150,6 +176,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
     n0 = n1 = 0;
   }
   int64_t e0 = 0, e1 = 0, a0 = 0, a1 = 0;
+  if (given && (s_eb[wv] < 0 || s_eb[wv + 1] < 0 || s_ab[wv] < 0 || s_ab[wv + 1] < 0)) bad = true;  // a corrupt table
   if (!bad) {
     const int64_t b0 = s_eb[wv] < LE ? s_eb[wv] : LE, b1 = s_eb[wv + 1] < LE ? s_eb[wv + 1] : LE;
     e0 = E0 + b0;
@@ -572,8 +599,35 @@ extern "C" int64_t tgp_sparse_pool_small_status_words(int64_t num_graphs, int mo
 #endif
 }
 
+// out[g] = first position of `values` (ascending, n entries) that is >= graph_ptr[g], g = 0..B: the per-graph offsets of a
+// row-sorted edge list (values = its row array) or of a node-sorted assignment (values = node_index) of a sorted batch.
+// A caller that pools the same edge list / batch vector again keeps them (tgp_sparse_pool_small_f32's edge_ptr).
+__global__ __launch_bounds__(256) void graph_lower_bounds_kernel(const int64_t* __restrict__ values, int64_t n,
+                                                                 const int64_t* __restrict__ gptr, int64_t B,
+                                                                 int64_t* __restrict__ out) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (g > B) return;
+  const int64_t key = gptr[g];
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (values[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  out[g] = lo;
+}
+
+extern "C" int tgp_graph_lower_bounds_i64(const int64_t* values, int64_t n, const int64_t* graph_ptr, int64_t B,
+                                          int64_t* out, void* stream_) {
+  TGP_REQUIRE(n >= 0 && B >= 0 && graph_ptr && out && (n == 0 || values), TGP_ERR_INVALID,
+              "tgp_graph_lower_bounds_i64: bad argument");
+  hipLaunchKernelGGL(graph_lower_bounds_kernel, dim3(cdiv(B + 1, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     values, n, graph_ptr, B, out);
+  return check_launch("tgp_graph_lower_bounds_i64");
+}
+
 extern "C" int tgp_sparse_pool_small_f32(const float* x, int64_t N, int64_t F, int64_t x_stride, const int64_t* graph_ptr,
-                                         int64_t B, const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                         int64_t B, const int64_t* edge_ptr, const int64_t* assign_ptr,
+                                         const int64_t* row, const int64_t* col, const float* w, int64_t E,
                                          const int64_t* node_index, const int64_t* cluster_index, const float* weight,
                                          int64_t nnz, int64_t K, int mode, int reduce_op, int flags, float eps,
                                          float* x_pool, int64_t* batch_pool, int64_t* out_row, int64_t* out_col,
@@ -591,7 +645,8 @@ extern "C" int tgp_sparse_pool_small_f32(const float* x, int64_t N, int64_t F, i
   TGP_REQUIRE(status_words >= tgp_sparse_pool_small_status_words(B, mode), TGP_ERR_WORKSPACE,
               "tgp_sparse_pool_small_f32: status buffer too small");
   SpsArgs a{x, N, F, x_stride, graph_ptr, B, row, col, w, E, node_index, cluster_index, weight, nnz, K, reduce_op, flags,
-            eps, x_pool, batch_pool, out_row, out_col, out_w, reinterpret_cast<unsigned long long*>(status),
+            eps, x_pool, batch_pool, out_row, out_col, out_w, edge_ptr, assign_ptr,
+            reinterpret_cast<unsigned long long*>(status),
             reinterpret_cast<unsigned long long*>(result), static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT};
   if (mode == 0) {
     hipLaunchKernelGGL((sparse_pool_small_kernel<0, SPS_WAVES_TOPK>), dim3(cdiv(B, SPS_WAVES_TOPK)),

@@ -74,7 +74,8 @@ SIGNATURES = {
     "tgp_connect_coalesce_fused_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_sparse_pool_small_max_graph_nodes": (_c_int, []),
     "tgp_sparse_pool_small_status_words": (_c_i64, [_c_i64, _c_int]),
-    "tgp_sparse_pool_small_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p,
+    "tgp_graph_lower_bounds_i64": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
+    "tgp_sparse_pool_small_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p,
                                            _c_p, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p,
                                            _c_p, _c_i64, _c_p, ctypes.c_uint32, _c_p]),
     "tgp_connect_coalesce_grouped_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
@@ -123,7 +124,7 @@ SIGNATURES = {
     "tgp_graclus_match_graphs_fused_max_graph_nodes": (_c_int, []),
     "tgp_graclus_match_graphs_fused_status_words": (_c_i64, [_c_i64]),
     "tgp_graclus_match_graphs_fused": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p,
-                                                _c_p, _c_p, _c_i64, _c_p, ctypes.c_uint32, _c_p]),
+                                                _c_p, _c_p, _c_p, _c_i64, _c_p, ctypes.c_uint32, _c_p]),
     "tgp_graclus_match_graphs": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_graclus_match_rounds": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_p, _c_p]),
     "tgp_batch_facts_i64": (_c_int, [_c_p, _c_i64, _c_p, _c_p, ctypes.c_double, _c_p]),

@@ -175,6 +175,8 @@ def _edge_rows(edge_index: Tensor) -> Tuple[Tensor, Tensor]:
 # ------------------------------------------------------------------------- A1 + A2 + A4/A5 + A6, batches of small graphs
 _SPS_STATE: dict = {}  # (device index, stream handle) -> _SpsState
 _SPS_DECLINED: dict = {}
+_SPS_ONE_ALLOC_BYTES = 32 << 20  # outputs of the one-launch sparse pooling below this size share one allocation
+_SPS_GIVE_PTRS = os.environ.get("TGP_SPS_GIVE_PTRS", "1") != "0"  # A/B switch: hand the per-graph offsets to the kernel
 _GRACLUS_FUSED = os.environ.get("TGP_GRACLUS_FUSED", "1") != "0"  # A/B switch: one-launch GraclusSelect of small graphs
 _PUBLISH_COUNTS = os.environ.get("TGP_PUBLISH_COUNTS", "1") != "0"  # A/B switch of _read_count (read once)
 SPS_COMPACT_BYTES = 1 << 30  # capacity buffers above this are replaced by exact copies when mostly empty
@@ -250,9 +252,39 @@ def sparse_pool_small_max_graph_nodes() -> int:
     return int(N.lib().tgp_sparse_pool_small_max_graph_nodes())
 
 
+_EDGE_PTR: dict = {}  # id(edge_index) -> (weakref, version, id(graph_ptr), weakref(graph_ptr), edge_ptr)
+
+
+def graph_edge_ptr(edge_index: Tensor, graph_ptr: Tensor) -> Tensor:
+    """First edge of every graph of a sorted batch in a row-sorted list ([B+1] int64: lower bounds of ``graph_ptr`` in the
+    row array), remembered per (edge list object + version, graph_ptr object): one tiny launch for a new pair, nothing
+    for a pair that is pooled again.  The consumers re-check what they read through it."""
+    import weakref
+    key = id(edge_index)
+    hit = _EDGE_PTR.get(key)
+    if (hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version and hit[2] == id(graph_ptr)
+            and hit[3]() is graph_ptr):
+        return hit[4]
+    dev = edge_index.device
+    gp = N.i64c(graph_ptr)
+    out = torch.empty(gp.numel(), dtype=torch.int64, device=dev)
+    row = edge_index[0]
+    N.check(N.lib().tgp_graph_lower_bounds_i64(N.ptr(row) if row.numel() else None, row.numel(), N.ptr(gp),
+                                               gp.numel() - 1, N.ptr(out), N.stream_ptr(dev)),
+            "tgp_graph_lower_bounds_i64")
+    if len(_EDGE_PTR) >= 16:
+        for k in [k for k, v in _EDGE_PTR.items() if v[0]() is None or v[3]() is None]:
+            del _EDGE_PTR[k]
+        while len(_EDGE_PTR) >= 16:
+            del _EDGE_PTR[next(iter(_EDGE_PTR))]
+    _EDGE_PTR[key] = (weakref.ref(edge_index), edge_index._version, id(graph_ptr), weakref.ref(graph_ptr), out)
+    return out
+
+
 def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor],
                       assign_index: Tensor, weight: Optional[Tensor], num_supernodes: int,
-                      mode: int, reduce_op: str = "sum", remove_self_loops: bool = True, want_batch: bool = True):
+                      mode: int, reduce_op: str = "sum", remove_self_loops: bool = True, want_batch: bool = True,
+                      assign_ptr: Optional[Tensor] = None):
     """Sparse Reduce + Connect of a sorted batch of graphs of at most 64 nodes in ONE launch
     (reduce/base_reduce.py:14-53,141-155; connect/base_conn.py:79-89; the filters of utils/ops.py:370-380):
     ``(x_pool [K,F], batch_pool [K] or None, edge_index' [2,E'], edge_weight' [E'] or None)``, bit-identical to
@@ -281,30 +313,62 @@ def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_wei
     gp = N.i64c(graph_ptr)
     wt = None if weight is None else N.f32c(weight.reshape(-1))
     n, F, K, B = x.size(0), x.size(1), int(num_supernodes), gp.numel() - 1
-    x_pool = torch.empty(K, F, dtype=torch.float32, device=dev)
-    batch_pool = torch.empty(K, dtype=torch.int64, device=dev) if want_batch else None
     ecap = max(E, 1)
-    cap = torch.empty(2, ecap, dtype=torch.int64, device=dev)
-    cap_w = None if w is None else torch.empty(ecap, dtype=torch.float32, device=dev)
-    cap_p = cap.data_ptr()
+    # ONE allocation for all four outputs when they are small (a batch of small graphs: a few MB): only addresses are
+    # needed to launch, and the typed views are made WHILE the kernel runs, behind the launch -- this wrapper sits in
+    # front of a ~10 us kernel and every allocation in front of the launch is ~1.2 us the GPU idles.  (Large inputs keep
+    # separate buffers: a retained x_pool must not pin tens of MB of edge capacity.)
+    ox = 0
+    ob = (ox + K * F * 4 + 15) & ~15
+    oe = (ob + (K * 8 if want_batch else 0) + 15) & ~15
+    ow = (oe + 2 * ecap * 8 + 15) & ~15
+    nbytes = (ow + (ecap * 4 if w is not None else 0) + 15) & ~15  # (viewed as int64 / float32 below)
+    one = nbytes <= _SPS_ONE_ALLOC_BYTES
+    if one:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        base = buf.data_ptr()
+        xp_p, bp_p, cap_p, cw_p = base + ox, (base + ob) if want_batch else None, base + oe, (base + ow) if w is not None else None
+    else:
+        x_pool = torch.empty(K, F, dtype=torch.float32, device=dev)
+        batch_pool = torch.empty(K, dtype=torch.int64, device=dev) if want_batch else None
+        cap = torch.empty(2, ecap, dtype=torch.int64, device=dev)
+        cap_w = None if w is None else torch.empty(ecap, dtype=torch.float32, device=dev)
+        xp_p, bp_p, cap_p, cw_p = x_pool.data_ptr(), N.ptr(batch_pool), cap.data_ptr(), N.ptr(cap_w)
     L = N.lib()
     st = N.stream_ptr(dev)
     state = _sps_state(dev, st, L.tgp_sparse_pool_small_status_words(B, mode))
     epoch = state.next_epoch()
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if w is not None else 0)
-    N.check(L.tgp_sparse_pool_small_f32(x.data_ptr(), n, F, x.stride(0), gp.data_ptr(), B, row_p if E else None,
+    # per-graph offsets the caller side already has: the kernel skips its searches (and re-checks what it reads)
+    eptr = graph_edge_ptr(edge_index, graph_ptr) if (E and _SPS_GIVE_PTRS) else None
+    aptr = None
+    if eptr is not None and mode == 0:
+        if assign_ptr is not None and assign_ptr.dtype == torch.int64 and assign_ptr.numel() == B + 1 and assign_ptr.is_cuda:
+            aptr = assign_ptr if assign_ptr.is_contiguous() else assign_ptr.contiguous()
+        else:
+            eptr = None  # (mode 0 needs both tables)
+    N.check(L.tgp_sparse_pool_small_f32(x.data_ptr(), n, F, x.stride(0), gp.data_ptr(), B, N.ptr(eptr), N.ptr(aptr),
+                                        row_p if E else None,
                                         col_p if E else None, N.ptr(w), E, ni_p, ci_p, N.ptr(wt),
                                         nnz, K, mode, N.REDUCE_OPS[reduce_op], flags, ops_eps(),
-                                        x_pool.data_ptr(), N.ptr(batch_pool), cap_p, cap_p + 8 * ecap, N.ptr(cap_w),
+                                        xp_p, bp_p, cap_p, cap_p + 8 * ecap, cw_p,
                                         state.status.data_ptr(), state.status.numel(), state.pinned.data_ptr(), epoch,
                                         st), "tgp_sparse_pool_small_f32")
+    if one:  # (behind the launch: the kernel is running)
+        f32, i64 = buf.view(torch.float32), buf.view(torch.int64)
+        x_pool = torch.as_strided(f32, (K, F), (F, 1), ox >> 2)
+        batch_pool = torch.as_strided(i64, (K,), (1,), ob >> 3) if want_batch else None
     total = state.wait(epoch)  # the call's one host wait (the reference's .item() syncs)
     if total & 0x80000000:
         _sps_remember_declined(edge_index)
         return None
     n_out = total & 0x7FFFFFFF
-    ei = cap[:, :n_out]
-    ew = None if cap_w is None else cap_w[:n_out]
+    if one:
+        ei = torch.as_strided(i64, (2, n_out), (ecap, 1), oe >> 3)
+        ew = torch.as_strided(f32, (n_out,), (1,), ow >> 2) if w is not None else None
+    else:
+        ei = cap[:, :n_out]
+        ew = None if cap_w is None else cap_w[:n_out]
     if E * 16 > SPS_COMPACT_BYTES and 2 * n_out < E:
         ei, ew = ei.contiguous(), None if ew is None else ew.clone()
     return x_pool, batch_pool, ei, ew
@@ -1084,7 +1148,9 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
         a_ptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
         a_perm = torch.empty(num_nodes, dtype=torch.int32, device=dev)
         ones = torch.empty(num_nodes, dtype=torch.float32, device=dev)
-        N.check(L.tgp_graclus_match_graphs_fused(N.ptr(row), N.ptr(col), N.ptr(w), num_nodes, E, N.ptr(gp), B, None,
+        eptr = graph_edge_ptr(edge_index, graph_ptr) if _SPS_GIVE_PTRS else None  # (memoised; sparse_pool_small reuses it)
+        N.check(L.tgp_graclus_match_graphs_fused(N.ptr(row), N.ptr(col), N.ptr(w), num_nodes, E, N.ptr(gp), B,
+                                                 N.ptr(eptr), None,
                                                  N.ptr(index), N.ptr(a_ptr), N.ptr(a_perm), N.ptr(ones),
                                                  state.status.data_ptr(), state.status.numel(),
                                                  state.pinned.data_ptr(), epoch, st), "tgp_graclus_match_graphs_fused")

@@ -583,6 +583,10 @@ class TopkSelect(Select):
         so._assign_index = assign
         so._lift_index = lift
         so.__dict__["_no_empty_cluster"] = True  # one supernode per kept node
+        if seg_max > 0 and koff.dtype == torch.int64 and koff.numel() == nb + 1:
+            # sorted batch: graph g's kept nodes are assignments [koff[g], koff[g + 1]) -- the one-launch Reduce + Connect
+            # takes its per-graph ranges from here instead of searching for them (it re-checks what it reads)
+            so.__dict__["_assign_ptr"] = koff
         if values.requires_grad:
             so._hold_values(values)
         return so

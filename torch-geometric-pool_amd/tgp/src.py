@@ -166,7 +166,8 @@ class SRCPooling(torch.nn.Module):
         if weight is not None and weight.dtype != torch.float32:
             return None
         out = K.sparse_pool_small(x, info.ptr, edge_index, ew, index, weight, so.num_supernodes, mode,
-                                  reduce_op=c.reduce_op, remove_self_loops=c.remove_self_loops)
+                                  reduce_op=c.reduce_op, remove_self_loops=c.remove_self_loops,
+                                  assign_ptr=so.__dict__.get("_assign_ptr") if mode == 0 else None)
         if out is None:
             return None
         x_pool, batch_pool, ei, w_pool = out
