@@ -708,3 +708,30 @@ def test_ndp_select_with_an_unsorted_batch_vector_stays_on_device(dev, monkeypat
     # the reference's so.L in the caller's numbering (built lazily on the host)
     L = so_u.L
     assert L.shape == (n, n) and abs(L.sum()) < 1e-3
+
+
+@pytest.mark.parametrize("alias", ["topk", "graclus"])
+def test_one_launch_pooling_rechecks_the_offsets_it_is_handed(dev, alias, monkeypatch):
+    """The per-graph edge offsets the caller hands to the one-launch kernels (tgp.kernels.graph_edge_ptr: memoised lower
+    bounds of graph_ptr in the row array) are NOT trusted: a table that is off by one edge somewhere makes an edge fall
+    outside its graph's node range -> refusal -> the staged operators give the same result as with a correct table."""
+    from tgp import kernels
+    from tgp.poolers import get_pooler
+    x, ei, ew, batch, sizes = _small_batch(200, 10, 60, 16, 77, dev)
+    kw = dict(in_channels=16, ratio=0.5) if alias == "topk" else {}
+    pooler = get_pooler(alias, **kw).to(dev).eval()
+    with torch.no_grad():
+        good = pooler(x=x, adj=ei, edge_weight=ew, batch=batch)
+    real = kernels.graph_edge_ptr
+
+    def off_by_one(edge_index, graph_ptr):
+        t = real(edge_index, graph_ptr).clone()
+        t[t.numel() // 2] += 1          # still ascending, still 0 .. E: one edge now sits in the wrong graph's range
+        return t
+    monkeypatch.setattr(kernels, "graph_edge_ptr", off_by_one)
+    ei2 = ei.clone()                     # (a new object: no "declined before" memo, no cached selection)
+    with torch.no_grad():
+        bad = pooler(x=x, adj=ei2, edge_weight=ew, batch=batch)
+    assert kernels.sparse_pool_small_declined(ei2)
+    assert torch.equal(bad.edge_index, good.edge_index) and torch.equal(bad.x, good.x)
+    assert torch.equal(bad.edge_weight, good.edge_weight) and torch.equal(bad.batch, good.batch)
