@@ -1144,16 +1144,25 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
         B = gp.numel() - 1
         state = _sps_state(dev, st, L.tgp_graclus_match_graphs_fused_status_words(B))
         epoch = state.next_epoch()
-        index = torch.empty(2, num_nodes, dtype=torch.int64, device=dev)
-        a_ptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
-        a_perm = torch.empty(num_nodes, dtype=torch.int32, device=dev)
-        ones = torch.empty(num_nodes, dtype=torch.float32, device=dev)
+        # one allocation for the four outputs (a batch of small graphs: a few hundred KB); the typed views are made
+        # behind the launch, while the kernel runs
+        o_idx = 0
+        o_ptr = (o_idx + 16 * num_nodes + 15) & ~15
+        o_perm = (o_ptr + 4 * (num_nodes + 1) + 15) & ~15
+        o_ones = (o_perm + 4 * num_nodes + 15) & ~15
+        buf = torch.empty((o_ones + 4 * num_nodes + 15) & ~15, dtype=torch.uint8, device=dev)
+        base = buf.data_ptr()
         eptr = graph_edge_ptr(edge_index, graph_ptr) if _SPS_GIVE_PTRS else None  # (memoised; sparse_pool_small reuses it)
         N.check(L.tgp_graclus_match_graphs_fused(N.ptr(row), N.ptr(col), N.ptr(w), num_nodes, E, N.ptr(gp), B,
                                                  N.ptr(eptr), None,
-                                                 N.ptr(index), N.ptr(a_ptr), N.ptr(a_perm), N.ptr(ones),
+                                                 base + o_idx, base + o_ptr, base + o_perm, base + o_ones,
                                                  state.status.data_ptr(), state.status.numel(),
                                                  state.pinned.data_ptr(), epoch, st), "tgp_graclus_match_graphs_fused")
+        i64, i32, f32 = buf.view(torch.int64), buf.view(torch.int32), buf.view(torch.float32)
+        index = torch.as_strided(i64, (2, num_nodes), (num_nodes, 1), o_idx >> 3)
+        a_ptr = torch.as_strided(i32, (num_nodes + 1,), (1,), o_ptr >> 2)
+        a_perm = torch.as_strided(i32, (num_nodes,), (1,), o_perm >> 2)
+        ones = torch.as_strided(f32, (num_nodes,), (1,), o_ones >> 2)
         word = state.wait(epoch)
         if not word & 0x80000000:
             k = word & 0x7FFFFFFF
