@@ -1050,19 +1050,38 @@ def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Te
     dev = N.require_device(score, batch, ptr, k, koff)
     score = N.f32c(score.reshape(-1))
     n = score.numel()
-    index = torch.empty(2, k_total, dtype=torch.int64, device=dev)  # the indices of the sparse S, written in place
-    values = torch.empty(k_total, dtype=torch.float32, device=dev) if with_values else None
-    perm = torch.empty(max(k_total, 1), dtype=torch.int32, device=dev)
-    # the packed one-to-one index {node, score} the sparse Reduce streams (when the scores ARE the weights of S)
-    pack = torch.empty(max(k_total, 1), dtype=torch.int64, device=dev) if with_values else None
+    kk = max(k_total, 1)
+    one = with_values and 32 * kk <= _SPS_ONE_ALLOC_BYTES  # (index 16 B + values 4 + perm 4 + pack 8 per kept node)
+    if one:
+        # the selector's outputs of a batch of small graphs are a few hundred KB: ONE allocation, typed views behind the
+        # launch (every torch.empty in front of a ~5 us kernel is ~1.2 us of idle GPU)
+        o_val = (16 * k_total + 15) & ~15
+        o_perm = (o_val + 4 * k_total + 15) & ~15
+        o_pack = (o_perm + 4 * kk + 15) & ~15
+        buf = torch.empty((o_pack + 8 * kk + 15) & ~15, dtype=torch.uint8, device=dev)
+        base = buf.data_ptr()
+        idx_p, val_p, perm_p, pack_p = base, base + o_val, base + o_perm, base + o_pack
+    else:
+        index = torch.empty(2, k_total, dtype=torch.int64, device=dev)  # the indices of the sparse S, written in place
+        values = torch.empty(k_total, dtype=torch.float32, device=dev) if with_values else None
+        perm = torch.empty(kk, dtype=torch.int32, device=dev)
+        # the packed one-to-one index {node, score} the sparse Reduce streams (when the scores ARE the weights of S)
+        pack = torch.empty(kk, dtype=torch.int64, device=dev) if with_values else None
+        idx_p, val_p, perm_p, pack_p = index.data_ptr(), N.ptr(values), perm.data_ptr(), N.ptr(pack)
     lift_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev) if with_lift and n > 0 else None
     with_lift = lift_ptr is not None
     L = N.lib()
     ws = N.workspace(L.tgp_topk_select_workspace_bytes(n), dev)
     N.check(L.tgp_topk_select(N.ptr(score), N.ptr(None if batch is None else N.i64c(batch)), n, num_graphs,
                               N.ptr(N.i64c(ptr)), N.ptr(N.i64c(k)), N.ptr(N.i64c(koff)), segments_max_nodes, N.ptr(ws),
-                              ws.numel(), N.ptr(index[0]), N.ptr(index[1]), N.ptr(perm), N.ptr(values),
-                              N.ptr(lift_ptr), N.ptr(pack), N.stream_ptr(dev)), "tgp_topk_select")
+                              ws.numel(), idx_p, idx_p + 8 * k_total, perm_p, val_p,
+                              N.ptr(lift_ptr), pack_p, N.stream_ptr(dev)), "tgp_topk_select")
+    if one:
+        i64, i32, f32 = buf.view(torch.int64), buf.view(torch.int32), buf.view(torch.float32)
+        index = torch.as_strided(i64, (2, k_total), (k_total, 1), 0)
+        values = torch.as_strided(f32, (k_total,), (1,), o_val >> 2)
+        perm = torch.as_strided(i32, (kk,), (1,), o_perm >> 2)
+        pack = torch.as_strided(i64, (kk,), (1,), o_pack >> 3)
     assign = AssignIndex(None, perm, k_total, k_total)
     if pack is not None and k_total > 0 and n < (1 << 31):
         assign.pack, assign.pack_key = pack, (index.data_ptr(), values.data_ptr())
