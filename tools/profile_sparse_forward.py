@@ -1,5 +1,8 @@
+"""Host profile of a whole sparse pooler forward (topk | graclus) on 2048 PROTEINS-shaped graphs: wall time per forward and
+cProfile of 2000 forwards.  python tools/profile_sparse_forward.py [topk|graclus]"""
 import cProfile, pstats, sys, os, time, torch
-sys.path.insert(0, "/root/repo/tools"); sys.path.insert(0, "/root/repo/torch-geometric-pool_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "torch-geometric-pool_amd"))
 import e2e_launches as E
 from tgp.poolers import get_pooler
 which = sys.argv[1] if len(sys.argv) > 1 else "topk"
