@@ -717,6 +717,8 @@ def test_one_launch_pooling_rechecks_the_offsets_it_is_handed(dev, alias, monkey
     outside its graph's node range -> refusal -> the staged operators give the same result as with a correct table."""
     from tgp import kernels
     from tgp.poolers import get_pooler
+    if not kernels._SPS_GIVE_PTRS:
+        pytest.skip("TGP_SPS_GIVE_PTRS=0: the kernels search for their ranges themselves")
     x, ei, ew, batch, sizes = _small_batch(200, 10, 60, 16, 77, dev)
     kw = dict(in_channels=16, ratio=0.5) if alias == "topk" else {}
     pooler = get_pooler(alias, **kw).to(dev).eval()
