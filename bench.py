@@ -763,7 +763,13 @@ class GraclusC4(Workload):
                      "(BASELINE configs[3])")
         self.extra = {"num_supernodes": self.k, "edges": int(self.ei.size(1)),
                       "edge_order": "random" if unsorted_edges else "row-major sorted (PyG convention)",
-                      "nodes_counted": "input nodes per step"}
+                      "nodes_counted": "input nodes per step",
+                      # what the SelectOutput brings along from GraclusSelect (outside the timed step), and what it does not
+                      "from_select": ("int32 CSR offsets of the row-sorted edge list (the Connect skips its pass over the "
+                                      "row array); S known to have row index 0..N-1 and unit values (the Reduce skips those "
+                                      "two loads per assignment)" if not unsorted_edges else
+                                      "S known to have row index 0..N-1 and unit values"),
+                      "rebuilt_every_step": "the supernode -> members index (counting sort, ~50 us: so._drop_caches())"}
 
     def step(self):
         so = self.so
