@@ -737,3 +737,88 @@ def test_one_launch_pooling_rechecks_the_offsets_it_is_handed(dev, alias, monkey
     assert kernels.sparse_pool_small_declined(ei2)
     assert torch.equal(bad.edge_index, good.edge_index) and torch.equal(bad.x, good.x)
     assert torch.equal(bad.edge_weight, good.edge_weight) and torch.equal(bad.batch, good.batch)
+
+
+def test_gather_unpack_kernels_with_three_simulated_ranks(dev):
+    """the device unpack of the variable-size gather for world > 1, which no 1-GPU box can reach through RCCL:
+    the gathered buffer of THREE ranks is laid out by hand (every rank's pooled graphs packed into its slot by
+    tgp_gather_pack_f32), then tgp_gather_unpack_f32 (one step) and tgp_gather_unpack_bucket_f32 (two steps per bucket,
+    rank stride = 2 slots) must give the merge rule of tgp/data/collate.py:144-153 -- node ids of rank r shifted by the
+    supernodes, graph ids by the graphs of the ranks before it -- bit for bit."""
+    import ctypes
+    from tgp import _native as N
+    L = N.lib()
+    st = N.stream_ptr(dev)
+    world, nsteps, F = 3, 2, 5
+    g = torch.Generator().manual_seed(123)
+
+    def part(seed_k):
+        K = int(torch.randint(3, 40, (1,), generator=g))
+        E = int(torch.randint(0, 90, (1,), generator=g))
+        B = int(torch.randint(1, 5, (1,), generator=g))
+        x = torch.randn(K, F, generator=g)
+        ei = torch.randint(0, K, (2, E), generator=g)
+        ew = torch.rand(E, generator=g)
+        b = torch.sort(torch.randint(0, B, (K,), generator=g))[0]
+        return x.to(dev), ei.to(dev), ew.to(dev), b.to(dev), B
+
+    parts = [[part(0) for _ in range(world)] for _ in range(nsteps)]          # parts[step][rank]
+    need = max(int(L.tgp_gather_pack_bytes(p[0].size(0), p[1].size(1), F, 1)) for s in parts for p in s)
+    cap = ((need + 4095) // 4096) * 4096
+    gathered = torch.zeros(world * nsteps * cap, dtype=torch.uint8, device=dev)   # [rank][step][cap]
+    for j in range(nsteps):
+        for r in range(world):
+            x, ei, ew, b, B = parts[j][r]
+            dst = gathered[(r * nsteps + j) * cap:]
+            N.check(L.tgp_gather_pack_f32(x.data_ptr(), x.stride(0), b.data_ptr(), ei[0].contiguous().data_ptr() if ei.size(1) else None,
+                                          ei[1].contiguous().data_ptr() if ei.size(1) else None, ew.data_ptr() if ei.size(1) else None,
+                                          x.size(0), ei.size(1), B, F, cap, dst.data_ptr(), st), "pack")
+
+    def expected(j):
+        xs, eis, ews, bs, koff, goff = [], [], [], [], 0, 0
+        for r in range(world):
+            x, ei, ew, b, B = parts[j][r]
+            xs.append(x); eis.append(ei + koff); ews.append(ew); bs.append(b + goff)
+            koff += x.size(0); goff += B
+        return torch.cat(xs), torch.cat(eis, 1), torch.cat(ews), torch.cat(bs)
+
+    k_cap = sum(max(p[0].size(0) for p in s) for s in parts) * world + 8
+    e_cap = sum(max(p[1].size(1) for p in s) for s in parts) * world + 8
+    pin = torch.zeros(8 * nsteps, dtype=torch.int64).pin_memory()
+    host = pin.numpy()
+    # (a) one step per launch: the step's slots sit nsteps * cap apart
+    for j in range(nsteps):
+        xo = torch.empty(k_cap, F, device=dev); bo = torch.empty(k_cap, dtype=torch.int64, device=dev)
+        eo = torch.empty(2, e_cap, dtype=torch.int64, device=dev); wo = torch.empty(e_cap, device=dev)
+        N.check(L.tgp_gather_unpack_f32(gathered.data_ptr() + j * cap, cap, nsteps * cap, world, cap // 4, k_cap, e_cap,
+                                        xo.data_ptr(), bo.data_ptr(), eo[0].data_ptr(), eo[1].data_ptr(), wo.data_ptr(),
+                                        pin.data_ptr() + 64 * j, 1000 + j, st), "unpack")
+        torch.cuda.synchronize()
+        assert int(host[8 * j]) == 1000 + j and int(host[8 * j + 4]) == 1
+        kt, et = int(host[8 * j + 1]), int(host[8 * j + 2])
+        ex, eei, eew, eb = expected(j)
+        assert kt == ex.size(0) and et == eei.size(1)
+        assert torch.equal(xo[:kt], ex) and torch.equal(bo[:kt], eb)
+        assert torch.equal(eo[:, :et], eei) and torch.equal(wo[:et], eew)
+    # (b) the whole bucket in one launch
+    outs, ptrs, dims = [], (ctypes.c_void_p * (6 * nsteps))(), (ctypes.c_int64 * (3 * nsteps))()
+    pin.zero_()
+    for j in range(nsteps):
+        xo = torch.empty(k_cap, F, device=dev); bo = torch.empty(k_cap, dtype=torch.int64, device=dev)
+        eo = torch.empty(2, e_cap, dtype=torch.int64, device=dev); wo = torch.empty(e_cap, device=dev)
+        outs.append((xo, bo, eo, wo))
+        o = 6 * j
+        ptrs[o], ptrs[o + 1], ptrs[o + 2], ptrs[o + 3] = xo.data_ptr(), bo.data_ptr(), eo[0].data_ptr(), eo[1].data_ptr()
+        ptrs[o + 4], ptrs[o + 5] = wo.data_ptr(), pin.data_ptr() + 64 * j
+        dims[3 * j], dims[3 * j + 1], dims[3 * j + 2] = k_cap, e_cap, 2000 + j
+    N.check(L.tgp_gather_unpack_bucket_f32(gathered.data_ptr(), cap, nsteps * cap, world, cap // 4, nsteps, ptrs, dims, st),
+            "unpack_bucket")
+    torch.cuda.synchronize()
+    for j in range(nsteps):
+        assert int(host[8 * j]) == 2000 + j and int(host[8 * j + 4]) == 1
+        kt, et = int(host[8 * j + 1]), int(host[8 * j + 2])
+        ex, eei, eew, eb = expected(j)
+        xo, bo, eo, wo = outs[j]
+        assert kt == ex.size(0) and et == eei.size(1)
+        assert torch.equal(xo[:kt], ex) and torch.equal(bo[:kt], eb)
+        assert torch.equal(eo[:, :et], eei) and torch.equal(wo[:et], eew)
