@@ -822,3 +822,51 @@ def test_gather_unpack_kernels_with_three_simulated_ranks(dev):
         assert kt == ex.size(0) and et == eei.size(1)
         assert torch.equal(xo[:kt], ex) and torch.equal(bo[:kt], eb)
         assert torch.equal(eo[:, :et], eei) and torch.equal(wo[:et], eew)
+
+
+def test_sparse_gather_device_path_with_a_simulated_second_rank(dev, monkeypatch):
+    """SparseGather's DEVICE path for world = 2 on one GPU: the collective is replaced by a stand-in that delivers the
+    local bucket twice (as if the second rank held the same graphs), everything else -- bucket packing, capacity growth from
+    the headers, slot arithmetic, the unpack launch per bucket, the offsets of rank 1 -- is the code the 8-GPU run takes.
+    Expected merge (tgp/data/collate.py:144-153): the local result followed by a copy shifted by K supernodes / G graphs."""
+    import torch.distributed as dist
+    from tgp import distributed as D
+    from tgp.poolers import get_pooler
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def fake_all_gather(out, inp, group=None, async_op=False):
+        n = inp.numel()
+        out[:n].copy_(inp)
+        out[n: 2 * n].copy_(inp)
+        return _Done()
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_all_gather)
+    x, ei, ew, batch, sizes = _small_batch(120, 5, 40, 8, 55, dev)
+    pooler = get_pooler("topk", in_channels=8, ratio=0.5).to(dev).eval()
+    G = int(batch.max()) + 1
+    sg = D.SparseGather(depth=2, bucket_steps=3, capacity=4096)   # too small at first: grown from the headers
+    sg.world, sg._collective = 2, True
+    steps = []
+    with torch.no_grad():
+        for s in range(7):                                         # 2 full buckets + a partial one
+            out = pooler(x=x * (s + 1), adj=ei, edge_weight=ew, batch=batch)
+            steps.append(out)
+            sg.start(out.x, out.edge_index, out.edge_weight, out.batch, G)
+            sg.take_ready()
+    got = []
+    sg2 = D.SparseGather(depth=2, bucket_steps=3, capacity=4096)
+    sg2.world, sg2._collective = 2, True
+    with torch.no_grad():
+        for out in steps:
+            sg2.start(out.x, out.edge_index, out.edge_weight, out.batch, G)
+            got.extend(sg2.take_ready())
+    got.extend(sg2.flush())
+    assert len(got) == len(steps)
+    for out, (gx, gei, gew, gb) in zip(steps, got):
+        K = out.x.size(0)
+        assert torch.equal(gx, torch.cat([out.x, out.x]))
+        assert torch.equal(gei, torch.cat([out.edge_index, out.edge_index + K], 1))
+        assert torch.equal(gew, torch.cat([out.edge_weight, out.edge_weight]))
+        assert torch.equal(gb, torch.cat([out.batch, out.batch + G]))
