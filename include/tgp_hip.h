@@ -16,9 +16,9 @@
  *     base_select.py:64; north_star's 1e-5 tolerance is stated in it).  r4: the HBM-bound operators also exist for
  *     float64 values (`*_f64`: sparse Reduce, subgraph / coalesce Connect, block-diagonal export, sparse and dense
  *     post-processing; see the section near the end), because the reference's ATen ops compute model.double() inputs
- *     in fp64.  The dense GEMM path (S^T X, S^T A S, the fused small-graph kernels, the losses) is fp32 only: a caller
- *     holding float64 tensors converts at that boundary, and the host mirror does exactly that with a one-time
- *     UserWarning saying the arithmetic is fp32's.  Two algorithms whose RESULT depends on wider arithmetic run in fp64
+ *     in fp64.  r5: the dense GEMM path has fp64 forms too (tgp_bmm_f64, tgp_dense_pool_f64, tgp_segment_gemm_*_f64,
+ *     tgp_spmm_csr_f64 on the fp64 matrix instruction); only the fused small-graph kernels and the fused loss kernels
+ *     are fp32-only, and the host mirror does not route float64 tensors to them.  Two algorithms whose RESULT depends on wider arithmetic run in fp64
  *     inside their kernels regardless of the I/O type: the Kron reduction (tgp_kron_batched_*) and NDPSelect's
  *     eigen-iteration (tgp_ndp_*); KronConnect also accepts fp64 Laplacian values (`val64`).
  *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it and
@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10025 /* 1.0.1 of the reference, ABI revision 25 (r4: one-launch sparse pooling, fp64 operators, tgp_count_publish) */
+#define TGP_ABI_VERSION 10026 /* 1.0.1 of the reference, ABI revision 26 (r5: fp64 dense path on v_mfma_f64_16x16x4_f64) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -707,8 +707,7 @@ int tgp_debug_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, i
  * (reduce/base_reduce.py:141-155, utils/ops.py:282-419); these entry points do the same for the operators that only
  * move and add values -- sparse Reduce, the edge-list Connect (subgraph / coalesce / block-diagonal export) and both
  * post-processings -- with the argument meaning of their fp32 twins above (`eps` as a double).  Same summation orders,
- * products rounded before the add.  The dense GEMM path (S^T X, S^T A S) has no fp64 form: the host mirror converts
- * there and says so.
+ * products rounded before the add.  (The dense GEMM path's fp64 forms follow in the next section, r5.)
  * ---------------------------------------------------------------------------------- */
 int tgp_reduce_sparse_f64(const double* x, int64_t num_nodes, int64_t num_features, int64_t x_row_stride,
                           const int64_t* node_index, const double* weight /* NULL = ones */,
@@ -745,38 +744,71 @@ int tgp_postprocess_dense_f64(const double* src, double* dst /* may alias src */
                               double eps, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * SURVEY 8(e): pack / unpack of the variable-size all-gather of pooled sparse outputs (r4).  A rank's pooled graphs
- * (x [K,F] fp32, batch [K] int64 or NULL, edge_index rows [E] int64, edge_weight [E] fp32 or NULL) go into one byte
- * buffer of `capacity` bytes behind a 128-byte header {magic, K, E, B, F, has_w, needed_bytes}; when needed_bytes >
- * capacity only the header is written (every rank then sees how much room the largest rank needs).  The buffers of all
- * ranks are all-gathered as they are; tgp_gather_unpack_f32 reads `world` of them ([world, capacity] bytes) and writes
- * the merged tensors, node ids of rank r shifted by the supernodes, graph ids by the graphs of the ranks before it
- * (tgp/data/collate.py:144-153).  Output sizes = sums over the headers (the caller reads them once).
+ * float64 dense path (r5): S^T X, S^T A S and the products of their gradients on v_mfma_f64_16x16x4_f64.  The reference
+ * computes model.double() inputs with torch.matmul in fp64 (reduce/base_reduce.py:158-161, connect/dense_conn.py:111-122;
+ * unbatched: base_reduce.py:170-190, dense_conn.py:140-208); the host mirror routes float64 tensors here, so the dense
+ * poolers pass torch.autograd.gradcheck in double.  Argument meaning of the fp32 twins above; same association
+ * (U = A S, then S^T [U | X] over slices of the node range, slabs added in slice order).
+ *   tgp_bmm_f64            C[b] (+)= op(A[b]) Bm[b]            (accumulate != 0: C += product)
+ *   tgp_dense_pool_f64     fused A3 + A7 + A8 of a padded batch (flags: TGP_* of tgp_dense_pool_f32, incl. TGP_ADJ_TRANSPOSED)
+ *   tgp_segment_gemm_*_f64 the per-graph products of an un-padded batch
+ *   tgp_spmm_csr_f64       T = A S for a row-sorted coalesced edge list (w NULL = ones)
  * ---------------------------------------------------------------------------------- */
-int64_t tgp_gather_pack_bytes(int64_t num_supernodes, int64_t num_edges, int64_t num_features, int has_weight);
+int tgp_bmm_f64(const double* A, const double* Bm, double* C, int64_t batch, int64_t M, int64_t Nc, int64_t Kd,
+                int trans_a, int64_t lda, int64_t ldb, int64_t ldc, int64_t sA, int64_t sB, int64_t sC, int accumulate,
+                void* stream);
+size_t tgp_dense_pool_workspace_bytes_f64(int64_t B, int64_t N, int64_t K, int64_t F);
+int tgp_dense_pool_f64(const double* S, const double* A /* NULL ok */, const double* X /* NULL ok */, int64_t B,
+                       int64_t N, int64_t K, int64_t F, int flags, double eps, double* x_pool, double* adj_raw,
+                       double* adj_pool, void* ws, size_t ws_bytes, void* stream);
+size_t tgp_segment_gemm_tn_workspace_bytes_f64(int64_t B, int64_t K, int64_t F, int64_t max_nodes);
+int tgp_segment_gemm_tn_f64(const double* S, const double* Y, const int64_t* ptr, double* C, int64_t B, int64_t Ntot,
+                            int64_t K, int64_t F, int64_t max_nodes, void* ws, size_t ws_bytes, void* stream);
+int tgp_segment_gemm_nn_f64(const double* A, const double* Bm, const int64_t* ptr, double* C, int64_t B, int64_t Ntot,
+                            int64_t Kd, int64_t Nc, int64_t max_nodes, void* stream);
+int tgp_spmm_csr_f64(const int32_t* row_ptr, const int64_t* col, const double* w, int64_t num_rows, int64_t nnz,
+                     const double* S, int64_t K, double* T, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * SURVEY 8(e): pack / unpack of the variable-size all-gather of pooled sparse outputs (r4).  A rank's pooled graphs
+ * (x [K,F], batch [K] int64 or NULL, edge_index rows [E] int64, edge_weight [E] or NULL) go into one byte buffer of
+ * `capacity` bytes behind a 128-byte header {magic, K, E, B, F, w_words, needed_bytes, x_words}; when needed_bytes >
+ * capacity only the header is written (every rank then sees how much room the largest rank needs).  r5: the VALUES
+ * travel as 4-byte words -- `F` and `x_row_stride` count words per feature row, `x_words` / `w_words` the words per
+ * element (1 = fp32 / int32, 2 = fp64 / int64; w_words 0 = no weights) -- so float64 features and weights cross ranks
+ * bit for bit (they were narrowed to fp32 before).  The buffers of all ranks are all-gathered as they are;
+ * tgp_gather_unpack_f32 reads `world` of them ([world, capacity] bytes) and writes the merged tensors, node ids of rank
+ * r shifted by the supernodes, graph ids by the graphs of the ranks before it (tgp/data/collate.py:144-153).  Output
+ * sizes = sums over the headers (the caller reads them once).
+ * ---------------------------------------------------------------------------------- */
+int64_t tgp_gather_pack_bytes(int64_t num_supernodes, int64_t num_edges, int64_t feature_words, int w_words);
 int tgp_gather_pack_f32(const float* x, int64_t x_row_stride, const int64_t* batch /* NULL ok */, const int64_t* row,
                         const int64_t* col, const float* edge_weight /* NULL ok */, int64_t num_supernodes,
-                        int64_t num_edges, int64_t num_graphs, int64_t num_features, int64_t capacity, void* out,
-                        void* stream);
+                        int64_t num_edges, int64_t num_graphs, int64_t feature_words, int w_words, int x_words,
+                        int64_t capacity, void* out, void* stream);
 int tgp_gather_unpack_f32(const void* gathered, int64_t capacity,
                           int64_t rank_stride /* bytes between two ranks' buffers (>= capacity: several steps' slots may be
                                                  gathered as one bucket) */,
                           int world, int64_t max_words /* 4-byte words of the largest payload: sizes the grid */,
-                          int64_t k_cap, int64_t e_cap /* rows the outputs can hold */, float* x_out,
-                          int64_t* batch_out /* NULL ok */, int64_t* row_out, int64_t* col_out,
+                          int64_t k_cap, int64_t e_cap /* rows the outputs can hold */,
+                          int64_t feature_words, int w_words, int x_words /* what THIS rank packed: every header must
+                                                                             say the same */,
+                          float* x_out, int64_t* batch_out /* NULL ok */, int64_t* row_out, int64_t* col_out,
                           float* weight_out /* NULL ok */,
                           uint64_t* result /* NULL, or 5 words of device-accessible (pinned host) memory: {tag, K total,
-                                              E total, largest needed_bytes, headers valid}, word 0 stored last; a
-                                              payload that does not fit capacity / k_cap / e_cap makes the launch a no-op
-                                              apart from this report */,
+                                              E total, largest needed_bytes, status}, word 0 stored last.  status bits:
+                                              1 = every header valid, 2 = every rank agrees on feature_words / w_words /
+                                              x_words, 4 = the totals fit k_cap / e_cap; a payload that does not fit
+                                              capacity, or a status other than 7, makes the launch a no-op apart from
+                                              this report */,
                           uint64_t tag, void* stream);
 /* The same for a whole BUCKET of steps in one launch each (r4): step j of at most tgp_gather_max_bucket_steps() (= 8) is
  * packed into out + j * capacity; after the single collective over the bucket ([world][n * capacity] bytes, rank_stride =
  * n * capacity or more) one launch unpacks all its steps.  ptrs / dims are HOST arrays read during the call:
- *   pack:   ptrs [n][5] = {x, batch (NULL ok), row, col, edge_weight (NULL ok)}, dims [n][5] = {x_row_stride,
- *           num_supernodes, num_edges, num_graphs, num_features};
+ *   pack:   ptrs [n][5] = {x, batch (NULL ok), row, col, edge_weight (NULL ok)}, dims [n][7] = {x_row_stride,
+ *           num_supernodes, num_edges, num_graphs, feature_words, w_words, x_words};
  *   unpack: ptrs [n][6] = {x_out, batch_out (NULL ok), row_out, col_out, weight_out (NULL ok), result (NULL ok)},
- *           dims [n][3] = {k_cap, e_cap, tag}. */
+ *           dims [n][6] = {k_cap, e_cap, tag, feature_words, w_words, x_words}. */
 int tgp_gather_max_bucket_steps(void);
 int tgp_gather_pack_bucket_f32(const void* const* ptrs, const int64_t* dims, int num_steps, int64_t capacity, void* out,
                                void* stream);

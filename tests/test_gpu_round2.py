@@ -195,21 +195,19 @@ def test_orthogonality_loss_accepts_a_single_2d_assignment(dev):
     torch.testing.assert_close(sd.grad.cpu(), sr.grad, rtol=1e-4, atol=1e-6)
 
 
-def test_float64_inputs_are_announced_as_fp32_arithmetic(dev):
+def test_float64_inputs_are_computed_in_float64(dev):
+    """r5 (was: "announced as fp32 arithmetic"): a float64 feature matrix through the dense Reduce gives the fp64 product,
+    no warning, as torch.matmul does in the reference (reduce/base_reduce.py:158-161)."""
     from tgp.reduce import BaseReduce
     from tgp.select import SelectOutput
-    from tgp.utils import ops as ops_module
-    # (r4: the sparse Reduce / Connect have fp64 kernels and do NOT warn -- tests/test_gpu_round4.py; the dense GEMM
-    #  path still computes in fp32 and says so)
-    ops_module._WARNED_F64 = False
-    so = SelectOutput(s=torch.softmax(torch.randn(1, 4, 2, device=dev), -1))
+    s = torch.softmax(torch.randn(1, 4, 2, device=dev, dtype=torch.float64), -1)
+    so = SelectOutput(s=s)
     x = torch.randn(1, 4, 3, dtype=torch.float64, device=dev)
-    with pytest.warns(UserWarning, match="float64 inputs are computed in float32"):
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
         out, _ = BaseReduce()(x, so)
     assert out.dtype == torch.float64
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")  # once per process
-        BaseReduce()(x, so)
+    torch.testing.assert_close(out, s.transpose(1, 2) @ x, rtol=1e-13, atol=1e-13)
 
 
 def test_to_dense_adj_edge_weight_gradient_is_native(dev, monkeypatch):

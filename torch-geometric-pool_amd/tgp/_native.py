@@ -194,10 +194,21 @@ SIGNATURES = {
                                          _c_p, _c_p]),
     "tgp_postprocess_dense_workspace_bytes_f64": (_c_sz, [_c_i64, _c_i64]),
     "tgp_postprocess_dense_f64": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_int, ctypes.c_double, _c_p, _c_sz, _c_p]),
+    "tgp_bmm_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _c_i64,
+                             _c_i64, _c_i64, _c_int, _c_p]),
+    "tgp_dense_pool_workspace_bytes_f64": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64]),
+    "tgp_dense_pool_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, ctypes.c_double, _c_p, _c_p,
+                                    _c_p, _c_p, _c_sz, _c_p]),
+    "tgp_segment_gemm_tn_workspace_bytes_f64": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64]),
+    "tgp_segment_gemm_tn_f64": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_sz,
+                                         _c_p]),
+    "tgp_segment_gemm_nn_f64": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+    "tgp_spmm_csr_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
     "tgp_gather_pack_bytes": (_c_i64, [_c_i64, _c_i64, _c_i64, _c_int]),
-    "tgp_gather_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
-    "tgp_gather_unpack_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p,
-                                       _c_p, ctypes.c_uint64, _c_p]),
+    "tgp_gather_pack_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int,
+                                     _c_i64, _c_p, _c_p]),
+    "tgp_gather_unpack_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_p,
+                                       _c_p, _c_p, _c_p, _c_p, _c_p, ctypes.c_uint64, _c_p]),
     "tgp_gather_max_bucket_steps": (_c_int, []),
     "tgp_gather_pack_bucket_f32": (_c_int, [_c_p, _c_p, _c_int, _c_i64, _c_p, _c_p]),
     "tgp_gather_unpack_bucket_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_int, _c_i64, _c_int, _c_p, _c_p, _c_p]),

@@ -231,41 +231,64 @@ def _gp_align(v: int) -> int:
     return (v + 15) & ~15
 
 
-def _gp_layout(K: int, E: int, F: int, has_w: bool):
+def _gp_layout(K: int, E: int, Fw: int, w_words: int):
+    """Byte offsets of a packed step (csrc/gather_pack.hip gp_layout): ``Fw`` = 4-byte words per feature row,
+    ``w_words`` = words per edge weight (0 = no weights)."""
     x = _GP_HEADER * 8
-    batch = _gp_align(x + K * F * 4)
+    batch = _gp_align(x + K * Fw * 4)
     row = _gp_align(batch + K * 8)
     col = _gp_align(row + E * 8)
     w = _gp_align(col + E * 8)
-    end = _gp_align(w + (E * 4 if has_w else 0))
+    end = _gp_align(w + E * 4 * w_words)
     return x, batch, row, col, w, end
+
+
+def _wire(t: Tensor) -> Tuple[Tensor, int]:
+    """A value tensor in the dtype it travels in, and its 4-byte words per element.  4- and 8-byte element types
+    (fp32, fp64, int32, int64) are copied bit for bit -- float64 features / weights used to be narrowed to fp32 on the
+    way through the gather; smaller types widen losslessly (bf16 / half -> fp32, small ints -> int32) and
+    are narrowed back on the receiving side."""
+    if t.element_size() in (4, 8):
+        return t, t.element_size() // 4
+    return (t.to(torch.float32) if t.is_floating_point() else t.to(torch.int32)), 1
 
 
 class SparseGather:
     """All-gather of VARIABLE-SIZE pooled sparse outputs (x [K,F], edge_index [2,E], edge_weight [E] or None, batch [K])
     as ONE payload collective per bucket of steps, asynchronous like :class:`PackedGather`.
 
-    ``start`` packs the rank's outputs behind a 128-byte header {K, E, B, F, has_w, needed bytes} into the next slot of
-    a byte buffer (one native launch on a device, ``tgp_gather_pack_f32``); ``bucket_steps`` slots go out as ONE
-    ``all_gather_into_tensor`` on the collective's own stream.  There is no count exchange in front of it: the slot
-    capacity is agreed FROM the headers -- every rank sees every header, so when some rank needs more room than the
-    current capacity all ranks reach the same verdict, grow to the same size and repeat the steps concerned (a
+    ``start`` packs the rank's outputs behind a 128-byte header {K, E, B, F, w words, needed bytes, x words} into the
+    next slot of a byte buffer (one native launch on a device, ``tgp_gather_pack_f32``); ``bucket_steps`` slots go out
+    as ONE ``all_gather_into_tensor`` on the collective's own stream.  There is no count exchange in front of it: the
+    slot capacity is agreed FROM the headers -- every rank sees every header, so when some rank needs more room than
+    the current capacity all ranks reach the same verdict, grow to the same size and repeat the steps concerned (a
     payload that does not fit travels as a header only).  On a device nothing of this blocks the host: behind the
-    collective (a stream dependency) one native launch per step unpacks into capacity-sized outputs, shifting node ids
+    collective (a stream dependency) one native launch per bucket unpacks into capacity-sized outputs, shifting node ids
     / graph ids of rank r by the totals of the ranks before it (``tgp_gather_unpack_f32``; the merge rule of
-    tgp/data/collate.py:144-153), and leaves the totals in a pinned host word that ``take_ready`` polls; the merged
-    tensors are views of the capacity buffers (``edge_index``: both rows contiguous).  At most ``depth`` buckets are in
-    flight, so a bucket's gather overlaps the next steps' kernels.  Every rank must call ``start`` (and ``flush``) the
-    same number of times.
+    tgp/data/collate.py:144-153), and leaves the totals in a pinned host word that ``take_ready`` polls.  At most
+    ``depth`` buckets are in flight, so a bucket's gather overlaps the next steps' kernels.  Every rank must call
+    ``start`` (and ``flush``) the same number of times.
+
+    Values keep their dtype: x and edge_weight travel as 4-byte words, float64 / int64 as two words per element (r5; r4
+    narrowed everything to fp32), and every rank must pack the same feature width and value types -- the unpack launch
+    checks the headers against what this rank packed and the host raises when they disagree.
 
     A result is ``(x, edge_index, edge_weight, batch)`` of ALL ranks' graphs, rank-major, as a single process would
-    have produced them for the concatenated batch."""
+    have produced them for the concatenated batch: new contiguous tensors of exactly the merged size, like the
+    reference's collate.  ``views=True`` hands out views of the bucket's capacity buffer instead (``edge_index`` then
+    has row stride e_cap; no copies -- what ``bench.py`` times).
+
+    A gather is consumed EITHER by polling (``take_ready`` ... ``flush``) OR by blocking (``wait`` ... ``flush``), not
+    both: a capacity change re-issues collectives, so it may only be decided at points every rank reaches in the same
+    order.  ``take_ready`` never decides one; ``wait`` does, and which bucket it looks at depends on what earlier
+    ``take_ready`` calls happened to find finished on THIS rank -- mixing the two lets ranks disagree about the next
+    collective.  The first call fixes the mode; the other one then raises."""
 
     INITIAL_CAPACITY = 64 * 1024  # bytes per step; the SAME on every rank (a collective needs equal buffer sizes): it
                                   # only grows, and only by the rule below, which every rank applies to the same headers
 
     def __init__(self, group=None, force_collective: bool = False, depth: int = 2, capacity: Optional[int] = None,
-                 bucket_steps: int = 1):
+                 bucket_steps: int = 1, views: bool = False):
         self.group = group
         self.world = _world(group)
         self._collective = self.world > 1 or (dist.is_available() and dist.is_initialized()
@@ -274,6 +297,7 @@ class SparseGather:
         self.bucket = min(max(int(bucket_steps), 1), 8)  # (tgp_gather_max_bucket_steps)
         # ``capacity``: a caller that knows its payloads may start larger (the same value on every rank!)
         self.capacity = max(int(capacity if capacity is not None else self.INITIAL_CAPACITY), _GP_HEADER * 8)
+        self.views = bool(views)
         self._send: Optional[Tensor] = None
         self._open: List[tuple] = []       # inputs of the steps packed into the open bucket
         self._inflight: List[dict] = []    # buckets whose collective has been issued
@@ -281,6 +305,7 @@ class SparseGather:
         self._pin = None                   # pinned result words (device path), 8 per step slot
         self._host = None
         self._tick = 0
+        self._mode: Optional[str] = None   # "poll" (take_ready) or "block" (wait): see the class docstring
 
     # ---- packing --------------------------------------------------------------------------------------------------
     @staticmethod
@@ -288,38 +313,46 @@ class SparseGather:
         K, F = (x.size(0), x.size(1)) if x.dim() == 2 else (x.size(0), 1)
         return K, F, edge_index.size(1)
 
+    @staticmethod
+    def _wire_step(inputs):
+        """(x2 [K,F] in its wire dtype with unit inner stride, xw, ei int64 rows, w wire / None, ww, batch int64 / None)"""
+        x, edge_index, edge_weight, batch, _ = inputs
+        K, F = (x.size(0), x.size(1)) if x.dim() == 2 else (x.size(0), 1)
+        E = edge_index.size(1)
+        x2, xw = _wire(x if x.dim() == 2 else x.reshape(K, F))
+        if not (F <= 1 or x2.stride(1) == 1):
+            x2 = x2.contiguous()
+        ei = edge_index
+        if not (ei.dtype == torch.int64 and (E <= 1 or ei.stride(1) == 1)):
+            ei = ei.to(torch.int64).contiguous()
+        w, ww = None, 0
+        if edge_weight is not None:
+            w, ww = _wire(edge_weight.reshape(-1))
+            if not (E <= 1 or w.stride(0) == 1):
+                w = w.contiguous()
+        b = batch
+        if b is not None and not (b.dtype == torch.int64 and b.dim() == 1 and (K <= 1 or b.stride(0) == 1)):
+            b = b.to(torch.int64).contiguous()
+        return x2, xw, ei, w, ww, b
+
     def _pack(self, inputs, dst: Tensor) -> None:
-        x, edge_index, edge_weight, batch, num_graphs = inputs
-        K, F, E = self._dims(x, edge_index)
+        """Host tensors (the gloo tests of the N > 1 logic): the layout of csrc/gather_pack.hip with torch ops."""
+        num_graphs = inputs[4]
+        x2, xw, ei, w, ww, b = self._wire_step(inputs)
+        K, F, E = x2.size(0), x2.size(1), ei.size(1)
         cap = dst.numel()
-        if x.is_cuda:
-            from . import _native as N
-            x2 = x.reshape(K, F)
-            x2 = x2 if x2.dtype == torch.float32 and x2.stride(1) == 1 else x2.to(torch.float32).contiguous()
-            ei = edge_index
-            if not (ei.dtype == torch.int64 and (ei.stride(1) == 1 or E <= 1)):
-                ei = ei.to(torch.int64).contiguous()
-            w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
-            b = None if batch is None else N.i64c(batch)
-            N.check(N.lib().tgp_gather_pack_f32(x2.data_ptr() if K * F else None, x2.stride(0) if K else F, N.ptr(b),
-                                                ei.data_ptr() if E else None,
-                                                ei.data_ptr() + 8 * ei.stride(0) if E else None, N.ptr(w), K, E,
-                                                int(num_graphs), F, cap, dst.data_ptr(), N.stream_ptr(x.device)),
-                    "tgp_gather_pack_f32")
-            return
-        # host tensors (the gloo tests of the N > 1 logic): the same layout with torch ops
-        ox, ob, orow, ocol, ow, end = _gp_layout(K, E, F, edge_weight is not None)
+        ox, ob, orow, ocol, ow, end = _gp_layout(K, E, F * xw, ww)
         head = torch.zeros(_GP_HEADER, dtype=torch.int64)
-        head[:7] = torch.tensor([_GP_MAGIC, K, E, int(num_graphs), F, int(edge_weight is not None), end])
+        head[:8] = torch.tensor([_GP_MAGIC, K, E, int(num_graphs), F * xw, ww, end, xw])
         dst[: _GP_HEADER * 8] = head.view(torch.uint8)
         if end <= cap:
-            dst[ox: ox + K * F * 4] = x.reshape(-1).to(torch.float32).contiguous().view(torch.uint8)
-            bb = torch.zeros(K, dtype=torch.int64) if batch is None else batch.to(torch.int64)
+            dst[ox: ox + K * F * xw * 4] = x2.reshape(-1).contiguous().view(torch.uint8)
+            bb = torch.zeros(K, dtype=torch.int64) if b is None else b
             dst[ob: ob + K * 8] = bb.contiguous().view(torch.uint8)
-            dst[orow: orow + E * 8] = edge_index[0].contiguous().view(torch.uint8)
-            dst[ocol: ocol + E * 8] = edge_index[1].contiguous().view(torch.uint8)
-            if edge_weight is not None:
-                dst[ow: ow + E * 4] = edge_weight.reshape(-1).to(torch.float32).contiguous().view(torch.uint8)
+            dst[orow: orow + E * 8] = ei[0].contiguous().view(torch.uint8)
+            dst[ocol: ocol + E * 8] = ei[1].contiguous().view(torch.uint8)
+            if w is not None:
+                dst[ow: ow + E * ww * 4] = w.contiguous().view(torch.uint8)
 
     def _pack_bucket(self, steps, cap: int) -> Tensor:
         """Device path: every step of the bucket into its slot of a fresh send buffer, ONE launch."""
@@ -329,22 +362,11 @@ class SparseGather:
         dev = steps[0][0].device
         send = torch.empty(n * cap, dtype=torch.uint8, device=dev)
         ptrs = (ctypes.c_void_p * (5 * n))()
-        dims = (ctypes.c_int64 * (5 * n))()
+        dims = (ctypes.c_int64 * (7 * n))()
         keep = []  # converted copies must outlive the launch (stream order: the allocator recycles them after it)
-        for j, (x, edge_index, edge_weight, batch, num_graphs) in enumerate(steps):
-            K, F, E = self._dims(x, edge_index)
-            x2 = x if x.dim() == 2 else x.reshape(K, F)
-            if not (x2.dtype == torch.float32 and (F <= 1 or x2.stride(1) == 1)):
-                x2 = x2.to(torch.float32).contiguous()
-            ei = edge_index
-            if not (ei.dtype == torch.int64 and (E <= 1 or ei.stride(1) == 1)):
-                ei = ei.to(torch.int64).contiguous()
-            w = edge_weight
-            if w is not None and not (w.dtype == torch.float32 and w.dim() == 1 and (E <= 1 or w.stride(0) == 1)):
-                w = N.f32c(w.reshape(-1))
-            b = batch
-            if b is not None and not (b.dtype == torch.int64 and b.dim() == 1 and (K <= 1 or b.stride(0) == 1)):
-                b = N.i64c(b)
+        for j, inputs in enumerate(steps):
+            x2, xw, ei, w, ww, b = self._wire_step(inputs)
+            K, F, E = x2.size(0), x2.size(1), ei.size(1)
             keep.append((x2, ei, w, b))
             o = 5 * j
             ptrs[o] = x2.data_ptr() if K * F else None
@@ -352,7 +374,9 @@ class SparseGather:
             ptrs[o + 2] = ei.data_ptr() if E else None
             ptrs[o + 3] = ei.data_ptr() + 8 * ei.stride(0) if E else None
             ptrs[o + 4] = None if w is None else w.data_ptr()
-            dims[o], dims[o + 1], dims[o + 2], dims[o + 3], dims[o + 4] = (x2.stride(0) if K else F), K, E, num_graphs, F
+            q = 7 * j
+            dims[q], dims[q + 1], dims[q + 2], dims[q + 3] = (x2.stride(0) if K else F) * xw, K, E, inputs[4]
+            dims[q + 4], dims[q + 5], dims[q + 6] = F * xw, ww, xw
         N.check(N.lib().tgp_gather_pack_bucket_f32(ptrs, dims, n, cap, send.data_ptr(), N.stream_ptr(dev)),
                 "tgp_gather_pack_bucket_f32")
         return send
@@ -406,7 +430,7 @@ class SparseGather:
 
     def _enqueue_unpack(self, bucket) -> None:
         """Device path: everything behind the collective is enqueued NOW (stream dependency, no host wait): one unpack
-        launch per step into capacity-sized outputs, totals into pinned words."""
+        launch per bucket into capacity-sized outputs, totals into pinned words."""
         from . import _native as N
         if bucket["work"] is not None:
             bucket["work"].wait()  # the current stream waits for the collective; the host does not
@@ -424,32 +448,35 @@ class SparseGather:
         for inputs in bucket["inputs"]:
             x, edge_index, edge_weight, batch, _ = inputs
             K, F, E = self._dims(x, edge_index)
-            has_w = edge_weight is not None
-            k_cap = self.world * (cap // (4 * F + 8) + 1)
-            e_cap = self.world * (cap // (20 if has_w else 16) + 1)
+            xw = x.element_size() // 4 if x.element_size() in (4, 8) else 1
+            ww = 0 if edge_weight is None else (edge_weight.element_size() // 4
+                                               if edge_weight.element_size() in (4, 8) else 1)
+            Fw = F * xw
+            k_cap = self.world * (cap // (4 * Fw + 8) + 1)
+            e_cap = self.world * (cap // (16 + 4 * ww) + 1)
             ox = total
-            ob = _gp_align(ox + k_cap * F * 4)
+            ob = _gp_align(ox + k_cap * Fw * 4)
             oe = _gp_align(ob + k_cap * 8)
             ow = _gp_align(oe + 2 * e_cap * 8)
-            total = _gp_align(ow + (e_cap * 4 if has_w else 0))
-            plan.append((F, has_w, k_cap, e_cap, ox, ob, oe, ow))
+            total = _gp_align(ow + e_cap * 4 * ww)
+            plan.append((F, xw, ww, k_cap, e_cap, ox, ob, oe, ow))
         import ctypes
         out8 = torch.empty(total, dtype=torch.uint8, device=dev)
         # two typed views of the bucket's output buffer, made once: every merged tensor is then ONE as_strided away
-        out = (out8.view(torch.float32), out8.view(torch.int64))
+        out = (out8.view(torch.float32), out8.view(torch.int64), out8)
         base, gbase = out8.data_ptr(), gathered.data_ptr()
         max_words = cap // 4
         ptrs = (ctypes.c_void_p * (6 * n))()
-        dims = (ctypes.c_int64 * (3 * n))()
+        dims = (ctypes.c_int64 * (6 * n))()
         pin = self._pin.data_ptr()
-        for j, (F, has_w, k_cap, e_cap, ox, ob, oe, ow) in enumerate(plan):
+        for j, (F, xw, ww, k_cap, e_cap, ox, ob, oe, ow) in enumerate(plan):
             self._tick += 1
             slot, tag = self._tick % nslots, self._tick
             o = 6 * j
             ptrs[o], ptrs[o + 1], ptrs[o + 2], ptrs[o + 3] = base + ox, base + ob, base + oe, base + oe + 8 * e_cap
-            ptrs[o + 4] = base + ow if has_w else None
+            ptrs[o + 4] = base + ow if ww else None
             ptrs[o + 5] = pin + slot * 64
-            dims[3 * j], dims[3 * j + 1], dims[3 * j + 2] = k_cap, e_cap, tag
+            dims[o], dims[o + 1], dims[o + 2], dims[o + 3], dims[o + 4], dims[o + 5] = k_cap, e_cap, tag, F * xw, ww, xw
             steps.append((slot, tag, out, plan[j]))
         # ONE launch for the whole bucket (grid z = step)
         N.check(L.tgp_gather_unpack_bucket_f32(gbase, cap, n * cap, self.world, max_words, n, ptrs, dims, st),
@@ -484,6 +511,27 @@ class SparseGather:
         for inp in redo:
             self.start(*inp)
 
+    @staticmethod
+    def _restore(t: Tensor, like: Tensor) -> Tensor:
+        """A merged value tensor back in the dtype its input had (bf16 / half / small ints travelled widened)."""
+        return t if t.dtype == like.dtype else t.to(like.dtype)
+
+    def _hand_out(self, x_in, w_in, b_in, xo, eo, wo, bo) -> None:
+        if x_in.dim() == 1:
+            xo = xo.reshape(-1)
+        xo = self._restore(xo, x_in)
+        if wo is not None:
+            wo = self._restore(wo, w_in)
+        if not self.views:  # the reference's collate hands out fresh tensors of the merged size: so does the default
+            def own(t, like=None):
+                if t is None:
+                    return None
+                # (a dtype restore above already made a fresh tensor)
+                fresh = t.untyped_storage().nbytes() == t.numel() * t.element_size() and t.is_contiguous()
+                return t if fresh else t.clone(memory_format=torch.contiguous_format)
+            xo, eo, wo, bo = own(xo), own(eo), own(wo), own(bo)
+        self._ready.append((xo, eo, wo, bo))
+
     def _finalise_oldest(self, block: bool, allow_redo: bool = False) -> bool:
         if not self._inflight:
             return False
@@ -492,33 +540,47 @@ class SparseGather:
             for (slot, tag, *_rest) in bucket["steps"]:
                 if not self._poll(slot, tag, block):
                     return False
-            results, need, valid = [], 0, True
+            results, need, status = [], 0, 7
             for inputs, (slot, tag, out, plan) in zip(bucket["inputs"], bucket["steps"]):
                 h = self._host[slot * 8: slot * 8 + 8]
-                kt, et, nd, ok = int(h[1]), int(h[2]), int(h[3]), int(h[4])
-                need, valid = max(need, nd), valid and ok == 1
+                kt, et, nd, st = int(h[1]), int(h[2]), int(h[3]), int(h[4])
+                need = max(need, nd)
+                status &= st | (0 if nd <= bucket["cap"] else 4)  # (room is only meaningful for a payload that fitted)
                 results.append((inputs, kt, et, out, plan))
-            if not valid:
+            if not status & 1:
                 raise RuntimeError("SparseGather: a gathered buffer does not start with a pack header")
+            if not status & 2:
+                raise RuntimeError("SparseGather: the ranks packed different feature widths / value dtypes / edge-weight "
+                                   "presence for the same step -- every rank must gather tensors of the same layout")
             if need > bucket["cap"]:
                 if not allow_redo:
                     return False
                 self._inflight.pop(0)
                 self._redo_with(need, bucket)
                 return self._finalise_oldest(block, allow_redo)
+            if not status & 4:
+                raise RuntimeError("SparseGather: merged outputs exceed the capacity buffers (internal sizing error)")
             self._inflight.pop(0)
-            for inputs, kt, et, out, (F, has_w, k_cap, e_cap, ox, ob, oe, ow) in results:
-                x_in, _, _, b_in, _ = inputs
-                f32, i64 = out
-                xo = torch.as_strided(f32, (kt, F), (F, 1), ox >> 2)
+            for inputs, kt, et, out, (F, xw, ww, k_cap, e_cap, ox, ob, oe, ow) in results:
+                x_in, _, w_in, b_in, _ = inputs
+                f32, i64, raw = out
+                x_wire = x_in.dtype if x_in.element_size() in (4, 8) else (
+                    torch.float32 if x_in.is_floating_point() else torch.int32)
+                if x_wire == torch.float32:
+                    xo = torch.as_strided(f32, (kt, F), (F, 1), ox >> 2)
+                else:
+                    xo = raw[ox: ox + kt * F * xw * 4].view(x_wire).view(kt, F)
                 eo = torch.as_strided(i64, (2, et), (e_cap, 1), oe >> 3)
-                wo = torch.as_strided(f32, (et,), (1,), ow >> 2) if has_w else None
+                wo = None
+                if ww:
+                    w_wire = w_in.dtype if w_in.element_size() in (4, 8) else (
+                        torch.float32 if w_in.is_floating_point() else torch.int32)
+                    if w_wire == torch.float32:
+                        wo = torch.as_strided(f32, (et,), (1,), ow >> 2)
+                    else:
+                        wo = raw[ow: ow + et * ww * 4].view(w_wire)
                 bo = torch.as_strided(i64, (kt,), (1,), ob >> 3) if b_in is not None else None
-                if x_in.dim() == 1:
-                    xo = xo.view(-1)
-                if x_in.dtype != torch.float32 and x_in.is_floating_point():
-                    xo = xo.to(x_in.dtype)
-                self._ready.append((xo, eo, wo, bo))
+                self._hand_out(x_in, w_in, b_in, xo, eo, wo, bo)
             return True
         # host tensors (gloo): synchronous, with torch ops
         if bucket["work"] is not None:
@@ -530,6 +592,12 @@ class SparseGather:
         if not bool((heads[..., 0] == _GP_MAGIC).all()):
             raise RuntimeError("SparseGather: a gathered buffer does not start with a pack header")
         need = int(heads[..., 6].max())
+        for j, inputs in enumerate(bucket["inputs"]):  # the same agreement check the unpack kernel makes
+            x2, xw, _, w, ww, _ = self._wire_step(inputs)
+            mine = torch.tensor([x2.size(1) * xw, ww, xw])
+            if not bool((heads[:, j][:, [4, 5, 7]] == mine).all()):
+                raise RuntimeError("SparseGather: the ranks packed different feature widths / value dtypes / edge-weight "
+                                   "presence for the same step -- every rank must gather tensors of the same layout")
         if need > cap:
             if not allow_redo:
                 return False
@@ -538,35 +606,44 @@ class SparseGather:
             return self._finalise_oldest(block, allow_redo)
         self._inflight.pop(0)
         for j, inputs in enumerate(bucket["inputs"]):
-            x_in, _, _, b_in, _ = inputs
+            x_in, _, w_in, b_in, _ = inputs
+            x2, xw, _, w2, ww, _ = self._wire_step(inputs)
             hj = heads[:, j]
-            F, has_w = int(hj[0, 4]), bool(hj[0, 5])
+            F = x2.size(1)
+            Fw = F * xw
             Kt, Et = int(hj[:, 1].sum()), int(hj[:, 2].sum())
-            x_out = torch.empty(Kt, F, dtype=torch.float32)
+            x_out = torch.empty(Kt * Fw * 4, dtype=torch.uint8)
             b_out = torch.empty(Kt, dtype=torch.int64)
             ei_out = torch.empty(2, Et, dtype=torch.int64)
-            w_out = torch.empty(Et, dtype=torch.float32) if has_w else None
+            w_out = torch.empty(Et * ww * 4, dtype=torch.uint8) if ww else None
             koff = eoff = goff = 0
             for r in range(world):
                 K, E, B = int(hj[r, 1]), int(hj[r, 2]), int(hj[r, 3])
-                ox, ob, orow, ocol, ow, _ = _gp_layout(K, E, F, has_w)
+                ox, ob, orow, ocol, ow, _ = _gp_layout(K, E, Fw, ww)
                 buf = g3[r, j]
-                x_out[koff: koff + K] = buf[ox: ox + K * F * 4].contiguous().view(torch.float32).view(K, F)
+                x_out[koff * Fw * 4: (koff + K) * Fw * 4] = buf[ox: ox + K * Fw * 4]
                 b_out[koff: koff + K] = buf[ob: ob + K * 8].contiguous().view(torch.int64) + goff
                 ei_out[0, eoff: eoff + E] = buf[orow: orow + E * 8].contiguous().view(torch.int64) + koff
                 ei_out[1, eoff: eoff + E] = buf[ocol: ocol + E * 8].contiguous().view(torch.int64) + koff
-                if has_w:
-                    w_out[eoff: eoff + E] = buf[ow: ow + E * 4].contiguous().view(torch.float32)
+                if ww:
+                    w_out[eoff * ww * 4: (eoff + E) * ww * 4] = buf[ow: ow + E * ww * 4]
                 koff, eoff, goff = koff + K, eoff + E, goff + B
-            if x_in.dim() == 1:
-                x_out = x_out.view(-1)
-            if x_in.dtype != torch.float32 and x_in.is_floating_point():
-                x_out = x_out.to(x_in.dtype)
-            self._ready.append((x_out, ei_out, w_out, b_out if b_in is not None else None))
+            xo = x_out.view(x2.dtype).view(Kt, F)
+            wo = w_out.view(w2.dtype) if ww else None
+            self._hand_out(x_in, w_in, b_in, xo, ei_out, wo, b_out if b_in is not None else None)
         return True
+
+    def _enter(self, mode: str) -> None:
+        if self._mode is None:
+            self._mode = mode
+        elif self._mode != mode:
+            raise RuntimeError("SparseGather: take_ready() and wait() must not be mixed on one gather (a capacity change "
+                               "re-issues collectives and may only be decided where every rank decides it: see the class "
+                               "docstring); use take_ready ... flush OR wait ... flush")
 
     def take_ready(self) -> List[tuple]:
         """Results of buckets whose unpack has already reported (never waits for a collective still in flight)."""
+        self._enter("poll")
         while self._inflight:
             bk = self._inflight[0]
             if bk["steps"] is None and bk["work"] is not None and not bk["work"].is_completed():
@@ -579,6 +656,7 @@ class SparseGather:
     def wait(self):
         """The oldest result not yet handed out (sends a partly filled bucket and waits if it has to), or None.  Like
         ``start`` / ``flush``, every rank must call it at the same place."""
+        self._enter("block")
         if not self._ready:
             if not self._inflight:
                 self._launch(partial=True)
@@ -595,16 +673,27 @@ class SparseGather:
         return res
 
 
+_SYNC_GATHERS: dict = {}
+
+
 def all_gather_sparse(x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor,
                       num_graphs_local: int, group=None, force_collective: bool = False):
     """Gather variable-size pooled graphs from every rank, synchronously: one :class:`SparseGather` step (one payload
     collective; node ids / graph ids of rank r shifted by the totals of ranks < r).  ``force_collective`` (or
-    ``TGP_FORCE_COLLECTIVE``): a one-rank process group still runs the collective."""
+    ``TGP_FORCE_COLLECTIVE``): a one-rank process group still runs the collective.  Returns new contiguous tensors in
+    the dtypes of the inputs.  The gather object -- and with it the slot capacity the ranks have agreed on so far -- is
+    kept per process group: a payload beyond the initial 64 KiB pays the header-only round and the regrowth once, not on
+    every call (growth is decided from the same headers on every rank, so the kept value is the same everywhere)."""
     world = _world(group)
     forced = (dist.is_available() and dist.is_initialized()
               and (force_collective or bool(os.environ.get("TGP_FORCE_COLLECTIVE"))))
     if world == 1 and not forced:
         return x, edge_index, edge_weight, batch
-    g = SparseGather(group=group, force_collective=force_collective, depth=1, bucket_steps=1)
+    key = (id(group) if group is not None else 0, bool(forced), world)
+    g = _SYNC_GATHERS.get(key)
+    if g is None or g.group is not group or g._inflight or g._open or g._ready:
+        if len(_SYNC_GATHERS) > 8:
+            _SYNC_GATHERS.clear()
+        g = _SYNC_GATHERS[key] = SparseGather(group=group, force_collective=force_collective, depth=1, bucket_steps=1)
     g.start(x, edge_index, edge_weight, batch, num_graphs_local)
     return g.wait()

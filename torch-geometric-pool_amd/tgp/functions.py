@@ -689,7 +689,8 @@ class ASProducts:
 
     @staticmethod
     def _product(s: Tensor, adj: Tensor, transposed: bool) -> Tensor:
-        mem, tflag = K._dense_adj_layout(adj)  # adj may be the transposed view of contiguous memory (src.py:442-443)
+        # adj may be the transposed view of contiguous memory (src.py:442-443); float64 operands stay float64
+        mem, tflag = K._dense_adj_layout(adj, torch.float64 if K._any_f64(s, adj) else torch.float32)
         return K.bmm(mem, s, trans_a=bool(tflag) != transposed)
 
     def get_u(self, s: Tensor, adj: Tensor) -> Tensor:

@@ -713,16 +713,22 @@ def normalize_edges_(edge_index: Tensor, edge_weight: Tensor, num_nodes: int, de
 
 
 # ------------------------------------------------------------------------- A3 / A7 / A8
+def _any_f64(*ts) -> bool:
+    """Does any operand carry float64?  Then the product runs on the fp64 matrix path (r5: the reference's
+    torch.matmul computes model.double() inputs in fp64, base_reduce.py:158-161, dense_conn.py:111-122)."""
+    return any(isinstance(t, Tensor) and t.dtype == torch.float64 for t in ts)
+
+
 def dense_flags(remove_self_loops: bool, degree_norm: bool, adj_transpose: bool, edge_weight_norm: bool) -> int:
     return ((N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.DEGREE_NORM if degree_norm else 0)
             | (N.SUM_AXIS_ROWS if adj_transpose else 0) | (N.EDGE_WEIGHT_NORM if edge_weight_norm else 0))
 
 
-def _dense_adj_layout(adj: Tensor) -> Tuple[Tensor, int]:
+def _dense_adj_layout(adj: Tensor, dtype: torch.dtype = torch.float32) -> Tuple[Tensor, int]:
     """Accept A [B,N,N] as contiguous or as the transposed view produced by
     DenseSRCPooling.preprocessing (src.py:442-443) without materialising the transpose."""
-    if adj.dtype != torch.float32:
-        adj = adj.to(torch.float32)
+    if adj.dtype != dtype:
+        adj = adj.to(dtype)
     if adj.is_contiguous():
         return adj, 0
     t = adj.transpose(-1, -2)
@@ -731,13 +737,44 @@ def _dense_adj_layout(adj: Tensor) -> Tuple[Tensor, int]:
     return adj.contiguous(), 0
 
 
-def _out_buffer(out: Optional[Tensor], shape, dev) -> Tensor:
+def _out_buffer(out: Optional[Tensor], shape, dev, dtype: torch.dtype = torch.float32) -> Tensor:
     if out is None:
-        return torch.empty(shape, dtype=torch.float32, device=dev)
-    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or out.device != dev or not out.is_contiguous():
-        raise ValueError(f"output buffer must be a contiguous float32 {tuple(shape)} tensor on {dev}, got "
+        return torch.empty(shape, dtype=dtype, device=dev)
+    if tuple(out.shape) != tuple(shape) or out.dtype != dtype or out.device != dev or not out.is_contiguous():
+        raise ValueError(f"output buffer must be a contiguous {dtype} {tuple(shape)} tensor on {dev}, got "
                          f"{tuple(out.shape)} {out.dtype} on {out.device}")
     return out
+
+
+def _dense_pool_f64(s, adj, x, flags, want_raw, want_post, out_x, out_adj):
+    """float64 operands: the same fused A3 + A7 + A8 call on v_mfma_f64_16x16x4_f64 (tgp_dense_pool_f64)."""
+    dev = N.require_device(s, adj, x)
+    s = N.f64c(s)
+    B, Nn, K = s.shape
+    F = 0
+    x_pool = adj_raw = adj_pool = None
+    if x is not None:
+        x = N.f64c(x)
+        if x.shape[:2] != (B, Nn):
+            raise ValueError(f"x {tuple(x.shape)} does not match s {tuple(s.shape)}")
+        F = x.size(2)
+        x_pool = _out_buffer(out_x, (B, K, F), dev, torch.float64)
+    a = None
+    if adj is not None:
+        if adj.shape != (B, Nn, Nn):
+            raise ValueError(f"adj {tuple(adj.shape)} does not match s {tuple(s.shape)}")
+        a, tflag = _dense_adj_layout(adj, torch.float64)
+        flags |= tflag
+        if want_raw:
+            adj_raw = torch.empty(B, K, K, dtype=torch.float64, device=dev)
+        if want_post:
+            adj_pool = _out_buffer(out_adj, (B, K, K), dev, torch.float64)
+    L = N.lib()
+    ws = N.workspace(L.tgp_dense_pool_workspace_bytes_f64(B, Nn, K, F), dev)
+    N.check(L.tgp_dense_pool_f64(N.ptr(s), N.ptr(a), N.ptr(x), B, Nn, K, F, flags, ops_eps(), N.ptr(x_pool),
+                                 N.ptr(adj_raw), N.ptr(adj_pool), N.ptr(ws), ws.numel(), N.stream_ptr(dev)),
+            "tgp_dense_pool_f64")
+    return x_pool, adj_raw, adj_pool
 
 
 def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int = 0, want_raw: bool = False,
@@ -747,7 +784,11 @@ def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int
     (reduce/base_reduce.py:158-161, connect/dense_conn.py:111-122, utils/ops.py:282-335).  ``graph_sizes`` [B]
     (optional): real nodes per graph when they are the leading rows and the padding is zero (to_dense_batch layout).
     ``mincut_terms``: return a fourth value, the [2,B] per-graph tails of MinCut's losses taken inside the pooling
-    kernel (batches of small graphs only; None when the batch takes another kernel)."""
+    kernel (batches of small graphs only; None when the batch takes another kernel).  float64 operands (any of the
+    three) run the fp64 form of the same call; ``graph_sizes`` is a speed hint the fp64 form does not use."""
+    if _any_f64(s, adj, x):
+        out = _dense_pool_f64(s, adj, x, flags, want_raw, want_post, out_x, out_adj)
+        return out + (None,) if mincut_terms else out
     dev = N.require_device(s, adj, x)
     s = N.f32c(s)
     B, Nn, K = s.shape
@@ -918,8 +959,13 @@ def _sizes_arg(graph_sizes: Optional[Tensor], num_graphs: int, dev) -> Optional[
 
 
 def link_loss_sq(s: Tensor, adj: Tensor, graph_sizes: Optional[Tensor] = None) -> Tensor:
-    """sq[b] = ||adj[b] - s[b] s[b]^T||_F^2 without materialising s s^T (utils/losses.py:644-708)."""
+    """sq[b] = ||adj[b] - s[b] s[b]^T||_F^2 without materialising s s^T (utils/losses.py:644-708).  float64: s s^T on
+    the fp64 matrix path and the residual as the reference writes it (losses.py:644-652)."""
     dev = N.require_device(s, adj)
+    if _any_f64(s, adj):
+        s64 = N.f64c(s)
+        sst = bmm(s64, s64.transpose(1, 2).contiguous())
+        return ((adj.to(torch.float64) - sst) ** 2).sum(dim=(1, 2))
     s, adj = N.f32c(s), N.f32c(adj)
     B, Nn, K = s.shape
     if adj.shape != (B, Nn, Nn):
@@ -956,6 +1002,8 @@ def diffpool_loss_tail(s: Tensor, adj: Tensor, graph_sizes: Optional[Tensor], li
 def entropy_sum(s: Tensor) -> Tensor:
     """0-d tensor sum(-s log(s + eps)) over every element (utils/losses.py:476-483 before / num_nodes)."""
     dev = N.require_device(s)
+    if s.dtype == torch.float64:  # one elementwise pass + a sum, in double like the reference's
+        return (-(s * torch.log(s + losses_eps()))).sum()
     s = N.f32c(s)
     out = torch.empty((), dtype=torch.float32, device=dev)
     L = N.lib()
@@ -970,6 +1018,10 @@ def cut_terms(adj: Tensor, s: Tensor, graph_sizes: Optional[Tensor] = None) -> T
     """(deg [B,N], q [B,N], den [B]): row sums of adj, squared row norms of s, trace(s^T D s)
     (utils/losses.py:39-81)."""
     dev = N.require_device(adj, s)
+    if _any_f64(adj, s):
+        a64, s64 = adj.to(torch.float64), s.to(torch.float64)
+        deg, q = a64.sum(-1), (s64 * s64).sum(-1)
+        return deg, q, (deg * q).sum(-1)
     adj, s = N.f32c(adj), N.f32c(s)
     B, Nn, K = s.shape
     if adj.shape != (B, Nn, Nn):
@@ -1342,6 +1394,8 @@ def edge_dot(s: Tensor, edge_index: Tensor) -> Tensor:
     """ss[e] = <S[row_e], S[col_e]> (utils/losses.py:73-127, 661-708: ``(S[src] * S[dst]).sum(-1)``) in one pass."""
     dev = N.require_device(s, edge_index)
     row, col = _edge_rows(edge_index)
+    if s.dtype == torch.float64:
+        return (s[row] * s[col]).sum(-1)
     s = N.f32c(s)
     out = torch.empty(row.numel(), dtype=torch.float32, device=dev)
     N.check(N.lib().tgp_edge_dot_f32(N.ptr(row), N.ptr(col), row.numel(), N.ptr(s), s.size(0), s.size(1), N.ptr(out),
@@ -1352,10 +1406,13 @@ def edge_dot(s: Tensor, edge_index: Tensor) -> Tensor:
 def bmm(a: Tensor, b: Tensor, trans_a: bool = False, accumulate_into: Optional[Tensor] = None) -> Tensor:
     """C[g] = op(A[g]) @ B[g] on the fp32 matrix cores.  a: [G,M,Kd] (or [G,Kd,M] when trans_a),
     b: [G,Kd,Nc]; 2-D operands are treated as G = 1.  ``accumulate_into`` (contiguous fp32 [G,M,Nc]): C += product in
-    the GEMM epilogue, returned as that tensor."""
+    the GEMM epilogue, returned as that tensor.  A float64 operand sends the product to the fp64 matrix path
+    (tgp_bmm_f64); the result is float64."""
     dev = N.require_device(a, b)
-    a3 = N.f32c(a if a.dim() == 3 else a.unsqueeze(0))
-    b3 = N.f32c(b if b.dim() == 3 else b.unsqueeze(0))
+    f64 = _any_f64(a, b) or (accumulate_into is not None and accumulate_into.dtype == torch.float64)
+    conv, dt = (N.f64c, torch.float64) if f64 else (N.f32c, torch.float32)
+    a3 = conv(a if a.dim() == 3 else a.unsqueeze(0))
+    b3 = conv(b if b.dim() == 3 else b.unsqueeze(0))
     G = max(a3.size(0), b3.size(0))
     if trans_a:
         Kd, M = a3.size(1), a3.size(2)
@@ -1368,15 +1425,24 @@ def bmm(a: Tensor, b: Tensor, trans_a: bool = False, accumulate_into: Optional[T
     sB = 0 if b3.size(0) == 1 else b3.stride(0)
     if accumulate_into is not None:
         out = accumulate_into
-        if (out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != G * M * Nc or out.device != dev):
-            raise ValueError("bmm: accumulate_into must be a contiguous float32 tensor of the product's shape")
+        if (out.dtype != dt or not out.is_contiguous() or out.numel() != G * M * Nc or out.device != dev):
+            raise ValueError(f"bmm: accumulate_into must be a contiguous {dt} tensor of the product's shape")
+        if f64:
+            N.check(N.lib().tgp_bmm_f64(N.ptr(a3), N.ptr(b3), N.ptr(out), G, M, Nc, Kd, 1 if trans_a else 0,
+                                        a3.stride(1), b3.stride(1), Nc, sA, sB, M * Nc, 1, N.stream_ptr(dev)),
+                    "tgp_bmm_f64")
+            return out
         N.check(N.lib().tgp_bmm_accumulate_f32(N.ptr(a3), N.ptr(b3), N.ptr(out), G, M, Nc, Kd, 1 if trans_a else 0,
                                                a3.stride(1), b3.stride(1), Nc, sA, sB, M * Nc, N.stream_ptr(dev)),
                 "tgp_bmm_accumulate_f32")
         return out
-    out = torch.empty(G, M, Nc, dtype=torch.float32, device=dev)
-    N.check(N.lib().tgp_bmm_f32(N.ptr(a3), N.ptr(b3), N.ptr(out), G, M, Nc, Kd, 1 if trans_a else 0, a3.stride(1),
-                                b3.stride(1), Nc, sA, sB, M * Nc, N.stream_ptr(dev)), "tgp_bmm_f32")
+    out = torch.empty(G, M, Nc, dtype=dt, device=dev)
+    if f64:
+        N.check(N.lib().tgp_bmm_f64(N.ptr(a3), N.ptr(b3), N.ptr(out), G, M, Nc, Kd, 1 if trans_a else 0, a3.stride(1),
+                                    b3.stride(1), Nc, sA, sB, M * Nc, 0, N.stream_ptr(dev)), "tgp_bmm_f64")
+    else:
+        N.check(N.lib().tgp_bmm_f32(N.ptr(a3), N.ptr(b3), N.ptr(out), G, M, Nc, Kd, 1 if trans_a else 0, a3.stride(1),
+                                    b3.stride(1), Nc, sA, sB, M * Nc, N.stream_ptr(dev)), "tgp_bmm_f32")
     return out if (a.dim() == 3 or b.dim() == 3) else out[0]
 
 
@@ -1425,6 +1491,16 @@ def segment_gemm_tn(s: Tensor, y: Tensor, ptr: Tensor, max_nodes: int) -> Tensor
     """C[b] = S_b^T Y_b over node rows ptr[b]..ptr[b+1] (reduce/base_reduce.py:170-182,
     connect/dense_conn.py:195-206) in one launch."""
     dev = N.require_device(s, y, ptr)
+    if _any_f64(s, y):
+        s, y, ptr = N.f64c(s), N.f64c(y), N.i64c(ptr)
+        B = ptr.numel() - 1
+        K, F = s.size(1), y.size(1)
+        out = torch.empty(B, K, F, dtype=torch.float64, device=dev)
+        L = N.lib()
+        ws = N.workspace(L.tgp_segment_gemm_tn_workspace_bytes_f64(B, K, F, max_nodes), dev)
+        N.check(L.tgp_segment_gemm_tn_f64(N.ptr(s), N.ptr(y), N.ptr(ptr), N.ptr(out), B, s.size(0), K, F, max_nodes,
+                                          N.ptr(ws), ws.numel(), N.stream_ptr(dev)), "tgp_segment_gemm_tn_f64")
+        return out
     s, y, ptr = N.f32c(s), N.f32c(y), N.i64c(ptr)
     B = ptr.numel() - 1
     K, F = s.size(1), y.size(1)
@@ -1440,10 +1516,17 @@ def segment_gemm_nn(a: Tensor, bm: Tensor, ptr: Tensor, max_nodes: int) -> Tenso
     """C[rows of graph b] = A[rows of graph b] @ Bm[b] (lift/base_lift.py:138-247 on an un-padded batch; the
     backward of :func:`segment_gemm_tn`) in one launch.  a: [Ntot,Kd], bm: [B,Kd,Nc]."""
     dev = N.require_device(a, bm, ptr)
-    a, bm, ptr = N.f32c(a), N.f32c(bm), N.i64c(ptr)
+    f64 = _any_f64(a, bm)
+    conv = N.f64c if f64 else N.f32c
+    a, bm, ptr = conv(a), conv(bm), N.i64c(ptr)
     B = ptr.numel() - 1
     if bm.dim() != 3 or bm.size(0) != B or bm.size(1) != a.size(1):
         raise ValueError(f"segment_gemm_nn: a {tuple(a.shape)} x bm {tuple(bm.shape)} with {B} graphs")
+    if f64:
+        out = torch.empty(a.size(0), bm.size(2), dtype=torch.float64, device=dev)
+        N.check(N.lib().tgp_segment_gemm_nn_f64(N.ptr(a), N.ptr(bm), N.ptr(ptr), N.ptr(out), B, a.size(0), a.size(1),
+                                                bm.size(2), max_nodes, N.stream_ptr(dev)), "tgp_segment_gemm_nn_f64")
+        return out
     out = torch.empty(a.size(0), bm.size(2), dtype=torch.float32, device=dev)
     N.check(N.lib().tgp_segment_gemm_nn_f32(N.ptr(a), N.ptr(bm), N.ptr(ptr), N.ptr(out), B, a.size(0), a.size(1),
                                             bm.size(2), max_nodes, N.stream_ptr(dev)), "tgp_segment_gemm_nn_f32")
@@ -1463,13 +1546,20 @@ def spmm_sorted(edge_index: Tensor, edge_weight: Optional[Tensor], num_rows: int
     """T = A S for a row-sorted (coalesced) edge list (connect/dense_conn.py:165,204)."""
     dev = N.require_device(edge_index, edge_weight, s)
     row, col = _edge_rows(edge_index)
-    s = N.f32c(s)
-    w = None if edge_weight is None else N.f32c(edge_weight)
+    f64 = _any_f64(s, edge_weight)
+    conv = N.f64c if f64 else N.f32c
+    s = conv(s)
+    w = None if edge_weight is None else conv(edge_weight)
     L = N.lib()
     st = N.stream_ptr(dev)
     row_ptr = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
     N.check(L.tgp_rowptr_from_sorted_i64(N.ptr(row), row.numel(), num_rows, N.ptr(row_ptr), st),
             "tgp_rowptr_from_sorted_i64")
+    if f64:
+        out = torch.empty(num_rows, s.size(1), dtype=torch.float64, device=dev)
+        N.check(L.tgp_spmm_csr_f64(N.ptr(row_ptr), N.ptr(col), N.ptr(w), num_rows, row.numel(), N.ptr(s), s.size(1),
+                                   N.ptr(out), st), "tgp_spmm_csr_f64")
+        return out
     out = torch.empty(num_rows, s.size(1), dtype=torch.float32, device=dev)
     N.check(L.tgp_spmm_csr_f32(N.ptr(row_ptr), N.ptr(col), N.ptr(w), num_rows, row.numel(), N.ptr(s), s.size(1),
                                N.ptr(out), st), "tgp_spmm_csr_f32")

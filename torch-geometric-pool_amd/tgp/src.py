@@ -385,9 +385,6 @@ class DenseSRCPooling(SRCPooling):
             raise ValueError("Assignment and adjacency batch sizes do not match: "
                              f"got s.size(0)={s.size(0)} and adj.size(0)={adj.size(0)}.")
         flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
-        if torch.float64 in (s.dtype, adj.dtype, x.dtype):
-            from .utils.ops import _warn_float64_once
-            _warn_float64_once()  # the GEMM path below is fp32 arithmetic: said once per process
         if torch.is_grad_enabled() and (s.requires_grad or adj.requires_grad or x.requires_grad):
             # training: batches of small graphs keep the fused kernel and get its one-launch backward (the adjacency
             # gets no gradient there, edge_weight_norm is not differentiated there: those keep the operator path)
@@ -408,7 +405,7 @@ class DenseSRCPooling(SRCPooling):
                            graph_sizes=getattr(so, "_graph_sizes", None), out_x=out_x, out_adj=out_adj,
                            mincut_terms=want_mincut_terms)
         x_pool, raw, adj_pool = out[:3]
-        # fp32 arithmetic; results carry the dtypes the reference's ATen ops would return
+        # fp32 arithmetic (fp64 when an operand is float64); results carry the dtypes the reference's ATen ops would return
         res = (like_input_dtype(x_pool, x), like_input_dtype(raw, s), like_input_dtype(adj_pool, s))
         # want_mincut_terms: a fourth value, the [2,B] loss tails from inside the pooling kernel (None when the batch
         # does not take the one-wave-per-graph kernel); want_diff_losses: a last value, None on this (no-grad) path --

@@ -35,29 +35,14 @@ def is_dense_adj(edge_index) -> bool:
 
 
 def as_compute_dtype(t):
-    """The kernels compute in fp32.  Floating tensors of another dtype (a ``model.double()`` run, bf16 / half
-    features) are converted on the way in -- differentiably -- and :func:`like_input_dtype` converts results back, so
-    the dtype a caller sees is the one the reference's ATen ops would return; the arithmetic stays fp32."""
-    if isinstance(t, Tensor) and not t.is_sparse and t.is_floating_point() and t.dtype != torch.float32:
-        if t.dtype == torch.float64:
-            _warn_float64_once()
+    """fp32 and fp64 are the arithmetic types of the kernels (r5: float64 tensors run on the fp64 forms, dense GEMM path
+    included, like the reference's ATen ops do for a ``model.double()`` run).  bf16 / half tensors are converted to
+    fp32 on the way in -- differentiably -- and :func:`like_input_dtype` converts results back, so the dtype a caller
+    sees is the one the reference would return."""
+    if (isinstance(t, Tensor) and not t.is_sparse and t.is_floating_point()
+            and t.dtype not in (torch.float32, torch.float64)):
         return t.float()
     return t
-
-
-_WARNED_F64 = False
-
-
-def _warn_float64_once() -> None:
-    """The reference computes ``model.double()`` inputs in true fp64 (ATen); this build's kernels are fp32.  Said out
-    loud, once per process, instead of silently narrowing (``torch.autograd.gradcheck`` in fp64 will not pass)."""
-    global _WARNED_F64
-    if not _WARNED_F64:
-        _WARNED_F64 = True
-        import warnings
-        warnings.warn("tgp (MI355X build): float64 inputs are computed in float32 by the HIP kernels and the results "
-                      "cast back to float64; the reference computes them in float64.  Precision is fp32's.",
-                      UserWarning, stacklevel=3)
 
 
 def like_input_dtype(out, like):
