@@ -23,8 +23,9 @@ Rank 0 prints ONE JSON line:
   "secondary"      the other north_star workloads, each with its own median-window timing and roofline:
                    c5 (N=8192,K=512,F=128: fp32 MFMA), topk1m (TopK scatter-reduce: HBM), topk_connect (TopK subgraph
                    Connect: HBM), c4_graclus (Reduce + coalesce Connect, both rooflines: HBM), c3 (MinCut small graphs:
-                   HBM), c4_ndp (NDP-shaped Reduce), topk_batch (batched sparse TopK Reduce + Connect; with ranks: +
-                   variable-size RCCL all-gather), e2e_diff_c2 / e2e_mincut_c3 (WHOLE pooler forwards on sparse
+                   HBM), c4_ndp (NDP-shaped Reduce), topk_batch / graclus_batch (batched sparse Reduce + Connect; with
+                   ranks: + variable-size RCCL all-gather) and their *_fresh twins (NEW tensor objects every step, as a
+                   DataLoader's mini-batches: the per-tensor memos miss), e2e_diff_c2 / e2e_mincut_c3 (WHOLE pooler forwards on sparse
                    inputs, eager and HIP-graph replayed, launches per forward), e2e_train_mincut_c3 (a whole MinCut
                    training step, forward + backward, launches per step).  With N > 1 only the graph-sharded
                    ones run; one giant graph (C4) does not shard.
@@ -516,6 +517,8 @@ class TopkBatch(Workload):
     payloads, then node-id / graph-id offsets: the merge rule of tgp/data/collate.py:144-153)."""
     shards = True
 
+    FRESH_COPIES = 24  # more distinct tensor objects than any per-tensor memo of the package holds (16)
+
     def __init__(self, ctx, force_collective=False, unfused=False, which="topk_batch"):
         from tgp.connect import SparseConnect
         from tgp.reduce import BaseReduce
@@ -523,14 +526,31 @@ class TopkBatch(Workload):
         dev = ctx.dev
         torch.manual_seed(ctx.rank)
         self.f = 32
+        self.fresh = which.endswith("_fresh")
+        which = which[: -len("_fresh")] if self.fresh else which
         self.which = which
         self.x, self.ei, self.batch = sparse_batch(_proteins_sizes(ctx.rank), 4, self.f, dev, seed=ctx.rank)
         self.ew = torch.rand(self.ei.size(1), device=dev) + 0.5
-        with torch.no_grad():
-            if which == "topk_batch":
-                self.so = TopkSelect(in_channels=self.f, ratio=0.5).to(dev)(x=self.x, batch=self.batch)
-            else:  # Graclus matching of every graph: many-to-one S, relabel + coalesce Connect
-                self.so = GraclusSelect()(self.ei, self.ew, num_nodes=self.x.size(0), batch=self.batch)
+        topk_sel = TopkSelect(in_channels=self.f, ratio=0.5).to(dev) if which == "topk_batch" else None
+
+        def select(x, ei, ew):
+            with torch.no_grad():
+                if topk_sel is not None:
+                    return topk_sel(x=x, batch=self.batch)
+                # Graclus matching of every graph: many-to-one S, relabel + coalesce Connect
+                return GraclusSelect()(ei, ew, num_nodes=x.size(0), batch=self.batch)
+        self.so = select(self.x, self.ei, self.ew)
+        # *_fresh (verdict r4 item 2): every step pools NEW tensor objects -- x, edge_index, edge_weight and the
+        # SelectOutput Select made from them -- as every mini-batch of a training loop does: the memos keyed on the edge
+        # list object (per-graph edge offsets, row order, declines) miss on every step.  Select has run on each copy (it
+        # is outside the metric), so what Select itself leaves behind is there, as in a real forward: the
+        # batch vector's facts and the by-products it attaches to its SelectOutput.
+        self.copies, self._turn = None, 0
+        if self.fresh:
+            self.copies = []
+            for _ in range(self.FRESH_COPIES):
+                xx, ee, ww = self.x.clone(), self.ei.clone(), self.ew.clone()
+                self.copies.append((xx, ee, ww, select(xx, ee, ww)))
         self.red, self.conn = BaseReduce(), SparseConnect()
         from tgp.src import SRCPooling
         self.pool = SRCPooling(reducer=self.red, connector=self.conn)
@@ -549,28 +569,43 @@ class TopkBatch(Workload):
         self.name = (("TopK (ratio 0.5) Reduce + subgraph Connect" if which == "topk_batch" else
                       "Graclus Reduce + coalesce Connect") +
                      " on 2048 PROTEINS-shaped graphs (n~U[20,60], F=32), graph-sharded"
+                     + (", NEW tensor objects every step (a DataLoader's mini-batches)" if self.fresh else "")
                      + (", pooled outputs all-gathered over RCCL (variable-size)" if self.gather else ""))
         self.extra = {"edges": int(self.ei.size(1)), "num_supernodes": int(self.so.num_supernodes),
                       "nodes_counted": "input nodes per step per GPU",
+                      "tensors": (f"rotates through {self.FRESH_COPIES} pre-made copies of (x, edge_index, edge_weight, "
+                                  "SelectOutput): more objects than any per-tensor memo holds, so every step misses"
+                                  if self.fresh else "the same tensor objects every step (full-batch training: the "
+                                  "per-graph edge offsets of the edge list come from a memo)"),
+                      "output_layout": "contiguous exact-size tensors (the default; capacity views are timed beside it)",
                       "step": ("BaseReduce then SparseConnect, operator by operator" if unfused else
                                "fused Reduce + Connect as the sparse poolers' forward calls it on a batch of small "
                                "graphs: SRCPooling.reduce_connect (one launch + the count read-back)")
                               + (" + SparseGather (one asynchronous payload collective per 8 steps)" if self.gather else "")}
 
-    def staged(self):
+    def _inputs(self):
+        if self.copies is None:
+            return self.x, self.ei, self.ew, self.so
+        self._turn = (self._turn + 1) % len(self.copies)
+        return self.copies[self._turn]
+
+    def staged(self, inputs=None):
+        x, e, w, so = inputs or self._inputs()
         with torch.no_grad():
-            xp, bp = self.red(self.x, self.so, batch=self.batch)
-            ei, ew = self.conn(self.ei, self.so, edge_weight=self.ew, batch_pooled=bp)
+            xp, bp = self.red(x, so, batch=self.batch)
+            ei, ew = self.conn(e, so, edge_weight=w, batch_pooled=bp)
         return xp, ei, ew, bp
 
     def compute(self):
+        inputs = self._inputs()
         if not self.unfused:
+            x, e, w, so = inputs
             with torch.no_grad():
-                fused = self.pool.reduce_connect(self.x, self.ei, self.ew, self.so, self.batch)
+                fused = self.pool.reduce_connect(x, e, w, so, self.batch)
             if fused is not None:
                 xp, bp, ei, ew = fused
                 return xp, ei, ew, bp
-        return self.staged()
+        return self.staged(inputs)
 
     def step(self):
         xp, ei, ew, bp = self.compute()
@@ -609,9 +644,18 @@ class TopkBatch(Workload):
                      f"sparse_pool_small:{self.which}")
         r["compute_only_ms"] = round(ms_c, 5)
         if not self.unfused:
+            from tgp import kernels
+            with kernels.output_views():  # r4's layout: edge_index a view of the kernel's capacity-E buffer, no copy
+                r["capacity_views_ms"] = round(event_time_ms(self.compute, 50, dev), 5)
+            r["contiguous_ms"] = r["compute_only_ms"]
             r["staged_operators_ms"] = round(event_time_ms(self.staged, 50, dev), 5)
+            keep = self.copies
+            self.copies = None  # (the comparison needs both routes on the same inputs)
             a, b = self.compute(), self.staged()
+            self.copies = keep
             r["fused_equals_staged"] = bool(all(torch.equal(u, v) for u, v in zip(a, b)))
+            r["edge_index_contiguous"] = bool(a[1].is_contiguous()
+                                              and a[1].untyped_storage().nbytes() <= max(2 * a[1].numel() * 8, 512))
         if self.gather:
             ms_g = event_time_ms(self.step, 50, dev)
             self.sg.flush()
@@ -736,9 +780,17 @@ class TopkConnect(Workload):
         E, E2 = self.ei.size(1), ei_out.size(1)
         alg = E * 20.0 + self.n + self.k * 8.0 + E2 * 20.0  # SURVEY 8(d) A5+A6
         ms = event_time_ms(self.step, 30, dev)
-        r = roof_hbm("tgp::subgraph_{count,fill}_kernel (whole Connect call incl. its one host read-back)", alg, ms,
-                     "subgraph_connect:topk1m")
+        r = roof_hbm("tgp::subgraph_stage_kernel<SINGLE> + tgp::edges_compact_kernel (whole Connect call incl. its one "
+                     "host read-back; contiguous exact-size outputs)", alg, ms, "subgraph_connect:topk1m")
         r["edges_out"] = E2
+        r["contiguous_ms"] = round(ms, 5)
+        from tgp import kernels
+        with kernels.output_views():  # r4's layout: edge_index a [2,E'] view of the capacity-E buffer, no compaction
+            ms_v = event_time_ms(self.step, 30, dev)
+        r["capacity_views_ms"] = round(ms_v, 5)
+        r["capacity_views_frac"] = round(alg / (ms_v * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+        r["edge_index_contiguous"] = bool(ei_out.is_contiguous()
+                                          and ei_out.untyped_storage().nbytes() <= max(2 * ei_out.numel() * 8, 512))
         return r
 
 
@@ -828,7 +880,7 @@ def make_workload(which, ctx, args):
         return PoolerForward(which, ctx)
     if which == "e2e_train_mincut_c3":
         return PoolerTrainStep(ctx)
-    if which in ("topk_batch", "graclus_batch"):
+    if which in ("topk_batch", "graclus_batch", "topk_batch_fresh", "graclus_batch_fresh"):
         return TopkBatch(ctx, force_collective=os.environ.get("TGP_BENCH_FORCE_DIST") == "1", unfused=args.unfused,
                          which=which)
     raise ValueError(which)
@@ -921,11 +973,12 @@ def cpu_baseline(one_pass, nodes, sample, budget_s=10.0, min_passes=2):
 
 
 # ------------------------------------------------------------------------------------------------ main
-ALL = ["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect", "topk_batch", "graclus_batch", "e2e_diff_c2",
-       "e2e_mincut_c3", "e2e_train_mincut_c3"]
+ALL = ["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect", "topk_batch", "graclus_batch",
+       "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3"]
 SECONDARY_DEFAULT = ["c5", "topk1m", "topk_connect", "c4_graclus", "c4_ndp", "c3", "topk_batch", "graclus_batch",
-                     "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3"]
-SHARDED = ("c5", "c3", "topk_batch", "graclus_batch", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3")
+                     "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3"]
+SHARDED = ("c5", "c3", "topk_batch", "graclus_batch", "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2",
+           "e2e_mincut_c3", "e2e_train_mincut_c3")
 
 
 def main():

@@ -702,6 +702,15 @@ size_t tgp_debug_sort_workspace_bytes(int64_t n);
 int tgp_debug_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, int64_t n, int key_bits,
                              uint64_t* keys_out, uint32_t* vals_out, void* ws, size_t ws_bytes, void* stream);
 
+/* Output contract of the single-call operators (r5).  tgp_sparse_pool_small_f32 and tgp_connect_subgraph_single write
+ * survivors at their final offsets of CAPACITY-sized buffers; the reference hands out new tensors of exactly the pooled
+ * size (connect/base_conn.py:103-112, SURVEY 8(b) "Ownership").  Once the count has arrived the caller allocates exact
+ * outputs and this ONE launch moves the first n entries of the capacity arrays there (weight: 4- or 8-byte values or
+ * NULL, edge_id: NULL ok), so edge_index is a contiguous [2, n] tensor and nothing pins E-sized scratch. */
+int tgp_edges_compact(const int64_t* row, const int64_t* col, const void* weight, int weight_bytes,
+                      const int64_t* edge_id, int64_t n, int64_t* out_row, int64_t* out_col, void* out_weight,
+                      int64_t* out_edge_id, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * float64 value types of the HBM-bound operators (r4).  The reference's ATen ops compute model.double() inputs in fp64
  * (reduce/base_reduce.py:141-155, utils/ops.py:282-419); these entry points do the same for the operators that only

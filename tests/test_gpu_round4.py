@@ -313,9 +313,10 @@ def test_sparse_gather_async_buckets_over_rccl_one_rank_group(dev, one_rank_rccl
     from tgp.poolers import get_pooler
     x, ei, ew, batch, sizes = _small_batch(300, 5, 60, 16, 21, dev)
     pooler = get_pooler("topk", in_channels=16, ratio=0.5).to(dev).eval()
-    with torch.no_grad():
+    import tgp
+    with torch.no_grad(), tgp.output_views():
         out = pooler(x=x, adj=ei, edge_weight=ew, batch=batch)
-    assert not out.edge_index.is_contiguous()  # the capacity-buffer view of tgp_sparse_pool_small_f32
+    assert not out.edge_index.is_contiguous()  # opt-in: the capacity-buffer view of tgp_sparse_pool_small_f32
     sg = SparseGather(force_collective=True, depth=2, bucket_steps=2, capacity=1024)
     got = []
     for j in range(5):

@@ -201,3 +201,140 @@ def test_float64_dense_pooler_forward_vs_fp64_oracle(dev):
         torch.testing.assert_close(out.edge_index.cpu(), ref["edge_index"], rtol=1e-11, atol=1e-12)
         for name, val in ref["loss"].items():
             torch.testing.assert_close(out.loss[name].cpu(), val, rtol=1e-10, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------ output contract (r5)
+def _er_batch(num_graphs, lo, hi, f, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    xs, eis, bs, off = [], [], [], 0
+    for gi in range(num_graphs):
+        n = int(torch.randint(lo, hi + 1, (1,), generator=g))
+        a = torch.triu(torch.rand(n, n, generator=g) < 4.0 / n, 1)
+        a = a | a.t()
+        eis.append(a.nonzero().t() + off)
+        xs.append(torch.randn(n, f, generator=g))
+        bs.append(torch.full((n,), gi))
+        off += n
+    x, ei, batch = torch.cat(xs), torch.cat(eis, 1), torch.cat(bs)
+    ew = torch.rand(ei.size(1), generator=g) + 0.1
+    return x.to(dev), ei.to(dev), ew.to(dev), batch.to(dev)
+
+
+@pytest.mark.parametrize("alias,kw", [("topk", dict(ratio=0.5)), ("graclus", {}), ("ndp", {})])
+@pytest.mark.parametrize("shape", ["small_graphs", "one_large_graph"])
+def test_sparse_poolers_hand_out_contiguous_exact_size_edge_lists(dev, alias, kw, shape):
+    """SURVEY 8(b) "Ownership" / connect/base_conn.py:103-112: every output is a NEW tensor of the pooled size.  r4's
+    one-launch operators returned ``edge_index`` as a [2, E'] view of a capacity-E buffer (torch.equal ignores strides, so
+    parity could not see it): ``.view(-1)`` failed where the reference's tensor works and E * 20 bytes stayed pinned.
+    Default now: contiguous, storage <= 2 x the logical size, on every sparse pooler and both size regimes; the view
+    layout is opt-in (``tgp.output_views``) and gives the same values."""
+    import tgp
+    from tgp.poolers import get_pooler
+    if shape == "small_graphs":
+        x, ei, ew, batch = _er_batch(200, 5, 60, 8, 7, dev)
+    else:
+        x, ei, ew, batch = _er_batch(1, 3000, 3000, 8, 8, dev)
+    torch.manual_seed(3)
+    pooler = get_pooler(alias, in_channels=8, **kw).to(dev).eval()
+    with torch.no_grad():
+        out = pooler(x=x, adj=ei, edge_weight=ew, batch=batch)
+        so = out.so
+        with tgp.output_views():
+            out_v = pooler(x=x, adj=ei, edge_weight=ew, batch=batch, so=so)
+        out2 = pooler(x=x, adj=ei, edge_weight=ew, batch=batch, so=so)
+    for o in (out, out2):
+        e = o.edge_index
+        assert e.is_contiguous() and e.stride() == (e.size(1), 1)
+        flat = e.view(-1)                                  # the reference's tensor allows this
+        assert flat.numel() == 2 * e.size(1)
+        assert e.untyped_storage().nbytes() <= max(2 * e.numel() * 8, 512)
+        if o.edge_weight is not None:
+            assert o.edge_weight.is_contiguous()
+            assert o.edge_weight.untyped_storage().nbytes() <= max(2 * o.edge_weight.numel() * 4, 512)
+        assert o.x.untyped_storage().nbytes() <= max(2 * o.x.numel() * 4, 512)
+    assert torch.equal(out2.edge_index, out_v.edge_index) and torch.equal(out2.x, out_v.x)
+    if out2.edge_weight is not None:
+        assert torch.equal(out2.edge_weight, out_v.edge_weight)
+    assert torch.equal(out2.batch, out_v.batch)
+
+
+def test_edges_compact_entry_point(dev):
+    """tgp_edges_compact through the C ABI: every alignment case (16-, 8-, 4-byte paths), fp32 and fp64 weights."""
+    from tgp import _native as N
+    L, st = N.lib(), N.stream_ptr(dev)
+    g = torch.Generator().manual_seed(1)
+    for cap, n, skew, wdt in [(1000, 777, 0, torch.float32), (1001, 1001, 1, torch.float64), (64, 1, 3, torch.float32),
+                              (5000, 4096, 2, torch.float64)]:
+        buf = torch.randint(0, 1 << 40, (2 * cap + skew,), generator=g).to(dev)
+        row, col = buf[skew: skew + cap], buf[skew + cap: skew + 2 * cap]
+        w = torch.rand(cap + skew, generator=g, dtype=wdt).to(dev)[skew:]
+        eid = torch.arange(cap + skew, device=dev)[skew:]
+        o_ei = torch.empty(2, n, dtype=torch.int64, device=dev)
+        o_w = torch.empty(n, dtype=wdt, device=dev)
+        o_id = torch.empty(n, dtype=torch.int64, device=dev)
+        N.check(L.tgp_edges_compact(row.data_ptr(), col.data_ptr(), w.data_ptr(), w.element_size(), eid.data_ptr(), n,
+                                    o_ei.data_ptr(), o_ei.data_ptr() + 8 * n, o_w.data_ptr(), o_id.data_ptr(), st), "compact")
+        assert torch.equal(o_ei[0], row[:n]) and torch.equal(o_ei[1], col[:n])
+        assert torch.equal(o_w, w[:n]) and torch.equal(o_id, eid[:n])
+
+
+def test_sparse_gather_device_path_keeps_float64_values(dev, monkeypatch):
+    """SparseGather sent x and edge_weight as float32.  Device path, world = 2 simulated (the stand-in
+    collective delivers the local bucket twice): float64 features / weights come back float64 and bit-identical, integer
+    features as integers, and the default results are contiguous exact-size tensors (views=True: views of the bucket)."""
+    import torch.distributed as dist
+    from tgp import distributed as D
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def fake_all_gather(out, inp, group=None, async_op=False):
+        n = inp.numel()
+        out[:n].copy_(inp)
+        out[n: 2 * n].copy_(inp)
+        return _Done()
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_all_gather)
+    g = torch.Generator().manual_seed(4)
+    K, F, E, B = 37, 5, 90, 4
+    x = (torch.randn(K, F, generator=g, dtype=torch.float64) * (1 + 2.0 ** -40)).to(dev)
+    ei = torch.randint(0, K, (2, E), generator=g).to(dev)
+    w = (torch.rand(E, generator=g, dtype=torch.float64) + 2.0 ** -45).to(dev)
+    b = torch.sort(torch.randint(0, B, (K,), generator=g))[0].to(dev)
+    for views in (False, True):
+        sg = D.SparseGather(depth=2, bucket_steps=2, capacity=1024, views=views)
+        sg.world, sg._collective = 2, True
+        got = []
+        for j in range(3):
+            sg.start(x * (j + 1), ei, w, b, B)
+            got.extend(sg.take_ready())
+        got.extend(sg.flush())
+        assert len(got) == 3 and sg.capacity > 1024
+        for j, (gx, gei, gw, gb) in enumerate(got):
+            assert gx.dtype == torch.float64 and gw.dtype == torch.float64
+            assert torch.equal(gx, torch.cat([x * (j + 1)] * 2)) and torch.equal(gw, torch.cat([w, w]))
+            assert torch.equal(gei, torch.cat([ei, ei + K], 1)) and torch.equal(gb, torch.cat([b, b + B]))
+            assert gei.is_contiguous() == (not views)
+            if not views:
+                assert gei.untyped_storage().nbytes() == gei.numel() * 8
+    # integer features (bit copy) and bf16 weights (widened on the wire, narrowed back)
+    sg = D.SparseGather(depth=1)
+    sg.world, sg._collective = 2, True
+    xi = torch.randint(-(1 << 40), 1 << 40, (K, F), generator=g).to(dev)
+    sg.start(xi, ei, w.bfloat16(), None, B)
+    gx, gei, gw, gb = sg.wait()
+    assert gx.dtype == torch.int64 and torch.equal(gx, torch.cat([xi, xi]))
+    assert gw.dtype == torch.bfloat16 and torch.equal(gw, torch.cat([w.bfloat16()] * 2)) and gb is None
+    # ranks that disagree on the layout: rank "1" (the copy) is made to look different by a wrong local expectation
+    sg = D.SparseGather(depth=1)
+    sg.world, sg._collective = 2, True
+    sg.start(x, ei, w, b, B)
+    sg._inflight or sg._launch(partial=True)
+    bucket = sg._inflight[0]
+    import numpy as np
+    torch.cuda.synchronize()
+    slot = bucket["steps"][0][0]
+    assert int(sg._host[slot * 8 + 4]) == 7
+    sg._host[slot * 8 + 4] = 5  # what the unpack launch reports when a rank packed another layout
+    with pytest.raises(RuntimeError, match="different feature widths"):
+        sg.flush()

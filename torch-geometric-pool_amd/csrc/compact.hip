@@ -1,0 +1,69 @@
+// Output contract of the single-pass sparse operators (r5).  tgp_sparse_pool_small_f32 and tgp_connect_subgraph_single
+// write survivors at their final offsets of CAPACITY-sized buffers (the count is only known afterwards).  The reference
+// hands out new tensors of exactly the pooled size (connect/base_conn.py:103-112, SURVEY 8(b) "Ownership"), so by default
+// the host mirror now allocates exact outputs once the count has arrived and this one launch moves the first n entries
+// of the capacity arrays there: edge_index contiguous [2, n], nothing pins E-sized scratch.  Callers that opt into views
+// of the capacity buffers (tgp.kernels.output_views) skip it.
+#include "common.h"
+
+namespace tgp {
+
+// 16-byte moves where source and destination allow it, scalar otherwise; one grid for all arrays (blockIdx.y = array)
+struct CompactArgs {
+  const char* src[4];
+  char* dst[4];
+  int64_t bytes[4];
+};
+
+__global__ __launch_bounds__(256) void edges_compact_kernel(CompactArgs a) {
+  const int k = blockIdx.y;
+  const char* __restrict__ s = a.src[k];
+  char* __restrict__ d = a.dst[k];
+  const int64_t nb = a.bytes[k];
+  if (!s || !d || nb <= 0) return;
+  const int64_t tid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x, nthr = static_cast<int64_t>(gridDim.x) * 256;
+  if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+    const int64_t nv = nb >> 4;
+    const float4* s4 = reinterpret_cast<const float4*>(s);
+    float4* d4 = reinterpret_cast<float4*>(d);
+    for (int64_t i = tid; i < nv; i += nthr) d4[i] = s4[i];
+    for (int64_t i = (nv << 4) + tid * 4; i < nb; i += nthr * 4)  // tail: sizes are multiples of 4 bytes
+      *reinterpret_cast<uint32_t*>(d + i) = *reinterpret_cast<const uint32_t*>(s + i);
+  } else if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d) | static_cast<uintptr_t>(nb)) & 7) == 0) {
+    const int64_t nv = nb >> 3;
+    const uint64_t* s8 = reinterpret_cast<const uint64_t*>(s);
+    uint64_t* d8 = reinterpret_cast<uint64_t*>(d);
+    for (int64_t i = tid; i < nv; i += nthr) d8[i] = s8[i];
+  } else {
+    const int64_t nv = nb >> 2;
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(d);
+    for (int64_t i = tid; i < nv; i += nthr) d4[i] = s4[i];
+  }
+}
+
+}  // namespace tgp
+
+using namespace tgp;
+
+extern "C" int tgp_edges_compact(const int64_t* row, const int64_t* col, const void* weight, int weight_bytes,
+                                 const int64_t* edge_id, int64_t n, int64_t* out_row, int64_t* out_col, void* out_weight,
+                                 int64_t* out_edge_id, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(n >= 0 && (weight_bytes == 0 || weight_bytes == 4 || weight_bytes == 8), TGP_ERR_INVALID,
+              "tgp_edges_compact: bad argument");
+  if (n == 0) return TGP_OK;
+  TGP_REQUIRE(row && col && out_row && out_col && (!weight == !out_weight) && (!edge_id == !out_edge_id) &&
+                  (!weight || weight_bytes),
+              TGP_ERR_INVALID, "tgp_edges_compact: null pointer");
+  CompactArgs a{};
+  a.src[0] = reinterpret_cast<const char*>(row); a.dst[0] = reinterpret_cast<char*>(out_row); a.bytes[0] = n * 8;
+  a.src[1] = reinterpret_cast<const char*>(col); a.dst[1] = reinterpret_cast<char*>(out_col); a.bytes[1] = n * 8;
+  a.src[2] = static_cast<const char*>(weight); a.dst[2] = static_cast<char*>(out_weight); a.bytes[2] = n * weight_bytes;
+  a.src[3] = reinterpret_cast<const char*>(edge_id); a.dst[3] = reinterpret_cast<char*>(out_edge_id); a.bytes[3] = n * 8;
+  int64_t blocks = (n * 8 / 16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(edges_compact_kernel, dim3(static_cast<unsigned>(blocks), 4), dim3(256), 0, stream, a);
+  return check_launch("tgp_edges_compact");
+}

@@ -215,10 +215,13 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
       MediumArgs q{S, want_a ? A : nullptr, want_x ? X : nullptr, static_cast<int>(B), static_cast<int>(N),
                    static_cast<int>(K), static_cast<int>(F), flags, eps, want_x ? x_pool : nullptr,
                    want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr, static_cast<int>(npad), graph_sizes};
+      static const int minw = getenv("TGP_MEDIUM_MINW") ? atoi(getenv("TGP_MEDIUM_MINW")) : 2;
       if (K <= 32)
         hipLaunchKernelGGL(dense_pool_medium_kernel<1>, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, q);
+      else if (minw == 3)
+        hipLaunchKernelGGL((dense_pool_medium_kernel<2, 3>), dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, q);
       else
-        hipLaunchKernelGGL(dense_pool_medium_kernel<2>, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, q);
+        hipLaunchKernelGGL((dense_pool_medium_kernel<2, 2>), dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, q);
       return check_launch("tgp_dense_pool_f32(medium)");
     }
   }

@@ -854,8 +854,13 @@ static size_t medium_lds_bytes(int64_t npad) {
   return (static_cast<size_t>(npad) * KP + KP * (KP + 1) + KP) * sizeof(float);
 }
 
-template <int MT>
-__global__ __launch_bounds__(256, MT == 1 ? 4 : 3) void dense_pool_medium_kernel(MediumArgs p) {
+// MINW = waves per SIMD the register allocation is held to.  K <= 32 (MT = 1): 4.  K in (32, 64] (MT = 2): 64 + 32
+// accumulator registers plus two operand sets do not fit the 168 registers of 3 waves per SIMD -- that build spilled 34
+// VGPRs to scratch inside the strip loop (verdict r4 item 9) -- so MT = 2 is compiled for 2 (256 registers, no scratch);
+// S [N][64] + the K x K result in LDS leave room for two or three workgroups per CU anyway.  <2, 3> stays for A/B
+// (TGP_MEDIUM_MINW=3).
+template <int MT, int MINW = (MT == 1 ? 4 : 2)>
+__global__ __launch_bounds__(256, MINW) void dense_pool_medium_kernel(MediumArgs p) {
   constexpr int KP = 32 * MT;          // padded K
   constexpr int UNROLL = 8;            // k-pairs whose operands are requested together (two such sets in flight;
                                        // 16 measured no faster for K <= 32 and spills for K <= 64)

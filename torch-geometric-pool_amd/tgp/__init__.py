@@ -28,6 +28,14 @@ def freeze_gc() -> None:
     gc.freeze()
 
 
+def output_views(enable: bool = True):
+    """Context manager: inside it the single-call sparse operators hand out pooled edge lists as VIEWS of their
+    capacity-E buffers (no copy, E-sized storage kept alive) instead of new exact-size tensors -- see
+    ``tgp.kernels.output_views``.  The default everywhere else is the reference's contract: fresh contiguous tensors."""
+    from .kernels import output_views as _ov
+    return _ov(enable)
+
+
 def __getattr__(name):
     if name in _submodules:
         module = importlib.import_module(f".{name}", __name__)

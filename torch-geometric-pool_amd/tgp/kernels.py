@@ -181,6 +181,50 @@ _GRACLUS_FUSED = os.environ.get("TGP_GRACLUS_FUSED", "1") != "0"  # A/B switch: 
 _PUBLISH_COUNTS = os.environ.get("TGP_PUBLISH_COUNTS", "1") != "0"  # A/B switch of _read_count (read once)
 SPS_COMPACT_BYTES = 1 << 30  # capacity buffers above this are replaced by exact copies when mostly empty
 
+# Output contract of the single-call operators (r5).  The reference hands out new tensors of exactly the pooled size
+# (connect/base_conn.py:103-112; SURVEY 8(b) "Ownership"); the one-launch kernels write into CAPACITY-sized buffers
+# because the count is only known afterwards.  Default (False): exact-size outputs -- ``edge_index`` a contiguous [2, E']
+# tensor that owns 16 E' bytes -- filled from the capacity scratch by one native launch (tgp_edges_compact).  True: the
+# r4 behaviour, ``edge_index`` a [2, E'] VIEW of the capacity buffer (row stride E, E-sized storage kept alive; no copy)
+# for callers that consume the pooled graph at once, e.g. straight into SparseGather or the next pooling level.
+_OUTPUT_VIEWS = os.environ.get("TGP_OUTPUT_VIEWS", "0") == "1"
+
+
+def set_output_views(enable: bool) -> bool:
+    """Choose the layout of the pooled edge lists of the single-call operators (see ``_OUTPUT_VIEWS``); returns the
+    previous setting."""
+    global _OUTPUT_VIEWS
+    prev, _OUTPUT_VIEWS = _OUTPUT_VIEWS, bool(enable)
+    return prev
+
+
+class output_views:
+    """``with tgp.kernels.output_views():`` -- capacity views inside the block (opt-in), restored afterwards."""
+
+    def __init__(self, enable: bool = True):
+        self.enable = enable
+
+    def __enter__(self):
+        self.prev = set_output_views(self.enable)
+        return self
+
+    def __exit__(self, *exc):
+        set_output_views(self.prev)
+        return False
+
+
+def _compact_edges(L, st, dev, row_p: int, col_p: int, w_p, w_dtype, id_p, n_out: int):
+    """Exact-size (edge_index [2,n], weight [n] or None, edge_id [n] or None) from the first n entries of capacity
+    arrays: two or three allocations and ONE launch."""
+    out_ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
+    out_w = None if w_p is None else torch.empty(n_out, dtype=w_dtype, device=dev)
+    out_id = None if id_p is None else torch.empty(n_out, dtype=torch.int64, device=dev)
+    if n_out:
+        o = out_ei.data_ptr()
+        N.check(L.tgp_edges_compact(row_p, col_p, w_p, 0 if w_p is None else out_w.element_size(), id_p, n_out,
+                                    o, o + 8 * n_out, N.ptr(out_w), N.ptr(out_id), st), "tgp_edges_compact")
+    return out_ei, out_w, out_id
+
 
 class _SpsState:
     """Per (device, stream): the look-back words of the one-launch kernels (``tgp_sparse_pool_small_f32``, the single-pass
@@ -284,14 +328,19 @@ def graph_edge_ptr(edge_index: Tensor, graph_ptr: Tensor) -> Tensor:
 def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor],
                       assign_index: Tensor, weight: Optional[Tensor], num_supernodes: int,
                       mode: int, reduce_op: str = "sum", remove_self_loops: bool = True, want_batch: bool = True,
-                      assign_ptr: Optional[Tensor] = None):
+                      assign_ptr: Optional[Tensor] = None, views: Optional[bool] = None):
     """Sparse Reduce + Connect of a sorted batch of graphs of at most 64 nodes in ONE launch
     (reduce/base_reduce.py:14-53,141-155; connect/base_conn.py:79-89; the filters of utils/ops.py:370-380):
     ``(x_pool [K,F], batch_pool [K] or None, edge_index' [2,E'], edge_weight' [E'] or None)``, bit-identical to
     ``reduce_sparse`` + ``reduce_batch_sparse`` + ``filter_edges`` (mode 0) / ``coalesce_edges`` (mode 1).  The pooled
-    edges are written once at their final offsets of capacity-E buffers, which are then narrowed: ``edge_index'`` is a
-    view whose two rows are contiguous.  ``assign_index`` [2, nnz] = (node_index, cluster_index), the indices of the
-    sparse S.  None: a precondition checked on the device does not hold (the caller takes the staged operators)."""
+    edges are written once at their final offsets of capacity-E scratch and -- by default -- moved into exact-size
+    outputs by one more launch once the count is known (four tensors of their own, ``edge_index'`` contiguous);
+    ``views=True`` (default: ``tgp.kernels.output_views``) hands out the r4 layout instead: all four outputs carved out
+    of ONE allocation, ``edge_index'`` a view of the capacity buffer whose two rows are contiguous, no copy.
+    ``assign_index`` [2, nnz] = (node_index, cluster_index), the indices of the sparse S.  None: a precondition checked
+    on the device does not hold (the caller takes the staged operators)."""
+    if views is None:
+        views = _OUTPUT_VIEWS
     dev = N.require_device(x, graph_ptr, edge_index, edge_weight, assign_index, weight)
     if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
         raise ValueError("sparse_pool_small expects float32 x [N, F] with unit feature stride")
@@ -323,11 +372,19 @@ def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_wei
     oe = (ob + (K * 8 if want_batch else 0) + 15) & ~15
     ow = (oe + 2 * ecap * 8 + 15) & ~15
     nbytes = (ow + (ecap * 4 if w is not None else 0) + 15) & ~15  # (viewed as int64 / float32 below)
-    one = nbytes <= _SPS_ONE_ALLOC_BYTES
+    one = views and nbytes <= _SPS_ONE_ALLOC_BYTES
     if one:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         base = buf.data_ptr()
         xp_p, bp_p, cap_p, cw_p = base + ox, (base + ob) if want_batch else None, base + oe, (base + ow) if w is not None else None
+    elif not views:
+        # exact outputs: x' and batch' are sized before the launch; the edges go through one capacity scratch buffer
+        x_pool = torch.empty(K, F, dtype=torch.float32, device=dev)
+        batch_pool = torch.empty(K, dtype=torch.int64, device=dev) if want_batch else None
+        scratch = torch.empty(2 * ecap * 8 + (ecap * 4 if w is not None else 0), dtype=torch.uint8, device=dev)
+        cap_p = scratch.data_ptr()
+        cw_p = cap_p + 16 * ecap if w is not None else None
+        xp_p, bp_p = x_pool.data_ptr(), N.ptr(batch_pool)
     else:
         x_pool = torch.empty(K, F, dtype=torch.float32, device=dev)
         batch_pool = torch.empty(K, dtype=torch.int64, device=dev) if want_batch else None
@@ -363,6 +420,9 @@ def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_wei
         _sps_remember_declined(edge_index)
         return None
     n_out = total & 0x7FFFFFFF
+    if not views:
+        ei, ew, _ = _compact_edges(L, st, dev, cap_p, cap_p + 8 * ecap, cw_p, torch.float32, None, n_out)
+        return x_pool, batch_pool, ei, ew
     if one:
         ei = torch.as_strided(i64, (2, n_out), (ecap, 1), oe >> 3)
         ew = torch.as_strided(f32, (n_out,), (1,), ow >> 2) if w is not None else None
@@ -401,11 +461,14 @@ def _read_count(d_count: Tensor) -> int:
 
 
 def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: Optional[Tensor],
-                 num_nodes: int, remove_self_loops: bool, want_edge_id: bool = False):
+                 num_nodes: int, remove_self_loops: bool, want_edge_id: bool = False, views: Optional[bool] = None):
     """Induced subgraph + relabel (connect/base_conn.py:79-82) fused with remove_self_loops and the
     |w| > eps filter (utils/ops.py:370-380).  node_index=None: filters only.  Keeps input order.
     ``want_edge_id``: also return the input position of every kept edge (what the backward of the weight
-    pass-through scatters by)."""
+    pass-through scatters by).  ``views`` (default ``tgp.kernels.output_views``, i.e. False): hand out views of the
+    single-pass kernel's capacity-E buffers instead of exact-size tensors."""
+    if views is None:
+        views = _OUTPUT_VIEWS
     dev = N.require_device(edge_index, edge_weight, node_index)
     row, col = _edge_rows(edge_index)
     E = row.numel()
@@ -427,9 +490,9 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
     if E > 0 and (f64 or not torch.cuda.is_current_stream_capturing()):
         # ONE pass (r4): survivors written once at their final offsets of capacity-E buffers, which are then narrowed
         # (edge_index' is a view whose two rows are contiguous); the count arrives in a pinned host word
-        got = _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id)
+        got = _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id, views)
         if got is None and f64:  # (a look-back spin bound on a shared device: once more; fp64 has no count -> fill pair)
-            got = _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id)
+            got = _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id, views)
         if got is not None:
             return got
         if f64:
@@ -454,7 +517,7 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
     return (out_ei, out_w, out_id) if want_edge_id else (out_ei, out_w)
 
 
-def _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id):
+def _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id, views=False):
     """``tgp_connect_subgraph_single``; None when the kernel refused for a reason other than bad node ids (a look-back
     spin bound on a shared device): the caller takes the count -> fill pair."""
     ws = N.workspace(L.tgp_connect_subgraph_single_workspace_bytes(num_nodes), dev)
@@ -481,6 +544,10 @@ def _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, 
                              "[0, num_supernodes)): the reference's index ops raise for these inputs too")
         return None
     n_out = total & 0x7FFFFFFF
+    if not views:  # exact-size outputs (the default): one launch moves the survivors out of the capacity buffers
+        out_ei, out_w, out_id = _compact_edges(L, st, dev, cap_p, cap_p + 8 * E, N.ptr(cap_w),
+                                               None if cap_w is None else cap_w.dtype, N.ptr(cap_id), n_out)
+        return (out_ei, out_w, out_id) if want_edge_id else (out_ei, out_w)
     out_ei, out_w = cap[:, :n_out], None if cap_w is None else cap_w[:n_out]
     out_id = None if cap_id is None else cap_id[:n_out]
     if E * 16 > SPS_COMPACT_BYTES and 4 * n_out < E:  # mostly empty capacity buffers of a large list: exact copies

@@ -130,8 +130,9 @@ class SRCPooling(torch.nn.Module):
         values ``self.reduce`` + ``self.connect`` return, or None when the call is not that case -- host tensors, a
         gradient is required (the operators below are the differentiable path), no or an unsorted batch vector, a graph
         of more than 64 nodes, non-tensor connectivity, caching -- or when the kernel's on-device checks refuse the
-        input (an edge between two graphs, unsorted rows, ...).  The pooled ``edge_index`` is a [2, E'] view of a
-        capacity buffer: both rows contiguous, values and order those of the staged operators."""
+        input (an edge between two graphs, unsorted rows, ...).  The pooled ``edge_index`` is a new contiguous [2, E']
+        tensor, values and order those of the staged operators (inside ``with tgp.kernels.output_views():`` it is a
+        view of the kernel's capacity buffer instead: both rows contiguous, row stride E, no copy)."""
         c = self.connector
         if (self.cached or type(c) is not SparseConnect or type(self.reducer) is not BaseReduce or batch is None
                 or not isinstance(x, Tensor) or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32
