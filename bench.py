@@ -753,14 +753,22 @@ class TopkConnect(Workload):
         g = torch.Generator(device=dev).manual_seed(0)
         n, self.ei = _big_graph(dev, g)
         self.ew = torch.ones(self.ei.size(1), device=dev)
-        keep_nodes = torch.sort(torch.randperm(n, device=dev, generator=g)[: n // 2])[0]
-        k = keep_nodes.numel()
-        self.so = SelectOutput(node_index=keep_nodes, num_nodes=n, cluster_index=torch.arange(k, device=dev),
-                               num_supernodes=k, weight=torch.rand(k, device=dev, generator=g))
+        # r5: the SelectOutput comes from the REAL selector (Select is outside the metric, SURVEY 8(d), and runs once
+        # here): what TopkSelect attaches to it -- since r5 the kept-node bitmap + rank directory of its compaction
+        # pass -- is there exactly as in a pooler's forward.  Random scores keep a random half of the nodes.
+        from tgp.select import TopkSelect
+        torch.manual_seed(0)
+        sel = TopkSelect(in_channels=8, ratio=0.5).to(dev)
+        with torch.no_grad():
+            self.so = sel(x=torch.randn(n, 8, device=dev, generator=g))
+        k = int(self.so.num_supernodes)
         self.conn = SparseConnect()
         self.nodes, self.n, self.k = n, n, k
         self.name = "TopK subgraph Connect (ratio 0.5) on one N=1M E=10M graph: induced subgraph + relabel + filters"
-        self.extra = {"edges": int(self.ei.size(1)), "num_supernodes": k, "nodes_counted": "input nodes per step"}
+        self.extra = {"edges": int(self.ei.size(1)), "num_supernodes": k, "nodes_counted": "input nodes per step",
+                      "select_output": "made by TopkSelect itself (once, outside the timed step): carries the kept-node "
+                                       "bitmap + rank directory its compaction pass writes",
+                      "output_layout": "contiguous exact-size tensors (the default; capacity views are timed beside it)"}
 
     def step(self):
         return self.conn(self.ei, self.so, edge_weight=self.ew)

@@ -142,15 +142,21 @@ int tgp_connect_subgraph_fill(const int64_t* row, const int64_t* col, const floa
  * cleared, one buffer per stream; 0 < epoch < 2^29 different for every call on it).  `*result` (device-accessible, e.g.
  * pinned host memory the caller polls) receives {epoch << 34 | refused << 31 | total} when the last chunk is done;
  * refused = an endpoint outside [0, num_nodes) was met (the count -> fill pair reports -2 for it), or a look-back
- * spin bound was hit (the device is shared: use the pair).  num_edges > 0. */
+ * spin bound was hit (the device is shared: use the pair).  The two are told apart by word [1] of `status`: a chunk that
+ * met a bad endpoint stores `epoch` into its low 32 bits (r5; r4 used a zeroed word of the workspace).  num_edges > 0.
+ * member_bits_in / rank128_in (r5, NULL ok, both or neither): the kept-node bitmap [4 * blocks] and its rank directory
+ * [blocks] (kept nodes with id < 128 b), blocks = tgp_topk_select_directory_blocks(num_nodes), as tgp_topk_select
+ * writes them for the selection whose ASCENDING node_index is passed here.  The call is then ONE launch: no memset, no
+ * scatter of the kept nodes into bitmap + relabel table, no directory scan in every workgroup (r4: 118 us per call at
+ * N = 1M / E = 10M of which the stage kernel was 76).  Needs bitmap + directory to fit LDS (num_nodes <= ~1.2 M);
+ * otherwise they are ignored. */
 size_t tgp_connect_subgraph_single_workspace_bytes(int64_t num_nodes);
 int64_t tgp_connect_subgraph_single_status_words(int64_t num_edges);
-/* byte offset in `ws` of the int32 flag "an endpoint outside [0, num_nodes) was met": tells the two refusals apart */
-int64_t tgp_connect_subgraph_single_bad_ids_offset(int64_t num_nodes);
 int tgp_connect_subgraph_single(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL ok */,
                                 int64_t num_edges, const int64_t* node_index /* NULL = filters only */, int64_t k,
                                 int64_t num_nodes, int flags, float eps, void* ws, size_t ws_bytes, int64_t* out_row,
                                 int64_t* out_col, float* out_weight, int64_t* out_edge_id /* NULL ok */,
+                                const uint32_t* member_bits_in, const uint32_t* rank128_in,
                                 uint64_t* status, int64_t status_words, uint64_t* result, uint32_t epoch, void* stream);
 
 /* ------------------------------------------------------------------------------------
@@ -271,6 +277,10 @@ int tgp_graph_lower_bounds_i64(const int64_t* values, int64_t n, const int64_t* 
 int tgp_sparse_pool_small_f32(const float* x, int64_t num_nodes, int64_t num_features, int64_t x_row_stride,
                               const int64_t* graph_ptr /* [B+1] */, int64_t num_graphs,
                               const int64_t* edge_ptr /* NULL ok */, const int64_t* assign_ptr /* NULL ok */,
+                              int64_t* edge_ptr_out /* NULL ok; [B+1]: r5 -- a call WITHOUT edge_ptr leaves the edge
+                                                       ranges it searched for here (valid when the call is not refused):
+                                                       a new edge list costs no tgp_graph_lower_bounds_i64 launch, the
+                                                       same list pooled again gets them back as edge_ptr */,
                               const int64_t* row,
                               const int64_t* col, const float* edge_weight /* NULL ok */, int64_t num_edges,
                               const int64_t* node_index, const int64_t* cluster_index,
@@ -401,7 +411,15 @@ int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t
                                              transposed index Reduce's backward and Lift walk; its perm is the identity) */,
                     uint64_t* assign_pack /* optional [k_total]: the packed one-to-one index of
                                              tgp_reduce_one_to_one_f32, {node id, score} of supernode c */,
+                    uint32_t* member_bits /* optional, with rank128 and directory_written (r5): by-products for the
+                                             subgraph Connect of the SAME selection -- the kept-node bitmap
+                                             [4 * tgp_topk_select_directory_blocks(N)] and */,
+                    uint32_t* rank128 /* the rank directory [..._directory_blocks(N)]: kept nodes with id < 128 b; hand
+                                         both to tgp_connect_subgraph_single (member_bits_in / rank128_in) */,
+                    int* directory_written /* HOST int: 1 when this call wrote them (the device-wide route, i.e. large
+                                              graphs; the per-graph sort routes of small-graph batches do not) */,
                     void* stream);
+int64_t tgp_topk_select_directory_blocks(int64_t N);
 
 /* ----------------------------------------------------------------------------------
  * A14  GraclusSelect's matching (select/graclus_select.py:62-81 -> torch_cluster 1.6.3 graclus_cluster, absent
@@ -573,6 +591,15 @@ int tgp_from_dense_batch_f32(const float* dense, int64_t N, int64_t F, const int
  * longest graph, number of non-empty graphs, sum over graphs of TopkSelect's k_g for topk_ratio (tgp_topk_plan's
  * arithmetic; 0 when topk_ratio <= 0)}. */
 int tgp_batch_facts_i64(const int64_t* batch, int64_t N, int64_t* sizes, int64_t* facts, double topk_ratio, void* stream);
+/* r5: the same facts for a SORTED vector in ONE launch, no memset, no copy back: ptr [N + 2] (CSR offsets: graph g owns
+ * nodes ptr[g] .. ptr[g + 1]), sizes [N + 1], and for topk_ratio > 0 TopkSelect's plan k [N + 1] / koff [N + 2] (NULL:
+ * not wanted).  `ticket`: two uint32 words owned by the caller per (device, stream), zero at entry, left zero.  `result`:
+ * six words of pinned host memory -- {tag, B - 1, flags, longest graph, non-empty graphs, sum_g k_g}, word 0 stored last
+ * (the caller polls it).  flags != 0 (1: not sorted, 2: an id outside [0, N], 4: more than 64 consecutive ids without a
+ * node): nothing else is meaningful, take tgp_batch_facts_i64. */
+int tgp_batch_facts_sorted_i64(const int64_t* batch, int64_t N, int64_t* ptr, int64_t* sizes, double topk_ratio,
+                               int64_t* k, int64_t* koff, uint32_t* ticket, uint64_t* result, uint64_t tag,
+                               void* stream);
 /* to_dense_batch for a SORTED batch vector (graph b = nodes ptr[b] .. ptr[b+1]): output-parallel, padding and mask
  * written by the same kernel (no memsets in front).  zero_buf / zero_count (optional): a second float buffer to zero-fill
  * in the same launch (the adjacency tgp_to_dense_adj_f32 scatters into next). */
@@ -727,8 +754,9 @@ int tgp_connect_subgraph_single_f64(const int64_t* row, const int64_t* col, cons
                                     int64_t num_edges, const int64_t* node_index, int64_t k, int64_t num_nodes, int flags,
                                     double eps, void* ws /* tgp_connect_subgraph_single_workspace_bytes */,
                                     size_t ws_bytes, int64_t* out_row, int64_t* out_col, double* out_weight,
-                                    int64_t* out_edge_id, uint64_t* status, int64_t status_words, uint64_t* result,
-                                    uint32_t epoch, void* stream);
+                                    int64_t* out_edge_id, const uint32_t* member_bits_in, const uint32_t* rank128_in,
+                                    uint64_t* status, int64_t status_words, uint64_t* result, uint32_t epoch,
+                                    void* stream);
 size_t tgp_connect_coalesce_workspace_bytes_f64(int64_t num_edges, int64_t num_nodes, int64_t num_supernodes);
 int tgp_connect_coalesce_count_f64(const int64_t* row, const int64_t* col, const double* edge_weight /* NULL ok */,
                                    int64_t num_edges, const int64_t* cluster_index, int64_t num_nodes,

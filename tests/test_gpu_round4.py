@@ -714,10 +714,11 @@ def test_ndp_select_with_an_unsorted_batch_vector_stays_on_device(dev, monkeypat
 
 
 @pytest.mark.parametrize("alias", ["topk", "graclus"])
-def test_one_launch_pooling_rechecks_the_offsets_it_is_handed(dev, alias, monkeypatch):
-    """The per-graph edge offsets the caller hands to the one-launch kernels (tgp.kernels.graph_edge_ptr: memoised lower
-    bounds of graph_ptr in the row array) are NOT trusted: a table that is off by one edge somewhere makes an edge fall
-    outside its graph's node range -> refusal -> the staged operators give the same result as with a correct table."""
+def test_one_launch_pooling_rechecks_the_offsets_it_is_handed(dev, alias):
+    """The per-graph edge offsets the one-launch kernels are handed (r5: left behind by the first call on an edge list --
+    `edge_ptr_out` -- and remembered per edge-list object; r4: a lower-bounds launch) are NOT trusted: a table that is off
+    by one edge somewhere makes an edge fall outside its graph's node range -> refusal -> the staged operators give the
+    same result as with a correct table."""
     from tgp import kernels
     from tgp.poolers import get_pooler
     if not kernels._SPS_GIVE_PTRS:
@@ -727,14 +728,16 @@ def test_one_launch_pooling_rechecks_the_offsets_it_is_handed(dev, alias, monkey
     pooler = get_pooler(alias, **kw).to(dev).eval()
     with torch.no_grad():
         good = pooler(x=x, adj=ei, edge_weight=ew, batch=batch)
-    real = kernels.graph_edge_ptr
-
-    def off_by_one(edge_index, graph_ptr):
-        t = real(edge_index, graph_ptr).clone()
-        t[t.numel() // 2] += 1          # still ascending, still 0 .. E: one edge now sits in the wrong graph's range
-        return t
-    monkeypatch.setattr(kernels, "graph_edge_ptr", off_by_one)
-    ei2 = ei.clone()                     # (a new object: no "declined before" memo, no cached selection)
+        ei2 = ei.clone()                 # (a new object: no "declined before" memo, no cached selection)
+        first = pooler(x=x, adj=ei2, edge_weight=ew, batch=batch)   # searches for its ranges, leaves them in the memo
+    assert not kernels.sparse_pool_small_declined(ei2)
+    assert torch.equal(first.edge_index, good.edge_index) and torch.equal(first.x, good.x)
+    hit = kernels._EDGE_PTR.get(id(ei2))
+    assert hit is not None and hit[0]() is ei2, "the first call must have remembered the ranges it searched for"
+    table = hit[4]
+    gp = hit[3]()                        # the batch vector's CSR offsets the table belongs to
+    assert torch.equal(table, torch.searchsorted(ei2[0].contiguous(), gp))  # = lower bounds of graph_ptr in the row array
+    table[table.numel() // 2] += 1       # still ascending, still 0 .. E: one edge now sits in the wrong graph's range
     with torch.no_grad():
         bad = pooler(x=x, adj=ei2, edge_weight=ew, batch=batch)
     assert kernels.sparse_pool_small_declined(ei2)

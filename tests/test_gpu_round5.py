@@ -338,3 +338,125 @@ def test_sparse_gather_device_path_keeps_float64_values(dev, monkeypatch):
     sg._host[slot * 8 + 4] = 5  # what the unpack launch reports when a rank packed another layout
     with pytest.raises(RuntimeError, match="different feature widths"):
         sg.flush()
+
+
+# ------------------------------------------------------------------------------------ fresh batches (r5)
+def test_one_launch_batch_facts_equal_the_general_route(dev, monkeypatch):
+    """tgp_batch_facts_sorted_i64 (one launch, pinned-word hand-over) against the two-kernel route and plain torch:
+    CSR offsets, sizes, graph count, longest graph, non-empty graphs, TopkSelect's plan -- sorted vectors with empty graph
+    ids, one graph, one node per graph; an unsorted vector / ids out of range / a long run of empty ids fall back."""
+    import tgp.utils.ops as ops
+    import tgp_oracle as O
+    g = torch.Generator().manual_seed(2)
+    cases = {
+        "proteins": torch.repeat_interleave(torch.arange(2048), torch.randint(20, 61, (2048,), generator=g)),
+        "with_empty_ids": torch.repeat_interleave(torch.tensor([0, 1, 4, 5, 9]), torch.tensor([3, 1, 70, 2, 300])),
+        "one_graph": torch.zeros(5000, dtype=torch.long),
+        "starts_late": torch.full((77,), 3),
+        "node_per_graph": torch.arange(3000),
+        "single_node": torch.zeros(1, dtype=torch.long),
+    }
+    for name, b in cases.items():
+        bd = b.to(dev)
+        ops._BATCH_INFO.clear()
+        monkeypatch.setattr(ops, "_BATCH_FACTS_ONE_LAUNCH", True)
+        a = ops.batch_info(bd, topk_ratio=0.5)
+        assert a.is_sorted and a.memo.get(("topk", 0.5)) is not None, name
+        ops._BATCH_INFO.clear()
+        monkeypatch.setattr(ops, "_BATCH_FACTS_ONE_LAUNCH", False)
+        r = ops.batch_info(bd, topk_ratio=0.5)
+        sizes = torch.bincount(b)
+        assert a.num_graphs == r.num_graphs == sizes.numel(), name
+        assert torch.equal(a.sizes.cpu(), sizes) and torch.equal(r.sizes.cpu(), sizes), name
+        ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+        assert torch.equal(a.ptr.cpu(), ptr) and torch.equal(r.ptr.cpu(), ptr), name
+        assert a.max_nodes == r.max_nodes == int(sizes.max()) and a.distinct == r.distinct == int((sizes > 0).sum()), name
+        total, k, koff = a.memo[("topk", 0.5)]
+        want_k = torch.ceil(torch.tensor(0.5, dtype=torch.float32) * sizes.float()).long()
+        assert torch.equal(k.cpu(), want_k) and total == int(want_k.sum()), name
+        assert torch.equal(koff.cpu(), torch.cat([torch.zeros(1, dtype=torch.long), want_k.cumsum(0)])), name
+    monkeypatch.setattr(ops, "_BATCH_FACTS_ONE_LAUNCH", True)
+    for name, b in {"unsorted": torch.tensor([0, 0, 2, 1, 2]), "long_gap": torch.tensor([0] * 10 + [500] * 10)}.items():
+        ops._BATCH_INFO.clear()
+        info = ops.batch_info(b.to(dev))
+        sizes = torch.bincount(b)
+        assert torch.equal(info.sizes.cpu(), sizes), name      # the general route took it
+        assert info.is_sorted == (name != "unsorted")
+    # back-to-back calls on one stream: the ticket / flag words are left clean by every call, also by a refused one
+    ops._BATCH_INFO.clear()
+    for _ in range(3):
+        for b in (cases["proteins"], torch.tensor([3, 2, 1]), cases["with_empty_ids"]):
+            ops._BATCH_INFO.clear()
+            info = ops.batch_info(b.to(dev))
+            assert torch.equal(info.sizes.cpu(), torch.bincount(b))
+
+
+def test_new_edge_lists_need_no_lower_bounds_launch(dev):
+    """r5: the one-launch sparse pooling searches for the per-graph edge ranges of an edge list it has not seen and
+    leaves them for the next call (edge_ptr_out): results of the first (searching) and the second (handed-over) call are
+    identical, and equal to the staged operators'."""
+    import tgp
+    from tgp import kernels
+    from tgp.poolers import get_pooler
+    x, ei, ew, batch = _er_batch(300, 3, 64, 12, 5, dev)
+    for alias, kw in (("topk", dict(in_channels=12, ratio=0.5)), ("graclus", {})):
+        torch.manual_seed(0)
+        pooler = get_pooler(alias, **kw).to(dev).eval()
+        e1 = ei.clone()
+        with torch.no_grad():
+            first = pooler(x=x, adj=e1, edge_weight=ew, batch=batch)
+            assert kernels._edge_ptr_memo(e1, kernels._EDGE_PTR[id(e1)][3]()) is not None
+            second = pooler(x=x, adj=e1, edge_weight=ew, batch=batch, so=first.so)
+            staged_x, staged_b = pooler.reducer(x, first.so, batch=batch)
+            staged_e, staged_w = pooler.connector(e1, first.so, edge_weight=ew, batch_pooled=staged_b)
+        for o in (first, second):
+            assert torch.equal(o.edge_index, staged_e) and torch.equal(o.edge_weight, staged_w)
+            assert torch.equal(o.x, staged_x) and torch.equal(o.batch, staged_b)
+
+
+def test_topk_select_directory_and_one_launch_subgraph_connect(dev):
+    """r5: TopkSelect on a large graph leaves the kept-node bitmap + rank directory of its compaction pass on the
+    SelectOutput; SparseConnect hands them to tgp_connect_subgraph_single, which then needs no memset / scatter /
+    directory scan.  The directory is checked against node_index, the Connect against the route without it (bit for
+    bit), against the oracle, and a bad endpoint still raises (now through the epoch-tagged status word)."""
+    import tgp_oracle as O
+    from tgp import kernels
+    from tgp.connect import SparseConnect
+    from tgp.select import TopkSelect
+    g = torch.Generator().manual_seed(11)
+    for n in (10_000, 131_072, 300_001):
+        e = 6 * n
+        a, b = torch.randint(0, n, (e,), generator=g), torch.randint(0, n, (e,), generator=g)
+        ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
+        ew = torch.rand(ei.size(1), generator=g)
+        ew[::17] = 0.0                                       # the |w| > eps filter has work
+        x = torch.randn(n, 4, generator=g)
+        torch.manual_seed(1)
+        sel = TopkSelect(in_channels=4, ratio=0.37).to(dev)
+        with torch.no_grad():
+            so = sel(x=x.to(dev))
+        md = so._assign_index.member_directory
+        assert md is not None, "the device-wide route of tgp_topk_select writes the directory"
+        nblk = md.numel() // 5
+        bits = md[: 4 * nblk].cpu().view(torch.int32)
+        member = torch.zeros(4 * nblk * 32, dtype=torch.bool)
+        member[so.node_index.cpu()] = True
+        want_bits = (member.view(-1, 32).long() << torch.arange(32)).sum(1)
+        assert torch.equal(bits.long() & 0xFFFFFFFF, want_bits)
+        rank = torch.cat([torch.zeros(1, dtype=torch.long), member.view(-1, 128).sum(1).cumsum(0)[:-1]])
+        assert torch.equal(md[4 * nblk:].cpu().long(), rank)
+        conn = SparseConnect()
+        ei_d, ew_d = ei.to(dev), ew.to(dev)
+        with kernels.output_views():
+            pe, pw = conn(ei_d, so, edge_weight=ew_d)        # with the directory: ONE launch
+        pe2, pw2 = kernels.filter_edges(ei_d, ew_d, so.node_index, n, True)   # without it
+        assert torch.equal(pe, pe2) and torch.equal(pw, pw2)
+        if n <= 131_072:
+            r_ei, r_ew = O.sparse_connect(ei, ew, so.node_index.cpu(), None, n, int(so.num_supernodes))
+            assert torch.equal(pe.cpu(), r_ei) and torch.equal(pw.cpu(), r_ew)
+    bad = ei_d.clone()
+    bad[1, 12345] = n + 7
+    with pytest.raises(IndexError, match="outside"):
+        conn(bad, so, edge_weight=ew_d)
+    pe3, pw3 = conn(ei_d, so, edge_weight=ew_d)              # the buffers of the refused call left nothing behind
+    assert torch.equal(pe3, pe2) and torch.equal(pw3, pw2)

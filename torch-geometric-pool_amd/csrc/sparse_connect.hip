@@ -69,12 +69,14 @@ struct SubgraphPredT {
   WT eps;                       // the caller's eps at call time (reference ops.py:377 reads the module global)
   int64_t n;                    // number of nodes: endpoints outside [0, n) set *bad_ids (the reference's index ops raise)
   int* bad_ids;
+  int bad_value;                // what is stored there: 1 into a zeroed word (count -> fill pair), or the call's epoch
+                                // into the low half of word [1] of the caller's never-cleared status buffer (single pass)
   // keep / drop only; r, c are the ORIGINAL endpoints (relabelling is injective, so r == c decides self loops)
   __device__ __forceinline__ bool operator()(int64_t e, int64_t& r, int64_t& c) const {
     r = row[e];
     c = col[e];
     if (static_cast<uint64_t>(r) >= static_cast<uint64_t>(n) || static_cast<uint64_t>(c) >= static_cast<uint64_t>(n)) {
-      *bad_ids = 1;
+      *bad_ids = bad_value;
       return false;
     }
     if (relabel) {
@@ -164,7 +166,7 @@ __device__ __forceinline__ bool sg_eval(const SubgraphPredT<WT>& pred, const uin
   for (int j = 0; j < SG_PER; ++j) {  // endpoints outside [0, n): flagged, never used as an index
     if (t.keep[j] && (static_cast<uint64_t>(t.r[j]) >= static_cast<uint64_t>(pred.n) ||
                       static_cast<uint64_t>(t.c[j]) >= static_cast<uint64_t>(pred.n))) {
-      *pred.bad_ids = 1;
+      *pred.bad_ids = pred.bad_value;
       met_bad = true;
       t.keep[j] = false;
       t.r[j] = 0;
@@ -245,10 +247,17 @@ struct SgSingleT {
   unsigned long long* status;
   unsigned long long* result;
   unsigned long long tag;
+  // r5: the rank directory rank128 (members with id < 128 b) when the selector made it together with the bitmap
+  // (TopkSelect's compaction pass writes both as by-products): the workgroups copy it instead of scanning for it,
+  // and the call needs neither the memset nor the scatter kernel in front of this one
+  const uint32_t* rank128;
 };
 using SgSingle = SgSingleT<float>;
 
-template <int LDSB, bool SINGLE, typename WT = float>
+// PRE (r5, with LDSB == 2 and SINGLE): bitmap AND rank directory come from the selector (sg.rank128): no scan, and the
+// relabel table / sortedness flag are never read -- a compile-time switch, the kernel sits at the 128-register limit of
+// a 1024-thread workgroup and a run-time branch here cost two spilled registers and 10 us
+template <int LDSB, bool SINGLE, typename WT = float, bool PRE = false>
 __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPredT<WT> pred, int64_t E, int nchunks,
                                                                     int nwords, SgStageT<WT> st,
                                                                     uint32_t* __restrict__ block_counts,
@@ -262,6 +271,10 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred
   if constexpr (LDSB >= 1) {
     lds_copy_words<SG_THREADS>(s_dyn, pred.member_bits, nwords);
     if constexpr (LDSB == 2) {
+      if constexpr (PRE) {  // the selector handed the directory over with the bitmap
+        by_rank = true;
+        lds_copy_words<SG_THREADS>(s_rank, sg.rank128, (nwords + 3) / 4);
+      } else {
       // rank directory rank128[b] = members with id < 128 b, computed here from the LDS copy of the bitmap by every
       // workgroup for itself, in parallel on every CU, instead of a 10 us single-workgroup kernel in front of this one
       by_rank = *pred.unsorted == 0;
@@ -283,12 +296,13 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred
         if (bb < nblocks) s_rank[bb] = carry + off;
         carry += total;
       }
+      }
     }
     __syncthreads();
   }
   auto new_id = [&](int64_t v) -> int32_t {
     if constexpr (LDSB == 2) {
-      if (by_rank) {  // rank of the 128-node block + the set bits below v inside it: one 16-byte LDS read, no loop
+      if (PRE || by_rank) {  // rank of the 128-node block + the set bits below v inside it: one 16-byte LDS read, no loop
         const int word = static_cast<int>(v >> 5), sub = word & 3;
         const uint4 b = *reinterpret_cast<const uint4*>(s_dyn + (word & ~3));
         const uint32_t below = (1u << (v & 31)) - 1u;
@@ -300,7 +314,8 @@ __global__ __launch_bounds__(SG_THREADS) void subgraph_stage_kernel(SubgraphPred
                                     __popc(b.w & m3));
       }
     }
-    return pred.relabel[v];
+    if constexpr (PRE) return 0;  // (unreachable)
+    else return pred.relabel[v];
   };
   // the (row, col) stream of the next chunk is requested before this chunk's dependent work starts
   SgEdges nxt;
@@ -969,7 +984,7 @@ extern "C" int tgp_connect_subgraph_count(const int64_t* row, const int64_t* col
   }
   const int nb = cdiv(E > 0 ? E : 1, SG_CHUNK);
   SubgraphPred pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.unsorted, flags, eps,
-                    N, s.unsorted + 1};
+                    N, s.unsorted + 1, 1};
   SgStage st = s.st;
   if (!w) st.w = nullptr;
   if (!(flags & TGP_WANT_EDGE_ID)) st.off = nullptr;  // input positions are only staged for callers that will ask for them
@@ -1028,19 +1043,11 @@ extern "C" size_t tgp_connect_subgraph_single_workspace_bytes(int64_t N) {
 
 extern "C" int64_t tgp_connect_subgraph_single_status_words(int64_t E) { return 2 + cdiv(E > 0 ? E : 1, SG_CHUNK); }
 
-// byte offset, inside the workspace, of the int32 flag "an endpoint outside [0, N) was met" (what a refusal means
-// unless a spin bound was hit: the caller reads it only after a refused call)
-extern "C" int64_t tgp_connect_subgraph_single_bad_ids_offset(int64_t N) {
-  SubgraphWs s;
-  char base[1];
-  subgraph_single_layout(base, N, &s);
-  return reinterpret_cast<char*>(s.unsorted + 1) - base;
-}
-
 template <typename WT>
 static int subgraph_single_impl(const int64_t* row, const int64_t* col, const WT* w, int64_t E,
                                 const int64_t* node_index, int64_t k, int64_t N, int flags, WT eps, void* ws,
                                 size_t ws_bytes, int64_t* out_row, int64_t* out_col, WT* out_w, int64_t* out_edge_id,
+                                const uint32_t* member_bits_in, const uint32_t* rank128_in,
                                 uint64_t* status, int64_t status_words, uint64_t* result, uint32_t epoch,
                                 void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -1057,9 +1064,15 @@ static int subgraph_single_impl(const int64_t* row, const int64_t* col, const WT
   SubgraphWs s;
   subgraph_single_layout(ws, N, &s);
   const int nwords = static_cast<int>((N > 0 ? N : 1) / 32 + 1);
-  // the membership bitmap and the four status words ([0] node_index not ascending, [1] bad node ids) sit next to each
+  const int nblocks_dir = (nwords + 3) / 4;
+  // r5: the selector's own bitmap + rank directory (TopkSelect writes them in its compaction pass): nothing to clear,
+  // nothing to scatter, the stage kernel is the whole call
+  const bool pre = node_index && member_bits_in && rank128_in && 5 * nblocks_dir <= SG_LDS_WORDS_MAX + 1984;
+  // the membership bitmap and the four status words ([0] node_index not ascending, [1] unused since r5) sit next to each
   // other in the workspace: ONE memset (a memset is a launch of its own: ~4 us of this 120 us call each)
-  if (node_index) {
+  if (pre) {
+    // (no launch in front of the stage kernel)
+  } else if (node_index) {
     (void)hipMemsetAsync(s.member_bits, 0,
                          static_cast<size_t>(reinterpret_cast<char*>(s.unsorted + 4) - reinterpret_cast<char*>(s.member_bits)),
                          stream);
@@ -1073,16 +1086,25 @@ static int subgraph_single_impl(const int64_t* row, const int64_t* col, const WT
 #ifdef TGP_GEMM_STAMPS
   if (getenv("TGP_SG_ABLATE")) flags |= (1 << 30);
 #endif
-  SubgraphPredT<WT> pred{row, col, w, node_index ? s.relabel : nullptr, s.member_bits, s.unsorted, flags, eps,
-                         N, s.unsorted + 1};
+  // a thread that meets an endpoint outside [0, N) stores the call's epoch into the low half of word [1] of the caller's
+  // status buffer (never cleared: a word of an earlier call holds another epoch); after a refused call the host tells
+  // bad ids (the reference's index ops raise) from a look-back spin bound by that word, read with a copy on this stream
+  SubgraphPredT<WT> pred{row, col, w, node_index ? s.relabel : nullptr, pre ? member_bits_in : s.member_bits, s.unsorted,
+                         flags, eps, N, reinterpret_cast<int*>(status + 1), static_cast<int>(epoch)};
   SgSingleT<WT> sg{out_row, out_col, w ? out_w : nullptr, out_edge_id, reinterpret_cast<unsigned long long*>(status),
-              reinterpret_cast<unsigned long long*>(result), static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT};
+              reinterpret_cast<unsigned long long*>(result), static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT,
+              pre ? rank128_in : nullptr};
   // persistent, every workgroup resident (the look-back waits for chunks of the same round): one per CU
   int cus = tgp_device_cu_count();
   if (cus <= 0) cus = 256;
   const int grid = nb < cus ? nb : cus;
   const int nblocks = (nwords + 3) / 4;
-  if (node_index && 5 * nblocks <= SG_LDS_WORDS_MAX + 1984) {
+  if (pre) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<2, true, WT, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (SG_LDS_WORDS_MAX + 1984 + 4) * 4);
+    hipLaunchKernelGGL((subgraph_stage_kernel<2, true, WT, true>), dim3(grid), dim3(SG_THREADS),
+                       (5 * nblocks + 4) * sizeof(uint32_t), stream, pred, E, nb, nwords, SgStageT<WT>{}, nullptr, sg);
+  } else if (node_index && 5 * nblocks <= SG_LDS_WORDS_MAX + 1984) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(subgraph_stage_kernel<2, true, WT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (SG_LDS_WORDS_MAX + 1984 + 4) * 4);
     hipLaunchKernelGGL((subgraph_stage_kernel<2, true, WT>), dim3(grid), dim3(SG_THREADS),
@@ -1102,10 +1124,12 @@ static int subgraph_single_impl(const int64_t* row, const int64_t* col, const WT
 extern "C" int tgp_connect_subgraph_single(const int64_t* row, const int64_t* col, const float* w, int64_t E,
                                            const int64_t* node_index, int64_t k, int64_t N, int flags, float eps,
                                            void* ws, size_t ws_bytes, int64_t* out_row, int64_t* out_col, float* out_w,
-                                           int64_t* out_edge_id, uint64_t* status, int64_t status_words,
+                                           int64_t* out_edge_id, const uint32_t* member_bits_in,
+                                           const uint32_t* rank128_in, uint64_t* status, int64_t status_words,
                                            uint64_t* result, uint32_t epoch, void* stream_) {
   return subgraph_single_impl<float>(row, col, w, E, node_index, k, N, flags, eps, ws, ws_bytes, out_row, out_col, out_w,
-                                     out_edge_id, status, status_words, result, epoch, stream_);
+                                     out_edge_id, member_bits_in, rank128_in, status, status_words, result, epoch,
+                                     stream_);
 }
 
 // float64 weights (model.double(): the reference's ATen ops keep them in fp64): they pass through and meet the
@@ -1113,10 +1137,12 @@ extern "C" int tgp_connect_subgraph_single(const int64_t* row, const int64_t* co
 extern "C" int tgp_connect_subgraph_single_f64(const int64_t* row, const int64_t* col, const double* w, int64_t E,
                                                const int64_t* node_index, int64_t k, int64_t N, int flags, double eps,
                                                void* ws, size_t ws_bytes, int64_t* out_row, int64_t* out_col,
-                                               double* out_w, int64_t* out_edge_id, uint64_t* status,
+                                               double* out_w, int64_t* out_edge_id, const uint32_t* member_bits_in,
+                                               const uint32_t* rank128_in, uint64_t* status,
                                                int64_t status_words, uint64_t* result, uint32_t epoch, void* stream_) {
   return subgraph_single_impl<double>(row, col, w, E, node_index, k, N, flags, eps, ws, ws_bytes, out_row, out_col,
-                                      out_w, out_edge_id, status, status_words, result, epoch, stream_);
+                                      out_w, out_edge_id, member_bits_in, rank128_in, status, status_words, result,
+                                      epoch, stream_);
 }
 
 // ------------------------------------------------------------------------------------- coalesce

@@ -60,6 +60,8 @@ struct SpsArgs {
   float* out_w;
   const int64_t* edge_ptr;     // NULL, or [B + 1]: first edge of every graph (lower bounds of gptr in `row`)
   const int64_t* assign_ptr;   // NULL, or [B + 1] (MODE 0): first assignment of every graph
+  int64_t* edge_ptr_out;       // NULL, or [B + 1]: r5 -- a call that searched for its edge ranges leaves them here, so
+                               // that the caller can hand them back (edge_ptr) when the same list is pooled again
   unsigned long long* status;  // [2 + tile] look-back state, epoch-tagged ([0], [1] reserved)
   unsigned long long* result;  // ONE word {epoch, refused (bit 31), total}; may live in pinned host memory
   unsigned long long tag;      // epoch << SPS_EPOCH_SHIFT
@@ -190,7 +192,10 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
     }
   }
   if (bad) e0 = e1 = a0 = a1 = 0;
-  (void)live;
+  if (!given && p.edge_ptr_out && live && !bad && lane == 0) {  // (a refused call's table is never used by the caller)
+    p.edge_ptr_out[g] = e0;
+    if (g == p.B - 1) p.edge_ptr_out[p.B] = e1;
+  }
   const bool has_w = p.w != nullptr;
   const bool rsl = (p.flags & TGP_REMOVE_SELF_LOOPS) != 0, epsf = has_w && (p.flags & TGP_EPS_FILTER) != 0;
   const bool vec = (p.F & 3) == 0 && (p.x_stride & 3) == 0;
@@ -627,6 +632,7 @@ extern "C" int tgp_graph_lower_bounds_i64(const int64_t* values, int64_t n, cons
 
 extern "C" int tgp_sparse_pool_small_f32(const float* x, int64_t N, int64_t F, int64_t x_stride, const int64_t* graph_ptr,
                                          int64_t B, const int64_t* edge_ptr, const int64_t* assign_ptr,
+                                         int64_t* edge_ptr_out,
                                          const int64_t* row, const int64_t* col, const float* w, int64_t E,
                                          const int64_t* node_index, const int64_t* cluster_index, const float* weight,
                                          int64_t nnz, int64_t K, int mode, int reduce_op, int flags, float eps,
@@ -645,7 +651,7 @@ extern "C" int tgp_sparse_pool_small_f32(const float* x, int64_t N, int64_t F, i
   TGP_REQUIRE(status_words >= tgp_sparse_pool_small_status_words(B, mode), TGP_ERR_WORKSPACE,
               "tgp_sparse_pool_small_f32: status buffer too small");
   SpsArgs a{x, N, F, x_stride, graph_ptr, B, row, col, w, E, node_index, cluster_index, weight, nnz, K, reduce_op, flags,
-            eps, x_pool, batch_pool, out_row, out_col, out_w, edge_ptr, assign_ptr,
+            eps, x_pool, batch_pool, out_row, out_col, out_w, edge_ptr, assign_ptr, edge_ptr_out,
             reinterpret_cast<unsigned long long*>(status),
             reinterpret_cast<unsigned long long*>(result), static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT};
   if (mode == 0) {

@@ -262,7 +262,9 @@ __global__ __launch_bounds__(256) void topk_fill_kernel(const int32_t* __restric
                                                         const float* __restrict__ score,
                                                         float* __restrict__ values,
                                                         int32_t* __restrict__ lift_ptr,
-                                                        uint2* __restrict__ assign_pack) {
+                                                        uint2* __restrict__ assign_pack,
+                                                        uint32_t* __restrict__ member_bits,
+                                                        uint32_t* __restrict__ rank128, int64_t dir_blocks) {
   __shared__ uint32_t s_cnt[kTopkItems * 4];
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kTopkTile;
   bool flag[kTopkItems];
@@ -277,6 +279,32 @@ __global__ __launch_bounds__(256) void topk_fill_kernel(const int32_t* __restric
   uint32_t total;
   block_compact_ranks<kTopkItems>(flag, rank, total, s_cnt);
   const uint32_t off = offsets[blockIdx.x];
+  if (member_bits) {
+    // r5, by-products for the subgraph Connect (connect/base_conn.py:79-82): the kept-node BITMAP (a wave's ballot is
+    // the two words of its 64 consecutive nodes: every word is written whole, no memset, no atomics) and the rank
+    // directory rank128[b] = kept nodes with id < 128 b (the exclusive rank this pass has just computed).  With them
+    // tgp_connect_subgraph_single needs neither its memset nor its scatter kernel nor the directory scan every
+    // workgroup ran: the Connect call is ONE launch.  dir_blocks 128-node blocks are covered (the tiles end earlier or
+    // later than that: the last workgroup pads).
+#pragma unroll
+    for (int it = 0; it < kTopkItems; ++it) {
+      const unsigned long long m = __ballot(flag[it]);
+      const int64_t i0 = base + it * 256 + (threadIdx.x & ~63);
+      if ((threadIdx.x & 63) == 0 && (i0 >> 7) < dir_blocks) {
+        member_bits[i0 >> 5] = static_cast<uint32_t>(m);
+        member_bits[(i0 >> 5) + 1] = static_cast<uint32_t>(m >> 32);
+      }
+      const int64_t i = base + it * 256 + threadIdx.x;
+      if ((i & 127) == 0 && (i >> 7) < dir_blocks) rank128[i >> 7] = off + rank[it];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+      const int64_t tile_end = base + kTopkTile;  // a multiple of 128
+      for (int64_t b = tile_end >> 7; b < dir_blocks; ++b) {
+        rank128[b] = off + total;
+        for (int q = 0; q < 4; ++q) member_bits[4 * b + q] = 0u;
+      }
+    }
+  }
   if (lift_ptr) {  // CSR offsets of the node -> assignment index: kept nodes are written in node order, so node i's
                    // (at most one) assignment is the number of kept nodes in front of it; perm is the identity
 #pragma unroll
@@ -631,11 +659,15 @@ using namespace tgp;
 
 extern "C" size_t tgp_topk_select_workspace_bytes(int64_t N) { return topk_layout(nullptr, N).bytes + 256; }
 
+extern "C" int64_t tgp_topk_select_directory_blocks(int64_t N) { return ((N > 0 ? N : 1) / 32 + 1 + 3) / 4; }
+
 extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t N, int64_t B, const int64_t* ptr,
                                const int64_t* k, const int64_t* koff, int64_t segments_max_nodes, void* ws,
                                size_t ws_bytes,
                                int64_t* node_index, int64_t* cluster_index, int32_t* assign_perm, float* values,
-                               int32_t* lift_row_ptr, uint64_t* assign_pack_, void* stream_) {
+                               int32_t* lift_row_ptr, uint64_t* assign_pack_, uint32_t* member_bits,
+                               uint32_t* rank128, int* directory_written, void* stream_) {
+  if (directory_written) *directory_written = 0;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   uint2* assign_pack = reinterpret_cast<uint2*>(assign_pack_);
   TGP_REQUIRE(N >= 0 && B >= 0, TGP_ERR_INVALID, "tgp_topk_select: negative size");
@@ -702,9 +734,13 @@ extern "C" int tgp_topk_select(const float* score, const int64_t* batch, int64_t
   hipLaunchKernelGGL(topk_count_kernel, dim3(nbt), dim3(256), 0, stream, s.rank_of, N, s.counts);
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, nbt, s.offsets, s.total,
                      static_cast<const int*>(nullptr));
-  if (node_index)
+  if (node_index) {
+    const bool dir = member_bits && rank128 && directory_written;
     hipLaunchKernelGGL(topk_fill_kernel, dim3(nbt), dim3(256), 0, stream, s.rank_of, N, s.offsets, node_index,
-                       cluster_index, assign_perm, score, values, lift_row_ptr, assign_pack);
+                       cluster_index, assign_perm, score, values, lift_row_ptr, assign_pack,
+                       dir ? member_bits : nullptr, dir ? rank128 : nullptr, tgp_topk_select_directory_blocks(N));
+    if (dir) *directory_written = 1;  // (the per-graph sort routes above do not write it: small graphs take the fused path)
+  }
   return check_launch("tgp_topk_select");
 }
 

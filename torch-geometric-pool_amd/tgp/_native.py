@@ -49,9 +49,8 @@ SIGNATURES = {
                                            _c_p, _c_p, _c_p, _c_p]),
     "tgp_connect_subgraph_single_workspace_bytes": (_c_sz, [_c_i64]),
     "tgp_connect_subgraph_single_status_words": (_c_i64, [_c_i64]),
-    "tgp_connect_subgraph_single_bad_ids_offset": (_c_i64, [_c_i64]),
     "tgp_connect_subgraph_single": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_sz, _c_p,
-                                             _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, ctypes.c_uint32, _c_p]),
+                                             _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, ctypes.c_uint32, _c_p]),
     "tgp_connect_coalesce_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tgp_connect_coalesce_count": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_int, _c_f,
                                             _c_p, _c_sz, _c_p, _c_p]),
@@ -75,7 +74,7 @@ SIGNATURES = {
     "tgp_sparse_pool_small_max_graph_nodes": (_c_int, []),
     "tgp_sparse_pool_small_status_words": (_c_i64, [_c_i64, _c_int]),
     "tgp_graph_lower_bounds_i64": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
-    "tgp_sparse_pool_small_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p,
+    "tgp_sparse_pool_small_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p,
                                            _c_p, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p,
                                            _c_p, _c_i64, _c_p, ctypes.c_uint32, _c_p]),
     "tgp_connect_coalesce_grouped_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
@@ -108,7 +107,8 @@ SIGNATURES = {
     "tgp_topk_plan": (_c_int, [_c_p, _c_i64, ctypes.c_double, _c_p, _c_p, _c_p]),
     "tgp_topk_select_workspace_bytes": (_c_sz, [_c_i64]),
     "tgp_topk_select": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_sz, _c_p, _c_p, _c_p,
-                                 _c_p, _c_p, _c_p, _c_p]),
+                                 _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "tgp_topk_select_directory_blocks": (_c_i64, [_c_i64]),
     "tgp_one_to_one_index_build": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_reduce_one_to_one_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_int, _c_i64, _c_p, _c_p]),
     "tgp_topk_minscore_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
@@ -128,6 +128,8 @@ SIGNATURES = {
     "tgp_graclus_match_graphs": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_graclus_match_rounds": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_p, _c_p]),
     "tgp_batch_facts_i64": (_c_int, [_c_p, _c_i64, _c_p, _c_p, ctypes.c_double, _c_p]),
+    "tgp_batch_facts_sorted_i64": (_c_int, [_c_p, _c_i64, _c_p, _c_p, ctypes.c_double, _c_p, _c_p, _c_p, _c_p,
+                                            ctypes.c_uint64, _c_p]),
     "tgp_topk_score_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_p]),
     "tgp_row_dot_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_weighted_colsum_workspace_bytes": (_c_sz, [_c_i64]),
@@ -179,8 +181,8 @@ SIGNATURES = {
     "tgp_softmax_bwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p]),
     "tgp_reduce_sparse_f64": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_connect_subgraph_single_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, ctypes.c_double,
-                                                 _c_p, _c_sz, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, ctypes.c_uint32,
-                                                 _c_p]),
+                                                 _c_p, _c_sz, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p,
+                                                 ctypes.c_uint32, _c_p]),
     "tgp_connect_coalesce_workspace_bytes_f64": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tgp_connect_coalesce_count_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, _c_int,
                                                 ctypes.c_double, _c_p, _c_sz, _c_p, _c_p]),

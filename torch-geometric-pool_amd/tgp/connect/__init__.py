@@ -54,7 +54,7 @@ def sparse_connect(edge_index, edge_weight: Optional[Tensor] = None, node_index:
                    cluster_index: Optional[Tensor] = None, num_nodes: int = None, num_supernodes: int = None,
                    remove_self_loops: bool = True, reduce_op: str = "sum", edge_weight_norm: bool = False,
                    batch_pooled: Optional[Tensor] = None, degree_norm: bool = False, assign_index=None,
-                   edge_csr: Optional[Tensor] = None):
+                   edge_csr: Optional[Tensor] = None, member_directory: Optional[Tensor] = None):
     r"""Coarsen an edge list (reference connect/base_conn.py:57-112).
 
     * kept-node selection (TopK): induced subgraph, endpoints relabelled to their position in the
@@ -73,7 +73,8 @@ def sparse_connect(edge_index, edge_weight: Optional[Tensor] = None, node_index:
     num_nodes = maybe_num_nodes(edge_index, num_nodes)
     # Fn.*: the native kernels, with the pooled weights kept differentiable w.r.t. edge_weight when it needs a gradient
     if node_index is not None and len(node_index) < num_nodes:
-        ei, ew = Fn.filter_edges(edge_index, edge_weight, node_index, num_nodes, remove_self_loops)
+        ei, ew = Fn.filter_edges(edge_index, edge_weight, node_index, num_nodes, remove_self_loops,
+                                 member_directory=member_directory)
     elif cluster_index is not None and len(cluster_index) == num_nodes:
         ei, ew = Fn.coalesce_edges(edge_index, edge_weight, cluster_index, num_supernodes, reduce_op,
                                    remove_self_loops, assign_index=assign_index,
@@ -115,7 +116,11 @@ class SparseConnect(Connect):
                                           edge_weight_norm=self.edge_weight_norm, batch_pooled=batch_pooled,
                                           degree_norm=self.degree_norm,
                                           assign_index=so.assign_index() if all_assigned else None,
-                                          edge_csr=so.edge_csr_for(edge_index) if all_assigned else None)
+                                          edge_csr=so.edge_csr_for(edge_index) if all_assigned else None,
+                                          # (TopkSelect on large graphs: the kept-node bitmap + rank directory its
+                                          #  compaction pass wrote -- the subgraph Connect is then ONE launch)
+                                          member_directory=getattr(so.__dict__.get("_assign_index"),
+                                                                   "member_directory", None))
         return adj_pool, like_input_dtype(w_pool, edge_weight)
 
     def __repr__(self) -> str:

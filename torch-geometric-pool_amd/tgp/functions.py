@@ -207,12 +207,13 @@ class _FilteredWeightsFn(torch.autograd.Function):
 
 
 def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: Optional[Tensor], num_nodes: int,
-                 remove_self_loops: bool):
+                 remove_self_loops: bool, member_directory: Optional[Tensor] = None):
     """K.filter_edges whose pooled weights stay differentiable w.r.t. ``edge_weight``."""
     if not _needs_grad(edge_weight):
-        return K.filter_edges(edge_index, edge_weight, node_index, num_nodes, remove_self_loops)
+        return K.filter_edges(edge_index, edge_weight, node_index, num_nodes, remove_self_loops,
+                              member_directory=member_directory)
     ei, ew, eid = K.filter_edges(edge_index, edge_weight.detach(), node_index, num_nodes, remove_self_loops,
-                                 want_edge_id=True)
+                                 want_edge_id=True, member_directory=member_directory)
     w32 = edge_weight if edge_weight.dtype in (torch.float32, torch.float64) else edge_weight.float()
     return ei, _FilteredWeightsFn.apply(w32.reshape(-1), eid, (ew,))
 

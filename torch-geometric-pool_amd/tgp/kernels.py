@@ -38,7 +38,7 @@ class AssignIndex:
     """Inverted index of a sparse assignment (supernode -> its assignments, in ascending
     assignment order).  A function of the SelectOutput only, so SelectOutput caches it."""
 
-    __slots__ = ("_row_ptr", "perm", "nnz", "num_targets", "_device", "pack", "pack_key")
+    __slots__ = ("_row_ptr", "perm", "nnz", "num_targets", "_device", "pack", "pack_key", "member_directory")
 
     def __init__(self, row_ptr: Optional[Tensor], perm: Optional[Tensor], nnz: int, num_targets: int, device=None):
         # row_ptr None: exactly one assignment per target (TopK, NDP) -- the table is arange and the Reduce kernel
@@ -55,6 +55,10 @@ class AssignIndex:
         # (source_index.data_ptr(), weight.data_ptr() or 0).  It is a snapshot of the selector's own output: like the
         # inverted index itself it is not refreshed if a caller edits S's indices / values in place afterwards.
         self.pack, self.pack_key = None, None
+        # r5 (TopkSelect on large graphs): int32 [5 * blocks] = the kept-node bitmap (4 words per 128-node block) followed
+        # by the rank directory (kept nodes in front of every block), by-products of the selector's compaction pass that
+        # the subgraph Connect of the same selection starts from (tgp_connect_subgraph_single's member_bits_in)
+        self.member_directory = None
         self._device = perm.device if perm is not None else (row_ptr.device if row_ptr is not None else
                                                               torch.device(device))
 
@@ -233,13 +237,38 @@ class _SpsState:
     workgroup stores {epoch, refused, total} into -- the host polls it instead of paying a device-to-host copy kernel
     and a stream synchronise for eight bytes (``tgp_count_publish`` gives every count -> fill pair the same read)."""
 
-    __slots__ = ("status", "epoch", "pinned", "host")
+    __slots__ = ("status", "epoch", "pinned", "host", "ticket", "facts_pinned", "facts_host", "facts_tag")
 
     def __init__(self, dev, words):
         self.status = torch.zeros(max(int(words), 4096), dtype=torch.int64, device=dev)
         self.epoch = 0
         self.pinned = torch.zeros(8, dtype=torch.int64).pin_memory()
         self.host = self.pinned.numpy()  # the same memory
+        # the one-launch batch facts (utils.ops._batch_facts_sorted): arrival ticket + flag word (zero between calls) and
+        # the pinned words {tag, B - 1, flags, longest graph, non-empty graphs, sum of TopK keep counts}
+        self.ticket = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.facts_pinned = torch.zeros(8 * 8, dtype=torch.int64).pin_memory()  # 8 slots of 8 words (prefetched calls)
+        self.facts_host = self.facts_pinned.numpy()
+        self.facts_tag = 0
+
+    def next_facts_tag(self) -> int:
+        self.facts_tag += 1
+        return self.facts_tag
+
+    def facts_slot(self, tag: int) -> int:
+        """Address of the pinned result words of call ``tag`` (calls rotate through eight slots: a prefetched call's
+        words are not overwritten by the calls enqueued behind it)."""
+        return self.facts_pinned.data_ptr() + 64 * (tag & 7)
+
+    def wait_facts(self, tag: int):
+        host, spins, o = self.facts_host, 0, 8 * (tag & 7)
+        while int(host[o]) != tag:
+            spins += 1
+            if spins > 4_000_000:
+                torch.cuda.synchronize(self.status.device)
+                if int(host[o]) != tag:
+                    raise N.TgpNativeError("tgp_batch_facts_sorted_i64 finished without storing its result word")
+        return int(host[o + 1]), int(host[o + 2]), int(host[o + 3]), int(host[o + 4]), int(host[o + 5])
 
     def next_epoch(self) -> int:
         self.epoch += 1
@@ -299,16 +328,31 @@ def sparse_pool_small_max_graph_nodes() -> int:
 _EDGE_PTR: dict = {}  # id(edge_index) -> (weakref, version, id(graph_ptr), weakref(graph_ptr), edge_ptr)
 
 
+def _edge_ptr_memo(edge_index: Tensor, graph_ptr: Tensor) -> Optional[Tensor]:
+    hit = _EDGE_PTR.get(id(edge_index))
+    if (hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version and hit[2] == id(graph_ptr)
+            and hit[3]() is graph_ptr):
+        return hit[4]
+    return None
+
+
+def _edge_ptr_remember(edge_index: Tensor, graph_ptr: Tensor, out: Tensor) -> None:
+    import weakref
+    if len(_EDGE_PTR) >= 16:
+        for k in [k for k, v in _EDGE_PTR.items() if v[0]() is None or v[3]() is None]:
+            del _EDGE_PTR[k]
+        while len(_EDGE_PTR) >= 16:
+            del _EDGE_PTR[next(iter(_EDGE_PTR))]
+    _EDGE_PTR[id(edge_index)] = (weakref.ref(edge_index), edge_index._version, id(graph_ptr), weakref.ref(graph_ptr), out)
+
+
 def graph_edge_ptr(edge_index: Tensor, graph_ptr: Tensor) -> Tensor:
     """First edge of every graph of a sorted batch in a row-sorted list ([B+1] int64: lower bounds of ``graph_ptr`` in the
     row array), remembered per (edge list object + version, graph_ptr object): one tiny launch for a new pair, nothing
     for a pair that is pooled again.  The consumers re-check what they read through it."""
-    import weakref
-    key = id(edge_index)
-    hit = _EDGE_PTR.get(key)
-    if (hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version and hit[2] == id(graph_ptr)
-            and hit[3]() is graph_ptr):
-        return hit[4]
+    hit = _edge_ptr_memo(edge_index, graph_ptr)
+    if hit is not None:
+        return hit
     dev = edge_index.device
     gp = N.i64c(graph_ptr)
     out = torch.empty(gp.numel(), dtype=torch.int64, device=dev)
@@ -316,12 +360,7 @@ def graph_edge_ptr(edge_index: Tensor, graph_ptr: Tensor) -> Tensor:
     N.check(N.lib().tgp_graph_lower_bounds_i64(N.ptr(row) if row.numel() else None, row.numel(), N.ptr(gp),
                                                gp.numel() - 1, N.ptr(out), N.stream_ptr(dev)),
             "tgp_graph_lower_bounds_i64")
-    if len(_EDGE_PTR) >= 16:
-        for k in [k for k, v in _EDGE_PTR.items() if v[0]() is None or v[3]() is None]:
-            del _EDGE_PTR[k]
-        while len(_EDGE_PTR) >= 16:
-            del _EDGE_PTR[next(iter(_EDGE_PTR))]
-    _EDGE_PTR[key] = (weakref.ref(edge_index), edge_index._version, id(graph_ptr), weakref.ref(graph_ptr), out)
+    _edge_ptr_remember(edge_index, graph_ptr, out)
     return out
 
 
@@ -396,8 +435,14 @@ def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_wei
     state = _sps_state(dev, st, L.tgp_sparse_pool_small_status_words(B, mode))
     epoch = state.next_epoch()
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if w is not None else 0)
-    # per-graph offsets the caller side already has: the kernel skips its searches (and re-checks what it reads)
-    eptr = graph_edge_ptr(edge_index, graph_ptr) if (E and _SPS_GIVE_PTRS) else None
+    # per-graph offsets the caller side already has: the kernel skips its searches (and re-checks what it reads).  r5: an
+    # edge list that is NEW to this process (every mini-batch of a training loop) no longer pays a lower-bounds launch
+    # for them: the kernel searches for its ranges as it did before r4 and LEAVES them in `eptr_out`, which is remembered
+    # for the next call on the same tensors
+    eptr = _edge_ptr_memo(edge_index, graph_ptr) if (E and _SPS_GIVE_PTRS) else None
+    eptr_out = None
+    if eptr is None and E and _SPS_GIVE_PTRS:
+        eptr_out = torch.empty(B + 1, dtype=torch.int64, device=dev)
     aptr = None
     if eptr is not None and mode == 0:
         if assign_ptr is not None and assign_ptr.dtype == torch.int64 and assign_ptr.numel() == B + 1 and assign_ptr.is_cuda:
@@ -405,7 +450,7 @@ def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_wei
         else:
             eptr = None  # (mode 0 needs both tables)
     N.check(L.tgp_sparse_pool_small_f32(x.data_ptr(), n, F, x.stride(0), gp.data_ptr(), B, N.ptr(eptr), N.ptr(aptr),
-                                        row_p if E else None,
+                                        N.ptr(eptr_out), row_p if E else None,
                                         col_p if E else None, N.ptr(w), E, ni_p, ci_p, N.ptr(wt),
                                         nnz, K, mode, N.REDUCE_OPS[reduce_op], flags, ops_eps(),
                                         xp_p, bp_p, cap_p, cap_p + 8 * ecap, cw_p,
@@ -419,6 +464,8 @@ def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_wei
     if total & 0x80000000:
         _sps_remember_declined(edge_index)
         return None
+    if eptr_out is not None:
+        _edge_ptr_remember(edge_index, graph_ptr, eptr_out)
     n_out = total & 0x7FFFFFFF
     if not views:
         ei, ew, _ = _compact_edges(L, st, dev, cap_p, cap_p + 8 * ecap, cw_p, torch.float32, None, n_out)
@@ -461,12 +508,15 @@ def _read_count(d_count: Tensor) -> int:
 
 
 def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: Optional[Tensor],
-                 num_nodes: int, remove_self_loops: bool, want_edge_id: bool = False, views: Optional[bool] = None):
+                 num_nodes: int, remove_self_loops: bool, want_edge_id: bool = False, views: Optional[bool] = None,
+                 member_directory: Optional[Tensor] = None):
     """Induced subgraph + relabel (connect/base_conn.py:79-82) fused with remove_self_loops and the
     |w| > eps filter (utils/ops.py:370-380).  node_index=None: filters only.  Keeps input order.
     ``want_edge_id``: also return the input position of every kept edge (what the backward of the weight
     pass-through scatters by).  ``views`` (default ``tgp.kernels.output_views``, i.e. False): hand out views of the
-    single-pass kernel's capacity-E buffers instead of exact-size tensors."""
+    single-pass kernel's capacity-E buffers instead of exact-size tensors.  ``member_directory``: the selector's own
+    bitmap + rank directory of ``node_index`` (``AssignIndex.member_directory``; node_index must be ascending, as a
+    SelectOutput's is): the call is then ONE launch -- no memset, no scatter of the kept nodes, no directory scan."""
     if views is None:
         views = _OUTPUT_VIEWS
     dev = N.require_device(edge_index, edge_weight, node_index)
@@ -490,9 +540,13 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
     if E > 0 and (f64 or not torch.cuda.is_current_stream_capturing()):
         # ONE pass (r4): survivors written once at their final offsets of capacity-E buffers, which are then narrowed
         # (edge_index' is a view whose two rows are contiguous); the count arrives in a pinned host word
-        got = _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id, views)
+        md = member_directory if (ni is not None and member_directory is not None and member_directory.is_cuda
+                                  and member_directory.dtype == torch.int32
+                                  and member_directory.numel() == 5 * int(L.tgp_topk_select_directory_blocks(num_nodes))
+                                  ) else None
+        got = _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id, views, md)
         if got is None and f64:  # (a look-back spin bound on a shared device: once more; fp64 has no count -> fill pair)
-            got = _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id, views)
+            got = _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id, views, md)
         if got is not None:
             return got
         if f64:
@@ -517,7 +571,7 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
     return (out_ei, out_w, out_id) if want_edge_id else (out_ei, out_w)
 
 
-def _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id, views=False):
+def _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id, views=False, md=None):
     """``tgp_connect_subgraph_single``; None when the kernel refused for a reason other than bad node ids (a look-back
     spin bound on a shared device): the caller takes the count -> fill pair."""
     ws = N.workspace(L.tgp_connect_subgraph_single_workspace_bytes(num_nodes), dev)
@@ -529,17 +583,20 @@ def _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, 
     cap_p = cap.data_ptr()
     entry = (L.tgp_connect_subgraph_single_f64 if (w is not None and w.dtype == torch.float64)
              else L.tgp_connect_subgraph_single)
+    nblk = 0 if md is None else md.numel() // 5
     N.check(entry(row.data_ptr(), col.data_ptr(), N.ptr(w), E, N.ptr(ni),
                                           0 if ni is None else ni.numel(), num_nodes, flags, eps, ws.data_ptr(),
                                           ws.numel(), cap_p, cap_p + 8 * E, N.ptr(cap_w), N.ptr(cap_id),
+                                          None if md is None else md.data_ptr(),
+                                          None if md is None else md.data_ptr() + 16 * nblk,
                                           state.status.data_ptr(), state.status.numel(), state.pinned.data_ptr(), epoch,
                                           st), "tgp_connect_subgraph_single")
     total = state.wait(epoch)
     if total & 0x80000000:
-        # refused: node ids outside [0, num_nodes) (flag word [1] of the workspace's status ints, behind the relabel
-        # table and the bitmap) -- the reference's index ops raise for these inputs too -- or a spin bound
-        off = L.tgp_connect_subgraph_single_bad_ids_offset(num_nodes)
-        if int(ws[off: off + 4].view(torch.int32)[0]) != 0:
+        # refused: node ids outside [0, num_nodes) -- the reference's index ops raise for these inputs too; a chunk that
+        # met one says so in word [1] of the status buffer, tagged with this call's epoch -- or a look-back spin bound
+        word = int(state.status[1])
+        if (word & 0xFFFFFFFF) == epoch:
             raise IndexError("edge_index holds node ids outside [0, num_nodes) (or cluster ids outside "
                              "[0, num_supernodes)): the reference's index ops raise for these inputs too")
         return None
@@ -1191,10 +1248,24 @@ def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Te
     with_lift = lift_ptr is not None
     L = N.lib()
     ws = N.workspace(L.tgp_topk_select_workspace_bytes(n), dev)
+    # r5: graphs beyond the per-graph sort routes (the device-wide route) also get the kept-node bitmap and its rank
+    # directory from the compaction pass -- what the subgraph Connect of this very selection starts from
+    directory = None
+    import ctypes as _ct
+    wrote = _ct.c_int(0)
+    if n > 0 and k_total > 0 and not (0 < segments_max_nodes <= 8192):
+        nblk = int(L.tgp_topk_select_directory_blocks(n))
+        directory = torch.empty(5 * nblk, dtype=torch.int32, device=dev)  # [4 nblk] bitmap words | [nblk] rank128
     N.check(L.tgp_topk_select(N.ptr(score), N.ptr(None if batch is None else N.i64c(batch)), n, num_graphs,
                               N.ptr(N.i64c(ptr)), N.ptr(N.i64c(k)), N.ptr(N.i64c(koff)), segments_max_nodes, N.ptr(ws),
                               ws.numel(), idx_p, idx_p + 8 * k_total, perm_p, val_p,
-                              N.ptr(lift_ptr), pack_p, N.stream_ptr(dev)), "tgp_topk_select")
+                              N.ptr(lift_ptr), pack_p,
+                              None if directory is None else directory.data_ptr(),
+                              None if directory is None else directory.data_ptr() + 16 * nblk,
+                              _ct.addressof(wrote) if directory is not None else None,
+                              N.stream_ptr(dev)), "tgp_topk_select")
+    if not wrote.value:
+        directory = None
     if one:
         i64, i32, f32 = buf.view(torch.int64), buf.view(torch.int32), buf.view(torch.float32)
         index = torch.as_strided(i64, (2, k_total), (k_total, 1), 0)
@@ -1202,6 +1273,7 @@ def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Te
         perm = torch.as_strided(i32, (kk,), (1,), o_perm >> 2)
         pack = torch.as_strided(i64, (kk,), (1,), o_pack >> 3)
     assign = AssignIndex(None, perm, k_total, k_total)
+    assign.member_directory = directory  # (bitmap | rank128) of the kept nodes, or None
     if pack is not None and k_total > 0 and n < (1 << 31):
         assign.pack, assign.pack_key = pack, (index.data_ptr(), values.data_ptr())
     out = (index, assign) + ((values,) if with_values else ())
@@ -1290,7 +1362,8 @@ def graclus_match(edge_index: Tensor, edge_weight: Optional[Tensor], num_nodes: 
         o_ones = (o_perm + 4 * num_nodes + 15) & ~15
         buf = torch.empty((o_ones + 4 * num_nodes + 15) & ~15, dtype=torch.uint8, device=dev)
         base = buf.data_ptr()
-        eptr = graph_edge_ptr(edge_index, graph_ptr) if _SPS_GIVE_PTRS else None  # (memoised; sparse_pool_small reuses it)
+        # (a list pooled before brings its per-graph offsets along; a new one lets the kernel search: r5, no launch for them)
+        eptr = _edge_ptr_memo(edge_index, graph_ptr) if _SPS_GIVE_PTRS else None
         N.check(L.tgp_graclus_match_graphs_fused(N.ptr(row), N.ptr(col), N.ptr(w), num_nodes, E, N.ptr(gp), B,
                                                  N.ptr(eptr), None,
                                                  base + o_idx, base + o_ptr, base + o_perm, base + o_ones,

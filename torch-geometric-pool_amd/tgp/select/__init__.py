@@ -496,7 +496,11 @@ class TopkSelect(Select):
                     and feats.dtype == torch.float32 and feats.dim() == 2 and feats.size(0) > 0
                     and self.weight.dtype == torch.float32):
                 # dot, norm, division (and, with nothing to differentiate, the activation) in the one pass over x;
-                # under autograd the whole score is one graph node (Fn.topk_score)
+                # under autograd the whole score is one graph node (Fn.topk_score).  A batch vector this process has not
+                # seen gets its facts kernel enqueued FIRST: the score pass then runs while the host reads them (r5)
+                if have_batch:
+                    from ..utils.ops import prefetch_batch_info
+                    prefetch_batch_info(batch, float(self.ratio))
                 score = Fn.topk_score(feats, self.weight, self._fused_act == "tanh")
                 return self._native_select(score, batch if have_batch else None, x.size(0))
             # x.w in a single native pass over x (the elementwise product + row sum of the reference,

@@ -72,6 +72,7 @@ class BatchInfo:
 
 
 _BATCH_INFO: dict = {}
+_BATCH_FACTS_ONE_LAUNCH = __import__("os").environ.get("TGP_BATCH_FACTS_ONE_LAUNCH", "1") != "0"  # A/B switch
 
 
 def _batch_facts_device(batch: Tensor, info: "BatchInfo", topk_ratio: float = 0.0) -> bool:
@@ -96,6 +97,86 @@ def _batch_facts_device(batch: Tensor, info: "BatchInfo", topk_ratio: float = 0.
     return True
 
 
+_FACTS_PENDING: dict = {}  # id(batch) -> (weakref, version, ratio, launched call) of prefetch_batch_info
+
+
+def prefetch_batch_info(batch: Optional[Tensor], topk_ratio: float = 0.0) -> None:
+    """Launch the one-launch batch facts NOW and read them later: a caller that has device work to enqueue first (TopK's
+    score pass over x) puts that work between this launch and the ``batch_info`` call that polls for the result, so the
+    host wait covers the facts kernel only and the rest runs while the host goes on.  A no-op when the facts are
+    memoised, the vector is not eligible, or a prefetch is already pending."""
+    import weakref
+    if (batch is None or not _BATCH_FACTS_ONE_LAUNCH or not batch.is_cuda or batch.dtype != torch.long
+            or not batch.is_contiguous() or batch.numel() == 0 or batch.numel() > (1 << 24)):
+        return
+    hit = _BATCH_INFO.get(id(batch))
+    if hit is not None and hit.ref() is batch and hit.version == batch._version:
+        return
+    if id(batch) in _FACTS_PENDING or torch.cuda.is_current_stream_capturing():
+        return
+    if len(_FACTS_PENDING) >= 8:
+        _FACTS_PENDING.clear()  # (abandoned prefetches: their launches complete on their own)
+    _FACTS_PENDING[id(batch)] = (weakref.ref(batch), batch._version, float(topk_ratio or 0.0),
+                                 _facts_sorted_launch(batch, topk_ratio))
+
+
+def _facts_sorted_launch(batch: Tensor, topk_ratio: float):
+    """Enqueue tgp_batch_facts_sorted_i64; returns what ``_facts_sorted_finish`` needs to read its result."""
+    from .. import _native as N
+    dev = batch.device
+    n = batch.numel()
+    st = N.stream_ptr(dev)
+    state = K._sps_state(dev, st, 0)
+    want_plan = bool(topk_ratio and topk_ratio > 0)
+    # one allocation: ptr [n + 2] | sizes [n + 1] (| k [n + 1] | koff [n + 2])
+    buf = torch.empty((2 * n + 3) + ((2 * n + 3) if want_plan else 0), dtype=torch.long, device=dev)
+    base = buf.data_ptr()
+    o_sizes, o_k, o_koff = n + 2, 2 * n + 3, 3 * n + 4
+    tag = state.next_facts_tag()
+    N.check(N.lib().tgp_batch_facts_sorted_i64(batch.data_ptr(), n, base, base + 8 * o_sizes, float(topk_ratio or 0.0),
+                                               (base + 8 * o_k) if want_plan else None,
+                                               (base + 8 * o_koff) if want_plan else None,
+                                               state.ticket.data_ptr(), state.facts_slot(tag), tag, st),
+            "tgp_batch_facts_sorted_i64")
+    return state, tag, buf, n, want_plan
+
+
+def _batch_facts_sorted(batch: Tensor, info: "BatchInfo", topk_ratio: float = 0.0) -> bool:
+    """r5: every fact of a SORTED batch vector -- CSR offsets, sizes, graph count, longest graph, non-empty graphs and,
+    for a TopK selector, its per-graph keep counts with their prefix sums -- from ONE launch
+    (csrc/densify.hip batch_facts_sorted_kernel: no memset, no counting atomics, no cumsum), handed over in a pinned host
+    word this thread polls (no device-to-host copy, no stream synchronise).  What a forward on a NEW batch vector paid
+    before: two memsets, two kernels, a copy back, a fill and a two-kernel cumsum (~60 us of device time on 2048 small
+    graphs, `profiles/r05_fresh_profile_before.txt`).  False: the vector is not sorted (or holds ids outside [0, N], or
+    long runs of ids without nodes) -- the general route below takes it."""
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    pend = _FACTS_PENDING.pop(id(batch), None)
+    launched = None
+    if pend is not None and pend[0]() is batch and pend[1] == batch._version:
+        if pend[2] == float(topk_ratio or 0.0) or pend[2] > 0:
+            launched = pend[3]
+            if pend[2] > 0 and not (topk_ratio and topk_ratio > 0):
+                topk_ratio = pend[2]  # (the prefetch also made a TopK plan: kept)
+    if launched is None:
+        launched = _facts_sorted_launch(batch, topk_ratio)
+    state, tag, buf, n, want_plan = launched
+    o_sizes, o_k, o_koff = n + 2, 2 * n + 3, 3 * n + 4
+    max_id, flags, longest, distinct, keep = state.wait_facts(tag)
+    if flags:
+        return False
+    nb = max_id + 1
+    info.num_graphs = nb
+    info.ptr = buf[: nb + 1]
+    info.sizes = buf[o_sizes: o_sizes + nb]
+    info.is_sorted = True
+    info.max_nodes, info.distinct = longest, distinct
+    if want_plan:  # TopkSelect's plan (total, k, koff) came with the same launch
+        info.memo[("topk", float(topk_ratio))] = (keep, buf[o_k: o_k + nb], buf[o_koff: o_koff + nb + 1])
+        info.memo[("topk_total", float(topk_ratio))] = keep
+    return True
+
+
 def batch_info(batch: Tensor, topk_ratio: float = 0.0) -> BatchInfo:
     """``topk_ratio``: a TopK selector asking first also gets its total number of kept nodes from the same read-back."""
     import weakref
@@ -105,12 +186,16 @@ def batch_info(batch: Tensor, topk_ratio: float = 0.0) -> BatchInfo:
     info = BatchInfo()
     info.ref, info.version, info.memo = weakref.ref(batch), batch._version, {}
     info._sizes_host = None
+    info.ptr = None
     if batch.numel() == 0:
         info.sizes = torch.zeros(0, dtype=torch.long, device=batch.device)
         info.num_graphs, info.max_nodes, info.distinct, info._sizes_host, info.is_sorted = 0, 0, 0, [], True
     elif (batch.is_cuda and batch.dtype == torch.long and batch.is_contiguous() and batch.numel() <= (1 << 24)
+          and _BATCH_FACTS_ONE_LAUNCH and _batch_facts_sorted(batch, info, topk_ratio)):
+        pass  # ONE launch, one pinned-word poll; the CSR offsets came with it
+    elif (batch.is_cuda and batch.dtype == torch.long and batch.is_contiguous() and batch.numel() <= (1 << 24)
           and _batch_facts_device(batch, info, topk_ratio)):  # (its size table has one slot per NODE: 128 MB at the cap)
-        pass  # two launches, ONE host read of four numbers
+        pass  # (unsorted vectors) two launches, ONE host read of four numbers
     else:
         info.sizes = torch.bincount(batch)  # sync 1: the output length is max(batch) + 1
         info.num_graphs = info.sizes.numel()
@@ -119,9 +204,10 @@ def batch_info(batch: Tensor, topk_ratio: float = 0.0) -> BatchInfo:
         info._sizes_host, info.is_sorted = host[:-1], host[-1] == 0
         info.max_nodes = max(info._sizes_host)
         info.distinct = info.num_graphs - info._sizes_host.count(0)  # (list.count: a generator over 2048 sizes was 60 us)
-    info.ptr = torch.zeros(info.num_graphs + 1, dtype=torch.long, device=batch.device)
-    if info.num_graphs:
-        torch.cumsum(info.sizes, 0, out=info.ptr[1:])
+    if getattr(info, "ptr", None) is None:
+        info.ptr = torch.zeros(info.num_graphs + 1, dtype=torch.long, device=batch.device)
+        if info.num_graphs:
+            torch.cumsum(info.sizes, 0, out=info.ptr[1:])
     if len(_BATCH_INFO) >= 16:  # a handful of live batch vectors at most; drop dead and old entries
         for key in [k for k, v in _BATCH_INFO.items() if v.ref() is None]:
             del _BATCH_INFO[key]
