@@ -460,3 +460,35 @@ def test_topk_select_directory_and_one_launch_subgraph_connect(dev):
         conn(bad, so, edge_weight=ew_d)
     pe3, pw3 = conn(ei_d, so, edge_weight=ew_d)              # the buffers of the refused call left nothing behind
     assert torch.equal(pe3, pe2) and torch.equal(pw3, pw2)
+
+
+def test_float64_filter_edges_has_a_staged_fallback(dev, monkeypatch):
+    """float64 edge weights had no count -> fill pair, so two refusals of the single-pass kernel (a look-back
+    spin bound on a shared device) raised.  Now the staged route takes over: indices through the fp32 pair, the
+    |w| > eps test on the gathered weights in double.  Forced here by making the single pass decline."""
+    import tgp_oracle as O
+    from tgp import kernels
+    g = torch.Generator().manual_seed(3)
+    n, e = 5000, 40000
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ew = torch.rand(e, generator=g, dtype=torch.float64) - 0.3
+    ew[::13] = 1e-9
+    keep = torch.sort(torch.randperm(n, generator=g)[: n // 3])[0]
+    want_ei, want_w = kernels.filter_edges(ei.to(dev), ew.to(dev), keep.to(dev), n, True)
+    calls = {"n": 0}
+
+    def declines(*a, **k):
+        calls["n"] += 1
+        return None
+    monkeypatch.setattr(kernels, "_filter_edges_single", declines)
+    got_ei, got_w, got_id = kernels.filter_edges(ei.to(dev), ew.to(dev), keep.to(dev), n, True, want_edge_id=True)
+    assert calls["n"] >= 2 and got_w.dtype == torch.float64
+    assert torch.equal(got_ei, want_ei) and torch.equal(got_w, want_w)
+    assert torch.equal(ew.to(dev)[got_id], got_w)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        r_ei, r_w = O.sparse_connect(ei, ew, keep, None, n, keep.numel())
+    finally:
+        torch.set_default_dtype(old)
+    assert torch.equal(got_ei.cpu(), r_ei) and torch.equal(got_w.cpu(), r_w)

@@ -230,7 +230,12 @@ __global__ __launch_bounds__(256) void cr_member_single_kernel(const int32_t* __
     if (threadIdx.x == 0) {
       s_off = excl;
       s_refused = refused ? 1 : 0;
-      if (refused) atomicOr(bad, 1);  // a look-back that ran into its spin bound declines the call
+      // a look-back that ran into its spin bound declines the call.  NOT through bad[0]: workgroup 0 resets that word
+      // with a plain store in this very launch, and a tile that times out does so exactly when workgroup 0 is late --
+      // the reset could land on top of the refusal.  The refusal goes to word [0] of this look-back's
+      // region of the status buffer, tagged with the call's epoch (never cleared, never reset); cr_raw_off_kernel,
+      // the next launch, folds it into bad[0] for everything behind it.
+      if (refused) sps_store(status, tag | 1ull);
     }
   }
   __syncthreads();
@@ -256,8 +261,14 @@ __global__ __launch_bounds__(256) void cr_raw_off_kernel(const int32_t* __restri
                                                          const uint32_t* __restrict__ seg_dst, int* __restrict__ bad,
                                                          uint32_t* __restrict__ raw_off,
                                                          uint32_t* __restrict__ huge_list,
-                                                         uint32_t* __restrict__ n_out) {
+                                                         uint32_t* __restrict__ n_out,
+                                                         const unsigned long long* __restrict__ refusal,
+                                                         unsigned long long tag) {
   const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (refusal && sps_load(refusal) == (tag | 1ull)) {  // cr_member_single_kernel declined (see there): uniform
+    if (r == 0) atomicOr(bad, 1);
+    return;
+  }
   if (r >= K || (*bad & 1)) return;
   const uint32_t lo = seg_dst[a_row_ptr[r]], hi = seg_dst[a_row_ptr[r + 1]];
   raw_off[r] = lo;
@@ -1658,7 +1669,8 @@ static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const floa
                        cluster_index, N, E, csr_ptr ? 1 : 0, s.bad, s.table, s.seg_src, s.seg_dst, st2,
                        static_cast<unsigned long long>(pub->epoch) << SPS_EPOCH_SHIFT);
     hipLaunchKernelGGL(cr_raw_off_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, assign_row_ptr, K, s.seg_dst, s.bad,
-                       s.raw_off, huge ? h.list : static_cast<uint32_t*>(nullptr), s.n_out);
+                       s.raw_off, huge ? h.list : static_cast<uint32_t*>(nullptr), s.n_out, st2,
+                       static_cast<unsigned long long>(pub->epoch) << SPS_EPOCH_SHIFT);
   } else {  // member segments: degree sums per tile (+ cluster table), scan, row offsets
     uint32_t* sums = s.scan_scratch;
     uint32_t* offs = s.scan_scratch + nt;
@@ -1674,7 +1686,8 @@ static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const floa
                          s.seg_src, s.seg_dst);
     }
     hipLaunchKernelGGL(cr_raw_off_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, assign_row_ptr, K, s.seg_dst, s.bad,
-                       s.raw_off, huge ? h.list : static_cast<uint32_t*>(nullptr), s.n_out);
+                       s.raw_off, huge ? h.list : static_cast<uint32_t*>(nullptr), s.n_out,
+                       static_cast<const unsigned long long*>(nullptr), 0ull);
   }
   if (huge) {  // rows beyond CR_LONG entries (hubs): their entries alone are sorted device-wide (see cr_huge_*_kernel)
     const int colbits = bits_for(static_cast<uint64_t>(K - 1));

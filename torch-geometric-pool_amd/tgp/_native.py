@@ -257,7 +257,10 @@ def require_device(*tensors: Optional[Tensor]) -> torch.device:
         if not t.is_cuda:
             raise TgpNativeError(
                 "tgp (MI355X build) runs Reduce/Connect only on ROCm device tensors; got a "
-                f"{t.device} tensor. Move inputs to 'cuda' - there is no CPU fallback.")
+                f"{t.device} tensor. Move inputs to 'cuda' - there is no CPU fallback.  (The reference's operators also "
+                "accept host tensors, reduce/base_reduce.py:141-155: this build does not.  Remedy: "
+                "`pooler.to('cuda')` and `x.to('cuda')`, `edge_index.to('cuda')`, `batch.to('cuda')` before the call; the "
+                "results come back on the device.)")
         if dev is None:
             dev = t.device
         elif t.device != dev:

@@ -537,7 +537,7 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
     L = N.lib()
     st = N.stream_ptr(dev)
     eps = ops_eps()
-    if E > 0 and (f64 or not torch.cuda.is_current_stream_capturing()):
+    if E > 0 and not torch.cuda.is_current_stream_capturing():
         # ONE pass (r4): survivors written once at their final offsets of capacity-E buffers, which are then narrowed
         # (edge_index' is a view whose two rows are contiguous); the count arrives in a pinned host word
         md = member_directory if (ni is not None and member_directory is not None and member_directory.is_cuda
@@ -549,11 +549,20 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
             got = _filter_edges_single(L, dev, st, row, col, w, E, ni, num_nodes, flags, eps, want_edge_id, views, md)
         if got is not None:
             return got
-        if f64:
-            raise N.TgpNativeError("tgp_connect_subgraph_single_f64 refused twice (is the device shared?)")
-    if f64:  # E == 0
+    if f64 and E == 0:
         out = (torch.empty(2, 0, dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.float64, device=dev))
         return out + (torch.empty(0, dtype=torch.int64, device=dev),) if want_edge_id else out
+    if f64:
+        # the single pass declined twice (a look-back spin bound: the device is shared) or a stream is being captured:
+        # staged route for float64 weights -- the count -> fill pair on the indices alone (node filter + self loops) with
+        # the kept edges' input positions, then the |w| > eps test on the gathered weights IN DOUBLE (this
+        # used to raise)
+        ei2, _, eid = filter_edges(edge_index, None, node_index, num_nodes, remove_self_loops, want_edge_id=True,
+                                   views=views)
+        w2 = w[eid]
+        keep = w2.abs() > eps
+        ei2, w2, eid = ei2[:, keep].contiguous(), w2[keep], eid[keep]
+        return (ei2, w2, eid) if want_edge_id else (ei2, w2)
     ws = N.workspace(L.tgp_connect_subgraph_workspace_bytes(E, num_nodes), dev)
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
     N.check(L.tgp_connect_subgraph_count(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(ni),
