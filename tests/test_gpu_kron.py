@@ -1,6 +1,7 @@
 """A9 / N4: the block-batched Kron reduction kernel (tgp_kron_batched_{count,fill}) against the oracle's restatement of
 the reference's scipy route (connect/kron_conn.py:117-165) on whole-batch Laplacians: edge_index bit-exact (row-major
 order of the pooled batch), weights within 1e-5 relative."""
+import os
 import warnings
 
 import numpy as np
@@ -78,7 +79,11 @@ def _blockwise_kron(ei, ew, batch, idx_pos, thr):
         if pos.numel() > 1:
             Ln = L[pos][:, pos]
             if neg.numel():
+                if m > 2000:  # (a large block: all host threads for this one solve)
+                    torch.set_num_threads(max(1, (os.cpu_count() or 1) // 2))
                 Ln = Ln - L[pos][:, neg] @ torch.linalg.solve(L[neg][:, neg], L[neg][:, pos])
+                if m > 2000:
+                    torch.set_num_threads(1)
             a = -Ln
             a = a * (a.abs() > thr) if thr > 0 else a
             a.fill_diagonal_(0)
@@ -142,6 +147,20 @@ def test_kron_batched_workspace_resident_graphs(dev):
     out = native_only(KronConnect())(ei.to(dev), so_of(idx_pos, n, dev, L=L), edge_weight=ew.to(dev),
                                      batch=batch.to(dev))
     check(out[0], out[1], ref, dev)
+
+
+def test_kron_graphs_of_up_to_8192_nodes_stay_on_the_native_route(dev):
+    """r5 (verdict r4 item 10): the panel kernels take graphs of up to 8192 nodes (4096 before): a 5000-node graph among
+    small ones, and alone, is reduced by the hand-written kernels -- every library / host route patched to raise --
+    and equals the dense fp64 Schur complement (kron_conn.py:117-146)."""
+    from tgp.connect import KronConnect
+    for sizes, seed in (([60, 5000, 33, 700], 21), ([4500], 22)):
+        ei, ew, batch, idx_pos = make_batch(sizes, seed=seed)
+        n = batch.numel()
+        ref = blockwise_kron(ei, ew, batch, idx_pos)
+        out = native_only(KronConnect())(ei.to(dev), so_of(idx_pos, n, dev), edge_weight=ew.to(dev),
+                                         batch=batch.to(dev))
+        check(out[0], out[1], ref, dev)
 
 
 def test_kron_from_edge_list_unsorted_duplicates_self_loops(dev):
@@ -233,7 +252,9 @@ def test_kron_mixed_batch_keeps_oversize_graphs_on_the_device(dev, monkeypatch, 
 
     def boom(*a, **k):
         raise AssertionError("KronConnect went to the host sparse solver")
-    big = K.kron_max_graph_nodes() + 60
+    limit = 1024  # (KronConnect(native_max_nodes=...): graphs beyond it are "oversize" for the kernels, r5 -- the
+    #                kernels' own limit, 8192 nodes, is beyond what the dense library solve takes on this box)
+    big = limit + 60
     sizes = [30, 45, big, 25, 200, big + 333, 40, 1]
     ei, ew, batch, idx_pos = make_batch(sizes, seed=9)
     n = batch.numel()
@@ -243,7 +264,7 @@ def test_kron_mixed_batch_keeps_oversize_graphs_on_the_device(dev, monkeypatch, 
     ref = blockwise_kron(ei, ew, batch, idx_pos)
     L = O.laplacian_scipy(ei, ew.double(), n).astype(np.float64) if source == "laplacian" else None
     monkeypatch.setattr(spla, "spsolve", boom)
-    conn = KronConnect()
+    conn = KronConnect(native_max_nodes=limit)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         out = conn(ei.to(dev), so_of(idx_pos, n, dev, L=L), edge_weight=ew.to(dev), batch=batch.to(dev))

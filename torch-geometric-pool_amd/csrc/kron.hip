@@ -28,7 +28,8 @@ namespace tgp {
 __device__ __forceinline__ double kron_upd(double m, double c, double u, double inv) { return __fma_rn(-(c * u), inv, m); }
 
 constexpr int KRON_LDS_MAX_N = 128;  // 128 x 129 doubles = 132 KB of the 160 KB LDS
-constexpr int KRON_MAX_N = 4096;       // r3: was 1024 (the multi-workgroup panel kernels do not care; 4096^2 doubles = 134 MB per graph)
+constexpr int KRON_MAX_N = 8192;       // r5: was 4096 (r3: 1024); the multi-workgroup panel kernels do not care, the slab of a
+                                       // graph is n^2 doubles: 537 MB at 8192 nodes, taken from the caller's workspace
 constexpr int KRON_REDO_MAX_N = 1024;  // what the one-workgroup damped redo of a singular graph can hold in LDS
 constexpr int KRON_THREADS = 256;
 constexpr int KRON_BIG_THREADS = 1024;
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(1024) void kron_plan_kernel(const int64_t* __restri
       const int64_t k = static_cast<int64_t>(rank[p1]) - static_cast<int64_t>(rank[p0]);
       desc.g = g; desc.n = static_cast<int>(n); desc.k = static_cast<int>(k); desc.m = static_cast<int>(n - k);
       desc.p0 = p0; desc.r0 = rank[p0];
-      const bool oversize = n > KRON_MAX_N;
+      // (with skip_oversize the caller's bound -- at most KRON_MAX_N -- is the size limit: larger graphs are the caller's)
+      const bool oversize = n > (skip_oversize ? static_cast<int64_t>(declared_max) : static_cast<int64_t>(KRON_MAX_N));
       if (n < 0 || (oversize && !skip_oversize)) atomicOr(status, KRON_TOO_LARGE);
       if (!oversize) {  // (skipped graphs take no scratch and emit nothing: the caller reduces them itself)
         sq = k * k;

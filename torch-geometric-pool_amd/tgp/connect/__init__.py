@@ -288,8 +288,8 @@ class KronConnect(Connect):
     The reference builds one sparse Laplacian for the whole batch and calls scipy's sparse LU on the host.  The batch
     Laplacian is block diagonal, so on the GPU every graph's Schur complement is taken independently by
     ``tgp_kron_batched_{count,fill}``: one workgroup per graph, dense fp64 elimination of the dropped nodes in LDS
-    (graphs up to 128 nodes) or panel by panel in a workspace slab (up to ``tgp_kron_batched_max_graph_nodes`` = 4096
-    nodes), threshold / zero-diagonal / fp32 cast fused,
+    (graphs up to 128 nodes) or panel by panel in a workspace slab (up to ``tgp_kron_batched_max_graph_nodes`` = 8192
+    nodes since r5; 4096 before), threshold / zero-diagonal / fp32 cast fused,
     edges emitted in the row-major order the reference's CSR -> COO conversion gives.  Nothing but the selector's
     Laplacian (uploaded once per SelectOutput) crosses PCIe.  Graphs beyond that size are skipped by the kernel and
     reduced one by one with the dense fp64 library solve on the device (``torch.linalg.solve`` -> rocSOLVER, up to
@@ -298,10 +298,14 @@ class KronConnect(Connect):
     unchanged.  All routes give the same
     edge set; weights agree to solver round-off before the fp32 cast."""
 
-    def __init__(self, sparse_threshold: float = 1e-2, dense_solve_max_nodes: int = 8192):
+    def __init__(self, sparse_threshold: float = 1e-2, dense_solve_max_nodes: int = 8192,
+                 native_max_nodes: Optional[int] = None):
         super().__init__()
         self.sparse_threshold = sparse_threshold
         self.dense_solve_max_nodes = dense_solve_max_nodes
+        # graphs beyond this many nodes leave the hand-written kernels for the library solve (None: the kernels' own
+        # limit, tgp_kron_batched_max_graph_nodes = 8192; a smaller value is a tuning / testing knob)
+        self.native_max_nodes = native_max_nodes
 
     # ---------------------------------------------------------------- native block-batched route
     @staticmethod
@@ -339,6 +343,8 @@ class KronConnect(Connect):
         else:
             ptr, max_nodes, sizes_host = torch.tensor([0, n], dtype=torch.long, device=dev), n, [n]
         limit = K.kron_max_graph_nodes()
+        if self.native_max_nodes is not None:
+            limit = max(1, min(limit, int(self.native_max_nodes)))
         oversize = None
         if max_nodes > limit:
             # A few graphs beyond the kernel's size limit must not send the whole batch to the host (one 1500-node
