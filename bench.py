@@ -47,6 +47,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "torch-geometric-pool_amd"))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+# v_mfma_f64_16x16x4_f64: the guide's matrix-core table has no fp64 row.  Half the fp32-input rate (32 FLOP/clk/SIMD) by
+# AMD's MI355X data sheet = 78.6 TFLOP/s; rocBLAS dgemm reaches 76.7 TFLOP/s at N = 8192 on this part
+# (profiles/r05_fp64_dense.txt), which pins the figure from below.
+PEAK_FP64_MFMA_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 COPY_RATE_GBS = 6290.0         # MI355X_MICROARCH.md: measured float4 copy (79 % of spec): the achievable streaming rate
 METRIC = "pooled nodes/sec (Reduce+Connect) on batched graphs"
@@ -225,20 +229,25 @@ class DenseDiffPool(Workload):
         from tgp.reduce import BaseReduce
         from tgp.select import SelectOutput
         from tgp.src import DenseSRCPooling
-        if which == "c2":
+        self.f64 = which == "c2_f64"
+        if which in ("c2", "c2_f64"):
             self.B, self.N, self.K, self.F = 32, 1024, 128, 64
             self.name = "DiffPool dense S^T X / S^T A S, batch=32 graphs N=1024 K=128 F=64 (BASELINE configs[1])"
+            if self.f64:
+                self.name += ", float64 tensors (a model.double() run: the fp64 matrix path, r5)"
         else:
             self.B, self.N, self.K, self.F = 2, 8192, 512, 128
             self.name = "DiffPool N=8192 K=512 F=128, 2 graphs per GPU (BASELINE configs[4] shape)"
         self.which, self.unfused = which, unfused
         self.S, self.A, self.X = dense_inputs(self.B, self.N, self.K, self.F, seed=ctx.rank, dev=ctx.dev)
+        if self.f64:
+            self.S, self.A, self.X = self.S.double(), self.A.double(), self.X.double()
         self.so = SelectOutput(s=self.S)
         self.reducer, self.connector = BaseReduce(), DenseConnect()
         self.pool = DenseSRCPooling(reducer=self.reducer, connector=self.connector, adj_transpose=True)
         # pooled outputs of every step are all-gathered; four steps share one collective (fewer, larger RCCL calls)
         self.gather = (PackedGather(bucket_steps=4, force_collective=force_collective)
-                       if ctx.dist is not None else None)
+                       if (ctx.dist is not None and not self.f64) else None)
         self.nodes = self.B * self.N
         if self.gather is not None:
             self.drain = self.gather.flush
@@ -270,7 +279,7 @@ class DenseDiffPool(Workload):
     def cpu_pass(self):
         """reference base_reduce.py:158-161 + dense_conn.py:111-122 + ops.py:282-335 on the first graphs of THIS batch."""
         O = _oracle()
-        bs = min(self.B, 8 if self.which == "c2" else 1)
+        bs = min(self.B, 8 if self.which in ("c2", "c2_f64") else 1)
         S, A, X = self.S[:bs].cpu(), self.A[:bs].cpu(), self.X[:bs].cpu()
 
         def one_pass():
@@ -278,12 +287,24 @@ class DenseDiffPool(Workload):
             O.postprocess_dense(O.dense_connect(S, A), True, True, True, False)
 
         return one_pass, bs * self.N, (f"the first {bs} of the {self.B} graphs of the measured batch "
-                                       f"(N={self.N},K={self.K},F={self.F})"), (10.0 if self.which == "c2" else 6.0)
+                                       f"(N={self.N},K={self.K},F={self.F})"), (10.0 if self.which != "c5" else 6.0)
 
     def rooflines(self, dev):
         from tgp import kernels
         flops = 2.0 * self.B * self.N * self.N * self.K
-        ms = event_time_ms(lambda: kernels.bmm(self.A, self.S), 50 if self.which == "c2" else 10, dev)
+        ms = event_time_ms(lambda: kernels.bmm(self.A, self.S), 50 if self.which != "c5" else 10, dev)
+        if self.f64:
+            a = flops / (ms * 1e-3) / 1e12
+            r = {"kernel": "tgp::gemm_f64_mfma_kernel<false, true> (U = A S on v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+                 "achieved": round(a, 2), "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(a / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": None, "traffic_source": None,
+                 "peak_source": "AMD MI355X data sheet (fp64 matrix = half the fp32-input MFMA rate); the guide has no "
+                                "fp64 row; rocBLAS dgemm reaches 76.7 TFLOP/s on this part",
+                 "flops_per_launch": flops, "avg_launch_ms": round(ms, 5)}
+            ms_lib = event_time_ms(lambda: torch.bmm(self.A, self.S), 50, dev)
+            r["rocblas_dgemm_same_operands_ms"] = round(ms_lib, 5)
+            r["whole_step_flops"] = flops + 2.0 * self.B * self.K * self.N * (self.K + self.F)
+            return r
         r = roof_mfma("tgp::gemm_f32_mfma_kernel<false> (U = A S)", flops, ms,
                       f"gemm_f32_mfma_kernel<false>:{self.which}")
         step_flops = flops + 2.0 * self.B * self.K * self.N * (self.K + self.F)
@@ -873,7 +894,7 @@ class GraclusC4(Workload):
 
 
 def make_workload(which, ctx, args):
-    if which in ("c2", "c5"):
+    if which in ("c2", "c5", "c2_f64"):
         return DenseDiffPool(which, ctx, unfused=args.unfused,
                              force_collective=os.environ.get("TGP_BENCH_FORCE_DIST") == "1")
     if which == "c3":
@@ -921,6 +942,11 @@ def run_secondary(which, ctx, args):
         fl = roofs[0]["whole_step_flops"]
         out["whole_step"] = {"flops": fl, "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
                              "frac_of_fp32_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+    if which == "c2_f64":
+        fl = roofs[0]["whole_step_flops"]
+        out["dtype"] = "f64"
+        out["whole_step"] = {"flops": fl, "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                             "frac_of_fp64_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS, 4)}
     if ctx.world == 1 and ctx.rank == 0 and not args.no_cpu_baseline and hasattr(wl, "cpu_pass"):
         out["cpu_baseline"] = cpu_baseline(*wl.cpu_pass())
     del wl
@@ -981,11 +1007,11 @@ def cpu_baseline(one_pass, nodes, sample, budget_s=10.0, min_passes=2):
 
 
 # ------------------------------------------------------------------------------------------------ main
-ALL = ["c2", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect", "topk_batch", "graclus_batch",
+ALL = ["c2", "c2_f64", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect", "topk_batch", "graclus_batch",
        "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3"]
-SECONDARY_DEFAULT = ["c5", "topk1m", "topk_connect", "c4_graclus", "c4_ndp", "c3", "topk_batch", "graclus_batch",
+SECONDARY_DEFAULT = ["c5", "c2_f64", "topk1m", "topk_connect", "c4_graclus", "c4_ndp", "c3", "topk_batch", "graclus_batch",
                      "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3"]
-SHARDED = ("c5", "c3", "topk_batch", "graclus_batch", "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2",
+SHARDED = ("c5", "c2_f64", "c3", "topk_batch", "graclus_batch", "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2",
            "e2e_mincut_c3", "e2e_train_mincut_c3")
 
 

@@ -577,6 +577,11 @@ int tgp_postprocess_dense_bwd_f32(const float* raw, const float* g_post, int64_t
 int tgp_to_dense_adj_f32(const int64_t* row, const int64_t* col, const float* edge_weight /* NULL = ones */,
                          int64_t num_edges, const int64_t* batch, const int64_t* ptr, int64_t B, int64_t Nmax,
                          int transposed, int adj_is_zeroed, float* adj, void* stream);
+/* the same for multi-channel edge attributes [E, C] (PyG to_dense_adj with a 2-D edge_attr): adj [B,Nmax,Nmax,C],
+ * zero-filled inside, duplicates summed per channel (r5) */
+int tgp_to_dense_adj_channels_f32(const int64_t* row, const int64_t* col, const float* edge_attr /* [E, C] */,
+                                  int64_t num_edges, int64_t num_channels, const int64_t* batch, const int64_t* ptr,
+                                  int64_t B, int64_t Nmax, int transposed, float* adj, void* stream);
 /* inverse gather of tgp_to_dense_adj_f32 (its backward w.r.t. the edge weights, which the reference gets from ATen
  * autograd over PyG's scatter, src.py:434): grad_weight[e] = grad_adj[slot of e], 0 for dropped entries */
 int tgp_from_dense_adj_f32(const float* grad_adj, const int64_t* row, const int64_t* col, int64_t num_edges,

@@ -492,3 +492,27 @@ def test_float64_filter_edges_has_a_staged_fallback(dev, monkeypatch):
     finally:
         torch.set_default_dtype(old)
     assert torch.equal(got_ei.cpu(), r_ei) and torch.equal(got_w.cpu(), r_w)
+
+
+def test_to_dense_adj_with_multi_channel_edge_attributes(dev):
+    """PyG to_dense_adj with edge_attr [E, C] (reference src.py:434): native scatter-add on the device (r5; a torch
+    index_add_ form before), against the torch form on the host, both orientations, duplicates summed, max_num_nodes."""
+    from tgp.src import to_dense_adj
+    g = torch.Generator().manual_seed(8)
+    sizes = torch.tensor([5, 9, 1, 7])
+    batch = torch.repeat_interleave(torch.arange(4), sizes)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    rows, cols = [], []
+    for b in range(4):
+        m = int(sizes[b])
+        r = torch.randint(0, m, (3 * m,), generator=g) + ptr[b]
+        c = torch.randint(0, m, (3 * m,), generator=g) + ptr[b]
+        rows.append(r); cols.append(c)
+    ei = torch.stack([torch.cat(rows), torch.cat(cols)])       # duplicates included
+    attr = torch.randn(ei.size(1), 3, generator=g)
+    for transposed in (False, True):
+        for nmax in (None, 6):
+            want = to_dense_adj(ei, batch, attr, max_num_nodes=nmax, transposed=transposed)          # host: torch form
+            got = to_dense_adj(ei.to(dev), batch.to(dev), attr.to(dev), max_num_nodes=nmax, transposed=transposed)
+            assert got.shape == want.shape
+            torch.testing.assert_close(got.cpu(), want.contiguous(), rtol=1e-6, atol=1e-6)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box into gpurun_out/<tag>/ (copy what is to be judged into profiles/).
 # usage: tools/collect_profiles.sh <tag>
-tag=${1:-r04}
+tag=${1:-r05}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/$tag
 mkdir -p $out
@@ -24,6 +24,9 @@ stats bench python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
 stats c4_graclus_sorted python3 bench.py --workload c4_graclus --secondary none --no-cpu-baseline --steps 50
 stats c4_graclus_unsorted python3 bench.py --workload c4_graclus --unsorted-edges --secondary none --no-cpu-baseline --steps 50
 stats topk_connect python3 bench.py --workload topk_connect --secondary none --no-cpu-baseline --steps 50
+stats c2_f64 python3 bench.py --workload c2_f64 --secondary none --no-cpu-baseline --steps 20
+python3 tools/bench_f64.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $out/fp64_dense.txt
+python3 tools/fresh_profile.py topk_c3 graclus_c3 mincut_c3 2>&1 | grep -E "^==|us  |GPU-busy" > $out/fresh_profile_kernels.txt
 stats kron python3 tools/bench_kron.py --no-reference
 python3 tools/bench_kron.py > $out/kron.txt 2>&1
 python3 tools/e2e_launches.py > $out/e2e_launches.txt 2>&1
@@ -39,6 +42,13 @@ for k in coalesce_c4_sorted subgraph_topk c3 reduce_topk reduce_ndp reduce_gracl
   pmc $k FETCH_SIZE python3 tools/run_kernel.py $k 4
   pmc $k WRITE_SIZE python3 tools/run_kernel.py $k 4
 done
+# r5 (verdict r4 item 5): L2 hit / miss of the coalesce Connect's kernels (the cluster-table look-ups of cr_gather_sort_kernel)
+pmc coalesce_c4_sorted TCC_HIT_sum python3 tools/run_kernel.py coalesce_c4_sorted 4
+pmc coalesce_c4_sorted TCC_MISS_sum python3 tools/run_kernel.py coalesce_c4_sorted 4
+cp $out/pmc_coalesce_c4_sorted_TCC_HIT_sum.csv $out/tcc_hit_coalesce.csv 2>/dev/null
+cp $out/pmc_coalesce_c4_sorted_TCC_MISS_sum.csv $out/tcc_miss_coalesce.csv 2>/dev/null
+rm -f $out/pmc_coalesce_c4_sorted_TCC_*.csv  # (pmc_summary.py reads every pmc_*_*.csv as a FETCH / WRITE pass)
+python3 tools/tcc_summary.py $out/tcc_hit_coalesce.csv $out/tcc_miss_coalesce.csv > $out/tcc_coalesce.md 2>&1
 python3 tools/pmc_summary.py $out --json $out/roofline_traffic.json --source profiles/${tag}_pmc_summary.md > $out/pmc_summary.md
-rm -rf $out/pmc_*_FETCH_SIZE $out/pmc_*_WRITE_SIZE $out/bench $out/c4_graclus_sorted $out/c4_graclus_unsorted $out/topk_connect $out/kron
+rm -rf $out/pmc_*_FETCH_SIZE $out/pmc_*_WRITE_SIZE $out/pmc_*_TCC_HIT_sum $out/pmc_*_TCC_MISS_sum $out/bench $out/c4_graclus_sorted $out/c4_graclus_unsorted $out/topk_connect $out/kron
 ls $out | head -60

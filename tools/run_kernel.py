@@ -104,9 +104,11 @@ elif which == "subgraph_topk":
     ei = torch.stack([torch.cat([a, b]), torch.cat([b, a])])
     ei = ei[:, torch.argsort(ei[0] * n + ei[1])].contiguous()
     ew = torch.ones(ei.size(1), device=dev)
-    kept = torch.sort(torch.randperm(n, device=dev, generator=g)[: n // 2])[0]
-    so = SelectOutput(node_index=kept, num_nodes=n, cluster_index=torch.arange(kept.numel(), device=dev),
-                      num_supernodes=kept.numel())
+    # (as bench.py's topk_connect: the SelectOutput of the real selector, with the bitmap + rank directory it attaches)
+    from tgp.select import TopkSelect
+    torch.manual_seed(0)
+    with torch.no_grad():
+        so = TopkSelect(in_channels=8, ratio=0.5).to(dev)(x=torch.randn(n, 8, device=dev, generator=g))
     conn = SparseConnect()
     marker()
     for _ in range(reps):

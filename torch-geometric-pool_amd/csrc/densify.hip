@@ -24,6 +24,25 @@ __global__ __launch_bounds__(256) void dense_adj_kernel(const int64_t* __restric
   atomicAdd(adj + o, w ? w[e] : 1.0f);
 }
 
+// Multi-channel edge attributes [E, C] -> [B, Nmax, Nmax, C] (PyG to_dense_adj with a 2-D edge_attr, src.py:434): one
+// thread per (edge, channel), channels contiguous, duplicates summed.  (r5: the last torch-form scatter of the path.)
+__global__ __launch_bounds__(256) void dense_adj_channels_kernel(const int64_t* __restrict__ row,
+                                                                 const int64_t* __restrict__ col,
+                                                                 const float* __restrict__ attr, int64_t E, int64_t C,
+                                                                 const int64_t* __restrict__ batch,
+                                                                 const int64_t* __restrict__ ptr, int64_t Nmax,
+                                                                 int transposed, float* __restrict__ adj) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= E * C) return;
+  const int64_t e = t / C, ch = t - e * C;
+  const int64_t r = row[e], c = col[e];
+  const int64_t b = batch[r];
+  const int64_t lr = r - ptr[b], lc = c - ptr[batch[c]];
+  if (lr >= Nmax || lc >= Nmax) return;
+  const int64_t o = transposed ? (b * Nmax + lc) * Nmax + lr : (b * Nmax + lr) * Nmax + lc;
+  atomicAdd(adj + o * C + ch, attr[t]);
+}
+
 // The inverse gather (backward of to_dense_adj w.r.t. the edge weights): dw[e] = g[b, r, c] at the slot edge e was
 // added to; 0 for entries a caller-imposed max_num_nodes dropped.  Duplicates each receive the slot's gradient.
 __global__ __launch_bounds__(256) void from_dense_adj_kernel(const float* __restrict__ g, const int64_t* __restrict__ row,
@@ -373,6 +392,21 @@ extern "C" int tgp_to_dense_adj_f32(const int64_t* row, const int64_t* col, cons
     hipLaunchKernelGGL(dense_adj_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, row, col, w, E, batch, ptr, Nmax,
                        transposed, adj);
   return check_launch("tgp_to_dense_adj_f32");
+}
+
+extern "C" int tgp_to_dense_adj_channels_f32(const int64_t* row, const int64_t* col, const float* attr, int64_t E,
+                                             int64_t C, const int64_t* batch, const int64_t* ptr, int64_t B,
+                                             int64_t Nmax, int transposed, float* adj, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E >= 0 && C >= 0 && B >= 0 && Nmax >= 0, TGP_ERR_INVALID, "tgp_to_dense_adj_channels_f32: negative size");
+  if (B == 0 || Nmax == 0 || C == 0) return TGP_OK;
+  TGP_REQUIRE(adj && (E == 0 || (row && col && attr && batch && ptr)), TGP_ERR_INVALID,
+              "tgp_to_dense_adj_channels_f32: null pointer");
+  (void)hipMemsetAsync(adj, 0, sizeof(float) * B * Nmax * Nmax * C, stream);
+  if (E > 0)
+    hipLaunchKernelGGL(dense_adj_channels_kernel, dim3(cdiv(E * C, 256)), dim3(256), 0, stream, row, col, attr, E, C,
+                       batch, ptr, Nmax, transposed, adj);
+  return check_launch("tgp_to_dense_adj_channels_f32");
 }
 
 extern "C" int tgp_to_dense_batch_f32(const float* x, int64_t N, int64_t F, const int64_t* batch,

@@ -140,31 +140,54 @@ __global__ __launch_bounds__(256) void f64_post_dense_kernel(const double* __res
   double* o = dst + b * K * K;
   double* d = deg_ws + b * K;
   const bool rsl = (flags & TGP_REMOVE_SELF_LOOPS) != 0;
-  auto at = [&](int64_t r, int64_t c) -> double { return (rsl && r == c) ? 0.0 : a[r * K + c]; };
+  // (the load is unconditional and the diagonal is masked afterwards: a conditional load is waited for before the next
+  //  one is issued -- r5: this kernel took 55 us at B = 32, K = 128 with one exposed round trip per element)
+  auto at = [&](int64_t r, int64_t c) -> double {
+    const double v = a[r * K + c];
+    return (rsl && r == c) ? 0.0 : v;
+  };
   if (flags & TGP_DEGREE_NORM) {
-    for (int64_t i = threadIdx.x; i < K; i += 256) {
-      double acc = 0.0;  // sum over axis -2 (rows) when adj_transpose, else over axis -1 (ops.py:312-314)
-      if (flags & TGP_SUM_AXIS_ROWS)
+    // sum over axis -2 (rows) when adj_transpose, else over axis -1 (ops.py:312-314), in index order.  Column sums: a
+    // thread per column (coalesced across the threads).  Row sums: a WAVE per row, lanes stride over the columns and
+    // keep eight loads in flight, partial sums folded by a fixed shuffle tree.
+    if (flags & TGP_SUM_AXIS_ROWS) {
+      for (int64_t i = threadIdx.x; i < K; i += 256) {
+        double acc = 0.0;
+#pragma unroll 8
         for (int64_t r = 0; r < K; ++r) acc += at(r, i);
-      else
-        for (int64_t c = 0; c < K; ++c) acc += at(i, c);
-      d[i] = sqrt(fmax(acc, eps));
+        d[i] = sqrt(fmax(acc, eps));
+      }
+    } else {
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      for (int64_t i = wv; i < K; i += 4) {
+        double acc = 0.0;
+#pragma unroll 4
+        for (int64_t c = lane; c < K; c += 64) acc += at(i, c);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) d[i] = sqrt(fmax(acc, eps));
+      }
     }
   }
   if (threadIdx.x == 0) s_max = 0ull;
   __syncthreads();
   unsigned long long m = 0;
-  for (int64_t i = threadIdx.x; i < K * K; i += 256) {
-    const int64_t r = i / K, c = i - r * K;
-    double v = at(r, c);
-    if (flags & TGP_DEGREE_NORM) {
-      // (adj / d) / d^T with d broadcast along the summed axis: d[c] then d[r] for axis -2, d[r] then d[c] for axis -1
-      if (flags & TGP_SUM_AXIS_ROWS) v = (v / d[c]) / d[r];
-      else v = (v / d[r]) / d[c];
+  {  // a wave per row, lanes over the columns: no 64-bit division per element
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t r = wv; r < K; r += 4) {
+      const double dr = (flags & TGP_DEGREE_NORM) ? d[r] : 1.0;
+      for (int64_t c = lane; c < K; c += 64) {
+        double v = at(r, c);
+        if (flags & TGP_DEGREE_NORM) {
+          // (adj / d) / d^T with d broadcast along the summed axis: d[c] then d[r] for axis -2, d[r] then d[c] for axis -1
+          if (flags & TGP_SUM_AXIS_ROWS) v = (v / d[c]) / dr;
+          else v = (v / dr) / d[c];
+        }
+        o[r * K + c] = v;
+        const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(v)));
+        m = m > bits ? m : bits;
+      }
     }
-    o[i] = v;
-    const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(fabs(v)));
-    m = m > bits ? m : bits;
   }
   if (flags & TGP_EDGE_WEIGHT_NORM) {
     atomicMax(&s_max, m);

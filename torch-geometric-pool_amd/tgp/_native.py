@@ -148,6 +148,8 @@ SIGNATURES = {
     "tgp_rowptr_from_sorted_i64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_spmm_csr_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p]),
     "tgp_to_dense_adj_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_int, _c_p, _c_p]),
+    "tgp_to_dense_adj_channels_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p,
+                                               _c_p]),
     "tgp_from_dense_adj_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_int, _c_p, _c_p]),
     "tgp_from_dense_batch_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_to_dense_batch_sorted_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p]),

@@ -1898,6 +1898,22 @@ def to_dense_adj(edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tenso
     return adj
 
 
+def to_dense_adj_channels(edge_index: Tensor, edge_attr: Tensor, batch: Tensor, ptr: Tensor, num_graphs: int,
+                          max_nodes: int, transposed: bool) -> Tensor:
+    """PyG to_dense_adj with multi-channel edge attributes [E, C] (src.py:434): [B,Nmax,Nmax,C], duplicates summed."""
+    dev = N.require_device(edge_index, edge_attr, batch, ptr)
+    row, col = _edge_rows(edge_index)
+    E = row.numel()
+    a = N.f32c(edge_attr.reshape(E, -1))
+    C = a.size(1)
+    batch, ptr = N.i64c(batch), N.i64c(ptr)
+    adj = torch.empty(num_graphs, max_nodes, max_nodes, C, dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_to_dense_adj_channels_f32(N.ptr(row), N.ptr(col), N.ptr(a), E, C, N.ptr(batch), N.ptr(ptr),
+                                                  num_graphs, max_nodes, 1 if transposed else 0, N.ptr(adj),
+                                                  N.stream_ptr(dev)), "tgp_to_dense_adj_channels_f32")
+    return adj.view((num_graphs, max_nodes, max_nodes) + tuple(edge_attr.shape[1:]))
+
+
 def from_dense_adj(grad_adj: Tensor, edge_index: Tensor, batch: Tensor, ptr: Tensor, max_nodes: int,
                    transposed: bool) -> Tensor:
     """grad of :func:`to_dense_adj` w.r.t. the edge weights: one gather kernel."""

@@ -271,7 +271,16 @@ def to_dense_adj(edge_index: Tensor, batch: Optional[Tensor] = None, edge_attr: 
         nmax = max_num_nodes if max_num_nodes is not None else max_graph_size(batch)
         # one HIP kernel; differentiable w.r.t. the edge weights through the matching gather kernel
         return Fn.to_dense_adj(edge_index, edge_attr, batch, ptr, batch_size, nmax, transposed)
-    # what is left for the torch form below: host tensors (CPU-side data preparation) and multi-channel edge attributes
+    if (edge_index.is_cuda and edge_attr is not None and edge_attr.dim() >= 2 and edge_attr.dtype == torch.float32
+            and edge_attr.size(0) == edge_index.size(1) and edge_attr[0].numel() > 0 and batch.numel() > 0
+            and not (torch.is_grad_enabled() and edge_attr.requires_grad)):
+        # multi-channel edge attributes (r5): one native scatter-add, [B,Nmax,Nmax,C]; `transposed` swaps the two node
+        # axes in the kernel (the torch form below returns the transposed view of the same values)
+        from . import kernels as K
+        nmax = max_num_nodes if max_num_nodes is not None else max_graph_size(batch)
+        return K.to_dense_adj_channels(edge_index, edge_attr, batch, ptr, batch_size, nmax, transposed)
+    # what is left for the torch form below: host tensors (CPU-side data preparation), float64 / differentiable
+    # multi-channel edge attributes
     g = batch[edge_index[0]]
     r = edge_index[0] - ptr[g]
     c = edge_index[1] - ptr[batch[edge_index[1]]]
