@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10026 /* 1.0.1 of the reference, ABI revision 26 (r5: fp64 dense path on v_mfma_f64_16x16x4_f64) */
+#define TGP_ABI_VERSION 10027 /* 1.0.1 of the reference, ABI revision 27 (r5: fp64 dense path on v_mfma_f64_16x16x4_f64; one-launch selector backward) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -344,21 +344,28 @@ int tgp_dense_pool_mincut_f32(const float* S, const float* A, const float* X, in
 int tgp_dense_pool_select_f32(const float* X, const float* A, const float* W, const float* bias,
                               const unsigned char* mask, int64_t B, int64_t N, int64_t K, int64_t F, int flags,
                               float eps, float loss_eps, float* S_out, float* x_pool, float* adj_raw, float* adj_pool,
-                              float* mincut_terms /* [2,B] or NULL */, void* stream);
+                              float* mincut_terms /* [2,B] or NULL */,
+                              int64_t* batch_pool /* [B*K] or NULL: arange(B).repeat_interleave(K), utils/ops.py:152-169 */,
+                              void* stream);
 
 /* Backward of that call for the same batches (what autograd derives operator by operator from base_reduce.py:158-161,
  * dense_conn.py:111-122, utils/ops.py:282-335 and utils/losses.py:39-70: ~80 launches in a MinCut training step), ONE
  * launch: from the upstream gradients of x_pool [B,K,F], of the post-processed adj_pool [B,K,K], of the raw S^T A S
  * [B,K,K] and of the two per-graph terms [2,B] (each may be NULL = zero) it writes gS [B,N,K] and, when gX is given,
  * gX [B,N,F].  flags as in the forward call (TGP_EDGE_WEIGHT_NORM is refused); A receives no gradient.
- * DiffPool's two batch-wide losses (utils/losses.py:644-658) ride along when g_diff [2] (upstream gradients of
- * link = link_scale * ||A - S S^T||_F and ent = ent_scale * sum(-S log(S + ent_eps))) and diff_losses [2] (their forward
- * values, tgp_diffpool_loss_tail_f32's output) are given; both NULL otherwise. */
+ * DiffPool's two batch-wide losses (utils/losses.py:644-658) ride along when diff_losses [2] (their forward values,
+ * tgp_diffpool_loss_tail_f32's output) and g_link / g_ent (device scalars: the upstream gradients of
+ * link = link_scale * ||A - S S^T||_F and ent = ent_scale * sum(-S log(S + ent_eps)); each may be NULL) are given.
+ * r5: g_mean_cut / g_mean_ortho (device scalars, each may be NULL): upstream gradients of the MEANS over the batch of
+ * the two per-graph terms -- what poolers/mincut.py:226-237 returns as cut_loss / ortho_loss -- added to g_terms[.,b]
+ * as *g / B inside the kernel; grad_bcast bit 0 / bit 1: g_x_pool / g_adj_pool points at ONE value that stands for
+ * every element (the gradient of `x_pool.sum()` arrives from autograd as an expanded scalar; no [B,K,F] copy is made). */
 int tgp_dense_pool_small_bwd_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K,
                                  int64_t F, int flags, float eps, float loss_eps, const float* g_x_pool,
                                  const float* g_adj_pool, const float* g_adj_raw, const float* g_terms,
-                                 const float* g_diff, const float* diff_losses, float link_scale, float ent_scale,
-                                 float ent_eps, float* gS, float* gX, void* stream);
+                                 const float* g_mean_cut, const float* g_mean_ortho, const float* g_link,
+                                 const float* g_ent, const float* diff_losses, float link_scale, float ent_scale,
+                                 float ent_eps, int grad_bcast, float* gS, float* gX, void* stream);
 
 /* Generic batched fp32 GEMM on the matrix cores, C[b] = op(A[b]) B[b] with B[b] [Kd,Nc] row-major.
  * trans_a = 0: A[b] is [M,Kd] row-major; 1: A[b] is stored [Kd,M] (C = A^T B).  Used by
@@ -726,6 +733,18 @@ int tgp_mlp_select_f32(const float* x, const float* weight, const float* bias, c
                        int64_t F, int64_t K, float* s_out, void* stream);
 int tgp_softmax_rows_f32(float* y, const float* bias, const unsigned char* mask, int64_t M, int64_t K, void* stream);
 int tgp_softmax_bwd_f32(const float* s, const float* ds, float* dy, int64_t M, int64_t K, void* stream);
+/* r5: the whole backward of that layer (K <= 32, F <= 64: tgp_mlp_select_bwd_fits) in one pass over S, dS and X: it
+ * forms dY = S (dS - <dS,S>) and writes gx [M,F] = dY W (accumulate_gx != 0: adds to what gx holds -- the gradient the
+ * pooling backward already left there), gw [K,F] = dY^T X and gb [K] = column sums of dY (gx / gw / gb may be NULL; gb
+ * needs gw).  What autograd derives from select/mlp_select.py:139-145 as softmax backward + two matmul backwards + a bias
+ * reduction + the accumulation of the two gradients of X: eight launches; here one, plus -- when gw is asked for -- a
+ * second tiny one that adds the workgroups' partial gw / gb (in `ws`, tgp_mlp_select_bwd_workspace_bytes) in a fixed
+ * order.  No float atomics: results are run-to-run identical. */
+int tgp_mlp_select_bwd_fits(int64_t F, int64_t K);
+size_t tgp_mlp_select_bwd_workspace_bytes(int64_t M, int64_t F, int64_t K);
+int tgp_mlp_select_bwd_f32(const float* s, const float* ds, const float* x, const float* weight, int64_t M, int64_t F,
+                           int64_t K, float* gx, int accumulate_gx, float* gw, float* gb, void* ws, size_t ws_bytes,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------
  * test hooks for the shared primitives (device-wide stable LSD radix sort, block scan)

@@ -2,6 +2,8 @@
 the per-graph products of the unbatched mode, their gradients -- against the oracle evaluated in float64, and
 torch.autograd.gradcheck in double on the dense poolers (reference: reduce/base_reduce.py:158-190,
 connect/dense_conn.py:111-208, which run model.double() inputs through torch.matmul in fp64)."""
+import os
+import sys
 import warnings
 
 import pytest
@@ -516,3 +518,186 @@ def test_to_dense_adj_with_multi_channel_edge_attributes(dev):
             got = to_dense_adj(ei.to(dev), batch.to(dev), attr.to(dev), max_num_nodes=nmax, transposed=transposed)
             assert got.shape == want.shape
             torch.testing.assert_close(got.cpu(), want.contiguous(), rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ r5: the dense poolers' training step in fewer launches
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,F", [(1000, 20, 32), (64 * 3 + 5, 7, 16), (5000, 32, 64), (300, 13, 50), (122880, 20, 32),
+                                   (63, 1, 1), (4097, 32, 33), (64, 4, 3), (129, 31, 17)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_selector_backward_in_one_launch_vs_autograd(dev, M, K, F, accumulate):
+    """tgp_mlp_select_bwd_f32 against torch autograd of softmax(x W^T + b) * mask in float64 (select/mlp_select.py:139-145):
+    gx (also added in place to an existing gradient), gw, gb; twice the same bits (fixed-order partial sums)."""
+    from tgp import kernels as K_
+    g = torch.Generator().manual_seed(M + 7 * K + F)
+    x = torch.randn(M, F, generator=g).to(dev)
+    w = (torch.randn(K, F, generator=g) * 0.3).to(dev)
+    b = torch.randn(K, generator=g).to(dev)
+    mask = (torch.rand(M, generator=g) < 0.9).to(dev)
+    gs = torch.randn(M, K, generator=g).to(dev)
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    s64 = torch.softmax(x64 @ w64.t() + b64, -1) * mask.unsqueeze(-1)
+    (s64 * gs.double()).sum().backward()
+    s = K_.mlp_select(x, w, b, mask)
+    torch.testing.assert_close(s, s64.detach().float(), rtol=1e-5, atol=1e-6)
+    base = torch.randn(M, F, generator=g).to(dev) if accumulate else None
+    gx, gw, gb = K_.mlp_select_bwd(s, gs, x, w, gx_accumulate=None if base is None else base.clone())
+    want_gx = x64.grad.float() + (base if base is not None else 0)
+    torch.testing.assert_close(gx, want_gx, rtol=1e-4, atol=1e-5 * max(1.0, float(want_gx.abs().max())))
+    scale = max(1.0, float(w64.grad.abs().max()))
+    torch.testing.assert_close(gw, w64.grad.float(), rtol=2e-4, atol=2e-5 * scale * max(1.0, (M / 1000) ** 0.5))
+    torch.testing.assert_close(gb, b64.grad.float(), rtol=2e-4, atol=2e-5 * max(1.0, float(b64.grad.abs().max())))
+    gx2, gw2, gb2 = K_.mlp_select_bwd(s, gs, x, w, gx_accumulate=None if base is None else base.clone())
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2) and torch.equal(gx, gx2)
+    # only some gradients asked for
+    gx3, gw3, gb3 = K_.mlp_select_bwd(s, gs, x, w, want_gx=False, want_gb=False)
+    assert gx3 is None and gb3 is None and torch.equal(gw3, gw)
+    gx4, gw4, gb4 = K_.mlp_select_bwd(s, gs, x, w, want_gw=False, want_gb=False)
+    assert gw4 is None and gb4 is None
+    if not accumulate:
+        assert torch.equal(gx4, gx)
+
+
+@pytest.mark.gpu
+def test_selector_backward_is_run_to_run_identical_under_load(dev):
+    """gW / gb are partial sums per workgroup added in a fixed order by a second launch: 200 calls interleaved with
+    streaming copies on another stream and calls of other sizes must all give the first call's bits."""
+    from tgp import kernels as K_
+    g = torch.Generator().manual_seed(1)
+    M, K, F = 122880, 20, 32
+    x = torch.randn(M, F, generator=g).to(dev)
+    w = (torch.randn(K, F, generator=g) * 0.3).to(dev)
+    gs = torch.randn(M, K, generator=g).to(dev)
+    s = torch.softmax(torch.randn(M, K, generator=g), -1).to(dev)
+    big = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    x2, gs2, s2 = x[:5000], gs[:5000], s[:5000].contiguous()
+    ref = K_.mlp_select_bwd(s, gs, x, w)
+    ref2 = K_.mlp_select_bwd(s2, gs2, x2, w)
+    side = torch.cuda.Stream()
+    for it in range(200):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                big.copy_(big.flip(0) if it % 6 == 0 else big)  # memory traffic from another stream
+        got = K_.mlp_select_bwd(s, gs, x, w)
+        got2 = K_.mlp_select_bwd(s2, gs2, x2, w)
+        assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), it
+        assert torch.equal(got2[1], ref2[1]) and torch.equal(got2[2], ref2[2]), it
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], ref[0])
+
+
+@pytest.mark.gpu
+def test_selector_backward_outside_its_shapes_is_refused(dev):
+    from tgp import kernels as K_, _native as N
+    assert K_.mlp_select_bwd_fits(32, 64) and not K_.mlp_select_bwd_fits(33, 8) and not K_.mlp_select_bwd_fits(8, 65)
+    s = torch.rand(10, 40, device=dev)
+    with pytest.raises(N.TgpNativeError):
+        K_.mlp_select_bwd(s, s.clone(), torch.rand(10, 8, device=dev), torch.rand(40, 8, device=dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["mincut", "diff"])
+def test_fused_function_hands_the_two_losses_out_as_scalars(dev, which):
+    """functions.dense_pool_small(loss_scalars=True): the two auxiliary losses are 0-dim outputs (LossPair); their values
+    and the gradients they send equal the [2,B]-terms / [2]-diff form's; a sum loss (expanded scalar gradients, read by
+    the kernel as ONE value) equals the same loss with materialised gradients; a loss that uses only one of the two
+    leaves the other's upstream gradient missing (NULL in the C call)."""
+    from tgp import functions as Fn, kernels as K_
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_round3 import _ragged_dense_batch
+    B, Nmax, K, F = 90, 40, 20, 32
+    A, X, logits, mask = _ragged_dense_batch(B, Nmax, K, F, seed=11, dev=dev)
+    flags = K_.dense_flags(True, True, True, False)
+    scales = (0.37, 1.0 / int(mask.sum())) if which == "diff" else None
+
+    def run(scalars, loss_of):
+        l = logits.clone().requires_grad_(True)
+        x = X.clone().requires_grad_(True)
+        S = torch.softmax(l, -1) * mask.unsqueeze(-1)
+        out = Fn.dense_pool_small(S, A, x, flags, which == "mincut", which == "mincut", scales, loss_scalars=scalars)
+        loss_of(out).backward()
+        return out, l.grad, x.grad
+
+    def pair_of(out):
+        return out[4] if which == "diff" else out[3]
+
+    def old_loss(out):
+        p = pair_of(out)
+        both = p if which == "diff" else p.mean(dim=1)
+        return out[0].sum() + out[2].sum() * 0.5 + both[0] * 1.7 - both[1] * 0.3
+
+    def new_loss(out):
+        p = pair_of(out)
+        assert isinstance(p, Fn.LossPair) and p[0].dim() == 0 and p[1].dim() == 0
+        return out[0].sum() + out[2].sum() * 0.5 + p[0] * 1.7 - p[1] * 0.3
+
+    o_old, gl_old, gx_old = run(False, old_loss)
+    o_new, gl_new, gx_new = run(True, new_loss)
+    p_old, p_new = pair_of(o_old), pair_of(o_new)
+    both_old = p_old if which == "diff" else p_old.mean(dim=1)
+    torch.testing.assert_close(torch.stack(list(p_new)), both_old.detach(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(gl_new, gl_old, rtol=1e-4, atol=1e-6 * max(1.0, float(gl_old.abs().max())))
+    torch.testing.assert_close(gx_new, gx_old, rtol=1e-5, atol=1e-6)
+    # materialised upstream gradients of the same sum loss
+    _, gl_m, gx_m = run(True, lambda out: (out[0] * torch.ones_like(out[0])).sum()
+                        + (out[2] * torch.full_like(out[2], 0.5)).sum() + pair_of(out)[0] * 1.7 - pair_of(out)[1] * 0.3)
+    torch.testing.assert_close(gl_new, gl_m, rtol=1e-5, atol=1e-7 * max(1.0, float(gl_m.abs().max())))
+    torch.testing.assert_close(gx_new, gx_m, rtol=1e-6, atol=1e-7)
+    # one loss only
+    _, gl_one, _ = run(True, lambda out: pair_of(out)[1] * 2.0)
+    _, gl_ref, _ = run(False, lambda out: (pair_of(out) if which == "diff" else pair_of(out).mean(dim=1))[1] * 2.0)
+    torch.testing.assert_close(gl_one, gl_ref, rtol=1e-4, atol=1e-6 * max(1.0, float(gl_ref.abs().max())))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alias", ["mincut", "diff"])
+def test_dense_pooler_training_step_as_one_autograd_node(dev, alias, monkeypatch):
+    """get_pooler('mincut' / 'diff') with a single-Linear selector on a PROTEINS-shaped sparse batch, training: Select +
+    Reduce + Connect + losses run as functions._SelectPoolSmallFn (forward tgp_dense_pool_select_f32, backward
+    tgp_dense_pool_small_bwd_f32 + tgp_mlp_select_bwd_f32); outputs, losses and every gradient equal the two-node form's
+    (TGP_FOLD_TRAINING=0), and S stays differentiable for a caller's own use."""
+    from tgp import kernels as K_
+    from tgp import poolers as P
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(5)
+    sizes = torch.randint(20, 61, (96,), generator=g)
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(96), sizes).to(dev)
+    start = (torch.cumsum(sizes, 0) - sizes).to(dev)
+    src = torch.arange(n, device=dev).repeat_interleave(2)
+    dst = start[batch[src]] + (torch.rand(src.numel(), device=dev) * sizes.to(dev)[batch[src]]).long()
+    keep = src != dst
+    key = torch.unique(torch.cat([src[keep] * n + dst[keep], dst[keep] * n + src[keep]]))
+    ei = torch.stack([key // n, key % n])
+    x0 = torch.randn(n, 32, device=dev)
+    torch.manual_seed(0)
+    pooler = get_pooler(alias, in_channels=32, k=20).to(dev).train()
+    calls = []
+    real = K_.mlp_select_bwd
+    monkeypatch.setattr(K_, "mlp_select_bwd", lambda *a, **k: (calls.append(k.get("gx_accumulate") is not None), real(*a, **k))[1])
+
+    def step(extra_s):
+        pooler.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        out = pooler(x=x, adj=ei, batch=batch)
+        loss = out.x.square().sum() + out.edge_index.sum() + sum(out.loss.values())
+        if extra_s:
+            loss = loss + (out.so.s * out.so.s).sum() * 0.1
+        loss.backward()
+        return (out.x.detach(), out.edge_index.detach(), {k: v.detach() for k, v in out.loss.items()}, x.grad,
+                [p.grad.clone() for p in pooler.parameters()])
+
+    for extra_s in (False, True):
+        calls.clear()
+        monkeypatch.setattr(P, "_FOLD_TRAINING", True)
+        new = step(extra_s)
+        assert calls == [True], calls  # one selector backward, accumulating into the pooling backward's gX
+        monkeypatch.setattr(P, "_FOLD_TRAINING", False)
+        old = step(extra_s)
+        torch.testing.assert_close(new[0], old[0], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(new[1], old[1], rtol=1e-5, atol=1e-6)
+        for k in old[2]:
+            torch.testing.assert_close(new[2][k], old[2][k], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(new[3], old[3], rtol=2e-4, atol=1e-5 * max(1.0, float(old[3].abs().max())))
+        for a, b in zip(new[4], old[4]):
+            torch.testing.assert_close(a, b, rtol=5e-4, atol=2e-5 * max(1.0, float(b.abs().max())))

@@ -4,7 +4,7 @@ launched a few times so that a profiler pass (`rocprofv3 --pmc TCC_HIT_sum TCC_M
     python3 tools/coalesce_variants.py VARIANT [--time]
 
 VARIANT: full | col32 (the int32 columns handed over with the CSR offsets: product code) | and, with the diagnostic
-build (`make -C torch-geometric-pool_amd/csrc stamps`): no_table (key = node id / 2, no look-up), dummy4 / dummy2 /
+build (full_diag / col32_diag = the same two on that build: its instrumentation costs time, compare within it), (`make -C torch-geometric-pool_amd/csrc stamps`): no_table (key = node id / 2, no look-up), dummy4 / dummy2 /
 dummy1 (that key plus a dropped look-up into 4- / 2- / 1-byte entries: table footprint 4 / 2 / 1 MB), nt_table
 (non-temporal look-ups), no_edges (synthetic node ids, look-ups stay).  Ablated variants give wrong edges: timing and
 counters only.  --time: median-free event timing of the whole Connect call instead (20 calls)."""
@@ -15,7 +15,7 @@ import sys
 import torch
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-ABLATE = {"no_table": 4, "dummy4": 256, "dummy2": 512, "dummy1": 1024, "nt_table": 16, "no_edges": 8}
+ABLATE = {"full_diag": 0, "col32_diag": 0, "no_table": 4, "dummy4": 256, "dummy2": 512, "dummy1": 1024, "nt_table": 16, "no_edges": 8}
 variant = sys.argv[1] if len(sys.argv) > 1 else "full"
 if variant in ABLATE:
     os.environ["TGP_HIP_LIB"] = os.path.join(ROOT, "torch-geometric-pool_amd", "lib", "libtgp_hip_stamps.so")
@@ -38,7 +38,7 @@ k = so.num_supernodes
 idx = so.assign_index()
 csr = (so.edge_csr_for(ei), None)  # what SparseConnect hands over: the offsets GraclusSelect built for this very list
 assert csr[0] is not None
-if variant == "col32":
+if variant in ("col32", "col32_diag"):
     csr = (csr[0], ei[1].to(torch.int32).contiguous())
 lib = _native.lib()
 if variant in ABLATE:

@@ -13,7 +13,7 @@ if os.path.exists(os.path.join(out, "times.txt")):
             times[p[0]] = float(p[4])
 print("| variant | whole Connect call, µs | gather-sort launches seen | TCC_HIT per launch | TCC_MISS per launch | hit rate |")
 print("|---|---|---|---|---|---|")
-for v in ("full", "col32", "no_table", "dummy4", "dummy2", "dummy1", "nt_table", "no_edges"):
+for v in ("full", "col32", "full_diag", "col32_diag", "no_table", "dummy4", "dummy2", "dummy1", "nt_table", "no_edges"):
     path = os.path.join(out, f"tcc_{v}.csv")
     if not os.path.exists(path):
         print(f"| {v} | {times.get(v, float('nan')):.1f} | (no counter file) | | | |")

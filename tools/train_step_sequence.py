@@ -25,10 +25,13 @@ kern = sorted([e for e in evs if e.device_type == torch.autograd.DeviceType.CUDA
 cpu = [e for e in evs if e.device_type == torch.autograd.DeviceType.CPU]
 print(f"{len(kern)} device activities in one step")
 t0 = kern[0].time_range.start
+owners = {}
+for c in cpu:
+    for k in getattr(c, "kernels", []):
+        key = (k.name, int(k.duration))
+        span = c.time_range.end - c.time_range.start
+        if key not in owners or span < owners[key][0]:
+            owners[key] = (span, c.name)
 for e in kern:
-    # innermost CPU op whose time range launched it: match through the correlation of linked kernels
-    owner = ""
-    for c in cpu:
-        if any(k is e or (k.name == e.name and k.time_range.start == e.time_range.start) for k in getattr(c, "kernels", [])):
-            owner = c.name
-    print(f"  +{(e.time_range.start - t0):8.1f} us  {e.device_time:7.1f} us  {e.name[:90]:90s}  <- {owner[:50]}")
+    owner = owners.get((e.name, int(e.device_time)), (0, ""))[1]
+    print(f"  +{(e.time_range.start - t0):8.1f} us  {e.device_time:7.1f} us  {e.name[:90]:90s}  <- {owner[:60]}")

@@ -122,7 +122,8 @@ extern "C" int tgp_dense_pool_mincut_f32(const float* S, const float* A, const f
 extern "C" int tgp_dense_pool_select_f32(const float* X, const float* A, const float* W, const float* bias,
                                          const unsigned char* mask, int64_t B, int64_t N, int64_t K, int64_t F,
                                          int flags, float eps, float loss_eps, float* S_out, float* x_pool,
-                                         float* adj_raw, float* adj_pool, float* mincut_terms, void* stream_) {
+                                         float* adj_raw, float* adj_pool, float* mincut_terms, int64_t* batch_pool,
+                                         void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0 && F >= 0, TGP_ERR_INVALID, "tgp_dense_pool_select_f32: negative size");
   if (B == 0 || N == 0 || K == 0) return TGP_OK;
@@ -133,7 +134,8 @@ extern "C" int tgp_dense_pool_select_f32(const float* X, const float* A, const f
   const bool want_a = A && (adj_raw || adj_pool);
   SmallArgs q{nullptr, want_a ? A : nullptr, X, static_cast<int>(B), static_cast<int>(N), static_cast<int>(K),
               static_cast<int>(F), flags, eps, x_pool, want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr,
-              want_a ? mincut_terms : nullptr, loss_eps, W, bias, mask, S_out};
+              want_a ? mincut_terms : nullptr, loss_eps, W, bias, mask, S_out,
+              reinterpret_cast<long long*>(batch_pool)};
   const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -146,9 +148,10 @@ extern "C" int tgp_dense_pool_select_f32(const float* X, const float* A, const f
 extern "C" int tgp_dense_pool_small_bwd_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N,
                                             int64_t K, int64_t F, int flags, float eps, float loss_eps,
                                             const float* g_x_pool, const float* g_adj_pool, const float* g_adj_raw,
-                                            const float* g_terms, const float* g_diff, const float* diff_losses,
-                                            float link_scale, float ent_scale, float ent_eps, float* gS, float* gX,
-                                            void* stream_) {
+                                            const float* g_terms, const float* g_mean_cut, const float* g_mean_ortho,
+                                            const float* g_link, const float* g_ent, const float* diff_losses,
+                                            float link_scale, float ent_scale, float ent_eps, int grad_bcast,
+                                            float* gS, float* gX, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0 && F >= 0, TGP_ERR_INVALID, "tgp_dense_pool_small_bwd_f32: negative size");
   if (B == 0 || N == 0 || K == 0) return TGP_OK;
@@ -158,10 +161,13 @@ extern "C" int tgp_dense_pool_small_bwd_f32(const float* S, const float* A, cons
   TGP_REQUIRE(!(flags & TGP_EDGE_WEIGHT_NORM), TGP_ERR_INVALID,
               "tgp_dense_pool_small_bwd_f32: edge_weight_norm is not differentiated by this entry");
   TGP_REQUIRE(!gX || X || !g_x_pool, TGP_ERR_INVALID, "tgp_dense_pool_small_bwd_f32: gX needs X");
-  TGP_REQUIRE(!g_diff || diff_losses, TGP_ERR_INVALID, "tgp_dense_pool_small_bwd_f32: g_diff needs diff_losses");
+  TGP_REQUIRE(!(g_link || g_ent) || diff_losses, TGP_ERR_INVALID,
+              "tgp_dense_pool_small_bwd_f32: g_link / g_ent need diff_losses");
+  TGP_REQUIRE((grad_bcast & ~3) == 0, TGP_ERR_INVALID, "tgp_dense_pool_small_bwd_f32: unknown grad_bcast bits");
   SmallBwdArgs q{S, A, X, static_cast<int>(B), static_cast<int>(N), static_cast<int>(K), static_cast<int>(F), flags,
-                 eps, loss_eps, X ? g_x_pool : nullptr, g_adj_pool, g_adj_raw, g_terms, g_diff, diff_losses, link_scale,
-                 ent_scale, ent_eps, gS, F > 0 ? gX : nullptr};
+                 eps, loss_eps, X ? g_x_pool : nullptr, g_adj_pool, g_adj_raw, g_terms, g_mean_cut, g_mean_ortho,
+                 grad_bcast, g_link, g_ent, (g_link || g_ent) ? diff_losses : nullptr, link_scale, ent_scale, ent_eps, gS,
+                 F > 0 ? gX : nullptr};
   const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_bwd_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -193,7 +199,7 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
     SmallArgs q{S, want_a ? A : nullptr, want_x ? X : nullptr, static_cast<int>(B), static_cast<int>(N),
                 static_cast<int>(K), static_cast<int>(F), flags, eps, want_x ? x_pool : nullptr,
                 want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr, want_a ? mincut_terms : nullptr, loss_eps,
-                nullptr, nullptr, nullptr, nullptr};
+                nullptr, nullptr, nullptr, nullptr, nullptr};
     const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -38,6 +38,9 @@ struct SmallArgs {
   // SelectOutput.s) and used from registers; p.S is ignored then.  sel_w [K,F], sel_b [K] or NULL, sel_mask [B,N] bytes
   // or NULL.
   const float* sel_w; const float* sel_b; const unsigned char* sel_mask; float* s_out;
+  // optional (r5) [B * K]: the pooled batch vector arange(B).repeat_interleave(K) (utils/ops.py:152-169), written by
+  // the graph's wave: one copy launch less per pooler call
+  long long* batch_pool;
 };
 
 __device__ __forceinline__ float sg_wave_sum(float v) {
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
   if (threadIdx.x == 0) s_issued = 0;
   __syncthreads();
   if (b >= p.B) return;
+  if (p.batch_pool && lane < K) p.batch_pool[static_cast<long>(b) * K + lane] = b;
   if (w >= SG_WAVES / 2) {  // second group: wait until the first group's requests are in the queue
     int first = p.B - static_cast<int>(blockIdx.x) * SG_WAVES;
     first = first < SG_WAVES / 2 ? first : SG_WAVES / 2;
@@ -436,9 +440,15 @@ struct SmallBwdArgs {
   const float* g_adj_pool;  // [B,K,K] or NULL
   const float* g_adj_raw;   // [B,K,K] or NULL
   const float* g_terms;     // [2,B] or NULL: upstream gradients of the per-graph cut / orthogonality terms
+  // ... or of their MEANS over the batch (what MinCutPooling hands out: two scalars, each may be NULL): a graph's
+  // term then receives *g_mean_* / B (r5: the mean's and the two selects' backward were seven launches of a few bytes)
+  const float* g_mean_cut; const float* g_mean_ortho;
+  // bit 0 / bit 1: g_x_pool / g_adj_pool is ONE value that stands for every element (the gradient of a plain sum
+  // arrives as an expanded scalar: no [B,K,F] copy of it is made)
+  int grad_bcast;
   // DiffPool's two batch-wide losses (utils/losses.py:644-658; both NULL = not part of this backward):
   //   link = link_scale * || A - S S^T ||_F over the whole batch,  ent = ent_scale * sum(-S log(S + ent_eps))
-  const float* g_diff;      // [2] upstream gradients of (link, ent)
+  const float* g_link; const float* g_ent;  // upstream gradients of (link, ent): two scalars, each may be NULL
   const float* diff_losses; // [2] the forward values (link = link_scale * norm gives the norm back)
   float link_scale, ent_scale, ent_eps;
   float* gS;                // [B,N,K]
@@ -535,13 +545,15 @@ __global__ __launch_bounds__(64 * SG_WAVES) void dense_pool_small_bwd_kernel(Sma
   }
   __builtin_amdgcn_wave_barrier();
   float c_link = 0.f, c_ent = 0.f;
-  if (p.g_diff) {
+  if (p.diff_losses) {
     const float lv = p.diff_losses[0];
-    c_link = lv != 0.f ? p.g_diff[0] * p.link_scale * p.link_scale / lv : 0.f;  // g * link_scale / ||A - S S^T||
-    c_ent = p.g_diff[1] * p.ent_scale;
+    if (p.g_link) c_link = lv != 0.f ? *p.g_link * p.link_scale * p.link_scale / lv : 0.f;  // g * link_scale / ||A - S S^T||
+    if (p.g_ent) c_ent = *p.g_ent * p.ent_scale;
   }
-  const float gt_cut = p.g_terms ? p.g_terms[b] : 0.f, gt_ortho = p.g_terms ? p.g_terms[p.B + b] : 0.f;
-  if (p.g_terms) {
+  float gt_cut = p.g_terms ? p.g_terms[b] : 0.f, gt_ortho = p.g_terms ? p.g_terms[p.B + b] : 0.f;
+  if (p.g_mean_cut) gt_cut += *p.g_mean_cut / static_cast<float>(p.B);
+  if (p.g_mean_ortho) gt_ortho += *p.g_mean_ortho / static_cast<float>(p.B);
+  if (p.g_terms || p.g_mean_cut) {
     float tr = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -605,6 +617,7 @@ __global__ __launch_bounds__(64 * SG_WAVES) void dense_pool_small_bwd_kernel(Sma
   __builtin_amdgcn_wave_barrier();  // the A tile is spent: its LDS is the transposition scratch from here on
 
   // ---- gR (C/D layout) -------------------------------------------------------------------------------------------
+  const int mx = (p.grad_bcast & 1) ? 0 : 1, ma = (p.grad_bcast & 2) ? 0 : 1;  // 0: the gradient is one broadcast value
   f32x16 gR;
   {
     float gP[16];
@@ -612,7 +625,8 @@ __global__ __launch_bounds__(64 * SG_WAVES) void dense_pool_small_bwd_kernel(Sma
     for (int r = 0; r < 16; ++r) {
       const int i = rho(r) + 4 * lk;
       const bool ok = p.g_adj_pool && i < K && lm < K;
-      const float t = *byte_off(p.g_adj_pool ? p.g_adj_pool + static_cast<long>(b) * K * K : p.S, ok ? (i * K + lm) * 4 : 0);
+      const float t = *byte_off(p.g_adj_pool ? p.g_adj_pool + static_cast<long>(b) * K * K * ma : p.S,
+                                ok ? (i * K + lm) * 4 * ma : 0);
       gP[r] = ok ? t : 0.f;
     }
     if (p.g_adj_pool && (p.flags & TGP_DEGREE_NORM)) {
@@ -746,13 +760,13 @@ __global__ __launch_bounds__(64 * SG_WAVES) void dense_pool_small_bwd_kernel(Sma
   }
   if (p.g_x_pool && p.X) {
     const float* Xb = p.X + static_cast<long>(b) * N * F;
-    const float* Gb = p.g_x_pool + static_cast<long>(b) * K * F;
+    const float* Gb = p.g_x_pool + static_cast<long>(b) * K * F * mx;
     float ga[16], xn0[16], xn1[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int f = rho(r) + 4 * lk;
       const bool okg = lm < K && f < F, ok0 = lm < N && f < F, ok1 = 32 + lm < N && f < F;
-      const float tg = *byte_off(Gb, okg ? (lm * F + f) * 4 : 0);
+      const float tg = *byte_off(Gb, okg ? (lm * F + f) * 4 * mx : 0);
       const float t0 = *byte_off(Xb, ok0 ? (lm * F + f) * 4 : 0), t1 = *byte_off(Xb, ok1 ? ((32 + lm) * F + f) * 4 : 0);
       ga[r] = okg ? tg : 0.f;
       xn0[r] = ok0 ? t0 : 0.f;
@@ -787,13 +801,13 @@ __global__ __launch_bounds__(64 * SG_WAVES) void dense_pool_small_bwd_kernel(Sma
 #pragma unroll
     for (int r = 0; r < 16; ++r) { gx0[r] = 0.f; gx1[r] = 0.f; }
     if (p.g_x_pool) {
-      const float* Gb = p.g_x_pool + static_cast<long>(b) * K * F;
+      const float* Gb = p.g_x_pool + static_cast<long>(b) * K * F * mx;
       float gb[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = rho(r) + 4 * lk;
         const bool ok = j < K && lm < F;
-        const float t = *byte_off(Gb, ok ? (j * F + lm) * 4 : 0);
+        const float t = *byte_off(Gb, ok ? (j * F + lm) * 4 * mx : 0);
         gb[r] = ok ? t : 0.f;
       }
 #pragma unroll

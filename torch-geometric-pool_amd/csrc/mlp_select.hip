@@ -20,6 +20,8 @@
 // K > 256 (more than 8 accumulator tiles): the caller runs tgp_bmm_f32 and softmax_rows_kernel (in place).
 // tgp_softmax_bwd_f32: dY = S * (dS - <dS, S>) per row -- with S = softmax * mask this is the gradient w.r.t. the
 // logits for kept rows and 0 for masked rows (their S is 0).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace tgp {
@@ -244,6 +246,222 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   }
 }
 
+// ---- backward of the selector's last layer: one launch (+ a one-round combine of gW / gb) ------------------------------
+// Given S = softmax(X W^T + b) * mask and the upstream dS:   dY = S (dS - <dS, S>)   (rows of masked nodes: S = 0 -> 0),
+//   gX (+)= dY W      [M,F]        gW = dY^T X   [K,F]        gb = column sums of dY   [K]
+// (what autograd derives from select/mlp_select.py:139-145: softmax backward, two matmul backwards, a bias reduction:
+// eight launches here before -- softmax_bwd, a GEMM + its split sum, a small bmm, two reductions with their memsets and
+// autograd's accumulation into gX).  K <= 32, F <= 64 (four feature tiles per wave spill: wider layers keep the staged
+// form).  A wave owns 64 node rows at a time: S and dS tiles are staged flat through LDS (coalesced), lane = row forms dY in registers and drops it back into LDS as [64][33]; both products
+// run on the fp32 matrix cores from that tile: gX = dY W with W held in registers as the B operand (lane = feature),
+// gW += dY^T X with X straight from memory as the B operand (lane = feature, k = row: a half-wave reads 128 contiguous
+// bytes of one row) and dY^T read down the LDS columns (lane = cluster: conflict-free); gb rides on the A operands.
+// The per-wave gW / gb accumulators are added in wave order through LDS, every workgroup stores one partial, and
+// mlp_select_bwd_combine_kernel adds the partials in workgroup order (deterministic; no float atomics).
+struct MlpSelBwdArgs {
+  const float* s; const float* gs; const float* x; const float* w;
+  float* gx; float* gw; float* gb;
+  float* part;            // [gridDim.x][K * F + K]: one partial of gW | gb per workgroup
+  long M, tiles;
+  int K, F, accumulate;
+};
+
+constexpr int MB_WAVES = 8;
+constexpr int MB_MAX_GRID = 256;  // workgroups (= partials of gW / gb) per launch
+constexpr int MB_ZP = 33;
+constexpr int MB_WAVE_FLOATS = 4096 + 64;  // flat S | dS tiles (2 x 2048), then dY [64][33]; at the end gW [32][32 FT] + gb [2][32]
+
+__device__ __forceinline__ int mb_rho(int r) { return (r & 3) + 8 * (r >> 2); }
+
+template <int FT>
+__global__ __launch_bounds__(64 * MB_WAVES) void mlp_select_bwd_kernel(MlpSelBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane(wave_id());
+  const int lm = lane & 31, lk = lane >> 5;
+  const int K = p.K, F = p.F;
+  float* buf = smem + w * MB_WAVE_FLOATS;
+  constexpr bool WREG = FT <= 2;
+  float wreg[WREG ? 16 : 1][FT];
+  auto w_at = [&](int kk, int ft) {
+    const int c = 2 * kk + lk, f = ft * 32 + lm;
+    return (c < K && f < F) ? p.w[c * F + f] : 0.f;
+  };
+  if constexpr (WREG) {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) wreg[kk][ft] = w_at(kk, ft);
+  }
+  f32x16 dw[FT];
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dw[ft][r] = 0.f;
+  float db = 0.f;
+  for (long tile = static_cast<long>(blockIdx.x) * MB_WAVES + w; tile < p.tiles;
+       tile += static_cast<long>(gridDim.x) * MB_WAVES) {
+    const long row0 = tile * 64;
+    const int nrows = static_cast<int>(p.M - row0 < 64 ? p.M - row0 : 64);
+    const int cnt = nrows * K;
+    // Buffer-descriptor loads: one lane offset per stream + scalar / immediate offsets, out-of-range dwords come back as
+    // zeros (rows past M in the last tile), dword alignment suffices for the 16-byte loads.  Every global load of the
+    // tile is requested before the first one is consumed: S and dS (staged flat through LDS), the X operand of gW for
+    // the first 32 features, and -- one feature tile, accumulating -- the gX values to add to.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.s + row0 * K), 0, cnt * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gs + row0 * K), 0, cnt * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + row0 * F), 0, nrows * F * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.gx ? p.gx + row0 * F : const_cast<float*>(p.x), 0,
+                                                                         p.gx ? nrows * F * 4 : 0, 0x00020000);
+    u32x4 sv[8], gv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      sv[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, q * 1024, 0);
+      gv[q] = __builtin_amdgcn_raw_buffer_load_b128(rg, lane * 16, q * 1024, 0);
+    }
+    // (gfx950 checks voffset + soffset against the record size: tools/micro/buffer_range_soffset.hip)
+    constexpr int OOB = 0x40000000;  // byte offset past any tile: a lane past the last feature reads zero / stores nothing
+    const int vx = lm < F ? (lk * F + lm) * 4 : OOB, vo = lm < F ? (4 * lk * F + lm) * 4 : OOB;
+    float xr[32];
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk)
+      xr[kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx, kk * 2 * F * 4, 0));
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      *reinterpret_cast<u32x4*>(buf + (q * 64 + lane) * 4) = sv[q];
+      *reinterpret_cast<u32x4*>(buf + 2048 + (q * 64 + lane) * 4) = gv[q];
+    }
+    float old[(FT == 1) ? 32 : 1];
+    if constexpr (FT == 1) {
+      if (p.gx && p.accumulate) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q)
+          old[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+              ro, vo, ((q >> 4) * 32 + mb_rho(q & 15)) * F * 4, 0));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float gz[32];
+    {
+      const bool live = lane < nrows;
+      const float* S = buf + lane * K;
+      const float* G = buf + 2048 + lane * K;
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; ++c)
+        if (c < K && live) dot = fmaf(G[c], S[c], dot);
+#pragma unroll
+      for (int c = 0; c < 32; ++c) gz[c] = (c < K && live) ? S[c] * (G[c] - dot) : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < 32; ++c) buf[lane * MB_ZP + c] = gz[c];
+    __builtin_amdgcn_wave_barrier();
+    if (p.gx) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int kk = 0; kk < 16; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[(rt * 32 + lm) * MB_ZP + 2 * kk + lk],
+                                                       WREG ? wreg[kk][ft] : w_at(kk, ft), acc, 0, 0, 0);
+          const int f = ft * 32 + lm;
+          const int voff = f < F ? (4 * lk * F + f) * 4 : OOB;  // (stores out of range are dropped)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int soff = (rt * 32 + mb_rho(r)) * F * 4;
+            float v = acc[r];
+            if (p.accumulate) {
+              if constexpr (FT == 1) v = __fadd_rn(old[rt * 16 + r], v);
+              else v = __fadd_rn(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, voff, soff, 0)), v);
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, voff, soff, 0);
+          }
+        }
+    }
+    if (p.gw) {
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        if (ft > 0) {
+          const int f = ft * 32 + lm, vx2 = f < F ? (lk * F + f) * 4 : OOB;
+#pragma unroll
+          for (int kk = 0; kk < 32; ++kk)
+            xr[kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx2, kk * 2 * F * 4, 0));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+          const float a = buf[(2 * kk + lk) * MB_ZP + lm];
+          dw[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xr[kk], dw[ft], 0, 0, 0);
+          if (ft == 0) db += a;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!p.gw) return;  // (uniform)
+  // ---- workgroup partial: waves added in wave order ---------------------------------------------------------------------
+  constexpr int FW = 32 * FT;
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf[(mb_rho(r) + 4 * lk) * FW + ft * 32 + lm] = dw[ft][r];
+  buf[4096 + lk * 32 + lm] = db;
+  __syncthreads();
+  const int n_out = K * F + K;
+  float* mine = p.part + static_cast<long>(blockIdx.x) * n_out;
+  for (int o = threadIdx.x; o < n_out; o += 64 * MB_WAVES) {
+    float v = 0.f;
+    if (o < K * F) {
+      const int c = o / F, f = o - c * F;
+#pragma unroll
+      for (int q = 0; q < MB_WAVES; ++q) v = __fadd_rn(v, smem[q * MB_WAVE_FLOATS + c * FW + f]);
+    } else {
+      const int c = o - K * F;
+#pragma unroll
+      for (int q = 0; q < MB_WAVES; ++q)
+        v = __fadd_rn(v, __fadd_rn(smem[q * MB_WAVE_FLOATS + 4096 + c], smem[q * MB_WAVE_FLOATS + 4096 + 32 + c]));
+    }
+    mine[o] = v;
+  }
+}
+
+// Second launch of the selector's backward: gW / gb = the workgroups' partials added in workgroup order.  One workgroup
+// per 64 outputs; wave q takes partials q, q + 8, ... (all its loads in flight at once: the grid has at most 256
+// partials), the eight waves' sums are added in wave order.  (Adding them inside the first launch -- the workgroup with
+// the last arrival ticket, also as two ticket levels with write-through partials -- was measured: 35 us against
+// 17.6 + 4 here; a hand-over through memory is five dependent round trips at 2-3 us each, profiles/r05_train_step.md.)
+__global__ __launch_bounds__(64 * MB_WAVES) void mlp_select_bwd_combine_kernel(const float* __restrict__ part, int P,
+                                                                                int n_out, int kf, float* __restrict__ gw,
+                                                                                float* __restrict__ gb) {
+  __shared__ float s_sum[MB_WAVES][64];
+  const int lane = lane_id(), w = wave_id();
+  const int o = blockIdx.x * 64 + lane;
+  float v[MB_MAX_GRID / MB_WAVES];
+#pragma unroll
+  for (int ji = 0; ji < MB_MAX_GRID / MB_WAVES; ++ji) {
+    const int j = w + ji * MB_WAVES;
+    const bool ok = o < n_out && j < P;
+    const float got = part[ok ? static_cast<long>(j) * n_out + o : 0];
+    v[ji] = ok ? got : 0.f;
+  }
+  float a = 0.f;
+#pragma unroll
+  for (int ji = 0; ji < MB_MAX_GRID / MB_WAVES; ++ji) a = __fadd_rn(a, v[ji]);
+  s_sum[w][lane] = a;
+  __syncthreads();
+  if (w == 0 && o < n_out) {
+    float r = 0.f;
+#pragma unroll
+    for (int q = 0; q < MB_WAVES; ++q) r = __fadd_rn(r, s_sum[q][lane]);
+    if (o < kf) gw[o] = r;
+    else if (gb) gb[o - kf] = r;
+  }
+}
+
 template <int KT>
 static int launch_mlp_select(const MlpSelArgs& a, bool vec, int grid, size_t lds, hipStream_t st) {
   if (vec)
@@ -320,4 +538,55 @@ extern "C" int tgp_softmax_bwd_f32(const float* s, const float* ds, float* dy, i
   else
     hipLaunchKernelGGL((softmax_bwd_kernel<64>), dim3(cdiv(M, 4)), dim3(256), 0, st, s, ds, dy, (long)M, (int)K);
   return check_launch("softmax_bwd_kernel");
+}
+
+extern "C" int tgp_mlp_select_bwd_fits(int64_t F, int64_t K) { return K >= 1 && K <= 32 && F >= 1 && F <= 64; }
+
+static int mlp_select_bwd_grid(int64_t M) {
+  // few, fat workgroups: every workgroup leaves one partial of gW / gb that the last one adds up
+  const int64_t tiles = (M + 63) / 64;
+  int64_t g = (tiles + MB_WAVES - 1) / MB_WAVES;
+  if (g > MB_MAX_GRID) g = MB_MAX_GRID;
+  return g < 1 ? 1 : static_cast<int>(g);
+}
+
+extern "C" size_t tgp_mlp_select_bwd_workspace_bytes(int64_t M, int64_t F, int64_t K) {
+  return align_up(static_cast<size_t>(mlp_select_bwd_grid(M)) * static_cast<size_t>(K * F + K) * sizeof(float));
+}
+
+extern "C" int tgp_mlp_select_bwd_f32(const float* s, const float* ds, const float* x, const float* weight, int64_t M,
+                                      int64_t F, int64_t K, float* gx, int accumulate_gx, float* gw, float* gb,
+                                      void* ws, size_t ws_bytes, void* stream) {
+  TGP_REQUIRE(M >= 0 && tgp_mlp_select_bwd_fits(F, K), TGP_ERR_INVALID,
+              "tgp_mlp_select_bwd_f32: M=%lld F=%lld K=%lld outside K <= 32, F <= 64", (long long)M, (long long)F,
+              (long long)K);
+  TGP_REQUIRE(M * (F > K ? F : K) < (1ll << 40), TGP_ERR_RANGE, "tgp_mlp_select_bwd_f32: too many rows");
+  if (M == 0) {
+    hipStream_t st0 = static_cast<hipStream_t>(stream);
+    if (gw) (void)hipMemsetAsync(gw, 0, sizeof(float) * K * F, st0);
+    if (gb) (void)hipMemsetAsync(gb, 0, sizeof(float) * K, st0);
+    return check_launch("tgp_mlp_select_bwd_f32");
+  }
+  TGP_REQUIRE(s && ds && x && weight && (gx || gw), TGP_ERR_INVALID, "tgp_mlp_select_bwd_f32: null pointer");
+  TGP_REQUIRE(!gb || gw, TGP_ERR_INVALID, "tgp_mlp_select_bwd_f32: gb comes with gw");
+  TGP_REQUIRE(!gw || (ws && ws_bytes >= tgp_mlp_select_bwd_workspace_bytes(M, F, K)), TGP_ERR_INVALID,
+              "tgp_mlp_select_bwd_f32: workspace missing or too small");
+  MlpSelBwdArgs a{s, ds, x, weight, gx, gw, gb, static_cast<float*>(ws), static_cast<long>(M),
+                  static_cast<long>((M + 63) / 64), static_cast<int>(K), static_cast<int>(F), accumulate_gx ? 1 : 0};
+  const int grid = mlp_select_bwd_grid(M);
+  const size_t lds = static_cast<size_t>(MB_WAVES) * MB_WAVE_FLOATS * sizeof(float);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * MB_WAVES), lds, st, a);
+  };
+  if (F <= 32) go(mlp_select_bwd_kernel<1>);
+  else go(mlp_select_bwd_kernel<2>);
+  if (gw) {
+    const int n_out = static_cast<int>(K * F + K);
+    hipLaunchKernelGGL(mlp_select_bwd_combine_kernel, dim3(cdiv(n_out, 64)), dim3(64 * MB_WAVES), 0, st,
+                       static_cast<const float*>(ws), grid, n_out, static_cast<int>(K * F), gw, gb);
+  }
+  return check_launch("mlp_select_bwd_kernel");
 }

@@ -90,9 +90,10 @@ SIGNATURES = {
     "tgp_dense_pool_mincut_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_f, _c_f, _c_p,
                                            _c_p, _c_p, _c_p, _c_p, _c_sz, _c_p]),
     "tgp_dense_pool_select_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_f, _c_f,
-                                           _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
+                                           _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "tgp_dense_pool_small_bwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_f, _c_f, _c_p,
-                                              _c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_p, _c_p, _c_p]),
+                                              _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_int,
+                                              _c_p, _c_p, _c_p]),
     "tgp_postprocess_dense_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
     "tgp_postprocess_dense_bwd_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_p]),
     "tgp_postprocess_dense_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_sz, _c_p]),
@@ -181,6 +182,10 @@ SIGNATURES = {
     "tgp_mlp_select_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_softmax_rows_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p]),
     "tgp_softmax_bwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p]),
+    "tgp_mlp_select_bwd_fits": (_c_int, [_c_i64, _c_i64]),
+    "tgp_mlp_select_bwd_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "tgp_mlp_select_bwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_int, _c_p, _c_p, _c_p,
+                                        _c_sz, _c_p]),
     "tgp_reduce_sparse_f64": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_connect_subgraph_single_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_int, ctypes.c_double,
                                                  _c_p, _c_sz, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p,

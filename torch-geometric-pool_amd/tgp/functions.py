@@ -339,6 +339,7 @@ class _ToDenseBatchFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, batch, ptr, num_graphs, max_nodes, also_zero=None):
+        ctx.set_materialize_grads(False)  # (the mask's "gradient" would be a zero fill of [B,N] bytes per step)
         out, mask = K.to_dense_batch(x, batch, ptr, num_graphs, max_nodes, also_zero)
         ctx.save_for_backward(batch, ptr)
         ctx.max_nodes = max_nodes
@@ -348,6 +349,8 @@ class _ToDenseBatchFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gmask):
         batch, ptr = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None, None, None
         # one gather kernel; nodes beyond a caller-imposed max_num_nodes were dropped in the forward: zero gradient
         return K.from_dense_batch(g, batch, ptr, ctx.max_nodes), None, None, None, None, None
 
@@ -454,6 +457,7 @@ class _MlpSelectFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, mask):
+        ctx.set_materialize_grads(False)
         s = K.mlp_select(x, weight, bias, mask)
         ctx.save_for_backward(x, weight, s)
         ctx.has_bias = bias is not None
@@ -462,6 +466,13 @@ class _MlpSelectFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, s = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None
+        if K.mlp_select_bwd_fits(s.size(-1), x.size(-1)):  # r5: one launch for all three gradients
+            need = ctx.needs_input_grad
+            gx, gw, gb = K.mlp_select_bwd(s, g, x, weight, want_gx=need[0], want_gw=need[1],
+                                          want_gb=ctx.has_bias and need[2])
+            return (gx.view(x.shape) if gx is not None else None), gw, gb, None
         dy = K.softmax_bwd(s, g)
         dy2 = dy.reshape(-1, dy.size(-1))
         gx = gw = gb = None
@@ -619,56 +630,163 @@ def topk_score(x: Tensor, w: Tensor, use_tanh: bool) -> Tensor:
 
 
 # ------------------------------------------------- A S and A^T S shared between Connect and the link loss
+class LossPair(tuple):
+    """Two scalar auxiliary losses that left a fused Function as separate 0-dim outputs (MinCut: the batch means of the
+    cut / orthogonality terms; DiffPool: link / entropy).  Selecting them from a [2] tensor instead would put two
+    select-backwards, two zero fills and an add into every training step."""
+    __slots__ = ()
+
+
+def _pool_small_forward(sd, ad, xd, flags, want_raw, want_terms, diff_scales, graph_sizes, scalars, pre=None):
+    """Shared forward of the two fused Functions below: (x_pool, raw, adj_pool, terms, diff, loss_a, loss_b)."""
+    from . import kernels as K
+    if pre is None:
+        x_pool, raw, adj_pool, terms = K.dense_pool(sd, ad, xd, flags, want_raw=want_raw, want_post=True,
+                                                    mincut_terms=True)
+    else:
+        x_pool, raw, adj_pool, terms = pre
+    if terms is None:
+        raise RuntimeError("the batch does not take the one-wave-per-graph kernel")
+    empty = sd.new_empty(0)
+    diff = empty
+    if diff_scales is not None:
+        diff = K.diffpool_loss_tail(sd, ad, graph_sizes, diff_scales[0], diff_scales[1])
+    la = lb = empty
+    if scalars:
+        if diff_scales is not None:
+            la, lb = diff[0], diff[1]
+        elif want_terms:
+            both = terms.mean(dim=1)
+            la, lb = both[0], both[1]
+    return x_pool, (empty if raw is None else raw), adj_pool, terms, diff, la, lb
+
+
 class _DensePoolSmallFn(torch.autograd.Function):
     """Reduce + Connect (+ MinCut's two loss tails, + DiffPool's two losses) of a batch of small graphs as ONE kernel in
     each direction (csrc/dense_graph_kernels.h: dense_pool_small_kernel / dense_pool_small_bwd_kernel).  Outputs:
-    x_pool, raw S^T A S, post-processed adj_pool, terms [2,B], diff [2]; raw / terms / diff are only differentiated
-    when they were asked for."""
+    x_pool, raw S^T A S, post-processed adj_pool, terms [2,B], diff [2], and -- ``scalars`` -- the two losses as 0-dim
+    tensors (MinCut: means of the terms over the batch; DiffPool: diff[0], diff[1]), which are then the differentiable
+    form; raw / terms / diff are only differentiated when they were asked for.  Upstream gradients that are missing
+    stay missing (no zero tensors are made for them): each is a NULL pointer of the C call."""
 
     @staticmethod
-    def forward(ctx, s, adj, x, flags, want_raw, want_terms, diff_scales, graph_sizes):
-        from . import kernels as K
+    def forward(ctx, s, adj, x, flags, want_raw, want_terms, diff_scales, graph_sizes, scalars=False):
+        ctx.set_materialize_grads(False)
         sd, ad = s.detach(), adj.detach()
-        x_pool, raw, adj_pool, terms = K.dense_pool(sd, ad, x.detach(), flags, want_raw=want_raw, want_post=True,
-                                                    mincut_terms=True)
-        if terms is None:
-            raise RuntimeError("_DensePoolSmallFn: the batch does not take the one-wave-per-graph kernel")
-        diff = s.new_empty(0)
-        if diff_scales is not None:
-            diff = K.diffpool_loss_tail(sd, ad, graph_sizes, diff_scales[0], diff_scales[1])
+        x_pool, raw, adj_pool, terms, diff, la, lb = _pool_small_forward(
+            sd, ad, x.detach(), flags, want_raw, want_terms, diff_scales, graph_sizes, scalars)
         ctx.save_for_backward(s, adj, x, diff)
         ctx.flags = flags
         ctx.want_gx = x.requires_grad
         ctx.diff_scales = diff_scales
-        if raw is None:
-            raw = s.new_empty(0)
-        if not want_terms:
-            terms = terms.detach()
-        ctx.mark_non_differentiable(*([] if want_raw else [raw]), *([] if want_terms else [terms]),
-                                    *([] if diff_scales is not None else [diff]))
-        return x_pool, raw, adj_pool, terms, diff
+        nd = [] if want_raw else [raw]
+        if scalars or not want_terms:
+            nd.append(terms)
+        if scalars or diff_scales is None:
+            nd.append(diff)
+        if not scalars or (diff_scales is None and not want_terms):
+            nd += [la, lb]
+        ctx.mark_non_differentiable(*nd)
+        return x_pool, raw, adj_pool, terms, diff, la, lb
 
     @staticmethod
-    def backward(ctx, g_x, g_raw, g_adj, g_terms, g_diff):
+    def backward(ctx, g_x, g_raw, g_adj, g_terms, g_diff, g_la, g_lb):
         from . import kernels as K
         s, adj, x, diff = ctx.saved_tensors
-        if g_raw is not None and g_raw.numel() == 0:
-            g_raw = None
-        ds = ctx.diff_scales
-        if ds is None or g_diff is None or g_diff.numel() == 0:
-            g_diff, ds = None, (0.0, 0.0)
-        gs, gx = K.dense_pool_small_bwd(s, adj, x, ctx.flags, g_x, g_adj, g_raw, g_terms, want_gx=ctx.want_gx,
-                                        g_diff=g_diff, diff_losses=diff if g_diff is not None else None,
-                                        link_scale=ds[0], ent_scale=ds[1])
-        return gs.to(s.dtype), None, (gx.to(x.dtype) if gx is not None else None), None, None, None, None, None
+        gs, gx = _pool_small_backward(ctx, s, adj, x, diff, g_x, g_raw, g_adj, g_terms, g_diff, g_la, g_lb)
+        return gs.to(s.dtype), None, (gx.to(x.dtype) if gx is not None else None), None, None, None, None, None, None
+
+
+def _pool_small_backward(ctx, s, adj, x, diff, g_x, g_raw, g_adj, g_terms, g_diff, g_la, g_lb):
+    from . import kernels as K
+    if g_raw is not None and g_raw.numel() == 0:
+        g_raw = None
+    if g_terms is not None and g_terms.numel() == 0:
+        g_terms = None
+    ds = ctx.diff_scales
+    mean_terms, diff_pair = (None, None), (None, None)
+    if ds is not None:
+        if g_diff is not None and g_diff.numel() == 0:
+            g_diff = None
+        diff_pair = (g_la, g_lb)
+    else:
+        g_diff, ds = None, (0.0, 0.0)
+        mean_terms = (g_la, g_lb)
+    need_losses = g_diff is not None or diff_pair[0] is not None or diff_pair[1] is not None
+    return K.dense_pool_small_bwd(s, adj, x, ctx.flags, g_x, g_adj, g_raw, g_terms, want_gx=ctx.want_gx,
+                                  g_diff=g_diff, diff_losses=diff if need_losses else None,
+                                  link_scale=ds[0], ent_scale=ds[1], g_mean_terms=mean_terms, g_diff_pair=diff_pair)
 
 
 def dense_pool_small(s: Tensor, adj: Tensor, x: Tensor, flags: int, want_raw: bool, want_terms: bool,
-                     diff_scales=None, graph_sizes: Optional[Tensor] = None):
+                     diff_scales=None, graph_sizes: Optional[Tensor] = None, loss_scalars: bool = False):
     """Differentiable fused Reduce + Connect for batches ``kernels.dense_pool_is_small`` accepts (adj gets no gradient:
-    callers check ``adj.requires_grad`` first).  ``diff_scales = (link_scale, ent_scale)``: also DiffPool's link and
-    entropy losses [2], differentiated by the same backward launch."""
-    return _DensePoolSmallFn.apply(s, adj, x, flags, want_raw, want_terms, diff_scales, graph_sizes)
+    callers check ``adj.requires_grad`` first): (x_pool, raw, adj_pool, terms, diff).  ``diff_scales = (link_scale,
+    ent_scale)``: also DiffPool's link and entropy losses [2], differentiated by the same backward launch.
+    ``loss_scalars``: the auxiliary losses come as a :class:`LossPair` of 0-dim tensors instead -- in place of ``terms``
+    the batch means of MinCut's two terms, in place of ``diff`` its two entries."""
+    out = _DensePoolSmallFn.apply(s, adj, x, flags, want_raw, want_terms, diff_scales, graph_sizes, loss_scalars)
+    if not loss_scalars:
+        return out[:5]
+    pair = LossPair((out[5], out[6]))
+    if diff_scales is not None:
+        return out[0], out[1], out[2], out[3], pair
+    return out[0], out[1], out[2], (pair if want_terms else out[3]), out[4]
+
+
+class _SelectPoolSmallFn(torch.autograd.Function):
+    """MLPSelect's last Linear + softmax + mask, Reduce, Connect, post-processing and the loss tails of a batch of small
+    graphs as ONE autograd node: forward = ``tgp_dense_pool_select_f32`` (one launch; DiffPool's two losses one more
+    call), backward = ``tgp_dense_pool_small_bwd_f32`` + ``tgp_mlp_select_bwd_f32`` (two launches: the selector's
+    backward adds its dX into the buffer the pooling backward wrote, so autograd has nothing to accumulate).  A MinCut
+    training step on a PROTEINS-shaped batch was 34 device launches with the selector and the pooling as two nodes and
+    the losses selected from small tensors (profiles/r05_e2e_train_steps.txt)."""
+
+    @staticmethod
+    def forward(ctx, x, adj, weight, bias, mask, flags, want_raw, want_terms, diff_scales, graph_sizes, want_batch):
+        from . import kernels as K
+        ctx.set_materialize_grads(False)
+        xd, ad = x.detach(), adj.detach()
+        s, x_pool, raw, adj_pool, terms, bp = K.dense_pool_select(
+            xd, ad, weight.detach(), None if bias is None else bias.detach(), mask, flags, want_raw=want_raw,
+            mincut_terms=True, want_batch=True) if want_batch else K.dense_pool_select(
+            xd, ad, weight.detach(), None if bias is None else bias.detach(), mask, flags, want_raw=want_raw,
+            mincut_terms=True) + (torch.empty(0, dtype=torch.long, device=x.device),)
+        x_pool, raw, adj_pool, terms, diff, la, lb = _pool_small_forward(
+            s, ad, xd, flags, want_raw, want_terms, diff_scales, graph_sizes, True, pre=(x_pool, raw, adj_pool, terms))
+        ctx.save_for_backward(s, adj, x, diff, weight)
+        ctx.flags = flags
+        ctx.want_gx = True
+        ctx.diff_scales = diff_scales
+        ctx.has_bias = bias is not None
+        nd = [terms, diff, bp] + ([] if want_raw else [raw])
+        if diff_scales is None and not want_terms:
+            nd += [la, lb]
+        ctx.mark_non_differentiable(*nd)
+        return s, x_pool, raw, adj_pool, terms, diff, la, lb, bp
+
+    @staticmethod
+    def backward(ctx, g_s, g_x, g_raw, g_adj, _g_terms, _g_diff, g_la, g_lb, _g_bp):
+        from . import kernels as K
+        s, adj, x, diff, weight = ctx.saved_tensors
+        gs, gx = _pool_small_backward(ctx, s, adj, x, diff, g_x, g_raw, g_adj, None, None, g_la, g_lb)
+        if g_s is not None:  # S was used outside the pooler as well
+            gs = gs + g_s
+        need = ctx.needs_input_grad
+        gx, gw, gb = K.mlp_select_bwd(s, gs, x, weight, want_gx=need[0], want_gw=need[2],
+                                      want_gb=ctx.has_bias and need[3], gx_accumulate=gx)
+        return ((gx.to(x.dtype) if need[0] else None), None, gw, (gb if ctx.has_bias else None), None, None, None, None,
+                None, None, None)
+
+
+def select_pool_small(x: Tensor, adj: Tensor, weight: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], flags: int,
+                      want_raw: bool, want_terms: bool, diff_scales=None, graph_sizes: Optional[Tensor] = None,
+                      want_batch: bool = False):
+    """(s, x_pool, raw, adj_pool, LossPair or None, pooled batch vector or None): see :class:`_SelectPoolSmallFn`."""
+    out = _SelectPoolSmallFn.apply(x, adj, weight, bias, mask, flags, want_raw, want_terms, diff_scales, graph_sizes,
+                                   want_batch)
+    pair = LossPair((out[6], out[7])) if (diff_scales is not None or want_terms) else None
+    return out[0], out[1], out[2], out[3], pair, (out[8] if want_batch else None)
 
 
 class ASProducts:

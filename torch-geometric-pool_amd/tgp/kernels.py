@@ -962,10 +962,12 @@ def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int
 
 
 def dense_pool_select(x: Tensor, adj: Tensor, weight: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], flags: int,
-                      want_raw: bool = False, mincut_terms: bool = False):
+                      want_raw: bool = False, mincut_terms: bool = False, want_batch: bool = False):
     """(s, x_pool, adj_raw, adj_pool, terms): MLPSelect's last Linear + softmax + mask, Reduce, Connect and the
     post-processing of a batch of small graphs in ONE launch (select/mlp_select.py:105-147, base_reduce.py:158-161,
-    dense_conn.py:111-122, utils/ops.py:282-335); callers check :func:`dense_pool_is_small` first."""
+    dense_conn.py:111-122, utils/ops.py:282-335); callers check :func:`dense_pool_is_small` first.  ``want_batch``: a
+    sixth value, the pooled batch vector ``arange(B).repeat_interleave(K)`` (utils/ops.py:152-169) written by the same
+    launch."""
     dev = N.require_device(x, adj, weight, bias, mask)
     x, weight = N.f32c(x), N.f32c(weight)
     B, Nn, F = x.shape
@@ -985,10 +987,14 @@ def dense_pool_select(x: Tensor, adj: Tensor, weight: Tensor, bias: Optional[Ten
     adj_pool = torch.empty(B, K, K, dtype=torch.float32, device=dev)
     adj_raw = torch.empty(B, K, K, dtype=torch.float32, device=dev) if want_raw else None
     terms = torch.empty(2, B, dtype=torch.float32, device=dev) if mincut_terms else None
+    bp = torch.empty(B * K, dtype=torch.int64, device=dev) if want_batch else None
     N.check(N.lib().tgp_dense_pool_select_f32(N.ptr(x), N.ptr(a), N.ptr(weight), N.ptr(b), N.ptr(m), B, Nn, K, F,
                                               flags | tflag, ops_eps(), losses_eps(), N.ptr(s), N.ptr(x_pool),
-                                              N.ptr(adj_raw), N.ptr(adj_pool), N.ptr(terms), N.stream_ptr(dev)),
+                                              N.ptr(adj_raw), N.ptr(adj_pool), N.ptr(terms), N.ptr(bp),
+                                              N.stream_ptr(dev)),
             "tgp_dense_pool_select_f32")
+    if want_batch:
+        return s, x_pool, adj_raw, adj_pool, terms, bp
     return s, x_pool, adj_raw, adj_pool, terms
 
 
@@ -997,12 +1003,28 @@ def dense_pool_is_small(B: int, Nn: int, K: int, F: int) -> bool:
     return bool(N.lib().tgp_dense_pool_is_small(B, Nn, K, F))
 
 
+def _bcast_or_dense(t: Optional[Tensor], shape) -> Tuple[Optional[Tensor], bool]:
+    """An upstream gradient as the kernel takes it: (contiguous fp32 tensor, False), or (one-element tensor, True) when
+    every stride is zero -- `loss = out.sum()` sends an expanded scalar, which is read as one value instead of being
+    materialised as a [B,K,F] copy."""
+    if t is None:
+        return None, False
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"upstream gradient {tuple(t.shape)} does not match {tuple(shape)}")
+    if t.dtype == torch.float32 and t.numel() > 1 and not any(t.stride()):
+        return t.as_strided((1,), (1,)), True
+    return N.f32c(t), False
+
+
 def dense_pool_small_bwd(s: Tensor, adj: Tensor, x: Optional[Tensor], flags: int, g_x_pool: Optional[Tensor],
                          g_adj_pool: Optional[Tensor], g_adj_raw: Optional[Tensor], g_terms: Optional[Tensor],
                          want_gx: bool = True, g_diff: Optional[Tensor] = None, diff_losses: Optional[Tensor] = None,
-                         link_scale: float = 0.0, ent_scale: float = 0.0):
+                         link_scale: float = 0.0, ent_scale: float = 0.0, g_mean_terms=(None, None),
+                         g_diff_pair=(None, None)):
     """Gradients (gS, gX) of ``dense_pool`` (with its in-kernel MinCut terms) for a batch of small graphs, one launch:
-    base_reduce.py:158-161, dense_conn.py:111-122, utils/ops.py:282-335, utils/losses.py:39-70 under autograd."""
+    base_reduce.py:158-161, dense_conn.py:111-122, utils/ops.py:282-335, utils/losses.py:39-70 under autograd.
+    ``g_mean_terms`` = upstream gradients (0-dim tensors or None) of the batch MEANS of the two per-graph terms;
+    ``g_diff_pair`` = those of DiffPool's (link, entropy) losses as two 0-dim tensors (``g_diff`` [2] is the other form)."""
     dev = N.require_device(s, adj, x)
     s = N.f32c(s)
     B, Nn, K = s.shape
@@ -1020,20 +1042,66 @@ def dense_pool_small_bwd(s: Tensor, adj: Tensor, x: Optional[Tensor], flags: int
             raise ValueError(f"upstream gradient {tuple(t.shape)} does not match {tuple(shape)}")
         return t
 
-    g_x_pool = grad(g_x_pool, (B, K, F)) if x is not None else None
-    g_adj_pool, g_adj_raw = grad(g_adj_pool, (B, K, K)), grad(g_adj_raw, (B, K, K))
+    g_x_pool, bx = _bcast_or_dense(g_x_pool, (B, K, F)) if x is not None else (None, False)
+    g_adj_pool, ba = _bcast_or_dense(g_adj_pool, (B, K, K))
+    g_adj_raw = grad(g_adj_raw, (B, K, K))
     g_terms = grad(g_terms, (2, B))
-    g_diff = grad(g_diff, (2,))
-    diff_losses = grad(diff_losses, (2,)) if g_diff is not None else None
+    g_link, g_ent = g_diff_pair
+    if g_diff is not None:
+        g_diff = grad(g_diff, (2,))
+        g_link, g_ent = g_diff[0], g_diff[1]
+    g_link, g_ent = grad(g_link, ()), grad(g_ent, ())
+    g_cut, g_ortho = grad(g_mean_terms[0], ()), grad(g_mean_terms[1], ())
+    diff_losses = grad(diff_losses, (2,)) if (g_link is not None or g_ent is not None) else None
     gs = torch.empty(B, Nn, K, dtype=torch.float32, device=dev)
     gx = torch.empty(B, Nn, F, dtype=torch.float32, device=dev) if (want_gx and x is not None) else None
     N.check(N.lib().tgp_dense_pool_small_bwd_f32(N.ptr(s), N.ptr(a), N.ptr(x), B, Nn, K, F, flags | tflag, ops_eps(),
                                                  losses_eps(), N.ptr(g_x_pool), N.ptr(g_adj_pool), N.ptr(g_adj_raw),
-                                                 N.ptr(g_terms), N.ptr(g_diff), N.ptr(diff_losses), float(link_scale),
-                                                 float(ent_scale), losses_eps(), N.ptr(gs), N.ptr(gx),
-                                                 N.stream_ptr(dev)),
+                                                 N.ptr(g_terms), N.ptr(g_cut), N.ptr(g_ortho), N.ptr(g_link),
+                                                 N.ptr(g_ent), N.ptr(diff_losses), float(link_scale),
+                                                 float(ent_scale), losses_eps(), (1 if bx else 0) | (2 if ba else 0),
+                                                 N.ptr(gs), N.ptr(gx), N.stream_ptr(dev)),
             "tgp_dense_pool_small_bwd_f32")
     return gs, gx
+
+
+def mlp_select_bwd_fits(K: int, F: int) -> bool:
+    return bool(N.lib().tgp_mlp_select_bwd_fits(F, K))
+
+
+def mlp_select_bwd(s: Tensor, g_s: Tensor, x: Tensor, weight: Tensor, want_gx: bool = True, want_gw: bool = True,
+                   want_gb: bool = True, gx_accumulate: Optional[Tensor] = None):
+    """(gx, gw, gb) of ``mlp_select`` in one pass over S, dS and X + a tiny combine of the workgroups' partial gw / gb
+    (select/mlp_select.py:139-145 under autograd; K <= 32, F <= 64):
+    dY = S (dS - <dS,S>), gx = dY W -- added IN PLACE to ``gx_accumulate`` when that is given (the gradient the pooling
+    backward already holds for the same X) --, gw = dY^T X, gb = column sums of dY."""
+    dev = N.require_device(s, g_s, x, weight)
+    s, g_s, x, weight = N.f32c(s), N.f32c(g_s), N.f32c(x), N.f32c(weight)
+    K = s.size(-1)
+    F = x.size(-1)
+    M = s.numel() // max(K, 1)
+    if g_s.shape != s.shape or x.numel() != M * F or weight.shape != (K, F):
+        raise ValueError(f"mlp_select_bwd: shapes s {tuple(s.shape)}, g_s {tuple(g_s.shape)}, x {tuple(x.shape)}, "
+                         f"weight {tuple(weight.shape)}")
+    gx = None
+    if gx_accumulate is not None:
+        if (gx_accumulate.dtype != torch.float32 or not gx_accumulate.is_contiguous()
+                or gx_accumulate.numel() != M * F):
+            raise ValueError("mlp_select_bwd: gx_accumulate must be a contiguous float32 tensor of x's size")
+        gx = gx_accumulate
+    elif want_gx:
+        gx = torch.empty_like(x)
+    gw = torch.empty(K, F, dtype=torch.float32, device=dev) if (want_gw or want_gb) else None
+    gb = torch.empty(K, dtype=torch.float32, device=dev) if want_gb else None
+    L = N.lib()
+    st = N.stream_ptr(dev)
+    ws = None
+    if gw is not None:
+        ws = N.workspace(L.tgp_mlp_select_bwd_workspace_bytes(M, F, K), dev)
+    N.check(L.tgp_mlp_select_bwd_f32(N.ptr(s), N.ptr(g_s), N.ptr(x), N.ptr(weight), M, F, K, N.ptr(gx),
+                                     1 if gx_accumulate is not None else 0, N.ptr(gw), N.ptr(gb), N.ptr(ws),
+                                     0 if ws is None else ws.numel(), st), "tgp_mlp_select_bwd_f32")
+    return gx, (gw if want_gw else None), gb
 
 
 def postprocess_dense(adj_pool: Tensor, flags: int, inplace: bool = False) -> Tensor:

@@ -33,6 +33,12 @@ from ..utils.losses import (
     unbatched_orthogonality_loss,
 )
 from ..utils.ops import connectivity_to_edge_index, postprocess_adj_pool_dense
+from ..functions import LossPair
+
+import os as _os
+
+# A/B switch (read once): 0 keeps the selector and the pooling as two autograd nodes in training
+_FOLD_TRAINING = _os.environ.get("TGP_FOLD_TRAINING", "1") != "0"
 
 
 # =============================================================================== sparse poolers
@@ -173,10 +179,11 @@ class _DenseMLPPooling(DenseSRCPooling):
     def _lift(self, x, so, batch, batch_pooled):
         return self.lift(x_pool=x, so=so, batch=batch, batch_pooled=batch_pooled)
 
-    def _select_reduce_connect(self, x, adj, mask):
+    def _select_reduce_connect(self, x, adj, mask, want_batch=False):
         """Inference on a batch of small graphs with a single-Linear selector: Select + Reduce + Connect as ONE launch
         (tgp_dense_pool_select_f32: S is formed in the pooling kernel's registers and written once).  Returns
-        ``(SelectOutput, (x_pool, raw, adj_pool[, terms]))`` or None when the case is not that one."""
+        ``(SelectOutput, (x_pool, raw, adj_pool[, terms]), pooled batch vector or None)`` or None when the case is not
+        that one."""
         from .. import kernels as K
         sel, c = self.selector, self.connector
         lins = getattr(getattr(sel, "mlp", None), "lins", None)
@@ -193,14 +200,47 @@ class _DenseMLPPooling(DenseSRCPooling):
                 or not K.dense_pool_is_small(x.size(0), x.size(1), last.weight.size(0), x.size(2))):
             return None
         flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
-        s, x_pool, raw, adj_pool, terms = K.dense_pool_select(
+        out = K.dense_pool_select(
             x, adj, last.weight.detach(), None if last.bias is None else last.bias.detach(), mask, flags,
-            want_raw=self._loss_needs_raw, mincut_terms=self._loss_needs_raw)
+            want_raw=self._loss_needs_raw, mincut_terms=self._loss_needs_raw, want_batch=want_batch)
+        s, x_pool, raw, adj_pool, terms = out[:5]
         so = SelectOutput(s=s, s_inv_op=sel.s_inv_op, in_mask=mask)
         fused = (x_pool, raw, adj_pool) + ((terms,) if self._loss_needs_raw else ())
         if self._fused_diff_scales(adj, mask) is not None:
             fused = fused + (None,)
-        return so, fused
+        return so, fused, (out[5] if want_batch else None)
+
+    def _select_reduce_connect_train(self, x, adj, mask, graph_sizes, want_batch=False):
+        """Training on a batch of small graphs with a single-Linear selector: Select + Reduce + Connect + loss tails as
+        ONE autograd node (functions._SelectPoolSmallFn: one forward launch, two backward launches; the selector and the
+        pooling were two nodes with eight + one backward launches and an accumulation of the two gradients of X).
+        Returns ``(SelectOutput, fused)`` like :meth:`_select_reduce_connect`, the losses as a ``LossPair``."""
+        from .. import functions as Fn, kernels as K
+        sel, c = self.selector, self.connector
+        lins = getattr(getattr(sel, "mlp", None), "lins", None)
+        if (type(sel) is not MLPSelect or lins is None or len(lins) != 1 or type(c) is not DenseConnect
+                or type(self.reducer) is not BaseReduce or not (isinstance(x, Tensor) and isinstance(adj, Tensor))
+                or x.dim() != 3 or adj.dim() != 3 or not x.is_cuda or x.dtype != torch.float32
+                or adj.dtype != torch.float32 or (mask is not None and mask.dtype != torch.bool)
+                or not torch.is_grad_enabled() or adj.requires_grad or c.edge_weight_norm):
+            return None
+        last = lins[0]
+        if (last.weight.dtype != torch.float32 or adj.shape != (x.size(0), x.size(1), x.size(1))
+                or not K.dense_pool_is_small(x.size(0), x.size(1), last.weight.size(0), x.size(2))
+                or not K.mlp_select_bwd_fits(last.weight.size(0), x.size(2))):
+            return None
+        flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
+        diff_scales = self._fused_diff_scales(adj, mask)
+        s, x_pool, raw, adj_pool, pair, bp = Fn.select_pool_small(
+            x, adj, last.weight, last.bias, mask, flags, self._loss_needs_raw, self._loss_needs_raw, diff_scales,
+            graph_sizes, want_batch)
+        so = SelectOutput(s=s, s_inv_op=sel.s_inv_op, in_mask=mask)
+        fused = (x_pool, raw if self._loss_needs_raw else None, adj_pool)
+        if self._loss_needs_raw:
+            fused = fused + (pair,)
+        if diff_scales is not None:
+            fused = fused + (pair,)
+        return so, fused, bp
 
     def _sizes_for(self, adj):
         """Real nodes per graph of the zero-padded batch ``adj`` belongs to, if forward() densified it itself."""
@@ -224,7 +264,9 @@ class _DenseMLPPooling(DenseSRCPooling):
             # costs ~25 us on the device for any mask size)
             self._known_nodes = None
             graph_sizes = None
+            sparse_in = False
             if not is_dense_adj(adj) and isinstance(x, Tensor) and x.dim() == 2:
+                sparse_in = True
                 self._known_nodes = x.size(0)
                 if batch is not None and batch.numel() > 0 and x.is_cuda:
                     graph_sizes = batch_info(batch).sizes  # memoised: the densification below asks for it anyway
@@ -232,7 +274,11 @@ class _DenseMLPPooling(DenseSRCPooling):
                 self._known_nodes = x.size(0) * x.size(1)
             x, adj, mask = self._ensure_batched_inputs(x=x, edge_index=adj, edge_weight=edge_weight, batch=batch,
                                                        mask=mask)
-            folded = self._select_reduce_connect(x, adj, mask)
+            # (the folded kernels also write the pooled batch vector: arange(B).repeat_interleave(K) of the B graphs)
+            want_bp = sparse_in and batch is not None and batch.dtype == torch.long and batch.numel() > 0
+            folded = self._select_reduce_connect(x, adj, mask, want_bp)
+            if folded is None and _FOLD_TRAINING:
+                folded = self._select_reduce_connect_train(x, adj, mask, graph_sizes, want_bp)
             so = folded[0] if folded is not None else self.select(x=x, mask=mask)
             self._sizes_hint = None
             if graph_sizes is not None and graph_sizes.numel() == x.size(0):
@@ -244,7 +290,10 @@ class _DenseMLPPooling(DenseSRCPooling):
                 want_diff_losses=diff_scales)
             if fused is not None:  # Reduce + Connect in one native call (training: batches of small graphs only)
                 x_pool, raw, adj_pool = fused[:3]
-                batch_pool = self.reducer.reduce_batch(so, batch if batch is not None else so.batch)
+                if folded is not None and folded[2] is not None:
+                    batch_pool = folded[2]
+                else:
+                    batch_pool = self.reducer.reduce_batch(so, batch if batch is not None else so.batch)
                 terms = fused[3] if self._loss_needs_raw else None
                 diff = fused[-1] if diff_scales is not None else None
                 loss = self._loss_from_fused(adj, so, mask, raw, terms, diff)
@@ -354,8 +403,9 @@ class MinCutPooling(_DenseMLPPooling):
 
     def _loss_from_fused(self, adj, so, mask, raw, terms=None, diff=None) -> dict:
         if terms is not None and so.s.dtype == torch.float32:
-            # both per-graph loss tails came out of the pooling kernel itself (batches of small graphs)
-            both = terms.mean(dim=1)
+            # both per-graph loss tails came out of the pooling kernel itself (batches of small graphs); under autograd
+            # their batch means arrive as two 0-dim outputs of the fused Function (functions.LossPair)
+            both = terms if isinstance(terms, LossPair) else terms.mean(dim=1)
             return {"cut_loss": both[0] if self.cut_loss_coeff == 1 else both[0] * self.cut_loss_coeff,
                     "ortho_loss": both[1] if self.ortho_loss_coeff == 1 else both[1] * self.ortho_loss_coeff}
         return self.compute_loss(adj, so.s, raw)

@@ -403,8 +403,10 @@ class DenseSRCPooling(SRCPooling):
                     or not K.dense_pool_is_small(s.size(0), s.size(1), s.size(2), x.size(2))):
                 return None
             # want_diff_losses = (link_scale, ent_scale): DiffPool's two losses ride along as a last value [2]
+            # (the auxiliary losses come as functions.LossPair: two 0-dim outputs of the fused Function)
             x_pool, raw, adj_pool, terms, diff = Fn.dense_pool_small(
-                s, adj, x, flags, want_raw, want_mincut_terms, want_diff_losses, getattr(so, "_graph_sizes", None))
+                s, adj, x, flags, want_raw, want_mincut_terms, want_diff_losses, getattr(so, "_graph_sizes", None),
+                loss_scalars=True)
             res = (x_pool, raw if want_raw else None, adj_pool)
             if want_mincut_terms:
                 res = res + (terms,)
