@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10027 /* 1.0.1 of the reference, ABI revision 27 (r5: fp64 dense path on v_mfma_f64_16x16x4_f64; one-launch selector backward) */
+#define TGP_ABI_VERSION 10028 /* 1.0.1 of the reference, ABI revision 28 (r5: fp64 dense path on v_mfma_f64_16x16x4_f64; selector backward in one pass; float64 row-local coalesce) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -222,6 +222,23 @@ int tgp_connect_coalesce_rows_count_published(const int64_t* row, const int64_t*
                                               const int32_t* csr_ptr /* NULL ok */, int reduce_op, int flags, float eps,
                                               void* ws, size_t ws_bytes, int64_t* d_count, uint64_t* status,
                                               int64_t status_words, uint64_t* result, uint32_t epoch, void* stream);
+/* r5: the same row-local pipeline for float64 edge weights (they took the general sort-based route before: 0.6 ms
+ * against 0.24 at C4).  Values are staged, merged (sum / mean / min / max / mul) and eps-filtered in double, as the
+ * reference's coalesce does for a double tensor (connect/base_conn.py:86-89).  Workspace of ..._workspace_bytes_f64;
+ * TGP_HUGE_ROWS is refused (float32 only): a list with a supernode row beyond 1024 raw entries answers -5 and the caller
+ * runs tgp_connect_coalesce_count_f64.  tgp_connect_coalesce_rows_fill_f64 follows a count >= 0. */
+size_t tgp_connect_coalesce_rows_workspace_bytes_f64(int64_t num_edges, int64_t num_nodes, int64_t num_supernodes);
+int tgp_connect_coalesce_rows_count_published_f64(const int64_t* row, const int64_t* col, const int32_t* csr_col /* NULL ok */,
+                                                  const double* edge_weight, int64_t num_edges,
+                                                  const int64_t* cluster_index, int64_t num_nodes, int64_t num_supernodes,
+                                                  const int32_t* assign_row_ptr, const int32_t* assign_perm,
+                                                  const int32_t* csr_ptr /* NULL ok */, int reduce_op, int flags,
+                                                  double eps, void* ws, size_t ws_bytes, int64_t* d_count,
+                                                  uint64_t* status, int64_t status_words, uint64_t* result,
+                                                  uint32_t epoch, void* stream);
+int tgp_connect_coalesce_rows_fill_f64(const void* ws, int64_t num_edges, int64_t num_nodes, int64_t num_supernodes,
+                                       int64_t num_out, int64_t* out_row, int64_t* out_col, double* out_weight,
+                                       void* stream);
 
 /* A4 + A6, row-sorted input, as ONE heavy kernel + a widening fill (r3).  Every workgroup derives its rows' member
  * edge ranges, LDS slots and survivor counts locally; the survivors in front of it come from a decoupled look-back, so

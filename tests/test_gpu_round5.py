@@ -701,3 +701,71 @@ def test_dense_pooler_training_step_as_one_autograd_node(dev, alias, monkeypatch
         torch.testing.assert_close(new[3], old[3], rtol=2e-4, atol=1e-5 * max(1.0, float(old[3].abs().max())))
         for a, b in zip(new[4], old[4]):
             torch.testing.assert_close(a, b, rtol=5e-4, atol=2e-5 * max(1.0, float(b.abs().max())))
+
+
+# ------------------------------------------------------------------ r5: float64 edge weights on the row-local coalesce
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", ["sum", "mean", "min", "max", "mul"])
+def test_float64_edge_weights_take_the_row_local_coalesce(dev, op):
+    """connect/base_conn.py:86-89 with a double weight tensor: the row-sorted list now runs the sort-free row-local
+    pipeline in double (it took the device-wide sort before).  Rows of every length class (<= 32, 33..64, 65..1024 raw
+    entries), duplicates, self loops, sub-eps weights: indices equal the general float64 route's and the oracle's,
+    weights to 1e-13; a list with a hub row (> 1024 raw entries) falls back to the general route by itself."""
+    import tgp_oracle as O
+    from tgp import kernels as K_
+    g = torch.Generator().manual_seed(17)
+    n, k = 6000, 1500
+    cl = torch.randint(0, k, (n,), generator=g)
+    cl[:k] = torch.arange(k)
+    deg = torch.randint(1, 9, (n,), generator=g)
+    members_of_7 = (cl == 7).nonzero().flatten()
+    deg[members_of_7[:3]] = 120          # supernode row 7: a few hundred raw entries -> the long-row kernel
+    members_of_9 = (cl == 9).nonzero().flatten()
+    deg[members_of_9[:1]] = 50           # supernode row 9: 33..64 entries
+    row = torch.repeat_interleave(torch.arange(n), deg)
+    col = torch.randint(0, n, (row.numel(),), generator=g)
+    col[::11] = row[::11]                # self loops
+    ei = torch.stack([row, col])
+    ew = torch.rand(row.numel(), generator=g, dtype=torch.float64) - 0.3
+    ew[torch.rand(row.numel(), generator=g) < 0.05] = 1e-9
+    eid, ewd, cld = ei.to(dev), ew.to(dev), cl.to(dev)
+    ai = K_.build_assign_index(cld, k)
+    for rsl in (True, False):
+        r_ei, r_ew = _oracle64(O.sparse_connect, ei, ew, torch.arange(n), cl, n, k, reduce_op=op, remove_self_loops=rsl)
+        got_rows = K_.coalesce_edges(eid, ewd, cld, k, op, rsl, assign_index=ai, route="rows")
+        got_gen = K_.coalesce_edges(eid, ewd, cld, k, op, rsl, route="general")
+        got_auto = K_.coalesce_edges(eid, ewd, cld, k, op, rsl, assign_index=ai)
+        for got in (got_rows, got_gen, got_auto):
+            assert got[1].dtype == torch.float64 and torch.equal(got[0].cpu(), r_ei)
+            torch.testing.assert_close(got[1].cpu(), r_ew, rtol=1e-13, atol=1e-13)
+        assert torch.equal(got_rows[1], got_auto[1])
+    # which route the automatic choice took
+    calls = []
+    L = K_.N.lib()
+    real = L.tgp_connect_coalesce_rows_count_published_f64
+
+    class Spy:
+        def __getattr__(self, name):
+            if name == "tgp_connect_coalesce_rows_count_published_f64":
+                return lambda *a: (calls.append(1), real(*a))[1]
+            return getattr(L, name)
+    old = K_.N.lib
+    K_.N.lib = lambda: Spy()
+    try:
+        K_.coalesce_edges(eid, ewd, cld, k, op, True, assign_index=ai)
+    finally:
+        K_.N.lib = old
+    assert calls == [1]
+    # a hub row: the row-local count answers -5 (float64 has no hub kernels), the general route takes the call
+    deg2 = deg.clone()
+    deg2[members_of_7[:3]] = 600
+    row2 = torch.repeat_interleave(torch.arange(n), deg2)
+    col2 = torch.randint(0, n, (row2.numel(),), generator=g)
+    ew2 = torch.rand(row2.numel(), generator=g, dtype=torch.float64)
+    ei2 = torch.stack([row2, col2])
+    r_ei, r_ew = _oracle64(O.sparse_connect, ei2, ew2, torch.arange(n), cl, n, k, reduce_op=op, remove_self_loops=True)
+    got = K_.coalesce_edges(ei2.to(dev), ew2.to(dev), cld, k, op, True, assign_index=ai)
+    assert torch.equal(got[0].cpu(), r_ei)
+    torch.testing.assert_close(got[1].cpu(), r_ew, rtol=1e-13, atol=1e-13)
+    with pytest.raises(RuntimeError):
+        K_.coalesce_edges(ei2.to(dev), ew2.to(dev), cld, k, op, True, assign_index=ai, route="rows")

@@ -300,6 +300,17 @@ __device__ __forceinline__ float cr_reduce(float acc, float v, int op) {
     default: return __fadd_rn(acc, v);
   }
 }
+// float64 edge weights (r5): the row-local routes merge in double, as the reference's coalesce does for a double tensor
+__device__ __forceinline__ double cr_reduce(double acc, double v, int op) {
+  switch (op) {
+    case TGP_MIN: return fmin(acc, v);
+    case TGP_MAX: return fmax(acc, v);
+    case TGP_MUL: return __dmul_rn(acc, v);
+    default: return __dadd_rn(acc, v);
+  }
+}
+__device__ __forceinline__ float cr_abs(float v) { return fabsf(v); }
+__device__ __forceinline__ double cr_abs(double v) { return fabs(v); }
 
 // ------------------------------------------------------------------ K4 + K5 fused: gather, sort, merge
 // One workgroup owns GS_ROWS consecutive supernode rows.  Their members are consecutive in the inverted index
@@ -371,9 +382,9 @@ __device__ __forceinline__ uint32_t cr_dpp(uint32_t v) {
   return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, true));
 }
 
-template <int LPR>
-__device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, float* s_val, uint32_t b, uint32_t T, bool mine,
-                                             uint32_t row_id, bool has_w, int reduce_op, int flags, float eps,
+template <int LPR, typename WT>
+__device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, WT* s_val, uint32_t b, uint32_t T, bool mine,
+                                             uint32_t row_id, bool has_w, int reduce_op, int flags, WT eps,
                                              uint32_t* __restrict__ n_out_row) {
   constexpr int PB = LPR == 8 ? 5 : 6;          // position bits: 32 or 64 entries per row
   constexpr uint32_t PM = (1u << PB) - 1u;
@@ -396,12 +407,12 @@ __device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, float* s_val, uint
   // sorted order = (lane, register); invalid keys (0xFFFFFFFF) are last
   uint32_t c[4];
   bool valid[4], head[4];
-  float acc[4];
+  WT acc[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     valid[q] = k[q] != 0xFFFFFFFFu;
     c[q] = k[q] >> PB;
-    acc[q] = (valid[q] && has_w) ? s_val[b + (k[q] & PM)] : 0.f;
+    acc[q] = (valid[q] && has_w) ? s_val[b + (k[q] & PM)] : WT(0);
   }
   const uint32_t pc = cr_dpp<0x111>(c[3]);  // row_shr:1; an earlier element of a valid one is valid
   head[0] = valid[0] && (l == 0 || pc != c[0]);
@@ -429,7 +440,14 @@ __device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, float* s_val, uint
   if (any_fold && !long_run) {  // runs of two: the head takes its successor's weight, in registers
     const uint32_t next_nh = cr_dpp<0x101>(nonhead[0] ? 1u : 0u);  // row_shl:1
     const bool next_nonhead = (l < LPR - 1) & (next_nh != 0u);
-    const float next_acc = __uint_as_float(cr_dpp<0x101>(__float_as_uint(acc[0])));
+    WT next_acc;
+    if constexpr (sizeof(WT) == 4) {
+      next_acc = __uint_as_float(cr_dpp<0x101>(__float_as_uint(acc[0])));
+    } else {  // a double travels as its two halves
+      const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(acc[0]));
+      const uint32_t lo = cr_dpp<0x101>(static_cast<uint32_t>(bits)), hi = cr_dpp<0x101>(static_cast<uint32_t>(bits >> 32));
+      next_acc = __longlong_as_double(static_cast<long long>((static_cast<unsigned long long>(hi) << 32) | lo));
+    }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       if (head[q] && nonhead[q + 1]) {
@@ -463,10 +481,10 @@ __device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, float* s_val, uint
   bool keep[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    if (has_w && reduce_op == TGP_MEAN) acc[q] = acc[q] / static_cast<float>(ncnt[q]);
+    if (has_w && reduce_op == TGP_MEAN) acc[q] = acc[q] / static_cast<WT>(ncnt[q]);
     keep[q] = head[q];
     if ((flags & TGP_REMOVE_SELF_LOOPS) && c[q] == row_id) keep[q] = false;
-    if (has_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc[q]) > eps)) keep[q] = false;
+    if (has_w && (flags & TGP_EPS_FILTER) && !(cr_abs(acc[q]) > eps)) keep[q] = false;
     cnt_lane += keep[q] ? 1u : 0u;
   }
   uint32_t incl = cnt_lane;  // inclusive scan over the LPR lanes of the row
@@ -498,16 +516,17 @@ __device__ __forceinline__ void cr_sort_rows(uint32_t* s_key, float* s_val, uint
 // DIRECT = true : `grouped` already holds the (cluster column | weight bits << 32) entries in supernode-row order
 //                 (the output of the 3-pass radix sort by supernode row, below); slot t of a row is grouped[...+t].
 // CT: int64 columns of the caller's list, or the int32 copy GraclusSelect's CSR already holds (half the column stream).
-template <bool DIRECT, typename CT = int64_t>
+// WT: the weights' type (float, or double for float64 edge weights: r5; DIRECT is float only).
+template <bool DIRECT, typename CT = int64_t, typename WT = float>
 __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
-    const CT* __restrict__ col, const float* __restrict__ w, int64_t E, const int32_t* __restrict__ table,
+    const CT* __restrict__ col, const WT* __restrict__ w, int64_t E, const int32_t* __restrict__ table,
     const int32_t* __restrict__ a_row_ptr, const uint32_t* __restrict__ seg_src, const uint32_t* __restrict__ seg_dst,
     const unsigned long long* __restrict__ grouped, const uint32_t* __restrict__ raw_off, int64_t K, int reduce_op,
-    int flags, float eps,
-    int* __restrict__ bad, uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w, uint32_t* __restrict__ n_out,
+    int flags, WT eps,
+    int* __restrict__ bad, uint32_t* __restrict__ tmp_c, WT* __restrict__ tmp_w, uint32_t* __restrict__ n_out,
     int64_t n_nodes, uint32_t* __restrict__ long_list) {
   __shared__ uint32_t s_key[GS_CAP];
-  __shared__ float s_val[GS_CAP];
+  __shared__ WT s_val[GS_CAP];
   __shared__ uint32_t s_roff[GS_ROWS + 1];
   __shared__ int32_t s_rp[GS_ROWS + 1];
   __shared__ int s_mid[GS_ROWS];
@@ -551,7 +570,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
       for (int t = tid; t < cnt; t += 256) {
         const unsigned long long v = grouped[base + t];
         s_key[t] = static_cast<uint32_t>(v);
-        s_val[t] = __uint_as_float(static_cast<uint32_t>(v >> 32));
+        if constexpr (sizeof(WT) == 4) s_val[t] = __uint_as_float(static_cast<uint32_t>(v >> 32));
       }
     } else {
     // (a+b) member-parallel gather: 8 lanes walk one member's edge range (a contiguous run of the row-sorted
@@ -575,7 +594,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
           dst[r] = d - base;
         }
         CT cc[GR][2];
-        float wv[GR][2];
+        WT wv[GR][2];
 #pragma unroll
         for (int r = 0; r < GR; ++r)
 #pragma unroll
@@ -594,7 +613,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
 #endif
             // streamed once: non-temporal, so that the edge list does not push the cluster table out of the L2
             cc[r][q] = ok ? __builtin_nontemporal_load(col + src[r] + j) : 0;
-            wv[r][q] = (ok && has_w) ? __builtin_nontemporal_load(w + src[r] + j) : 0.f;
+            wv[r][q] = (ok && has_w) ? __builtin_nontemporal_load(w + src[r] + j) : WT(0);
           }
 #pragma unroll
         for (int r = 0; r < GR; ++r)
@@ -647,7 +666,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
             const bool inr = static_cast<uint64_t>(c) < static_cast<uint64_t>(n_nodes);
             if (!inr) *bad = 4;
             s_key[dst[r] + j] = inr ? static_cast<uint32_t>(table[c]) : 0u;
-            s_val[dst[r] + j] = has_w ? w[src[r] + j] : 0.f;
+            s_val[dst[r] + j] = has_w ? w[src[r] + j] : WT(0);
           }
       }
     }
@@ -681,8 +700,8 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
         if (i < re && T > 64 && T <= static_cast<uint32_t>(CR_LONG) && (tid & (LPR - 1)) == 0)
           long_list[atomicAdd(bad + 1, 1)] = static_cast<uint32_t>(r0 + i);
         const bool mine = i < re && T <= 32;
-        cr_sort_rows<LPR>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), has_w, reduce_op, flags,
-                          eps, n_out + r0 + i);
+        cr_sort_rows<LPR, WT>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), has_w, reduce_op,
+                              flags, eps, n_out + r0 + i);
       }
     }
     __syncthreads();
@@ -696,8 +715,8 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
         const bool mine = li < nmid;
         const int i = mine ? s_mid[li] : rs;
         const uint32_t b = s_roff[i] - base, T = s_roff[i + 1] - s_roff[i];
-        cr_sort_rows<LPR>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), has_w, reduce_op, flags,
-                          eps, n_out + r0 + i);
+        cr_sort_rows<LPR, WT>(s_key, s_val, b, mine ? T : 0, mine, static_cast<uint32_t>(r0 + i), has_w, reduce_op,
+                              flags, eps, n_out + r0 + i);
       }
     }
     __syncthreads();
@@ -715,14 +734,15 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
 
 // Rows of 65..1024 raw entries (rare: hub supernodes), left raw in tmp and listed by the gather kernel: a workgroup
 // takes every gridDim.x-th row of the list; bitonic sort of (column << 32 | position) in LDS, sorted + merged in place.
-__global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict__ tmp_c, float* __restrict__ tmp_w,
+template <typename WT>
+__global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict__ tmp_c, WT* __restrict__ tmp_w,
                                                            const uint32_t* __restrict__ raw_off, int64_t K,
-                                                           int64_t E, int reduce_op, int flags, float eps,
+                                                           int64_t E, int reduce_op, int flags, WT eps,
                                                            const int* __restrict__ bad,
                                                            const uint32_t* __restrict__ long_list,
                                                            uint32_t* __restrict__ n_out) {
   __shared__ unsigned long long s_key[CR_LONG];
-  __shared__ float s_w[CR_LONG];
+  __shared__ WT s_w[CR_LONG];
   __shared__ uint32_t s_cnt[4 * 4];
   if (*bad) return;
   const int tid = threadIdx.x;
@@ -735,7 +755,7 @@ __global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict_
     while (P < T) P <<= 1;
     for (uint32_t i = tid; i < P; i += 256) {
       s_key[i] = i < T ? (static_cast<unsigned long long>(tmp_c[b + i]) << 32) | i : ~0ull;
-      s_w[i] = (i < T && tmp_w) ? tmp_w[b + i] : 0.f;
+      s_w[i] = (i < T && tmp_w) ? tmp_w[b + i] : WT(0);
     }
     __syncthreads();
     for (uint32_t k = 2; k <= P; k <<= 1) {
@@ -747,7 +767,7 @@ __global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict_
             const unsigned long long a = s_key[i], c2 = s_key[x];
             if ((a > c2) == up) {
               s_key[i] = c2; s_key[x] = a;
-              const float t = s_w[i]; s_w[i] = s_w[x]; s_w[x] = t;
+              const WT t = s_w[i]; s_w[i] = s_w[x]; s_w[x] = t;
             }
           }
         }
@@ -756,23 +776,23 @@ __global__ __launch_bounds__(256) void cr_rows_long_kernel(uint32_t* __restrict_
     }
     bool keep[4];
     uint32_t rank[4], col[4];
-    float val[4];
+    WT val[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const uint32_t i = it * 256 + tid;
-      keep[it] = false; col[it] = 0; val[it] = 0.f;
+      keep[it] = false; col[it] = 0; val[it] = WT(0);
       if (i < T) {
         const uint32_t c = static_cast<uint32_t>(s_key[i] >> 32);
         const bool head = i == 0 || static_cast<uint32_t>(s_key[i - 1] >> 32) != c;
         if (head) {
-          float acc = s_w[i];
+          WT acc = s_w[i];
           uint32_t cnt = 1;
           for (uint32_t q = i + 1; q < T && static_cast<uint32_t>(s_key[q] >> 32) == c; ++q, ++cnt)
             acc = cr_reduce(acc, s_w[q], reduce_op);
-          if (tmp_w && reduce_op == TGP_MEAN) acc = acc / static_cast<float>(cnt);
+          if (tmp_w && reduce_op == TGP_MEAN) acc = acc / static_cast<WT>(cnt);
           bool k2 = true;
           if ((flags & TGP_REMOVE_SELF_LOOPS) && c == static_cast<uint32_t>(r)) k2 = false;
-          if (tmp_w && (flags & TGP_EPS_FILTER) && !(fabsf(acc) > eps)) k2 = false;
+          if (tmp_w && (flags & TGP_EPS_FILTER) && !(cr_abs(acc) > eps)) k2 = false;
           keep[it] = k2; col[it] = c; val[it] = acc;
         }
       }
@@ -951,14 +971,15 @@ constexpr int FILL_ROWS = 64;
 // left to cr_fill_huge_kernel, which spreads each over the whole grid -- one workgroup walking a 200 000-entry row slot
 // by slot took 3.5 ms (r4, ten hubs)
 constexpr uint32_t FILL_LONG = CR_LONG;
+template <typename WT>
 __global__ __launch_bounds__(256) void cr_fill_kernel(const uint32_t* __restrict__ tmp_c,
-                                                      const float* __restrict__ tmp_w,
+                                                      const WT* __restrict__ tmp_w,
                                                       const uint32_t* __restrict__ raw_off,
                                                       const uint32_t* __restrict__ out_off,
                                                       const int64_t* __restrict__ total, int64_t K,
                                                       const int* __restrict__ bad /* NULL, or: declined -> no-op */,
                                                       int64_t* __restrict__ out_row, int64_t* __restrict__ out_col,
-                                                      float* __restrict__ out_w) {
+                                                      WT* __restrict__ out_w) {
   __shared__ uint32_t s_out[FILL_ROWS + 1], s_raw[FILL_ROWS];
   __shared__ unsigned long long s_hub;
   if (bad && *bad) return;
@@ -1525,7 +1546,7 @@ struct CrWs {
   uint32_t* long_list;   // [E / 64 + 2] long rows in the order the gather kernel met them
 };
 
-static size_t cr_layout(void* ws, int64_t E, int64_t N, int64_t K, CrWs* out) {
+static size_t cr_layout(void* ws, int64_t E, int64_t N, int64_t K, CrWs* out, size_t weight_bytes = sizeof(float)) {
   Carver cv(ws);
   const size_t n = static_cast<size_t>(N > 0 ? N : 1), k = static_cast<size_t>(K > 0 ? K : 1);
   const size_t e = static_cast<size_t>(E > 0 ? E : 1);
@@ -1538,7 +1559,7 @@ static size_t cr_layout(void* ws, int64_t E, int64_t N, int64_t K, CrWs* out) {
   s.n_out = cv.take<uint32_t>(k);
   s.out_off = cv.take<uint32_t>(k);
   s.tmp_c = cv.take<uint32_t>(e);
-  s.tmp_w = cv.take<float>(e);
+  s.tmp_w = reinterpret_cast<float*>(cv.take<char>(e * weight_bytes));  // (doubles for the float64 entry points)
   s.scan_scratch = cv.take<uint32_t>(2 * static_cast<size_t>(cdiv(k, SCAN_TILE) + cdiv(n, MS_TILE)) + 16);
   s.total = cv.take<int64_t>(2);
   s.bad = cv.take<int>(4);
@@ -1586,6 +1607,9 @@ using namespace tgp;
 extern "C" size_t tgp_connect_coalesce_rows_workspace_bytes(int64_t E, int64_t N, int64_t K) {
   return cr_layout(nullptr, E, N, K, nullptr) + 256;
 }
+extern "C" size_t tgp_connect_coalesce_rows_workspace_bytes_f64(int64_t E, int64_t N, int64_t K) {
+  return cr_layout(nullptr, E, N, K, nullptr, sizeof(double)) + 256;
+}
 // with TGP_HUGE_ROWS in the flags of tgp_connect_coalesce_rows_count: room for the device-wide sort of the hub rows
 extern "C" size_t tgp_connect_coalesce_rows_huge_workspace_bytes(int64_t E, int64_t N, int64_t K) {
   return huge_layout(nullptr, align_up(cr_layout(nullptr, E, N, K, nullptr)), E, nullptr) + 256;
@@ -1622,10 +1646,12 @@ struct CrPublish {  // the single-launch survivor scan with the count handed to 
   uint32_t epoch;
 };
 
-static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+template <typename WT>
+static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const WT* w, int64_t E,
                               const int64_t* cluster_index, int64_t N, int64_t K, const int32_t* assign_row_ptr,
-                              const int32_t* assign_perm, const int32_t* csr_ptr, int reduce_op, int flags, float eps,
+                              const int32_t* assign_perm, const int32_t* csr_ptr, int reduce_op, int flags, WT eps,
                               void* ws, size_t ws_bytes, int64_t* d_count, const CrPublish* pub, void* stream_) {
+  constexpr bool F64 = sizeof(WT) == 8;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(E >= 0 && N >= 0 && K >= 0 && d_count, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_count: bad argument");
   TGP_REQUIRE(E == 0 || (row && col && cluster_index && assign_row_ptr && assign_perm), TGP_ERR_INVALID,
@@ -1635,8 +1661,12 @@ static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const floa
   TGP_REQUIRE(E < (1ll << 31) && K < (1ll << 26) && N < (1ll << 31), TGP_ERR_RANGE,
               "tgp_connect_coalesce_rows_count: E/N >= 2^31 or K >= 2^26");
   const bool huge = (flags & TGP_HUGE_ROWS) != 0;
-  TGP_REQUIRE(ws && ws_bytes >= (huge ? tgp_connect_coalesce_rows_huge_workspace_bytes(E, N, K)
-                                      : tgp_connect_coalesce_rows_workspace_bytes(E, N, K)),
+  TGP_REQUIRE(!(F64 && huge), TGP_ERR_INVALID,
+              "tgp_connect_coalesce_rows_count_published_f64: TGP_HUGE_ROWS is float32 only (a list with hub rows answers "
+              "-5 and the caller takes the general float64 route)");
+  TGP_REQUIRE(ws && ws_bytes >= (F64 ? tgp_connect_coalesce_rows_workspace_bytes_f64(E, N, K)
+                                 : huge ? tgp_connect_coalesce_rows_huge_workspace_bytes(E, N, K)
+                                        : tgp_connect_coalesce_rows_workspace_bytes(E, N, K)),
               TGP_ERR_WORKSPACE, "tgp_connect_coalesce_rows_count: workspace too small");
   if (E == 0 || K == 0) {
     (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
@@ -1647,10 +1677,10 @@ static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const floa
     return check_launch("tgp_connect_coalesce_rows_count");
   }
   CrWs s;
-  const size_t cr_end = cr_layout(ws, E, N, K, &s);
+  const size_t cr_end = cr_layout(ws, E, N, K, &s, sizeof(WT));
   HugeWs h{};
   if (huge) huge_layout(ws, align_up(cr_end), E, &h);
-  float* tmp_w = w ? s.tmp_w : nullptr;
+  WT* tmp_w = w ? reinterpret_cast<WT*>(s.tmp_w) : nullptr;
   if (!csr_ptr) (void)hipMemsetAsync(s.bad, 0, 4 * sizeof(int), stream);
   if (csr_ptr) {
     // CSR offsets of this very list from the caller (GraclusSelect builds them): no pass over the row array
@@ -1689,6 +1719,7 @@ static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const floa
                        s.raw_off, huge ? h.list : static_cast<uint32_t*>(nullptr), s.n_out,
                        static_cast<const unsigned long long*>(nullptr), 0ull);
   }
+  if constexpr (!F64)
   if (huge) {  // rows beyond CR_LONG entries (hubs): their entries alone are sorted device-wide (see cr_huge_*_kernel)
     const int colbits = bits_for(static_cast<uint64_t>(K - 1));
     const uint32_t* n_dev = reinterpret_cast<const uint32_t*>(s.bad + 3);
@@ -1710,15 +1741,15 @@ static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const floa
   // (measured r2: splitting the gather into an edge-parallel permute pass + the DIRECT sort kernel costs 114 + 103 us
   //  against 185 us for the fused gather: the 10 M random 4-byte table look-ups take ~50 us wherever they run)
   if (pub && pub->csr_col && csr_ptr)
-    hipLaunchKernelGGL((cr_gather_sort_kernel<false, int32_t>), dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, pub->csr_col,
+    hipLaunchKernelGGL((cr_gather_sort_kernel<false, int32_t, WT>), dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, pub->csr_col,
                        w, E, s.table, assign_row_ptr, s.seg_src, s.seg_dst,
                        static_cast<const unsigned long long*>(nullptr), s.raw_off, K, reduce_op, flags, eps, s.bad,
                        s.tmp_c, tmp_w, s.n_out, N, s.long_list);
   else
-    hipLaunchKernelGGL((cr_gather_sort_kernel<false, int64_t>), dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, col, w, E,
+    hipLaunchKernelGGL((cr_gather_sort_kernel<false, int64_t, WT>), dim3(cdiv(K, GS_ROWS)), dim3(256), 0, stream, col, w, E,
                        s.table, assign_row_ptr, s.seg_src, s.seg_dst, static_cast<const unsigned long long*>(nullptr),
                        s.raw_off, K, reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out, N, s.long_list);
-  hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cr_long_grid(K)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
+  hipLaunchKernelGGL(cr_rows_long_kernel<WT>, dim3(cr_long_grid(K)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
                      reduce_op, flags, eps, s.bad, s.long_list, s.n_out);
   if (pub) {
     hipLaunchKernelGGL(cr_scan_publish_kernel, dim3(cdiv(K, SCAN_TILE)), dim3(256), 0, stream, s.n_out, K, s.out_off,
@@ -1736,8 +1767,8 @@ extern "C" int tgp_connect_coalesce_rows_count(const int64_t* row, const int64_t
                                                const int32_t* assign_row_ptr, const int32_t* assign_perm,
                                                const int32_t* csr_ptr, int reduce_op, int flags, float eps, void* ws,
                                                size_t ws_bytes, int64_t* d_count, void* stream_) {
-  return cr_rows_count_impl(row, col, w, E, cluster_index, N, K, assign_row_ptr, assign_perm, csr_ptr, reduce_op, flags,
-                            eps, ws, ws_bytes, d_count, nullptr, stream_);
+  return cr_rows_count_impl<float>(row, col, w, E, cluster_index, N, K, assign_row_ptr, assign_perm, csr_ptr, reduce_op,
+                                   flags, eps, ws, ws_bytes, d_count, nullptr, stream_);
 }
 
 // The same pipeline with the survivor scan as one launch (decoupled look-back over `status`, epoch-tagged: caller-owned,
@@ -1763,8 +1794,30 @@ extern "C" int tgp_connect_coalesce_rows_count_published(const int64_t* row, con
   TGP_REQUIRE(!csr_col || csr_ptr, TGP_ERR_INVALID,
               "tgp_connect_coalesce_rows_count_published: int32 columns without the offsets of the same list");
   const CrPublish pub{csr_col, status, result, epoch};
-  return cr_rows_count_impl(row, col, w, E, cluster_index, N, K, assign_row_ptr, assign_perm, csr_ptr, reduce_op, flags,
-                            eps, ws, ws_bytes, d_count, &pub, stream_);
+  return cr_rows_count_impl<float>(row, col, w, E, cluster_index, N, K, assign_row_ptr, assign_perm, csr_ptr, reduce_op,
+                                   flags, eps, ws, ws_bytes, d_count, &pub, stream_);
+}
+
+// float64 edge weights on the same row-local pipeline (r5: they took the general sort-based route, 0.6 ms against 0.24
+// at C4): values staged, merged (sum / mean / min / max / mul) and eps-filtered in double, as the reference's coalesce does
+// for a double tensor (connect/base_conn.py:86-89).  Workspace: tgp_connect_coalesce_rows_workspace_bytes_f64; hub rows
+// (TGP_HUGE_ROWS) are float32 only: such a list answers -5 here and the caller takes tgp_connect_coalesce_count_f64.
+extern "C" int tgp_connect_coalesce_rows_count_published_f64(
+    const int64_t* row, const int64_t* col, const int32_t* csr_col, const double* w, int64_t E,
+    const int64_t* cluster_index, int64_t N, int64_t K, const int32_t* assign_row_ptr, const int32_t* assign_perm,
+    const int32_t* csr_ptr, int reduce_op, int flags, double eps, void* ws, size_t ws_bytes, int64_t* d_count,
+    uint64_t* status, int64_t status_words, uint64_t* result, uint32_t epoch, void* stream_) {
+  TGP_REQUIRE(status && result && d_count && w, TGP_ERR_INVALID,
+              "tgp_connect_coalesce_rows_count_published_f64: bad argument");
+  TGP_REQUIRE(status_words >= tgp_connect_coalesce_rows_count_status_words(K, N), TGP_ERR_WORKSPACE,
+              "tgp_connect_coalesce_rows_count_published_f64: status buffer too small");
+  TGP_REQUIRE(epoch != 0 && epoch < (1u << 29), TGP_ERR_RANGE,
+              "tgp_connect_coalesce_rows_count_published_f64: epoch out of range");
+  TGP_REQUIRE(!csr_col || csr_ptr, TGP_ERR_INVALID,
+              "tgp_connect_coalesce_rows_count_published_f64: int32 columns without the offsets of the same list");
+  const CrPublish pub{csr_col, status, result, epoch};
+  return cr_rows_count_impl<double>(row, col, w, E, cluster_index, N, K, assign_row_ptr, assign_perm, csr_ptr, reduce_op,
+                                    flags, eps, ws, ws_bytes, d_count, &pub, stream_);
 }
 
 // ------------------------------------------------------------------ fused row-sorted path (r3), see cr_fused_kernel
@@ -1999,7 +2052,7 @@ extern "C" int tgp_connect_coalesce_grouped_count(const int64_t* row, const int6
                      static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr),
                      static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), vals, s.raw_off, K,
                      reduce_op, flags, eps, s.bad, s.tmp_c, tmp_w, s.n_out, N, s.long_list);
-  hipLaunchKernelGGL(cr_rows_long_kernel, dim3(cr_long_grid(K)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
+  hipLaunchKernelGGL(cr_rows_long_kernel<float>, dim3(cr_long_grid(K)), dim3(256), 0, stream, s.tmp_c, tmp_w, s.raw_off, K, E,
                      reduce_op, flags, eps, s.bad, s.long_list, s.n_out);
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);
   return check_launch("tgp_connect_coalesce_grouped_count");
@@ -2016,7 +2069,7 @@ extern "C" int tgp_connect_coalesce_rows_fill(const void* ws, int64_t E, int64_t
   CrWs s;
   const size_t cr_end = cr_layout(const_cast<void*>(ws), E, N, K, &s);
   const bool weights = (has_weight & 1) != 0;
-  hipLaunchKernelGGL(cr_fill_kernel, dim3(cdiv(K, FILL_ROWS)), dim3(256), 0, stream, s.tmp_c,
+  hipLaunchKernelGGL(cr_fill_kernel<float>, dim3(cdiv(K, FILL_ROWS)), dim3(256), 0, stream, s.tmp_c,
                      weights ? s.tmp_w : nullptr, s.raw_off, s.out_off, s.total, K, static_cast<const int*>(nullptr),
                      out_row, out_col, weights ? out_w : nullptr);
   if (has_weight & 2) {  // the count call ran with TGP_HUGE_ROWS: hub rows are copied by the whole grid
@@ -2026,6 +2079,20 @@ extern "C" int tgp_connect_coalesce_rows_fill(const void* ws, int64_t E, int64_t
                        s.raw_off, s.out_off, s.n_out, K, h.list, s.bad, out_row, out_col, weights ? out_w : nullptr);
   }
   return check_launch("tgp_connect_coalesce_rows_fill");
+}
+
+extern "C" int tgp_connect_coalesce_rows_fill_f64(const void* ws, int64_t E, int64_t N, int64_t K, int64_t num_out,
+                                                  int64_t* out_row, int64_t* out_col, double* out_w, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(ws && num_out >= 0, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_fill_f64: bad argument");
+  if (num_out == 0 || E == 0 || K == 0) return TGP_OK;
+  TGP_REQUIRE(out_row && out_col && out_w, TGP_ERR_INVALID, "tgp_connect_coalesce_rows_fill_f64: null output");
+  CrWs s;
+  cr_layout(const_cast<void*>(ws), E, N, K, &s, sizeof(double));
+  hipLaunchKernelGGL(cr_fill_kernel<double>, dim3(cdiv(K, FILL_ROWS)), dim3(256), 0, stream, s.tmp_c,
+                     reinterpret_cast<const double*>(s.tmp_w), s.raw_off, s.out_off, s.total, K,
+                     static_cast<const int*>(nullptr), out_row, out_col, out_w);
+  return check_launch("tgp_connect_coalesce_rows_fill_f64");
 }
 
 #ifdef TGP_GEMM_STAMPS

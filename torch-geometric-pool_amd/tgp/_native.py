@@ -67,6 +67,11 @@ SIGNATURES = {
                                                            _c_i64, _c_p, ctypes.c_uint32, _c_p]),
     "tgp_connect_coalesce_rows_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_p, _c_p, _c_p,
                                                 _c_p]),
+    "tgp_connect_coalesce_rows_workspace_bytes_f64": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "tgp_connect_coalesce_rows_count_published_f64": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p,
+                                                               _c_p, _c_p, _c_int, _c_int, ctypes.c_double, _c_p, _c_sz,
+                                                               _c_p, _c_p, _c_i64, _c_p, ctypes.c_uint32, _c_p]),
+    "tgp_connect_coalesce_rows_fill_f64": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p]),
     "tgp_connect_coalesce_fused_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
     "tgp_connect_coalesce_fused_count": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p,
                                                   _c_p, _c_int, _c_int, _c_f, _c_p, _c_p, _c_sz, _c_p, _c_p]),

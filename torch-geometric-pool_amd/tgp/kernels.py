@@ -654,13 +654,54 @@ def coalesce_edges(edge_index: Tensor, edge_weight: Optional[Tensor], cluster_in
     row, col = _edge_rows(edge_index)
     E = row.numel()
     if edge_weight is not None and edge_weight.dtype == torch.float64:
-        # fp64 weights are merged in fp64 (the reference's coalesce / scatter do): the sort-based route, in double
-        if route not in (None, "general"):
-            raise RuntimeError("float64 edge weights take the general coalesce route")
+        # fp64 weights are merged in fp64 (the reference's coalesce / scatter do).  r5: row-sorted input with the
+        # assignment's member index at hand takes the row-local pipeline in double (no device-wide sort); anything else
+        # (unsorted rows, a hub row, stream capture) the sort-based route, in double too
+        if route not in (None, "general", "staged", "rows"):
+            raise RuntimeError("float64 edge weights take the staged row-local or the general coalesce route")
         w = N.f64c(edge_weight.reshape(-1))
         cl = N.i64c(cluster_index)
         flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if eps_filter else 0)
         L = N.lib()
+        rowish = route in ("staged", "rows")
+        if rowish and assign_index is None:
+            assign_index = build_assign_index(cl, num_supernodes)
+        if csr is not None and (csr[0].dtype != torch.int32 or csr[0].numel() != cl.numel() + 1
+                                or not csr[0].is_contiguous()):
+            raise ValueError("csr must be (int32 [N+1], int32 [E] or None) contiguous tensors of this edge list")
+        rows_ok = (route != "general" and assign_index is not None and assign_index.nnz == cl.numel()
+                   and assign_index.num_targets == num_supernodes and num_supernodes < (1 << 26) and E > 0
+                   and not torch.cuda.is_current_stream_capturing()
+                   and (rowish or csr is not None or _rows_sorted_memo(edge_index) is not False))
+        if rows_ok:
+            st = N.stream_ptr(dev)
+            ws = N.workspace(L.tgp_connect_coalesce_rows_workspace_bytes_f64(E, cl.numel(), num_supernodes), dev)
+            d_count = torch.empty(1, dtype=torch.int64, device=dev)
+            state = _sps_state(dev, st, L.tgp_connect_coalesce_rows_count_status_words(num_supernodes, cl.numel()))
+            epoch = state.next_epoch()
+            N.check(L.tgp_connect_coalesce_rows_count_published_f64(
+                N.ptr(row), N.ptr(col), None, N.ptr(w), E, N.ptr(cl), cl.numel(), num_supernodes,
+                N.ptr(assign_index.row_ptr), N.ptr(assign_index.perm), N.ptr(csr[0]) if csr is not None else None,
+                N.REDUCE_OPS[reduce_op], flags, ops_eps(), N.ptr(ws), ws.numel(), N.ptr(d_count),
+                state.status.data_ptr(), state.status.numel(), state.pinned.data_ptr(), epoch, st),
+                "tgp_connect_coalesce_rows_count_published_f64")
+            n_out = _decode_count(state.wait(epoch))
+            if n_out >= 0:
+                out_ei = torch.empty(2, n_out, dtype=torch.int64, device=dev)
+                out_w = torch.empty(n_out, dtype=torch.float64, device=dev)
+                N.check(L.tgp_connect_coalesce_rows_fill_f64(N.ptr(ws), E, cl.numel(), num_supernodes, n_out,
+                                                             N.ptr(out_ei[0]) if n_out else None,
+                                                             N.ptr(out_ei[1]) if n_out else None,
+                                                             N.ptr(out_w) if n_out else None, st),
+                        "tgp_connect_coalesce_rows_fill_f64")
+                return out_ei, out_w
+            del ws
+            if rowish:
+                raise RuntimeError("row-local coalesce route declined (unsorted rows or a supernode row too long)")
+            if n_out == -1 and csr is None and _rows_sorted_memo(edge_index) is None:
+                _rows_sorted(edge_index, row)  # remember an unsorted list: later calls skip the attempt
+        elif rowish:
+            raise RuntimeError("row-local coalesce route not applicable")
         ws = N.workspace(L.tgp_connect_coalesce_workspace_bytes_f64(E, cl.numel(), num_supernodes), dev)
         d_count = torch.empty(1, dtype=torch.int64, device=dev)
         st = N.stream_ptr(dev)
