@@ -30,6 +30,9 @@ python3 tools/fresh_profile.py topk_c3 graclus_c3 mincut_c3 2>&1 | grep -E "^==|
 stats kron python3 tools/bench_kron.py --no-reference
 python3 tools/bench_kron.py > $out/kron.txt 2>&1
 python3 tools/e2e_launches.py > $out/e2e_launches.txt 2>&1
+python3 tools/train_step_sequence.py 2>&1 | grep -v -i 'warn\|amdgpu.ids' | cut -c1-170 > $out/train_step_sequence.txt
+python3 tools/bench_mlp_select_bwd.py 2>&1 | grep -v -i 'warn\|amdgpu.ids' > $out/mlp_select_bwd.txt
+python3 tools/bench_coalesce_f64.py 2>&1 | grep -v -i 'warn\|amdgpu.ids' > $out/coalesce_f64.txt
 python3 tools/e2e_fresh_batch.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $out/e2e_fresh_batch.txt
 python3 tools/bench_poolers_e2e.py > $out/e2e_poolers.txt 2>&1
 python3 tools/bench_ndp_large.py > $out/ndp_large.txt 2>&1
