@@ -583,7 +583,10 @@ class TopkBatch(Workload):
         if self.gather:
             # ONE payload collective per bucket of eight steps, asynchronous, two deep: a gather overlaps the next steps' kernels
             from tgp.distributed import SparseGather
+            # the merged outputs are handed out as exact-size contiguous tensors (SparseGather's default, the reference's
+            # collate contract); `sg_views` hands out views of the receive buffer instead and is timed beside it
             self.sg = SparseGather(force_collective=force_collective, depth=2, bucket_steps=8)
+            self.sg_views = SparseGather(force_collective=force_collective, depth=2, bucket_steps=8, views=True)
             self.drain = self.sg.flush
         self.nodes = self.x.size(0)
         self.num_graphs = 2048
@@ -629,11 +632,16 @@ class TopkBatch(Workload):
         return self.staged(inputs)
 
     def step(self):
-        xp, ei, ew, bp = self.compute()
         if self.gather:
+            # the step's outputs go straight into the gather's pack launch: the capacity views are enough for that
+            # hand-off (tgp.output_views(): no compaction launch); what the gather hands OUT are exact-size tensors
+            from tgp import kernels
+            with kernels.output_views():
+                xp, ei, ew, bp = self.compute()
             self.sg.start(xp, ei, ew, bp, self.num_graphs)
             self.sg.take_ready()  # a consumer would use these; the bench only must not accumulate them
-        return xp, ei, ew, bp
+            return xp, ei, ew, bp
+        return self.compute()
 
     def cpu_pass(self):
         O = _oracle()
@@ -681,9 +689,14 @@ class TopkBatch(Workload):
             ms_g = event_time_ms(self.step, 50, dev)
             self.sg.flush()
             r["compute_plus_gather_ms"] = round(ms_g, 5)
+            exact, self.sg = self.sg, self.sg_views
+            r["compute_plus_gather_views_ms"] = round(event_time_ms(self.step, 50, dev), 5)
+            self.sg.flush()
+            self.sg = exact
             r["gather"] = ("SparseGather: one pack launch, one payload collective and one unpack (+ id offsets) launch per "
                            "bucket of 8 steps, asynchronous (two buckets in flight), totals through pinned host words (no "
-                           "host wait)")
+                           "host wait); the step's own outputs are handed to it as capacity views, the merged outputs "
+                           "leave it as exact-size contiguous tensors (one tgp_copy_arrays launch per step)")
             from tgp.distributed import all_gather_sparse
             merged = all_gather_sparse(xp, ei, ew, bp, self.num_graphs, force_collective=self.force)
             if self.dist_world == 1:  # one-rank group: the merged result must be the local one, bit for bit

@@ -778,6 +778,10 @@ int tgp_debug_sort_pairs_u64(const uint64_t* keys_in, const uint32_t* vals_in, i
 int tgp_edges_compact(const int64_t* row, const int64_t* col, const void* weight, int weight_bytes,
                       const int64_t* edge_id, int64_t n, int64_t* out_row, int64_t* out_col, void* out_weight,
                       int64_t* out_edge_id, void* stream);
+/* The same kernel for up to eight unrelated arrays (host arrays of `count` device pointers / byte counts, each a multiple
+ * of 4): the merged outputs of a gathered step (tgp/data/collate.py:144-153) leave the receive buffer as exact-size
+ * tensors in one launch. */
+int tgp_copy_arrays(const void* const* src, void* const* dst, const int64_t* bytes, int count, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * float64 value types of the HBM-bound operators (r4).  The reference's ATen ops compute model.double() inputs in fp64

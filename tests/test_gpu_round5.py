@@ -769,3 +769,21 @@ def test_float64_edge_weights_take_the_row_local_coalesce(dev, op):
     torch.testing.assert_close(got[1].cpu(), r_ew, rtol=1e-13, atol=1e-13)
     with pytest.raises(RuntimeError):
         K_.coalesce_edges(ei2.to(dev), ew2.to(dev), cld, k, op, True, assign_index=ai, route="rows")
+
+
+@pytest.mark.gpu
+def test_copy_arrays_entry_point(dev):
+    """tgp_copy_arrays: up to eight unrelated arrays in one launch (16-, 8- and 4-byte paths, empty arrays, odd offsets)."""
+    import ctypes
+    from tgp import _native as N
+    g = torch.Generator().manual_seed(3)
+    srcs = [torch.randn(n, generator=g).to(dev) for n in (1000, 7, 0, 4096, 33, 1, 12345, 64)]
+    srcs[4] = srcs[4][1:]  # 4-byte aligned only
+    dsts = [torch.full_like(s, -1.0) for s in srcs]
+    n = len(srcs)
+    N.check(N.lib().tgp_copy_arrays((ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs]),
+                                    (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts]),
+                                    (ctypes.c_int64 * n)(*[s.numel() * 4 for s in srcs]), n, N.stream_ptr(dev)),
+            "tgp_copy_arrays")
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(s, d)

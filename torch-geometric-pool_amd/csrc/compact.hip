@@ -9,10 +9,11 @@
 namespace tgp {
 
 // 16-byte moves where source and destination allow it, scalar otherwise; one grid for all arrays (blockIdx.y = array)
+constexpr int COMPACT_MAX = 8;
 struct CompactArgs {
-  const char* src[4];
-  char* dst[4];
-  int64_t bytes[4];
+  const char* src[COMPACT_MAX];
+  char* dst[COMPACT_MAX];
+  int64_t bytes[COMPACT_MAX];
 };
 
 __global__ __launch_bounds__(256) void edges_compact_kernel(CompactArgs a) {
@@ -66,4 +67,26 @@ extern "C" int tgp_edges_compact(const int64_t* row, const int64_t* col, const v
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(edges_compact_kernel, dim3(static_cast<unsigned>(blocks), 4), dim3(256), 0, stream, a);
   return check_launch("tgp_edges_compact");
+}
+
+// Up to eight independent arrays in ONE launch (byte counts multiples of 4): the merged outputs of a gathered step leave
+// the receive buffer as exact-size tensors this way (tgp.distributed.SparseGather: four clone launches per step before).
+extern "C" int tgp_copy_arrays(const void* const* src, void* const* dst, const int64_t* bytes, int count, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(src && dst && bytes && count >= 0 && count <= COMPACT_MAX, TGP_ERR_INVALID, "tgp_copy_arrays: bad argument");
+  CompactArgs a{};
+  int64_t longest = 0;
+  for (int i = 0; i < count; ++i) {
+    TGP_REQUIRE(bytes[i] >= 0 && (bytes[i] & 3) == 0 && (bytes[i] == 0 || (src[i] && dst[i])), TGP_ERR_INVALID,
+                "tgp_copy_arrays: array %d: null pointer or a size that is not a multiple of 4 bytes", i);
+    a.src[i] = static_cast<const char*>(src[i]); a.dst[i] = static_cast<char*>(dst[i]); a.bytes[i] = bytes[i];
+    if (bytes[i] > longest) longest = bytes[i];
+  }
+  if (longest == 0) return TGP_OK;
+  int64_t blocks = (longest / 16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(edges_compact_kernel, dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(count)), dim3(256), 0,
+                     stream, a);
+  return check_launch("tgp_copy_arrays");
 }

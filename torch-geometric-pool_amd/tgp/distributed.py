@@ -17,6 +17,11 @@ import torch.distributed as dist
 from torch import Tensor
 
 
+import ctypes as _ctypes
+
+_COPY_SRC, _COPY_DST, _COPY_BYTES = (_ctypes.c_void_p * 8)(), (_ctypes.c_void_p * 8)(), (_ctypes.c_int64 * 8)()
+
+
 def shard_bounds(num_graphs: int, world_size: int) -> List[Tuple[int, int]]:
     """Contiguous, balanced graph-id ranges (``batch`` stays sorted inside every shard)."""
     base, extra = divmod(num_graphs, world_size)
@@ -523,14 +528,42 @@ class SparseGather:
         if wo is not None:
             wo = self._restore(wo, w_in)
         if not self.views:  # the reference's collate hands out fresh tensors of the merged size: so does the default
-            def own(t, like=None):
-                if t is None:
-                    return None
-                # (a dtype restore above already made a fresh tensor)
-                fresh = t.untyped_storage().nbytes() == t.numel() * t.element_size() and t.is_contiguous()
-                return t if fresh else t.clone(memory_format=torch.contiguous_format)
-            xo, eo, wo, bo = own(xo), own(eo), own(wo), own(bo)
+            xo, eo, wo, bo = self._own(xo, eo, wo, bo)
         self._ready.append((xo, eo, wo, bo))
+
+    @staticmethod
+    def _own(*tensors):
+        """Exact-size copies of the slices of a receive buffer: device tensors in ONE launch (tgp_copy_arrays; a tensor
+        the dtype restore already made fresh is kept), host tensors with clone()."""
+        out = list(tensors)
+        todo = [i for i, t in enumerate(out)
+                if t is not None and not (t.is_contiguous() and t.untyped_storage().nbytes() == t.numel() * t.element_size())]
+        if not todo:
+            return out
+        first = out[todo[0]]
+        if not first.is_cuda or any((out[i].numel() * out[i].element_size()) & 3 for i in todo):
+            for i in todo:
+                out[i] = out[i].clone(memory_format=torch.contiguous_format)
+            return out
+        from . import _native as N
+        src, dst, nbytes = _COPY_SRC, _COPY_DST, _COPY_BYTES  # (reused ctypes arrays: the call reads them at once)
+        n = 0
+        for i in todo:
+            t = out[i]
+            es = t.element_size()
+            new = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+            if t.dim() == 2 and not t.is_contiguous():  # edge_index: a [2, E'] view whose rows are contiguous
+                rows, cols = t.shape
+                sp, dp, step = t.data_ptr(), new.data_ptr(), t.stride(0) * es
+                for r in range(rows):
+                    src[n], dst[n], nbytes[n] = sp + r * step, dp + r * cols * es, cols * es
+                    n += 1
+            else:
+                src[n], dst[n], nbytes[n] = t.data_ptr(), new.data_ptr(), t.numel() * es
+                n += 1
+            out[i] = new
+        N.check(N.lib().tgp_copy_arrays(src, dst, nbytes, n, N.stream_ptr(first.device)), "tgp_copy_arrays")
+        return out
 
     def _finalise_oldest(self, block: bool, allow_redo: bool = False) -> bool:
         if not self._inflight:
