@@ -29,7 +29,7 @@ static const int kStage2TileM = getenv("TGP_STAGE2_TILE_M") ? atoi(getenv("TGP_S
 struct DensePlan {
   int splits, tile, tile_m;
   int k_per_split;
-  size_t u_floats, aslab_floats, xslab_floats, post_floats;
+  size_t u_floats, aslab_floats, xslab_floats, post_floats, colsum_floats;
 };
 
 static DensePlan dense_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
@@ -72,6 +72,7 @@ static DensePlan dense_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
   p.aslab_floats = static_cast<size_t>(B) * splits * K * K;
   p.xslab_floats = static_cast<size_t>(B) * splits * K * F;
   p.post_floats = post_ws_floats(B, K);
+  p.colsum_floats = static_cast<size_t>(B) * splits * ((K + 63) / 64) * K;  // post_rows_kernel's degree partials
   return p;
 }
 
@@ -83,7 +84,7 @@ extern "C" size_t tgp_dense_pool_workspace_bytes(int64_t B, int64_t N, int64_t K
   if (B <= 0 || N <= 0 || K <= 0) return 256;
   const DensePlan p = dense_plan(B, N, K, F > 0 ? F : 0);
   return align_up(p.u_floats * 4) + align_up(p.aslab_floats * 4) + align_up(p.xslab_floats * 4) +
-         align_up(p.post_floats * 4) + 256;
+         align_up(p.post_floats * 4) + align_up(p.colsum_floats * 4) + 256;
 }
 
 static bool dense_pool_small_ok(int64_t B, int64_t N, int64_t K, int64_t F) {
@@ -239,6 +240,7 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
   float* aslab = cv.take<float>(p.aslab_floats);
   float* xslab = cv.take<float>(p.xslab_floats);
   float* postws = cv.take<float>(p.post_floats);
+  float* colpart = cv.take<float>(p.colsum_floats);
 
   if (want_a) {
     // U[b] = A[b] S[b]     (M = N, Kd = N, Nc = K)
@@ -267,7 +269,28 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
       h.rhs[0] = want_a ? ra : rx;
 
     }
-    launch_gemm<true>(h, static_cast<int>(B), stream);
+    // r5: K / 16 workgroups per graph post-process (post_rows_kernel) when the second product can leave the partial
+    // column sums the degree vector needs (64 x 64 tiles, sum over dim -2, no edge_weight_norm)
+    if (want_a && post_rows_ok(K, flags, aslab, adj_raw, adj_pool) && p.tile == 64 && p.tile_m == 64 &&
+        p.splits <= PR_MAX_SPLITS && p.splits * ((K + 63) / 64) <= 2 * PR_MAX_SPLITS) {
+      h.colsum = colpart;
+      h.colsum_skip_diag = (flags & TGP_REMOVE_SELF_LOOPS) ? 1 : 0;
+    }
+    int tiles_m = 0;
+    const bool have_colsum = launch_gemm<true>(h, static_cast<int>(B), stream, &tiles_m);
+    if (have_colsum) {
+      PostRowsArgs r{};
+      r.slab = aslab; r.splits = p.splits; r.s_split = K * K; r.s_batch = static_cast<long>(p.splits) * K * K;
+      r.colsum = (flags & TGP_DEGREE_NORM) ? colpart : nullptr; r.tiles_m = tiles_m;
+      r.K = static_cast<int>(K); r.flags = flags; r.eps = eps; r.raw = adj_raw; r.dst = adj_pool;
+      if (want_x) {
+        r.xslab = xslab; r.xs_split = K * F; r.xs_batch = static_cast<long>(p.splits) * K * F;
+        r.F = static_cast<int>(F); r.x_pool = x_pool;
+      }
+      const unsigned grid = static_cast<unsigned>(B * ((K + PR_ROWS - 1) / PR_ROWS));
+      hipLaunchKernelGGL(post_rows_kernel, dim3(grid), dim3(512), 0, stream, r);
+      return check_launch("tgp_dense_pool_f32");
+    }
   }
   bool x_done = !want_x;
   if (want_a) {

@@ -409,6 +409,138 @@ __global__ __launch_bounds__(1024) void post_lds_kernel(PostArgs p, int B, XComb
   }
 }
 
+// r5: the same post-processing SPREAD over K / 16 workgroups per graph (C2: 9.5 us for one 1024-thread workgroup per
+// graph -- 32 CUs walking four dependent phases over 256 KB each -- against ~5 us here).  A workgroup owns 16 rows of
+// A'.  It does not read the other rows to learn their degrees: the second product's epilogue left partial COLUMN sums
+// per (split, row tile, column) (GemmArgs.colsum, the diagonal left out when the self loops are removed), so the degree
+// vector d_j = sqrt(max(sum_i R1_ij, eps)) of utils/ops.py:311-320 (sum over dim -2, R1 = R with its diagonal cleared)
+// costs splits * tiles_m numbers per column.  Only for TGP_SUM_AXIS_ROWS (column sums: the connectors' default adj_transpose=True) without
+// edge_weight_norm; K % 4 == 0.  The summation order of d differs from post_lds_kernel's (partials per 64-row tile
+// first): both orders are fixed, results agree to rounding.
+struct PostRowsArgs {
+  const float* slab; int splits; long s_split, s_batch;  // [B][splits][K][K]
+  const float* colsum; int tiles_m;                       // [B][splits][tiles_m][K] or NULL (no degree norm)
+  int K, flags; float eps;
+  float* raw; float* dst;                                 // [B][K][K], raw optional
+  const float* xslab; long xs_split, xs_batch; int F; float* x_pool;  // [B][splits][K][F] -> [B][K][F], or NULL
+};
+
+constexpr int PR_ROWS = 16;
+constexpr int PR_MAX_SPLITS = 8;  // node-range splits of the second product this kernel takes (x 2 row tiles for K <= 128...)
+
+__global__ __launch_bounds__(512) void post_rows_kernel(PostRowsArgs p) {
+  __shared__ float s_d[1024];
+  const int K = p.K, tid = threadIdx.x;
+  const int blocks_per_graph = (K + PR_ROWS - 1) / PR_ROWS;
+  const int b = blockIdx.x / blocks_per_graph, rb = blockIdx.x - b * blocks_per_graph;
+  const int i0 = rb * PR_ROWS;
+  const float* sb = p.slab + static_cast<long>(b) * p.s_batch;
+  const bool rsl = p.flags & TGP_REMOVE_SELF_LOOPS, dn = (p.flags & TGP_DEGREE_NORM) && p.colsum;
+  const int kq = K >> 2;  // float4 per row
+  // this workgroup's elements: requested first, consumed behind the degree vector
+  float4 acc[2];
+  bool mine[2];
+  int ei[2], ej[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + u * 512;  // float4 index inside the 16-row block
+    const int il = e / kq, jq = e - il * kq;
+    ei[u] = i0 + il; ej[u] = jq * 4;
+    mine[u] = il < PR_ROWS && ei[u] < K;
+    // every slab's value is requested before the first add (a loop with a run-time trip count waits per load)
+    float4 v[PR_MAX_SPLITS];
+    const float* q = sb + (mine[u] ? static_cast<long>(ei[u]) * K + ej[u] : 0);
+#pragma unroll
+    for (int sp = 0; sp < PR_MAX_SPLITS; ++sp)
+      v[sp] = *reinterpret_cast<const float4*>(q + (sp < p.splits ? sp * p.s_split : 0));
+    float4 t = v[0];
+#pragma unroll
+    for (int sp = 1; sp < PR_MAX_SPLITS; ++sp)
+      if (sp < p.splits) {
+        t.x = __fadd_rn(t.x, v[sp].x); t.y = __fadd_rn(t.y, v[sp].y);
+        t.z = __fadd_rn(t.z, v[sp].z); t.w = __fadd_rn(t.w, v[sp].w);
+      }
+    acc[u] = t;
+  }
+  // x_pool rows of the same block (fixed-order slab sum): the first two elements per thread are requested here as well,
+  // so that everything this workgroup reads is one round trip
+  const int xrows = K - i0 < PR_ROWS ? K - i0 : PR_ROWS;
+  const int xcount = p.x_pool ? xrows * p.F : 0;
+  const float* xb = p.x_pool ? p.xslab + static_cast<long>(b) * p.xs_batch + static_cast<long>(i0) * p.F : sb;
+  float xv[2][PR_MAX_SPLITS];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + u * 512;
+#pragma unroll
+    for (int sp = 0; sp < PR_MAX_SPLITS; ++sp)
+      xv[u][sp] = xb[(e < xcount && sp < p.splits) ? sp * p.xs_split + e : 0];
+  }
+  if (dn) {
+    const int parts = p.splits * p.tiles_m;  // <= 2 * PR_MAX_SPLITS: all in flight at once
+    for (int j = tid; j < K; j += 512) {
+      const float* cs = p.colsum + static_cast<long>(b) * parts * K + j;
+      float pv[2 * PR_MAX_SPLITS];
+#pragma unroll
+      for (int qq = 0; qq < 2 * PR_MAX_SPLITS; ++qq) pv[qq] = cs[qq < parts ? static_cast<long>(qq) * K : 0];
+      float c = 0.f;  // (the partial sums already leave the diagonal out when the self loops are removed)
+#pragma unroll
+      for (int qq = 0; qq < 2 * PR_MAX_SPLITS; ++qq)
+        if (qq < parts) c = __fadd_rn(c, pv[qq]);
+      s_d[j] = sqrtf(fmaxf(c, p.eps));
+    }
+  }
+  __syncthreads();
+  float* rawb = p.raw ? p.raw + static_cast<long>(b) * K * K : nullptr;
+  float* dstb = p.dst ? p.dst + static_cast<long>(b) * K * K : nullptr;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (!mine[u]) continue;
+    float4 t = acc[u];
+    const long off = static_cast<long>(ei[u]) * K + ej[u];
+    if (rawb) *reinterpret_cast<float4*>(rawb + off) = t;
+    if (!dstb) continue;
+    if (rsl) {
+      if (ei[u] == ej[u]) t.x = 0.f;
+      if (ei[u] == ej[u] + 1) t.y = 0.f;
+      if (ei[u] == ej[u] + 2) t.z = 0.f;
+      if (ei[u] == ej[u] + 3) t.w = 0.f;
+    }
+    if (dn) {  // (adj / d[1,K]) / d[K,1]
+      const float di = s_d[ei[u]];
+      const float4 dj = *reinterpret_cast<const float4*>(s_d + ej[u]);
+      t.x = (t.x / dj.x) / di; t.y = (t.y / dj.y) / di; t.z = (t.z / dj.z) / di; t.w = (t.w / dj.w) / di;
+    }
+    *reinterpret_cast<float4*>(dstb + off) = t;
+  }
+  if (p.x_pool) {
+    float* xo = p.x_pool + static_cast<long>(b) * K * p.F + static_cast<long>(i0) * p.F;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + u * 512;
+      if (e < xcount) {
+        float v = xv[u][0];
+#pragma unroll
+        for (int sp = 1; sp < PR_MAX_SPLITS; ++sp)
+          if (sp < p.splits) v = __fadd_rn(v, xv[u][sp]);
+        xo[e] = v;
+      }
+    }
+    for (int e = tid + 1024; e < xcount; e += 512) {  // F > 64
+      float v = xb[e];
+      for (int sp = 1; sp < p.splits; ++sp) v = __fadd_rn(v, xb[sp * p.xs_split + e]);
+      xo[e] = v;
+    }
+  }
+}
+
+// K <= 256 so that a 16-row block is at most two float4 per thread and d fits s_d
+static bool post_rows_ok(int64_t K, int flags, const void* slab, const void* raw, const void* dst) {
+  static const int off = getenv("TGP_NO_POST_ROWS") ? atoi(getenv("TGP_NO_POST_ROWS")) : 0;
+  return !off && K % 4 == 0 && K > 64 && K <= 256 && !(flags & TGP_EDGE_WEIGHT_NORM) &&
+         (!(flags & TGP_DEGREE_NORM) || (flags & TGP_SUM_AXIS_ROWS)) && reinterpret_cast<uintptr_t>(slab) % 16 == 0 &&
+         (!raw || reinterpret_cast<uintptr_t>(raw) % 16 == 0) && (!dst || reinterpret_cast<uintptr_t>(dst) % 16 == 0);
+}
+
 static size_t post_ws_floats(int64_t B, int64_t K) { return static_cast<size_t>(B * K + B * POST_BLOCKS); }
 
 // Returns true when the X' slab combine described by xc (if any) was folded into the launch.

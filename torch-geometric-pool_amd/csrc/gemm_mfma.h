@@ -65,6 +65,11 @@ struct GemmArgs {
   const int64_t* sizes;
   // MODE 0, splits == 1: C += op(A) Bm (the second term of a two-term gradient lands in the first term's buffer: r4)
   int accumulate;
+  // MODE 2 (= MODE 0 + this, r5): [batches][splits][tiles_m][rhs[0].Nc] partial COLUMN sums of the rhs[0] tiles, one
+  // value per (row tile, column): the degree vector of the post-processing (utils/ops.py:311-320 with the sum over
+  // dim -2) then needs 8 numbers per column instead of a pass over the K x K slabs
+  float* colsum;
+  int colsum_skip_diag;    // leave C[i][i] out of the sums (the post-processing clears the diagonal before it sums)
 };
 
 // Row of a [rows][BK+1] LDS tile served by slot t = 8*g + r (8 lanes per slot, slot = one 128-byte row segment).
@@ -101,7 +106,7 @@ __device__ __forceinline__ float4 ld4_guarded(const float* p, bool ok) {
 // ALIGNED: buffer-descriptor path, all traffic is 16-byte vectors with one predicate per vector; bases and
 // leading dimensions need dword alignment only (see gemm_aligned).  Otherwise: scalar guarded path (matrices too
 // large for 32-bit descriptor offsets).
-// MODE 0: C = op(A) Bm.  MODE 1 (link-prediction residual, utils/losses.py:644-708): Bm is stored
+// MODE 0: C = op(A) Bm (MODE 2: the same + GemmArgs.colsum).  MODE 1 (link-prediction residual, utils/losses.py:644-708): Bm is stored
 // [Nc][Kd] (n-major, i.e. the product is A Bm^T), and instead of storing C the epilogue accumulates
 // sum((resid - C)^2) over the tile, so S S^T never exists in memory.
 template <bool A_KMAJOR, bool ALIGNED, int BM, int BN, int MODE, int WN = 2>
@@ -470,6 +475,29 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
       }
     }
   }
+  if constexpr (MODE == 2) {
+    // column sums of this tile (rows beyond M are zero: the operands were zero-filled): registers in order, the two
+    // half-waves, then the row waves in order through LDS (the k-loop's last barrier has passed: smem is free)
+    if (g.colsum && which == 0) {  // (workgroup-uniform)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float cs = 0.f;
+        const int dcol = n0 + wn * (BN / WN) + j * 32 + lm - (m0 + wm * 32 + 4 * lk);  // row offset of the diagonal
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          cs = __fadd_rn(cs, (g.colsum_skip_diag && (r & 3) + 8 * (r >> 2) == dcol) ? 0.f : acc[j][r]);
+        cs = __fadd_rn(cs, __shfl_xor(cs, 32, 64));
+        if (lk == 0) smem[wm * BN + wn * (BN / WN) + j * 32 + lm] = cs;
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < Nc) {
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < BM / 32; ++q) tot = __fadd_rn(tot, smem[q * BN + tid]);
+        g.colsum[((static_cast<long>(batch) * g.splits + split) * g.tiles_m + tm) * Nc + n0 + tid] = tot;
+      }
+    }
+  }
   TGP_STAMP(3);
 }
 
@@ -528,18 +556,25 @@ static void launch_gemm_cfg(const GemmArgs& g_in, int batches, hipStream_t strea
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KMAJOR, false, BM, BN, MODE, WN>), dim3(nwg), dim3(BM * 2 * WN), lds, stream, g);
 }
 
-// g.tiles_* are filled in here: they follow from the tile shape chosen for this problem.
+// g.tiles_* are filled in here: they follow from the tile shape chosen for this problem.  Returns whether g.colsum was
+// written (only the 64 x 64 tile has the MODE 2 epilogue; *tiles_m_out = row tiles per batch element of that layout).
 template <bool A_KMAJOR>
-static void launch_gemm(GemmArgs g, int batches, hipStream_t stream) {
+static bool launch_gemm(GemmArgs g, int batches, hipStream_t stream, int* tiles_m_out = nullptr) {
   const int64_t max_nc = g.rhs[1].Bm && g.rhs[1].Nc > g.rhs[0].Nc ? g.rhs[1].Nc : g.rhs[0].Nc;
   const TileCfg t = pick_tile(g.M, max_nc, static_cast<int64_t>(batches) * g.splits, g);
   g.tiles_m = cdiv(g.M, t.bm);
   g.tiles_n0 = cdiv(g.rhs[0].Nc, t.bn);
   g.tiles_n = g.tiles_n0 + (g.rhs[1].Bm ? cdiv(g.rhs[1].Nc, t.bn) : 0);
+  if (tiles_m_out) *tiles_m_out = g.tiles_m;
+  if (t.bm == 64 && t.bn == 64 && g.colsum) {
+    launch_gemm_cfg<A_KMAJOR, 64, 64, 2>(g, batches, stream);
+    return true;
+  }
   if (t.bm == 64 && t.bn == 64) launch_gemm_cfg<A_KMAJOR, 64, 64>(g, batches, stream);
   else if (t.bm == 64) launch_gemm_cfg<A_KMAJOR, 64, 128>(g, batches, stream);
   else if (t.bn == 64) launch_gemm_cfg<A_KMAJOR, 128, 64>(g, batches, stream);
   else launch_gemm_cfg<A_KMAJOR, 128, 128, 0, 4>(g, batches, stream);  // 16 waves (4 x 4), one 32x32 tile each
+  return false;
 }
 
 // MODE 1 launch: sum((resid - A Bm^T)^2) per tile into g.partial; returns tiles per batch element.
