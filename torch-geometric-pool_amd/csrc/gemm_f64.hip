@@ -287,6 +287,106 @@ __global__ __launch_bounds__(256) void combine_slabs_f64_kernel(const double* __
   }
 }
 
+// ---- tail of the fused float64 call, spread over K / 16 workgroups per graph (r5) ----------------------------------------
+// r5 first had: slab combine (A), slab combine (X), f64_post_dense_kernel (one workgroup per graph): 5 + 5 + 29 us at
+// C2 behind a 35 us second product.  Now two launches of B * ceil(K / 16) workgroups:
+//   (1) dense64_combine_kernel: the block's 16 rows of S^T A S (and of S^T X) = slabs added in split order, written to
+//       `raw`; and the block's partial COLUMN sums of those rows (diagonal left out when the self loops are removed);
+//   (2) dense64_post_rows_kernel: d_j = sqrt(max(sum of the column's partials in block order, eps)) for every column,
+//       then the block's rows of (R1 / d[1,K]) / d[K,1] (utils/ops.py:311-320 with the sum over dim -2).
+// Only that axis (the connectors' default adj_transpose=True) without edge_weight_norm; other flags keep the composed form.
+constexpr int D64_ROWS = 16;
+
+__global__ __launch_bounds__(256) void dense64_combine_kernel(const double* __restrict__ aslab, int splits, long as_split,
+                                                              long as_batch, const double* __restrict__ xslab,
+                                                              long xs_split, long xs_batch, int K, int F, int skip_diag,
+                                                              double* __restrict__ raw, double* __restrict__ x_pool,
+                                                              double* __restrict__ colpart) {
+  const int nb = (K + D64_ROWS - 1) / D64_ROWS;
+  const int b = blockIdx.x / nb, rb = blockIdx.x - b * nb;
+  const int i0 = rb * D64_ROWS, rows = K - i0 < D64_ROWS ? K - i0 : D64_ROWS;
+  if (aslab) {
+    const double* sb = aslab + static_cast<long>(b) * as_batch;
+    for (int j = threadIdx.x; j < K; j += 256) {  // a thread per column: coalesced across the threads
+      // the 16 rows of a slab are requested together (a loop with a run-time trip count would wait per load)
+      double acc[D64_ROWS];
+#pragma unroll
+      for (int r = 0; r < D64_ROWS; ++r) acc[r] = sb[static_cast<long>(i0 + (r < rows ? r : 0)) * K + j];
+      for (int q = 1; q < splits; ++q) {
+        double v[D64_ROWS];
+#pragma unroll
+        for (int r = 0; r < D64_ROWS; ++r) v[r] = sb[q * as_split + static_cast<long>(i0 + (r < rows ? r : 0)) * K + j];
+#pragma unroll
+        for (int r = 0; r < D64_ROWS; ++r) acc[r] += v[r];
+      }
+      double cs = 0.0;
+#pragma unroll
+      for (int r = 0; r < D64_ROWS; ++r) {
+        if (r < rows) {
+          if (raw) raw[static_cast<long>(b) * K * K + static_cast<long>(i0 + r) * K + j] = acc[r];
+          if (!(skip_diag && i0 + r == j)) cs += acc[r];
+        }
+      }
+      if (colpart) colpart[(static_cast<long>(b) * nb + rb) * K + j] = cs;
+    }
+  }
+  if (xslab) {
+    const double* xb = xslab + static_cast<long>(b) * xs_batch + static_cast<long>(i0) * F;
+    double* xo = x_pool + static_cast<long>(b) * K * F + static_cast<long>(i0) * F;
+    for (int e0 = threadIdx.x; e0 < rows * F; e0 += 256 * 4) {  // four elements per thread in flight
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = xb[e0 + u * 256 < rows * F ? e0 + u * 256 : 0];
+      for (int q = 1; q < splits; ++q) {
+        double w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = xb[q * xs_split + (e0 + u * 256 < rows * F ? e0 + u * 256 : 0)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] += w[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e0 + u * 256 < rows * F) xo[e0 + u * 256] = v[u];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void dense64_post_rows_kernel(const double* __restrict__ raw,
+                                                                const double* __restrict__ colpart, int K, int flags,
+                                                                double eps, double* __restrict__ dst) {
+  extern __shared__ double s_d64[];
+  const int nb = (K + D64_ROWS - 1) / D64_ROWS;
+  const int b = blockIdx.x / nb, rb = blockIdx.x - b * nb;
+  const int i0 = rb * D64_ROWS, rows = K - i0 < D64_ROWS ? K - i0 : D64_ROWS;
+  const bool rsl = flags & TGP_REMOVE_SELF_LOOPS, dn = (flags & TGP_DEGREE_NORM) && colpart;
+  if (dn) {
+    for (int j = threadIdx.x; j < K; j += 256) {
+      const double* cp = colpart + static_cast<long>(b) * nb * K + j;
+      double c = 0.0;
+      for (int q = 0; q < nb; ++q) c += cp[static_cast<long>(q) * K];
+      s_d64[j] = sqrt(fmax(c, eps));
+    }
+  }
+  __syncthreads();
+  const double* a = raw + static_cast<long>(b) * K * K + static_cast<long>(i0) * K;
+  double* o = dst + static_cast<long>(b) * K * K + static_cast<long>(i0) * K;
+  for (int j = threadIdx.x; j < K; j += 256) {  // a thread per column, the block's rows requested together (raw may
+    double v[D64_ROWS];                           // BE dst: loads could not pass the stores of an element loop)
+#pragma unroll
+    for (int r = 0; r < D64_ROWS; ++r) v[r] = a[static_cast<long>(r < rows ? r : 0) * K + j];
+    const double dj = dn ? s_d64[j] : 1.0;
+#pragma unroll
+    for (int r = 0; r < D64_ROWS; ++r) {
+      if (r < rows) {
+        double x = v[r];
+        if (rsl && i0 + r == j) x = 0.0;
+        if (dn) x = (x / dj) / s_d64[i0 + r];
+        o[static_cast<long>(r) * K + j] = x;
+      }
+    }
+  }
+}
+
 // node-range split of S^T [U | X]: aim at ~3 workgroups per CU, keep >= 4 k-tiles per workgroup
 static int splits_for(int64_t batches, int64_t tiles, int64_t span) {
   const int64_t wgs = (batches > 0 ? batches : 1) * (tiles > 0 ? tiles : 1);
@@ -299,7 +399,7 @@ static int splits_for(int64_t batches, int64_t tiles, int64_t span) {
 
 struct Dense64Plan {
   int splits, k_per_split;
-  size_t u, aslab, xslab, deg;
+  size_t u, aslab, xslab, deg, colpart;
 };
 
 static Dense64Plan dense64_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
@@ -316,6 +416,7 @@ static Dense64Plan dense64_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
   p.aslab = static_cast<size_t>(B) * splits * K * K;
   p.xslab = static_cast<size_t>(B) * splits * K * F;
   p.deg = static_cast<size_t>(B) * K;
+  p.colpart = static_cast<size_t>(B) * ((K + 15) / 16) * K;  // dense64_combine_kernel's partial column sums
   return p;
 }
 
@@ -377,7 +478,7 @@ extern "C" size_t tgp_dense_pool_workspace_bytes_f64(int64_t B, int64_t N, int64
   if (B <= 0 || N <= 0 || K <= 0) return 256;
   const Dense64Plan p = dense64_plan(B, N, K, F > 0 ? F : 0);
   return align_up(p.u * 8) + align_up(p.aslab * 8) + align_up(p.xslab * 8) + align_up(p.deg * 8) +
-         tgp_postprocess_dense_workspace_bytes_f64(B, K) + 256;
+         align_up(p.colpart * 8) + tgp_postprocess_dense_workspace_bytes_f64(B, K) + 256;
 }
 
 extern "C" int tgp_dense_pool_f64(const double* S, const double* A, const double* X, int64_t B, int64_t N, int64_t K,
@@ -429,6 +530,25 @@ extern "C" int tgp_dense_pool_f64(const double* S, const double* A, const double
     if (want_a && want_x) { h.rhs[0] = ra; h.rhs[1] = rx; }
     else h.rhs[0] = want_a ? ra : rx;
     launch_gemm64<true>(h, static_cast<int>(B), stream);
+    static const int no_rows = getenv("TGP_NO_POST_ROWS") ? atoi(getenv("TGP_NO_POST_ROWS")) : 0;
+    if (!no_rows && want_a && adj_pool && !(flags & TGP_EDGE_WEIGHT_NORM) && K <= 2048 &&
+        (!(flags & TGP_DEGREE_NORM) || (flags & TGP_SUM_AXIS_ROWS))) {
+      // (1) + (2) above: `raw` is the caller's adj_raw, or adj_pool itself post-processed in place (elementwise per
+      // block: every element is read and written by one thread)
+      double* raw = adj_raw ? adj_raw : adj_pool;
+      const unsigned grid = static_cast<unsigned>(B * ((K + D64_ROWS - 1) / D64_ROWS));
+      double* colpart = (flags & TGP_DEGREE_NORM) ? cv.take<double>(p.colpart) : nullptr;
+      hipLaunchKernelGGL(dense64_combine_kernel, dim3(grid), dim3(256), 0, stream, direct ? a_dst : aslab,
+                         direct ? 1 : p.splits, static_cast<long>(K * K),
+                         direct ? static_cast<long>(K * K) : static_cast<long>(p.splits) * K * K,
+                         (want_x && !direct) ? xslab : static_cast<const double*>(nullptr), static_cast<long>(K * F),
+                         static_cast<long>(p.splits) * K * F, static_cast<int>(K), static_cast<int>(F),
+                         (flags & TGP_REMOVE_SELF_LOOPS) ? 1 : 0, direct ? static_cast<double*>(nullptr) : raw, x_pool,
+                         colpart);
+      hipLaunchKernelGGL(dense64_post_rows_kernel, dim3(grid), dim3(256), static_cast<size_t>(K) * sizeof(double), stream,
+                         raw, colpart, static_cast<int>(K), flags, eps, adj_pool);
+      return check_launch("tgp_dense_pool_f64");
+    }
     if (!direct) {
       if (want_a) {
         const long total = K * K;
