@@ -787,3 +787,37 @@ def test_copy_arrays_entry_point(dev):
             "tgp_copy_arrays")
     for s, d in zip(srcs, dsts):
         assert torch.equal(s, d)
+
+
+# ------------------------------------------------------------------ r5: the post-processing spread over K / 16 workgroups
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [68, 100, 128, 132, 200, 256])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_fused_dense_call_with_the_spread_post_processing(dev, K, dtype, monkeypatch):
+    """tgp_dense_pool_f32 / _f64 on batches that take the tiled GEMM path with 64 < K <= 256: the second product leaves
+    partial column sums, K / 16 workgroups per graph post-process (post_rows_kernel / dense64_post_rows_kernel).  Ragged
+    row tiles (K not a multiple of 64 or 16), every combination of remove_self_loops / degree_norm / raw output, against
+    the oracle (utils/ops.py:282-335); adj_transpose=False and edge_weight_norm keep the one-workgroup kernels and must
+    agree as well."""
+    import tgp_oracle as O
+    from tgp import kernels as K_
+    B, N, F = 3, 700, 24
+    g = torch.Generator().manual_seed(K)
+    A = ((torch.rand(B, N, N, generator=g) < 0.02).double() * torch.rand(B, N, N, generator=g, dtype=torch.float64))
+    X = torch.randn(B, N, F, generator=g, dtype=torch.float64)
+    S = torch.softmax(torch.randn(B, N, K, generator=g, dtype=torch.float64) * 2, -1)
+    Ad, Xd, Sd = (t.to(dev, dtype) for t in (A, X, S))
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-11, atol=1e-12)
+    raw_ref = _oracle64(O.dense_connect, S, A) if dtype == torch.float64 else O.dense_connect(S.float(), A.float()).double()
+    xref = S.transpose(1, 2) @ X
+    for rsl in (True, False):
+        for dn in (True, False):
+            for at, ewn in ((True, False), (False, False), (True, True)):
+                for want_raw in (False, True):
+                    flags = K_.dense_flags(rsl, dn, at, ewn)
+                    xp, raw, ap = K_.dense_pool(Sd, Ad, Xd, flags, want_raw=want_raw, want_post=True)[:3]
+                    ref = _oracle64(O.postprocess_dense, raw_ref, rsl, dn, at, ewn)
+                    torch.testing.assert_close(ap.double().cpu(), ref, **tol)
+                    torch.testing.assert_close(xp.double().cpu(), xref, rtol=tol["rtol"] * 10, atol=tol["atol"] * 100)
+                    if want_raw:
+                        torch.testing.assert_close(raw.double().cpu(), raw_ref, **tol)
