@@ -32,6 +32,9 @@ constexpr int BK = 32;
 #ifndef TGP_SPREAD
 #define TGP_SPREAD 0
 #endif
+#ifndef TGP_VEC_EPILOGUE
+#define TGP_VEC_EPILOGUE 1
+#endif
 
 constexpr int LDA_ROWMAJOR = BK + 1;
 
@@ -463,6 +466,30 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
     }
     return;
   }
+  // Interior tiles of an aligned C leave as 16-byte stores (r5): a wave's 32 x 32 accumulator tile goes through its own
+  // LDS patch [32][36] (the k-loop's last barrier has passed) and 8 lanes write one 128-byte row segment: 4 store
+  // instructions per lane and tile where the scalar form issues 16 -- with 16 waves per CU the stores' address path
+  // was ~1.5 us of the launch.  Edge tiles, C += and unaligned C keep the scalar stores.
+  constexpr bool PATCH_FITS = (THREADS / 64) * (32 * 36) <= 2 * STAGE_FLOATS;  // (not the 16-wave 128 x 128 tile)
+  const bool vec_store = ALIGNED && PATCH_FITS && TGP_VEC_EPILOGUE && !g.accumulate && (R.ldc & 3) == 0 &&
+                         (reinterpret_cast<uintptr_t>(C) & 15) == 0 && m0 + BM <= M && n0 + BN <= Nc;
+  if (vec_store) {  // (workgroup-uniform)
+    float* patch = smem + wave * (32 * 36);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * 36 + lm] = acc[j][r];
+      __builtin_amdgcn_wave_barrier();
+      const int c4 = (lane & 7) * 4, r8 = lane >> 3;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rr = r8 + 8 * q;
+        const float4 v = *reinterpret_cast<const float4*>(patch + rr * 36 + c4);
+        *reinterpret_cast<float4*>(C + static_cast<long>(m0 + wm * 32 + rr) * R.ldc + n0 + wn * (BN / WN) + j * 32 + c4) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + wn * (BN / WN) + j * 32 + lm;
@@ -475,7 +502,9 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
       }
     }
   }
+  }
   if constexpr (MODE == 2) {
+    if (vec_store) __syncthreads();  // (the patches are read; the column sums below reuse the same LDS)
     // column sums of this tile (rows beyond M are zero: the operands were zero-filled): registers in order, the two
     // half-waves, then the row waves in order through LDS (the k-loop's last barrier has passed: smem is free)
     if (g.colsum && which == 0) {  // (workgroup-uniform)
