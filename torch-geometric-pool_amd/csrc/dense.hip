@@ -650,6 +650,7 @@ static tgp::GemmArgs link_loss_args(const float* S, const float* A, int64_t N, i
   g.rhs[0] = tgp::GemmRhs{S, nullptr, static_cast<int>(N), K, 0, N * K, 0, 0};
   g.splits = 1; g.k_per_split = static_cast<int>((K + tgp::BK - 1) / tgp::BK * tgp::BK);
   g.resid = A; g.ldr = N; g.sR = N * N;
+  g.symmetric = 1;  // S S^T: tiles below the diagonal are their mirror images' job (launch_gemm_residual checks the rest)
   return g;
 }
 
