@@ -687,6 +687,18 @@ def test_dense_pooler_training_step_as_one_autograd_node(dev, alias, monkeypatch
         return (out.x.detach(), out.edge_index.detach(), {k: v.detach() for k, v in out.loss.items()}, x.grad,
                 [p.grad.clone() for p in pooler.parameters()])
 
+    # node features that need no gradient (input data): only the parameters get one, and it is the same
+    monkeypatch.setattr(P, "_FOLD_TRAINING", True)
+    pooler.zero_grad(set_to_none=True)
+    out = pooler(x=x0, adj=ei, batch=batch)
+    (out.x.square().sum() + sum(out.loss.values())).backward()
+    g_data = [p.grad.clone() for p in pooler.parameters()]
+    pooler.zero_grad(set_to_none=True)
+    xr = x0.clone().requires_grad_(True)
+    out = pooler(x=xr, adj=ei, batch=batch)
+    (out.x.square().sum() + sum(out.loss.values())).backward()
+    for a, b in zip(g_data, [p.grad for p in pooler.parameters()]):
+        assert torch.equal(a, b)
     for extra_s in (False, True):
         calls.clear()
         monkeypatch.setattr(P, "_FOLD_TRAINING", True)

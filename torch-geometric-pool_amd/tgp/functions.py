@@ -756,7 +756,7 @@ class _SelectPoolSmallFn(torch.autograd.Function):
             s, ad, xd, flags, want_raw, want_terms, diff_scales, graph_sizes, True, pre=(x_pool, raw, adj_pool, terms))
         ctx.save_for_backward(s, adj, x, diff, weight)
         ctx.flags = flags
-        ctx.want_gx = True
+        ctx.want_gx = x.requires_grad  # (node features that are data, not activations: neither backward forms dX)
         ctx.diff_scales = diff_scales
         ctx.has_bias = bias is not None
         nd = [terms, diff, bp] + ([] if want_raw else [raw])
@@ -774,7 +774,7 @@ class _SelectPoolSmallFn(torch.autograd.Function):
             gs = gs + g_s
         need = ctx.needs_input_grad
         gx, gw, gb = K.mlp_select_bwd(s, gs, x, weight, want_gx=need[0], want_gw=need[2],
-                                      want_gb=ctx.has_bias and need[3], gx_accumulate=gx)
+                                      want_gb=ctx.has_bias and need[3], gx_accumulate=gx if need[0] else None)
         return ((gx.to(x.dtype) if need[0] else None), None, gw, (gb if ctx.has_bias else None), None, None, None, None,
                 None, None, None)
 
