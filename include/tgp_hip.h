@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10028 /* 1.0.1 of the reference, ABI revision 28 (r5: fp64 dense path on v_mfma_f64_16x16x4_f64; selector backward in one pass; float64 row-local coalesce) */
+#define TGP_ABI_VERSION 10029 /* 1.0.1 of the reference, ABI revision 28 (r5: fp64 dense path on v_mfma_f64_16x16x4_f64; selector backward in one pass; float64 row-local coalesce; sparse-input select + pool) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -364,6 +364,32 @@ int tgp_dense_pool_select_f32(const float* X, const float* A, const float* W, co
                               float* mincut_terms /* [2,B] or NULL */,
                               int64_t* batch_pool /* [B*K] or NULL: arange(B).repeat_interleave(K), utils/ops.py:152-169 */,
                               void* stream);
+
+/* r5: the same call on the batch as a PyG loader hands it over -- x [Ntot,F] un-padded, a ROW-SORTED edge list
+ * (row, col, w or NULL = ones; E entries), batch [Ntot] sorted, node_ptr / edge_ptr [B+1] = first node / first edge of
+ * every graph.  The graph's wave builds its adjacency tile in LDS from its edges (duplicates summed, entries beyond N
+ * dropped, a column of another graph placed by its local id there: to_dense_adj, src.py:434-443; adj_transpose != 0:
+ * the transposed scatter of src.py:442-443), reads its own rows of x, and writes S_out [B,N,K] (zero rows behind the
+ * graph's nodes) and mask_out [B,N] (to_dense_batch's mask): neither to_dense_batch nor to_dense_adj runs and no [B,N,N]
+ * tensor exists -- three launches -> one in front of a dense pooler on sparse inputs.  N = the longest graph (<= 64).
+ * The caller guarantees the row order and the ranges (tgp_graph_lower_bounds_i64, or tgp_edge_facts_sorted_i64 below,
+ * whose flag word may be read AFTER this launch: what is read through edge_ptr is clamped to [0, E], columns outside
+ * [0, Ntot) are dropped); inference (the backward kernels read the padded tensors). */
+int tgp_dense_pool_select_sparse_f32(const float* x, int64_t Ntot, const int64_t* row, const int64_t* col, const float* w,
+                                     int64_t E, const int64_t* batch, const int64_t* node_ptr, const int64_t* edge_ptr,
+                                     const float* W, const float* bias, int64_t B, int64_t N, int64_t K, int64_t F,
+                                     int flags, int adj_transpose, float eps, float loss_eps, float* S_out,
+                                     unsigned char* mask_out, float* x_pool, float* adj_raw, float* adj_pool,
+                                     float* mincut_terms /* [2,B] or NULL */, int64_t* batch_pool /* [B*K] or NULL */,
+                                     void* stream);
+
+/* Facts of a NEW edge list for that call, one launch, no host round trip in front of the consumer: edge_ptr [N+2]
+ * (entries [0, B] written: first entry whose source node belongs to a graph >= g) and one flag word in pinned host
+ * memory (result[2]; result[0] = tag stored last): 1 = rows not grouped by ascending source node, 2 = a source id outside
+ * [0, N), 4 = more than 64 consecutive graph ids without an entry.  ticket: two zeroed uint32 words owned by the caller
+ * per (device, stream), left zero (not the pair of tgp_batch_facts_sorted_i64).  E > 0, N > 0, batch sorted. */
+int tgp_edge_facts_sorted_i64(const int64_t* row, int64_t E, const int64_t* batch, int64_t N, int64_t* edge_ptr,
+                              uint32_t* ticket, uint64_t* result, uint64_t tag, void* stream);
 
 /* Backward of that call for the same batches (what autograd derives operator by operator from base_reduce.py:158-161,
  * dense_conn.py:111-122, utils/ops.py:282-335 and utils/losses.py:39-70: ~80 launches in a MinCut training step), ONE

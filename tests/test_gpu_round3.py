@@ -927,12 +927,15 @@ def test_pooler_inference_with_the_folded_selector_equals_the_separate_path(dev,
     torch.manual_seed(0)
     pooler = get_pooler(alias, in_channels=32, k=20).to(dev).eval()
     calls = []
-    real = K_.dense_pool_select
+    real, real_sparse = K_.dense_pool_select, K_.dense_pool_select_sparse
     monkeypatch.setattr(K_, "dense_pool_select", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    # (r5: MinCut on sparse inputs takes the form of the same kernel that reads the un-padded batch)
+    monkeypatch.setattr(K_, "dense_pool_select_sparse", lambda *a, **k: (calls.append(2), real_sparse(*a, **k))[1])
     with torch.no_grad():
         folded = pooler(x=x, adj=ei, batch=batch)
-    assert calls, "the folded kernel did not run"
+    assert calls == ([2] if alias == "mincut" else [1]), "the folded kernel did not run"
     monkeypatch.setattr(type(pooler), "_select_reduce_connect", lambda self, *a: None)
+    monkeypatch.setattr(type(pooler), "_select_reduce_connect_sparse", lambda self, *a: None)
     with torch.no_grad():
         plain = pooler(x=x, adj=ei, batch=batch)
     torch.testing.assert_close(folded.so.s, plain.so.s, rtol=1e-5, atol=1e-6)

@@ -833,3 +833,84 @@ def test_fused_dense_call_with_the_spread_post_processing(dev, K, dtype, monkeyp
                     torch.testing.assert_close(xp.double().cpu(), xref, rtol=tol["rtol"] * 10, atol=tol["atol"] * 100)
                     if want_raw:
                         torch.testing.assert_close(raw.double().cpu(), raw_ref, **tol)
+
+
+# ------------------------------------------------------------------ r5: the dense poolers' forward straight from sparse inputs
+@pytest.mark.gpu
+@pytest.mark.parametrize("adj_transpose", [True, False])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_mincut_forward_from_the_unpadded_batch_equals_the_densified_one(dev, adj_transpose, weighted, monkeypatch):
+    """get_pooler('mincut') in inference on a sorted batch of small graphs given as PyG hands it over: ONE launch builds
+    every graph's adjacency tile in LDS from its edges (tgp_dense_pool_select_sparse_f32) -- no to_dense_batch, no
+    to_dense_adj.  Outputs, losses, S, mask and the pooled batch vector equal the densified path's (src.py:434-450 in
+    front of the same fused call): duplicates summed, self loops, a graph without edges, a graph of more than 512
+    entries, a column that leaves its row's graph.  An unsorted list keeps the densified path."""
+    from tgp import kernels as K_
+    from tgp import poolers as P
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(23)
+    B = 80
+    sizes = torch.randint(5, 61, (B,), generator=g)
+    sizes[3] = 60
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(B), sizes)
+    start = torch.cumsum(sizes, 0) - sizes
+    deg = torch.randint(0, 7, (n,), generator=g)
+    deg[batch == 5] = 0                                  # a graph without edges
+    deg[batch == 3] = 12                                 # 60 nodes x 12 = 720 entries: the tail loop behind 512
+    row = torch.repeat_interleave(torch.arange(n), deg)
+    col = start[batch[row]] + (torch.rand(row.numel(), generator=g) * sizes[batch[row]]).long()
+    col[::7] = row[::7]                                  # self loops
+    col[1::13] = col[0::13][: col[1::13].numel()]        # (some duplicates)
+    cross = (batch[row] == 10).nonzero().flatten()[:2]
+    col[cross] = start[11] + 1                           # a column in the next graph
+    ei = torch.stack([row, col]).to(dev)
+    ew = (torch.rand(row.numel(), generator=g) + 0.1).to(dev) if weighted else None
+    x = torch.randn(n, 32, generator=g).to(dev)
+    bd = batch.to(dev)
+    torch.manual_seed(0)
+    calls = []
+    real = K_.dense_pool_select_sparse
+    monkeypatch.setattr(K_, "dense_pool_select_sparse", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    for sparse_output in (False, True):
+        pooler = get_pooler("mincut", in_channels=32, k=20, adj_transpose=adj_transpose,
+                            sparse_output=sparse_output).to(dev).eval()
+        calls.clear()
+        with torch.no_grad():
+            monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", True)
+            new = pooler(x=x, adj=ei, edge_weight=ew, batch=bd)
+            assert calls == [1]
+            monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", False)
+            old = pooler(x=x, adj=ei, edge_weight=ew, batch=bd)
+            assert calls == [1]
+        torch.testing.assert_close(new.x, old.x, rtol=1e-6, atol=1e-6)
+        if sparse_output:
+            assert torch.equal(new.edge_index, old.edge_index) and torch.equal(new.batch, old.batch)
+            torch.testing.assert_close(new.edge_weight, old.edge_weight, rtol=1e-5, atol=1e-6)
+        else:
+            torch.testing.assert_close(new.edge_index, old.edge_index, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(new.so.s, old.so.s, rtol=1e-6, atol=1e-7)
+        assert torch.equal(new.so.in_mask, old.so.in_mask)
+        for k in old.loss:
+            torch.testing.assert_close(new.loss[k], old.loss[k], rtol=1e-5, atol=1e-6)
+    # rows not sorted: the densified path takes the call, same result
+    perm = torch.randperm(ei.size(1), generator=g).to(dev)
+    ei2, ew2 = ei[:, perm].contiguous(), (None if ew is None else ew[perm].contiguous())
+    calls.clear()
+    with torch.no_grad():
+        monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", True)
+        shuffled = pooler(x=x, adj=ei2, edge_weight=ew2, batch=bd)
+        # (a NEW list is tried optimistically -- the kernel runs on clamped ranges while the facts kernel's verdict
+        #  travels -- and its outputs are dropped; the verdict is remembered: the second call does not try)
+        assert calls == [1] and K_._rows_sorted_memo(ei2) is False
+        again = pooler(x=x, adj=ei2, edge_weight=ew2, batch=bd)
+        assert calls == [1]
+    torch.testing.assert_close(shuffled.x, old.x, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(again.x, old.x, rtol=1e-5, atol=1e-5)
+    # a NEW sorted list: ranges and verdict from the one facts launch, no lower-bounds launch, remembered afterwards
+    ei3 = ei.clone()
+    calls.clear()
+    with torch.no_grad():
+        fresh = pooler(x=x, adj=ei3, edge_weight=ew, batch=bd.clone())
+    assert calls == [1] and K_._rows_sorted_memo(ei3) is True
+    torch.testing.assert_close(fresh.x, old.x, rtol=1e-6, atol=1e-6)

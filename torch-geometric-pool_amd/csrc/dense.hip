@@ -138,12 +138,49 @@ extern "C" int tgp_dense_pool_select_f32(const float* X, const float* A, const f
               want_a ? mincut_terms : nullptr, loss_eps, W, bias, mask, S_out,
               reinterpret_cast<long long*>(batch_pool)};
   const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(SG_WAVES * SG_WAVE_FLOATS * sizeof(float)));
-  hipLaunchKernelGGL(dense_pool_small_kernel, dim3(grid), dim3(64 * SG_WAVES),
+  hipLaunchKernelGGL(dense_pool_small_kernel<false>, dim3(grid), dim3(64 * SG_WAVES),
                      SG_WAVES * SG_WAVE_FLOATS * sizeof(float), stream, q);
   return check_launch("tgp_dense_pool_select_f32");
+}
+
+// The same call on the batch as a PyG loader hands it over (r5): x [Ntot,F] un-padded, a ROW-SORTED edge list with the
+// per-graph ranges node_ptr / edge_ptr [B+1] -- the graph's wave builds its adjacency tile in LDS from its edges, so
+// neither to_dense_batch nor to_dense_adj runs and no [B,N,N] tensor exists (src.py:434-450 + the call above: three
+// launches -> one).  N = the longest graph (<= 64).  The caller has checked that the rows are sorted and the ranges are
+// the lower bounds of node_ptr in the row array; `batch` [Ntot] serves columns that leave their row's graph.
+extern "C" int tgp_dense_pool_select_sparse_f32(const float* x, int64_t Ntot, const int64_t* row, const int64_t* col,
+                                                const float* w, int64_t E, const int64_t* batch, const int64_t* node_ptr,
+                                                const int64_t* edge_ptr, const float* W, const float* bias, int64_t B,
+                                                int64_t N, int64_t K, int64_t F, int flags, int adj_transpose, float eps,
+                                                float loss_eps, float* S_out, unsigned char* mask_out, float* x_pool,
+                                                float* adj_raw, float* adj_pool, float* mincut_terms,
+                                                int64_t* batch_pool, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0 && F >= 0 && E >= 0 && Ntot >= 0, TGP_ERR_INVALID,
+              "tgp_dense_pool_select_sparse_f32: negative size");
+  if (B == 0 || N == 0 || K == 0) return TGP_OK;
+  TGP_REQUIRE(x && W && S_out && F > 0 && node_ptr && edge_ptr && batch && (E == 0 || (row && col)), TGP_ERR_INVALID,
+              "tgp_dense_pool_select_sparse_f32: x, W, S_out, batch, node_ptr, edge_ptr (and the edge list) are required");
+  TGP_REQUIRE(dense_pool_small_ok(B, N, K, F), TGP_ERR_INVALID,
+              "tgp_dense_pool_select_sparse_f32: only batches the one-wave-per-graph kernel takes (tgp_dense_pool_is_small)");
+  TGP_REQUIRE(!(flags & TGP_ADJ_TRANSPOSED), TGP_ERR_INVALID,
+              "tgp_dense_pool_select_sparse_f32: TGP_ADJ_TRANSPOSED describes a dense layout (use adj_transpose)");
+  SmallArgs q{nullptr, nullptr, x, static_cast<int>(B), static_cast<int>(N), static_cast<int>(K), static_cast<int>(F),
+              flags, eps, x_pool, adj_raw, adj_pool, mincut_terms, loss_eps, W, bias, nullptr, S_out,
+              reinterpret_cast<long long*>(batch_pool), reinterpret_cast<const long long*>(E > 0 ? row : nullptr),
+              reinterpret_cast<const long long*>(col), w, reinterpret_cast<const long long*>(node_ptr),
+              reinterpret_cast<const long long*>(edge_ptr), reinterpret_cast<const long long*>(batch),
+              adj_transpose ? 1 : 0, mask_out, static_cast<long long>(E), static_cast<long long>(Ntot)};
+  const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(SG_WAVES * SG_WAVE_FLOATS * sizeof(float)));
+  hipLaunchKernelGGL(dense_pool_small_kernel<true>, dim3(grid), dim3(64 * SG_WAVES),
+                     SG_WAVES * SG_WAVE_FLOATS * sizeof(float), stream, q);
+  return check_launch("tgp_dense_pool_select_sparse_f32");
 }
 
 extern "C" int tgp_dense_pool_small_bwd_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N,
@@ -202,10 +239,10 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
                 want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr, want_a ? mincut_terms : nullptr, loss_eps,
                 nullptr, nullptr, nullptr, nullptr, nullptr};
     const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(SG_WAVES * SG_WAVE_FLOATS * sizeof(float)));
-    hipLaunchKernelGGL(dense_pool_small_kernel, dim3(grid), dim3(64 * SG_WAVES),
+    hipLaunchKernelGGL(dense_pool_small_kernel<false>, dim3(grid), dim3(64 * SG_WAVES),
                        SG_WAVES * SG_WAVE_FLOATS * sizeof(float), stream, q);
     return check_launch("tgp_dense_pool_f32(small)");
   }

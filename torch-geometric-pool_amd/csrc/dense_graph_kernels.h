@@ -41,6 +41,18 @@ struct SmallArgs {
   // optional (r5) [B * K]: the pooled batch vector arange(B).repeat_interleave(K) (utils/ops.py:152-169), written by
   // the graph's wave: one copy launch less per pooler call
   long long* batch_pool;
+  // optional (r5, selector folded in, dense_pool_small_kernel<true>): the batch as a PyG loader hands it over -- x
+  // [Ntot,F] un-padded in `X`, a ROW-SORTED edge list -- instead of the padded X and the dense A: graph b owns node rows
+  // node_ptr[b] .. node_ptr[b+1] and edges edge_ptr[b] .. edge_ptr[b+1] (the caller has checked the order and computed
+  // the ranges).  The wave zeroes its LDS tile and adds its edges there (duplicates summed, entries beyond N dropped,
+  // a column outside the graph placed by its local id in its own graph: to_dense_adj, src.py:434-443); e_transposed:
+  // adj_transpose (the logical A is the transposed scatter).  Neither to_dense_batch nor to_dense_adj runs, and no
+  // [B,N,N] tensor exists.  mask_out [B,N]: to_dense_batch's node mask.
+  const long long* e_row; const long long* e_col; const float* e_w;
+  const long long* node_ptr; const long long* edge_ptr; const long long* e_batch;
+  int e_transposed;
+  unsigned char* mask_out;
+  long long e_count, n_total;  // E and Ntot: what is read through edge_ptr / e_col is clamped / range-checked against them
 };
 
 __device__ __forceinline__ float sg_wave_sum(float v) {
@@ -108,6 +120,8 @@ __device__ __forceinline__ const float* byte_off(const float* base, int bytes) {
 // a CU needs ~7 loading waves to reach its ~26 GB/s, so with 8 resident waves (187 VGPRs) the overlap is small:
 // 22.0 -> 21.3 us.  Real overlap needs 16 lighter waves per CU (two waves per graph); see DESIGN.md known gaps.
 constexpr int SG_WAVES = 8;
+constexpr int SG_EDGE_ROUNDS = 8;  // edges of a graph requested up front by the sparse form (64 per round)
+template <bool SPARSE>
 __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(SmallArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int s_issued;
@@ -122,6 +136,19 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
   __syncthreads();
   if (b >= p.B) return;
   if (p.batch_pool && lane < K) p.batch_pool[static_cast<long>(b) * K + lane] = b;
+  [[maybe_unused]] long long n0 = 0, e0 = 0, e1 = 0;
+  int nb = N;  // real nodes of the graph (sparse form: from node_ptr; dense form: the padding is zero / masked)
+  if constexpr (SPARSE) {
+    n0 = p.node_ptr[b];
+    const long long nn = p.node_ptr[b + 1] - n0;
+    nb = nn < N ? static_cast<int>(nn) : N;
+    // (clamped: the ranges may come from a facts kernel whose verdict the host reads only after this launch)
+    e0 = p.edge_ptr[b];
+    e1 = p.edge_ptr[b + 1];
+    e0 = e0 < 0 ? 0 : (e0 > p.e_count ? p.e_count : e0);
+    e1 = e1 < e0 ? e0 : (e1 > p.e_count ? p.e_count : e1);
+    if (p.mask_out && lane < N) p.mask_out[static_cast<long>(b) * N + lane] = lane < nb ? 1 : 0;
+  }
   if (w >= SG_WAVES / 2) {  // second group: wait until the first group's requests are in the queue
     int first = p.B - static_cast<int>(blockIdx.x) * SG_WAVES;
     first = first < SG_WAVES / 2 ? first : SG_WAVES / 2;
@@ -133,7 +160,20 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
     // ---- request everything up front: A (float4 rows), then S and X in operand order ------------
     // out-of-range elements read element 0 of the graph (always valid) and are replaced by 0 afterwards, so
     // the loads stay unconditional and are issued back to back
-    float4 v[16];
+    float4 v[SPARSE ? 1 : 16];
+    [[maybe_unused]] long long er[SPARSE ? SG_EDGE_ROUNDS : 1], ec[SPARSE ? SG_EDGE_ROUNDS : 1];
+    [[maybe_unused]] float ew[SPARSE ? SG_EDGE_ROUNDS : 1];
+    if constexpr (SPARSE) {  // the graph's first 512 edges (clamped loads: edge 0 of the list when out of range)
+#pragma unroll
+      for (int q = 0; q < SG_EDGE_ROUNDS; ++q) {
+        const long long e = e0 + q * 64 + lane;
+        const long long ee = (p.e_row && e < e1) ? e : 0;
+        er[q] = p.e_row ? p.e_row[ee] : 0;
+        ec[q] = p.e_row ? p.e_col[ee] : 0;
+        ew[q] = (p.e_row && p.e_w) ? p.e_w[ee] : 1.0f;
+      }
+    }
+    if constexpr (!SPARSE)
     if (p.A) {  // 16 lanes per row (64 floats), 4 rows per wave-instruction, 16 instructions
       const float* Ab = p.A + static_cast<long>(b) * N * N;
       const int q = lane & 15;
@@ -167,12 +207,12 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
       }
     }
     if (p.X) {
-      const float* Xb = p.X + static_cast<long>(b) * N * F;
+      const float* Xb = SPARSE ? p.X + n0 * F : p.X + static_cast<long>(b) * N * F;  // (sparse: the graph's own rows of x)
       const bool cok = lm < F;
 #pragma unroll
       for (int q = 0; q < 32; ++q) {
         const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
-        const bool ok = cok && node < N;
+        const bool ok = cok && node < nb;
         const float r = *byte_off(Xb, ok ? (node * F + lm) * 4 : 0);
         xr[q] = ok ? r : 0.f;
       }
@@ -226,7 +266,7 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int node = 32 * T + rho(r) + 4 * lk;
-          const bool on = node < N && (!mk || mk[node < N ? node : 0] != 0);
+          const bool on = node < nb && (!mk || mk[node < N ? node : 0] != 0);
           const float sv = on ? ex[r] * __builtin_amdgcn_rcpf(sm[r]) : 0.f;  // (1 ulp reciprocal: far inside 1e-5)
           sr[16 * T + r] = sv;
           if (So && node < N && lm < K) So[node * K + lm] = sv;
@@ -234,7 +274,26 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
       }
       __builtin_amdgcn_wave_barrier();  // (the A tile overwrites Xs below)
     }
-    if (p.A) {
+    if constexpr (SPARSE) {
+      // the adjacency tile is BUILT here: zeroed, then the graph's edges added in LDS (to_dense_adj, src.py:434-443)
+      for (int i = lane * 4; i < SG_N * SG_LDA; i += 256) *reinterpret_cast<float4*>(As + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      __builtin_amdgcn_wave_barrier();
+      auto add_edge = [&](long long r, long long c, float wv) {
+        const long long lr = r - n0;
+        if (c < 0 || c >= p.n_total) return;  // (never used as an index)
+        // a column of another graph keeps the local id it has THERE (PyG subtracts ptr[batch[col]])
+        const long long lc = (c >= n0 && c < n0 + nb) ? c - n0 : c - p.node_ptr[p.e_batch[c]];
+        if (lr >= 0 && lr < N && lc >= 0 && lc < N) {
+          const int i = static_cast<int>(p.e_transposed ? lc : lr), j = static_cast<int>(p.e_transposed ? lr : lc);
+          __hip_atomic_fetch_add(As + i * SG_LDA + j, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      };
+#pragma unroll
+      for (int q = 0; q < SG_EDGE_ROUNDS; ++q)
+        if (e0 + q * 64 + lane < e1) add_edge(er[q], ec[q], ew[q]);
+      for (long long e = e0 + SG_EDGE_ROUNDS * 64 + lane; e < e1; e += 64)  // a graph of more than 512 edges
+        add_edge(p.e_row[e], p.e_col[e], p.e_w ? p.e_w[e] : 1.0f);
+    } else if (p.A) {
       const int q = lane & 15;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
@@ -271,7 +330,7 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
 
     TGP_WSTAMP(2);
     // ---- U = A S (kept in accumulators), A' = S^T U -----------------------------------------
-    if (p.A && (p.adj_raw || p.adj_pool)) {
+    if ((SPARSE || p.A) && (p.adj_raw || p.adj_pool)) {
       f32x16 u[2], aa;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { u[0][r] = 0.f; u[1][r] = 0.f; aa[r] = 0.f; }

@@ -336,6 +336,62 @@ __global__ __launch_bounds__(256) void batch_facts_sorted_kernel(const int64_t* 
   }
 }
 
+// r5: what the sparse-input fused call (tgp_dense_pool_select_sparse_f32) needs to know about a NEW edge list, from one
+// launch and without a host round trip in front of the consumer: edge_ptr[g] = first entry whose source node belongs
+// to a graph >= g (entry e with graph(row[e]) != graph(row[e-1]) writes the offsets of its graph and of the empty ids in
+// between, at most 64; the last entry writes the tail up to B = batch[n-1] + 1), and -- through the workgroup with the
+// last ticket -- ONE flag word in pinned host memory: 1 = the rows are not grouped by ascending source node (or the
+// batch vector is not sorted), 2 = a source id outside [0, n), 4 = a run of more than 64 graph ids without an entry.
+// The consumer may be launched behind this kernel at once (it clamps what it reads through edge_ptr); the host looks
+// at the flags afterwards and discards the consumer's outputs when they are set.
+__global__ __launch_bounds__(256) void edge_facts_sorted_kernel(const int64_t* __restrict__ row, int64_t E,
+                                                                const int64_t* __restrict__ batch, int64_t n,
+                                                                int64_t* __restrict__ edge_ptr,
+                                                                unsigned int* __restrict__ ticket,
+                                                                unsigned int* __restrict__ bad,
+                                                                unsigned long long* __restrict__ result,
+                                                                unsigned long long tag) {
+  __shared__ bool s_last;
+  unsigned int flags = 0;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < E; e += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t r = row[e];
+    if (r < 0 || r >= n) { flags |= 2u; continue; }
+    const int64_t rp = e > 0 ? row[e - 1] : -1;
+    if (e > 0 && (rp < 0 || rp >= n)) continue;  // (the predecessor's thread reports it)
+    if (r < rp) { flags |= 1u; continue; }
+    const int64_t g = batch[r], gp = e > 0 ? batch[rp] : -1;
+    if (g < gp || g < 0 || g > n) { flags |= 1u; continue; }
+    if (g - gp > 64) { flags |= 4u; continue; }
+    for (int64_t gg = gp + 1; gg <= g; ++gg) edge_ptr[gg] = e;
+    if (e == E - 1) {
+      const int64_t B = batch[n - 1] + 1;
+      if (B < g || B - g > 64) flags |= 4u;
+      else
+        for (int64_t gg = g + 1; gg <= B; ++gg) edge_ptr[gg] = E;
+    }
+  }
+  if (flags) atomicOr(bad, flags);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned int fl = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *ticket = 0;  // ready for the next call on this stream
+      *bad = 0;
+      result[1] = 0ull;
+      result[2] = fl;
+      result[3] = result[4] = result[5] = 0ull;
+      __threadfence_system();
+      __hip_atomic_store(result, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 }  // namespace tgp
 
 using namespace tgp;
@@ -478,4 +534,20 @@ extern "C" int tgp_from_dense_batch_f32(const float* dense, int64_t N, int64_t F
   hipLaunchKernelGGL(from_dense_batch_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, dense, N, F,
                      batch, ptr, Nmax, x);
   return check_launch("tgp_from_dense_batch_f32");
+}
+
+// edge_ptr [N + 2] (entries [0, B] are written); ticket: two zeroed uint32 words owned by the caller per (device,
+// stream) -- not the pair tgp_batch_facts_sorted_i64 uses --, left zero; result: 6 words of pinned host memory, word 0 =
+// `tag` stored last, word 2 = the flags (see edge_facts_sorted_kernel).  E > 0, N > 0.
+extern "C" int tgp_edge_facts_sorted_i64(const int64_t* row, int64_t E, const int64_t* batch, int64_t N, int64_t* edge_ptr,
+                                         uint32_t* ticket, uint64_t* result, uint64_t tag, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E > 0 && N > 0 && row && batch && edge_ptr && ticket && result, TGP_ERR_INVALID,
+              "tgp_edge_facts_sorted_i64: bad argument");
+  int64_t blocks = (E + 2047) / 2048;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(edge_facts_sorted_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, row, E, batch, N,
+                     edge_ptr, ticket, ticket + 1, reinterpret_cast<unsigned long long*>(result),
+                     static_cast<unsigned long long>(tag));
+  return check_launch("tgp_edge_facts_sorted_i64");
 }

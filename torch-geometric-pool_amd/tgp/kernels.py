@@ -1039,6 +1039,74 @@ def dense_pool_select(x: Tensor, adj: Tensor, weight: Tensor, bias: Optional[Ten
     return s, x_pool, adj_raw, adj_pool, terms
 
 
+def edge_facts_launch(edge_index: Tensor, batch: Tensor):
+    """Enqueue ``tgp_edge_facts_sorted_i64`` for a NEW row-sorted edge list: the per-graph edge ranges land in a device
+    buffer the consumer can be launched on at once, the verdict (rows sorted?) in a pinned host word that
+    :func:`edge_facts_finish` reads afterwards.  None when there is nothing to look at (no entries) or a stream is being
+    captured."""
+    row, _ = _edge_rows(edge_index)
+    E, n = row.numel(), batch.numel()
+    if E == 0 or n == 0 or torch.cuda.is_current_stream_capturing():
+        return None
+    dev = edge_index.device
+    st = N.stream_ptr(dev)
+    state = _sps_state(dev, st, 0)
+    buf = torch.empty(n + 2, dtype=torch.long, device=dev)
+    tag = state.next_facts_tag()
+    N.check(N.lib().tgp_edge_facts_sorted_i64(N.ptr(row), E, N.ptr(N.i64c(batch)), n, N.ptr(buf),
+                                              state.ticket.data_ptr() + 8, state.facts_slot(tag), tag, st),
+            "tgp_edge_facts_sorted_i64")
+    return state, tag, buf
+
+
+def edge_facts_finish(handle, edge_index: Tensor, graph_ptr: Tensor) -> bool:
+    """The verdict of :func:`edge_facts_launch`: True = the rows are grouped by ascending source node and the ranges in the
+    buffer are exact (both are remembered for this tensor object: later calls need no launch), False = not (remembered
+    as well: later calls skip the attempt)."""
+    state, tag, buf = handle
+    _, flags, _, _, _ = state.wait_facts(tag)
+    if flags:
+        _remember_rows_sorted(edge_index, False)
+        return False
+    _remember_rows_sorted(edge_index, True)
+    _edge_ptr_remember(edge_index, graph_ptr, buf[: graph_ptr.numel()])
+    return True
+
+
+def dense_pool_select_sparse(x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor,
+                             node_ptr: Tensor, edge_ptr: Tensor, num_graphs: int, max_nodes: int, weight: Tensor,
+                             bias: Optional[Tensor], flags: int, adj_transpose: bool, want_raw: bool = False,
+                             mincut_terms: bool = False):
+    """(s [B,N,K], mask [B,N], x_pool, adj_raw, adj_pool, terms, batch_pool): :func:`dense_pool_select` straight from
+    the un-padded batch -- x [Ntot,F], a ROW-SORTED ``edge_index`` with the per-graph ranges ``node_ptr`` / ``edge_ptr``
+    [B+1] -- in ONE launch: the adjacency tiles are built in LDS from the edges, neither ``to_dense_batch`` nor
+    ``to_dense_adj`` runs, no [B,N,N] tensor exists (src.py:434-450 + select/mlp_select.py:105-147 + the fused Reduce /
+    Connect call).  The caller has checked the row order (``_rows_sorted``) and the ranges (``graph_edge_ptr``)."""
+    dev = N.require_device(x, edge_index, edge_weight, batch, node_ptr, edge_ptr, weight, bias)
+    x, weight = N.f32c(x), N.f32c(weight)
+    F = x.size(1)
+    K, B, Nn = weight.size(0), int(num_graphs), int(max_nodes)
+    if weight.shape != (K, F) or batch.numel() != x.size(0) or node_ptr.numel() != B + 1 or edge_ptr.numel() < B + 1:
+        raise ValueError("dense_pool_select_sparse: inconsistent shapes")
+    row, col = _edge_rows(edge_index)
+    E = row.numel()
+    w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
+    b = None if bias is None else N.f32c(bias)
+    s = torch.empty(B, Nn, K, dtype=torch.float32, device=dev)
+    mask = torch.empty(B, Nn, dtype=torch.bool, device=dev)
+    x_pool = torch.empty(B, K, F, dtype=torch.float32, device=dev)
+    adj_pool = torch.empty(B, K, K, dtype=torch.float32, device=dev)
+    adj_raw = torch.empty(B, K, K, dtype=torch.float32, device=dev) if want_raw else None
+    terms = torch.empty(2, B, dtype=torch.float32, device=dev) if mincut_terms else None
+    bp = torch.empty(B * K, dtype=torch.int64, device=dev)
+    N.check(N.lib().tgp_dense_pool_select_sparse_f32(
+        N.ptr(x), x.size(0), N.ptr(row) if E else None, N.ptr(col) if E else None, N.ptr(w), E, N.ptr(N.i64c(batch)),
+        N.ptr(N.i64c(node_ptr)), N.ptr(N.i64c(edge_ptr)), N.ptr(weight), N.ptr(b), B, Nn, K, F, flags,
+        1 if adj_transpose else 0, ops_eps(), losses_eps(), N.ptr(s), mask.data_ptr(), N.ptr(x_pool), N.ptr(adj_raw),
+        N.ptr(adj_pool), N.ptr(terms), N.ptr(bp), N.stream_ptr(dev)), "tgp_dense_pool_select_sparse_f32")
+    return s, mask, x_pool, adj_raw, adj_pool, terms, bp
+
+
 def dense_pool_is_small(B: int, Nn: int, K: int, F: int) -> bool:
     """Does the one-wave-per-graph kernel take this padded batch (and so its fused backward)?"""
     return bool(N.lib().tgp_dense_pool_is_small(B, Nn, K, F))

@@ -39,6 +39,8 @@ import os as _os
 
 # A/B switch (read once): 0 keeps the selector and the pooling as two autograd nodes in training
 _FOLD_TRAINING = _os.environ.get("TGP_FOLD_TRAINING", "1") != "0"
+# ... 0 densifies sparse inputs (to_dense_batch + to_dense_adj) in front of the fused inference call as before
+_FOLD_SPARSE_INPUTS = _os.environ.get("TGP_FOLD_SPARSE_INPUTS", "1") != "0"
 
 
 # =============================================================================== sparse poolers
@@ -210,6 +212,61 @@ class _DenseMLPPooling(DenseSRCPooling):
             fused = fused + (None,)
         return so, fused, (out[5] if want_batch else None)
 
+    def _select_reduce_connect_sparse(self, x, edge_index, edge_weight, batch):
+        """Inference on a sorted batch of small graphs that arrives as PyG hands it over (x [N,F], a row-sorted
+        ``edge_index``): Select + Reduce + Connect + loss tails straight from the un-padded batch in ONE launch
+        (tgp_dense_pool_select_sparse_f32: every graph's adjacency tile is built in LDS from its edges) -- neither
+        ``to_dense_batch`` nor ``to_dense_adj`` runs and no [B,N,N] tensor exists.  Only for poolers whose losses come out
+        of the kernel (MinCut); returns ``(SelectOutput, fused, pooled batch vector)`` or None."""
+        from .. import kernels as K
+        sel, c = self.selector, self.connector
+        lins = getattr(getattr(sel, "mlp", None), "lins", None)
+        if (not _FOLD_SPARSE_INPUTS or not self._loss_needs_raw or self.cache_preprocessing
+                or type(sel) is not MLPSelect or lins is None or len(lins) != 1 or type(c) is not DenseConnect
+                or type(self.reducer) is not BaseReduce or not (isinstance(x, Tensor) and isinstance(edge_index, Tensor))
+                or x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or edge_index.dim() != 2
+                or edge_index.size(0) != 2 or edge_index.dtype != torch.long or not edge_index.is_cuda
+                or batch is None or batch.dtype != torch.long or batch.numel() != x.size(0) or x.size(0) == 0
+                or (edge_weight is not None and (edge_weight.dim() != 1 or edge_weight.dtype != torch.float32))):
+            return None
+        last = lins[0]
+        if torch.is_grad_enabled() and (x.requires_grad or last.weight.requires_grad
+                                        or (last.bias is not None and last.bias.requires_grad)
+                                        or (edge_weight is not None and edge_weight.requires_grad)):
+            return None
+        # the one-launch kernel walks every graph's edge range: the list must be grouped by ascending source node (what
+        # PyG's loaders produce).  Known per tensor object once it has been looked at; a NEW list gets its ranges and
+        # its verdict from one facts launch enqueued here, in front of the wait for the batch facts: the pooling kernel
+        # is launched on the ranges at once and the verdict is read behind it (a list that fails it is remembered, the
+        # outputs are dropped and the densified path below takes the call)
+        known = K._rows_sorted_memo(edge_index) if edge_index.size(1) > 1 else True
+        if known is False:
+            return None
+        pending = None
+        if known is None:
+            from ..utils.ops import prefetch_batch_info
+            prefetch_batch_info(batch)
+            pending = K.edge_facts_launch(edge_index, batch)
+            if pending is None:
+                return None
+        info = batch_info(batch)  # (memoised per batch vector)
+        if (not info.is_sorted or last.weight.dtype != torch.float32
+                or not K.dense_pool_is_small(info.num_graphs, info.max_nodes, last.weight.size(0), x.size(1))):
+            if pending is not None:
+                K.edge_facts_finish(pending, edge_index, info.ptr)  # (the launch is out: keep what it found)
+            return None
+        edge_ptr = pending[2] if pending is not None else K.graph_edge_ptr(edge_index, info.ptr)
+        flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
+        s, mask, x_pool, raw, adj_pool, terms, bp = K.dense_pool_select_sparse(
+            x, edge_index, edge_weight, batch, info.ptr, edge_ptr, info.num_graphs, info.max_nodes,
+            last.weight.detach(), None if last.bias is None else last.bias.detach(), flags, self.adj_transpose,
+            want_raw=True, mincut_terms=True)
+        if pending is not None and not K.edge_facts_finish(pending, edge_index, info.ptr):
+            return None  # rows not sorted: what the kernel computed on clamped ranges is dropped
+        so = SelectOutput(s=s, s_inv_op=sel.s_inv_op, in_mask=mask)
+        so._graph_sizes = info.sizes
+        return so, (x_pool, raw, adj_pool, terms), bp
+
     def _select_reduce_connect_train(self, x, adj, mask, graph_sizes, want_batch=False):
         """Training on a batch of small graphs with a single-Linear selector: Select + Reduce + Connect + loss tails as
         ONE autograd node (functions._SelectPoolSmallFn: one forward launch, two backward launches; the selector and the
@@ -260,6 +317,19 @@ class _DenseMLPPooling(DenseSRCPooling):
         if lifting:
             return self._lift(x, so, batch, batch_pooled)
         if self.batched:
+            if so is None and mask is None and not is_dense_adj(adj):
+                sparse = self._select_reduce_connect_sparse(x, adj, edge_weight, batch)
+                if sparse is not None:  # inference straight from the un-padded batch: no densification at all
+                    so, fused, batch_pool = sparse
+                    x_pool, raw, adj_pool, terms = fused
+                    self._known_nodes, self._sizes_hint = x.size(0), None
+                    loss = self._loss_from_fused(adj, so, None, raw, terms, None)
+                    if self.sparse_output:
+                        x_pool, ei, ew, batch_pool = self._finalize_sparse_output(
+                            x_pool=x_pool, adj_pool=adj_pool, batch=batch, batch_pooled=batch_pool, so=so)
+                        return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so,
+                                             loss=loss)
+                    return PoolingOutput(x=x_pool, edge_index=adj_pool, so=so, loss=loss)
             # number of real nodes behind the padded batch, when the host already knows it (a reduction over the mask
             # costs ~25 us on the device for any mask size)
             self._known_nodes = None
