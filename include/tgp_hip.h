@@ -374,13 +374,16 @@ int tgp_dense_pool_select_f32(const float* X, const float* A, const float* W, co
  * tensor exists -- three launches -> one in front of a dense pooler on sparse inputs.  N = the longest graph (<= 64).
  * The caller guarantees the row order and the ranges (tgp_graph_lower_bounds_i64, or tgp_edge_facts_sorted_i64 below,
  * whose flag word may be read AFTER this launch: what is read through edge_ptr is clamped to [0, E], columns outside
- * [0, Ntot) are dropped); inference (the backward kernels read the padded tensors). */
+ * [0, Ntot) are dropped).  x_dense_out / adj_dense_out (optional): the zero-padded x and the adjacency tiles as the kernel
+ * holds them, for a training step -- the backward kernels read the padded tensors; what to_dense_batch / to_dense_adj
+ * would have written, without their launches and without the zero fill. */
 int tgp_dense_pool_select_sparse_f32(const float* x, int64_t Ntot, const int64_t* row, const int64_t* col, const float* w,
                                      int64_t E, const int64_t* batch, const int64_t* node_ptr, const int64_t* edge_ptr,
                                      const float* W, const float* bias, int64_t B, int64_t N, int64_t K, int64_t F,
                                      int flags, int adj_transpose, float eps, float loss_eps, float* S_out,
                                      unsigned char* mask_out, float* x_pool, float* adj_raw, float* adj_pool,
                                      float* mincut_terms /* [2,B] or NULL */, int64_t* batch_pool /* [B*K] or NULL */,
+                                     float* x_dense_out /* [B,N,F] or NULL */, float* adj_dense_out /* [B,N,N] or NULL */,
                                      void* stream);
 
 /* Facts of a NEW edge list for that call, one launch, no host round trip in front of the consumer: edge_ptr [N+2]

@@ -914,3 +914,60 @@ def test_mincut_forward_from_the_unpadded_batch_equals_the_densified_one(dev, ad
         fresh = pooler(x=x, adj=ei3, edge_weight=ew, batch=bd.clone())
     assert calls == [1] and K_._rows_sorted_memo(ei3) is True
     torch.testing.assert_close(fresh.x, old.x, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("adj_transpose", [True, False])
+def test_mincut_training_step_from_the_unpadded_batch(dev, adj_transpose, monkeypatch):
+    """get_pooler('mincut') in training on a sorted batch of small graphs given as sparse tensors: the forward is the
+    launch that reads the un-padded batch (the padded x and the dense adjacency the backward kernels need are its side
+    outputs: no to_dense_batch / to_dense_adj launches), the backward ends with the gather back to the un-padded rows.
+    Outputs, losses and every gradient equal the densified path's."""
+    from tgp import kernels as K_
+    from tgp import poolers as P
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(31)
+    B = 96
+    sizes = torch.randint(8, 61, (B,), generator=g)
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(B), sizes)
+    start = torch.cumsum(sizes, 0) - sizes
+    deg = torch.randint(1, 6, (n,), generator=g)
+    row = torch.repeat_interleave(torch.arange(n), deg)
+    col = start[batch[row]] + (torch.rand(row.numel(), generator=g) * sizes[batch[row]]).long()
+    ei, bd = torch.stack([row, col]).to(dev), batch.to(dev)
+    ew = (torch.rand(row.numel(), generator=g) + 0.1).to(dev)
+    x0 = torch.randn(n, 32, generator=g).to(dev)
+    torch.manual_seed(0)
+    pooler = get_pooler("mincut", in_channels=32, k=20, adj_transpose=adj_transpose).to(dev).train()
+    calls = []
+    real = K_.dense_pool_select_sparse
+    monkeypatch.setattr(K_, "dense_pool_select_sparse", lambda *a, **k: (calls.append(k.get("want_dense")), real(*a, **k))[1])
+
+    def step(x_needs_grad):
+        pooler.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(x_needs_grad)
+        out = pooler(x=x, adj=ei, edge_weight=ew, batch=bd)
+        loss = out.x.square().sum() + (out.edge_index * 0.5).sum() + sum(out.loss.values()) + (out.so.s ** 2).sum() * 0.1
+        loss.backward()
+        return (out.x.detach(), out.edge_index.detach(), {k: v.detach() for k, v in out.loss.items()}, x.grad,
+                [p.grad.clone() for p in pooler.parameters()])
+
+    for x_needs_grad in (True, False):
+        calls.clear()
+        monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", True)
+        new = step(x_needs_grad)
+        assert calls == [True]
+        monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", False)
+        old = step(x_needs_grad)
+        assert calls == [True]
+        torch.testing.assert_close(new[0], old[0], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(new[1], old[1], rtol=1e-5, atol=1e-6)
+        for k in old[2]:
+            torch.testing.assert_close(new[2][k], old[2][k], rtol=1e-5, atol=1e-6)
+        if x_needs_grad:
+            torch.testing.assert_close(new[3], old[3], rtol=1e-4, atol=1e-5 * max(1.0, float(old[3].abs().max())))
+        else:
+            assert new[3] is None and old[3] is None
+        for a, b in zip(new[4], old[4]):
+            torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-5 * max(1.0, float(b.abs().max())))

@@ -53,6 +53,9 @@ struct SmallArgs {
   int e_transposed;
   unsigned char* mask_out;
   long long e_count, n_total;  // E and Ntot: what is read through edge_ptr / e_col is clamped / range-checked against them
+  // optional side outputs of the sparse form (training: the backward kernels read the padded tensors): the adjacency
+  // tile as it stands in LDS -> a_dense_out [B,N,N], the graph's rows of x zero-padded -> x_dense_out [B,N,F]
+  float* a_dense_out; float* x_dense_out;
 };
 
 __device__ __forceinline__ float sg_wave_sum(float v) {
@@ -310,6 +313,23 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
     // the tile belongs to this wave alone and LDS serves a wave's requests in order: no workgroup barrier
     __builtin_amdgcn_wave_barrier();
     TGP_WSTAMP(1);
+    if constexpr (SPARSE) {
+      if (p.a_dense_out) {  // what to_dense_adj would have written for this graph (rows of N floats, coalesced)
+        float* o = p.a_dense_out + static_cast<long>(b) * N * N;
+        for (int e = lane; e < N * N; e += 64) {
+          const int i = e / N, j = e - i * N;
+          o[e] = As[i * SG_LDA + j];
+        }
+      }
+      if (p.x_dense_out && lm < F) {  // to_dense_batch's rows of this graph (zero behind its nodes)
+        float* o = p.x_dense_out + static_cast<long>(b) * N * F;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+          const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
+          if (node < N) o[node * F + lm] = xr[q];
+        }
+      }
+    }
 
     // ---- X' = S^T X ---------------------------------------------------------------------
     if (p.X && p.x_pool) {

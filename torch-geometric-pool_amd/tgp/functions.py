@@ -779,6 +779,60 @@ class _SelectPoolSmallFn(torch.autograd.Function):
                 None, None, None)
 
 
+class _SelectPoolSparseFn(torch.autograd.Function):
+    """:class:`_SelectPoolSmallFn` on the batch as PyG hands it over (x [Ntot,F], a row-sorted edge list): the forward is
+    ``tgp_dense_pool_select_sparse_f32`` -- the adjacency tiles are built in LDS from the edges, and the zero-padded x and
+    the dense adjacency the BACKWARD kernels read leave the same launch as side outputs (no ``to_dense_batch`` /
+    ``to_dense_adj`` launches, no zero fill) --, the backward the pooling backward, the selector's backward and the gather
+    back to the un-padded rows (``tgp_from_dense_batch_f32``).  MinCut (the losses come out of the kernel); the edge
+    weights get no gradient here."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, edge_index, edge_weight, batch, node_ptr, edge_ptr, num_graphs, max_nodes, flags,
+                adj_transpose, want_terms):
+        from . import kernels as K
+        ctx.set_materialize_grads(False)
+        s, mask, x_pool, raw, adj_pool, terms, bp, xd, ad = K.dense_pool_select_sparse(
+            x.detach(), edge_index, edge_weight, batch, node_ptr, edge_ptr, num_graphs, max_nodes, weight.detach(),
+            None if bias is None else bias.detach(), flags, adj_transpose, want_raw=True, mincut_terms=True,
+            want_dense=True)
+        empty = s.new_empty(0)
+        la = lb = empty
+        if want_terms:
+            both = terms.mean(dim=1)
+            la, lb = both[0], both[1]
+        ctx.save_for_backward(s, ad, xd, weight, batch, node_ptr)
+        ctx.flags, ctx.max_nodes = flags, max_nodes
+        ctx.want_gx = x.requires_grad
+        ctx.diff_scales = None
+        ctx.has_bias = bias is not None
+        ctx.mark_non_differentiable(mask, bp, *([] if want_terms else [la, lb]))
+        return s, mask, x_pool, raw, adj_pool, la, lb, bp
+
+    @staticmethod
+    def backward(ctx, g_s, _g_mask, g_x, g_raw, g_adj, g_la, g_lb, _g_bp):
+        from . import kernels as K
+        s, ad, xd, weight, batch, node_ptr = ctx.saved_tensors
+        gs, gxd = _pool_small_backward(ctx, s, ad, xd, s.new_empty(0), g_x, g_raw, g_adj, None, None, g_la, g_lb)
+        if g_s is not None:
+            gs = gs + g_s
+        need = ctx.needs_input_grad
+        gxd, gw, gb = K.mlp_select_bwd(s, gs, xd, weight, want_gx=need[0], want_gw=need[1],
+                                       want_gb=ctx.has_bias and need[2], gx_accumulate=gxd if need[0] else None)
+        gx = K.from_dense_batch(gxd, batch, node_ptr, ctx.max_nodes) if need[0] else None
+        return (gx, gw, (gb if ctx.has_bias else None), None, None, None, None, None, None, None, None, None, None)
+
+
+def select_pool_sparse(x: Tensor, weight: Tensor, bias: Optional[Tensor], edge_index: Tensor,
+                       edge_weight: Optional[Tensor], batch: Tensor, node_ptr: Tensor, edge_ptr: Tensor, num_graphs: int,
+                       max_nodes: int, flags: int, adj_transpose: bool, want_terms: bool):
+    """(s, mask, x_pool, raw, adj_pool, LossPair or None, pooled batch vector): see :class:`_SelectPoolSparseFn`."""
+    out = _SelectPoolSparseFn.apply(x, weight, bias, edge_index, edge_weight, batch, node_ptr, edge_ptr, num_graphs,
+                                    max_nodes, flags, adj_transpose, want_terms)
+    pair = LossPair((out[5], out[6])) if want_terms else None
+    return out[0], out[1], out[2], out[3], out[4], pair, out[7]
+
+
 def select_pool_small(x: Tensor, adj: Tensor, weight: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], flags: int,
                       want_raw: bool, want_terms: bool, diff_scales=None, graph_sizes: Optional[Tensor] = None,
                       want_batch: bool = False):

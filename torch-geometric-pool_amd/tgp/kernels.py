@@ -1076,7 +1076,7 @@ def edge_facts_finish(handle, edge_index: Tensor, graph_ptr: Tensor) -> bool:
 def dense_pool_select_sparse(x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor,
                              node_ptr: Tensor, edge_ptr: Tensor, num_graphs: int, max_nodes: int, weight: Tensor,
                              bias: Optional[Tensor], flags: int, adj_transpose: bool, want_raw: bool = False,
-                             mincut_terms: bool = False):
+                             mincut_terms: bool = False, want_dense: bool = False):
     """(s [B,N,K], mask [B,N], x_pool, adj_raw, adj_pool, terms, batch_pool): :func:`dense_pool_select` straight from
     the un-padded batch -- x [Ntot,F], a ROW-SORTED ``edge_index`` with the per-graph ranges ``node_ptr`` / ``edge_ptr``
     [B+1] -- in ONE launch: the adjacency tiles are built in LDS from the edges, neither ``to_dense_batch`` nor
@@ -1099,11 +1099,17 @@ def dense_pool_select_sparse(x: Tensor, edge_index: Tensor, edge_weight: Optiona
     adj_raw = torch.empty(B, K, K, dtype=torch.float32, device=dev) if want_raw else None
     terms = torch.empty(2, B, dtype=torch.float32, device=dev) if mincut_terms else None
     bp = torch.empty(B * K, dtype=torch.int64, device=dev)
+    # want_dense (training): also the zero-padded x [B,N,F] and the adjacency [B,N,N] the backward kernels read
+    xd = torch.empty(B, Nn, F, dtype=torch.float32, device=dev) if want_dense else None
+    ad = torch.empty(B, Nn, Nn, dtype=torch.float32, device=dev) if want_dense else None
     N.check(N.lib().tgp_dense_pool_select_sparse_f32(
         N.ptr(x), x.size(0), N.ptr(row) if E else None, N.ptr(col) if E else None, N.ptr(w), E, N.ptr(N.i64c(batch)),
         N.ptr(N.i64c(node_ptr)), N.ptr(N.i64c(edge_ptr)), N.ptr(weight), N.ptr(b), B, Nn, K, F, flags,
         1 if adj_transpose else 0, ops_eps(), losses_eps(), N.ptr(s), mask.data_ptr(), N.ptr(x_pool), N.ptr(adj_raw),
-        N.ptr(adj_pool), N.ptr(terms), N.ptr(bp), N.stream_ptr(dev)), "tgp_dense_pool_select_sparse_f32")
+        N.ptr(adj_pool), N.ptr(terms), N.ptr(bp), N.ptr(xd), N.ptr(ad), N.stream_ptr(dev)),
+        "tgp_dense_pool_select_sparse_f32")
+    if want_dense:
+        return s, mask, x_pool, adj_raw, adj_pool, terms, bp, xd, ad
     return s, mask, x_pool, adj_raw, adj_pool, terms, bp
 
 

@@ -213,11 +213,13 @@ class _DenseMLPPooling(DenseSRCPooling):
         return so, fused, (out[5] if want_batch else None)
 
     def _select_reduce_connect_sparse(self, x, edge_index, edge_weight, batch):
-        """Inference on a sorted batch of small graphs that arrives as PyG hands it over (x [N,F], a row-sorted
+        """A sorted batch of small graphs that arrives as PyG hands it over (x [N,F], a row-sorted
         ``edge_index``): Select + Reduce + Connect + loss tails straight from the un-padded batch in ONE launch
         (tgp_dense_pool_select_sparse_f32: every graph's adjacency tile is built in LDS from its edges) -- neither
-        ``to_dense_batch`` nor ``to_dense_adj`` runs and no [B,N,N] tensor exists.  Only for poolers whose losses come out
-        of the kernel (MinCut); returns ``(SelectOutput, fused, pooled batch vector)`` or None."""
+        ``to_dense_batch`` nor ``to_dense_adj`` runs and no [B,N,N] tensor exists.  Training takes the same launch as one
+        autograd node (functions._SelectPoolSparseFn: the padded tensors the backward kernels read are side outputs).  Only
+        for poolers whose losses come out of the kernel (MinCut); returns ``(SelectOutput, fused, pooled batch vector)``
+        or None."""
         from .. import kernels as K
         sel, c = self.selector, self.connector
         lins = getattr(getattr(sel, "mlp", None), "lins", None)
@@ -230,9 +232,12 @@ class _DenseMLPPooling(DenseSRCPooling):
                 or (edge_weight is not None and (edge_weight.dim() != 1 or edge_weight.dtype != torch.float32))):
             return None
         last = lins[0]
-        if torch.is_grad_enabled() and (x.requires_grad or last.weight.requires_grad
-                                        or (last.bias is not None and last.bias.requires_grad)
-                                        or (edge_weight is not None and edge_weight.requires_grad)):
+        if torch.is_grad_enabled() and edge_weight is not None and edge_weight.requires_grad:
+            return None  # (the edge weights get no gradient from the fused backward)
+        training = torch.is_grad_enabled() and (x.requires_grad or last.weight.requires_grad
+                                                or (last.bias is not None and last.bias.requires_grad))
+        if training and not (_FOLD_TRAINING and not c.edge_weight_norm
+                             and K.mlp_select_bwd_fits(last.weight.size(0), x.size(1))):
             return None
         # the one-launch kernel walks every graph's edge range: the list must be grouped by ascending source node (what
         # PyG's loaders produce).  Known per tensor object once it has been looked at; a NEW list gets its ranges and
@@ -257,10 +262,16 @@ class _DenseMLPPooling(DenseSRCPooling):
             return None
         edge_ptr = pending[2] if pending is not None else K.graph_edge_ptr(edge_index, info.ptr)
         flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
-        s, mask, x_pool, raw, adj_pool, terms, bp = K.dense_pool_select_sparse(
-            x, edge_index, edge_weight, batch, info.ptr, edge_ptr, info.num_graphs, info.max_nodes,
-            last.weight.detach(), None if last.bias is None else last.bias.detach(), flags, self.adj_transpose,
-            want_raw=True, mincut_terms=True)
+        if training:  # one autograd node; the padded tensors the backward reads are side outputs of the same launch
+            from .. import functions as Fn
+            s, mask, x_pool, raw, adj_pool, terms, bp = Fn.select_pool_sparse(
+                x, last.weight, last.bias, edge_index, edge_weight, batch, info.ptr, edge_ptr, info.num_graphs,
+                info.max_nodes, flags, self.adj_transpose, True)
+        else:
+            s, mask, x_pool, raw, adj_pool, terms, bp = K.dense_pool_select_sparse(
+                x, edge_index, edge_weight, batch, info.ptr, edge_ptr, info.num_graphs, info.max_nodes,
+                last.weight.detach(), None if last.bias is None else last.bias.detach(), flags, self.adj_transpose,
+                want_raw=True, mincut_terms=True)
         if pending is not None and not K.edge_facts_finish(pending, edge_index, info.ptr):
             return None  # rows not sorted: what the kernel computed on clamped ranges is dropped
         so = SelectOutput(s=s, s_inv_op=sel.s_inv_op, in_mask=mask)
