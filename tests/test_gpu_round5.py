@@ -837,6 +837,38 @@ def test_fused_dense_call_with_the_spread_post_processing(dev, K, dtype, monkeyp
 
 # ------------------------------------------------------------------ r5: the dense poolers' forward straight from sparse inputs
 @pytest.mark.gpu
+def test_diffpool_inference_from_the_unpadded_batch_equals_the_densified_one(dev, monkeypatch):
+    """get_pooler('diff') in inference on sparse inputs takes the same launch; its two losses (the link loss needs the
+    dense adjacency, utils/losses.py:644-658) are computed from the adjacency the launch leaves as a side output."""
+    from tgp import kernels as K_
+    from tgp import poolers as P
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(41)
+    B = 72
+    sizes = torch.randint(6, 61, (B,), generator=g)
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(B), sizes)
+    start = torch.cumsum(sizes, 0) - sizes
+    row = torch.repeat_interleave(torch.arange(n), torch.randint(1, 6, (n,), generator=g))
+    col = start[batch[row]] + (torch.rand(row.numel(), generator=g) * sizes[batch[row]]).long()
+    ei, bd, x = torch.stack([row, col]).to(dev), batch.to(dev), torch.randn(n, 32, generator=g).to(dev)
+    for at in (True, False):
+        torch.manual_seed(0)
+        pooler = get_pooler("diff", in_channels=32, k=20, adj_transpose=at).to(dev).eval()
+        with torch.no_grad():
+            monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", True)
+            new = pooler(x=x, adj=ei, batch=bd)
+            monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", False)
+            old = pooler(x=x, adj=ei, batch=bd)
+        torch.testing.assert_close(new.x, old.x, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(new.edge_index, old.edge_index, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(new.so.s, old.so.s, rtol=1e-6, atol=1e-7)
+        assert set(new.loss) == set(old.loss) == {"link_loss", "entropy_loss"}
+        for k in old.loss:
+            torch.testing.assert_close(new.loss[k], old.loss[k], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("adj_transpose", [True, False])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_mincut_forward_from_the_unpadded_batch_equals_the_densified_one(dev, adj_transpose, weighted, monkeypatch):

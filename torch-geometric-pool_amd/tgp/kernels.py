@@ -1100,7 +1100,8 @@ def dense_pool_select_sparse(x: Tensor, edge_index: Tensor, edge_weight: Optiona
     terms = torch.empty(2, B, dtype=torch.float32, device=dev) if mincut_terms else None
     bp = torch.empty(B * K, dtype=torch.int64, device=dev)
     # want_dense (training): also the zero-padded x [B,N,F] and the adjacency [B,N,N] the backward kernels read
-    xd = torch.empty(B, Nn, F, dtype=torch.float32, device=dev) if want_dense else None
+    # (want_dense="adj": the adjacency alone -- DiffPool's losses read it in inference)
+    xd = torch.empty(B, Nn, F, dtype=torch.float32, device=dev) if want_dense is True else None
     ad = torch.empty(B, Nn, Nn, dtype=torch.float32, device=dev) if want_dense else None
     N.check(N.lib().tgp_dense_pool_select_sparse_f32(
         N.ptr(x), x.size(0), N.ptr(row) if E else None, N.ptr(col) if E else None, N.ptr(w), E, N.ptr(N.i64c(batch)),

@@ -223,7 +223,7 @@ class _DenseMLPPooling(DenseSRCPooling):
         from .. import kernels as K
         sel, c = self.selector, self.connector
         lins = getattr(getattr(sel, "mlp", None), "lins", None)
-        if (not _FOLD_SPARSE_INPUTS or not self._loss_needs_raw or self.cache_preprocessing
+        if (not _FOLD_SPARSE_INPUTS or self.cache_preprocessing
                 or type(sel) is not MLPSelect or lins is None or len(lins) != 1 or type(c) is not DenseConnect
                 or type(self.reducer) is not BaseReduce or not (isinstance(x, Tensor) and isinstance(edge_index, Tensor))
                 or x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or edge_index.dim() != 2
@@ -236,7 +236,9 @@ class _DenseMLPPooling(DenseSRCPooling):
             return None  # (the edge weights get no gradient from the fused backward)
         training = torch.is_grad_enabled() and (x.requires_grad or last.weight.requires_grad
                                                 or (last.bias is not None and last.bias.requires_grad))
-        if training and not (_FOLD_TRAINING and not c.edge_weight_norm
+        # (a pooler whose losses need the dense adjacency -- DiffPool's link loss -- takes the launch in inference, with
+        #  the adjacency as a side output; its training step keeps the densified form)
+        if training and not (_FOLD_TRAINING and self._loss_needs_raw and not c.edge_weight_norm
                              and K.mlp_select_bwd_fits(last.weight.size(0), x.size(1))):
             return None
         # the one-launch kernel walks every graph's edge range: the list must be grouped by ascending source node (what
@@ -267,16 +269,24 @@ class _DenseMLPPooling(DenseSRCPooling):
             s, mask, x_pool, raw, adj_pool, terms, bp = Fn.select_pool_sparse(
                 x, last.weight, last.bias, edge_index, edge_weight, batch, info.ptr, edge_ptr, info.num_graphs,
                 info.max_nodes, flags, self.adj_transpose, True)
-        else:
+        elif self._loss_needs_raw:
             s, mask, x_pool, raw, adj_pool, terms, bp = K.dense_pool_select_sparse(
                 x, edge_index, edge_weight, batch, info.ptr, edge_ptr, info.num_graphs, info.max_nodes,
                 last.weight.detach(), None if last.bias is None else last.bias.detach(), flags, self.adj_transpose,
                 want_raw=True, mincut_terms=True)
+        else:  # the losses are computed behind the launch from the dense adjacency it leaves (no zero fill, no scatter)
+            s, mask, x_pool, raw, adj_pool, terms, bp, _xd, ad = K.dense_pool_select_sparse(
+                x, edge_index, edge_weight, batch, info.ptr, edge_ptr, info.num_graphs, info.max_nodes,
+                last.weight.detach(), None if last.bias is None else last.bias.detach(), flags, self.adj_transpose,
+                want_raw=False, mincut_terms=False, want_dense="adj")
         if pending is not None and not K.edge_facts_finish(pending, edge_index, info.ptr):
             return None  # rows not sorted: what the kernel computed on clamped ranges is dropped
         so = SelectOutput(s=s, s_inv_op=sel.s_inv_op, in_mask=mask)
         so._graph_sizes = info.sizes
-        return so, (x_pool, raw, adj_pool, terms), bp
+        if not self._loss_needs_raw:
+            self._sizes_hint = (weakref.ref(ad), info.sizes)
+            return so, (x_pool, None, adj_pool, None), bp, ad
+        return so, (x_pool, raw, adj_pool, terms), bp, None
 
     def _select_reduce_connect_train(self, x, adj, mask, graph_sizes, want_batch=False):
         """Training on a batch of small graphs with a single-Linear selector: Select + Reduce + Connect + loss tails as
@@ -329,12 +339,13 @@ class _DenseMLPPooling(DenseSRCPooling):
             return self._lift(x, so, batch, batch_pooled)
         if self.batched:
             if so is None and mask is None and not is_dense_adj(adj):
+                self._sizes_hint = None
                 sparse = self._select_reduce_connect_sparse(x, adj, edge_weight, batch)
-                if sparse is not None:  # inference straight from the un-padded batch: no densification at all
-                    so, fused, batch_pool = sparse
+                if sparse is not None:  # straight from the un-padded batch: no densification launches
+                    self._known_nodes = x.size(0)
+                    so, fused, batch_pool, dense_adj = sparse
                     x_pool, raw, adj_pool, terms = fused
-                    self._known_nodes, self._sizes_hint = x.size(0), None
-                    loss = self._loss_from_fused(adj, so, None, raw, terms, None)
+                    loss = self._loss_from_fused(dense_adj if dense_adj is not None else adj, so, None, raw, terms, None)
                     if self.sparse_output:
                         x_pool, ei, ew, batch_pool = self._finalize_sparse_output(
                             x_pool=x_pool, adj_pool=adj_pool, batch=batch, batch_pooled=batch_pool, so=so)
