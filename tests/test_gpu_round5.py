@@ -949,9 +949,10 @@ def test_mincut_forward_from_the_unpadded_batch_equals_the_densified_one(dev, ad
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("alias", ["mincut", "diff"])
 @pytest.mark.parametrize("adj_transpose", [True, False])
-def test_mincut_training_step_from_the_unpadded_batch(dev, adj_transpose, monkeypatch):
-    """get_pooler('mincut') in training on a sorted batch of small graphs given as sparse tensors: the forward is the
+def test_dense_pooler_training_step_from_the_unpadded_batch(dev, alias, adj_transpose, monkeypatch):
+    """get_pooler('mincut' / 'diff') in training on a sorted batch of small graphs given as sparse tensors: the forward is the
     launch that reads the un-padded batch (the padded x and the dense adjacency the backward kernels need are its side
     outputs: no to_dense_batch / to_dense_adj launches), the backward ends with the gather back to the un-padded rows.
     Outputs, losses and every gradient equal the densified path's."""
@@ -971,7 +972,7 @@ def test_mincut_training_step_from_the_unpadded_batch(dev, adj_transpose, monkey
     ew = (torch.rand(row.numel(), generator=g) + 0.1).to(dev)
     x0 = torch.randn(n, 32, generator=g).to(dev)
     torch.manual_seed(0)
-    pooler = get_pooler("mincut", in_channels=32, k=20, adj_transpose=adj_transpose).to(dev).train()
+    pooler = get_pooler(alias, in_channels=32, k=20, adj_transpose=adj_transpose).to(dev).train()
     calls = []
     real = K_.dense_pool_select_sparse
     monkeypatch.setattr(K_, "dense_pool_select_sparse", lambda *a, **k: (calls.append(k.get("want_dense")), real(*a, **k))[1])

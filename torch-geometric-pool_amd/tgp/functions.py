@@ -789,7 +789,7 @@ class _SelectPoolSparseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, edge_index, edge_weight, batch, node_ptr, edge_ptr, num_graphs, max_nodes, flags,
-                adj_transpose, want_terms):
+                adj_transpose, want_terms, diff_scales=None, graph_sizes=None):
         from . import kernels as K
         ctx.set_materialize_grads(False)
         s, mask, x_pool, raw, adj_pool, terms, bp, xd, ad = K.dense_pool_select_sparse(
@@ -797,39 +797,44 @@ class _SelectPoolSparseFn(torch.autograd.Function):
             None if bias is None else bias.detach(), flags, adj_transpose, want_raw=True, mincut_terms=True,
             want_dense=True)
         empty = s.new_empty(0)
-        la = lb = empty
-        if want_terms:
+        la = lb = diff = empty
+        if diff_scales is not None:  # DiffPool's two losses from the adjacency the launch left (utils/losses.py:644-658)
+            diff = K.diffpool_loss_tail(s, ad, graph_sizes, diff_scales[0], diff_scales[1])
+            la, lb = diff[0], diff[1]
+        elif want_terms:
             both = terms.mean(dim=1)
             la, lb = both[0], both[1]
-        ctx.save_for_backward(s, ad, xd, weight, batch, node_ptr)
+        ctx.save_for_backward(s, ad, xd, weight, batch, node_ptr, diff)
         ctx.flags, ctx.max_nodes = flags, max_nodes
         ctx.want_gx = x.requires_grad
-        ctx.diff_scales = None
+        ctx.diff_scales = diff_scales
         ctx.has_bias = bias is not None
-        ctx.mark_non_differentiable(mask, bp, *([] if want_terms else [la, lb]))
+        ctx.mark_non_differentiable(mask, bp, *([] if (want_terms or diff_scales is not None) else [la, lb]))
         return s, mask, x_pool, raw, adj_pool, la, lb, bp
 
     @staticmethod
     def backward(ctx, g_s, _g_mask, g_x, g_raw, g_adj, g_la, g_lb, _g_bp):
         from . import kernels as K
-        s, ad, xd, weight, batch, node_ptr = ctx.saved_tensors
-        gs, gxd = _pool_small_backward(ctx, s, ad, xd, s.new_empty(0), g_x, g_raw, g_adj, None, None, g_la, g_lb)
+        s, ad, xd, weight, batch, node_ptr, diff = ctx.saved_tensors
+        gs, gxd = _pool_small_backward(ctx, s, ad, xd, diff, g_x, g_raw, g_adj, None, None, g_la, g_lb)
         if g_s is not None:
             gs = gs + g_s
         need = ctx.needs_input_grad
         gxd, gw, gb = K.mlp_select_bwd(s, gs, xd, weight, want_gx=need[0], want_gw=need[1],
                                        want_gb=ctx.has_bias and need[2], gx_accumulate=gxd if need[0] else None)
         gx = K.from_dense_batch(gxd, batch, node_ptr, ctx.max_nodes) if need[0] else None
-        return (gx, gw, (gb if ctx.has_bias else None), None, None, None, None, None, None, None, None, None, None)
+        return (gx, gw, (gb if ctx.has_bias else None)) + (None,) * 12
 
 
 def select_pool_sparse(x: Tensor, weight: Tensor, bias: Optional[Tensor], edge_index: Tensor,
                        edge_weight: Optional[Tensor], batch: Tensor, node_ptr: Tensor, edge_ptr: Tensor, num_graphs: int,
-                       max_nodes: int, flags: int, adj_transpose: bool, want_terms: bool):
-    """(s, mask, x_pool, raw, adj_pool, LossPair or None, pooled batch vector): see :class:`_SelectPoolSparseFn`."""
+                       max_nodes: int, flags: int, adj_transpose: bool, want_terms: bool, diff_scales=None,
+                       graph_sizes: Optional[Tensor] = None):
+    """(s, mask, x_pool, raw, adj_pool, LossPair or None, pooled batch vector): see :class:`_SelectPoolSparseFn`.
+    ``diff_scales`` = (link_scale, ent_scale): the pair holds DiffPool's two losses instead of MinCut's."""
     out = _SelectPoolSparseFn.apply(x, weight, bias, edge_index, edge_weight, batch, node_ptr, edge_ptr, num_graphs,
-                                    max_nodes, flags, adj_transpose, want_terms)
-    pair = LossPair((out[5], out[6])) if want_terms else None
+                                    max_nodes, flags, adj_transpose, want_terms, diff_scales, graph_sizes)
+    pair = LossPair((out[5], out[6])) if (want_terms or diff_scales is not None) else None
     return out[0], out[1], out[2], out[3], out[4], pair, out[7]
 
 

@@ -171,8 +171,9 @@ class _DenseMLPPooling(DenseSRCPooling):
 
     _loss_needs_raw = False  # MinCut's cut loss reads the raw S^T A S
 
-    def _fused_diff_scales(self, adj, mask):
-        """(link_scale, ent_scale) when the pooler's two losses can ride on the fused training call (DiffPool)."""
+    def _fused_diff_scales(self, adj, mask, adj_numel=None):
+        """(link_scale, ent_scale) when the pooler's two losses can ride on the fused training call (DiffPool).
+        ``adj_numel``: B * N * N of the padded adjacency when ``adj`` is not that tensor (sparse inputs)."""
         return None
 
     def _loss_from_fused(self, adj, so, mask, raw, terms=None, diff=None) -> dict:
@@ -236,9 +237,8 @@ class _DenseMLPPooling(DenseSRCPooling):
             return None  # (the edge weights get no gradient from the fused backward)
         training = torch.is_grad_enabled() and (x.requires_grad or last.weight.requires_grad
                                                 or (last.bias is not None and last.bias.requires_grad))
-        # (a pooler whose losses need the dense adjacency -- DiffPool's link loss -- takes the launch in inference, with
-        #  the adjacency as a side output; its training step keeps the densified form)
-        if training and not (_FOLD_TRAINING and self._loss_needs_raw and not c.edge_weight_norm
+        # (a pooler whose losses need the dense adjacency -- DiffPool's link loss -- gets it as a side output of the launch)
+        if training and not (_FOLD_TRAINING and not c.edge_weight_norm
                              and K.mlp_select_bwd_fits(last.weight.size(0), x.size(1))):
             return None
         # the one-launch kernel walks every graph's edge range: the list must be grouped by ascending source node (what
@@ -264,11 +264,20 @@ class _DenseMLPPooling(DenseSRCPooling):
             return None
         edge_ptr = pending[2] if pending is not None else K.graph_edge_ptr(edge_index, info.ptr)
         flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
+        ad = None
         if training:  # one autograd node; the padded tensors the backward reads are side outputs of the same launch
             from .. import functions as Fn
+            diff_scales = None
+            if not self._loss_needs_raw:
+                self._known_nodes = x.size(0)
+                diff_scales = self._fused_diff_scales(None, None, info.num_graphs * info.max_nodes * info.max_nodes)
+                if diff_scales is None:
+                    if pending is not None:
+                        K.edge_facts_finish(pending, edge_index, info.ptr)
+                    return None
             s, mask, x_pool, raw, adj_pool, terms, bp = Fn.select_pool_sparse(
                 x, last.weight, last.bias, edge_index, edge_weight, batch, info.ptr, edge_ptr, info.num_graphs,
-                info.max_nodes, flags, self.adj_transpose, True)
+                info.max_nodes, flags, self.adj_transpose, self._loss_needs_raw, diff_scales, info.sizes)
         elif self._loss_needs_raw:
             s, mask, x_pool, raw, adj_pool, terms, bp = K.dense_pool_select_sparse(
                 x, edge_index, edge_weight, batch, info.ptr, edge_ptr, info.num_graphs, info.max_nodes,
@@ -284,9 +293,11 @@ class _DenseMLPPooling(DenseSRCPooling):
         so = SelectOutput(s=s, s_inv_op=sel.s_inv_op, in_mask=mask)
         so._graph_sizes = info.sizes
         if not self._loss_needs_raw:
+            if training:  # (both losses came with the fused call: a LossPair in the slot of `diff`)
+                return so, (x_pool, None, adj_pool, None, terms), bp, None
             self._sizes_hint = (weakref.ref(ad), info.sizes)
-            return so, (x_pool, None, adj_pool, None), bp, ad
-        return so, (x_pool, raw, adj_pool, terms), bp, None
+            return so, (x_pool, None, adj_pool, None, None), bp, ad
+        return so, (x_pool, raw, adj_pool, terms, None), bp, None
 
     def _select_reduce_connect_train(self, x, adj, mask, graph_sizes, want_batch=False):
         """Training on a batch of small graphs with a single-Linear selector: Select + Reduce + Connect + loss tails as
@@ -344,8 +355,8 @@ class _DenseMLPPooling(DenseSRCPooling):
                 if sparse is not None:  # straight from the un-padded batch: no densification launches
                     self._known_nodes = x.size(0)
                     so, fused, batch_pool, dense_adj = sparse
-                    x_pool, raw, adj_pool, terms = fused
-                    loss = self._loss_from_fused(dense_adj if dense_adj is not None else adj, so, None, raw, terms, None)
+                    x_pool, raw, adj_pool, terms, diff = fused
+                    loss = self._loss_from_fused(dense_adj if dense_adj is not None else adj, so, None, raw, terms, diff)
                     if self.sparse_output:
                         x_pool, ei, ew, batch_pool = self._finalize_sparse_output(
                             x_pool=x_pool, adj_pool=adj_pool, batch=batch, batch_pooled=batch_pool, so=so)
@@ -427,11 +438,12 @@ class DiffPool(_DenseMLPPooling):
         loss = self.compute_loss(adj=adj, S=so.s, num_nodes=self._real_nodes(mask))
         return adj_pool, loss
 
-    def _fused_diff_scales(self, adj, mask):
+    def _fused_diff_scales(self, adj, mask, adj_numel=None):
         num_nodes = self._real_nodes(mask)
         if not (isinstance(num_nodes, int) and num_nodes > 0 and torch.is_grad_enabled()):
             return None
-        link_scale = self.link_loss_coeff / adj.numel() if self.normalize_loss is True else self.link_loss_coeff
+        numel = adj.numel() if adj_numel is None else adj_numel
+        link_scale = self.link_loss_coeff / numel if self.normalize_loss is True else self.link_loss_coeff
         return (float(link_scale), float(self.ent_loss_coeff) / num_nodes)
 
     def _loss_from_fused(self, adj, so, mask, raw, terms=None, diff=None) -> dict:
