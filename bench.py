@@ -445,10 +445,13 @@ class PoolerForward(Workload):
             flops = 2.0 * B * N * F * K + 4.0 * B * N * N * K + 2.0 * B * K * N * (K + F)
             r = roof_mfma("whole forward (all kernels of the call, eager)", flops, ms)
         else:
-            # edge list + x in; dense A written and read once; X, S written and read once; pooled outputs
-            alg = (self.ei.size(1) * 16.0 + self.nodes * F * 4.0 + 2 * 4.0 * B * N * N + 2 * 4.0 * B * N * (F + K)
+            # r5: what the call has to move now that nothing is densified -- edge list + x in, S [B,N,K] + node mask out,
+            # pooled outputs (the r4 line also counted a dense A and a padded X written and read once: 2.7 x these bytes)
+            alg = (self.ei.size(1) * 16.0 + self.nodes * F * 4.0 + 4.0 * B * N * K + B * N
                    + 4.0 * B * (2 * K * K + K * F))
             r = roof_hbm("whole forward (all kernels of the call, eager)", alg, ms)
+            r["bytes_counted"] = ("edge list + x read, S [B,N,K] + mask + pooled outputs written (no dense adjacency: it is "
+                                  "not materialised)")
         r["launches_per_forward"] = count_kernels(self.step)
         try:  # the same forward replayed from a HIP graph (inputs resident, sizes memoised per batch vector)
             gph = torch.cuda.CUDAGraph()
