@@ -1983,6 +1983,29 @@ def kron_max_graph_nodes() -> int:
     return int(N.lib().tgp_kron_batched_max_graph_nodes())
 
 
+_KRON_CAPS: dict = {}
+
+
+def _kron_caps(graph_sizes_host) -> Tuple[int, int, int]:
+    """Workspace figures of the Kron kernels from the graphs' node counts: (sum of n^2 over the graphs inside the kernel's
+    size limit, sum of n (n | 1) over those beyond the LDS kernel's 128 nodes, how many those are).  Vectorised and
+    remembered per sizes list (r5: three Python passes over 2048 graphs were ~120 us of every NDP pooler call)."""
+    import numpy as np
+    key = id(graph_sizes_host)
+    hit = _KRON_CAPS.get(key)
+    if hit is not None and hit[0] is graph_sizes_host and hit[1] == len(graph_sizes_host):
+        return hit[2]
+    lim, lds = kron_max_graph_nodes(), 128
+    v = np.asarray(graph_sizes_host, dtype=np.int64)
+    v = v[v <= lim]
+    big = v[v > lds]
+    caps = (int((v * v).sum()), int((big * (big | 1)).sum()), int(big.size))
+    if len(_KRON_CAPS) > 16:
+        _KRON_CAPS.clear()
+    _KRON_CAPS[key] = (graph_sizes_host, len(graph_sizes_host), caps)  # (holds the list: the id stays its own)
+    return caps
+
+
 def kron_batched(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optional[Tensor], from_adjacency: bool,
                  num_nodes: int, graph_ptr: Tensor, max_graph_nodes: int, node_index: Tensor,
                  threshold: float, skip_oversize: bool = False,
@@ -1996,11 +2019,7 @@ def kron_batched(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optio
     dev = N.require_device(indptr, col, val, perm, graph_ptr, node_index)
     cap_dense = cap_big = num_big = -1
     if graph_sizes_host is not None:
-        lim, lds = kron_max_graph_nodes(), 128
-        inside = [int(v) for v in graph_sizes_host if v <= lim]
-        cap_dense = sum(v * v for v in inside)
-        cap_big = sum(v * (v | 1) for v in inside if v > lds)
-        num_big = sum(1 for v in inside if v > lds)
+        cap_dense, cap_big, num_big = _kron_caps(graph_sizes_host)
     if indptr.dtype != torch.int32 or (perm is not None and perm.dtype != torch.int32):
         raise ValueError("kron_batched: indptr / perm must be int32")
     col, graph_ptr, node_index = N.i64c(col), N.i64c(graph_ptr), N.i64c(node_index)
