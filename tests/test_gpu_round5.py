@@ -1004,3 +1004,53 @@ def test_dense_pooler_training_step_from_the_unpadded_batch(dev, alias, adj_tran
             assert new[3] is None and old[3] is None
         for a, b in zip(new[4], old[4]):
             torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-5 * max(1.0, float(b.abs().max())))
+
+
+# ------------------------------------------------------------------------ sparse poolers, training step (r5, late)
+@pytest.mark.parametrize("alias,kw", [("topk", dict(ratio=0.5)), ("topk", dict(ratio=0.3, multiplier=2.0)), ("graclus", {})])
+@pytest.mark.parametrize("weighted", [True, False])
+def test_sparse_pooler_training_forward_is_the_one_launch_call(dev, alias, kw, weighted, monkeypatch):
+    """A batch of small graphs in TRAINING: Reduce + Connect are the same single launch as in inference
+    (SRCPooling.reduce_connect) with the sparse Reduce's backward attached to x' -- where r4 took the staged operators
+    (6 launches for TopK, 10 for Graclus) whenever a gradient was required.  Outputs and every gradient (x, the TopK
+    projection through the kept scores, the scores again through ``so.s``) equal the staged route's bit for bit: the
+    forward sums are the same sums in the same order and the backward is the same node."""
+    import tgp.src as S
+    from tgp import kernels as K_
+    from tgp.poolers import get_pooler
+    x0, ei, ew, batch = _er_batch(150, 4, 60, 16, 21, dev)
+    ew = ew if weighted else None
+    torch.manual_seed(5)
+    pooler = get_pooler(alias, in_channels=16, **kw).to(dev).train()
+    calls = []
+    real = K_.sparse_pool_small
+    monkeypatch.setattr(K_, "sparse_pool_small", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+
+    def step(x_needs_grad):
+        pooler.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(x_needs_grad)
+        out = pooler(x=x, adj=ei, edge_weight=ew, batch=batch)
+        loss = out.x.square().sum()
+        if alias == "topk":
+            loss = loss + (out.so.s.coalesce().values() ** 2).sum() * 0.1
+        loss.backward()
+        return (out.x.detach(), out.edge_index, out.edge_weight, out.batch, x.grad,
+                [p.grad.clone() for p in pooler.parameters() if p.grad is not None])
+
+    for x_needs_grad in (True, False):
+        if alias == "graclus" and not x_needs_grad:
+            continue  # (nothing to differentiate: the inference call)
+        calls.clear()
+        monkeypatch.setattr(S, "_FOLD_TRAINING", True)
+        new = step(x_needs_grad)
+        assert calls == [1]
+        monkeypatch.setattr(S, "_FOLD_TRAINING", False)
+        old = step(x_needs_grad)
+        assert calls == [1]  # (the staged operators)
+        assert torch.equal(new[0], old[0]) and torch.equal(new[1], old[1]) and torch.equal(new[3], old[3])
+        assert (new[2] is None and old[2] is None) or torch.equal(new[2], old[2])
+        if x_needs_grad:
+            assert torch.equal(new[4], old[4])
+        assert len(new[5]) == len(old[5]) and (alias != "topk" or len(new[5]) == 1)
+        for a, b in zip(new[5], old[5]):
+            assert torch.equal(a, b)

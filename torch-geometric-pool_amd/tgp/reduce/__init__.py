@@ -92,11 +92,16 @@ class _SparseReduceFn(torch.autograd.Function):
     (dX = S dX') plus a row-dot for the assignment weights (TopK trains its scores through them)."""
 
     @staticmethod
-    def forward(ctx, x, weight, so):
-        # a clustering whose S has row index 0..N-1 and unit values (GraclusSelect; a cluster vector): known, not probed
-        out = K.reduce_sparse(x, so.node_index, weight, so.assign_index(),
-                              identity_source=bool(so.__dict__.get("_identity_nodes", False)),
-                              unit_weight=bool(so.__dict__.get("_unit_values", False)))
+    def forward(ctx, x, weight, so, computed=None):
+        # ``computed``: [x_pool] when the caller already has it -- SRCPooling.reduce_connect's one launch for Reduce +
+        # Connect, which computes the same sums in the same order; this node then only supplies the backward
+        if computed is not None:
+            out = computed[0]
+        else:
+            # a clustering whose S has row index 0..N-1 and unit values (GraclusSelect; a cluster vector): known, not probed
+            out = K.reduce_sparse(x, so.node_index, weight, so.assign_index(),
+                                  identity_source=bool(so.__dict__.get("_identity_nodes", False)),
+                                  unit_weight=bool(so.__dict__.get("_unit_values", False)))
         ctx.so = so
         ctx.save_for_backward(x, weight)
         return out
@@ -115,7 +120,7 @@ class _SparseReduceFn(torch.autograd.Function):
                 gw = K.pair_dot(x, so.node_index, grad_out, so.cluster_index)
             else:
                 gw = (x[so.node_index] * grad_out[so.cluster_index]).reshape(so.node_index.numel(), -1).sum(-1)
-        return gx, gw, None
+        return gx, gw, None, None
 
 
 class _DenseReduceFn(torch.autograd.Function):

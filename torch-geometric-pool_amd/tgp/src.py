@@ -2,6 +2,7 @@
 pre-coarsening mix-ins (public surface of reference tgp/src.py)."""
 from __future__ import annotations
 
+import os as _os
 from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Dict, Iterator, List, Optional, Tuple, Union
@@ -14,11 +15,15 @@ from . import kernels as K
 from .connect import Connect, SparseConnect, _normalize_pooled_edges
 from .imports import HAS_PYG
 from .lift import Lift
-from .reduce import BaseReduce, Reduce
+from .reduce import BaseReduce, Reduce, _SparseReduceFn
 from .select import Select, SelectOutput
 from .utils import Signature, connectivity_to_edge_index, foo_signature
 from .utils.ops import (batch_info, build_pooled_batch, graph_ptr, is_dense_adj, like_input_dtype, max_graph_size,
                         num_graphs_of)
+
+
+# A/B switch (read once): 0 keeps the staged sparse operators whenever a gradient is required
+_FOLD_TRAINING = _os.environ.get("TGP_FOLD_TRAINING", "1") != "0"
 
 
 @dataclass
@@ -127,8 +132,9 @@ class SRCPooling(torch.nn.Module):
                        batch: Optional[Tensor]):
         """Sparse Reduce + Connect of a batch of SMALL graphs as ONE native launch (fused A1 + A2 +
         A4/A5 + A6; ``tgp_sparse_pool_small_f32``): ``(x_pool, batch_pool, edge_index_pool, edge_weight_pool)`` with the
-        values ``self.reduce`` + ``self.connect`` return, or None when the call is not that case -- host tensors, a
-        gradient is required (the operators below are the differentiable path), no or an unsorted batch vector, a graph
+        values ``self.reduce`` + ``self.connect`` return, or None when the call is not that case -- host tensors, edge
+        weights that need a gradient (the staged Connect is the differentiable one; x and the assignment weights get
+        theirs from the sparse Reduce's backward attached to this call's x'), no or an unsorted batch vector, a graph
         of more than 64 nodes, non-tensor connectivity, caching -- or when the kernel's on-device checks refuse the
         input (an edge between two graphs, unsorted rows, ...).  The pooled ``edge_index`` is a new contiguous [2, E']
         tensor, values and order those of the staged operators (inside ``with tgp.kernels.output_views():`` it is a
@@ -147,8 +153,13 @@ class SRCPooling(torch.nn.Module):
                 return None
             ew = ew.reshape(-1)
         weight = so.weight
-        if torch.is_grad_enabled() and (x.requires_grad or (ew is not None and ew.requires_grad)
-                                        or (weight is not None and weight.requires_grad)):
+        # training (r5, late): the same launch with the sparse Reduce's backward attached to x' (x and the assignment
+        # weights -- TopK's scores -- get their gradients from it); edge weights that need a gradient keep the staged
+        # operators, whose Connect is differentiable
+        train = torch.is_grad_enabled() and (x.requires_grad or (weight is not None and weight.requires_grad))
+        if torch.is_grad_enabled() and ew is not None and ew.requires_grad:
+            return None
+        if train and not _FOLD_TRAINING:
             return None
         if torch.cuda.is_current_stream_capturing():
             return None  # the call waits for its edge count on the host (the staged operators raise for the same reason)
@@ -166,12 +177,15 @@ class SRCPooling(torch.nn.Module):
             return None
         if weight is not None and weight.dtype != torch.float32:
             return None
-        out = K.sparse_pool_small(x, info.ptr, edge_index, ew, index, weight, so.num_supernodes, mode,
+        out = K.sparse_pool_small(x.detach() if train else x, info.ptr, edge_index, ew, index,
+                                  weight.detach() if (train and weight is not None) else weight, so.num_supernodes, mode,
                                   reduce_op=c.reduce_op, remove_self_loops=c.remove_self_loops,
                                   assign_ptr=so.__dict__.get("_assign_ptr") if mode == 0 else None)
         if out is None:
             return None
         x_pool, batch_pool, ei, w_pool = out
+        if train:
+            x_pool = _SparseReduceFn.apply(x, weight, so, [x_pool])
         ei, w_pool = _normalize_pooled_edges(ei, w_pool, so.num_supernodes, c.degree_norm, c.edge_weight_norm,
                                              batch_pool)
         return x_pool, batch_pool, ei, w_pool
