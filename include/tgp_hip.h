@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10029 /* 1.0.1 of the reference, ABI revision 28 (r5: fp64 dense path on v_mfma_f64_16x16x4_f64; selector backward in one pass; float64 row-local coalesce; sparse-input select + pool) */
+#define TGP_ABI_VERSION 10030 /* 1.0.1 of the reference, ABI revision 29 (r5: fp64 dense path on v_mfma_f64_16x16x4_f64; selector backward in one pass; float64 row-local coalesce; sparse-input select + pool; TopK pooling backward) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -549,6 +549,20 @@ int tgp_topk_score_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const 
 size_t tgp_weighted_colsum_workspace_bytes(int64_t F);
 int tgp_weighted_colsum_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const float* g, float* out, void* ws,
                             size_t ws_bytes, void* stream);
+/* Backward of TopK pooling's trained path in one pass over the KEPT rows (r5; the reference gets it from ATen autograd
+ * through poolers/topk.py:150-190 = select/topk_select.py:176-184 (t = x w / ||w||, s = act(t)), the kept scores as
+ * the values of S (select/base_select.py:19-71) and reduce/base_reduce.py:141-155 (x'[c_a] = s_a x[i_a])).
+ * Inputs: x [N,F] (row stride ldx, 16-byte aligned rows), node / cluster / values [K] = the assignments of the
+ * one-to-one S (cluster NULL: 0..K-1), g_xpool = dL/dx' [K,F] contiguous or NULL, g_values = dL/d(values of S) [K] or
+ * NULL, w [F], act 0 = identity, 1 = tanh.  Outputs: gx [N,F] contiguous, written entirely (rows of nodes that were
+ * not kept are zero; NULL: not wanted), gw [F] (NULL: not wanted; fixed-order sums, run-to-run identical).
+ * F % 4 == 0, F <= 256 (tgp_topk_pool_bwd_fits); other widths keep the operator-by-operator backward. */
+int tgp_topk_pool_bwd_fits(int64_t F);
+size_t tgp_topk_pool_bwd_workspace_bytes(int64_t F);
+int tgp_topk_pool_bwd_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const int64_t* node,
+                          const int64_t* cluster, const float* values, int64_t K, const float* g_xpool,
+                          const float* g_values, const float* w, int act, float* gx, float* gw, void* ws,
+                          size_t ws_bytes, void* stream);
 
 /* ss[e] = <S[row_e,:], S[col_e,:]> for every edge: the entries of S S^T that the sparse (unbatched) losses
  * read (utils/losses.py:73-127 sparse_mincut_loss, :661-708 sparse_link_pred_loss: (S[src] * S[dst]).sum(-1)),

@@ -1037,11 +1037,13 @@ def test_sparse_pooler_training_forward_is_the_one_launch_call(dev, alias, kw, w
         return (out.x.detach(), out.edge_index, out.edge_weight, out.batch, x.grad,
                 [p.grad.clone() for p in pooler.parameters() if p.grad is not None])
 
+    import tgp.poolers as P
     for x_needs_grad in (True, False):
         if alias == "graclus" and not x_needs_grad:
             continue  # (nothing to differentiate: the inference call)
         calls.clear()
         monkeypatch.setattr(S, "_FOLD_TRAINING", True)
+        monkeypatch.setattr(P, "_FOLD_TRAINING", False)  # (TopK's one-node path has its own test below)
         new = step(x_needs_grad)
         assert calls == [1]
         monkeypatch.setattr(S, "_FOLD_TRAINING", False)
@@ -1054,3 +1056,120 @@ def test_sparse_pooler_training_forward_is_the_one_launch_call(dev, alias, kw, w
         assert len(new[5]) == len(old[5]) and (alias != "topk" or len(new[5]) == 1)
         for a, b in zip(new[5], old[5]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("F", [4, 16, 32, 64, 100, 128, 256])
+@pytest.mark.parametrize("use_tanh", [True, False])
+def test_topk_pool_backward_kernel_vs_autograd_in_double(dev, F, use_tanh):
+    """tgp_topk_pool_bwd_f32 against torch autograd of the same expression evaluated in float64 (select/topk_select.py:
+    176-184 score, kept values as the weights of S, reduce/base_reduce.py:141-155 gate): every combination of present /
+    absent incoming gradients and wanted outputs, a permuted supernode order, rows of dropped nodes exactly zero."""
+    from tgp import kernels as K_
+    g = torch.Generator().manual_seed(F + int(use_tanh))
+    n, k = 3001, 1234
+    x = torch.randn(n, F, generator=g)
+    w = torch.randn(F, generator=g)
+    node = torch.randperm(n, generator=g)[:k].sort().values
+    cluster = torch.randperm(k, generator=g)
+    gp = torch.randn(k, F, generator=g)
+    gv = torch.randn(k, generator=g)
+
+    def want(use_gp, use_gv):
+        xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        t = (xd @ wd) / wd.norm()
+        s = torch.tanh(t) if use_tanh else t
+        vals = s[node]
+        xp = torch.zeros(k, F, dtype=torch.float64).index_add(0, cluster, vals[:, None] * xd[node])
+        loss = 0
+        if use_gp:
+            loss = loss + (xp * gp.double()).sum()
+        if use_gv:
+            loss = loss + (vals * gv.double()).sum()
+        loss.backward()
+        return xd.grad, wd.grad, vals.detach().float()
+
+    xg, wg = x.to(dev), w.to(dev)
+    assert K_.topk_pool_bwd_fits(xg, wg) == (F % 4 == 0)
+    if F % 4:
+        return
+    for use_gp, use_gv in ((True, True), (True, False), (False, True)):
+        ex, ew_, vals = want(use_gp, use_gv)
+        for want_gx, want_gw in ((True, True), (True, False), (False, True)):
+            gx, gw = K_.topk_pool_bwd(xg, node.to(dev), cluster.to(dev), vals.to(dev), gp.to(dev) if use_gp else None,
+                                      gv.to(dev) if use_gv else None, wg, use_tanh, want_gx, want_gw)
+            assert (gx is not None) == want_gx and (gw is not None) == want_gw
+            if want_gx:
+                torch.testing.assert_close(gx.cpu().double(), ex, rtol=2e-5, atol=2e-5)
+                dropped = torch.ones(n, dtype=torch.bool)
+                dropped[node] = False
+                assert not gx.cpu()[dropped].any()
+            if want_gw:
+                torch.testing.assert_close(gw.cpu().double(), ew_, rtol=2e-4, atol=2e-4 * float(ew_.abs().max()))
+    # identity supernode order (cluster = None) and an empty selection
+    ex, ew_, vals = want(True, True)
+    gx, gw = K_.topk_pool_bwd(xg, node.to(dev), None, vals.to(dev), gp.to(dev)[cluster.to(dev)], gv.to(dev), wg,
+                              use_tanh, True, True)
+    torch.testing.assert_close(gx.cpu().double(), ex, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(gw.cpu().double(), ew_, rtol=2e-4, atol=2e-4 * float(ew_.abs().max()))
+    empty = torch.empty(0, dtype=torch.long, device=dev)
+    gx, gw = K_.topk_pool_bwd(xg, empty, None, torch.empty(0, device=dev), None, torch.empty(0, device=dev), wg, use_tanh,
+                              True, True)
+    assert not gx.any() and not gw.any()
+    again = K_.topk_pool_bwd(xg, node.to(dev), cluster.to(dev), vals.to(dev), gp.to(dev), gv.to(dev), wg, use_tanh, True, True)
+    once = K_.topk_pool_bwd(xg, node.to(dev), cluster.to(dev), vals.to(dev), gp.to(dev), gv.to(dev), wg, use_tanh, True, True)
+    assert torch.equal(again[0], once[0]) and torch.equal(again[1], once[1])  # fixed-order sums
+
+
+@pytest.mark.parametrize("shape", ["small_graphs", "one_large_graph", "no_batch"])
+@pytest.mark.parametrize("kw", [dict(ratio=0.5), dict(ratio=0.25, multiplier=1.5, nonlinearity="identity"), dict(ratio=7)])
+def test_topk_pooler_training_step_as_one_autograd_node(dev, shape, kw, monkeypatch):
+    """TopkPooling in training (poolers/topk.py:150-190): the forward is the inference call, one node carries the
+    gradient.  Outputs equal the operator-by-operator graph's (the score's tanh is the fused kernel's instead of ATen's:
+    a few ulp), gradients of x and the projection agree to fp32 accumulation-order tolerance -- including what reaches
+    the projection through ``so.s`` (Lift) -- and the backward is ONE native call."""
+    import tgp.poolers as P
+    import tgp.src as S
+    from tgp import kernels as K_
+    from tgp.poolers import get_pooler
+    if shape == "small_graphs":
+        x0, ei, ew, batch = _er_batch(120, 4, 60, 32, 31, dev)
+    else:
+        x0, ei, ew, batch = _er_batch(1, 2500, 2500, 32, 32, dev)
+        if shape == "no_batch":
+            batch = None
+    torch.manual_seed(9)
+    pooler = get_pooler("topk", in_channels=32, **kw).to(dev).train()
+    calls = []
+    real = K_.topk_pool_bwd
+    monkeypatch.setattr(K_, "topk_pool_bwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+
+    def step(x_needs_grad):
+        pooler.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(x_needs_grad)
+        out = pooler(x=x, adj=ei, edge_weight=ew, batch=batch)
+        lifted = pooler(x=out.x, so=out.so, lifting=True)
+        loss = out.x.square().sum() + (lifted * x0).sum() * 0.3 + (out.so.s.coalesce().values() ** 3).sum() * 0.1
+        loss.backward()
+        return (out.x.detach(), out.edge_index, out.edge_weight, out.batch, out.so.s.detach().coalesce(), x.grad,
+                pooler.selector.weight.grad.clone())
+
+    for x_needs_grad in (True, False):
+        calls.clear()
+        monkeypatch.setattr(P, "_FOLD_TRAINING", True)
+        monkeypatch.setattr(S, "_FOLD_TRAINING", True)
+        new = step(x_needs_grad)
+        assert calls == [1]
+        monkeypatch.setattr(P, "_FOLD_TRAINING", False)
+        monkeypatch.setattr(S, "_FOLD_TRAINING", False)
+        old = step(x_needs_grad)
+        assert calls == [1]
+        assert torch.equal(new[4].indices(), old[4].indices())
+        torch.testing.assert_close(new[4].values(), old[4].values(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(new[0], old[0], rtol=1e-5, atol=1e-6)
+        assert torch.equal(new[1], old[1]) and torch.equal(new[2], old[2])
+        assert (new[3] is None and old[3] is None) or torch.equal(new[3], old[3])
+        if x_needs_grad:
+            torch.testing.assert_close(new[5], old[5], rtol=1e-4, atol=1e-5 * max(1.0, float(old[5].abs().max())))
+        else:
+            assert new[5] is None and old[5] is None
+        torch.testing.assert_close(new[6], old[6], rtol=2e-4, atol=2e-5 * max(1.0, float(old[6].abs().max())))

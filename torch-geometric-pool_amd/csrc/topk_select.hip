@@ -481,6 +481,183 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   if (threadIdx.x == 0) out[f] = s_t[0];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Backward of TopK pooling's trained path (r5): score t = x w / ||w||, s = act(t) (select/topk_select.py:176-184), the
+// kept nodes' scores are the values of S, and x'[c_a] = s_a x[i_a] (reduce/base_reduce.py:141-155 with one assignment
+// per supernode).  From g' = dL/dx' [K,F] and ge = dL/d(values of S) [K] (either may be absent), per assignment a:
+//   gv = ge_a + <g'[c_a], x[i_a]>,  g_t = gv (1 - s_a^2) (tanh) or gv,  g~ = g_t / ||w||,  t_a = <x[i_a], w> / ||w||
+//   gx[i_a] = s_a g'[c_a] + g~ w          (rows of nodes that were not kept stay zero)
+//   gw      = sum_a g~ x[i_a] - (sum_a g~ t_a) w / ||w||
+// where the stock autograd graph runs ~18 launches over [N] and [N,F] temporaries.  Eight lanes share a row (16 bytes
+// each, CPL chunks per lane: F <= 32 CPL), two rows per lane group in flight; the gw sums stay in registers per lane,
+// are folded over the wave's eight groups by shuffles, over the four waves through LDS in wave order, and leave as
+// one partial per workgroup; topk_pool_bwd_final_kernel adds the partials in workgroup order (deterministic).
+struct TopkPoolBwdArgs {
+  const float* x; int64_t ldx;
+  const int64_t* node; const int64_t* cluster;  // [K] i_a, c_a (cluster NULL: c_a = a)
+  const float* values;                          // [K] s_a
+  const float* g_xpool;                         // [K,F] contiguous, or NULL
+  const float* g_values;                        // [K], or NULL
+  const float* w;                               // [F]
+  float* gx;                                    // [N,F] contiguous, zeroed; or NULL
+  float* part;                                  // [gridDim.x][F + 1]; or NULL
+  int64_t K; int F; int use_tanh;
+};
+constexpr int TPB_MAX_GRID = 256;
+
+template <int CPL>
+__global__ __launch_bounds__(256) void topk_pool_bwd_kernel(TopkPoolBwdArgs p) {
+  __shared__ float s_red[4][CPL * 32 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wv_id = tid >> 6, sub = lane & 7, grp = tid >> 3;
+  const int F = p.F, chunks = F >> 2;
+  float4 wr[CPL];
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int c = sub + 8 * j;
+    wr[j] = c < chunks ? *reinterpret_cast<const float4*>(p.w + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sq = fmaf(wr[j].x, wr[j].x, sq); sq = fmaf(wr[j].y, wr[j].y, sq);
+    sq = fmaf(wr[j].z, wr[j].z, sq); sq = fmaf(wr[j].w, wr[j].w, sq);
+  }
+#pragma unroll
+  for (int off = 4; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+  const float inv = 1.f / sqrtf(sq);
+  float4 acc[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float accc = 0.f;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 32;
+  for (int64_t a0 = static_cast<int64_t>(blockIdx.x) * 32 + grp; a0 < p.K; a0 += 2 * stride) {
+    // two assignments per lane group: every load of both is requested before the first sum
+    int64_t node[2], clu[2];
+    float sv[2], ge[2];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t a = a0 + u * stride;
+      ok[u] = a < p.K;
+      const int64_t aa = ok[u] ? a : a0;
+      node[u] = p.node[aa];
+      clu[u] = p.cluster ? p.cluster[aa] : aa;
+      sv[u] = p.values[aa];
+      ge[u] = p.g_values ? p.g_values[aa] : 0.f;
+    }
+    float4 xr[2][CPL], gp[2][CPL];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int c = sub + 8 * j;
+        const bool in = c < chunks;
+        xr[u][j] = in ? *reinterpret_cast<const float4*>(p.x + node[u] * p.ldx + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gp[u][j] = (in && p.g_xpool) ? *reinterpret_cast<const float4*>(p.g_xpool + clu[u] * F + 4 * c)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        d1 = fmaf(gp[u][j].x, xr[u][j].x, d1); d1 = fmaf(gp[u][j].y, xr[u][j].y, d1);
+        d1 = fmaf(gp[u][j].z, xr[u][j].z, d1); d1 = fmaf(gp[u][j].w, xr[u][j].w, d1);
+        d2 = fmaf(xr[u][j].x, wr[j].x, d2); d2 = fmaf(xr[u][j].y, wr[j].y, d2);
+        d2 = fmaf(xr[u][j].z, wr[j].z, d2); d2 = fmaf(xr[u][j].w, wr[j].w, d2);
+      }
+#pragma unroll
+      for (int off = 4; off > 0; off >>= 1) {
+        d1 += __shfl_xor(d1, off);
+        d2 += __shfl_xor(d2, off);
+      }
+      const float gv = ge[u] + d1;
+      const float gt = p.use_tanh ? gv * (1.f - sv[u] * sv[u]) : gv;
+      const float gtn = ok[u] ? gt * inv : 0.f;
+      const float t = d2 * inv;
+      accc = fmaf(gtn, t, accc);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        acc[j].x = fmaf(gtn, xr[u][j].x, acc[j].x); acc[j].y = fmaf(gtn, xr[u][j].y, acc[j].y);
+        acc[j].z = fmaf(gtn, xr[u][j].z, acc[j].z); acc[j].w = fmaf(gtn, xr[u][j].w, acc[j].w);
+        const int c = sub + 8 * j;
+        if (p.gx && ok[u] && c < chunks) {
+          float4 o;
+          o.x = fmaf(gp[u][j].x, sv[u], gtn * wr[j].x); o.y = fmaf(gp[u][j].y, sv[u], gtn * wr[j].y);
+          o.z = fmaf(gp[u][j].z, sv[u], gtn * wr[j].z); o.w = fmaf(gp[u][j].w, sv[u], gtn * wr[j].w);
+          *reinterpret_cast<float4*>(p.gx + node[u] * F + 4 * c) = o;
+        }
+      }
+    }
+  }
+  if (!p.part) return;
+  // the wave's eight lane groups (lane bits 3..5), then the four waves in wave order
+#pragma unroll
+  for (int off = 8; off < 64; off <<= 1) {
+    accc += __shfl_xor(accc, off);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      acc[j].x += __shfl_xor(acc[j].x, off); acc[j].y += __shfl_xor(acc[j].y, off);
+      acc[j].z += __shfl_xor(acc[j].z, off); acc[j].w += __shfl_xor(acc[j].w, off);
+    }
+  }
+  if (lane < 8) {
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      float* d = &s_red[wv_id][4 * (sub + 8 * j)];
+      d[0] = acc[j].x; d[1] = acc[j].y; d[2] = acc[j].z; d[3] = acc[j].w;
+    }
+    if (lane == 0) s_red[wv_id][CPL * 32] = accc;
+  }
+  __syncthreads();
+  float* out = p.part + static_cast<int64_t>(blockIdx.x) * (F + 1);
+  for (int f = tid; f <= F; f += 256) {
+    const int src = f < F ? f : CPL * 32;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t = __fadd_rn(t, s_red[q][src]);
+    out[f] = t;
+  }
+}
+
+// gw[f] = sum_b part[b][f] - (sum_b part[b][F]) w[f] / ||w||: wave q adds partials q, q + 8, ... (all of a wave's loads
+// requested together), the eight sums are added in wave order.  One workgroup; F <= 256.
+__global__ __launch_bounds__(512) void topk_pool_bwd_final_kernel(const float* __restrict__ part, int P, int F,
+                                                                  const float* __restrict__ w, float* __restrict__ gw) {
+  __shared__ float s_sum[8][320];
+  __shared__ float s_tot[320];
+  __shared__ float s_inv;
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, n_out = F + 1;
+  for (int o0 = 0; o0 < n_out; o0 += 64) {
+    const int o = o0 + lane;
+    float v[TPB_MAX_GRID / 8];
+#pragma unroll
+    for (int ji = 0; ji < TPB_MAX_GRID / 8; ++ji) {
+      const int j = q + 8 * ji;
+      const bool ok = o < n_out && j < P;
+      const float got = part[ok ? static_cast<long>(j) * n_out + o : 0];
+      v[ji] = ok ? got : 0.f;
+    }
+    float a = 0.f;
+#pragma unroll
+    for (int ji = 0; ji < TPB_MAX_GRID / 8; ++ji) a = __fadd_rn(a, v[ji]);
+    if (o < n_out) s_sum[q][o] = a;
+  }
+  if (q == 0) {
+    float sq = 0.f;
+    for (int f = lane; f < F; f += 64) sq = fmaf(w[f], w[f], sq);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    if (lane == 0) s_inv = 1.f / sqrtf(sq);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < n_out; o += 512) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r = __fadd_rn(r, s_sum[k][o]);
+    s_tot[o] = r;
+  }
+  __syncthreads();
+  for (int f = threadIdx.x; f < F; f += 512) gw[f] = s_tot[f] - s_tot[F] * s_inv * w[f];
+}
+
 template <int G, bool VEC>
 static void launch_row_dot(const float* x, int64_t n, int F, int64_t ldx, const float* w, float* out,
                            hipStream_t stream, int post = 0) {
@@ -816,6 +993,48 @@ extern "C" int tgp_weighted_colsum_f32(const float* x, int64_t N, int64_t F, int
   hipLaunchKernelGGL(colsum_final_kernel, dim3(static_cast<unsigned>(F)), dim3(256), 0, stream, partial, blocks,
                      static_cast<int>(F), out);
   return check_launch("tgp_weighted_colsum_f32");
+}
+
+extern "C" int tgp_topk_pool_bwd_fits(int64_t F) { return (F > 0 && F % 4 == 0 && F <= 256) ? 1 : 0; }
+
+extern "C" size_t tgp_topk_pool_bwd_workspace_bytes(int64_t F) {
+  return static_cast<size_t>(TPB_MAX_GRID) * static_cast<size_t>(F + 1) * sizeof(float) + 256;
+}
+
+// x [N,F] (row stride ldx, rows 16-byte aligned), node / cluster / values [K] = the assignments of the one-to-one S
+// (cluster NULL: 0..K-1), g_xpool [K,F] contiguous or NULL, g_values [K] or NULL, w [F].  gx [N,F] contiguous (NULL: not
+// wanted) is written entirely -- zero rows for nodes that were not kept; gw [F] (NULL: not wanted).
+extern "C" int tgp_topk_pool_bwd_f32(const float* x, int64_t N, int64_t F, int64_t ldx, const int64_t* node,
+                                     const int64_t* cluster, const float* values, int64_t K, const float* g_xpool,
+                                     const float* g_values, const float* w, int use_tanh, float* gx, float* gw,
+                                     void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(N >= 0 && K >= 0 && tgp_topk_pool_bwd_fits(F) && ldx >= F && ldx % 4 == 0, TGP_ERR_INVALID,
+              "tgp_topk_pool_bwd_f32: bad size (F must be a multiple of 4, at most 256)");
+  TGP_REQUIRE(w && (K == 0 || (x && node && values)), TGP_ERR_INVALID, "tgp_topk_pool_bwd_f32: null pointer");
+  TGP_REQUIRE((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(gx) |
+               reinterpret_cast<uintptr_t>(g_xpool)) % 16 == 0,
+              TGP_ERR_INVALID, "tgp_topk_pool_bwd_f32: x, w, gx and g_xpool must be 16-byte aligned");
+  TGP_REQUIRE(!gw || (ws && ws_bytes >= tgp_topk_pool_bwd_workspace_bytes(F)), TGP_ERR_WORKSPACE,
+              "tgp_topk_pool_bwd_f32: workspace too small");
+  if (gx && N > 0) (void)hipMemsetAsync(gx, 0, sizeof(float) * static_cast<size_t>(N) * static_cast<size_t>(F), stream);
+  if (K == 0) {
+    if (gw) (void)hipMemsetAsync(gw, 0, sizeof(float) * static_cast<size_t>(F), stream);
+    return check_launch("tgp_topk_pool_bwd_f32");
+  }
+  int64_t grid = cdiv(K, static_cast<int64_t>(64));  // two assignments per lane group and round
+  if (grid > TPB_MAX_GRID) grid = TPB_MAX_GRID;
+  TopkPoolBwdArgs a{x, ldx, node, cluster, values, g_xpool, g_values, w, gx, gw ? static_cast<float*>(ws) : nullptr,
+                    K, static_cast<int>(F), use_tanh};
+  const dim3 g(static_cast<unsigned>(grid)), b(256);
+  if (F <= 32) hipLaunchKernelGGL(topk_pool_bwd_kernel<1>, g, b, 0, stream, a);
+  else if (F <= 64) hipLaunchKernelGGL(topk_pool_bwd_kernel<2>, g, b, 0, stream, a);
+  else if (F <= 128) hipLaunchKernelGGL(topk_pool_bwd_kernel<4>, g, b, 0, stream, a);
+  else hipLaunchKernelGGL(topk_pool_bwd_kernel<8>, g, b, 0, stream, a);
+  if (gw)
+    hipLaunchKernelGGL(topk_pool_bwd_final_kernel, dim3(1), dim3(512), 0, stream, static_cast<const float*>(ws),
+                       static_cast<int>(grid), static_cast<int>(F), w, gw);
+  return check_launch("tgp_topk_pool_bwd_f32");
 }
 
 extern "C" int tgp_topk_plan(const int64_t* sizes, int64_t B, double ratio, int64_t* k, int64_t* koff, void* stream_) {

@@ -144,6 +144,10 @@ SIGNATURES = {
     "tgp_row_dot_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_weighted_colsum_workspace_bytes": (_c_sz, [_c_i64]),
     "tgp_weighted_colsum_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_sz, _c_p]),
+    "tgp_topk_pool_bwd_fits": (_c_int, [_c_i64]),
+    "tgp_topk_pool_bwd_workspace_bytes": (_c_sz, [_c_i64]),
+    "tgp_topk_pool_bwd_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_int,
+                                       _c_p, _c_p, _c_p, _c_sz, _c_p]),
     "tgp_pair_dot_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p]),
     "tgp_edge_dot_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_link_loss_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),

@@ -629,6 +629,38 @@ def topk_score(x: Tensor, w: Tensor, use_tanh: bool) -> Tensor:
     return _TopkScoreFn.apply(x, w, use_tanh) if _needs_grad(x, w) else K.topk_score(x, w, use_tanh)
 
 
+class _TopkPoolTrainFn(torch.autograd.Function):
+    """The ONE autograd node of TopK pooling's trained path (r5): x' = s_a x[i_a] and the kept scores s_a = act(x w /
+    ||w||)[i_a] (the values of S) as functions of x and the projection w.  The forward values come from the caller --
+    the inference kernels, run without a graph: fused score, selection, the one-launch Reduce + Connect where it
+    applies -- this node supplies the backward, one pass over the kept rows (kernels.topk_pool_bwd), where the
+    operator-by-operator graph (score, indexing, sparse Reduce) ran ~18 launches."""
+
+    @staticmethod
+    def forward(ctx, x, w, computed, node_index, cluster_index, use_tanh):
+        x_pool, values = computed
+        ctx.save_for_backward(x, w, node_index, cluster_index, values)
+        ctx.use_tanh = use_tanh
+        ctx.set_materialize_grads(False)
+        return x_pool, values
+
+    @staticmethod
+    def backward(ctx, g_xpool, g_values):
+        x, w, node_index, cluster_index, values = ctx.saved_tensors
+        want_gx, want_gw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if g_xpool is None and g_values is None:
+            return None, None, None, None, None, None
+        gx, gw = K.topk_pool_bwd(x, node_index, cluster_index, values, g_xpool, g_values, w, ctx.use_tanh, want_gx,
+                                 want_gw)
+        return gx, (gw.view_as(w) if gw is not None else None), None, None, None, None
+
+
+def topk_pool_train(x: Tensor, w: Tensor, x_pool: Tensor, values: Tensor, node_index: Tensor, cluster_index: Tensor,
+                    use_tanh: bool):
+    """``(x_pool, values)`` attached to the graph of ``x`` and ``w`` (see :class:`_TopkPoolTrainFn`)."""
+    return _TopkPoolTrainFn.apply(x, w, [x_pool, values], node_index, cluster_index, use_tanh)
+
+
 # ------------------------------------------------- A S and A^T S shared between Connect and the link loss
 class LossPair(tuple):
     """Two scalar auxiliary losses that left a fused Function as separate 0-dim outputs (MinCut: the batch means of the

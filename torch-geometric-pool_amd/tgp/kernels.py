@@ -1711,6 +1711,37 @@ def weighted_colsum(x: Tensor, g: Tensor) -> Tensor:
     return out
 
 
+def topk_pool_bwd_fits(x: Tensor, w: Tensor) -> bool:
+    """Shapes / layouts :func:`topk_pool_bwd` takes (the others keep the operator-by-operator backward)."""
+    return bool(x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and w.dtype == torch.float32
+                and w.numel() == x.size(1) and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+                and N.lib().tgp_topk_pool_bwd_fits(x.size(1)))
+
+
+def topk_pool_bwd(x: Tensor, node_index: Tensor, cluster_index: Optional[Tensor], values: Tensor,
+                  g_xpool: Optional[Tensor], g_values: Optional[Tensor], w: Tensor, use_tanh: bool,
+                  want_gx: bool, want_gw: bool):
+    """``(gx [N,F] or None, gw [F] or None)``: backward of TopK pooling's trained path -- score, kept values of S, gated
+    Reduce -- in one pass over the kept rows (``tgp_topk_pool_bwd_f32``; poolers/topk.py:150-190)."""
+    dev = N.require_device(x, node_index, cluster_index, values, g_xpool, g_values, w)
+    n, F = x.size(0), x.size(1)
+    k = node_index.numel()
+    ni = N.i64c(node_index)
+    ci = None if cluster_index is None else N.i64c(cluster_index)
+    vals = N.f32c(values.reshape(-1))
+    gp = None if g_xpool is None else N.f32c(g_xpool.reshape(k, F))
+    gv = None if g_values is None else N.f32c(g_values.reshape(-1))
+    wc = N.f32c(w.reshape(-1))
+    gx = torch.empty(n, F, dtype=torch.float32, device=dev) if want_gx else None
+    gw = torch.empty(F, dtype=torch.float32, device=dev) if want_gw else None
+    L = N.lib()
+    ws = N.workspace(L.tgp_topk_pool_bwd_workspace_bytes(F), dev) if want_gw else None
+    N.check(L.tgp_topk_pool_bwd_f32(x.data_ptr(), n, F, x.stride(0), N.ptr(ni), N.ptr(ci), N.ptr(vals), k, N.ptr(gp),
+                                    N.ptr(gv), N.ptr(wc), 1 if use_tanh else 0, N.ptr(gx), N.ptr(gw), N.ptr(ws),
+                                    ws.numel() if ws is not None else 0, N.stream_ptr(dev)), "tgp_topk_pool_bwd_f32")
+    return gx, gw
+
+
 def pair_dot(a: Tensor, ia: Tensor, b: Tensor, ib: Tensor) -> Tensor:
     """out[e] = <a[ia_e,:], b[ib_e,:]>: the assignment-weight gradient of the sparse Reduce / Lift."""
     dev = N.require_device(a, ia, b, ib)

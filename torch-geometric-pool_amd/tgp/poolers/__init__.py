@@ -14,6 +14,8 @@ from typing import Callable, List, Optional, Union
 import torch
 from torch import Tensor
 
+from .. import functions as Fn
+from .. import kernels as K
 from ..connect import DenseConnect, KronConnect, SparseConnect
 from ..lift import BaseLift
 from ..reduce import BaseReduce
@@ -67,6 +69,10 @@ class TopkPooling(SRCPooling):
                 attn: Optional[Tensor] = None, lifting: bool = False, **kwargs):
         if lifting:
             return self.lift(x_pool=x, so=so)
+        if self._one_node_training(x, edge_weight, attn):
+            out = self._forward_one_node(x, adj, edge_weight, batch)
+            if out is not None:
+                return out
         so = self.select(x=x if attn is None else attn, batch=batch)
         fused = self.reduce_connect(x, adj, edge_weight, so, batch)  # batches of small graphs, inference: ONE launch
         if fused is not None:
@@ -78,6 +84,42 @@ class TopkPooling(SRCPooling):
         if self.multiplier != 1:
             x_pool = self.multiplier * x_pool
         ei, ew = self.connect(so=so, edge_index=adj, edge_weight=edge_weight, batch_pooled=batch_pool)
+        return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so)
+
+    def _one_node_training(self, x, edge_weight, attn) -> bool:
+        """Training on device tensors in the selector's fused-score mode: the forward is the inference call and ONE
+        autograd node carries the gradient to x and the projection (Fn.topk_pool_train)."""
+        sel = self.selector
+        return bool(_FOLD_TRAINING and attn is None and not self.cached and torch.is_grad_enabled()
+                    and isinstance(x, Tensor) and x.is_cuda and x.dim() == 2 and x.size(0) > 0
+                    and type(sel) is TopkSelect and sel.weight is not None and sel.min_score is None
+                    and sel.ratio is not None and sel._fused_act is not None and type(self.reducer) is BaseReduce
+                    and (x.requires_grad or sel.weight.requires_grad)
+                    and not (edge_weight is not None and edge_weight.requires_grad)
+                    and not torch.cuda.is_current_stream_capturing()
+                    and K.topk_pool_bwd_fits(x, sel.weight))
+
+    def _forward_one_node(self, x, adj, edge_weight, batch):
+        sel = self.selector
+        with torch.no_grad():
+            so = self.select(x=x, batch=batch)
+            if not so.is_sparse or so.num_supernodes == 0 or so.s._nnz() != so.num_supernodes:
+                return None
+            fused = self.reduce_connect(x, adj, edge_weight, so, batch)
+            if fused is not None:
+                x_pool, batch_pool, ei, ew = fused
+            else:
+                x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch)
+        index = so.s.indices()
+        x_pool, values = Fn.topk_pool_train(x, sel.weight, x_pool, so.weight, index[0], index[1],
+                                            sel._fused_act == "tanh")
+        # S with the tracked values: what reads so.s downstream (Lift, a user's loss) reaches the projection through them
+        so.s = torch.sparse_coo_tensor(index, values, so.s.size(), is_coalesced=True)
+        so._hold_values(values)
+        if self.multiplier != 1:
+            x_pool = self.multiplier * x_pool
+        if fused is None:
+            ei, ew = self.connect(so=so, edge_index=adj, edge_weight=edge_weight, batch_pooled=batch_pool)
         return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so)
 
     def extra_repr_args(self) -> dict:
