@@ -26,8 +26,8 @@ Rank 0 prints ONE JSON line:
                    HBM), c4_ndp (NDP-shaped Reduce), topk_batch / graclus_batch (batched sparse Reduce + Connect; with
                    ranks: + variable-size RCCL all-gather) and their *_fresh twins (NEW tensor objects every step, as a
                    DataLoader's mini-batches: the per-tensor memos miss), e2e_diff_c2 / e2e_mincut_c3 (WHOLE pooler forwards on sparse
-                   inputs, eager and HIP-graph replayed, launches per forward), e2e_train_mincut_c3 (a whole MinCut
-                   training step, forward + backward, launches per step).  With N > 1 only the graph-sharded
+                   inputs, eager and HIP-graph replayed, launches per forward), e2e_train_mincut_c3 / e2e_train_topk_c3
+                   (a whole MinCut / TopK training step, forward + backward, launches per step).  With N > 1 only the graph-sharded
                    ones run; one giant graph (C4) does not shard.
 `--workload X` makes X the headline of the line instead; the driver's line is the default c2.
 """
@@ -470,43 +470,60 @@ class PoolerForward(Workload):
 
 
 class PoolerTrainStep(Workload):
-    """e2e_train_mincut_c3: a WHOLE training step of ``get_pooler('mincut')`` on the PROTEINS-shaped sparse batch --
-    forward (preprocessing, MLPSelect, fused Reduce + Connect + loss terms), a scalar loss over the pooled outputs and
-    both auxiliary losses, backward to the input features and the selector's parameters (the fused one-launch backward of
-    csrc/dense_graph_kernels.h for Reduce + Connect + losses).  Eager, and launches per step; what a user's step costs."""
+    """e2e_train_mincut_c3 / e2e_train_topk_c3: a WHOLE training step of ``get_pooler('mincut')`` / ``('topk')`` on the
+    PROTEINS-shaped sparse batch -- forward, a scalar loss over the pooled outputs (and MinCut's two auxiliary losses),
+    backward to the input features and the selector's parameters.  MinCut: MLPSelect + the fused one-launch Reduce +
+    Connect + loss terms and its one-launch backward (csrc/dense_graph_kernels.h); TopK: fused score, selection, the
+    one-launch Reduce + subgraph Connect, and ONE backward pass over the kept rows (tgp_topk_pool_bwd_f32).  Eager, and
+    launches per step; what a user's step costs."""
     shards = True
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, alias="mincut"):
         from tgp.poolers import get_pooler
         dev = ctx.dev
         torch.manual_seed(ctx.rank)
+        self.alias = alias
         self.B, self.N, self.K, self.F = 2048, 60, 20, 32
         self.x, self.ei, self.batch = sparse_batch(_proteins_sizes(ctx.rank), 4, self.F, dev, seed=ctx.rank)
         self.x.requires_grad_(True)
-        self.pooler = get_pooler("mincut", in_channels=self.F, k=self.K).to(dev).train()
+        kw = dict(k=self.K) if alias == "mincut" else dict(ratio=0.5)
+        self.pooler = get_pooler(alias, in_channels=self.F, **kw).to(dev).train()
         self.nodes = self.x.size(0)
-        self.name = ("get_pooler('mincut') whole TRAINING step (forward + backward) on sparse inputs: 2048 graphs "
-                     "n~U[20,60], K=20, F=32")
+        self.name = (f"get_pooler('{alias}') whole TRAINING step (forward + backward) on sparse inputs: 2048 graphs "
+                     "n~U[20,60], " + ("K=20, " if alias == "mincut" else "ratio 0.5, ") + "F=32")
         self.extra = {"nodes_counted": "real input nodes per step", "edges": int(self.ei.size(1)),
                       "step": "forward + loss + backward to x and the selector's parameters, eager"}
+
+    def _loss(self, out):
+        if self.alias == "mincut":
+            return out.x.sum() + out.edge_index.sum() + out.loss["cut_loss"] + out.loss["ortho_loss"]
+        return out.x.square().sum()
 
     def step(self):
         self.pooler.zero_grad(set_to_none=True)
         self.x.grad = None
-        out = self.pooler(x=self.x, adj=self.ei, batch=self.batch)
-        loss = out.x.sum() + out.edge_index.sum() + out.loss["cut_loss"] + out.loss["ortho_loss"]
+        loss = self._loss(self.pooler(x=self.x, adj=self.ei, batch=self.batch))
         loss.backward()
         return loss
 
     def rooflines(self, dev):
         B, N, K, F = self.B, self.N, self.K, self.F
         ms = event_time_ms(self.step, 50, dev)
-        # forward traffic (as e2e_mincut_c3) + backward: A, S, X read again, gS, gX and the dense gradients written / read
-        fwd = (self.ei.size(1) * 16.0 + self.nodes * F * 4.0 + 2 * 4.0 * B * N * N + 2 * 4.0 * B * N * (F + K)
-               + 4.0 * B * (2 * K * K + K * F))
-        bwd = 4.0 * B * N * N + 3 * 4.0 * B * N * (F + K) + 4.0 * B * (K * K + K * F) + 2 * self.nodes * F * 4.0
+        if self.alias == "mincut":
+            # forward traffic (as e2e_mincut_c3) + backward: A, S, X read again, gS, gX and the dense gradients written / read
+            fwd = (self.ei.size(1) * 16.0 + self.nodes * F * 4.0 + 2 * 4.0 * B * N * N + 2 * 4.0 * B * N * (F + K)
+                   + 4.0 * B * (2 * K * K + K * F))
+            bwd = 4.0 * B * N * N + 3 * 4.0 * B * N * (F + K) + 4.0 * B * (K * K + K * F) + 2 * self.nodes * F * 4.0
+        else:
+            # forward: x read by the score pass and (kept rows) by Reduce, x' written; edges read once (16 B), survivors
+            # written (16 B; a quarter at ratio 0.5); backward: g' and the kept rows of x read, gx [N,F] written
+            kept = 0.5 * self.nodes
+            fwd = self.nodes * F * 4.0 + 2 * kept * F * 4.0 + self.ei.size(1) * 16.0 * 1.25 + self.nodes * 16.0
+            bwd = 2 * kept * F * 4.0 + self.nodes * F * 4.0
         r = roof_hbm("whole training step (all kernels of forward + backward, eager)", fwd + bwd, ms)
         r["launches_per_step"] = count_kernels(self.step)
+        if self.alias != "mincut":
+            return r  # (the sparse selection waits for its counts on the host: not capturable)
         try:  # the same step with forward and backward replayed from HIP graphs (torch.cuda.make_graphed_callables)
             pooler, ei, batch = self.pooler, self.ei, self.batch
 
@@ -923,8 +940,8 @@ def make_workload(which, ctx, args):
         return GraclusC4(ctx, unsorted_edges=args.unsorted_edges)
     if which in ("e2e_diff_c2", "e2e_mincut_c3"):
         return PoolerForward(which, ctx)
-    if which == "e2e_train_mincut_c3":
-        return PoolerTrainStep(ctx)
+    if which in ("e2e_train_mincut_c3", "e2e_train_topk_c3"):
+        return PoolerTrainStep(ctx, alias="mincut" if which == "e2e_train_mincut_c3" else "topk")
     if which in ("topk_batch", "graclus_batch", "topk_batch_fresh", "graclus_batch_fresh"):
         return TopkBatch(ctx, force_collective=os.environ.get("TGP_BENCH_FORCE_DIST") == "1", unfused=args.unfused,
                          which=which)
@@ -1024,11 +1041,13 @@ def cpu_baseline(one_pass, nodes, sample, budget_s=10.0, min_passes=2):
 
 # ------------------------------------------------------------------------------------------------ main
 ALL = ["c2", "c2_f64", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect", "topk_batch", "graclus_batch",
-       "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3"]
+       "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3",
+       "e2e_train_topk_c3"]
 SECONDARY_DEFAULT = ["c5", "c2_f64", "topk1m", "topk_connect", "c4_graclus", "c4_ndp", "c3", "topk_batch", "graclus_batch",
-                     "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3"]
+                     "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3",
+                     "e2e_train_topk_c3"]
 SHARDED = ("c5", "c2_f64", "c3", "topk_batch", "graclus_batch", "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2",
-           "e2e_mincut_c3", "e2e_train_mincut_c3")
+           "e2e_mincut_c3", "e2e_train_mincut_c3", "e2e_train_topk_c3")
 
 
 def main():
