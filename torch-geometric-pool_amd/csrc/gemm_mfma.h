@@ -29,6 +29,9 @@ constexpr int BK = 32;
 #ifndef TGP_STORE_AT
 #define TGP_STORE_AT 3
 #endif
+#ifndef TGP_STEADY_LOOP
+#define TGP_STEADY_LOOP 1
+#endif
 #ifndef TGP_SPREAD
 #define TGP_SPREAD 0
 #endif
@@ -392,15 +395,22 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
   float* L0 = smem;
   float* L1 = smem + STAGE_FLOATS;
   auto kof = [&](int t) { return k_begin + t * BK; };
-  auto stage = [&](auto par_c, int t) {
+  // STEADY (r5, late): the stage as the middle of the k-loop runs it -- tile t + 1 is stored, tile t + 2 is loaded, and
+  // that tile is a full one -- with all three facts known at compile time.  The general form decides them per stage,
+  // and the waits for the staged registers then sit inside conditional blocks: on the path that skips a block the
+  // compiler must assume the loads into a register set are still pending when the next stage overwrites it, and it
+  // put an `s_waitcnt vmcnt(0)` in front of the B tile's load -- right behind the two A loads of the same stage, so
+  // every wave sat out a full memory round trip per k-step -- plus ~25 branches per step.
+  auto stage = [&](auto par_c, auto steady_c, int t) {
     constexpr int PAR = decltype(par_c)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
     const float* As = PAR ? L1 : L0;
     const float* Bs = As + A_TILE_FLOATS;
     float* An = PAR ? L0 : L1;
     float* Bn = An + A_TILE_FLOATS;
-    const bool do_store = t + 1 < nk, do_load = t + 2 < nk;
+    const bool do_store = STEADY || t + 1 < nk, do_load = STEADY || t + 2 < nk;
     const int k2 = kof(t + 2);
-    const bool tail = k2 + BK > k_end;
+    const bool tail = !STEADY && k2 + BK > k_end;
 #ifdef TGP_GEMM_STAMPS
     // phase clock of one k-step in the middle of the loop (wave 0 of every workgroup): slots 8.. hold the time at
     // step start, before / after the LDS stores, before / after the global loads, before / after the barrier
@@ -462,13 +472,26 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
   }
   __syncthreads();
   TGP_STAMP(1);
-  for (int t = 0; t < nk; t += 2) {
+  int t = 0;
+  using std::integral_constant;
+  if constexpr (ALIGNED && TGP_STEADY_LOOP) {
+    // pairs of stages whose loaded tiles (t + 2 and t + 3) exist and are full
+    for (; t + 3 < nk && kof(t + 3) + BK <= k_end; t += 2) {
+#ifdef TGP_GEMM_STAMPS
+      if (t == (nk / 2 & ~1)) TGP_STAMP(6);
+      if (t == ((3 * nk) / 4 & ~1)) TGP_STAMP(7);
+#endif
+      stage(integral_constant<int, 0>{}, integral_constant<bool, true>{}, t);
+      stage(integral_constant<int, 1>{}, integral_constant<bool, true>{}, t + 1);
+    }
+  }
+  for (; t < nk; t += 2) {
 #ifdef TGP_GEMM_STAMPS
     if (t == (nk / 2 & ~1)) TGP_STAMP(6);
     if (t == ((3 * nk) / 4 & ~1)) TGP_STAMP(7);
 #endif
-    stage(std::integral_constant<int, 0>{}, t);
-    if (t + 1 < nk) stage(std::integral_constant<int, 1>{}, t + 1);
+    stage(integral_constant<int, 0>{}, integral_constant<bool, false>{}, t);
+    if (t + 1 < nk) stage(integral_constant<int, 1>{}, integral_constant<bool, false>{}, t + 1);
   }
   TGP_STAMP(2);
 
