@@ -33,7 +33,7 @@ constexpr int BK = 32;
 #define TGP_STEADY_LOOP 1
 #endif
 #ifndef TGP_SPREAD
-#define TGP_SPREAD 0
+#define TGP_SPREAD 1
 #endif
 #ifndef TGP_VEC_EPILOGUE
 #define TGP_VEC_EPILOGUE 1
