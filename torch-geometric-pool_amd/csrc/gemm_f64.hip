@@ -147,9 +147,9 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_kernel(Gemm64Args g) {
     d.y = __hiloint2double(static_cast<int>(v.w), static_cast<int>(v.z));
     return d;
   };
-  auto load_tiles = [&](int k0) {
+  auto load_tiles = [&](int k0, auto steady_c) {
     if constexpr (BUF) {
-      const bool tail = k0 + DBK > k_end;
+      const bool tail = !decltype(steady_c)::value && k0 + DBK > k_end;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int soff_a = A_KMAJOR ? k0 * static_cast<int>(lda) * 8 : k0 * 8;
@@ -207,15 +207,11 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_kernel(Gemm64Args g) {
   const int b_off = lk * D_KMAJOR_LD + wn * 32 + l15;
 
   if (nk > 0) {
-    load_tiles(k_begin);
+    load_tiles(k_begin, std::false_type{});
     store_tiles(smem, smem + D_STAGE);
   }
   __syncthreads();
-  for (int t = 0; t < nk; ++t) {
-    const double* As = smem + (t & 1) * 2 * D_STAGE;
-    const double* Bs = As + D_STAGE;
-    const bool more = t + 1 < nk;
-    if (more) load_tiles(k_begin + (t + 1) * DBK);  // in flight while this tile is multiplied
+  auto multiply = [&](const double* As, const double* Bs) {
 #pragma unroll
     for (int kk = 0; kk < DBK / 4; ++kk) {
       const double a0 = As[a_off + kk * a_kstep], a1 = As[a_off + kk * a_kstep + a_sub];
@@ -225,6 +221,26 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_kernel(Gemm64Args g) {
       acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
+  };
+  int t = 0;
+  if constexpr (BUF) {
+    // the middle of the k-loop (r5, late; as in gemm_mfma.h): the next tile exists and is a full one, known at compile
+    // time -- no branch in the loop, and no wait that the compiler must place for the path that skips a block (the
+    // general form below had an `s_waitcnt vmcnt(0)` between the loads of one k-tile)
+    for (; t + 1 < nk && k_begin + (t + 2) * DBK <= k_end; ++t) {
+      const double* As = smem + (t & 1) * 2 * D_STAGE;
+      load_tiles(k_begin + (t + 1) * DBK, std::true_type{});
+      multiply(As, As + D_STAGE);
+      double* An = smem + ((t + 1) & 1) * 2 * D_STAGE;
+      store_tiles(An, An + D_STAGE);
+      __syncthreads();
+    }
+  }
+  for (; t < nk; ++t) {
+    const double* As = smem + (t & 1) * 2 * D_STAGE;
+    const bool more = t + 1 < nk;
+    if (more) load_tiles(k_begin + (t + 1) * DBK, std::false_type{});  // in flight while this tile is multiplied
+    multiply(As, As + D_STAGE);
     if (more) {
       double* An = smem + ((t + 1) & 1) * 2 * D_STAGE;
       store_tiles(An, An + D_STAGE);
