@@ -615,6 +615,23 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
             cc[r][q] = ok ? __builtin_nontemporal_load(col + src[r] + j) : 0;
             wv[r][q] = (ok && has_w) ? __builtin_nontemporal_load(w + src[r] + j) : WT(0);
           }
+        // The table look-ups of ALL the lane's edges are requested before the first one is consumed (r5, late):
+        // unconditional loads through a clamped index (entry 0 for a slot without an edge or a column out of range).
+        // Written as `inr ? table[c] : 0` inside the `j < len` block below, as r2-r5 had it, every look-up compiled to
+        // branch + load + `s_waitcnt vmcnt(0)` + LDS store: the 2 GR look-ups of a lane went out one at a time.
+        // (Measured at C4, same box: 0.2336 ms per Connect call both ways -- with eight waves per SIMD the other
+        //  waves' look-ups cover a lane's serial ones; the kernel is bound by what the misses move, not by their
+        //  latency: profiles/r05_tcc_coalesce.md.  Kept: it is the form the comment above the loop describes.)
+        uint32_t tv[GR][2];
+#pragma unroll
+        for (int r = 0; r < GR; ++r)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint32_t j = static_cast<uint32_t>(l + 8 * q);
+            const bool inr = static_cast<uint64_t>(static_cast<int64_t>(cc[r][q])) < static_cast<uint64_t>(n_nodes);
+            const int64_t idx = (j < len[r] && inr) ? static_cast<int64_t>(cc[r][q]) : 0;
+            tv[r][q] = static_cast<uint32_t>(table[idx]);
+          }
 #pragma unroll
         for (int r = 0; r < GR; ++r)
 #pragma unroll
@@ -655,7 +672,7 @@ __global__ __launch_bounds__(256) void cr_gather_sort_kernel(
                 continue;
               }
 #endif
-              s_key[dst[r] + j] = inr ? static_cast<uint32_t>(table[cc[r][q]]) : 0u;
+              s_key[dst[r] + j] = inr ? tv[r][q] : 0u;
               s_val[dst[r] + j] = wv[r][q];
             }
           }
@@ -1356,6 +1373,16 @@ __global__ __launch_bounds__(256, 6) void cr_fused_kernel(
             cc[r][q] = ok ? __builtin_nontemporal_load(col + src[r] + j) : 0;
             wv[r][q] = (ok && has_w) ? __builtin_nontemporal_load(w + src[r] + j) : 0.f;
           }
+        uint32_t tv[GR][2];  // all table look-ups of the lane in flight together (see cr_gather_sort_kernel)
+#pragma unroll
+        for (int r = 0; r < GR; ++r)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const uint32_t j = static_cast<uint32_t>(l + 8 * q);
+            const bool inr = static_cast<uint64_t>(static_cast<int64_t>(cc[r][q])) < static_cast<uint64_t>(n_nodes);
+            const int64_t idx = (j < len[r] && inr) ? static_cast<int64_t>(cc[r][q]) : 0;
+            tv[r][q] = static_cast<uint32_t>(table[idx]);
+          }
 #pragma unroll
         for (int r = 0; r < GR; ++r)
 #pragma unroll
@@ -1364,7 +1391,7 @@ __global__ __launch_bounds__(256, 6) void cr_fused_kernel(
             if (j < len[r]) {
               const bool inr = static_cast<uint64_t>(static_cast<int64_t>(cc[r][q])) < static_cast<uint64_t>(n_nodes);
               if (!inr) atomicOr(bad, 4);
-              s_key[dst[r] + j] = inr ? static_cast<uint32_t>(table[cc[r][q]]) : 0u;
+              s_key[dst[r] + j] = inr ? tv[r][q] : 0u;
               s_val[dst[r] + j] = wv[r][q];
             }
           }
