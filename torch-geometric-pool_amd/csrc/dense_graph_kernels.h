@@ -249,6 +249,11 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
       const float bz = lm < K ? (p.sel_b ? p.sel_b[lm] : 0.f) : -__builtin_inff();
       const unsigned char* mk = p.sel_mask ? p.sel_mask + static_cast<long>(b) * N : nullptr;
       float* So = p.s_out ? p.s_out + static_cast<long>(b) * N * K : nullptr;
+      // the graph's mask bytes as ONE load (lane = node) and a ballot (r5, late): tested as `mk[node] != 0` inside the
+      // loop below, each of the 32 tests compiled to a byte load + `s_waitcnt vmcnt(0)` in front of the store of S --
+      // 32 dependent round trips per graph
+      unsigned long long mbits = ~0ull;
+      if (mk) mbits = __ballot(mk[lane < N ? lane : 0] != 0);
 #pragma unroll
       for (int T = 0; T < 2; ++T) {
         f32x16 z;
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int node = 32 * T + rho(r) + 4 * lk;
-          const bool on = node < nb && (!mk || mk[node < N ? node : 0] != 0);
+          const bool on = node < nb && ((mbits >> node) & 1ull) != 0;
           const float sv = on ? ex[r] * __builtin_amdgcn_rcpf(sm[r]) : 0.f;  // (1 ulp reciprocal: far inside 1e-5)
           sr[16 * T + r] = sv;
           if (So && node < N && lm < K) So[node * K + lm] = sv;
