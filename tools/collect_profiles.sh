@@ -37,6 +37,8 @@ python3 tools/e2e_fresh_batch.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $out/e2e
 python3 tools/bench_poolers_e2e.py > $out/e2e_poolers.txt 2>&1
 python3 tools/bench_ndp_large.py > $out/ndp_large.txt 2>&1
 python3 tools/e2e_train_step.py mincut_c3 diff_c3 mincut_c2 diff_c2 topk_c3 graclus_c3 --top 8 2>&1 | grep -v -i "warn" > $out/e2e_train_steps.txt
+(echo "== TGP_FOLD_TRAINING=0 (operator-by-operator graph, staged Reduce + Connect: r4 form)"; TGP_FOLD_TRAINING=0 python3 tools/e2e_train_step.py topk_c3 graclus_c3 --sequence 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-180; echo; echo "== default (r5, late)"; python3 tools/e2e_train_step.py topk_c3 graclus_c3 --sequence 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-180) > $out/sparse_train_steps.txt
+python3 tools/bench_select_fold.py 2>&1 | grep select > $out/select_fold.txt
 python3 tools/ndp_small_ab.py 2>&1 | grep -v -i "warn" > $out/ndp_small.txt
 bash tools/ndp_large_ab.sh 2>&1 | grep -v -i "warn\|amdgpu.ids" > $out/ndp_mid_ab.txt
 python3 tools/bench_reference_harness.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $out/reference_harness.txt
