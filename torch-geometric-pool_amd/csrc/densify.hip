@@ -218,15 +218,33 @@ __global__ __launch_bounds__(256) void batch_facts_sorted_kernel(const int64_t* 
   __shared__ long long s_carry;
   __shared__ bool s_last;
   unsigned int flags = 0;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) {
-    const int64_t b = batch[i];
-    const int64_t prev = i > 0 ? batch[i - 1] : -1;
-    if (b < 0 || b > n) { flags |= 2u; continue; }
-    if (b < prev) { flags |= 1u; continue; }
-    if (prev < 0 && i > 0) continue;              // (the predecessor is out of range: its own thread reports it)
-    if (b - prev > 64) { flags |= 4u; continue; } // a long run of ids without nodes: left to the general route
-    for (int64_t g = prev + 1; g <= b; ++g) ptr[g] = i;   // first node of graph b; empty ranges for skipped ids
-    if (i == n - 1) ptr[b + 1] = n;
+  // eight elements per thread and round, all sixteen loads (the element and its predecessor) requested before the first
+  // comparison (r5, late: one element per round was load -> wait -> compare -> store, eight dependent round trips per
+  // thread for the usual 2048 elements of a workgroup -- most of this kernel's 12-14 us)
+  constexpr int UN = 8;
+  for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * 256 * UN + threadIdx.x; i0 < n;
+       i0 += static_cast<int64_t>(gridDim.x) * 256 * UN) {
+    int64_t bv[UN], pv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t i = i0 + u * 256;
+      const int64_t ic = i < n ? i : n - 1;      // (clamped: unconditional loads)
+      bv[u] = batch[ic];
+      pv[u] = batch[ic > 0 ? ic - 1 : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t i = i0 + u * 256;
+      if (i >= n) continue;
+      const int64_t b = bv[u];
+      const int64_t prev = i > 0 ? pv[u] : -1;
+      if (b < 0 || b > n) { flags |= 2u; continue; }
+      if (b < prev) { flags |= 1u; continue; }
+      if (prev < 0 && i > 0) continue;              // (the predecessor is out of range: its own thread reports it)
+      if (b - prev > 64) { flags |= 4u; continue; } // a long run of ids without nodes: left to the general route
+      for (int64_t g = prev + 1; g <= b; ++g) ptr[g] = i;   // first node of graph b; empty ranges for skipped ids
+      if (i == n - 1) ptr[b + 1] = n;
+    }
   }
   if (flags) atomicOr(bad, flags);
   // hand-off to the workgroup that takes the last ticket (MI355X_MICROARCH.md, "Valid forms"): every storing wave drains
@@ -257,6 +275,9 @@ __global__ __launch_bounds__(256) void batch_facts_sorted_kernel(const int64_t* 
       long long pv[IT + 1];
 #pragma unroll
       for (int q = 0; q <= IT; ++q) pv[q] = g0 + q <= B ? ptr[g0 + q] : 0;   // one round trip for the thread's graphs
+      // (all of them have landed before the first store below: vmcnt also counts stores not yet acknowledged, and with
+      //  the stores in conditional blocks every later wait for one of these loads would be a wait for the stores too)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
       long long kv[IT], mine = 0;
 #pragma unroll
       for (int q = 0; q < IT; ++q) {
