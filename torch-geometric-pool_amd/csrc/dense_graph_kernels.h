@@ -1053,15 +1053,28 @@ __global__ __launch_bounds__(256, MINW) void dense_pool_medium_kernel(MediumArgs
         }
       }
     };
+    // NPV is a multiple of 32 = 4 * UNROLL node rows: every round consumes both register sets.  All rounds but the last
+    // request the next round's first set UNCONDITIONALLY (r5, late): with `if (more) request(...)` in the loop, as r1-r5
+    // had it, the wait in front of a set's MFMAs could only be written as vmcnt(0) -- it also waited for the set that
+    // had just been requested, so the two sets were never in flight together (the k-loop finding of gemm_mfma.h).
     auto k_loop = [&](auto is_a_c) {
+      if (NPV <= 0) return;
+      // (the scheduling barriers keep a set's loads IN FRONT of the other set's MFMAs: left alone, the scheduler sinks
+      //  each load to the MFMA that frees its register, i.e. one set of registers and a quarter of the time in flight)
       request(0, 0);
-      for (int k0 = 0; k0 < NPV; k0 += 4 * UNROLL) {  // NPV is a multiple of 32 = 4 * UNROLL node rows
-        if (k0 + 2 * UNROLL < NPV) request(1, k0 + 2 * UNROLL);
+      int k0 = 0;
+      for (; k0 + 4 * UNROLL < NPV; k0 += 4 * UNROLL) {
+        request(1, k0 + 2 * UNROLL);
+        __builtin_amdgcn_sched_barrier(0);
         consume(is_a_c, 0, k0);
-        if (k0 + 2 * UNROLL >= NPV) break;
-        if (k0 + 4 * UNROLL < NPV) request(0, k0 + 4 * UNROLL);
+        request(0, k0 + 4 * UNROLL);
+        __builtin_amdgcn_sched_barrier(0);
         consume(is_a_c, 1, k0 + 2 * UNROLL);
       }
+      request(1, k0 + 2 * UNROLL);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(is_a_c, 0, k0);
+      consume(is_a_c, 1, k0 + 2 * UNROLL);
     };
     if (is_a) k_loop(std::true_type{});   // wave-uniform branch: one operand order per loop body
     else k_loop(std::false_type{});
