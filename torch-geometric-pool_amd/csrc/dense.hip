@@ -262,12 +262,23 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
                    static_cast<int>(K), static_cast<int>(F), flags, eps, want_x ? x_pool : nullptr,
                    want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr, static_cast<int>(npad), graph_sizes};
       static const int minw = getenv("TGP_MEDIUM_MINW") ? atoi(getenv("TGP_MEDIUM_MINW")) : 2;
-      if (K <= 32)
-        hipLaunchKernelGGL(dense_pool_medium_kernel<1>, dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, q);
-      else if (minw == 3)
-        hipLaunchKernelGGL((dense_pool_medium_kernel<2, 3>), dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, q);
-      else
-        hipLaunchKernelGGL((dense_pool_medium_kernel<2, 2>), dim3(static_cast<unsigned>(B)), dim3(256), lds, stream, q);
+      // eight waves per graph (r5, late) when there are at least eight strips to deal out and the S tile (> 80 KB) leaves a
+      // single workgroup per CU (four waves would be one wave per SIMD): N = 300 / K = 64 / F = 128 151.8 -> 139.8 us.
+      // Where two four-wave workgroups fit, they balance the strips better (N = 200 / K = 50: 132 us against 193 us
+      // with eight waves).  TGP_MEDIUM_WAVES = 4 / 8 forces one form
+      static const int force_waves = getenv("TGP_MEDIUM_WAVES") ? atoi(getenv("TGP_MEDIUM_WAVES")) : 0;
+      const int64_t strips = (want_a ? (N + 31) / 32 : 0) + (want_x ? (F + 31) / 32 : 0);
+      const bool eight = force_waves ? force_waves == 8 : (strips >= 8 && lds > 80 * 1024);
+      const dim3 g(static_cast<unsigned>(B));
+      if (K <= 32) {
+        if (eight) hipLaunchKernelGGL((dense_pool_medium_kernel<1, 4, 8>), g, dim3(512), lds, stream, q);
+        else hipLaunchKernelGGL((dense_pool_medium_kernel<1>), g, dim3(256), lds, stream, q);
+      } else if (minw == 3) {
+        hipLaunchKernelGGL((dense_pool_medium_kernel<2, 3>), g, dim3(256), lds, stream, q);
+      } else {
+        if (eight) hipLaunchKernelGGL((dense_pool_medium_kernel<2, 2, 8>), g, dim3(512), lds, stream, q);
+        else hipLaunchKernelGGL((dense_pool_medium_kernel<2, 2>), g, dim3(256), lds, stream, q);
+      }
       return check_launch("tgp_dense_pool_f32(medium)");
     }
   }

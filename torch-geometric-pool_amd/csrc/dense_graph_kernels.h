@@ -957,8 +957,12 @@ static size_t medium_lds_bytes(int64_t npad) {
 // VGPRs to scratch inside the strip loop (verdict r4 item 9) -- so MT = 2 is compiled for 2 (256 registers, no scratch);
 // S [N][64] + the K x K result in LDS leave room for two or three workgroups per CU anyway.  <2, 3> stays for A/B
 // (TGP_MEDIUM_MINW=3).
-template <int MT, int MINW = (MT == 1 ? 4 : 2)>
-__global__ __launch_bounds__(256, MINW) void dense_pool_medium_kernel(MediumArgs p) {
+// WAVES (r5, late): 4, or 8 for graphs with at least eight strips whose S tile leaves one workgroup per CU -- with four
+// waves that is ONE wave per SIMD and nothing but the wave's own double buffering hides a load; eight waves put two on
+// every SIMD and halve the strips per wave.
+template <int MT, int MINW = (MT == 1 ? 4 : 2), int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, MINW) void dense_pool_medium_kernel(MediumArgs p) {
+  constexpr int NT = 64 * WAVES;  // threads
   constexpr int KP = 32 * MT;          // padded K
   constexpr int UNROLL = 8;            // k-pairs whose operands are requested together (two such sets in flight;
                                        // 16 measured no faster for K <= 32 and spills for K <= 64)
@@ -986,17 +990,17 @@ __global__ __launch_bounds__(256, MINW) void dense_pool_medium_kernel(MediumArgs
     // NP * KP / 256 times (measured: 22 us of a 92 us workgroup at N = 200, K = 50)
     const float* Sb = p.S + static_cast<long>(b) * N * K;
     constexpr int UB = 8;
-    for (int base = 0; base < NPV * KP; base += 256 * UB) {
+    for (int base = 0; base < NPV * KP; base += NT * UB) {
       float v[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int e = base + u * 256 + tid;
+        const int e = base + u * NT + tid;
         const int r = e / KP, c = e - r * KP;
         v[u] = (r < NV && c < K) ? Sb[r * K + c] : 0.f;  // r < NV also covers e beyond the tile (NPV >= NV)
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        const int e = base + u * 256 + tid;
+        const int e = base + u * NT + tid;
         if (e < NPV * KP) Ss[e] = v[u];
       }
     }
@@ -1017,7 +1021,7 @@ __global__ __launch_bounds__(256, MINW) void dense_pool_medium_kernel(MediumArgs
   constexpr int OOB = static_cast<int>(0x80000000u);
   // Strips are dealt round-robin, starting at a wave that rotates with the graph index: wave w always runs on SIMD
   // w, so a fixed start would pile every graph's extra strip onto the same SIMD of the CU.
-  for (int job = (w + 4 - (b & 3)) & 3; job < nt_a + nt_x; job += 4) {
+  for (int job = (w + WAVES - (b & (WAVES - 1))) & (WAVES - 1); job < nt_a + nt_x; job += WAVES) {
     const bool is_a = job < nt_a;
     const int n0 = (is_a ? job : job - nt_a) * 32;
     const int ld = is_a ? N : F;
@@ -1111,7 +1115,7 @@ __global__ __launch_bounds__(256, MINW) void dense_pool_medium_kernel(MediumArgs
 
   // ---- A' = sum of the four partial products, in wave order ---------------------------------
   const bool at = p.flags & TGP_ADJ_TRANSPOSED;
-  for (int turn = 0; turn < 4; ++turn) {
+  for (int turn = 0; turn < WAVES; ++turn) {
     if (w == turn) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -1132,7 +1136,7 @@ __global__ __launch_bounds__(256, MINW) void dense_pool_medium_kernel(MediumArgs
   // element loops run over the padded [K][KP] index space: row / column come from shifts, not divisions
   const long obase = static_cast<long>(b) * K * K;
   if (p.adj_raw) {
-    for (int e = tid; e < K * KP; e += 256) {
+    for (int e = tid; e < K * KP; e += NT) {
       const int i = e / KP, j = e % KP;
       if (j < K) p.adj_raw[obase + i * K + j] = Rs[i * (KP + 1) + j];
     }
@@ -1151,7 +1155,7 @@ __global__ __launch_bounds__(256, MINW) void dense_pool_medium_kernel(MediumArgs
       ds[tid] = sqrtf(fmaxf(t, p.eps));
     }
     __syncthreads();
-    for (int e = tid; e < K * KP; e += 256) {
+    for (int e = tid; e < K * KP; e += NT) {
       const int i = e / KP, j = e % KP;
       if (j < K) {
         const float first = rows ? ds[j] : ds[i], second = rows ? ds[i] : ds[j];
@@ -1163,7 +1167,7 @@ __global__ __launch_bounds__(256, MINW) void dense_pool_medium_kernel(MediumArgs
   float scale = 1.f;
   if (p.flags & TGP_EDGE_WEIGHT_NORM) {
     float m = 0.f;
-    for (int e = tid; e < K * KP; e += 256) {
+    for (int e = tid; e < K * KP; e += NT) {
       const int i = e / KP, j = e % KP;
       if (j < K) m = fmaxf(m, fabsf(Rs[i * (KP + 1) + j]));
     }
@@ -1172,10 +1176,12 @@ __global__ __launch_bounds__(256, MINW) void dense_pool_medium_kernel(MediumArgs
     __syncthreads();
     if (lane == 0) ds[w] = m;
     __syncthreads();
-    scale = fmaxf(fmaxf(ds[0], ds[1]), fmaxf(ds[2], ds[3]));
+    scale = 0.f;
+#pragma unroll
+    for (int q = 0; q < WAVES; ++q) scale = fmaxf(scale, ds[q]);
     if (scale == 0.f) scale = 1.f;
   }
-  for (int e = tid; e < K * KP; e += 256) {
+  for (int e = tid; e < K * KP; e += NT) {
     const int i = e / KP, j = e % KP;
     if (j < K) {
       const float v = Rs[i * (KP + 1) + j];
