@@ -35,6 +35,9 @@ constexpr int BK = 32;
 #ifndef TGP_SPREAD
 #define TGP_SPREAD 1
 #endif
+#ifndef TGP_MIRROR_ROWS
+#define TGP_MIRROR_ROWS 1
+#endif
 #ifndef TGP_VEC_EPILOGUE
 #define TGP_VEC_EPILOGUE 1
 #endif
@@ -332,6 +335,11 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
   float rres[MODE == 1 ? NT : 1][16];
   [[maybe_unused]] float rmir[MODE == 1 ? NT : 1][16];  // the mirror tile's residual, transposed into the C/D layout
   [[maybe_unused]] const bool mirror = MODE == 1 && g.symmetric && m0 < n0;
+  // the mirror tile read row-wise + an LDS transposition (interior, aligned tiles; one [32][33] patch per wave)
+  constexpr bool MIRROR_PATCH_FITS = (THREADS / 64) * (32 * 33) <= 2 * STAGE_FLOATS;
+  [[maybe_unused]] const bool mirror_rows = mirror && MIRROR_PATCH_FITS && TGP_MIRROR_ROWS && (g.ldr & 3) == 0 &&
+                                            (reinterpret_cast<uintptr_t>(g.resid + static_cast<long>(batch) * g.sR) & 15) == 0 &&
+                                            m0 + BM <= M && n0 + BN <= Nc && n0 + BN <= M && m0 + BM <= Nc;
   if constexpr (MODE == 1) {
     const float* __restrict__ Rm = g.resid + static_cast<long>(batch) * g.sR;
 #pragma unroll
@@ -343,7 +351,23 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
         rres[j][r] = (row < M && col < Nc) ? Rm[static_cast<long>(row) * g.ldr + col] : 0.f;
       }
     }
-    if (mirror) {  // (workgroup-uniform)  resid[col][row]: a lane's four consecutive rows are 16 contiguous bytes
+    if (mirror && mirror_rows) {
+      // r5, late: the mirror tile is read the way it lies in memory -- 8 lanes per 128-byte row segment, a wave's 32 x 32
+      // block in four passes -- and turned into the C/D layout through the wave's LDS patch in the epilogue.  Read
+      // directly in that layout (below: lane = row of the residual, 16 bytes each) every lane touches another row:
+      // 64 separate sectors per instruction for the half of the residual that goes this way.  (Measured at C2, same
+      // box: 0.0757 -> 0.0745 ms per link-loss call -- the four passes of a lane cover its sector after all, the L2
+      // absorbed the rest; the kernel is bound by its 4352 short-lived workgroups, not by these loads.)
+      const float* __restrict__ base = Rm + static_cast<long>(n0 + wn * (BN / WN) + (lane >> 3)) * g.ldr + m0 + wm * 32 +
+                                       4 * (lane & 7);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(base + static_cast<long>(j * 32 + 8 * q) * g.ldr);
+          rmir[j][4 * q] = v.x; rmir[j][4 * q + 1] = v.y; rmir[j][4 * q + 2] = v.z; rmir[j][4 * q + 3] = v.w;
+        }
+    } else if (mirror) {  // (workgroup-uniform)  resid[col][row]: a lane's four consecutive rows are 16 contiguous bytes
       const bool v4 = (g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(Rm) & 15) == 0;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -506,7 +530,24 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
         const float d = rres[j][r] - acc[j][r];
         sq = fmaf(d, d, sq);
       }
-    if (mirror) {
+    if (mirror && mirror_rows) {  // (workgroup-uniform; the k-loop's last barrier has passed: the LDS is free)
+      float* patch = smem + wave * (32 * 33);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // patch[a][b] = resid[n0' + a][m0' + b]
+          float* d = patch + ((lane >> 3) + 8 * q) * 33 + 4 * (lane & 7);
+          d[0] = rmir[j][4 * q]; d[1] = rmir[j][4 * q + 1]; d[2] = rmir[j][4 * q + 2]; d[3] = rmir[j][4 * q + 3];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = patch[lm * 33 + (r & 3) + 8 * (r >> 2) + 4 * lk] - acc[j][r];
+          sq = fmaf(d, d, sq);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else if (mirror) {
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
