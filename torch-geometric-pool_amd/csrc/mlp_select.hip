@@ -117,29 +117,38 @@ __global__ __launch_bounds__(64 * MS_WAVES, KT > 6 ? 1 : 2) void mlp_select_mfma
         __syncthreads();
       }
       const int width = fc < Fpad - k0 ? fc : Fpad - k0;
-      for (int c = 0; c < width; c += 32) {
-        // X operand: k = k0 + c + 16 h + j
-        float xb[16];
+      // X operand of chunk c: k = k0 + c + 16 h + j.  Two register sets: the next chunk's four 16-byte loads are requested
+      // before this chunk's MFMAs, unconditionally in all rounds but the last, and pinned in front of them (r5, late:
+      // left to itself the scheduler sank every load to the MFMAs that use it -- load, `s_waitcnt vmcnt(0)`, 16 MFMAs,
+      // four times per chunk: eight dependent round trips per tile at F = 64).
+      // unconditional loads from clamped addresses, zeroed afterwards (guards would put every load in a branch of
+      // its own): with F % 4 == 0 a 16-byte vector is wholly inside or wholly outside the row
+      auto request = [&](float4 (&dst)[4], int c) {
         const int kb = k0 + c + 16 * h;
-        // unconditional loads from clamped addresses, zeroed afterwards (guards would put every load in a branch of
-        // its own): with F % 4 == 0 a 16-byte vector is wholly inside or wholly outside the row
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int k = kb + 4 * q;
-          float4 v;
           if (VEC) {
-            v = *reinterpret_cast<const float4*>(xrow + (k < F ? k : F - 4));
+            dst[q] = *reinterpret_cast<const float4*>(xrow + (k < F ? k : F - 4));
           } else {
-            v.x = xrow[k < F ? k : F - 1];
-            v.y = xrow[k + 1 < F ? k + 1 : F - 1];
-            v.z = xrow[k + 2 < F ? k + 2 : F - 1];
-            v.w = xrow[k + 3 < F ? k + 3 : F - 1];
+            dst[q].x = xrow[k < F ? k : F - 1];
+            dst[q].y = xrow[k + 1 < F ? k + 1 : F - 1];
+            dst[q].z = xrow[k + 2 < F ? k + 2 : F - 1];
+            dst[q].w = xrow[k + 3 < F ? k + 3 : F - 1];
           }
+        }
+      };
+      auto consume = [&](const float4 (&src)[4], int c) {
+        float xb[16];
+        const int kb = k0 + c + 16 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = kb + 4 * q;
           const bool in = row_ok && k < F;
-          xb[4 * q] = in ? v.x : 0.f;
-          xb[4 * q + 1] = (VEC ? in : row_ok && k + 1 < F) ? v.y : 0.f;
-          xb[4 * q + 2] = (VEC ? in : row_ok && k + 2 < F) ? v.z : 0.f;
-          xb[4 * q + 3] = (VEC ? in : row_ok && k + 3 < F) ? v.w : 0.f;
+          xb[4 * q] = in ? src[q].x : 0.f;
+          xb[4 * q + 1] = (VEC ? in : row_ok && k + 1 < F) ? src[q].y : 0.f;
+          xb[4 * q + 2] = (VEC ? in : row_ok && k + 2 < F) ? src[q].z : 0.f;
+          xb[4 * q + 3] = (VEC ? in : row_ok && k + 3 < F) ? src[q].w : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
@@ -152,6 +161,33 @@ __global__ __launch_bounds__(64 * MS_WAVES, KT > 6 ? 1 : 2) void mlp_select_mfma
           }
 #pragma unroll
           for (int j = 0; j < 16; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], xb[j], acc[t], 0, 0, 0);
+        }
+      };
+      float4 xa[4];
+      [[maybe_unused]] float4 xn[4];
+      if constexpr (KT > 4) {  // (the second register set does not fit next to more than four accumulator tiles)
+        for (int c = 0; c < width; c += 32) {
+          request(xa, c);
+          consume(xa, c);
+        }
+      } else if (width > 0) {
+        request(xa, 0);
+        int c = 0;
+        for (; c + 64 < width; c += 64) {
+          request(xn, c + 32);
+          __builtin_amdgcn_sched_barrier(0);
+          consume(xa, c);
+          request(xa, c + 64);
+          __builtin_amdgcn_sched_barrier(0);
+          consume(xn, c + 32);
+        }
+        if (c + 32 < width) {
+          request(xn, c + 32);
+          __builtin_amdgcn_sched_barrier(0);
+          consume(xa, c);
+          consume(xn, c + 32);
+        } else {
+          consume(xa, c);
         }
       }
     }
