@@ -112,7 +112,9 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_kernel(Gemm64Args g) {
   const int nk = k_end > k_begin ? (k_end - k_begin + DBK - 1) / DBK : 0;
 
   // global -> register staging: two double2 per operand per thread and k-tile
-  double2 ra[2], rb[2];
+  // (two sets, r5 late: tile t + 2 is loaded into one during stage t while tile t + 1 is stored from the other -- a
+  //  load has a whole stage and a half to land, where the single set gave it one stage's MFMAs)
+  double2 ra2[2][2], rb2[2][2];
   constexpr int OOB = static_cast<int>(0x80000000u);
   [[maybe_unused]] __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
   [[maybe_unused]] int voff_a[2], voff_b[2], kloc_a[2], kloc_b[2];
@@ -147,7 +149,9 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_kernel(Gemm64Args g) {
     d.y = __hiloint2double(static_cast<int>(v.w), static_cast<int>(v.z));
     return d;
   };
-  auto load_tiles = [&](int k0, auto steady_c) {
+  auto load_tiles = [&](auto set_c, int k0, auto steady_c) {
+    double2 (&ra)[2] = ra2[decltype(set_c)::value];
+    double2 (&rb)[2] = rb2[decltype(set_c)::value];
     if constexpr (BUF) {
       const bool tail = !decltype(steady_c)::value && k0 + DBK > k_end;
 #pragma unroll
@@ -180,7 +184,9 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_kernel(Gemm64Args g) {
       }
     }
   };
-  auto store_tiles = [&](double* As, double* Bs) {
+  auto store_tiles = [&](auto set_c, double* As, double* Bs) {
+    const double2 (&ra)[2] = ra2[decltype(set_c)::value];
+    const double2 (&rb)[2] = rb2[decltype(set_c)::value];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + i * 256;
@@ -206,9 +212,12 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_kernel(Gemm64Args g) {
   constexpr int a_kstep = A_KMAJOR ? 4 * D_KMAJOR_LD : 4;     // next MFMA k-group
   const int b_off = lk * D_KMAJOR_LD + wn * 32 + l15;
 
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
   if (nk > 0) {
-    load_tiles(k_begin, std::false_type{});
-    store_tiles(smem, smem + D_STAGE);
+    load_tiles(S0{}, k_begin, std::false_type{});
+    if (nk > 1) load_tiles(S1{}, k_begin + DBK, std::false_type{});
+    store_tiles(S0{}, smem, smem + D_STAGE);
   }
   __syncthreads();
   auto multiply = [&](const double* As, const double* Bs) {
@@ -222,30 +231,31 @@ __global__ __launch_bounds__(256) void gemm_f64_mfma_kernel(Gemm64Args g) {
       acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
   };
-  int t = 0;
-  if constexpr (BUF) {
-    // the middle of the k-loop (r5, late; as in gemm_mfma.h): the next tile exists and is a full one, known at compile
-    // time -- no branch in the loop, and no wait that the compiler must place for the path that skips a block (the
-    // general form below had an `s_waitcnt vmcnt(0)` between the loads of one k-tile)
-    for (; t + 1 < nk && k_begin + (t + 2) * DBK <= k_end; ++t) {
-      const double* As = smem + (t & 1) * 2 * D_STAGE;
-      load_tiles(k_begin + (t + 1) * DBK, std::true_type{});
-      multiply(As, As + D_STAGE);
-      double* An = smem + ((t + 1) & 1) * 2 * D_STAGE;
-      store_tiles(An, An + D_STAGE);
-      __syncthreads();
-    }
-  }
-  for (; t < nk; ++t) {
-    const double* As = smem + (t & 1) * 2 * D_STAGE;
-    const bool more = t + 1 < nk;
-    if (more) load_tiles(k_begin + (t + 1) * DBK, std::false_type{});  // in flight while this tile is multiplied
+  // stage t (parity PAR = t & 1): tile t is in LDS buffer PAR; tile t + 2 is loaded into register set PAR, tile t + 1
+  // (in set 1 - PAR since the previous stage) is stored to buffer 1 - PAR behind the MFMAs.  STEADY: both exist and the
+  // loaded one is full, known at compile time (no branch, no wait the compiler must place for a skipped block).
+  auto stage = [&](auto par_c, auto steady_c, int t) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
+    const double* As = smem + PAR * 2 * D_STAGE;
+    if (STEADY || t + 2 < nk) load_tiles(par_c, k_begin + (t + 2) * DBK, steady_c);
     multiply(As, As + D_STAGE);
-    if (more) {
-      double* An = smem + ((t + 1) & 1) * 2 * D_STAGE;
-      store_tiles(An, An + D_STAGE);
+    if (STEADY || t + 1 < nk) {
+      double* An = smem + (1 - PAR) * 2 * D_STAGE;
+      store_tiles(std::integral_constant<int, 1 - PAR>{}, An, An + D_STAGE);
     }
     __syncthreads();
+  };
+  int t = 0;
+  if constexpr (BUF) {
+    for (; t + 3 < nk && k_begin + (t + 4) * DBK <= k_end; t += 2) {
+      stage(S0{}, std::true_type{}, t);
+      stage(S1{}, std::true_type{}, t + 1);
+    }
+  }
+  for (; t < nk; t += 2) {
+    stage(S0{}, std::false_type{}, t);
+    if (t + 1 < nk) stage(S1{}, std::false_type{}, t + 1);
   }
 
   // epilogue: D[(lane >> 4) + 4 r][lane & 15] of every 16 x 16 tile
