@@ -155,6 +155,10 @@ def event_time_ms(fn, reps, dev):
     avgs = []
     for _ in range(groups):
         start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # a ~0.5 ms spin kernel in front of the bracket lets the host run ahead of the GPU: for a 20 us kernel behind a
+        # 25 us Python wrapper the bracket otherwise measures the wrapper (c3 read 26 us against 21.4 us in the kernel
+        # trace and in the 200-step windows on a slow host)
+        torch.cuda._sleep(1_000_000)
         start.record(stream)
         for _ in range(per):
             fn()
