@@ -1173,34 +1173,3 @@ def test_topk_pooler_training_step_as_one_autograd_node(dev, shape, kw, monkeypa
         else:
             assert new[5] is None and old[5] is None
         torch.testing.assert_close(new[6], old[6], rtol=2e-4, atol=2e-5 * max(1.0, float(old[6].abs().max())))
-
-
-@pytest.mark.parametrize("weighted", [True, False])
-@pytest.mark.parametrize("with_batch", [True, False])
-def test_sparse_mincut_loss_segment_sums_native_vs_index_add(dev, weighted, with_batch, monkeypatch):
-    """utils/losses.py:126-215 (sparse_mincut_loss): the per-row and per-graph sums on the CSR SpMM + the per-graph product
-    (fixed order) against the index_add_ form, value and gradients (S, edge weights), and against the float64 oracle."""
-    import tgp.utils.losses as LS
-    x, ei, ew, batch = _er_batch(37 if with_batch else 1, 5 if with_batch else 300, 70 if with_batch else 300, 8, 41, dev)
-    n, k = x.size(0), 6
-    torch.manual_seed(2)
-    s0 = torch.softmax(torch.randn(n, k, device=dev), -1)
-    b = batch if with_batch else None
-
-    def run(native):
-        monkeypatch.setattr(LS, "_SEGMENT_SUMS_NATIVE", native)
-        s = s0.clone().requires_grad_(True)
-        w = ew.clone().requires_grad_(True) if weighted else None
-        loss = LS.sparse_mincut_loss(ei, s, w, b, "mean")
-        loss.backward()
-        return loss.detach(), s.grad, (w.grad if weighted else None)
-
-    new, old = run(True), run(False)
-    torch.testing.assert_close(new[0], old[0], rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(new[1], old[1], rtol=1e-4, atol=1e-6)
-    if weighted:
-        torch.testing.assert_close(new[2], old[2], rtol=1e-4, atol=1e-6)
-    import tgp_oracle as O
-    want = _oracle64(O.sparse_mincut_loss, ei.cpu(), s0.cpu().double(), ew.cpu().double() if weighted else None,
-                     b.cpu() if with_batch else None)
-    torch.testing.assert_close(new[0].cpu().double(), want.double(), rtol=1e-5, atol=1e-6)

@@ -9,7 +9,6 @@ backward.  The unbatched (sparse-adjacency) variants are differentiable torch op
 from __future__ import annotations
 
 import math
-import os
 from typing import Optional
 
 import torch
@@ -18,11 +17,7 @@ from torch import Tensor
 from .. import eps
 from .. import functions as Fn
 from .. import kernels as K
-from .ops import batch_info, check_and_filter_edge_weights, graph_ptr, max_graph_size, num_graphs_of
-
-
-# A/B switch (read once): 0 keeps index_add_ for the segment sums of the sparse losses
-_SEGMENT_SUMS_NATIVE = os.environ.get("TGP_SEGMENT_SUMS_NATIVE", "1") != "0"
+from .ops import check_and_filter_edge_weights, graph_ptr, max_graph_size, num_graphs_of
 
 
 def _reduce(loss: Tensor, how: str) -> Tensor:
@@ -216,27 +211,10 @@ def sparse_mincut_loss(edge_index: Tensor, S: Tensor, edge_weight: Optional[Tens
     n = S.size(0)
     w = _edge_weights(edge_index, edge_weight, S)
     nb = num_graphs_of(batch)
-    contrib = w * Fn.edge_dot(S, edge_index)
-    if _SEGMENT_SUMS_NATIVE and S.is_cuda and S.dtype == torch.float32 and w.dtype == torch.float32 and n > 0 \
-            and edge_index.size(1) > 0 and (batch is None or batch_info(batch).is_sorted) \
-            and K._rows_sorted(edge_index, edge_index[0]):
-        # the three segment sums (weights per row, both terms per graph) on the CSR SpMM and the per-graph product the
-        # unbatched Connect already uses, in a fixed order -- `index_add_` into 32 or 2048 graph slots is an atomic per
-        # element on a handful of addresses: 58-125 us of this loss at the C2 / C3 shapes (r5, late)
-        ones = S.new_ones(n, 1)
-        deg = Fn.spmm_sorted(edge_index, w, n, ones).view(-1)
-        per_row = Fn.spmm_sorted(edge_index, contrib, n, ones).view(-1)
-        if batch is None:
-            ptr, longest = torch.tensor([0, n], dtype=torch.long, device=S.device), n
-        else:
-            _, ptr = graph_ptr(batch, nb)
-            longest = max_graph_size(batch)
-        both = Fn.segment_gemm_tn(ones, torch.stack([deg * (S * S).sum(-1), per_row], dim=1), ptr, longest)  # [B,1,2]
-        den, num = both[:, 0, 0], both[:, 0, 1]
-        return _reduce(-(num / (den + eps)), batch_reduction)
     batch = _batch_or_zeros(batch, n, S.device)
     deg = _seg_sum(w, edge_index[0], n)
     den = _seg_sum(deg * (S * S).sum(-1), batch, nb)
+    contrib = w * Fn.edge_dot(S, edge_index)
     num = _seg_sum(contrib, batch[edge_index[0]], nb)
     return _reduce(-(num / (den + eps)), batch_reduction)
 
