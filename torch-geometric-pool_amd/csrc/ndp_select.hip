@@ -511,12 +511,31 @@ __global__ __launch_bounds__(64) void ndp_partition_wave_kernel(const int32_t* _
   }
   __builtin_amdgcn_wave_barrier();
   const int r_beg = e_beg - e_lo, r_end = e_end - e_lo;
+  // the lane's first NDP_RC matrix entries stay in registers for the whole iteration (r5, late): they never change, and
+  // read from LDS every step the mat-vec was a chain of two dependent LDS reads per entry (value + column, then the
+  // vector element); now the vector elements of those entries are requested together.  Same products added in the same
+  // order (missing entries add 0 x xs[lane]).
+  constexpr int NDP_RC = 8;
+  double rc_val[NDP_RC];
+  int rc_col[NDP_RC];
+#pragma unroll
+  for (int q = 0; q < NDP_RC; ++q) {
+    const int e = r_beg + q;
+    const bool ok = cached && on && e < r_end;
+    rc_val[q] = ok ? mval[ok ? e : 0] : 0.0;
+    rc_col[q] = ok ? static_cast<int>(mcol[ok ? e : 0]) : lane;
+  }
   auto matvec = [&](double src) -> double {  // (Ls src)[lane]
     xs[lane] = src;
     __builtin_amdgcn_wave_barrier();
     double acc = 0.0;
     if (cached) {
-      for (int e = r_beg; e < r_end; ++e) acc += mval[e] * xs[mcol[e]];
+      double t[NDP_RC];
+#pragma unroll
+      for (int q = 0; q < NDP_RC; ++q) t[q] = xs[rc_col[q]];
+#pragma unroll
+      for (int q = 0; q < NDP_RC; ++q) acc += rc_val[q] * t[q];
+      for (int e = r_beg + NDP_RC; e < r_end; ++e) acc += mval[e] * xs[mcol[e]];
     } else {
       for (int e = e_beg; e < e_end; ++e) {
         const int64_t c = col[e];
