@@ -1173,3 +1173,41 @@ def test_topk_pooler_training_step_as_one_autograd_node(dev, shape, kw, monkeypa
         else:
             assert new[5] is None and old[5] is None
         torch.testing.assert_close(new[6], old[6], rtol=2e-4, atol=2e-5 * max(1.0, float(old[6].abs().max())))
+
+
+# ------------------------------------------------------------------- medium graphs, eight waves per graph (r5, late)
+@pytest.mark.parametrize("B,N,K,F", [(9, 300, 64, 128), (10, 333, 40, 19), (9, 700, 32, 40), (12, 512, 64, 64)])
+@pytest.mark.parametrize("waves", ["auto", "4", "8"])
+def test_medium_graph_kernel_four_and_eight_waves_vs_oracle(dev, B, N, K, F, waves):
+    """dense_pool_medium_kernel<MT, MINW, WAVES>: shapes whose S tile leaves one workgroup per CU take eight waves per
+    graph (TGP_MEDIUM_WAVES forces either form, read once per process: a child process per setting); every form against
+    the oracle (base_reduce.py:158-161, dense_conn.py:111-122, utils/ops.py:282-335) with ragged graph sizes."""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, torch
+sys.path.insert(0, {os.path.join(ROOT, 'torch-geometric-pool_amd')!r}); sys.path.insert(0, {os.path.join(ROOT, 'oracle')!r})
+import tgp_oracle as O
+from tgp import kernels as K
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed({B * N + K})
+B, N, Kc, F = {B}, {N}, {K}, {F}
+sizes = torch.randint(N // 2, N + 1, (B,), generator=g); sizes[0] = N
+mask = torch.arange(N)[None, :] < sizes[:, None]
+A = (torch.rand(B, N, N, generator=g) < 0.02).float() * mask[:, :, None] * mask[:, None, :]
+X = torch.randn(B, N, F, generator=g) * mask[..., None]
+S = torch.softmax(torch.randn(B, N, Kc, generator=g), -1) * mask[..., None]
+flags = K.dense_flags(True, True, False, False)
+xp, raw, pooled = K.dense_pool(S.to(dev), A.to(dev), X.to(dev), flags=flags, want_raw=True, graph_sizes=sizes.to(dev))[:3]
+raw_ref = O.dense_connect(S, A)
+torch.testing.assert_close(xp.cpu(), O.reduce_dense(S, X), rtol=2e-4, atol=2e-4)
+torch.testing.assert_close(raw.cpu(), raw_ref, rtol=2e-4, atol=2e-4)
+torch.testing.assert_close(pooled.cpu(), O.postprocess_dense(raw_ref, True, True, False, False), rtol=2e-4, atol=2e-4)
+print('ok')
+"""
+    env = dict(os.environ)
+    env.pop("TGP_MEDIUM_WAVES", None)
+    if waves != "auto":
+        env["TGP_MEDIUM_WAVES"] = waves
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
