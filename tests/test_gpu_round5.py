@@ -1211,3 +1211,35 @@ print('ok')
         env["TGP_MEDIUM_WAVES"] = waves
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_topk_pool_backward_is_linear_in_the_upstream_gradients_at_full_size(dev):
+    """tgp_topk_pool_bwd_f32 at BASELINE configs[3]'s size (N = 1M, F = 128, ratio 0.5): the gradients are linear in
+    (dL/dx', dL/d values) -- bwd(a g1 + b g2) = a bwd(g1) + b bwd(g2) to fp32 rounding --, rows of dropped nodes are
+    exactly zero, two runs agree bit for bit."""
+    from tgp import kernels as K_
+    g = torch.Generator(device=dev).manual_seed(11)
+    n, F = 1_000_000, 128
+    x = torch.randn(n, F, device=dev, generator=g)
+    w = torch.randn(F, device=dev, generator=g)
+    keep = torch.rand(n, device=dev, generator=g) < 0.5
+    node = keep.nonzero().view(-1)
+    k = node.numel()
+    vals = torch.tanh((x[node] @ w) / w.norm())
+    g1, g2 = torch.randn(k, F, device=dev, generator=g), torch.randn(k, F, device=dev, generator=g)
+    v1, v2 = torch.randn(k, device=dev, generator=g), torch.randn(k, device=dev, generator=g)
+
+    def bwd(gp, gv):
+        return K_.topk_pool_bwd(x, node, None, vals, gp, gv, w, True, True, True)
+
+    a, b = 0.75, -1.5
+    x1, w1 = bwd(g1, v1)
+    x2, w2 = bwd(g2, v2)
+    xc, wc = bwd(a * g1 + b * g2, a * v1 + b * v2)
+    ref_x, ref_w = a * x1 + b * x2, a * w1 + b * w2
+    scale_x = float(ref_x.abs().max())
+    assert float((xc - ref_x).abs().max()) <= 2e-5 * scale_x
+    assert float((wc - ref_w).abs().max()) <= 2e-4 * float(ref_w.abs().max())
+    assert not xc[~keep].any()
+    again_x, again_w = bwd(g1, v1)
+    assert torch.equal(again_x, x1) and torch.equal(again_w, w1)
