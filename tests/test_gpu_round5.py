@@ -1115,6 +1115,14 @@ def test_topk_pool_backward_kernel_vs_autograd_in_double(dev, F, use_tanh):
     gx, gw = K_.topk_pool_bwd(xg, empty, None, torch.empty(0, device=dev), None, torch.empty(0, device=dev), wg, use_tanh,
                               True, True)
     assert not gx.any() and not gw.any()
+    # an upstream gradient and a projection that sit at odd offsets of larger buffers (4-byte aligned only)
+    big = torch.empty(k * F + 1, device=dev)
+    big[1:] = gp.to(dev).reshape(-1)
+    wbig = torch.empty(F + 1, device=dev)
+    wbig[1:] = wg
+    odd = K_.topk_pool_bwd(xg, node.to(dev), cluster.to(dev), vals.to(dev), big[1:].view(k, F), gv.to(dev), wbig[1:], use_tanh,
+                           True, True)
+    torch.testing.assert_close(odd[0].cpu().double(), ex, rtol=2e-5, atol=2e-5)
     again = K_.topk_pool_bwd(xg, node.to(dev), cluster.to(dev), vals.to(dev), gp.to(dev), gv.to(dev), wg, use_tanh, True, True)
     once = K_.topk_pool_bwd(xg, node.to(dev), cluster.to(dev), vals.to(dev), gp.to(dev), gv.to(dev), wg, use_tanh, True, True)
     assert torch.equal(again[0], once[0]) and torch.equal(again[1], once[1])  # fixed-order sums

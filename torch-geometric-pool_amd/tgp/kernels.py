@@ -1732,6 +1732,12 @@ def topk_pool_bwd(x: Tensor, node_index: Tensor, cluster_index: Optional[Tensor]
     gp = None if g_xpool is None else N.f32c(g_xpool.reshape(k, F))
     gv = None if g_values is None else N.f32c(g_values.reshape(-1))
     wc = N.f32c(w.reshape(-1))
+    # 16-byte loads: an upstream gradient or a parameter that is a view at an odd offset of a larger buffer (a flattened
+    # parameter bucket, a slice of a concatenation) is copied once
+    if gp is not None and gp.data_ptr() % 16:
+        gp = gp.clone()
+    if wc.data_ptr() % 16:
+        wc = wc.clone()
     gx = torch.empty(n, F, dtype=torch.float32, device=dev) if want_gx else None
     gw = torch.empty(F, dtype=torch.float32, device=dev) if want_gw else None
     L = N.lib()
