@@ -11,7 +11,9 @@ K = 128, F = 64 (fp32, the precision the reference computes in).  Select and the
 excluded; inputs are resident in HBM when the timed region starts.  With N > 1 every rank pools its
 own B graphs (weak scaling, seed = rank) and the pooled outputs are all-gathered over RCCL inside the timed region.
 
-Rank 0 prints ONE JSON line:
+Rank 0 prints one JSON line per secondary workload as it is measured (short keys, no prose) and, as the LAST stdout
+line, the headline (< 4 KB: contract fields, windows, roofline, whole_step, cpu_baseline); everything, prose included,
+also goes to gpurun_out/bench_detail.json ($TGP_BENCH_DETAIL).  The headline line:
   contract fields  `value` / `ms_per_step` come from ONE window of EXACTLY --steps steps after --warmup warm-up steps
                    (+ "settle_steps" more untimed steps: ~50 ms of the same workload, so that the window does not sit
                    on the device's clock ramp), bracketed by barrier + device synchronise on both sides, MAX over ranks;
@@ -20,7 +22,7 @@ Rank 0 prints ONE JSON line:
                    events on the launch stream;
   "cpu_baseline"   the CPU oracle (port of the reference algorithm) on a bounded sample of the same workload on this
                    box's host cores (rank 0, N = 1 only);
-  "secondary"      the other north_star workloads, each with its own median-window timing and roofline:
+Secondary lines ({"secondary": name, ...}): the other north_star workloads, each with its own median-window timing and roofline:
                    c5 (N=8192,K=512,F=128: fp32 MFMA), topk1m (TopK scatter-reduce: HBM), topk_connect (TopK subgraph
                    Connect: HBM), c4_graclus (Reduce + coalesce Connect, both rooflines: HBM), c3 (MinCut small graphs:
                    HBM), c4_ndp (NDP-shaped Reduce), topk_batch / graclus_batch (batched sparse Reduce + Connect; with
@@ -1043,6 +1045,86 @@ def cpu_baseline(one_pass, nodes, sample, budget_s=10.0, min_passes=2):
             "host": {"cpu_count": os.cpu_count(), "model": _host_model()}}
 
 
+# ------------------------------------------------------------------------------------------------ output
+HEADLINE_LIMIT = 4096  # bytes: the driver keeps a bounded tail of stdout and parses its LAST line (round 5's one
+#                        23.5 KB line carrying 15 secondaries was cut and read as "parsed: null")
+HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "settle_steps", "ms_per_step",
+                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "windows", "roofline",
+                 "whole_step", "cpu_baseline", "detail")
+_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "flops_per_launch",
+              "bytes_per_launch", "avg_launch_ms", "whole_step_flops")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "mean_value", "one_thread", "host")
+_PROSE = ("step", "nodes_counted", "tensors", "output_layout", "from_select", "rebuilt_every_step", "select_output",
+          "gather", "bytes_counted", "peak_source", "quote")  # sentences: BASELINE.md / DESIGN.md describe each workload
+
+
+def _clip(text, n):
+    return text if len(text) <= n else text[: n - 1] + "~"
+
+
+def _slim(obj, keys=None):
+    """Numbers, flags and short labels of `obj`; prose fields (`_PROSE`) stay in the detail file."""
+    out = {}
+    for k, v in obj.items():
+        if k in _PROSE or (keys is not None and k not in keys):
+            continue
+        out[k] = _clip(v, 120) if isinstance(v, str) else v
+    return out
+
+
+def headline_text(line):
+    """The LAST stdout line: the contract fields + windows, roofline, whole_step, cpu_baseline; < HEADLINE_LIMIT."""
+    out = {k: line[k] for k in HEADLINE_KEYS if k in line}
+    out["config"] = _slim(line["config"])
+    out["roofline"] = _slim(line["roofline"], _ROOF_KEYS)
+    if "cpu_baseline" in line:
+        out["cpu_baseline"] = _slim(line["cpu_baseline"], _CPU_KEYS)
+    text = json.dumps(out)
+    if len(text) >= HEADLINE_LIMIT:  # never expected; rather lose the optional blocks than the parse
+        for k in ("windows", "whole_step", "detail"):
+            out.pop(k, None)
+        text = json.dumps(out)
+    return text
+
+
+def secondary_text(sec):
+    """One earlier stdout line per secondary workload: short keys, no prose."""
+    if "error" in sec:
+        return json.dumps({"secondary": sec["workload"], "error": _clip(sec["error"], 300)})
+    out = {"secondary": sec["workload"], "ms_per_step": sec["ms_per_step"], "value": sec["value"], "unit": sec["unit"]}
+    if "dtype" in sec:
+        out["dtype"] = sec["dtype"]
+    out["windows"] = sec["windows"]
+    out["roofline"] = _slim(sec["roofline"])
+    if "roofline_other" in sec:
+        out["roofline_other"] = [_slim(r) for r in sec["roofline_other"]]
+    if "whole_step" in sec:
+        out["whole_step"] = sec["whole_step"]
+    if sec.get("config"):
+        out["config"] = _slim(sec["config"])
+    if "cpu_baseline" in sec:
+        out["cpu_baseline"] = _slim(sec["cpu_baseline"], ("value", "unit", "cores", "kind", "one_thread"))
+    return json.dumps(out)
+
+
+def output_lines(line, secondary):
+    """stdout of rank 0: one line per secondary workload, then the headline as the last line."""
+    return [secondary_text(s) for s in secondary] + [headline_text(line)]
+
+
+def write_detail(line, secondary):
+    """Everything (prose included) as one JSON document beside the run's log: $TGP_BENCH_DETAIL, else
+    gpurun_out/bench_detail.json under the repository; returns the path written, or None."""
+    path = os.environ.get("TGP_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(dict(line, secondary=secondary), fh, indent=1)
+        return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError:
+        return None
+
+
 # ------------------------------------------------------------------------------------------------ main
 ALL = ["c2", "c2_f64", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect", "topk_batch", "graclus_batch",
        "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3",
@@ -1158,6 +1240,8 @@ def main():
         except Exception as exc:  # a failing secondary must not lose the headline; it is reported, not hidden
             secondary.append({"workload": s, "error": f"{type(exc).__name__}: {exc}"})
             torch.cuda.empty_cache()
+        if rank == 0:
+            print(secondary_text(secondary[-1]), flush=True)  # its own line, as soon as it is measured
 
     if rank == 0:
         line = {
@@ -1175,9 +1259,10 @@ def main():
                                   "frac_of_fp32_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
         if cpu_job is not None:
             line["cpu_baseline"] = cpu_baseline(*cpu_job)
-        if secondary:
-            line["secondary"] = secondary
-        print(json.dumps(line), flush=True)
+        detail = write_detail(line, secondary)
+        if detail:
+            line["detail"] = detail
+        print(headline_text(line), flush=True)  # the LAST stdout line: what the driver parses
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

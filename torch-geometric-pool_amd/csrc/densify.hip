@@ -386,7 +386,10 @@ __global__ __launch_bounds__(256) void edge_facts_sorted_kernel(const int64_t* _
     for (int64_t gg = gp + 1; gg <= g; ++gg) edge_ptr[gg] = e;
     if (e == E - 1) {
       const int64_t B = batch[n - 1] + 1;
-      if (B < g || B - g > 64) flags |= 4u;
+      // edge_ptr holds n + 2 entries: a last graph id beyond the node count is a malformed batch vector (as `g > n`
+      // above), reported and nothing written
+      if (B < 0 || B > n + 1) flags |= 1u;
+      else if (B < g || B - g > 64) flags |= 4u;
       else
         for (int64_t gg = g + 1; gg <= B; ++gg) edge_ptr[gg] = E;
     }
