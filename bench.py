@@ -1150,6 +1150,13 @@ def main():
     ap.add_argument("--unsorted-edges", action="store_true",
                     help="c4_graclus: leave the synthetic edge list in random order (forces the sort-based coalesce)")
     args = ap.parse_args()
+    # stdout carries the JSON lines and nothing else; stderr stays free of the profiler's / autograd's advisory warnings
+    import warnings
+    warnings.filterwarnings("ignore")
+    try:
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+    except AttributeError:
+        pass
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

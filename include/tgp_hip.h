@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10030 /* 1.0.1 of the reference, ABI revision 29 (r5: fp64 dense path on v_mfma_f64_16x16x4_f64; selector backward in one pass; float64 row-local coalesce; sparse-input select + pool; TopK pooling backward) */
+#define TGP_ABI_VERSION 10031 /* 1.0.1 of the reference, ABI revision 30 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -615,6 +615,46 @@ int tgp_mincut_loss_terms_f32(const float* raw, const float* den, const float* g
  * dS = S (W + W^T)). */
 int tgp_mincut_loss_terms_bwd_f32(const float* raw, const float* den, const float* gram, const float* g_terms, int64_t B,
                                   int64_t K, float eps, float* g_raw, float* c1, float* W, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * N1 (r6)  The dense poolers' TRAINING step for graphs beyond the one-wave / one-workgroup kernels (C2: B = 32,
+ * N = 1024, K = 128, F = 64), as the pieces ONE autograd node is made of (host side: functions._PoolLargeFn).  What the
+ * reference gets from ATen autograd over poolers/mincut.py:220-237 / diffpool.py:208-218 (harness:
+ * examples/time_and_mem_test.py:396-401).
+ *
+ * tgp_dense_pool_train_fwd_f32: tgp_dense_pool_f32's three launches (U = A S; S^T [U | X | S] split over N; slab
+ *   combine + post-processing), with U written where the caller says -- row stride ldu >= K: column block 0 of the
+ *   [B,N,3K+F] operand buffer [U | V | X | S] the backward's single GEMM reads -- and, when `gram` is not NULL,
+ *   G = S^T S [B,K,K] as a third right-hand side of the second product.  adj_raw is required, adj_pool optional;
+ *   flags as tgp_dense_pool_f32 (TGP_ADJ_TRANSPOSED: A is stored transposed).
+ * tgp_mincut_terms_fused_f32: MinCut's per-graph loss tails out [2,B] (as tgp_mincut_loss_terms_f32) with
+ *   den[b] = sum_i deg[b,i] q[b,i] formed in the same launch (deg, q [B,N] from tgp_cut_terms_f32) and kept for the backward.
+ * tgp_dense_pool_train_rhs_f32: the K-sized right-hand sides of  gS = [U | V | X | S] [RU ; RV ; RX ; RS]  into
+ *   rcat [B][3K+F][K]: with gR = g_raw_a + g_raw_b (either may be NULL) + the loss' diagonal term,
+ *   RV = gR, RU = gR^T, RX = g_x^T (g_x [B,K,F], or one value when gx_bcast), RS by mode:
+ *   0: not written (the caller multiplies the first 2K+F rows only);
+ *   1 (MinCut): RS = W + W^T, gR -= (g_cut / (den + eps)) I, c1[b] = g_cut trace(raw) / (den + eps)^2, with
+ *      g_cut = *g_la * scale, g_ortho = *g_lb * scale (0-dim device values or NULL; scale = 1 / B for the batch means);
+ *   2 (DiffPool): c = link_scale^2 *g_la / *link_loss (0 when the loss is 0), gR -= c I, RS = 2 c G.
+ * tgp_softmax_bwd_ex_f32: tgp_softmax_bwd_f32 on dS + extra + 2 c1[m / rows_per_graph] deg[m] S
+ *   - *ent_g ent_scale (log(S + eps) + S / (S + eps))   (extra, c1/deg, ent_g: each optional).
+ * tgp_copy_cols2_f32: dst[r, col_a:col_a+wa] = a[r,:], dst[r, col_b:col_b+wb] = b[r,:] (row stride ld) in one pass.
+ * ---------------------------------------------------------------------------------- */
+size_t tgp_dense_pool_train_workspace_bytes(int64_t B, int64_t N, int64_t K, int64_t F);
+int tgp_dense_pool_train_fwd_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K,
+                                 int64_t F, int flags, float eps, float* U, int64_t ldu, float* x_pool, float* adj_raw,
+                                 float* adj_pool, float* gram, void* ws, size_t ws_bytes, void* stream);
+int tgp_mincut_terms_fused_f32(const float* raw, const float* gram, const float* deg, const float* q, int64_t B,
+                               int64_t N, int64_t K, float eps, float* den, float* out, void* stream);
+int tgp_dense_pool_train_rhs_f32(const float* g_raw_a, const float* g_raw_b, int mode, const float* raw, const float* den,
+                                 const float* gram, const float* g_la, const float* g_lb, float scale,
+                                 const float* link_loss, float link_scale, float eps, const float* g_x, int gx_bcast,
+                                 int64_t B, int64_t K, int64_t F, float* rcat, float* c1, void* stream);
+int tgp_softmax_bwd_ex_f32(const float* s, const float* ds, const float* extra, const float* c1, const float* deg,
+                           int64_t rows_per_graph, const float* ent_g, float ent_scale, float ent_eps, float* dy,
+                           int64_t M, int64_t K, void* stream);
+int tgp_copy_cols2_f32(const float* a, int64_t wa, const float* b, int64_t wb, int64_t rows, float* dst, int64_t ld,
+                       int64_t col_a, int64_t col_b, void* stream);
 
 /* A7'  sparse A times dense S (connect/dense_conn.py:165,204: torch.sparse.mm), A in CSR built from a
  * row-sorted coalesced edge list: T[i,:] = sum_{e in row i} w[e] * S[col[e],:].  w may be NULL. */

@@ -1,0 +1,185 @@
+"""Training step of the dense poolers on graphs beyond the one-wave kernels (r6: functions._PoolLargeFn, ONE autograd
+node for Select + Reduce + Connect + post-processing + the two auxiliary losses): values and gradients against the CPU
+oracle's plain-torch restatement run in float64 under autograd (reference poolers/mincut.py:220-237,
+diffpool.py:208-218, utils/losses.py:39-70, 476-483, 644-658)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _batch(sizes, f, deg, seed, weighted=True):
+    """Sorted PyG-style batch on the host: x [Ntot,F], symmetric duplicate-free edge_index, weights, batch vector."""
+    g = torch.Generator().manual_seed(seed)
+    xs, eis, bs, off = [], [], [], 0
+    for gi, n in enumerate(sizes):
+        a = torch.triu(torch.rand(n, n, generator=g) < deg / n, 1)
+        a = a | a.t()
+        eis.append(a.nonzero().t() + off)
+        xs.append(torch.randn(n, f, generator=g))
+        bs.append(torch.full((n,), gi))
+        off += n
+    x, ei, batch = torch.cat(xs), torch.cat(eis, 1), torch.cat(bs)
+    ew = (torch.rand(ei.size(1), generator=g) + 0.25) if weighted else None
+    return x, ei, ew, batch
+
+
+def _node_names(fn, seen=None, out=None):
+    seen, out = seen if seen is not None else set(), out if out is not None else []
+    if fn is None or fn in seen:
+        return out
+    seen.add(fn)
+    out.append(type(fn).__name__)
+    for nxt, _ in fn.next_functions:
+        _node_names(nxt, seen, out)
+    return out
+
+
+CASES = [  # alias, graph sizes, K, F, weighted edges
+    ("mincut", [130, 97, 160], 40, 24, True),     # K <= 64: one-wave post-processing, 64 x 64 tiles
+    ("mincut", [260, 199], 72, 16, False),        # 64 < K <= 256, K % 4 == 0: post_rows + the gram workgroups
+    ("diff", [130, 97, 160], 40, 24, True),
+    ("diff", [260, 199], 72, 16, True),
+    ("mincut", [150, 140], 66, 10, True),         # K % 4 != 0, F % 4 != 0: scalar copy / general post-processing
+    ("diff", [150, 140], 66, 10, False),
+]
+
+
+@pytest.mark.parametrize("alias,sizes,k,f,weighted", CASES)
+def test_large_graph_training_step_matches_oracle_autograd(dev, alias, sizes, k, f, weighted):
+    import tgp_oracle as O
+    from tgp.poolers import get_pooler
+    x, ei, ew, batch = _batch(sizes, f, 8.0, seed=len(sizes) * 100 + k, weighted=weighted)
+    pooler = get_pooler(alias, in_channels=f, k=k).to(dev).train()
+    lin = pooler.selector.mlp.lins[0]
+    g = torch.Generator().manual_seed(5)
+    B = len(sizes)
+    wx, wa = torch.randn(B, k, f, generator=g), torch.randn(B, k, k, generator=g)
+    c1, c2 = 0.7, 1.3
+
+    xg = x.to(dev).requires_grad_(True)
+    out = pooler(x=xg, adj=ei.to(dev), edge_weight=None if ew is None else ew.to(dev), batch=batch.to(dev))
+    names = _node_names(out.x.grad_fn)
+    assert any("_PoolLargeFn" in n for n in names), names  # the one-node path took the call
+    l1, l2 = list(out.loss.values())
+    obj = (out.x * wx.to(dev)).sum() + (out.edge_index * wa.to(dev)).sum() + c1 * l1 + c2 * l2
+    obj.backward()
+
+    # the oracle in float64 under autograd
+    xr = x.double().requires_grad_(True)
+    wr = lin.weight.detach().cpu().double().requires_grad_(True)
+    br = lin.bias.detach().cpu().double().requires_grad_(True)
+    ref = O.dense_pool(alias, xr, ei, (torch.ones(ei.size(1)) if ew is None else ew).double(), batch, [wr], [br])
+    r1, r2 = list(ref["loss"].values())
+    robj = (ref["x"] * wx.double()).sum() + (ref["edge_index"] * wa.double()).sum() + c1 * r1 + c2 * r2
+    robj.backward()
+
+    torch.testing.assert_close(out.x.detach().cpu().double(), ref["x"].detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out.edge_index.detach().cpu().double(), ref["edge_index"].detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out.so.s.detach().cpu().double(), ref["s"].detach(), rtol=1e-5, atol=1e-7)
+    for got, want in ((l1, r1), (l2, r2)):
+        torch.testing.assert_close(got.detach().cpu().double(), want.detach(), rtol=1e-5, atol=1e-6)
+
+    def close(got, want, what):
+        scale = float(want.abs().max())
+        torch.testing.assert_close(got.cpu().double(), want, rtol=2e-4, atol=2e-5 * max(scale, 1e-3),
+                                   msg=lambda m: f"{what}: {m}")
+
+    close(xg.grad, xr.grad, "dX")
+    close(lin.weight.grad, wr.grad, "dW")
+    close(lin.bias.grad, br.grad, "db")
+
+
+@pytest.mark.parametrize("alias", ["mincut", "diff"])
+def test_large_graph_training_step_two_layer_selector(dev, alias):
+    """A selector with a hidden layer keeps its own autograd nodes; the pooling step behind it is still the one node (S is
+    handed over), and the elementwise loss terms are added to dS there."""
+    import tgp_oracle as O
+    from tgp.poolers import get_pooler
+    sizes, k, f, h = [120, 150], 36, 12, 20
+    x, ei, ew, batch = _batch(sizes, f, 8.0, seed=77)
+    pooler = get_pooler(alias, in_channels=[f, h], k=k, act="tanh").to(dev).train()
+    lins = pooler.selector.mlp.lins
+    xg = x.to(dev).requires_grad_(True)
+    out = pooler(x=xg, adj=ei.to(dev), edge_weight=ew.to(dev), batch=batch.to(dev))
+    assert any("_PoolLargeFn" in n for n in _node_names(out.x.grad_fn))
+    l1, l2 = list(out.loss.values())
+    (out.x.square().sum() + out.edge_index.square().sum() + l1 + 0.5 * l2).backward()
+
+    xr = x.double().requires_grad_(True)
+    ws = [l.weight.detach().cpu().double().requires_grad_(True) for l in lins]
+    bs = [l.bias.detach().cpu().double().requires_grad_(True) for l in lins]
+    ref = O.dense_pool(alias, xr, ei, ew.double(), batch, ws, bs, act="tanh")
+    r1, r2 = list(ref["loss"].values())
+    (ref["x"].square().sum() + ref["edge_index"].square().sum() + r1 + 0.5 * r2).backward()
+    for got, want in ((l1, r1), (l2, r2)):
+        torch.testing.assert_close(got.detach().cpu().double(), want.detach(), rtol=1e-5, atol=1e-6)
+    for got, want, what in [(xg.grad, xr.grad, "dX")] + [(l.weight.grad, w.grad, f"dW{i}") for i, (l, w) in
+                                                          enumerate(zip(lins, ws))]:
+        scale = float(want.abs().max())
+        torch.testing.assert_close(got.cpu().double(), want, rtol=2e-4, atol=2e-5 * max(scale, 1e-3),
+                                   msg=lambda m: f"{what}: {m}")
+
+
+def test_large_graph_training_step_dense_inputs_and_partial_gradients(dev):
+    """Dense [B,N,N] inputs (no preprocessing), only the pooled features used downstream (no gradient reaches adj_pool
+    or the losses), and node features that are data (x.requires_grad False): every absent upstream gradient is skipped."""
+    from tgp.poolers import get_pooler
+    g = torch.Generator(device=dev).manual_seed(3)
+    B, N, K, F = 2, 200, 48, 16
+    A = (torch.rand(B, N, N, device=dev, generator=g) < 0.05).float()
+    A = torch.maximum(A, A.transpose(1, 2)).contiguous()
+    X = torch.randn(B, N, F, device=dev, generator=g)
+    pooler = get_pooler("mincut", in_channels=F, k=K).to(dev).train()
+    lin = pooler.selector.mlp.lins[0]
+    out = pooler(x=X, adj=A)
+    assert any("_PoolLargeFn" in n for n in _node_names(out.x.grad_fn))
+    out.x.square().sum().backward()
+    got_w, got_b = lin.weight.grad.clone(), lin.bias.grad.clone()
+
+    W = lin.weight.detach().double().requires_grad_(True)
+    b = lin.bias.detach().double().requires_grad_(True)
+    S = torch.softmax(X.double() @ W.t() + b, -1)
+    (S.transpose(1, 2) @ X.double()).square().sum().backward()
+    torch.testing.assert_close(got_w.double(), W.grad, rtol=2e-4, atol=1e-5 * float(W.grad.abs().max()))
+    torch.testing.assert_close(got_b.double(), b.grad, rtol=2e-4, atol=1e-5 * float(b.grad.abs().max()))
+
+
+def test_train_kernels_pieces(dev):
+    """The C-ABI pieces on their own: strided products into column blocks, the column copy, S^T S riding on the second
+    product, the fused MinCut tail against the staged kernels."""
+    from tgp import kernels as K
+    g = torch.Generator(device=dev).manual_seed(11)
+    B, N, Kc, F = 2, 333, 72, 20
+    S = torch.softmax(torch.randn(B, N, Kc, device=dev, generator=g), -1)
+    A = torch.rand(B, N, N, device=dev, generator=g)
+    X = torch.randn(B, N, F, device=dev, generator=g)
+    ld = 3 * Kc + F
+    acat = torch.full((B, N, ld), float("nan"), device=dev)
+    x_pool, raw, adj_pool, gram = K.dense_pool_train_fwd(S, A, X, K.dense_flags(True, True, True, False), acat, True)
+    ref_x, ref_raw, ref_pool = K.dense_pool(S, A, X, K.dense_flags(True, True, True, False), want_raw=True)
+    assert torch.equal(x_pool, ref_x) or torch.allclose(x_pool, ref_x, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(raw, ref_raw, rtol=1e-6, atol=1e-5)
+    torch.testing.assert_close(adj_pool, ref_pool, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(acat[:, :, :Kc], A @ S, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(gram, S.transpose(1, 2) @ S, rtol=1e-5, atol=1e-5)
+    assert torch.isnan(acat[:, :, Kc:]).all()  # nothing else was touched
+    K.bmm_into(A, S, acat[:, :, Kc:2 * Kc], trans_a=True)
+    torch.testing.assert_close(acat[:, :, Kc:2 * Kc], A.transpose(1, 2) @ S, rtol=1e-5, atol=1e-4)
+    K.copy_cols2(X.view(B * N, F), S.view(B * N, Kc), acat.view(B * N, ld), 2 * Kc, 2 * Kc + F)
+    assert torch.equal(acat[:, :, 2 * Kc:2 * Kc + F], X) and torch.equal(acat[:, :, 2 * Kc + F:], S)
+    R = torch.randn(B, ld, Kc, device=dev, generator=g)
+    out = torch.empty(B, N, Kc, device=dev)
+    K.bmm_into(acat, R, out)
+    torch.testing.assert_close(out, acat @ R, rtol=1e-4, atol=1e-3)
+    deg, q = K.cut_rows(A, S)
+    deg2, q2, den2 = K.cut_terms(A, S)
+    assert torch.equal(deg, deg2) and torch.equal(q, q2)
+    den, terms = K.mincut_terms_fused(raw, gram, deg, q)
+    torch.testing.assert_close(den, den2, rtol=1e-6, atol=0)
+    torch.testing.assert_close(terms, K.mincut_loss_terms(raw, den2, gram), rtol=1e-6, atol=1e-7)

@@ -32,7 +32,7 @@ struct DensePlan {
   size_t u_floats, aslab_floats, xslab_floats, post_floats, colsum_floats;
 };
 
-static DensePlan dense_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
+static DensePlan dense_plan(int64_t B, int64_t N, int64_t K, int64_t F, bool with_gram = false) {
   DensePlan p;
   // second product: output is only K x (K+F) per graph -> split N so the chip is filled.  Small K: 64 x 64
   // tiles (256-thread workgroups) need fewer splits for the same number of workgroups, i.e. longer k-loops
@@ -40,7 +40,7 @@ static DensePlan dense_plan(int64_t B, int64_t N, int64_t K, int64_t F) {
   p.tile = (kStage2Tile == 64 || kStage2Tile == 128) ? kStage2Tile : 64;
   p.tile_m = (kStage2TileM == 64 || kStage2TileM == 128) ? kStage2TileM : p.tile;
   const int64_t T = p.tile, TM = p.tile_m;
-  const int64_t tiles = ((K + TM - 1) / TM) * (((K + T - 1) / T) + ((F + T - 1) / T));
+  const int64_t tiles = ((K + TM - 1) / TM) * ((with_gram ? 2 : 1) * ((K + T - 1) / T) + ((F + T - 1) / T));
   const int64_t base = B * (tiles > 0 ? tiles : 1);
   // Split count: every workgroup of this grid is resident at once (<= 4 per CU), so the launch ends with the
   // busiest CU.  Cost model: (k-steps per workgroup + ~3 steps of prologue and epilogue) x (time of a k-step with n
@@ -100,6 +100,9 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
                            int flags, float eps, const int64_t* graph_sizes, float* x_pool, float* adj_raw,
                            float* adj_pool, float* mincut_terms, float loss_eps, void* ws, size_t ws_bytes,
                            void* stream_);
+static int dense_pool_tiled(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K, int64_t F,
+                            int flags, float eps, float* x_pool, float* adj_raw, float* adj_pool, float* U, int64_t ldu,
+                            float* gram, const DensePlan& p, Carver& cv, hipStream_t stream);
 
 extern "C" int tgp_dense_pool_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N,
                                   int64_t K, int64_t F, int flags, float eps, const int64_t* graph_sizes,
@@ -287,17 +290,29 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
   const DensePlan p = dense_plan(B, N, K, F);
   Carver cv(ws);
   float* U = cv.take<float>(p.u_floats);
+  return dense_pool_tiled(S, A, X, B, N, K, F, flags, eps, x_pool, adj_raw, adj_pool, U, K, nullptr, p, cv, stream);
+}
+
+// The tiled path: U = A S (row stride ldu: the training step keeps U inside a wider buffer), S^T [U | X (| S)] split
+// over N into slabs, and the slab combine + post-processing.  `gram` (optional, [B,K,K]): S^T S rides along as a third
+// right-hand side of the second product (MinCut's orthogonality loss and DiffPool's link-loss gradient need it).
+static int dense_pool_tiled(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K, int64_t F,
+                            int flags, float eps, float* x_pool, float* adj_raw, float* adj_pool, float* U, int64_t ldu,
+                            float* gram, const DensePlan& p, Carver& cv, hipStream_t stream) {
+  const bool want_x = X && x_pool && F > 0;
+  const bool want_a = A && (adj_raw || adj_pool);
   float* aslab = cv.take<float>(p.aslab_floats);
   float* xslab = cv.take<float>(p.xslab_floats);
   float* postws = cv.take<float>(p.post_floats);
   float* colpart = cv.take<float>(p.colsum_floats);
+  float* gslab = gram ? cv.take<float>(p.aslab_floats) : nullptr;
 
   if (want_a) {
     // U[b] = A[b] S[b]     (M = N, Kd = N, Nc = K)
     GemmArgs g{};
     g.A = A; g.lda = N; g.sA = N * N;
     g.M = static_cast<int>(N); g.Kd = static_cast<int>(N);
-    g.rhs[0] = GemmRhs{S, U, static_cast<int>(K), K, K, N * K, N * K, 0};
+    g.rhs[0] = GemmRhs{S, U, static_cast<int>(K), K, ldu, N * K, N * ldu, 0};
     g.splits = 1; g.k_per_split = static_cast<int>((N + BK - 1) / BK * BK);
     
     if (flags & TGP_ADJ_TRANSPOSED) launch_gemm<true>(g, static_cast<int>(B), stream);
@@ -310,15 +325,13 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
     h.M = static_cast<int>(K); h.Kd = static_cast<int>(N);
     h.splits = p.splits; h.k_per_split = p.k_per_split;
     h.force_bm = p.tile_m; h.force_bn = p.tile;
-    const GemmRhs ra{U, aslab, static_cast<int>(K), K, K, N * K, static_cast<long>(p.splits) * K * K, K * K};
+    const GemmRhs ra{U, aslab, static_cast<int>(K), ldu, K, N * ldu, static_cast<long>(p.splits) * K * K, K * K};
     const GemmRhs rx{X, xslab, static_cast<int>(F), F, F, N * F, static_cast<long>(p.splits) * K * F, K * F};
-    if (want_a && want_x) {
-      h.rhs[0] = ra; h.rhs[1] = rx;
-
-    } else {
-      h.rhs[0] = want_a ? ra : rx;
-
-    }
+    const GemmRhs rg{S, gslab, static_cast<int>(K), K, K, N * K, static_cast<long>(p.splits) * K * K, K * K};
+    int nr = 0;
+    if (want_a) h.rhs[nr++] = ra;
+    if (want_x) h.rhs[nr++] = rx;
+    if (gram) h.rhs[nr++] = rg;
     // r5: K / 16 workgroups per graph post-process (post_rows_kernel) when the second product can leave the partial
     // column sums the degree vector needs (64 x 64 tiles, sum over dim -2, no edge_weight_norm)
     if (want_a && post_rows_ok(K, flags, aslab, adj_raw, adj_pool) && p.tile == 64 && p.tile_m == 64 &&
@@ -337,10 +350,22 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
         r.xslab = xslab; r.xs_split = K * F; r.xs_batch = static_cast<long>(p.splits) * K * F;
         r.F = static_cast<int>(F); r.x_pool = x_pool;
       }
-      const unsigned grid = static_cast<unsigned>(B * ((K + PR_ROWS - 1) / PR_ROWS));
+      unsigned grid = static_cast<unsigned>(B * ((K + PR_ROWS - 1) / PR_ROWS));
+      r.main_blocks = static_cast<int>(grid);
+      if (gram) {  // the same launch adds the S^T S slabs up (a second set of workgroups, no post-processing)
+        r.gslab = gslab; r.gram = gram;
+        grid *= 2;
+      }
       hipLaunchKernelGGL(post_rows_kernel, dim3(grid), dim3(512), 0, stream, r);
       return check_launch("tgp_dense_pool_f32");
     }
+  }
+  if (gram) {
+    const long total = K * K;
+    int gx = static_cast<int>((total + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(combine_slabs_kernel, dim3(gx, static_cast<unsigned>(B)), dim3(256), 0, stream, gslab,
+                       p.splits, K * K, static_cast<long>(p.splits) * K * K, total, gram);
   }
   bool x_done = !want_x;
   if (want_a) {
@@ -358,6 +383,83 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
                        p.splits, K * F, static_cast<long>(p.splits) * K * F, total, x_pool);
   }
   return check_launch("tgp_dense_pool_f32");
+}
+
+// ---- r6: forward of the dense poolers' TRAINING step for graphs beyond the one-wave / one-workgroup kernels ----------
+// (C2-sized: B = 32, N = 1024, K = 128).  The same three launches as tgp_dense_pool_f32's tiled path, but U = A S is
+// written where the caller says (row stride ldu >= K: column block 0 of the [B,N,3K+F] operand buffer the backward's
+// single sum-of-products GEMM reads, see tgp_dense_pool_train_rhs_f32) and G = S^T S -- MinCut's orthogonality loss,
+// DiffPool's link-loss gradient -- rides along as a third right-hand side of the second product.
+// reference: base_reduce.py:158-161, dense_conn.py:111-122, utils/ops.py:282-335, utils/losses.py:59-70.
+extern "C" size_t tgp_dense_pool_train_workspace_bytes(int64_t B, int64_t N, int64_t K, int64_t F) {
+  if (B <= 0 || N <= 0 || K <= 0) return 256;
+  size_t best = 0;
+  for (int with_gram = 0; with_gram < 2; ++with_gram) {  // (the split count depends on the number of column tiles)
+    const DensePlan p = dense_plan(B, N, K, F > 0 ? F : 0, with_gram != 0);
+    const size_t bytes = 2 * align_up(p.aslab_floats * 4) + align_up(p.xslab_floats * 4) + align_up(p.post_floats * 4) +
+                         align_up(p.colsum_floats * 4) + 256;
+    if (bytes > best) best = bytes;
+  }
+  return best;
+}
+
+extern "C" int tgp_dense_pool_train_fwd_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N,
+                                            int64_t K, int64_t F, int flags, float eps, float* U, int64_t ldu,
+                                            float* x_pool, float* adj_raw, float* adj_pool, float* gram, void* ws,
+                                            size_t ws_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B > 0 && N > 0 && K > 0 && F >= 0, TGP_ERR_INVALID, "tgp_dense_pool_train_fwd_f32: empty or negative size");
+  TGP_REQUIRE(S && A && U && adj_raw && (F == 0 || (X && x_pool)), TGP_ERR_INVALID,
+              "tgp_dense_pool_train_fwd_f32: null pointer");
+  TGP_REQUIRE(ldu >= K, TGP_ERR_INVALID, "tgp_dense_pool_train_fwd_f32: ldu < K");
+  TGP_REQUIRE(N < (1ll << 31) && K <= 16000 && F < (1ll << 31) && B < 65536 && N * ldu * 4 < (1ll << 31) - 4096,
+              TGP_ERR_RANGE, "tgp_dense_pool_train_fwd_f32: dimension too large");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_dense_pool_train_workspace_bytes(B, N, K, F), TGP_ERR_WORKSPACE,
+              "tgp_dense_pool_train_fwd_f32: workspace too small");
+  const DensePlan p = dense_plan(B, N, K, F, gram != nullptr);
+  Carver cv(ws);
+  return dense_pool_tiled(S, A, F > 0 ? X : nullptr, B, N, K, F, flags, eps, x_pool, adj_raw, adj_pool, U, ldu, gram,
+                          p, cv, stream);
+}
+
+// dst[r, col_a : col_a + wa] = a[r, :], dst[r, col_b : col_b + wb] = b[r, :] for r < rows: the S and X column blocks
+// of the backward's operand buffer in one pass (float4 when everything is 16-byte aligned).
+namespace tgp {
+__global__ __launch_bounds__(256) void copy_cols2_kernel(const float* __restrict__ a, int wa, const float* __restrict__ b,
+                                                         int wb, long rows, float* __restrict__ dst, long ld, int col_a,
+                                                         int col_b, int vec) {
+  const int per_row = vec ? (wa + wb) / 4 : wa + wb;
+  const long total = rows * per_row;
+  for (long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<long>(gridDim.x) * 256) {
+    const long r = e / per_row;
+    int c = static_cast<int>(e - r * per_row) * (vec ? 4 : 1);
+    const float* src;
+    float* out;
+    if (c < wa) { src = a + r * wa + c; out = dst + r * ld + col_a + c; }
+    else { c -= wa; src = b + r * wb + c; out = dst + r * ld + col_b + c; }
+    if (vec) *reinterpret_cast<float4*>(out) = *reinterpret_cast<const float4*>(src);
+    else *out = *src;
+  }
+}
+}  // namespace tgp
+
+extern "C" int tgp_copy_cols2_f32(const float* a, int64_t wa, const float* b, int64_t wb, int64_t rows, float* dst,
+                                  int64_t ld, int64_t col_a, int64_t col_b, void* stream_) {
+  TGP_REQUIRE(rows >= 0 && wa >= 0 && wb >= 0 && ld >= 0, TGP_ERR_INVALID, "tgp_copy_cols2_f32: negative size");
+  if (rows == 0 || wa + wb == 0) return TGP_OK;
+  TGP_REQUIRE(dst && (wa == 0 || a) && (wb == 0 || b), TGP_ERR_INVALID, "tgp_copy_cols2_f32: null pointer");
+  TGP_REQUIRE(col_a + wa <= ld && col_b + wb <= ld && wa + wb < (1ll << 30), TGP_ERR_INVALID,
+              "tgp_copy_cols2_f32: column block outside the row");
+  const int vec = (wa % 4 == 0 && wb % 4 == 0 && ld % 4 == 0 && col_a % 4 == 0 && col_b % 4 == 0 &&
+                   reinterpret_cast<uintptr_t>(a) % 16 == 0 && reinterpret_cast<uintptr_t>(b) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(dst) % 16 == 0) ? 1 : 0;
+  const int64_t total = rows * ((wa + wb) / (vec ? 4 : 1));
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(copy_cols2_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     a, static_cast<int>(wa), b, static_cast<int>(wb), static_cast<long>(rows), dst, static_cast<long>(ld),
+                     static_cast<int>(col_a), static_cast<int>(col_b), vec);
+  return check_launch("tgp_copy_cols2_f32");
 }
 
 extern "C" size_t tgp_postprocess_dense_workspace_bytes(int64_t B, int64_t K) {

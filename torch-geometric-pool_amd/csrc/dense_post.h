@@ -423,6 +423,9 @@ struct PostRowsArgs {
   int K, flags; float eps;
   float* raw; float* dst;                                 // [B][K][K], raw optional
   const float* xslab; long xs_split, xs_batch; int F; float* x_pool;  // [B][splits][K][F] -> [B][K][F], or NULL
+  // r6 (training step): workgroups >= main_blocks add up a second slab set of the same shape (S^T S) into `gram`,
+  // no post-processing
+  int main_blocks; const float* gslab; float* gram;
 };
 
 constexpr int PR_ROWS = 16;
@@ -432,6 +435,23 @@ __global__ __launch_bounds__(512) void post_rows_kernel(PostRowsArgs p) {
   __shared__ float s_d[1024];
   const int K = p.K, tid = threadIdx.x;
   const int blocks_per_graph = (K + PR_ROWS - 1) / PR_ROWS;
+  if (p.gram && static_cast<int>(blockIdx.x) >= p.main_blocks) {  // (workgroup-uniform) fixed-order slab sum of S^T S
+    const int id = blockIdx.x - p.main_blocks;
+    const int gb_ = id / blocks_per_graph, grb = id - gb_ * blocks_per_graph;
+    const int rows = K - grb * PR_ROWS < PR_ROWS ? K - grb * PR_ROWS : PR_ROWS;
+    const long base = static_cast<long>(grb) * PR_ROWS * K;
+    const float* src = p.gslab + static_cast<long>(gb_) * p.s_batch + base;
+    float* dst = p.gram + static_cast<long>(gb_) * K * K + base;
+    for (int e = tid * 4; e < rows * K; e += 2048) {
+      float4 t = *reinterpret_cast<const float4*>(src + e);
+      for (int sp = 1; sp < p.splits; ++sp) {
+        const float4 v = *reinterpret_cast<const float4*>(src + sp * p.s_split + e);
+        t.x = __fadd_rn(t.x, v.x); t.y = __fadd_rn(t.y, v.y); t.z = __fadd_rn(t.z, v.z); t.w = __fadd_rn(t.w, v.w);
+      }
+      *reinterpret_cast<float4*>(dst + e) = t;
+    }
+    return;
+  }
   const int b = blockIdx.x / blocks_per_graph, rb = blockIdx.x - b * blocks_per_graph;
   const int i0 = rb * PR_ROWS;
   const float* sb = p.slab + static_cast<long>(b) * p.s_batch;

@@ -44,8 +44,9 @@ constexpr int BK = 32;
 
 constexpr int LDA_ROWMAJOR = BK + 1;
 
-// One right-hand side / output pair.  A launch may carry two (column tiles >= tiles_n0 use the
-// second), which lets S^T [U | X] run as a single grid.
+// One right-hand side / output pair.  A launch may carry up to three (column tiles >= tiles_n0 use the
+// second, those >= tiles_n1 the third), which lets S^T [U | X] -- and, for the training step, S^T [U | X | S] --
+// run as a single grid.
 struct GemmRhs {
   const float* Bm;
   float* C;
@@ -57,8 +58,9 @@ struct GemmArgs {
   const float* A;
   long lda, sA;
   int M, Kd;               // C[M,Nc] = op(A)[M,Kd] * Bm[Kd,Nc]
-  GemmRhs rhs[2];
-  int tiles_m, tiles_n0, tiles_n;  // tiles_n = tiles_n0 + tiles of rhs[1]
+  GemmRhs rhs[3];
+  int tiles_m, tiles_n0, tiles_n;  // tiles_n = tiles_n0 + tiles of rhs[1] (+ tiles of rhs[2])
+  int tiles_n1;            // first column tile of rhs[2]; 0 = there is no third right-hand side
   int splits;              // split of Kd across workgroups
   int k_per_split;         // multiple of BK
   const int64_t* k_ptr;    // optional [batches+1]: batch b reduces over rows k_ptr[b]..k_ptr[b+1]
@@ -156,8 +158,8 @@ __global__ __launch_bounds__(BM * 2 * WN) void gemm_f32_mfma_kernel(GemmArgs g) 
   const int tm = bid % g.tiles_m; bid /= g.tiles_m;
   const int split = bid % g.splits;
   const int batch = bid / g.splits;
-  const int which = tn_all >= g.tiles_n0 ? 1 : 0;
-  const int tn = which ? tn_all - g.tiles_n0 : tn_all;
+  const int which = tn_all >= g.tiles_n0 ? ((g.tiles_n1 && tn_all >= g.tiles_n1) ? 2 : 1) : 0;
+  const int tn = which == 2 ? tn_all - g.tiles_n1 : (which ? tn_all - g.tiles_n0 : tn_all);
   const GemmRhs& R = g.rhs[which];
 
   const float* __restrict__ A = g.A + static_cast<long>(batch) * g.sA;
@@ -646,8 +648,8 @@ static bool gemm_aligned(const GemmArgs& g, bool /*k_rows*/) {
   bool a = ok(g.A, g.lda, g.sA);
   const long lim = (1l << 31) - 4096;
   a = a && (static_cast<long>(g.M) * g.lda * 4 < lim) && (static_cast<long>(g.Kd) * g.lda * 4 < lim);
-  for (int w = 0; w < 2; ++w)
-    if (w == 0 || g.tiles_n > g.tiles_n0)
+  for (int w = 0; w < 3; ++w)
+    if (w == 0 || (w == 1 && g.tiles_n > g.tiles_n0) || (w == 2 && g.tiles_n1))
       a = a && ok(g.rhs[w].Bm, g.rhs[w].ldb, g.rhs[w].sB) &&
           (static_cast<long>(g.Kd) * g.rhs[w].ldb * 4 < lim) && (static_cast<long>(g.rhs[w].Nc) * g.rhs[w].ldb * 4 < lim);
   return a;
@@ -665,6 +667,7 @@ static TileCfg pick_tile(int64_t M, int64_t max_nc, int64_t batches_x_splits, co
     int64_t tn = 0;
     tn += (g.rhs[0].Nc + bn - 1) / bn;
     if (g.rhs[1].Bm) tn += (g.rhs[1].Nc + bn - 1) / bn;
+    if (g.rhs[1].Bm && g.rhs[2].Bm) tn += (g.rhs[2].Nc + bn - 1) / bn;
     return ((M + bm - 1) / bm) * tn * batches_x_splits;
   };
   if (M <= 64) t.bm = 64;
@@ -692,11 +695,18 @@ static void launch_gemm_cfg(const GemmArgs& g_in, int batches, hipStream_t strea
 // written (only the 64 x 64 tile has the MODE 2 epilogue; *tiles_m_out = row tiles per batch element of that layout).
 template <bool A_KMAJOR>
 static bool launch_gemm(GemmArgs g, int batches, hipStream_t stream, int* tiles_m_out = nullptr) {
-  const int64_t max_nc = g.rhs[1].Bm && g.rhs[1].Nc > g.rhs[0].Nc ? g.rhs[1].Nc : g.rhs[0].Nc;
+  int64_t max_nc = g.rhs[1].Bm && g.rhs[1].Nc > g.rhs[0].Nc ? g.rhs[1].Nc : g.rhs[0].Nc;
+  const bool third = g.rhs[1].Bm && g.rhs[2].Bm;  // (a third right-hand side only behind a second one)
+  if (third && g.rhs[2].Nc > max_nc) max_nc = g.rhs[2].Nc;
   const TileCfg t = pick_tile(g.M, max_nc, static_cast<int64_t>(batches) * g.splits, g);
   g.tiles_m = cdiv(g.M, t.bm);
   g.tiles_n0 = cdiv(g.rhs[0].Nc, t.bn);
   g.tiles_n = g.tiles_n0 + (g.rhs[1].Bm ? cdiv(g.rhs[1].Nc, t.bn) : 0);
+  g.tiles_n1 = 0;
+  if (third) {
+    g.tiles_n1 = g.tiles_n;
+    g.tiles_n += cdiv(g.rhs[2].Nc, t.bn);
+  }
   if (tiles_m_out) *tiles_m_out = g.tiles_m;
   if (t.bm == 64 && t.bn == 64 && g.colsum) {
     launch_gemm_cfg<A_KMAJOR, 64, 64, 2>(g, batches, stream);

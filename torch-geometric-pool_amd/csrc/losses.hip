@@ -339,9 +339,9 @@ extern "C" int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int6
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_cut_terms_f32: negative size");
   if (B == 0) return TGP_OK;
-  TGP_REQUIRE(den, TGP_ERR_INVALID, "tgp_cut_terms_f32: null output");
+  TGP_REQUIRE(den || (deg && q), TGP_ERR_INVALID, "tgp_cut_terms_f32: null output");
   if (N == 0) {
-    (void)hipMemsetAsync(den, 0, B * sizeof(float), stream);
+    if (den) (void)hipMemsetAsync(den, 0, B * sizeof(float), stream);
     return check_launch("tgp_cut_terms_f32");
   }
   TGP_REQUIRE(A && deg && q && (K == 0 || S), TGP_ERR_INVALID, "tgp_cut_terms_f32: null pointer");
@@ -353,7 +353,8 @@ extern "C" int tgp_cut_terms_f32(const float* A, const float* S, int64_t B, int6
   else
     hipLaunchKernelGGL(cut_rows_kernel<64>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, A, S, rows, static_cast<int>(N),
                        static_cast<int>(K), graph_sizes, deg, q);
-  hipLaunchKernelGGL(cut_den_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, deg, q, static_cast<int>(N), den);
+  if (den)  // (r6: NULL = the caller's fused loss tail forms the dot product itself)
+    hipLaunchKernelGGL(cut_den_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, deg, q, static_cast<int>(N), den);
   return check_launch("tgp_cut_terms_f32");
 }
 
@@ -389,6 +390,175 @@ extern "C" int tgp_mincut_loss_terms_bwd_f32(const float* raw, const float* den,
                        static_cast<hipStream_t>(stream_), raw, den, gram, g_terms, static_cast<int>(K), eps,
                        static_cast<int>(B), g_raw, c1, W);
   return check_launch("tgp_mincut_loss_terms_bwd_f32");
+}
+
+// ---- r6: the loss tails of the dense poolers' training step at C2 scale (one autograd node, functions._PoolLargeFn) ---
+// MinCut's two per-graph terms with den = trace(S^T D S) = sum_i deg_i q_i formed in the same launch (the forward had a
+// kernel of its own for that dot product); den is kept for the backward.
+namespace tgp {
+template <int T>
+__global__ __launch_bounds__(T) void mincut_tail2_kernel(const float* __restrict__ raw, const float* __restrict__ gram,
+                                                           const float* __restrict__ deg, const float* __restrict__ q,
+                                                           int N, int K, float eps, int B, float* __restrict__ den,
+                                                           float* __restrict__ out) {
+  __shared__ float sh[T / 64];
+  const int b = blockIdx.x;
+  const float* R = raw + static_cast<int64_t>(b) * K * K;
+  const float* G = gram + static_cast<int64_t>(b) * K * K;
+  const float* d = deg + static_cast<int64_t>(b) * N;
+  const float* qq = q + static_cast<int64_t>(b) * N;
+  float dn = 0.f, tr = 0.f, sq = 0.f;
+  for (int i = threadIdx.x; i < N; i += T) dn = fmaf(d[i], qq[i], dn);
+  for (int i = threadIdx.x; i < K; i += T) tr += R[static_cast<int64_t>(i) * K + i];
+  for (int i = threadIdx.x; i < K * K; i += T) sq = fmaf(G[i], G[i], sq);
+  dn = block_sum_t<T>(dn, sh);
+  tr = block_sum_t<T>(tr, sh);
+  sq = block_sum_t<T>(sq, sh);
+  const float n = sqrtf(sq);
+  const float t = 1.0f / sqrtf(static_cast<float>(K));
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < K * K; i += T) {
+    const float y = G[i] / n - ((i / K == i % K) ? t : 0.f);
+    acc = fmaf(y, y, acc);
+  }
+  acc = block_sum_t<T>(acc, sh);
+  if (threadIdx.x == 0) {
+    den[b] = dn;
+    out[b] = -(tr / (dn + eps));
+    out[B + b] = sqrtf(acc);
+  }
+}
+
+// The K-sized right-hand sides of the backward's ONE sum-of-products GEMM
+//     gS = [U | V | X | S] [RU ; RV ; RX ; RS],     U = A S, V = A^T S
+// for one graph per workgroup.  With gR = the total gradient of raw = S^T A S (post-processing backward `ga` + an
+// upstream gradient of raw `gb` + the loss' own diagonal term):
+//     RV = gR,  RU = gR^T                      (dense_conn.py:111-122 under autograd: dS = U dR^T + V dR)
+//     RX = g_x^T                               (base_reduce.py:158-161: dS = X dX'^T)
+//     RS = W + W^T (MinCut, W = d ortho / d G, losses.py:59-70)   or   2 c G (DiffPool, losses.py:644-658)
+// mode 1 (MinCut): gR += -(g_cut / (den + eps)) I, c1[b] = g_cut trace(raw) / (den + eps)^2 (the gradient of den: the
+// caller folds 2 c1 D S into the softmax backward); g_cut / g_ortho are the upstream gradients of the batch MEANS
+// (0-dim tensors, or NULL) and `scale` = 1 / B.  mode 2 (DiffPool): c = link_scale^2 g_link / link_loss (0 when the
+// loss is 0: torch.norm's subgradient), gR += -c I, RS = 2 c G.  rcat: [B][2K + F + K][K], rows RU | RV | RX | RS.
+struct TrainRhsArgs {
+  const float* ga; const float* gb;
+  const float* raw; const float* den; const float* gram;
+  const float* g_la; const float* g_lb; float scale;
+  const float* link_loss; float link_scale, eps;
+  const float* g_x; int gx_bcast;
+  int K, F, mode;
+  float* rcat; float* c1;
+};
+
+template <int T>
+__global__ __launch_bounds__(T) void train_rhs_kernel(TrainRhsArgs p) {
+  __shared__ float sh[T / 64];
+  const int b = blockIdx.x, K = p.K, F = p.F;
+  const int64_t off = static_cast<int64_t>(b) * K * K;
+  const float* ga = p.ga ? p.ga + off : nullptr;
+  const float* gb = p.gb ? p.gb + off : nullptr;
+  float* out = p.rcat + static_cast<int64_t>(b) * (3 * K + F) * K;
+  float* RU = out;
+  float* RV = out + static_cast<int64_t>(K) * K;
+  float* RX = out + static_cast<int64_t>(2 * K) * K;
+  float* RS = out + static_cast<int64_t>(2 * K + F) * K;
+  float diag = 0.f;
+  if (p.mode == 1) {
+    const float* R = p.raw + off;
+    const float* G = p.gram + off;
+    float tr = 0.f, sq = 0.f;
+    for (int i = threadIdx.x; i < K; i += T) tr += R[static_cast<int64_t>(i) * K + i];
+    for (int i = threadIdx.x; i < K * K; i += T) sq = fmaf(G[i], G[i], sq);
+    tr = block_sum_t<T>(tr, sh);
+    sq = block_sum_t<T>(sq, sh);
+    const float n = sqrtf(sq);
+    const float t = 1.0f / sqrtf(static_cast<float>(K));
+    float ny2 = 0.f, gy = 0.f;
+    for (int i = threadIdx.x; i < K * K; i += T) {
+      const float y = G[i] / n - ((i / K == i % K) ? t : 0.f);
+      ny2 = fmaf(y, y, ny2);
+      gy = fmaf(G[i], y, gy);
+    }
+    ny2 = block_sum_t<T>(ny2, sh);
+    gy = block_sum_t<T>(gy, sh);
+    const float ny = sqrtf(ny2);
+    const float g_cut = p.g_la ? p.g_la[0] * p.scale : 0.f, g_ortho = p.g_lb ? p.g_lb[0] * p.scale : 0.f;
+    const float dd = p.den[b] + p.eps;
+    diag = -g_cut / dd;
+    const float coef = ny > 0.f ? g_ortho / (ny * n) : 0.f;
+    const float gq = gy / sq;
+    for (int i = threadIdx.x; i < K * K; i += T) {
+      const int r = i / K, c = i - r * K;
+      const float gij = G[i], gji = G[static_cast<int64_t>(c) * K + r];
+      const float dg = (r == c) ? t : 0.f;
+      const float wij = coef * ((gij / n - dg) - gij * gq), wji = coef * ((gji / n - dg) - gji * gq);
+      RS[i] = wij + wji;
+    }
+    if (threadIdx.x == 0 && p.c1) p.c1[b] = g_cut * tr / (dd * dd);
+  } else if (p.mode == 2) {
+    const float* G = p.gram + off;
+    const float loss = p.link_loss ? p.link_loss[0] : 0.f;
+    const float c = (p.g_la && loss > 0.f) ? p.link_scale * p.link_scale * p.g_la[0] / loss : 0.f;
+    diag = -c;
+    for (int i = threadIdx.x; i < K * K; i += T) RS[i] = 2.0f * c * G[i];
+  }
+  for (int i = threadIdx.x; i < K * K; i += T) {
+    const int r = i / K, c = i - r * K;
+    const int64_t tr_i = static_cast<int64_t>(c) * K + r;
+    float v = 0.f, vt = 0.f;
+    if (ga) { v += ga[i]; vt += ga[tr_i]; }
+    if (gb) { v += gb[i]; vt += gb[tr_i]; }
+    const float dg = (r == c) ? diag : 0.f;
+    RV[i] = v + dg;
+    RU[i] = vt + dg;
+  }
+  if (F > 0) {
+    const float* gx = p.g_x ? (p.gx_bcast ? p.g_x : p.g_x + static_cast<int64_t>(b) * K * F) : nullptr;
+    for (int i = threadIdx.x; i < F * K; i += T) {
+      const int f = i / K, k = i - f * K;
+      RX[i] = gx ? (p.gx_bcast ? gx[0] : gx[static_cast<int64_t>(k) * F + f]) : 0.f;
+    }
+  }
+}
+}  // namespace tgp
+
+extern "C" int tgp_mincut_terms_fused_f32(const float* raw, const float* gram, const float* deg, const float* q,
+                                          int64_t B, int64_t N, int64_t K, float eps, float* den, float* out,
+                                          void* stream_) {
+  TGP_REQUIRE(B >= 0 && N >= 0 && K >= 1 && K < 32768 && N < (1ll << 31), TGP_ERR_INVALID,
+              "tgp_mincut_terms_fused_f32: bad shape");
+  if (B == 0) return TGP_OK;
+  TGP_REQUIRE(raw && gram && den && out && (N == 0 || (deg && q)), TGP_ERR_INVALID,
+              "tgp_mincut_terms_fused_f32: null pointer");
+  TGP_REQUIRE(B < (1ll << 31), TGP_ERR_RANGE, "tgp_mincut_terms_fused_f32: too many graphs");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (K >= 64)
+    hipLaunchKernelGGL(mincut_tail2_kernel<1024>, dim3(static_cast<unsigned>(B)), dim3(1024), 0, stream, raw, gram, deg, q,
+                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out);
+  else
+    hipLaunchKernelGGL(mincut_tail2_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, raw, gram, deg, q,
+                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out);
+  return check_launch("tgp_mincut_terms_fused_f32");
+}
+
+extern "C" int tgp_dense_pool_train_rhs_f32(const float* g_raw_a, const float* g_raw_b, int mode, const float* raw,
+                                            const float* den, const float* gram, const float* g_la, const float* g_lb,
+                                            float scale, const float* link_loss, float link_scale, float eps,
+                                            const float* g_x, int gx_bcast, int64_t B, int64_t K, int64_t F, float* rcat,
+                                            float* c1, void* stream_) {
+  TGP_REQUIRE(B >= 0 && K >= 1 && K < 32768 && F >= 0 && F < (1ll << 24) && mode >= 0 && mode <= 2, TGP_ERR_INVALID,
+              "tgp_dense_pool_train_rhs_f32: bad shape or mode");
+  if (B == 0) return TGP_OK;
+  TGP_REQUIRE(rcat && B < (1ll << 31), TGP_ERR_INVALID, "tgp_dense_pool_train_rhs_f32: null output");
+  TGP_REQUIRE(mode != 1 || (raw && den && gram && c1), TGP_ERR_INVALID,
+              "tgp_dense_pool_train_rhs_f32: mode 1 needs raw, den, gram and c1");
+  TGP_REQUIRE(mode != 2 || gram, TGP_ERR_INVALID, "tgp_dense_pool_train_rhs_f32: mode 2 needs gram");
+  tgp::TrainRhsArgs a{g_raw_a, g_raw_b, raw, den, gram, g_la, g_lb, scale, link_loss, link_scale, eps, g_x, gx_bcast,
+                      static_cast<int>(K), static_cast<int>(F), mode, rcat, c1};
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (K >= 64) hipLaunchKernelGGL(train_rhs_kernel<1024>, dim3(static_cast<unsigned>(B)), dim3(1024), 0, stream, a);
+  else hipLaunchKernelGGL(train_rhs_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, a);
+  return check_launch("tgp_dense_pool_train_rhs_f32");
 }
 
 static int pair_dot(const int64_t* row, const int64_t* col, int64_t E, const float* S, const float* S2, int64_t K,

@@ -282,6 +282,46 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   }
 }
 
+// r6 (training step at C2 scale): the same softmax backward with the elementwise parts of the pooling step's gradient
+// folded in, so that they cost no pass of their own over [B,N,K]:
+//   dS_eff = dS + extra + 2 c1[graph] deg[row] S   (MinCut: gradient of den = trace(S^T D S), utils/losses.py:39-56)
+//                       - g_ent ent_scale (log(S + eps) + S / (S + eps))   (DiffPool's entropy loss, losses.py:476-483)
+// `extra` (optional): an upstream gradient of S itself (S used outside the pooler).  rows_per_graph = N of the padded batch.
+template <int G>
+__global__ __launch_bounds__(256) void softmax_bwd_ex_kernel(const float* __restrict__ s, const float* __restrict__ ds,
+                                                             const float* __restrict__ extra,
+                                                             const float* __restrict__ c1, const float* __restrict__ deg,
+                                                             long rows_per_graph, const float* __restrict__ ent_g,
+                                                             float ent_scale, float ent_eps, float* __restrict__ dy,
+                                                             long M, int K) {
+  const int sub = threadIdx.x % G;
+  const long m = static_cast<long>(blockIdx.x) * (256 / G) + threadIdx.x / G;
+  const bool ok = m < M;
+  const long base = (ok ? m : 0) * K;
+  const float* sr = s + base;
+  const float* dr = ds + base;
+  const float* er = extra ? extra + base : nullptr;
+  const float rowc = (ok && c1) ? 2.0f * c1[m / rows_per_graph] * deg[m] : 0.f;
+  const float ge = ent_g ? ent_g[0] * ent_scale : 0.f;
+  auto eff = [&](int k) -> float {
+    const float sv = sr[k];
+    float v = dr[k];
+    if (er) v += er[k];
+    if (c1) v = fmaf(rowc, sv, v);
+    if (ent_g) v -= ge * (logf(sv + ent_eps) + sv / (sv + ent_eps));
+    return v;
+  };
+  float dot = 0.f;
+  if (ok)
+    for (int k = sub; k < K; k += G) dot = fmaf(eff(k), sr[k], dot);
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+  if (ok) {
+    float* out = dy + m * K;
+    for (int k = sub; k < K; k += G) out[k] = sr[k] * (eff(k) - dot);
+  }
+}
+
 // ---- backward of the selector's last layer: one launch (+ a one-round combine of gW / gb) ------------------------------
 // Given S = softmax(X W^T + b) * mask and the upstream dS:   dY = S (dS - <dS, S>)   (rows of masked nodes: S = 0 -> 0),
 //   gX (+)= dY W      [M,F]        gW = dY^T X   [K,F]        gb = column sums of dY   [K]
@@ -574,6 +614,24 @@ extern "C" int tgp_softmax_bwd_f32(const float* s, const float* ds, float* dy, i
   else
     hipLaunchKernelGGL((softmax_bwd_kernel<64>), dim3(cdiv(M, 4)), dim3(256), 0, st, s, ds, dy, (long)M, (int)K);
   return check_launch("softmax_bwd_kernel");
+}
+
+extern "C" int tgp_softmax_bwd_ex_f32(const float* s, const float* ds, const float* extra, const float* c1,
+                                      const float* deg, int64_t rows_per_graph, const float* ent_g, float ent_scale,
+                                      float ent_eps, float* dy, int64_t M, int64_t K, void* stream_) {
+  TGP_REQUIRE(M >= 0 && K >= 1 && K < (1ll << 31), TGP_ERR_INVALID, "tgp_softmax_bwd_ex_f32: bad shape");
+  if (M == 0) return TGP_OK;
+  TGP_REQUIRE(s && ds && dy && (!c1 || (deg && rows_per_graph > 0)), TGP_ERR_INVALID,
+              "tgp_softmax_bwd_ex_f32: null pointer");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int k = static_cast<int>(K);
+  if (K <= 16)
+    hipLaunchKernelGGL(softmax_bwd_ex_kernel<16>, dim3(cdiv(M, 16)), dim3(256), 0, stream, s, ds, extra, c1, deg,
+                       static_cast<long>(rows_per_graph), ent_g, ent_scale, ent_eps, dy, static_cast<long>(M), k);
+  else
+    hipLaunchKernelGGL(softmax_bwd_ex_kernel<64>, dim3(cdiv(M, 4)), dim3(256), 0, stream, s, ds, extra, c1, deg,
+                       static_cast<long>(rows_per_graph), ent_g, ent_scale, ent_eps, dy, static_cast<long>(M), k);
+  return check_launch("tgp_softmax_bwd_ex_f32");
 }
 
 extern "C" int tgp_mlp_select_bwd_fits(int64_t F, int64_t K) { return K >= 1 && K <= 32 && F >= 1 && F <= 64; }

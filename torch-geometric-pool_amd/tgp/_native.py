@@ -157,6 +157,15 @@ SIGNATURES = {
     "tgp_entropy_sum_f32": (_c_int, [_c_p, _c_i64, _c_f, _c_p, _c_p, _c_sz, _c_p]),
     "tgp_cut_terms_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "tgp_mincut_loss_terms_bwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_f, _c_p, _c_p, _c_p, _c_p]),
+    "tgp_dense_pool_train_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64]),
+    "tgp_dense_pool_train_fwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_i64,
+                                              _c_p, _c_p, _c_p, _c_p, _c_p, _c_sz, _c_p]),
+    "tgp_mincut_terms_fused_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_f, _c_p, _c_p, _c_p]),
+    "tgp_dense_pool_train_rhs_f32": (_c_int, [_c_p, _c_p, _c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_p, _c_f, _c_f,
+                                              _c_p, _c_int, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
+    "tgp_softmax_bwd_ex_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_f, _c_f, _c_p, _c_i64, _c_i64,
+                                        _c_p]),
+    "tgp_copy_cols2_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "tgp_mincut_loss_terms_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_f, _c_p, _c_p]),
     "tgp_rowptr_from_sorted_flag_i64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_rowptr_from_sorted_i64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p]),

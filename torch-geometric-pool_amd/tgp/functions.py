@@ -880,6 +880,133 @@ def select_pool_small(x: Tensor, adj: Tensor, weight: Tensor, bias: Optional[Ten
     return out[0], out[1], out[2], out[3], pair, (out[8] if want_batch else None)
 
 
+# ----------------------------------------- the dense poolers' training step beyond the one-wave kernels (r6)
+class _PoolLargeFn(torch.autograd.Function):
+    """Select (optional) + Reduce + Connect + post-processing + the pooler's two auxiliary losses of a padded batch whose
+    graphs are too large for the one-wave / one-workgroup kernels (C2: 32 x 1024 nodes, K = 128), as ONE autograd node
+    (reference poolers/mincut.py:220-237, diffpool.py:208-218 under ATen autograd; harness
+    examples/time_and_mem_test.py:396-401).  The operator-by-operator graph ran 65-71 launches per step there.
+
+    forward  (mode 1 = MinCut, 2 = DiffPool, 0 = no losses):
+        [S = softmax(X W^T + b) mask]            tgp_mlp_select_f32            (selector form only)
+        U = A S -> acat[:, :, :K]; S^T [U | X | S] -> raw, x_pool, gram; adj_pool     tgp_dense_pool_train_fwd_f32 (3 launches)
+        MinCut: deg, q (one pass over A), den + both per-graph terms, batch means    3 launches
+        DiffPool: link residual in the GEMM epilogue, entropy partials, tail         4 launches
+    backward: with gR = the gradient of raw (post-processing backward + upstream + the loss' diagonal term)
+        gS = [U | V | X | S] [gR^T ; gR ; g_x'^T ; RS]          ONE GEMM over the operand buffer acat [B,N,3K+F]
+             (V = A^T S is written into its column block by the one N^2 K product of the backward; X and S are copied
+             into theirs by one launch; RS = W + W^T (MinCut's orthogonality term) or 2 c G (DiffPool's link term), the
+             -c I / -(g_cut / den) I terms sit on the diagonals of the first two blocks: tgp_dense_pool_train_rhs_f32)
+        selector form: dY = softmax backward of gS + 2 c1 D S (MinCut) - g_ent (log S + ...) (DiffPool) in one launch,
+             gX = S g_x' + dY W (two products, the second accumulating), gW = dY^T X, gb = column sums of dY.
+    The adjacency gets no gradient (callers check); edge_weight_norm is not differentiated here (callers check)."""
+
+    @staticmethod
+    def forward(ctx, x, adj, weight, bias, mask, s_given, flags, mode, scales, graph_sizes):
+        from . import _native as N
+        ctx.set_materialize_grads(False)
+        xd = N.f32c(x.detach())
+        B, Nn, F = xd.shape
+        selector = s_given is None
+        if selector:
+            s = K.mlp_select(xd, weight.detach(), None if bias is None else bias.detach(), mask)
+        else:
+            s = N.f32c(s_given.detach())
+        Kc = s.size(-1)
+        ad = adj.detach()
+        mem, tflag = K._dense_adj_layout(ad)
+        acat = torch.empty(B, Nn, 3 * Kc + F, dtype=torch.float32, device=xd.device)
+        x_pool, raw, adj_pool, gram = K.dense_pool_train_fwd(s, mem, xd, flags | tflag, acat, want_gram=mode != 0)
+        empty = s.new_empty(0)
+        la, lb = s.new_empty(0), s.new_empty(0)  # (distinct objects: both are outputs of this node)
+        deg = den = lossv = None
+        if mode == 1:
+            deg, q = K.cut_rows(ad, s, graph_sizes)
+            den, terms = K.mincut_terms_fused(raw, gram, deg, q)
+            both = terms.mean(dim=1)
+            la, lb = both[0], both[1]
+        elif mode == 2:
+            lossv = K.diffpool_loss_tail(s, ad, graph_sizes, scales[0], scales[1])
+            la, lb = lossv[0], lossv[1]
+        keep = [t if t is not None else empty for t in (gram, deg, den, lossv)]
+        ctx.save_for_backward(s, mem, xd, empty if weight is None else weight, acat, raw, *keep)
+        ctx.flags, ctx.tflag, ctx.mode, ctx.scales, ctx.selector = flags, tflag, mode, scales, selector
+        ctx.has_bias = bias is not None
+        if mode == 0:
+            ctx.mark_non_differentiable(la, lb)
+        if selector:
+            return s, x_pool, raw, adj_pool, la, lb
+        no_s = s.new_empty(0)
+        ctx.mark_non_differentiable(no_s)
+        return no_s, x_pool, raw, adj_pool, la, lb
+
+    @staticmethod
+    def backward(ctx, g_s, g_xp, g_raw, g_adj, g_la, g_lb):
+        from . import _native as N
+        s, mem, xd, weight, acat, raw, gram, deg, den, lossv = ctx.saved_tensors
+        B, Nn, Kc = s.shape
+        F = xd.size(2)
+        mode, selector = ctx.mode, ctx.selector
+        dev = s.device
+        if mode == 0:
+            g_la = g_lb = None
+        want_gx = ctx.needs_input_grad[0]
+        nothing = (None,) * 10
+        if g_s is None and g_xp is None and g_raw is None and g_adj is None and g_la is None and g_lb is None:
+            return nothing
+        ga = None
+        if g_adj is not None:
+            ga = K.postprocess_dense_bwd(raw, g_adj, ctx.flags)
+            if ga is None:
+                raise RuntimeError("dense pooling backward: K > 4096 is not supported by the post-processing backward")
+        gb = None if g_raw is None else N.f32c(g_raw)
+        gx_t, gx_bc = K._bcast_or_dense(g_xp, (B, Kc, F))
+        link_loss = lossv[0:1] if mode == 2 else None
+        rcat, c1 = K.dense_pool_train_rhs(ga, gb, mode, raw if mode == 1 else None, den if mode == 1 else None,
+                                          gram if mode else None, g_la, g_lb if mode == 1 else None, 1.0 / B, link_loss,
+                                          ctx.scales[0] if mode == 2 else 0.0, gx_t, gx_bc, B, Kc, F, dev)
+        # V = A^T S into its column block (mem holds A, or A^T when tflag), then X and S into theirs
+        K.bmm_into(mem, s, acat[:, :, Kc:2 * Kc], trans_a=not ctx.tflag)
+        ld = 3 * Kc + F
+        K.copy_cols2(xd.view(B * Nn, F), s.view(B * Nn, Kc), acat.view(B * Nn, ld), 2 * Kc, 2 * Kc + F)
+        kd = ld if mode else 2 * Kc + F
+        gs = torch.empty(B, Nn, Kc, dtype=torch.float32, device=dev)
+        K.bmm_into(acat[:, :, :kd], rcat[:, :kd, :], gs)
+        ent_g = g_lb if mode == 2 else None
+        gxd = None
+        if want_gx and g_xp is not None:
+            gxd = K.bmm(s, g_xp.contiguous() if gx_bc else gx_t)
+        if not selector:
+            if mode == 1 and c1 is not None:
+                gs.addcmul_((2.0 * c1).view(-1, 1, 1) * deg.unsqueeze(-1), s)
+            if ent_g is not None:
+                gs += K.entropy_bwd(s, ent_g, ctx.scales[1])
+            return (gxd, None, None, None, None, gs, None, None, None, None)
+        dy = K.softmax_bwd_ex(s, gs, extra=g_s, c1=c1 if mode == 1 else None, deg=deg if mode == 1 else None,
+                              ent_g=ent_g, ent_scale=ctx.scales[1] if mode == 2 else 0.0)
+        dy2 = dy.view(B * Nn, Kc)
+        gw = gbias = None
+        if want_gx:
+            if gxd is None:
+                gxd = K.bmm(dy2, weight).view(B, Nn, F)
+            else:
+                K.bmm(dy2, weight, accumulate_into=gxd.view(1, B * Nn, F))
+        if ctx.needs_input_grad[2]:
+            gw = _tall_skinny_tn(dy2, xd.view(B * Nn, F))
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            gbias = dy2.sum(0)
+        return (gxd, None, gw, gbias, None, None, None, None, None, None)
+
+
+def pool_large(x: Tensor, adj: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], mask: Optional[Tensor],
+               s: Optional[Tensor], flags: int, mode: int, scales=(0.0, 0.0), graph_sizes: Optional[Tensor] = None):
+    """(s, x_pool, raw, adj_pool, LossPair or None): see :class:`_PoolLargeFn`.  Give either the selector's single Linear
+    (``weight`` [K,F], ``bias``, ``mask``: S is formed inside and returned) or ``s`` itself."""
+    out = _PoolLargeFn.apply(x, adj, weight, bias, mask, s, flags, mode, tuple(scales), graph_sizes)
+    pair = LossPair((out[4], out[5])) if mode else None
+    return (out[0] if s is None else s), out[1], out[2], out[3], pair
+
+
 class ASProducts:
     """U = A S and V = A^T S of one (S, A) pair, computed at most once.  DiffPool's training step needs U in the
     Connect forward, U and V in its backward and both again in the link-prediction loss' backward

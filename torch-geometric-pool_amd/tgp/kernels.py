@@ -1351,6 +1351,124 @@ def cut_terms(adj: Tensor, s: Tensor, graph_sizes: Optional[Tensor] = None) -> T
     return deg, q, den
 
 
+def cut_rows(adj: Tensor, s: Tensor, graph_sizes: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """(deg [B,N], q [B,N]) of :func:`cut_terms` without the per-graph dot product (one launch: the training step's fused
+    loss tail forms den itself, :func:`mincut_terms_fused`)."""
+    dev = N.require_device(adj, s)
+    adj, s = N.f32c(adj), N.f32c(s)
+    B, Nn, K = s.shape
+    if adj.shape != (B, Nn, Nn):
+        raise ValueError(f"adj {tuple(adj.shape)} does not match s {tuple(s.shape)}")
+    deg = torch.empty(B, Nn, dtype=torch.float32, device=dev)
+    q = torch.empty(B, Nn, dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_cut_terms_f32(N.ptr(adj), N.ptr(s), B, Nn, K, N.ptr(_sizes_arg(graph_sizes, B, dev)), N.ptr(deg),
+                                      N.ptr(q), None, N.stream_ptr(dev)), "tgp_cut_terms_f32")
+    return deg, q
+
+
+def mincut_terms_fused(raw: Tensor, gram: Tensor, deg: Tensor, q: Tensor) -> Tuple[Tensor, Tensor]:
+    """(den [B], terms [2,B]): MinCut's per-graph loss tails with den = sum_i deg_i q_i formed in the same launch
+    (utils/losses.py:39-70)."""
+    dev = N.require_device(raw, gram, deg, q)
+    raw, gram, deg, q = N.f32c(raw), N.f32c(gram), N.f32c(deg), N.f32c(q)
+    B, Kc, Nn = raw.size(0), raw.size(-1), deg.size(-1)
+    den = torch.empty(B, dtype=torch.float32, device=dev)
+    out = torch.empty(2, B, dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_mincut_terms_fused_f32(N.ptr(raw), N.ptr(gram), N.ptr(deg), N.ptr(q), B, Nn, Kc, losses_eps(),
+                                               N.ptr(den), N.ptr(out), N.stream_ptr(dev)), "tgp_mincut_terms_fused_f32")
+    return den, out
+
+
+def dense_pool_train_fwd(s: Tensor, adj_mem: Tensor, x: Tensor, flags: int, acat: Tensor, want_gram: bool,
+                         want_post: bool = True):
+    """(x_pool, raw, adj_pool, gram): forward of the dense poolers' training step beyond the one-wave kernels
+    (base_reduce.py:158-161, dense_conn.py:111-122, utils/ops.py:282-335).  ``adj_mem`` is the contiguous adjacency
+    memory (``flags`` carries ``ADJ_TRANSPOSED`` when it holds A^T), ``acat`` [B,N,3K+F] the operand buffer of the
+    backward whose first K columns receive U = A S; ``gram`` = S^T S when asked for."""
+    dev = N.require_device(s, adj_mem, x, acat)
+    B, Nn, Kc = s.shape
+    F = x.size(2)
+    ld = acat.size(2)
+    if (adj_mem.shape != (B, Nn, Nn) or x.shape[:2] != (B, Nn) or acat.shape[:2] != (B, Nn) or ld < Kc
+            or not (s.is_contiguous() and adj_mem.is_contiguous() and x.is_contiguous() and acat.is_contiguous())):
+        raise ValueError("dense_pool_train_fwd: inconsistent shapes or non-contiguous operands")
+    x_pool = torch.empty(B, Kc, F, dtype=torch.float32, device=dev)
+    raw = torch.empty(B, Kc, Kc, dtype=torch.float32, device=dev)
+    adj_pool = torch.empty(B, Kc, Kc, dtype=torch.float32, device=dev) if want_post else None
+    gram = torch.empty(B, Kc, Kc, dtype=torch.float32, device=dev) if want_gram else None
+    L = N.lib()
+    ws = N.workspace(L.tgp_dense_pool_train_workspace_bytes(B, Nn, Kc, F), dev)
+    N.check(L.tgp_dense_pool_train_fwd_f32(N.ptr(s), N.ptr(adj_mem), N.ptr(x), B, Nn, Kc, F, flags, ops_eps(),
+                                           N.ptr(acat), ld, N.ptr(x_pool), N.ptr(raw), N.ptr(adj_pool), N.ptr(gram),
+                                           N.ptr(ws), ws.numel(), N.stream_ptr(dev)), "tgp_dense_pool_train_fwd_f32")
+    return x_pool, raw, adj_pool, gram
+
+
+def dense_pool_train_rhs(g_raw_a: Optional[Tensor], g_raw_b: Optional[Tensor], mode: int, raw: Optional[Tensor],
+                         den: Optional[Tensor], gram: Optional[Tensor], g_la: Optional[Tensor], g_lb: Optional[Tensor],
+                         scale: float, link_loss: Optional[Tensor], link_scale: float, g_x: Optional[Tensor],
+                         gx_bcast: bool, B: int, Kc: int, F: int, dev):
+    """(rcat [B,3K+F,K], c1 [B] or None): the right-hand sides [RU ; RV ; RX ; RS] of the training step's backward GEMM
+    (see tgp_dense_pool_train_rhs_f32 in include/tgp_hip.h)."""
+    rcat = torch.empty(B, 3 * Kc + F, Kc, dtype=torch.float32, device=dev)
+    c1 = torch.empty(B, dtype=torch.float32, device=dev) if mode == 1 else None
+    N.check(N.lib().tgp_dense_pool_train_rhs_f32(N.ptr(g_raw_a), N.ptr(g_raw_b), mode, N.ptr(raw), N.ptr(den),
+                                                 N.ptr(gram), N.ptr(g_la), N.ptr(g_lb), float(scale), N.ptr(link_loss),
+                                                 float(link_scale), losses_eps(), N.ptr(g_x), 1 if gx_bcast else 0, B,
+                                                 Kc, F, N.ptr(rcat), N.ptr(c1), N.stream_ptr(dev)),
+            "tgp_dense_pool_train_rhs_f32")
+    return rcat, c1
+
+
+def softmax_bwd_ex(s: Tensor, ds: Tensor, extra: Optional[Tensor] = None, c1: Optional[Tensor] = None,
+                   deg: Optional[Tensor] = None, ent_g: Optional[Tensor] = None, ent_scale: float = 0.0) -> Tensor:
+    """:func:`softmax_bwd` on dS + extra + 2 c1[graph] deg[row] S - ent_g ent_scale (log(S + eps) + S / (S + eps)):
+    the elementwise parts of the pooling step's gradient folded into the selector's softmax backward.  s [B,N,K]."""
+    dev = N.require_device(s, ds)
+    B, Nn, Kc = s.shape
+    s2, d2 = N.f32c(s), N.f32c(ds)
+    ex = None if extra is None else N.f32c(extra)
+    if d2.numel() != s2.numel() or (ex is not None and ex.numel() != s2.numel()):
+        raise ValueError("softmax_bwd_ex: gradient shapes do not match s")
+    out = torch.empty_like(s2)
+    N.check(N.lib().tgp_softmax_bwd_ex_f32(N.ptr(s2), N.ptr(d2), N.ptr(ex), N.ptr(None if c1 is None else N.f32c(c1)),
+                                           N.ptr(None if deg is None else N.f32c(deg)), Nn,
+                                           N.ptr(None if ent_g is None else N.f32c(ent_g.reshape(1))), float(ent_scale),
+                                           losses_eps(), N.ptr(out), B * Nn, Kc, N.stream_ptr(dev)),
+            "tgp_softmax_bwd_ex_f32")
+    return out
+
+
+def copy_cols2(a: Tensor, b: Tensor, dst: Tensor, col_a: int, col_b: int) -> None:
+    """dst[:, col_a:col_a+wa] = a, dst[:, col_b:col_b+wb] = b for row-major 2-D float32 tensors, one launch."""
+    dev = N.require_device(a, b, dst)
+    if not (a.is_contiguous() and b.is_contiguous() and dst.is_contiguous()) or a.size(0) != dst.size(0) \
+            or b.size(0) != dst.size(0):
+        raise ValueError("copy_cols2: operands must be contiguous with equal row counts")
+    N.check(N.lib().tgp_copy_cols2_f32(N.ptr(a), a.size(1), N.ptr(b), b.size(1), dst.size(0), N.ptr(dst), dst.size(1),
+                                       col_a, col_b, N.stream_ptr(dev)), "tgp_copy_cols2_f32")
+
+
+def bmm_into(a: Tensor, b: Tensor, out: Tensor, trans_a: bool = False, accumulate: bool = False) -> Tensor:
+    """out[g] (+)= op(a[g]) @ b[g] for float32 3-D VIEWS: any batch / row strides, unit stride along the last dimension
+    (column blocks of a wider buffer: no copies in, no copy out)."""
+    dev = N.require_device(a, b, out)
+    for t in (a, b, out):
+        if t.dim() != 3 or t.dtype != torch.float32 or t.stride(2) != 1:
+            raise ValueError("bmm_into: float32 3-D views with unit last stride expected")
+    G = out.size(0)
+    Kd, M = (a.size(1), a.size(2)) if trans_a else (a.size(2), a.size(1))
+    Nc = b.size(2)
+    if b.size(1) != Kd or out.shape[1:] != (M, Nc) or a.size(0) not in (1, G) or b.size(0) not in (1, G):
+        raise ValueError(f"bmm_into: shapes {tuple(a.shape)} x {tuple(b.shape)} -> {tuple(out.shape)}")
+    sA = 0 if a.size(0) == 1 else a.stride(0)
+    sB = 0 if b.size(0) == 1 else b.stride(0)
+    fn = N.lib().tgp_bmm_accumulate_f32 if accumulate else N.lib().tgp_bmm_f32
+    N.check(fn(a.data_ptr(), b.data_ptr(), out.data_ptr(), G, M, Nc, Kd, 1 if trans_a else 0, a.stride(1), b.stride(1),
+               out.stride(1), sA, sB, out.stride(0), N.stream_ptr(dev)), "tgp_bmm_f32")
+    return out
+
+
 def mincut_loss_terms(raw: Tensor, den: Tensor, gram: Tensor) -> Tensor:
     """[2,B]: per-graph -trace(raw)/(den + eps) and ||G/||G|| - I/sqrt(K)||_F (utils/losses.py:39-70), one launch."""
     dev = N.require_device(raw, den, gram)

@@ -373,6 +373,50 @@ class _DenseMLPPooling(DenseSRCPooling):
             fused = fused + (pair,)
         return so, fused, bp
 
+    def _select_reduce_connect_large(self, x, adj, mask, graph_sizes, so=None):
+        """Training on a padded batch whose graphs are beyond the one-wave kernels (C2-sized), r6: Select (single-Linear
+        selector; otherwise ``so`` holds S) + Reduce + Connect + post-processing + the pooler's two losses as ONE
+        autograd node (functions._PoolLargeFn: ~10 forward and ~13 backward launches where the operator-by-operator graph
+        ran 65-71).  Returns ``(SelectOutput, fused, None)`` like :meth:`_select_reduce_connect_train`, or None."""
+        from .. import functions as Fn, kernels as K
+        sel, c = self.selector, self.connector
+        if (not _FOLD_TRAINING or type(c) is not DenseConnect or type(self.reducer) is not BaseReduce
+                or not (isinstance(x, Tensor) and isinstance(adj, Tensor)) or x.dim() != 3 or adj.dim() != 3
+                or not x.is_cuda or x.dtype != torch.float32 or adj.dtype != torch.float32
+                or (mask is not None and mask.dtype != torch.bool) or not torch.is_grad_enabled()
+                or adj.requires_grad or c.edge_weight_norm or adj.shape != (x.size(0), x.size(1), x.size(1))
+                or x.size(0) == 0 or x.size(1) == 0 or x.size(2) == 0):
+            return None
+        lins = getattr(getattr(sel, "mlp", None), "lins", None)
+        weight = bias = s = None
+        if so is None:
+            if type(sel) is not MLPSelect or lins is None or len(lins) != 1 or lins[0].weight.dtype != torch.float32:
+                return None
+            weight, bias = lins[0].weight, lins[0].bias
+            k = weight.size(0)
+            if not (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+                return None
+        else:
+            s = so.s
+            if not (isinstance(s, Tensor) and s.dim() == 3 and s.dtype == torch.float32 and s.is_cuda
+                    and s.shape[:2] == x.shape[:2] and (s.requires_grad or x.requires_grad)):
+                return None
+            k = s.size(2)
+        if k == 0 or k > 4096 or K.dense_pool_is_small(x.size(0), x.size(1), k, x.size(2)):
+            return None
+        flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
+        mode, scales = (1, (0.0, 0.0)) if self._loss_needs_raw else (0, (0.0, 0.0))
+        if not self._loss_needs_raw:
+            diff_scales = self._fused_diff_scales(adj, mask)
+            if diff_scales is None:
+                return None
+            mode, scales = 2, diff_scales
+        s_out, x_pool, raw, adj_pool, pair = Fn.pool_large(x, adj, weight, bias, mask, s, flags, mode, scales, graph_sizes)
+        if so is None:
+            so = SelectOutput(s=s_out, s_inv_op=sel.s_inv_op, in_mask=mask)
+        fused = (x_pool, raw if self._loss_needs_raw else None, adj_pool, pair)
+        return so, fused, None
+
     def _sizes_for(self, adj):
         """Real nodes per graph of the zero-padded batch ``adj`` belongs to, if forward() densified it itself."""
         hint = getattr(self, "_sizes_hint", None)
@@ -424,6 +468,8 @@ class _DenseMLPPooling(DenseSRCPooling):
             folded = self._select_reduce_connect(x, adj, mask, want_bp)
             if folded is None and _FOLD_TRAINING:
                 folded = self._select_reduce_connect_train(x, adj, mask, graph_sizes, want_bp)
+            if folded is None and _FOLD_TRAINING:  # graphs beyond the one-wave kernels: one autograd node as well (r6)
+                folded = self._select_reduce_connect_large(x, adj, mask, graph_sizes)
             so = folded[0] if folded is not None else self.select(x=x, mask=mask)
             self._sizes_hint = None
             if graph_sizes is not None and graph_sizes.numel() == x.size(0):
@@ -433,6 +479,10 @@ class _DenseMLPPooling(DenseSRCPooling):
             fused = folded[1] if folded is not None else self.reduce_connect(
                 x, adj, so, want_raw=self._loss_needs_raw, want_mincut_terms=self._loss_needs_raw,
                 want_diff_losses=diff_scales)
+            if fused is None and _FOLD_TRAINING:  # a selector with hidden layers made S: the pooling step is one node still
+                big = self._select_reduce_connect_large(x, adj, mask, graph_sizes, so=so)
+                if big is not None:
+                    fused = big[1]
             if fused is not None:  # Reduce + Connect in one native call (training: batches of small graphs only)
                 x_pool, raw, adj_pool = fused[:3]
                 if folded is not None and folded[2] is not None:
