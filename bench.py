@@ -29,7 +29,8 @@ Secondary lines ({"secondary": name, ...}): the other north_star workloads, each
                    ranks: + variable-size RCCL all-gather) and their *_fresh twins (NEW tensor objects every step, as a
                    DataLoader's mini-batches: the per-tensor memos miss), e2e_diff_c2 / e2e_mincut_c3 (WHOLE pooler forwards on sparse
                    inputs, eager and HIP-graph replayed, launches per forward), e2e_train_mincut_c3 / e2e_train_topk_c3
-                   (a whole MinCut / TopK training step, forward + backward, launches per step).  With N > 1 only the graph-sharded
+                   (a whole MinCut / TopK training step, forward + backward, launches per step), e2e_train_mincut_c2 /
+                   e2e_train_diff_c2 (the same at the headline shape, 32 x 1024 nodes, K = 128).  With N > 1 only the graph-sharded
                    ones run; one giant graph (C4) does not shard.
 `--workload X` makes X the headline of the line instead; the driver's line is the default c2.
 """
@@ -484,25 +485,31 @@ class PoolerTrainStep(Workload):
     launches per step; what a user's step costs."""
     shards = True
 
-    def __init__(self, ctx, alias="mincut"):
+    def __init__(self, ctx, alias="mincut", scale="c3"):
         from tgp.poolers import get_pooler
         dev = ctx.dev
         torch.manual_seed(ctx.rank)
-        self.alias = alias
-        self.B, self.N, self.K, self.F = 2048, 60, 20, 32
-        self.x, self.ei, self.batch = sparse_batch(_proteins_sizes(ctx.rank), 4, self.F, dev, seed=ctx.rank)
+        self.alias, self.scale = alias, scale
+        if scale == "c2":  # the headline shape: 32 graphs x 1024 nodes, K = 128, F = 64 (r6: one autograd node there too)
+            self.B, self.N, self.K, self.F = 32, 1024, 128, 64
+            sizes, deg = [1024] * 32, 10
+            shape = "32 graphs x 1024 nodes, K=128, F=64"
+        else:
+            self.B, self.N, self.K, self.F = 2048, 60, 20, 32
+            sizes, deg = _proteins_sizes(ctx.rank), 4
+            shape = "2048 graphs n~U[20,60], " + ("K=20, " if alias != "topk" else "ratio 0.5, ") + "F=32"
+        self.x, self.ei, self.batch = sparse_batch(sizes, deg, self.F, dev, seed=ctx.rank)
         self.x.requires_grad_(True)
-        kw = dict(k=self.K) if alias == "mincut" else dict(ratio=0.5)
+        kw = dict(k=self.K) if alias != "topk" else dict(ratio=0.5)
         self.pooler = get_pooler(alias, in_channels=self.F, **kw).to(dev).train()
         self.nodes = self.x.size(0)
-        self.name = (f"get_pooler('{alias}') whole TRAINING step (forward + backward) on sparse inputs: 2048 graphs "
-                     "n~U[20,60], " + ("K=20, " if alias == "mincut" else "ratio 0.5, ") + "F=32")
+        self.name = f"get_pooler('{alias}') whole TRAINING step (forward + backward) on sparse inputs: {shape}"
         self.extra = {"nodes_counted": "real input nodes per step", "edges": int(self.ei.size(1)),
                       "step": "forward + loss + backward to x and the selector's parameters, eager"}
 
     def _loss(self, out):
-        if self.alias == "mincut":
-            return out.x.sum() + out.edge_index.sum() + out.loss["cut_loss"] + out.loss["ortho_loss"]
+        if self.alias in ("mincut", "diff"):
+            return out.x.sum() + out.edge_index.sum() + sum(out.loss.values())
         return out.x.square().sum()
 
     def step(self):
@@ -515,6 +522,17 @@ class PoolerTrainStep(Workload):
     def rooflines(self, dev):
         B, N, K, F = self.B, self.N, self.K, self.F
         ms = event_time_ms(self.step, 50, dev)
+        if self.scale == "c2":
+            # the N^2 K products the step needs: U = A S (forward), V = A^T S (backward; not for a symmetric A, which the
+            # pooler detects), DiffPool's link residual S S^T; + the K-sized products of both directions
+            big = 2.0 * B * N * N * K
+            small = 2.0 * B * N * K * (2 * K + F) + 2.0 * B * N * K * (3 * K + F) + 4.0 * B * N * K * F + 2.0 * B * N * F * K
+            flops = big * (2 if self.alias == "diff" else 1) + small
+            r = roof_mfma("whole training step (all kernels of forward + backward, eager)", flops, ms)
+            r["launches_per_step"] = count_kernels(self.step)
+            from tgp import functions as Fn
+            r["backward_route"] = dict(Fn.POOL_LARGE_STATS)
+            return self._graphed(r, dev)
         if self.alias == "mincut":
             # forward traffic (as e2e_mincut_c3) + backward: A, S, X read again, gS, gX and the dense gradients written / read
             fwd = (self.ei.size(1) * 16.0 + self.nodes * F * 4.0 + 2 * 4.0 * B * N * N + 2 * 4.0 * B * N * (F + K)
@@ -530,8 +548,12 @@ class PoolerTrainStep(Workload):
         r["launches_per_step"] = count_kernels(self.step)
         if self.alias != "mincut":
             return r  # (the sparse selection waits for its counts on the host: not capturable)
-        try:  # the same step with forward and backward replayed from HIP graphs (torch.cuda.make_graphed_callables)
-            pooler, ei, batch = self.pooler, self.ei, self.batch
+        return self._graphed(r, dev)
+
+    def _graphed(self, r, dev):
+        """The same step with forward and backward replayed from HIP graphs (torch.cuda.make_graphed_callables)."""
+        try:
+            pooler, ei, batch, loss_of = self.pooler, self.ei, self.batch, self._loss
 
             class Step(torch.nn.Module):
                 def __init__(self):
@@ -539,8 +561,7 @@ class PoolerTrainStep(Workload):
                     self.pooler = pooler
 
                 def forward(self, x):
-                    out = self.pooler(x=x, adj=ei, batch=batch)
-                    return out.x.sum() + out.edge_index.sum() + out.loss["cut_loss"] + out.loss["ortho_loss"]
+                    return loss_of(self.pooler(x=x, adj=ei, batch=batch))
 
             xg = self.x.detach().clone().requires_grad_(True)
             graphed = torch.cuda.make_graphed_callables(Step(), (xg,), num_warmup_iters=3)
@@ -946,8 +967,9 @@ def make_workload(which, ctx, args):
         return GraclusC4(ctx, unsorted_edges=args.unsorted_edges)
     if which in ("e2e_diff_c2", "e2e_mincut_c3"):
         return PoolerForward(which, ctx)
-    if which in ("e2e_train_mincut_c3", "e2e_train_topk_c3"):
-        return PoolerTrainStep(ctx, alias="mincut" if which == "e2e_train_mincut_c3" else "topk")
+    if which in ("e2e_train_mincut_c3", "e2e_train_topk_c3", "e2e_train_mincut_c2", "e2e_train_diff_c2"):
+        _, _, alias, scale = which.split("_")
+        return PoolerTrainStep(ctx, alias=alias, scale=scale)
     if which in ("topk_batch", "graclus_batch", "topk_batch_fresh", "graclus_batch_fresh"):
         return TopkBatch(ctx, force_collective=os.environ.get("TGP_BENCH_FORCE_DIST") == "1", unfused=args.unfused,
                          which=which)
@@ -1128,12 +1150,12 @@ def write_detail(line, secondary):
 # ------------------------------------------------------------------------------------------------ main
 ALL = ["c2", "c2_f64", "c5", "c3", "c4_graclus", "c4_ndp", "topk1m", "topk_connect", "topk_batch", "graclus_batch",
        "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3",
-       "e2e_train_topk_c3"]
+       "e2e_train_topk_c3", "e2e_train_mincut_c2", "e2e_train_diff_c2"]
 SECONDARY_DEFAULT = ["c5", "c2_f64", "topk1m", "topk_connect", "c4_graclus", "c4_ndp", "c3", "topk_batch", "graclus_batch",
                      "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2", "e2e_mincut_c3", "e2e_train_mincut_c3",
-                     "e2e_train_topk_c3"]
+                     "e2e_train_topk_c3", "e2e_train_mincut_c2", "e2e_train_diff_c2"]
 SHARDED = ("c5", "c2_f64", "c3", "topk_batch", "graclus_batch", "topk_batch_fresh", "graclus_batch_fresh", "e2e_diff_c2",
-           "e2e_mincut_c3", "e2e_train_mincut_c3", "e2e_train_topk_c3")
+           "e2e_mincut_c3", "e2e_train_mincut_c3", "e2e_train_topk_c3", "e2e_train_mincut_c2", "e2e_train_diff_c2")
 
 
 def main():

@@ -622,39 +622,53 @@ int tgp_mincut_loss_terms_bwd_f32(const float* raw, const float* den, const floa
  * reference gets from ATen autograd over poolers/mincut.py:220-237 / diffpool.py:208-218 (harness:
  * examples/time_and_mem_test.py:396-401).
  *
+ * The operand buffer of the backward, acat [B][N][3K+F+4], has the column blocks  [U | X | 1 0 0 0 | S | V]:
+ *   gS = acat [RU ; RX ; 0 ; RS ; RV]  is ONE product; for a symmetric A (V = U) its first 2K+F+4 columns / rows suffice
+ *   and V is never formed; dY^T [X | 1 0 0 0] is the selector's weight AND bias gradient; dY is written over the V block,
+ *   which lies behind S, so gX = [S | dY] [g_x ; W] is one product as well.
+ *
  * tgp_dense_pool_train_fwd_f32: tgp_dense_pool_f32's three launches (U = A S; S^T [U | X | S] split over N; slab
- *   combine + post-processing), with U written where the caller says -- row stride ldu >= K: column block 0 of the
- *   [B,N,3K+F] operand buffer [U | V | X | S] the backward's single GEMM reads -- and, when `gram` is not NULL,
- *   G = S^T S [B,K,K] as a third right-hand side of the second product.  adj_raw is required, adj_pool optional;
- *   flags as tgp_dense_pool_f32 (TGP_ADJ_TRANSPOSED: A is stored transposed).
+ *   combine + post-processing), with U written where the caller says -- row stride ldu >= K: column block 0 of acat --
+ *   and, when `gram` is not NULL, G = S^T S [B,K,K] as a third right-hand side of the second product.  adj_raw is
+ *   required, adj_pool optional; flags as tgp_dense_pool_f32 (TGP_ADJ_TRANSPOSED: A is stored transposed).
  * tgp_mincut_terms_fused_f32: MinCut's per-graph loss tails out [2,B] (as tgp_mincut_loss_terms_f32) with
- *   den[b] = sum_i deg[b,i] q[b,i] formed in the same launch (deg, q [B,N] from tgp_cut_terms_f32) and kept for the backward.
- * tgp_dense_pool_train_rhs_f32: the K-sized right-hand sides of  gS = [U | V | X | S] [RU ; RV ; RX ; RS]  into
- *   rcat [B][3K+F][K]: with gR = g_raw_a + g_raw_b (either may be NULL) + the loss' diagonal term,
- *   RV = gR, RU = gR^T, RX = g_x^T (g_x [B,K,F], or one value when gx_bcast), RS by mode:
- *   0: not written (the caller multiplies the first 2K+F rows only);
- *   1 (MinCut): RS = W + W^T, gR -= (g_cut / (den + eps)) I, c1[b] = g_cut trace(raw) / (den + eps)^2, with
+ *   den[b] = sum_i deg[b,i] q[b,i] formed in the same launch (deg, q [B,N] from tgp_cut_terms_f32) and kept for the
+ *   backward together with stats [B,4] = (trace(raw), |G|_F^2, trace(G), |G / |G| - I / sqrt(K)|_F) per graph (optional).
+ * tgp_dense_pool_train_rhs_f32: the right-hand sides into rcat [B][3K+F+4][K], rows [RU ; RX ; four zero rows ; RS ; RV]:
+ *   with gR = g_raw_a + g_raw_b (either may be NULL) + the loss' diagonal term, RV = gR, RU = gR^T (`symmetric`:
+ *   RU = gR + gR^T, RV not written), RX = g_x^T (g_x [B,K,F], or one value when gx_bcast), RS by mode:
+ *   0: zeros;
+ *   1 (MinCut): RS = W + W^T, gR -= (g_cut / (den + eps)) I, c1[b] = g_cut trace(raw) / (den + eps)^2 (the per-graph
+ *      scalars from the forward's `stats`: the launch is purely elementwise, 32 x 32 tiles), with
  *      g_cut = *g_la * scale, g_ortho = *g_lb * scale (0-dim device values or NULL; scale = 1 / B for the batch means);
  *   2 (DiffPool): c = link_scale^2 *g_la / *link_loss (0 when the loss is 0), gR -= c I, RS = 2 c G.
+ *   gw (optional, [B][2K][F], needs the selector weight W [K][F]): gw[b] = [g_x[b] ; W].
  * tgp_softmax_bwd_ex_f32: tgp_softmax_bwd_f32 on dS + extra + 2 c1[m / rows_per_graph] deg[m] S
- *   - *ent_g ent_scale (log(S + eps) + S / (S + eps))   (extra, c1/deg, ent_g: each optional).
- * tgp_copy_cols2_f32: dst[r, col_a:col_a+wa] = a[r,:], dst[r, col_b:col_b+wb] = b[r,:] (row stride ld) in one pass.
+ *   - *ent_g ent_scale (log(S + eps) + S / (S + eps))   (extra, c1/deg, ent_g: each optional); dy with row stride ld_dy.
+ * tgp_copy_cols2_f32: dst[r, col_a:col_a+wa] = a[r,:], dst[r, col_b:col_b+wb] = b[r,:] (row stride ld) in one pass;
+ *   one_col >= 0: also dst[r, one_col:one_col+4] = [1 0 0 0].
+ * tgp_adj_symmetry_f32: is the [B,Nmax,Nmax] adjacency the edge list (row, col) was scattered into symmetric?  One
+ *   thread per entry compares adj[b,r,c] with adj[b,c,r]; the verdict arrives in pinned host words (protocol of
+ *   tgp_edge_facts_sorted_i64: result word 0 = tag stored last, word 2 = 1 when some entry differs from its mirror).
  * ---------------------------------------------------------------------------------- */
 size_t tgp_dense_pool_train_workspace_bytes(int64_t B, int64_t N, int64_t K, int64_t F);
 int tgp_dense_pool_train_fwd_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K,
                                  int64_t F, int flags, float eps, float* U, int64_t ldu, float* x_pool, float* adj_raw,
                                  float* adj_pool, float* gram, void* ws, size_t ws_bytes, void* stream);
 int tgp_mincut_terms_fused_f32(const float* raw, const float* gram, const float* deg, const float* q, int64_t B,
-                               int64_t N, int64_t K, float eps, float* den, float* out, void* stream);
-int tgp_dense_pool_train_rhs_f32(const float* g_raw_a, const float* g_raw_b, int mode, const float* raw, const float* den,
+                               int64_t N, int64_t K, float eps, float* den, float* out, float* stats, void* stream);
+int tgp_dense_pool_train_rhs_f32(const float* g_raw_a, const float* g_raw_b, int mode, const float* stats, const float* den,
                                  const float* gram, const float* g_la, const float* g_lb, float scale,
                                  const float* link_loss, float link_scale, float eps, const float* g_x, int gx_bcast,
-                                 int64_t B, int64_t K, int64_t F, float* rcat, float* c1, void* stream);
+                                 int symmetric, const float* W, int64_t B, int64_t K, int64_t F, float* rcat, float* c1,
+                                 float* gw, void* stream);
 int tgp_softmax_bwd_ex_f32(const float* s, const float* ds, const float* extra, const float* c1, const float* deg,
                            int64_t rows_per_graph, const float* ent_g, float ent_scale, float ent_eps, float* dy,
-                           int64_t M, int64_t K, void* stream);
+                           int64_t ld_dy, int64_t M, int64_t K, void* stream);
+int tgp_adj_symmetry_f32(const int64_t* row, const int64_t* col, int64_t E, const int64_t* batch, const int64_t* ptr,
+                         int64_t Nmax, const float* adj, uint32_t* ticket, uint64_t* result, uint64_t tag, void* stream);
 int tgp_copy_cols2_f32(const float* a, int64_t wa, const float* b, int64_t wb, int64_t rows, float* dst, int64_t ld,
-                       int64_t col_a, int64_t col_b, void* stream);
+                       int64_t col_a, int64_t col_b, int64_t one_col, void* stream);
 
 /* A7'  sparse A times dense S (connect/dense_conn.py:165,204: torch.sparse.mm), A in CSR built from a
  * row-sorted coalesced edge list: T[i,:] = sum_{e in row i} w[e] * S[col[e],:].  w may be NULL. */

@@ -62,6 +62,8 @@ def test_large_graph_training_step_matches_oracle_autograd(dev, alias, sizes, k,
     wx, wa = torch.randn(B, k, f, generator=g), torch.randn(B, k, k, generator=g)
     c1, c2 = 0.7, 1.3
 
+    from tgp import functions as Fn
+    before = dict(Fn.POOL_LARGE_STATS)
     xg = x.to(dev).requires_grad_(True)
     out = pooler(x=xg, adj=ei.to(dev), edge_weight=None if ew is None else ew.to(dev), batch=batch.to(dev))
     names = _node_names(out.x.grad_fn)
@@ -69,6 +71,10 @@ def test_large_graph_training_step_matches_oracle_autograd(dev, alias, sizes, k,
     l1, l2 = list(out.loss.values())
     obj = (out.x * wx.to(dev)).sum() + (out.edge_index * wa.to(dev)).sum() + c1 * l1 + c2 * l2
     obj.backward()
+    # unit weights on a mirrored edge list: A = A^T is detected and V = A^T S is never formed; random weights per
+    # direction: the general route
+    route = "general" if weighted else "symmetric"
+    assert Fn.POOL_LARGE_STATS[route] == before[route] + 1, (Fn.POOL_LARGE_STATS, before)
 
     # the oracle in float64 under autograd
     xr = x.double().requires_grad_(True)
@@ -159,7 +165,7 @@ def test_train_kernels_pieces(dev):
     S = torch.softmax(torch.randn(B, N, Kc, device=dev, generator=g), -1)
     A = torch.rand(B, N, N, device=dev, generator=g)
     X = torch.randn(B, N, F, device=dev, generator=g)
-    ld = 3 * Kc + F
+    ld = 3 * Kc + F + K.TRAIN_PAD
     acat = torch.full((B, N, ld), float("nan"), device=dev)
     x_pool, raw, adj_pool, gram = K.dense_pool_train_fwd(S, A, X, K.dense_flags(True, True, True, False), acat, True)
     ref_x, ref_raw, ref_pool = K.dense_pool(S, A, X, K.dense_flags(True, True, True, False), want_raw=True)
@@ -171,8 +177,9 @@ def test_train_kernels_pieces(dev):
     assert torch.isnan(acat[:, :, Kc:]).all()  # nothing else was touched
     K.bmm_into(A, S, acat[:, :, Kc:2 * Kc], trans_a=True)
     torch.testing.assert_close(acat[:, :, Kc:2 * Kc], A.transpose(1, 2) @ S, rtol=1e-5, atol=1e-4)
-    K.copy_cols2(X.view(B * N, F), S.view(B * N, Kc), acat.view(B * N, ld), 2 * Kc, 2 * Kc + F)
-    assert torch.equal(acat[:, :, 2 * Kc:2 * Kc + F], X) and torch.equal(acat[:, :, 2 * Kc + F:], S)
+    K.copy_cols2(X.view(B * N, F), S.view(B * N, Kc), acat.view(B * N, ld), 2 * Kc, 2 * Kc + F + 4, one_col=2 * Kc + F)
+    assert torch.equal(acat[:, :, 2 * Kc:2 * Kc + F], X) and torch.equal(acat[:, :, 2 * Kc + F + 4:], S)
+    assert torch.equal(acat[:, :, 2 * Kc + F:2 * Kc + F + 4], torch.tensor([1.0, 0, 0, 0], device=dev).expand(B, N, 4))
     R = torch.randn(B, ld, Kc, device=dev, generator=g)
     out = torch.empty(B, N, Kc, device=dev)
     K.bmm_into(acat, R, out)
@@ -180,6 +187,41 @@ def test_train_kernels_pieces(dev):
     deg, q = K.cut_rows(A, S)
     deg2, q2, den2 = K.cut_terms(A, S)
     assert torch.equal(deg, deg2) and torch.equal(q, q2)
-    den, terms = K.mincut_terms_fused(raw, gram, deg, q)
+    den, terms, _ = K.mincut_terms_fused(raw, gram, deg, q)
     torch.testing.assert_close(den, den2, rtol=1e-6, atol=0)
     torch.testing.assert_close(terms, K.mincut_loss_terms(raw, den2, gram), rtol=1e-6, atol=1e-7)
+
+
+def test_adjacency_symmetry_probe(dev):
+    """kernels.AdjSymmetry: exact comparison of every entry with its mirror image in the densified adjacency; remembered per
+    (edge_index, edge_weight) objects; a verdict whose pinned slot was reused by later launches reads as 'not known'."""
+    from tgp import kernels as K
+    from tgp.src import to_dense_adj
+    from tgp.utils.ops import batch_info
+    x, ei, ew, batch = _batch([40, 55, 33], 4, 6.0, seed=9)
+    ei, batch = ei.to(dev), batch.to(dev)
+    info = batch_info(batch)
+    sym_w = torch.rand(ei.size(1), device=dev)
+    key = torch.minimum(ei[0], ei[1]) * 1000 + torch.maximum(ei[0], ei[1])
+    sym_w = torch.rand(int(key.max()) + 1, device=dev)[key]  # one weight per undirected pair
+    cases = [(None, True), (sym_w, True), (ew.to(dev), False)]
+    for w, want in cases:
+        adj = to_dense_adj(ei, batch, w)
+        probe = K.AdjSymmetry(ei, w, adj, batch, info.ptr)
+        assert probe.get() is want
+        assert K._adj_symmetric_memo(ei, w) is want  # remembered for these tensor objects
+        again = K.AdjSymmetry(ei, w, adj, batch, info.ptr)
+        assert again.tag is None and again.get() is want  # no second launch
+    # a single asymmetric entry among many
+    w2 = sym_w.clone()
+    w2[7] += 0.5
+    assert K.AdjSymmetry(ei, w2, to_dense_adj(ei, batch, w2), batch, info.ptr).get() is False
+    # nine launches later the first one's slot holds a newer tag: 'not known' = False, and nothing is remembered
+    w3 = sym_w.clone()
+    adj3 = to_dense_adj(ei, batch, w3)
+    first = K.AdjSymmetry(ei, w3, adj3, batch, info.ptr)
+    for _ in range(9):
+        other = sym_w.clone()
+        K.AdjSymmetry(ei, other, adj3, batch, info.ptr)
+    torch.cuda.synchronize()
+    assert first.get() is False and K._adj_symmetric_memo(ei, w3) is None

@@ -422,43 +422,46 @@ extern "C" int tgp_dense_pool_train_fwd_f32(const float* S, const float* A, cons
                           p, cv, stream);
 }
 
-// dst[r, col_a : col_a + wa] = a[r, :], dst[r, col_b : col_b + wb] = b[r, :] for r < rows: the S and X column blocks
-// of the backward's operand buffer in one pass (float4 when everything is 16-byte aligned).
+// dst[r, col_a : col_a + wa] = a[r, :], dst[r, col_b : col_b + wb] = b[r, :] for r < rows: the X and S column blocks
+// of the backward's operand buffer in one pass (float4 when everything is 16-byte aligned); one_col >= 0: also
+// dst[r, one_col : one_col + 4] = [1 0 0 0] (the column that turns dY^T [X | 1] into the weight AND bias gradient).
 namespace tgp {
 __global__ __launch_bounds__(256) void copy_cols2_kernel(const float* __restrict__ a, int wa, const float* __restrict__ b,
                                                          int wb, long rows, float* __restrict__ dst, long ld, int col_a,
-                                                         int col_b, int vec) {
-  const int per_row = vec ? (wa + wb) / 4 : wa + wb;
+                                                         int col_b, int one_col, int vec) {
+  const int w_all = wa + wb + (one_col >= 0 ? 4 : 0);
+  const int per_row = vec ? w_all / 4 : w_all;
   const long total = rows * per_row;
   for (long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<long>(gridDim.x) * 256) {
     const long r = e / per_row;
     int c = static_cast<int>(e - r * per_row) * (vec ? 4 : 1);
-    const float* src;
+    const float* src = nullptr;
     float* out;
     if (c < wa) { src = a + r * wa + c; out = dst + r * ld + col_a + c; }
-    else { c -= wa; src = b + r * wb + c; out = dst + r * ld + col_b + c; }
-    if (vec) *reinterpret_cast<float4*>(out) = *reinterpret_cast<const float4*>(src);
-    else *out = *src;
+    else if (c < wa + wb) { c -= wa; src = b + r * wb + c; out = dst + r * ld + col_b + c; }
+    else { c -= wa + wb; out = dst + r * ld + one_col + c; }
+    if (vec) *reinterpret_cast<float4*>(out) = src ? *reinterpret_cast<const float4*>(src) : make_float4(1.f, 0.f, 0.f, 0.f);
+    else *out = src ? *src : (c == 0 ? 1.f : 0.f);
   }
 }
 }  // namespace tgp
 
 extern "C" int tgp_copy_cols2_f32(const float* a, int64_t wa, const float* b, int64_t wb, int64_t rows, float* dst,
-                                  int64_t ld, int64_t col_a, int64_t col_b, void* stream_) {
+                                  int64_t ld, int64_t col_a, int64_t col_b, int64_t one_col, void* stream_) {
   TGP_REQUIRE(rows >= 0 && wa >= 0 && wb >= 0 && ld >= 0, TGP_ERR_INVALID, "tgp_copy_cols2_f32: negative size");
-  if (rows == 0 || wa + wb == 0) return TGP_OK;
+  if (rows == 0 || wa + wb + (one_col >= 0 ? 4 : 0) == 0) return TGP_OK;
   TGP_REQUIRE(dst && (wa == 0 || a) && (wb == 0 || b), TGP_ERR_INVALID, "tgp_copy_cols2_f32: null pointer");
-  TGP_REQUIRE(col_a + wa <= ld && col_b + wb <= ld && wa + wb < (1ll << 30), TGP_ERR_INVALID,
-              "tgp_copy_cols2_f32: column block outside the row");
+  TGP_REQUIRE(col_a + wa <= ld && col_b + wb <= ld && wa + wb < (1ll << 30) && (one_col < 0 || one_col + 4 <= ld),
+              TGP_ERR_INVALID, "tgp_copy_cols2_f32: column block outside the row");
   const int vec = (wa % 4 == 0 && wb % 4 == 0 && ld % 4 == 0 && col_a % 4 == 0 && col_b % 4 == 0 &&
-                   reinterpret_cast<uintptr_t>(a) % 16 == 0 && reinterpret_cast<uintptr_t>(b) % 16 == 0 &&
-                   reinterpret_cast<uintptr_t>(dst) % 16 == 0) ? 1 : 0;
-  const int64_t total = rows * ((wa + wb) / (vec ? 4 : 1));
+                   (one_col < 0 || one_col % 4 == 0) && reinterpret_cast<uintptr_t>(a) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(b) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0) ? 1 : 0;
+  const int64_t total = rows * ((wa + wb + (one_col >= 0 ? 4 : 0)) / (vec ? 4 : 1));
   int64_t grid = (total + 255) / 256;
   if (grid > 256 * 16) grid = 256 * 16;
   hipLaunchKernelGGL(copy_cols2_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      a, static_cast<int>(wa), b, static_cast<int>(wb), static_cast<long>(rows), dst, static_cast<long>(ld),
-                     static_cast<int>(col_a), static_cast<int>(col_b), vec);
+                     static_cast<int>(col_a), static_cast<int>(col_b), static_cast<int>(one_col >= 0 ? one_col : -1), vec);
   return check_launch("tgp_copy_cols2_f32");
 }
 

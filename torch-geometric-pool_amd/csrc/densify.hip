@@ -416,6 +416,51 @@ __global__ __launch_bounds__(256) void edge_facts_sorted_kernel(const int64_t* _
   }
 }
 
+// r6: is the dense adjacency the edge list was scattered into SYMMETRIC?  One thread per entry compares adj[b,r,c] with
+// adj[b,c,r] (exact: a sum of duplicates that came out in another order counts as a mismatch); every other element of
+// the buffer is zero on both sides.  The answer lets the dense poolers' training step skip V = A^T S, the second of its
+// two N^2 K products (V = U for a symmetric A).  Verdict through the pinned host words of edge_facts_sorted_kernel's
+// protocol (word 2: 1 = some entry differs from its mirror image): launched in the forward, read in the backward.
+__global__ __launch_bounds__(256) void adj_symmetry_kernel(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                                                           int64_t E, const int64_t* __restrict__ batch,
+                                                           const int64_t* __restrict__ ptr, int64_t Nmax,
+                                                           const float* __restrict__ adj,
+                                                           unsigned int* __restrict__ ticket,
+                                                           unsigned int* __restrict__ bad,
+                                                           unsigned long long* __restrict__ result,
+                                                           unsigned long long tag) {
+  __shared__ bool s_last;
+  unsigned int flags = 0;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < E; e += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t r = row[e], c = col[e];
+    const int64_t b = batch[r];
+    const int64_t lr = r - ptr[b], lc = c - ptr[batch[c]];
+    if (lr >= Nmax || lc >= Nmax || lr < 0 || lc < 0) continue;  // (dropped by the scatter as well)
+    const float* g = adj + b * Nmax * Nmax;
+    if (g[lr * Nmax + lc] != g[lc * Nmax + lr]) flags = 1u;
+  }
+  if (flags) atomicOr(bad, flags);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned int fl = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *ticket = 0;  // ready for the next call on this stream
+      *bad = 0;
+      result[1] = 0ull;
+      result[2] = fl;
+      result[3] = result[4] = result[5] = 0ull;
+      __threadfence_system();
+      __hip_atomic_store(result, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 }  // namespace tgp
 
 using namespace tgp;
@@ -574,4 +619,21 @@ extern "C" int tgp_edge_facts_sorted_i64(const int64_t* row, int64_t E, const in
                      edge_ptr, ticket, ticket + 1, reinterpret_cast<unsigned long long*>(result),
                      static_cast<unsigned long long>(tag));
   return check_launch("tgp_edge_facts_sorted_i64");
+}
+
+// r6: symmetry of a densified adjacency, see adj_symmetry_kernel.  `ticket` / `result` / `tag` as
+// tgp_edge_facts_sorted_i64 (two zeroed uint32 words per (device, stream); 6 pinned host words, word 0 = tag stored last,
+// word 2 = 1 when some entry differs from its mirror image).
+extern "C" int tgp_adj_symmetry_f32(const int64_t* row, const int64_t* col, int64_t E, const int64_t* batch,
+                                    const int64_t* ptr, int64_t Nmax, const float* adj, uint32_t* ticket,
+                                    uint64_t* result, uint64_t tag, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E > 0 && Nmax > 0 && row && col && batch && ptr && adj && ticket && result, TGP_ERR_INVALID,
+              "tgp_adj_symmetry_f32: bad argument");
+  int64_t blocks = (E + 1023) / 1024;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(adj_symmetry_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, row, col, E, batch, ptr,
+                     Nmax, adj, ticket, ticket + 1, reinterpret_cast<unsigned long long*>(result),
+                     static_cast<unsigned long long>(tag));
+  return check_launch("tgp_adj_symmetry_f32");
 }

@@ -400,19 +400,23 @@ template <int T>
 __global__ __launch_bounds__(T) void mincut_tail2_kernel(const float* __restrict__ raw, const float* __restrict__ gram,
                                                            const float* __restrict__ deg, const float* __restrict__ q,
                                                            int N, int K, float eps, int B, float* __restrict__ den,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, float* __restrict__ stats) {
   __shared__ float sh[T / 64];
   const int b = blockIdx.x;
   const float* R = raw + static_cast<int64_t>(b) * K * K;
   const float* G = gram + static_cast<int64_t>(b) * K * K;
   const float* d = deg + static_cast<int64_t>(b) * N;
   const float* qq = q + static_cast<int64_t>(b) * N;
-  float dn = 0.f, tr = 0.f, sq = 0.f;
+  float dn = 0.f, tr = 0.f, sq = 0.f, trg = 0.f;
   for (int i = threadIdx.x; i < N; i += T) dn = fmaf(d[i], qq[i], dn);
-  for (int i = threadIdx.x; i < K; i += T) tr += R[static_cast<int64_t>(i) * K + i];
+  for (int i = threadIdx.x; i < K; i += T) {
+    tr += R[static_cast<int64_t>(i) * K + i];
+    trg += G[static_cast<int64_t>(i) * K + i];
+  }
   for (int i = threadIdx.x; i < K * K; i += T) sq = fmaf(G[i], G[i], sq);
   dn = block_sum_t<T>(dn, sh);
   tr = block_sum_t<T>(tr, sh);
+  trg = block_sum_t<T>(trg, sh);
   sq = block_sum_t<T>(sq, sh);
   const float n = sqrtf(sq);
   const float t = 1.0f / sqrtf(static_cast<float>(K));
@@ -426,97 +430,149 @@ __global__ __launch_bounds__(T) void mincut_tail2_kernel(const float* __restrict
     den[b] = dn;
     out[b] = -(tr / (dn + eps));
     out[B + b] = sqrtf(acc);
+    if (stats) {  // what the backward's right-hand sides need of this graph, so that they need no reduction of their own
+      stats[4 * b] = tr; stats[4 * b + 1] = sq; stats[4 * b + 2] = trg; stats[4 * b + 3] = sqrtf(acc);
+    }
   }
 }
 
 // The K-sized right-hand sides of the backward's ONE sum-of-products GEMM
-//     gS = [U | V | X | S] [RU ; RV ; RX ; RS],     U = A S, V = A^T S
-// for one graph per workgroup.  With gR = the total gradient of raw = S^T A S (post-processing backward `ga` + an
-// upstream gradient of raw `gb` + the loss' own diagonal term):
+//     gS = [U | X | 1000 | S | V] [RU ; RX ; 0 ; RS ; RV],     U = A S, V = A^T S
+// in 32 x 32 tiles.  With gR = the total gradient of raw = S^T A S (post-processing backward `ga` + an upstream
+// gradient of raw `gb` + the loss' own diagonal term):
 //     RV = gR,  RU = gR^T                      (dense_conn.py:111-122 under autograd: dS = U dR^T + V dR)
 //     RX = g_x^T                               (base_reduce.py:158-161: dS = X dX'^T)
-//     RS = W + W^T (MinCut, W = d ortho / d G, losses.py:59-70)   or   2 c G (DiffPool, losses.py:644-658)
+//     RS = W + W^T (MinCut, W = d ortho / d G, losses.py:59-70)   or   2 c G (DiffPool, losses.py:644-658)   or 0
+// `symmetric` (A = A^T, so V = U): RU = gR + gR^T and the RV rows are not written -- the caller multiplies the first
+// 2K + F + 4 rows only and never forms V.
 // mode 1 (MinCut): gR += -(g_cut / (den + eps)) I, c1[b] = g_cut trace(raw) / (den + eps)^2 (the gradient of den: the
 // caller folds 2 c1 D S into the softmax backward); g_cut / g_ortho are the upstream gradients of the batch MEANS
 // (0-dim tensors, or NULL) and `scale` = 1 / B.  mode 2 (DiffPool): c = link_scale^2 g_link / link_loss (0 when the
-// loss is 0: torch.norm's subgradient), gR += -c I, RS = 2 c G.  rcat: [B][2K + F + K][K], rows RU | RV | RX | RS.
+// loss is 0: torch.norm's subgradient), gR += -c I, RS = 2 c G.  rcat: [B][3K + F + 4][K]; the four zero rows face the
+// operand buffer's [1 0 0 0] column block, which gives the selector's bias gradient from the same product as its weight
+// gradient.  gw (optional, [B][2K][F]) = [g_x ; W]: the right-hand side of gX = [S | dY] [g_x ; W] (dY overwrites the
+// V block, which lies behind S).
+constexpr int TGP_TRAIN_PAD = 4;  // the [1 0 0 0] column block of the operand buffer (tgp_copy_cols2_f32 writes it)
+
 struct TrainRhsArgs {
   const float* ga; const float* gb;
-  const float* raw; const float* den; const float* gram;
+  const float* stats; const float* den; const float* gram;
   const float* g_la; const float* g_lb; float scale;
   const float* link_loss; float link_scale, eps;
   const float* g_x; int gx_bcast;
-  int K, F, mode;
+  int K, F, mode, tiles_k, tiles_f, symmetric;
   float* rcat; float* c1;
+  const float* W; float* gw;  // selector weight [K][F] and [B][2K][F] = [g_x ; W], or NULL
 };
 
-template <int T>
-__global__ __launch_bounds__(T) void train_rhs_kernel(TrainRhsArgs p) {
-  __shared__ float sh[T / 64];
-  const int b = blockIdx.x, K = p.K, F = p.F;
+// 32 x 32 tiles, 256 threads; blockIdx.y = graph.  Tiles 0 .. tiles_k^2 - 1: tile (ti, tj) of RU / RV / RS (the
+// transposed operands come through LDS patches of the mirror tile); the tiles behind them: RX = g_x^T.
+// MinCut's scalars come from the forward's stats [B,4] = (trace(raw), |G|^2, trace(G), |Y|):
+//   <G, Y> = |G|^2 / |G| - trace(G) / sqrt(K)   (Y = G / |G| - I / sqrt(K)): no reduction here.
+__global__ __launch_bounds__(256) void train_rhs_kernel(TrainRhsArgs p) {
+  __shared__ float t_a[32][33], t_g[32][33];
+  const int b = blockIdx.y, K = p.K, F = p.F, tid = threadIdx.x;
+  const int tx = tid & 31, ty = tid >> 5;  // ty: 0..7, four rows each
   const int64_t off = static_cast<int64_t>(b) * K * K;
+  float* out = p.rcat + static_cast<int64_t>(b) * (3 * K + F + TGP_TRAIN_PAD) * K;
+  const int kt = p.tiles_k;
+  const int tile = blockIdx.x;
+  if (tile >= kt * kt + p.tiles_f * kt) {  // gw[b] = [g_x[b] ; W], 1024 elements per workgroup
+    const int64_t kf = static_cast<int64_t>(K) * F;
+    const float* gx = p.g_x ? (p.gx_bcast ? p.g_x : p.g_x + static_cast<int64_t>(b) * kf) : nullptr;
+    float* dst = p.gw + static_cast<int64_t>(b) * 2 * kf;
+    const int64_t e0 = static_cast<int64_t>(tile - kt * kt - p.tiles_f * kt) * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t e = e0 + q * 256 + tid;
+      if (e < kf) dst[e] = gx ? (p.gx_bcast ? gx[0] : gx[e]) : 0.f;
+      else if (e < 2 * kf) dst[e] = p.W[e - kf];
+    }
+    return;
+  }
+  if (tile >= kt * kt) {  // RX[f][k] = g_x[k][f]
+    const int id = tile - kt * kt;
+    const int tf = id / kt, tk = id - tf * kt;
+    float* RX = out + static_cast<int64_t>(K) * K;
+    const float* gx = p.g_x ? (p.gx_bcast ? p.g_x : p.g_x + static_cast<int64_t>(b) * K * F) : nullptr;
+    if (gx && !p.gx_bcast) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // patch[k][f], read along f
+        const int k = tk * 32 + ty * 4 + q, f = tf * 32 + tx;
+        t_a[ty * 4 + q][tx] = (k < K && f < F) ? gx[static_cast<int64_t>(k) * F + f] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = tf * 32 + ty * 4 + q, k = tk * 32 + tx;
+      if (f < F && k < K) RX[static_cast<int64_t>(f) * K + k] = gx ? (p.gx_bcast ? gx[0] : t_a[tx][ty * 4 + q]) : 0.f;
+    }
+    return;
+  }
+  const int ti = tile / kt, tj = tile - ti * kt;
   const float* ga = p.ga ? p.ga + off : nullptr;
   const float* gb = p.gb ? p.gb + off : nullptr;
-  float* out = p.rcat + static_cast<int64_t>(b) * (3 * K + F) * K;
-  float* RU = out;
-  float* RV = out + static_cast<int64_t>(K) * K;
-  float* RX = out + static_cast<int64_t>(2 * K) * K;
-  float* RS = out + static_cast<int64_t>(2 * K + F) * K;
-  float diag = 0.f;
+  const float* G = p.gram ? p.gram + off : nullptr;
+  float diag = 0.f, coef = 0.f, gq = 0.f, n = 1.f, two_c = 0.f;
+  const float t = 1.0f / sqrtf(static_cast<float>(K));
   if (p.mode == 1) {
-    const float* R = p.raw + off;
-    const float* G = p.gram + off;
-    float tr = 0.f, sq = 0.f;
-    for (int i = threadIdx.x; i < K; i += T) tr += R[static_cast<int64_t>(i) * K + i];
-    for (int i = threadIdx.x; i < K * K; i += T) sq = fmaf(G[i], G[i], sq);
-    tr = block_sum_t<T>(tr, sh);
-    sq = block_sum_t<T>(sq, sh);
-    const float n = sqrtf(sq);
-    const float t = 1.0f / sqrtf(static_cast<float>(K));
-    float ny2 = 0.f, gy = 0.f;
-    for (int i = threadIdx.x; i < K * K; i += T) {
-      const float y = G[i] / n - ((i / K == i % K) ? t : 0.f);
-      ny2 = fmaf(y, y, ny2);
-      gy = fmaf(G[i], y, gy);
-    }
-    ny2 = block_sum_t<T>(ny2, sh);
-    gy = block_sum_t<T>(gy, sh);
-    const float ny = sqrtf(ny2);
+    const float tr = p.stats[4 * b], sq = p.stats[4 * b + 1], trg = p.stats[4 * b + 2], ny = p.stats[4 * b + 3];
+    n = sqrtf(sq);
     const float g_cut = p.g_la ? p.g_la[0] * p.scale : 0.f, g_ortho = p.g_lb ? p.g_lb[0] * p.scale : 0.f;
     const float dd = p.den[b] + p.eps;
     diag = -g_cut / dd;
-    const float coef = ny > 0.f ? g_ortho / (ny * n) : 0.f;
-    const float gq = gy / sq;
-    for (int i = threadIdx.x; i < K * K; i += T) {
-      const int r = i / K, c = i - r * K;
-      const float gij = G[i], gji = G[static_cast<int64_t>(c) * K + r];
-      const float dg = (r == c) ? t : 0.f;
-      const float wij = coef * ((gij / n - dg) - gij * gq), wji = coef * ((gji / n - dg) - gji * gq);
-      RS[i] = wij + wji;
-    }
-    if (threadIdx.x == 0 && p.c1) p.c1[b] = g_cut * tr / (dd * dd);
+    coef = ny > 0.f ? g_ortho / (ny * n) : 0.f;
+    gq = (sq / n - t * trg) / sq;  // <G, Y> / |G|^2
+    if (tile == 0 && tid == 0 && p.c1) p.c1[b] = g_cut * tr / (dd * dd);
   } else if (p.mode == 2) {
-    const float* G = p.gram + off;
     const float loss = p.link_loss ? p.link_loss[0] : 0.f;
     const float c = (p.g_la && loss > 0.f) ? p.link_scale * p.link_scale * p.g_la[0] / loss : 0.f;
     diag = -c;
-    for (int i = threadIdx.x; i < K * K; i += T) RS[i] = 2.0f * c * G[i];
+    two_c = 2.0f * c;
   }
-  for (int i = threadIdx.x; i < K * K; i += T) {
-    const int r = i / K, c = i - r * K;
-    const int64_t tr_i = static_cast<int64_t>(c) * K + r;
-    float v = 0.f, vt = 0.f;
-    if (ga) { v += ga[i]; vt += ga[tr_i]; }
-    if (gb) { v += gb[i]; vt += gb[tr_i]; }
+  // mirror tile (tj, ti) of gR (and of G for MinCut's W^T) into LDS, read along its rows
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = tj * 32 + ty * 4 + q, c = ti * 32 + tx;
+    const bool ok = r < K && c < K;
+    const int64_t e = static_cast<int64_t>(r) * K + c;
+    float v = 0.f;
+    if (ok && ga) v += ga[e];
+    if (ok && gb) v += gb[e];
+    t_a[ty * 4 + q][tx] = v;
+    if (p.mode == 1) t_g[ty * 4 + q][tx] = ok ? G[e] : 0.f;
+  }
+  __syncthreads();
+  float* RU = out;
+  float* RS = out + static_cast<int64_t>(K + F + TGP_TRAIN_PAD) * K;
+  float* RV = out + static_cast<int64_t>(2 * K + F + TGP_TRAIN_PAD) * K;
+  if (tile == 0)
+    for (int i = tid; i < TGP_TRAIN_PAD * K; i += 256) out[static_cast<int64_t>(K + F) * K + i] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = ti * 32 + ty * 4 + q, c = tj * 32 + tx;
+    if (r >= K || c >= K) continue;
+    const int64_t e = static_cast<int64_t>(r) * K + c;
+    float v = 0.f;
+    if (ga) v += ga[e];
+    if (gb) v += gb[e];
     const float dg = (r == c) ? diag : 0.f;
-    RV[i] = v + dg;
-    RU[i] = vt + dg;
-  }
-  if (F > 0) {
-    const float* gx = p.g_x ? (p.gx_bcast ? p.g_x : p.g_x + static_cast<int64_t>(b) * K * F) : nullptr;
-    for (int i = threadIdx.x; i < F * K; i += T) {
-      const int f = i / K, k = i - f * K;
-      RX[i] = gx ? (p.gx_bcast ? gx[0] : gx[static_cast<int64_t>(k) * F + f]) : 0.f;
+    const float vt = t_a[tx][ty * 4 + q];  // gR[c][r]
+    if (p.symmetric) {
+      RU[e] = (v + dg) + (vt + dg);
+    } else {
+      RV[e] = v + dg;
+      RU[e] = vt + dg;
+    }
+    if (p.mode == 0) {
+      RS[e] = 0.f;
+    } else if (p.mode == 1) {
+      const float gij = G[e], gji = t_g[tx][ty * 4 + q];
+      const float dt = (r == c) ? t : 0.f;
+      RS[e] = coef * ((gij / n - dt) - gij * gq) + coef * ((gji / n - dt) - gji * gq);
+    } else if (p.mode == 2) {
+      RS[e] = two_c * G[e];
     }
   }
 }
@@ -524,7 +580,7 @@ __global__ __launch_bounds__(T) void train_rhs_kernel(TrainRhsArgs p) {
 
 extern "C" int tgp_mincut_terms_fused_f32(const float* raw, const float* gram, const float* deg, const float* q,
                                           int64_t B, int64_t N, int64_t K, float eps, float* den, float* out,
-                                          void* stream_) {
+                                          float* stats, void* stream_) {
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 1 && K < 32768 && N < (1ll << 31), TGP_ERR_INVALID,
               "tgp_mincut_terms_fused_f32: bad shape");
   if (B == 0) return TGP_OK;
@@ -534,30 +590,32 @@ extern "C" int tgp_mincut_terms_fused_f32(const float* raw, const float* gram, c
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (K >= 64)
     hipLaunchKernelGGL(mincut_tail2_kernel<1024>, dim3(static_cast<unsigned>(B)), dim3(1024), 0, stream, raw, gram, deg, q,
-                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out);
+                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out, stats);
   else
     hipLaunchKernelGGL(mincut_tail2_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, raw, gram, deg, q,
-                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out);
+                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out, stats);
   return check_launch("tgp_mincut_terms_fused_f32");
 }
 
-extern "C" int tgp_dense_pool_train_rhs_f32(const float* g_raw_a, const float* g_raw_b, int mode, const float* raw,
+extern "C" int tgp_dense_pool_train_rhs_f32(const float* g_raw_a, const float* g_raw_b, int mode, const float* stats,
                                             const float* den, const float* gram, const float* g_la, const float* g_lb,
                                             float scale, const float* link_loss, float link_scale, float eps,
-                                            const float* g_x, int gx_bcast, int64_t B, int64_t K, int64_t F, float* rcat,
-                                            float* c1, void* stream_) {
+                                            const float* g_x, int gx_bcast, int symmetric, const float* W, int64_t B,
+                                            int64_t K, int64_t F, float* rcat, float* c1, float* gw, void* stream_) {
   TGP_REQUIRE(B >= 0 && K >= 1 && K < 32768 && F >= 0 && F < (1ll << 24) && mode >= 0 && mode <= 2, TGP_ERR_INVALID,
               "tgp_dense_pool_train_rhs_f32: bad shape or mode");
   if (B == 0) return TGP_OK;
-  TGP_REQUIRE(rcat && B < (1ll << 31), TGP_ERR_INVALID, "tgp_dense_pool_train_rhs_f32: null output");
-  TGP_REQUIRE(mode != 1 || (raw && den && gram && c1), TGP_ERR_INVALID,
-              "tgp_dense_pool_train_rhs_f32: mode 1 needs raw, den, gram and c1");
+  TGP_REQUIRE(rcat && B < 65536, TGP_ERR_INVALID, "tgp_dense_pool_train_rhs_f32: null output or B >= 65536");
+  TGP_REQUIRE(mode != 1 || (stats && den && gram && c1), TGP_ERR_INVALID,
+              "tgp_dense_pool_train_rhs_f32: mode 1 needs stats, den, gram and c1");
   TGP_REQUIRE(mode != 2 || gram, TGP_ERR_INVALID, "tgp_dense_pool_train_rhs_f32: mode 2 needs gram");
-  tgp::TrainRhsArgs a{g_raw_a, g_raw_b, raw, den, gram, g_la, g_lb, scale, link_loss, link_scale, eps, g_x, gx_bcast,
-                      static_cast<int>(K), static_cast<int>(F), mode, rcat, c1};
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (K >= 64) hipLaunchKernelGGL(train_rhs_kernel<1024>, dim3(static_cast<unsigned>(B)), dim3(1024), 0, stream, a);
-  else hipLaunchKernelGGL(train_rhs_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, a);
+  TGP_REQUIRE(!gw || (W && F > 0), TGP_ERR_INVALID, "tgp_dense_pool_train_rhs_f32: gw needs W and F > 0");
+  const int kt = static_cast<int>((K + 31) / 32), ft = static_cast<int>((F + 31) / 32);
+  const int64_t gw_blocks = gw ? (2 * K * F + 1023) / 1024 : 0;
+  tgp::TrainRhsArgs a{g_raw_a, g_raw_b, stats, den, gram, g_la, g_lb, scale, link_loss, link_scale, eps, g_x, gx_bcast,
+                      static_cast<int>(K), static_cast<int>(F), mode, kt, ft, symmetric ? 1 : 0, rcat, c1, W, gw};
+  hipLaunchKernelGGL(train_rhs_kernel, dim3(static_cast<unsigned>(kt * kt + ft * kt + gw_blocks), static_cast<unsigned>(B)),
+                     dim3(256), 0, static_cast<hipStream_t>(stream_), a);
   return check_launch("tgp_dense_pool_train_rhs_f32");
 }
 

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_ex_kernel(const float* __rest
                                                              const float* __restrict__ c1, const float* __restrict__ deg,
                                                              long rows_per_graph, const float* __restrict__ ent_g,
                                                              float ent_scale, float ent_eps, float* __restrict__ dy,
-                                                             long M, int K) {
+                                                             long ld_dy, long M, int K) {
   const int sub = threadIdx.x % G;
   const long m = static_cast<long>(blockIdx.x) * (256 / G) + threadIdx.x / G;
   const bool ok = m < M;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_ex_kernel(const float* __rest
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
   if (ok) {
-    float* out = dy + m * K;
+    float* out = dy + m * ld_dy;
     for (int k = sub; k < K; k += G) out[k] = sr[k] * (eff(k) - dot);
   }
 }
@@ -618,8 +618,8 @@ extern "C" int tgp_softmax_bwd_f32(const float* s, const float* ds, float* dy, i
 
 extern "C" int tgp_softmax_bwd_ex_f32(const float* s, const float* ds, const float* extra, const float* c1,
                                       const float* deg, int64_t rows_per_graph, const float* ent_g, float ent_scale,
-                                      float ent_eps, float* dy, int64_t M, int64_t K, void* stream_) {
-  TGP_REQUIRE(M >= 0 && K >= 1 && K < (1ll << 31), TGP_ERR_INVALID, "tgp_softmax_bwd_ex_f32: bad shape");
+                                      float ent_eps, float* dy, int64_t ld_dy, int64_t M, int64_t K, void* stream_) {
+  TGP_REQUIRE(M >= 0 && K >= 1 && K < (1ll << 31) && ld_dy >= K, TGP_ERR_INVALID, "tgp_softmax_bwd_ex_f32: bad shape");
   if (M == 0) return TGP_OK;
   TGP_REQUIRE(s && ds && dy && (!c1 || (deg && rows_per_graph > 0)), TGP_ERR_INVALID,
               "tgp_softmax_bwd_ex_f32: null pointer");
@@ -627,10 +627,12 @@ extern "C" int tgp_softmax_bwd_ex_f32(const float* s, const float* ds, const flo
   const int k = static_cast<int>(K);
   if (K <= 16)
     hipLaunchKernelGGL(softmax_bwd_ex_kernel<16>, dim3(cdiv(M, 16)), dim3(256), 0, stream, s, ds, extra, c1, deg,
-                       static_cast<long>(rows_per_graph), ent_g, ent_scale, ent_eps, dy, static_cast<long>(M), k);
+                       static_cast<long>(rows_per_graph), ent_g, ent_scale, ent_eps, dy, static_cast<long>(ld_dy),
+                       static_cast<long>(M), k);
   else
     hipLaunchKernelGGL(softmax_bwd_ex_kernel<64>, dim3(cdiv(M, 4)), dim3(256), 0, stream, s, ds, extra, c1, deg,
-                       static_cast<long>(rows_per_graph), ent_g, ent_scale, ent_eps, dy, static_cast<long>(M), k);
+                       static_cast<long>(rows_per_graph), ent_g, ent_scale, ent_eps, dy, static_cast<long>(ld_dy),
+                       static_cast<long>(M), k);
   return check_launch("tgp_softmax_bwd_ex_f32");
 }
 

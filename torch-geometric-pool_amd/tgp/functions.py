@@ -881,6 +881,9 @@ def select_pool_small(x: Tensor, adj: Tensor, weight: Tensor, bias: Optional[Ten
 
 
 # ----------------------------------------- the dense poolers' training step beyond the one-wave kernels (r6)
+POOL_LARGE_STATS = {"symmetric": 0, "general": 0}  # backward passes by route (diagnostics / tests)
+
+
 class _PoolLargeFn(torch.autograd.Function):
     """Select (optional) + Reduce + Connect + post-processing + the pooler's two auxiliary losses of a padded batch whose
     graphs are too large for the one-wave / one-workgroup kernels (C2: 32 x 1024 nodes, K = 128), as ONE autograd node
@@ -893,16 +896,18 @@ class _PoolLargeFn(torch.autograd.Function):
         MinCut: deg, q (one pass over A), den + both per-graph terms, batch means    3 launches
         DiffPool: link residual in the GEMM epilogue, entropy partials, tail         4 launches
     backward: with gR = the gradient of raw (post-processing backward + upstream + the loss' diagonal term)
-        gS = [U | V | X | S] [gR^T ; gR ; g_x'^T ; RS]          ONE GEMM over the operand buffer acat [B,N,3K+F]
-             (V = A^T S is written into its column block by the one N^2 K product of the backward; X and S are copied
-             into theirs by one launch; RS = W + W^T (MinCut's orthogonality term) or 2 c G (DiffPool's link term), the
+        gS = [U | X | 1000 | S | V] [gR^T ; g_x'^T ; 0 ; RS ; gR]   ONE GEMM over the operand buffer acat [B,N,3K+F+4]
+             (V = A^T S is written into its column block by the one N^2 K product of the backward -- not at all when A is
+             known to be symmetric (kernels.AdjSymmetry: V = U, the first block's right-hand side becomes gR + gR^T); X, a
+             [1 0 0 0] block and S are copied into theirs by one launch; RS = W + W^T (MinCut's orthogonality term) or 2 c G (DiffPool's link term), the
              -c I / -(g_cut / den) I terms sit on the diagonals of the first two blocks: tgp_dense_pool_train_rhs_f32)
         selector form: dY = softmax backward of gS + 2 c1 D S (MinCut) - g_ent (log S + ...) (DiffPool) in one launch,
-             gX = S g_x' + dY W (two products, the second accumulating), gW = dY^T X, gb = column sums of dY.
+             written over the V block; gX = [S | dY] [g_x' ; W] (one product over acat's last two blocks),
+             [gW | gb] = dY^T [X | 1] (one product over acat's X block and the column of ones behind it).
     The adjacency gets no gradient (callers check); edge_weight_norm is not differentiated here (callers check)."""
 
     @staticmethod
-    def forward(ctx, x, adj, weight, bias, mask, s_given, flags, mode, scales, graph_sizes):
+    def forward(ctx, x, adj, weight, bias, mask, s_given, flags, mode, scales, graph_sizes, sym):
         from . import _native as N
         ctx.set_materialize_grads(False)
         xd = N.f32c(x.detach())
@@ -915,23 +920,24 @@ class _PoolLargeFn(torch.autograd.Function):
         Kc = s.size(-1)
         ad = adj.detach()
         mem, tflag = K._dense_adj_layout(ad)
-        acat = torch.empty(B, Nn, 3 * Kc + F, dtype=torch.float32, device=xd.device)
+        acat = torch.empty(B, Nn, 3 * Kc + F + K.TRAIN_PAD, dtype=torch.float32, device=xd.device)
         x_pool, raw, adj_pool, gram = K.dense_pool_train_fwd(s, mem, xd, flags | tflag, acat, want_gram=mode != 0)
         empty = s.new_empty(0)
         la, lb = s.new_empty(0), s.new_empty(0)  # (distinct objects: both are outputs of this node)
-        deg = den = lossv = None
+        deg = den = lossv = stats = None
         if mode == 1:
             deg, q = K.cut_rows(ad, s, graph_sizes)
-            den, terms = K.mincut_terms_fused(raw, gram, deg, q)
+            den, terms, stats = K.mincut_terms_fused(raw, gram, deg, q)
             both = terms.mean(dim=1)
             la, lb = both[0], both[1]
         elif mode == 2:
             lossv = K.diffpool_loss_tail(s, ad, graph_sizes, scales[0], scales[1])
             la, lb = lossv[0], lossv[1]
-        keep = [t if t is not None else empty for t in (gram, deg, den, lossv)]
+        keep = [t if t is not None else empty for t in (gram, deg, den, lossv, stats)]
         ctx.save_for_backward(s, mem, xd, empty if weight is None else weight, acat, raw, *keep)
         ctx.flags, ctx.tflag, ctx.mode, ctx.scales, ctx.selector = flags, tflag, mode, scales, selector
         ctx.has_bias = bias is not None
+        ctx.sym = sym
         if mode == 0:
             ctx.mark_non_differentiable(la, lb)
         if selector:
@@ -943,7 +949,7 @@ class _PoolLargeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_s, g_xp, g_raw, g_adj, g_la, g_lb):
         from . import _native as N
-        s, mem, xd, weight, acat, raw, gram, deg, den, lossv = ctx.saved_tensors
+        s, mem, xd, weight, acat, raw, gram, deg, den, lossv, stats = ctx.saved_tensors
         B, Nn, Kc = s.shape
         F = xd.size(2)
         mode, selector = ctx.mode, ctx.selector
@@ -951,7 +957,7 @@ class _PoolLargeFn(torch.autograd.Function):
         if mode == 0:
             g_la = g_lb = None
         want_gx = ctx.needs_input_grad[0]
-        nothing = (None,) * 10
+        nothing = (None,) * 11
         if g_s is None and g_xp is None and g_raw is None and g_adj is None and g_la is None and g_lb is None:
             return nothing
         ga = None
@@ -962,47 +968,67 @@ class _PoolLargeFn(torch.autograd.Function):
         gb = None if g_raw is None else N.f32c(g_raw)
         gx_t, gx_bc = K._bcast_or_dense(g_xp, (B, Kc, F))
         link_loss = lossv[0:1] if mode == 2 else None
-        rcat, c1 = K.dense_pool_train_rhs(ga, gb, mode, raw if mode == 1 else None, den if mode == 1 else None,
-                                          gram if mode else None, g_la, g_lb if mode == 1 else None, 1.0 / B, link_loss,
-                                          ctx.scales[0] if mode == 2 else 0.0, gx_t, gx_bc, B, Kc, F, dev)
-        # V = A^T S into its column block (mem holds A, or A^T when tflag), then X and S into theirs
-        K.bmm_into(mem, s, acat[:, :, Kc:2 * Kc], trans_a=not ctx.tflag)
-        ld = 3 * Kc + F
-        K.copy_cols2(xd.view(B * Nn, F), s.view(B * Nn, Kc), acat.view(B * Nn, ld), 2 * Kc, 2 * Kc + F)
-        kd = ld if mode else 2 * Kc + F
+        symmetric = ctx.sym is not None and ctx.sym.get()  # A = A^T: V = U, the second N^2 K product is not needed
+        POOL_LARGE_STATS["symmetric" if symmetric else "general"] += 1
+        fold_gx = selector and want_gx  # gX = [S | dY] [g_x ; W] as one product over acat's last two blocks
+        rcat, c1, gwcat = K.dense_pool_train_rhs(
+            ga, gb, mode, stats if mode == 1 else None, den if mode == 1 else None, gram if mode else None, g_la,
+            g_lb if mode == 1 else None, 1.0 / B, link_loss, ctx.scales[0] if mode == 2 else 0.0, gx_t, gx_bc, symmetric,
+            weight if fold_gx else None, B, Kc, F, dev)
+        pad = K.TRAIN_PAD
+        ld = 3 * Kc + F + pad
+        c_x, c_one, c_s, c_v = Kc, Kc + F, Kc + F + pad, 2 * Kc + F + pad
+        vblock = acat[:, :, c_v:]
+        if not symmetric:  # V = A^T S into its column block (mem holds A, or A^T when tflag)
+            K.bmm_into(mem, s, vblock, trans_a=not ctx.tflag)
+        K.copy_cols2(xd.view(B * Nn, F), s.view(B * Nn, Kc), acat.view(B * Nn, ld), c_x, c_s, one_col=c_one)
+        kd = c_v if symmetric else ld
         gs = torch.empty(B, Nn, Kc, dtype=torch.float32, device=dev)
         K.bmm_into(acat[:, :, :kd], rcat[:, :kd, :], gs)
         ent_g = g_lb if mode == 2 else None
-        gxd = None
-        if want_gx and g_xp is not None:
-            gxd = K.bmm(s, g_xp.contiguous() if gx_bc else gx_t)
         if not selector:
+            gxd = None
+            if want_gx and g_xp is not None:
+                gxd = K.bmm(s, g_xp.contiguous() if gx_bc else gx_t)
             if mode == 1 and c1 is not None:
                 gs.addcmul_((2.0 * c1).view(-1, 1, 1) * deg.unsqueeze(-1), s)
             if ent_g is not None:
                 gs += K.entropy_bwd(s, ent_g, ctx.scales[1])
-            return (gxd, None, None, None, None, gs, None, None, None, None)
-        dy = K.softmax_bwd_ex(s, gs, extra=g_s, c1=c1 if mode == 1 else None, deg=deg if mode == 1 else None,
-                              ent_g=ent_g, ent_scale=ctx.scales[1] if mode == 2 else 0.0)
-        dy2 = dy.view(B * Nn, Kc)
-        gw = gbias = None
+            return (gxd, None, None, None, None, gs, None, None, None, None, None)
+        # the selector's backward: dY over the V block (no longer needed), then two products
+        K.softmax_bwd_ex(s, gs, extra=g_s, c1=c1 if mode == 1 else None, deg=deg if mode == 1 else None,
+                         ent_g=ent_g, ent_scale=ctx.scales[1] if mode == 2 else 0.0, out=vblock)
+        gxd = gw = gbias = None
         if want_gx:
-            if gxd is None:
-                gxd = K.bmm(dy2, weight).view(B, Nn, F)
-            else:
-                K.bmm(dy2, weight, accumulate_into=gxd.view(1, B * Nn, F))
-        if ctx.needs_input_grad[2]:
-            gw = _tall_skinny_tn(dy2, xd.view(B * Nn, F))
-        if ctx.has_bias and ctx.needs_input_grad[3]:
-            gbias = dy2.sum(0)
-        return (gxd, None, gw, gbias, None, None, None, None, None, None)
+            gxd = torch.empty(B, Nn, F, dtype=torch.float32, device=dev)
+            K.bmm_into(acat[:, :, c_s:], gwcat, gxd)
+        want_gw, want_gb = ctx.needs_input_grad[2], ctx.has_bias and ctx.needs_input_grad[3]
+        if want_gw or want_gb:
+            # dY^T [X | 1 0 0 0]: weight and bias gradient from one product over the operand buffer's X block and the
+            # column of ones behind it, as a batched product over row slabs + the sum of the slab results (20 us at
+            # 32768 x 128 x 64; the slab-wise small product + a column sum of dY took 47 us)
+            rows = B * Nn
+            slabs = 64
+            while slabs > 1 and (rows % slabs or rows // slabs < 256):
+                slabs //= 2
+            part = torch.empty(slabs, Kc, F + pad, dtype=torch.float32, device=dev)
+            flat = acat.view(slabs, rows // slabs, ld)
+            K.bmm_into(flat[:, :, c_v:], flat[:, :, c_x:c_x + F + pad], part, trans_a=True)
+            both = part.sum(0) if slabs > 1 else part[0]
+            if want_gw:
+                gw = both[:, :F]
+            if want_gb:
+                gbias = both[:, F]
+        return (gxd, None, gw, gbias, None, None, None, None, None, None, None)
 
 
 def pool_large(x: Tensor, adj: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], mask: Optional[Tensor],
-               s: Optional[Tensor], flags: int, mode: int, scales=(0.0, 0.0), graph_sizes: Optional[Tensor] = None):
+               s: Optional[Tensor], flags: int, mode: int, scales=(0.0, 0.0), graph_sizes: Optional[Tensor] = None,
+               symmetry=None):
     """(s, x_pool, raw, adj_pool, LossPair or None): see :class:`_PoolLargeFn`.  Give either the selector's single Linear
-    (``weight`` [K,F], ``bias``, ``mask``: S is formed inside and returned) or ``s`` itself."""
-    out = _PoolLargeFn.apply(x, adj, weight, bias, mask, s, flags, mode, tuple(scales), graph_sizes)
+    (``weight`` [K,F], ``bias``, ``mask``: S is formed inside and returned) or ``s`` itself.  ``symmetry``: a
+    :class:`kernels.AdjSymmetry` (or anything with ``get() -> bool``) when the caller can tell whether A = A^T."""
+    out = _PoolLargeFn.apply(x, adj, weight, bias, mask, s, flags, mode, tuple(scales), graph_sizes, symmetry)
     pair = LossPair((out[4], out[5])) if mode else None
     return (out[0] if s is None else s), out[1], out[2], out[3], pair
 

@@ -270,6 +270,21 @@ class _SpsState:
                     raise N.TgpNativeError("tgp_batch_facts_sorted_i64 finished without storing its result word")
         return int(host[o + 1]), int(host[o + 2]), int(host[o + 3]), int(host[o + 4]), int(host[o + 5])
 
+    def peek_facts(self, tag: int):
+        """The flag word of call ``tag``, or None when its slot has been reused by a later call (eight slots rotate)."""
+        host, spins, o = self.facts_host, 0, 8 * (tag & 7)
+        while True:
+            have = int(host[o])
+            if have == tag:
+                return int(host[o + 2])
+            if have > tag:
+                return None
+            spins += 1
+            if spins > 4_000_000:
+                torch.cuda.synchronize(self.status.device)
+                if int(host[o]) < tag:
+                    raise N.TgpNativeError("a facts launch finished without storing its result word")
+
     def next_epoch(self) -> int:
         self.epoch += 1
         if self.epoch >= (1 << 29) - 1:  # epochs of a buffer never repeat: start over on a cleared buffer
@@ -1073,6 +1088,71 @@ def edge_facts_finish(handle, edge_index: Tensor, graph_ptr: Tensor) -> bool:
     return True
 
 
+_ADJ_SYMMETRIC: dict = {}  # id(edge_index) -> (weakref, version, weakref of the weights or None, its version, flag)
+
+
+def _adj_symmetric_memo(edge_index: Tensor, edge_weight: Optional[Tensor]) -> Optional[bool]:
+    hit = _ADJ_SYMMETRIC.get(id(edge_index))
+    if (hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version
+            and ((hit[2] is None and edge_weight is None)
+                 or (hit[2] is not None and hit[2]() is edge_weight and hit[3] == edge_weight._version))):
+        return hit[4]
+    return None
+
+
+def _remember_adj_symmetric(edge_index: Tensor, edge_weight: Optional[Tensor], flag: bool) -> None:
+    import weakref
+    if len(_ADJ_SYMMETRIC) >= 16:
+        for key in [k for k, v in _ADJ_SYMMETRIC.items() if v[0]() is None]:
+            del _ADJ_SYMMETRIC[key]
+        while len(_ADJ_SYMMETRIC) >= 16:
+            del _ADJ_SYMMETRIC[next(iter(_ADJ_SYMMETRIC))]
+    _ADJ_SYMMETRIC[id(edge_index)] = (weakref.ref(edge_index), edge_index._version,
+                                      None if edge_weight is None else weakref.ref(edge_weight),
+                                      None if edge_weight is None else edge_weight._version, flag)
+
+
+class AdjSymmetry:
+    """Is the dense adjacency ``to_dense_adj`` built from this edge list symmetric?  Asked in the forward of the dense
+    poolers' training step (one launch over the entries, tgp_adj_symmetry_f32, verdict into a pinned host word),
+    answered in its backward -- hundreds of microseconds later, so the answer is simply there.  A symmetric A makes
+    V = A^T S equal to U = A S: the backward then runs ONE N^2 K product less.  Remembered per (edge_index, edge_weight)
+    tensor objects.  ``get()`` = True only when the answer is known to be yes."""
+
+    __slots__ = ("state", "tag", "answer", "ei", "ew")
+
+    def __init__(self, edge_index: Tensor, edge_weight: Optional[Tensor], adj: Tensor, batch: Tensor, ptr: Tensor):
+        import weakref
+        self.state = self.tag = None
+        self.ei, self.ew = weakref.ref(edge_index), (None if edge_weight is None else weakref.ref(edge_weight))
+        self.answer = _adj_symmetric_memo(edge_index, edge_weight)
+        if self.answer is not None:
+            return
+        row, col = _edge_rows(edge_index)
+        E = row.numel()
+        if (E == 0 or adj.dim() != 3 or adj.size(1) != adj.size(2) or not adj.is_contiguous() or adj.dtype != torch.float32
+                or torch.cuda.is_current_stream_capturing()):
+            self.answer = E == 0 and not torch.cuda.is_current_stream_capturing()
+            return
+        dev = adj.device
+        st = N.stream_ptr(dev)
+        self.state = _sps_state(dev, st, 0)
+        self.tag = self.state.next_facts_tag()
+        N.check(N.lib().tgp_adj_symmetry_f32(N.ptr(row), N.ptr(col), E, N.ptr(N.i64c(batch)), N.ptr(N.i64c(ptr)),
+                                             adj.size(1), N.ptr(adj), self.state.ticket.data_ptr() + 8,
+                                             self.state.facts_slot(self.tag), self.tag, st), "tgp_adj_symmetry_f32")
+
+    def get(self) -> bool:
+        if self.answer is None:
+            flags = self.state.peek_facts(self.tag)
+            self.answer = flags == 0 if flags is not None else False  # (slot reused by later calls: not known)
+            if flags is not None:
+                ei, ew = self.ei(), (None if self.ew is None else self.ew())
+                if ei is not None and (self.ew is None or ew is not None):
+                    _remember_adj_symmetric(ei, ew, self.answer)
+        return bool(self.answer)
+
+
 def dense_pool_select_sparse(x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor,
                              node_ptr: Tensor, edge_ptr: Tensor, num_graphs: int, max_nodes: int, weight: Tensor,
                              bias: Optional[Tensor], flags: int, adj_transpose: bool, want_raw: bool = False,
@@ -1366,24 +1446,27 @@ def cut_rows(adj: Tensor, s: Tensor, graph_sizes: Optional[Tensor] = None) -> Tu
     return deg, q
 
 
-def mincut_terms_fused(raw: Tensor, gram: Tensor, deg: Tensor, q: Tensor) -> Tuple[Tensor, Tensor]:
-    """(den [B], terms [2,B]): MinCut's per-graph loss tails with den = sum_i deg_i q_i formed in the same launch
-    (utils/losses.py:39-70)."""
+def mincut_terms_fused(raw: Tensor, gram: Tensor, deg: Tensor, q: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """(den [B], terms [2,B], stats [B,4]): MinCut's per-graph loss tails with den = sum_i deg_i q_i formed in the same
+    launch (utils/losses.py:39-70); stats = (trace(raw), |G|^2, trace(G), |Y|) per graph, the scalars the backward's
+    right-hand sides need."""
     dev = N.require_device(raw, gram, deg, q)
     raw, gram, deg, q = N.f32c(raw), N.f32c(gram), N.f32c(deg), N.f32c(q)
     B, Kc, Nn = raw.size(0), raw.size(-1), deg.size(-1)
     den = torch.empty(B, dtype=torch.float32, device=dev)
     out = torch.empty(2, B, dtype=torch.float32, device=dev)
+    stats = torch.empty(B, 4, dtype=torch.float32, device=dev)
     N.check(N.lib().tgp_mincut_terms_fused_f32(N.ptr(raw), N.ptr(gram), N.ptr(deg), N.ptr(q), B, Nn, Kc, losses_eps(),
-                                               N.ptr(den), N.ptr(out), N.stream_ptr(dev)), "tgp_mincut_terms_fused_f32")
-    return den, out
+                                               N.ptr(den), N.ptr(out), N.ptr(stats), N.stream_ptr(dev)),
+            "tgp_mincut_terms_fused_f32")
+    return den, out, stats
 
 
 def dense_pool_train_fwd(s: Tensor, adj_mem: Tensor, x: Tensor, flags: int, acat: Tensor, want_gram: bool,
                          want_post: bool = True):
     """(x_pool, raw, adj_pool, gram): forward of the dense poolers' training step beyond the one-wave kernels
     (base_reduce.py:158-161, dense_conn.py:111-122, utils/ops.py:282-335).  ``adj_mem`` is the contiguous adjacency
-    memory (``flags`` carries ``ADJ_TRANSPOSED`` when it holds A^T), ``acat`` [B,N,3K+F] the operand buffer of the
+    memory (``flags`` carries ``ADJ_TRANSPOSED`` when it holds A^T), ``acat`` [B,N,3K+F+4] the operand buffer of the
     backward whose first K columns receive U = A S; ``gram`` = S^T S when asked for."""
     dev = N.require_device(s, adj_mem, x, acat)
     B, Nn, Kc = s.shape
@@ -1404,49 +1487,62 @@ def dense_pool_train_fwd(s: Tensor, adj_mem: Tensor, x: Tensor, flags: int, acat
     return x_pool, raw, adj_pool, gram
 
 
-def dense_pool_train_rhs(g_raw_a: Optional[Tensor], g_raw_b: Optional[Tensor], mode: int, raw: Optional[Tensor],
+def dense_pool_train_rhs(g_raw_a: Optional[Tensor], g_raw_b: Optional[Tensor], mode: int, stats: Optional[Tensor],
                          den: Optional[Tensor], gram: Optional[Tensor], g_la: Optional[Tensor], g_lb: Optional[Tensor],
                          scale: float, link_loss: Optional[Tensor], link_scale: float, g_x: Optional[Tensor],
-                         gx_bcast: bool, B: int, Kc: int, F: int, dev):
-    """(rcat [B,3K+F,K], c1 [B] or None): the right-hand sides [RU ; RV ; RX ; RS] of the training step's backward GEMM
+                         gx_bcast: bool, symmetric: bool, weight: Optional[Tensor], B: int, Kc: int, F: int, dev):
+    """(rcat [B,3K+F+4,K], c1 [B] or None, gw [B,2K,F] or None): the right-hand sides [RU ; RX ; 0 ; RS ; RV] of the
+    training step's backward GEMM and, with the selector's ``weight``, [g_x ; W] for gX = [S | dY] [g_x ; W]
     (see tgp_dense_pool_train_rhs_f32 in include/tgp_hip.h)."""
-    rcat = torch.empty(B, 3 * Kc + F, Kc, dtype=torch.float32, device=dev)
+    rcat = torch.empty(B, 3 * Kc + F + TRAIN_PAD, Kc, dtype=torch.float32, device=dev)
     c1 = torch.empty(B, dtype=torch.float32, device=dev) if mode == 1 else None
-    N.check(N.lib().tgp_dense_pool_train_rhs_f32(N.ptr(g_raw_a), N.ptr(g_raw_b), mode, N.ptr(raw), N.ptr(den),
+    gw = torch.empty(B, 2 * Kc, F, dtype=torch.float32, device=dev) if weight is not None else None
+    w = None if weight is None else N.f32c(weight.detach())
+    N.check(N.lib().tgp_dense_pool_train_rhs_f32(N.ptr(g_raw_a), N.ptr(g_raw_b), mode, N.ptr(stats), N.ptr(den),
                                                  N.ptr(gram), N.ptr(g_la), N.ptr(g_lb), float(scale), N.ptr(link_loss),
-                                                 float(link_scale), losses_eps(), N.ptr(g_x), 1 if gx_bcast else 0, B,
-                                                 Kc, F, N.ptr(rcat), N.ptr(c1), N.stream_ptr(dev)),
-            "tgp_dense_pool_train_rhs_f32")
-    return rcat, c1
+                                                 float(link_scale), losses_eps(), N.ptr(g_x), 1 if gx_bcast else 0,
+                                                 1 if symmetric else 0, N.ptr(w), B, Kc, F, N.ptr(rcat), N.ptr(c1),
+                                                 N.ptr(gw), N.stream_ptr(dev)), "tgp_dense_pool_train_rhs_f32")
+    return rcat, c1, gw
 
 
 def softmax_bwd_ex(s: Tensor, ds: Tensor, extra: Optional[Tensor] = None, c1: Optional[Tensor] = None,
-                   deg: Optional[Tensor] = None, ent_g: Optional[Tensor] = None, ent_scale: float = 0.0) -> Tensor:
+                   deg: Optional[Tensor] = None, ent_g: Optional[Tensor] = None, ent_scale: float = 0.0,
+                   out: Optional[Tensor] = None) -> Tensor:
     """:func:`softmax_bwd` on dS + extra + 2 c1[graph] deg[row] S - ent_g ent_scale (log(S + eps) + S / (S + eps)):
-    the elementwise parts of the pooling step's gradient folded into the selector's softmax backward.  s [B,N,K]."""
+    the elementwise parts of the pooling step's gradient folded into the selector's softmax backward.  s [B,N,K];
+    ``out``: a [B,N,K] float32 view with unit last stride and uniform row stride (a column block of a wider buffer)."""
     dev = N.require_device(s, ds)
     B, Nn, Kc = s.shape
     s2, d2 = N.f32c(s), N.f32c(ds)
     ex = None if extra is None else N.f32c(extra)
     if d2.numel() != s2.numel() or (ex is not None and ex.numel() != s2.numel()):
         raise ValueError("softmax_bwd_ex: gradient shapes do not match s")
-    out = torch.empty_like(s2)
+    if out is None:
+        out = torch.empty_like(s2)
+    elif (out.shape != s2.shape or out.dtype != torch.float32 or out.stride(2) != 1
+          or out.stride(0) != Nn * out.stride(1)):
+        raise ValueError("softmax_bwd_ex: out must be a float32 [B,N,K] view with a uniform row stride")
     N.check(N.lib().tgp_softmax_bwd_ex_f32(N.ptr(s2), N.ptr(d2), N.ptr(ex), N.ptr(None if c1 is None else N.f32c(c1)),
                                            N.ptr(None if deg is None else N.f32c(deg)), Nn,
                                            N.ptr(None if ent_g is None else N.f32c(ent_g.reshape(1))), float(ent_scale),
-                                           losses_eps(), N.ptr(out), B * Nn, Kc, N.stream_ptr(dev)),
+                                           losses_eps(), out.data_ptr(), out.stride(1), B * Nn, Kc, N.stream_ptr(dev)),
             "tgp_softmax_bwd_ex_f32")
     return out
 
 
-def copy_cols2(a: Tensor, b: Tensor, dst: Tensor, col_a: int, col_b: int) -> None:
-    """dst[:, col_a:col_a+wa] = a, dst[:, col_b:col_b+wb] = b for row-major 2-D float32 tensors, one launch."""
+TRAIN_PAD = 4  # width of the [1 0 0 0] column block of the training step's operand buffer (csrc/losses.hip)
+
+
+def copy_cols2(a: Tensor, b: Tensor, dst: Tensor, col_a: int, col_b: int, one_col: int = -1) -> None:
+    """dst[:, col_a:col_a+wa] = a, dst[:, col_b:col_b+wb] = b for row-major 2-D float32 tensors, one launch;
+    ``one_col >= 0``: also dst[:, one_col:one_col+4] = [1 0 0 0]."""
     dev = N.require_device(a, b, dst)
     if not (a.is_contiguous() and b.is_contiguous() and dst.is_contiguous()) or a.size(0) != dst.size(0) \
             or b.size(0) != dst.size(0):
         raise ValueError("copy_cols2: operands must be contiguous with equal row counts")
     N.check(N.lib().tgp_copy_cols2_f32(N.ptr(a), a.size(1), N.ptr(b), b.size(1), dst.size(0), N.ptr(dst), dst.size(1),
-                                       col_a, col_b, N.stream_ptr(dev)), "tgp_copy_cols2_f32")
+                                       col_a, col_b, one_col, N.stream_ptr(dev)), "tgp_copy_cols2_f32")
 
 
 def bmm_into(a: Tensor, b: Tensor, out: Tensor, trans_a: bool = False, accumulate: bool = False) -> Tensor:

@@ -373,7 +373,7 @@ class _DenseMLPPooling(DenseSRCPooling):
             fused = fused + (pair,)
         return so, fused, bp
 
-    def _select_reduce_connect_large(self, x, adj, mask, graph_sizes, so=None):
+    def _select_reduce_connect_large(self, x, adj, mask, graph_sizes, so=None, symmetry=None):
         """Training on a padded batch whose graphs are beyond the one-wave kernels (C2-sized), r6: Select (single-Linear
         selector; otherwise ``so`` holds S) + Reduce + Connect + post-processing + the pooler's two losses as ONE
         autograd node (functions._PoolLargeFn: ~10 forward and ~13 backward launches where the operator-by-operator graph
@@ -411,11 +411,25 @@ class _DenseMLPPooling(DenseSRCPooling):
             if diff_scales is None:
                 return None
             mode, scales = 2, diff_scales
-        s_out, x_pool, raw, adj_pool, pair = Fn.pool_large(x, adj, weight, bias, mask, s, flags, mode, scales, graph_sizes)
+        s_out, x_pool, raw, adj_pool, pair = Fn.pool_large(x, adj, weight, bias, mask, s, flags, mode, scales, graph_sizes,
+                                                           symmetry() if callable(symmetry) else symmetry)
         if so is None:
             so = SelectOutput(s=s_out, s_inv_op=sel.s_inv_op, in_mask=mask)
         fused = (x_pool, raw if self._loss_needs_raw else None, adj_pool, pair)
         return so, fused, None
+
+    @staticmethod
+    def _adj_symmetry(edge_index, edge_weight, dense_adj, batch):
+        """kernels.AdjSymmetry for the adjacency forward() densified from this edge list, or None."""
+        from .. import kernels as K
+        if not (isinstance(edge_index, Tensor) and edge_index.dim() == 2 and edge_index.size(0) == 2
+                and edge_index.dtype == torch.long and edge_index.is_cuda and batch is not None
+                and (edge_weight is None or isinstance(edge_weight, Tensor))):
+            return None
+        info = batch_info(batch)
+        if not info.is_sorted or info.num_graphs != dense_adj.size(0):
+            return None
+        return K.AdjSymmetry(edge_index, edge_weight, dense_adj, batch, info.ptr)
 
     def _sizes_for(self, adj):
         """Real nodes per graph of the zero-padded batch ``adj`` belongs to, if forward() densified it itself."""
@@ -461,6 +475,7 @@ class _DenseMLPPooling(DenseSRCPooling):
                     graph_sizes = batch_info(batch).sizes  # memoised: the densification below asks for it anyway
             elif mask is None and isinstance(x, Tensor) and x.dim() == 3:
                 self._known_nodes = x.size(0) * x.size(1)
+            sparse_edges = (adj, edge_weight) if sparse_in else None
             x, adj, mask = self._ensure_batched_inputs(x=x, edge_index=adj, edge_weight=edge_weight, batch=batch,
                                                        mask=mask)
             # (the folded kernels also write the pooled batch vector: arange(B).repeat_interleave(K) of the B graphs)
@@ -468,8 +483,13 @@ class _DenseMLPPooling(DenseSRCPooling):
             folded = self._select_reduce_connect(x, adj, mask, want_bp)
             if folded is None and _FOLD_TRAINING:
                 folded = self._select_reduce_connect_train(x, adj, mask, graph_sizes, want_bp)
+            symmetry = None
+            if sparse_in and _FOLD_TRAINING and torch.is_grad_enabled() and isinstance(adj, Tensor) and adj.dim() == 3:
+                # (asked only when the one-node path takes the call: a launch over the entries, answered in its backward)
+                dense_adj, ei_in, ew_in = adj, sparse_edges[0], sparse_edges[1]
+                symmetry = lambda: self._adj_symmetry(ei_in, ew_in, dense_adj, batch)  # noqa: E731
             if folded is None and _FOLD_TRAINING:  # graphs beyond the one-wave kernels: one autograd node as well (r6)
-                folded = self._select_reduce_connect_large(x, adj, mask, graph_sizes)
+                folded = self._select_reduce_connect_large(x, adj, mask, graph_sizes, symmetry=symmetry)
             so = folded[0] if folded is not None else self.select(x=x, mask=mask)
             self._sizes_hint = None
             if graph_sizes is not None and graph_sizes.numel() == x.size(0):
@@ -480,7 +500,7 @@ class _DenseMLPPooling(DenseSRCPooling):
                 x, adj, so, want_raw=self._loss_needs_raw, want_mincut_terms=self._loss_needs_raw,
                 want_diff_losses=diff_scales)
             if fused is None and _FOLD_TRAINING:  # a selector with hidden layers made S: the pooling step is one node still
-                big = self._select_reduce_connect_large(x, adj, mask, graph_sizes, so=so)
+                big = self._select_reduce_connect_large(x, adj, mask, graph_sizes, so=so, symmetry=symmetry)
                 if big is not None:
                     fused = big[1]
             if fused is not None:  # Reduce + Connect in one native call (training: batches of small graphs only)
