@@ -634,6 +634,7 @@ int tgp_mincut_loss_terms_bwd_f32(const float* raw, const float* den, const floa
  * tgp_mincut_terms_fused_f32: MinCut's per-graph loss tails out [2,B] (as tgp_mincut_loss_terms_f32) with
  *   den[b] = sum_i deg[b,i] q[b,i] formed in the same launch (deg, q [B,N] from tgp_cut_terms_f32) and kept for the
  *   backward together with stats [B,4] = (trace(raw), |G|_F^2, trace(G), |G / |G| - I / sqrt(K)|_F) per graph (optional).
+ *   ptr (optional, [B+1]): deg / q are those of an UN-padded batch, graph b owns entries ptr[b] .. ptr[b+1] (N unused).
  * tgp_dense_pool_train_rhs_f32: the right-hand sides into rcat [B][3K+F+4][K], rows [RU ; RX ; four zero rows ; RS ; RV]:
  *   with gR = g_raw_a + g_raw_b (either may be NULL) + the loss' diagonal term, RV = gR, RU = gR^T (`symmetric`:
  *   RU = gR + gR^T, RV not written), RX = g_x^T (g_x [B,K,F], or one value when gx_bcast), RS by mode:
@@ -656,7 +657,8 @@ int tgp_dense_pool_train_fwd_f32(const float* S, const float* A, const float* X,
                                  int64_t F, int flags, float eps, float* U, int64_t ldu, float* x_pool, float* adj_raw,
                                  float* adj_pool, float* gram, void* ws, size_t ws_bytes, void* stream);
 int tgp_mincut_terms_fused_f32(const float* raw, const float* gram, const float* deg, const float* q, int64_t B,
-                               int64_t N, int64_t K, float eps, float* den, float* out, float* stats, void* stream);
+                               int64_t N, int64_t K, float eps, float* den, float* out, float* stats, const int64_t* ptr,
+                               void* stream);
 int tgp_dense_pool_train_rhs_f32(const float* g_raw_a, const float* g_raw_b, int mode, const float* stats, const float* den,
                                  const float* gram, const float* g_la, const float* g_lb, float scale,
                                  const float* link_loss, float link_scale, float eps, const float* g_x, int gx_bcast,
@@ -665,6 +667,32 @@ int tgp_dense_pool_train_rhs_f32(const float* g_raw_a, const float* g_raw_b, int
 int tgp_softmax_bwd_ex_f32(const float* s, const float* ds, const float* extra, const float* c1, const float* deg,
                            int64_t rows_per_graph, const float* ent_g, float ent_scale, float ent_eps, float* dy,
                            int64_t ld_dy, int64_t M, int64_t K, void* stream);
+/* ------------------------------------------------------------------------------------
+ * N3 (r6)  The UNBATCHED dense poolers' forward (mincut_u / diff_u: S [Ntot,K], sparse A) from the products their
+ * Connect forms anyway -- no per-edge dot products, no index_add scatters (utils/losses.py:73-127, 204-240, 661-708;
+ * connect/dense_conn.py:140-208; reduce/base_reduce.py:170-182):
+ *   sum_{e in g} w_e <S_row, S_col> = trace(S_g^T (A S)_g) = trace(raw_g)       (sparse_mincut_loss' numerator)
+ *   |A - S S^T|_F^2 = sum_e w_e^2 - 2 sum_g trace(raw_g) + sum_g |S_g^T S_g|_F^2  (sparse_link_pred_loss)
+ * tgp_segment_gemm_tn3_f32: C_j[b] = S_b^T Y_j,b for up to three right-hand sides Y_j [Ntot,F_j] in one grid (+ one
+ *   combine launch): S^T [A S | X | S] = raw pooled adjacency, pooled features, per-graph Gram matrices.
+ * tgp_edge_row_stats_f32: deg[i] = sum of w over CSR row i (entry count when w is NULL), q[i] = |S_i|^2.
+ * tgp_diffpool_unbatched_tail_f32: out2 = (sqrt(max(sw2 - 2 sum_b trace(raw_b) + sum_b |gram_b|^2, 0)) link_scale,
+ *   (sum of ent_partial) ent_scale); sw2 = sum_e w_e^2 from *sw2_dev when not NULL, else sw2_host; stats [B,2] scratch.
+ * ---------------------------------------------------------------------------------- */
+size_t tgp_segment_gemm_tn3_workspace_bytes(int64_t B, int64_t K, int64_t F0, int64_t F1, int64_t F2, int64_t max_nodes);
+int tgp_segment_gemm_tn3_f32(const float* S, const float* Y0, int64_t F0, const float* Y1, int64_t F1, const float* Y2,
+                             int64_t F2, const int64_t* ptr, float* C0, float* C1, float* C2, int64_t B, int64_t Ntot,
+                             int64_t K, int64_t max_nodes, void* ws, size_t ws_bytes, void* stream);
+int tgp_edge_row_stats_f32(const int32_t* row_ptr, const float* w, const float* S, int64_t N, int64_t K, float* deg,
+                           float* q, void* stream);
+int tgp_diffpool_unbatched_tail_f32(const float* raw, const float* gram, int64_t B, int64_t K, const float* sw2_dev,
+                                    float sw2_host, const float* ent_partial, int n_partial, float link_scale,
+                                    float ent_scale, float* stats, float* out2, void* stream);
+
+/* part [slabs][K][W] (W >= F + 1: dY^T [X | 1 0 0 0] per row slab) -> gw [K][F] (columns 0..F-1) and gb [K] (column F), the
+ * slabs added in order; either output may be NULL. */
+int tgp_slab_sum_split_f32(const float* part, int64_t slabs, int64_t K, int64_t F, int64_t W, float* gw, float* gb,
+                           void* stream);
 int tgp_adj_symmetry_f32(const int64_t* row, const int64_t* col, int64_t E, const int64_t* batch, const int64_t* ptr,
                          int64_t Nmax, const float* adj, uint32_t* ticket, uint64_t* result, uint64_t tag, void* stream);
 int tgp_copy_cols2_f32(const float* a, int64_t wa, const float* b, int64_t wb, int64_t rows, float* dst, int64_t ld,

@@ -465,6 +465,37 @@ extern "C" int tgp_copy_cols2_f32(const float* a, int64_t wa, const float* b, in
   return check_launch("tgp_copy_cols2_f32");
 }
 
+// part [slabs][K][F + 4] (dY^T [X | 1 0 0 0] per row slab) -> gw [K][F] and gb [K], slabs added in order: the weight and
+// bias gradient of the selector leave as two contiguous tensors (a strided view of one sum would be copied once more by
+// autograd's gradient accumulation).
+namespace tgp {
+__global__ __launch_bounds__(256) void slab_sum_split_kernel(const float* __restrict__ part, int slabs, int K, int F, int W,
+                                                             float* __restrict__ gw, float* __restrict__ gb) {
+  const long total = static_cast<long>(K) * (F + 1);
+  for (long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<long>(gridDim.x) * 256) {
+    const int k = static_cast<int>(e / (F + 1)), f = static_cast<int>(e - static_cast<long>(k) * (F + 1));
+    const float* src = part + static_cast<long>(k) * W + f;
+    float v = 0.f;
+    for (int sp = 0; sp < slabs; ++sp) v = __fadd_rn(v, src[static_cast<long>(sp) * K * W]);
+    if (f < F) { if (gw) gw[static_cast<long>(k) * F + f] = v; }
+    else if (gb) gb[k] = v;
+  }
+}
+}  // namespace tgp
+
+extern "C" int tgp_slab_sum_split_f32(const float* part, int64_t slabs, int64_t K, int64_t F, int64_t W, float* gw,
+                                      float* gb, void* stream_) {
+  TGP_REQUIRE(slabs >= 1 && K >= 1 && F >= 0 && W >= F + 1 && slabs < (1ll << 20) && K < (1ll << 24) && W < (1ll << 24),
+              TGP_ERR_INVALID, "tgp_slab_sum_split_f32: bad shape");
+  TGP_REQUIRE(part && (gw || gb), TGP_ERR_INVALID, "tgp_slab_sum_split_f32: null pointer");
+  const int64_t total = K * (F + 1);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(slab_sum_split_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     part, static_cast<int>(slabs), static_cast<int>(K), static_cast<int>(F), static_cast<int>(W), gw, gb);
+  return check_launch("tgp_slab_sum_split_f32");
+}
+
 extern "C" size_t tgp_postprocess_dense_workspace_bytes(int64_t B, int64_t K) {
   if (B <= 0 || K <= 0) return 256;
   return align_up(post_ws_floats(B, K) * 4) + 256;
@@ -753,6 +784,97 @@ extern "C" int tgp_segment_gemm_tn_f32(const float* S, const float* Y, const int
                        K * F, static_cast<long>(splits) * K * F, total, C);
   }
   return check_launch("tgp_segment_gemm_tn_f32");
+}
+
+// r6: the same product with up to THREE right-hand sides in one grid -- C_j[b] = S_b^T Y_j,b -- for the unbatched dense
+// poolers' forward: S^T [T | X | S] gives the raw pooled adjacency (T = A S from the CSR SpMM), the pooled features and
+// the per-graph Gram matrices (orthogonality / link losses) from one pass over S (dense_conn.py:195-206,
+// base_reduce.py:170-182, utils/losses.py:204-240).  Slabs [B][splits][K][F_j] per right-hand side, combined in split
+// order by one launch.
+namespace tgp {
+struct Combine3Args {
+  const float* src[3]; float* dst[3]; long total[3];
+  int splits;
+};
+__global__ __launch_bounds__(256) void combine_slabs3_kernel(Combine3Args a) {
+  const int b = blockIdx.y, j = blockIdx.z;
+  const long total = a.total[j];
+  if (total == 0) return;
+  const float* sb = a.src[j] + static_cast<long>(b) * a.splits * total;
+  float* db = a.dst[j] + static_cast<long>(b) * total;
+  for (long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<long>(gridDim.x) * 256) {
+    float v = sb[e];
+    for (int sp = 1; sp < a.splits; ++sp) v = __fadd_rn(v, sb[sp * total + e]);
+    db[e] = v;
+  }
+}
+}  // namespace tgp
+
+static int segment3_splits(int64_t B, int64_t K, int64_t F0, int64_t F1, int64_t F2, int64_t span) {
+  const int64_t tiles = ((K + 63) / 64) * (((F0 + 63) / 64) + ((F1 + 63) / 64) + ((F2 + 63) / 64));
+  const int64_t wgs = (B > 0 ? B : 1) * (tiles > 0 ? tiles : 1);
+  int64_t splits = (3 * 256 + wgs - 1) / wgs;
+  const int64_t max_splits = (span + 4 * BK - 1) / (4 * BK);
+  if (splits > max_splits) splits = max_splits;
+  if (splits > 64) splits = 64;
+  return splits < 1 ? 1 : static_cast<int>(splits);
+}
+
+extern "C" size_t tgp_segment_gemm_tn3_workspace_bytes(int64_t B, int64_t K, int64_t F0, int64_t F1, int64_t F2,
+                                                       int64_t max_nodes) {
+  if (B <= 0 || K <= 0) return 256;
+  const int splits = segment3_splits(B, K, F0, F1, F2, max_nodes);
+  size_t bytes = 256;
+  const int64_t fs[3] = {F0, F1, F2};
+  for (int j = 0; j < 3; ++j)
+    if (fs[j] > 0) bytes += align_up(static_cast<size_t>(B) * splits * K * fs[j] * sizeof(float));
+  return bytes;
+}
+
+extern "C" int tgp_segment_gemm_tn3_f32(const float* S, const float* Y0, int64_t F0, const float* Y1, int64_t F1,
+                                        const float* Y2, int64_t F2, const int64_t* ptr, float* C0, float* C1, float* C2,
+                                        int64_t B, int64_t Ntot, int64_t K, int64_t max_nodes, void* ws, size_t ws_bytes,
+                                        void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && Ntot >= 0 && K >= 0 && F0 > 0 && F1 >= 0 && F2 >= 0 && (F1 > 0 || F2 == 0), TGP_ERR_INVALID,
+              "tgp_segment_gemm_tn3_f32: bad sizes (right-hand sides are filled front to back)");
+  if (B == 0 || K == 0) return TGP_OK;
+  TGP_REQUIRE(ptr && C0 && (F1 == 0 || C1) && (F2 == 0 || C2) && (Ntot == 0 || (S && Y0 && (F1 == 0 || Y1) && (F2 == 0 || Y2))),
+              TGP_ERR_INVALID, "tgp_segment_gemm_tn3_f32: null pointer");
+  TGP_REQUIRE(Ntot < (1ll << 31) && K < (1ll << 31) && F0 < (1ll << 31) && F1 < (1ll << 31) && F2 < (1ll << 31),
+              TGP_ERR_RANGE, "tgp_segment_gemm_tn3_f32: too large");
+  const int64_t span = max_nodes > 0 ? max_nodes : Ntot;
+  const int splits = segment3_splits(B, K, F0, F1, F2, span);
+  TGP_REQUIRE(ws && ws_bytes >= tgp_segment_gemm_tn3_workspace_bytes(B, K, F0, F1, F2, max_nodes), TGP_ERR_WORKSPACE,
+              "tgp_segment_gemm_tn3_f32: workspace too small");
+  const float* Y[3] = {Y0, Y1, Y2};
+  float* C[3] = {C0, C1, C2};
+  const int64_t fs[3] = {F0, F1, F2};
+  Carver cv(ws);
+  GemmArgs g{};
+  g.A = S; g.lda = K; g.sA = 0;
+  g.M = static_cast<int>(K); g.Kd = static_cast<int>(Ntot);
+  Combine3Args ca{};
+  ca.splits = splits;
+  long max_total = 0;
+  for (int j = 0; j < 3; ++j) {
+    if (fs[j] <= 0) continue;
+    float* slab = cv.take<float>(static_cast<size_t>(B) * splits * K * fs[j]);
+    g.rhs[j] = GemmRhs{Y[j], slab, static_cast<int>(fs[j]), fs[j], fs[j], 0, static_cast<long>(splits) * K * fs[j], K * fs[j]};
+    ca.src[j] = slab; ca.dst[j] = C[j]; ca.total[j] = K * fs[j];
+    if (ca.total[j] > max_total) max_total = ca.total[j];
+  }
+  g.splits = splits;
+  int64_t kps = ((span + splits - 1) / splits + BK - 1) / BK * BK;
+  if (kps < BK) kps = BK;
+  g.k_per_split = static_cast<int>(kps);
+  g.k_ptr = ptr;
+  g.force_bm = 64; g.force_bn = 64;
+  launch_gemm<true>(g, static_cast<int>(B), stream);
+  int gx = static_cast<int>((max_total + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(combine_slabs3_kernel, dim3(gx, static_cast<unsigned>(B), 3), dim3(256), 0, stream, ca);
+  return check_launch("tgp_segment_gemm_tn3_f32");
 }
 
 // Row-side counterpart (lift/base_lift.py:138-247 on an un-padded batch; backward of the products above):

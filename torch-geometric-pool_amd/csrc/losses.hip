@@ -400,13 +400,17 @@ template <int T>
 __global__ __launch_bounds__(T) void mincut_tail2_kernel(const float* __restrict__ raw, const float* __restrict__ gram,
                                                            const float* __restrict__ deg, const float* __restrict__ q,
                                                            int N, int K, float eps, int B, float* __restrict__ den,
-                                                           float* __restrict__ out, float* __restrict__ stats) {
+                                                           float* __restrict__ out, float* __restrict__ stats,
+                                                           const int64_t* __restrict__ ptr) {
   __shared__ float sh[T / 64];
   const int b = blockIdx.x;
   const float* R = raw + static_cast<int64_t>(b) * K * K;
   const float* G = gram + static_cast<int64_t>(b) * K * K;
-  const float* d = deg + static_cast<int64_t>(b) * N;
-  const float* qq = q + static_cast<int64_t>(b) * N;
+  // padded batch: graph b owns entries b N .. b N + N of deg / q; un-padded (ptr): entries ptr[b] .. ptr[b + 1]
+  const int64_t lo = ptr ? ptr[b] : static_cast<int64_t>(b) * N;
+  if (ptr) N = static_cast<int>(ptr[b + 1] - lo);
+  const float* d = deg + lo;
+  const float* qq = q + lo;
   float dn = 0.f, tr = 0.f, sq = 0.f, trg = 0.f;
   for (int i = threadIdx.x; i < N; i += T) dn = fmaf(d[i], qq[i], dn);
   for (int i = threadIdx.x; i < K; i += T) {
@@ -578,9 +582,114 @@ __global__ __launch_bounds__(256) void train_rhs_kernel(TrainRhsArgs p) {
 }
 }  // namespace tgp
 
+// ---- r6: the unbatched dense poolers' losses from the products their Connect forms anyway ---------------------------
+// sparse_mincut_loss (utils/losses.py:73-127): num_g = sum_{e in g} w_e <S_row, S_col> = sum_{i in g} <S_i, (A S)_i>
+//   = trace(S_g^T (A S)_g) = trace(raw_g);  den_g = sum_{i in g} deg_i |S_i|^2 with deg_i = sum of the weights of row i.
+// sparse_link_pred_loss (losses.py:661-708): |A - S S^T|^2 = sum_e (w_e - ss_e)^2 + sum_g |G_g|^2 - sum_e ss_e^2
+//   = sum_e w_e^2 - 2 sum_g trace(raw_g) + sum_g |G_g|^2   (ss_e = <S_row, S_col>; sum_e w_e ss_e = sum_g trace(raw_g)).
+// So the per-edge dot products, the index_add_ scatters and the masks behind them (40-45 launches per forward, r5) are
+// replaced by: one pass over the CSR rows (deg, q), the S^T [T | X | S] product, and a per-graph tail.
+namespace tgp {
+// deg[i] = sum of w over row i's entries (their count when w is NULL), q[i] = |S_i|^2; G lanes per row.
+template <int G>
+__global__ __launch_bounds__(256) void edge_row_stats_kernel(const int* __restrict__ row_ptr, const float* __restrict__ w,
+                                                             const float* __restrict__ S, int64_t N, int K,
+                                                             float* __restrict__ deg, float* __restrict__ q) {
+  const int sub = threadIdx.x % G;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * (256 / G) + threadIdx.x / G;
+  float d = 0.f, qq = 0.f;
+  if (i < N) {
+    const int e0 = row_ptr[i], e1 = row_ptr[i + 1];
+    if (w) for (int e = e0 + sub; e < e1; e += G) d += w[e];
+    else d = sub == 0 ? static_cast<float>(e1 - e0) : 0.f;
+    const float* s = S + i * K;
+    for (int k = sub; k < K; k += G) qq = fmaf(s[k], s[k], qq);
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) {
+    d += __shfl_xor(d, o, 64);
+    qq += __shfl_xor(qq, o, 64);
+  }
+  if (i < N && sub == 0) {
+    deg[i] = d;
+    q[i] = qq;
+  }
+}
+
+// per graph: stats[b] = (trace(raw_b), |G_b|_F^2)
+template <int T>
+__global__ __launch_bounds__(T) void graph_trace_gsq_kernel(const float* __restrict__ raw, const float* __restrict__ gram,
+                                                            int K, float* __restrict__ stats) {
+  __shared__ float sh[T / 64];
+  const int b = blockIdx.x;
+  const float* R = raw + static_cast<int64_t>(b) * K * K;
+  const float* G = gram + static_cast<int64_t>(b) * K * K;
+  float tr = 0.f, sq = 0.f;
+  for (int i = threadIdx.x; i < K; i += T) tr += R[static_cast<int64_t>(i) * K + i];
+  for (int i = threadIdx.x; i < K * K; i += T) sq = fmaf(G[i], G[i], sq);
+  tr = block_sum_t<T>(tr, sh);
+  sq = block_sum_t<T>(sq, sh);
+  if (threadIdx.x == 0) { stats[2 * b] = tr; stats[2 * b + 1] = sq; }
+}
+
+// out[0] = sqrt(max(sw2 - 2 sum_b trace_b + sum_b gsq_b, 0)) * link_scale, out[1] = (sum of the entropy partials) * ent_scale
+__global__ __launch_bounds__(256) void diffpool_u_final_kernel(const float* __restrict__ stats, int B,
+                                                               const float* __restrict__ sw2_dev, float sw2_host,
+                                                               const float* __restrict__ ent_partial, int n_partial,
+                                                               float link_scale, float ent_scale, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float tr = 0.f, gs = 0.f, e = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) { tr += stats[2 * i]; gs += stats[2 * i + 1]; }
+  for (int i = threadIdx.x; i < n_partial; i += 256) e += ent_partial[i];
+  tr = block_sum_256(tr, sh);
+  gs = block_sum_256(gs, sh);
+  e = block_sum_256(e, sh);
+  if (threadIdx.x == 0) {
+    const float sw2 = sw2_dev ? sw2_dev[0] : sw2_host;
+    out[0] = sqrtf(fmaxf((sw2 - 2.0f * tr) + gs, 0.f)) * link_scale;
+    out[1] = e * ent_scale;
+  }
+}
+}  // namespace tgp
+
+extern "C" int tgp_edge_row_stats_f32(const int32_t* row_ptr, const float* w, const float* S, int64_t N, int64_t K,
+                                      float* deg, float* q, void* stream_) {
+  TGP_REQUIRE(N >= 0 && K >= 0 && K < (1ll << 31), TGP_ERR_INVALID, "tgp_edge_row_stats_f32: bad shape");
+  if (N == 0) return TGP_OK;
+  TGP_REQUIRE(row_ptr && deg && q && (K == 0 || S), TGP_ERR_INVALID, "tgp_edge_row_stats_f32: null pointer");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (K <= 32)
+    hipLaunchKernelGGL(edge_row_stats_kernel<8>, dim3(cdiv(N, 32)), dim3(256), 0, stream, row_ptr, w, S, N,
+                       static_cast<int>(K), deg, q);
+  else
+    hipLaunchKernelGGL(edge_row_stats_kernel<32>, dim3(cdiv(N, 8)), dim3(256), 0, stream, row_ptr, w, S, N,
+                       static_cast<int>(K), deg, q);
+  return check_launch("tgp_edge_row_stats_f32");
+}
+
+extern "C" int tgp_diffpool_unbatched_tail_f32(const float* raw, const float* gram, int64_t B, int64_t K,
+                                               const float* sw2_dev, float sw2_host, const float* ent_partial,
+                                               int n_partial, float link_scale, float ent_scale, float* stats,
+                                               float* out2, void* stream_) {
+  TGP_REQUIRE(B >= 1 && B < (1ll << 31) && K >= 1 && K < 32768 && n_partial >= 0, TGP_ERR_INVALID,
+              "tgp_diffpool_unbatched_tail_f32: bad shape");
+  TGP_REQUIRE(raw && gram && stats && out2 && (n_partial == 0 || ent_partial), TGP_ERR_INVALID,
+              "tgp_diffpool_unbatched_tail_f32: null pointer");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (K >= 64)
+    hipLaunchKernelGGL(graph_trace_gsq_kernel<1024>, dim3(static_cast<unsigned>(B)), dim3(1024), 0, stream, raw, gram,
+                       static_cast<int>(K), stats);
+  else
+    hipLaunchKernelGGL(graph_trace_gsq_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, raw, gram,
+                       static_cast<int>(K), stats);
+  hipLaunchKernelGGL(diffpool_u_final_kernel, dim3(1), dim3(256), 0, stream, stats, static_cast<int>(B), sw2_dev, sw2_host,
+                     ent_partial, n_partial, link_scale, ent_scale, out2);
+  return check_launch("tgp_diffpool_unbatched_tail_f32");
+}
+
 extern "C" int tgp_mincut_terms_fused_f32(const float* raw, const float* gram, const float* deg, const float* q,
                                           int64_t B, int64_t N, int64_t K, float eps, float* den, float* out,
-                                          float* stats, void* stream_) {
+                                          float* stats, const int64_t* ptr, void* stream_) {
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 1 && K < 32768 && N < (1ll << 31), TGP_ERR_INVALID,
               "tgp_mincut_terms_fused_f32: bad shape");
   if (B == 0) return TGP_OK;
@@ -590,10 +699,10 @@ extern "C" int tgp_mincut_terms_fused_f32(const float* raw, const float* gram, c
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (K >= 64)
     hipLaunchKernelGGL(mincut_tail2_kernel<1024>, dim3(static_cast<unsigned>(B)), dim3(1024), 0, stream, raw, gram, deg, q,
-                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out, stats);
+                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out, stats, ptr);
   else
     hipLaunchKernelGGL(mincut_tail2_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, raw, gram, deg, q,
-                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out, stats);
+                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out, stats, ptr);
   return check_launch("tgp_mincut_terms_fused_f32");
 }
 

@@ -170,9 +170,13 @@ def coalesce_sum(edge_index: Tensor, edge_weight: Tensor, num_nodes: int):
     """Row-sorted, duplicate-summed copy of the list (what ``.coalesce()`` does, connect/dense_conn.py:163,202)."""
     if edge_index.size(1) > 0:
         # PyG hands out coalesced lists; one fused comparison + the same single host round trip the count -> fill
-        # pair would cost tells us the sort can be skipped altogether
+        # pair would cost tells us the sort can be skipped altogether (remembered per tensor object: five launches and
+        # the round trip once, not once per forward)
+        if K.coalesced_memo(edge_index, num_nodes):
+            return edge_index, edge_weight
         key = edge_index[0] * num_nodes + edge_index[1]
         if bool((key[1:] > key[:-1]).all()):
+            K.remember_coalesced(edge_index, num_nodes)
             return edge_index, edge_weight
     ident = torch.arange(num_nodes, device=edge_index.device)
     ei, ew = K.coalesce_edges(edge_index, edge_weight, ident, num_nodes, "sum", remove_self_loops=False,
@@ -1014,11 +1018,7 @@ class _PoolLargeFn(torch.autograd.Function):
             part = torch.empty(slabs, Kc, F + pad, dtype=torch.float32, device=dev)
             flat = acat.view(slabs, rows // slabs, ld)
             K.bmm_into(flat[:, :, c_v:], flat[:, :, c_x:c_x + F + pad], part, trans_a=True)
-            both = part.sum(0) if slabs > 1 else part[0]
-            if want_gw:
-                gw = both[:, :F]
-            if want_gb:
-                gbias = both[:, F]
+            gw, gbias = K.slab_sum_split(part, F, want_gw, want_gb)  # two contiguous tensors, slabs added in order
         return (gxd, None, gw, gbias, None, None, None, None, None, None, None)
 
 

@@ -1088,6 +1088,24 @@ def edge_facts_finish(handle, edge_index: Tensor, graph_ptr: Tensor) -> bool:
     return True
 
 
+_COALESCED: dict = {}  # id(edge_index) -> (weakref, version, num_nodes): the list is strictly row-major sorted (no duplicates)
+
+
+def coalesced_memo(edge_index: Tensor, num_nodes: int) -> bool:
+    hit = _COALESCED.get(id(edge_index))
+    return bool(hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version and hit[2] == num_nodes)
+
+
+def remember_coalesced(edge_index: Tensor, num_nodes: int) -> None:
+    import weakref
+    if len(_COALESCED) >= 16:
+        for key in [k for k, v in _COALESCED.items() if v[0]() is None]:
+            del _COALESCED[key]
+        while len(_COALESCED) >= 16:
+            del _COALESCED[next(iter(_COALESCED))]
+    _COALESCED[id(edge_index)] = (weakref.ref(edge_index), edge_index._version, num_nodes)
+
+
 _ADJ_SYMMETRIC: dict = {}  # id(edge_index) -> (weakref, version, weakref of the weights or None, its version, flag)
 
 
@@ -1446,7 +1464,8 @@ def cut_rows(adj: Tensor, s: Tensor, graph_sizes: Optional[Tensor] = None) -> Tu
     return deg, q
 
 
-def mincut_terms_fused(raw: Tensor, gram: Tensor, deg: Tensor, q: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+def mincut_terms_fused(raw: Tensor, gram: Tensor, deg: Tensor, q: Tensor,
+                       ptr: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """(den [B], terms [2,B], stats [B,4]): MinCut's per-graph loss tails with den = sum_i deg_i q_i formed in the same
     launch (utils/losses.py:39-70); stats = (trace(raw), |G|^2, trace(G), |Y|) per graph, the scalars the backward's
     right-hand sides need."""
@@ -1456,8 +1475,10 @@ def mincut_terms_fused(raw: Tensor, gram: Tensor, deg: Tensor, q: Tensor) -> Tup
     den = torch.empty(B, dtype=torch.float32, device=dev)
     out = torch.empty(2, B, dtype=torch.float32, device=dev)
     stats = torch.empty(B, 4, dtype=torch.float32, device=dev)
+    # ptr: deg / q belong to an un-padded batch (graph b owns entries ptr[b] .. ptr[b+1])
     N.check(N.lib().tgp_mincut_terms_fused_f32(N.ptr(raw), N.ptr(gram), N.ptr(deg), N.ptr(q), B, Nn, Kc, losses_eps(),
-                                               N.ptr(den), N.ptr(out), N.ptr(stats), N.stream_ptr(dev)),
+                                               N.ptr(den), N.ptr(out), N.ptr(stats),
+                                               N.ptr(None if ptr is None else N.i64c(ptr)), N.stream_ptr(dev)),
             "tgp_mincut_terms_fused_f32")
     return den, out, stats
 
@@ -1543,6 +1564,17 @@ def copy_cols2(a: Tensor, b: Tensor, dst: Tensor, col_a: int, col_b: int, one_co
         raise ValueError("copy_cols2: operands must be contiguous with equal row counts")
     N.check(N.lib().tgp_copy_cols2_f32(N.ptr(a), a.size(1), N.ptr(b), b.size(1), dst.size(0), N.ptr(dst), dst.size(1),
                                        col_a, col_b, one_col, N.stream_ptr(dev)), "tgp_copy_cols2_f32")
+
+
+def slab_sum_split(part: Tensor, F: int, want_gw: bool = True, want_gb: bool = True):
+    """(gw [K,F], gb [K]) from part [slabs,K,W]: columns 0..F-1 and column F of the slab sum as two contiguous tensors."""
+    dev = N.require_device(part)
+    slabs, Kc, W = part.shape
+    gw = torch.empty(Kc, F, dtype=torch.float32, device=dev) if want_gw else None
+    gb = torch.empty(Kc, dtype=torch.float32, device=dev) if want_gb else None
+    N.check(N.lib().tgp_slab_sum_split_f32(N.ptr(part), slabs, Kc, F, W, N.ptr(gw), N.ptr(gb), N.stream_ptr(dev)),
+            "tgp_slab_sum_split_f32")
+    return gw, gb
 
 
 def bmm_into(a: Tensor, b: Tensor, out: Tensor, trans_a: bool = False, accumulate: bool = False) -> Tensor:
@@ -2147,6 +2179,82 @@ def spmm_sorted(edge_index: Tensor, edge_weight: Optional[Tensor], num_rows: int
     out = torch.empty(num_rows, s.size(1), dtype=torch.float32, device=dev)
     N.check(L.tgp_spmm_csr_f32(N.ptr(row_ptr), N.ptr(col), N.ptr(w), num_rows, row.numel(), N.ptr(s), s.size(1),
                                N.ptr(out), st), "tgp_spmm_csr_f32")
+    return out
+
+
+def spmm_sorted_csr(edge_index: Tensor, edge_weight: Optional[Tensor], num_rows: int, s: Tensor):
+    """(T, row_ptr int32 [num_rows+1]): :func:`spmm_sorted` for float32 operands, handing the CSR offsets it built back."""
+    dev = N.require_device(edge_index, edge_weight, s)
+    row, col = _edge_rows(edge_index)
+    s = N.f32c(s)
+    w = None if edge_weight is None else N.f32c(edge_weight)
+    L = N.lib()
+    st = N.stream_ptr(dev)
+    row_ptr = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
+    N.check(L.tgp_rowptr_from_sorted_i64(N.ptr(row), row.numel(), num_rows, N.ptr(row_ptr), st),
+            "tgp_rowptr_from_sorted_i64")
+    out = torch.empty(num_rows, s.size(1), dtype=torch.float32, device=dev)
+    N.check(L.tgp_spmm_csr_f32(N.ptr(row_ptr), N.ptr(col), N.ptr(w), num_rows, row.numel(), N.ptr(s), s.size(1),
+                               N.ptr(out), st), "tgp_spmm_csr_f32")
+    return out, row_ptr
+
+
+def edge_row_stats(row_ptr: Tensor, edge_weight: Optional[Tensor], s: Tensor) -> Tuple[Tensor, Tensor]:
+    """(deg [N], q [N]): row sums of the weights of a CSR edge list (entry counts without weights) and |S_i|^2, one
+    launch (utils/losses.py:73-127: the degree term of sparse_mincut_loss without an index_add)."""
+    dev = N.require_device(row_ptr, edge_weight, s)
+    s = N.f32c(s)
+    n = s.size(0)
+    w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
+    deg = torch.empty(n, dtype=torch.float32, device=dev)
+    q = torch.empty(n, dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_edge_row_stats_f32(N.ptr(row_ptr), N.ptr(w), N.ptr(s), n, s.size(1), N.ptr(deg), N.ptr(q),
+                                           N.stream_ptr(dev)), "tgp_edge_row_stats_f32")
+    return deg, q
+
+
+def segment_gemm_tn3(s: Tensor, ys, ptr: Tensor, max_nodes: int):
+    """[S_b^T Y_j,b for j] for up to three float32 right-hand sides [Ntot,F_j] over node rows ptr[b]..ptr[b+1]: ONE
+    product grid + one combine launch (the unbatched dense poolers' S^T [A S | X | S])."""
+    dev = N.require_device(s, ptr, *ys)
+    s, ptr = N.f32c(s), N.i64c(ptr)
+    ys = [N.f32c(y) for y in ys]
+    if not 1 <= len(ys) <= 3 or any(y.dim() != 2 or y.size(0) != s.size(0) for y in ys):
+        raise ValueError("segment_gemm_tn3: one to three [Ntot,F] right-hand sides expected")
+    B, Kc = ptr.numel() - 1, s.size(1)
+    fs = [y.size(1) for y in ys] + [0] * (3 - len(ys))
+    outs = [torch.empty(B, Kc, y.size(1), dtype=torch.float32, device=dev) for y in ys]
+    yp = [N.ptr(y) for y in ys] + [None] * (3 - len(ys))
+    op = [N.ptr(o) for o in outs] + [None] * (3 - len(ys))
+    L = N.lib()
+    ws = N.workspace(L.tgp_segment_gemm_tn3_workspace_bytes(B, Kc, fs[0], fs[1], fs[2], max_nodes), dev)
+    N.check(L.tgp_segment_gemm_tn3_f32(N.ptr(s), yp[0], fs[0], yp[1], fs[1], yp[2], fs[2], N.ptr(ptr), op[0], op[1], op[2],
+                                       B, s.size(0), Kc, max_nodes, N.ptr(ws), ws.numel(), N.stream_ptr(dev)),
+            "tgp_segment_gemm_tn3_f32")
+    return outs
+
+
+def diffpool_unbatched_tail(raw: Tensor, gram: Tensor, s: Tensor, sw2, link_scale: float, ent_scale: float) -> Tensor:
+    """[2]: DiffPool's unbatched link-prediction loss sqrt(max(sum_e w_e^2 - 2 sum_b trace(raw_b) + sum_b |gram_b|^2, 0))
+    * link_scale and entropy loss sum(-s log(s + eps)) * ent_scale (utils/losses.py:661-708, 476-483); ``sw2``: a
+    0-dim device tensor or a Python number."""
+    dev = N.require_device(raw, gram, s)
+    raw, gram, s32 = N.f32c(raw), N.f32c(gram), N.f32c(s)
+    B, Kc = raw.size(0), raw.size(-1)
+    L = N.lib()
+    ws = N.workspace(L.tgp_entropy_sum_workspace_bytes(s32.numel()), dev)
+    import ctypes as _ct
+    n_partial = _ct.c_int(0)
+    st = N.stream_ptr(dev)
+    N.check(L.tgp_entropy_partials_f32(N.ptr(s32), s32.numel(), losses_eps(), N.ptr(ws), ws.numel(),
+                                       _ct.addressof(n_partial), st), "tgp_entropy_partials_f32")
+    stats = torch.empty(B, 2, dtype=torch.float32, device=dev)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    sw2_dev = N.f32c(sw2.reshape(1)) if isinstance(sw2, Tensor) else None
+    N.check(L.tgp_diffpool_unbatched_tail_f32(N.ptr(raw), N.ptr(gram), B, Kc, N.ptr(sw2_dev),
+                                              0.0 if sw2_dev is not None else float(sw2), N.ptr(ws), n_partial.value,
+                                              float(link_scale), float(ent_scale), N.ptr(stats), N.ptr(out), st),
+            "tgp_diffpool_unbatched_tail_f32")
     return out
 
 

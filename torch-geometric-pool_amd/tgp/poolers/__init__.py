@@ -431,6 +431,61 @@ class _DenseMLPPooling(DenseSRCPooling):
             return None
         return K.AdjSymmetry(edge_index, edge_weight, dense_adj, batch, info.ptr)
 
+    def _unbatched_fused(self, x, edge_index, edge_weight, batch, so):
+        """Unbatched mode outside autograd: Reduce, Connect and both auxiliary losses from ONE S^T [A S | X | S] product
+        (tgp_segment_gemm_tn3_f32) behind the CSR SpMM -- the mincut numerator is trace(S_g^T (A S)_g), the link
+        residual sum_e w_e^2 - 2 sum_g trace(raw_g) + sum_g |S_g^T S_g|^2 -- instead of per-edge dot products and
+        index_add scatters (reference utils/losses.py:73-127, 204-240, 661-708; dense_conn.py:140-208;
+        base_reduce.py:170-182): 40-45 launches -> ~10.  Returns (x_pool [B,K,F], adj_pool [B,K,K], pooled batch vector,
+        losses) or None when the case is not this one (training, sparse_output, host tensors, ...)."""
+        from .. import kernels as K
+        from .. import functions as Fn
+        c, s = self.connector, so.s
+        if (self.sparse_output or type(c) is not DenseConnect or type(self.reducer) is not BaseReduce
+                or not (isinstance(x, Tensor) and isinstance(edge_index, Tensor) and isinstance(s, Tensor))
+                or x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or s.dim() != 2 or s.dtype != torch.float32
+                or edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.long
+                or not edge_index.is_cuda or edge_index.size(1) == 0 or x.size(0) == 0 or x.size(1) == 0
+                or (edge_weight is not None and (not isinstance(edge_weight, Tensor) or edge_weight.dtype != torch.float32
+                                                 or edge_weight.numel() != edge_index.size(1)))
+                or (batch is not None and (batch.dtype != torch.long or batch.numel() != x.size(0)))):
+            return None
+        if torch.is_grad_enabled() and (s.requires_grad or x.requires_grad
+                                        or (edge_weight is not None and edge_weight.requires_grad)):
+            return None
+        n, k = s.shape
+        if batch is not None:
+            info = batch_info(batch)
+            if not info.is_sorted:
+                return None
+            ptr, nb, max_nodes = info.ptr, info.num_graphs, info.max_nodes
+        else:
+            ptr, nb, max_nodes = Fn._whole_range(n, x.device), 1, n
+        w_in = None if edge_weight is None else edge_weight.reshape(-1)
+        ones = w_in is None
+        # sorted + duplicate-summed A (what the reference's per-graph `.coalesce()` does), T = A S, then one product grid
+        ei, w = Fn.coalesce_sum(edge_index, torch.ones(edge_index.size(1), device=x.device) if ones else w_in, n)
+        unit = ones and ei is edge_index  # (nothing merged: the weights are still all one)
+        t, row_ptr = K.spmm_sorted_csr(ei, None if unit else w, n, s)
+        raw, x_pool, gram = K.segment_gemm_tn3(s, [t, x, s], ptr, max_nodes)
+        if self._loss_needs_raw:  # MinCut
+            deg, q = K.edge_row_stats(row_ptr, None if unit else w, s)
+            _, terms, _ = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr)
+            both = terms.mean(dim=1)
+            loss = {"cut_loss": both[0] if self.cut_loss_coeff == 1 else both[0] * self.cut_loss_coeff,
+                    "ortho_loss": both[1] if self.ortho_loss_coeff == 1 else both[1] * self.ortho_loss_coeff}
+        else:  # DiffPool: sum_e w_e^2 runs over the list as given (duplicates not merged, losses.py:680-690)
+            sw2 = float(edge_index.size(1)) if ones else torch.dot(w_in, w_in)
+            link_scale = float(self.link_loss_coeff)
+            if self.normalize_loss is True:
+                denom = sum(v * v for v in info.sizes_host) if batch is not None else n * n
+                link_scale = link_scale / max(denom, 1)
+            both = K.diffpool_unbatched_tail(raw, gram, s, sw2, link_scale, float(self.ent_loss_coeff) / n)
+            loss = {"link_loss": both[0], "entropy_loss": both[1]}
+        adj_pool = postprocess_adj_pool_dense(raw, remove_self_loops=c.remove_self_loops, degree_norm=c.degree_norm,
+                                              adj_transpose=False, edge_weight_norm=c.edge_weight_norm)
+        return x_pool, adj_pool, self.reducer.reduce_batch(so, batch if batch is not None else so.batch), loss
+
     def _sizes_for(self, adj):
         """Real nodes per graph of the zero-padded batch ``adj`` belongs to, if forward() densified it itself."""
         hint = getattr(self, "_sizes_hint", None)
@@ -522,6 +577,10 @@ class _DenseMLPPooling(DenseSRCPooling):
             return PoolingOutput(x=x_pool, edge_index=adj_pool, so=so, loss=loss)
         # unbatched: S [N,K], sparse A, sparse losses
         so = self.select(x=x, batch=batch)
+        fused = self._unbatched_fused(x, adj, edge_weight, batch, so)
+        if fused is not None:  # inference: the losses from the products the Connect forms anyway (r6)
+            x_pool, adj_pool, batch_pool, loss = fused
+            return PoolingOutput(x=x_pool, edge_index=adj_pool, edge_weight=None, batch=batch_pool, so=so, loss=loss)
         loss = self.compute_sparse_loss(adj, edge_weight, so.s, batch)
         x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch, return_batched=not self.sparse_output)
         ei, ew = self.connect(edge_index=adj, so=so, edge_weight=edge_weight, batch=batch,
