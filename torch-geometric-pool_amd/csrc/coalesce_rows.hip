@@ -182,11 +182,13 @@ __global__ __launch_bounds__(256) void cr_member_single_kernel(const int32_t* __
                                                                int32_t* __restrict__ table,
                                                                uint32_t* __restrict__ seg_src,
                                                                uint32_t* __restrict__ seg_dst,
-                                                               unsigned long long* status, unsigned long long tag) {
+                                                               unsigned long long* status, unsigned long long tag,
+                                                               int ticket) {
   __shared__ uint32_t s_w[4];
   __shared__ uint32_t s_off;
   __shared__ int s_refused;
-  const int tile = blockIdx.x;
+  __shared__ int s_tile;
+  const int tile = sps_tile_id(status + 1, tag, ticket, &s_tile);
   const int64_t base = static_cast<int64_t>(tile) * MS_TILE + static_cast<int64_t>(threadIdx.x) * MS_ITEMS;
 #pragma unroll
   for (int i = 0; i < MS_ITEMS; ++i)
@@ -1073,11 +1075,12 @@ __global__ __launch_bounds__(256) void cr_scan_publish_kernel(const uint32_t* __
                                                               int64_t* __restrict__ total, const int* __restrict__ bad,
                                                               int64_t* __restrict__ d_count,
                                                               unsigned long long* status, unsigned long long* result,
-                                                              unsigned long long tag) {
+                                                              unsigned long long tag, int ticket) {
   __shared__ uint32_t s_w[4];
   __shared__ uint32_t s_base;
+  __shared__ int s_tile;
   const int tid = threadIdx.x;
-  const int tile = blockIdx.x;
+  const int tile = sps_tile_id(status + 1, tag, ticket, &s_tile);
   const int64_t base = static_cast<int64_t>(tile) * SCAN_TILE + static_cast<int64_t>(tid) * SCAN_ITEMS;
   uint32_t v[SCAN_ITEMS], sacc = 0;
   if (base + SCAN_ITEMS <= K) {  // (the workspace carves 256-byte aligned arrays)
@@ -1724,7 +1727,7 @@ static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const WT* 
     unsigned long long* st2 = reinterpret_cast<unsigned long long*>(pub->status) + 2 + cdiv(K > 0 ? K : 1, SCAN_TILE);
     hipLaunchKernelGGL(cr_member_single_kernel, dim3(nt), dim3(256), 0, stream, assign_perm, N, s.node_ptr,
                        cluster_index, N, E, csr_ptr ? 1 : 0, s.bad, s.table, s.seg_src, s.seg_dst, st2,
-                       static_cast<unsigned long long>(pub->epoch) << SPS_EPOCH_SHIFT);
+                       static_cast<unsigned long long>(pub->epoch) << SPS_EPOCH_SHIFT, kLookbackTicket);
     hipLaunchKernelGGL(cr_raw_off_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, assign_row_ptr, K, s.seg_dst, s.bad,
                        s.raw_off, huge ? h.list : static_cast<uint32_t*>(nullptr), s.n_out, st2,
                        static_cast<unsigned long long>(pub->epoch) << SPS_EPOCH_SHIFT);
@@ -1782,7 +1785,7 @@ static int cr_rows_count_impl(const int64_t* row, const int64_t* col, const WT* 
     hipLaunchKernelGGL(cr_scan_publish_kernel, dim3(cdiv(K, SCAN_TILE)), dim3(256), 0, stream, s.n_out, K, s.out_off,
                        s.total, s.bad, d_count, reinterpret_cast<unsigned long long*>(pub->status),
                        reinterpret_cast<unsigned long long*>(pub->result),
-                       static_cast<unsigned long long>(pub->epoch) << SPS_EPOCH_SHIFT);
+                       static_cast<unsigned long long>(pub->epoch) << SPS_EPOCH_SHIFT, kLookbackTicket);
     return check_launch("tgp_connect_coalesce_rows_count_published");
   }
   device_scan_u32(s.n_out, K, s.out_off, s.total, s.scan_scratch, stream, s.bad, d_count);

@@ -7,6 +7,8 @@
 // the words: the last tile knows the verdict of the whole call and leaves ONE result word {epoch, refused, total},
 // stored with system scope -- the caller may point it at pinned host memory and poll it.
 #pragma once
+#include <stdlib.h>
+
 #include "primitives.h"
 
 namespace tgp {
@@ -21,6 +23,36 @@ __device__ __forceinline__ void sps_store(unsigned long long* p, unsigned long l
 }
 __device__ __forceinline__ bool sps_current(unsigned long long word, unsigned long long tag) {
   return (word >> SPS_EPOCH_SHIFT) == (tag >> SPS_EPOCH_SHIFT);
+}
+
+// Tile ids.  The look-back needs every predecessor tile of a workgroup to be running (or done) when it spins on their
+// words.  By default a workgroup's tile is its blockIdx.x: the dispatcher hands a 1-D grid out in index order, so the
+// predecessors of a resident workgroup were dispatched before it (and a bounded spin turns anything else into a refusal
+// + the caller's fallback).  TGP_LOOKBACK_TICKET=1 (read once by the library) makes the order explicit instead: the tile is
+// the workgroup's ARRIVAL number, taken from an epoch-tagged ticket word ([1] of the look-back's status region) as the
+// first thing the workgroup does -- forward progress then holds by construction, at the price of one device-scope
+// atomic round trip in front of every workgroup (profiles/r06_lookback_ticket.txt).  A word of another epoch is stale
+// (the buffer is never cleared) and is claimed with a compare-and-swap.
+static const int kLookbackTicket = getenv("TGP_LOOKBACK_TICKET") ? atoi(getenv("TGP_LOOKBACK_TICKET")) : 0;
+
+__device__ __forceinline__ int sps_tile_id(unsigned long long* ticket_word, unsigned long long tag, int use_ticket,
+                                           int* s_tile) {
+  if (!use_ticket) return static_cast<int>(blockIdx.x);
+  if (threadIdx.x == 0) {
+    const unsigned long long ep = (tag >> SPS_EPOCH_SHIFT) << SPS_EPOCH_SHIFT;
+    int got = -1;
+    while (got < 0) {
+      const unsigned long long cur = __hip_atomic_load(ticket_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((cur >> SPS_EPOCH_SHIFT) == (tag >> SPS_EPOCH_SHIFT)) {
+        got = static_cast<int>(atomicAdd(ticket_word, 1ull) & 0xFFFFFFFFull);
+      } else if (atomicCAS(ticket_word, cur, ep | 1ull) == cur) {
+        got = 0;
+      }
+    }
+    *s_tile = got;
+  }
+  __syncthreads();
+  return *s_tile;
 }
 
 __device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {

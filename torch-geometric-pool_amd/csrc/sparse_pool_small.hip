@@ -65,6 +65,7 @@ struct SpsArgs {
   unsigned long long* status;  // [2 + tile] look-back state, epoch-tagged ([0], [1] reserved)
   unsigned long long* result;  // ONE word {epoch, refused (bit 31), total}; may live in pinned host memory
   unsigned long long tag;      // epoch << SPS_EPOCH_SHIFT
+  int ticket;                  // tile = arrival number (status[1]) instead of blockIdx.x (TGP_LOOKBACK_TICKET)
 };
 
 __device__ __forceinline__ float sps_reduce(float acc, float v, int op) {
@@ -106,9 +107,11 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
   __shared__ int s_eb[WAVES + 1], s_ab[WAVES + 1];
   __shared__ int64_t s_rng[4];  // the workgroup's edge range and assignment slice
   __shared__ SpsClusterLds s_cl_all[MODE == 1 ? WAVES : 1];
+  __shared__ int s_tile;
   const int lane = lane_id(), wv = wave_id();
   SPS_STAMP(0);
-  const int64_t g0 = static_cast<int64_t>(blockIdx.x) * WAVES;
+  const int tile_id = sps_tile_id(p.status + 1, p.tag, p.ticket, &s_tile);
+  const int64_t g0 = static_cast<int64_t>(tile_id) * WAVES;
   const int64_t g = g0 + wv;
   const bool live = g < p.B;
   if (threadIdx.x <= WAVES) {
@@ -163,8 +166,8 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
   bool bad = false;
   // the workgroups' ranges tile the arrays: consecutive workgroups search for the same key (a deterministic function of
   // array and key, sorted or not), the first range starts at 0, the last one ends at the end
-  if (LE < 0 || LA < 0 || (blockIdx.x == 0 && (E0 != 0 || A0 != 0 || s_nb[0] != 0)) ||
-      (blockIdx.x == gridDim.x - 1 && (E1 != p.E || (MODE == 0 && A1 != p.nnz) || s_nb[WAVES] != p.N)))
+  if (LE < 0 || LA < 0 || (tile_id == 0 && (E0 != 0 || A0 != 0 || s_nb[0] != 0)) ||
+      (tile_id == static_cast<int>(gridDim.x) - 1 && (E1 != p.E || (MODE == 0 && A1 != p.nnz) || s_nb[WAVES] != p.N)))
     bad = true;
   if (!bad && !given) {
     sps_boundaries<WAVES>(p.row, E0, LE, s_nb, s_eb);
@@ -428,11 +431,11 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
     tile_tot = wave_sum32(mine & 0x7FFFFFFFu);
     tile_refused = __any((mine >> 31) != 0u);
     if (lane == 0)
-      sps_store(p.status + 2 + blockIdx.x, p.tag | (blockIdx.x == 0 ? SPS_PRE : SPS_AGG) |
+      sps_store(p.status + 2 + tile_id, p.tag | (tile_id == 0 ? SPS_PRE : SPS_AGG) |
                                                (tile_refused ? 0x80000000ull : 0ull) | tile_tot);
   }
   SpsLook look;  // the predecessors' words are requested now and consumed behind the Reduce part
-  if (wv == 0 && blockIdx.x > 0) sps_lookback_issue(p.status, blockIdx.x, p.tag, look);
+  if (wv == 0 && tile_id > 0) sps_lookback_issue(p.status, tile_id, p.tag, look);
   // ------------------------------------------------------------------- A1 + A2, while the look-back words travel
   if (!bad) {
     if constexpr (MODE == 0) {
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(WAVES * 64) void sparse_pool_small_kernel(SpsArgs p
     }
   }
   if (wv == 0) {
-    const int tile = blockIdx.x;
+    const int tile = tile_id;
     uint32_t excl = 0;
     bool refused = tile_refused;
     if (tile > 0) {
@@ -653,7 +656,8 @@ extern "C" int tgp_sparse_pool_small_f32(const float* x, int64_t N, int64_t F, i
   SpsArgs a{x, N, F, x_stride, graph_ptr, B, row, col, w, E, node_index, cluster_index, weight, nnz, K, reduce_op, flags,
             eps, x_pool, batch_pool, out_row, out_col, out_w, edge_ptr, assign_ptr, edge_ptr_out,
             reinterpret_cast<unsigned long long*>(status),
-            reinterpret_cast<unsigned long long*>(result), static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT};
+            reinterpret_cast<unsigned long long*>(result), static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT,
+            kLookbackTicket};
   if (mode == 0) {
     hipLaunchKernelGGL((sparse_pool_small_kernel<0, SPS_WAVES_TOPK>), dim3(cdiv(B, SPS_WAVES_TOPK)),
                        dim3(SPS_WAVES_TOPK * 64), 0, stream, a);
