@@ -645,7 +645,8 @@ int tgp_mincut_loss_terms_bwd_f32(const float* raw, const float* den, const floa
  *   2 (DiffPool): c = link_scale^2 *g_la / *link_loss (0 when the loss is 0), gR -= c I, RS = 2 c G.
  *   gw (optional, [B][2K][F], needs the selector weight W [K][F]): gw[b] = [g_x[b] ; W].
  * tgp_softmax_bwd_ex_f32: tgp_softmax_bwd_f32 on dS + extra + 2 c1[m / rows_per_graph] deg[m] S
- *   - *ent_g ent_scale (log(S + eps) + S / (S + eps))   (extra, c1/deg, ent_g: each optional); dy with row stride ld_dy.
+ *   - *ent_g ent_scale (log(S + eps) + S / (S + eps))   (extra, c1/deg, ent_g: each optional); dy with row stride ld_dy;
+ *   batch (optional, [M]): the graph of row m is batch[m] (un-padded batch) instead of m / rows_per_graph.
  * tgp_copy_cols2_f32: dst[r, col_a:col_a+wa] = a[r,:], dst[r, col_b:col_b+wb] = b[r,:] (row stride ld) in one pass;
  *   one_col >= 0: also dst[r, one_col:one_col+4] = [1 0 0 0].
  * tgp_adj_symmetry_f32: is the [B,Nmax,Nmax] adjacency the edge list (row, col) was scattered into symmetric?  One
@@ -666,7 +667,7 @@ int tgp_dense_pool_train_rhs_f32(const float* g_raw_a, const float* g_raw_b, int
                                  float* gw, void* stream);
 int tgp_softmax_bwd_ex_f32(const float* s, const float* ds, const float* extra, const float* c1, const float* deg,
                            int64_t rows_per_graph, const float* ent_g, float ent_scale, float ent_eps, float* dy,
-                           int64_t ld_dy, int64_t M, int64_t K, void* stream);
+                           int64_t ld_dy, int64_t M, int64_t K, const int64_t* batch, void* stream);
 /* ------------------------------------------------------------------------------------
  * N3 (r6)  The UNBATCHED dense poolers' forward (mincut_u / diff_u: S [Ntot,K], sparse A) from the products their
  * Connect forms anyway -- no per-edge dot products, no index_add scatters (utils/losses.py:73-127, 204-240, 661-708;
@@ -685,6 +686,18 @@ int tgp_segment_gemm_tn3_f32(const float* S, const float* Y0, int64_t F0, const 
                              int64_t K, int64_t max_nodes, void* ws, size_t ws_bytes, void* stream);
 int tgp_edge_row_stats_f32(const int32_t* row_ptr, const float* w, const float* S, int64_t N, int64_t K, float* deg,
                            float* q, void* stream);
+/* the two segment products with explicit row strides (operands that are column blocks of a wider buffer: the unbatched
+ * training step): nn: C[rows of b] = A[rows of b, 0:Kd] Bm[b] (A row stride lda; Bm [B][Kd][Nc], row stride ldb, batch
+ * stride sB; C row stride ldc);  tn: C[b] = A[rows of b]^T Y[rows of b] ([B][M][Nc], no node-range split). */
+int tgp_segment_gemm_nn_ld_f32(const float* A, int64_t lda, const float* Bm, int64_t ldb, int64_t sB, const int64_t* ptr,
+                               float* C, int64_t ldc, int64_t B, int64_t Ntot, int64_t Kd, int64_t Nc, int64_t max_nodes,
+                               void* stream);
+int tgp_segment_gemm_tn_ld_f32(const float* A, int64_t lda, const float* Y, int64_t ldy, const int64_t* ptr, float* C,
+                               int64_t B, int64_t Ntot, int64_t M, int64_t Nc, void* stream);
+/* is the COALESCED row-sorted list (row, col, w) with CSR offsets row_ptr symmetric: has every entry (r, c, w) a mirror
+ * entry (c, r, w)?  Verdict as tgp_adj_symmetry_f32 (pinned result word 2 = 1: no). */
+int tgp_edge_symmetry_f32(const int64_t* row, const int64_t* col, const float* w, int64_t E, const int32_t* row_ptr,
+                          int64_t N, uint32_t* ticket, uint64_t* result, uint64_t tag, void* stream);
 int tgp_diffpool_unbatched_tail_f32(const float* raw, const float* gram, int64_t B, int64_t K, const float* sw2_dev,
                                     float sw2_host, const float* ent_partial, int n_partial, float link_scale,
                                     float ent_scale, float* stats, float* out2, void* stream);

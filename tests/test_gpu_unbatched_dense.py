@@ -97,12 +97,76 @@ def test_batched_equals_unbatched(dev, alias):
         torch.testing.assert_close(ob.loss[name], ou.loss[name], rtol=1e-4, atol=1e-5, msg=lambda m: f"{name}: {m}")
 
 
-def test_unbatched_training_keeps_the_differentiable_path(dev):
-    """Under autograd the composed differentiable operators still take the call (the fused forward has no backward)."""
+def _node_names(fn, seen=None, out=None):
+    seen, out = seen if seen is not None else set(), out if out is not None else []
+    if fn is None or fn in seen:
+        return out
+    seen.add(fn)
+    out.append(type(fn).__name__)
+    for nxt, _ in fn.next_functions:
+        _node_names(nxt, seen, out)
+    return out
+
+
+TRAIN_CASES = [  # alias, graph sizes, K, F, weighted (random weights per direction: the general route), hidden layer
+    ("mincut_u", [130, 97, 160], 40, 24, True, None),
+    ("mincut_u", [260, 199], 72, 16, False, None),      # unit weights on a mirrored list: the symmetric route
+    ("diff_u", [130, 97, 160], 40, 24, True, None),
+    ("diff_u", [260, 199], 72, 16, False, None),
+    ("mincut_u", [150, 140], 66, 10, True, 20),          # a selector with a hidden layer hands S over
+    ("diff_u", [77], 10, 6, False, None),                # one graph
+]
+
+
+@pytest.mark.parametrize("alias,sizes,k,f,weighted,hidden", TRAIN_CASES)
+def test_unbatched_training_step_matches_oracle_autograd(dev, alias, sizes, k, f, weighted, hidden):
+    """Training in the unbatched mode is ONE autograd node (functions._PoolUnbatchedFn): values and gradients against the
+    oracle's per-edge / per-graph restatement run in float64 under autograd."""
+    import tgp_oracle as O
+    from tgp import functions as Fn
+    from tgp.poolers import get_pooler
+    x, ei, ew, batch = _batch(sizes, f, 8.0, seed=len(sizes) * 10 + k, weighted=weighted)
+    chans = f if hidden is None else [f, hidden]
+    pooler = get_pooler(alias, in_channels=chans, k=k, **({} if hidden is None else {"act": "tanh"})).to(dev).train()
+    lins = pooler.selector.mlp.lins
+    g = torch.Generator().manual_seed(5)
+    B = len(sizes)
+    wx, wa = torch.randn(B, k, f, generator=g), torch.randn(B, k, k, generator=g)
+    before = dict(Fn.POOL_LARGE_STATS)
+    xg = x.to(dev).requires_grad_(True)
+    out = pooler(x=xg, adj=ei.to(dev), edge_weight=None if ew is None else ew.to(dev), batch=batch.to(dev))
+    assert any("_PoolUnbatchedFn" in n for n in _node_names(out.x.grad_fn))
+    l1, l2 = list(out.loss.values())
+    ((out.x * wx.to(dev)).sum() + (out.edge_index * wa.to(dev)).sum() + 0.7 * l1 + 1.3 * l2).backward()
+    route = "general" if weighted else "symmetric"
+    assert Fn.POOL_LARGE_STATS[route] == before[route] + 1, (Fn.POOL_LARGE_STATS, before)
+
+    xr = x.double().requires_grad_(True)
+    ws = [l.weight.detach().cpu().double().requires_grad_(True) for l in lins]
+    bs = [l.bias.detach().cpu().double().requires_grad_(True) for l in lins]
+    ref = O.dense_pool(alias[:-2], xr, ei, (torch.ones(ei.size(1)) if ew is None else ew).double(), batch, ws, bs,
+                       act=None if hidden is None else "tanh", batched=False)
+    r1, r2 = list(ref["loss"].values())
+    ((ref["x"] * wx.double()).sum() + (ref["edge_index"] * wa.double()).sum() + 0.7 * r1 + 1.3 * r2).backward()
+    torch.testing.assert_close(out.x.detach().cpu().double(), ref["x"].detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out.edge_index.detach().cpu().double(), ref["edge_index"].detach(), rtol=1e-5, atol=1e-6)
+    for got, want in ((l1, r1), (l2, r2)):
+        torch.testing.assert_close(got.detach().cpu().double(), want.detach(), rtol=2e-5, atol=1e-6)
+    pairs = [(xg.grad, xr.grad, "dX")] + [(l.weight.grad, w.grad, f"dW{i}") for i, (l, w) in enumerate(zip(lins, ws))] \
+        + [(l.bias.grad, b.grad, f"db{i}") for i, (l, b) in enumerate(zip(lins, bs))]
+    for got, want, what in pairs:
+        scale = float(want.abs().max())
+        torch.testing.assert_close(got.cpu().double(), want, rtol=2e-4, atol=2e-5 * max(scale, 1e-3),
+                                   msg=lambda m: f"{what}: {m}")
+
+
+def test_unbatched_training_with_weight_gradients_keeps_the_operator_path(dev):
+    """Edge weights that require a gradient are not differentiated by the one-node path: the composed operators take the call."""
     from tgp.poolers import get_pooler
     x, ei, ew, batch = _batch([40, 30], 8, 5.0, seed=1)
     pooler = get_pooler("mincut_u", in_channels=8, k=5).to(dev).train()
-    out = pooler(x=x.to(dev), adj=ei.to(dev), edge_weight=ew.to(dev), batch=batch.to(dev))
+    w = ew.to(dev).requires_grad_(True)
+    out = pooler(x=x.to(dev), adj=ei.to(dev), edge_weight=w, batch=batch.to(dev))
+    assert not any("_PoolUnbatchedFn" in n for n in _node_names(out.x.grad_fn))
     (out.x.sum() + out.edge_index.sum() + sum(out.loss.values())).backward()
-    lin = pooler.selector.mlp.lins[0]
-    assert lin.weight.grad is not None and torch.isfinite(lin.weight.grad).all()
+    assert w.grad is not None and torch.isfinite(w.grad).all()

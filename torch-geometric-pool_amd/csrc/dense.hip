@@ -264,7 +264,6 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
       MediumArgs q{S, want_a ? A : nullptr, want_x ? X : nullptr, static_cast<int>(B), static_cast<int>(N),
                    static_cast<int>(K), static_cast<int>(F), flags, eps, want_x ? x_pool : nullptr,
                    want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr, static_cast<int>(npad), graph_sizes};
-      static const int minw = getenv("TGP_MEDIUM_MINW") ? atoi(getenv("TGP_MEDIUM_MINW")) : 2;
       // eight waves per graph (r5, late) when there are at least eight strips to deal out and the S tile (> 80 KB) leaves a
       // single workgroup per CU (four waves would be one wave per SIMD): N = 300 / K = 64 / F = 128 151.8 -> 139.8 us.
       // Where two four-wave workgroups fit, they balance the strips better (N = 200 / K = 50: 132 us against 193 us
@@ -276,9 +275,7 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
       if (K <= 32) {
         if (eight) hipLaunchKernelGGL((dense_pool_medium_kernel<1, 4, 8>), g, dim3(512), lds, stream, q);
         else hipLaunchKernelGGL((dense_pool_medium_kernel<1>), g, dim3(256), lds, stream, q);
-      } else if (minw == 3) {
-        hipLaunchKernelGGL((dense_pool_medium_kernel<2, 3>), g, dim3(256), lds, stream, q);
-      } else {
+      } else {  // (r6: the three-waves-per-SIMD instantiation <2, 3> -- a tuning knob that spilled 12 VGPRs -- is gone)
         if (eight) hipLaunchKernelGGL((dense_pool_medium_kernel<2, 2, 8>), g, dim3(512), lds, stream, q);
         else hipLaunchKernelGGL((dense_pool_medium_kernel<2, 2>), g, dim3(256), lds, stream, q);
       }
@@ -471,14 +468,27 @@ extern "C" int tgp_copy_cols2_f32(const float* a, int64_t wa, const float* b, in
 namespace tgp {
 __global__ __launch_bounds__(256) void slab_sum_split_kernel(const float* __restrict__ part, int slabs, int K, int F, int W,
                                                              float* __restrict__ gw, float* __restrict__ gb) {
+  // eight lanes per output element: lane q adds slabs q, q + 8, ... (their loads in flight together), the eight
+  // partial sums are folded in a fixed order -- one thread per element walked 64 dependent loads (17.7 us at 64 x 128 x 68)
   const long total = static_cast<long>(K) * (F + 1);
-  for (long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<long>(gridDim.x) * 256) {
-    const int k = static_cast<int>(e / (F + 1)), f = static_cast<int>(e - static_cast<long>(k) * (F + 1));
+  const int q = threadIdx.x & 7;
+  for (long e0 = static_cast<long>(blockIdx.x) * 32; e0 < total; e0 += static_cast<long>(gridDim.x) * 32) {
+    const long e = e0 + (threadIdx.x >> 3);
+    const bool ok = e < total;
+    const int k = ok ? static_cast<int>(e / (F + 1)) : 0, f = ok ? static_cast<int>(e - static_cast<long>(k) * (F + 1)) : 0;
     const float* src = part + static_cast<long>(k) * W + f;
     float v = 0.f;
-    for (int sp = 0; sp < slabs; ++sp) v = __fadd_rn(v, src[static_cast<long>(sp) * K * W]);
-    if (f < F) { if (gw) gw[static_cast<long>(k) * F + f] = v; }
-    else if (gb) gb[k] = v;
+    if (ok) {
+#pragma unroll 4
+      for (int sp = q; sp < slabs; sp += 8) v = __fadd_rn(v, src[static_cast<long>(sp) * K * W]);
+    }
+    v = __fadd_rn(v, __shfl_xor(v, 1, 64));
+    v = __fadd_rn(v, __shfl_xor(v, 2, 64));
+    v = __fadd_rn(v, __shfl_xor(v, 4, 64));
+    if (ok && q == 0) {
+      if (f < F) { if (gw) gw[static_cast<long>(k) * F + f] = v; }
+      else if (gb) gb[k] = v;
+    }
   }
 }
 }  // namespace tgp
@@ -489,8 +499,8 @@ extern "C" int tgp_slab_sum_split_f32(const float* part, int64_t slabs, int64_t 
               TGP_ERR_INVALID, "tgp_slab_sum_split_f32: bad shape");
   TGP_REQUIRE(part && (gw || gb), TGP_ERR_INVALID, "tgp_slab_sum_split_f32: null pointer");
   const int64_t total = K * (F + 1);
-  int64_t grid = (total + 255) / 256;
-  if (grid > 1024) grid = 1024;
+  int64_t grid = (total + 31) / 32;
+  if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(slab_sum_split_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      part, static_cast<int>(slabs), static_cast<int>(K), static_cast<int>(F), static_cast<int>(W), gw, gb);
   return check_launch("tgp_slab_sum_split_f32");
@@ -784,6 +794,56 @@ extern "C" int tgp_segment_gemm_tn_f32(const float* S, const float* Y, const int
                        K * F, static_cast<long>(splits) * K * F, total, C);
   }
   return check_launch("tgp_segment_gemm_tn_f32");
+}
+
+// r6: the two segment products with explicit row strides, for operands that are column blocks of a wider buffer (the
+// unbatched training step's operand buffer [T | X | 1000 | S | T'], functions._PoolUnbatchedFn):
+//   nn: C[rows of b] = A[rows of b, 0:Kd] Bm[b]        (A row stride lda, Bm [B][Kd][Nc] with row stride ldb / batch sB)
+//   tn: C[b] = A[rows of b]^T Y[rows of b]             (no node-range split: the caller passes short row ranges)
+extern "C" int tgp_segment_gemm_nn_ld_f32(const float* A, int64_t lda, const float* Bm, int64_t ldb, int64_t sB,
+                                          const int64_t* ptr, float* C, int64_t ldc, int64_t B, int64_t Ntot, int64_t Kd,
+                                          int64_t Nc, int64_t max_nodes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && Ntot >= 0 && Kd >= 0 && Nc >= 0 && lda >= Kd && ldb >= Nc && ldc >= Nc, TGP_ERR_INVALID,
+              "tgp_segment_gemm_nn_ld_f32: bad sizes");
+  if (B == 0 || Ntot == 0 || Nc == 0) return TGP_OK;
+  TGP_REQUIRE(C && ptr && (Kd == 0 || (A && Bm)), TGP_ERR_INVALID, "tgp_segment_gemm_nn_ld_f32: null pointer");
+  TGP_REQUIRE(Ntot < (1ll << 31) && Kd < (1ll << 31) && Nc < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_segment_gemm_nn_ld_f32: too large");
+  const int64_t span = max_nodes > 0 ? max_nodes : Ntot;
+  TGP_REQUIRE(B * ((span + 63) / 64) * ((Nc + 63) / 64) < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_segment_gemm_nn_ld_f32: grid too large");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.sA = 0;
+  g.M = static_cast<int>(span); g.Kd = static_cast<int>(Kd);
+  g.rhs[0] = GemmRhs{Bm, C, static_cast<int>(Nc), ldb, ldc, sB, 0, 0};
+  g.splits = 1; g.k_per_split = static_cast<int>((Kd + BK - 1) / BK * BK);
+  if (g.k_per_split < BK) g.k_per_split = BK;
+  g.m_ptr = ptr;
+  launch_gemm<false>(g, static_cast<int>(B), stream);
+  return check_launch("tgp_segment_gemm_nn_ld_f32");
+}
+
+extern "C" int tgp_segment_gemm_tn_ld_f32(const float* A, int64_t lda, const float* Y, int64_t ldy, const int64_t* ptr,
+                                          float* C, int64_t B, int64_t Ntot, int64_t M, int64_t Nc, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && Ntot >= 0 && M >= 0 && Nc >= 0 && lda >= M && ldy >= Nc, TGP_ERR_INVALID,
+              "tgp_segment_gemm_tn_ld_f32: bad sizes");
+  if (B == 0 || M == 0 || Nc == 0) return TGP_OK;
+  TGP_REQUIRE(C && ptr && (Ntot == 0 || (A && Y)), TGP_ERR_INVALID, "tgp_segment_gemm_tn_ld_f32: null pointer");
+  TGP_REQUIRE(Ntot < (1ll << 31) && M < (1ll << 31) && Nc < (1ll << 31) &&
+                  B * ((M + 63) / 64) * ((Nc + 63) / 64) < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_segment_gemm_tn_ld_f32: too large");
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.sA = 0;
+  g.M = static_cast<int>(M); g.Kd = static_cast<int>(Ntot);
+  g.rhs[0] = GemmRhs{Y, C, static_cast<int>(Nc), ldy, Nc, 0, M * Nc, 0};
+  g.splits = 1;
+  g.k_per_split = static_cast<int>((Ntot + BK - 1) / BK * BK);
+  if (g.k_per_split < BK) g.k_per_split = BK;
+  g.k_ptr = ptr;
+  launch_gemm<true>(g, static_cast<int>(B), stream);
+  return check_launch("tgp_segment_gemm_tn_ld_f32");
 }
 
 // r6: the same product with up to THREE right-hand sides in one grid -- C_j[b] = S_b^T Y_j,b -- for the unbatched dense

@@ -621,6 +621,66 @@ extern "C" int tgp_edge_facts_sorted_i64(const int64_t* row, int64_t E, const in
   return check_launch("tgp_edge_facts_sorted_i64");
 }
 
+// r6: the same question for a COALESCED row-sorted edge list with its CSR offsets (the unbatched dense poolers never
+// densify): entry (r, c, w) must have a mirror entry (c, r, w) -- found by binary search in row c.
+namespace tgp {
+__global__ __launch_bounds__(256) void edge_symmetry_kernel(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                                                            const float* __restrict__ w, int64_t E,
+                                                            const int* __restrict__ row_ptr, int64_t N,
+                                                            unsigned int* __restrict__ ticket,
+                                                            unsigned int* __restrict__ bad,
+                                                            unsigned long long* __restrict__ result,
+                                                            unsigned long long tag) {
+  __shared__ bool s_last;
+  unsigned int flags = 0;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; e < E; e += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t r = row[e], c = col[e];
+    if (r == c) continue;
+    if (c < 0 || c >= N) { flags = 1u; continue; }
+    int lo = row_ptr[c], hi = row_ptr[c + 1];
+    while (lo < hi) {  // first entry of row c whose column is >= r
+      const int mid = (lo + hi) >> 1;
+      if (col[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= row_ptr[c + 1] || col[lo] != r || (w && w[lo] != w[e])) flags = 1u;
+  }
+  if (flags) atomicOr(bad, flags);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned int fl = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *ticket = 0;
+      *bad = 0;
+      result[1] = 0ull;
+      result[2] = fl;
+      result[3] = result[4] = result[5] = 0ull;
+      __threadfence_system();
+      __hip_atomic_store(result, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+}  // namespace tgp
+
+extern "C" int tgp_edge_symmetry_f32(const int64_t* row, const int64_t* col, const float* w, int64_t E,
+                                     const int32_t* row_ptr, int64_t N, uint32_t* ticket, uint64_t* result, uint64_t tag,
+                                     void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(E > 0 && N > 0 && row && col && row_ptr && ticket && result, TGP_ERR_INVALID,
+              "tgp_edge_symmetry_f32: bad argument");
+  int64_t blocks = (E + 1023) / 1024;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(edge_symmetry_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, row, col, w, E, row_ptr,
+                     N, ticket, ticket + 1, reinterpret_cast<unsigned long long*>(result),
+                     static_cast<unsigned long long>(tag));
+  return check_launch("tgp_edge_symmetry_f32");
+}
+
 // r6: symmetry of a densified adjacency, see adj_symmetry_kernel.  `ticket` / `result` / `tag` as
 // tgp_edge_facts_sorted_i64 (two zeroed uint32 words per (device, stream); 6 pinned host words, word 0 = tag stored last,
 // word 2 = 1 when some entry differs from its mirror image).

@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void softmax_bwd_ex_kernel(const float* __rest
                                                              const float* __restrict__ c1, const float* __restrict__ deg,
                                                              long rows_per_graph, const float* __restrict__ ent_g,
                                                              float ent_scale, float ent_eps, float* __restrict__ dy,
-                                                             long ld_dy, long M, int K) {
+                                                             long ld_dy, long M, int K,
+                                                             const int64_t* __restrict__ batch) {
   const int sub = threadIdx.x % G;
   const long m = static_cast<long>(blockIdx.x) * (256 / G) + threadIdx.x / G;
   const bool ok = m < M;
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(256) void softmax_bwd_ex_kernel(const float* __rest
   const float* sr = s + base;
   const float* dr = ds + base;
   const float* er = extra ? extra + base : nullptr;
-  const float rowc = (ok && c1) ? 2.0f * c1[m / rows_per_graph] * deg[m] : 0.f;
+  // graph of the row: m / rows_per_graph (padded batch) or batch[m] (un-padded batch)
+  const float rowc = (ok && c1) ? 2.0f * c1[batch ? batch[m] : m / rows_per_graph] * deg[m] : 0.f;
   const float ge = ent_g ? ent_g[0] * ent_scale : 0.f;
   auto eff = [&](int k) -> float {
     const float sv = sr[k];
@@ -618,21 +620,22 @@ extern "C" int tgp_softmax_bwd_f32(const float* s, const float* ds, float* dy, i
 
 extern "C" int tgp_softmax_bwd_ex_f32(const float* s, const float* ds, const float* extra, const float* c1,
                                       const float* deg, int64_t rows_per_graph, const float* ent_g, float ent_scale,
-                                      float ent_eps, float* dy, int64_t ld_dy, int64_t M, int64_t K, void* stream_) {
+                                      float ent_eps, float* dy, int64_t ld_dy, int64_t M, int64_t K,
+                                      const int64_t* batch, void* stream_) {
   TGP_REQUIRE(M >= 0 && K >= 1 && K < (1ll << 31) && ld_dy >= K, TGP_ERR_INVALID, "tgp_softmax_bwd_ex_f32: bad shape");
   if (M == 0) return TGP_OK;
-  TGP_REQUIRE(s && ds && dy && (!c1 || (deg && rows_per_graph > 0)), TGP_ERR_INVALID,
+  TGP_REQUIRE(s && ds && dy && (!c1 || (deg && (rows_per_graph > 0 || batch))), TGP_ERR_INVALID,
               "tgp_softmax_bwd_ex_f32: null pointer");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int k = static_cast<int>(K);
   if (K <= 16)
     hipLaunchKernelGGL(softmax_bwd_ex_kernel<16>, dim3(cdiv(M, 16)), dim3(256), 0, stream, s, ds, extra, c1, deg,
                        static_cast<long>(rows_per_graph), ent_g, ent_scale, ent_eps, dy, static_cast<long>(ld_dy),
-                       static_cast<long>(M), k);
+                       static_cast<long>(M), k, batch);
   else
     hipLaunchKernelGGL(softmax_bwd_ex_kernel<64>, dim3(cdiv(M, 4)), dim3(256), 0, stream, s, ds, extra, c1, deg,
                        static_cast<long>(rows_per_graph), ent_g, ent_scale, ent_eps, dy, static_cast<long>(ld_dy),
-                       static_cast<long>(M), k);
+                       static_cast<long>(M), k, batch);
   return check_launch("tgp_softmax_bwd_ex_f32");
 }
 

@@ -1022,6 +1022,149 @@ class _PoolLargeFn(torch.autograd.Function):
         return (gxd, None, gw, gbias, None, None, None, None, None, None, None)
 
 
+def _slab_ptr(rows: int, device) -> Tensor:
+    """Row ranges of ~equal length (at least 256 rows, at most 64 ranges): the slabs of a weight-gradient product."""
+    slabs = max(1, min(64, rows // 256))
+    key = ("slab", rows, slabs, str(device))
+    if key not in _WHOLE_RANGE:
+        if len(_WHOLE_RANGE) > 64:
+            _WHOLE_RANGE.clear()
+        _WHOLE_RANGE[key] = (torch.arange(slabs + 1, dtype=torch.long, device=device) * rows) // slabs
+    return _WHOLE_RANGE[key]
+
+
+class _PoolUnbatchedFn(torch.autograd.Function):
+    """:class:`_PoolLargeFn` for the UNBATCHED mode (S [Ntot,K], sparse A, sorted batch vector; reference
+    connect/dense_conn.py:140-208, reduce/base_reduce.py:170-182, utils/losses.py:73-127, 204-240, 661-708 under ATen
+    autograd): one autograd node for Select (optional) + Reduce + Connect + post-processing + both losses, no dense
+    adjacency anywhere.
+    forward: T = A S (CSR SpMM), S^T [T | X | S] per graph (one product grid + a combine), the loss tail; the mincut
+    numerator is trace(raw_g), the link residual sum_e w_e^2 - 2 sum_g trace(raw_g) + sum_g |G_g|^2.
+    backward: the same K-sized right-hand sides as the padded form (tgp_dense_pool_train_rhs_f32), then
+        gS = [T | X | 1000 | S | T'] [gR^T ; g_x'^T ; 0 ; RS ; gR]  as ONE segment product over the operand buffer
+    (T' = A^T S: a second SpMM over the column-sorted list -- not at all when the list is symmetric, which one launch
+    in the forward finds out: kernels.AdjSymmetry.of_edge_list), softmax backward with the elementwise loss terms folded
+    in, gX = [S | dY] [g_x' ; W], [gW | gb] = dY^T [X | 1] over row slabs.  ``ei`` / ``ew``: the coalesced row-sorted
+    list; the edge weights get no gradient here (callers check)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, s_given, ei, ew, row_ptr, ptr, batch, max_nodes, flags, mode, scales, sw2, sym):
+        from . import _native as N
+        ctx.set_materialize_grads(False)
+        xd = N.f32c(x.detach())
+        n, F = xd.shape
+        selector = s_given is None
+        s = K.mlp_select(xd, weight.detach(), None if bias is None else bias.detach(), None) if selector \
+            else N.f32c(s_given.detach())
+        Kc = s.size(1)
+        B = ptr.numel() - 1
+        t = K.spmm_csr(row_ptr, ei, ew, n, s)
+        raw, x_pool, gram = K.segment_gemm_tn3(s, [t, xd, s], ptr, max_nodes)
+        adj_pool = K.postprocess_dense(raw, flags)
+        empty = s.new_empty(0)
+        la, lb = s.new_empty(0), s.new_empty(0)
+        deg = den = lossv = stats = None
+        if mode == 1:
+            deg, q = K.edge_row_stats(row_ptr, ew, s)
+            den, terms, stats = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr)
+            both = terms.mean(dim=1)
+            la, lb = both[0], both[1]
+        elif mode == 2:
+            lossv = K.diffpool_unbatched_tail(raw, gram, s, sw2, scales[0], scales[1])
+            la, lb = lossv[0], lossv[1]
+        keep = [v if v is not None else empty for v in (gram, deg, den, lossv, stats, ew, batch)]
+        ctx.save_for_backward(s, t, xd, empty if weight is None else weight, raw, ei, row_ptr, ptr, *keep)
+        ctx.flags, ctx.mode, ctx.scales, ctx.selector, ctx.max_nodes = flags, mode, scales, selector, max_nodes
+        ctx.has_bias, ctx.sym, ctx.has_w, ctx.has_batch = bias is not None, sym, ew is not None, batch is not None
+        if mode == 0:
+            ctx.mark_non_differentiable(la, lb)
+        if selector:
+            return s, x_pool, raw, adj_pool, la, lb
+        no_s = s.new_empty(0)
+        ctx.mark_non_differentiable(no_s)
+        return no_s, x_pool, raw, adj_pool, la, lb
+
+    @staticmethod
+    def backward(ctx, g_s, g_xp, g_raw, g_adj, g_la, g_lb):
+        from . import _native as N
+        s, t, xd, weight, raw, ei, row_ptr, ptr, gram, deg, den, lossv, stats, ew, batch = ctx.saved_tensors
+        ew = ew if ctx.has_w else None
+        batch = batch if ctx.has_batch else None
+        n, Kc = s.shape
+        F = xd.size(1)
+        B = ptr.numel() - 1
+        mode, selector = ctx.mode, ctx.selector
+        dev = s.device
+        if mode == 0:
+            g_la = g_lb = None
+        nothing = (None,) * 15
+        if g_s is None and g_xp is None and g_raw is None and g_adj is None and g_la is None and g_lb is None:
+            return nothing
+        want_gx = ctx.needs_input_grad[0]
+        ga = None
+        if g_adj is not None:
+            ga = K.postprocess_dense_bwd(raw, g_adj, ctx.flags)
+            if ga is None:
+                raise RuntimeError("dense pooling backward: K > 4096 is not supported by the post-processing backward")
+        gb = None if g_raw is None else N.f32c(g_raw)
+        gx_t, gx_bc = K._bcast_or_dense(g_xp, (B, Kc, F))
+        symmetric = ctx.sym is not None and ctx.sym.get()
+        POOL_LARGE_STATS["symmetric" if symmetric else "general"] += 1
+        fold_gx = selector and want_gx
+        rcat, c1, gwcat = K.dense_pool_train_rhs(
+            ga, gb, mode, stats if mode == 1 else None, den if mode == 1 else None, gram if mode else None, g_la,
+            g_lb if mode == 1 else None, 1.0 / B, lossv[0:1] if mode == 2 else None,
+            ctx.scales[0] if mode == 2 else 0.0, gx_t, gx_bc, symmetric, weight if fold_gx else None, B, Kc, F, dev)
+        pad = K.TRAIN_PAD
+        ld = 3 * Kc + F + pad
+        c_x, c_one, c_s, c_v = Kc, Kc + F, Kc + F + pad, 2 * Kc + F + pad
+        acat = torch.empty(n, ld, dtype=torch.float32, device=dev)
+        K.copy_cols2(t, xd, acat, 0, c_x, one_col=c_one)
+        vblock = acat[:, c_v:]
+        if not symmetric:  # T' = A^T S: the SpMM over the column-sorted list (the list is coalesced: nothing merges)
+            ident = torch.arange(n, device=dev)
+            w1 = ew if ew is not None else torch.ones(ei.size(1), device=dev)
+            ei_t, w_t = K.coalesce_edges(ei.flip(0), w1, ident, n, "sum", remove_self_loops=False, eps_filter=False)
+            K.copy_cols2(s, K.spmm_sorted(ei_t, w_t, n, s), acat, c_s, c_v)
+        else:
+            K.copy_cols2(s, s.new_empty(n, 0), acat, c_s, c_v)
+        kd = c_v if symmetric else ld
+        gs = torch.empty(n, Kc, dtype=torch.float32, device=dev)
+        K.segment_gemm_nn_into(acat[:, :kd], rcat[:, :kd, :], ptr, gs, ctx.max_nodes)
+        ent_g = g_lb if mode == 2 else None
+        if not selector:
+            gxd = None
+            if want_gx and g_xp is not None:
+                gxd = K.segment_gemm_nn(s, g_xp.contiguous() if gx_bc else gx_t, ptr, ctx.max_nodes)
+            if mode == 1 and c1 is not None:
+                rowc = 2.0 * (c1[batch] if batch is not None else c1) * deg
+                gs.addcmul_(rowc.unsqueeze(-1), s)
+            if ent_g is not None:
+                gs += K.entropy_bwd(s, ent_g, ctx.scales[1])
+            return (gxd, None, None, gs) + (None,) * 11
+        K.softmax_bwd_ex(s, gs, extra=g_s, c1=c1 if mode == 1 else None, deg=deg if mode == 1 else None, ent_g=ent_g,
+                         ent_scale=ctx.scales[1] if mode == 2 else 0.0, out=vblock, batch=batch)
+        gxd = gw = gbias = None
+        if want_gx:
+            gxd = torch.empty(n, F, dtype=torch.float32, device=dev)
+            K.segment_gemm_nn_into(acat[:, c_s:], gwcat, ptr, gxd, ctx.max_nodes)
+        want_gw, want_gb = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if want_gw or want_gb:
+            part = K.segment_gemm_tn_into(acat[:, c_v:], acat[:, c_x:c_x + F + pad], _slab_ptr(n, dev))
+            gw, gbias = K.slab_sum_split(part, F, want_gw, want_gb)
+        return (gxd, gw, gbias) + (None,) * 12
+
+
+def pool_unbatched(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], s: Optional[Tensor], ei: Tensor,
+                   ew: Optional[Tensor], row_ptr: Tensor, ptr: Tensor, batch: Optional[Tensor], max_nodes: int, flags: int,
+                   mode: int, scales=(0.0, 0.0), sw2=0.0, symmetry=None):
+    """(s, x_pool [B,K,F], raw, adj_pool, LossPair or None): see :class:`_PoolUnbatchedFn`."""
+    out = _PoolUnbatchedFn.apply(x, weight, bias, s, ei, ew, row_ptr, ptr, batch, max_nodes, flags, mode, tuple(scales), sw2,
+                                 symmetry)
+    pair = LossPair((out[4], out[5])) if mode else None
+    return (out[0] if s is None else s), out[1], out[2], out[3], pair
+
+
 def pool_large(x: Tensor, adj: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], mask: Optional[Tensor],
                s: Optional[Tensor], flags: int, mode: int, scales=(0.0, 0.0), graph_sizes: Optional[Tensor] = None,
                symmetry=None):

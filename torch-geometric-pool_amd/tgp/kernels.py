@@ -1160,6 +1160,33 @@ class AdjSymmetry:
                                              adj.size(1), N.ptr(adj), self.state.ticket.data_ptr() + 8,
                                              self.state.facts_slot(self.tag), self.tag, st), "tgp_adj_symmetry_f32")
 
+    @classmethod
+    def of_edge_list(cls, key_index: Tensor, key_weight: Optional[Tensor], edge_index: Tensor,
+                     edge_weight: Optional[Tensor], row_ptr: Tensor, num_nodes: int) -> "AdjSymmetry":
+        """The same question for a COALESCED row-sorted list with its CSR offsets (tgp_edge_symmetry_f32: every entry must
+        have a mirror entry of equal weight); remembered for the (key_index, key_weight) objects the caller holds."""
+        import weakref
+        self = cls.__new__(cls)
+        self.state = self.tag = None
+        self.ei, self.ew = weakref.ref(key_index), (None if key_weight is None else weakref.ref(key_weight))
+        self.answer = _adj_symmetric_memo(key_index, key_weight)
+        if self.answer is not None:
+            return self
+        row, col = _edge_rows(edge_index)
+        E = row.numel()
+        if E == 0 or torch.cuda.is_current_stream_capturing():
+            self.answer = E == 0 and not torch.cuda.is_current_stream_capturing()
+            return self
+        dev = edge_index.device
+        st = N.stream_ptr(dev)
+        self.state = _sps_state(dev, st, 0)
+        self.tag = self.state.next_facts_tag()
+        w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
+        N.check(N.lib().tgp_edge_symmetry_f32(N.ptr(row), N.ptr(col), N.ptr(w), E, N.ptr(row_ptr), num_nodes,
+                                              self.state.ticket.data_ptr() + 8, self.state.facts_slot(self.tag), self.tag,
+                                              st), "tgp_edge_symmetry_f32")
+        return self
+
     def get(self) -> bool:
         if self.answer is None:
             flags = self.state.peek_facts(self.tag)
@@ -1529,25 +1556,29 @@ def dense_pool_train_rhs(g_raw_a: Optional[Tensor], g_raw_b: Optional[Tensor], m
 
 def softmax_bwd_ex(s: Tensor, ds: Tensor, extra: Optional[Tensor] = None, c1: Optional[Tensor] = None,
                    deg: Optional[Tensor] = None, ent_g: Optional[Tensor] = None, ent_scale: float = 0.0,
-                   out: Optional[Tensor] = None) -> Tensor:
+                   out: Optional[Tensor] = None, batch: Optional[Tensor] = None) -> Tensor:
     """:func:`softmax_bwd` on dS + extra + 2 c1[graph] deg[row] S - ent_g ent_scale (log(S + eps) + S / (S + eps)):
     the elementwise parts of the pooling step's gradient folded into the selector's softmax backward.  s [B,N,K];
     ``out``: a [B,N,K] float32 view with unit last stride and uniform row stride (a column block of a wider buffer)."""
     dev = N.require_device(s, ds)
-    B, Nn, Kc = s.shape
+    if s.dim() == 2:  # un-padded batch [Ntot,K]: the graph of a row comes from ``batch`` (one graph without it)
+        B, (Nn, Kc) = 1, s.shape
+    else:
+        B, Nn, Kc = s.shape
     s2, d2 = N.f32c(s), N.f32c(ds)
     ex = None if extra is None else N.f32c(extra)
     if d2.numel() != s2.numel() or (ex is not None and ex.numel() != s2.numel()):
         raise ValueError("softmax_bwd_ex: gradient shapes do not match s")
     if out is None:
         out = torch.empty_like(s2)
-    elif (out.shape != s2.shape or out.dtype != torch.float32 or out.stride(2) != 1
-          or out.stride(0) != Nn * out.stride(1)):
-        raise ValueError("softmax_bwd_ex: out must be a float32 [B,N,K] view with a uniform row stride")
+    elif (out.shape != s2.shape or out.dtype != torch.float32 or out.stride(-1) != 1
+          or (out.dim() == 3 and out.stride(0) != Nn * out.stride(1))):
+        raise ValueError("softmax_bwd_ex: out must be a float32 view of s's shape with a uniform row stride")
     N.check(N.lib().tgp_softmax_bwd_ex_f32(N.ptr(s2), N.ptr(d2), N.ptr(ex), N.ptr(None if c1 is None else N.f32c(c1)),
                                            N.ptr(None if deg is None else N.f32c(deg)), Nn,
                                            N.ptr(None if ent_g is None else N.f32c(ent_g.reshape(1))), float(ent_scale),
-                                           losses_eps(), out.data_ptr(), out.stride(1), B * Nn, Kc, N.stream_ptr(dev)),
+                                           losses_eps(), out.data_ptr(), out.stride(-2), B * Nn, Kc,
+                                           N.ptr(None if batch is None else N.i64c(batch)), N.stream_ptr(dev)),
             "tgp_softmax_bwd_ex_f32")
     return out
 
@@ -2199,6 +2230,25 @@ def spmm_sorted_csr(edge_index: Tensor, edge_weight: Optional[Tensor], num_rows:
     return out, row_ptr
 
 
+def csr_offsets(edge_index: Tensor, num_rows: int) -> Tensor:
+    """int32 [num_rows+1] CSR offsets of a row-sorted list (one launch)."""
+    row, _ = _edge_rows(edge_index)
+    out = torch.empty(num_rows + 1, dtype=torch.int32, device=edge_index.device)
+    return rowptr_from_sorted(row, num_rows, out)
+
+
+def spmm_csr(row_ptr: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], num_rows: int, s: Tensor) -> Tensor:
+    """T = A S for a row-sorted coalesced float32 list whose CSR offsets the caller holds (one launch)."""
+    dev = N.require_device(edge_index, edge_weight, s, row_ptr)
+    _, col = _edge_rows(edge_index)
+    s = N.f32c(s)
+    w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
+    out = torch.empty(num_rows, s.size(1), dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_spmm_csr_f32(N.ptr(row_ptr), N.ptr(col), N.ptr(w), num_rows, col.numel(), N.ptr(s), s.size(1),
+                                     N.ptr(out), N.stream_ptr(dev)), "tgp_spmm_csr_f32")
+    return out
+
+
 def edge_row_stats(row_ptr: Tensor, edge_weight: Optional[Tensor], s: Tensor) -> Tuple[Tensor, Tensor]:
     """(deg [N], q [N]): row sums of the weights of a CSR edge list (entry counts without weights) and |S_i|^2, one
     launch (utils/losses.py:73-127: the degree term of sparse_mincut_loss without an index_add)."""
@@ -2232,6 +2282,38 @@ def segment_gemm_tn3(s: Tensor, ys, ptr: Tensor, max_nodes: int):
                                        B, s.size(0), Kc, max_nodes, N.ptr(ws), ws.numel(), N.stream_ptr(dev)),
             "tgp_segment_gemm_tn3_f32")
     return outs
+
+
+def segment_gemm_nn_into(a: Tensor, bm: Tensor, ptr: Tensor, out: Tensor, max_nodes: int) -> Tensor:
+    """out[rows of graph b] = a[rows of graph b] @ bm[b] for float32 VIEWS with unit last stride: ``a`` [Ntot,Kd] and
+    ``out`` [Ntot,Nc] with any row stride (column blocks of a wider buffer), ``bm`` [B,Kd,Nc] with any row / batch stride."""
+    dev = N.require_device(a, bm, ptr, out)
+    if (a.dim() != 2 or bm.dim() != 3 or out.dim() != 2 or a.stride(1) != 1 or bm.stride(2) != 1 or out.stride(1) != 1
+            or bm.size(1) != a.size(1) or out.size(1) != bm.size(2) or out.size(0) != a.size(0)
+            or any(t.dtype != torch.float32 for t in (a, bm, out))):
+        raise ValueError(f"segment_gemm_nn_into: {tuple(a.shape)} x {tuple(bm.shape)} -> {tuple(out.shape)}")
+    ptr = N.i64c(ptr)
+    N.check(N.lib().tgp_segment_gemm_nn_ld_f32(a.data_ptr(), a.stride(0), bm.data_ptr(), bm.stride(1), bm.stride(0),
+                                               N.ptr(ptr), out.data_ptr(), out.stride(0), ptr.numel() - 1, a.size(0),
+                                               a.size(1), bm.size(2), max_nodes, N.stream_ptr(dev)),
+            "tgp_segment_gemm_nn_ld_f32")
+    return out
+
+
+def segment_gemm_tn_into(a: Tensor, y: Tensor, ptr: Tensor) -> Tensor:
+    """[a[rows of b]^T @ y[rows of b] for b] -> [B,M,Nc] for float32 2-D VIEWS with unit last stride and any row stride
+    (no node-range split: meant for short row ranges, e.g. the row slabs of a weight gradient)."""
+    dev = N.require_device(a, y, ptr)
+    if (a.dim() != 2 or y.dim() != 2 or a.stride(1) != 1 or y.stride(1) != 1 or a.size(0) != y.size(0)
+            or a.dtype != torch.float32 or y.dtype != torch.float32):
+        raise ValueError(f"segment_gemm_tn_into: {tuple(a.shape)}^T x {tuple(y.shape)}")
+    ptr = N.i64c(ptr)
+    B = ptr.numel() - 1
+    out = torch.empty(B, a.size(1), y.size(1), dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_segment_gemm_tn_ld_f32(a.data_ptr(), a.stride(0), y.data_ptr(), y.stride(0), N.ptr(ptr),
+                                               N.ptr(out), B, a.size(0), a.size(1), y.size(1), N.stream_ptr(dev)),
+            "tgp_segment_gemm_tn_ld_f32")
+    return out
 
 
 def diffpool_unbatched_tail(raw: Tensor, gram: Tensor, s: Tensor, sw2, link_scale: float, ent_scale: float) -> Tensor:

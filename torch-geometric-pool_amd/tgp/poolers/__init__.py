@@ -431,60 +431,102 @@ class _DenseMLPPooling(DenseSRCPooling):
             return None
         return K.AdjSymmetry(edge_index, edge_weight, dense_adj, batch, info.ptr)
 
-    def _unbatched_fused(self, x, edge_index, edge_weight, batch, so):
-        """Unbatched mode outside autograd: Reduce, Connect and both auxiliary losses from ONE S^T [A S | X | S] product
+    def _unbatched_fused(self, x, edge_index, edge_weight, batch):
+        """Unbatched mode, r6: Select, Reduce, Connect and both auxiliary losses from ONE S^T [A S | X | S] product
         (tgp_segment_gemm_tn3_f32) behind the CSR SpMM -- the mincut numerator is trace(S_g^T (A S)_g), the link
         residual sum_e w_e^2 - 2 sum_g trace(raw_g) + sum_g |S_g^T S_g|^2 -- instead of per-edge dot products and
         index_add scatters (reference utils/losses.py:73-127, 204-240, 661-708; dense_conn.py:140-208;
-        base_reduce.py:170-182): 40-45 launches -> ~10.  Returns (x_pool [B,K,F], adj_pool [B,K,K], pooled batch vector,
-        losses) or None when the case is not this one (training, sparse_output, host tensors, ...)."""
+        base_reduce.py:170-182): 40-45 launches -> ~10 per forward.  Under autograd the same forward is ONE autograd
+        node with the backward of the padded form on the un-padded rows (functions._PoolUnbatchedFn).  Returns
+        (SelectOutput, x_pool [B,K,F], adj_pool [B,K,K], pooled batch vector, losses) or None when the case is not this
+        one (sparse_output, host tensors, edge weights that require a gradient, ...)."""
         from .. import kernels as K
         from .. import functions as Fn
-        c, s = self.connector, so.s
+        c, sel = self.connector, self.selector
         if (self.sparse_output or type(c) is not DenseConnect or type(self.reducer) is not BaseReduce
-                or not (isinstance(x, Tensor) and isinstance(edge_index, Tensor) and isinstance(s, Tensor))
-                or x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or s.dim() != 2 or s.dtype != torch.float32
+                or not (isinstance(x, Tensor) and isinstance(edge_index, Tensor))
+                or x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32
                 or edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.long
                 or not edge_index.is_cuda or edge_index.size(1) == 0 or x.size(0) == 0 or x.size(1) == 0
                 or (edge_weight is not None and (not isinstance(edge_weight, Tensor) or edge_weight.dtype != torch.float32
                                                  or edge_weight.numel() != edge_index.size(1)))
                 or (batch is not None and (batch.dtype != torch.long or batch.numel() != x.size(0)))):
             return None
-        if torch.is_grad_enabled() and (s.requires_grad or x.requires_grad
-                                        or (edge_weight is not None and edge_weight.requires_grad)):
+        grad = torch.is_grad_enabled()
+        if grad and edge_weight is not None and edge_weight.requires_grad:
             return None
-        n, k = s.shape
+        n = x.size(0)
+        info = None
         if batch is not None:
             info = batch_info(batch)
             if not info.is_sorted:
                 return None
-            ptr, nb, max_nodes = info.ptr, info.num_graphs, info.max_nodes
+            ptr, max_nodes = info.ptr, info.max_nodes
         else:
-            ptr, nb, max_nodes = Fn._whole_range(n, x.device), 1, n
+            ptr, max_nodes = Fn._whole_range(n, x.device), n
+        # the selector: folded into the training node when it is a single Linear, else run in front (its S handed over)
+        lins = getattr(getattr(sel, "mlp", None), "lins", None)
+        single = type(sel) is MLPSelect and lins is not None and len(lins) == 1 and lins[0].weight.dtype == torch.float32
+        so = weight = bias = None
+        if not (grad and single and _FOLD_TRAINING):
+            so = self.select(x=x, batch=batch)
+            s = so.s
+            if not (isinstance(s, Tensor) and s.dim() == 2 and s.dtype == torch.float32 and s.size(0) == n):
+                return (so,)  # (the caller goes on with this SelectOutput on the operator path)
+            training = grad and (s.requires_grad or x.requires_grad)
+        else:
+            weight, bias = lins[0].weight, lins[0].bias
+            s = None
+            training = x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)
+            if not training:
+                so = self.select(x=x, batch=batch)
+                s = so.s
+        k = s.size(1) if s is not None else weight.size(0)
+        if training and (not _FOLD_TRAINING or c.edge_weight_norm or k > 4096):
+            if so is None:
+                so = self.select(x=x, batch=batch)
+            return None if so is None else (so,)  # (the caller goes on with this SelectOutput on the operator path)
         w_in = None if edge_weight is None else edge_weight.reshape(-1)
         ones = w_in is None
         # sorted + duplicate-summed A (what the reference's per-graph `.coalesce()` does), T = A S, then one product grid
-        ei, w = Fn.coalesce_sum(edge_index, torch.ones(edge_index.size(1), device=x.device) if ones else w_in, n)
+        ei, w = Fn.coalesce_sum(edge_index, torch.ones(edge_index.size(1), device=x.device) if ones else w_in.detach(), n)
         unit = ones and ei is edge_index  # (nothing merged: the weights are still all one)
-        t, row_ptr = K.spmm_sorted_csr(ei, None if unit else w, n, s)
-        raw, x_pool, gram = K.segment_gemm_tn3(s, [t, x, s], ptr, max_nodes)
-        if self._loss_needs_raw:  # MinCut
-            deg, q = K.edge_row_stats(row_ptr, None if unit else w, s)
-            _, terms, _ = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr)
-            both = terms.mean(dim=1)
-            loss = {"cut_loss": both[0] if self.cut_loss_coeff == 1 else both[0] * self.cut_loss_coeff,
-                    "ortho_loss": both[1] if self.ortho_loss_coeff == 1 else both[1] * self.ortho_loss_coeff}
-        else:  # DiffPool: sum_e w_e^2 runs over the list as given (duplicates not merged, losses.py:680-690)
-            sw2 = float(edge_index.size(1)) if ones else torch.dot(w_in, w_in)
+        w_used = None if unit else w
+        row_ptr = K.csr_offsets(ei, n)
+        flags = K.dense_flags(c.remove_self_loops, c.degree_norm, False, c.edge_weight_norm)
+        mincut = self._loss_needs_raw
+        sw2, scales = 0.0, (0.0, 0.0)
+        if not mincut:  # DiffPool: sum_e w_e^2 runs over the list as given (duplicates not merged, losses.py:680-690)
+            sw2 = float(edge_index.size(1)) if ones else torch.dot(w_in.detach(), w_in.detach())
             link_scale = float(self.link_loss_coeff)
             if self.normalize_loss is True:
-                denom = sum(v * v for v in info.sizes_host) if batch is not None else n * n
+                denom = sum(v * v for v in info.sizes_host) if info is not None else n * n
                 link_scale = link_scale / max(denom, 1)
-            both = K.diffpool_unbatched_tail(raw, gram, s, sw2, link_scale, float(self.ent_loss_coeff) / n)
+            scales = (link_scale, float(self.ent_loss_coeff) / n)
+        if training:
+            sym = K.AdjSymmetry.of_edge_list(edge_index, edge_weight, ei, w_used, row_ptr, n)
+            s_out, x_pool, raw, adj_pool, pair = Fn.pool_unbatched(
+                x, weight, bias, s, ei, w_used, row_ptr, ptr, batch, max_nodes, flags, 1 if mincut else 2, scales, sw2, sym)
+            if so is None:
+                so = SelectOutput(s=s_out, s_inv_op=sel.s_inv_op, batch=batch)
+            both = pair
+        else:
+            t = K.spmm_csr(row_ptr, ei, w_used, n, s)
+            raw, x_pool, gram = K.segment_gemm_tn3(s, [t, x, s], ptr, max_nodes)
+            if mincut:
+                deg, q = K.edge_row_stats(row_ptr, w_used, s)
+                _, terms, _ = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr)
+                both = terms.mean(dim=1)
+            else:
+                both = K.diffpool_unbatched_tail(raw, gram, s, sw2, scales[0], scales[1])
+            adj_pool = K.postprocess_dense(raw, flags)
+        if mincut:
+            loss = {"cut_loss": both[0] if self.cut_loss_coeff == 1 else both[0] * self.cut_loss_coeff,
+                    "ortho_loss": both[1] if self.ortho_loss_coeff == 1 else both[1] * self.ortho_loss_coeff}
+        else:
             loss = {"link_loss": both[0], "entropy_loss": both[1]}
-        adj_pool = postprocess_adj_pool_dense(raw, remove_self_loops=c.remove_self_loops, degree_norm=c.degree_norm,
-                                              adj_transpose=False, edge_weight_norm=c.edge_weight_norm)
-        return x_pool, adj_pool, self.reducer.reduce_batch(so, batch if batch is not None else so.batch), loss
+        batch_pool = self.reducer.reduce_batch(so, batch if batch is not None else so.batch)
+        return so, x_pool, adj_pool, batch_pool, loss
 
     def _sizes_for(self, adj):
         """Real nodes per graph of the zero-padded batch ``adj`` belongs to, if forward() densified it itself."""
@@ -576,11 +618,11 @@ class _DenseMLPPooling(DenseSRCPooling):
                 return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so, loss=loss)
             return PoolingOutput(x=x_pool, edge_index=adj_pool, so=so, loss=loss)
         # unbatched: S [N,K], sparse A, sparse losses
-        so = self.select(x=x, batch=batch)
-        fused = self._unbatched_fused(x, adj, edge_weight, batch, so)
-        if fused is not None:  # inference: the losses from the products the Connect forms anyway (r6)
-            x_pool, adj_pool, batch_pool, loss = fused
+        fused = self._unbatched_fused(x, adj, edge_weight, batch)
+        if fused is not None and len(fused) == 5:  # the losses from the products the Connect forms anyway (r6)
+            so, x_pool, adj_pool, batch_pool, loss = fused
             return PoolingOutput(x=x_pool, edge_index=adj_pool, edge_weight=None, batch=batch_pool, so=so, loss=loss)
+        so = fused[0] if fused is not None else self.select(x=x, batch=batch)
         loss = self.compute_sparse_loss(adj, edge_weight, so.s, batch)
         x_pool, batch_pool = self.reduce(x=x, so=so, batch=batch, return_batched=not self.sparse_output)
         ei, ew = self.connect(edge_index=adj, so=so, edge_weight=edge_weight, batch=batch,
