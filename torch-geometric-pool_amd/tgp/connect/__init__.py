@@ -119,8 +119,8 @@ class SparseConnect(Connect):
                                           edge_csr=so.edge_csr_for(edge_index) if all_assigned else None,
                                           # (TopkSelect on large graphs: the kept-node bitmap + rank directory its
                                           #  compaction pass wrote -- the subgraph Connect is then ONE launch)
-                                          member_directory=getattr(so.__dict__.get("_assign_index"),
-                                                                   "member_directory", None))
+                                          member_directory=K.member_directory_for(so.__dict__.get("_assign_index"),
+                                                                                  so.node_index))
         return adj_pool, like_input_dtype(w_pool, edge_weight)
 
     def __repr__(self) -> str:

@@ -38,7 +38,8 @@ class AssignIndex:
     """Inverted index of a sparse assignment (supernode -> its assignments, in ascending
     assignment order).  A function of the SelectOutput only, so SelectOutput caches it."""
 
-    __slots__ = ("_row_ptr", "perm", "nnz", "num_targets", "_device", "pack", "pack_key", "member_directory")
+    __slots__ = ("_row_ptr", "perm", "nnz", "num_targets", "_device", "pack", "pack_key", "member_directory",
+                 "member_directory_key")
 
     def __init__(self, row_ptr: Optional[Tensor], perm: Optional[Tensor], nnz: int, num_targets: int, device=None):
         # row_ptr None: exactly one assignment per target (TopK, NDP) -- the table is arange and the Reduce kernel
@@ -58,7 +59,10 @@ class AssignIndex:
         # r5 (TopkSelect on large graphs): int32 [5 * blocks] = the kept-node bitmap (4 words per 128-node block) followed
         # by the rank directory (kept nodes in front of every block), by-products of the selector's compaction pass that
         # the subgraph Connect of the same selection starts from (tgp_connect_subgraph_single's member_bits_in)
+        # ... valid for exactly the node_index storage named by member_directory_key = (data_ptr, length) (a
+        # SelectOutput whose S was replaced must not get a Connect relabelled by the stale selection)
         self.member_directory = None
+        self.member_directory_key = None
         self._device = perm.device if perm is not None else (row_ptr.device if row_ptr is not None else
                                                               torch.device(device))
 
@@ -520,6 +524,18 @@ def _read_count(d_count: Tensor) -> int:
         raise IndexError("edge_index holds node ids outside [0, num_nodes) (or cluster ids outside [0, num_supernodes)): "
                          "the reference's index ops raise for these inputs too")
     return n
+
+
+def member_directory_for(assign: Optional["AssignIndex"], node_index: Optional[Tensor]) -> Optional[Tensor]:
+    """The selector's kept-node bitmap + rank directory, if it still describes ``node_index`` (the same storage and length
+    as when TopkSelect wrote it: a SelectOutput whose ``s`` was replaced does not get the old selection's directory);
+    None otherwise."""
+    if assign is None or node_index is None:
+        return None
+    md, key = getattr(assign, "member_directory", None), getattr(assign, "member_directory_key", None)
+    if md is None or key is None or key != (node_index.data_ptr(), node_index.numel()):
+        return None
+    return md
 
 
 def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: Optional[Tensor],
@@ -1744,6 +1760,7 @@ def topk_select(score: Tensor, batch: Optional[Tensor], num_graphs: int, ptr: Te
         pack = torch.as_strided(i64, (kk,), (1,), o_pack >> 3)
     assign = AssignIndex(None, perm, k_total, k_total)
     assign.member_directory = directory  # (bitmap | rank128) of the kept nodes, or None
+    assign.member_directory_key = (index.data_ptr(), k_total) if directory is not None else None
     if pack is not None and k_total > 0 and n < (1 << 31):
         assign.pack, assign.pack_key = pack, (index.data_ptr(), values.data_ptr())
     out = (index, assign) + ((values,) if with_values else ())

@@ -154,7 +154,10 @@ def _batch_facts_sorted(batch: Tensor, info: "BatchInfo", topk_ratio: float = 0.
     pend = _FACTS_PENDING.pop(id(batch), None)
     launched = None
     if pend is not None and pend[0]() is batch and pend[1] == batch._version:
-        if pend[2] == float(topk_ratio or 0.0) or pend[2] > 0:
+        # a prefetch whose pinned slot (eight rotate: tag & 7) has been handed to a later launch is not waited for -- its
+        # words are gone and the wait would spin into its bound: the facts are launched again
+        fresh = pend[3][0].facts_tag - pend[3][1] < 8
+        if fresh and (pend[2] == float(topk_ratio or 0.0) or pend[2] > 0):
             launched = pend[3]
             if pend[2] > 0 and not (topk_ratio and topk_ratio > 0):
                 topk_ratio = pend[2]  # (the prefetch also made a TopK plan: kept)
