@@ -725,8 +725,13 @@ def all_gather_sparse(x: Tensor, edge_index: Tensor, edge_weight: Optional[Tenso
     key = (id(group) if group is not None else 0, bool(forced), world)
     g = _SYNC_GATHERS.get(key)
     if g is None or g.group is not group or g._inflight or g._open or g._ready:
-        if len(_SYNC_GATHERS) > 8:
-            _SYNC_GATHERS.clear()
-        g = _SYNC_GATHERS[key] = SparseGather(group=group, force_collective=force_collective, depth=1, bucket_steps=1)
+        # A gather that an exception left with open steps is replaced -- with the capacity it had reached: capacity only
+        # ever grows, by a rule every rank applies to the same headers, so carrying it over keeps the ranks' buffer sizes
+        # equal even when only ONE rank went through the exception.  Entries are never dropped by a per-rank
+        # count either (ranks in different numbers of groups would then disagree): a dead group's entry is replaced when
+        # its id is reused (`g.group is not group`).
+        keep = g.capacity if (g is not None and g.group is group) else None
+        g = _SYNC_GATHERS[key] = SparseGather(group=group, force_collective=force_collective, depth=1, bucket_steps=1,
+                                              capacity=keep)
     g.start(x, edge_index, edge_weight, batch, num_graphs_local)
     return g.wait()

@@ -195,14 +195,20 @@ SPS_COMPACT_BYTES = 1 << 30  # capacity buffers above this are replaced by exact
 # tensor that owns 16 E' bytes -- filled from the capacity scratch by one native launch (tgp_edges_compact).  True: the
 # r4 behaviour, ``edge_index`` a [2, E'] VIEW of the capacity buffer (row stride E, E-sized storage kept alive; no copy)
 # for callers that consume the pooled graph at once, e.g. straight into SparseGather or the next pooling level.
-_OUTPUT_VIEWS = os.environ.get("TGP_OUTPUT_VIEWS", "0") == "1"
+_OUTPUT_VIEWS_DEFAULT = os.environ.get("TGP_OUTPUT_VIEWS", "0") == "1"
+_OUTPUT_VIEWS_LOCAL = __import__("threading").local()  # per thread: a `with output_views()` in one thread must not
+#                                                        change the layout other threads (autograd workers) hand out
+
+
+def _output_views() -> bool:
+    return getattr(_OUTPUT_VIEWS_LOCAL, "value", _OUTPUT_VIEWS_DEFAULT)
 
 
 def set_output_views(enable: bool) -> bool:
-    """Choose the layout of the pooled edge lists of the single-call operators (see ``_OUTPUT_VIEWS``); returns the
-    previous setting."""
-    global _OUTPUT_VIEWS
-    prev, _OUTPUT_VIEWS = _OUTPUT_VIEWS, bool(enable)
+    """Choose the layout of the pooled edge lists of the single-call operators for THIS thread (default: the process-wide
+    ``TGP_OUTPUT_VIEWS`` setting); returns the previous setting."""
+    prev = _output_views()
+    _OUTPUT_VIEWS_LOCAL.value = bool(enable)
     return prev
 
 
@@ -398,7 +404,7 @@ def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_wei
     ``assign_index`` [2, nnz] = (node_index, cluster_index), the indices of the sparse S.  None: a precondition checked
     on the device does not hold (the caller takes the staged operators)."""
     if views is None:
-        views = _OUTPUT_VIEWS
+        views = _output_views()
     dev = N.require_device(x, graph_ptr, edge_index, edge_weight, assign_index, weight)
     if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
         raise ValueError("sparse_pool_small expects float32 x [N, F] with unit feature stride")
@@ -549,7 +555,7 @@ def filter_edges(edge_index: Tensor, edge_weight: Optional[Tensor], node_index: 
     bitmap + rank directory of ``node_index`` (``AssignIndex.member_directory``; node_index must be ascending, as a
     SelectOutput's is): the call is then ONE launch -- no memset, no scatter of the kept nodes, no directory scan."""
     if views is None:
-        views = _OUTPUT_VIEWS
+        views = _output_views()
     dev = N.require_device(edge_index, edge_weight, node_index)
     row, col = _edge_rows(edge_index)
     E = row.numel()
@@ -2444,23 +2450,31 @@ def kron_max_graph_nodes() -> int:
 _KRON_CAPS: dict = {}
 
 
-def _kron_caps(graph_sizes_host) -> Tuple[int, int, int]:
-    """Workspace figures of the Kron kernels from the graphs' node counts: (sum of n^2 over the graphs inside the kernel's
-    size limit, sum of n (n | 1) over those beyond the LDS kernel's 128 nodes, how many those are).  Vectorised and
-    remembered per sizes list (r5: three Python passes over 2048 graphs were ~120 us of every NDP pooler call)."""
+def _kron_caps(graph_sizes_host, limit: Optional[int] = None) -> Tuple[int, int, int]:
+    """Workspace figures of the Kron kernels from the graphs' node counts: (sum of n^2 over the graphs inside the size
+    limit of THIS call -- the kernels' own, or the smaller ``limit`` a caller declared: graphs beyond it are skipped by
+    the kernel and get no slab --, sum of n (n | 1) over those beyond the LDS kernel's 128 nodes, how many those are).
+    Vectorised and remembered per sizes list (r5: three Python passes over 2048 graphs were ~120 us of every NDP pooler
+    call); the memo holds the list object and re-checks its length, its sum and the limit, so a list edited in place
+    does not hand back stale figures."""
     import numpy as np
+    lim = kron_max_graph_nodes() if limit is None else max(1, min(int(limit), kron_max_graph_nodes()))
     key = id(graph_sizes_host)
     hit = _KRON_CAPS.get(key)
-    if hit is not None and hit[0] is graph_sizes_host and hit[1] == len(graph_sizes_host):
-        return hit[2]
-    lim, lds = kron_max_graph_nodes(), 128
-    v = np.asarray(graph_sizes_host, dtype=np.int64)
+    v = None
+    if hit is not None and hit[0] is graph_sizes_host and hit[1] == len(graph_sizes_host) and hit[3] == lim:
+        v = np.asarray(graph_sizes_host, dtype=np.int64)
+        if int(v.sum()) == hit[4]:
+            return hit[2]
+    if v is None:
+        v = np.asarray(graph_sizes_host, dtype=np.int64)
+    total = int(v.sum())
     v = v[v <= lim]
-    big = v[v > lds]
+    big = v[v > 128]
     caps = (int((v * v).sum()), int((big * (big | 1)).sum()), int(big.size))
     if len(_KRON_CAPS) > 16:
         _KRON_CAPS.clear()
-    _KRON_CAPS[key] = (graph_sizes_host, len(graph_sizes_host), caps)  # (holds the list: the id stays its own)
+    _KRON_CAPS[key] = (graph_sizes_host, len(graph_sizes_host), caps, lim, total)  # (holds the list: the id stays its own)
     return caps
 
 
@@ -2477,7 +2491,7 @@ def kron_batched(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optio
     dev = N.require_device(indptr, col, val, perm, graph_ptr, node_index)
     cap_dense = cap_big = num_big = -1
     if graph_sizes_host is not None:
-        cap_dense, cap_big, num_big = _kron_caps(graph_sizes_host)
+        cap_dense, cap_big, num_big = _kron_caps(graph_sizes_host, max_graph_nodes)
     if indptr.dtype != torch.int32 or (perm is not None and perm.dtype != torch.int32):
         raise ValueError("kron_batched: indptr / perm must be int32")
     col, graph_ptr, node_index = N.i64c(col), N.i64c(graph_ptr), N.i64c(node_index)
