@@ -635,9 +635,10 @@ int tgp_mincut_loss_terms_bwd_f32(const float* raw, const float* den, const floa
  *   den[b] = sum_i deg[b,i] q[b,i] formed in the same launch (deg, q [B,N] from tgp_cut_terms_f32) and kept for the
  *   backward together with stats [B,4] = (trace(raw), |G|_F^2, trace(G), |G / |G| - I / sqrt(K)|_F) per graph (optional).
  *   ptr (optional, [B+1]): deg / q are those of an UN-padded batch, graph b owns entries ptr[b] .. ptr[b+1] (N unused).
+ *   q may be NULL: den[b] = sum_i deg[b,i] (the caller's deg already carries the factor, e.g. (A q)_i).
  * tgp_dense_pool_train_rhs_f32: the right-hand sides into rcat [B][3K+F+4][K], rows [RU ; RX ; four zero rows ; RS ; RV]:
- *   with gR = g_raw_a + g_raw_b (either may be NULL) + the loss' diagonal term, RV = gR, RU = gR^T (`symmetric`:
- *   RU = gR + gR^T, RV not written), RX = g_x^T (g_x [B,K,F], or one value when gx_bcast), RS by mode:
+ *   with gR = g_raw_a + g_raw_b (either may be NULL) + the loss' diagonal term, RV = gR, RU = gR^T (`symmetric` bit 0:
+ *   RU = gR + gR^T, RV not written; bit 1: RU = gR, RV = gR^T -- the buffer's first block holds A S while raw = S^T A^T S), RX = g_x^T (g_x [B,K,F], or one value when gx_bcast), RS by mode:
  *   0: zeros;
  *   1 (MinCut): RS = W + W^T, gR -= (g_cut / (den + eps)) I, c1[b] = g_cut trace(raw) / (den + eps)^2 (the per-graph
  *      scalars from the forward's `stats`: the launch is purely elementwise, 32 x 32 tiles), with

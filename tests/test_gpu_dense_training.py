@@ -13,6 +13,14 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture
+def dense_route(monkeypatch):
+    """These cases exercise the DENSIFYING route of the batched poolers (functions._PoolLargeFn): the un-padded rows route
+    that sparse inputs below the density bound take since r6 is switched off for them."""
+    import tgp.poolers as P
+    monkeypatch.setattr(P, "_ROWS_ROUTE_DENSITY", 0.0)
+
+
 def _batch(sizes, f, deg, seed, weighted=True):
     """Sorted PyG-style batch on the host: x [Ntot,F], symmetric duplicate-free edge_index, weights, batch vector."""
     g = torch.Generator().manual_seed(seed)
@@ -51,7 +59,7 @@ CASES = [  # alias, graph sizes, K, F, weighted edges
 
 
 @pytest.mark.parametrize("alias,sizes,k,f,weighted", CASES)
-def test_large_graph_training_step_matches_oracle_autograd(dev, alias, sizes, k, f, weighted):
+def test_large_graph_training_step_matches_oracle_autograd(dev, dense_route, alias, sizes, k, f, weighted):
     import tgp_oracle as O
     from tgp.poolers import get_pooler
     x, ei, ew, batch = _batch(sizes, f, 8.0, seed=len(sizes) * 100 + k, weighted=weighted)
@@ -102,7 +110,7 @@ def test_large_graph_training_step_matches_oracle_autograd(dev, alias, sizes, k,
 
 
 @pytest.mark.parametrize("alias", ["mincut", "diff"])
-def test_large_graph_training_step_two_layer_selector(dev, alias):
+def test_large_graph_training_step_two_layer_selector(dev, dense_route, alias):
     """A selector with a hidden layer keeps its own autograd nodes; the pooling step behind it is still the one node (S is
     handed over), and the elementwise loss terms are added to dS there."""
     import tgp_oracle as O
@@ -225,3 +233,73 @@ def test_adjacency_symmetry_probe(dev):
         K.AdjSymmetry(ei, other, adj3, batch, info.ptr)
     torch.cuda.synchronize()
     assert first.get() is False and K._adj_symmetric_memo(ei, w3) is None
+
+
+ROWS_CASES = [  # alias, graph sizes, K, F, weighted, adj_transpose, hidden layer
+    ("mincut", [400, 300], 40, 24, True, True, None),     # random weights per direction: S^T A^T S != S^T A S
+    ("mincut", [400, 300], 40, 24, True, False, None),
+    ("mincut", [350, 420, 380], 72, 16, False, True, None),
+    ("diff", [400, 300], 40, 24, True, True, None),
+    ("diff", [350, 420, 380], 72, 16, False, True, None),
+    ("diff", [400, 300], 36, 12, True, False, 20),         # a selector with a hidden layer
+]
+
+
+@pytest.mark.parametrize("alias,sizes,k,f,weighted,adj_t,hidden", ROWS_CASES)
+def test_batched_poolers_sparse_input_rows_route(dev, alias, sizes, k, f, weighted, adj_t, hidden):
+    """r6: a batched dense pooler on a SPARSE input whose graphs are large and sparse never builds [B,N,N]: Reduce, Connect
+    and the losses run on the un-padded rows (poolers._unbatched_fused(batched_out=True), functions._PoolUnbatchedFn with
+    the transposed form for adj_transpose).  Inference and training against the oracle's BATCHED restatement (densify,
+    transpose, bmm; reference src.py:374-452, dense_conn.py:111-122, utils/losses.py:39-70, 644-658)."""
+    import tgp_oracle as O
+    from tgp import functions as Fn
+    from tgp.poolers import get_pooler
+    x, ei, ew, batch = _batch(sizes, f, 6.0, seed=sum(sizes) + k, weighted=weighted)
+    chans = f if hidden is None else [f, hidden]
+    kw = dict(adj_transpose=adj_t, **({} if hidden is None else {"act": "tanh"}))
+    pooler = get_pooler(alias, in_channels=chans, k=k, **kw).to(dev)
+    lins = pooler.selector.mlp.lins
+    args = dict(adj=ei.to(dev), edge_weight=None if ew is None else ew.to(dev), batch=batch.to(dev))
+    wts = (torch.ones(ei.size(1)) if ew is None else ew)
+
+    # inference
+    pooler.eval()
+    with torch.no_grad():
+        out = pooler(x=x.to(dev), **args)
+    ref = O.dense_pool(alias, x, ei, wts, batch, [l.weight.detach().cpu() for l in lins], [l.bias.detach().cpu() for l in lins],
+                       act=None if hidden is None else "tanh", adj_transpose=adj_t)
+    torch.testing.assert_close(out.x.cpu(), ref["x"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out.edge_index.cpu(), ref["edge_index"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out.so.s.cpu(), ref["s"], rtol=1e-5, atol=1e-7)
+    assert out.so.s.shape == (len(sizes), max(sizes), k) and torch.equal(out.mask.cpu(), ref["mask"])
+    for name, want in ref["loss"].items():
+        torch.testing.assert_close(out.loss[name].cpu(), want, rtol=2e-5, atol=1e-6, msg=lambda m: f"{name}: {m}")
+
+    # training
+    pooler.train()
+    g = torch.Generator().manual_seed(5)
+    B = len(sizes)
+    wx, wa = torch.randn(B, k, f, generator=g), torch.randn(B, k, k, generator=g)
+    before = dict(Fn.POOL_LARGE_STATS)
+    xg = x.to(dev).requires_grad_(True)
+    out = pooler(x=xg, **args)
+    assert any("_PoolUnbatchedFn" in n for n in _node_names(out.x.grad_fn))
+    l1, l2 = list(out.loss.values())
+    ((out.x * wx.to(dev)).sum() + (out.edge_index * wa.to(dev)).sum() + 0.7 * l1 + 1.3 * l2).backward()
+    route = "general" if weighted else "symmetric"
+    assert Fn.POOL_LARGE_STATS[route] == before[route] + 1
+    xr = x.double().requires_grad_(True)
+    ws = [l.weight.detach().cpu().double().requires_grad_(True) for l in lins]
+    bs = [l.bias.detach().cpu().double().requires_grad_(True) for l in lins]
+    ref = O.dense_pool(alias, xr, ei, wts.double(), batch, ws, bs, act=None if hidden is None else "tanh",
+                       adj_transpose=adj_t)
+    r1, r2 = list(ref["loss"].values())
+    ((ref["x"] * wx.double()).sum() + (ref["edge_index"] * wa.double()).sum() + 0.7 * r1 + 1.3 * r2).backward()
+    for got, want in ((l1, r1), (l2, r2)):
+        torch.testing.assert_close(got.detach().cpu().double(), want.detach(), rtol=2e-5, atol=1e-6)
+    pairs = [(xg.grad, xr.grad, "dX")] + [(l.weight.grad, w.grad, f"dW{i}") for i, (l, w) in enumerate(zip(lins, ws))] \
+        + [(l.bias.grad, b.grad, f"db{i}") for i, (l, b) in enumerate(zip(lins, bs))]
+    for got, want, what in pairs:
+        scale = float(want.abs().max())
+        torch.testing.assert_close(got.cpu().double(), want, rtol=2e-4, atol=2e-5 * max(scale, 1e-3),
+                                   msg=lambda m: f"{what}: {m}")

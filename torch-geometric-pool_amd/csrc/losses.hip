@@ -412,7 +412,8 @@ __global__ __launch_bounds__(T) void mincut_tail2_kernel(const float* __restrict
   const float* d = deg + lo;
   const float* qq = q + lo;
   float dn = 0.f, tr = 0.f, sq = 0.f, trg = 0.f;
-  for (int i = threadIdx.x; i < N; i += T) dn = fmaf(d[i], qq[i], dn);
+  if (q) { for (int i = threadIdx.x; i < N; i += T) dn = fmaf(d[i], qq[i], dn); }
+  else { for (int i = threadIdx.x; i < N; i += T) dn += d[i]; }  // (deg already carries the factor: (A q)_i)
   for (int i = threadIdx.x; i < K; i += T) {
     tr += R[static_cast<int64_t>(i) * K + i];
     trg += G[static_cast<int64_t>(i) * K + i];
@@ -464,7 +465,7 @@ struct TrainRhsArgs {
   const float* g_la; const float* g_lb; float scale;
   const float* link_loss; float link_scale, eps;
   const float* g_x; int gx_bcast;
-  int K, F, mode, tiles_k, tiles_f, symmetric;
+  int K, F, mode, tiles_k, tiles_f, symmetric;  // symmetric bit 1: swap the RU / RV slots (the first block holds V)
   float* rcat; float* c1;
   const float* W; float* gw;  // selector weight [K][F] and [B][2K][F] = [g_x ; W], or NULL
 };
@@ -563,8 +564,11 @@ __global__ __launch_bounds__(256) void train_rhs_kernel(TrainRhsArgs p) {
     if (gb) v += gb[e];
     const float dg = (r == c) ? diag : 0.f;
     const float vt = t_a[tx][ty * 4 + q];  // gR[c][r]
-    if (p.symmetric) {
+    if (p.symmetric & 1) {
       RU[e] = (v + dg) + (vt + dg);
+    } else if (p.symmetric & 2) {  // the operand buffer's first block is A S where raw = S^T A^T S: the slots trade places
+      RU[e] = v + dg;
+      RV[e] = vt + dg;
     } else {
       RV[e] = v + dg;
       RU[e] = vt + dg;
@@ -693,7 +697,7 @@ extern "C" int tgp_mincut_terms_fused_f32(const float* raw, const float* gram, c
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 1 && K < 32768 && N < (1ll << 31), TGP_ERR_INVALID,
               "tgp_mincut_terms_fused_f32: bad shape");
   if (B == 0) return TGP_OK;
-  TGP_REQUIRE(raw && gram && den && out && (N == 0 || (deg && q)), TGP_ERR_INVALID,
+  TGP_REQUIRE(raw && gram && den && out && (N == 0 || deg), TGP_ERR_INVALID,
               "tgp_mincut_terms_fused_f32: null pointer");
   TGP_REQUIRE(B < (1ll << 31), TGP_ERR_RANGE, "tgp_mincut_terms_fused_f32: too many graphs");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -722,7 +726,7 @@ extern "C" int tgp_dense_pool_train_rhs_f32(const float* g_raw_a, const float* g
   const int kt = static_cast<int>((K + 31) / 32), ft = static_cast<int>((F + 31) / 32);
   const int64_t gw_blocks = gw ? (2 * K * F + 1023) / 1024 : 0;
   tgp::TrainRhsArgs a{g_raw_a, g_raw_b, stats, den, gram, g_la, g_lb, scale, link_loss, link_scale, eps, g_x, gx_bcast,
-                      static_cast<int>(K), static_cast<int>(F), mode, kt, ft, symmetric ? 1 : 0, rcat, c1, W, gw};
+                      static_cast<int>(K), static_cast<int>(F), mode, kt, ft, symmetric & 3, rcat, c1, W, gw};
   hipLaunchKernelGGL(train_rhs_kernel, dim3(static_cast<unsigned>(kt * kt + ft * kt + gw_blocks), static_cast<unsigned>(B)),
                      dim3(256), 0, static_cast<hipStream_t>(stream_), a);
   return check_launch("tgp_dense_pool_train_rhs_f32");

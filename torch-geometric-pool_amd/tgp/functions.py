@@ -1048,7 +1048,10 @@ class _PoolUnbatchedFn(torch.autograd.Function):
     list; the edge weights get no gradient here (callers check)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, s_given, ei, ew, row_ptr, ptr, batch, max_nodes, flags, mode, scales, sw2, sym):
+    def forward(ctx, x, weight, bias, s_given, ei, ew, row_ptr, ptr, batch, max_nodes, flags, mode, scales, sw2, sym,
+                transposed=False):
+        # transposed: the pooled adjacency is S^T A^T S (what the BATCHED poolers compute from a sparse input with
+        # adj_transpose=True, src.py:442-443) = the transpose of S^T (A S); MinCut's degrees are then the in-degrees
         from . import _native as N
         ctx.set_materialize_grads(False)
         xd = N.f32c(x.detach())
@@ -1060,13 +1063,19 @@ class _PoolUnbatchedFn(torch.autograd.Function):
         B = ptr.numel() - 1
         t = K.spmm_csr(row_ptr, ei, ew, n, s)
         raw, x_pool, gram = K.segment_gemm_tn3(s, [t, xd, s], ptr, max_nodes)
+        if transposed:
+            raw = raw.transpose(1, 2).contiguous()
         adj_pool = K.postprocess_dense(raw, flags)
         empty = s.new_empty(0)
         la, lb = s.new_empty(0), s.new_empty(0)
         deg = den = lossv = stats = None
         if mode == 1:
-            deg, q = K.edge_row_stats(row_ptr, ew, s)
-            den, terms, stats = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr)
+            deg, q = K.edge_row_stats(row_ptr, ew, s)  # out-degrees and |S_i|^2
+            if transposed:  # den = sum_i indeg_i q_i = sum_i (A q)_i: one SpMV over the same row-sorted list
+                aq = K.spmm_csr(row_ptr, ei, ew, n, q.view(n, 1)).view(n)
+                den, terms, stats = K.mincut_terms_fused(raw, gram, aq, None, ptr=ptr)
+            else:
+                den, terms, stats = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr)
             both = terms.mean(dim=1)
             la, lb = both[0], both[1]
         elif mode == 2:
@@ -1076,6 +1085,7 @@ class _PoolUnbatchedFn(torch.autograd.Function):
         ctx.save_for_backward(s, t, xd, empty if weight is None else weight, raw, ei, row_ptr, ptr, *keep)
         ctx.flags, ctx.mode, ctx.scales, ctx.selector, ctx.max_nodes = flags, mode, scales, selector, max_nodes
         ctx.has_bias, ctx.sym, ctx.has_w, ctx.has_batch = bias is not None, sym, ew is not None, batch is not None
+        ctx.transposed = transposed
         if mode == 0:
             ctx.mark_non_differentiable(la, lb)
         if selector:
@@ -1097,7 +1107,7 @@ class _PoolUnbatchedFn(torch.autograd.Function):
         dev = s.device
         if mode == 0:
             g_la = g_lb = None
-        nothing = (None,) * 15
+        nothing = (None,) * 16
         if g_s is None and g_xp is None and g_raw is None and g_adj is None and g_la is None and g_lb is None:
             return nothing
         want_gx = ctx.needs_input_grad[0]
@@ -1111,10 +1121,13 @@ class _PoolUnbatchedFn(torch.autograd.Function):
         symmetric = ctx.sym is not None and ctx.sym.get()
         POOL_LARGE_STATS["symmetric" if symmetric else "general"] += 1
         fold_gx = selector and want_gx
+        # the operand buffer's first block holds T = A S.  With raw = S^T A S that is "U" (right-hand side gR^T) and
+        # T' = A^T S is "V" (gR); for the transposed form raw = S^T A^T S the two trade places (flag bit 1).
+        sym_flags = 1 if symmetric else (2 if ctx.transposed else 0)
         rcat, c1, gwcat = K.dense_pool_train_rhs(
             ga, gb, mode, stats if mode == 1 else None, den if mode == 1 else None, gram if mode else None, g_la,
             g_lb if mode == 1 else None, 1.0 / B, lossv[0:1] if mode == 2 else None,
-            ctx.scales[0] if mode == 2 else 0.0, gx_t, gx_bc, symmetric, weight if fold_gx else None, B, Kc, F, dev)
+            ctx.scales[0] if mode == 2 else 0.0, gx_t, gx_bc, sym_flags, weight if fold_gx else None, B, Kc, F, dev)
         pad = K.TRAIN_PAD
         ld = 3 * Kc + F + pad
         c_x, c_one, c_s, c_v = Kc, Kc + F, Kc + F + pad, 2 * Kc + F + pad
@@ -1125,7 +1138,10 @@ class _PoolUnbatchedFn(torch.autograd.Function):
             ident = torch.arange(n, device=dev)
             w1 = ew if ew is not None else torch.ones(ei.size(1), device=dev)
             ei_t, w_t = K.coalesce_edges(ei.flip(0), w1, ident, n, "sum", remove_self_loops=False, eps_filter=False)
-            K.copy_cols2(s, K.spmm_sorted(ei_t, w_t, n, s), acat, c_s, c_v)
+            rp_t = K.csr_offsets(ei_t, n)
+            K.copy_cols2(s, K.spmm_csr(rp_t, ei_t, w_t, n, s), acat, c_s, c_v)
+            if ctx.transposed and mode == 1:  # the in-degrees: row sums of the transposed list
+                deg = K.edge_row_stats(rp_t, w_t, s)[0]
         else:
             K.copy_cols2(s, s.new_empty(n, 0), acat, c_s, c_v)
         kd = c_v if symmetric else ld
@@ -1141,7 +1157,7 @@ class _PoolUnbatchedFn(torch.autograd.Function):
                 gs.addcmul_(rowc.unsqueeze(-1), s)
             if ent_g is not None:
                 gs += K.entropy_bwd(s, ent_g, ctx.scales[1])
-            return (gxd, None, None, gs) + (None,) * 11
+            return (gxd, None, None, gs) + (None,) * 12
         K.softmax_bwd_ex(s, gs, extra=g_s, c1=c1 if mode == 1 else None, deg=deg if mode == 1 else None, ent_g=ent_g,
                          ent_scale=ctx.scales[1] if mode == 2 else 0.0, out=vblock, batch=batch)
         gxd = gw = gbias = None
@@ -1152,15 +1168,15 @@ class _PoolUnbatchedFn(torch.autograd.Function):
         if want_gw or want_gb:
             part = K.segment_gemm_tn_into(acat[:, c_v:], acat[:, c_x:c_x + F + pad], _slab_ptr(n, dev))
             gw, gbias = K.slab_sum_split(part, F, want_gw, want_gb)
-        return (gxd, gw, gbias) + (None,) * 12
+        return (gxd, gw, gbias) + (None,) * 13
 
 
 def pool_unbatched(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], s: Optional[Tensor], ei: Tensor,
                    ew: Optional[Tensor], row_ptr: Tensor, ptr: Tensor, batch: Optional[Tensor], max_nodes: int, flags: int,
-                   mode: int, scales=(0.0, 0.0), sw2=0.0, symmetry=None):
+                   mode: int, scales=(0.0, 0.0), sw2=0.0, symmetry=None, transposed: bool = False):
     """(s, x_pool [B,K,F], raw, adj_pool, LossPair or None): see :class:`_PoolUnbatchedFn`."""
     out = _PoolUnbatchedFn.apply(x, weight, bias, s, ei, ew, row_ptr, ptr, batch, max_nodes, flags, mode, tuple(scales), sw2,
-                                 symmetry)
+                                 symmetry, bool(transposed))
     pair = LossPair((out[4], out[5])) if mode else None
     return (out[0] if s is None else s), out[1], out[2], out[3], pair
 

@@ -1513,13 +1513,14 @@ def cut_rows(adj: Tensor, s: Tensor, graph_sizes: Optional[Tensor] = None) -> Tu
     return deg, q
 
 
-def mincut_terms_fused(raw: Tensor, gram: Tensor, deg: Tensor, q: Tensor,
+def mincut_terms_fused(raw: Tensor, gram: Tensor, deg: Tensor, q: Optional[Tensor],
                        ptr: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
     """(den [B], terms [2,B], stats [B,4]): MinCut's per-graph loss tails with den = sum_i deg_i q_i formed in the same
     launch (utils/losses.py:39-70); stats = (trace(raw), |G|^2, trace(G), |Y|) per graph, the scalars the backward's
     right-hand sides need."""
     dev = N.require_device(raw, gram, deg, q)
-    raw, gram, deg, q = N.f32c(raw), N.f32c(gram), N.f32c(deg), N.f32c(q)
+    raw, gram, deg = N.f32c(raw), N.f32c(gram), N.f32c(deg)
+    q = None if q is None else N.f32c(q)  # (None: deg already carries the factor, den = sum of deg)
     B, Kc, Nn = raw.size(0), raw.size(-1), deg.size(-1)
     den = torch.empty(B, dtype=torch.float32, device=dev)
     out = torch.empty(2, B, dtype=torch.float32, device=dev)
@@ -1563,7 +1564,8 @@ def dense_pool_train_rhs(g_raw_a: Optional[Tensor], g_raw_b: Optional[Tensor], m
                          gx_bcast: bool, symmetric: bool, weight: Optional[Tensor], B: int, Kc: int, F: int, dev):
     """(rcat [B,3K+F+4,K], c1 [B] or None, gw [B,2K,F] or None): the right-hand sides [RU ; RX ; 0 ; RS ; RV] of the
     training step's backward GEMM and, with the selector's ``weight``, [g_x ; W] for gX = [S | dY] [g_x ; W]
-    (see tgp_dense_pool_train_rhs_f32 in include/tgp_hip.h)."""
+    (see tgp_dense_pool_train_rhs_f32 in include/tgp_hip.h).  ``symmetric``: bool, or the flag word (bit 0: A = A^T,
+    bit 1: the RU / RV slots trade places)."""
     rcat = torch.empty(B, 3 * Kc + F + TRAIN_PAD, Kc, dtype=torch.float32, device=dev)
     c1 = torch.empty(B, dtype=torch.float32, device=dev) if mode == 1 else None
     gw = torch.empty(B, 2 * Kc, F, dtype=torch.float32, device=dev) if weight is not None else None
@@ -1571,7 +1573,7 @@ def dense_pool_train_rhs(g_raw_a: Optional[Tensor], g_raw_b: Optional[Tensor], m
     N.check(N.lib().tgp_dense_pool_train_rhs_f32(N.ptr(g_raw_a), N.ptr(g_raw_b), mode, N.ptr(stats), N.ptr(den),
                                                  N.ptr(gram), N.ptr(g_la), N.ptr(g_lb), float(scale), N.ptr(link_loss),
                                                  float(link_scale), losses_eps(), N.ptr(g_x), 1 if gx_bcast else 0,
-                                                 1 if symmetric else 0, N.ptr(w), B, Kc, F, N.ptr(rcat), N.ptr(c1),
+                                                 int(symmetric), N.ptr(w), B, Kc, F, N.ptr(rcat), N.ptr(c1),
                                                  N.ptr(gw), N.stream_ptr(dev)), "tgp_dense_pool_train_rhs_f32")
     return rcat, c1, gw
 

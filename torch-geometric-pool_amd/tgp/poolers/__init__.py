@@ -39,6 +39,10 @@ from ..functions import LossPair
 
 import os as _os
 
+# r6: batched dense poolers on a SPARSE input whose graphs are large and sparse take the un-padded rows route (no [B,N,N]
+# adjacency): TGP_ROWS_ROUTE=0 keeps the densifying route; the density bound is entries / (N x longest graph)
+_ROWS_ROUTE = _os.environ.get("TGP_ROWS_ROUTE", "1") != "0"
+_ROWS_ROUTE_DENSITY = float(_os.environ.get("TGP_ROWS_ROUTE_DENSITY", "0.03"))
 # A/B switch (read once): 0 keeps the selector and the pooling as two autograd nodes in training
 _FOLD_TRAINING = _os.environ.get("TGP_FOLD_TRAINING", "1") != "0"
 # ... 0 densifies sparse inputs (to_dense_batch + to_dense_adj) in front of the fused inference call as before
@@ -431,19 +435,28 @@ class _DenseMLPPooling(DenseSRCPooling):
             return None
         return K.AdjSymmetry(edge_index, edge_weight, dense_adj, batch, info.ptr)
 
-    def _unbatched_fused(self, x, edge_index, edge_weight, batch):
-        """Unbatched mode, r6: Select, Reduce, Connect and both auxiliary losses from ONE S^T [A S | X | S] product
+    def _unbatched_fused(self, x, edge_index, edge_weight, batch, batched_out: bool = False):
+        """Reduce, Connect and both auxiliary losses on the UN-padded rows, r6: ONE S^T [A S | X | S] product
         (tgp_segment_gemm_tn3_f32) behind the CSR SpMM -- the mincut numerator is trace(S_g^T (A S)_g), the link
         residual sum_e w_e^2 - 2 sum_g trace(raw_g) + sum_g |S_g^T S_g|^2 -- instead of per-edge dot products and
         index_add scatters (reference utils/losses.py:73-127, 204-240, 661-708; dense_conn.py:140-208;
-        base_reduce.py:170-182): 40-45 launches -> ~10 per forward.  Under autograd the same forward is ONE autograd
-        node with the backward of the padded form on the un-padded rows (functions._PoolUnbatchedFn).  Returns
-        (SelectOutput, x_pool [B,K,F], adj_pool [B,K,K], pooled batch vector, losses) or None when the case is not this
-        one (sparse_output, host tensors, edge weights that require a gradient, ...)."""
+        base_reduce.py:170-182): 40-45 launches -> ~10 per forward in the unbatched mode.  Under autograd the same
+        forward is ONE autograd node (functions._PoolUnbatchedFn).
+
+        ``batched_out`` (r6, late): the BATCHED poolers take the same route for a sparse input whose graphs are too
+        large for the one-launch kernels and sparse enough (E <= TGP_ROWS_ROUTE_DENSITY x N x longest graph, default 3 %):
+        no [B,N,N] adjacency is ever built (reference src.py:374-452 densifies first; at the C2 shape that is 134 MB
+        written and read three times per training step for 0.33 M entries).  The results are those of the batched mode:
+        S^T A^T S when adj_transpose (= the transpose of S^T (A S); MinCut's degrees are then in-degrees, sum_i (A q)_i),
+        S handed out padded [B,Nmax,K] with its mask, losses normalised as the batched forms do.
+
+        Returns (SelectOutput, x_pool [B,K,F], adj_pool [B,K,K], pooled batch vector, losses); ``(SelectOutput,)`` when
+        only Select could be done here (unbatched mode); None when the case is not this one."""
         from .. import kernels as K
         from .. import functions as Fn
         c, sel = self.connector, self.selector
-        if (self.sparse_output or type(c) is not DenseConnect or type(self.reducer) is not BaseReduce
+        if (type(c) is not DenseConnect or type(self.reducer) is not BaseReduce
+                or (self.sparse_output and not batched_out)
                 or not (isinstance(x, Tensor) and isinstance(edge_index, Tensor))
                 or x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32
                 or edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.long
@@ -461,31 +474,45 @@ class _DenseMLPPooling(DenseSRCPooling):
             info = batch_info(batch)
             if not info.is_sorted:
                 return None
-            ptr, max_nodes = info.ptr, info.max_nodes
+            ptr, max_nodes, nb = info.ptr, info.max_nodes, info.num_graphs
         else:
-            ptr, max_nodes = Fn._whole_range(n, x.device), n
-        # the selector: folded into the training node when it is a single Linear, else run in front (its S handed over)
+            ptr, max_nodes, nb = Fn._whole_range(n, x.device), n, 1
         lins = getattr(getattr(sel, "mlp", None), "lins", None)
         single = type(sel) is MLPSelect and lins is not None and len(lins) == 1 and lins[0].weight.dtype == torch.float32
+        if batched_out:  # every check comes BEFORE Select here: a bail-out must leave the batched flow untouched
+            if (not _ROWS_ROUTE or self.cache_preprocessing or type(sel) is not MLPSelect or lins is None
+                    or lins[-1].weight.dtype != torch.float32
+                    or edge_index.size(1) > _ROWS_ROUTE_DENSITY * float(n) * float(max_nodes)
+                    or K.dense_pool_is_small(nb, max_nodes, lins[-1].weight.size(0), x.size(1))):
+                return None
+            k_out = lins[-1].weight.size(0)
+            will_train = grad and (x.requires_grad or any(p.requires_grad for p in sel.parameters()))
+            if will_train and (not _FOLD_TRAINING or c.edge_weight_norm or k_out > 4096):
+                return None
+        # the selector: folded into the training node when it is a single Linear, else run in front (its S handed over)
         so = weight = bias = None
         if not (grad and single and _FOLD_TRAINING):
-            so = self.select(x=x, batch=batch)
+            so = self.select(x=x, batch=batch) if not batched_out else self.select(x=x)
             s = so.s
+            if batched_out and isinstance(s, Tensor) and s.dim() == 3 and s.size(0) == 1:
+                s = s[0]  # (MLPSelect in its batched representation treats [N,F] as one padded graph)
             if not (isinstance(s, Tensor) and s.dim() == 2 and s.dtype == torch.float32 and s.size(0) == n):
-                return (so,)  # (the caller goes on with this SelectOutput on the operator path)
+                return None if batched_out else (so,)  # (the caller goes on with this SelectOutput on the operator path)
             training = grad and (s.requires_grad or x.requires_grad)
         else:
             weight, bias = lins[0].weight, lins[0].bias
             s = None
             training = x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)
             if not training:
-                so = self.select(x=x, batch=batch)
-                s = so.s
+                so = self.select(x=x, batch=batch) if not batched_out else self.select(x=x)
+                s = so.s[0] if (batched_out and so.s.dim() == 3) else so.s
         k = s.size(1) if s is not None else weight.size(0)
         if training and (not _FOLD_TRAINING or c.edge_weight_norm or k > 4096):
+            if batched_out:
+                return None
             if so is None:
                 so = self.select(x=x, batch=batch)
-            return None if so is None else (so,)  # (the caller goes on with this SelectOutput on the operator path)
+            return (so,)
         w_in = None if edge_weight is None else edge_weight.reshape(-1)
         ones = w_in is None
         # sorted + duplicate-summed A (what the reference's per-graph `.coalesce()` does), T = A S, then one product grid
@@ -493,33 +520,57 @@ class _DenseMLPPooling(DenseSRCPooling):
         unit = ones and ei is edge_index  # (nothing merged: the weights are still all one)
         w_used = None if unit else w
         row_ptr = K.csr_offsets(ei, n)
-        flags = K.dense_flags(c.remove_self_loops, c.degree_norm, False, c.edge_weight_norm)
+        transposed = bool(batched_out and self.adj_transpose)
+        flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose if batched_out else False,
+                              c.edge_weight_norm)
         mincut = self._loss_needs_raw
         sw2, scales = 0.0, (0.0, 0.0)
         if not mincut:  # DiffPool: sum_e w_e^2 runs over the list as given (duplicates not merged, losses.py:680-690)
-            sw2 = float(edge_index.size(1)) if ones else torch.dot(w_in.detach(), w_in.detach())
+            # (batched form, losses.py:644-652: the dense A has the duplicates summed -- the same list after coalescing)
+            if batched_out and not unit:
+                sw2 = torch.dot(w, w)
+            else:
+                sw2 = float(edge_index.size(1)) if ones else torch.dot(w_in.detach(), w_in.detach())
             link_scale = float(self.link_loss_coeff)
             if self.normalize_loss is True:
-                denom = sum(v * v for v in info.sizes_host) if info is not None else n * n
+                if batched_out:  # adj.numel() of the padded batch (losses.py:651)
+                    denom = nb * max_nodes * max_nodes
+                else:
+                    denom = sum(v * v for v in info.sizes_host) if info is not None else n * n
                 link_scale = link_scale / max(denom, 1)
             scales = (link_scale, float(self.ent_loss_coeff) / n)
         if training:
             sym = K.AdjSymmetry.of_edge_list(edge_index, edge_weight, ei, w_used, row_ptr, n)
             s_out, x_pool, raw, adj_pool, pair = Fn.pool_unbatched(
-                x, weight, bias, s, ei, w_used, row_ptr, ptr, batch, max_nodes, flags, 1 if mincut else 2, scales, sw2, sym)
-            if so is None:
-                so = SelectOutput(s=s_out, s_inv_op=sel.s_inv_op, batch=batch)
+                x, weight, bias, s, ei, w_used, row_ptr, ptr, batch, max_nodes, flags, 1 if mincut else 2, scales, sw2, sym,
+                transposed)
+            s_flat = s_out
             both = pair
         else:
             t = K.spmm_csr(row_ptr, ei, w_used, n, s)
             raw, x_pool, gram = K.segment_gemm_tn3(s, [t, x, s], ptr, max_nodes)
+            if transposed:
+                raw = raw.transpose(1, 2).contiguous()
             if mincut:
                 deg, q = K.edge_row_stats(row_ptr, w_used, s)
-                _, terms, _ = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr)
+                if transposed:  # in-degrees: sum_i indeg_i q_i = sum_i (A q)_i
+                    aq = K.spmm_csr(row_ptr, ei, w_used, n, q.view(n, 1)).view(n)
+                    _, terms, _ = K.mincut_terms_fused(raw, gram, aq, None, ptr=ptr)
+                else:
+                    _, terms, _ = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr)
                 both = terms.mean(dim=1)
             else:
                 both = K.diffpool_unbatched_tail(raw, gram, s, sw2, scales[0], scales[1])
             adj_pool = K.postprocess_dense(raw, flags)
+            s_flat = s
+        if batched_out:  # S as the batched mode hands it out: padded [B,Nmax,K] + the node mask (differentiable view of S)
+            from ..src import to_dense_batch
+            s_pad, mask = to_dense_batch(s_flat, batch, max_nodes, nb)
+            so = SelectOutput(s=s_pad, s_inv_op=sel.s_inv_op, in_mask=mask)
+            if info is not None:
+                so._graph_sizes = info.sizes
+        elif so is None:
+            so = SelectOutput(s=s_flat, s_inv_op=sel.s_inv_op, batch=batch)
         if mincut:
             loss = {"cut_loss": both[0] if self.cut_loss_coeff == 1 else both[0] * self.cut_loss_coeff,
                     "ortho_loss": both[1] if self.ortho_loss_coeff == 1 else both[1] * self.ortho_loss_coeff}
@@ -554,6 +605,15 @@ class _DenseMLPPooling(DenseSRCPooling):
                     so, fused, batch_pool, dense_adj = sparse
                     x_pool, raw, adj_pool, terms, diff = fused
                     loss = self._loss_from_fused(dense_adj if dense_adj is not None else adj, so, None, raw, terms, diff)
+                    if self.sparse_output:
+                        x_pool, ei, ew, batch_pool = self._finalize_sparse_output(
+                            x_pool=x_pool, adj_pool=adj_pool, batch=batch, batch_pooled=batch_pool, so=so)
+                        return PoolingOutput(x=x_pool, edge_index=ei, edge_weight=ew, batch=batch_pool, so=so,
+                                             loss=loss)
+                    return PoolingOutput(x=x_pool, edge_index=adj_pool, so=so, loss=loss)
+                rows = self._unbatched_fused(x, adj, edge_weight, batch, batched_out=True)
+                if rows is not None:  # large sparse graphs: the un-padded rows route, no dense adjacency (r6)
+                    so, x_pool, adj_pool, batch_pool, loss = rows
                     if self.sparse_output:
                         x_pool, ei, ew, batch_pool = self._finalize_sparse_output(
                             x_pool=x_pool, adj_pool=adj_pool, batch=batch, batch_pooled=batch_pool, so=so)
