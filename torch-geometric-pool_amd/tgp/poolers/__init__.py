@@ -516,7 +516,10 @@ class _DenseMLPPooling(DenseSRCPooling):
         w_in = None if edge_weight is None else edge_weight.reshape(-1)
         ones = w_in is None
         # sorted + duplicate-summed A (what the reference's per-graph `.coalesce()` does), T = A S, then one product grid
-        ei, w = Fn.coalesce_sum(edge_index, torch.ones(edge_index.size(1), device=x.device) if ones else w_in.detach(), n)
+        if ones and K.coalesced_memo(edge_index, n):  # (known to be coalesced: no vector of ones is made for the check)
+            ei, w = edge_index, None
+        else:
+            ei, w = Fn.coalesce_sum(edge_index, torch.ones(edge_index.size(1), device=x.device) if ones else w_in.detach(), n)
         unit = ones and ei is edge_index  # (nothing merged: the weights are still all one)
         w_used = None if unit else w
         row_ptr = K.csr_offsets(ei, n)
@@ -564,8 +567,12 @@ class _DenseMLPPooling(DenseSRCPooling):
             adj_pool = K.postprocess_dense(raw, flags)
             s_flat = s
         if batched_out:  # S as the batched mode hands it out: padded [B,Nmax,K] + the node mask (differentiable view of S)
-            from ..src import to_dense_batch
-            s_pad, mask = to_dense_batch(s_flat, batch, max_nodes, nb)
+            if n == nb * max_nodes:  # graphs of one size: the padded form is a view, the mask a constant
+                s_pad = s_flat.view(nb, max_nodes, k)
+                mask = torch.ones(nb, max_nodes, dtype=torch.bool, device=x.device)  # (a tensor of the caller's own)
+            else:
+                from ..src import to_dense_batch
+                s_pad, mask = to_dense_batch(s_flat, batch, max_nodes, nb)
             so = SelectOutput(s=s_pad, s_inv_op=sel.s_inv_op, in_mask=mask)
             if info is not None:
                 so._graph_sizes = info.sizes
