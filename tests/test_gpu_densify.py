@@ -1,0 +1,325 @@
+"""Sparse -> padded dense preprocessing and batch facts (csrc/densify.hip; reference src.py:374-452) and the dense poolers straight from the un-padded batch.
+
+Regrouped by operator in round 6 from the per-round files test_gpu_round2..5.py; the test bodies are unchanged."""
+import math
+import warnings
+import pytest
+import torch
+import os
+import sys
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------ batch facts in one read-back
+def _batch_info_torch(batch):
+    sizes = torch.bincount(batch)
+    return dict(num_graphs=sizes.numel(), sizes=sizes.tolist(), is_sorted=bool((batch[1:] >= batch[:-1]).all()),
+                max_nodes=int(sizes.max()), distinct=int((sizes > 0).sum()))
+
+
+def test_to_dense_adj_edge_weight_gradient_is_native(dev, monkeypatch):
+    """VERDICT r1 missing #5: the gradient of the edge weights through the dense poolers' densification
+    (src.py:434-443) comes from the native gather kernel, not from a torch index_add_ dual path; duplicates, both
+    orientations and a max_num_nodes cut are covered; DiffPool trains its input edge weights end to end."""
+    from tgp import kernels as K
+    from tgp.src import to_dense_adj
+    g = torch.Generator().manual_seed(4)
+    sizes = [7, 12, 5]
+    batch = torch.cat([torch.full((m,), i) for i, m in enumerate(sizes)])
+    off = torch.tensor([0, 7, 19])
+    eis = []
+    for i, m in enumerate(sizes):
+        eis.append(torch.randint(0, m, (2, 30), generator=g) + off[i])
+    ei = torch.cat(eis, 1)
+    w = torch.rand(ei.size(1), generator=g)
+    calls = []
+    real = K.from_dense_adj
+    monkeypatch.setattr(K, "from_dense_adj", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    for transposed, nmax in ((False, None), (True, None), (True, 9)):
+        wd = w.to(dev).requires_grad_(True)
+        adj = to_dense_adj(ei.to(dev), batch.to(dev), wd, max_num_nodes=nmax, transposed=transposed)
+        n_max = nmax or max(sizes)
+        wr = w.clone().requires_grad_(True)
+        b = batch[ei[0]]
+        r, c = ei[0] - off[b], ei[1] - off[b]
+        ok = (r < n_max) & (c < n_max)
+        ref = torch.zeros(3, n_max, n_max).index_put((b[ok], r[ok], c[ok]), wr[ok], accumulate=True)
+        ref = ref.transpose(1, 2) if transposed else ref
+        torch.testing.assert_close(adj.detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-6)
+        coef = torch.randn(3, n_max, n_max, generator=g)
+        (adj * coef.to(dev)).sum().backward()
+        (ref * coef).sum().backward()
+        torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=1e-6, atol=1e-6)
+    assert len(calls) == 3
+    from tgp.poolers import get_pooler
+    pool = get_pooler("diff", in_channels=6, k=4).to(dev)
+    x = torch.randn(24, 6, generator=g).to(dev)
+    wd = w.to(dev).requires_grad_(True)
+    out = pool(x=x, adj=ei.to(dev), edge_weight=wd, batch=batch.to(dev))
+    (out.edge_index.sum() + sum(out.loss.values())).backward()
+    assert wd.grad is not None and float(wd.grad.abs().sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transposed", [False, True])
+def test_densify_together_equals_the_separate_functions(dev, transposed):
+    """to_dense_batch zero-filling the adjacency buffer in its own launch + to_dense_adj scattering into it (what the
+    dense poolers' preprocessing runs) against the two stand-alone functions: same x, mask, adjacency (duplicates
+    summed), gradients of x and of the edge weights."""
+    from tgp.connect import DenseConnect
+    from tgp.reduce import BaseReduce
+    from tgp.src import DenseSRCPooling, to_dense_adj, to_dense_batch
+    g = torch.Generator().manual_seed(6)
+    sizes = torch.tensor([5, 1, 17, 3, 9])
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(5), sizes).to(dev)
+    start = (torch.cumsum(sizes, 0) - sizes).to(dev)
+    src = torch.arange(n, device=dev).repeat_interleave(3)
+    dst = start[batch[src]] + (torch.rand(src.numel(), device=dev) * sizes.to(dev)[batch[src]]).long()
+    ei = torch.stack([src, dst])                       # duplicates and self loops included
+    ew = torch.rand(ei.size(1), generator=g).to(dev).requires_grad_(True)
+    x = torch.randn(n, 7, generator=g).to(dev).requires_grad_(True)
+    pool = DenseSRCPooling(reducer=BaseReduce(), connector=DenseConnect(), adj_transpose=transposed)
+    xd, adj, mask = pool.preprocessing(x=x, edge_index=ei, edge_weight=ew, batch=batch)
+    wx, wa = torch.randn_like(xd), torch.randn_like(adj)
+    ((xd * wx).sum() + (adj * wa).sum()).backward()
+    gx, gw = x.grad.clone(), ew.grad.clone()
+    x.grad = None
+    ew.grad = None
+    adj2 = to_dense_adj(ei, batch, ew, None, None, transposed=transposed)
+    xd2, mask2 = to_dense_batch(x, batch, None, None)
+    ((xd2 * wx).sum() + (adj2 * wa).sum()).backward()
+    assert torch.equal(xd, xd2) and torch.equal(mask, mask2)
+    torch.testing.assert_close(adj, adj2, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(gx, x.grad, rtol=0, atol=0)
+    torch.testing.assert_close(gw, ew.grad, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["sorted", "unsorted", "gaps", "one", "single_node", "long_runs", "big"])
+def test_batch_facts_kernel_equals_the_torch_ops(dev, case):
+    """utils.ops.batch_info through tgp_batch_facts_i64 (one read-back) = bincount / comparison / max on the same vector;
+    ids beyond N or negative ids decline to the torch route."""
+    from tgp.utils.ops import batch_info
+    g = torch.Generator().manual_seed(3)
+    if case == "sorted":
+        batch = torch.repeat_interleave(torch.arange(300), torch.randint(1, 70, (300,), generator=g))
+    elif case == "unsorted":
+        batch = torch.randint(0, 50, (5000,), generator=g)
+    elif case == "gaps":      # empty graphs in the middle and a sorted vector
+        batch = torch.sort(torch.randint(0, 40, (200,), generator=g) * 3).values
+    elif case == "one":
+        batch = torch.zeros(1000, dtype=torch.long)
+    elif case == "single_node":
+        batch = torch.tensor([0])
+    elif case == "long_runs":  # runs longer than a wave and crossing workgroup boundaries
+        batch = torch.repeat_interleave(torch.arange(7), torch.tensor([1, 63, 64, 65, 700, 256, 1]))
+    else:
+        batch = torch.repeat_interleave(torch.arange(20000), torch.randint(20, 61, (20000,), generator=g))
+    want = _batch_info_torch(batch)
+    info = batch_info(batch.to(dev))
+    assert info.num_graphs == want["num_graphs"] and info.is_sorted == want["is_sorted"]
+    assert info.max_nodes == want["max_nodes"] and info.distinct == want["distinct"]
+    assert info.sizes.tolist() == want["sizes"] and info.sizes_host == want["sizes"]
+    assert info.ptr.tolist() == [0] + torch.cumsum(torch.tensor(want["sizes"]), 0).tolist()
+
+
+def test_batch_facts_kernel_declines_ids_it_cannot_count(dev):
+    from tgp.utils.ops import batch_info
+    info = batch_info(torch.tensor([0, 7], device=dev))     # more graph ids than nodes: legal, torch route
+    assert info.num_graphs == 8 and info.sizes.tolist() == [1, 0, 0, 0, 0, 0, 0, 1] and info.distinct == 2
+    with pytest.raises(RuntimeError):
+        batch_info(torch.tensor([0, -1], device=dev))       # (bincount's own error, as before)
+
+
+# ------------------------------------------------------------------------------------ fresh batches (r5)
+def test_one_launch_batch_facts_equal_the_general_route(dev, monkeypatch):
+    """tgp_batch_facts_sorted_i64 (one launch, pinned-word hand-over) against the two-kernel route and plain torch:
+    CSR offsets, sizes, graph count, longest graph, non-empty graphs, TopkSelect's plan -- sorted vectors with empty graph
+    ids, one graph, one node per graph; an unsorted vector / ids out of range / a long run of empty ids fall back."""
+    import tgp.utils.ops as ops
+    import tgp_oracle as O
+    g = torch.Generator().manual_seed(2)
+    cases = {
+        "proteins": torch.repeat_interleave(torch.arange(2048), torch.randint(20, 61, (2048,), generator=g)),
+        "with_empty_ids": torch.repeat_interleave(torch.tensor([0, 1, 4, 5, 9]), torch.tensor([3, 1, 70, 2, 300])),
+        "one_graph": torch.zeros(5000, dtype=torch.long),
+        "starts_late": torch.full((77,), 3),
+        "node_per_graph": torch.arange(3000),
+        "single_node": torch.zeros(1, dtype=torch.long),
+    }
+    for name, b in cases.items():
+        bd = b.to(dev)
+        ops._BATCH_INFO.clear()
+        monkeypatch.setattr(ops, "_BATCH_FACTS_ONE_LAUNCH", True)
+        a = ops.batch_info(bd, topk_ratio=0.5)
+        assert a.is_sorted and a.memo.get(("topk", 0.5)) is not None, name
+        ops._BATCH_INFO.clear()
+        monkeypatch.setattr(ops, "_BATCH_FACTS_ONE_LAUNCH", False)
+        r = ops.batch_info(bd, topk_ratio=0.5)
+        sizes = torch.bincount(b)
+        assert a.num_graphs == r.num_graphs == sizes.numel(), name
+        assert torch.equal(a.sizes.cpu(), sizes) and torch.equal(r.sizes.cpu(), sizes), name
+        ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+        assert torch.equal(a.ptr.cpu(), ptr) and torch.equal(r.ptr.cpu(), ptr), name
+        assert a.max_nodes == r.max_nodes == int(sizes.max()) and a.distinct == r.distinct == int((sizes > 0).sum()), name
+        total, k, koff = a.memo[("topk", 0.5)]
+        want_k = torch.ceil(torch.tensor(0.5, dtype=torch.float32) * sizes.float()).long()
+        assert torch.equal(k.cpu(), want_k) and total == int(want_k.sum()), name
+        assert torch.equal(koff.cpu(), torch.cat([torch.zeros(1, dtype=torch.long), want_k.cumsum(0)])), name
+    monkeypatch.setattr(ops, "_BATCH_FACTS_ONE_LAUNCH", True)
+    for name, b in {"unsorted": torch.tensor([0, 0, 2, 1, 2]), "long_gap": torch.tensor([0] * 10 + [500] * 10)}.items():
+        ops._BATCH_INFO.clear()
+        info = ops.batch_info(b.to(dev))
+        sizes = torch.bincount(b)
+        assert torch.equal(info.sizes.cpu(), sizes), name      # the general route took it
+        assert info.is_sorted == (name != "unsorted")
+    # back-to-back calls on one stream: the ticket / flag words are left clean by every call, also by a refused one
+    ops._BATCH_INFO.clear()
+    for _ in range(3):
+        for b in (cases["proteins"], torch.tensor([3, 2, 1]), cases["with_empty_ids"]):
+            ops._BATCH_INFO.clear()
+            info = ops.batch_info(b.to(dev))
+            assert torch.equal(info.sizes.cpu(), torch.bincount(b))
+
+
+def test_to_dense_adj_with_multi_channel_edge_attributes(dev):
+    """PyG to_dense_adj with edge_attr [E, C] (reference src.py:434): native scatter-add on the device (r5; a torch
+    index_add_ form before), against the torch form on the host, both orientations, duplicates summed, max_num_nodes."""
+    from tgp.src import to_dense_adj
+    g = torch.Generator().manual_seed(8)
+    sizes = torch.tensor([5, 9, 1, 7])
+    batch = torch.repeat_interleave(torch.arange(4), sizes)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), sizes.cumsum(0)])
+    rows, cols = [], []
+    for b in range(4):
+        m = int(sizes[b])
+        r = torch.randint(0, m, (3 * m,), generator=g) + ptr[b]
+        c = torch.randint(0, m, (3 * m,), generator=g) + ptr[b]
+        rows.append(r); cols.append(c)
+    ei = torch.stack([torch.cat(rows), torch.cat(cols)])       # duplicates included
+    attr = torch.randn(ei.size(1), 3, generator=g)
+    for transposed in (False, True):
+        for nmax in (None, 6):
+            want = to_dense_adj(ei, batch, attr, max_num_nodes=nmax, transposed=transposed)          # host: torch form
+            got = to_dense_adj(ei.to(dev), batch.to(dev), attr.to(dev), max_num_nodes=nmax, transposed=transposed)
+            assert got.shape == want.shape
+            torch.testing.assert_close(got.cpu(), want.contiguous(), rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ r5: the dense poolers' forward straight from sparse inputs
+@pytest.mark.gpu
+def test_diffpool_inference_from_the_unpadded_batch_equals_the_densified_one(dev, monkeypatch):
+    """get_pooler('diff') in inference on sparse inputs takes the same launch; its two losses (the link loss needs the
+    dense adjacency, utils/losses.py:644-658) are computed from the adjacency the launch leaves as a side output."""
+    from tgp import kernels as K_
+    from tgp import poolers as P
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(41)
+    B = 72
+    sizes = torch.randint(6, 61, (B,), generator=g)
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(B), sizes)
+    start = torch.cumsum(sizes, 0) - sizes
+    row = torch.repeat_interleave(torch.arange(n), torch.randint(1, 6, (n,), generator=g))
+    col = start[batch[row]] + (torch.rand(row.numel(), generator=g) * sizes[batch[row]]).long()
+    ei, bd, x = torch.stack([row, col]).to(dev), batch.to(dev), torch.randn(n, 32, generator=g).to(dev)
+    for at in (True, False):
+        torch.manual_seed(0)
+        pooler = get_pooler("diff", in_channels=32, k=20, adj_transpose=at).to(dev).eval()
+        with torch.no_grad():
+            monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", True)
+            new = pooler(x=x, adj=ei, batch=bd)
+            monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", False)
+            old = pooler(x=x, adj=ei, batch=bd)
+        torch.testing.assert_close(new.x, old.x, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(new.edge_index, old.edge_index, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(new.so.s, old.so.s, rtol=1e-6, atol=1e-7)
+        assert set(new.loss) == set(old.loss) == {"link_loss", "entropy_loss"}
+        for k in old.loss:
+            torch.testing.assert_close(new.loss[k], old.loss[k], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("adj_transpose", [True, False])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_mincut_forward_from_the_unpadded_batch_equals_the_densified_one(dev, adj_transpose, weighted, monkeypatch):
+    """get_pooler('mincut') in inference on a sorted batch of small graphs given as PyG hands it over: ONE launch builds
+    every graph's adjacency tile in LDS from its edges (tgp_dense_pool_select_sparse_f32) -- no to_dense_batch, no
+    to_dense_adj.  Outputs, losses, S, mask and the pooled batch vector equal the densified path's (src.py:434-450 in
+    front of the same fused call): duplicates summed, self loops, a graph without edges, a graph of more than 512
+    entries, a column that leaves its row's graph.  An unsorted list keeps the densified path."""
+    from tgp import kernels as K_
+    from tgp import poolers as P
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(23)
+    B = 80
+    sizes = torch.randint(5, 61, (B,), generator=g)
+    sizes[3] = 60
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(B), sizes)
+    start = torch.cumsum(sizes, 0) - sizes
+    deg = torch.randint(0, 7, (n,), generator=g)
+    deg[batch == 5] = 0                                  # a graph without edges
+    deg[batch == 3] = 12                                 # 60 nodes x 12 = 720 entries: the tail loop behind 512
+    row = torch.repeat_interleave(torch.arange(n), deg)
+    col = start[batch[row]] + (torch.rand(row.numel(), generator=g) * sizes[batch[row]]).long()
+    col[::7] = row[::7]                                  # self loops
+    col[1::13] = col[0::13][: col[1::13].numel()]        # (some duplicates)
+    cross = (batch[row] == 10).nonzero().flatten()[:2]
+    col[cross] = start[11] + 1                           # a column in the next graph
+    ei = torch.stack([row, col]).to(dev)
+    ew = (torch.rand(row.numel(), generator=g) + 0.1).to(dev) if weighted else None
+    x = torch.randn(n, 32, generator=g).to(dev)
+    bd = batch.to(dev)
+    torch.manual_seed(0)
+    calls = []
+    real = K_.dense_pool_select_sparse
+    monkeypatch.setattr(K_, "dense_pool_select_sparse", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    for sparse_output in (False, True):
+        pooler = get_pooler("mincut", in_channels=32, k=20, adj_transpose=adj_transpose,
+                            sparse_output=sparse_output).to(dev).eval()
+        calls.clear()
+        with torch.no_grad():
+            monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", True)
+            new = pooler(x=x, adj=ei, edge_weight=ew, batch=bd)
+            assert calls == [1]
+            monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", False)
+            old = pooler(x=x, adj=ei, edge_weight=ew, batch=bd)
+            assert calls == [1]
+        torch.testing.assert_close(new.x, old.x, rtol=1e-6, atol=1e-6)
+        if sparse_output:
+            assert torch.equal(new.edge_index, old.edge_index) and torch.equal(new.batch, old.batch)
+            torch.testing.assert_close(new.edge_weight, old.edge_weight, rtol=1e-5, atol=1e-6)
+        else:
+            torch.testing.assert_close(new.edge_index, old.edge_index, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(new.so.s, old.so.s, rtol=1e-6, atol=1e-7)
+        assert torch.equal(new.so.in_mask, old.so.in_mask)
+        for k in old.loss:
+            torch.testing.assert_close(new.loss[k], old.loss[k], rtol=1e-5, atol=1e-6)
+    # rows not sorted: the densified path takes the call, same result
+    perm = torch.randperm(ei.size(1), generator=g).to(dev)
+    ei2, ew2 = ei[:, perm].contiguous(), (None if ew is None else ew[perm].contiguous())
+    calls.clear()
+    with torch.no_grad():
+        monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", True)
+        shuffled = pooler(x=x, adj=ei2, edge_weight=ew2, batch=bd)
+        # (a NEW list is tried optimistically -- the kernel runs on clamped ranges while the facts kernel's verdict
+        #  travels -- and its outputs are dropped; the verdict is remembered: the second call does not try)
+        assert calls == [1] and K_._rows_sorted_memo(ei2) is False
+        again = pooler(x=x, adj=ei2, edge_weight=ew2, batch=bd)
+        assert calls == [1]
+    torch.testing.assert_close(shuffled.x, old.x, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(again.x, old.x, rtol=1e-5, atol=1e-5)
+    # a NEW sorted list: ranges and verdict from the one facts launch, no lower-bounds launch, remembered afterwards
+    ei3 = ei.clone()
+    calls.clear()
+    with torch.no_grad():
+        fresh = pooler(x=x, adj=ei3, edge_weight=ew, batch=bd.clone())
+    assert calls == [1] and K_._rows_sorted_memo(ei3) is True
+    torch.testing.assert_close(fresh.x, old.x, rtol=1e-6, atol=1e-6)
