@@ -448,9 +448,12 @@ class PoolerForward(Workload):
         B, N, K, F = self.B, self.N, self.K, self.F
         ms = event_time_ms(self.step, 50, dev)
         if self.which == "e2e_diff_c2":
-            # Select 2MFK + Reduce/Connect 2BN^2K + 2BKN(K+F) + link-prediction residual 2BN^2K
-            flops = 2.0 * B * N * F * K + 4.0 * B * N * N * K + 2.0 * B * K * N * (K + F)
-            r = roof_mfma("whole forward (all kernels of the call, eager)", flops, ms)
+            # r6: a sparse input of this size takes the un-padded rows route -- no [B,N,N] adjacency, no N^2 K product
+            # (r5 priced this line against 2BN^2K x 2 flops that are no longer executed): what the call has to move is
+            # the edge list + x in, S and the pooled outputs out
+            alg = self.ei.size(1) * 16.0 + self.nodes * F * 4.0 + 4.0 * self.nodes * K + B * N + 4.0 * B * (K * K + K * F)
+            r = roof_hbm("whole forward (all kernels of the call, eager; rows route: no dense adjacency)", alg, ms)
+            r["bytes_counted"] = "edge list + x read, S + mask + pooled outputs written"
         else:
             # r5: what the call has to move now that nothing is densified -- edge list + x in, S [B,N,K] + node mask out,
             # pooled outputs (the r4 line also counted a dense A and a padded X written and read once: 2.7 x these bytes)
@@ -525,10 +528,14 @@ class PoolerTrainStep(Workload):
         if self.scale == "c2":
             # the N^2 K products the step needs: U = A S (forward), V = A^T S (backward; not for a symmetric A, which the
             # pooler detects), DiffPool's link residual S S^T; + the K-sized products of both directions
-            big = 2.0 * B * N * N * K
-            small = 2.0 * B * N * K * (2 * K + F) + 2.0 * B * N * K * (3 * K + F) + 4.0 * B * N * K * F + 2.0 * B * N * F * K
-            flops = big * (2 if self.alias == "diff" else 1) + small
-            r = roof_mfma("whole training step (all kernels of forward + backward, eager)", flops, ms)
+            # r6: sparse inputs of this size take the un-padded rows route (no [B,N,N] adjacency, no N^2 K product): the
+            # step is priced by what it has to move -- forward: edge list + x in, S / T = A S written and read by the
+            # S^T [T | X | S] product, pooled outputs; backward: the operand buffer [T | X | 1 | S | dY] written and read,
+            # dS, dX, the K-sized right-hand sides
+            n, E = float(self.nodes), float(self.ei.size(1))
+            fwd = E * 16.0 + n * F * 4.0 + 2 * 4.0 * n * (2 * K + F) + 4.0 * B * (2 * K * K + K * F)
+            bwd = 2 * 4.0 * n * (3 * K + F) + 4.0 * n * (K + F) + 4.0 * B * (3 * K + F) * K + n * F * 4.0
+            r = roof_hbm("whole training step (all kernels of forward + backward, eager; rows route)", fwd + bwd, ms)
             r["launches_per_step"] = count_kernels(self.step)
             from tgp import functions as Fn
             r["backward_route"] = dict(Fn.POOL_LARGE_STATS)

@@ -303,3 +303,49 @@ def test_batched_poolers_sparse_input_rows_route(dev, alias, sizes, k, f, weight
         scale = float(want.abs().max())
         torch.testing.assert_close(got.cpu().double(), want, rtol=2e-4, atol=2e-5 * max(scale, 1e-3),
                                    msg=lambda m: f"{what}: {m}")
+
+
+@pytest.mark.parametrize("alias,kw", [("mincut", {}), ("diff", {"normalize_loss": True}), ("mincut", {"sparse_output": True}),
+                                      ("diff", {"sparse_output": True, "adj_transpose": False})])
+def test_rows_route_equals_the_densifying_route(dev, monkeypatch, alias, kw):
+    """The same pooler call with the rows route on and off (poolers._ROWS_ROUTE_DENSITY): pooled features, adjacency (or
+    its block-diagonal edge list), S, mask, losses and a lift of the pooled features agree at the 1e-5 tolerance; also
+    against the oracle's batched restatement where it covers the options (sparse_output, normalize_loss)."""
+    import tgp_oracle as O
+    import tgp.poolers as P
+    from tgp.poolers import get_pooler
+    sizes, k, f = [300, 0 + 260, 410], 24, 12
+    x, ei, ew, batch = _batch(sizes, f, 5.0, seed=31, weighted=True)
+    pooler = get_pooler(alias, in_channels=f, k=k, **kw).to(dev).eval()
+    lin = pooler.selector.mlp.lins[0]
+    args = dict(x=x.to(dev), adj=ei.to(dev), edge_weight=ew.to(dev), batch=batch.to(dev))
+    outs = []
+    for density in (0.03, 0.0):
+        monkeypatch.setattr(P, "_ROWS_ROUTE_DENSITY", density)
+        with torch.no_grad():
+            out = pooler(**args)
+            lifted = pooler(x=out.x, so=out.so, batch=args["batch"], batch_pooled=out.batch, lifting=True)
+        outs.append((out, lifted))
+    (a, la), (b, lb) = outs
+    torch.testing.assert_close(a.x, b.x, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a.so.s, b.so.s, rtol=1e-6, atol=1e-7)
+    assert torch.equal(a.mask, b.mask)
+    if kw.get("sparse_output"):
+        assert torch.equal(a.edge_index, b.edge_index) and torch.equal(a.batch, b.batch)
+        torch.testing.assert_close(a.edge_weight, b.edge_weight, rtol=1e-5, atol=1e-6)
+    else:
+        torch.testing.assert_close(a.edge_index, b.edge_index, rtol=1e-5, atol=1e-6)
+    for name in a.loss:
+        torch.testing.assert_close(a.loss[name], b.loss[name], rtol=2e-5, atol=1e-6, msg=lambda m: f"{name}: {m}")
+    torch.testing.assert_close(la, lb, rtol=1e-5, atol=1e-5)
+    ref = O.dense_pool(alias, x, ei, ew, batch, [lin.weight.detach().cpu()], [lin.bias.detach().cpu()],
+                       adj_transpose=kw.get("adj_transpose", True), sparse_output=kw.get("sparse_output", False),
+                       normalize_loss=kw.get("normalize_loss", False))
+    torch.testing.assert_close(a.x.cpu(), ref["x"], rtol=1e-5, atol=1e-5)
+    for name, want in ref["loss"].items():
+        torch.testing.assert_close(a.loss[name].cpu(), want, rtol=2e-5, atol=1e-6, msg=lambda m: f"{name}: {m}")
+    if kw.get("sparse_output"):
+        assert torch.equal(a.edge_index.cpu(), ref["edge_index"])
+        torch.testing.assert_close(a.edge_weight.cpu(), ref["edge_weight"], rtol=1e-5, atol=1e-6)
+    else:
+        torch.testing.assert_close(a.edge_index.cpu(), ref["edge_index"], rtol=1e-5, atol=1e-6)
