@@ -636,6 +636,9 @@ int tgp_mincut_loss_terms_bwd_f32(const float* raw, const float* den, const floa
  *   backward together with stats [B,4] = (trace(raw), |G|_F^2, trace(G), |G / |G| - I / sqrt(K)|_F) per graph (optional).
  *   ptr (optional, [B+1]): deg / q are those of an UN-padded batch, graph b owns entries ptr[b] .. ptr[b+1] (N unused).
  *   q may be NULL: den[b] = sum_i deg[b,i] (the caller's deg already carries the factor, e.g. (A q)_i).
+ *   means (optional, [2]): the batch means of the two terms, formed by the workgroup that arrives last (terms added in
+ *   graph order: independent of the arrival order); needs `ticket`, one zeroed uint32 word per (device, stream) that the
+ *   call leaves zero.
  * tgp_dense_pool_train_rhs_f32: the right-hand sides into rcat [B][3K+F+4][K], rows [RU ; RX ; four zero rows ; RS ; RV]:
  *   with gR = g_raw_a + g_raw_b (either may be NULL) + the loss' diagonal term, RV = gR, RU = gR^T (`symmetric` bit 0:
  *   RU = gR + gR^T, RV not written; bit 1: RU = gR, RV = gR^T -- the buffer's first block holds A S while raw = S^T A^T S), RX = g_x^T (g_x [B,K,F], or one value when gx_bcast), RS by mode:
@@ -660,7 +663,7 @@ int tgp_dense_pool_train_fwd_f32(const float* S, const float* A, const float* X,
                                  float* adj_pool, float* gram, void* ws, size_t ws_bytes, void* stream);
 int tgp_mincut_terms_fused_f32(const float* raw, const float* gram, const float* deg, const float* q, int64_t B,
                                int64_t N, int64_t K, float eps, float* den, float* out, float* stats, const int64_t* ptr,
-                               void* stream);
+                               uint32_t* ticket, float* means, void* stream);
 int tgp_dense_pool_train_rhs_f32(const float* g_raw_a, const float* g_raw_b, int mode, const float* stats, const float* den,
                                  const float* gram, const float* g_la, const float* g_lb, float scale,
                                  const float* link_loss, float link_scale, float eps, const float* g_x, int gx_bcast,
@@ -676,7 +679,8 @@ int tgp_softmax_bwd_ex_f32(const float* s, const float* ds, const float* extra, 
  *   sum_{e in g} w_e <S_row, S_col> = trace(S_g^T (A S)_g) = trace(raw_g)       (sparse_mincut_loss' numerator)
  *   |A - S S^T|_F^2 = sum_e w_e^2 - 2 sum_g trace(raw_g) + sum_g |S_g^T S_g|_F^2  (sparse_link_pred_loss)
  * tgp_segment_gemm_tn3_f32: C_j[b] = S_b^T Y_j,b for up to three right-hand sides Y_j [Ntot,F_j] in one grid (+ one
- *   combine launch): S^T [A S | X | S] = raw pooled adjacency, pooled features, per-graph Gram matrices.
+ *   combine launch): S^T [A S | X | S] = raw pooled adjacency, pooled features, per-graph Gram matrices.  transpose0:
+ *   the first output (K x K) is written transposed by the combine launch (S^T A^T S from the slabs of S^T (A S)).
  * tgp_edge_row_stats_f32: deg[i] = sum of w over CSR row i (entry count when w is NULL), q[i] = |S_i|^2.
  * tgp_diffpool_unbatched_tail_f32: out2 = (sqrt(max(sw2 - 2 sum_b trace(raw_b) + sum_b |gram_b|^2, 0)) link_scale,
  *   (sum of ent_partial) ent_scale); sw2 = sum_e w_e^2 from *sw2_dev when not NULL, else sw2_host; stats [B,2] scratch.
@@ -684,7 +688,7 @@ int tgp_softmax_bwd_ex_f32(const float* s, const float* ds, const float* extra, 
 size_t tgp_segment_gemm_tn3_workspace_bytes(int64_t B, int64_t K, int64_t F0, int64_t F1, int64_t F2, int64_t max_nodes);
 int tgp_segment_gemm_tn3_f32(const float* S, const float* Y0, int64_t F0, const float* Y1, int64_t F1, const float* Y2,
                              int64_t F2, const int64_t* ptr, float* C0, float* C1, float* C2, int64_t B, int64_t Ntot,
-                             int64_t K, int64_t max_nodes, void* ws, size_t ws_bytes, void* stream);
+                             int64_t K, int64_t max_nodes, int transpose0, void* ws, size_t ws_bytes, void* stream);
 int tgp_edge_row_stats_f32(const int32_t* row_ptr, const float* w, const float* S, int64_t N, int64_t K, float* deg,
                            float* q, void* stream);
 /* the two segment products with explicit row strides (operands that are column blocks of a wider buffer: the unbatched
@@ -711,6 +715,9 @@ int tgp_adj_symmetry_f32(const int64_t* row, const int64_t* col, int64_t E, cons
                          int64_t Nmax, const float* adj, uint32_t* ticket, uint64_t* result, uint64_t tag, void* stream);
 int tgp_copy_cols2_f32(const float* a, int64_t wa, const float* b, int64_t wb, int64_t rows, float* dst, int64_t ld,
                        int64_t col_a, int64_t col_b, int64_t one_col, void* stream);
+/* the same with a third source block c [rows, wc] -> dst[:, col_c : col_c + wc] */
+int tgp_copy_cols3_f32(const float* a, int64_t wa, const float* b, int64_t wb, const float* c, int64_t wc, int64_t rows,
+                       float* dst, int64_t ld, int64_t col_a, int64_t col_b, int64_t col_c, int64_t one_col, void* stream);
 
 /* A7'  sparse A times dense S (connect/dense_conn.py:165,204: torch.sparse.mm), A in CSR built from a
  * row-sorted coalesced edge list: T[i,:] = sum_{e in row i} w[e] * S[col[e],:].  w may be NULL. */

@@ -196,6 +196,8 @@ def test_train_kernels_pieces(dev):
     deg2, q2, den2 = K.cut_terms(A, S)
     assert torch.equal(deg, deg2) and torch.equal(q, q2)
     den, terms, _ = K.mincut_terms_fused(raw, gram, deg, q)
+    means = K.mincut_terms_fused(raw, gram, deg, q, want_means=True)[3]
+    torch.testing.assert_close(means, terms.mean(dim=1), rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(den, den2, rtol=1e-6, atol=0)
     torch.testing.assert_close(terms, K.mincut_loss_terms(raw, den2, gram), rtol=1e-6, atol=1e-7)
 

@@ -424,9 +424,10 @@ extern "C" int tgp_dense_pool_train_fwd_f32(const float* S, const float* A, cons
 // dst[r, one_col : one_col + 4] = [1 0 0 0] (the column that turns dY^T [X | 1] into the weight AND bias gradient).
 namespace tgp {
 __global__ __launch_bounds__(256) void copy_cols2_kernel(const float* __restrict__ a, int wa, const float* __restrict__ b,
-                                                         int wb, long rows, float* __restrict__ dst, long ld, int col_a,
-                                                         int col_b, int one_col, int vec) {
-  const int w_all = wa + wb + (one_col >= 0 ? 4 : 0);
+                                                         int wb, const float* __restrict__ c3, int wc, long rows,
+                                                         float* __restrict__ dst, long ld, int col_a, int col_b, int col_c,
+                                                         int one_col, int vec) {
+  const int w_all = wa + wb + wc + (one_col >= 0 ? 4 : 0);
   const int per_row = vec ? w_all / 4 : w_all;
   const long total = rows * per_row;
   for (long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<long>(gridDim.x) * 256) {
@@ -436,7 +437,8 @@ __global__ __launch_bounds__(256) void copy_cols2_kernel(const float* __restrict
     float* out;
     if (c < wa) { src = a + r * wa + c; out = dst + r * ld + col_a + c; }
     else if (c < wa + wb) { c -= wa; src = b + r * wb + c; out = dst + r * ld + col_b + c; }
-    else { c -= wa + wb; out = dst + r * ld + one_col + c; }
+    else if (c < wa + wb + wc) { c -= wa + wb; src = c3 + r * wc + c; out = dst + r * ld + col_c + c; }
+    else { c -= wa + wb + wc; out = dst + r * ld + one_col + c; }
     if (vec) *reinterpret_cast<float4*>(out) = src ? *reinterpret_cast<const float4*>(src) : make_float4(1.f, 0.f, 0.f, 0.f);
     else *out = src ? *src : (c == 0 ? 1.f : 0.f);
   }
@@ -445,21 +447,30 @@ __global__ __launch_bounds__(256) void copy_cols2_kernel(const float* __restrict
 
 extern "C" int tgp_copy_cols2_f32(const float* a, int64_t wa, const float* b, int64_t wb, int64_t rows, float* dst,
                                   int64_t ld, int64_t col_a, int64_t col_b, int64_t one_col, void* stream_) {
-  TGP_REQUIRE(rows >= 0 && wa >= 0 && wb >= 0 && ld >= 0, TGP_ERR_INVALID, "tgp_copy_cols2_f32: negative size");
-  if (rows == 0 || wa + wb + (one_col >= 0 ? 4 : 0) == 0) return TGP_OK;
-  TGP_REQUIRE(dst && (wa == 0 || a) && (wb == 0 || b), TGP_ERR_INVALID, "tgp_copy_cols2_f32: null pointer");
-  TGP_REQUIRE(col_a + wa <= ld && col_b + wb <= ld && wa + wb < (1ll << 30) && (one_col < 0 || one_col + 4 <= ld),
-              TGP_ERR_INVALID, "tgp_copy_cols2_f32: column block outside the row");
-  const int vec = (wa % 4 == 0 && wb % 4 == 0 && ld % 4 == 0 && col_a % 4 == 0 && col_b % 4 == 0 &&
-                   (one_col < 0 || one_col % 4 == 0) && reinterpret_cast<uintptr_t>(a) % 16 == 0 &&
-                   reinterpret_cast<uintptr_t>(b) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0) ? 1 : 0;
-  const int64_t total = rows * ((wa + wb + (one_col >= 0 ? 4 : 0)) / (vec ? 4 : 1));
+  return tgp_copy_cols3_f32(a, wa, b, wb, nullptr, 0, rows, dst, ld, col_a, col_b, 0, one_col, stream_);
+}
+
+extern "C" int tgp_copy_cols3_f32(const float* a, int64_t wa, const float* b, int64_t wb, const float* c, int64_t wc,
+                                  int64_t rows, float* dst, int64_t ld, int64_t col_a, int64_t col_b, int64_t col_c,
+                                  int64_t one_col, void* stream_) {
+  TGP_REQUIRE(rows >= 0 && wa >= 0 && wb >= 0 && wc >= 0 && ld >= 0, TGP_ERR_INVALID, "tgp_copy_cols3_f32: negative size");
+  if (rows == 0 || wa + wb + wc + (one_col >= 0 ? 4 : 0) == 0) return TGP_OK;
+  TGP_REQUIRE(dst && (wa == 0 || a) && (wb == 0 || b) && (wc == 0 || c), TGP_ERR_INVALID, "tgp_copy_cols3_f32: null pointer");
+  TGP_REQUIRE(col_a + wa <= ld && col_b + wb <= ld && col_c + wc <= ld && wa + wb + wc < (1ll << 30) &&
+                  (one_col < 0 || one_col + 4 <= ld),
+              TGP_ERR_INVALID, "tgp_copy_cols3_f32: column block outside the row");
+  const int vec = (wa % 4 == 0 && wb % 4 == 0 && wc % 4 == 0 && ld % 4 == 0 && col_a % 4 == 0 && col_b % 4 == 0 &&
+                   col_c % 4 == 0 && (one_col < 0 || one_col % 4 == 0) && reinterpret_cast<uintptr_t>(a) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(b) % 16 == 0 && reinterpret_cast<uintptr_t>(c) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(dst) % 16 == 0) ? 1 : 0;
+  const int64_t total = rows * ((wa + wb + wc + (one_col >= 0 ? 4 : 0)) / (vec ? 4 : 1));
   int64_t grid = (total + 255) / 256;
   if (grid > 256 * 16) grid = 256 * 16;
   hipLaunchKernelGGL(copy_cols2_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, static_cast<hipStream_t>(stream_),
-                     a, static_cast<int>(wa), b, static_cast<int>(wb), static_cast<long>(rows), dst, static_cast<long>(ld),
-                     static_cast<int>(col_a), static_cast<int>(col_b), static_cast<int>(one_col >= 0 ? one_col : -1), vec);
-  return check_launch("tgp_copy_cols2_f32");
+                     a, static_cast<int>(wa), b, static_cast<int>(wb), c, static_cast<int>(wc), static_cast<long>(rows), dst,
+                     static_cast<long>(ld), static_cast<int>(col_a), static_cast<int>(col_b), static_cast<int>(col_c),
+                     static_cast<int>(one_col >= 0 ? one_col : -1), vec);
+  return check_launch("tgp_copy_cols3_f32");
 }
 
 // part [slabs][K][F + 4] (dY^T [X | 1 0 0 0] per row slab) -> gw [K][F] and gb [K], slabs added in order: the weight and
@@ -855,6 +866,7 @@ namespace tgp {
 struct Combine3Args {
   const float* src[3]; float* dst[3]; long total[3];
   int splits;
+  int transpose0, K;  // output 0 is K x K and is written transposed (raw = S^T A^T S from the slabs of S^T (A S))
 };
 __global__ __launch_bounds__(256) void combine_slabs3_kernel(Combine3Args a) {
   const int b = blockIdx.y, j = blockIdx.z;
@@ -862,10 +874,12 @@ __global__ __launch_bounds__(256) void combine_slabs3_kernel(Combine3Args a) {
   if (total == 0) return;
   const float* sb = a.src[j] + static_cast<long>(b) * a.splits * total;
   float* db = a.dst[j] + static_cast<long>(b) * total;
+  const bool tr = j == 0 && a.transpose0;
   for (long e = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; e < total; e += static_cast<long>(gridDim.x) * 256) {
     float v = sb[e];
     for (int sp = 1; sp < a.splits; ++sp) v = __fadd_rn(v, sb[sp * total + e]);
-    db[e] = v;
+    const long r = e / a.K;
+    db[tr ? (e - r * a.K) * a.K + r : e] = v;
   }
 }
 }  // namespace tgp
@@ -893,8 +907,8 @@ extern "C" size_t tgp_segment_gemm_tn3_workspace_bytes(int64_t B, int64_t K, int
 
 extern "C" int tgp_segment_gemm_tn3_f32(const float* S, const float* Y0, int64_t F0, const float* Y1, int64_t F1,
                                         const float* Y2, int64_t F2, const int64_t* ptr, float* C0, float* C1, float* C2,
-                                        int64_t B, int64_t Ntot, int64_t K, int64_t max_nodes, void* ws, size_t ws_bytes,
-                                        void* stream_) {
+                                        int64_t B, int64_t Ntot, int64_t K, int64_t max_nodes, int transpose0, void* ws,
+                                        size_t ws_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && Ntot >= 0 && K >= 0 && F0 > 0 && F1 >= 0 && F2 >= 0 && (F1 > 0 || F2 == 0), TGP_ERR_INVALID,
               "tgp_segment_gemm_tn3_f32: bad sizes (right-hand sides are filled front to back)");
@@ -914,8 +928,11 @@ extern "C" int tgp_segment_gemm_tn3_f32(const float* S, const float* Y0, int64_t
   GemmArgs g{};
   g.A = S; g.lda = K; g.sA = 0;
   g.M = static_cast<int>(K); g.Kd = static_cast<int>(Ntot);
+  TGP_REQUIRE(!transpose0 || F0 == K, TGP_ERR_INVALID, "tgp_segment_gemm_tn3_f32: transpose0 needs a K x K first output");
   Combine3Args ca{};
   ca.splits = splits;
+  ca.transpose0 = transpose0 ? 1 : 0;
+  ca.K = static_cast<int>(K);
   long max_total = 0;
   for (int j = 0; j < 3; ++j) {
     if (fs[j] <= 0) continue;

@@ -401,8 +401,10 @@ __global__ __launch_bounds__(T) void mincut_tail2_kernel(const float* __restrict
                                                            const float* __restrict__ deg, const float* __restrict__ q,
                                                            int N, int K, float eps, int B, float* __restrict__ den,
                                                            float* __restrict__ out, float* __restrict__ stats,
-                                                           const int64_t* __restrict__ ptr) {
+                                                           const int64_t* __restrict__ ptr,
+                                                           unsigned int* __restrict__ ticket, float* __restrict__ means) {
   __shared__ float sh[T / 64];
+  __shared__ bool s_last;
   const int b = blockIdx.x;
   const float* R = raw + static_cast<int64_t>(b) * K * K;
   const float* G = gram + static_cast<int64_t>(b) * K * K;
@@ -438,6 +440,29 @@ __global__ __launch_bounds__(T) void mincut_tail2_kernel(const float* __restrict
     if (stats) {  // what the backward's right-hand sides need of this graph, so that they need no reduction of their own
       stats[4 * b] = tr; stats[4 * b + 1] = sq; stats[4 * b + 2] = trg; stats[4 * b + 3] = sqrtf(acc);
     }
+  }
+  if (!means) return;
+  // the batch means of the two terms (what MinCutPooling hands out) by the workgroup that arrives last: every term
+  // added in graph order by one workgroup, so the value does not depend on the arrival order (a separate reduction
+  // launch + two selects before)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  float a0 = 0.f, a1 = 0.f;
+  for (int i = threadIdx.x; i < B; i += T) {
+    a0 += __hip_atomic_load(out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a1 += __hip_atomic_load(out + B + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  a0 = block_sum_t<T>(a0, sh);
+  a1 = block_sum_t<T>(a1, sh);
+  if (threadIdx.x == 0) {
+    means[0] = a0 / static_cast<float>(B);
+    means[1] = a1 / static_cast<float>(B);
+    *ticket = 0;  // ready for the next call on this stream
   }
 }
 
@@ -693,20 +718,23 @@ extern "C" int tgp_diffpool_unbatched_tail_f32(const float* raw, const float* gr
 
 extern "C" int tgp_mincut_terms_fused_f32(const float* raw, const float* gram, const float* deg, const float* q,
                                           int64_t B, int64_t N, int64_t K, float eps, float* den, float* out,
-                                          float* stats, const int64_t* ptr, void* stream_) {
+                                          float* stats, const int64_t* ptr, uint32_t* ticket, float* means,
+                                          void* stream_) {
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 1 && K < 32768 && N < (1ll << 31), TGP_ERR_INVALID,
               "tgp_mincut_terms_fused_f32: bad shape");
   if (B == 0) return TGP_OK;
   TGP_REQUIRE(raw && gram && den && out && (N == 0 || deg), TGP_ERR_INVALID,
               "tgp_mincut_terms_fused_f32: null pointer");
   TGP_REQUIRE(B < (1ll << 31), TGP_ERR_RANGE, "tgp_mincut_terms_fused_f32: too many graphs");
+  TGP_REQUIRE(!means || ticket, TGP_ERR_INVALID, "tgp_mincut_terms_fused_f32: means need a zeroed ticket word");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (K >= 64)
     hipLaunchKernelGGL(mincut_tail2_kernel<1024>, dim3(static_cast<unsigned>(B)), dim3(1024), 0, stream, raw, gram, deg, q,
-                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out, stats, ptr);
+                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out, stats, ptr, ticket, means);
   else
     hipLaunchKernelGGL(mincut_tail2_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, raw, gram, deg, q,
-                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out, stats, ptr);
+                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out, stats, ptr, ticket,
+                       means);
   return check_launch("tgp_mincut_terms_fused_f32");
 }
 

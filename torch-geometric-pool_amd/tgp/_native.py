@@ -161,10 +161,10 @@ SIGNATURES = {
     "tgp_dense_pool_train_fwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_i64,
                                               _c_p, _c_p, _c_p, _c_p, _c_p, _c_sz, _c_p]),
     "tgp_mincut_terms_fused_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_f, _c_p, _c_p, _c_p,
-                                            _c_p, _c_p]),
+                                            _c_p, _c_p, _c_p, _c_p]),
     "tgp_segment_gemm_tn3_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
     "tgp_segment_gemm_tn3_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64,
-                                          _c_i64, _c_i64, _c_i64, _c_p, _c_sz, _c_p]),
+                                          _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_sz, _c_p]),
     "tgp_edge_row_stats_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_diffpool_unbatched_tail_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_p, _c_f, _c_p, _c_int, _c_f, _c_f, _c_p,
                                                  _c_p, _c_p]),
@@ -180,6 +180,8 @@ SIGNATURES = {
     "tgp_slab_sum_split_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_adj_symmetry_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, ctypes.c_uint64, _c_p]),
     "tgp_copy_cols2_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+    "tgp_copy_cols3_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_i64,
+                                    _c_i64, _c_p]),
     "tgp_mincut_loss_terms_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_f, _c_p, _c_p]),
     "tgp_rowptr_from_sorted_flag_i64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_rowptr_from_sorted_i64": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p]),

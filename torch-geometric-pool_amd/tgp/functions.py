@@ -931,8 +931,7 @@ class _PoolLargeFn(torch.autograd.Function):
         deg = den = lossv = stats = None
         if mode == 1:
             deg, q = K.cut_rows(ad, s, graph_sizes)
-            den, terms, stats = K.mincut_terms_fused(raw, gram, deg, q)
-            both = terms.mean(dim=1)
+            den, terms, stats, both = K.mincut_terms_fused(raw, gram, deg, q, want_means=True)
             la, lb = both[0], both[1]
         elif mode == 2:
             lossv = K.diffpool_loss_tail(s, ad, graph_sizes, scales[0], scales[1])
@@ -1062,9 +1061,7 @@ class _PoolUnbatchedFn(torch.autograd.Function):
         Kc = s.size(1)
         B = ptr.numel() - 1
         t = K.spmm_csr(row_ptr, ei, ew, n, s)
-        raw, x_pool, gram = K.segment_gemm_tn3(s, [t, xd, s], ptr, max_nodes)
-        if transposed:
-            raw = raw.transpose(1, 2).contiguous()
+        raw, x_pool, gram = K.segment_gemm_tn3(s, [t, xd, s], ptr, max_nodes, transpose0=transposed)
         adj_pool = K.postprocess_dense(raw, flags)
         empty = s.new_empty(0)
         la, lb = s.new_empty(0), s.new_empty(0)
@@ -1073,10 +1070,9 @@ class _PoolUnbatchedFn(torch.autograd.Function):
             deg, q = K.edge_row_stats(row_ptr, ew, s)  # out-degrees and |S_i|^2
             if transposed:  # den = sum_i indeg_i q_i = sum_i (A q)_i: one SpMV over the same row-sorted list
                 aq = K.spmm_csr(row_ptr, ei, ew, n, q.view(n, 1)).view(n)
-                den, terms, stats = K.mincut_terms_fused(raw, gram, aq, None, ptr=ptr)
+                den, terms, stats, both = K.mincut_terms_fused(raw, gram, aq, None, ptr=ptr, want_means=True)
             else:
-                den, terms, stats = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr)
-            both = terms.mean(dim=1)
+                den, terms, stats, both = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr, want_means=True)
             la, lb = both[0], both[1]
         elif mode == 2:
             lossv = K.diffpool_unbatched_tail(raw, gram, s, sw2, scales[0], scales[1])
@@ -1132,18 +1128,16 @@ class _PoolUnbatchedFn(torch.autograd.Function):
         ld = 3 * Kc + F + pad
         c_x, c_one, c_s, c_v = Kc, Kc + F, Kc + F + pad, 2 * Kc + F + pad
         acat = torch.empty(n, ld, dtype=torch.float32, device=dev)
-        K.copy_cols2(t, xd, acat, 0, c_x, one_col=c_one)
+        K.copy_cols3(t, xd, s, acat, 0, c_x, c_s, one_col=c_one)  # [T | X | 1 0 0 0 | S | .]: one launch
         vblock = acat[:, c_v:]
         if not symmetric:  # T' = A^T S: the SpMM over the column-sorted list (the list is coalesced: nothing merges)
             ident = torch.arange(n, device=dev)
             w1 = ew if ew is not None else torch.ones(ei.size(1), device=dev)
             ei_t, w_t = K.coalesce_edges(ei.flip(0), w1, ident, n, "sum", remove_self_loops=False, eps_filter=False)
             rp_t = K.csr_offsets(ei_t, n)
-            K.copy_cols2(s, K.spmm_csr(rp_t, ei_t, w_t, n, s), acat, c_s, c_v)
+            K.copy_cols2(K.spmm_csr(rp_t, ei_t, w_t, n, s), s.new_empty(n, 0), acat, c_v, c_v)
             if ctx.transposed and mode == 1:  # the in-degrees: row sums of the transposed list
                 deg = K.edge_row_stats(rp_t, w_t, s)[0]
-        else:
-            K.copy_cols2(s, s.new_empty(n, 0), acat, c_s, c_v)
         kd = c_v if symmetric else ld
         gs = torch.empty(n, Kc, dtype=torch.float32, device=dev)
         K.segment_gemm_nn_into(acat[:, :kd], rcat[:, :kd, :], ptr, gs, ctx.max_nodes)

@@ -256,7 +256,8 @@ class _SpsState:
         self.host = self.pinned.numpy()  # the same memory
         # the one-launch batch facts (utils.ops._batch_facts_sorted): arrival ticket + flag word (zero between calls) and
         # the pinned words {tag, B - 1, flags, longest graph, non-empty graphs, sum of TopK keep counts}
-        self.ticket = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.ticket = torch.zeros(8, dtype=torch.int32, device=dev)  # words 0-1 batch facts, 2-3 edge facts / symmetry,
+        #                                                               4 the MinCut tail's batch means (r6)
         self.facts_pinned = torch.zeros(8 * 8, dtype=torch.int64).pin_memory()  # 8 slots of 8 words (prefetched calls)
         self.facts_host = self.facts_pinned.numpy()
         self.facts_tag = 0
@@ -1514,10 +1515,10 @@ def cut_rows(adj: Tensor, s: Tensor, graph_sizes: Optional[Tensor] = None) -> Tu
 
 
 def mincut_terms_fused(raw: Tensor, gram: Tensor, deg: Tensor, q: Optional[Tensor],
-                       ptr: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
-    """(den [B], terms [2,B], stats [B,4]): MinCut's per-graph loss tails with den = sum_i deg_i q_i formed in the same
-    launch (utils/losses.py:39-70); stats = (trace(raw), |G|^2, trace(G), |Y|) per graph, the scalars the backward's
-    right-hand sides need."""
+                       ptr: Optional[Tensor] = None, want_means: bool = False):
+    """(den [B], terms [2,B], stats [B,4][, means [2]]): MinCut's per-graph loss tails with den = sum_i deg_i q_i formed
+    in the same launch (utils/losses.py:39-70); stats = (trace(raw), |G|^2, trace(G), |Y|) per graph, the scalars the
+    backward's right-hand sides need; ``want_means``: also the batch means of the two terms (what the pooler hands out)."""
     dev = N.require_device(raw, gram, deg, q)
     raw, gram, deg = N.f32c(raw), N.f32c(gram), N.f32c(deg)
     q = None if q is None else N.f32c(q)  # (None: deg already carries the factor, den = sum of deg)
@@ -1525,11 +1526,20 @@ def mincut_terms_fused(raw: Tensor, gram: Tensor, deg: Tensor, q: Optional[Tenso
     den = torch.empty(B, dtype=torch.float32, device=dev)
     out = torch.empty(2, B, dtype=torch.float32, device=dev)
     stats = torch.empty(B, 4, dtype=torch.float32, device=dev)
+    st = N.stream_ptr(dev)
+    means = ticket = None
+    if want_means and B <= 256 and not torch.cuda.is_current_stream_capturing():
+        # the batch means come with the same launch (its last workgroup adds the terms up in graph order); for thousands
+        # of graphs the arrival tickets on ONE word cost more than the reduction launch they save (2048 graphs: +40 us)
+        means = torch.empty(2, dtype=torch.float32, device=dev)
+        ticket = _sps_state(dev, st, 0).ticket.data_ptr() + 16
     # ptr: deg / q belong to an un-padded batch (graph b owns entries ptr[b] .. ptr[b+1])
     N.check(N.lib().tgp_mincut_terms_fused_f32(N.ptr(raw), N.ptr(gram), N.ptr(deg), N.ptr(q), B, Nn, Kc, losses_eps(),
                                                N.ptr(den), N.ptr(out), N.ptr(stats),
-                                               N.ptr(None if ptr is None else N.i64c(ptr)), N.stream_ptr(dev)),
+                                               N.ptr(None if ptr is None else N.i64c(ptr)), ticket, N.ptr(means), st),
             "tgp_mincut_terms_fused_f32")
+    if want_means:
+        return den, out, stats, (means if means is not None else out.mean(dim=1))
     return den, out, stats
 
 
@@ -1619,6 +1629,16 @@ def copy_cols2(a: Tensor, b: Tensor, dst: Tensor, col_a: int, col_b: int, one_co
         raise ValueError("copy_cols2: operands must be contiguous with equal row counts")
     N.check(N.lib().tgp_copy_cols2_f32(N.ptr(a), a.size(1), N.ptr(b), b.size(1), dst.size(0), N.ptr(dst), dst.size(1),
                                        col_a, col_b, one_col, N.stream_ptr(dev)), "tgp_copy_cols2_f32")
+
+
+def copy_cols3(a: Tensor, b: Tensor, c: Tensor, dst: Tensor, col_a: int, col_b: int, col_c: int, one_col: int = -1) -> None:
+    """:func:`copy_cols2` with a third source block: dst[:, col_c:col_c+wc] = c."""
+    dev = N.require_device(a, b, c, dst)
+    if not all(t.is_contiguous() and t.size(0) == dst.size(0) for t in (a, b, c)) or not dst.is_contiguous():
+        raise ValueError("copy_cols3: operands must be contiguous with equal row counts")
+    N.check(N.lib().tgp_copy_cols3_f32(N.ptr(a), a.size(1), N.ptr(b), b.size(1), N.ptr(c), c.size(1), dst.size(0),
+                                       N.ptr(dst), dst.size(1), col_a, col_b, col_c, one_col, N.stream_ptr(dev)),
+            "tgp_copy_cols3_f32")
 
 
 def slab_sum_split(part: Tensor, F: int, want_gw: bool = True, want_gb: bool = True):
@@ -2288,7 +2308,7 @@ def edge_row_stats(row_ptr: Tensor, edge_weight: Optional[Tensor], s: Tensor) ->
     return deg, q
 
 
-def segment_gemm_tn3(s: Tensor, ys, ptr: Tensor, max_nodes: int):
+def segment_gemm_tn3(s: Tensor, ys, ptr: Tensor, max_nodes: int, transpose0: bool = False):
     """[S_b^T Y_j,b for j] for up to three float32 right-hand sides [Ntot,F_j] over node rows ptr[b]..ptr[b+1]: ONE
     product grid + one combine launch (the unbatched dense poolers' S^T [A S | X | S])."""
     dev = N.require_device(s, ptr, *ys)
@@ -2303,9 +2323,10 @@ def segment_gemm_tn3(s: Tensor, ys, ptr: Tensor, max_nodes: int):
     op = [N.ptr(o) for o in outs] + [None] * (3 - len(ys))
     L = N.lib()
     ws = N.workspace(L.tgp_segment_gemm_tn3_workspace_bytes(B, Kc, fs[0], fs[1], fs[2], max_nodes), dev)
+    # transpose0: the first result (K x K) leaves the combine launch transposed
     N.check(L.tgp_segment_gemm_tn3_f32(N.ptr(s), yp[0], fs[0], yp[1], fs[1], yp[2], fs[2], N.ptr(ptr), op[0], op[1], op[2],
-                                       B, s.size(0), Kc, max_nodes, N.ptr(ws), ws.numel(), N.stream_ptr(dev)),
-            "tgp_segment_gemm_tn3_f32")
+                                       B, s.size(0), Kc, max_nodes, 1 if transpose0 else 0, N.ptr(ws), ws.numel(),
+                                       N.stream_ptr(dev)), "tgp_segment_gemm_tn3_f32")
     return outs
 
 

@@ -551,17 +551,14 @@ class _DenseMLPPooling(DenseSRCPooling):
             both = pair
         else:
             t = K.spmm_csr(row_ptr, ei, w_used, n, s)
-            raw, x_pool, gram = K.segment_gemm_tn3(s, [t, x, s], ptr, max_nodes)
-            if transposed:
-                raw = raw.transpose(1, 2).contiguous()
+            raw, x_pool, gram = K.segment_gemm_tn3(s, [t, x, s], ptr, max_nodes, transpose0=transposed)
             if mincut:
                 deg, q = K.edge_row_stats(row_ptr, w_used, s)
                 if transposed:  # in-degrees: sum_i indeg_i q_i = sum_i (A q)_i
                     aq = K.spmm_csr(row_ptr, ei, w_used, n, q.view(n, 1)).view(n)
-                    _, terms, _ = K.mincut_terms_fused(raw, gram, aq, None, ptr=ptr)
+                    both = K.mincut_terms_fused(raw, gram, aq, None, ptr=ptr, want_means=True)[3]
                 else:
-                    _, terms, _ = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr)
-                both = terms.mean(dim=1)
+                    both = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr, want_means=True)[3]
             else:
                 both = K.diffpool_unbatched_tail(raw, gram, s, sw2, scales[0], scales[1])
             adj_pool = K.postprocess_dense(raw, flags)
