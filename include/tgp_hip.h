@@ -701,6 +701,9 @@ int tgp_segment_gemm_tn_ld_f32(const float* A, int64_t lda, const float* Y, int6
                                int64_t B, int64_t Ntot, int64_t M, int64_t Nc, void* stream);
 /* is the COALESCED row-sorted list (row, col, w) with CSR offsets row_ptr symmetric: has every entry (r, c, w) a mirror
  * entry (c, r, w)?  Verdict as tgp_adj_symmetry_f32 (pinned result word 2 = 1: no). */
+/* ... and for a dense [B,N,N] adjacency: every entry equals its mirror image?  (one pass, 32 x 32 tile pairs) */
+int tgp_dense_symmetry_f32(const float* adj, int64_t B, int64_t N, uint32_t* ticket, uint64_t* result, uint64_t tag,
+                           void* stream);
 int tgp_edge_symmetry_f32(const int64_t* row, const int64_t* col, const float* w, int64_t E, const int32_t* row_ptr,
                           int64_t N, uint32_t* ticket, uint64_t* result, uint64_t tag, void* stream);
 int tgp_diffpool_unbatched_tail_f32(const float* raw, const float* gram, int64_t B, int64_t K, const float* sw2_dev,

@@ -351,3 +351,36 @@ def test_rows_route_equals_the_densifying_route(dev, monkeypatch, alias, kw):
         torch.testing.assert_close(a.edge_weight.cpu(), ref["edge_weight"], rtol=1e-5, atol=1e-6)
     else:
         torch.testing.assert_close(a.edge_index.cpu(), ref["edge_index"], rtol=1e-5, atol=1e-6)
+
+
+def test_dense_adjacency_symmetry_probe(dev):
+    """kernels.AdjSymmetry.of_dense: one pass over a dense [B,N,N] adjacency (32 x 32 tile pairs), exact comparison, the
+    verdict remembered per tensor object + version; the training node of a pooler called with a DENSE adjacency uses it."""
+    from tgp import functions as Fn, kernels as K
+    from tgp.poolers import get_pooler
+    g = torch.Generator(device=dev).manual_seed(2)
+    for B, N in ((1, 77), (3, 200), (2, 64)):
+        A = torch.rand(B, N, N, device=dev, generator=g)
+        S = torch.maximum(A, A.transpose(1, 2)).contiguous()
+        assert K.AdjSymmetry.of_dense(S).get() is True
+        assert K.AdjSymmetry.of_dense(S).tag is None  # remembered: no second launch
+        assert K.AdjSymmetry.of_dense(A).get() is False
+        T = S.clone()
+        T[B - 1, N - 1, 0] += 1.0  # one entry in the last tile row
+        assert K.AdjSymmetry.of_dense(T).get() is False
+        S[0, 1, 0] += 0.5  # an in-place edit bumps the version: asked again
+        assert K.AdjSymmetry.of_dense(S).get() is False
+    B, N, Kc, F = 2, 200, 48, 16
+    A = (torch.rand(B, N, N, device=dev, generator=g) < 0.05).float()
+    A = torch.maximum(A, A.transpose(1, 2)).contiguous()
+    X = torch.randn(B, N, F, device=dev, generator=g)
+    pooler = get_pooler("mincut", in_channels=F, k=Kc).to(dev).train()
+    before = dict(Fn.POOL_LARGE_STATS)
+    out = pooler(x=X, adj=A)
+    (out.x.square().sum() + out.edge_index.sum() + sum(out.loss.values())).backward()
+    assert Fn.POOL_LARGE_STATS["symmetric"] == before["symmetric"] + 1
+    Au = A.clone()
+    Au[0, 3, 5] += 1.0
+    out = pooler(x=X, adj=Au)
+    (out.x.square().sum() + out.edge_index.sum() + sum(out.loss.values())).backward()
+    assert Fn.POOL_LARGE_STATS["general"] == before["general"] + 1

@@ -621,6 +621,80 @@ extern "C" int tgp_edge_facts_sorted_i64(const int64_t* row, int64_t E, const in
   return check_launch("tgp_edge_facts_sorted_i64");
 }
 
+// r6: and for a dense [B,N,N] adjacency the caller holds (a fixed dense graph pooled every epoch): 32 x 32 tiles on and
+// above the diagonal are compared with their mirror tiles through an LDS patch; one pass over the matrix, once per tensor
+// object (the answer is remembered).
+namespace tgp {
+__global__ __launch_bounds__(256) void dense_symmetry_kernel(const float* __restrict__ adj, int N, int tiles,
+                                                             unsigned int* __restrict__ ticket,
+                                                             unsigned int* __restrict__ bad,
+                                                             unsigned long long* __restrict__ result,
+                                                             unsigned long long tag) {
+  __shared__ float t_m[32][33];
+  __shared__ bool s_last;
+  const int b = blockIdx.y;
+  const float* A = adj + static_cast<long>(b) * N * N;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  unsigned int flags = 0;
+  // upper-triangular tile pairs (ti <= tj), dealt out over the grid's x dimension
+  const long pairs = static_cast<long>(tiles) * (tiles + 1) / 2;
+  for (long pi = blockIdx.x; pi < pairs; pi += gridDim.x) {
+    // (ti, tj) of the pi-th pair in row-major order of the upper triangle
+    int ti = 0;
+    long rem = pi;
+    while (rem >= tiles - ti) { rem -= tiles - ti; ++ti; }
+    const int tj = ti + static_cast<int>(rem);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // mirror tile (tj, ti), read along its rows
+      const int r = tj * 32 + ty * 4 + q, c = ti * 32 + tx;
+      t_m[ty * 4 + q][tx] = (r < N && c < N) ? A[static_cast<long>(r) * N + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = ti * 32 + ty * 4 + q, c = tj * 32 + tx;
+      if (r < N && c < N && A[static_cast<long>(r) * N + c] != t_m[tx][ty * 4 + q]) flags = 1u;
+    }
+  }
+  if (flags) atomicOr(bad, flags);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned int fl = __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *ticket = 0;
+      *bad = 0;
+      result[1] = 0ull;
+      result[2] = fl;
+      result[3] = result[4] = result[5] = 0ull;
+      __threadfence_system();
+      __hip_atomic_store(result, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+}  // namespace tgp
+
+extern "C" int tgp_dense_symmetry_f32(const float* adj, int64_t B, int64_t N, uint32_t* ticket, uint64_t* result,
+                                      uint64_t tag, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B > 0 && N > 0 && B < 65536 && N < (1ll << 20) && adj && ticket && result, TGP_ERR_INVALID,
+              "tgp_dense_symmetry_f32: bad argument");
+  const int tiles = static_cast<int>((N + 31) / 32);
+  int64_t gx = static_cast<int64_t>(tiles) * (tiles + 1) / 2;
+  if (gx * B > 4096) gx = (4096 + B - 1) / B;  // a few workgroups per CU, every one walks several tile pairs
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(dense_symmetry_kernel, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(B)), dim3(256), 0, stream, adj,
+                     static_cast<int>(N), tiles, ticket, ticket + 1, reinterpret_cast<unsigned long long*>(result),
+                     static_cast<unsigned long long>(tag));
+  return check_launch("tgp_dense_symmetry_f32");
+}
+
 // r6: the same question for a COALESCED row-sorted edge list with its CSR offsets (the unbatched dense poolers never
 // densify): entry (r, c, w) must have a mirror entry (c, r, w) -- found by binary search in row c.
 namespace tgp {

@@ -176,6 +176,7 @@ SIGNATURES = {
     "tgp_segment_gemm_nn_ld_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64,
                                             _c_i64, _c_i64, _c_p]),
     "tgp_segment_gemm_tn_ld_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+    "tgp_dense_symmetry_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, ctypes.c_uint64, _c_p]),
     "tgp_edge_symmetry_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, ctypes.c_uint64, _c_p]),
     "tgp_slab_sum_split_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
     "tgp_adj_symmetry_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, ctypes.c_uint64, _c_p]),

@@ -1184,6 +1184,29 @@ class AdjSymmetry:
                                              self.state.facts_slot(self.tag), self.tag, st), "tgp_adj_symmetry_f32")
 
     @classmethod
+    def of_dense(cls, adj: Tensor) -> "AdjSymmetry":
+        """The same question for a dense [B,N,N] float32 adjacency the caller holds (tgp_dense_symmetry_f32: one pass over
+        the matrix); remembered for this tensor object + version, so a fixed dense graph pooled every epoch pays it once."""
+        import weakref
+        self = cls.__new__(cls)
+        self.state = self.tag = None
+        self.ei, self.ew = weakref.ref(adj), None
+        self.answer = _adj_symmetric_memo(adj, None)
+        if self.answer is not None:
+            return self
+        if (adj.dim() != 3 or adj.size(1) != adj.size(2) or adj.dtype != torch.float32 or not adj.is_cuda
+                or not adj.is_contiguous() or adj.numel() == 0 or torch.cuda.is_current_stream_capturing()):
+            self.answer = False
+            return self
+        dev = adj.device
+        st = N.stream_ptr(dev)
+        self.state = _sps_state(dev, st, 0)
+        self.tag = self.state.next_facts_tag()
+        N.check(N.lib().tgp_dense_symmetry_f32(N.ptr(adj), adj.size(0), adj.size(1), self.state.ticket.data_ptr() + 8,
+                                               self.state.facts_slot(self.tag), self.tag, st), "tgp_dense_symmetry_f32")
+        return self
+
+    @classmethod
     def of_edge_list(cls, key_index: Tensor, key_weight: Optional[Tensor], edge_index: Tensor,
                      edge_weight: Optional[Tensor], row_ptr: Tensor, num_nodes: int) -> "AdjSymmetry":
         """The same question for a COALESCED row-sorted list with its CSR offsets (tgp_edge_symmetry_f32: every entry must

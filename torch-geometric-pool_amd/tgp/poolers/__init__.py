@@ -645,10 +645,17 @@ class _DenseMLPPooling(DenseSRCPooling):
             if folded is None and _FOLD_TRAINING:
                 folded = self._select_reduce_connect_train(x, adj, mask, graph_sizes, want_bp)
             symmetry = None
+            from .. import kernels as K_
             if sparse_in and _FOLD_TRAINING and torch.is_grad_enabled() and isinstance(adj, Tensor) and adj.dim() == 3:
                 # (asked only when the one-node path takes the call: a launch over the entries, answered in its backward)
                 dense_adj, ei_in, ew_in = adj, sparse_edges[0], sparse_edges[1]
                 symmetry = lambda: self._adj_symmetry(ei_in, ew_in, dense_adj, batch)  # noqa: E731
+            elif (not sparse_in and _FOLD_TRAINING and torch.is_grad_enabled() and isinstance(adj, Tensor)
+                  and adj.dim() == 3 and adj.is_contiguous()):
+                # a dense adjacency the caller holds (e.g. one fixed graph pooled every epoch): one pass over it, once
+                # per tensor object, tells whether A = A^T (the backward then forms one N^2 K product less)
+                held = adj
+                symmetry = lambda: K_.AdjSymmetry.of_dense(held)  # noqa: E731
             if folded is None and _FOLD_TRAINING:  # graphs beyond the one-wave kernels: one autograd node as well (r6)
                 folded = self._select_reduce_connect_large(x, adj, mask, graph_sizes, symmetry=symmetry)
             so = folded[0] if folded is not None else self.select(x=x, mask=mask)
