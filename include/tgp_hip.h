@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10031 /* 1.0.1 of the reference, ABI revision 30 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32) */
+#define TGP_ABI_VERSION 10032 /* 1.0.1 of the reference, ABI revision 31 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -931,6 +931,13 @@ int tgp_edges_compact(const int64_t* row, const int64_t* col, const void* weight
  * of 4): the merged outputs of a gathered step (tgp/data/collate.py:144-153) leave the receive buffer as exact-size
  * tensors in one launch. */
 int tgp_copy_arrays(const void* const* src, void* const* dst, const int64_t* bytes, int count, void* stream);
+/* r6: the host wait of tgp_sparse_pool_small_f32 + the launch that makes its edge_index contiguous, in one call (the
+ * reference's own host reads: `.item()` in utils/ops.py:370-380 / the nonzero of connect/base_conn.py:79-89).  Spins on
+ * the PINNED result word until call `epoch` has stored it; unless the kernel refused the input (bit 31 of the word) the
+ * n = word & 0x7fffffff columns the kernel left in `col_scratch` are moved behind the n rows at the front of `out_rows`
+ * (capacity >= 2 n: edge_index' [2, n] contiguous afterwards).  The caller reads the word from the pinned memory. */
+int tgp_result_wait_pack_cols(const uint64_t* result, uint32_t epoch, const int64_t* col_scratch, int64_t* out_rows,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------
  * float64 value types of the HBM-bound operators (r4).  The reference's ATen ops compute model.double() inputs in fp64

@@ -228,16 +228,21 @@ def test_one_launch_pooling_rechecks_the_offsets_it_is_handed(dev, alias):
 
 
 @pytest.mark.parametrize("alias,kw", [("topk", dict(ratio=0.5)), ("graclus", {}), ("ndp", {})])
-@pytest.mark.parametrize("shape", ["small_graphs", "one_large_graph"])
-def test_sparse_poolers_hand_out_contiguous_exact_size_edge_lists(dev, alias, kw, shape):
+@pytest.mark.parametrize("shape", ["small_graphs", "small_graphs_own_tensors", "one_large_graph"])
+def test_sparse_poolers_hand_out_contiguous_exact_size_edge_lists(dev, alias, kw, shape, monkeypatch):
     """SURVEY 8(b) "Ownership" / connect/base_conn.py:103-112: every output is a NEW tensor of the pooled size.  r4's
     one-launch operators returned ``edge_index`` as a [2, E'] view of a capacity-E buffer (torch.equal ignores strides, so
     parity could not see it): ``.view(-1)`` failed where the reference's tensor works and E * 20 bytes stayed pinned.
-    Default now: contiguous, storage <= 2 x the logical size, on every sparse pooler and both size regimes; the view
-    layout is opt-in (``tgp.output_views``) and gives the same values."""
+    Since r5: contiguous [2, E'] on every sparse pooler and both size regimes; the view layout is opt-in
+    (``tgp.output_views``) and gives the same values.  Storage: <= 2 x the logical size -- except (r6) the one-launch
+    pooling of a batch of small graphs, whose four outputs are disjoint pieces of ONE allocation of at most
+    ``kernels._SPS_ARENA_BYTES`` (verdict r5 item 5: host time); ``TGP_SPS_ARENA=0`` gives them tensors of their own."""
     import tgp
+    from tgp import kernels
     from tgp.poolers import get_pooler
-    if shape == "small_graphs":
+    if shape == "small_graphs_own_tensors":
+        monkeypatch.setattr(kernels, "_SPS_ARENA", False)
+    if shape.startswith("small_graphs"):
         x, ei, ew, batch = _er_batch(200, 5, 60, 8, 7, dev)
     else:
         x, ei, ew, batch = _er_batch(1, 3000, 3000, 8, 8, dev)
@@ -254,11 +259,20 @@ def test_sparse_poolers_hand_out_contiguous_exact_size_edge_lists(dev, alias, kw
         assert e.is_contiguous() and e.stride() == (e.size(1), 1)
         flat = e.view(-1)                                  # the reference's tensor allows this
         assert flat.numel() == 2 * e.size(1)
-        assert e.untyped_storage().nbytes() <= max(2 * e.numel() * 8, 512)
+        shared = e.untyped_storage().data_ptr() == o.x.untyped_storage().data_ptr()
+        if shared:  # the arena: one allocation, bounded, the outputs disjoint
+            assert shape == "small_graphs" and alias != "ndp"
+            assert e.untyped_storage().nbytes() <= kernels._SPS_ARENA_BYTES
+            spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size())
+                           for t in (o.x, e, o.edge_weight, o.batch) if t is not None and t.numel())
+            assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+        else:
+            assert e.untyped_storage().nbytes() <= max(2 * e.numel() * 8, 512)
+            if o.edge_weight is not None:
+                assert o.edge_weight.untyped_storage().nbytes() <= max(2 * o.edge_weight.numel() * 4, 512)
+            assert o.x.untyped_storage().nbytes() <= max(2 * o.x.numel() * 4, 512)
         if o.edge_weight is not None:
             assert o.edge_weight.is_contiguous()
-            assert o.edge_weight.untyped_storage().nbytes() <= max(2 * o.edge_weight.numel() * 4, 512)
-        assert o.x.untyped_storage().nbytes() <= max(2 * o.x.numel() * 4, 512)
     assert torch.equal(out2.edge_index, out_v.edge_index) and torch.equal(out2.x, out_v.x)
     if out2.edge_weight is not None:
         assert torch.equal(out2.edge_weight, out_v.edge_weight)

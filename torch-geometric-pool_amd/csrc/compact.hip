@@ -90,3 +90,37 @@ extern "C" int tgp_copy_arrays(const void* const* src, void* const* dst, const i
                      stream, a);
   return check_launch("tgp_copy_arrays");
 }
+
+// r6 (fresh mini-batches: host time).  The host wait of a single-pass operator and the launch that makes its edge_index
+// contiguous, in ONE call: spin on the pinned result word until call `epoch` has stored it, then -- unless the kernel
+// refused the input (bit 31) -- move the n = word & 0x7fffffff columns the kernel left in `col_scratch` behind the n
+// rows it wrote at the front of `out_rows` (capacity 2 E: [2, n] contiguous afterwards; rows and weights are already
+// where they belong).  The caller reads the word itself from the pinned memory afterwards.
+extern "C" int tgp_result_wait_pack_cols(const uint64_t* result, uint32_t epoch, const int64_t* col_scratch,
+                                         int64_t* out_rows, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(result && epoch != 0, TGP_ERR_INVALID, "tgp_result_wait_pack_cols: bad argument");
+  uint64_t word = 0;
+  for (int64_t spins = 0;; ++spins) {
+    word = __atomic_load_n(result, __ATOMIC_ACQUIRE);
+    if ((word >> 34) == epoch) break;
+    if (spins > (1ll << 24)) {  // a stream that is busy with something long: wait for it properly, then look once more
+      TGP_REQUIRE(hipStreamSynchronize(stream) == hipSuccess, TGP_ERR_LAUNCH, "tgp_result_wait_pack_cols: the stream faulted");
+      word = __atomic_load_n(result, __ATOMIC_ACQUIRE);
+      TGP_REQUIRE((word >> 34) == epoch, TGP_ERR_LAUNCH,
+                  "tgp_result_wait_pack_cols: the kernel finished without storing its result word");
+      break;
+    }
+  }
+  if (word & 0x80000000ull) return TGP_OK;
+  const int64_t n = static_cast<int64_t>(word & 0x7fffffffull);
+  if (n == 0) return TGP_OK;
+  TGP_REQUIRE(col_scratch && out_rows, TGP_ERR_INVALID, "tgp_result_wait_pack_cols: null pointer");
+  CompactArgs a{};
+  a.src[0] = reinterpret_cast<const char*>(col_scratch); a.dst[0] = reinterpret_cast<char*>(out_rows + n); a.bytes[0] = n * 8;
+  int64_t blocks = (n * 8 / 16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(edges_compact_kernel, dim3(static_cast<unsigned>(blocks), 1), dim3(256), 0, stream, a);
+  return check_launch("tgp_result_wait_pack_cols");
+}

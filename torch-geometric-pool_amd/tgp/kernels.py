@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import os
 from typing import Optional, Sequence, Tuple
+from weakref import ref as _weakref
 
 import torch
 from torch import Tensor
@@ -183,6 +184,11 @@ def _edge_rows(edge_index: Tensor) -> Tuple[Tensor, Tensor]:
 # ------------------------------------------------------------------------- A1 + A2 + A4/A5 + A6, batches of small graphs
 _SPS_STATE: dict = {}  # (device index, stream handle) -> _SpsState
 _SPS_DECLINED: dict = {}
+_SPS_WORDS: dict = {}  # (graphs, mode) -> look-back words of the one-launch kernel (a native call otherwise)
+# r6: the exact-size outputs of the one-launch sparse pooling are carved out of ONE allocation of at most this many bytes
+# (what a retained x' can pin); TGP_SPS_ARENA=0: four allocations of their own, sized once the count has arrived
+_SPS_ARENA = os.environ.get("TGP_SPS_ARENA", "1") != "0"
+_SPS_ARENA_BYTES = 16 << 20
 _SPS_ONE_ALLOC_BYTES = 32 << 20  # outputs of the one-launch sparse pooling below this size share one allocation
 _SPS_GIVE_PTRS = os.environ.get("TGP_SPS_GIVE_PTRS", "1") != "0"  # A/B switch: hand the per-graph offsets to the kernel
 _GRACLUS_FUSED = os.environ.get("TGP_GRACLUS_FUSED", "1") != "0"  # A/B switch: one-launch GraclusSelect of small graphs
@@ -363,13 +369,12 @@ def _edge_ptr_memo(edge_index: Tensor, graph_ptr: Tensor) -> Optional[Tensor]:
 
 
 def _edge_ptr_remember(edge_index: Tensor, graph_ptr: Tensor, out: Tensor) -> None:
-    import weakref
-    if len(_EDGE_PTR) >= 16:
-        for k in [k for k, v in _EDGE_PTR.items() if v[0]() is None or v[3]() is None]:
-            del _EDGE_PTR[k]
-        while len(_EDGE_PTR) >= 16:
-            del _EDGE_PTR[next(iter(_EDGE_PTR))]
-    _EDGE_PTR[id(edge_index)] = (weakref.ref(edge_index), edge_index._version, id(graph_ptr), weakref.ref(graph_ptr), out)
+    key = id(edge_index)
+    if key in _EDGE_PTR:
+        del _EDGE_PTR[key]  # (re-inserted at the young end)
+    elif len(_EDGE_PTR) >= 16:
+        del _EDGE_PTR[next(iter(_EDGE_PTR))]  # the oldest entry (dicts keep insertion order): no scan on the hot path
+    _EDGE_PTR[key] = (_weakref(edge_index), edge_index._version, id(graph_ptr), _weakref(graph_ptr), out)
 
 
 def graph_edge_ptr(edge_index: Tensor, graph_ptr: Tensor) -> Tensor:
@@ -393,7 +398,7 @@ def graph_edge_ptr(edge_index: Tensor, graph_ptr: Tensor) -> Tensor:
 def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor],
                       assign_index: Tensor, weight: Optional[Tensor], num_supernodes: int,
                       mode: int, reduce_op: str = "sum", remove_self_loops: bool = True, want_batch: bool = True,
-                      assign_ptr: Optional[Tensor] = None, views: Optional[bool] = None):
+                      assign_ptr: Optional[Tensor] = None, views: Optional[bool] = None, checked: bool = False):
     """Sparse Reduce + Connect of a sorted batch of graphs of at most 64 nodes in ONE launch
     (reduce/base_reduce.py:14-53,141-155; connect/base_conn.py:79-89; the filters of utils/ops.py:370-380):
     ``(x_pool [K,F], batch_pool [K] or None, edge_index' [2,E'], edge_weight' [E'] or None)``, bit-identical to
@@ -406,42 +411,61 @@ def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_wei
     on the device does not hold (the caller takes the staged operators)."""
     if views is None:
         views = _output_views()
-    dev = N.require_device(x, graph_ptr, edge_index, edge_weight, assign_index, weight)
-    if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
-        raise ValueError("sparse_pool_small expects float32 x [N, F] with unit feature stride")
-    # (this wrapper sits in front of a ~10 us kernel: pointers by arithmetic instead of row views, no re-validation of
-    #  what SRCPooling.reduce_connect has checked)
+    # (this wrapper sits in front of a ~10 us kernel: pointers by arithmetic instead of row views; `checked`: the caller
+    #  -- SRCPooling.reduce_connect -- has validated x, edge_index and the weights' dtypes: no second pass over them)
+    if checked:
+        dev = x.device
+        if not (graph_ptr.is_cuda and assign_index.is_cuda and (weight is None or weight.is_cuda)):
+            dev = N.require_device(x, graph_ptr, edge_index, edge_weight, assign_index, weight)
+    else:
+        dev = N.require_device(x, graph_ptr, edge_index, edge_weight, assign_index, weight)
+        if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
+            raise ValueError("sparse_pool_small expects float32 x [N, F] with unit feature stride")
     ei = edge_index
-    if not (ei.dtype == torch.int64 and ei.dim() == 2 and ei.size(0) == 2 and (ei.stride(1) == 1 or ei.size(1) <= 1)):
+    es0, es1 = ei.stride() if ei.dim() == 2 else (0, 0)
+    if not (ei.dtype == torch.int64 and ei.dim() == 2 and ei.size(0) == 2 and (es1 == 1 or ei.size(1) <= 1)):
         ei = N.i64c(ei)
+        es0 = ei.stride(0)
     E = ei.size(1)
     row_p = ei.data_ptr()
-    col_p = row_p + 8 * ei.stride(0)
-    w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
+    col_p = row_p + 8 * es0
+    w = edge_weight
+    if w is not None and not (w.dim() == 1 and w.dtype == torch.float32 and (w.stride(0) == 1 or E <= 1)):
+        w = N.f32c(w.reshape(-1))
     ai = assign_index
-    if not (ai.dtype == torch.int64 and ai.dim() == 2 and ai.size(0) == 2 and (ai.stride(1) == 1 or ai.size(1) <= 1)):
+    as0, as1 = ai.stride() if ai.dim() == 2 else (0, 0)
+    if not (ai.dtype == torch.int64 and ai.dim() == 2 and ai.size(0) == 2 and (as1 == 1 or ai.size(1) <= 1)):
         ai = N.i64c(ai)
+        as0 = ai.stride(0)
     nnz = ai.size(1)
     ni_p = ai.data_ptr()
-    ci_p = ni_p + 8 * ai.stride(0)
-    gp = N.i64c(graph_ptr)
-    wt = None if weight is None else N.f32c(weight.reshape(-1))
-    n, F, K, B = x.size(0), x.size(1), int(num_supernodes), gp.numel() - 1
+    ci_p = ni_p + 8 * as0
+    gp = graph_ptr if (graph_ptr.dtype == torch.int64 and graph_ptr.is_contiguous()) else N.i64c(graph_ptr)
+    wt = weight
+    if wt is not None and not (wt.dim() == 1 and wt.dtype == torch.float32 and (wt.stride(0) == 1 or nnz <= 1)):
+        wt = N.f32c(wt.reshape(-1))
+    (n, F), K, B = x.shape, int(num_supernodes), gp.numel() - 1
     ecap = max(E, 1)
     # ONE allocation for all four outputs when they are small (a batch of small graphs: a few MB): only addresses are
     # needed to launch, and the typed views are made WHILE the kernel runs, behind the launch -- this wrapper sits in
     # front of a ~10 us kernel and every allocation in front of the launch is ~1.2 us the GPU idles.  (Large inputs keep
     # separate buffers: a retained x_pool must not pin tens of MB of edge capacity.)
-    ox = 0
-    ob = (ox + K * F * 4 + 15) & ~15
+    #   views (tgp.kernels.output_views):  x' | batch' | rows cap | cols cap | w cap        edge_index' = [2, n] of row
+    #                                      stride ecap, no copy
+    #   default (r6: the arena):           x' | batch' | rows cap + room for n cols | w cap | col scratch
+    #                                      the kernel's rows and weights ARE the outputs; one launch moves the n columns
+    #                                      behind the n rows once the count is known: edge_index' contiguous [2, n]
+    ob = (K * F * 4 + 15) & ~15
     oe = (ob + (K * 8 if want_batch else 0) + 15) & ~15
     ow = (oe + 2 * ecap * 8 + 15) & ~15
-    nbytes = (ow + (ecap * 4 if w is not None else 0) + 15) & ~15  # (viewed as int64 / float32 below)
-    one = views and nbytes <= _SPS_ONE_ALLOC_BYTES
-    if one:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    oc = (ow + (ecap * 4 if w is not None else 0) + 15) & ~15
+    arena = (not views) and _SPS_ARENA and E > 0 and oc + 8 * ecap <= _SPS_ARENA_BYTES
+    one = views and oc <= _SPS_ONE_ALLOC_BYTES
+    if one or arena:
+        buf = torch.empty((oc + (8 * ecap if arena else 0)) >> 3, dtype=torch.int64, device=dev)
         base = buf.data_ptr()
-        xp_p, bp_p, cap_p, cw_p = base + ox, (base + ob) if want_batch else None, base + oe, (base + ow) if w is not None else None
+        xp_p, bp_p, cap_p, cw_p = base, (base + ob) if want_batch else None, base + oe, (base + ow) if w is not None else None
+        col_out = base + oc if arena else cap_p + 8 * ecap
     elif not views:
         # exact outputs: x' and batch' are sized before the launch; the edges go through one capacity scratch buffer
         x_pool = torch.empty(K, F, dtype=torch.float32, device=dev)
@@ -450,15 +474,22 @@ def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_wei
         cap_p = scratch.data_ptr()
         cw_p = cap_p + 16 * ecap if w is not None else None
         xp_p, bp_p = x_pool.data_ptr(), N.ptr(batch_pool)
+        col_out = cap_p + 8 * ecap
     else:
         x_pool = torch.empty(K, F, dtype=torch.float32, device=dev)
         batch_pool = torch.empty(K, dtype=torch.int64, device=dev) if want_batch else None
         cap = torch.empty(2, ecap, dtype=torch.int64, device=dev)
         cap_w = None if w is None else torch.empty(ecap, dtype=torch.float32, device=dev)
         xp_p, bp_p, cap_p, cw_p = x_pool.data_ptr(), N.ptr(batch_pool), cap.data_ptr(), N.ptr(cap_w)
+        col_out = cap_p + 8 * ecap
     L = N.lib()
     st = N.stream_ptr(dev)
-    state = _sps_state(dev, st, L.tgp_sparse_pool_small_status_words(B, mode))
+    words = _SPS_WORDS.get((B, mode))
+    if words is None:
+        if len(_SPS_WORDS) > 256:
+            _SPS_WORDS.clear()
+        words = _SPS_WORDS[(B, mode)] = int(L.tgp_sparse_pool_small_status_words(B, mode))
+    state = _sps_state(dev, st, words)
     epoch = state.next_epoch()
     flags = (N.REMOVE_SELF_LOOPS if remove_self_loops else 0) | (N.EPS_FILTER if w is not None else 0)
     # per-graph offsets the caller side already has: the kernel skips its searches (and re-checks what it reads).  r5: an
@@ -475,29 +506,43 @@ def sparse_pool_small(x: Tensor, graph_ptr: Tensor, edge_index: Tensor, edge_wei
             aptr = assign_ptr if assign_ptr.is_contiguous() else assign_ptr.contiguous()
         else:
             eptr = None  # (mode 0 needs both tables)
+    pinned_p = state.pinned.data_ptr()
     N.check(L.tgp_sparse_pool_small_f32(x.data_ptr(), n, F, x.stride(0), gp.data_ptr(), B, N.ptr(eptr), N.ptr(aptr),
                                         N.ptr(eptr_out), row_p if E else None,
                                         col_p if E else None, N.ptr(w), E, ni_p, ci_p, N.ptr(wt),
                                         nnz, K, mode, N.REDUCE_OPS[reduce_op], flags, ops_eps(),
-                                        xp_p, bp_p, cap_p, cap_p + 8 * ecap, cw_p,
-                                        state.status.data_ptr(), state.status.numel(), state.pinned.data_ptr(), epoch,
+                                        xp_p, bp_p, cap_p, col_out, cw_p,
+                                        state.status.data_ptr(), state.status.numel(), pinned_p, epoch,
                                         st), "tgp_sparse_pool_small_f32")
-    if one:  # (behind the launch: the kernel is running)
-        f32, i64 = buf.view(torch.float32), buf.view(torch.int64)
-        x_pool = torch.as_strided(f32, (K, F), (F, 1), ox >> 2)
-        batch_pool = torch.as_strided(i64, (K,), (1,), ob >> 3) if want_batch else None
-    total = state.wait(epoch)  # the call's one host wait (the reference's .item() syncs)
+    if one or arena:  # (behind the launch: the kernel is running)
+        f32 = buf.view(torch.float32)
+        x_pool = torch.as_strided(f32, (K, F), (F, 1), 0)
+        batch_pool = torch.as_strided(buf, (K,), (1,), ob >> 3) if want_batch else None
+    if eptr_out is not None:  # (forgotten again below if the kernel refuses the input)
+        _edge_ptr_remember(edge_index, graph_ptr, eptr_out)
+    if arena:
+        # the call's one host wait (the reference's .item() syncs) and the column move, in one native call (r6)
+        N.check(L.tgp_result_wait_pack_cols(pinned_p, epoch, col_out, cap_p, st), "tgp_result_wait_pack_cols")
+        total = int(state.host[0])
+        if (total >> 34) != epoch:
+            raise N.TgpNativeError("tgp_result_wait_pack_cols returned before the result word of its call was stored")
+    else:
+        total = state.wait(epoch)
     if total & 0x80000000:
+        if eptr_out is not None:
+            _EDGE_PTR.pop(id(edge_index), None)
         _sps_remember_declined(edge_index)
         return None
-    if eptr_out is not None:
-        _edge_ptr_remember(edge_index, graph_ptr, eptr_out)
     n_out = total & 0x7FFFFFFF
+    if arena:
+        ei = torch.as_strided(buf, (2, n_out), (max(n_out, 1), 1), oe >> 3)
+        ew = torch.as_strided(f32, (n_out,), (1,), ow >> 2) if w is not None else None
+        return x_pool, batch_pool, ei, ew
     if not views:
-        ei, ew, _ = _compact_edges(L, st, dev, cap_p, cap_p + 8 * ecap, cw_p, torch.float32, None, n_out)
+        ei, ew, _ = _compact_edges(L, st, dev, cap_p, col_out, cw_p, torch.float32, None, n_out)
         return x_pool, batch_pool, ei, ew
     if one:
-        ei = torch.as_strided(i64, (2, n_out), (ecap, 1), oe >> 3)
+        ei = torch.as_strided(buf, (2, n_out), (ecap, 1), oe >> 3)
         ew = torch.as_strided(f32, (n_out,), (1,), ow >> 2) if w is not None else None
     else:
         ei = cap[:, :n_out]

@@ -141,17 +141,20 @@ class SRCPooling(torch.nn.Module):
         view of the kernel's capacity buffer instead: both rows contiguous, row stride E, no copy)."""
         c = self.connector
         if (self.cached or type(c) is not SparseConnect or type(self.reducer) is not BaseReduce or batch is None
-                or not isinstance(x, Tensor) or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32
-                or x.size(0) == 0 or x.size(1) == 0 or x.stride(1) != 1 or not isinstance(edge_index, Tensor)
-                or edge_index.is_sparse or edge_index.dim() != 2 or edge_index.size(0) != 2
-                or edge_index.dtype != torch.int64 or edge_index.size(1) == 0 or not so.is_sparse
-                or batch.dtype != torch.int64 or batch.numel() != x.size(0) or so.num_nodes != x.size(0)):
+                or not isinstance(x, Tensor) or not x.is_cuda or x.dtype != torch.float32
+                or not isinstance(edge_index, Tensor) or edge_index.is_sparse or edge_index.dtype != torch.int64):
+            return None
+        xs, es, s = x.shape, edge_index.shape, so.s  # (this sits in front of a ~10 us kernel: every call here is counted)
+        if (len(xs) != 2 or xs[0] == 0 or xs[1] == 0 or x.stride(1) != 1 or len(es) != 2 or es[0] != 2 or es[1] == 0
+                or not (isinstance(s, Tensor) and s.is_sparse) or batch.dtype != torch.int64 or batch.numel() != xs[0]
+                or s.size(-2) != xs[0]):
             return None
         ew = edge_weight
         if ew is not None:
-            if ew.dtype != torch.float32 or ew.numel() != edge_index.size(1):
+            if ew.dtype != torch.float32 or ew.numel() != es[1]:
                 return None
-            ew = ew.reshape(-1)
+            if ew.dim() != 1:
+                ew = ew.reshape(-1)
         weight = so.weight
         # training (r5, late): the same launch with the sparse Reduce's backward attached to x' (x and the assignment
         # weights -- TopK's scores -- get their gradients from it); edge weights that need a gradient keep the staged
@@ -167,8 +170,8 @@ class SRCPooling(torch.nn.Module):
         if (not info.is_sorted or info.num_graphs < 2 or info.max_nodes > K.sparse_pool_small_max_graph_nodes()
                 or K.sparse_pool_small_declined(edge_index)):
             return None
-        index = so.s.indices()  # [2, nnz]: (node_index, cluster_index)
-        nnz, n = index.size(1), so.num_nodes
+        index = s.indices()  # [2, nnz]: (node_index, cluster_index)
+        nnz, n = index.size(1), xs[0]
         if nnz < n:
             mode = 0  # sparse_connect's first branch: kept-node selection (base_conn.py:79-82)
         elif nnz == n:
@@ -177,17 +180,18 @@ class SRCPooling(torch.nn.Module):
             return None
         if weight is not None and weight.dtype != torch.float32:
             return None
+        num_supernodes = s.size(-1)
         out = K.sparse_pool_small(x.detach() if train else x, info.ptr, edge_index, ew, index,
-                                  weight.detach() if (train and weight is not None) else weight, so.num_supernodes, mode,
+                                  weight.detach() if (train and weight is not None) else weight, num_supernodes, mode,
                                   reduce_op=c.reduce_op, remove_self_loops=c.remove_self_loops,
-                                  assign_ptr=so.__dict__.get("_assign_ptr") if mode == 0 else None)
+                                  assign_ptr=so.__dict__.get("_assign_ptr") if mode == 0 else None, checked=True)
         if out is None:
             return None
         x_pool, batch_pool, ei, w_pool = out
         if train:
             x_pool = _SparseReduceFn.apply(x, weight, so, [x_pool])
-        ei, w_pool = _normalize_pooled_edges(ei, w_pool, so.num_supernodes, c.degree_norm, c.edge_weight_norm,
-                                             batch_pool)
+        if c.degree_norm or c.edge_weight_norm:
+            ei, w_pool = _normalize_pooled_edges(ei, w_pool, num_supernodes, c.degree_norm, c.edge_weight_norm, batch_pool)
         return x_pool, batch_pool, ei, w_pool
 
     def preprocessing(self, x: Tensor, edge_index, **kwargs):
