@@ -49,10 +49,10 @@ def _random_batch(seed):
     return sizes, k, f, x, ei, ew, batch
 
 
-def _check(dev, alias, seed, oracle_alias=None, node=None):
+def _check(dev, alias, seed, oracle_alias=None, node=None, made=None):
     import tgp_oracle as O
     from tgp.poolers import get_pooler
-    sizes, k, f, x, ei, ew, batch = _random_batch(seed)
+    sizes, k, f, x, ei, ew, batch = made or _random_batch(seed)
     what = f"seed {seed}: sizes {sizes} K {k} F {f} E {ei.size(1)} weighted {ew is not None}"
     torch.manual_seed(seed)
     pooler = get_pooler(alias, in_channels=f, k=k).to(dev).train()
@@ -116,3 +116,29 @@ def test_fuzz_rows_route(dev, monkeypatch, alias, seed):
 @pytest.mark.parametrize("alias", ["mincut_u", "diff_u"])
 def test_fuzz_unbatched_poolers(dev, alias, seed):
     _check(dev, alias, seed, oracle_alias=alias[:-2])
+
+
+def _edgeless_batch(sizes, edgeless, f, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    xs, eis, bs, off = [], [], [], 0
+    for gi, n in enumerate(sizes):
+        a = torch.triu(torch.rand(n, n, generator=g) < 6.0 / n, 1)
+        a = a | a.t()
+        if gi in edgeless:
+            a[:] = False
+        eis.append(a.nonzero().t() + off)
+        xs.append(torch.randn(n, f, generator=g))
+        bs.append(torch.full((n,), gi))
+        off += n
+    return sizes, k, f, torch.cat(xs), torch.cat(eis, 1), None, torch.cat(bs)
+
+
+@pytest.mark.parametrize("sizes,edgeless", [([90, 70, 120], {1}), ([90, 70], {0, 1}), ([90, 70, 120], {0}), ([90, 70, 120], {2})])
+@pytest.mark.parametrize("alias", ["mincut", "diff", "mincut_u", "diff_u"])
+@pytest.mark.parametrize("density", [0.0, 2.0])
+def test_graphs_without_edges(dev, monkeypatch, alias, sizes, edgeless, density):
+    """A graph without a single edge inside a batch, and a batch without any edge (E = 0): zero degree vectors, zero
+    S^T A S, MinCut's 0 / (0 + eps); both routes of the batched poolers and the unbatched ones, values and gradients."""
+    import tgp.poolers as P
+    monkeypatch.setattr(P, "_ROWS_ROUTE_DENSITY", density)
+    _check(dev, alias, 7, oracle_alias=alias.replace("_u", ""), made=_edgeless_batch(sizes, edgeless, 8, 12, 3))
