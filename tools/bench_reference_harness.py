@@ -69,7 +69,10 @@ def main():
     print(f"{'pooler':10s} {'forward ms':>11s} {'backward ms':>12s} {'fwd peak MB':>12s} {'bwd peak MB':>12s}")
     cfgs = {"topk": dict(in_channels=F_DIM, ratio=0.1), "graclus": dict(), "ndp": dict(),
             "diff": dict(in_channels=F_DIM, k=k), "mincut": dict(in_channels=F_DIM, k=k)}
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     for name, kw in cfgs.items():
+        if only is not None and name != only:
+            continue
         torch.manual_seed(seed)
         pooler = get_pooler(name, **kw).to(dev).train()
 

@@ -15,6 +15,7 @@ pmc() {  # name, counter, command...
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_${name}_$ctr -o run -- "$@" > /dev/null 2> $out/pmc_${name}_$ctr.err
   cp $(find $out/pmc_${name}_$ctr -name "*counter_collection.csv" | head -1) $out/pmc_${name}_$ctr.csv 2>/dev/null
 }
+( time python3 bench.py > $out/bench_default.json 2> $out/bench_default.err ) 2> $out/bench_default_time.txt
 python3 bench.py --steps 20 --warmup 5 > $out/bench_line.json 2> $out/bench_line.err
 TGP_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29617 python3 bench.py --workload topk_batch --secondary none --no-cpu-baseline --steps 50 2> $out/bench_topk_batch_rccl.err | grep '^{' > $out/bench_topk_batch_rccl.json
 TGP_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29618 python3 bench.py --workload c2 --secondary none --no-cpu-baseline --steps 50 2> $out/bench_c2_rccl.err | grep '^{' > $out/bench_c2_rccl.json
@@ -40,6 +41,10 @@ python3 tools/e2e_train_step.py mincut_c3 diff_c3 mincut_c2 diff_c2 topk_c3 grac
 # r6: the C2-sized training step, launch by launch, with bench.py's loss: the rows route (default for sparse inputs) and
 # the densifying route (TGP_ROWS_ROUTE=0, functions._PoolLargeFn), and the r5 operator-by-operator graph (TGP_FOLD_TRAINING=0)
 (echo "== default: un-padded rows route (functions._PoolUnbatchedFn)"; python3 tools/e2e_train_step.py mincut_c2 diff_c2 --sequence --bench-loss 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-170; echo; echo "== TGP_ROWS_ROUTE=0: densifying route (functions._PoolLargeFn)"; TGP_ROWS_ROUTE=0 python3 tools/e2e_train_step.py mincut_c2 diff_c2 --sequence --bench-loss 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-170; echo; echo "== TGP_ROWS_ROUTE=0 TGP_FOLD_TRAINING=0: operator by operator (r5)"; TGP_ROWS_ROUTE=0 TGP_FOLD_TRAINING=0 python3 tools/e2e_train_step.py mincut_c2 diff_c2 --bench-loss 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-170) > $out/train_step_c2.txt
+# r6: host time of the batched sparse poolers on NEW tensor objects (verdict r5 item 5), and the relabel pass a look-up-free
+# coalesce Connect would need (item 4)
+(for w in topk_batch_fresh graclus_batch_fresh e2e:topk_c3 e2e:graclus_c3 e2e:diff_c3; do python3 tools/host_profile_fresh.py $w 2>&1 | grep -v -i "amdgpu.ids\|warn" | head -16; echo; done; echo "== TGP_SPS_ARENA=0 (four allocations of their own + the compaction wrapper: r5 form)"; for w in topk_batch_fresh graclus_batch_fresh; do TGP_SPS_ARENA=0 python3 tools/host_profile_fresh.py $w 2>&1 | grep -v -i "amdgpu.ids\|warn" | head -1; done) > $out/host_time_fresh.txt
+python3 tools/coalesce_relabel_cost.py 2>&1 | grep -v -i "amdgpu.ids\|warn" > $out/coalesce_relabel_cost.txt
 python3 tools/profile_unbatched.py 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-150 > $out/unbatched_forward.txt
 (echo "== TGP_FOLD_TRAINING=0 (operator-by-operator graph, staged Reduce + Connect: r4 form)"; TGP_FOLD_TRAINING=0 python3 tools/e2e_train_step.py topk_c3 graclus_c3 --sequence 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-180; echo; echo "== default (r5, late)"; python3 tools/e2e_train_step.py topk_c3 graclus_c3 --sequence 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-180) > $out/sparse_train_steps.txt
 python3 tools/bench_select_fold.py 2>&1 | grep select > $out/select_fold.txt
