@@ -922,6 +922,61 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict
   }
 }
 
+
+// r6: T = A S for the dense poolers' rows route (K >= 64 floats per row of S, every row of S read by ~deg rows of A).
+// The sparse Reduce's gather-sum (tgp_reduce_sparse_f32, the r5 route) streams its rows with non-temporal loads and
+// hands consecutive row chunks to consecutive workgroups, i.e. round-robin over the eight XCDs: right for a Reduce (every
+// row read once), wrong here -- the rows of one graph re-read that graph's block of S (N_g x K floats), and spread over
+// all XCDs every private L2 sees all of S (16.8 MB at C2 against 4 MB of L2).  This kernel keeps a contiguous range of
+// rows -- whole graphs of a sorted batch -- on ONE XCD (the guide's bijective T1 remap of blockIdx: blocks with equal
+// blockIdx % 8 share an XCD; a speed choice only), loads S with the default cache policy, and has four row gathers of
+// a lane in flight.  Same products, same order of adds as spmm_csr_kernel / the Reduce route: bit-identical.
+template <int G>
+__global__ __launch_bounds__(256) void spmm_rows_vec4_kernel(const int32_t* __restrict__ row_ptr,
+                                                             const int64_t* __restrict__ col,
+                                                             const float* __restrict__ w, int64_t num_rows,
+                                                             const float* __restrict__ S, int64_t K,
+                                                             float* __restrict__ T, int rows_per_block) {
+  constexpr int RPB = 256 / G;
+  const int nwg = static_cast<int>(gridDim.x), orig = static_cast<int>(blockIdx.x);
+  const int xcd = orig % 8, qq = nwg / 8, rr = nwg % 8;
+  const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + orig / 8;
+  const int g = threadIdx.x % G, sub = threadIdx.x / G;
+  const int64_t r0 = static_cast<int64_t>(bid) * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > num_rows) r1 = num_rows;
+  for (int64_t i = r0 + sub; i < r1; i += RPB) {
+    const int32_t beg = row_ptr[i], end = row_ptr[i + 1];
+    for (int64_t f = 4 * g; f < K; f += 4 * G) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int32_t e0 = beg; e0 < end; e0 += 4) {
+        int64_t c[4];
+        float wv[4];
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int32_t e = e0 + q < end ? e0 + q : end - 1;  // (clamped: what it returns is dropped below)
+          c[q] = col[e];
+          wv[q] = w ? w[e] : 1.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(S + c[q] * K + f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool on = e0 + q < end;  // product rounded before the add, as the reference's two-step form
+          const float px = __fadd_rn(acc.x, __fmul_rn(wv[q], v[q].x)), py = __fadd_rn(acc.y, __fmul_rn(wv[q], v[q].y));
+          const float pz = __fadd_rn(acc.z, __fmul_rn(wv[q], v[q].z)), pw = __fadd_rn(acc.w, __fmul_rn(wv[q], v[q].w));
+          acc.x = on ? px : acc.x;
+          acc.y = on ? py : acc.y;
+          acc.z = on ? pz : acc.z;
+          acc.w = on ? pw : acc.w;
+        }
+      }
+      *reinterpret_cast<float4*>(T + i * K + f) = acc;
+    }
+  }
+}
+
 }  // namespace tgp
 
 using namespace tgp;
@@ -1453,8 +1508,29 @@ extern "C" int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, cons
   // T[i,:] = sum over row i of w[e] S[col[e],:] is the sparse Reduce with identity assignment order: wide rows take
   // its vectorised segmented gather-sum (N = 32768, E = 524288, K = 128: 91 -> 51 us, bit-identical); narrow rows
   // (K < 64) are faster with one lane per output element
-  if (K >= 64 && K % 4 == 0 && reinterpret_cast<uintptr_t>(S) % 16 == 0 && reinterpret_cast<uintptr_t>(T) % 16 == 0)
-    return tgp_reduce_sparse_f32(S, 0, K, K, col, w, row_ptr, nullptr, nnz, num_rows, T, stream_);
+  if (K >= 64 && K % 4 == 0 && reinterpret_cast<uintptr_t>(S) % 16 == 0 && reinterpret_cast<uintptr_t>(T) % 16 == 0) {
+    static const int legacy = getenv("TGP_SPMM_REDUCE_ROUTE") ? atoi(getenv("TGP_SPMM_REDUCE_ROUTE")) : 0;  // A/B switch
+    if (legacy) return tgp_reduce_sparse_f32(S, 0, K, K, col, w, row_ptr, nullptr, nnz, num_rows, T, stream_);
+    TGP_REQUIRE(num_rows < (1ll << 31), TGP_ERR_RANGE, "tgp_spmm_csr_f32: num_rows >= 2^31");
+    // r6: rows in contiguous chunks, a chunk = one workgroup, workgroups that share an XCD take neighbouring chunks
+    const int G = K <= 64 ? 16 : (K <= 128 ? 32 : 64);
+    const int rpb_unit = 256 / G;
+    static const int kIter = getenv("TGP_SPMM_ROWS_ITER") ? atoi(getenv("TGP_SPMM_ROWS_ITER")) : 1;
+    int rows_per_block = rpb_unit * (kIter > 0 ? kIter : 1);
+    int64_t blocks = (num_rows + rows_per_block - 1) / rows_per_block;
+    while (blocks > 256 * 32) {  // (very long lists: longer chunks instead of more workgroups)
+      rows_per_block *= 2;
+      blocks = (num_rows + rows_per_block - 1) / rows_per_block;
+    }
+    const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+    if (G == 16)
+      hipLaunchKernelGGL(spmm_rows_vec4_kernel<16>, grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, rows_per_block);
+    else if (G == 32)
+      hipLaunchKernelGGL(spmm_rows_vec4_kernel<32>, grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, rows_per_block);
+    else
+      hipLaunchKernelGGL(spmm_rows_vec4_kernel<64>, grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, rows_per_block);
+    return check_launch("tgp_spmm_csr_f32");
+  }
   int64_t blocks = (num_rows * K + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(spmm_csr_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, row_ptr, col, w,
