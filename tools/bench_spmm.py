@@ -44,7 +44,8 @@ def timed(fn, reps=200):
 
 tag = "reduce route (r5)" if os.environ.get("TGP_SPMM_REDUCE_ROUTE") == "1" else \
     f"row kernel, ITER={os.environ.get('TGP_SPMM_ROWS_ITER', '1')}"
-for B, n, deg, kk in ((32, 1024, 5.0, 128), (32, 1024, 5.0, 64), (32, 1024, 5.0, 256), (2048, 40, 2.8, 64), (4, 8192, 8.0, 128)):
+for B, n, deg, kk in ((32, 1024, 5.0, 128), (32, 1024, 5.0, 64), (32, 1024, 5.0, 256), (2048, 40, 2.8, 64), (4, 8192, 8.0, 128),
+                      (2048, 40, 2.8, 20), (2048, 40, 2.8, 32), (32, 1024, 5.0, 16), (32, 1024, 5.0, 8)):
     ei = batch(B, n, deg)
     N = B * n
     w = torch.rand(ei.size(1), device=dev, generator=g) + 0.5

@@ -1505,15 +1505,17 @@ extern "C" int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, cons
   TGP_REQUIRE(num_rows >= 0 && nnz >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_spmm_csr_f32: negative size");
   if (num_rows == 0 || K == 0) return TGP_OK;
   TGP_REQUIRE(row_ptr && T && (nnz == 0 || (col && S)), TGP_ERR_INVALID, "tgp_spmm_csr_f32: null pointer");
-  // T[i,:] = sum over row i of w[e] S[col[e],:] is the sparse Reduce with identity assignment order: wide rows take
-  // its vectorised segmented gather-sum (N = 32768, E = 524288, K = 128: 91 -> 51 us, bit-identical); narrow rows
-  // (K < 64) are faster with one lane per output element
-  if (K >= 64 && K % 4 == 0 && reinterpret_cast<uintptr_t>(S) % 16 == 0 && reinterpret_cast<uintptr_t>(T) % 16 == 0) {
+  // T[i,:] = sum over row i of w[e] S[col[e],:]: rows of 16-byte vectors (K % 4 == 0, K >= 16) take the XCD-grouped row
+  // kernel (r6: C2, K = 128: 40 -> 21 us against the r5 route through the sparse Reduce's gather-sum; 2048 graphs of 40
+  // nodes, K = 20 / 32: 20.9 / 31.1 -> 12.3 / 11.5 us against one lane per output element), bit-identical; other shapes
+  // one lane per output element
+  static const int kMinK = getenv("TGP_SPMM_ROWS_MIN_K") ? atoi(getenv("TGP_SPMM_ROWS_MIN_K")) : 16;
+  if (K >= kMinK && K % 4 == 0 && reinterpret_cast<uintptr_t>(S) % 16 == 0 && reinterpret_cast<uintptr_t>(T) % 16 == 0) {
     static const int legacy = getenv("TGP_SPMM_REDUCE_ROUTE") ? atoi(getenv("TGP_SPMM_REDUCE_ROUTE")) : 0;  // A/B switch
     if (legacy) return tgp_reduce_sparse_f32(S, 0, K, K, col, w, row_ptr, nullptr, nnz, num_rows, T, stream_);
     TGP_REQUIRE(num_rows < (1ll << 31), TGP_ERR_RANGE, "tgp_spmm_csr_f32: num_rows >= 2^31");
     // r6: rows in contiguous chunks, a chunk = one workgroup, workgroups that share an XCD take neighbouring chunks
-    const int G = K <= 64 ? 16 : (K <= 128 ? 32 : 64);
+    const int G = K <= 32 ? 8 : (K <= 64 ? 16 : (K <= 128 ? 32 : 64));
     const int rpb_unit = 256 / G;
     static const int kIter = getenv("TGP_SPMM_ROWS_ITER") ? atoi(getenv("TGP_SPMM_ROWS_ITER")) : 1;
     int rows_per_block = rpb_unit * (kIter > 0 ? kIter : 1);
@@ -1523,7 +1525,9 @@ extern "C" int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, cons
       blocks = (num_rows + rows_per_block - 1) / rows_per_block;
     }
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
-    if (G == 16)
+    if (G == 8)
+      hipLaunchKernelGGL(spmm_rows_vec4_kernel<8>, grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, rows_per_block);
+    else if (G == 16)
       hipLaunchKernelGGL(spmm_rows_vec4_kernel<16>, grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, rows_per_block);
     else if (G == 32)
       hipLaunchKernelGGL(spmm_rows_vec4_kernel<32>, grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, rows_per_block);
