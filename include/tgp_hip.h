@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10032 /* 1.0.1 of the reference, ABI revision 31 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols) */
+#define TGP_ABI_VERSION 10033 /* 1.0.1 of the reference, ABI revision 32 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -732,6 +732,10 @@ int tgp_rowptr_from_sorted_flag_i64(const int64_t* rows, int64_t n, int64_t num_
                                     void* stream);
 int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows, int64_t nnz,
                      const float* S, int64_t K, float* T, void* stream);
+/* r6: the same product with MinCut's degree term riding along (utils/losses.py:73-127): deg[i] = sum of row i's weights
+ * (entry count when w is NULL), q[i] = |S_i|^2 -- the outputs of tgp_edge_row_stats_f32 without its launch. */
+int tgp_spmm_csr_stats_f32(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows, int64_t nnz,
+                           const float* S, int64_t K, float* T, float* deg, float* q, void* stream);
 
 /* A8 alone: post-process a [B,K,K] pooled adjacency (src may equal dst).                */
 size_t tgp_postprocess_dense_workspace_bytes(int64_t B, int64_t K);

@@ -170,3 +170,27 @@ def test_unbatched_training_with_weight_gradients_keeps_the_operator_path(dev):
     assert not any("_PoolUnbatchedFn" in n for n in _node_names(out.x.grad_fn))
     (out.x.sum() + out.edge_index.sum() + sum(out.loss.values())).backward()
     assert w.grad is not None and torch.isfinite(w.grad).all()
+
+
+@pytest.mark.parametrize("n,k,weighted", [(300, 128, True), (777, 20, True), (500, 64, False), (260, 72, True), (90, 10, True)])
+def test_spmm_with_degree_stats_equals_the_two_launches(dev, n, k, weighted):
+    """r6: ``spmm_csr(want_stats=True)`` = T of ``spmm_csr`` bit for bit (same products, same order of adds) and the
+    (deg, q) of ``edge_row_stats`` at fp32 rounding (another summation order), on rows of 16-byte vectors (the row kernel)
+    and on shapes that take the scalar kernel + the stats launch (K = 10)."""
+    from tgp import kernels as K
+    g = torch.Generator().manual_seed(n + k)
+    a = torch.rand(n, n, generator=g) < 8.0 / n
+    a[n // 3] = False  # a row without entries
+    ei = a.nonzero().t().contiguous().to(dev)
+    w = (torch.rand(ei.size(1), generator=g) + 0.25).to(dev) if weighted else None
+    s = torch.softmax(torch.randn(n, k, generator=g), -1).to(dev)
+    rp = K.csr_offsets(ei, n)
+    t0 = K.spmm_csr(rp, ei, w, n, s)
+    d0, q0 = K.edge_row_stats(rp, w, s)
+    t1, d1, q1 = K.spmm_csr(rp, ei, w, n, s, want_stats=True)
+    assert torch.equal(t0, t1)
+    torch.testing.assert_close(d1, d0, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(q1, q0, rtol=1e-6, atol=1e-7)
+    ref = torch.zeros(n, k, dtype=torch.float64, device=dev).index_add_(
+        0, ei[0], s[ei[1]].double() * (1.0 if w is None else w.double()[:, None]))
+    torch.testing.assert_close(t1.double(), ref, rtol=1e-5, atol=1e-6)

@@ -931,12 +931,16 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict
 // rows -- whole graphs of a sorted batch -- on ONE XCD (the guide's bijective T1 remap of blockIdx: blocks with equal
 // blockIdx % 8 share an XCD; a speed choice only), loads S with the default cache policy, and has four row gathers of
 // a lane in flight.  Same products, same order of adds as spmm_csr_kernel / the Reduce route: bit-identical.
-template <int G>
+// STATS (MinCut's degree term, utils/losses.py:73-127): also deg[i] = the row's weight sum (entry count without weights)
+// and q[i] = |S_i|^2 -- the row's entries are in hand anyway, S_i is 16 more bytes per lane (tgp_edge_row_stats_f32 was a
+// launch of its own for these).
+template <int G, bool STATS>
 __global__ __launch_bounds__(256) void spmm_rows_vec4_kernel(const int32_t* __restrict__ row_ptr,
                                                              const int64_t* __restrict__ col,
                                                              const float* __restrict__ w, int64_t num_rows,
                                                              const float* __restrict__ S, int64_t K,
-                                                             float* __restrict__ T, int rows_per_block) {
+                                                             float* __restrict__ T, int rows_per_block,
+                                                             float* __restrict__ deg, float* __restrict__ qout) {
   constexpr int RPB = 256 / G;
   const int nwg = static_cast<int>(gridDim.x), orig = static_cast<int>(blockIdx.x);
   const int xcd = orig % 8, qq = nwg / 8, rr = nwg % 8;
@@ -947,8 +951,14 @@ __global__ __launch_bounds__(256) void spmm_rows_vec4_kernel(const int32_t* __re
   if (r1 > num_rows) r1 = num_rows;
   for (int64_t i = r0 + sub; i < r1; i += RPB) {
     const int32_t beg = row_ptr[i], end = row_ptr[i + 1];
+    [[maybe_unused]] float dsum = 0.f, qsum = 0.f;
     for (int64_t f = 4 * g; f < K; f += 4 * G) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (STATS) {
+        const float4 si = *reinterpret_cast<const float4*>(S + i * K + f);
+        qsum = fmaf(si.x, si.x, qsum); qsum = fmaf(si.y, si.y, qsum);
+        qsum = fmaf(si.z, si.z, qsum); qsum = fmaf(si.w, si.w, qsum);
+      }
       for (int32_t e0 = beg; e0 < end; e0 += 4) {
         int64_t c[4];
         float wv[4];
@@ -970,9 +980,20 @@ __global__ __launch_bounds__(256) void spmm_rows_vec4_kernel(const int32_t* __re
           acc.y = on ? py : acc.y;
           acc.z = on ? pz : acc.z;
           acc.w = on ? pw : acc.w;
+          if constexpr (STATS) {
+            if (f == 4 * g && on) dsum += wv[q];  // (every lane of the group holds the same sum)
+          }
         }
       }
       *reinterpret_cast<float4*>(T + i * K + f) = acc;
+    }
+    if constexpr (STATS) {
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) qsum += __shfl_xor(qsum, o, 64);
+      if (g == 0) {
+        deg[i] = dsum;
+        qout[i] = qsum;
+      }
     }
   }
 }
@@ -1499,12 +1520,16 @@ extern "C" int tgp_rowptr_from_sorted_i64(const int64_t* rows, int64_t n, int64_
   return check_launch("tgp_rowptr_from_sorted_i64");
 }
 
-extern "C" int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows,
-                                int64_t nnz, const float* S, int64_t K, float* T, void* stream_) {
+extern "C" int tgp_edge_row_stats_f32(const int32_t* row_ptr, const float* w, const float* S, int64_t N, int64_t K,
+                                      float* deg, float* q, void* stream_);
+
+// deg / q: optional outputs (both or none) of the STATS form
+static int spmm_csr_impl(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows, int64_t nnz,
+                         const float* S, int64_t K, float* T, float* deg, float* q, void* stream_, const char* what) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  TGP_REQUIRE(num_rows >= 0 && nnz >= 0 && K >= 0, TGP_ERR_INVALID, "tgp_spmm_csr_f32: negative size");
+  TGP_REQUIRE(num_rows >= 0 && nnz >= 0 && K >= 0, TGP_ERR_INVALID, "%s: negative size", what);
   if (num_rows == 0 || K == 0) return TGP_OK;
-  TGP_REQUIRE(row_ptr && T && (nnz == 0 || (col && S)), TGP_ERR_INVALID, "tgp_spmm_csr_f32: null pointer");
+  TGP_REQUIRE(row_ptr && T && (nnz == 0 || (col && S)) && (!deg == !q) && (!deg || S), TGP_ERR_INVALID, "%s: null pointer", what);
   // T[i,:] = sum over row i of w[e] S[col[e],:]: rows of 16-byte vectors (K % 4 == 0, K >= 16) take the XCD-grouped row
   // kernel (r6: C2, K = 128: 40 -> 21 us against the r5 route through the sparse Reduce's gather-sum; 2048 graphs of 40
   // nodes, K = 20 / 32: 20.9 / 31.1 -> 12.3 / 11.5 us against one lane per output element), bit-identical; other shapes
@@ -1512,8 +1537,11 @@ extern "C" int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, cons
   static const int kMinK = getenv("TGP_SPMM_ROWS_MIN_K") ? atoi(getenv("TGP_SPMM_ROWS_MIN_K")) : 16;
   if (K >= kMinK && K % 4 == 0 && reinterpret_cast<uintptr_t>(S) % 16 == 0 && reinterpret_cast<uintptr_t>(T) % 16 == 0) {
     static const int legacy = getenv("TGP_SPMM_REDUCE_ROUTE") ? atoi(getenv("TGP_SPMM_REDUCE_ROUTE")) : 0;  // A/B switch
-    if (legacy) return tgp_reduce_sparse_f32(S, 0, K, K, col, w, row_ptr, nullptr, nnz, num_rows, T, stream_);
-    TGP_REQUIRE(num_rows < (1ll << 31), TGP_ERR_RANGE, "tgp_spmm_csr_f32: num_rows >= 2^31");
+    if (legacy) {
+      const int rc = tgp_reduce_sparse_f32(S, 0, K, K, col, w, row_ptr, nullptr, nnz, num_rows, T, stream_);
+      return (rc == TGP_OK && deg) ? tgp_edge_row_stats_f32(row_ptr, w, S, num_rows, K, deg, q, stream_) : rc;
+    }
+    TGP_REQUIRE(num_rows < (1ll << 31), TGP_ERR_RANGE, "%s: num_rows >= 2^31", what);
     // r6: rows in contiguous chunks, a chunk = one workgroup, workgroups that share an XCD take neighbouring chunks
     const int G = K <= 32 ? 8 : (K <= 64 ? 16 : (K <= 128 ? 32 : 64));
     const int rpb_unit = 256 / G;
@@ -1525,19 +1553,38 @@ extern "C" int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, cons
       blocks = (num_rows + rows_per_block - 1) / rows_per_block;
     }
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
-    if (G == 8)
-      hipLaunchKernelGGL(spmm_rows_vec4_kernel<8>, grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, rows_per_block);
-    else if (G == 16)
-      hipLaunchKernelGGL(spmm_rows_vec4_kernel<16>, grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, rows_per_block);
-    else if (G == 32)
-      hipLaunchKernelGGL(spmm_rows_vec4_kernel<32>, grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, rows_per_block);
-    else
-      hipLaunchKernelGGL(spmm_rows_vec4_kernel<64>, grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, rows_per_block);
-    return check_launch("tgp_spmm_csr_f32");
+#define TGP_SPMM_ROWS(GG)                                                                                              \
+  do {                                                                                                                 \
+    if (deg)                                                                                                           \
+      hipLaunchKernelGGL((spmm_rows_vec4_kernel<GG, true>), grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, \
+                         rows_per_block, deg, q);                                                                      \
+    else                                                                                                               \
+      hipLaunchKernelGGL((spmm_rows_vec4_kernel<GG, false>), grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, \
+                         rows_per_block, deg, q);                                                                      \
+  } while (0)
+    if (G == 8) TGP_SPMM_ROWS(8);
+    else if (G == 16) TGP_SPMM_ROWS(16);
+    else if (G == 32) TGP_SPMM_ROWS(32);
+    else TGP_SPMM_ROWS(64);
+#undef TGP_SPMM_ROWS
+    return check_launch(what);
   }
   int64_t blocks = (num_rows * K + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(spmm_csr_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, row_ptr, col, w,
                      num_rows, S, K, T);
-  return check_launch("tgp_spmm_csr_f32");
+  const int rc = check_launch(what);
+  return (rc == TGP_OK && deg) ? tgp_edge_row_stats_f32(row_ptr, w, S, num_rows, K, deg, q, stream_) : rc;
+}
+
+extern "C" int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows,
+                                int64_t nnz, const float* S, int64_t K, float* T, void* stream_) {
+  return spmm_csr_impl(row_ptr, col, w, num_rows, nnz, S, K, T, nullptr, nullptr, stream_, "tgp_spmm_csr_f32");
+}
+
+extern "C" int tgp_spmm_csr_stats_f32(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows,
+                                      int64_t nnz, const float* S, int64_t K, float* T, float* deg, float* q,
+                                      void* stream_) {
+  TGP_REQUIRE(deg && q, TGP_ERR_INVALID, "tgp_spmm_csr_stats_f32: null output");
+  return spmm_csr_impl(row_ptr, col, w, num_rows, nnz, S, K, T, deg, q, stream_, "tgp_spmm_csr_stats_f32");
 }

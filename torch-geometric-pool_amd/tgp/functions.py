@@ -1060,14 +1060,17 @@ class _PoolUnbatchedFn(torch.autograd.Function):
             else N.f32c(s_given.detach())
         Kc = s.size(1)
         B = ptr.numel() - 1
-        t = K.spmm_csr(row_ptr, ei, ew, n, s)
+        deg = q = None
+        if mode == 1:  # MinCut: out-degrees and |S_i|^2 ride along with T = A S
+            t, deg, q = K.spmm_csr(row_ptr, ei, ew, n, s, want_stats=True)
+        else:
+            t = K.spmm_csr(row_ptr, ei, ew, n, s)
         raw, x_pool, gram = K.segment_gemm_tn3(s, [t, xd, s], ptr, max_nodes, transpose0=transposed)
         adj_pool = K.postprocess_dense(raw, flags)
         empty = s.new_empty(0)
         la, lb = s.new_empty(0), s.new_empty(0)
-        deg = den = lossv = stats = None
+        den = lossv = stats = None
         if mode == 1:
-            deg, q = K.edge_row_stats(row_ptr, ew, s)  # out-degrees and |S_i|^2
             if transposed:  # den = sum_i indeg_i q_i = sum_i (A q)_i: one SpMV over the same row-sorted list
                 aq = K.spmm_csr(row_ptr, ei, ew, n, q.view(n, 1)).view(n)
                 den, terms, stats, both = K.mincut_terms_fused(raw, gram, aq, None, ptr=ptr, want_means=True)

@@ -2350,13 +2350,24 @@ def csr_offsets(edge_index: Tensor, num_rows: int) -> Tensor:
     return rowptr_from_sorted(row, num_rows, out)
 
 
-def spmm_csr(row_ptr: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], num_rows: int, s: Tensor) -> Tensor:
-    """T = A S for a row-sorted coalesced float32 list whose CSR offsets the caller holds (one launch)."""
+def spmm_csr(row_ptr: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], num_rows: int, s: Tensor,
+             want_stats: bool = False):
+    """T = A S for a row-sorted coalesced float32 list whose CSR offsets the caller holds (one launch).
+    ``want_stats``: ``(T, deg, q)`` -- the row sums of the weights and |S_i|^2 from the same launch
+    (:func:`edge_row_stats` without its own pass; needs num_rows == S rows)."""
     dev = N.require_device(edge_index, edge_weight, s, row_ptr)
     _, col = _edge_rows(edge_index)
     s = N.f32c(s)
     w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
     out = torch.empty(num_rows, s.size(1), dtype=torch.float32, device=dev)
+    if want_stats:
+        if s.size(0) != num_rows:
+            raise ValueError("spmm_csr(want_stats=True) needs a square A: one row of S per row of A")
+        dq = torch.empty(2, num_rows, dtype=torch.float32, device=dev)
+        N.check(N.lib().tgp_spmm_csr_stats_f32(N.ptr(row_ptr), N.ptr(col), N.ptr(w), num_rows, col.numel(), N.ptr(s),
+                                               s.size(1), N.ptr(out), dq.data_ptr(), dq.data_ptr() + 4 * num_rows,
+                                               N.stream_ptr(dev)), "tgp_spmm_csr_stats_f32")
+        return out, dq[0], dq[1]
     N.check(N.lib().tgp_spmm_csr_f32(N.ptr(row_ptr), N.ptr(col), N.ptr(w), num_rows, col.numel(), N.ptr(s), s.size(1),
                                      N.ptr(out), N.stream_ptr(dev)), "tgp_spmm_csr_f32")
     return out

@@ -550,10 +550,12 @@ class _DenseMLPPooling(DenseSRCPooling):
             s_flat = s_out
             both = pair
         else:
-            t = K.spmm_csr(row_ptr, ei, w_used, n, s)
+            if mincut:  # out-degrees and |S_i|^2 ride along with T = A S
+                t, deg, q = K.spmm_csr(row_ptr, ei, w_used, n, s, want_stats=True)
+            else:
+                t = K.spmm_csr(row_ptr, ei, w_used, n, s)
             raw, x_pool, gram = K.segment_gemm_tn3(s, [t, x, s], ptr, max_nodes, transpose0=transposed)
             if mincut:
-                deg, q = K.edge_row_stats(row_ptr, w_used, s)
                 if transposed:  # in-degrees: sum_i indeg_i q_i = sum_i (A q)_i
                     aq = K.spmm_csr(row_ptr, ei, w_used, n, q.view(n, 1)).view(n)
                     both = K.mincut_terms_fused(raw, gram, aq, None, ptr=ptr, want_means=True)[3]
