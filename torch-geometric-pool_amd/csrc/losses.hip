@@ -34,6 +34,28 @@ __device__ __forceinline__ float block_sum_t(float v, float* sh) {  // sh: T / 6
   return t;
 }
 
+// four sums behind ONE pair of barriers (sh: 4 * T / 64 floats); each sum in the order block_sum_t adds it
+template <int T>
+__device__ __forceinline__ void block_sum4_t(float (&v)[4], float* sh) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sh[q * (T / 64) + (threadIdx.x >> 6)] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < T / 64; ++w) t += sh[q * (T / 64) + w];
+    v[q] = t;
+  }
+}
+
 __device__ __forceinline__ float ent_term(float s, float eps) { return -s * logf(s + eps); }
 
 __global__ __launch_bounds__(256) void entropy_partial_kernel(const float* __restrict__ S, int64_t n, float eps,
@@ -403,7 +425,7 @@ __global__ __launch_bounds__(T) void mincut_tail2_kernel(const float* __restrict
                                                            float* __restrict__ out, float* __restrict__ stats,
                                                            const int64_t* __restrict__ ptr,
                                                            unsigned int* __restrict__ ticket, float* __restrict__ means) {
-  __shared__ float sh[T / 64];
+  __shared__ float sh[4 * (T / 64)];
   __shared__ bool s_last;
   const int b = blockIdx.x;
   const float* R = raw + static_cast<int64_t>(b) * K * K;
@@ -414,23 +436,55 @@ __global__ __launch_bounds__(T) void mincut_tail2_kernel(const float* __restrict
   const float* d = deg + lo;
   const float* qq = q + lo;
   float dn = 0.f, tr = 0.f, sq = 0.f, trg = 0.f;
+  // r6 (late): the Gram matrix stays in registers between its two sweeps when it fits (K <= 128 at 1024 threads), all
+  // its loads requested before the first is used, and the four sums share one pair of barriers (18 -> 15 us at B = 32,
+  // K = 128: the kernel is a chain of dependent round trips and barriers on B workgroups); same adds in the same order
+  constexpr int GV = 16;
+  const int KK = K * K;
+  const bool inreg = KK <= GV * T;
+  float gv[GV];
+  if (inreg) {
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int i = threadIdx.x + j * T;
+      gv[j] = i < KK ? G[i] : 0.f;
+    }
+  }
   if (q) { for (int i = threadIdx.x; i < N; i += T) dn = fmaf(d[i], qq[i], dn); }
   else { for (int i = threadIdx.x; i < N; i += T) dn += d[i]; }  // (deg already carries the factor: (A q)_i)
   for (int i = threadIdx.x; i < K; i += T) {
     tr += R[static_cast<int64_t>(i) * K + i];
     trg += G[static_cast<int64_t>(i) * K + i];
   }
-  for (int i = threadIdx.x; i < K * K; i += T) sq = fmaf(G[i], G[i], sq);
-  dn = block_sum_t<T>(dn, sh);
-  tr = block_sum_t<T>(tr, sh);
-  trg = block_sum_t<T>(trg, sh);
-  sq = block_sum_t<T>(sq, sh);
+  if (inreg) {
+#pragma unroll
+    for (int j = 0; j < GV; ++j)
+      if (threadIdx.x + j * T < KK) sq = fmaf(gv[j], gv[j], sq);
+  } else {
+    for (int i = threadIdx.x; i < KK; i += T) sq = fmaf(G[i], G[i], sq);
+  }
+  {
+    float four[4] = {dn, tr, trg, sq};
+    block_sum4_t<T>(four, sh);
+    dn = four[0]; tr = four[1]; trg = four[2]; sq = four[3];
+  }
   const float n = sqrtf(sq);
   const float t = 1.0f / sqrtf(static_cast<float>(K));
   float acc = 0.f;
-  for (int i = threadIdx.x; i < K * K; i += T) {
-    const float y = G[i] / n - ((i / K == i % K) ? t : 0.f);
-    acc = fmaf(y, y, acc);
+  if (inreg) {
+#pragma unroll
+    for (int j = 0; j < GV; ++j) {
+      const int i = threadIdx.x + j * T;
+      if (i < KK) {
+        const float y = gv[j] / n - ((i / K == i % K) ? t : 0.f);
+        acc = fmaf(y, y, acc);
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < KK; i += T) {
+      const float y = G[i] / n - ((i / K == i % K) ? t : 0.f);
+      acc = fmaf(y, y, acc);
+    }
   }
   acc = block_sum_t<T>(acc, sh);
   if (threadIdx.x == 0) {
