@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10033 /* 1.0.1 of the reference, ABI revision 32 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32) */
+#define TGP_ABI_VERSION 10034 /* 1.0.1 of the reference, ABI revision 33 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32; tgp_segment_gemm_tn3_post_f32) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -689,6 +689,15 @@ size_t tgp_segment_gemm_tn3_workspace_bytes(int64_t B, int64_t K, int64_t F0, in
 int tgp_segment_gemm_tn3_f32(const float* S, const float* Y0, int64_t F0, const float* Y1, int64_t F1, const float* Y2,
                              int64_t F2, const int64_t* ptr, float* C0, float* C1, float* C2, int64_t B, int64_t Ntot,
                              int64_t K, int64_t max_nodes, int transpose0, void* ws, size_t ws_bytes, void* stream);
+/* r6: the same products (Y0 must be [Ntot,K]: the first output is raw = S^T Y0 [B,K,K]) and raw's post-processing
+ * (utils/ops.py:282-335; flags = TGP_REMOVE_SELF_LOOPS | TGP_DEGREE_NORM | ..., eps its degree clamp) -> adj_pool [B,K,K]
+ * in one call: for 64 < K <= 176 the post-processing launch sums the slabs of all three products itself (two launches in
+ * all); otherwise the combine launch and the post-processing kernels of that size follow the product. */
+size_t tgp_segment_gemm_tn3_post_workspace_bytes(int64_t B, int64_t K, int64_t F1, int64_t F2, int64_t max_nodes);
+int tgp_segment_gemm_tn3_post_f32(const float* S, const float* Y0, const float* Y1, int64_t F1, const float* Y2, int64_t F2,
+                                  const int64_t* ptr, float* raw, float* C1, float* C2, float* adj_pool, int64_t B,
+                                  int64_t Ntot, int64_t K, int64_t max_nodes, int transpose0, int flags, float eps,
+                                  void* ws, size_t ws_bytes, void* stream);
 int tgp_edge_row_stats_f32(const int32_t* row_ptr, const float* w, const float* S, int64_t N, int64_t K, float* deg,
                            float* q, void* stream);
 /* the two segment products with explicit row strides (operands that are column blocks of a wider buffer: the unbatched

@@ -954,6 +954,90 @@ extern "C" int tgp_segment_gemm_tn3_f32(const float* S, const float* Y0, int64_t
   return check_launch("tgp_segment_gemm_tn3_f32");
 }
 
+// r6: the same three products with the post-processing of the first one (raw = S^T (A S) -> adj_pool, utils/ops.py:282-335)
+// behind them in ONE more launch: for 64 < K <= 176 the workgroup that post-processes a graph sums that graph's raw
+// slabs itself (post_lds_kernel) and the X' / Gram slabs are summed by extra workgroups of the same launch -- the
+// combine launch and the re-read of raw are gone (mincut_u / diff_u forward at C2: 3 -> 2 launches behind the product,
+// -6 us).  Other K: the combine launch + the post-processing kernels of that size.  Same adds in the same (slab) order.
+extern "C" size_t tgp_segment_gemm_tn3_post_workspace_bytes(int64_t B, int64_t K, int64_t F1, int64_t F2, int64_t max_nodes) {
+  if (B <= 0 || K <= 0) return 256;
+  return tgp_segment_gemm_tn3_workspace_bytes(B, K, K, F1, F2, max_nodes) + align_up(post_ws_floats(B, K) * 4) + 256;
+}
+
+extern "C" int tgp_segment_gemm_tn3_post_f32(const float* S, const float* Y0, const float* Y1, int64_t F1, const float* Y2,
+                                             int64_t F2, const int64_t* ptr, float* raw, float* C1, float* C2,
+                                             float* adj_pool, int64_t B, int64_t Ntot, int64_t K, int64_t max_nodes,
+                                             int transpose0, int flags, float eps, void* ws, size_t ws_bytes,
+                                             void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && Ntot >= 0 && K >= 0 && F1 >= 0 && F2 >= 0 && (F1 > 0 || F2 == 0), TGP_ERR_INVALID,
+              "tgp_segment_gemm_tn3_post_f32: bad sizes (right-hand sides are filled front to back)");
+  if (B == 0 || K == 0) return TGP_OK;
+  TGP_REQUIRE(ptr && raw && adj_pool && (F1 == 0 || C1) && (F2 == 0 || C2) &&
+                  (Ntot == 0 || (S && Y0 && (F1 == 0 || Y1) && (F2 == 0 || Y2))),
+              TGP_ERR_INVALID, "tgp_segment_gemm_tn3_post_f32: null pointer");
+  TGP_REQUIRE(Ntot < (1ll << 31) && K <= 16000 && B < 65536 && F1 < (1ll << 31) && F2 < (1ll << 31), TGP_ERR_RANGE,
+              "tgp_segment_gemm_tn3_post_f32: too large");
+  TGP_REQUIRE(ws && ws_bytes >= tgp_segment_gemm_tn3_post_workspace_bytes(B, K, F1, F2, max_nodes), TGP_ERR_WORKSPACE,
+              "tgp_segment_gemm_tn3_post_f32: workspace too small");
+  const int64_t span = max_nodes > 0 ? max_nodes : Ntot;
+  const int splits = segment3_splits(B, K, K, F1, F2, span);
+  const float* Y[3] = {Y0, Y1, Y2};
+  float* C[3] = {raw, C1, C2};
+  const int64_t fs[3] = {K, F1, F2};
+  Carver cv(ws);
+  GemmArgs g{};
+  g.A = S; g.lda = K; g.sA = 0;
+  g.M = static_cast<int>(K); g.Kd = static_cast<int>(Ntot);
+  Combine3Args ca{};
+  ca.splits = splits;
+  ca.transpose0 = transpose0 ? 1 : 0;
+  ca.K = static_cast<int>(K);
+  float* slab[3] = {nullptr, nullptr, nullptr};
+  for (int j = 0; j < 3; ++j) {
+    if (fs[j] <= 0) continue;
+    slab[j] = cv.take<float>(static_cast<size_t>(B) * splits * K * fs[j]);
+    g.rhs[j] = GemmRhs{Y[j], slab[j], static_cast<int>(fs[j]), fs[j], fs[j], 0, static_cast<long>(splits) * K * fs[j], K * fs[j]};
+    ca.src[j] = slab[j]; ca.dst[j] = C[j]; ca.total[j] = K * fs[j];
+  }
+  float* postws = cv.take<float>(post_ws_floats(B, K));
+  g.splits = splits;
+  int64_t kps = ((span + splits - 1) / splits + BK - 1) / BK * BK;
+  if (kps < BK) kps = BK;
+  g.k_per_split = static_cast<int>(kps);
+  g.k_ptr = ptr;
+  g.force_bm = 64; g.force_bn = 64;
+  launch_gemm<true>(g, static_cast<int>(B), stream);
+  PostArgs q{};
+  q.K = static_cast<int>(K); q.flags = flags; q.eps = eps; q.dst = adj_pool; q.ld_src = K;
+  bool folded = false;
+  if (transpose0) {  // raw leaves the combine transposed; the post-processing then reads it as a finished matrix
+    q.src = raw; q.splits = 1; q.s_split = 0; q.s_batch = K * K; q.raw = nullptr;
+  } else {
+    q.src = slab[0]; q.splits = splits; q.s_split = K * K; q.s_batch = static_cast<long>(splits) * K * K; q.raw = raw;
+    ca.total[0] = 0;  // (summed by the post-processing itself)
+  }
+  long max_total = 0;
+  for (int j = 0; j < 3; ++j)
+    if (ca.total[j] > max_total) max_total = ca.total[j];
+  auto combine = [&]() {
+    if (max_total == 0) return;
+    int gx = static_cast<int>((max_total + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(combine_slabs3_kernel, dim3(gx, static_cast<unsigned>(B), 3), dim3(256), 0, stream, ca);
+  };
+  if (transpose0) {
+    combine();
+    launch_post(q, B, postws, stream);
+  } else {
+    XCombineArgs x1{slab[1], splits, K * F1, static_cast<long>(splits) * K * F1, K * F1, C1, 0};
+    XCombineArgs x2{slab[2], splits, K * F2, static_cast<long>(splits) * K * F2, K * F2, C2, 0};
+    folded = launch_post(q, B, postws, stream, F1 > 0 ? &x1 : nullptr, F2 > 0 ? &x2 : nullptr);
+    if (!folded) combine();
+  }
+  return check_launch("tgp_segment_gemm_tn3_post_f32");
+}
+
 // Row-side counterpart (lift/base_lift.py:138-247 on an un-padded batch; backward of the products above):
 // C[rows of graph b] = A[rows of graph b] Bm[b], A [Ntot,Kd], Bm [B,Kd,Nc], C [Ntot,Nc]; one launch.
 extern "C" int tgp_segment_gemm_nn_f32(const float* A, const float* Bm, const int64_t* ptr, float* C, int64_t B,

@@ -289,11 +289,15 @@ struct XCombineArgs {
   const float* src; int splits; long s_split, s_batch, total; float* dst; int blocks_per_graph;
 };
 
-__global__ __launch_bounds__(1024) void post_lds_kernel(PostArgs p, int B, XCombineArgs xc) {
+__global__ __launch_bounds__(1024) void post_lds_kernel(PostArgs p, int B, XCombineArgs xc, XCombineArgs xc2) {
   extern __shared__ __attribute__((aligned(16))) float m[];
   const int tid = threadIdx.x;
-  if (static_cast<int>(blockIdx.x) >= B) {  // ---- X' slab combine ------------------------------------------
-    const int xb = blockIdx.x - B;
+  if (static_cast<int>(blockIdx.x) >= B) {  // ---- X' slab combine (r6: and a second one, the Gram slabs) -----------
+    int xb = blockIdx.x - B;
+    if (xb >= B * xc.blocks_per_graph) {
+      xb -= B * xc.blocks_per_graph;
+      xc = xc2;
+    }
     const int b = xb / xc.blocks_per_graph, part = xb - b * xc.blocks_per_graph;
     const float* sb = xc.src + static_cast<long>(b) * xc.s_batch;
     for (long e = static_cast<long>(part) * 1024 + tid; e < xc.total; e += static_cast<long>(xc.blocks_per_graph) * 1024) {
@@ -563,8 +567,9 @@ static bool post_rows_ok(int64_t K, int flags, const void* slab, const void* raw
 
 static size_t post_ws_floats(int64_t B, int64_t K) { return static_cast<size_t>(B * K + B * POST_BLOCKS); }
 
-// Returns true when the X' slab combine described by xc (if any) was folded into the launch.
-static bool launch_post(PostArgs p, int64_t B, float* ws, hipStream_t stream, const XCombineArgs* xc = nullptr) {
+// Returns whether the slab combines described by xc / xc2 (if any) were folded into the launch (both or none).
+static bool launch_post(PostArgs p, int64_t B, float* ws, hipStream_t stream, const XCombineArgs* xc = nullptr,
+                        const XCombineArgs* xc2 = nullptr) {
   const int K = p.K;
   if (K <= 64) {  // one wave per graph: one launch instead of three or four
     const dim3 grid(static_cast<unsigned>((B + 3) / 4));
@@ -576,18 +581,25 @@ static bool launch_post(PostArgs p, int64_t B, float* ws, hipStream_t stream, co
   if (!no_lds && K <= POST_LDS_MAX_K && K % 4 == 0 && p.ld_src == K && p.s_split % 4 == 0 && p.s_batch % 4 == 0 &&
       reinterpret_cast<uintptr_t>(p.src) % 16 == 0 && (!p.raw || reinterpret_cast<uintptr_t>(p.raw) % 16 == 0) &&
       (!p.dst || reinterpret_cast<uintptr_t>(p.dst) % 16 == 0)) {
-    XCombineArgs x{};
+    XCombineArgs x{}, x2{};
+    auto blocks_of = [](XCombineArgs& a) {
+      a.blocks_per_graph = static_cast<int>((a.total + 4095) / 4096);
+      if (a.blocks_per_graph < 1) a.blocks_per_graph = 1;
+      if (a.blocks_per_graph > 8) a.blocks_per_graph = 8;
+    };
     if (xc) {
       x = *xc;
-      x.blocks_per_graph = static_cast<int>((x.total + 4095) / 4096);
-      if (x.blocks_per_graph < 1) x.blocks_per_graph = 1;
-      if (x.blocks_per_graph > 8) x.blocks_per_graph = 8;
+      blocks_of(x);
+    }
+    if (xc && xc2) {
+      x2 = *xc2;
+      blocks_of(x2);
     }
     const size_t lds = (static_cast<size_t>(K) * K + K + 1024 + 16) * sizeof(float);
-    const unsigned grid = static_cast<unsigned>(B + (xc ? B * x.blocks_per_graph : 0));
+    const unsigned grid = static_cast<unsigned>(B + (xc ? B * x.blocks_per_graph : 0) + (xc && xc2 ? B * x2.blocks_per_graph : 0));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(post_lds_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(post_lds_kernel, dim3(grid), dim3(1024), lds, stream, p, static_cast<int>(B), x);
+    hipLaunchKernelGGL(post_lds_kernel, dim3(grid), dim3(1024), lds, stream, p, static_cast<int>(B), x, x2);
     return xc != nullptr;
   }
   p.dvec = ws;

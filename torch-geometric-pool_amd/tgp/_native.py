@@ -163,6 +163,9 @@ SIGNATURES = {
     "tgp_mincut_terms_fused_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_f, _c_p, _c_p, _c_p,
                                             _c_p, _c_p, _c_p, _c_p]),
     "tgp_segment_gemm_tn3_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
+    "tgp_segment_gemm_tn3_post_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
+    "tgp_segment_gemm_tn3_post_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64,
+                                               _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_f, _c_p, _c_sz, _c_p]),
     "tgp_segment_gemm_tn3_f32": (_c_int, [_c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64,
                                           _c_i64, _c_i64, _c_i64, _c_int, _c_p, _c_sz, _c_p]),
     "tgp_edge_row_stats_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p]),

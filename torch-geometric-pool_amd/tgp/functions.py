@@ -1065,8 +1065,8 @@ class _PoolUnbatchedFn(torch.autograd.Function):
             t, deg, q = K.spmm_csr(row_ptr, ei, ew, n, s, want_stats=True)
         else:
             t = K.spmm_csr(row_ptr, ei, ew, n, s)
-        raw, x_pool, gram = K.segment_gemm_tn3(s, [t, xd, s], ptr, max_nodes, transpose0=transposed)
-        adj_pool = K.postprocess_dense(raw, flags)
+        raw, x_pool, gram, adj_pool = K.segment_gemm_tn3(s, [t, xd, s], ptr, max_nodes, transpose0=transposed,
+                                                         post_flags=flags)
         empty = s.new_empty(0)
         la, lb = s.new_empty(0), s.new_empty(0)
         den = lossv = stats = None

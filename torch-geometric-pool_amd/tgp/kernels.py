@@ -2387,9 +2387,13 @@ def edge_row_stats(row_ptr: Tensor, edge_weight: Optional[Tensor], s: Tensor) ->
     return deg, q
 
 
-def segment_gemm_tn3(s: Tensor, ys, ptr: Tensor, max_nodes: int, transpose0: bool = False):
+def segment_gemm_tn3(s: Tensor, ys, ptr: Tensor, max_nodes: int, transpose0: bool = False,
+                     post_flags: Optional[int] = None):
     """[S_b^T Y_j,b for j] for up to three float32 right-hand sides [Ntot,F_j] over node rows ptr[b]..ptr[b+1]: ONE
-    product grid + one combine launch (the unbatched dense poolers' S^T [A S | X | S])."""
+    product grid + one combine launch (the unbatched dense poolers' S^T [A S | X | S]).
+    ``post_flags`` (r6; ys[0] must be [Ntot,K]): a last value ``adj_pool`` = the post-processing of the first product
+    (utils/ops.py:282-335) from the same native call -- for 64 < K <= 176 its launch sums the slabs of all the products
+    itself, no combine launch."""
     dev = N.require_device(s, ptr, *ys)
     s, ptr = N.f32c(s), N.i64c(ptr)
     ys = [N.f32c(y) for y in ys]
@@ -2401,6 +2405,16 @@ def segment_gemm_tn3(s: Tensor, ys, ptr: Tensor, max_nodes: int, transpose0: boo
     yp = [N.ptr(y) for y in ys] + [None] * (3 - len(ys))
     op = [N.ptr(o) for o in outs] + [None] * (3 - len(ys))
     L = N.lib()
+    if post_flags is not None:
+        if fs[0] != Kc:
+            raise ValueError("segment_gemm_tn3(post_flags=...): the first right-hand side must be [Ntot,K]")
+        adj_pool = torch.empty(B, Kc, Kc, dtype=torch.float32, device=dev)
+        ws = N.workspace(L.tgp_segment_gemm_tn3_post_workspace_bytes(B, Kc, fs[1], fs[2], max_nodes), dev)
+        N.check(L.tgp_segment_gemm_tn3_post_f32(N.ptr(s), yp[0], yp[1], fs[1], yp[2], fs[2], N.ptr(ptr), op[0], op[1],
+                                                op[2], N.ptr(adj_pool), B, s.size(0), Kc, max_nodes,
+                                                1 if transpose0 else 0, int(post_flags), ops_eps(), N.ptr(ws),
+                                                ws.numel(), N.stream_ptr(dev)), "tgp_segment_gemm_tn3_post_f32")
+        return outs + [adj_pool]
     ws = N.workspace(L.tgp_segment_gemm_tn3_workspace_bytes(B, Kc, fs[0], fs[1], fs[2], max_nodes), dev)
     # transpose0: the first result (K x K) leaves the combine launch transposed
     N.check(L.tgp_segment_gemm_tn3_f32(N.ptr(s), yp[0], fs[0], yp[1], fs[1], yp[2], fs[2], N.ptr(ptr), op[0], op[1], op[2],

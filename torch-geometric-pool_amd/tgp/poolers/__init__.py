@@ -554,7 +554,8 @@ class _DenseMLPPooling(DenseSRCPooling):
                 t, deg, q = K.spmm_csr(row_ptr, ei, w_used, n, s, want_stats=True)
             else:
                 t = K.spmm_csr(row_ptr, ei, w_used, n, s)
-            raw, x_pool, gram = K.segment_gemm_tn3(s, [t, x, s], ptr, max_nodes, transpose0=transposed)
+            raw, x_pool, gram, adj_pool = K.segment_gemm_tn3(s, [t, x, s], ptr, max_nodes, transpose0=transposed,
+                                                             post_flags=flags)
             if mincut:
                 if transposed:  # in-degrees: sum_i indeg_i q_i = sum_i (A q)_i
                     aq = K.spmm_csr(row_ptr, ei, w_used, n, q.view(n, 1)).view(n)
@@ -563,7 +564,6 @@ class _DenseMLPPooling(DenseSRCPooling):
                     both = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr, want_means=True)[3]
             else:
                 both = K.diffpool_unbatched_tail(raw, gram, s, sw2, scales[0], scales[1])
-            adj_pool = K.postprocess_dense(raw, flags)
             s_flat = s
         if batched_out:  # S as the batched mode hands it out: padded [B,Nmax,K] + the node mask (differentiable view of S)
             if n == nb * max_nodes:  # graphs of one size: the padded form is a view, the mask a constant
