@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10034 /* 1.0.1 of the reference, ABI revision 33 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32; tgp_segment_gemm_tn3_post_f32) */
+#define TGP_ABI_VERSION 10035 /* 1.0.1 of the reference, ABI revision 34 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -745,6 +745,12 @@ int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, const float* w,
  * (entry count when w is NULL), q[i] = |S_i|^2 -- the outputs of tgp_edge_row_stats_f32 without its launch. */
 int tgp_spmm_csr_stats_f32(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows, int64_t nnz,
                            const float* S, int64_t K, float* T, float* deg, float* q, void* stream);
+/* r6: ... and with DiffPool's entropy loss riding along (utils/losses.py:476-483): partial[0 .. *n_partial) = per-workgroup
+ * shares of sum(-S log(S + eps)) over S [num_rows,K] (partial: >= num_rows floats; the sum of the shares is what
+ * tgp_diffpool_unbatched_tail_f32 takes as its entropy partials).  *n_partial = -1: the shape does not take the row
+ * kernel -- T is computed, the shares are not. */
+int tgp_spmm_csr_entropy_f32(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows, int64_t nnz,
+                             const float* S, int64_t K, float* T, float eps, float* partial, int* n_partial, void* stream);
 
 /* A8 alone: post-process a [B,K,K] pooled adjacency (src may equal dst).                */
 size_t tgp_postprocess_dense_workspace_bytes(int64_t B, int64_t K);

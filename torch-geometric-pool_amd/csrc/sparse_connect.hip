@@ -934,13 +934,16 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int32_t* __restrict
 // STATS (MinCut's degree term, utils/losses.py:73-127): also deg[i] = the row's weight sum (entry count without weights)
 // and q[i] = |S_i|^2 -- the row's entries are in hand anyway, S_i is 16 more bytes per lane (tgp_edge_row_stats_f32 was a
 // launch of its own for these).
-template <int G, bool STATS>
+// STATS == 2 (DiffPool's entropy loss, utils/losses.py:476-483): deg[logical block] = the block's share of
+// sum(-S log(S + eps)) over its rows of S (q unused): the loss' pass over S rides along as well.
+template <int G, int STATS>
 __global__ __launch_bounds__(256) void spmm_rows_vec4_kernel(const int32_t* __restrict__ row_ptr,
                                                              const int64_t* __restrict__ col,
                                                              const float* __restrict__ w, int64_t num_rows,
                                                              const float* __restrict__ S, int64_t K,
                                                              float* __restrict__ T, int rows_per_block,
-                                                             float* __restrict__ deg, float* __restrict__ qout) {
+                                                             float* __restrict__ deg, float* __restrict__ qout,
+                                                             float ent_eps) {
   constexpr int RPB = 256 / G;
   const int nwg = static_cast<int>(gridDim.x), orig = static_cast<int>(blockIdx.x);
   const int xcd = orig % 8, qq = nwg / 8, rr = nwg % 8;
@@ -949,15 +952,21 @@ __global__ __launch_bounds__(256) void spmm_rows_vec4_kernel(const int32_t* __re
   const int64_t r0 = static_cast<int64_t>(bid) * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   if (r1 > num_rows) r1 = num_rows;
+  [[maybe_unused]] float esum = 0.f;
   for (int64_t i = r0 + sub; i < r1; i += RPB) {
     const int32_t beg = row_ptr[i], end = row_ptr[i + 1];
     [[maybe_unused]] float dsum = 0.f, qsum = 0.f;
     for (int64_t f = 4 * g; f < K; f += 4 * G) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if constexpr (STATS) {
+      if constexpr (STATS == 1) {
         const float4 si = *reinterpret_cast<const float4*>(S + i * K + f);
         qsum = fmaf(si.x, si.x, qsum); qsum = fmaf(si.y, si.y, qsum);
         qsum = fmaf(si.z, si.z, qsum); qsum = fmaf(si.w, si.w, qsum);
+      }
+      if constexpr (STATS == 2) {
+        const float4 si = *reinterpret_cast<const float4*>(S + i * K + f);
+        esum += (-si.x * logf(si.x + ent_eps) - si.y * logf(si.y + ent_eps)) +
+                (-si.z * logf(si.z + ent_eps) - si.w * logf(si.w + ent_eps));
       }
       for (int32_t e0 = beg; e0 < end; e0 += 4) {
         int64_t c[4];
@@ -980,14 +989,14 @@ __global__ __launch_bounds__(256) void spmm_rows_vec4_kernel(const int32_t* __re
           acc.y = on ? py : acc.y;
           acc.z = on ? pz : acc.z;
           acc.w = on ? pw : acc.w;
-          if constexpr (STATS) {
+          if constexpr (STATS == 1) {
             if (f == 4 * g && on) dsum += wv[q];  // (every lane of the group holds the same sum)
           }
         }
       }
       *reinterpret_cast<float4*>(T + i * K + f) = acc;
     }
-    if constexpr (STATS) {
+    if constexpr (STATS == 1) {
 #pragma unroll
       for (int o = G / 2; o > 0; o >>= 1) qsum += __shfl_xor(qsum, o, 64);
       if (g == 0) {
@@ -995,6 +1004,14 @@ __global__ __launch_bounds__(256) void spmm_rows_vec4_kernel(const int32_t* __re
         qout[i] = qsum;
       }
     }
+  }
+  if constexpr (STATS == 2) {
+    __shared__ float s_e[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
+    if ((threadIdx.x & 63) == 0) s_e[threadIdx.x >> 6] = esum;
+    __syncthreads();
+    if (threadIdx.x == 0) deg[bid] = (s_e[0] + s_e[1]) + (s_e[2] + s_e[3]);
   }
 }
 
@@ -1524,12 +1541,18 @@ extern "C" int tgp_edge_row_stats_f32(const int32_t* row_ptr, const float* w, co
                                       float* deg, float* q, void* stream_);
 
 // deg / q: optional outputs (both or none) of the STATS form
+// entropy (mode 2): deg = the per-block partial array (>= num_rows floats of room), *n_partial = entries written, or -1 when
+// this shape does not take the row kernel (the caller then runs the loss' own pass)
 static int spmm_csr_impl(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows, int64_t nnz,
-                         const float* S, int64_t K, float* T, float* deg, float* q, void* stream_, const char* what) {
+                         const float* S, int64_t K, float* T, float* deg, float* q, void* stream_, const char* what,
+                         float ent_eps = 0.f, int* n_partial = nullptr) {
+  const bool entropy = n_partial != nullptr;
+  if (entropy) *n_partial = -1;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(num_rows >= 0 && nnz >= 0 && K >= 0, TGP_ERR_INVALID, "%s: negative size", what);
   if (num_rows == 0 || K == 0) return TGP_OK;
-  TGP_REQUIRE(row_ptr && T && (nnz == 0 || (col && S)) && (!deg == !q) && (!deg || S), TGP_ERR_INVALID, "%s: null pointer", what);
+  TGP_REQUIRE(row_ptr && T && (nnz == 0 || (col && S)) && (entropy || (!deg == !q)) && (!deg || S), TGP_ERR_INVALID,
+              "%s: null pointer", what);
   // T[i,:] = sum over row i of w[e] S[col[e],:]: rows of 16-byte vectors (K % 4 == 0, K >= 16) take the XCD-grouped row
   // kernel (r6: C2, K = 128: 40 -> 21 us against the r5 route through the sparse Reduce's gather-sum; 2048 graphs of 40
   // nodes, K = 20 / 32: 20.9 / 31.1 -> 12.3 / 11.5 us against one lane per output element), bit-identical; other shapes
@@ -1539,7 +1562,7 @@ static int spmm_csr_impl(const int32_t* row_ptr, const int64_t* col, const float
     static const int legacy = getenv("TGP_SPMM_REDUCE_ROUTE") ? atoi(getenv("TGP_SPMM_REDUCE_ROUTE")) : 0;  // A/B switch
     if (legacy) {
       const int rc = tgp_reduce_sparse_f32(S, 0, K, K, col, w, row_ptr, nullptr, nnz, num_rows, T, stream_);
-      return (rc == TGP_OK && deg) ? tgp_edge_row_stats_f32(row_ptr, w, S, num_rows, K, deg, q, stream_) : rc;
+      return (rc == TGP_OK && deg && !entropy) ? tgp_edge_row_stats_f32(row_ptr, w, S, num_rows, K, deg, q, stream_) : rc;
     }
     TGP_REQUIRE(num_rows < (1ll << 31), TGP_ERR_RANGE, "%s: num_rows >= 2^31", what);
     // r6: rows in contiguous chunks, a chunk = one workgroup, workgroups that share an XCD take neighbouring chunks
@@ -1555,13 +1578,17 @@ static int spmm_csr_impl(const int32_t* row_ptr, const int64_t* col, const float
     const dim3 grid(static_cast<unsigned>(blocks)), block(256);
 #define TGP_SPMM_ROWS(GG)                                                                                              \
   do {                                                                                                                 \
-    if (deg)                                                                                                           \
-      hipLaunchKernelGGL((spmm_rows_vec4_kernel<GG, true>), grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, \
-                         rows_per_block, deg, q);                                                                      \
+    if (entropy)                                                                                                       \
+      hipLaunchKernelGGL((spmm_rows_vec4_kernel<GG, 2>), grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T,   \
+                         rows_per_block, deg, q, ent_eps);                                                             \
+    else if (deg)                                                                                                      \
+      hipLaunchKernelGGL((spmm_rows_vec4_kernel<GG, 1>), grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T,   \
+                         rows_per_block, deg, q, 0.f);                                                                 \
     else                                                                                                               \
-      hipLaunchKernelGGL((spmm_rows_vec4_kernel<GG, false>), grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T, \
-                         rows_per_block, deg, q);                                                                      \
+      hipLaunchKernelGGL((spmm_rows_vec4_kernel<GG, 0>), grid, block, 0, stream, row_ptr, col, w, num_rows, S, K, T,   \
+                         rows_per_block, deg, q, 0.f);                                                                 \
   } while (0)
+    if (entropy) *n_partial = static_cast<int>(blocks);
     if (G == 8) TGP_SPMM_ROWS(8);
     else if (G == 16) TGP_SPMM_ROWS(16);
     else if (G == 32) TGP_SPMM_ROWS(32);
@@ -1574,7 +1601,7 @@ static int spmm_csr_impl(const int32_t* row_ptr, const int64_t* col, const float
   hipLaunchKernelGGL(spmm_csr_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, row_ptr, col, w,
                      num_rows, S, K, T);
   const int rc = check_launch(what);
-  return (rc == TGP_OK && deg) ? tgp_edge_row_stats_f32(row_ptr, w, S, num_rows, K, deg, q, stream_) : rc;
+  return (rc == TGP_OK && deg && !entropy) ? tgp_edge_row_stats_f32(row_ptr, w, S, num_rows, K, deg, q, stream_) : rc;
 }
 
 extern "C" int tgp_spmm_csr_f32(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows,
@@ -1587,4 +1614,15 @@ extern "C" int tgp_spmm_csr_stats_f32(const int32_t* row_ptr, const int64_t* col
                                       void* stream_) {
   TGP_REQUIRE(deg && q, TGP_ERR_INVALID, "tgp_spmm_csr_stats_f32: null output");
   return spmm_csr_impl(row_ptr, col, w, num_rows, nnz, S, K, T, deg, q, stream_, "tgp_spmm_csr_stats_f32");
+}
+
+// r6: T = A S with DiffPool's entropy sum riding along: partial[0 .. *n_partial) = per-workgroup shares of
+// sum(-S log(S + eps)) over all of S (S has num_rows rows); *n_partial = -1: this shape does not take the row kernel
+// (T is computed, the partials are not: the caller runs tgp_entropy_partials_f32).  partial: >= num_rows floats.
+extern "C" int tgp_spmm_csr_entropy_f32(const int32_t* row_ptr, const int64_t* col, const float* w, int64_t num_rows,
+                                        int64_t nnz, const float* S, int64_t K, float* T, float eps, float* partial,
+                                        int* n_partial, void* stream_) {
+  TGP_REQUIRE(partial && n_partial, TGP_ERR_INVALID, "tgp_spmm_csr_entropy_f32: null output");
+  return spmm_csr_impl(row_ptr, col, w, num_rows, nnz, S, K, T, partial, nullptr, stream_, "tgp_spmm_csr_entropy_f32", eps,
+                       n_partial);
 }

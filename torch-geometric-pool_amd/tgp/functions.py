@@ -1060,9 +1060,11 @@ class _PoolUnbatchedFn(torch.autograd.Function):
             else N.f32c(s_given.detach())
         Kc = s.size(1)
         B = ptr.numel() - 1
-        deg = q = None
+        deg = q = ent_part = None
         if mode == 1:  # MinCut: out-degrees and |S_i|^2 ride along with T = A S
             t, deg, q = K.spmm_csr(row_ptr, ei, ew, n, s, want_stats=True)
+        elif mode == 2:  # DiffPool: the entropy sum over S rides along
+            t, ent_part = K.spmm_csr(row_ptr, ei, ew, n, s, want_stats="entropy")
         else:
             t = K.spmm_csr(row_ptr, ei, ew, n, s)
         raw, x_pool, gram, adj_pool = K.segment_gemm_tn3(s, [t, xd, s], ptr, max_nodes, transpose0=transposed,
@@ -1078,7 +1080,7 @@ class _PoolUnbatchedFn(torch.autograd.Function):
                 den, terms, stats, both = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr, want_means=True)
             la, lb = both[0], both[1]
         elif mode == 2:
-            lossv = K.diffpool_unbatched_tail(raw, gram, s, sw2, scales[0], scales[1])
+            lossv = K.diffpool_unbatched_tail(raw, gram, s, sw2, scales[0], scales[1], ent_partials=ent_part)
             la, lb = lossv[0], lossv[1]
         keep = [v if v is not None else empty for v in (gram, deg, den, lossv, stats, ew, batch)]
         ctx.save_for_backward(s, t, xd, empty if weight is None else weight, raw, ei, row_ptr, ptr, *keep)

@@ -2360,6 +2360,18 @@ def spmm_csr(row_ptr: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor],
     s = N.f32c(s)
     w = None if edge_weight is None else N.f32c(edge_weight.reshape(-1))
     out = torch.empty(num_rows, s.size(1), dtype=torch.float32, device=dev)
+    if want_stats == "entropy":
+        # (T, partials or None): DiffPool's entropy sum over S rides along as per-workgroup shares (None: this shape does
+        # not take the row kernel; diffpool_unbatched_tail then runs its own pass over S)
+        if s.size(0) != num_rows:
+            raise ValueError("spmm_csr(want_stats='entropy') needs a square A: one row of S per row of A")
+        import ctypes as _ct
+        part = torch.empty(max(num_rows, 1), dtype=torch.float32, device=dev)
+        n_part = _ct.c_int(-1)
+        N.check(N.lib().tgp_spmm_csr_entropy_f32(N.ptr(row_ptr), N.ptr(col), N.ptr(w), num_rows, col.numel(), N.ptr(s),
+                                                  s.size(1), N.ptr(out), losses_eps(), N.ptr(part),
+                                                  _ct.addressof(n_part), N.stream_ptr(dev)), "tgp_spmm_csr_entropy_f32")
+        return out, (part[: n_part.value] if n_part.value >= 0 else None)
     if want_stats:
         if s.size(0) != num_rows:
             raise ValueError("spmm_csr(want_stats=True) needs a square A: one row of S per row of A")
@@ -2455,20 +2467,27 @@ def segment_gemm_tn_into(a: Tensor, y: Tensor, ptr: Tensor) -> Tensor:
     return out
 
 
-def diffpool_unbatched_tail(raw: Tensor, gram: Tensor, s: Tensor, sw2, link_scale: float, ent_scale: float) -> Tensor:
+def diffpool_unbatched_tail(raw: Tensor, gram: Tensor, s: Tensor, sw2, link_scale: float, ent_scale: float,
+                            ent_partials: Optional[Tensor] = None) -> Tensor:
     """[2]: DiffPool's unbatched link-prediction loss sqrt(max(sum_e w_e^2 - 2 sum_b trace(raw_b) + sum_b |gram_b|^2, 0))
     * link_scale and entropy loss sum(-s log(s + eps)) * ent_scale (utils/losses.py:661-708, 476-483); ``sw2``: a
-    0-dim device tensor or a Python number."""
-    dev = N.require_device(raw, gram, s)
-    raw, gram, s32 = N.f32c(raw), N.f32c(gram), N.f32c(s)
+    0-dim device tensor or a Python number.  ``ent_partials``: shares of the entropy sum that are already there
+    (``spmm_csr(want_stats="entropy")``): no pass over S here."""
+    dev = N.require_device(raw, gram, s, ent_partials)
+    raw, gram = N.f32c(raw), N.f32c(gram)
     B, Kc = raw.size(0), raw.size(-1)
     L = N.lib()
-    ws = N.workspace(L.tgp_entropy_sum_workspace_bytes(s32.numel()), dev)
+    st = N.stream_ptr(dev)
     import ctypes as _ct
     n_partial = _ct.c_int(0)
-    st = N.stream_ptr(dev)
-    N.check(L.tgp_entropy_partials_f32(N.ptr(s32), s32.numel(), losses_eps(), N.ptr(ws), ws.numel(),
-                                       _ct.addressof(n_partial), st), "tgp_entropy_partials_f32")
+    if ent_partials is not None:
+        ws = N.f32c(ent_partials.reshape(-1))
+        n_partial.value = ws.numel()
+    else:
+        s32 = N.f32c(s)
+        ws = N.workspace(L.tgp_entropy_sum_workspace_bytes(s32.numel()), dev)
+        N.check(L.tgp_entropy_partials_f32(N.ptr(s32), s32.numel(), losses_eps(), N.ptr(ws), ws.numel(),
+                                           _ct.addressof(n_partial), st), "tgp_entropy_partials_f32")
     stats = torch.empty(B, 2, dtype=torch.float32, device=dev)
     out = torch.empty(2, dtype=torch.float32, device=dev)
     sw2_dev = N.f32c(sw2.reshape(1)) if isinstance(sw2, Tensor) else None

@@ -552,8 +552,8 @@ class _DenseMLPPooling(DenseSRCPooling):
         else:
             if mincut:  # out-degrees and |S_i|^2 ride along with T = A S
                 t, deg, q = K.spmm_csr(row_ptr, ei, w_used, n, s, want_stats=True)
-            else:
-                t = K.spmm_csr(row_ptr, ei, w_used, n, s)
+            else:       # DiffPool: the entropy sum over S rides along
+                t, ent_part = K.spmm_csr(row_ptr, ei, w_used, n, s, want_stats="entropy")
             raw, x_pool, gram, adj_pool = K.segment_gemm_tn3(s, [t, x, s], ptr, max_nodes, transpose0=transposed,
                                                              post_flags=flags)
             if mincut:
@@ -563,7 +563,7 @@ class _DenseMLPPooling(DenseSRCPooling):
                 else:
                     both = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr, want_means=True)[3]
             else:
-                both = K.diffpool_unbatched_tail(raw, gram, s, sw2, scales[0], scales[1])
+                both = K.diffpool_unbatched_tail(raw, gram, s, sw2, scales[0], scales[1], ent_partials=ent_part)
             s_flat = s
         if batched_out:  # S as the batched mode hands it out: padded [B,Nmax,K] + the node mask (differentiable view of S)
             if n == nb * max_nodes:  # graphs of one size: the padded form is a view, the mask a constant
