@@ -172,7 +172,8 @@ def test_unbatched_training_with_weight_gradients_keeps_the_operator_path(dev):
     assert w.grad is not None and torch.isfinite(w.grad).all()
 
 
-@pytest.mark.parametrize("n,k,weighted", [(300, 128, True), (777, 20, True), (500, 64, False), (260, 72, True), (90, 10, True)])
+@pytest.mark.parametrize("n,k,weighted", [(300, 128, True), (777, 20, True), (500, 64, False), (260, 72, True), (90, 10, True),
+                                          (200, 320, True), (33, 16, False), (1, 64, True), (4100, 256, True)])
 def test_spmm_with_degree_stats_equals_the_two_launches(dev, n, k, weighted):
     """r6: ``spmm_csr(want_stats=True)`` = T of ``spmm_csr`` bit for bit (same products, same order of adds) and the
     (deg, q) of ``edge_row_stats`` at fp32 rounding (another summation order), on rows of 16-byte vectors (the row kernel)
@@ -189,6 +190,13 @@ def test_spmm_with_degree_stats_equals_the_two_launches(dev, n, k, weighted):
     d0, q0 = K.edge_row_stats(rp, w, s)
     t1, d1, q1 = K.spmm_csr(rp, ei, w, n, s, want_stats=True)
     assert torch.equal(t0, t1)
+    t2, part = K.spmm_csr(rp, ei, w, n, s, want_stats="entropy")
+    assert torch.equal(t0, t2)
+    if part is not None:  # (None: the shape takes the scalar kernel, the loss runs its own pass)
+        ent = -(s.double() * torch.log(s.double() + 1e-15)).sum()
+        torch.testing.assert_close(part.double().sum(), ent, rtol=1e-5, atol=1e-6)
+    else:
+        assert k % 4 != 0 or k < 16
     torch.testing.assert_close(d1, d0, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(q1, q0, rtol=1e-6, atol=1e-7)
     ref = torch.zeros(n, k, dtype=torch.float64, device=dev).index_add_(
