@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10035 /* 1.0.1 of the reference, ABI revision 34 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
+#define TGP_ABI_VERSION 10036 /* 1.0.1 of the reference, ABI revision 35 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -661,9 +661,12 @@ size_t tgp_dense_pool_train_workspace_bytes(int64_t B, int64_t N, int64_t K, int
 int tgp_dense_pool_train_fwd_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N, int64_t K,
                                  int64_t F, int flags, float eps, float* U, int64_t ldu, float* x_pool, float* adj_raw,
                                  float* adj_pool, float* gram, void* ws, size_t ws_bytes, void* stream);
+/* (edge_row_ptr / edge_col / edge_w, optional, un-padded batches only: den = sum over a graph's entries of
+ *  w_e q[col_e] = sum_j indeg_j q_j, the in-degree form of the batched poolers' S^T A^T S -- deg is then not read) */
 int tgp_mincut_terms_fused_f32(const float* raw, const float* gram, const float* deg, const float* q, int64_t B,
                                int64_t N, int64_t K, float eps, float* den, float* out, float* stats, const int64_t* ptr,
-                               uint32_t* ticket, float* means, void* stream);
+                               uint32_t* ticket, float* means, const int32_t* edge_row_ptr, const int64_t* edge_col,
+                               const float* edge_w, void* stream);
 int tgp_dense_pool_train_rhs_f32(const float* g_raw_a, const float* g_raw_b, int mode, const float* stats, const float* den,
                                  const float* gram, const float* g_la, const float* g_lb, float scale,
                                  const float* link_loss, float link_scale, float eps, const float* g_x, int gx_bcast,

@@ -424,7 +424,9 @@ __global__ __launch_bounds__(T) void mincut_tail2_kernel(const float* __restrict
                                                            int N, int K, float eps, int B, float* __restrict__ den,
                                                            float* __restrict__ out, float* __restrict__ stats,
                                                            const int64_t* __restrict__ ptr,
-                                                           unsigned int* __restrict__ ticket, float* __restrict__ means) {
+                                                           unsigned int* __restrict__ ticket, float* __restrict__ means,
+                                                           const int* __restrict__ erp, const int64_t* __restrict__ ecol,
+                                                           const float* __restrict__ ew) {
   __shared__ float sh[4 * (T / 64)];
   __shared__ bool s_last;
   const int b = blockIdx.x;
@@ -450,8 +452,17 @@ __global__ __launch_bounds__(T) void mincut_tail2_kernel(const float* __restrict
       gv[j] = i < KK ? G[i] : 0.f;
     }
   }
-  if (q) { for (int i = threadIdx.x; i < N; i += T) dn = fmaf(d[i], qq[i], dn); }
-  else { for (int i = threadIdx.x; i < N; i += T) dn += d[i]; }  // (deg already carries the factor: (A q)_i)
+  if (erp) {
+    // in-degree form (the batched poolers' S^T A^T S on the rows route): den = sum_j indeg_j q_j = sum over the graph's
+    // entries of w_e q[col_e], straight from the CSR list (the graph's entries are rows lo .. lo + N of it) -- the SpMV
+    // A q this replaces was a launch of its own
+    const int e_lo = erp[lo], e_hi = erp[lo + N];
+    for (int e = e_lo + threadIdx.x; e < e_hi; e += T) dn = fmaf(ew ? ew[e] : 1.0f, q[ecol[e]], dn);
+  } else if (q) {
+    for (int i = threadIdx.x; i < N; i += T) dn = fmaf(d[i], qq[i], dn);
+  } else {
+    for (int i = threadIdx.x; i < N; i += T) dn += d[i];  // (deg already carries the factor: (A q)_i)
+  }
   for (int i = threadIdx.x; i < K; i += T) {
     tr += R[static_cast<int64_t>(i) * K + i];
     trg += G[static_cast<int64_t>(i) * K + i];
@@ -773,22 +784,26 @@ extern "C" int tgp_diffpool_unbatched_tail_f32(const float* raw, const float* gr
 extern "C" int tgp_mincut_terms_fused_f32(const float* raw, const float* gram, const float* deg, const float* q,
                                           int64_t B, int64_t N, int64_t K, float eps, float* den, float* out,
                                           float* stats, const int64_t* ptr, uint32_t* ticket, float* means,
+                                          const int32_t* edge_row_ptr, const int64_t* edge_col, const float* edge_w,
                                           void* stream_) {
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 1 && K < 32768 && N < (1ll << 31), TGP_ERR_INVALID,
               "tgp_mincut_terms_fused_f32: bad shape");
   if (B == 0) return TGP_OK;
-  TGP_REQUIRE(raw && gram && den && out && (N == 0 || deg), TGP_ERR_INVALID,
+  TGP_REQUIRE(raw && gram && den && out && (N == 0 || deg || edge_row_ptr), TGP_ERR_INVALID,
               "tgp_mincut_terms_fused_f32: null pointer");
+  TGP_REQUIRE(!edge_row_ptr || (ptr && q && edge_col), TGP_ERR_INVALID,
+              "tgp_mincut_terms_fused_f32: the edge form needs ptr, q and the column array");
   TGP_REQUIRE(B < (1ll << 31), TGP_ERR_RANGE, "tgp_mincut_terms_fused_f32: too many graphs");
   TGP_REQUIRE(!means || ticket, TGP_ERR_INVALID, "tgp_mincut_terms_fused_f32: means need a zeroed ticket word");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (K >= 64)
     hipLaunchKernelGGL(mincut_tail2_kernel<1024>, dim3(static_cast<unsigned>(B)), dim3(1024), 0, stream, raw, gram, deg, q,
-                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out, stats, ptr, ticket, means);
+                       static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out, stats, ptr, ticket, means,
+                       edge_row_ptr, edge_col, edge_w);
   else
     hipLaunchKernelGGL(mincut_tail2_kernel<256>, dim3(static_cast<unsigned>(B)), dim3(256), 0, stream, raw, gram, deg, q,
                        static_cast<int>(N), static_cast<int>(K), eps, static_cast<int>(B), den, out, stats, ptr, ticket,
-                       means);
+                       means, edge_row_ptr, edge_col, edge_w);
   return check_launch("tgp_mincut_terms_fused_f32");
 }
 

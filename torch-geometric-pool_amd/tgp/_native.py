@@ -161,7 +161,7 @@ SIGNATURES = {
     "tgp_dense_pool_train_fwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_f, _c_p, _c_i64,
                                               _c_p, _c_p, _c_p, _c_p, _c_p, _c_sz, _c_p]),
     "tgp_mincut_terms_fused_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_f, _c_p, _c_p, _c_p,
-                                            _c_p, _c_p, _c_p, _c_p]),
+                                            _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "tgp_segment_gemm_tn3_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
     "tgp_segment_gemm_tn3_post_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
     "tgp_segment_gemm_tn3_post_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64,

@@ -1073,9 +1073,9 @@ class _PoolUnbatchedFn(torch.autograd.Function):
         la, lb = s.new_empty(0), s.new_empty(0)
         den = lossv = stats = None
         if mode == 1:
-            if transposed:  # den = sum_i indeg_i q_i = sum_i (A q)_i: one SpMV over the same row-sorted list
-                aq = K.spmm_csr(row_ptr, ei, ew, n, q.view(n, 1)).view(n)
-                den, terms, stats, both = K.mincut_terms_fused(raw, gram, aq, None, ptr=ptr, want_means=True)
+            if transposed:  # den = sum_j indeg_j q_j = sum_e w_e q[col_e]: the tail walks the graph's entries itself
+                den, terms, stats, both = K.mincut_terms_fused(raw, gram, None, q, ptr=ptr, want_means=True,
+                                                               edges=(row_ptr, ei, ew))
             else:
                 den, terms, stats, both = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr, want_means=True)
             la, lb = both[0], both[1]

@@ -1582,15 +1582,25 @@ def cut_rows(adj: Tensor, s: Tensor, graph_sizes: Optional[Tensor] = None) -> Tu
     return deg, q
 
 
-def mincut_terms_fused(raw: Tensor, gram: Tensor, deg: Tensor, q: Optional[Tensor],
-                       ptr: Optional[Tensor] = None, want_means: bool = False):
+def mincut_terms_fused(raw: Tensor, gram: Tensor, deg: Optional[Tensor], q: Optional[Tensor],
+                       ptr: Optional[Tensor] = None, want_means: bool = False, edges=None):
     """(den [B], terms [2,B], stats [B,4][, means [2]]): MinCut's per-graph loss tails with den = sum_i deg_i q_i formed
     in the same launch (utils/losses.py:39-70); stats = (trace(raw), |G|^2, trace(G), |Y|) per graph, the scalars the
     backward's right-hand sides need; ``want_means``: also the batch means of the two terms (what the pooler hands out)."""
     dev = N.require_device(raw, gram, deg, q)
-    raw, gram, deg = N.f32c(raw), N.f32c(gram), N.f32c(deg)
+    raw, gram = N.f32c(raw), N.f32c(gram)
+    deg = None if deg is None else N.f32c(deg)
     q = None if q is None else N.f32c(q)  # (None: deg already carries the factor, den = sum of deg)
-    B, Kc, Nn = raw.size(0), raw.size(-1), deg.size(-1)
+    # edges = (row_ptr int32 [Ntot+1], edge_index, weights or None) of an un-padded batch: den = sum_e w_e q[col_e], the
+    # in-degree form (S^T A^T S of the batched poolers on the rows route); deg is then not read
+    e_rp = e_col = e_w = None
+    if edges is not None:
+        if ptr is None or q is None:
+            raise ValueError("mincut_terms_fused(edges=...) needs ptr and q")
+        e_rp, e_ei, e_w = edges
+        e_col = _edge_rows(e_ei)[1]
+        e_w = None if e_w is None else N.f32c(e_w.reshape(-1))
+    B, Kc, Nn = raw.size(0), raw.size(-1), (deg if deg is not None else q).size(-1)
     den = torch.empty(B, dtype=torch.float32, device=dev)
     out = torch.empty(2, B, dtype=torch.float32, device=dev)
     stats = torch.empty(B, 4, dtype=torch.float32, device=dev)
@@ -1604,7 +1614,8 @@ def mincut_terms_fused(raw: Tensor, gram: Tensor, deg: Tensor, q: Optional[Tenso
     # ptr: deg / q belong to an un-padded batch (graph b owns entries ptr[b] .. ptr[b+1])
     N.check(N.lib().tgp_mincut_terms_fused_f32(N.ptr(raw), N.ptr(gram), N.ptr(deg), N.ptr(q), B, Nn, Kc, losses_eps(),
                                                N.ptr(den), N.ptr(out), N.ptr(stats),
-                                               N.ptr(None if ptr is None else N.i64c(ptr)), ticket, N.ptr(means), st),
+                                               N.ptr(None if ptr is None else N.i64c(ptr)), ticket, N.ptr(means),
+                                               N.ptr(e_rp), N.ptr(e_col), N.ptr(e_w), st),
             "tgp_mincut_terms_fused_f32")
     if want_means:
         return den, out, stats, (means if means is not None else out.mean(dim=1))
@@ -2343,11 +2354,26 @@ def spmm_sorted_csr(edge_index: Tensor, edge_weight: Optional[Tensor], num_rows:
     return out, row_ptr
 
 
+_CSR_OFFSETS: dict = {}  # id(edge_index) -> (weakref, version, num_rows, row_ptr)
+
+
 def csr_offsets(edge_index: Tensor, num_rows: int) -> Tensor:
-    """int32 [num_rows+1] CSR offsets of a row-sorted list (one launch)."""
+    """int32 [num_rows+1] CSR offsets of a row-sorted list: one launch for a new list, remembered per tensor object +
+    version (full-batch training pools the same ``edge_index`` every step), like the per-graph edge ranges."""
+    key = id(edge_index)
+    hit = _CSR_OFFSETS.get(key)
+    if hit is not None and hit[0]() is edge_index and hit[1] == edge_index._version and hit[2] == num_rows:
+        return hit[3]
     row, _ = _edge_rows(edge_index)
     out = torch.empty(num_rows + 1, dtype=torch.int32, device=edge_index.device)
-    return rowptr_from_sorted(row, num_rows, out)
+    rowptr_from_sorted(row, num_rows, out)
+    if not torch.cuda.is_current_stream_capturing():
+        if key in _CSR_OFFSETS:
+            del _CSR_OFFSETS[key]
+        elif len(_CSR_OFFSETS) >= 16:
+            del _CSR_OFFSETS[next(iter(_CSR_OFFSETS))]
+        _CSR_OFFSETS[key] = (_weakref(edge_index), edge_index._version, num_rows, out)
+    return out
 
 
 def spmm_csr(row_ptr: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], num_rows: int, s: Tensor,

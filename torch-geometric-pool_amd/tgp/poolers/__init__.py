@@ -557,9 +557,9 @@ class _DenseMLPPooling(DenseSRCPooling):
             raw, x_pool, gram, adj_pool = K.segment_gemm_tn3(s, [t, x, s], ptr, max_nodes, transpose0=transposed,
                                                              post_flags=flags)
             if mincut:
-                if transposed:  # in-degrees: sum_i indeg_i q_i = sum_i (A q)_i
-                    aq = K.spmm_csr(row_ptr, ei, w_used, n, q.view(n, 1)).view(n)
-                    both = K.mincut_terms_fused(raw, gram, aq, None, ptr=ptr, want_means=True)[3]
+                if transposed:  # in-degrees: sum_j indeg_j q_j = sum_e w_e q[col_e]
+                    both = K.mincut_terms_fused(raw, gram, None, q, ptr=ptr, want_means=True,
+                                                edges=(row_ptr, ei, w_used))[3]
                 else:
                     both = K.mincut_terms_fused(raw, gram, deg, q, ptr=ptr, want_means=True)[3]
             else:
