@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10036 /* 1.0.1 of the reference, ABI revision 35 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
+#define TGP_ABI_VERSION 10037 /* 1.0.1 of the reference, ABI revision 36 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -384,7 +384,15 @@ int tgp_dense_pool_select_sparse_f32(const float* x, int64_t Ntot, const int64_t
                                      unsigned char* mask_out, float* x_pool, float* adj_raw, float* adj_pool,
                                      float* mincut_terms /* [2,B] or NULL */, int64_t* batch_pool /* [B*K] or NULL */,
                                      float* x_dense_out /* [B,N,F] or NULL */, float* adj_dense_out /* [B,N,N] or NULL */,
+                                     float* diff_stats /* r6, [B,4] or NULL: (sum A^2, trace(S^T A S), |S^T S|_F^2,
+                                                          sum -S log(S + loss_eps)) per graph: DiffPool's two losses
+                                                          (utils/losses.py:644-658, 476-483) without the dense adjacency */,
                                      void* stream);
+/* r6: DiffPool's link-prediction and entropy losses from those records: out2[0] = sqrt(max(sum_b (a2 - 2 tr + fro), 0)) *
+ * link_scale, out2[1] = (sum_b ent) * ent_scale; one launch (the residual product, its partial sum, the entropy pass and
+ * the tail were four). */
+int tgp_diffpool_stats_tail_f32(const float* stats /* [B,4], 16-byte aligned */, int64_t B, float link_scale,
+                                float ent_scale, float* out2, void* stream);
 
 /* Facts of a NEW edge list for that call, one launch, no host round trip in front of the consumer: edge_ptr [N+2]
  * (entries [0, B] written: first entry whose source node belongs to a graph >= g) and one flag word in pinned host

@@ -161,10 +161,12 @@ extern "C" int tgp_dense_pool_select_sparse_f32(const float* x, int64_t Ntot, co
                                                 float loss_eps, float* S_out, unsigned char* mask_out, float* x_pool,
                                                 float* adj_raw, float* adj_pool, float* mincut_terms,
                                                 int64_t* batch_pool, float* x_dense_out, float* adj_dense_out,
-                                                void* stream_) {
+                                                float* diff_stats, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0 && F >= 0 && E >= 0 && Ntot >= 0, TGP_ERR_INVALID,
               "tgp_dense_pool_select_sparse_f32: negative size");
+  TGP_REQUIRE(!diff_stats || adj_pool || adj_raw, TGP_ERR_INVALID,
+              "tgp_dense_pool_select_sparse_f32: diff_stats come with the Connect product (adj_pool or adj_raw)");
   if (B == 0 || N == 0 || K == 0) return TGP_OK;
   TGP_REQUIRE(x && W && S_out && F > 0 && node_ptr && edge_ptr && batch && (E == 0 || (row && col)), TGP_ERR_INVALID,
               "tgp_dense_pool_select_sparse_f32: x, W, S_out, batch, node_ptr, edge_ptr (and the edge list) are required");
@@ -178,7 +180,7 @@ extern "C" int tgp_dense_pool_select_sparse_f32(const float* x, int64_t Ntot, co
               reinterpret_cast<const long long*>(col), w, reinterpret_cast<const long long*>(node_ptr),
               reinterpret_cast<const long long*>(edge_ptr), reinterpret_cast<const long long*>(batch),
               adj_transpose ? 1 : 0, mask_out, static_cast<long long>(E), static_cast<long long>(Ntot), adj_dense_out,
-              x_dense_out};
+              x_dense_out, diff_stats};
   const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -56,6 +56,12 @@ struct SmallArgs {
   // optional side outputs of the sparse form (training: the backward kernels read the padded tensors): the adjacency
   // tile as it stands in LDS -> a_dense_out [B,N,N], the graph's rows of x zero-padded -> x_dense_out [B,N,F]
   float* a_dense_out; float* x_dense_out;
+  // optional (r6) [B,4]: what DiffPool's two losses need of this graph, taken where A, S and S^T A S sit in LDS /
+  // registers: (sum of A_ij^2, trace(S^T A S), |S^T S|_F^2, sum of -S log(S + loss_eps)).  With
+  //   |A - S S^T|_F^2 = sum A^2 - 2 trace(S^T A S) + |S^T S|_F^2      (utils/losses.py:644-658, 476-483)
+  // the link-prediction residual needs neither the dense adjacency outside this kernel nor a product of its own: the
+  // inference call no longer writes [B,N,N] and the four launches of the loss tail become one (tgp_diffpool_stats_tail_f32).
+  float* diff_stats;
 };
 
 __device__ __forceinline__ float sg_wave_sum(float v) {
@@ -419,6 +425,37 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
         if (lane == 0) {
           p.mincut_terms[b] = -(tr / (den + p.loss_eps));
           p.mincut_terms[p.B + b] = sqrtf(acc);
+        }
+      }
+      if (p.diff_stats) {
+        float tr = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (rho(r) + 4 * lk == lm) tr += aa[r];
+        tr = sg_wave_sum(tr);
+        float a2 = 0.f;  // lane i sweeps row i of the adjacency tile (rows / columns beyond N are zero)
+        {
+          const float* rowp = As + lane * SG_LDA;
+#pragma unroll 16
+          for (int j = 0; j < SG_N; ++j) a2 = fmaf(rowp[j], rowp[j], a2);
+        }
+        a2 = sg_wave_sum(a2);
+        f32x16 gg;  // S^T S: lane = column, register r = row rho(r) + 4 lk
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gg[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) gg = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[q], sr[q], gg, 0, 0, 0);
+        float fro = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fro = fmaf(gg[r], gg[r], fro);
+        fro = sg_wave_sum(fro);
+        float ent = 0.f;  // (padded nodes / columns hold S = 0: -0 log(eps) = 0)
+#pragma unroll
+        for (int q = 0; q < 32; ++q) ent -= sr[q] * logf(sr[q] + p.loss_eps);
+        ent = sg_wave_sum(ent);
+        if (lane == 0) {
+          float* o = p.diff_stats + static_cast<long>(b) * 4;
+          o[0] = a2; o[1] = tr; o[2] = fro; o[3] = ent;
         }
       }
       if (p.adj_raw && lm < K) {

@@ -746,6 +746,39 @@ __global__ __launch_bounds__(256) void diffpool_u_final_kernel(const float* __re
 }
 }  // namespace tgp
 
+namespace tgp {
+// out[0] = sqrt(max(sum_b (a2_b - 2 tr_b + fro_b), 0)) * link_scale, out[1] = (sum_b ent_b) * ent_scale from the [B,4]
+// records of dense_pool_small_kernel (SmallArgs.diff_stats); one workgroup, sums in graph order per thread, fixed tree
+__global__ __launch_bounds__(256) void diffpool_stats_tail_kernel(const float* __restrict__ stats, int B, float link_scale,
+                                                                  float ent_scale, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float a2 = 0.f, tr = 0.f, fro = 0.f, ent = 0.f;
+  const float4* s4 = reinterpret_cast<const float4*>(stats);
+  for (int i = threadIdx.x; i < B; i += 256) {
+    const float4 v = s4[i];
+    a2 += v.x; tr += v.y; fro += v.z; ent += v.w;
+  }
+  a2 = block_sum_256(a2, sh);
+  tr = block_sum_256(tr, sh);
+  fro = block_sum_256(fro, sh);
+  ent = block_sum_256(ent, sh);
+  if (threadIdx.x == 0) {
+    out[0] = sqrtf(fmaxf((a2 - 2.0f * tr) + fro, 0.f)) * link_scale;
+    out[1] = ent * ent_scale;
+  }
+}
+}  // namespace tgp
+
+extern "C" int tgp_diffpool_stats_tail_f32(const float* stats, int64_t B, float link_scale, float ent_scale, float* out2,
+                                           void* stream_) {
+  TGP_REQUIRE(B >= 1 && B < (1ll << 31), TGP_ERR_INVALID, "tgp_diffpool_stats_tail_f32: bad shape");
+  TGP_REQUIRE(stats && out2 && reinterpret_cast<uintptr_t>(stats) % 16 == 0, TGP_ERR_INVALID,
+              "tgp_diffpool_stats_tail_f32: null or misaligned pointer");
+  hipLaunchKernelGGL(tgp::diffpool_stats_tail_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), stats,
+                     static_cast<int>(B), link_scale, ent_scale, out2);
+  return check_launch("tgp_diffpool_stats_tail_f32");
+}
+
 extern "C" int tgp_edge_row_stats_f32(const int32_t* row_ptr, const float* w, const float* S, int64_t N, int64_t K,
                                       float* deg, float* q, void* stream_) {
   TGP_REQUIRE(N >= 0 && K >= 0 && K < (1ll << 31), TGP_ERR_INVALID, "tgp_edge_row_stats_f32: bad shape");

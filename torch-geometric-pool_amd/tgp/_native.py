@@ -99,7 +99,8 @@ SIGNATURES = {
     "tgp_edge_facts_sorted_i64": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, ctypes.c_uint64, _c_p]),
     "tgp_dense_pool_select_sparse_f32": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64,
                                                   _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_f, _c_f, _c_p, _c_p, _c_p,
-                                                  _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
+                                                  _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "tgp_diffpool_stats_tail_f32": (_c_int, [_c_p, _c_i64, _c_f, _c_f, _c_p, _c_p]),
     "tgp_dense_pool_small_bwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_f, _c_f, _c_p,
                                               _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_int,
                                               _c_p, _c_p, _c_p]),

@@ -828,14 +828,17 @@ class _SelectPoolSparseFn(torch.autograd.Function):
                 adj_transpose, want_terms, diff_scales=None, graph_sizes=None):
         from . import kernels as K
         ctx.set_materialize_grads(False)
-        s, mask, x_pool, raw, adj_pool, terms, bp, xd, ad = K.dense_pool_select_sparse(
+        got = K.dense_pool_select_sparse(
             x.detach(), edge_index, edge_weight, batch, node_ptr, edge_ptr, num_graphs, max_nodes, weight.detach(),
-            None if bias is None else bias.detach(), flags, adj_transpose, want_raw=True, mincut_terms=True,
-            want_dense=True)
+            None if bias is None else bias.detach(), flags, adj_transpose, want_raw=True,
+            mincut_terms=diff_scales is None, want_dense=True, diff_stats=diff_scales is not None)
+        s, mask, x_pool, raw, adj_pool, terms, bp, xd, ad = got[:9]
         empty = s.new_empty(0)
         la = lb = diff = empty
-        if diff_scales is not None:  # DiffPool's two losses from the adjacency the launch left (utils/losses.py:644-658)
-            diff = K.diffpool_loss_tail(s, ad, graph_sizes, diff_scales[0], diff_scales[1])
+        if diff_scales is not None:
+            # DiffPool's two losses from the per-graph records the launch left (utils/losses.py:644-658, 476-483):
+            # |A - S S^T|^2 = sum A^2 - 2 trace(S^T A S) + |S^T S|^2 -- one tail launch (r6; four behind the adjacency)
+            diff = K.diffpool_stats_tail(got[9], diff_scales[0], diff_scales[1])
             la, lb = diff[0], diff[1]
         elif want_terms:
             both = terms.mean(dim=1)

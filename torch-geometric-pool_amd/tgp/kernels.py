@@ -1292,7 +1292,7 @@ class AdjSymmetry:
 def dense_pool_select_sparse(x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], batch: Tensor,
                              node_ptr: Tensor, edge_ptr: Tensor, num_graphs: int, max_nodes: int, weight: Tensor,
                              bias: Optional[Tensor], flags: int, adj_transpose: bool, want_raw: bool = False,
-                             mincut_terms: bool = False, want_dense: bool = False):
+                             mincut_terms: bool = False, want_dense: bool = False, diff_stats: bool = False):
     """(s [B,N,K], mask [B,N], x_pool, adj_raw, adj_pool, terms, batch_pool): :func:`dense_pool_select` straight from
     the un-padded batch -- x [Ntot,F], a ROW-SORTED ``edge_index`` with the per-graph ranges ``node_ptr`` / ``edge_ptr``
     [B+1] -- in ONE launch: the adjacency tiles are built in LDS from the edges, neither ``to_dense_batch`` nor
@@ -1319,15 +1319,30 @@ def dense_pool_select_sparse(x: Tensor, edge_index: Tensor, edge_weight: Optiona
     # (want_dense="adj": the adjacency alone -- DiffPool's losses read it in inference)
     xd = torch.empty(B, Nn, F, dtype=torch.float32, device=dev) if want_dense is True else None
     ad = torch.empty(B, Nn, Nn, dtype=torch.float32, device=dev) if want_dense else None
+    # diff_stats (r6): a LAST value [B,4] = per-graph (sum A^2, trace(S^T A S), |S^T S|_F^2, entropy sum): DiffPool's two
+    # losses without the dense adjacency (:func:`diffpool_stats_tail`)
+    dstats = torch.empty(B, 4, dtype=torch.float32, device=dev) if diff_stats else None
     N.check(N.lib().tgp_dense_pool_select_sparse_f32(
         N.ptr(x), x.size(0), N.ptr(row) if E else None, N.ptr(col) if E else None, N.ptr(w), E, N.ptr(N.i64c(batch)),
         N.ptr(N.i64c(node_ptr)), N.ptr(N.i64c(edge_ptr)), N.ptr(weight), N.ptr(b), B, Nn, K, F, flags,
         1 if adj_transpose else 0, ops_eps(), losses_eps(), N.ptr(s), mask.data_ptr(), N.ptr(x_pool), N.ptr(adj_raw),
-        N.ptr(adj_pool), N.ptr(terms), N.ptr(bp), N.ptr(xd), N.ptr(ad), N.stream_ptr(dev)),
+        N.ptr(adj_pool), N.ptr(terms), N.ptr(bp), N.ptr(xd), N.ptr(ad), N.ptr(dstats), N.stream_ptr(dev)),
         "tgp_dense_pool_select_sparse_f32")
+    tail = (dstats,) if diff_stats else ()
     if want_dense:
-        return s, mask, x_pool, adj_raw, adj_pool, terms, bp, xd, ad
-    return s, mask, x_pool, adj_raw, adj_pool, terms, bp
+        return (s, mask, x_pool, adj_raw, adj_pool, terms, bp, xd, ad) + tail
+    return (s, mask, x_pool, adj_raw, adj_pool, terms, bp) + tail
+
+
+def diffpool_stats_tail(stats: Tensor, link_scale: float, ent_scale: float) -> Tensor:
+    """[2]: DiffPool's (link loss * link_scale, entropy sum * ent_scale) from the [B,4] records of
+    ``dense_pool_select_sparse(diff_stats=True)`` (utils/losses.py:644-658, 476-483), one launch."""
+    dev = N.require_device(stats)
+    stats = N.f32c(stats)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    N.check(N.lib().tgp_diffpool_stats_tail_f32(N.ptr(stats), stats.size(0), float(link_scale), float(ent_scale),
+                                                N.ptr(out), N.stream_ptr(dev)), "tgp_diffpool_stats_tail_f32")
+    return out
 
 
 def dense_pool_is_small(B: int, Nn: int, K: int, F: int) -> bool:

@@ -329,20 +329,21 @@ class _DenseMLPPooling(DenseSRCPooling):
                 x, edge_index, edge_weight, batch, info.ptr, edge_ptr, info.num_graphs, info.max_nodes,
                 last.weight.detach(), None if last.bias is None else last.bias.detach(), flags, self.adj_transpose,
                 want_raw=True, mincut_terms=True)
-        else:  # the losses are computed behind the launch from the dense adjacency it leaves (no zero fill, no scatter)
-            s, mask, x_pool, raw, adj_pool, terms, bp, _xd, ad = K.dense_pool_select_sparse(
+        else:  # DiffPool, inference (r6): both losses from per-graph records of the same launch -- no dense adjacency
+            s, mask, x_pool, raw, adj_pool, terms, bp, dstats = K.dense_pool_select_sparse(
                 x, edge_index, edge_weight, batch, info.ptr, edge_ptr, info.num_graphs, info.max_nodes,
                 last.weight.detach(), None if last.bias is None else last.bias.detach(), flags, self.adj_transpose,
-                want_raw=False, mincut_terms=False, want_dense="adj")
+                want_raw=False, mincut_terms=False, diff_stats=True)
+            numel = info.num_graphs * info.max_nodes * info.max_nodes  # adj.numel() of the padded batch (losses.py:651)
+            link_scale = self.link_loss_coeff / numel if self.normalize_loss is True else self.link_loss_coeff
+            terms = K.diffpool_stats_tail(dstats, float(link_scale), float(self.ent_loss_coeff) / x.size(0))
         if pending is not None and not K.edge_facts_finish(pending, edge_index, info.ptr):
             return None  # rows not sorted: what the kernel computed on clamped ranges is dropped
         so = SelectOutput(s=s, s_inv_op=sel.s_inv_op, in_mask=mask)
         so._graph_sizes = info.sizes
         if not self._loss_needs_raw:
-            if training:  # (both losses came with the fused call: a LossPair in the slot of `diff`)
-                return so, (x_pool, None, adj_pool, None, terms), bp, None
-            self._sizes_hint = (weakref.ref(ad), info.sizes)
-            return so, (x_pool, None, adj_pool, None, None), bp, ad
+            # (both losses came with the fused call: a LossPair -- training -- or a [2] tensor in the slot of `diff`)
+            return so, (x_pool, None, adj_pool, None, terms), bp, None
         return so, (x_pool, raw, adj_pool, terms, None), bp, None
 
     def _select_reduce_connect_train(self, x, adj, mask, graph_sizes, want_batch=False):
