@@ -323,3 +323,50 @@ def test_mincut_forward_from_the_unpadded_batch_equals_the_densified_one(dev, ad
         fresh = pooler(x=x, adj=ei3, edge_weight=ew, batch=bd.clone())
     assert calls == [1] and K_._rows_sorted_memo(ei3) is True
     torch.testing.assert_close(fresh.x, old.x, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("adj_transpose", [True, False])
+@pytest.mark.parametrize("weighted,normalize", [(False, False), (True, True)])
+def test_diffpool_forward_losses_from_the_pooling_launch(dev, adj_transpose, weighted, normalize, monkeypatch):
+    """r6: get_pooler('diff') in inference on a sorted batch of small graphs: both losses come from per-graph records of the
+    pooling launch -- |A - S S^T|^2 = sum A^2 - 2 trace(S^T A S) + |S^T S|^2 (utils/losses.py:644-658) and the entropy sum
+    (476-483) -- and one tail launch; no dense adjacency is written.  Equal to the densified path, whose link loss is the
+    residual product on the dense [B,N,N] adjacency: duplicates summed, self loops, a graph without edges, a column that
+    leaves its row's graph."""
+    from tgp import kernels as K_
+    from tgp import poolers as P
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(29)
+    B = 70
+    sizes = torch.randint(5, 61, (B,), generator=g)
+    n = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(B), sizes)
+    start = torch.cumsum(sizes, 0) - sizes
+    deg = torch.randint(0, 7, (n,), generator=g)
+    deg[batch == 5] = 0
+    row = torch.repeat_interleave(torch.arange(n), deg)
+    col = start[batch[row]] + (torch.rand(row.numel(), generator=g) * sizes[batch[row]]).long()
+    col[::7] = row[::7]
+    col[1::13] = col[0::13][: col[1::13].numel()]
+    ei = torch.stack([row, col]).to(dev)
+    ew = (torch.rand(row.numel(), generator=g) + 0.1).to(dev) if weighted else None
+    x = torch.randn(n, 32, generator=g).to(dev)
+    bd = batch.to(dev)
+    torch.manual_seed(0)
+    pooler = get_pooler("diff", in_channels=32, k=20, adj_transpose=adj_transpose, normalize_loss=normalize).to(dev).eval()
+    seen = []
+    real = K_.dense_pool_select_sparse
+    monkeypatch.setattr(K_, "dense_pool_select_sparse",
+                        lambda *a, **k: (seen.append((k.get("diff_stats"), k.get("want_dense"))), real(*a, **k))[1])
+    with torch.no_grad():
+        monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", True)
+        new = pooler(x=x, adj=ei, edge_weight=ew, batch=bd)
+        assert seen == [(True, None)]  # records asked for, no dense adjacency
+        monkeypatch.setattr(P, "_FOLD_SPARSE_INPUTS", False)
+        old = pooler(x=x, adj=ei, edge_weight=ew, batch=bd)
+    torch.testing.assert_close(new.x, old.x, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(new.edge_index, old.edge_index, rtol=1e-5, atol=1e-6)
+    assert set(new.loss) == set(old.loss) == {"link_loss", "entropy_loss"}
+    for k in old.loss:
+        torch.testing.assert_close(new.loss[k], old.loss[k], rtol=1e-5, atol=1e-7)
