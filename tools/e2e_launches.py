@@ -69,6 +69,9 @@ CASES = {
     "mincut_c2": ("mincut", dict(in_channels=64, k=128), [1024] * 32, 10, 64),
     "mincut_c3": ("mincut", dict(in_channels=32, k=20), None, 4, 32),
     "diff_c3": ("diff", dict(in_channels=32, k=20), None, 4, 32),
+    "mincut_u_c3": ("mincut_u", dict(in_channels=32, k=20), None, 4, 32),
+    "diff_u_c3": ("diff_u", dict(in_channels=32, k=20), None, 4, 32),
+    "mincut_u_c2": ("mincut_u", dict(in_channels=64, k=128), [1024] * 32, 10, 64),
     "topk_c3": ("topk", dict(in_channels=32, ratio=0.5), None, 4, 32),
     "graclus_c3": ("graclus", dict(), None, 4, 32),
     "ndp_c3": ("ndp", dict(), None, 4, 32),
