@@ -22,6 +22,9 @@ TGP_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29618 python3 bench.py 
 python3 tools/bench_graclus_hubs.py 2>&1 | grep -v -i 'warn\|amdgpu.ids' > $out/graclus_hubs.txt
 python3 tools/bench_ndp_hubs.py 2>&1 | grep -v -i 'warn\|amdgpu.ids' > $out/ndp_hubs_after.txt
 stats bench python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
+# the headline alone: the secondaries (training steps) launch the same GEMM instantiation on other shapes, so only this
+# run's average for gemm_f32_mfma_kernel<false,true,128,64,0,2> is the headline kernel's duration
+stats bench_headline python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --secondary none
 stats c4_graclus_sorted python3 bench.py --workload c4_graclus --secondary none --no-cpu-baseline --steps 50
 stats c4_graclus_unsorted python3 bench.py --workload c4_graclus --unsorted-edges --secondary none --no-cpu-baseline --steps 50
 stats topk_connect python3 bench.py --workload topk_connect --secondary none --no-cpu-baseline --steps 50
@@ -64,5 +67,5 @@ cp $out/pmc_coalesce_c4_sorted_TCC_MISS_sum.csv $out/tcc_miss_coalesce.csv 2>/de
 rm -f $out/pmc_coalesce_c4_sorted_TCC_*.csv  # (pmc_summary.py reads every pmc_*_*.csv as a FETCH / WRITE pass)
 python3 tools/tcc_summary.py $out/tcc_hit_coalesce.csv $out/tcc_miss_coalesce.csv > $out/tcc_coalesce.md 2>&1
 python3 tools/pmc_summary.py $out --json $out/roofline_traffic.json --source profiles/${tag}_pmc_summary.md > $out/pmc_summary.md
-rm -rf $out/pmc_*_FETCH_SIZE $out/pmc_*_WRITE_SIZE $out/pmc_*_TCC_HIT_sum $out/pmc_*_TCC_MISS_sum $out/bench $out/c4_graclus_sorted $out/c4_graclus_unsorted $out/topk_connect $out/kron
+rm -rf $out/pmc_*_FETCH_SIZE $out/pmc_*_WRITE_SIZE $out/pmc_*_TCC_HIT_sum $out/pmc_*_TCC_MISS_sum $out/bench $out/bench_headline $out/c4_graclus_sorted $out/c4_graclus_unsorted $out/topk_connect $out/kron
 ls $out | head -60
