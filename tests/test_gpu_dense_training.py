@@ -244,6 +244,11 @@ ROWS_CASES = [  # alias, graph sizes, K, F, weighted, adj_transpose, hidden laye
     ("diff", [400, 300], 40, 24, True, True, None),
     ("diff", [350, 420, 380], 72, 16, False, True, None),
     ("diff", [400, 300], 36, 12, True, False, 20),         # a selector with a hidden layer
+    # K % 16 == 0 in (64, 176] with adj_transpose: the post-processing launch sums the slabs AND transposes them (r6, late)
+    ("mincut", [400, 300], 80, 24, True, True, None),
+    ("diff", [350, 420, 380], 128, 16, False, True, None),
+    ("mincut", [500, 480], 176, 8, True, True, None),
+    ("diff", [400, 300], 112, 20, True, False, None),       # the same K range without the transposition
 ]
 
 
@@ -268,14 +273,17 @@ def test_batched_poolers_sparse_input_rows_route(dev, alias, sizes, k, f, weight
     pooler.eval()
     with torch.no_grad():
         out = pooler(x=x.to(dev), **args)
-    ref = O.dense_pool(alias, x, ei, wts, batch, [l.weight.detach().cpu() for l in lins], [l.bias.detach().cpu() for l in lins],
-                       act=None if hidden is None else "tanh", adj_transpose=adj_t)
-    torch.testing.assert_close(out.x.cpu(), ref["x"], rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(out.edge_index.cpu(), ref["edge_index"], rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(out.so.s.cpu(), ref["s"], rtol=1e-5, atol=1e-7)
+    # (the oracle in float64: its float32 run of |A - S S^T| over [B,N,N] carries more rounding error than the 1e-5 asked
+    #  of the kernels -- 2.6e-5 on the K = 128 case against 1e-8 for the product path, tools/link_loss_precision.py)
+    ref = O.dense_pool(alias, x.double(), ei, wts.double(), batch, [l.weight.detach().cpu().double() for l in lins],
+                       [l.bias.detach().cpu().double() for l in lins], act=None if hidden is None else "tanh",
+                       adj_transpose=adj_t)
+    torch.testing.assert_close(out.x.cpu().double(), ref["x"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out.edge_index.cpu().double(), ref["edge_index"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out.so.s.cpu().double(), ref["s"], rtol=1e-5, atol=1e-7)
     assert out.so.s.shape == (len(sizes), max(sizes), k) and torch.equal(out.mask.cpu(), ref["mask"])
     for name, want in ref["loss"].items():
-        torch.testing.assert_close(out.loss[name].cpu(), want, rtol=2e-5, atol=1e-6, msg=lambda m: f"{name}: {m}")
+        torch.testing.assert_close(out.loss[name].cpu().double(), want, rtol=1e-5, atol=1e-6, msg=lambda m: f"{name}: {m}")
 
     # training
     pooler.train()

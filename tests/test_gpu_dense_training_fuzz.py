@@ -21,7 +21,7 @@ def _random_batch(seed):
     n_graphs = r(1, 5)
     sizes = [r(2, 6) if r(0, 3) == 0 else r(40, 230) for _ in range(n_graphs)]
     sizes[r(0, n_graphs - 1)] = r(70, 260)  # at least one graph beyond the one-wave kernels
-    k = [3, 7, 20, 33, 65, 130][r(0, 5)]
+    k = [3, 7, 20, 33, 65, 130, 80, 112][r(0, 7)]
     f = [1, 3, 5, 17, 32][r(0, 4)]
     directed, weighted, duplicates = r(0, 1) == 1, r(0, 2) > 0, r(0, 3) == 0
     xs, eis, bs, off = [], [], [], 0

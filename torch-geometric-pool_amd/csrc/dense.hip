@@ -1088,10 +1088,16 @@ extern "C" int tgp_segment_gemm_tn3_post_f32(const float* S, const float* Y0, co
   PostArgs q{};
   q.K = static_cast<int>(K); q.flags = flags; q.eps = eps; q.dst = adj_pool; q.ld_src = K;
   bool folded = false;
-  if (transpose0) {  // raw leaves the combine transposed; the post-processing then reads it as a finished matrix
+  // (r6, late) K % 16 == 0 in post_lds_kernel's range: that kernel also transposes while it sums the slabs
+  static const int no_tr_fold = getenv("TGP_NO_TRANSPOSED_POST") ? 1 : 0;
+  PostArgs qs = q;  // the form that reads the slabs of the first product itself
+  qs.src = slab[0]; qs.splits = splits; qs.s_split = K * K; qs.s_batch = static_cast<long>(splits) * K * K; qs.raw = raw;
+  const bool fold_tr = transpose0 && !no_tr_fold && K % 16 == 0 && post_lds_takes(qs);
+  if (transpose0 && !fold_tr) {  // raw leaves the combine transposed; the post-processing then reads it as a finished matrix
     q.src = raw; q.splits = 1; q.s_split = 0; q.s_batch = K * K; q.raw = nullptr;
   } else {
-    q.src = slab[0]; q.splits = splits; q.s_split = K * K; q.s_batch = static_cast<long>(splits) * K * K; q.raw = raw;
+    q = qs;
+    q.transpose_src = transpose0 ? 1 : 0;
     ca.total[0] = 0;  // (summed by the post-processing itself)
   }
   long max_total = 0;
@@ -1103,7 +1109,7 @@ extern "C" int tgp_segment_gemm_tn3_post_f32(const float* S, const float* Y0, co
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(combine_slabs3_kernel, dim3(gx, static_cast<unsigned>(B), 3), dim3(256), 0, stream, ca);
   };
-  if (transpose0) {
+  if (transpose0 && !fold_tr) {
     combine();
     launch_post(q, B, postws, stream);
   } else {

@@ -27,6 +27,9 @@ struct PostArgs {
   float* dst;        // optional [B][K][K]
   float* dvec;       // [B][K]
   float* maxpart;    // [B][POST_BLOCKS]
+  // r6 (post_lds_kernel only, K % 16 == 0): the slabs hold the TRANSPOSE of the matrix to post-process (the rows route's
+  // S^T (A S) when the batched poolers want S^T A^T S): summed slab element (a, b) becomes element (b, a) of raw / dst
+  int transpose_src;
 };
 
 template <int VEC>
@@ -323,6 +326,28 @@ __global__ __launch_bounds__(1024) void post_lds_kernel(PostArgs p, int B, XComb
   float* dstb = p.dst ? p.dst + static_cast<long>(b) * kk : nullptr;
   const bool rsl = p.flags & TGP_REMOVE_SELF_LOOPS;
   // pass 1: fixed-order slab sum -> raw output, diag-cleared copy in LDS  (K % 4 == 0, ld_src == K here)
+  if (p.transpose_src) {
+    // 16 x 16 patches: 4 lanes cover 64 contiguous bytes of a source row, 16 lanes the patch's 16 source rows; the
+    // transposed stores then run along the 16 source rows: 64-byte runs in memory, 16 distinct LDS banks (4-way conflicts)
+    const int kt = K >> 4;
+    for (int v = tid; v < kk / 4; v += 1024) {
+      const int lb = v & 3, la = (v >> 2) & 15, tile = v >> 6;
+      const int a = 16 * (tile / kt) + la, bq = 16 * (tile % kt) + 4 * lb;
+      const int e = a * K + bq;
+      float4 t = *reinterpret_cast<const float4*>(sb + e);
+      for (int sp = 1; sp < p.splits; ++sp) {
+        const float4 u = *reinterpret_cast<const float4*>(sb + sp * p.s_split + e);
+        t.x = __fadd_rn(t.x, u.x); t.y = __fadd_rn(t.y, u.y); t.z = __fadd_rn(t.z, u.z); t.w = __fadd_rn(t.w, u.w);
+      }
+      const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int i = bq + c;  // destination row = source column
+        if (rawb) rawb[i * K + a] = tv[c];
+        m[i * K + a] = (rsl && i == a) ? 0.f : tv[c];
+      }
+    }
+  } else
   for (int e = tid * 4; e < kk; e += 4096) {
     float4 t = *reinterpret_cast<const float4*>(sb + e);
     auto add4 = [](float4& a, const float4& u) {
@@ -567,6 +592,15 @@ static bool post_rows_ok(int64_t K, int flags, const void* slab, const void* raw
 
 static size_t post_ws_floats(int64_t B, int64_t K) { return static_cast<size_t>(B * K + B * POST_BLOCKS); }
 
+// does launch_post hand this problem to post_lds_kernel (the only kernel that honours PostArgs.transpose_src)?
+static bool post_lds_takes(const PostArgs& p) {
+  static const int no_lds = getenv("TGP_NO_POST_LDS") ? 1 : 0;
+  const int K = p.K;
+  return !no_lds && K > 64 && K <= POST_LDS_MAX_K && K % 4 == 0 && p.ld_src == K && p.s_split % 4 == 0 &&
+         p.s_batch % 4 == 0 && reinterpret_cast<uintptr_t>(p.src) % 16 == 0 &&
+         (!p.raw || reinterpret_cast<uintptr_t>(p.raw) % 16 == 0) && (!p.dst || reinterpret_cast<uintptr_t>(p.dst) % 16 == 0);
+}
+
 // Returns whether the slab combines described by xc / xc2 (if any) were folded into the launch (both or none).
 static bool launch_post(PostArgs p, int64_t B, float* ws, hipStream_t stream, const XCombineArgs* xc = nullptr,
                         const XCombineArgs* xc2 = nullptr) {
@@ -577,10 +611,7 @@ static bool launch_post(PostArgs p, int64_t B, float* ws, hipStream_t stream, co
     else hipLaunchKernelGGL(post_small_kernel, grid, dim3(256), 0, stream, p, static_cast<int>(B));
     return false;
   }
-  static const int no_lds = getenv("TGP_NO_POST_LDS") ? 1 : 0;
-  if (!no_lds && K <= POST_LDS_MAX_K && K % 4 == 0 && p.ld_src == K && p.s_split % 4 == 0 && p.s_batch % 4 == 0 &&
-      reinterpret_cast<uintptr_t>(p.src) % 16 == 0 && (!p.raw || reinterpret_cast<uintptr_t>(p.raw) % 16 == 0) &&
-      (!p.dst || reinterpret_cast<uintptr_t>(p.dst) % 16 == 0)) {
+  if (post_lds_takes(p)) {
     XCombineArgs x{}, x2{};
     auto blocks_of = [](XCombineArgs& a) {
       a.blocks_per_graph = static_cast<int>((a.total + 4095) / 4096);
