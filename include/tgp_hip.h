@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10037 /* 1.0.1 of the reference, ABI revision 36 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
+#define TGP_ABI_VERSION 10038 /* 1.0.1 of the reference, ABI revision 37 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -388,6 +388,13 @@ int tgp_dense_pool_select_sparse_f32(const float* x, int64_t Ntot, const int64_t
                                                           sum -S log(S + loss_eps)) per graph: DiffPool's two losses
                                                           (utils/losses.py:644-658, 476-483) without the dense adjacency */,
                                      void* stream);
+/* r6: the same records from the one-wave-per-graph kernel on PADDED inputs (x [B,N,F], adj [B,N,N]; what the second
+ * pooling layer of a hierarchical model is handed): S [B,N,K] given (W = NULL), or the selector folded in (S = NULL: W
+ * [K,F], bias, mask [B,N] bytes or NULL; S_out [B,N,K] is written).  Batches tgp_dense_pool_is_small accepts. */
+int tgp_dense_pool_small_diff_f32(const float* S, const float* A, const float* X, const float* W, const float* bias,
+                                  const unsigned char* mask, int64_t B, int64_t N, int64_t K, int64_t F, int flags,
+                                  float eps, float loss_eps, float* S_out, float* x_pool, float* adj_raw, float* adj_pool,
+                                  float* diff_stats /* [B,4] */, int64_t* batch_pool /* [B*K] or NULL */, void* stream);
 /* r6: DiffPool's link-prediction and entropy losses from those records: out2[0] = sqrt(max(sum_b (a2 - 2 tr + fro), 0)) *
  * link_scale, out2[1] = (sum_b ent) * ent_scale; one launch (the residual product, its partial sum, the entropy pass and
  * the tail were four). */

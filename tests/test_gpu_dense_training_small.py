@@ -398,3 +398,50 @@ def test_dense_pooler_training_step_from_the_unpadded_batch(dev, alias, adj_tran
             assert new[3] is None and old[3] is None
         for a, b in zip(new[4], old[4]):
             torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-5 * max(1.0, float(b.abs().max())))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden", [None, 12])
+@pytest.mark.parametrize("train", [False, True])
+def test_diffpool_padded_small_graphs_losses_from_the_pooling_launch(dev, monkeypatch, hidden, train):
+    """r6: DiffPool on PADDED inputs that take the one-wave-per-graph kernel (x [B,N,F], adj [B,N,N] -- what the second
+    layer of a hierarchical model gets): both losses come from the launch's per-graph records and ONE tail launch
+    (tgp_dense_pool_small_diff_f32 + tgp_diffpool_stats_tail_f32), with the selector folded in (single Linear) or S handed
+    over (hidden layer); inference and training.  Against the oracle in float64 (utils/losses.py:644-658, 476-483)."""
+    import tgp_oracle as O
+    from tgp import kernels as K_
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(41)
+    B, Nn, F, k = 80, 40, 16, 12  # (the one-wave-per-graph kernel takes batches of >= 64 graphs)
+    a = (torch.rand(B, Nn, Nn, generator=g) < 0.15).float() * (torch.rand(B, Nn, Nn, generator=g) + 0.2)
+    a = a + a.transpose(1, 2)
+    x = torch.randn(B, Nn, F, generator=g)
+    chans = F if hidden is None else [F, hidden]
+    torch.manual_seed(3)
+    pooler = get_pooler("diff", in_channels=chans, k=k, **({} if hidden is None else {"act": "tanh"})).to(dev)
+    pooler.train(train)
+    lins = pooler.selector.mlp.lins
+    tails = []
+    real = K_.diffpool_stats_tail
+    monkeypatch.setattr(K_, "diffpool_stats_tail", lambda *a_, **k_: (tails.append(1), real(*a_, **k_))[1])
+    xg = x.to(dev).requires_grad_(train)
+    with torch.set_grad_enabled(train):
+        out = pooler(x=xg, adj=a.to(dev))
+    assert tails == [1]  # the losses took the records path
+    ws = [l.weight.detach().cpu().double().requires_grad_(train) for l in lins]
+    bs = [l.bias.detach().cpu().double().requires_grad_(train) for l in lins]
+    xr = x.double().requires_grad_(train)
+    ref = O.dense_pool("diff", xr, a.double(), None, None, ws, bs, act=None if hidden is None else "tanh")
+    torch.testing.assert_close(out.x.detach().cpu().double(), ref["x"].detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out.edge_index.detach().cpu().double(), ref["edge_index"].detach(), rtol=1e-5, atol=1e-6)
+    for name, want in ref["loss"].items():
+        torch.testing.assert_close(out.loss[name].detach().cpu().double(), want.detach(), rtol=1e-5, atol=1e-7,
+                                   msg=lambda m, n=name: f"{n}: {m}")
+    if train:
+        (out.x.sum() * 0.3 + out.edge_index.square().sum() + 0.7 * out.loss["link_loss"] + 1.3 * out.loss["entropy_loss"]).backward()
+        (ref["x"].sum() * 0.3 + ref["edge_index"].square().sum() + 0.7 * ref["loss"]["link_loss"]
+         + 1.3 * ref["loss"]["entropy_loss"]).backward()
+        pairs = [(xg.grad, xr.grad)] + [(l.weight.grad, w.grad) for l, w in zip(lins, ws)] + \
+            [(l.bias.grad, b.grad) for l, b in zip(lins, bs)]
+        for got, want in pairs:
+            torch.testing.assert_close(got.cpu().double(), want, rtol=2e-4, atol=1e-5 * max(1.0, float(want.abs().max())))

@@ -190,6 +190,34 @@ extern "C" int tgp_dense_pool_select_sparse_f32(const float* x, int64_t Ntot, co
   return check_launch("tgp_dense_pool_select_sparse_f32");
 }
 
+// r6: the one-wave-per-graph kernel on PADDED inputs with DiffPool's per-graph records (SmallArgs.diff_stats) -- the form a
+// second pooling layer of a hierarchical model meets (x [B,N,F], adj [B,N,N] dense).  S given (W == NULL) or the selector
+// folded in (S == NULL: S_out [B,N,K] is written).  The losses then need tgp_diffpool_stats_tail_f32 only.
+extern "C" int tgp_dense_pool_small_diff_f32(const float* S, const float* A, const float* X, const float* W,
+                                             const float* bias, const unsigned char* mask, int64_t B, int64_t N,
+                                             int64_t K, int64_t F, int flags, float eps, float loss_eps, float* S_out,
+                                             float* x_pool, float* adj_raw, float* adj_pool, float* diff_stats,
+                                             int64_t* batch_pool, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(B >= 0 && N >= 0 && K >= 0 && F >= 0, TGP_ERR_INVALID, "tgp_dense_pool_small_diff_f32: negative size");
+  if (B == 0 || N == 0 || K == 0) return TGP_OK;
+  TGP_REQUIRE(A && X && F > 0 && diff_stats && (adj_raw || adj_pool) && ((S && !W) || (W && S_out && !S)), TGP_ERR_INVALID,
+              "tgp_dense_pool_small_diff_f32: A, X, diff_stats, a Connect output and either S or (W, S_out) are required");
+  TGP_REQUIRE(dense_pool_small_ok(B, N, K, F), TGP_ERR_INVALID,
+              "tgp_dense_pool_small_diff_f32: only batches the one-wave-per-graph kernel takes (tgp_dense_pool_is_small)");
+  SmallArgs q{S, A, X, static_cast<int>(B), static_cast<int>(N), static_cast<int>(K), static_cast<int>(F), flags, eps,
+              x_pool, adj_raw, adj_pool, nullptr, loss_eps, W, W ? bias : nullptr, W ? mask : nullptr, W ? S_out : nullptr,
+              reinterpret_cast<long long*>(batch_pool)};
+  q.diff_stats = diff_stats;
+  const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(SG_WAVES * SG_WAVE_FLOATS * sizeof(float)));
+  hipLaunchKernelGGL(dense_pool_small_kernel<false>, dim3(grid), dim3(64 * SG_WAVES),
+                     SG_WAVES * SG_WAVE_FLOATS * sizeof(float), stream, q);
+  return check_launch("tgp_dense_pool_small_diff_f32");
+}
+
 extern "C" int tgp_dense_pool_small_bwd_f32(const float* S, const float* A, const float* X, int64_t B, int64_t N,
                                             int64_t K, int64_t F, int flags, float eps, float loss_eps,
                                             const float* g_x_pool, const float* g_adj_pool, const float* g_adj_raw,

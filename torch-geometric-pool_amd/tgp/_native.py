@@ -101,6 +101,8 @@ SIGNATURES = {
                                                   _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_f, _c_f, _c_p, _c_p, _c_p,
                                                   _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "tgp_diffpool_stats_tail_f32": (_c_int, [_c_p, _c_i64, _c_f, _c_f, _c_p, _c_p]),
+    "tgp_dense_pool_small_diff_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
+                                               _c_f, _c_f, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "tgp_dense_pool_small_bwd_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_f, _c_f, _c_p,
                                               _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_f, _c_f, _c_int,
                                               _c_p, _c_p, _c_p]),

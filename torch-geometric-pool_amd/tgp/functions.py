@@ -676,16 +676,24 @@ class LossPair(tuple):
 def _pool_small_forward(sd, ad, xd, flags, want_raw, want_terms, diff_scales, graph_sizes, scalars, pre=None):
     """Shared forward of the two fused Functions below: (x_pool, raw, adj_pool, terms, diff, loss_a, loss_b)."""
     from . import kernels as K
-    if pre is None:
+    stats = None
+    if pre is None and diff_scales is not None and not want_terms:
+        # DiffPool (r6): the kernel leaves per-graph records instead of MinCut's terms; both losses are one tail launch
+        x_pool, raw, adj_pool, stats = K.dense_pool(sd, ad, xd, flags, want_raw=want_raw, want_post=True, diff_stats=True)
+        terms = sd.new_empty(0) if stats is not None else None
+    elif pre is None:
         x_pool, raw, adj_pool, terms = K.dense_pool(sd, ad, xd, flags, want_raw=want_raw, want_post=True,
                                                     mincut_terms=True)
     else:
-        x_pool, raw, adj_pool, terms = pre
+        x_pool, raw, adj_pool, terms = pre[:4]
+        stats = pre[4] if len(pre) > 4 else None
     if terms is None:
         raise RuntimeError("the batch does not take the one-wave-per-graph kernel")
     empty = sd.new_empty(0)
     diff = empty
-    if diff_scales is not None:
+    if diff_scales is not None and stats is not None:
+        diff = K.diffpool_stats_tail(stats, diff_scales[0], diff_scales[1])
+    elif diff_scales is not None:
         diff = K.diffpool_loss_tail(sd, ad, graph_sizes, diff_scales[0], diff_scales[1])
     la = lb = empty
     if scalars:
@@ -783,13 +791,15 @@ class _SelectPoolSmallFn(torch.autograd.Function):
         from . import kernels as K
         ctx.set_materialize_grads(False)
         xd, ad = x.detach(), adj.detach()
+        dstats = diff_scales is not None and not want_terms  # DiffPool (r6): per-graph records instead of MinCut's terms
         s, x_pool, raw, adj_pool, terms, bp = K.dense_pool_select(
             xd, ad, weight.detach(), None if bias is None else bias.detach(), mask, flags, want_raw=want_raw,
-            mincut_terms=True, want_batch=True) if want_batch else K.dense_pool_select(
+            mincut_terms=not dstats, want_batch=True, diff_stats=dstats) if want_batch else K.dense_pool_select(
             xd, ad, weight.detach(), None if bias is None else bias.detach(), mask, flags, want_raw=want_raw,
-            mincut_terms=True) + (torch.empty(0, dtype=torch.long, device=x.device),)
+            mincut_terms=not dstats, diff_stats=dstats) + (torch.empty(0, dtype=torch.long, device=x.device),)
+        pre = (x_pool, raw, adj_pool, s.new_empty(0), terms) if dstats else (x_pool, raw, adj_pool, terms)
         x_pool, raw, adj_pool, terms, diff, la, lb = _pool_small_forward(
-            s, ad, xd, flags, want_raw, want_terms, diff_scales, graph_sizes, True, pre=(x_pool, raw, adj_pool, terms))
+            s, ad, xd, flags, want_raw, want_terms, diff_scales, graph_sizes, True, pre=pre)
         ctx.save_for_backward(s, adj, x, diff, weight)
         ctx.flags = flags
         ctx.want_gx = x.requires_grad  # (node features that are data, not activations: neither backward forms dX)

@@ -1036,7 +1036,7 @@ def _dense_pool_f64(s, adj, x, flags, want_raw, want_post, out_x, out_adj):
 
 def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int = 0, want_raw: bool = False,
                want_post: bool = True, graph_sizes: Optional[Tensor] = None, out_x: Optional[Tensor] = None,
-               out_adj: Optional[Tensor] = None, mincut_terms: bool = False):
+               out_adj: Optional[Tensor] = None, mincut_terms: bool = False, diff_stats: bool = False):
     """(x_pool, adj_raw, adj_pool) = (S^T X, S^T A S, postprocess(S^T A S)) for a padded batch
     (reduce/base_reduce.py:158-161, connect/dense_conn.py:111-122, utils/ops.py:282-335).  ``graph_sizes`` [B]
     (optional): real nodes per graph when they are the leading rows and the padding is zero (to_dense_batch layout).
@@ -1068,6 +1068,17 @@ def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int
         if want_post:
             adj_pool = _out_buffer(out_adj, (B, K, K), dev)
     L = N.lib()
+    if diff_stats:
+        # (r6) a fourth value: DiffPool's per-graph records [B,4] from the one-wave-per-graph kernel (:func:`diffpool_stats_tail`),
+        # or None when the batch does not take that kernel (the caller computes the losses from the adjacency)
+        if (a is None or x is None or out_x is not None or out_adj is not None or not (want_raw or want_post)
+                or not L.tgp_dense_pool_is_small(B, Nn, K, F)):
+            return dense_pool(s, adj, x, flags & ~N.ADJ_TRANSPOSED, want_raw, want_post, graph_sizes, out_x, out_adj) + (None,)
+        stats = torch.empty(B, 4, dtype=torch.float32, device=dev)
+        N.check(L.tgp_dense_pool_small_diff_f32(N.ptr(s), N.ptr(a), N.ptr(x), None, None, None, B, Nn, K, F, flags, ops_eps(),
+                                                losses_eps(), None, N.ptr(x_pool), N.ptr(adj_raw), N.ptr(adj_pool),
+                                                N.ptr(stats), None, N.stream_ptr(dev)), "tgp_dense_pool_small_diff_f32")
+        return x_pool, adj_raw, adj_pool, stats
     ws = N.workspace(L.tgp_dense_pool_workspace_bytes(B, Nn, K, F), dev)
     if mincut_terms:
         terms = None
@@ -1086,7 +1097,8 @@ def dense_pool(s: Tensor, adj: Optional[Tensor], x: Optional[Tensor], flags: int
 
 
 def dense_pool_select(x: Tensor, adj: Tensor, weight: Tensor, bias: Optional[Tensor], mask: Optional[Tensor], flags: int,
-                      want_raw: bool = False, mincut_terms: bool = False, want_batch: bool = False):
+                      want_raw: bool = False, mincut_terms: bool = False, want_batch: bool = False,
+                      diff_stats: bool = False):
     """(s, x_pool, adj_raw, adj_pool, terms): MLPSelect's last Linear + softmax + mask, Reduce, Connect and the
     post-processing of a batch of small graphs in ONE launch (select/mlp_select.py:105-147, base_reduce.py:158-161,
     dense_conn.py:111-122, utils/ops.py:282-335); callers check :func:`dense_pool_is_small` first.  ``want_batch``: a
@@ -1112,6 +1124,13 @@ def dense_pool_select(x: Tensor, adj: Tensor, weight: Tensor, bias: Optional[Ten
     adj_raw = torch.empty(B, K, K, dtype=torch.float32, device=dev) if want_raw else None
     terms = torch.empty(2, B, dtype=torch.float32, device=dev) if mincut_terms else None
     bp = torch.empty(B * K, dtype=torch.int64, device=dev) if want_batch else None
+    if diff_stats:  # (r6) DiffPool: `terms` holds the per-graph records [B,4] of :func:`diffpool_stats_tail` instead
+        terms = torch.empty(B, 4, dtype=torch.float32, device=dev)
+        N.check(N.lib().tgp_dense_pool_small_diff_f32(None, N.ptr(a), N.ptr(x), N.ptr(weight), N.ptr(b), N.ptr(m), B, Nn, K,
+                                                      F, flags | tflag, ops_eps(), losses_eps(), N.ptr(s), N.ptr(x_pool),
+                                                      N.ptr(adj_raw), N.ptr(adj_pool), N.ptr(terms), N.ptr(bp),
+                                                      N.stream_ptr(dev)), "tgp_dense_pool_small_diff_f32")
+        return (s, x_pool, adj_raw, adj_pool, terms, bp) if want_batch else (s, x_pool, adj_raw, adj_pool, terms)
     N.check(N.lib().tgp_dense_pool_select_f32(N.ptr(x), N.ptr(a), N.ptr(weight), N.ptr(b), N.ptr(m), B, Nn, K, F,
                                               flags | tflag, ops_eps(), losses_eps(), N.ptr(s), N.ptr(x_pool),
                                               N.ptr(adj_raw), N.ptr(adj_pool), N.ptr(terms), N.ptr(bp),

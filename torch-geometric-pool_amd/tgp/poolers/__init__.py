@@ -249,14 +249,16 @@ class _DenseMLPPooling(DenseSRCPooling):
                 or not K.dense_pool_is_small(x.size(0), x.size(1), last.weight.size(0), x.size(2))):
             return None
         flags = K.dense_flags(c.remove_self_loops, c.degree_norm, c.adj_transpose, c.edge_weight_norm)
+        diff_scales = self._fused_diff_scales(adj, mask)
         out = K.dense_pool_select(
             x, adj, last.weight.detach(), None if last.bias is None else last.bias.detach(), mask, flags,
-            want_raw=self._loss_needs_raw, mincut_terms=self._loss_needs_raw, want_batch=want_batch)
+            want_raw=self._loss_needs_raw, mincut_terms=self._loss_needs_raw, want_batch=want_batch,
+            diff_stats=diff_scales is not None)
         s, x_pool, raw, adj_pool, terms = out[:5]
         so = SelectOutput(s=s, s_inv_op=sel.s_inv_op, in_mask=mask)
         fused = (x_pool, raw, adj_pool) + ((terms,) if self._loss_needs_raw else ())
-        if self._fused_diff_scales(adj, mask) is not None:
-            fused = fused + (None,)
+        if diff_scales is not None:  # DiffPool (r6): both losses from the launch's per-graph records, one tail launch
+            fused = fused + (K.diffpool_stats_tail(terms, diff_scales[0], diff_scales[1]),)
         return so, fused, (out[5] if want_batch else None)
 
     def _select_reduce_connect_sparse(self, x, edge_index, edge_weight, batch):
@@ -727,7 +729,7 @@ class DiffPool(_DenseMLPPooling):
 
     def _fused_diff_scales(self, adj, mask, adj_numel=None):
         num_nodes = self._real_nodes(mask)
-        if not (isinstance(num_nodes, int) and num_nodes > 0 and torch.is_grad_enabled()):
+        if not (isinstance(num_nodes, int) and num_nodes > 0):
             return None
         numel = adj.numel() if adj_numel is None else adj_numel
         link_scale = self.link_loss_coeff / numel if self.normalize_loss is True else self.link_loss_coeff

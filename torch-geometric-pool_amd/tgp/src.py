@@ -431,9 +431,19 @@ class DenseSRCPooling(SRCPooling):
             return res + (diff,) if want_diff_losses is not None else res
         # out_x / out_adj (optional, float32 [B,K,F] / [B,K,K]): the kernels write the pooled outputs straight into
         # caller memory, e.g. the next slot of distributed.PackedGather's send buffer (no pack copy before the RCCL call)
-        out = K.dense_pool(s, adj, x, flags, want_raw=want_raw, want_post=True,
-                           graph_sizes=getattr(so, "_graph_sizes", None), out_x=out_x, out_adj=out_adj,
-                           mincut_terms=want_mincut_terms)
+        diff = None
+        if (want_diff_losses is not None and not want_mincut_terms and out_x is None and out_adj is None
+                and s.dtype == torch.float32 and x.dtype == torch.float32 and adj.dtype == torch.float32):
+            # DiffPool, inference, a batch of small graphs (r6): both losses from the pooling launch's per-graph records
+            # (stats is None when the batch takes another kernel: the caller's own tail computes them then)
+            out = K.dense_pool(s, adj, x, flags, want_raw=want_raw, want_post=True,
+                               graph_sizes=getattr(so, "_graph_sizes", None), diff_stats=True)
+            if out[3] is not None:
+                diff = K.diffpool_stats_tail(out[3], want_diff_losses[0], want_diff_losses[1])
+        else:
+            out = K.dense_pool(s, adj, x, flags, want_raw=want_raw, want_post=True,
+                               graph_sizes=getattr(so, "_graph_sizes", None), out_x=out_x, out_adj=out_adj,
+                               mincut_terms=want_mincut_terms)
         x_pool, raw, adj_pool = out[:3]
         # fp32 arithmetic (fp64 when an operand is float64); results carry the dtypes the reference's ATen ops would return
         res = (like_input_dtype(x_pool, x), like_input_dtype(raw, s), like_input_dtype(adj_pool, s))
@@ -442,7 +452,7 @@ class DenseSRCPooling(SRCPooling):
         # the caller's own inference tail computes the two losses
         if want_mincut_terms:
             res = res + (out[3],)
-        return res + (None,) if want_diff_losses is not None else res
+        return res + (diff,) if want_diff_losses is not None else res
 
     def _finalize_sparse_output(self, x_pool: Tensor, adj_pool: Tensor, batch: Optional[Tensor],
                                 batch_pooled: Optional[Tensor], so: SelectOutput):
