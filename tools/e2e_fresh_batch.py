@@ -12,7 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "torch-geometric-pool_amd"))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from e2e_launches import CASES, batch_graphs  # noqa: E402
+from e2e_launches import CASES, batch_graphs, resolve_sizes  # noqa: E402
 from tgp.poolers import get_pooler  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -31,9 +31,7 @@ def wall(fn, n=200):
 
 for name in ([a for a in sys.argv[1:] if a in CASES] or ["mincut_c3", "diff_c3", "topk_c3", "graclus_c3", "ndp_c3"]):
     alias, kw, sizes, deg, f = CASES[name]
-    if sizes is None:
-        g = torch.Generator().manual_seed(0)
-        sizes = torch.randint(20, 61, (2048,), generator=g).tolist()
+    sizes = resolve_sizes(sizes)
     x, ei, batch = batch_graphs(sizes, deg, f)
     pooler = get_pooler(alias, **kw).to(dev).eval()
 

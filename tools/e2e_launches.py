@@ -69,6 +69,10 @@ CASES = {
     "mincut_c2": ("mincut", dict(in_channels=64, k=128), [1024] * 32, 10, 64),
     "mincut_c3": ("mincut", dict(in_channels=32, k=20), None, 4, 32),
     "diff_c3": ("diff", dict(in_channels=32, k=20), None, 4, 32),
+    # medium graphs (TU-dataset-like: 512 graphs of 100..200 nodes, ~8 entries per row): beyond the one-wave kernels,
+    # denser than the rows route's bound
+    "mincut_med": ("mincut", dict(in_channels=32, k=32), "med", 8, 32),
+    "diff_med": ("diff", dict(in_channels=32, k=32), "med", 8, 32),
     "mincut_u_c3": ("mincut_u", dict(in_channels=32, k=20), None, 4, 32),
     "diff_u_c3": ("diff_u", dict(in_channels=32, k=20), None, 4, 32),
     "mincut_u_c2": ("mincut_u", dict(in_channels=64, k=128), [1024] * 32, 10, 64),
@@ -80,14 +84,21 @@ CASES = {
 }
 
 
+def resolve_sizes(sizes):
+    """None: 2048 PROTEINS-shaped graphs of 20..60 nodes; "med": 512 graphs of 100..200 nodes; a list: as given."""
+    if sizes is None:
+        return torch.randint(20, 61, (2048,), generator=torch.Generator().manual_seed(0)).tolist()
+    if isinstance(sizes, str) and sizes == "med":
+        return torch.randint(100, 201, (512,), generator=torch.Generator().manual_seed(0)).tolist()
+    return sizes
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     list_kernels = "--list-kernels" in sys.argv
     for name in (args or list(CASES)):
         alias, kw, sizes, deg, f = CASES[name]
-        if sizes is None:
-            g = torch.Generator().manual_seed(0)
-            sizes = torch.randint(20, 61, (2048,), generator=g).tolist()
+        sizes = resolve_sizes(sizes)
         x, ei, batch = batch_graphs(sizes, deg, f)
         pooler = get_pooler(alias, **kw).to(dev).eval()
 

@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "torch-geometric-pool_amd"))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from e2e_launches import CASES, batch_graphs, wall  # noqa: E402
+from e2e_launches import CASES, batch_graphs, resolve_sizes, wall  # noqa: E402
 from tgp.poolers import get_pooler  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -23,9 +23,7 @@ def main():
     seq = "--sequence" in sys.argv  # kernels of one step in launch order
     for name in (args or ["mincut_c3", "diff_c3", "mincut_c2", "diff_c2"]):
         alias, kw, sizes, deg, f = CASES[name]
-        if sizes is None:
-            g = torch.Generator().manual_seed(0)
-            sizes = torch.randint(20, 61, (2048,), generator=g).tolist()
+        sizes = resolve_sizes(sizes)
         x, ei, batch = batch_graphs(sizes, deg, f)
         x.requires_grad_(True)
         pooler = get_pooler(alias, **kw).to(dev).train()

@@ -13,7 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "torch-geometric-pool_amd"))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from e2e_launches import CASES, batch_graphs, count_kernels  # noqa: E402
+from e2e_launches import CASES, batch_graphs, resolve_sizes, count_kernels  # noqa: E402
 from tgp.poolers import get_pooler  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -32,9 +32,7 @@ def wall(fn, n=300):
 
 for name in ([a for a in sys.argv[1:] if a in CASES] or ["topk_c3", "graclus_c3", "mincut_c3"]):
     alias, kw, sizes, deg, f = CASES[name]
-    if sizes is None:
-        g = torch.Generator().manual_seed(0)
-        sizes = torch.randint(20, 61, (2048,), generator=g).tolist()
+    sizes = resolve_sizes(sizes)
     x, ei, batch = batch_graphs(sizes, deg, f)
     pooler = get_pooler(alias, **kw).to(dev).eval()
     R = 24

@@ -21,11 +21,10 @@ calls = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 ctx = bench.Ctx(torch.device("cuda:0"), 0, 1, None)
 if which.startswith("e2e:"):  # a whole pooler forward on new edge_index / batch objects (tools/e2e_fresh_batch.py's case)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from e2e_launches import CASES, batch_graphs
+    from e2e_launches import CASES, batch_graphs, resolve_sizes
     from tgp.poolers import get_pooler
     alias, kw, sizes, deg, f = CASES[which[4:]]
-    if sizes is None:
-        sizes = torch.randint(20, 61, (2048,), generator=torch.Generator().manual_seed(0)).tolist()
+    sizes = resolve_sizes(sizes)
     x, ei, batch = batch_graphs(sizes, deg, f)
     pooler = get_pooler(alias, **kw).to(ctx.dev).eval()
     copies = [(ei.clone(), batch.clone()) for _ in range(24)]

@@ -42,7 +42,16 @@ import os as _os
 # r6: batched dense poolers on a SPARSE input whose graphs are large and sparse take the un-padded rows route (no [B,N,N]
 # adjacency): TGP_ROWS_ROUTE=0 keeps the densifying route; the density bound is entries / (N x longest graph)
 _ROWS_ROUTE = _os.environ.get("TGP_ROWS_ROUTE", "1") != "0"
-_ROWS_ROUTE_DENSITY = float(_os.environ.get("TGP_ROWS_ROUTE_DENSITY", "0.03"))
+# (a number: THE bound; None: the measured default 0.03 + 8 / K, at most 0.3 -- the rows route costs E x K gathered floats,
+#  the densifying route N x Nmax x K flops on the matrix cores plus two passes over the dense adjacency, so the break-even
+#  density falls with K: K = 256 ties at 5.8 %, K <= 128 still wins at 11-29 %, profiles/r06_rows_route_crossover.txt)
+_ROWS_ROUTE_DENSITY = float(_os.environ["TGP_ROWS_ROUTE_DENSITY"]) if "TGP_ROWS_ROUTE_DENSITY" in _os.environ else None
+
+
+def _rows_route_density(k: int) -> float:
+    if _ROWS_ROUTE_DENSITY is not None:
+        return float(_ROWS_ROUTE_DENSITY)
+    return min(0.3, 0.03 + 8.0 / max(int(k), 1))
 # A/B switch (read once): 0 keeps the selector and the pooling as two autograd nodes in training
 _FOLD_TRAINING = _os.environ.get("TGP_FOLD_TRAINING", "1") != "0"
 # ... 0 densifies sparse inputs (to_dense_batch + to_dense_adj) in front of the fused inference call as before
@@ -447,7 +456,8 @@ class _DenseMLPPooling(DenseSRCPooling):
         forward is ONE autograd node (functions._PoolUnbatchedFn).
 
         ``batched_out`` (r6, late): the BATCHED poolers take the same route for a sparse input whose graphs are too
-        large for the one-launch kernels and sparse enough (E <= TGP_ROWS_ROUTE_DENSITY x N x longest graph, default 3 %):
+        large for the one-launch kernels and sparse enough (E <= d x N x longest graph, d = TGP_ROWS_ROUTE_DENSITY or the
+        measured default 0.03 + 8 / K, at most 0.3):
         no [B,N,N] adjacency is ever built (reference src.py:374-452 densifies first; at the C2 shape that is 134 MB
         written and read three times per training step for 0.33 M entries).  The results are those of the batched mode:
         S^T A^T S when adj_transpose (= the transpose of S^T (A S); MinCut's degrees are then in-degrees, sum_i (A q)_i),
@@ -485,7 +495,7 @@ class _DenseMLPPooling(DenseSRCPooling):
         if batched_out:  # every check comes BEFORE Select here: a bail-out must leave the batched flow untouched
             if (not _ROWS_ROUTE or self.cache_preprocessing or type(sel) is not MLPSelect or lins is None
                     or lins[-1].weight.dtype != torch.float32
-                    or edge_index.size(1) > _ROWS_ROUTE_DENSITY * float(n) * float(max_nodes)
+                    or edge_index.size(1) > _rows_route_density(lins[-1].weight.size(0)) * float(n) * float(max_nodes)
                     or K.dense_pool_is_small(nb, max_nodes, lins[-1].weight.size(0), x.size(1))):
                 return None
             k_out = lins[-1].weight.size(0)
