@@ -40,7 +40,7 @@ python3 tools/bench_coalesce_f64.py 2>&1 | grep -v -i 'warn\|amdgpu.ids' > $out/
 python3 tools/e2e_fresh_batch.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $out/e2e_fresh_batch.txt
 python3 tools/bench_poolers_e2e.py > $out/e2e_poolers.txt 2>&1
 python3 tools/bench_ndp_large.py > $out/ndp_large.txt 2>&1
-python3 tools/e2e_train_step.py mincut_c3 diff_c3 mincut_c2 diff_c2 topk_c3 graclus_c3 --top 8 2>&1 | grep -v -i "warn" > $out/e2e_train_steps.txt
+python3 tools/e2e_train_step.py mincut_c3 diff_c3 mincut_c2 diff_c2 mincut_med diff_med topk_c3 graclus_c3 --top 8 2>&1 | grep -v -i "warn" > $out/e2e_train_steps.txt
 # r6: the C2-sized training step, launch by launch, with bench.py's loss: the rows route (default for sparse inputs) and
 # the densifying route (TGP_ROWS_ROUTE=0, functions._PoolLargeFn), and the r5 operator-by-operator graph (TGP_FOLD_TRAINING=0)
 (echo "== default: un-padded rows route (functions._PoolUnbatchedFn)"; python3 tools/e2e_train_step.py mincut_c2 diff_c2 --sequence --bench-loss 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-170; echo; echo "== TGP_ROWS_ROUTE=0: densifying route (functions._PoolLargeFn)"; TGP_ROWS_ROUTE=0 python3 tools/e2e_train_step.py mincut_c2 diff_c2 --sequence --bench-loss 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-170; echo; echo "== TGP_ROWS_ROUTE=0 TGP_FOLD_TRAINING=0: operator by operator (r5)"; TGP_ROWS_ROUTE=0 TGP_FOLD_TRAINING=0 python3 tools/e2e_train_step.py mincut_c2 diff_c2 --bench-loss 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-170) > $out/train_step_c2.txt
@@ -48,6 +48,7 @@ python3 tools/e2e_train_step.py mincut_c3 diff_c3 mincut_c2 diff_c2 topk_c3 grac
 # coalesce Connect would need (item 4)
 (for w in topk_batch_fresh graclus_batch_fresh e2e:topk_c3 e2e:graclus_c3 e2e:diff_c3; do python3 tools/host_profile_fresh.py $w 2>&1 | grep -v -i "amdgpu.ids\|warn" | head -16; echo; done; echo "== TGP_SPS_ARENA=0 (four allocations of their own + the compaction wrapper: r5 form)"; for w in topk_batch_fresh graclus_batch_fresh; do TGP_SPS_ARENA=0 python3 tools/host_profile_fresh.py $w 2>&1 | grep -v -i "amdgpu.ids\|warn" | head -1; done) > $out/host_time_fresh.txt
 python3 tools/coalesce_relabel_cost.py 2>&1 | grep -v -i "amdgpu.ids\|warn" > $out/coalesce_relabel_cost.txt
+python3 tools/rows_route_crossover.py 2>&1 | grep -v -i "amdgpu.ids\|warn" > $out/rows_route_crossover.txt
 python3 tools/profile_unbatched.py 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-150 > $out/unbatched_forward.txt
 (echo "== TGP_FOLD_TRAINING=0 (operator-by-operator graph, staged Reduce + Connect: r4 form)"; TGP_FOLD_TRAINING=0 python3 tools/e2e_train_step.py topk_c3 graclus_c3 --sequence 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-180; echo; echo "== default (r5, late)"; python3 tools/e2e_train_step.py topk_c3 graclus_c3 --sequence 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-180) > $out/sparse_train_steps.txt
 python3 tools/bench_select_fold.py 2>&1 | grep select > $out/select_fold.txt
