@@ -775,7 +775,8 @@ size_t tgp_postprocess_dense_workspace_bytes(int64_t B, int64_t K);
 int tgp_postprocess_dense_f32(const float* src, float* dst, int64_t B, int64_t K, int flags, float eps, void* ws,
                               size_t ws_bytes, void* stream);
 /* Its backward (what autograd derives from utils/ops.py:282-335): g_raw [B,K,K] from the raw S^T A S and the upstream
- * gradient of the post-processed tensor; one launch, K <= 4096, TGP_EDGE_WEIGHT_NORM refused (not differentiated here). */
+ * gradient of the post-processed tensor; one launch, K <= 4096, TGP_EDGE_WEIGHT_NORM refused (not differentiated here).
+ * flags bit 16 (r6): g_post is ONE value that stands for every element (the gradient of a plain sum: an expanded scalar). */
 int tgp_postprocess_dense_bwd_f32(const float* raw, const float* g_post, int64_t B, int64_t K, int flags, float eps,
                                   float* g_raw, void* stream);
 

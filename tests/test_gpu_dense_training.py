@@ -392,3 +392,17 @@ def test_dense_adjacency_symmetry_probe(dev):
     out = pooler(x=X, adj=Au)
     (out.x.square().sum() + out.edge_index.sum() + sum(out.loss.values())).backward()
     assert Fn.POOL_LARGE_STATS["general"] == before["general"] + 1
+
+
+@pytest.mark.parametrize("k", [20, 96, 128, 200])
+def test_postprocess_backward_takes_an_expanded_scalar_gradient(dev, k):
+    """The gradient of a plain ``.sum()`` over the pooled adjacency arrives as an expanded scalar: the post-processing
+    backward reads it as ONE value (flags bit 16) instead of a materialised [B,K,K] copy -- same result, bit for bit."""
+    from tgp import kernels as K
+    g = torch.Generator().manual_seed(k)
+    raw = (torch.rand(5, k, k, generator=g) + 0.05).to(dev)
+    flags = K.dense_flags(True, True, True, False)
+    one = torch.full((), 0.7, device=dev).expand(5, k, k)
+    got = K.postprocess_dense_bwd(raw, one, flags)
+    want = K.postprocess_dense_bwd(raw, one.contiguous(), flags)
+    assert torch.equal(got, want)

@@ -580,14 +580,18 @@ __global__ __launch_bounds__(IN_LDS ? 1024 : 256) void post_bwd_kernel(const flo
   const int ld = IN_LDS ? K + 1 : K;
   const long off = static_cast<long>(blockIdx.x) * K * K;
   const float* Rb = R + off;
-  const float* Gb = G + off;
+  // bit 16 of flags (internal: tgp_postprocess_dense_bwd_f32 documents it): G is ONE value that stands for every element
+  // (the gradient of a plain sum arrives as an expanded scalar: no [B,K,K] copy of it is made)
+  const bool g_one = flags & (1 << 16);
+  const float g_val = g_one ? G[0] : 0.f;
+  const float* Gb = g_one ? G : G + off;
   float* ob = out + off;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool rsl = flags & TGP_REMOVE_SELF_LOOPS, dn = flags & TGP_DEGREE_NORM, cols = flags & TGP_SUM_AXIS_ROWS;
   if (!dn) {
     for (long e = tid; e < static_cast<long>(K) * K; e += T) {
       const int i = static_cast<int>(e / K), j = static_cast<int>(e - static_cast<long>(i) * K);
-      ob[e] = (rsl && i == j) ? 0.f : Gb[e];
+      ob[e] = (rsl && i == j) ? 0.f : (g_one ? g_val : Gb[e]);
     }
     return;
   }
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(IN_LDS ? 1024 : 256) void post_bwd_kernel(const flo
         if (j < K) {
           const float r = (rsl && i == j) ? 0.f : Rb[static_cast<long>(i) * K + j];
           sR[i * ld + j] = r;
-          sG[i * ld + j] = Gb[static_cast<long>(i) * K + j];
+          sG[i * ld + j] = g_one ? g_val : Gb[static_cast<long>(i) * K + j];
           racc += r;
           cacc[jj] += r;
         }
@@ -680,7 +684,7 @@ __global__ __launch_bounds__(IN_LDS ? 1024 : 256) void post_bwd_kernel(const flo
   };
   auto gv = [&](int i, int j) -> float {
     if constexpr (IN_LDS) return sG[i * ld + j];
-    return Gb[static_cast<long>(i) * K + j];
+    return g_one ? g_val : Gb[static_cast<long>(i) * K + j];
   };
   // column sums of f(i, j) into dst[j]: a thread per column, or (IN_LDS) 8 row phases per column folded in phase order
   auto col_sweep = [&](auto f, float* dst) {

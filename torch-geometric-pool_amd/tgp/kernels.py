@@ -1496,13 +1496,15 @@ def postprocess_dense_bwd(raw: Tensor, g_post: Tensor, flags: int) -> Optional[T
     """Gradient of :func:`postprocess_dense` with respect to its input (utils/ops.py:282-335 under autograd), one
     launch; None when the kernel does not take the case (K > 4096)."""
     dev = N.require_device(raw, g_post)
-    raw, g_post = N.f32c(raw), N.f32c(g_post)
+    raw = N.f32c(raw)
     B, K = raw.size(0), raw.size(1)
     if K > 4096 or tuple(g_post.shape) != tuple(raw.shape):
         return None
+    # an expanded scalar (the gradient of a plain `.sum()`) is handed over as one value: no [B,K,K] copy of it (r6)
+    g_post, one = _bcast_or_dense(g_post, raw.shape)
     out = torch.empty_like(raw)
-    N.check(N.lib().tgp_postprocess_dense_bwd_f32(N.ptr(raw), N.ptr(g_post), B, K, flags, ops_eps(), N.ptr(out),
-                                                  N.stream_ptr(dev)), "tgp_postprocess_dense_bwd_f32")
+    N.check(N.lib().tgp_postprocess_dense_bwd_f32(N.ptr(raw), N.ptr(g_post), B, K, flags | ((1 << 16) if one else 0),
+                                                  ops_eps(), N.ptr(out), N.stream_ptr(dev)), "tgp_postprocess_dense_bwd_f32")
     return out
 
 
