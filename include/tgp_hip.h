@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10038 /* 1.0.1 of the reference, ABI revision 37 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
+#define TGP_ABI_VERSION 10039 /* 1.0.1 of the reference, ABI revision 38 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -716,6 +716,20 @@ int tgp_segment_gemm_tn3_post_f32(const float* S, const float* Y0, const float* 
                                   const int64_t* ptr, float* raw, float* C1, float* C2, float* adj_pool, int64_t B,
                                   int64_t Ntot, int64_t K, int64_t max_nodes, int transpose0, int flags, float eps,
                                   void* ws, size_t ws_bytes, void* stream);
+/* r6 (late): the forward of the un-padded rows route as ONE call (host time: four wrapper calls -> one).  Strings together
+ * tgp_mlp_select_f32 (W != NULL: S [Ntot,K] is written; W == NULL: S is read), tgp_spmm_csr_{,stats_,entropy_}f32 (T = A S
+ * [Ntot,K]; rowstat = [2,Ntot] deg | q for mode 1, [Ntot] entropy shares for mode 2), tgp_segment_gemm_tn3_post_f32 (raw,
+ * x_pool [B,K,F], gram (modes 1, 2), adj_pool) and the loss tail: mode 1 tgp_mincut_terms_fused_f32 (den [B], terms [2,B],
+ * stats [B,4], means [2] + ticket or NULL; transposed: the in-degree denominator from the entries), mode 2
+ * tgp_diffpool_unbatched_tail_f32 (dstats [B,2], out2 [2]; sw2 as for that entry).  Same launches, same results. */
+size_t tgp_pool_rows_fwd_workspace_bytes(int64_t B, int64_t K, int64_t F, int64_t max_nodes, int64_t Ntot);
+int tgp_pool_rows_fwd_f32(const float* x, int64_t Ntot, int64_t F, const float* W, const float* bias, float* S,
+                          const int32_t* row_ptr, const int64_t* col, const float* w, int64_t nnz, const int64_t* ptr,
+                          int64_t B, int64_t K, int64_t max_nodes, int transposed, int post_flags, float eps,
+                          float loss_eps, int mode, const float* sw2_dev, float sw2_host, float link_scale,
+                          float ent_scale, float* T, float* raw, float* x_pool, float* gram, float* adj_pool,
+                          float* rowstat, float* den, float* terms, float* stats, float* means, uint32_t* ticket,
+                          float* dstats, float* out2, void* ws, size_t ws_bytes, void* stream);
 int tgp_edge_row_stats_f32(const int32_t* row_ptr, const float* w, const float* S, int64_t N, int64_t K, float* deg,
                            float* q, void* stream);
 /* the two segment products with explicit row strides (operands that are column blocks of a wider buffer: the unbatched

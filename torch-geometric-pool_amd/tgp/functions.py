@@ -1074,6 +1074,23 @@ class _PoolUnbatchedFn(torch.autograd.Function):
         xd = N.f32c(x.detach())
         n, F = xd.shape
         selector = s_given is None
+        one = K.pool_rows_forward(xd, None if weight is None else weight.detach(), None if bias is None else bias.detach(),
+                                  None if selector else N.f32c(s_given.detach()), row_ptr, ei, ew, ptr, max_nodes,
+                                  transposed, flags, mode, scales, sw2)
+        if one is not None:  # the whole forward as ONE native call (r6, late: same launches, no host work between them)
+            s, t, raw, x_pool, gram, adj_pool = (one[k] for k in ("s", "t", "raw", "x_pool", "gram", "adj_pool"))
+            empty = s.new_empty(0)
+            la, lb = s.new_empty(0), s.new_empty(0)
+            deg = den = lossv = stats = None
+            if mode == 1:
+                deg, den, stats, both = one["deg"], one["den"], one["stats"], one["both"]
+                la, lb = both[0], both[1]
+            elif mode == 2:
+                lossv = one["lossv"]
+                la, lb = lossv[0], lossv[1]
+            return _PoolUnbatchedFn._finish_forward(ctx, s, t, xd, weight, raw, ei, row_ptr, ptr, gram, deg, den, lossv,
+                                                    stats, ew, batch, flags, mode, scales, selector, max_nodes, bias, sym,
+                                                    transposed, x_pool, adj_pool, la, lb)
         s = K.mlp_select(xd, weight.detach(), None if bias is None else bias.detach(), None) if selector \
             else N.f32c(s_given.detach())
         Kc = s.size(1)
@@ -1100,6 +1117,14 @@ class _PoolUnbatchedFn(torch.autograd.Function):
         elif mode == 2:
             lossv = K.diffpool_unbatched_tail(raw, gram, s, sw2, scales[0], scales[1], ent_partials=ent_part)
             la, lb = lossv[0], lossv[1]
+        return _PoolUnbatchedFn._finish_forward(ctx, s, t, xd, weight, raw, ei, row_ptr, ptr, gram, deg, den, lossv, stats,
+                                                ew, batch, flags, mode, scales, selector, max_nodes, bias, sym, transposed,
+                                                x_pool, adj_pool, la, lb)
+
+    @staticmethod
+    def _finish_forward(ctx, s, t, xd, weight, raw, ei, row_ptr, ptr, gram, deg, den, lossv, stats, ew, batch, flags, mode,
+                        scales, selector, max_nodes, bias, sym, transposed, x_pool, adj_pool, la, lb):
+        empty = s.new_empty(0)
         keep = [v if v is not None else empty for v in (gram, deg, den, lossv, stats, ew, batch)]
         ctx.save_for_backward(s, t, xd, empty if weight is None else weight, raw, ei, row_ptr, ptr, *keep)
         ctx.flags, ctx.mode, ctx.scales, ctx.selector, ctx.max_nodes = flags, mode, scales, selector, max_nodes

@@ -2497,6 +2497,86 @@ def segment_gemm_tn3(s: Tensor, ys, ptr: Tensor, max_nodes: int, transpose0: boo
     return outs
 
 
+_POOL_ROWS_ONE_CALL = os.environ.get("TGP_POOL_ROWS_ONE_CALL", "1") != "0"  # A/B switch (read once)
+
+
+def pool_rows_forward(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor], s_given: Optional[Tensor],
+                      row_ptr: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], ptr: Tensor, max_nodes: int,
+                      transposed: bool, flags: int, mode: int, scales=(0.0, 0.0), sw2=0.0):
+    """The forward of the dense poolers' un-padded rows route as ONE native call (``tgp_pool_rows_fwd_f32``: selector,
+    T = A S with the losses' row statistics, S^T [T | X | S] + post-processing, loss tail) -- the launches of
+    :func:`mlp_select`, :func:`spmm_csr`, :func:`segment_gemm_tn3` and :func:`mincut_terms_fused` /
+    :func:`diffpool_unbatched_tail`, without the host work between them.  ``mode`` 0: no losses, 1: MinCut, 2: DiffPool.
+    Returns a dict: s, t, raw, x_pool, gram, adj_pool and -- mode 1 -- deg, q, den, terms, stats, both; -- mode 2 --
+    lossv.  None when the case is not this entry's (the caller composes the operators): float32 contiguous operands, a
+    selector of at most 256 clusters."""
+    if not _POOL_ROWS_ONE_CALL or x.dtype != torch.float32 or x.dim() != 2 or not x.is_contiguous():
+        return None
+    selector = s_given is None
+    n, F = x.shape
+    if selector:
+        if (weight is None or weight.dtype != torch.float32 or weight.dim() != 2 or weight.size(1) != F
+                or not weight.is_contiguous() or weight.size(0) > 256
+                or (bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()))):
+            return None
+        Kc = weight.size(0)
+    else:
+        if s_given.dtype != torch.float32 or s_given.dim() != 2 or s_given.size(0) != n or not s_given.is_contiguous():
+            return None
+        Kc = s_given.size(1)
+    if (n == 0 or Kc == 0 or row_ptr.dtype != torch.int32 or row_ptr.numel() != n + 1 or ptr.dtype != torch.int64
+            or not ptr.is_contiguous()):
+        return None
+    w = edge_weight
+    if w is not None:
+        if w.dtype != torch.float32:
+            return None
+        w = w.reshape(-1)
+        if not w.is_contiguous():
+            w = w.contiguous()
+    dev = N.require_device(x, weight, bias, s_given, row_ptr, edge_index, w, ptr)
+    _, col = _edge_rows(edge_index)
+    B = ptr.numel() - 1
+    f32 = dict(dtype=torch.float32, device=dev)
+    s = torch.empty(n, Kc, **f32) if selector else s_given
+    t = torch.empty(n, Kc, **f32)
+    raw = torch.empty(B, Kc, Kc, **f32)
+    x_pool = torch.empty(B, Kc, F, **f32)
+    adj_pool = torch.empty(B, Kc, Kc, **f32)
+    gram = torch.empty(B, Kc, Kc, **f32) if mode else None
+    rowstat = den = terms = stats = means = dstats = out2 = None
+    ticket = None
+    L = N.lib()
+    st = N.stream_ptr(dev)
+    sw2_dev = None
+    if mode == 1:
+        rowstat = torch.empty(2, n, **f32)
+        den, terms, stats = torch.empty(B, **f32), torch.empty(2, B, **f32), torch.empty(B, 4, **f32)
+        if B <= 256 and not torch.cuda.is_current_stream_capturing():
+            means = torch.empty(2, **f32)
+            ticket = _sps_state(dev, st, 0).ticket.data_ptr() + 16
+    elif mode == 2:
+        rowstat = torch.empty(n, **f32)
+        dstats, out2 = torch.empty(B, 2, **f32), torch.empty(2, **f32)
+        sw2_dev = N.f32c(sw2.reshape(1)) if isinstance(sw2, Tensor) else None
+    ws = N.workspace(L.tgp_pool_rows_fwd_workspace_bytes(B, Kc, F, max_nodes, n), dev)
+    N.check(L.tgp_pool_rows_fwd_f32(
+        x.data_ptr(), n, F, N.ptr(weight) if selector else None, N.ptr(bias) if selector else None, s.data_ptr(),
+        row_ptr.data_ptr(), N.ptr(col), N.ptr(w), col.numel(), ptr.data_ptr(), B, Kc, max_nodes, 1 if transposed else 0,
+        int(flags), ops_eps(), losses_eps(), int(mode), N.ptr(sw2_dev),
+        0.0 if (sw2_dev is not None or mode != 2) else float(sw2), float(scales[0]), float(scales[1]), t.data_ptr(),
+        raw.data_ptr(), x_pool.data_ptr(), N.ptr(gram), adj_pool.data_ptr(), N.ptr(rowstat), N.ptr(den), N.ptr(terms),
+        N.ptr(stats), N.ptr(means), ticket, N.ptr(dstats), N.ptr(out2), ws.data_ptr(), ws.numel(), st),
+        "tgp_pool_rows_fwd_f32")
+    out = dict(s=s, t=t, raw=raw, x_pool=x_pool, gram=gram, adj_pool=adj_pool)
+    if mode == 1:
+        out.update(deg=rowstat[0], q=rowstat[1], den=den, terms=terms, stats=stats,
+                   both=means if means is not None else terms.mean(dim=1))
+    elif mode == 2:
+        out.update(lossv=out2)
+    return out
+
+
 def segment_gemm_nn_into(a: Tensor, bm: Tensor, ptr: Tensor, out: Tensor, max_nodes: int) -> Tensor:
     """out[rows of graph b] = a[rows of graph b] @ bm[b] for float32 VIEWS with unit last stride: ``a`` [Ntot,Kd] and
     ``out`` [Ntot,Nc] with any row stride (column blocks of a wider buffer), ``bm`` [B,Kd,Nc] with any row / batch stride."""

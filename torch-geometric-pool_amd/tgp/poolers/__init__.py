@@ -504,7 +504,14 @@ class _DenseMLPPooling(DenseSRCPooling):
                 return None
         # the selector: folded into the training node when it is a single Linear, else run in front (its S handed over)
         so = weight = bias = None
-        if not (grad and single and _FOLD_TRAINING):
+        # inference with a single-Linear selector (r6, late): the selector rides in the ONE native call of the forward
+        # (kernels.pool_rows_forward); the SelectOutput is built from the S it leaves
+        fold_inference = (not grad and single and K._POOL_ROWS_ONE_CALL and x.dtype == torch.float32 and x.is_contiguous()
+                          and lins[0].weight.size(0) <= 256)
+        if fold_inference:
+            weight, bias = lins[0].weight.detach(), None if lins[0].bias is None else lins[0].bias.detach()
+            s, training = None, False
+        elif not (grad and single and _FOLD_TRAINING):
             so = self.select(x=x, batch=batch) if not batched_out else self.select(x=x)
             s = so.s
             if batched_out and isinstance(s, Tensor) and s.dim() == 3 and s.size(0) == 1:
@@ -563,6 +570,16 @@ class _DenseMLPPooling(DenseSRCPooling):
             s_flat = s_out
             both = pair
         else:
+            one = K.pool_rows_forward(x, weight if s is None else None, bias if s is None else None, s, row_ptr, ei, w_used,
+                                      ptr, max_nodes, transposed, flags, 1 if mincut else 2, scales, sw2)
+            if one is None and s is None:  # (not the one-call entry's case after all: the selector runs on its own)
+                so = self.select(x=x, batch=batch) if not batched_out else self.select(x=x)
+                s = so.s[0] if (batched_out and so.s.dim() == 3) else so.s
+        if not training and one is not None:
+            s, raw, x_pool, adj_pool = one["s"], one["raw"], one["x_pool"], one["adj_pool"]
+            both = one["both"] if mincut else one["lossv"]
+            s_flat = s
+        elif not training:
             if mincut:  # out-degrees and |S_i|^2 ride along with T = A S
                 t, deg, q = K.spmm_csr(row_ptr, ei, w_used, n, s, want_stats=True)
             else:       # DiffPool: the entropy sum over S rides along
