@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10039 /* 1.0.1 of the reference, ABI revision 38 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
+#define TGP_ABI_VERSION 10040 /* 1.0.1 of the reference, ABI revision 39 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -730,6 +730,23 @@ int tgp_pool_rows_fwd_f32(const float* x, int64_t Ntot, int64_t F, const float* 
                           float ent_scale, float* T, float* raw, float* x_pool, float* gram, float* adj_pool,
                           float* rowstat, float* den, float* terms, float* stats, float* means, uint32_t* ticket,
                           float* dstats, float* out2, void* ws, size_t ws_bytes, void* stream);
+/* ... and its backward for the common case -- selector folded in (W [K,F]), A = A^T (T serves as U and V) -- as ONE call:
+ * tgp_postprocess_dense_bwd_f32 (g_adj, an expanded scalar when g_adj_bcast), tgp_dense_pool_train_rhs_f32,
+ * tgp_copy_cols3_f32, tgp_segment_gemm_nn_ld_f32 (gS, gX), tgp_softmax_bwd_ex_f32, tgp_segment_gemm_tn_ld_f32 over
+ * `slabs` row ranges slab_ptr [slabs+1] and tgp_slab_sum_split_f32.  Saved by the forward: S, T, raw, gram, stats, den, deg,
+ * link_loss ([1], mode 2).  Upstream gradients (each may be NULL): g_adj, g_raw [B,K,K], g_x [B,K,F] (one value when
+ * g_x_bcast), g_s [Ntot,K], g_la / g_lb (0-dim: the two losses).  Buffers: ga [B,K,K] (with g_adj), rcat [B,3K+F+4,K], c1
+ * [B] (mode 1), gwcat [B,2K,F] (with gX), acat [Ntot,3K+F+4], gS [Ntot,K], part [slabs,K,F+4] (with gW / gbias).
+ * Outputs: gX [Ntot,F], gW [K,F], gbias [K] (each optional). */
+int tgp_pool_rows_bwd_f32(const float* S, const float* T, const float* X, const float* W, const float* raw,
+                          const float* gram, const float* stats, const float* den, const float* deg,
+                          const float* link_loss, const int64_t* ptr, const int64_t* batch, const int64_t* slab_ptr,
+                          int64_t slabs, int64_t Ntot, int64_t B, int64_t K, int64_t F, int64_t max_nodes, int post_flags,
+                          float eps, float loss_eps, int mode, int transposed, float inv_b, float link_scale,
+                          float ent_scale, const float* g_adj, int g_adj_bcast, const float* g_raw, const float* g_x,
+                          int g_x_bcast, const float* g_s, const float* g_la, const float* g_lb, float* ga, float* rcat,
+                          float* c1, float* gwcat, float* acat, float* gS, float* gX, float* part, float* gW, float* gbias,
+                          void* stream);
 int tgp_edge_row_stats_f32(const int32_t* row_ptr, const float* w, const float* S, int64_t N, int64_t K, float* deg,
                            float* q, void* stream);
 /* the two segment products with explicit row strides (operands that are column blocks of a wider buffer: the unbatched

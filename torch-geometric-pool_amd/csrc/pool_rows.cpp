@@ -66,3 +66,61 @@ extern "C" int tgp_pool_rows_fwd_f32(const float* x, int64_t Ntot, int64_t F, co
                                            ent_scale, dstats, out2, stream);
   return TGP_OK;
 }
+
+// The backward of the same step as ONE native call, for the common case: the selector folded in (single Linear) and A = A^T
+// (so T = A S serves as both U and V).  Strings together tgp_postprocess_dense_bwd_f32, tgp_dense_pool_train_rhs_f32,
+// tgp_copy_cols3_f32, tgp_segment_gemm_nn_ld_f32 (gS, then gX), tgp_softmax_bwd_ex_f32, tgp_segment_gemm_tn_ld_f32 and
+// tgp_slab_sum_split_f32 -- the launches functions._PoolUnbatchedFn.backward makes one by one (eight wrappers, ~110 us of
+// host time in front of ~150 us of kernels).  Layout of the operand buffer acat [Ntot, 3K+F+4] = [T | X | 1 0 0 0 | S | dY]
+// and of rcat [B, 3K+F+4, K]: DESIGN.md section 4.5.  Optional outputs are NULL when not wanted.
+extern "C" int tgp_pool_rows_bwd_f32(const float* S, const float* T, const float* X, const float* W, const float* raw,
+                                     const float* gram, const float* stats, const float* den, const float* deg,
+                                     const float* link_loss, const int64_t* ptr, const int64_t* batch,
+                                     const int64_t* slab_ptr, int64_t slabs, int64_t Ntot, int64_t B, int64_t K, int64_t F,
+                                     int64_t max_nodes, int post_flags, float eps, float loss_eps, int mode, int transposed,
+                                     float inv_b, float link_scale, float ent_scale, const float* g_adj, int g_adj_bcast,
+                                     const float* g_raw, const float* g_x, int g_x_bcast, const float* g_s,
+                                     const float* g_la, const float* g_lb, float* ga, float* rcat, float* c1, float* gwcat,
+                                     float* acat, float* gS, float* gX, float* part, float* gW, float* gbias,
+                                     void* stream) {
+  TGP_REQUIRE(Ntot >= 1 && B >= 1 && K >= 1 && F >= 1 && slabs >= 1 && mode >= 0 && mode <= 2, TGP_ERR_INVALID,
+              "tgp_pool_rows_bwd_f32: bad shape or mode");
+  TGP_REQUIRE(S && T && X && raw && ptr && slab_ptr && rcat && acat && gS && (!gX || (W && gwcat)), TGP_ERR_INVALID,
+              "tgp_pool_rows_bwd_f32: null pointer");
+  TGP_REQUIRE(!g_adj || ga, TGP_ERR_INVALID, "tgp_pool_rows_bwd_f32: g_adj needs the ga buffer");
+  TGP_REQUIRE(mode != 1 || (stats && den && gram && c1 && deg), TGP_ERR_INVALID, "tgp_pool_rows_bwd_f32: MinCut operands");
+  TGP_REQUIRE(mode != 2 || (gram && link_loss), TGP_ERR_INVALID, "tgp_pool_rows_bwd_f32: DiffPool operands");
+  TGP_REQUIRE((!gW && !gbias) || part, TGP_ERR_INVALID, "tgp_pool_rows_bwd_f32: the weight gradient needs the slab buffer");
+  const int64_t pad = 4, ld = 3 * K + F + pad;
+  const int64_t c_x = K, c_one = K + F, c_s = K + F + pad, c_v = 2 * K + F + pad;
+  int rc = TGP_OK;
+  if (g_adj) {
+    rc = tgp_postprocess_dense_bwd_f32(raw, g_adj, B, K, post_flags | (g_adj_bcast ? (1 << 16) : 0), eps, ga, stream);
+    if (rc != TGP_OK) return rc;
+  }
+  // A = A^T: bit 0 (the first block's right-hand side becomes gR + gR^T, the V rows are not written)
+  rc = tgp_dense_pool_train_rhs_f32(g_adj ? ga : nullptr, g_raw, mode, mode == 1 ? stats : nullptr, mode == 1 ? den : nullptr,
+                                    mode ? gram : nullptr, mode ? g_la : nullptr, mode == 1 ? g_lb : nullptr, inv_b,
+                                    mode == 2 ? link_loss : nullptr, mode == 2 ? link_scale : 0.f, loss_eps, g_x, g_x_bcast,
+                                    1, gX ? W : nullptr, B, K, F, rcat, mode == 1 ? c1 : nullptr, gX ? gwcat : nullptr,
+                                    stream);
+  if (rc != TGP_OK) return rc;
+  rc = tgp_copy_cols3_f32(T, K, X, F, S, K, Ntot, acat, ld, 0, c_x, c_s, c_one, stream);
+  if (rc != TGP_OK) return rc;
+  rc = tgp_segment_gemm_nn_ld_f32(acat, ld, rcat, K, ld * K, ptr, gS, K, B, Ntot, c_v, K, max_nodes, stream);
+  if (rc != TGP_OK) return rc;
+  rc = tgp_softmax_bwd_ex_f32(S, gS, g_s, mode == 1 ? c1 : nullptr, mode == 1 ? deg : nullptr, Ntot,
+                              mode == 2 ? g_lb : nullptr, mode == 2 ? ent_scale : 0.f, loss_eps, acat + c_v, ld, Ntot, K,
+                              batch, stream);
+  if (rc != TGP_OK) return rc;
+  if (gX) {
+    rc = tgp_segment_gemm_nn_ld_f32(acat + c_s, ld, gwcat, F, 2 * K * F, ptr, gX, F, B, Ntot, 2 * K, F, max_nodes, stream);
+    if (rc != TGP_OK) return rc;
+  }
+  if (gW || gbias) {
+    rc = tgp_segment_gemm_tn_ld_f32(acat + c_v, ld, acat + c_x, ld, slab_ptr, part, slabs, Ntot, K, F + pad, stream);
+    if (rc != TGP_OK) return rc;
+    rc = tgp_slab_sum_split_f32(part, slabs, K, F, F + pad, gW, gbias, stream);
+  }
+  return rc;
+}

@@ -168,6 +168,8 @@ SIGNATURES = {
     "tgp_segment_gemm_tn3_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
     "tgp_segment_gemm_tn3_post_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
     "tgp_pool_rows_fwd_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
+    "tgp_pool_rows_bwd_f32": (_c_int, [_c_p] * 13 + [_c_i64] * 6 + [_c_int, _c_f, _c_f, _c_int, _c_int, _c_f, _c_f, _c_f, _c_p,
+                                       _c_int, _c_p, _c_p, _c_int, _c_p, _c_p, _c_p] + [_c_p] * 10 + [_c_p]),
     "tgp_pool_rows_fwd_f32": (_c_int, [_c_p, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_i64, _c_i64,
                                        _c_i64, _c_int, _c_int, _c_f, _c_f, _c_int, _c_p, _c_f, _c_f, _c_f, _c_p, _c_p, _c_p,
                                        _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_sz, _c_p]),

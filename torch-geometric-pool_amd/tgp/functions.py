@@ -1155,6 +1155,19 @@ class _PoolUnbatchedFn(torch.autograd.Function):
         if g_s is None and g_xp is None and g_raw is None and g_adj is None and g_la is None and g_lb is None:
             return nothing
         want_gx = ctx.needs_input_grad[0]
+        symmetric = ctx.sym is not None and ctx.sym.get()
+        POOL_LARGE_STATS["symmetric" if symmetric else "general"] += 1
+        if selector and symmetric and weight.numel() and Kc <= 4096:
+            # the common case as ONE native call (r6, late): the same launches as below, no host work between them
+            want_gw, want_gb = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+            one = K.pool_rows_backward(s, t, xd, N.f32c(weight.detach()), raw, gram if mode else None,
+                                       stats if mode == 1 else None, den if mode == 1 else None, deg if mode == 1 else None,
+                                       lossv[0:1] if mode == 2 else None, ptr, batch, _slab_ptr(n, dev), ctx.max_nodes,
+                                       ctx.flags, mode, ctx.transposed, ctx.scales, g_adj,
+                                       None if g_raw is None else N.f32c(g_raw), g_xp, g_s, g_la, g_lb, want_gx, want_gw,
+                                       want_gb)
+            if one is not None:
+                return (one[0], one[1], one[2]) + (None,) * 13
         ga = None
         if g_adj is not None:
             ga = K.postprocess_dense_bwd(raw, g_adj, ctx.flags)
@@ -1162,8 +1175,6 @@ class _PoolUnbatchedFn(torch.autograd.Function):
                 raise RuntimeError("dense pooling backward: K > 4096 is not supported by the post-processing backward")
         gb = None if g_raw is None else N.f32c(g_raw)
         gx_t, gx_bc = K._bcast_or_dense(g_xp, (B, Kc, F))
-        symmetric = ctx.sym is not None and ctx.sym.get()
-        POOL_LARGE_STATS["symmetric" if symmetric else "general"] += 1
         fold_gx = selector and want_gx
         # the operand buffer's first block holds T = A S.  With raw = S^T A S that is "U" (right-hand side gR^T) and
         # T' = A^T S is "V" (gR); for the transposed form raw = S^T A^T S the two trade places (flag bit 1).

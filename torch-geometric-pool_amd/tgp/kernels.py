@@ -2577,6 +2577,62 @@ def pool_rows_forward(x: Tensor, weight: Optional[Tensor], bias: Optional[Tensor
     return out
 
 
+def pool_rows_backward(s: Tensor, t: Tensor, x: Tensor, weight: Tensor, raw: Tensor, gram, stats, den, deg, lossv,
+                       ptr: Tensor, batch, slab_ptr: Tensor, max_nodes: int, flags: int, mode: int, transposed: bool,
+                       scales, g_adj, g_raw, g_xp, g_s, g_la, g_lb, want_gx: bool, want_gw: bool, want_gb: bool):
+    """(gX, gW, gbias) of the rows route's training step as ONE native call (``tgp_pool_rows_bwd_f32``) for the common
+    case -- the selector folded in, A = A^T --, or None when an operand is not float32 / contiguous (the caller then makes
+    the same launches one by one).  See functions._PoolUnbatchedFn.backward for the arithmetic."""
+    if not _POOL_ROWS_ONE_CALL:
+        return None
+    n, Kc = s.shape
+    F = x.size(1)
+    B = ptr.numel() - 1
+    dev = s.device
+    f32 = torch.float32
+
+    def ok(v, shape=None):
+        return v is None or (v.dtype == f32 and v.is_contiguous() and (shape is None or tuple(v.shape) == tuple(shape)))
+
+    if not (ok(s) and ok(t, (n, Kc)) and ok(x, (n, F)) and ok(weight, (Kc, F)) and ok(raw, (B, Kc, Kc)) and ok(gram)
+            and ok(stats) and ok(den) and ok(deg) and ok(lossv) and ptr.dtype == torch.int64 and ptr.is_contiguous()
+            and (batch is None or (batch.dtype == torch.int64 and batch.is_contiguous())) and ok(g_raw, (B, Kc, Kc))
+            and ok(g_s, (n, Kc)) and (g_la is None or g_la.dtype == f32) and (g_lb is None or g_lb.dtype == f32)):
+        return None
+    ga_bc = gx_bc = False
+    if g_adj is not None:
+        if tuple(g_adj.shape) != (B, Kc, Kc) or g_adj.dtype != f32:
+            return None
+        g_adj, ga_bc = _bcast_or_dense(g_adj, (B, Kc, Kc))
+    if g_xp is not None:
+        if tuple(g_xp.shape) != (B, Kc, F) or g_xp.dtype != f32:
+            return None
+        g_xp, gx_bc = _bcast_or_dense(g_xp, (B, Kc, F))
+    pad = TRAIN_PAD
+    ld = 3 * Kc + F + pad
+    e = dict(dtype=f32, device=dev)
+    ga = torch.empty(B, Kc, Kc, **e) if g_adj is not None else None
+    rcat = torch.empty(B, ld, Kc, **e)
+    c1 = torch.empty(B, **e) if mode == 1 else None
+    gwcat = torch.empty(B, 2 * Kc, F, **e) if want_gx else None
+    acat = torch.empty(n, ld, **e)
+    gs = torch.empty(n, Kc, **e)
+    gx = torch.empty(n, F, **e) if want_gx else None
+    slabs = slab_ptr.numel() - 1
+    part = torch.empty(slabs, Kc, F + pad, **e) if (want_gw or want_gb) else None
+    gw = torch.empty(Kc, F, **e) if want_gw else None
+    gb = torch.empty(Kc, **e) if want_gb else None
+    N.check(N.lib().tgp_pool_rows_bwd_f32(
+        s.data_ptr(), t.data_ptr(), x.data_ptr(), weight.data_ptr(), raw.data_ptr(), N.ptr(gram), N.ptr(stats), N.ptr(den),
+        N.ptr(deg), N.ptr(lossv), ptr.data_ptr(), N.ptr(batch), slab_ptr.data_ptr(), slabs, n, B, Kc, F, max_nodes,
+        int(flags), ops_eps(), losses_eps(), int(mode), 1 if transposed else 0, 1.0 / B,
+        float(scales[0]) if mode == 2 else 0.0, float(scales[1]) if mode == 2 else 0.0, N.ptr(g_adj), 1 if ga_bc else 0,
+        N.ptr(g_raw), N.ptr(g_xp), 1 if gx_bc else 0, N.ptr(g_s), N.ptr(g_la), N.ptr(g_lb), N.ptr(ga), rcat.data_ptr(),
+        N.ptr(c1), N.ptr(gwcat), acat.data_ptr(), gs.data_ptr(), N.ptr(gx), N.ptr(part), N.ptr(gw), N.ptr(gb),
+        N.stream_ptr(dev)), "tgp_pool_rows_bwd_f32")
+    return gx, gw, gb
+
+
 def segment_gemm_nn_into(a: Tensor, bm: Tensor, ptr: Tensor, out: Tensor, max_nodes: int) -> Tensor:
     """out[rows of graph b] = a[rows of graph b] @ bm[b] for float32 VIEWS with unit last stride: ``a`` [Ntot,Kd] and
     ``out`` [Ntot,Nc] with any row stride (column blocks of a wider buffer), ``bm`` [B,Kd,Nc] with any row / batch stride."""
