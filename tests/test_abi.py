@@ -157,3 +157,39 @@ def test_graft_entry_build_from_a_clean_tree(tmp_path):
                        cwd=dst, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "BUILD-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert (dst / "torch-geometric-pool_amd" / "lib" / "libtgp_hip.so").exists()
+
+
+def test_round6_entry_points_reject_bad_arguments_without_a_gpu():
+    """The r6 entries validate before any HIP call too: null outputs, workspaces that are too small, modes out of range."""
+    from tgp import _native
+    lib = _native.lib()
+    d = (ctypes.c_int64 * 4)()
+    p = ctypes.addressof(d)
+    # the rows route's one-call forward: workspace too small (-2), a loss mode without its outputs (-1), a bad mode (-1)
+    need = lib.tgp_pool_rows_fwd_workspace_bytes(4, 16, 8, 64, 200)
+    assert need >= lib.tgp_segment_gemm_tn3_post_workspace_bytes(4, 16, 8, 16, 64)
+    args = [p, 200, 8, p, None, p, p, p, None, 100, p, 4, 16, 64, 0, 3, 1e-12, 1e-15]
+    tail = [None, 0.0, 1.0, 1.0, p, p, p, p, p]
+    assert lib.tgp_pool_rows_fwd_f32(*args, 0, *tail, None, None, None, None, None, None, None, None, p, 8, None) == -2
+    assert b"workspace too small" in lib.tgp_last_error()
+    assert lib.tgp_pool_rows_fwd_f32(*args, 1, *tail, None, None, None, None, None, None, None, None, p, need, None) == -1
+    assert b"MinCut outputs" in lib.tgp_last_error()
+    assert lib.tgp_pool_rows_fwd_f32(*args, 7, *tail, None, None, None, None, None, None, None, None, p, need, None) == -1
+    # its backward: the weight gradient needs the slab buffer; DiffPool needs the forward's link loss
+    base = [p, p, p, p, p, p, None, None, None, None, p, None, p, 1, 200, 4, 16, 8, 64, 3, 1e-12, 1e-15]
+    grads = [None, 0, None, None, 0, None, None, None]
+    assert lib.tgp_pool_rows_bwd_f32(*base, 0, 0, 0.25, 0.0, 0.0, *grads, None, p, None, p, p, p, p, None, p, None,
+                                     None) == -1
+    assert b"slab buffer" in lib.tgp_last_error()
+    assert lib.tgp_pool_rows_bwd_f32(*base, 2, 0, 0.25, 1.0, 1.0, *grads, None, p, None, p, p, p, p, p, p, None,
+                                     None) == -1
+    assert b"DiffPool operands" in lib.tgp_last_error()
+    # the count wait needs an epoch; the per-graph records tail a 16-byte aligned table; the SpMM riders their outputs
+    assert lib.tgp_result_wait_pack_cols(p, 0, p, p, None) == -1
+    assert lib.tgp_diffpool_stats_tail_f32(p + 4, 3, 1.0, 1.0, p, None) == -1
+    assert lib.tgp_spmm_csr_stats_f32(p, p, None, 4, 4, p, 16, p, None, None, None) == -1
+    n_part = ctypes.c_int(0)
+    assert lib.tgp_spmm_csr_entropy_f32(p, p, None, 4, 4, p, 16, p, 1e-15, None, ctypes.addressof(n_part), None) == -1
+    assert lib.tgp_dense_pool_small_diff_f32(p, p, p, p, None, None, 64, 40, 12, 16, 3, 1e-12, 1e-15, p, p, None, p, p,
+                                             None, None) == -1  # S and W at once
+    assert lib.tgp_segment_gemm_tn3_post_f32(p, p, p, 8, p, 16, p, p, p, p, p, 4, 200, 16, 64, 0, 3, 1e-12, p, 8, None) == -2
