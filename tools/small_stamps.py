@@ -3,6 +3,7 @@
 2 X' done + stored, 3 U and A' MFMAs done, 4 post-processing done, 5 end."""
 import ctypes
 import os
+import sys
 
 import torch
 
@@ -13,7 +14,7 @@ lib.tgp_dense_pool_workspace_bytes.restype = sz
 lib.tgp_dense_pool_workspace_bytes.argtypes = [i64] * 4
 lib.tgp_dense_pool_f32.argtypes = [p, p, p, i64, i64, i64, i64, ci, ctypes.c_float, p, p, p, p, p, sz, p]
 lib.tgp_debug_set_gemm_stamps.argtypes = [p]
-B, N, K, F = 2048, 60, 20, 32
+B, N, K, F = (int(sys.argv[1]) if len(sys.argv) > 1 else 2048), 60, 20, 32
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 S = torch.softmax(torch.randn(B, N, K, device=dev), -1)
@@ -46,3 +47,9 @@ for i, nm in enumerate(names):
     d = (st[:, i] - st[:, i - 1]) if i else col
     print(f"  {nm:18s} at {col.quantile(0.5):6.2f} us (p10 {col.quantile(0.1):6.2f}, p90 {col.quantile(0.9):6.2f})"
           f"   phase {d.quantile(0.5):6.2f} us (p90 {d.quantile(0.9):6.2f})")
+
+# the two load groups of a workgroup separately (waves 0-3 request first, waves 4-7 queue behind them)
+grp = (torch.arange(st.size(0)) % 8) >= 4
+for gi, gname in ((False, "waves 0-3"), (True, "waves 4-7")):
+    sub = st[grp == gi]
+    print(f"  {gname}: " + ", ".join(f"{nm} {sub[:, i].quantile(0.5):5.2f}" for i, nm in enumerate(names)))

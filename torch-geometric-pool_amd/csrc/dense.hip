@@ -274,10 +274,10 @@ static int dense_pool_impl(const float* S, const float* A, const float* X, int64
                 want_a ? adj_raw : nullptr, want_a ? adj_pool : nullptr, want_a ? mincut_terms : nullptr, loss_eps,
                 nullptr, nullptr, nullptr, nullptr, nullptr};
     const int grid = static_cast<int>((B + SG_WAVES - 1) / SG_WAVES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_pool_small_kernel<false, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(SG_WAVES * SG_WAVE_FLOATS * sizeof(float)));
-    hipLaunchKernelGGL(dense_pool_small_kernel<false>, dim3(grid), dim3(64 * SG_WAVES),
+    hipLaunchKernelGGL((dense_pool_small_kernel<false, true>), dim3(grid), dim3(64 * SG_WAVES),
                        SG_WAVES * SG_WAVE_FLOATS * sizeof(float), stream, q);
     return check_launch("tgp_dense_pool_f32(small)");
   }

@@ -130,8 +130,15 @@ __device__ __forceinline__ const float* byte_off(const float* base, int bytes) {
 // 22.0 -> 21.3 us.  Real overlap needs 16 lighter waves per CU (two waves per graph); see DESIGN.md known gaps.
 constexpr int SG_WAVES = 8;
 constexpr int SG_EDGE_ROUNDS = 8;  // edges of a graph requested up front by the sparse form (64 per round)
-template <bool SPARSE>
+// LATE_X (r6, the form without a folded selector: S is an input): the chain A, S -> U -> A' -> post-processing does not
+// need X, whose 32 requests are the last a wave makes.  They are made on every path (a call without X reads element 0 of
+// S), so that the compiler can COUNT them and wait for A and S with `vmcnt(32)` instead of `vmcnt(0)`; X' = S^T X runs
+// last, on operands that landed while the adjacency phases ran.  A separate instantiation: with the selector folded in X
+// is needed first, and carrying both orders behind a run-time test costs the folded form 3 us (profiles/r06_c3_experiments.md).
+template <bool SPARSE, bool LATE_X = false>
 __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(SmallArgs p) {
+  static_assert(!(SPARSE && LATE_X), "the sparse form builds its operands from X's rows first");
+  const float* const sel_w = LATE_X ? nullptr : p.sel_w;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int s_issued;
   const int lane = lane_id();
@@ -158,7 +165,9 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
     e1 = e1 < e0 ? e0 : (e1 > p.e_count ? p.e_count : e1);
     if (p.mask_out && lane < N) p.mask_out[static_cast<long>(b) * N + lane] = lane < nb ? 1 : 0;
   }
-  if (w >= SG_WAVES / 2) {  // second group: wait until the first group's requests are in the queue
+  // second group: wait until the first group's requests are in the queue.  (Not with the selector folded in: there a wave
+  // starts with a softmax pass over X, which staggers the groups on its own -- measured r6, 0.044 -> 0.042 ms per forward.)
+  if (w >= SG_WAVES / 2 && !sel_w) {
     int first = p.B - static_cast<int>(blockIdx.x) * SG_WAVES;
     first = first < SG_WAVES / 2 ? first : SG_WAVES / 2;
     while (__hip_atomic_load(&s_issued, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < first)
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
     }
     // step q of every product contracts node rows node(q) = 32*(q>>4) + rho(q&15) + 4*lk
     float sr[32], xr[32];
-    if (!p.sel_w) {
+    if (!sel_w) {
       const float* Sb = p.S + static_cast<long>(b) * N * K;
       const bool cok = lm < K;
 #pragma unroll
@@ -215,29 +224,33 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
         sr[q] = ok ? r : 0.f;
       }
     }
-    if (p.X) {
-      const float* Xb = SPARSE ? p.X + n0 * F : p.X + static_cast<long>(b) * N * F;  // (sparse: the graph's own rows of x)
-      const bool cok = lm < F;
+    if (LATE_X || p.X) {
+      const float* Xb = (LATE_X && !p.X) ? p.S : SPARSE ? p.X + n0 * F : p.X + static_cast<long>(b) * N * F;  // (sparse: the graph's own rows of x)
+      const bool cok = (!LATE_X || p.X) && lm < F;
 #pragma unroll
       for (int q = 0; q < 32; ++q) {
         const int node = 32 * (q >> 4) + rho(q & 15) + 4 * lk;
         const bool ok = cok && node < nb;
         const float r = *byte_off(Xb, ok ? (node * F + lm) * 4 : 0);
-        xr[q] = ok ? r : 0.f;
+        if constexpr (LATE_X) xr[q] = r;  // (left as loaded; x_at() zeroes the out-of-range lanes where X' consumes them)
+        else xr[q] = ok ? r : 0.f;
       }
     }
+    [[maybe_unused]] auto x_at = [&](int q) {
+      return (p.X && lm < F && 32 * (q >> 4) + rho(q & 15) + 4 * lk < nb) ? xr[q] : 0.f;
+    };
     float wl[16];
-    if (p.sel_w) {  // W [K,F] row by row (lane = feature: coalesced), two rows per load instruction; staged in LDS below
+    if (sel_w) {  // W [K,F] row by row (lane = feature: coalesced), two rows per load instruction; staged in LDS below
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int kr = 2 * t + lk;
         const bool ok = kr < K && lm < F;
-        const float v0 = *byte_off(p.sel_w, ok ? (kr * F + lm) * 4 : 0);
+        const float v0 = *byte_off(sel_w, ok ? (kr * F + lm) * 4 : 0);
         wl[t] = ok ? v0 : 0.f;
       }
     }
     if (w < SG_WAVES / 2 && lane == 0) atomicAdd(&s_issued, 1);  // this wave's loads are all issued
-    if (p.sel_w) {
+    if (sel_w) {
       // ---- S = softmax(X W^T + b) * mask, straight into the operand registers sr[] ------------------------------
       // X is in registers with lane = feature; the product needs it with lane = node: through the (still unused) A tile
       // in LDS.  The accumulators of Z_T = X_T W^T (lane = cluster, register r = node 32 T + rho(r) + 4 lk) ARE the
@@ -342,22 +355,25 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
       }
     }
 
-    // ---- X' = S^T X ---------------------------------------------------------------------
-    if (p.X && p.x_pool) {
-      f32x16 ax;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ax[r] = 0.f;
-#pragma unroll
-      for (int q = 0; q < 32; ++q) ax = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[q], xr[q], ax, 0, 0, 0);
-      if (lm < F) {
-        float* o = p.x_pool + static_cast<long>(b) * K * F;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = rho(r) + 4 * lk;
-          if (c < K) o[c * F + lm] = ax[r];
+    // ---- X' = S^T X (in front of the adjacency phases, or behind them: LATE_X) -------------------------------
+    auto x_prime = [&]() {
+      if (p.X && p.x_pool) {
+        f32x16 ax;
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) ax[r] = 0.f;
+  #pragma unroll
+        for (int q = 0; q < 32; ++q) ax = __builtin_amdgcn_mfma_f32_32x32x2f32(sr[q], LATE_X ? x_at(q) : xr[q], ax, 0, 0, 0);
+        if (lm < F) {
+          float* o = p.x_pool + static_cast<long>(b) * K * F;
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = rho(r) + 4 * lk;
+            if (c < K) o[c * F + lm] = ax[r];
+          }
         }
       }
-    }
+    };
+    if constexpr (!LATE_X) x_prime();
 
     TGP_WSTAMP(2);
     // ---- U = A S (kept in accumulators), A' = S^T U -----------------------------------------
@@ -530,6 +546,7 @@ __global__ __launch_bounds__(64 * SG_WAVES, 2) void dense_pool_small_kernel(Smal
         }
       }
     }
+    if constexpr (LATE_X) x_prime();
   }
   TGP_WSTAMP(5);
 }
