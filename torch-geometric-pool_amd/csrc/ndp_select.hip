@@ -196,11 +196,12 @@ __device__ __forceinline__ void ndp_eig3_largest_f32(const double ad[3][3], int 
 // trigonometric solution of the characteristic cubic, the eigenvector as the largest of the three cross products of rows
 // of H - theta I.  ~100 instructions where four Jacobi sweeps are ~1000 (5.6 k cycles per step of the one-wave kernel,
 // more than half of it).  When the largest eigenvalue is (nearly) double the cross products vanish: the Jacobi sweeps
-// take over (rare: two coinciding Ritz values).  c comes back with unit length.
+// take over (rare: two coinciding Ritz values).  c comes back with unit length.  Square roots and reciprocals are the
+// 1-ulp hardware ones (r6): the coefficients only pick the next search direction.
 __device__ __forceinline__ void ndp_rr_largest_f32(const double ad[3][3], int dim, double c[3]) {
   const float a00 = static_cast<float>(ad[0][0]), a11 = static_cast<float>(ad[1][1]), a01 = static_cast<float>(ad[0][1]);
   if (dim == 2) {
-    const float t = 0.5f * (a00 - a11), sr = sqrtf(t * t + a01 * a01);
+    const float t = 0.5f * (a00 - a11), sr = __builtin_amdgcn_sqrtf(t * t + a01 * a01);
     const float theta = 0.5f * (a00 + a11) + sr;
     // rows of H - theta I: (a00 - theta, a01) and (a01, a11 - theta); eigenvector orthogonal to the larger one
     const float u0 = theta - a11, u1 = a01;      // from the second row
@@ -208,7 +209,7 @@ __device__ __forceinline__ void ndp_rr_largest_f32(const double ad[3][3], int di
     const float nu = u0 * u0 + u1 * u1, nv = v0 * v0 + v1 * v1;
     const float x0 = nu >= nv ? u0 : v0, x1 = nu >= nv ? u1 : v1, nn = nu >= nv ? nu : nv;
     if (nn > 0.f) {
-      const float inv = 1.0f / sqrtf(nn);
+      const float inv = __builtin_amdgcn_rsqf(nn);
       c[0] = static_cast<double>(x0 * inv); c[1] = static_cast<double>(x1 * inv); c[2] = 0.0;
     } else {  // a multiple of the identity
       c[0] = 1.0; c[1] = 0.0; c[2] = 0.0;
@@ -222,7 +223,7 @@ __device__ __forceinline__ void ndp_rr_largest_f32(const double ad[3][3], int di
   const float p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0f * p1;
   bool ok = p2 > 0.f;
   if (ok) {
-    const float pp = sqrtf(p2 * (1.0f / 6.0f)), ip = 1.0f / pp;
+    const float pp = __builtin_amdgcn_sqrtf(p2 * (1.0f / 6.0f)), ip = __builtin_amdgcn_rcpf(pp);
     const float c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
     float r = 0.5f * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
     r = fminf(1.0f, fmaxf(-1.0f, r));
@@ -240,11 +241,23 @@ __device__ __forceinline__ void ndp_rr_largest_f32(const double ad[3][3], int di
     if (n01 > best) { best = n01; y0 = x01[0]; y1 = x01[1]; y2 = x01[2]; }
     ok = best > 1e-6f * p2 * p2;  // (gap to the other eigenvalues) x (spread) well above fp32 noise
     if (ok) {
-      const float inv = 1.0f / sqrtf(best);
+      const float inv = __builtin_amdgcn_rsqf(best);
       c[0] = static_cast<double>(y0 * inv); c[1] = static_cast<double>(y1 * inv); c[2] = static_cast<double>(y2 * inv);
     }
   }
   if (!ok) ndp_eig3_largest_f32(ad, dim, c);  // (wave-uniform)
+}
+
+// 1 / sqrt(v) for the per-graph kernels (r6): v_rsq_f64 (~26 bits) and two Newton steps -- a dozen dependent instructions
+// where `1.0 / sqrt(v)` is a correctly rounded square root AND a division (~40); four of them sit in the chain of every
+// step.  Full double precision to a few ulp: the iteration re-evaluates |x|, the Rayleigh quotient and the residual from
+// the vectors every step, so nothing accumulates.
+__device__ __forceinline__ double ndp_rsqrt(double v) {
+  double y = __builtin_amdgcn_rsq(v);
+  const double h = 0.5 * v;
+  y = fma(y, fma(-h * y, y, 0.5), y);
+  y = fma(y, fma(-h * y, y, 0.5), y);
+  return y;
 }
 
 // indptr / col / w: CSR over all nodes of the batch of a SYMMETRIC adjacency without self loops (the caller
@@ -347,7 +360,10 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
     for (int i = tid; i < n; i += THREADS) sq += x[i] * x[i];
     const double x2 = ndp_block_sum<THREADS>(sq, s_red);
     __syncthreads();
-    for (int i = tid; i < n; i += THREADS) { x[i] *= 1.0 / sqrt(x2); pv[i] = 0.0; ap[i] = 0.0; }
+    {
+      const double ix0 = ndp_rsqrt(x2);
+      for (int i = tid; i < n; i += THREADS) { x[i] *= ix0; pv[i] = 0.0; ap[i] = 0.0; }
+    }
     __syncthreads();
     matvec(x, ax);
     double dt = 0.0;
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
       ndp_block_sums<THREADS, 3>(sa, s_red);
       const double rn2 = sa[0];
       if (!(rn2 > tol * tol * lam * lam)) break;  // |Ls x - lambda x| <= tol * lambda: converged
-      const double inv_r = 1.0 / sqrt(rn2);
+      const double inv_r = ndp_rsqrt(rn2);
       const double cxp = sa[1], cwp = sa[2] * inv_r;
       __syncthreads();
       for (int i = tid; i < n; i += THREADS) wv[i] *= inv_r;
@@ -395,7 +411,7 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
       }
       ndp_block_sums<THREADS, 6>(sb, s_red);
       const int dim = (has_p && sb[0] > 1e-24) ? 3 : 2;  // p was unit length: what is left of it outside span{x, w}
-      const double ip = dim == 3 ? 1.0 / sqrt(sb[0]) : 0.0;
+      const double ip = dim == 3 ? ndp_rsqrt(sb[0]) : 0.0;
       double h[3][3] = {{lam, sb[1], sb[3] * ip}, {sb[1], sb[2], sb[4] * ip}, {sb[3] * ip, sb[4] * ip, sb[5] * ip * ip}};
       double c[3];
       ndp_rr_largest_f32(h, dim, c);
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
       // x <- c0 x + c1 w + c2 p^, p <- (c1 w + c2 p^) / |.| (the same combinations of Ls x, Ls w, Ls p^)
       const double c2p = c[2] * ip;
       const double pn2 = c[1] * c[1] + c[2] * c[2];
-      const double sp = pn2 > 1e-300 ? 1.0 / sqrt(pn2) : 0.0;
+      const double sp = pn2 > 1e-300 ? ndp_rsqrt(pn2) : 0.0;
       double sc[2] = {0.0, 0.0};
       for (int i = tid; i < n; i += THREADS) {
         const double pn = c[1] * wv[i] + c2p * pv[i], apn = c[1] * aw[i] + c2p * ap[i];
@@ -416,12 +432,12 @@ __global__ __launch_bounds__(THREADS) void ndp_partition_kernel(const int32_t* _
         sc[1] += xn * axn;
       }
       ndp_block_sums<THREADS, 2>(sc, s_red);
-      const double ix = 1.0 / sqrt(sc[0]);
+      const double ix = ndp_rsqrt(sc[0]);
       for (int i = tid; i < n; i += THREADS) {
         x[i] *= ix;
         ax[i] *= ix;
       }
-      lam = sc[1] / sc[0];
+      lam = sc[1] * ix * ix;
       has_p = sp > 0.0;
       __syncthreads();
     }
@@ -554,7 +570,7 @@ __global__ __launch_bounds__(64) void ndp_partition_wave_kernel(const int32_t* _
                 : 0.0;
   if (!random_part) {
     const double x2 = ndp_wave_sum(x * x);
-    x *= 1.0 / sqrt(x2);
+    x *= ndp_rsqrt(x2);
     double ax = matvec(x), pv = 0.0, ap = 0.0;
     double lam = ndp_wave_sum(x * ax);
     bool has_p = false;
@@ -564,7 +580,7 @@ __global__ __launch_bounds__(64) void ndp_partition_wave_kernel(const int32_t* _
       ndp_block_sums<64, 3>(sa, nullptr);
       const double rn2 = sa[0];
       if (!(rn2 > tol * tol * lam * lam)) break;  // |Ls x - lambda x| <= tol * lambda: converged
-      const double inv_r = 1.0 / sqrt(rn2);
+      const double inv_r = ndp_rsqrt(rn2);
       const double cxp = sa[1], cwp = sa[2] * inv_r;
       const double wv = r * inv_r;
       const double aw = matvec(wv);
@@ -578,24 +594,24 @@ __global__ __launch_bounds__(64) void ndp_partition_wave_kernel(const int32_t* _
       double sb[6] = {pv * pv, x * aw, wv * aw, x * ap, wv * ap, pv * ap};
       ndp_block_sums<64, 6>(sb, nullptr);
       const int dim = (has_p && sb[0] > 1e-24) ? 3 : 2;
-      const double ip = dim == 3 ? 1.0 / sqrt(sb[0]) : 0.0;
+      const double ip = dim == 3 ? ndp_rsqrt(sb[0]) : 0.0;
       const double h[3][3] = {{lam, sb[1], sb[3] * ip}, {sb[1], sb[2], sb[4] * ip}, {sb[3] * ip, sb[4] * ip, sb[5] * ip * ip}};
       double c[3];
       ndp_rr_largest_f32(h, dim, c);
       if (c[0] < 0.0) { c[0] = -c[0]; c[1] = -c[1]; c[2] = -c[2]; }
       const double c2p = c[2] * ip;
       const double pn2 = c[1] * c[1] + c[2] * c[2];
-      const double sp = pn2 > 1e-300 ? 1.0 / sqrt(pn2) : 0.0;
+      const double sp = pn2 > 1e-300 ? ndp_rsqrt(pn2) : 0.0;
       const double pn = c[1] * wv + c2p * pv, apn = c[1] * aw + c2p * ap;
       const double xn = c[0] * x + pn, axn = c[0] * ax + apn;
       pv = pn * sp;
       ap = apn * sp;
       double sc[2] = {xn * xn, xn * axn};
       ndp_block_sums<64, 2>(sc, nullptr);
-      const double ix = 1.0 / sqrt(sc[0]);
+      const double ix = ndp_rsqrt(sc[0]);
       x = xn * ix;
       ax = axn * ix;
-      lam = sc[1] / sc[0];
+      lam = sc[1] * ix * ix;  // (= sc[1] / sc[0] to rounding, without the division's ~15 dependent instructions)
       has_p = sp > 0.0;
     }
     if (!(lam > 0.0)) random_part = true;
