@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10040 /* 1.0.1 of the reference, ABI revision 39 (r6: the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
+#define TGP_ABI_VERSION 10041 /* 1.0.1 of the reference, ABI revision 40 (r6: tgp_mask_index_*; the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
 
 enum tgp_status {
   TGP_OK = 0,
@@ -1000,6 +1000,18 @@ int tgp_edges_compact(const int64_t* row, const int64_t* col, const void* weight
  * of 4): the merged outputs of a gathered step (tgp/data/collate.py:144-153) leave the receive buffer as exact-size
  * tensors in one launch. */
 int tgp_copy_arrays(const void* const* src, void* const* dst, const int64_t* bytes, int count, void* stream);
+/* r6: a byte mask [n] as the sorted list of its non-zero positions -- the `nonzero` with which NDPSelect turns its +-1
+ * partition into the kept nodes, and the [2, k] index / value arrays of the one-node-per-supernode S built around it
+ * (select/ndp_select.py:257-262, select/base_select.py:142-161).  tgp_mask_index_count: per-tile counts into `scratch`
+ * (tgp_mask_index_scratch_words(n) 32-bit words, word 0 an arrival ticket that is zero between calls: clear the buffer
+ * once), then {epoch << 34 | k} in the PINNED word `result` (k = -3 in 34-bit two's complement when `*declined` (device,
+ * optional) is non-zero).  tgp_mask_index_fill, once the host has read k: pos_out[k] the positions in increasing order,
+ * rank_out[k] = 0..k-1 and ones_out[k] = 1 (both optional).  n < 2^31. */
+int64_t tgp_mask_index_scratch_words(int64_t n);
+int tgp_mask_index_count(const uint8_t* mask, int64_t n, const int32_t* declined, uint32_t* scratch, uint64_t* result,
+                         uint32_t epoch, void* stream);
+int tgp_mask_index_fill(const uint8_t* mask, int64_t n, const uint32_t* scratch, int64_t k, int64_t* pos_out,
+                        int64_t* rank_out, float* ones_out, void* stream);
 /* r6: the host wait of tgp_sparse_pool_small_f32 + the launch that makes its edge_index contiguous, in one call (the
  * reference's own host reads: `.item()` in utils/ops.py:370-380 / the nonzero of connect/base_conn.py:79-89).  Spins on
  * the PINNED result word until call `epoch` has stored it; unless the kernel refused the input (bit 31 of the word) the

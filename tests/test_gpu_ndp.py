@@ -313,3 +313,45 @@ def test_ndp_select_with_an_unsorted_batch_vector_stays_on_device(dev, monkeypat
     # the reference's so.L in the caller's numbering (built lazily on the host)
     L = so_u.L
     assert L.shape == (n, n) and abs(L.sum()) < 1e-3
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 4095, 4096, 4097, 100_003, 1_000_000])
+@pytest.mark.parametrize("density", [0.0, 0.03, 0.5, 1.0])
+def test_mask_index_matches_nonzero(dev, n, density):
+    """tgp_mask_index_count / _fill (r6) against torch's nonzero: positions in increasing order, the rank row, the unit
+    values; bytes other than 0 / 1 count as set; the mask may start at any byte offset (reference:
+    select/ndp_select.py:257-262)."""
+    from tgp import kernels as K
+    g = torch.Generator(device=dev).manual_seed(n + int(density * 100))
+    base = torch.zeros(n + 3, dtype=torch.uint8, device=dev)
+    mask = base[3:]  # an odd byte offset: the 16-byte loads are not available to every thread
+    if n:
+        hit = torch.rand(n, device=dev, generator=g) < density
+        mask.copy_(hit.to(torch.uint8) * torch.randint(1, 256, (n,), device=dev, generator=g, dtype=torch.int32).to(torch.uint8))
+    want = mask.nonzero().view(-1)
+    for want_rank, want_ones in ((True, True), (False, False)):
+        index, ones = K.mask_index(mask, None, want_rank=want_rank, want_ones=want_ones)
+        assert index.shape == (2 if want_rank else 1, want.numel()) and index.dtype == torch.long
+        assert torch.equal(index[0], want)
+        if want_rank:
+            assert torch.equal(index[1], torch.arange(want.numel(), device=dev))
+        if want_ones:
+            assert torch.equal(ones, torch.ones(want.numel(), device=dev))
+        else:
+            assert ones is None
+    # the producer's flag rides with the count: non-zero -> no result, and the next call is unaffected
+    flag = torch.ones(1, dtype=torch.int32, device=dev)
+    assert K.mask_index(mask, flag) is None
+    flag.zero_()
+    assert torch.equal(K.mask_index(mask, flag)[0][0], want)
+
+
+def test_mask_index_refuses_stream_capture(dev, monkeypatch):
+    """The count is read on the host between the two launches: under capture the wait would never end, so the call raises
+    (checked with the capture test patched: a real failed capture would leave the stream unusable for the next tests)."""
+    from tgp import kernels as K
+    mask = torch.ones(64, dtype=torch.uint8, device=dev)
+    assert K.mask_index(mask)[0].shape == (1, 64)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    with pytest.raises(RuntimeError, match="not capturable"):
+        K.mask_index(mask)

@@ -5,6 +5,8 @@
 // of the capacity arrays there: edge_index contiguous [2, n], nothing pins E-sized scratch.  Callers that opt into views
 // of the capacity buffers (tgp.kernels.output_views) skip it.
 #include "common.h"
+#include "lookback.h"
+#include "primitives.h"
 
 namespace tgp {
 
@@ -89,6 +91,120 @@ extern "C" int tgp_copy_arrays(const void* const* src, void* const* dst, const i
   hipLaunchKernelGGL(edges_compact_kernel, dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(count)), dim3(256), 0,
                      stream, a);
   return check_launch("tgp_copy_arrays");
+}
+
+// ---- r6: a byte mask as the sorted list of its set positions (NDPSelect's kept nodes: the reference's `nonzero` of
+// select/ndp_select.py:257-262 and the [2, k] index / value arrays of S around it).  Two launches with the host's size
+// read between them: (1) per-tile counts, the LAST tile to arrive adds them up and stores {epoch, count} in a pinned word
+// (count = -3 when `*declined` is non-zero: the producer of the mask refused its input); (2) every tile re-adds the counts
+// in front of it (at most n / 4096 numbers) and writes its positions.  Fixed order, no atomics on the data path.
+constexpr int MI_TILE = 4096;  // mask bytes per 256-thread workgroup (16 per thread)
+
+__device__ __forceinline__ uint32_t mi_nonzero_bytes(uint32_t w) {  // one bit per non-zero byte, at the byte's bit 0
+  uint32_t t = w | (w >> 4);
+  t |= t >> 2;
+  t |= t >> 1;
+  return t & 0x01010101u;
+}
+// the 16 mask bytes of thread `tid` of tile `tile` as 16 flag bits (bit j = byte j is non-zero)
+__device__ __forceinline__ uint32_t mi_flags16(const uint8_t* __restrict__ mask, int64_t n, int64_t base) {
+  uint32_t bits = 0;
+  if (base + 16 <= n && (reinterpret_cast<uintptr_t>(mask + base) & 15) == 0) {
+    const uint4 v = *reinterpret_cast<const uint4*>(mask + base);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t f = mi_nonzero_bytes(w[q]);  // bits 0, 8, 16, 24
+      bits |= ((f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u)) << (4 * q);
+    }
+  } else {
+    for (int j = 0; j < 16; ++j)
+      if (base + j < n && mask[base + j] != 0) bits |= 1u << j;
+  }
+  return bits;
+}
+
+__global__ __launch_bounds__(256) void mask_index_count_kernel(const uint8_t* __restrict__ mask, int64_t n, int ntiles,
+                                                               uint32_t* __restrict__ tile_counts, uint32_t* ticket,
+                                                               const int32_t* __restrict__ declined,
+                                                               unsigned long long* result, unsigned long long tag) {
+  __shared__ uint32_t s_w[4];
+  __shared__ bool s_last;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * MI_TILE + static_cast<int64_t>(threadIdx.x) * 16;
+  const uint32_t mine = base < n ? __popc(mi_flags16(mask, n, base)) : 0u;
+  uint32_t total;
+  (void)block_excl_scan_256(mine, s_w, &total);
+  if (threadIdx.x == 0) {
+    tile_counts[blockIdx.x] = total;
+    __threadfence();
+    s_last = atomicAdd(ticket, 1u) == static_cast<uint32_t>(ntiles - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  uint32_t part = 0;
+  for (int t = threadIdx.x; t < ntiles; t += 256) part += __hip_atomic_load(tile_counts + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t sum;
+  (void)block_excl_scan_256(part, s_w, &sum);
+  if (threadIdx.x == 0) {
+    *ticket = 0;  // (the next call on this stream finds it cleared)
+    const bool refused = declined && *declined != 0;
+    const unsigned long long count = refused ? ((1ull << SPS_EPOCH_SHIFT) - 3ull) : static_cast<unsigned long long>(sum);
+    __hip_atomic_store(result, tag | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+__global__ __launch_bounds__(256) void mask_index_fill_kernel(const uint8_t* __restrict__ mask, int64_t n,
+                                                              const uint32_t* __restrict__ tile_counts, int64_t k,
+                                                              int64_t* __restrict__ pos_out, int64_t* __restrict__ rank_out,
+                                                              float* __restrict__ ones_out) {
+  __shared__ uint32_t s_w[4];
+  uint32_t part = 0;
+  for (int t = threadIdx.x; t < static_cast<int>(blockIdx.x); t += 256) part += tile_counts[t];
+  uint32_t before;
+  (void)block_excl_scan_256(part, s_w, &before);
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * MI_TILE + static_cast<int64_t>(threadIdx.x) * 16;
+  const uint32_t bits = base < n ? mi_flags16(mask, n, base) : 0u;
+  int64_t at = static_cast<int64_t>(before) + block_excl_scan_256(__popc(bits), s_w, nullptr);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if ((bits >> j) & 1u) {
+      if (at < k) {  // (k is what the count pass published for this mask: never exceeded)
+        pos_out[at] = base + j;
+        if (rank_out) rank_out[at] = at;
+        if (ones_out) ones_out[at] = 1.0f;
+      }
+      ++at;
+    }
+  }
+}
+
+extern "C" int64_t tgp_mask_index_scratch_words(int64_t n) { return 2 + (n > 0 ? (n + MI_TILE - 1) / MI_TILE : 1); }
+
+extern "C" int tgp_mask_index_count(const uint8_t* mask, int64_t n, const int32_t* declined, uint32_t* scratch,
+                                    uint64_t* result, uint32_t epoch, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(n >= 0 && result && epoch > 0 && epoch < (1u << 30) && scratch && (n == 0 || mask), TGP_ERR_INVALID,
+              "tgp_mask_index_count: bad argument");
+  TGP_REQUIRE(n < (1ll << 31), TGP_ERR_RANGE, "tgp_mask_index_count: more than 2^31 - 1 mask bytes");
+  const int ntiles = static_cast<int>(n > 0 ? (n + MI_TILE - 1) / MI_TILE : 1);
+  // scratch: word 0 the arrival ticket (zero between calls: the caller clears the buffer once), words 2.. the tile counts
+  hipLaunchKernelGGL(mask_index_count_kernel, dim3(ntiles), dim3(256), 0, stream, mask, n, ntiles, scratch + 2, scratch,
+                     declined, reinterpret_cast<unsigned long long*>(result),
+                     static_cast<unsigned long long>(epoch) << SPS_EPOCH_SHIFT);
+  return check_launch("tgp_mask_index_count");
+}
+
+extern "C" int tgp_mask_index_fill(const uint8_t* mask, int64_t n, const uint32_t* scratch, int64_t k, int64_t* pos_out,
+                                   int64_t* rank_out, float* ones_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  TGP_REQUIRE(n >= 0 && k >= 0 && k <= n && scratch && (n == 0 || mask) && (k == 0 || pos_out), TGP_ERR_INVALID,
+              "tgp_mask_index_fill: bad argument");
+  if (k == 0 || n == 0) return TGP_OK;
+  const int ntiles = static_cast<int>((n + MI_TILE - 1) / MI_TILE);
+  hipLaunchKernelGGL(mask_index_fill_kernel, dim3(ntiles), dim3(256), 0, stream, mask, n, scratch + 2, k, pos_out, rank_out,
+                     ones_out);
+  return check_launch("tgp_mask_index_fill");
 }
 
 // r6 (fresh mini-batches: host time).  The host wait of a single-pass operator and the launch that makes its edge_index

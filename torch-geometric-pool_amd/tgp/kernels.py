@@ -2737,6 +2737,47 @@ def ndp_partition(indptr: Tensor, col: Tensor, weight: Optional[Tensor], num_nod
     return (keep[:num_nodes] if raw_keep else keep[:num_nodes].bool()), info[:B], status
 
 
+_MASK_INDEX_SCRATCH: dict = {}
+
+
+def mask_index(mask: Tensor, declined: Optional[Tensor] = None, want_rank: bool = False, want_ones: bool = False):
+    """The sorted positions of the non-zero bytes of ``mask`` [n] uint8 -- `mask.nonzero().view(-1)` in two launches with
+    one pinned-word wait between them (torch's own: seven launches and a synchronising copy) -- as row 0 of an int64
+    ``[2, k]`` array whose row 1 is ``arange(k)`` (``want_rank``; the indices of NDPSelect's S), plus ``ones [k]`` fp32
+    (``want_ones``; its values).  ``declined`` (int32 [1] on the device): when non-zero the call returns None (the flag
+    of the kernel that made the mask; read with the count, no copy of its own).  Returns (index [2,k] or [1,k], ones or
+    None).  reference: select/ndp_select.py:257-262."""
+    dev = N.require_device(mask, declined)
+    if mask.dtype != torch.uint8 or not mask.is_contiguous():
+        raise ValueError("mask_index: a contiguous uint8 mask is required")
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("mask_index reads its count on the host between two launches: not capturable")
+    n = mask.numel()
+    L = N.lib()
+    st = N.stream_ptr(dev)
+    words = int(L.tgp_mask_index_scratch_words(n))
+    key = (dev.index, st)
+    scratch = _MASK_INDEX_SCRATCH.get(key)
+    if scratch is None or scratch.numel() < words:
+        scratch = torch.zeros(max(words, 1024), dtype=torch.int32, device=dev)
+        _MASK_INDEX_SCRATCH[key] = scratch
+    state = _sps_state(dev, st, 0)
+    epoch = state.next_epoch()
+    N.check(L.tgp_mask_index_count(N.ptr(mask), n, N.ptr(declined), N.ptr(scratch), state.pinned.data_ptr(), epoch, st),
+            "tgp_mask_index_count")
+    k = _decode_count(state.wait(epoch))
+    if k < 0:
+        return None
+    rows = 2 if want_rank else 1
+    index = torch.empty((rows, k), dtype=torch.long, device=dev)
+    ones = torch.empty(k, dtype=torch.float32, device=dev) if want_ones else None
+    if k:
+        N.check(L.tgp_mask_index_fill(N.ptr(mask), n, N.ptr(scratch), k, N.ptr(index),
+                                      index.data_ptr() + 8 * k if want_rank else None, N.ptr(ones), st),
+                "tgp_mask_index_fill")
+    return index, ones
+
+
 def ndp_partition_large(indptr: Tensor, col: Tensor, weight: Optional[Tensor], p0: int, p1: int, seed: int,
                         keep: Tensor, status: Tensor, max_iter: int = 2000, tol: float = 1e-6,
                         steps_per_batch: int = 16, want_state: bool = False):

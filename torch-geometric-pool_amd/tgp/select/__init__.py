@@ -918,8 +918,7 @@ class NDPSelect(Select):
             ptr, max_nodes, sizes_host = torch.tensor([0, n], dtype=torch.long, device=dev), n, [n]
         limit = K.ndp_max_graph_nodes()
         oversize = [g for g, m in enumerate(sizes_host) if m > limit] if max_nodes > limit else []
-        ident = torch.arange(n, device=dev)
-        w0 = torch.ones(edge_index.size(1), device=dev) if edge_weight is None else edge_weight.detach().reshape(-1).float()
+        w0 = None if edge_weight is None else edge_weight.detach().reshape(-1).float()
         # self loops out, duplicates summed (get_laplacian + COO -> CSR), then max with the transpose
         # (to_undirected(reduce="max"), ndp_select.py:198-202): a row-sorted, symmetric, coalesced list
         # A list that already is that (the usual PyG dataset of undirected graphs) is recognised by one kernel and used
@@ -928,10 +927,13 @@ class NDPSelect(Select):
         ei2 = None
         if edge_index.size(1) > 0:
             K.rowptr_from_sorted(edge_index[0], n, indptr)
-            w_sym, flag = K.ndp_symmetric_max(edge_index, None if edge_weight is None else w0, n, indptr)
+            w_sym, flag = K.ndp_symmetric_max(edge_index, w0, n, indptr)
             if int(flag.item()) == 0:
                 ei2, w2 = edge_index, w_sym
         if ei2 is None:
+            ident = torch.arange(n, device=dev)
+            if w0 is None:
+                w0 = torch.ones(edge_index.size(1), device=dev)
             ei1, w1 = K.coalesce_edges(edge_index, w0, ident, n, "sum", remove_self_loops=True, eps_filter=False)
             ei2, w2 = K.coalesce_edges(torch.cat([ei1, ei1.flip(0)], 1), torch.cat([w1, w1]), ident, n, "max",
                                        remove_self_loops=False, eps_filter=False)
@@ -974,13 +976,15 @@ class NDPSelect(Select):
                 status = status | status_l
             for g, info_g in infos:
                 part_info[g: g + 1] = info_g
-        keep = keep8.bool()
-        idx_pos = keep.nonzero().view(-1)  # (host round trip: the size of S; also orders the status read below)
-        if int(status.item()) != 0:
+        # the kept nodes as S's [2, k] indices and unit values: two launches and one pinned-word wait that also carries
+        # the kernels' status (r6; before: bool copy + torch's nonzero + status.item() + arange + stack + ones = 13 launches
+        # and two synchronising copies)
+        got = K.mask_index(keep8.contiguous(), status, want_rank=True, want_ones=True)
+        if got is None:
             return None
-        k = idx_pos.numel()
-        s = torch.sparse_coo_tensor(torch.stack([idx_pos, torch.arange(k, device=dev)]), torch.ones(k, device=dev),
-                                    size=(n, k), is_coalesced=True)
+        s_index, s_ones = got
+        k = s_index.size(1)
+        s = torch.sparse_coo_tensor(s_index, s_ones, size=(n, k), is_coalesced=True)
         so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
         so.__dict__["_no_empty_cluster"] = True  # one supernode per kept node
         so._extra_args.add("L")
