@@ -1532,14 +1532,25 @@ extern "C" int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, cons
   TGP_REQUIRE(N >= 0 && B >= 0 && nnz >= 0 && max_iter > 0 && tol >= 0.0, TGP_ERR_INVALID,
               "tgp_ndp_partition: bad argument");
   TGP_REQUIRE(d_status, TGP_ERR_INVALID, "tgp_ndp_partition: null status");
-  (void)hipMemsetAsync(d_status, 0, sizeof(int), stream);
-  if (N == 0 || B == 0) return check_launch("tgp_ndp_partition");
+  if (N == 0 || B == 0) {
+    (void)hipMemsetAsync(d_status, 0, sizeof(int), stream);
+    return check_launch("tgp_ndp_partition");
+  }
   TGP_REQUIRE(indptr && graph_ptr && keep && info && (col || nnz == 0), TGP_ERR_INVALID,
               "tgp_ndp_partition: null pointer");
   TGP_REQUIRE(N < (1ll << 31) && nnz < (1ll << 31) && B < (1ll << 31), TGP_ERR_RANGE,
               "tgp_ndp_partition: N / nnz / B >= 2^31");
-  (void)hipMemsetAsync(keep, 0, static_cast<size_t>(N), stream);
-  (void)hipMemsetAsync(info, 0, static_cast<size_t>(B) * sizeof(int32_t), stream);
+  // status | info | keep are cleared; ONE memset when the caller laid them out back to back (status at the front of a
+  // 16-byte slot, info padded to a multiple of four entries: the host mirror does), three otherwise
+  const size_t info_bytes = static_cast<size_t>((B + 3) / 4 * 4) * sizeof(int32_t);
+  if (reinterpret_cast<uint8_t*>(info) == reinterpret_cast<uint8_t*>(d_status) + 16 &&
+      keep == reinterpret_cast<uint8_t*>(info) + info_bytes) {
+    (void)hipMemsetAsync(d_status, 0, 16 + info_bytes + static_cast<size_t>(N), stream);
+  } else {
+    (void)hipMemsetAsync(d_status, 0, sizeof(int), stream);
+    (void)hipMemsetAsync(keep, 0, static_cast<size_t>(N), stream);
+    (void)hipMemsetAsync(info, 0, static_cast<size_t>(B) * sizeof(int32_t), stream);
+  }
   int64_t cap = max_graph_nodes < NDP_MAX_N ? max_graph_nodes : NDP_MAX_N;
   if (cap < 2) cap = 2;
   // entries of a graph's matrix kept in LDS: four times the batch average (graph sizes are not known on the host),

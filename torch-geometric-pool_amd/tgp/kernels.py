@@ -2727,9 +2727,12 @@ def ndp_partition(indptr: Tensor, col: Tensor, weight: Optional[Tensor], num_nod
     col, graph_ptr = N.i64c(col), N.i64c(graph_ptr)
     w = None if weight is None else N.f32c(weight.reshape(-1))
     B = graph_ptr.numel() - 1
-    keep = torch.empty(max(num_nodes, 1), dtype=torch.uint8, device=dev)
-    info = torch.empty(max(B, 1), dtype=torch.int32, device=dev)
-    status = torch.empty(1, dtype=torch.int32, device=dev)
+    # status | info | keep in one allocation, laid out as tgp_ndp_partition clears them with a single memset (r6)
+    b_pad, n_keep = (max(B, 1) + 3) // 4 * 4, max(num_nodes, 1)
+    buf = torch.empty(16 + 4 * b_pad + n_keep, dtype=torch.uint8, device=dev)
+    status = buf[:4].view(torch.int32)
+    info = buf[16:16 + 4 * b_pad].view(torch.int32)
+    keep = buf[16 + 4 * b_pad:]
     N.check(N.lib().tgp_ndp_partition(N.ptr(indptr.contiguous()), N.ptr(col), N.ptr(w), num_nodes, col.numel(),
                                       N.ptr(graph_ptr), B, max_graph_nodes, int(seed) & ((1 << 64) - 1), max_iter,
                                       float(tol), N.ptr(keep), N.ptr(info), N.ptr(status), N.stream_ptr(dev)),
