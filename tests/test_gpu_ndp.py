@@ -303,13 +303,28 @@ def test_ndp_select_with_an_unsorted_batch_vector_stays_on_device(dev, monkeypat
     kept_u_in_sorted_ids = kept_u[perm]
     spectral = (so_sorted._partition_info >= 0) & (so_u._partition_info >= 0)
     assert int(spectral.sum()) > 0
+    # ... on the nodes where the partition is DEFINED: a node whose entry of the top eigenvector is zero (an isolated node,
+    # a node of another component) gets the sign of rounding noise from any solver, the reference's eigsh included, and
+    # the two numberings start from different vectors (r6: the Lanczos warm start converges to the eigenvector itself,
+    # where the LOBPCG iterates kept the start vector's sign on such nodes)
     same = 0
+    A = torch.zeros(n, n, dtype=torch.float64)
+    A[ei[0].cpu(), ei[1].cpu()] = ew.double().cpu()
+    A = torch.maximum(A, A.t())
     for g in spectral.nonzero().view(-1).tolist():
         m = batch == g
-        a, b = kept_sorted[m], kept_u_in_sorted_ids[m]
-        assert torch.equal(a, b) or torch.equal(a, ~b)   # the sign of an eigenvector is a convention
+        a, b = kept_sorted[m].cpu(), kept_u_in_sorted_ids[m].cpu()
+        idx = m.nonzero().view(-1).cpu()
+        ag = A[idx][:, idx]
+        deg = ag.sum(1)
+        dis = torch.where(deg > 0, deg.clamp(min=1e-300).rsqrt(), torch.zeros_like(deg))
+        vals, vecs = torch.linalg.eigh(torch.eye(idx.numel(), dtype=torch.float64) - dis[:, None] * ag * dis[None, :])
+        if float(vals[-1] - vals[-2]) < 1e-3:
+            continue  # (two directions share the top of the spectrum: any of their combinations is an answer)
+        firm = vecs[:, -1].abs() > 1e-5
+        assert torch.equal(a[firm], b[firm]) or torch.equal(a[firm], ~b[firm])   # the eigenvector's sign is a convention
         same += 1
-    assert same == int(spectral.sum())
+    assert same >= int(spectral.sum()) - 3 and same > 20
     # the reference's so.L in the caller's numbering (built lazily on the host)
     L = so_u.L
     assert L.shape == (n, n) and abs(L.sum()) < 1e-3

@@ -31,20 +31,21 @@ def run():
         keep, info, status = K.ndp_partition(indptr, ei[1], None, n, ptr, 64, seed=1)
     t1.record()
     torch.cuda.synchronize()
-    return keep.cpu(), info.cpu(), t0.elapsed_time(t1) / 20, ptr.cpu()
+    return keep.cpu(), info.cpu(), t0.elapsed_time(t1) / 20, ptr.cpu(), ei.cpu()
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
-        keep, info, ms, ptr = run()
+        keep, info, ms, ptr, _ = run()
         torch.save((keep, info, ms), sys.argv[2])
         sys.exit(0)
-    keep, info, ms, ptr = run()
+    keep, info, ms, ptr, ei = run()
     out = "/tmp/ndp_generic.pt"
     env = dict(os.environ, TGP_NDP_GENERIC_KERNEL="1")
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "child", out], env=env)
     keep_g, info_g, ms_g = torch.load(out)
     same = flipped = differ = 0
+    odd = []
     for b in range(2048):
         a, c = keep[ptr[b]:ptr[b + 1]], keep_g[ptr[b]:ptr[b + 1]]
         if torch.equal(a, c):
@@ -53,7 +54,28 @@ if __name__ == "__main__":
             flipped += 1
         else:
             differ += 1
+            odd.append(b)
     print(f"one-wave kernel {ms:.3f} ms per call (steps: median {int(info[info >= 0].median())}, max {int(info.max())}, "
           f"random fallbacks {int((info < 0).sum())});  LDS-vector kernel {ms_g:.3f} ms (median "
           f"{int(info_g[info_g >= 0].median())}, max {int(info_g.max())}, random {int((info_g < 0).sum())})")
     print(f"partitions: identical {same}, globally sign-flipped {flipped}, different {differ} of 2048 graphs")
+    # where the two kernels disagree: is the partition defined at all?  (dense eigen-decomposition of the graph's Ls on
+    # the host: gap to the second eigenvalue, smallest |entry| of the top eigenvector, nodes on which the kernels differ)
+    for b in odd[:12]:
+        p0, p1 = int(ptr[b]), int(ptr[b + 1])
+        m = p1 - p0
+        sel = (ei[0] >= p0) & (ei[0] < p1)
+        a = torch.zeros(m, m, dtype=torch.float64)
+        a[ei[0][sel] - p0, ei[1][sel] - p0] = 1.0
+        deg = a.sum(1)
+        dis = torch.where(deg > 0, deg.clamp(min=1e-300).rsqrt(), torch.zeros_like(deg))
+        ls = torch.eye(m, dtype=torch.float64) - dis[:, None] * a * dis[None, :]
+        vals, vecs = torch.linalg.eigh(ls)
+        v = vecs[:, -1]
+        kw, kg = keep[p0:p1].bool(), keep_g[p0:p1].bool()
+        want = v >= 0
+        fit = lambda k: min(int((k != want).sum()), int((k != ~want).sum()))
+        dn = (kw != kg).nonzero().view(-1)
+        print(f"  graph {b} ({m} nodes): gap {float(vals[-1] - vals[-2]):.2e}, min |v| {float(v.abs().min()):.1e}, |v| on the "
+              f"{dn.numel()} nodes that differ <= {float(v.abs()[dn].max()):.1e}; nodes off the exact sign pattern: "
+              f"one-wave {fit(kw)}, LDS-vector {fit(kg)}")

@@ -481,7 +481,8 @@ __global__ __launch_bounds__(64) void ndp_partition_wave_kernel(const int32_t* _
                                                                 const int64_t* __restrict__ graph_ptr,
                                                                 unsigned long long seed, int max_iter, double tol,
                                                                 int ncap, int ecap, uint8_t* __restrict__ keep,
-                                                                int32_t* __restrict__ info, int* __restrict__ status) {
+                                                                int32_t* __restrict__ info, int* __restrict__ status,
+                                                                int warm) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
   const int g = blockIdx.x, lane = threadIdx.x;
   const int64_t p0 = graph_ptr[g], p1 = graph_ptr[g + 1];
@@ -571,6 +572,99 @@ __global__ __launch_bounds__(64) void ndp_partition_wave_kernel(const int32_t* _
   if (!random_part) {
     const double x2 = ndp_wave_sum(x * x);
     x *= ndp_rsqrt(x2);
+    if (warm) {
+      // ---- r6: Lanczos warm start.  A LOBPCG step is ~5 k cycles of reductions and Rayleigh-Ritz around a 150-cycle
+      // mat-vec; a Lanczos step is the mat-vec and two reductions.  n steps from the same start vector span (in exact
+      // arithmetic) the whole Krylov space of a graph of n <= 64 nodes: T = tridiag(alpha, beta) is kept one entry per
+      // lane, its largest eigenvalue comes from 64-section on the sign of the leading minors of sigma I - T (lane =
+      // shift; no divisions), its eigenvector from two inverse iterations with sigma just above it (sigma I - T is
+      // positive definite: LDL^T without pivoting), and x = V y from a second run of the recurrence (the vectors are not
+      // stored).  The LOBPCG loop below then starts from x: it keeps the stopping rule, so what leaves the kernel
+      // satisfies the same residual bound as before -- from a start that usually satisfies it already.
+      const double x0 = x;
+      double ta = 0.0, tb = 0.0, tib = 0.0;  // lane j: alpha_j, beta_j (= |u_j|, links j -> j + 1), 1 / beta_j
+      int m = 0;
+      {
+        double v = x0, vp = 0.0, bprev = 0.0;
+        for (int j = 0; j < n; ++j) {
+          double u = matvec(v);
+          const double a = ndp_wave_sum(u * v);
+          u = (u - a * v) - bprev * vp;
+          const double b2 = ndp_wave_sum(u * u);
+          if (lane == j) ta = a;
+          m = j + 1;
+          if (!(b2 > 1e-26)) break;  // an invariant subspace: T is exact
+          const double ib = ndp_rsqrt(b2), b = b2 * ib;
+          if (lane == j) { tb = b; tib = ib; }
+          vp = v;
+          v = u * ib;
+          bprev = b;
+        }
+      }
+      if (m >= 2) {
+        double lo = -1.0, hi = 3.0;  // the spectrum of Ls lies in [0, 2]
+        for (int pass = 0; pass < 9; ++pass) {
+          const double step = (hi - lo) * (1.0 / 65.0);
+          const double sig = lo + step * (lane + 1);
+          double d0 = 1.0, d1 = sig - ndp_readlane_f64(ta, 0);
+          bool ok = d1 > 0.0;
+          for (int j = 1; j < m; ++j) {
+            const double aj = ndp_readlane_f64(ta, j), bj = ndp_readlane_f64(tb, j - 1);
+            const double d2 = (sig - aj) * d1 - (bj * bj) * d0;
+            d0 = d1;
+            d1 = d2;
+            ok = ok && d2 > 0.0;
+          }
+          const unsigned long long okm = __ballot(ok);
+          const int f = okm ? __ffsll(static_cast<long long>(okm)) - 1 : 64;  // first shift above the largest eigenvalue
+          const double nlo = lo + step * f, nhi = f == 64 ? hi : lo + step * (f + 1);
+          lo = nlo;
+          hi = nhi;
+        }
+        const double sig = hi + 4e-16 * (fabs(hi) + 1.0);
+        double yl = lane < m ? 1.0 : 0.0;  // lane j: y_j
+        double dinv = 0.0, zl = 0.0;
+        for (int rep = 0; rep < 2; ++rep) {
+          // (sigma I - T) y = b:  delta_0 = sigma - a_0, delta_j = (sigma - a_j) - b_{j-1}^2 / delta_{j-1},
+          // z_j = b_j + b_{j-1} z_{j-1} / delta_{j-1};  y_{m-1} = z_{m-1} / delta_{m-1}, y_j = (z_j + b_j y_{j+1}) / delta_j
+          double dprev_inv = 0.0, zprev = 0.0;
+          for (int j = 0; j < m; ++j) {
+            const double aj = ndp_readlane_f64(ta, j), bjm = j ? ndp_readlane_f64(tb, j - 1) : 0.0;
+            double dj = (sig - aj) - bjm * bjm * dprev_inv;
+            if (!(dj > 1e-20)) dj = 1e-20;
+            const double zj = ndp_readlane_f64(yl, j) + bjm * zprev * dprev_inv;
+            dprev_inv = 1.0 / dj;
+            zprev = zj;
+            if (lane == j) { dinv = dprev_inv; zl = zj; }
+          }
+          double ynext = 0.0;
+          for (int j = m - 1; j >= 0; --j) {
+            const double bj = j + 1 < m ? ndp_readlane_f64(tb, j) : 0.0;
+            const double yj = (ndp_readlane_f64(zl, j) + bj * ynext) * ndp_readlane_f64(dinv, j);
+            ynext = yj;
+            if (lane == j) yl = yj;
+          }
+          const double y2 = ndp_wave_sum(lane < m ? yl * yl : 0.0);
+          yl = lane < m ? yl * ndp_rsqrt(y2) : 0.0;
+        }
+        double v = x0, vp = 0.0, bprev = 0.0, xn = 0.0;
+        for (int j = 0; j < m; ++j) {
+          xn += ndp_readlane_f64(yl, j) * v;
+          if (j + 1 == m) break;
+          double u = matvec(v);
+          u = (u - ndp_readlane_f64(ta, j) * v) - bprev * vp;
+          vp = v;
+          v = u * ndp_readlane_f64(tib, j);
+          bprev = ndp_readlane_f64(tb, j);
+        }
+        double sn[2] = {xn * xn, xn * x0};
+        ndp_block_sums<64, 2>(sn, nullptr);
+        if (sn[0] > 1e-200 && sn[0] < 1e200) {  // (else: keep the start vector; the loop below does the work as before)
+          const double sc = ndp_rsqrt(sn[0]);
+          x = xn * (sn[1] < 0.0 ? -sc : sc);  // the start vector's side, as the LOBPCG iterates keep it (c0 >= 0)
+        }
+      }
+    }
     double ax = matvec(x), pv = 0.0, ap = 0.0;
     double lam = ndp_wave_sum(x * ax);
     bool has_p = false;
@@ -1565,13 +1659,14 @@ extern "C" int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, cons
   const int ncap = static_cast<int>(cap), ec = static_cast<int>(ecap);
   if (cap <= 64) {
     static const int generic = getenv("TGP_NDP_GENERIC_KERNEL") ? 1 : 0;  // (A/B switch: the LDS-vector kernel)
+    static const int no_warm = getenv("TGP_NDP_LANCZOS") && atoi(getenv("TGP_NDP_LANCZOS")) == 0;  // (A/B: LOBPCG alone)
     if (generic)
       hipLaunchKernelGGL(ndp_partition_kernel<64>, dim3(static_cast<unsigned>(B)), dim3(64), lds, stream, indptr, col, w,
                          graph_ptr, static_cast<unsigned long long>(seed), max_iter, tol, ncap, ec, keep, info, d_status);
     else
       hipLaunchKernelGGL(ndp_partition_wave_kernel, dim3(static_cast<unsigned>(B)), dim3(64), lds, stream, indptr, col,
                          w, graph_ptr, static_cast<unsigned long long>(seed), max_iter, tol, ncap, ec, keep, info,
-                         d_status);
+                         d_status, no_warm ? 0 : 1);
   } else {
     // graphs of 513 .. 2048 nodes: 512 threads per graph (64 graphs of 600 .. 2000 nodes 10.7 -> 7.1 ms; 1024 threads
     // were measured slower than 256: profiles/r03_c3_small_kernel_experiments.md).  TGP_NDP_THREADS=256: A/B switch
