@@ -252,6 +252,12 @@ __device__ __forceinline__ void ndp_rr_largest_f32(const double ad[3][3], int di
 // where `1.0 / sqrt(v)` is a correctly rounded square root AND a division (~40); four of them sit in the chain of every
 // step.  Full double precision to a few ulp: the iteration re-evaluates |x|, the Rayleigh quotient and the residual from
 // the vectors every step, so nothing accumulates.
+__device__ __forceinline__ double ndp_rcp(double v) {  // 1 / v: v_rcp_f64 and two Newton steps (a few ulp)
+  double y = __builtin_amdgcn_rcp(v);
+  y = fma(y, fma(-v, y, 1.0), y);
+  y = fma(y, fma(-v, y, 1.0), y);
+  return y;
+}
 __device__ __forceinline__ double ndp_rsqrt(double v) {
   double y = __builtin_amdgcn_rsq(v);
   const double h = 0.5 * v;
@@ -582,11 +588,12 @@ __global__ __launch_bounds__(64) void ndp_partition_wave_kernel(const int32_t* _
       // stored).  The LOBPCG loop below then starts from x: it keeps the stopping rule, so what leaves the kernel
       // satisfies the same residual bound as before -- from a start that usually satisfies it already.
       const double x0 = x;
-      double ta = 0.0, tb = 0.0, tib = 0.0;  // lane j: alpha_j, beta_j (= |u_j|, links j -> j + 1), 1 / beta_j
+      double ta = 0.0, tb = 0.0, tib = 0.0, tb2 = 0.0;  // lane j: alpha_j, beta_j (= |u_j|, links j -> j + 1), 1 / beta_j, beta_j^2
       int m = 0;
       {
         double v = x0, vp = 0.0, bprev = 0.0;
-        for (int j = 0; j < n; ++j) {
+        const int mmax = n < warm ? n : warm;
+        for (int j = 0; j < mmax; ++j) {
           double u = matvec(v);
           const double a = ndp_wave_sum(u * v);
           u = (u - a * v) - bprev * vp;
@@ -595,22 +602,22 @@ __global__ __launch_bounds__(64) void ndp_partition_wave_kernel(const int32_t* _
           m = j + 1;
           if (!(b2 > 1e-26)) break;  // an invariant subspace: T is exact
           const double ib = ndp_rsqrt(b2), b = b2 * ib;
-          if (lane == j) { tb = b; tib = ib; }
+          if (lane == j) { tb = b; tib = ib; tb2 = b2; }
           vp = v;
           v = u * ib;
           bprev = b;
         }
       }
       if (m >= 2) {
-        double lo = -1.0, hi = 3.0;  // the spectrum of Ls lies in [0, 2]
-        for (int pass = 0; pass < 9; ++pass) {
+        double lo = -1e-6, hi = 2.0 + 1e-6;  // the spectrum of Ls lies in [0, 2], the Ritz values inside it
+        for (int pass = 0; pass < 6; ++pass) {  // 2 / 65^6 = 3e-11: with the two inverse iterations below, enough
           const double step = (hi - lo) * (1.0 / 65.0);
           const double sig = lo + step * (lane + 1);
           double d0 = 1.0, d1 = sig - ndp_readlane_f64(ta, 0);
           bool ok = d1 > 0.0;
           for (int j = 1; j < m; ++j) {
-            const double aj = ndp_readlane_f64(ta, j), bj = ndp_readlane_f64(tb, j - 1);
-            const double d2 = (sig - aj) * d1 - (bj * bj) * d0;
+            const double aj = ndp_readlane_f64(ta, j), bb = ndp_readlane_f64(tb2, j - 1);
+            const double d2 = (sig - aj) * d1 - bb * d0;
             d0 = d1;
             d1 = d2;
             ok = ok && d2 > 0.0;
@@ -633,7 +640,7 @@ __global__ __launch_bounds__(64) void ndp_partition_wave_kernel(const int32_t* _
             double dj = (sig - aj) - bjm * bjm * dprev_inv;
             if (!(dj > 1e-20)) dj = 1e-20;
             const double zj = ndp_readlane_f64(yl, j) + bjm * zprev * dprev_inv;
-            dprev_inv = 1.0 / dj;
+            dprev_inv = ndp_rcp(dj);
             zprev = zj;
             if (lane == j) { dinv = dprev_inv; zl = zj; }
           }
@@ -1659,14 +1666,17 @@ extern "C" int tgp_ndp_partition(const int32_t* indptr, const int64_t* col, cons
   const int ncap = static_cast<int>(cap), ec = static_cast<int>(ecap);
   if (cap <= 64) {
     static const int generic = getenv("TGP_NDP_GENERIC_KERNEL") ? 1 : 0;  // (A/B switch: the LDS-vector kernel)
-    static const int no_warm = getenv("TGP_NDP_LANCZOS") && atoi(getenv("TGP_NDP_LANCZOS")) == 0;  // (A/B: LOBPCG alone)
+    // Lanczos steps of the warm start: at most the graph's size and 48 (measured on 2048 graphs of 20-60 nodes: 32 steps
+    // leave up to 34 LOBPCG steps to the slowest graph, 48 none, 64 cost 19 us more; profiles/r06_ndp_small.txt).
+    // TGP_NDP_LANCZOS=0: LOBPCG alone -- the A/B switch
+    static const int warm_steps = getenv("TGP_NDP_LANCZOS") ? atoi(getenv("TGP_NDP_LANCZOS")) : 48;
     if (generic)
       hipLaunchKernelGGL(ndp_partition_kernel<64>, dim3(static_cast<unsigned>(B)), dim3(64), lds, stream, indptr, col, w,
                          graph_ptr, static_cast<unsigned long long>(seed), max_iter, tol, ncap, ec, keep, info, d_status);
     else
       hipLaunchKernelGGL(ndp_partition_wave_kernel, dim3(static_cast<unsigned>(B)), dim3(64), lds, stream, indptr, col,
                          w, graph_ptr, static_cast<unsigned long long>(seed), max_iter, tol, ncap, ec, keep, info,
-                         d_status, no_warm ? 0 : 1);
+                         d_status, warm_steps < 0 ? 0 : (warm_steps > 64 ? 64 : warm_steps));
   } else {
     // graphs of 513 .. 2048 nodes: 512 threads per graph (64 graphs of 600 .. 2000 nodes 10.7 -> 7.1 ms; 1024 threads
     // were measured slower than 256: profiles/r03_c3_small_kernel_experiments.md).  TGP_NDP_THREADS=256: A/B switch
