@@ -5,9 +5,25 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "torch-geometric-pool_amd"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-from test_gpu_sparse_pool_small import _er_batch  # noqa: E402
 from tgp.select import NDPSelect  # noqa: E402
+
+
+def _er_batch(num_graphs, lo, hi, f, seed, dev):
+    """The batch of tests/test_gpu_sparse_pool_small.py: Erdos-Renyi graphs of lo..hi nodes, ~4 neighbours per node."""
+    g = torch.Generator().manual_seed(seed)
+    xs, eis, bs, off = [], [], [], 0
+    for gi in range(num_graphs):
+        n = int(torch.randint(lo, hi + 1, (1,), generator=g))
+        a = torch.triu(torch.rand(n, n, generator=g) < 4.0 / n, 1)
+        a = a | a.t()
+        eis.append(a.nonzero().t() + off)
+        xs.append(torch.randn(n, f, generator=g))
+        bs.append(torch.full((n,), gi))
+        off += n
+    x, ei, batch = torch.cat(xs), torch.cat(eis, 1), torch.cat(bs)
+    ew = torch.rand(ei.size(1), generator=g) + 0.1
+    return x.to(dev), ei.to(dev), ew.to(dev), batch.to(dev)
+
 
 dev = torch.device("cuda:0")
 gsel = [int(a) for a in sys.argv[1:]] or [166]
