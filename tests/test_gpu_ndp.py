@@ -370,3 +370,37 @@ def test_mask_index_refuses_stream_capture(dev, monkeypatch):
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
     with pytest.raises(RuntimeError, match="not capturable"):
         K.mask_index(mask)
+
+
+def test_ndp_select_reuses_the_preparation_of_a_list_it_has_seen(dev, monkeypatch):
+    """r6: the CSR offsets and symmetrised weights of a clean edge list are remembered per tensor object + version
+    (select/ndp_select.py:198-202 is a pure function of the list): the second call launches neither the offsets kernel
+    nor the symmetry check, gives the same selection, and an in-place edit of the list or its weights is noticed."""
+    from tgp import kernels as K
+    from tgp.select import NDPSelect
+    x, ei, ew, batch, sizes = _small_batch(40, 8, 50, 4, 21, dev)
+    ew = torch.maximum(ew, torch.full_like(ew, 0.3))
+    n = x.size(0)
+    sel = NDPSelect()
+    calls = {"sym": 0}
+    real = K.ndp_symmetric_max
+
+    def counting(*a, **k):
+        calls["sym"] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(K, "ndp_symmetric_max", counting)
+    torch.manual_seed(1)
+    a = sel(ei, ew, batch=batch, num_nodes=n)
+    torch.manual_seed(1)
+    b = sel(ei, ew, batch=batch, num_nodes=n)
+    assert calls["sym"] == 1 and torch.equal(a.node_index, b.node_index)
+    ew.mul_(1.0)                      # same values, new version: the memo must not be trusted
+    torch.manual_seed(1)
+    c = sel(ei, ew, batch=batch, num_nodes=n)
+    assert calls["sym"] == 2 and torch.equal(a.node_index, c.node_index)
+    torch.manual_seed(1)
+    d = sel(ei.clone(), ew, batch=batch, num_nodes=n)   # another object: prepared anew
+    assert calls["sym"] == 3 and torch.equal(a.node_index, d.node_index)
+    torch.manual_seed(1)
+    e = sel(ei, None, batch=batch, num_nodes=n)          # the same list without weights is another problem
+    assert calls["sym"] == 4 and e.num_supernodes > 0

@@ -792,6 +792,40 @@ def _ndp_side_stream(dev):
     return st
 
 
+_NDP_PREP: dict = {}  # id(edge_index) -> (weakref, version, weakref(edge_weight) | None, its version, n, indptr, w_sym)
+
+
+def _ndp_prep_memo(edge_index: Tensor, edge_weight: Optional[Tensor], n: int):
+    """(indptr, symmetrised weights) of an edge list NDPSelect has already recognised as row-sorted, duplicate-free,
+    loop-free and pattern-symmetric -- per tensor OBJECT and version (an in-place edit bumps the version), like the other
+    per-list memos of the package; the outputs are never written to by their consumers."""
+    hit = _NDP_PREP.get(id(edge_index))
+    if hit is None or hit[0]() is not edge_index or hit[1] != edge_index._version or hit[4] != n:
+        return None
+    if edge_weight is None:
+        if hit[2] is not None:
+            return None
+    elif hit[2] is None or hit[2]() is not edge_weight or hit[3] != edge_weight._version:
+        return None
+    return hit[5], hit[6]
+
+
+def _ndp_prep_remember(edge_index: Tensor, edge_weight: Optional[Tensor], n: int, indptr: Tensor, w_sym: Tensor) -> None:
+    import weakref
+    if edge_index.size(1) > (1 << 22):
+        return  # (the memo would pin > 16 MB per list; at that size the two launches it saves are noise)
+    for dead in [k for k, v in _NDP_PREP.items() if v[0]() is None]:
+        del _NDP_PREP[dead]  # a list that is gone must not keep its offsets and weights alive
+    key = id(edge_index)
+    if key in _NDP_PREP:
+        del _NDP_PREP[key]
+    elif len(_NDP_PREP) >= 8:
+        del _NDP_PREP[next(iter(_NDP_PREP))]  # the oldest entry
+    _NDP_PREP[key] = (weakref.ref(edge_index), edge_index._version,
+                      None if edge_weight is None else weakref.ref(edge_weight),
+                      0 if edge_weight is None else edge_weight._version, n, indptr, w_sym)
+
+
 class NDPSelect(Select):
     r"""Node Decimation Pooling selection: keep the positive side of the sign partition of the largest
     eigenvector of the symmetric normalised Laplacian of every graph; random +-1 partition when the cut
@@ -923,13 +957,19 @@ class NDPSelect(Select):
         # (to_undirected(reduce="max"), ndp_select.py:198-202): a row-sorted, symmetric, coalesced list
         # A list that already is that (the usual PyG dataset of undirected graphs) is recognised by one kernel and used
         # as it is (r3: the two coalesce calls were two dozen launches and two host read-backs of the NDP forward).
-        indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         ei2 = None
-        if edge_index.size(1) > 0:
-            K.rowptr_from_sorted(edge_index[0], n, indptr)
-            w_sym, flag = K.ndp_symmetric_max(edge_index, w0, n, indptr)
-            if int(flag.item()) == 0:
-                ei2, w2 = edge_index, w_sym
+        prep = _ndp_prep_memo(edge_index, edge_weight, n)
+        if prep is not None:  # this very list (object + version) was recognised as clean before: its CSR offsets and
+            indptr, w_sym = prep  # symmetrised weights are reused -- two launches and a host read less per call (r6)
+            ei2, w2 = edge_index, w_sym
+        else:
+            indptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            if edge_index.size(1) > 0:
+                K.rowptr_from_sorted(edge_index[0], n, indptr)
+                w_sym, flag = K.ndp_symmetric_max(edge_index, w0, n, indptr)
+                if int(flag.item()) == 0:
+                    ei2, w2 = edge_index, w_sym
+                    _ndp_prep_remember(edge_index, edge_weight, n, indptr, w_sym)
         if ei2 is None:
             ident = torch.arange(n, device=dev)
             if w0 is None:
