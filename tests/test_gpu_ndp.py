@@ -404,3 +404,69 @@ def test_ndp_select_reuses_the_preparation_of_a_list_it_has_seen(dev, monkeypatc
     torch.manual_seed(1)
     e = sel(ei, None, batch=batch, num_nodes=n)          # the same list without weights is another problem
     assert calls["sym"] == 4 and e.num_supernodes > 0
+
+
+def test_ndp_partition_contract_on_structured_graphs(dev):
+    """The one-wave kernel's Lanczos warm start + LOBPCG finisher (r6) on graphs whose spectra are anything but generic:
+    paths and cycles (tiny gaps), stars and complete bipartite graphs (lambda_max = 2 simple, everything else at 1),
+    complete graphs (an (n-1)-fold top eigenvalue), grids, two equal components (a double top eigenvalue), a graph
+    with isolated nodes, weights spread over six orders of magnitude.  Contract of select/ndp_select.py:187-256 per graph:
+    a spectral answer (info >= 0) cuts >= 0.5 and, where the top eigenvector is well separated and has no tiny entry,
+    equals its sign pattern up to the global sign; a fallback (info == -1) keeps node 0 and drops node 1."""
+    from tgp import kernels as K
+    graphs = []
+
+    def add(n, edges, w=None):
+        e = torch.tensor(edges, dtype=torch.long).t()
+        graphs.append((n, e, torch.ones(e.size(1), dtype=torch.float64) if w is None else w))
+    for n in (2, 3, 17, 40, 64):
+        add(n, [(i, i + 1) for i in range(n - 1)])                                   # path
+        add(n, [(i, (i + 1) % n) for i in range(n)] if n > 2 else [(0, 1)])          # cycle
+        add(n, [(0, i) for i in range(1, n)])                                        # star
+        add(n, [(i, j) for i in range(n) for j in range(i + 1, n)])                  # complete
+    add(30, [(i, j) for i in range(12) for j in range(12, 30)])                      # complete bipartite
+    add(48, [(r * 8 + c, r * 8 + c + 1) for r in range(6) for c in range(7)] +
+            [(r * 8 + c, (r + 1) * 8 + c) for r in range(5) for c in range(8)])       # 6 x 8 grid
+    tri = [(0, 1), (1, 2), (0, 2), (2, 3)]
+    add(8, tri + [(a + 4, b + 4) for a, b in tri])                                   # two equal components
+    add(20, [(i, i + 1) for i in range(9)] + [(12, 13), (13, 14), (12, 14)])         # isolated nodes 10, 11, 15..19
+    g = torch.Generator().manual_seed(4)
+    er = [(i, j) for i in range(50) for j in range(i + 1, 50) if float(torch.rand(1, generator=g)) < 0.12]
+    add(50, er, torch.pow(10.0, 6 * torch.rand(len(er), generator=g, dtype=torch.float64) - 3))
+    rows, cols, vals, ptr, off = [], [], [], [0], 0
+    for n, e, w in graphs:
+        rows += [e[0] + off, e[1] + off]
+        cols += [e[1] + off, e[0] + off]
+        vals += [w, w]
+        off += n
+        ptr.append(off)
+    row, col, val = torch.cat(rows), torch.cat(cols), torch.cat(vals)
+    order = torch.argsort(row * off + col)
+    row, col, val = row[order], col[order], val[order]
+    indptr = torch.zeros(off + 1, dtype=torch.int32)
+    indptr[1:] = torch.cumsum(torch.bincount(row, minlength=off), 0).int()
+    keep, info, status = K.ndp_partition(indptr.to(dev), col.to(dev), val.float().to(dev), off,
+                                         torch.tensor(ptr, device=dev), 64, seed=7)
+    assert int(status.item()) == 0
+    keep, info = keep.cpu(), info.cpu()
+    firm = 0
+    for gi, (n, e, w) in enumerate(graphs):
+        a = torch.zeros(n, n, dtype=torch.float64)
+        a[e[0], e[1]] = w.float().double()
+        a = a + a.t()
+        deg = a.sum(1)
+        dis = torch.where(deg > 0, deg.clamp(min=1e-300).rsqrt(), torch.zeros_like(deg))
+        vals_, vecs = torch.linalg.eigh(torch.eye(n, dtype=torch.float64) - dis[:, None] * a * dis[None, :])
+        L = torch.diag(deg) - a
+        kp = keep[ptr[gi]:ptr[gi + 1]].bool()
+        z = torch.where(kp, 1.0, -1.0).double()
+        cut = float(z @ (L @ z)) / (2 * float(deg.sum()))
+        if int(info[gi]) == -1:
+            assert bool(kp[0]) and not bool(kp[1]), gi
+            continue
+        assert int(info[gi]) >= 0 and cut >= 0.5 - 1e-9, (gi, n, cut)
+        v = vecs[:, -1]
+        if float(vals_[-1] - vals_[-2]) > 1e-3 and float(v.abs().min()) > 1e-5:
+            firm += 1
+            assert torch.equal(kp, v >= 0) or torch.equal(kp, v < 0), (gi, n)
+    assert firm >= 8
