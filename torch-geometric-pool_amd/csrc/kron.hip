@@ -813,10 +813,6 @@ __global__ __launch_bounds__(256) void kron_big_finish_kernel(KronArgs a) {
   if (lane == 0 && mine) atomicAdd(&a.counts[q.g], mine);
 }
 
-__global__ void kron_finish_count_kernel(const int* __restrict__ status, int64_t* __restrict__ d_count) {
-  if (*status != 0) *d_count = -1;  // declined: see KronStatus
-}
-
 // edge list of the surviving entries in (graph, row, col) order = row-major order of the whole pooled batch
 __global__ __launch_bounds__(KRON_THREADS) void kron_fill_kernel(const int64_t* __restrict__ graph_ptr,
                                                                  const uint32_t* __restrict__ rank,
@@ -1108,9 +1104,9 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
     if (!joined || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) (void)hipStreamSynchronize(side->stream);
     side_lock.unlock();
   }
+  // (the status word rides along: a declined call -- see KronStatus -- leaves -1 instead of the count; r6: one launch less)
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, s.counts, static_cast<int>(B), s.out_off,
-                     d_count, static_cast<const int*>(nullptr));
-  hipLaunchKernelGGL(kron_finish_count_kernel, dim3(1), dim3(1), 0, stream, s.status, d_count);
+                     d_count, static_cast<const int*>(s.status), -1ll);
   return check_launch("tgp_kron_batched_count");
 }
 

@@ -58,11 +58,13 @@ __device__ __forceinline__ void block_compact_ranks(const bool (&flag)[ITEMS], u
 }
 
 // counts[nb] -> exclusive offsets[nb], *total (int64).  One 1024-thread workgroup.  `refuse` (optional): a device
-// flag; when set, *total becomes -2 (the count -> fill protocol's "bad input" code) instead of the sum.
+// flag; when set, *total becomes `refuse_code` (-2: the count -> fill protocol's "bad input" code; KronConnect passes its
+// status word and -1, "declined") instead of the sum.
 static __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t* __restrict__ counts, int nb,
                                                            uint32_t* __restrict__ offsets,
                                                            int64_t* __restrict__ total,
-                                                           const int* __restrict__ refuse) {
+                                                           const int* __restrict__ refuse,
+                                                           long long refuse_code = -2) {
   __shared__ uint32_t s_w[16];
   __shared__ uint32_t s_carry;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -86,7 +88,7 @@ static __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t
     if (tid == 0) s_carry += tot;
     __syncthreads();
   }
-  if (tid == 0) *total = (refuse && *refuse) ? -2 : static_cast<int64_t>(s_carry);
+  if (tid == 0) *total = (refuse && *refuse) ? static_cast<int64_t>(refuse_code) : static_cast<int64_t>(s_carry);
 }
 
 constexpr int SCAN_ITEMS = 16;
