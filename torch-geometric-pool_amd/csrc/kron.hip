@@ -1019,8 +1019,10 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
   kron_layout(ws, N, B, max_graph_nodes, cap_dense, cap_big, &s);
   if (num_big < 0 || num_big > B) num_big = B;
   (void)hipMemsetAsync(s.flags, 0, reinterpret_cast<char*>(s.status + 1) - reinterpret_cast<char*>(s.flags), stream);
-  (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
-  if (B == 0 || N == 0) return check_launch("tgp_kron_batched_count");
+  if (B == 0 || N == 0) {  // (otherwise the count scan at the end of this call writes *d_count)
+    (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
+    return check_launch("tgp_kron_batched_count");
+  }
   if (num_kept > 0)
     hipLaunchKernelGGL(kron_flags_kernel, dim3(cdiv(num_kept, 256)), dim3(256), 0, stream, node_index, num_kept, N,
                        s.flags, s.status);
