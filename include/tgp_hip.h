@@ -1006,12 +1006,14 @@ int tgp_copy_arrays(const void* const* src, void* const* dst, const int64_t* byt
  * (tgp_mask_index_scratch_words(n) 32-bit words, word 0 an arrival ticket that is zero between calls: clear the buffer
  * once), then {epoch << 34 | k} in the PINNED word `result` (k = -3 in 34-bit two's complement when `*declined` (device,
  * optional) is non-zero).  tgp_mask_index_fill, once the host has read k: pos_out[k] the positions in increasing order,
- * rank_out[k] = 0..k-1 and ones_out[k] = 1 (both optional).  n < 2^31. */
+ * rank_out[k] = 0..k-1 and ones_out[k] = 1 (both optional); perm_out[k] = 0..k-1 (int32) and pack_out[k] = {uint32
+ * position, fp32 1.0} (both optional): the one-to-one inverted index tgp_one_to_one_index_build would make of the three
+ * arrays, for the Reduce of the same selection.  n < 2^31. */
 int64_t tgp_mask_index_scratch_words(int64_t n);
 int tgp_mask_index_count(const uint8_t* mask, int64_t n, const int32_t* declined, uint32_t* scratch, uint64_t* result,
                          uint32_t epoch, void* stream);
 int tgp_mask_index_fill(const uint8_t* mask, int64_t n, const uint32_t* scratch, int64_t k, int64_t* pos_out,
-                        int64_t* rank_out, float* ones_out, void* stream);
+                        int64_t* rank_out, float* ones_out, int32_t* perm_out, uint64_t* pack_out, void* stream);
 /* r6: the host wait of tgp_sparse_pool_small_f32 + the launch that makes its edge_index contiguous, in one call (the
  * reference's own host reads: `.item()` in utils/ops.py:370-380 / the nonzero of connect/base_conn.py:79-89).  Spins on
  * the PINNED result word until call `epoch` has stored it; unless the kernel refused the input (bit 31 of the word) the

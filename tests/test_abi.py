@@ -191,8 +191,8 @@ def test_round6_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.tgp_mask_index_count(p, 16, None, p, p, 0, None) == -1
     assert lib.tgp_mask_index_count(p, 16, None, None, p, 1, None) == -1
     assert lib.tgp_mask_index_count(p, 1 << 31, None, p, p, 1, None) == -4
-    assert lib.tgp_mask_index_fill(p, 16, p, 17, p, None, None, None) == -1
-    assert lib.tgp_mask_index_fill(p, 16, p, 0, None, None, None, None) == 0
+    assert lib.tgp_mask_index_fill(p, 16, p, 17, p, None, None, None, None, None) == -1
+    assert lib.tgp_mask_index_fill(p, 16, p, 0, None, None, None, None, None, None) == 0
     assert lib.tgp_diffpool_stats_tail_f32(p + 4, 3, 1.0, 1.0, p, None) == -1
     assert lib.tgp_spmm_csr_stats_f32(p, p, None, 4, 4, p, 16, p, None, None, None) == -1
     n_part = ctypes.c_int(0)

@@ -354,6 +354,14 @@ def test_mask_index_matches_nonzero(dev, n, density):
             assert torch.equal(ones, torch.ones(want.numel(), device=dev))
         else:
             assert ones is None
+    # the one-to-one inverted index of the assignment (positions -> supernodes 0..k-1, weight 1) from the same launch
+    index, ones, assign = K.mask_index(mask, None, want_rank=True, want_ones=True, want_assign=True)
+    if want.numel():
+        ref = K.one_to_one_index(index[0], index[1], ones)
+        assert torch.equal(assign.perm, ref.perm) and torch.equal(assign.pack, ref.pack)
+        assert assign.pack_key == (index.data_ptr(), ones.data_ptr()) and assign.nnz == want.numel()
+    else:
+        assert assign is None
     # the producer's flag rides with the count: non-zero -> no result, and the next call is unaffected
     flag = torch.ones(1, dtype=torch.int32, device=dev)
     assert K.mask_index(mask, flag) is None

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void mask_index_count_kernel(const uint8_t* __
 __global__ __launch_bounds__(256) void mask_index_fill_kernel(const uint8_t* __restrict__ mask, int64_t n,
                                                               const uint32_t* __restrict__ tile_counts, int64_t k,
                                                               int64_t* __restrict__ pos_out, int64_t* __restrict__ rank_out,
-                                                              float* __restrict__ ones_out) {
+                                                              float* __restrict__ ones_out, int32_t* __restrict__ perm_out,
+                                                              uint2* __restrict__ pack_out) {
   __shared__ uint32_t s_w[4];
   uint32_t part = 0;
   for (int t = threadIdx.x; t < static_cast<int>(blockIdx.x); t += 256) part += tile_counts[t];
@@ -173,6 +174,10 @@ __global__ __launch_bounds__(256) void mask_index_fill_kernel(const uint8_t* __r
         pos_out[at] = base + j;
         if (rank_out) rank_out[at] = at;
         if (ones_out) ones_out[at] = 1.0f;
+        // the one-to-one inverted index of the assignment (supernode `at` owns node base + j with weight 1): what
+        // tgp_one_to_one_index_build would make of (pos_out, rank_out, ones_out) in a launch of its own
+        if (perm_out) perm_out[at] = static_cast<int32_t>(at);
+        if (pack_out) pack_out[at] = make_uint2(static_cast<uint32_t>(base + j), 0x3F800000u);
       }
       ++at;
     }
@@ -196,14 +201,15 @@ extern "C" int tgp_mask_index_count(const uint8_t* mask, int64_t n, const int32_
 }
 
 extern "C" int tgp_mask_index_fill(const uint8_t* mask, int64_t n, const uint32_t* scratch, int64_t k, int64_t* pos_out,
-                                   int64_t* rank_out, float* ones_out, void* stream_) {
+                                   int64_t* rank_out, float* ones_out, int32_t* perm_out, uint64_t* pack_out,
+                                   void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(n >= 0 && k >= 0 && k <= n && scratch && (n == 0 || mask) && (k == 0 || pos_out), TGP_ERR_INVALID,
               "tgp_mask_index_fill: bad argument");
   if (k == 0 || n == 0) return TGP_OK;
   const int ntiles = static_cast<int>((n + MI_TILE - 1) / MI_TILE);
   hipLaunchKernelGGL(mask_index_fill_kernel, dim3(ntiles), dim3(256), 0, stream, mask, n, scratch + 2, k, pos_out, rank_out,
-                     ones_out);
+                     ones_out, perm_out, reinterpret_cast<uint2*>(pack_out));
   return check_launch("tgp_mask_index_fill");
 }
 

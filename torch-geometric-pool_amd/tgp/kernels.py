@@ -2743,13 +2743,16 @@ def ndp_partition(indptr: Tensor, col: Tensor, weight: Optional[Tensor], num_nod
 _MASK_INDEX_SCRATCH: dict = {}
 
 
-def mask_index(mask: Tensor, declined: Optional[Tensor] = None, want_rank: bool = False, want_ones: bool = False):
+def mask_index(mask: Tensor, declined: Optional[Tensor] = None, want_rank: bool = False, want_ones: bool = False,
+               want_assign: bool = False):
     """The sorted positions of the non-zero bytes of ``mask`` [n] uint8 -- `mask.nonzero().view(-1)` in two launches with
     one pinned-word wait between them (torch's own: seven launches and a synchronising copy) -- as row 0 of an int64
     ``[2, k]`` array whose row 1 is ``arange(k)`` (``want_rank``; the indices of NDPSelect's S), plus ``ones [k]`` fp32
     (``want_ones``; its values).  ``declined`` (int32 [1] on the device): when non-zero the call returns None (the flag
     of the kernel that made the mask; read with the count, no copy of its own).  Returns (index [2,k] or [1,k], ones or
-    None).  reference: select/ndp_select.py:257-262."""
+    None) -- and with ``want_assign`` (needs both) a third item: the one-to-one :class:`AssignIndex` (perm + packed
+    {row, weight}) of the assignment these arrays describe, which :func:`one_to_one_index` would build in a launch of its
+    own.  reference: select/ndp_select.py:257-262."""
     dev = N.require_device(mask, declined)
     if mask.dtype != torch.uint8 or not mask.is_contiguous():
         raise ValueError("mask_index: a contiguous uint8 mask is required")
@@ -2774,11 +2777,20 @@ def mask_index(mask: Tensor, declined: Optional[Tensor] = None, want_rank: bool 
     rows = 2 if want_rank else 1
     index = torch.empty((rows, k), dtype=torch.long, device=dev)
     ones = torch.empty(k, dtype=torch.float32, device=dev) if want_ones else None
+    assign = want_assign and want_rank and want_ones and 0 < k and n < (1 << 31)
+    perm = torch.empty(k, dtype=torch.int32, device=dev) if assign else None
+    pack = torch.empty(k, dtype=torch.int64, device=dev) if assign else None
     if k:
         N.check(L.tgp_mask_index_fill(N.ptr(mask), n, N.ptr(scratch), k, N.ptr(index),
-                                      index.data_ptr() + 8 * k if want_rank else None, N.ptr(ones), st),
-                "tgp_mask_index_fill")
-    return index, ones
+                                      index.data_ptr() + 8 * k if want_rank else None, N.ptr(ones), N.ptr(perm),
+                                      N.ptr(pack), st), "tgp_mask_index_fill")
+    if not want_assign:
+        return index, ones
+    a_index = None
+    if assign:
+        a_index = AssignIndex(None, perm, k, k)
+        a_index.pack, a_index.pack_key = pack, (index.data_ptr(), ones.data_ptr())
+    return index, ones, a_index
 
 
 def ndp_partition_large(indptr: Tensor, col: Tensor, weight: Optional[Tensor], p0: int, p1: int, seed: int,

@@ -1019,10 +1019,10 @@ class NDPSelect(Select):
         # the kept nodes as S's [2, k] indices and unit values: two launches and one pinned-word wait that also carries
         # the kernels' status (r6; before: bool copy + torch's nonzero + status.item() + arange + stack + ones = 13 launches
         # and two synchronising copies)
-        got = K.mask_index(keep8.contiguous(), status, want_rank=True, want_ones=True)
+        got = K.mask_index(keep8.contiguous(), status, want_rank=True, want_ones=True, want_assign=True)
         if got is None:
             return None
-        s_index, s_ones = got
+        s_index, s_ones, assign = got
         k = s_index.size(1)
         s = torch.sparse_coo_tensor(s_index, s_ones, size=(n, k), is_coalesced=True)
         so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
@@ -1038,7 +1038,11 @@ class NDPSelect(Select):
         so.__dict__["_L_factory"] = laplacian_on_host
         so._adj_device_csr = (indptr, ei2[1], w2)  # KronConnect's kernel forms L = D - A from these directly
         so._partition_info = part_info
-        so._set_one_to_one_index()
+        if assign is not None and so.node_index.data_ptr() == s_index.data_ptr():
+            so._assign_index = assign  # (written by the same launch as S's arrays: no index-build launch)
+            so.__dict__["_values_of"] = (so.s, s_ones)
+        else:
+            so._set_one_to_one_index()
         so._node_batch = batch
         return so
 
