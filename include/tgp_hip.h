@@ -934,12 +934,16 @@ int tgp_kron_batched_max_graph_nodes(void);
  * than 128 nodes) keep the workspace at what the batch needs; -1 = the worst case from max_graph_nodes alone
  * (num_nodes * max_graph_nodes).  The real totals are checked on the device (too small: *d_count = -1).
  * num_big: how many graphs have more than 128 (and at most tgp_kron_batched_max_graph_nodes()) nodes, an upper
- * bound, -1 = unknown (num_graphs): it sizes the launches of the multi-workgroup elimination those graphs take. */
+ * bound, -1 = unknown (num_graphs): it sizes the launches of the multi-workgroup elimination those graphs take.
+ * node_rank (r6, optional, [num_nodes + 1] on the device): node_rank[i] = kept nodes in front of node i (so
+ * node_rank[num_nodes] = num_kept), from a caller that compacted the kept nodes itself (tgp_mask_index_fill) and thereby
+ * knows node_index to be ascending and in range: the call then skips its own flag scatter and scan (three launches). */
 int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col, const float* val32, const double* val64,
                            const int32_t* perm, int from_adjacency, int64_t num_nodes, int64_t nnz,
                            const int64_t* graph_ptr, int64_t num_graphs, int64_t max_graph_nodes, int64_t cap_dense,
                            int64_t cap_big, int64_t num_big, const int64_t* node_index, int64_t num_kept,
-                           double threshold, void* ws, size_t ws_bytes, int64_t* d_count, void* stream);
+                           double threshold, const uint32_t* node_rank, void* ws, size_t ws_bytes, int64_t* d_count,
+                           void* stream);
 int tgp_kron_batched_fill(const void* ws, int64_t num_nodes, int64_t num_graphs, int64_t max_graph_nodes,
                           int64_t cap_dense, int64_t cap_big, int64_t num_big, const int64_t* graph_ptr,
                           int64_t num_out, int64_t* out_row, int64_t* out_col, float* out_weight, void* stream);
@@ -1008,12 +1012,14 @@ int tgp_copy_arrays(const void* const* src, void* const* dst, const int64_t* byt
  * optional) is non-zero).  tgp_mask_index_fill, once the host has read k: pos_out[k] the positions in increasing order,
  * rank_out[k] = 0..k-1 and ones_out[k] = 1 (both optional); perm_out[k] = 0..k-1 (int32) and pack_out[k] = {uint32
  * position, fp32 1.0} (both optional): the one-to-one inverted index tgp_one_to_one_index_build would make of the three
- * arrays, for the Reduce of the same selection.  n < 2^31. */
+ * arrays, for the Reduce of the same selection; node_rank_out[n + 1] (optional): non-zero bytes in front of every
+ * position, total at [n] (what tgp_kron_batched_count takes as node_rank).  n < 2^31. */
 int64_t tgp_mask_index_scratch_words(int64_t n);
 int tgp_mask_index_count(const uint8_t* mask, int64_t n, const int32_t* declined, uint32_t* scratch, uint64_t* result,
                          uint32_t epoch, void* stream);
 int tgp_mask_index_fill(const uint8_t* mask, int64_t n, const uint32_t* scratch, int64_t k, int64_t* pos_out,
-                        int64_t* rank_out, float* ones_out, int32_t* perm_out, uint64_t* pack_out, void* stream);
+                        int64_t* rank_out, float* ones_out, int32_t* perm_out, uint64_t* pack_out,
+                        uint32_t* node_rank_out, void* stream);
 /* r6: the host wait of tgp_sparse_pool_small_f32 + the launch that makes its edge_index contiguous, in one call (the
  * reference's own host reads: `.item()` in utils/ops.py:370-380 / the nonzero of connect/base_conn.py:79-89).  Spins on
  * the PINNED result word until call `epoch` has stored it; unless the kernel refused the input (bit 31 of the word) the

@@ -104,8 +104,8 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.tgp_dense_pool_f32(p, p, p, 1, 1 << 31, 4, 4, 0, 1e-8, None, p, None, p, p, 1 << 20, None) == -4  # TGP_ERR_RANGE
     assert lib.tgp_block_diag_count(p, 70000, 70000, None, 0, 1e-8, p, 1 << 20, p, None) == -4
     # Kron: fp32 and fp64 values at once is a caller error; sizes beyond the int32 internals are refused
-    assert lib.tgp_kron_batched_count(p, p, p, p, None, 0, 4, 4, p, 1, 4, -1, -1, -1, p, 2, 1e-2, p, 1 << 20, p, None) == -1
-    assert lib.tgp_kron_batched_count(p, p, None, None, None, 0, 1 << 31, 4, p, 1, 4, -1, -1, -1, p, 2, 1e-2, p, 1 << 20, p, None) == -4
+    assert lib.tgp_kron_batched_count(p, p, p, p, None, 0, 4, 4, p, 1, 4, -1, -1, -1, p, 2, 1e-2, None, p, 1 << 20, p, None) == -1
+    assert lib.tgp_kron_batched_count(p, p, None, None, None, 0, 1 << 31, 4, p, 1, 4, -1, -1, -1, p, 2, 1e-2, None, p, 1 << 20, p, None) == -4
 
 
 def test_ctypes_signatures_match_the_header_parameter_by_parameter():
@@ -191,8 +191,8 @@ def test_round6_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.tgp_mask_index_count(p, 16, None, p, p, 0, None) == -1
     assert lib.tgp_mask_index_count(p, 16, None, None, p, 1, None) == -1
     assert lib.tgp_mask_index_count(p, 1 << 31, None, p, p, 1, None) == -4
-    assert lib.tgp_mask_index_fill(p, 16, p, 17, p, None, None, None, None, None) == -1
-    assert lib.tgp_mask_index_fill(p, 16, p, 0, None, None, None, None, None, None) == 0
+    assert lib.tgp_mask_index_fill(p, 16, p, 17, p, None, None, None, None, None, None) == -1
+    assert lib.tgp_mask_index_fill(p, 16, p, 0, None, None, None, None, None, None, None) == 0
     assert lib.tgp_diffpool_stats_tail_f32(p + 4, 3, 1.0, 1.0, p, None) == -1
     assert lib.tgp_spmm_csr_stats_f32(p, p, None, 4, 4, p, 16, p, None, None, None) == -1
     n_part = ctypes.c_int(0)

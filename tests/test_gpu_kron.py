@@ -479,3 +479,31 @@ def test_kron_singular_block_in_a_mid_size_graph_is_damped(dev):
                                          batch=batch.to(dev))
     assert torch.equal(out[0].cpu(), torch.stack([torch.cat(rows), torch.cat(cols)]))
     torch.testing.assert_close(out[1].cpu(), torch.cat(vals), rtol=1e-5, atol=1e-7)
+
+
+def test_kron_batched_with_the_selectors_node_rank_equals_its_own_scan(dev):
+    """r6: NDPSelect hands KronConnect the prefix counts of its kept nodes (tgp_mask_index_fill's node_rank_out); the
+    Kron kernels then skip their flag scatter and scan.  Same edges and weights, bit for bit, as the call that builds
+    the table itself -- on the whole pooler and on the operator called directly (connect/kron_conn.py:117-165)."""
+    from tgp import kernels as K
+    from tgp.poolers import get_pooler
+    g = torch.Generator().manual_seed(3)
+    sizes = torch.randint(5, 61, (120,), generator=g).tolist() + [150, 300]
+    ei, ew, batch, _ = make_batch(sizes, seed=5, density=0.2, connected=True)
+    ei, ew, batch = ei.to(dev), ew.to(dev), batch.to(dev)
+    n = batch.numel()
+    x = torch.randn(n, 8, device=dev)
+    pooler = get_pooler("ndp").to(dev).eval()
+    torch.manual_seed(9)
+    with torch.no_grad():
+        out = pooler(x=x, adj=ei, edge_weight=ew, batch=batch)
+    so = out.so
+    held = so.__dict__.get("_node_rank")
+    assert held is not None and held[0].numel() == n + 1 and int(held[0][-1]) == so.num_supernodes
+    keep = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    keep[so.node_index] = 1
+    assert torch.equal(held[0], (torch.cumsum(keep, 0) - keep).int())
+    so.__dict__.pop("_node_rank")          # the operator now scatters and scans itself
+    with torch.no_grad():
+        ei2, ew2 = pooler.connector(ei, so, edge_weight=ew, batch=batch)
+    assert torch.equal(out.edge_index, ei2) and torch.equal(out.edge_weight, ew2)

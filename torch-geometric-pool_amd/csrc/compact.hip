@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void mask_index_fill_kernel(const uint8_t* __r
                                                               const uint32_t* __restrict__ tile_counts, int64_t k,
                                                               int64_t* __restrict__ pos_out, int64_t* __restrict__ rank_out,
                                                               float* __restrict__ ones_out, int32_t* __restrict__ perm_out,
-                                                              uint2* __restrict__ pack_out) {
+                                                              uint2* __restrict__ pack_out,
+                                                              uint32_t* __restrict__ node_rank_out) {
   __shared__ uint32_t s_w[4];
   uint32_t part = 0;
   for (int t = threadIdx.x; t < static_cast<int>(blockIdx.x); t += 256) part += tile_counts[t];
@@ -167,6 +168,12 @@ __global__ __launch_bounds__(256) void mask_index_fill_kernel(const uint8_t* __r
   const int64_t base = static_cast<int64_t>(blockIdx.x) * MI_TILE + static_cast<int64_t>(threadIdx.x) * 16;
   const uint32_t bits = base < n ? mi_flags16(mask, n, base) : 0u;
   int64_t at = static_cast<int64_t>(before) + block_excl_scan_256(__popc(bits), s_w, nullptr);
+  if (node_rank_out && base < n) {  // set positions in front of every position of this thread's 16, total at [n]
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (base + j < n) node_rank_out[base + j] = static_cast<uint32_t>(at) + __popc(bits & ((1u << j) - 1u));
+    if (base + 16 >= n) node_rank_out[n] = static_cast<uint32_t>(at) + __popc(bits);
+  }
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     if ((bits >> j) & 1u) {
@@ -202,14 +209,14 @@ extern "C" int tgp_mask_index_count(const uint8_t* mask, int64_t n, const int32_
 
 extern "C" int tgp_mask_index_fill(const uint8_t* mask, int64_t n, const uint32_t* scratch, int64_t k, int64_t* pos_out,
                                    int64_t* rank_out, float* ones_out, int32_t* perm_out, uint64_t* pack_out,
-                                   void* stream_) {
+                                   uint32_t* node_rank_out, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(n >= 0 && k >= 0 && k <= n && scratch && (n == 0 || mask) && (k == 0 || pos_out), TGP_ERR_INVALID,
               "tgp_mask_index_fill: bad argument");
-  if (k == 0 || n == 0) return TGP_OK;
+  if (n == 0 || (k == 0 && !node_rank_out)) return TGP_OK;
   const int ntiles = static_cast<int>((n + MI_TILE - 1) / MI_TILE);
   hipLaunchKernelGGL(mask_index_fill_kernel, dim3(ntiles), dim3(256), 0, stream, mask, n, scratch + 2, k, pos_out, rank_out,
-                     ones_out, perm_out, reinterpret_cast<uint2*>(pack_out));
+                     ones_out, perm_out, reinterpret_cast<uint2*>(pack_out), node_rank_out);
   return check_launch("tgp_mask_index_fill");
 }
 

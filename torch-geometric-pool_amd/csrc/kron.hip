@@ -1004,8 +1004,9 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
                                       const double* val64, const int32_t* perm, int from_adjacency, int64_t N,
                                       int64_t nnz, const int64_t* graph_ptr, int64_t B, int64_t max_graph_nodes,
                                       int64_t cap_dense, int64_t cap_big, int64_t num_big,
-                                      const int64_t* node_index, int64_t num_kept, double threshold, void* ws,
-                                      size_t ws_bytes, int64_t* d_count, void* stream_) {
+                                      const int64_t* node_index, int64_t num_kept, double threshold,
+                                      const uint32_t* node_rank, void* ws, size_t ws_bytes, int64_t* d_count,
+                                      void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(N >= 0 && B >= 0 && nnz >= 0 && num_kept >= 0 && d_count && graph_ptr && indptr && (col || nnz == 0) &&
                   (node_index || num_kept == 0),
@@ -1018,15 +1019,23 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
   KronWs s;
   kron_layout(ws, N, B, max_graph_nodes, cap_dense, cap_big, &s);
   if (num_big < 0 || num_big > B) num_big = B;
-  (void)hipMemsetAsync(s.flags, 0, reinterpret_cast<char*>(s.status + 1) - reinterpret_cast<char*>(s.flags), stream);
+  // r6, node_rank [N + 1] (optional): the exclusive prefix sums of the keep flags, when the caller already has them (a
+  // selector that compacted the kept nodes itself: tgp_mask_index_fill) -- the flags scatter and the two scan launches
+  // fall away, and only the counters behind the flags are cleared
+  uint32_t* const clear_from = node_rank ? s.counts : s.flags;
+  (void)hipMemsetAsync(clear_from, 0, reinterpret_cast<char*>(s.status + 1) - reinterpret_cast<char*>(clear_from), stream);
   if (B == 0 || N == 0) {  // (otherwise the count scan at the end of this call writes *d_count)
     (void)hipMemsetAsync(d_count, 0, sizeof(int64_t), stream);
     return check_launch("tgp_kron_batched_count");
   }
-  if (num_kept > 0)
-    hipLaunchKernelGGL(kron_flags_kernel, dim3(cdiv(num_kept, 256)), dim3(256), 0, stream, node_index, num_kept, N,
-                       s.flags, s.status);
-  device_scan_u32(s.flags, N + 1, s.rank, s.scan_total, s.scan_tiles, stream);  // (one workgroup took 73 us at N = 82 k)
+  if (node_rank) {
+    (void)hipMemcpyAsync(s.rank, node_rank, static_cast<size_t>(N + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+  } else {
+    if (num_kept > 0)
+      hipLaunchKernelGGL(kron_flags_kernel, dim3(cdiv(num_kept, 256)), dim3(256), 0, stream, node_index, num_kept, N,
+                         s.flags, s.status);
+    device_scan_u32(s.flags, N + 1, s.rank, s.scan_total, s.scan_tiles, stream);  // (one workgroup took 73 us at N = 82 k)
+  }
   const int cap = static_cast<int>(max_graph_nodes < KRON_LDS_MAX_N ? max_graph_nodes : KRON_LDS_MAX_N);
   hipLaunchKernelGGL(kron_plan_kernel, dim3(1), dim3(1024), 0, stream, graph_ptr, static_cast<int>(B), s.rank, s.sq_off,
                      s.big_off, s.cap_dense, s.cap_big, (from_adjacency & 2) ? 1 : 0, cap, max_graph_nodes, s.big_desc, s.big_count,

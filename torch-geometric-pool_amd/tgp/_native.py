@@ -228,7 +228,8 @@ SIGNATURES = {
     "tgp_kron_batched_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
     "tgp_kron_batched_max_graph_nodes": (_c_int, []),
     "tgp_kron_batched_count": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_i64, _c_i64, _c_p, _c_i64, _c_i64,
-                                        _c_i64, _c_i64, _c_i64, _c_p, _c_i64, ctypes.c_double, _c_p, _c_sz, _c_p, _c_p]),
+                                        _c_i64, _c_i64, _c_i64, _c_p, _c_i64, ctypes.c_double, _c_p, _c_p, _c_sz, _c_p,
+                                        _c_p]),
     "tgp_kron_batched_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p,
                                        _c_p, _c_p]),
     "tgp_mlp_select_max_fused_k": (_c_int, []),
@@ -261,7 +262,7 @@ SIGNATURES = {
     "tgp_result_wait_pack_cols": (_c_int, [_c_p, ctypes.c_uint32, _c_p, _c_p, _c_p]),
     "tgp_mask_index_scratch_words": (_c_i64, [_c_i64]),
     "tgp_mask_index_count": (_c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, ctypes.c_uint32, _c_p]),
-    "tgp_mask_index_fill": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "tgp_mask_index_fill": (_c_int, [_c_p, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "tgp_bmm_f64": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _c_i64,
                              _c_i64, _c_i64, _c_int, _c_p]),
     "tgp_dense_pool_workspace_bytes_f64": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64]),

@@ -373,8 +373,14 @@ class KronConnect(Connect):
                 index = K.build_assign_index(row, n)
                 indptr, perm = index.row_ptr, index.perm
             col, val, from_adj = edge_index[1], edge_weight, True
+        # NDPSelect compacted the kept nodes itself and left their prefix counts: valid for exactly the node_index it built
+        held = so.__dict__.get("_node_rank")
+        node_rank = None
+        if held is not None and held[0] is not None and (idx_pos.data_ptr(), idx_pos.numel()) == (held[1], held[2]):
+            node_rank = held[0]
         out = K.kron_batched(indptr, col, val, perm, from_adj, n, ptr, min(max_nodes, limit), idx_pos,
-                             self.sparse_threshold, skip_oversize=oversize is not None, graph_sizes_host=sizes_host)
+                             self.sparse_threshold, skip_oversize=oversize is not None, graph_sizes_host=sizes_host,
+                             node_rank=node_rank)
         if out is None or not oversize:
             return out
         eis, ews = [out[0]], [out[1]]

@@ -2744,7 +2744,7 @@ _MASK_INDEX_SCRATCH: dict = {}
 
 
 def mask_index(mask: Tensor, declined: Optional[Tensor] = None, want_rank: bool = False, want_ones: bool = False,
-               want_assign: bool = False):
+               want_assign: bool = False, want_node_rank: bool = False):
     """The sorted positions of the non-zero bytes of ``mask`` [n] uint8 -- `mask.nonzero().view(-1)` in two launches with
     one pinned-word wait between them (torch's own: seven launches and a synchronising copy) -- as row 0 of an int64
     ``[2, k]`` array whose row 1 is ``arange(k)`` (``want_rank``; the indices of NDPSelect's S), plus ``ones [k]`` fp32
@@ -2752,7 +2752,8 @@ def mask_index(mask: Tensor, declined: Optional[Tensor] = None, want_rank: bool 
     of the kernel that made the mask; read with the count, no copy of its own).  Returns (index [2,k] or [1,k], ones or
     None) -- and with ``want_assign`` (needs both) a third item: the one-to-one :class:`AssignIndex` (perm + packed
     {row, weight}) of the assignment these arrays describe, which :func:`one_to_one_index` would build in a launch of its
-    own.  reference: select/ndp_select.py:257-262."""
+    own.  ``want_node_rank``: one more item, int32 ``[n + 1]`` = set positions in front of every position (total at
+    ``[n]``): what :func:`kron_batched` takes as ``node_rank``.  reference: select/ndp_select.py:257-262."""
     dev = N.require_device(mask, declined)
     if mask.dtype != torch.uint8 or not mask.is_contiguous():
         raise ValueError("mask_index: a contiguous uint8 mask is required")
@@ -2780,17 +2781,21 @@ def mask_index(mask: Tensor, declined: Optional[Tensor] = None, want_rank: bool 
     assign = want_assign and want_rank and want_ones and 0 < k and n < (1 << 31)
     perm = torch.empty(k, dtype=torch.int32, device=dev) if assign else None
     pack = torch.empty(k, dtype=torch.int64, device=dev) if assign else None
-    if k:
-        N.check(L.tgp_mask_index_fill(N.ptr(mask), n, N.ptr(scratch), k, N.ptr(index),
-                                      index.data_ptr() + 8 * k if want_rank else None, N.ptr(ones), N.ptr(perm),
-                                      N.ptr(pack), st), "tgp_mask_index_fill")
-    if not want_assign:
-        return index, ones
-    a_index = None
-    if assign:
-        a_index = AssignIndex(None, perm, k, k)
-        a_index.pack, a_index.pack_key = pack, (index.data_ptr(), ones.data_ptr())
-    return index, ones, a_index
+    node_rank = torch.empty(n + 1, dtype=torch.int32, device=dev) if want_node_rank and n else None
+    if k or node_rank is not None:
+        N.check(L.tgp_mask_index_fill(N.ptr(mask), n, N.ptr(scratch), k, N.ptr(index) if k else None,
+                                      index.data_ptr() + 8 * k if want_rank and k else None, N.ptr(ones) if k else None,
+                                      N.ptr(perm), N.ptr(pack), N.ptr(node_rank), st), "tgp_mask_index_fill")
+    out = (index, ones)
+    if want_assign:
+        a_index = None
+        if assign:
+            a_index = AssignIndex(None, perm, k, k)
+            a_index.pack, a_index.pack_key = pack, (index.data_ptr(), ones.data_ptr())
+        out = out + (a_index,)
+    if want_node_rank:
+        out = out + (node_rank,)
+    return out
 
 
 def ndp_partition_large(indptr: Tensor, col: Tensor, weight: Optional[Tensor], p0: int, p1: int, seed: int,
@@ -2870,12 +2875,15 @@ def _kron_caps(graph_sizes_host, limit: Optional[int] = None) -> Tuple[int, int,
 def kron_batched(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optional[Tensor], from_adjacency: bool,
                  num_nodes: int, graph_ptr: Tensor, max_graph_nodes: int, node_index: Tensor,
                  threshold: float, skip_oversize: bool = False,
-                 graph_sizes_host: Optional[Sequence[int]] = None) -> Optional[Tuple[Tensor, Tensor]]:
+                 graph_sizes_host: Optional[Sequence[int]] = None,
+                 node_rank: Optional[Tensor] = None) -> Optional[Tuple[Tensor, Tensor]]:
     """Block-batched Kron reduction (connect/kron_conn.py:117-165): one workgroup per graph, fp64 elimination of the
     dropped nodes, thresholded fp32 edge list in row-major order.  ``indptr`` int32 [N+1] / ``col`` int64 / ``val``
     fp32 or fp64 (None = ones) / ``perm`` int32 (None = identity) describe the Laplacian entries, or the edge weights
     when ``from_adjacency``.  ``graph_sizes_host``: the graphs' node counts on the host (the caller's memoised
     batch info): the workspace is then sized from the real graphs instead of num_nodes x longest graph.
+    ``node_rank`` (int32 [num_nodes + 1], optional): kept nodes in front of every node, from the selector that compacted
+    ``node_index`` itself (:func:`mask_index`): the call skips its flag scatter and scan.
     Returns None when the library declines (see include/tgp_hip.h)."""
     dev = N.require_device(indptr, col, val, perm, graph_ptr, node_index)
     cap_dense = cap_big = num_big = -1
@@ -2892,6 +2900,9 @@ def kron_batched(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optio
             v32 = N.f32c(val.reshape(-1))
     B = graph_ptr.numel() - 1
     L = N.lib()
+    if node_rank is not None and not (node_rank.dtype == torch.int32 and node_rank.numel() == num_nodes + 1
+                                      and node_rank.is_contiguous() and node_rank.device == dev):
+        node_rank = None  # (not the table of THIS batch: the call builds its own)
     ws = N.workspace(L.tgp_kron_batched_workspace_bytes(num_nodes, B, max_graph_nodes, cap_dense, cap_big), dev)
     d_count = torch.empty(1, dtype=torch.int64, device=dev)
     st = N.stream_ptr(dev)
@@ -2900,7 +2911,8 @@ def kron_batched(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optio
                                      (1 if from_adjacency else 0) | (2 if skip_oversize else 0),
                                      num_nodes, col.numel(), N.ptr(graph_ptr), B, max_graph_nodes, cap_dense, cap_big,
                                      num_big, N.ptr(node_index),
-                                     node_index.numel(), float(threshold), N.ptr(ws), ws.numel(), N.ptr(d_count), st),
+                                     node_index.numel(), float(threshold), N.ptr(node_rank), N.ptr(ws), ws.numel(),
+                                     N.ptr(d_count), st),
             "tgp_kron_batched_count")
     n_out = _read_count(d_count)
     if n_out < 0:

@@ -274,7 +274,7 @@ class SelectOutput:
         factory = state.pop("_L_factory", None)  # a closure over device tensors: the pickle carries the Laplacian itself
         if factory is not None and "L" not in state:
             state["L"] = factory()
-        for helper in ("_adj_device_csr", "_kron_csr", "_node_batch", "_partition_info", "_values_of"):
+        for helper in ("_adj_device_csr", "_kron_csr", "_node_batch", "_partition_info", "_values_of", "_node_rank"):
             state.pop(helper, None)  # device-side shortcuts of this process; KronConnect rebuilds what it needs from L
         return state
 
@@ -329,7 +329,7 @@ class SelectOutput:
                 setattr(self, name, self._apply_to_value(getattr(self, name), func))
         self._drop_caches()
         self._edge_csr = None  # belongs to a tensor on the old device
-        for helper in ("_adj_device_csr", "_kron_csr"):  # device-side shortcuts built for the old placement
+        for helper in ("_adj_device_csr", "_kron_csr", "_node_rank"):  # device-side shortcuts built for the old placement
             self.__dict__.pop(helper, None)
         nb = self.__dict__.get("_node_batch")
         if isinstance(nb, Tensor):
@@ -1019,10 +1019,11 @@ class NDPSelect(Select):
         # the kept nodes as S's [2, k] indices and unit values: two launches and one pinned-word wait that also carries
         # the kernels' status (r6; before: bool copy + torch's nonzero + status.item() + arange + stack + ones = 13 launches
         # and two synchronising copies)
-        got = K.mask_index(keep8.contiguous(), status, want_rank=True, want_ones=True, want_assign=True)
+        got = K.mask_index(keep8.contiguous(), status, want_rank=True, want_ones=True, want_assign=True,
+                           want_node_rank=True)
         if got is None:
             return None
-        s_index, s_ones, assign = got
+        s_index, s_ones, assign, node_rank = got
         k = s_index.size(1)
         s = torch.sparse_coo_tensor(s_index, s_ones, size=(n, k), is_coalesced=True)
         so = SelectOutput(s=s, s_inv_op=self.s_inv_op)
@@ -1038,6 +1039,8 @@ class NDPSelect(Select):
         so.__dict__["_L_factory"] = laplacian_on_host
         so._adj_device_csr = (indptr, ei2[1], w2)  # KronConnect's kernel forms L = D - A from these directly
         so._partition_info = part_info
+        # kept nodes in front of every node: KronConnect's kernels start from it (valid for exactly this node_index)
+        so._node_rank = (node_rank, s_index.data_ptr(), k)
         if assign is not None and so.node_index.data_ptr() == s_index.data_ptr():
             so._assign_index = assign  # (written by the same launch as S's arrays: no index-build launch)
             so.__dict__["_values_of"] = (so.s, s_ones)
