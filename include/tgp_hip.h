@@ -946,7 +946,8 @@ int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col, const floa
                            void* stream);
 int tgp_kron_batched_fill(const void* ws, int64_t num_nodes, int64_t num_graphs, int64_t max_graph_nodes,
                           int64_t cap_dense, int64_t cap_big, int64_t num_big, const int64_t* graph_ptr,
-                          int64_t num_out, int64_t* out_row, int64_t* out_col, float* out_weight, void* stream);
+                          int64_t num_out, int64_t* out_row, int64_t* out_col, float* out_weight,
+                          const uint32_t* node_rank /* what the count call was given, or NULL */, void* stream);
 
 /* A12, min_score mode (select/topk_select.py:186-194): prob = per-graph softmax of `score` (PyG utils.softmax: max
  * subtraction, +1e-16 in the denominator), kept = prob > min(max_g(prob) - tol, min_score) (PyG topk; tol 1e-7), kept

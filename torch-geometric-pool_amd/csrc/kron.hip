@@ -1029,7 +1029,7 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
     return check_launch("tgp_kron_batched_count");
   }
   if (node_rank) {
-    (void)hipMemcpyAsync(s.rank, node_rank, static_cast<size_t>(N + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+    s.rank = const_cast<uint32_t*>(node_rank);  // (read-only from here on; tgp_kron_batched_fill is handed the same table)
   } else {
     if (num_kept > 0)
       hipLaunchKernelGGL(kron_flags_kernel, dim3(cdiv(num_kept, 256)), dim3(256), 0, stream, node_index, num_kept, N,
@@ -1123,7 +1123,8 @@ extern "C" int tgp_kron_batched_count(const int32_t* indptr, const int64_t* col,
 
 extern "C" int tgp_kron_batched_fill(const void* ws, int64_t N, int64_t B, int64_t max_graph_nodes, int64_t cap_dense,
                                      int64_t cap_big, int64_t num_big, const int64_t* graph_ptr, int64_t num_out,
-                                     int64_t* out_row, int64_t* out_col, float* out_weight, void* stream_) {
+                                     int64_t* out_row, int64_t* out_col, float* out_weight, const uint32_t* node_rank,
+                                     void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   TGP_REQUIRE(ws && N >= 0 && B >= 0 && num_out >= 0 && graph_ptr, TGP_ERR_INVALID,
               "tgp_kron_batched_fill: bad argument");
@@ -1131,6 +1132,7 @@ extern "C" int tgp_kron_batched_fill(const void* ws, int64_t N, int64_t B, int64
   TGP_REQUIRE(out_row && out_col && out_weight, TGP_ERR_INVALID, "tgp_kron_batched_fill: null output");
   KronWs s;
   kron_layout(const_cast<void*>(ws), N, B, max_graph_nodes, cap_dense, cap_big, &s);
+  if (node_rank) s.rank = const_cast<uint32_t*>(node_rank);  // (the table the count call was given)
   const int cap = static_cast<int>(max_graph_nodes < KRON_LDS_MAX_N ? max_graph_nodes : KRON_LDS_MAX_N);
   hipLaunchKernelGGL(kron_fill_kernel, dim3(static_cast<unsigned>(B)), dim3(KRON_THREADS), 0, stream, graph_ptr, s.rank,
                      s.sq_off, s.dense, s.out_off, cap, out_row, out_col, out_weight);

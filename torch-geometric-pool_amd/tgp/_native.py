@@ -231,7 +231,7 @@ SIGNATURES = {
                                         _c_i64, _c_i64, _c_i64, _c_p, _c_i64, ctypes.c_double, _c_p, _c_p, _c_sz, _c_p,
                                         _c_p]),
     "tgp_kron_batched_fill": (_c_int, [_c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_i64, _c_p, _c_p,
-                                       _c_p, _c_p]),
+                                       _c_p, _c_p, _c_p]),
     "tgp_mlp_select_max_fused_k": (_c_int, []),
     "tgp_mlp_select_f32": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
     "tgp_softmax_rows_f32": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p]),

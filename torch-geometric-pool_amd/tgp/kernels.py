@@ -2922,7 +2922,7 @@ def kron_batched(indptr: Tensor, col: Tensor, val: Optional[Tensor], perm: Optio
     N.check(L.tgp_kron_batched_fill(N.ptr(ws), num_nodes, B, max_graph_nodes, cap_dense, cap_big, num_big,
                                     N.ptr(graph_ptr), n_out,
                                     N.ptr(ei[0]) if n_out else None, N.ptr(ei[1]) if n_out else None,
-                                    N.ptr(ew) if n_out else None, st), "tgp_kron_batched_fill")
+                                    N.ptr(ew) if n_out else None, N.ptr(node_rank), st), "tgp_kron_batched_fill")
     return ei, ew
 
 
