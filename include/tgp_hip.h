@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 10041 /* 1.0.1 of the reference, ABI revision 40 (r6: tgp_mask_index_*; the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
+#define TGP_ABI_VERSION 10042 /* 1.0.1 of the reference, ABI revision 41 (r6: tgp_mask_index_*, node_rank on tgp_kron_batched_count / _fill; the dense poolers' training step at C2 scale: tgp_dense_pool_train_*, tgp_mincut_terms_fused_f32, tgp_softmax_bwd_ex_f32, tgp_copy_cols2_f32; tgp_result_wait_pack_cols; tgp_spmm_csr_stats_f32 / _entropy_f32; tgp_segment_gemm_tn3_post_f32) */
 
 enum tgp_status {
   TGP_OK = 0,
