@@ -53,6 +53,7 @@ python3 tools/profile_unbatched.py 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c
 (echo "== TGP_FOLD_TRAINING=0 (operator-by-operator graph, staged Reduce + Connect: r4 form)"; TGP_FOLD_TRAINING=0 python3 tools/e2e_train_step.py topk_c3 graclus_c3 --sequence 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-180; echo; echo "== default (r5, late)"; python3 tools/e2e_train_step.py topk_c3 graclus_c3 --sequence 2>&1 | grep -v -i "amdgpu.ids\|warn" | cut -c1-180) > $out/sparse_train_steps.txt
 python3 tools/bench_select_fold.py 2>&1 | grep select > $out/select_fold.txt
 python3 tools/ndp_small_ab.py 2>&1 | grep -v -i "warn" > $out/ndp_small.txt
+python3 tools/ndp_launch_list.py 2>&1 | grep -E " us  |GPU-busy" | cut -c1-150 > $out/ndp_forward_kernels.txt
 bash tools/ndp_large_ab.sh 2>&1 | grep -v -i "warn\|amdgpu.ids" > $out/ndp_mid_ab.txt
 python3 tools/bench_reference_harness.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $out/reference_harness.txt
 python3 tools/kron_timeline.py $(find $out/kron -name "*kernel_trace.csv" | head -1) > $out/kron_timeline.txt 2>&1
